@@ -1,0 +1,69 @@
+"""ctypes mirror of include/hipnlp.h (POD descriptors).  Pure data layout, no compute."""
+import ctypes as C
+
+NJ, NL, NC, NXK, NPK, NXG, NPG = 23, 24, 8, 189, 79, 6, 326
+NCOST_TERMS = 12
+
+EXPR_SKIP, EXPR_SUBJECT_TO, EXPR_MINIMIZE = 0, 1, 2
+TERRAIN_PLANAR = 0
+FRAME_LEFT_SOLE, FRAME_RIGHT_SOLE, FRAME_CHEST = 0, 1, 2
+
+OK, E_INVALID, E_NODEVICE, E_ALLOC, E_PARAMS, E_NUMERIC = 0, -1, -2, -3, -4, -5
+
+
+class RobotModelC(C.Structure):
+    _fields_ = [
+        ("parent", C.c_int32 * NJ),
+        ("R_fix", (C.c_double * 9) * NJ),
+        ("o_fix", (C.c_double * 3) * NJ),
+        ("axis", (C.c_double * 3) * NJ),
+        ("mass", C.c_double * NL),
+        ("com", (C.c_double * 3) * NL),
+        ("inertia", (C.c_double * 9) * NL),
+        ("frame_link", C.c_int32 * 3),
+        ("frame_R", (C.c_double * 9) * 3),
+        ("frame_o", (C.c_double * 3) * 3),
+    ]
+
+
+class SettingsC(C.Structure):
+    _fields_ = [
+        ("horizon", C.c_int32),
+        ("terrain", C.c_int32),
+        ("final_state_type", C.c_int32),
+        ("periodicity_type", C.c_int32),
+        ("joint_reg_as_coded", C.c_int32),
+        ("yaw_corner", (C.c_int32 * 3) * 2),
+        ("final_state_weight", C.c_double),
+        ("periodicity_weight", C.c_double),
+        ("contacts_centroid_cost_multiplier", C.c_double),
+        ("com_linear_velocity_cost_weights", C.c_double * 3),
+        ("com_linear_velocity_cost_multiplier", C.c_double),
+        ("desired_frame_quaternion_cost_multiplier", C.c_double),
+        ("base_quaternion_cost_multiplier", C.c_double),
+        ("base_quaternion_velocity_cost_multiplier", C.c_double),
+        ("joint_regularization_cost_weights", C.c_double * NJ),
+        ("joint_regularization_cost_multiplier", C.c_double),
+        ("force_regularization_cost_multiplier", C.c_double),
+        ("foot_yaw_regularization_cost_multiplier", C.c_double),
+        ("swing_foot_height_cost_multiplier", C.c_double),
+        ("contact_velocity_control_cost_multiplier", C.c_double),
+        ("contact_force_control_cost_multiplier", C.c_double),
+    ]
+
+
+class DescC(C.Structure):
+    _fields_ = [
+        ("settings", SettingsC),
+        ("model", RobotModelC),
+        ("batch", C.c_int32),
+        ("knot_begin", C.c_int32),
+        ("knot_end", C.c_int32),
+        ("device", C.c_int32),
+    ]
+
+
+class DimsC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n", "m", "nnz", "np", "nnz_knot", "m_knot",
+        "shard_g_rows", "shard_nnz", "shard_grad", "shard_jac_off", "shard_grad_off")]

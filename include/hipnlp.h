@@ -1,0 +1,208 @@
+/*
+ * hipnlp.h — C-ABI of the MI355X-native multiple-shooting NLP-callback engine.
+ *
+ * Drop-in boundary for ONE hot path of ami-iit/hippopt: the per-knot evaluation of
+ * (f, grad f, g, jac g) of the humanoid kinodynamic multiple-shooting NLP that the
+ * reference assembles in
+ *   src/hippopt/turnkey_planners/humanoid_kinodynamic/planner.py:26-176
+ * and evaluates, through CasADi's Opti/nlpsol, once per IPOPT callback in
+ *   src/hippopt/base/opti_solver.py:479   (self._solver.solve()).
+ *
+ * What each entry point replaces on the reference side
+ *   hipnlp_create       <- cs.Opti("nlp") + opti.variable()/parameter() creation order
+ *                          (base/opti_solver.py:139-175, 251-333) and the planner's
+ *                          subject_to/minimize call order (planner.py:124-176)
+ *   hipnlp_set_params   <- opti.set_value(parameter, value)     (opti_solver.py:236-249)
+ *   hipnlp_bounds       <- Opti's canonical lbg/ubg of every subject_to
+ *   hipnlp_sparsity     <- nlp_jac_g sparsity (CCS, column-major)  [CasADi, 3rd party]
+ *   hipnlp_eval         <- nlp_f / nlp_grad_f / nlp_g / nlp_jac_g   [CasADi SX VM, 3rd party]
+ *                          = IPOPT's eval_f / eval_grad_f / eval_g / eval_jac_g
+ *                          (IpStdCInterface.h callback quartet; no eval_h: the reference
+ *                          runs hessian_approximation=limited-memory,
+ *                          main_periodic_step.py:116)
+ *   hipnlp_eval_device  <- same, device-resident in/out (no PCIe), used by bench.py and
+ *                          by the multi-GPU path (RCCL all-gather of the output shards)
+ *
+ * Conventions
+ *   - all reals are IEEE fp64; all indices are 0-based int32
+ *   - return value 0 = ok, negative = error (see HIPNLP_E_*); no exceptions cross the ABI
+ *   - the caller owns every host buffer; the library owns device memory
+ *   - one handle is used by one thread at a time (IPOPT is single threaded)
+ *   - x, lambda order  = reference creation order: [knot 0 (189) | ... | knot N-1 | initial_state.centroidal_momentum (6)]
+ *   - p order          = reference parameter creation order (tests/golden/kinodyn_structure.json)
+ *   - g order          = reference subject_to call order (constraint-type-major, knot-minor)
+ *   - jac order        = CCS (sorted by column, then row), fixed at create time
+ */
+#ifndef HIPNLP_H
+#define HIPNLP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPNLP_NJ 23        /* actuated joints (ergoCub: torso 3, arms 4+4, legs 6+6) */
+#define HIPNLP_NL 24        /* links = root + one per joint                            */
+#define HIPNLP_NC 8         /* contact points: left[0..3], right[0..3]                 */
+#define HIPNLP_NXK 189      /* decision variables per knot                             */
+#define HIPNLP_NPK 79       /* parameters per knot (24 descriptors + 55 references)    */
+#define HIPNLP_NXG 6        /* horizon-global decision variables                       */
+#define HIPNLP_NPG 326      /* horizon-global parameters                               */
+
+/* error codes */
+#define HIPNLP_OK 0
+#define HIPNLP_E_INVALID (-1)   /* bad argument / inconsistent descriptor */
+#define HIPNLP_E_NODEVICE (-2)  /* no HIP device / HIP runtime error      */
+#define HIPNLP_E_ALLOC (-3)
+#define HIPNLP_E_PARAMS (-4)    /* parameters not set before eval (opti_solver.py:447-450) */
+#define HIPNLP_E_NUMERIC (-5)   /* NaN/Inf produced by the kernel (IPOPT callback must return false) */
+
+/* ExpressionType of base/problem.py:15-19 */
+#define HIPNLP_EXPR_SKIP 0
+#define HIPNLP_EXPR_SUBJECT_TO 1
+#define HIPNLP_EXPR_MINIMIZE 2
+
+/* Terrain kinds (robot_planning/utilities/planar_terrain.py; smooth_terrain.py is a later row) */
+#define HIPNLP_TERRAIN_PLANAR 0
+
+/* Frame slots of hipnlp_robot_model.frame_* */
+#define HIPNLP_FRAME_LEFT_SOLE 0
+#define HIPNLP_FRAME_RIGHT_SOLE 1
+#define HIPNLP_FRAME_CHEST 2
+
+/*
+ * Kinematic tree, adam-robotics conventions:
+ *   child link of joint j is link j+1; parent[j] < j+1 (topological order); link 0 = root_link.
+ *   parent_T_child(s_j) = [ R_fix[j] * Rot(axis[j], s_j) , o_fix[j] ]   (URDF origin xyz/rpy, then axis rotation)
+ *   inertials are expressed in the link frame: mass, com, 3x3 inertia about the com (row-major).
+ *   frames: rigidly attached to frame_link[f] with link_T_frame = [frame_R[f], frame_o[f]].
+ */
+typedef struct hipnlp_robot_model {
+    int32_t parent[HIPNLP_NJ];
+    double R_fix[HIPNLP_NJ][9];
+    double o_fix[HIPNLP_NJ][3];
+    double axis[HIPNLP_NJ][3];
+    double mass[HIPNLP_NL];
+    double com[HIPNLP_NL][3];
+    double inertia[HIPNLP_NL][9];
+    int32_t frame_link[3];
+    double frame_R[3][9];
+    double frame_o[3][3];
+} hipnlp_robot_model;
+
+/*
+ * Everything that is a python-side *setting* (a constant baked into the CasADi graph) in the
+ * reference, as opposed to an Opti parameter.  Field -> reference:
+ *   horizon                       settings.horizon_length                 (settings.py:19)
+ *   final_state_type/weight       settings.final_state_expression_*       (planner.py:417-425)
+ *   periodicity_type/weight       settings.periodicity_expression_*       (planner.py:923-930)
+ *   *_multiplier / *_weights      settings.*                              (planner.py:249-264,433-520,746-895)
+ *   yaw_corner[foot][0..2]        bottom-right / top-right / top-left point index per foot,
+ *                                 chosen from the descriptor geometry     (planner.py:773-828)
+ *   joint_reg_as_coded            1: evaluate joint_positions_error exactly as coded
+ *                                 (elementwise * of a 23x23 diagonal with a 23x1 vector,
+ *                                 planner.py:505-520);  0: intended sum_i (sdot_i + w_i e_i)^2
+ */
+typedef struct hipnlp_settings {
+    int32_t horizon;
+    int32_t terrain;
+    int32_t final_state_type;
+    int32_t periodicity_type;
+    int32_t joint_reg_as_coded;
+    int32_t yaw_corner[2][3];
+    double final_state_weight;
+    double periodicity_weight;
+    double contacts_centroid_cost_multiplier;
+    double com_linear_velocity_cost_weights[3];
+    double com_linear_velocity_cost_multiplier;
+    double desired_frame_quaternion_cost_multiplier;
+    double base_quaternion_cost_multiplier;
+    double base_quaternion_velocity_cost_multiplier;
+    double joint_regularization_cost_weights[HIPNLP_NJ];
+    double joint_regularization_cost_multiplier;
+    double force_regularization_cost_multiplier;
+    double foot_yaw_regularization_cost_multiplier;
+    double swing_foot_height_cost_multiplier;
+    double contact_velocity_control_cost_multiplier;
+    double contact_force_control_cost_multiplier;
+} hipnlp_settings;
+
+typedef struct hipnlp_desc {
+    hipnlp_settings settings;
+    hipnlp_robot_model model;
+    int32_t batch;       /* independent trajectories evaluated per call (>=1); x/p/outputs get a leading batch dim */
+    int32_t knot_begin;  /* shard: this handle evaluates knots [knot_begin, knot_end) of every trajectory   */
+    int32_t knot_end;    /*        (0, horizon) = whole horizon.  See DESIGN.md §6 (multi-GPU)              */
+    int32_t device;      /* HIP device ordinal                                                               */
+} hipnlp_desc;
+
+typedef struct hipnlp_dims {
+    int32_t n;        /* decision variables per trajectory = 189*N + 6                */
+    int32_t m;        /* constraint rows per trajectory                               */
+    int32_t nnz;      /* structural non-zeros of jac g per trajectory                 */
+    int32_t np;       /* parameters per trajectory = 79*N + 326                       */
+    int32_t nnz_knot; /* non-zeros in the column block of one interior knot           */
+    int32_t m_knot;   /* rows owned by one interior knot                              */
+    /* shard view (== full view when the handle owns the whole horizon) */
+    int32_t shard_g_rows;   /* rows written by this handle          */
+    int32_t shard_nnz;      /* jac values written by this handle    */
+    int32_t shard_grad;     /* grad entries written by this handle  */
+    int32_t shard_jac_off;  /* offset of the handle's jac block in the CCS value array */
+    int32_t shard_grad_off; /* offset of the handle's block in grad f                  */
+} hipnlp_dims;
+
+typedef struct hipnlp_handle hipnlp_handle;
+
+int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out);
+void hipnlp_destroy(hipnlp_handle* h);
+const char* hipnlp_last_error(const hipnlp_handle* h); /* h may be NULL: last create() error */
+int hipnlp_get_dims(const hipnlp_handle* h, hipnlp_dims* out);
+
+/* p: [batch][np] host array in reference parameter order. Computes bounds, uploads device copies. */
+int hipnlp_set_params(hipnlp_handle* h, const double* p);
+
+/* Canonical bounds (CasADi Opti canon form), valid after set_params.  Any pointer may be NULL.
+ * lbx/ubx: [n] (+-inf: the reference adds no explicit variable bounds; see hipnlp_simple_rows)
+ * lbg/ubg: [m] of trajectory 0 (bounds depend on parameters only)                              */
+int hipnlp_bounds(const hipnlp_handle* h, double* lbx, double* ubx, double* lbg, double* ubg);
+
+/* is_simple[m]: 1 where row i of g is exactly one decision variable (candidate for
+ * nlpsol's detect_simple_bounds, main_periodic_step.py:110); var_index[m]: that variable or -1. */
+int hipnlp_simple_rows(const hipnlp_handle* h, int32_t* is_simple, int32_t* var_index);
+
+/* CCS pattern as triplets sorted by (col,row): irow[nnz], jcol[nnz] (IPOPT eval_jac_g, values==NULL call) */
+int hipnlp_sparsity(const hipnlp_handle* h, int32_t* irow, int32_t* jcol);
+
+/* Host-buffer callback quartet (IPOPT eval_f/eval_grad_f/eval_g/eval_jac_g in one fused launch).
+ * x: [batch][n]; f: [batch]; grad_f: [batch][n]; g: [batch][m]; jac: [batch][nnz].  Any output may be NULL.
+ * new_x = 0 lets the library return cached results of the previous evaluation.                */
+int hipnlp_eval(hipnlp_handle* h, const double* x, int new_x,
+                double* f, double* grad_f, double* g, double* jac);
+
+/* Device-resident variant: all pointers are device pointers on desc.device, same shapes.
+ * Work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the handle's own stream)
+ * and NOT synchronised.  cost_knot (optional, [batch][N]) receives the per-knot cost partials. */
+int hipnlp_eval_device(hipnlp_handle* h, const double* x_dev,
+                       double* f_dev, double* grad_dev, double* g_dev, double* jac_dev,
+                       void* stream);
+
+/* Per-named-cost values of the last evaluation (Output.cost_values, base/problem.py:28-56):
+ * values[batch][HIPNLP_NCOST_TERMS], summed over knots, in the order of hipnlp_cost_term_name(). */
+#define HIPNLP_NCOST_TERMS 12
+int hipnlp_cost_terms(hipnlp_handle* h, double* values);
+const char* hipnlp_cost_term_name(int i);
+
+/* Row-block directory: name (reference constraint base name), first row, rows per knot, first knot, knots. */
+int hipnlp_num_row_blocks(const hipnlp_handle* h);
+int hipnlp_row_block(const hipnlp_handle* h, int i, const char** name,
+                     int32_t* first_row, int32_t* rows_per_knot, int32_t* first_knot, int32_t* n_knots);
+
+/* Timing of the last hipnlp_eval()/hipnlp_eval_device() kernel, measured with hipEvents on the
+ * stream the kernel ran on (ms).  Blocks until the launch has finished.                          */
+int hipnlp_last_kernel_ms(hipnlp_handle* h, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPNLP_H */

@@ -1,0 +1,95 @@
+"""ctypes access to the CPU oracle (oracle/kinodyn_oracle.cpp).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from hippopt_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "oracle", "_build", "libkinodyn_oracle.so")
+
+
+def build(force=False):
+    src = [os.path.join(ROOT, "oracle", f) for f in ("kinodyn_oracle.cpp", "kinodyn_formulas.hpp", "scalar_types.hpp")]
+    if force or not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in src):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    return SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.oracle_create.restype = C.c_void_p
+        _lib.oracle_create.argtypes = [C.POINTER(_abi.DescC)]
+        _lib.oracle_destroy.argtypes = [C.c_void_p]
+        _lib.oracle_cost_term_name.restype = C.c_char_p
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+class Oracle:
+    def __init__(self, settings, model):
+        self.desc = _abi.DescC()
+        self.desc.settings = settings.to_c()
+        self.desc.model = model.to_c()
+        self.desc.batch = 1
+        self.desc.knot_begin = 0
+        self.desc.knot_end = settings.horizon_length
+        self.h = lib().oracle_create(C.byref(self.desc))
+        assert self.h
+        n, m, nnz, npar = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        lib().oracle_dims(C.c_void_p(self.h), C.byref(n), C.byref(m), C.byref(nnz), C.byref(npar))
+        self.n, self.m, self.nnz, self.np = n.value, m.value, nnz.value, npar.value
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().oracle_destroy(C.c_void_p(self.h))
+            self.h = None
+
+    def sparsity(self):
+        ir = np.zeros(self.nnz, np.int32)
+        jc = np.zeros(self.nnz, np.int32)
+        lib().oracle_sparsity(C.c_void_p(self.h), ir.ctypes.data_as(C.POINTER(C.c_int)), jc.ctypes.data_as(C.POINTER(C.c_int)))
+        return ir, jc
+
+    def bounds(self, p):
+        lb, ub = np.zeros(self.m), np.zeros(self.m)
+        lib().oracle_bounds(C.c_void_p(self.h), _dp(np.ascontiguousarray(p)), _dp(lb), _dp(ub))
+        return lb, ub
+
+    def eval_fg(self, x, p):
+        f = C.c_double()
+        g = np.zeros(self.m)
+        lib().oracle_eval_fg(C.c_void_p(self.h), _dp(np.ascontiguousarray(x)), _dp(np.ascontiguousarray(p)), C.byref(f), _dp(g))
+        return f.value, g
+
+    def eval(self, x, p):
+        f = C.c_double()
+        grad, g, jac = np.zeros(self.n), np.zeros(self.m), np.zeros(self.nnz)
+        lib().oracle_eval(C.c_void_p(self.h), _dp(np.ascontiguousarray(x)), _dp(np.ascontiguousarray(p)),
+                          C.byref(f), _dp(grad), _dp(g), _dp(jac))
+        return f.value, grad, g, jac
+
+    def cost_terms(self):
+        out = np.zeros(_abi.NCOST_TERMS)
+        lib().oracle_cost_terms(C.c_void_p(self.h), _dp(out))
+        return out
+
+    def row_blocks(self):
+        out = []
+        nb = lib().oracle_num_row_blocks(C.c_void_p(self.h))
+        for i in range(nb):
+            name = C.c_char_p()
+            a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            lib().oracle_row_block(C.c_void_p(self.h), i, C.byref(name), C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+            out.append((name.value.decode(), a.value, b.value, c.value, d.value))
+        return out
