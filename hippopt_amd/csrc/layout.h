@@ -1,0 +1,405 @@
+// layout.h — host-side structure of the NLP: the row-block directory in the reference's subject_to
+// order, the map from the kernel's native slots to global rows / CCS positions, bounds.
+// Header-only; used by the C-ABI implementation (hipnlp.hip) and by the test-only host emulation.
+//
+// Reference: call order of turnkey_planners/humanoid_kinodynamic/planner.py:124-176, row naming of
+// base/multiple_shooting_solver.py:682-742,807-824 (name[0] initial-condition rows, name[k] per knot),
+// Opti canonical forms.
+#pragma once
+#include <algorithm>
+#include <limits>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "knot_body.h"
+
+namespace hipnlp {
+
+struct RowBlock {
+    std::string name;
+    int first_row, rows, k0, nk;
+};
+
+enum Variant : int { VAR_FIRST = 0, VAR_INTERIOR = 1, VAR_LAST = 2 };
+
+// recording emitter: remembers which row / column every native slot belongs to
+struct RecordEm {
+    int* grow;        // [gs::COUNT] row id or -1
+    int* jrowid;      // [js::COUNT]
+    int* jcol;        // [js::COUNT]
+    bool* dup;
+    void G(int slot, int rid, double) { if (grow[slot] != -1) *dup = true; grow[slot] = rid; }
+    void J(int slot, int rid, int col, double) { if (jrowid[slot] != -1) *dup = true; jrowid[slot] = rid; jcol[slot] = col; }
+};
+
+// parameter offsets in reference creation order (tests/golden/kinodyn_structure.json)
+struct ParamOffsets {
+    int N;
+    explicit ParamOffsets(int n) : N(n) {}
+    int desc(int k, int c) const { return 24 * k + 3 * c; }
+    int mass() const { return 24 * N; }
+    int init() const { return 24 * N + 3; }
+    int fin() const { return init() + 105; }
+    int sc() const { return fin() + 105; }
+    int dt() const { return sc(); }
+    int gravity() const { return sc() + 1; }
+    int kt() const { return sc() + 7; }
+    int kbs() const { return sc() + 8; }
+    int eps() const { return sc() + 9; }
+    int mu() const { return sc() + 10; }
+    int umax() const { return sc() + 11; }
+    int fdmax() const { return sc() + 14; }
+    int lmax() const { return sc() + 17; }
+    int hmin() const { return sc() + 18; }
+    int dmin() const { return sc() + 19; }
+    int hmax() const { return sc() + 20; }
+    int jpmax() const { return sc() + 21; }
+    int jpmin() const { return sc() + 44; }
+    int jvmax() const { return sc() + 67; }
+    int jvmin() const { return sc() + 90; }
+    int ref(int k) const { return sc() + 113 + 55 * k; }
+    int np() const { return 79 * N + 326; }
+};
+
+struct Layout {
+    int N = 0, n = 0, m = 0, nnz = 0;
+    bool has_final = false, has_per = false, has_hx0 = false;
+    std::vector<RowBlock> blocks;
+    int blk[RK_COUNT][NC];                // directory index of (kind, point) or -1
+    // kernel tables
+    std::vector<int32_t> g_a[3];          // [gs::COUNT] row of slot at knot k is g_a + g_b*k ; -1 = not written
+    std::vector<int32_t> g_b;
+    std::vector<int32_t> jperm[3];        // CCS position (within the knot's column block) -> native slot
+    std::vector<int32_t> jperm_glob;      // entries in the horizon-global columns (written by knot 0)
+    int nnz_v[3] = {0, 0, 0};
+    int jac_glob_base = 0;
+    std::vector<int32_t> irow, jcol;      // full pattern, CCS order
+    std::string error;
+
+    static std::string point_name(int c) {
+        return std::string("system.contact_points.") + (c < 4 ? "left[" : "right[") + std::to_string(c % 4) + "]";
+    }
+    int variant_of(int k) const { return k == 0 ? VAR_FIRST : (k == N - 1 ? VAR_LAST : VAR_INTERIOR); }
+    long jac_base(int k) const { return k == 0 ? 0 : long(nnz_v[VAR_FIRST]) + long(k - 1) * nnz_v[VAR_INTERIOR]; }
+
+    int add(const std::string& name, int rows, int k0, int nk) {
+        RowBlock b{name, m, rows, k0, nk};
+        m += rows * nk;
+        blocks.push_back(b);
+        return int(blocks.size()) - 1;
+    }
+    void add_dyn(const std::string& name, int L, int kin, int c, bool x0) {
+        if (x0) blk[kin + 2][c] = add(name + "[0]", L, 0, 1);
+        blk[kin][c] = blk[kin + 1][c] = add(name, L, 1, N - 1);
+    }
+
+    // global row of (row id) as seen from knot k, or -1
+    int resolve(int rid, int k) const {
+        const int kind = rid_kind(rid), c = rid_point(rid), i = rid_index(rid);
+        const int bi = blk[kind][c];
+        if (bi < 0) return -1;
+        const RowBlock& b = blocks[size_t(bi)];
+        switch (kind) {
+            case RK_FDYN_OUT: case RK_PDYN_OUT: case RK_PBDYN_OUT: case RK_QBDYN_OUT: case RK_SDYN_OUT: case RK_COMDYN_OUT: case RK_HDYN_OUT:
+                return (k + 1 <= N - 1) ? b.first_row + b.rows * k + i : -1;   // row of knot k+1 (k0 = 1)
+            case RK_FDYN_X0: case RK_PDYN_X0: case RK_PBDYN_X0: case RK_QBDYN_X0: case RK_SDYN_X0: case RK_COMDYN_X0: case RK_HDYN_X0: case RK_PER0:
+                return k == 0 ? b.first_row + i : -1;
+            case RK_FIN: case RK_PERN:
+                return k == N - 1 ? b.first_row + i : -1;
+            default:
+                return (k >= b.k0 && k < b.k0 + b.nk) ? b.first_row + b.rows * (k - b.k0) + i : -1;
+        }
+    }
+
+    bool build(const hipnlp_settings& st, const KinTables& kt) {
+        N = st.horizon;
+        if (N < 2) { error = "horizon must be >= 2"; return false; }
+        n = NXK * N + NXG;
+        m = 0;
+        blocks.clear();
+        for (int a = 0; a < RK_COUNT; ++a) for (int c = 0; c < NC; ++c) blk[a][c] = -1;
+        has_final = st.final_state_type == HIPNLP_EXPR_SUBJECT_TO;
+        has_per = st.periodicity_type == HIPNLP_EXPR_SUBJECT_TO;
+        has_hx0 = st.periodicity_type == HIPNLP_EXPR_SKIP;  // planner.py:580-584
+        // ---- directory in the reference's call order --------------------------------------------
+        for (int c = 0; c < NC; ++c) {  // planner.py:124-147
+            const std::string pn = point_name(c);
+            add_dyn(pn + ".f_dynamics", 3, RK_FDYN_IN, c, true);
+            add_dyn(pn + ".p_dynamics", 3, RK_PDYN_IN, c, true);
+            blk[RK_PLANAR][c] = add(pn + ".p_planar_complementarity", 3, 0, N);
+            blk[RK_DCC][c] = add(pn + ".p_dcc", 1, 0, N);
+            blk[RK_HEIGHT][c] = add(pn + ".p_height", 1, 1, N - 1);
+            blk[RK_NORMAL][c] = add(pn + ".f_normal", 1, 1, N - 1);
+            blk[RK_FRICTION][c] = add(pn + ".f_friction", 1, 1, N - 1);
+            blk[RK_UB][c] = add(pn + ".u_v_bounds", 3, 0, N);
+            blk[RK_FDB][c] = add(pn + ".f_dot_bounds", 3, 0, N);
+            blk[RK_KINC][c] = add(pn + ".p_kinematics_consistency", 3, 1, N - 1);
+        }
+        add_dyn("base_position_dynamics", 3, RK_PBDYN_IN, 0, true);       // planner.py:522-588
+        add_dyn("base_quaternion_dynamics", 4, RK_QBDYN_IN, 0, true);
+        add_dyn("joint_position_dynamics", NJ, RK_SDYN_IN, 0, true);
+        add_dyn("com_dynamics", 3, RK_COMDYN_IN, 0, true);
+        add_dyn("centroidal_momentum_dynamics", 6, RK_HDYN_IN, 0, has_hx0);
+        blk[RK_UNITQ][0] = add("unitary_quaternion", 1, 1, N - 1);      // planner.py:266-425
+        blk[RK_COMC][0] = add("com_kinematics_consistency", 3, 1, N - 1);
+        blk[RK_CMMC][0] = add("centroidal_momentum_kinematics_consistency", 3, 0, N);
+        blk[RK_AMB][0] = add("angular_momentum_bounds", 3, 0, N);
+        blk[RK_COMH][0] = add("minimum_com_height", 1, 1, N - 1);
+        blk[RK_FEETD][0] = add("minimum_feet_distance", 1, 1, N - 1);
+        blk[RK_JPB][0] = add("joint_position_bounds", NJ, 1, N - 1);
+        blk[RK_JVB][0] = add("joint_velocity_bounds", NJ, 0, N);
+        if (has_final) blk[RK_FIN][0] = add("final_state_expression", 105, N - 1, 1);
+        blk[RK_FEETH][0] = add("maximum_feet_relative_height", 1, 1, N - 1);  // planner.py:215-247
+        if (has_per) blk[RK_PER0][0] = blk[RK_PERN][0] = add("periodicity_expression", 84, N - 1, 1);  // planner.py:897-930
+
+        // ---- record the kernel body's native slots --------------------------------------------------
+        std::vector<int> grow(gs::COUNT, -1), jrid(js::COUNT, -1), jc(js::COUNT, -1);
+        bool dup = false;
+        {
+            KnotScratch* s = new KnotScratch();
+            std::fill(reinterpret_cast<double*>(s), reinterpret_cast<double*>(s) + sizeof(KnotScratch) / sizeof(double), 0.0);
+            s->x[QB_ + 3] = 1.0;
+            KSettings ks = make_ksettings(st);
+            GParams gp{};
+            gp.dt = 0.1; gp.mass = 1.0;
+            KnotInfo ki{0, N, 1, 1};
+            RecordEm em{grow.data(), jrid.data(), jc.data(), &dup};
+            Ctx<RecordEm> cx(*s, kt, ks, gp, ki, em);
+            const int maxd = kt.max_depth;
+#define HOST_RUN(fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
+#define HOST_RUNL(fn, nt, lvl) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_, lvl);
+            HIPNLP_KNOT_PROGRAM(HOST_RUN, HOST_RUNL, , maxd)
+#undef HOST_RUN
+#undef HOST_RUNL
+            delete s;
+        }
+        if (dup) { error = "internal: native slot emitted twice"; return false; }
+
+        // ---- g tables ------------------------------------------------------------------------------------
+        g_b.assign(gs::COUNT, 0);
+        for (int v = 0; v < 3; ++v) g_a[v].assign(gs::COUNT, -1);
+        const int krep[3] = {0, 1, N - 1};
+        for (int slot = 0; slot < gs::COUNT; ++slot) {
+            if (grow[size_t(slot)] < 0) continue;
+            const int rid = grow[size_t(slot)];
+            const int bi = blk[rid_kind(rid)][rid_point(rid)];
+            if (bi < 0) continue;
+            const int stride = blocks[size_t(bi)].nk > 1 ? blocks[size_t(bi)].rows : 0;
+            g_b[size_t(slot)] = stride;
+            for (int v = 0; v < 3; ++v) {
+                if (v == VAR_INTERIOR && N < 3) continue;
+                const int r = resolve(rid, krep[v]);
+                if (r >= 0) g_a[v][size_t(slot)] = r - stride * krep[v];
+            }
+        }
+        // ---- jac tables: CCS order inside the column block of a knot ------------------------------------
+        jperm_glob.clear();
+        for (int v = 0; v < 3; ++v) {
+            jperm[v].clear();
+            nnz_v[v] = 0;
+            if (v == VAR_INTERIOR && N < 3) continue;
+            std::vector<std::pair<std::pair<int, int>, int>> ent, glob;  // ((col,row),slot)
+            for (int slot = 0; slot < js::COUNT; ++slot) {
+                if (jrid[size_t(slot)] < 0) continue;
+                const int r = resolve(jrid[size_t(slot)], krep[v]);
+                if (r < 0) continue;
+                if (jc[size_t(slot)] >= COL_GLOBAL) glob.push_back({{jc[size_t(slot)], r}, slot});
+                else ent.push_back({{jc[size_t(slot)], r}, slot});
+            }
+            std::sort(ent.begin(), ent.end());
+            for (size_t i = 1; i < ent.size(); ++i)
+                if (ent[i].first == ent[i - 1].first) { error = "internal: duplicate jacobian entry"; return false; }
+            for (auto& e : ent) jperm[v].push_back(e.second);
+            nnz_v[v] = int(ent.size());
+            if (v == VAR_FIRST) { std::sort(glob.begin(), glob.end()); for (auto& e : glob) jperm_glob.push_back(e.second); }
+        }
+        jac_glob_base = int(jac_base(N - 1)) + nnz_v[VAR_LAST];
+        nnz = jac_glob_base + int(jperm_glob.size());
+        // ---- full pattern ---------------------------------------------------------------------------------
+        irow.clear(); jcol.clear();
+        irow.reserve(size_t(nnz)); jcol.reserve(size_t(nnz));
+        for (int k = 0; k < N; ++k) {
+            const int v = variant_of(k);
+            for (int slot : jperm[v]) { irow.push_back(resolve(jrid[size_t(slot)], k)); jcol.push_back(NXK * k + jc[size_t(slot)]); }
+        }
+        for (int slot : jperm_glob) { irow.push_back(resolve(jrid[size_t(slot)], 0)); jcol.push_back(NXK * N + (jc[size_t(slot)] - COL_GLOBAL)); }
+        for (size_t i = 1; i < irow.size(); ++i)
+            if (!(jcol[i - 1] < jcol[i] || (jcol[i - 1] == jcol[i] && irow[i - 1] < irow[i]))) { error = "internal: pattern not in CCS order"; return false; }
+        if (int(irow.size()) != nnz) { error = "internal: nnz mismatch"; return false; }
+        return true;
+    }
+
+    static KSettings make_ksettings(const hipnlp_settings& st) {
+        KSettings k{};
+        k.horizon = st.horizon;
+        k.final_type = st.final_state_type;
+        k.periodicity_type = st.periodicity_type;
+        k.joint_reg_as_coded = st.joint_reg_as_coded;
+        k.hdyn_x0 = st.periodicity_type == HIPNLP_EXPR_SKIP;
+        for (int f = 0; f < 2; ++f) for (int i = 0; i < 3; ++i) k.yaw_corner[f][i] = st.yaw_corner[f][i];
+        k.final_weight = st.final_state_weight;
+        k.periodicity_weight = st.periodicity_weight;
+        k.m_centroid = st.contacts_centroid_cost_multiplier;
+        for (int i = 0; i < 3; ++i) k.w_comvel[i] = st.com_linear_velocity_cost_weights[i];
+        k.m_comvel = st.com_linear_velocity_cost_multiplier;
+        k.m_frameq = st.desired_frame_quaternion_cost_multiplier;
+        k.m_baseq = st.base_quaternion_cost_multiplier;
+        k.m_baseqv = st.base_quaternion_velocity_cost_multiplier;
+        for (int i = 0; i < NJ; ++i) k.w_jreg[i] = st.joint_regularization_cost_weights[i];
+        k.m_jreg = st.joint_regularization_cost_multiplier;
+        k.m_freg = st.force_regularization_cost_multiplier;
+        k.m_yaw = st.foot_yaw_regularization_cost_multiplier;
+        k.m_swing = st.swing_foot_height_cost_multiplier;
+        k.m_ureg = st.contact_velocity_control_cost_multiplier;
+        k.m_fdreg = st.contact_force_control_cost_multiplier;
+        return k;
+    }
+
+    // Kinematic tables from the C descriptor; validates the topology the kernel is specialised for.
+    static bool make_kin_tables(const hipnlp_robot_model& md, KinTables& kt, std::string& err) {
+        kt = KinTables{};
+        kt.max_depth = 0;
+        kt.link_depth[0] = 0;
+        for (int l = 0; l < NL; ++l) kt.nchild[l] = 0;
+        for (int j = 0; j < NJ; ++j) {
+            const int par = md.parent[j];
+            if (par < 0 || par > j) { err = "robot model: parent[j] must satisfy 0 <= parent[j] <= j (topological order)"; return false; }
+            kt.parent[j] = par;
+            kt.depth[j] = kt.link_depth[par] + 1;
+            kt.link_depth[j + 1] = kt.depth[j];
+            kt.max_depth = std::max(kt.max_depth, kt.depth[j]);
+            if (kt.nchild[par] >= 4) { err = "robot model: more than 4 children on one link"; return false; }
+            kt.child[par][kt.nchild[par]++] = j + 1;
+            double an = 0;
+            for (int i = 0; i < 3; ++i) { kt.o_fix[j][i] = md.o_fix[j][i]; kt.axis[j][i] = md.axis[j][i]; an += md.axis[j][i] * md.axis[j][i]; }
+            if (!(an > 0.999999 && an < 1.000001)) { err = "robot model: joint axes must be unit vectors"; return false; }
+            for (int i = 0; i < 9; ++i) kt.R_fix[j][i] = md.R_fix[j][i];
+        }
+        kt.total_mass = 0;
+        for (int l = 0; l < NL; ++l) {
+            kt.mass[l] = md.mass[l];
+            kt.total_mass += md.mass[l];
+            for (int i = 0; i < 3; ++i) kt.com[l][i] = md.com[l][i];
+            for (int i = 0; i < 9; ++i) kt.inertia[l][i] = md.inertia[l][i];
+        }
+        if (!(kt.total_mass > 0)) { err = "robot model: total mass must be positive"; return false; }
+        for (int j = 0; j < NJ; ++j) { kt.leg_pos[0][j] = kt.leg_pos[1][j] = kt.chest_pos[j] = -1; }
+        for (int f = 0; f < 3; ++f) {
+            kt.frame_link[f] = md.frame_link[f];
+            if (md.frame_link[f] < 0 || md.frame_link[f] >= NL) { err = "robot model: bad frame link"; return false; }
+            for (int i = 0; i < 9; ++i) kt.frame_R[f][i] = md.frame_R[f][i];
+            for (int i = 0; i < 3; ++i) kt.frame_o[f][i] = md.frame_o[f][i];
+            std::vector<int> path;
+            for (int l = md.frame_link[f]; l > 0; l = md.parent[l - 1]) path.push_back(l - 1);
+            std::sort(path.begin(), path.end());
+            const int want = f == HIPNLP_FRAME_CHEST ? CHEST_PATH : LEG_PATH;
+            if (int(path.size()) != want) { err = "robot model: the kernel is specialised for 6-joint leg chains and a 3-joint chest chain"; return false; }
+            for (int q = 0; q < want; ++q) {
+                if (f == HIPNLP_FRAME_CHEST) kt.chest_pos[path[size_t(q)]] = q;
+                else { kt.leg_pos[f][path[size_t(q)]] = q; kt.leg_joint[f][q] = path[size_t(q)]; }
+            }
+        }
+        for (int j = 0; j < NJ; ++j)
+            if (kt.leg_pos[0][j] >= 0 && kt.leg_pos[1][j] >= 0) { err = "robot model: the two leg chains must be disjoint"; return false; }
+        return true;
+    }
+
+    // Canonical bounds (CasADi Opti canon form) from the parameter vector p (one trajectory)
+    void bounds(const double* p, double* lbg, double* ubg) const {
+        const double inf = std::numeric_limits<double>::infinity();
+        const ParamOffsets po(N);
+        auto fill = [&](int kind, int c, auto fn) {
+            const int bi = blk[kind][c];
+            if (bi < 0) return;
+            const RowBlock& b = blocks[size_t(bi)];
+            for (int kk = 0; kk < b.nk; ++kk)
+                for (int i = 0; i < b.rows; ++i) { double lo, hi; fn(b.k0 + kk, i, lo, hi); lbg[b.first_row + b.rows * kk + i] = lo; ubg[b.first_row + b.rows * kk + i] = hi; }
+        };
+        auto eq0 = [](int, int, double& lo, double& hi) { lo = hi = 0.0; };
+        auto ge0 = [inf](int, int, double& lo, double& hi) { lo = 0.0; hi = inf; };
+        for (int c = 0; c < NC; ++c) {
+            fill(RK_FDYN_X0, c, [&](int, int i, double& lo, double& hi) { lo = hi = p[po.init() + 9 * c + 3 + i]; });
+            fill(RK_FDYN_IN, c, eq0);
+            fill(RK_PDYN_X0, c, [&](int, int i, double& lo, double& hi) { lo = hi = p[po.init() + 9 * c + i]; });
+            fill(RK_PDYN_IN, c, eq0);
+            fill(RK_PLANAR, c, eq0);
+            fill(RK_DCC, c, ge0); fill(RK_HEIGHT, c, ge0); fill(RK_NORMAL, c, ge0); fill(RK_FRICTION, c, ge0);
+            fill(RK_UB, c, [&](int, int i, double& lo, double& hi) { hi = p[po.umax() + i]; lo = -hi; });
+            fill(RK_FDB, c, [&](int, int i, double& lo, double& hi) { hi = p[po.fdmax() + i]; lo = -hi; });
+            fill(RK_KINC, c, eq0);
+        }
+        fill(RK_PBDYN_X0, 0, [&](int, int i, double& lo, double& hi) { lo = hi = p[po.init() + 72 + i]; });
+        fill(RK_QBDYN_X0, 0, [&](int, int i, double& lo, double& hi) { lo = hi = p[po.init() + 75 + i]; });
+        fill(RK_SDYN_X0, 0, [&](int, int i, double& lo, double& hi) { lo = hi = p[po.init() + 79 + i]; });
+        fill(RK_COMDYN_X0, 0, [&](int, int i, double& lo, double& hi) { lo = hi = p[po.init() + 102 + i]; });
+        fill(RK_HDYN_X0, 0, eq0);
+        fill(RK_PBDYN_IN, 0, eq0); fill(RK_QBDYN_IN, 0, eq0); fill(RK_SDYN_IN, 0, eq0); fill(RK_COMDYN_IN, 0, eq0); fill(RK_HDYN_IN, 0, eq0);
+        fill(RK_UNITQ, 0, [](int, int, double& lo, double& hi) { lo = hi = 1.0; });
+        fill(RK_COMC, 0, eq0); fill(RK_CMMC, 0, eq0);
+        fill(RK_AMB, 0, [&](int, int, double& lo, double& hi) { hi = p[po.lmax()]; lo = -hi; });
+        fill(RK_COMH, 0, [&](int, int, double& lo, double& hi) { lo = p[po.hmin()]; hi = inf; });
+        fill(RK_FEETD, 0, [&](int, int, double& lo, double& hi) { lo = p[po.dmin()]; hi = inf; });
+        fill(RK_JPB, 0, [&](int, int i, double& lo, double& hi) { lo = p[po.jpmin() + i]; hi = p[po.jpmax() + i]; });
+        fill(RK_JVB, 0, [&](int, int i, double& lo, double& hi) { lo = p[po.jvmin() + i]; hi = p[po.jvmax() + i]; });
+        fill(RK_FEETH, 0, [&](int, int, double& lo, double& hi) { hi = p[po.hmax()]; lo = -hi; });
+        fill(RK_FIN, 0, [&](int, int i, double& lo, double& hi) { lo = hi = final_rhs(p, po, i); });
+        fill(RK_PERN, 0, eq0);
+    }
+    // right-hand side of final-state row i: the final_state parameter matching the sorted to_list() order
+    static double final_rhs(const double* p, const ParamOffsets& po, int i) {
+        const int fo = po.fin();
+        if (i < 3) return p[fo + 102 + i];
+        int r = i - 3;
+        if (r < 72) { const int c = r / 9, q = r % 9; return q < 3 ? p[fo + 9 * c + 6 + q] : (q < 6 ? p[fo + 9 * c + 3 + (q - 3)] : p[fo + 9 * c + (q - 6)]); }
+        r -= 72;
+        if (r < 3) return p[fo + 72 + r];
+        r -= 3;
+        if (r < 4) return p[fo + 75 + r];
+        return p[fo + 79 + (r - 4)];
+    }
+    // rows that are exactly one decision variable (candidates for nlpsol detect_simple_bounds)
+    void simple_rows(int32_t* is_simple, int32_t* var) const {
+        for (int i = 0; i < m; ++i) { is_simple[i] = 0; var[i] = -1; }
+        auto mark = [&](int kind, int c, auto varfn) {
+            const int bi = blk[kind][c];
+            if (bi < 0) return;
+            const RowBlock& b = blocks[size_t(bi)];
+            for (int kk = 0; kk < b.nk; ++kk)
+                for (int i = 0; i < b.rows; ++i) {
+                    const int v = varfn(i);
+                    if (v < 0) continue;
+                    is_simple[b.first_row + b.rows * kk + i] = 1;
+                    var[b.first_row + b.rows * kk + i] = NXK * (b.k0 + kk) + v;
+                }
+        };
+        for (int c = 0; c < NC; ++c) {
+            mark(RK_FDYN_X0, c, [c](int i) { return PT_ * c + F_ + i; });
+            mark(RK_PDYN_X0, c, [c](int i) { return PT_ * c + P_ + i; });
+            mark(RK_UB, c, [c](int i) { return PT_ * c + U_ + i; });
+        }
+        mark(RK_PBDYN_X0, 0, [](int i) { return PB_ + i; });
+        mark(RK_QBDYN_X0, 0, [](int i) { return QB_ + i; });
+        mark(RK_SDYN_X0, 0, [](int i) { return S_ + i; });
+        mark(RK_COMDYN_X0, 0, [](int i) { return COM_ + i; });
+        mark(RK_JPB, 0, [](int i) { return S_ + i; });
+        mark(RK_JVB, 0, [](int i) { return SD_ + i; });
+        mark(RK_FIN, 0, [](int i) { int slot, dp, dc; return final_row_var(i, &slot, &dp, &dc); });
+    }
+};
+
+// pack the device-side parameter records of one trajectory from the reference-order vector p
+inline void pack_params(const double* p, int N, double* pk /*[N][PK_STRIDE]*/, GParams& gp) {
+    const ParamOffsets po(N);
+    for (int k = 0; k < N; ++k) {
+        double* r = pk + size_t(k) * PK_STRIDE;
+        for (int i = 0; i < 24; ++i) r[PK_DESC + i] = p[po.desc(k, 0) + i];
+        for (int i = 0; i < 55; ++i) r[PK_REF + i] = p[po.ref(k) + i];
+        r[79] = 0.0;
+    }
+    gp.dt = p[po.dt()]; gp.kt = p[po.kt()]; gp.kbs = p[po.kbs()]; gp.eps = p[po.eps()]; gp.mu = p[po.mu()]; gp.mass = p[po.mass()];
+    for (int i = 0; i < 6; ++i) gp.gravity[i] = p[po.gravity() + i];
+    for (int i = 0; i < 105; ++i) gp.final_rhs[i] = Layout::final_rhs(p, po, i);
+}
+
+}  // namespace hipnlp

@@ -1,0 +1,141 @@
+// nlp_defs.h — shared constants of the hipnlp engine: per-knot variable offsets, the device-side
+// parameter records, the kernel's NATIVE output slots and the symbolic row/column ids the
+// kernel body attaches to every value it produces.
+//
+// The body (knot_body.h) is compiled three ways from ONE source:
+//   device  : values go to LDS at native slots (ids are dead code)
+//   record  : host, values ignored, ids recorded -> layout.cpp derives g rows / CCS positions
+//   hostemu : tests only (tests/hostemu), values + ids on the CPU to debug the body without a GPU
+#pragma once
+#include <stdint.h>
+
+#include "../../include/hipnlp.h"
+
+#if defined(__HIPCC__)
+#define HD __host__ __device__ __forceinline__
+#else
+#define HD inline
+#endif
+
+namespace hipnlp {
+
+constexpr int NJ = HIPNLP_NJ, NL = HIPNLP_NL, NC = HIPNLP_NC, NXK = HIPNLP_NXK, NXG = HIPNLP_NXG;
+constexpr int LEG_PATH = 6;    // joints between root_link and each sole frame (ergoCub topology)
+constexpr int CHEST_PATH = 3;  // joints between root_link and the chest frame
+constexpr int XPAD = 192;      // LDS stride of one knot record
+
+// ---- per-knot variable offsets (reference creation order, tests/golden/kinodyn_structure.json) --
+enum : int { V_ = 0, FD_ = 3, P_ = 6, F_ = 9, U_ = 12, PT_ = 15,
+             VB_ = 120, QD_ = 123, PB_ = 127, QB_ = 130, SD_ = 134, S_ = 157, COM_ = 180, H_ = 183 };
+
+// ---- per-knot parameter record on the device: [descriptors 24 | references 55 | pad] -----------
+constexpr int PK_STRIDE = 80;
+enum : int { PK_DESC = 0, PK_REF = 24,
+             R_ALPHA_L = 0, R_YAW_L = 4, R_ALPHA_R = 5, R_YAW_R = 9, R_SWING = 10, R_CW = 11, R_CREF = 14,
+             R_VREF = 17, R_FQ = 20, R_BQ = 24, R_BQV = 28, R_JREG = 32 };
+
+// ---- horizon-global parameters the kernels need (bounds-only parameters stay on the host) -----
+struct GParams {
+    double dt, kt, kbs, eps, mu, mass;
+    double gravity[6];
+    double final_rhs[105];  // final_state values in final-row order (only read in `minimize` mode)
+};
+
+// ---- kinematic tree tables (device copy of hipnlp_robot_model + derived topology) ----------------
+struct KinTables {
+    int32_t parent[NJ];
+    int32_t depth[NJ];          // 1 = attached to the root
+    int32_t max_depth;
+    int32_t link_depth[NL];     // 0 for the root
+    int32_t nchild[NL];
+    int32_t child[NL][4];       // child LINK indices
+    int32_t leg_pos[2][NJ];     // position of joint j in the root->sole path (0..5) or -1
+    int32_t leg_joint[2][LEG_PATH];
+    int32_t chest_pos[NJ];      // position in the root->chest path or -1
+    int32_t frame_link[3];
+    double R_fix[NJ][9], o_fix[NJ][3], axis[NJ][3];
+    double mass[NL], com[NL][3], inertia[NL][9];
+    double frame_R[3][9], frame_o[3][3];
+    double total_mass;
+};
+
+// ---- graph constants (hipnlp_settings, flattened for the kernel) ------------------------------------
+struct KSettings {
+    int32_t horizon, final_type, periodicity_type, joint_reg_as_coded, hdyn_x0;
+    int32_t yaw_corner[2][3];
+    double final_weight, periodicity_weight;
+    double m_centroid, w_comvel[3], m_comvel, m_frameq, m_baseq, m_baseqv, w_jreg[NJ], m_jreg, m_freg, m_yaw, m_swing, m_ureg, m_fdreg;
+};
+
+// ---- cost terms (Output.cost_values grouping; order = hipnlp_cost_term_name) -------------------------
+enum : int { CT_SWING = 0, CT_UREG, CT_FDREG, CT_COMVEL, CT_FRAMEQ, CT_BASEQ, CT_BASEQV, CT_JREG, CT_CENTROID, CT_FREG, CT_YAW, CT_ENDS, NCT };
+static_assert(NCT == HIPNLP_NCOST_TERMS, "cost term count");
+
+// =====================================================================================================
+// Row ids: which constraint row a native g slot / jac slot belongs to.
+// =====================================================================================================
+enum RowKind : int {
+    // per contact point (c = 0..7)
+    RK_FDYN_IN = 0, RK_FDYN_OUT, RK_FDYN_X0, RK_PDYN_IN, RK_PDYN_OUT, RK_PDYN_X0,
+    RK_PLANAR, RK_DCC, RK_HEIGHT, RK_NORMAL, RK_FRICTION, RK_UB, RK_FDB, RK_KINC,
+    // global
+    RK_PBDYN_IN, RK_PBDYN_OUT, RK_PBDYN_X0, RK_QBDYN_IN, RK_QBDYN_OUT, RK_QBDYN_X0,
+    RK_SDYN_IN, RK_SDYN_OUT, RK_SDYN_X0, RK_COMDYN_IN, RK_COMDYN_OUT, RK_COMDYN_X0,
+    RK_HDYN_IN, RK_HDYN_OUT, RK_HDYN_X0,
+    RK_UNITQ, RK_COMC, RK_CMMC, RK_AMB, RK_COMH, RK_FEETD, RK_JPB, RK_JVB, RK_FEETH,
+    RK_FIN, RK_PER0, RK_PERN, RK_COUNT
+};
+HD constexpr int row_id(int kind, int c, int i) { return (kind << 16) | (c << 8) | i; }
+HD constexpr int rid_kind(int id) { return id >> 16; }
+HD constexpr int rid_point(int id) { return (id >> 8) & 0xff; }
+HD constexpr int rid_index(int id) { return id & 0xff; }
+constexpr int COL_GLOBAL = NXK;  // column ids >= NXK address the horizon-global variables
+
+// =====================================================================================================
+// Native g slots (per knot)
+// =====================================================================================================
+namespace gs {
+constexpr int FDYN = 0, PDYN = 3, PLANAR = 6, DCC = 9, HEIGHT = 10, NORMAL = 11, FRICTION = 12, UB = 13, FDB = 16, KINC = 19,
+              FDYN_X0 = 22, PDYN_X0 = 25, PT_STRIDE = 28;
+constexpr int G0 = NC * PT_STRIDE;  // 224
+constexpr int PBDYN = G0, QBDYN = PBDYN + 3, SDYN = QBDYN + 4, COMDYN = SDYN + NJ, HDYN = COMDYN + 3,
+              UNITQ = HDYN + 6, COMC = UNITQ + 1, CMMC = COMC + 3, AMB = CMMC + 3, COMH = AMB + 3, FEETD = COMH + 1,
+              JPB = FEETD + 1, JVB = JPB + NJ, FEETH = JVB + NJ,
+              PB_X0 = FEETH + 1, QB_X0 = PB_X0 + 3, S_X0 = QB_X0 + 4, COM_X0 = S_X0 + NJ, H_X0 = COM_X0 + 3,
+              FIN = H_X0 + 6, PER = FIN + 105, COUNT = PER + 84;
+}  // namespace gs
+
+// =====================================================================================================
+// Native jac slots (per knot): every structural entry of the knot's COLUMN block
+// =====================================================================================================
+namespace js {
+// per point
+constexpr int FDYN = 0;          // IN_X 3, IN_Y 3, OUT_X 3, OUT_Y 3, X0 3
+constexpr int PDYN = 15;
+constexpr int PLANAR_V = 30, PLANAR_U = 33, PLANAR_PZ = 36;
+constexpr int DCC = 38;          // PZ, FZ, VZ, FDZ
+constexpr int HEIGHT = 42, NORMAL = 43, FRICTION = 44, UB = 47, FDB = 50;
+constexpr int KINC_P = 53, KINC_PB = 56, KINC_QB = 59, KINC_S = 71;  // QB [3][4], S [3][LEG_PATH]
+constexpr int PT_STRIDE = 71 + 3 * LEG_PATH;  // 89
+constexpr int G0 = NC * PT_STRIDE;            // 712
+// trivial dynamics blocks: L*5 slots each: IN_X, IN_Y, OUT_X, OUT_Y, X0
+constexpr int PBDYN = G0, QBDYN = PBDYN + 15, SDYN = QBDYN + 20, COMDYN = SDYN + 5 * NJ;
+constexpr int HDYN_SELF_IN = COMDYN + 15, HDYN_SELF_OUT = HDYN_SELF_IN + 6, HDYN_X0 = HDYN_SELF_OUT + 6, HDYN_X0G = HDYN_X0 + 6;
+constexpr int HDYN_LIN_F_IN = HDYN_X0G + 6, HDYN_LIN_F_OUT = HDYN_LIN_F_IN + 24;            // [c][i]
+constexpr int HDYN_ANG_P_IN = HDYN_LIN_F_OUT + 24, HDYN_ANG_P_OUT = HDYN_ANG_P_IN + 48;     // [c][6]
+constexpr int HDYN_ANG_F_IN = HDYN_ANG_P_OUT + 48, HDYN_ANG_F_OUT = HDYN_ANG_F_IN + 48;
+constexpr int HDYN_ANG_COM_IN = HDYN_ANG_F_OUT + 48, HDYN_ANG_COM_OUT = HDYN_ANG_COM_IN + 6;
+constexpr int UNITQ = HDYN_ANG_COM_OUT + 6;
+constexpr int COMC_COM = UNITQ + 4, COMC_PB = COMC_COM + 3, COMC_QB = COMC_PB + 3, COMC_S = COMC_QB + 12;  // S [3][NJ]
+constexpr int CMMC_H = COMC_S + 3 * NJ, CMMC_QB = CMMC_H + 3, CMMC_QD = CMMC_QB + 12, CMMC_S = CMMC_QD + 12, CMMC_SD = CMMC_S + 3 * NJ;
+constexpr int AMB = CMMC_SD + 3 * NJ, COMH = AMB + 3, FEETD = COMH + 1;  // FEETD [2][LEG_PATH]
+constexpr int JPB = FEETD + 2 * LEG_PATH, JVB = JPB + NJ, FEETH = JVB + NJ;
+constexpr int FIN = FEETH + NC, PER0 = FIN + 81, PERN = PER0 + 84, COUNT = PERN + 84;
+}  // namespace js
+
+// the six structural entries of d(a x b)/db = [a]x, in (row, col) order
+HD constexpr int cross_row(int e) { return e / 2; }
+HD constexpr int cross_col(int e) { return (e % 2 == 0) ? (e / 2 == 0 ? 1 : 0) : (e / 2 == 2 ? 1 : 2); }
+// e: 0 (0,1) 1 (0,2) 2 (1,0) 3 (1,2) 4 (2,0) 5 (2,1)
+
+}  // namespace hipnlp

@@ -1,0 +1,101 @@
+// TEST-ONLY host emulation of the HIP kernel's knot program.
+// It runs the *same* knot_body.h phases the gfx950 kernel runs (one "lane task" at a time, a loop
+// instead of a wavefront) and the same layout tables for the copy-out, so the kernel mathematics and
+// the CCS bookkeeping can be debugged against the oracle on a machine without a GPU.
+// It is NOT part of the product: libhipnlp.so does not contain it and hipnlp_eval never falls back to it.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../hippopt_amd/csrc/layout.h"
+
+using namespace hipnlp;
+
+struct ValueEm {
+    double* g;
+    double* jac;
+    void G(int slot, int, double v) { g[slot] = v; }
+    void J(int slot, int, int, double v) { jac[slot] = v; }
+};
+
+struct hostemu_handle {
+    hipnlp_desc d;
+    KinTables kt;
+    KSettings ks;
+    Layout L;
+};
+
+extern "C" {
+
+hostemu_handle* hostemu_create(const hipnlp_desc* desc, char* err, int errlen) {
+    hostemu_handle* h = new hostemu_handle();
+    h->d = *desc;
+    std::string e;
+    if (!Layout::make_kin_tables(desc->model, h->kt, e) || !h->L.build(desc->settings, h->kt)) {
+        if (e.empty()) e = h->L.error;
+        std::strncpy(err, e.c_str(), size_t(errlen - 1));
+        delete h;
+        return nullptr;
+    }
+    h->ks = Layout::make_ksettings(desc->settings);
+    return h;
+}
+void hostemu_destroy(hostemu_handle* h) { delete h; }
+void hostemu_dims(const hostemu_handle* h, int* n, int* m, int* nnz) { *n = h->L.n; *m = h->L.m; *nnz = h->L.nnz; }
+void hostemu_sparsity(const hostemu_handle* h, int* irow, int* jcol) {
+    for (int i = 0; i < h->L.nnz; ++i) { irow[i] = h->L.irow[size_t(i)]; jcol[i] = h->L.jcol[size_t(i)]; }
+}
+void hostemu_bounds(const hostemu_handle* h, const double* p, double* lbg, double* ubg) { h->L.bounds(p, lbg, ubg); }
+void hostemu_simple_rows(const hostemu_handle* h, int* is_simple, int* var) { h->L.simple_rows(is_simple, var); }
+int hostemu_num_row_blocks(const hostemu_handle* h) { return int(h->L.blocks.size()); }
+void hostemu_row_block(const hostemu_handle* h, int i, const char** name, int* first, int* rows, int* k0, int* nk) {
+    const RowBlock& b = h->L.blocks[size_t(i)];
+    *name = b.name.c_str(); *first = b.first_row; *rows = b.rows; *k0 = b.k0; *nk = b.nk;
+}
+
+void hostemu_eval(const hostemu_handle* h, const double* x, const double* p, double* f, double* grad, double* g, double* jac, double* cost_terms) {
+    const Layout& L = h->L;
+    const int N = L.N;
+    std::vector<double> pk(size_t(N) * PK_STRIDE);
+    GParams gp;
+    pack_params(p, N, pk.data(), gp);
+    for (int i = 0; i < NCT; ++i) cost_terms[i] = 0.0;
+    for (int i = 0; i < L.n; ++i) grad[i] = 0.0;
+    KnotScratch* s = new KnotScratch();
+    for (int k = 0; k < N; ++k) {
+        std::fill(reinterpret_cast<double*>(s), reinterpret_cast<double*>(s) + sizeof(KnotScratch) / sizeof(double), std::nan(""));
+        for (int i = 0; i < XPAD; ++i) { s->x[i] = 0; s->xm[i] = 0; s->xo[i] = 0; }
+        for (int i = 0; i < NXK; ++i) {
+            s->x[i] = x[NXK * k + i];
+            s->xm[i] = k > 0 ? x[NXK * (k - 1) + i] : 0.0;
+            s->xo[i] = k == 0 ? x[NXK * (N - 1) + i] : (k == N - 1 ? x[i] : 0.0);
+        }
+        for (int i = 0; i < NXG; ++i) s->xg[i] = x[NXK * N + i];
+        for (int i = 0; i < PK_STRIDE; ++i) s->pk[i] = pk[size_t(k) * PK_STRIDE + i];
+        KnotInfo ki{k, N, k == 0, k == N - 1};
+        ValueEm em{s->g, s->jac};
+        Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
+        const int maxd = h->kt.max_depth;
+#define HOST_RUN(fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
+#define HOST_RUNL(fn, nt, lvl) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_, lvl);
+        HIPNLP_KNOT_PROGRAM(HOST_RUN, HOST_RUNL, , maxd)
+#undef HOST_RUN
+#undef HOST_RUNL
+        // copy-out exactly as the kernel does
+        const int v = L.variant_of(k);
+        const long jb = L.jac_base(k);
+        for (int i = 0; i < L.nnz_v[v]; ++i) jac[jb + i] = s->jac[L.jperm[v][size_t(i)]];
+        if (k == 0) for (size_t i = 0; i < L.jperm_glob.size(); ++i) jac[L.jac_glob_base + long(i)] = s->jac[L.jperm_glob[i]];
+        for (int slot = 0; slot < gs::COUNT; ++slot) {
+            const int a = L.g_a[v][size_t(slot)];
+            if (a >= 0) g[a + L.g_b[size_t(slot)] * k] = s->g[slot];
+        }
+        for (int i = 0; i < NXK; ++i) grad[NXK * k + i] = s->grad[i];
+        for (int i = 0; i < NCT; ++i) cost_terms[i] += s->cost[i];
+    }
+    delete s;
+    double ft = 0.0;
+    for (int i = 0; i < NCT; ++i) ft += cost_terms[i];
+    *f = ft;
+}
+}  // extern "C"
