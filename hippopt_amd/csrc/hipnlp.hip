@@ -1,0 +1,451 @@
+// hipnlp.hip — gfx950 kernels and the C-ABI (include/hipnlp.h) of the multiple-shooting NLP-callback engine.
+//
+// Execution model: one 64-lane workgroup (= one CDNA4 wavefront) per shooting knot.
+// The wave stages the knot record x_k (189 fp64, contiguous => three coalesced 512-B wave loads), its
+// predecessor x_{k-1} (trapezoid halo) and the per-knot parameter record in LDS, runs the knot program of
+// knot_body.h with lanes mapped to contact points / joints / tree levels, collects all outputs of the knot
+// in LDS at compile-time native slots and finally streams them out: the knot's CCS column block of jac g
+// as ONE contiguous run (permuted through an L2-resident int table), grad f contiguous, g scattered into
+// the reference's constraint-type-major order, the cost partials per knot.  A second tiny kernel reduces
+// the per-knot cost partials in a fixed order (bitwise reproducible f).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "layout.h"
+
+using namespace hipnlp;
+
+namespace {
+
+constexpr int WG = 64;
+
+struct DeviceTables {
+    KinTables kt;
+    KSettings ks;
+    int32_t g_a[3][gs::COUNT];
+    int32_t g_b[gs::COUNT];
+    int32_t jperm[3][js::COUNT];
+    int32_t jperm_glob[16];
+    int32_t nnz_v[3];
+    int32_t n_glob, jac_glob_base;
+};
+
+struct KArgs {
+    const DeviceTables* tb;
+    const double* x;        // [batch][n]
+    const double* pk;       // [batch][N][PK_STRIDE]
+    const GParams* gp;      // [batch]
+    double* g;              // [batch][m]      or null
+    double* jac;            // [batch][nnz]    or null
+    double* grad;           // [batch][n]      or null
+    double* cost_knot;      // [batch][nk][NCT]
+    int32_t* flags;         // [batch][nk]  non-finite detector
+    int32_t N, n, m, nnz, knot_begin, nk;
+};
+
+struct DevEm {
+    double* g;
+    double* jac;
+    __device__ __forceinline__ void G(int slot, int, double v) { g[slot] = v; }
+    __device__ __forceinline__ void J(int slot, int, int, double v) { jac[slot] = v; }
+};
+
+__global__ __launch_bounds__(WG) void hipnlp_knot_kernel(KArgs a) {
+    __shared__ KnotScratch s;
+    const int tid = threadIdx.x;
+    const int kk = blockIdx.x, b = blockIdx.y;
+    const int k = a.knot_begin + kk;
+    const int N = a.N;
+    const double* x = a.x + size_t(b) * a.n;
+    const int first = k == 0, last = k == N - 1;
+    // ---- stage the knot records in LDS (coalesced: consecutive lanes read consecutive doubles) ----
+    for (int i = tid; i < XPAD; i += WG) {
+        const bool in = i < NXK;
+        s.x[i] = in ? x[size_t(NXK) * k + i] : 0.0;
+        s.xm[i] = (in && !first) ? x[size_t(NXK) * (k - 1) + i] : 0.0;
+        s.xo[i] = (in && (first || last)) ? x[size_t(NXK) * (first ? N - 1 : 0) + i] : 0.0;
+    }
+    for (int i = tid; i < PK_STRIDE; i += WG) s.pk[i] = a.pk[(size_t(b) * N + k) * PK_STRIDE + i];
+    if (tid < 8) s.xg[tid] = tid < NXG ? x[size_t(NXK) * N + tid] : 0.0;
+    __syncthreads();
+
+    const DeviceTables& tb = *a.tb;
+    KnotInfo ki{k, N, first, last};
+    DevEm em{s.g, s.jac};
+    Ctx<DevEm> cx(s, tb.kt, tb.ks, a.gp[b], ki, em);
+    const int maxd = tb.kt.max_depth;
+#define DEV_RUN(fn, nt) for (int t_ = tid; t_ < (nt); t_ += WG) fn(cx, t_);
+#define DEV_RUNL(fn, nt, lvl) for (int t_ = tid; t_ < (nt); t_ += WG) fn(cx, t_, lvl);
+#define DEV_BARRIER __syncthreads();
+    HIPNLP_KNOT_PROGRAM(DEV_RUN, DEV_RUNL, DEV_BARRIER, maxd)
+#undef DEV_RUN
+#undef DEV_RUNL
+#undef DEV_BARRIER
+
+    // ---- stream the knot's outputs ---------------------------------------------------------------------
+    const int v = first ? VAR_FIRST : (last ? VAR_LAST : VAR_INTERIOR);
+    int bad = 0;
+    if (a.jac) {
+        double* out = a.jac + size_t(b) * a.nnz + (first ? 0 : size_t(tb.nnz_v[VAR_FIRST]) + size_t(k - 1) * tb.nnz_v[VAR_INTERIOR]);
+        const int cnt = tb.nnz_v[v];
+        const int32_t* perm = tb.jperm[v];
+        for (int i = tid; i < cnt; i += WG) {
+            const double val = s.jac[perm[i]];
+            bad |= !isfinite(val);
+            out[i] = val;
+        }
+        if (first && tid < tb.n_glob) a.jac[size_t(b) * a.nnz + tb.jac_glob_base + tid] = s.jac[tb.jperm_glob[tid]];
+    }
+    if (a.g) {
+        double* out = a.g + size_t(b) * a.m;
+        for (int slot = tid; slot < gs::COUNT; slot += WG) {
+            const int ga = tb.g_a[v][slot];
+            if (ga >= 0) {
+                const double val = s.g[slot];
+                bad |= !isfinite(val);
+                out[ga + tb.g_b[slot] * k] = val;
+            }
+        }
+    }
+    if (a.grad) {
+        double* out = a.grad + size_t(b) * a.n + size_t(NXK) * k;
+        for (int i = tid; i < NXK; i += WG) {
+            const double val = s.grad[i];
+            bad |= !isfinite(val);
+            out[i] = val;
+        }
+        if (last && tid < NXG) a.grad[size_t(b) * a.n + size_t(NXK) * N + tid] = 0.0;  // the global variables carry no cost
+    }
+    if (tid < NCT) {
+        const double val = s.cost[tid];
+        bad |= !isfinite(val);
+        a.cost_knot[(size_t(b) * a.nk + kk) * NCT + tid] = val;
+    }
+    const int anybad = __syncthreads_or(bad);
+    if (tid == 0) a.flags[size_t(b) * a.nk + kk] = anybad;
+}
+
+// f[b] = sum over knots and terms, fixed order; cost_terms[b][t] = sum over knots; flag[b] = any non-finite
+__global__ __launch_bounds__(WG) void hipnlp_reduce_kernel(const double* cost_knot, const int32_t* flags, int nk,
+                                                           double* f, double* cost_terms, int32_t* flag_out) {
+    __shared__ double terms[NCT];
+    __shared__ int anyflag;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) anyflag = 0;
+    __syncthreads();
+    if (tid < NCT) {
+        double acc = 0.0;
+        for (int k = 0; k < nk; ++k) acc += cost_knot[(size_t(b) * nk + k) * NCT + tid];
+        terms[tid] = acc;
+        if (cost_terms) cost_terms[size_t(b) * NCT + tid] = acc;
+    }
+    int bad = 0;
+    for (int k = tid; k < nk; k += WG) bad |= flags[size_t(b) * nk + k];
+    if (bad) atomicOr(&anyflag, 1);
+    __syncthreads();
+    if (tid == 0) {
+        double acc = 0.0;
+        for (int t = 0; t < NCT; ++t) acc += terms[t];
+        if (f) f[b] = acc;
+        flag_out[b] = anyflag;
+    }
+}
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct hipnlp_handle {
+    hipnlp_desc d;
+    Layout L;
+    KinTables kt;
+    int batch = 1, kb = 0, ke = 0, nk = 0, np = 0;
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing_valid = false;
+    DeviceTables* d_tb = nullptr;
+    double *d_x = nullptr, *d_pk = nullptr, *d_g = nullptr, *d_jac = nullptr, *d_grad = nullptr, *d_f = nullptr;
+    double *d_cost_knot = nullptr, *d_cost_terms = nullptr;
+    GParams* d_gp = nullptr;
+    int32_t *d_flags = nullptr, *d_flag = nullptr;
+    // pinned host staging
+    double *h_x = nullptr, *h_g = nullptr, *h_jac = nullptr, *h_grad = nullptr, *h_f = nullptr, *h_cost_terms = nullptr;
+    int32_t* h_flag = nullptr;
+    std::vector<double> p;
+    bool params_set = false, have_result = false;
+    std::string err;
+};
+
+#define HIP_TRY(h, call)                                                                            \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+            return HIPNLP_E_NODEVICE;                                                               \
+        }                                                                                           \
+    } while (0)
+
+static void free_all(hipnlp_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->dev);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* dptrs[] = {h->d_tb, h->d_x, h->d_pk, h->d_g, h->d_jac, h->d_grad, h->d_f, h->d_cost_knot, h->d_cost_terms, h->d_gp, h->d_flags, h->d_flag};
+    for (void* q : dptrs) if (q) (void)hipFree(q);
+    void* hptrs[] = {h->h_x, h->h_g, h->h_jac, h->h_grad, h->h_f, h->h_cost_terms, h->h_flag};
+    for (void* q : hptrs) if (q) (void)hipHostFree(q);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" {
+
+const char* hipnlp_last_error(const hipnlp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
+    if (!desc || !out) { g_create_error = "null argument"; return HIPNLP_E_INVALID; }
+    *out = nullptr;
+    hipnlp_handle* h = new (std::nothrow) hipnlp_handle();
+    if (!h) { g_create_error = "out of memory"; return HIPNLP_E_ALLOC; }
+    h->d = *desc;
+    const hipnlp_settings& st = desc->settings;
+    auto fail = [&](int code, const std::string& msg) { g_create_error = msg; free_all(h); return code; };
+    if (st.horizon < 2) return fail(HIPNLP_E_INVALID, "settings.horizon must be >= 2");
+    if (st.terrain != HIPNLP_TERRAIN_PLANAR) return fail(HIPNLP_E_INVALID, "only HIPNLP_TERRAIN_PLANAR is implemented");
+    if (desc->batch < 1) return fail(HIPNLP_E_INVALID, "batch must be >= 1");
+    for (int f = 0; f < 2; ++f) for (int i = 0; i < 3; ++i)
+        if (st.yaw_corner[f][i] < 0 || st.yaw_corner[f][i] > 3) return fail(HIPNLP_E_INVALID, "yaw_corner indices must be in 0..3");
+    h->batch = desc->batch;
+    h->kb = desc->knot_begin; h->ke = desc->knot_end;
+    if (h->kb == 0 && h->ke == 0) h->ke = st.horizon;
+    if (h->kb < 0 || h->ke > st.horizon || h->kb >= h->ke) return fail(HIPNLP_E_INVALID, "bad knot shard [knot_begin, knot_end)");
+    h->nk = h->ke - h->kb;
+    std::string e;
+    if (!Layout::make_kin_tables(desc->model, h->kt, e)) return fail(HIPNLP_E_INVALID, e);
+    if (!h->L.build(st, h->kt)) return fail(HIPNLP_E_INVALID, h->L.error);
+    h->np = ParamOffsets(st.horizon).np();
+    if (h->L.jperm_glob.size() > 16) return fail(HIPNLP_E_INVALID, "internal: too many global-column entries");
+
+    // ---- device -------------------------------------------------------------------------------------
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(HIPNLP_E_NODEVICE, "no HIP device available (the engine has no CPU fallback)");
+    if (desc->device < 0 || desc->device >= ndev) return fail(HIPNLP_E_INVALID, "bad device ordinal");
+    h->dev = desc->device;
+#define CREATE_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(HIPNLP_E_NODEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+    CREATE_TRY(hipSetDevice(h->dev));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreate(&h->ev0));
+    CREATE_TRY(hipEventCreate(&h->ev1));
+    const size_t B = size_t(h->batch), n = size_t(h->L.n), m = size_t(h->L.m), nnz = size_t(h->L.nnz), N = size_t(st.horizon);
+    CREATE_TRY(hipMalloc(&h->d_tb, sizeof(DeviceTables)));
+    CREATE_TRY(hipMalloc(&h->d_x, B * n * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_pk, B * N * PK_STRIDE * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_gp, B * sizeof(GParams)));
+    CREATE_TRY(hipMalloc(&h->d_g, B * m * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_jac, B * nnz * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_grad, B * n * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_f, B * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_cost_knot, B * size_t(h->nk) * NCT * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_cost_terms, B * NCT * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_flags, B * size_t(h->nk) * sizeof(int32_t)));
+    CREATE_TRY(hipMalloc(&h->d_flag, B * sizeof(int32_t)));
+    CREATE_TRY(hipHostMalloc(&h->h_x, B * n * sizeof(double)));
+    CREATE_TRY(hipHostMalloc(&h->h_g, B * m * sizeof(double)));
+    CREATE_TRY(hipHostMalloc(&h->h_jac, B * nnz * sizeof(double)));
+    CREATE_TRY(hipHostMalloc(&h->h_grad, B * n * sizeof(double)));
+    CREATE_TRY(hipHostMalloc(&h->h_f, B * sizeof(double)));
+    CREATE_TRY(hipHostMalloc(&h->h_cost_terms, B * NCT * sizeof(double)));
+    CREATE_TRY(hipHostMalloc(&h->h_flag, B * sizeof(int32_t)));
+    CREATE_TRY(hipMemset(h->d_g, 0, B * m * sizeof(double)));
+    CREATE_TRY(hipMemset(h->d_jac, 0, B * nnz * sizeof(double)));
+    CREATE_TRY(hipMemset(h->d_grad, 0, B * n * sizeof(double)));
+    // tables
+    DeviceTables* tb = new DeviceTables();
+    std::memset(tb, 0, sizeof(DeviceTables));
+    tb->kt = h->kt;
+    tb->ks = Layout::make_ksettings(st);
+    for (int v = 0; v < 3; ++v) {
+        for (int s = 0; s < gs::COUNT; ++s) tb->g_a[v][s] = h->L.g_a[v][size_t(s)];
+        for (size_t i = 0; i < h->L.jperm[v].size(); ++i) tb->jperm[v][i] = h->L.jperm[v][i];
+        tb->nnz_v[v] = h->L.nnz_v[v];
+    }
+    for (int s = 0; s < gs::COUNT; ++s) tb->g_b[s] = h->L.g_b[size_t(s)];
+    tb->n_glob = int(h->L.jperm_glob.size());
+    for (int i = 0; i < tb->n_glob; ++i) tb->jperm_glob[i] = h->L.jperm_glob[size_t(i)];
+    tb->jac_glob_base = h->L.jac_glob_base;
+    hipError_t ce = hipMemcpy(h->d_tb, tb, sizeof(DeviceTables), hipMemcpyHostToDevice);
+    delete tb;
+    if (ce != hipSuccess) return fail(HIPNLP_E_NODEVICE, std::string("hipMemcpy tables: ") + hipGetErrorString(ce));
+#undef CREATE_TRY
+    *out = h;
+    return HIPNLP_OK;
+}
+
+void hipnlp_destroy(hipnlp_handle* h) { free_all(h); }
+
+int hipnlp_get_dims(const hipnlp_handle* h, hipnlp_dims* o) {
+    if (!h || !o) return HIPNLP_E_INVALID;
+    const Layout& L = h->L;
+    o->n = L.n; o->m = L.m; o->nnz = L.nnz; o->np = h->np;
+    o->nnz_knot = L.N >= 3 ? L.nnz_v[VAR_INTERIOR] : 0;
+    int mk = 0;
+    for (const RowBlock& b : L.blocks) if (b.nk > 1) mk += b.rows;
+    o->m_knot = mk;
+    o->shard_grad = NXK * h->nk;
+    o->shard_grad_off = NXK * h->kb;
+    o->shard_jac_off = int(L.jac_base(h->kb));
+    o->shard_nnz = int((h->ke == L.N ? long(L.jac_glob_base) : L.jac_base(h->ke)) - L.jac_base(h->kb));
+    int rows = 0;
+    for (int k = h->kb; k < h->ke; ++k) {
+        const int v = L.variant_of(k);
+        for (int s = 0; s < gs::COUNT; ++s) rows += L.g_a[v][size_t(s)] >= 0;
+    }
+    o->shard_g_rows = rows;
+    return HIPNLP_OK;
+}
+
+int hipnlp_set_params(hipnlp_handle* h, const double* p) {
+    if (!h || !p) return HIPNLP_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->dev));
+    const size_t B = size_t(h->batch), N = size_t(h->L.N);
+    h->p.assign(p, p + B * size_t(h->np));
+    std::vector<double> pk(B * N * PK_STRIDE);
+    std::vector<GParams> gp(B);
+    for (size_t b = 0; b < B; ++b) pack_params(p + b * size_t(h->np), int(N), pk.data() + b * N * PK_STRIDE, gp[b]);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(h->d_pk, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_gp, gp.data(), gp.size() * sizeof(GParams), hipMemcpyHostToDevice));
+    h->params_set = true;
+    h->have_result = false;
+    return HIPNLP_OK;
+}
+
+int hipnlp_bounds(const hipnlp_handle* h, double* lbx, double* ubx, double* lbg, double* ubg) {
+    if (!h) return HIPNLP_E_INVALID;
+    if (!h->params_set) return HIPNLP_E_PARAMS;
+    const double inf = std::numeric_limits<double>::infinity();
+    if (lbx) for (int i = 0; i < h->L.n; ++i) lbx[i] = -inf;
+    if (ubx) for (int i = 0; i < h->L.n; ++i) ubx[i] = inf;
+    if (lbg || ubg) {
+        std::vector<double> lo(size_t(h->L.m)), hi(size_t(h->L.m));
+        h->L.bounds(h->p.data(), lo.data(), hi.data());
+        if (lbg) std::memcpy(lbg, lo.data(), lo.size() * sizeof(double));
+        if (ubg) std::memcpy(ubg, hi.data(), hi.size() * sizeof(double));
+    }
+    return HIPNLP_OK;
+}
+
+int hipnlp_simple_rows(const hipnlp_handle* h, int32_t* is_simple, int32_t* var_index) {
+    if (!h || !is_simple || !var_index) return HIPNLP_E_INVALID;
+    h->L.simple_rows(is_simple, var_index);
+    return HIPNLP_OK;
+}
+
+int hipnlp_sparsity(const hipnlp_handle* h, int32_t* irow, int32_t* jcol) {
+    if (!h || !irow || !jcol) return HIPNLP_E_INVALID;
+    std::memcpy(irow, h->L.irow.data(), size_t(h->L.nnz) * sizeof(int32_t));
+    std::memcpy(jcol, h->L.jcol.data(), size_t(h->L.nnz) * sizeof(int32_t));
+    return HIPNLP_OK;
+}
+
+static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, hipStream_t s) {
+    KArgs a;
+    a.tb = h->d_tb; a.x = x_dev; a.pk = h->d_pk; a.gp = h->d_gp;
+    a.g = g_dev; a.jac = jac_dev; a.grad = grad_dev;
+    a.cost_knot = h->d_cost_knot; a.flags = h->d_flags;
+    a.N = h->L.N; a.n = h->L.n; a.m = h->L.m; a.nnz = h->L.nnz; a.knot_begin = h->kb; a.nk = h->nk;
+    HIP_TRY(h, hipEventRecord(h->ev0, s));
+    hipLaunchKernelGGL(hipnlp_knot_kernel, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(WG), 0, s, a);
+    hipLaunchKernelGGL(hipnlp_reduce_kernel, dim3(unsigned(h->batch)), dim3(WG), 0, s,
+                       (const double*)h->d_cost_knot, (const int32_t*)h->d_flags, h->nk, f_dev, h->d_cost_terms, h->d_flag);
+    HIP_TRY(h, hipEventRecord(h->ev1, s));
+    HIP_TRY(h, hipGetLastError());
+    h->timing_valid = true;
+    return HIPNLP_OK;
+}
+
+int hipnlp_eval_device(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, void* stream) {
+    if (!h || !x_dev) return HIPNLP_E_INVALID;
+    if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
+    HIP_TRY(h, hipSetDevice(h->dev));
+    h->have_result = false;
+    return launch(h, x_dev, f_dev ? f_dev : h->d_f, grad_dev, g_dev, jac_dev, stream ? hipStream_t(stream) : h->stream);
+}
+
+int hipnlp_eval(hipnlp_handle* h, const double* x, int new_x, double* f, double* grad_f, double* g, double* jac) {
+    if (!h || !x) return HIPNLP_E_INVALID;
+    if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
+    const size_t B = size_t(h->batch), n = size_t(h->L.n), m = size_t(h->L.m), nnz = size_t(h->L.nnz);
+    if (new_x || !h->have_result) {
+        HIP_TRY(h, hipSetDevice(h->dev));
+        std::memcpy(h->h_x, x, B * n * sizeof(double));
+        HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_x, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        int rc = launch(h, h->d_x, h->d_f, h->d_grad, h->d_g, h->d_jac, h->stream);
+        if (rc != HIPNLP_OK) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->h_f, h->d_f, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->h_flag, h->d_flag, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->h_cost_terms, h->d_cost_terms, B * NCT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->h_grad, h->d_grad, B * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->h_g, h->d_g, B * m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->h_jac, h->d_jac, B * nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->have_result = true;
+    }
+    if (f) std::memcpy(f, h->h_f, B * sizeof(double));
+    if (grad_f) std::memcpy(grad_f, h->h_grad, B * n * sizeof(double));
+    if (g) std::memcpy(g, h->h_g, B * m * sizeof(double));
+    if (jac) std::memcpy(jac, h->h_jac, B * nnz * sizeof(double));
+    for (size_t b = 0; b < B; ++b)
+        if (h->h_flag[b]) { h->err = "non-finite value produced by the evaluation"; return HIPNLP_E_NUMERIC; }
+    return HIPNLP_OK;
+}
+
+int hipnlp_cost_terms(hipnlp_handle* h, double* values) {
+    if (!h || !values) return HIPNLP_E_INVALID;
+    if (!h->have_result) {
+        HIP_TRY(h, hipSetDevice(h->dev));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipMemcpy(h->h_cost_terms, h->d_cost_terms, size_t(h->batch) * NCT * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    std::memcpy(values, h->h_cost_terms, size_t(h->batch) * NCT * sizeof(double));
+    return HIPNLP_OK;
+}
+
+const char* hipnlp_cost_term_name(int i) {
+    static const char* names[NCT] = {"swing_height_regularization", "u_v_regularization", "f_dot_regularization", "com_velocity_error",
+                                     "frame_quaternion_error", "base_quaternion_error", "base_quaternion_velocity_error", "joint_positions_error",
+                                     "contacts_centroid_cost", "f_regularization", "yaw_regularization", "final_and_periodicity"};
+    return (i >= 0 && i < NCT) ? names[i] : "";
+}
+
+int hipnlp_num_row_blocks(const hipnlp_handle* h) { return h ? int(h->L.blocks.size()) : HIPNLP_E_INVALID; }
+
+int hipnlp_row_block(const hipnlp_handle* h, int i, const char** name, int32_t* first_row, int32_t* rows_per_knot, int32_t* first_knot, int32_t* n_knots) {
+    if (!h || i < 0 || i >= int(h->L.blocks.size())) return HIPNLP_E_INVALID;
+    const RowBlock& b = h->L.blocks[size_t(i)];
+    if (name) *name = b.name.c_str();
+    if (first_row) *first_row = b.first_row;
+    if (rows_per_knot) *rows_per_knot = b.rows;
+    if (first_knot) *first_knot = b.k0;
+    if (n_knots) *n_knots = b.nk;
+    return HIPNLP_OK;
+}
+
+int hipnlp_last_kernel_ms(hipnlp_handle* h, float* ms) {
+    if (!h || !ms) return HIPNLP_E_INVALID;
+    if (!h->timing_valid) { h->err = "no evaluation has been launched yet"; return HIPNLP_E_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->dev));
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return HIPNLP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+"""ctypes binding of the C-ABI in include/hipnlp.h (libhipnlp.so, built by __graft_entry__.build()).
+
+There is no CPU fallback: loading fails loudly when the library is missing, and `HipNlp(...)`
+raises when no HIP device is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhipnlp.so")
+_lib = None
+
+EXPORTS = [
+    "hipnlp_create", "hipnlp_destroy", "hipnlp_last_error", "hipnlp_get_dims", "hipnlp_set_params",
+    "hipnlp_bounds", "hipnlp_simple_rows", "hipnlp_sparsity", "hipnlp_eval", "hipnlp_eval_device",
+    "hipnlp_cost_terms", "hipnlp_cost_term_name", "hipnlp_num_row_blocks", "hipnlp_row_block",
+    "hipnlp_last_kernel_ms",
+]
+
+
+class HipNlpError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"hipnlp error {code}: {message}")
+        self.code = code
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). The engine has no CPU fallback.")
+    lib = C.CDLL(_LIB_PATH)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
+    lib.hipnlp_create.argtypes = [C.POINTER(_abi.DescC), C.POINTER(vp)]
+    lib.hipnlp_destroy.argtypes = [vp]
+    lib.hipnlp_destroy.restype = None
+    lib.hipnlp_last_error.argtypes = [vp]
+    lib.hipnlp_last_error.restype = C.c_char_p
+    lib.hipnlp_get_dims.argtypes = [vp, C.POINTER(_abi.DimsC)]
+    lib.hipnlp_set_params.argtypes = [vp, dp]
+    lib.hipnlp_bounds.argtypes = [vp, dp, dp, dp, dp]
+    lib.hipnlp_simple_rows.argtypes = [vp, ip, ip]
+    lib.hipnlp_sparsity.argtypes = [vp, ip, ip]
+    lib.hipnlp_eval.argtypes = [vp, dp, C.c_int, dp, dp, dp, dp]
+    lib.hipnlp_eval_device.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.hipnlp_cost_terms.argtypes = [vp, dp]
+    lib.hipnlp_cost_term_name.argtypes = [C.c_int]
+    lib.hipnlp_cost_term_name.restype = C.c_char_p
+    lib.hipnlp_num_row_blocks.argtypes = [vp]
+    lib.hipnlp_row_block.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), ip, ip, ip, ip]
+    lib.hipnlp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    _lib = lib
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class HipNlp:
+    """One engine handle: a kinodynamic NLP (settings + robot model) on one HIP device."""
+
+    def __init__(self, settings, model, batch=1, knot_begin=0, knot_end=0, device=0):
+        self.lib = load_library()
+        self.desc = _abi.DescC()
+        self.desc.settings = settings.to_c()
+        self.desc.model = model.to_c()
+        self.desc.batch = int(batch)
+        self.desc.knot_begin, self.desc.knot_end = int(knot_begin), int(knot_end)
+        self.desc.device = int(device)
+        h = C.c_void_p()
+        rc = self.lib.hipnlp_create(C.byref(self.desc), C.byref(h))
+        if rc != 0:
+            raise HipNlpError(rc, self.lib.hipnlp_last_error(None).decode())
+        self.h = h
+        d = _abi.DimsC()
+        self._check(self.lib.hipnlp_get_dims(self.h, C.byref(d)))
+        self.dims = d
+        self.batch = int(batch)
+        self.n, self.m, self.nnz, self.np = d.n, d.m, d.nnz, d.np
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hipnlp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise HipNlpError(rc, self.lib.hipnlp_last_error(self.h).decode())
+
+    def set_params(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float64).reshape(self.batch, self.np)
+        self._check(self.lib.hipnlp_set_params(self.h, _dp(p)))
+
+    def bounds(self):
+        lbx, ubx, lbg, ubg = np.empty(self.n), np.empty(self.n), np.empty(self.m), np.empty(self.m)
+        self._check(self.lib.hipnlp_bounds(self.h, _dp(lbx), _dp(ubx), _dp(lbg), _dp(ubg)))
+        return lbx, ubx, lbg, ubg
+
+    def simple_rows(self):
+        a, b = np.zeros(self.m, np.int32), np.zeros(self.m, np.int32)
+        self._check(self.lib.hipnlp_simple_rows(self.h, _ip(a), _ip(b)))
+        return a, b
+
+    def sparsity(self):
+        ir, jc = np.zeros(self.nnz, np.int32), np.zeros(self.nnz, np.int32)
+        self._check(self.lib.hipnlp_sparsity(self.h, _ip(ir), _ip(jc)))
+        return ir, jc
+
+    def row_blocks(self):
+        out = []
+        for i in range(self.lib.hipnlp_num_row_blocks(self.h)):
+            name = C.c_char_p()
+            a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+            self._check(self.lib.hipnlp_row_block(self.h, i, C.byref(name), C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+            out.append((name.value.decode(), a.value, b.value, c.value, d.value))
+        return out
+
+    def eval(self, x, new_x=True, want=("f", "grad", "g", "jac")):
+        """Host-buffer callback set.  Returns (f[batch], grad[batch,n], g[batch,m], jac[batch,nnz])."""
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.batch, self.n)
+        f = np.empty(self.batch) if "f" in want else None
+        grad = np.empty((self.batch, self.n)) if "grad" in want else None
+        g = np.empty((self.batch, self.m)) if "g" in want else None
+        jac = np.empty((self.batch, self.nnz)) if "jac" in want else None
+        self._check(self.lib.hipnlp_eval(self.h, _dp(x), 1 if new_x else 0, _dp(f), _dp(grad), _dp(g), _dp(jac)))
+        return f, grad, g, jac
+
+    def eval_device(self, x_ptr, f_ptr=0, grad_ptr=0, g_ptr=0, jac_ptr=0, stream=0):
+        """Device-pointer variant (ints from tensor.data_ptr()); asynchronous on `stream`."""
+        self._check(self.lib.hipnlp_eval_device(self.h, C.c_void_p(x_ptr), C.c_void_p(f_ptr or None), C.c_void_p(grad_ptr or None),
+                                                C.c_void_p(g_ptr or None), C.c_void_p(jac_ptr or None), C.c_void_p(stream or None)))
+
+    def cost_terms(self):
+        out = np.empty((self.batch, _abi.NCOST_TERMS))
+        self._check(self.lib.hipnlp_cost_terms(self.h, _dp(out)))
+        names = [self.lib.hipnlp_cost_term_name(i).decode() for i in range(_abi.NCOST_TERMS)]
+        return names, out
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._check(self.lib.hipnlp_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
