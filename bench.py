@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py — NLP callback throughput (knots/s) of the hipnlp engine on MI355X.
+
+One "step" = one complete callback set {f, grad f, g, jac g} of the ergoCub-shaped kinodynamic
+multiple-shooting NLP (BASELINE.json metric) on synthetic, HBM-resident inputs.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--horizon 100] [--batch 1] [--shard knots|batch]
+
+N = 1 : workload "kinodynamic periodic walking, N = 100 knots" (BASELINE config 4 on one GPU).
+N > 1 : launched by torch.distributed.run, one rank per GPU.  Default `--shard knots` (north_star): the
+        horizon grows with N (100 knots per GPU, weak scaling), shooting intervals are sharded contiguously
+        and every step ends with ONE RCCL all-gather of the fused shard buffers + the reassembly of
+        [grad f | jac g | g] in reference order on every rank.  `--shard batch`: N independent 100-knot
+        trajectories, no collective (the MPC / batched-initial-guess shape).
+The JSON line carries `roofline` (HIP-event timed knot kernel vs the 8 TB/s HBM peak) and `cpu_baseline`
+(the CPU oracle timed on the host, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from hippopt_amd.hipnlp import HipNlp  # noqa: E402
+from hippopt_amd.kinodyn_settings import periodic_step_settings  # noqa: E402
+from hippopt_amd.robot_model import synthetic_ergocub  # noqa: E402
+from hippopt_amd.synthetic import make_workload  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (guides/MI355X_MICROARCH.md)
+KNOTS_PER_GPU = 100
+
+
+def algorithmic_bytes_per_knot(nnz_knot):
+    """read x_k and the per-knot parameters, write g_k, the knot's jac values and grad f_k."""
+    return 8 * (189 + 79 + 274 + nnz_knot + 189)
+
+
+def cpu_baseline(settings, model, x, p, budget_s=12.0):
+    """The CPU oracle (oracle/kinodyn_oracle.cpp, single thread) on the same workload, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Oracle
+    orc = Oracle(settings, model)
+    orc.eval(x, p)  # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        orc.eval(x, p)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or reps >= 1000:
+            break
+    return {"value": settings.horizon_length * reps / el, "unit": "knots/s", "cores": 1, "kind": "port",
+            "sample": "%d full callback sets (f, grad f, g, jac g by forward AD) of the N=%d workload in %.1f s, 1 thread"
+                      % (reps, settings.horizon_length, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--horizon", type=int, default=KNOTS_PER_GPU)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--shard", choices=["knots", "batch"], default="knots")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="exercise the sharded path on one GPU (debug)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if args.gpus != world:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    model = synthetic_ergocub()
+    knot_sharded = (world > 1 and args.shard == "knots") or args.force_sharded
+    horizon = args.horizon * world if knot_sharded else args.horizon
+    settings = periodic_step_settings(horizon, model)
+    seed = 1004 if knot_sharded else 1004 + rank
+    x_np, p_np = make_workload(settings, model, batch=args.batch, seed=seed)
+    nvar = 4  # a few distinct iterates, cycled: "x changes every call, parameters fixed" 
+    rng = np.random.RandomState(5)
+    xs = [torch.from_numpy(x_np + 1e-3 * i * rng.standard_normal(x_np.shape)).to(device) for i in range(nvar)]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    if knot_sharded:
+        from hippopt_amd.sharded import ShardedCallback, hip_shard_backend, hip_shard_info, knot_range
+        assert args.batch == 1, "knot sharding evaluates one trajectory"
+        kb, ke = knot_range(horizon, world, rank)
+        eng = HipNlp(settings, model, batch=1, knot_begin=kb, knot_end=ke, device=local_rank)
+        eng.set_params(p_np)
+        cb = ShardedCallback(horizon, eng.n, eng.m, eng.nnz, hip_shard_info(eng, kb, ke), hip_shard_backend(eng), device)
+
+        def step(i):
+            cb(xs[i % nvar])
+        knots_per_step_total = horizon
+        local_knots = ke - kb
+    else:
+        eng = HipNlp(settings, model, batch=args.batch, device=local_rank)
+        eng.set_params(p_np)
+        f_d = torch.empty(args.batch, dtype=torch.float64, device=device)
+        grad_d = torch.empty(args.batch * eng.n, dtype=torch.float64, device=device)
+        g_d = torch.empty(args.batch * eng.m, dtype=torch.float64, device=device)
+        jac_d = torch.empty(args.batch * eng.nnz, dtype=torch.float64, device=device)
+
+        def step(i):
+            eng.eval_device(xs[i % nvar].data_ptr(), f_d.data_ptr(), grad_d.data_ptr(), g_d.data_ptr(), jac_d.data_ptr(), stream=stream)
+        knots_per_step_total = horizon * args.batch * world
+        local_knots = horizon * args.batch
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    eng.profile_begin(args.steps)        # HIP events around every knot-kernel launch of the timed region
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    el = time.perf_counter() - t0
+    kern_ms, launch_ms, nprof = eng.profile_end()
+    t = torch.tensor([el], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+
+    if rank == 0:
+        d = eng.dims
+        nnz_knot = int(d.nnz_knot)
+        bytes_knot = algorithmic_bytes_per_knot(nnz_knot)
+        bytes_launch = bytes_knot * local_knots
+        achieved = bytes_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                tj = json.load(open(tp))
+                key = "N%d_B%d" % (horizon, args.batch)
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        line = {
+            "metric": "NLP callback (f, grad f, g, jac g) throughput, ergoCub-shaped kinodynamic multiple shooting",
+            "value": knots_per_step_total * args.steps / el,
+            "unit": "knots/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * el / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (seeded trajectories on a synthetic 23-DoF ergoCub-topology model; no URDF/CasADi in the image)",
+            "config": {"workload": "kinodynamic periodic walking, N=%d knots per GPU, batch %d (BASELINE config 4 shape)" % (args.horizon, args.batch),
+                       "horizon": horizon, "batch": args.batch, "knots_per_step": knots_per_step_total,
+                       "parallelism": ("knot-sharded x%d + all-gather" % world) if knot_sharded else ("replica x%d" % world),
+                       "n": int(d.n), "m": int(d.m), "nnz": int(d.nnz), "nnz_per_knot": nnz_knot},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "hipnlp_knot_kernel", "kernel_ms": kern_ms, "launch_ms": launch_ms,
+                         "launches_timed": nprof, "algorithmic_bytes_per_knot": bytes_knot, "knots_per_launch": local_knots},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(settings, model, x_np[0], p_np[0])
+            line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

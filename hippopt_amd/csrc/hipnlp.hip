@@ -24,6 +24,7 @@ using namespace hipnlp;
 namespace {
 
 constexpr int WG = 64;
+static_assert(gs::COUNT == HIPNLP_G_STAGE, "HIPNLP_G_STAGE must equal the native g slot count");
 
 struct DeviceTables {
     KinTables kt;
@@ -44,9 +45,11 @@ struct KArgs {
     double* g;              // [batch][m]      or null
     double* jac;            // [batch][nnz]    or null
     double* grad;           // [batch][n]      or null
+    double* g_stage;        // [batch][nk][gs::COUNT] knot-major staging of g (sharded mode) or null
     double* cost_knot;      // [batch][nk][NCT]
     int32_t* flags;         // [batch][nk]  non-finite detector
     int32_t N, n, m, nnz, knot_begin, nk;
+    int64_t jac_stride, jac_off, grad_stride, grad_off;  // output addressing: full arrays (stride nnz / n, offset 0) or shard-local
 };
 
 struct DevEm {
@@ -92,7 +95,8 @@ __global__ __launch_bounds__(WG) void hipnlp_knot_kernel(KArgs a) {
     const int v = first ? VAR_FIRST : (last ? VAR_LAST : VAR_INTERIOR);
     int bad = 0;
     if (a.jac) {
-        double* out = a.jac + size_t(b) * a.nnz + (first ? 0 : size_t(tb.nnz_v[VAR_FIRST]) + size_t(k - 1) * tb.nnz_v[VAR_INTERIOR]);
+        const int64_t jbase = first ? 0 : int64_t(tb.nnz_v[VAR_FIRST]) + int64_t(k - 1) * tb.nnz_v[VAR_INTERIOR];
+        double* out = a.jac + int64_t(b) * a.jac_stride + (jbase - a.jac_off);
         const int cnt = tb.nnz_v[v];
         const int32_t* perm = tb.jperm[v];
         for (int i = tid; i < cnt; i += WG) {
@@ -100,7 +104,8 @@ __global__ __launch_bounds__(WG) void hipnlp_knot_kernel(KArgs a) {
             bad |= !isfinite(val);
             out[i] = val;
         }
-        if (first && tid < tb.n_glob) a.jac[size_t(b) * a.nnz + tb.jac_glob_base + tid] = s.jac[tb.jperm_glob[tid]];
+        // entries in the horizon-global columns (constants) sit right behind the last knot's block: the last knot writes them
+        if (last && tid < tb.n_glob) a.jac[int64_t(b) * a.jac_stride + (int64_t(tb.jac_glob_base) - a.jac_off) + tid] = s.jac[tb.jperm_glob[tid]];
     }
     if (a.g) {
         double* out = a.g + size_t(b) * a.m;
@@ -113,14 +118,23 @@ __global__ __launch_bounds__(WG) void hipnlp_knot_kernel(KArgs a) {
             }
         }
     }
+    if (a.g_stage) {
+        double* out = a.g_stage + (size_t(b) * a.nk + kk) * gs::COUNT;
+        for (int slot = tid; slot < gs::COUNT; slot += WG) {
+            const bool valid = tb.g_a[v][slot] >= 0;
+            const double val = valid ? s.g[slot] : 0.0;
+            bad |= !isfinite(val);
+            out[slot] = val;
+        }
+    }
     if (a.grad) {
-        double* out = a.grad + size_t(b) * a.n + size_t(NXK) * k;
+        double* out = a.grad + int64_t(b) * a.grad_stride + (int64_t(NXK) * k - a.grad_off);
         for (int i = tid; i < NXK; i += WG) {
             const double val = s.grad[i];
             bad |= !isfinite(val);
             out[i] = val;
         }
-        if (last && tid < NXG) a.grad[size_t(b) * a.n + size_t(NXK) * N + tid] = 0.0;  // the global variables carry no cost
+        if (last && tid < NXG) a.grad[int64_t(b) * a.grad_stride + (int64_t(NXK) * N - a.grad_off) + tid] = 0.0;  // the global variables carry no cost
     }
     if (tid < NCT) {
         const double val = s.cost[tid];
@@ -170,6 +184,8 @@ struct hipnlp_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_valid = false;
+    std::vector<hipEvent_t> prof_ev;  // triples
+    int prof_cap = 0, prof_n = 0;
     DeviceTables* d_tb = nullptr;
     double *d_x = nullptr, *d_pk = nullptr, *d_g = nullptr, *d_jac = nullptr, *d_grad = nullptr, *d_f = nullptr;
     double *d_cost_knot = nullptr, *d_cost_terms = nullptr;
@@ -200,6 +216,7 @@ static void free_all(hipnlp_handle* h) {
     for (void* q : dptrs) if (q) (void)hipFree(q);
     void* hptrs[] = {h->h_x, h->h_g, h->h_jac, h->h_grad, h->h_f, h->h_cost_terms, h->h_flag};
     for (void* q : hptrs) if (q) (void)hipHostFree(q);
+    for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -299,10 +316,10 @@ int hipnlp_get_dims(const hipnlp_handle* h, hipnlp_dims* o) {
     int mk = 0;
     for (const RowBlock& b : L.blocks) if (b.nk > 1) mk += b.rows;
     o->m_knot = mk;
-    o->shard_grad = NXK * h->nk;
+    o->shard_grad = NXK * h->nk + (h->ke == L.N ? NXG : 0);
     o->shard_grad_off = NXK * h->kb;
     o->shard_jac_off = int(L.jac_base(h->kb));
-    o->shard_nnz = int((h->ke == L.N ? long(L.jac_glob_base) : L.jac_base(h->ke)) - L.jac_base(h->kb));
+    o->shard_nnz = int((h->ke == L.N ? long(L.nnz) : L.jac_base(h->ke)) - L.jac_base(h->kb));
     int rows = 0;
     for (int k = h->kb; k < h->ke; ++k) {
         const int v = L.variant_of(k);
@@ -356,17 +373,30 @@ int hipnlp_sparsity(const hipnlp_handle* h, int32_t* irow, int32_t* jcol) {
     return HIPNLP_OK;
 }
 
-static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, hipStream_t s) {
+static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, hipStream_t s,
+                  double* g_stage = nullptr, bool shard_local = false) {
     KArgs a;
     a.tb = h->d_tb; a.x = x_dev; a.pk = h->d_pk; a.gp = h->d_gp;
-    a.g = g_dev; a.jac = jac_dev; a.grad = grad_dev;
+    a.g = g_dev; a.jac = jac_dev; a.grad = grad_dev; a.g_stage = g_stage;
+    if (shard_local) {
+        hipnlp_dims dd;
+        hipnlp_get_dims(h, &dd);
+        a.jac_stride = dd.shard_nnz; a.jac_off = dd.shard_jac_off; a.grad_stride = dd.shard_grad; a.grad_off = dd.shard_grad_off;
+    } else {
+        a.jac_stride = h->L.nnz; a.jac_off = 0; a.grad_stride = h->L.n; a.grad_off = 0;
+    }
     a.cost_knot = h->d_cost_knot; a.flags = h->d_flags;
     a.N = h->L.N; a.n = h->L.n; a.m = h->L.m; a.nnz = h->L.nnz; a.knot_begin = h->kb; a.nk = h->nk;
-    HIP_TRY(h, hipEventRecord(h->ev0, s));
+    const bool prof = h->prof_n < h->prof_cap;
+    hipEvent_t e0 = prof ? h->prof_ev[size_t(3 * h->prof_n)] : h->ev0;
+    hipEvent_t e2 = prof ? h->prof_ev[size_t(3 * h->prof_n + 2)] : h->ev1;
+    HIP_TRY(h, hipEventRecord(e0, s));
     hipLaunchKernelGGL(hipnlp_knot_kernel, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(WG), 0, s, a);
+    if (prof) HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 1)], s));
     hipLaunchKernelGGL(hipnlp_reduce_kernel, dim3(unsigned(h->batch)), dim3(WG), 0, s,
                        (const double*)h->d_cost_knot, (const int32_t*)h->d_flags, h->nk, f_dev, h->d_cost_terms, h->d_flag);
-    HIP_TRY(h, hipEventRecord(h->ev1, s));
+    HIP_TRY(h, hipEventRecord(e2, s));
+    if (prof) { h->prof_n++; h->timing_valid = false; HIP_TRY(h, hipGetLastError()); return HIPNLP_OK; }
     HIP_TRY(h, hipGetLastError());
     h->timing_valid = true;
     return HIPNLP_OK;
@@ -378,6 +408,24 @@ int hipnlp_eval_device(hipnlp_handle* h, const double* x_dev, double* f_dev, dou
     HIP_TRY(h, hipSetDevice(h->dev));
     h->have_result = false;
     return launch(h, x_dev, f_dev ? f_dev : h->d_f, grad_dev, g_dev, jac_dev, stream ? hipStream_t(stream) : h->stream);
+}
+
+int hipnlp_eval_device_shard(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_shard, double* g_stage, double* jac_shard, void* stream) {
+    if (!h || !x_dev) return HIPNLP_E_INVALID;
+    if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
+    HIP_TRY(h, hipSetDevice(h->dev));
+    h->have_result = false;
+    return launch(h, x_dev, f_dev ? f_dev : h->d_f, grad_shard, nullptr, jac_shard, stream ? hipStream_t(stream) : h->stream, g_stage, true);
+}
+
+int hipnlp_stage_rows(const hipnlp_handle* h, int k, int32_t* rows) {
+    if (!h || !rows || k < 0 || k >= h->L.N) return HIPNLP_E_INVALID;
+    const int v = h->L.variant_of(k);
+    for (int s = 0; s < gs::COUNT; ++s) {
+        const int a = h->L.g_a[v][size_t(s)];
+        rows[s] = a >= 0 ? a + h->L.g_b[size_t(s)] * k : -1;
+    }
+    return HIPNLP_OK;
 }
 
 int hipnlp_eval(hipnlp_handle* h, const double* x, int new_x, double* f, double* grad_f, double* g, double* jac) {
@@ -445,6 +493,38 @@ int hipnlp_last_kernel_ms(hipnlp_handle* h, float* ms) {
     HIP_TRY(h, hipSetDevice(h->dev));
     HIP_TRY(h, hipEventSynchronize(h->ev1));
     HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return HIPNLP_OK;
+}
+
+int hipnlp_profile_begin(hipnlp_handle* h, int max_launches) {
+    if (!h || max_launches < 0) return HIPNLP_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->dev));
+    while (int(h->prof_ev.size()) < 3 * max_launches) {
+        hipEvent_t e;
+        HIP_TRY(h, hipEventCreate(&e));
+        h->prof_ev.push_back(e);
+    }
+    h->prof_cap = max_launches;
+    h->prof_n = 0;
+    return HIPNLP_OK;
+}
+
+int hipnlp_profile_end(hipnlp_handle* h, double* mean_knot_kernel_ms, double* mean_launch_ms, int* count) {
+    if (!h) return HIPNLP_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->dev));
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < h->prof_n; ++i) {
+        float m1 = 0.f, m2 = 0.f;
+        HIP_TRY(h, hipEventSynchronize(h->prof_ev[size_t(3 * i + 2)]));
+        HIP_TRY(h, hipEventElapsedTime(&m1, h->prof_ev[size_t(3 * i)], h->prof_ev[size_t(3 * i + 1)]));
+        HIP_TRY(h, hipEventElapsedTime(&m2, h->prof_ev[size_t(3 * i)], h->prof_ev[size_t(3 * i + 2)]));
+        a += m1; b += m2;
+    }
+    if (count) *count = h->prof_n;
+    if (mean_knot_kernel_ms) *mean_knot_kernel_ms = h->prof_n ? a / h->prof_n : 0.0;
+    if (mean_launch_ms) *mean_launch_ms = h->prof_n ? b / h->prof_n : 0.0;
+    h->prof_cap = 0;
+    h->prof_n = 0;
     return HIPNLP_OK;
 }
 

@@ -17,8 +17,10 @@ EXPORTS = [
     "hipnlp_create", "hipnlp_destroy", "hipnlp_last_error", "hipnlp_get_dims", "hipnlp_set_params",
     "hipnlp_bounds", "hipnlp_simple_rows", "hipnlp_sparsity", "hipnlp_eval", "hipnlp_eval_device",
     "hipnlp_cost_terms", "hipnlp_cost_term_name", "hipnlp_num_row_blocks", "hipnlp_row_block",
-    "hipnlp_last_kernel_ms",
+    "hipnlp_last_kernel_ms", "hipnlp_profile_begin", "hipnlp_profile_end",
+    "hipnlp_eval_device_shard", "hipnlp_stage_rows",
 ]
+G_STAGE = 550
 
 
 class HipNlpError(RuntimeError):
@@ -59,6 +61,10 @@ def load_library():
     lib.hipnlp_num_row_blocks.argtypes = [vp]
     lib.hipnlp_row_block.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), ip, ip, ip, ip]
     lib.hipnlp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.hipnlp_eval_device_shard.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.hipnlp_stage_rows.argtypes = [vp, C.c_int, ip]
+    lib.hipnlp_profile_begin.argtypes = [vp, C.c_int]
+    lib.hipnlp_profile_end.argtypes = [vp, dp, dp, C.POINTER(C.c_int)]
     _lib = lib
     return lib
 
@@ -161,3 +167,21 @@ class HipNlp:
         ms = C.c_float()
         self._check(self.lib.hipnlp_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
+
+    def profile_begin(self, max_launches):
+        self._check(self.lib.hipnlp_profile_begin(self.h, int(max_launches)))
+
+    def profile_end(self):
+        """(mean knot-kernel ms, mean launch ms incl. the cost reduction kernel, launches)"""
+        a, b, n = C.c_double(), C.c_double(), C.c_int()
+        self._check(self.lib.hipnlp_profile_end(self.h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
+    def eval_device_shard(self, x_ptr, f_ptr, grad_ptr, g_stage_ptr, jac_ptr, stream=0):
+        self._check(self.lib.hipnlp_eval_device_shard(self.h, C.c_void_p(x_ptr), C.c_void_p(f_ptr or None), C.c_void_p(grad_ptr or None),
+                                                      C.c_void_p(g_stage_ptr or None), C.c_void_p(jac_ptr or None), C.c_void_p(stream or None)))
+
+    def stage_rows(self, k):
+        rows = np.zeros(G_STAGE, np.int32)
+        self._check(self.lib.hipnlp_stage_rows(self.h, int(k), _ip(rows)))
+        return rows

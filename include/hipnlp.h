@@ -187,6 +187,18 @@ int hipnlp_eval_device(hipnlp_handle* h, const double* x_dev,
                        double* f_dev, double* grad_dev, double* g_dev, double* jac_dev,
                        void* stream);
 
+/* Sharded variant (multi-GPU): the handle owns knots [knot_begin, knot_end).  Outputs are
+ * shard-local and contiguous so that one RCCL all-gather reassembles them:
+ *   grad_shard [batch][shard_grad]  = grad f entries of the shard's knots (+ the 6 global entries on the last shard)
+ *   jac_shard  [batch][shard_nnz]   = the CCS value run of the shard's column blocks
+ *   g_stage    [batch][nk][HIPNLP_G_STAGE] knot-major staging of the rows each knot owns; hipnlp_stage_rows()
+ *              gives the global row of every staging slot (-1 = unused) for the scatter after the gather
+ *   f_dev      [batch] partial cost of the shard's knots                                                     */
+#define HIPNLP_G_STAGE 550
+int hipnlp_eval_device_shard(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_shard,
+                             double* g_stage, double* jac_shard, void* stream);
+int hipnlp_stage_rows(const hipnlp_handle* h, int k, int32_t* rows /*[HIPNLP_G_STAGE]*/);
+
 /* Per-named-cost values of the last evaluation (Output.cost_values, base/problem.py:28-56):
  * values[batch][HIPNLP_NCOST_TERMS], summed over knots, in the order of hipnlp_cost_term_name(). */
 #define HIPNLP_NCOST_TERMS 12
@@ -201,6 +213,12 @@ int hipnlp_row_block(const hipnlp_handle* h, int i, const char** name,
 /* Timing of the last hipnlp_eval()/hipnlp_eval_device() kernel, measured with hipEvents on the
  * stream the kernel ran on (ms).  Blocks until the launch has finished.                          */
 int hipnlp_last_kernel_ms(hipnlp_handle* h, float* ms);
+
+/* Per-launch HIP-event timing over a region of launches (bench.py roofline leg).  profile_begin arms up to
+ * max_launches event triples recorded on the launch stream (before the knot kernel, after it, after the
+ * reduction kernel); profile_end synchronises and returns the mean durations (ms) and the launch count.   */
+int hipnlp_profile_begin(hipnlp_handle* h, int max_launches);
+int hipnlp_profile_end(hipnlp_handle* h, double* mean_knot_kernel_ms, double* mean_launch_ms, int* count);
 
 #ifdef __cplusplus
 }

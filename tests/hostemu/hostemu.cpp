@@ -85,7 +85,7 @@ void hostemu_eval(const hostemu_handle* h, const double* x, const double* p, dou
         const int v = L.variant_of(k);
         const long jb = L.jac_base(k);
         for (int i = 0; i < L.nnz_v[v]; ++i) jac[jb + i] = s->jac[L.jperm[v][size_t(i)]];
-        if (k == 0) for (size_t i = 0; i < L.jperm_glob.size(); ++i) jac[L.jac_glob_base + long(i)] = s->jac[L.jperm_glob[i]];
+        if (k == N - 1) for (size_t i = 0; i < L.jperm_glob.size(); ++i) jac[L.jac_glob_base + long(i)] = s->jac[L.jperm_glob[i]];
         for (int slot = 0; slot < gs::COUNT; ++slot) {
             const int a = L.g_a[v][size_t(slot)];
             if (a >= 0) g[a + L.g_b[size_t(slot)] * k] = s->g[slot];
