@@ -53,6 +53,11 @@ void hostemu_row_block(const hostemu_handle* h, int i, const char** name, int* f
     *name = b.name.c_str(); *first = b.first_row; *rows = b.rows; *k0 = b.k0; *nk = b.nk;
 }
 
+void hostemu_stage_rows(const hostemu_handle* h, int k, int* rows) {
+    const int v = h->L.variant_of(k);
+    for (int s = 0; s < gs::COUNT; ++s) { const int a = h->L.g_a[v][size_t(s)]; rows[s] = a >= 0 ? a + h->L.g_b[size_t(s)] * k : -1; }
+}
+
 void hostemu_eval(const hostemu_handle* h, const double* x, const double* p, double* f, double* grad, double* g, double* jac, double* cost_terms) {
     const Layout& L = h->L;
     const int N = L.N;

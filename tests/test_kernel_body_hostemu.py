@@ -1,0 +1,83 @@
+"""The kernel's knot program (hippopt_amd/csrc/knot_body.h) and the layout tables, run through the
+TEST-ONLY host emulation (tests/hostemu), against the AD oracle.  This checks the hand-derived analytic
+Jacobians and the CCS bookkeeping on a machine without a GPU; the GPU parity tests proper are in
+test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from hippopt_amd import _abi
+from hippopt_amd.kinodyn_settings import periodic_step_settings, single_step_settings
+from hippopt_amd.synthetic import make_workload
+from hostemu_lib import HostEmu
+from oracle_lib import Oracle
+
+TOL = 1e-11
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+@pytest.mark.parametrize("maker", [periodic_step_settings, single_step_settings])
+@pytest.mark.parametrize("horizon", [2, 3, 6])
+def test_body_matches_oracle(model, maker, horizon):
+    st = maker(horizon, model)
+    o, e = Oracle(st, model), HostEmu(st, model)
+    assert (o.n, o.m, o.nnz) == (e.n, e.m, e.nnz)
+    assert o.row_blocks() == e.row_blocks()
+    ir, jc = o.sparsity()
+    ir2, jc2 = e.sparsity()
+    assert np.array_equal(ir, ir2) and np.array_equal(jc, jc2)
+    x, p = make_workload(st, model, 1, 100 + horizon)
+    f, grad, g, jac = o.eval(x[0], p[0])
+    f2, grad2, g2, jac2, ct = e.eval(x[0], p[0])
+    assert not np.isnan(g2).any() and not np.isnan(jac2).any()   # every row / entry is written by exactly one knot
+    assert rel(np.array(f2), np.array(f)) < TOL and rel(grad2, grad) < TOL and rel(g2, g) < TOL and rel(jac2, jac) < TOL
+    assert np.allclose(ct, o.cost_terms(), rtol=1e-12, atol=1e-10)
+    lb, ub = o.bounds(p[0])
+    lb2, ub2 = e.bounds(p[0])
+    assert np.array_equal(lb, lb2) and np.array_equal(ub, ub2)
+
+
+def test_cost_modes(model):
+    st = periodic_step_settings(4, model)
+    st.final_state_expression_type = _abi.EXPR_MINIMIZE
+    st.periodicity_expression_type = _abi.EXPR_MINIMIZE
+    st.final_state_expression_weight, st.periodicity_expression_weight = 2.5, 0.3
+    st.joint_reg_as_coded = False
+    st.contacts_centroid_cost_multiplier = 100.0
+    o, e = Oracle(st, model), HostEmu(st, model)
+    x, p = make_workload(st, model, 1, 21)
+    f, grad, g, jac = o.eval(x[0], p[0])
+    f2, grad2, g2, jac2, ct = e.eval(x[0], p[0])
+    assert (o.m, o.nnz) == (e.m, e.nnz)
+    assert rel(np.array(f2), np.array(f)) < TOL and rel(grad2, grad) < TOL and rel(g2, g) < TOL and rel(jac2, jac) < TOL
+
+
+def test_far_from_origin_base_position(model):
+    """Base-centred kinematics: accuracy must not degrade with |p_b| (N = 800 knots walk 8 m)."""
+    st = single_step_settings(3, model)
+    x, p = make_workload(st, model, 1, 22)
+    for k in range(3):
+        x[0][189 * k + 127:189 * k + 130] += [50.0, -30.0, 0.0]
+        for c in range(8):
+            x[0][189 * k + 15 * c + 6:189 * k + 15 * c + 9] += [50.0, -30.0, 0.0]
+        x[0][189 * k + 180:189 * k + 183] += [50.0, -30.0, 0.0]
+    o, e = Oracle(st, model), HostEmu(st, model)
+    f, grad, g, jac = o.eval(x[0], p[0])
+    f2, grad2, g2, jac2, ct = e.eval(x[0], p[0])
+    assert rel(g2, g) < 1e-10 and rel(jac2, jac) < 1e-10 and rel(grad2, grad) < 1e-10
+
+
+def test_invalid_models_are_rejected(model):
+    import copy
+    bad = copy.deepcopy(model)
+    bad.parent = bad.parent.copy()
+    bad.parent[5] = 9  # parent after child: not topologically ordered
+    with pytest.raises(RuntimeError):
+        HostEmu(periodic_step_settings(3, bad), bad)
+    bad2 = copy.deepcopy(model)
+    bad2.frame_link = bad2.frame_link.copy()
+    bad2.frame_link[0] = 15  # sole on the knee link: 4-joint chain, the kernel wants 6
+    with pytest.raises(RuntimeError):
+        HostEmu(periodic_step_settings(3, bad2), bad2)

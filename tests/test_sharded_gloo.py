@@ -1,0 +1,106 @@
+"""World-size-2 `gloo` test of the knot-sharded callback plumbing (hippopt_amd/sharded.py): shard offsets,
+fused shard buffer, all-gather, reassembly of [grad | jac | g] in reference order.  The per-rank compute is
+emulated on the CPU (host emulation of the knot program, sliced to the rank's shard) because there is no GPU
+here; on the GPU box the same class is driven by HipNlp.eval_device_shard (bench.py --gpus N)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _emulated_shard(emu, layout_rows, kb, ke, horizon, x_np, p_np):
+    """What HipNlp.eval_device_shard produces for knots [kb, ke): partial f, grad shard, jac shard, g staging."""
+    f, grad, g, jac, ct = emu.eval(x_np, p_np)
+    ir, jc = emu.sparsity()
+    col_knot = np.minimum(jc // 189, horizon - 1)  # the 6 global columns ride with the last knot
+    sel = (col_knot >= kb) & (col_knot < ke)
+    glen = 189 * (ke - kb) + (6 if ke == horizon else 0)
+    stage = np.zeros((ke - kb, 550))
+    for kk in range(ke - kb):
+        rows = layout_rows[kb + kk]
+        valid = rows >= 0
+        stage[kk, valid] = g[rows[valid]]
+    return grad[189 * kb:189 * kb + glen], jac[sel], stage
+
+
+def _worker(rank, world, port, horizon, result_q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hippopt_amd.kinodyn_settings import periodic_step_settings
+    from hippopt_amd.robot_model import synthetic_ergocub
+    from hippopt_amd.sharded import ShardedCallback, knot_range
+    from hippopt_amd.synthetic import make_workload
+    from hostemu_lib import HostEmu
+    from stage_rows_ref import stage_rows_from_blocks
+
+    model = synthetic_ergocub()
+    st = periodic_step_settings(horizon, model)
+    x, p = make_workload(st, model, 1, 31)
+    emu = HostEmu(st, model)
+    rows_all = stage_rows_from_blocks(emu, horizon)
+    kb, ke = knot_range(horizon, world, rank)
+    ir, jc = emu.sparsity()
+    col_knot = np.minimum(jc // 189, horizon - 1)
+    info = {"glen": 189 * (ke - kb) + (6 if ke == horizon else 0), "jlen": int(((col_knot >= kb) & (col_knot < ke)).sum()),
+            "nk": ke - kb, "stage_rows": np.stack([rows_all[k] for k in range(kb, ke)])}
+
+    def compute(xt, f_view, grad_view, jac_view, stage_view):
+        gs, js, stg = _emulated_shard(emu, rows_all, kb, ke, horizon, xt.numpy(), p[0])
+        f_view[0] = float(rank + 1)  # partial costs: checked as a sum below
+        grad_view.copy_(torch.from_numpy(np.ascontiguousarray(gs)))
+        jac_view.copy_(torch.from_numpy(np.ascontiguousarray(js)))
+        stage_view.copy_(torch.from_numpy(stg.reshape(-1)))
+
+    cb = ShardedCallback(horizon, emu.n, emu.m, emu.nnz, info, compute, torch.device("cpu"))
+    f, grad, jac, g = cb(torch.from_numpy(x[0]))
+    f_ref, grad_ref, g_ref, jac_ref, _ = emu.eval(x[0], p[0])
+    ok = (np.array_equal(grad.numpy(), grad_ref) and np.array_equal(jac.numpy(), jac_ref) and np.array_equal(g.numpy(), g_ref)
+          and float(f) == sum(range(1, world + 1)))
+    result_q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("horizon", [7, 10])
+def test_sharded_reassembly_world2(horizon):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, horizon, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_knot_range_tiles_the_horizon():
+    from hippopt_amd.sharded import knot_range
+    for horizon in (7, 100, 101, 800):
+        for world in (1, 2, 4, 8):
+            cover = []
+            for r in range(world):
+                a, b = knot_range(horizon, world, r)
+                cover += list(range(a, b))
+            assert cover == list(range(horizon))
