@@ -23,7 +23,7 @@ using namespace hipnlp;
 
 namespace {
 
-constexpr int WG = 64;
+constexpr int WG = 256;  // four wavefronts per knot: role-specialised waves (knot_body.h, HIPNLP_KNOT_PROGRAM)
 static_assert(gs::COUNT == HIPNLP_G_STAGE, "HIPNLP_G_STAGE must equal the native g slot count");
 
 struct DeviceTables {
@@ -59,15 +59,36 @@ struct DevEm {
     __device__ __forceinline__ void J(int slot, int, int, double v) { jac[slot] = v; }
 };
 
+// LDS image of the read-only tables every phase indexes per lane (global memory would cost one L2 round trip per phase)
+struct SharedTables {
+    KinTables kt;
+    KSettings ks;
+    GParams gp;
+};
+
 __global__ __launch_bounds__(WG) void hipnlp_knot_kernel(KArgs a) {
     __shared__ KnotScratch s;
-    const int tid = threadIdx.x;
+    __shared__ SharedTables tabs;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int kk = blockIdx.x, b = blockIdx.y;
     const int k = a.knot_begin + kk;
     const int N = a.N;
     const double* x = a.x + size_t(b) * a.n;
     const int first = k == 0, last = k == N - 1;
-    // ---- stage the knot records in LDS (coalesced: consecutive lanes read consecutive doubles) ----
+    const DeviceTables& tb = *a.tb;
+    // ---- stage the knot records and the tables in LDS (coalesced: consecutive lanes read consecutive words) ----
+    {
+        static_assert(sizeof(KinTables) % 4 == 0 && sizeof(KSettings) % 4 == 0 && sizeof(GParams) % 4 == 0, "word copy");
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&tb.kt);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&tabs.kt);
+        for (int i = tid; i < int(sizeof(KinTables) / 4); i += WG) dst[i] = src[i];
+        src = reinterpret_cast<const uint32_t*>(&tb.ks);
+        dst = reinterpret_cast<uint32_t*>(&tabs.ks);
+        for (int i = tid; i < int(sizeof(KSettings) / 4); i += WG) dst[i] = src[i];
+        src = reinterpret_cast<const uint32_t*>(a.gp + b);
+        dst = reinterpret_cast<uint32_t*>(&tabs.gp);
+        for (int i = tid; i < int(sizeof(GParams) / 4); i += WG) dst[i] = src[i];
+    }
     for (int i = tid; i < XPAD; i += WG) {
         const bool in = i < NXK;
         s.x[i] = in ? x[size_t(NXK) * k + i] : 0.0;
@@ -78,17 +99,13 @@ __global__ __launch_bounds__(WG) void hipnlp_knot_kernel(KArgs a) {
     if (tid < 8) s.xg[tid] = tid < NXG ? x[size_t(NXK) * N + tid] : 0.0;
     __syncthreads();
 
-    const DeviceTables& tb = *a.tb;
     KnotInfo ki{k, N, first, last};
     DevEm em{s.g, s.jac};
-    Ctx<DevEm> cx(s, tb.kt, tb.ks, a.gp[b], ki, em);
-    const int maxd = tb.kt.max_depth;
-#define DEV_RUN(fn, nt) for (int t_ = tid; t_ < (nt); t_ += WG) fn(cx, t_);
-#define DEV_RUNL(fn, nt, lvl) for (int t_ = tid; t_ < (nt); t_ += WG) fn(cx, t_, lvl);
+    Ctx<DevEm> cx(s, tabs.kt, tabs.ks, tabs.gp, ki, em);
+#define DEV_R(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_BARRIER __syncthreads();
-    HIPNLP_KNOT_PROGRAM(DEV_RUN, DEV_RUNL, DEV_BARRIER, maxd)
-#undef DEV_RUN
-#undef DEV_RUNL
+    HIPNLP_KNOT_PROGRAM(DEV_R, DEV_BARRIER)
+#undef DEV_R
 #undef DEV_BARRIER
 
     // ---- stream the knot's outputs ---------------------------------------------------------------------
@@ -145,28 +162,34 @@ __global__ __launch_bounds__(WG) void hipnlp_knot_kernel(KArgs a) {
     if (tid == 0) a.flags[size_t(b) * a.nk + kk] = anybad;
 }
 
-// f[b] = sum over knots and terms, fixed order; cost_terms[b][t] = sum over knots; flag[b] = any non-finite
-__global__ __launch_bounds__(WG) void hipnlp_reduce_kernel(const double* cost_knot, const int32_t* flags, int nk,
-                                                           double* f, double* cost_terms, int32_t* flag_out) {
-    __shared__ double terms[NCT];
+// f[b] = sum over knots and terms; cost_terms[b][t] = sum over knots; flag[b] = any non-finite.
+// Fixed summation tree (thread-strided partials, then a shared-memory tree): bitwise reproducible.
+constexpr int RWG = 256;
+__global__ __launch_bounds__(RWG) void hipnlp_reduce_kernel(const double* cost_knot, const int32_t* flags, int nk,
+                                                            double* f, double* cost_terms, int32_t* flag_out) {
+    __shared__ double part[NCT][RWG];
     __shared__ int anyflag;
     const int b = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) anyflag = 0;
-    __syncthreads();
-    if (tid < NCT) {
-        double acc = 0.0;
-        for (int k = 0; k < nk; ++k) acc += cost_knot[(size_t(b) * nk + k) * NCT + tid];
-        terms[tid] = acc;
-        if (cost_terms) cost_terms[size_t(b) * NCT + tid] = acc;
-    }
+    double acc[NCT];
+    for (int t = 0; t < NCT; ++t) acc[t] = 0.0;
     int bad = 0;
-    for (int k = tid; k < nk; k += WG) bad |= flags[size_t(b) * nk + k];
-    if (bad) atomicOr(&anyflag, 1);
+    for (int k = tid; k < nk; k += RWG) {
+        const double* row = cost_knot + (size_t(b) * nk + k) * NCT;
+        for (int t = 0; t < NCT; ++t) acc[t] += row[t];
+        bad |= flags[size_t(b) * nk + k];
+    }
+    for (int t = 0; t < NCT; ++t) part[t][tid] = acc[t];
     __syncthreads();
+    if (bad) atomicOr(&anyflag, 1);
+    for (int stride = RWG / 2; stride > 0; stride >>= 1) {
+        if (tid < stride) for (int t = 0; t < NCT; ++t) part[t][tid] += part[t][tid + stride];
+        __syncthreads();
+    }
     if (tid == 0) {
-        double acc = 0.0;
-        for (int t = 0; t < NCT; ++t) acc += terms[t];
-        if (f) f[b] = acc;
+        double tot = 0.0;
+        for (int t = 0; t < NCT; ++t) { tot += part[t][0]; if (cost_terms) cost_terms[size_t(b) * NCT + t] = part[t][0]; }
+        if (f) f[b] = tot;
         flag_out[b] = anyflag;
     }
 }
@@ -393,7 +416,7 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     HIP_TRY(h, hipEventRecord(e0, s));
     hipLaunchKernelGGL(hipnlp_knot_kernel, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(WG), 0, s, a);
     if (prof) HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 1)], s));
-    hipLaunchKernelGGL(hipnlp_reduce_kernel, dim3(unsigned(h->batch)), dim3(WG), 0, s,
+    hipLaunchKernelGGL(hipnlp_reduce_kernel, dim3(unsigned(h->batch)), dim3(RWG), 0, s,
                        (const double*)h->d_cost_knot, (const int32_t*)h->d_flags, h->nk, f_dev, h->d_cost_terms, h->d_flag);
     HIP_TRY(h, hipEventRecord(e2, s));
     if (prof) { h->prof_n++; h->timing_valid = false; HIP_TRY(h, hipGetLastError()); return HIPNLP_OK; }

@@ -1,12 +1,14 @@
 // knot_body.h — the per-knot mathematics of the hipnlp engine, written once and compiled for the
-// device (HIP kernel, gfx950), for the host layout recorder (layout.cpp) and for the test-only host
-// emulation (tests/hostemu).  One workgroup evaluates ONE knot: its rows of g (own algebraic rows and
-// the trapezoid defect that ends at the knot), its COLUMN block of jac g (so the CCS output of a knot is
-// one contiguous run), its slice of grad f and its cost partials.
+// device (HIP kernel, gfx950), for the host layout recorder (layout.h) and for the test-only host
+// emulation (tests/hostemu).  One workgroup of FOUR wavefronts evaluates ONE knot: its rows of g (own
+// algebraic rows and the trapezoid defect that ends at the knot), its COLUMN block of jac g (so the CCS
+// output of a knot is one contiguous run), its slice of grad f and its cost partials.
 //
-// Every `phase_*(cx, t)` is a lane task: the kernel runs task t on thread t (tasks of one phase are
-// independent), with a workgroup barrier between phases.  Values leave through an emitter:
-// em.G(slot, row_id, v) / em.J(slot, row_id, col, v); slots are compile-time native positions.
+// Every `t_*(cx, t)` is a lane task.  The knot program at the bottom of this file assigns task groups
+// to waves ("roles"): tasks of one group run on consecutive lanes of one wave, different groups of a
+// phase run concurrently on different waves (different SIMDs of the CU), a workgroup barrier separates
+// phases.  Values leave through an emitter: em.G(slot, row_id, v) / em.J(slot, row_id, col, v); slots
+// are compile-time native positions in LDS.
 //
 // Mathematics (citations relative to /root/reference/src/hippopt/):
 //   contact rows   robot_planning/expressions/complementarity.py:27-32,71-87; contacts.py:22-24,54-66,158-166
@@ -49,7 +51,10 @@ struct KnotScratch {
     double chest_w[3], chest_dc;  // ax(R_c R_d^T);  d cost / d trace
     double hd[2][NC][6];          // per point contribution to hdot at knots k-1 (0) and k (1)
     double cen_g[3];              // d centroid cost / d p_c,i (same for the 8 points)
-    double cpt[NC][3], cjt[NJ], cft[2][2];  // cost partials: per point (swing,u,fdot), per joint, per foot (freg,yaw)
+    double yaw_sc[2][4], yaw_e[2][2];  // per foot: sin/cos of yaw and of yaw+pi/2; alignment errors (forward, sideways)
+    // cost partials, reduced by t_reduce
+    double c_pt[NC][3], c_joint[NJ], c_force[2][3], c_yaw[2], c_comvel[3], c_ends[105 + 84];
+    double g_ends[105 + 84];      // minimize-mode end terms: gradient share of row i
     double cost[NCT];
     double grad[XPAD];
     double g[gs::COUNT];
@@ -81,6 +86,10 @@ HD void cross3(const double* a, const double* b, double* r) {
     const double r2 = a[0] * b[1] - a[1] * b[0];
     r[0] = r0; r[1] = r1; r[2] = r2;
 }
+HD double cross_comp(const double* a, const double* b, int i) {  // component i of a x b
+    const int i1 = i == 2 ? 0 : i + 1, i2 = i == 0 ? 2 : i - 1;
+    return a[i1] * b[i2] - a[i2] * b[i1];
+}
 HD double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 HD void matvec3(const double* M, const double* v, double* r) {
     const double r0 = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
@@ -108,6 +117,11 @@ HD double skew_entry(const double* a, int e) {  // entry e of [a]x, e -> (cross_
         default: return a[0];
     }
 }
+HD double skew_rc(const double* a, int r, int c) {  // [a]x(r, c):  (0,1)=-a2 (0,2)=a1 (1,0)=a2 (1,2)=-a0 (2,0)=-a1 (2,1)=a0
+    if (r == c) return 0.0;
+    const int k = 3 - r - c;
+    return (c == (r + 2) % 3) ? a[k] : -a[k];
+}
 // R = I + 2 w [v]x + 2 [v]x^2  (liecasadi SO3.as_matrix, xyzw)
 HD void rot_from_quat(const double* q, double* R) {
     const double x = q[0], y = q[1], z = q[2], w = q[3];
@@ -117,44 +131,71 @@ HD void rot_from_quat(const double* q, double* R) {
 }
 
 // ===================================================================================================
-// PHASE A tasks (all depend only on the loaded knot records; no barrier needed between them)
+// PHASE A — everything that depends only on the loaded knot records
 // ===================================================================================================
 
-// --- A1: contact points, lane c (8).  planner.py:124-147, planar terrain ---------------------------
-template <class Em> HD void phase_points(Ctx<Em>& cx, int c) {
+// --- contact points, component-wise: lane (c, i), 24 tasks.  planner.py:721-744, 646-654, 699-719 ----
+template <class Em> HD void t_points_vec(Ctx<Em>& cx, int t) {
     KnotScratch& s = cx.s;
+    const int c = t / 3, i = t - 3 * c;
     const double* x = s.x + PT_ * c;
     const double* xm = s.xm + PT_ * c;
     const double half = 0.5 * cx.gp.dt;
     const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
     Em& em = cx.em;
-    for (int i = 0; i < 3; ++i) {  // trapezoid defects of dot(f) = f_dot, dot(p) = v (T7) + x0 rows
-        em.G(gb + gs::FDYN + i, row_id(RK_FDYN_IN, c, i), x[F_ + i] - (xm[F_ + i] + half * (xm[FD_ + i] + x[FD_ + i])));
-        em.G(gb + gs::PDYN + i, row_id(RK_PDYN_IN, c, i), x[P_ + i] - (xm[P_ + i] + half * (xm[V_ + i] + x[V_ + i])));
-        em.G(gb + gs::FDYN_X0 + i, row_id(RK_FDYN_X0, c, i), x[F_ + i]);
-        em.G(gb + gs::PDYN_X0 + i, row_id(RK_PDYN_X0, c, i), x[P_ + i]);
-        em.J(jb + js::FDYN + 0 + i, row_id(RK_FDYN_IN, c, i), cb + F_ + i, 1.0);
-        em.J(jb + js::FDYN + 3 + i, row_id(RK_FDYN_IN, c, i), cb + FD_ + i, -half);
-        em.J(jb + js::FDYN + 6 + i, row_id(RK_FDYN_OUT, c, i), cb + F_ + i, -1.0);
-        em.J(jb + js::FDYN + 9 + i, row_id(RK_FDYN_OUT, c, i), cb + FD_ + i, -half);
-        em.J(jb + js::FDYN + 12 + i, row_id(RK_FDYN_X0, c, i), cb + F_ + i, 1.0);
-        em.J(jb + js::PDYN + 0 + i, row_id(RK_PDYN_IN, c, i), cb + P_ + i, 1.0);
-        em.J(jb + js::PDYN + 3 + i, row_id(RK_PDYN_IN, c, i), cb + V_ + i, -half);
-        em.J(jb + js::PDYN + 6 + i, row_id(RK_PDYN_OUT, c, i), cb + P_ + i, -1.0);
-        em.J(jb + js::PDYN + 9 + i, row_id(RK_PDYN_OUT, c, i), cb + V_ + i, -half);
-        em.J(jb + js::PDYN + 12 + i, row_id(RK_PDYN_X0, c, i), cb + P_ + i, 1.0);
-    }
-    const double pz = x[P_ + 2], fz = x[F_ + 2], vz = x[V_ + 2], fdz = x[FD_ + 2];
+    // trapezoid defects of dot(f) = f_dot, dot(p) = v (T7) + x0 rows
+    em.G(gb + gs::FDYN + i, row_id(RK_FDYN_IN, c, i), x[F_ + i] - (xm[F_ + i] + half * (xm[FD_ + i] + x[FD_ + i])));
+    em.G(gb + gs::PDYN + i, row_id(RK_PDYN_IN, c, i), x[P_ + i] - (xm[P_ + i] + half * (xm[V_ + i] + x[V_ + i])));
+    em.G(gb + gs::FDYN_X0 + i, row_id(RK_FDYN_X0, c, i), x[F_ + i]);
+    em.G(gb + gs::PDYN_X0 + i, row_id(RK_PDYN_X0, c, i), x[P_ + i]);
+    em.J(jb + js::FDYN + 0 + i, row_id(RK_FDYN_IN, c, i), cb + F_ + i, 1.0);
+    em.J(jb + js::FDYN + 3 + i, row_id(RK_FDYN_IN, c, i), cb + FD_ + i, -half);
+    em.J(jb + js::FDYN + 6 + i, row_id(RK_FDYN_OUT, c, i), cb + F_ + i, -1.0);
+    em.J(jb + js::FDYN + 9 + i, row_id(RK_FDYN_OUT, c, i), cb + FD_ + i, -half);
+    em.J(jb + js::FDYN + 12 + i, row_id(RK_FDYN_X0, c, i), cb + F_ + i, 1.0);
+    em.J(jb + js::PDYN + 0 + i, row_id(RK_PDYN_IN, c, i), cb + P_ + i, 1.0);
+    em.J(jb + js::PDYN + 3 + i, row_id(RK_PDYN_IN, c, i), cb + V_ + i, -half);
+    em.J(jb + js::PDYN + 6 + i, row_id(RK_PDYN_OUT, c, i), cb + P_ + i, -1.0);
+    em.J(jb + js::PDYN + 9 + i, row_id(RK_PDYN_OUT, c, i), cb + V_ + i, -half);
+    em.J(jb + js::PDYN + 12 + i, row_id(RK_PDYN_X0, c, i), cb + P_ + i, 1.0);
     // planar complementarity  v - R_t diag(tau,tau,1) u,  tau = tanh(kt h(p))   (E3; R_t = I, h = p_z)
+    const double pz = x[P_ + 2];
     const double tau = tanh(cx.gp.kt * pz);
-    const double dtau = cx.gp.kt * (1.0 - tau * tau);
-    for (int i = 0; i < 3; ++i) {
-        const double mult = i < 2 ? tau : 1.0;
-        em.G(gb + gs::PLANAR + i, row_id(RK_PLANAR, c, i), x[V_ + i] - mult * x[U_ + i]);
-        em.J(jb + js::PLANAR_V + i, row_id(RK_PLANAR, c, i), cb + V_ + i, 1.0);
-        em.J(jb + js::PLANAR_U + i, row_id(RK_PLANAR, c, i), cb + U_ + i, -mult);
-        if (i < 2) em.J(jb + js::PLANAR_PZ + i, row_id(RK_PLANAR, c, i), cb + P_ + 2, -dtau * x[U_ + i]);
+    const double mult = i < 2 ? tau : 1.0;
+    em.G(gb + gs::PLANAR + i, row_id(RK_PLANAR, c, i), x[V_ + i] - mult * x[U_ + i]);
+    em.J(jb + js::PLANAR_V + i, row_id(RK_PLANAR, c, i), cb + V_ + i, 1.0);
+    em.J(jb + js::PLANAR_U + i, row_id(RK_PLANAR, c, i), cb + U_ + i, -mult);
+    if (i < 2) em.J(jb + js::PLANAR_PZ + i, row_id(RK_PLANAR, c, i), cb + P_ + 2, -(cx.gp.kt * (1.0 - tau * tau)) * x[U_ + i]);
+    // control bound rows
+    em.G(gb + gs::UB + i, row_id(RK_UB, c, i), x[U_ + i]);
+    em.J(jb + js::UB + i, row_id(RK_UB, c, i), cb + U_ + i, 1.0);
+    em.G(gb + gs::FDB + i, row_id(RK_FDB, c, i), x[FD_ + i] * cx.gp.mass);
+    em.J(jb + js::FDB + i, row_id(RK_FDB, c, i), cb + FD_ + i, cx.gp.mass);
+    // gradient of the point-local costs (k >= 1): swing height (E10), ||u_v||^2, ||f_dot||^2
+    const double on = cx.ki.first ? 0.0 : 1.0;
+    double* gr = s.grad + cb;
+    gr[V_ + i] = i < 2 ? on * cx.st.m_swing * x[V_ + i] : 0.0;
+    gr[P_ + i] = i == 2 ? on * cx.st.m_swing * (pz - s.pk[PK_REF + R_SWING]) : 0.0;
+    gr[U_ + i] = 2.0 * on * cx.st.m_ureg * x[U_ + i];
+    gr[FD_ + i] = 2.0 * on * cx.st.m_fdreg * x[FD_ + i];
+    gr[F_ + i] = 0.0;
+    // contribution of this point to hdot at k-1 and k   (E1): component i of f and of (p - com) x f
+    for (int w = 0; w < 2; ++w) {
+        const double* xx = w ? s.x : s.xm;
+        double r[3];
+        for (int q = 0; q < 3; ++q) r[q] = xx[cb + P_ + q] - xx[COM_ + q];
+        s.hd[w][c][i] = xx[cb + F_ + i];
+        s.hd[w][c][3 + i] = cross_comp(r, xx + cb + F_, i);
     }
+}
+
+// --- contact points, scalar rows and cost values: lane c, 8 tasks.  planner.py:656-697, 855-895 --------
+template <class Em> HD void t_points_scalar(Ctx<Em>& cx, int c) {
+    KnotScratch& s = cx.s;
+    const double* x = s.x + PT_ * c;
+    const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
+    Em& em = cx.em;
+    const double pz = x[P_ + 2], fz = x[F_ + 2], vz = x[V_ + 2], fdz = x[FD_ + 2];
     // dcc margin  eps - k h (n.f) - [hdot (n.f) + h f.ndot + h (n.fdot)]   (E4; n = e_z, ndot = 0, hdot = v_z)
     em.G(gb + gs::DCC, row_id(RK_DCC, c, 0), cx.gp.eps - cx.gp.kbs * (pz * fz) - (vz * fz + pz * fdz));
     em.J(jb + js::DCC + 0, row_id(RK_DCC, c, 0), cb + P_ + 2, -cx.gp.kbs * fz - fdz);
@@ -171,35 +212,16 @@ template <class Em> HD void phase_points(Ctx<Em>& cx, int c) {
     em.J(jb + js::FRICTION + 0, row_id(RK_FRICTION, c, 0), cb + F_ + 0, -2.0 * x[F_]);
     em.J(jb + js::FRICTION + 1, row_id(RK_FRICTION, c, 0), cb + F_ + 1, -2.0 * x[F_ + 1]);
     em.J(jb + js::FRICTION + 2, row_id(RK_FRICTION, c, 0), cb + F_ + 2, 2.0 * mu2 * fz);
-    for (int i = 0; i < 3; ++i) {  // control bound rows
-        em.G(gb + gs::UB + i, row_id(RK_UB, c, i), x[U_ + i]);
-        em.J(jb + js::UB + i, row_id(RK_UB, c, i), cb + U_ + i, 1.0);
-        em.G(gb + gs::FDB + i, row_id(RK_FDB, c, i), x[FD_ + i] * cx.gp.mass);
-        em.J(jb + js::FDB + i, row_id(RK_FDB, c, i), cb + FD_ + i, cx.gp.mass);
-    }
-    // point-local costs (k >= 1): swing height heuristic (E10), ||u_v||^2, ||f_dot||^2
+    // values of the point-local costs (k >= 1)
     const double on = cx.ki.first ? 0.0 : 1.0;
     const double dh = pz - s.pk[PK_REF + R_SWING];
-    double* gr = s.grad + cb;
-    const double msw = on * cx.st.m_swing, mur = on * cx.st.m_ureg, mfd = on * cx.st.m_fdreg;
-    s.cpt[c][0] = msw * (0.5 * (dh * dh + (x[V_] * x[V_] + x[V_ + 1] * x[V_ + 1])));
-    s.cpt[c][1] = mur * (x[U_] * x[U_] + x[U_ + 1] * x[U_ + 1] + x[U_ + 2] * x[U_ + 2]);
-    s.cpt[c][2] = mfd * (x[FD_] * x[FD_] + x[FD_ + 1] * x[FD_ + 1] + x[FD_ + 2] * x[FD_ + 2]);
-    gr[V_ + 0] = msw * x[V_]; gr[V_ + 1] = msw * x[V_ + 1]; gr[V_ + 2] = 0.0;
-    gr[P_ + 0] = 0.0; gr[P_ + 1] = 0.0; gr[P_ + 2] = msw * dh;
-    for (int i = 0; i < 3; ++i) { gr[U_ + i] = 2.0 * mur * x[U_ + i]; gr[FD_ + i] = 2.0 * mfd * x[FD_ + i]; gr[F_ + i] = 0.0; }
-    // contribution of this point to hdot at k-1 and k   (E1)
-    for (int w = 0; w < 2; ++w) {
-        const double* xx = w ? s.x : s.xm;
-        double r[3], t[3];
-        for (int i = 0; i < 3; ++i) r[i] = xx[cb + P_ + i] - xx[COM_ + i];
-        cross3(r, xx + cb + F_, t);
-        for (int i = 0; i < 3; ++i) { s.hd[w][c][i] = xx[cb + F_ + i]; s.hd[w][c][3 + i] = t[i]; }
-    }
+    s.c_pt[c][0] = on * cx.st.m_swing * (0.5 * (dh * dh + (x[V_] * x[V_] + x[V_ + 1] * x[V_ + 1])));
+    s.c_pt[c][1] = on * cx.st.m_ureg * (x[U_] * x[U_] + x[U_ + 1] * x[U_ + 1] + x[U_ + 2] * x[U_ + 2]);
+    s.c_pt[c][2] = on * cx.st.m_fdreg * (x[FD_] * x[FD_] + x[FD_ + 1] * x[FD_ + 1] + x[FD_ + 2] * x[FD_ + 2]);
 }
 
-// --- A2: trivial dynamics of base / joints / com, lane e over 33 state components.  planner.py:522-564
-template <class Em> HD void phase_dyn(Ctx<Em>& cx, int e) {
+// --- trivial dynamics of base / joints / com, lane e over 33 state components.  planner.py:522-564 -----
+template <class Em> HD void t_dyn(Ctx<Em>& cx, int e) {
     KnotScratch& s = cx.s;
     const double half = 0.5 * cx.gp.dt;
     int X, Y, L, i, kin, gslot, gx0, jslot;
@@ -218,8 +240,8 @@ template <class Em> HD void phase_dyn(Ctx<Em>& cx, int e) {
     em.J(jslot + 4 * L + i, row_id(kx0, 0, i), X, 1.0);
 }
 
-// --- A3: joint-wise rows and joint regularisation cost, lane j (23) + local joint transform -----------
-template <class Em> HD void phase_joints(Ctx<Em>& cx, int j) {
+// --- joint-wise rows, joint regularisation cost and the local joint transform, lane j (23) -------------
+template <class Em> HD void t_joints(Ctx<Em>& cx, int j) {
     KnotScratch& s = cx.s;
     Em& em = cx.em;
     em.G(gs::JPB + j, row_id(RK_JPB, 0, j), s.x[S_ + j]);
@@ -233,7 +255,7 @@ template <class Em> HD void phase_joints(Ctx<Em>& cx, int j) {
     const double t = sd + w * (s.x[S_ + j] - s.pk[PK_REF + R_JREG + j]);
     double c = t * t, gsd = 2.0 * t;
     if (cx.st.joint_reg_as_coded) { c += double(NJ - 1) * (sd * sd); gsd += 2.0 * double(NJ - 1) * sd; }
-    s.cjt[j] = m * c;
+    s.c_joint[j] = m * c;
     s.grad[S_ + j] = 2.0 * m * t * w;
     s.grad[SD_ + j] = m * gsd;
     // parent_R_child = R_fix * (cq (I - a a^T) + sq [a]x + a a^T)   (adam R_from_axis_angle)
@@ -249,213 +271,360 @@ template <class Em> HD void phase_joints(Ctx<Em>& cx, int j) {
     matmul3(cx.kt.R_fix[j], Ra, s.Rloc[j]);
 }
 
-// --- A4: one-off global tasks --------------------------------------------------------------------------
-constexpr int MISC_TASKS = 6;
-template <class Em> HD void phase_misc(Ctx<Em>& cx, int t) {
+// --- unitary quaternion row (planner.py:276-282) + base quaternion error cost (E13, raw q), 1 task ------
+template <class Em> HD void t_unitq(Ctx<Em>& cx, int) {
     KnotScratch& s = cx.s;
     Em& em = cx.em;
     const double on = cx.ki.first ? 0.0 : 1.0;
-    switch (t) {
-        case 0: {  // unitary quaternion sumsqr(q) == 1 (planner.py:276-282); base quaternion error cost (E13, raw q)
-            const double* q = s.x + QB_;
-            em.G(gs::UNITQ, row_id(RK_UNITQ, 0, 0), q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-            for (int l = 0; l < 4; ++l) em.J(js::UNITQ + l, row_id(RK_UNITQ, 0, 0), QB_ + l, 2.0 * q[l]);
-            const double* d = s.pk + PK_REF + R_BQ;
-            const double ax = -d[0], ay = -d[1], az = -d[2], aw = d[3];  // conj(q_d)
-            double e[4];
-            e[0] = aw * q[0] + ax * q[3] + ay * q[2] - az * q[1];
-            e[1] = aw * q[1] - ax * q[2] + ay * q[3] + az * q[0];
-            e[2] = aw * q[2] + ax * q[1] - ay * q[0] + az * q[3];
-            e[3] = aw * q[3] - ax * q[0] - ay * q[1] - az * q[2] - 1.0;
-            const double m = on * cx.st.m_baseq;
-            s.cost[CT_BASEQ] = m * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
-            s.grad[QB_ + 0] = 2.0 * m * (e[0] * aw + e[1] * az - e[2] * ay - e[3] * ax);
-            s.grad[QB_ + 1] = 2.0 * m * (-e[0] * az + e[1] * aw + e[2] * ax - e[3] * ay);
-            s.grad[QB_ + 2] = 2.0 * m * (e[0] * ay - e[1] * ax + e[2] * aw - e[3] * az);
-            s.grad[QB_ + 3] = 2.0 * m * (e[0] * ax + e[1] * ay + e[2] * az + e[3] * aw);
-        } break;
-        case 1: {  // angular momentum bound rows h[3:]*mass; com velocity cost (k >= 0)
-            double c = 0.0;
-            for (int i = 0; i < 3; ++i) {
-                em.G(gs::AMB + i, row_id(RK_AMB, 0, i), s.x[H_ + 3 + i] * cx.gp.mass);
-                em.J(js::AMB + i, row_id(RK_AMB, 0, i), H_ + 3 + i, cx.gp.mass);
-                const double e = s.x[H_ + i] - s.pk[PK_REF + R_VREF + i];
-                c += e * cx.st.w_comvel[i] * e;
-                s.grad[H_ + i] = 2.0 * cx.st.m_comvel * cx.st.w_comvel[i] * e;
-                s.grad[H_ + 3 + i] = 0.0;
-            }
-            s.cost[CT_COMVEL] = cx.st.m_comvel * c;
-        } break;
-        case 2: {  // minimum com height: h_terrain(com) = com_z
-            em.G(gs::COMH, row_id(RK_COMH, 0, 0), s.x[COM_ + 2]);
-            em.J(js::COMH, row_id(RK_COMH, 0, 0), COM_ + 2, 1.0);
-            for (int i = 0; i < 3; ++i) { s.grad[COM_ + i] = 0.0; s.grad[PB_ + i] = 0.0; s.grad[VB_ + i] = 0.0; }
-        } break;
-        case 3: {  // base quaternion velocity cost (k >= 0)
-            double c = 0.0;
-            for (int i = 0; i < 4; ++i) {
-                const double e = s.x[QD_ + i] - s.pk[PK_REF + R_BQV + i];
-                c += e * e;
-                s.grad[QD_ + i] = 2.0 * cx.st.m_baseqv * e;
-            }
-            s.cost[CT_BASEQV] = cx.st.m_baseqv * c;
-        } break;
-        case 4: {  // feet centroids: relative height row + centroid cost (k >= 1)   planner.py:215-264
-            double cl[3] = {0, 0, 0}, cr[3] = {0, 0, 0};
-            for (int c = 0; c < 4; ++c)
-                for (int i = 0; i < 3; ++i) { cl[i] += s.x[PT_ * c + P_ + i]; cr[i] += s.x[PT_ * (c + 4) + P_ + i]; }
-            for (int i = 0; i < 3; ++i) { cl[i] = cl[i] / 4.0; cr[i] = cr[i] / 4.0; }
-            em.G(gs::FEETH, row_id(RK_FEETH, 0, 0), cl[2] - cr[2]);
-            for (int c = 0; c < NC; ++c) em.J(js::FEETH + c, row_id(RK_FEETH, 0, 0), PT_ * c + P_ + 2, c < 4 ? 0.25 : -0.25);
-            double cost = 0.0;
-            const double m = on * cx.st.m_centroid;
-            for (int i = 0; i < 3; ++i) {
-                const double e = s.pk[PK_REF + R_CREF + i] - 0.5 * (cl[i] + cr[i]);
-                const double w = s.pk[PK_REF + R_CW + i];
-                cost += e * w * e;
-                s.cen_g[i] = -0.25 * m * w * e;  // 2 w e * d e / d p_c,i = 2 w e (-0.5/4)
-            }
-            s.cost[CT_CENTROID] = m * cost;
-        } break;
-        case 5: {  // base orientation: normalised quaternion (E11), R_b, G, omega (E12), d omega / d q_b
-            const double* q = s.x + QB_;
-            const double* qd = s.x + QD_;
-            const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-            s.qnorm = n;
-            double qn[4];
-            for (int i = 0; i < 4; ++i) { qn[i] = q[i] / n; s.qn[i] = qn[i]; }
-            rot_from_quat(qn, s.Rb);
-            const double vx = qn[0], vy = qn[1], vz = qn[2], w = qn[3];
-            // G = 2 [ w I + [v]x | -v ]
-            double* G = s.G;
-            G[0] = 2.0 * w;   G[1] = -2.0 * vz; G[2] = 2.0 * vy;  G[3] = -2.0 * vx;
-            G[4] = 2.0 * vz;  G[5] = 2.0 * w;   G[6] = -2.0 * vx; G[7] = -2.0 * vy;
-            G[8] = -2.0 * vy; G[9] = 2.0 * vx;  G[10] = 2.0 * w;  G[11] = -2.0 * vz;
-            for (int e = 0; e < 3; ++e) s.omega[e] = G[4 * e] * qd[0] + G[4 * e + 1] * qd[1] + G[4 * e + 2] * qd[2] + G[4 * e + 3] * qd[3];
-            // omega = H(qdot) qhat,  H = 2 [ -qd_w I - [qd_v]x | qd_v ];  d omega / d q = H (I - qn qn^T) / |q|
-            double H[12];
-            H[0] = -2.0 * qd[3]; H[1] = 2.0 * qd[2];  H[2] = -2.0 * qd[1]; H[3] = 2.0 * qd[0];
-            H[4] = -2.0 * qd[2]; H[5] = -2.0 * qd[3]; H[6] = 2.0 * qd[0];  H[7] = 2.0 * qd[1];
-            H[8] = 2.0 * qd[1];  H[9] = -2.0 * qd[0]; H[10] = -2.0 * qd[3]; H[11] = 2.0 * qd[2];
-            for (int e = 0; e < 3; ++e) {
-                const double hq = H[4 * e] * qn[0] + H[4 * e + 1] * qn[1] + H[4 * e + 2] * qn[2] + H[4 * e + 3] * qn[3];
-                for (int l = 0; l < 4; ++l) s.dwq[4 * e + l] = (H[4 * e + l] - hq * qn[l]) / n;
-            }
-            // root link pose and velocity in base-centred coordinates
-            for (int i = 0; i < 9; ++i) s.Rw[0][i] = s.Rb[i];
-            for (int i = 0; i < 3; ++i) { s.ow[0][i] = 0.0; s.wv[0][i] = s.omega[i]; s.vo[0][i] = 0.0; }
-        } break;
-        default: break;
+    const double* q = s.x + QB_;
+    em.G(gs::UNITQ, row_id(RK_UNITQ, 0, 0), q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int l = 0; l < 4; ++l) em.J(js::UNITQ + l, row_id(RK_UNITQ, 0, 0), QB_ + l, 2.0 * q[l]);
+    const double* d = s.pk + PK_REF + R_BQ;
+    const double ax = -d[0], ay = -d[1], az = -d[2], aw = d[3];  // conj(q_d)
+    double e[4];
+    e[0] = aw * q[0] + ax * q[3] + ay * q[2] - az * q[1];
+    e[1] = aw * q[1] - ax * q[2] + ay * q[3] + az * q[0];
+    e[2] = aw * q[2] + ax * q[1] - ay * q[0] + az * q[3];
+    e[3] = aw * q[3] - ax * q[0] - ay * q[1] - az * q[2] - 1.0;
+    const double m = on * cx.st.m_baseq;
+    s.cost[CT_BASEQ] = m * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
+    s.grad[QB_ + 0] = 2.0 * m * (e[0] * aw + e[1] * az - e[2] * ay - e[3] * ax);
+    s.grad[QB_ + 1] = 2.0 * m * (-e[0] * az + e[1] * aw + e[2] * ax - e[3] * ay);
+    s.grad[QB_ + 2] = 2.0 * m * (e[0] * ay - e[1] * ax + e[2] * aw - e[3] * az);
+    s.grad[QB_ + 3] = 2.0 * m * (e[0] * ax + e[1] * ay + e[2] * az + e[3] * aw);
+}
+
+// --- small global rows / costs: lanes 0..2 component-wise, lane 3 scalar: 4 tasks ---------------------------
+template <class Em> HD void t_small(Ctx<Em>& cx, int t) {
+    KnotScratch& s = cx.s;
+    Em& em = cx.em;
+    if (t < 3) {  // angular momentum bound rows h[3:]*mass (planner.py:342-350); com velocity cost (k >= 0)
+        const int i = t;
+        em.G(gs::AMB + i, row_id(RK_AMB, 0, i), s.x[H_ + 3 + i] * cx.gp.mass);
+        em.J(js::AMB + i, row_id(RK_AMB, 0, i), H_ + 3 + i, cx.gp.mass);
+        const double e = s.x[H_ + i] - s.pk[PK_REF + R_VREF + i];
+        s.c_comvel[i] = cx.st.m_comvel * (e * cx.st.w_comvel[i] * e);
+        s.grad[H_ + i] = 2.0 * cx.st.m_comvel * cx.st.w_comvel[i] * e;
+        s.grad[H_ + 3 + i] = 0.0;
+        s.grad[COM_ + i] = 0.0; s.grad[PB_ + i] = 0.0; s.grad[VB_ + i] = 0.0;
+    } else {      // minimum com height: h_terrain(com) = com_z ; base quaternion velocity cost (k >= 0)
+        em.G(gs::COMH, row_id(RK_COMH, 0, 0), s.x[COM_ + 2]);
+        em.J(js::COMH, row_id(RK_COMH, 0, 0), COM_ + 2, 1.0);
+        double c = 0.0;
+        for (int i = 0; i < 4; ++i) {
+            const double e = s.x[QD_ + i] - s.pk[PK_REF + R_BQV + i];
+            c += e * e;
+            s.grad[QD_ + i] = 2.0 * cx.st.m_baseqv * e;
+        }
+        s.cost[CT_BASEQV] = cx.st.m_baseqv * c;
     }
 }
 
-// ===================================================================================================
-// PHASE B(d): forward kinematics + link velocities, one tree level per phase; lane j (joints of depth d)
-// ===================================================================================================
-template <class Em> HD void phase_fk_level(Ctx<Em>& cx, int j, int d) {
-    if (cx.kt.depth[j] != d) return;
+// --- feet: lane 0 centroids (relative height row + centroid cost, planner.py:215-264);
+//           lanes 1,2 yaw alignment errors of the left / right foot (E9, planner.py:773-853): 3 tasks -------
+template <class Em> HD void t_feet(Ctx<Em>& cx, int t) {
     KnotScratch& s = cx.s;
-    const int i = j + 1, par = cx.kt.parent[j];
-    matmul3(s.Rw[par], s.Rloc[j], s.Rw[i]);
-    double t[3];
-    matvec3(s.Rw[par], cx.kt.o_fix[j], t);
-    for (int r = 0; r < 3; ++r) s.ow[i][r] = s.ow[par][r] + t[r];
-    matvec3(s.Rw[i], cx.kt.axis[j], s.aw[j]);
-    const double sd = s.x[SD_ + j];
-    double oxa[3];
-    cross3(s.ow[i], s.aw[j], oxa);
-    for (int r = 0; r < 3; ++r) { s.wv[i][r] = s.wv[par][r] + s.aw[j][r] * sd; s.vo[i][r] = s.vo[par][r] + oxa[r] * sd; }
+    Em& em = cx.em;
+    const double on = cx.ki.first ? 0.0 : 1.0;
+    if (t == 0) {
+        double cl[3] = {0, 0, 0}, cr[3] = {0, 0, 0};
+        for (int c = 0; c < 4; ++c)
+            for (int i = 0; i < 3; ++i) { cl[i] += s.x[PT_ * c + P_ + i]; cr[i] += s.x[PT_ * (c + 4) + P_ + i]; }
+        for (int i = 0; i < 3; ++i) { cl[i] = cl[i] / 4.0; cr[i] = cr[i] / 4.0; }
+        em.G(gs::FEETH, row_id(RK_FEETH, 0, 0), cl[2] - cr[2]);
+        for (int c = 0; c < NC; ++c) em.J(js::FEETH + c, row_id(RK_FEETH, 0, 0), PT_ * c + P_ + 2, c < 4 ? 0.25 : -0.25);
+        double cost = 0.0;
+        const double m = on * cx.st.m_centroid;
+        for (int i = 0; i < 3; ++i) {
+            const double e = s.pk[PK_REF + R_CREF + i] - 0.5 * (cl[i] + cr[i]);
+            const double w = s.pk[PK_REF + R_CW + i];
+            cost += e * w * e;
+            s.cen_g[i] = -0.25 * m * w * e;  // 2 w e * d e / d p_c,i = 2 w e (-0.5/4)
+        }
+        s.cost[CT_CENTROID] = m * cost;
+    } else {
+        const int foot = t - 1;
+        const double yaw = s.pk[PK_REF + (foot == 0 ? R_YAW_L : R_YAW_R)];
+        const int br = 4 * foot + cx.st.yaw_corner[foot][0], tr = 4 * foot + cx.st.yaw_corner[foot][1], tl = 4 * foot + cx.st.yaw_corner[foot][2];
+        double s1, c1, s2, c2;
+        sincos(yaw, &s1, &c1);
+        sincos(yaw + M_PI / 2, &s2, &c2);
+        const double* pbr = s.x + PT_ * br + P_;
+        const double* ptr = s.x + PT_ * tr + P_;
+        const double* ptl = s.x + PT_ * tl + P_;
+        const double ef = -s1 * (ptr[0] - pbr[0]) + c1 * (ptr[1] - pbr[1]);
+        const double es = -s2 * (ptl[0] - ptr[0]) + c2 * (ptl[1] - ptr[1]);
+        s.yaw_sc[foot][0] = s1; s.yaw_sc[foot][1] = c1; s.yaw_sc[foot][2] = s2; s.yaw_sc[foot][3] = c2;
+        s.yaw_e[foot][0] = ef; s.yaw_e[foot][1] = es;
+        s.c_yaw[foot] = on * cx.st.m_yaw * (0.5 * (ef * ef + es * es));
+    }
+}
+
+// --- base orientation: normalised quaternion (E11), R_b, G, omega (E12), d omega / d q_b: 1 task -----------
+template <class Em> HD void t_base(Ctx<Em>& cx, int) {
+    KnotScratch& s = cx.s;
+    const double* q = s.x + QB_;
+    const double* qd = s.x + QD_;
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    s.qnorm = n;
+    double qn[4];
+    for (int i = 0; i < 4; ++i) { qn[i] = q[i] / n; s.qn[i] = qn[i]; }
+    rot_from_quat(qn, s.Rb);
+    const double vx = qn[0], vy = qn[1], vz = qn[2], w = qn[3];
+    double* G = s.G;  // G = 2 [ w I + [v]x | -v ]
+    G[0] = 2.0 * w;   G[1] = -2.0 * vz; G[2] = 2.0 * vy;  G[3] = -2.0 * vx;
+    G[4] = 2.0 * vz;  G[5] = 2.0 * w;   G[6] = -2.0 * vx; G[7] = -2.0 * vy;
+    G[8] = -2.0 * vy; G[9] = 2.0 * vx;  G[10] = 2.0 * w;  G[11] = -2.0 * vz;
+    for (int e = 0; e < 3; ++e) s.omega[e] = G[4 * e] * qd[0] + G[4 * e + 1] * qd[1] + G[4 * e + 2] * qd[2] + G[4 * e + 3] * qd[3];
+    // omega = H(qdot) qhat,  H = 2 [ -qd_w I - [qd_v]x | qd_v ];  d omega / d q = H (I - qn qn^T) / |q|
+    double H[12];
+    H[0] = -2.0 * qd[3]; H[1] = 2.0 * qd[2];  H[2] = -2.0 * qd[1]; H[3] = 2.0 * qd[0];
+    H[4] = -2.0 * qd[2]; H[5] = -2.0 * qd[3]; H[6] = 2.0 * qd[0];  H[7] = 2.0 * qd[1];
+    H[8] = 2.0 * qd[1];  H[9] = -2.0 * qd[0]; H[10] = -2.0 * qd[3]; H[11] = 2.0 * qd[2];
+    for (int e = 0; e < 3; ++e) {
+        const double hq = H[4 * e] * qn[0] + H[4 * e + 1] * qn[1] + H[4 * e + 2] * qn[2] + H[4 * e + 3] * qn[3];
+        for (int l = 0; l < 4; ++l) s.dwq[4 * e + l] = (H[4 * e + l] - hq * qn[l]) / n;
+    }
+    // root link pose and velocity in base-centred coordinates
+    for (int i = 0; i < 9; ++i) s.Rw[0][i] = s.Rb[i];
+    for (int i = 0; i < 3; ++i) { s.ow[0][i] = 0.0; s.wv[0][i] = s.omega[i]; s.vo[0][i] = 0.0; }
 }
 
 // ===================================================================================================
-// PHASE C: per-link spatial inertia at the origin and link momentum, lane i (24 links);
-//          frames (lanes 24..26)
+// PHASE B — wave 0: forward kinematics + link velocities, ONE LANE PER ROOT->LEAF CHAIN (the chain state
+// stays in registers; shared prefixes are recomputed, identical values are stored twice).
+// Other waves meanwhile: momentum-dynamics rows, foot costs, horizon-end rows.
 // ===================================================================================================
-template <class Em> HD void phase_links(Ctx<Em>& cx, int t) {
+template <class Em> HD void t_fk_chain(Ctx<Em>& cx, int leaf) {
     KnotScratch& s = cx.s;
-    if (t < NL) {
-        const int i = t;
-        const double m = cx.kt.mass[i];
-        double c[3], RI[9], Iw[9], Rt[9];
-        matvec3(s.Rw[i], cx.kt.com[i], c);
-        for (int r = 0; r < 3; ++r) c[r] += s.ow[i][r];
-        matmul3(s.Rw[i], cx.kt.inertia[i], RI);
-        for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) Rt[3 * r + q] = s.Rw[i][3 * q + r];
-        matmul3(RI, Rt, Iw);
-        const double c2 = dot3(c, c);
-        s.cm[i] = m;
-        for (int r = 0; r < 3; ++r) s.ch[i][r] = m * c[r];
-        s.cI[i][0] = Iw[0] + m * (c2 - c[0] * c[0]);
-        s.cI[i][1] = 0.5 * (Iw[1] + Iw[3]) - m * c[0] * c[1];
-        s.cI[i][2] = 0.5 * (Iw[2] + Iw[6]) - m * c[0] * c[2];
-        s.cI[i][3] = Iw[4] + m * (c2 - c[1] * c[1]);
-        s.cI[i][4] = 0.5 * (Iw[5] + Iw[7]) - m * c[1] * c[2];
-        s.cI[i][5] = Iw[8] + m * (c2 - c[2] * c[2]);
-        // link momentum about the origin:  lin = m vO + w x h ;  ang = I_O w + h x vO
-        double a[3], b[3];
-        cross3(s.wv[i], s.ch[i], a);
-        for (int r = 0; r < 3; ++r) s.ckl[i][r] = m * s.vo[i][r] + a[r];
-        symvec(s.cI[i], s.wv[i], a);
-        cross3(s.ch[i], s.vo[i], b);
-        for (int r = 0; r < 3; ++r) s.cka[i][r] = a[r] + b[r];
-    } else if (t < NL + 3) {
-        const int f = t - NL, L = cx.kt.frame_link[f];
-        matmul3(s.Rw[L], cx.kt.frame_R[f], s.fr_R[f]);
-        double o[3];
-        matvec3(s.Rw[L], cx.kt.frame_o[f], o);
-        for (int r = 0; r < 3; ++r) s.fr_o[f][r] = s.ow[L][r] + o[r];
-        if (f == HIPNLP_FRAME_CHEST) {  // rotation error R_chest R(q_d)^T  (K5) -> trace and ax()
-            double Rd[9], M[9], Rdt[9];
-            rot_from_quat(s.pk + PK_REF + R_FQ, Rd);
-            for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) Rdt[3 * r + q] = Rd[3 * q + r];
-            matmul3(s.fr_R[f], Rdt, M);
-            const double e = (M[0] + M[4] + M[8]) - 3.0;
-            const double on = cx.ki.first ? 0.0 : 1.0;
-            const double m = on * cx.st.m_frameq;
-            s.cost[CT_FRAMEQ] = m * (e * e);
-            s.chest_dc = 2.0 * m * e;
-            s.chest_w[0] = M[7] - M[5]; s.chest_w[1] = M[2] - M[6]; s.chest_w[2] = M[3] - M[1];
+    double R[9], o[3] = {0.0, 0.0, 0.0}, w[3], vo[3] = {0.0, 0.0, 0.0};
+    for (int i = 0; i < 9; ++i) R[i] = s.Rb[i];
+    for (int i = 0; i < 3; ++i) w[i] = s.omega[i];
+    const int len = cx.kt.path_len[leaf];
+    for (int q = 0; q < len; ++q) {
+        const int j = cx.kt.path[leaf][q], i = j + 1;
+        double Rn[9], t[3], a[3], oxa[3];
+        matmul3(R, s.Rloc[j], Rn);
+        matvec3(R, cx.kt.o_fix[j], t);
+        for (int r = 0; r < 3; ++r) o[r] += t[r];
+        matvec3(Rn, cx.kt.axis[j], a);
+        const double sd = s.x[SD_ + j];
+        cross3(o, a, oxa);
+        for (int r = 0; r < 3; ++r) { w[r] += a[r] * sd; vo[r] += oxa[r] * sd; }
+        for (int r = 0; r < 9; ++r) { R[r] = Rn[r]; s.Rw[i][r] = Rn[r]; }
+        for (int r = 0; r < 3; ++r) { s.ow[i][r] = o[r]; s.aw[j][r] = a[r]; s.wv[i][r] = w[r]; s.vo[i][r] = vo[r]; }
+    }
+}
+
+// --- centroidal momentum dynamics (T7 on E1): lanes (c, e) 48 entry tasks + lanes 48..59 row tasks -----------
+constexpr int HDYN_TASKS = 60;
+template <class Em> HD void t_hdyn(Ctx<Em>& cx, int t) {
+    KnotScratch& s = cx.s;
+    Em& em = cx.em;
+    const double half = 0.5 * cx.gp.dt;
+    if (t < 48) {
+        const int c = t / 6, e = t - 6 * c, cb = PT_ * c;
+        double rc[3];
+        for (int i = 0; i < 3; ++i) rc[i] = s.x[cb + P_ + i] - s.x[COM_ + i];
+        const int row = 3 + cross_row(e), col = cross_col(e);
+        const double vp = half * skew_entry(s.x + cb + F_, e);   // -half * d[(p-com) x f]/dp = -half * (-[f]x)
+        const double vf = -half * skew_entry(rc, e);             // -half * [p-com]x
+        em.J(js::HDYN_ANG_P_IN + 6 * c + e, row_id(RK_HDYN_IN, 0, row), cb + P_ + col, vp);
+        em.J(js::HDYN_ANG_P_OUT + 6 * c + e, row_id(RK_HDYN_OUT, 0, row), cb + P_ + col, vp);
+        em.J(js::HDYN_ANG_F_IN + 6 * c + e, row_id(RK_HDYN_IN, 0, row), cb + F_ + col, vf);
+        em.J(js::HDYN_ANG_F_OUT + 6 * c + e, row_id(RK_HDYN_OUT, 0, row), cb + F_ + col, vf);
+        if (e < 3) {
+            em.J(js::HDYN_LIN_F_IN + 3 * c + e, row_id(RK_HDYN_IN, 0, e), cb + F_ + e, -half);
+            em.J(js::HDYN_LIN_F_OUT + 3 * c + e, row_id(RK_HDYN_OUT, 0, e), cb + F_ + e, -half);
+        }
+    } else if (t < 54) {  // the six rows
+        const int i = t - 48;
+        double h0 = cx.gp.gravity[i], h1 = cx.gp.gravity[i];
+        for (int c = 0; c < NC; ++c) { h0 += s.hd[0][c][i]; h1 += s.hd[1][c][i]; }
+        em.G(gs::HDYN + i, row_id(RK_HDYN_IN, 0, i), s.x[H_ + i] - (s.xm[H_ + i] + half * (h0 + h1)));
+        em.G(gs::H_X0 + i, row_id(RK_HDYN_X0, 0, i), s.x[H_ + i] - s.xg[i]);
+        em.J(js::HDYN_SELF_IN + i, row_id(RK_HDYN_IN, 0, i), H_ + i, 1.0);
+        em.J(js::HDYN_SELF_OUT + i, row_id(RK_HDYN_OUT, 0, i), H_ + i, -1.0);
+        em.J(js::HDYN_X0 + i, row_id(RK_HDYN_X0, 0, i), H_ + i, 1.0);
+        em.J(js::HDYN_X0G + i, row_id(RK_HDYN_X0, 0, i), COL_GLOBAL + i, -1.0);
+    } else {              // d/dcom sum (p - com) x f = [sum f]x
+        const int e = t - 54;
+        double fs[3] = {0.0, 0.0, 0.0};
+        for (int c = 0; c < NC; ++c) for (int i = 0; i < 3; ++i) fs[i] += s.x[PT_ * c + F_ + i];
+        const double v = -half * skew_entry(fs, e);
+        em.J(js::HDYN_ANG_COM_IN + e, row_id(RK_HDYN_IN, 0, 3 + cross_row(e)), COM_ + cross_col(e), v);
+        em.J(js::HDYN_ANG_COM_OUT + e, row_id(RK_HDYN_OUT, 0, 3 + cross_row(e)), COM_ + cross_col(e), v);
+    }
+}
+
+// --- foot costs (k >= 1): lanes (foot, i) 6: force-ratio regularisation; lanes 6..29 (c, i): gradient of the
+//     centroid and yaw costs on p.  planner.py:746-853, 249-264 ----------------------------------------------
+constexpr int FOOT_TASKS = 30;
+template <class Em> HD void t_foot_costs(Ctx<Em>& cx, int t) {
+    KnotScratch& s = cx.s;
+    const double on = cx.ki.first ? 0.0 : 1.0;
+    if (t < 6) {
+        const int foot = t / 3, i = t - 3 * foot;
+        const double mf = on * cx.st.m_freg;
+        const double* alpha = s.pk + PK_REF + (foot == 0 ? R_ALPHA_L : R_ALPHA_R);
+        double sum = 0.0, e[4], ae = 0.0, cost = 0.0;
+        for (int c = 0; c < 4; ++c) sum += s.x[PT_ * (4 * foot + c) + F_ + i];
+        for (int c = 0; c < 4; ++c) { e[c] = s.x[PT_ * (4 * foot + c) + F_ + i] - alpha[c] * sum; cost += e[c] * e[c]; ae += alpha[c] * e[c]; }
+        for (int c = 0; c < 4; ++c) s.grad[PT_ * (4 * foot + c) + F_ + i] += 2.0 * mf * (e[c] - ae);
+        s.c_force[foot][i] = mf * cost;
+    } else {
+        const int q = t - 6, c = q / 3, i = q - 3 * c, foot = c / 4, cl = c - 4 * foot;
+        double gsum = s.cen_g[i];
+        if (i < 2) {
+            const double my = on * cx.st.m_yaw;
+            const double ef = s.yaw_e[foot][0], es = s.yaw_e[foot][1];
+            const double s1 = s.yaw_sc[foot][0], c1 = s.yaw_sc[foot][1], s2 = s.yaw_sc[foot][2], c2 = s.yaw_sc[foot][3];
+            // d ef: (p_tr - p_br) . (-s1, c1) ; d es: (p_tl - p_tr) . (-s2, c2)
+            const double df = i == 0 ? -s1 : c1, ds = i == 0 ? -s2 : c2;
+            if (cl == cx.st.yaw_corner[foot][0]) gsum += -my * ef * df;
+            if (cl == cx.st.yaw_corner[foot][1]) gsum += my * ef * df - my * es * ds;
+            if (cl == cx.st.yaw_corner[foot][2]) gsum += my * es * ds;
+        }
+        s.grad[PT_ * c + P_ + i] += gsum;
+    }
+}
+
+// --- horizon-end rows (final state planner.py:407-425, periodicity :897-930), lanes over rows ----------------
+constexpr int ENDS_TASKS = 105 + 84;
+template <class Em> HD void t_ends(Ctx<Em>& cx, int t) {
+    KnotScratch& s = cx.s;
+    Em& em = cx.em;
+    s.c_ends[t] = 0.0;
+    s.g_ends[t] = 0.0;
+    if (t < 105) {
+        if (!cx.ki.last) return;
+        const int var = cx.kt.fin_var[t];
+        const double lhs = var >= 0 ? s.x[var] : s.pk[PK_DESC + cx.kt.fin_desc[t]];
+        if (cx.st.final_type == HIPNLP_EXPR_MINIMIZE) {
+            const double e = lhs - cx.gp.final_rhs[t];
+            s.c_ends[t] = cx.st.final_weight * e * e;
+            s.g_ends[t] = 2.0 * cx.st.final_weight * e;
+        } else if (cx.st.final_type == HIPNLP_EXPR_SUBJECT_TO) {
+            em.G(gs::FIN + t, row_id(RK_FIN, 0, t), lhs);
+            if (var >= 0) em.J(js::FIN + cx.kt.fin_slot[t], row_id(RK_FIN, 0, t), var, 1.0);
+        }
+    } else {
+        const int i = t - 105;
+        const int var = cx.kt.per_var[i];
+        if (cx.st.periodicity_type == HIPNLP_EXPR_MINIMIZE) {
+            if (!cx.ki.first && !cx.ki.last) return;
+            // e = x_0 - x_{N-1};  at the last knot xo = x_0, at the first knot xo = x_{N-1}
+            const double e = cx.ki.last ? (s.xo[var] - s.x[var]) : (s.x[var] - s.xo[var]);
+            if (cx.ki.last) s.c_ends[t] = cx.st.periodicity_weight * e * e;
+            s.g_ends[t] = (cx.ki.last ? -2.0 : 2.0) * cx.st.periodicity_weight * e;  // d/dx_{N-1} = -2we, d/dx_0 = +2we
+        } else if (cx.st.periodicity_type == HIPNLP_EXPR_SUBJECT_TO) {
+            if (cx.ki.last) {
+                em.G(gs::PER + i, row_id(RK_PERN, 0, i), s.xo[var] - s.x[var]);
+                em.J(js::PERN + i, row_id(RK_PERN, 0, i), var, -1.0);
+            }
+            if (cx.ki.first) em.J(js::PER0 + i, row_id(RK_PER0, 0, i), var, 1.0);
         }
     }
 }
 
 // ===================================================================================================
-// PHASE D(d): composite quantities, backward over tree levels; lane i (links of depth d gather children)
+// PHASE C — per-link spatial inertia at the origin and link momentum, lane i (24 links); frames (3 lanes)
 // ===================================================================================================
-template <class Em> HD void phase_composite_level(Ctx<Em>& cx, int i, int d) {
-    if (cx.kt.link_depth[i] != d) return;
+template <class Em> HD void t_links(Ctx<Em>& cx, int i) {
     KnotScratch& s = cx.s;
-    for (int q = 0; q < cx.kt.nchild[i]; ++q) {
-        const int c = cx.kt.child[i][q];
-        s.cm[i] += s.cm[c];
-        for (int r = 0; r < 3; ++r) { s.ch[i][r] += s.ch[c][r]; s.ckl[i][r] += s.ckl[c][r]; s.cka[i][r] += s.cka[c][r]; }
-        for (int r = 0; r < 6; ++r) s.cI[i][r] += s.cI[c][r];
+    const double m = cx.kt.mass[i];
+    double c[3], RI[9], Iw[9], Rt[9];
+    matvec3(s.Rw[i], cx.kt.com[i], c);
+    for (int r = 0; r < 3; ++r) c[r] += s.ow[i][r];
+    matmul3(s.Rw[i], cx.kt.inertia[i], RI);
+    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) Rt[3 * r + q] = s.Rw[i][3 * q + r];
+    matmul3(RI, Rt, Iw);
+    const double c2 = dot3(c, c);
+    s.cm[i] = m;
+    for (int r = 0; r < 3; ++r) s.ch[i][r] = m * c[r];
+    s.cI[i][0] = Iw[0] + m * (c2 - c[0] * c[0]);
+    s.cI[i][1] = 0.5 * (Iw[1] + Iw[3]) - m * c[0] * c[1];
+    s.cI[i][2] = 0.5 * (Iw[2] + Iw[6]) - m * c[0] * c[2];
+    s.cI[i][3] = Iw[4] + m * (c2 - c[1] * c[1]);
+    s.cI[i][4] = 0.5 * (Iw[5] + Iw[7]) - m * c[1] * c[2];
+    s.cI[i][5] = Iw[8] + m * (c2 - c[2] * c[2]);
+    // link momentum about the origin:  lin = m vO + w x h ;  ang = I_O w + h x vO
+    double a[3], b[3];
+    cross3(s.wv[i], s.ch[i], a);
+    for (int r = 0; r < 3; ++r) s.ckl[i][r] = m * s.vo[i][r] + a[r];
+    symvec(s.cI[i], s.wv[i], a);
+    cross3(s.ch[i], s.vo[i], b);
+    for (int r = 0; r < 3; ++r) s.cka[i][r] = a[r] + b[r];
+}
+template <class Em> HD void t_frames(Ctx<Em>& cx, int f) {
+    KnotScratch& s = cx.s;
+    const int L = cx.kt.frame_link[f];
+    matmul3(s.Rw[L], cx.kt.frame_R[f], s.fr_R[f]);
+    double o[3];
+    matvec3(s.Rw[L], cx.kt.frame_o[f], o);
+    for (int r = 0; r < 3; ++r) s.fr_o[f][r] = s.ow[L][r] + o[r];
+    if (f == HIPNLP_FRAME_CHEST) {  // rotation error R_chest R(q_d)^T  (K5) -> trace and ax()
+        double Rd[9], M[9], Rdt[9];
+        rot_from_quat(s.pk + PK_REF + R_FQ, Rd);
+        for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) Rdt[3 * r + q] = Rd[3 * q + r];
+        matmul3(s.fr_R[f], Rdt, M);
+        const double e = (M[0] + M[4] + M[8]) - 3.0;
+        const double on = cx.ki.first ? 0.0 : 1.0;
+        const double m = on * cx.st.m_frameq;
+        s.cost[CT_FRAMEQ] = m * (e * e);
+        s.chest_dc = 2.0 * m * e;
+        s.chest_w[0] = M[7] - M[5]; s.chest_w[1] = M[2] - M[6]; s.chest_w[2] = M[3] - M[1];
     }
 }
 
 // ===================================================================================================
-// PHASE E: totals (lane 0) and contact point kinematics (lanes 1..8)
+// PHASE D — composite quantities.  Stage 1: one lane per leaf walks up its single-child chain with the
+// running sums in registers.  Stage 2: one lane finishes the links that have several children and their
+// ancestors (reverse topological order), then the totals.  Contact-point kinematics ride along.
 // ===================================================================================================
-template <class Em> HD void phase_totals(Ctx<Em>& cx, int t) {
+template <class Em> HD void t_composite_chain(Ctx<Em>& cx, int leaf) {
     KnotScratch& s = cx.s;
-    if (t == 0) {
-        const double M = cx.kt.total_mass;
-        double t3[3];
-        for (int r = 0; r < 3; ++r) { s.com[r] = s.ch[0][r] / M; s.klin[r] = s.ckl[0][r]; s.kang[r] = s.cka[0][r]; }
-        cross3(s.com, s.klin, t3);
-        for (int r = 0; r < 3; ++r) s.hang[r] = s.kang[r] - t3[r];
-    } else if (t <= NC) {
-        const int c = t - 1, f = c < 4 ? 0 : 1;
-        double r3[3];
-        matvec3(s.fr_R[f], s.pk + PK_DESC + 3 * c, r3);
-        for (int r = 0; r < 3; ++r) s.pkin[c][r] = s.fr_o[f][r] + r3[r];
+    const int len = cx.kt.up_len[leaf];
+    double m = 0.0, h[3] = {0, 0, 0}, I[6] = {0, 0, 0, 0, 0, 0}, kl[3] = {0, 0, 0}, ka[3] = {0, 0, 0};
+    for (int q = 0; q < len; ++q) {
+        const int i = cx.kt.up_link[leaf][q];
+        m += s.cm[i];
+        for (int r = 0; r < 3; ++r) { h[r] += s.ch[i][r]; kl[r] += s.ckl[i][r]; ka[r] += s.cka[i][r]; }
+        for (int r = 0; r < 6; ++r) I[r] += s.cI[i][r];
+        s.cm[i] = m;
+        for (int r = 0; r < 3; ++r) { s.ch[i][r] = h[r]; s.ckl[i][r] = kl[r]; s.cka[i][r] = ka[r]; }
+        for (int r = 0; r < 6; ++r) s.cI[i][r] = I[r];
     }
+}
+template <class Em> HD void t_composite_rest(Ctx<Em>& cx, int) {
+    KnotScratch& s = cx.s;
+    for (int q = 0; q < cx.kt.s2_len; ++q) {
+        const int i = cx.kt.s2_link[q];
+        for (int n = 0; n < cx.kt.nchild[i]; ++n) {
+            const int c = cx.kt.child[i][n];
+            s.cm[i] += s.cm[c];
+            for (int r = 0; r < 3; ++r) { s.ch[i][r] += s.ch[c][r]; s.ckl[i][r] += s.ckl[c][r]; s.cka[i][r] += s.cka[c][r]; }
+            for (int r = 0; r < 6; ++r) s.cI[i][r] += s.cI[c][r];
+        }
+    }
+    const double M = cx.kt.total_mass;
+    double t3[3];
+    for (int r = 0; r < 3; ++r) { s.com[r] = s.ch[0][r] / M; s.klin[r] = s.ckl[0][r]; s.kang[r] = s.cka[0][r]; }
+    cross3(s.com, s.klin, t3);
+    for (int r = 0; r < 3; ++r) s.hang[r] = s.kang[r] - t3[r];
+}
+template <class Em> HD void t_pkin(Ctx<Em>& cx, int c) {
+    KnotScratch& s = cx.s;
+    const int f = c < 4 ? 0 : 1;
+    double r3[3];
+    matvec3(s.fr_R[f], s.pk + PK_DESC + 3 * c, r3);
+    for (int r = 0; r < 3; ++r) s.pkin[c][r] = s.fr_o[f][r] + r3[r];
 }
 
 // ===================================================================================================
-// PHASE F: derivative columns.  lanes 0..22: joint j ; lanes 23..25: base rotation theta_e / omega_e
+// PHASE F — derivative columns.  lanes 0..22: joint j ; lanes 23..25: base rotation theta_e / omega_e
 // ===================================================================================================
-template <class Em> HD void phase_columns(Ctx<Em>& cx, int t) {
+template <class Em> HD void t_columns(Ctx<Em>& cx, int t) {
     KnotScratch& s = cx.s;
     Em& em = cx.em;
     const double M = cx.kt.total_mass, mass = cx.gp.mass;
@@ -527,280 +696,137 @@ template <class Em> HD void phase_columns(Ctx<Em>& cx, int t) {
 }
 
 // ===================================================================================================
-// PHASE G: row assembly.  tasks: 0..7 contact-point kinematic consistency + hdot entries of point c ;
-//          8 com rows ; 9 cmm rows ; 10 feet distance g + chest grad on q_b ; 11 hdot rows ; 12,13 foot costs
+// PHASE G — row assembly
 // ===================================================================================================
-constexpr int ASSEMBLE_TASKS = 14;
-template <class Em> HD void phase_assemble(Ctx<Em>& cx, int t) {
+// contact-point kinematic consistency  p - (p_b + pkin)  (K1, planner.py:590-632): lane (c, i), 24 tasks
+template <class Em> HD void t_kinc(Ctx<Em>& cx, int t) {
     KnotScratch& s = cx.s;
     Em& em = cx.em;
-    const double half = 0.5 * cx.gp.dt;
-    const double on = cx.ki.first ? 0.0 : 1.0;
-    if (t < NC) {
-        const int c = t, f = c < 4 ? 0 : 1, jb = js::PT_STRIDE * c, gb = gs::PT_STRIDE * c, cb = PT_ * c;
-        const double* r = s.pkin[c];  // base-centred
-        // p - (p_b + pkin)   (K1 with the normalised base quaternion, planner.py:590-632)
-        for (int i = 0; i < 3; ++i) {
-            em.G(gb + gs::KINC + i, row_id(RK_KINC, c, i), s.x[cb + P_ + i] - (s.x[PB_ + i] + r[i]));
-            em.J(jb + js::KINC_P + i, row_id(RK_KINC, c, i), cb + P_ + i, 1.0);
-            em.J(jb + js::KINC_PB + i, row_id(RK_KINC, c, i), PB_ + i, -1.0);
-        }
-        // d pkin / d q_b = -[r]x G / |q|   ->  row entries = +[r]x G / |q|
-        const double X[9] = {0.0, -r[2], r[1], r[2], 0.0, -r[0], -r[1], r[0], 0.0};
-        for (int i = 0; i < 3; ++i)
-            for (int l = 0; l < 4; ++l)
-                em.J(jb + js::KINC_QB + 4 * i + l, row_id(RK_KINC, c, i), QB_ + l,
-                     (X[3 * i] * s.G[l] + X[3 * i + 1] * s.G[4 + l] + X[3 * i + 2] * s.G[8 + l]) / s.qnorm);
-        // d pkin / d s_j = a_j x (pkin - o_j) for the joints of the leg path
-        for (int q = 0; q < LEG_PATH; ++q) {
-            const int j = cx.kt.leg_joint[f][q];
-            double d[3], cxd[3];
-            for (int i = 0; i < 3; ++i) d[i] = r[i] - s.ow[j + 1][i];
-            cross3(s.aw[j], d, cxd);
-            for (int i = 0; i < 3; ++i) em.J(jb + js::KINC_S + LEG_PATH * i + q, row_id(RK_KINC, c, i), S_ + j, -cxd[i]);
-        }
-        // centroidal momentum dynamics (E1): entries of this point, identical for the IN ([k]) and OUT ([k+1]) rows
-        double rc[3];
-        for (int i = 0; i < 3; ++i) rc[i] = s.x[cb + P_ + i] - s.x[COM_ + i];
-        for (int i = 0; i < 3; ++i) {
-            em.J(js::HDYN_LIN_F_IN + 3 * c + i, row_id(RK_HDYN_IN, 0, i), cb + F_ + i, -half);
-            em.J(js::HDYN_LIN_F_OUT + 3 * c + i, row_id(RK_HDYN_OUT, 0, i), cb + F_ + i, -half);
-        }
-        for (int e = 0; e < 6; ++e) {
-            const int row = 3 + cross_row(e), col = cross_col(e);
-            const double vp = half * skew_entry(s.x + cb + F_, e);   // -half * d[(p-com) x f]/dp = -half * (-[f]x)
-            const double vf = -half * skew_entry(rc, e);             // -half * [p-com]x
-            em.J(js::HDYN_ANG_P_IN + 6 * c + e, row_id(RK_HDYN_IN, 0, row), cb + P_ + col, vp);
-            em.J(js::HDYN_ANG_P_OUT + 6 * c + e, row_id(RK_HDYN_OUT, 0, row), cb + P_ + col, vp);
-            em.J(js::HDYN_ANG_F_IN + 6 * c + e, row_id(RK_HDYN_IN, 0, row), cb + F_ + col, vf);
-            em.J(js::HDYN_ANG_F_OUT + 6 * c + e, row_id(RK_HDYN_OUT, 0, row), cb + F_ + col, vf);
-        }
-        return;
-    }
-    switch (t - NC) {
-        case 0: {  // com == CoM(pb, qn, s)   (K2, planner.py:285-306)
-            for (int i = 0; i < 3; ++i) {
-                em.G(gs::COMC + i, row_id(RK_COMC, 0, i), s.x[COM_ + i] - (s.x[PB_ + i] + s.com[i]));
-                em.J(js::COMC_COM + i, row_id(RK_COMC, 0, i), COM_ + i, 1.0);
-                em.J(js::COMC_PB + i, row_id(RK_COMC, 0, i), PB_ + i, -1.0);
-            }
-            const double* r = s.com;
-            const double X[9] = {0.0, -r[2], r[1], r[2], 0.0, -r[0], -r[1], r[0], 0.0};
-            for (int i = 0; i < 3; ++i)
-                for (int l = 0; l < 4; ++l)
-                    em.J(js::COMC_QB + 4 * i + l, row_id(RK_COMC, 0, i), QB_ + l,
-                         (X[3 * i] * s.G[l] + X[3 * i + 1] * s.G[4 + l] + X[3 * i + 2] * s.G[8 + l]) / s.qnorm);
-        } break;
-        case 1: {  // h[3:] == CMM(...)[3:] / mass   (K3, planner.py:309-339)
-            const double mass = cx.gp.mass;
-            for (int i = 0; i < 3; ++i) {
-                em.G(gs::CMMC + i, row_id(RK_CMMC, 0, i), s.x[H_ + 3 + i] - s.hang[i] / mass);
-                em.J(js::CMMC_H + i, row_id(RK_CMMC, 0, i), H_ + 3 + i, 1.0);
-                for (int l = 0; l < 4; ++l) {
-                    double dq = 0.0, dqd = 0.0;
-                    for (int e = 0; e < 3; ++e) {
-                        dq += s.dth_h[e][i] * s.G[4 * e + l] / s.qnorm + s.Aw[e][i] * s.dwq[4 * e + l];
-                        dqd += s.Aw[e][i] * s.G[4 * e + l];
-                    }
-                    em.J(js::CMMC_QB + 4 * i + l, row_id(RK_CMMC, 0, i), QB_ + l, -dq / mass);
-                    em.J(js::CMMC_QD + 4 * i + l, row_id(RK_CMMC, 0, i), QD_ + l, -dqd / mass);
-                }
-            }
-        } break;
-        case 2: {  // feet distance value (K4); chest cost gradient on q_b
-            const double* yr = s.fr_R[1];
-            double d[3];
-            for (int i = 0; i < 3; ++i) d[i] = s.fr_o[0][i] - s.fr_o[1][i];
-            em.G(gs::FEETD, row_id(RK_FEETD, 0, 0), yr[1] * d[0] + yr[4] * d[1] + yr[7] * d[2]);
-            for (int l = 0; l < 4; ++l) {
-                double acc = 0.0;
-                for (int e = 0; e < 3; ++e) acc += -s.chest_w[e] * s.G[4 * e + l];
-                s.grad[QB_ + l] += s.chest_dc * acc / s.qnorm;
-            }
-        } break;
-        case 3: {  // centroidal momentum dynamics rows (T7 on E1) and their self / com entries
-            double hdot[2][6], fs[3] = {0.0, 0.0, 0.0};
-            for (int w = 0; w < 2; ++w)
-                for (int i = 0; i < 6; ++i) {
-                    double acc = cx.gp.gravity[i];
-                    for (int c = 0; c < NC; ++c) acc += s.hd[w][c][i];
-                    hdot[w][i] = acc;
-                }
-            for (int c = 0; c < NC; ++c) for (int i = 0; i < 3; ++i) fs[i] += s.x[PT_ * c + F_ + i];
-            for (int i = 0; i < 6; ++i) {
-                em.G(gs::HDYN + i, row_id(RK_HDYN_IN, 0, i), s.x[H_ + i] - (s.xm[H_ + i] + half * (hdot[0][i] + hdot[1][i])));
-                em.G(gs::H_X0 + i, row_id(RK_HDYN_X0, 0, i), s.x[H_ + i] - s.xg[i]);
-                em.J(js::HDYN_SELF_IN + i, row_id(RK_HDYN_IN, 0, i), H_ + i, 1.0);
-                em.J(js::HDYN_SELF_OUT + i, row_id(RK_HDYN_OUT, 0, i), H_ + i, -1.0);
-                em.J(js::HDYN_X0 + i, row_id(RK_HDYN_X0, 0, i), H_ + i, 1.0);
-                em.J(js::HDYN_X0G + i, row_id(RK_HDYN_X0, 0, i), COL_GLOBAL + i, -1.0);
-            }
-            for (int e = 0; e < 6; ++e) {  // d/dcom sum (p - com) x f = [sum f]x
-                const double v = -half * skew_entry(fs, e);
-                em.J(js::HDYN_ANG_COM_IN + e, row_id(RK_HDYN_IN, 0, 3 + cross_row(e)), COM_ + cross_col(e), v);
-                em.J(js::HDYN_ANG_COM_OUT + e, row_id(RK_HDYN_OUT, 0, 3 + cross_row(e)), COM_ + cross_col(e), v);
-            }
-        } break;
-        case 4:
-        case 5: {  // foot costs (k >= 1): force-ratio regularisation and yaw alignment   planner.py:746-853
-            const int foot = t - NC - 4;
-            const double mf = on * cx.st.m_freg, my = on * cx.st.m_yaw;
-            const double* alpha = s.pk + PK_REF + (foot == 0 ? R_ALPHA_L : R_ALPHA_R);
-            double cost = 0.0;
-            for (int i = 0; i < 3; ++i) {
-                double sum = 0.0, e[4], ae = 0.0;
-                for (int c = 0; c < 4; ++c) sum += s.x[PT_ * (4 * foot + c) + F_ + i];
-                for (int c = 0; c < 4; ++c) { e[c] = s.x[PT_ * (4 * foot + c) + F_ + i] - alpha[c] * sum; cost += e[c] * e[c]; ae += alpha[c] * e[c]; }
-                for (int c = 0; c < 4; ++c) s.grad[PT_ * (4 * foot + c) + F_ + i] += 2.0 * mf * (e[c] - ae);
-            }
-            s.cft[foot][0] = mf * cost;
-            const double yaw = s.pk[PK_REF + (foot == 0 ? R_YAW_L : R_YAW_R)];
-            const int br = 4 * foot + cx.st.yaw_corner[foot][0], tr = 4 * foot + cx.st.yaw_corner[foot][1], tl = 4 * foot + cx.st.yaw_corner[foot][2];
-            double s1, c1, s2, c2;
-            sincos(yaw, &s1, &c1);
-            sincos(yaw + M_PI / 2, &s2, &c2);
-            const double* pbr = s.x + PT_ * br + P_;
-            const double* ptr = s.x + PT_ * tr + P_;
-            const double* ptl = s.x + PT_ * tl + P_;
-            const double ef = -s1 * (ptr[0] - pbr[0]) + c1 * (ptr[1] - pbr[1]);  // E9
-            const double es = -s2 * (ptl[0] - ptr[0]) + c2 * (ptl[1] - ptr[1]);
-            s.cft[foot][1] = my * (0.5 * (ef * ef + es * es));
-            // centroid cost gradient (same vector for every point) + yaw gradient
-            for (int c = 0; c < 4; ++c)
-                for (int i = 0; i < 3; ++i) s.grad[PT_ * (4 * foot + c) + P_ + i] += s.cen_g[i];
-            s.grad[PT_ * br + P_ + 0] += my * ef * s1;   s.grad[PT_ * br + P_ + 1] += -my * ef * c1;
-            s.grad[PT_ * tr + P_ + 0] += -my * ef * s1 + my * es * s2;
-            s.grad[PT_ * tr + P_ + 1] += my * ef * c1 - my * es * c2;
-            s.grad[PT_ * tl + P_ + 0] += -my * es * s2;  s.grad[PT_ * tl + P_ + 1] += my * es * c2;
-        } break;
-        default: break;
+    const int c = t / 3, i = t - 3 * c, f = c < 4 ? 0 : 1, jb = js::PT_STRIDE * c, gb = gs::PT_STRIDE * c, cb = PT_ * c;
+    const double* r = s.pkin[c];  // base-centred
+    em.G(gb + gs::KINC + i, row_id(RK_KINC, c, i), s.x[cb + P_ + i] - (s.x[PB_ + i] + r[i]));
+    em.J(jb + js::KINC_P + i, row_id(RK_KINC, c, i), cb + P_ + i, 1.0);
+    em.J(jb + js::KINC_PB + i, row_id(RK_KINC, c, i), PB_ + i, -1.0);
+    // d pkin / d q_b = -[r]x G / |q|   ->  row entries = +[r]x G / |q|
+    const double X0 = skew_rc(r, i, 0), X1 = skew_rc(r, i, 1), X2 = skew_rc(r, i, 2);
+    for (int l = 0; l < 4; ++l)
+        em.J(jb + js::KINC_QB + 4 * i + l, row_id(RK_KINC, c, i), QB_ + l, (X0 * s.G[l] + X1 * s.G[4 + l] + X2 * s.G[8 + l]) / s.qnorm);
+    // d pkin / d s_j = a_j x (pkin - o_j) for the joints of the leg path
+    for (int q = 0; q < LEG_PATH; ++q) {
+        const int j = cx.kt.leg_joint[f][q];
+        double d[3];
+        for (int n = 0; n < 3; ++n) d[n] = r[n] - s.ow[j + 1][n];
+        em.J(jb + js::KINC_S + LEG_PATH * i + q, row_id(RK_KINC, c, i), S_ + j, -cross_comp(s.aw[j], d, i));
     }
 }
-
-// ===================================================================================================
-// PHASE H: horizon-end rows (final state, periodicity), lanes over rows; only at the first / last knot
-// ===================================================================================================
-// variable behind final-state row i (0..104), or -1 for the descriptor rows; *slot = index among the 81 variable rows
-HD int final_row_var(int i, int* slot, int* desc_point, int* desc_comp) {
-    *desc_point = -1; *desc_comp = 0; *slot = -1;
-    if (i < 3) { *slot = i; return COM_ + i; }
-    int r = i - 3;
-    if (r < 72) {
-        const int c = r / 9, q = r % 9;
-        if (q < 3) { *desc_point = c; *desc_comp = q; return -1; }
-        if (q < 6) { *slot = 3 + 6 * c + (q - 3); return PT_ * c + F_ + (q - 3); }
-        *slot = 3 + 6 * c + 3 + (q - 6); return PT_ * c + P_ + (q - 6);
-    }
-    r -= 72;
-    if (r < 3) { *slot = 51 + r; return PB_ + r; }
-    r -= 3;
-    if (r < 4) { *slot = 54 + r; return QB_ + r; }
-    r -= 4;
-    *slot = 58 + r;
-    return S_ + r;
-}
-// variable behind periodicity row i (0..83)
-HD int periodicity_row_var(int i) {
-    if (i < 48) { const int c = i / 6, q = i % 6; return PT_ * c + (q < 3 ? U_ + q : FD_ + (q - 3)); }
-    if (i < 54) return H_ + (i - 48);
-    if (i < 57) return VB_ + (i - 54);
-    if (i < 61) return QD_ + (i - 57);
-    return SD_ + (i - 61);
-}
-constexpr int ENDS_TASKS = 105 + 84;
-template <class Em> HD void phase_ends(Ctx<Em>& cx, int t) {
+// com == CoM(pb, qn, s)  (K2, planner.py:285-306): lanes (i, l) 12 for the q_b entries, lanes 12..14 rows
+template <class Em> HD void t_comc(Ctx<Em>& cx, int t) {
     KnotScratch& s = cx.s;
     Em& em = cx.em;
-    if (t < 105) {
-        if (!cx.ki.last) return;
-        int slot, dp, dc;
-        const int var = final_row_var(t, &slot, &dp, &dc);
-        const double lhs = var >= 0 ? s.x[var] : s.pk[PK_DESC + 3 * dp + dc];
-        if (cx.st.final_type == HIPNLP_EXPR_MINIMIZE) {
-            const double e = lhs - cx.gp.final_rhs[t];
-            s.g[gs::FIN + t] = cx.st.final_weight * e * e;        // partial, reduced in phase_reduce
-            if (var >= 0) s.jac[js::FIN + slot] = 2.0 * cx.st.final_weight * e;  // grad share, applied in phase_reduce
-        } else {
-            em.G(gs::FIN + t, row_id(RK_FIN, 0, t), lhs);
-            if (var >= 0) em.J(js::FIN + slot, row_id(RK_FIN, 0, t), var, 1.0);
-        }
+    const double* r = s.com;
+    if (t < 12) {
+        const int i = t / 4, l = t - 4 * i;
+        const double X0 = skew_rc(r, i, 0), X1 = skew_rc(r, i, 1), X2 = skew_rc(r, i, 2);
+        em.J(js::COMC_QB + 4 * i + l, row_id(RK_COMC, 0, i), QB_ + l, (X0 * s.G[l] + X1 * s.G[4 + l] + X2 * s.G[8 + l]) / s.qnorm);
     } else {
-        const int i = t - 105;
-        const int var = periodicity_row_var(i);
-        if (cx.st.periodicity_type == HIPNLP_EXPR_MINIMIZE) {
-            if (!cx.ki.first && !cx.ki.last) return;
-            // e = x_0 - x_{N-1};  at the last knot xo = x_0, at the first knot xo = x_{N-1}
-            const double e = cx.ki.last ? (s.xo[var] - s.x[var]) : (s.x[var] - s.xo[var]);
-            s.g[gs::PER + i] = cx.st.periodicity_weight * e * e;
-            s.jac[js::PERN + i] = 2.0 * cx.st.periodicity_weight * e;
-        } else {
-            if (cx.ki.last) {
-                em.G(gs::PER + i, row_id(RK_PERN, 0, i), s.xo[var] - s.x[var]);
-                em.J(js::PERN + i, row_id(RK_PERN, 0, i), var, -1.0);
-            }
-            if (cx.ki.first) em.J(js::PER0 + i, row_id(RK_PER0, 0, i), var, 1.0);
+        const int i = t - 12;
+        em.G(gs::COMC + i, row_id(RK_COMC, 0, i), s.x[COM_ + i] - (s.x[PB_ + i] + r[i]));
+        em.J(js::COMC_COM + i, row_id(RK_COMC, 0, i), COM_ + i, 1.0);
+        em.J(js::COMC_PB + i, row_id(RK_COMC, 0, i), PB_ + i, -1.0);
+    }
+}
+// h[3:] == CMM(...)[3:] / mass  (K3, planner.py:309-339): lanes (i, l) 12 for q_b / qdot_b, lanes 12..14 rows
+template <class Em> HD void t_cmmc(Ctx<Em>& cx, int t) {
+    KnotScratch& s = cx.s;
+    Em& em = cx.em;
+    const double mass = cx.gp.mass;
+    if (t < 12) {
+        const int i = t / 4, l = t - 4 * i;
+        double dq = 0.0, dqd = 0.0;
+        for (int e = 0; e < 3; ++e) {
+            dq += s.dth_h[e][i] * s.G[4 * e + l] / s.qnorm + s.Aw[e][i] * s.dwq[4 * e + l];
+            dqd += s.Aw[e][i] * s.G[4 * e + l];
         }
+        em.J(js::CMMC_QB + 4 * i + l, row_id(RK_CMMC, 0, i), QB_ + l, -dq / mass);
+        em.J(js::CMMC_QD + 4 * i + l, row_id(RK_CMMC, 0, i), QD_ + l, -dqd / mass);
+    } else {
+        const int i = t - 12;
+        em.G(gs::CMMC + i, row_id(RK_CMMC, 0, i), s.x[H_ + 3 + i] - s.hang[i] / mass);
+        em.J(js::CMMC_H + i, row_id(RK_CMMC, 0, i), H_ + 3 + i, 1.0);
+    }
+}
+// feet distance value (K4) on lane 4; chest cost gradient on q_b, lanes 0..3: 5 tasks
+template <class Em> HD void t_feetd(Ctx<Em>& cx, int t) {
+    KnotScratch& s = cx.s;
+    Em& em = cx.em;
+    if (t == 4) {
+        const double* yr = s.fr_R[1];
+        double d[3];
+        for (int i = 0; i < 3; ++i) d[i] = s.fr_o[0][i] - s.fr_o[1][i];
+        em.G(gs::FEETD, row_id(RK_FEETD, 0, 0), yr[1] * d[0] + yr[4] * d[1] + yr[7] * d[2]);
+    } else {
+        const int l = t;
+        double acc = 0.0;
+        for (int e = 0; e < 3; ++e) acc += -s.chest_w[e] * s.G[4 * e + l];
+        s.grad[QB_ + l] += s.chest_dc * acc / s.qnorm;
     }
 }
 
 // ===================================================================================================
-// PHASE I: reductions of the cost partials (lane 0) ; cost-mode end terms applied to grad (lanes 1..)
+// PHASE I — reductions of the cost partials (lane 0) ; minimize-mode end terms applied to grad (lanes 1..189)
 // ===================================================================================================
-template <class Em> HD void phase_reduce(Ctx<Em>& cx, int t) {
+constexpr int REDUCE_TASKS = 1 + ENDS_TASKS;
+template <class Em> HD void t_reduce(Ctx<Em>& cx, int t) {
     KnotScratch& s = cx.s;
     if (t == 0) {
         double a = 0.0, b = 0.0, c = 0.0;
-        for (int p = 0; p < NC; ++p) { a += s.cpt[p][0]; b += s.cpt[p][1]; c += s.cpt[p][2]; }
+        for (int p = 0; p < NC; ++p) { a += s.c_pt[p][0]; b += s.c_pt[p][1]; c += s.c_pt[p][2]; }
         s.cost[CT_SWING] = a; s.cost[CT_UREG] = b; s.cost[CT_FDREG] = c;
         double j = 0.0;
-        for (int q = 0; q < NJ; ++q) j += s.cjt[q];
+        for (int q = 0; q < NJ; ++q) j += s.c_joint[q];
         s.cost[CT_JREG] = j;
-        s.cost[CT_FREG] = s.cft[0][0] + s.cft[1][0];
-        s.cost[CT_YAW] = s.cft[0][1] + s.cft[1][1];
+        s.cost[CT_COMVEL] = (s.c_comvel[0] + s.c_comvel[1]) + s.c_comvel[2];
+        s.cost[CT_FREG] = ((s.c_force[0][0] + s.c_force[0][1]) + s.c_force[0][2]) + ((s.c_force[1][0] + s.c_force[1][1]) + s.c_force[1][2]);
+        s.cost[CT_YAW] = s.c_yaw[0] + s.c_yaw[1];
         double e = 0.0;
-        if (cx.ki.last && cx.st.final_type == HIPNLP_EXPR_MINIMIZE)
-            for (int i = 0; i < 105; ++i) e += s.g[gs::FIN + i];
-        if (cx.ki.last && cx.st.periodicity_type == HIPNLP_EXPR_MINIMIZE)
-            for (int i = 0; i < 84; ++i) e += s.g[gs::PER + i];
+        for (int i = 0; i < ENDS_TASKS; ++i) e += s.c_ends[i];
         s.cost[CT_ENDS] = e;
-    } else if (t == 1) {
-        if (cx.ki.last && cx.st.final_type == HIPNLP_EXPR_MINIMIZE)
-            for (int i = 0; i < 105; ++i) {
-                int slot, dp, dc;
-                const int var = final_row_var(i, &slot, &dp, &dc);
-                if (var >= 0) s.grad[var] += s.jac[js::FIN + slot];
-            }
-        if ((cx.ki.last || cx.ki.first) && cx.st.periodicity_type == HIPNLP_EXPR_MINIMIZE)
-            for (int i = 0; i < 84; ++i) {
-                const int var = periodicity_row_var(i);
-                // d/dx_0 = +2 w e ; d/dx_{N-1} = -2 w e, with e = x_0 - x_{N-1}
-                s.grad[var] += cx.ki.first && !cx.ki.last ? s.jac[js::PERN + i] : -s.jac[js::PERN + i];
-            }
+    } else {
+        const int i = t - 1;
+        const double gv = s.g_ends[i];
+        if (gv != 0.0) {
+            const int var = i < 105 ? cx.kt.fin_var[i] : cx.kt.per_var[i - 105];
+            if (var >= 0) s.grad[var] += gv;  // every variable appears in at most one final row and one periodicity row,
+        }                                      // and the two row sets are disjoint (states vs controls/velocities)
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// The knot program: the ordered list of phases.  RUN(fn, ntasks) / RUNL(fn, ntasks, level) are
-// supplied by the caller (device: one task per thread + barrier; host: plain loops).
+// The knot program.  R(w, fn, n): run tasks 0..n-1 of fn on the lanes of wave w (host: plain loop).
+// Groups of one phase run concurrently on different waves; BARRIER separates phases.
 // ---------------------------------------------------------------------------------------------------
-#define HIPNLP_KNOT_PROGRAM(RUN, RUNL, BARRIER, MAXD)                                     \
-    RUN(phase_points, NC)                                                                 \
-    RUN(phase_dyn, 7 + NJ + 3)                                                            \
-    RUN(phase_joints, NJ)                                                                 \
-    RUN(phase_misc, MISC_TASKS)                                                           \
+#define HIPNLP_KNOT_PROGRAM(R, BARRIER)                                                   \
+    R(0, t_points_vec, 3 * NC)                                                            \
+    R(1, t_points_scalar, NC) R(1, t_dyn, 7 + NJ + 3) R(1, t_unitq, 1)                    \
+    R(2, t_joints, NJ)                                                                    \
+    R(3, t_base, 1) R(3, t_small, 4) R(3, t_feet, 3)                                      \
     BARRIER                                                                               \
-    for (int d_ = 1; d_ <= (MAXD); ++d_) { RUNL(phase_fk_level, NJ, d_) BARRIER }         \
-    RUN(phase_links, NL + 3)                                                              \
+    R(0, t_fk_chain, cx.kt.n_leaf)                                                        \
+    R(1, t_hdyn, HDYN_TASKS)                                                              \
+    R(2, t_foot_costs, FOOT_TASKS)                                                        \
+    R(3, t_ends, ENDS_TASKS)                                                              \
     BARRIER                                                                               \
-    for (int d_ = (MAXD) - 1; d_ >= 0; --d_) { RUNL(phase_composite_level, NL, d_) BARRIER } \
-    RUN(phase_totals, NC + 1)                                                             \
+    R(0, t_links, NL) R(1, t_frames, 3)                                                   \
     BARRIER                                                                               \
-    RUN(phase_columns, NJ + 3)                                                            \
+    R(0, t_composite_chain, cx.kt.n_leaf) R(1, t_pkin, NC)                                \
     BARRIER                                                                               \
-    RUN(phase_assemble, ASSEMBLE_TASKS)                                                   \
-    RUN(phase_ends, ENDS_TASKS)                                                           \
+    R(0, t_composite_rest, 1)                                                             \
     BARRIER                                                                               \
-    RUN(phase_reduce, 2)                                                                  \
+    R(0, t_columns, NJ + 3)                                                               \
+    BARRIER                                                                               \
+    R(0, t_kinc, 3 * NC) R(1, t_comc, 15) R(2, t_cmmc, 15) R(3, t_feetd, 5)               \
+    BARRIER                                                                               \
+    R(0, t_reduce, REDUCE_TASKS)                                                          \
     BARRIER
 
 }  // namespace hipnlp

@@ -16,6 +16,35 @@
 
 namespace hipnlp {
 
+// variable behind final-state row i (0..104), or -1 for the descriptor rows; *slot = index among the 81 variable
+// rows; *desc = 3c+comp of the descriptor entry.  Row order = HumanoidState.to_list() (sorted flat keys).
+inline int final_row_var(int i, int* slot, int* desc) {
+    *desc = -1; *slot = -1;
+    if (i < 3) { *slot = i; return COM_ + i; }
+    int r = i - 3;
+    if (r < 72) {
+        const int c = r / 9, q = r % 9;
+        if (q < 3) { *desc = 3 * c + q; return -1; }
+        if (q < 6) { *slot = 3 + 6 * c + (q - 3); return PT_ * c + F_ + (q - 3); }
+        *slot = 3 + 6 * c + 3 + (q - 6); return PT_ * c + P_ + (q - 6);
+    }
+    r -= 72;
+    if (r < 3) { *slot = 51 + r; return PB_ + r; }
+    r -= 3;
+    if (r < 4) { *slot = 54 + r; return QB_ + r; }
+    r -= 4;
+    *slot = 58 + r;
+    return S_ + r;
+}
+// variable behind periodicity row i (0..83): per point (u_v, f_dot), then h, v_b, qdot_b, sdot (planner.py:897-922)
+inline int periodicity_row_var(int i) {
+    if (i < 48) { const int c = i / 6, q = i % 6; return PT_ * c + (q < 3 ? U_ + q : FD_ + (q - 3)); }
+    if (i < 54) return H_ + (i - 48);
+    if (i < 57) return VB_ + (i - 54);
+    if (i < 61) return QD_ + (i - 57);
+    return SD_ + (i - 61);
+}
+
 struct RowBlock {
     std::string name;
     int first_row, rows, k0, nk;
@@ -166,12 +195,9 @@ struct Layout {
             KnotInfo ki{0, N, 1, 1};
             RecordEm em{grow.data(), jrid.data(), jc.data(), &dup};
             Ctx<RecordEm> cx(*s, kt, ks, gp, ki, em);
-            const int maxd = kt.max_depth;
-#define HOST_RUN(fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
-#define HOST_RUNL(fn, nt, lvl) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_, lvl);
-            HIPNLP_KNOT_PROGRAM(HOST_RUN, HOST_RUNL, , maxd)
-#undef HOST_RUN
-#undef HOST_RUNL
+#define HOST_R(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
+            HIPNLP_KNOT_PROGRAM(HOST_R, )
+#undef HOST_R
             delete s;
         }
         if (dup) { error = "internal: native slot emitted twice"; return false; }
@@ -302,6 +328,35 @@ struct Layout {
         }
         for (int j = 0; j < NJ; ++j)
             if (kt.leg_pos[0][j] >= 0 && kt.leg_pos[1][j] >= 0) { err = "robot model: the two leg chains must be disjoint"; return false; }
+        // chain decomposition: one root->leaf joint path per leaf link; single-child up-chains; the rest
+        kt.n_leaf = 0;
+        std::vector<bool> covered(NL, false);
+        for (int l = 1; l < NL; ++l) {
+            if (kt.nchild[l] != 0) continue;
+            if (kt.n_leaf >= 8) { err = "robot model: more than 8 leaf links"; return false; }
+            const int leaf = kt.n_leaf++;
+            std::vector<int> path;
+            for (int q = l; q > 0; q = md.parent[q - 1]) path.push_back(q - 1);
+            if (path.size() > 8) { err = "robot model: a chain is deeper than 8 joints"; return false; }
+            std::sort(path.begin(), path.end());
+            kt.path_len[leaf] = int(path.size());
+            for (size_t q = 0; q < path.size(); ++q) kt.path[leaf][q] = path[q];
+            int n = 0;
+            for (int q = l; q > 0 && kt.nchild[q] <= 1; q = md.parent[q - 1]) { kt.up_link[leaf][n++] = q; covered[size_t(q)] = true; }
+            kt.up_len[leaf] = n;
+        }
+        kt.s2_len = 0;
+        for (int l = NL - 1; l >= 0; --l)
+            if (!covered[size_t(l)]) {
+                if (kt.s2_len >= 8) { err = "robot model: too many branching links"; return false; }
+                kt.s2_link[kt.s2_len++] = l;
+            }
+        for (int i = 0; i < 105; ++i) {
+            int slot, desc;
+            const int var = final_row_var(i, &slot, &desc);
+            kt.fin_var[i] = int16_t(var); kt.fin_slot[i] = int16_t(slot); kt.fin_desc[i] = int16_t(desc);
+        }
+        for (int i = 0; i < 84; ++i) kt.per_var[i] = int16_t(periodicity_row_var(i));
         return true;
     }
 
@@ -384,7 +439,7 @@ struct Layout {
         mark(RK_COMDYN_X0, 0, [](int i) { return COM_ + i; });
         mark(RK_JPB, 0, [](int i) { return S_ + i; });
         mark(RK_JVB, 0, [](int i) { return SD_ + i; });
-        mark(RK_FIN, 0, [](int i) { int slot, dp, dc; return final_row_var(i, &slot, &dp, &dc); });
+        mark(RK_FIN, 0, [](int i) { int slot, desc; return final_row_var(i, &slot, &desc); });
     }
 };
 

@@ -53,6 +53,14 @@ struct KinTables {
     int32_t leg_joint[2][LEG_PATH];
     int32_t chest_pos[NJ];      // position in the root->chest path or -1
     int32_t frame_link[3];
+    // chain decomposition of the tree (one lane walks one chain, no per-level barriers)
+    int32_t n_leaf;
+    int32_t path_len[8], path[8][8];    // joints from the root to leaf l (shared prefixes are recomputed per lane)
+    int32_t up_len[8], up_link[8][8];   // links from leaf l upward while they have a single child (composite pass, stage 1)
+    int32_t s2_len, s2_link[8];         // the remaining links in reverse topological order (stage 2, one lane)
+    // horizon-end rows
+    int16_t fin_var[105], fin_slot[105], fin_desc[105];  // variable / slot among the 81 variable rows / descriptor index (3c+i) or -1
+    int16_t per_var[84];
     double R_fix[NJ][9], o_fix[NJ][3], axis[NJ][3];
     double mass[NL], com[NL][3], inertia[NL][9];
     double frame_R[3][9], frame_o[3][3];

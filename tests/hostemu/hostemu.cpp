@@ -80,12 +80,9 @@ void hostemu_eval(const hostemu_handle* h, const double* x, const double* p, dou
         KnotInfo ki{k, N, k == 0, k == N - 1};
         ValueEm em{s->g, s->jac};
         Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
-        const int maxd = h->kt.max_depth;
-#define HOST_RUN(fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
-#define HOST_RUNL(fn, nt, lvl) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_, lvl);
-        HIPNLP_KNOT_PROGRAM(HOST_RUN, HOST_RUNL, , maxd)
-#undef HOST_RUN
-#undef HOST_RUNL
+#define HOST_R(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
+        HIPNLP_KNOT_PROGRAM(HOST_R, )
+#undef HOST_R
         // copy-out exactly as the kernel does
         const int v = L.variant_of(k);
         const long jb = L.jac_base(k);
