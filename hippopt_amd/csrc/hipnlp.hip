@@ -50,6 +50,9 @@ struct KArgs {
     int32_t* flags;         // [batch][nk]  non-finite detector
     int32_t N, n, m, nnz, knot_begin, nk;
     int64_t jac_stride, jac_off, grad_stride, grad_off;  // output addressing: full arrays (stride nnz / n, offset 0) or shard-local
+#ifdef HIPNLP_STAMPS
+    unsigned long long* stamps;  // diagnostic build only: [blocks][32] s_memtime at every barrier (never in the product library)
+#endif
 };
 
 struct DevEm {
@@ -99,49 +102,75 @@ __global__ __launch_bounds__(WG) void hipnlp_knot_kernel(KArgs a) {
     if (tid < 8) s.xg[tid] = tid < NXG ? x[size_t(NXK) * N + tid] : 0.0;
     __syncthreads();
 
+    // copy-out tables of this knot's variant, fetched now so their latency hides behind the knot program
+    const int v = first ? VAR_FIRST : (last ? VAR_LAST : VAR_INTERIOR);
+    constexpr int JP_ITERS = (js::COUNT + WG - 1) / WG, G_ITERS = (gs::COUNT + WG - 1) / WG;
+    const int jcnt = tb.nnz_v[v];
+    int32_t jp[JP_ITERS], ga[G_ITERS], gb[G_ITERS];
+#pragma unroll
+    for (int it = 0; it < JP_ITERS; ++it) { const int i = tid + it * WG; jp[it] = i < jcnt ? tb.jperm[v][i] : -1; }
+#pragma unroll
+    for (int it = 0; it < G_ITERS; ++it) {
+        const int slot = tid + it * WG;
+        ga[it] = slot < gs::COUNT ? tb.g_a[v][slot] : -1;
+        gb[it] = slot < gs::COUNT ? tb.g_b[slot] : 0;
+    }
+
     KnotInfo ki{k, N, first, last};
     DevEm em{s.g, s.jac};
     Ctx<DevEm> cx(s, tabs.kt, tabs.ks, tabs.gp, ki, em);
 #define DEV_R(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
+#ifdef HIPNLP_STAMPS
+    // per wave: arrival time at every barrier (before waiting), 16 slots per wave
+    int sidx = 0;
+    unsigned long long* stamp_out = a.stamps + (size_t(blockIdx.y) * gridDim.x + blockIdx.x) * 64 + wave * 16;
+    if (lane == 0) stamp_out[sidx] = __builtin_amdgcn_s_memtime();
+    sidx++;
+#define DEV_BARRIER if (lane == 0 && sidx < 15) stamp_out[sidx] = __builtin_amdgcn_s_memtime(); sidx++; __syncthreads();
+#else
 #define DEV_BARRIER __syncthreads();
+#endif
     HIPNLP_KNOT_PROGRAM(DEV_R, DEV_BARRIER)
 #undef DEV_R
 #undef DEV_BARRIER
 
     // ---- stream the knot's outputs ---------------------------------------------------------------------
-    const int v = first ? VAR_FIRST : (last ? VAR_LAST : VAR_INTERIOR);
     int bad = 0;
     if (a.jac) {
         const int64_t jbase = first ? 0 : int64_t(tb.nnz_v[VAR_FIRST]) + int64_t(k - 1) * tb.nnz_v[VAR_INTERIOR];
         double* out = a.jac + int64_t(b) * a.jac_stride + (jbase - a.jac_off);
-        const int cnt = tb.nnz_v[v];
-        const int32_t* perm = tb.jperm[v];
-        for (int i = tid; i < cnt; i += WG) {
-            const double val = s.jac[perm[i]];
-            bad |= !isfinite(val);
-            out[i] = val;
+#pragma unroll
+        for (int it = 0; it < JP_ITERS; ++it) {
+            if (jp[it] >= 0) {
+                const double val = s.jac[jp[it]];
+                bad |= !isfinite(val);
+                out[tid + it * WG] = val;
+            }
         }
         // entries in the horizon-global columns (constants) sit right behind the last knot's block: the last knot writes them
         if (last && tid < tb.n_glob) a.jac[int64_t(b) * a.jac_stride + (int64_t(tb.jac_glob_base) - a.jac_off) + tid] = s.jac[tb.jperm_glob[tid]];
     }
     if (a.g) {
         double* out = a.g + size_t(b) * a.m;
-        for (int slot = tid; slot < gs::COUNT; slot += WG) {
-            const int ga = tb.g_a[v][slot];
-            if (ga >= 0) {
-                const double val = s.g[slot];
+#pragma unroll
+        for (int it = 0; it < G_ITERS; ++it) {
+            if (ga[it] >= 0) {
+                const double val = s.g[tid + it * WG];
                 bad |= !isfinite(val);
-                out[ga + tb.g_b[slot] * k] = val;
+                out[ga[it] + gb[it] * k] = val;
             }
         }
     }
     if (a.g_stage) {
         double* out = a.g_stage + (size_t(b) * a.nk + kk) * gs::COUNT;
-        for (int slot = tid; slot < gs::COUNT; slot += WG) {
-            const bool valid = tb.g_a[v][slot] >= 0;
-            const double val = valid ? s.g[slot] : 0.0;
-            bad |= !isfinite(val);
-            out[slot] = val;
+#pragma unroll
+        for (int it = 0; it < G_ITERS; ++it) {
+            const int slot = tid + it * WG;
+            if (slot < gs::COUNT) {
+                const double val = ga[it] >= 0 ? s.g[slot] : 0.0;
+                bad |= !isfinite(val);
+                out[slot] = val;
+            }
         }
     }
     if (a.grad) {
@@ -160,6 +189,9 @@ __global__ __launch_bounds__(WG) void hipnlp_knot_kernel(KArgs a) {
     }
     const int anybad = __syncthreads_or(bad);
     if (tid == 0) a.flags[size_t(b) * a.nk + kk] = anybad;
+#ifdef HIPNLP_STAMPS
+    if (lane == 0) { stamp_out[sidx < 15 ? sidx : 14] = __builtin_amdgcn_s_memtime(); stamp_out[15] = (unsigned long long)sidx; }
+#endif
 }
 
 // f[b] = sum over knots and terms; cost_terms[b][t] = sum over knots; flag[b] = any non-finite.
@@ -214,6 +246,7 @@ struct hipnlp_handle {
     double *d_cost_knot = nullptr, *d_cost_terms = nullptr;
     GParams* d_gp = nullptr;
     int32_t *d_flags = nullptr, *d_flag = nullptr;
+    unsigned long long* d_stamps = nullptr;
     // pinned host staging
     double *h_x = nullptr, *h_g = nullptr, *h_jac = nullptr, *h_grad = nullptr, *h_f = nullptr, *h_cost_terms = nullptr;
     int32_t* h_flag = nullptr;
@@ -413,6 +446,10 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     const bool prof = h->prof_n < h->prof_cap;
     hipEvent_t e0 = prof ? h->prof_ev[size_t(3 * h->prof_n)] : h->ev0;
     hipEvent_t e2 = prof ? h->prof_ev[size_t(3 * h->prof_n + 2)] : h->ev1;
+#ifdef HIPNLP_STAMPS
+    if (!h->d_stamps) HIP_TRY(h, hipMalloc(&h->d_stamps, size_t(h->nk) * size_t(h->batch) * 64 * sizeof(unsigned long long)));
+    a.stamps = h->d_stamps;
+#endif
     HIP_TRY(h, hipEventRecord(e0, s));
     hipLaunchKernelGGL(hipnlp_knot_kernel, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(WG), 0, s, a);
     if (prof) HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 1)], s));
@@ -550,5 +587,15 @@ int hipnlp_profile_end(hipnlp_handle* h, double* mean_knot_kernel_ms, double* me
     h->prof_n = 0;
     return HIPNLP_OK;
 }
+
+#ifdef HIPNLP_STAMPS
+int hipnlp_debug_stamps(hipnlp_handle* h, unsigned long long* out /*[nk*batch][4][16]*/) {
+    HIP_TRY(h, hipSetDevice(h->dev));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(out, h->d_stamps, size_t(h->nk) * size_t(h->batch) * 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return HIPNLP_OK;
+}
+#endif
 
 }  // extern "C"

@@ -24,11 +24,26 @@
 
 #include "nlp_defs.h"
 
+// Lanes of ONE wavefront exchanging data through LDS (no other wave involved): the hardware executes a
+// wave's LDS operations in order, so only the compiler must be kept from moving accesses across this point.
+#if defined(__HIPCC__)
+#define HIPNLP_UNROLL _Pragma("unroll")
+#else
+#define HIPNLP_UNROLL
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HIPNLP_WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier()
+#else
+#define HIPNLP_WAVE_SYNC() ((void)0)
+#endif
+
 namespace hipnlp {
 
 // ---------------------------------------------------------------------------------------------------
 // scratch (LDS on the device)
 // ---------------------------------------------------------------------------------------------------
+struct EndTerms { double c[105 + 84], g[105 + 84]; };  // minimize-mode end rows: cost partial and gradient share of row i
+
 struct KnotScratch {
     double x[XPAD];    // knot k
     double xm[XPAD];   // knot k-1 (zeros at k = 0)
@@ -36,13 +51,16 @@ struct KnotScratch {
     double xg[8];      // horizon-global variables (initial_state.centroidal_momentum)
     double pk[PK_STRIDE];
     // base orientation
-    double qn[4], qnorm, Rb[9], G[12] /* 3x4: dtheta = G dqhat */, omega[3], dwq[12] /* d omega/d qb (3x4) */;
+    double qn[4], qnorm, inv_qnorm, Rb[9], G[12] /* 3x4: dtheta = G dqhat */, omega[3], dwq[12] /* d omega/d qb (3x4) */;
     // kinematics in base-centred coordinates (origin = base origin; h_ang and relative positions are
     // invariant to the base position / linear velocity)
-    double Rloc[NJ][9];
+    union {  // Rchain is dead once the forward kinematics has run; the (rare) minimize-mode end terms reuse its space
+        double Rchain[MAX_LEAF * 8][9];  // parent_R_child of every chain step, in chain order (written by t_joints)
+        EndTerms ends;
+    };
     double Rw[NL][9], ow[NL][3], aw[NJ][3];
     double wv[NL][3], vo[NL][3];  // link angular velocity; velocity of the body point at the origin
-    double cm[NL], ch[NL][3], cI[NL][6], ckl[NL][3], cka[NL][3];  // composite m, first moment, inertia@O, subtree momentum
+    double comp[NL][16];  // composite per link: [m | first moment h (3) | inertia@O xx,xy,xz,yy,yz,zz (6) | subtree momentum lin (3) | ang (3)]
     double com[3], klin[3], kang[3], hang[3];
     double dth_h[3][3];  // d hang / d theta_e   [e][i]
     double Aw[3][3];     // d hang / d omega_e   [e][i]
@@ -53,13 +71,14 @@ struct KnotScratch {
     double cen_g[3];              // d centroid cost / d p_c,i (same for the 8 points)
     double yaw_sc[2][4], yaw_e[2][2];  // per foot: sin/cos of yaw and of yaw+pi/2; alignment errors (forward, sideways)
     // cost partials, reduced by t_reduce
-    double c_pt[NC][3], c_joint[NJ], c_force[2][3], c_yaw[2], c_comvel[3], c_ends[105 + 84];
-    double g_ends[105 + 84];      // minimize-mode end terms: gradient share of row i
+    double c_pt[NC][3], c_joint[NJ], c_force[2][3], c_yaw[2];
     double cost[NCT];
     double grad[XPAD];
     double g[gs::COUNT];
     double jac[js::COUNT];
 };
+
+enum : int { CM = 0, CH = 1, CI = 4, CKL = 10, CKA = 13 };  // offsets inside KnotScratch::comp[i]
 
 struct KnotInfo {
     int k, N;
@@ -220,6 +239,15 @@ template <class Em> HD void t_points_scalar(Ctx<Em>& cx, int c) {
     s.c_pt[c][2] = on * cx.st.m_fdreg * (x[FD_] * x[FD_] + x[FD_ + 1] * x[FD_ + 1] + x[FD_ + 2] * x[FD_ + 2]);
 }
 
+// sums of the point-local cost partials: lane = term (swing, u_v, f_dot), runs behind t_points_scalar on the same wave
+template <class Em> HD void t_points_cost(Ctx<Em>& cx, int t) {
+    KnotScratch& s = cx.s;
+    HIPNLP_WAVE_SYNC();
+    double acc = 0.0;
+    for (int p = 0; p < NC; ++p) acc += s.c_pt[p][t];
+    s.cost[CT_SWING + t] = acc;
+}
+
 // --- trivial dynamics of base / joints / com, lane e over 33 state components.  planner.py:522-564 -----
 template <class Em> HD void t_dyn(Ctx<Em>& cx, int e) {
     KnotScratch& s = cx.s;
@@ -268,7 +296,20 @@ template <class Em> HD void t_joints(Ctx<Em>& cx, int j) {
     Ra[1] -= sq * a[2]; Ra[2] += sq * a[1];
     Ra[3] += sq * a[2]; Ra[5] -= sq * a[0];
     Ra[6] -= sq * a[1]; Ra[7] += sq * a[0];
-    matmul3(cx.kt.R_fix[j], Ra, s.Rloc[j]);
+    double Rl[9];
+    matmul3(cx.kt.R_fix[j], Ra, Rl);
+    for (int n = 0; n < 4; ++n) {
+        const int slot = cx.kt.chain_slot[j][n];
+        if (slot >= 0) for (int r = 0; r < 9; ++r) s.Rchain[slot][r] = Rl[r];
+    }
+}
+
+template <class Em> HD void t_joint_cost(Ctx<Em>& cx, int) {  // behind t_joints on the same wave
+    KnotScratch& s = cx.s;
+    HIPNLP_WAVE_SYNC();
+    double acc = 0.0;
+    for (int q = 0; q < NJ; ++q) acc += s.c_joint[q];
+    s.cost[CT_JREG] = acc;
 }
 
 // --- unitary quaternion row (planner.py:276-282) + base quaternion error cost (E13, raw q), 1 task ------
@@ -298,16 +339,15 @@ template <class Em> HD void t_unitq(Ctx<Em>& cx, int) {
 template <class Em> HD void t_small(Ctx<Em>& cx, int t) {
     KnotScratch& s = cx.s;
     Em& em = cx.em;
-    if (t < 3) {  // angular momentum bound rows h[3:]*mass (planner.py:342-350); com velocity cost (k >= 0)
+    if (t < 3) {  // angular momentum bound rows h[3:]*mass (planner.py:342-350); gradient of the com velocity cost
         const int i = t;
         em.G(gs::AMB + i, row_id(RK_AMB, 0, i), s.x[H_ + 3 + i] * cx.gp.mass);
         em.J(js::AMB + i, row_id(RK_AMB, 0, i), H_ + 3 + i, cx.gp.mass);
         const double e = s.x[H_ + i] - s.pk[PK_REF + R_VREF + i];
-        s.c_comvel[i] = cx.st.m_comvel * (e * cx.st.w_comvel[i] * e);
         s.grad[H_ + i] = 2.0 * cx.st.m_comvel * cx.st.w_comvel[i] * e;
         s.grad[H_ + 3 + i] = 0.0;
         s.grad[COM_ + i] = 0.0; s.grad[PB_ + i] = 0.0; s.grad[VB_ + i] = 0.0;
-    } else {      // minimum com height: h_terrain(com) = com_z ; base quaternion velocity cost (k >= 0)
+    } else {      // minimum com height: h_terrain(com) = com_z ; com velocity and base quaternion velocity costs (k >= 0)
         em.G(gs::COMH, row_id(RK_COMH, 0, 0), s.x[COM_ + 2]);
         em.J(js::COMH, row_id(RK_COMH, 0, 0), COM_ + 2, 1.0);
         double c = 0.0;
@@ -317,6 +357,9 @@ template <class Em> HD void t_small(Ctx<Em>& cx, int t) {
             s.grad[QD_ + i] = 2.0 * cx.st.m_baseqv * e;
         }
         s.cost[CT_BASEQV] = cx.st.m_baseqv * c;
+        double cv = 0.0;
+        for (int i = 0; i < 3; ++i) { const double e = s.x[H_ + i] - s.pk[PK_REF + R_VREF + i]; cv += e * cx.st.w_comvel[i] * e; }
+        s.cost[CT_COMVEL] = cx.st.m_comvel * cv;
     }
 }
 
@@ -346,9 +389,10 @@ template <class Em> HD void t_feet(Ctx<Em>& cx, int t) {
         const int foot = t - 1;
         const double yaw = s.pk[PK_REF + (foot == 0 ? R_YAW_L : R_YAW_R)];
         const int br = 4 * foot + cx.st.yaw_corner[foot][0], tr = 4 * foot + cx.st.yaw_corner[foot][1], tl = 4 * foot + cx.st.yaw_corner[foot][2];
-        double s1, c1, s2, c2;
-        sincos(yaw, &s1, &c1);
-        sincos(yaw + M_PI / 2, &s2, &c2);
+        // sin/cos of the yaw reference and of yaw + pi/2: parameters only, precomputed by pack_params
+        const double* sc = s.pk + PK_YAWSC + 4 * foot;
+        const double s1 = sc[0], c1 = sc[1], s2 = sc[2], c2 = sc[3];
+        (void)yaw;
         const double* pbr = s.x + PT_ * br + P_;
         const double* ptr = s.x + PT_ * tr + P_;
         const double* ptl = s.x + PT_ * tl + P_;
@@ -366,9 +410,11 @@ template <class Em> HD void t_base(Ctx<Em>& cx, int) {
     const double* q = s.x + QB_;
     const double* qd = s.x + QD_;
     const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const double inv_n = 1.0 / n;
     s.qnorm = n;
+    s.inv_qnorm = inv_n;
     double qn[4];
-    for (int i = 0; i < 4; ++i) { qn[i] = q[i] / n; s.qn[i] = qn[i]; }
+    for (int i = 0; i < 4; ++i) { qn[i] = q[i] * inv_n; s.qn[i] = qn[i]; }
     rot_from_quat(qn, s.Rb);
     const double vx = qn[0], vy = qn[1], vz = qn[2], w = qn[3];
     double* G = s.G;  // G = 2 [ w I + [v]x | -v ]
@@ -383,7 +429,7 @@ template <class Em> HD void t_base(Ctx<Em>& cx, int) {
     H[8] = 2.0 * qd[1];  H[9] = -2.0 * qd[0]; H[10] = -2.0 * qd[3]; H[11] = 2.0 * qd[2];
     for (int e = 0; e < 3; ++e) {
         const double hq = H[4 * e] * qn[0] + H[4 * e + 1] * qn[1] + H[4 * e + 2] * qn[2] + H[4 * e + 3] * qn[3];
-        for (int l = 0; l < 4; ++l) s.dwq[4 * e + l] = (H[4 * e + l] - hq * qn[l]) / n;
+        for (int l = 0; l < 4; ++l) s.dwq[4 * e + l] = (H[4 * e + l] - hq * qn[l]) * inv_n;
     }
     // root link pose and velocity in base-centred coordinates
     for (int i = 0; i < 9; ++i) s.Rw[0][i] = s.Rb[i];
@@ -395,24 +441,50 @@ template <class Em> HD void t_base(Ctx<Em>& cx, int) {
 // stays in registers; shared prefixes are recomputed, identical values are stored twice).
 // Other waves meanwhile: momentum-dynamics rows, foot costs, horizon-end rows.
 // ===================================================================================================
-template <class Em> HD void t_fk_chain(Ctx<Em>& cx, int leaf) {
+constexpr int FK_TASKS = MAX_LEAF * 3;
+template <class Em> HD void t_fk_chain(Ctx<Em>& cx, int t) {  // lane (leaf, matrix row r): row r of R_i = row r of R_parent times R_loc
     KnotScratch& s = cx.s;
-    double R[9], o[3] = {0.0, 0.0, 0.0}, w[3], vo[3] = {0.0, 0.0, 0.0};
-    for (int i = 0; i < 9; ++i) R[i] = s.Rb[i];
-    for (int i = 0; i < 3; ++i) w[i] = s.omega[i];
+    const int leaf = t / 3, r = t - 3 * leaf;
+    if (leaf >= cx.kt.n_leaf) return;
+    double R0 = s.Rb[3 * r], R1 = s.Rb[3 * r + 1], R2 = s.Rb[3 * r + 2];
+    double o = 0.0;
     const int len = cx.kt.path_len[leaf];
-    for (int q = 0; q < len; ++q) {
-        const int j = cx.kt.path[leaf][q], i = j + 1;
-        double Rn[9], t[3], a[3], oxa[3];
-        matmul3(R, s.Rloc[j], Rn);
-        matvec3(R, cx.kt.o_fix[j], t);
-        for (int r = 0; r < 3; ++r) o[r] += t[r];
-        matvec3(Rn, cx.kt.axis[j], a);
+    HIPNLP_UNROLL
+    for (int q = 0; q < 8; ++q) {
+        if (q >= len) break;
+        const int i = cx.kt.chain_link[leaf][q];
+        const double* L = s.Rchain[8 * leaf + q];
+        const double* of = cx.kt.chain_ofix[leaf][q];
+        const double* ax = cx.kt.chain_axis[leaf][q];
+        o += R0 * of[0] + R1 * of[1] + R2 * of[2];
+        const double N0 = R0 * L[0] + R1 * L[3] + R2 * L[6];
+        const double N1 = R0 * L[1] + R1 * L[4] + R2 * L[7];
+        const double N2 = R0 * L[2] + R1 * L[5] + R2 * L[8];
+        const double a = N0 * ax[0] + N1 * ax[1] + N2 * ax[2];
+        R0 = N0; R1 = N1; R2 = N2;
+        s.Rw[i][3 * r] = N0; s.Rw[i][3 * r + 1] = N1; s.Rw[i][3 * r + 2] = N2;
+        s.ow[i][r] = o;
+        s.aw[i - 1][r] = a;
+    }
+}
+// link velocities along the chains (needs all components of o and a, stored by the row-lanes above; the
+// two groups run back to back on the same wave): lane (leaf, r)
+template <class Em> HD void t_vel_chain(Ctx<Em>& cx, int t) {
+    KnotScratch& s = cx.s;
+    HIPNLP_WAVE_SYNC();
+    const int leaf = t / 3, r = t - 3 * leaf;
+    if (leaf >= cx.kt.n_leaf) return;
+    double w = s.omega[r], vo = 0.0;
+    const int len = cx.kt.path_len[leaf];
+    HIPNLP_UNROLL
+    for (int q = 0; q < 8; ++q) {
+        if (q >= len) break;
+        const int i = cx.kt.chain_link[leaf][q], j = i - 1;
         const double sd = s.x[SD_ + j];
-        cross3(o, a, oxa);
-        for (int r = 0; r < 3; ++r) { w[r] += a[r] * sd; vo[r] += oxa[r] * sd; }
-        for (int r = 0; r < 9; ++r) { R[r] = Rn[r]; s.Rw[i][r] = Rn[r]; }
-        for (int r = 0; r < 3; ++r) { s.ow[i][r] = o[r]; s.aw[j][r] = a[r]; s.wv[i][r] = w[r]; s.vo[i][r] = vo[r]; }
+        w += s.aw[j][r] * sd;
+        vo += cross_comp(s.ow[i], s.aw[j], r) * sd;
+        s.wv[i][r] = w;
+        s.vo[i][r] = vo;
     }
 }
 
@@ -489,21 +561,29 @@ template <class Em> HD void t_foot_costs(Ctx<Em>& cx, int t) {
     }
 }
 
+template <class Em> HD void t_foot_cost_sum(Ctx<Em>& cx, int t) {  // behind t_foot_costs (force partials) / t_feet (yaw)
+    KnotScratch& s = cx.s;
+    HIPNLP_WAVE_SYNC();
+    if (t == 0) s.cost[CT_FREG] = ((s.c_force[0][0] + s.c_force[0][1]) + s.c_force[0][2]) + ((s.c_force[1][0] + s.c_force[1][1]) + s.c_force[1][2]);
+    else s.cost[CT_YAW] = s.c_yaw[0] + s.c_yaw[1];
+}
+
 // --- horizon-end rows (final state planner.py:407-425, periodicity :897-930), lanes over rows ----------------
 constexpr int ENDS_TASKS = 105 + 84;
 template <class Em> HD void t_ends(Ctx<Em>& cx, int t) {
     KnotScratch& s = cx.s;
     Em& em = cx.em;
-    s.c_ends[t] = 0.0;
-    s.g_ends[t] = 0.0;
+    if (!cx.ki.first && !cx.ki.last) return;
+    s.ends.c[t] = 0.0;
+    s.ends.g[t] = 0.0;
     if (t < 105) {
         if (!cx.ki.last) return;
         const int var = cx.kt.fin_var[t];
         const double lhs = var >= 0 ? s.x[var] : s.pk[PK_DESC + cx.kt.fin_desc[t]];
         if (cx.st.final_type == HIPNLP_EXPR_MINIMIZE) {
             const double e = lhs - cx.gp.final_rhs[t];
-            s.c_ends[t] = cx.st.final_weight * e * e;
-            s.g_ends[t] = 2.0 * cx.st.final_weight * e;
+            s.ends.c[t] = cx.st.final_weight * e * e;
+            s.ends.g[t] = 2.0 * cx.st.final_weight * e;
         } else if (cx.st.final_type == HIPNLP_EXPR_SUBJECT_TO) {
             em.G(gs::FIN + t, row_id(RK_FIN, 0, t), lhs);
             if (var >= 0) em.J(js::FIN + cx.kt.fin_slot[t], row_id(RK_FIN, 0, t), var, 1.0);
@@ -515,8 +595,8 @@ template <class Em> HD void t_ends(Ctx<Em>& cx, int t) {
             if (!cx.ki.first && !cx.ki.last) return;
             // e = x_0 - x_{N-1};  at the last knot xo = x_0, at the first knot xo = x_{N-1}
             const double e = cx.ki.last ? (s.xo[var] - s.x[var]) : (s.x[var] - s.xo[var]);
-            if (cx.ki.last) s.c_ends[t] = cx.st.periodicity_weight * e * e;
-            s.g_ends[t] = (cx.ki.last ? -2.0 : 2.0) * cx.st.periodicity_weight * e;  // d/dx_{N-1} = -2we, d/dx_0 = +2we
+            if (cx.ki.last) s.ends.c[t] = cx.st.periodicity_weight * e * e;
+            s.ends.g[t] = (cx.ki.last ? -2.0 : 2.0) * cx.st.periodicity_weight * e;  // d/dx_{N-1} = -2we, d/dx_0 = +2we
         } else if (cx.st.periodicity_type == HIPNLP_EXPR_SUBJECT_TO) {
             if (cx.ki.last) {
                 em.G(gs::PER + i, row_id(RK_PERN, 0, i), s.xo[var] - s.x[var]);
@@ -540,21 +620,24 @@ template <class Em> HD void t_links(Ctx<Em>& cx, int i) {
     for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) Rt[3 * r + q] = s.Rw[i][3 * q + r];
     matmul3(RI, Rt, Iw);
     const double c2 = dot3(c, c);
-    s.cm[i] = m;
-    for (int r = 0; r < 3; ++r) s.ch[i][r] = m * c[r];
-    s.cI[i][0] = Iw[0] + m * (c2 - c[0] * c[0]);
-    s.cI[i][1] = 0.5 * (Iw[1] + Iw[3]) - m * c[0] * c[1];
-    s.cI[i][2] = 0.5 * (Iw[2] + Iw[6]) - m * c[0] * c[2];
-    s.cI[i][3] = Iw[4] + m * (c2 - c[1] * c[1]);
-    s.cI[i][4] = 0.5 * (Iw[5] + Iw[7]) - m * c[1] * c[2];
-    s.cI[i][5] = Iw[8] + m * (c2 - c[2] * c[2]);
+    double* cp = s.comp[i];
+    double h[3], I6[6];
+    cp[CM] = m;
+    for (int r = 0; r < 3; ++r) { h[r] = m * c[r]; cp[CH + r] = h[r]; }
+    I6[0] = Iw[0] + m * (c2 - c[0] * c[0]);
+    I6[1] = 0.5 * (Iw[1] + Iw[3]) - m * c[0] * c[1];
+    I6[2] = 0.5 * (Iw[2] + Iw[6]) - m * c[0] * c[2];
+    I6[3] = Iw[4] + m * (c2 - c[1] * c[1]);
+    I6[4] = 0.5 * (Iw[5] + Iw[7]) - m * c[1] * c[2];
+    I6[5] = Iw[8] + m * (c2 - c[2] * c[2]);
+    for (int r = 0; r < 6; ++r) cp[CI + r] = I6[r];
     // link momentum about the origin:  lin = m vO + w x h ;  ang = I_O w + h x vO
     double a[3], b[3];
-    cross3(s.wv[i], s.ch[i], a);
-    for (int r = 0; r < 3; ++r) s.ckl[i][r] = m * s.vo[i][r] + a[r];
-    symvec(s.cI[i], s.wv[i], a);
-    cross3(s.ch[i], s.vo[i], b);
-    for (int r = 0; r < 3; ++r) s.cka[i][r] = a[r] + b[r];
+    cross3(s.wv[i], h, a);
+    for (int r = 0; r < 3; ++r) cp[CKL + r] = m * s.vo[i][r] + a[r];
+    symvec(I6, s.wv[i], a);
+    cross3(h, s.vo[i], b);
+    for (int r = 0; r < 3; ++r) cp[CKA + r] = a[r] + b[r];
 }
 template <class Em> HD void t_frames(Ctx<Em>& cx, int f) {
     KnotScratch& s = cx.s;
@@ -582,36 +665,39 @@ template <class Em> HD void t_frames(Ctx<Em>& cx, int f) {
 // running sums in registers.  Stage 2: one lane finishes the links that have several children and their
 // ancestors (reverse topological order), then the totals.  Contact-point kinematics ride along.
 // ===================================================================================================
-template <class Em> HD void t_composite_chain(Ctx<Em>& cx, int leaf) {
+constexpr int COMP_CHAIN_TASKS = MAX_LEAF * 16;
+template <class Em> HD void t_composite_chain(Ctx<Em>& cx, int t) {  // lane (leaf, component r)
     KnotScratch& s = cx.s;
+    const int leaf = t >> 4, r = t & 15;
+    if (leaf >= cx.kt.n_leaf) return;
     const int len = cx.kt.up_len[leaf];
-    double m = 0.0, h[3] = {0, 0, 0}, I[6] = {0, 0, 0, 0, 0, 0}, kl[3] = {0, 0, 0}, ka[3] = {0, 0, 0};
-    for (int q = 0; q < len; ++q) {
+    double acc = 0.0;
+    HIPNLP_UNROLL
+    for (int q = 0; q < 8; ++q) {
+        if (q >= len) break;
         const int i = cx.kt.up_link[leaf][q];
-        m += s.cm[i];
-        for (int r = 0; r < 3; ++r) { h[r] += s.ch[i][r]; kl[r] += s.ckl[i][r]; ka[r] += s.cka[i][r]; }
-        for (int r = 0; r < 6; ++r) I[r] += s.cI[i][r];
-        s.cm[i] = m;
-        for (int r = 0; r < 3; ++r) { s.ch[i][r] = h[r]; s.ckl[i][r] = kl[r]; s.cka[i][r] = ka[r]; }
-        for (int r = 0; r < 6; ++r) s.cI[i][r] = I[r];
+        acc += s.comp[i][r];
+        s.comp[i][r] = acc;
     }
 }
-template <class Em> HD void t_composite_rest(Ctx<Em>& cx, int) {
+template <class Em> HD void t_composite_rest(Ctx<Em>& cx, int r) {  // lane = component r (16); runs right behind the chains on the same wave
     KnotScratch& s = cx.s;
-    for (int q = 0; q < cx.kt.s2_len; ++q) {
-        const int i = cx.kt.s2_link[q];
-        for (int n = 0; n < cx.kt.nchild[i]; ++n) {
-            const int c = cx.kt.child[i][n];
-            s.cm[i] += s.cm[c];
-            for (int r = 0; r < 3; ++r) { s.ch[i][r] += s.ch[c][r]; s.ckl[i][r] += s.ckl[c][r]; s.cka[i][r] += s.cka[c][r]; }
-            for (int r = 0; r < 6; ++r) s.cI[i][r] += s.cI[c][r];
+    HIPNLP_WAVE_SYNC();
+    const int n_ops = cx.kt.s2_n;
+    int cur = -1, prev = -1;
+    double acc = 0.0, prev_val = 0.0;
+    HIPNLP_UNROLL
+    for (int n = 0; n < 12; ++n) {
+        if (n >= n_ops) break;
+        const int dst = cx.kt.s2_dst[n], src = cx.kt.s2_src[n];
+        if (dst != cur) {
+            if (cur >= 0) { s.comp[cur][r] = acc; prev = cur; prev_val = acc; }
+            cur = dst;
+            acc = s.comp[dst][r];
         }
+        acc += (src == prev) ? prev_val : s.comp[src][r];
     }
-    const double M = cx.kt.total_mass;
-    double t3[3];
-    for (int r = 0; r < 3; ++r) { s.com[r] = s.ch[0][r] / M; s.klin[r] = s.ckl[0][r]; s.kang[r] = s.cka[0][r]; }
-    cross3(s.com, s.klin, t3);
-    for (int r = 0; r < 3; ++r) s.hang[r] = s.kang[r] - t3[r];
+    if (cur >= 0) s.comp[cur][r] = acc;
 }
 template <class Em> HD void t_pkin(Ctx<Em>& cx, int c) {
     KnotScratch& s = cx.s;
@@ -627,20 +713,31 @@ template <class Em> HD void t_pkin(Ctx<Em>& cx, int c) {
 template <class Em> HD void t_columns(Ctx<Em>& cx, int t) {
     KnotScratch& s = cx.s;
     Em& em = cx.em;
-    const double M = cx.kt.total_mass, mass = cx.gp.mass;
+    const double inv_M = 1.0 / cx.kt.total_mass, inv_mass = 1.0 / cx.gp.mass;
+    // totals of the whole tree (every lane needs them; lane 0 publishes them for the row assembly)
+    double com[3], klin[3], kang[3], t1[3], t2[3];
+    for (int r = 0; r < 3; ++r) { com[r] = s.comp[0][CH + r] * inv_M; klin[r] = s.comp[0][CKL + r]; kang[r] = s.comp[0][CKA + r]; }
+    if (t == 0) {
+        cross3(com, klin, t1);
+        for (int r = 0; r < 3; ++r) { s.com[r] = com[r]; s.klin[r] = klin[r]; s.kang[r] = kang[r]; s.hang[r] = kang[r] - t1[r]; }
+    }
     double a[3], o[3] = {0.0, 0.0, 0.0};
     int i;  // link whose composite / velocity is used
     if (t < NJ) { i = t + 1; for (int r = 0; r < 3; ++r) { a[r] = s.aw[t][r]; o[r] = s.ow[i][r]; } }
     else { i = 0; for (int r = 0; r < 3; ++r) a[r] = (r == t - NJ) ? 1.0 : 0.0; }
-    double oxa[3], lin[3], ang[3], t1[3], t2[3], A[3];
+    const double cm = s.comp[i][CM];
+    double ch[3], cI[6], ckl[3], cka[3];
+    for (int r = 0; r < 3; ++r) { ch[r] = s.comp[i][CH + r]; ckl[r] = s.comp[i][CKL + r]; cka[r] = s.comp[i][CKA + r]; }
+    for (int r = 0; r < 6; ++r) cI[r] = s.comp[i][CI + r];
+    double oxa[3], lin[3], ang[3], A[3];
     cross3(o, a, oxa);
     // momentum of the subtree moving with the unit motion S = (a ; o x a):  I_sub S
-    cross3(a, s.ch[i], t1);
-    for (int r = 0; r < 3; ++r) lin[r] = s.cm[i] * oxa[r] + t1[r];
-    symvec(s.cI[i], a, t1);
-    cross3(s.ch[i], oxa, t2);
+    cross3(a, ch, t1);
+    for (int r = 0; r < 3; ++r) lin[r] = cm * oxa[r] + t1[r];
+    symvec(cI, a, t1);
+    cross3(ch, oxa, t2);
     for (int r = 0; r < 3; ++r) ang[r] = t1[r] + t2[r];
-    cross3(s.com, lin, t1);
+    cross3(com, lin, t1);
     for (int r = 0; r < 3; ++r) A[r] = ang[r] - t1[r];                // column of the centroidal momentum matrix (angular rows)
     // configuration derivative:  dk = S x* k_sub - I_sub (S x v_i)
     double xw[3], xv[3], Il[3], Ia[3], dkl[3], dka[3], dcom[3], dh[3];
@@ -648,28 +745,28 @@ template <class Em> HD void t_columns(Ctx<Em>& cx, int t) {
     cross3(a, s.vo[i], t1);
     cross3(oxa, s.wv[i], t2);
     for (int r = 0; r < 3; ++r) xv[r] = t1[r] + t2[r];
-    cross3(xw, s.ch[i], t1);
-    for (int r = 0; r < 3; ++r) Il[r] = s.cm[i] * xv[r] + t1[r];
-    symvec(s.cI[i], xw, t1);
-    cross3(s.ch[i], xv, t2);
+    cross3(xw, ch, t1);
+    for (int r = 0; r < 3; ++r) Il[r] = cm * xv[r] + t1[r];
+    symvec(cI, xw, t1);
+    cross3(ch, xv, t2);
     for (int r = 0; r < 3; ++r) Ia[r] = t1[r] + t2[r];
-    cross3(a, s.ckl[i], t1);
+    cross3(a, ckl, t1);
     for (int r = 0; r < 3; ++r) dkl[r] = t1[r] - Il[r];
-    cross3(a, s.cka[i], t1);
-    cross3(oxa, s.ckl[i], t2);
+    cross3(a, cka, t1);
+    cross3(oxa, ckl, t2);
     for (int r = 0; r < 3; ++r) dka[r] = t1[r] + t2[r] - Ia[r];
-    for (int r = 0; r < 3; ++r) t1[r] = s.ch[i][r] - s.cm[i] * o[r];
+    for (int r = 0; r < 3; ++r) t1[r] = ch[r] - cm * o[r];
     cross3(a, t1, dcom);
-    for (int r = 0; r < 3; ++r) dcom[r] = dcom[r] / M;
-    cross3(dcom, s.klin, t1);
-    cross3(s.com, dkl, t2);
+    for (int r = 0; r < 3; ++r) dcom[r] = dcom[r] * inv_M;
+    cross3(dcom, klin, t1);
+    cross3(com, dkl, t2);
     for (int r = 0; r < 3; ++r) dh[r] = dka[r] - t1[r] - t2[r];
     if (t < NJ) {
         const int j = t;
         for (int r = 0; r < 3; ++r) {
             em.J(js::COMC_S + NJ * r + j, row_id(RK_COMC, 0, r), S_ + j, -dcom[r]);
-            em.J(js::CMMC_S + NJ * r + j, row_id(RK_CMMC, 0, r), S_ + j, -dh[r] / mass);
-            em.J(js::CMMC_SD + NJ * r + j, row_id(RK_CMMC, 0, r), SD_ + j, -A[r] / mass);
+            em.J(js::CMMC_S + NJ * r + j, row_id(RK_CMMC, 0, r), S_ + j, -dh[r] * inv_mass);
+            em.J(js::CMMC_SD + NJ * r + j, row_id(RK_CMMC, 0, r), SD_ + j, -A[r] * inv_mass);
         }
         // chest-frame orientation cost: d trace = -(ax(M) . a_j) d s_j for joints on the root->chest path
         if (cx.kt.chest_pos[j] >= 0) s.grad[S_ + j] += s.chest_dc * (-dot3(s.chest_w, a));
@@ -710,7 +807,7 @@ template <class Em> HD void t_kinc(Ctx<Em>& cx, int t) {
     // d pkin / d q_b = -[r]x G / |q|   ->  row entries = +[r]x G / |q|
     const double X0 = skew_rc(r, i, 0), X1 = skew_rc(r, i, 1), X2 = skew_rc(r, i, 2);
     for (int l = 0; l < 4; ++l)
-        em.J(jb + js::KINC_QB + 4 * i + l, row_id(RK_KINC, c, i), QB_ + l, (X0 * s.G[l] + X1 * s.G[4 + l] + X2 * s.G[8 + l]) / s.qnorm);
+        em.J(jb + js::KINC_QB + 4 * i + l, row_id(RK_KINC, c, i), QB_ + l, (X0 * s.G[l] + X1 * s.G[4 + l] + X2 * s.G[8 + l]) * s.inv_qnorm);
     // d pkin / d s_j = a_j x (pkin - o_j) for the joints of the leg path
     for (int q = 0; q < LEG_PATH; ++q) {
         const int j = cx.kt.leg_joint[f][q];
@@ -727,7 +824,7 @@ template <class Em> HD void t_comc(Ctx<Em>& cx, int t) {
     if (t < 12) {
         const int i = t / 4, l = t - 4 * i;
         const double X0 = skew_rc(r, i, 0), X1 = skew_rc(r, i, 1), X2 = skew_rc(r, i, 2);
-        em.J(js::COMC_QB + 4 * i + l, row_id(RK_COMC, 0, i), QB_ + l, (X0 * s.G[l] + X1 * s.G[4 + l] + X2 * s.G[8 + l]) / s.qnorm);
+        em.J(js::COMC_QB + 4 * i + l, row_id(RK_COMC, 0, i), QB_ + l, (X0 * s.G[l] + X1 * s.G[4 + l] + X2 * s.G[8 + l]) * s.inv_qnorm);
     } else {
         const int i = t - 12;
         em.G(gs::COMC + i, row_id(RK_COMC, 0, i), s.x[COM_ + i] - (s.x[PB_ + i] + r[i]));
@@ -739,19 +836,19 @@ template <class Em> HD void t_comc(Ctx<Em>& cx, int t) {
 template <class Em> HD void t_cmmc(Ctx<Em>& cx, int t) {
     KnotScratch& s = cx.s;
     Em& em = cx.em;
-    const double mass = cx.gp.mass;
+    const double inv_mass = 1.0 / cx.gp.mass;
     if (t < 12) {
         const int i = t / 4, l = t - 4 * i;
         double dq = 0.0, dqd = 0.0;
         for (int e = 0; e < 3; ++e) {
-            dq += s.dth_h[e][i] * s.G[4 * e + l] / s.qnorm + s.Aw[e][i] * s.dwq[4 * e + l];
+            dq += s.dth_h[e][i] * s.G[4 * e + l] * s.inv_qnorm + s.Aw[e][i] * s.dwq[4 * e + l];
             dqd += s.Aw[e][i] * s.G[4 * e + l];
         }
-        em.J(js::CMMC_QB + 4 * i + l, row_id(RK_CMMC, 0, i), QB_ + l, -dq / mass);
-        em.J(js::CMMC_QD + 4 * i + l, row_id(RK_CMMC, 0, i), QD_ + l, -dqd / mass);
+        em.J(js::CMMC_QB + 4 * i + l, row_id(RK_CMMC, 0, i), QB_ + l, -dq * inv_mass);
+        em.J(js::CMMC_QD + 4 * i + l, row_id(RK_CMMC, 0, i), QD_ + l, -dqd * inv_mass);
     } else {
         const int i = t - 12;
-        em.G(gs::CMMC + i, row_id(RK_CMMC, 0, i), s.x[H_ + 3 + i] - s.hang[i] / mass);
+        em.G(gs::CMMC + i, row_id(RK_CMMC, 0, i), s.x[H_ + 3 + i] - s.hang[i] * inv_mass);
         em.J(js::CMMC_H + i, row_id(RK_CMMC, 0, i), H_ + 3 + i, 1.0);
     }
 }
@@ -768,32 +865,23 @@ template <class Em> HD void t_feetd(Ctx<Em>& cx, int t) {
         const int l = t;
         double acc = 0.0;
         for (int e = 0; e < 3; ++e) acc += -s.chest_w[e] * s.G[4 * e + l];
-        s.grad[QB_ + l] += s.chest_dc * acc / s.qnorm;
+        s.grad[QB_ + l] += s.chest_dc * acc * s.inv_qnorm;
     }
 }
 
-// ===================================================================================================
-// PHASE I — reductions of the cost partials (lane 0) ; minimize-mode end terms applied to grad (lanes 1..189)
-// ===================================================================================================
-constexpr int REDUCE_TASKS = 1 + ENDS_TASKS;
-template <class Em> HD void t_reduce(Ctx<Em>& cx, int t) {
+// minimize-mode end terms: lane 0 sums the cost partials, lanes 1.. add the gradient shares (phase G, behind t_feetd)
+constexpr int ENDS_FINISH_TASKS = 1 + ENDS_TASKS;
+template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
     KnotScratch& s = cx.s;
+    HIPNLP_WAVE_SYNC();
+    const bool active = (cx.ki.last || cx.ki.first) && (cx.st.final_type == HIPNLP_EXPR_MINIMIZE || cx.st.periodicity_type == HIPNLP_EXPR_MINIMIZE);
     if (t == 0) {
-        double a = 0.0, b = 0.0, c = 0.0;
-        for (int p = 0; p < NC; ++p) { a += s.c_pt[p][0]; b += s.c_pt[p][1]; c += s.c_pt[p][2]; }
-        s.cost[CT_SWING] = a; s.cost[CT_UREG] = b; s.cost[CT_FDREG] = c;
-        double j = 0.0;
-        for (int q = 0; q < NJ; ++q) j += s.c_joint[q];
-        s.cost[CT_JREG] = j;
-        s.cost[CT_COMVEL] = (s.c_comvel[0] + s.c_comvel[1]) + s.c_comvel[2];
-        s.cost[CT_FREG] = ((s.c_force[0][0] + s.c_force[0][1]) + s.c_force[0][2]) + ((s.c_force[1][0] + s.c_force[1][1]) + s.c_force[1][2]);
-        s.cost[CT_YAW] = s.c_yaw[0] + s.c_yaw[1];
         double e = 0.0;
-        for (int i = 0; i < ENDS_TASKS; ++i) e += s.c_ends[i];
+        if (active && cx.ki.last) for (int i = 0; i < ENDS_TASKS; ++i) e += s.ends.c[i];
         s.cost[CT_ENDS] = e;
-    } else {
+    } else if (active) {
         const int i = t - 1;
-        const double gv = s.g_ends[i];
+        const double gv = s.ends.g[i];
         if (gv != 0.0) {
             const int var = i < 105 ? cx.kt.fin_var[i] : cx.kt.per_var[i - 105];
             if (var >= 0) s.grad[var] += gv;  // every variable appears in at most one final row and one periodicity row,
@@ -807,26 +895,21 @@ template <class Em> HD void t_reduce(Ctx<Em>& cx, int t) {
 // ---------------------------------------------------------------------------------------------------
 #define HIPNLP_KNOT_PROGRAM(R, BARRIER)                                                   \
     R(0, t_points_vec, 3 * NC)                                                            \
-    R(1, t_points_scalar, NC) R(1, t_dyn, 7 + NJ + 3) R(1, t_unitq, 1)                    \
-    R(2, t_joints, NJ)                                                                    \
+    R(1, t_points_scalar, NC) R(1, t_points_cost, 3) R(1, t_dyn, 7 + NJ + 3) R(1, t_unitq, 1) \
+    R(2, t_joints, NJ) R(2, t_joint_cost, 1)                                              \
     R(3, t_base, 1) R(3, t_small, 4) R(3, t_feet, 3)                                      \
     BARRIER                                                                               \
-    R(0, t_fk_chain, cx.kt.n_leaf)                                                        \
+    R(0, t_fk_chain, FK_TASKS) R(0, t_vel_chain, FK_TASKS)                                \
     R(1, t_hdyn, HDYN_TASKS)                                                              \
-    R(2, t_foot_costs, FOOT_TASKS)                                                        \
-    R(3, t_ends, ENDS_TASKS)                                                              \
+    R(2, t_foot_costs, FOOT_TASKS) R(2, t_foot_cost_sum, 2)                               \
     BARRIER                                                                               \
-    R(0, t_links, NL) R(1, t_frames, 3)                                                   \
+    R(0, t_links, NL) R(1, t_frames, 3) R(3, t_ends, ENDS_TASKS)                          \
     BARRIER                                                                               \
-    R(0, t_composite_chain, cx.kt.n_leaf) R(1, t_pkin, NC)                                \
-    BARRIER                                                                               \
-    R(0, t_composite_rest, 1)                                                             \
+    R(0, t_composite_chain, COMP_CHAIN_TASKS) R(0, t_composite_rest, 16) R(1, t_pkin, NC) \
     BARRIER                                                                               \
     R(0, t_columns, NJ + 3)                                                               \
     BARRIER                                                                               \
-    R(0, t_kinc, 3 * NC) R(1, t_comc, 15) R(2, t_cmmc, 15) R(3, t_feetd, 5)               \
-    BARRIER                                                                               \
-    R(0, t_reduce, REDUCE_TASKS)                                                          \
+    R(0, t_kinc, 3 * NC) R(1, t_comc, 15) R(2, t_cmmc, 15) R(3, t_feetd, 5) R(3, t_ends_finish, ENDS_FINISH_TASKS) \
     BARRIER
 
 }  // namespace hipnlp

@@ -7,6 +7,7 @@
 // Opti canonical forms.
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <limits>
 #include <string>
 #include <utility>
@@ -285,20 +286,15 @@ struct Layout {
     // Kinematic tables from the C descriptor; validates the topology the kernel is specialised for.
     static bool make_kin_tables(const hipnlp_robot_model& md, KinTables& kt, std::string& err) {
         kt = KinTables{};
-        kt.max_depth = 0;
-        kt.link_depth[0] = 0;
-        for (int l = 0; l < NL; ++l) kt.nchild[l] = 0;
+        int nchild[NL], child[NL][4];
+        for (int l = 0; l < NL; ++l) nchild[l] = 0;
         for (int j = 0; j < NJ; ++j) {
             const int par = md.parent[j];
             if (par < 0 || par > j) { err = "robot model: parent[j] must satisfy 0 <= parent[j] <= j (topological order)"; return false; }
-            kt.parent[j] = par;
-            kt.depth[j] = kt.link_depth[par] + 1;
-            kt.link_depth[j + 1] = kt.depth[j];
-            kt.max_depth = std::max(kt.max_depth, kt.depth[j]);
-            if (kt.nchild[par] >= 4) { err = "robot model: more than 4 children on one link"; return false; }
-            kt.child[par][kt.nchild[par]++] = j + 1;
+            if (nchild[par] >= 4) { err = "robot model: more than 4 children on one link"; return false; }
+            child[par][nchild[par]++] = j + 1;
             double an = 0;
-            for (int i = 0; i < 3; ++i) { kt.o_fix[j][i] = md.o_fix[j][i]; kt.axis[j][i] = md.axis[j][i]; an += md.axis[j][i] * md.axis[j][i]; }
+            for (int i = 0; i < 3; ++i) { kt.axis[j][i] = md.axis[j][i]; an += md.axis[j][i] * md.axis[j][i]; }
             if (!(an > 0.999999 && an < 1.000001)) { err = "robot model: joint axes must be unit vectors"; return false; }
             for (int i = 0; i < 9; ++i) kt.R_fix[j][i] = md.R_fix[j][i];
         }
@@ -328,29 +324,40 @@ struct Layout {
         }
         for (int j = 0; j < NJ; ++j)
             if (kt.leg_pos[0][j] >= 0 && kt.leg_pos[1][j] >= 0) { err = "robot model: the two leg chains must be disjoint"; return false; }
-        // chain decomposition: one root->leaf joint path per leaf link; single-child up-chains; the rest
+        // chain decomposition: one root->leaf joint path per leaf link; single-child up-chains; the rest as add-ops
         kt.n_leaf = 0;
+        for (int j = 0; j < NJ; ++j) for (int n = 0; n < 4; ++n) kt.chain_slot[j][n] = -1;
         std::vector<bool> covered(NL, false);
         for (int l = 1; l < NL; ++l) {
-            if (kt.nchild[l] != 0) continue;
-            if (kt.n_leaf >= 8) { err = "robot model: more than 8 leaf links"; return false; }
+            if (nchild[l] != 0) continue;
+            if (kt.n_leaf >= MAX_LEAF) { err = "robot model: too many leaf links"; return false; }
             const int leaf = kt.n_leaf++;
             std::vector<int> path;
             for (int q = l; q > 0; q = md.parent[q - 1]) path.push_back(q - 1);
             if (path.size() > 8) { err = "robot model: a chain is deeper than 8 joints"; return false; }
             std::sort(path.begin(), path.end());
             kt.path_len[leaf] = int(path.size());
-            for (size_t q = 0; q < path.size(); ++q) kt.path[leaf][q] = path[q];
+            for (size_t q = 0; q < path.size(); ++q) {
+                const int j = path[q];
+                kt.chain_link[leaf][q] = j + 1;
+                for (int i = 0; i < 3; ++i) { kt.chain_ofix[leaf][q][i] = md.o_fix[j][i]; kt.chain_axis[leaf][q][i] = md.axis[j][i]; }
+                int n = 0;
+                while (n < 4 && kt.chain_slot[j][n] >= 0) ++n;
+                if (n >= 4) { err = "robot model: a joint is shared by more than 4 chains"; return false; }
+                kt.chain_slot[j][n] = 8 * leaf + int(q);
+            }
             int n = 0;
-            for (int q = l; q > 0 && kt.nchild[q] <= 1; q = md.parent[q - 1]) { kt.up_link[leaf][n++] = q; covered[size_t(q)] = true; }
+            for (int q = l; q > 0 && nchild[q] <= 1; q = md.parent[q - 1]) { kt.up_link[leaf][n++] = q; covered[size_t(q)] = true; }
             kt.up_len[leaf] = n;
         }
-        kt.s2_len = 0;
+        kt.s2_n = 0;
         for (int l = NL - 1; l >= 0; --l)
-            if (!covered[size_t(l)]) {
-                if (kt.s2_len >= 8) { err = "robot model: too many branching links"; return false; }
-                kt.s2_link[kt.s2_len++] = l;
-            }
+            if (!covered[size_t(l)])
+                for (int n = 0; n < nchild[l]; ++n) {
+                    if (kt.s2_n >= 12) { err = "robot model: too many branching links"; return false; }
+                    kt.s2_dst[kt.s2_n] = l;
+                    kt.s2_src[kt.s2_n++] = child[l][n];
+                }
         for (int i = 0; i < 105; ++i) {
             int slot, desc;
             const int var = final_row_var(i, &slot, &desc);
@@ -450,7 +457,12 @@ inline void pack_params(const double* p, int N, double* pk /*[N][PK_STRIDE]*/, G
         double* r = pk + size_t(k) * PK_STRIDE;
         for (int i = 0; i < 24; ++i) r[PK_DESC + i] = p[po.desc(k, 0) + i];
         for (int i = 0; i < 55; ++i) r[PK_REF + i] = p[po.ref(k) + i];
-        r[79] = 0.0;
+        for (int foot = 0; foot < 2; ++foot) {  // E9 needs sin/cos of yaw and of yaw + pi/2 (planner.py:831-841): parameters only
+            const double yaw = r[PK_REF + (foot == 0 ? R_YAW_L : R_YAW_R)];
+            r[PK_YAWSC + 4 * foot + 0] = std::sin(yaw); r[PK_YAWSC + 4 * foot + 1] = std::cos(yaw);
+            r[PK_YAWSC + 4 * foot + 2] = std::sin(yaw + M_PI / 2); r[PK_YAWSC + 4 * foot + 3] = std::cos(yaw + M_PI / 2);
+        }
+        r[87] = 0.0;
     }
     gp.dt = p[po.dt()]; gp.kt = p[po.kt()]; gp.kbs = p[po.kbs()]; gp.eps = p[po.eps()]; gp.mu = p[po.mu()]; gp.mass = p[po.mass()];
     for (int i = 0; i < 6; ++i) gp.gravity[i] = p[po.gravity() + i];

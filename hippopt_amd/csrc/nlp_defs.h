@@ -23,14 +23,15 @@ constexpr int NJ = HIPNLP_NJ, NL = HIPNLP_NL, NC = HIPNLP_NC, NXK = HIPNLP_NXK, 
 constexpr int LEG_PATH = 6;    // joints between root_link and each sole frame (ergoCub topology)
 constexpr int CHEST_PATH = 3;  // joints between root_link and the chest frame
 constexpr int XPAD = 192;      // LDS stride of one knot record
+constexpr int MAX_LEAF = 6;    // leaf links of the kinematic tree (ergoCub: 2 hands + 2 feet)
 
 // ---- per-knot variable offsets (reference creation order, tests/golden/kinodyn_structure.json) --
 enum : int { V_ = 0, FD_ = 3, P_ = 6, F_ = 9, U_ = 12, PT_ = 15,
              VB_ = 120, QD_ = 123, PB_ = 127, QB_ = 130, SD_ = 134, S_ = 157, COM_ = 180, H_ = 183 };
 
 // ---- per-knot parameter record on the device: [descriptors 24 | references 55 | pad] -----------
-constexpr int PK_STRIDE = 80;
-enum : int { PK_DESC = 0, PK_REF = 24,
+constexpr int PK_STRIDE = 88;   // [descriptors 24 | references 55 | sin/cos of the yaw references 8 | pad 1]
+enum : int { PK_DESC = 0, PK_REF = 24, PK_YAWSC = 79,
              R_ALPHA_L = 0, R_YAW_L = 4, R_ALPHA_R = 5, R_YAW_R = 9, R_SWING = 10, R_CW = 11, R_CREF = 14,
              R_VREF = 17, R_FQ = 20, R_BQ = 24, R_BQV = 28, R_JREG = 32 };
 
@@ -43,25 +44,22 @@ struct GParams {
 
 // ---- kinematic tree tables (device copy of hipnlp_robot_model + derived topology) ----------------
 struct KinTables {
-    int32_t parent[NJ];
-    int32_t depth[NJ];          // 1 = attached to the root
-    int32_t max_depth;
-    int32_t link_depth[NL];     // 0 for the root
-    int32_t nchild[NL];
-    int32_t child[NL][4];       // child LINK indices
     int32_t leg_pos[2][NJ];     // position of joint j in the root->sole path (0..5) or -1
     int32_t leg_joint[2][LEG_PATH];
     int32_t chest_pos[NJ];      // position in the root->chest path or -1
     int32_t frame_link[3];
-    // chain decomposition of the tree (one lane walks one chain, no per-level barriers)
-    int32_t n_leaf;
-    int32_t path_len[8], path[8][8];    // joints from the root to leaf l (shared prefixes are recomputed per lane)
-    int32_t up_len[8], up_link[8][8];   // links from leaf l upward while they have a single child (composite pass, stage 1)
-    int32_t s2_len, s2_link[8];         // the remaining links in reverse topological order (stage 2, one lane)
+    // chain decomposition of the tree (one lane group walks one root->leaf chain; no per-level barriers)
+    int32_t n_leaf;                          // <= MAX_LEAF
+    int32_t path_len[MAX_LEAF];
+    int32_t chain_link[MAX_LEAF][8];         // link reached by step q of chain l
+    int32_t chain_slot[NJ][4];               // chain slots (8*l + q) in which joint j appears, -1 = unused
+    int32_t up_len[MAX_LEAF], up_link[MAX_LEAF][8];  // links from leaf l upward while they have a single child (composite pass, stage 1)
+    int32_t s2_n, s2_dst[12], s2_src[12];    // stage 2: comp[dst] += comp[src], in dependency order
     // horizon-end rows
     int16_t fin_var[105], fin_slot[105], fin_desc[105];  // variable / slot among the 81 variable rows / descriptor index (3c+i) or -1
     int16_t per_var[84];
-    double R_fix[NJ][9], o_fix[NJ][3], axis[NJ][3];
+    double chain_ofix[MAX_LEAF][8][3], chain_axis[MAX_LEAF][8][3];  // o_fix / axis in chain order (addresses independent of loaded indices)
+    double R_fix[NJ][9], axis[NJ][3];
     double mass[NL], com[NL][3], inertia[NL][9];
     double frame_R[3][9], frame_o[3][3];
     double total_mass;
