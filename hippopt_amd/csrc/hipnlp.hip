@@ -121,12 +121,16 @@ __global__ __launch_bounds__(WG) void hipnlp_knot_kernel(KArgs a) {
     Ctx<DevEm> cx(s, tabs.kt, tabs.ks, tabs.gp, ki, em);
 #define DEV_R(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #ifdef HIPNLP_STAMPS
-    // per wave: arrival time at every barrier (before waiting), 16 slots per wave
-    int sidx = 0;
-    unsigned long long* stamp_out = a.stamps + (size_t(blockIdx.y) * gridDim.x + blockIdx.x) * 64 + wave * 16;
-    if (lane == 0) stamp_out[sidx] = __builtin_amdgcn_s_memtime();
+    // diagnostic build: every wave stamps the END of each task group it runs and its ARRIVAL at each barrier
+    // (before waiting).  Per wave 64 slots of {id, time}: id = group sequence number, or 1000 + barrier number.
+    int sidx = 0, gid = 0, bid = 0;
+    unsigned long long* stamp_out = a.stamps + ((size_t(blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 128;
+    if (lane == 0) { stamp_out[0] = 999; stamp_out[1] = __builtin_amdgcn_s_memtime(); }
     sidx++;
-#define DEV_BARRIER if (lane == 0 && sidx < 15) stamp_out[sidx] = __builtin_amdgcn_s_memtime(); sidx++; __syncthreads();
+#undef DEV_R
+#define DEV_R(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); \
+        if (lane == 0 && sidx < 63) { stamp_out[2 * sidx] = gid; stamp_out[2 * sidx + 1] = __builtin_amdgcn_s_memtime(); } sidx++; } gid++;
+#define DEV_BARRIER if (lane == 0 && sidx < 63) { stamp_out[2 * sidx] = 1000 + bid; stamp_out[2 * sidx + 1] = __builtin_amdgcn_s_memtime(); } sidx++; bid++; __syncthreads();
 #else
 #define DEV_BARRIER __syncthreads();
 #endif
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(WG) void hipnlp_knot_kernel(KArgs a) {
     const int anybad = __syncthreads_or(bad);
     if (tid == 0) a.flags[size_t(b) * a.nk + kk] = anybad;
 #ifdef HIPNLP_STAMPS
-    if (lane == 0) { stamp_out[sidx < 15 ? sidx : 14] = __builtin_amdgcn_s_memtime(); stamp_out[15] = (unsigned long long)sidx; }
+    if (lane == 0) { if (sidx < 63) { stamp_out[2 * sidx] = 2000; stamp_out[2 * sidx + 1] = __builtin_amdgcn_s_memtime(); } stamp_out[126] = (unsigned long long)(sidx + 1); }
 #endif
 }
 
@@ -447,7 +451,7 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     hipEvent_t e0 = prof ? h->prof_ev[size_t(3 * h->prof_n)] : h->ev0;
     hipEvent_t e2 = prof ? h->prof_ev[size_t(3 * h->prof_n + 2)] : h->ev1;
 #ifdef HIPNLP_STAMPS
-    if (!h->d_stamps) HIP_TRY(h, hipMalloc(&h->d_stamps, size_t(h->nk) * size_t(h->batch) * 64 * sizeof(unsigned long long)));
+    if (!h->d_stamps) HIP_TRY(h, hipMalloc(&h->d_stamps, size_t(h->nk) * size_t(h->batch) * 512 * sizeof(unsigned long long)));
     a.stamps = h->d_stamps;
 #endif
     HIP_TRY(h, hipEventRecord(e0, s));
@@ -593,7 +597,7 @@ int hipnlp_debug_stamps(hipnlp_handle* h, unsigned long long* out /*[nk*batch][4
     HIP_TRY(h, hipSetDevice(h->dev));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipMemcpy(out, h->d_stamps, size_t(h->nk) * size_t(h->batch) * 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(out, h->d_stamps, size_t(h->nk) * size_t(h->batch) * 512 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return HIPNLP_OK;
 }
 #endif

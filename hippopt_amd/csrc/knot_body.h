@@ -54,12 +54,15 @@ struct KnotScratch {
     double qn[4], qnorm, inv_qnorm, Rb[9], G[12] /* 3x4: dtheta = G dqhat */, omega[3], dwq[12] /* d omega/d qb (3x4) */;
     // kinematics in base-centred coordinates (origin = base origin; h_ang and relative positions are
     // invariant to the base position / linear velocity)
-    union {  // Rchain is dead once the forward kinematics has run; the (rare) minimize-mode end terms reuse its space
-        double Rchain[MAX_LEAF * 8][9];  // parent_R_child of every chain step, in chain order (written by t_joints)
+    double Lj[NJ + 1][9];   // parent_R_child of joint j; slot NJ = identity (padding of the ancestor lists)
+    double Tj[NJ + 1][3];   // R_parent o_fix_j ; slot NJ = 0
+    double Uj[NJ + 1][3];   // (o_j x a_j) sdot_j ; slot NJ = 0
+    double Rw[NL][9], ow[NL][3], aw[NJ + 1][3];  // aw slot NJ = 0
+    double wv[NL][3], vo[NL][3];  // link angular velocity; velocity of the body point at the origin
+    union {  // own[] is dead once the composites are formed; the (rare) minimize-mode end terms reuse its space
+        double own[NL + 1][16];  // per link, same layout as comp; slot NL = 0 (padding of the descendant lists)
         EndTerms ends;
     };
-    double Rw[NL][9], ow[NL][3], aw[NJ][3];
-    double wv[NL][3], vo[NL][3];  // link angular velocity; velocity of the body point at the origin
     double comp[NL][16];  // composite per link: [m | first moment h (3) | inertia@O xx,xy,xz,yy,yz,zz (6) | subtree momentum lin (3) | ang (3)]
     double com[3], klin[3], kang[3], hang[3];
     double dth_h[3][3];  // d hang / d theta_e   [e][i]
@@ -296,12 +299,7 @@ template <class Em> HD void t_joints(Ctx<Em>& cx, int j) {
     Ra[1] -= sq * a[2]; Ra[2] += sq * a[1];
     Ra[3] += sq * a[2]; Ra[5] -= sq * a[0];
     Ra[6] -= sq * a[1]; Ra[7] += sq * a[0];
-    double Rl[9];
-    matmul3(cx.kt.R_fix[j], Ra, Rl);
-    for (int n = 0; n < 4; ++n) {
-        const int slot = cx.kt.chain_slot[j][n];
-        if (slot >= 0) for (int r = 0; r < 9; ++r) s.Rchain[slot][r] = Rl[r];
-    }
+    matmul3(cx.kt.R_fix[j], Ra, s.Lj[j]);
 }
 
 template <class Em> HD void t_joint_cost(Ctx<Em>& cx, int) {  // behind t_joints on the same wave
@@ -433,7 +431,9 @@ template <class Em> HD void t_base(Ctx<Em>& cx, int) {
     }
     // root link pose and velocity in base-centred coordinates
     for (int i = 0; i < 9; ++i) s.Rw[0][i] = s.Rb[i];
-    for (int i = 0; i < 3; ++i) { s.ow[0][i] = 0.0; s.wv[0][i] = s.omega[i]; s.vo[0][i] = 0.0; }
+    for (int i = 0; i < 3; ++i) { s.ow[0][i] = 0.0; s.wv[0][i] = s.omega[i]; s.vo[0][i] = 0.0; s.Tj[NJ][i] = 0.0; s.Uj[NJ][i] = 0.0; s.aw[NJ][i] = 0.0; }
+    for (int i = 0; i < 9; ++i) s.Lj[NJ][i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < 16; ++i) s.own[NL][i] = 0.0;
 }
 
 // ===================================================================================================
@@ -441,51 +441,62 @@ template <class Em> HD void t_base(Ctx<Em>& cx, int) {
 // stays in registers; shared prefixes are recomputed, identical values are stored twice).
 // Other waves meanwhile: momentum-dynamics rows, foot costs, horizon-end rows.
 // ===================================================================================================
-constexpr int FK_TASKS = MAX_LEAF * 3;
-template <class Em> HD void t_fk_chain(Ctx<Em>& cx, int t) {  // lane (leaf, matrix row r): row r of R_i = row r of R_parent times R_loc
+// Forward kinematics and link velocities as ANCESTOR SUMS: lane (joint j, component r), 69 tasks per pass.
+// Every lane walks its own (padded) ancestor list, so no lane waits for another one inside a pass; the passes
+// run back to back on one wave (HIPNLP_WAVE_SYNC between them).
+constexpr int FK_TASKS = 3 * NJ;
+template <class Em> HD void t_fk_rot(Ctx<Em>& cx, int t) {  // row r of R_j = row r of R_b L_a1 L_a2 ... L_j ; axis
     KnotScratch& s = cx.s;
-    const int leaf = t / 3, r = t - 3 * leaf;
-    if (leaf >= cx.kt.n_leaf) return;
-    double R0 = s.Rb[3 * r], R1 = s.Rb[3 * r + 1], R2 = s.Rb[3 * r + 2];
-    double o = 0.0;
-    const int len = cx.kt.path_len[leaf];
+    const int j = t / 3, r = t - 3 * j;
+    double v0 = s.Rb[3 * r], v1 = s.Rb[3 * r + 1], v2 = s.Rb[3 * r + 2];
     HIPNLP_UNROLL
     for (int q = 0; q < 8; ++q) {
-        if (q >= len) break;
-        const int i = cx.kt.chain_link[leaf][q];
-        const double* L = s.Rchain[8 * leaf + q];
-        const double* of = cx.kt.chain_ofix[leaf][q];
-        const double* ax = cx.kt.chain_axis[leaf][q];
-        o += R0 * of[0] + R1 * of[1] + R2 * of[2];
-        const double N0 = R0 * L[0] + R1 * L[3] + R2 * L[6];
-        const double N1 = R0 * L[1] + R1 * L[4] + R2 * L[7];
-        const double N2 = R0 * L[2] + R1 * L[5] + R2 * L[8];
-        const double a = N0 * ax[0] + N1 * ax[1] + N2 * ax[2];
-        R0 = N0; R1 = N1; R2 = N2;
-        s.Rw[i][3 * r] = N0; s.Rw[i][3 * r + 1] = N1; s.Rw[i][3 * r + 2] = N2;
-        s.ow[i][r] = o;
-        s.aw[i - 1][r] = a;
+        const double* L = s.Lj[cx.kt.anc[j][q]];
+        const double n0 = v0 * L[0] + v1 * L[3] + v2 * L[6];
+        const double n1 = v0 * L[1] + v1 * L[4] + v2 * L[7];
+        const double n2 = v0 * L[2] + v1 * L[5] + v2 * L[8];
+        v0 = n0; v1 = n1; v2 = n2;
     }
+    s.Rw[j + 1][3 * r] = v0; s.Rw[j + 1][3 * r + 1] = v1; s.Rw[j + 1][3 * r + 2] = v2;
+    const double* ax = cx.kt.axis[j];
+    s.aw[j][r] = v0 * ax[0] + v1 * ax[1] + v2 * ax[2];
 }
-// link velocities along the chains (needs all components of o and a, stored by the row-lanes above; the
-// two groups run back to back on the same wave): lane (leaf, r)
-template <class Em> HD void t_vel_chain(Ctx<Em>& cx, int t) {
+template <class Em> HD void t_fk_terms(Ctx<Em>& cx, int t) {  // T_j = R_parent o_fix_j
     KnotScratch& s = cx.s;
     HIPNLP_WAVE_SYNC();
-    const int leaf = t / 3, r = t - 3 * leaf;
-    if (leaf >= cx.kt.n_leaf) return;
-    double w = s.omega[r], vo = 0.0;
-    const int len = cx.kt.path_len[leaf];
+    const int j = t / 3, r = t - 3 * j;
+    const double* Rp = s.Rw[cx.kt.par_link[j]] + 3 * r;
+    const double* of = cx.kt.o_fix[j];
+    s.Tj[j][r] = Rp[0] * of[0] + Rp[1] * of[1] + Rp[2] * of[2];
+}
+template <class Em> HD void t_fk_pos(Ctx<Em>& cx, int t) {  // o_j = sum T_anc ; w_j = omega + sum a_anc sdot_anc
+    KnotScratch& s = cx.s;
+    HIPNLP_WAVE_SYNC();
+    const int j = t / 3, r = t - 3 * j;
+    double o = 0.0, w = s.omega[r];
     HIPNLP_UNROLL
     for (int q = 0; q < 8; ++q) {
-        if (q >= len) break;
-        const int i = cx.kt.chain_link[leaf][q], j = i - 1;
-        const double sd = s.x[SD_ + j];
-        w += s.aw[j][r] * sd;
-        vo += cross_comp(s.ow[i], s.aw[j], r) * sd;
-        s.wv[i][r] = w;
-        s.vo[i][r] = vo;
+        const int a = cx.kt.anc[j][q];
+        o += s.Tj[a][r];
+        w += s.aw[a][r] * s.x[SD_ + a];  // padding slot: aw[NJ] = 0
     }
+    s.ow[j + 1][r] = o;
+    s.wv[j + 1][r] = w;
+}
+template <class Em> HD void t_fk_uterms(Ctx<Em>& cx, int t) {  // U_j = (o_j x a_j) sdot_j
+    KnotScratch& s = cx.s;
+    HIPNLP_WAVE_SYNC();
+    const int j = t / 3, r = t - 3 * j;
+    s.Uj[j][r] = cross_comp(s.ow[j + 1], s.aw[j], r) * s.x[SD_ + j];
+}
+template <class Em> HD void t_fk_vel(Ctx<Em>& cx, int t) {  // vO_j = sum U_anc
+    KnotScratch& s = cx.s;
+    HIPNLP_WAVE_SYNC();
+    const int j = t / 3, r = t - 3 * j;
+    double v = 0.0;
+    HIPNLP_UNROLL
+    for (int q = 0; q < 8; ++q) v += s.Uj[cx.kt.anc[j][q]][r];
+    s.vo[j + 1][r] = v;
 }
 
 // --- centroidal momentum dynamics (T7 on E1): lanes (c, e) 48 entry tasks + lanes 48..59 row tasks -----------
@@ -620,7 +631,7 @@ template <class Em> HD void t_links(Ctx<Em>& cx, int i) {
     for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) Rt[3 * r + q] = s.Rw[i][3 * q + r];
     matmul3(RI, Rt, Iw);
     const double c2 = dot3(c, c);
-    double* cp = s.comp[i];
+    double* cp = s.own[i];
     double h[3], I6[6];
     cp[CM] = m;
     for (int r = 0; r < 3; ++r) { h[r] = m * c[r]; cp[CH + r] = h[r]; }
@@ -665,40 +676,20 @@ template <class Em> HD void t_frames(Ctx<Em>& cx, int f) {
 // running sums in registers.  Stage 2: one lane finishes the links that have several children and their
 // ancestors (reverse topological order), then the totals.  Contact-point kinematics ride along.
 // ===================================================================================================
-constexpr int COMP_CHAIN_TASKS = MAX_LEAF * 16;
-template <class Em> HD void t_composite_chain(Ctx<Em>& cx, int t) {  // lane (leaf, component r)
+// composite (subtree) quantities as DESCENDANT SUMS: lane (link i, component r), 384 tasks spread over the four waves
+constexpr int COMP_TASKS_PER_WAVE = NL * 16 / 4;
+template <class Em> HD void t_composite(Ctx<Em>& cx, int t) {
     KnotScratch& s = cx.s;
-    const int leaf = t >> 4, r = t & 15;
-    if (leaf >= cx.kt.n_leaf) return;
-    const int len = cx.kt.up_len[leaf];
+    const int i = t >> 4, r = t & 15;
     double acc = 0.0;
     HIPNLP_UNROLL
-    for (int q = 0; q < 8; ++q) {
-        if (q >= len) break;
-        const int i = cx.kt.up_link[leaf][q];
-        acc += s.comp[i][r];
-        s.comp[i][r] = acc;
-    }
+    for (int n = 0; n < NL; ++n) acc += s.own[cx.kt.desc[i][n]][r];  // padding slot: own[NL] = 0
+    s.comp[i][r] = acc;
 }
-template <class Em> HD void t_composite_rest(Ctx<Em>& cx, int r) {  // lane = component r (16); runs right behind the chains on the same wave
-    KnotScratch& s = cx.s;
-    HIPNLP_WAVE_SYNC();
-    const int n_ops = cx.kt.s2_n;
-    int cur = -1, prev = -1;
-    double acc = 0.0, prev_val = 0.0;
-    HIPNLP_UNROLL
-    for (int n = 0; n < 12; ++n) {
-        if (n >= n_ops) break;
-        const int dst = cx.kt.s2_dst[n], src = cx.kt.s2_src[n];
-        if (dst != cur) {
-            if (cur >= 0) { s.comp[cur][r] = acc; prev = cur; prev_val = acc; }
-            cur = dst;
-            acc = s.comp[dst][r];
-        }
-        acc += (src == prev) ? prev_val : s.comp[src][r];
-    }
-    if (cur >= 0) s.comp[cur][r] = acc;
-}
+template <class Em> HD void t_composite_w0(Ctx<Em>& cx, int t) { t_composite(cx, t); }
+template <class Em> HD void t_composite_w1(Ctx<Em>& cx, int t) { t_composite(cx, t + COMP_TASKS_PER_WAVE); }
+template <class Em> HD void t_composite_w2(Ctx<Em>& cx, int t) { t_composite(cx, t + 2 * COMP_TASKS_PER_WAVE); }
+template <class Em> HD void t_composite_w3(Ctx<Em>& cx, int t) { t_composite(cx, t + 3 * COMP_TASKS_PER_WAVE); }
 template <class Em> HD void t_pkin(Ctx<Em>& cx, int c) {
     KnotScratch& s = cx.s;
     const int f = c < 4 ? 0 : 1;
@@ -894,20 +885,21 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
 // Groups of one phase run concurrently on different waves; BARRIER separates phases.
 // ---------------------------------------------------------------------------------------------------
 #define HIPNLP_KNOT_PROGRAM(R, BARRIER)                                                   \
-    R(0, t_points_vec, 3 * NC)                                                            \
+    R(0, t_points_vec, 3 * NC) R(0, t_small, 4)                                           \
     R(1, t_points_scalar, NC) R(1, t_points_cost, 3) R(1, t_dyn, 7 + NJ + 3) R(1, t_unitq, 1) \
     R(2, t_joints, NJ) R(2, t_joint_cost, 1)                                              \
-    R(3, t_base, 1) R(3, t_small, 4) R(3, t_feet, 3)                                      \
+    R(3, t_base, 1) R(3, t_feet, 3)                                                       \
     BARRIER                                                                               \
-    R(0, t_fk_chain, FK_TASKS) R(0, t_vel_chain, FK_TASKS)                                \
+    R(0, t_fk_rot, FK_TASKS) R(0, t_fk_terms, FK_TASKS) R(0, t_fk_pos, FK_TASKS) R(0, t_fk_uterms, FK_TASKS) R(0, t_fk_vel, FK_TASKS) \
     R(1, t_hdyn, HDYN_TASKS)                                                              \
     R(2, t_foot_costs, FOOT_TASKS) R(2, t_foot_cost_sum, 2)                               \
     BARRIER                                                                               \
-    R(0, t_links, NL) R(1, t_frames, 3) R(3, t_ends, ENDS_TASKS)                          \
+    R(0, t_links, NL) R(1, t_frames, 3)                                                   \
     BARRIER                                                                               \
-    R(0, t_composite_chain, COMP_CHAIN_TASKS) R(0, t_composite_rest, 16) R(1, t_pkin, NC) \
+    R(0, t_composite_w0, COMP_TASKS_PER_WAVE) R(1, t_composite_w1, COMP_TASKS_PER_WAVE)   \
+    R(2, t_composite_w2, COMP_TASKS_PER_WAVE) R(3, t_composite_w3, COMP_TASKS_PER_WAVE) R(1, t_pkin, NC) \
     BARRIER                                                                               \
-    R(0, t_columns, NJ + 3)                                                               \
+    R(0, t_columns, NJ + 3) R(3, t_ends, ENDS_TASKS)                                      \
     BARRIER                                                                               \
     R(0, t_kinc, 3 * NC) R(1, t_comc, 15) R(2, t_cmmc, 15) R(3, t_feetd, 5) R(3, t_ends_finish, ENDS_FINISH_TASKS) \
     BARRIER

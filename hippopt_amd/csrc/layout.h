@@ -324,40 +324,26 @@ struct Layout {
         }
         for (int j = 0; j < NJ; ++j)
             if (kt.leg_pos[0][j] >= 0 && kt.leg_pos[1][j] >= 0) { err = "robot model: the two leg chains must be disjoint"; return false; }
-        // chain decomposition: one root->leaf joint path per leaf link; single-child up-chains; the rest as add-ops
-        kt.n_leaf = 0;
-        for (int j = 0; j < NJ; ++j) for (int n = 0; n < 4; ++n) kt.chain_slot[j][n] = -1;
-        std::vector<bool> covered(NL, false);
-        for (int l = 1; l < NL; ++l) {
-            if (nchild[l] != 0) continue;
-            if (kt.n_leaf >= MAX_LEAF) { err = "robot model: too many leaf links"; return false; }
-            const int leaf = kt.n_leaf++;
+        // ancestor lists (path root -> j) and descendant lists (subtree of link i)
+        for (int j = 0; j < NJ; ++j) {
+            kt.par_link[j] = md.parent[j];
+            for (int i = 0; i < 3; ++i) kt.o_fix[j][i] = md.o_fix[j][i];
             std::vector<int> path;
-            for (int q = l; q > 0; q = md.parent[q - 1]) path.push_back(q - 1);
+            for (int q = j + 1; q > 0; q = md.parent[q - 1]) path.push_back(q - 1);
             if (path.size() > 8) { err = "robot model: a chain is deeper than 8 joints"; return false; }
             std::sort(path.begin(), path.end());
-            kt.path_len[leaf] = int(path.size());
-            for (size_t q = 0; q < path.size(); ++q) {
-                const int j = path[q];
-                kt.chain_link[leaf][q] = j + 1;
-                for (int i = 0; i < 3; ++i) { kt.chain_ofix[leaf][q][i] = md.o_fix[j][i]; kt.chain_axis[leaf][q][i] = md.axis[j][i]; }
-                int n = 0;
-                while (n < 4 && kt.chain_slot[j][n] >= 0) ++n;
-                if (n >= 4) { err = "robot model: a joint is shared by more than 4 chains"; return false; }
-                kt.chain_slot[j][n] = 8 * leaf + int(q);
-            }
-            int n = 0;
-            for (int q = l; q > 0 && nchild[q] <= 1; q = md.parent[q - 1]) { kt.up_link[leaf][n++] = q; covered[size_t(q)] = true; }
-            kt.up_len[leaf] = n;
+            for (int q = 0; q < 8; ++q) kt.anc[j][q] = q < int(path.size()) ? path[size_t(q)] : NJ;
         }
-        kt.s2_n = 0;
-        for (int l = NL - 1; l >= 0; --l)
-            if (!covered[size_t(l)])
-                for (int n = 0; n < nchild[l]; ++n) {
-                    if (kt.s2_n >= 12) { err = "robot model: too many branching links"; return false; }
-                    kt.s2_dst[kt.s2_n] = l;
-                    kt.s2_src[kt.s2_n++] = child[l][n];
-                }
+        for (int i = 0; i < NL; ++i) {
+            int n = 0;
+            for (int l = 0; l < NL; ++l) {
+                bool in = false;
+                for (int q = l; ; q = md.parent[q - 1]) { if (q == i) { in = true; break; } if (q == 0) break; }
+                if (in) kt.desc[i][n++] = int16_t(l);
+            }
+            for (; n < NL; ++n) kt.desc[i][n] = int16_t(NL);
+        }
+        (void)nchild; (void)child;
         for (int i = 0; i < 105; ++i) {
             int slot, desc;
             const int var = final_row_var(i, &slot, &desc);

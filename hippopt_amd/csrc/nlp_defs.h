@@ -48,18 +48,14 @@ struct KinTables {
     int32_t leg_joint[2][LEG_PATH];
     int32_t chest_pos[NJ];      // position in the root->chest path or -1
     int32_t frame_link[3];
-    // chain decomposition of the tree (one lane group walks one root->leaf chain; no per-level barriers)
-    int32_t n_leaf;                          // <= MAX_LEAF
-    int32_t path_len[MAX_LEAF];
-    int32_t chain_link[MAX_LEAF][8];         // link reached by step q of chain l
-    int32_t chain_slot[NJ][4];               // chain slots (8*l + q) in which joint j appears, -1 = unused
-    int32_t up_len[MAX_LEAF], up_link[MAX_LEAF][8];  // links from leaf l upward while they have a single child (composite pass, stage 1)
-    int32_t s2_n, s2_dst[12], s2_src[12];    // stage 2: comp[dst] += comp[src], in dependency order
+    // tree as ancestor / descendant lists: every lane sums over its own list, no loop-carried dependence
+    int32_t par_link[NJ];       // parent link of joint j
+    int32_t anc[NJ][8];         // joints on the path root -> j (inclusive, ascending), padded with NJ (identity / zero slot)
+    int16_t desc[NL][NL];       // links of the subtree rooted at link i (inclusive), padded with NL (zero slot)
     // horizon-end rows
     int16_t fin_var[105], fin_slot[105], fin_desc[105];  // variable / slot among the 81 variable rows / descriptor index (3c+i) or -1
     int16_t per_var[84];
-    double chain_ofix[MAX_LEAF][8][3], chain_axis[MAX_LEAF][8][3];  // o_fix / axis in chain order (addresses independent of loaded indices)
-    double R_fix[NJ][9], axis[NJ][3];
+    double R_fix[NJ][9], o_fix[NJ][3], axis[NJ][3];
     double mass[NL], com[NL][3], inertia[NL][9];
     double frame_R[3][9], frame_o[3][3];
     double total_mass;

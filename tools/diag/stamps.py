@@ -36,19 +36,24 @@ if __name__ == "__main__":
     eng.set_params(p)
     for _ in range(20):
         eng.eval(x)
-    out = np.zeros((100 * batch, 4, 16), np.uint64)
+    import re
+    prog = open(os.path.join(ROOT, "hippopt_amd", "csrc", "knot_body.h")).read()
+    prog = prog[prog.index("#define HIPNLP_KNOT_PROGRAM"):]
+    groups = re.findall(r"R\((\d), (\w+),", prog)
+    out = np.zeros((100 * batch, 4, 64, 2), np.uint64)
     eng.lib.hipnlp_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
     eng.lib.hipnlp_debug_stamps(eng.h, out.ctypes.data_as(C.c_void_p))
-    n = int(out[0, 0, 15])
-    t = out[:, :, :n + 1].astype(np.int64)
-    t0 = t[:, :, 0].min(axis=1)[:, None, None]
-    rel = t - t0                      # [block][wave][stamp]: arrival of each wave at barrier s (stamp 0 = after the load barrier)
-    names = ["start", "A", "B fk|hdyn|foot", "C links|frames|ends", "D composite|pkin", "F columns", "G kinc|comc|cmmc|feetd", "end (copy-out)"]
-    med = np.median(rel, axis=0)      # [wave][stamp]
-    print("arrival (cycles since block start) of wave 0..3 at each barrier; the latest wave bounds the phase")
-    prev = 0.0
-    for sidx in range(n + 1):
-        row = med[:, sidx]
-        print("%-26s w0 %7.0f  w1 %7.0f  w2 %7.0f  w3 %7.0f   phase %6.0f" % (names[sidx] if sidx < len(names) else "s%d" % sidx, row[0], row[1], row[2], row[3], row.max() - prev))
-        prev = row.max()
+    blk = out[len(out) // 2]  # an interior knot
+    t0 = min(int(blk[w, 0, 1]) for w in range(4))
+    print("interior knot: per wave, end time of each group / arrival at each barrier (cycles since block start) and duration")
+    for w in range(4):
+        n = int(out[len(out) // 2, w, 63, 0])
+        prev = int(blk[w, 0, 1]) - t0
+        line = []
+        for i in range(1, n):
+            gid, tm = int(blk[w, i, 0]), int(blk[w, i, 1]) - t0
+            name = groups[gid][1] if gid < 1000 else ("|B%d" % (gid - 1000) if gid < 2000 else "END")
+            line.append("%s %d(+%d)" % (name, tm, tm - prev))
+            prev = tm
+        print("wave %d: " % w + "  ".join(line))
     print("kernel ms:", eng.last_kernel_ms())
