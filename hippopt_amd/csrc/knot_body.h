@@ -262,6 +262,10 @@ template <class Em> HD void t_dyn(Ctx<Em>& cx, int e) {
     else { i = e - 7 - NJ; L = 3; X = COM_ + i; Y = H_ + i; kin = RK_COMDYN_IN; gslot = gs::COMDYN; gx0 = gs::COM_X0; jslot = js::COMDYN; }
     const int kout = kin + 1, kx0 = kin + 2;
     Em& em = cx.em;
+    // padding slots of the ancestor / descendant lists (identity rotation, zero terms), one element per lane
+    if (e < 16) s.own[NL][e] = 0.0;
+    if (e < 9) s.Lj[NJ][e] = (e % 4 == 0) ? 1.0 : 0.0;
+    if (e < 3) { s.Tj[NJ][e] = 0.0; s.Uj[NJ][e] = 0.0; s.aw[NJ][e] = 0.0; }
     em.G(gslot + i, row_id(kin, 0, i), s.x[X] - (s.xm[X] + half * (s.xm[Y] + s.x[Y])));
     em.G(gx0 + i, row_id(kx0, 0, i), s.x[X]);
     em.J(jslot + 0 * L + i, row_id(kin, 0, i), X, 1.0);
@@ -431,9 +435,7 @@ template <class Em> HD void t_base(Ctx<Em>& cx, int) {
     }
     // root link pose and velocity in base-centred coordinates
     for (int i = 0; i < 9; ++i) s.Rw[0][i] = s.Rb[i];
-    for (int i = 0; i < 3; ++i) { s.ow[0][i] = 0.0; s.wv[0][i] = s.omega[i]; s.vo[0][i] = 0.0; s.Tj[NJ][i] = 0.0; s.Uj[NJ][i] = 0.0; s.aw[NJ][i] = 0.0; }
-    for (int i = 0; i < 9; ++i) s.Lj[NJ][i] = (i % 4 == 0) ? 1.0 : 0.0;
-    for (int i = 0; i < 16; ++i) s.own[NL][i] = 0.0;
+    for (int i = 0; i < 3; ++i) { s.ow[0][i] = 0.0; s.wv[0][i] = s.omega[i]; s.vo[0][i] = 0.0; }
 }
 
 // ===================================================================================================
