@@ -179,6 +179,16 @@ def main():
                          "traffic": traffic, "kernel": "hipnlp_knot_kernel", "kernel_ms": kern_ms, "launch_ms": launch_ms,
                          "launches_timed": nprof, "algorithmic_bytes_per_knot": bytes_knot, "knots_per_launch": local_knots},
         }
+        if world == 1 and not knot_sharded:
+            # PCIe-inclusive rate of the host-buffer boundary (hipnlp_eval: H2D x, launch, D2H f/grad/g/jac); never `value`
+            eng.eval(x_np)
+            t1 = time.perf_counter()
+            reps = 30
+            for i in range(reps):
+                eng.eval(x_np)
+            dt_host = (time.perf_counter() - t1) / reps
+            line["pcie_inclusive"] = {"ms_per_call": 1e3 * dt_host, "knots_per_s": horizon * args.batch / dt_host,
+                                      "note": "hipnlp_eval with host buffers (pinned staging), all four outputs copied back"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(settings, model, x_np[0], p_np[0])
             line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
