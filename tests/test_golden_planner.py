@@ -1,0 +1,91 @@
+"""The oracle against golden vectors produced by EXECUTING THE REFERENCE'S OWN planner code
+(hippopt/turnkey_planners/humanoid_kinodynamic/planner.py and everything it calls in hippopt.base,
+hippopt.integrators, hippopt.robot_planning) on a functional stand-in of the CasADi / adam / liecasadi APIs
+(tools/gen_planner_fixtures.py; the third-party arithmetic itself stays unpinned).
+This pins the ASSEMBLY: row order, names, knot ranges, canonical bounds, cost scaling and every expression as coded."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from hippopt_amd import _abi
+from hippopt_amd.kinodyn_settings import periodic_step_settings, single_step_settings
+from oracle_lib import Oracle
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-11
+
+
+def settings_for(meta, model):
+    N = meta["horizon"]
+    if meta["config"] == "single":
+        return single_step_settings(N, model)
+    st = periodic_step_settings(N, model)
+    if meta["config"] == "costends":
+        st.final_state_expression_type = _abi.EXPR_MINIMIZE
+        st.periodicity_expression_type = _abi.EXPR_MINIMIZE
+        st.final_state_expression_weight, st.periodicity_expression_weight = 2.0, 0.5
+        st.contacts_centroid_cost_multiplier = 100.0
+    return st
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if np.size(a) else 0.0
+
+
+@pytest.mark.parametrize("name", ["planner_periodic_N3", "planner_single_N3", "planner_costends_N2"])
+def test_oracle_matches_reference_planner_assembly(model, name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    st = settings_for(meta, model)
+    o = Oracle(st, model)
+    x, p = z["x"], z["p"]
+    assert (o.n, o.m) == (x.size, z["g"].size)
+    f, grad, g, jac = o.eval(x, p)
+    lb, ub = o.bounds(p)
+    # values, in the reference's row order
+    assert rel(g, z["g"]) < TOL
+    assert np.array_equal(lb, z["lbg"]) and np.array_equal(ub, z["ubg"])
+    assert abs(f - float(z["f"])) / max(1.0, abs(float(z["f"]))) < TOL
+    assert rel(grad, z["grad"]) < TOL
+    # Jacobian: every numeric non-zero of the reference run is in the oracle's structural pattern with the same value;
+    # structural entries the reference run did not report are (numerically) zero
+    ir, jc = o.sparsity()
+    pos = {(int(r), int(c)): i for i, (r, c) in enumerate(zip(ir, jc))}
+    seen = np.zeros(o.nnz, bool)
+    for r, c, v in zip(z["jac_row"], z["jac_col"], z["jac_val"]):
+        i = pos.get((int(r), int(c)))
+        if i is None:
+            assert abs(v) < 1e-12, ("entry outside the pattern", r, c, v)  # e.g. round-off of an identically-zero derivative
+            continue
+        seen[i] = True
+        assert abs(jac[i] - v) <= TOL * max(1.0, abs(v)), (r, c, jac[i], v)
+    assert np.max(np.abs(jac[~seen]), initial=0.0) < 1e-12
+    # row-block directory: names and sizes in the reference's subject_to order
+    blocks = o.row_blocks()
+    names, rows = [str(s) for s in z["names"]], z["rows"]
+    expect = []
+    for bname, first, nrows, k0, nk in blocks:
+        if bname.endswith("[0]"):      # x0 rows: one named constraint per state variable "name[0]{0}"
+            expect.append((bname + "{0}", nrows))
+        elif nk == 1 and k0 == st.horizon_length - 1 and bname in ("final_state_expression", "periodicity_expression"):
+            expect.append((bname, nrows))
+        else:
+            for k in range(k0, k0 + nk):
+                is_dyn = bname.endswith("_dynamics")
+                expect.append((bname + "[%d]" % k + ("{0}" if is_dyn else ""), nrows))
+    got = list(zip(names, [int(r) for r in rows]))
+    # the reference interleaves knots of one constraint type the same way (type-major, knot-minor)
+    assert got == expect
+
+
+def test_fixture_cost_names_cover_the_cost_terms():
+    z = np.load(os.path.join(GOLD, "planner_periodic_N3.npz"))
+    names = [str(s) for s in z["cost_names"]]
+    bases = sorted({re.sub(r"\[\d+\]$", "", n).split(".")[-1] for n in names})
+    for term in ("swing_height_regularization", "u_v_regularization", "f_dot_regularization", "com_velocity_error",
+                 "frame_quaternion_error", "base_quaternion_error", "base_quaternion_velocity_error", "joint_positions_error",
+                 "contacts_centroid_cost", "f_regularization", "left_yaw_regularization", "right_yaw_regularization"):
+        assert any(b.endswith(term) for b in bases), term

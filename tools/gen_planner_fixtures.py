@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Generate golden vectors of the kinodynamic NLP by EXECUTING THE REFERENCE'S OWN PYTHON in this container:
+  hippopt.turnkey_planners.humanoid_kinodynamic.planner.Planner.__init__           (planner.py:26-176)
+  -> MultipleShootingSolver.add_dynamics / add_expression_to_horizon / initial / final
+  -> Problem.add_expression / add_cost / add_constraint, OptiSolver.add_cost / add_constraint
+  -> robot_planning/expressions/*.py, integrators/implicit_trapezoid.py, utilities/planar_terrain.py
+on top of FUNCTIONAL STAND-INS of the third-party modules that cannot be installed here
+(tools/casadi_standin: casadi, liecasadi, adam.casadi on the synthetic robot).
+
+What this pins: the assembly of the NLP exactly as the reference code performs it — constraint order, names, knot
+ranges (k>=0 / k>=1), trapezoid coupling, cost scaling, every formula of robot_planning/expressions as coded.
+What it does NOT pin: CasADi's own numerics / AD / Opti canonicalisation (restated in the stand-in), adam's FK/CoM/CMM
+on the real URDF, liecasadi.  DESIGN.md §7 states this in every parity claim.
+
+Output: tests/golden/planner_<config>_N<horizon>.npz with x, p, g, lbg, ubg, f, grad f, the non-zeros of jac g and the
+constraint names with their row counts.  Run:  python3 tools/gen_planner_fixtures.py
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (os.path.join(HERE, "refstub"), os.path.join(HERE, "casadi_standin"), "/root/reference/src", ROOT):
+    sys.path.insert(0, p)
+sys.path.insert(0, os.path.join(HERE, "casadi_standin"))
+
+import numpy as np  # noqa: E402
+import casadi as cs  # noqa: E402  (the stand-in)
+import adam.casadi  # noqa: E402   (the stand-in)
+
+import hippopt as hp  # noqa: E402
+import hippopt.robot_planning as hp_rp  # noqa: E402
+import hippopt.turnkey_planners.humanoid_kinodynamic.planner as walking_planner  # noqa: E402
+import hippopt.turnkey_planners.humanoid_kinodynamic.settings as walking_settings  # noqa: E402
+
+from hippopt_amd import _abi  # noqa: E402
+from hippopt_amd.kinodyn_settings import periodic_step_settings, single_step_settings  # noqa: E402
+from hippopt_amd.robot_model import JOINT_NAMES, synthetic_ergocub  # noqa: E402
+from hippopt_amd.synthetic import make_workload  # noqa: E402
+
+EXPR = {_abi.EXPR_SKIP: hp.ExpressionType.skip, _abi.EXPR_SUBJECT_TO: hp.ExpressionType.subject_to, _abi.EXPR_MINIMIZE: hp.ExpressionType.minimize}
+
+
+def reference_settings(mine):
+    """The reference's Settings object filled from the numeric mirror (same constants as the main scripts)."""
+    s = walking_settings.Settings()
+    s.robot_urdf = "synthetic://ergocub-topology"
+    s.joints_name_list = list(JOINT_NAMES)
+    s.root_link = "root_link"
+    s.horizon_length = mine.horizon_length
+    s.time_step = mine.time_step
+    s.contact_points = hp_rp.FeetContactPointDescriptors()
+    s.contact_points.left = hp_rp.ContactPointDescriptor.rectangular_foot("l_sole", 0.232, 0.1, np.array([0.116, 0.05, 0.0]))
+    s.contact_points.right = hp_rp.ContactPointDescriptor.rectangular_foot("r_sole", 0.232, 0.1, np.array([0.116, 0.05, 0.0]))
+    for k in ("planar_dcc_height_multiplier", "dcc_gain", "dcc_epsilon", "static_friction", "maximum_velocity_control",
+              "maximum_force_derivative", "maximum_angular_momentum", "minimum_com_height", "minimum_feet_lateral_distance",
+              "maximum_feet_relative_height", "maximum_joint_positions", "minimum_joint_positions", "maximum_joint_velocities",
+              "minimum_joint_velocities", "joint_regularization_cost_weights", "contacts_centroid_cost_multiplier",
+              "com_linear_velocity_cost_weights", "com_linear_velocity_cost_multiplier", "desired_frame_quaternion_cost_multiplier",
+              "base_quaternion_cost_multiplier", "base_quaternion_velocity_cost_multiplier", "joint_regularization_cost_multiplier",
+              "force_regularization_cost_multiplier", "foot_yaw_regularization_cost_multiplier", "swing_foot_height_cost_multiplier",
+              "contact_velocity_control_cost_multiplier", "contact_force_control_cost_multiplier"):
+        setattr(s, k, getattr(mine, k))
+    s.desired_frame_quaternion_cost_frame_name = "chest"
+    s.final_state_expression_type = EXPR[mine.final_state_expression_type]
+    s.final_state_expression_weight = mine.final_state_expression_weight
+    s.periodicity_expression_type = EXPR[mine.periodicity_expression_type]
+    s.periodicity_expression_weight = mine.periodicity_expression_weight
+    s.casadi_function_options = {"cse": True}
+    s.casadi_opti_options = {"expand": True, "detect_simple_bounds": True}
+    s.casadi_solver_options = {}
+    assert s.is_valid()
+    return s
+
+
+def is_parametric(e, var_ids):
+    return not any(s._id in var_ids for s in cs.symvar(e))
+
+
+def canon(c, var_ids):
+    """CasADi Opti canonical form of one subject_to expression -> (g expr, lb expr/val, ub expr/val)."""
+    if c.is_op(cs.OP_EQ):
+        a, b = c.dep(0), c.dep(1)
+        if is_parametric(a, var_ids):
+            return b, a, a
+        if is_parametric(b, var_ids):
+            return a, b, b
+        return a - b, cs.DM(0.0), cs.DM(0.0)
+    if c.is_op(cs.OP_LE) or c.is_op(cs.OP_LT):
+        a, b = c.dep(0), c.dep(1)
+        if a.op == "cmp":  # lb <= expr <= ub
+            lb, ex = a.dep(0), a.dep(1)
+            assert is_parametric(lb, var_ids) and is_parametric(b, var_ids)
+            return ex, lb, b
+        if is_parametric(a, var_ids):
+            return b, a, cs.DM(cs.inf)
+        if is_parametric(b, var_ids):
+            return a, cs.DM(-cs.inf), b
+        return a - b, cs.DM(-cs.inf), cs.DM(0.0)
+    raise ValueError("unsupported constraint")
+
+
+def generate(tag, mine, model, seed):
+    adam.casadi.STANDIN_MODEL = model
+    planner = walking_planner.Planner(reference_settings(mine))
+    solver = planner.optimization_solver
+    opti = solver._solver
+    N = mine.horizon_length
+    x, p = make_workload(mine, model, 1, seed)
+    x, p = x[0], p[0]
+    nx = sum(v.numel() for v in opti.variables)
+    npar = sum(q.numel() for q in opti.parameters)
+    assert nx == x.size and npar == p.size, (nx, x.size, npar, p.size)
+    # names in creation order must match our flat layout (already pinned by kinodyn_structure.json)
+    values, seeds, off = {}, {}, 0
+    for v in opti.variables:
+        k = v.numel()
+        values[v._id] = x[off:off + k].reshape(v.shape, order="F")
+        sd = np.zeros(v.shape + (nx,))
+        for i in range(k):
+            sd[i % v.shape[0], i // v.shape[0], off + i] = 1.0
+        seeds[v._id] = sd
+        off += k
+    off = 0
+    for q in opti.parameters:
+        k = q.numel()
+        values[q._id] = p[off:off + k].reshape(q.shape, order="F")
+        off += k
+    var_ids = {v._id for v in opti.variables}
+    names, rows, gs, lbs, ubs = [], [], [], [], []
+    for name, c in solver.get_constraint_expressions().items():
+        g, lb, ub = canon(c, var_ids)
+        gs.append(g)
+        ones = cs.DM(np.ones(g.shape))
+        lbs.append(lb * ones)
+        ubs.append(ub * ones)
+        names.append(name)
+        rows.append(g.numel())
+    cost_names = list(solver.get_cost_expressions().keys())
+    f_expr = solver.cost_function()
+    G = cs.vertcat(*gs)
+    (gv, fv), (gt, ft) = cs.evaluate([G, f_expr], values, seeds, nx)
+    (lbv, ubv), _ = cs.evaluate([cs.vertcat(*lbs), cs.vertcat(*ubs)], values)
+    J = gt[:, 0, :] if gt is not None else np.zeros((G.shape[0], nx))
+    grad = ft[0, 0, :] if ft is not None else np.zeros(nx)
+    ir, jc = np.nonzero(J)
+    order = np.lexsort((ir, jc))
+    ir, jc = ir[order], jc[order]
+    out = os.path.join(ROOT, "tests", "golden", "planner_%s_N%d.npz" % (tag, N))
+    np.savez_compressed(out, x=x, p=p, g=gv.reshape(-1), lbg=lbv.reshape(-1), ubg=ubv.reshape(-1), f=float(fv), grad=grad,
+                        jac_row=ir.astype(np.int32), jac_col=jc.astype(np.int32), jac_val=J[ir, jc],
+                        names=np.array(names), rows=np.array(rows, np.int32), cost_names=np.array(cost_names),
+                        meta=np.array(json.dumps({"config": tag, "horizon": N, "seed": seed, "final": mine.final_state_expression_type,
+                                                  "periodicity": mine.periodicity_expression_type,
+                                                  "generator": "reference planner.py on tools/casadi_standin (stand-in, not CasADi)"})))
+    print(tag, "N", N, "n", nx, "m", int(G.shape[0]), "nnz(numeric)", len(ir), "f", float(fv), "->", os.path.relpath(out, ROOT))
+
+
+def main():
+    model = synthetic_ergocub()
+    generate("periodic", periodic_step_settings(3, model), model, 4003)
+    generate("single", single_step_settings(3, model), model, 4004)
+    st = periodic_step_settings(2, model)
+    st.final_state_expression_type = _abi.EXPR_MINIMIZE
+    st.periodicity_expression_type = _abi.EXPR_MINIMIZE
+    st.final_state_expression_weight, st.periodicity_expression_weight = 2.0, 0.5
+    st.contacts_centroid_cost_multiplier = 100.0
+    generate("costends", st, model, 4005)
+
+
+if __name__ == "__main__":
+    main()
