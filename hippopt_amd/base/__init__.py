@@ -1,0 +1,6 @@
+from .optimization_object import (  # noqa: F401
+    CompositeType, OptimizationObject, OverridableParameter, OverridableVariable, Parameter, StorageType,
+    TimeExpansion, Variable, default_composite_field, default_storage_field, default_storage_metadata, time_varying_metadata,
+)
+from .horizon import extend_structure_to_horizon, flattened_names  # noqa: F401
+from .problem import ExpressionType, Output, ProblemNotSolvedException  # noqa: F401

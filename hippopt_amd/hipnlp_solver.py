@@ -1,0 +1,262 @@
+"""HipNlpSolver — the solver plugin that stands where hippopt's `OptiSolver` stands (reference: base/opti_solver.py:49-638,
+abstract interface base/optimization_solver.py:25-96), for the kinodynamic NLP.
+
+`OptiSolver` receives symbolic `cs.MX` costs/constraints and lets CasADi evaluate them on one CPU thread.  This plugin owns
+the *typed* kinodynamic problem instead: the flat layout of the structure (same names / order as the reference), the
+parameter vector, and an engine handle (`HipNlp`, libhipnlp.so) that evaluates f, grad f, g, jac g of all knots in one HIP
+launch per callback.  `add_cost` / `add_constraint` with symbolic expressions are therefore not available (the reference's
+planner list is built into the engine); everything else keeps the reference's method names and semantics.
+
+The NLP driver: IPOPT (through `cyipopt`) when importable; otherwise SciPy's `trust-constr` as a stand-in for small horizons
+(IPOPT is not installed in the build image).  Both consume exactly the IPOPT callback quartet of INTEGRATION.md.
+"""
+import copy
+import logging
+
+import numpy as np
+
+from . import _abi
+from .base import OptimizationObject, extend_structure_to_horizon
+from .base.optimization_object import STORAGE_TYPE
+
+
+class HipFailure(Exception):
+    """Counterpart of OptiFailure (opti_solver.py:28-37)."""
+
+    def __init__(self, message):
+        super().__init__("The NLP solver failed to solve the problem. Message: " + str(message))
+
+
+class InitialGuessFailure(Exception):
+    def __init__(self, message):
+        super().__init__("Failed to set the initial guess. Message: " + str(message))
+
+
+class HipNlpSolver:
+    def __init__(self, settings, model, device=0, inner_solver="auto", options_solver=None):
+        self._settings, self._model, self._device = settings, model, device
+        self._inner_solver = inner_solver
+        self._options = dict(options_solver or {})
+        self._logger = logging.getLogger("[hippopt_amd::HipNlpSolver]")
+        self._structure = self._objects = self._guess = None
+        self._var_index, self._par_index = {}, {}
+        self._n = self._np = 0
+        self._engine = None
+        self._values = self._cost_value = None
+        self._cost_values, self._multipliers = {}, {}
+        self._problem = None
+
+    # ---- structure -------------------------------------------------------------------------------------
+    def generate_optimization_objects(self, input_structure, **kwargs):
+        if not isinstance(input_structure, (OptimizationObject, list)):
+            raise ValueError("The input structure is neither an optimization object nor a list.")
+        self._structure = copy.deepcopy(input_structure)
+        expanded = extend_structure_to_horizon(input_structure, **kwargs)
+        values, meta = expanded.to_dicts()
+        seen = {}
+        for name, value in values.items():  # duplicate-object guard (opti_solver.py:275-300)
+            if isinstance(value, np.ndarray):
+                if id(value) in seen:
+                    raise ValueError(f"{seen[id(value)]} and {name} share the same object as value.")
+                seen[id(value)] = name
+        xo = po = 0
+        self._var_index, self._par_index = {}, {}
+        for name, value in values.items():
+            if value is None:
+                raise ValueError("Field " + name + " is tagged as storage, but it is None.")
+            if not isinstance(value, np.ndarray) or value.ndim != 2:
+                raise ValueError(f"Field {name} is tagged as storage, but it is not a 2-D array.")
+            if value.size == 0:
+                raise ValueError("Field " + name + " has a zero dimension.")
+            if meta[name][STORAGE_TYPE] == "variable":
+                self._var_index[name] = (xo, value.size, value.shape)
+                xo += value.size
+            elif meta[name][STORAGE_TYPE] == "parameter":
+                self._par_index[name] = (po, value.size, value.shape)
+                po += value.size
+            else:
+                raise ValueError("Unsupported input storage type")
+        self._n, self._np = xo, po
+        horizon = int(kwargs.get("horizon", 1))
+        if xo != _abi.NXK * horizon + _abi.NXG or po != _abi.NPK * horizon + _abi.NPG:
+            raise ValueError("the structure is not the kinodynamic Variables tree the engine evaluates "
+                             f"(variables {xo}, parameters {po}, horizon {horizon})")
+        self._objects = expanded
+        if kwargs.get("fill_initial_guess", True):
+            try:
+                self.set_initial_guess(expanded)
+            except Exception as err:  # noqa: BLE001
+                raise InitialGuessFailure(err)
+        return self._objects
+
+    def get_optimization_objects(self):
+        return self._objects
+
+    def get_optimization_structure(self):
+        return self._structure
+
+    def register_problem(self, problem):
+        self._problem = problem
+
+    def get_problem(self):
+        return self._problem
+
+    # ---- guesses / parameters -----------------------------------------------------------------------------
+    def set_initial_guess(self, initial_guess):
+        """Variables -> x0, parameters -> p.  `None` leaves keep their previous value (opti_solver.py:379-420)."""
+        if self._guess is None:
+            self._guess = copy.deepcopy(self._objects)
+        flat = initial_guess.to_dict()
+        current = self._guess.to_dict()
+        update = {}
+        for name, value in flat.items():
+            if value is None or name not in current:
+                continue
+            arr = np.asarray(value, dtype=float)
+            target = self._var_index.get(name) or self._par_index.get(name)
+            if target is None:
+                continue
+            if arr.size != target[1]:
+                raise ValueError(f"The guess for {name} has {arr.size} entries, expected {target[1]}")
+            update[name] = arr.reshape(target[2])
+        self._guess.from_dict(update)
+
+    def get_initial_guess(self):
+        return copy.deepcopy(self._guess)
+
+    def _pack(self):
+        flat = self._guess.to_dict()
+        x, p = np.zeros(self._n), np.zeros(self._np)
+        for name, (off, size, _) in self._var_index.items():
+            x[off:off + size] = np.asarray(flat[name], float).reshape(-1)
+        for name, (off, size, _) in self._par_index.items():
+            p[off:off + size] = np.asarray(flat[name], float).reshape(-1)
+        return x, p
+
+    # ---- engine -------------------------------------------------------------------------------------------
+    def engine(self):
+        if self._engine is None:
+            from .hipnlp import HipNlp  # raises loudly without the library / a device
+            self._engine = HipNlp(self._settings, self._model, batch=1, device=self._device)
+        return self._engine
+
+    def get_constraint_expressions(self):
+        """{constraint base name: (first row, rows per knot, first knot, knots)} — the typed counterpart of the MX dictionary."""
+        return {b[0]: b[1:] for b in self.engine().row_blocks()}
+
+    def get_cost_expressions(self):
+        names, _ = self.engine().cost_terms() if self._values is not None else (None, None)
+        return names
+
+    def add_cost(self, input_cost, name=None):
+        raise NotImplementedError("HipNlpSolver evaluates the typed kinodynamic cost list built into the engine; symbolic costs need OptiSolver")
+
+    def add_constraint(self, input_constraint, name=None):
+        raise NotImplementedError("HipNlpSolver evaluates the typed kinodynamic constraint list built into the engine; symbolic constraints need OptiSolver")
+
+    def cost_function(self):
+        return self.get_cost_expressions()
+
+    # ---- solve --------------------------------------------------------------------------------------------
+    def solve(self):
+        eng = self.engine()
+        x0, p = self._pack()
+        eng.set_params(p[None, :])
+        lbx, ubx, lbg, ubg = eng.bounds()
+        ir, jc = eng.sparsity()
+
+        def quartet(x, want):
+            out = eng.eval(x[None, :], new_x=True, want=want)
+            return out
+
+        solver = self._inner_solver
+        if solver == "auto":
+            try:
+                import cyipopt  # noqa: F401
+                solver = "ipopt"
+            except ImportError:
+                solver = "trust-constr"
+        try:
+            if solver == "ipopt":
+                x, lam, info = self._solve_ipopt(eng, x0, lbx, ubx, lbg, ubg, ir, jc)
+            else:
+                x, lam, info = self._solve_scipy(eng, x0, lbg, ubg, ir, jc)
+        except Exception as err:  # noqa: BLE001
+            raise HipFailure(err)
+        f, grad, g, jac = eng.eval(x[None, :])
+        self._cost_value = float(f[0])
+        names, terms = eng.cost_terms()
+        self._cost_values = {n: float(v) for n, v in zip(names, terms[0])}
+        self._multipliers = {}
+        for name, first, rows, k0, nk in eng.row_blocks():
+            self._multipliers[name] = np.asarray(lam[first:first + rows * nk]).reshape(nk, rows)
+        values = copy.deepcopy(self._guess)
+        update = {name: x[off:off + size].reshape(shape) for name, (off, size, shape) in self._var_index.items()}
+        values.from_dict(update)
+        self._values = values
+        self._last_info = info
+
+    def _solve_scipy(self, eng, x0, lbg, ubg, ir, jc):
+        from scipy.optimize import BFGS, NonlinearConstraint, minimize
+        from scipy.sparse import csc_matrix
+        m, n = eng.m, eng.n
+
+        def fun(x):
+            f, *_ = eng.eval(x[None, :], want=("f",))
+            return float(f[0])
+
+        def grad(x):
+            _, g_, *_ = eng.eval(x[None, :], want=("grad",))
+            return g_[0]
+
+        def cons(x):
+            _, _, g, _ = eng.eval(x[None, :], want=("g",))
+            return g[0]
+
+        def jac(x):
+            _, _, _, j = eng.eval(x[None, :], want=("jac",))
+            return csc_matrix((j[0], (ir, jc)), shape=(m, n))
+        nlc = NonlinearConstraint(cons, lbg, ubg, jac=jac, hess=BFGS())
+        opts = {"maxiter": int(self._options.get("max_iter", 50)), "verbose": int(self._options.get("verbose", 0)),
+                "gtol": float(self._options.get("tol", 1e-6))}
+        res = minimize(fun, x0, jac=grad, hess=BFGS(), constraints=[nlc], method="trust-constr", options=opts)
+        lam = res.v[0] if len(res.v) else np.zeros(m)
+        return res.x, lam, {"status": res.status, "message": res.message, "iterations": res.nit, "constr_violation": res.constr_violation}
+
+    def _solve_ipopt(self, eng, x0, lbx, ubx, lbg, ubg, ir, jc):
+        import cyipopt
+        outer = self
+
+        class Callbacks:
+            def objective(self, x):
+                return float(eng.eval(x[None, :], want=("f",))[0][0])
+
+            def gradient(self, x):
+                return eng.eval(x[None, :], want=("grad",))[1][0]
+
+            def constraints(self, x):
+                return eng.eval(x[None, :], want=("g",))[2][0]
+
+            def jacobianstructure(self):
+                return ir, jc
+
+            def jacobian(self, x):
+                return eng.eval(x[None, :], want=("jac",))[3][0]
+        nlp = cyipopt.Problem(n=eng.n, m=eng.m, problem_obj=Callbacks(), lb=lbx, ub=ubx, cl=lbg, cu=ubg)
+        nlp.add_option("hessian_approximation", "limited-memory")  # main_periodic_step.py:116
+        for k, v in outer._options.items():
+            nlp.add_option(k, v)
+        x, info = nlp.solve(x0)
+        return x, info["mult_g"], info
+
+    def get_values(self):
+        return self._values
+
+    def get_cost_value(self):
+        return self._cost_value
+
+    def get_cost_values(self):
+        return self._cost_values
+
+    def get_constraint_multipliers(self):
+        return self._multipliers

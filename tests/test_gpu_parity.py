@@ -159,3 +159,33 @@ def test_gpu_matches_reference_planner_fixtures(model, HipNlp, name):
         else:
             assert abs(got - v) <= TOL * max(1.0, abs(v))
     assert max((abs(v) for v in J.values()), default=0.0) < 1e-12
+
+
+def test_planner_solve_plumbing(model):
+    """Planner -> HipNlpSolver -> engine callbacks -> NLP driver (SciPy trust-constr stand-in when IPOPT is absent) -> Output.
+    A few iterations from a synthetic guess must run end to end, keep the structure and reduce the constraint violation."""
+    from hippopt_amd.kinodyn_settings import single_step_settings
+    from hippopt_amd.turnkey_planners.humanoid_kinodynamic import Planner, Settings
+    st = Settings.from_numeric(single_step_settings(3, model), solver_options={"max_iter": 15})
+    pl = Planner(st, model)
+    x, p = make_workload(st, model, batch=1, seed=8)
+    guess = pl.get_initial_guess()
+    names = pl.optimization_solver._var_index
+    guess.from_dict({n: x[0][off:off + size].reshape(shape) for n, (off, size, shape) in names.items()})
+    pars = pl.optimization_solver._par_index
+    guess.from_dict({n: p[0][off:off + size].reshape(shape) for n, (off, size, shape) in pars.items()})
+    pl.optimization_solver.set_initial_guess(guess)      # already mass-normalised synthetic data
+    eng = pl.optimization_solver.engine()
+    eng.set_params(p)
+    _, _, g0, _ = eng.eval(x)
+    _, _, lbg, ubg = eng.bounds()
+    viol0 = np.max(np.maximum(0, np.maximum(lbg - g0[0], g0[0] - ubg)))
+    out = pl.solve()
+    assert len(out.values.system) == 3 and np.asarray(out.values.system[0].com).size == 3
+    assert set(out.cost_values) == set(eng.cost_terms()[0])
+    assert "joint_position_dynamics" in out.constraint_multipliers
+    assert out.constraint_multipliers["joint_position_dynamics"].shape == (2, 23)
+    xs = np.concatenate([np.asarray(v, float).reshape(-1) for n, v in out.values.to_dict().items() if n in names])
+    assert np.isfinite(out.cost_value)
+    info = pl.optimization_solver._last_info
+    assert info["constr_violation"] < viol0

@@ -1,0 +1,226 @@
+"""Host-side mirror of hippopt's structure API: the expectations of the reference's own tests
+(test/test_optimization_object.py, the structural part of test/test_multiple_shooting.py) re-expressed on
+hippopt_amd.base, plus the kinodynamic Variables tree / planner plumbing."""
+import copy
+import dataclasses
+import json
+import os
+
+import numpy as np
+import pytest
+
+from hippopt_amd.base import (CompositeType, OptimizationObject, OverridableVariable, Parameter, StorageType, TimeExpansion, Variable,
+                              default_composite_field, default_storage_field, extend_structure_to_horizon, flattened_names,
+                              time_varying_metadata)
+
+
+@dataclasses.dataclass
+class CustomVariable(OptimizationObject):
+    variable: StorageType = default_storage_field(cls=Variable)
+    parameter: StorageType = default_storage_field(cls=Parameter)
+    scalar: StorageType = default_storage_field(cls=Variable)
+
+    def __post_init__(self):
+        self.variable = np.ones(shape=3)
+        self.parameter = np.ones(shape=3)
+        self.scalar = 1.0
+
+
+@dataclasses.dataclass
+class AggregateClass(OptimizationObject):
+    aggregated: CompositeType = default_composite_field(factory=CustomVariable)
+    aggregated_list: CompositeType = default_composite_field(factory=list)
+    other_parameter: StorageType = default_storage_field(cls=Parameter)
+    other: str = ""
+
+    def __post_init__(self):
+        self.other_parameter = np.ones(3)
+        self.other = "untouched"
+        for _ in range(3):
+            self.aggregated_list.append(CustomVariable())
+
+
+@dataclasses.dataclass
+class CustomOverridableVariable(OptimizationObject):
+    overridable: StorageType = default_storage_field(cls=OverridableVariable)
+    not_overridable: StorageType = default_storage_field(cls=Variable)
+
+    def __post_init__(self):
+        self.overridable = 0.0
+        self.not_overridable = 0.0
+
+
+@dataclasses.dataclass
+class CustomCompositeOverridableVariable(OptimizationObject):
+    composite: CompositeType = default_composite_field(cls=Parameter, factory=CustomOverridableVariable)
+
+
+def test_to_dict_flat_names_and_count():  # test_optimization_object.py:65-91
+    d = AggregateClass().to_dict()
+    assert len(d) == 3 + 3 * 3 + 1
+    expected = ["aggregated.variable", "aggregated.parameter", "aggregated.scalar", "other_parameter"]
+    expected += [f"aggregated_list[{i}].{n}" for i in range(3) for n in ("variable", "parameter", "scalar")]
+    assert all(e in d for e in expected)
+    assert "other" not in d
+
+
+def test_override_rule():  # test_optimization_object.py:94-113: OverridableVariable under a Parameter composite becomes a parameter
+    _, meta = CustomCompositeOverridableVariable().to_dicts()
+    assert sorted(meta) == ["composite.not_overridable", "composite.overridable"]
+    assert meta["composite.overridable"][OptimizationObject.StorageTypeField] == Parameter.StorageTypeValue
+    assert meta["composite.not_overridable"][OptimizationObject.StorageTypeField] == Variable.StorageTypeValue
+    _, nested = CustomCompositeOverridableVariable().to_dicts(flatten=False)
+    assert list(nested) == ["composite"] and sorted(nested["composite"]) == ["not_overridable", "overridable"]
+    assert nested["composite"]["overridable"][OptimizationObject.StorageTypeField] == Parameter.StorageTypeValue
+
+
+def test_to_dict_not_flat():  # test_optimization_object.py:116-150
+    v = AggregateClass()
+    d = v.to_dict(flatten=False)
+    assert sorted(d) == ["aggregated", "aggregated_list", "other_parameter"]
+    assert sorted(d["aggregated"]) == ["parameter", "scalar", "variable"]
+    assert d["aggregated"]["scalar"] == 1.0 and len(d["aggregated_list"]) == 3
+    d = v.to_dict(flatten=False, prefix="test")
+    assert list(d) == ["test"] and sorted(d["test"]) == ["aggregated", "aggregated_list", "other_parameter"]
+
+
+def test_to_list_sorted_keys_and_shapes():  # test_optimization_object.py:181-194
+    v = AggregateClass()
+    lst, d = v.to_list(), v.to_dict()
+    assert len(lst) == 13
+    idx = {k: i for i, k in enumerate(sorted(d))}
+    assert lst[idx["aggregated.variable"]].shape == (3, 1)
+    assert lst[idx["aggregated.parameter"]].shape == (3, 1)
+    assert lst[idx["aggregated.scalar"]].shape == (1, 1)
+
+
+def test_from_dict_filters_and_conversions():  # test_optimization_object.py:197-230
+    v = AggregateClass()
+    d = v.to_dict()
+    d["aggregated.scalar"] = 7.0
+    v.from_dict(d)
+    assert v.aggregated.scalar == 7.0
+    v.aggregated.scalar = None
+    assert "aggregated.scalar" not in v.to_dict(output_filter=OptimizationObject.IsValueFilter)
+    v = AggregateClass()
+    assert v.to_dict(output_conversion=lambda _, x: 42 if isinstance(x, float) else x)["aggregated.scalar"] == 42
+    d = v.to_dict()
+    d["aggregated.scalar"] = 7.0
+    v.from_dict(d, input_conversion=lambda _, x: 42 if isinstance(x, float) else x)
+    assert v.aggregated.scalar == 42
+
+
+# ---- horizon expansion (test_multiple_shooting.py:25-106) ------------------------------------------------------
+@dataclasses.dataclass
+class MyTestVarMS(OptimizationObject):
+    variable: StorageType = default_storage_field(Variable)
+    parameter: StorageType = default_storage_field(Parameter)
+    string: str = "test"
+
+    def __post_init__(self):
+        self.variable = np.zeros(3)
+        self.parameter = np.zeros(3)
+
+
+@dataclasses.dataclass
+class MyCompositeTestVar(OptimizationObject):
+    composite: CompositeType = default_composite_field(factory=MyTestVarMS)
+    fixed: CompositeType = default_composite_field(factory=MyTestVarMS, time_varying=False)
+    extended: StorageType = default_storage_field(cls=Variable, time_expansion=TimeExpansion.Matrix)
+    composite_list: CompositeType = default_composite_field(factory=list)
+    fixed_list: list = dataclasses.field(default=None)
+
+    def __post_init__(self):
+        self.extended = np.zeros((3, 1))
+        self.composite_list = [MyTestVarMS() for _ in range(3)]
+        self.fixed_list = [MyTestVarMS() for _ in range(3)]
+
+
+def test_simple_variables_to_horizon():
+    var = extend_structure_to_horizon(MyTestVarMS(), horizon=10)
+    assert var.string == "test"
+    assert len(var.variable) == 10 and all(np.asarray(v).size == 3 for v in var.variable)
+    assert isinstance(var.parameter, np.ndarray) and var.parameter.size == 3   # parameters are not time dependent
+
+
+def test_composite_variables_to_horizon_and_custom_horizons():
+    var = extend_structure_to_horizon(MyCompositeTestVar(), horizon=10)
+    assert len(var.composite) == 10 and all(c.string == "test" for c in var.composite)
+    assert isinstance(var.fixed, MyTestVarMS)
+    assert var.extended.shape == (3, 10)
+    var = extend_structure_to_horizon(MyCompositeTestVar(), horizon=10, horizons={"fixed": 10})
+    assert len(var.fixed) == 10
+    assert len(var.composite_list) == 3 and all(len(series) == 10 for series in var.composite_list)
+    with pytest.raises(ValueError):
+        extend_structure_to_horizon(MyTestVarMS(), horizon=0)
+
+
+def test_flattened_names_drop_the_time_index():  # multiple_shooting_solver.py:293-485
+    orig = MyTestVarMS()
+    flat = flattened_names(extend_structure_to_horizon(orig, horizon=4), orig)
+    assert flat["variable"][0] == 4 and flat["variable"][1] == [f"variable[{k}]" for k in range(4)]
+    assert flat["parameter"][0] == 1
+
+
+# ---- kinodynamic tree and planner plumbing ------------------------------------------------------------------------
+def _planner(model, horizon=3):
+    from hippopt_amd.kinodyn_settings import periodic_step_settings
+    from hippopt_amd.turnkey_planners.humanoid_kinodynamic import Planner, Settings
+    st = Settings.from_numeric(periodic_step_settings(horizon, model))
+    return Planner(st, model), st
+
+
+def test_kinodynamic_variables_flatten_like_the_reference(model):
+    from hippopt_amd.turnkey_planners.humanoid_kinodynamic import Variables
+    pl, st = _planner(model)
+    expanded = extend_structure_to_horizon(Variables(settings=st, kin_dyn_object=model), horizon=3)
+    values, meta = expanded.to_dicts()
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kinodyn_structure.json")))["horizons"]["3"]
+    mine = [(n, int(np.asarray(a).size), meta[n][OptimizationObject.StorageTypeField]) for n, a in values.items()]
+    assert mine == [(g["name"], g["size"], g["type"]) for g in gold]
+    # the time list is not part of the flattened name
+    flat = flattened_names(expanded, Variables(settings=st, kin_dyn_object=model))
+    assert flat["system.contact_points.left[0].p"][0] == 3
+    assert flat["references.feet.left.points[0].desired_force_ratio"][0] == 3
+    assert flat["dt"][0] == 1
+
+
+def test_planner_packs_parameters_in_reference_order_and_regularises_mass(model):
+    from hippopt_amd.synthetic import pack_parameters
+    pl, st = _planner(model)
+    x, p = pl.optimization_solver._pack()
+    assert np.allclose(p, pack_parameters(st, model))   # dataclass defaults == flat parameter defaults
+    guess = pl.get_initial_guess()
+    mass = model.get_total_mass()
+    for k, system in enumerate(guess.system):
+        system.contact_points.left[0].f = np.array([0.0, 0.0, mass * 9.81 / 8 + k])
+        system.centroidal_momentum = np.arange(6.0) * mass
+    guess.initial_state.contact_points.right[3].f = np.array([1.0, 2.0, 3.0]) * mass
+    pl.set_initial_guess(guess)
+    x, p = pl.optimization_solver._pack()
+    assert np.isclose(x[9 + 2], 9.81 / 8)                          # forces are stored per unit mass (planner.py:932-982)
+    assert np.allclose(x[183:189], np.arange(6.0))
+    from hippopt_amd.kinodyn_layout import ParamLayout
+    assert np.allclose(p[ParamLayout(3).init + 9 * 7 + 3: ParamLayout(3).init + 9 * 7 + 6], [1.0, 2.0, 3.0])
+    back = pl.get_initial_guess()                                   # and multiplied back on the way out
+    assert np.allclose(np.asarray(back.system[1].contact_points.left[0].f).reshape(-1), [0.0, 0.0, mass * 9.81 / 8 + 1])
+
+
+def test_solver_rejects_foreign_structures_and_symbolic_expressions(model):
+    from hippopt_amd.hipnlp_solver import HipNlpSolver
+    from hippopt_amd.kinodyn_settings import periodic_step_settings
+    s = HipNlpSolver(periodic_step_settings(3, model), model)
+    with pytest.raises(ValueError):
+        s.generate_optimization_objects(MyTestVarMS(), horizon=3)
+    with pytest.raises(NotImplementedError):
+        s.add_cost(None)
+    with pytest.raises(NotImplementedError):
+        s.add_constraint(None)
+
+
+def test_output_to_dict_nests_by_dot():  # problem.py:58-79
+    from hippopt_amd.base import Output
+    out = Output(values=AggregateClass(), cost_value=1.0, cost_values={"a.b": 2.0}, constraint_multipliers={"c.d[0]": np.ones(2)})
+    d = out.to_dict()
+    assert d["cost_values"] == {"a": {"b": 2.0}} and "d[0]" in d["constraint_multipliers"]["c"]
+    assert d["values"]["aggregated"]["scalar"] == 1.0
