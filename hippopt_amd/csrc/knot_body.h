@@ -406,36 +406,33 @@ template <class Em> HD void t_feet(Ctx<Em>& cx, int t) {
     }
 }
 
-// --- base orientation: normalised quaternion (E11), R_b, G, omega (E12), d omega / d q_b: 1 task -----------
-template <class Em> HD void t_base(Ctx<Em>& cx, int) {
+// --- base orientation: normalised quaternion (E11), R_b, G, omega (E12), d omega / d q_b: lane e = row (3 tasks) ---------
+template <class Em> HD void t_base(Ctx<Em>& cx, int e) {
     KnotScratch& s = cx.s;
     const double* q = s.x + QB_;
     const double* qd = s.x + QD_;
     const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     const double inv_n = 1.0 / n;
-    s.qnorm = n;
-    s.inv_qnorm = inv_n;
     double qn[4];
-    for (int i = 0; i < 4; ++i) { qn[i] = q[i] * inv_n; s.qn[i] = qn[i]; }
-    rot_from_quat(qn, s.Rb);
-    const double vx = qn[0], vy = qn[1], vz = qn[2], w = qn[3];
-    double* G = s.G;  // G = 2 [ w I + [v]x | -v ]
-    G[0] = 2.0 * w;   G[1] = -2.0 * vz; G[2] = 2.0 * vy;  G[3] = -2.0 * vx;
-    G[4] = 2.0 * vz;  G[5] = 2.0 * w;   G[6] = -2.0 * vx; G[7] = -2.0 * vy;
-    G[8] = -2.0 * vy; G[9] = 2.0 * vx;  G[10] = 2.0 * w;  G[11] = -2.0 * vz;
-    for (int e = 0; e < 3; ++e) s.omega[e] = G[4 * e] * qd[0] + G[4 * e + 1] * qd[1] + G[4 * e + 2] * qd[2] + G[4 * e + 3] * qd[3];
-    // omega = H(qdot) qhat,  H = 2 [ -qd_w I - [qd_v]x | qd_v ];  d omega / d q = H (I - qn qn^T) / |q|
-    double H[12];
-    H[0] = -2.0 * qd[3]; H[1] = 2.0 * qd[2];  H[2] = -2.0 * qd[1]; H[3] = 2.0 * qd[0];
-    H[4] = -2.0 * qd[2]; H[5] = -2.0 * qd[3]; H[6] = 2.0 * qd[0];  H[7] = 2.0 * qd[1];
-    H[8] = 2.0 * qd[1];  H[9] = -2.0 * qd[0]; H[10] = -2.0 * qd[3]; H[11] = 2.0 * qd[2];
-    for (int e = 0; e < 3; ++e) {
-        const double hq = H[4 * e] * qn[0] + H[4 * e + 1] * qn[1] + H[4 * e + 2] * qn[2] + H[4 * e + 3] * qn[3];
-        for (int l = 0; l < 4; ++l) s.dwq[4 * e + l] = (H[4 * e + l] - hq * qn[l]) * inv_n;
+    for (int i = 0; i < 4; ++i) qn[i] = q[i] * inv_n;
+    if (e == 0) { s.qnorm = n; s.inv_qnorm = inv_n; for (int i = 0; i < 4; ++i) s.qn[i] = qn[i]; }
+    double R[9];
+    rot_from_quat(qn, R);
+    for (int i = 0; i < 3; ++i) { s.Rb[3 * e + i] = R[3 * e + i]; s.Rw[0][3 * e + i] = R[3 * e + i]; }
+    const double v[3] = {qn[0], qn[1], qn[2]}, w = qn[3];
+    // G = 2 [ w I + [v]x | -v ] ; omega = G qdot ; H = 2 [ -qd_w I - [qd_v]x | qd_v ] ; d omega/d q = H (I - qn qn^T)/|q|
+    double Ge[4], He[4];
+    for (int c = 0; c < 3; ++c) {
+        Ge[c] = 2.0 * ((c == e ? w : 0.0) + skew_rc(v, e, c));
+        He[c] = 2.0 * ((c == e ? -qd[3] : 0.0) - skew_rc(qd, e, c));
     }
-    // root link pose and velocity in base-centred coordinates
-    for (int i = 0; i < 9; ++i) s.Rw[0][i] = s.Rb[i];
-    for (int i = 0; i < 3; ++i) { s.ow[0][i] = 0.0; s.wv[0][i] = s.omega[i]; s.vo[0][i] = 0.0; }
+    Ge[3] = -2.0 * v[e];
+    He[3] = 2.0 * qd[e];
+    const double om = Ge[0] * qd[0] + Ge[1] * qd[1] + Ge[2] * qd[2] + Ge[3] * qd[3];
+    const double hq = He[0] * qn[0] + He[1] * qn[1] + He[2] * qn[2] + He[3] * qn[3];
+    for (int l = 0; l < 4; ++l) { s.G[4 * e + l] = Ge[l]; s.dwq[4 * e + l] = (He[l] - hq * qn[l]) * inv_n; }
+    s.omega[e] = om;
+    s.ow[0][e] = 0.0; s.wv[0][e] = om; s.vo[0][e] = 0.0;   // root link in base-centred coordinates
 }
 
 // ===================================================================================================
@@ -446,59 +443,55 @@ template <class Em> HD void t_base(Ctx<Em>& cx, int) {
 // Forward kinematics and link velocities as ANCESTOR SUMS: lane (joint j, component r), 69 tasks per pass.
 // Every lane walks its own (padded) ancestor list, so no lane waits for another one inside a pass; the passes
 // run back to back on one wave (HIPNLP_WAVE_SYNC between them).
-constexpr int FK_TASKS = 3 * NJ;
-template <class Em> HD void t_fk_rot(Ctx<Em>& cx, int t) {  // row r of R_j = row r of R_b L_a1 L_a2 ... L_j ; axis
+constexpr int FK_SPLIT = 11;                         // joints [0, FK_SPLIT) on one wave, the rest on another
+constexpr int FK_TASKS_A = 3 * FK_SPLIT, FK_TASKS_B = 3 * (NJ - FK_SPLIT);
+template <class Em> HD void t_fk_rot_at(Ctx<Em>& cx, int t) {  // row r of R_j = row r of R_b L_a1 ... L_j ; axis ; T_j = R_parent o_fix_j
     KnotScratch& s = cx.s;
     const int j = t / 3, r = t - 3 * j;
     double v0 = s.Rb[3 * r], v1 = s.Rb[3 * r + 1], v2 = s.Rb[3 * r + 2];
     HIPNLP_UNROLL
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < 7; ++q) {
         const double* L = s.Lj[cx.kt.anc[j][q]];
         const double n0 = v0 * L[0] + v1 * L[3] + v2 * L[6];
         const double n1 = v0 * L[1] + v1 * L[4] + v2 * L[7];
         const double n2 = v0 * L[2] + v1 * L[5] + v2 * L[8];
         v0 = n0; v1 = n1; v2 = n2;
     }
-    s.Rw[j + 1][3 * r] = v0; s.Rw[j + 1][3 * r + 1] = v1; s.Rw[j + 1][3 * r + 2] = v2;
-    const double* ax = cx.kt.axis[j];
-    s.aw[j][r] = v0 * ax[0] + v1 * ax[1] + v2 * ax[2];
-}
-template <class Em> HD void t_fk_terms(Ctx<Em>& cx, int t) {  // T_j = R_parent o_fix_j
-    KnotScratch& s = cx.s;
-    HIPNLP_WAVE_SYNC();
-    const int j = t / 3, r = t - 3 * j;
-    const double* Rp = s.Rw[cx.kt.par_link[j]] + 3 * r;
+    // (v0,v1,v2) is now row r of the PARENT's rotation (front-padded list: the last element is joint j itself)
     const double* of = cx.kt.o_fix[j];
-    s.Tj[j][r] = Rp[0] * of[0] + Rp[1] * of[1] + Rp[2] * of[2];
+    s.Tj[j][r] = v0 * of[0] + v1 * of[1] + v2 * of[2];
+    const double* L = s.Lj[j];
+    const double n0 = v0 * L[0] + v1 * L[3] + v2 * L[6];
+    const double n1 = v0 * L[1] + v1 * L[4] + v2 * L[7];
+    const double n2 = v0 * L[2] + v1 * L[5] + v2 * L[8];
+    s.Rw[j + 1][3 * r] = n0; s.Rw[j + 1][3 * r + 1] = n1; s.Rw[j + 1][3 * r + 2] = n2;
+    const double* ax = cx.kt.axis[j];
+    s.aw[j][r] = n0 * ax[0] + n1 * ax[1] + n2 * ax[2];
 }
-template <class Em> HD void t_fk_pos(Ctx<Em>& cx, int t) {  // o_j = sum T_anc ; w_j = omega + sum a_anc sdot_anc
+template <class Em> HD void t_fk_rot_a(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t); }
+template <class Em> HD void t_fk_rot_b(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t + FK_TASKS_A); }
+// lane j (23): o_j = sum T_anc ; w_j = omega + sum a_anc sdot_anc ; U_j = (o_j x a_j) sdot_j   (all three components in-lane)
+template <class Em> HD void t_fk_pos(Ctx<Em>& cx, int j) {
     KnotScratch& s = cx.s;
-    HIPNLP_WAVE_SYNC();
-    const int j = t / 3, r = t - 3 * j;
-    double o = 0.0, w = s.omega[r];
+    double o[3] = {0.0, 0.0, 0.0}, w[3] = {s.omega[0], s.omega[1], s.omega[2]};
     HIPNLP_UNROLL
     for (int q = 0; q < 8; ++q) {
         const int a = cx.kt.anc[j][q];
-        o += s.Tj[a][r];
-        w += s.aw[a][r] * s.x[SD_ + a];  // padding slot: aw[NJ] = 0
+        const double sd = s.x[SD_ + a];  // padding slot: aw[NJ] = 0
+        for (int r = 0; r < 3; ++r) { o[r] += s.Tj[a][r]; w[r] += s.aw[a][r] * sd; }
     }
-    s.ow[j + 1][r] = o;
-    s.wv[j + 1][r] = w;
+    double u[3];
+    cross3(o, s.aw[j], u);
+    const double sdj = s.x[SD_ + j];
+    for (int r = 0; r < 3; ++r) { s.ow[j + 1][r] = o[r]; s.wv[j + 1][r] = w[r]; s.Uj[j][r] = u[r] * sdj; }
 }
-template <class Em> HD void t_fk_uterms(Ctx<Em>& cx, int t) {  // U_j = (o_j x a_j) sdot_j
+template <class Em> HD void t_fk_vel(Ctx<Em>& cx, int j) {  // vO_j = sum U_anc, lane j (23), behind t_fk_pos on the same wave
     KnotScratch& s = cx.s;
     HIPNLP_WAVE_SYNC();
-    const int j = t / 3, r = t - 3 * j;
-    s.Uj[j][r] = cross_comp(s.ow[j + 1], s.aw[j], r) * s.x[SD_ + j];
-}
-template <class Em> HD void t_fk_vel(Ctx<Em>& cx, int t) {  // vO_j = sum U_anc
-    KnotScratch& s = cx.s;
-    HIPNLP_WAVE_SYNC();
-    const int j = t / 3, r = t - 3 * j;
-    double v = 0.0;
+    double v[3] = {0.0, 0.0, 0.0};
     HIPNLP_UNROLL
-    for (int q = 0; q < 8; ++q) v += s.Uj[cx.kt.anc[j][q]][r];
-    s.vo[j + 1][r] = v;
+    for (int q = 0; q < 8; ++q) { const int a = cx.kt.anc[j][q]; for (int r = 0; r < 3; ++r) v[r] += s.Uj[a][r]; }
+    for (int r = 0; r < 3; ++r) s.vo[j + 1][r] = v[r];
 }
 
 // --- centroidal momentum dynamics (T7 on E1): lanes (c, e) 48 entry tasks + lanes 48..59 row tasks -----------
@@ -722,16 +715,8 @@ template <class Em> HD void t_columns(Ctx<Em>& cx, int t) {
     double ch[3], cI[6], ckl[3], cka[3];
     for (int r = 0; r < 3; ++r) { ch[r] = s.comp[i][CH + r]; ckl[r] = s.comp[i][CKL + r]; cka[r] = s.comp[i][CKA + r]; }
     for (int r = 0; r < 6; ++r) cI[r] = s.comp[i][CI + r];
-    double oxa[3], lin[3], ang[3], A[3];
+    double oxa[3];
     cross3(o, a, oxa);
-    // momentum of the subtree moving with the unit motion S = (a ; o x a):  I_sub S
-    cross3(a, ch, t1);
-    for (int r = 0; r < 3; ++r) lin[r] = cm * oxa[r] + t1[r];
-    symvec(cI, a, t1);
-    cross3(ch, oxa, t2);
-    for (int r = 0; r < 3; ++r) ang[r] = t1[r] + t2[r];
-    cross3(com, lin, t1);
-    for (int r = 0; r < 3; ++r) A[r] = ang[r] - t1[r];                // column of the centroidal momentum matrix (angular rows)
     // configuration derivative:  dk = S x* k_sub - I_sub (S x v_i)
     double xw[3], xv[3], Il[3], Ia[3], dkl[3], dka[3], dcom[3], dh[3];
     cross3(a, s.wv[i], xw);
@@ -759,7 +744,6 @@ template <class Em> HD void t_columns(Ctx<Em>& cx, int t) {
         for (int r = 0; r < 3; ++r) {
             em.J(js::COMC_S + NJ * r + j, row_id(RK_COMC, 0, r), S_ + j, -dcom[r]);
             em.J(js::CMMC_S + NJ * r + j, row_id(RK_CMMC, 0, r), S_ + j, -dh[r] * inv_mass);
-            em.J(js::CMMC_SD + NJ * r + j, row_id(RK_CMMC, 0, r), SD_ + j, -A[r] * inv_mass);
         }
         // chest-frame orientation cost: d trace = -(ax(M) . a_j) d s_j for joints on the root->chest path
         if (cx.kt.chest_pos[j] >= 0) s.grad[S_ + j] += s.chest_dc * (-dot3(s.chest_w, a));
@@ -781,8 +765,34 @@ template <class Em> HD void t_columns(Ctx<Em>& cx, int t) {
         }
     } else {
         const int e = t - NJ;
-        for (int r = 0; r < 3; ++r) { s.dth_h[e][r] = dh[r]; s.Aw[e][r] = A[r]; }
+        for (int r = 0; r < 3; ++r) s.dth_h[e][r] = dh[r];
     }
+}
+
+// columns of the centroidal momentum matrix (angular rows): d hang / d sdot_j = I_sub S_j about the CoM; lanes as t_columns,
+// on another wave of the same phase
+template <class Em> HD void t_cmm_columns(Ctx<Em>& cx, int t) {
+    KnotScratch& s = cx.s;
+    Em& em = cx.em;
+    const double inv_M = 1.0 / cx.kt.total_mass, inv_mass = 1.0 / cx.gp.mass;
+    double com[3], a[3], o[3] = {0.0, 0.0, 0.0}, t1[3], t2[3];
+    for (int r = 0; r < 3; ++r) com[r] = s.comp[0][CH + r] * inv_M;
+    int i;
+    if (t < NJ) { i = t + 1; for (int r = 0; r < 3; ++r) { a[r] = s.aw[t][r]; o[r] = s.ow[i][r]; } }
+    else { i = 0; for (int r = 0; r < 3; ++r) a[r] = (r == t - NJ) ? 1.0 : 0.0; }
+    const double cm = s.comp[i][CM];
+    double ch[3], cI[6], oxa[3], lin[3], ang[3];
+    for (int r = 0; r < 3; ++r) ch[r] = s.comp[i][CH + r];
+    for (int r = 0; r < 6; ++r) cI[r] = s.comp[i][CI + r];
+    cross3(o, a, oxa);
+    cross3(a, ch, t1);
+    for (int r = 0; r < 3; ++r) lin[r] = cm * oxa[r] + t1[r];
+    symvec(cI, a, t1);
+    cross3(ch, oxa, t2);
+    for (int r = 0; r < 3; ++r) ang[r] = t1[r] + t2[r];
+    cross3(com, lin, t1);
+    if (t < NJ) { for (int r = 0; r < 3; ++r) em.J(js::CMMC_SD + NJ * r + t, row_id(RK_CMMC, 0, r), SD_ + t, -(ang[r] - t1[r]) * inv_mass); }
+    else { for (int r = 0; r < 3; ++r) s.Aw[t - NJ][r] = ang[r] - t1[r]; }
 }
 
 // ===================================================================================================
@@ -887,21 +897,23 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
 // Groups of one phase run concurrently on different waves; BARRIER separates phases.
 // ---------------------------------------------------------------------------------------------------
 #define HIPNLP_KNOT_PROGRAM(R, BARRIER)                                                   \
-    R(0, t_points_vec, 3 * NC) R(0, t_small, 4)                                           \
-    R(1, t_points_scalar, NC) R(1, t_points_cost, 3) R(1, t_dyn, 7 + NJ + 3) R(1, t_unitq, 1) \
+    R(0, t_points_vec, 3 * NC) R(0, t_feet, 3)                                            \
+    R(1, t_points_scalar, NC) R(1, t_points_cost, 3) R(1, t_dyn, 7 + NJ + 3)              \
     R(2, t_joints, NJ) R(2, t_joint_cost, 1)                                              \
-    R(3, t_base, 1) R(3, t_feet, 3)                                                       \
+    R(3, t_base, 3) R(3, t_small, 4) R(3, t_unitq, 1)                                     \
     BARRIER                                                                               \
-    R(0, t_fk_rot, FK_TASKS) R(0, t_fk_terms, FK_TASKS) R(0, t_fk_pos, FK_TASKS) R(0, t_fk_uterms, FK_TASKS) R(0, t_fk_vel, FK_TASKS) \
+    R(0, t_fk_rot_a, FK_TASKS_A) R(3, t_fk_rot_b, FK_TASKS_B)                             \
     R(1, t_hdyn, HDYN_TASKS)                                                              \
     R(2, t_foot_costs, FOOT_TASKS) R(2, t_foot_cost_sum, 2)                               \
+    BARRIER                                                                               \
+    R(0, t_fk_pos, NJ) R(0, t_fk_vel, NJ)                                                 \
     BARRIER                                                                               \
     R(0, t_links, NL) R(1, t_frames, 3)                                                   \
     BARRIER                                                                               \
     R(0, t_composite_w0, COMP_TASKS_PER_WAVE) R(1, t_composite_w1, COMP_TASKS_PER_WAVE)   \
     R(2, t_composite_w2, COMP_TASKS_PER_WAVE) R(3, t_composite_w3, COMP_TASKS_PER_WAVE) R(1, t_pkin, NC) \
     BARRIER                                                                               \
-    R(0, t_columns, NJ + 3) R(3, t_ends, ENDS_TASKS)                                      \
+    R(0, t_columns, NJ + 3) R(1, t_cmm_columns, NJ + 3) R(3, t_ends, ENDS_TASKS)          \
     BARRIER                                                                               \
     R(0, t_kinc, 3 * NC) R(1, t_comc, 15) R(2, t_cmmc, 15) R(3, t_feetd, 5) R(3, t_ends_finish, ENDS_FINISH_TASKS) \
     BARRIER

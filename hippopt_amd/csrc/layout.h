@@ -332,7 +332,9 @@ struct Layout {
             for (int q = j + 1; q > 0; q = md.parent[q - 1]) path.push_back(q - 1);
             if (path.size() > 8) { err = "robot model: a chain is deeper than 8 joints"; return false; }
             std::sort(path.begin(), path.end());
-            for (int q = 0; q < 8; ++q) kt.anc[j][q] = q < int(path.size()) ? path[size_t(q)] : NJ;
+            // FRONT padded: the last element is always joint j itself, so the state before the last product is the parent's
+            const int npad = 8 - int(path.size());
+            for (int q = 0; q < 8; ++q) kt.anc[j][q] = q < npad ? NJ : path[size_t(q - npad)];
         }
         for (int i = 0; i < NL; ++i) {
             int n = 0;

@@ -50,7 +50,7 @@ struct KinTables {
     int32_t frame_link[3];
     // tree as ancestor / descendant lists: every lane sums over its own list, no loop-carried dependence
     int32_t par_link[NJ];       // parent link of joint j
-    int32_t anc[NJ][8];         // joints on the path root -> j (inclusive, ascending), padded with NJ (identity / zero slot)
+    int32_t anc[NJ][8];         // joints on the path root -> j (inclusive, ascending, j LAST), FRONT padded with NJ (identity / zero slot)
     int16_t desc[NL][NL];       // links of the subtree rooted at link i (inclusive), padded with NL (zero slot)
     // horizon-end rows
     int16_t fin_var[105], fin_slot[105], fin_desc[105];  // variable / slot among the 81 variable rows / descriptor index (3c+i) or -1
