@@ -189,3 +189,26 @@ def test_planner_solve_plumbing(model):
     assert np.isfinite(out.cost_value)
     info = pl.optimization_solver._last_info
     assert info["constr_violation"] < viol0
+
+
+def test_in_launch_reduction_stress(model, HipNlp):
+    """The cost reduction happens inside the knot kernel (last workgroup of a trajectory, sc1 hand-off + ticket).
+    Many back-to-back launches at a batch that fills the chip several times must give bitwise identical f / per-term costs."""
+    st = periodic_step_settings(40, model)
+    batch = 96
+    x, p = make_workload(st, model, batch=batch, seed=17)
+    eng = HipNlp(st, model, batch=batch)
+    eng.set_params(p)
+    f0, *_ = eng.eval(x, want=("f",))
+    _, t0 = eng.cost_terms()
+    assert np.all(np.isfinite(f0)) and np.allclose(t0.sum(axis=1), f0, rtol=1e-13)
+    for _ in range(150):
+        f, *_ = eng.eval(x, want=("f",))
+        assert np.array_equal(f, f0)
+    _, t1 = eng.cost_terms()
+    assert np.array_equal(t0, t1)
+    from oracle_lib import Oracle
+    orc = Oracle(st, model)
+    for b in (0, 37, 95):
+        fo, _ = orc.eval_fg(x[b], p[b])
+        assert abs(f0[b] - fo) / max(1.0, abs(fo)) < 1e-11
