@@ -5,7 +5,7 @@ NJ, NL, NC, NXK, NPK, NXG, NPG = 23, 24, 8, 189, 79, 6, 326
 NCOST_TERMS = 12
 
 EXPR_SKIP, EXPR_SUBJECT_TO, EXPR_MINIMIZE = 0, 1, 2
-TERRAIN_PLANAR = 0
+TERRAIN_PLANAR, TERRAIN_SMOOTH_STEPS, MAX_TERRAIN_STEPS = 0, 1, 4
 FRAME_LEFT_SOLE, FRAME_RIGHT_SOLE, FRAME_CHEST = 0, 1, 2
 
 OK, E_INVALID, E_NODEVICE, E_ALLOC, E_PARAMS, E_NUMERIC = 0, -1, -2, -3, -4, -5
@@ -24,6 +24,11 @@ class RobotModelC(C.Structure):
         ("frame_R", (C.c_double * 9) * 3),
         ("frame_o", (C.c_double * 3) * 3),
     ]
+
+
+class TerrainStepC(C.Structure):
+    _fields_ = [("length", C.c_double), ("width", C.c_double), ("height", C.c_double), ("position", C.c_double * 3),
+                ("orientation", C.c_double), ("edge_sharpness", C.c_int32), ("side_sharpness", C.c_int32)]
 
 
 class SettingsC(C.Structure):
@@ -49,6 +54,9 @@ class SettingsC(C.Structure):
         ("swing_foot_height_cost_multiplier", C.c_double),
         ("contact_velocity_control_cost_multiplier", C.c_double),
         ("contact_force_control_cost_multiplier", C.c_double),
+        ("n_terrain_steps", C.c_int32),
+        ("reserved_", C.c_int32),
+        ("terrain_steps", TerrainStepC * MAX_TERRAIN_STEPS),
     ]
 
 

@@ -16,6 +16,7 @@ class KinodynSettings:
     time_step: float = 0.1
     gravity: np.ndarray = dataclasses.field(default_factory=lambda: np.array([0.0, 0.0, -9.80665, 0.0, 0.0, 0.0]))
     terrain: int = _abi.TERRAIN_PLANAR
+    terrain_steps: list = dataclasses.field(default_factory=list)  # SMOOTH_STEPS: dicts(length, width, height, position, orientation, edge_sharpness, side_sharpness)
     left_descriptors: np.ndarray = None
     right_descriptors: np.ndarray = None
     # Opti parameters (settings.py:100-125 defaults, overridden by the main scripts)
@@ -102,6 +103,15 @@ class KinodynSettings:
         s.swing_foot_height_cost_multiplier = float(self.swing_foot_height_cost_multiplier)
         s.contact_velocity_control_cost_multiplier = float(self.contact_velocity_control_cost_multiplier)
         s.contact_force_control_cost_multiplier = float(self.contact_force_control_cost_multiplier)
+        s.n_terrain_steps = len(self.terrain_steps)
+        for i, st in enumerate(self.terrain_steps):
+            t = s.terrain_steps[i]
+            t.length, t.width, t.height = float(st["length"]), float(st["width"]), float(st["height"])
+            for j in range(3):
+                t.position[j] = float(st.get("position", (0.0, 0.0, 0.0))[j])
+            t.orientation = float(st.get("orientation", 0.0))
+            t.edge_sharpness = int(st.get("edge_sharpness", 5))
+            t.side_sharpness = int(st.get("side_sharpness", 10))
         return s
 
 
@@ -128,5 +138,24 @@ def single_step_settings(horizon=30, model=None) -> KinodynSettings:
     s.desired_frame_quaternion_cost_multiplier = 90.0
     s.joint_regularization_cost_multiplier = 0.1
     s.final_state_expression_type = _abi.EXPR_SKIP
+    s.periodicity_expression_type = _abi.EXPR_SKIP
+    return s
+
+
+def stairs_terrain_steps(length=0.45, width=0.8, height=0.1):
+    """The two-step stairs of main_walking_on_stairs.py:18-28; the script calls get_terrain(length=step_length / 2 = 0.45,
+    width=0.8, height=step_height = 0.1) (:397-403)."""
+    return [
+        {"length": 2 * length, "width": width, "height": height, "position": (1.5 * length, 0.0, 0.0)},
+        {"length": 0.9 * length, "width": width, "height": height, "position": (2 * length, 0.0, 0.0)},
+    ]
+
+
+def stairs_settings(horizon=50, model=None) -> KinodynSettings:
+    """Constants of main_walking_on_stairs.py:70-148 that differ from the periodic step: smooth two-step terrain, final-state
+    constraint, no periodicity (the remaining gains / weights are the periodic-step ones)."""
+    s = periodic_step_settings(horizon, model)
+    s.terrain = _abi.TERRAIN_SMOOTH_STEPS
+    s.terrain_steps = stairs_terrain_steps()
     s.periodicity_expression_type = _abi.EXPR_SKIP
     return s

@@ -63,8 +63,23 @@ extern "C" {
 #define HIPNLP_EXPR_SUBJECT_TO 1
 #define HIPNLP_EXPR_MINIMIZE 2
 
-/* Terrain kinds (robot_planning/utilities/planar_terrain.py; smooth_terrain.py is a later row) */
+/* Terrain kinds.
+ *   PLANAR        robot_planning/utilities/planar_terrain.py:7-41       h = p_z, n = e_z, R_t = I
+ *   SMOOTH_STEPS  TerrainSum of SmoothTerrain.step bumps (utilities/smooth_terrain.py:201-227,266-336, terrain_sum.py:19-38;
+ *                 the stairs of main_walking_on_stairs.py:18-28):  h = p_z - sum_s [ H_s exp(-g_s^(2 side_s)) + o_s,z ],
+ *                 g_s = (2 q_x / L_s)^(2 edge_s) + (2 q_y / W_s)^(2 edge_s),  q = Rz(orientation_s)^T (p - o_s);
+ *                 normal / orientation from the TerrainDescriptor defaults (utilities/terrain_descriptor.py:45-80)      */
 #define HIPNLP_TERRAIN_PLANAR 0
+#define HIPNLP_TERRAIN_SMOOTH_STEPS 1
+#define HIPNLP_MAX_TERRAIN_STEPS 4
+
+typedef struct hipnlp_terrain_step {
+    double length, width, height;
+    double position[3];
+    double orientation;     /* yaw of the bump (rad) */
+    int32_t edge_sharpness; /* default 5  (exponent 2*edge on the footprint) */
+    int32_t side_sharpness; /* default 10 (exponent 2*side on g)            */
+} hipnlp_terrain_step;
 
 /* Frame slots of hipnlp_robot_model.frame_* */
 #define HIPNLP_FRAME_LEFT_SOLE 0
@@ -126,6 +141,9 @@ typedef struct hipnlp_settings {
     double swing_foot_height_cost_multiplier;
     double contact_velocity_control_cost_multiplier;
     double contact_force_control_cost_multiplier;
+    int32_t n_terrain_steps;   /* SMOOTH_STEPS: number of bumps (1..HIPNLP_MAX_TERRAIN_STEPS) */
+    int32_t reserved_;
+    hipnlp_terrain_step terrain_steps[HIPNLP_MAX_TERRAIN_STEPS];
 } hipnlp_settings;
 
 typedef struct hipnlp_desc {

@@ -109,26 +109,85 @@ template <class S> Q4<S> quaternion_xyzw_error(const Q4<S>& q, const Q4<S>& qd) 
 }
 
 // ---------------------------------------------------------------------------------------------
-// terrain: PlanarTerrain  (robot_planning/utilities/planar_terrain.py:7-41)
+// terrains.  ts.terrain == HIPNLP_TERRAIN_PLANAR : PlanarTerrain (robot_planning/utilities/planar_terrain.py:7-41),
+//            h = p_z, n = e_z, R_t = I, all as CONSTANTS (so the structural pattern is the planar one).
+//            HIPNLP_TERRAIN_SMOOTH_STEPS : TerrainSum (terrain_sum.py:19-38) of SmoothTerrain.step bumps
+//            (smooth_terrain.py:201-227 height, :266-336 step), normal / orientation from the TerrainDescriptor defaults
+//            (terrain_descriptor.py:45-80), derivatives the way the reference takes them (cs.gradient / cs.jtimes -> D1<>).
 // ---------------------------------------------------------------------------------------------
-template <class S> S terrain_height(int /*terrain*/, const V3<S>& p) { return p[2]; }
-template <class S> V3<S> terrain_normal(int, const V3<S>&) { return v3<S>(S(0.0), S(0.0), S(1.0)); }
-template <class S> M3<S> terrain_orientation(int, const V3<S>&) { return eye3<S>(); }
-// jtimes(height, p, v) and jtimes(normal, p, v) of complementarity.py:74-75 for the planar terrain
-template <class S> S terrain_height_derivative(int, const V3<S>&, const V3<S>& v) { return v[2]; }
-template <class S> V3<S> terrain_normal_derivative(int, const V3<S>&, const V3<S>&) { return v3<S>(S(0.0), S(0.0), S(0.0)); }
+using TerrainSpec = hipnlp_settings;
+template <class S> S ipow(const S& x, int n) {  // x ** n for the integer-valued float exponents 2*edge_sharpness, 2*side_sharpness
+    S r = S(1.0), b = x;
+    while (n > 0) { if (n & 1) r = r * b; n >>= 1; if (n) b = b * b; }
+    return r;
+}
+template <class S> S terrain_height(const TerrainSpec& ts, const V3<S>& p) {
+    if (ts.terrain == HIPNLP_TERRAIN_PLANAR) return p[2];
+    S h = p[2];  // sum_s h_s - (n-1) p_z  with  h_s = p_z - (z_terrain,s + o_s,z)   (terrain_sum.py:30-34)
+    for (int i = 0; i < ts.n_terrain_steps; ++i) {
+        const hipnlp_terrain_step& st = ts.terrain_steps[i];
+        const double c = std::cos(st.orientation), sn = std::sin(st.orientation);
+        S dx = p[0] - S(st.position[0]), dy = p[1] - S(st.position[1]);
+        S qx = S(c) * dx + S(sn) * dy, qy = S(-sn) * dx + S(c) * dy;           // inv(T) (p - offset), T = Rz(orientation)
+        S g = ipow(S(2.0 / st.length) * qx, 2 * st.edge_sharpness) + ipow(S(2.0 / st.width) * qy, 2 * st.edge_sharpness);
+        S z_terrain = exp(-ipow(g, 2 * st.side_sharpness)) * S(st.height);      // smooth_terrain.py:211 (top surface = height)
+        h = h - (z_terrain + S(st.position[2]));
+    }
+    return h;
+}
+template <class S> V3<S> terrain_gradient(const TerrainSpec& ts, const V3<S>& p) {  // cs.gradient(height(p), p)
+    V3<S> g;
+    for (int i = 0; i < 3; ++i) {
+        V3<D1<S>> pd;
+        for (int j = 0; j < 3; ++j) pd[j] = D1<S>(p[j], S(i == j ? 1.0 : 0.0));
+        g[i] = terrain_height(ts, pd).d;
+    }
+    return g;
+}
+template <class S> V3<S> terrain_normal(const TerrainSpec& ts, const V3<S>& p) {
+    if (ts.terrain == HIPNLP_TERRAIN_PLANAR) return v3<S>(S(0.0), S(0.0), S(1.0));
+    V3<S> g = terrain_gradient(ts, p);                                   // terrain_descriptor.py:49-53
+    S n = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    return v3<S>(g[0] / n, g[1] / n, g[2] / n);
+}
+template <class S> M3<S> terrain_orientation(const TerrainSpec& ts, const V3<S>& p) {
+    if (ts.terrain == HIPNLP_TERRAIN_PLANAR) return eye3<S>();
+    V3<S> n = terrain_normal(ts, p);                                     // terrain_descriptor.py:64-72
+    V3<S> y = cross(n, v3<S>(S(1.0), S(0.0), S(0.0)));
+    V3<S> x = cross(y, n);
+    S xn = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    x = v3<S>(x[0] / xn, x[1] / xn, x[2] / xn);
+    y = cross(n, x);
+    M3<S> R;
+    for (int i = 0; i < 3; ++i) { R.m[i][0] = x[i]; R.m[i][1] = y[i]; R.m[i][2] = n[i]; }
+    return R;
+}
+// jtimes(height, p, v) and jtimes(normal, p, v) of complementarity.py:74-75
+template <class S> S terrain_height_derivative(const TerrainSpec& ts, const V3<S>& p, const V3<S>& v) {
+    if (ts.terrain == HIPNLP_TERRAIN_PLANAR) return v[2];
+    V3<D1<S>> pd;
+    for (int j = 0; j < 3; ++j) pd[j] = D1<S>(p[j], v[j]);
+    return terrain_height(ts, pd).d;
+}
+template <class S> V3<S> terrain_normal_derivative(const TerrainSpec& ts, const V3<S>& p, const V3<S>& v) {
+    if (ts.terrain == HIPNLP_TERRAIN_PLANAR) return v3<S>(S(0.0), S(0.0), S(0.0));
+    V3<D1<S>> pd;
+    for (int j = 0; j < 3; ++j) pd[j] = D1<S>(p[j], v[j]);
+    V3<D1<S>> n = terrain_normal(ts, pd);
+    return v3<S>(n[0].d, n[1].d, n[2].d);
+}
 
 // ---------------------------------------------------------------------------------------------
 // closed-form expressions
 // ---------------------------------------------------------------------------------------------
 // E3  expressions/complementarity.py:27-32
-template <class S> V3<S> dcc_planar_complementarity(int terrain, const V3<S>& p, const S& kt, const V3<S>& u) {
+template <class S> V3<S> dcc_planar_complementarity(const TerrainSpec& terrain, const V3<S>& p, const S& kt, const V3<S>& u) {
     S tau = tanh(kt * terrain_height(terrain, p));
     V3<S> mu = v3<S>(tau * u[0], tau * u[1], u[2]);
     return mul(terrain_orientation(terrain, p), mu);
 }
 // E4  expressions/complementarity.py:71-87
-template <class S> S dcc_complementarity_margin(int terrain, const V3<S>& p, const V3<S>& f, const V3<S>& v, const V3<S>& fdot,
+template <class S> S dcc_complementarity_margin(const TerrainSpec& terrain, const V3<S>& p, const V3<S>& f, const V3<S>& v, const V3<S>& fdot,
                                                 const S& k_bs, const S& eps) {
     S height = terrain_height(terrain, p);
     V3<S> n = terrain_normal(terrain, p);
@@ -141,9 +200,9 @@ template <class S> S dcc_complementarity_margin(int terrain, const V3<S>& p, con
     return eps - k_bs * complementarity - csi;
 }
 // E6  expressions/contacts.py:22-24
-template <class S> S normal_force_component(int terrain, const V3<S>& p, const V3<S>& f) { return dot(terrain_normal(terrain, p), f); }
+template <class S> S normal_force_component(const TerrainSpec& terrain, const V3<S>& p, const V3<S>& f) { return dot(terrain_normal(terrain, p), f); }
 // E7  expressions/contacts.py:54-66
-template <class S> S friction_cone_square_margin(int terrain, const V3<S>& p, const V3<S>& f, const S& mu) {
+template <class S> S friction_cone_square_margin(const TerrainSpec& terrain, const V3<S>& p, const V3<S>& f, const S& mu) {
     V3<S> fc = mul(transpose(terrain_orientation(terrain, p)), f);
     return S(-1.0) * (fc[0] * fc[0]) + S(-1.0) * (fc[1] * fc[1]) + (mu * mu) * (fc[2] * fc[2]);
 }
@@ -152,7 +211,7 @@ template <class S> S contact_points_yaw_alignment_error(const V3<S>& p0, const V
     return -sin(yaw) * (p1[0] - p0[0]) + cos(yaw) * (p1[1] - p0[1]);
 }
 // E10 expressions/contacts.py:158-166
-template <class S> S swing_height_heuristic(int terrain, const V3<S>& p, const V3<S>& v, const S& hd) {
+template <class S> S swing_height_heuristic(const TerrainSpec& terrain, const V3<S>& p, const V3<S>& v, const S& hd) {
     S dh = terrain_height(terrain, p) - hd;
     V3<S> pv = mul(transpose(terrain_orientation(terrain, p)), v);
     return S(0.5) * (dh * dh + (pv[0] * pv[0] + pv[1] * pv[1]));

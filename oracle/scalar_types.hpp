@@ -115,6 +115,23 @@ inline Dep exp(const Dep& a) { return dep_unary(a, std::exp(a.c)); }
 
 inline double value_of(double a) { return a; }
 
+// ---- generic first-order forward-mode wrapper over ANY scalar type (nests: D1<D1<S>>) -----------------------
+// Used where the reference itself differentiates: cs.gradient(height, p) (terrain_descriptor.py:49-52) and
+// cs.jtimes(height / normal, p, v) (complementarity.py:74-75).
+template <class S> struct D1 {
+    S v, d;
+    D1() : v(0.0), d(0.0) {}
+    D1(double c) : v(c), d(0.0) {}  // NOLINT
+    D1(const S& val, const S& der) : v(val), d(der) {}
+};
+template <class S> D1<S> operator+(const D1<S>& a, const D1<S>& b) { return D1<S>(a.v + b.v, a.d + b.d); }
+template <class S> D1<S> operator-(const D1<S>& a, const D1<S>& b) { return D1<S>(a.v - b.v, a.d - b.d); }
+template <class S> D1<S> operator-(const D1<S>& a) { return D1<S>(-a.v, -a.d); }
+template <class S> D1<S> operator*(const D1<S>& a, const D1<S>& b) { return D1<S>(a.v * b.v, a.d * b.v + a.v * b.d); }
+template <class S> D1<S> operator/(const D1<S>& a, const D1<S>& b) { S q = a.v / b.v; return D1<S>(q, (a.d - q * b.d) / b.v); }
+template <class S> D1<S> sqrt(const D1<S>& a) { using std::sqrt; S r = sqrt(a.v); return D1<S>(r, a.d / (S(2.0) * r)); }
+template <class S> D1<S> exp(const D1<S>& a) { using std::exp; S e = exp(a.v); return D1<S>(e, e * a.d); }
+
 // seeding helper: make an S from a value and a direction index
 template <class S> struct Seeder { static S make(double v, int dir) { return S::seed(v, dir); } };
 template <> struct Seeder<double> { static double make(double v, int) { return v; } };

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from hippopt_amd import _abi
-from hippopt_amd.kinodyn_settings import periodic_step_settings, single_step_settings
+from hippopt_amd.kinodyn_settings import periodic_step_settings, single_step_settings, stairs_settings
 from oracle_lib import Oracle
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -22,6 +22,8 @@ def settings_for(meta, model):
     N = meta["horizon"]
     if meta["config"] == "single":
         return single_step_settings(N, model)
+    if meta["config"] == "stairs":
+        return stairs_settings(N, model)
     st = periodic_step_settings(N, model)
     if meta["config"] == "costends":
         st.final_state_expression_type = _abi.EXPR_MINIMIZE
@@ -35,7 +37,7 @@ def rel(a, b):
     return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if np.size(a) else 0.0
 
 
-@pytest.mark.parametrize("name", ["planner_periodic_N3", "planner_single_N3", "planner_costends_N2"])
+@pytest.mark.parametrize("name", ["planner_periodic_N3", "planner_single_N3", "planner_costends_N2", "planner_stairs_N3"])
 def test_oracle_matches_reference_planner_assembly(model, name):
     z = np.load(os.path.join(GOLD, name + ".npz"))
     meta = json.loads(str(z["meta"]))

@@ -688,6 +688,12 @@ class Function:
     def n_out(self):
         return len(self._outs)
 
+    def numel_in(self, i=None):
+        return sum(x.numel() for x in self._ins) if i is None else self._ins[self._names_in.index(i) if isinstance(i, str) else i].numel()
+
+    def numel_out(self, i=None):
+        return sum(x.numel() for x in self._outs) if i is None else self._outs[i].numel()
+
     def size_in(self, i):
         k = self._names_in.index(i) if isinstance(i, str) else i
         return self._ins[k]._shape

@@ -35,7 +35,7 @@ import hippopt.turnkey_planners.humanoid_kinodynamic.planner as walking_planner 
 import hippopt.turnkey_planners.humanoid_kinodynamic.settings as walking_settings  # noqa: E402
 
 from hippopt_amd import _abi  # noqa: E402
-from hippopt_amd.kinodyn_settings import periodic_step_settings, single_step_settings  # noqa: E402
+from hippopt_amd.kinodyn_settings import periodic_step_settings, single_step_settings, stairs_settings  # noqa: E402
 from hippopt_amd.robot_model import JOINT_NAMES, synthetic_ergocub  # noqa: E402
 from hippopt_amd.synthetic import make_workload  # noqa: E402
 
@@ -67,6 +67,14 @@ def reference_settings(mine):
     s.final_state_expression_weight = mine.final_state_expression_weight
     s.periodicity_expression_type = EXPR[mine.periodicity_expression_type]
     s.periodicity_expression_weight = mine.periodicity_expression_weight
+    if mine.terrain == _abi.TERRAIN_SMOOTH_STEPS:   # main_walking_on_stairs.py:18-28: sum of SmoothTerrain.step bumps
+        terrain = None
+        for st in mine.terrain_steps:
+            step = hp_rp.SmoothTerrain.step(length=st["length"], width=st["width"], height=st["height"],
+                                            position=np.array(st["position"], float), orientation=st.get("orientation", 0.0),
+                                            edge_sharpness=st.get("edge_sharpness", 5), side_sharpness=st.get("side_sharpness", 10))
+            terrain = step if terrain is None else terrain + step
+        s.terrain = terrain
     s.casadi_function_options = {"cse": True}
     s.casadi_opti_options = {"expand": True, "detect_simple_bounds": True}
     s.casadi_solver_options = {}
@@ -101,7 +109,7 @@ def canon(c, var_ids):
     raise ValueError("unsupported constraint")
 
 
-def generate(tag, mine, model, seed):
+def generate(tag, mine, model, seed, tweak=None):
     adam.casadi.STANDIN_MODEL = model
     planner = walking_planner.Planner(reference_settings(mine))
     solver = planner.optimization_solver
@@ -109,6 +117,8 @@ def generate(tag, mine, model, seed):
     N = mine.horizon_length
     x, p = make_workload(mine, model, 1, seed)
     x, p = x[0], p[0]
+    if tweak is not None:
+        tweak(x)
     nx = sum(v.numel() for v in opti.variables)
     npar = sum(q.numel() for q in opti.parameters)
     assert nx == x.size and npar == p.size, (nx, x.size, npar, p.size)
@@ -167,6 +177,30 @@ def main():
     st.final_state_expression_weight, st.periodicity_expression_weight = 2.0, 0.5
     st.contacts_centroid_cost_multiplier = 100.0
     generate("costends", st, model, 4005)
+
+    # stairs (smooth two-step terrain, main_walking_on_stairs.py): put the contact points and the com on the flanks of the
+    # bumps, where exp(-g^20) actually varies (it is 1 or 0 to machine precision almost everywhere else)
+    stairs = stairs_settings(3, model)
+
+    def on_the_flanks(x):
+        rng = np.random.RandomState(9)
+        steps = stairs.terrain_steps
+        for k in range(3):
+            for c in range(8):
+                st = steps[(k + c) % 2]
+                a = rng.uniform(0.95, 1.01)            # |2 q_x / L| on the x flank
+                b = rng.uniform(0.0, 0.9)              # well inside in y, or on the y flank for some points
+                if c % 3 == 0:
+                    a, b = b, rng.uniform(0.95, 1.01)
+                sx, sy = rng.choice([-1.0, 1.0]), rng.choice([-1.0, 1.0])
+                o = 189 * k + 15 * c + 6
+                x[o + 0] = st["position"][0] + sx * 0.5 * st["length"] * a
+                x[o + 1] = st["position"][1] + sy * 0.5 * st["width"] * b
+                x[o + 2] = 0.05 + 0.05 * rng.standard_normal()
+            st = steps[k % 2]
+            x[189 * k + 180] = st["position"][0] - 0.5 * st["length"] * rng.uniform(0.96, 1.0)
+            x[189 * k + 181] = 0.1 * rng.standard_normal()
+    generate("stairs", stairs, model, 4006, tweak=on_the_flanks)
 
 
 if __name__ == "__main__":
