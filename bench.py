@@ -29,9 +29,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from hippopt_amd.hipnlp import HipNlp  # noqa: E402
-from hippopt_amd.kinodyn_settings import periodic_step_settings  # noqa: E402
+from hippopt_amd.kinodyn_settings import periodic_step_settings, single_step_settings, stairs_settings  # noqa: E402
 from hippopt_amd.robot_model import synthetic_ergocub  # noqa: E402
-from hippopt_amd.synthetic import make_workload  # noqa: E402
+from hippopt_amd.synthetic import make_workload, place_on_step_flanks  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (guides/MI355X_MICROARCH.md)
 KNOTS_PER_GPU = 100
@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--horizon", type=int, default=KNOTS_PER_GPU)
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--workload", choices=["periodic", "single", "stairs"], default="periodic",
+                    help="periodic walking (BASELINE metric, default) | single step (final state / periodicity skipped) | stairs (smooth terrain)")
     ap.add_argument("--shard", choices=["knots", "batch"], default="knots")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the sharded path on one GPU (debug)")
@@ -92,9 +94,11 @@ def main():
     model = synthetic_ergocub()
     knot_sharded = (world > 1 and args.shard == "knots") or args.force_sharded
     horizon = args.horizon * world if knot_sharded else args.horizon
-    settings = periodic_step_settings(horizon, model)
+    settings = {"periodic": periodic_step_settings, "single": single_step_settings, "stairs": stairs_settings}[args.workload](horizon, model)
     seed = 1004 if knot_sharded else 1004 + rank
     x_np, p_np = make_workload(settings, model, batch=args.batch, seed=seed)
+    if args.workload == "stairs":   # contact points on the flanks of the bumps: no exp-underflow shortcut in the terrain jets
+        place_on_step_flanks(x_np, settings, seed=seed)
     nvar = 4  # a few distinct iterates, cycled: "x changes every call, parameters fixed" 
     rng = np.random.RandomState(5)
     xs = [torch.from_numpy(x_np + 1e-3 * i * rng.standard_normal(x_np.shape)).to(device) for i in range(nvar)]
@@ -171,7 +175,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic (seeded trajectories on a synthetic 23-DoF ergoCub-topology model; no URDF/CasADi in the image)",
-            "config": {"workload": "kinodynamic periodic walking, N=%d knots per GPU, batch %d (BASELINE config 4 shape)" % (args.horizon, args.batch),
+            "config": {"workload": {"periodic": "kinodynamic periodic walking, N=%d knots per GPU, batch %d (BASELINE config 4 shape)",
+                                    "single": "kinodynamic single step on flat ground, N=%d knots per GPU, batch %d (BASELINE config 3 shape)",
+                                    "stairs": "kinodynamic walking on stairs (smooth two-step terrain), N=%d knots per GPU, batch %d (BASELINE config 5 shape)"}[args.workload]
+                                   % (args.horizon, args.batch),
                        "horizon": horizon, "batch": args.batch, "knots_per_step": knots_per_step_total,
                        "parallelism": ("knot-sharded x%d + all-gather" % world) if knot_sharded else ("replica x%d" % world),
                        "n": int(d.n), "m": int(d.m), "nnz": int(d.nnz), "nnz_per_knot": nnz_knot},

@@ -152,6 +152,69 @@ HD void rot_from_quat(const double* q, double* R) {
     R[6] = 2.0 * (x * z - w * y);       R[7] = 2.0 * (y * z + w * x);       R[8] = 1.0 - 2.0 * (x * x + y * y);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Smooth step terrain (TerrainSum of SmoothTerrain.step, robot_planning/utilities/smooth_terrain.py:201-227,266-336,
+// terrain_sum.py:19-38):  h(p) = p_z - Z(p_x, p_y),  Z = sum_s [ H_s exp(-g_s^r) + o_s,z ],  g = a^m + b^m.
+// The rows need the normal n = grad h / |grad h|, the orientation R_t = [x y n] (terrain_descriptor.py:45-80), the
+// directional derivatives hdot = grad h . v and ndot = (dn/dp) v (complementarity.py:74-75) AND their derivatives with
+// respect to p: partials of Z up to THIRD order, evaluated in closed form (Faa di Bruno on psi(g) = H exp(-g^r)); everything
+// that is built from them is propagated with a 2-direction dual number (d/dp_x, d/dp_y; nothing but h depends on p_z).
+// ---------------------------------------------------------------------------------------------------
+struct D2 {
+    double v, x, y;
+    HD D2() : v(0.0), x(0.0), y(0.0) {}
+    HD D2(double c) : v(c), x(0.0), y(0.0) {}
+    HD D2(double v_, double x_, double y_) : v(v_), x(x_), y(y_) {}
+};
+HD D2 operator+(const D2& a, const D2& b) { return D2(a.v + b.v, a.x + b.x, a.y + b.y); }
+HD D2 operator-(const D2& a, const D2& b) { return D2(a.v - b.v, a.x - b.x, a.y - b.y); }
+HD D2 operator-(const D2& a) { return D2(-a.v, -a.x, -a.y); }
+HD D2 operator*(const D2& a, const D2& b) { return D2(a.v * b.v, a.x * b.v + a.v * b.x, a.y * b.v + a.v * b.y); }
+HD D2 operator*(const D2& a, double c) { return D2(a.v * c, a.x * c, a.y * c); }
+HD D2 operator*(double c, const D2& a) { return D2(a.v * c, a.x * c, a.y * c); }
+HD D2 operator/(const D2& a, const D2& b) { const double q = a.v / b.v, i = 1.0 / b.v; return D2(q, (a.x - q * b.x) * i, (a.y - q * b.y) * i); }
+HD D2 d2sqrt(const D2& a) { const double r = sqrt(a.v), i = 0.5 / r; return D2(r, a.x * i, a.y * i); }
+HD D2 d2tanh(const D2& a) { const double t = tanh(a.v), d = 1.0 - t * t; return D2(t, a.x * d, a.y * d); }
+
+HD double ipow_d(double x, int n) { double r = 1.0, b = x; while (n > 0) { if (n & 1) r *= b; n >>= 1; if (n) b *= b; } return r; }
+
+// Z and its partials up to third order: out = [Z, Zx, Zy, Zxx, Zxy, Zyy, Zxxx, Zxxy, Zxyy, Zyyy]
+HD void terrain_Z_jet(const KSettings& st, double px, double py, int order, double* out) {
+    for (int i = 0; i < 10; ++i) out[i] = 0.0;
+    for (int sidx = 0; sidx < st.n_steps; ++sidx) {
+        const TerrainStepK& t = st.steps[sidx];
+        out[0] += t.oz;
+        const double dx = px - t.ox, dy = py - t.oy;
+        const double a = t.ax * dx + t.ay * dy, b = t.bx * dx + t.by * dy;
+        const int m = t.m, r = t.r;
+        const double am3 = ipow_d(a, m - 3), bm3 = ipow_d(b, m - 3);
+        const double A0 = am3 * a * a * a, A1 = m * am3 * a * a, A2 = double(m * (m - 1)) * am3 * a, A3 = double(m * (m - 1) * (m - 2)) * am3;
+        const double B0 = bm3 * b * b * b, B1 = m * bm3 * b * b, B2 = double(m * (m - 1)) * bm3 * b, B3 = double(m * (m - 1) * (m - 2)) * bm3;
+        const double g = A0 + B0;
+        const double gr3 = ipow_d(g, r - 3);
+        const double w = gr3 * g * g * g;
+        if (!(w < 700.0)) continue;  // exp(-w) underflows (also catches inf / nan of far-away points): the bump and all its derivatives vanish
+        const double w1 = r * gr3 * g * g, w2 = double(r * (r - 1)) * gr3 * g, w3 = double(r * (r - 1) * (r - 2)) * gr3;
+        const double psi = t.height * exp(-w);
+        const double p1 = -psi * w1, p2 = psi * (w1 * w1 - w2), p3 = psi * (-w1 * w1 * w1 + 3.0 * w1 * w2 - w3);
+        const double gx = A1 * t.ax + B1 * t.bx, gy = A1 * t.ay + B1 * t.by;
+        out[0] += psi;
+        out[1] += p1 * gx;
+        out[2] += p1 * gy;
+        if (order < 2) continue;
+        const double gxx = A2 * t.ax * t.ax + B2 * t.bx * t.bx, gxy = A2 * t.ax * t.ay + B2 * t.bx * t.by, gyy = A2 * t.ay * t.ay + B2 * t.by * t.by;
+        out[3] += p2 * gx * gx + p1 * gxx;
+        out[4] += p2 * gx * gy + p1 * gxy;
+        out[5] += p2 * gy * gy + p1 * gyy;
+        const double gxxx = A3 * t.ax * t.ax * t.ax + B3 * t.bx * t.bx * t.bx, gxxy = A3 * t.ax * t.ax * t.ay + B3 * t.bx * t.bx * t.by;
+        const double gxyy = A3 * t.ax * t.ay * t.ay + B3 * t.bx * t.by * t.by, gyyy = A3 * t.ay * t.ay * t.ay + B3 * t.by * t.by * t.by;
+        out[6] += p3 * gx * gx * gx + p2 * (3.0 * gxx * gx) + p1 * gxxx;
+        out[7] += p3 * gx * gx * gy + p2 * (gxx * gy + 2.0 * gxy * gx) + p1 * gxxy;
+        out[8] += p3 * gx * gy * gy + p2 * (gyy * gx + 2.0 * gxy * gy) + p1 * gxyy;
+        out[9] += p3 * gy * gy * gy + p2 * (3.0 * gyy * gy) + p1 * gyyy;
+    }
+}
+
 // ===================================================================================================
 // PHASE A — everything that depends only on the loaded knot records
 // ===================================================================================================
@@ -180,14 +243,16 @@ template <class Em> HD void t_points_vec(Ctx<Em>& cx, int t) {
     em.J(jb + js::PDYN + 6 + i, row_id(RK_PDYN_OUT, c, i), cb + P_ + i, -1.0);
     em.J(jb + js::PDYN + 9 + i, row_id(RK_PDYN_OUT, c, i), cb + V_ + i, -half);
     em.J(jb + js::PDYN + 12 + i, row_id(RK_PDYN_X0, c, i), cb + P_ + i, 1.0);
-    // planar complementarity  v - R_t diag(tau,tau,1) u,  tau = tanh(kt h(p))   (E3; R_t = I, h = p_z)
     const double pz = x[P_ + 2];
-    const double tau = tanh(cx.gp.kt * pz);
-    const double mult = i < 2 ? tau : 1.0;
-    em.G(gb + gs::PLANAR + i, row_id(RK_PLANAR, c, i), x[V_ + i] - mult * x[U_ + i]);
+    const bool planar = cx.st.terrain == HIPNLP_TERRAIN_PLANAR;
     em.J(jb + js::PLANAR_V + i, row_id(RK_PLANAR, c, i), cb + V_ + i, 1.0);
-    em.J(jb + js::PLANAR_U + i, row_id(RK_PLANAR, c, i), cb + U_ + i, -mult);
-    if (i < 2) em.J(jb + js::PLANAR_PZ + i, row_id(RK_PLANAR, c, i), cb + P_ + 2, -(cx.gp.kt * (1.0 - tau * tau)) * x[U_ + i]);
+    if (planar) {  // planar complementarity  v - R_t diag(tau,tau,1) u,  tau = tanh(kt h(p))   (E3; R_t = I, h = p_z)
+        const double tau = tanh(cx.gp.kt * pz);
+        const double mult = i < 2 ? tau : 1.0;
+        em.G(gb + gs::PLANAR + i, row_id(RK_PLANAR, c, i), x[V_ + i] - mult * x[U_ + i]);
+        em.J(jb + js::PLANAR_U + 3 * i + i, row_id(RK_PLANAR, c, i), cb + U_ + i, -mult);
+        if (i < 2) em.J(jb + js::PLANAR_P + 3 * i + 2, row_id(RK_PLANAR, c, i), cb + P_ + 2, -(cx.gp.kt * (1.0 - tau * tau)) * x[U_ + i]);
+    }
     // control bound rows
     em.G(gb + gs::UB + i, row_id(RK_UB, c, i), x[U_ + i]);
     em.J(jb + js::UB + i, row_id(RK_UB, c, i), cb + U_ + i, 1.0);
@@ -196,8 +261,10 @@ template <class Em> HD void t_points_vec(Ctx<Em>& cx, int t) {
     // gradient of the point-local costs (k >= 1): swing height (E10), ||u_v||^2, ||f_dot||^2
     const double on = cx.ki.first ? 0.0 : 1.0;
     double* gr = s.grad + cb;
-    gr[V_ + i] = i < 2 ? on * cx.st.m_swing * x[V_ + i] : 0.0;
-    gr[P_ + i] = i == 2 ? on * cx.st.m_swing * (pz - s.pk[PK_REF + R_SWING]) : 0.0;
+    if (planar) {  // (smooth terrain: t_points_terrain writes these two)
+        gr[V_ + i] = i < 2 ? on * cx.st.m_swing * x[V_ + i] : 0.0;
+        gr[P_ + i] = i == 2 ? on * cx.st.m_swing * (pz - s.pk[PK_REF + R_SWING]) : 0.0;
+    }
     gr[U_ + i] = 2.0 * on * cx.st.m_ureg * x[U_ + i];
     gr[FD_ + i] = 2.0 * on * cx.st.m_fdreg * x[FD_ + i];
     gr[F_ + i] = 0.0;
@@ -211,35 +278,123 @@ template <class Em> HD void t_points_vec(Ctx<Em>& cx, int t) {
     }
 }
 
+// --- contact point rows on the SMOOTH terrain, lane c (called from t_points_scalar).  E3, E4, E6, E7, E10, E14-E17 -----------
+template <class Em> HD void t_points_terrain(Ctx<Em>& cx, int c) {
+    KnotScratch& s = cx.s;
+    const double* x = s.x + PT_ * c;
+    const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
+    Em& em = cx.em;
+    const double* p = x + P_;
+    const double* f = x + F_;
+    const double* v = x + V_;
+    const double* fd = x + FD_;
+    const double* u = x + U_;
+    double Z[10];
+    terrain_Z_jet(cx.st, p[0], p[1], 3, Z);
+    // grad h = (u1, u2, 1); the D2 tangents are d/dp_x, d/dp_y
+    const D2 u1(-Z[1], -Z[3], -Z[4]), u2(-Z[2], -Z[4], -Z[5]);
+    const D2 h(p[2] - Z[0], -Z[1], -Z[2]);
+    const D2 ud1(-(Z[3] * v[0] + Z[4] * v[1]), -(Z[6] * v[0] + Z[7] * v[1]), -(Z[7] * v[0] + Z[8] * v[1]));  // (d grad h/dp) v
+    const D2 ud2(-(Z[4] * v[0] + Z[5] * v[1]), -(Z[7] * v[0] + Z[8] * v[1]), -(Z[8] * v[0] + Z[9] * v[1]));
+    const D2 hdot = u1 * v[0] + u2 * v[1] + D2(v[2]);
+    const D2 nn = d2sqrt(D2(1.0) + u1 * u1 + u2 * u2);
+    const D2 inn = D2(1.0) / nn;
+    D2 n[3] = {u1 * inn, u2 * inn, inn};
+    const D2 ndu = n[0] * ud1 + n[1] * ud2;                                  // n . udot   (udot_z = 0)
+    D2 nd[3] = {(ud1 - n[0] * ndu) * inn, (ud2 - n[1] * ndu) * inn, (-(n[2] * ndu)) * inn};  // ndot = (udot - n (n.udot)) / |grad h|
+    // R_t = [xv yv n]:  y0 = n x e_x, xv = (y0 x n)/|.|, yv = n x xv      (terrain_descriptor.py:64-72)
+    D2 xv[3] = {n[2] * n[2] + n[1] * n[1], -(n[1] * n[0]), -(n[2] * n[0])};
+    const D2 ixn = D2(1.0) / d2sqrt(xv[0] * xv[0] + xv[1] * xv[1] + xv[2] * xv[2]);
+    for (int i = 0; i < 3; ++i) xv[i] = xv[i] * ixn;
+    D2 yv[3] = {n[1] * xv[2] - n[2] * xv[1], n[2] * xv[0] - n[0] * xv[2], n[0] * xv[1] - n[1] * xv[0]};
+    const double kt = cx.gp.kt, kbs = cx.gp.kbs;
+    // ---- planar complementarity  v - R_t diag(tau,tau,1) u   (E3)
+    const D2 tau = d2tanh(h * kt);
+    const double dtau_z = kt * (1.0 - tau.v * tau.v);                       // d tau / d p_z
+    for (int i = 0; i < 3; ++i) {
+        const D2 r = xv[i] * tau * u[0] + yv[i] * tau * u[1] + n[i] * u[2];
+        em.G(gb + gs::PLANAR + i, row_id(RK_PLANAR, c, i), v[i] - r.v);
+        em.J(jb + js::PLANAR_U + 3 * i + 0, row_id(RK_PLANAR, c, i), cb + U_ + 0, -(xv[i].v * tau.v));
+        em.J(jb + js::PLANAR_U + 3 * i + 1, row_id(RK_PLANAR, c, i), cb + U_ + 1, -(yv[i].v * tau.v));
+        em.J(jb + js::PLANAR_U + 3 * i + 2, row_id(RK_PLANAR, c, i), cb + U_ + 2, -n[i].v);
+        em.J(jb + js::PLANAR_P + 3 * i + 0, row_id(RK_PLANAR, c, i), cb + P_ + 0, -r.x);
+        em.J(jb + js::PLANAR_P + 3 * i + 1, row_id(RK_PLANAR, c, i), cb + P_ + 1, -r.y);
+        em.J(jb + js::PLANAR_P + 3 * i + 2, row_id(RK_PLANAR, c, i), cb + P_ + 2, -(xv[i].v * u[0] + yv[i].v * u[1]) * dtau_z);
+    }
+    // ---- dcc margin  eps - k h (n.f) - [hdot (n.f) + h f.ndot + h (n.fdot)]   (E4)
+    const D2 nf = n[0] * f[0] + n[1] * f[1] + n[2] * f[2];
+    const D2 nfd = n[0] * fd[0] + n[1] * fd[1] + n[2] * fd[2];
+    const D2 fnd = nd[0] * f[0] + nd[1] * f[1] + nd[2] * f[2];
+    const D2 margin = D2(cx.gp.eps) - h * nf * kbs - (hdot * nf + h * fnd + h * nfd);
+    em.G(gb + gs::DCC, row_id(RK_DCC, c, 0), margin.v);
+    em.J(jb + js::DCC_P + 0, row_id(RK_DCC, c, 0), cb + P_ + 0, margin.x);
+    em.J(jb + js::DCC_P + 1, row_id(RK_DCC, c, 0), cb + P_ + 1, margin.y);
+    em.J(jb + js::DCC_P + 2, row_id(RK_DCC, c, 0), cb + P_ + 2, -kbs * nf.v - (fnd.v + nfd.v));   // only h depends on p_z (dh/dp_z = 1)
+    const double gradh[3] = {u1.v, u2.v, 1.0};
+    for (int j = 0; j < 3; ++j) {
+        em.J(jb + js::DCC_F + j, row_id(RK_DCC, c, 0), cb + F_ + j, -kbs * h.v * n[j].v - hdot.v * n[j].v - h.v * nd[j].v);
+        em.J(jb + js::DCC_FD + j, row_id(RK_DCC, c, 0), cb + FD_ + j, -h.v * n[j].v);
+        // d/dv_j: hdot = grad h . v ; ndot = (dn/dp) v -> d ndot / d v_j = dn/dp_j (zero for j = z)
+        const double dndvj_f = j == 0 ? (n[0].x * f[0] + n[1].x * f[1] + n[2].x * f[2]) : (j == 1 ? (n[0].y * f[0] + n[1].y * f[1] + n[2].y * f[2]) : 0.0);
+        em.J(jb + js::DCC_V + j, row_id(RK_DCC, c, 0), cb + V_ + j, -gradh[j] * nf.v - h.v * dndvj_f);
+    }
+    // ---- height, normal force, friction cone  (E15-E17, E6, E7)
+    em.G(gb + gs::HEIGHT, row_id(RK_HEIGHT, c, 0), h.v);
+    for (int j = 0; j < 3; ++j) em.J(jb + js::HEIGHT + j, row_id(RK_HEIGHT, c, 0), cb + P_ + j, gradh[j]);
+    em.G(gb + gs::NORMAL, row_id(RK_NORMAL, c, 0), nf.v);
+    em.J(jb + js::NORMAL_P + 0, row_id(RK_NORMAL, c, 0), cb + P_ + 0, nf.x);
+    em.J(jb + js::NORMAL_P + 1, row_id(RK_NORMAL, c, 0), cb + P_ + 1, nf.y);
+    for (int j = 0; j < 3; ++j) em.J(jb + js::NORMAL_F + j, row_id(RK_NORMAL, c, 0), cb + F_ + j, n[j].v);
+    const double mu2 = cx.gp.mu * cx.gp.mu;
+    const D2 fcx = xv[0] * f[0] + xv[1] * f[1] + xv[2] * f[2], fcy = yv[0] * f[0] + yv[1] * f[1] + yv[2] * f[2], fcz = nf;
+    const D2 fric = -(fcx * fcx) - (fcy * fcy) + (fcz * fcz) * mu2;
+    em.G(gb + gs::FRICTION, row_id(RK_FRICTION, c, 0), fric.v);
+    em.J(jb + js::FRICTION_P + 0, row_id(RK_FRICTION, c, 0), cb + P_ + 0, fric.x);
+    em.J(jb + js::FRICTION_P + 1, row_id(RK_FRICTION, c, 0), cb + P_ + 1, fric.y);
+    for (int j = 0; j < 3; ++j)
+        em.J(jb + js::FRICTION_F + j, row_id(RK_FRICTION, c, 0), cb + F_ + j, -2.0 * fcx.v * xv[j].v - 2.0 * fcy.v * yv[j].v + 2.0 * mu2 * fcz.v * n[j].v);
+    // ---- swing height heuristic (E10):  0.5 [ (h - hd)^2 + |(R_t^T v)_xy|^2 ]   (k >= 1)
+    const double on = cx.ki.first ? 0.0 : 1.0;
+    const double msw = on * cx.st.m_swing;
+    const D2 dh = h - D2(s.pk[PK_REF + R_SWING]);
+    const D2 pvx = xv[0] * v[0] + xv[1] * v[1] + xv[2] * v[2], pvy = yv[0] * v[0] + yv[1] * v[1] + yv[2] * v[2];
+    const D2 sw = (dh * dh + pvx * pvx + pvy * pvy) * 0.5;
+    s.c_pt[c][0] = msw * sw.v;
+    double* gr = s.grad + cb;
+    gr[P_ + 0] = msw * sw.x; gr[P_ + 1] = msw * sw.y; gr[P_ + 2] = msw * dh.v;
+    for (int j = 0; j < 3; ++j) gr[V_ + j] = msw * (pvx.v * xv[j].v + pvy.v * yv[j].v);
+}
+
 // --- contact points, scalar rows and cost values: lane c, 8 tasks.  planner.py:656-697, 855-895 --------
 template <class Em> HD void t_points_scalar(Ctx<Em>& cx, int c) {
     KnotScratch& s = cx.s;
     const double* x = s.x + PT_ * c;
     const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
     Em& em = cx.em;
+    const double on = cx.ki.first ? 0.0 : 1.0;
+    s.c_pt[c][1] = on * cx.st.m_ureg * (x[U_] * x[U_] + x[U_ + 1] * x[U_ + 1] + x[U_ + 2] * x[U_ + 2]);
+    s.c_pt[c][2] = on * cx.st.m_fdreg * (x[FD_] * x[FD_] + x[FD_ + 1] * x[FD_ + 1] + x[FD_ + 2] * x[FD_ + 2]);
+    if (cx.st.terrain != HIPNLP_TERRAIN_PLANAR) { t_points_terrain(cx, c); return; }
     const double pz = x[P_ + 2], fz = x[F_ + 2], vz = x[V_ + 2], fdz = x[FD_ + 2];
     // dcc margin  eps - k h (n.f) - [hdot (n.f) + h f.ndot + h (n.fdot)]   (E4; n = e_z, ndot = 0, hdot = v_z)
     em.G(gb + gs::DCC, row_id(RK_DCC, c, 0), cx.gp.eps - cx.gp.kbs * (pz * fz) - (vz * fz + pz * fdz));
-    em.J(jb + js::DCC + 0, row_id(RK_DCC, c, 0), cb + P_ + 2, -cx.gp.kbs * fz - fdz);
-    em.J(jb + js::DCC + 1, row_id(RK_DCC, c, 0), cb + F_ + 2, -cx.gp.kbs * pz - vz);
-    em.J(jb + js::DCC + 2, row_id(RK_DCC, c, 0), cb + V_ + 2, -fz);
-    em.J(jb + js::DCC + 3, row_id(RK_DCC, c, 0), cb + FD_ + 2, -pz);
+    em.J(jb + js::DCC_P + 2, row_id(RK_DCC, c, 0), cb + P_ + 2, -cx.gp.kbs * fz - fdz);
+    em.J(jb + js::DCC_F + 2, row_id(RK_DCC, c, 0), cb + F_ + 2, -cx.gp.kbs * pz - vz);
+    em.J(jb + js::DCC_V + 2, row_id(RK_DCC, c, 0), cb + V_ + 2, -fz);
+    em.J(jb + js::DCC_FD + 2, row_id(RK_DCC, c, 0), cb + FD_ + 2, -pz);
     // height, normal force, friction cone  (E14, E6, E7)
     em.G(gb + gs::HEIGHT, row_id(RK_HEIGHT, c, 0), pz);
-    em.J(jb + js::HEIGHT, row_id(RK_HEIGHT, c, 0), cb + P_ + 2, 1.0);
+    em.J(jb + js::HEIGHT + 2, row_id(RK_HEIGHT, c, 0), cb + P_ + 2, 1.0);
     em.G(gb + gs::NORMAL, row_id(RK_NORMAL, c, 0), fz);
-    em.J(jb + js::NORMAL, row_id(RK_NORMAL, c, 0), cb + F_ + 2, 1.0);
+    em.J(jb + js::NORMAL_F + 2, row_id(RK_NORMAL, c, 0), cb + F_ + 2, 1.0);
     const double mu2 = cx.gp.mu * cx.gp.mu;
     em.G(gb + gs::FRICTION, row_id(RK_FRICTION, c, 0), -(x[F_] * x[F_]) - (x[F_ + 1] * x[F_ + 1]) + mu2 * (fz * fz));
-    em.J(jb + js::FRICTION + 0, row_id(RK_FRICTION, c, 0), cb + F_ + 0, -2.0 * x[F_]);
-    em.J(jb + js::FRICTION + 1, row_id(RK_FRICTION, c, 0), cb + F_ + 1, -2.0 * x[F_ + 1]);
-    em.J(jb + js::FRICTION + 2, row_id(RK_FRICTION, c, 0), cb + F_ + 2, 2.0 * mu2 * fz);
-    // values of the point-local costs (k >= 1)
-    const double on = cx.ki.first ? 0.0 : 1.0;
+    em.J(jb + js::FRICTION_F + 0, row_id(RK_FRICTION, c, 0), cb + F_ + 0, -2.0 * x[F_]);
+    em.J(jb + js::FRICTION_F + 1, row_id(RK_FRICTION, c, 0), cb + F_ + 1, -2.0 * x[F_ + 1]);
+    em.J(jb + js::FRICTION_F + 2, row_id(RK_FRICTION, c, 0), cb + F_ + 2, 2.0 * mu2 * fz);
+    // value of the swing-height cost (k >= 1)
     const double dh = pz - s.pk[PK_REF + R_SWING];
     s.c_pt[c][0] = on * cx.st.m_swing * (0.5 * (dh * dh + (x[V_] * x[V_] + x[V_ + 1] * x[V_ + 1])));
-    s.c_pt[c][1] = on * cx.st.m_ureg * (x[U_] * x[U_] + x[U_ + 1] * x[U_ + 1] + x[U_ + 2] * x[U_ + 2]);
-    s.c_pt[c][2] = on * cx.st.m_fdreg * (x[FD_] * x[FD_] + x[FD_ + 1] * x[FD_ + 1] + x[FD_ + 2] * x[FD_ + 2]);
 }
 
 // sums of the point-local cost partials: lane = term (swing, u_v, f_dot), runs behind t_points_scalar on the same wave
@@ -350,8 +505,17 @@ template <class Em> HD void t_small(Ctx<Em>& cx, int t) {
         s.grad[H_ + 3 + i] = 0.0;
         s.grad[COM_ + i] = 0.0; s.grad[PB_ + i] = 0.0; s.grad[VB_ + i] = 0.0;
     } else {      // minimum com height: h_terrain(com) = com_z ; com velocity and base quaternion velocity costs (k >= 0)
-        em.G(gs::COMH, row_id(RK_COMH, 0, 0), s.x[COM_ + 2]);
-        em.J(js::COMH, row_id(RK_COMH, 0, 0), COM_ + 2, 1.0);
+        if (cx.st.terrain == HIPNLP_TERRAIN_PLANAR) {
+            em.G(gs::COMH, row_id(RK_COMH, 0, 0), s.x[COM_ + 2]);
+            em.J(js::COMH + 2, row_id(RK_COMH, 0, 0), COM_ + 2, 1.0);
+        } else {
+            double Z[10];
+            terrain_Z_jet(cx.st, s.x[COM_], s.x[COM_ + 1], 1, Z);
+            em.G(gs::COMH, row_id(RK_COMH, 0, 0), s.x[COM_ + 2] - Z[0]);
+            em.J(js::COMH + 0, row_id(RK_COMH, 0, 0), COM_ + 0, -Z[1]);
+            em.J(js::COMH + 1, row_id(RK_COMH, 0, 0), COM_ + 1, -Z[2]);
+            em.J(js::COMH + 2, row_id(RK_COMH, 0, 0), COM_ + 2, 1.0);
+        }
         double c = 0.0;
         for (int i = 0; i < 4; ++i) {
             const double e = s.x[QD_ + i] - s.pk[PK_REF + R_BQV + i];

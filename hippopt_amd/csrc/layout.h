@@ -264,6 +264,17 @@ struct Layout {
         k.periodicity_type = st.periodicity_type;
         k.joint_reg_as_coded = st.joint_reg_as_coded;
         k.hdyn_x0 = st.periodicity_type == HIPNLP_EXPR_SKIP;
+        k.terrain = st.terrain;
+        k.n_steps = st.terrain == HIPNLP_TERRAIN_SMOOTH_STEPS ? st.n_terrain_steps : 0;
+        for (int i = 0; i < k.n_steps; ++i) {
+            const hipnlp_terrain_step& t = st.terrain_steps[i];
+            const double c = std::cos(t.orientation), sn = std::sin(t.orientation);
+            TerrainStepK& o = k.steps[i];
+            o.ox = t.position[0]; o.oy = t.position[1]; o.oz = t.position[2]; o.height = t.height;
+            o.ax = 2.0 / t.length * c; o.ay = 2.0 / t.length * sn;       // a = (2/L) q_x,  q = Rz^T (p - o)
+            o.bx = -2.0 / t.width * sn; o.by = 2.0 / t.width * c;        // b = (2/W) q_y
+            o.m = 2 * t.edge_sharpness; o.r = 2 * t.side_sharpness;
+        }
         for (int f = 0; f < 2; ++f) for (int i = 0; i < 3; ++i) k.yaw_corner[f][i] = st.yaw_corner[f][i];
         k.final_weight = st.final_state_weight;
         k.periodicity_weight = st.periodicity_weight;

@@ -62,8 +62,14 @@ struct KinTables {
 };
 
 // ---- graph constants (hipnlp_settings, flattened for the kernel) ------------------------------------
+struct TerrainStepK {   // one SmoothTerrain.step bump, pre-digested: a = ax dx + ay dy, b = bx dx + by dy (dx = p_x - ox, ...)
+    double ox, oy, oz, height, ax, ay, bx, by;
+    int32_t m, r;       // exponents 2*edge_sharpness and 2*side_sharpness
+};
 struct KSettings {
     int32_t horizon, final_type, periodicity_type, joint_reg_as_coded, hdyn_x0;
+    int32_t terrain, n_steps;
+    TerrainStepK steps[HIPNLP_MAX_TERRAIN_STEPS];
     int32_t yaw_corner[2][3];
     double final_weight, periodicity_weight;
     double m_centroid, w_comvel[3], m_comvel, m_frameq, m_baseq, m_baseqv, w_jreg[NJ], m_jreg, m_freg, m_yaw, m_swing, m_ureg, m_fdreg;
@@ -114,11 +120,17 @@ namespace js {
 // per point
 constexpr int FDYN = 0;          // IN_X 3, IN_Y 3, OUT_X 3, OUT_Y 3, X0 3
 constexpr int PDYN = 15;
-constexpr int PLANAR_V = 30, PLANAR_U = 33, PLANAR_PZ = 36;
-constexpr int DCC = 38;          // PZ, FZ, VZ, FDZ
-constexpr int HEIGHT = 42, NORMAL = 43, FRICTION = 44, UB = 47, FDB = 50;
-constexpr int KINC_P = 53, KINC_PB = 56, KINC_QB = 59, KINC_S = 71;  // QB [3][4], S [3][LEG_PATH]
-constexpr int PT_STRIDE = 71 + 3 * LEG_PATH;  // 89
+// terrain-dependent rows: superset of the entries of the planar and the smooth terrains (unused slots are simply never emitted)
+constexpr int PLANAR_V = 30;                  // [3]       d row_i / d v_i
+constexpr int PLANAR_U = 33;                  // [3][3]    d row_i / d u_j   (planar terrain: diagonal only)
+constexpr int PLANAR_P = 42;                  // [3][3]    d row_i / d p_j   (planar terrain: rows 0,1 x column 2)
+constexpr int DCC_P = 51, DCC_F = 54, DCC_V = 57, DCC_FD = 60;   // [3] each (planar terrain: z component only)
+constexpr int HEIGHT = 63;                    // [3]  d h / d p          (planar: z)
+constexpr int NORMAL_P = 66, NORMAL_F = 68;   // [2] d(n.f)/d p_x,p_y ; [3] d/d f   (planar: f_z)
+constexpr int FRICTION_P = 71, FRICTION_F = 73;  // [2] ; [3]
+constexpr int UB = 76, FDB = 79;
+constexpr int KINC_P = 82, KINC_PB = 85, KINC_QB = 88, KINC_S = 100;  // QB [3][4], S [3][LEG_PATH]
+constexpr int PT_STRIDE = 100 + 3 * LEG_PATH;  // 118
 constexpr int G0 = NC * PT_STRIDE;            // 712
 // trivial dynamics blocks: L*5 slots each: IN_X, IN_Y, OUT_X, OUT_Y, X0
 constexpr int PBDYN = G0, QBDYN = PBDYN + 15, SDYN = QBDYN + 20, COMDYN = SDYN + 5 * NJ;
@@ -130,7 +142,7 @@ constexpr int HDYN_ANG_COM_IN = HDYN_ANG_F_OUT + 48, HDYN_ANG_COM_OUT = HDYN_ANG
 constexpr int UNITQ = HDYN_ANG_COM_OUT + 6;
 constexpr int COMC_COM = UNITQ + 4, COMC_PB = COMC_COM + 3, COMC_QB = COMC_PB + 3, COMC_S = COMC_QB + 12;  // S [3][NJ]
 constexpr int CMMC_H = COMC_S + 3 * NJ, CMMC_QB = CMMC_H + 3, CMMC_QD = CMMC_QB + 12, CMMC_S = CMMC_QD + 12, CMMC_SD = CMMC_S + 3 * NJ;
-constexpr int AMB = CMMC_SD + 3 * NJ, COMH = AMB + 3, FEETD = COMH + 1;  // FEETD [2][LEG_PATH]
+constexpr int AMB = CMMC_SD + 3 * NJ, COMH = AMB + 3 /* [3] d h(com)/d com (planar: z) */, FEETD = COMH + 3;  // FEETD [2][LEG_PATH]
 constexpr int JPB = FEETD + 2 * LEG_PATH, JVB = JPB + NJ, FEETH = JVB + NJ;
 constexpr int FIN = FEETH + NC, PER0 = FIN + 81, PERN = PER0 + 84, COUNT = PERN + 84;
 }  // namespace js

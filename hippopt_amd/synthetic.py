@@ -150,3 +150,30 @@ def make_workload(settings: KinodynSettings, model: RobotModel, batch: int = 1, 
         r = np.random.RandomState(2000 + b)
         xs.append(x0 + 0.02 * r.standard_normal(x0.shape))
     return np.stack(xs), np.tile(p0, (batch, 1))
+
+
+def place_on_step_flanks(x: np.ndarray, settings: KinodynSettings, seed: int = 9) -> np.ndarray:
+    """Move the contact points and the com of every knot of x[(batch,) n] onto the flanks of the smooth terrain steps, where
+    exp(-g^(2 side)) actually varies (it is 0 or 1 to machine precision almost everywhere else), so that the terrain
+    derivatives up to third order take part in a parity check."""
+    rng = np.random.RandomState(seed)
+    steps = settings.terrain_steps
+    xs = x.reshape(-1, x.shape[-1])
+    for row in xs:
+        for k in range(settings.horizon_length):
+            for c in range(8):
+                st = steps[(k + c) % len(steps)]
+                a, b = rng.uniform(0.95, 1.01), rng.uniform(0.0, 0.9)
+                if c % 3 == 0:
+                    a, b = b, rng.uniform(0.95, 1.01)
+                sx, sy = rng.choice([-1.0, 1.0]), rng.choice([-1.0, 1.0])
+                co, sn = np.cos(st.get("orientation", 0.0)), np.sin(st.get("orientation", 0.0))
+                qx, qy = sx * 0.5 * st["length"] * a, sy * 0.5 * st["width"] * b
+                o = 189 * k + 15 * c + 6
+                row[o + 0] = st["position"][0] + co * qx - sn * qy
+                row[o + 1] = st["position"][1] + sn * qx + co * qy
+                row[o + 2] = 0.05 + 0.05 * rng.standard_normal()
+            st = steps[k % len(steps)]
+            row[189 * k + 180] = st["position"][0] - 0.5 * st["length"] * rng.uniform(0.96, 1.0)
+            row[189 * k + 181] = st["position"][1] + 0.1 * rng.standard_normal()
+    return x

@@ -4,8 +4,8 @@ import numpy as np
 import pytest
 
 from hippopt_amd import _abi
-from hippopt_amd.kinodyn_settings import periodic_step_settings, single_step_settings
-from hippopt_amd.synthetic import make_workload
+from hippopt_amd.kinodyn_settings import periodic_step_settings, single_step_settings, stairs_settings
+from hippopt_amd.synthetic import make_workload, place_on_step_flanks
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-11
@@ -46,6 +46,29 @@ def test_callback_matches_oracle(model, HipNlp, maker, horizon):
     assert np.array_equal(lbg, lbo) and np.array_equal(ubg, ubo)
     names, terms = eng.cost_terms()
     assert np.allclose(terms[0], orc.cost_terms(), rtol=1e-12, atol=1e-10)
+
+
+@pytest.mark.parametrize("horizon", [3, 50])
+def test_smooth_terrain_matches_oracle(model, HipNlp, horizon):
+    """Stairs configuration (main_walking_on_stairs.py, BASELINE configs[4]: smooth two-step terrain, N = 50): contact points on
+    the flanks of the bumps (batch row 0) and anywhere (row 1); an oriented, offset, differently-sharp step in the mix."""
+    from oracle_lib import Oracle
+    st = stairs_settings(horizon, model)
+    if horizon == 3:
+        st.terrain_steps[1].update(orientation=-0.7, position=(0.8, 0.2, 0.03), edge_sharpness=3, side_sharpness=4)
+    x, p = make_workload(st, model, batch=2, seed=2000 + horizon)
+    place_on_step_flanks(x[0], st, seed=horizon)
+    eng, orc = HipNlp(st, model), Oracle(st, model)
+    assert (eng.n, eng.m, eng.nnz, eng.np) == (orc.n, orc.m, orc.nnz, orc.np)
+    ir, jc = eng.sparsity()
+    iro, jco = orc.sparsity()
+    assert np.array_equal(ir, iro) and np.array_equal(jc, jco)
+    eng.set_params(p)
+    f, grad, g, jac = eng.eval(x)
+    for b in range(2):
+        fo, grado, go, jaco = orc.eval(x[b], p[b])
+        assert rel(f[b], fo) < TOL and rel(grad[b], grado) < TOL and rel(g[b], go) < TOL and rel(jac[b], jaco) < TOL
+    assert np.abs(jac[0]).max() > 1e3   # the flank derivatives really are exercised
 
 
 def test_minimize_modes_and_intended_joint_cost(model, HipNlp):
@@ -135,7 +158,7 @@ def test_large_horizon_properties(model, HipNlp):
     assert np.max(np.abs(gr[0][first:first + rows * nk])) < 1e-13
 
 
-@pytest.mark.parametrize("name", ["planner_periodic_N3", "planner_single_N3", "planner_costends_N2"])
+@pytest.mark.parametrize("name", ["planner_periodic_N3", "planner_single_N3", "planner_costends_N2", "planner_stairs_N3"])
 def test_gpu_matches_reference_planner_fixtures(model, HipNlp, name):
     """HIP path against the golden vectors generated by executing the reference's planner code on the CasADi-API stand-in
     (tools/gen_planner_fixtures.py): same x, p -> g (reference row order), bounds, f, grad f, jac g."""

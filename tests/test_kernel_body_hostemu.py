@@ -6,8 +6,8 @@ import numpy as np
 import pytest
 
 from hippopt_amd import _abi
-from hippopt_amd.kinodyn_settings import periodic_step_settings, single_step_settings
-from hippopt_amd.synthetic import make_workload
+from hippopt_amd.kinodyn_settings import periodic_step_settings, single_step_settings, stairs_settings
+from hippopt_amd.synthetic import make_workload, place_on_step_flanks
 from hostemu_lib import HostEmu
 from oracle_lib import Oracle
 
@@ -37,6 +37,52 @@ def test_body_matches_oracle(model, maker, horizon):
     lb, ub = o.bounds(p[0])
     lb2, ub2 = e.bounds(p[0])
     assert np.array_equal(lb, lb2) and np.array_equal(ub, ub2)
+
+
+@pytest.mark.parametrize("horizon", [2, 5])
+@pytest.mark.parametrize("oriented", [False, True])
+def test_smooth_terrain_body_matches_oracle(model, horizon, oriented):
+    """Stairs configuration (main_walking_on_stairs.py): closed-form third-order terrain jets of the kernel against the nested
+    forward-mode oracle, with the points ON the flanks of the bumps and far away from them (exp underflow branch)."""
+    st = stairs_settings(horizon, model)
+    if oriented:
+        st.terrain_steps[0]["orientation"] = 0.4
+        st.terrain_steps[1]["orientation"] = -1.1
+        st.terrain_steps[1]["position"] = (0.8, 0.2, 0.03)
+        st.terrain_steps[1]["edge_sharpness"], st.terrain_steps[1]["side_sharpness"] = 3, 4
+    o, e = Oracle(st, model), HostEmu(st, model)
+    assert (o.n, o.m, o.nnz) == (e.n, e.m, e.nnz)
+    assert o.row_blocks() == e.row_blocks()
+    ir, jc = o.sparsity()
+    ir2, jc2 = e.sparsity()
+    assert np.array_equal(ir, ir2) and np.array_equal(jc, jc2)
+    for flank in (True, False):
+        x, p = make_workload(st, model, 1, 300 + horizon)
+        if flank:
+            place_on_step_flanks(x, st, seed=horizon)
+        f, grad, g, jac = o.eval(x[0], p[0])
+        f2, grad2, g2, jac2, ct = e.eval(x[0], p[0])
+        assert not np.isnan(g2).any() and not np.isnan(jac2).any()
+        assert rel(np.array(f2), np.array(f)) < 1e-9 and rel(grad2, grad) < 1e-9 and rel(g2, g) < TOL and rel(jac2, jac) < 1e-9
+        assert np.allclose(ct, o.cost_terms(), rtol=1e-10, atol=1e-9)
+
+
+def test_smooth_terrain_body_matches_reference_planner_fixture(model):
+    """The kernel body (host emulation) directly against the stairs golden vectors of the reference's planner code."""
+    import json
+    import os
+    from test_golden_planner import GOLD, settings_for
+    z = np.load(os.path.join(GOLD, "planner_stairs_N3.npz"))
+    st = settings_for(json.loads(str(z["meta"])), model)
+    e = HostEmu(st, model)
+    f, grad, g, jac, _ = e.eval(z["x"], z["p"])
+    assert rel(g, z["g"]) < TOL and rel(grad, z["grad"]) < 1e-10 and abs(f - float(z["f"])) < 1e-10 * max(1.0, abs(float(z["f"])))
+    ir, jc = e.sparsity()
+    J = {(int(r), int(c)): v for r, c, v in zip(ir, jc, jac)}
+    for r, c, v in zip(z["jac_row"], z["jac_col"], z["jac_val"]):
+        got = J.pop((int(r), int(c)), None)
+        assert (abs(v) < 1e-12) if got is None else (abs(got - v) <= 1e-10 * max(1.0, abs(v)))
+    assert max((abs(v) for v in J.values()), default=0.0) < 1e-12
 
 
 def test_cost_modes(model):
