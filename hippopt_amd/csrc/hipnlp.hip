@@ -55,7 +55,8 @@ struct KArgs {
 #endif
 };
 
-struct DevEm {
+template <int TERRAIN> struct DevEm {
+    static constexpr int kTerrain = TERRAIN;
     double* g;
     double* jac;
     __device__ __forceinline__ void G(int slot, int, double v) { g[slot] = v; }
@@ -69,7 +70,7 @@ struct SharedTables {
     GParams gp;
 };
 
-__global__ __launch_bounds__(WG) void hipnlp_knot_kernel(KArgs a) {
+template <int TERRAIN> __global__ __launch_bounds__(WG) void hipnlp_knot_kernel(KArgs a) {
     __shared__ KnotScratch s;
     __shared__ SharedTables tabs;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -117,8 +118,8 @@ __global__ __launch_bounds__(WG) void hipnlp_knot_kernel(KArgs a) {
     }
 
     KnotInfo ki{k, N, first, last};
-    DevEm em{s.g, s.jac};
-    Ctx<DevEm> cx(s, tabs.kt, tabs.ks, tabs.gp, ki, em);
+    DevEm<TERRAIN> em{s.g, s.jac};
+    Ctx<DevEm<TERRAIN>> cx(s, tabs.kt, tabs.ks, tabs.gp, ki, em);
 #define DEV_R(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #ifdef HIPNLP_STAMPS
     // diagnostic build: every wave stamps the END of each task group it runs and its ARRIVAL at each barrier
@@ -463,7 +464,10 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     a.stamps = h->d_stamps;
 #endif
     HIP_TRY(h, hipEventRecord(e0, s));
-    hipLaunchKernelGGL(hipnlp_knot_kernel, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(WG), 0, s, a);
+    if (h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR)
+        hipLaunchKernelGGL(hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR>, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(WG), 0, s, a);
+    else
+        hipLaunchKernelGGL(hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS>, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(WG), 0, s, a);
     if (prof) HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 1)], s));
     hipLaunchKernelGGL(hipnlp_reduce_kernel, dim3(unsigned(h->batch)), dim3(RWG), 0, s,
                        (const double*)h->d_cost_knot, (const int32_t*)h->d_flags, h->nk, f_dev, h->d_cost_terms, h->d_flag);

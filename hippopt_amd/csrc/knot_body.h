@@ -99,6 +99,13 @@ template <class Em> struct Ctx {
         : s(s_), kt(kt_), st(st_), gp(gp_), ki(ki_), em(em_) {}
 };
 
+// The terrain kind is a COMPILE-TIME constant of the device emitters (one kernel instantiation per terrain: the planar kernel
+// must not pay registers for the smooth-terrain jets) and a run-time value (Em::kTerrain < 0) for the host-side recorders.
+template <class Em> HD bool terrain_is_planar(const Ctx<Em>& cx) {
+    if constexpr (Em::kTerrain >= 0) return Em::kTerrain == HIPNLP_TERRAIN_PLANAR;
+    else return cx.st.terrain == HIPNLP_TERRAIN_PLANAR;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // tiny helpers on raw arrays
 // ---------------------------------------------------------------------------------------------------
@@ -244,7 +251,7 @@ template <class Em> HD void t_points_vec(Ctx<Em>& cx, int t) {
     em.J(jb + js::PDYN + 9 + i, row_id(RK_PDYN_OUT, c, i), cb + V_ + i, -half);
     em.J(jb + js::PDYN + 12 + i, row_id(RK_PDYN_X0, c, i), cb + P_ + i, 1.0);
     const double pz = x[P_ + 2];
-    const bool planar = cx.st.terrain == HIPNLP_TERRAIN_PLANAR;
+    const bool planar = terrain_is_planar(cx);
     em.J(jb + js::PLANAR_V + i, row_id(RK_PLANAR, c, i), cb + V_ + i, 1.0);
     if (planar) {  // planar complementarity  v - R_t diag(tau,tau,1) u,  tau = tanh(kt h(p))   (E3; R_t = I, h = p_z)
         const double tau = tanh(cx.gp.kt * pz);
@@ -374,7 +381,7 @@ template <class Em> HD void t_points_scalar(Ctx<Em>& cx, int c) {
     const double on = cx.ki.first ? 0.0 : 1.0;
     s.c_pt[c][1] = on * cx.st.m_ureg * (x[U_] * x[U_] + x[U_ + 1] * x[U_ + 1] + x[U_ + 2] * x[U_ + 2]);
     s.c_pt[c][2] = on * cx.st.m_fdreg * (x[FD_] * x[FD_] + x[FD_ + 1] * x[FD_ + 1] + x[FD_ + 2] * x[FD_ + 2]);
-    if (cx.st.terrain != HIPNLP_TERRAIN_PLANAR) { t_points_terrain(cx, c); return; }
+    if (!terrain_is_planar(cx)) { t_points_terrain(cx, c); return; }
     const double pz = x[P_ + 2], fz = x[F_ + 2], vz = x[V_ + 2], fdz = x[FD_ + 2];
     // dcc margin  eps - k h (n.f) - [hdot (n.f) + h f.ndot + h (n.fdot)]   (E4; n = e_z, ndot = 0, hdot = v_z)
     em.G(gb + gs::DCC, row_id(RK_DCC, c, 0), cx.gp.eps - cx.gp.kbs * (pz * fz) - (vz * fz + pz * fdz));
@@ -505,7 +512,7 @@ template <class Em> HD void t_small(Ctx<Em>& cx, int t) {
         s.grad[H_ + 3 + i] = 0.0;
         s.grad[COM_ + i] = 0.0; s.grad[PB_ + i] = 0.0; s.grad[VB_ + i] = 0.0;
     } else {      // minimum com height: h_terrain(com) = com_z ; com velocity and base quaternion velocity costs (k >= 0)
-        if (cx.st.terrain == HIPNLP_TERRAIN_PLANAR) {
+        if (terrain_is_planar(cx)) {
             em.G(gs::COMH, row_id(RK_COMH, 0, 0), s.x[COM_ + 2]);
             em.J(js::COMH + 2, row_id(RK_COMH, 0, 0), COM_ + 2, 1.0);
         } else {

@@ -55,6 +55,7 @@ enum Variant : int { VAR_FIRST = 0, VAR_INTERIOR = 1, VAR_LAST = 2 };
 
 // recording emitter: remembers which row / column every native slot belongs to
 struct RecordEm {
+    static constexpr int kTerrain = -1;  // terrain kind read from KSettings at run time
     int* grow;        // [gs::COUNT] row id or -1
     int* jrowid;      // [js::COUNT]
     int* jcol;        // [js::COUNT]

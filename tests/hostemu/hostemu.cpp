@@ -12,6 +12,7 @@
 using namespace hipnlp;
 
 struct ValueEm {
+    static constexpr int kTerrain = -1;
     double* g;
     double* jac;
     void G(int slot, int, double v) { g[slot] = v; }

@@ -58,7 +58,7 @@ def test_smooth_terrain_matches_oracle(model, HipNlp, horizon):
         st.terrain_steps[1].update(orientation=-0.7, position=(0.8, 0.2, 0.03), edge_sharpness=3, side_sharpness=4)
     x, p = make_workload(st, model, batch=2, seed=2000 + horizon)
     place_on_step_flanks(x[0], st, seed=horizon)
-    eng, orc = HipNlp(st, model), Oracle(st, model)
+    eng, orc = HipNlp(st, model, batch=2), Oracle(st, model)
     assert (eng.n, eng.m, eng.nnz, eng.np) == (orc.n, orc.m, orc.nnz, orc.np)
     ir, jc = eng.sparsity()
     iro, jco = orc.sparsity()
@@ -68,7 +68,7 @@ def test_smooth_terrain_matches_oracle(model, HipNlp, horizon):
     for b in range(2):
         fo, grado, go, jaco = orc.eval(x[b], p[b])
         assert rel(f[b], fo) < TOL and rel(grad[b], grado) < TOL and rel(g[b], go) < TOL and rel(jac[b], jaco) < TOL
-    assert np.abs(jac[0]).max() > 1e3   # the flank derivatives really are exercised
+    assert np.abs(jac[0]).max() > 100.0   # the flank derivatives really are exercised (planar entries are O(1))
 
 
 def test_minimize_modes_and_intended_joint_cost(model, HipNlp):
