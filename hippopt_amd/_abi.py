@@ -75,3 +75,35 @@ class DimsC(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n", "m", "nnz", "np", "nnz_knot", "m_knot",
         "shard_g_rows", "shard_nnz", "shard_grad", "shard_jac_off", "shard_grad_off")]
+
+
+# ---- static pose finder (hipnlp_pose_*) ----------------------------------------------------------------------
+POSE_NX, POSE_NP, POSE_NCOST_TERMS = 81, 202, 7
+
+
+class PoseSettingsC(C.Structure):
+    _fields_ = [
+        ("terrain", C.c_int32),
+        ("n_terrain_steps", C.c_int32),
+        ("terrain_steps", TerrainStepC * MAX_TERRAIN_STEPS),
+        ("com_position_type", C.c_int32),
+        ("left_point_position_type", C.c_int32),
+        ("right_point_position_type", C.c_int32),
+        ("reserved_", C.c_int32),
+        ("base_quaternion_cost_multiplier", C.c_double),
+        ("desired_frame_quaternion_cost_multiplier", C.c_double),
+        ("com_regularization_cost_multiplier", C.c_double),
+        ("joint_regularization_cost_weights", C.c_double * NJ),
+        ("joint_regularization_cost_multiplier", C.c_double),
+        ("force_regularization_cost_multiplier", C.c_double),
+        ("average_force_regularization_cost_multiplier", C.c_double),
+        ("point_position_regularization_cost_multiplier", C.c_double),
+    ]
+
+
+class PoseDescC(C.Structure):
+    _fields_ = [("settings", PoseSettingsC), ("model", RobotModelC), ("batch", C.c_int32), ("device", C.c_int32)]
+
+
+class PoseDimsC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n", "m", "nnz", "np")]

@@ -103,16 +103,23 @@ class KinodynSettings:
         s.swing_foot_height_cost_multiplier = float(self.swing_foot_height_cost_multiplier)
         s.contact_velocity_control_cost_multiplier = float(self.contact_velocity_control_cost_multiplier)
         s.contact_force_control_cost_multiplier = float(self.contact_force_control_cost_multiplier)
-        s.n_terrain_steps = len(self.terrain_steps)
-        for i, st in enumerate(self.terrain_steps):
-            t = s.terrain_steps[i]
-            t.length, t.width, t.height = float(st["length"]), float(st["width"]), float(st["height"])
-            for j in range(3):
-                t.position[j] = float(st.get("position", (0.0, 0.0, 0.0))[j])
-            t.orientation = float(st.get("orientation", 0.0))
-            t.edge_sharpness = int(st.get("edge_sharpness", 5))
-            t.side_sharpness = int(st.get("side_sharpness", 10))
+        _fill_terrain_steps(s, self.terrain_steps)
         return s
+
+
+def _fill_terrain_steps(s, terrain_steps):
+    """SmoothTerrain.step arguments (smooth_terrain.py:266-336) -> hipnlp_terrain_step[]."""
+    if len(terrain_steps) > _abi.MAX_TERRAIN_STEPS:
+        raise ValueError("at most %d terrain steps" % _abi.MAX_TERRAIN_STEPS)
+    s.n_terrain_steps = len(terrain_steps)
+    for i, st in enumerate(terrain_steps):
+        t = s.terrain_steps[i]
+        t.length, t.width, t.height = float(st["length"]), float(st["width"]), float(st["height"])
+        for j in range(3):
+            t.position[j] = float(st.get("position", (0.0, 0.0, 0.0))[j])
+        t.orientation = float(st.get("orientation", 0.0))
+        t.edge_sharpness = int(st.get("edge_sharpness", 5))
+        t.side_sharpness = int(st.get("side_sharpness", 10))
 
 
 def periodic_step_settings(horizon=30, model=None) -> KinodynSettings:

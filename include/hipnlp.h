@@ -238,6 +238,77 @@ int hipnlp_last_kernel_ms(hipnlp_handle* h, float* ms);
 int hipnlp_profile_begin(hipnlp_handle* h, int max_launches);
 int hipnlp_profile_end(hipnlp_handle* h, double* mean_knot_kernel_ms, double* mean_launch_ms, int* count);
 
+/* =====================================================================================================================
+ * Static pose finder (BASELINE config 2): the single-knot NLP of
+ *   src/hippopt/turnkey_planners/humanoid_pose_finder/planner.py:323-399 (Planner.__init__) with
+ *   _add_contact_point_feasibility :670-722, _add_contact_kinematic_consistency :631-668,
+ *   _add_kinematics_constraints :446-519, _add_kinematics_regularization :521-629, _add_foot_regularization :724-768.
+ * One handle evaluates `batch` independent poses per launch (one workgroup per pose).
+ *
+ *   x [81]   reference creation order: per contact point c (left[0..3], right[0..3]): p (3), f (3); base position (3),
+ *            base quaternion xyzw (4), joint positions (23), com (3)
+ *   p [202]  reference creation order: descriptors 8x3 | mass | parametric_link_length_multipliers (1) |
+ *            parametric_link_densities (1) | gravity 6 | references.state: per point p,f,descriptor (9 each) |
+ *            base position 3 | base quaternion 4 | joints 23 | com 3 | references.frame_quaternion_xyzw 4 |
+ *            left_hand_position 3 | right_hand_position 3 | relaxed_complementarity_epsilon | static_friction |
+ *            maximum_joint_positions 23 | minimum_joint_positions 23 | left/right_hand_position_in_frame 3+3
+ *   g        subject_to call order: per point {complementarity, height, normal, friction, kinematics_consistency(3)},
+ *            unitary_quaternion, com_kinematics_consistency(3), centroidal_momentum_dynamics(6),
+ *            joint_position_bounds(23), then the optional sumsqr(.) == 0 rows of com / point positions in subject_to mode
+ *   f        base_quaternion_error, frame_rotation_error, com_position_error, joint_positions_error, per foot the
+ *            force average / point position / force regularisations
+ * Not built (HIPNLP_E_INVALID): the hand position expressions (settings default: skip) and the parametric-link model
+ * (adam.parametric; parametric_link_names is None in humanoid_pose_finder/main.py).
+ * ===================================================================================================================== */
+#define HIPNLP_POSE_NX 81
+#define HIPNLP_POSE_NP 202
+#define HIPNLP_POSE_NCOST_TERMS 7
+
+typedef struct hipnlp_pose_settings {
+    int32_t terrain;                    /* settings.terrain: HIPNLP_TERRAIN_*                       (planner.py:80) */
+    int32_t n_terrain_steps;
+    hipnlp_terrain_step terrain_steps[HIPNLP_MAX_TERRAIN_STEPS];
+    int32_t com_position_type;          /* settings.com_position_expression_type          (planner.py:566-573) */
+    int32_t left_point_position_type;   /* settings.left_point_position_expression_type   (planner.py:385-390) */
+    int32_t right_point_position_type;  /* settings.right_point_position_expression_type  (planner.py:391-396) */
+    int32_t reserved_;
+    double base_quaternion_cost_multiplier;
+    double desired_frame_quaternion_cost_multiplier;
+    double com_regularization_cost_multiplier;
+    double joint_regularization_cost_weights[HIPNLP_NJ];
+    double joint_regularization_cost_multiplier;
+    double force_regularization_cost_multiplier;
+    double average_force_regularization_cost_multiplier;
+    double point_position_regularization_cost_multiplier;
+} hipnlp_pose_settings;
+
+typedef struct hipnlp_pose_desc {
+    hipnlp_pose_settings settings;
+    hipnlp_robot_model model;
+    int32_t batch;    /* independent poses per call (>= 1) */
+    int32_t device;
+} hipnlp_pose_desc;
+
+typedef struct hipnlp_pose_dims { int32_t n, m, nnz, np; } hipnlp_pose_dims;
+typedef struct hipnlp_pose_handle hipnlp_pose_handle;
+
+/* Same contracts as the hipnlp_* functions of the same name above (shapes with n = 81, np = 202). */
+int hipnlp_pose_create(const hipnlp_pose_desc* desc, hipnlp_pose_handle** out);
+void hipnlp_pose_destroy(hipnlp_pose_handle* h);
+const char* hipnlp_pose_last_error(const hipnlp_pose_handle* h);
+int hipnlp_pose_get_dims(const hipnlp_pose_handle* h, hipnlp_pose_dims* out);
+int hipnlp_pose_set_params(hipnlp_pose_handle* h, const double* p /*[batch][202]*/);
+int hipnlp_pose_bounds(const hipnlp_pose_handle* h, double* lbg, double* ubg /*[batch][m]: bounds of every pose*/);
+int hipnlp_pose_sparsity(const hipnlp_pose_handle* h, int32_t* irow, int32_t* jcol);
+int hipnlp_pose_eval(hipnlp_pose_handle* h, const double* x, double* f, double* grad_f, double* g, double* jac);
+int hipnlp_pose_eval_device(hipnlp_pose_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev,
+                            double* jac_dev, void* stream);
+int hipnlp_pose_cost_terms(hipnlp_pose_handle* h, double* values /*[batch][HIPNLP_POSE_NCOST_TERMS]*/);
+const char* hipnlp_pose_cost_term_name(int i);
+int hipnlp_pose_num_row_blocks(const hipnlp_pose_handle* h);
+int hipnlp_pose_row_block(const hipnlp_pose_handle* h, int i, const char** name, int32_t* first_row, int32_t* rows);
+int hipnlp_pose_last_kernel_ms(hipnlp_pose_handle* h, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,7 +115,12 @@ template <class S> Q4<S> quaternion_xyzw_error(const Q4<S>& q, const Q4<S>& qd) 
 //            (smooth_terrain.py:201-227 height, :266-336 step), normal / orientation from the TerrainDescriptor defaults
 //            (terrain_descriptor.py:45-80), derivatives the way the reference takes them (cs.gradient / cs.jtimes -> D1<>).
 // ---------------------------------------------------------------------------------------------
-using TerrainSpec = hipnlp_settings;
+struct TerrainSpec {   // the terrain part of hipnlp_settings / hipnlp_pose_settings
+    int terrain, n_terrain_steps;
+    const hipnlp_terrain_step* terrain_steps;
+    TerrainSpec(const hipnlp_settings& s) : terrain(s.terrain), n_terrain_steps(s.n_terrain_steps), terrain_steps(s.terrain_steps) {}
+    TerrainSpec(const hipnlp_pose_settings& s) : terrain(s.terrain), n_terrain_steps(s.n_terrain_steps), terrain_steps(s.terrain_steps) {}
+};
 template <class S> S ipow(const S& x, int n) {  // x ** n for the integer-valued float exponents 2*edge_sharpness, 2*side_sharpness
     S r = S(1.0), b = x;
     while (n > 0) { if (n & 1) r = r * b; n >>= 1; if (n) b = b * b; }
@@ -198,6 +203,10 @@ template <class S> S dcc_complementarity_margin(const TerrainSpec& terrain, cons
     S complementarity = height * normal_force;
     S csi = height_derivative * normal_force + height * dot(f, normal_derivative) + height * normal_force_derivative;
     return eps - k_bs * complementarity - csi;
+}
+// E5  expressions/complementarity.py:113-150
+template <class S> S relaxed_complementarity_margin(const TerrainSpec& terrain, const V3<S>& p, const V3<S>& f, const S& eps) {
+    return eps - terrain_height(terrain, p) * dot(terrain_normal(terrain, p), f);
 }
 // E6  expressions/contacts.py:22-24
 template <class S> S normal_force_component(const TerrainSpec& terrain, const V3<S>& p, const V3<S>& f) { return dot(terrain_normal(terrain, p), f); }

@@ -132,6 +132,10 @@ template <class S> D1<S> operator/(const D1<S>& a, const D1<S>& b) { S q = a.v /
 template <class S> D1<S> sqrt(const D1<S>& a) { using std::sqrt; S r = sqrt(a.v); return D1<S>(r, a.d / (S(2.0) * r)); }
 template <class S> D1<S> exp(const D1<S>& a) { using std::exp; S e = exp(a.v); return D1<S>(e, e * a.d); }
 
+// an Opti *parameter*: symbolic for the structure tracer (never a literal constant), a number otherwise
+template <class S> struct ParamMaker { static S make(double v) { return S(v); } };
+template <> struct ParamMaker<Dep> { static Dep make(double) { Dep r; r.is_const = false; return r; } };
+
 // seeding helper: make an S from a value and a direction index
 template <class S> struct Seeder { static S make(double v, int dir) { return S::seed(v, dir); } };
 template <> struct Seeder<double> { static double make(double v, int) { return v; } };

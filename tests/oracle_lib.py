@@ -12,7 +12,7 @@ SO = os.path.join(ROOT, "oracle", "_build", "libkinodyn_oracle.so")
 
 
 def build(force=False):
-    src = [os.path.join(ROOT, "oracle", f) for f in ("kinodyn_oracle.cpp", "kinodyn_formulas.hpp", "scalar_types.hpp")]
+    src = [os.path.join(ROOT, "oracle", f) for f in ("kinodyn_oracle.cpp", "pose_oracle.cpp", "kinodyn_formulas.hpp", "scalar_types.hpp")]
     if force or not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in src):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
     return SO
@@ -29,6 +29,10 @@ def lib():
         _lib.oracle_create.argtypes = [C.POINTER(_abi.DescC)]
         _lib.oracle_destroy.argtypes = [C.c_void_p]
         _lib.oracle_cost_term_name.restype = C.c_char_p
+        _lib.oracle_pose_create.restype = C.c_void_p
+        _lib.oracle_pose_create.argtypes = [C.POINTER(_abi.PoseDescC)]
+        _lib.oracle_pose_destroy.argtypes = [C.c_void_p]
+        _lib.oracle_pose_cost_term_name.restype = C.c_char_p
     return _lib
 
 
@@ -92,4 +96,58 @@ class Oracle:
             a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
             lib().oracle_row_block(C.c_void_p(self.h), i, C.byref(name), C.byref(a), C.byref(b), C.byref(c), C.byref(d))
             out.append((name.value.decode(), a.value, b.value, c.value, d.value))
+        return out
+
+
+class PoseOracle:
+    """oracle/pose_oracle.cpp: the static pose finder NLP (one pose)."""
+
+    def __init__(self, settings, model):
+        self.desc = _abi.PoseDescC()
+        self.desc.settings = settings.to_c()
+        self.desc.model = model.to_c()
+        self.desc.batch = 1
+        self.h = lib().oracle_pose_create(C.byref(self.desc))
+        assert self.h
+        n, m, nnz, npar = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        lib().oracle_pose_dims(C.c_void_p(self.h), C.byref(n), C.byref(m), C.byref(nnz), C.byref(npar))
+        self.n, self.m, self.nnz, self.np = n.value, m.value, nnz.value, npar.value
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().oracle_pose_destroy(C.c_void_p(self.h))
+            self.h = None
+
+    def sparsity(self):
+        ir, jc = np.zeros(self.nnz, np.int32), np.zeros(self.nnz, np.int32)
+        lib().oracle_pose_sparsity(C.c_void_p(self.h), ir.ctypes.data_as(C.POINTER(C.c_int)), jc.ctypes.data_as(C.POINTER(C.c_int)))
+        return ir, jc
+
+    def bounds(self, p):
+        lb, ub = np.zeros(self.m), np.zeros(self.m)
+        lib().oracle_pose_bounds(C.c_void_p(self.h), _dp(np.ascontiguousarray(p)), _dp(lb), _dp(ub))
+        return lb, ub
+
+    def eval(self, x, p):
+        f = C.c_double()
+        grad, g, jac = np.zeros(self.n), np.zeros(self.m), np.zeros(self.nnz)
+        lib().oracle_pose_eval(C.c_void_p(self.h), _dp(np.ascontiguousarray(x)), _dp(np.ascontiguousarray(p)),
+                               C.byref(f), _dp(grad), _dp(g), _dp(jac))
+        return f.value, grad, g, jac
+
+    def cost_terms(self):
+        out = np.zeros(_abi.POSE_NCOST_TERMS)
+        lib().oracle_pose_cost_terms(C.c_void_p(self.h), _dp(out))
+        return out
+
+    def cost_term_names(self):
+        return [lib().oracle_pose_cost_term_name(i).decode() for i in range(_abi.POSE_NCOST_TERMS)]
+
+    def row_blocks(self):
+        out = []
+        for i in range(lib().oracle_pose_num_row_blocks(C.c_void_p(self.h))):
+            name = C.c_char_p()
+            a, b = C.c_int(), C.c_int()
+            lib().oracle_pose_row_block(C.c_void_p(self.h), i, C.byref(name), C.byref(a), C.byref(b))
+            out.append((name.value.decode(), a.value, b.value))
         return out

@@ -1,0 +1,105 @@
+"""The pose-finder oracle against golden vectors produced by EXECUTING THE REFERENCE'S OWN pose finder
+(hippopt/turnkey_planners/humanoid_pose_finder/planner.py and what it calls) on the CasADi / adam / liecasadi API stand-ins
+(tools/gen_pose_fixtures.py; third-party arithmetic itself unpinned)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from hippopt_amd import _abi
+from hippopt_amd.pose_settings import pose_finder_settings
+from oracle_lib import PoseOracle
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-11
+
+
+def pose_settings_for(meta, model):
+    st = pose_finder_settings(model)
+    if meta["config"] == "step_constrained":
+        st.terrain = _abi.TERRAIN_SMOOTH_STEPS
+        st.terrain_steps = [{"length": 0.6, "width": 0.8, "height": 0.2, "position": (0.45, 0.0, 0.0)}]
+        st.com_position_expression_type = _abi.EXPR_SUBJECT_TO
+        st.left_point_position_expression_type = _abi.EXPR_SUBJECT_TO
+        st.right_point_position_expression_type = _abi.EXPR_SKIP
+    return st
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if np.size(a) else 0.0
+
+
+def check_against_fixture(z, ir, jc, f, grad, g, jac, lb, ub, tol=TOL):
+    assert rel(g, z["g"]) < tol
+    assert np.array_equal(lb, z["lbg"]) and np.array_equal(ub, z["ubg"])
+    assert abs(f - float(z["f"])) / max(1.0, abs(float(z["f"]))) < tol
+    assert rel(grad, z["grad"]) < tol
+    pos = {(int(r), int(c)): i for i, (r, c) in enumerate(zip(ir, jc))}
+    seen = np.zeros(len(ir), bool)
+    for r, c, v in zip(z["jac_row"], z["jac_col"], z["jac_val"]):
+        i = pos.get((int(r), int(c)))
+        if i is None:
+            assert abs(v) < 1e-12, ("entry outside the pattern", r, c, v)
+            continue
+        seen[i] = True
+        assert abs(jac[i] - v) <= tol * max(1.0, abs(v)), (r, c, jac[i], v)
+    assert np.max(np.abs(jac[~seen]), initial=0.0) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["pose_default", "pose_step_constrained"])
+def test_pose_oracle_matches_reference_assembly(model, name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    st = pose_settings_for(json.loads(str(z["meta"])), model)
+    o = PoseOracle(st, model)
+    assert (o.n, o.m, o.np) == (z["x"].size, z["g"].size, z["p"].size)
+    f, grad, g, jac = o.eval(z["x"], z["p"])
+    lb, ub = o.bounds(z["p"])
+    ir, jc = o.sparsity()
+    check_against_fixture(z, ir, jc, f, grad, g, jac, lb, ub)
+    # constraint names and sizes in the reference's subject_to order ("state." prefix is the reference's flattened name)
+    # (the reference builds the names from MX.name() of the Opti variable, "opti_x_<i>_..." on the stand-in: i-th created
+    #  variable -> its flattened hippopt name)
+    import re
+    vnames = [str(s).rsplit(":", 1)[0] for s in z["vnames"]]
+    expand = lambda n: re.sub(r"^opti_x_(\d+)", lambda mo: vnames[int(mo.group(1))], n)  # noqa: E731
+    got = [(n, r) for n, _, r in o.row_blocks()]
+    assert got == list(zip([expand(str(s)) for s in z["names"]], [int(r) for r in z["rows"]]))
+    # per-name cost values grouped into the engine's cost terms
+    terms = dict(zip(o.cost_term_names(), o.cost_terms()))
+    ref = {}
+    for n, v in zip([expand(str(s)) for s in z["cost_names"]], z["cost_values"]):
+        key = ("average_force_regularization" if n.endswith("_average_regularization") else
+               "point_position_regularization" if n.endswith(".p_regularization") else
+               "force_regularization" if n.endswith(".f_regularization") else n)
+        ref[key] = ref.get(key, 0.0) + float(v)
+    for k, v in ref.items():
+        assert abs(terms[k] - v) <= 1e-11 * max(1.0, abs(v)), k
+    assert abs(sum(terms.values()) - float(z["f"])) < 1e-10
+
+
+def test_pose_fixture_layout_names():
+    """Variable / parameter creation order the engine's x [81] / p [202] layouts assume (include/hipnlp.h)."""
+    z = np.load(os.path.join(GOLD, "pose_default.npz"))
+    v = [str(s) for s in z["vnames"]]
+    assert v[:4] == ["state.contact_points.left[0].p:3", "state.contact_points.left[0].f:3",
+                     "state.contact_points.left[1].p:3", "state.contact_points.left[1].f:3"]
+    assert v[16:] == ["state.kinematics.base.position:3", "state.kinematics.base.quaternion_xyzw:4",
+                      "state.kinematics.joints.positions:23", "state.com:3"]
+    p = [str(s) for s in z["pnames"]]
+    sizes = [int(s.rsplit(":", 1)[1]) for s in p]
+    names = [s.rsplit(":", 1)[0] for s in p]
+    off = dict(zip(names, np.concatenate([[0], np.cumsum(sizes)[:-1]])))
+    from hippopt_amd import pose_settings as ps
+    assert sum(sizes) == _abi.POSE_NP
+    assert off["mass"] == ps.P_MASS and off["gravity"] == ps.P_GRAV
+    assert off["references.state.contact_points.left[0].p"] == ps.P_REF
+    assert off["references.state.contact_points.left[0].f"] == ps.P_REF + 3
+    assert off["references.state.contact_points.right[3].p"] == ps.P_REF + 63
+    assert off["references.state.kinematics.base.position"] == ps.P_REF_PB
+    assert off["references.state.kinematics.base.quaternion_xyzw"] == ps.P_REF_QB
+    assert off["references.state.kinematics.joints.positions"] == ps.P_REF_S
+    assert off["references.state.com"] == ps.P_REF_COM
+    assert off["references.frame_quaternion_xyzw"] == ps.P_REF_FQ
+    assert off["relaxed_complementarity_epsilon"] == ps.P_EPS and off["static_friction"] == ps.P_MU
+    assert off["maximum_joint_positions"] == ps.P_SMAX and off["minimum_joint_positions"] == ps.P_SMIN
