@@ -297,15 +297,7 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     const hipnlp_settings& st = desc->settings;
     auto fail = [&](int code, const std::string& msg) { g_create_error = msg; free_all(h); return code; };
     if (st.horizon < 2) return fail(HIPNLP_E_INVALID, "settings.horizon must be >= 2");
-    if (st.terrain != HIPNLP_TERRAIN_PLANAR && st.terrain != HIPNLP_TERRAIN_SMOOTH_STEPS) return fail(HIPNLP_E_INVALID, "unknown terrain kind");
-    if (st.terrain == HIPNLP_TERRAIN_SMOOTH_STEPS) {
-        if (st.n_terrain_steps < 1 || st.n_terrain_steps > HIPNLP_MAX_TERRAIN_STEPS) return fail(HIPNLP_E_INVALID, "n_terrain_steps must be in 1..HIPNLP_MAX_TERRAIN_STEPS");
-        for (int i = 0; i < st.n_terrain_steps; ++i) {
-            const hipnlp_terrain_step& t = st.terrain_steps[i];
-            if (!(t.length > 0) || !(t.width > 0) || t.edge_sharpness < 2 || t.side_sharpness < 2)
-                return fail(HIPNLP_E_INVALID, "terrain step: length, width must be positive and the sharpness exponents >= 2");
-        }
-    }
+    if (const char* te = Layout::check_terrain(st.terrain, st.n_terrain_steps, st.terrain_steps)) return fail(HIPNLP_E_INVALID, te);
     if (desc->batch < 1) return fail(HIPNLP_E_INVALID, "batch must be >= 1");
     for (int f = 0; f < 2; ++f) for (int i = 0; i < 3; ++i)
         if (st.yaw_corner[f][i] < 0 || st.yaw_corner[f][i] > 3) return fail(HIPNLP_E_INVALID, "yaw_corner indices must be in 0..3");

@@ -213,6 +213,7 @@ HD void terrain_Z_jet(const KSettings& st, double px, double py, int order, doub
         out[3] += p2 * gx * gx + p1 * gxx;
         out[4] += p2 * gx * gy + p1 * gxy;
         out[5] += p2 * gy * gy + p1 * gyy;
+        if (order < 3) continue;
         const double gxxx = A3 * t.ax * t.ax * t.ax + B3 * t.bx * t.bx * t.bx, gxxy = A3 * t.ax * t.ax * t.ay + B3 * t.bx * t.bx * t.by;
         const double gxyy = A3 * t.ax * t.ay * t.ay + B3 * t.bx * t.by * t.by, gyyy = A3 * t.ay * t.ay * t.ay + B3 * t.by * t.by * t.by;
         out[6] += p3 * gx * gx * gx + p2 * (3.0 * gxx * gx) + p1 * gxxx;
@@ -285,6 +286,63 @@ template <class Em> HD void t_points_vec(Ctx<Em>& cx, int t) {
     }
 }
 
+// height, normal and orientation of the smooth terrain at one point with their d/dp_x, d/dp_y (E15: terrain_descriptor.py:45-80)
+// from the jet of Z (second order suffices for the frame itself; the tangents of u1, u2 use Zxx, Zxy, Zyy)
+struct TerrainFrame { D2 u1, u2, h, inn, n[3], xv[3], yv[3]; };
+HD void terrain_frame(const double* Z, double pz, TerrainFrame& t) {
+    t.u1 = D2(-Z[1], -Z[3], -Z[4]);           // grad h = (u1, u2, 1); the D2 tangents are d/dp_x, d/dp_y
+    t.u2 = D2(-Z[2], -Z[4], -Z[5]);
+    t.h = D2(pz - Z[0], -Z[1], -Z[2]);
+    const D2 nn = d2sqrt(D2(1.0) + t.u1 * t.u1 + t.u2 * t.u2);
+    t.inn = D2(1.0) / nn;
+    t.n[0] = t.u1 * t.inn; t.n[1] = t.u2 * t.inn; t.n[2] = t.inn;
+    // R_t = [xv yv n]:  y0 = n x e_x, xv = (y0 x n)/|.|, yv = n x xv      (terrain_descriptor.py:64-72)
+    t.xv[0] = t.n[2] * t.n[2] + t.n[1] * t.n[1]; t.xv[1] = -(t.n[1] * t.n[0]); t.xv[2] = -(t.n[2] * t.n[0]);
+    const D2 ixn = D2(1.0) / d2sqrt(t.xv[0] * t.xv[0] + t.xv[1] * t.xv[1] + t.xv[2] * t.xv[2]);
+    for (int i = 0; i < 3; ++i) t.xv[i] = t.xv[i] * ixn;
+    t.yv[0] = t.n[1] * t.xv[2] - t.n[2] * t.xv[1]; t.yv[1] = t.n[2] * t.xv[0] - t.n[0] * t.xv[2]; t.yv[2] = t.n[0] * t.xv[1] - t.n[1] * t.xv[0];
+}
+
+// height, normal force, friction cone rows of contact point c on the smooth terrain  (E15-E17, E6, E7); shared with pose_body.h
+template <class Em> HD void point_hnf_smooth(Ctx<Em>& cx, int c, const TerrainFrame& tf) {
+    Em& em = cx.em;
+    const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
+    const double* f = cx.s.x + cb + F_;
+    const D2 *n = tf.n, *xv = tf.xv, *yv = tf.yv;
+    const double gradh[3] = {tf.u1.v, tf.u2.v, 1.0};
+    const D2 nf = n[0] * f[0] + n[1] * f[1] + n[2] * f[2];
+    em.G(gb + gs::HEIGHT, row_id(RK_HEIGHT, c, 0), tf.h.v);
+    for (int j = 0; j < 3; ++j) em.J(jb + js::HEIGHT + j, row_id(RK_HEIGHT, c, 0), cb + P_ + j, gradh[j]);
+    em.G(gb + gs::NORMAL, row_id(RK_NORMAL, c, 0), nf.v);
+    em.J(jb + js::NORMAL_P + 0, row_id(RK_NORMAL, c, 0), cb + P_ + 0, nf.x);
+    em.J(jb + js::NORMAL_P + 1, row_id(RK_NORMAL, c, 0), cb + P_ + 1, nf.y);
+    for (int j = 0; j < 3; ++j) em.J(jb + js::NORMAL_F + j, row_id(RK_NORMAL, c, 0), cb + F_ + j, n[j].v);
+    const double mu2 = cx.gp.mu * cx.gp.mu;
+    const D2 fcx = xv[0] * f[0] + xv[1] * f[1] + xv[2] * f[2], fcy = yv[0] * f[0] + yv[1] * f[1] + yv[2] * f[2], fcz = nf;
+    const D2 fric = -(fcx * fcx) - (fcy * fcy) + (fcz * fcz) * mu2;
+    em.G(gb + gs::FRICTION, row_id(RK_FRICTION, c, 0), fric.v);
+    em.J(jb + js::FRICTION_P + 0, row_id(RK_FRICTION, c, 0), cb + P_ + 0, fric.x);
+    em.J(jb + js::FRICTION_P + 1, row_id(RK_FRICTION, c, 0), cb + P_ + 1, fric.y);
+    for (int j = 0; j < 3; ++j)
+        em.J(jb + js::FRICTION_F + j, row_id(RK_FRICTION, c, 0), cb + F_ + j, -2.0 * fcx.v * xv[j].v - 2.0 * fcy.v * yv[j].v + 2.0 * mu2 * fcz.v * n[j].v);
+}
+// the same three rows on the planar terrain (E14: h = p_z, n = e_z, R_t = I)
+template <class Em> HD void point_hnf_planar(Ctx<Em>& cx, int c) {
+    Em& em = cx.em;
+    const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
+    const double* x = cx.s.x + cb;
+    const double pz = x[P_ + 2], fz = x[F_ + 2];
+    em.G(gb + gs::HEIGHT, row_id(RK_HEIGHT, c, 0), pz);
+    em.J(jb + js::HEIGHT + 2, row_id(RK_HEIGHT, c, 0), cb + P_ + 2, 1.0);
+    em.G(gb + gs::NORMAL, row_id(RK_NORMAL, c, 0), fz);
+    em.J(jb + js::NORMAL_F + 2, row_id(RK_NORMAL, c, 0), cb + F_ + 2, 1.0);
+    const double mu2 = cx.gp.mu * cx.gp.mu;
+    em.G(gb + gs::FRICTION, row_id(RK_FRICTION, c, 0), -(x[F_] * x[F_]) - (x[F_ + 1] * x[F_ + 1]) + mu2 * (fz * fz));
+    em.J(jb + js::FRICTION_F + 0, row_id(RK_FRICTION, c, 0), cb + F_ + 0, -2.0 * x[F_]);
+    em.J(jb + js::FRICTION_F + 1, row_id(RK_FRICTION, c, 0), cb + F_ + 1, -2.0 * x[F_ + 1]);
+    em.J(jb + js::FRICTION_F + 2, row_id(RK_FRICTION, c, 0), cb + F_ + 2, 2.0 * mu2 * fz);
+}
+
 // --- contact point rows on the SMOOTH terrain, lane c (called from t_points_scalar).  E3, E4, E6, E7, E10, E14-E17 -----------
 template <class Em> HD void t_points_terrain(Ctx<Em>& cx, int c) {
     KnotScratch& s = cx.s;
@@ -298,22 +356,15 @@ template <class Em> HD void t_points_terrain(Ctx<Em>& cx, int c) {
     const double* u = x + U_;
     double Z[10];
     terrain_Z_jet(cx.st, p[0], p[1], 3, Z);
-    // grad h = (u1, u2, 1); the D2 tangents are d/dp_x, d/dp_y
-    const D2 u1(-Z[1], -Z[3], -Z[4]), u2(-Z[2], -Z[4], -Z[5]);
-    const D2 h(p[2] - Z[0], -Z[1], -Z[2]);
+    TerrainFrame tf;
+    terrain_frame(Z, p[2], tf);
+    const D2 &u1 = tf.u1, &u2 = tf.u2, &h = tf.h, &inn = tf.inn;
+    const D2 *n = tf.n, *xv = tf.xv, *yv = tf.yv;
     const D2 ud1(-(Z[3] * v[0] + Z[4] * v[1]), -(Z[6] * v[0] + Z[7] * v[1]), -(Z[7] * v[0] + Z[8] * v[1]));  // (d grad h/dp) v
     const D2 ud2(-(Z[4] * v[0] + Z[5] * v[1]), -(Z[7] * v[0] + Z[8] * v[1]), -(Z[8] * v[0] + Z[9] * v[1]));
     const D2 hdot = u1 * v[0] + u2 * v[1] + D2(v[2]);
-    const D2 nn = d2sqrt(D2(1.0) + u1 * u1 + u2 * u2);
-    const D2 inn = D2(1.0) / nn;
-    D2 n[3] = {u1 * inn, u2 * inn, inn};
     const D2 ndu = n[0] * ud1 + n[1] * ud2;                                  // n . udot   (udot_z = 0)
     D2 nd[3] = {(ud1 - n[0] * ndu) * inn, (ud2 - n[1] * ndu) * inn, (-(n[2] * ndu)) * inn};  // ndot = (udot - n (n.udot)) / |grad h|
-    // R_t = [xv yv n]:  y0 = n x e_x, xv = (y0 x n)/|.|, yv = n x xv      (terrain_descriptor.py:64-72)
-    D2 xv[3] = {n[2] * n[2] + n[1] * n[1], -(n[1] * n[0]), -(n[2] * n[0])};
-    const D2 ixn = D2(1.0) / d2sqrt(xv[0] * xv[0] + xv[1] * xv[1] + xv[2] * xv[2]);
-    for (int i = 0; i < 3; ++i) xv[i] = xv[i] * ixn;
-    D2 yv[3] = {n[1] * xv[2] - n[2] * xv[1], n[2] * xv[0] - n[0] * xv[2], n[0] * xv[1] - n[1] * xv[0]};
     const double kt = cx.gp.kt, kbs = cx.gp.kbs;
     // ---- planar complementarity  v - R_t diag(tau,tau,1) u   (E3)
     const D2 tau = d2tanh(h * kt);
@@ -345,21 +396,7 @@ template <class Em> HD void t_points_terrain(Ctx<Em>& cx, int c) {
         const double dndvj_f = j == 0 ? (n[0].x * f[0] + n[1].x * f[1] + n[2].x * f[2]) : (j == 1 ? (n[0].y * f[0] + n[1].y * f[1] + n[2].y * f[2]) : 0.0);
         em.J(jb + js::DCC_V + j, row_id(RK_DCC, c, 0), cb + V_ + j, -gradh[j] * nf.v - h.v * dndvj_f);
     }
-    // ---- height, normal force, friction cone  (E15-E17, E6, E7)
-    em.G(gb + gs::HEIGHT, row_id(RK_HEIGHT, c, 0), h.v);
-    for (int j = 0; j < 3; ++j) em.J(jb + js::HEIGHT + j, row_id(RK_HEIGHT, c, 0), cb + P_ + j, gradh[j]);
-    em.G(gb + gs::NORMAL, row_id(RK_NORMAL, c, 0), nf.v);
-    em.J(jb + js::NORMAL_P + 0, row_id(RK_NORMAL, c, 0), cb + P_ + 0, nf.x);
-    em.J(jb + js::NORMAL_P + 1, row_id(RK_NORMAL, c, 0), cb + P_ + 1, nf.y);
-    for (int j = 0; j < 3; ++j) em.J(jb + js::NORMAL_F + j, row_id(RK_NORMAL, c, 0), cb + F_ + j, n[j].v);
-    const double mu2 = cx.gp.mu * cx.gp.mu;
-    const D2 fcx = xv[0] * f[0] + xv[1] * f[1] + xv[2] * f[2], fcy = yv[0] * f[0] + yv[1] * f[1] + yv[2] * f[2], fcz = nf;
-    const D2 fric = -(fcx * fcx) - (fcy * fcy) + (fcz * fcz) * mu2;
-    em.G(gb + gs::FRICTION, row_id(RK_FRICTION, c, 0), fric.v);
-    em.J(jb + js::FRICTION_P + 0, row_id(RK_FRICTION, c, 0), cb + P_ + 0, fric.x);
-    em.J(jb + js::FRICTION_P + 1, row_id(RK_FRICTION, c, 0), cb + P_ + 1, fric.y);
-    for (int j = 0; j < 3; ++j)
-        em.J(jb + js::FRICTION_F + j, row_id(RK_FRICTION, c, 0), cb + F_ + j, -2.0 * fcx.v * xv[j].v - 2.0 * fcy.v * yv[j].v + 2.0 * mu2 * fcz.v * n[j].v);
+    point_hnf_smooth(cx, c, tf);
     // ---- swing height heuristic (E10):  0.5 [ (h - hd)^2 + |(R_t^T v)_xy|^2 ]   (k >= 1)
     const double on = cx.ki.first ? 0.0 : 1.0;
     const double msw = on * cx.st.m_swing;
@@ -389,16 +426,7 @@ template <class Em> HD void t_points_scalar(Ctx<Em>& cx, int c) {
     em.J(jb + js::DCC_F + 2, row_id(RK_DCC, c, 0), cb + F_ + 2, -cx.gp.kbs * pz - vz);
     em.J(jb + js::DCC_V + 2, row_id(RK_DCC, c, 0), cb + V_ + 2, -fz);
     em.J(jb + js::DCC_FD + 2, row_id(RK_DCC, c, 0), cb + FD_ + 2, -pz);
-    // height, normal force, friction cone  (E14, E6, E7)
-    em.G(gb + gs::HEIGHT, row_id(RK_HEIGHT, c, 0), pz);
-    em.J(jb + js::HEIGHT + 2, row_id(RK_HEIGHT, c, 0), cb + P_ + 2, 1.0);
-    em.G(gb + gs::NORMAL, row_id(RK_NORMAL, c, 0), fz);
-    em.J(jb + js::NORMAL_F + 2, row_id(RK_NORMAL, c, 0), cb + F_ + 2, 1.0);
-    const double mu2 = cx.gp.mu * cx.gp.mu;
-    em.G(gb + gs::FRICTION, row_id(RK_FRICTION, c, 0), -(x[F_] * x[F_]) - (x[F_ + 1] * x[F_ + 1]) + mu2 * (fz * fz));
-    em.J(jb + js::FRICTION_F + 0, row_id(RK_FRICTION, c, 0), cb + F_ + 0, -2.0 * x[F_]);
-    em.J(jb + js::FRICTION_F + 1, row_id(RK_FRICTION, c, 0), cb + F_ + 1, -2.0 * x[F_ + 1]);
-    em.J(jb + js::FRICTION_F + 2, row_id(RK_FRICTION, c, 0), cb + F_ + 2, 2.0 * mu2 * fz);
+    point_hnf_planar(cx, c);
     // value of the swing-height cost (k >= 1)
     const double dh = pz - s.pk[PK_REF + R_SWING];
     s.c_pt[c][0] = on * cx.st.m_swing * (0.5 * (dh * dh + (x[V_] * x[V_] + x[V_ + 1] * x[V_ + 1])));
@@ -413,6 +441,13 @@ template <class Em> HD void t_points_cost(Ctx<Em>& cx, int t) {
     s.cost[CT_SWING + t] = acc;
 }
 
+// identity / zero padding slots of the ancestor and descendant lists, lanes e < 16
+HD void scratch_padding(KnotScratch& s, int e) {
+    if (e < 16) s.own[NL][e] = 0.0;
+    if (e < 9) s.Lj[NJ][e] = (e % 4 == 0) ? 1.0 : 0.0;
+    if (e < 3) { s.Tj[NJ][e] = 0.0; s.Uj[NJ][e] = 0.0; s.aw[NJ][e] = 0.0; }
+}
+
 // --- trivial dynamics of base / joints / com, lane e over 33 state components.  planner.py:522-564 -----
 template <class Em> HD void t_dyn(Ctx<Em>& cx, int e) {
     KnotScratch& s = cx.s;
@@ -425,9 +460,7 @@ template <class Em> HD void t_dyn(Ctx<Em>& cx, int e) {
     const int kout = kin + 1, kx0 = kin + 2;
     Em& em = cx.em;
     // padding slots of the ancestor / descendant lists (identity rotation, zero terms), one element per lane
-    if (e < 16) s.own[NL][e] = 0.0;
-    if (e < 9) s.Lj[NJ][e] = (e % 4 == 0) ? 1.0 : 0.0;
-    if (e < 3) { s.Tj[NJ][e] = 0.0; s.Uj[NJ][e] = 0.0; s.aw[NJ][e] = 0.0; }
+    scratch_padding(s, e);
     em.G(gslot + i, row_id(kin, 0, i), s.x[X] - (s.xm[X] + half * (s.xm[Y] + s.x[Y])));
     em.G(gx0 + i, row_id(kx0, 0, i), s.x[X]);
     em.J(jslot + 0 * L + i, row_id(kin, 0, i), X, 1.0);
@@ -435,6 +468,21 @@ template <class Em> HD void t_dyn(Ctx<Em>& cx, int e) {
     em.J(jslot + 2 * L + i, row_id(kout, 0, i), X, -1.0);
     em.J(jslot + 3 * L + i, row_id(kout, 0, i), Y, -half);
     em.J(jslot + 4 * L + i, row_id(kx0, 0, i), X, 1.0);
+}
+
+// parent_R_child = R_fix * (cq (I - a a^T) + sq [a]x + a a^T)   (adam R_from_axis_angle) -> s.Lj[j]
+template <class Em> HD void joint_transform(Ctx<Em>& cx, int j) {
+    KnotScratch& s = cx.s;
+    const double* a = cx.kt.axis[j];
+    double sq, cq;
+    sincos(s.x[S_ + j], &sq, &cq);
+    double Ra[9];
+    for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc) { const double aa = a[r] * a[cc]; Ra[3 * r + cc] = cq * ((r == cc ? 1.0 : 0.0) - aa) + aa; }
+    Ra[1] -= sq * a[2]; Ra[2] += sq * a[1];
+    Ra[3] += sq * a[2]; Ra[5] -= sq * a[0];
+    Ra[6] -= sq * a[1]; Ra[7] += sq * a[0];
+    matmul3(cx.kt.R_fix[j], Ra, s.Lj[j]);
 }
 
 // --- joint-wise rows, joint regularisation cost and the local joint transform, lane j (23) -------------
@@ -455,17 +503,7 @@ template <class Em> HD void t_joints(Ctx<Em>& cx, int j) {
     s.c_joint[j] = m * c;
     s.grad[S_ + j] = 2.0 * m * t * w;
     s.grad[SD_ + j] = m * gsd;
-    // parent_R_child = R_fix * (cq (I - a a^T) + sq [a]x + a a^T)   (adam R_from_axis_angle)
-    const double* a = cx.kt.axis[j];
-    double sq, cq;
-    sincos(s.x[S_ + j], &sq, &cq);
-    double Ra[9];
-    for (int r = 0; r < 3; ++r)
-        for (int cc = 0; cc < 3; ++cc) { const double aa = a[r] * a[cc]; Ra[3 * r + cc] = cq * ((r == cc ? 1.0 : 0.0) - aa) + aa; }
-    Ra[1] -= sq * a[2]; Ra[2] += sq * a[1];
-    Ra[3] += sq * a[2]; Ra[5] -= sq * a[0];
-    Ra[6] -= sq * a[1]; Ra[7] += sq * a[0];
-    matmul3(cx.kt.R_fix[j], Ra, s.Lj[j]);
+    joint_transform(cx, j);
 }
 
 template <class Em> HD void t_joint_cost(Ctx<Em>& cx, int) {  // behind t_joints on the same wave

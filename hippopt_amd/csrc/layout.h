@@ -258,17 +258,12 @@ struct Layout {
         return true;
     }
 
-    static KSettings make_ksettings(const hipnlp_settings& st) {
-        KSettings k{};
-        k.horizon = st.horizon;
-        k.final_type = st.final_state_type;
-        k.periodicity_type = st.periodicity_type;
-        k.joint_reg_as_coded = st.joint_reg_as_coded;
-        k.hdyn_x0 = st.periodicity_type == HIPNLP_EXPR_SKIP;
-        k.terrain = st.terrain;
-        k.n_steps = st.terrain == HIPNLP_TERRAIN_SMOOTH_STEPS ? st.n_terrain_steps : 0;
+    // terrain description of the C-ABI -> pre-digested form the terrain jets read
+    static void fill_terrain(KSettings& k, int terrain, int n_steps, const hipnlp_terrain_step* steps) {
+        k.terrain = terrain;
+        k.n_steps = terrain == HIPNLP_TERRAIN_SMOOTH_STEPS ? n_steps : 0;
         for (int i = 0; i < k.n_steps; ++i) {
-            const hipnlp_terrain_step& t = st.terrain_steps[i];
+            const hipnlp_terrain_step& t = steps[i];
             const double c = std::cos(t.orientation), sn = std::sin(t.orientation);
             TerrainStepK& o = k.steps[i];
             o.ox = t.position[0]; o.oy = t.position[1]; o.oz = t.position[2]; o.height = t.height;
@@ -276,6 +271,26 @@ struct Layout {
             o.bx = -2.0 / t.width * sn; o.by = 2.0 / t.width * c;        // b = (2/W) q_y
             o.m = 2 * t.edge_sharpness; o.r = 2 * t.side_sharpness;
         }
+    }
+    // validation shared by hipnlp_create / hipnlp_pose_create; returns an error message or nullptr
+    static const char* check_terrain(int terrain, int n_steps, const hipnlp_terrain_step* steps) {
+        if (terrain != HIPNLP_TERRAIN_PLANAR && terrain != HIPNLP_TERRAIN_SMOOTH_STEPS) return "unknown terrain kind";
+        if (terrain == HIPNLP_TERRAIN_SMOOTH_STEPS) {
+            if (n_steps < 1 || n_steps > HIPNLP_MAX_TERRAIN_STEPS) return "n_terrain_steps must be in 1..HIPNLP_MAX_TERRAIN_STEPS";
+            for (int i = 0; i < n_steps; ++i)
+                if (!(steps[i].length > 0) || !(steps[i].width > 0) || steps[i].edge_sharpness < 2 || steps[i].side_sharpness < 2)
+                    return "terrain step: length, width must be positive and the sharpness exponents >= 2";
+        }
+        return nullptr;
+    }
+    static KSettings make_ksettings(const hipnlp_settings& st) {
+        KSettings k{};
+        k.horizon = st.horizon;
+        k.final_type = st.final_state_type;
+        k.periodicity_type = st.periodicity_type;
+        k.joint_reg_as_coded = st.joint_reg_as_coded;
+        k.hdyn_x0 = st.periodicity_type == HIPNLP_EXPR_SKIP;
+        fill_terrain(k, st.terrain, st.n_terrain_steps, st.terrain_steps);
         for (int f = 0; f < 2; ++f) for (int i = 0; i < 3; ++i) k.yaw_corner[f][i] = st.yaw_corner[f][i];
         k.final_weight = st.final_state_weight;
         k.periodicity_weight = st.periodicity_weight;

@@ -73,6 +73,9 @@ struct KSettings {
     int32_t yaw_corner[2][3];
     double final_weight, periodicity_weight;
     double m_centroid, w_comvel[3], m_comvel, m_frameq, m_baseq, m_baseqv, w_jreg[NJ], m_jreg, m_freg, m_yaw, m_swing, m_ureg, m_fdreg;
+    // static pose finder only (pose_body.h): expression types of the com / left / right point position terms and their multipliers
+    int32_t pose_com_type, pose_left_type, pose_right_type, pose_pad_;
+    double m_pcom, m_favg, m_preg;
 };
 
 // ---- cost terms (Output.cost_values grouping; order = hipnlp_cost_term_name) -------------------------
@@ -91,7 +94,9 @@ enum RowKind : int {
     RK_SDYN_IN, RK_SDYN_OUT, RK_SDYN_X0, RK_COMDYN_IN, RK_COMDYN_OUT, RK_COMDYN_X0,
     RK_HDYN_IN, RK_HDYN_OUT, RK_HDYN_X0,
     RK_UNITQ, RK_COMC, RK_CMMC, RK_AMB, RK_COMH, RK_FEETD, RK_JPB, RK_JVB, RK_FEETH,
-    RK_FIN, RK_PER0, RK_PERN, RK_COUNT
+    RK_FIN, RK_PER0, RK_PERN,
+    // static pose finder only (pose_body.h)
+    RK_PCOMPL, RK_PBAL, RK_PCOMERR, RK_PPREG, RK_COUNT
 };
 HD constexpr int row_id(int kind, int c, int i) { return (kind << 16) | (c << 8) | i; }
 HD constexpr int rid_kind(int id) { return id >> 16; }

@@ -1,0 +1,177 @@
+// pose_body.h — the static pose finder NLP (BASELINE config 2) on the knot machinery: one workgroup of four wavefronts
+// evaluates ONE pose.  The pose's 81 variables are loaded into a knot record (velocities zero), so the kinematic tasks of
+// knot_body.h (base orientation, forward kinematics as ancestor sums, composites as descendant sums, CoM / contact-point
+// consistency rows with their analytic Jacobians, chest-frame and base-quaternion costs) run unchanged; the tasks below add
+// what only the pose finder has.
+//
+// Reference (relative to /root/reference/src/hippopt/turnkey_planners/humanoid_pose_finder/planner.py):
+//   :670-722 contact point feasibility (relaxed complementarity E5, height, normal force, friction cone)
+//   :487-509 static balance  0 = g + sum_i [ f_i ; (p_i - com) x f_i ]   (E1, unit mass)
+//   :511-519 joint position bounds (Opti_bounded -> rows of g: the pose finder runs Opti without detect_simple_bounds)
+//   :521-629 regularisations (base quaternion, chest frame, com, joints)   :724-768 foot regularisations
+#pragma once
+#include "knot_body.h"
+
+namespace hipnlp {
+
+constexpr int POSE_NX = HIPNLP_POSE_NX, POSE_NP = HIPNLP_POSE_NP, POSE_NCT = HIPNLP_POSE_NCOST_TERMS;
+// pose references live in the (otherwise unused) previous-knot record of the scratch: s.xm[XR_*]
+enum : int { XR_P = 0, XR_F = 24, XR_COM = 48, XR_COUNT = 51 };
+// pose variable i (reference creation order) -> column of the knot record
+HD constexpr int pose_to_knot_col(int i) {
+    return i < 48 ? PT_ * (i / 6) + ((i % 6) < 3 ? P_ + (i % 6) : F_ + (i % 6) - 3)
+                  : (i < 51 ? PB_ + (i - 48) : (i < 55 ? QB_ + (i - 51) : (i < 78 ? S_ + (i - 55) : COM_ + (i - 78))));
+}
+
+// --- contact point c: relaxed complementarity, height, normal force, friction rows; point regularisations.  lane c (8) ------
+template <class Em> HD void t_pose_points(Ctx<Em>& cx, int c) {
+    KnotScratch& s = cx.s;
+    Em& em = cx.em;
+    const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
+    const double* p = s.x + cb + P_;
+    const double* f = s.x + cb + F_;
+    const double mass = cx.gp.mass;
+    if (terrain_is_planar(cx)) {   // eps - h(p) (n . f mass)  with  h = p_z, n = e_z
+        em.G(gb + gs::DCC, row_id(RK_PCOMPL, c, 0), cx.gp.eps - p[2] * (f[2] * mass));
+        em.J(jb + js::DCC_P + 2, row_id(RK_PCOMPL, c, 0), cb + P_ + 2, -(f[2] * mass));
+        em.J(jb + js::DCC_F + 2, row_id(RK_PCOMPL, c, 0), cb + F_ + 2, -(p[2] * mass));
+        point_hnf_planar(cx, c);
+    } else {
+        double Z[10];
+        terrain_Z_jet(cx.st, p[0], p[1], 2, Z);
+        TerrainFrame tf;
+        terrain_frame(Z, p[2], tf);
+        const D2 nf = tf.n[0] * f[0] + tf.n[1] * f[1] + tf.n[2] * f[2];
+        const D2 margin = D2(cx.gp.eps) - tf.h * nf * mass;
+        em.G(gb + gs::DCC, row_id(RK_PCOMPL, c, 0), margin.v);
+        em.J(jb + js::DCC_P + 0, row_id(RK_PCOMPL, c, 0), cb + P_ + 0, margin.x);
+        em.J(jb + js::DCC_P + 1, row_id(RK_PCOMPL, c, 0), cb + P_ + 1, margin.y);
+        em.J(jb + js::DCC_P + 2, row_id(RK_PCOMPL, c, 0), cb + P_ + 2, -(nf.v * mass));   // only h depends on p_z
+        for (int j = 0; j < 3; ++j) em.J(jb + js::DCC_F + j, row_id(RK_PCOMPL, c, 0), cb + F_ + j, -(tf.h.v * tf.n[j].v * mass));
+        point_hnf_smooth(cx, c, tf);
+    }
+    // regularisations of the foot the point belongs to  (planner.py:724-768)
+    const int foot = c >> 2;
+    const int mode = foot == 0 ? cx.st.pose_left_type : cx.st.pose_right_type;
+    double mean[3] = {0.0, 0.0, 0.0};
+    for (int q = 4 * foot; q < 4 * foot + 4; ++q) for (int i = 0; i < 3; ++i) mean[i] += s.x[PT_ * q + F_ + i];
+    double cp = 0.0, cf = 0.0, ca = 0.0, ep[3];
+    for (int i = 0; i < 3; ++i) {
+        ep[i] = p[i] - s.xm[XR_P + 3 * c + i];
+        const double ef = f[i] - s.xm[XR_F + 3 * c + i];
+        const double ea = f[i] - 0.25 * mean[i];
+        cp += ep[i] * ep[i]; cf += ef * ef; ca += ea * ea;
+        s.grad[cb + P_ + i] = mode == HIPNLP_EXPR_MINIMIZE ? 2.0 * cx.st.m_preg * ep[i] : 0.0;
+        s.grad[cb + F_ + i] = 2.0 * cx.st.m_freg * ef + 2.0 * cx.st.m_favg * ea;   // sum_c (f_c - mean) = 0: no cross terms
+    }
+    s.c_pt[c][0] = mode == HIPNLP_EXPR_MINIMIZE ? cx.st.m_preg * cp : 0.0;
+    s.c_pt[c][1] = cx.st.m_freg * cf;
+    s.c_pt[c][2] = cx.st.m_favg * ca;
+    if (mode == HIPNLP_EXPR_SUBJECT_TO) {   // sumsqr(p - p_ref) == 0   (base/problem.py:146-151)
+        em.G(gb + gs::UB, row_id(RK_PPREG, c, 0), cp);
+        for (int i = 0; i < 3; ++i) em.J(jb + js::UB + i, row_id(RK_PPREG, c, 0), cb + P_ + i, 2.0 * ep[i]);
+    }
+}
+
+// --- static balance (planner.py:487-509): lanes (c, e) 48 Jacobian entries, lanes 48..53 rows, lanes 54..59 com entries --------
+constexpr int POSE_BALANCE_TASKS = 60;
+template <class Em> HD void t_pose_balance(Ctx<Em>& cx, int t) {
+    KnotScratch& s = cx.s;
+    Em& em = cx.em;
+    const double* com = s.x + COM_;
+    scratch_padding(s, t);
+    if (t < 48) {
+        const int c = t / 6, e = t - 6 * c, r = cross_row(e), q = cross_col(e), cb = PT_ * c;
+        const double* f = s.x + cb + F_;
+        const double a[3] = {s.x[cb + P_] - com[0], s.x[cb + P_ + 1] - com[1], s.x[cb + P_ + 2] - com[2]};
+        em.J(js::HDYN_ANG_P_OUT + 6 * c + e, row_id(RK_PBAL, 0, 3 + r), cb + P_ + q, -skew_entry(f, e));   // d (a x f)/d a = -[f]x
+        em.J(js::HDYN_ANG_F_OUT + 6 * c + e, row_id(RK_PBAL, 0, 3 + r), cb + F_ + q, skew_entry(a, e));    // d (a x f)/d f =  [a]x
+        if (e < 3) em.J(js::HDYN_LIN_F_OUT + 3 * c + e, row_id(RK_PBAL, 0, e), cb + F_ + e, 1.0);
+    } else if (t < 54) {
+        const int i = t - 48;
+        double acc = cx.gp.gravity[i];
+        for (int c = 0; c < NC; ++c) {
+            const int cb = PT_ * c;
+            if (i < 3) acc += s.x[cb + F_ + i];
+            else {
+                const double a[3] = {s.x[cb + P_] - com[0], s.x[cb + P_ + 1] - com[1], s.x[cb + P_ + 2] - com[2]};
+                acc += cross_comp(a, s.x + cb + F_, i - 3);
+            }
+        }
+        em.G(gs::HDYN + i, row_id(RK_PBAL, 0, i), acc);
+    } else {
+        const int e = t - 54, r = cross_row(e), q = cross_col(e);
+        double fs[3] = {0.0, 0.0, 0.0};
+        for (int c = 0; c < NC; ++c) for (int i = 0; i < 3; ++i) fs[i] += s.x[PT_ * c + F_ + i];
+        em.J(js::HDYN_ANG_COM_OUT + e, row_id(RK_PBAL, 0, 3 + r), COM_ + q, skew_entry(fs, e));   // d/d com = +[sum f]x
+    }
+}
+
+// --- joints: bound rows, e^T diag(w) e regularisation (planner.py:575-589), local joint transform.  lane j (23) --------------
+template <class Em> HD void t_pose_joints(Ctx<Em>& cx, int j) {
+    KnotScratch& s = cx.s;
+    Em& em = cx.em;
+    em.G(gs::JPB + j, row_id(RK_JPB, 0, j), s.x[S_ + j]);
+    em.J(js::JPB + j, row_id(RK_JPB, 0, j), S_ + j, 1.0);
+    const double e = s.x[S_ + j] - s.pk[PK_REF + R_JREG + j];
+    const double mw = cx.st.m_jreg * cx.st.w_jreg[j];
+    s.c_joint[j] = mw * e * e;
+    s.grad[S_ + j] = 2.0 * mw * e;
+    joint_transform(cx, j);
+}
+
+// --- com position error (planner.py:566-573): lanes 0..2 components, lane 3 value.  4 tasks -----------------------------------
+template <class Em> HD void t_pose_com(Ctx<Em>& cx, int t) {
+    KnotScratch& s = cx.s;
+    Em& em = cx.em;
+    const int mode = cx.st.pose_com_type;
+    if (t < 3) {
+        const double e = s.x[COM_ + t] - s.xm[XR_COM + t];
+        s.grad[COM_ + t] = mode == HIPNLP_EXPR_MINIMIZE ? 2.0 * cx.st.m_pcom * e : 0.0;
+        s.grad[PB_ + t] = 0.0;
+        if (mode == HIPNLP_EXPR_SUBJECT_TO) em.J(js::COMH + t, row_id(RK_PCOMERR, 0, 0), COM_ + t, 2.0 * e);
+    } else {
+        double c = 0.0;
+        for (int i = 0; i < 3; ++i) { const double e = s.x[COM_ + i] - s.xm[XR_COM + i]; c += e * e; }
+        s.cost[CT_COMVEL] = mode == HIPNLP_EXPR_MINIMIZE ? cx.st.m_pcom * c : 0.0;
+        if (mode == HIPNLP_EXPR_SUBJECT_TO) em.G(gs::COMH, row_id(RK_PCOMERR, 0, 0), c);
+    }
+}
+
+// cost term t of the pose (order of hipnlp_pose_cost_term_name) from the scratch, after the program has run
+HD double pose_cost_term(const KnotScratch& s, int t) {
+    switch (t) {
+        case 0: return s.cost[CT_BASEQ];
+        case 1: return s.cost[CT_FRAMEQ];
+        case 2: return s.cost[CT_COMVEL];
+        case 3: return s.cost[CT_JREG];
+        default: {
+            const int k = t == 4 ? 2 : (t == 5 ? 0 : 1);   // average force | point position | force
+            double a = 0.0;
+            for (int c = 0; c < NC; ++c) a += s.c_pt[c][k];
+            return a;
+        }
+    }
+}
+
+// The pose program: same notation as HIPNLP_KNOT_PROGRAM.
+#define HIPNLP_POSE_PROGRAM(R, BARRIER)                                                   \
+    R(0, t_pose_points, NC) R(1, t_pose_balance, POSE_BALANCE_TASKS)                      \
+    R(2, t_pose_joints, NJ) R(2, t_joint_cost, 1)                                         \
+    R(3, t_base, 3) R(3, t_pose_com, 4) R(3, t_unitq, 1)                                  \
+    BARRIER                                                                               \
+    R(0, t_fk_rot_a, FK_TASKS_A) R(3, t_fk_rot_b, FK_TASKS_B)                             \
+    BARRIER                                                                               \
+    R(0, t_fk_pos, NJ) R(0, t_fk_vel, NJ)                                                 \
+    BARRIER                                                                               \
+    R(0, t_links, NL) R(1, t_frames, 3)                                                   \
+    BARRIER                                                                               \
+    R(0, t_composite_w0, COMP_TASKS_PER_WAVE) R(1, t_composite_w1, COMP_TASKS_PER_WAVE)   \
+    R(2, t_composite_w2, COMP_TASKS_PER_WAVE) R(3, t_composite_w3, COMP_TASKS_PER_WAVE) R(1, t_pkin, NC) \
+    BARRIER                                                                               \
+    R(0, t_columns, NJ + 3)                                                               \
+    BARRIER                                                                               \
+    R(0, t_kinc, 3 * NC) R(1, t_comc, 15) R(3, t_feetd, 4)                                \
+    BARRIER
+
+}  // namespace hipnlp

@@ -7,7 +7,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../../hippopt_amd/csrc/layout.h"
+#include "../../hippopt_amd/csrc/pose_layout.h"
 
 using namespace hipnlp;
 
@@ -100,5 +100,63 @@ void hostemu_eval(const hostemu_handle* h, const double* x, const double* p, dou
     double ft = 0.0;
     for (int i = 0; i < NCT; ++i) ft += cost_terms[i];
     *f = ft;
+}
+
+// ---- static pose finder: the pose program of pose_body.h + the copy-out of hipnlp_pose_kernel -------------------------------
+struct hostemu_pose_handle {
+    hipnlp_pose_desc d;
+    KinTables kt;
+    KSettings ks;
+    PoseLayout L;
+};
+
+hostemu_pose_handle* hostemu_pose_create(const hipnlp_pose_desc* desc, char* err, int errlen) {
+    hostemu_pose_handle* h = new hostemu_pose_handle();
+    h->d = *desc;
+    std::string e;
+    if (!Layout::make_kin_tables(desc->model, h->kt, e) || !h->L.build(desc->settings, h->kt)) {
+        if (e.empty()) e = h->L.error;
+        std::strncpy(err, e.c_str(), size_t(errlen - 1));
+        delete h;
+        return nullptr;
+    }
+    h->ks = PoseLayout::make_ksettings(desc->settings);
+    return h;
+}
+void hostemu_pose_destroy(hostemu_pose_handle* h) { delete h; }
+void hostemu_pose_dims(const hostemu_pose_handle* h, int* n, int* m, int* nnz) { *n = h->L.n; *m = h->L.m; *nnz = h->L.nnz; }
+void hostemu_pose_sparsity(const hostemu_pose_handle* h, int* irow, int* jcol) {
+    for (int i = 0; i < h->L.nnz; ++i) { irow[i] = h->L.irow[size_t(i)]; jcol[i] = h->L.jcol[size_t(i)]; }
+}
+void hostemu_pose_bounds(const hostemu_pose_handle* h, const double* p, double* lbg, double* ubg) { h->L.bounds(p, lbg, ubg); }
+int hostemu_pose_num_row_blocks(const hostemu_pose_handle* h) { return int(h->L.blocks.size()); }
+void hostemu_pose_row_block(const hostemu_pose_handle* h, int i, const char** name, int* first, int* rows) {
+    const PoseRowBlock& b = h->L.blocks[size_t(i)];
+    *name = b.name.c_str(); *first = b.first_row; *rows = b.rows;
+}
+void hostemu_pose_eval(const hostemu_pose_handle* h, const double* x, const double* p, double* f, double* grad, double* g, double* jac, double* cost_terms) {
+    const PoseLayout& L = h->L;
+    double pk[PK_STRIDE], xr[64];
+    GParams gp;
+    pack_pose_params(p, pk, xr, gp);
+    KnotScratch* s = new KnotScratch();
+    std::fill(reinterpret_cast<double*>(s), reinterpret_cast<double*>(s) + sizeof(KnotScratch) / sizeof(double), std::nan(""));
+    for (int i = 0; i < XPAD; ++i) { s->x[i] = 0; s->xm[i] = 0; s->xo[i] = 0; }
+    for (int i = 0; i < POSE_NX; ++i) s->x[pose_to_knot_col(i)] = x[i];
+    for (int i = 0; i < 64; ++i) s->xm[i] = xr[i];
+    for (int i = 0; i < PK_STRIDE; ++i) s->pk[i] = pk[i];
+    KnotInfo ki{1, 3, 0, 0};
+    ValueEm em{s->g, s->jac};
+    Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
+#define HOST_R(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
+    HIPNLP_POSE_PROGRAM(HOST_R, )
+#undef HOST_R
+    for (int e = 0; e < L.nnz; ++e) jac[e] = s->jac[L.jperm[size_t(e)]];
+    for (int slot = 0; slot < gs::COUNT; ++slot) if (L.g_row[size_t(slot)] >= 0) g[L.g_row[size_t(slot)]] = s->g[slot];
+    for (int i = 0; i < POSE_NX; ++i) grad[i] = s->grad[pose_to_knot_col(i)];
+    double ft = 0.0;
+    for (int t = 0; t < POSE_NCT; ++t) { cost_terms[t] = pose_cost_term(*s, t); ft += cost_terms[t]; }
+    *f = ft;
+    delete s;
 }
 }  // extern "C"

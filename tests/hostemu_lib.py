@@ -10,7 +10,7 @@ from hippopt_amd import _abi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = os.path.join(ROOT, "tests", "_build", "libhipnlp_hostemu.so")
 SRC = [os.path.join(ROOT, "tests", "hostemu", "hostemu.cpp")] + [
-    os.path.join(ROOT, "hippopt_amd", "csrc", f) for f in ("layout.h", "knot_body.h", "nlp_defs.h")]
+    os.path.join(ROOT, "hippopt_amd", "csrc", f) for f in ("layout.h", "knot_body.h", "nlp_defs.h", "pose_body.h", "pose_layout.h")]
 
 
 def build():
@@ -69,4 +69,49 @@ class HostEmu:
         grad, g, jac, ct = np.zeros(self.n), np.full(self.m, np.nan), np.full(self.nnz, np.nan), np.zeros(_abi.NCOST_TERMS)
         self.lib.hostemu_eval(C.c_void_p(self.h), _dp(np.ascontiguousarray(x)), _dp(np.ascontiguousarray(p)),
                               C.byref(f), _dp(grad), _dp(g), _dp(jac), _dp(ct))
+        return f.value, grad, g, jac, ct
+
+
+class PoseHostEmu:
+    """Host emulation of the pose program (pose_body.h) + the pose layout tables."""
+
+    def __init__(self, settings, model):
+        self.lib = C.CDLL(build())
+        self.lib.hostemu_pose_create.restype = C.c_void_p
+        self.desc = _abi.PoseDescC()
+        self.desc.settings = settings.to_c()
+        self.desc.model = model.to_c()
+        self.desc.batch = 1
+        err = C.create_string_buffer(256)
+        self.h = self.lib.hostemu_pose_create(C.byref(self.desc), err, 256)
+        if not self.h:
+            raise RuntimeError(err.value.decode())
+        n, m, nnz = C.c_int(), C.c_int(), C.c_int()
+        self.lib.hostemu_pose_dims(C.c_void_p(self.h), C.byref(n), C.byref(m), C.byref(nnz))
+        self.n, self.m, self.nnz = n.value, m.value, nnz.value
+
+    def sparsity(self):
+        ir, jc = np.zeros(self.nnz, np.int32), np.zeros(self.nnz, np.int32)
+        self.lib.hostemu_pose_sparsity(C.c_void_p(self.h), _ip(ir), _ip(jc))
+        return ir, jc
+
+    def bounds(self, p):
+        lb, ub = np.zeros(self.m), np.zeros(self.m)
+        self.lib.hostemu_pose_bounds(C.c_void_p(self.h), _dp(np.ascontiguousarray(p)), _dp(lb), _dp(ub))
+        return lb, ub
+
+    def row_blocks(self):
+        out = []
+        for i in range(self.lib.hostemu_pose_num_row_blocks(C.c_void_p(self.h))):
+            name = C.c_char_p()
+            a, b = C.c_int(), C.c_int()
+            self.lib.hostemu_pose_row_block(C.c_void_p(self.h), i, C.byref(name), C.byref(a), C.byref(b))
+            out.append((name.value.decode(), a.value, b.value))
+        return out
+
+    def eval(self, x, p):
+        f = C.c_double()
+        grad, g, jac, ct = np.zeros(self.n), np.full(self.m, np.nan), np.full(self.nnz, np.nan), np.zeros(_abi.POSE_NCOST_TERMS)
+        self.lib.hostemu_pose_eval(C.c_void_p(self.h), _dp(np.ascontiguousarray(x)), _dp(np.ascontiguousarray(p)),
+                                   C.byref(f), _dp(grad), _dp(g), _dp(jac), _dp(ct))
         return f.value, grad, g, jac, ct

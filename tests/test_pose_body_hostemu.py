@@ -1,0 +1,71 @@
+"""The pose program (hippopt_amd/csrc/pose_body.h) and the pose layout tables through the TEST-ONLY host emulation, against
+the AD oracle and the golden vectors of the reference's pose finder.  GPU parity proper: test_gpu_pose.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from hippopt_amd import _abi
+from hippopt_amd.pose_settings import make_pose_workload, pose_finder_settings
+from hostemu_lib import PoseHostEmu
+from oracle_lib import PoseOracle
+from test_golden_pose import GOLD, check_against_fixture, pose_settings_for
+
+TOL = 1e-11
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+def variants(model):
+    a = pose_finder_settings(model)
+    b = pose_finder_settings(model)
+    b.com_position_expression_type = _abi.EXPR_SUBJECT_TO
+    b.left_point_position_expression_type = _abi.EXPR_SKIP
+    b.right_point_position_expression_type = _abi.EXPR_SUBJECT_TO
+    c = pose_finder_settings(model)
+    c.terrain = _abi.TERRAIN_SMOOTH_STEPS
+    c.terrain_steps = [{"length": 0.6, "width": 0.8, "height": 0.2, "position": (0.45, 0.0, 0.0)},
+                       {"length": 0.3, "width": 0.5, "height": 0.1, "position": (-0.2, 0.1, 0.02), "orientation": 0.6, "edge_sharpness": 3, "side_sharpness": 4}]
+    c.com_position_expression_type = _abi.EXPR_SKIP
+    return {"default": a, "constrained": b, "steps": c}
+
+
+@pytest.mark.parametrize("name", ["default", "constrained", "steps"])
+def test_pose_body_matches_oracle(model, name):
+    st = variants(model)[name]
+    o, e = PoseOracle(st, model), PoseHostEmu(st, model)
+    assert (o.n, o.m, o.nnz) == (e.n, e.m, e.nnz)
+    assert o.row_blocks() == e.row_blocks()
+    ir, jc = o.sparsity()
+    ir2, jc2 = e.sparsity()
+    assert np.array_equal(ir, ir2) and np.array_equal(jc, jc2)
+    x, p = make_pose_workload(st, model, 3, 700)
+    if name == "steps":   # contact points on the flanks of the first bump
+        rng = np.random.RandomState(1)
+        for c in range(8):
+            x[0][6 * c] = 0.45 + rng.choice([-1.0, 1.0]) * 0.3 * rng.uniform(0.95, 1.01)
+            x[0][6 * c + 1] = 0.3 * rng.uniform(-1, 1)
+            x[0][6 * c + 2] = 0.1 + 0.05 * rng.standard_normal()
+    for b in range(3):
+        f, grad, g, jac = o.eval(x[b], p[b])
+        f2, grad2, g2, jac2, ct = e.eval(x[b], p[b])
+        assert not np.isnan(g2).any() and not np.isnan(jac2).any()
+        assert rel(np.array(f2), np.array(f)) < TOL and rel(grad2, grad) < TOL and rel(g2, g) < TOL and rel(jac2, jac) < 1e-10
+        assert np.allclose(ct, o.cost_terms(), rtol=1e-12, atol=1e-12)
+        lb, ub = o.bounds(p[b])
+        lb2, ub2 = e.bounds(p[b])
+        assert np.array_equal(lb, lb2) and np.array_equal(ub, ub2)
+
+
+@pytest.mark.parametrize("name", ["pose_default", "pose_step_constrained"])
+def test_pose_body_matches_reference_fixture(model, name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    st = pose_settings_for(json.loads(str(z["meta"])), model)
+    e = PoseHostEmu(st, model)
+    f, grad, g, jac, _ = e.eval(z["x"], z["p"])
+    lb, ub = e.bounds(z["p"])
+    ir, jc = e.sparsity()
+    check_against_fixture(z, ir, jc, f, grad, g, jac, lb, ub, tol=1e-10)
