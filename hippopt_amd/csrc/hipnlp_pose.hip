@@ -1,0 +1,355 @@
+// hipnlp_pose.hip — gfx950 kernel and the C-ABI (include/hipnlp.h, hipnlp_pose_*) of the static pose finder NLP
+// (BASELINE config 2; turnkey_planners/humanoid_pose_finder/planner.py:323-788).
+//
+// One 256-thread workgroup (four role-specialised wavefronts, pose_body.h HIPNLP_POSE_PROGRAM) per pose: the 81 variables are
+// gathered into a knot record in LDS (velocities zero), the kinematic tasks of knot_body.h and the pose tasks fill the native
+// g / jac / grad slots in LDS, and the workgroup streams out the pose's CCS value run, its rows of g, grad f and the cost terms.
+// The total cost of a pose is summed inside the same workgroup in a fixed order (bitwise reproducible); no second kernel.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pose_layout.h"
+
+using namespace hipnlp;
+
+namespace {
+
+constexpr int WG = 256;
+constexpr int XR_STRIDE = 64;
+constexpr int POSE_MAX_NNZ = 1024;
+static_assert(XR_COUNT <= XR_STRIDE, "pose reference record");
+
+struct PoseTables {
+    KinTables kt;
+    KSettings ks;
+    int32_t g_row[gs::COUNT];
+    int32_t jperm[POSE_MAX_NNZ];
+    int32_t nnz, m;
+};
+
+struct PArgs {
+    const PoseTables* tb;
+    const double* x;    // [batch][81]
+    const double* pk;   // [batch][PK_STRIDE]
+    const double* xr;   // [batch][XR_STRIDE]
+    const GParams* gp;  // [batch]
+    double* f;          // [batch]           or null
+    double* grad;       // [batch][81]       or null
+    double* g;          // [batch][m]        or null
+    double* jac;        // [batch][nnz]      or null
+    double* cost_terms; // [batch][POSE_NCT]
+    int32_t* flags;     // [batch]
+};
+
+template <int TERRAIN> struct PoseEm {
+    static constexpr int kTerrain = TERRAIN;
+    double* g;
+    double* jac;
+    __device__ __forceinline__ void G(int slot, int, double v) { g[slot] = v; }
+    __device__ __forceinline__ void J(int slot, int, int, double v) { jac[slot] = v; }
+};
+
+struct PoseShared {
+    KinTables kt;
+    KSettings ks;
+    GParams gp;
+};
+
+template <int TERRAIN> __global__ __launch_bounds__(WG) void hipnlp_pose_kernel(PArgs a) {
+    __shared__ KnotScratch s;
+    __shared__ PoseShared tabs;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.x;
+    const PoseTables& tb = *a.tb;
+    {
+        static_assert(sizeof(KinTables) % 4 == 0 && sizeof(KSettings) % 4 == 0 && sizeof(GParams) % 4 == 0, "word copy");
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&tb.kt);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&tabs.kt);
+        for (int i = tid; i < int(sizeof(KinTables) / 4); i += WG) dst[i] = src[i];
+        src = reinterpret_cast<const uint32_t*>(&tb.ks);
+        dst = reinterpret_cast<uint32_t*>(&tabs.ks);
+        for (int i = tid; i < int(sizeof(KSettings) / 4); i += WG) dst[i] = src[i];
+        src = reinterpret_cast<const uint32_t*>(a.gp + b);
+        dst = reinterpret_cast<uint32_t*>(&tabs.gp);
+        for (int i = tid; i < int(sizeof(GParams) / 4); i += WG) dst[i] = src[i];
+    }
+    for (int i = tid; i < XPAD; i += WG) { s.x[i] = 0.0; s.xm[i] = i < XR_STRIDE ? a.xr[size_t(b) * XR_STRIDE + i] : 0.0; }
+    for (int i = tid; i < PK_STRIDE; i += WG) s.pk[i] = a.pk[size_t(b) * PK_STRIDE + i];
+    __syncthreads();
+    if (tid < POSE_NX) s.x[pose_to_knot_col(tid)] = a.x[size_t(b) * POSE_NX + tid];
+    __syncthreads();
+
+    KnotInfo ki{1, 3, 0, 0};   // "interior knot": the k >= 1 rows / costs of the shared tasks are active
+    PoseEm<TERRAIN> em{s.g, s.jac};
+    Ctx<PoseEm<TERRAIN>> cx(s, tabs.kt, tabs.ks, tabs.gp, ki, em);
+#define DEV_R(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
+#define DEV_BARRIER __syncthreads();
+    HIPNLP_POSE_PROGRAM(DEV_R, DEV_BARRIER)
+#undef DEV_R
+#undef DEV_BARRIER
+
+    int bad = 0;
+    if (a.jac) {
+        double* out = a.jac + size_t(b) * tb.nnz;
+        for (int e = tid; e < tb.nnz; e += WG) { const double v = s.jac[tb.jperm[e]]; bad |= !isfinite(v); out[e] = v; }
+    }
+    if (a.g) {
+        double* out = a.g + size_t(b) * tb.m;
+        for (int slot = tid; slot < gs::COUNT; slot += WG) {
+            const int r = tb.g_row[slot];
+            if (r >= 0) { const double v = s.g[slot]; bad |= !isfinite(v); out[r] = v; }
+        }
+    }
+    if (a.grad && tid < POSE_NX) { const double v = s.grad[pose_to_knot_col(tid)]; bad |= !isfinite(v); a.grad[size_t(b) * POSE_NX + tid] = v; }
+    if (tid == 0) {
+        double tot = 0.0;
+        for (int t = 0; t < POSE_NCT; ++t) { const double v = pose_cost_term(s, t); tot += v; a.cost_terms[size_t(b) * POSE_NCT + t] = v; }
+        bad |= !isfinite(tot);
+        if (a.f) a.f[b] = tot;
+    }
+    const int anybad = __syncthreads_or(bad);
+    if (tid == 0) a.flags[b] = anybad;
+}
+
+thread_local std::string g_pose_create_error;
+
+}  // namespace
+
+struct hipnlp_pose_handle {
+    hipnlp_pose_desc d;
+    PoseLayout L;
+    KinTables kt;
+    int batch = 1, dev = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing_valid = false, params_set = false, have_result = false;
+    PoseTables* d_tb = nullptr;
+    double *d_x = nullptr, *d_pk = nullptr, *d_xr = nullptr, *d_f = nullptr, *d_grad = nullptr, *d_g = nullptr, *d_jac = nullptr, *d_cost = nullptr;
+    GParams* d_gp = nullptr;
+    int32_t* d_flags = nullptr;
+    double *h_x = nullptr, *h_f = nullptr, *h_grad = nullptr, *h_g = nullptr, *h_jac = nullptr, *h_cost = nullptr;
+    int32_t* h_flags = nullptr;
+    std::vector<double> p;
+    std::string err;
+};
+
+#define HIP_TRY(h, call)                                                                            \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+            return HIPNLP_E_NODEVICE;                                                               \
+        }                                                                                           \
+    } while (0)
+
+static void pose_free_all(hipnlp_pose_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->dev);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* dptrs[] = {h->d_tb, h->d_x, h->d_pk, h->d_xr, h->d_f, h->d_grad, h->d_g, h->d_jac, h->d_cost, h->d_gp, h->d_flags};
+    for (void* q : dptrs) if (q) (void)hipFree(q);
+    void* hptrs[] = {h->h_x, h->h_f, h->h_grad, h->h_g, h->h_jac, h->h_cost, h->h_flags};
+    for (void* q : hptrs) if (q) (void)hipHostFree(q);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static int pose_launch(hipnlp_pose_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, hipStream_t s) {
+    PArgs a;
+    a.tb = h->d_tb; a.x = x_dev; a.pk = h->d_pk; a.xr = h->d_xr; a.gp = h->d_gp;
+    a.f = f_dev; a.grad = grad_dev; a.g = g_dev; a.jac = jac_dev; a.cost_terms = h->d_cost; a.flags = h->d_flags;
+    HIP_TRY(h, hipEventRecord(h->ev0, s));
+    if (h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR)
+        hipLaunchKernelGGL(hipnlp_pose_kernel<HIPNLP_TERRAIN_PLANAR>, dim3(unsigned(h->batch)), dim3(WG), 0, s, a);
+    else
+        hipLaunchKernelGGL(hipnlp_pose_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS>, dim3(unsigned(h->batch)), dim3(WG), 0, s, a);
+    HIP_TRY(h, hipEventRecord(h->ev1, s));
+    HIP_TRY(h, hipGetLastError());
+    h->timing_valid = true;
+    return HIPNLP_OK;
+}
+
+extern "C" {
+
+const char* hipnlp_pose_last_error(const hipnlp_pose_handle* h) { return h ? h->err.c_str() : g_pose_create_error.c_str(); }
+
+int hipnlp_pose_create(const hipnlp_pose_desc* desc, hipnlp_pose_handle** out) {
+    if (!desc || !out) { g_pose_create_error = "null argument"; return HIPNLP_E_INVALID; }
+    *out = nullptr;
+    hipnlp_pose_handle* h = new (std::nothrow) hipnlp_pose_handle();
+    if (!h) { g_pose_create_error = "out of memory"; return HIPNLP_E_ALLOC; }
+    h->d = *desc;
+    const hipnlp_pose_settings& st = desc->settings;
+    auto fail = [&](int code, const std::string& msg) { g_pose_create_error = msg; pose_free_all(h); return code; };
+    if (const char* te = Layout::check_terrain(st.terrain, st.n_terrain_steps, st.terrain_steps)) return fail(HIPNLP_E_INVALID, te);
+    for (int t : {st.com_position_type, st.left_point_position_type, st.right_point_position_type})
+        if (t != HIPNLP_EXPR_SKIP && t != HIPNLP_EXPR_SUBJECT_TO && t != HIPNLP_EXPR_MINIMIZE) return fail(HIPNLP_E_INVALID, "bad expression type");
+    if (desc->batch < 1) return fail(HIPNLP_E_INVALID, "batch must be >= 1");
+    h->batch = desc->batch;
+    std::string e;
+    if (!Layout::make_kin_tables(desc->model, h->kt, e)) return fail(HIPNLP_E_INVALID, e);
+    if (!h->L.build(st, h->kt)) return fail(HIPNLP_E_INVALID, h->L.error);
+    if (h->L.nnz > POSE_MAX_NNZ) return fail(HIPNLP_E_INVALID, "internal: pose pattern larger than POSE_MAX_NNZ");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(HIPNLP_E_NODEVICE, "no HIP device available (the engine has no CPU fallback)");
+    if (desc->device < 0 || desc->device >= ndev) return fail(HIPNLP_E_INVALID, "bad device ordinal");
+    h->dev = desc->device;
+#define CREATE_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(HIPNLP_E_NODEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+    CREATE_TRY(hipSetDevice(h->dev));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreate(&h->ev0));
+    CREATE_TRY(hipEventCreate(&h->ev1));
+    const size_t B = size_t(h->batch), m = size_t(h->L.m), nnz = size_t(h->L.nnz);
+    CREATE_TRY(hipMalloc(&h->d_tb, sizeof(PoseTables)));
+    CREATE_TRY(hipMalloc(&h->d_x, B * POSE_NX * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_pk, B * PK_STRIDE * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_xr, B * XR_STRIDE * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_gp, B * sizeof(GParams)));
+    CREATE_TRY(hipMalloc(&h->d_f, B * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_grad, B * POSE_NX * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_g, B * m * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_jac, B * nnz * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_cost, B * POSE_NCT * sizeof(double)));
+    CREATE_TRY(hipMalloc(&h->d_flags, B * sizeof(int32_t)));
+    CREATE_TRY(hipHostMalloc(&h->h_x, B * POSE_NX * sizeof(double)));
+    CREATE_TRY(hipHostMalloc(&h->h_f, B * sizeof(double)));
+    CREATE_TRY(hipHostMalloc(&h->h_grad, B * POSE_NX * sizeof(double)));
+    CREATE_TRY(hipHostMalloc(&h->h_g, B * m * sizeof(double)));
+    CREATE_TRY(hipHostMalloc(&h->h_jac, B * nnz * sizeof(double)));
+    CREATE_TRY(hipHostMalloc(&h->h_cost, B * POSE_NCT * sizeof(double)));
+    CREATE_TRY(hipHostMalloc(&h->h_flags, B * sizeof(int32_t)));
+    PoseTables* tb = new PoseTables();
+    std::memset(tb, 0, sizeof(PoseTables));
+    tb->kt = h->kt;
+    tb->ks = PoseLayout::make_ksettings(st);
+    for (int s = 0; s < gs::COUNT; ++s) tb->g_row[s] = h->L.g_row[size_t(s)];
+    for (int e = 0; e < h->L.nnz; ++e) tb->jperm[e] = h->L.jperm[size_t(e)];
+    tb->nnz = h->L.nnz; tb->m = h->L.m;
+    hipError_t ce = hipMemcpy(h->d_tb, tb, sizeof(PoseTables), hipMemcpyHostToDevice);
+    delete tb;
+    if (ce != hipSuccess) return fail(HIPNLP_E_NODEVICE, std::string("hipMemcpy tables: ") + hipGetErrorString(ce));
+#undef CREATE_TRY
+    *out = h;
+    return HIPNLP_OK;
+}
+
+void hipnlp_pose_destroy(hipnlp_pose_handle* h) { pose_free_all(h); }
+
+int hipnlp_pose_get_dims(const hipnlp_pose_handle* h, hipnlp_pose_dims* o) {
+    if (!h || !o) return HIPNLP_E_INVALID;
+    o->n = POSE_NX; o->m = h->L.m; o->nnz = h->L.nnz; o->np = POSE_NP;
+    return HIPNLP_OK;
+}
+
+int hipnlp_pose_set_params(hipnlp_pose_handle* h, const double* p) {
+    if (!h || !p) return HIPNLP_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->dev));
+    const size_t B = size_t(h->batch);
+    h->p.assign(p, p + B * POSE_NP);
+    std::vector<double> pk(B * PK_STRIDE), xr(B * XR_STRIDE);
+    std::vector<GParams> gp(B);
+    for (size_t b = 0; b < B; ++b) pack_pose_params(p + b * POSE_NP, pk.data() + b * PK_STRIDE, xr.data() + b * XR_STRIDE, gp[b]);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(h->d_pk, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_xr, xr.data(), xr.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_gp, gp.data(), gp.size() * sizeof(GParams), hipMemcpyHostToDevice));
+    h->params_set = true;
+    h->have_result = false;
+    return HIPNLP_OK;
+}
+
+int hipnlp_pose_bounds(const hipnlp_pose_handle* h, double* lbg, double* ubg) {
+    if (!h || !lbg || !ubg) return HIPNLP_E_INVALID;
+    if (!h->params_set) return HIPNLP_E_PARAMS;
+    for (int b = 0; b < h->batch; ++b) h->L.bounds(h->p.data() + size_t(b) * POSE_NP, lbg + size_t(b) * size_t(h->L.m), ubg + size_t(b) * size_t(h->L.m));
+    return HIPNLP_OK;
+}
+
+int hipnlp_pose_sparsity(const hipnlp_pose_handle* h, int32_t* irow, int32_t* jcol) {
+    if (!h || !irow || !jcol) return HIPNLP_E_INVALID;
+    std::memcpy(irow, h->L.irow.data(), size_t(h->L.nnz) * sizeof(int32_t));
+    std::memcpy(jcol, h->L.jcol.data(), size_t(h->L.nnz) * sizeof(int32_t));
+    return HIPNLP_OK;
+}
+
+int hipnlp_pose_eval_device(hipnlp_pose_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, void* stream) {
+    if (!h || !x_dev) return HIPNLP_E_INVALID;
+    if (!h->params_set) { h->err = "parameters not set (hipnlp_pose_set_params)"; return HIPNLP_E_PARAMS; }
+    HIP_TRY(h, hipSetDevice(h->dev));
+    h->have_result = false;
+    return pose_launch(h, x_dev, f_dev ? f_dev : h->d_f, grad_dev, g_dev, jac_dev, stream ? hipStream_t(stream) : h->stream);
+}
+
+int hipnlp_pose_eval(hipnlp_pose_handle* h, const double* x, double* f, double* grad_f, double* g, double* jac) {
+    if (!h || !x) return HIPNLP_E_INVALID;
+    if (!h->params_set) { h->err = "parameters not set (hipnlp_pose_set_params)"; return HIPNLP_E_PARAMS; }
+    const size_t B = size_t(h->batch), m = size_t(h->L.m), nnz = size_t(h->L.nnz);
+    HIP_TRY(h, hipSetDevice(h->dev));
+    std::memcpy(h->h_x, x, B * POSE_NX * sizeof(double));
+    HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_x, B * POSE_NX * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const int rc = pose_launch(h, h->d_x, h->d_f, h->d_grad, h->d_g, h->d_jac, h->stream);
+    if (rc != HIPNLP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->h_f, h->d_f, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_cost, h->d_cost, B * POSE_NCT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_grad, h->d_grad, B * POSE_NX * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_g, h->d_g, B * m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_jac, h->d_jac, B * nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->have_result = true;
+    if (f) std::memcpy(f, h->h_f, B * sizeof(double));
+    if (grad_f) std::memcpy(grad_f, h->h_grad, B * POSE_NX * sizeof(double));
+    if (g) std::memcpy(g, h->h_g, B * m * sizeof(double));
+    if (jac) std::memcpy(jac, h->h_jac, B * nnz * sizeof(double));
+    for (size_t b = 0; b < B; ++b)
+        if (h->h_flags[b]) { h->err = "non-finite value produced by the evaluation"; return HIPNLP_E_NUMERIC; }
+    return HIPNLP_OK;
+}
+
+int hipnlp_pose_cost_terms(hipnlp_pose_handle* h, double* values) {
+    if (!h || !values) return HIPNLP_E_INVALID;
+    if (!h->have_result) {
+        HIP_TRY(h, hipSetDevice(h->dev));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipMemcpy(h->h_cost, h->d_cost, size_t(h->batch) * POSE_NCT * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    std::memcpy(values, h->h_cost, size_t(h->batch) * POSE_NCT * sizeof(double));
+    return HIPNLP_OK;
+}
+
+const char* hipnlp_pose_cost_term_name(int i) {
+    static const char* names[POSE_NCT] = {"base_quaternion_error", "frame_rotation_error", "com_position_error", "joint_positions_error",
+                                          "average_force_regularization", "point_position_regularization", "force_regularization"};
+    return (i >= 0 && i < POSE_NCT) ? names[i] : "";
+}
+
+int hipnlp_pose_num_row_blocks(const hipnlp_pose_handle* h) { return h ? int(h->L.blocks.size()) : HIPNLP_E_INVALID; }
+
+int hipnlp_pose_row_block(const hipnlp_pose_handle* h, int i, const char** name, int32_t* first_row, int32_t* rows) {
+    if (!h || i < 0 || i >= int(h->L.blocks.size())) return HIPNLP_E_INVALID;
+    const PoseRowBlock& b = h->L.blocks[size_t(i)];
+    if (name) *name = b.name.c_str();
+    if (first_row) *first_row = b.first_row;
+    if (rows) *rows = b.rows;
+    return HIPNLP_OK;
+}
+
+int hipnlp_pose_last_kernel_ms(hipnlp_pose_handle* h, float* ms) {
+    if (!h || !ms) return HIPNLP_E_INVALID;
+    if (!h->timing_valid) { h->err = "no evaluation has been launched yet"; return HIPNLP_E_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->dev));
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return HIPNLP_OK;
+}
+
+}  // extern "C"

@@ -19,6 +19,9 @@ EXPORTS = [
     "hipnlp_cost_terms", "hipnlp_cost_term_name", "hipnlp_num_row_blocks", "hipnlp_row_block",
     "hipnlp_last_kernel_ms", "hipnlp_profile_begin", "hipnlp_profile_end",
     "hipnlp_eval_device_shard", "hipnlp_stage_rows",
+    "hipnlp_pose_create", "hipnlp_pose_destroy", "hipnlp_pose_last_error", "hipnlp_pose_get_dims", "hipnlp_pose_set_params",
+    "hipnlp_pose_bounds", "hipnlp_pose_sparsity", "hipnlp_pose_eval", "hipnlp_pose_eval_device", "hipnlp_pose_cost_terms",
+    "hipnlp_pose_cost_term_name", "hipnlp_pose_num_row_blocks", "hipnlp_pose_row_block", "hipnlp_pose_last_kernel_ms",
 ]
 G_STAGE = 550
 
@@ -65,6 +68,23 @@ def load_library():
     lib.hipnlp_stage_rows.argtypes = [vp, C.c_int, ip]
     lib.hipnlp_profile_begin.argtypes = [vp, C.c_int]
     lib.hipnlp_profile_end.argtypes = [vp, dp, dp, C.POINTER(C.c_int)]
+    lib.hipnlp_pose_create.argtypes = [C.POINTER(_abi.PoseDescC), C.POINTER(vp)]
+    lib.hipnlp_pose_destroy.argtypes = [vp]
+    lib.hipnlp_pose_destroy.restype = None
+    lib.hipnlp_pose_last_error.argtypes = [vp]
+    lib.hipnlp_pose_last_error.restype = C.c_char_p
+    lib.hipnlp_pose_get_dims.argtypes = [vp, C.POINTER(_abi.PoseDimsC)]
+    lib.hipnlp_pose_set_params.argtypes = [vp, dp]
+    lib.hipnlp_pose_bounds.argtypes = [vp, dp, dp]
+    lib.hipnlp_pose_sparsity.argtypes = [vp, ip, ip]
+    lib.hipnlp_pose_eval.argtypes = [vp, dp, dp, dp, dp, dp]
+    lib.hipnlp_pose_eval_device.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.hipnlp_pose_cost_terms.argtypes = [vp, dp]
+    lib.hipnlp_pose_cost_term_name.argtypes = [C.c_int]
+    lib.hipnlp_pose_cost_term_name.restype = C.c_char_p
+    lib.hipnlp_pose_num_row_blocks.argtypes = [vp]
+    lib.hipnlp_pose_row_block.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), ip, ip]
+    lib.hipnlp_pose_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     _lib = lib
     return lib
 
@@ -185,3 +205,83 @@ class HipNlp:
         rows = np.zeros(G_STAGE, np.int32)
         self._check(self.lib.hipnlp_stage_rows(self.h, int(k), _ip(rows)))
         return rows
+
+
+class HipPose:
+    """One pose-finder handle (hipnlp_pose_*): `batch` independent static poses per launch on one HIP device."""
+
+    def __init__(self, settings, model, batch=1, device=0):
+        self.lib = load_library()
+        self.desc = _abi.PoseDescC()
+        self.desc.settings = settings.to_c()
+        self.desc.model = model.to_c()
+        self.desc.batch = int(batch)
+        self.desc.device = int(device)
+        h = C.c_void_p()
+        rc = self.lib.hipnlp_pose_create(C.byref(self.desc), C.byref(h))
+        if rc != 0:
+            raise HipNlpError(rc, self.lib.hipnlp_pose_last_error(None).decode())
+        self.h = h
+        d = _abi.PoseDimsC()
+        self._check(self.lib.hipnlp_pose_get_dims(self.h, C.byref(d)))
+        self.batch = int(batch)
+        self.n, self.m, self.nnz, self.np = d.n, d.m, d.nnz, d.np
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hipnlp_pose_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise HipNlpError(rc, self.lib.hipnlp_pose_last_error(self.h).decode())
+
+    def set_params(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float64).reshape(self.batch, self.np)
+        self._check(self.lib.hipnlp_pose_set_params(self.h, _dp(p)))
+
+    def bounds(self):
+        lb, ub = np.zeros((self.batch, self.m)), np.zeros((self.batch, self.m))
+        self._check(self.lib.hipnlp_pose_bounds(self.h, _dp(lb), _dp(ub)))
+        return lb, ub
+
+    def sparsity(self):
+        ir, jc = np.zeros(self.nnz, np.int32), np.zeros(self.nnz, np.int32)
+        self._check(self.lib.hipnlp_pose_sparsity(self.h, _ip(ir), _ip(jc)))
+        return ir, jc
+
+    def eval(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.batch, self.n)
+        f, grad = np.zeros(self.batch), np.zeros((self.batch, self.n))
+        g, jac = np.zeros((self.batch, self.m)), np.zeros((self.batch, self.nnz))
+        self._check(self.lib.hipnlp_pose_eval(self.h, _dp(x), _dp(f), _dp(grad), _dp(g), _dp(jac)))
+        return f, grad, g, jac
+
+    def eval_device(self, x_ptr, f_ptr, grad_ptr, g_ptr, jac_ptr, stream=None):
+        self._check(self.lib.hipnlp_pose_eval_device(self.h, x_ptr, f_ptr, grad_ptr, g_ptr, jac_ptr, stream))
+
+    def cost_terms(self):
+        names = [self.lib.hipnlp_pose_cost_term_name(i).decode() for i in range(_abi.POSE_NCOST_TERMS)]
+        v = np.zeros((self.batch, _abi.POSE_NCOST_TERMS))
+        self._check(self.lib.hipnlp_pose_cost_terms(self.h, _dp(v)))
+        return names, v
+
+    def row_blocks(self):
+        out = []
+        for i in range(self.lib.hipnlp_pose_num_row_blocks(self.h)):
+            name = C.c_char_p()
+            a, b = C.c_int32(), C.c_int32()
+            self._check(self.lib.hipnlp_pose_row_block(self.h, i, C.byref(name), C.byref(a), C.byref(b)))
+            out.append((name.value.decode(), a.value, b.value))
+        return out
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._check(self.lib.hipnlp_pose_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
