@@ -32,8 +32,38 @@ class InitialGuessFailure(Exception):
         super().__init__("Failed to set the initial guess. Message: " + str(message))
 
 
+class _PoseEngine:
+    """HipPose behind the method set the NLP drivers use on HipNlp (single pose)."""
+
+    def __init__(self, pose):
+        self._pose = pose
+        self.n, self.m, self.nnz = pose.n, pose.m, pose.nnz
+
+    def set_params(self, p):
+        self._pose.set_params(p)
+
+    def bounds(self):
+        lb, ub = self._pose.bounds()
+        return np.full(self.n, -np.inf), np.full(self.n, np.inf), lb[0], ub[0]
+
+    def sparsity(self):
+        return self._pose.sparsity()
+
+    def eval(self, x, new_x=True, want=("f", "grad", "g", "jac")):
+        return self._pose.eval(x)
+
+    def cost_terms(self):
+        return self._pose.cost_terms()
+
+    def row_blocks(self):
+        return [(name, first, rows, 0, 1) for name, first, rows in self._pose.row_blocks()]
+
+
 class HipNlpSolver:
-    def __init__(self, settings, model, device=0, inner_solver="auto", options_solver=None):
+    def __init__(self, settings, model, device=0, inner_solver="auto", options_solver=None, problem="kinodynamic"):
+        if problem not in ("kinodynamic", "pose"):
+            raise ValueError("problem must be 'kinodynamic' or 'pose'")
+        self._problem_kind = problem
         self._settings, self._model, self._device = settings, model, device
         self._inner_solver = inner_solver
         self._options = dict(options_solver or {})
@@ -78,7 +108,10 @@ class HipNlpSolver:
                 raise ValueError("Unsupported input storage type")
         self._n, self._np = xo, po
         horizon = int(kwargs.get("horizon", 1))
-        if xo != _abi.NXK * horizon + _abi.NXG or po != _abi.NPK * horizon + _abi.NPG:
+        if self._problem_kind == "pose":
+            if xo != _abi.POSE_NX or po != _abi.POSE_NP:
+                raise ValueError(f"the structure is not the pose finder Variables tree the engine evaluates (variables {xo}, parameters {po})")
+        elif xo != _abi.NXK * horizon + _abi.NXG or po != _abi.NPK * horizon + _abi.NPG:
             raise ValueError("the structure is not the kinodynamic Variables tree the engine evaluates "
                              f"(variables {xo}, parameters {po}, horizon {horizon})")
         self._objects = expanded
@@ -136,8 +169,11 @@ class HipNlpSolver:
     # ---- engine -------------------------------------------------------------------------------------------
     def engine(self):
         if self._engine is None:
-            from .hipnlp import HipNlp  # raises loudly without the library / a device
-            self._engine = HipNlp(self._settings, self._model, batch=1, device=self._device)
+            from .hipnlp import HipNlp, HipPose  # raises loudly without the library / a device
+            if self._problem_kind == "pose":
+                self._engine = _PoseEngine(HipPose(self._settings, self._model, batch=1, device=self._device))
+            else:
+                self._engine = HipNlp(self._settings, self._model, batch=1, device=self._device)
         return self._engine
 
     def get_constraint_expressions(self):

@@ -224,3 +224,55 @@ def test_output_to_dict_nests_by_dot():  # problem.py:58-79
     d = out.to_dict()
     assert d["cost_values"] == {"a": {"b": 2.0}} and "d[0]" in d["constraint_multipliers"]["c"]
     assert d["values"]["aggregated"]["scalar"] == 1.0
+
+
+# ---- static pose finder (turnkey_planners/humanoid_pose_finder) ------------------------------------------------------------
+def test_pose_variables_flatten_like_the_reference(model):
+    """Names / sizes / kinds of the pose finder's Variables tree against the reference's own to_dicts() (recorded in
+    tests/golden/pose_default.npz by tools/gen_pose_fixtures.py)."""
+    from hippopt_amd.turnkey_planners.humanoid_pose_finder import Settings, Variables
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "pose_default.npz"))
+    values, meta = Variables(settings=Settings(), kin_dyn_object=model).to_dicts()
+    v = ["%s:%d" % (n, np.asarray(a, float).size) for n, a in values.items() if meta[n][OptimizationObject.StorageTypeField] == "variable"]
+    p = ["%s:%d" % (n, np.asarray(a, float).size) for n, a in values.items() if meta[n][OptimizationObject.StorageTypeField] == "parameter"]
+    assert v == [str(s) for s in z["vnames"]]
+    assert p == [str(s) for s in z["pnames"]]
+
+
+def test_pose_planner_packs_parameters_and_regularises_mass(model):
+    from hippopt_amd import pose_settings as ps
+    from hippopt_amd.turnkey_planners.humanoid_pose_finder import Planner, References, Settings
+    st = Settings()
+    pl = Planner(st, model)
+    mass = model.get_total_mass()
+    refs = References(contact_point_descriptors=st.contact_points, number_of_joints=23)
+    refs.state.com = np.array([0.0, 0.0, 0.7])
+    refs.state.contact_points.left[2].p = np.array([0.1, 0.2, 0.3])
+    refs.state.contact_points.right[1].f = np.array([0.0, 0.0, mass * 2.0])
+    refs.frame_quaternion_xyzw = np.array([0.0, 0.1, 0.0, 0.99])
+    pl.set_references(refs)
+    guess = pl.get_initial_guess()
+    guess.state.contact_points.left[0].f = np.array([0.0, 0.0, mass * 9.81 / 8])
+    guess.state.kinematics.joints.positions = np.linspace(-0.2, 0.2, 23)
+    pl.set_initial_guess(guess)
+    x, p = pl.optimization_solver._pack()
+    assert x.size == 81 and p.size == 202
+    assert np.isclose(x[3 + 2], 9.81 / 8)                      # forces per unit mass (planner.py:795-819)
+    assert np.allclose(x[ps.X_S:ps.X_S + 23], np.linspace(-0.2, 0.2, 23))
+    assert np.allclose(x[ps.X_QB:ps.X_QB + 4], [0, 0, 0, 1])
+    assert np.isclose(p[ps.P_MASS], mass) and np.allclose(p[ps.P_GRAV:ps.P_GRAV + 6], st.gravity)
+    assert np.allclose(p[ps.P_REF + 9 * 2:ps.P_REF + 9 * 2 + 3], [0.1, 0.2, 0.3])
+    assert np.allclose(p[ps.P_REF + 9 * 5 + 3:ps.P_REF + 9 * 5 + 6], [0.0, 0.0, 2.0])
+    assert np.allclose(p[ps.P_REF_COM:ps.P_REF_COM + 3], [0.0, 0.0, 0.7])
+    assert np.allclose(p[ps.P_REF_FQ:ps.P_REF_FQ + 4], [0.0, 0.1, 0.0, 0.99])
+    assert np.isclose(p[ps.P_EPS], st.relaxed_complementarity_epsilon) and np.isclose(p[ps.P_MU], st.static_friction)
+    assert np.allclose(p[ps.P_DESC:ps.P_DESC + 3], [0.116, 0.05, 0.0]) and np.allclose(p[ps.P_REF + 6:ps.P_REF + 9], [0.116, 0.05, 0.0])
+    back = pl.get_initial_guess()
+    assert np.allclose(np.asarray(back.state.contact_points.left[0].f).reshape(-1), [0.0, 0.0, mass * 9.81 / 8])
+    assert np.allclose(np.asarray(back.references.state.contact_points.right[1].f).reshape(-1), [0.0, 0.0, mass * 2.0])
+    # packed defaults == pack_pose_parameters of the numeric mirror
+    pl2 = Planner(Settings(), model)
+    _, p2 = pl2.optimization_solver._pack()
+    zero = {"point_p": np.zeros((8, 3)), "point_f": np.zeros((8, 3)), "base_position": np.zeros(3), "base_quaternion": [0, 0, 0, 1.0],
+            "joints": np.zeros(23), "com": np.zeros(3), "frame_quaternion": [0, 0, 0, 1.0]}
+    assert np.allclose(p2, ps.pack_pose_parameters(Settings(), model, zero))
