@@ -12,6 +12,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -70,7 +71,8 @@ struct SharedTables {
     GParams gp;
 };
 
-template <int TERRAIN> __global__ __launch_bounds__(WG) void hipnlp_knot_kernel(KArgs a) {
+// 3 waves per SIMD = 3 workgroups per CU (the LDS bound): cap the register allocation there (<= 168 VGPRs)
+template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3, 3))) void hipnlp_knot_kernel(KArgs a) {
     __shared__ KnotScratch s;
     __shared__ SharedTables tabs;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -200,34 +202,34 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) void hipnlp_knot_kernel(
 }
 
 // f[b] = sum over knots and terms; cost_terms[b][t] = sum over knots; flag[b] = any non-finite.
-// Fixed summation tree (thread-strided partials, then a shared-memory tree): bitwise reproducible.
-constexpr int RWG = 256;
+// ONE wavefront per trajectory: lane l accumulates knots l, l+64, ... in registers, then a fixed butterfly over the 64 lanes
+// (ds_swizzle-free __shfl_xor) — no LDS, no workgroup barrier, bitwise reproducible (the summation tree is fixed by nk).
+constexpr int RWG = 64;
 __global__ __launch_bounds__(RWG) void hipnlp_reduce_kernel(const double* cost_knot, const int32_t* flags, int nk,
                                                             double* f, double* cost_terms, int32_t* flag_out) {
-    __shared__ double part[NCT][RWG];
-    __shared__ int anyflag;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    if (tid == 0) anyflag = 0;
+    const int b = blockIdx.x, lane = threadIdx.x;
     double acc[NCT];
+#pragma unroll
     for (int t = 0; t < NCT; ++t) acc[t] = 0.0;
     int bad = 0;
-    for (int k = tid; k < nk; k += RWG) {
+    for (int k = lane; k < nk; k += RWG) {
         const double* row = cost_knot + (size_t(b) * nk + k) * NCT;
+#pragma unroll
         for (int t = 0; t < NCT; ++t) acc[t] += row[t];
         bad |= flags[size_t(b) * nk + k];
     }
-    for (int t = 0; t < NCT; ++t) part[t][tid] = acc[t];
-    __syncthreads();
-    if (bad) atomicOr(&anyflag, 1);
-    for (int stride = RWG / 2; stride > 0; stride >>= 1) {
-        if (tid < stride) for (int t = 0; t < NCT; ++t) part[t][tid] += part[t][tid + stride];
-        __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) acc[t] += __shfl_xor(acc[t], off, 64);
+        bad |= __shfl_xor(bad, off, 64);
     }
-    if (tid == 0) {
+    if (lane == 0) {
         double tot = 0.0;
-        for (int t = 0; t < NCT; ++t) { tot += part[t][0]; if (cost_terms) cost_terms[size_t(b) * NCT + t] = part[t][0]; }
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) { tot += acc[t]; if (cost_terms) cost_terms[size_t(b) * NCT + t] = acc[t]; }
         if (f) f[b] = tot;
-        flag_out[b] = anyflag;
+        flag_out[b] = bad;
     }
 }
 
@@ -244,8 +246,9 @@ struct hipnlp_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_valid = false;
+    hipEvent_t last_e0 = nullptr, last_e2 = nullptr;  // events around the last TIMED launch
     std::vector<hipEvent_t> prof_ev;  // triples
-    int prof_cap = 0, prof_n = 0;
+    int prof_cap = 0, prof_n = 0, prof_stride = 1, prof_seen = 0;
     DeviceTables* d_tb = nullptr;
     double *d_x = nullptr, *d_pk = nullptr, *d_g = nullptr, *d_jac = nullptr, *d_grad = nullptr, *d_f = nullptr;
     double *d_cost_knot = nullptr, *d_cost_terms = nullptr;
@@ -434,8 +437,11 @@ int hipnlp_sparsity(const hipnlp_handle* h, int32_t* irow, int32_t* jcol) {
     return HIPNLP_OK;
 }
 
+// Timing: an event record drains the stream around the kernel and costs several microseconds, more than a third of a
+// 100-knot callback.  The host-buffer path (hipnlp_eval, PCIe bound anyway) is always timed; the device path is timed only for
+// the launches an armed profile selects (every stride-th launch), so that measuring does not change what is measured.
 static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, hipStream_t s,
-                  double* g_stage = nullptr, bool shard_local = false) {
+                  double* g_stage = nullptr, bool shard_local = false, bool always_timed = false) {
     KArgs a;
     a.tb = h->d_tb; a.x = x_dev; a.pk = h->d_pk; a.gp = h->d_gp;
     a.g = g_dev; a.jac = jac_dev; a.grad = grad_dev; a.g_stage = g_stage;
@@ -448,14 +454,16 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     }
     a.cost_knot = h->d_cost_knot; a.flags = h->d_flags;
     a.N = h->L.N; a.n = h->L.n; a.m = h->L.m; a.nnz = h->L.nnz; a.knot_begin = h->kb; a.nk = h->nk;
-    const bool prof = h->prof_n < h->prof_cap;
+    bool prof = false;
+    if (h->prof_cap > 0) { prof = h->prof_n < h->prof_cap && (h->prof_seen % h->prof_stride) == 0; h->prof_seen++; }
+    const bool timed = prof || always_timed;
     hipEvent_t e0 = prof ? h->prof_ev[size_t(3 * h->prof_n)] : h->ev0;
     hipEvent_t e2 = prof ? h->prof_ev[size_t(3 * h->prof_n + 2)] : h->ev1;
 #ifdef HIPNLP_STAMPS
     if (!h->d_stamps) HIP_TRY(h, hipMalloc(&h->d_stamps, size_t(h->nk) * size_t(h->batch) * 512 * sizeof(unsigned long long)));
     a.stamps = h->d_stamps;
 #endif
-    HIP_TRY(h, hipEventRecord(e0, s));
+    if (timed) HIP_TRY(h, hipEventRecord(e0, s));
     if (h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR)
         hipLaunchKernelGGL(hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR>, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(WG), 0, s, a);
     else
@@ -463,10 +471,10 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     if (prof) HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 1)], s));
     hipLaunchKernelGGL(hipnlp_reduce_kernel, dim3(unsigned(h->batch)), dim3(RWG), 0, s,
                        (const double*)h->d_cost_knot, (const int32_t*)h->d_flags, h->nk, f_dev, h->d_cost_terms, h->d_flag);
-    HIP_TRY(h, hipEventRecord(e2, s));
-    if (prof) { h->prof_n++; h->timing_valid = false; HIP_TRY(h, hipGetLastError()); return HIPNLP_OK; }
+    if (timed) HIP_TRY(h, hipEventRecord(e2, s));
     HIP_TRY(h, hipGetLastError());
-    h->timing_valid = true;
+    if (prof) h->prof_n++;
+    if (timed) { h->last_e0 = e0; h->last_e2 = e2; h->timing_valid = true; }
     return HIPNLP_OK;
 }
 
@@ -504,7 +512,7 @@ int hipnlp_eval(hipnlp_handle* h, const double* x, int new_x, double* f, double*
         HIP_TRY(h, hipSetDevice(h->dev));
         std::memcpy(h->h_x, x, B * n * sizeof(double));
         HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_x, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        int rc = launch(h, h->d_x, h->d_f, h->d_grad, h->d_g, h->d_jac, h->stream);
+        int rc = launch(h, h->d_x, h->d_f, h->d_grad, h->d_g, h->d_jac, h->stream, nullptr, false, true);
         if (rc != HIPNLP_OK) return rc;
         HIP_TRY(h, hipMemcpyAsync(h->h_f, h->d_f, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipMemcpyAsync(h->h_flag, h->d_flag, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -557,15 +565,15 @@ int hipnlp_row_block(const hipnlp_handle* h, int i, const char** name, int32_t* 
 
 int hipnlp_last_kernel_ms(hipnlp_handle* h, float* ms) {
     if (!h || !ms) return HIPNLP_E_INVALID;
-    if (!h->timing_valid) { h->err = "no evaluation has been launched yet"; return HIPNLP_E_INVALID; }
+    if (!h->timing_valid) { h->err = "no timed evaluation yet (hipnlp_eval, or a launch sampled by hipnlp_profile_begin)"; return HIPNLP_E_INVALID; }
     HIP_TRY(h, hipSetDevice(h->dev));
-    HIP_TRY(h, hipEventSynchronize(h->ev1));
-    HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    HIP_TRY(h, hipEventSynchronize(h->last_e2));
+    HIP_TRY(h, hipEventElapsedTime(ms, h->last_e0, h->last_e2));
     return HIPNLP_OK;
 }
 
-int hipnlp_profile_begin(hipnlp_handle* h, int max_launches) {
-    if (!h || max_launches < 0) return HIPNLP_E_INVALID;
+int hipnlp_profile_begin(hipnlp_handle* h, int max_launches, int stride) {
+    if (!h || max_launches < 0 || stride < 1) return HIPNLP_E_INVALID;
     HIP_TRY(h, hipSetDevice(h->dev));
     while (int(h->prof_ev.size()) < 3 * max_launches) {
         hipEvent_t e;
@@ -574,6 +582,9 @@ int hipnlp_profile_begin(hipnlp_handle* h, int max_launches) {
     }
     h->prof_cap = max_launches;
     h->prof_n = 0;
+    h->prof_stride = stride;
+    h->prof_seen = 0;
+    h->timing_valid = false;
     return HIPNLP_OK;
 }
 
@@ -593,6 +604,7 @@ int hipnlp_profile_end(hipnlp_handle* h, double* mean_knot_kernel_ms, double* me
     if (mean_launch_ms) *mean_launch_ms = h->prof_n ? b / h->prof_n : 0.0;
     h->prof_cap = 0;
     h->prof_n = 0;
+    h->timing_valid = false;
     return HIPNLP_OK;
 }
 

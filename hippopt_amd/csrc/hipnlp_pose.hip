@@ -61,7 +61,8 @@ struct PoseShared {
     GParams gp;
 };
 
-template <int TERRAIN> __global__ __launch_bounds__(WG) void hipnlp_pose_kernel(PArgs a) {
+// 3 waves per SIMD = 3 workgroups per CU (the LDS bound): cap the register allocation there (<= 168 VGPRs)
+template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3, 3))) void hipnlp_pose_kernel(PArgs a) {
     __shared__ KnotScratch s;
     __shared__ PoseShared tabs;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -162,18 +163,19 @@ static void pose_free_all(hipnlp_pose_handle* h) {
     delete h;
 }
 
-static int pose_launch(hipnlp_pose_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, hipStream_t s) {
+static int pose_launch(hipnlp_pose_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, hipStream_t s,
+                       bool timed) {
     PArgs a;
     a.tb = h->d_tb; a.x = x_dev; a.pk = h->d_pk; a.xr = h->d_xr; a.gp = h->d_gp;
     a.f = f_dev; a.grad = grad_dev; a.g = g_dev; a.jac = jac_dev; a.cost_terms = h->d_cost; a.flags = h->d_flags;
-    HIP_TRY(h, hipEventRecord(h->ev0, s));
+    if (timed) HIP_TRY(h, hipEventRecord(h->ev0, s));   // host-buffer path only (an event record drains the stream)
     if (h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR)
         hipLaunchKernelGGL(hipnlp_pose_kernel<HIPNLP_TERRAIN_PLANAR>, dim3(unsigned(h->batch)), dim3(WG), 0, s, a);
     else
         hipLaunchKernelGGL(hipnlp_pose_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS>, dim3(unsigned(h->batch)), dim3(WG), 0, s, a);
-    HIP_TRY(h, hipEventRecord(h->ev1, s));
+    if (timed) HIP_TRY(h, hipEventRecord(h->ev1, s));
     HIP_TRY(h, hipGetLastError());
-    h->timing_valid = true;
+    if (timed) h->timing_valid = true;
     return HIPNLP_OK;
 }
 
@@ -286,7 +288,7 @@ int hipnlp_pose_eval_device(hipnlp_pose_handle* h, const double* x_dev, double* 
     if (!h->params_set) { h->err = "parameters not set (hipnlp_pose_set_params)"; return HIPNLP_E_PARAMS; }
     HIP_TRY(h, hipSetDevice(h->dev));
     h->have_result = false;
-    return pose_launch(h, x_dev, f_dev ? f_dev : h->d_f, grad_dev, g_dev, jac_dev, stream ? hipStream_t(stream) : h->stream);
+    return pose_launch(h, x_dev, f_dev ? f_dev : h->d_f, grad_dev, g_dev, jac_dev, stream ? hipStream_t(stream) : h->stream, false);
 }
 
 int hipnlp_pose_eval(hipnlp_pose_handle* h, const double* x, double* f, double* grad_f, double* g, double* jac) {
@@ -296,7 +298,7 @@ int hipnlp_pose_eval(hipnlp_pose_handle* h, const double* x, double* f, double* 
     HIP_TRY(h, hipSetDevice(h->dev));
     std::memcpy(h->h_x, x, B * POSE_NX * sizeof(double));
     HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_x, B * POSE_NX * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    const int rc = pose_launch(h, h->d_x, h->d_f, h->d_grad, h->d_g, h->d_jac, h->stream);
+    const int rc = pose_launch(h, h->d_x, h->d_f, h->d_grad, h->d_g, h->d_jac, h->stream, true);
     if (rc != HIPNLP_OK) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->h_f, h->d_f, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -345,7 +347,7 @@ int hipnlp_pose_row_block(const hipnlp_pose_handle* h, int i, const char** name,
 
 int hipnlp_pose_last_kernel_ms(hipnlp_pose_handle* h, float* ms) {
     if (!h || !ms) return HIPNLP_E_INVALID;
-    if (!h->timing_valid) { h->err = "no evaluation has been launched yet"; return HIPNLP_E_INVALID; }
+    if (!h->timing_valid) { h->err = "no timed evaluation yet (hipnlp_pose_eval)"; return HIPNLP_E_INVALID; }
     HIP_TRY(h, hipSetDevice(h->dev));
     HIP_TRY(h, hipEventSynchronize(h->ev1));
     HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));

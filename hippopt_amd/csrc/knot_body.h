@@ -55,9 +55,7 @@ struct KnotScratch {
     // kinematics in base-centred coordinates (origin = base origin; h_ang and relative positions are
     // invariant to the base position / linear velocity)
     double Lj[NJ + 1][9];   // parent_R_child of joint j; slot NJ = identity (padding of the ancestor lists)
-    double Tj[NJ + 1][3];   // R_parent o_fix_j ; slot NJ = 0
-    double Uj[NJ + 1][3];   // (o_j x a_j) sdot_j ; slot NJ = 0
-    double Rw[NL][9], ow[NL][3], aw[NJ + 1][3];  // aw slot NJ = 0
+    double Rw[NL][9], ow[NL + 1][3], aw[NJ + 1][3];  // padding slots aw[NJ] = 0, ow[NL] = 0
     double wv[NL][3], vo[NL][3];  // link angular velocity; velocity of the body point at the origin
     union {  // own[] is dead once the composites are formed; the (rare) minimize-mode end terms reuse its space
         double own[NL + 1][16];  // per link, same layout as comp; slot NL = 0 (padding of the descendant lists)
@@ -445,7 +443,7 @@ template <class Em> HD void t_points_cost(Ctx<Em>& cx, int t) {
 HD void scratch_padding(KnotScratch& s, int e) {
     if (e < 16) s.own[NL][e] = 0.0;
     if (e < 9) s.Lj[NJ][e] = (e % 4 == 0) ? 1.0 : 0.0;
-    if (e < 3) { s.Tj[NJ][e] = 0.0; s.Uj[NJ][e] = 0.0; s.aw[NJ][e] = 0.0; }
+    if (e < 3) { s.aw[NJ][e] = 0.0; s.ow[NL][e] = 0.0; }
 }
 
 // --- trivial dynamics of base / joints / com, lane e over 33 state components.  planner.py:522-564 -----
@@ -654,53 +652,49 @@ template <class Em> HD void t_base(Ctx<Em>& cx, int e) {
 // run back to back on one wave (HIPNLP_WAVE_SYNC between them).
 constexpr int FK_SPLIT = 11;                         // joints [0, FK_SPLIT) on one wave, the rest on another
 constexpr int FK_TASKS_A = 3 * FK_SPLIT, FK_TASKS_B = 3 * (NJ - FK_SPLIT);
-template <class Em> HD void t_fk_rot_at(Ctx<Em>& cx, int t) {  // row r of R_j = row r of R_b L_a1 ... L_j ; axis ; T_j = R_parent o_fix_j
+template <class Em> HD void t_fk_rot_at(Ctx<Em>& cx, int t) {
+    // lane (joint j, component r) walks the front-padded ancestor list of j ONCE and accumulates, for its component r:
+    //   row r of R_j = row r of R_b L_a1 ... L_j        o_j[r] = sum_a (row r of R_parent(a)) . o_fix_a
+    //   a_j[r] = (row r of R_j) . axis_j                w_j[r] = omega[r] + sum_a a_a[r] sdot_a
+    // (padding slot NJ: L = I, o_fix = axis = 0)
     KnotScratch& s = cx.s;
     const int j = t / 3, r = t - 3 * j;
     double v0 = s.Rb[3 * r], v1 = s.Rb[3 * r + 1], v2 = s.Rb[3 * r + 2];
+    double o = 0.0, w = s.omega[r], ar = 0.0;
     HIPNLP_UNROLL
-    for (int q = 0; q < 7; ++q) {
-        const double* L = s.Lj[cx.kt.anc[j][q]];
+    for (int q = 0; q < 8; ++q) {
+        const int a = cx.kt.anc[j][q];
+        const double* of = cx.kt.o_fix[a];
+        o += v0 * of[0] + v1 * of[1] + v2 * of[2];
+        const double* L = s.Lj[a];
         const double n0 = v0 * L[0] + v1 * L[3] + v2 * L[6];
         const double n1 = v0 * L[1] + v1 * L[4] + v2 * L[7];
         const double n2 = v0 * L[2] + v1 * L[5] + v2 * L[8];
         v0 = n0; v1 = n1; v2 = n2;
+        const double* ax = cx.kt.axis[a];
+        ar = n0 * ax[0] + n1 * ax[1] + n2 * ax[2];
+        w += ar * s.x[SD_ + a];   // padding slot: x[SD_ + NJ] is finite (first joint position), ar = 0
     }
-    // (v0,v1,v2) is now row r of the PARENT's rotation (front-padded list: the last element is joint j itself)
-    const double* of = cx.kt.o_fix[j];
-    s.Tj[j][r] = v0 * of[0] + v1 * of[1] + v2 * of[2];
-    const double* L = s.Lj[j];
-    const double n0 = v0 * L[0] + v1 * L[3] + v2 * L[6];
-    const double n1 = v0 * L[1] + v1 * L[4] + v2 * L[7];
-    const double n2 = v0 * L[2] + v1 * L[5] + v2 * L[8];
-    s.Rw[j + 1][3 * r] = n0; s.Rw[j + 1][3 * r + 1] = n1; s.Rw[j + 1][3 * r + 2] = n2;
-    const double* ax = cx.kt.axis[j];
-    s.aw[j][r] = n0 * ax[0] + n1 * ax[1] + n2 * ax[2];
+    s.Rw[j + 1][3 * r] = v0; s.Rw[j + 1][3 * r + 1] = v1; s.Rw[j + 1][3 * r + 2] = v2;
+    s.aw[j][r] = ar;
+    s.ow[j + 1][r] = o;
+    s.wv[j + 1][r] = w;
 }
 template <class Em> HD void t_fk_rot_a(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t); }
 template <class Em> HD void t_fk_rot_b(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t + FK_TASKS_A); }
-// lane j (23): o_j = sum T_anc ; w_j = omega + sum a_anc sdot_anc ; U_j = (o_j x a_j) sdot_j   (all three components in-lane)
-template <class Em> HD void t_fk_pos(Ctx<Em>& cx, int j) {
-    KnotScratch& s = cx.s;
-    double o[3] = {0.0, 0.0, 0.0}, w[3] = {s.omega[0], s.omega[1], s.omega[2]};
+// velocity of the body point of link i at the (base-centred) origin: vO_i = sum over the joints a on the path root -> i of
+// (o_a x a_a) sdot_a ; computed in-lane by the link task (padding slot: aw[NJ] = 0, ow[NL] = 0)
+HD void link_origin_velocity(const KnotScratch& s, const KinTables& kt, int i, double* v) {
+    v[0] = v[1] = v[2] = 0.0;
+    if (i == 0) return;
     HIPNLP_UNROLL
     for (int q = 0; q < 8; ++q) {
-        const int a = cx.kt.anc[j][q];
-        const double sd = s.x[SD_ + a];  // padding slot: aw[NJ] = 0
-        for (int r = 0; r < 3; ++r) { o[r] += s.Tj[a][r]; w[r] += s.aw[a][r] * sd; }
+        const int a = kt.anc[i - 1][q];
+        double u[3];
+        cross3(s.ow[a + 1], s.aw[a], u);
+        const double sd = s.x[SD_ + a];
+        for (int r = 0; r < 3; ++r) v[r] += u[r] * sd;
     }
-    double u[3];
-    cross3(o, s.aw[j], u);
-    const double sdj = s.x[SD_ + j];
-    for (int r = 0; r < 3; ++r) { s.ow[j + 1][r] = o[r]; s.wv[j + 1][r] = w[r]; s.Uj[j][r] = u[r] * sdj; }
-}
-template <class Em> HD void t_fk_vel(Ctx<Em>& cx, int j) {  // vO_j = sum U_anc, lane j (23), behind t_fk_pos on the same wave
-    KnotScratch& s = cx.s;
-    HIPNLP_WAVE_SYNC();
-    double v[3] = {0.0, 0.0, 0.0};
-    HIPNLP_UNROLL
-    for (int q = 0; q < 8; ++q) { const int a = cx.kt.anc[j][q]; for (int r = 0; r < 3; ++r) v[r] += s.Uj[a][r]; }
-    for (int r = 0; r < 3; ++r) s.vo[j + 1][r] = v[r];
 }
 
 // --- centroidal momentum dynamics (T7 on E1): lanes (c, e) 48 entry tasks + lanes 48..59 row tasks -----------
@@ -828,6 +822,9 @@ template <class Em> HD void t_ends(Ctx<Em>& cx, int t) {
 template <class Em> HD void t_links(Ctx<Em>& cx, int i) {
     KnotScratch& s = cx.s;
     const double m = cx.kt.mass[i];
+    double vo[3];
+    link_origin_velocity(s, cx.kt, i, vo);
+    for (int r = 0; r < 3; ++r) s.vo[i][r] = vo[r];
     double c[3], RI[9], Iw[9], Rt[9];
     matvec3(s.Rw[i], cx.kt.com[i], c);
     for (int r = 0; r < 3; ++r) c[r] += s.ow[i][r];
@@ -849,9 +846,9 @@ template <class Em> HD void t_links(Ctx<Em>& cx, int i) {
     // link momentum about the origin:  lin = m vO + w x h ;  ang = I_O w + h x vO
     double a[3], b[3];
     cross3(s.wv[i], h, a);
-    for (int r = 0; r < 3; ++r) cp[CKL + r] = m * s.vo[i][r] + a[r];
+    for (int r = 0; r < 3; ++r) cp[CKL + r] = m * vo[r] + a[r];
     symvec(I6, s.wv[i], a);
-    cross3(h, s.vo[i], b);
+    cross3(h, vo, b);
     for (int r = 0; r < 3; ++r) cp[CKA + r] = a[r] + b[r];
 }
 template <class Em> HD void t_frames(Ctx<Em>& cx, int f) {
@@ -880,20 +877,23 @@ template <class Em> HD void t_frames(Ctx<Em>& cx, int f) {
 // running sums in registers.  Stage 2: one lane finishes the links that have several children and their
 // ancestors (reverse topological order), then the totals.  Contact-point kinematics ride along.
 // ===================================================================================================
-// composite (subtree) quantities as DESCENDANT SUMS: lane (link i, component r), 384 tasks spread over the four waves
-constexpr int COMP_TASKS_PER_WAVE = NL * 16 / 4;
+// composite (subtree) quantities as DESCENDANT SUMS: lane (link slot, component r).  The links are visited in the order of
+// decreasing subtree size (kt.comp_order), every lane sums exactly its own descendant list (kt.ndesc), so a wave iteration
+// costs the largest subtree among its four links: 24 + 6 + 4 + 3 + 2 + 1 steps on the ergoCub tree instead of 6 x 24.
+// Wave 0 takes the four largest subtrees, wave 1 the next eight, wave 2 the twelve smallest.
+constexpr int COMP_TASKS_W0 = 4 * 16, COMP_TASKS_W1 = 8 * 16, COMP_TASKS_W2 = 12 * 16;
+static_assert(COMP_TASKS_W0 + COMP_TASKS_W1 + COMP_TASKS_W2 == NL * 16, "composite task split");
 template <class Em> HD void t_composite(Ctx<Em>& cx, int t) {
     KnotScratch& s = cx.s;
-    const int i = t >> 4, r = t & 15;
+    const int i = cx.kt.comp_order[t >> 4], r = t & 15;
+    const int cnt = cx.kt.ndesc[i];
     double acc = 0.0;
-    HIPNLP_UNROLL
-    for (int n = 0; n < NL; ++n) acc += s.own[cx.kt.desc[i][n]][r];  // padding slot: own[NL] = 0
+    for (int n = 0; n < cnt; ++n) acc += s.own[cx.kt.desc[i][n]][r];
     s.comp[i][r] = acc;
 }
 template <class Em> HD void t_composite_w0(Ctx<Em>& cx, int t) { t_composite(cx, t); }
-template <class Em> HD void t_composite_w1(Ctx<Em>& cx, int t) { t_composite(cx, t + COMP_TASKS_PER_WAVE); }
-template <class Em> HD void t_composite_w2(Ctx<Em>& cx, int t) { t_composite(cx, t + 2 * COMP_TASKS_PER_WAVE); }
-template <class Em> HD void t_composite_w3(Ctx<Em>& cx, int t) { t_composite(cx, t + 3 * COMP_TASKS_PER_WAVE); }
+template <class Em> HD void t_composite_w1(Ctx<Em>& cx, int t) { t_composite(cx, t + COMP_TASKS_W0); }
+template <class Em> HD void t_composite_w2(Ctx<Em>& cx, int t) { t_composite(cx, t + COMP_TASKS_W0 + COMP_TASKS_W1); }
 template <class Em> HD void t_pkin(Ctx<Em>& cx, int c) {
     KnotScratch& s = cx.s;
     const int f = c < 4 ? 0 : 1;
@@ -954,27 +954,36 @@ template <class Em> HD void t_columns(Ctx<Em>& cx, int t) {
             em.J(js::COMC_S + NJ * r + j, row_id(RK_COMC, 0, r), S_ + j, -dcom[r]);
             em.J(js::CMMC_S + NJ * r + j, row_id(RK_CMMC, 0, r), S_ + j, -dh[r] * inv_mass);
         }
-        // chest-frame orientation cost: d trace = -(ax(M) . a_j) d s_j for joints on the root->chest path
-        if (cx.kt.chest_pos[j] >= 0) s.grad[S_ + j] += s.chest_dc * (-dot3(s.chest_w, a));
-        // feet lateral distance  y_r . (o_l - o_r)   (K4): joints of the two leg paths
-        const double* yr = s.fr_R[1];  // second column of R_rsole: entries [1],[4],[7]
-        const double y[3] = {yr[1], yr[4], yr[7]};
-        if (cx.kt.leg_pos[0][j] >= 0) {
-            double d[3], cxd[3];
-            for (int r = 0; r < 3; ++r) d[r] = s.fr_o[0][r] - o[r];
-            cross3(a, d, cxd);
-            em.J(js::FEETD + cx.kt.leg_pos[0][j], row_id(RK_FEETD, 0, 0), S_ + j, dot3(y, cxd));
-        }
-        if (cx.kt.leg_pos[1][j] >= 0) {
-            double d[3], e3[3], ay[3], cxd[3];
-            for (int r = 0; r < 3; ++r) { d[r] = s.fr_o[0][r] - s.fr_o[1][r]; e3[r] = s.fr_o[1][r] - o[r]; }
-            cross3(a, y, ay);
-            cross3(a, e3, cxd);
-            em.J(js::FEETD + LEG_PATH + cx.kt.leg_pos[1][j], row_id(RK_FEETD, 0, 0), S_ + j, dot3(ay, d) - dot3(y, cxd));
-        }
     } else {
         const int e = t - NJ;
         for (int r = 0; r < 3; ++r) s.dth_h[e][r] = dh[r];
+    }
+}
+
+// joint columns of the frame-based terms, lane j (23), on a wave of its own in the column phase: chest-frame orientation cost
+// gradient and the feet lateral distance row
+template <class Em> HD void t_frame_columns(Ctx<Em>& cx, int j) {
+    KnotScratch& s = cx.s;
+    Em& em = cx.em;
+    const double* a = s.aw[j];
+    const double* o = s.ow[j + 1];
+    // chest-frame orientation cost: d trace = -(ax(M) . a_j) d s_j for joints on the root->chest path
+    if (cx.kt.chest_pos[j] >= 0) s.grad[S_ + j] += s.chest_dc * (-dot3(s.chest_w, a));
+    // feet lateral distance  y_r . (o_l - o_r)   (K4): joints of the two leg paths
+    const double* yr = s.fr_R[1];  // second column of R_rsole: entries [1],[4],[7]
+    const double y[3] = {yr[1], yr[4], yr[7]};
+    if (cx.kt.leg_pos[0][j] >= 0) {
+        double d[3], cxd[3];
+        for (int r = 0; r < 3; ++r) d[r] = s.fr_o[0][r] - o[r];
+        cross3(a, d, cxd);
+        em.J(js::FEETD + cx.kt.leg_pos[0][j], row_id(RK_FEETD, 0, 0), S_ + j, dot3(y, cxd));
+    }
+    if (cx.kt.leg_pos[1][j] >= 0) {
+        double d[3], e3[3], ay[3], cxd[3];
+        for (int r = 0; r < 3; ++r) { d[r] = s.fr_o[0][r] - s.fr_o[1][r]; e3[r] = s.fr_o[1][r] - o[r]; }
+        cross3(a, y, ay);
+        cross3(a, e3, cxd);
+        em.J(js::FEETD + LEG_PATH + cx.kt.leg_pos[1][j], row_id(RK_FEETD, 0, 0), S_ + j, dot3(ay, d) - dot3(y, cxd));
     }
 }
 
@@ -1011,7 +1020,7 @@ template <class Em> HD void t_cmm_columns(Ctx<Em>& cx, int t) {
 template <class Em> HD void t_kinc(Ctx<Em>& cx, int t) {
     KnotScratch& s = cx.s;
     Em& em = cx.em;
-    const int c = t / 3, i = t - 3 * c, f = c < 4 ? 0 : 1, jb = js::PT_STRIDE * c, gb = gs::PT_STRIDE * c, cb = PT_ * c;
+    const int c = t / 3, i = t - 3 * c, jb = js::PT_STRIDE * c, gb = gs::PT_STRIDE * c, cb = PT_ * c;
     const double* r = s.pkin[c];  // base-centred
     em.G(gb + gs::KINC + i, row_id(RK_KINC, c, i), s.x[cb + P_ + i] - (s.x[PB_ + i] + r[i]));
     em.J(jb + js::KINC_P + i, row_id(RK_KINC, c, i), cb + P_ + i, 1.0);
@@ -1020,13 +1029,18 @@ template <class Em> HD void t_kinc(Ctx<Em>& cx, int t) {
     const double X0 = skew_rc(r, i, 0), X1 = skew_rc(r, i, 1), X2 = skew_rc(r, i, 2);
     for (int l = 0; l < 4; ++l)
         em.J(jb + js::KINC_QB + 4 * i + l, row_id(RK_KINC, c, i), QB_ + l, (X0 * s.G[l] + X1 * s.G[4 + l] + X2 * s.G[8 + l]) * s.inv_qnorm);
-    // d pkin / d s_j = a_j x (pkin - o_j) for the joints of the leg path
-    for (int q = 0; q < LEG_PATH; ++q) {
-        const int j = cx.kt.leg_joint[f][q];
-        double d[3];
-        for (int n = 0; n < 3; ++n) d[n] = r[n] - s.ow[j + 1][n];
-        em.J(jb + js::KINC_S + LEG_PATH * i + q, row_id(RK_KINC, c, i), S_ + j, -cross_comp(s.aw[j], d, i));
-    }
+}
+// d pkin / d s_j = a_j x (pkin - o_j) for the joints of the leg path: lane (c, q) 48 tasks, three rows each (another wave)
+template <class Em> HD void t_kinc_s(Ctx<Em>& cx, int t) {
+    KnotScratch& s = cx.s;
+    Em& em = cx.em;
+    const int c = t / LEG_PATH, q = t - LEG_PATH * c, f = c < 4 ? 0 : 1, jb = js::PT_STRIDE * c;
+    const int j = cx.kt.leg_joint[f][q];
+    const double* r = s.pkin[c];
+    double d[3], x[3];
+    for (int n = 0; n < 3; ++n) d[n] = r[n] - s.ow[j + 1][n];
+    cross3(s.aw[j], d, x);
+    for (int i = 0; i < 3; ++i) em.J(jb + js::KINC_S + LEG_PATH * i + q, row_id(RK_KINC, c, i), S_ + j, -x[i]);
 }
 // com == CoM(pb, qn, s)  (K2, planner.py:285-306): lanes (i, l) 12 for the q_b entries, lanes 12..14 rows
 template <class Em> HD void t_comc(Ctx<Em>& cx, int t) {
@@ -1115,16 +1129,15 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
     R(1, t_hdyn, HDYN_TASKS)                                                              \
     R(2, t_foot_costs, FOOT_TASKS) R(2, t_foot_cost_sum, 2)                               \
     BARRIER                                                                               \
-    R(0, t_fk_pos, NJ) R(0, t_fk_vel, NJ)                                                 \
-    BARRIER                                                                               \
     R(0, t_links, NL) R(1, t_frames, 3)                                                   \
     BARRIER                                                                               \
-    R(0, t_composite_w0, COMP_TASKS_PER_WAVE) R(1, t_composite_w1, COMP_TASKS_PER_WAVE)   \
-    R(2, t_composite_w2, COMP_TASKS_PER_WAVE) R(3, t_composite_w3, COMP_TASKS_PER_WAVE) R(1, t_pkin, NC) \
+    R(0, t_composite_w0, COMP_TASKS_W0) R(1, t_composite_w1, COMP_TASKS_W1)               \
+    R(2, t_composite_w2, COMP_TASKS_W2) R(3, t_pkin, NC)                                  \
     BARRIER                                                                               \
-    R(0, t_columns, NJ + 3) R(1, t_cmm_columns, NJ + 3) R(3, t_ends, ENDS_TASKS)          \
+    R(0, t_columns, NJ + 3) R(1, t_cmm_columns, NJ + 3) R(2, t_frame_columns, NJ) R(3, t_ends, ENDS_TASKS) \
     BARRIER                                                                               \
-    R(0, t_kinc, 3 * NC) R(1, t_comc, 15) R(2, t_cmmc, 15) R(3, t_feetd, 5) R(3, t_ends_finish, ENDS_FINISH_TASKS) \
+    R(0, t_kinc, 3 * NC) R(1, t_comc, 15) R(2, t_cmmc, 15) R(2, t_kinc_s, NC * LEG_PATH)  \
+    R(3, t_feetd, 5) R(3, t_ends_finish, ENDS_FINISH_TASKS)                               \
     BARRIER
 
 }  // namespace hipnlp

@@ -370,7 +370,14 @@ struct Layout {
                 for (int q = l; ; q = md.parent[q - 1]) { if (q == i) { in = true; break; } if (q == 0) break; }
                 if (in) kt.desc[i][n++] = int16_t(l);
             }
+            kt.ndesc[i] = int16_t(n);
             for (; n < NL; ++n) kt.desc[i][n] = int16_t(NL);
+        }
+        {
+            std::vector<int> order(NL);
+            for (int i = 0; i < NL; ++i) order[size_t(i)] = i;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return kt.ndesc[a] > kt.ndesc[b]; });
+            for (int i = 0; i < NL; ++i) kt.comp_order[i] = int16_t(order[size_t(i)]);
         }
         (void)nchild; (void)child;
         for (int i = 0; i < 105; ++i) {

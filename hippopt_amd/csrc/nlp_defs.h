@@ -52,10 +52,12 @@ struct KinTables {
     int32_t par_link[NJ];       // parent link of joint j
     int32_t anc[NJ][8];         // joints on the path root -> j (inclusive, ascending, j LAST), FRONT padded with NJ (identity / zero slot)
     int16_t desc[NL][NL];       // links of the subtree rooted at link i (inclusive), padded with NL (zero slot)
+    int16_t ndesc[NL];          // size of that subtree
+    int16_t comp_order[NL];     // links by decreasing subtree size (order of the composite tasks)
     // horizon-end rows
     int16_t fin_var[105], fin_slot[105], fin_desc[105];  // variable / slot among the 81 variable rows / descriptor index (3c+i) or -1
     int16_t per_var[84];
-    double R_fix[NJ][9], o_fix[NJ][3], axis[NJ][3];
+    double R_fix[NJ][9], o_fix[NJ + 1][3], axis[NJ + 1][3];   // slot NJ = 0: padding of the ancestor lists
     double mass[NL], com[NL][3], inertia[NL][9];
     double frame_R[3][9], frame_o[3][3];
     double total_mass;

@@ -66,7 +66,7 @@ def load_library():
     lib.hipnlp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.hipnlp_eval_device_shard.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.hipnlp_stage_rows.argtypes = [vp, C.c_int, ip]
-    lib.hipnlp_profile_begin.argtypes = [vp, C.c_int]
+    lib.hipnlp_profile_begin.argtypes = [vp, C.c_int, C.c_int]
     lib.hipnlp_profile_end.argtypes = [vp, dp, dp, C.POINTER(C.c_int)]
     lib.hipnlp_pose_create.argtypes = [C.POINTER(_abi.PoseDescC), C.POINTER(vp)]
     lib.hipnlp_pose_destroy.argtypes = [vp]
@@ -188,8 +188,9 @@ class HipNlp:
         self._check(self.lib.hipnlp_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
 
-    def profile_begin(self, max_launches):
-        self._check(self.lib.hipnlp_profile_begin(self.h, int(max_launches)))
+    def profile_begin(self, max_launches, stride=1):
+        """Arm HIP-event timing of every `stride`-th device-path launch (at most max_launches samples)."""
+        self._check(self.lib.hipnlp_profile_begin(self.h, int(max_launches), int(stride)))
 
     def profile_end(self):
         """(mean knot-kernel ms, mean launch ms incl. the cost reduction kernel, launches)"""

@@ -228,14 +228,15 @@ int hipnlp_num_row_blocks(const hipnlp_handle* h);
 int hipnlp_row_block(const hipnlp_handle* h, int i, const char** name,
                      int32_t* first_row, int32_t* rows_per_knot, int32_t* first_knot, int32_t* n_knots);
 
-/* Timing of the last hipnlp_eval()/hipnlp_eval_device() kernel, measured with hipEvents on the
- * stream the kernel ran on (ms).  Blocks until the launch has finished.                          */
+/* Kernel time (ms) of the last TIMED evaluation, measured with hipEvents on the stream the kernels ran on; blocks until
+ * that launch has finished.  hipnlp_eval() launches are always timed; hipnlp_eval_device*() launches only when selected by an
+ * armed profile (an event record drains the stream and costs microseconds: it must not sit around every device-path launch). */
 int hipnlp_last_kernel_ms(hipnlp_handle* h, float* ms);
 
-/* Per-launch HIP-event timing over a region of launches (bench.py roofline leg).  profile_begin arms up to
- * max_launches event triples recorded on the launch stream (before the knot kernel, after it, after the
- * reduction kernel); profile_end synchronises and returns the mean durations (ms) and the launch count.   */
-int hipnlp_profile_begin(hipnlp_handle* h, int max_launches);
+/* HIP-event timing over a region of launches (bench.py roofline leg).  profile_begin arms up to max_launches event triples;
+ * every stride-th launch from then on is bracketed (before the knot kernel, after it, after the reduction kernel) on the
+ * launch stream.  profile_end synchronises and returns the mean durations (ms) and the number of timed launches.   */
+int hipnlp_profile_begin(hipnlp_handle* h, int max_launches, int stride);
 int hipnlp_profile_end(hipnlp_handle* h, double* mean_knot_kernel_ms, double* mean_launch_ms, int* count);
 
 /* =====================================================================================================================

@@ -16,7 +16,7 @@ SO = os.path.join(ROOT, "tools", "diag", "_build", "libhipnlp_stamps.so")
 def build():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DHIPNLP_STAMPS",
-                           "-o", SO, os.path.join(ROOT, "hippopt_amd", "csrc", "hipnlp.hip")])
+                           "-o", SO, os.path.join(ROOT, "hippopt_amd", "csrc", "hipnlp.hip"), os.path.join(ROOT, "hippopt_amd", "csrc", "hipnlp_pose.hip")])
 
 
 if __name__ == "__main__":
