@@ -33,8 +33,10 @@
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define HIPNLP_WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier()
+#define HIPNLP_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)   // a value the caller knows to be the same in every lane -> SGPR
 #else
 #define HIPNLP_WAVE_SYNC() ((void)0)
+#define HIPNLP_UNIFORM(x) (x)
 #endif
 
 namespace hipnlp {
@@ -44,7 +46,10 @@ namespace hipnlp {
 // ---------------------------------------------------------------------------------------------------
 struct EndTerms { double c[105 + 84], g[105 + 84]; };  // minimize-mode end rows: cost partial and gradient share of row i
 
-struct KnotScratch {
+struct alignas(16) JointRec { double L[9], of[3], c[3], sd; };
+static_assert(sizeof(JointRec) == 128, "joint record");
+
+struct alignas(16) KnotScratch {
     double x[XPAD];    // knot k
     double xm[XPAD];   // knot k-1 (zeros at k = 0)
     double xo[XPAD];   // the other end of the horizon (only loaded at k = 0 and k = N-1)
@@ -54,8 +59,11 @@ struct KnotScratch {
     double qn[4], qnorm, inv_qnorm, Rb[9], G[12] /* 3x4: dtheta = G dqhat */, omega[3], dwq[12] /* d omega/d qb (3x4) */;
     // kinematics in base-centred coordinates (origin = base origin; h_ang and relative positions are
     // invariant to the base position / linear velocity)
-    double Lj[NJ + 1][9];   // parent_R_child of joint j; slot NJ = identity (padding of the ancestor lists)
-    double Rw[NL][9], ow[NL + 1][3], aw[NJ + 1][3];  // padding slots aw[NJ] = 0, ow[NL] = 0
+    // per joint, ONE 128-byte record the FK lanes stream with 16-byte LDS reads: [ parent_R_child (9) | o_fix (3) |
+    // c = R_fix axis = parent-frame joint axis (3) | sdot ]; slot NJ = [identity | 0 | 0 | 0] (padding of the ancestor lists)
+    JointRec Jr[NJ + 1];
+    double Uj[NJ + 1][3];   // (o_j x a_j) sdot_j ; slot NJ = 0
+    double Rw[NL][9], ow[NL][3], aw[NJ + 1][3];  // padding slot aw[NJ] = 0
     double wv[NL][3], vo[NL][3];  // link angular velocity; velocity of the body point at the origin
     union {  // own[] is dead once the composites are formed; the (rare) minimize-mode end terms reuse its space
         double own[NL + 1][16];  // per link, same layout as comp; slot NL = 0 (padding of the descendant lists)
@@ -442,8 +450,10 @@ template <class Em> HD void t_points_cost(Ctx<Em>& cx, int t) {
 // identity / zero padding slots of the ancestor and descendant lists, lanes e < 16
 HD void scratch_padding(KnotScratch& s, int e) {
     if (e < 16) s.own[NL][e] = 0.0;
-    if (e < 9) s.Lj[NJ][e] = (e % 4 == 0) ? 1.0 : 0.0;
-    if (e < 3) { s.aw[NJ][e] = 0.0; s.ow[NL][e] = 0.0; }
+    if (e < 9) s.Jr[NJ].L[e] = (e % 4 == 0) ? 1.0 : 0.0;
+    if (e < 3) { s.Jr[NJ].of[e] = 0.0; s.Jr[NJ].c[e] = 0.0; }
+    if (e == 0) s.Jr[NJ].sd = 0.0;
+    if (e < 3) { s.aw[NJ][e] = 0.0; s.Uj[NJ][e] = 0.0; }
 }
 
 // --- trivial dynamics of base / joints / com, lane e over 33 state components.  planner.py:522-564 -----
@@ -468,7 +478,8 @@ template <class Em> HD void t_dyn(Ctx<Em>& cx, int e) {
     em.J(jslot + 4 * L + i, row_id(kx0, 0, i), X, 1.0);
 }
 
-// parent_R_child = R_fix * (cq (I - a a^T) + sq [a]x + a a^T)   (adam R_from_axis_angle) -> s.Lj[j]
+// parent_R_child = R_fix * (cq (I - a a^T) + sq [a]x + a a^T)   (adam R_from_axis_angle) -> the joint record s.Jr[j]
+// (a rotation about the joint axis leaves the axis in place: parent_R_child axis = R_fix axis, a constant)
 template <class Em> HD void joint_transform(Ctx<Em>& cx, int j) {
     KnotScratch& s = cx.s;
     const double* a = cx.kt.axis[j];
@@ -480,7 +491,11 @@ template <class Em> HD void joint_transform(Ctx<Em>& cx, int j) {
     Ra[1] -= sq * a[2]; Ra[2] += sq * a[1];
     Ra[3] += sq * a[2]; Ra[5] -= sq * a[0];
     Ra[6] -= sq * a[1]; Ra[7] += sq * a[0];
-    matmul3(cx.kt.R_fix[j], Ra, s.Lj[j]);
+    JointRec& rec = s.Jr[j];
+    matmul3(cx.kt.R_fix[j], Ra, rec.L);
+    matvec3(cx.kt.R_fix[j], a, rec.c);
+    for (int r = 0; r < 3; ++r) rec.of[r] = cx.kt.o_fix[j][r];
+    rec.sd = s.x[SD_ + j];
 }
 
 // --- joint-wise rows, joint regularisation cost and the local joint transform, lane j (23) -------------
@@ -650,30 +665,27 @@ template <class Em> HD void t_base(Ctx<Em>& cx, int e) {
 // Forward kinematics and link velocities as ANCESTOR SUMS: lane (joint j, component r), 69 tasks per pass.
 // Every lane walks its own (padded) ancestor list, so no lane waits for another one inside a pass; the passes
 // run back to back on one wave (HIPNLP_WAVE_SYNC between them).
-constexpr int FK_SPLIT = 11;                         // joints [0, FK_SPLIT) on one wave, the rest on another
 constexpr int FK_TASKS_A = 3 * FK_SPLIT, FK_TASKS_B = 3 * (NJ - FK_SPLIT);
 template <class Em> HD void t_fk_rot_at(Ctx<Em>& cx, int t) {
     // lane (joint j, component r) walks the front-padded ancestor list of j ONCE and accumulates, for its component r:
     //   row r of R_j = row r of R_b L_a1 ... L_j        o_j[r] = sum_a (row r of R_parent(a)) . o_fix_a
     //   a_j[r] = (row r of R_j) . axis_j                w_j[r] = omega[r] + sum_a a_a[r] sdot_a
-    // (padding slot NJ: L = I, o_fix = axis = 0)
+    // (padding slot NJ: L = I, o_fix = c = sdot = 0)
     KnotScratch& s = cx.s;
     const int j = t / 3, r = t - 3 * j;
     double v0 = s.Rb[3 * r], v1 = s.Rb[3 * r + 1], v2 = s.Rb[3 * r + 2];
     double o = 0.0, w = s.omega[r], ar = 0.0;
     HIPNLP_UNROLL
     for (int q = 0; q < 8; ++q) {
-        const int a = cx.kt.anc[j][q];
-        const double* of = cx.kt.o_fix[a];
-        o += v0 * of[0] + v1 * of[1] + v2 * of[2];
-        const double* L = s.Lj[a];
+        const JointRec& rec = s.Jr[cx.kt.anc[j][q]];
+        o += v0 * rec.of[0] + v1 * rec.of[1] + v2 * rec.of[2];
+        ar = v0 * rec.c[0] + v1 * rec.c[1] + v2 * rec.c[2];   // (row r of R_parent) . (R_fix axis) = (row r of R_a) . axis
+        w += ar * rec.sd;
+        const double* L = rec.L;
         const double n0 = v0 * L[0] + v1 * L[3] + v2 * L[6];
         const double n1 = v0 * L[1] + v1 * L[4] + v2 * L[7];
         const double n2 = v0 * L[2] + v1 * L[5] + v2 * L[8];
         v0 = n0; v1 = n1; v2 = n2;
-        const double* ax = cx.kt.axis[a];
-        ar = n0 * ax[0] + n1 * ax[1] + n2 * ax[2];
-        w += ar * s.x[SD_ + a];   // padding slot: x[SD_ + NJ] is finite (first joint position), ar = 0
     }
     s.Rw[j + 1][3 * r] = v0; s.Rw[j + 1][3 * r + 1] = v1; s.Rw[j + 1][3 * r + 2] = v2;
     s.aw[j][r] = ar;
@@ -682,18 +694,24 @@ template <class Em> HD void t_fk_rot_at(Ctx<Em>& cx, int t) {
 }
 template <class Em> HD void t_fk_rot_a(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t); }
 template <class Em> HD void t_fk_rot_b(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t + FK_TASKS_A); }
+// (A level-synchronous variant — one step per joint, the wave walking the tree level by level behind wave-level fences — was
+//  measured at 4.7 k cycles against 3.4 k for these ancestor sums: a level costs two dependent LDS round trips, ~680 cycles.)
 // velocity of the body point of link i at the (base-centred) origin: vO_i = sum over the joints a on the path root -> i of
-// (o_a x a_a) sdot_a ; computed in-lane by the link task (padding slot: aw[NJ] = 0, ow[NL] = 0)
+// U_a = (o_a x a_a) sdot_a.  t_link_u (lane j) forms U_j, t_links (same wave, behind it) sums the ancestors' (padding: U_NJ = 0)
+template <class Em> HD void t_link_u(Ctx<Em>& cx, int j) {
+    KnotScratch& s = cx.s;
+    double u[3];
+    cross3(s.ow[j + 1], s.aw[j], u);
+    const double sd = s.x[SD_ + j];
+    for (int r = 0; r < 3; ++r) s.Uj[j][r] = u[r] * sd;
+}
 HD void link_origin_velocity(const KnotScratch& s, const KinTables& kt, int i, double* v) {
     v[0] = v[1] = v[2] = 0.0;
     if (i == 0) return;
     HIPNLP_UNROLL
     for (int q = 0; q < 8; ++q) {
-        const int a = kt.anc[i - 1][q];
-        double u[3];
-        cross3(s.ow[a + 1], s.aw[a], u);
-        const double sd = s.x[SD_ + a];
-        for (int r = 0; r < 3; ++r) v[r] += u[r] * sd;
+        const double* u = s.Uj[kt.anc[i - 1][q]];
+        for (int r = 0; r < 3; ++r) v[r] += u[r];
     }
 }
 
@@ -822,6 +840,7 @@ template <class Em> HD void t_ends(Ctx<Em>& cx, int t) {
 template <class Em> HD void t_links(Ctx<Em>& cx, int i) {
     KnotScratch& s = cx.s;
     const double m = cx.kt.mass[i];
+    HIPNLP_WAVE_SYNC();   // U_j of the same wave (t_link_u)
     double vo[3];
     link_origin_velocity(s, cx.kt, i, vo);
     for (int r = 0; r < 3; ++r) s.vo[i][r] = vo[r];
@@ -878,22 +897,29 @@ template <class Em> HD void t_frames(Ctx<Em>& cx, int f) {
 // ancestors (reverse topological order), then the totals.  Contact-point kinematics ride along.
 // ===================================================================================================
 // composite (subtree) quantities as DESCENDANT SUMS: lane (link slot, component r).  The links are visited in the order of
-// decreasing subtree size (kt.comp_order), every lane sums exactly its own descendant list (kt.ndesc), so a wave iteration
-// costs the largest subtree among its four links: 24 + 6 + 4 + 3 + 2 + 1 steps on the ergoCub tree instead of 6 x 24.
-// Wave 0 takes the four largest subtrees, wave 1 the next eight, wave 2 the twelve smallest.
-constexpr int COMP_TASKS_W0 = 4 * 16, COMP_TASKS_W1 = 8 * 16, COMP_TASKS_W2 = 12 * 16;
-static_assert(COMP_TASKS_W0 + COMP_TASKS_W1 + COMP_TASKS_W2 == NL * 16, "composite task split");
+// decreasing subtree size (kt.comp_order) and a wave iteration runs as many steps as the largest subtree among its four links
+// (kt.comp_cnt), so it costs: 24 + 6 + 4 + 3 + 2 + 1 steps on the ergoCub tree instead of 6 x 24.
+// Wave 0 takes the four largest subtrees, waves 1 and 2 the next eight each, wave 3 the four smallest (an iteration has a fixed
+// cost of several hundred cycles of index chasing on top of its steps).
+constexpr int COMP_TASKS_W0 = 4 * 16, COMP_TASKS_W1 = 8 * 16, COMP_TASKS_W2 = 8 * 16, COMP_TASKS_W3 = 4 * 16;
+static_assert(COMP_TASKS_W0 + COMP_TASKS_W1 + COMP_TASKS_W2 + COMP_TASKS_W3 == NL * 16, "composite task split");
 template <class Em> HD void t_composite(Ctx<Em>& cx, int t) {
     KnotScratch& s = cx.s;
     const int i = cx.kt.comp_order[t >> 4], r = t & 15;
-    const int cnt = cx.kt.ndesc[i];
+    // trip count of the wave iteration = largest subtree among its four links (uniform: scalar loop); shorter lists are padded
+    // with the zero slot own[NL]
+    const int cnt = HIPNLP_UNIFORM(int(cx.kt.comp_cnt[t >> 6]));
     double acc = 0.0;
+#if defined(__HIPCC__)
+#pragma unroll 4
+#endif
     for (int n = 0; n < cnt; ++n) acc += s.own[cx.kt.desc[i][n]][r];
     s.comp[i][r] = acc;
 }
 template <class Em> HD void t_composite_w0(Ctx<Em>& cx, int t) { t_composite(cx, t); }
 template <class Em> HD void t_composite_w1(Ctx<Em>& cx, int t) { t_composite(cx, t + COMP_TASKS_W0); }
 template <class Em> HD void t_composite_w2(Ctx<Em>& cx, int t) { t_composite(cx, t + COMP_TASKS_W0 + COMP_TASKS_W1); }
+template <class Em> HD void t_composite_w3(Ctx<Em>& cx, int t) { t_composite(cx, t + COMP_TASKS_W0 + COMP_TASKS_W1 + COMP_TASKS_W2); }
 template <class Em> HD void t_pkin(Ctx<Em>& cx, int c) {
     KnotScratch& s = cx.s;
     const int f = c < 4 ? 0 : 1;
@@ -1129,10 +1155,10 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
     R(1, t_hdyn, HDYN_TASKS)                                                              \
     R(2, t_foot_costs, FOOT_TASKS) R(2, t_foot_cost_sum, 2)                               \
     BARRIER                                                                               \
-    R(0, t_links, NL) R(1, t_frames, 3)                                                   \
+    R(0, t_link_u, NJ) R(0, t_links, NL) R(1, t_frames, 3)                                \
     BARRIER                                                                               \
     R(0, t_composite_w0, COMP_TASKS_W0) R(1, t_composite_w1, COMP_TASKS_W1)               \
-    R(2, t_composite_w2, COMP_TASKS_W2) R(3, t_pkin, NC)                                  \
+    R(2, t_composite_w2, COMP_TASKS_W2) R(3, t_composite_w3, COMP_TASKS_W3) R(3, t_pkin, NC) \
     BARRIER                                                                               \
     R(0, t_columns, NJ + 3) R(1, t_cmm_columns, NJ + 3) R(2, t_frame_columns, NJ) R(3, t_ends, ENDS_TASKS) \
     BARRIER                                                                               \

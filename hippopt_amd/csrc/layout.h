@@ -361,23 +361,24 @@ struct Layout {
             std::sort(path.begin(), path.end());
             // FRONT padded: the last element is always joint j itself, so the state before the last product is the parent's
             const int npad = 8 - int(path.size());
-            for (int q = 0; q < 8; ++q) kt.anc[j][q] = q < npad ? NJ : path[size_t(q - npad)];
+            for (int q = 0; q < 8; ++q) kt.anc[j][q] = int8_t(q < npad ? NJ : path[size_t(q - npad)]);
         }
         for (int i = 0; i < NL; ++i) {
             int n = 0;
             for (int l = 0; l < NL; ++l) {
                 bool in = false;
                 for (int q = l; ; q = md.parent[q - 1]) { if (q == i) { in = true; break; } if (q == 0) break; }
-                if (in) kt.desc[i][n++] = int16_t(l);
+                if (in) kt.desc[i][n++] = int8_t(l);
             }
             kt.ndesc[i] = int16_t(n);
-            for (; n < NL; ++n) kt.desc[i][n] = int16_t(NL);
+            for (; n < NL; ++n) kt.desc[i][n] = int8_t(NL);
         }
         {
             std::vector<int> order(NL);
             for (int i = 0; i < NL; ++i) order[size_t(i)] = i;
             std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return kt.ndesc[a] > kt.ndesc[b]; });
             for (int i = 0; i < NL; ++i) kt.comp_order[i] = int16_t(order[size_t(i)]);
+            for (int g = 0; g < NL / 4; ++g) kt.comp_cnt[g] = kt.ndesc[order[size_t(4 * g)]];   // sorted: the first of the group is the largest
         }
         (void)nchild; (void)child;
         for (int i = 0; i < 105; ++i) {

@@ -23,6 +23,7 @@ constexpr int NJ = HIPNLP_NJ, NL = HIPNLP_NL, NC = HIPNLP_NC, NXK = HIPNLP_NXK, 
 constexpr int LEG_PATH = 6;    // joints between root_link and each sole frame (ergoCub topology)
 constexpr int CHEST_PATH = 3;  // joints between root_link and the chest frame
 constexpr int XPAD = 192;      // LDS stride of one knot record
+constexpr int FK_SPLIT = 11;   // forward kinematics: joints [0, FK_SPLIT) on one wave, the rest on another (both parent-closed)
 constexpr int MAX_LEAF = 6;    // leaf links of the kinematic tree (ergoCub: 2 hands + 2 feet)
 
 // ---- per-knot variable offsets (reference creation order, tests/golden/kinodyn_structure.json) --
@@ -50,14 +51,15 @@ struct KinTables {
     int32_t frame_link[3];
     // tree as ancestor / descendant lists: every lane sums over its own list, no loop-carried dependence
     int32_t par_link[NJ];       // parent link of joint j
-    int32_t anc[NJ][8];         // joints on the path root -> j (inclusive, ascending, j LAST), FRONT padded with NJ (identity / zero slot)
-    int16_t desc[NL][NL];       // links of the subtree rooted at link i (inclusive), padded with NL (zero slot)
+    int8_t anc[NJ][8];          // joints on the path root -> j (inclusive, ascending, j LAST), FRONT padded with NJ (identity / zero slot)
+    int8_t desc[NL][NL];        // links of the subtree rooted at link i (inclusive), padded with NL (zero slot)
     int16_t ndesc[NL];          // size of that subtree
     int16_t comp_order[NL];     // links by decreasing subtree size (order of the composite tasks)
+    int16_t comp_cnt[NL / 4];   // largest subtree in each group of four links of that order
     // horizon-end rows
     int16_t fin_var[105], fin_slot[105], fin_desc[105];  // variable / slot among the 81 variable rows / descriptor index (3c+i) or -1
     int16_t per_var[84];
-    double R_fix[NJ][9], o_fix[NJ + 1][3], axis[NJ + 1][3];   // slot NJ = 0: padding of the ancestor lists
+    double R_fix[NJ][9], o_fix[NJ][3], axis[NJ][3];
     double mass[NL], com[NL][3], inertia[NL][9];
     double frame_R[3][9], frame_o[3][3];
     double total_mass;

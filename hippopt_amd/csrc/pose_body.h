@@ -162,10 +162,10 @@ HD double pose_cost_term(const KnotScratch& s, int t) {
     BARRIER                                                                               \
     R(0, t_fk_rot_a, FK_TASKS_A) R(3, t_fk_rot_b, FK_TASKS_B)                             \
     BARRIER                                                                               \
-    R(0, t_links, NL) R(1, t_frames, 3)                                                   \
+    R(0, t_link_u, NJ) R(0, t_links, NL) R(1, t_frames, 3)                                \
     BARRIER                                                                               \
     R(0, t_composite_w0, COMP_TASKS_W0) R(1, t_composite_w1, COMP_TASKS_W1)               \
-    R(2, t_composite_w2, COMP_TASKS_W2) R(3, t_pkin, NC)                                  \
+    R(2, t_composite_w2, COMP_TASKS_W2) R(3, t_composite_w3, COMP_TASKS_W3) R(3, t_pkin, NC) \
     BARRIER                                                                               \
     R(0, t_columns, NJ + 3) R(2, t_frame_columns, NJ)                                     \
     BARRIER                                                                               \
