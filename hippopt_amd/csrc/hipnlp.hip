@@ -146,12 +146,16 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     if (a.jac) {
         const int64_t jbase = first ? 0 : int64_t(tb.nnz_v[VAR_FIRST]) + int64_t(k - 1) * tb.nnz_v[VAR_INTERIOR];
         double* out = a.jac + int64_t(b) * a.jac_stride + (jbase - a.jac_off);
+        // all LDS reads first (clamped index, no branch), ONE wait, then the predicated stores: a branch per entry would
+        // expose one LDS round trip per entry
+        double vals[JP_ITERS];
+#pragma unroll
+        for (int it = 0; it < JP_ITERS; ++it) vals[it] = s.jac[jp[it] >= 0 ? jp[it] : 0];
 #pragma unroll
         for (int it = 0; it < JP_ITERS; ++it) {
             if (jp[it] >= 0) {
-                const double val = s.jac[jp[it]];
-                bad |= !isfinite(val);
-                out[tid + it * WG] = val;
+                bad |= !isfinite(vals[it]);
+                out[tid + it * WG] = vals[it];
             }
         }
         // entries in the horizon-global columns (constants) sit right behind the last knot's block: the last knot writes them
@@ -159,12 +163,14 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     }
     if (a.g) {
         double* out = a.g + size_t(b) * a.m;
+        double vals[G_ITERS];
+#pragma unroll
+        for (int it = 0; it < G_ITERS; ++it) vals[it] = s.g[(tid + it * WG) < gs::COUNT ? tid + it * WG : 0];
 #pragma unroll
         for (int it = 0; it < G_ITERS; ++it) {
             if (ga[it] >= 0) {
-                const double val = s.g[tid + it * WG];
-                bad |= !isfinite(val);
-                out[ga[it] + gb[it] * k] = val;
+                bad |= !isfinite(vals[it]);
+                out[ga[it] + gb[it] * k] = vals[it];
             }
         }
     }
@@ -202,34 +208,46 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
 }
 
 // f[b] = sum over knots and terms; cost_terms[b][t] = sum over knots; flag[b] = any non-finite.
-// ONE wavefront per trajectory: lane l accumulates knots l, l+64, ... in registers, then a fixed butterfly over the 64 lanes
-// (ds_swizzle-free __shfl_xor) — no LDS, no workgroup barrier, bitwise reproducible (the summation tree is fixed by nk).
-constexpr int RWG = 64;
+// One workgroup per trajectory.  Thread (group g = tid / 16, column c = tid % 16) sums column c (12 cost terms + the flag) of the
+// knots g, g + 16, ...: all its loads are independent and issued together (ONE memory round trip), then a fixed tree: two
+// lane-shuffles inside the wave, four waves through LDS, twelve terms in order.  Bitwise reproducible (the tree depends on nk only).
+constexpr int RWG = 256, RCOL = 16, RGRP = RWG / RCOL, RUNR = 8;
+static_assert(NCT + 1 <= RCOL, "reduce columns");
 __global__ __launch_bounds__(RWG) void hipnlp_reduce_kernel(const double* cost_knot, const int32_t* flags, int nk,
                                                             double* f, double* cost_terms, int32_t* flag_out) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    double acc[NCT];
-#pragma unroll
-    for (int t = 0; t < NCT; ++t) acc[t] = 0.0;
+    __shared__ double part[RWG / 64][RCOL];
+    __shared__ int pflag[RWG / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, c = tid % RCOL, g = tid / RCOL, lane = tid & 63, wave = tid >> 6;
+    double acc = 0.0;
     int bad = 0;
-    for (int k = lane; k < nk; k += RWG) {
-        const double* row = cost_knot + (size_t(b) * nk + k) * NCT;
+    for (int k0 = g; k0 < nk; k0 += RGRP * RUNR) {
+        double v[RUNR];
+        int fl[RUNR];
 #pragma unroll
-        for (int t = 0; t < NCT; ++t) acc[t] += row[t];
-        bad |= flags[size_t(b) * nk + k];
+        for (int u = 0; u < RUNR; ++u) {
+            const int k = k0 + u * RGRP;
+            v[u] = (c < NCT && k < nk) ? cost_knot[(size_t(b) * nk + k) * NCT + c] : 0.0;
+            fl[u] = (c == NCT && k < nk) ? flags[size_t(b) * nk + k] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < RUNR; ++u) { acc += v[u]; bad |= fl[u]; }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-        for (int t = 0; t < NCT; ++t) acc[t] += __shfl_xor(acc[t], off, 64);
-        bad |= __shfl_xor(bad, off, 64);
-    }
-    if (lane == 0) {
+    acc += __shfl_xor(acc, 16, 64); bad |= __shfl_xor(bad, 16, 64);
+    acc += __shfl_xor(acc, 32, 64); bad |= __shfl_xor(bad, 32, 64);
+    if (lane < RCOL) part[wave][lane] = acc;
+    if (lane == NCT) pflag[wave] = bad;
+    __syncthreads();
+    if (tid == 0) {
         double tot = 0.0;
-#pragma unroll
-        for (int t = 0; t < NCT; ++t) { tot += acc[t]; if (cost_terms) cost_terms[size_t(b) * NCT + t] = acc[t]; }
+        int anybad = 0;
+        for (int t = 0; t < NCT; ++t) {
+            const double term = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
+            tot += term;
+            if (cost_terms) cost_terms[size_t(b) * NCT + t] = term;
+        }
+        for (int w = 0; w < RWG / 64; ++w) anybad |= pflag[w];
         if (f) f[b] = tot;
-        flag_out[b] = bad;
+        flag_out[b] = anybad;
     }
 }
 

@@ -589,7 +589,7 @@ template <class Em> HD void t_small(Ctx<Em>& cx, int t) {
 
 // --- feet: lane 0 centroids (relative height row + centroid cost, planner.py:215-264);
 //           lanes 1,2 yaw alignment errors of the left / right foot (E9, planner.py:773-853): 3 tasks -------
-template <class Em> HD void t_feet(Ctx<Em>& cx, int t) {
+template <class Em> HD void t_feet(Ctx<Em>& cx, int t) {   // t = 0: centroids; t = 1, 2: yaw of the left / right foot
     KnotScratch& s = cx.s;
     Em& em = cx.em;
     const double on = cx.ki.first ? 0.0 : 1.0;
@@ -627,6 +627,10 @@ template <class Em> HD void t_feet(Ctx<Em>& cx, int t) {
         s.c_yaw[foot] = on * cx.st.m_yaw * (0.5 * (ef * ef + es * es));
     }
 }
+
+// the two branches of t_feet as task groups of their own, so that they can sit on different waves of phase A
+template <class Em> HD void t_feet_centroid(Ctx<Em>& cx, int) { t_feet(cx, 0); }
+template <class Em> HD void t_feet_yaw(Ctx<Em>& cx, int foot) { t_feet(cx, 1 + foot); }
 
 // --- base orientation: normalised quaternion (E11), R_b, G, omega (E12), d omega / d q_b: lane e = row (3 tasks) ---------
 template <class Em> HD void t_base(Ctx<Em>& cx, int e) {
@@ -1146,10 +1150,10 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
 // Groups of one phase run concurrently on different waves; BARRIER separates phases.
 // ---------------------------------------------------------------------------------------------------
 #define HIPNLP_KNOT_PROGRAM(R, BARRIER)                                                   \
-    R(0, t_points_vec, 3 * NC) R(0, t_feet, 3)                                            \
-    R(1, t_points_scalar, NC) R(1, t_points_cost, 3) R(1, t_dyn, 7 + NJ + 3)              \
-    R(2, t_joints, NJ) R(2, t_joint_cost, 1)                                              \
-    R(3, t_base, 3) R(3, t_small, 4) R(3, t_unitq, 1)                                     \
+    R(0, t_points_vec, 3 * NC) R(0, t_unitq, 1)                                           \
+    R(1, t_points_scalar, NC) R(1, t_points_cost, 3) R(1, t_dyn, 7 + NJ + 3) R(1, t_feet_centroid, 1) \
+    R(2, t_joints, NJ) R(2, t_joint_cost, 1) R(2, t_feet_yaw, 2)                          \
+    R(3, t_base, 3) R(3, t_small, 4)                                                      \
     BARRIER                                                                               \
     R(0, t_fk_rot_a, FK_TASKS_A) R(3, t_fk_rot_b, FK_TASKS_B)                             \
     R(1, t_hdyn, HDYN_TASKS)                                                              \
