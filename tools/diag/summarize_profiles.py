@@ -16,9 +16,18 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 
+def newest(pattern):
+    """gpurun merges every run into gpurun_out/: keep only the files of the latest run of each pass."""
+    files = glob.glob(pattern)
+    if not files:
+        return []
+    t = max(os.path.getmtime(f) for f in files)
+    return [f for f in files if os.path.getmtime(f) >= t - 1.0]
+
+
 def counter_means(d, kernel_substr):
     out = {}
-    for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+    for f in newest(os.path.join(d, "*", "*counter_collection.csv")):
         acc = {}
         for r in csv.DictReader(open(f)):
             if kernel_substr in r["Kernel_Name"]:
@@ -43,7 +52,7 @@ summary = {"calibration_8B_per_lane": calib, "workloads": {}}
 traffic = {}
 for B in (1, 64, 1024):
     w = {}
-    for f in glob.glob(os.path.join(src, "trace_B%d" % B, "*", "*kernel_stats.csv")):
+    for f in newest(os.path.join(src, "trace_B%d" % B, "*", "*kernel_stats.csv")):
         shutil.copy(f, os.path.join(dst, "%s_kernel_stats_N100_B%d.csv" % (tag, B)))
         for r in csv.DictReader(open(f)):
             if "knot_kernel" in r["Name"]:
