@@ -211,6 +211,9 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
 // One workgroup per trajectory.  Thread (group g = tid / 16, column c = tid % 16) sums column c (12 cost terms + the flag) of the
 // knots g, g + 16, ...: all its loads are independent and issued together (ONE memory round trip), then a fixed tree: two
 // lane-shuffles inside the wave, four waves through LDS, twelve terms in order.  Bitwise reproducible (the tree depends on nk only).
+// (Measured alternative: the last knot workgroup to arrive reduces inside the knot kernel — agent-scope stores of the 13-double
+//  record, vmcnt(0), ticket atomic, sc1 loads by the last arriver.  Correct and reproducible, but every workgroup then ends
+//  with two dependent memory round trips: 15.2 us vs 14.3 us per 100-knot step, 48 M vs 61 M knots/s at batch 64.)
 constexpr int RWG = 256, RCOL = 16, RGRP = RWG / RCOL, RUNR = 8;
 static_assert(NCT + 1 <= RCOL, "reduce columns");
 __global__ __launch_bounds__(RWG) void hipnlp_reduce_kernel(const double* cost_knot, const int32_t* flags, int nk,

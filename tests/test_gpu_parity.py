@@ -215,8 +215,8 @@ def test_planner_solve_plumbing(model):
 
 
 def test_in_launch_reduction_stress(model, HipNlp):
-    """The cost reduction happens inside the knot kernel (last workgroup of a trajectory, sc1 hand-off + ticket).
-    Many back-to-back launches at a batch that fills the chip several times must give bitwise identical f / per-term costs."""
+    """Cost reduction (per-knot partials -> f, per-term costs) over many back-to-back launches at a batch that fills the chip
+    several times, alternating between two iterates: bitwise identical results every time (no stale partials, fixed tree)."""
     st = periodic_step_settings(40, model)
     batch = 96
     x, p = make_workload(st, model, batch=batch, seed=17)
@@ -225,9 +225,13 @@ def test_in_launch_reduction_stress(model, HipNlp):
     f0, *_ = eng.eval(x, want=("f",))
     _, t0 = eng.cost_terms()
     assert np.all(np.isfinite(f0)) and np.allclose(t0.sum(axis=1), f0, rtol=1e-13)
-    for _ in range(150):
-        f, *_ = eng.eval(x, want=("f",))
-        assert np.array_equal(f, f0)
+    x2 = x + 1e-3 * np.random.RandomState(3).standard_normal(x.shape)   # alternate iterates: a stale record would show
+    f2, *_ = eng.eval(x2, want=("f",))
+    assert not np.array_equal(f2, f0)
+    for i in range(150):
+        f, *_ = eng.eval(x if i % 2 == 0 else x2, want=("f",))
+        assert np.array_equal(f, f0 if i % 2 == 0 else f2)
+    eng.eval(x, want=("f",))
     _, t1 = eng.cost_terms()
     assert np.array_equal(t0, t1)
     from oracle_lib import Oracle
