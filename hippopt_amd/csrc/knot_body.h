@@ -704,11 +704,14 @@ template <class Em> HD void t_fk_rot_b(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t +
 // U_a = (o_a x a_a) sdot_a.  t_link_u (lane j) forms U_j, t_links (same wave, behind it) sums the ancestors' (padding: U_NJ = 0)
 template <class Em> HD void t_link_u(Ctx<Em>& cx, int j) {
     KnotScratch& s = cx.s;
+    HIPNLP_WAVE_SYNC();   // o_j, a_j: components written by three lanes of this wave (t_fk_rot_a / _b)
     double u[3];
     cross3(s.ow[j + 1], s.aw[j], u);
     const double sd = s.x[SD_ + j];
     for (int r = 0; r < 3; ++r) s.Uj[j][r] = u[r] * sd;
 }
+template <class Em> HD void t_link_u_a(Ctx<Em>& cx, int j) { t_link_u(cx, j); }              // behind t_fk_rot_a on its wave
+template <class Em> HD void t_link_u_b(Ctx<Em>& cx, int j) { t_link_u(cx, j + FK_SPLIT); }   // behind t_fk_rot_b on its wave
 HD void link_origin_velocity(const KnotScratch& s, const KinTables& kt, int i, double* v) {
     v[0] = v[1] = v[2] = 0.0;
     if (i == 0) return;
@@ -719,6 +722,10 @@ HD void link_origin_velocity(const KnotScratch& s, const KinTables& kt, int i, d
     }
 }
 
+// (the branches of t_hdyn diverge inside a wave: entries and rows + com entries are task groups of their own)
+template <class Em> HD void t_hdyn(Ctx<Em>& cx, int t);
+template <class Em> HD void t_hdyn_entries(Ctx<Em>& cx, int t) { t_hdyn(cx, t); }
+template <class Em> HD void t_hdyn_rows(Ctx<Em>& cx, int t) { t_hdyn(cx, t + 48); }
 // --- centroidal momentum dynamics (T7 on E1): lanes (c, e) 48 entry tasks + lanes 48..59 row tasks -----------
 constexpr int HDYN_TASKS = 60;
 template <class Em> HD void t_hdyn(Ctx<Em>& cx, int t) {
@@ -844,7 +851,6 @@ template <class Em> HD void t_ends(Ctx<Em>& cx, int t) {
 template <class Em> HD void t_links(Ctx<Em>& cx, int i) {
     KnotScratch& s = cx.s;
     const double m = cx.kt.mass[i];
-    HIPNLP_WAVE_SYNC();   // U_j of the same wave (t_link_u)
     double vo[3];
     link_origin_velocity(s, cx.kt, i, vo);
     for (int r = 0; r < 3; ++r) s.vo[i][r] = vo[r];
@@ -1155,11 +1161,12 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
     R(2, t_joints, NJ) R(2, t_joint_cost, 1) R(2, t_feet_yaw, 2)                          \
     R(3, t_base, 3) R(3, t_small, 4)                                                      \
     BARRIER                                                                               \
-    R(0, t_fk_rot_a, FK_TASKS_A) R(3, t_fk_rot_b, FK_TASKS_B)                             \
-    R(1, t_hdyn, HDYN_TASKS)                                                              \
+    R(0, t_fk_rot_a, FK_TASKS_A) R(0, t_link_u_a, FK_SPLIT)                               \
+    R(3, t_fk_rot_b, FK_TASKS_B) R(3, t_link_u_b, NJ - FK_SPLIT)                          \
+    R(1, t_hdyn_entries, 48) R(1, t_hdyn_rows, HDYN_TASKS - 48)                           \
     R(2, t_foot_costs, FOOT_TASKS) R(2, t_foot_cost_sum, 2)                               \
     BARRIER                                                                               \
-    R(0, t_link_u, NJ) R(0, t_links, NL) R(1, t_frames, 3)                                \
+    R(0, t_links, NL) R(1, t_frames, 3)                                                   \
     BARRIER                                                                               \
     R(0, t_composite_w0, COMP_TASKS_W0) R(1, t_composite_w1, COMP_TASKS_W1)               \
     R(2, t_composite_w2, COMP_TASKS_W2) R(3, t_composite_w3, COMP_TASKS_W3) R(3, t_pkin, NC) \

@@ -160,9 +160,10 @@ HD double pose_cost_term(const KnotScratch& s, int t) {
     R(2, t_pose_joints, NJ) R(2, t_joint_cost, 1)                                         \
     R(3, t_base, 3) R(3, t_pose_com, 4) R(3, t_unitq, 1)                                  \
     BARRIER                                                                               \
-    R(0, t_fk_rot_a, FK_TASKS_A) R(3, t_fk_rot_b, FK_TASKS_B)                             \
+    R(0, t_fk_rot_a, FK_TASKS_A) R(0, t_link_u_a, FK_SPLIT)                               \
+    R(3, t_fk_rot_b, FK_TASKS_B) R(3, t_link_u_b, NJ - FK_SPLIT)                          \
     BARRIER                                                                               \
-    R(0, t_link_u, NJ) R(0, t_links, NL) R(1, t_frames, 3)                                \
+    R(0, t_links, NL) R(1, t_frames, 3)                                                   \
     BARRIER                                                                               \
     R(0, t_composite_w0, COMP_TASKS_W0) R(1, t_composite_w1, COMP_TASKS_W1)               \
     R(2, t_composite_w2, COMP_TASKS_W2) R(3, t_composite_w3, COMP_TASKS_W3) R(3, t_pkin, NC) \
