@@ -17,14 +17,16 @@ import numpy as np
 
 from . import _abi
 from .base import OptimizationObject, extend_structure_to_horizon
+from .base.opti_callback import CallbackCriterion, IterateInfo, SaveBestUnsolvedVariablesCallback
 from .base.optimization_object import STORAGE_TYPE
 
 
 class HipFailure(Exception):
     """Counterpart of OptiFailure (opti_solver.py:28-37)."""
 
-    def __init__(self, message):
-        super().__init__("The NLP solver failed to solve the problem. Message: " + str(message))
+    def __init__(self, message, callback_used=False):
+        info = " and the callback did not manage to save an intermediate solution" if callback_used else ""
+        super().__init__(f"The NLP solver failed to solve the problem{info}. Message: {message}")
 
 
 class InitialGuessFailure(Exception):
@@ -60,7 +62,17 @@ class _PoseEngine:
 
 
 class HipNlpSolver:
-    def __init__(self, settings, model, device=0, inner_solver="auto", options_solver=None, problem="kinodynamic"):
+    def __init__(self, settings, model, device=0, inner_solver="auto", options_solver=None, problem="kinodynamic",
+                 callback_criterion: CallbackCriterion = None, callback_save_costs=True, callback_save_constraint_multipliers=True,
+                 error_on_fail=True):
+        """callback_* as in OptiSolver (opti_solver.py:105-131).  error_on_fail: CasADi's Opti raises when IPOPT does not report
+        success (e.g. Maximum_Iterations_Exceeded), which is what triggers the best-iterate fallback of opti_solver.py:479-520;
+        False keeps the last iterate of an unconverged run instead (useful for smoke runs with a few iterations)."""
+        self._callback_criterion = callback_criterion
+        self._callback_save_costs = callback_save_costs
+        self._callback_save_constraint_multipliers = callback_save_constraint_multipliers
+        self._callback = None
+        self._error_on_fail = error_on_fail
         if problem not in ("kinodynamic", "pose"):
             raise ValueError("problem must be 'kinodynamic' or 'pose'")
         self._problem_kind = problem
@@ -201,10 +213,6 @@ class HipNlpSolver:
         lbx, ubx, lbg, ubg = eng.bounds()
         ir, jc = eng.sparsity()
 
-        def quartet(x, want):
-            out = eng.eval(x[None, :], new_x=True, want=want)
-            return out
-
         solver = self._inner_solver
         if solver == "auto":
             try:
@@ -212,25 +220,60 @@ class HipNlpSolver:
                 solver = "ipopt"
             except ImportError:
                 solver = "trust-constr"
+        use_callback = self._callback_criterion is not None
+        self._callback = None
+        if use_callback:   # opti_solver.py:451-477
+            self._callback = SaveBestUnsolvedVariablesCallback(self._callback_criterion, self._callback_save_costs,
+                                                               self._callback_save_constraint_multipliers)
+
+        def cost_values_at(xk):
+            eng.eval(xk[None, :], want=("f",))
+            names, terms = eng.cost_terms()
+            return {n: float(v) for n, v in zip(names, terms[0])}
+        self._cost_values_at = cost_values_at
+        failure = None
         try:
             if solver == "ipopt":
                 x, lam, info = self._solve_ipopt(eng, x0, lbx, ubx, lbg, ubg, ir, jc)
             else:
                 x, lam, info = self._solve_scipy(eng, x0, lbg, ubg, ir, jc)
+            if self._error_on_fail and not info.get("success", True):
+                failure = RuntimeError("solver status: " + str(info.get("message", info.get("status"))))
         except Exception as err:  # noqa: BLE001
-            raise HipFailure(err)
+            failure, info = err, {"success": False, "message": str(err)}
+        self._last_info = info
+        if failure is not None:   # opti_solver.py:479-520: fall back to the best iterate the callback saved, else raise
+            cb = self._callback
+            if not use_callback or cb.best_iteration is None:
+                raise HipFailure(failure, callback_used=use_callback)
+            self._logger.warning("The solver failed to solve the problem, but the callback managed to save an intermediate "
+                                 f"solution at iteration {cb.best_iteration}.")
+            x = cb.best_x
+            lam = cb.best_constraint_multipliers if cb.best_constraint_multipliers is not None else np.zeros(eng.m)
+            self._cost_value = float(cb.best_cost)
+            self._cost_values = dict(cb.best_cost_values) if self._callback_save_costs else {}
+            self._store_solution(eng, x, lam, with_multipliers=self._callback_save_constraint_multipliers)
+            return
         f, grad, g, jac = eng.eval(x[None, :])
         self._cost_value = float(f[0])
         names, terms = eng.cost_terms()
         self._cost_values = {n: float(v) for n, v in zip(names, terms[0])}
+        self._store_solution(eng, x, lam)
+
+    def _store_solution(self, eng, x, lam, with_multipliers=True):
         self._multipliers = {}
-        for name, first, rows, k0, nk in eng.row_blocks():
-            self._multipliers[name] = np.asarray(lam[first:first + rows * nk]).reshape(nk, rows)
+        if with_multipliers:
+            for name, first, rows, k0, nk in eng.row_blocks():
+                self._multipliers[name] = np.asarray(lam[first:first + rows * nk]).reshape(nk, rows)
         values = copy.deepcopy(self._guess)
         update = {name: x[off:off + size].reshape(shape) for name, (off, size, shape) in self._var_index.items()}
         values.from_dict(update)
         self._values = values
-        self._last_info = info
+
+    def _iterate_callback(self, iteration, x, cost, inf_pr, multipliers):
+        if self._callback is not None:
+            self._callback(IterateInfo(int(iteration), float(cost), float(inf_pr)), x, multipliers,
+                           (lambda: self._cost_values_at(np.asarray(x, float))) if self._callback_save_costs else None)
 
     def _solve_scipy(self, eng, x0, lbg, ubg, ir, jc):
         from scipy.optimize import BFGS, NonlinearConstraint, minimize
@@ -255,9 +298,13 @@ class HipNlpSolver:
         nlc = NonlinearConstraint(cons, lbg, ubg, jac=jac, hess=BFGS())
         opts = {"maxiter": int(self._options.get("max_iter", 50)), "verbose": int(self._options.get("verbose", 0)),
                 "gtol": float(self._options.get("tol", 1e-6))}
-        res = minimize(fun, x0, jac=grad, hess=BFGS(), constraints=[nlc], method="trust-constr", options=opts)
+        def on_iterate(xk, state):
+            self._iterate_callback(state.nit, xk, state.fun, state.constr_violation, state.v[0] if len(state.v) else None)
+            return False
+        res = minimize(fun, x0, jac=grad, hess=BFGS(), constraints=[nlc], method="trust-constr", options=opts, callback=on_iterate)
         lam = res.v[0] if len(res.v) else np.zeros(m)
-        return res.x, lam, {"status": res.status, "message": res.message, "iterations": res.nit, "constr_violation": res.constr_violation}
+        return res.x, lam, {"status": res.status, "success": res.status in (1, 2), "message": res.message, "iterations": res.nit,
+                            "constr_violation": res.constr_violation}
 
     def _solve_ipopt(self, eng, x0, lbx, ubx, lbg, ubg, ir, jc):
         import cyipopt
@@ -277,12 +324,28 @@ class HipNlpSolver:
                 return ir, jc
 
             def jacobian(self, x):
+                self.x_last = np.array(x, copy=True)
                 return eng.eval(x[None, :], want=("jac",))[3][0]
+
+            def intermediate(self, alg_mod, iter_count, obj_value, inf_pr, inf_du, mu, d_norm, regularization_size, alpha_du, alpha_pr,
+                             ls_trials):
+                x_it = getattr(self, "x_last", x0)   # cyipopt < 1.3 has no get_current_iterate: the last point the Jacobian saw
+                lam_it = None
+                try:
+                    it = nlp.get_current_iterate()
+                    x_it, lam_it = it["x"], it["mult_g"]
+                except Exception:  # noqa: BLE001
+                    pass
+                outer._iterate_callback(iter_count, x_it, obj_value, inf_pr, lam_it)
+                return True
         nlp = cyipopt.Problem(n=eng.n, m=eng.m, problem_obj=Callbacks(), lb=lbx, ub=ubx, cl=lbg, cu=ubg)
         nlp.add_option("hessian_approximation", "limited-memory")  # main_periodic_step.py:116
         for k, v in outer._options.items():
             nlp.add_option(k, v)
         x, info = nlp.solve(x0)
+        info = dict(info)
+        info["success"] = info.get("status", -1) in (0, 1)   # Solve_Succeeded / Solved_To_Acceptable_Level
+        info["message"] = info.get("status_msg", "")
         return x, info["mult_g"], info
 
     def get_values(self):

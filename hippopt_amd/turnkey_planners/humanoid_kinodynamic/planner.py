@@ -4,21 +4,28 @@ get_variables_structure), with the engine-backed solver plugin in place of OptiS
 import copy
 
 from ...base import Output, extend_structure_to_horizon  # noqa: F401
+from ...base.opti_callback import AcceptablePrimalInfeasibility, BestCost
 from ...hipnlp_solver import HipNlpSolver
 from .settings import Settings
 from .variables import Variables
 
 
 class Planner:
-    def __init__(self, settings: Settings, model, device: int = 0, inner_solver: str = "auto") -> None:
+    def __init__(self, settings: Settings, model, device: int = 0, inner_solver: str = "auto", error_on_fail: bool = True) -> None:
         if not settings.is_valid():
             raise ValueError("Settings are not valid")
         self.settings = copy.deepcopy(settings)
         self.kin_dyn_object = model                       # the adam KinDynComputations counterpart (planner.py:43-50)
         self.numeric_mass = model.get_total_mass()
         variables = Variables(settings=self.settings, kin_dyn_object=model)
+        opti_callback = None
+        if self.settings.use_opti_callback:   # planner.py:56-63
+            opti_callback = BestCost() & AcceptablePrimalInfeasibility(self.settings.acceptable_constraint_violation)
         self.optimization_solver = HipNlpSolver(self.settings, model, device=device, inner_solver=inner_solver,
-                                                options_solver=self.settings.solver_options)
+                                                options_solver=self.settings.solver_options, callback_criterion=opti_callback,
+                                                callback_save_costs=self.settings.opti_callback_save_costs,
+                                                callback_save_constraint_multipliers=self.settings.opti_callback_save_constraint_multipliers,
+                                                error_on_fail=error_on_fail)
         self.optimization_solver.generate_optimization_objects(variables, horizon=self.settings.horizon_length)
         self.variables = self.optimization_solver.get_optimization_structure()
 

@@ -12,8 +12,10 @@ class Settings(KinodynSettings):
     root_link: str = "root_link"
     contact_points: hp_rp.FeetContactPointDescriptors = None
     desired_frame_quaternion_cost_frame_name: str = "chest"
-    use_opti_callback: bool = False
+    use_opti_callback: bool = False                       # settings.py:75, :135-145
     acceptable_constraint_violation: float = 1e-3
+    opti_callback_save_costs: bool = True
+    opti_callback_save_constraint_multipliers: bool = True
     solver_options: dict = dataclasses.field(default_factory=dict)
 
     def __post_init__(self):

@@ -86,7 +86,7 @@ class Variables(OptimizationObject):
 
 
 class Planner:
-    def __init__(self, settings: Settings, model, device: int = 0, inner_solver: str = "auto") -> None:
+    def __init__(self, settings: Settings, model, device: int = 0, inner_solver: str = "auto", error_on_fail: bool = True) -> None:
         if not settings.is_valid():
             raise ValueError("Settings are not valid")
         self.settings = copy.deepcopy(settings)
@@ -94,7 +94,7 @@ class Planner:
         self.numeric_mass = model.get_total_mass()
         self.variables = Variables(settings=self.settings, kin_dyn_object=model)
         self.optimization_solver = HipNlpSolver(self.settings, model, device=device, inner_solver=inner_solver,
-                                                options_solver=self.settings.solver_options, problem="pose")
+                                                options_solver=self.settings.solver_options, problem="pose", error_on_fail=error_on_fail)
         self.optimization_solver.generate_optimization_objects(self.variables)
 
     # ---- mass regularisation (planner.py:788-850): contact forces of the state and of the references / mass ----------

@@ -190,7 +190,7 @@ def test_planner_solve_plumbing(model):
     from hippopt_amd.kinodyn_settings import single_step_settings
     from hippopt_amd.turnkey_planners.humanoid_kinodynamic import Planner, Settings
     st = Settings.from_numeric(single_step_settings(3, model), solver_options={"max_iter": 15})
-    pl = Planner(st, model)
+    pl = Planner(st, model, error_on_fail=False)   # a handful of iterations: keep the last iterate of the unconverged run
     x, p = make_workload(st, model, batch=1, seed=8)
     guess = pl.get_initial_guess()
     names = pl.optimization_solver._var_index
@@ -239,3 +239,35 @@ def test_in_launch_reduction_stress(model, HipNlp):
     for b in (0, 37, 95):
         fo, _ = orc.eval_fg(x[b], p[b])
         assert abs(f0[b] - fo) / max(1.0, abs(fo)) < 1e-11
+
+
+def test_best_iterate_callback_fallback(model):
+    """use_opti_callback (planner.py:56-63, opti_solver.py:451-520): a run that stops at the iteration limit counts as a failure
+    (CasADi's Opti raises); without a criterion the solver plugin raises, with BestCost & AcceptablePrimalInfeasibility it returns
+    the best iterate the callback saved, with its cost, per-term costs and multipliers."""
+    from hippopt_amd.hipnlp_solver import HipFailure
+    from hippopt_amd.kinodyn_settings import single_step_settings
+    from hippopt_amd.turnkey_planners.humanoid_kinodynamic import Planner, Settings
+
+    def planner(**kw):
+        st = Settings.from_numeric(single_step_settings(3, model), solver_options={"max_iter": 12}, **kw)
+        pl = Planner(st, model)
+        x, p = make_workload(st, model, batch=1, seed=8)
+        guess = pl.get_initial_guess()
+        guess.from_dict({n: x[0][off:off + size].reshape(shape) for n, (off, size, shape) in pl.optimization_solver._var_index.items()})
+        guess.from_dict({n: p[0][off:off + size].reshape(shape) for n, (off, size, shape) in pl.optimization_solver._par_index.items()})
+        pl.optimization_solver.set_initial_guess(guess)
+        return pl
+    with pytest.raises(HipFailure):
+        planner().solve()
+    with pytest.raises(HipFailure):     # a criterion nothing satisfies: "the callback did not manage to save ..."
+        planner(use_opti_callback=True, acceptable_constraint_violation=0.0).solve()
+    pl = planner(use_opti_callback=True, acceptable_constraint_violation=np.inf)
+    out = pl.solve()
+    cb = pl.optimization_solver._callback
+    assert cb.best_iteration is not None and np.isclose(out.cost_value, cb.best_cost)
+    assert set(out.cost_values) == set(pl.optimization_solver.engine().cost_terms()[0])
+    assert abs(sum(out.cost_values.values()) - out.cost_value) <= 1e-9 * max(1.0, abs(out.cost_value))
+    assert out.constraint_multipliers["joint_position_dynamics"].shape == (2, 23)
+    # the values are the saved iterate (forces / momenta are multiplied back by the mass on the way out: compare the joints)
+    assert np.allclose(np.asarray(out.values.system[1].kinematics.joints.positions).reshape(-1), cb.best_x[189 + 157:189 + 180])

@@ -107,7 +107,7 @@ def test_pose_planner_solves(model):
     st = Settings(solver_options={"max_iter": 40})
     st.maximum_joint_positions = np.array(model.max_joint_positions, float)
     st.minimum_joint_positions = np.array(model.min_joint_positions, float)
-    pl = Planner(st, model)
+    pl = Planner(st, model, error_on_fail=False)
     mass = model.get_total_mass()
     x, _ = make_pose_workload(st, model, 1, 42)
     refs = References(contact_point_descriptors=st.contact_points, number_of_joints=23)

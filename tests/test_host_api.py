@@ -276,3 +276,27 @@ def test_pose_planner_packs_parameters_and_regularises_mass(model):
     zero = {"point_p": np.zeros((8, 3)), "point_f": np.zeros((8, 3)), "base_position": np.zeros(3), "base_quaternion": [0, 0, 0, 1.0],
             "joints": np.zeros(23), "com": np.zeros(3), "frame_quaternion": [0, 0, 0, 1.0]}
     assert np.allclose(p2, ps.pack_pose_parameters(Settings(), model, zero))
+
+
+# ---- iterate-callback criteria (hippopt.base.opti_callback) ------------------------------------------------------------------
+def test_callback_criteria_and_best_iterate_store():
+    from hippopt_amd.base.opti_callback import (AcceptableCost, AcceptablePrimalInfeasibility, BestCost, BestPrimalInfeasibility,
+                                                IterateInfo, SaveBestUnsolvedVariablesCallback)
+    crit = BestCost() & AcceptablePrimalInfeasibility(1e-2)        # the kinodynamic planner's criterion (planner.py:56-63)
+    cb = SaveBestUnsolvedVariablesCallback(crit)
+    seq = [(10.0, 1.0), (8.0, 5e-3), (9.0, 1e-3), (7.0, 5e-2), (6.0, 9e-3), (6.5, 1e-4)]
+    for i, (cost, inf) in enumerate(seq):
+        cb(IterateInfo(i, cost, inf), np.full(3, float(i)), np.full(2, float(i)), {"a": cost})
+    # i=0 infeasible; i=1 ok (best 8); i=2 cost not better; i=3 infeasible; i=4 ok (best 6); i=5 cost not better
+    assert cb.best_iteration == 4 and cb.best_cost == 6.0 and np.all(cb.best_x == 4.0) and cb.best_cost_values == {"a": 6.0}
+    assert np.all(cb.best_constraint_multipliers == 4.0)
+    assert crit.lhs.best_cost == 6.0 and crit.rhs.best_acceptable_primal_infeasibility == 5e-3   # updated only when BOTH hold
+    either = BestPrimalInfeasibility() | AcceptableCost(1.0)
+    cb2 = SaveBestUnsolvedVariablesCallback(either, save_costs=False, save_constraint_multipliers=False)
+    for i, (cost, inf) in enumerate(seq):
+        cb2(IterateInfo(i, cost, inf), np.full(3, float(i)), np.full(2, float(i)), {"a": cost})
+    assert cb2.best_iteration == 5 and cb2.best_cost_values == {} and cb2.best_constraint_multipliers is None
+    with pytest.raises(TypeError):
+        BestCost() & 3
+    crit.reset()
+    assert crit.lhs.best_cost == np.inf
