@@ -56,15 +56,50 @@ class ContactPointStateDerivative(OptimizationObject):
 
 @dataclasses.dataclass
 class FootContactState(list, OptimizationObject):
+    def set_from_parent_frame_transform(self, transform):   # contacts.py:103-107
+        for contact_point in self:
+            contact_point.p = transform.translation() + transform.rotation().act(contact_point.descriptor.position_in_foot_frame)
+
     @staticmethod
     def from_list(input_list):
         out = FootContactState()
         out.extend(input_list)
         return out
 
+    @staticmethod
+    def from_parent_frame_transform(descriptor, transform):   # contacts.py:116-127
+        out = FootContactState()
+        for contact_point_descriptor in descriptor:
+            out.append(ContactPointState(input_descriptor=contact_point_descriptor))
+        out.set_from_parent_frame_transform(transform)
+        return out
+
 
 @dataclasses.dataclass
 class FeetContactPointDescriptors:
+    left: list = dataclasses.field(default_factory=list)
+    right: list = dataclasses.field(default_factory=list)
+
+
+@dataclasses.dataclass
+class FootContactPhaseDescriptor:   # contacts.py:142-160
+    transform: object = None
+    mid_swing_transform: object = None
+    force: np.ndarray = None
+    activation_time: float = None
+    deactivation_time: float = None
+
+    def __post_init__(self):
+        from .transforms import SE3, SO3
+        if self.transform is None:
+            self.transform = SE3.from_translation_and_rotation(np.zeros(3), SO3.Identity())
+        if self.force is None:
+            self.force = np.zeros(3)
+            self.force[2] = 100
+
+
+@dataclasses.dataclass
+class FeetContactPhasesDescriptor:   # contacts.py:163-166
     left: list = dataclasses.field(default_factory=list)
     right: list = dataclasses.field(default_factory=list)
 

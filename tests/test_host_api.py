@@ -300,3 +300,29 @@ def test_callback_criteria_and_best_iterate_store():
         BestCost() & 3
     crit.reset()
     assert crit.lhs.best_cost == np.inf
+
+
+def test_output_and_guess_round_trip_through_mat(model, tmp_path):
+    """{"output": output.to_dict(), "guess": guess.to_dict(flatten=False)} (main_periodic_step.py:503-513) through a .mat file."""
+    from hippopt_amd.base import Output
+    from hippopt_amd.serialization import load_mat, save_mat
+    pl, st = _planner(model)
+    guess = pl.get_initial_guess()
+    guess.system[1].kinematics.joints.positions = np.linspace(-1, 1, 23)
+    guess.system[2].contact_points.left[3].f = np.array([1.0, 2.0, 3.0])
+    out = Output(values=guess, cost_value=12.5, cost_values={"com_velocity_error": 1.5, "system.contact_points.left[0].f_regularization": 2.0},
+                 constraint_multipliers={"joint_position_dynamics": np.arange(46.0).reshape(2, 23)})
+    f = str(tmp_path / "humanoid_walking_periodic.mat")
+    save_mat(f, output=out, guess=guess)
+    back = load_mat(f)
+    assert set(back) == {"output", "guess"}
+    assert float(back["output"]["cost_value"]) == 12.5
+    assert np.allclose(back["output"]["constraint_multipliers"]["joint_position_dynamics"], np.arange(46.0).reshape(2, 23))
+    assert float(back["output"]["cost_values"]["com_velocity_error"]) == 1.5
+    nested = back["output"]["cost_values"]["system"]["contact_points"]       # keys are split at '.', problem.py:58-79
+    assert float(nested["left[0]"]["f_regularization"]) == 2.0
+    sys_list = back["output"]["values"]["system"]
+    assert len(sys_list) == 3
+    assert np.allclose(np.asarray(sys_list[1]["kinematics"]["joints"]["positions"]).reshape(-1), np.linspace(-1, 1, 23))
+    assert np.allclose(np.asarray(back["guess"]["system"][2]["contact_points"]["left"][3]["f"]).reshape(-1), [1.0, 2.0, 3.0])
+    assert np.isclose(float(back["guess"]["mass"]), model.get_total_mass())
