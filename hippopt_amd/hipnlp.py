@@ -44,6 +44,12 @@ def load_library():
         raise ImportError(
             f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). The engine has no CPU fallback.")
+    try:
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64; if libhipnlp.so pulled in /opt/rocm's copy first, a
+        # later `import torch` would bind to that one and find no devices.  Loading torch first makes both share torch's.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(_LIB_PATH)
     dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
     lib.hipnlp_create.argtypes = [C.POINTER(_abi.DescC), C.POINTER(vp)]

