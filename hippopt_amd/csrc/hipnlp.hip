@@ -24,7 +24,7 @@ using namespace hipnlp;
 
 namespace {
 
-constexpr int WG = 256;  // four wavefronts per knot: role-specialised waves (knot_body.h, HIPNLP_KNOT_PROGRAM)
+// four (or eight) wavefronts per knot: role-specialised waves (knot_body.h, HIPNLP_KNOT_PROGRAM)
 static_assert(gs::COUNT == HIPNLP_G_STAGE, "HIPNLP_G_STAGE must equal the native g slot count");
 
 struct DeviceTables {
@@ -71,8 +71,13 @@ struct SharedTables {
     GParams gp;
 };
 
-// 3 waves per SIMD = 3 workgroups per CU (the LDS bound): cap the register allocation there (<= 168 VGPRs)
-template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3, 3))) void hipnlp_knot_kernel(KArgs a) {
+// WAVES = 4: 256 threads; 3 waves per SIMD = 3 workgroups per CU (the LDS bound): the register allocation is capped there
+//            (<= 168 VGPRs).  The throughput variant.
+// WAVES = 8: 512 threads, the roles of the knot program spread over twice the waves (two per SIMD).  The latency variant, used
+//            when the launch has at most one workgroup per CU anyway (knots x batch <= 256), e.g. one 100-knot trajectory.
+template <int TERRAIN, int WAVES> __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 3 : 2, WAVES == 4 ? 3 : 2)))
+void hipnlp_knot_kernel(KArgs a) {
+    constexpr int WG = 64 * WAVES;
     __shared__ KnotScratch s;
     __shared__ SharedTables tabs;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -122,16 +127,16 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     KnotInfo ki{k, N, first, last};
     DevEm<TERRAIN> em{s.g, s.jac};
     Ctx<DevEm<TERRAIN>> cx(s, tabs.kt, tabs.ks, tabs.gp, ki, em);
-#define DEV_R(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
+#define DEV_R(w4, w8, fn, nt) if (wave == (WAVES == 4 ? (w4) : (w8))) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #ifdef HIPNLP_STAMPS
     // diagnostic build: every wave stamps the END of each task group it runs and its ARRIVAL at each barrier
     // (before waiting).  Per wave 64 slots of {id, time}: id = group sequence number, or 1000 + barrier number.
     int sidx = 0, gid = 0, bid = 0;
-    unsigned long long* stamp_out = a.stamps + ((size_t(blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 128;
+    unsigned long long* stamp_out = a.stamps + ((size_t(blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 128;
     if (lane == 0) { stamp_out[0] = 999; stamp_out[1] = __builtin_amdgcn_s_memtime(); }
     sidx++;
 #undef DEV_R
-#define DEV_R(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); \
+#define DEV_R(w4, w8, fn, nt) if (wave == (WAVES == 4 ? (w4) : (w8))) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); \
         if (lane == 0 && sidx < 63) { stamp_out[2 * sidx] = gid; stamp_out[2 * sidx + 1] = __builtin_amdgcn_s_memtime(); } sidx++; } gid++;
 #define DEV_BARRIER if (lane == 0 && sidx < 63) { stamp_out[2 * sidx] = 1000 + bid; stamp_out[2 * sidx + 1] = __builtin_amdgcn_s_memtime(); } sidx++; bid++; __syncthreads();
 #else
@@ -263,6 +268,7 @@ struct hipnlp_handle {
     Layout L;
     KinTables kt;
     int batch = 1, kb = 0, ke = 0, nk = 0, np = 0;
+    bool wide = false;   // eight-wave kernel variant (launches of at most one workgroup per CU)
     int dev = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -330,6 +336,10 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     if (h->kb == 0 && h->ke == 0) h->ke = st.horizon;
     if (h->kb < 0 || h->ke > st.horizon || h->kb >= h->ke) return fail(HIPNLP_E_INVALID, "bad knot shard [knot_begin, knot_end)");
     h->nk = h->ke - h->kb;
+    {
+        const char* force = std::getenv("HIPNLP_WAVES");   // diagnostic override: 4 or 8
+        h->wide = force ? std::atoi(force) == 8 : (long(h->nk) * long(desc->batch) <= 256);
+    }
     std::string e;
     if (!Layout::make_kin_tables(desc->model, h->kt, e)) return fail(HIPNLP_E_INVALID, e);
     if (!h->L.build(st, h->kt)) return fail(HIPNLP_E_INVALID, h->L.error);
@@ -481,14 +491,19 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     hipEvent_t e0 = prof ? h->prof_ev[size_t(3 * h->prof_n)] : h->ev0;
     hipEvent_t e2 = prof ? h->prof_ev[size_t(3 * h->prof_n + 2)] : h->ev1;
 #ifdef HIPNLP_STAMPS
-    if (!h->d_stamps) HIP_TRY(h, hipMalloc(&h->d_stamps, size_t(h->nk) * size_t(h->batch) * 512 * sizeof(unsigned long long)));
+    if (!h->d_stamps) HIP_TRY(h, hipMalloc(&h->d_stamps, size_t(h->nk) * size_t(h->batch) * 1024 * sizeof(unsigned long long)));
     a.stamps = h->d_stamps;
 #endif
     if (timed) HIP_TRY(h, hipEventRecord(e0, s));
-    if (h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR)
-        hipLaunchKernelGGL(hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR>, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(WG), 0, s, a);
-    else
-        hipLaunchKernelGGL(hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS>, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(WG), 0, s, a);
+    const dim3 grid(unsigned(h->nk), unsigned(h->batch));
+    const bool planar = h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR;
+    if (h->wide) {   // at most one workgroup per CU: eight waves per knot
+        if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8>), grid, dim3(512), 0, s, a);
+    } else {
+        if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 4>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 4>), grid, dim3(256), 0, s, a);
+    }
     if (prof) HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 1)], s));
     hipLaunchKernelGGL(hipnlp_reduce_kernel, dim3(unsigned(h->batch)), dim3(RWG), 0, s,
                        (const double*)h->d_cost_knot, (const int32_t*)h->d_flags, h->nk, f_dev, h->d_cost_terms, h->d_flag);
@@ -634,7 +649,7 @@ int hipnlp_debug_stamps(hipnlp_handle* h, unsigned long long* out /*[nk*batch][4
     HIP_TRY(h, hipSetDevice(h->dev));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipMemcpy(out, h->d_stamps, size_t(h->nk) * size_t(h->batch) * 512 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(out, h->d_stamps, size_t(h->nk) * size_t(h->batch) * 1024 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return HIPNLP_OK;
 }
 #endif

@@ -909,10 +909,9 @@ template <class Em> HD void t_frames(Ctx<Em>& cx, int f) {
 // composite (subtree) quantities as DESCENDANT SUMS: lane (link slot, component r).  The links are visited in the order of
 // decreasing subtree size (kt.comp_order) and a wave iteration runs as many steps as the largest subtree among its four links
 // (kt.comp_cnt), so it costs: 24 + 6 + 4 + 3 + 2 + 1 steps on the ergoCub tree instead of 6 x 24.
-// Wave 0 takes the four largest subtrees, waves 1 and 2 the next eight each, wave 3 the four smallest (an iteration has a fixed
-// cost of several hundred cycles of index chasing on top of its steps).
-constexpr int COMP_TASKS_W0 = 4 * 16, COMP_TASKS_W1 = 8 * 16, COMP_TASKS_W2 = 8 * 16, COMP_TASKS_W3 = 4 * 16;
-static_assert(COMP_TASKS_W0 + COMP_TASKS_W1 + COMP_TASKS_W2 + COMP_TASKS_W3 == NL * 16, "composite task split");
+// An iteration has a fixed cost of several hundred cycles of index chasing on top of its steps: six iteration groups, spread
+// 1-2-2-1 over four waves or one per wave over eight.
+static_assert(NL * 16 == 6 * 64, "six wave iterations of composite tasks");
 template <class Em> HD void t_composite(Ctx<Em>& cx, int t) {
     KnotScratch& s = cx.s;
     const int i = cx.kt.comp_order[t >> 4], r = t & 15;
@@ -926,10 +925,12 @@ template <class Em> HD void t_composite(Ctx<Em>& cx, int t) {
     for (int n = 0; n < cnt; ++n) acc += s.own[cx.kt.desc[i][n]][r];
     s.comp[i][r] = acc;
 }
-template <class Em> HD void t_composite_w0(Ctx<Em>& cx, int t) { t_composite(cx, t); }
-template <class Em> HD void t_composite_w1(Ctx<Em>& cx, int t) { t_composite(cx, t + COMP_TASKS_W0); }
-template <class Em> HD void t_composite_w2(Ctx<Em>& cx, int t) { t_composite(cx, t + COMP_TASKS_W0 + COMP_TASKS_W1); }
-template <class Em> HD void t_composite_w3(Ctx<Em>& cx, int t) { t_composite(cx, t + COMP_TASKS_W0 + COMP_TASKS_W1 + COMP_TASKS_W2); }
+template <class Em> HD void t_composite_g0(Ctx<Em>& cx, int t) { t_composite(cx, t); }          // the four largest subtrees
+template <class Em> HD void t_composite_g1(Ctx<Em>& cx, int t) { t_composite(cx, t + 64); }
+template <class Em> HD void t_composite_g2(Ctx<Em>& cx, int t) { t_composite(cx, t + 128); }
+template <class Em> HD void t_composite_g3(Ctx<Em>& cx, int t) { t_composite(cx, t + 192); }
+template <class Em> HD void t_composite_g4(Ctx<Em>& cx, int t) { t_composite(cx, t + 256); }
+template <class Em> HD void t_composite_g5(Ctx<Em>& cx, int t) { t_composite(cx, t + 320); }   // the four smallest
 template <class Em> HD void t_pkin(Ctx<Em>& cx, int c) {
     KnotScratch& s = cx.s;
     const int f = c < 4 ? 0 : 1;
@@ -1152,29 +1153,31 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// The knot program.  R(w, fn, n): run tasks 0..n-1 of fn on the lanes of wave w (host: plain loop).
-// Groups of one phase run concurrently on different waves; BARRIER separates phases.
+// The knot program.  R(w4, w8, fn, n): run tasks 0..n-1 of fn on the lanes of wave w4 of a four-wave workgroup, or of wave w8
+// of an eight-wave workgroup (the kernel variant for launches that leave most CUs idle: one workgroup per CU anyway, so the
+// phases are spread over twice the waves); host: plain loop.  Groups of one phase run concurrently on different waves;
+// BARRIER separates phases.  Groups that rely on running BEHIND another group of their wave (HIPNLP_WAVE_SYNC) share both ids.
 // ---------------------------------------------------------------------------------------------------
 #define HIPNLP_KNOT_PROGRAM(R, BARRIER)                                                   \
-    R(0, t_points_vec, 3 * NC) R(0, t_unitq, 1)                                           \
-    R(1, t_points_scalar, NC) R(1, t_points_cost, 3) R(1, t_dyn, 7 + NJ + 3) R(1, t_feet_centroid, 1) \
-    R(2, t_joints, NJ) R(2, t_joint_cost, 1) R(2, t_feet_yaw, 2)                          \
-    R(3, t_base, 3) R(3, t_small, 4)                                                      \
+    R(0, 0, t_points_vec, 3 * NC) R(0, 1, t_unitq, 1)                                     \
+    R(1, 2, t_points_scalar, NC) R(1, 2, t_points_cost, 3) R(1, 3, t_dyn, 7 + NJ + 3) R(1, 1, t_feet_centroid, 1) \
+    R(2, 4, t_joints, NJ) R(2, 4, t_joint_cost, 1) R(2, 1, t_feet_yaw, 2)                 \
+    R(3, 5, t_base, 3) R(3, 6, t_small, 4)                                                \
     BARRIER                                                                               \
-    R(0, t_fk_rot_a, FK_TASKS_A) R(0, t_link_u_a, FK_SPLIT)                               \
-    R(3, t_fk_rot_b, FK_TASKS_B) R(3, t_link_u_b, NJ - FK_SPLIT)                          \
-    R(1, t_hdyn_entries, 48) R(1, t_hdyn_rows, HDYN_TASKS - 48)                           \
-    R(2, t_foot_costs, FOOT_TASKS) R(2, t_foot_cost_sum, 2)                               \
+    R(0, 0, t_fk_rot_a, FK_TASKS_A) R(0, 0, t_link_u_a, FK_SPLIT)                         \
+    R(3, 1, t_fk_rot_b, FK_TASKS_B) R(3, 1, t_link_u_b, NJ - FK_SPLIT)                    \
+    R(1, 2, t_hdyn_entries, 48) R(1, 3, t_hdyn_rows, HDYN_TASKS - 48)                     \
+    R(2, 4, t_foot_costs, FOOT_TASKS) R(2, 4, t_foot_cost_sum, 2)                         \
     BARRIER                                                                               \
-    R(0, t_links, NL) R(1, t_frames, 3)                                                   \
+    R(0, 0, t_links, NL) R(1, 1, t_frames, 3)                                             \
     BARRIER                                                                               \
-    R(0, t_composite_w0, COMP_TASKS_W0) R(1, t_composite_w1, COMP_TASKS_W1)               \
-    R(2, t_composite_w2, COMP_TASKS_W2) R(3, t_composite_w3, COMP_TASKS_W3) R(3, t_pkin, NC) \
+    R(0, 0, t_composite_g0, 64) R(1, 1, t_composite_g1, 64) R(1, 2, t_composite_g2, 64)   \
+    R(2, 3, t_composite_g3, 64) R(2, 4, t_composite_g4, 64) R(3, 5, t_composite_g5, 64) R(3, 6, t_pkin, NC) \
     BARRIER                                                                               \
-    R(0, t_columns, NJ + 3) R(1, t_cmm_columns, NJ + 3) R(2, t_frame_columns, NJ) R(3, t_ends, ENDS_TASKS) \
+    R(0, 0, t_columns, NJ + 3) R(1, 1, t_cmm_columns, NJ + 3) R(2, 2, t_frame_columns, NJ) R(3, 3, t_ends, ENDS_TASKS) \
     BARRIER                                                                               \
-    R(0, t_kinc, 3 * NC) R(1, t_comc, 15) R(2, t_cmmc, 15) R(2, t_kinc_s, NC * LEG_PATH)  \
-    R(3, t_feetd, 5) R(3, t_ends_finish, ENDS_FINISH_TASKS)                               \
+    R(0, 0, t_kinc, 3 * NC) R(1, 1, t_comc, 15) R(2, 2, t_cmmc, 15) R(2, 3, t_kinc_s, NC * LEG_PATH) \
+    R(3, 4, t_feetd, 5) R(3, 4, t_ends_finish, ENDS_FINISH_TASKS)                         \
     BARRIER
 
 }  // namespace hipnlp

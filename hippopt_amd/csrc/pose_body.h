@@ -154,23 +154,23 @@ HD double pose_cost_term(const KnotScratch& s, int t) {
     }
 }
 
-// The pose program: same notation as HIPNLP_KNOT_PROGRAM.
+// The pose program: same notation as HIPNLP_KNOT_PROGRAM (always four waves: both role ids are the same).
 #define HIPNLP_POSE_PROGRAM(R, BARRIER)                                                   \
-    R(0, t_pose_points, NC) R(1, t_pose_balance, POSE_BALANCE_TASKS)                      \
-    R(2, t_pose_joints, NJ) R(2, t_joint_cost, 1)                                         \
-    R(3, t_base, 3) R(3, t_pose_com, 4) R(3, t_unitq, 1)                                  \
+    R(0, 0, t_pose_points, NC) R(1, 1, t_pose_balance, POSE_BALANCE_TASKS)                \
+    R(2, 2, t_pose_joints, NJ) R(2, 2, t_joint_cost, 1)                                   \
+    R(3, 3, t_base, 3) R(3, 3, t_pose_com, 4) R(3, 3, t_unitq, 1)                         \
     BARRIER                                                                               \
-    R(0, t_fk_rot_a, FK_TASKS_A) R(0, t_link_u_a, FK_SPLIT)                               \
-    R(3, t_fk_rot_b, FK_TASKS_B) R(3, t_link_u_b, NJ - FK_SPLIT)                          \
+    R(0, 0, t_fk_rot_a, FK_TASKS_A) R(0, 0, t_link_u_a, FK_SPLIT)                         \
+    R(3, 3, t_fk_rot_b, FK_TASKS_B) R(3, 3, t_link_u_b, NJ - FK_SPLIT)                    \
     BARRIER                                                                               \
-    R(0, t_links, NL) R(1, t_frames, 3)                                                   \
+    R(0, 0, t_links, NL) R(1, 1, t_frames, 3)                                             \
     BARRIER                                                                               \
-    R(0, t_composite_w0, COMP_TASKS_W0) R(1, t_composite_w1, COMP_TASKS_W1)               \
-    R(2, t_composite_w2, COMP_TASKS_W2) R(3, t_composite_w3, COMP_TASKS_W3) R(3, t_pkin, NC) \
+    R(0, 0, t_composite_g0, 64) R(1, 1, t_composite_g1, 64) R(1, 1, t_composite_g2, 64)   \
+    R(2, 2, t_composite_g3, 64) R(2, 2, t_composite_g4, 64) R(3, 3, t_composite_g5, 64) R(3, 3, t_pkin, NC) \
     BARRIER                                                                               \
-    R(0, t_columns, NJ + 3) R(2, t_frame_columns, NJ)                                     \
+    R(0, 0, t_columns, NJ + 3) R(2, 2, t_frame_columns, NJ)                               \
     BARRIER                                                                               \
-    R(0, t_kinc, 3 * NC) R(1, t_comc, 15) R(2, t_kinc_s, NC * LEG_PATH) R(3, t_feetd, 4)   \
+    R(0, 0, t_kinc, 3 * NC) R(1, 1, t_comc, 15) R(2, 2, t_kinc_s, NC * LEG_PATH) R(3, 3, t_feetd, 4) \
     BARRIER
 
 }  // namespace hipnlp

@@ -91,7 +91,7 @@ struct PoseLayout {
             KnotInfo ki{1, 3, 0, 0};
             RecordEm em{grow.data(), jrid.data(), jc.data(), &dup};
             Ctx<RecordEm> cx(*s, kt, ks, gp, ki, em);
-#define HOST_R(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
+#define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
             HIPNLP_POSE_PROGRAM(HOST_R, )
 #undef HOST_R
             delete s;

@@ -81,7 +81,7 @@ void hostemu_eval(const hostemu_handle* h, const double* x, const double* p, dou
         KnotInfo ki{k, N, k == 0, k == N - 1};
         ValueEm em{s->g, s->jac};
         Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
-#define HOST_R(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
+#define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
         HIPNLP_KNOT_PROGRAM(HOST_R, )
 #undef HOST_R
         // copy-out exactly as the kernel does
@@ -148,7 +148,7 @@ void hostemu_pose_eval(const hostemu_pose_handle* h, const double* x, const doub
     KnotInfo ki{1, 3, 0, 0};
     ValueEm em{s->g, s->jac};
     Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
-#define HOST_R(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
+#define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
     HIPNLP_POSE_PROGRAM(HOST_R, )
 #undef HOST_R
     for (int e = 0; e < L.nnz; ++e) jac[e] = s->jac[L.jperm[size_t(e)]];

@@ -43,20 +43,21 @@ if __name__ == "__main__":
     import re
     prog = open(os.path.join(ROOT, "hippopt_amd", "csrc", "knot_body.h")).read()
     prog = prog[prog.index("#define HIPNLP_KNOT_PROGRAM"):]
-    groups = re.findall(r"R\((\d), (\w+),", prog)
-    out = np.zeros((100 * batch, 4, 64, 2), np.uint64)
+    groups = re.findall(r"R\((\d), (\d), (\w+),", prog)
+    out = np.zeros((100 * batch, 8, 64, 2), np.uint64)
     eng.lib.hipnlp_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
     eng.lib.hipnlp_debug_stamps(eng.h, out.ctypes.data_as(C.c_void_p))
     blk = out[len(out) // 2]  # an interior knot
-    t0 = min(int(blk[w, 0, 1]) for w in range(4))
+    waves = [w for w in range(8) if int(blk[w, 0, 0]) == 999]
+    t0 = min(int(blk[w, 0, 1]) for w in waves)
     print("interior knot: per wave, end time of each group / arrival at each barrier (cycles since block start) and duration")
-    for w in range(4):
+    for w in waves:
         n = int(out[len(out) // 2, w, 63, 0])
         prev = int(blk[w, 0, 1]) - t0
         line = []
         for i in range(1, n):
             gid, tm = int(blk[w, i, 0]), int(blk[w, i, 1]) - t0
-            name = groups[gid][1] if gid < 1000 else ("|B%d" % (gid - 1000) if gid < 2000 else "END")
+            name = groups[gid][2] if gid < 1000 else ("|B%d" % (gid - 1000) if gid < 2000 else "END")
             line.append("%s %d(+%d)" % (name, tm, tm - prev))
             prev = tm
         print("wave %d: " % w + "  ".join(line))
