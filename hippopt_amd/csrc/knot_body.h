@@ -275,7 +275,7 @@ template <class Em> HD void t_points_vec(Ctx<Em>& cx, int t) {
     // gradient of the point-local costs (k >= 1): swing height (E10), ||u_v||^2, ||f_dot||^2
     const double on = cx.ki.first ? 0.0 : 1.0;
     double* gr = s.grad + cb;
-    if (planar) {  // (smooth terrain: t_points_terrain writes these two)
+    if (planar) {  // (smooth terrain: t_terrain_hnf writes these two)
         gr[V_ + i] = i < 2 ? on * cx.st.m_swing * x[V_ + i] : 0.0;
         gr[P_ + i] = i == 2 ? on * cx.st.m_swing * (pz - s.pk[PK_REF + R_SWING]) : 0.0;
     }
@@ -302,11 +302,13 @@ HD void terrain_frame(const double* Z, double pz, TerrainFrame& t) {
     const D2 nn = d2sqrt(D2(1.0) + t.u1 * t.u1 + t.u2 * t.u2);
     t.inn = D2(1.0) / nn;
     t.n[0] = t.u1 * t.inn; t.n[1] = t.u2 * t.inn; t.n[2] = t.inn;
-    // R_t = [xv yv n]:  y0 = n x e_x, xv = (y0 x n)/|.|, yv = n x xv      (terrain_descriptor.py:64-72)
-    t.xv[0] = t.n[2] * t.n[2] + t.n[1] * t.n[1]; t.xv[1] = -(t.n[1] * t.n[0]); t.xv[2] = -(t.n[2] * t.n[0]);
-    const D2 ixn = D2(1.0) / d2sqrt(t.xv[0] * t.xv[0] + t.xv[1] * t.xv[1] + t.xv[2] * t.xv[2]);
-    for (int i = 0; i < 3; ++i) t.xv[i] = t.xv[i] * ixn;
-    t.yv[0] = t.n[1] * t.xv[2] - t.n[2] * t.xv[1]; t.yv[1] = t.n[2] * t.xv[0] - t.n[0] * t.xv[2]; t.yv[2] = t.n[0] * t.xv[1] - t.n[1] * t.xv[0];
+    // R_t = [xv yv n]:  y0 = n x e_x = (0, n_z, -n_y), x = y0 x n = (n_y^2 + n_z^2, -n_y n_x, -n_z n_x), xv = x / |x|, yv = n x xv
+    // (terrain_descriptor.py:64-72).  n is a unit vector orthogonal to y0, so |x|^2 = (n_y^2 + n_z^2) =: q and
+    // n x (y0 x n) = y0: xv = x / sqrt(q), yv = y0 / sqrt(q) — the same vectors with half the arithmetic.
+    const D2 q = t.n[1] * t.n[1] + t.n[2] * t.n[2];
+    const D2 iq = D2(1.0) / d2sqrt(q);
+    t.xv[0] = q * iq; t.xv[1] = -(t.n[1] * t.n[0]) * iq; t.xv[2] = -(t.n[2] * t.n[0]) * iq;
+    t.yv[0] = D2(0.0); t.yv[1] = t.n[2] * iq; t.yv[2] = -(t.n[1] * iq);
 }
 
 // height, normal force, friction cone rows of contact point c on the smooth terrain  (E15-E17, E6, E7); shared with pose_body.h
@@ -349,31 +351,36 @@ template <class Em> HD void point_hnf_planar(Ctx<Em>& cx, int c) {
     em.J(jb + js::FRICTION_F + 2, row_id(RK_FRICTION, c, 0), cb + F_ + 2, 2.0 * mu2 * fz);
 }
 
-// --- contact point rows on the SMOOTH terrain, lane c (called from t_points_scalar).  E3, E4, E6, E7, E10, E14-E17 -----------
-template <class Em> HD void t_points_terrain(Ctx<Em>& cx, int c) {
+// --- contact point rows on the SMOOTH terrain (E3, E4, E6, E7, E10, E14-E17) in two stages:
+//   t_terrain_stage (phase A, lane c): third-order jet of the bump sum and the terrain frame with its d/dp_x, d/dp_y, parked in
+//       the (not yet used) per-link area of the scratch;
+//   t_terrain_planar / _dcc / _hnf (phase B, lane c each, on three different waves): the rows and their Jacobian entries.
+struct TerrainStage { TerrainFrame tf; double Zh[7]; };   // Zh = Z[3..9]: second and third derivatives (for udot)
+static_assert(sizeof(TerrainStage) * NC <= sizeof(double) * NL * 16, "terrain staging must fit in own[0..NL) (own[NL] is the zero slot)");
+HD TerrainStage* terrain_stage(KnotScratch& s, int c) { return reinterpret_cast<TerrainStage*>(&s.own[0][0]) + c; }
+
+template <class Em> HD void t_terrain_stage(Ctx<Em>& cx, int c) {
+    if (terrain_is_planar(cx)) return;
     KnotScratch& s = cx.s;
-    const double* x = s.x + PT_ * c;
-    const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
-    Em& em = cx.em;
-    const double* p = x + P_;
-    const double* f = x + F_;
-    const double* v = x + V_;
-    const double* fd = x + FD_;
-    const double* u = x + U_;
+    const double* p = s.x + PT_ * c + P_;
     double Z[10];
     terrain_Z_jet(cx.st, p[0], p[1], 3, Z);
-    TerrainFrame tf;
-    terrain_frame(Z, p[2], tf);
-    const D2 &u1 = tf.u1, &u2 = tf.u2, &h = tf.h, &inn = tf.inn;
+    TerrainStage* st = terrain_stage(s, c);
+    terrain_frame(Z, p[2], st->tf);
+    for (int i = 0; i < 7; ++i) st->Zh[i] = Z[3 + i];
+}
+// planar complementarity  v - R_t diag(tau,tau,1) u   (E3)
+template <class Em> HD void t_terrain_planar(Ctx<Em>& cx, int c) {
+    if (terrain_is_planar(cx)) return;
+    KnotScratch& s = cx.s;
+    Em& em = cx.em;
+    const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
+    const double* v = s.x + cb + V_;
+    const double* u = s.x + cb + U_;
+    const TerrainFrame& tf = terrain_stage(s, c)->tf;
     const D2 *n = tf.n, *xv = tf.xv, *yv = tf.yv;
-    const D2 ud1(-(Z[3] * v[0] + Z[4] * v[1]), -(Z[6] * v[0] + Z[7] * v[1]), -(Z[7] * v[0] + Z[8] * v[1]));  // (d grad h/dp) v
-    const D2 ud2(-(Z[4] * v[0] + Z[5] * v[1]), -(Z[7] * v[0] + Z[8] * v[1]), -(Z[8] * v[0] + Z[9] * v[1]));
-    const D2 hdot = u1 * v[0] + u2 * v[1] + D2(v[2]);
-    const D2 ndu = n[0] * ud1 + n[1] * ud2;                                  // n . udot   (udot_z = 0)
-    D2 nd[3] = {(ud1 - n[0] * ndu) * inn, (ud2 - n[1] * ndu) * inn, (-(n[2] * ndu)) * inn};  // ndot = (udot - n (n.udot)) / |grad h|
-    const double kt = cx.gp.kt, kbs = cx.gp.kbs;
-    // ---- planar complementarity  v - R_t diag(tau,tau,1) u   (E3)
-    const D2 tau = d2tanh(h * kt);
+    const double kt = cx.gp.kt;
+    const D2 tau = d2tanh(tf.h * kt);
     const double dtau_z = kt * (1.0 - tau.v * tau.v);                       // d tau / d p_z
     for (int i = 0; i < 3; ++i) {
         const D2 r = xv[i] * tau * u[0] + yv[i] * tau * u[1] + n[i] * u[2];
@@ -385,7 +392,27 @@ template <class Em> HD void t_points_terrain(Ctx<Em>& cx, int c) {
         em.J(jb + js::PLANAR_P + 3 * i + 1, row_id(RK_PLANAR, c, i), cb + P_ + 1, -r.y);
         em.J(jb + js::PLANAR_P + 3 * i + 2, row_id(RK_PLANAR, c, i), cb + P_ + 2, -(xv[i].v * u[0] + yv[i].v * u[1]) * dtau_z);
     }
-    // ---- dcc margin  eps - k h (n.f) - [hdot (n.f) + h f.ndot + h (n.fdot)]   (E4)
+}
+// dcc margin  eps - k h (n.f) - [hdot (n.f) + h f.ndot + h (n.fdot)]   (E4)
+template <class Em> HD void t_terrain_dcc(Ctx<Em>& cx, int c) {
+    if (terrain_is_planar(cx)) return;
+    KnotScratch& s = cx.s;
+    Em& em = cx.em;
+    const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
+    const double* f = s.x + cb + F_;
+    const double* v = s.x + cb + V_;
+    const double* fd = s.x + cb + FD_;
+    const TerrainStage* st = terrain_stage(s, c);
+    const TerrainFrame& tf = st->tf;
+    const double* Z = st->Zh - 3;   // Z[3..9]
+    const D2 &u1 = tf.u1, &u2 = tf.u2, &h = tf.h, &inn = tf.inn;
+    const D2* n = tf.n;
+    const D2 ud1(-(Z[3] * v[0] + Z[4] * v[1]), -(Z[6] * v[0] + Z[7] * v[1]), -(Z[7] * v[0] + Z[8] * v[1]));  // (d grad h/dp) v
+    const D2 ud2(-(Z[4] * v[0] + Z[5] * v[1]), -(Z[7] * v[0] + Z[8] * v[1]), -(Z[8] * v[0] + Z[9] * v[1]));
+    const D2 hdot = u1 * v[0] + u2 * v[1] + D2(v[2]);
+    const D2 ndu = n[0] * ud1 + n[1] * ud2;                                  // n . udot   (udot_z = 0)
+    D2 nd[3] = {(ud1 - n[0] * ndu) * inn, (ud2 - n[1] * ndu) * inn, (-(n[2] * ndu)) * inn};  // ndot = (udot - n (n.udot)) / |grad h|
+    const double kbs = cx.gp.kbs;
     const D2 nf = n[0] * f[0] + n[1] * f[1] + n[2] * f[2];
     const D2 nfd = n[0] * fd[0] + n[1] * fd[1] + n[2] * fd[2];
     const D2 fnd = nd[0] * f[0] + nd[1] * f[1] + nd[2] * f[2];
@@ -402,11 +429,19 @@ template <class Em> HD void t_points_terrain(Ctx<Em>& cx, int c) {
         const double dndvj_f = j == 0 ? (n[0].x * f[0] + n[1].x * f[1] + n[2].x * f[2]) : (j == 1 ? (n[0].y * f[0] + n[1].y * f[1] + n[2].y * f[2]) : 0.0);
         em.J(jb + js::DCC_V + j, row_id(RK_DCC, c, 0), cb + V_ + j, -gradh[j] * nf.v - h.v * dndvj_f);
     }
+}
+// height, normal force, friction cone rows; swing height heuristic (E10):  0.5 [ (h - hd)^2 + |(R_t^T v)_xy|^2 ]   (k >= 1)
+template <class Em> HD void t_terrain_hnf(Ctx<Em>& cx, int c) {
+    if (terrain_is_planar(cx)) return;
+    KnotScratch& s = cx.s;
+    const int cb = PT_ * c;
+    const double* v = s.x + cb + V_;
+    const TerrainFrame& tf = terrain_stage(s, c)->tf;
+    const D2 *xv = tf.xv, *yv = tf.yv;
     point_hnf_smooth(cx, c, tf);
-    // ---- swing height heuristic (E10):  0.5 [ (h - hd)^2 + |(R_t^T v)_xy|^2 ]   (k >= 1)
     const double on = cx.ki.first ? 0.0 : 1.0;
     const double msw = on * cx.st.m_swing;
-    const D2 dh = h - D2(s.pk[PK_REF + R_SWING]);
+    const D2 dh = tf.h - D2(s.pk[PK_REF + R_SWING]);
     const D2 pvx = xv[0] * v[0] + xv[1] * v[1] + xv[2] * v[2], pvy = yv[0] * v[0] + yv[1] * v[1] + yv[2] * v[2];
     const D2 sw = (dh * dh + pvx * pvx + pvy * pvy) * 0.5;
     s.c_pt[c][0] = msw * sw.v;
@@ -424,7 +459,7 @@ template <class Em> HD void t_points_scalar(Ctx<Em>& cx, int c) {
     const double on = cx.ki.first ? 0.0 : 1.0;
     s.c_pt[c][1] = on * cx.st.m_ureg * (x[U_] * x[U_] + x[U_ + 1] * x[U_ + 1] + x[U_ + 2] * x[U_ + 2]);
     s.c_pt[c][2] = on * cx.st.m_fdreg * (x[FD_] * x[FD_] + x[FD_ + 1] * x[FD_ + 1] + x[FD_ + 2] * x[FD_ + 2]);
-    if (!terrain_is_planar(cx)) { t_points_terrain(cx, c); return; }
+    if (!terrain_is_planar(cx)) return;   // smooth terrain: t_terrain_stage / _planar / _dcc / _hnf
     const double pz = x[P_ + 2], fz = x[F_ + 2], vz = x[V_ + 2], fdz = x[FD_ + 2];
     // dcc margin  eps - k h (n.f) - [hdot (n.f) + h f.ndot + h (n.fdot)]   (E4; n = e_z, ndot = 0, hdot = v_z)
     em.G(gb + gs::DCC, row_id(RK_DCC, c, 0), cx.gp.eps - cx.gp.kbs * (pz * fz) - (vz * fz + pz * fdz));
@@ -772,6 +807,7 @@ template <class Em> HD void t_hdyn(Ctx<Em>& cx, int t) {
 constexpr int FOOT_TASKS = 30;
 template <class Em> HD void t_foot_costs(Ctx<Em>& cx, int t) {
     KnotScratch& s = cx.s;
+    HIPNLP_WAVE_SYNC();   // smooth terrain: the swing-cost gradient of the same wave's t_terrain_hnf is accumulated into below
     const double on = cx.ki.first ? 0.0 : 1.0;
     if (t < 6) {
         const int foot = t / 3, i = t - 3 * foot;
@@ -1160,14 +1196,15 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
 // ---------------------------------------------------------------------------------------------------
 #define HIPNLP_KNOT_PROGRAM(R, BARRIER)                                                   \
     R(0, 0, t_points_vec, 3 * NC) R(0, 1, t_unitq, 1)                                     \
-    R(1, 2, t_points_scalar, NC) R(1, 2, t_points_cost, 3) R(1, 3, t_dyn, 7 + NJ + 3) R(1, 1, t_feet_centroid, 1) \
+    R(1, 2, t_points_scalar, NC) R(1, 3, t_dyn, 7 + NJ + 3) R(1, 1, t_feet_centroid, 1) R(1, 7, t_terrain_stage, NC) \
     R(2, 4, t_joints, NJ) R(2, 4, t_joint_cost, 1) R(2, 1, t_feet_yaw, 2)                 \
     R(3, 5, t_base, 3) R(3, 6, t_small, 4)                                                \
     BARRIER                                                                               \
     R(0, 0, t_fk_rot_a, FK_TASKS_A) R(0, 0, t_link_u_a, FK_SPLIT)                         \
     R(3, 1, t_fk_rot_b, FK_TASKS_B) R(3, 1, t_link_u_b, NJ - FK_SPLIT)                    \
     R(1, 2, t_hdyn_entries, 48) R(1, 3, t_hdyn_rows, HDYN_TASKS - 48)                     \
-    R(2, 4, t_foot_costs, FOOT_TASKS) R(2, 4, t_foot_cost_sum, 2)                         \
+    R(2, 4, t_terrain_hnf, NC) R(2, 4, t_points_cost, 3) R(2, 4, t_foot_costs, FOOT_TASKS) R(2, 4, t_foot_cost_sum, 2) \
+    R(1, 5, t_terrain_planar, NC) R(0, 6, t_terrain_dcc, NC)                              \
     BARRIER                                                                               \
     R(0, 0, t_links, NL) R(1, 1, t_frames, 3)                                             \
     BARRIER                                                                               \
