@@ -1,13 +1,13 @@
 // hipnlp.hip — gfx950 kernels and the C-ABI (include/hipnlp.h) of the multiple-shooting NLP-callback engine.
 //
-// Execution model: one 64-lane workgroup (= one CDNA4 wavefront) per shooting knot.
-// The wave stages the knot record x_k (189 fp64, contiguous => three coalesced 512-B wave loads), its
-// predecessor x_{k-1} (trapezoid halo) and the per-knot parameter record in LDS, runs the knot program of
-// knot_body.h with lanes mapped to contact points / joints / tree levels, collects all outputs of the knot
-// in LDS at compile-time native slots and finally streams them out: the knot's CCS column block of jac g
-// as ONE contiguous run (permuted through an L2-resident int table), grad f contiguous, g scattered into
-// the reference's constraint-type-major order, the cost partials per knot.  A second tiny kernel reduces
-// the per-knot cost partials in a fixed order (bitwise reproducible f).
+// Execution model: one workgroup of four (or eight) role-specialised wavefronts per shooting knot.
+// The workgroup stages the knot record x_k (189 fp64, contiguous => coalesced loads), its predecessor x_{k-1} (trapezoid
+// halo), the per-knot parameter record and the read-only tables in LDS, runs the knot program of knot_body.h (task groups on
+// waves, workgroup barriers between dependent phases; lanes mapped to contact points / joints / (joint, row) / (link,
+// component) / Jacobian entries), collects all outputs of the knot in LDS at compile-time native slots and finally streams
+// them out: the knot's CCS column block of jac g as ONE contiguous run (permuted through a prefetched int table), grad f
+// contiguous, g scattered into the reference's constraint-type-major order, the cost partials per knot.  A second tiny kernel
+// reduces the per-knot cost partials in a fixed order (bitwise reproducible f).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
