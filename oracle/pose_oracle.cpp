@@ -196,6 +196,25 @@ void oracle_pose_eval(Handle* h, const double* x, const double* p, double* f, do
     if (jac) for (int e = 0; e < h->nnz; ++e) jac[e] = gd[size_t(h->irow[size_t(e)])].d[h->jcol[size_t(e)]];
     Dual::K = kMaxDir;
 }
+// Exact Hessian of the Lagrangian  sigma f(x) + lambda^T g(x)  (what CasADi's nlp_hess_l hands IPOPT's eval_h; the reference
+// pose finder runs IPOPT with its default exact-Hessian option: humanoid_pose_finder/main.py:101, casadi_solver_options = {}).
+// Forward-over-forward AD: the outer D1<> carries ONE direction j, the inner Dual all 81; H [81][81] dense, row major
+// (H[j][i] = d^2 L / dx_i dx_j; symmetric up to rounding).
+void oracle_pose_hess(Handle* h, const double* x, const double* p, double sigma, const double* lambda, double* H) {
+    Dual::K = NX;
+    typedef D1<Dual> DD;
+    std::vector<DD> xd(NX), gd;
+    std::vector<DD> cost(NCT);
+    for (int j = 0; j < NX; ++j) {
+        for (int i = 0; i < NX; ++i) xd[size_t(i)] = DD(Dual::seed(x[i], i), Dual(i == j ? 1.0 : 0.0));
+        evaluate<DD>(h->d, xd.data(), p, gd, cost.data(), nullptr, nullptr, nullptr);
+        Dual acc(0.0);
+        for (int t = 0; t < NCT; ++t) acc = acc + Dual(sigma) * cost[size_t(t)].d;
+        for (int r = 0; r < h->m; ++r) if (lambda[r] != 0.0) acc = acc + Dual(lambda[r]) * gd[size_t(r)].d;
+        for (int i = 0; i < NX; ++i) H[size_t(j) * NX + i] = acc.d[i];
+    }
+    Dual::K = kMaxDir;
+}
 void oracle_pose_cost_terms(const Handle* h, double* out) { for (int t = 0; t < NCT; ++t) out[t] = h->cost_terms[t]; }
 const char* oracle_pose_cost_term_name(int i) { return (i >= 0 && i < NCT) ? kCostNames[i] : ""; }
 

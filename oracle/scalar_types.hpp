@@ -131,6 +131,9 @@ template <class S> D1<S> operator*(const D1<S>& a, const D1<S>& b) { return D1<S
 template <class S> D1<S> operator/(const D1<S>& a, const D1<S>& b) { S q = a.v / b.v; return D1<S>(q, (a.d - q * b.d) / b.v); }
 template <class S> D1<S> sqrt(const D1<S>& a) { using std::sqrt; S r = sqrt(a.v); return D1<S>(r, a.d / (S(2.0) * r)); }
 template <class S> D1<S> exp(const D1<S>& a) { using std::exp; S e = exp(a.v); return D1<S>(e, e * a.d); }
+template <class S> D1<S> sin(const D1<S>& a) { using std::sin; using std::cos; return D1<S>(sin(a.v), cos(a.v) * a.d); }
+template <class S> D1<S> cos(const D1<S>& a) { using std::sin; using std::cos; return D1<S>(cos(a.v), -(sin(a.v) * a.d)); }
+template <class S> D1<S> tanh(const D1<S>& a) { using std::tanh; S t = tanh(a.v); return D1<S>(t, (S(1.0) - t * t) * a.d); }
 
 // an Opti *parameter*: symbolic for the structure tracer (never a literal constant), a number otherwise
 template <class S> struct ParamMaker { static S make(double v) { return S(v); } };

@@ -135,6 +135,13 @@ class PoseOracle:
                                C.byref(f), _dp(grad), _dp(g), _dp(jac))
         return f.value, grad, g, jac
 
+    def hess(self, x, p, sigma, lam):
+        """dense [81][81] Hessian of sigma f + lam^T g (forward-over-forward AD)"""
+        H = np.zeros((self.n, self.n))
+        lib().oracle_pose_hess(C.c_void_p(self.h), _dp(np.ascontiguousarray(x)), _dp(np.ascontiguousarray(p)), C.c_double(sigma),
+                               _dp(np.ascontiguousarray(lam, dtype=float)), _dp(H))
+        return H
+
     def cost_terms(self):
         out = np.zeros(_abi.POSE_NCOST_TERMS)
         lib().oracle_pose_cost_terms(C.c_void_p(self.h), _dp(out))

@@ -103,3 +103,41 @@ def test_pose_fixture_layout_names():
     assert off["references.frame_quaternion_xyzw"] == ps.P_REF_FQ
     assert off["relaxed_complementarity_epsilon"] == ps.P_EPS and off["static_friction"] == ps.P_MU
     assert off["maximum_joint_positions"] == ps.P_SMAX and off["minimum_joint_positions"] == ps.P_SMIN
+
+
+@pytest.mark.parametrize("name", ["pose_default", "pose_step_constrained"])
+def test_pose_oracle_hessian_matches_reference_graph(model, name):
+    """Hessian of the Lagrangian (IPOPT eval_h; the reference pose finder runs IPOPT with the exact Hessian,
+    humanoid_pose_finder/main.py:101): the oracle's forward-over-forward AD against second derivatives taken on the reference
+    planner's own expression graph (tools/gen_pose_fixtures.py: cs.jtimes + numeric tangents on the stand-in)."""
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    st = pose_settings_for(json.loads(str(z["meta"])), model)
+    o = PoseOracle(st, model)
+    H = o.hess(z["x"], z["p"], float(z["hess_sigma"]), z["hess_lambda"])
+    assert rel(H, z["hess"]) < TOL
+    assert np.array_equal(H != 0.0, z["hess"] != 0.0) or np.max(np.abs(H[(H != 0.0) != (z["hess"] != 0.0)])) < 1e-9
+
+
+def test_pose_oracle_hessian_vs_finite_differences(model):
+    st = pose_finder_settings(model)
+    from hippopt_amd.pose_settings import make_pose_workload
+    x, p = make_pose_workload(st, model, batch=1, seed=3)
+    x, p = x[0], p[0]
+    o = PoseOracle(st, model)
+    rng = np.random.default_rng(0)
+    lam, sigma = rng.normal(size=o.m), 0.7
+    H = o.hess(x, p, sigma, lam)
+    assert np.max(np.abs(H - H.T)) < 1e-10
+    ir, jc = o.sparsity()
+
+    def grad_lagrangian(xx):
+        _, grad, _, jac = o.eval(xx, p)
+        J = np.zeros((o.m, o.n))
+        J[ir, jc] = jac
+        return sigma * grad + J.T @ lam
+    Hfd = np.zeros_like(H)
+    for j in range(o.n):
+        e = np.zeros(o.n)
+        e[j] = 1e-6
+        Hfd[j] = (grad_lagrangian(x + e) - grad_lagrangian(x - e)) / 2e-6
+    assert np.max(np.abs(H - Hfd) / np.maximum(1.0, np.abs(H))) < 1e-6

@@ -118,12 +118,29 @@ def generate(tag, mine, model, seed, tweak=None):
     ir, jc = np.nonzero(J)
     order = np.lexsort((ir, jc))
     ir, jc = ir[order], jc[order]
+    # Hessian of the Lagrangian sigma f + lambda^T g (what nlp_hess_l gives IPOPT's eval_h: the pose finder runs IPOPT with
+    # the exact Hessian, humanoid_pose_finder/main.py:101): symbolic forward derivative of L along every variable component
+    # (cs.jtimes on the reference's own graph), then its numeric tangents with respect to all variables.
+    rng = np.random.RandomState(seed + 1)
+    sigma = 0.75
+    lam = rng.standard_normal(int(G.shape[0]))
+    lag = sigma * f_expr + cs.mtimes(cs.DM(lam.reshape(1, -1)), G)
+    rows_h = []
+    for v in opti.variables:
+        for i in range(v.numel()):
+            e = np.zeros(v.shape)
+            e[i % v.shape[0], i // v.shape[0]] = 1.0
+            rows_h.append(cs.jtimes(lag, v, cs.DM(e)))
+    _, ht = cs.evaluate(rows_h, values, seeds, nx)
+    hess = np.stack([np.zeros(nx) if t is None else t[0, 0, :] for t in ht])
+    assert np.max(np.abs(hess - hess.T)) < 1e-9 * max(1.0, np.max(np.abs(hess)))
     out = os.path.join(ROOT, "tests", "golden", "pose_%s.npz" % tag)
     np.savez_compressed(out, x=x, p=p, g=gv.reshape(-1), lbg=lbv.reshape(-1), ubg=ubv.reshape(-1), f=float(fv), grad=grad,
                         jac_row=ir.astype(np.int32), jac_col=jc.astype(np.int32), jac_val=J[ir, jc],
                         names=np.array(names), rows=np.array(rows, np.int32), cost_names=np.array(cost_names),
                         cost_values=np.array([float(np.asarray(c).reshape(-1)[0]) for c in cvals]),
                         vnames=np.array(vnames), pnames=np.array(pnames),
+                        hess_sigma=sigma, hess_lambda=lam, hess=hess,
                         meta=np.array(json.dumps({"config": tag, "seed": seed,
                                                   "generator": "reference humanoid_pose_finder/planner.py on tools/casadi_standin (stand-in, not CasADi)"})))
     print(tag, "n", nx, "m", int(G.shape[0]), "nnz(numeric)", len(ir), "f", float(fv), "->", os.path.relpath(out, ROOT))
