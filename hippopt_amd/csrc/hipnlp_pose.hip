@@ -23,6 +23,7 @@ namespace {
 constexpr int WG = 256;
 constexpr int XR_STRIDE = 64;
 constexpr int POSE_MAX_NNZ = 1024;
+constexpr int POSE_MAX_HNNZ = hs::COUNT;
 static_assert(XR_COUNT <= XR_STRIDE, "pose reference record");
 
 struct PoseTables {
@@ -31,6 +32,8 @@ struct PoseTables {
     int32_t g_row[gs::COUNT];
     int32_t jperm[POSE_MAX_NNZ];
     int32_t nnz, m;
+    int32_t hperm[POSE_MAX_HNNZ];
+    int32_t hnnz, pad_;
 };
 
 struct PArgs {
@@ -45,6 +48,10 @@ struct PArgs {
     double* jac;        // [batch][nnz]      or null
     double* cost_terms; // [batch][POSE_NCT]
     int32_t* flags;     // [batch]
+    // Hessian kernel only
+    const double* sigma;   // [batch]   objective factor
+    const double* lambda;  // [batch][m]
+    double* hess;          // [batch][hnnz]
 };
 
 template <int TERRAIN> struct PoseEm {
@@ -55,11 +62,41 @@ template <int TERRAIN> struct PoseEm {
     __device__ __forceinline__ void J(int slot, int, int, double v) { jac[slot] = v; }
 };
 
+template <int TERRAIN> struct PoseHessEm {
+    static constexpr int kTerrain = TERRAIN;
+    double* g;
+    double* jac;
+    double* h;
+    __device__ __forceinline__ void G(int slot, int, double v) { g[slot] = v; }
+    __device__ __forceinline__ void J(int slot, int, int, double v) { jac[slot] = v; }
+    __device__ __forceinline__ void H(int slot, int, int, double v) { h[slot] = v; }
+};
+
 struct PoseShared {
     KinTables kt;
     KSettings ks;
     GParams gp;
 };
+
+// tables, parameters and the pose's variables -> LDS (ends with a workgroup barrier)
+__device__ __forceinline__ void pose_stage(const PArgs& a, KnotScratch& s, PoseShared& tabs, int b, int tid) {
+    const PoseTables& tb = *a.tb;
+    static_assert(sizeof(KinTables) % 4 == 0 && sizeof(KSettings) % 4 == 0 && sizeof(GParams) % 4 == 0, "word copy");
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&tb.kt);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&tabs.kt);
+    for (int i = tid; i < int(sizeof(KinTables) / 4); i += WG) dst[i] = src[i];
+    src = reinterpret_cast<const uint32_t*>(&tb.ks);
+    dst = reinterpret_cast<uint32_t*>(&tabs.ks);
+    for (int i = tid; i < int(sizeof(KSettings) / 4); i += WG) dst[i] = src[i];
+    src = reinterpret_cast<const uint32_t*>(a.gp + b);
+    dst = reinterpret_cast<uint32_t*>(&tabs.gp);
+    for (int i = tid; i < int(sizeof(GParams) / 4); i += WG) dst[i] = src[i];
+    for (int i = tid; i < XPAD; i += WG) { s.x[i] = 0.0; s.xm[i] = i < XR_STRIDE ? a.xr[size_t(b) * XR_STRIDE + i] : 0.0; }
+    for (int i = tid; i < PK_STRIDE; i += WG) s.pk[i] = a.pk[size_t(b) * PK_STRIDE + i];
+    __syncthreads();
+    if (tid < POSE_NX) s.x[pose_to_knot_col(tid)] = a.x[size_t(b) * POSE_NX + tid];
+    __syncthreads();
+}
 
 // 3 waves per SIMD = 3 workgroups per CU (the LDS bound): cap the register allocation there (<= 168 VGPRs)
 template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3, 3))) void hipnlp_pose_kernel(PArgs a) {
@@ -68,23 +105,7 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = blockIdx.x;
     const PoseTables& tb = *a.tb;
-    {
-        static_assert(sizeof(KinTables) % 4 == 0 && sizeof(KSettings) % 4 == 0 && sizeof(GParams) % 4 == 0, "word copy");
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(&tb.kt);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&tabs.kt);
-        for (int i = tid; i < int(sizeof(KinTables) / 4); i += WG) dst[i] = src[i];
-        src = reinterpret_cast<const uint32_t*>(&tb.ks);
-        dst = reinterpret_cast<uint32_t*>(&tabs.ks);
-        for (int i = tid; i < int(sizeof(KSettings) / 4); i += WG) dst[i] = src[i];
-        src = reinterpret_cast<const uint32_t*>(a.gp + b);
-        dst = reinterpret_cast<uint32_t*>(&tabs.gp);
-        for (int i = tid; i < int(sizeof(GParams) / 4); i += WG) dst[i] = src[i];
-    }
-    for (int i = tid; i < XPAD; i += WG) { s.x[i] = 0.0; s.xm[i] = i < XR_STRIDE ? a.xr[size_t(b) * XR_STRIDE + i] : 0.0; }
-    for (int i = tid; i < PK_STRIDE; i += WG) s.pk[i] = a.pk[size_t(b) * PK_STRIDE + i];
-    __syncthreads();
-    if (tid < POSE_NX) s.x[pose_to_knot_col(tid)] = a.x[size_t(b) * POSE_NX + tid];
-    __syncthreads();
+    pose_stage(a, s, tabs, b, tid);
 
     KnotInfo ki{1, 3, 0, 0};   // "interior knot": the k >= 1 rows / costs of the shared tasks are active
     PoseEm<TERRAIN> em{s.g, s.jac};
@@ -118,6 +139,41 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     if (tid == 0) a.flags[b] = anybad;
 }
 
+// Exact Hessian of the Lagrangian (IPOPT eval_h, pose_hess_body.h): the pose program runs as in hipnlp_pose_kernel (its g / jac
+// values stay in LDS, unused), the Hessian tasks run behind it and the workgroup streams out the lower-triangle CCS value run.
+template <int TERRAIN> __global__ __launch_bounds__(WG) void hipnlp_pose_hess_kernel(PArgs a) {
+    __shared__ KnotScratch s;
+    __shared__ PoseShared tabs;
+    __shared__ HessScratch hx;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.x;
+    const PoseTables& tb = *a.tb;
+    for (int slot = tid; slot < gs::COUNT; slot += WG) {
+        const int r = tb.g_row[slot];
+        hx.lam[slot] = r >= 0 ? a.lambda[size_t(b) * tb.m + r] : 0.0;
+    }
+    if (tid == 0) hx.sigma = a.sigma[b];
+    pose_stage(a, s, tabs, b, tid);
+
+    KnotInfo ki{1, 3, 0, 0};
+    PoseHessEm<TERRAIN> em{s.g, s.jac, hx.H};
+    Ctx<PoseHessEm<TERRAIN>> cx(s, tabs.kt, tabs.ks, tabs.gp, ki, em);
+    HCtx<PoseHessEm<TERRAIN>> hcx{cx, hx};
+#define DEV_R(w, w8, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
+#define DEV_RH(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); }
+#define DEV_BARRIER __syncthreads();
+    HIPNLP_POSE_PROGRAM(DEV_R, DEV_BARRIER)
+    HIPNLP_POSE_HESS_PROGRAM(DEV_RH, DEV_BARRIER)
+#undef DEV_R
+#undef DEV_RH
+#undef DEV_BARRIER
+    int bad = 0;
+    double* out = a.hess + size_t(b) * tb.hnnz;
+    for (int e = tid; e < tb.hnnz; e += WG) { const double v = hx.H[tb.hperm[e]]; bad |= !isfinite(v); out[e] = v; }
+    const int anybad = __syncthreads_or(bad);
+    if (tid == 0) a.flags[b] = anybad;
+}
+
 thread_local std::string g_pose_create_error;
 
 }  // namespace
@@ -136,6 +192,8 @@ struct hipnlp_pose_handle {
     int32_t* d_flags = nullptr;
     double *h_x = nullptr, *h_f = nullptr, *h_grad = nullptr, *h_g = nullptr, *h_jac = nullptr, *h_cost = nullptr;
     int32_t* h_flags = nullptr;
+    // Hessian path (allocated on first use)
+    double *d_sigma = nullptr, *d_lambda = nullptr, *d_hess = nullptr, *h_sigma = nullptr, *h_lambda = nullptr, *h_hess = nullptr;
     std::vector<double> p;
     std::string err;
 };
@@ -153,9 +211,9 @@ static void pose_free_all(hipnlp_pose_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* dptrs[] = {h->d_tb, h->d_x, h->d_pk, h->d_xr, h->d_f, h->d_grad, h->d_g, h->d_jac, h->d_cost, h->d_gp, h->d_flags};
+    void* dptrs[] = {h->d_tb, h->d_x, h->d_pk, h->d_xr, h->d_f, h->d_grad, h->d_g, h->d_jac, h->d_cost, h->d_gp, h->d_flags, h->d_sigma, h->d_lambda, h->d_hess};
     for (void* q : dptrs) if (q) (void)hipFree(q);
-    void* hptrs[] = {h->h_x, h->h_f, h->h_grad, h->h_g, h->h_jac, h->h_cost, h->h_flags};
+    void* hptrs[] = {h->h_x, h->h_f, h->h_grad, h->h_g, h->h_jac, h->h_cost, h->h_flags, h->h_sigma, h->h_lambda, h->h_hess};
     for (void* q : hptrs) if (q) (void)hipHostFree(q);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -236,6 +294,8 @@ int hipnlp_pose_create(const hipnlp_pose_desc* desc, hipnlp_pose_handle** out) {
     for (int s = 0; s < gs::COUNT; ++s) tb->g_row[s] = h->L.g_row[size_t(s)];
     for (int e = 0; e < h->L.nnz; ++e) tb->jperm[e] = h->L.jperm[size_t(e)];
     tb->nnz = h->L.nnz; tb->m = h->L.m;
+    for (int e = 0; e < h->L.hnnz; ++e) tb->hperm[e] = h->L.hperm[size_t(e)];
+    tb->hnnz = h->L.hnnz;
     hipError_t ce = hipMemcpy(h->d_tb, tb, sizeof(PoseTables), hipMemcpyHostToDevice);
     delete tb;
     if (ce != hipSuccess) return fail(HIPNLP_E_NODEVICE, std::string("hipMemcpy tables: ") + hipGetErrorString(ce));
@@ -312,6 +372,74 @@ int hipnlp_pose_eval(hipnlp_pose_handle* h, const double* x, double* f, double* 
     if (grad_f) std::memcpy(grad_f, h->h_grad, B * POSE_NX * sizeof(double));
     if (g) std::memcpy(g, h->h_g, B * m * sizeof(double));
     if (jac) std::memcpy(jac, h->h_jac, B * nnz * sizeof(double));
+    for (size_t b = 0; b < B; ++b)
+        if (h->h_flags[b]) { h->err = "non-finite value produced by the evaluation"; return HIPNLP_E_NUMERIC; }
+    return HIPNLP_OK;
+}
+
+int hipnlp_pose_hess_nnz(const hipnlp_pose_handle* h, int32_t* nnz_h) {
+    if (!h || !nnz_h) return HIPNLP_E_INVALID;
+    *nnz_h = h->L.hnnz;
+    return HIPNLP_OK;
+}
+
+int hipnlp_pose_hess_sparsity(const hipnlp_pose_handle* h, int32_t* irow, int32_t* jcol) {
+    if (!h || !irow || !jcol) return HIPNLP_E_INVALID;
+    std::memcpy(irow, h->L.hrow.data(), size_t(h->L.hnnz) * sizeof(int32_t));
+    std::memcpy(jcol, h->L.hcol.data(), size_t(h->L.hnnz) * sizeof(int32_t));
+    return HIPNLP_OK;
+}
+
+static int pose_hess_launch(hipnlp_pose_handle* h, const double* x_dev, const double* sigma_dev, const double* lambda_dev, double* hess_dev,
+                            hipStream_t s, bool timed) {
+    PArgs a{};
+    a.tb = h->d_tb; a.x = x_dev; a.pk = h->d_pk; a.xr = h->d_xr; a.gp = h->d_gp;
+    a.cost_terms = h->d_cost; a.flags = h->d_flags;
+    a.sigma = sigma_dev; a.lambda = lambda_dev; a.hess = hess_dev;
+    if (timed) HIP_TRY(h, hipEventRecord(h->ev0, s));
+    if (h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR)
+        hipLaunchKernelGGL(hipnlp_pose_hess_kernel<HIPNLP_TERRAIN_PLANAR>, dim3(unsigned(h->batch)), dim3(WG), 0, s, a);
+    else
+        hipLaunchKernelGGL(hipnlp_pose_hess_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS>, dim3(unsigned(h->batch)), dim3(WG), 0, s, a);
+    if (timed) HIP_TRY(h, hipEventRecord(h->ev1, s));
+    HIP_TRY(h, hipGetLastError());
+    if (timed) h->timing_valid = true;
+    return HIPNLP_OK;
+}
+
+int hipnlp_pose_eval_hess_device(hipnlp_pose_handle* h, const double* x_dev, const double* obj_factor_dev, const double* lambda_dev,
+                                 double* hess_dev, void* stream) {
+    if (!h || !x_dev || !obj_factor_dev || !lambda_dev || !hess_dev) return HIPNLP_E_INVALID;
+    if (!h->params_set) { h->err = "parameters not set (hipnlp_pose_set_params)"; return HIPNLP_E_PARAMS; }
+    HIP_TRY(h, hipSetDevice(h->dev));
+    return pose_hess_launch(h, x_dev, obj_factor_dev, lambda_dev, hess_dev, stream ? hipStream_t(stream) : h->stream, false);
+}
+
+int hipnlp_pose_eval_hess(hipnlp_pose_handle* h, const double* x, const double* obj_factor, const double* lambda, double* hess) {
+    if (!h || !x || !obj_factor || !lambda || !hess) return HIPNLP_E_INVALID;
+    if (!h->params_set) { h->err = "parameters not set (hipnlp_pose_set_params)"; return HIPNLP_E_PARAMS; }
+    const size_t B = size_t(h->batch), m = size_t(h->L.m), hn = size_t(h->L.hnnz);
+    HIP_TRY(h, hipSetDevice(h->dev));
+    if (!h->d_hess) {
+        HIP_TRY(h, hipMalloc(&h->d_sigma, B * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&h->d_lambda, B * m * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&h->d_hess, B * hn * sizeof(double)));
+        HIP_TRY(h, hipHostMalloc(&h->h_sigma, B * sizeof(double)));
+        HIP_TRY(h, hipHostMalloc(&h->h_lambda, B * m * sizeof(double)));
+        HIP_TRY(h, hipHostMalloc(&h->h_hess, B * hn * sizeof(double)));
+    }
+    std::memcpy(h->h_x, x, B * POSE_NX * sizeof(double));
+    std::memcpy(h->h_sigma, obj_factor, B * sizeof(double));
+    std::memcpy(h->h_lambda, lambda, B * m * sizeof(double));
+    HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_x, B * POSE_NX * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_sigma, h->h_sigma, B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_lambda, h->h_lambda, B * m * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const int rc = pose_hess_launch(h, h->d_x, h->d_sigma, h->d_lambda, h->d_hess, h->stream, true);
+    if (rc != HIPNLP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->h_hess, h->d_hess, B * hn * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_flags, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::memcpy(hess, h->h_hess, B * hn * sizeof(double));
     for (size_t b = 0; b < B; ++b)
         if (h->h_flags[b]) { h->err = "non-finite value produced by the evaluation"; return HIPNLP_E_NUMERIC; }
     return HIPNLP_OK;

@@ -60,6 +60,9 @@ struct RecordEm {
     int* jrowid;      // [js::COUNT]
     int* jcol;        // [js::COUNT]
     bool* dup;
+    int* hrow = nullptr;   // [hs::COUNT] Hessian slots (pose_hess_body.h): row / column variable or -1
+    int* hcol = nullptr;
+    void H(int slot, int row, int col, double) { if (hrow[slot] != -1) *dup = true; hrow[slot] = row; hcol[slot] = col; }
     void G(int slot, int rid, double) { if (grow[slot] != -1) *dup = true; grow[slot] = rid; }
     void J(int slot, int rid, int col, double) { if (jrowid[slot] != -1) *dup = true; jrowid[slot] = rid; jcol[slot] = col; }
 };

@@ -1,0 +1,312 @@
+// pose_hess_body.h — exact Hessian of the Lagrangian  sigma f(x) + lambda^T g(x)  of the static pose finder NLP (IPOPT's eval_h;
+// SURVEY §8f rank 1).  The reference pose finder runs IPOPT with its default exact-Hessian option
+// (turnkey_planners/humanoid_pose_finder/main.py:101 `casadi_solver_options = {}`; planner.py:334-339), CasADi derives
+// nlp_hess_l by AD of the graph.  Here every second derivative is written out by hand and evaluated by tasks that run BEHIND the
+// pose program of pose_body.h in the same workgroup (they read the kinematic quantities that program left in LDS).
+//
+// Lower triangle in pose variable order (x [81]: per point p, f | p_b | q_b | s | com).  Second derivatives that exist:
+//   point block (p_c, f_c)   relaxed complementarity / height / normal force / friction rows on the terrain (second-order jets of
+//                            the terrain frame), the bilinear (p - com) x f of the static balance, the quadratic regularisations
+//   (com, f_c), com          static balance, com regularisation
+//   (q_b, q_b)               <M, R(q/|q|)> of the kinematic rows and of the chest-frame cost through the normalisation; unit norm row
+//   (s_j, q_b), (s_j, s_i)   a base rotation acts like an outermost ancestor joint:  with  Y_j = d/d theta [ dL/ds_j ]
+//                            d2L/ds_i ds_j = a_i . Y_j  (i ancestor-or-self of j),   d2L/dq_l ds_j = G_l . Y_j / |q|
+// where for a point P rigidly attached below joint j:  d2P/ds_i ds_j = a_i x (a_j x (P - o_j))  (Jacobi identity).
+#pragma once
+#include "pose_body.h"
+
+namespace hipnlp {
+
+namespace pv {  // pose variable indices (reference creation order, include/hipnlp.h)
+HD constexpr int P(int c, int i) { return 6 * c + i; }
+HD constexpr int F(int c, int i) { return 6 * c + 3 + i; }
+constexpr int PB = 48, QB = 51, S = 55, COM = 78;
+}  // namespace pv
+
+namespace hs {  // native slots of the Hessian values
+constexpr int PT_PP = 0;    // [6]  lower 3x3 of (p, p):  r (r + 1) / 2 + c
+constexpr int PT_FP = 6;    // [3][3]  row f_j, column p_i
+constexpr int PT_FF = 15;   // [6]  lower 3x3 of (f, f)
+constexpr int PT_STRIDE = 21;
+constexpr int FAVG = NC * PT_STRIDE;   // [foot 2][pair 6][component 3]   (f_c', f_c), c' > c on one foot
+constexpr int COMF = FAVG + 36;        // [c][6]   row com_r, column f_q  (r != q)
+constexpr int COMD = COMF + 6 * NC;    // [3]      com diagonal
+constexpr int QQ = COMD + 3;           // [10]     lower 4x4 of (q_b, q_b)
+constexpr int QS = QQ + 10;            // [NJ][4]  row s_j, column q_l
+constexpr int SS = QS + 4 * NJ;        // [NJ (NJ + 1) / 2]  row s_j, column s_i (i <= j): j (j + 1) / 2 + i; ancestor pairs only
+constexpr int COUNT = SS + NJ * (NJ + 1) / 2;
+}  // namespace hs
+
+struct HessScratch {
+    double lam[gs::COUNT];   // multiplier of the row a native g slot belongs to (0 for slots without a row)
+    double sigma, pad_;
+    double Y[NJ][3];
+    double H[hs::COUNT];
+};
+
+template <class Em> struct HCtx {
+    Ctx<Em>& cx;
+    HessScratch& hx;
+};
+
+// ---- second-order Taylor coefficients in two variables (p_x, p_y) ------------------------------------------------------
+struct T2 {
+    double v, x, y, xx, xy, yy;
+    HD T2() : v(0.0), x(0.0), y(0.0), xx(0.0), xy(0.0), yy(0.0) {}
+    HD T2(double c) : v(c), x(0.0), y(0.0), xx(0.0), xy(0.0), yy(0.0) {}
+    HD T2(double v_, double x_, double y_, double xx_, double xy_, double yy_) : v(v_), x(x_), y(y_), xx(xx_), xy(xy_), yy(yy_) {}
+};
+HD T2 operator+(const T2& a, const T2& b) { return T2(a.v + b.v, a.x + b.x, a.y + b.y, a.xx + b.xx, a.xy + b.xy, a.yy + b.yy); }
+HD T2 operator-(const T2& a, const T2& b) { return T2(a.v - b.v, a.x - b.x, a.y - b.y, a.xx - b.xx, a.xy - b.xy, a.yy - b.yy); }
+HD T2 operator-(const T2& a) { return T2(-a.v, -a.x, -a.y, -a.xx, -a.xy, -a.yy); }
+HD T2 operator*(const T2& a, double c) { return T2(a.v * c, a.x * c, a.y * c, a.xx * c, a.xy * c, a.yy * c); }
+HD T2 operator*(double c, const T2& a) { return a * c; }
+HD T2 operator*(const T2& a, const T2& b) {
+    return T2(a.v * b.v, a.x * b.v + a.v * b.x, a.y * b.v + a.v * b.y,
+              a.xx * b.v + 2.0 * (a.x * b.x) + a.v * b.xx,
+              a.xy * b.v + a.x * b.y + a.y * b.x + a.v * b.xy,
+              a.yy * b.v + 2.0 * (a.y * b.y) + a.v * b.yy);
+}
+HD T2 t2inv(const T2& b) {
+    const double i = 1.0 / b.v, i2 = i * i, i3 = 2.0 * i2 * i;
+    return T2(i, -i2 * b.x, -i2 * b.y, i3 * b.x * b.x - i2 * b.xx, i3 * b.x * b.y - i2 * b.xy, i3 * b.y * b.y - i2 * b.yy);
+}
+HD T2 t2sqrt(const T2& a) {
+    const double r = sqrt(a.v), h = 0.5 / r, q = 0.25 / (r * a.v);
+    return T2(r, a.x * h, a.y * h, a.xx * h - q * a.x * a.x, a.xy * h - q * a.x * a.y, a.yy * h - q * a.y * a.y);
+}
+
+// terrain frame (terrain_descriptor.py:45-80) with second-order dependence on (p_x, p_y); Z = third-order jet of the bump sum
+struct TerrainFrame2 { T2 h, n[3], xv[3], yv[3]; };
+HD void terrain_frame2(const double* Z, double pz, TerrainFrame2& t) {
+    const T2 u1(-Z[1], -Z[3], -Z[4], -Z[6], -Z[7], -Z[8]);   // grad h = (u1, u2, 1)
+    const T2 u2(-Z[2], -Z[4], -Z[5], -Z[7], -Z[8], -Z[9]);
+    t.h = T2(pz - Z[0], -Z[1], -Z[2], -Z[3], -Z[4], -Z[5]);
+    const T2 inn = t2inv(t2sqrt(T2(1.0) + u1 * u1 + u2 * u2));
+    t.n[0] = u1 * inn; t.n[1] = u2 * inn; t.n[2] = inn;
+    const T2 q = t.n[1] * t.n[1] + t.n[2] * t.n[2];          // same closed form as terrain_frame (knot_body.h)
+    const T2 iq = t2inv(t2sqrt(q));
+    t.xv[0] = q * iq; t.xv[1] = -(t.n[1] * t.n[0]) * iq; t.xv[2] = -(t.n[2] * t.n[0]) * iq;
+    t.yv[0] = T2(0.0); t.yv[1] = t.n[2] * iq; t.yv[2] = -(t.n[1] * iq);
+}
+
+HD constexpr int tri(int r, int c) { return r * (r + 1) / 2 + c; }   // r >= c
+
+// --- point block (p_c, f_c): lane c (8) -------------------------------------------------------------------------------------
+//   rows: complementarity  eps - h(p) (n(p).f) mass   (planner.py:680-689),  height h(p),  normal force n.f,  friction
+//         -(x.f)^2 - (y.f)^2 + mu^2 (n.f)^2   (:691-722);  static balance  lam_ang . ((p - com) x f)   (:487-509)
+//   costs: point position / force / average force regularisations  (:724-768)
+template <class Em> HD void t_hess_point(HCtx<Em>& h, int c) {
+    Ctx<Em>& cx = h.cx;
+    KnotScratch& s = cx.s;
+    const double* lam = h.hx.lam;
+    const double sigma = h.hx.sigma;
+    const int gb = gs::PT_STRIDE * c, hb = hs::PT_STRIDE * c, cb = PT_ * c;
+    const double l_c = lam[gb + gs::DCC], l_h = lam[gb + gs::HEIGHT], l_n = lam[gb + gs::NORMAL], l_f = lam[gb + gs::FRICTION];
+    const double* la = lam + gs::HDYN + 3;   // angular rows of the static balance
+    const double mass = cx.gp.mass, mu2 = cx.gp.mu * cx.gp.mu;
+    const int mode = (c >> 2) == 0 ? cx.st.pose_left_type : cx.st.pose_right_type;
+    const double dpp = mode == HIPNLP_EXPR_MINIMIZE ? 2.0 * sigma * cx.st.m_preg : (mode == HIPNLP_EXPR_SUBJECT_TO ? 2.0 * lam[gb + gs::UB] : 0.0);
+    const double dff = sigma * (2.0 * cx.st.m_freg + 1.5 * cx.st.m_favg);   // d2/df_c^2 of m sum_c |f_c - mean|^2 = m (2 - 1/2)
+    Em& em = cx.em;
+    if (terrain_is_planar(cx)) {
+        if (mode != HIPNLP_EXPR_SKIP) for (int i = 0; i < 3; ++i) em.H(hb + hs::PT_PP + tri(i, i), pv::P(c, i), pv::P(c, i), dpp);
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) {
+                if (i == j && i < 2) continue;   // structurally zero on the planar terrain
+                em.H(hb + hs::PT_FP + 3 * j + i, pv::F(c, j), pv::P(c, i), (i == j ? -(l_c * mass) : 0.0) + skew_rc(la, j, i));
+            }
+        em.H(hb + hs::PT_FF + tri(0, 0), pv::F(c, 0), pv::F(c, 0), dff - 2.0 * l_f);
+        em.H(hb + hs::PT_FF + tri(1, 1), pv::F(c, 1), pv::F(c, 1), dff - 2.0 * l_f);
+        em.H(hb + hs::PT_FF + tri(2, 2), pv::F(c, 2), pv::F(c, 2), dff + 2.0 * mu2 * l_f);
+        return;
+    }
+    const double* p = s.x + cb + P_;
+    const double* f = s.x + cb + F_;
+    double Z[10];
+    terrain_Z_jet(cx.st, p[0], p[1], 3, Z);
+    TerrainFrame2 tf;
+    terrain_frame2(Z, p[2], tf);
+    const T2 nf = tf.n[0] * f[0] + tf.n[1] * f[1] + tf.n[2] * f[2];
+    const T2 fcx = tf.xv[0] * f[0] + tf.xv[1] * f[1] + tf.xv[2] * f[2], fcy = tf.yv[0] * f[0] + tf.yv[1] * f[1] + tf.yv[2] * f[2];
+    const T2 fric = (nf * nf) * mu2 - fcx * fcx - fcy * fcy;
+    const T2 Lp = (tf.h * nf) * (-(l_c * mass)) + tf.h * l_h + nf * l_n + fric * l_f;
+    em.H(hb + hs::PT_PP + tri(0, 0), pv::P(c, 0), pv::P(c, 0), Lp.xx + dpp);
+    em.H(hb + hs::PT_PP + tri(1, 0), pv::P(c, 1), pv::P(c, 0), Lp.xy);
+    em.H(hb + hs::PT_PP + tri(1, 1), pv::P(c, 1), pv::P(c, 1), Lp.yy + dpp);
+    em.H(hb + hs::PT_PP + tri(2, 0), pv::P(c, 2), pv::P(c, 0), -(l_c * mass) * nf.x);   // d/dp_z acts on h only (dh/dp_z = 1)
+    em.H(hb + hs::PT_PP + tri(2, 1), pv::P(c, 2), pv::P(c, 1), -(l_c * mass) * nf.y);
+    if (mode != HIPNLP_EXPR_SKIP) em.H(hb + hs::PT_PP + tri(2, 2), pv::P(c, 2), pv::P(c, 2), dpp);
+    for (int j = 0; j < 3; ++j) {
+        // dL/df_j as a function of p
+        const T2 q = (tf.h * tf.n[j]) * (-(l_c * mass)) + tf.n[j] * l_n + ((nf * tf.n[j]) * mu2 - fcx * tf.xv[j] - fcy * tf.yv[j]) * (2.0 * l_f);
+        em.H(hb + hs::PT_FP + 3 * j + 0, pv::F(c, j), pv::P(c, 0), q.x + skew_rc(la, j, 0));
+        em.H(hb + hs::PT_FP + 3 * j + 1, pv::F(c, j), pv::P(c, 1), q.y + skew_rc(la, j, 1));
+        em.H(hb + hs::PT_FP + 3 * j + 2, pv::F(c, j), pv::P(c, 2), -(l_c * mass) * tf.n[j].v + skew_rc(la, j, 2));
+        for (int i = 0; i <= j; ++i)
+            em.H(hb + hs::PT_FF + tri(j, i), pv::F(c, j), pv::F(c, i),
+                 2.0 * l_f * (mu2 * tf.n[j].v * tf.n[i].v - tf.xv[j].v * tf.xv[i].v - tf.yv[j].v * tf.yv[i].v) + (i == j ? dff : 0.0));
+    }
+}
+
+// --- average force regularisation across the points of one foot: lanes (foot, pair, i) 36; static balance (com, f): lanes 36..83;
+//     com diagonal: lanes 84..86 ------------------------------------------------------------------------------------------------
+constexpr int HESS_MISC_TASKS = 36 + 6 * NC + 3;
+template <class Em> HD void t_hess_misc(HCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    Em& em = cx.em;
+    const double sigma = h.hx.sigma;
+    if (t < 36) {
+        const int foot = t / 18, r = t - 18 * foot, pair = r / 3, i = r - 3 * pair;
+        // pairs (c' > c) of {0,1,2,3}: (1,0) (2,0) (2,1) (3,0) (3,1) (3,2)
+        const int hi = pair < 1 ? 1 : (pair < 3 ? 2 : 3), lo = pair - (hi == 1 ? 0 : (hi == 2 ? 1 : 3));
+        em.H(hs::FAVG + t, pv::F(4 * foot + hi, i), pv::F(4 * foot + lo, i), -0.5 * sigma * cx.st.m_favg);
+    } else if (t < 36 + 6 * NC) {
+        const int q = t - 36, c = q / 6, e = q - 6 * c, r = cross_row(e), col = cross_col(e);
+        // lam_ang . ((p - com) x f) = f . (lam_ang x (p - com)):  d2 / d f_col d com_r = -[lam_ang]x (col, r)
+        em.H(hs::COMF + q, pv::COM + r, pv::F(c, col), -skew_rc(h.hx.lam + gs::HDYN + 3, col, r));
+    } else {
+        const int i = t - 36 - 6 * NC;
+        const int mode = cx.st.pose_com_type;
+        if (mode == HIPNLP_EXPR_SKIP) return;
+        em.H(hs::COMD + i, pv::COM + i, pv::COM + i, mode == HIPNLP_EXPR_MINIMIZE ? 2.0 * sigma * cx.st.m_pcom : 2.0 * h.hx.lam[gs::COMH]);
+    }
+}
+
+// chest-frame rotation error  E = R_chest R(q_d)^T  (K5) recomputed from the frame the pose program left in the scratch
+HD void chest_error(const KnotScratch& s, double* E) {
+    double Rd[9], Rdt[9];
+    rot_from_quat(s.pk + PK_REF + R_FQ, Rd);
+    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) Rdt[3 * r + q] = Rd[3 * q + r];
+    matmul3(s.fr_R[HIPNLP_FRAME_CHEST], Rdt, E);
+}
+
+// --- Y_j = d/d theta [ dL/ds_j ]  (theta: world-frame rotation of the base), lane j (23) -------------------------------------------
+//   L = sum_c w_c . pkin_c + w_com . com_kin + sigma m (tr E - 3)^2,   w_c = -lambda(kinematics consistency), w_com = -lambda(com consistency)
+template <class Em> HD void t_hess_Y(HCtx<Em>& h, int j) {
+    Ctx<Em>& cx = h.cx;
+    KnotScratch& s = cx.s;
+    const double* lam = h.hx.lam;
+    const double* a = s.aw[j];
+    const double* o = s.ow[j + 1];
+    double Y[3] = {0.0, 0.0, 0.0}, t1[3], t2[3];
+    {   // com: d com / d s_j = a_j x (h_sub - m_sub o_j) / M
+        const double* cp = s.comp[j + 1];
+        const double inv_M = 1.0 / cx.kt.total_mass;
+        for (int r = 0; r < 3; ++r) t1[r] = (cp[CH + r] - cp[CM] * o[r]) * inv_M;
+        cross3(a, t1, t2);
+        const double w[3] = {-lam[gs::COMC], -lam[gs::COMC + 1], -lam[gs::COMC + 2]};
+        cross3(t2, w, t1);
+        for (int r = 0; r < 3; ++r) Y[r] += t1[r];
+    }
+    for (int foot = 0; foot < 2; ++foot) {
+        if (cx.kt.leg_pos[foot][j] < 0) continue;
+        for (int c = 4 * foot; c < 4 * foot + 4; ++c) {
+            for (int r = 0; r < 3; ++r) t1[r] = s.pkin[c][r] - o[r];
+            cross3(a, t1, t2);
+            const double* lk = lam + gs::PT_STRIDE * c + gs::KINC;
+            const double w[3] = {-lk[0], -lk[1], -lk[2]};
+            cross3(t2, w, t1);
+            for (int r = 0; r < 3; ++r) Y[r] += t1[r];
+        }
+    }
+    if (cx.kt.chest_pos[j] >= 0) {
+        double E[9], Ea[3];
+        chest_error(s, E);
+        const double trE = E[0] + E[4] + E[8], e = trE - 3.0;
+        const double ax[3] = {E[7] - E[5], E[2] - E[6], E[3] - E[1]};
+        matvec3(E, a, Ea);
+        const double de = -dot3(ax, a);                     // d e / d s_j
+        const double m2 = 2.0 * h.hx.sigma * cx.st.m_frameq;
+        for (int r = 0; r < 3; ++r) Y[r] += m2 * (e * (Ea[r] - trE * a[r]) + de * (-ax[r]));
+    }
+    for (int r = 0; r < 3; ++r) h.hx.Y[j][r] = Y[r];
+}
+
+// --- (s_j, s_i), i ancestor-or-self of j: lanes over the lower triangle ---------------------------------------------------------
+constexpr int HESS_SS_TASKS = NJ * (NJ + 1) / 2;
+template <class Em> HD void t_hess_ss(HCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    int j = 0;
+    while ((j + 1) * (j + 2) / 2 <= t) ++j;
+    const int i = t - j * (j + 1) / 2;
+    bool anc = false;
+    for (int q = 0; q < 8; ++q) anc = anc || (int(cx.kt.anc[j][q]) == i);
+    if (!anc) return;
+    double v = dot3(cx.s.aw[i], h.hx.Y[j]);
+    if (i == j) v += 2.0 * h.hx.sigma * cx.st.m_jreg * cx.st.w_jreg[j];
+    cx.em.H(hs::SS + t, pv::S + j, pv::S + i, v);
+}
+
+// --- (s_j, q_l): lanes (j, l) ---------------------------------------------------------------------------------------------------
+template <class Em> HD void t_hess_qs(HCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    const KnotScratch& s = cx.s;
+    const int j = t >> 2, l = t & 3;
+    const double* Y = h.hx.Y[j];
+    cx.em.H(hs::QS + t, pv::S + j, pv::QB + l, (s.G[l] * Y[0] + s.G[4 + l] * Y[1] + s.G[8 + l] * Y[2]) * s.inv_qnorm);
+}
+
+// --- (q_b, q_b): lanes over the lower triangle (10); every lane forms the small matrices itself ------------------------------------
+//   F(q) = <M, R(q / |q|)>,  R(qh) = I + 2 w [v]x + 2 [v]x^2:  Phi(qh) = tr M + 2 w v.ax(M) + 2 v^T M v - 2 (v.v) tr M
+//   Hess_q F = J B J + ( -(g qh^T + qh g^T + (g.qh) I) + 3 (g.qh) qh qh^T ) / |q|^2,   J = (I - qh qh^T) / |q|,  g, B = gradient, Hessian of Phi
+template <class Em> HD void t_hess_qq(HCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    const KnotScratch& s = cx.s;
+    const double* lam = h.hx.lam;
+    const double sigma = h.hx.sigma;
+    int r = 0;
+    while ((r + 1) * (r + 2) / 2 <= t) ++r;
+    const int c = t - r * (r + 1) / 2;
+    double E[9];
+    chest_error(s, E);
+    const double trE = E[0] + E[4] + E[8], e = trE - 3.0;
+    const double axE[3] = {E[7] - E[5], E[2] - E[6], E[3] - E[1]};
+    const double m2 = 2.0 * sigma * cx.st.m_frameq;
+    // Mw = sum_c w_c pkin_c^T + w_com com^T + sigma 2 m e E^T  (world frame);  M = Mw R_b
+    double Mw[9], M[9];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            double acc = -lam[gs::COMC + a] * s.com[b] + m2 * e * E[3 * b + a];
+            for (int p = 0; p < NC; ++p) acc += -lam[gs::PT_STRIDE * p + gs::KINC + a] * s.pkin[p][b];
+            Mw[3 * a + b] = acc;
+        }
+    matmul3(Mw, s.Rb, M);
+    const double trM = M[0] + M[4] + M[8];
+    const double al[3] = {M[7] - M[5], M[2] - M[6], M[3] - M[1]};
+    const double* qh = s.qn;
+    const double inv_n = s.inv_qnorm;
+    double B[16], g[4];
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) B[4 * a + b] = 2.0 * (M[3 * a + b] + M[3 * b + a]) - (a == b ? 4.0 * trM : 0.0);
+        B[4 * a + 3] = B[12 + a] = 2.0 * al[a];
+    }
+    B[15] = 0.0;
+    for (int a = 0; a < 3; ++a) g[a] = 2.0 * qh[3] * al[a] + B[4 * a] * qh[0] + B[4 * a + 1] * qh[1] + B[4 * a + 2] * qh[2];
+    g[3] = 2.0 * (qh[0] * al[0] + qh[1] * al[1] + qh[2] * al[2]);
+    const double gq = g[0] * qh[0] + g[1] * qh[1] + g[2] * qh[2] + g[3] * qh[3];
+    // (J B J)(r, c) with J = (I - qh qh^T)/|q|:  rows of J
+    double Jr[4], Jc[4], BJc[4];
+    for (int a = 0; a < 4; ++a) { Jr[a] = ((a == r ? 1.0 : 0.0) - qh[r] * qh[a]) * inv_n; Jc[a] = ((a == c ? 1.0 : 0.0) - qh[c] * qh[a]) * inv_n; }
+    for (int a = 0; a < 4; ++a) BJc[a] = B[4 * a] * Jc[0] + B[4 * a + 1] * Jc[1] + B[4 * a + 2] * Jc[2] + B[4 * a + 3] * Jc[3];
+    double v = Jr[0] * BJc[0] + Jr[1] * BJc[1] + Jr[2] * BJc[2] + Jr[3] * BJc[3];
+    v += (-(g[r] * qh[c] + qh[r] * g[c] + (r == c ? gq : 0.0)) + 3.0 * gq * qh[r] * qh[c]) * (inv_n * inv_n);
+    // chest cost, outer product part: d e / d q_l = -(ax(E) . G_l) / |q|
+    const double ger = -(axE[0] * s.G[r] + axE[1] * s.G[4 + r] + axE[2] * s.G[8 + r]) * inv_n;
+    const double gec = -(axE[0] * s.G[c] + axE[1] * s.G[4 + c] + axE[2] * s.G[8 + c]) * inv_n;
+    v += m2 * ger * gec;
+    if (r == c) {
+        const double* qd = s.pk + PK_REF + R_BQ;   // base quaternion error is linear in q: Hessian 2 m |q_d|^2 I  (E13)
+        v += 2.0 * lam[gs::UNITQ] + 2.0 * sigma * cx.st.m_baseq * (qd[0] * qd[0] + qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3]);
+    }
+    cx.em.H(hs::QQ + t, pv::QB + r, pv::QB + c, v);
+}
+
+// The Hessian tasks, run behind HIPNLP_POSE_PROGRAM (RH(w, fn, n): tasks 0..n-1 of fn on wave w)
+#define HIPNLP_POSE_HESS_PROGRAM(RH, BARRIER)                                             \
+    RH(0, t_hess_point, NC) RH(1, t_hess_misc, HESS_MISC_TASKS) RH(2, t_hess_Y, NJ) RH(3, t_hess_qq, 10) \
+    BARRIER                                                                               \
+    RH(0, t_hess_ss, HESS_SS_TASKS) RH(1, t_hess_qs, 4 * NJ)                              \
+    BARRIER
+
+}  // namespace hipnlp

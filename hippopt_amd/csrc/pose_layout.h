@@ -2,7 +2,7 @@
 // (turnkey_planners/humanoid_pose_finder/planner.py:360-399), native slot -> row / CCS position tables, bounds, parameters.
 #pragma once
 #include "layout.h"
-#include "pose_body.h"
+#include "pose_hess_body.h"
 
 namespace hipnlp {
 
@@ -21,6 +21,10 @@ struct PoseLayout {
     std::vector<int32_t> g_row;      // [gs::COUNT] row of the native slot or -1
     std::vector<int32_t> jperm;      // CCS position -> native jac slot
     std::vector<int32_t> irow, jcol;
+    // Hessian of the Lagrangian (pose_hess_body.h): lower triangle, CCS order
+    int hnnz = 0;
+    std::vector<int32_t> hperm;      // CCS position -> native Hessian slot
+    std::vector<int32_t> hrow, hcol;
     std::string error;
 
     static std::string point_name(int c) { return std::string("state.contact_points.") + (c < 4 ? "left[" : "right[") + std::to_string(c % 4) + "]"; }
@@ -79,7 +83,7 @@ struct PoseLayout {
             if (mode == HIPNLP_EXPR_SUBJECT_TO) add(RK_PPREG, c, point_name(c) + ".p_regularization", 1);
         }
         // ---- record the native slots of the pose program ------------------------------------------------------
-        std::vector<int> grow(gs::COUNT, -1), jrid(js::COUNT, -1), jc(js::COUNT, -1);
+        std::vector<int> grow(gs::COUNT, -1), jrid(js::COUNT, -1), jc(js::COUNT, -1), hr(hs::COUNT, -1), hc(hs::COUNT, -1);
         bool dup = false;
         {
             KnotScratch* s = new KnotScratch();
@@ -89,11 +93,18 @@ struct PoseLayout {
             GParams gp{};
             gp.mass = 1.0;
             KnotInfo ki{1, 3, 0, 0};
-            RecordEm em{grow.data(), jrid.data(), jc.data(), &dup};
+            RecordEm em{grow.data(), jrid.data(), jc.data(), &dup, hr.data(), hc.data()};
             Ctx<RecordEm> cx(*s, kt, ks, gp, ki, em);
 #define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
             HIPNLP_POSE_PROGRAM(HOST_R, )
 #undef HOST_R
+            HessScratch* hx = new HessScratch();
+            std::fill(reinterpret_cast<double*>(hx), reinterpret_cast<double*>(hx) + sizeof(HessScratch) / sizeof(double), 1.0);
+            HCtx<RecordEm> hcx{cx, *hx};
+#define HOST_RH(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(hcx, t_);
+            HIPNLP_POSE_HESS_PROGRAM(HOST_RH, )
+#undef HOST_RH
+            delete hx;
             delete s;
         }
         if (dup) { error = "internal: native slot emitted twice"; return false; }
@@ -113,6 +124,18 @@ struct PoseLayout {
         jperm.clear(); irow.clear(); jcol.clear();
         for (auto& e : ent) { jperm.push_back(e.second); jcol.push_back(e.first.first); irow.push_back(e.first.second); }
         nnz = int(ent.size());
+        // Hessian pattern: lower triangle, column major, every entry produced by exactly one slot
+        std::vector<std::pair<std::pair<int, int>, int>> hent;
+        for (int slot = 0; slot < hs::COUNT; ++slot) {
+            if (hr[size_t(slot)] < 0) continue;
+            if (hr[size_t(slot)] < hc[size_t(slot)] || hr[size_t(slot)] >= POSE_NX) { error = "internal: Hessian entry outside the lower triangle"; return false; }
+            hent.push_back({{hc[size_t(slot)], hr[size_t(slot)]}, slot});
+        }
+        std::sort(hent.begin(), hent.end());
+        for (size_t i = 1; i < hent.size(); ++i) if (hent[i].first == hent[i - 1].first) { error = "internal: duplicate Hessian entry"; return false; }
+        hperm.clear(); hrow.clear(); hcol.clear();
+        for (auto& e : hent) { hperm.push_back(e.second); hcol.push_back(e.first.first); hrow.push_back(e.first.second); }
+        hnnz = int(hent.size());
         // every row of the directory must be produced by exactly one slot
         std::vector<int> seen(size_t(m), 0);
         for (int slot = 0; slot < gs::COUNT; ++slot) if (g_row[size_t(slot)] >= 0) seen[size_t(g_row[size_t(slot)])]++;

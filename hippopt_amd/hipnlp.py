@@ -22,6 +22,7 @@ EXPORTS = [
     "hipnlp_pose_create", "hipnlp_pose_destroy", "hipnlp_pose_last_error", "hipnlp_pose_get_dims", "hipnlp_pose_set_params",
     "hipnlp_pose_bounds", "hipnlp_pose_sparsity", "hipnlp_pose_eval", "hipnlp_pose_eval_device", "hipnlp_pose_cost_terms",
     "hipnlp_pose_cost_term_name", "hipnlp_pose_num_row_blocks", "hipnlp_pose_row_block", "hipnlp_pose_last_kernel_ms",
+    "hipnlp_pose_hess_nnz", "hipnlp_pose_hess_sparsity", "hipnlp_pose_eval_hess", "hipnlp_pose_eval_hess_device",
 ]
 G_STAGE = 550
 
@@ -272,6 +273,30 @@ class HipPose:
 
     def eval_device(self, x_ptr, f_ptr, grad_ptr, g_ptr, jac_ptr, stream=None):
         self._check(self.lib.hipnlp_pose_eval_device(self.h, x_ptr, f_ptr, grad_ptr, g_ptr, jac_ptr, stream))
+
+    # ---- exact Hessian of the Lagrangian (IPOPT eval_h): lower triangle, column major ------------------------------------
+    def hess_sparsity(self):
+        n = C.c_int32()
+        self._check(self.lib.hipnlp_pose_hess_nnz(self.h, C.byref(n)))
+        ir, jc = np.zeros(n.value, np.int32), np.zeros(n.value, np.int32)
+        self._check(self.lib.hipnlp_pose_hess_sparsity(self.h, _ip(ir), _ip(jc)))
+        return ir, jc
+
+    def eval_hess(self, x, obj_factor, lam):
+        """values [batch][nnz_h] of  obj_factor * hess f + sum_r lam_r hess g_r  at x (obj_factor: scalar or [batch])"""
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.batch, self.n)
+        lam = np.ascontiguousarray(lam, dtype=np.float64).reshape(self.batch, self.m)
+        sig = np.ascontiguousarray(np.broadcast_to(np.asarray(obj_factor, dtype=np.float64), (self.batch,)))
+        if not hasattr(self, "_hnnz"):
+            n = C.c_int32()
+            self._check(self.lib.hipnlp_pose_hess_nnz(self.h, C.byref(n)))
+            self._hnnz = n.value
+        out = np.zeros((self.batch, self._hnnz))
+        self._check(self.lib.hipnlp_pose_eval_hess(self.h, _dp(x), _dp(sig), _dp(lam), _dp(out)))
+        return out
+
+    def eval_hess_device(self, x_ptr, obj_factor_ptr, lam_ptr, hess_ptr, stream=None):
+        self._check(self.lib.hipnlp_pose_eval_hess_device(self.h, x_ptr, obj_factor_ptr, lam_ptr, hess_ptr, stream))
 
     def cost_terms(self):
         names = [self.lib.hipnlp_pose_cost_term_name(i).decode() for i in range(_abi.POSE_NCOST_TERMS)]

@@ -304,6 +304,18 @@ int hipnlp_pose_sparsity(const hipnlp_pose_handle* h, int32_t* irow, int32_t* jc
 int hipnlp_pose_eval(hipnlp_pose_handle* h, const double* x, double* f, double* grad_f, double* g, double* jac);
 int hipnlp_pose_eval_device(hipnlp_pose_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev,
                             double* jac_dev, void* stream);
+/* Exact Hessian of the Lagrangian  obj_factor * f(x) + lambda^T g(x)  (IPOPT eval_h: bool eval_h(n, x, new_x, obj_factor, m,
+ * lambda, new_lambda, nele_hess, iRow, jCol, values, ud)).  The reference reaches it through CasADi's nlp_hess_l: the pose finder
+ * runs IPOPT with its default exact-Hessian option (humanoid_pose_finder/main.py:101 `casadi_solver_options = {}`,
+ * planner.py:334-339 -> base/opti_solver.py:123-125,479).  Lower triangle (irow >= jcol), column major, fixed pattern:
+ *   hipnlp_pose_hess_nnz / _sparsity   structure (the `values == NULL` call of eval_h)
+ *   hipnlp_pose_eval_hess              host buffers: x [batch][81], obj_factor [batch], lambda [batch][m] -> hess [batch][nnz_h]
+ *   hipnlp_pose_eval_hess_device       device pointers, enqueued on `stream`, not synchronised                                  */
+int hipnlp_pose_hess_nnz(const hipnlp_pose_handle* h, int32_t* nnz_h);
+int hipnlp_pose_hess_sparsity(const hipnlp_pose_handle* h, int32_t* irow, int32_t* jcol);
+int hipnlp_pose_eval_hess(hipnlp_pose_handle* h, const double* x, const double* obj_factor, const double* lambda, double* hess);
+int hipnlp_pose_eval_hess_device(hipnlp_pose_handle* h, const double* x_dev, const double* obj_factor_dev, const double* lambda_dev,
+                                 double* hess_dev, void* stream);
 int hipnlp_pose_cost_terms(hipnlp_pose_handle* h, double* values /*[batch][HIPNLP_POSE_NCOST_TERMS]*/);
 const char* hipnlp_pose_cost_term_name(int i);
 int hipnlp_pose_num_row_blocks(const hipnlp_pose_handle* h);

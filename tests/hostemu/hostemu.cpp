@@ -15,8 +15,10 @@ struct ValueEm {
     static constexpr int kTerrain = -1;
     double* g;
     double* jac;
+    double* hess = nullptr;
     void G(int slot, int, double v) { g[slot] = v; }
     void J(int slot, int, int, double v) { jac[slot] = v; }
+    void H(int slot, int, int, double v) { hess[slot] = v; }
 };
 
 struct hostemu_handle {
@@ -157,6 +159,40 @@ void hostemu_pose_eval(const hostemu_pose_handle* h, const double* x, const doub
     double ft = 0.0;
     for (int t = 0; t < POSE_NCT; ++t) { cost_terms[t] = pose_cost_term(*s, t); ft += cost_terms[t]; }
     *f = ft;
+    delete s;
+}
+void hostemu_pose_hess_dims(const hostemu_pose_handle* h, int* hnnz) { *hnnz = h->L.hnnz; }
+void hostemu_pose_hess_sparsity(const hostemu_pose_handle* h, int* irow, int* jcol) {
+    for (int i = 0; i < h->L.hnnz; ++i) { irow[i] = h->L.hrow[size_t(i)]; jcol[i] = h->L.hcol[size_t(i)]; }
+}
+// the Hessian tasks of pose_hess_body.h behind the pose program, copy-out of hipnlp_pose_hess_kernel
+void hostemu_pose_hess(const hostemu_pose_handle* h, const double* x, const double* p, double sigma, const double* lambda, double* hess) {
+    const PoseLayout& L = h->L;
+    double pk[PK_STRIDE], xr[64];
+    GParams gp;
+    pack_pose_params(p, pk, xr, gp);
+    KnotScratch* s = new KnotScratch();
+    HessScratch* hx = new HessScratch();
+    std::fill(reinterpret_cast<double*>(s), reinterpret_cast<double*>(s) + sizeof(KnotScratch) / sizeof(double), std::nan(""));
+    std::fill(reinterpret_cast<double*>(hx), reinterpret_cast<double*>(hx) + sizeof(HessScratch) / sizeof(double), std::nan(""));
+    for (int i = 0; i < XPAD; ++i) { s->x[i] = 0; s->xm[i] = 0; s->xo[i] = 0; }
+    for (int i = 0; i < POSE_NX; ++i) s->x[pose_to_knot_col(i)] = x[i];
+    for (int i = 0; i < 64; ++i) s->xm[i] = xr[i];
+    for (int i = 0; i < PK_STRIDE; ++i) s->pk[i] = pk[i];
+    for (int slot = 0; slot < gs::COUNT; ++slot) hx->lam[slot] = L.g_row[size_t(slot)] >= 0 ? lambda[L.g_row[size_t(slot)]] : 0.0;
+    hx->sigma = sigma;
+    KnotInfo ki{1, 3, 0, 0};
+    ValueEm em{s->g, s->jac, hx->H};
+    Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
+#define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
+    HIPNLP_POSE_PROGRAM(HOST_R, )
+#undef HOST_R
+    HCtx<ValueEm> hcx{cx, *hx};
+#define HOST_RH(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(hcx, t_);
+    HIPNLP_POSE_HESS_PROGRAM(HOST_RH, )
+#undef HOST_RH
+    for (int e = 0; e < L.hnnz; ++e) hess[e] = hx->H[L.hperm[size_t(e)]];
+    delete hx;
     delete s;
 }
 }  // extern "C"

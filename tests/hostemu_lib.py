@@ -10,7 +10,7 @@ from hippopt_amd import _abi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = os.path.join(ROOT, "tests", "_build", "libhipnlp_hostemu.so")
 SRC = [os.path.join(ROOT, "tests", "hostemu", "hostemu.cpp")] + [
-    os.path.join(ROOT, "hippopt_amd", "csrc", f) for f in ("layout.h", "knot_body.h", "nlp_defs.h", "pose_body.h", "pose_layout.h")]
+    os.path.join(ROOT, "hippopt_amd", "csrc", f) for f in ("layout.h", "knot_body.h", "nlp_defs.h", "pose_body.h", "pose_hess_body.h", "pose_layout.h")]
 
 
 def build():
@@ -115,3 +115,17 @@ class PoseHostEmu:
         self.lib.hostemu_pose_eval(C.c_void_p(self.h), _dp(np.ascontiguousarray(x)), _dp(np.ascontiguousarray(p)),
                                    C.byref(f), _dp(grad), _dp(g), _dp(jac), _dp(ct))
         return f.value, grad, g, jac, ct
+
+    def hess_sparsity(self):
+        n = C.c_int()
+        self.lib.hostemu_pose_hess_dims(C.c_void_p(self.h), C.byref(n))
+        ir, jc = np.zeros(n.value, np.int32), np.zeros(n.value, np.int32)
+        self.lib.hostemu_pose_hess_sparsity(C.c_void_p(self.h), _ip(ir), _ip(jc))
+        return ir, jc
+
+    def hess(self, x, p, sigma, lam):
+        ir, _ = self.hess_sparsity()
+        out = np.full(ir.size, np.nan)
+        self.lib.hostemu_pose_hess(C.c_void_p(self.h), _dp(np.ascontiguousarray(x)), _dp(np.ascontiguousarray(p)), C.c_double(sigma),
+                                   _dp(np.ascontiguousarray(lam, dtype=float)), _dp(out))
+        return out

@@ -141,3 +141,72 @@ def test_pose_planner_solves(model):
     assert pl.optimization_solver._last_info["constr_violation"] < 0.5 * viol0
     f_out = np.asarray(out.values.state.contact_points.left[0].f).reshape(-1)
     assert np.all(np.isfinite(f_out))
+
+
+# ---- exact Hessian of the Lagrangian (IPOPT eval_h) through the C-ABI --------------------------------------------------------
+@pytest.mark.parametrize("name", ["default", "constrained", "steps"])
+def test_pose_hessian_matches_oracle(model, name):
+    from hippopt_amd.hipnlp import HipPose
+    from oracle_lib import PoseOracle
+    from test_pose_body_hostemu import flank_points, hess_check
+    st = variants(model)[name]
+    B = 6
+    x, p = make_pose_workload(st, model, B, 950)
+    if name == "steps":
+        flank_points(x[0], 4)
+        flank_points(x[1], 6)
+    eng, orc = HipPose(st, model, batch=B), PoseOracle(st, model)
+    eng.set_params(p)
+    ir, jc = eng.hess_sparsity()
+    rng = np.random.RandomState(8)
+    lam = rng.standard_normal((B, eng.m))
+    sig = rng.uniform(0.2, 2.0, B)
+    vals = eng.eval_hess(x, sig, lam)
+    for b in range(B):
+        hess_check(ir, jc, vals[b], orc.hess(x[b], p[b], float(sig[b]), lam[b]), 1e-10 if name == "steps" else TOL)
+    assert np.array_equal(vals, eng.eval_hess(x, sig, lam))     # bitwise reproducible
+    # the first-order callbacks are unaffected by a Hessian call in between
+    f, grad, g, jac = eng.eval(x)
+    fo, grado, go, jaco = orc.eval(x[2], p[2])
+    assert rel(f[2], fo) < TOL and rel(grad[2], grado) < TOL and rel(g[2], go) < TOL and rel(jac[2], jaco) < TOL
+
+
+@pytest.mark.parametrize("name", ["pose_default", "pose_step_constrained"])
+def test_pose_hessian_matches_reference_fixture(model, name):
+    from hippopt_amd.hipnlp import HipPose
+    from test_pose_body_hostemu import hess_check
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    st = pose_settings_for(json.loads(str(z["meta"])), model)
+    eng = HipPose(st, model)
+    eng.set_params(z["p"][None, :])
+    ir, jc = eng.hess_sparsity()
+    vals = eng.eval_hess(z["x"][None, :], float(z["hess_sigma"]), z["hess_lambda"][None, :])
+    hess_check(ir, jc, vals[0], z["hess"], 1e-10)
+
+
+def test_pose_hessian_large_batch_and_errors(model):
+    from hippopt_amd.hipnlp import HipNlpError, HipPose
+    from oracle_lib import PoseOracle
+    from test_pose_body_hostemu import hess_check
+    st = variants(model)["default"]
+    B = 2048
+    xs, ps = make_pose_workload(st, model, 16, 3)
+    xb, pb = np.tile(xs, (B // 16, 1)), np.tile(ps, (B // 16, 1))
+    rng = np.random.RandomState(1)
+    xb += 1e-3 * rng.standard_normal(xb.shape)
+    eng = HipPose(st, model, batch=B)
+    lam = rng.standard_normal((B, eng.m))
+    with pytest.raises(HipNlpError) as ei:
+        eng.eval_hess(xb, 1.0, lam)
+    assert ei.value.code == -4                      # parameters not set
+    eng.set_params(pb)
+    vals = eng.eval_hess(xb, 1.0, lam)
+    print("pose Hessian kernel, batch %d: %.3f ms" % (B, eng.last_kernel_ms()))
+    orc = PoseOracle(st, model)
+    ir, jc = eng.hess_sparsity()
+    for b in (0, 31, 1025, B - 1):
+        hess_check(ir, jc, vals[b], orc.hess(xb[b], pb[b], 1.0, lam[b]), TOL)
+    xb[3][51:55] = 0.0
+    with pytest.raises(HipNlpError) as ei:
+        eng.eval_hess(xb, 1.0, lam)
+    assert ei.value.code == -5

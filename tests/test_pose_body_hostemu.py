@@ -69,3 +69,60 @@ def test_pose_body_matches_reference_fixture(model, name):
     lb, ub = e.bounds(z["p"])
     ir, jc = e.sparsity()
     check_against_fixture(z, ir, jc, f, grad, g, jac, lb, ub, tol=1e-10)
+
+
+# ---- exact Hessian of the Lagrangian (pose_hess_body.h) -------------------------------------------------------------------
+def hess_check(ir, jc, vals, Href, tol):
+    """vals on the lower-triangle pattern (ir >= jc, column major) against a dense symmetric reference"""
+    assert np.all(ir >= jc)
+    assert np.array_equal(np.lexsort((ir, jc)), np.arange(ir.size))           # CCS order, no duplicates
+    assert len(set(zip(ir.tolist(), jc.tolist()))) == ir.size
+    H = np.zeros_like(Href)
+    H[ir, jc] = vals
+    L = np.tril(Href)
+    scale = np.maximum(1.0, np.abs(L))
+    assert np.max(np.abs(H - L) / scale) < tol
+    inside = np.zeros_like(Href, bool)
+    inside[ir, jc] = True
+    assert np.max(np.abs(L[~inside]), initial=0.0) == 0.0                        # nothing outside the pattern
+
+
+def flank_points(x, seed):
+    rng = np.random.RandomState(seed)
+    for c in range(8):
+        x[6 * c] = 0.45 + rng.choice([-1.0, 1.0]) * 0.3 * rng.uniform(0.95, 1.01)
+        x[6 * c + 1] = 0.3 * rng.uniform(-1, 1)
+        x[6 * c + 2] = 0.1 + 0.05 * rng.standard_normal()
+
+
+@pytest.mark.parametrize("name", ["default", "constrained", "steps"])
+def test_pose_hessian_body_matches_oracle(model, name):
+    st = variants(model)[name]
+    o, e = PoseOracle(st, model), PoseHostEmu(st, model)
+    ir, jc = e.hess_sparsity()
+    x, p = make_pose_workload(st, model, 3, 900)
+    if name == "steps":
+        flank_points(x[0], 4)
+    rng = np.random.RandomState(5)
+    pattern = np.zeros((o.n, o.n), bool)
+    for b in range(3):
+        lam, sigma = rng.standard_normal(o.m), float(rng.uniform(0.2, 2.0))
+        Href = o.hess(x[b], p[b], sigma, lam)
+        vals = e.hess(x[b], p[b], sigma, lam)
+        assert not np.isnan(vals).any()
+        hess_check(ir, jc, vals, Href, 1e-10 if name == "steps" else TOL)
+        pattern |= np.tril(Href) != 0.0
+    # the pattern is tight: every entry of it is non-zero at some sample
+    mine = np.zeros_like(pattern)
+    mine[ir, jc] = True
+    assert np.array_equal(mine, pattern)
+
+
+@pytest.mark.parametrize("name", ["pose_default", "pose_step_constrained"])
+def test_pose_hessian_body_matches_reference_fixture(model, name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    st = pose_settings_for(json.loads(str(z["meta"])), model)
+    e = PoseHostEmu(st, model)
+    ir, jc = e.hess_sparsity()
+    vals = e.hess(z["x"], z["p"], float(z["hess_sigma"]), z["hess_lambda"])
+    hess_check(ir, jc, vals, z["hess"], 1e-10)
