@@ -60,6 +60,14 @@ class _PoseEngine:
     def row_blocks(self):
         return [(name, first, rows, 0, 1) for name, first, rows in self._pose.row_blocks()]
 
+    # exact Hessian of the Lagrangian (the reference pose finder runs IPOPT with its default exact-Hessian option,
+    # humanoid_pose_finder/main.py:101): lower triangle (row >= col)
+    def hess_sparsity(self):
+        return self._pose.hess_sparsity()
+
+    def eval_hess(self, x, obj_factor, lam):
+        return self._pose.eval_hess(x, obj_factor, lam)[0]
+
 
 class HipNlpSolver:
     def __init__(self, settings, model, device=0, inner_solver="auto", options_solver=None, problem="kinodynamic",
@@ -295,13 +303,24 @@ class HipNlpSolver:
         def jac(x):
             _, _, _, j = eng.eval(x[None, :], want=("jac",))
             return csc_matrix((j[0], (ir, jc)), shape=(m, n))
-        nlc = NonlinearConstraint(cons, lbg, ubg, jac=jac, hess=BFGS())
+        exact = hasattr(eng, "eval_hess") and self._options.get("hessian_approximation", "exact") != "limited-memory"
+        hess_f, hess_c = BFGS(), BFGS()
+        if exact:   # exact second derivatives from the engine (lower triangle -> symmetric matrix)
+            hr, hc = eng.hess_sparsity()
+            off = hr != hc
+
+            def sym(vals):
+                return csc_matrix((np.concatenate([vals, vals[off]]), (np.concatenate([hr, hc[off]]), np.concatenate([hc, hr[off]]))), shape=(n, n))
+            zero_lam = np.zeros(m)
+            hess_f = lambda x: sym(eng.eval_hess(x[None, :], 1.0, zero_lam[None, :]))      # noqa: E731
+            hess_c = lambda x, v: sym(eng.eval_hess(x[None, :], 0.0, np.asarray(v)[None, :]))  # noqa: E731
+        nlc = NonlinearConstraint(cons, lbg, ubg, jac=jac, hess=hess_c)
         opts = {"maxiter": int(self._options.get("max_iter", 50)), "verbose": int(self._options.get("verbose", 0)),
                 "gtol": float(self._options.get("tol", 1e-6))}
         def on_iterate(xk, state):
             self._iterate_callback(state.nit, xk, state.fun, state.constr_violation, state.v[0] if len(state.v) else None)
             return False
-        res = minimize(fun, x0, jac=grad, hess=BFGS(), constraints=[nlc], method="trust-constr", options=opts, callback=on_iterate)
+        res = minimize(fun, x0, jac=grad, hess=hess_f, constraints=[nlc], method="trust-constr", options=opts, callback=on_iterate)
         lam = res.v[0] if len(res.v) else np.zeros(m)
         return res.x, lam, {"status": res.status, "success": res.status in (1, 2), "message": res.message, "iterations": res.nit,
                             "constr_violation": res.constr_violation}
@@ -338,8 +357,14 @@ class HipNlpSolver:
                     pass
                 outer._iterate_callback(iter_count, x_it, obj_value, inf_pr, lam_it)
                 return True
+        exact = hasattr(eng, "eval_hess") and outer._options.get("hessian_approximation", "exact") != "limited-memory"
+        if exact:   # eval_h from the engine: the pose finder runs IPOPT with the exact Hessian (humanoid_pose_finder/main.py:101)
+            hr, hc = eng.hess_sparsity()
+            Callbacks.hessianstructure = lambda self: (hr, hc)
+            Callbacks.hessian = lambda self, x, lagrange, obj_factor: eng.eval_hess(x[None, :], obj_factor, np.asarray(lagrange)[None, :])
         nlp = cyipopt.Problem(n=eng.n, m=eng.m, problem_obj=Callbacks(), lb=lbx, ub=ubx, cl=lbg, cu=ubg)
-        nlp.add_option("hessian_approximation", "limited-memory")  # main_periodic_step.py:116
+        if not exact:
+            nlp.add_option("hessian_approximation", "limited-memory")  # main_periodic_step.py:116
         for k, v in outer._options.items():
             nlp.add_option(k, v)
         x, info = nlp.solve(x0)
