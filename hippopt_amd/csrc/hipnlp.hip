@@ -28,8 +28,7 @@ namespace {
 static_assert(gs::COUNT == HIPNLP_G_STAGE, "HIPNLP_G_STAGE must equal the native g slot count");
 
 struct DeviceTables {
-    KinTables kt;
-    KSettings ks;
+    HeadTables head;
     int32_t g_a[3][gs::COUNT];
     int32_t g_b[gs::COUNT];
     int32_t jperm[3][js::COUNT];
@@ -48,7 +47,7 @@ struct KArgs {
     double* grad;           // [batch][n]      or null
     double* g_stage;        // [batch][nk][gs::COUNT] knot-major staging of g (sharded mode) or null
     double* cost_knot;      // [batch][nk][NCT]
-    int32_t* flags;         // [batch][nk]  non-finite detector
+    int32_t* flags;         // [batch][nk][8]  non-finite detector, one word per wavefront (no workgroup vote at the end)
     int32_t N, n, m, nnz, knot_begin, nk;
     int64_t jac_stride, jac_off, grad_stride, grad_off;  // output addressing: full arrays (stride nnz / n, offset 0) or shard-local
 #ifdef HIPNLP_STAMPS
@@ -66,8 +65,7 @@ template <int TERRAIN> struct DevEm {
 
 // LDS image of the read-only tables every phase indexes per lane (global memory would cost one L2 round trip per phase)
 struct SharedTables {
-    KinTables kt;
-    KSettings ks;
+    HeadTables head;
     GParams gp;
 };
 
@@ -80,6 +78,9 @@ void hipnlp_knot_kernel(KArgs a) {
     constexpr int WG = 64 * WAVES;
     __shared__ KnotScratch s;
     __shared__ SharedTables tabs;
+#ifdef HIPNLP_STAMPS
+    const unsigned long long st_entry = __builtin_amdgcn_s_memtime(), st_real0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int kk = blockIdx.x, b = blockIdx.y;
     const int k = a.knot_begin + kk;
@@ -87,33 +88,52 @@ void hipnlp_knot_kernel(KArgs a) {
     const double* x = a.x + size_t(b) * a.n;
     const int first = k == 0, last = k == N - 1;
     const DeviceTables& tb = *a.tb;
-    // ---- stage the knot records and the tables in LDS (coalesced: consecutive lanes read consecutive words) ----
+    // ---- stage the knot records and the tables in LDS.  Every global load is issued before the first LDS store waits for
+    // one (compile-time trip counts, 16-byte words): ONE memory round trip instead of one per loop iteration.
     {
-        static_assert(sizeof(KinTables) % 4 == 0 && sizeof(KSettings) % 4 == 0 && sizeof(GParams) % 4 == 0, "word copy");
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(&tb.kt);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&tabs.kt);
-        for (int i = tid; i < int(sizeof(KinTables) / 4); i += WG) dst[i] = src[i];
-        src = reinterpret_cast<const uint32_t*>(&tb.ks);
-        dst = reinterpret_cast<uint32_t*>(&tabs.ks);
-        for (int i = tid; i < int(sizeof(KSettings) / 4); i += WG) dst[i] = src[i];
-        src = reinterpret_cast<const uint32_t*>(a.gp + b);
-        dst = reinterpret_cast<uint32_t*>(&tabs.gp);
-        for (int i = tid; i < int(sizeof(GParams) / 4); i += WG) dst[i] = src[i];
+        constexpr int HV = int(sizeof(HeadTables) / 16), HV_ITERS = (HV + WG - 1) / WG;
+        constexpr int GV = int(sizeof(GParams) / 8), GV_ITERS = (GV + WG - 1) / WG;
+        constexpr int XV_ITERS = (XPAD + WG - 1) / WG;
+        static_assert(PK_STRIDE <= WG && NXG <= 8, "one parameter word per thread");
+        const uint4* hsrc = reinterpret_cast<const uint4*>(&tb.head);
+        const double* gsrc = reinterpret_cast<const double*>(a.gp + b);
+        uint4 hv[HV_ITERS];
+        double gv[GV_ITERS], xv[XV_ITERS], xmv[XV_ITERS], xov[XV_ITERS];
+#pragma unroll
+        for (int it = 0; it < HV_ITERS; ++it) { const int i = tid + it * WG; hv[it] = i < HV ? hsrc[i] : uint4{0u, 0u, 0u, 0u}; }
+#pragma unroll
+        for (int it = 0; it < GV_ITERS; ++it) { const int i = tid + it * WG; gv[it] = i < GV ? gsrc[i] : 0.0; }
+#pragma unroll
+        for (int it = 0; it < XV_ITERS; ++it) {
+            const int i = tid + it * WG;
+            const bool in = i < NXK;
+            xv[it] = in ? x[size_t(NXK) * k + i] : 0.0;
+            xmv[it] = (in && !first) ? x[size_t(NXK) * (k - 1) + i] : 0.0;
+            xov[it] = (i < NPER && (first || last)) ? x[size_t(NXK) * (first ? N - 1 : 0) + periodicity_row_var(i)] : 0.0;
+        }
+        const double pkv = tid < PK_STRIDE ? a.pk[(size_t(b) * N + k) * PK_STRIDE + tid] : 0.0;
+        const double xgv = tid < NXG ? x[size_t(NXK) * N + tid] : 0.0;
+        uint4* hdst = reinterpret_cast<uint4*>(&tabs.head);
+        double* gdst = reinterpret_cast<double*>(&tabs.gp);
+#pragma unroll
+        for (int it = 0; it < HV_ITERS; ++it) { const int i = tid + it * WG; if (i < HV) hdst[i] = hv[it]; }
+#pragma unroll
+        for (int it = 0; it < GV_ITERS; ++it) { const int i = tid + it * WG; if (i < GV) gdst[i] = gv[it]; }
+#pragma unroll
+        for (int it = 0; it < XV_ITERS; ++it) { const int i = tid + it * WG; if (i < XPAD) { s.x[i] = xv[it]; s.xm[i] = xmv[it]; } if (i < NPER) s.xo[i] = xov[it]; }
+        if (tid < PK_STRIDE) s.pk[tid] = pkv;
+        if (tid < 8) s.xg[tid] = xgv;
     }
-    for (int i = tid; i < XPAD; i += WG) {
-        const bool in = i < NXK;
-        s.x[i] = in ? x[size_t(NXK) * k + i] : 0.0;
-        s.xm[i] = (in && !first) ? x[size_t(NXK) * (k - 1) + i] : 0.0;
-        s.xo[i] = (in && (first || last)) ? x[size_t(NXK) * (first ? N - 1 : 0) + i] : 0.0;
-    }
-    for (int i = tid; i < PK_STRIDE; i += WG) s.pk[i] = a.pk[(size_t(b) * N + k) * PK_STRIDE + i];
-    if (tid < 8) s.xg[tid] = tid < NXG ? x[size_t(NXK) * N + tid] : 0.0;
     __syncthreads();
 
     // copy-out tables of this knot's variant, fetched now so their latency hides behind the knot program
     const int v = first ? VAR_FIRST : (last ? VAR_LAST : VAR_INTERIOR);
     constexpr int JP_ITERS = (js::COUNT + WG - 1) / WG, G_ITERS = (gs::COUNT + WG - 1) / WG;
     const int jcnt = tb.nnz_v[v];
+    // everything the copy-out needs from the global tables, fetched here as well
+    const int64_t jbase = first ? 0 : int64_t(tb.nnz_v[VAR_FIRST]) + int64_t(k - 1) * tb.nnz_v[VAR_INTERIOR];
+    const int n_glob = last ? tb.n_glob : 0, jac_glob_base = tb.jac_glob_base;
+    const int jpg = (last && tid < 16) ? tb.jperm_glob[tid] : 0;
     int32_t jp[JP_ITERS], ga[G_ITERS], gb[G_ITERS];
 #pragma unroll
     for (int it = 0; it < JP_ITERS; ++it) { const int i = tid + it * WG; jp[it] = i < jcnt ? tb.jperm[v][i] : -1; }
@@ -126,19 +146,15 @@ void hipnlp_knot_kernel(KArgs a) {
 
     KnotInfo ki{k, N, first, last};
     DevEm<TERRAIN> em{s.g, s.jac};
-    Ctx<DevEm<TERRAIN>> cx(s, tabs.kt, tabs.ks, tabs.gp, ki, em);
+    Ctx<DevEm<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
 #define DEV_R(w4, w8, fn, nt) if (wave == (WAVES == 4 ? (w4) : (w8))) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #ifdef HIPNLP_STAMPS
-    // diagnostic build: every wave stamps the END of each task group it runs and its ARRIVAL at each barrier
-    // (before waiting).  Per wave 64 slots of {id, time}: id = group sequence number, or 1000 + barrier number.
-    int sidx = 0, gid = 0, bid = 0;
-    unsigned long long* stamp_out = a.stamps + ((size_t(blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 128;
-    if (lane == 0) { stamp_out[0] = 999; stamp_out[1] = __builtin_amdgcn_s_memtime(); }
-    sidx++;
-#undef DEV_R
-#define DEV_R(w4, w8, fn, nt) if (wave == (WAVES == 4 ? (w4) : (w8))) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); \
-        if (lane == 0 && sidx < 63) { stamp_out[2 * sidx] = gid; stamp_out[2 * sidx + 1] = __builtin_amdgcn_s_memtime(); } sidx++; } gid++;
-#define DEV_BARRIER if (lane == 0 && sidx < 63) { stamp_out[2 * sidx] = 1000 + bid; stamp_out[2 * sidx + 1] = __builtin_amdgcn_s_memtime(); } sidx++; bid++; __syncthreads();
+    // diagnostic build: every wave keeps, IN REGISTERS, its arrival time at each barrier and the time it leaves it; one store
+    // per wave at the very end (a store before a barrier would make the barrier wait for its acknowledgement).
+    unsigned long long st_arr[8], st_dep[8];
+    const unsigned long long st_staged = __builtin_amdgcn_s_memtime();
+    int bid = 0;
+#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); __syncthreads(); st_dep[bid] = __builtin_amdgcn_s_memtime(); bid++;
 #else
 #define DEV_BARRIER __syncthreads();
 #endif
@@ -147,68 +163,71 @@ void hipnlp_knot_kernel(KArgs a) {
 #undef DEV_BARRIER
 
     // ---- stream the knot's outputs ---------------------------------------------------------------------
+    // All LDS reads and the non-finite check come first, then nothing but stores; the non-finite flag is kept per wavefront
+    // (the reduction kernel ORs them), so no workgroup barrier stands between the last task and the stores.
     int bad = 0;
+    constexpr int GR_ITERS = (NXK + WG - 1) / WG;
+    double jvals[JP_ITERS], gvals[G_ITERS], grvals[GR_ITERS];
+    // (unconditional, clamped indices, no branch: every LDS read of the copy-out is in flight before the first wait)
+#pragma unroll
+    for (int it = 0; it < JP_ITERS; ++it) jvals[it] = s.jac[jp[it] >= 0 ? jp[it] : 0];
+#pragma unroll
+    for (int it = 0; it < G_ITERS; ++it) gvals[it] = s.g[(tid + it * WG) < gs::COUNT ? tid + it * WG : 0];
+#pragma unroll
+    for (int it = 0; it < GR_ITERS; ++it) grvals[it] = s.grad[(tid + it * WG) < NXK ? tid + it * WG : 0];
+    const double cval = s.cost[tid < NCT ? tid : 0];
+#pragma unroll
+    for (int it = 0; it < JP_ITERS; ++it) bad |= (jp[it] >= 0) & !isfinite(jvals[it]);
+#pragma unroll
+    for (int it = 0; it < G_ITERS; ++it) bad |= (ga[it] >= 0) & !isfinite(gvals[it]);
+#pragma unroll
+    for (int it = 0; it < GR_ITERS; ++it) bad |= ((tid + it * WG) < NXK) & !isfinite(grvals[it]);
+    bad |= (tid < NCT) & !isfinite(cval);
+    const int anybad = __any(bad);
+#ifdef HIPNLP_DIAG_SKIP
+    if (HIPNLP_DIAG_SKIP & 1) a.jac = nullptr;
+    if (HIPNLP_DIAG_SKIP & 2) a.g = nullptr;
+    if (HIPNLP_DIAG_SKIP & 4) a.grad = nullptr;
+#endif
     if (a.jac) {
-        const int64_t jbase = first ? 0 : int64_t(tb.nnz_v[VAR_FIRST]) + int64_t(k - 1) * tb.nnz_v[VAR_INTERIOR];
         double* out = a.jac + int64_t(b) * a.jac_stride + (jbase - a.jac_off);
-        // all LDS reads first (clamped index, no branch), ONE wait, then the predicated stores: a branch per entry would
-        // expose one LDS round trip per entry
-        double vals[JP_ITERS];
 #pragma unroll
-        for (int it = 0; it < JP_ITERS; ++it) vals[it] = s.jac[jp[it] >= 0 ? jp[it] : 0];
-#pragma unroll
-        for (int it = 0; it < JP_ITERS; ++it) {
-            if (jp[it] >= 0) {
-                bad |= !isfinite(vals[it]);
-                out[tid + it * WG] = vals[it];
-            }
-        }
+        for (int it = 0; it < JP_ITERS; ++it) if (jp[it] >= 0) out[tid + it * WG] = jvals[it];
         // entries in the horizon-global columns (constants) sit right behind the last knot's block: the last knot writes them
-        if (last && tid < tb.n_glob) a.jac[int64_t(b) * a.jac_stride + (int64_t(tb.jac_glob_base) - a.jac_off) + tid] = s.jac[tb.jperm_glob[tid]];
+        if (last && tid < n_glob) a.jac[int64_t(b) * a.jac_stride + (int64_t(jac_glob_base) - a.jac_off) + tid] = s.jac[jpg];
     }
     if (a.g) {
         double* out = a.g + size_t(b) * a.m;
-        double vals[G_ITERS];
 #pragma unroll
-        for (int it = 0; it < G_ITERS; ++it) vals[it] = s.g[(tid + it * WG) < gs::COUNT ? tid + it * WG : 0];
-#pragma unroll
-        for (int it = 0; it < G_ITERS; ++it) {
-            if (ga[it] >= 0) {
-                bad |= !isfinite(vals[it]);
-                out[ga[it] + gb[it] * k] = vals[it];
-            }
-        }
+        for (int it = 0; it < G_ITERS; ++it) if (ga[it] >= 0) out[ga[it] + gb[it] * k] = gvals[it];
     }
     if (a.g_stage) {
         double* out = a.g_stage + (size_t(b) * a.nk + kk) * gs::COUNT;
 #pragma unroll
         for (int it = 0; it < G_ITERS; ++it) {
             const int slot = tid + it * WG;
-            if (slot < gs::COUNT) {
-                const double val = ga[it] >= 0 ? s.g[slot] : 0.0;
-                bad |= !isfinite(val);
-                out[slot] = val;
-            }
+            if (slot < gs::COUNT) out[slot] = ga[it] >= 0 ? gvals[it] : 0.0;
         }
     }
     if (a.grad) {
         double* out = a.grad + int64_t(b) * a.grad_stride + (int64_t(NXK) * k - a.grad_off);
-        for (int i = tid; i < NXK; i += WG) {
-            const double val = s.grad[i];
-            bad |= !isfinite(val);
-            out[i] = val;
-        }
+#pragma unroll
+        for (int it = 0; it < GR_ITERS; ++it) { const int i = tid + it * WG; if (i < NXK) out[i] = grvals[it]; }
         if (last && tid < NXG) a.grad[int64_t(b) * a.grad_stride + (int64_t(NXK) * N - a.grad_off) + tid] = 0.0;  // the global variables carry no cost
     }
-    if (tid < NCT) {
-        const double val = s.cost[tid];
-        bad |= !isfinite(val);
-        a.cost_knot[(size_t(b) * a.nk + kk) * NCT + tid] = val;
-    }
-    const int anybad = __syncthreads_or(bad);
-    if (tid == 0) a.flags[size_t(b) * a.nk + kk] = anybad;
+    if (tid < NCT) a.cost_knot[(size_t(b) * a.nk + kk) * NCT + tid] = cval;
+    if (lane == 0) a.flags[(size_t(b) * a.nk + kk) * 8 + wave] = anybad;
+    if (WAVES == 4 && tid < 4) a.flags[(size_t(b) * a.nk + kk) * 8 + 4 + tid] = 0;
 #ifdef HIPNLP_STAMPS
-    if (lane == 0) { if (sidx < 63) { stamp_out[2 * sidx] = 2000; stamp_out[2 * sidx + 1] = __builtin_amdgcn_s_memtime(); } stamp_out[126] = (unsigned long long)(sidx + 1); }
+    {
+        st_arr[bid] = __builtin_amdgcn_s_memtime();   // after the vote and the store issue
+        unsigned long long* stamp_out = a.stamps + ((size_t(blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 128;
+        if (lane == 0) {
+            stamp_out[0] = st_entry; stamp_out[1] = st_staged; stamp_out[2] = (unsigned long long)bid;
+            for (int i = 0; i < 8; ++i) { stamp_out[8 + 2 * i] = i <= bid ? st_arr[i] : 0; stamp_out[9 + 2 * i] = i < bid ? st_dep[i] : 0; }
+            stamp_out[3] = st_real0; stamp_out[4] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
 #endif
 }
 
@@ -235,7 +254,12 @@ __global__ __launch_bounds__(RWG) void hipnlp_reduce_kernel(const double* cost_k
         for (int u = 0; u < RUNR; ++u) {
             const int k = k0 + u * RGRP;
             v[u] = (c < NCT && k < nk) ? cost_knot[(size_t(b) * nk + k) * NCT + c] : 0.0;
-            fl[u] = (c == NCT && k < nk) ? flags[size_t(b) * nk + k] : 0;
+            fl[u] = 0;
+            if (c == NCT && k < nk) {
+                const int4* fw = reinterpret_cast<const int4*>(flags + (size_t(b) * nk + k) * 8);
+                const int4 f0 = fw[0], f1 = fw[1];
+                fl[u] = f0.x | f0.y | f0.z | f0.w | f1.x | f1.y | f1.z | f1.w;
+            }
         }
 #pragma unroll
         for (int u = 0; u < RUNR; ++u) { acc += v[u]; bad |= fl[u]; }
@@ -367,7 +391,7 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     CREATE_TRY(hipMalloc(&h->d_f, B * sizeof(double)));
     CREATE_TRY(hipMalloc(&h->d_cost_knot, B * size_t(h->nk) * NCT * sizeof(double)));
     CREATE_TRY(hipMalloc(&h->d_cost_terms, B * NCT * sizeof(double)));
-    CREATE_TRY(hipMalloc(&h->d_flags, B * size_t(h->nk) * sizeof(int32_t)));
+    CREATE_TRY(hipMalloc(&h->d_flags, B * size_t(h->nk) * 8 * sizeof(int32_t)));
     CREATE_TRY(hipMalloc(&h->d_flag, B * sizeof(int32_t)));
     CREATE_TRY(hipHostMalloc(&h->h_x, B * n * sizeof(double)));
     CREATE_TRY(hipHostMalloc(&h->h_g, B * m * sizeof(double)));
@@ -382,8 +406,8 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     // tables
     DeviceTables* tb = new DeviceTables();
     std::memset(tb, 0, sizeof(DeviceTables));
-    tb->kt = h->kt;
-    tb->ks = Layout::make_ksettings(st);
+    tb->head.kt = h->kt;
+    tb->head.ks = Layout::make_ksettings(st);
     for (int v = 0; v < 3; ++v) {
         for (int s = 0; s < gs::COUNT; ++s) tb->g_a[v][s] = h->L.g_a[v][size_t(s)];
         for (size_t i = 0; i < h->L.jperm[v].size(); ++i) tb->jperm[v][i] = h->L.jperm[v][i];

@@ -27,8 +27,7 @@ constexpr int POSE_MAX_HNNZ = hs::COUNT;
 static_assert(XR_COUNT <= XR_STRIDE, "pose reference record");
 
 struct PoseTables {
-    KinTables kt;
-    KSettings ks;
+    HeadTables head;
     int32_t g_row[gs::COUNT];
     int32_t jperm[POSE_MAX_NNZ];
     int32_t nnz, m;
@@ -73,28 +72,38 @@ template <int TERRAIN> struct PoseHessEm {
 };
 
 struct PoseShared {
-    KinTables kt;
-    KSettings ks;
+    HeadTables head;
     GParams gp;
 };
 
 // tables, parameters and the pose's variables -> LDS (ends with a workgroup barrier)
 __device__ __forceinline__ void pose_stage(const PArgs& a, KnotScratch& s, PoseShared& tabs, int b, int tid) {
     const PoseTables& tb = *a.tb;
-    static_assert(sizeof(KinTables) % 4 == 0 && sizeof(KSettings) % 4 == 0 && sizeof(GParams) % 4 == 0, "word copy");
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(&tb.kt);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&tabs.kt);
-    for (int i = tid; i < int(sizeof(KinTables) / 4); i += WG) dst[i] = src[i];
-    src = reinterpret_cast<const uint32_t*>(&tb.ks);
-    dst = reinterpret_cast<uint32_t*>(&tabs.ks);
-    for (int i = tid; i < int(sizeof(KSettings) / 4); i += WG) dst[i] = src[i];
-    src = reinterpret_cast<const uint32_t*>(a.gp + b);
-    dst = reinterpret_cast<uint32_t*>(&tabs.gp);
-    for (int i = tid; i < int(sizeof(GParams) / 4); i += WG) dst[i] = src[i];
-    for (int i = tid; i < XPAD; i += WG) { s.x[i] = 0.0; s.xm[i] = i < XR_STRIDE ? a.xr[size_t(b) * XR_STRIDE + i] : 0.0; }
-    for (int i = tid; i < PK_STRIDE; i += WG) s.pk[i] = a.pk[size_t(b) * PK_STRIDE + i];
+    // every global load in flight before the first LDS store waits for one (see hipnlp_knot_kernel)
+    constexpr int HV = int(sizeof(HeadTables) / 16), HV_ITERS = (HV + WG - 1) / WG;
+    constexpr int GV = int(sizeof(GParams) / 8), GV_ITERS = (GV + WG - 1) / WG;
+    static_assert(XPAD <= WG && PK_STRIDE <= WG && POSE_NX <= WG, "one record word per thread");
+    const uint4* hsrc = reinterpret_cast<const uint4*>(&tb.head);
+    const double* gsrc = reinterpret_cast<const double*>(a.gp + b);
+    uint4 hv[HV_ITERS];
+    double gv[GV_ITERS];
+#pragma unroll
+    for (int it = 0; it < HV_ITERS; ++it) { const int i = tid + it * WG; hv[it] = i < HV ? hsrc[i] : uint4{0u, 0u, 0u, 0u}; }
+#pragma unroll
+    for (int it = 0; it < GV_ITERS; ++it) { const int i = tid + it * WG; gv[it] = i < GV ? gsrc[i] : 0.0; }
+    const double xrv = tid < XR_STRIDE ? a.xr[size_t(b) * XR_STRIDE + tid] : 0.0;
+    const double pkv = tid < PK_STRIDE ? a.pk[size_t(b) * PK_STRIDE + tid] : 0.0;
+    const double xval = tid < POSE_NX ? a.x[size_t(b) * POSE_NX + tid] : 0.0;
+    uint4* hdst = reinterpret_cast<uint4*>(&tabs.head);
+    double* gdst = reinterpret_cast<double*>(&tabs.gp);
+#pragma unroll
+    for (int it = 0; it < HV_ITERS; ++it) { const int i = tid + it * WG; if (i < HV) hdst[i] = hv[it]; }
+#pragma unroll
+    for (int it = 0; it < GV_ITERS; ++it) { const int i = tid + it * WG; if (i < GV) gdst[i] = gv[it]; }
+    if (tid < XPAD) { s.x[tid] = 0.0; s.xm[tid] = xrv; }
+    if (tid < PK_STRIDE) s.pk[tid] = pkv;
     __syncthreads();
-    if (tid < POSE_NX) s.x[pose_to_knot_col(tid)] = a.x[size_t(b) * POSE_NX + tid];
+    if (tid < POSE_NX) s.x[pose_to_knot_col(tid)] = xval;
     __syncthreads();
 }
 
@@ -109,7 +118,7 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
 
     KnotInfo ki{1, 3, 0, 0};   // "interior knot": the k >= 1 rows / costs of the shared tasks are active
     PoseEm<TERRAIN> em{s.g, s.jac};
-    Ctx<PoseEm<TERRAIN>> cx(s, tabs.kt, tabs.ks, tabs.gp, ki, em);
+    Ctx<PoseEm<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
 #define DEV_R(w, w8, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_BARRIER __syncthreads();
     HIPNLP_POSE_PROGRAM(DEV_R, DEV_BARRIER)
@@ -157,7 +166,7 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) void hipnlp_pose_hess_ke
 
     KnotInfo ki{1, 3, 0, 0};
     PoseHessEm<TERRAIN> em{s.g, s.jac, hx.H};
-    Ctx<PoseHessEm<TERRAIN>> cx(s, tabs.kt, tabs.ks, tabs.gp, ki, em);
+    Ctx<PoseHessEm<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
     HCtx<PoseHessEm<TERRAIN>> hcx{cx, hx};
 #define DEV_R(w, w8, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_RH(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); }
@@ -289,8 +298,8 @@ int hipnlp_pose_create(const hipnlp_pose_desc* desc, hipnlp_pose_handle** out) {
     CREATE_TRY(hipHostMalloc(&h->h_flags, B * sizeof(int32_t)));
     PoseTables* tb = new PoseTables();
     std::memset(tb, 0, sizeof(PoseTables));
-    tb->kt = h->kt;
-    tb->ks = PoseLayout::make_ksettings(st);
+    tb->head.kt = h->kt;
+    tb->head.ks = PoseLayout::make_ksettings(st);
     for (int s = 0; s < gs::COUNT; ++s) tb->g_row[s] = h->L.g_row[size_t(s)];
     for (int e = 0; e < h->L.nnz; ++e) tb->jperm[e] = h->L.jperm[size_t(e)];
     tb->nnz = h->L.nnz; tb->m = h->L.m;

@@ -44,15 +44,22 @@ namespace hipnlp {
 // ---------------------------------------------------------------------------------------------------
 // scratch (LDS on the device)
 // ---------------------------------------------------------------------------------------------------
+// stride of the per-link records own[] / comp[] (16 used): 17 doubles, so that lanes indexed by LINK hit different LDS banks
+constexpr int LSTR = 17;
 struct EndTerms { double c[105 + 84], g[105 + 84]; };  // minimize-mode end rows: cost partial and gradient share of row i
 
-struct alignas(16) JointRec { double L[9], of[3], c[3], sd; };
+// Joint record: 16 doubles [ L (9) | of (3) | c (3) | sd ] in eight 16-byte chunks.  The FK lanes read the SAME chunk of DIFFERENT
+// records in one instruction; at the natural 128-byte stride those all sit in the same four LDS banks.  Chunk q of record i is
+// therefore stored at position q ^ (i & 7): eight consecutive records put any given chunk in eight different bank groups.
+struct alignas(16) JointRec { double d[16]; };
 static_assert(sizeof(JointRec) == 128, "joint record");
+enum : int { JR_L = 0, JR_OF = 9, JR_C = 12, JR_SD = 15 };
+HD constexpr int jr_pos(int i, int e) { return ((((e >> 1) ^ (i & 7)) << 1) | (e & 1)); }   // physical position of logical double e of record i
 
 struct alignas(16) KnotScratch {
     double x[XPAD];    // knot k
     double xm[XPAD];   // knot k-1 (zeros at k = 0)
-    double xo[XPAD];   // the other end of the horizon (only loaded at k = 0 and k = N-1)
+    double xo[NPER];   // periodicity variables of the other end of the horizon, by periodicity row (only loaded at k = 0 and k = N-1)
     double xg[8];      // horizon-global variables (initial_state.centroidal_momentum)
     double pk[PK_STRIDE];
     // base orientation
@@ -66,10 +73,10 @@ struct alignas(16) KnotScratch {
     double Rw[NL][9], ow[NL][3], aw[NJ + 1][3];  // padding slot aw[NJ] = 0
     double wv[NL][3], vo[NL][3];  // link angular velocity; velocity of the body point at the origin
     union {  // own[] is dead once the composites are formed; the (rare) minimize-mode end terms reuse its space
-        double own[NL + 1][16];  // per link, same layout as comp; slot NL = 0 (padding of the descendant lists)
+        double own[NL + 1][LSTR];  // per link, same layout as comp; slot NL = 0 (padding of the descendant lists)
         EndTerms ends;
     };
-    double comp[NL][16];  // composite per link: [m | first moment h (3) | inertia@O xx,xy,xz,yy,yz,zz (6) | subtree momentum lin (3) | ang (3)]
+    double comp[NL][LSTR];  // composite per link: [m | first moment h (3) | inertia@O xx,xy,xz,yy,yz,zz (6) | subtree momentum lin (3) | ang (3)]
     double com[3], klin[3], kang[3], hang[3];
     double dth_h[3][3];  // d hang / d theta_e   [e][i]
     double Aw[3][3];     // d hang / d omega_e   [e][i]
@@ -163,6 +170,20 @@ HD void rot_from_quat(const double* q, double* R) {
     R[0] = 1.0 - 2.0 * (y * y + z * z); R[1] = 2.0 * (x * y - w * z);       R[2] = 2.0 * (x * z + w * y);
     R[3] = 2.0 * (x * y + w * z);       R[4] = 1.0 - 2.0 * (x * x + z * z); R[5] = 2.0 * (y * z - w * x);
     R[6] = 2.0 * (x * z - w * y);       R[7] = 2.0 * (y * z + w * x);       R[8] = 1.0 - 2.0 * (x * x + y * y);
+}
+
+// 1 / sqrt(x).  Device: hardware estimate (v_rsq_f64) + two Newton steps (one IEEE sqrt and one IEEE division cost several
+// hundred cycles of dependent instructions); x = 0 gives a non-finite result, as 1 / sqrt(0) does.
+HD double inv_sqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    r = r * (1.5 - hx * r * r);
+    r = r * (1.5 - hx * r * r);
+    return r;
+#else
+    return 1.0 / sqrt(x);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -356,7 +377,7 @@ template <class Em> HD void point_hnf_planar(Ctx<Em>& cx, int c) {
 //       the (not yet used) per-link area of the scratch;
 //   t_terrain_planar / _dcc / _hnf (phase B, lane c each, on three different waves): the rows and their Jacobian entries.
 struct TerrainStage { TerrainFrame tf; double Zh[7]; };   // Zh = Z[3..9]: second and third derivatives (for udot)
-static_assert(sizeof(TerrainStage) * NC <= sizeof(double) * NL * 16, "terrain staging must fit in own[0..NL) (own[NL] is the zero slot)");
+static_assert(sizeof(TerrainStage) * NC <= sizeof(double) * NL * LSTR, "terrain staging must fit in own[0..NL) (own[NL] is the zero slot)");
 HD TerrainStage* terrain_stage(KnotScratch& s, int c) { return reinterpret_cast<TerrainStage*>(&s.own[0][0]) + c; }
 
 template <class Em> HD void t_terrain_stage(Ctx<Em>& cx, int c) {
@@ -485,9 +506,7 @@ template <class Em> HD void t_points_cost(Ctx<Em>& cx, int t) {
 // identity / zero padding slots of the ancestor and descendant lists, lanes e < 16
 HD void scratch_padding(KnotScratch& s, int e) {
     if (e < 16) s.own[NL][e] = 0.0;
-    if (e < 9) s.Jr[NJ].L[e] = (e % 4 == 0) ? 1.0 : 0.0;
-    if (e < 3) { s.Jr[NJ].of[e] = 0.0; s.Jr[NJ].c[e] = 0.0; }
-    if (e == 0) s.Jr[NJ].sd = 0.0;
+    if (e < 16) s.Jr[NJ].d[jr_pos(NJ, e)] = (e < 9 && e % 4 == 0) ? 1.0 : 0.0;   // L = I, of = c = 0, sd = 0
     if (e < 3) { s.aw[NJ][e] = 0.0; s.Uj[NJ][e] = 0.0; }
 }
 
@@ -526,11 +545,14 @@ template <class Em> HD void joint_transform(Ctx<Em>& cx, int j) {
     Ra[1] -= sq * a[2]; Ra[2] += sq * a[1];
     Ra[3] += sq * a[2]; Ra[5] -= sq * a[0];
     Ra[6] -= sq * a[1]; Ra[7] += sq * a[0];
-    JointRec& rec = s.Jr[j];
-    matmul3(cx.kt.R_fix[j], Ra, rec.L);
-    matvec3(cx.kt.R_fix[j], a, rec.c);
-    for (int r = 0; r < 3; ++r) rec.of[r] = cx.kt.o_fix[j][r];
-    rec.sd = s.x[SD_ + j];
+    double L[9], c[3];
+    matmul3(cx.kt.R_fix[j], Ra, L);
+    matvec3(cx.kt.R_fix[j], a, c);
+    double* rec = s.Jr[j].d;
+    const int sw = (j & 7) << 1;   // jr_pos(j, e) = e ^ sw
+    for (int e = 0; e < 9; ++e) rec[(JR_L + e) ^ sw] = L[e];
+    for (int r = 0; r < 3; ++r) { rec[(JR_OF + r) ^ sw] = cx.kt.o_fix[j][r]; rec[(JR_C + r) ^ sw] = c[r]; }
+    rec[JR_SD ^ sw] = s.x[SD_ + j];
 }
 
 // --- joint-wise rows, joint regularisation cost and the local joint transform, lane j (23) -------------
@@ -669,29 +691,30 @@ template <class Em> HD void t_feet_yaw(Ctx<Em>& cx, int foot) { t_feet(cx, 1 + f
 
 // --- base orientation: normalised quaternion (E11), R_b, G, omega (E12), d omega / d q_b: lane e = row (3 tasks) ---------
 template <class Em> HD void t_base(Ctx<Em>& cx, int e) {
+    // lane e works on row e with the cyclic index triple (e, e1, e2): every entry of R, G, H has one closed form in
+    // (a, b, c) = (q_e, q_e1, q_e2), so no lane indexes a register array with a run-time index
     KnotScratch& s = cx.s;
     const double* q = s.x + QB_;
     const double* qd = s.x + QD_;
-    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    const double inv_n = 1.0 / n;
-    double qn[4];
-    for (int i = 0; i < 4; ++i) qn[i] = q[i] * inv_n;
-    if (e == 0) { s.qnorm = n; s.inv_qnorm = inv_n; for (int i = 0; i < 4; ++i) s.qn[i] = qn[i]; }
-    double R[9];
-    rot_from_quat(qn, R);
-    for (int i = 0; i < 3; ++i) { s.Rb[3 * e + i] = R[3 * e + i]; s.Rw[0][3 * e + i] = R[3 * e + i]; }
-    const double v[3] = {qn[0], qn[1], qn[2]}, w = qn[3];
+    const int e1 = e == 2 ? 0 : e + 1, e2 = e == 0 ? 2 : e - 1;
+    const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    const double inv_n = inv_sqrt(n2);
+    const double a = q[e] * inv_n, b = q[e1] * inv_n, c = q[e2] * inv_n, w = q[3] * inv_n;
+    if (e == 0) { s.qnorm = n2 * inv_n; s.inv_qnorm = inv_n; s.qn[3] = w; }
+    s.qn[e] = a;
+    // row e of R = I + 2 w [v]x + 2 [v]x^2
+    const double Ree = 1.0 - 2.0 * (b * b + c * c), Re1 = 2.0 * (a * b - w * c), Re2 = 2.0 * (a * c + w * b);
+    s.Rb[3 * e + e] = Ree; s.Rb[3 * e + e1] = Re1; s.Rb[3 * e + e2] = Re2;
+    s.Rw[0][3 * e + e] = Ree; s.Rw[0][3 * e + e1] = Re1; s.Rw[0][3 * e + e2] = Re2;
     // G = 2 [ w I + [v]x | -v ] ; omega = G qdot ; H = 2 [ -qd_w I - [qd_v]x | qd_v ] ; d omega/d q = H (I - qn qn^T)/|q|
-    double Ge[4], He[4];
-    for (int c = 0; c < 3; ++c) {
-        Ge[c] = 2.0 * ((c == e ? w : 0.0) + skew_rc(v, e, c));
-        He[c] = 2.0 * ((c == e ? -qd[3] : 0.0) - skew_rc(qd, e, c));
-    }
-    Ge[3] = -2.0 * v[e];
-    He[3] = 2.0 * qd[e];
-    const double om = Ge[0] * qd[0] + Ge[1] * qd[1] + Ge[2] * qd[2] + Ge[3] * qd[3];
-    const double hq = He[0] * qn[0] + He[1] * qn[1] + He[2] * qn[2] + He[3] * qn[3];
-    for (int l = 0; l < 4; ++l) { s.G[4 * e + l] = Ge[l]; s.dwq[4 * e + l] = (He[l] - hq * qn[l]) * inv_n; }
+    const double Ge = 2.0 * w, Ge1 = -2.0 * c, Ge2 = 2.0 * b, G3 = -2.0 * a;
+    const double He = -2.0 * qd[3], He1 = 2.0 * qd[e2], He2 = -2.0 * qd[e1], H3 = 2.0 * qd[e];
+    const double om = Ge * qd[e] + Ge1 * qd[e1] + Ge2 * qd[e2] + G3 * qd[3];
+    const double hq = He * a + He1 * b + He2 * c + H3 * w;
+    double* Gr = s.G + 4 * e;
+    double* Dr = s.dwq + 4 * e;
+    Gr[e] = Ge; Gr[e1] = Ge1; Gr[e2] = Ge2; Gr[3] = G3;
+    Dr[e] = (He - hq * a) * inv_n; Dr[e1] = (He1 - hq * b) * inv_n; Dr[e2] = (He2 - hq * c) * inv_n; Dr[3] = (H3 - hq * w) * inv_n;
     s.omega[e] = om;
     s.ow[0][e] = 0.0; s.wv[0][e] = om; s.vo[0][e] = 0.0;   // root link in base-centred coordinates
 }
@@ -705,7 +728,7 @@ template <class Em> HD void t_base(Ctx<Em>& cx, int e) {
 // Every lane walks its own (padded) ancestor list, so no lane waits for another one inside a pass; the passes
 // run back to back on one wave (HIPNLP_WAVE_SYNC between them).
 constexpr int FK_TASKS_A = 3 * FK_SPLIT, FK_TASKS_B = 3 * (NJ - FK_SPLIT);
-template <class Em> HD void t_fk_rot_at(Ctx<Em>& cx, int t) {
+template <class Em> HD void t_fk_rot_at(Ctx<Em>& cx, int t, int q0) {
     // lane (joint j, component r) walks the front-padded ancestor list of j ONCE and accumulates, for its component r:
     //   row r of R_j = row r of R_b L_a1 ... L_j        o_j[r] = sum_a (row r of R_parent(a)) . o_fix_a
     //   a_j[r] = (row r of R_j) . axis_j                w_j[r] = omega[r] + sum_a a_a[r] sdot_a
@@ -714,13 +737,21 @@ template <class Em> HD void t_fk_rot_at(Ctx<Em>& cx, int t) {
     const int j = t / 3, r = t - 3 * j;
     double v0 = s.Rb[3 * r], v1 = s.Rb[3 * r + 1], v2 = s.Rb[3 * r + 2];
     double o = 0.0, w = s.omega[r], ar = 0.0;
+    // q0: every list of this task group is padded up to there (group-uniform: the leading identity steps are skipped)
     HIPNLP_UNROLL
-    for (int q = 0; q < 8; ++q) {
-        const JointRec& rec = s.Jr[cx.kt.anc[j][q]];
-        o += v0 * rec.of[0] + v1 * rec.of[1] + v2 * rec.of[2];
-        ar = v0 * rec.c[0] + v1 * rec.c[1] + v2 * rec.c[2];   // (row r of R_parent) . (R_fix axis) = (row r of R_a) . axis
-        w += ar * rec.sd;
-        const double* L = rec.L;
+    for (int q = q0; q < 8; ++q) {
+        const int ia = cx.kt.anc[j][q];
+        const double* rp = s.Jr[ia].d;
+        const int sw = (ia & 7) << 1;
+        double rec[16];   // the eight 16-byte chunks of the record, un-swizzled into registers
+        HIPNLP_UNROLL
+        for (int ch = 0; ch < 8; ++ch) { const int pp = (2 * ch) ^ sw; rec[2 * ch] = rp[pp]; rec[2 * ch + 1] = rp[pp + 1]; }
+        const double* L = rec + JR_L;
+        const double* of = rec + JR_OF;
+        const double* cc = rec + JR_C;
+        o += v0 * of[0] + v1 * of[1] + v2 * of[2];
+        ar = v0 * cc[0] + v1 * cc[1] + v2 * cc[2];   // (row r of R_parent) . (R_fix axis) = (row r of R_a) . axis
+        w += ar * rec[JR_SD];
         const double n0 = v0 * L[0] + v1 * L[3] + v2 * L[6];
         const double n1 = v0 * L[1] + v1 * L[4] + v2 * L[7];
         const double n2 = v0 * L[2] + v1 * L[5] + v2 * L[8];
@@ -731,8 +762,8 @@ template <class Em> HD void t_fk_rot_at(Ctx<Em>& cx, int t) {
     s.ow[j + 1][r] = o;
     s.wv[j + 1][r] = w;
 }
-template <class Em> HD void t_fk_rot_a(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t); }
-template <class Em> HD void t_fk_rot_b(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t + FK_TASKS_A); }
+template <class Em> HD void t_fk_rot_a(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t, HIPNLP_UNIFORM(cx.kt.fk_first[0])); }
+template <class Em> HD void t_fk_rot_b(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t + FK_TASKS_A, HIPNLP_UNIFORM(cx.kt.fk_first[1])); }
 // (A level-synchronous variant — one step per joint, the wave walking the tree level by level behind wave-level fences — was
 //  measured at 4.7 k cycles against 3.4 k for these ancestor sums: a level costs two dependent LDS round trips, ~680 cycles.)
 // velocity of the body point of link i at the (base-centred) origin: vO_i = sum over the joints a on the path root -> i of
@@ -868,12 +899,12 @@ template <class Em> HD void t_ends(Ctx<Em>& cx, int t) {
         if (cx.st.periodicity_type == HIPNLP_EXPR_MINIMIZE) {
             if (!cx.ki.first && !cx.ki.last) return;
             // e = x_0 - x_{N-1};  at the last knot xo = x_0, at the first knot xo = x_{N-1}
-            const double e = cx.ki.last ? (s.xo[var] - s.x[var]) : (s.x[var] - s.xo[var]);
+            const double e = cx.ki.last ? (s.xo[i] - s.x[var]) : (s.x[var] - s.xo[i]);
             if (cx.ki.last) s.ends.c[t] = cx.st.periodicity_weight * e * e;
             s.ends.g[t] = (cx.ki.last ? -2.0 : 2.0) * cx.st.periodicity_weight * e;  // d/dx_{N-1} = -2we, d/dx_0 = +2we
         } else if (cx.st.periodicity_type == HIPNLP_EXPR_SUBJECT_TO) {
             if (cx.ki.last) {
-                em.G(gs::PER + i, row_id(RK_PERN, 0, i), s.xo[var] - s.x[var]);
+                em.G(gs::PER + i, row_id(RK_PERN, 0, i), s.xo[i] - s.x[var]);
                 em.J(js::PERN + i, row_id(RK_PERN, 0, i), var, -1.0);
             }
             if (cx.ki.first) em.J(js::PER0 + i, row_id(RK_PER0, 0, i), var, 1.0);
@@ -884,37 +915,50 @@ template <class Em> HD void t_ends(Ctx<Em>& cx, int t) {
 // ===================================================================================================
 // PHASE C — per-link spatial inertia at the origin and link momentum, lane i (24 links); frames (3 lanes)
 // ===================================================================================================
+// t_links (lane i): first moment, origin velocity and momentum of the link;  t_link_inertia (lane i, another wave): rotational
+// inertia about the origin.  The momentum takes I_O w as R (I (R^T w)) + m (c^2 w - c (c.w)), so neither waits for the other.
 template <class Em> HD void t_links(Ctx<Em>& cx, int i) {
     KnotScratch& s = cx.s;
     const double m = cx.kt.mass[i];
     double vo[3];
     link_origin_velocity(s, cx.kt, i, vo);
     for (int r = 0; r < 3; ++r) s.vo[i][r] = vo[r];
-    double c[3], RI[9], Iw[9], Rt[9];
-    matvec3(s.Rw[i], cx.kt.com[i], c);
+    const double* R = s.Rw[i];
+    const double* w = s.wv[i];
+    double c[3], h[3], wl[3], Iwl[3], Iw[3];
+    matvec3(R, cx.kt.com[i], c);
     for (int r = 0; r < 3; ++r) c[r] += s.ow[i][r];
-    matmul3(s.Rw[i], cx.kt.inertia[i], RI);
-    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) Rt[3 * r + q] = s.Rw[i][3 * q + r];
-    matmul3(RI, Rt, Iw);
-    const double c2 = dot3(c, c);
+    for (int r = 0; r < 3; ++r) wl[r] = R[r] * w[0] + R[3 + r] * w[1] + R[6 + r] * w[2];   // R^T w
+    matvec3(cx.kt.inertia[i], wl, Iwl);
+    matvec3(R, Iwl, Iw);
+    const double c2 = dot3(c, c), cw = dot3(c, w);
     double* cp = s.own[i];
-    double h[3], I6[6];
     cp[CM] = m;
     for (int r = 0; r < 3; ++r) { h[r] = m * c[r]; cp[CH + r] = h[r]; }
-    I6[0] = Iw[0] + m * (c2 - c[0] * c[0]);
-    I6[1] = 0.5 * (Iw[1] + Iw[3]) - m * c[0] * c[1];
-    I6[2] = 0.5 * (Iw[2] + Iw[6]) - m * c[0] * c[2];
-    I6[3] = Iw[4] + m * (c2 - c[1] * c[1]);
-    I6[4] = 0.5 * (Iw[5] + Iw[7]) - m * c[1] * c[2];
-    I6[5] = Iw[8] + m * (c2 - c[2] * c[2]);
-    for (int r = 0; r < 6; ++r) cp[CI + r] = I6[r];
     // link momentum about the origin:  lin = m vO + w x h ;  ang = I_O w + h x vO
     double a[3], b[3];
-    cross3(s.wv[i], h, a);
+    cross3(w, h, a);
     for (int r = 0; r < 3; ++r) cp[CKL + r] = m * vo[r] + a[r];
-    symvec(I6, s.wv[i], a);
     cross3(h, vo, b);
-    for (int r = 0; r < 3; ++r) cp[CKA + r] = a[r] + b[r];
+    for (int r = 0; r < 3; ++r) cp[CKA + r] = Iw[r] + m * (c2 * w[r] - c[r] * cw) + b[r];
+}
+template <class Em> HD void t_link_inertia(Ctx<Em>& cx, int i) {
+    KnotScratch& s = cx.s;
+    const double m = cx.kt.mass[i];
+    const double* R = s.Rw[i];
+    double c[3], RI[9];
+    matvec3(R, cx.kt.com[i], c);
+    for (int r = 0; r < 3; ++r) c[r] += s.ow[i][r];
+    matmul3(R, cx.kt.inertia[i], RI);
+    // (R I R^T)(r, q) = RI row r . R row q; the six entries of the symmetric part
+    const double c2 = dot3(c, c);
+    double* cp = s.own[i] + CI;
+    cp[0] = dot3(RI, R) + m * (c2 - c[0] * c[0]);
+    cp[1] = 0.5 * (dot3(RI, R + 3) + dot3(RI + 3, R)) - m * c[0] * c[1];
+    cp[2] = 0.5 * (dot3(RI, R + 6) + dot3(RI + 6, R)) - m * c[0] * c[2];
+    cp[3] = dot3(RI + 3, R + 3) + m * (c2 - c[1] * c[1]);
+    cp[4] = 0.5 * (dot3(RI + 3, R + 6) + dot3(RI + 6, R + 3)) - m * c[1] * c[2];
+    cp[5] = dot3(RI + 6, R + 6) + m * (c2 - c[2] * c[2]);
 }
 template <class Em> HD void t_frames(Ctx<Em>& cx, int f) {
     KnotScratch& s = cx.s;
@@ -947,7 +991,7 @@ template <class Em> HD void t_frames(Ctx<Em>& cx, int f) {
 // (kt.comp_cnt), so it costs: 24 + 6 + 4 + 3 + 2 + 1 steps on the ergoCub tree instead of 6 x 24.
 // An iteration has a fixed cost of several hundred cycles of index chasing on top of its steps: six iteration groups, spread
 // 1-2-2-1 over four waves or one per wave over eight.
-static_assert(NL * 16 == 6 * 64, "six wave iterations of composite tasks");
+static_assert(NL * 16 == 6 * 64, "six wave iterations of composite tasks (16 used components per link)");
 template <class Em> HD void t_composite(Ctx<Em>& cx, int t) {
     KnotScratch& s = cx.s;
     const int i = cx.kt.comp_order[t >> 4], r = t & 15;
@@ -1197,7 +1241,7 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
 #define HIPNLP_KNOT_PROGRAM(R, BARRIER)                                                   \
     R(0, 0, t_points_vec, 3 * NC) R(0, 1, t_unitq, 1)                                     \
     R(1, 2, t_points_scalar, NC) R(1, 3, t_dyn, 7 + NJ + 3) R(1, 1, t_feet_centroid, 1) R(1, 7, t_terrain_stage, NC) \
-    R(2, 4, t_joints, NJ) R(2, 4, t_joint_cost, 1) R(2, 1, t_feet_yaw, 2)                 \
+    R(2, 4, t_joints, NJ) R(2, 1, t_feet_yaw, 2)                                          \
     R(3, 5, t_base, 3) R(3, 6, t_small, 4)                                                \
     BARRIER                                                                               \
     R(0, 0, t_fk_rot_a, FK_TASKS_A) R(0, 0, t_link_u_a, FK_SPLIT)                         \
@@ -1206,7 +1250,7 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
     R(2, 4, t_terrain_hnf, NC) R(2, 4, t_points_cost, 3) R(2, 4, t_foot_costs, FOOT_TASKS) R(2, 4, t_foot_cost_sum, 2) \
     R(1, 5, t_terrain_planar, NC) R(0, 6, t_terrain_dcc, NC)                              \
     BARRIER                                                                               \
-    R(0, 0, t_links, NL) R(1, 1, t_frames, 3)                                             \
+    R(0, 0, t_links, NL) R(1, 1, t_frames, 3) R(2, 2, t_link_inertia, NL) R(3, 3, t_joint_cost, 1) \
     BARRIER                                                                               \
     R(0, 0, t_composite_g0, 64) R(1, 1, t_composite_g1, 64) R(1, 2, t_composite_g2, 64)   \
     R(2, 3, t_composite_g3, 64) R(2, 4, t_composite_g4, 64) R(3, 5, t_composite_g5, 64) R(3, 6, t_pkin, NC) \

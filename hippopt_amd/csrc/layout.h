@@ -37,15 +37,6 @@ inline int final_row_var(int i, int* slot, int* desc) {
     *slot = 58 + r;
     return S_ + r;
 }
-// variable behind periodicity row i (0..83): per point (u_v, f_dot), then h, v_b, qdot_b, sdot (planner.py:897-922)
-inline int periodicity_row_var(int i) {
-    if (i < 48) { const int c = i / 6, q = i % 6; return PT_ * c + (q < 3 ? U_ + q : FD_ + (q - 3)); }
-    if (i < 54) return H_ + (i - 48);
-    if (i < 57) return VB_ + (i - 54);
-    if (i < 61) return QD_ + (i - 57);
-    return SD_ + (i - 61);
-}
-
 struct RowBlock {
     std::string name;
     int first_row, rows, k0, nk;
@@ -365,6 +356,8 @@ struct Layout {
             // FRONT padded: the last element is always joint j itself, so the state before the last product is the parent's
             const int npad = 8 - int(path.size());
             for (int q = 0; q < 8; ++q) kt.anc[j][q] = int8_t(q < npad ? NJ : path[size_t(q - npad)]);
+            int& ff = kt.fk_first[j < FK_SPLIT ? 0 : 1];
+            if (j == 0 || j == FK_SPLIT || npad < ff) ff = npad;
         }
         for (int i = 0; i < NL; ++i) {
             int n = 0;

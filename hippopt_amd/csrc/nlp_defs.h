@@ -51,6 +51,7 @@ struct KinTables {
     int32_t frame_link[3];
     // tree as ancestor / descendant lists: every lane sums over its own list, no loop-carried dependence
     int32_t par_link[NJ];       // parent link of joint j
+    int32_t fk_first[2];        // first useful position of the (front-padded) ancestor lists of joints [0, FK_SPLIT) / [FK_SPLIT, NJ)
     int8_t anc[NJ][8];          // joints on the path root -> j (inclusive, ascending, j LAST), FRONT padded with NJ (identity / zero slot)
     int8_t desc[NL][NL];        // links of the subtree rooted at link i (inclusive), padded with NL (zero slot)
     int16_t ndesc[NL];          // size of that subtree
@@ -81,6 +82,14 @@ struct KSettings {
     int32_t pose_com_type, pose_left_type, pose_right_type, pose_pad_;
     double m_pcom, m_favg, m_preg;
 };
+
+// the read-only tables every workgroup stages into LDS, as ONE 16-byte-aligned block (copied with 16-byte loads, all in flight at once)
+struct alignas(16) HeadTables {
+    KinTables kt;
+    KSettings ks;
+};
+static_assert(sizeof(HeadTables) % 16 == 0, "HeadTables is copied in 16-byte words");
+static_assert(sizeof(GParams) % 8 == 0, "GParams is copied in 8-byte words");
 
 // ---- cost terms (Output.cost_values grouping; order = hipnlp_cost_term_name) -------------------------
 enum : int { CT_SWING = 0, CT_UREG, CT_FDREG, CT_COMVEL, CT_FRAMEQ, CT_BASEQ, CT_BASEQV, CT_JREG, CT_CENTROID, CT_FREG, CT_YAW, CT_ENDS, NCT };
@@ -155,6 +164,13 @@ constexpr int AMB = CMMC_SD + 3 * NJ, COMH = AMB + 3 /* [3] d h(com)/d com (plan
 constexpr int JPB = FEETD + 2 * LEG_PATH, JVB = JPB + NJ, FEETH = JVB + NJ;
 constexpr int FIN = FEETH + NC, PER0 = FIN + 81, PERN = PER0 + 84, COUNT = PERN + 84;
 }  // namespace js
+
+// variable behind periodicity row i (0..83): per point (u_v, f_dot), then h, v_b, qdot_b, sdot (planner.py:897-922)
+constexpr int NPER = 84;
+HD constexpr int periodicity_row_var(int i) {
+    return i < 48 ? PT_ * (i / 6) + ((i % 6) < 3 ? U_ + (i % 6) : FD_ + ((i % 6) - 3))
+                  : (i < 54 ? H_ + (i - 48) : (i < 57 ? VB_ + (i - 54) : (i < 61 ? QD_ + (i - 57) : SD_ + (i - 61))));
+}
 
 // the six structural entries of d(a x b)/db = [a]x, in (row, col) order
 HD constexpr int cross_row(int e) { return e / 2; }

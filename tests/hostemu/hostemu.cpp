@@ -72,12 +72,13 @@ void hostemu_eval(const hostemu_handle* h, const double* x, const double* p, dou
     KnotScratch* s = new KnotScratch();
     for (int k = 0; k < N; ++k) {
         std::fill(reinterpret_cast<double*>(s), reinterpret_cast<double*>(s) + sizeof(KnotScratch) / sizeof(double), std::nan(""));
-        for (int i = 0; i < XPAD; ++i) { s->x[i] = 0; s->xm[i] = 0; s->xo[i] = 0; }
+        for (int i = 0; i < XPAD; ++i) { s->x[i] = 0; s->xm[i] = 0; }
+        for (int i = 0; i < NPER; ++i) s->xo[i] = 0;
         for (int i = 0; i < NXK; ++i) {
             s->x[i] = x[NXK * k + i];
             s->xm[i] = k > 0 ? x[NXK * (k - 1) + i] : 0.0;
-            s->xo[i] = k == 0 ? x[NXK * (N - 1) + i] : (k == N - 1 ? x[i] : 0.0);
         }
+        for (int i = 0; i < NPER; ++i) s->xo[i] = k == 0 ? x[NXK * (N - 1) + periodicity_row_var(i)] : (k == N - 1 ? x[periodicity_row_var(i)] : 0.0);
         for (int i = 0; i < NXG; ++i) s->xg[i] = x[NXK * N + i];
         for (int i = 0; i < PK_STRIDE; ++i) s->pk[i] = pk[size_t(k) * PK_STRIDE + i];
         KnotInfo ki{k, N, k == 0, k == N - 1};
@@ -143,7 +144,8 @@ void hostemu_pose_eval(const hostemu_pose_handle* h, const double* x, const doub
     pack_pose_params(p, pk, xr, gp);
     KnotScratch* s = new KnotScratch();
     std::fill(reinterpret_cast<double*>(s), reinterpret_cast<double*>(s) + sizeof(KnotScratch) / sizeof(double), std::nan(""));
-    for (int i = 0; i < XPAD; ++i) { s->x[i] = 0; s->xm[i] = 0; s->xo[i] = 0; }
+    for (int i = 0; i < XPAD; ++i) { s->x[i] = 0; s->xm[i] = 0; }
+    for (int i = 0; i < NPER; ++i) s->xo[i] = 0;
     for (int i = 0; i < POSE_NX; ++i) s->x[pose_to_knot_col(i)] = x[i];
     for (int i = 0; i < 64; ++i) s->xm[i] = xr[i];
     for (int i = 0; i < PK_STRIDE; ++i) s->pk[i] = pk[i];
@@ -175,7 +177,8 @@ void hostemu_pose_hess(const hostemu_pose_handle* h, const double* x, const doub
     HessScratch* hx = new HessScratch();
     std::fill(reinterpret_cast<double*>(s), reinterpret_cast<double*>(s) + sizeof(KnotScratch) / sizeof(double), std::nan(""));
     std::fill(reinterpret_cast<double*>(hx), reinterpret_cast<double*>(hx) + sizeof(HessScratch) / sizeof(double), std::nan(""));
-    for (int i = 0; i < XPAD; ++i) { s->x[i] = 0; s->xm[i] = 0; s->xo[i] = 0; }
+    for (int i = 0; i < XPAD; ++i) { s->x[i] = 0; s->xm[i] = 0; }
+    for (int i = 0; i < NPER; ++i) s->xo[i] = 0;
     for (int i = 0; i < POSE_NX; ++i) s->x[pose_to_knot_col(i)] = x[i];
     for (int i = 0; i < 64; ++i) s->xm[i] = xr[i];
     for (int i = 0; i < PK_STRIDE; ++i) s->pk[i] = pk[i];

@@ -10,12 +10,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-SO = os.path.join(ROOT, "tools", "diag", "_build", "libhipnlp_stamps.so")
+SO = os.path.join(ROOT, "tools", "diag", "_build", "libhipnlp_stamps%s.so" % os.environ.get("STAMPS_VARIANT", ""))
 
 
 def build():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DHIPNLP_STAMPS",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DHIPNLP_STAMPS"] + ([] if not os.environ.get("STAMPS_VARIANT") else ["-DHIPNLP_DIAG_SKIP=" + os.environ["STAMPS_VARIANT"]]) + [
                            "-o", SO, os.path.join(ROOT, "hippopt_amd", "csrc", "hipnlp.hip"), os.path.join(ROOT, "hippopt_amd", "csrc", "hipnlp_pose.hip")])
 
 
@@ -40,25 +40,28 @@ if __name__ == "__main__":
     eng.set_params(p)
     for _ in range(20):
         eng.eval(x)
-    import re
-    prog = open(os.path.join(ROOT, "hippopt_amd", "csrc", "knot_body.h")).read()
-    prog = prog[prog.index("#define HIPNLP_KNOT_PROGRAM"):]
-    groups = re.findall(r"R\((\d), (\d), (\w+),", prog)
-    out = np.zeros((100 * batch, 8, 64, 2), np.uint64)
+    out = np.zeros((100 * batch, 8, 128), np.uint64)
     eng.lib.hipnlp_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
     eng.lib.hipnlp_debug_stamps(eng.h, out.ctypes.data_as(C.c_void_p))
-    blk = out[len(out) // 2]  # an interior knot
-    waves = [w for w in range(8) if int(blk[w, 0, 0]) == 999]
-    t0 = min(int(blk[w, 0, 1]) for w in waves)
-    print("interior knot: per wave, end time of each group / arrival at each barrier (cycles since block start) and duration")
-    for w in waves:
-        n = int(out[len(out) // 2, w, 63, 0])
-        prev = int(blk[w, 0, 1]) - t0
-        line = []
-        for i in range(1, n):
-            gid, tm = int(blk[w, i, 0]), int(blk[w, i, 1]) - t0
-            name = groups[gid][2] if gid < 1000 else ("|B%d" % (gid - 1000) if gid < 2000 else "END")
-            line.append("%s %d(+%d)" % (name, tm, tm - prev))
-            prev = tm
-        print("wave %d: " % w + "  ".join(line))
+    blk = out[len(out) // 2].astype(np.int64)  # an interior knot
+    waves = [w for w in range(8) if blk[w, 0] != 0]
+    t0 = min(blk[w, 0] for w in waves)
+    nb = int(blk[waves[0], 2])
+    print("interior knot, %d waves, cycles since the first wave entered the kernel (s_memtime); per barrier: arrival of every wave" % len(waves))
+    print("staged (after the first barrier):", [int(blk[w, 1] - t0) for w in waves])
+    prev = max(blk[w, 1] for w in waves) - t0
+    for i in range(nb):
+        arr = [int(blk[w, 8 + 2 * i] - t0) for w in waves]
+        dep = max(int(blk[w, 9 + 2 * i] - t0) for w in waves)
+        print("B%d arrivals %s  last %d (phase %+d)  released %d" % (i, arr, max(arr), max(arr) - prev, dep))
+        prev = dep
+    end = [int(blk[w, 8 + 2 * nb] - t0) for w in waves]
+    print("end (stores issued) %s  (+%d)" % (end, max(end) - prev))
+    real = [(int(blk[w, 4] - blk[w, 3])) for w in waves]
+    cyc = [(int(blk[w, 8 + 2 * nb] - blk[w, 0])) for w in waves]
+    print("realtime ticks (100 MHz) per wave %s -> shader clock ~ %.0f MHz" % (real, 100.0 * np.mean(cyc) / max(1.0, np.mean(real))))
+    # spread over the grid: entry time of every workgroup relative to the first, and total
+    ent = out[:, 0, 0].astype(np.int64)
+    endt = out[:, :, 8 + 2 * nb].astype(np.int64).max(axis=1)
+    print("grid: first entry -> last entry %d cycles, first entry -> last end %d cycles" % (ent.max() - ent.min(), endt.max() - ent.min()))
     print("kernel ms:", eng.last_kernel_ms())
