@@ -74,20 +74,23 @@ struct SharedTables {
 // WAVES = 8: 512 threads, the roles of the knot program spread over twice the waves (two per SIMD).  The latency variant, used
 //            when the launch has at most one workgroup per CU anyway (knots x batch <= 256), e.g. one 100-knot trajectory.
 template <int TERRAIN, int WAVES> __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 3 : 2, WAVES == 4 ? 3 : 2)))
-void hipnlp_knot_kernel(KArgs a) {
+void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const double* pk_p, const GParams* gp_p, int N_p, int n_p, int kb_p, KArgs a) {
+    // the leading scalar arguments repeat what the staging loads need: the build preloads them into SGPRs
+    // (-mllvm -amdgpu-kernarg-preload-count), so the first global loads do not wait for a kernarg fetch
     constexpr int WG = 64 * WAVES;
     __shared__ KnotScratch s;
     __shared__ SharedTables tabs;
 #ifdef HIPNLP_STAMPS
     const unsigned long long st_entry = __builtin_amdgcn_s_memtime(), st_real0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_issued = 0, st_loaded = 0;
 #endif
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int kk = blockIdx.x, b = blockIdx.y;
-    const int k = a.knot_begin + kk;
-    const int N = a.N;
-    const double* x = a.x + size_t(b) * a.n;
+    const int k = kb_p + kk;
+    const int N = N_p;
+    const double* x = x_p + size_t(b) * n_p;
     const int first = k == 0, last = k == N - 1;
-    const DeviceTables& tb = *a.tb;
+    const DeviceTables& tb = *tb_p;
     // ---- stage the knot records and the tables in LDS.  Every global load is issued before the first LDS store waits for
     // one (compile-time trip counts, 16-byte words): ONE memory round trip instead of one per loop iteration.
     {
@@ -96,7 +99,7 @@ void hipnlp_knot_kernel(KArgs a) {
         constexpr int XV_ITERS = (XPAD + WG - 1) / WG;
         static_assert(PK_STRIDE <= WG && NXG <= 8, "one parameter word per thread");
         const uint4* hsrc = reinterpret_cast<const uint4*>(&tb.head);
-        const double* gsrc = reinterpret_cast<const double*>(a.gp + b);
+        const double* gsrc = reinterpret_cast<const double*>(gp_p + b);
         uint4 hv[HV_ITERS];
         double gv[GV_ITERS], xv[XV_ITERS], xmv[XV_ITERS], xov[XV_ITERS];
 #pragma unroll
@@ -111,8 +114,13 @@ void hipnlp_knot_kernel(KArgs a) {
             xmv[it] = (in && !first) ? x[size_t(NXK) * (k - 1) + i] : 0.0;
             xov[it] = (i < NPER && (first || last)) ? x[size_t(NXK) * (first ? N - 1 : 0) + periodicity_row_var(i)] : 0.0;
         }
-        const double pkv = tid < PK_STRIDE ? a.pk[(size_t(b) * N + k) * PK_STRIDE + tid] : 0.0;
+        const double pkv = tid < PK_STRIDE ? pk_p[(size_t(b) * N + k) * PK_STRIDE + tid] : 0.0;
         const double xgv = tid < NXG ? x[size_t(NXK) * N + tid] : 0.0;
+#ifdef HIPNLP_STAMPS
+        st_issued = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_loaded = __builtin_amdgcn_s_memtime();
+#endif
         uint4* hdst = reinterpret_cast<uint4*>(&tabs.head);
         double* gdst = reinterpret_cast<double*>(&tabs.gp);
 #pragma unroll
@@ -127,10 +135,12 @@ void hipnlp_knot_kernel(KArgs a) {
     __syncthreads();
 
     // copy-out tables of this knot's variant, fetched now so their latency hides behind the knot program
-    const int v = first ? VAR_FIRST : (last ? VAR_LAST : VAR_INTERIOR);
     constexpr int JP_ITERS = (js::COUNT + WG - 1) / WG, G_ITERS = (gs::COUNT + WG - 1) / WG;
+    // (scalars of the copy-out: read behind the barrier on purpose.  Known before it, the compiler issues the copy-out table loads
+    //  before the barrier as well, which then waits for them: +14 % kernel time at batch 1024; kernarg copies of these scalars
+    //  measured +22 %)
+    const int v = first ? VAR_FIRST : (last ? VAR_LAST : VAR_INTERIOR);
     const int jcnt = tb.nnz_v[v];
-    // everything the copy-out needs from the global tables, fetched here as well
     const int64_t jbase = first ? 0 : int64_t(tb.nnz_v[VAR_FIRST]) + int64_t(k - 1) * tb.nnz_v[VAR_INTERIOR];
     const int n_glob = last ? tb.n_glob : 0, jac_glob_base = tb.jac_glob_base;
     const int jpg = (last && tid < 16) ? tb.jperm_glob[tid] : 0;
@@ -225,7 +235,7 @@ void hipnlp_knot_kernel(KArgs a) {
         if (lane == 0) {
             stamp_out[0] = st_entry; stamp_out[1] = st_staged; stamp_out[2] = (unsigned long long)bid;
             for (int i = 0; i < 8; ++i) { stamp_out[8 + 2 * i] = i <= bid ? st_arr[i] : 0; stamp_out[9 + 2 * i] = i < bid ? st_dep[i] : 0; }
-            stamp_out[3] = st_real0; stamp_out[4] = __builtin_amdgcn_s_memrealtime();
+            stamp_out[3] = st_real0; stamp_out[4] = __builtin_amdgcn_s_memrealtime(); stamp_out[5] = st_issued; stamp_out[6] = st_loaded;
         }
     }
 #endif
@@ -522,11 +532,11 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     const dim3 grid(unsigned(h->nk), unsigned(h->batch));
     const bool planar = h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR;
     if (h->wide) {   // at most one workgroup per CU: eight waves per knot
-        if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8>), grid, dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8>), grid, dim3(512), 0, s, a);
+        if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a);
+        else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a);
     } else {
-        if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 4>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 4>), grid, dim3(256), 0, s, a);
+        if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 4>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a);
+        else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 4>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a);
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 1)], s));
     hipLaunchKernelGGL(hipnlp_reduce_kernel, dim3(unsigned(h->batch)), dim3(RWG), 0, s,

@@ -10,7 +10,8 @@ import numpy as np
 
 from . import _abi
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhipnlp.so")
+# (HIPNLP_LIB_PATH: diagnostic override to load another BUILD of the same HIP library, e.g. an A/B variant under tools/diag/_build)
+_LIB_PATH = os.environ.get("HIPNLP_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhipnlp.so")
 _lib = None
 
 EXPORTS = [

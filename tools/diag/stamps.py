@@ -15,7 +15,7 @@ SO = os.path.join(ROOT, "tools", "diag", "_build", "libhipnlp_stamps%s.so" % os.
 
 def build():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DHIPNLP_STAMPS"] + ([] if not os.environ.get("STAMPS_VARIANT") else ["-DHIPNLP_DIAG_SKIP=" + os.environ["STAMPS_VARIANT"]]) + [
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DHIPNLP_STAMPS", "-mllvm", "-amdgpu-kernarg-preload-count=16"] + ([] if not os.environ.get("STAMPS_VARIANT") else ["-DHIPNLP_DIAG_SKIP=" + os.environ["STAMPS_VARIANT"]]) + [
                            "-o", SO, os.path.join(ROOT, "hippopt_amd", "csrc", "hipnlp.hip"), os.path.join(ROOT, "hippopt_amd", "csrc", "hipnlp_pose.hip")])
 
 
@@ -48,6 +48,7 @@ if __name__ == "__main__":
     t0 = min(blk[w, 0] for w in waves)
     nb = int(blk[waves[0], 2])
     print("interior knot, %d waves, cycles since the first wave entered the kernel (s_memtime); per barrier: arrival of every wave" % len(waves))
+    print("loads issued:", [int(blk[w, 5] - t0) for w in waves], " loads arrived:", [int(blk[w, 6] - t0) for w in waves])
     print("staged (after the first barrier):", [int(blk[w, 1] - t0) for w in waves])
     prev = max(blk[w, 1] for w in waves) - t0
     for i in range(nb):
