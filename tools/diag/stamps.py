@@ -43,7 +43,8 @@ if __name__ == "__main__":
     out = np.zeros((100 * batch, 8, 128), np.uint64)
     eng.lib.hipnlp_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
     eng.lib.hipnlp_debug_stamps(eng.h, out.ctypes.data_as(C.c_void_p))
-    blk = out[len(out) // 2].astype(np.int64)  # an interior knot
+    which = int(os.environ.get('STAMPS_WG', len(out) // 2))
+    blk = out[which].astype(np.int64)  # an interior knot (STAMPS_WG: linear workgroup index)
     waves = [w for w in range(8) if blk[w, 0] != 0]
     t0 = min(blk[w, 0] for w in waves)
     nb = int(blk[waves[0], 2])
