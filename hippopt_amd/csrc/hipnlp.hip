@@ -46,8 +46,12 @@ struct KArgs {
     double* jac;            // [batch][nnz]    or null
     double* grad;           // [batch][n]      or null
     double* g_stage;        // [batch][nk][gs::COUNT] knot-major staging of g (sharded mode) or null
-    double* cost_knot;      // [batch][nk][NCT]
-    int32_t* flags;         // [batch][nk][8]  non-finite detector, one word per wavefront (no workgroup vote at the end)
+    double* cost_knot;      // [batch][nk][NCT] per-knot cost partials (published with agent-scope stores, see publish_costs)
+    double* f;              // [batch]        total cost, written by the LAST workgroup of a trajectory to publish its partials
+    double* cost_terms;     // [batch][NCT]   per-term totals, same writer
+    unsigned long long* ticket;   // [batch]  arrivals so far, never reset: launch number `seq` is complete at seq * nk
+    int32_t* flag;          // [batch]        generation flag of the non-finite detector: == seq after a launch that produced one
+    int32_t seq, pad_;      // launch number of this handle (1, 2, ...)
     int32_t N, n, m, nnz, knot_begin, nk;
     int64_t jac_stride, jac_off, grad_stride, grad_off;  // output addressing: full arrays (stride nnz / n, offset 0) or shard-local
 #ifdef HIPNLP_STAMPS
@@ -131,6 +135,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         for (int it = 0; it < XV_ITERS; ++it) { const int i = tid + it * WG; if (i < XPAD) { s.x[i] = xv[it]; s.xm[i] = xmv[it]; } if (i < NPER) s.xo[i] = xov[it]; }
         if (tid < PK_STRIDE) s.pk[tid] = pkv;
         if (tid < 8) s.xg[tid] = xgv;
+        if (tid == 0) s.pub_ready = 0;
     }
     __syncthreads();
 
@@ -154,6 +159,91 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         gb[it] = slot < gs::COUNT ? tb.g_b[slot] : 0;
     }
 
+    // ---- total cost without a second kernel --------------------------------------------------------------------------------
+    // One wave (PUBW: idle in the late phases) PUBLISHES the knot's cost partials as soon as they are final — agent-scope stores,
+    // their acknowledgement, one ticket (fetch-add) per knot — spread over the barriers of the program so that every memory round
+    // trip hides behind a phase.  The workgroup that draws the last ticket of its trajectory reads all partials back (agent-scope
+    // loads) and sums them in a FIXED order (bitwise reproducible whatever the arrival order); nobody ever waits for another
+    // workgroup.  Only the (rare) minimize-mode horizon-end terms of the first / last knot are final too late for the hiding.
+    constexpr int PUBW = WAVES == 8 ? 7 : 3;
+    const bool ends_late = (first || last) && (tabs.head.ks.final_type == HIPNLP_EXPR_MINIMIZE || tabs.head.ks.periodicity_type == HIPNLP_EXPR_MINIMIZE);
+    unsigned long long pub_old = 0;
+    int pub_bad = 0;
+    auto pub_store = [&]() {
+        if (lane < NCT) {
+            const double cv = (lane == CT_ENDS && !ends_late) ? 0.0 : s.cost[lane];   // (t_ends_finish writes that zero only in phase F)
+            pub_bad |= !isfinite(cv);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.cost_knot + (size_t(b) * a.nk + kk) * NCT + lane),
+                               __double_as_longlong(cv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto pub_ticket = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the partials are in memory (agent-scope stores are write-through)
+        unsigned long long old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(a.ticket + b, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pub_old = old;
+    };
+    // last arriver: the SAME summation tree as hipnlp_reduce_kernel (both variants give bitwise the same f): knot k belongs to
+    // group k % 16; groups are summed in ascending k, combined (g0 + g1) + (g2 + g3) four at a time, then ((P0 + P1) + P2) + P3.
+    // Lane (term t = lane % 16, q = lane / 16) holds the groups 4 w + q, w = 0..3: the knots k = q + 4 j, group index w = j % 4.
+    // 32 loads per lane in flight at once (one memory round trip for a horizon of up to 128 knots).
+    bool pub_last = false;
+    double pub_v[32];
+    const unsigned long long* pub_base = reinterpret_cast<const unsigned long long*>(a.cost_knot + size_t(b) * a.nk * NCT);
+    auto pub_issue = [&](int k0) {
+        const int t = lane & 15;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int kq = k0 + 4 * u;
+            pub_v[u] = (t < NCT && kq < a.nk) ? __longlong_as_double((long long)__hip_atomic_load(pub_base + size_t(kq) * NCT + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
+        }
+    };
+    auto pub_await_ticket = [&]() {   // waits for the ticket; the last arriver puts its first 32 loads per lane in flight
+        const unsigned long long old = (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane(int(pub_old & 0xffffffffull)) |
+                                       ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane(int(pub_old >> 32)) << 32);
+        pub_last = old + 1ull == (unsigned long long)a.seq * (unsigned long long)a.nk;   // (wave-uniform)
+        if (pub_last) pub_issue(lane >> 4);
+    };
+    auto pub_sum = [&]() {
+        if (!pub_last) return;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = lane >> 4;;) {
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc[u & 3] += pub_v[u];
+            k0 += 128;
+            if (k0 >= a.nk) break;
+            pub_issue(k0);
+        }
+        double P[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            double pw = acc[w];
+            pw += __shfl_xor(pw, 16, 64);
+            pw += __shfl_xor(pw, 32, 64);
+            P[w] = pw;
+        }
+        const double term = ((P[0] + P[1]) + P[2]) + P[3];
+        if (lane < NCT) a.cost_terms[size_t(b) * NCT + lane] = term;
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < NCT; ++q) tot += __shfl(term, q, 64);
+        if (lane == 0) a.f[b] = tot;
+    };
+    // called by every wave right behind barrier number `passed` (0 = the one that ends phase A)
+    auto pub_step = [&](int passed) {
+        // (throughput variant: under load the acknowledgement of the partials takes long enough to stall the publishing wave at
+        //  its next barrier — measured -13 % at batch 64 — so it keeps the separate reduction kernel, cheap next to a long launch)
+        if (WAVES != 8 || wave != PUBW) return;
+        if (!ends_late) {
+            // Every cost term of an ordinary knot is final at the end of phase C; this wave has no task in phases D - F (eight-wave
+            // program): it waits for the acknowledgement of the partials inside phase D and for the ticket inside phase E.
+            // (Measured: publishing earlier, from inside phase C behind an LDS flag of t_frames, makes EVERY workgroup wait for the
+            //  acknowledgement — about 3 k cycles — at the barrier that ends phase C: 12.1 us per 100-knot step instead of 11.8.)
+            if (passed == 2) { pub_store(); pub_ticket(); }
+            else if (passed == 3) { pub_await_ticket(); pub_sum(); }
+        } else if (passed == 5) { pub_store(); pub_ticket(); pub_await_ticket(); pub_sum(); }
+    };
+
     KnotInfo ki{k, N, first, last};
     DevEm<TERRAIN> em{s.g, s.jac};
     Ctx<DevEm<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
@@ -164,9 +254,10 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     unsigned long long st_arr[8], st_dep[8];
     const unsigned long long st_staged = __builtin_amdgcn_s_memtime();
     int bid = 0;
-#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); __syncthreads(); st_dep[bid] = __builtin_amdgcn_s_memtime(); bid++;
+#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); __syncthreads(); st_dep[bid] = __builtin_amdgcn_s_memtime(); pub_step(bid); bid++;
 #else
-#define DEV_BARRIER __syncthreads();
+    int bid = 0;
+#define DEV_BARRIER __syncthreads(); pub_step(bid); bid++;
 #endif
     HIPNLP_KNOT_PROGRAM(DEV_R, DEV_BARRIER)
 #undef DEV_R
@@ -185,14 +276,18 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     for (int it = 0; it < G_ITERS; ++it) gvals[it] = s.g[(tid + it * WG) < gs::COUNT ? tid + it * WG : 0];
 #pragma unroll
     for (int it = 0; it < GR_ITERS; ++it) grvals[it] = s.grad[(tid + it * WG) < NXK ? tid + it * WG : 0];
-    const double cval = s.cost[tid < NCT ? tid : 0];
 #pragma unroll
     for (int it = 0; it < JP_ITERS; ++it) bad |= (jp[it] >= 0) & !isfinite(jvals[it]);
 #pragma unroll
     for (int it = 0; it < G_ITERS; ++it) bad |= (ga[it] >= 0) & !isfinite(gvals[it]);
 #pragma unroll
     for (int it = 0; it < GR_ITERS; ++it) bad |= ((tid + it * WG) < NXK) & !isfinite(grvals[it]);
-    bad |= (tid < NCT) & !isfinite(cval);
+    if (WAVES == 8) { if (wave == PUBW) bad |= pub_bad; }
+    else if (tid < NCT) {
+        const double cval = s.cost[tid];
+        bad |= !isfinite(cval);
+        a.cost_knot[(size_t(b) * a.nk + kk) * NCT + tid] = cval;
+    }
     const int anybad = __any(bad);
 #ifdef HIPNLP_DIAG_SKIP
     if (HIPNLP_DIAG_SKIP & 1) a.jac = nullptr;
@@ -225,9 +320,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         for (int it = 0; it < GR_ITERS; ++it) { const int i = tid + it * WG; if (i < NXK) out[i] = grvals[it]; }
         if (last && tid < NXG) a.grad[int64_t(b) * a.grad_stride + (int64_t(NXK) * N - a.grad_off) + tid] = 0.0;  // the global variables carry no cost
     }
-    if (tid < NCT) a.cost_knot[(size_t(b) * a.nk + kk) * NCT + tid] = cval;
-    if (lane == 0) a.flags[(size_t(b) * a.nk + kk) * 8 + wave] = anybad;
-    if (WAVES == 4 && tid < 4) a.flags[(size_t(b) * a.nk + kk) * 8 + 4 + tid] = 0;
+    if (anybad && lane == 0) atomicMax(a.flag + b, a.seq);   // generation flag: nothing to reset between launches
 #ifdef HIPNLP_STAMPS
     {
         st_arr[bid] = __builtin_amdgcn_s_memtime();   // after the vote and the store issue
@@ -241,55 +334,38 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 #endif
 }
 
-// f[b] = sum over knots and terms; cost_terms[b][t] = sum over knots; flag[b] = any non-finite.
-// One workgroup per trajectory.  Thread (group g = tid / 16, column c = tid % 16) sums column c (12 cost terms + the flag) of the
-// knots g, g + 16, ...: all its loads are independent and issued together (ONE memory round trip), then a fixed tree: two
-// lane-shuffles inside the wave, four waves through LDS, twelve terms in order.  Bitwise reproducible (the tree depends on nk only).
-// (Measured alternative: the last knot workgroup to arrive reduces inside the knot kernel — agent-scope stores of the 13-double
-//  record, vmcnt(0), ticket atomic, sc1 loads by the last arriver.  Correct and reproducible, but every workgroup then ends
-//  with two dependent memory round trips: 15.2 us vs 14.3 us per 100-knot step, 48 M vs 61 M knots/s at batch 64.)
+// Throughput variant only (4 waves; the latency variant sums inside the knot kernel, see pub_step): f[b] = sum over knots and
+// terms, cost_terms[b][t] = sum over knots.  One workgroup per trajectory.  Thread (group g = tid / 16, column c = tid % 16) sums
+// column c of the knots g, g + 16, ...: all its loads are independent and issued together (ONE memory round trip), then a fixed
+// tree: two lane-shuffles inside the wave, four waves through LDS, twelve terms in order.  Bitwise reproducible.
 constexpr int RWG = 256, RCOL = 16, RGRP = RWG / RCOL, RUNR = 8;
-static_assert(NCT + 1 <= RCOL, "reduce columns");
-__global__ __launch_bounds__(RWG) void hipnlp_reduce_kernel(const double* cost_knot, const int32_t* flags, int nk,
-                                                            double* f, double* cost_terms, int32_t* flag_out) {
+static_assert(NCT <= RCOL, "reduce columns");
+__global__ __launch_bounds__(RWG) void hipnlp_reduce_kernel(const double* cost_knot, int nk, double* f, double* cost_terms) {
     __shared__ double part[RWG / 64][RCOL];
-    __shared__ int pflag[RWG / 64];
     const int b = blockIdx.x, tid = threadIdx.x, c = tid % RCOL, g = tid / RCOL, lane = tid & 63, wave = tid >> 6;
     double acc = 0.0;
-    int bad = 0;
     for (int k0 = g; k0 < nk; k0 += RGRP * RUNR) {
         double v[RUNR];
-        int fl[RUNR];
 #pragma unroll
         for (int u = 0; u < RUNR; ++u) {
             const int k = k0 + u * RGRP;
             v[u] = (c < NCT && k < nk) ? cost_knot[(size_t(b) * nk + k) * NCT + c] : 0.0;
-            fl[u] = 0;
-            if (c == NCT && k < nk) {
-                const int4* fw = reinterpret_cast<const int4*>(flags + (size_t(b) * nk + k) * 8);
-                const int4 f0 = fw[0], f1 = fw[1];
-                fl[u] = f0.x | f0.y | f0.z | f0.w | f1.x | f1.y | f1.z | f1.w;
-            }
         }
 #pragma unroll
-        for (int u = 0; u < RUNR; ++u) { acc += v[u]; bad |= fl[u]; }
+        for (int u = 0; u < RUNR; ++u) acc += v[u];
     }
-    acc += __shfl_xor(acc, 16, 64); bad |= __shfl_xor(bad, 16, 64);
-    acc += __shfl_xor(acc, 32, 64); bad |= __shfl_xor(bad, 32, 64);
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
     if (lane < RCOL) part[wave][lane] = acc;
-    if (lane == NCT) pflag[wave] = bad;
     __syncthreads();
     if (tid == 0) {
         double tot = 0.0;
-        int anybad = 0;
         for (int t = 0; t < NCT; ++t) {
             const double term = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
             tot += term;
             if (cost_terms) cost_terms[size_t(b) * NCT + t] = term;
         }
-        for (int w = 0; w < RWG / 64; ++w) anybad |= pflag[w];
         if (f) f[b] = tot;
-        flag_out[b] = anybad;
     }
 }
 
@@ -314,7 +390,9 @@ struct hipnlp_handle {
     double *d_x = nullptr, *d_pk = nullptr, *d_g = nullptr, *d_jac = nullptr, *d_grad = nullptr, *d_f = nullptr;
     double *d_cost_knot = nullptr, *d_cost_terms = nullptr;
     GParams* d_gp = nullptr;
-    int32_t *d_flags = nullptr, *d_flag = nullptr;
+    int32_t* d_flag = nullptr;              // [batch] generation flag of the non-finite detector (== seq of the launch that raised it)
+    unsigned long long* d_ticket = nullptr;  // [batch] arrivals, never reset
+    int32_t seq = 0, seq_result = -1;        // launches so far; launch the cached host result belongs to
     unsigned long long* d_stamps = nullptr;
     // pinned host staging
     double *h_x = nullptr, *h_g = nullptr, *h_jac = nullptr, *h_grad = nullptr, *h_f = nullptr, *h_cost_terms = nullptr;
@@ -337,7 +415,7 @@ static void free_all(hipnlp_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* dptrs[] = {h->d_tb, h->d_x, h->d_pk, h->d_g, h->d_jac, h->d_grad, h->d_f, h->d_cost_knot, h->d_cost_terms, h->d_gp, h->d_flags, h->d_flag};
+    void* dptrs[] = {h->d_tb, h->d_x, h->d_pk, h->d_g, h->d_jac, h->d_grad, h->d_f, h->d_cost_knot, h->d_cost_terms, h->d_gp, h->d_ticket, h->d_flag};
     for (void* q : dptrs) if (q) (void)hipFree(q);
     void* hptrs[] = {h->h_x, h->h_g, h->h_jac, h->h_grad, h->h_f, h->h_cost_terms, h->h_flag};
     for (void* q : hptrs) if (q) (void)hipHostFree(q);
@@ -401,8 +479,10 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     CREATE_TRY(hipMalloc(&h->d_f, B * sizeof(double)));
     CREATE_TRY(hipMalloc(&h->d_cost_knot, B * size_t(h->nk) * NCT * sizeof(double)));
     CREATE_TRY(hipMalloc(&h->d_cost_terms, B * NCT * sizeof(double)));
-    CREATE_TRY(hipMalloc(&h->d_flags, B * size_t(h->nk) * 8 * sizeof(int32_t)));
+    CREATE_TRY(hipMalloc(&h->d_ticket, B * sizeof(unsigned long long)));
     CREATE_TRY(hipMalloc(&h->d_flag, B * sizeof(int32_t)));
+    CREATE_TRY(hipMemset(h->d_ticket, 0, B * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemset(h->d_flag, 0, B * sizeof(int32_t)));
     CREATE_TRY(hipHostMalloc(&h->h_x, B * n * sizeof(double)));
     CREATE_TRY(hipHostMalloc(&h->h_g, B * m * sizeof(double)));
     CREATE_TRY(hipHostMalloc(&h->h_jac, B * nnz * sizeof(double)));
@@ -517,7 +597,8 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     } else {
         a.jac_stride = h->L.nnz; a.jac_off = 0; a.grad_stride = h->L.n; a.grad_off = 0;
     }
-    a.cost_knot = h->d_cost_knot; a.flags = h->d_flags;
+    a.cost_knot = h->d_cost_knot; a.f = f_dev; a.cost_terms = h->d_cost_terms; a.ticket = h->d_ticket; a.flag = h->d_flag;
+    a.seq = ++h->seq; a.pad_ = 0;
     a.N = h->L.N; a.n = h->L.n; a.m = h->L.m; a.nnz = h->L.nnz; a.knot_begin = h->kb; a.nk = h->nk;
     bool prof = false;
     if (h->prof_cap > 0) { prof = h->prof_n < h->prof_cap && (h->prof_seen % h->prof_stride) == 0; h->prof_seen++; }
@@ -539,8 +620,8 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
         else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 4>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a);
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 1)], s));
-    hipLaunchKernelGGL(hipnlp_reduce_kernel, dim3(unsigned(h->batch)), dim3(RWG), 0, s,
-                       (const double*)h->d_cost_knot, (const int32_t*)h->d_flags, h->nk, f_dev, h->d_cost_terms, h->d_flag);
+    if (!h->wide)
+        hipLaunchKernelGGL(hipnlp_reduce_kernel, dim3(unsigned(h->batch)), dim3(RWG), 0, s, (const double*)h->d_cost_knot, h->nk, f_dev, h->d_cost_terms);
     if (timed) HIP_TRY(h, hipEventRecord(e2, s));
     HIP_TRY(h, hipGetLastError());
     if (prof) h->prof_n++;
@@ -592,13 +673,14 @@ int hipnlp_eval(hipnlp_handle* h, const double* x, int new_x, double* f, double*
         HIP_TRY(h, hipMemcpyAsync(h->h_jac, h->d_jac, B * nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         h->have_result = true;
+        h->seq_result = h->seq;
     }
     if (f) std::memcpy(f, h->h_f, B * sizeof(double));
     if (grad_f) std::memcpy(grad_f, h->h_grad, B * n * sizeof(double));
     if (g) std::memcpy(g, h->h_g, B * m * sizeof(double));
     if (jac) std::memcpy(jac, h->h_jac, B * nnz * sizeof(double));
     for (size_t b = 0; b < B; ++b)
-        if (h->h_flag[b]) { h->err = "non-finite value produced by the evaluation"; return HIPNLP_E_NUMERIC; }
+        if (h->h_flag[b] == h->seq_result) { h->err = "non-finite value produced by the evaluation"; return HIPNLP_E_NUMERIC; }
     return HIPNLP_OK;
 }
 

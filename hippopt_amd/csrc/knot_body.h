@@ -89,6 +89,7 @@ struct alignas(16) KnotScratch {
     // cost partials, reduced by t_reduce
     double c_pt[NC][3], c_joint[NJ], c_force[2][3], c_yaw[2];
     double cost[NCT];
+    int pub_ready, pub_pad_;   // set by t_frames once the last cost term of an ordinary knot is final (device: polled by the publishing wave)
     double grad[XPAD];
     double g[gs::COUNT];
     double jac[js::COUNT];
@@ -976,6 +977,7 @@ template <class Em> HD void t_frames(Ctx<Em>& cx, int f) {
         const double on = cx.ki.first ? 0.0 : 1.0;
         const double m = on * cx.st.m_frameq;
         s.cost[CT_FRAMEQ] = m * (e * e);
+        s.pub_ready = 1;   // (behind the cost in this lane's LDS order)
         s.chest_dc = 2.0 * m * e;
         s.chest_w[0] = M[7] - M[5]; s.chest_w[1] = M[2] - M[6]; s.chest_w[2] = M[3] - M[1];
     }
@@ -1248,9 +1250,9 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
     R(3, 1, t_fk_rot_b, FK_TASKS_B) R(3, 1, t_link_u_b, NJ - FK_SPLIT)                    \
     R(1, 2, t_hdyn_entries, 48) R(1, 3, t_hdyn_rows, HDYN_TASKS - 48)                     \
     R(2, 4, t_terrain_hnf, NC) R(2, 4, t_points_cost, 3) R(2, 4, t_foot_costs, FOOT_TASKS) R(2, 4, t_foot_cost_sum, 2) \
-    R(1, 5, t_terrain_planar, NC) R(0, 6, t_terrain_dcc, NC)                              \
+    R(1, 5, t_terrain_planar, NC) R(0, 6, t_terrain_dcc, NC) R(-1, 7, t_joint_cost, 1)    \
     BARRIER                                                                               \
-    R(0, 0, t_links, NL) R(1, 1, t_frames, 3) R(2, 2, t_link_inertia, NL) R(3, 3, t_joint_cost, 1) \
+    R(0, 0, t_links, NL) R(1, 1, t_frames, 3) R(2, 2, t_link_inertia, NL) R(3, -1, t_joint_cost, 1) \
     BARRIER                                                                               \
     R(0, 0, t_composite_g0, 64) R(1, 1, t_composite_g1, 64) R(1, 2, t_composite_g2, 64)   \
     R(2, 3, t_composite_g3, 64) R(2, 4, t_composite_g4, 64) R(3, 5, t_composite_g5, 64) R(3, 6, t_pkin, NC) \

@@ -44,6 +44,11 @@ if __name__ == "__main__":
     eng.lib.hipnlp_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
     eng.lib.hipnlp_debug_stamps(eng.h, out.ctypes.data_as(C.c_void_p))
     which = int(os.environ.get('STAMPS_WG', len(out) // 2))
+    if which < 0:   # the workgroup with the longest entry -> end
+        nb_ = int(out[0, 0, 2])
+        oo = out.astype(np.int64)
+        which = int(np.argmax(oo[:, :, 8 + 2 * nb_].max(axis=1) - oo[:, :, 0].min(axis=1)))
+        print('last workgroup to end:', which)
     blk = out[which].astype(np.int64)  # an interior knot (STAMPS_WG: linear workgroup index)
     waves = [w for w in range(8) if blk[w, 0] != 0]
     t0 = min(blk[w, 0] for w in waves)
@@ -66,4 +71,12 @@ if __name__ == "__main__":
     ent = out[:, 0, 0].astype(np.int64)
     endt = out[:, :, 8 + 2 * nb].astype(np.int64).max(axis=1)
     print("grid: first entry -> last entry %d cycles, first entry -> last end %d cycles" % (ent.max() - ent.min(), endt.max() - ent.min()))
+    o = out.astype(np.int64)
+    if len(waves) == 8:   # publishing wave (7): time from the release of B4 to its arrival at B5, per workgroup
+        d = o[:, 7, 8 + 2 * 5] - o[:, 7, 9 + 2 * 4]
+        print("wave 7, phase F (release B4 -> arrival B5): median %d  max %d (workgroup %d)" % (np.median(d), d.max(), int(np.argmax(d))))
+        e = o[:, :, 8 + 2 * nb].max(axis=1) - o[:, :, 0].min(axis=1)
+        print("entry -> end per workgroup: median %d  max %d (workgroup %d)" % (np.median(e), e.max(), int(np.argmax(e))))
+        t_first = o[:, :, 0].min()
+        print("first entry of the grid -> last end of the grid: %d cycles; last entry %d" % (o[:, :, 8 + 2 * nb].max() - t_first, o[:, :, 0].min(axis=1).max() - t_first))
     print("kernel ms:", eng.last_kernel_ms())
