@@ -140,14 +140,23 @@ def main():
     fence()
     # HIP events around every `stride`-th knot-kernel launch of the timed region: an event record drains the stream and costs
     # microseconds, bracketing EVERY launch would inflate a 100-knot step by two thirds ("Measuring")
+    # When a step is exactly ONE kernel launch of ~10 us (latency variant of the engine, no sharded reassembly), an event pair around
+    # a single launch would be a quarter of what it measures: the events then bracket RUNS of `stride` consecutive launches
+    # (nothing in between) and the run duration is divided by the run length (dispatch gaps inside a run included).
     stride = max(1, args.event_stride)
-    eng.profile_begin((args.steps + stride - 1) // stride, stride)
+    single_kernel_step = (not knot_sharded) and eng.kernels_per_eval() == 1
+    if single_kernel_step:
+        eng.profile_begin_runs(max(1, args.steps // (4 * stride)), stride)
+    else:
+        eng.profile_begin((args.steps + stride - 1) // stride, stride)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     fence()
     el = time.perf_counter() - t0
     kern_ms, launch_ms, nprof = eng.profile_end()
+    timing = ("HIP events around runs of %d consecutive launches / %d (one kernel launch per step)" % (stride, stride)) if single_kernel_step \
+        else ("HIP events around every %d-th knot-kernel launch" % stride)
     t = torch.tensor([el], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -205,7 +214,7 @@ def main():
                        "n": int(d.n), "m": int(d.m), "nnz": int(d.nnz), "nnz_per_knot": nnz_knot},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "hipnlp_knot_kernel", "kernel_ms": kern_ms, "launch_ms": launch_ms,
-                         "launches_timed": nprof, "event_stride": stride, "algorithmic_bytes_per_knot": bytes_knot, "knots_per_launch": local_knots},
+                         "launches_timed": nprof, "event_stride": stride, "timing": timing, "algorithmic_bytes_per_knot": bytes_knot, "knots_per_launch": local_knots},
         }
         if shard_resident is not None:
             line["shard_resident"] = shard_resident

@@ -388,6 +388,8 @@ struct hipnlp_handle {
     hipEvent_t last_e0 = nullptr, last_e2 = nullptr;  // events around the last TIMED launch
     std::vector<hipEvent_t> prof_ev;  // triples
     int prof_cap = 0, prof_n = 0, prof_stride = 1, prof_seen = 0;
+    int prof_run = 0;         // > 0: brackets of prof_run consecutive launches (hipnlp_profile_begin_runs)
+    bool prof_open = false;
     DeviceTables* d_tb = nullptr;
     double *d_x = nullptr, *d_pk = nullptr, *d_g = nullptr, *d_jac = nullptr, *d_grad = nullptr, *d_f = nullptr;
     double *d_cost_knot = nullptr, *d_cost_terms = nullptr;
@@ -602,11 +604,17 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     a.cost_knot = h->d_cost_knot; a.f = f_dev; a.cost_terms = h->d_cost_terms; a.ticket = h->d_ticket; a.flag = h->d_flag;
     a.seq = ++h->seq; a.pad_ = 0;
     a.N = h->L.N; a.n = h->L.n; a.m = h->L.m; a.nnz = h->L.nnz; a.knot_begin = h->kb; a.nk = h->nk;
-    bool prof = false;
-    if (h->prof_cap > 0) { prof = h->prof_n < h->prof_cap && (h->prof_seen % h->prof_stride) == 0; h->prof_seen++; }
+    bool prof = false, run_first = false, run_last = false;
+    if (h->prof_cap > 0 && h->prof_run > 0) {        // runs of consecutive launches: one event before the first, one after the last
+        const int pos = h->prof_seen % h->prof_run;
+        run_first = !h->prof_open && h->prof_n < h->prof_cap && pos == 0;
+        run_last = (h->prof_open || run_first) && pos == h->prof_run - 1;
+        h->prof_seen++;
+    } else if (h->prof_cap > 0) { prof = h->prof_n < h->prof_cap && (h->prof_seen % h->prof_stride) == 0; h->prof_seen++; }
     const bool timed = prof || always_timed;
     hipEvent_t e0 = prof ? h->prof_ev[size_t(3 * h->prof_n)] : h->ev0;
     hipEvent_t e2 = prof ? h->prof_ev[size_t(3 * h->prof_n + 2)] : h->ev1;
+    if (run_first) { HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n)], s)); h->prof_open = true; }
 #ifdef HIPNLP_STAMPS
     if (!h->d_stamps) HIP_TRY(h, hipMalloc(&h->d_stamps, size_t(h->nk) * size_t(h->batch) * 1024 * sizeof(unsigned long long)));
     a.stamps = h->d_stamps;
@@ -625,6 +633,12 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     if (!h->wide)
         hipLaunchKernelGGL(hipnlp_reduce_kernel, dim3(unsigned(h->batch)), dim3(RWG), 0, s, (const double*)h->d_cost_knot, h->nk, f_dev, h->d_cost_terms);
     if (timed) HIP_TRY(h, hipEventRecord(e2, s));
+    if (run_last) {
+        HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 1)], s));
+        HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 2)], s));
+        h->prof_open = false;
+        h->prof_n++;
+    }
     HIP_TRY(h, hipGetLastError());
     if (prof) h->prof_n++;
     if (timed) { h->last_e0 = e0; h->last_e2 = e2; h->timing_valid = true; }
@@ -738,9 +752,20 @@ int hipnlp_profile_begin(hipnlp_handle* h, int max_launches, int stride) {
     h->prof_n = 0;
     h->prof_stride = stride;
     h->prof_seen = 0;
+    h->prof_run = 0;
+    h->prof_open = false;
     h->timing_valid = false;
     return HIPNLP_OK;
 }
+int hipnlp_profile_begin_runs(hipnlp_handle* h, int max_runs, int run_len) {
+    if (!h || run_len < 1) return HIPNLP_E_INVALID;
+    const int rc = hipnlp_profile_begin(h, max_runs, 1);
+    if (rc != HIPNLP_OK) return rc;
+    h->prof_run = run_len;
+    return HIPNLP_OK;
+}
+
+int hipnlp_kernels_per_eval(const hipnlp_handle* h) { return h ? (h->wide ? 1 : 2) : HIPNLP_E_INVALID; }
 
 int hipnlp_profile_end(hipnlp_handle* h, double* mean_knot_kernel_ms, double* mean_launch_ms, int* count) {
     if (!h) return HIPNLP_E_INVALID;
@@ -753,9 +778,12 @@ int hipnlp_profile_end(hipnlp_handle* h, double* mean_knot_kernel_ms, double* me
         HIP_TRY(h, hipEventElapsedTime(&m2, h->prof_ev[size_t(3 * i)], h->prof_ev[size_t(3 * i + 2)]));
         a += m1; b += m2;
     }
-    if (count) *count = h->prof_n;
-    if (mean_knot_kernel_ms) *mean_knot_kernel_ms = h->prof_n ? a / h->prof_n : 0.0;
-    if (mean_launch_ms) *mean_launch_ms = h->prof_n ? b / h->prof_n : 0.0;
+    const double per = double(h->prof_n) * double(h->prof_run > 0 ? h->prof_run : 1);   // launches behind the sums
+    if (count) *count = int(per);
+    if (mean_knot_kernel_ms) *mean_knot_kernel_ms = h->prof_n ? a / per : 0.0;
+    if (mean_launch_ms) *mean_launch_ms = h->prof_n ? b / per : 0.0;
+    h->prof_run = 0;
+    h->prof_open = false;
     h->prof_cap = 0;
     h->prof_n = 0;
     h->timing_valid = false;

@@ -18,7 +18,7 @@ EXPORTS = [
     "hipnlp_create", "hipnlp_destroy", "hipnlp_last_error", "hipnlp_get_dims", "hipnlp_set_params",
     "hipnlp_bounds", "hipnlp_simple_rows", "hipnlp_sparsity", "hipnlp_eval", "hipnlp_eval_device",
     "hipnlp_cost_terms", "hipnlp_cost_term_name", "hipnlp_num_row_blocks", "hipnlp_row_block",
-    "hipnlp_last_kernel_ms", "hipnlp_profile_begin", "hipnlp_profile_end",
+    "hipnlp_last_kernel_ms", "hipnlp_profile_begin", "hipnlp_profile_end", "hipnlp_kernels_per_eval", "hipnlp_profile_begin_runs",
     "hipnlp_eval_device_shard", "hipnlp_stage_rows",
     "hipnlp_pose_create", "hipnlp_pose_destroy", "hipnlp_pose_last_error", "hipnlp_pose_get_dims", "hipnlp_pose_set_params",
     "hipnlp_pose_bounds", "hipnlp_pose_sparsity", "hipnlp_pose_eval", "hipnlp_pose_eval_device", "hipnlp_pose_cost_terms",
@@ -200,11 +200,19 @@ class HipNlp:
         """Arm HIP-event timing of every `stride`-th device-path launch (at most max_launches samples)."""
         self._check(self.lib.hipnlp_profile_begin(self.h, int(max_launches), int(stride)))
 
+    def profile_begin_runs(self, max_runs, run_len):
+        """HIP events around RUNS of run_len consecutive launches (see include/hipnlp.h)"""
+        self._check(self.lib.hipnlp_profile_begin_runs(self.h, int(max_runs), int(run_len)))
+
     def profile_end(self):
         """(mean knot-kernel ms, mean launch ms incl. the cost reduction kernel, launches)"""
         a, b, n = C.c_double(), C.c_double(), C.c_int()
         self._check(self.lib.hipnlp_profile_end(self.h, C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
+
+    def kernels_per_eval(self):
+        """1: latency variant (cost summed inside the knot kernel), 2: throughput variant (knot kernel + reduction kernel)"""
+        return int(self.lib.hipnlp_kernels_per_eval(self.h))
 
     def eval_device_shard(self, x_ptr, f_ptr, grad_ptr, g_stage_ptr, jac_ptr, stream=0):
         self._check(self.lib.hipnlp_eval_device_shard(self.h, C.c_void_p(x_ptr), C.c_void_p(f_ptr or None), C.c_void_p(grad_ptr or None),

@@ -238,6 +238,13 @@ int hipnlp_last_kernel_ms(hipnlp_handle* h, float* ms);
  * launch stream.  profile_end synchronises and returns the mean durations (ms) and the number of timed launches.   */
 int hipnlp_profile_begin(hipnlp_handle* h, int max_launches, int stride);
 int hipnlp_profile_end(hipnlp_handle* h, double* mean_knot_kernel_ms, double* mean_launch_ms, int* count);
+/* Runs instead of single launches: one event before the first and one after the last of every run_len consecutive launches (nothing
+ * in between); profile_end then returns the mean duration per launch of the runs (dispatch gaps between the launches of a run
+ * included) and the number of launches measured.  For launches so short that an event pair around each would dominate. */
+int hipnlp_profile_begin_runs(hipnlp_handle* h, int max_runs, int run_len);
+/* Kernel launches behind one device-path evaluation: 1 (latency variant: launches of at most 256 knots, the cost is summed inside
+ * the knot kernel) or 2 (throughput variant: knot kernel + cost reduction kernel). */
+int hipnlp_kernels_per_eval(const hipnlp_handle* h);
 
 /* =====================================================================================================================
  * Static pose finder (BASELINE config 2): the single-knot NLP of
