@@ -371,6 +371,19 @@ __global__ __launch_bounds__(RWG) void hipnlp_reduce_kernel(const double* cost_k
     }
 }
 
+// Reassembly behind the all-gather of the knot-sharded path: out[i] = gathered[src[i]], and block 0 adds the
+// per-rank cost partials in rank order.  One launch instead of an index-select, a second gather and a sum.
+__global__ __launch_bounds__(256) void hipnlp_reassemble_kernel(const double* gathered, const int64_t* src, double* out, int64_t count,
+                                                                int world, int64_t shard_len, double* f_out) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = gathered[src[i]];
+    if (f_out && blockIdx.x == 0 && threadIdx.x == 0) {
+        double f = 0.0;
+        for (int r = 0; r < world; ++r) f += gathered[int64_t(r) * shard_len];
+        *f_out = f;
+    }
+}
+
 thread_local std::string g_create_error;
 
 }  // namespace
@@ -763,6 +776,15 @@ int hipnlp_profile_begin_runs(hipnlp_handle* h, int max_runs, int run_len) {
     if (rc != HIPNLP_OK) return rc;
     h->prof_run = run_len;
     return HIPNLP_OK;
+}
+
+int hipnlp_reassemble(const double* gathered_dev, const int64_t* src_dev, double* out_dev, int64_t count, int world, int64_t shard_len,
+                      double* f_out_dev, void* stream) {
+    if (!gathered_dev || !src_dev || !out_dev || count < 0 || world < 1) return HIPNLP_E_INVALID;
+    const int64_t blocks = (count + 255) / 256;
+    const unsigned grid = unsigned(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
+    hipLaunchKernelGGL(hipnlp_reassemble_kernel, dim3(grid), dim3(256), 0, hipStream_t(stream), gathered_dev, src_dev, out_dev, count, world, shard_len, f_out_dev);
+    return hipGetLastError() == hipSuccess ? HIPNLP_OK : HIPNLP_E_NODEVICE;
 }
 
 int hipnlp_kernels_per_eval(const hipnlp_handle* h) { return h ? (h->wide ? 1 : 2) : HIPNLP_E_INVALID; }

@@ -71,7 +71,13 @@ class ShardedCallback:
             raise ValueError("shards do not tile the problem: grad %d/%d jac %d/%d missing %d" % (go, n, jo, nnz, int((src < 0).sum())))
         self.src = torch.from_numpy(src).to(device)
         self.f_src = torch.arange(self.world, device=device) * self.shard_len
-        self.out = torch.empty(n + nnz + m, dtype=torch.float64, device=device)
+        self.out = torch.empty(n + nnz + m + 1, dtype=torch.float64, device=device)   # [grad | jac | g | f]
+        self._lib = None
+        if torch.device(device).type == "cuda":   # one HIP launch for the whole reassembly (hipnlp_reassemble); CPU tests: torch ops
+            import ctypes as C
+            from .hipnlp import load_library
+            self._lib = load_library()
+            self._lib.hipnlp_reassemble.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
 
     def __call__(self, x):
         """One callback set for the whole horizon.  Returns (f, grad, jac, g) views of the reassembled buffer."""
@@ -81,9 +87,17 @@ class ShardedCallback:
             gathered = self.all
         else:
             gathered = self.buf
-        torch.index_select(gathered, 0, self.src, out=self.out)
-        f = gathered.index_select(0, self.f_src).sum()
-        return f, self.out[:self.n], self.out[self.n:self.n + self.nnz], self.out[self.n + self.nnz:]
+        tot = self.n + self.nnz + self.m
+        if self._lib is not None:
+            rc = self._lib.hipnlp_reassemble(gathered.data_ptr(), self.src.data_ptr(), self.out.data_ptr(), tot, self.world, self.shard_len,
+                                             self.out.data_ptr() + 8 * tot, torch.cuda.current_stream().cuda_stream)
+            if rc != 0:
+                raise RuntimeError("hipnlp_reassemble failed (%d)" % rc)
+            f = self.out[tot]
+        else:
+            torch.index_select(gathered, 0, self.src, out=self.out[:tot])
+            f = gathered.index_select(0, self.f_src).sum()
+        return f, self.out[:self.n], self.out[self.n:self.n + self.nnz], self.out[self.n + self.nnz:tot]
 
 
 def hip_shard_backend(engine):

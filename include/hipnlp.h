@@ -216,6 +216,11 @@ int hipnlp_eval_device(hipnlp_handle* h, const double* x_dev,
 int hipnlp_eval_device_shard(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_shard,
                              double* g_stage, double* jac_shard, void* stream);
 int hipnlp_stage_rows(const hipnlp_handle* h, int k, int32_t* rows /*[HIPNLP_G_STAGE]*/);
+/* Reassembly behind the all-gather of the fused shard buffers: out[i] = gathered[src[i]] (i < count: [grad | jac | g] in reference
+ * order) and *f_out = sum over ranks, in rank order, of gathered[r * shard_len] (the cost partials); device pointers on the current
+ * device, enqueued on `stream`, not synchronised.  Stateless (no handle). */
+int hipnlp_reassemble(const double* gathered_dev, const int64_t* src_dev, double* out_dev, int64_t count, int world, int64_t shard_len,
+                      double* f_out_dev, void* stream);
 
 /* Per-named-cost values of the last evaluation (Output.cost_values, base/problem.py:28-56):
  * values[batch][HIPNLP_NCOST_TERMS], summed over knots, in the order of hipnlp_cost_term_name(). */

@@ -321,3 +321,26 @@ def test_maximum_sizes_and_shard_consistency(model, HipNlp):
     f1, grad1, g1, jac1 = one.eval(xs)
     for b in (0, 9, 1027, B - 1):
         assert np.array_equal(jacb[b], jac1[b % 8]) and np.array_equal(gb[b], g1[b % 8]) and fb[b] == f1[b % 8]
+
+
+def test_sharded_callback_reassembly_on_gpu(model, HipNlp):
+    """ShardedCallback on the GPU at world size 1: the fused shard buffer of the whole horizon goes through the
+    library's one-launch reassembly (hipnlp_reassemble) and must equal the unsharded callback bit for bit; f is the in-kernel sum."""
+    import torch
+    from hippopt_amd.sharded import ShardedCallback, hip_shard_backend, hip_shard_info
+    N = 24
+    st = periodic_step_settings(N, model)
+    x, p = make_workload(st, model, batch=1, seed=77)
+    full = HipNlp(st, model)
+    full.set_params(p)
+    f, grad, g, jac = full.eval(x)
+    dev = torch.device("cuda", 0)
+    sh = HipNlp(st, model, knot_begin=0, knot_end=N)
+    sh.set_params(p)
+    cb = ShardedCallback(N, sh.n, sh.m, sh.nnz, hip_shard_info(sh, 0, N), hip_shard_backend(sh), dev)
+    xd = torch.from_numpy(x[0]).to(dev)
+    for _ in range(3):
+        fs, grads, jacs, gs = cb(xd)
+    torch.cuda.synchronize()
+    assert float(fs) == f[0]
+    assert np.array_equal(grads.cpu().numpy(), grad[0]) and np.array_equal(jacs.cpu().numpy(), jac[0]) and np.array_equal(gs.cpu().numpy(), g[0])
