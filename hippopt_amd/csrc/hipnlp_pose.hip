@@ -107,8 +107,9 @@ __device__ __forceinline__ void pose_stage(const PArgs& a, KnotScratch& s, PoseS
     __syncthreads();
 }
 
-// 3 waves per SIMD = 3 workgroups per CU (the LDS bound): cap the register allocation there (<= 168 VGPRs)
-template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3, 3))) void hipnlp_pose_kernel(PArgs a) {
+// Two waves per SIMD (<= 256 VGPRs, two workgroups per CU).  Capped at 168 for the three workgroups the LDS would allow, the
+// compiler spilled 12-18 VGPRs to scratch and the kernel ran 3.6x slower (0.33 ms vs 0.09 ms for 4096 poses).
+template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void hipnlp_pose_kernel(PArgs a) {
     __shared__ KnotScratch s;
     __shared__ PoseShared tabs;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -150,7 +151,7 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
 
 // Exact Hessian of the Lagrangian (IPOPT eval_h, pose_hess_body.h): the pose program runs as in hipnlp_pose_kernel (its g / jac
 // values stay in LDS, unused), the Hessian tasks run behind it and the workgroup streams out the lower-triangle CCS value run.
-template <int TERRAIN> __global__ __launch_bounds__(WG) void hipnlp_pose_hess_kernel(PArgs a) {
+template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void hipnlp_pose_hess_kernel(PArgs a) {
     __shared__ KnotScratch s;
     __shared__ PoseShared tabs;
     __shared__ HessScratch hx;
