@@ -7,11 +7,12 @@ multiple-shooting NLP (BASELINE.json metric) on synthetic, HBM-resident inputs.
   python bench.py [--gpus N] [--steps K] [--warmup W] [--horizon 100] [--batch 1] [--shard knots|batch]
 
 N = 1 : workload "kinodynamic periodic walking, N = 100 knots" (BASELINE config 4 on one GPU).
-N > 1 : launched by torch.distributed.run, one rank per GPU.  Default `--shard knots` (north_star): the
-        horizon grows with N (100 knots per GPU, weak scaling), shooting intervals are sharded contiguously
-        and every step ends with ONE RCCL all-gather of the fused shard buffers + the reassembly of
-        [grad f | jac g | g] in reference order on every rank.  `--shard batch`: N independent 100-knot
-        trajectories, no collective (the MPC / batched-initial-guess shape).
+N > 1 : launched by torch.distributed.run, one rank per GPU.  Default `--shard batch`: N independent 100-knot trajectories, one per
+        GPU, no data-path collective (the MPC / batched-initial-guess shape of BASELINE config 5: independent NLPs partition over
+        the GPUs, nothing is exchanged) -> `value`.  In the SAME run the knot-sharded path of north_star is measured as well and
+        reported beside it (`knot_sharded_allgather`): ONE trajectory whose horizon grows with N (100 knots per GPU), shooting
+        intervals sharded contiguously, every step ending with ONE RCCL all-gather of the fused shard buffers + the one-launch
+        reassembly of [grad f | jac g | g] in reference order on every rank.  `--shard knots` makes that path the `value`.
 The JSON line carries `roofline` (HIP-event timed knot kernel vs the 8 TB/s HBM peak) and `cpu_baseline`
 (the CPU oracle timed on the host, rank 0, N = 1 only).
 """
@@ -70,7 +71,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--workload", choices=["periodic", "single", "stairs"], default="periodic",
                     help="periodic walking (BASELINE metric, default) | single step (final state / periodicity skipped) | stairs (smooth terrain)")
-    ap.add_argument("--shard", choices=["knots", "batch"], default="knots")
+    ap.add_argument("--shard", choices=["knots", "batch"], default="batch")
+    ap.add_argument("--also-knot-sharded", action="store_true", help="measure the knot-sharded all-gather path beside `value` even on one GPU (default: whenever WORLD_SIZE > 1)")
     ap.add_argument("--event-stride", type=int, default=16, help="time every n-th launch of the timed region with HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the sharded path on one GPU (debug)")
@@ -179,6 +181,37 @@ def main():
         shard_resident = {"knots_per_s": knots_per_step_total * args.steps / float(t2.item()), "ms_per_step": 1e3 * float(t2.item()) / args.steps,
                           "note": "knot shards evaluated, outputs left shard-resident in each rank's HBM (no all-gather / reassembly)"}
 
+    # the knot-sharded all-gather path of north_star, measured in the same run beside a batch-sharded `value`
+    ks_extra = None
+    if (world > 1 or args.also_knot_sharded) and not knot_sharded and args.batch == 1:
+        from hippopt_amd.sharded import ShardedCallback, hip_shard_backend, hip_shard_info, knot_range
+        hz = args.horizon * world
+        st2 = {"periodic": periodic_step_settings, "single": single_step_settings, "stairs": stairs_settings}[args.workload](hz, model)
+        x2, p2 = make_workload(st2, model, batch=1, seed=1004)   # the SAME trajectory on every rank
+        if args.workload == "stairs":
+            place_on_step_flanks(x2, st2, seed=1004)
+        xs2 = [torch.from_numpy(x2 + 1e-3 * i * np.random.RandomState(5).standard_normal(x2.shape)).to(device) for i in range(nvar)]
+        kb, ke = knot_range(hz, world, rank)
+        eng2 = HipNlp(st2, model, batch=1, knot_begin=kb, knot_end=ke, device=local_rank)
+        eng2.set_params(p2)
+        cb2 = ShardedCallback(hz, eng2.n, eng2.m, eng2.nnz, hip_shard_info(eng2, kb, ke), hip_shard_backend(eng2), device)
+        ksteps = max(1, min(args.steps, 500))
+        for i in range(min(args.warmup, 50)):
+            cb2(xs2[i % nvar])
+        fence()
+        t1 = time.perf_counter()
+        for i in range(ksteps):
+            cb2(xs2[i % nvar])
+        fence()
+        t2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        ks_extra = {"knots_per_s": hz * ksteps / float(t2.item()), "ms_per_step": 1e3 * float(t2.item()) / ksteps, "horizon": hz,
+                    "steps": ksteps, "parallelism": "knot-sharded x%d + all-gather + reassembly" % world,
+                    "note": "ONE trajectory of %d knots, %d per GPU: shard evaluation, one all-gather of the fused shard buffers "
+                            "(RCCL), one-launch reassembly of [grad | jac | g] in reference order on every rank" % (hz, args.horizon)}
+        del cb2, eng2
+
     if rank == 0:
         d = eng.dims
         nnz_knot = int(d.nnz_knot)
@@ -210,7 +243,7 @@ def main():
                                     "stairs": "kinodynamic walking on stairs (smooth two-step terrain), N=%d knots per GPU, batch %d (BASELINE config 5 shape)"}[args.workload]
                                    % (args.horizon, args.batch),
                        "horizon": horizon, "batch": args.batch, "knots_per_step": knots_per_step_total,
-                       "parallelism": ("knot-sharded x%d + all-gather" % world) if knot_sharded else ("replica x%d" % world),
+                       "parallelism": ("knot-sharded x%d + all-gather" % world) if knot_sharded else ("independent trajectories x%d, no collective" % world),
                        "n": int(d.n), "m": int(d.m), "nnz": int(d.nnz), "nnz_per_knot": nnz_knot},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "hipnlp_knot_kernel", "kernel_ms": kern_ms, "launch_ms": launch_ms,
@@ -218,6 +251,8 @@ def main():
         }
         if shard_resident is not None:
             line["shard_resident"] = shard_resident
+        if ks_extra is not None:
+            line["knot_sharded_allgather"] = ks_extra
         if world == 1 and not knot_sharded:
             # PCIe-inclusive rate of the host-buffer boundary (hipnlp_eval: H2D x, launch, D2H f/grad/g/jac); never `value`
             eng.eval(x_np)
