@@ -184,6 +184,7 @@ def main():
     # the knot-sharded all-gather path of north_star, measured in the same run beside a batch-sharded `value`
     ks_extra = None
     if (world > 1 or args.also_knot_sharded) and not knot_sharded and args.batch == 1:
+      try:
         from hippopt_amd.sharded import ShardedCallback, hip_shard_backend, hip_shard_info, knot_range
         hz = args.horizon * world
         st2 = {"periodic": periodic_step_settings, "single": single_step_settings, "stairs": stairs_settings}[args.workload](hz, model)
@@ -211,6 +212,8 @@ def main():
                     "note": "ONE trajectory of %d knots, %d per GPU: shard evaluation, one all-gather of the fused shard buffers "
                             "(RCCL), one-launch reassembly of [grad | jac | g] in reference order on every rank" % (hz, args.horizon)}
         del cb2, eng2
+      except Exception as err:  # noqa: BLE001  (the extra measurement must not take `value` down with it)
+        ks_extra = {"error": "%s: %s" % (type(err).__name__, err)}
 
     if rank == 0:
         d = eng.dims
