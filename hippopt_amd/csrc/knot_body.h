@@ -34,7 +34,13 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 #define HIPNLP_WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier()
 #define HIPNLP_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)   // a value the caller knows to be the same in every lane -> SGPR
+// Everything above this line is issued before anything below it: used between a batch of independent LDS reads and the first
+// use of their values.  Left alone, the scheduler puts every read next to its use and waits for each one in turn (eight
+// dependent round trips of ~130 cycles for an eight-term sum).  Only where a sum of LDS values is long: staging the operands of
+// ordinary tasks this way measured slower.
+#define HIPNLP_ISSUE_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
+#define HIPNLP_ISSUE_FENCE() ((void)0)
 #define HIPNLP_WAVE_SYNC() ((void)0)
 #define HIPNLP_UNIFORM(x) (x)
 #endif
@@ -739,6 +745,8 @@ template <class Em> HD void t_fk_rot_at(Ctx<Em>& cx, int t, int q0) {
     double v0 = s.Rb[3 * r], v1 = s.Rb[3 * r + 1], v2 = s.Rb[3 * r + 2];
     double o = 0.0, w = s.omega[r], ar = 0.0;
     // q0: every list of this task group is padded up to there (group-uniform: the leading identity steps are skipped)
+    // (measured: reading the record of step q + 1 while step q is computed — explicit software pipelining — is 5 % slower on the
+    //  eight-wave kernel, which then holds 248 VGPRs, and no faster at batch)
     HIPNLP_UNROLL
     for (int q = q0; q < 8; ++q) {
         const int ia = cx.kt.anc[j][q];
@@ -782,11 +790,16 @@ template <class Em> HD void t_link_u_b(Ctx<Em>& cx, int j) { t_link_u(cx, j + FK
 HD void link_origin_velocity(const KnotScratch& s, const KinTables& kt, int i, double* v) {
     v[0] = v[1] = v[2] = 0.0;
     if (i == 0) return;
+    double u[8][3];
     HIPNLP_UNROLL
     for (int q = 0; q < 8; ++q) {
-        const double* u = s.Uj[kt.anc[i - 1][q]];
-        for (int r = 0; r < 3; ++r) v[r] += u[r];
+        const double* uq = s.Uj[kt.anc[i - 1][q]];
+        for (int r = 0; r < 3; ++r) u[q][r] = uq[r];
     }
+    HIPNLP_ISSUE_FENCE();   // all 24 reads in flight before the first add
+    HIPNLP_UNROLL
+    for (int q = 0; q < 8; ++q)
+        for (int r = 0; r < 3; ++r) v[r] += u[q][r];
 }
 
 // (the branches of t_hdyn diverge inside a wave: entries and rows + com entries are task groups of their own)
@@ -1000,11 +1013,22 @@ template <class Em> HD void t_composite(Ctx<Em>& cx, int t) {
     // trip count of the wave iteration = largest subtree among its four links (uniform: scalar loop); shorter lists are padded
     // with the zero slot own[NL]
     const int cnt = HIPNLP_UNIFORM(int(cx.kt.comp_cnt[t >> 6]));
+    // the whole descendant list of the link first (24 bytes, three 8-byte reads in flight together), then eight records per
+    // step, all eight reads in flight before the first add
+    static_assert(NL == 24 && sizeof(cx.kt.desc[0]) == 24, "descendant lists are read as three 8-byte words");
+    const unsigned long long* dw = reinterpret_cast<const unsigned long long*>(cx.kt.desc[i]);
+    const unsigned long long w3[3] = {dw[0], dw[1], dw[2]};
     double acc = 0.0;
-#if defined(__HIPCC__)
-#pragma unroll 4
-#endif
-    for (int n = 0; n < cnt; ++n) acc += s.own[cx.kt.desc[i][n]][r];
+    HIPNLP_UNROLL
+    for (int c = 0; c < 3; ++c) {
+        if (8 * c >= cnt) break;   // (wave-uniform)
+        double v[8];
+        HIPNLP_UNROLL
+        for (int u = 0; u < 8; ++u) v[u] = s.own[int((w3[c] >> (8 * u)) & 0xffull)][r];
+        HIPNLP_ISSUE_FENCE();
+        HIPNLP_UNROLL
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
     s.comp[i][r] = acc;
 }
 template <class Em> HD void t_composite_g0(Ctx<Em>& cx, int t) { t_composite(cx, t); }          // the four largest subtrees

@@ -52,8 +52,8 @@ struct KinTables {
     // tree as ancestor / descendant lists: every lane sums over its own list, no loop-carried dependence
     int32_t par_link[NJ];       // parent link of joint j
     int32_t fk_first[2];        // first useful position of the (front-padded) ancestor lists of joints [0, FK_SPLIT) / [FK_SPLIT, NJ)
-    int8_t anc[NJ][8];          // joints on the path root -> j (inclusive, ascending, j LAST), FRONT padded with NJ (identity / zero slot)
-    int8_t desc[NL][NL];        // links of the subtree rooted at link i (inclusive), padded with NL (zero slot)
+    alignas(8) int8_t anc[NJ][8];  // (read as one 8-byte word) joints on the path root -> j (inclusive, ascending, j LAST), FRONT padded with NJ (identity / zero slot)
+    alignas(8) int8_t desc[NL][NL];  // (read as 8-byte words) links of the subtree rooted at link i (inclusive), padded with NL (zero slot)
     int16_t ndesc[NL];          // size of that subtree
     int16_t comp_order[NL];     // links by decreasing subtree size (order of the composite tasks)
     int16_t comp_cnt[NL / 4];   // largest subtree in each group of four links of that order
