@@ -236,13 +236,18 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         if (WAVES != 8 || wave != PUBW) return;
         if (!ends_late) {
             // Every cost term of an ordinary knot is final at the end of phase C; this wave has no task in phases D - F (eight-wave
-            // program): it waits for the acknowledgement of the partials inside phase D and for the ticket inside phase E.
+            // program).
             // (Measured: publishing earlier, from inside phase C behind an LDS flag of t_frames, makes EVERY workgroup wait for the
             //  acknowledgement — about 3 k cycles — at the barrier that ends phase C: 12.1 us per 100-knot step instead of 11.8.
             //  Taking each step one phase after the previous one instead of waiting right away: 12.5 us.  What is left of the
             //  tail, about 3 k cycles on the last arriver, is the serialisation of the hundred same-address ticket atomics.)
-            if (passed == 2) { pub_store(); pub_ticket(); }
-            else if (passed == 3) { pub_await_ticket(); pub_sum(); }
+            // partials at the end of phase C, ticket one phase later (the acknowledgement, ~3 k cycles, is back by then: waiting for
+            // it right away held EVERY workgroup at the barrier behind the now short composite phase), read-back and sum by the last
+            // arriver one phase after that.  (Measured per 100-knot step: 11.59 us store+ticket / sum; 11.54 us with the sum a
+            // further phase later; 11.09 us as below.)
+            if (passed == 2) pub_store();
+            else if (passed == 3) pub_ticket();
+            else if (passed == 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pub_await_ticket(); pub_sum(); }
         } else if (passed == 5) { pub_store(); pub_ticket(); pub_await_ticket(); pub_sum(); }
     };
 

@@ -262,7 +262,8 @@ HD void terrain_Z_jet(const KSettings& st, double px, double py, int order, doub
 // ===================================================================================================
 
 // --- contact points, component-wise: lane (c, i), 24 tasks.  planner.py:721-744, 646-654, 699-719 ----
-template <class Em> HD void t_points_vec(Ctx<Em>& cx, int t) {
+// (the trapezoid defects of the point states are a task group of their own: they share nothing with the rest but the knot record)
+template <class Em> HD void t_points_dyn(Ctx<Em>& cx, int t) {
     KnotScratch& s = cx.s;
     const int c = t / 3, i = t - 3 * c;
     const double* x = s.x + PT_ * c;
@@ -285,6 +286,13 @@ template <class Em> HD void t_points_vec(Ctx<Em>& cx, int t) {
     em.J(jb + js::PDYN + 6 + i, row_id(RK_PDYN_OUT, c, i), cb + P_ + i, -1.0);
     em.J(jb + js::PDYN + 9 + i, row_id(RK_PDYN_OUT, c, i), cb + V_ + i, -half);
     em.J(jb + js::PDYN + 12 + i, row_id(RK_PDYN_X0, c, i), cb + P_ + i, 1.0);
+}
+template <class Em> HD void t_points_vec(Ctx<Em>& cx, int t) {
+    KnotScratch& s = cx.s;
+    const int c = t / 3, i = t - 3 * c;
+    const double* x = s.x + PT_ * c;
+    const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
+    Em& em = cx.em;
     const double pz = x[P_ + 2];
     const bool planar = terrain_is_planar(cx);
     em.J(jb + js::PLANAR_V + i, row_id(RK_PLANAR, c, i), cb + V_ + i, 1.0);
@@ -563,7 +571,7 @@ template <class Em> HD void joint_transform(Ctx<Em>& cx, int j) {
 }
 
 // --- joint-wise rows, joint regularisation cost and the local joint transform, lane j (23) -------------
-template <class Em> HD void t_joints(Ctx<Em>& cx, int j) {
+template <class Em> HD void t_joint_rows(Ctx<Em>& cx, int j) {
     KnotScratch& s = cx.s;
     Em& em = cx.em;
     em.G(gs::JPB + j, row_id(RK_JPB, 0, j), s.x[S_ + j]);
@@ -580,8 +588,9 @@ template <class Em> HD void t_joints(Ctx<Em>& cx, int j) {
     s.c_joint[j] = m * c;
     s.grad[S_ + j] = 2.0 * m * t * w;
     s.grad[SD_ + j] = m * gsd;
-    joint_transform(cx, j);
 }
+// the local joint transforms (records of the FK pass), on a wave of their own: the longest task of the first phase
+template <class Em> HD void t_joints(Ctx<Em>& cx, int j) { joint_transform(cx, j); }
 
 template <class Em> HD void t_joint_cost(Ctx<Em>& cx, int) {  // behind t_joints on the same wave
     KnotScratch& s = cx.s;
@@ -1265,10 +1274,10 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
 // BARRIER separates phases.  Groups that rely on running BEHIND another group of their wave (HIPNLP_WAVE_SYNC) share both ids.
 // ---------------------------------------------------------------------------------------------------
 #define HIPNLP_KNOT_PROGRAM(R, BARRIER)                                                   \
-    R(0, 0, t_points_vec, 3 * NC) R(0, 1, t_unitq, 1)                                     \
-    R(1, 2, t_points_scalar, NC) R(1, 3, t_dyn, 7 + NJ + 3) R(1, 1, t_feet_centroid, 1) R(1, 7, t_terrain_stage, NC) \
-    R(2, 4, t_joints, NJ) R(2, 1, t_feet_yaw, 2)                                          \
-    R(3, 5, t_base, 3) R(3, 6, t_small, 4)                                                \
+    R(0, 0, t_points_vec, 3 * NC) R(0, 2, t_joint_rows, NJ)                               \
+    R(1, 2, t_points_scalar, NC) R(1, 3, t_dyn, 7 + NJ + 3) R(1, 7, t_terrain_stage, NC) R(1, 1, t_unitq, 1) \
+    R(2, 4, t_joints, NJ) R(2, 1, t_feet_yaw, 2) R(2, 1, t_feet_centroid, 1)              \
+    R(3, 5, t_base, 3) R(3, 6, t_small, 4) R(3, 7, t_points_dyn, 3 * NC)                  \
     BARRIER                                                                               \
     R(0, 0, t_fk_rot_a, FK_TASKS_A) R(0, 0, t_link_u_a, FK_SPLIT)                         \
     R(3, 1, t_fk_rot_b, FK_TASKS_B) R(3, 1, t_link_u_b, NJ - FK_SPLIT)                    \
