@@ -344,3 +344,28 @@ def test_sharded_callback_reassembly_on_gpu(model, HipNlp):
     torch.cuda.synchronize()
     assert float(fs) == f[0]
     assert np.array_equal(grads.cpu().numpy(), grad[0]) and np.array_equal(jacs.cpu().numpy(), jac[0]) and np.array_equal(gs.cpu().numpy(), g[0])
+
+
+def test_profile_runs_and_kernel_count(model, HipNlp):
+    """hipnlp_kernels_per_eval (1 for launches of at most 256 knots, 2 beyond) and the run-bracketed event timing."""
+    import torch
+    st = periodic_step_settings(12, model)
+    x, p = make_workload(st, model, batch=1, seed=3)
+    small = HipNlp(st, model)
+    small.set_params(p)
+    assert small.kernels_per_eval() == 1
+    xb, pb = make_workload(st, model, batch=32, seed=3)
+    big = HipNlp(st, model, batch=32)
+    assert big.kernels_per_eval() == 2
+    dev = torch.device("cuda", 0)
+    xd = torch.from_numpy(x).to(dev)
+    outs = [torch.empty(k, dtype=torch.float64, device=dev) for k in (1, small.n, small.m, small.nnz)]
+    small.profile_begin_runs(4, 8)
+    for _ in range(40):
+        small.eval_device(xd.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(),
+                          stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    kern_ms, launch_ms, n = small.profile_end()
+    assert n == 32 and 0.0 < kern_ms < 1.0 and launch_ms >= kern_ms
+    f, grad, g, jac = small.eval(x)
+    assert float(outs[0].cpu()[0]) == f[0] and np.array_equal(outs[3].cpu().numpy(), jac[0])
