@@ -258,14 +258,14 @@ def main():
             line["knot_sharded_allgather"] = ks_extra
         if world == 1 and not knot_sharded:
             # PCIe-inclusive rate of the host-buffer boundary (hipnlp_eval: H2D x, launch, D2H f/grad/g/jac); never `value`
-            eng.eval(x_np)
+            outs = eng.eval(x_np)
             t1 = time.perf_counter()
             reps = 30
             for i in range(reps):
-                eng.eval(x_np)
+                eng.eval(x_np, out=outs)   # caller-owned output arrays reused, as IPOPT does
             dt_host = (time.perf_counter() - t1) / reps
             line["pcie_inclusive"] = {"ms_per_call": 1e3 * dt_host, "knots_per_s": horizon * args.batch / dt_host,
-                                      "note": "hipnlp_eval with host buffers (pinned staging), all four outputs copied back"}
+                                      "note": "hipnlp_eval with host buffers (pinned staging, one fused D2H copy), all four outputs copied back into caller-owned arrays"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(settings, model, x_np[0], p_np[0])
             line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "layout.h"
@@ -421,7 +422,9 @@ struct hipnlp_handle {
     int32_t seq = 0, seq_result = -1;        // launches so far; launch the cached host result belongs to
     unsigned long long* d_stamps = nullptr;
     // pinned host staging
-    double *h_x = nullptr, *h_g = nullptr, *h_jac = nullptr, *h_grad = nullptr, *h_f = nullptr, *h_cost_terms = nullptr;
+    double *h_x = nullptr, *h_g = nullptr, *h_jac = nullptr, *h_grad = nullptr, *h_f = nullptr, *h_cost_terms = nullptr;   // (h_* outputs: views of h_out)
+    void *d_out = nullptr, *h_out = nullptr;   // output block [f | cost terms | grad | g | jac | flag] and its pinned mirror
+    size_t out_bytes = 0;
     int32_t* h_flag = nullptr;
     std::vector<double> p;
     bool params_set = false, have_result = false;
@@ -441,9 +444,9 @@ static void free_all(hipnlp_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* dptrs[] = {h->d_tb, h->d_x, h->d_pk, h->d_g, h->d_jac, h->d_grad, h->d_f, h->d_cost_knot, h->d_cost_terms, h->d_gp, h->d_ticket, h->d_flag};
+    void* dptrs[] = {h->d_tb, h->d_x, h->d_pk, h->d_cost_knot, h->d_gp, h->d_ticket, h->d_out};
     for (void* q : dptrs) if (q) (void)hipFree(q);
-    void* hptrs[] = {h->h_x, h->h_g, h->h_jac, h->h_grad, h->h_f, h->h_cost_terms, h->h_flag};
+    void* hptrs[] = {h->h_x, h->h_out};
     for (void* q : hptrs) if (q) (void)hipHostFree(q);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -499,23 +502,28 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     CREATE_TRY(hipMalloc(&h->d_x, B * n * sizeof(double)));
     CREATE_TRY(hipMalloc(&h->d_pk, B * N * PK_STRIDE * sizeof(double)));
     CREATE_TRY(hipMalloc(&h->d_gp, B * sizeof(GParams)));
-    CREATE_TRY(hipMalloc(&h->d_g, B * m * sizeof(double)));
-    CREATE_TRY(hipMalloc(&h->d_jac, B * nnz * sizeof(double)));
-    CREATE_TRY(hipMalloc(&h->d_grad, B * n * sizeof(double)));
-    CREATE_TRY(hipMalloc(&h->d_f, B * sizeof(double)));
+    // every output of the host-buffer path in ONE device block and ONE pinned mirror: [f | cost terms | grad | g | jac | flag],
+    // copied back with a single asynchronous copy (six separate copies cost ~8 us each in launch overhead alone)
+    const size_t out_doubles = B * (1 + NCT + n + m + nnz);
+    h->out_bytes = out_doubles * sizeof(double) + ((B * sizeof(int32_t) + 7) / 8) * 8;
+    CREATE_TRY(hipMalloc(&h->d_out, h->out_bytes));
+    CREATE_TRY(hipHostMalloc(&h->h_out, h->out_bytes));
+    auto carve = [&](char* base) {
+        double* p = reinterpret_cast<double*>(base);
+        double* f_ = p; p += B;
+        double* ct_ = p; p += B * NCT;
+        double* gr_ = p; p += B * n;
+        double* g_ = p; p += B * m;
+        double* j_ = p; p += B * nnz;
+        return std::make_tuple(f_, ct_, gr_, g_, j_, reinterpret_cast<int32_t*>(p));
+    };
+    std::tie(h->d_f, h->d_cost_terms, h->d_grad, h->d_g, h->d_jac, h->d_flag) = carve(static_cast<char*>(h->d_out));
+    std::tie(h->h_f, h->h_cost_terms, h->h_grad, h->h_g, h->h_jac, h->h_flag) = carve(static_cast<char*>(h->h_out));
     CREATE_TRY(hipMalloc(&h->d_cost_knot, B * size_t(h->nk) * NCT * sizeof(double)));
-    CREATE_TRY(hipMalloc(&h->d_cost_terms, B * NCT * sizeof(double)));
     CREATE_TRY(hipMalloc(&h->d_ticket, B * sizeof(unsigned long long)));
-    CREATE_TRY(hipMalloc(&h->d_flag, B * sizeof(int32_t)));
     CREATE_TRY(hipMemset(h->d_ticket, 0, B * sizeof(unsigned long long)));
     CREATE_TRY(hipMemset(h->d_flag, 0, B * sizeof(int32_t)));
     CREATE_TRY(hipHostMalloc(&h->h_x, B * n * sizeof(double)));
-    CREATE_TRY(hipHostMalloc(&h->h_g, B * m * sizeof(double)));
-    CREATE_TRY(hipHostMalloc(&h->h_jac, B * nnz * sizeof(double)));
-    CREATE_TRY(hipHostMalloc(&h->h_grad, B * n * sizeof(double)));
-    CREATE_TRY(hipHostMalloc(&h->h_f, B * sizeof(double)));
-    CREATE_TRY(hipHostMalloc(&h->h_cost_terms, B * NCT * sizeof(double)));
-    CREATE_TRY(hipHostMalloc(&h->h_flag, B * sizeof(int32_t)));
     CREATE_TRY(hipMemset(h->d_g, 0, B * m * sizeof(double)));
     CREATE_TRY(hipMemset(h->d_jac, 0, B * nnz * sizeof(double)));
     CREATE_TRY(hipMemset(h->d_grad, 0, B * n * sizeof(double)));
@@ -703,12 +711,7 @@ int hipnlp_eval(hipnlp_handle* h, const double* x, int new_x, double* f, double*
         HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_x, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
         int rc = launch(h, h->d_x, h->d_f, h->d_grad, h->d_g, h->d_jac, h->stream, nullptr, false, true);
         if (rc != HIPNLP_OK) return rc;
-        HIP_TRY(h, hipMemcpyAsync(h->h_f, h->d_f, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->h_flag, h->d_flag, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->h_cost_terms, h->d_cost_terms, B * NCT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->h_grad, h->d_grad, B * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->h_g, h->d_g, B * m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->h_jac, h->d_jac, B * nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, h->out_bytes, hipMemcpyDeviceToHost, h->stream));   // all outputs, one copy
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         h->have_result = true;
         h->seq_result = h->seq;

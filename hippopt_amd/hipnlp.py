@@ -170,13 +170,18 @@ class HipNlp:
             out.append((name.value.decode(), a.value, b.value, c.value, d.value))
         return out
 
-    def eval(self, x, new_x=True, want=("f", "grad", "g", "jac")):
-        """Host-buffer callback set.  Returns (f[batch], grad[batch,n], g[batch,m], jac[batch,nnz])."""
+    def eval(self, x, new_x=True, want=("f", "grad", "g", "jac"), out=None):
+        """Host-buffer callback set.  Returns (f[batch], grad[batch,n], g[batch,m], jac[batch,nnz]).
+        out: (f, grad, g, jac) arrays of a previous call to fill again (what a C caller such as IPOPT does with its own arrays:
+        fresh 1 MB numpy arrays cost an mmap and their page faults on every call)."""
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.batch, self.n)
-        f = np.empty(self.batch) if "f" in want else None
-        grad = np.empty((self.batch, self.n)) if "grad" in want else None
-        g = np.empty((self.batch, self.m)) if "g" in want else None
-        jac = np.empty((self.batch, self.nnz)) if "jac" in want else None
+        if out is not None:
+            f, grad, g, jac = out
+        else:
+            f = np.empty(self.batch) if "f" in want else None
+            grad = np.empty((self.batch, self.n)) if "grad" in want else None
+            g = np.empty((self.batch, self.m)) if "g" in want else None
+            jac = np.empty((self.batch, self.nnz)) if "jac" in want else None
         self._check(self.lib.hipnlp_eval(self.h, _dp(x), 1 if new_x else 0, _dp(f), _dp(grad), _dp(g), _dp(jac)))
         return f, grad, g, jac
 
