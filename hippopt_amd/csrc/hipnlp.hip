@@ -6,8 +6,9 @@
 // waves, workgroup barriers between dependent phases; lanes mapped to contact points / joints / (joint, row) / (link,
 // component) / Jacobian entries), collects all outputs of the knot in LDS at compile-time native slots and finally streams
 // them out: the knot's CCS column block of jac g as ONE contiguous run (permuted through a prefetched int table), grad f
-// contiguous, g scattered into the reference's constraint-type-major order, the cost partials per knot.  A second tiny kernel
-// reduces the per-knot cost partials in a fixed order (bitwise reproducible f).
+// contiguous, g scattered into the reference's constraint-type-major order, the cost partials per knot.  The total cost is summed
+// in a fixed order (bitwise reproducible f): inside the knot kernel by the workgroup that publishes its partials last (eight-wave
+// latency variant: one kernel launch per callback set), by a second tiny kernel behind the four-wave throughput variant.
 #include <hip/hip_runtime.h>
 
 #include <cmath>

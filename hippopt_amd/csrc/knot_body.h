@@ -1,6 +1,6 @@
 // knot_body.h — the per-knot mathematics of the hipnlp engine, written once and compiled for the
 // device (HIP kernel, gfx950), for the host layout recorder (layout.h) and for the test-only host
-// emulation (tests/hostemu).  One workgroup of FOUR wavefronts evaluates ONE knot: its rows of g (own
+// emulation (tests/hostemu).  One workgroup of FOUR (or eight) wavefronts evaluates ONE knot: its rows of g (own
 // algebraic rows and the trapezoid defect that ends at the knot), its COLUMN block of jac g (so the CCS
 // output of a knot is one contiguous run), its slice of grad f and its cost partials.
 //
