@@ -57,9 +57,26 @@ def cpu_baseline(settings, model, x, p, budget_s=12.0):
         el = time.perf_counter() - t0
         if el > budget_s or reps >= 1000:
             break
-    return {"value": settings.horizon_length * reps / el, "unit": "knots/s", "cores": 1, "kind": "port",
-            "sample": "%d full callback sets (f, grad f, g, jac g by forward AD) of the N=%d workload in %.1f s, 1 thread"
-                      % (reps, settings.horizon_length, el)}
+    out = {"value": settings.horizon_length * reps / el, "unit": "knots/s", "cores": 1, "kind": "port",
+           "sample": "%d full callback sets (f, grad f, g, jac g by forward AD) of the N=%d workload in %.1f s, 1 thread"
+                     % (reps, settings.horizon_length, el)}
+    # beside it: the kernel's own analytic per-knot program run on one CPU thread (the test-only host emulation, tests/hostemu) —
+    # hand-derived Jacobians instead of forward AD, i.e. closer to what CasADi's expanded SX graph costs per callback set
+    try:
+        from hostemu_lib import HostEmu
+        emu = HostEmu(settings, model)
+        emu.eval(x, p)
+        t0 = time.perf_counter()
+        r2 = 0
+        while time.perf_counter() - t0 < 3.0:
+            emu.eval(x, p)
+            r2 += 1
+        e2 = time.perf_counter() - t0
+        out["analytic_port"] = {"value": settings.horizon_length * r2 / e2, "unit": "knots/s", "cores": 1,
+                                "sample": "%d callback sets of the analytic knot program on the host (tests/hostemu) in %.1f s, 1 thread" % (r2, e2)}
+    except Exception as err:  # noqa: BLE001
+        out["analytic_port"] = {"error": str(err)}
+    return out
 
 
 def main():
