@@ -782,6 +782,10 @@ template <class Em> HD void t_fk_rot_at(Ctx<Em>& cx, int t, int q0) {
 }
 template <class Em> HD void t_fk_rot_a(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t, HIPNLP_UNIFORM(cx.kt.fk_first[0])); }
 template <class Em> HD void t_fk_rot_b(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t + FK_TASKS_A, HIPNLP_UNIFORM(cx.kt.fk_first[1])); }
+// (Measured alternative: FK as a parallel prefix over the ancestor chains — pointer doubling with affine elements (L, of, wl),
+//  three steps + the base element instead of up to seven ancestor steps, ping-pong between the joint records and comp[].  Correct
+//  (all GPU tests), phase B 3.5 k -> 2.9 k cycles, +1.3 % at batch 64, but -2.6 % on the 100-knot step, whose duration is set by
+//  the workgroup that finishes the cost reduction; not kept.)
 // (A level-synchronous variant — one step per joint, the wave walking the tree level by level behind wave-level fences — was
 //  measured at 4.7 k cycles against 3.4 k for these ancestor sums: a level costs two dependent LDS round trips, ~680 cycles.)
 // velocity of the body point of link i at the (base-centred) origin: vO_i = sum over the joints a on the path root -> i of
