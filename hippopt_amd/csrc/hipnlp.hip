@@ -246,7 +246,8 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             //  read-back) of 2 - 3 k cycles each against the 7 k cycles left of the kernel; eight ticket counters by kk % 8 plus a
             //  completion check — less same-address contention, one more round trip — measured slower: 11.47 vs 11.09 us; making
             //  every cost term final one phase earlier (chest-frame cost from the joint records beside the forward kinematics) and
-            //  starting the protocol there: 11.14 us, and -8 % at batch for the extra task.)
+            //  starting the protocol there: 11.14 us, and -8 % at batch for the extra task; finishing the protocol behind the
+            //  last barrier instead of inside phase F: 11.61 us.)
             // partials at the end of phase C, ticket one phase later (the acknowledgement, ~3 k cycles, is back by then: waiting for
             // it right away held EVERY workgroup at the barrier behind the now short composite phase), read-back and sum by the last
             // arriver one phase after that.  (Measured per 100-knot step: 11.59 us store+ticket / sum; 11.54 us with the sum a
