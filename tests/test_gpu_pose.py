@@ -210,3 +210,40 @@ def test_pose_hessian_large_batch_and_errors(model):
     with pytest.raises(HipNlpError) as ei:
         eng.eval_hess(xb, 1.0, lam)
     assert ei.value.code == -5
+
+
+def test_pose_planner_converges_with_exact_hessian(model):
+    """The pose finder mirror with the engine's exact Hessian of the Lagrangian in the NLP driver (what the reference's pose finder
+    gives IPOPT, main.py:101) converges from the perturbed start; the quasi-Newton stand-in does not within the same budget."""
+    from hippopt_amd.turnkey_planners.humanoid_pose_finder import Planner, References, Settings
+    results = {}
+    for mode in ("exact", "limited-memory"):
+        st = Settings(solver_options={"max_iter": 150, "hessian_approximation": mode})
+        st.maximum_joint_positions = np.array(model.max_joint_positions, float)
+        st.minimum_joint_positions = np.array(model.min_joint_positions, float)
+        pl = Planner(st, model, error_on_fail=False)
+        mass = model.get_total_mass()
+        x, _ = make_pose_workload(st, model, 1, 42)
+        refs = References(contact_point_descriptors=st.contact_points, number_of_joints=23)
+        refs.state.com = x[0][78:81].copy()
+        for c, pt in enumerate(refs.state.contact_points.left + refs.state.contact_points.right):
+            pt.p = x[0][6 * c:6 * c + 3].copy()
+            pt.p[2] = 0.0
+            pt.f = np.array([0.0, 0.0, mass * 9.80665 / 8])
+        refs.state.kinematics.joints.positions = x[0][55:78].copy()
+        pl.set_references(refs)
+        guess = pl.get_initial_guess()
+        for c, pt in enumerate(guess.state.contact_points.left + guess.state.contact_points.right):
+            pt.p = x[0][6 * c:6 * c + 3].copy()
+            pt.f = x[0][6 * c + 3:6 * c + 6] * mass
+        guess.state.kinematics.base.position = x[0][48:51].copy()
+        guess.state.kinematics.base.quaternion_xyzw = x[0][51:55].copy()
+        guess.state.kinematics.joints.positions = x[0][55:78].copy()
+        guess.state.com = x[0][78:81].copy()
+        pl.set_initial_guess(guess)
+        out = pl.solve()
+        info = pl.optimization_solver._last_info
+        results[mode] = (info["iterations"], info["constr_violation"], out.cost_value, info["status"])
+    it, viol, cost, status = results["exact"]
+    assert status in (1, 2) and it < 150 and viol < 1e-8
+    assert cost <= results["limited-memory"][2] + 1e-9
