@@ -93,6 +93,13 @@ def load_library():
     lib.hipnlp_pose_num_row_blocks.argtypes = [vp]
     lib.hipnlp_pose_row_block.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), ip, ip]
     lib.hipnlp_pose_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.hipnlp_pose_hess_nnz.argtypes = [vp, ip]
+    lib.hipnlp_pose_hess_sparsity.argtypes = [vp, ip, ip]
+    lib.hipnlp_pose_eval_hess.argtypes = [vp, dp, dp, dp, dp]
+    lib.hipnlp_pose_eval_hess_device.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.hipnlp_kernels_per_eval.argtypes = [vp]
+    lib.hipnlp_profile_begin_runs.argtypes = [vp, C.c_int, C.c_int]
+    lib.hipnlp_reassemble.argtypes = [vp, vp, vp, C.c_int64, C.c_int, C.c_int64, vp, vp]
     _lib = lib
     return lib
 
@@ -286,7 +293,11 @@ class HipPose:
         return f, grad, g, jac
 
     def eval_device(self, x_ptr, f_ptr, grad_ptr, g_ptr, jac_ptr, stream=None):
-        self._check(self.lib.hipnlp_pose_eval_device(self.h, x_ptr, f_ptr, grad_ptr, g_ptr, jac_ptr, stream))
+        """Device-pointer variant (ints from tensor.data_ptr()); asynchronous on `stream`.  (Every pointer goes through c_void_p:
+        a bare Python int would be passed as a 32-bit C int.)"""
+        vp = C.c_void_p
+        self._check(self.lib.hipnlp_pose_eval_device(self.h, vp(x_ptr), vp(f_ptr or None), vp(grad_ptr or None), vp(g_ptr or None),
+                                                     vp(jac_ptr or None), vp(stream or None)))
 
     # ---- exact Hessian of the Lagrangian (IPOPT eval_h): lower triangle, column major ------------------------------------
     def hess_sparsity(self):
@@ -310,7 +321,8 @@ class HipPose:
         return out
 
     def eval_hess_device(self, x_ptr, obj_factor_ptr, lam_ptr, hess_ptr, stream=None):
-        self._check(self.lib.hipnlp_pose_eval_hess_device(self.h, x_ptr, obj_factor_ptr, lam_ptr, hess_ptr, stream))
+        vp = C.c_void_p
+        self._check(self.lib.hipnlp_pose_eval_hess_device(self.h, vp(x_ptr), vp(obj_factor_ptr), vp(lam_ptr), vp(hess_ptr), vp(stream or None)))
 
     def cost_terms(self):
         names = [self.lib.hipnlp_pose_cost_term_name(i).decode() for i in range(_abi.POSE_NCOST_TERMS)]
