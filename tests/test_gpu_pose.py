@@ -247,3 +247,33 @@ def test_pose_planner_converges_with_exact_hessian(model):
     it, viol, cost, status = results["exact"]
     assert status in (1, 2) and it < 150 and viol < 1e-8
     assert cost <= results["limited-memory"][2] + 1e-9
+
+
+def test_pose_device_pointer_paths(model):
+    """hipnlp_pose_eval_device / hipnlp_pose_eval_hess_device with torch device pointers equal the host-buffer paths bit for bit."""
+    import torch
+    from hippopt_amd.hipnlp import HipPose
+    st = variants(model)["default"]
+    B = 7
+    x, p = make_pose_workload(st, model, B, 77)
+    eng = HipPose(st, model, batch=B)
+    eng.set_params(p)
+    f, grad, g, jac = eng.eval(x)
+    rng = np.random.RandomState(4)
+    lam, sig = rng.standard_normal((B, eng.m)), rng.uniform(0.5, 1.5, B)
+    hv = eng.eval_hess(x, sig, lam)
+    dev = torch.device("cuda", 0)
+    xd = torch.from_numpy(x).to(dev)
+    fd = torch.empty(B, dtype=torch.float64, device=dev)
+    gradd = torch.empty(B * eng.n, dtype=torch.float64, device=dev)
+    gd = torch.empty(B * eng.m, dtype=torch.float64, device=dev)
+    jacd = torch.empty(B * eng.nnz, dtype=torch.float64, device=dev)
+    hd = torch.empty(hv.size, dtype=torch.float64, device=dev)
+    lamd, sigd = torch.from_numpy(lam).to(dev), torch.from_numpy(sig).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    eng.eval_device(xd.data_ptr(), fd.data_ptr(), gradd.data_ptr(), gd.data_ptr(), jacd.data_ptr(), stream)
+    eng.eval_hess_device(xd.data_ptr(), sigd.data_ptr(), lamd.data_ptr(), hd.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(fd.cpu().numpy(), f) and np.array_equal(jacd.cpu().numpy().reshape(B, -1), jac)
+    assert np.array_equal(gd.cpu().numpy().reshape(B, -1), g) and np.array_equal(gradd.cpu().numpy().reshape(B, -1), grad)
+    assert np.array_equal(hd.cpu().numpy().reshape(B, -1), hv)
