@@ -219,42 +219,43 @@ HD D2 d2tanh(const D2& a) { const double t = tanh(a.v), d = 1.0 - t * t; return 
 
 HD double ipow_d(double x, int n) { double r = 1.0, b = x; while (n > 0) { if (n & 1) r *= b; n >>= 1; if (n) b *= b; } return r; }
 
+// contribution of ONE bump to the jet (out is accumulated into)
+HD void terrain_bump_jet(const TerrainStepK& t, double px, double py, int order, double* out) {
+    out[0] += t.oz;
+    const double dx = px - t.ox, dy = py - t.oy;
+    const double a = t.ax * dx + t.ay * dy, b = t.bx * dx + t.by * dy;
+    const int m = t.m, r = t.r;
+    const double am3 = ipow_d(a, m - 3), bm3 = ipow_d(b, m - 3);
+    const double A0 = am3 * a * a * a, A1 = m * am3 * a * a, A2 = double(m * (m - 1)) * am3 * a, A3 = double(m * (m - 1) * (m - 2)) * am3;
+    const double B0 = bm3 * b * b * b, B1 = m * bm3 * b * b, B2 = double(m * (m - 1)) * bm3 * b, B3 = double(m * (m - 1) * (m - 2)) * bm3;
+    const double g = A0 + B0;
+    const double gr3 = ipow_d(g, r - 3);
+    const double w = gr3 * g * g * g;
+    if (!(w < 700.0)) return;  // exp(-w) underflows (also catches inf / nan of far-away points): the bump and all its derivatives vanish
+    const double w1 = r * gr3 * g * g, w2 = double(r * (r - 1)) * gr3 * g, w3 = double(r * (r - 1) * (r - 2)) * gr3;
+    const double psi = t.height * exp(-w);
+    const double p1 = -psi * w1, p2 = psi * (w1 * w1 - w2), p3 = psi * (-w1 * w1 * w1 + 3.0 * w1 * w2 - w3);
+    const double gx = A1 * t.ax + B1 * t.bx, gy = A1 * t.ay + B1 * t.by;
+    out[0] += psi;
+    out[1] += p1 * gx;
+    out[2] += p1 * gy;
+    if (order < 2) return;
+    const double gxx = A2 * t.ax * t.ax + B2 * t.bx * t.bx, gxy = A2 * t.ax * t.ay + B2 * t.bx * t.by, gyy = A2 * t.ay * t.ay + B2 * t.by * t.by;
+    out[3] += p2 * gx * gx + p1 * gxx;
+    out[4] += p2 * gx * gy + p1 * gxy;
+    out[5] += p2 * gy * gy + p1 * gyy;
+    if (order < 3) return;
+    const double gxxx = A3 * t.ax * t.ax * t.ax + B3 * t.bx * t.bx * t.bx, gxxy = A3 * t.ax * t.ax * t.ay + B3 * t.bx * t.bx * t.by;
+    const double gxyy = A3 * t.ax * t.ay * t.ay + B3 * t.bx * t.by * t.by, gyyy = A3 * t.ay * t.ay * t.ay + B3 * t.by * t.by * t.by;
+    out[6] += p3 * gx * gx * gx + p2 * (3.0 * gxx * gx) + p1 * gxxx;
+    out[7] += p3 * gx * gx * gy + p2 * (gxx * gy + 2.0 * gxy * gx) + p1 * gxxy;
+    out[8] += p3 * gx * gy * gy + p2 * (gyy * gx + 2.0 * gxy * gy) + p1 * gxyy;
+    out[9] += p3 * gy * gy * gy + p2 * (3.0 * gyy * gy) + p1 * gyyy;
+}
 // Z and its partials up to third order: out = [Z, Zx, Zy, Zxx, Zxy, Zyy, Zxxx, Zxxy, Zxyy, Zyyy]
 HD void terrain_Z_jet(const KSettings& st, double px, double py, int order, double* out) {
     for (int i = 0; i < 10; ++i) out[i] = 0.0;
-    for (int sidx = 0; sidx < st.n_steps; ++sidx) {
-        const TerrainStepK& t = st.steps[sidx];
-        out[0] += t.oz;
-        const double dx = px - t.ox, dy = py - t.oy;
-        const double a = t.ax * dx + t.ay * dy, b = t.bx * dx + t.by * dy;
-        const int m = t.m, r = t.r;
-        const double am3 = ipow_d(a, m - 3), bm3 = ipow_d(b, m - 3);
-        const double A0 = am3 * a * a * a, A1 = m * am3 * a * a, A2 = double(m * (m - 1)) * am3 * a, A3 = double(m * (m - 1) * (m - 2)) * am3;
-        const double B0 = bm3 * b * b * b, B1 = m * bm3 * b * b, B2 = double(m * (m - 1)) * bm3 * b, B3 = double(m * (m - 1) * (m - 2)) * bm3;
-        const double g = A0 + B0;
-        const double gr3 = ipow_d(g, r - 3);
-        const double w = gr3 * g * g * g;
-        if (!(w < 700.0)) continue;  // exp(-w) underflows (also catches inf / nan of far-away points): the bump and all its derivatives vanish
-        const double w1 = r * gr3 * g * g, w2 = double(r * (r - 1)) * gr3 * g, w3 = double(r * (r - 1) * (r - 2)) * gr3;
-        const double psi = t.height * exp(-w);
-        const double p1 = -psi * w1, p2 = psi * (w1 * w1 - w2), p3 = psi * (-w1 * w1 * w1 + 3.0 * w1 * w2 - w3);
-        const double gx = A1 * t.ax + B1 * t.bx, gy = A1 * t.ay + B1 * t.by;
-        out[0] += psi;
-        out[1] += p1 * gx;
-        out[2] += p1 * gy;
-        if (order < 2) continue;
-        const double gxx = A2 * t.ax * t.ax + B2 * t.bx * t.bx, gxy = A2 * t.ax * t.ay + B2 * t.bx * t.by, gyy = A2 * t.ay * t.ay + B2 * t.by * t.by;
-        out[3] += p2 * gx * gx + p1 * gxx;
-        out[4] += p2 * gx * gy + p1 * gxy;
-        out[5] += p2 * gy * gy + p1 * gyy;
-        if (order < 3) continue;
-        const double gxxx = A3 * t.ax * t.ax * t.ax + B3 * t.bx * t.bx * t.bx, gxxy = A3 * t.ax * t.ax * t.ay + B3 * t.bx * t.bx * t.by;
-        const double gxyy = A3 * t.ax * t.ay * t.ay + B3 * t.bx * t.by * t.by, gyyy = A3 * t.ay * t.ay * t.ay + B3 * t.by * t.by * t.by;
-        out[6] += p3 * gx * gx * gx + p2 * (3.0 * gxx * gx) + p1 * gxxx;
-        out[7] += p3 * gx * gx * gy + p2 * (gxx * gy + 2.0 * gxy * gx) + p1 * gxxy;
-        out[8] += p3 * gx * gy * gy + p2 * (gyy * gx + 2.0 * gxy * gy) + p1 * gxyy;
-        out[9] += p3 * gy * gy * gy + p2 * (3.0 * gyy * gy) + p1 * gyyy;
-    }
+    for (int sidx = 0; sidx < st.n_steps; ++sidx) terrain_bump_jet(st.steps[sidx], px, py, order, out);
 }
 
 // ===================================================================================================
@@ -390,17 +391,39 @@ template <class Em> HD void point_hnf_planar(Ctx<Em>& cx, int c) {
 // --- contact point rows on the SMOOTH terrain (E3, E4, E6, E7, E10, E14-E17) in two stages:
 //   t_terrain_stage (phase A, lane c): third-order jet of the bump sum and the terrain frame with its d/dp_x, d/dp_y, parked in
 //       the (not yet used) per-link area of the scratch;
-//   t_terrain_planar / _dcc / _hnf (phase B, lane c each, on three different waves): the rows and their Jacobian entries.
+//   t_terrain_planar / _dcc / _hnf / _swing (phase B, lane c each, on different waves): the rows, their Jacobian entries, the swing cost.
 struct TerrainStage { TerrainFrame tf; double Zh[7]; };   // Zh = Z[3..9]: second and third derivatives (for udot)
 static_assert(sizeof(TerrainStage) * NC <= sizeof(double) * NL * LSTR, "terrain staging must fit in own[0..NL) (own[NL] is the zero slot)");
 HD TerrainStage* terrain_stage(KnotScratch& s, int c) { return reinterpret_cast<TerrainStage*>(&s.own[0][0]) + c; }
 
+// the jet of ONE bump at ONE point: lane (c, bump), NC x HIPNLP_MAX_TERRAIN_STEPS tasks; parked in the composite area (written only
+// three phases later).  t_terrain_stage follows on the same wave, adds the bumps in order and builds the frame.
+constexpr int TERRAIN_BUMP_TASKS = NC * HIPNLP_MAX_TERRAIN_STEPS;
+static_assert(sizeof(double) * 10 * TERRAIN_BUMP_TASKS <= sizeof(double) * NL * LSTR, "bump jets must fit in comp[]");
+HD double* terrain_bump_part(KnotScratch& s, int c, int sidx) { return &s.comp[0][0] + 10 * (HIPNLP_MAX_TERRAIN_STEPS * c + sidx); }
+template <class Em> HD void t_terrain_bump(Ctx<Em>& cx, int t) {
+    if (terrain_is_planar(cx)) return;
+    KnotScratch& s = cx.s;
+    const int c = t / HIPNLP_MAX_TERRAIN_STEPS, sidx = t - HIPNLP_MAX_TERRAIN_STEPS * c;
+    if (sidx >= cx.st.n_steps) return;
+    const double* p = s.x + PT_ * c + P_;
+    double Z[10];
+    for (int i = 0; i < 10; ++i) Z[i] = 0.0;
+    terrain_bump_jet(cx.st.steps[sidx], p[0], p[1], 3, Z);
+    double* out = terrain_bump_part(s, c, sidx);
+    for (int i = 0; i < 10; ++i) out[i] = Z[i];
+}
 template <class Em> HD void t_terrain_stage(Ctx<Em>& cx, int c) {
     if (terrain_is_planar(cx)) return;
     KnotScratch& s = cx.s;
+    HIPNLP_WAVE_SYNC();   // the bump jets of this wave's t_terrain_bump
     const double* p = s.x + PT_ * c + P_;
     double Z[10];
-    terrain_Z_jet(cx.st, p[0], p[1], 3, Z);
+    for (int i = 0; i < 10; ++i) Z[i] = 0.0;
+    for (int sidx = 0; sidx < cx.st.n_steps; ++sidx) {   // same order as terrain_Z_jet
+        const double* part = terrain_bump_part(s, c, sidx);
+        for (int i = 0; i < 10; ++i) Z[i] += part[i];
+    }
     TerrainStage* st = terrain_stage(s, c);
     terrain_frame(Z, p[2], st->tf);
     for (int i = 0; i < 7; ++i) st->Zh[i] = Z[3 + i];
@@ -469,12 +492,16 @@ template <class Em> HD void t_terrain_dcc(Ctx<Em>& cx, int c) {
 // height, normal force, friction cone rows; swing height heuristic (E10):  0.5 [ (h - hd)^2 + |(R_t^T v)_xy|^2 ]   (k >= 1)
 template <class Em> HD void t_terrain_hnf(Ctx<Em>& cx, int c) {
     if (terrain_is_planar(cx)) return;
+    point_hnf_smooth(cx, c, terrain_stage(cx.s, c)->tf);
+}
+// swing height heuristic on the smooth terrain (value and gradient; t_foot_costs adds to that gradient: same wave, behind this)
+template <class Em> HD void t_terrain_swing(Ctx<Em>& cx, int c) {
+    if (terrain_is_planar(cx)) return;
     KnotScratch& s = cx.s;
     const int cb = PT_ * c;
     const double* v = s.x + cb + V_;
     const TerrainFrame& tf = terrain_stage(s, c)->tf;
     const D2 *xv = tf.xv, *yv = tf.yv;
-    point_hnf_smooth(cx, c, tf);
     const double on = cx.ki.first ? 0.0 : 1.0;
     const double msw = on * cx.st.m_swing;
     const D2 dh = tf.h - D2(s.pk[PK_REF + R_SWING]);
@@ -1279,14 +1306,14 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
 // ---------------------------------------------------------------------------------------------------
 #define HIPNLP_KNOT_PROGRAM(R, BARRIER)                                                   \
     R(0, 0, t_points_vec, 3 * NC) R(0, 2, t_joint_rows, NJ)                               \
-    R(1, 2, t_points_scalar, NC) R(1, 3, t_dyn, 7 + NJ + 3) R(1, 7, t_terrain_stage, NC) R(1, 1, t_unitq, 1) \
+    R(1, 2, t_points_scalar, NC) R(1, 3, t_dyn, 7 + NJ + 3) R(1, 7, t_terrain_bump, TERRAIN_BUMP_TASKS) R(1, 7, t_terrain_stage, NC) R(1, 1, t_unitq, 1) \
     R(2, 4, t_joints, NJ) R(2, 1, t_feet_yaw, 2) R(2, 1, t_feet_centroid, 1)              \
-    R(3, 5, t_base, 3) R(3, 6, t_small, 4) R(3, 7, t_points_dyn, 3 * NC)                  \
+    R(3, 5, t_base, 3) R(3, 6, t_small, 4) R(3, 3, t_points_dyn, 3 * NC)                  \
     BARRIER                                                                               \
     R(0, 0, t_fk_rot_a, FK_TASKS_A) R(0, 0, t_link_u_a, FK_SPLIT)                         \
     R(3, 1, t_fk_rot_b, FK_TASKS_B) R(3, 1, t_link_u_b, NJ - FK_SPLIT)                    \
     R(1, 2, t_hdyn_entries, 48) R(1, 3, t_hdyn_rows, HDYN_TASKS - 48)                     \
-    R(2, 4, t_terrain_hnf, NC) R(2, 4, t_points_cost, 3) R(2, 4, t_foot_costs, FOOT_TASKS) R(2, 4, t_foot_cost_sum, 2) \
+    R(2, 7, t_terrain_hnf, NC) R(2, 4, t_terrain_swing, NC) R(2, 4, t_points_cost, 3) R(2, 4, t_foot_costs, FOOT_TASKS) R(2, 4, t_foot_cost_sum, 2) \
     R(1, 5, t_terrain_planar, NC) R(0, 6, t_terrain_dcc, NC) R(-1, 7, t_joint_cost, 1)    \
     BARRIER                                                                               \
     R(0, 0, t_links, NL) R(1, 1, t_frames, 3) R(2, 2, t_link_inertia, NL) R(3, -1, t_joint_cost, 1) \
