@@ -397,7 +397,8 @@ static_assert(sizeof(TerrainStage) * NC <= sizeof(double) * NL * LSTR, "terrain 
 HD TerrainStage* terrain_stage(KnotScratch& s, int c) { return reinterpret_cast<TerrainStage*>(&s.own[0][0]) + c; }
 
 // the jet of ONE bump at ONE point: lane (c, bump), NC x HIPNLP_MAX_TERRAIN_STEPS tasks; parked in the composite area (written only
-// three phases later).  t_terrain_stage follows on the same wave, adds the bumps in order and builds the frame.
+// three phases later).  (Splitting a bump's jet further over three lanes by derivative order, and the com height jet over bump
+// lanes, measured slower: the common prefix — powers and the exponential — dominates and is then computed three times.)  t_terrain_stage follows on the same wave, adds the bumps in order and builds the frame.
 constexpr int TERRAIN_BUMP_TASKS = NC * HIPNLP_MAX_TERRAIN_STEPS;
 static_assert(sizeof(double) * 10 * TERRAIN_BUMP_TASKS <= sizeof(double) * NL * LSTR, "bump jets must fit in comp[]");
 HD double* terrain_bump_part(KnotScratch& s, int c, int sidx) { return &s.comp[0][0] + 10 * (HIPNLP_MAX_TERRAIN_STEPS * c + sidx); }
