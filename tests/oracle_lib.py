@@ -88,6 +88,18 @@ class Oracle:
         lib().oracle_cost_terms(C.c_void_p(self.h), _dp(out))
         return out
 
+    def hess(self, x, p, sigma, lam):
+        """Exact Hessian of sigma f + lam^T g: numerically nonzero LOWER-triangle entries (rows, cols, vals), sorted by (col, row)."""
+        fn = lib().oracle_eval_hess
+        fn.restype = C.c_long
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        x = np.ascontiguousarray(x, np.float64); p = np.ascontiguousarray(p, np.float64); lam = np.ascontiguousarray(lam, np.float64)
+        assert lam.size == self.m
+        cnt = fn(self.h, x.ctypes.data, p.ctypes.data, float(sigma), lam.ctypes.data, None, None, None)
+        rows, cols, vals = np.zeros(cnt, np.int32), np.zeros(cnt, np.int32), np.zeros(cnt)
+        fn(self.h, x.ctypes.data, p.ctypes.data, float(sigma), lam.ctypes.data, rows.ctypes.data, cols.ctypes.data, vals.ctypes.data)
+        return rows, cols, vals
+
     def row_blocks(self):
         out = []
         nb = lib().oracle_num_row_blocks(C.c_void_p(self.h))

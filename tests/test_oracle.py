@@ -99,6 +99,48 @@ def test_ad_jacobian_matches_finite_differences(model, maker):
         assert abs((fp - fm) / (2 * eps) - grad @ d) / max(1.0, abs(grad @ d)) < 1e-7
 
 
+def lagrangian_gradient(o, x, p, sigma, lam):
+    _, grad, _, jac = o.eval(x, p)
+    ir, jc = o.sparsity()
+    out = sigma * grad
+    np.add.at(out, jc, jac * lam[ir])
+    return out
+
+
+@pytest.mark.parametrize("maker,kw", [(periodic_step_settings, {}), (single_step_settings, {}),
+                                      (periodic_step_settings, {"minimize": True}), (periodic_step_settings, {"stairs": True})])
+def test_ad_hessian_matches_finite_differences_of_the_lagrangian_gradient(model, maker, kw):
+    st = maker(3, model)
+    if kw.get("minimize"):
+        st.periodicity_expression_type = st.final_state_expression_type = _abi.EXPR_MINIMIZE
+    if kw.get("stairs"):
+        from hippopt_amd.kinodyn_settings import stairs_settings
+        st = stairs_settings(3, model)
+    x, p = make_workload(st, model, 1, 17)
+    o = Oracle(st, model)
+    rng = np.random.RandomState(1)
+    lam = rng.standard_normal(o.m)
+    sigma = 0.7
+    rows, cols, vals = o.hess(x[0], p[0], sigma, lam)
+    assert np.all(rows >= cols) and np.all(np.diff(cols.astype(np.int64) * o.n + rows) > 0)
+    H = np.zeros((o.n, o.n))
+    H[rows, cols] = vals
+    H = H + np.tril(H, -1).T
+    eps = 1e-6
+    for _ in range(4):
+        d = rng.standard_normal(o.n)
+        fd = (lagrangian_gradient(o, x[0] + eps * d, p[0], sigma, lam) - lagrangian_gradient(o, x[0] - eps * d, p[0], sigma, lam)) / (2 * eps)
+        # (the stairs terrain has exponents 10 and 20: the truncation error of the central difference is larger there)
+        assert np.max(np.abs(fd - H @ d)) / max(1.0, np.max(np.abs(H @ d))) < (5e-6 if kw.get("stairs") else 2e-7)
+    # block structure (block-diagonal by knot; only the first/last costs couple two knots)
+    kr, kc = np.minimum(rows // 189, st.horizon_length), np.minimum(cols // 189, st.horizon_length)
+    off = (kr != kc)
+    if not kw.get("minimize"):
+        assert not off.any()
+    else:
+        assert set(zip(kr[off], kc[off])) <= {(st.horizon_length - 1, 0)}
+
+
 def test_centroidal_momentum_rows_do_not_depend_on_base_position_or_velocity(model):
     st = periodic_step_settings(3, model)
     x, p = make_workload(st, model, 1, 14)

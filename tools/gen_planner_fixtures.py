@@ -109,7 +109,7 @@ def canon(c, var_ids):
     raise ValueError("unsupported constraint")
 
 
-def generate(tag, mine, model, seed, tweak=None):
+def generate(tag, mine, model, seed, tweak=None, with_hessian=True):
     adam.casadi.STANDIN_MODEL = model
     planner = walking_planner.Planner(reference_settings(mine))
     solver = planner.optimization_solver
@@ -157,8 +157,31 @@ def generate(tag, mine, model, seed, tweak=None):
     ir, jc = np.nonzero(J)
     order = np.lexsort((ir, jc))
     ir, jc = ir[order], jc[order]
+    # Hessian of the Lagrangian sigma f + lambda^T g (what nlp_hess_l would hand IPOPT's eval_h): symbolic forward
+    # derivative of L along every variable component (cs.jtimes on the reference's own graph), then its numeric tangents with
+    # respect to all variables.  Stored as the numerically nonzero lower triangle.
+    hess_extra = {}
+    if with_hessian:
+        rng = np.random.RandomState(seed + 1)
+        sigma = 0.75
+        lam = rng.standard_normal(int(G.shape[0]))
+        lag = sigma * f_expr + cs.mtimes(cs.DM(lam.reshape(1, -1)), G)
+        rows_h = []
+        for v in opti.variables:
+            for i in range(v.numel()):
+                e = np.zeros(v.shape)
+                e[i % v.shape[0], i // v.shape[0]] = 1.0
+                rows_h.append(cs.jtimes(lag, v, cs.DM(e)))
+        _, ht = cs.evaluate(rows_h, values, seeds, nx)
+        hess = np.stack([np.zeros(nx) if t is None else t[0, 0, :] for t in ht])
+        assert np.max(np.abs(hess - hess.T)) < 1e-9 * max(1.0, np.max(np.abs(hess)))
+        hr, hc = np.nonzero(np.tril(hess))
+        order = np.lexsort((hr, hc))
+        hr, hc = hr[order], hc[order]
+        hess_extra = dict(hess_sigma=sigma, hess_lambda=lam, hess_row=hr.astype(np.int32), hess_col=hc.astype(np.int32), hess_val=hess[hr, hc])
+        print(tag, "hessian: lower-triangle nonzeros", len(hr))
     out = os.path.join(ROOT, "tests", "golden", "planner_%s_N%d.npz" % (tag, N))
-    np.savez_compressed(out, x=x, p=p, g=gv.reshape(-1), lbg=lbv.reshape(-1), ubg=ubv.reshape(-1), f=float(fv), grad=grad,
+    np.savez_compressed(out, **hess_extra, x=x, p=p, g=gv.reshape(-1), lbg=lbv.reshape(-1), ubg=ubv.reshape(-1), f=float(fv), grad=grad,
                         jac_row=ir.astype(np.int32), jac_col=jc.astype(np.int32), jac_val=J[ir, jc],
                         names=np.array(names), rows=np.array(rows, np.int32), cost_names=np.array(cost_names),
                         meta=np.array(json.dumps({"config": tag, "horizon": N, "seed": seed, "final": mine.final_state_expression_type,
@@ -169,6 +192,10 @@ def generate(tag, mine, model, seed, tweak=None):
 
 def main():
     model = synthetic_ergocub()
+    only = set(sys.argv[1:])   # optional: names of the configurations to (re)generate
+    if only:
+        real = generate
+        globals()["generate"] = lambda tag, *a, **k: real(tag, *a, **k) if tag in only else None
     generate("periodic", periodic_step_settings(3, model), model, 4003)
     generate("single", single_step_settings(3, model), model, 4004)
     st = periodic_step_settings(2, model)
