@@ -1,0 +1,594 @@
+// knot_hess_body.h — exact Hessian of the Lagrangian  sigma f(x) + lambda^T g(x)  of the kinodynamic multiple-shooting NLP
+// (IPOPT's eval_h; SURVEY §8f rank 1: what CasADi's nlp_hess_l computes when a script drops `hessian_approximation =
+// limited-memory`).  PLANAR terrain only (the smooth-terrain rows need fourth-order terrain jets: not built).
+//
+// Structure.  Every constraint row and cost term depends on ONE knot, except the trapezoid defects, which are sums of a term
+// in x_{k-1} and a term in x_k (implicit_trapezoid.py:24-39), and the two horizon-end costs.  The Hessian of the Lagrangian is
+// therefore block diagonal by knot (189 x 189 lower triangles), plus — periodicity in `minimize` mode only — the 84 entries
+// that couple the last knot with the first.  The tasks below run BEHIND the knot program of knot_body.h in the same workgroup
+// and read the kinematic quantities it left in the scratch (base-centred coordinates: origin = base origin, v_b = 0).
+//
+// Second derivatives that exist on the planar terrain (hand-derived; checked against forward-over-forward AD of the oracle):
+//   per point      tanh complementarity (p_z, p_z), (u_v, p_z); dcc margin (f_z, p_z), (f_z, v_z), (p_z, fdot_z); friction cone
+//                  (f, f); the bilinear (p - com) x f of the momentum dynamics at BOTH intervals the knot belongs to:
+//                  multiplier  nu = -dt/2 (lambda_k + lambda_{k+1})  on (f, p) and (com, f); quadratic regularisations
+//   across points  force-ratio regularisation (f, f') on one foot; contact centroid (p, p') over all eight points; yaw
+//                  alignment (p_xy, p'_xy) between the corners of one foot
+//   kinematics     contact-point and com consistency rows, chest-frame cost, feet distance (K4), centroidal momentum (K3):
+//                  (q_b, s, qdot_b, sdot) block, 54 variables
+// Centroidal momentum  Phi = mu . L_G(q, s, qdot, sdot),  mu = -lambda / mass.  Spatial vectors [angular; linear] about the origin:
+//   S_j = [a_j; o_j x a_j] joint motion vector, I^C_j / h^C_j composite inertia / momentum of the subtree of joint j, v_j the
+//   velocity of its child link, l = [mu; com x mu] (rigid rotation mu about the CoM), Phi = l . h_O.  With
+//     E_j = S_j x* h^C_j - I^C_j (S_j x v_j)      (= d h_O / d s_j)         G_j = I^C_j S_j   (= d h_O / d sdot_j)
+//     C_j = I^C_j (S_j x l) - S_j x* (I^C_j l)                                w_j = S_j x v_j
+//   for k ancestor-or-self of j:   l . d2 h_O / ds_k ds_j = -(S_k x l) . E_j + w_k . C_j
+//                                  d/ds_k [l . G_j] = -(S_k x l) . G_j ;     d/ds_j [l . G_k] = -C_j . S_k
+//   plus the terms through com(s) in l:  (dcom_k x mu) . dP_j + (dcom_j x mu) . dP_k + d2com_kj . (mu x P)   (every pair).
+//   A rotation of the base about world axis e acts like an outermost joint with S = [e; 0], w = S x v_0; the chain to the
+//   quaternion uses  dtheta = G dq / |q|  and  omega = G qdot;  the (q_b, q_b) block is taken in the body frame,
+//   Phi = u^T I~(s) w + u^T A~(s) sdot  with  u = R^T mu, w = R^T omega  (tools/diag/proto_momentum_hess.py is the numpy
+//   derivation these tasks were written from).
+#pragma once
+#include "pose_hess_body.h"
+
+namespace hipnlp {
+
+constexpr int COL_FIRST = 2 * NXK;   // column ids >= COL_FIRST address variable (id - COL_FIRST) of the FIRST knot (periodicity coupling)
+
+namespace hk {  // native slots of the Hessian values of one knot
+// per point (stride PT): rows/cols are offsets inside the knot record
+constexpr int PL_U = 0;      // [2]  (u_i, p_z), i = x, y
+constexpr int DC_FP = 2, DC_FV = 3, DC_PFD = 4;   // (f_z, p_z), (f_z, v_z), (p_z, fdot_z)
+constexpr int FD = 5;        // [3]  (f_i, f_i)
+constexpr int HD_FP = 8;     // [6]  (f_row, p_col) off-diagonal, cross_row / cross_col order
+constexpr int CF = 14;       // [6]  (com_r, f_q)
+constexpr int VD = 20, FDD = 23, UD = 26;   // [3] each: diagonals of v, f_dot, u_v
+constexpr int PT = 29;
+constexpr int FF = NC * PT;                 // [foot 2][pair 6][i 3]   (f_c', f_c), c' > c on one foot
+constexpr int PP = FF + 36;                 // [pair 36][5]  (p_c', p_c), c' >= c: same coordinate x, y, z; (y, x); (x, y)
+constexpr int DG = PP + 36 * 5;             // [42] diagonals of v_b 3, p_b 3, com 3, h 6, qdot_b 4, sdot 23
+constexpr int QQ = DG + 42;                 // [10] lower 4x4 (q_b, q_b)
+constexpr int QQD = QQ + 10;                // [4][4] row q_r, column qdot_c
+constexpr int SDQ = QQD + 16;               // [NJ][4] row sdot_j, column q_l
+constexpr int SQD = SDQ + 4 * NJ;           // [NJ][4] row s_j, column qdot_l
+constexpr int SQ = SQD + 4 * NJ;            // [NJ][4] row s_j, column q_l
+constexpr int SSD = SQ + 4 * NJ;            // [NJ][NJ] row s_k, column sdot_l
+constexpr int SS = SSD + NJ * NJ;           // lower triangle (s_j, s_i), i <= j
+constexpr int PERC = SS + NJ * (NJ + 1) / 2;   // [84] periodicity cost: (x_{N-1}, x_0) coupling, written by the last knot
+constexpr int COUNT = PERC + 84;
+}  // namespace hk
+
+struct SV6 { double a[3], l[3]; };   // spatial vector [angular; linear]
+
+struct KHessScratch {
+    double lam[gs::COUNT];   // multiplier of the row a native g slot belongs to at this knot (0 for slots without a row)
+    double lam_next[3];      // multipliers of the angular momentum-dynamics rows of the NEXT interval (owned by knot k + 1)
+    double sigma;
+    double Y[NJ][3];
+    // centroidal momentum: per joint j (0..NJ-1) and per base rotation axis e (NJ + e)
+    SV6 S[NJ + 3], E[NJ + 3], Gm[NJ + 3], Sxl[NJ + 3], Cv[NJ + 3], Wv[NJ + 3];
+    double dc[NJ + 3][3];    // d com / d (s_j | theta_e)
+    double mu[3], muP[3], K[3], LG[3], IG[9], ell_l[3];
+    double H[hk::COUNT];
+};
+
+template <class Em> struct KHCtx {
+    Ctx<Em>& cx;
+    KHessScratch& hx;
+};
+
+HD double dot6(const SV6& x, const SV6& y) { return dot3(x.a, y.a) + dot3(x.l, y.l); }
+HD void crm6(const SV6& S, const SV6& x, SV6& r) {   // S x (motion)
+    double t[3];
+    cross3(S.a, x.a, r.a);
+    cross3(S.l, x.a, r.l);
+    cross3(S.a, x.l, t);
+    for (int i = 0; i < 3; ++i) r.l[i] += t[i];
+}
+HD void crf6(const SV6& S, const SV6& f, SV6& r) {   // S x* (force)
+    double t[3];
+    cross3(S.a, f.a, r.a);
+    cross3(S.l, f.l, t);
+    for (int i = 0; i < 3; ++i) r.a[i] += t[i];
+    cross3(S.a, f.l, r.l);
+}
+// composite spatial inertia of link i (comp[i]: m, first moment h, rotational inertia about the origin) applied to a motion vector
+HD void inertia6(const double* cp, const SV6& x, SV6& r) {
+    double t[3];
+    symvec(cp + CI, x.a, r.a);
+    cross3(cp + CH, x.l, t);
+    for (int i = 0; i < 3; ++i) r.a[i] += t[i];
+    cross3(cp + CH, x.a, t);
+    for (int i = 0; i < 3; ++i) r.l[i] = cp[CM] * x.l[i] - t[i];
+}
+HD bool is_anc(const KinTables& kt, int i, int j) {   // joint i on the path root -> j (inclusive)
+    bool a = false;
+    for (int q = 0; q < 8; ++q) a = a || (int(kt.anc[j][q]) == i);
+    return a;
+}
+
+// diagonal share of the horizon-end costs (final state planner.py:407-425, periodicity :897-930, `minimize` mode) for variable var
+template <class Em> HD double ends_diag(const KHCtx<Em>& h, int var) {
+    const Ctx<Em>& cx = h.cx;
+    double v = 0.0;
+    if (cx.ki.last && cx.st.final_type == HIPNLP_EXPR_MINIMIZE)
+        for (int t = 0; t < 105; ++t) if (int(cx.kt.fin_var[t]) == var) v += 2.0 * h.hx.sigma * cx.st.final_weight;
+    if ((cx.ki.first || cx.ki.last) && cx.st.periodicity_type == HIPNLP_EXPR_MINIMIZE)
+        for (int t = 0; t < 84; ++t) if (int(cx.kt.per_var[t]) == var) v += 2.0 * h.hx.sigma * cx.st.periodicity_weight;
+    return v;
+}
+
+// effective multiplier of  sum_c (p_c - com) x f_c  at this knot: the trapezoid rule puts -dt/2 hdot(x_k) into the momentum
+// rows of the interval that ends here and of the one that starts here
+template <class Em> HD void hdyn_multiplier(const KHCtx<Em>& h, double* nu) {
+    const double half = 0.5 * h.cx.gp.dt;
+    for (int i = 0; i < 3; ++i) nu[i] = -half * (h.hx.lam[gs::HDYN + 3 + i] + h.hx.lam_next[i]);
+}
+
+// --- point-local entries: lane c (8) --------------------------------------------------------------------------------------------
+template <class Em> HD void t_kh_point(KHCtx<Em>& h, int c) {
+    Ctx<Em>& cx = h.cx;
+    KnotScratch& s = cx.s;
+    Em& em = cx.em;
+    const double* lam = h.hx.lam;
+    const double sigma = h.hx.sigma;
+    const int gb = gs::PT_STRIDE * c, hb = hk::PT * c, cb = PT_ * c;
+    const double* x = s.x + cb;
+    const double on = cx.ki.first ? 0.0 : 1.0;
+    // planar complementarity  v_i - tanh(kt p_z) u_i  (E3)
+    const double kt = cx.gp.kt, tau = tanh(kt * x[P_ + 2]), dtau = kt * (1.0 - tau * tau);
+    for (int i = 0; i < 2; ++i) em.H(hb + hk::PL_U + i, cb + U_ + i, cb + P_ + 2, -lam[gb + gs::PLANAR + i] * dtau);
+    // dcc margin  eps - kbs p_z f_z - (v_z f_z + p_z fdot_z)  (E4)
+    const double l_d = lam[gb + gs::DCC];
+    em.H(hb + hk::DC_FP, cb + F_ + 2, cb + P_ + 2, -cx.gp.kbs * l_d);
+    em.H(hb + hk::DC_FV, cb + F_ + 2, cb + V_ + 2, -l_d);
+    em.H(hb + hk::DC_PFD, cb + P_ + 2, cb + FD_ + 2, -l_d);
+    // friction cone + own share of the force-ratio regularisation
+    const int foot = c >> 2, cl = c & 3;
+    const double* alpha = s.pk + PK_REF + (foot == 0 ? R_ALPHA_L : R_ALPHA_R);
+    const double a2 = alpha[0] * alpha[0] + alpha[1] * alpha[1] + alpha[2] * alpha[2] + alpha[3] * alpha[3];
+    const double dff = 2.0 * sigma * on * cx.st.m_freg * (1.0 - 2.0 * alpha[cl] + a2);
+    const double l_f = lam[gb + gs::FRICTION], mu2 = cx.gp.mu * cx.gp.mu;
+    for (int i = 0; i < 3; ++i)
+        em.H(hb + hk::FD + i, cb + F_ + i, cb + F_ + i, dff + (i < 2 ? -2.0 * l_f : 2.0 * mu2 * l_f) + ends_diag(h, cb + F_ + i));
+    // nu . ((p - com) x f)
+    double nu[3];
+    hdyn_multiplier(h, nu);
+    for (int e = 0; e < 6; ++e) {
+        const int r = cross_row(e), q = cross_col(e);
+        em.H(hb + hk::HD_FP + e, cb + F_ + r, cb + P_ + q, skew_rc(nu, r, q));
+        em.H(hb + hk::CF + e, COM_ + r, cb + F_ + q, -skew_rc(nu, q, r));
+    }
+    // swing height (E10, planar), ||u_v||^2, ||f_dot||^2   (k >= 1)
+    for (int i = 0; i < 3; ++i) {
+        em.H(hb + hk::VD + i, cb + V_ + i, cb + V_ + i, (i < 2 ? sigma * on * cx.st.m_swing : 0.0) + ends_diag(h, cb + V_ + i));
+        em.H(hb + hk::FDD + i, cb + FD_ + i, cb + FD_ + i, 2.0 * sigma * on * cx.st.m_fdreg + ends_diag(h, cb + FD_ + i));
+        em.H(hb + hk::UD + i, cb + U_ + i, cb + U_ + i, 2.0 * sigma * on * cx.st.m_ureg + ends_diag(h, cb + U_ + i));
+    }
+}
+
+// --- force-ratio regularisation across the points of one foot (planner.py:746-771): lanes (foot, pair, i) 36 ------------------
+template <class Em> HD void t_kh_ff(KHCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    const int foot = t / 18, r = t - 18 * foot, pair = r / 3, i = r - 3 * pair;
+    const int hi = pair < 1 ? 1 : (pair < 3 ? 2 : 3), lo = pair - (hi == 1 ? 0 : (hi == 2 ? 1 : 3));
+    const double* alpha = cx.s.pk + PK_REF + (foot == 0 ? R_ALPHA_L : R_ALPHA_R);
+    const double a2 = alpha[0] * alpha[0] + alpha[1] * alpha[1] + alpha[2] * alpha[2] + alpha[3] * alpha[3];
+    const double on = cx.ki.first ? 0.0 : 1.0;
+    cx.em.H(hk::FF + t, PT_ * (4 * foot + hi) + F_ + i, PT_ * (4 * foot + lo) + F_ + i,
+            2.0 * h.hx.sigma * on * cx.st.m_freg * (a2 - alpha[hi] - alpha[lo]));
+}
+
+// --- (p_c', p_c), c' >= c: lanes (pair, e) 180.  e = 0..2 same coordinate; e = 3: (y of c', x of c); e = 4: (x of c', y of c) ----
+//   contact centroid cost (planner.py:249-264): 2 m w_i / 64 for every pair;  yaw alignment (E9, :773-853) between the
+//   corners of one foot;  on the diagonal: swing height, the tanh complementarity, horizon-end costs
+template <class Em> HD void t_kh_pp(KHCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    KnotScratch& s = cx.s;
+    const int pair = t / 5, e = t - 5 * pair;
+    int hi = 0;
+    while ((hi + 1) * (hi + 2) / 2 <= pair) ++hi;
+    const int lo = pair - hi * (hi + 1) / 2;
+    const double sigma = h.hx.sigma, on = cx.ki.first ? 0.0 : 1.0;
+    const int a = e < 3 ? e : (e == 3 ? 1 : 0), b = e < 3 ? e : (e == 3 ? 0 : 1);   // coordinate of c' (row), of c (column)
+    if (hi == lo && e == 4) return;   // upper triangle
+    // yaw alignment: gradient coefficients of the forward / sideways errors on the corners
+    const int foot = hi >> 2;
+    double yaw = 0.0;
+    bool yaw_struct = false;
+    if ((lo >> 2) == foot && a < 2 && b < 2) {
+        const int br = cx.st.yaw_corner[foot][0], tr = cx.st.yaw_corner[foot][1], tl = cx.st.yaw_corner[foot][2];
+        const int ch = hi & 3, cl = lo & 3;
+        const double cfh = ch == tr ? 1.0 : (ch == br ? -1.0 : 0.0), cfl = cl == tr ? 1.0 : (cl == br ? -1.0 : 0.0);   // d ef
+        const double csh = ch == tl ? 1.0 : (ch == tr ? -1.0 : 0.0), csl = cl == tl ? 1.0 : (cl == tr ? -1.0 : 0.0);   // d es
+        yaw_struct = (cfh != 0.0 && cfl != 0.0) || (csh != 0.0 && csl != 0.0);
+        const double* sc = s.pk + PK_YAWSC + 4 * foot;
+        const double d1[2] = {-sc[0], sc[1]}, d2[2] = {-sc[2], sc[3]};
+        yaw = on * cx.st.m_yaw * (cfh * cfl * d1[a] * d1[b] + csh * csl * d2[a] * d2[b]);
+    }
+    if (e >= 3) {
+        if (yaw_struct) cx.em.H(hk::PP + t, PT_ * hi + P_ + a, PT_ * lo + P_ + b, sigma * yaw);
+        return;
+    }
+    double v = sigma * (yaw + 2.0 * on * cx.st.m_centroid * s.pk[PK_REF + R_CW + e] / 64.0);
+    if (hi == lo) {
+        v += ends_diag(h, PT_ * hi + P_ + e);
+        if (e == 2) {
+            const double* x = s.x + PT_ * hi;
+            const double kt = cx.gp.kt, tau = tanh(kt * x[P_ + 2]), dtau = kt * (1.0 - tau * tau), ddtau = -2.0 * kt * tau * dtau;
+            const double* lp = h.hx.lam + gs::PT_STRIDE * hi + gs::PLANAR;
+            v += sigma * on * cx.st.m_swing - (lp[0] * x[U_] + lp[1] * x[U_ + 1]) * ddtau;
+        }
+    }
+    cx.em.H(hk::PP + t, PT_ * hi + P_ + e, PT_ * lo + P_ + e, v);
+}
+
+// --- remaining diagonals: lanes 42: v_b 3, p_b 3, com 3, h 6, qdot_b 4, sdot 23 ----------------------------------------------------
+template <class Em> HD void t_kh_diag(KHCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    const double sigma = h.hx.sigma, on = cx.ki.first ? 0.0 : 1.0;
+    int var;
+    double v = 0.0;
+    if (t < 3) var = VB_ + t;
+    else if (t < 6) var = PB_ + (t - 3);
+    else if (t < 9) var = COM_ + (t - 6);
+    else if (t < 15) { var = H_ + (t - 9); if (t < 12) v = 2.0 * sigma * cx.st.m_comvel * cx.st.w_comvel[t - 9]; }   // com velocity cost (k >= 0)
+    else if (t < 19) { var = QD_ + (t - 15); v = 2.0 * sigma * cx.st.m_baseqv; }                                      // base quaternion velocity cost
+    else { var = SD_ + (t - 19); v = 2.0 * sigma * on * cx.st.m_jreg * (cx.st.joint_reg_as_coded ? double(NJ) : 1.0); }   // J6
+    cx.em.H(hk::DG + t, var, var, v + ends_diag(h, var));
+}
+
+// --- periodicity cost, coupling of the last knot with the first: lanes 84 (last knot only) -------------------------------------
+template <class Em> HD void t_kh_percouple(KHCtx<Em>& h, int i) {
+    Ctx<Em>& cx = h.cx;
+    if (cx.st.periodicity_type != HIPNLP_EXPR_MINIMIZE || !cx.ki.last) return;
+    cx.em.H(hk::PERC + i, int(cx.kt.per_var[i]), COL_FIRST + int(cx.kt.per_var[i]), -2.0 * h.hx.sigma * cx.st.periodicity_weight);
+}
+
+// --- centroidal momentum, shared quantities: lane 0 ---------------------------------------------------------------------------------
+template <class Em> HD void t_kh_mom0(KHCtx<Em>& h, int) {
+    Ctx<Em>& cx = h.cx;
+    KnotScratch& s = cx.s;
+    KHessScratch& hx = h.hx;
+    const double* c0 = s.comp[0];
+    const double M = cx.kt.total_mass;
+    for (int i = 0; i < 3; ++i) hx.mu[i] = -hx.lam[gs::CMMC + i] / cx.gp.mass;
+    double com[3];
+    for (int i = 0; i < 3; ++i) com[i] = c0[CH + i] / M;
+    cross3(com, hx.mu, hx.ell_l);
+    cross3(hx.mu, c0 + CKL, hx.muP);
+    // L_G = L_O - com x P ;  I_G = I_O - M (|c|^2 1 - c c^T) ;  K = I_G mu
+    double t[3];
+    cross3(com, c0 + CKL, t);
+    for (int i = 0; i < 3; ++i) hx.LG[i] = c0[CKA + i] - t[i];
+    const double c2 = dot3(com, com);
+    const double* I6 = c0 + CI;
+    const double IO[9] = {I6[0], I6[1], I6[2], I6[1], I6[3], I6[4], I6[2], I6[4], I6[5]};
+    for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 3; ++q) hx.IG[3 * r + q] = IO[3 * r + q] - M * ((r == q ? c2 : 0.0) - com[r] * com[q]);
+    matvec3(hx.IG, hx.mu, hx.K);
+}
+
+// --- centroidal momentum, per joint / base axis: lanes NJ + 3 (behind t_kh_mom0) -----------------------------------------------------
+template <class Em> HD void t_kh_joint(KHCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    KnotScratch& s = cx.s;
+    KHessScratch& hx = h.hx;
+    SV6 S, v, hC, ell, t1, t2;
+    const int link = t < NJ ? t + 1 : 0;
+    if (t < NJ) {
+        for (int i = 0; i < 3; ++i) S.a[i] = s.aw[t][i];
+        cross3(s.ow[t + 1], s.aw[t], S.l);
+    } else {
+        for (int i = 0; i < 3; ++i) { S.a[i] = (i == t - NJ) ? 1.0 : 0.0; S.l[i] = 0.0; }
+    }
+    const double* cp = s.comp[link];
+    for (int i = 0; i < 3; ++i) { v.a[i] = s.wv[link][i]; v.l[i] = s.vo[link][i]; hC.a[i] = cp[CKA + i]; hC.l[i] = cp[CKL + i]; ell.a[i] = hx.mu[i]; ell.l[i] = hx.ell_l[i]; }
+    hx.S[t] = S;
+    crm6(S, v, hx.Wv[t]);                 // w = S x v
+    crf6(S, hC, t1);
+    inertia6(cp, hx.Wv[t], t2);
+    for (int i = 0; i < 3; ++i) { hx.E[t].a[i] = t1.a[i] - t2.a[i]; hx.E[t].l[i] = t1.l[i] - t2.l[i]; }
+    inertia6(cp, S, hx.Gm[t]);
+    crm6(S, ell, hx.Sxl[t]);
+    inertia6(cp, hx.Sxl[t], t1);          // B = I^C (S x l)
+    inertia6(cp, ell, t2);
+    SV6 t3;
+    crf6(S, t2, t3);
+    for (int i = 0; i < 3; ++i) { hx.Cv[t].a[i] = t1.a[i] - t3.a[i]; hx.Cv[t].l[i] = t1.l[i] - t3.l[i]; }
+    for (int i = 0; i < 3; ++i) hx.dc[t][i] = hx.Gm[t].l[i] / cx.kt.total_mass;
+}
+
+// --- Y_j = d/d theta [ dL/ds_j ]  (theta: world-frame rotation of the base) for the part of the Lagrangian that is LINEAR in
+//     points rigidly attached to links: contact points, com (incl. the com inside the momentum term: weight mu x P), chest cost.
+//     Same construction as t_hess_Y of the pose finder.  lane j (23) -----------------------------------------------------------------
+template <class Em> HD void t_kh_Y(KHCtx<Em>& h, int j) {
+    Ctx<Em>& cx = h.cx;
+    KnotScratch& s = cx.s;
+    const double* lam = h.hx.lam;
+    const double* a = s.aw[j];
+    const double* o = s.ow[j + 1];
+    const double on = cx.ki.first ? 0.0 : 1.0;
+    double Y[3] = {0.0, 0.0, 0.0}, t1[3], t2[3];
+    {
+        const double* cp = s.comp[j + 1];
+        const double inv_M = 1.0 / cx.kt.total_mass;
+        for (int r = 0; r < 3; ++r) t1[r] = (cp[CH + r] - cp[CM] * o[r]) * inv_M;
+        cross3(a, t1, t2);
+        const double w[3] = {-lam[gs::COMC] + h.hx.muP[0], -lam[gs::COMC + 1] + h.hx.muP[1], -lam[gs::COMC + 2] + h.hx.muP[2]};
+        cross3(t2, w, t1);
+        for (int r = 0; r < 3; ++r) Y[r] += t1[r];
+    }
+    for (int foot = 0; foot < 2; ++foot) {
+        if (cx.kt.leg_pos[foot][j] < 0) continue;
+        for (int c = 4 * foot; c < 4 * foot + 4; ++c) {
+            for (int r = 0; r < 3; ++r) t1[r] = s.pkin[c][r] - o[r];
+            cross3(a, t1, t2);
+            const double* lk = lam + gs::PT_STRIDE * c + gs::KINC;
+            const double w[3] = {-lk[0], -lk[1], -lk[2]};
+            cross3(t2, w, t1);
+            for (int r = 0; r < 3; ++r) Y[r] += t1[r];
+        }
+    }
+    if (cx.kt.chest_pos[j] >= 0) {
+        double E[9], Ea[3];
+        chest_error(s, E);
+        const double trE = E[0] + E[4] + E[8], e = trE - 3.0;
+        const double ax[3] = {E[7] - E[5], E[2] - E[6], E[3] - E[1]};
+        matvec3(E, a, Ea);
+        const double de = -dot3(ax, a);
+        const double m2 = 2.0 * h.hx.sigma * on * cx.st.m_frameq;
+        for (int r = 0; r < 3; ++r) Y[r] += m2 * (e * (Ea[r] - trE * a[r]) + de * (-ax[r]));
+    }
+    for (int r = 0; r < 3; ++r) h.hx.Y[j][r] = Y[r];
+}
+
+// momentum entries of the theta-level blocks for base axis m (0..2) and joint j
+template <class Em> HD double mom_theta_s(const KHCtx<Em>& h, int m, int j) {   // (theta_m, s_j) without the d2com term (in Y)
+    const KHessScratch& hx = h.hx;
+    const int b = NJ + m;
+    double t[3];
+    double v = -dot6(hx.Sxl[b], hx.E[j]) + dot6(hx.Wv[b], hx.Cv[j]);
+    cross3(hx.dc[b], hx.mu, t); v += dot3(t, hx.E[j].l);
+    cross3(hx.dc[j], hx.mu, t); v += dot3(t, hx.E[b].l);
+    return v;
+}
+template <class Em> HD double mom_theta_sd(const KHCtx<Em>& h, int m, int j) {   // (theta_m, sdot_j)
+    const KHessScratch& hx = h.hx;
+    const int b = NJ + m;
+    double t[3];
+    cross3(hx.dc[b], hx.mu, t);
+    return dot3(t, hx.Gm[j].l) - dot6(hx.Sxl[b], hx.Gm[j]);
+}
+template <class Em> HD double mom_omega_s(const KHCtx<Em>& h, int m, int j) {   // (omega_m, s_j)
+    const KHessScratch& hx = h.hx;
+    const int b = NJ + m;
+    double t[3];
+    cross3(hx.dc[j], hx.mu, t);
+    return dot3(t, hx.Gm[b].l) - dot6(hx.Cv[j], hx.S[b]);
+}
+
+// --- (s_j, s_i), i <= j: lanes over the lower triangle 276 -------------------------------------------------------------------------------
+constexpr int KH_SS_TASKS = NJ * (NJ + 1) / 2;
+template <class Em> HD void t_kh_ss(KHCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    KnotScratch& s = cx.s;
+    const KHessScratch& hx = h.hx;
+    int j = 0;
+    while ((j + 1) * (j + 2) / 2 <= t) ++j;
+    const int i = t - j * (j + 1) / 2;
+    const double on = cx.ki.first ? 0.0 : 1.0;
+    const bool ij = is_anc(cx.kt, i, j), ji = !ij && is_anc(cx.kt, j, i);
+    const int k = ij ? i : j, d = ij ? j : i;   // k ancestor-or-self of d (when related)
+    double tt[3];
+    // centroidal momentum
+    cross3(hx.dc[i], hx.mu, tt);
+    double v = dot3(tt, hx.E[j].l);
+    cross3(hx.dc[j], hx.mu, tt);
+    v += dot3(tt, hx.E[i].l);
+    if (ij || ji) {
+        v += -dot6(hx.Sxl[k], hx.E[d]) + dot6(hx.Wv[k], hx.Cv[d]);
+        v += dot3(s.aw[k], hx.Y[d]);   // points, com, chest
+    }
+    // feet lateral distance  D = y_r . (o_l - o_r)  (K4; base fixed).  For j on the left leg dD/ds_j = y . (a_j x (o_l - o_j)),
+    // on the right leg dD/ds_j = (a_j x y) . (o_l - o_j)
+    const double lfd = hx.lam[gs::FEETD];
+    const int Li = cx.kt.leg_pos[0][i], Lj = cx.kt.leg_pos[0][j], Ri = cx.kt.leg_pos[1][i], Rj = cx.kt.leg_pos[1][j];
+    if ((Li >= 0 || Ri >= 0) && (Lj >= 0 || Rj >= 0)) {
+        const double* yr = s.fr_R[1];
+        const double y[3] = {yr[1], yr[4], yr[7]};
+        const double* ol = s.fr_o[0];
+        double fd = 0.0, u1[3], u2[3], u3[3];
+        if ((Li >= 0 && Lj >= 0) && (ij || ji)) {          // both on the left leg: y . (a_k x (a_d x (o_l - o_d)))
+            for (int r = 0; r < 3; ++r) u1[r] = ol[r] - s.ow[d + 1][r];
+            cross3(s.aw[d], u1, u2);
+            cross3(s.aw[k], u2, u3);
+            fd = dot3(y, u3);
+        } else if ((Ri >= 0 && Rj >= 0) && (ij || ji)) {   // both on the right leg
+            cross3(s.aw[d], y, u1);                         // a_d x y
+            cross3(s.aw[k], u1, u2);
+            for (int r = 0; r < 3; ++r) u3[r] = ol[r] - s.ow[d + 1][r];
+            fd = dot3(u2, u3);
+            for (int r = 0; r < 3; ++r) u3[r] = s.ow[d + 1][r] - s.ow[k + 1][r];
+            cross3(s.aw[k], u3, u2);
+            fd -= dot3(u1, u2);
+        } else if ((Li >= 0 && Rj >= 0) || (Ri >= 0 && Lj >= 0)) {   // one on each leg: (a_R x y) . (a_L x (o_l - o_L))
+            const int jl = Li >= 0 ? i : j, jr = Li >= 0 ? j : i;
+            cross3(s.aw[jr], y, u1);
+            for (int r = 0; r < 3; ++r) u3[r] = ol[r] - s.ow[jl + 1][r];
+            cross3(s.aw[jl], u3, u2);
+            fd = dot3(u1, u2);
+        }
+        v += lfd * fd;
+    }
+    if (i == j) v += 2.0 * hx.sigma * on * cx.st.m_jreg * cx.st.w_jreg[j] * cx.st.w_jreg[j] + ends_diag(h, S_ + j);
+    cx.em.H(hk::SS + t, S_ + j, S_ + i, v);
+}
+
+// --- (s_k, sdot_l): lanes NJ x NJ ---------------------------------------------------------------------------------------------------------
+template <class Em> HD void t_kh_ssd(KHCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    const KHessScratch& hx = h.hx;
+    const int k = t / NJ, l = t - NJ * k;
+    const double on = cx.ki.first ? 0.0 : 1.0;
+    double tt[3];
+    cross3(hx.dc[k], hx.mu, tt);
+    double v = dot3(tt, hx.Gm[l].l);
+    if (is_anc(cx.kt, k, l)) v += -dot6(hx.Sxl[k], hx.Gm[l]);
+    else if (is_anc(cx.kt, l, k)) v += -dot6(hx.Cv[k], hx.S[l]);
+    if (k == l) v += 2.0 * hx.sigma * on * cx.st.m_jreg * cx.st.w_jreg[k];   // J6: d2 (sd + w (s - ref))^2 / ds dsd
+    cx.em.H(hk::SSD + t, S_ + k, SD_ + l, v);
+}
+
+// --- (s_j, q_l), (s_j, qdot_l), (sdot_j, q_l): lanes (j, l) 92 each -------------------------------------------------------------------------
+template <class Em> HD void t_kh_sq(KHCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    const KnotScratch& s = cx.s;
+    const int j = t >> 2, l = t & 3;
+    const double* Y = h.hx.Y[j];
+    double v = (s.G[l] * Y[0] + s.G[4 + l] * Y[1] + s.G[8 + l] * Y[2]) * s.inv_qnorm;
+    for (int m = 0; m < 3; ++m) v += s.G[4 * m + l] * s.inv_qnorm * mom_theta_s(h, m, j) + s.dwq[4 * m + l] * mom_omega_s(h, m, j);
+    cx.em.H(hk::SQ + t, S_ + j, QB_ + l, v);
+}
+template <class Em> HD void t_kh_sqd(KHCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    const KnotScratch& s = cx.s;
+    const int j = t >> 2, l = t & 3;
+    double v = 0.0;
+    for (int m = 0; m < 3; ++m) v += s.G[4 * m + l] * mom_omega_s(h, m, j);   // d omega / d qdot = G
+    cx.em.H(hk::SQD + t, S_ + j, QD_ + l, v);
+}
+template <class Em> HD void t_kh_sdq(KHCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    const KnotScratch& s = cx.s;
+    const int j = t >> 2, l = t & 3;
+    double v = 0.0;
+    for (int m = 0; m < 3; ++m) v += s.G[4 * m + l] * s.inv_qnorm * mom_theta_sd(h, m, j);
+    cx.em.H(hk::SDQ + t, SD_ + j, QB_ + l, v);
+}
+
+// second derivative of  g . (q / |q|)  with respect to q, entry (r, c)
+HD double norm2_entry(const double* g4, const double* qh, double inv_n, int r, int c) {
+    const double gq = g4[0] * qh[0] + g4[1] * qh[1] + g4[2] * qh[2] + g4[3] * qh[3];
+    return (-(g4[r] * qh[c] + qh[r] * g4[c] + (r == c ? gq : 0.0)) + 3.0 * gq * qh[r] * qh[c]) * (inv_n * inv_n);
+}
+// column l of  W(t) = 2 [ t_w 1 + [t_v]x | -t_v ]   (dtheta = W(qhat) dqhat, omega = W(qhat) qdot)
+HD void What_col(const double* t, int l, double* out) {
+    if (l == 3) { out[0] = -2.0 * t[0]; out[1] = -2.0 * t[1]; out[2] = -2.0 * t[2]; return; }
+    for (int r = 0; r < 3; ++r) out[r] = 2.0 * ((r == l ? t[3] : 0.0) + skew_rc(t, r, l));
+}
+
+// --- (q_r, qdot_c): lanes 16 ------------------------------------------------------------------------------------------------------------------
+template <class Em> HD void t_kh_qqd(KHCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    const KnotScratch& s = cx.s;
+    const KHessScratch& hx = h.hx;
+    const int r = t >> 2, c = t & 3;
+    // (theta_m, omega_m') = (dcom_m x mu) . G_m'.l - (S_m x l) . G_m' - (I^C_0 l) . (S_m x S_m')
+    SV6 ell, Il, sx;
+    for (int i = 0; i < 3; ++i) { ell.a[i] = hx.mu[i]; ell.l[i] = hx.ell_l[i]; }
+    inertia6(s.comp[0], ell, Il);
+    double v = 0.0, tt[3];
+    for (int m = 0; m < 3; ++m) {
+        const double gm = s.G[4 * m + r] * s.inv_qnorm;
+        cross3(hx.dc[NJ + m], hx.mu, tt);
+        for (int m2 = 0; m2 < 3; ++m2) {
+            crm6(hx.S[NJ + m], hx.S[NJ + m2], sx);
+            const double tw = dot3(tt, hx.Gm[NJ + m2].l) - dot6(hx.Sxl[NJ + m], hx.Gm[NJ + m2]) - dot6(Il, sx);
+            v += gm * tw * s.G[4 * m2 + c];
+        }
+    }
+    // K . d2 omega / dq_r dqdot_c = K . W(J[:, r])[:, c],  J = (1 - qh qh^T) / |q|
+    double Jr[4], col[3];
+    for (int a = 0; a < 4; ++a) Jr[a] = ((a == r ? 1.0 : 0.0) - s.qn[r] * s.qn[a]) * s.inv_qnorm;
+    What_col(Jr, c, col);
+    v += dot3(hx.K, col);
+    cx.em.H(hk::QQD + t, QB_ + r, QD_ + c, v);
+}
+
+// --- (q_b, q_b): lanes over the lower triangle (10) -----------------------------------------------------------------------------------------
+template <class Em> HD void t_kh_qq(KHCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    const KnotScratch& s = cx.s;
+    const KHessScratch& hx = h.hx;
+    const double* lam = hx.lam;
+    const double sigma = hx.sigma, on = cx.ki.first ? 0.0 : 1.0;
+    int r = 0;
+    while ((r + 1) * (r + 2) / 2 <= t) ++r;
+    const int c = t - r * (r + 1) / 2;
+    double E[9];
+    chest_error(s, E);
+    const double trE = E[0] + E[4] + E[8], e = trE - 3.0;
+    const double axE[3] = {E[7] - E[5], E[2] - E[6], E[3] - E[1]};
+    const double m2 = 2.0 * sigma * on * cx.st.m_frameq;
+    // Mw = sum_c w_c pkin_c^T + w_com com^T + sigma 2 m e E^T + mu L_G^T + omega K^T  (world frame);  M = Mw R_b
+    double Mw[9], M[9];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            double acc = -lam[gs::COMC + a] * s.com[b] + m2 * e * E[3 * b + a] + hx.mu[a] * hx.LG[b] + s.omega[a] * hx.K[b];
+            for (int p = 0; p < NC; ++p) acc += -lam[gs::PT_STRIDE * p + gs::KINC + a] * s.pkin[p][b];
+            Mw[3 * a + b] = acc;
+        }
+    matmul3(Mw, s.Rb, M);
+    const double trM = M[0] + M[4] + M[8];
+    const double al[3] = {M[7] - M[5], M[2] - M[6], M[3] - M[1]};
+    const double* qh = s.qn;
+    const double inv_n = s.inv_qnorm;
+    double B[16], g[4];
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) B[4 * a + b] = 2.0 * (M[3 * a + b] + M[3 * b + a]) - (a == b ? 4.0 * trM : 0.0);
+        B[4 * a + 3] = B[12 + a] = 2.0 * al[a];
+    }
+    B[15] = 0.0;
+    for (int a = 0; a < 3; ++a) g[a] = 2.0 * qh[3] * al[a] + B[4 * a] * qh[0] + B[4 * a + 1] * qh[1] + B[4 * a + 2] * qh[2];
+    g[3] = 2.0 * (qh[0] * al[0] + qh[1] * al[1] + qh[2] * al[2]);
+    double Jr[4], Jc[4], BJc[4];
+    for (int a = 0; a < 4; ++a) { Jr[a] = ((a == r ? 1.0 : 0.0) - qh[r] * qh[a]) * inv_n; Jc[a] = ((a == c ? 1.0 : 0.0) - qh[c] * qh[a]) * inv_n; }
+    for (int a = 0; a < 4; ++a) BJc[a] = B[4 * a] * Jc[0] + B[4 * a + 1] * Jc[1] + B[4 * a + 2] * Jc[2] + B[4 * a + 3] * Jc[3];
+    double v = Jr[0] * BJc[0] + Jr[1] * BJc[1] + Jr[2] * BJc[2] + Jr[3] * BJc[3];
+    v += norm2_entry(g, qh, inv_n, r, c);
+    // chest cost, outer product part: d e / d q_l = -(ax(E) . G_l) / |q|
+    const double ger = -(axE[0] * s.G[r] + axE[1] * s.G[4 + r] + axE[2] * s.G[8 + r]) * inv_n;
+    const double gec = -(axE[0] * s.G[c] + axE[1] * s.G[4 + c] + axE[2] * s.G[8 + c]) * inv_n;
+    v += m2 * ger * gec;
+    // centroidal momentum, remaining terms: omega = Wq(qdot) qhat with Wq = 2 [ -qd_w 1 - [qd_v]x | qd_v ]
+    {
+        const double* qd = s.x + QD_;
+        double g4[4];
+        for (int l = 0; l < 3; ++l) g4[l] = -2.0 * qd[3] * hx.K[l] - 2.0 * (skew_rc(qd, 0, l) * hx.K[0] + skew_rc(qd, 1, l) * hx.K[1] + skew_rc(qd, 2, l) * hx.K[2]);
+        g4[3] = 2.0 * dot3(qd, hx.K);
+        v += norm2_entry(g4, qh, inv_n, r, c);
+        double gr[3], gc[3], wr[3], wc[3], t1[3], t2[3], t3[3];
+        for (int m = 0; m < 3; ++m) { gr[m] = s.G[4 * m + r] * inv_n; gc[m] = s.G[4 * m + c] * inv_n; wr[m] = s.dwq[4 * m + r]; wc[m] = s.dwq[4 * m + c]; }
+        cross3(gc, hx.K, t1); v += dot3(wr, t1);
+        cross3(gr, hx.K, t1); v += dot3(wc, t1);
+        // (mu x g_r) . I_G (omega x g_c + dw_c) + (mu x g_c) . I_G (omega x g_r + dw_r)
+        cross3(hx.mu, gr, t1);
+        cross3(s.omega, gc, t2);
+        for (int m = 0; m < 3; ++m) t2[m] += wc[m];
+        matvec3(hx.IG, t2, t3);
+        v += dot3(t1, t3);
+        cross3(hx.mu, gc, t1);
+        cross3(s.omega, gr, t2);
+        for (int m = 0; m < 3; ++m) t2[m] += wr[m];
+        matvec3(hx.IG, t2, t3);
+        v += dot3(t1, t3);
+    }
+    if (r == c) {
+        const double* qd = s.pk + PK_REF + R_BQ;   // base quaternion error is linear in q: Hessian 2 m |q_d|^2 1  (E13)
+        v += 2.0 * lam[gs::UNITQ] + 2.0 * sigma * on * cx.st.m_baseq * (qd[0] * qd[0] + qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3]) + ends_diag(h, QB_ + r);
+    }
+    cx.em.H(hk::QQ + t, QB_ + r, QB_ + c, v);
+}
+
+// The Hessian tasks, run behind HIPNLP_KNOT_PROGRAM (RH(w, fn, n): tasks 0..n-1 of fn on wave w of four)
+#define HIPNLP_KNOT_HESS_PROGRAM(RH, BARRIER)                                                                    \
+    RH(0, t_kh_point, NC) RH(0, t_kh_ff, 36) RH(1, t_kh_pp, 180) RH(2, t_kh_diag, 42) RH(2, t_kh_percouple, 84) RH(3, t_kh_mom0, 1) \
+    BARRIER                                                                                                      \
+    RH(0, t_kh_joint, NJ + 3) RH(1, t_kh_Y, NJ)                                                                  \
+    BARRIER                                                                                                      \
+    RH(0, t_kh_ss, KH_SS_TASKS) RH(1, t_kh_ssd, NJ * NJ) RH(2, t_kh_sq, 4 * NJ) RH(2, t_kh_sqd, 4 * NJ)         \
+    RH(3, t_kh_sdq, 4 * NJ) RH(3, t_kh_qq, 10) RH(3, t_kh_qqd, 16)                                              \
+    BARRIER
+
+}  // namespace hipnlp

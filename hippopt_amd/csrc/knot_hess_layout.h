@@ -1,0 +1,85 @@
+// knot_hess_layout.h — sparsity pattern of the Hessian of the Lagrangian of the kinodynamic NLP, recorded from the tasks of
+// knot_hess_body.h (the same single-source pattern as the Jacobian: what a task emits IS the structure).
+// Lower triangle, triplets.  Order: knot 0 block | knot 1 block | ... | knot N-1 block | periodicity coupling (last x first),
+// every knot block sorted by (column, row).  All knots share one block pattern (rows that do not exist at a knot have a zero
+// multiplier there; costs that start at k = 1 are switched off numerically at k = 0).
+#pragma once
+#include <algorithm>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "knot_hess_body.h"
+#include "layout.h"
+
+namespace hipnlp {
+
+struct HessLayout {
+    int N = 0;
+    int nnz_knot = 0;                 // entries of one knot block
+    int n_couple = 0;                 // periodicity-coupling entries (0 or 84)
+    long nnz = 0;
+    std::vector<int32_t> perm;        // [nnz_knot] position in the knot block -> native slot
+    std::vector<int32_t> lrow, lcol;  // [nnz_knot] variable offsets inside the knot record
+    std::vector<int32_t> perm_couple, crow, ccol;   // coupling: slot, variable of the last knot (row), of the first knot (column)
+    std::string error;
+
+    bool build(const hipnlp_settings& st, const KinTables& kt) {
+        N = st.horizon;
+        if (st.terrain != HIPNLP_TERRAIN_PLANAR) { error = "exact Hessian: only the planar terrain is built"; return false; }
+        std::vector<int> grow(gs::COUNT, -1), jrid(js::COUNT, -1), jc(js::COUNT, -1), hrow(hk::COUNT, -1), hcol(hk::COUNT, -1);
+        bool dup = false;
+        KnotScratch* s = new KnotScratch();
+        KHessScratch* hx = new KHessScratch();
+        std::fill(reinterpret_cast<double*>(s), reinterpret_cast<double*>(s) + sizeof(KnotScratch) / sizeof(double), 0.0);
+        std::fill(reinterpret_cast<double*>(hx), reinterpret_cast<double*>(hx) + sizeof(KHessScratch) / sizeof(double), 0.0);
+        s->x[QB_ + 3] = 1.0;
+        KSettings ks = Layout::make_ksettings(st);
+        GParams gp{};
+        gp.dt = 0.1; gp.mass = 1.0;
+        KnotInfo ki{0, N, 1, 1};
+        RecordEm em{grow.data(), jrid.data(), jc.data(), &dup, hrow.data(), hcol.data()};
+        Ctx<RecordEm> cx(*s, kt, ks, gp, ki, em);
+#define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
+        HIPNLP_KNOT_PROGRAM(HOST_R, )
+#undef HOST_R
+        dup = false;   // (the knot program's own slots were checked by Layout::build)
+        KHCtx<RecordEm> hcx{cx, *hx};
+#define HOST_RH(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(hcx, t_);
+        HIPNLP_KNOT_HESS_PROGRAM(HOST_RH, )
+#undef HOST_RH
+        delete hx;
+        delete s;
+        if (dup) { error = "internal: native Hessian slot emitted twice"; return false; }
+        std::vector<std::pair<std::pair<int, int>, int>> ent, cpl;   // ((col, row), slot)
+        for (int slot = 0; slot < hk::COUNT; ++slot) {
+            if (hrow[size_t(slot)] < 0) continue;
+            if (hcol[size_t(slot)] >= COL_FIRST) cpl.push_back({{hcol[size_t(slot)] - COL_FIRST, hrow[size_t(slot)]}, slot});
+            else {
+                if (hrow[size_t(slot)] < hcol[size_t(slot)]) { error = "internal: Hessian entry above the diagonal"; return false; }
+                ent.push_back({{hcol[size_t(slot)], hrow[size_t(slot)]}, slot});
+            }
+        }
+        std::sort(ent.begin(), ent.end());
+        std::sort(cpl.begin(), cpl.end());
+        for (size_t i = 1; i < ent.size(); ++i)
+            if (ent[i].first == ent[i - 1].first) { error = "internal: duplicate Hessian entry"; return false; }
+        perm.clear(); lrow.clear(); lcol.clear(); perm_couple.clear(); crow.clear(); ccol.clear();
+        for (auto& e : ent) { perm.push_back(e.second); lcol.push_back(e.first.first); lrow.push_back(e.first.second); }
+        for (auto& e : cpl) { perm_couple.push_back(e.second); ccol.push_back(e.first.first); crow.push_back(e.first.second); }
+        nnz_knot = int(perm.size());
+        n_couple = int(perm_couple.size());
+        nnz = long(nnz_knot) * N + n_couple;
+        return true;
+    }
+    long knot_base(int k) const { return long(nnz_knot) * k; }
+    long couple_base() const { return long(nnz_knot) * N; }
+    void pattern(int* irow, int* jcol) const {
+        long e = 0;
+        for (int k = 0; k < N; ++k)
+            for (int i = 0; i < nnz_knot; ++i, ++e) { irow[e] = NXK * k + lrow[size_t(i)]; jcol[e] = NXK * k + lcol[size_t(i)]; }
+        for (int i = 0; i < n_couple; ++i, ++e) { irow[e] = NXK * (N - 1) + crow[size_t(i)]; jcol[e] = ccol[size_t(i)]; }
+    }
+};
+
+}  // namespace hipnlp

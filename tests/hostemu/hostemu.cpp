@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 
+#include "../../hippopt_amd/csrc/knot_hess_layout.h"
 #include "../../hippopt_amd/csrc/pose_layout.h"
 
 using namespace hipnlp;
@@ -26,6 +27,8 @@ struct hostemu_handle {
     KinTables kt;
     KSettings ks;
     Layout L;
+    HessLayout HL;
+    bool has_hess = false;
 };
 
 extern "C" {
@@ -41,9 +44,56 @@ hostemu_handle* hostemu_create(const hipnlp_desc* desc, char* err, int errlen) {
         return nullptr;
     }
     h->ks = Layout::make_ksettings(desc->settings);
+    h->has_hess = h->HL.build(desc->settings, h->kt);
     return h;
 }
 void hostemu_destroy(hostemu_handle* h) { delete h; }
+long hostemu_hess_nnz(const hostemu_handle* h) { return h->has_hess ? h->HL.nnz : -1; }
+const char* hostemu_hess_error(const hostemu_handle* h) { return h->HL.error.c_str(); }
+void hostemu_hess_sparsity(const hostemu_handle* h, int* irow, int* jcol) { h->HL.pattern(irow, jcol); }
+// the Hessian tasks of knot_hess_body.h behind the knot program, multiplier gather and copy-out as in hipnlp_knot_hess_kernel
+void hostemu_hess(const hostemu_handle* h, const double* x, const double* p, double sigma, const double* lambda, double* hess) {
+    const Layout& L = h->L;
+    const HessLayout& HL = h->HL;
+    const int N = L.N;
+    std::vector<double> pk(size_t(N) * PK_STRIDE);
+    GParams gp;
+    pack_params(p, N, pk.data(), gp);
+    KnotScratch* s = new KnotScratch();
+    KHessScratch* hx = new KHessScratch();
+    for (int k = 0; k < N; ++k) {
+        std::fill(reinterpret_cast<double*>(s), reinterpret_cast<double*>(s) + sizeof(KnotScratch) / sizeof(double), std::nan(""));
+        std::fill(reinterpret_cast<double*>(hx), reinterpret_cast<double*>(hx) + sizeof(KHessScratch) / sizeof(double), std::nan(""));
+        for (int i = 0; i < XPAD; ++i) { s->x[i] = 0; s->xm[i] = 0; }
+        for (int i = 0; i < NPER; ++i) s->xo[i] = 0;
+        for (int i = 0; i < NXK; ++i) { s->x[i] = x[NXK * k + i]; s->xm[i] = k > 0 ? x[NXK * (k - 1) + i] : 0.0; }
+        for (int i = 0; i < NPER; ++i) s->xo[i] = k == 0 ? x[NXK * (N - 1) + periodicity_row_var(i)] : (k == N - 1 ? x[periodicity_row_var(i)] : 0.0);
+        for (int i = 0; i < NXG; ++i) s->xg[i] = x[NXK * N + i];
+        for (int i = 0; i < PK_STRIDE; ++i) s->pk[i] = pk[size_t(k) * PK_STRIDE + i];
+        const int v = L.variant_of(k);
+        for (int slot = 0; slot < gs::COUNT; ++slot) { const int a = L.g_a[v][size_t(slot)]; hx->lam[slot] = a >= 0 ? lambda[a + L.g_b[size_t(slot)] * k] : 0.0; }
+        for (int i = 0; i < 3; ++i) {
+            const int slot = gs::HDYN + 3 + i, vn = L.variant_of(k + 1);
+            const int a = k + 1 < N ? L.g_a[vn][size_t(slot)] : -1;
+            hx->lam_next[i] = a >= 0 ? lambda[a + L.g_b[size_t(slot)] * (k + 1)] : 0.0;
+        }
+        hx->sigma = sigma;
+        KnotInfo ki{k, N, k == 0, k == N - 1};
+        ValueEm em{s->g, s->jac, hx->H};
+        Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
+#define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
+        HIPNLP_KNOT_PROGRAM(HOST_R, )
+#undef HOST_R
+        KHCtx<ValueEm> hcx{cx, *hx};
+#define HOST_RH(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(hcx, t_);
+        HIPNLP_KNOT_HESS_PROGRAM(HOST_RH, )
+#undef HOST_RH
+        for (int i = 0; i < HL.nnz_knot; ++i) hess[HL.knot_base(k) + i] = hx->H[HL.perm[size_t(i)]];
+        if (k == N - 1) for (int i = 0; i < HL.n_couple; ++i) hess[HL.couple_base() + i] = hx->H[HL.perm_couple[size_t(i)]];
+    }
+    delete hx;
+    delete s;
+}
 void hostemu_dims(const hostemu_handle* h, int* n, int* m, int* nnz) { *n = h->L.n; *m = h->L.m; *nnz = h->L.nnz; }
 void hostemu_sparsity(const hostemu_handle* h, int* irow, int* jcol) {
     for (int i = 0; i < h->L.nnz; ++i) { irow[i] = h->L.irow[size_t(i)]; jcol[i] = h->L.jcol[size_t(i)]; }

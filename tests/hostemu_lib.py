@@ -10,7 +10,7 @@ from hippopt_amd import _abi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = os.path.join(ROOT, "tests", "_build", "libhipnlp_hostemu.so")
 SRC = [os.path.join(ROOT, "tests", "hostemu", "hostemu.cpp")] + [
-    os.path.join(ROOT, "hippopt_amd", "csrc", f) for f in ("layout.h", "knot_body.h", "nlp_defs.h", "pose_body.h", "pose_hess_body.h", "pose_layout.h")]
+    os.path.join(ROOT, "hippopt_amd", "csrc", f) for f in ("layout.h", "knot_body.h", "nlp_defs.h", "pose_body.h", "pose_hess_body.h", "pose_layout.h", "knot_hess_body.h", "knot_hess_layout.h")]
 
 
 def build():
@@ -70,6 +70,30 @@ class HostEmu:
         self.lib.hostemu_eval(C.c_void_p(self.h), _dp(np.ascontiguousarray(x)), _dp(np.ascontiguousarray(p)),
                               C.byref(f), _dp(grad), _dp(g), _dp(jac), _dp(ct))
         return f.value, grad, g, jac, ct
+
+
+def _hostemu_hess_methods():
+    def hess_sparsity(self):
+        self.lib.hostemu_hess_nnz.restype = C.c_long
+        nnz = self.lib.hostemu_hess_nnz(C.c_void_p(self.h))
+        if nnz < 0:
+            self.lib.hostemu_hess_error.restype = C.c_char_p
+            raise RuntimeError(self.lib.hostemu_hess_error(C.c_void_p(self.h)).decode())
+        ir, jc = np.zeros(nnz, np.int32), np.zeros(nnz, np.int32)
+        self.lib.hostemu_hess_sparsity(C.c_void_p(self.h), _ip(ir), _ip(jc))
+        return ir, jc
+
+    def hess(self, x, p, sigma, lam):
+        ir, _ = self.hess_sparsity()
+        out = np.full(ir.size, np.nan)
+        self.lib.hostemu_hess(C.c_void_p(self.h), _dp(np.ascontiguousarray(x)), _dp(np.ascontiguousarray(p)), C.c_double(sigma),
+                              _dp(np.ascontiguousarray(lam, np.float64)), _dp(out))
+        return out
+    HostEmu.hess_sparsity = hess_sparsity
+    HostEmu.hess = hess
+
+
+_hostemu_hess_methods()
 
 
 class PoseHostEmu:
