@@ -20,6 +20,7 @@
 #include <tuple>
 #include <vector>
 
+#include "knot_hess_layout.h"
 #include "layout.h"
 
 using namespace hipnlp;
@@ -357,6 +358,111 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 #endif
 }
 
+// =====================================================================================================================
+// Exact Hessian of the Lagrangian (knot_hess_body.h): one workgroup of four waves per knot runs the knot program (its g / jac
+// outputs stay in LDS, unused) and, behind it, the Hessian tasks; the knot's block of the triplet values leaves as one contiguous
+// run.  Multipliers arrive in the reference's row order and are gathered through the same slot -> row map that scatters g.
+// =====================================================================================================================
+struct HessTables {
+    int32_t perm[hk::COUNT];      // position in the knot block -> native slot
+    int32_t perm_couple[84];
+    int32_t nnz_knot, n_couple;
+};
+struct HArgs {
+    const DeviceTables* tb;
+    const HessTables* ht;
+    const double* x;        // [batch][n]
+    const double* pk;
+    const GParams* gp;
+    const double* sigma;    // [batch]
+    const double* lambda;   // [batch][m]
+    double* hess;           // [batch][nnz_h]
+    int32_t* flag;          // [batch] set to 1 by a trajectory that produced a non-finite value
+    int32_t N, n, m, knot_begin;
+    int64_t hstride, hoff;  // values of trajectory b start at hess + b * hstride; the handle's first knot block sits at -hoff
+};
+template <int TERRAIN> struct DevEmH {
+    static constexpr int kTerrain = TERRAIN;
+    double* g;
+    double* jac;
+    double* hess;
+    __device__ __forceinline__ void G(int slot, int, double v) { g[slot] = v; }
+    __device__ __forceinline__ void J(int slot, int, int, double v) { jac[slot] = v; }
+    __device__ __forceinline__ void H(int slot, int, int, double v) { hess[slot] = v; }
+};
+
+__global__ __launch_bounds__(256) void hipnlp_knot_hess_kernel(HArgs a) {
+    constexpr int WG = 256;
+    __shared__ KnotScratch s;
+    __shared__ SharedTables tabs;
+    __shared__ KHessScratch hx;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.y;
+    const int kk = int((blockIdx.x & 7u) * (gridDim.x >> 3) + min(blockIdx.x & 7u, gridDim.x & 7u) + (blockIdx.x >> 3));   // (XCD-aware, as in hipnlp_knot_kernel)
+    const int k = a.knot_begin + kk, N = a.N;
+    const int first = k == 0, last = k == N - 1;
+    const double* x = a.x + size_t(b) * a.n;
+    const DeviceTables& tb = *a.tb;
+    {
+        constexpr int HV = int(sizeof(HeadTables) / 16), GV = int(sizeof(GParams) / 8);
+        const uint4* hsrc = reinterpret_cast<const uint4*>(&tb.head);
+        uint4* hdst = reinterpret_cast<uint4*>(&tabs.head);
+        for (int i = tid; i < HV; i += WG) hdst[i] = hsrc[i];
+        const double* gsrc = reinterpret_cast<const double*>(a.gp + b);
+        double* gdst = reinterpret_cast<double*>(&tabs.gp);
+        for (int i = tid; i < GV; i += WG) gdst[i] = gsrc[i];
+        for (int i = tid; i < XPAD; i += WG) {
+            const bool in = i < NXK;
+            s.x[i] = in ? x[size_t(NXK) * k + i] : 0.0;
+            s.xm[i] = (in && !first) ? x[size_t(NXK) * (k - 1) + i] : 0.0;
+        }
+        for (int i = tid; i < NPER; i += WG) s.xo[i] = (first || last) ? x[size_t(NXK) * (first ? N - 1 : 0) + periodicity_row_var(i)] : 0.0;
+        if (tid < PK_STRIDE) s.pk[tid] = a.pk[(size_t(b) * N + k) * PK_STRIDE + tid];
+        if (tid < 8) s.xg[tid] = tid < NXG ? x[size_t(NXK) * N + tid] : 0.0;
+        // multipliers of the rows this knot owns, by native slot; of the next interval's angular momentum rows
+        const double* lam = a.lambda + size_t(b) * a.m;
+        const int v = first ? VAR_FIRST : (last ? VAR_LAST : VAR_INTERIOR);
+        for (int slot = tid; slot < gs::COUNT; slot += WG) {
+            const int ga = tb.g_a[v][slot];
+            hx.lam[slot] = ga >= 0 ? lam[ga + tb.g_b[slot] * k] : 0.0;
+        }
+        if (tid < 3) {
+            const int slot = gs::HDYN + 3 + tid;
+            const int ga = k + 1 < N ? tb.g_a[k + 1 == N - 1 ? VAR_LAST : VAR_INTERIOR][slot] : -1;
+            hx.lam_next[tid] = ga >= 0 ? lam[ga + tb.g_b[slot] * (k + 1)] : 0.0;
+        }
+        if (tid == 0) { hx.sigma = a.sigma[b]; s.pub_ready = 0; }
+    }
+    __syncthreads();
+    KnotInfo ki{k, N, first, last};
+    DevEmH<HIPNLP_TERRAIN_PLANAR> em{s.g, s.jac, hx.H};
+    Ctx<DevEmH<HIPNLP_TERRAIN_PLANAR>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
+#define DEV_R(w4, w8, fn, nt) if (wave == (w4)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
+#define DEV_BARRIER __syncthreads();
+    HIPNLP_KNOT_PROGRAM(DEV_R, DEV_BARRIER)
+#undef DEV_R
+    KHCtx<DevEmH<HIPNLP_TERRAIN_PLANAR>> hcx{cx, hx};
+#define DEV_RH(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); }
+    HIPNLP_KNOT_HESS_PROGRAM(DEV_RH, DEV_BARRIER)
+#undef DEV_RH
+#undef DEV_BARRIER
+    const HessTables& ht = *a.ht;
+    const int cnt = ht.nnz_knot;
+    double* out = a.hess + int64_t(b) * a.hstride + (int64_t(cnt) * k - a.hoff);
+    int bad = 0;
+    for (int i = tid; i < cnt; i += WG) {
+        const double v = hx.H[ht.perm[i]];
+        bad |= !isfinite(v);
+        out[i] = v;
+    }
+    if (last) {
+        double* oc = a.hess + int64_t(b) * a.hstride + (int64_t(cnt) * N - a.hoff);
+        for (int i = tid; i < ht.n_couple; i += WG) { const double v = hx.H[ht.perm_couple[i]]; bad |= !isfinite(v); oc[i] = v; }
+    }
+    if (__any(bad) && lane == 0) atomicOr(a.flag + b, 1);
+}
+
+
 // Throughput variant only (4 waves; the latency variant sums inside the knot kernel, see pub_step): f[b] = sum over knots and
 // terms, cost_terms[b][t] = sum over knots.  One workgroup per trajectory.  Thread (group g = tid / 16, column c = tid % 16) sums
 // column c of the knots g, g + 16, ...: all its loads are independent and issued together (ONE memory round trip), then a fixed
@@ -439,6 +545,12 @@ struct hipnlp_handle {
     int32_t* h_flag = nullptr;
     std::vector<double> p;
     bool params_set = false, have_result = false;
+    // exact Hessian (allocated on first use)
+    HessLayout HL;
+    int hess_state = 0;   // 0: not built yet, 1: ready, -1: not available (HL.error)
+    HessTables* d_ht = nullptr;
+    double *d_sigma = nullptr, *d_lambda = nullptr, *d_hess = nullptr, *h_hess = nullptr;
+    int32_t *d_hflag = nullptr, *h_hflag = nullptr;
     std::string err;
 };
 
@@ -455,9 +567,9 @@ static void free_all(hipnlp_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* dptrs[] = {h->d_tb, h->d_x, h->d_pk, h->d_cost_knot, h->d_gp, h->d_ticket, h->d_out};
+    void* dptrs[] = {h->d_tb, h->d_x, h->d_pk, h->d_cost_knot, h->d_gp, h->d_ticket, h->d_out, h->d_ht, h->d_sigma, h->d_lambda, h->d_hess, h->d_hflag};
     for (void* q : dptrs) if (q) (void)hipFree(q);
-    void* hptrs[] = {h->h_x, h->h_out};
+    void* hptrs[] = {h->h_x, h->h_out, h->h_hess, h->h_hflag};
     for (void* q : hptrs) if (q) (void)hipHostFree(q);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -683,6 +795,99 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     HIP_TRY(h, hipGetLastError());
     if (prof) h->prof_n++;
     if (timed) { h->last_e0 = e0; h->last_e2 = e2; h->timing_valid = true; }
+    return HIPNLP_OK;
+}
+
+
+// ---- exact Hessian of the Lagrangian (IPOPT eval_h) ----------------------------------------------------------------------------
+static int hess_prepare(hipnlp_handle* h) {
+    if (h->hess_state == 1) return HIPNLP_OK;
+    if (h->hess_state == 0) {
+        h->hess_state = h->HL.build(h->d.settings, h->kt) ? 1 : -1;
+        if (h->hess_state == 1) {
+            HIP_TRY(h, hipSetDevice(h->dev));
+            HessTables* t = new HessTables();
+            std::memset(t, 0, sizeof(HessTables));
+            for (int i = 0; i < h->HL.nnz_knot; ++i) t->perm[i] = h->HL.perm[size_t(i)];
+            for (int i = 0; i < h->HL.n_couple; ++i) t->perm_couple[i] = h->HL.perm_couple[size_t(i)];
+            t->nnz_knot = h->HL.nnz_knot; t->n_couple = h->HL.n_couple;
+            hipError_t e = hipMalloc(&h->d_ht, sizeof(HessTables));
+            if (e == hipSuccess) e = hipMemcpy(h->d_ht, t, sizeof(HessTables), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMalloc(&h->d_hflag, size_t(h->batch) * sizeof(int32_t));
+            if (e == hipSuccess) e = hipHostMalloc(&h->h_hflag, size_t(h->batch) * sizeof(int32_t));
+            delete t;
+            if (e != hipSuccess) { h->hess_state = 0; h->err = std::string("Hessian tables: ") + hipGetErrorString(e); return HIPNLP_E_NODEVICE; }
+        }
+    }
+    if (h->hess_state != 1) { h->err = h->HL.error; return HIPNLP_E_UNSUPPORTED; }
+    return HIPNLP_OK;
+}
+// entries of THIS handle's knots (a shard handle owns the blocks of its knots; the coupling entries belong to the last knot)
+static int64_t hess_count(const hipnlp_handle* h) { return int64_t(h->HL.nnz_knot) * h->nk + (h->ke == h->L.N ? h->HL.n_couple : 0); }
+
+int hipnlp_hess_nnz(hipnlp_handle* h, int64_t* nnz_h) {
+    if (!h || !nnz_h) return HIPNLP_E_INVALID;
+    const int rc = hess_prepare(h);
+    if (rc != HIPNLP_OK) return rc;
+    *nnz_h = hess_count(h);
+    return HIPNLP_OK;
+}
+int hipnlp_hess_sparsity(hipnlp_handle* h, int32_t* irow, int32_t* jcol) {
+    if (!h || !irow || !jcol) return HIPNLP_E_INVALID;
+    const int rc = hess_prepare(h);
+    if (rc != HIPNLP_OK) return rc;
+    std::vector<int32_t> ir(size_t(h->HL.nnz)), jc(size_t(h->HL.nnz));
+    h->HL.pattern(ir.data(), jc.data());
+    const int64_t off = h->HL.knot_base(h->kb), cnt = hess_count(h);
+    std::memcpy(irow, ir.data() + off, size_t(cnt) * sizeof(int32_t));
+    std::memcpy(jcol, jc.data() + off, size_t(cnt) * sizeof(int32_t));
+    return HIPNLP_OK;
+}
+static int hess_launch(hipnlp_handle* h, const double* x_dev, const double* sigma_dev, const double* lambda_dev, double* hess_dev, hipStream_t s) {
+    HArgs a;
+    a.tb = h->d_tb; a.ht = h->d_ht; a.x = x_dev; a.pk = h->d_pk; a.gp = h->d_gp;
+    a.sigma = sigma_dev; a.lambda = lambda_dev; a.hess = hess_dev; a.flag = h->d_hflag;
+    a.N = h->L.N; a.n = h->L.n; a.m = h->L.m; a.knot_begin = h->kb;
+    a.hstride = hess_count(h); a.hoff = h->HL.knot_base(h->kb);
+    HIP_TRY(h, hipMemsetAsync(h->d_hflag, 0, size_t(h->batch) * sizeof(int32_t), s));
+    hipLaunchKernelGGL(hipnlp_knot_hess_kernel, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(256), 0, s, a);
+    HIP_TRY(h, hipGetLastError());
+    return HIPNLP_OK;
+}
+int hipnlp_eval_hess_device(hipnlp_handle* h, const double* x_dev, const double* obj_factor_dev, const double* lambda_dev, double* hess_dev, void* stream) {
+    if (!h || !x_dev || !obj_factor_dev || !lambda_dev || !hess_dev) return HIPNLP_E_INVALID;
+    if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
+    const int rc = hess_prepare(h);
+    if (rc != HIPNLP_OK) return rc;
+    HIP_TRY(h, hipSetDevice(h->dev));
+    return hess_launch(h, x_dev, obj_factor_dev, lambda_dev, hess_dev, stream ? hipStream_t(stream) : h->stream);
+}
+int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor, const double* lambda, double* hess) {
+    if (!h || !x || !obj_factor || !lambda || !hess) return HIPNLP_E_INVALID;
+    if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
+    int rc = hess_prepare(h);
+    if (rc != HIPNLP_OK) return rc;
+    const size_t B = size_t(h->batch), n = size_t(h->L.n), m = size_t(h->L.m), hn = size_t(hess_count(h));
+    HIP_TRY(h, hipSetDevice(h->dev));
+    if (!h->d_hess) {
+        HIP_TRY(h, hipMalloc(&h->d_sigma, B * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&h->d_lambda, B * m * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&h->d_hess, B * hn * sizeof(double)));
+        HIP_TRY(h, hipHostMalloc(&h->h_hess, B * hn * sizeof(double)));
+    }
+    h->have_result = false;   // (the staging copy of x is shared with hipnlp_eval)
+    std::memcpy(h->h_x, x, B * n * sizeof(double));
+    HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_x, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_sigma, obj_factor, B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_lambda, lambda, B * m * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    rc = hess_launch(h, h->d_x, h->d_sigma, h->d_lambda, h->d_hess, h->stream);
+    if (rc != HIPNLP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->h_hess, h->d_hess, B * hn * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_hflag, h->d_hflag, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::memcpy(hess, h->h_hess, B * hn * sizeof(double));
+    for (size_t b = 0; b < B; ++b)
+        if (h->h_hflag[b]) { h->err = "non-finite value produced by the evaluation"; return HIPNLP_E_NUMERIC; }
     return HIPNLP_OK;
 }
 

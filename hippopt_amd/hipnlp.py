@@ -20,6 +20,7 @@ EXPORTS = [
     "hipnlp_cost_terms", "hipnlp_cost_term_name", "hipnlp_num_row_blocks", "hipnlp_row_block",
     "hipnlp_last_kernel_ms", "hipnlp_profile_begin", "hipnlp_profile_end", "hipnlp_kernels_per_eval", "hipnlp_profile_begin_runs",
     "hipnlp_eval_device_shard", "hipnlp_stage_rows", "hipnlp_reassemble",
+    "hipnlp_hess_nnz", "hipnlp_hess_sparsity", "hipnlp_eval_hess", "hipnlp_eval_hess_device",
     "hipnlp_pose_create", "hipnlp_pose_destroy", "hipnlp_pose_last_error", "hipnlp_pose_get_dims", "hipnlp_pose_set_params",
     "hipnlp_pose_bounds", "hipnlp_pose_sparsity", "hipnlp_pose_eval", "hipnlp_pose_eval_device", "hipnlp_pose_cost_terms",
     "hipnlp_pose_cost_term_name", "hipnlp_pose_num_row_blocks", "hipnlp_pose_row_block", "hipnlp_pose_last_kernel_ms",
@@ -97,6 +98,10 @@ def load_library():
     lib.hipnlp_pose_hess_sparsity.argtypes = [vp, ip, ip]
     lib.hipnlp_pose_eval_hess.argtypes = [vp, dp, dp, dp, dp]
     lib.hipnlp_pose_eval_hess_device.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.hipnlp_hess_nnz.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.hipnlp_hess_sparsity.argtypes = [vp, ip, ip]
+    lib.hipnlp_eval_hess.argtypes = [vp, dp, dp, dp, dp]
+    lib.hipnlp_eval_hess_device.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.hipnlp_kernels_per_eval.argtypes = [vp]
     lib.hipnlp_profile_begin_runs.argtypes = [vp, C.c_int, C.c_int]
     lib.hipnlp_reassemble.argtypes = [vp, vp, vp, C.c_int64, C.c_int, C.c_int64, vp, vp]
@@ -196,6 +201,32 @@ class HipNlp:
         """Device-pointer variant (ints from tensor.data_ptr()); asynchronous on `stream`."""
         self._check(self.lib.hipnlp_eval_device(self.h, C.c_void_p(x_ptr), C.c_void_p(f_ptr or None), C.c_void_p(grad_ptr or None),
                                                 C.c_void_p(g_ptr or None), C.c_void_p(jac_ptr or None), C.c_void_p(stream or None)))
+
+    # ---- exact Hessian of the Lagrangian (IPOPT eval_h): lower-triangle triplets, block diagonal by knot ---------------------
+    def hess_nnz(self):
+        if not hasattr(self, "_hnnz"):
+            n = C.c_int64()
+            self._check(self.lib.hipnlp_hess_nnz(self.h, C.byref(n)))
+            self._hnnz = n.value
+        return self._hnnz
+
+    def hess_sparsity(self):
+        ir, jc = np.zeros(self.hess_nnz(), np.int32), np.zeros(self.hess_nnz(), np.int32)
+        self._check(self.lib.hipnlp_hess_sparsity(self.h, _ip(ir), _ip(jc)))
+        return ir, jc
+
+    def eval_hess(self, x, obj_factor, lam):
+        """values [batch][nnz_h] of  obj_factor * hess f + sum_r lam_r hess g_r  at x (obj_factor: scalar or [batch])"""
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.batch, self.n)
+        lam = np.ascontiguousarray(lam, dtype=np.float64).reshape(self.batch, self.m)
+        sig = np.ascontiguousarray(np.broadcast_to(np.asarray(obj_factor, dtype=np.float64), (self.batch,)))
+        out = np.zeros((self.batch, self.hess_nnz()))
+        self._check(self.lib.hipnlp_eval_hess(self.h, _dp(x), _dp(sig), _dp(lam), _dp(out)))
+        return out
+
+    def eval_hess_device(self, x_ptr, obj_factor_ptr, lam_ptr, hess_ptr, stream=None):
+        vp = C.c_void_p
+        self._check(self.lib.hipnlp_eval_hess_device(self.h, vp(x_ptr), vp(obj_factor_ptr), vp(lam_ptr), vp(hess_ptr), vp(stream or None)))
 
     def cost_terms(self):
         out = np.empty((self.batch, _abi.NCOST_TERMS))

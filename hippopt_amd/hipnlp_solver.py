@@ -19,6 +19,7 @@ from . import _abi
 from .base import OptimizationObject, extend_structure_to_horizon
 from .base.opti_callback import CallbackCriterion, IterateInfo, SaveBestUnsolvedVariablesCallback
 from .base.optimization_object import STORAGE_TYPE
+from .hipnlp import HipNlpError
 
 
 class HipFailure(Exception):
@@ -305,15 +306,21 @@ class HipNlpSolver:
             return csc_matrix((j[0], (ir, jc)), shape=(m, n))
         exact = hasattr(eng, "eval_hess") and self._options.get("hessian_approximation", "exact") != "limited-memory"
         hess_f, hess_c = BFGS(), BFGS()
+        if exact:
+            try:
+                hr, hc = eng.hess_sparsity()
+            except HipNlpError as err:   # smooth terrain: the exact Hessian is not built -> quasi-Newton, as with `limited-memory`
+                if err.code != -6:
+                    raise
+                exact = False
         if exact:   # exact second derivatives from the engine (lower triangle -> symmetric matrix)
-            hr, hc = eng.hess_sparsity()
             off = hr != hc
 
             def sym(vals):
                 return csc_matrix((np.concatenate([vals, vals[off]]), (np.concatenate([hr, hc[off]]), np.concatenate([hc, hr[off]]))), shape=(n, n))
             zero_lam = np.zeros(m)
-            hess_f = lambda x: sym(eng.eval_hess(x[None, :], 1.0, zero_lam[None, :]))      # noqa: E731
-            hess_c = lambda x, v: sym(eng.eval_hess(x[None, :], 0.0, np.asarray(v)[None, :]))  # noqa: E731
+            hess_f = lambda x: sym(np.asarray(eng.eval_hess(x[None, :], 1.0, zero_lam[None, :])).reshape(-1))      # noqa: E731
+            hess_c = lambda x, v: sym(np.asarray(eng.eval_hess(x[None, :], 0.0, np.asarray(v)[None, :])).reshape(-1))  # noqa: E731
         nlc = NonlinearConstraint(cons, lbg, ubg, jac=jac, hess=hess_c)
         opts = {"maxiter": int(self._options.get("max_iter", 50)), "verbose": int(self._options.get("verbose", 0)),
                 "gtol": float(self._options.get("tol", 1e-6))}
@@ -358,10 +365,16 @@ class HipNlpSolver:
                 outer._iterate_callback(iter_count, x_it, obj_value, inf_pr, lam_it)
                 return True
         exact = hasattr(eng, "eval_hess") and outer._options.get("hessian_approximation", "exact") != "limited-memory"
+        if exact:
+            try:
+                hr, hc = eng.hess_sparsity()
+            except HipNlpError as err:   # smooth terrain: the exact Hessian is not built -> limited-memory
+                if err.code != -6:
+                    raise
+                exact = False
         if exact:   # eval_h from the engine: the pose finder runs IPOPT with the exact Hessian (humanoid_pose_finder/main.py:101)
-            hr, hc = eng.hess_sparsity()
             Callbacks.hessianstructure = lambda self: (hr, hc)
-            Callbacks.hessian = lambda self, x, lagrange, obj_factor: eng.eval_hess(x[None, :], obj_factor, np.asarray(lagrange)[None, :])
+            Callbacks.hessian = lambda self, x, lagrange, obj_factor: np.asarray(eng.eval_hess(x[None, :], obj_factor, np.asarray(lagrange)[None, :])).reshape(-1)
         nlp = cyipopt.Problem(n=eng.n, m=eng.m, problem_obj=Callbacks(), lb=lbx, ub=ubx, cl=lbg, cu=ubg)
         if not exact:
             nlp.add_option("hessian_approximation", "limited-memory")  # main_periodic_step.py:116

@@ -57,6 +57,7 @@ extern "C" {
 #define HIPNLP_E_ALLOC (-3)
 #define HIPNLP_E_PARAMS (-4)    /* parameters not set before eval (opti_solver.py:447-450) */
 #define HIPNLP_E_NUMERIC (-5)   /* NaN/Inf produced by the kernel (IPOPT callback must return false) */
+#define HIPNLP_E_UNSUPPORTED (-6) /* the request is valid but this part is not built (hipnlp_last_error says which) */
 
 /* ExpressionType of base/problem.py:15-19 */
 #define HIPNLP_EXPR_SKIP 0
@@ -198,6 +199,22 @@ int hipnlp_sparsity(const hipnlp_handle* h, int32_t* irow, int32_t* jcol);
 int hipnlp_eval(hipnlp_handle* h, const double* x, int new_x,
                 double* f, double* grad_f, double* g, double* jac);
 
+
+/* Exact Hessian of the Lagrangian  sigma f(x) + lambda^T g(x)  of the kinodynamic NLP — IPOPT's eval_h (IpStdCInterface.h:
+ * Eval_H_CB(n, x, new_x, obj_factor, m, lambda, new_lambda, nele_hess, iRow, jCol, values, ud)); what CasADi's nlp_hess_l
+ * computes for the reference when a script does not set `hessian_approximation = limited-memory` (SURVEY 8f rank 1;
+ * opti_solver.py:123-125,479).  Lower triangle (irow >= jcol) as triplets with a fixed pattern: the Hessian is block diagonal
+ * by knot (the trapezoid defects are sums of one-knot terms), plus the 84 entries coupling the last knot with the first when
+ * the periodicity expression is a cost.  Order: knot blocks in knot order, each sorted by (column, row), then the coupling.
+ * Planar terrain only: HIPNLP_E_UNSUPPORTED on the smooth-steps terrain (its rows need fourth-order terrain jets; not built).
+ *   hipnlp_hess_nnz / _sparsity   structure (the `values == NULL` call of eval_h); a shard handle reports its own knots' blocks
+ *   hipnlp_eval_hess              host buffers: x [batch][n], obj_factor [batch], lambda [batch][m] -> values [batch][nnz_h]
+ *   hipnlp_eval_hess_device       device pointers, enqueued on `stream`, not synchronised                                   */
+int hipnlp_hess_nnz(hipnlp_handle* h, int64_t* nnz_h);
+int hipnlp_hess_sparsity(hipnlp_handle* h, int32_t* irow, int32_t* jcol);
+int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor, const double* lambda, double* values);
+int hipnlp_eval_hess_device(hipnlp_handle* h, const double* x_dev, const double* obj_factor_dev, const double* lambda_dev,
+                            double* values_dev, void* stream);
 /* Device-resident variant: all pointers are device pointers on desc.device, same shapes.
  * Work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the handle's own stream)
  * and NOT synchronised.  cost_knot (optional, [batch][N]) receives the per-knot cost partials. */

@@ -369,3 +369,83 @@ def test_profile_runs_and_kernel_count(model, HipNlp):
     assert n == 32 and 0.0 < kern_ms < 1.0 and launch_ms >= kern_ms
     f, grad, g, jac = small.eval(x)
     assert float(outs[0].cpu()[0]) == f[0] and np.array_equal(outs[3].cpu().numpy(), jac[0])
+
+
+# ---- exact Hessian of the Lagrangian (hipnlp_eval_hess) ----------------------------------------------------------------------------
+@pytest.mark.parametrize("maker", [periodic_step_settings, single_step_settings])
+@pytest.mark.parametrize("horizon", [2, 3, 9])
+def test_hessian_matches_oracle(model, HipNlp, maker, horizon):
+    from hess_util import hess_mismatch, triplets_to_dict
+    from oracle_lib import Oracle
+    st = maker(horizon, model)
+    x, p = make_workload(st, model, batch=1, seed=3000 + horizon)
+    o = Oracle(st, model)
+    eng = HipNlp(st, model)
+    eng.set_params(p)
+    lam = np.random.RandomState(horizon).standard_normal(o.m)
+    ir, jc = eng.hess_sparsity()
+    vals = eng.eval_hess(x, 0.8, lam)[0]
+    err, where = hess_mismatch(triplets_to_dict(ir, jc, vals), triplets_to_dict(*o.hess(x[0], p[0], 0.8, lam)))
+    assert err <= TOL, where
+    # the callback quartet is untouched by a Hessian evaluation in between
+    f, grad, g, jac = eng.eval(x)
+    fo, grado, go, jaco = o.eval(x[0], p[0])
+    assert rel(f[0], fo) <= TOL and rel(g[0], go) <= TOL and rel(jac[0], jaco) <= TOL and rel(grad[0], grado) <= TOL
+
+
+def test_hessian_cost_modes_batch_and_shards(model, HipNlp):
+    from hess_util import hess_mismatch, triplets_to_dict
+    from oracle_lib import Oracle
+    st = periodic_step_settings(6, model)
+    st.final_state_expression_type = st.periodicity_expression_type = _abi.EXPR_MINIMIZE
+    st.final_state_expression_weight, st.periodicity_expression_weight = 2.0, 0.5
+    B = 3
+    x, p = make_workload(st, model, batch=B, seed=3100)
+    o = Oracle(st, model)
+    eng = HipNlp(st, model, batch=B)
+    eng.set_params(p)
+    rng = np.random.RandomState(5)
+    lam = rng.standard_normal((B, o.m))
+    sig = np.array([1.0, 0.3, 0.0])
+    ir, jc = eng.hess_sparsity()
+    vals = eng.eval_hess(x, sig, lam)
+    assert np.array_equal(vals, eng.eval_hess(x, sig, lam))   # deterministic
+    for b in range(B):
+        err, where = hess_mismatch(triplets_to_dict(ir, jc, vals[b]), triplets_to_dict(*o.hess(x[b], p[b], sig[b], lam[b])))
+        assert err <= TOL, (b, where)
+    # knot shards: every shard handle evaluates the blocks of its own knots (bitwise the same values)
+    parts_v, parts_r, parts_c = [], [], []
+    for kb, ke in ((0, 2), (2, 5), (5, 6)):
+        sh = HipNlp(st, model, batch=B, knot_begin=kb, knot_end=ke)
+        sh.set_params(p)
+        r, c = sh.hess_sparsity()
+        parts_r.append(r); parts_c.append(c); parts_v.append(sh.eval_hess(x, sig, lam))
+    assert np.array_equal(np.concatenate(parts_r), ir) and np.array_equal(np.concatenate(parts_c), jc)
+    assert np.array_equal(np.concatenate(parts_v, axis=1), vals)
+
+
+def test_hessian_errors_and_device_pointers(model, HipNlp):
+    import torch
+    from hippopt_amd.hipnlp import HipNlpError
+    stairs = HipNlp(stairs_settings(3, model), model)
+    with pytest.raises(HipNlpError) as e:
+        stairs.hess_nnz()
+    assert e.value.code == -6 and "planar" in str(e.value)
+    st = periodic_step_settings(4, model)
+    x, p = make_workload(st, model, batch=2, seed=3200)
+    eng = HipNlp(st, model, batch=2)
+    with pytest.raises(HipNlpError):
+        eng.eval_hess(x, 1.0, np.zeros((2, eng.m)))   # parameters not set
+    eng.set_params(p)
+    lam = np.random.RandomState(2).standard_normal((2, eng.m))
+    host = eng.eval_hess(x, 1.0, lam)
+    xd, ld, sd = torch.tensor(x, device="cuda"), torch.tensor(lam, device="cuda"), torch.ones(2, dtype=torch.float64, device="cuda")
+    out = torch.zeros((2, eng.hess_nnz()), dtype=torch.float64, device="cuda")
+    eng.eval_hess_device(xd.data_ptr(), sd.data_ptr(), ld.data_ptr(), out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), host)
+    xb = x.copy()
+    xb[1, 130:134] = 0.0   # zero quaternion: the normalisation divides by zero
+    with pytest.raises(HipNlpError) as e:
+        eng.eval_hess(xb, 1.0, lam)
+    assert e.value.code == -5

@@ -127,3 +127,51 @@ def test_invalid_models_are_rejected(model):
     bad2.frame_link[0] = 15  # sole on the knee link: 4-joint chain, the kernel wants 6
     with pytest.raises(RuntimeError):
         HostEmu(periodic_step_settings(3, bad2), bad2)
+
+
+# ---- exact Hessian of the Lagrangian (knot_hess_body.h) -------------------------------------------------------------------------
+def hess_case(model, st, seed, sigma=0.8):
+    from hess_util import hess_mismatch, triplets_to_dict
+    x, p = make_workload(st, model, 1, seed)
+    x, p = x[0], p[0]
+    o, he = Oracle(st, model), HostEmu(st, model)
+    lam = np.random.RandomState(seed).standard_normal(o.m)
+    ref = triplets_to_dict(*o.hess(x, p, sigma, lam))
+    ir, jc = he.hess_sparsity()
+    mine = triplets_to_dict(ir, jc, he.hess(x, p, sigma, lam))
+    return hess_mismatch(mine, ref), ir, jc, st
+
+
+@pytest.mark.parametrize("maker", [periodic_step_settings, single_step_settings])
+@pytest.mark.parametrize("horizon", [2, 3, 5])
+def test_hessian_body_matches_oracle(model, maker, horizon):
+    (err, where), ir, jc, st = hess_case(model, maker(horizon, model), 700 + horizon)
+    assert err <= TOL, where
+    # block diagonal by knot, the same block pattern at every knot
+    assert np.all(ir // 189 == jc // 189)
+    nk = ir.size // horizon
+    assert ir.size == nk * horizon
+    for k in range(1, horizon):
+        assert np.array_equal(ir[k * nk:(k + 1) * nk] - 189 * k, ir[:nk]) and np.array_equal(jc[k * nk:(k + 1) * nk] - 189 * k, jc[:nk])
+
+
+def test_hessian_body_cost_modes(model):
+    """horizon-end expressions as costs (first / last coupling), the joint cost as intended, other weights"""
+    st = periodic_step_settings(3, model)
+    st.final_state_expression_type = st.periodicity_expression_type = _abi.EXPR_MINIMIZE
+    st.final_state_expression_weight, st.periodicity_expression_weight = 2.0, 0.5
+    st.contacts_centroid_cost_multiplier = 100.0
+    (err, where), ir, jc, _ = hess_case(model, st, 711)
+    assert err <= TOL, where
+    off = ir // 189 != jc // 189
+    assert off.sum() == 84 and np.all(ir[off] // 189 == 2) and np.all(jc[off] // 189 == 0)
+    st = single_step_settings(3, model)
+    st.joint_reg_as_coded = not st.joint_reg_as_coded
+    (err, where), *_ = hess_case(model, st, 712, sigma=1.0)
+    assert err <= TOL, where
+
+
+def test_hessian_is_not_built_for_the_smooth_terrain(model):
+    he = HostEmu(stairs_settings(3, model), model)
+    with pytest.raises(RuntimeError, match="planar"):
+        he.hess_sparsity()
