@@ -391,7 +391,8 @@ template <int TERRAIN> struct DevEmH {
     __device__ __forceinline__ void H(int slot, int, int, double v) { hess[slot] = v; }
 };
 
-__global__ __launch_bounds__(256) void hipnlp_knot_hess_kernel(HArgs a) {
+// (79 KB of LDS: two workgroups per CU = two waves per SIMD: the register allocation is capped there)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void hipnlp_knot_hess_kernel(HArgs a) {
     constexpr int WG = 256;
     __shared__ KnotScratch s;
     __shared__ SharedTables tabs;

@@ -69,6 +69,8 @@ struct KHessScratch {
     SV6 S[NJ + 3], E[NJ + 3], Gm[NJ + 3], Sxl[NJ + 3], Cv[NJ + 3], Wv[NJ + 3];
     double dc[NJ + 3][3];    // d com / d (s_j | theta_e)
     double mu[3], muP[3], K[3], LG[3], IG[9], ell_l[3];
+    double TS[3][NJ], TSD[3][NJ], WS[3][NJ];   // centroidal momentum: (theta_m, s_j), (theta_m, sdot_j), (omega_m, s_j)
+    double qqB[16], qqg[4], qq_axE[3], qq_m2;   // (q_b, q_b): Hessian B and gradient g of Phi(qhat) = <M, R(qhat)>, chest-error axis
     double H[hk::COUNT];
 };
 
@@ -102,8 +104,10 @@ HD void inertia6(const double* cp, const SV6& x, SV6& r) {
     for (int i = 0; i < 3; ++i) r.l[i] = cp[CM] * x.l[i] - t[i];
 }
 HD bool is_anc(const KinTables& kt, int i, int j) {   // joint i on the path root -> j (inclusive)
+    static_assert(sizeof(kt.anc[0]) == 8, "the ancestor list is read as one 8-byte word");
+    const unsigned long long w = *reinterpret_cast<const unsigned long long*>(kt.anc[j]);
     bool a = false;
-    for (int q = 0; q < 8; ++q) a = a || (int(kt.anc[j][q]) == i);
+    for (int q = 0; q < 8; ++q) a = a || (int((w >> (8 * q)) & 0xffull) == i);
     return a;
 }
 
@@ -440,14 +444,23 @@ template <class Em> HD void t_kh_ssd(KHCtx<Em>& h, int t) {
     cx.em.H(hk::SSD + t, S_ + k, SD_ + l, v);
 }
 
-// --- (s_j, q_l), (s_j, qdot_l), (sdot_j, q_l): lanes (j, l) 92 each -------------------------------------------------------------------------
+// --- centroidal momentum, theta-level mixed entries: lanes (m, j) 69 -------------------------------------------------------------------
+template <class Em> HD void t_kh_theta(KHCtx<Em>& h, int t) {
+    const int m = t / NJ, j = t - NJ * m;
+    h.hx.TS[m][j] = mom_theta_s(h, m, j);
+    h.hx.TSD[m][j] = mom_theta_sd(h, m, j);
+    h.hx.WS[m][j] = mom_omega_s(h, m, j);
+}
+// --- (s_j, q_l), (s_j, qdot_l), (sdot_j, q_l): lanes (j, l) 92 each, behind t_kh_theta on the same wave ---------------------------------
+//     chain to the quaternion:  dtheta = G dq / |q|,  d omega / dq = dwq,  d omega / d qdot = G
 template <class Em> HD void t_kh_sq(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
     const KnotScratch& s = cx.s;
+    HIPNLP_WAVE_SYNC();
     const int j = t >> 2, l = t & 3;
     const double* Y = h.hx.Y[j];
     double v = (s.G[l] * Y[0] + s.G[4 + l] * Y[1] + s.G[8 + l] * Y[2]) * s.inv_qnorm;
-    for (int m = 0; m < 3; ++m) v += s.G[4 * m + l] * s.inv_qnorm * mom_theta_s(h, m, j) + s.dwq[4 * m + l] * mom_omega_s(h, m, j);
+    for (int m = 0; m < 3; ++m) v += s.G[4 * m + l] * s.inv_qnorm * h.hx.TS[m][j] + s.dwq[4 * m + l] * h.hx.WS[m][j];
     cx.em.H(hk::SQ + t, S_ + j, QB_ + l, v);
 }
 template <class Em> HD void t_kh_sqd(KHCtx<Em>& h, int t) {
@@ -455,7 +468,7 @@ template <class Em> HD void t_kh_sqd(KHCtx<Em>& h, int t) {
     const KnotScratch& s = cx.s;
     const int j = t >> 2, l = t & 3;
     double v = 0.0;
-    for (int m = 0; m < 3; ++m) v += s.G[4 * m + l] * mom_omega_s(h, m, j);   // d omega / d qdot = G
+    for (int m = 0; m < 3; ++m) v += s.G[4 * m + l] * h.hx.WS[m][j];
     cx.em.H(hk::SQD + t, S_ + j, QD_ + l, v);
 }
 template <class Em> HD void t_kh_sdq(KHCtx<Em>& h, int t) {
@@ -463,7 +476,7 @@ template <class Em> HD void t_kh_sdq(KHCtx<Em>& h, int t) {
     const KnotScratch& s = cx.s;
     const int j = t >> 2, l = t & 3;
     double v = 0.0;
-    for (int m = 0; m < 3; ++m) v += s.G[4 * m + l] * s.inv_qnorm * mom_theta_sd(h, m, j);
+    for (int m = 0; m < 3; ++m) v += s.G[4 * m + l] * s.inv_qnorm * h.hx.TSD[m][j];
     cx.em.H(hk::SDQ + t, SD_ + j, QB_ + l, v);
 }
 
@@ -506,21 +519,20 @@ template <class Em> HD void t_kh_qqd(KHCtx<Em>& h, int t) {
     cx.em.H(hk::QQD + t, QB_ + r, QD_ + c, v);
 }
 
-// --- (q_b, q_b): lanes over the lower triangle (10) -----------------------------------------------------------------------------------------
-template <class Em> HD void t_kh_qq(KHCtx<Em>& h, int t) {
+// --- (q_b, q_b), shared part: lane 0 forms  M = Mw R_b  and from it the Hessian B and the gradient g of  Phi(qhat) = <M, R(qhat)>
+//     (R(qh) = I + 2 w [v]x + 2 [v]x^2:  Phi = tr M + 2 w v.ax(M) + 2 v^T M v - 2 (v.v) tr M), behind t_kh_mom0 ---------------------
+template <class Em> HD void t_kh_qq0(KHCtx<Em>& h, int) {
     Ctx<Em>& cx = h.cx;
     const KnotScratch& s = cx.s;
-    const KHessScratch& hx = h.hx;
+    KHessScratch& hx = h.hx;
     const double* lam = hx.lam;
-    const double sigma = hx.sigma, on = cx.ki.first ? 0.0 : 1.0;
-    int r = 0;
-    while ((r + 1) * (r + 2) / 2 <= t) ++r;
-    const int c = t - r * (r + 1) / 2;
+    const double on = cx.ki.first ? 0.0 : 1.0;
     double E[9];
     chest_error(s, E);
     const double trE = E[0] + E[4] + E[8], e = trE - 3.0;
-    const double axE[3] = {E[7] - E[5], E[2] - E[6], E[3] - E[1]};
-    const double m2 = 2.0 * sigma * on * cx.st.m_frameq;
+    const double m2 = 2.0 * hx.sigma * on * cx.st.m_frameq;
+    hx.qq_axE[0] = E[7] - E[5]; hx.qq_axE[1] = E[2] - E[6]; hx.qq_axE[2] = E[3] - E[1];
+    hx.qq_m2 = m2;
     // Mw = sum_c w_c pkin_c^T + w_com com^T + sigma 2 m e E^T + mu L_G^T + omega K^T  (world frame);  M = Mw R_b
     double Mw[9], M[9];
     for (int a = 0; a < 3; ++a)
@@ -533,24 +545,40 @@ template <class Em> HD void t_kh_qq(KHCtx<Em>& h, int t) {
     const double trM = M[0] + M[4] + M[8];
     const double al[3] = {M[7] - M[5], M[2] - M[6], M[3] - M[1]};
     const double* qh = s.qn;
-    const double inv_n = s.inv_qnorm;
-    double B[16], g[4];
+    double* B = hx.qqB;
     for (int a = 0; a < 3; ++a) {
         for (int b = 0; b < 3; ++b) B[4 * a + b] = 2.0 * (M[3 * a + b] + M[3 * b + a]) - (a == b ? 4.0 * trM : 0.0);
         B[4 * a + 3] = B[12 + a] = 2.0 * al[a];
     }
     B[15] = 0.0;
-    for (int a = 0; a < 3; ++a) g[a] = 2.0 * qh[3] * al[a] + B[4 * a] * qh[0] + B[4 * a + 1] * qh[1] + B[4 * a + 2] * qh[2];
-    g[3] = 2.0 * (qh[0] * al[0] + qh[1] * al[1] + qh[2] * al[2]);
+    for (int a = 0; a < 3; ++a) hx.qqg[a] = 2.0 * qh[3] * al[a] + B[4 * a] * qh[0] + B[4 * a + 1] * qh[1] + B[4 * a + 2] * qh[2];
+    hx.qqg[3] = 2.0 * (qh[0] * al[0] + qh[1] * al[1] + qh[2] * al[2]);
+}
+
+// --- (q_b, q_b): lanes over the lower triangle (10), behind t_kh_qq0 -----------------------------------------------------------------
+//   Hess_q Phi(q / |q|) = J B J + ( -(g qh^T + qh g^T + (g.qh) I) + 3 (g.qh) qh qh^T ) / |q|^2,   J = (I - qh qh^T) / |q|
+template <class Em> HD void t_kh_qq(KHCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    const KnotScratch& s = cx.s;
+    const KHessScratch& hx = h.hx;
+    const double* lam = hx.lam;
+    const double sigma = hx.sigma, on = cx.ki.first ? 0.0 : 1.0;
+    int r = 0;
+    while ((r + 1) * (r + 2) / 2 <= t) ++r;
+    const int c = t - r * (r + 1) / 2;
+    const double* qh = s.qn;
+    const double inv_n = s.inv_qnorm;
+    const double* B = hx.qqB;
     double Jr[4], Jc[4], BJc[4];
     for (int a = 0; a < 4; ++a) { Jr[a] = ((a == r ? 1.0 : 0.0) - qh[r] * qh[a]) * inv_n; Jc[a] = ((a == c ? 1.0 : 0.0) - qh[c] * qh[a]) * inv_n; }
     for (int a = 0; a < 4; ++a) BJc[a] = B[4 * a] * Jc[0] + B[4 * a + 1] * Jc[1] + B[4 * a + 2] * Jc[2] + B[4 * a + 3] * Jc[3];
     double v = Jr[0] * BJc[0] + Jr[1] * BJc[1] + Jr[2] * BJc[2] + Jr[3] * BJc[3];
-    v += norm2_entry(g, qh, inv_n, r, c);
+    v += norm2_entry(hx.qqg, qh, inv_n, r, c);
     // chest cost, outer product part: d e / d q_l = -(ax(E) . G_l) / |q|
+    const double* axE = hx.qq_axE;
     const double ger = -(axE[0] * s.G[r] + axE[1] * s.G[4 + r] + axE[2] * s.G[8 + r]) * inv_n;
     const double gec = -(axE[0] * s.G[c] + axE[1] * s.G[4 + c] + axE[2] * s.G[8 + c]) * inv_n;
-    v += m2 * ger * gec;
+    v += hx.qq_m2 * ger * gec;
     // centroidal momentum, remaining terms: omega = Wq(qdot) qhat with Wq = 2 [ -qd_w 1 - [qd_v]x | qd_v ]
     {
         const double* qd = s.x + QD_;
@@ -581,14 +609,20 @@ template <class Em> HD void t_kh_qq(KHCtx<Em>& h, int t) {
     cx.em.H(hk::QQ + t, QB_ + r, QB_ + c, v);
 }
 
+// (s_k, sdot_l) in two lane ranges, so that the largest group of the last phase spreads over two waves
+constexpr int KH_SSD_SPLIT = 265;
+template <class Em> HD void t_kh_ssd_a(KHCtx<Em>& h, int t) { t_kh_ssd(h, t); }
+template <class Em> HD void t_kh_ssd_b(KHCtx<Em>& h, int t) { t_kh_ssd(h, t + KH_SSD_SPLIT); }
+
 // The Hessian tasks, run behind HIPNLP_KNOT_PROGRAM (RH(w, fn, n): tasks 0..n-1 of fn on wave w of four)
 #define HIPNLP_KNOT_HESS_PROGRAM(RH, BARRIER)                                                                    \
     RH(0, t_kh_point, NC) RH(0, t_kh_ff, 36) RH(1, t_kh_pp, 180) RH(2, t_kh_diag, 42) RH(2, t_kh_percouple, 84) RH(3, t_kh_mom0, 1) \
     BARRIER                                                                                                      \
-    RH(0, t_kh_joint, NJ + 3) RH(1, t_kh_Y, NJ)                                                                  \
+    RH(0, t_kh_joint, NJ + 3) RH(1, t_kh_Y, NJ) RH(2, t_kh_qq0, 1)                                               \
     BARRIER                                                                                                      \
-    RH(0, t_kh_ss, KH_SS_TASKS) RH(1, t_kh_ssd, NJ * NJ) RH(2, t_kh_sq, 4 * NJ) RH(2, t_kh_sqd, 4 * NJ)         \
-    RH(3, t_kh_sdq, 4 * NJ) RH(3, t_kh_qq, 10) RH(3, t_kh_qqd, 16)                                              \
+    RH(0, t_kh_ss, KH_SS_TASKS) RH(0, t_kh_qq, 10)                                                               \
+    RH(1, t_kh_ssd_a, KH_SSD_SPLIT) RH(2, t_kh_ssd_b, NJ * NJ - KH_SSD_SPLIT)                                    \
+    RH(3, t_kh_theta, 3 * NJ) RH(3, t_kh_sq, 4 * NJ) RH(3, t_kh_sqd, 4 * NJ) RH(3, t_kh_sdq, 4 * NJ) RH(3, t_kh_qqd, 16) \
     BARRIER
 
 }  // namespace hipnlp

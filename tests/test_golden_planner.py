@@ -83,6 +83,31 @@ def test_oracle_matches_reference_planner_assembly(model, name):
     assert got == expect
 
 
+HESS_FIXTURES = ["planner_periodic_N3", "planner_single_N3", "planner_costends_N2", "planner_stairs_N3"]
+
+
+def hessian_times(rows, cols, vals, n, D):
+    from scipy.sparse import coo_matrix
+    L = coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
+    off = rows != cols
+    U = coo_matrix((vals[off], (cols[off], rows[off])), shape=(n, n)).tocsr()
+    return L @ D + U @ D
+
+
+@pytest.mark.parametrize("name", HESS_FIXTURES)
+def test_oracle_hessian_matches_reference_planner_graph(model, name):
+    """Hessian of the Lagrangian: H d for a few directions d, taken from the reference planner's own graph by forward
+    derivatives of the stand-in (tools/gen_planner_fixtures.py), against the oracle's forward-over-forward AD."""
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    if "hess_dirs" not in z.files:
+        pytest.skip("fixture without Hessian-vector products")
+    st = settings_for(json.loads(str(z["meta"])), model)
+    o = Oracle(st, model)
+    rows, cols, vals = o.hess(z["x"], z["p"], float(z["hess_sigma"]), z["hess_lambda"])
+    HD = hessian_times(rows, cols, vals, o.n, z["hess_dirs"])
+    assert rel(HD, z["hess_times_dirs"]) < TOL
+
+
 def test_fixture_cost_names_cover_the_cost_terms():
     z = np.load(os.path.join(GOLD, "planner_periodic_N3.npz"))
     names = [str(s) for s in z["cost_names"]]

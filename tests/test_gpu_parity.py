@@ -182,6 +182,11 @@ def test_gpu_matches_reference_planner_fixtures(model, HipNlp, name):
         else:
             assert abs(got - v) <= TOL * max(1.0, abs(v))
     assert max((abs(v) for v in J.values()), default=0.0) < 1e-12
+    if "hess_dirs" in z.files and st.terrain == _abi.TERRAIN_PLANAR:   # Hessian-vector products of the reference planner's graph
+        from test_golden_planner import hessian_times
+        hr, hc = eng.hess_sparsity()
+        hv = eng.eval_hess(z["x"][None, :], float(z["hess_sigma"]), z["hess_lambda"][None, :])[0]
+        assert rel(hessian_times(hr, hc, hv, eng.n, z["hess_dirs"]), z["hess_times_dirs"]) < TOL
 
 
 def test_planner_solve_plumbing(model):

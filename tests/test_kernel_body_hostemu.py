@@ -175,3 +175,17 @@ def test_hessian_is_not_built_for_the_smooth_terrain(model):
     he = HostEmu(stairs_settings(3, model), model)
     with pytest.raises(RuntimeError, match="planar"):
         he.hess_sparsity()
+
+
+@pytest.mark.parametrize("name", ["planner_periodic_N3", "planner_single_N3", "planner_costends_N2"])
+def test_hessian_body_matches_reference_planner_fixture(model, name):
+    import json
+    import os
+    from test_golden_planner import GOLD, hessian_times, settings_for
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    if "hess_dirs" not in z.files:
+        pytest.skip("fixture without Hessian-vector products")
+    he = HostEmu(settings_for(json.loads(str(z["meta"])), model), model)
+    ir, jc = he.hess_sparsity()
+    vals = he.hess(z["x"], z["p"], float(z["hess_sigma"]), z["hess_lambda"])
+    assert rel(hessian_times(ir, jc, vals, he.n, z["hess_dirs"]), z["hess_times_dirs"]) <= TOL

@@ -157,29 +157,35 @@ def generate(tag, mine, model, seed, tweak=None, with_hessian=True):
     ir, jc = np.nonzero(J)
     order = np.lexsort((ir, jc))
     ir, jc = ir[order], jc[order]
-    # Hessian of the Lagrangian sigma f + lambda^T g (what nlp_hess_l would hand IPOPT's eval_h): symbolic forward
-    # derivative of L along every variable component (cs.jtimes on the reference's own graph), then its numeric tangents with
-    # respect to all variables.  Stored as the numerically nonzero lower triangle.
+    # Hessian of the Lagrangian sigma f + lambda^T g (what nlp_hess_l would hand IPOPT's eval_h), pinned through
+    # Hessian-vector products: for a few random directions d, the symbolic forward derivative of L along d (cs.jtimes on the
+    # reference's own graph, variable by variable), then its numeric gradient with respect to all variables = H d.
+    # (All n rows of H at once, as for the pose finder, exhaust the memory of this container at n = 573.)
     hess_extra = {}
     if with_hessian:
         rng = np.random.RandomState(seed + 1)
         sigma = 0.75
         lam = rng.standard_normal(int(G.shape[0]))
         lag = sigma * f_expr + cs.mtimes(cs.DM(lam.reshape(1, -1)), G)
-        rows_h = []
-        for v in opti.variables:
-            for i in range(v.numel()):
-                e = np.zeros(v.shape)
-                e[i % v.shape[0], i // v.shape[0]] = 1.0
-                rows_h.append(cs.jtimes(lag, v, cs.DM(e)))
-        _, ht = cs.evaluate(rows_h, values, seeds, nx)
-        hess = np.stack([np.zeros(nx) if t is None else t[0, 0, :] for t in ht])
-        assert np.max(np.abs(hess - hess.T)) < 1e-9 * max(1.0, np.max(np.abs(hess)))
-        hr, hc = np.nonzero(np.tril(hess))
-        order = np.lexsort((hr, hc))
-        hr, hc = hr[order], hc[order]
-        hess_extra = dict(hess_sigma=sigma, hess_lambda=lam, hess_row=hr.astype(np.int32), hess_col=hc.astype(np.int32), hess_val=hess[hr, hc])
-        print(tag, "hessian: lower-triangle nonzeros", len(hr))
+        ndir = 4
+        D = rng.standard_normal((nx, ndir))
+        D[:, 0] = 0.0
+        D[rng.randint(0, nx, 12), 0] = 1.0          # one sparse direction: isolates single columns
+        HD = np.zeros((nx, ndir))
+        for d in range(ndir):
+            dl, off = None, 0
+            for v in opti.variables:
+                k = v.numel()
+                e = D[off:off + k, d].reshape(v.shape, order="F")
+                off += k
+                if not np.any(e):
+                    continue
+                t = cs.jtimes(lag, v, cs.DM(e))
+                dl = t if dl is None else dl + t
+            _, ht = cs.evaluate([dl], values, seeds, nx)
+            HD[:, d] = 0.0 if ht[0] is None else ht[0][0, 0, :]
+            print(tag, "hessian direction", d, "done", flush=True)
+        hess_extra = dict(hess_sigma=sigma, hess_lambda=lam, hess_dirs=D, hess_times_dirs=HD)
     out = os.path.join(ROOT, "tests", "golden", "planner_%s_N%d.npz" % (tag, N))
     np.savez_compressed(out, **hess_extra, x=x, p=p, g=gv.reshape(-1), lbg=lbv.reshape(-1), ubg=ubv.reshape(-1), f=float(fv), grad=grad,
                         jac_row=ir.astype(np.int32), jac_col=jc.astype(np.int32), jac_val=J[ir, jc],
