@@ -79,6 +79,34 @@ def cpu_baseline(settings, model, x, p, budget_s=12.0):
     return out
 
 
+def time_hessian(eng, x_np, knots):
+    """ms per evaluation of the exact Hessian of the Lagrangian with device pointers, timed with events on a non-default stream
+    (the library maps a null stream pointer to its own stream, which torch events would not see)"""
+    import torch
+    B = eng.batch
+    hn = eng.hess_nnz()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        xd = torch.tensor(x_np, device="cuda")
+        ld = torch.tensor(np.random.RandomState(0).standard_normal((B, eng.m)), device="cuda")
+        sd = torch.ones(B, dtype=torch.float64, device="cuda")
+        out = torch.zeros((B, hn), dtype=torch.float64, device="cuda")
+        reps = 100 if B <= 64 else 20
+        for _ in range(5):
+            eng.eval_hess_device(xd.data_ptr(), sd.data_ptr(), ld.data_ptr(), out.data_ptr(), stream=stream.cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            eng.eval_hess_device(xd.data_ptr(), sd.data_ptr(), ld.data_ptr(), out.data_ptr(), stream=stream.cuda_stream)
+        e1.record(stream)
+    stream.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    bytes_knot = 8.0 * (189 + 79 + 274 + hn / (knots / B))
+    return {"ms_per_eval": ms, "knots_per_s": knots / (ms * 1e-3), "triplets": int(hn), "algorithmic_bytes_per_knot": bytes_knot,
+            "GBps": bytes_knot * knots / (ms * 1e-3) / 1e9, "kernel": "hipnlp_knot_hess_kernel",
+            "note": "lower-triangle triplets of sigma hess f + lambda^T hess g, block diagonal by knot; device pointers, no PCIe"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +120,7 @@ def main():
     ap.add_argument("--also-knot-sharded", action="store_true", help="measure the knot-sharded all-gather path beside `value` even on one GPU (default: whenever WORLD_SIZE > 1)")
     ap.add_argument("--event-stride", type=int, default=16, help="time every n-th launch of the timed region with HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hessian", action="store_true", help="skip the exact-Hessian figure reported beside the callback quartet")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the sharded path on one GPU (debug)")
     args = ap.parse_args()
 
@@ -283,6 +312,12 @@ def main():
             dt_host = (time.perf_counter() - t1) / reps
             line["pcie_inclusive"] = {"ms_per_call": 1e3 * dt_host, "knots_per_s": horizon * args.batch / dt_host,
                                       "note": "hipnlp_eval with host buffers (pinned staging, one fused D2H copy), all four outputs copied back into caller-owned arrays"}
+        if world == 1 and not knot_sharded and args.workload != "stairs" and not args.no_hessian:
+            # beside the callback quartet (never `value`): the exact Hessian of the Lagrangian of the same NLP (hipnlp_eval_hess_device)
+            try:
+                line["exact_hessian"] = time_hessian(eng, x_np, horizon * args.batch)
+            except Exception as err:  # noqa: BLE001  (reported, never fatal to the bench line)
+                line["exact_hessian"] = {"error": str(err)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(settings, model, x_np[0], p_np[0])
             line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]

@@ -9,6 +9,7 @@
 // contiguous, g scattered into the reference's constraint-type-major order, the cost partials per knot.  The total cost is summed
 // in a fixed order (bitwise reproducible f): inside the knot kernel by the workgroup that publishes its partials last (eight-wave
 // latency variant: one kernel launch per callback set), by a second tiny kernel behind the four-wave throughput variant.
+// hipnlp_knot_hess_kernel evaluates the exact Hessian of the Lagrangian (knot_hess_body.h) behind the same knot program.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
