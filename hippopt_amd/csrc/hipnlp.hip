@@ -378,8 +378,8 @@ struct HArgs {
     const double* sigma;    // [batch]
     const double* lambda;   // [batch][m]
     double* hess;           // [batch][nnz_h]
-    int32_t* flag;          // [batch] set to 1 by a trajectory that produced a non-finite value
-    int32_t N, n, m, knot_begin;
+    int32_t* flag;          // [batch] generation flag: == seq after a launch in which the trajectory produced a non-finite value
+    int32_t N, n, m, knot_begin, seq, pad_;
     int64_t hstride, hoff;  // values of trajectory b start at hess + b * hstride; the handle's first knot block sits at -hoff
 };
 template <int TERRAIN> struct DevEmH {
@@ -436,6 +436,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (tid == 0) { hx.sigma = a.sigma[b]; s.pub_ready = 0; }
     }
     __syncthreads();
+    // copy-out permutation, fetched now so that its latency hides behind the programs
+    const HessTables& ht = *a.ht;
+    constexpr int HP_ITERS = (hk::COUNT + WG - 1) / WG;
+    const int cnt = ht.nnz_knot, ncpl = last ? ht.n_couple : 0;
+    int32_t hp[HP_ITERS];
+#pragma unroll
+    for (int it = 0; it < HP_ITERS; ++it) { const int i = tid + it * WG; hp[it] = i < cnt ? ht.perm[i] : -1; }
+    const int hpc = tid < ncpl ? ht.perm_couple[tid] : -1;
     KnotInfo ki{k, N, first, last};
     DevEmH<HIPNLP_TERRAIN_PLANAR> em{s.g, s.jac, hx.H};
     Ctx<DevEmH<HIPNLP_TERRAIN_PLANAR>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
@@ -448,20 +456,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     HIPNLP_KNOT_HESS_PROGRAM(DEV_RH, DEV_BARRIER)
 #undef DEV_RH
 #undef DEV_BARRIER
-    const HessTables& ht = *a.ht;
-    const int cnt = ht.nnz_knot;
     double* out = a.hess + int64_t(b) * a.hstride + (int64_t(cnt) * k - a.hoff);
     int bad = 0;
-    for (int i = tid; i < cnt; i += WG) {
-        const double v = hx.H[ht.perm[i]];
-        bad |= !isfinite(v);
-        out[i] = v;
-    }
-    if (last) {
-        double* oc = a.hess + int64_t(b) * a.hstride + (int64_t(cnt) * N - a.hoff);
-        for (int i = tid; i < ht.n_couple; i += WG) { const double v = hx.H[ht.perm_couple[i]]; bad |= !isfinite(v); oc[i] = v; }
-    }
-    if (__any(bad) && lane == 0) atomicOr(a.flag + b, 1);
+    double hv[HP_ITERS];
+#pragma unroll
+    for (int it = 0; it < HP_ITERS; ++it) hv[it] = hx.H[hp[it] >= 0 ? hp[it] : 0];   // every LDS read in flight before the first store
+    const double hvc = hx.H[hpc >= 0 ? hpc : 0];
+#pragma unroll
+    for (int it = 0; it < HP_ITERS; ++it) if (hp[it] >= 0) { bad |= !isfinite(hv[it]); out[tid + it * WG] = hv[it]; }
+    if (hpc >= 0) { bad |= !isfinite(hvc); a.hess[int64_t(b) * a.hstride + (int64_t(cnt) * N - a.hoff) + tid] = hvc; }
+    if (__any(bad) && lane == 0) atomicMax(a.flag + b, a.seq);   // nothing to reset between launches
 }
 
 
@@ -553,6 +557,7 @@ struct hipnlp_handle {
     HessTables* d_ht = nullptr;
     double *d_sigma = nullptr, *d_lambda = nullptr, *d_hess = nullptr, *h_hess = nullptr;
     int32_t *d_hflag = nullptr, *h_hflag = nullptr;
+    int32_t hseq = 0;   // Hessian launches so far (generation of d_hflag)
     std::string err;
 };
 
@@ -816,6 +821,7 @@ static int hess_prepare(hipnlp_handle* h) {
             hipError_t e = hipMalloc(&h->d_ht, sizeof(HessTables));
             if (e == hipSuccess) e = hipMemcpy(h->d_ht, t, sizeof(HessTables), hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMalloc(&h->d_hflag, size_t(h->batch) * sizeof(int32_t));
+            if (e == hipSuccess) e = hipMemset(h->d_hflag, 0, size_t(h->batch) * sizeof(int32_t));
             if (e == hipSuccess) e = hipHostMalloc(&h->h_hflag, size_t(h->batch) * sizeof(int32_t));
             delete t;
             if (e != hipSuccess) { h->hess_state = 0; h->err = std::string("Hessian tables: ") + hipGetErrorString(e); return HIPNLP_E_NODEVICE; }
@@ -851,7 +857,7 @@ static int hess_launch(hipnlp_handle* h, const double* x_dev, const double* sigm
     a.sigma = sigma_dev; a.lambda = lambda_dev; a.hess = hess_dev; a.flag = h->d_hflag;
     a.N = h->L.N; a.n = h->L.n; a.m = h->L.m; a.knot_begin = h->kb;
     a.hstride = hess_count(h); a.hoff = h->HL.knot_base(h->kb);
-    HIP_TRY(h, hipMemsetAsync(h->d_hflag, 0, size_t(h->batch) * sizeof(int32_t), s));
+    a.seq = ++h->hseq; a.pad_ = 0;
     hipLaunchKernelGGL(hipnlp_knot_hess_kernel, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(256), 0, s, a);
     HIP_TRY(h, hipGetLastError());
     return HIPNLP_OK;
@@ -889,7 +895,7 @@ int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     std::memcpy(hess, h->h_hess, B * hn * sizeof(double));
     for (size_t b = 0; b < B; ++b)
-        if (h->h_hflag[b]) { h->err = "non-finite value produced by the evaluation"; return HIPNLP_E_NUMERIC; }
+        if (h->h_hflag[b] == h->hseq) { h->err = "non-finite value produced by the evaluation"; return HIPNLP_E_NUMERIC; }
     return HIPNLP_OK;
 }
 
