@@ -43,4 +43,4 @@ for B in [int(b) for b in os.environ.get("HESS_BATCHES", "1,16,64,256").split(",
     bytes_per_knot = 8 * (189 + 79 + 274 + hn / N)   # x, p, lambda in; triplet values out
     print(json.dumps({"workload": "exact Hessian of the Lagrangian, N=%d x batch %d" % (N, B), "ms_per_eval": ms, "knots_per_s": N * B / (ms * 1e-3),
                       "nnz_h": hn, "algorithmic_bytes_per_knot": bytes_per_knot, "GBps": bytes_per_knot * N * B / (ms * 1e-3) / 1e9,
-                      "note": "includes the memset of the non-finite flag and the launch (device pointers, no PCIe)"}), flush=True)
+                      "note": "device pointers, no PCIe; one kernel launch per evaluation"}), flush=True)

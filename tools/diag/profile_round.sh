@@ -15,6 +15,7 @@ for B in 1 64 1024; do
   run write_B$B --pmc WRITE_SIZE --output-format csv -d $OUT/write_B$B -- python3 bench.py --steps 20 --warmup 5 --batch $B --no-cpu-baseline
   run sq_B$B --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/sq_B$B -- python3 bench.py --steps 20 --warmup 5 --batch $B --no-cpu-baseline
 done
+HESS_BATCHES=1,64 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_hess -- python3 tools/diag/hess_bench.py > $OUT/hess_bench.jsonl 2> $OUT/trace_hess.log
 run calib_fetch --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -- tools/diag/_build/calib
 run calib_write --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -- tools/diag/_build/calib
 for B in 1 64 1024; do python3 bench.py --steps $([ $B = 1024 ] && echo 50 || echo 1000) --warmup 50 --batch $B --no-cpu-baseline > $OUT/bench_B$B.json 2>/dev/null; done

@@ -77,6 +77,13 @@ for B in (1, 64, 1024):
         w["bench"] = json.load(open(bj))
         shutil.copy(bj, os.path.join(dst, "%s_bench_N100_B%d.json" % (tag, B)))
     summary["workloads"]["N100_B%d" % B] = w
+for f in newest(os.path.join(src, "trace_hess", "*", "*kernel_stats.csv")):
+    shutil.copy(f, os.path.join(dst, "%s_hess_kernel_stats.csv" % tag))
+hb = os.path.join(src, "hess_bench.jsonl")
+if os.path.exists(hb):
+    lines = [l for l in open(hb) if l.startswith("{")]
+    open(os.path.join(dst, "%s_hess_bench.jsonl" % tag), "w").writelines(lines)
+    summary["exact_hessian"] = [json.loads(l) for l in lines]
 json.dump(summary, open(os.path.join(dst, "%s_summary.json" % tag), "w"), indent=1)
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk not in ("bench", "sq")} for k, v in summary["workloads"].items()}, indent=1))
