@@ -393,7 +393,8 @@ template <int TERRAIN> struct DevEmH {
 };
 
 // (79 KB of LDS: two workgroups per CU = two waves per SIMD: the register allocation is capped there)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void hipnlp_knot_hess_kernel(HArgs a) {
+template <int TERRAIN> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void hipnlp_knot_hess_kernel(HArgs a) {
+    static_assert(sizeof(KnotScratch) + sizeof(SharedTables) + sizeof(KHessScratch) <= 80 * 1024, "two workgroups per CU");
     constexpr int WG = 256;
     __shared__ KnotScratch s;
     __shared__ SharedTables tabs;
@@ -421,13 +422,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int i = tid; i < NPER; i += WG) s.xo[i] = (first || last) ? x[size_t(NXK) * (first ? N - 1 : 0) + periodicity_row_var(i)] : 0.0;
         if (tid < PK_STRIDE) s.pk[tid] = a.pk[(size_t(b) * N + k) * PK_STRIDE + tid];
         if (tid < 8) s.xg[tid] = tid < NXG ? x[size_t(NXK) * N + tid] : 0.0;
-        // multipliers of the rows this knot owns, by native slot; of the next interval's angular momentum rows
+        // multipliers of the next interval's angular momentum rows (those of the knot's own rows: behind the knot program)
         const double* lam = a.lambda + size_t(b) * a.m;
-        const int v = first ? VAR_FIRST : (last ? VAR_LAST : VAR_INTERIOR);
-        for (int slot = tid; slot < gs::COUNT; slot += WG) {
-            const int ga = tb.g_a[v][slot];
-            hx.lam[slot] = ga >= 0 ? lam[ga + tb.g_b[slot] * k] : 0.0;
-        }
         if (tid < 3) {
             const int slot = gs::HDYN + 3 + tid;
             const int ga = k + 1 < N ? tb.g_a[k + 1 == N - 1 ? VAR_LAST : VAR_INTERIOR][slot] : -1;
@@ -444,14 +440,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int it = 0; it < HP_ITERS; ++it) { const int i = tid + it * WG; hp[it] = i < cnt ? ht.perm[i] : -1; }
     const int hpc = tid < ncpl ? ht.perm_couple[tid] : -1;
+    // multipliers of the rows this knot owns, by native slot (the same slot -> row map that scatters g): fetched now into the
+    // (still unused) Hessian value area, moved to the g staging area of the scratch once the knot program is done with it
+    {
+        const double* lam = a.lambda + size_t(b) * a.m;
+        const int v = first ? VAR_FIRST : (last ? VAR_LAST : VAR_INTERIOR);
+        for (int slot = tid; slot < gs::COUNT; slot += WG) {
+            const int ga = tb.g_a[v][slot];
+            hx.H[slot] = ga >= 0 ? lam[ga + tb.g_b[slot] * k] : 0.0;
+        }
+    }
     KnotInfo ki{k, N, first, last};
-    DevEmH<HIPNLP_TERRAIN_PLANAR> em{s.g, s.jac, hx.H};
-    Ctx<DevEmH<HIPNLP_TERRAIN_PLANAR>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
+    DevEmH<TERRAIN> em{s.g, s.jac, hx.H};
+    Ctx<DevEmH<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
 #define DEV_R(w4, w8, fn, nt) if (wave == (w4)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_BARRIER __syncthreads();
     HIPNLP_KNOT_PROGRAM(DEV_R, DEV_BARRIER)
 #undef DEV_R
-    KHCtx<DevEmH<HIPNLP_TERRAIN_PLANAR>> hcx{cx, hx};
+    static_assert(hk::COUNT >= gs::COUNT, "the multipliers are parked in the Hessian value area");
+    for (int slot = tid; slot < gs::COUNT; slot += WG) s.g[slot] = hx.H[slot];
+    __syncthreads();
+    KHCtx<DevEmH<TERRAIN>> hcx{cx, hx, s.g};
 #define DEV_RH(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); }
     HIPNLP_KNOT_HESS_PROGRAM(DEV_RH, DEV_BARRIER)
 #undef DEV_RH
@@ -858,7 +867,10 @@ static int hess_launch(hipnlp_handle* h, const double* x_dev, const double* sigm
     a.N = h->L.N; a.n = h->L.n; a.m = h->L.m; a.knot_begin = h->kb;
     a.hstride = hess_count(h); a.hoff = h->HL.knot_base(h->kb);
     a.seq = ++h->hseq; a.pad_ = 0;
-    hipLaunchKernelGGL(hipnlp_knot_hess_kernel, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(256), 0, s, a);
+    if (h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR)
+        hipLaunchKernelGGL(hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_PLANAR>, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS>, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(256), 0, s, a);
     HIP_TRY(h, hipGetLastError());
     return HIPNLP_OK;
 }

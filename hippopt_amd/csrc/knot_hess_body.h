@@ -1,6 +1,6 @@
 // knot_hess_body.h — exact Hessian of the Lagrangian  sigma f(x) + lambda^T g(x)  of the kinodynamic multiple-shooting NLP
 // (IPOPT's eval_h; SURVEY §8f rank 1: what CasADi's nlp_hess_l computes when a script drops `hessian_approximation =
-// limited-memory`).  PLANAR terrain only (the smooth-terrain rows need fourth-order terrain jets: not built).
+// limited-memory`).  Planar terrain and the smooth-steps terrain (its contact rows: knot_hess_terrain.h).
 //
 // Structure.  Every constraint row and cost term depends on ONE knot, except the trapezoid defects, which are sums of a term
 // in x_{k-1} and a term in x_k (implicit_trapezoid.py:24-39), and the two horizon-end costs.  The Hessian of the Lagrangian is
@@ -29,6 +29,7 @@
 //   Phi = u^T I~(s) w + u^T A~(s) sdot  with  u = R^T mu, w = R^T omega  (tools/diag/proto_momentum_hess.py is the numpy
 //   derivation these tasks were written from).
 #pragma once
+#include "knot_hess_terrain.h"
 #include "pose_hess_body.h"
 
 namespace hipnlp {
@@ -55,13 +56,24 @@ constexpr int SQ = SQD + 4 * NJ;            // [NJ][4] row s_j, column q_l
 constexpr int SSD = SQ + 4 * NJ;            // [NJ][NJ] row s_k, column sdot_l
 constexpr int SS = SSD + NJ * NJ;           // lower triangle (s_j, s_i), i <= j
 constexpr int PERC = SS + NJ * (NJ + 1) / 2;   // [84] periodicity cost: (x_{N-1}, x_0) coupling, written by the last knot
-constexpr int COUNT = PERC + 84;
+// smooth terrain only: dense blocks of one contact point (they replace PL_U, DC_*, FD, HD_FP, VD and the same-point part of PP)
+constexpr int SP = PERC + 84;
+constexpr int SP_PP = 0;      // [6]  lower 3x3 (p, p)
+constexpr int SP_UP = 6;      // [3][3] row u_a, column p_j
+constexpr int SP_FP = 15;     // [3][3] row f_j, column p_i
+constexpr int SP_FF = 24;     // [6]  lower 3x3 (f, f)
+constexpr int SP_PV = 30;     // [3][3] row p_j, column v_i
+constexpr int SP_FV = 39;     // [3][3] row f_j, column v_i
+constexpr int SP_VV = 48;     // [6]  lower 3x3 (v, v)
+constexpr int SP_PFD = 54;    // [3][3] row p_j, column fdot_i
+constexpr int SP_STRIDE = 63;
+constexpr int COMXY = SP + NC * SP_STRIDE;   // (com_y, com_x) of the minimum-com-height row
+constexpr int COUNT = COMXY + 1;
 }  // namespace hk
 
 struct SV6 { double a[3], l[3]; };   // spatial vector [angular; linear]
 
 struct KHessScratch {
-    double lam[gs::COUNT];   // multiplier of the row a native g slot belongs to at this knot (0 for slots without a row)
     double lam_next[3];      // multipliers of the angular momentum-dynamics rows of the NEXT interval (owned by knot k + 1)
     double sigma;
     double Y[NJ][3];
@@ -77,6 +89,8 @@ struct KHessScratch {
 template <class Em> struct KHCtx {
     Ctx<Em>& cx;
     KHessScratch& hx;
+    const double* lam;   // [gs::COUNT] multiplier of the row a native g slot belongs to at this knot (0 for slots without a row):
+                         // gathered into the g staging area of the knot scratch once the knot program is done with it
 };
 
 HD double dot6(const SV6& x, const SV6& y) { return dot3(x.a, y.a) + dot3(x.l, y.l); }
@@ -126,7 +140,16 @@ template <class Em> HD double ends_diag(const KHCtx<Em>& h, int var) {
 // rows of the interval that ends here and of the one that starts here
 template <class Em> HD void hdyn_multiplier(const KHCtx<Em>& h, double* nu) {
     const double half = 0.5 * h.cx.gp.dt;
-    for (int i = 0; i < 3; ++i) nu[i] = -half * (h.hx.lam[gs::HDYN + 3 + i] + h.hx.lam_next[i]);
+    for (int i = 0; i < 3; ++i) nu[i] = -half * (h.lam[gs::HDYN + 3 + i] + h.hx.lam_next[i]);
+}
+
+// own share of the force-ratio regularisation on (f_c, f_c)
+template <class Em> HD double freg_diag(const KHCtx<Em>& h, int c) {
+    const Ctx<Em>& cx = h.cx;
+    const int foot = c >> 2, cl = c & 3;
+    const double* alpha = cx.s.pk + PK_REF + (foot == 0 ? R_ALPHA_L : R_ALPHA_R);
+    const double a2 = alpha[0] * alpha[0] + alpha[1] * alpha[1] + alpha[2] * alpha[2] + alpha[3] * alpha[3];
+    return 2.0 * h.hx.sigma * (cx.ki.first ? 0.0 : 1.0) * cx.st.m_freg * (1.0 - 2.0 * alpha[cl] + a2);
 }
 
 // --- point-local entries: lane c (8) --------------------------------------------------------------------------------------------
@@ -134,38 +157,36 @@ template <class Em> HD void t_kh_point(KHCtx<Em>& h, int c) {
     Ctx<Em>& cx = h.cx;
     KnotScratch& s = cx.s;
     Em& em = cx.em;
-    const double* lam = h.hx.lam;
+    const double* lam = h.lam;
     const double sigma = h.hx.sigma;
     const int gb = gs::PT_STRIDE * c, hb = hk::PT * c, cb = PT_ * c;
     const double* x = s.x + cb;
     const double on = cx.ki.first ? 0.0 : 1.0;
-    // planar complementarity  v_i - tanh(kt p_z) u_i  (E3)
-    const double kt = cx.gp.kt, tau = tanh(kt * x[P_ + 2]), dtau = kt * (1.0 - tau * tau);
-    for (int i = 0; i < 2; ++i) em.H(hb + hk::PL_U + i, cb + U_ + i, cb + P_ + 2, -lam[gb + gs::PLANAR + i] * dtau);
-    // dcc margin  eps - kbs p_z f_z - (v_z f_z + p_z fdot_z)  (E4)
-    const double l_d = lam[gb + gs::DCC];
-    em.H(hb + hk::DC_FP, cb + F_ + 2, cb + P_ + 2, -cx.gp.kbs * l_d);
-    em.H(hb + hk::DC_FV, cb + F_ + 2, cb + V_ + 2, -l_d);
-    em.H(hb + hk::DC_PFD, cb + P_ + 2, cb + FD_ + 2, -l_d);
-    // friction cone + own share of the force-ratio regularisation
-    const int foot = c >> 2, cl = c & 3;
-    const double* alpha = s.pk + PK_REF + (foot == 0 ? R_ALPHA_L : R_ALPHA_R);
-    const double a2 = alpha[0] * alpha[0] + alpha[1] * alpha[1] + alpha[2] * alpha[2] + alpha[3] * alpha[3];
-    const double dff = 2.0 * sigma * on * cx.st.m_freg * (1.0 - 2.0 * alpha[cl] + a2);
-    const double l_f = lam[gb + gs::FRICTION], mu2 = cx.gp.mu * cx.gp.mu;
-    for (int i = 0; i < 3; ++i)
-        em.H(hb + hk::FD + i, cb + F_ + i, cb + F_ + i, dff + (i < 2 ? -2.0 * l_f : 2.0 * mu2 * l_f) + ends_diag(h, cb + F_ + i));
-    // nu . ((p - com) x f)
+    const bool planar = terrain_is_planar(cx);
     double nu[3];
     hdyn_multiplier(h, nu);
-    for (int e = 0; e < 6; ++e) {
-        const int r = cross_row(e), q = cross_col(e);
-        em.H(hb + hk::HD_FP + e, cb + F_ + r, cb + P_ + q, skew_rc(nu, r, q));
-        em.H(hb + hk::CF + e, COM_ + r, cb + F_ + q, -skew_rc(nu, q, r));
+    if (planar) {   // (smooth terrain: t_kh_point_smooth emits the dense blocks that contain these)
+        // planar complementarity  v_i - tanh(kt p_z) u_i  (E3)
+        const double kt = cx.gp.kt, tau = tanh(kt * x[P_ + 2]), dtau = kt * (1.0 - tau * tau);
+        for (int i = 0; i < 2; ++i) em.H(hb + hk::PL_U + i, cb + U_ + i, cb + P_ + 2, -lam[gb + gs::PLANAR + i] * dtau);
+        // dcc margin  eps - kbs p_z f_z - (v_z f_z + p_z fdot_z)  (E4)
+        const double l_d = lam[gb + gs::DCC];
+        em.H(hb + hk::DC_FP, cb + F_ + 2, cb + P_ + 2, -cx.gp.kbs * l_d);
+        em.H(hb + hk::DC_FV, cb + F_ + 2, cb + V_ + 2, -l_d);
+        em.H(hb + hk::DC_PFD, cb + P_ + 2, cb + FD_ + 2, -l_d);
+        // friction cone + own share of the force-ratio regularisation
+        const double dff = freg_diag(h, c);
+        const double l_f = lam[gb + gs::FRICTION], mu2 = cx.gp.mu * cx.gp.mu;
+        for (int i = 0; i < 3; ++i)
+            em.H(hb + hk::FD + i, cb + F_ + i, cb + F_ + i, dff + (i < 2 ? -2.0 * l_f : 2.0 * mu2 * l_f) + ends_diag(h, cb + F_ + i));
+        // nu . ((p - com) x f)
+        for (int e = 0; e < 6; ++e) em.H(hb + hk::HD_FP + e, cb + F_ + cross_row(e), cb + P_ + cross_col(e), skew_rc(nu, cross_row(e), cross_col(e)));
+        // swing height (E10, planar)  (k >= 1)
+        for (int i = 0; i < 3; ++i) em.H(hb + hk::VD + i, cb + V_ + i, cb + V_ + i, (i < 2 ? sigma * on * cx.st.m_swing : 0.0) + ends_diag(h, cb + V_ + i));
     }
-    // swing height (E10, planar), ||u_v||^2, ||f_dot||^2   (k >= 1)
+    for (int e = 0; e < 6; ++e) em.H(hb + hk::CF + e, COM_ + cross_row(e), cb + F_ + cross_col(e), -skew_rc(nu, cross_col(e), cross_row(e)));
+    // ||u_v||^2, ||f_dot||^2   (k >= 1)
     for (int i = 0; i < 3; ++i) {
-        em.H(hb + hk::VD + i, cb + V_ + i, cb + V_ + i, (i < 2 ? sigma * on * cx.st.m_swing : 0.0) + ends_diag(h, cb + V_ + i));
         em.H(hb + hk::FDD + i, cb + FD_ + i, cb + FD_ + i, 2.0 * sigma * on * cx.st.m_fdreg + ends_diag(h, cb + FD_ + i));
         em.H(hb + hk::UD + i, cb + U_ + i, cb + U_ + i, 2.0 * sigma * on * cx.st.m_ureg + ends_diag(h, cb + U_ + i));
     }
@@ -186,20 +207,14 @@ template <class Em> HD void t_kh_ff(KHCtx<Em>& h, int t) {
 // --- (p_c', p_c), c' >= c: lanes (pair, e) 180.  e = 0..2 same coordinate; e = 3: (y of c', x of c); e = 4: (x of c', y of c) ----
 //   contact centroid cost (planner.py:249-264): 2 m w_i / 64 for every pair;  yaw alignment (E9, :773-853) between the
 //   corners of one foot;  on the diagonal: swing height, the tanh complementarity, horizon-end costs
-template <class Em> HD void t_kh_pp(KHCtx<Em>& h, int t) {
-    Ctx<Em>& cx = h.cx;
-    KnotScratch& s = cx.s;
-    const int pair = t / 5, e = t - 5 * pair;
-    int hi = 0;
-    while ((hi + 1) * (hi + 2) / 2 <= pair) ++hi;
-    const int lo = pair - hi * (hi + 1) / 2;
-    const double sigma = h.hx.sigma, on = cx.ki.first ? 0.0 : 1.0;
-    const int a = e < 3 ? e : (e == 3 ? 1 : 0), b = e < 3 ? e : (e == 3 ? 0 : 1);   // coordinate of c' (row), of c (column)
-    if (hi == lo && e == 4) return;   // upper triangle
-    // yaw alignment: gradient coefficients of the forward / sideways errors on the corners
+// contact centroid + yaw alignment share of (p_hi[a], p_lo[b]); structural tells whether a cross-coordinate entry exists at all
+template <class Em> HD double pp_costs(const KHCtx<Em>& h, int hi, int lo, int a, int b, bool& yaw_struct) {
+    const Ctx<Em>& cx = h.cx;
+    const KnotScratch& s = cx.s;
+    const double on = cx.ki.first ? 0.0 : 1.0;
     const int foot = hi >> 2;
     double yaw = 0.0;
-    bool yaw_struct = false;
+    yaw_struct = false;
     if ((lo >> 2) == foot && a < 2 && b < 2) {
         const int br = cx.st.yaw_corner[foot][0], tr = cx.st.yaw_corner[foot][1], tl = cx.st.yaw_corner[foot][2];
         const int ch = hi & 3, cl = lo & 3;
@@ -210,21 +225,106 @@ template <class Em> HD void t_kh_pp(KHCtx<Em>& h, int t) {
         const double d1[2] = {-sc[0], sc[1]}, d2[2] = {-sc[2], sc[3]};
         yaw = on * cx.st.m_yaw * (cfh * cfl * d1[a] * d1[b] + csh * csl * d2[a] * d2[b]);
     }
+    return h.hx.sigma * (yaw + (a == b ? 2.0 * on * cx.st.m_centroid * s.pk[PK_REF + R_CW + a] / 64.0 : 0.0));
+}
+template <class Em> HD void t_kh_pp(KHCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    KnotScratch& s = cx.s;
+    const int pair = t / 5, e = t - 5 * pair;
+    int hi = 0;
+    while ((hi + 1) * (hi + 2) / 2 <= pair) ++hi;
+    const int lo = pair - hi * (hi + 1) / 2;
+    const double sigma = h.hx.sigma, on = cx.ki.first ? 0.0 : 1.0;
+    const int a = e < 3 ? e : (e == 3 ? 1 : 0), b = e < 3 ? e : (e == 3 ? 0 : 1);   // coordinate of c' (row), of c (column)
+    if (hi == lo && (e == 4 || !terrain_is_planar(cx))) return;   // upper triangle; smooth terrain: the point's own (p, p) block is dense
+    bool yaw_struct;
+    double v = pp_costs(h, hi, lo, a, b, yaw_struct);
     if (e >= 3) {
-        if (yaw_struct) cx.em.H(hk::PP + t, PT_ * hi + P_ + a, PT_ * lo + P_ + b, sigma * yaw);
+        if (yaw_struct) cx.em.H(hk::PP + t, PT_ * hi + P_ + a, PT_ * lo + P_ + b, v);
         return;
     }
-    double v = sigma * (yaw + 2.0 * on * cx.st.m_centroid * s.pk[PK_REF + R_CW + e] / 64.0);
     if (hi == lo) {
         v += ends_diag(h, PT_ * hi + P_ + e);
         if (e == 2) {
             const double* x = s.x + PT_ * hi;
             const double kt = cx.gp.kt, tau = tanh(kt * x[P_ + 2]), dtau = kt * (1.0 - tau * tau), ddtau = -2.0 * kt * tau * dtau;
-            const double* lp = h.hx.lam + gs::PT_STRIDE * hi + gs::PLANAR;
+            const double* lp = h.lam + gs::PT_STRIDE * hi + gs::PLANAR;
             v += sigma * on * cx.st.m_swing - (lp[0] * x[U_] + lp[1] * x[U_ + 1]) * ddtau;
         }
     }
     cx.em.H(hk::PP + t, PT_ * hi + P_ + e, PT_ * lo + P_ + e, v);
+}
+
+// --- smooth terrain: the dense blocks of one contact point, lane c (8).  Lagrangian of the point with f, v, f_dot, u_v constant:
+//       L = C_u . u + l_d (-kbs h nf - hdot nf - h (ndot . f) - h (n . fdot)) + l_h h + l_n nf + l_f (mu^2 nf^2 - (x.f)^2 - (y.f)^2)
+//           + sigma m_sw/2 ((h - h_d)^2 + (x.v)^2 + (y.v)^2),      C_u = -sum_i l_pl,i (x_i tau, y_i tau, n_i),  tau = tanh(kt h)
+template <class Em> HD void t_kh_point_smooth(KHCtx<Em>& h, int c) {
+    Ctx<Em>& cx = h.cx;
+    if (terrain_is_planar(cx)) return;
+    KnotScratch& s = cx.s;
+    Em& em = cx.em;
+    const double* lam = h.lam;
+    const int gb = gs::PT_STRIDE * c, hb = hk::SP + hk::SP_STRIDE * c, cb = PT_ * c;
+    const double* x = s.x + cb;
+    const double* f = x + F_;
+    const double* v = x + V_;
+    const double* fd = x + FD_;
+    const double* u = x + U_;
+    const double on = cx.ki.first ? 0.0 : 1.0, msw = h.hx.sigma * on * cx.st.m_swing;
+    const double l_d = lam[gb + gs::DCC], l_h = lam[gb + gs::HEIGHT], l_n = lam[gb + gs::NORMAL], l_f = lam[gb + gs::FRICTION];
+    const double* lp = lam + gb + gs::PLANAR;
+    const double kbs = cx.gp.kbs, kt = cx.gp.kt, mu2 = cx.gp.mu * cx.gp.mu;
+    TerrainFrameT3 tf;
+    terrain_frame_t3(cx.st, x + P_, tf);
+    const double tv = tanh(kt * tf.h.v), t1 = kt * (1.0 - tv * tv), t2 = -2.0 * kt * tv * t1;
+    const T3 tau = t3_chain(tf.h, tv, t1, t2);
+    // coefficients of u
+    T3 Cu[3];
+    Cu[0] = (tf.xv[0] * lp[0] + tf.xv[1] * lp[1] + tf.xv[2] * lp[2]) * tau * -1.0;
+    Cu[1] = (tf.yv[0] * lp[0] + tf.yv[1] * lp[1] + tf.yv[2] * lp[2]) * tau * -1.0;
+    Cu[2] = (tf.n[0] * lp[0] + tf.n[1] * lp[1] + tf.n[2] * lp[2]) * -1.0;
+    const T3 nf = tf.n[0] * f[0] + tf.n[1] * f[1] + tf.n[2] * f[2];
+    const T3 xf = tf.xv[0] * f[0] + tf.xv[1] * f[1] + tf.xv[2] * f[2], yf = tf.yv[0] * f[0] + tf.yv[1] * f[1] + tf.yv[2] * f[2];
+    const T3 xvv = tf.xv[0] * v[0] + tf.xv[1] * v[1] + tf.xv[2] * v[2], yvv = tf.yv[0] * v[0] + tf.yv[1] * v[1] + tf.yv[2] * v[2];
+    const T3 nfd = tf.n[0] * fd[0] + tf.n[1] * fd[1] + tf.n[2] * fd[2];
+    const T3 hdot = tf.gh[0] * v[0] + tf.gh[1] * v[1] + tf.gh[2] * v[2];
+    T3 nd[3];   // ndot_j = sum_i dn_j/dp_i v_i
+    for (int j = 0; j < 3; ++j) nd[j] = tf.dn[j][0] * v[0] + tf.dn[j][1] * v[1];
+    const T3 fnd = nd[0] * f[0] + nd[1] * f[1] + nd[2] * f[2];
+    T3 dh = tf.h;
+    dh.v -= s.pk[PK_REF + R_SWING];
+    const T3 L = Cu[0] * u[0] + Cu[1] * u[1] + Cu[2] * u[2]
+               + (tf.h * nf * kbs + hdot * nf + tf.h * fnd + tf.h * nfd) * (-l_d)
+               + tf.h * l_h + nf * l_n + (nf * nf * mu2 - xf * xf - yf * yf) * l_f
+               + (dh * dh + xvv * xvv + yvv * yvv) * (0.5 * msw);
+    bool ys;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b <= a; ++b)
+            em.H(hb + hk::SP_PP + tri(a, b), cb + P_ + a, cb + P_ + b, L.H[t3h(a, b)] + pp_costs(h, c, c, a, b, ys) + (a == b ? ends_diag(h, cb + P_ + a) : 0.0));
+    double nu[3];
+    hdyn_multiplier(h, nu);
+    const double dff = freg_diag(h, c);
+    for (int j = 0; j < 3; ++j) {
+        for (int i = 0; i < 3; ++i) em.H(hb + hk::SP_UP + 3 * j + i, cb + U_ + j, cb + P_ + i, Cu[j].g[i]);
+        const T3 dLdf = (tf.h * tf.n[j] * kbs + hdot * tf.n[j] + tf.h * nd[j]) * (-l_d) + tf.n[j] * l_n + (nf * tf.n[j] * mu2 - xf * tf.xv[j] - yf * tf.yv[j]) * (2.0 * l_f);
+        for (int i = 0; i < 3; ++i) em.H(hb + hk::SP_FP + 3 * j + i, cb + F_ + j, cb + P_ + i, dLdf.g[i] + skew_rc(nu, j, i));
+        for (int i = 0; i <= j; ++i)
+            em.H(hb + hk::SP_FF + tri(j, i), cb + F_ + j, cb + F_ + i,
+                 2.0 * l_f * (mu2 * tf.n[j].v * tf.n[i].v - tf.xv[j].v * tf.xv[i].v - tf.yv[j].v * tf.yv[i].v) + (i == j ? dff + ends_diag(h, cb + F_ + j) : 0.0));
+        const T3 dLdfd = tf.h * tf.n[j] * (-l_d);
+        for (int i = 0; i < 3; ++i) em.H(hb + hk::SP_PFD + 3 * i + j, cb + P_ + i, cb + FD_ + j, dLdfd.g[i]);
+    }
+    for (int i = 0; i < 3; ++i) {
+        // dL/dv_i = l_d (-gh_i nf - h sum_j dn_j/dp_i f_j) + m_sw ((x.v) x_i + (y.v) y_i)
+        T3 dnf = T3(0.0);
+        if (i < 2) dnf = tf.dn[0][i] * f[0] + tf.dn[1][i] * f[1] + tf.dn[2][i] * f[2];
+        const T3 dLdv = (tf.gh[i] * nf + tf.h * dnf) * (-l_d) + (xvv * tf.xv[i] + yvv * tf.yv[i]) * msw;
+        for (int j = 0; j < 3; ++j) em.H(hb + hk::SP_PV + 3 * j + i, cb + P_ + j, cb + V_ + i, dLdv.g[j]);
+        for (int j = 0; j < 3; ++j)
+            em.H(hb + hk::SP_FV + 3 * j + i, cb + F_ + j, cb + V_ + i, -l_d * (tf.gh[i].v * tf.n[j].v + tf.h.v * (i < 2 ? tf.dn[j][i].v : 0.0)));
+        for (int j = 0; j <= i; ++j)
+            em.H(hb + hk::SP_VV + tri(i, j), cb + V_ + i, cb + V_ + j, msw * (tf.xv[i].v * tf.xv[j].v + tf.yv[i].v * tf.yv[j].v) + (i == j ? ends_diag(h, cb + V_ + i) : 0.0));
+    }
 }
 
 // --- remaining diagonals: lanes 42: v_b 3, p_b 3, com 3, h 6, qdot_b 4, sdot 23 ----------------------------------------------------
@@ -235,7 +335,15 @@ template <class Em> HD void t_kh_diag(KHCtx<Em>& h, int t) {
     double v = 0.0;
     if (t < 3) var = VB_ + t;
     else if (t < 6) var = PB_ + (t - 3);
-    else if (t < 9) var = COM_ + (t - 6);
+    else if (t < 9) {
+        var = COM_ + (t - 6);
+        if (!terrain_is_planar(cx) && t < 8) {   // minimum com height  com_z - Z(com_x, com_y)  (planner.py:353-358)
+            double Z[10];
+            terrain_Z_jet(cx.st, cx.s.x[COM_], cx.s.x[COM_ + 1], 2, Z);
+            v = -h.lam[gs::COMH] * (t == 6 ? Z[3] : Z[5]);
+            if (t == 7) cx.em.H(hk::COMXY, COM_ + 1, COM_, -h.lam[gs::COMH] * Z[4]);
+        }
+    }
     else if (t < 15) { var = H_ + (t - 9); if (t < 12) v = 2.0 * sigma * cx.st.m_comvel * cx.st.w_comvel[t - 9]; }   // com velocity cost (k >= 0)
     else if (t < 19) { var = QD_ + (t - 15); v = 2.0 * sigma * cx.st.m_baseqv; }                                      // base quaternion velocity cost
     else { var = SD_ + (t - 19); v = 2.0 * sigma * on * cx.st.m_jreg * (cx.st.joint_reg_as_coded ? double(NJ) : 1.0); }   // J6
@@ -256,7 +364,7 @@ template <class Em> HD void t_kh_mom0(KHCtx<Em>& h, int) {
     KHessScratch& hx = h.hx;
     const double* c0 = s.comp[0];
     const double M = cx.kt.total_mass;
-    for (int i = 0; i < 3; ++i) hx.mu[i] = -hx.lam[gs::CMMC + i] / cx.gp.mass;
+    for (int i = 0; i < 3; ++i) hx.mu[i] = -h.lam[gs::CMMC + i] / cx.gp.mass;
     double com[3];
     for (int i = 0; i < 3; ++i) com[i] = c0[CH + i] / M;
     cross3(com, hx.mu, hx.ell_l);
@@ -309,7 +417,7 @@ template <class Em> HD void t_kh_joint(KHCtx<Em>& h, int t) {
 template <class Em> HD void t_kh_Y(KHCtx<Em>& h, int j) {
     Ctx<Em>& cx = h.cx;
     KnotScratch& s = cx.s;
-    const double* lam = h.hx.lam;
+    const double* lam = h.lam;
     const double* a = s.aw[j];
     const double* o = s.ow[j + 1];
     const double on = cx.ki.first ? 0.0 : 1.0;
@@ -396,7 +504,7 @@ template <class Em> HD void t_kh_ss(KHCtx<Em>& h, int t) {
     }
     // feet lateral distance  D = y_r . (o_l - o_r)  (K4; base fixed).  For j on the left leg dD/ds_j = y . (a_j x (o_l - o_j)),
     // on the right leg dD/ds_j = (a_j x y) . (o_l - o_j)
-    const double lfd = hx.lam[gs::FEETD];
+    const double lfd = h.lam[gs::FEETD];
     const int Li = cx.kt.leg_pos[0][i], Lj = cx.kt.leg_pos[0][j], Ri = cx.kt.leg_pos[1][i], Rj = cx.kt.leg_pos[1][j];
     if ((Li >= 0 || Ri >= 0) && (Lj >= 0 || Rj >= 0)) {
         const double* yr = s.fr_R[1];
@@ -525,7 +633,7 @@ template <class Em> HD void t_kh_qq0(KHCtx<Em>& h, int) {
     Ctx<Em>& cx = h.cx;
     const KnotScratch& s = cx.s;
     KHessScratch& hx = h.hx;
-    const double* lam = hx.lam;
+    const double* lam = h.lam;
     const double on = cx.ki.first ? 0.0 : 1.0;
     double E[9];
     chest_error(s, E);
@@ -561,7 +669,7 @@ template <class Em> HD void t_kh_qq(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
     const KnotScratch& s = cx.s;
     const KHessScratch& hx = h.hx;
-    const double* lam = hx.lam;
+    const double* lam = h.lam;
     const double sigma = hx.sigma, on = cx.ki.first ? 0.0 : 1.0;
     int r = 0;
     while ((r + 1) * (r + 2) / 2 <= t) ++r;
@@ -616,7 +724,7 @@ template <class Em> HD void t_kh_ssd_b(KHCtx<Em>& h, int t) { t_kh_ssd(h, t + KH
 
 // The Hessian tasks, run behind HIPNLP_KNOT_PROGRAM (RH(w, fn, n): tasks 0..n-1 of fn on wave w of four)
 #define HIPNLP_KNOT_HESS_PROGRAM(RH, BARRIER)                                                                    \
-    RH(0, t_kh_point, NC) RH(0, t_kh_ff, 36) RH(1, t_kh_pp, 180) RH(2, t_kh_diag, 42) RH(2, t_kh_percouple, 84) RH(3, t_kh_mom0, 1) \
+    RH(0, t_kh_point, NC) RH(0, t_kh_ff, 36) RH(1, t_kh_pp, 180) RH(2, t_kh_diag, 42) RH(2, t_kh_percouple, 84) RH(3, t_kh_mom0, 1) RH(3, t_kh_point_smooth, NC) \
     BARRIER                                                                                                      \
     RH(0, t_kh_joint, NJ + 3) RH(1, t_kh_Y, NJ) RH(2, t_kh_qq0, 1)                                               \
     BARRIER                                                                                                      \

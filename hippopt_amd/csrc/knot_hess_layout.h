@@ -26,7 +26,6 @@ struct HessLayout {
 
     bool build(const hipnlp_settings& st, const KinTables& kt) {
         N = st.horizon;
-        if (st.terrain != HIPNLP_TERRAIN_PLANAR) { error = "exact Hessian: only the planar terrain is built"; return false; }
         std::vector<int> grow(gs::COUNT, -1), jrid(js::COUNT, -1), jc(js::COUNT, -1), hrow(hk::COUNT, -1), hcol(hk::COUNT, -1);
         bool dup = false;
         KnotScratch* s = new KnotScratch();
@@ -44,7 +43,7 @@ struct HessLayout {
         HIPNLP_KNOT_PROGRAM(HOST_R, )
 #undef HOST_R
         dup = false;   // (the knot program's own slots were checked by Layout::build)
-        KHCtx<RecordEm> hcx{cx, *hx};
+        KHCtx<RecordEm> hcx{cx, *hx, s->g};
 #define HOST_RH(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(hcx, t_);
         HIPNLP_KNOT_HESS_PROGRAM(HOST_RH, )
 #undef HOST_RH

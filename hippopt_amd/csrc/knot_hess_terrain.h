@@ -1,0 +1,149 @@
+// knot_hess_terrain.h — second derivatives of the contact-point rows on the SMOOTH terrain (TerrainSum of SmoothTerrain.step,
+// robot_planning/utilities/smooth_terrain.py:201-227,266-336; terrain_descriptor.py:45-80; complementarity.py:27-32,71-87;
+// contacts.py:22-66,158-166).  The dcc margin contains  ndot = (dn/dp) v,  so its Hessian with respect to p needs the THIRD
+// derivatives of the normal, i.e. the FOURTH derivatives of the bump sum Z.  Instead of more closed forms, the Hessian tasks
+// carry truncated Taylor polynomials:
+//   J2<K>  a function of (p_x, p_y) up to total degree K, scaled coefficients c_ij = d^(i+j) f / dx^i dy^j / (i! j!)
+//          (product = truncated polynomial product; composition with an analytic g by Horner on its Taylor coefficients);
+//          Z as J2<4>, the terrain frame (n, x, y) and grad h as J2<3>, dn/dp as J2<2> by differentiation;
+//   T3     a function of (p_x, p_y, p_z) to second order (value, gradient, Hessian), in which the Lagrangian of the point is
+//          assembled with f, v, f_dot, u_v as constants: its Hessian is the (p, p) block, the gradients of dL/df, dL/dv, ... are
+//          the mixed blocks.
+#pragma once
+#include "knot_body.h"
+
+namespace hipnlp {
+
+template <int K> struct J2 {
+    static constexpr int NC_ = (K + 1) * (K + 2) / 2;
+    double c[NC_];
+    HD J2() { for (int i = 0; i < NC_; ++i) c[i] = 0.0; }
+    HD explicit J2(double v) { for (int i = 0; i < NC_; ++i) c[i] = 0.0; c[0] = v; }
+    HD static constexpr int idx(int i, int j) { return (i + j) * (i + j + 1) / 2 + j; }   // x^i y^j
+};
+template <int K> HD J2<K> operator+(const J2<K>& a, const J2<K>& b) { J2<K> r; for (int i = 0; i < J2<K>::NC_; ++i) r.c[i] = a.c[i] + b.c[i]; return r; }
+template <int K> HD J2<K> operator-(const J2<K>& a, const J2<K>& b) { J2<K> r; for (int i = 0; i < J2<K>::NC_; ++i) r.c[i] = a.c[i] - b.c[i]; return r; }
+template <int K> HD J2<K> operator-(const J2<K>& a) { J2<K> r; for (int i = 0; i < J2<K>::NC_; ++i) r.c[i] = -a.c[i]; return r; }
+template <int K> HD J2<K> operator*(const J2<K>& a, double s) { J2<K> r; for (int i = 0; i < J2<K>::NC_; ++i) r.c[i] = a.c[i] * s; return r; }
+template <int K> HD J2<K> operator*(const J2<K>& a, const J2<K>& b) {
+    J2<K> r;
+    for (int d1 = 0; d1 <= K; ++d1)
+        for (int j1 = 0; j1 <= d1; ++j1) {
+            const double av = a.c[d1 * (d1 + 1) / 2 + j1];
+            for (int d2 = 0; d1 + d2 <= K; ++d2)
+                for (int j2 = 0; j2 <= d2; ++j2) {
+                    const int d = d1 + d2;
+                    r.c[d * (d + 1) / 2 + j1 + j2] += av * b.c[d2 * (d2 + 1) / 2 + j2];
+                }
+        }
+    return r;
+}
+// g(a) for an analytic g with Taylor coefficients gn[n] = g^(n)(a_0) / n!
+template <int K> HD J2<K> j2_compose(const J2<K>& a, const double* gn) {
+    J2<K> d = a;
+    d.c[0] = 0.0;
+    J2<K> r(gn[K]);
+    for (int n = K - 1; n >= 0; --n) { r = r * d; r.c[0] += gn[n]; }
+    return r;
+}
+template <int K> HD J2<K> j2_ipow(const J2<K>& a, int m) {   // a^m, integer m > K (a_0 may be zero or negative)
+    double gn[K + 1];
+    double binom = 1.0;
+    for (int n = 0; n <= K; ++n) { gn[n] = binom * ipow_d(a.c[0], m - n); binom = binom * double(m - n) / double(n + 1); }
+    return j2_compose(a, gn);
+}
+template <int K> HD J2<K> j2_pow(const J2<K>& a, double alpha) {   // a^alpha, a_0 > 0
+    double gn[K + 1];
+    gn[0] = pow(a.c[0], alpha);
+    for (int n = 1; n <= K; ++n) gn[n] = gn[n - 1] * (alpha - double(n - 1)) / (double(n) * a.c[0]);
+    return j2_compose(a, gn);
+}
+template <int K> HD J2<K - 1> j2_dx(const J2<K>& a) {
+    J2<K - 1> r;
+    for (int i = 0; i + 1 <= K; ++i) for (int j = 0; i + 1 + j <= K; ++j) r.c[J2<K - 1>::idx(i, j)] = double(i + 1) * a.c[J2<K>::idx(i + 1, j)];
+    return r;
+}
+template <int K> HD J2<K - 1> j2_dy(const J2<K>& a) {
+    J2<K - 1> r;
+    for (int j = 0; j + 1 <= K; ++j) for (int i = 0; i + j + 1 <= K; ++i) r.c[J2<K - 1>::idx(i, j)] = double(j + 1) * a.c[J2<K>::idx(i, j + 1)];
+    return r;
+}
+template <int K, int L> HD J2<L> j2_trunc(const J2<K>& a) { J2<L> r; for (int i = 0; i < J2<L>::NC_; ++i) r.c[i] = a.c[i]; return r; }
+
+// Z(p_x, p_y) of the terrain as a fourth-order jet (same guard against underflow as terrain_bump_jet)
+HD J2<4> terrain_Z_j4(const KSettings& st, double px, double py) {
+    J2<4> Z;
+    for (int sidx = 0; sidx < st.n_steps; ++sidx) {
+        const TerrainStepK& t = st.steps[sidx];
+        Z.c[0] += t.oz;
+        const double dx = px - t.ox, dy = py - t.oy;
+        J2<4> a, b;
+        a.c[0] = t.ax * dx + t.ay * dy; a.c[J2<4>::idx(1, 0)] = t.ax; a.c[J2<4>::idx(0, 1)] = t.ay;
+        b.c[0] = t.bx * dx + t.by * dy; b.c[J2<4>::idx(1, 0)] = t.bx; b.c[J2<4>::idx(0, 1)] = t.by;
+        const J2<4> g = j2_ipow(a, t.m) + j2_ipow(b, t.m);
+        const J2<4> w = j2_ipow(g, t.r);
+        if (!(w.c[0] < 700.0)) continue;
+        double gn[5];
+        const double e = t.height * exp(-w.c[0]);
+        gn[0] = e; gn[1] = -e; gn[2] = e / 2.0; gn[3] = -e / 6.0; gn[4] = e / 24.0;   // H exp(-w) in powers of (w - w_0)
+        Z = Z + j2_compose(w, gn);
+    }
+    return Z;
+}
+
+// ---- second order in three variables (p_x, p_y, p_z) -------------------------------------------------------------------------------
+struct T3 {
+    double v, g[3], H[6];   // H: xx, xy, xz, yy, yz, zz
+    HD T3() : v(0.0) { for (int i = 0; i < 3; ++i) g[i] = 0.0; for (int i = 0; i < 6; ++i) H[i] = 0.0; }
+    HD explicit T3(double c) : v(c) { for (int i = 0; i < 3; ++i) g[i] = 0.0; for (int i = 0; i < 6; ++i) H[i] = 0.0; }
+};
+HD constexpr int t3h(int a, int b) { return a <= b ? (a == 0 ? b : (a == 1 ? 2 + b : 5)) : (b == 0 ? a : (b == 1 ? 2 + a : 5)); }
+HD T3 operator+(const T3& a, const T3& b) { T3 r; r.v = a.v + b.v; for (int i = 0; i < 3; ++i) r.g[i] = a.g[i] + b.g[i]; for (int i = 0; i < 6; ++i) r.H[i] = a.H[i] + b.H[i]; return r; }
+HD T3 operator-(const T3& a, const T3& b) { T3 r; r.v = a.v - b.v; for (int i = 0; i < 3; ++i) r.g[i] = a.g[i] - b.g[i]; for (int i = 0; i < 6; ++i) r.H[i] = a.H[i] - b.H[i]; return r; }
+HD T3 operator*(const T3& a, double s) { T3 r; r.v = a.v * s; for (int i = 0; i < 3; ++i) r.g[i] = a.g[i] * s; for (int i = 0; i < 6; ++i) r.H[i] = a.H[i] * s; return r; }
+HD T3 operator*(const T3& a, const T3& b) {
+    T3 r;
+    r.v = a.v * b.v;
+    for (int i = 0; i < 3; ++i) r.g[i] = a.g[i] * b.v + a.v * b.g[i];
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 3; ++j) r.H[t3h(i, j)] = a.H[t3h(i, j)] * b.v + a.g[i] * b.g[j] + a.g[j] * b.g[i] + a.v * b.H[t3h(i, j)];
+    return r;
+}
+HD T3 t3_chain(const T3& a, double f0, double f1, double f2) {   // f(a): f, f', f'' at a.v
+    T3 r;
+    r.v = f0;
+    for (int i = 0; i < 3; ++i) r.g[i] = f1 * a.g[i];
+    for (int i = 0; i < 3; ++i) for (int j = i; j < 3; ++j) r.H[t3h(i, j)] = f1 * a.H[t3h(i, j)] + f2 * a.g[i] * a.g[j];
+    return r;
+}
+template <int K> HD T3 t3_from(const J2<K>& a) {   // a function of (p_x, p_y) only
+    T3 r;
+    r.v = a.c[0]; r.g[0] = a.c[J2<K>::idx(1, 0)]; r.g[1] = a.c[J2<K>::idx(0, 1)];
+    r.H[0] = 2.0 * a.c[J2<K>::idx(2, 0)]; r.H[1] = a.c[J2<K>::idx(1, 1)]; r.H[3] = 2.0 * a.c[J2<K>::idx(0, 2)];
+    return r;
+}
+
+// terrain frame at (p_x, p_y) with everything the point rows differentiate (terrain_descriptor.py:45-80)
+struct TerrainFrameT3 {
+    T3 h, gh[3], n[3], xv[3], yv[3];
+    T3 dn[3][2];   // d n_j / d p_i, i = x, y  (n does not depend on p_z)
+};
+HD void terrain_frame_t3(const KSettings& st, const double* p, TerrainFrameT3& t) {
+    const J2<4> Z = terrain_Z_j4(st, p[0], p[1]);
+    const J2<3> u1 = -j2_dx(Z), u2 = -j2_dy(Z);   // grad h = (u1, u2, 1)
+    const J2<3> inn = j2_pow(J2<3>(1.0) + u1 * u1 + u2 * u2, -0.5);
+    const J2<3> n0 = u1 * inn, n1 = u2 * inn, n2 = inn;
+    const J2<3> q = n1 * n1 + n2 * n2;            // same closed form as terrain_frame (knot_body.h)
+    const J2<3> iq = j2_pow(q, -0.5);
+    t.h = t3_from(-j2_trunc<4, 2>(Z));
+    t.h.v += p[2]; t.h.g[2] = 1.0;
+    t.gh[0] = t3_from(u1); t.gh[1] = t3_from(u2); t.gh[2] = T3(1.0);
+    t.n[0] = t3_from(n0); t.n[1] = t3_from(n1); t.n[2] = t3_from(n2);
+    t.xv[0] = t3_from(q * iq); t.xv[1] = t3_from(-(n1 * n0) * iq); t.xv[2] = t3_from(-(n2 * n0) * iq);
+    t.yv[0] = T3(0.0); t.yv[1] = t3_from(n2 * iq); t.yv[2] = t3_from(-(n1 * iq));
+    t.dn[0][0] = t3_from(j2_dx(n0)); t.dn[0][1] = t3_from(j2_dy(n0));
+    t.dn[1][0] = t3_from(j2_dx(n1)); t.dn[1][1] = t3_from(j2_dy(n1));
+    t.dn[2][0] = t3_from(j2_dx(n2)); t.dn[2][1] = t3_from(j2_dy(n2));
+}
+
+}  // namespace hipnlp

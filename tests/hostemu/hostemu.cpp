@@ -71,7 +71,6 @@ void hostemu_hess(const hostemu_handle* h, const double* x, const double* p, dou
         for (int i = 0; i < NXG; ++i) s->xg[i] = x[NXK * N + i];
         for (int i = 0; i < PK_STRIDE; ++i) s->pk[i] = pk[size_t(k) * PK_STRIDE + i];
         const int v = L.variant_of(k);
-        for (int slot = 0; slot < gs::COUNT; ++slot) { const int a = L.g_a[v][size_t(slot)]; hx->lam[slot] = a >= 0 ? lambda[a + L.g_b[size_t(slot)] * k] : 0.0; }
         for (int i = 0; i < 3; ++i) {
             const int slot = gs::HDYN + 3 + i, vn = L.variant_of(k + 1);
             const int a = k + 1 < N ? L.g_a[vn][size_t(slot)] : -1;
@@ -84,7 +83,9 @@ void hostemu_hess(const hostemu_handle* h, const double* x, const double* p, dou
 #define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
         HIPNLP_KNOT_PROGRAM(HOST_R, )
 #undef HOST_R
-        KHCtx<ValueEm> hcx{cx, *hx};
+        // multipliers by native slot, into the g staging area the knot program is done with
+        for (int slot = 0; slot < gs::COUNT; ++slot) { const int a = L.g_a[v][size_t(slot)]; s->g[slot] = a >= 0 ? lambda[a + L.g_b[size_t(slot)] * k] : 0.0; }
+        KHCtx<ValueEm> hcx{cx, *hx, s->g};
 #define HOST_RH(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(hcx, t_);
         HIPNLP_KNOT_HESS_PROGRAM(HOST_RH, )
 #undef HOST_RH

@@ -171,13 +171,35 @@ def test_hessian_body_cost_modes(model):
     assert err <= TOL, where
 
 
-def test_hessian_is_not_built_for_the_smooth_terrain(model):
-    he = HostEmu(stairs_settings(3, model), model)
-    with pytest.raises(RuntimeError, match="planar"):
-        he.hess_sparsity()
+@pytest.mark.parametrize("oriented", [False, True])
+def test_hessian_body_smooth_terrain(model, oriented):
+    """Stairs configuration: truncated Taylor polynomials of the terrain (fourth-order Z, knot_hess_terrain.h) against the oracle's
+    nested forward AD, points ON the flanks of the bumps and far from them.  The terrain exponents (10, 20) make single entries
+    of the point blocks as large as 1e7-1e8 next to O(1) ones: tolerance 1e-9 entrywise, as for the smooth-terrain Jacobian."""
+    from hess_util import hess_mismatch, triplets_to_dict
+    st = stairs_settings(3, model)
+    if oriented:
+        st.terrain_steps[0]["orientation"] = 0.4
+        st.terrain_steps[1]["orientation"] = -1.1
+        st.terrain_steps[1]["position"] = (0.8, 0.2, 0.03)
+        st.terrain_steps[1]["edge_sharpness"], st.terrain_steps[1]["side_sharpness"] = 3, 4
+    o, he = Oracle(st, model), HostEmu(st, model)
+    ir, jc = he.hess_sparsity()
+    for flank in (True, False):
+        x, p = make_workload(st, model, 1, 303)
+        if flank:
+            place_on_step_flanks(x, st, seed=3)
+        lam = np.random.RandomState(3).standard_normal(o.m)
+        ref = triplets_to_dict(*o.hess(x[0], p[0], 0.8, lam))
+        vals = he.hess(x[0], p[0], 0.8, lam)
+        assert not np.isnan(vals).any()
+        err, where = hess_mismatch(triplets_to_dict(ir, jc, vals), ref)
+        assert err <= 1e-9, where
+        if flank:
+            assert max(abs(v) for v in ref.values()) > 1e5   # the flanks are really exercised
 
 
-@pytest.mark.parametrize("name", ["planner_periodic_N3", "planner_single_N3", "planner_costends_N2"])
+@pytest.mark.parametrize("name", ["planner_periodic_N3", "planner_single_N3", "planner_costends_N2", "planner_stairs_N3"])
 def test_hessian_body_matches_reference_planner_fixture(model, name):
     import json
     import os
@@ -188,4 +210,4 @@ def test_hessian_body_matches_reference_planner_fixture(model, name):
     he = HostEmu(settings_for(json.loads(str(z["meta"])), model), model)
     ir, jc = he.hess_sparsity()
     vals = he.hess(z["x"], z["p"], float(z["hess_sigma"]), z["hess_lambda"])
-    assert rel(hessian_times(ir, jc, vals, he.n, z["hess_dirs"]), z["hess_times_dirs"]) <= TOL
+    assert rel(hessian_times(ir, jc, vals, he.n, z["hess_dirs"]), z["hess_times_dirs"]) <= (1e-9 if "stairs" in name else TOL)

@@ -167,7 +167,7 @@ def generate(tag, mine, model, seed, tweak=None, with_hessian=True):
         sigma = 0.75
         lam = rng.standard_normal(int(G.shape[0]))
         lag = sigma * f_expr + cs.mtimes(cs.DM(lam.reshape(1, -1)), G)
-        ndir = 4
+        ndir = int(os.environ.get("HESS_DIRS", "4"))
         D = rng.standard_normal((nx, ndir))
         D[:, 0] = 0.0
         D[rng.randint(0, nx, 12), 0] = 1.0          # one sparse direction: isolates single columns
