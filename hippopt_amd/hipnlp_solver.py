@@ -309,7 +309,7 @@ class HipNlpSolver:
         if exact:
             try:
                 hr, hc = eng.hess_sparsity()
-            except HipNlpError as err:   # smooth terrain: the exact Hessian is not built -> quasi-Newton, as with `limited-memory`
+            except HipNlpError as err:   # a part the engine reports as not built -> quasi-Newton, as with `limited-memory`
                 if err.code != -6:
                     raise
                 exact = False
@@ -368,7 +368,7 @@ class HipNlpSolver:
         if exact:
             try:
                 hr, hc = eng.hess_sparsity()
-            except HipNlpError as err:   # smooth terrain: the exact Hessian is not built -> limited-memory
+            except HipNlpError as err:   # a part the engine reports as not built -> limited-memory
                 if err.code != -6:
                     raise
                 exact = False

@@ -206,7 +206,8 @@ int hipnlp_eval(hipnlp_handle* h, const double* x, int new_x,
  * opti_solver.py:123-125,479).  Lower triangle (irow >= jcol) as triplets with a fixed pattern: the Hessian is block diagonal
  * by knot (the trapezoid defects are sums of one-knot terms), plus the 84 entries coupling the last knot with the first when
  * the periodicity expression is a cost.  Order: knot blocks in knot order, each sorted by (column, row), then the coupling.
- * Planar terrain only: HIPNLP_E_UNSUPPORTED on the smooth-steps terrain (its rows need fourth-order terrain jets; not built).
+ * Both terrains (1539 triplets per knot on the planar terrain, 1878 on the smooth steps, whose contact rows need the bump sum to
+ * fourth order: truncated Taylor polynomials, knot_hess_terrain.h).
  *   hipnlp_hess_nnz / _sparsity   structure (the `values == NULL` call of eval_h); a shard handle reports its own knots' blocks
  *   hipnlp_eval_hess              host buffers: x [batch][n], obj_factor [batch], lambda [batch][m] -> values [batch][nnz_h]
  *   hipnlp_eval_hess_device       device pointers, enqueued on `stream`, not synchronised                                   */

@@ -10,7 +10,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from hippopt_amd.hipnlp import HipNlp  # noqa: E402
-from hippopt_amd.kinodyn_settings import periodic_step_settings  # noqa: E402
+from hippopt_amd.kinodyn_settings import periodic_step_settings, stairs_settings  # noqa: E402
 from hippopt_amd.robot_model import synthetic_ergocub  # noqa: E402
 from hippopt_amd.synthetic import make_workload  # noqa: E402
 
@@ -19,7 +19,7 @@ model = synthetic_ergocub()
 torch_stream = torch.cuda.Stream()   # (a non-default stream: the library maps a null stream pointer to its own stream)
 torch.cuda.set_stream(torch_stream)
 for B in [int(b) for b in os.environ.get("HESS_BATCHES", "1,16,64,256").split(",")]:
-    st = periodic_step_settings(N, model)
+    st = stairs_settings(N, model) if os.environ.get("HESS_WORKLOAD", "periodic") == "stairs" else periodic_step_settings(N, model)
     x, p = make_workload(st, model, batch=B, seed=5)
     eng = HipNlp(st, model, batch=B)
     eng.set_params(p)
@@ -41,6 +41,6 @@ for B in [int(b) for b in os.environ.get("HESS_BATCHES", "1,16,64,256").split(",
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
     bytes_per_knot = 8 * (189 + 79 + 274 + hn / N)   # x, p, lambda in; triplet values out
-    print(json.dumps({"workload": "exact Hessian of the Lagrangian, N=%d x batch %d" % (N, B), "ms_per_eval": ms, "knots_per_s": N * B / (ms * 1e-3),
+    print(json.dumps({"workload": "exact Hessian of the Lagrangian, %s, N=%d x batch %d" % (os.environ.get("HESS_WORKLOAD", "periodic"), N, B), "ms_per_eval": ms, "knots_per_s": N * B / (ms * 1e-3),
                       "nnz_h": hn, "algorithmic_bytes_per_knot": bytes_per_knot, "GBps": bytes_per_knot * N * B / (ms * 1e-3) / 1e9,
                       "note": "device pointers, no PCIe; one kernel launch per evaluation"}), flush=True)

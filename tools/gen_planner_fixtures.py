@@ -171,6 +171,12 @@ def generate(tag, mine, model, seed, tweak=None, with_hessian=True):
         D = rng.standard_normal((nx, ndir))
         D[:, 0] = 0.0
         D[rng.randint(0, nx, 12), 0] = 1.0          # one sparse direction: isolates single columns
+        if N > 2:                                   # the others: dense in the variables of ONE knot (the graphs of N >= 3 knots
+            for d in range(1, ndir):                # differentiated along every variable at once do not fit this container)
+                keep = np.zeros(nx, bool)
+                kd = (d - 1) % N
+                keep[189 * kd:189 * (kd + 1)] = True
+                D[~keep, d] = 0.0
         HD = np.zeros((nx, ndir))
         for d in range(ndir):
             dl, off = None, 0
