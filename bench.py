@@ -312,7 +312,7 @@ def main():
             dt_host = (time.perf_counter() - t1) / reps
             line["pcie_inclusive"] = {"ms_per_call": 1e3 * dt_host, "knots_per_s": horizon * args.batch / dt_host,
                                       "note": "hipnlp_eval with host buffers (pinned staging, one fused D2H copy), all four outputs copied back into caller-owned arrays"}
-        if world == 1 and not knot_sharded and args.workload != "stairs" and not args.no_hessian:
+        if world == 1 and not knot_sharded and not args.no_hessian:
             # beside the callback quartet (never `value`): the exact Hessian of the Lagrangian of the same NLP (hipnlp_eval_hess_device)
             try:
                 line["exact_hessian"] = time_hessian(eng, x_np, horizon * args.batch)

@@ -476,3 +476,36 @@ def test_hessian_smooth_terrain_matches_oracle(model, HipNlp, oriented):
     for b in range(B):
         err, where = hess_mismatch(triplets_to_dict(ir, jc, vals[b]), triplets_to_dict(*o.hess(x[b], p[b], 0.8, lam[b])))
         assert err <= 1e-9, (b, where)
+
+
+@pytest.mark.parametrize("workload", ["periodic", "stairs"])
+def test_hessian_at_full_size_is_the_derivative_of_the_lagrangian_gradient(model, HipNlp, workload):
+    """BASELINE sizes (N=100 x batch 4; stairs: N=200 x 2), where the oracle is too slow: H d against central differences of the
+    engine's OWN Lagrangian gradient  sigma grad f + J^T lambda  (size-independent property; fp64 differences: 1e-6 relative
+    to the largest entry of H d; looser on the stairs, whose terrain exponents inflate the truncation error)."""
+    from test_golden_planner import hessian_times
+    N, B = (100, 4) if workload == "periodic" else (200, 2)
+    st = periodic_step_settings(N, model) if workload == "periodic" else stairs_settings(N, model)
+    x, p = make_workload(st, model, batch=B, seed=3400)
+    eng = HipNlp(st, model, batch=B)
+    eng.set_params(p)
+    rng = np.random.RandomState(11)
+    lam = rng.standard_normal((B, eng.m))
+    sigma = 0.6
+    ir, jc = eng.sparsity()
+    hr, hc = eng.hess_sparsity()
+    assert hr.size == eng.hess_nnz() and np.all(hr >= hc) and np.all(hr // 189 == hc // 189)   # block diagonal by knot
+
+    def lag_grad(xx):
+        _, grad, _, jac = eng.eval(xx)
+        out = sigma * grad
+        for b in range(B):
+            np.add.at(out[b], jc, jac[b] * lam[b][ir])
+        return out
+    vals = eng.eval_hess(x, sigma, lam)
+    d = rng.standard_normal(x.shape)
+    eps = 1e-6
+    fd = (lag_grad(x + eps * d) - lag_grad(x - eps * d)) / (2 * eps)
+    for b in range(B):
+        Hd = hessian_times(hr, hc, vals[b], eng.n, d[b])
+        assert np.max(np.abs(Hd - fd[b])) <= (1e-6 if workload == "periodic" else 1e-4) * max(1.0, np.max(np.abs(Hd)))
