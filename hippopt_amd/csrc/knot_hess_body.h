@@ -255,6 +255,9 @@ template <class Em> HD void t_kh_pp(KHCtx<Em>& h, int t) {
     cx.em.H(hk::PP + t, PT_ * hi + P_ + e, PT_ * lo + P_ + e, v);
 }
 
+// (Measured: the same work staged over three task groups — one lane per (point, bump) for the jets, per point for the frame parked in
+//  the dead jac area, per (point, block) for the entries — ran no faster alone (48.6 us per 100-knot stairs Hessian either way) and
+//  slower at batch 64 (0.72 vs 0.63 ms): kept as one task per point.)
 // --- smooth terrain: the dense blocks of one contact point, lane c (8).  Lagrangian of the point with f, v, f_dot, u_v constant:
 //       L = C_u . u + l_d (-kbs h nf - hdot nf - h (ndot . f) - h (n . fdot)) + l_h h + l_n nf + l_f (mu^2 nf^2 - (x.f)^2 - (y.f)^2)
 //           + sigma m_sw/2 ((h - h_d)^2 + (x.v)^2 + (y.v)^2),      C_u = -sum_i l_pl,i (x_i tau, y_i tau, n_i),  tau = tanh(kt h)
@@ -723,14 +726,21 @@ template <class Em> HD void t_kh_ssd_a(KHCtx<Em>& h, int t) { t_kh_ssd(h, t); }
 template <class Em> HD void t_kh_ssd_b(KHCtx<Em>& h, int t) { t_kh_ssd(h, t + KH_SSD_SPLIT); }
 
 // The Hessian tasks, run behind HIPNLP_KNOT_PROGRAM (RH(w, fn, n): tasks 0..n-1 of fn on wave w of four)
-#define HIPNLP_KNOT_HESS_PROGRAM(RH, BARRIER)                                                                    \
+#define HIPNLP_KNOT_HESS_PHASE1(RH, BARRIER)                                                                     \
     RH(0, t_kh_point, NC) RH(0, t_kh_ff, 36) RH(1, t_kh_pp, 180) RH(2, t_kh_diag, 42) RH(2, t_kh_percouple, 84) RH(3, t_kh_mom0, 1) RH(3, t_kh_point_smooth, NC) \
-    BARRIER                                                                                                      \
+    BARRIER
+#define HIPNLP_KNOT_HESS_PHASE2(RH, BARRIER)                                                                     \
     RH(0, t_kh_joint, NJ + 3) RH(1, t_kh_Y, NJ) RH(2, t_kh_qq0, 1)                                               \
-    BARRIER                                                                                                      \
+    BARRIER
+#define HIPNLP_KNOT_HESS_PHASE3(RH, BARRIER)                                                                     \
     RH(0, t_kh_ss, KH_SS_TASKS) RH(0, t_kh_qq, 10)                                                               \
     RH(1, t_kh_ssd_a, KH_SSD_SPLIT) RH(2, t_kh_ssd_b, NJ * NJ - KH_SSD_SPLIT)                                    \
     RH(3, t_kh_theta, 3 * NJ) RH(3, t_kh_sq, 4 * NJ) RH(3, t_kh_sqd, 4 * NJ) RH(3, t_kh_sdq, 4 * NJ) RH(3, t_kh_qqd, 16) \
     BARRIER
+#if defined(HIPNLP_HESS_DIAG_PHASES)   // diagnostic builds only (tools/diag): 0 = no Hessian task, 1 = first phase only, 2 = first two
+#define HIPNLP_KNOT_HESS_PROGRAM(RH, BARRIER) HIPNLP_HESS_DIAG_SELECT(RH, BARRIER)
+#else
+#define HIPNLP_KNOT_HESS_PROGRAM(RH, BARRIER) HIPNLP_KNOT_HESS_PHASE1(RH, BARRIER) HIPNLP_KNOT_HESS_PHASE2(RH, BARRIER) HIPNLP_KNOT_HESS_PHASE3(RH, BARRIER)
+#endif
 
 }  // namespace hipnlp
