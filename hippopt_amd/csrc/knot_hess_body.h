@@ -79,7 +79,7 @@ struct KHessScratch {
     double Y[NJ][3];
     // centroidal momentum: per joint j (0..NJ-1) and per base rotation axis e (NJ + e)
     SV6 S[NJ + 3], E[NJ + 3], Gm[NJ + 3], Sxl[NJ + 3], Cv[NJ + 3], Wv[NJ + 3];
-    double dc[NJ + 3][3];    // d com / d (s_j | theta_e)
+    double dcmu[NJ + 3][3];  // (d com / d (s_j | theta_e)) x mu   (the com enters through l = [mu; com x mu] only)
     double mu[3], muP[3], K[3], LG[3], IG[9], ell_l[3];
     double TS[3][NJ], TSD[3][NJ], WS[3][NJ];   // centroidal momentum: (theta_m, s_j), (theta_m, sdot_j), (omega_m, s_j)
     double qqB[16], qqg[4], qq_axE[3], qq_m2;   // (q_b, q_b): Hessian B and gradient g of Phi(qhat) = <M, R(qhat)>, chest-error axis
@@ -123,6 +123,13 @@ HD bool is_anc(const KinTables& kt, int i, int j) {   // joint i on the path roo
     bool a = false;
     for (int q = 0; q < 8; ++q) a = a || (int((w >> (8 * q)) & 0xffull) == i);
     return a;
+}
+// row r of the packed lower triangle that holds entry t:  r (r + 1) / 2 <= t < (r + 1)(r + 2) / 2
+HD int tri_row(int t) {
+    int r = int((sqrt(8.0 * double(t) + 1.0) - 1.0) * 0.5);
+    if ((r + 1) * (r + 2) / 2 <= t) ++r;
+    if (r * (r + 1) / 2 > t) --r;
+    return r;
 }
 
 // diagonal share of the horizon-end costs (final state planner.py:407-425, periodicity :897-930, `minimize` mode) for variable var
@@ -231,8 +238,7 @@ template <class Em> HD void t_kh_pp(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
     KnotScratch& s = cx.s;
     const int pair = t / 5, e = t - 5 * pair;
-    int hi = 0;
-    while ((hi + 1) * (hi + 2) / 2 <= pair) ++hi;
+    const int hi = tri_row(pair);
     const int lo = pair - hi * (hi + 1) / 2;
     const double sigma = h.hx.sigma, on = cx.ki.first ? 0.0 : 1.0;
     const int a = e < 3 ? e : (e == 3 ? 1 : 0), b = e < 3 ? e : (e == 3 ? 0 : 1);   // coordinate of c' (row), of c (column)
@@ -411,7 +417,9 @@ template <class Em> HD void t_kh_joint(KHCtx<Em>& h, int t) {
     SV6 t3;
     crf6(S, t2, t3);
     for (int i = 0; i < 3; ++i) { hx.Cv[t].a[i] = t1.a[i] - t3.a[i]; hx.Cv[t].l[i] = t1.l[i] - t3.l[i]; }
-    for (int i = 0; i < 3; ++i) hx.dc[t][i] = hx.Gm[t].l[i] / cx.kt.total_mass;
+    double dcv[3];
+    for (int i = 0; i < 3; ++i) dcv[i] = hx.Gm[t].l[i] / cx.kt.total_mass;
+    cross3(dcv, hx.mu, hx.dcmu[t]);
 }
 
 // --- Y_j = d/d theta [ dL/ds_j ]  (theta: world-frame rotation of the base) for the part of the Lagrangian that is LINEAR in
@@ -462,25 +470,20 @@ template <class Em> HD void t_kh_Y(KHCtx<Em>& h, int j) {
 template <class Em> HD double mom_theta_s(const KHCtx<Em>& h, int m, int j) {   // (theta_m, s_j) without the d2com term (in Y)
     const KHessScratch& hx = h.hx;
     const int b = NJ + m;
-    double t[3];
     double v = -dot6(hx.Sxl[b], hx.E[j]) + dot6(hx.Wv[b], hx.Cv[j]);
-    cross3(hx.dc[b], hx.mu, t); v += dot3(t, hx.E[j].l);
-    cross3(hx.dc[j], hx.mu, t); v += dot3(t, hx.E[b].l);
+    v += dot3(hx.dcmu[b], hx.E[j].l);
+    v += dot3(hx.dcmu[j], hx.E[b].l);
     return v;
 }
 template <class Em> HD double mom_theta_sd(const KHCtx<Em>& h, int m, int j) {   // (theta_m, sdot_j)
     const KHessScratch& hx = h.hx;
     const int b = NJ + m;
-    double t[3];
-    cross3(hx.dc[b], hx.mu, t);
-    return dot3(t, hx.Gm[j].l) - dot6(hx.Sxl[b], hx.Gm[j]);
+    return dot3(hx.dcmu[b], hx.Gm[j].l) - dot6(hx.Sxl[b], hx.Gm[j]);
 }
 template <class Em> HD double mom_omega_s(const KHCtx<Em>& h, int m, int j) {   // (omega_m, s_j)
     const KHessScratch& hx = h.hx;
     const int b = NJ + m;
-    double t[3];
-    cross3(hx.dc[j], hx.mu, t);
-    return dot3(t, hx.Gm[b].l) - dot6(hx.Cv[j], hx.S[b]);
+    return dot3(hx.dcmu[j], hx.Gm[b].l) - dot6(hx.Cv[j], hx.S[b]);
 }
 
 // --- (s_j, s_i), i <= j: lanes over the lower triangle 276 -------------------------------------------------------------------------------
@@ -489,18 +492,14 @@ template <class Em> HD void t_kh_ss(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
     KnotScratch& s = cx.s;
     const KHessScratch& hx = h.hx;
-    int j = 0;
-    while ((j + 1) * (j + 2) / 2 <= t) ++j;
+    const int j = tri_row(t);
     const int i = t - j * (j + 1) / 2;
     const double on = cx.ki.first ? 0.0 : 1.0;
     const bool ij = is_anc(cx.kt, i, j), ji = !ij && is_anc(cx.kt, j, i);
     const int k = ij ? i : j, d = ij ? j : i;   // k ancestor-or-self of d (when related)
-    double tt[3];
     // centroidal momentum
-    cross3(hx.dc[i], hx.mu, tt);
-    double v = dot3(tt, hx.E[j].l);
-    cross3(hx.dc[j], hx.mu, tt);
-    v += dot3(tt, hx.E[i].l);
+    double v = dot3(hx.dcmu[i], hx.E[j].l);
+    v += dot3(hx.dcmu[j], hx.E[i].l);
     if (ij || ji) {
         v += -dot6(hx.Sxl[k], hx.E[d]) + dot6(hx.Wv[k], hx.Cv[d]);
         v += dot3(s.aw[k], hx.Y[d]);   // points, com, chest
@@ -546,9 +545,7 @@ template <class Em> HD void t_kh_ssd(KHCtx<Em>& h, int t) {
     const KHessScratch& hx = h.hx;
     const int k = t / NJ, l = t - NJ * k;
     const double on = cx.ki.first ? 0.0 : 1.0;
-    double tt[3];
-    cross3(hx.dc[k], hx.mu, tt);
-    double v = dot3(tt, hx.Gm[l].l);
+    double v = dot3(hx.dcmu[k], hx.Gm[l].l);
     if (is_anc(cx.kt, k, l)) v += -dot6(hx.Sxl[k], hx.Gm[l]);
     else if (is_anc(cx.kt, l, k)) v += -dot6(hx.Cv[k], hx.S[l]);
     if (k == l) v += 2.0 * hx.sigma * on * cx.st.m_jreg * cx.st.w_jreg[k];   // J6: d2 (sd + w (s - ref))^2 / ds dsd
@@ -612,10 +609,10 @@ template <class Em> HD void t_kh_qqd(KHCtx<Em>& h, int t) {
     SV6 ell, Il, sx;
     for (int i = 0; i < 3; ++i) { ell.a[i] = hx.mu[i]; ell.l[i] = hx.ell_l[i]; }
     inertia6(s.comp[0], ell, Il);
-    double v = 0.0, tt[3];
+    double v = 0.0;
     for (int m = 0; m < 3; ++m) {
         const double gm = s.G[4 * m + r] * s.inv_qnorm;
-        cross3(hx.dc[NJ + m], hx.mu, tt);
+        const double* tt = hx.dcmu[NJ + m];
         for (int m2 = 0; m2 < 3; ++m2) {
             crm6(hx.S[NJ + m], hx.S[NJ + m2], sx);
             const double tw = dot3(tt, hx.Gm[NJ + m2].l) - dot6(hx.Sxl[NJ + m], hx.Gm[NJ + m2]) - dot6(Il, sx);
