@@ -32,6 +32,14 @@
 #include "knot_hess_terrain.h"
 #include "pose_hess_body.h"
 
+// Loops that are deliberately NOT unrolled: the Hessian tasks are straight-line code executed once per workgroup, so the kernel's
+// time follows its code size (instruction fetch); bodies that only index LDS with the loop variable stay rolled.
+#if defined(__HIPCC__)
+#define HIPNLP_ROLLED _Pragma("clang loop unroll(disable)")
+#else
+#define HIPNLP_ROLLED
+#endif
+
 namespace hipnlp {
 
 constexpr int COL_FIRST = 2 * NXK;   // column ids >= COL_FIRST address variable (id - COL_FIRST) of the FIRST knot (periodicity coupling)
@@ -444,6 +452,7 @@ template <class Em> HD void t_kh_Y(KHCtx<Em>& h, int j) {
     }
     for (int foot = 0; foot < 2; ++foot) {
         if (cx.kt.leg_pos[foot][j] < 0) continue;
+        HIPNLP_ROLLED
         for (int c = 4 * foot; c < 4 * foot + 4; ++c) {
             for (int r = 0; r < 3; ++r) t1[r] = s.pkin[c][r] - o[r];
             cross3(a, t1, t2);
@@ -610,9 +619,11 @@ template <class Em> HD void t_kh_qqd(KHCtx<Em>& h, int t) {
     for (int i = 0; i < 3; ++i) { ell.a[i] = hx.mu[i]; ell.l[i] = hx.ell_l[i]; }
     inertia6(s.comp[0], ell, Il);
     double v = 0.0;
+    HIPNLP_ROLLED
     for (int m = 0; m < 3; ++m) {
         const double gm = s.G[4 * m + r] * s.inv_qnorm;
         const double* tt = hx.dcmu[NJ + m];
+        HIPNLP_ROLLED
         for (int m2 = 0; m2 < 3; ++m2) {
             crm6(hx.S[NJ + m], hx.S[NJ + m2], sx);
             const double tw = dot3(tt, hx.Gm[NJ + m2].l) - dot6(hx.Sxl[NJ + m], hx.Gm[NJ + m2]) - dot6(Il, sx);
