@@ -89,6 +89,7 @@ struct KHessScratch {
     SV6 S[NJ + 3], E[NJ + 3], Gm[NJ + 3], Sxl[NJ + 3], Cv[NJ + 3], Wv[NJ + 3];
     double dcmu[NJ + 3][3];  // (d com / d (s_j | theta_e)) x mu   (the com enters through l = [mu; com x mu] only)
     double mu[3], muP[3], K[3], LG[3], IG[9], ell_l[3];
+    uint32_t rel[NJ + 1];    // bit i set: joint i lies on the path root -> j (inclusive)
     double TS[3][NJ], TSD[3][NJ], WS[3][NJ];   // centroidal momentum: (theta_m, s_j), (theta_m, sdot_j), (omega_m, s_j)
     double qqB[16], qqg[4], qq_axE[3], qq_m2;   // (q_b, q_b): Hessian B and gradient g of Phi(qhat) = <M, R(qhat)>, chest-error axis
     double H[hk::COUNT];
@@ -406,6 +407,9 @@ template <class Em> HD void t_kh_joint(KHCtx<Em>& h, int t) {
     SV6 S, v, hC, ell, t1, t2;
     const int link = t < NJ ? t + 1 : 0;
     if (t < NJ) {
+        uint32_t mask = 0u;
+        for (int q = 0; q < 8; ++q) { const int a = int(cx.kt.anc[t][q]); if (a < NJ) mask |= 1u << unsigned(a); }
+        hx.rel[t] = mask;
         for (int i = 0; i < 3; ++i) S.a[i] = s.aw[t][i];
         cross3(s.ow[t + 1], s.aw[t], S.l);
     } else {
@@ -495,39 +499,62 @@ template <class Em> HD double mom_omega_s(const KHCtx<Em>& h, int m, int j) {   
     return dot3(hx.dcmu[j], hx.Gm[b].l) - dot6(hx.Cv[j], hx.S[b]);
 }
 
-// --- (s_j, s_i), i <= j: lanes over the lower triangle 276 -------------------------------------------------------------------------------
+// --- (s_j, s_i) and (s_k, sdot_l).  Most joint pairs are UNRELATED (neither on the other's path to the root): only the dense terms
+//     through com(s) reach them — a few multiply-adds.  The related pairs (each joint with the <= 8 joints of its own path) carry the
+//     second derivatives proper.  Two task groups each, so that a wave iteration is either all light or all heavy:
+//       t_kh_ss_far   lanes over the lower triangle 276, skips related pairs (+ the feet-distance term of one joint on each leg)
+//       t_kh_ss_near  lanes (j, q) 184: the pair (anc[j][q], j)
+//       t_kh_ssd_far  lanes NJ x NJ, skips related pairs
+//       t_kh_ssd_near lanes (j, q, direction) 368: (k, l) = (anc[j][q], j) and (j, anc[j][q])
+HD bool kh_related(const KHessScratch& hx, int i, int j) { return (((hx.rel[j] >> unsigned(i)) | (hx.rel[i] >> unsigned(j))) & 1u) != 0u; }
 constexpr int KH_SS_TASKS = NJ * (NJ + 1) / 2;
-template <class Em> HD void t_kh_ss(KHCtx<Em>& h, int t) {
+template <class Em> HD void t_kh_ss_far(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
     KnotScratch& s = cx.s;
     const KHessScratch& hx = h.hx;
     const int j = tri_row(t);
     const int i = t - j * (j + 1) / 2;
-    const double on = cx.ki.first ? 0.0 : 1.0;
-    const bool ij = is_anc(cx.kt, i, j), ji = !ij && is_anc(cx.kt, j, i);
-    const int k = ij ? i : j, d = ij ? j : i;   // k ancestor-or-self of d (when related)
-    // centroidal momentum
-    double v = dot3(hx.dcmu[i], hx.E[j].l);
-    v += dot3(hx.dcmu[j], hx.E[i].l);
-    if (ij || ji) {
-        v += -dot6(hx.Sxl[k], hx.E[d]) + dot6(hx.Wv[k], hx.Cv[d]);
-        v += dot3(s.aw[k], hx.Y[d]);   // points, com, chest
-    }
-    // feet lateral distance  D = y_r . (o_l - o_r)  (K4; base fixed).  For j on the left leg dD/ds_j = y . (a_j x (o_l - o_j)),
-    // on the right leg dD/ds_j = (a_j x y) . (o_l - o_j)
-    const double lfd = h.lam[gs::FEETD];
+    if (kh_related(hx, i, j)) return;
+    double v = dot3(hx.dcmu[i], hx.E[j].l) + dot3(hx.dcmu[j], hx.E[i].l);
+    // feet lateral distance  D = y_r . (o_l - o_r)  (K4; base fixed), one joint on each leg:  (a_R x y) . (a_L x (o_l - o_L))
     const int Li = cx.kt.leg_pos[0][i], Lj = cx.kt.leg_pos[0][j], Ri = cx.kt.leg_pos[1][i], Rj = cx.kt.leg_pos[1][j];
-    if ((Li >= 0 || Ri >= 0) && (Lj >= 0 || Rj >= 0)) {
+    if ((Li >= 0 && Rj >= 0) || (Ri >= 0 && Lj >= 0)) {
         const double* yr = s.fr_R[1];
         const double y[3] = {yr[1], yr[4], yr[7]};
         const double* ol = s.fr_o[0];
-        double fd = 0.0, u1[3], u2[3], u3[3];
-        if ((Li >= 0 && Lj >= 0) && (ij || ji)) {          // both on the left leg: y . (a_k x (a_d x (o_l - o_d)))
+        const int jl = Li >= 0 ? i : j, jr = Li >= 0 ? j : i;
+        double u1[3], u2[3], u3[3];
+        cross3(s.aw[jr], y, u1);
+        for (int r = 0; r < 3; ++r) u3[r] = ol[r] - s.ow[jl + 1][r];
+        cross3(s.aw[jl], u3, u2);
+        v += h.lam[gs::FEETD] * dot3(u1, u2);
+    }
+    cx.em.H(hk::SS + t, S_ + j, S_ + i, v);
+}
+constexpr int KH_NEAR_TASKS = NJ * 8;
+template <class Em> HD void t_kh_ss_near(KHCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    KnotScratch& s = cx.s;
+    const KHessScratch& hx = h.hx;
+    const int d = t >> 3, k = int(cx.kt.anc[d][t & 7]);   // k on the path root -> d (inclusive)
+    if (k >= NJ) return;
+    const double on = cx.ki.first ? 0.0 : 1.0;
+    // centroidal momentum; points, com, chest
+    double v = dot3(hx.dcmu[k], hx.E[d].l) + dot3(hx.dcmu[d], hx.E[k].l) - dot6(hx.Sxl[k], hx.E[d]) + dot6(hx.Wv[k], hx.Cv[d]) + dot3(s.aw[k], hx.Y[d]);
+    // feet lateral distance, both joints on one leg.  For j on the left leg dD/ds_j = y . (a_j x (o_l - o_j)), on the right leg
+    // dD/ds_j = (a_j x y) . (o_l - o_j)
+    const int Lk = cx.kt.leg_pos[0][k], Ld = cx.kt.leg_pos[0][d], Rk = cx.kt.leg_pos[1][k], Rd = cx.kt.leg_pos[1][d];
+    if ((Lk >= 0 && Ld >= 0) || (Rk >= 0 && Rd >= 0)) {
+        const double* yr = s.fr_R[1];
+        const double y[3] = {yr[1], yr[4], yr[7]};
+        const double* ol = s.fr_o[0];
+        double fd, u1[3], u2[3], u3[3];
+        if (Lk >= 0) {            // y . (a_k x (a_d x (o_l - o_d)))
             for (int r = 0; r < 3; ++r) u1[r] = ol[r] - s.ow[d + 1][r];
             cross3(s.aw[d], u1, u2);
             cross3(s.aw[k], u2, u3);
             fd = dot3(y, u3);
-        } else if ((Ri >= 0 && Rj >= 0) && (ij || ji)) {   // both on the right leg
+        } else {
             cross3(s.aw[d], y, u1);                         // a_d x y
             cross3(s.aw[k], u1, u2);
             for (int r = 0; r < 3; ++r) u3[r] = ol[r] - s.ow[d + 1][r];
@@ -535,30 +562,33 @@ template <class Em> HD void t_kh_ss(KHCtx<Em>& h, int t) {
             for (int r = 0; r < 3; ++r) u3[r] = s.ow[d + 1][r] - s.ow[k + 1][r];
             cross3(s.aw[k], u3, u2);
             fd -= dot3(u1, u2);
-        } else if ((Li >= 0 && Rj >= 0) || (Ri >= 0 && Lj >= 0)) {   // one on each leg: (a_R x y) . (a_L x (o_l - o_L))
-            const int jl = Li >= 0 ? i : j, jr = Li >= 0 ? j : i;
-            cross3(s.aw[jr], y, u1);
-            for (int r = 0; r < 3; ++r) u3[r] = ol[r] - s.ow[jl + 1][r];
-            cross3(s.aw[jl], u3, u2);
-            fd = dot3(u1, u2);
         }
-        v += lfd * fd;
+        v += h.lam[gs::FEETD] * fd;
     }
-    if (i == j) v += 2.0 * hx.sigma * on * cx.st.m_jreg * cx.st.w_jreg[j] * cx.st.w_jreg[j] + ends_diag(h, S_ + j);
-    cx.em.H(hk::SS + t, S_ + j, S_ + i, v);
+    if (k == d) v += 2.0 * hx.sigma * on * cx.st.m_jreg * cx.st.w_jreg[d] * cx.st.w_jreg[d] + ends_diag(h, S_ + d);
+    const int hi = k > d ? k : d, lo = k > d ? d : k;
+    cx.em.H(hk::SS + hi * (hi + 1) / 2 + lo, S_ + hi, S_ + lo, v);
 }
-
-// --- (s_k, sdot_l): lanes NJ x NJ ---------------------------------------------------------------------------------------------------------
-template <class Em> HD void t_kh_ssd(KHCtx<Em>& h, int t) {
+template <class Em> HD void t_kh_ssd_far(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
     const KHessScratch& hx = h.hx;
     const int k = t / NJ, l = t - NJ * k;
+    if (kh_related(hx, k, l)) return;
+    cx.em.H(hk::SSD + t, S_ + k, SD_ + l, dot3(hx.dcmu[k], hx.Gm[l].l));
+}
+template <class Em> HD void t_kh_ssd_near(KHCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    const KHessScratch& hx = h.hx;
+    const int dir = t >= KH_NEAR_TASKS ? 1 : 0, tt = t - dir * KH_NEAR_TASKS;
+    const int d = tt >> 3, a = int(cx.kt.anc[d][tt & 7]);   // a on the path root -> d (inclusive)
+    if (a >= NJ || (dir == 1 && a == d)) return;
+    const int k = dir == 0 ? a : d, l = dir == 0 ? d : a;   // row s_k, column sdot_l
     const double on = cx.ki.first ? 0.0 : 1.0;
     double v = dot3(hx.dcmu[k], hx.Gm[l].l);
-    if (is_anc(cx.kt, k, l)) v += -dot6(hx.Sxl[k], hx.Gm[l]);
-    else if (is_anc(cx.kt, l, k)) v += -dot6(hx.Cv[k], hx.S[l]);
+    if (dir == 0) v += -dot6(hx.Sxl[k], hx.Gm[l]);   // k ancestor-or-self of l
+    else v += -dot6(hx.Cv[k], hx.S[l]);              // l strict ancestor of k
     if (k == l) v += 2.0 * hx.sigma * on * cx.st.m_jreg * cx.st.w_jreg[k];   // J6: d2 (sd + w (s - ref))^2 / ds dsd
-    cx.em.H(hk::SSD + t, S_ + k, SD_ + l, v);
+    cx.em.H(hk::SSD + k * NJ + l, S_ + k, SD_ + l, v);
 }
 
 // --- centroidal momentum, theta-level mixed entries: lanes (m, j) 69 -------------------------------------------------------------------
@@ -728,10 +758,10 @@ template <class Em> HD void t_kh_qq(KHCtx<Em>& h, int t) {
     cx.em.H(hk::QQ + t, QB_ + r, QB_ + c, v);
 }
 
-// (s_k, sdot_l) in two lane ranges, so that the largest group of the last phase spreads over two waves
-constexpr int KH_SSD_SPLIT = 265;
-template <class Em> HD void t_kh_ssd_a(KHCtx<Em>& h, int t) { t_kh_ssd(h, t); }
-template <class Em> HD void t_kh_ssd_b(KHCtx<Em>& h, int t) { t_kh_ssd(h, t + KH_SSD_SPLIT); }
+// the light (s, sdot) group in two lane ranges
+constexpr int KH_SSD_SPLIT = 5 * 64;
+template <class Em> HD void t_kh_ssd_far_a(KHCtx<Em>& h, int t) { t_kh_ssd_far(h, t); }
+template <class Em> HD void t_kh_ssd_far_b(KHCtx<Em>& h, int t) { t_kh_ssd_far(h, t + KH_SSD_SPLIT); }
 
 // The Hessian tasks, run behind HIPNLP_KNOT_PROGRAM (RH(w, fn, n): tasks 0..n-1 of fn on wave w of four)
 #define HIPNLP_KNOT_HESS_PHASE1(RH, BARRIER)                                                                     \
@@ -741,9 +771,11 @@ template <class Em> HD void t_kh_ssd_b(KHCtx<Em>& h, int t) { t_kh_ssd(h, t + KH
     RH(0, t_kh_joint, NJ + 3) RH(1, t_kh_Y, NJ) RH(2, t_kh_qq0, 1)                                               \
     BARRIER
 #define HIPNLP_KNOT_HESS_PHASE3(RH, BARRIER)                                                                     \
-    RH(0, t_kh_ss, KH_SS_TASKS) RH(0, t_kh_qq, 10)                                                               \
-    RH(1, t_kh_ssd_a, KH_SSD_SPLIT) RH(2, t_kh_ssd_b, NJ * NJ - KH_SSD_SPLIT)                                    \
+    RH(0, t_kh_ss_near, KH_NEAR_TASKS) RH(0, t_kh_qq, 10)                                                        \
+    RH(1, t_kh_ssd_near, 2 * KH_NEAR_TASKS)                                                                      \
+    RH(2, t_kh_ss_far, KH_SS_TASKS) RH(2, t_kh_ssd_far_a, KH_SSD_SPLIT)                                          \
     RH(3, t_kh_theta, 3 * NJ) RH(3, t_kh_sq, 4 * NJ) RH(3, t_kh_sqd, 4 * NJ) RH(3, t_kh_sdq, 4 * NJ) RH(3, t_kh_qqd, 16) \
+    RH(3, t_kh_ssd_far_b, NJ * NJ - KH_SSD_SPLIT)                                                                \
     BARRIER
 #if defined(HIPNLP_HESS_DIAG_PHASES)   // diagnostic builds only (tools/diag): 0 = no Hessian task, 1 = first phase only, 2 = first two
 #define HIPNLP_KNOT_HESS_PROGRAM(RH, BARRIER) HIPNLP_HESS_DIAG_SELECT(RH, BARRIER)
