@@ -360,9 +360,10 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 }
 
 // =====================================================================================================================
-// Exact Hessian of the Lagrangian (knot_hess_body.h): one workgroup of four waves per knot runs the knot program (its g / jac
-// outputs stay in LDS, unused) and, behind it, the Hessian tasks; the knot's block of the triplet values leaves as one contiguous
-// run.  Multipliers arrive in the reference's row order and are gathered through the same slot -> row map that scatters g.
+// Exact Hessian of the Lagrangian (knot_hess_body.h): one workgroup of four waves per knot runs the KINEMATIC part of the knot program
+// (none of its rows or Jacobian columns) with the Hessian tasks that need no kinematics on its idle waves, then the kinematic
+// Hessian tasks; the knot's block of the triplet values leaves as one contiguous run.  Multipliers arrive in the reference's row
+// order and are gathered through the same slot -> row map that scatters g.
 // =====================================================================================================================
 struct HessTables {
     int32_t perm[hk::COUNT];      // position in the knot block -> native slot
@@ -422,8 +423,14 @@ template <int TERRAIN> __global__ __launch_bounds__(256) __attribute__((amdgpu_w
         for (int i = tid; i < NPER; i += WG) s.xo[i] = (first || last) ? x[size_t(NXK) * (first ? N - 1 : 0) + periodicity_row_var(i)] : 0.0;
         if (tid < PK_STRIDE) s.pk[tid] = a.pk[(size_t(b) * N + k) * PK_STRIDE + tid];
         if (tid < 8) s.xg[tid] = tid < NXG ? x[size_t(NXK) * N + tid] : 0.0;
-        // multipliers of the next interval's angular momentum rows (those of the knot's own rows: behind the knot program)
+        // multipliers of the rows this knot owns, by native slot (the same slot -> row map that scatters g), in the g staging area of
+        // the scratch (the Hessian program emits no g); of the next interval's angular momentum rows
         const double* lam = a.lambda + size_t(b) * a.m;
+        const int v = first ? VAR_FIRST : (last ? VAR_LAST : VAR_INTERIOR);
+        for (int slot = tid; slot < gs::COUNT; slot += WG) {
+            const int ga = tb.g_a[v][slot];
+            s.g[slot] = ga >= 0 ? lam[ga + tb.g_b[slot] * k] : 0.0;
+        }
         if (tid < 3) {
             const int slot = gs::HDYN + 3 + tid;
             const int ga = k + 1 < N ? tb.g_a[k + 1 == N - 1 ? VAR_LAST : VAR_INTERIOR][slot] : -1;
@@ -440,29 +447,15 @@ template <int TERRAIN> __global__ __launch_bounds__(256) __attribute__((amdgpu_w
 #pragma unroll
     for (int it = 0; it < HP_ITERS; ++it) { const int i = tid + it * WG; hp[it] = i < cnt ? ht.perm[i] : -1; }
     const int hpc = tid < ncpl ? ht.perm_couple[tid] : -1;
-    // multipliers of the rows this knot owns, by native slot (the same slot -> row map that scatters g): fetched now into the
-    // (still unused) Hessian value area, moved to the g staging area of the scratch once the knot program is done with it
-    {
-        const double* lam = a.lambda + size_t(b) * a.m;
-        const int v = first ? VAR_FIRST : (last ? VAR_LAST : VAR_INTERIOR);
-        for (int slot = tid; slot < gs::COUNT; slot += WG) {
-            const int ga = tb.g_a[v][slot];
-            hx.H[slot] = ga >= 0 ? lam[ga + tb.g_b[slot] * k] : 0.0;
-        }
-    }
     KnotInfo ki{k, N, first, last};
     DevEmH<TERRAIN> em{s.g, s.jac, hx.H};
     Ctx<DevEmH<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
-#define DEV_R(w4, w8, fn, nt) if (wave == (w4)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
-#define DEV_BARRIER __syncthreads();
-    HIPNLP_KNOT_PROGRAM(DEV_R, DEV_BARRIER)
-#undef DEV_R
-    static_assert(hk::COUNT >= gs::COUNT, "the multipliers are parked in the Hessian value area");
-    for (int slot = tid; slot < gs::COUNT; slot += WG) s.g[slot] = hx.H[slot];
-    __syncthreads();
     KHCtx<DevEmH<TERRAIN>> hcx{cx, hx, s.g};
+#define DEV_KIN(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_RH(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); }
-    HIPNLP_KNOT_HESS_PROGRAM(DEV_RH, DEV_BARRIER)
+#define DEV_BARRIER __syncthreads();
+    HIPNLP_KNOT_HESS_PROGRAM(DEV_KIN, DEV_RH, DEV_BARRIER)
+#undef DEV_KIN
 #undef DEV_RH
 #undef DEV_BARRIER
     double* out = a.hess + int64_t(b) * a.hstride + (int64_t(cnt) * k - a.hoff);

@@ -88,7 +88,7 @@ struct KHessScratch {
     // centroidal momentum: per joint j (0..NJ-1) and per base rotation axis e (NJ + e)
     SV6 S[NJ + 3], E[NJ + 3], Gm[NJ + 3], Sxl[NJ + 3], Cv[NJ + 3], Wv[NJ + 3];
     double dcmu[NJ + 3][3];  // (d com / d (s_j | theta_e)) x mu   (the com enters through l = [mu; com x mu] only)
-    double mu[3], muP[3], K[3], LG[3], IG[9], ell_l[3];
+    double mu[3], muP[3], K[3], LG[3], IG[9], ell_l[3], com[3];
     uint32_t rel[NJ + 1];    // bit i set: joint i lies on the path root -> j (inclusive)
     double TS[3][NJ], TSD[3][NJ], WS[3][NJ];   // centroidal momentum: (theta_m, s_j), (theta_m, sdot_j), (omega_m, s_j)
     double qqB[16], qqg[4], qq_axE[3], qq_m2;   // (q_b, q_b): Hessian B and gradient g of Phi(qhat) = <M, R(qhat)>, chest-error axis
@@ -384,7 +384,7 @@ template <class Em> HD void t_kh_mom0(KHCtx<Em>& h, int) {
     const double M = cx.kt.total_mass;
     for (int i = 0; i < 3; ++i) hx.mu[i] = -h.lam[gs::CMMC + i] / cx.gp.mass;
     double com[3];
-    for (int i = 0; i < 3; ++i) com[i] = c0[CH + i] / M;
+    for (int i = 0; i < 3; ++i) { com[i] = c0[CH + i] / M; hx.com[i] = com[i]; }
     cross3(com, hx.mu, hx.ell_l);
     cross3(hx.mu, c0 + CKL, hx.muP);
     // L_G = L_O - com x P ;  I_G = I_O - M (|c|^2 1 - c c^T) ;  K = I_G mu
@@ -416,7 +416,11 @@ template <class Em> HD void t_kh_joint(KHCtx<Em>& h, int t) {
         for (int i = 0; i < 3; ++i) { S.a[i] = (i == t - NJ) ? 1.0 : 0.0; S.l[i] = 0.0; }
     }
     const double* cp = s.comp[link];
-    for (int i = 0; i < 3; ++i) { v.a[i] = s.wv[link][i]; v.l[i] = s.vo[link][i]; hC.a[i] = cp[CKA + i]; hC.l[i] = cp[CKL + i]; ell.a[i] = hx.mu[i]; ell.l[i] = hx.ell_l[i]; }
+    // l = [mu; com x mu], formed by every lane itself (t_kh_mom0 runs beside this task, not before it)
+    double mu[3], comv[3];
+    for (int i = 0; i < 3; ++i) { mu[i] = -h.lam[gs::CMMC + i] / cx.gp.mass; comv[i] = s.comp[0][CH + i] / cx.kt.total_mass; }
+    cross3(comv, mu, ell.l);
+    for (int i = 0; i < 3; ++i) { v.a[i] = s.wv[link][i]; v.l[i] = s.vo[link][i]; hC.a[i] = cp[CKA + i]; hC.l[i] = cp[CKL + i]; ell.a[i] = mu[i]; }
     hx.S[t] = S;
     crm6(S, v, hx.Wv[t]);                 // w = S x v
     crf6(S, hC, t1);
@@ -431,7 +435,7 @@ template <class Em> HD void t_kh_joint(KHCtx<Em>& h, int t) {
     for (int i = 0; i < 3; ++i) { hx.Cv[t].a[i] = t1.a[i] - t3.a[i]; hx.Cv[t].l[i] = t1.l[i] - t3.l[i]; }
     double dcv[3];
     for (int i = 0; i < 3; ++i) dcv[i] = hx.Gm[t].l[i] / cx.kt.total_mass;
-    cross3(dcv, hx.mu, hx.dcmu[t]);
+    cross3(dcv, mu, hx.dcmu[t]);
 }
 
 // --- Y_j = d/d theta [ dL/ds_j ]  (theta: world-frame rotation of the base) for the part of the Lagrangian that is LINEAR in
@@ -450,7 +454,10 @@ template <class Em> HD void t_kh_Y(KHCtx<Em>& h, int j) {
         const double inv_M = 1.0 / cx.kt.total_mass;
         for (int r = 0; r < 3; ++r) t1[r] = (cp[CH + r] - cp[CM] * o[r]) * inv_M;
         cross3(a, t1, t2);
-        const double w[3] = {-lam[gs::COMC] + h.hx.muP[0], -lam[gs::COMC + 1] + h.hx.muP[1], -lam[gs::COMC + 2] + h.hx.muP[2]};
+        double mu[3], muP[3];   // mu x P, formed here (t_kh_mom0 runs beside this task)
+        for (int r = 0; r < 3; ++r) mu[r] = -lam[gs::CMMC + r] / cx.gp.mass;
+        cross3(mu, s.comp[0] + CKL, muP);
+        const double w[3] = {-lam[gs::COMC] + muP[0], -lam[gs::COMC + 1] + muP[1], -lam[gs::COMC + 2] + muP[2]};
         cross3(t2, w, t1);
         for (int r = 0; r < 3; ++r) Y[r] += t1[r];
     }
@@ -671,6 +678,7 @@ template <class Em> HD void t_kh_qqd(KHCtx<Em>& h, int t) {
 // --- (q_b, q_b), shared part: lane 0 forms  M = Mw R_b  and from it the Hessian B and the gradient g of  Phi(qhat) = <M, R(qhat)>
 //     (R(qh) = I + 2 w [v]x + 2 [v]x^2:  Phi = tr M + 2 w v.ax(M) + 2 v^T M v - 2 (v.v) tr M), behind t_kh_mom0 ---------------------
 template <class Em> HD void t_kh_qq0(KHCtx<Em>& h, int) {
+    HIPNLP_WAVE_SYNC();   // behind t_kh_mom0 on its wave
     Ctx<Em>& cx = h.cx;
     const KnotScratch& s = cx.s;
     KHessScratch& hx = h.hx;
@@ -686,7 +694,7 @@ template <class Em> HD void t_kh_qq0(KHCtx<Em>& h, int) {
     double Mw[9], M[9];
     for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b) {
-            double acc = -lam[gs::COMC + a] * s.com[b] + m2 * e * E[3 * b + a] + hx.mu[a] * hx.LG[b] + s.omega[a] * hx.K[b];
+            double acc = -lam[gs::COMC + a] * hx.com[b] + m2 * e * E[3 * b + a] + hx.mu[a] * hx.LG[b] + s.omega[a] * hx.K[b];
             for (int p = 0; p < NC; ++p) acc += -lam[gs::PT_STRIDE * p + gs::KINC + a] * s.pkin[p][b];
             Mw[3 * a + b] = acc;
         }
@@ -763,24 +771,36 @@ constexpr int KH_SSD_SPLIT = 5 * 64;
 template <class Em> HD void t_kh_ssd_far_a(KHCtx<Em>& h, int t) { t_kh_ssd_far(h, t); }
 template <class Em> HD void t_kh_ssd_far_b(KHCtx<Em>& h, int t) { t_kh_ssd_far(h, t + KH_SSD_SPLIT); }
 
-// The Hessian tasks, run behind HIPNLP_KNOT_PROGRAM (RH(w, fn, n): tasks 0..n-1 of fn on wave w of four)
-#define HIPNLP_KNOT_HESS_PHASE1(RH, BARRIER)                                                                     \
-    RH(0, t_kh_point, NC) RH(0, t_kh_ff, 36) RH(1, t_kh_pp, 180) RH(2, t_kh_diag, 42) RH(2, t_kh_percouple, 84) RH(3, t_kh_mom0, 1) RH(3, t_kh_point_smooth, NC) \
+// The Hessian program.  KIN(fn, n) runs a task of knot_body.h, RH(w, fn, n) a Hessian task, on wave w of four.  Only the KINEMATIC part
+// of the knot program runs (joint transforms, forward kinematics, link momenta, composites, contact-point kinematics: none of the
+// rows / Jacobian columns), and the Hessian tasks that need no kinematics fill the waves it leaves idle.
+template <class Em> HD void t_kin_padding(Ctx<Em>& cx, int e) { scratch_padding(cx.s, e); }
+#define HIPNLP_KNOT_HESS_PHASE1(KIN, RH, BARRIER)                                                                \
+    KIN(0, t_joints, NJ) KIN(1, t_base, 3) KIN(1, t_kin_padding, 16)                                             \
+    RH(1, t_kh_diag, 42) RH(1, t_kh_percouple, 84) RH(2, t_kh_point, NC) RH(2, t_kh_ff, 36) RH(3, t_kh_pp, 180)  \
+    BARRIER                                                                                                      \
+    KIN(0, t_fk_rot_a, FK_TASKS_A) KIN(0, t_link_u_a, FK_SPLIT) KIN(3, t_fk_rot_b, FK_TASKS_B) KIN(3, t_link_u_b, NJ - FK_SPLIT) \
+    RH(2, t_kh_point_smooth, NC)                                                                                 \
+    BARRIER                                                                                                      \
+    KIN(0, t_links, NL) KIN(1, t_frames, 3) KIN(2, t_link_inertia, NL)                                           \
+    BARRIER                                                                                                      \
+    KIN(0, t_composite_g0, 64) KIN(1, t_composite_g1, 64) KIN(1, t_composite_g2, 64)                             \
+    KIN(2, t_composite_g3, 64) KIN(2, t_composite_g4, 64) KIN(3, t_composite_g5, 64) KIN(3, t_pkin, NC)          \
     BARRIER
-#define HIPNLP_KNOT_HESS_PHASE2(RH, BARRIER)                                                                     \
-    RH(0, t_kh_joint, NJ + 3) RH(1, t_kh_Y, NJ) RH(2, t_kh_qq0, 1)                                               \
+#define HIPNLP_KNOT_HESS_PHASE2(KIN, RH, BARRIER)                                                                \
+    RH(0, t_kh_joint, NJ + 3) RH(1, t_kh_Y, NJ) RH(2, t_kh_mom0, 1) RH(2, t_kh_qq0, 1)                           \
     BARRIER
-#define HIPNLP_KNOT_HESS_PHASE3(RH, BARRIER)                                                                     \
+#define HIPNLP_KNOT_HESS_PHASE3(KIN, RH, BARRIER)                                                                \
     RH(0, t_kh_ss_near, KH_NEAR_TASKS) RH(0, t_kh_qq, 10)                                                        \
     RH(1, t_kh_ssd_near, 2 * KH_NEAR_TASKS)                                                                      \
     RH(2, t_kh_ss_far, KH_SS_TASKS) RH(2, t_kh_ssd_far_a, KH_SSD_SPLIT)                                          \
     RH(3, t_kh_theta, 3 * NJ) RH(3, t_kh_sq, 4 * NJ) RH(3, t_kh_sqd, 4 * NJ) RH(3, t_kh_sdq, 4 * NJ) RH(3, t_kh_qqd, 16) \
     RH(3, t_kh_ssd_far_b, NJ * NJ - KH_SSD_SPLIT)                                                                \
     BARRIER
-#if defined(HIPNLP_HESS_DIAG_PHASES)   // diagnostic builds only (tools/diag): 0 = no Hessian task, 1 = first phase only, 2 = first two
-#define HIPNLP_KNOT_HESS_PROGRAM(RH, BARRIER) HIPNLP_HESS_DIAG_SELECT(RH, BARRIER)
+#if defined(HIPNLP_HESS_DIAG_PHASES)   // diagnostic builds only (tools/diag): the program truncated behind its first / second part
+#define HIPNLP_KNOT_HESS_PROGRAM(KIN, RH, BARRIER) HIPNLP_HESS_DIAG_SELECT(KIN, RH, BARRIER)
 #else
-#define HIPNLP_KNOT_HESS_PROGRAM(RH, BARRIER) HIPNLP_KNOT_HESS_PHASE1(RH, BARRIER) HIPNLP_KNOT_HESS_PHASE2(RH, BARRIER) HIPNLP_KNOT_HESS_PHASE3(RH, BARRIER)
+#define HIPNLP_KNOT_HESS_PROGRAM(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE1(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE2(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE3(KIN, RH, BARRIER)
 #endif
 
 }  // namespace hipnlp

@@ -39,13 +39,11 @@ struct HessLayout {
         KnotInfo ki{0, N, 1, 1};
         RecordEm em{grow.data(), jrid.data(), jc.data(), &dup, hrow.data(), hcol.data()};
         Ctx<RecordEm> cx(*s, kt, ks, gp, ki, em);
-#define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
-        HIPNLP_KNOT_PROGRAM(HOST_R, )
-#undef HOST_R
-        dup = false;   // (the knot program's own slots were checked by Layout::build)
         KHCtx<RecordEm> hcx{cx, *hx, s->g};
+#define HOST_KIN(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
 #define HOST_RH(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(hcx, t_);
-        HIPNLP_KNOT_HESS_PROGRAM(HOST_RH, )
+        HIPNLP_KNOT_HESS_PROGRAM(HOST_KIN, HOST_RH, )
+#undef HOST_KIN
 #undef HOST_RH
         delete hx;
         delete s;

@@ -80,14 +80,13 @@ void hostemu_hess(const hostemu_handle* h, const double* x, const double* p, dou
         KnotInfo ki{k, N, k == 0, k == N - 1};
         ValueEm em{s->g, s->jac, hx->H};
         Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
-#define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
-        HIPNLP_KNOT_PROGRAM(HOST_R, )
-#undef HOST_R
-        // multipliers by native slot, into the g staging area the knot program is done with
+        // multipliers by native slot, in the g staging area of the scratch (the Hessian program emits no g)
         for (int slot = 0; slot < gs::COUNT; ++slot) { const int a = L.g_a[v][size_t(slot)]; s->g[slot] = a >= 0 ? lambda[a + L.g_b[size_t(slot)] * k] : 0.0; }
         KHCtx<ValueEm> hcx{cx, *hx, s->g};
+#define HOST_KIN(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
 #define HOST_RH(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(hcx, t_);
-        HIPNLP_KNOT_HESS_PROGRAM(HOST_RH, )
+        HIPNLP_KNOT_HESS_PROGRAM(HOST_KIN, HOST_RH, )
+#undef HOST_KIN
 #undef HOST_RH
         for (int i = 0; i < HL.nnz_knot; ++i) hess[HL.knot_base(k) + i] = hx->H[HL.perm[size_t(i)]];
         if (k == N - 1) for (int i = 0; i < HL.n_couple; ++i) hess[HL.couple_base() + i] = hx->H[HL.perm_couple[size_t(i)]];
