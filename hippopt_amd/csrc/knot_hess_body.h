@@ -273,6 +273,9 @@ template <class Em> HD void t_kh_pp(KHCtx<Em>& h, int t) {
 // (Measured: the same work staged over three task groups — one lane per (point, bump) for the jets, per point for the frame parked in
 //  the dead jac area, per (point, block) for the entries — ran no faster alone (48.6 us per 100-knot stairs Hessian either way) and
 //  slower at batch 64 (0.72 vs 0.63 ms): kept as one task per point.)
+// (Also measured, behind the kinematics-only program: the terrain frame evaluated one phase earlier and parked in the dead jac area, the
+//  entries split four ways over the four waves — 34.3 us / 0.460 ms against 35.8 us / 0.457 ms for this single task: the truncated-Taylor
+//  arithmetic of the frame itself is the long pole, not the assembly.)
 // --- smooth terrain: the dense blocks of one contact point, lane c (8).  Lagrangian of the point with f, v, f_dot, u_v constant:
 //       L = C_u . u + l_d (-kbs h nf - hdot nf - h (ndot . f) - h (n . fdot)) + l_h h + l_n nf + l_f (mu^2 nf^2 - (x.f)^2 - (y.f)^2)
 //           + sigma m_sw/2 ((h - h_d)^2 + (x.v)^2 + (y.v)^2),      C_u = -sum_i l_pl,i (x_i tau, y_i tau, n_i),  tau = tanh(kt h)
