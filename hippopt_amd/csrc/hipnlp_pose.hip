@@ -169,12 +169,11 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     PoseHessEm<TERRAIN> em{s.g, s.jac, hx.H};
     Ctx<PoseHessEm<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
     HCtx<PoseHessEm<TERRAIN>> hcx{cx, hx};
-#define DEV_R(w, w8, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
+#define DEV_KIN(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_RH(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); }
 #define DEV_BARRIER __syncthreads();
-    HIPNLP_POSE_PROGRAM(DEV_R, DEV_BARRIER)
-    HIPNLP_POSE_HESS_PROGRAM(DEV_RH, DEV_BARRIER)
-#undef DEV_R
+    HIPNLP_POSE_HESS_PROGRAM(DEV_KIN, DEV_RH, DEV_BARRIER)
+#undef DEV_KIN
 #undef DEV_RH
 #undef DEV_BARRIER
     int bad = 0;

@@ -777,7 +777,6 @@ template <class Em> HD void t_kh_ssd_far_b(KHCtx<Em>& h, int t) { t_kh_ssd_far(h
 // The Hessian program.  KIN(fn, n) runs a task of knot_body.h, RH(w, fn, n) a Hessian task, on wave w of four.  Only the KINEMATIC part
 // of the knot program runs (joint transforms, forward kinematics, link momenta, composites, contact-point kinematics: none of the
 // rows / Jacobian columns), and the Hessian tasks that need no kinematics fill the waves it leaves idle.
-template <class Em> HD void t_kin_padding(Ctx<Em>& cx, int e) { scratch_padding(cx.s, e); }
 #define HIPNLP_KNOT_HESS_PHASE1(KIN, RH, BARRIER)                                                                \
     KIN(0, t_joints, NJ) KIN(1, t_base, 3) KIN(1, t_kin_padding, 16)                                             \
     RH(1, t_kh_diag, 42) RH(1, t_kh_percouple, 84) RH(2, t_kh_point, NC) RH(2, t_kh_ff, 36) RH(3, t_kh_pp, 180)  \

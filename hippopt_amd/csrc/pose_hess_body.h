@@ -1,8 +1,8 @@
 // pose_hess_body.h — exact Hessian of the Lagrangian  sigma f(x) + lambda^T g(x)  of the static pose finder NLP (IPOPT's eval_h;
 // SURVEY §8f rank 1).  The reference pose finder runs IPOPT with its default exact-Hessian option
 // (turnkey_planners/humanoid_pose_finder/main.py:101 `casadi_solver_options = {}`; planner.py:334-339), CasADi derives
-// nlp_hess_l by AD of the graph.  Here every second derivative is written out by hand and evaluated by tasks that run BEHIND the
-// pose program of pose_body.h in the same workgroup (they read the kinematic quantities that program left in LDS).
+// nlp_hess_l by AD of the graph.  Here every second derivative is written out by hand and evaluated by tasks that run behind the
+// KINEMATIC tasks of the pose program in the same workgroup (they read the kinematic quantities those left in LDS).
 //
 // Lower triangle in pose variable order (x [81]: per point p, f | p_b | q_b | s | com).  Second derivatives that exist:
 //   point block (p_c, f_c)   relaxed complementarity / height / normal force / friction rows on the terrain (second-order jets of
@@ -267,7 +267,7 @@ template <class Em> HD void t_hess_qq(HCtx<Em>& h, int t) {
     double Mw[9], M[9];
     for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b) {
-            double acc = -lam[gs::COMC + a] * s.com[b] + m2 * e * E[3 * b + a];
+            double acc = -lam[gs::COMC + a] * (s.comp[0][CH + b] / cx.kt.total_mass) + m2 * e * E[3 * b + a];   // com = first moment of the whole tree / mass
             for (int p = 0; p < NC; ++p) acc += -lam[gs::PT_STRIDE * p + gs::KINC + a] * s.pkin[p][b];
             Mw[3 * a + b] = acc;
         }
@@ -302,11 +302,23 @@ template <class Em> HD void t_hess_qq(HCtx<Em>& h, int t) {
     cx.em.H(hs::QQ + t, pv::QB + r, pv::QB + c, v);
 }
 
-// The Hessian tasks, run behind HIPNLP_POSE_PROGRAM (RH(w, fn, n): tasks 0..n-1 of fn on wave w)
-#define HIPNLP_POSE_HESS_PROGRAM(RH, BARRIER)                                             \
-    RH(0, t_hess_point, NC) RH(1, t_hess_misc, HESS_MISC_TASKS) RH(2, t_hess_Y, NJ) RH(3, t_hess_qq, 10) \
-    BARRIER                                                                               \
-    RH(0, t_hess_ss, HESS_SS_TASKS) RH(1, t_hess_qs, 4 * NJ)                              \
+// The Hessian program of the pose finder.  KIN(w, fn, n) runs a task of knot_body.h, RH(w, fn, n) a Hessian task, on wave w of four.
+// Only the KINEMATIC part of the pose program runs (joint transforms, forward kinematics, link quantities, composites, contact-point
+// kinematics: none of the rows / Jacobian columns); the Hessian tasks that need no kinematics sit on the waves its first phase leaves idle.
+template <class Em> HD void t_kin_padding(Ctx<Em>& cx, int e) { scratch_padding(cx.s, e); }
+#define HIPNLP_POSE_HESS_PROGRAM(KIN, RH, BARRIER)                                                                \
+    KIN(0, t_joints, NJ) KIN(1, t_base, 3) KIN(1, t_kin_padding, 16) RH(2, t_hess_point, NC) RH(3, t_hess_misc, HESS_MISC_TASKS) \
+    BARRIER                                                                                                       \
+    KIN(0, t_fk_rot_a, FK_TASKS_A) KIN(0, t_link_u_a, FK_SPLIT) KIN(3, t_fk_rot_b, FK_TASKS_B) KIN(3, t_link_u_b, NJ - FK_SPLIT) \
+    BARRIER                                                                                                       \
+    KIN(0, t_links, NL) KIN(1, t_frames, 3) KIN(2, t_link_inertia, NL)                                            \
+    BARRIER                                                                                                       \
+    KIN(0, t_composite_g0, 64) KIN(1, t_composite_g1, 64) KIN(1, t_composite_g2, 64)                              \
+    KIN(2, t_composite_g3, 64) KIN(2, t_composite_g4, 64) KIN(3, t_composite_g5, 64) KIN(3, t_pkin, NC)           \
+    BARRIER                                                                                                       \
+    RH(2, t_hess_Y, NJ) RH(3, t_hess_qq, 10)                                                                      \
+    BARRIER                                                                                                       \
+    RH(0, t_hess_ss, HESS_SS_TASKS) RH(1, t_hess_qs, 4 * NJ)                                                      \
     BARRIER
 
 }  // namespace hipnlp

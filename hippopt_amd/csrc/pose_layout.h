@@ -101,8 +101,10 @@ struct PoseLayout {
             HessScratch* hx = new HessScratch();
             std::fill(reinterpret_cast<double*>(hx), reinterpret_cast<double*>(hx) + sizeof(HessScratch) / sizeof(double), 1.0);
             HCtx<RecordEm> hcx{cx, *hx};
+#define HOST_KIN(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
 #define HOST_RH(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(hcx, t_);
-            HIPNLP_POSE_HESS_PROGRAM(HOST_RH, )
+            HIPNLP_POSE_HESS_PROGRAM(HOST_KIN, HOST_RH, )
+#undef HOST_KIN
 #undef HOST_RH
             delete hx;
             delete s;

@@ -237,12 +237,11 @@ void hostemu_pose_hess(const hostemu_pose_handle* h, const double* x, const doub
     KnotInfo ki{1, 3, 0, 0};
     ValueEm em{s->g, s->jac, hx->H};
     Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
-#define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
-    HIPNLP_POSE_PROGRAM(HOST_R, )
-#undef HOST_R
     HCtx<ValueEm> hcx{cx, *hx};
+#define HOST_KIN(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
 #define HOST_RH(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(hcx, t_);
-    HIPNLP_POSE_HESS_PROGRAM(HOST_RH, )
+    HIPNLP_POSE_HESS_PROGRAM(HOST_KIN, HOST_RH, )
+#undef HOST_KIN
 #undef HOST_RH
     for (int e = 0; e < L.hnnz; ++e) hess[e] = hx->H[L.hperm[size_t(e)]];
     delete hx;
