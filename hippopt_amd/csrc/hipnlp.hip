@@ -557,7 +557,7 @@ struct hipnlp_handle {
     HessLayout HL;
     int hess_state = 0;   // 0: not built yet, 1: ready, -1: not available (HL.error)
     HessTables* d_ht = nullptr;
-    double *d_sigma = nullptr, *d_lambda = nullptr, *d_hess = nullptr, *h_hess = nullptr;
+    double *d_sigma = nullptr, *d_lambda = nullptr /* inside the d_sigma block */, *d_hess = nullptr, *h_hess = nullptr, *h_sl = nullptr;
     int32_t *d_hflag = nullptr, *h_hflag = nullptr;
     int32_t hseq = 0;   // Hessian launches so far (generation of d_hflag)
     std::string err;
@@ -576,9 +576,9 @@ static void free_all(hipnlp_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* dptrs[] = {h->d_tb, h->d_x, h->d_pk, h->d_cost_knot, h->d_gp, h->d_ticket, h->d_out, h->d_ht, h->d_sigma, h->d_lambda, h->d_hess, h->d_hflag};
+    void* dptrs[] = {h->d_tb, h->d_x, h->d_pk, h->d_cost_knot, h->d_gp, h->d_ticket, h->d_out, h->d_ht, h->d_sigma, h->d_hess, h->d_hflag};
     for (void* q : dptrs) if (q) (void)hipFree(q);
-    void* hptrs[] = {h->h_x, h->h_out, h->h_hess, h->h_hflag};
+    void* hptrs[] = {h->h_x, h->h_out, h->h_hess, h->h_hflag, h->h_sl};
     for (void* q : hptrs) if (q) (void)hipHostFree(q);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -882,17 +882,19 @@ int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor
     if (rc != HIPNLP_OK) return rc;
     const size_t B = size_t(h->batch), n = size_t(h->L.n), m = size_t(h->L.m), hn = size_t(hess_count(h));
     HIP_TRY(h, hipSetDevice(h->dev));
-    if (!h->d_hess) {
-        HIP_TRY(h, hipMalloc(&h->d_sigma, B * sizeof(double)));
-        HIP_TRY(h, hipMalloc(&h->d_lambda, B * m * sizeof(double)));
+    if (!h->d_hess) {   // inputs [sigma | lambda] in one device block with a pinned mirror: one H2D copy beside the one of x
+        HIP_TRY(h, hipMalloc(&h->d_sigma, B * (1 + m) * sizeof(double)));
+        h->d_lambda = h->d_sigma + B;
+        HIP_TRY(h, hipHostMalloc(&h->h_sl, B * (1 + m) * sizeof(double)));
         HIP_TRY(h, hipMalloc(&h->d_hess, B * hn * sizeof(double)));
         HIP_TRY(h, hipHostMalloc(&h->h_hess, B * hn * sizeof(double)));
     }
     h->have_result = false;   // (the staging copy of x is shared with hipnlp_eval)
     std::memcpy(h->h_x, x, B * n * sizeof(double));
+    std::memcpy(h->h_sl, obj_factor, B * sizeof(double));
+    std::memcpy(h->h_sl + B, lambda, B * m * sizeof(double));
     HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_x, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_sigma, obj_factor, B * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_lambda, lambda, B * m * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_sigma, h->h_sl, B * (1 + m) * sizeof(double), hipMemcpyHostToDevice, h->stream));
     rc = hess_launch(h, h->d_x, h->d_sigma, h->d_lambda, h->d_hess, h->stream);
     if (rc != HIPNLP_OK) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->h_hess, h->d_hess, B * hn * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -215,12 +215,14 @@ class HipNlp:
         self._check(self.lib.hipnlp_hess_sparsity(self.h, _ip(ir), _ip(jc)))
         return ir, jc
 
-    def eval_hess(self, x, obj_factor, lam):
-        """values [batch][nnz_h] of  obj_factor * hess f + sum_r lam_r hess g_r  at x (obj_factor: scalar or [batch])"""
+    def eval_hess(self, x, obj_factor, lam, out=None):
+        """values [batch][nnz_h] of  obj_factor * hess f + sum_r lam_r hess g_r  at x (obj_factor: scalar or [batch]).
+        out: the array of a previous call to fill again (a fresh 1.2 MB numpy array costs its page faults on every call)."""
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.batch, self.n)
         lam = np.ascontiguousarray(lam, dtype=np.float64).reshape(self.batch, self.m)
         sig = np.ascontiguousarray(np.broadcast_to(np.asarray(obj_factor, dtype=np.float64), (self.batch,)))
-        out = np.zeros((self.batch, self.hess_nnz()))
+        if out is None:
+            out = np.empty((self.batch, self.hess_nnz()))
         self._check(self.lib.hipnlp_eval_hess(self.h, _dp(x), _dp(sig), _dp(lam), _dp(out)))
         return out
 

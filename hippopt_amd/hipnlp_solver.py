@@ -53,7 +53,7 @@ class _PoseEngine:
         return self._pose.sparsity()
 
     def eval(self, x, new_x=True, want=("f", "grad", "g", "jac")):
-        return self._pose.eval(x)
+        return self._pose.eval(x)   # (81 variables: always evaluated)
 
     def cost_terms(self):
         return self._pose.cost_terms()
@@ -68,6 +68,29 @@ class _PoseEngine:
 
     def eval_hess(self, x, obj_factor, lam):
         return self._pose.eval_hess(x, obj_factor, lam)[0]
+
+
+class _CallbackCache:
+    """What IPOPT's `new_x` flag does for a C caller: the four callbacks of one iterate share ONE evaluation (one kernel launch, one
+    device-to-host copy); a callback at an x the engine has already evaluated only copies its own output out of the staging block."""
+
+    def __init__(self, eng):
+        self._eng = eng
+        self._x = None
+
+    def eval(self, x, want):
+        x = np.asarray(x, dtype=np.float64)
+        new_x = self._x is None or not np.array_equal(x, self._x)
+        if new_x:
+            self._x = x.copy()
+        try:
+            return self._eng.eval(x[None, :], new_x=new_x, want=want)
+        except Exception:
+            self._x = None   # a failed evaluation leaves nothing to reuse
+            raise
+
+    def invalidate(self):
+        self._x = None
 
 
 class HipNlpSolver:
@@ -289,20 +312,22 @@ class HipNlpSolver:
         from scipy.sparse import csc_matrix
         m, n = eng.m, eng.n
 
+        cache = _CallbackCache(eng)
+
         def fun(x):
-            f, *_ = eng.eval(x[None, :], want=("f",))
+            f, *_ = cache.eval(x, ("f",))
             return float(f[0])
 
         def grad(x):
-            _, g_, *_ = eng.eval(x[None, :], want=("grad",))
+            _, g_, *_ = cache.eval(x, ("grad",))
             return g_[0]
 
         def cons(x):
-            _, _, g, _ = eng.eval(x[None, :], want=("g",))
+            _, _, g, _ = cache.eval(x, ("g",))
             return g[0]
 
         def jac(x):
-            _, _, _, j = eng.eval(x[None, :], want=("jac",))
+            _, _, _, j = cache.eval(x, ("jac",))
             return csc_matrix((j[0], (ir, jc)), shape=(m, n))
         exact = hasattr(eng, "eval_hess") and self._options.get("hessian_approximation", "exact") != "limited-memory"
         hess_f, hess_c = BFGS(), BFGS()
@@ -319,8 +344,13 @@ class HipNlpSolver:
             def sym(vals):
                 return csc_matrix((np.concatenate([vals, vals[off]]), (np.concatenate([hr, hc[off]]), np.concatenate([hc, hr[off]]))), shape=(n, n))
             zero_lam = np.zeros(m)
-            hess_f = lambda x: sym(np.asarray(eng.eval_hess(x[None, :], 1.0, zero_lam[None, :])).reshape(-1))      # noqa: E731
-            hess_c = lambda x, v: sym(np.asarray(eng.eval_hess(x[None, :], 0.0, np.asarray(v)[None, :])).reshape(-1))  # noqa: E731
+            def hess_f(x):   # (the Hessian evaluation reuses the engine's staging of x: the cached callback set is gone)
+                cache.invalidate()
+                return sym(np.asarray(eng.eval_hess(x[None, :], 1.0, zero_lam[None, :])).reshape(-1))
+
+            def hess_c(x, v):
+                cache.invalidate()
+                return sym(np.asarray(eng.eval_hess(x[None, :], 0.0, np.asarray(v)[None, :])).reshape(-1))
         nlc = NonlinearConstraint(cons, lbg, ubg, jac=jac, hess=hess_c)
         opts = {"maxiter": int(self._options.get("max_iter", 50)), "verbose": int(self._options.get("verbose", 0)),
                 "gtol": float(self._options.get("tol", 1e-6))}
@@ -336,22 +366,24 @@ class HipNlpSolver:
         import cyipopt
         outer = self
 
+        cache = _CallbackCache(eng)
+
         class Callbacks:
             def objective(self, x):
-                return float(eng.eval(x[None, :], want=("f",))[0][0])
+                return float(cache.eval(x, ("f",))[0][0])
 
             def gradient(self, x):
-                return eng.eval(x[None, :], want=("grad",))[1][0]
+                return cache.eval(x, ("grad",))[1][0]
 
             def constraints(self, x):
-                return eng.eval(x[None, :], want=("g",))[2][0]
+                return cache.eval(x, ("g",))[2][0]
 
             def jacobianstructure(self):
                 return ir, jc
 
             def jacobian(self, x):
                 self.x_last = np.array(x, copy=True)
-                return eng.eval(x[None, :], want=("jac",))[3][0]
+                return cache.eval(x, ("jac",))[3][0]
 
             def intermediate(self, alg_mod, iter_count, obj_value, inf_pr, inf_du, mu, d_norm, regularization_size, alpha_du, alpha_pr,
                              ls_trials):
@@ -374,7 +406,10 @@ class HipNlpSolver:
                 exact = False
         if exact:   # eval_h from the engine: the pose finder runs IPOPT with the exact Hessian (humanoid_pose_finder/main.py:101)
             Callbacks.hessianstructure = lambda self: (hr, hc)
-            Callbacks.hessian = lambda self, x, lagrange, obj_factor: np.asarray(eng.eval_hess(x[None, :], obj_factor, np.asarray(lagrange)[None, :])).reshape(-1)
+            def _hessian(self, x, lagrange, obj_factor):
+                cache.invalidate()   # (the Hessian evaluation reuses the engine's staging of x)
+                return np.asarray(eng.eval_hess(x[None, :], obj_factor, np.asarray(lagrange)[None, :])).reshape(-1)
+            Callbacks.hessian = _hessian
         nlp = cyipopt.Problem(n=eng.n, m=eng.m, problem_obj=Callbacks(), lb=lbx, ub=ubx, cl=lbg, cu=ubg)
         if not exact:
             nlp.add_option("hessian_approximation", "limited-memory")  # main_periodic_step.py:116
