@@ -27,3 +27,17 @@ for _ in range(200): eng.eval(x, out=outs)
 t5 = time.perf_counter()
 print("caller-owned arrays reused: eval_hess %.1f us, eval %.1f us" % (1e6 * (t4 - t3) / 200, 1e6 * (t5 - t4) / 200))
 print("eval_hess host path %.1f us per call; eval host path %.1f us per call" % (1e6 * (t1 - t0) / 200, 1e6 * (t2 - t1) / 200))
+fo = eng.eval(x, want=("f",))
+t6 = time.perf_counter()
+for _ in range(200): eng.eval(x, want=("f",), out=(fo[0], None, None, None))
+t7 = time.perf_counter()
+print("eval, only f copied to the caller (evaluation + the whole device-to-host block): %.1f us" % (1e6 * (t7 - t6) / 200))
+import torch
+xd = torch.tensor(x, device="cuda")
+torch.cuda.synchronize()
+t8 = time.perf_counter()
+for _ in range(200):
+    eng.eval_device(xd.data_ptr())
+    torch.cuda.synchronize()
+t9 = time.perf_counter()
+print("eval_device + synchronize (no copies): %.1f us" % (1e6 * (t9 - t8) / 200))
