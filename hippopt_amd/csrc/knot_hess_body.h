@@ -146,8 +146,10 @@ template <class Em> HD double ends_diag(const KHCtx<Em>& h, int var) {
     const Ctx<Em>& cx = h.cx;
     double v = 0.0;
     if (cx.ki.last && cx.st.final_type == HIPNLP_EXPR_MINIMIZE)
+        HIPNLP_ROLLED
         for (int t = 0; t < 105; ++t) if (int(cx.kt.fin_var[t]) == var) v += 2.0 * h.hx.sigma * cx.st.final_weight;
     if ((cx.ki.first || cx.ki.last) && cx.st.periodicity_type == HIPNLP_EXPR_MINIMIZE)
+        HIPNLP_ROLLED
         for (int t = 0; t < 84; ++t) if (int(cx.kt.per_var[t]) == var) v += 2.0 * h.hx.sigma * cx.st.periodicity_weight;
     return v;
 }
