@@ -19,6 +19,7 @@
 #include <new>
 #include <string>
 #include <tuple>
+#include <type_traits>
 #include <vector>
 
 #include "knot_hess_layout.h"
@@ -180,7 +181,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     const bool ends_late = (first || last) && (tabs.head.ks.final_type == HIPNLP_EXPR_MINIMIZE || tabs.head.ks.periodicity_type == HIPNLP_EXPR_MINIMIZE);
     unsigned long long pub_old = 0;
     int pub_bad = 0;
-    auto pub_store = [&]() {
+    auto pub_store = [&]() __attribute__((always_inline)) {
         if (lane < NCT) {
             const double cv = (lane == CT_ENDS && !ends_late) ? 0.0 : s.cost[lane];   // (t_ends_finish writes that zero only in phase F)
             pub_bad |= !isfinite(cv);
@@ -188,7 +189,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
                                __double_as_longlong(cv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
-    auto pub_ticket = [&]() {
+    auto pub_ticket = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the partials are in memory (agent-scope stores are write-through)
         unsigned long long old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(a.ticket + b, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -201,7 +202,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     bool pub_last = false;
     double pub_v[32];
     const unsigned long long* pub_base = reinterpret_cast<const unsigned long long*>(a.cost_knot + size_t(b) * a.nk * NCT);
-    auto pub_issue = [&](int k0) {
+    auto pub_issue = [&](int k0) __attribute__((always_inline)) {
         const int t = lane & 15;
 #pragma unroll
         for (int u = 0; u < 32; ++u) {
@@ -209,13 +210,13 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             pub_v[u] = (t < NCT && kq < a.nk) ? __longlong_as_double((long long)__hip_atomic_load(pub_base + size_t(kq) * NCT + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
         }
     };
-    auto pub_await_ticket = [&]() {   // waits for the ticket; the last arriver puts its first 32 loads per lane in flight
+    auto pub_await_ticket = [&]() __attribute__((always_inline)) {   // waits for the ticket; the last arriver puts its first 32 loads per lane in flight
         const unsigned long long old = (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane(int(pub_old & 0xffffffffull)) |
                                        ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane(int(pub_old >> 32)) << 32);
         pub_last = old + 1ull == (unsigned long long)a.seq * (unsigned long long)a.nk;   // (wave-uniform)
         if (pub_last) pub_issue(lane >> 4);
     };
-    auto pub_sum = [&]() {
+    auto pub_sum = [&]() __attribute__((always_inline)) {
         if (!pub_last) return;
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
         for (int k0 = lane >> 4;;) {
@@ -241,7 +242,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         if (lane == 0) a.f[b] = tot;
     };
     // called by every wave right behind barrier number `passed` (0 = the one that ends phase A)
-    auto pub_step = [&](int passed) {
+    auto pub_step = [&](int passed) __attribute__((always_inline)) {
         // (throughput variant: under load the acknowledgement of the partials takes long enough to stall the publishing wave at
         //  its next barrier — measured -13 % at batch 64 — so it keeps the separate reduction kernel, cheap next to a long launch)
         if (WAVES != 8 || wave != PUBW) return;
@@ -272,19 +273,37 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     KnotInfo ki{k, N, first, last};
     DevEm<TERRAIN> em{s.g, s.jac};
     Ctx<DevEm<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
-#define DEV_R(w4, w8, fn, nt) if (wave == (WAVES == 4 ? (w4) : (w8))) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
+    // The program is instantiated ONCE PER WAVE (a generic lambda over the wave number as a compile-time constant: a task group is
+    // compiled into the one instance whose wave runs it) and dispatched by one switch, so that every wave executes a CONTIGUOUS
+    // instruction stream from the first phase to the last.  Written as `if (wave == w) { ... }` blocks phase after phase, every
+    // wave jumped over the other waves' code several times per phase, each jump a cold instruction-cache line.  The waves still meet
+    // at the same barriers: every instance contains all of them.
+#define DEV_R(w4, w8, fn, nt) if constexpr ((WAVES == 4 ? (w4) : (w8)) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #ifdef HIPNLP_STAMPS
     // diagnostic build: every wave keeps, IN REGISTERS, its arrival time at each barrier and the time it leaves it; one store
     // per wave at the very end (a store before a barrier would make the barrier wait for its acknowledgement).
     unsigned long long st_arr[8], st_dep[8];
     const unsigned long long st_staged = __builtin_amdgcn_s_memtime();
     int bid = 0;
-#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); __syncthreads(); st_dep[bid] = __builtin_amdgcn_s_memtime(); pub_step(bid); bid++;
+#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); __syncthreads(); st_dep[bid] = __builtin_amdgcn_s_memtime(); if constexpr (WAVES == 8 && W == PUBW) pub_step(bid); bid++;
 #else
     int bid = 0;
-#define DEV_BARRIER __syncthreads(); pub_step(bid); bid++;
+#define DEV_BARRIER __syncthreads(); if constexpr (WAVES == 8 && W == PUBW) pub_step(bid); bid++;
 #endif
-    HIPNLP_KNOT_PROGRAM(DEV_R, DEV_BARRIER)
+    auto run_wave = [&](auto wc) __attribute__((always_inline)) {
+        constexpr int W = decltype(wc)::value;
+        HIPNLP_KNOT_PROGRAM(DEV_R, DEV_BARRIER)
+    };
+    switch (wave) {
+        case 0: run_wave(std::integral_constant<int, 0>{}); break;
+        case 1: run_wave(std::integral_constant<int, 1>{}); break;
+        case 2: run_wave(std::integral_constant<int, 2>{}); break;
+        case 3: run_wave(std::integral_constant<int, 3>{}); break;
+        case 4: if constexpr (WAVES == 8) run_wave(std::integral_constant<int, 4>{}); break;
+        case 5: if constexpr (WAVES == 8) run_wave(std::integral_constant<int, 5>{}); break;
+        case 6: if constexpr (WAVES == 8) run_wave(std::integral_constant<int, 6>{}); break;
+        default: if constexpr (WAVES == 8) run_wave(std::integral_constant<int, 7>{}); break;
+    }
 #undef DEV_R
 #undef DEV_BARRIER
 
@@ -451,10 +470,20 @@ template <int TERRAIN> __global__ __launch_bounds__(256) __attribute__((amdgpu_w
     DevEmH<TERRAIN> em{s.g, s.jac, hx.H};
     Ctx<DevEmH<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
     KHCtx<DevEmH<TERRAIN>> hcx{cx, hx, s.g};
-#define DEV_KIN(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
-#define DEV_RH(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); }
+    // (one contiguous program instance per wave, as in hipnlp_knot_kernel)
+#define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
+#define DEV_RH(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); }
 #define DEV_BARRIER __syncthreads();
-    HIPNLP_KNOT_HESS_PROGRAM(DEV_KIN, DEV_RH, DEV_BARRIER)
+    auto run_wave = [&](auto wc) __attribute__((always_inline)) {
+        constexpr int W = decltype(wc)::value;
+        HIPNLP_KNOT_HESS_PROGRAM(DEV_KIN, DEV_RH, DEV_BARRIER)
+    };
+    switch (wave) {
+        case 0: run_wave(std::integral_constant<int, 0>{}); break;
+        case 1: run_wave(std::integral_constant<int, 1>{}); break;
+        case 2: run_wave(std::integral_constant<int, 2>{}); break;
+        default: run_wave(std::integral_constant<int, 3>{}); break;
+    }
 #undef DEV_KIN
 #undef DEV_RH
 #undef DEV_BARRIER

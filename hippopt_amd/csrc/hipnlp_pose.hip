@@ -7,6 +7,8 @@
 // The total cost of a pose is summed inside the same workgroup in a fixed order (bitwise reproducible); no second kernel.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -120,9 +122,19 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     KnotInfo ki{1, 3, 0, 0};   // "interior knot": the k >= 1 rows / costs of the shared tasks are active
     PoseEm<TERRAIN> em{s.g, s.jac};
     Ctx<PoseEm<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
-#define DEV_R(w, w8, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
+    // (one contiguous program instance per wave, as in hipnlp_knot_kernel: no wave jumps over the other waves' code)
+#define DEV_R(w, w8, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_BARRIER __syncthreads();
-    HIPNLP_POSE_PROGRAM(DEV_R, DEV_BARRIER)
+    auto run_wave = [&](auto wc) __attribute__((always_inline)) {
+        constexpr int W = decltype(wc)::value;
+        HIPNLP_POSE_PROGRAM(DEV_R, DEV_BARRIER)
+    };
+    switch (wave) {
+        case 0: run_wave(std::integral_constant<int, 0>{}); break;
+        case 1: run_wave(std::integral_constant<int, 1>{}); break;
+        case 2: run_wave(std::integral_constant<int, 2>{}); break;
+        default: run_wave(std::integral_constant<int, 3>{}); break;
+    }
 #undef DEV_R
 #undef DEV_BARRIER
 
@@ -169,10 +181,20 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     PoseHessEm<TERRAIN> em{s.g, s.jac, hx.H};
     Ctx<PoseHessEm<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
     HCtx<PoseHessEm<TERRAIN>> hcx{cx, hx};
-#define DEV_KIN(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
-#define DEV_RH(w, fn, nt) if (wave == (w)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); }
+    // (one contiguous program instance per wave, as in hipnlp_knot_kernel: no wave jumps over the other waves' code)
+#define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
+#define DEV_RH(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); }
 #define DEV_BARRIER __syncthreads();
-    HIPNLP_POSE_HESS_PROGRAM(DEV_KIN, DEV_RH, DEV_BARRIER)
+    auto run_wave = [&](auto wc) __attribute__((always_inline)) {
+        constexpr int W = decltype(wc)::value;
+        HIPNLP_POSE_HESS_PROGRAM(DEV_KIN, DEV_RH, DEV_BARRIER)
+    };
+    switch (wave) {
+        case 0: run_wave(std::integral_constant<int, 0>{}); break;
+        case 1: run_wave(std::integral_constant<int, 1>{}); break;
+        case 2: run_wave(std::integral_constant<int, 2>{}); break;
+        default: run_wave(std::integral_constant<int, 3>{}); break;
+    }
 #undef DEV_KIN
 #undef DEV_RH
 #undef DEV_BARRIER
