@@ -111,7 +111,7 @@ __device__ __forceinline__ void pose_stage(const PArgs& a, KnotScratch& s, PoseS
 
 // Two waves per SIMD (<= 256 VGPRs, two workgroups per CU).  Capped at 168 for the three workgroups the LDS would allow, the
 // compiler spilled 12-18 VGPRs to scratch and the kernel ran 3.6x slower (0.33 ms vs 0.09 ms for 4096 poses).
-template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void hipnlp_pose_kernel(PArgs a) {
+template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3, 3))) void hipnlp_pose_kernel(PArgs a) {
     __shared__ KnotScratch s;
     __shared__ PoseShared tabs;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
