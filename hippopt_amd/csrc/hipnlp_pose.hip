@@ -7,6 +7,7 @@
 // The total cost of a pose is summed inside the same workgroup in a fixed order (bitwise reproducible); no second kernel.
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <type_traits>
 
 #include <cmath>
@@ -163,8 +164,12 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
 
 // Exact Hessian of the Lagrangian (IPOPT eval_h, pose_hess_body.h): the pose program runs as in hipnlp_pose_kernel (its g / jac
 // values stay in LDS, unused), the Hessian tasks run behind it and the workgroup streams out the lower-triangle CCS value run.
-template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void hipnlp_pose_hess_kernel(PArgs a) {
-    __shared__ KnotScratch s;
+// The Hessian program runs none of the tasks that emit Jacobian entries: the jac staging area (the last 15.7 KB of the scratch) is not
+// allocated, which brings the workgroup to 46 KB of LDS — three per CU (register cap 168).
+template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3, 3))) void hipnlp_pose_hess_kernel(PArgs a) {
+    static_assert(offsetof(KnotScratch, jac) + sizeof(KnotScratch::jac) == sizeof(KnotScratch), "jac is the last member of the scratch");
+    __shared__ alignas(16) double s_raw[offsetof(KnotScratch, jac) / sizeof(double)];
+    KnotScratch& s = *reinterpret_cast<KnotScratch*>(s_raw);
     __shared__ PoseShared tabs;
     __shared__ HessScratch hx;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -178,7 +183,7 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     pose_stage(a, s, tabs, b, tid);
 
     KnotInfo ki{1, 3, 0, 0};
-    PoseHessEm<TERRAIN> em{s.g, s.jac, hx.H};
+    PoseHessEm<TERRAIN> em{s.g, nullptr, hx.H};   // (no task of the Hessian program emits a Jacobian entry)
     Ctx<PoseHessEm<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
     HCtx<PoseHessEm<TERRAIN>> hcx{cx, hx};
     // (one contiguous program instance per wave, as in hipnlp_knot_kernel: no wave jumps over the other waves' code)
