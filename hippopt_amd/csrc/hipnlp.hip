@@ -157,13 +157,13 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     //  before the barrier as well, which then waits for them: +14 % kernel time at batch 1024; kernarg copies of these scalars
     //  measured +22 %)
     const int v = first ? VAR_FIRST : (last ? VAR_LAST : VAR_INTERIOR);
-    const int jcnt = tb.nnz_v[v];
     const int64_t jbase = first ? 0 : int64_t(tb.nnz_v[VAR_FIRST]) + int64_t(k - 1) * tb.nnz_v[VAR_INTERIOR];
     const int n_glob = last ? tb.n_glob : 0, jac_glob_base = tb.jac_glob_base;
     const int jpg = (last && tid < 16) ? tb.jperm_glob[tid] : 0;
     int32_t jp[JP_ITERS], ga[G_ITERS], gb[G_ITERS];
 #pragma unroll
-    for (int it = 0; it < JP_ITERS; ++it) { const int i = tid + it * WG; jp[it] = i < jcnt ? tb.jperm[v][i] : -1; }
+    // (the table is padded with -1 behind the knot variant's entries: the loads do not wait for the entry count, a global scalar)
+    for (int it = 0; it < JP_ITERS; ++it) { const int i = tid + it * WG; jp[it] = i < js::COUNT ? tb.jperm[v][i] : -1; }
 #pragma unroll
     for (int it = 0; it < G_ITERS; ++it) {
         const int slot = tid + it * WG;
@@ -461,11 +461,11 @@ template <int TERRAIN> __global__ __launch_bounds__(256) __attribute__((amdgpu_w
     // copy-out permutation, fetched now so that its latency hides behind the programs
     const HessTables& ht = *a.ht;
     constexpr int HP_ITERS = (hk::COUNT + WG - 1) / WG;
-    const int cnt = ht.nnz_knot, ncpl = last ? ht.n_couple : 0;
+    const int cnt = ht.nnz_knot;
     int32_t hp[HP_ITERS];
 #pragma unroll
-    for (int it = 0; it < HP_ITERS; ++it) { const int i = tid + it * WG; hp[it] = i < cnt ? ht.perm[i] : -1; }
-    const int hpc = tid < ncpl ? ht.perm_couple[tid] : -1;
+    for (int it = 0; it < HP_ITERS; ++it) { const int i = tid + it * WG; hp[it] = i < hk::COUNT ? ht.perm[i] : -1; }   // (padded with -1 on the host)
+    const int hpc = (last && tid < 84) ? ht.perm_couple[tid] : -1;   // (padded with -1 on the host)
     KnotInfo ki{k, N, first, last};
     DevEmH<TERRAIN> em{s.g, s.jac, hx.H};
     Ctx<DevEmH<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
@@ -695,7 +695,7 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     tb->head.ks = Layout::make_ksettings(st);
     for (int v = 0; v < 3; ++v) {
         for (int s = 0; s < gs::COUNT; ++s) tb->g_a[v][s] = h->L.g_a[v][size_t(s)];
-        for (size_t i = 0; i < h->L.jperm[v].size(); ++i) tb->jperm[v][i] = h->L.jperm[v][i];
+        for (int i = 0; i < js::COUNT; ++i) tb->jperm[v][i] = size_t(i) < h->L.jperm[v].size() ? h->L.jperm[v][size_t(i)] : -1;
         tb->nnz_v[v] = h->L.nnz_v[v];
     }
     for (int s = 0; s < gs::COUNT; ++s) tb->g_b[s] = h->L.g_b[size_t(s)];
@@ -846,8 +846,8 @@ static int hess_prepare(hipnlp_handle* h) {
             HIP_TRY(h, hipSetDevice(h->dev));
             HessTables* t = new HessTables();
             std::memset(t, 0, sizeof(HessTables));
-            for (int i = 0; i < h->HL.nnz_knot; ++i) t->perm[i] = h->HL.perm[size_t(i)];
-            for (int i = 0; i < h->HL.n_couple; ++i) t->perm_couple[i] = h->HL.perm_couple[size_t(i)];
+            for (int i = 0; i < hk::COUNT; ++i) t->perm[i] = i < h->HL.nnz_knot ? h->HL.perm[size_t(i)] : -1;
+            for (int i = 0; i < 84; ++i) t->perm_couple[i] = i < h->HL.n_couple ? h->HL.perm_couple[size_t(i)] : -1;
             t->nnz_knot = h->HL.nnz_knot; t->n_couple = h->HL.n_couple;
             hipError_t e = hipMalloc(&h->d_ht, sizeof(HessTables));
             if (e == hipSuccess) e = hipMemcpy(h->d_ht, t, sizeof(HessTables), hipMemcpyHostToDevice);
