@@ -4,38 +4,72 @@
 One "step" = one complete callback set {f, grad f, g, jac g} of the ergoCub-shaped kinodynamic
 multiple-shooting NLP (BASELINE.json metric) on synthetic, HBM-resident inputs.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--horizon 100] [--batch 1] [--shard knots|batch]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--horizon 100] [--batch 1] [--workload periodic|single|stairs]
 
-N = 1 : workload "kinodynamic periodic walking, N = 100 knots" (BASELINE config 4 on one GPU).
-N > 1 : launched by torch.distributed.run, one rank per GPU.  Default `--shard batch`: N independent 100-knot trajectories, one per
-        GPU, no data-path collective (the MPC / batched-initial-guess shape of BASELINE config 5: independent NLPs partition over
-        the GPUs, nothing is exchanged) -> `value`.  In the SAME run the knot-sharded path of north_star is measured as well and
-        reported beside it (`knot_sharded_allgather`): ONE trajectory whose horizon grows with N (100 knots per GPU), shooting
-        intervals sharded contiguously, every step ending with ONE RCCL all-gather of the fused shard buffers + the one-launch
-        reassembly of [grad f | jac g | g] in reference order on every rank.  `--shard knots` makes that path the `value`.
-The JSON line carries `roofline` (HIP-event timed knot kernel vs the 8 TB/s HBM peak) and `cpu_baseline`
-(the CPU oracle timed on the host, rank 0, N = 1 only).
+N = 1 : workload "kinodynamic periodic walking, N = 100 knots" (BASELINE config 4 on one GPU), outputs left in HBM -> `value`.
+        Beside it (never `value`): the host-visible rate of the boundary IPOPT binds (`host_visible`, per callback kind), the exact
+        Hessian, and the CPU baselines timed on this box's host cores in the same run (`cpu_baseline`).
+N > 1 : one rank per GPU.  `python bench.py --gpus N` started WITHOUT torch.distributed.run spawns its own N ranks (fresh child
+        processes, before anything touches a GPU) and relays rank 0's JSON line; started BY torch.distributed.run (WORLD_SIZE set) it
+        is one of the ranks.  `value` is north_star's path: ONE trajectory whose horizon grows with N (100 knots per GPU, weak
+        scaling), shooting intervals sharded contiguously, every step ending with ONE RCCL all-gather of the fused shard buffers + the
+        one-launch reassembly of [grad f | jac g | g] in reference order on every rank.  Beside it: `independent_trajectories` (N
+        replicas, no collective — BASELINE config 5's batched-guess shape) and `host_sink` (no collective either: every rank's kernel
+        stores its shard straight into ONE shared pinned host buffer, what a CPU-side IPOPT consumes).
+The JSON line carries `roofline` (HIP-event timed knot kernel vs the 8 TB/s HBM peak, plus the fp64 VALU-issue ceiling) and
+`cpu_baseline` (rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-from hippopt_amd.hipnlp import HipNlp  # noqa: E402
-from hippopt_amd.kinodyn_settings import periodic_step_settings, single_step_settings, stairs_settings  # noqa: E402
-from hippopt_amd.robot_model import synthetic_ergocub  # noqa: E402
-from hippopt_amd.synthetic import make_workload, place_on_step_flanks  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (guides/MI355X_MICROARCH.md)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0   # G wave-instructions/s: 256 CUs x 4 SIMDs x 2.4 GHz, 4 issue cycles per wave64 VALU instruction
 KNOTS_PER_GPU = 100
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--horizon", type=int, default=KNOTS_PER_GPU, help="knots per GPU")
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--workload", choices=["periodic", "single", "stairs"], default="periodic",
+                    help="periodic walking (BASELINE metric, default) | single step (final state / periodicity skipped) | stairs (smooth terrain)")
+    ap.add_argument("--shard", choices=["knots", "batch"], default=None,
+                    help="what `value` is for N > 1: knots (default: north_star's knot-sharded all-gather path) | batch (independent trajectories)")
+    ap.add_argument("--event-stride", type=int, default=16, help="time every n-th launch of the timed region with HIP events")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hessian", action="store_true", help="skip the exact-Hessian figure reported beside the callback quartet")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-visible (PCIe-inclusive) figures")
+    ap.add_argument("--force-sharded", action="store_true", help="exercise the sharded paths on one GPU (debug)")
+    return ap.parse_args()
+
+
+def spawn_ranks(n):
+    """`bench.py --gpus N` without a launcher: start N fresh rank processes (torch.distributed.run) BEFORE this process touches a
+    GPU, relay their output, exit with their code.  (Never an exec of a process that has initialised the GPU.)"""
+    import torch
+    have = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+    if have < n:
+        sys.stderr.write("bench.py --gpus %d: only %d HIP device(s) visible; refusing to report a smaller world as n_gpus=%d\n" % (n, have, n))
+        sys.exit(2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def algorithmic_bytes_per_knot(nnz_knot):
@@ -43,45 +77,85 @@ def algorithmic_bytes_per_knot(nnz_knot):
     return 8 * (189 + 79 + 274 + nnz_knot + 189)
 
 
-def cpu_baseline(settings, model, x, p, budget_s=12.0):
-    """The CPU oracle (oracle/kinodyn_oracle.cpp, single thread) on the same workload, bounded sample."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle_lib import Oracle
-    orc = Oracle(settings, model)
-    orc.eval(x, p)  # warm-up
+def timed_loop(fn, budget_s, min_reps=3, max_reps=100000):
+    fn()
     t0 = time.perf_counter()
     reps = 0
     while True:
-        orc.eval(x, p)
+        fn()
         reps += 1
         el = time.perf_counter() - t0
-        if el > budget_s or reps >= 1000:
-            break
-    out = {"value": settings.horizon_length * reps / el, "unit": "knots/s", "cores": 1, "kind": "port",
-           "sample": "%d full callback sets (f, grad f, g, jac g by forward AD) of the N=%d workload in %.1f s, 1 thread"
-                     % (reps, settings.horizon_length, el)}
-    # beside it: the kernel's own analytic per-knot program run on one CPU thread (the test-only host emulation, tests/hostemu) —
-    # hand-derived Jacobians instead of forward AD, i.e. closer to what CasADi's expanded SX graph costs per callback set
+        if (el > budget_s and reps >= min_reps) or reps >= max_reps:
+            return reps, el
+
+
+def cpu_baseline(settings, model, x, p):
+    """CPU baselines on THIS box's host cores, same workload, bounded samples:
+    B1 `value`     the analytic knot program (hand-derived Jacobians, the kernel's own source) on ONE thread, -O3 -march=native:
+                   the honest comparator for CasADi's single-threaded SX VM
+    B2 all_cores   the same with OpenMP over knots on every host core
+       ad_oracle   the forward-AD oracle (the parity checker; slow by construction, secondary)
+    B3 casadi      probed: timed only if `import casadi` works on this box"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    N = settings.horizon_length
+    out = {"unit": "knots/s", "cores": 1, "kind": "port"}
+    from analytic_port_lib import AnalyticPort
     try:
-        from hostemu_lib import HostEmu
-        emu = HostEmu(settings, model)
-        emu.eval(x, p)
-        t0 = time.perf_counter()
-        r2 = 0
-        while time.perf_counter() - t0 < 3.0:
-            emu.eval(x, p)
-            r2 += 1
-        e2 = time.perf_counter() - t0
-        out["analytic_port"] = {"value": settings.horizon_length * r2 / e2, "unit": "knots/s", "cores": 1,
-                                "sample": "%d callback sets of the analytic knot program on the host (tests/hostemu) in %.1f s, 1 thread" % (r2, e2)}
-    except Exception as err:  # noqa: BLE001
-        out["analytic_port"] = {"error": str(err)}
+        port = AnalyticPort(settings, model, native=True)
+        flags = "-O3 -march=native -fopenmp"
+    except Exception:  # noqa: BLE001  (no compiler on the box: the prebuilt portable build)
+        port = AnalyticPort(settings, model, native=False)
+        flags = "-O3 -march=x86-64-v3 -fopenmp (prebuilt)"
+    port.set_params(p)
+    xs = [x + 1e-3 * i * np.random.RandomState(7).standard_normal(x.shape) for i in range(4)]   # fresh x each call, parameters fixed
+    it = [0]
+
+    def one(threads):
+        def f():
+            port.eval(xs[it[0] % 4], threads)
+            it[0] += 1
+        return f
+    reps, el = timed_loop(one(1), 6.0)
+    out["value"] = N * reps / el
+    out["sample"] = ("%d callback sets {f, grad f, g, jac g} of the N=%d workload in %.1f s: the analytic knot program "
+                     "(oracle/analytic_port.cpp, %s), 1 thread" % (reps, N, el, flags))
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # OpenMP over the knots of ONE callback set: the best thread count is reported (N = 100 knots of ~7 us each do not feed every core of
+    # a large host: beyond a few dozen threads the fork/join costs more than it buys); candidates up to the host's core count
+    best = None
+    tried = {}
+    for threads in [t for t in (2, 4, 8, 16, 32) if t <= min(ncpu, port.max_threads)]:
+        for _ in range(30):
+            port.eval(xs[0], threads)   # (the OpenMP team is created on the first parallel region of a thread count)
+        reps, el = timed_loop(one(threads), 1.0)
+        tried[threads] = N * reps / el
+        if best is None or tried[threads] > best[1]:
+            best = (threads, tried[threads], reps, el)
+    if best is not None:
+        out["all_cores"] = {"value": best[1], "unit": "knots/s", "cores": best[0], "nproc": ncpu,
+                            "sample": "%d callback sets in %.1f s, OpenMP over knots, best of the thread counts tried" % (best[2], best[3]),
+                            "knots_per_s_by_threads": tried}
+    else:
+        out["all_cores"] = {"value": out["value"], "unit": "knots/s", "cores": 1, "nproc": ncpu, "sample": "single-core host"}
+    from oracle_lib import Oracle
+    orc = Oracle(settings, model)
+    reps, el = timed_loop(lambda: orc.eval(x, p), 5.0, max_reps=1000)
+    out["ad_oracle"] = {"value": N * reps / el, "unit": "knots/s", "cores": 1,
+                        "sample": "%d callback sets by dense forward AD (oracle/kinodyn_oracle.cpp, the parity checker) in %.1f s" % (reps, el)}
+    try:
+        import casadi  # noqa: F401
+        out["casadi"] = {"status": "importable (version %s) but no build-owned CasADi graph of this NLP is shipped: not timed" % casadi.__version__}
+    except ImportError:
+        out["casadi"] = {"status": "absent: `import casadi` fails on this box; the >= 20x target is quoted against `value` "
+                                   "(CPU restatement, 1 thread), not against CasADi"}
     return out
 
 
 def time_hessian(eng, x_np, knots):
     """ms per evaluation of the exact Hessian of the Lagrangian with device pointers, timed with events on a non-default stream
     (the library maps a null stream pointer to its own stream, which torch events would not see)"""
+    import numpy as np
     import torch
     B = eng.batch
     hn = eng.hess_nnz()
@@ -102,186 +176,284 @@ def time_hessian(eng, x_np, knots):
     stream.synchronize()
     ms = e0.elapsed_time(e1) / reps
     bytes_knot = 8.0 * (189 + 79 + 274 + hn / (knots / B))
-    return {"ms_per_eval": ms, "knots_per_s": knots / (ms * 1e-3), "triplets": int(hn), "algorithmic_bytes_per_knot": bytes_knot,
-            "GBps": bytes_knot * knots / (ms * 1e-3) / 1e9, "kernel": "hipnlp_knot_hess_kernel",
-            "note": "lower-triangle triplets of sigma hess f + lambda^T hess g, block diagonal by knot; device pointers, no PCIe"}
+    res = {"ms_per_eval": ms, "knots_per_s": knots / (ms * 1e-3), "triplets": int(hn), "algorithmic_bytes_per_knot": bytes_knot,
+           "GBps": bytes_knot * knots / (ms * 1e-3) / 1e9, "kernel": "hipnlp_knot_hess_kernel",
+           "note": "lower-triangle triplets of sigma hess f + lambda^T hess g, block diagonal by knot; device pointers, no PCIe"}
+    lam = np.random.RandomState(0).standard_normal((B, eng.m))
+    hv = eng.eval_hess(x_np, 1.0, lam)
+    t0 = time.perf_counter()
+    for _ in range(30):
+        eng.eval_hess(x_np, 1.0, lam, out=hv)
+    res["host_visible_ms"] = 1e3 * (time.perf_counter() - t0) / 30
+    return res
+
+
+def host_visible(eng, x_np, horizon, batch):
+    """The rate at the boundary IPOPT binds: hipnlp_eval with host buffers, per callback kind (the call's non-NULL outputs are its
+    want mask).  x changes on every call (new_x = 1), caller-owned output arrays reused as IPOPT's are.  Never `value`."""
+    import numpy as np
+    rng = np.random.RandomState(11)
+    xs = [x_np + 1e-3 * i * rng.standard_normal(x_np.shape) for i in range(4)]
+    outs = eng.eval(x_np)
+    kinds = {"f": ("f",), "g": ("g",), "grad": ("grad",), "jac": ("jac",), "f+g (trial point)": ("f", "g"), "all": ("f", "grad", "g", "jac")}
+    res = {}
+    reps = 200
+    eng.set_prefetch(())   # exactly what the call asks for crosses PCIe
+    for name, want in kinds.items():
+        out = tuple(o if k in want else None for k, o in zip(("f", "grad", "g", "jac"), outs))
+        for i in range(10):
+            eng.eval(xs[i % 4], want=want, out=out)
+        t0 = time.perf_counter()
+        for i in range(reps):
+            eng.eval(xs[i % 4], want=want, out=out)
+        res[name] = {"ms_per_call": 1e3 * (time.perf_counter() - t0) / reps}
+    for i in range(10):
+        eng.eval_pinned(xs[i % 4])
+    t0 = time.perf_counter()
+    for i in range(reps):
+        eng.eval_pinned(xs[i % 4])
+    res["all (zero-copy views of the pinned block)"] = {"ms_per_call": 1e3 * (time.perf_counter() - t0) / reps}
+    # caller arrays registered with the library once (hipnlp_host_register): the kernel stores straight into them, no staging copy
+    eng.register_outputs(outs)
+    try:
+        for name, want in (("g", ("g",)), ("jac", ("jac",)), ("all", ("f", "grad", "g", "jac"))):
+            out = tuple(o if k in want else None for k, o in zip(("f", "grad", "g", "jac"), outs))
+            for i in range(10):
+                eng.eval(xs[i % 4], want=want, out=out)
+            t0 = time.perf_counter()
+            for i in range(reps):
+                eng.eval(xs[i % 4], want=want, out=out)
+            res[name + " (caller arrays registered: direct kernel stores)"] = {"ms_per_call": 1e3 * (time.perf_counter() - t0) / reps}
+    finally:
+        eng.unregister_outputs(outs)
+    # an IPOPT iterate with the default prefetch set {f, grad, g}: f and g at the trial point (new x), then grad f and jac g at the
+    # accepted point (new_x = 0: grad is already on the host, jac is fetched from HBM)
+    eng.set_prefetch(("f", "grad", "g"))
+    f_, grad_, g_, jac_ = outs
+    for i in range(10):
+        eng.eval(xs[i % 4], want=("f",), out=(f_, None, None, None))
+    t0 = time.perf_counter()
+    for i in range(reps):
+        eng.eval(xs[i % 4], new_x=True, want=("f",), out=(f_, None, None, None))
+        eng.eval(xs[i % 4], new_x=False, want=("g",), out=(None, None, g_, None))
+        eng.eval(xs[i % 4], new_x=False, want=("grad",), out=(None, grad_, None, None))
+        eng.eval(xs[i % 4], new_x=False, want=("jac",), out=(None, None, None, jac_))
+    res["ipopt iterate: eval_f, eval_g, eval_grad_f, eval_jac_g as four calls"] = {"ms_per_call": 1e3 * (time.perf_counter() - t0) / reps}
+    for v in res.values():
+        v["knots_per_s"] = horizon * batch / (v["ms_per_call"] * 1e-3)
+    return res
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--horizon", type=int, default=KNOTS_PER_GPU)
-    ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--workload", choices=["periodic", "single", "stairs"], default="periodic",
-                    help="periodic walking (BASELINE metric, default) | single step (final state / periodicity skipped) | stairs (smooth terrain)")
-    ap.add_argument("--shard", choices=["knots", "batch"], default="batch")
-    ap.add_argument("--also-knot-sharded", action="store_true", help="measure the knot-sharded all-gather path beside `value` even on one GPU (default: whenever WORLD_SIZE > 1)")
-    ap.add_argument("--event-stride", type=int, default=16, help="time every n-th launch of the timed region with HIP events")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-hessian", action="store_true", help="skip the exact-Hessian figure reported beside the callback quartet")
-    ap.add_argument("--force-sharded", action="store_true", help="exercise the sharded path on one GPU (debug)")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        spawn_ranks(args.gpus)     # does not return
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to run (the JSON line's n_gpus must be the number of ranks "
+                         "that ran)\n" % (args.gpus, world))
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from hippopt_amd.hipnlp import HipNlp
+    from hippopt_amd.kinodyn_settings import periodic_step_settings, single_step_settings, stairs_settings
+    from hippopt_amd.robot_model import synthetic_ergocub
+    from hippopt_amd.synthetic import make_workload, place_on_step_flanks
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the engine has no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no device %d (%d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    if args.gpus != world:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+        assert dist.get_world_size() == world
 
     model = synthetic_ergocub()
-    knot_sharded = (world > 1 and args.shard == "knots") or args.force_sharded
-    horizon = args.horizon * world if knot_sharded else args.horizon
-    settings = {"periodic": periodic_step_settings, "single": single_step_settings, "stairs": stairs_settings}[args.workload](horizon, model)
-    seed = 1004 if knot_sharded else 1004 + rank
-    x_np, p_np = make_workload(settings, model, batch=args.batch, seed=seed)
-    if args.workload == "stairs":   # contact points on the flanks of the bumps: no exp-underflow shortcut in the terrain jets
-        place_on_step_flanks(x_np, settings, seed=seed)
+    maker = {"periodic": periodic_step_settings, "single": single_step_settings, "stairs": stairs_settings}[args.workload]
+    shard_mode = args.shard or ("knots" if world > 1 else "batch")
+    knot_sharded_value = (world > 1 and shard_mode == "knots") or args.force_sharded
     nvar = 4  # a few distinct iterates, cycled: "x changes every call, parameters fixed" (SURVEY §8d)
-    rng = np.random.RandomState(5)
-    xs = [torch.from_numpy(x_np + 1e-3 * i * rng.standard_normal(x_np.shape)).to(device) for i in range(nvar)]
-    stream = torch.cuda.current_stream().cuda_stream
-
-    if knot_sharded:
-        from hippopt_amd.sharded import ShardedCallback, hip_shard_backend, hip_shard_info, knot_range
-        assert args.batch == 1, "knot sharding evaluates one trajectory"
-        kb, ke = knot_range(horizon, world, rank)
-        eng = HipNlp(settings, model, batch=1, knot_begin=kb, knot_end=ke, device=local_rank)
-        eng.set_params(p_np)
-        cb = ShardedCallback(horizon, eng.n, eng.m, eng.nnz, hip_shard_info(eng, kb, ke), hip_shard_backend(eng), device)
-
-        def step(i):
-            cb(xs[i % nvar])
-        knots_per_step_total = horizon
-        local_knots = ke - kb
-    else:
-        eng = HipNlp(settings, model, batch=args.batch, device=local_rank)
-        eng.set_params(p_np)
-        f_d = torch.empty(args.batch, dtype=torch.float64, device=device)
-        grad_d = torch.empty(args.batch * eng.n, dtype=torch.float64, device=device)
-        g_d = torch.empty(args.batch * eng.m, dtype=torch.float64, device=device)
-        jac_d = torch.empty(args.batch * eng.nnz, dtype=torch.float64, device=device)
-
-        def step(i):
-            eng.eval_device(xs[i % nvar].data_ptr(), f_d.data_ptr(), grad_d.data_ptr(), g_d.data_ptr(), jac_d.data_ptr(), stream=stream)
-        knots_per_step_total = horizon * args.batch * world
-        local_knots = horizon * args.batch
+    stride = max(1, args.event_stride)
+    work_stream = torch.cuda.Stream(device=device)   # an explicit stream for every library call (NULL would be the handle's own)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    # HIP events around every `stride`-th knot-kernel launch of the timed region: an event record drains the stream and costs
-    # microseconds, bracketing EVERY launch would inflate a 100-knot step by two thirds ("Measuring")
-    # When a step is exactly ONE kernel launch of ~10 us (latency variant of the engine, no sharded reassembly), an event pair around
-    # a single launch would be a quarter of what it measures: the events then bracket RUNS of `stride` consecutive launches
-    # (nothing in between) and the run duration is divided by the run length (dispatch gaps inside a run included).
-    stride = max(1, args.event_stride)
-    single_kernel_step = (not knot_sharded) and eng.kernels_per_eval() == 1
-    if single_kernel_step:
-        eng.profile_begin_runs(max(1, args.steps // (4 * stride)), stride)
-    else:
-        eng.profile_begin((args.steps + stride - 1) // stride, stride)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    fence()
-    el = time.perf_counter() - t0
-    kern_ms, launch_ms, nprof = eng.profile_end()
-    timing = ("HIP events around runs of %d consecutive launches / %d (one kernel launch per step)" % (stride, stride)) if single_kernel_step \
-        else ("HIP events around every %d-th knot-kernel launch" % stride)
-    t = torch.tensor([el], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el = float(t.item())
-
-    shard_resident = None
-    if knot_sharded:
-        # the same sharded evaluation WITHOUT the reassembly: every rank leaves its shard's outputs in its own HBM.  Reported
-        # beside `value` (which includes the all-gather north_star names), like the PCIe-inclusive rate: never as `value`.
-        for i in range(min(args.warmup, 50)):
-            cb.compute_shard(xs[i % nvar], *cb.views)
-        fence()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            cb.compute_shard(xs[i % nvar], *cb.views)
-        fence()
-        t2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+    def max_over_ranks(seconds):
+        t = torch.tensor([seconds], dtype=torch.float64, device=device)
         if world > 1:
-            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
-        shard_resident = {"knots_per_s": knots_per_step_total * args.steps / float(t2.item()), "ms_per_step": 1e3 * float(t2.item()) / args.steps,
-                          "note": "knot shards evaluated, outputs left shard-resident in each rank's HBM (no all-gather / reassembly)"}
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    # the knot-sharded all-gather path of north_star, measured in the same run beside a batch-sharded `value`
-    ks_extra = None
-    if (world > 1 or args.also_knot_sharded) and not knot_sharded and args.batch == 1:
-      try:
-        from hippopt_amd.sharded import ShardedCallback, hip_shard_backend, hip_shard_info, knot_range
+    def workload(horizon, batch, seed):
+        st = maker(horizon, model)
+        x_np, p_np = make_workload(st, model, batch=batch, seed=seed)
+        if args.workload == "stairs":   # contact points on the flanks of the bumps: no exp-underflow shortcut in the terrain jets
+            place_on_step_flanks(x_np, st, seed=seed)
+        rng = np.random.RandomState(5)
+        xs = [torch.from_numpy(x_np + 1e-3 * i * rng.standard_normal(x_np.shape)).to(device) for i in range(nvar)]
+        return st, x_np, p_np, xs
+
+    def run_timed(step, eng, steps, warmup, single_kernel_step):
+        """W warm-up steps, then exactly K steps between two fences; HIP events on the launch stream for the knot kernel."""
+        for i in range(warmup):
+            step(i)
+        fence()
+        # HIP events around every `stride`-th knot-kernel launch: an event record drains the stream and costs microseconds, bracketing
+        # EVERY launch would inflate a 100-knot step by two thirds (DESIGN.md §5 "Measuring").  When a step is exactly ONE kernel
+        # launch of ~10 us the events bracket RUNS of `stride` consecutive launches and the run duration is divided by the run length.
+        if single_kernel_step:
+            eng.profile_begin_runs(max(1, steps // (4 * stride)), stride)
+        else:
+            eng.profile_begin((steps + stride - 1) // stride, stride)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        fence()
+        el = max_over_ranks(time.perf_counter() - t0)
+        kern_ms, launch_ms, nprof = eng.profile_end()
+        return el, kern_ms, launch_ms, nprof
+
+    # ---- independent trajectories: every rank evaluates its own NLP(s), nothing is exchanged ---------------------------------------
+    def run_replicas(steps, warmup):
+        st, x_np, p_np, xs = workload(args.horizon, args.batch, 1004 + rank)
+        eng = HipNlp(st, model, batch=args.batch, device=local_rank)
+        eng.set_params(p_np)
+        f_d = torch.empty(args.batch, dtype=torch.float64, device=device)
+        grad_d = torch.empty(args.batch * eng.n, dtype=torch.float64, device=device)
+        g_d = torch.empty(args.batch * eng.m, dtype=torch.float64, device=device)
+        jac_d = torch.empty(args.batch * eng.nnz, dtype=torch.float64, device=device)
+        torch.cuda.synchronize()
+
+        def step(i):
+            eng.eval_device(xs[i % nvar].data_ptr(), f_d.data_ptr(), grad_d.data_ptr(), g_d.data_ptr(), jac_d.data_ptr(), stream=work_stream.cuda_stream)
+        single = eng.kernels_per_eval() == 1
+        el, kern_ms, launch_ms, nprof = run_timed(step, eng, steps, warmup, single)
+        knots = args.horizon * args.batch * world
+        return {"eng": eng, "st": st, "x_np": x_np, "p_np": p_np, "el": el, "kern_ms": kern_ms, "launch_ms": launch_ms, "nprof": nprof,
+                "knots_per_step": knots, "local_knots": args.horizon * args.batch, "single_kernel_step": single,
+                "parallelism": "independent trajectories x%d, no collective" % world, "horizon": args.horizon}
+
+    # ---- north_star: one trajectory, knot shards, one RCCL all-gather + one-launch reassembly per step ----------------------------
+    def run_knot_sharded(steps, warmup):
+        from hippopt_amd.sharded import HostSink, ShardedCallback, hip_shard_backend, hip_shard_info, knot_range
+        assert args.batch == 1, "knot sharding evaluates one trajectory"
         hz = args.horizon * world
-        st2 = {"periodic": periodic_step_settings, "single": single_step_settings, "stairs": stairs_settings}[args.workload](hz, model)
-        x2, p2 = make_workload(st2, model, batch=1, seed=1004)   # the SAME trajectory on every rank
-        if args.workload == "stairs":
-            place_on_step_flanks(x2, st2, seed=1004)
-        xs2 = [torch.from_numpy(x2 + 1e-3 * i * np.random.RandomState(5).standard_normal(x2.shape)).to(device) for i in range(nvar)]
+        st, x_np, p_np, xs = workload(hz, 1, 1004)   # the SAME trajectory on every rank
         kb, ke = knot_range(hz, world, rank)
-        eng2 = HipNlp(st2, model, batch=1, knot_begin=kb, knot_end=ke, device=local_rank)
-        eng2.set_params(p2)
-        cb2 = ShardedCallback(hz, eng2.n, eng2.m, eng2.nnz, hip_shard_info(eng2, kb, ke), hip_shard_backend(eng2), device)
-        ksteps = max(1, min(args.steps, 500))
-        for i in range(min(args.warmup, 50)):
-            cb2(xs2[i % nvar])
-        fence()
-        t1 = time.perf_counter()
-        for i in range(ksteps):
-            cb2(xs2[i % nvar])
-        fence()
-        t2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+        eng = HipNlp(st, model, batch=1, knot_begin=kb, knot_end=ke, device=local_rank)
+        eng.set_params(p_np)
+        cb = ShardedCallback(hz, eng.n, eng.m, eng.nnz, hip_shard_info(eng, kb, ke), hip_shard_backend(eng), device)
+        torch.cuda.synchronize()
+        # the whole loop runs on the callback's own stream (shard evaluation, all-gather and reassembly are ordered on it; entering it
+        # once here saves two cross-stream event waits per step)
+        with torch.cuda.stream(cb.stream):
+            el, kern_ms, launch_ms, nprof = run_timed(lambda i: cb(xs[i % nvar]), eng, steps, warmup, False)
+        res = {"eng": eng, "st": st, "x_np": x_np, "p_np": p_np, "el": el, "kern_ms": kern_ms, "launch_ms": launch_ms, "nprof": nprof,
+               "knots_per_step": hz, "local_knots": ke - kb, "single_kernel_step": False, "horizon": hz,
+               "parallelism": "knot-sharded x%d (contiguous shooting intervals) + one RCCL all-gather + one-launch reassembly" % world}
+        # beside it: the shards evaluated and left in each rank's HBM (what the exchange costs on top)
+        ksteps = max(1, min(steps, 1000))
+        with torch.cuda.stream(cb.stream):
+            for i in range(min(warmup, 50)):
+                cb.shard_only(xs[i % nvar])
+            fence()
+            t1 = time.perf_counter()
+            for i in range(ksteps):
+                cb.shard_only(xs[i % nvar])
+            fence()
+            e2 = max_over_ranks(time.perf_counter() - t1)
+        res["shard_resident"] = {"knots_per_s": hz * ksteps / e2, "ms_per_step": 1e3 * e2 / ksteps, "steps": ksteps,
+                                 "note": "knot shards evaluated, outputs left shard-resident in each rank's HBM (no all-gather / reassembly)"}
+        # beside it: no collective, every rank's kernel stores its shard straight into ONE shared pinned host buffer (SURVEY §5)
+        try:
+            name = "hipnlp_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid() if world > 1 else os.getpid())
+            sink = HostSink(name, eng.n, eng.m, eng.nnz, world, rank, barrier=(dist.barrier if world > 1 else None))
+            fp, gradp, gp, jacp = sink.pointers()
+
+            def hstep(i):
+                eng.eval_device(xs[i % nvar].data_ptr(), fp, gradp, gp, jacp, stream=work_stream.cuda_stream)
+            for i in range(min(warmup, 50)):
+                hstep(i)
+            fence()
+            t1 = time.perf_counter()
+            for i in range(ksteps):
+                hstep(i)
+                work_stream.synchronize()    # the consumer (IPOPT) needs this callback before it produces the next x
+            fence()
+            e3 = max_over_ranks(time.perf_counter() - t1)
+            res["host_sink"] = {"knots_per_s": hz * ksteps / e3, "ms_per_step": 1e3 * e3 / ksteps, "steps": ksteps,
+                                "f": sink.f(),
+                                "note": "no collective: each rank's knot kernel stores its shard of [grad | jac | g] straight into ONE "
+                                        "shared pinned host buffer (POSIX shared memory registered with HIP by every rank), in reference "
+                                        "order; synchronised after every step"}
+            sink.close()
+        except Exception as err:  # noqa: BLE001  (an extra measurement must not take `value` down with it)
+            res["host_sink"] = {"error": "%s: %s" % (type(err).__name__, err)}
+        return res
+
+    if knot_sharded_value:
+        main_res = run_knot_sharded(args.steps, args.warmup)
+        side = None
         if world > 1:
-            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
-        ks_extra = {"knots_per_s": hz * ksteps / float(t2.item()), "ms_per_step": 1e3 * float(t2.item()) / ksteps, "horizon": hz,
-                    "steps": ksteps, "parallelism": "knot-sharded x%d + all-gather + reassembly" % world,
-                    "note": "ONE trajectory of %d knots, %d per GPU: shard evaluation, one all-gather of the fused shard buffers "
-                            "(RCCL), one-launch reassembly of [grad | jac | g] in reference order on every rank" % (hz, args.horizon)}
-        del cb2, eng2
-      except Exception as err:  # noqa: BLE001  (the extra measurement must not take `value` down with it)
-        ks_extra = {"error": "%s: %s" % (type(err).__name__, err)}
+            try:
+                r = run_replicas(max(1, min(args.steps, 1000)), min(args.warmup, 100))
+                side = {"knots_per_s": r["knots_per_step"] * max(1, min(args.steps, 1000)) / r["el"], "ms_per_step": 1e3 * r["el"] / max(1, min(args.steps, 1000)),
+                        "parallelism": r["parallelism"], "note": "one 100-knot NLP per GPU (BASELINE config 5's batched-guess / MPC shape)"}
+            except Exception as err:  # noqa: BLE001
+                side = {"error": "%s: %s" % (type(err).__name__, err)}
+    else:
+        main_res = run_replicas(args.steps, args.warmup)
+        side = None
+        if world > 1 and args.batch == 1:
+            try:
+                r = run_knot_sharded(max(1, min(args.steps, 500)), min(args.warmup, 50))
+                k = max(1, min(args.steps, 500))
+                side = {"knots_per_s": r["knots_per_step"] * k / r["el"], "ms_per_step": 1e3 * r["el"] / k, "parallelism": r["parallelism"],
+                        "shard_resident": r.get("shard_resident"), "host_sink": r.get("host_sink")}
+            except Exception as err:  # noqa: BLE001
+                side = {"error": "%s: %s" % (type(err).__name__, err)}
 
     if rank == 0:
+        eng, st = main_res["eng"], main_res["st"]
         d = eng.dims
         nnz_knot = int(d.nnz_knot)
         bytes_knot = algorithmic_bytes_per_knot(nnz_knot)
-        bytes_launch = bytes_knot * local_knots
-        achieved = bytes_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        traffic = None
+        local_knots = main_res["local_knots"]
+        kern_ms = main_res["kern_ms"]
+        achieved = bytes_knot * local_knots / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        timing = ("HIP events around runs of %d consecutive launches / %d (one kernel launch per step)" % (stride, stride)) if main_res["single_kernel_step"] \
+            else ("HIP events around every %d-th knot-kernel launch" % stride)
+        # PMC-derived figures cannot be collected inside a timed run (rocprofv3 --pmc passes are separate processes): they are looked up
+        # in the committed summary of the same command and labelled as such
+        traffic = valu = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
-                tj = json.load(open(tp))
-                key = "N%d_B%d" % (horizon, args.batch)
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                ent = json.load(open(tp)).get("%s_N%d_B%d" % (args.workload, main_res["horizon"], args.batch), {})
+                traffic = ent.get("hbm_bytes_per_launch")
+                valu = ent.get("valu_wave_insts_per_knot")
             except Exception:  # noqa: BLE001
-                traffic = None
+                pass
         line = {
             "metric": "NLP callback (f, grad f, g, jac g) throughput, ergoCub-shaped kinodynamic multiple shooting",
-            "value": knots_per_step_total * args.steps / el,
+            "value": main_res["knots_per_step"] * args.steps / main_res["el"],
             "unit": "knots/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * el / args.steps,
+            "ms_per_step": 1e3 * main_res["el"] / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -291,37 +463,56 @@ def main():
                                     "single": "kinodynamic single step on flat ground, N=%d knots per GPU, batch %d (BASELINE config 3 shape)",
                                     "stairs": "kinodynamic walking on stairs (smooth two-step terrain), N=%d knots per GPU, batch %d (BASELINE config 5 shape)"}[args.workload]
                                    % (args.horizon, args.batch),
-                       "horizon": horizon, "batch": args.batch, "knots_per_step": knots_per_step_total,
-                       "parallelism": ("knot-sharded x%d + all-gather" % world) if knot_sharded else ("independent trajectories x%d, no collective" % world),
+                       "horizon": main_res["horizon"], "batch": args.batch, "knots_per_step": main_res["knots_per_step"],
+                       "parallelism": main_res["parallelism"], "ranks": world,
+                       "collective_backend": ("nccl (RCCL), %d ranks" % dist.get_world_size()) if world > 1 else None,
                        "n": int(d.n), "m": int(d.m), "nnz": int(d.nnz), "nnz_per_knot": nnz_knot},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "hipnlp_knot_kernel", "kernel_ms": kern_ms, "launch_ms": launch_ms,
-                         "launches_timed": nprof, "event_stride": stride, "timing": timing, "algorithmic_bytes_per_knot": bytes_knot, "knots_per_launch": local_knots},
+                         "traffic": traffic,
+                         "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command in a separate session; null = not profiled)",
+                         "kernel": "hipnlp_knot_kernel", "kernel_ms": kern_ms, "launch_ms": main_res["launch_ms"],
+                         "launches_timed": main_res["nprof"], "event_stride": stride, "timing": timing,
+                         "algorithmic_bytes_per_knot": bytes_knot, "knots_per_launch": local_knots,
+                         "regime": "latency bound: %d workgroups on 256 CUs, one dependent knot program each" % local_knots if local_knots <= 256 else
+                                   "issue / latency bound (fp64 VALU), not HBM bound: see `valu`"},
         }
-        if shard_resident is not None:
-            line["shard_resident"] = shard_resident
-        if ks_extra is not None:
-            line["knot_sharded_allgather"] = ks_extra
-        if world == 1 and not knot_sharded:
-            # PCIe-inclusive rate of the host-buffer boundary (hipnlp_eval: H2D x, launch, D2H f/grad/g/jac); never `value`
-            outs = eng.eval(x_np)
-            t1 = time.perf_counter()
-            reps = 30
-            for i in range(reps):
-                eng.eval(x_np, out=outs)   # caller-owned output arrays reused, as IPOPT does
-            dt_host = (time.perf_counter() - t1) / reps
-            line["pcie_inclusive"] = {"ms_per_call": 1e3 * dt_host, "knots_per_s": horizon * args.batch / dt_host,
-                                      "note": "hipnlp_eval with host buffers (pinned staging, one fused D2H copy), all four outputs copied back into caller-owned arrays"}
-        if world == 1 and not knot_sharded and not args.no_hessian:
+        if valu and kern_ms > 0:
+            ginst = valu * local_knots / (kern_ms * 1e-3) / 1e9
+            line["roofline"]["valu"] = {"bound": "fp64 valu issue", "achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                                        "frac": ginst / VALU_PEAK_GINST, "valu_wave_insts_per_knot": valu,
+                                        "source": "SQ_INSTS_VALU per launch from profiles/traffic.json (separate rocprofv3 --pmc pass) x this run's kernel rate; "
+                                                  "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 issue cycles per wave64 instruction"}
+        for key in ("shard_resident", "host_sink"):
+            if main_res.get(key) is not None:
+                line[key] = main_res[key]
+        if side is not None:
+            line["independent_trajectories" if knot_sharded_value else "knot_sharded_allgather"] = side
+        solo = world == 1 and not knot_sharded_value
+        if solo and not args.no_host:
+            try:
+                hv = host_visible(eng, main_res["x_np"], args.horizon, args.batch)
+                line["host_visible"] = hv
+                line["pcie_inclusive"] = dict(hv["all"], note="hipnlp_eval with caller-owned host arrays, all four outputs, new x every call: x copied to a pinned "
+                                                             "block the kernel reads directly, outputs stored by the kernel straight into the pinned output block, "
+                                                             "then copied into the caller's arrays; per callback kind in `host_visible`")
+            except Exception as err:  # noqa: BLE001
+                line["host_visible"] = {"error": "%s: %s" % (type(err).__name__, err)}
+        if solo and not args.no_hessian:
             # beside the callback quartet (never `value`): the exact Hessian of the Lagrangian of the same NLP (hipnlp_eval_hess_device)
             try:
-                line["exact_hessian"] = time_hessian(eng, x_np, horizon * args.batch)
+                line["exact_hessian"] = time_hessian(eng, main_res["x_np"], args.horizon * args.batch)
             except Exception as err:  # noqa: BLE001  (reported, never fatal to the bench line)
                 line["exact_hessian"] = {"error": str(err)}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(settings, model, x_np[0], p_np[0])
-            line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
-        print(json.dumps(line))
+            cb = cpu_baseline(st, model, main_res["x_np"][0], main_res["p_np"][0])
+            cb["gpu_over_cpu"] = {"device_resident_vs_1_thread": line["value"] / cb["value"],
+                                  "device_resident_vs_all_cores": line["value"] / cb["all_cores"]["value"]}
+            if "host_visible" in line and "all" in line["host_visible"]:
+                hv_rate = line["host_visible"]["all"]["knots_per_s"]
+                cb["gpu_over_cpu"]["host_visible_vs_1_thread"] = hv_rate / cb["value"]
+                cb["gpu_over_cpu"]["host_visible_vs_all_cores"] = hv_rate / cb["all_cores"]["value"]
+            line["cpu_baseline"] = cb
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -15,7 +15,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <tuple>
@@ -56,6 +58,9 @@ struct KArgs {
     double* cost_terms;     // [batch][NCT]   per-term totals, same writer
     unsigned long long* ticket;   // [batch]  arrivals so far, never reset: launch number `seq` is complete at seq * nk
     int32_t* flag;          // [batch]        generation flag of the non-finite detector: == seq after a launch that produced one
+    int32_t* flag_host;     // [batch] or null: the same flag in pinned host memory (host-buffer path: a plain store of seq — every
+                            //         writer of a launch stores the same value, launches of a handle are stream ordered — so the
+                            //         host needs no copy of the device flag behind the launch)
     int32_t seq, pad_;      // launch number of this handle (1, 2, ...)
     int32_t N, n, m, nnz, knot_begin, nk;
     int64_t jac_stride, jac_off, grad_stride, grad_off;  // output addressing: full arrays (stride nnz / n, offset 0) or shard-local
@@ -364,7 +369,10 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         for (int it = 0; it < GR_ITERS; ++it) { const int i = tid + it * WG; if (i < NXK) out[i] = grvals[it]; }
         if (last && tid < NXG) a.grad[int64_t(b) * a.grad_stride + (int64_t(NXK) * N - a.grad_off) + tid] = 0.0;  // the global variables carry no cost
     }
-    if (anybad && lane == 0) atomicMax(a.flag + b, a.seq);   // generation flag: nothing to reset between launches
+    if (anybad && lane == 0) {   // generation flag: nothing to reset between launches
+        atomicMax(a.flag + b, a.seq);
+        if (a.flag_host) a.flag_host[b] = a.seq;
+    }
 #ifdef HIPNLP_STAMPS
     {
         st_arr[bid] = __builtin_amdgcn_s_memtime();   // after the vote and the store issue
@@ -399,6 +407,7 @@ struct HArgs {
     const double* lambda;   // [batch][m]
     double* hess;           // [batch][nnz_h]
     int32_t* flag;          // [batch] generation flag: == seq after a launch in which the trajectory produced a non-finite value
+    int32_t* flag_host;     // [batch] or null: the same flag in pinned host memory (plain store of seq, see KArgs)
     int32_t N, n, m, knot_begin, seq, pad_;
     int64_t hstride, hoff;  // values of trajectory b start at hess + b * hstride; the handle's first knot block sits at -hoff
 };
@@ -496,7 +505,10 @@ template <int TERRAIN> __global__ __launch_bounds__(256) __attribute__((amdgpu_w
 #pragma unroll
     for (int it = 0; it < HP_ITERS; ++it) if (hp[it] >= 0) { bad |= !isfinite(hv[it]); out[tid + it * WG] = hv[it]; }
     if (hpc >= 0) { bad |= !isfinite(hvc); a.hess[int64_t(b) * a.hstride + (int64_t(cnt) * N - a.hoff) + tid] = hvc; }
-    if (__any(bad) && lane == 0) atomicMax(a.flag + b, a.seq);   // nothing to reset between launches
+    if (__any(bad) && lane == 0) {   // nothing to reset between launches
+        atomicMax(a.flag + b, a.seq);
+        if (a.flag_host) a.flag_host[b] = a.seq;
+    }
 }
 
 
@@ -550,6 +562,20 @@ __global__ __launch_bounds__(256) void hipnlp_reassemble_kernel(const double* ga
 
 thread_local std::string g_create_error;
 
+// host ranges registered through hipnlp_host_register: a caller-owned output array inside one of them is stored to DIRECTLY by the
+// kernel (hipnlp_eval looks its pointers up here), no staging copy
+struct HostRange { char* host; size_t bytes; char* dev; };
+std::mutex g_ranges_mutex;
+std::vector<HostRange> g_ranges;
+double* device_address_of(const void* p, size_t bytes) {
+    if (!p) return nullptr;
+    std::lock_guard<std::mutex> lock(g_ranges_mutex);
+    const char* q = static_cast<const char*>(p);
+    for (const HostRange& r : g_ranges)
+        if (q >= r.host && q + bytes <= r.host + r.bytes) return reinterpret_cast<double*>(r.dev + (q - r.host));
+    return nullptr;
+}
+
 }  // namespace
 
 struct hipnlp_handle {
@@ -580,14 +606,26 @@ struct hipnlp_handle {
     void *d_out = nullptr, *h_out = nullptr;   // output block [f | cost terms | grad | g | jac | flag] and its pinned mirror
     size_t out_bytes = 0;
     int32_t* h_flag = nullptr;
+    // host-buffer path (hipnlp_eval / hipnlp_eval_pinned): the kernel stores the wanted outputs STRAIGHT into the pinned mirror and
+    // reads x straight out of the pinned staging copy — device-visible addresses of the pinned blocks:
+    double *hd_x = nullptr, *hd_f = nullptr, *hd_cost_terms = nullptr, *hd_grad = nullptr, *hd_g = nullptr, *hd_jac = nullptr;
+    int32_t* hd_flag = nullptr;
+    bool x_zero_copy = true;      // the kernel reads x from pinned host memory (small problems) instead of an H2D copy first
+    unsigned prefetch = HIPNLP_WANT_F | HIPNLP_WANT_GRAD | HIPNLP_WANT_G;   // brought to the host by every new evaluation
+    unsigned on_host = 0;         // outputs of the cached result that are in the pinned block
+    unsigned gone = 0;            // outputs of the cached result the kernel stored into registered caller arrays (in neither block)
+    bool time_host = false;       // bracket host-path launches with events (hipnlp_set_host_timing)
+    double host_us[4] = {0, 0, 0, 0};   // wall clock of the last host-path evaluation: x staging, enqueue, wait for the GPU, copies out
     std::vector<double> p;
     bool params_set = false, have_result = false;
     // exact Hessian (allocated on first use)
     HessLayout HL;
     int hess_state = 0;   // 0: not built yet, 1: ready, -1: not available (HL.error)
+    bool hess_layout_built = false, hess_layout_ok = false;
     HessTables* d_ht = nullptr;
     double *d_sigma = nullptr, *d_lambda = nullptr /* inside the d_sigma block */, *d_hess = nullptr, *h_hess = nullptr, *h_sl = nullptr;
-    int32_t *d_hflag = nullptr, *h_hflag = nullptr;
+    int32_t *d_hflag = nullptr, *h_hflag = nullptr, *hd_hflag = nullptr /* device-visible address of h_hflag */;
+    double* hd_hess = nullptr;   // device-visible address of h_hess
     int32_t hseq = 0;   // Hessian launches so far (generation of d_hflag)
     std::string err;
 };
@@ -680,11 +718,25 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     };
     std::tie(h->d_f, h->d_cost_terms, h->d_grad, h->d_g, h->d_jac, h->d_flag) = carve(static_cast<char*>(h->d_out));
     std::tie(h->h_f, h->h_cost_terms, h->h_grad, h->h_g, h->h_jac, h->h_flag) = carve(static_cast<char*>(h->h_out));
+    {
+        void* od = nullptr;
+        CREATE_TRY(hipHostGetDevicePointer(&od, h->h_out, 0));
+        std::tie(h->hd_f, h->hd_cost_terms, h->hd_grad, h->hd_g, h->hd_jac, h->hd_flag) = carve(static_cast<char*>(od));
+        std::memset(h->h_out, 0, h->out_bytes);
+    }
     CREATE_TRY(hipMalloc(&h->d_cost_knot, B * size_t(h->nk) * NCT * sizeof(double)));
     CREATE_TRY(hipMalloc(&h->d_ticket, B * sizeof(unsigned long long)));
     CREATE_TRY(hipMemset(h->d_ticket, 0, B * sizeof(unsigned long long)));
     CREATE_TRY(hipMemset(h->d_flag, 0, B * sizeof(int32_t)));
     CREATE_TRY(hipHostMalloc(&h->h_x, B * n * sizeof(double)));
+    {
+        void* xd = nullptr;
+        CREATE_TRY(hipHostGetDevicePointer(&xd, h->h_x, 0));
+        h->hd_x = static_cast<double*>(xd);
+        // x over PCIe by the kernel itself (the halo record is read twice): wins while x is small (151 KB at 100 knots: ~5 us
+        // less than the copy command, profiles/r02_pcie_probe.txt); big batches go through one H2D copy and the L2
+        h->x_zero_copy = B * n * sizeof(double) <= (size_t(1) << 20);
+    }
     CREATE_TRY(hipMemset(h->d_g, 0, B * m * sizeof(double)));
     CREATE_TRY(hipMemset(h->d_jac, 0, B * nnz * sizeof(double)));
     CREATE_TRY(hipMemset(h->d_grad, 0, B * n * sizeof(double)));
@@ -781,7 +833,7 @@ int hipnlp_sparsity(const hipnlp_handle* h, int32_t* irow, int32_t* jcol) {
 // 100-knot callback.  The host-buffer path (hipnlp_eval, PCIe bound anyway) is always timed; the device path is timed only for
 // the launches an armed profile selects (every stride-th launch), so that measuring does not change what is measured.
 static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, hipStream_t s,
-                  double* g_stage = nullptr, bool shard_local = false, bool always_timed = false) {
+                  double* g_stage = nullptr, bool shard_local = false, bool always_timed = false, bool host_block = false) {
     KArgs a;
     a.tb = h->d_tb; a.x = x_dev; a.pk = h->d_pk; a.gp = h->d_gp;
     a.g = g_dev; a.jac = jac_dev; a.grad = grad_dev; a.g_stage = g_stage;
@@ -792,7 +844,10 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     } else {
         a.jac_stride = h->L.nnz; a.jac_off = 0; a.grad_stride = h->L.n; a.grad_off = 0;
     }
-    a.cost_knot = h->d_cost_knot; a.f = f_dev; a.cost_terms = h->d_cost_terms; a.ticket = h->d_ticket; a.flag = h->d_flag;
+    a.cost_knot = h->d_cost_knot; a.f = f_dev; a.ticket = h->d_ticket; a.flag = h->d_flag;
+    // host-buffer path: per-term costs (96 B per trajectory) and the non-finite flag go straight to the pinned block
+    a.cost_terms = host_block ? h->hd_cost_terms : h->d_cost_terms;
+    a.flag_host = host_block ? h->hd_flag : nullptr;
     a.seq = ++h->seq; a.pad_ = 0;
     a.N = h->L.N; a.n = h->L.n; a.m = h->L.m; a.nnz = h->L.nnz; a.knot_begin = h->kb; a.nk = h->nk;
     bool prof = false, run_first = false, run_last = false;
@@ -822,7 +877,7 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 1)], s));
     if (!h->wide)
-        hipLaunchKernelGGL(hipnlp_reduce_kernel, dim3(unsigned(h->batch)), dim3(RWG), 0, s, (const double*)h->d_cost_knot, h->nk, f_dev, h->d_cost_terms);
+        hipLaunchKernelGGL(hipnlp_reduce_kernel, dim3(unsigned(h->batch)), dim3(RWG), 0, s, (const double*)h->d_cost_knot, h->nk, f_dev, a.cost_terms);
     if (timed) HIP_TRY(h, hipEventRecord(e2, s));
     if (run_last) {
         HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 1)], s));
@@ -840,25 +895,34 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
 // ---- exact Hessian of the Lagrangian (IPOPT eval_h) ----------------------------------------------------------------------------
 static int hess_prepare(hipnlp_handle* h) {
     if (h->hess_state == 1) return HIPNLP_OK;
-    if (h->hess_state == 0) {
-        h->hess_state = h->HL.build(h->d.settings, h->kt) ? 1 : -1;
-        if (h->hess_state == 1) {
-            HIP_TRY(h, hipSetDevice(h->dev));
-            HessTables* t = new HessTables();
-            std::memset(t, 0, sizeof(HessTables));
-            for (int i = 0; i < hk::COUNT; ++i) t->perm[i] = i < h->HL.nnz_knot ? h->HL.perm[size_t(i)] : -1;
-            for (int i = 0; i < 84; ++i) t->perm_couple[i] = i < h->HL.n_couple ? h->HL.perm_couple[size_t(i)] : -1;
-            t->nnz_knot = h->HL.nnz_knot; t->n_couple = h->HL.n_couple;
-            hipError_t e = hipMalloc(&h->d_ht, sizeof(HessTables));
-            if (e == hipSuccess) e = hipMemcpy(h->d_ht, t, sizeof(HessTables), hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = hipMalloc(&h->d_hflag, size_t(h->batch) * sizeof(int32_t));
-            if (e == hipSuccess) e = hipMemset(h->d_hflag, 0, size_t(h->batch) * sizeof(int32_t));
-            if (e == hipSuccess) e = hipHostMalloc(&h->h_hflag, size_t(h->batch) * sizeof(int32_t));
-            delete t;
-            if (e != hipSuccess) { h->hess_state = 0; h->err = std::string("Hessian tables: ") + hipGetErrorString(e); return HIPNLP_E_NODEVICE; }
-        }
+    if (h->hess_state == 0 && !h->hess_layout_built) {
+        h->hess_layout_ok = h->HL.build(h->d.settings, h->kt);
+        h->hess_layout_built = true;
     }
-    if (h->hess_state != 1) { h->err = h->HL.error; return HIPNLP_E_UNSUPPORTED; }
+    if (!h->hess_layout_ok) { h->hess_state = -1; h->err = h->HL.error; return HIPNLP_E_UNSUPPORTED; }
+    // device side: every piece is allocated at most once; a failure leaves the pieces that exist for the next attempt
+    HIP_TRY(h, hipSetDevice(h->dev));
+    if (!h->d_ht) HIP_TRY(h, hipMalloc(&h->d_ht, sizeof(HessTables)));
+    if (!h->d_hflag) {
+        HIP_TRY(h, hipMalloc(&h->d_hflag, size_t(h->batch) * sizeof(int32_t)));
+        HIP_TRY(h, hipMemset(h->d_hflag, 0, size_t(h->batch) * sizeof(int32_t)));
+    }
+    if (!h->h_hflag) {
+        HIP_TRY(h, hipHostMalloc(&h->h_hflag, size_t(h->batch) * sizeof(int32_t)));
+        std::memset(h->h_hflag, 0, size_t(h->batch) * sizeof(int32_t));
+        void* fd = nullptr;
+        HIP_TRY(h, hipHostGetDevicePointer(&fd, h->h_hflag, 0));
+        h->hd_hflag = static_cast<int32_t*>(fd);
+    }
+    HessTables* t = new HessTables();
+    std::memset(t, 0, sizeof(HessTables));
+    for (int i = 0; i < hk::COUNT; ++i) t->perm[i] = i < h->HL.nnz_knot ? h->HL.perm[size_t(i)] : -1;
+    for (int i = 0; i < 84; ++i) t->perm_couple[i] = i < h->HL.n_couple ? h->HL.perm_couple[size_t(i)] : -1;
+    t->nnz_knot = h->HL.nnz_knot; t->n_couple = h->HL.n_couple;
+    const hipError_t e = hipMemcpy(h->d_ht, t, sizeof(HessTables), hipMemcpyHostToDevice);
+    delete t;
+    if (e != hipSuccess) { h->err = std::string("Hessian tables: ") + hipGetErrorString(e); return HIPNLP_E_NODEVICE; }
+    h->hess_state = 1;
     return HIPNLP_OK;
 }
 // entries of THIS handle's knots (a shard handle owns the blocks of its knots; the coupling entries belong to the last knot)
@@ -882,10 +946,12 @@ int hipnlp_hess_sparsity(hipnlp_handle* h, int32_t* irow, int32_t* jcol) {
     std::memcpy(jcol, jc.data() + off, size_t(cnt) * sizeof(int32_t));
     return HIPNLP_OK;
 }
-static int hess_launch(hipnlp_handle* h, const double* x_dev, const double* sigma_dev, const double* lambda_dev, double* hess_dev, hipStream_t s) {
+static int hess_launch(hipnlp_handle* h, const double* x_dev, const double* sigma_dev, const double* lambda_dev, double* hess_dev, hipStream_t s,
+                       bool host_block = false) {
     HArgs a;
     a.tb = h->d_tb; a.ht = h->d_ht; a.x = x_dev; a.pk = h->d_pk; a.gp = h->d_gp;
     a.sigma = sigma_dev; a.lambda = lambda_dev; a.hess = hess_dev; a.flag = h->d_hflag;
+    a.flag_host = host_block ? h->hd_hflag : nullptr;
     a.N = h->L.N; a.n = h->L.n; a.m = h->L.m; a.knot_begin = h->kb;
     a.hstride = hess_count(h); a.hoff = h->HL.knot_base(h->kb);
     a.seq = ++h->hseq; a.pad_ = 0;
@@ -911,23 +977,30 @@ int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor
     if (rc != HIPNLP_OK) return rc;
     const size_t B = size_t(h->batch), n = size_t(h->L.n), m = size_t(h->L.m), hn = size_t(hess_count(h));
     HIP_TRY(h, hipSetDevice(h->dev));
-    if (!h->d_hess) {   // inputs [sigma | lambda] in one device block with a pinned mirror: one H2D copy beside the one of x
-        HIP_TRY(h, hipMalloc(&h->d_sigma, B * (1 + m) * sizeof(double)));
-        h->d_lambda = h->d_sigma + B;
-        HIP_TRY(h, hipHostMalloc(&h->h_sl, B * (1 + m) * sizeof(double)));
-        HIP_TRY(h, hipMalloc(&h->d_hess, B * hn * sizeof(double)));
+    // inputs [sigma | lambda] in one device block with a pinned mirror: one H2D copy (the kernel gathers the multipliers through the
+    // slot -> row map: scattered 8-byte reads belong in HBM, not on PCIe); every piece allocated at most once
+    if (!h->d_sigma) { HIP_TRY(h, hipMalloc(&h->d_sigma, B * (1 + m) * sizeof(double))); h->d_lambda = h->d_sigma + B; }
+    if (!h->h_sl) HIP_TRY(h, hipHostMalloc(&h->h_sl, B * (1 + m) * sizeof(double)));
+    if (!h->d_hess) HIP_TRY(h, hipMalloc(&h->d_hess, B * hn * sizeof(double)));
+    if (!h->h_hess) {
         HIP_TRY(h, hipHostMalloc(&h->h_hess, B * hn * sizeof(double)));
+        void* hd = nullptr;
+        HIP_TRY(h, hipHostGetDevicePointer(&hd, h->h_hess, 0));
+        h->hd_hess = static_cast<double*>(hd);
     }
     h->have_result = false;   // (the staging copy of x is shared with hipnlp_eval)
     std::memcpy(h->h_x, x, B * n * sizeof(double));
     std::memcpy(h->h_sl, obj_factor, B * sizeof(double));
     std::memcpy(h->h_sl + B, lambda, B * m * sizeof(double));
-    HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_x, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const double* xsrc = h->hd_x;   // x: read by the kernel straight from the pinned staging copy, as in hipnlp_eval
+    if (!h->x_zero_copy) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_x, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        xsrc = h->d_x;
+    }
     HIP_TRY(h, hipMemcpyAsync(h->d_sigma, h->h_sl, B * (1 + m) * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    rc = hess_launch(h, h->d_x, h->d_sigma, h->d_lambda, h->d_hess, h->stream);
+    // the values leave the kernel as PCIe stores into the pinned block: no copy command behind the launch
+    rc = hess_launch(h, xsrc, h->d_sigma, h->d_lambda, h->hd_hess, h->stream, true);
     if (rc != HIPNLP_OK) return rc;
-    HIP_TRY(h, hipMemcpyAsync(h->h_hess, h->d_hess, B * hn * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->h_hflag, h->d_hflag, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     std::memcpy(hess, h->h_hess, B * hn * sizeof(double));
     for (size_t b = 0; b < B; ++b)
@@ -961,33 +1034,150 @@ int hipnlp_stage_rows(const hipnlp_handle* h, int k, int32_t* rows) {
     return HIPNLP_OK;
 }
 
-int hipnlp_eval(hipnlp_handle* h, const double* x, int new_x, double* f, double* grad_f, double* g, double* jac) {
-    if (!h || !x) return HIPNLP_E_INVALID;
-    if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
+// Host-buffer path.  Makes the outputs named by `want` of the evaluation at x present in the pinned block.
+// A NEW evaluation: x is copied into the pinned staging block (the kernel reads it from there), ONE kernel launch evaluates all four
+// outputs; the ones in want | prefetch are stored by the kernel straight into the pinned block (PCIe stores, no copy command, no
+// staging copy), the others stay in device memory.  A cached evaluation (new_x = 0): outputs not on the host yet are fetched from
+// the device copies with one asynchronous copy each.  (Measured on MI355X, profiles/r02_pcie_probe.txt: launch + synchronise 11.6 us;
+// kernel stores to pinned memory 56 GB/s; the same bytes through device memory + hipMemcpyAsync: + 10 us.)
+struct HostDest { double *f = nullptr, *grad = nullptr, *g = nullptr, *jac = nullptr; };   // device-visible addresses of registered caller arrays (or null)
+static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned want, const HostDest& dst = HostDest(), unsigned* direct = nullptr) {
     const size_t B = size_t(h->batch), n = size_t(h->L.n), m = size_t(h->L.m), nnz = size_t(h->L.nnz);
+    if (direct) *direct = 0;
     if (new_x || !h->have_result) {
         HIP_TRY(h, hipSetDevice(h->dev));
-        std::memcpy(h->h_x, x, B * n * sizeof(double));
-        HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_x, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        int rc = launch(h, h->d_x, h->d_f, h->d_grad, h->d_g, h->d_jac, h->stream, nullptr, false, true);
+        const unsigned to_host = (want | h->prefetch) & HIPNLP_WANT_ALL;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (x != h->h_x) std::memcpy(h->h_x, x, B * n * sizeof(double));
+        const auto t1 = std::chrono::steady_clock::now();
+        const double* xsrc = h->hd_x;
+        if (!h->x_zero_copy) {
+            HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_x, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            xsrc = h->d_x;
+        }
+        h->have_result = false;
+        // a wanted output whose caller array is registered leaves the kernel straight into that array (and is then NOT in the pinned
+        // block: a later new_x = 0 request for it is served from the device copy... which it is not in either, so such an output is
+        // simply marked absent and re-evaluated on demand — IPOPT never asks twice for the same output at one x)
+        unsigned dmask = 0;
+        double* of = (to_host & HIPNLP_WANT_F) ? h->hd_f : h->d_f;
+        double* ograd = (to_host & HIPNLP_WANT_GRAD) ? h->hd_grad : h->d_grad;
+        double* og = (to_host & HIPNLP_WANT_G) ? h->hd_g : h->d_g;
+        double* ojac = (to_host & HIPNLP_WANT_JAC) ? h->hd_jac : h->d_jac;
+        if ((want & HIPNLP_WANT_GRAD) && dst.grad) { ograd = dst.grad; dmask |= HIPNLP_WANT_GRAD; }
+        if ((want & HIPNLP_WANT_G) && dst.g) { og = dst.g; dmask |= HIPNLP_WANT_G; }
+        if ((want & HIPNLP_WANT_JAC) && dst.jac) { ojac = dst.jac; dmask |= HIPNLP_WANT_JAC; }
+        int rc = launch(h, xsrc, of, ograd, og, ojac, h->stream, nullptr, false, h->time_host, true);
         if (rc != HIPNLP_OK) return rc;
-        HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, h->out_bytes, hipMemcpyDeviceToHost, h->stream));   // all outputs, one copy
+        const auto t2 = std::chrono::steady_clock::now();
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+        const auto t3 = std::chrono::steady_clock::now();
+        h->host_us[0] = std::chrono::duration<double, std::micro>(t1 - t0).count();
+        h->host_us[1] = std::chrono::duration<double, std::micro>(t2 - t1).count();
+        h->host_us[2] = std::chrono::duration<double, std::micro>(t3 - t2).count();
         h->have_result = true;
         h->seq_result = h->seq;
+        h->on_host = to_host & ~dmask;
+        h->gone = dmask;
+        if (direct) *direct = dmask;
     }
-    if (f) std::memcpy(f, h->h_f, B * sizeof(double));
-    if (grad_f) std::memcpy(grad_f, h->h_grad, B * n * sizeof(double));
-    if (g) std::memcpy(g, h->h_g, B * m * sizeof(double));
-    if (jac) std::memcpy(jac, h->h_jac, B * nnz * sizeof(double));
-    for (size_t b = 0; b < B; ++b)
+    unsigned missing = want & HIPNLP_WANT_ALL & ~h->on_host & ~(direct ? *direct : 0u);
+    if (missing & h->gone) {   // stored into a caller array by the evaluation and now asked for again: evaluate again (rare)
+        h->have_result = false;
+        return host_evaluate(h, h->h_x, 1, want, dst, direct);
+    }
+    if (missing) {
+        HIP_TRY(h, hipSetDevice(h->dev));
+        if (missing & HIPNLP_WANT_F) HIP_TRY(h, hipMemcpyAsync(h->h_f, h->d_f, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (missing & HIPNLP_WANT_GRAD) HIP_TRY(h, hipMemcpyAsync(h->h_grad, h->d_grad, B * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (missing & HIPNLP_WANT_G) HIP_TRY(h, hipMemcpyAsync(h->h_g, h->d_g, B * m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (missing & HIPNLP_WANT_JAC) HIP_TRY(h, hipMemcpyAsync(h->h_jac, h->d_jac, B * nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->on_host |= missing;
+    }
+    return HIPNLP_OK;
+}
+static int host_numeric_status(hipnlp_handle* h) {
+    for (int b = 0; b < h->batch; ++b)
         if (h->h_flag[b] == h->seq_result) { h->err = "non-finite value produced by the evaluation"; return HIPNLP_E_NUMERIC; }
     return HIPNLP_OK;
 }
 
+int hipnlp_eval(hipnlp_handle* h, const double* x, int new_x, double* f, double* grad_f, double* g, double* jac) {
+    if (!h || !x) return HIPNLP_E_INVALID;
+    if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
+    const size_t B = size_t(h->batch), n = size_t(h->L.n), m = size_t(h->L.m), nnz = size_t(h->L.nnz);
+    const unsigned want = (f ? HIPNLP_WANT_F : 0u) | (grad_f ? HIPNLP_WANT_GRAD : 0u) | (g ? HIPNLP_WANT_G : 0u) | (jac ? HIPNLP_WANT_JAC : 0u);
+    HostDest dst;   // caller arrays inside a range registered with hipnlp_host_register: direct kernel outputs
+    dst.grad = device_address_of(grad_f, B * n * sizeof(double));
+    dst.g = device_address_of(g, B * m * sizeof(double));
+    dst.jac = device_address_of(jac, B * nnz * sizeof(double));
+    unsigned direct = 0;
+    const int rc = host_evaluate(h, x, new_x, want, dst, &direct);
+    if (rc != HIPNLP_OK) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (f) std::memcpy(f, h->h_f, B * sizeof(double));
+    if (grad_f && !(direct & HIPNLP_WANT_GRAD)) std::memcpy(grad_f, h->h_grad, B * n * sizeof(double));
+    if (g && !(direct & HIPNLP_WANT_G)) std::memcpy(g, h->h_g, B * m * sizeof(double));
+    if (jac && !(direct & HIPNLP_WANT_JAC)) std::memcpy(jac, h->h_jac, B * nnz * sizeof(double));
+    h->host_us[3] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    return host_numeric_status(h);   // (the outputs are copied first: the caller may want to look at the NaNs, as IPOPT does)
+}
+
+int hipnlp_eval_pinned(hipnlp_handle* h, const double* x, int new_x, unsigned want, const double** f, const double** grad_f, const double** g,
+                       const double** jac) {
+    if (!h || !x) return HIPNLP_E_INVALID;
+    if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
+    const int rc = host_evaluate(h, x, new_x, want);
+    if (rc != HIPNLP_OK) return rc;
+    if (f) *f = (want & HIPNLP_WANT_F) ? h->h_f : nullptr;
+    if (grad_f) *grad_f = (want & HIPNLP_WANT_GRAD) ? h->h_grad : nullptr;
+    if (g) *g = (want & HIPNLP_WANT_G) ? h->h_g : nullptr;
+    if (jac) *jac = (want & HIPNLP_WANT_JAC) ? h->h_jac : nullptr;
+    return host_numeric_status(h);
+}
+
+int hipnlp_set_prefetch(hipnlp_handle* h, unsigned mask) {
+    if (!h || (mask & ~HIPNLP_WANT_ALL)) return HIPNLP_E_INVALID;
+    h->prefetch = mask;
+    return HIPNLP_OK;
+}
+
+int hipnlp_host_breakdown(const hipnlp_handle* h, double* us) {
+    if (!h || !us) return HIPNLP_E_INVALID;
+    for (int i = 0; i < 4; ++i) us[i] = h->host_us[i];
+    return HIPNLP_OK;
+}
+
+int hipnlp_set_host_timing(hipnlp_handle* h, int on) {
+    if (!h) return HIPNLP_E_INVALID;
+    h->time_host = on != 0;
+    return HIPNLP_OK;
+}
+
+int hipnlp_host_register(void* p, size_t bytes, void** dev_ptr) {
+    if (!p || !bytes) return HIPNLP_E_INVALID;
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) return HIPNLP_E_NODEVICE;
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) { (void)hipHostUnregister(p); return HIPNLP_E_NODEVICE; }
+    if (dev_ptr) *dev_ptr = d;
+    std::lock_guard<std::mutex> lock(g_ranges_mutex);
+    g_ranges.push_back(HostRange{static_cast<char*>(p), bytes, static_cast<char*>(d)});
+    return HIPNLP_OK;
+}
+int hipnlp_host_unregister(void* p) {
+    if (!p) return HIPNLP_E_INVALID;
+    {
+        std::lock_guard<std::mutex> lock(g_ranges_mutex);
+        for (size_t i = 0; i < g_ranges.size(); ++i)
+            if (g_ranges[i].host == static_cast<char*>(p)) { g_ranges.erase(g_ranges.begin() + long(i)); break; }
+    }
+    return hipHostUnregister(p) == hipSuccess ? HIPNLP_OK : HIPNLP_E_NODEVICE;
+}
+
 int hipnlp_cost_terms(hipnlp_handle* h, double* values) {
     if (!h || !values) return HIPNLP_E_INVALID;
-    if (!h->have_result) {
+    if (!h->have_result) {   // a device-path evaluation: its per-term costs are in device memory (the host path stores them straight to the pinned block)
         HIP_TRY(h, hipSetDevice(h->dev));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         HIP_TRY(h, hipMemcpy(h->h_cost_terms, h->d_cost_terms, size_t(h->batch) * NCT * sizeof(double), hipMemcpyDeviceToHost));

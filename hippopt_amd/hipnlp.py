@@ -21,6 +21,8 @@ EXPORTS = [
     "hipnlp_last_kernel_ms", "hipnlp_profile_begin", "hipnlp_profile_end", "hipnlp_kernels_per_eval", "hipnlp_profile_begin_runs",
     "hipnlp_eval_device_shard", "hipnlp_stage_rows", "hipnlp_reassemble",
     "hipnlp_hess_nnz", "hipnlp_hess_sparsity", "hipnlp_eval_hess", "hipnlp_eval_hess_device",
+    "hipnlp_eval_pinned", "hipnlp_set_prefetch", "hipnlp_set_host_timing", "hipnlp_host_register", "hipnlp_host_unregister",
+    "hipnlp_host_breakdown",
     "hipnlp_pose_create", "hipnlp_pose_destroy", "hipnlp_pose_last_error", "hipnlp_pose_get_dims", "hipnlp_pose_set_params",
     "hipnlp_pose_bounds", "hipnlp_pose_sparsity", "hipnlp_pose_eval", "hipnlp_pose_eval_device", "hipnlp_pose_cost_terms",
     "hipnlp_pose_cost_term_name", "hipnlp_pose_num_row_blocks", "hipnlp_pose_row_block", "hipnlp_pose_last_kernel_ms",
@@ -105,6 +107,12 @@ def load_library():
     lib.hipnlp_kernels_per_eval.argtypes = [vp]
     lib.hipnlp_profile_begin_runs.argtypes = [vp, C.c_int, C.c_int]
     lib.hipnlp_reassemble.argtypes = [vp, vp, vp, C.c_int64, C.c_int, C.c_int64, vp, vp]
+    lib.hipnlp_eval_pinned.argtypes = [vp, dp, C.c_int, C.c_uint, C.POINTER(dp), C.POINTER(dp), C.POINTER(dp), C.POINTER(dp)]
+    lib.hipnlp_set_prefetch.argtypes = [vp, C.c_uint]
+    lib.hipnlp_set_host_timing.argtypes = [vp, C.c_int]
+    lib.hipnlp_host_register.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.hipnlp_host_unregister.argtypes = [vp]
+    lib.hipnlp_host_breakdown.argtypes = [vp, dp]
     _lib = lib
     return lib
 
@@ -182,10 +190,13 @@ class HipNlp:
             out.append((name.value.decode(), a.value, b.value, c.value, d.value))
         return out
 
-    def eval(self, x, new_x=True, want=("f", "grad", "g", "jac"), out=None):
-        """Host-buffer callback set.  Returns (f[batch], grad[batch,n], g[batch,m], jac[batch,nnz]).
+    def eval(self, x, new_x=True, want=("f", "grad", "g", "jac"), out=None, nan_ok=False):
+        """Host-buffer callback set.  Returns (f[batch], grad[batch,n], g[batch,m], jac[batch,nnz]); only the outputs in `want`
+        cross PCIe (the others are None).
         out: (f, grad, g, jac) arrays of a previous call to fill again (what a C caller such as IPOPT does with its own arrays:
-        fresh 1 MB numpy arrays cost an mmap and their page faults on every call)."""
+        fresh 1 MB numpy arrays cost an mmap and their page faults on every call).
+        nan_ok: a non-finite evaluation (HIPNLP_E_NUMERIC) returns the arrays as filled — NaN/Inf included — instead of raising:
+        what an NLP driver wants at a line-search trial point (the reference hands CasADi's NaNs to IPOPT, which cuts the step)."""
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.batch, self.n)
         if out is not None:
             f, grad, g, jac = out
@@ -194,8 +205,56 @@ class HipNlp:
             grad = np.empty((self.batch, self.n)) if "grad" in want else None
             g = np.empty((self.batch, self.m)) if "g" in want else None
             jac = np.empty((self.batch, self.nnz)) if "jac" in want else None
-        self._check(self.lib.hipnlp_eval(self.h, _dp(x), 1 if new_x else 0, _dp(f), _dp(grad), _dp(g), _dp(jac)))
+        rc = self.lib.hipnlp_eval(self.h, _dp(x), 1 if new_x else 0, _dp(f), _dp(grad), _dp(g), _dp(jac))
+        if not (nan_ok and rc == -5):
+            self._check(rc)
         return f, grad, g, jac
+
+    WANT = {"f": 1, "grad": 2, "g": 4, "jac": 8}
+
+    def eval_pinned(self, x, new_x=True, want=("f", "grad", "g", "jac")):
+        """Zero-copy host callback set: (f[batch], grad[batch,n], g[batch,m], jac[batch,nnz]) as numpy VIEWS of the library's pinned
+        output block (None for outputs not in `want`); valid until the next evaluation on this handle.  A non-finite evaluation
+        raises HipNlpError(-5) with the views left in `self.last_views` (the caller may hand the NaNs on, as IPOPT expects)."""
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.batch, self.n)
+        mask = 0
+        for w in want:
+            mask |= self.WANT[w]
+        ptrs = [C.POINTER(C.c_double)() for _ in range(4)]
+        rc = self.lib.hipnlp_eval_pinned(self.h, _dp(x), 1 if new_x else 0, mask, *[C.byref(q) for q in ptrs])
+        shapes = ((self.batch,), (self.batch, self.n), (self.batch, self.m), (self.batch, self.nnz))
+        self.last_views = tuple(np.ctypeslib.as_array(q, shape=sh) if q else None for q, sh in zip(ptrs, shapes)) if rc in (0, -5) else None
+        self._check(rc)
+        return self.last_views
+
+    def set_prefetch(self, want=("f", "grad", "g")):
+        """outputs every new evaluation brings to the host besides the ones its call asks for (hipnlp_set_prefetch)"""
+        mask = 0
+        for w in want:
+            mask |= self.WANT[w]
+        self._check(self.lib.hipnlp_set_prefetch(self.h, mask))
+
+    def host_breakdown(self):
+        """us of the last host-path evaluation: (x staging copy, enqueue, wait for the GPU, copies into unregistered caller arrays)"""
+        us = np.zeros(4)
+        self._check(self.lib.hipnlp_host_breakdown(self.h, _dp(us)))
+        return us
+
+    def register_outputs(self, arrays):
+        """hipnlp_host_register for each numpy array: the kernel then stores straight into them when they are passed as `out`"""
+        for a in arrays:
+            if a is not None and a.nbytes >= 4096:
+                rc = self.lib.hipnlp_host_register(C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes), None)
+                if rc != 0:
+                    raise HipNlpError(rc, "hipnlp_host_register failed")
+
+    def unregister_outputs(self, arrays):
+        for a in arrays:
+            if a is not None and a.nbytes >= 4096:
+                self.lib.hipnlp_host_unregister(C.c_void_p(a.ctypes.data))
+
+    def set_host_timing(self, on=True):
+        self._check(self.lib.hipnlp_set_host_timing(self.h, 1 if on else 0))
 
     def eval_device(self, x_ptr, f_ptr=0, grad_ptr=0, g_ptr=0, jac_ptr=0, stream=0):
         """Device-pointer variant (ints from tensor.data_ptr()); asynchronous on `stream`."""

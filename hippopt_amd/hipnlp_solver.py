@@ -52,8 +52,14 @@ class _PoseEngine:
     def sparsity(self):
         return self._pose.sparsity()
 
-    def eval(self, x, new_x=True, want=("f", "grad", "g", "jac")):
-        return self._pose.eval(x)   # (81 variables: always evaluated)
+    def eval(self, x, new_x=True, want=("f", "grad", "g", "jac"), nan_ok=False):
+        try:
+            return self._pose.eval(x)   # (81 variables: always evaluated)
+        except HipNlpError as err:
+            if not (nan_ok and err.code == -5):
+                raise
+            nan = np.full
+            return nan(1, np.nan), nan((1, self.n), np.nan), nan((1, self.m), np.nan), nan((1, self.nnz), np.nan)
 
     def cost_terms(self):
         return self._pose.cost_terms()
@@ -77,14 +83,21 @@ class _CallbackCache:
     def __init__(self, eng):
         self._eng = eng
         self._x = None
+        self.calls = {}          # callbacks served, by kind
+        self.evaluations = 0     # of which new evaluations (kernel launches)
 
     def eval(self, x, want):
+        """A non-finite evaluation (HIPNLP_E_NUMERIC) is NOT an exception here: the arrays come back as the kernel filled them and
+        the NLP driver sees the NaN / Inf, as IPOPT does with CasADi's (it cuts the step and goes on; a Python exception out of a
+        cyipopt callback would abort the solve).  Every other engine error still raises."""
         x = np.asarray(x, dtype=np.float64)
         new_x = self._x is None or not np.array_equal(x, self._x)
         if new_x:
             self._x = x.copy()
+        self.calls[want[0] if len(want) == 1 else "all"] = self.calls.get(want[0] if len(want) == 1 else "all", 0) + 1
+        self.evaluations += int(new_x)
         try:
-            return self._eng.eval(x[None, :], new_x=new_x, want=want)
+            return self._eng.eval(x[None, :], new_x=new_x, want=want, nan_ok=True)
         except Exception:
             self._x = None   # a failed evaluation leaves nothing to reuse
             raise
@@ -259,10 +272,13 @@ class HipNlpSolver:
                                                                self._callback_save_constraint_multipliers)
 
         def cost_values_at(xk):
-            eng.eval(xk[None, :], want=("f",))
+            # through the SAME cache as the callbacks: the engine's cached result then always belongs to cache._x (an evaluation
+            # behind the cache's back would let a later new_x = False callback at the older point read this point's outputs)
+            self._cache.eval(xk, ("f",))
             names, terms = eng.cost_terms()
             return {n: float(v) for n, v in zip(names, terms[0])}
         self._cost_values_at = cost_values_at
+        self._cache = _CallbackCache(eng)
         failure = None
         try:
             if solver == "ipopt":
@@ -312,7 +328,7 @@ class HipNlpSolver:
         from scipy.sparse import csc_matrix
         m, n = eng.m, eng.n
 
-        cache = _CallbackCache(eng)
+        cache = self._cache
 
         def fun(x):
             f, *_ = cache.eval(x, ("f",))
@@ -366,7 +382,7 @@ class HipNlpSolver:
         import cyipopt
         outer = self
 
-        cache = _CallbackCache(eng)
+        cache = self._cache
 
         class Callbacks:
             def objective(self, x):

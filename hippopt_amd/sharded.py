@@ -1,13 +1,18 @@
-"""Knot-interval data parallelism: contiguous knot shards, one process per GPU, ONE
-all-gather (RCCL over xGMI via torch.distributed backend "nccl"; "gloo" in the CPU tests) of a fused
-per-rank output buffer, then one index-select that reassembles [grad f | jac values | g] in the
-reference's order.  The reference has no distributed code at all; this is the
-build's addition for horizons sharded across the GPUs of one node.
+"""Knot-interval data parallelism: contiguous knot shards, one process per GPU.  The reference has no
+distributed code at all; this is the build's addition for horizons sharded across the GPUs of one node.
 
-Fused shard buffer of rank r (all ranks use the same padded length so the all-gather is regular):
-    [ f partial (1) | grad shard (glen_max) | jac shard (jlen_max) | g staging (nk_max * G_STAGE) ]
+Two ways to hand the shards' outputs to the consumer of the callback:
+
+* `ShardedCallback` — north_star's exchange: ONE all-gather (RCCL over xGMI via torch.distributed backend "nccl"; "gloo" in the
+  CPU tests) of a fused per-rank output buffer, then ONE launch (hipnlp_reassemble) that writes [grad f | jac values | g] in the
+  reference's order on every rank.  Fused shard buffer of rank r (all ranks use the same padded length, the all-gather is regular):
+      [ f partial (1) | grad shard (glen_max) | jac shard (jlen_max) | g staging (nk_max * G_STAGE) ]
+* `HostSink` — SURVEY §5's alternative for a CPU-side IPOPT: no collective at all.  Every rank's knot kernel stores its shard of
+  g / jac / grad f straight into ONE shared, pinned host buffer (a POSIX shared-memory segment every rank maps and registers with the
+  HIP runtime), already in the reference's order; rank partial costs land in f_parts[rank] and are summed in rank order.
 """
-import math
+import mmap
+import os
 
 import numpy as np
 import torch
@@ -17,13 +22,25 @@ G_STAGE = 550
 
 
 def knot_range(horizon, world, rank):
-    """GPU r of R owns knots [r*ceil(N/R), (r+1)*ceil(N/R))  (SURVEY §8e)."""
-    per = int(math.ceil(horizon / world))
-    return min(rank * per, horizon), min((rank + 1) * per, horizon)
+    """Contiguous, balanced, never empty: the first (horizon mod world) ranks own one knot more (SURVEY §8e partitioning;
+    defects of interval k -> k+1 belong to the owner of knot k+1, base/multiple_shooting_solver.py:728)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    if world > horizon:
+        raise ValueError(f"{world} ranks cannot share a horizon of {horizon} knots (every rank needs at least one knot)")
+    q, r = divmod(horizon, world)
+    begin = rank * q + min(rank, r)
+    return begin, begin + q + (1 if rank < r else 0)
 
 
 class ShardedCallback:
-    """compute_shard(x, f_view, grad_view, jac_view, stage_view) fills the rank's views (any backend)."""
+    """compute_shard(x, f_view, grad_view, jac_view, stage_view, stream) fills the rank's views (any backend).
+
+    Stream discipline on the GPU: shard evaluation, all-gather and reassembly run on ONE dedicated (non-default) torch stream whose
+    handle is passed to both library calls — the library would map a NULL stream to the handle's own non-blocking stream for the
+    evaluation but to the legacy default stream for hipnlp_reassemble, and nothing orders those two.  The dedicated stream waits
+    for the caller's current stream first (x is ready) and the caller's stream waits for it at the end (the returned views are
+    ordered for whoever uses them next, and the next call cannot overwrite buffers still being read)."""
 
     def __init__(self, horizon, n, m, nnz, shard_info, compute_shard, device, group=None):
         """shard_info: dict(glen, jlen, nk, stage_rows [nk, G_STAGE] int32 global rows or -1) of THIS rank."""
@@ -32,7 +49,7 @@ class ShardedCallback:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.n, self.m, self.nnz, self.horizon = n, m, nnz, horizon
         self.compute_shard = compute_shard
-        self.device = device
+        self.device = torch.device(device)
         infos = [None] * self.world
         if self.world > 1:
             dist.all_gather_object(infos, shard_info, group=group)
@@ -55,8 +72,9 @@ class ShardedCallback:
             self.buf[self.o_jac:self.o_jac + me["jlen"]],
             self.buf[self.o_stage:self.o_stage + me["nk"] * G_STAGE],
         )
-        # index of every entry of [grad | jac | g] inside the gathered buffer
+        # index of every entry of [grad | jac | g] inside the gathered buffer; every slot is written exactly once
         src = np.full(n + nnz + m, -1, dtype=np.int64)
+        hits = np.zeros(m, dtype=np.int64)
         go, jo = 0, 0
         for r, inf in enumerate(infos):
             base = r * self.shard_len
@@ -66,22 +84,27 @@ class ShardedCallback:
             jo += inf["jlen"]
             rows = np.asarray(inf["stage_rows"], dtype=np.int64).reshape(-1)
             valid = np.nonzero(rows >= 0)[0]
+            np.add.at(hits, rows[valid], 1)
             src[n + nnz + rows[valid]] = base + self.o_stage + valid
-        if go != n or jo != nnz or (src < 0).any():
-            raise ValueError("shards do not tile the problem: grad %d/%d jac %d/%d missing %d" % (go, n, jo, nnz, int((src < 0).sum())))
+        if go != n or jo != nnz or (src < 0).any() or (hits != 1).any():
+            raise ValueError("shards do not tile the problem: grad %d/%d jac %d/%d rows missing %d, rows written twice %d"
+                             % (go, n, jo, nnz, int((hits == 0).sum()), int((hits > 1).sum())))
         self.src = torch.from_numpy(src).to(device)
         self.f_src = torch.arange(self.world, device=device) * self.shard_len
         self.out = torch.empty(n + nnz + m + 1, dtype=torch.float64, device=device)   # [grad | jac | g | f]
         self._lib = None
-        if torch.device(device).type == "cuda":   # one HIP launch for the whole reassembly (hipnlp_reassemble); CPU tests: torch ops
+        self.stream = None
+        if self.device.type == "cuda":   # one HIP launch for the whole reassembly (hipnlp_reassemble); CPU tests: torch ops
             import ctypes as C
             from .hipnlp import load_library
             self._lib = load_library()
             self._lib.hipnlp_reassemble.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+            self.stream = torch.cuda.Stream(device=self.device)
+            if not self.stream.cuda_stream:
+                raise RuntimeError("expected a non-default HIP stream")
 
-    def __call__(self, x):
-        """One callback set for the whole horizon.  Returns (f, grad, jac, g) views of the reassembled buffer."""
-        self.compute_shard(x, *self.views)
+    def _run(self, x, stream_handle):
+        self.compute_shard(x, *self.views, stream_handle)
         if self.world > 1:
             dist.all_gather_into_tensor(self.all, self.buf, group=self.group)
             gathered = self.all
@@ -90,7 +113,7 @@ class ShardedCallback:
         tot = self.n + self.nnz + self.m
         if self._lib is not None:
             rc = self._lib.hipnlp_reassemble(gathered.data_ptr(), self.src.data_ptr(), self.out.data_ptr(), tot, self.world, self.shard_len,
-                                             self.out.data_ptr() + 8 * tot, torch.cuda.current_stream().cuda_stream)
+                                             self.out.data_ptr() + 8 * tot, stream_handle)
             if rc != 0:
                 raise RuntimeError("hipnlp_reassemble failed (%d)" % rc)
             f = self.out[tot]
@@ -99,12 +122,42 @@ class ShardedCallback:
             f = gathered.index_select(0, self.f_src).sum()
         return f, self.out[:self.n], self.out[self.n:self.n + self.nnz], self.out[self.n + self.nnz:tot]
 
+    def __call__(self, x):
+        """One callback set for the whole horizon.  Returns (f, grad, jac, g) views of the reassembled buffer."""
+        if self.stream is None:
+            return self._run(x, 0)
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream == self.stream.cuda_stream:   # the caller already works on the callback's stream (`with
+            return self._run(x, self.stream.cuda_stream)  # torch.cuda.stream(cb.stream)`): nothing to order, no event traffic
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            out = self._run(x, self.stream.cuda_stream)
+        cur.wait_stream(self.stream)
+        return out
+
+    def shard_only(self, x):
+        """The rank's shard evaluated into its fused buffer, nothing exchanged (bench.py: outputs left shard-resident)."""
+        if self.stream is None:
+            self.compute_shard(x, *self.views, 0)
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream == self.stream.cuda_stream:
+            self.compute_shard(x, *self.views, self.stream.cuda_stream)
+            return
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.compute_shard(x, *self.views, self.stream.cuda_stream)
+        cur.wait_stream(self.stream)
+
 
 def hip_shard_backend(engine):
     """compute_shard backed by the HIP engine handle that owns this rank's knots."""
-    def compute(x, f_view, grad_view, jac_view, stage_view):
+    def compute(x, f_view, grad_view, jac_view, stage_view, stream_handle):
+        if not stream_handle:
+            raise RuntimeError("the sharded path needs an explicit (non-default) stream: a NULL stream means different streams to "
+                               "hipnlp_eval_device_shard and hipnlp_reassemble")
         engine.eval_device_shard(x.data_ptr(), f_view.data_ptr(), grad_view.data_ptr(), stage_view.data_ptr(), jac_view.data_ptr(),
-                                 stream=torch.cuda.current_stream().cuda_stream)
+                                 stream=stream_handle)
     return compute
 
 
@@ -112,3 +165,80 @@ def hip_shard_info(engine, knot_begin, knot_end):
     d = engine.dims
     rows = np.stack([engine.stage_rows(k) for k in range(knot_begin, knot_end)])
     return {"glen": int(d.shard_grad), "jlen": int(d.shard_nnz), "nk": knot_end - knot_begin, "stage_rows": rows}
+
+
+class HostSink:
+    """One shared, pinned host buffer [f_parts (world, padded to 8) | grad (n) | jac (nnz) | g (m)] that every rank's knot kernel
+    stores into directly (no collective, no staging copy): SURVEY §5's "each rank D2H's its own slice into one pinned host buffer",
+    what a CPU-side IPOPT process wants.  The segment lives in /dev/shm; every rank maps it and registers the mapping with the HIP
+    runtime (hipHostRegister), which yields the device-visible address the kernel stores to.
+
+    name: shared-memory name all ranks agree on (rank 0 creates, the others open after a barrier the caller provides through
+    `barrier()`); world = 1 needs no barrier."""
+
+    def __init__(self, name, n, m, nnz, world, rank, barrier=None):
+        import ctypes as C
+        from .hipnlp import load_library
+        self.n, self.m, self.nnz, self.world, self.rank = n, m, nnz, world, rank
+        self.o_grad = 8 * ((world + 7) // 8)
+        self.o_jac = self.o_grad + n
+        self.o_g = self.o_jac + nnz
+        self.count = self.o_g + m
+        nbytes = ((self.count * 8 + 4095) // 4096) * 4096
+        self.path = os.path.join("/dev/shm", name)
+        if rank == 0:
+            fd = os.open(self.path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
+            os.ftruncate(fd, nbytes)
+        if barrier is not None:
+            barrier()
+        if rank != 0:
+            fd = os.open(self.path, os.O_RDWR)
+        self._mm = mmap.mmap(fd, nbytes)
+        os.close(fd)
+        self.host = np.frombuffer(self._mm, dtype=np.float64, count=self.count)
+        self._lib = load_library()
+        self._lib.hipnlp_host_register.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        self._lib.hipnlp_host_unregister.argtypes = [C.c_void_p]
+        dev = C.c_void_p()
+        self._addr = self.host.ctypes.data
+        rc = self._lib.hipnlp_host_register(C.c_void_p(self._addr), C.c_size_t(nbytes), C.byref(dev))
+        if rc != 0:
+            raise RuntimeError("hipnlp_host_register failed (%d)" % rc)
+        self.dev = dev.value
+        if barrier is not None:
+            barrier()   # every rank holds its mapping: the name can go
+        if rank == 0:
+            os.unlink(self.path)
+
+    def pointers(self):
+        """device-visible addresses (f partial of this rank, grad, g, jac) for HipNlp.eval_device on a shard handle"""
+        return (self.dev + 8 * self.rank, self.dev + 8 * self.o_grad, self.dev + 8 * self.o_g, self.dev + 8 * self.o_jac)
+
+    def views(self):
+        """(f_parts[world], grad[n], jac[nnz], g[m]) numpy views of the shared buffer"""
+        h = self.host
+        return h[:self.world], h[self.o_grad:self.o_jac], h[self.o_jac:self.o_g], h[self.o_g:self.count]
+
+    def f(self):
+        parts = self.host[:self.world]
+        tot = 0.0
+        for r in range(self.world):   # rank order, as hipnlp_reassemble
+            tot += float(parts[r])
+        return tot
+
+    def close(self):
+        if getattr(self, "dev", None):
+            import ctypes as C
+            self._lib.hipnlp_host_unregister(C.c_void_p(self._addr))
+            self.dev = None
+            self.host = None
+            try:
+                self._mm.close()
+            except BufferError:   # a numpy view is still alive somewhere: the mapping goes with it
+                pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -36,6 +36,7 @@
 #ifndef HIPNLP_H
 #define HIPNLP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -195,9 +196,44 @@ int hipnlp_sparsity(const hipnlp_handle* h, int32_t* irow, int32_t* jcol);
 
 /* Host-buffer callback quartet (IPOPT eval_f/eval_grad_f/eval_g/eval_jac_g in one fused launch).
  * x: [batch][n]; f: [batch]; grad_f: [batch][n]; g: [batch][m]; jac: [batch][nnz].  Any output may be NULL.
- * new_x = 0 lets the library return cached results of the previous evaluation.                */
+ * new_x = 0 lets the library return cached results of the previous evaluation.
+ *
+ * What crosses PCIe (the non-NULL outputs are the call's WANT MASK): a new evaluation copies x into a pinned staging block the
+ * kernel reads directly, evaluates all four outputs in ONE launch and lets the kernel store the wanted ones — plus the handle's
+ * prefetch set — straight into a pinned output block (no copy command, no second staging copy); the others stay in HBM and are
+ * fetched by one asynchronous copy if a later call with new_x = 0 asks for them.  An eval_g at a line-search trial point therefore
+ * moves 0.2 MB, not the 1.1 MB of jac g.  Returns HIPNLP_E_NUMERIC when the evaluation produced a NaN/Inf — AFTER filling the
+ * outputs (IPOPT's callback returns false; the reference hands CasADi's NaNs to IPOPT, which cuts the step).                    */
 int hipnlp_eval(hipnlp_handle* h, const double* x, int new_x,
                 double* f, double* grad_f, double* g, double* jac);
+
+#define HIPNLP_WANT_F 1u
+#define HIPNLP_WANT_GRAD 2u
+#define HIPNLP_WANT_G 4u
+#define HIPNLP_WANT_JAC 8u
+#define HIPNLP_WANT_ALL 15u
+/* Same evaluation, zero-copy: returns pointers INTO the library's pinned output block (valid until the next call on the handle)
+ * for the outputs named in `want` (HIPNLP_WANT_*), NULL for the others.  What a binding that must copy anyway (cyipopt copies the
+ * callback's return value into IPOPT's array) uses to avoid a second copy.                                                      */
+int hipnlp_eval_pinned(hipnlp_handle* h, const double* x, int new_x, unsigned want,
+                       const double** f, const double** grad_f, const double** g, const double** jac);
+/* Outputs every NEW evaluation brings to the host besides the ones its call asks for.  Default F | GRAD | G (0.37 MB at 100 knots:
+ * +7 us): IPOPT asks for f and g at every trial point and for grad f and jac g (new_x = 0) only at accepted ones.
+ * HIPNLP_WANT_ALL makes every new evaluation move everything (one launch, no second round trip for jac g).                      */
+int hipnlp_set_prefetch(hipnlp_handle* h, unsigned mask);
+/* Bracket host-path launches with HIP events (for hipnlp_last_kernel_ms); off by default: an event pair costs microseconds. */
+int hipnlp_set_host_timing(hipnlp_handle* h, int on);
+/* Wall clock (us) of the last hipnlp_eval on the host side: us[0] staging copy of x, us[1] enqueue (launch call), us[2] waiting for
+ * the GPU (kernel + its PCIe stores), us[3] copies into caller arrays that are not registered.  Diagnostic. */
+int hipnlp_host_breakdown(const hipnlp_handle* h, double* us /*[4]*/);
+/* Caller-owned host arrays as DIRECT kernel outputs: register the array once (page-locks it; dev_ptr, optional, receives its
+ * device-visible address).  From then on a grad_f / g / jac pointer of hipnlp_eval that lies inside a registered range is stored
+ * to by the kernel itself — no staging copy at all (IPOPT's TNLP adapter keeps its g and jac-value arrays for the whole solve: the
+ * binding registers them at the first callback).  The device-visible address can also be passed to hipnlp_eval_device as
+ * grad_dev / g_dev / jac_dev.  Also how several processes share ONE host buffer (a shared-memory segment mapped and registered by
+ * each: hippopt_amd/sharded.py HostSink).  Process-wide (no handle); the caller unregisters before freeing the memory.           */
+int hipnlp_host_register(void* p, size_t bytes, void** dev_ptr);
+int hipnlp_host_unregister(void* p);
 
 
 /* Exact Hessian of the Lagrangian  sigma f(x) + lambda^T g(x)  of the kinodynamic NLP — IPOPT's eval_h (IpStdCInterface.h:
@@ -216,9 +252,10 @@ int hipnlp_hess_sparsity(hipnlp_handle* h, int32_t* irow, int32_t* jcol);
 int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor, const double* lambda, double* values);
 int hipnlp_eval_hess_device(hipnlp_handle* h, const double* x_dev, const double* obj_factor_dev, const double* lambda_dev,
                             double* values_dev, void* stream);
-/* Device-resident variant: all pointers are device pointers on desc.device, same shapes.
- * Work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the handle's own stream)
- * and NOT synchronised.  cost_knot (optional, [batch][N]) receives the per-knot cost partials. */
+/* Device-resident variant: all pointers are device pointers on desc.device (or device-visible addresses of registered host
+ * memory, hipnlp_host_register), same shapes.  Work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the handle's
+ * own non-blocking stream — NOT the legacy default stream: order other work against it with an explicit stream) and NOT
+ * synchronised. */
 int hipnlp_eval_device(hipnlp_handle* h, const double* x_dev,
                        double* f_dev, double* grad_dev, double* g_dev, double* jac_dev,
                        void* stream);
@@ -236,7 +273,9 @@ int hipnlp_eval_device_shard(hipnlp_handle* h, const double* x_dev, double* f_de
 int hipnlp_stage_rows(const hipnlp_handle* h, int k, int32_t* rows /*[HIPNLP_G_STAGE]*/);
 /* Reassembly behind the all-gather of the fused shard buffers: out[i] = gathered[src[i]] (i < count: [grad | jac | g] in reference
  * order) and *f_out = sum over ranks, in rank order, of gathered[r * shard_len] (the cost partials); device pointers on the current
- * device, enqueued on `stream`, not synchronised.  Stateless (no handle). */
+ * device, enqueued on `stream`, not synchronised.  Stateless (no handle): `stream` must be the stream the shard evaluation and the
+ * all-gather were enqueued on (a NULL stream here is the legacy default stream, which nothing orders against a handle's own
+ * stream: hippopt_amd/sharded.py passes one explicit stream to both calls). */
 int hipnlp_reassemble(const double* gathered_dev, const int64_t* src_dev, double* out_dev, int64_t count, int world, int64_t shard_len,
                       double* f_out_dev, void* stream);
 

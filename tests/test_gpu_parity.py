@@ -125,6 +125,63 @@ def test_new_x_cache_and_errors(model, HipNlp):
     assert e.value.code == _abi.E_NUMERIC
 
 
+def test_config5_stairs_200x16_matches_oracle(model, HipNlp):
+    """BASELINE config 5 at its own shape: walking on stairs (smooth two-step terrain), N = 200 knots x 16 batched initial guesses
+    (base trajectory + N(0, 0.02^2) per guess) in ONE launch.  Entrywise against the oracle for four of the sixteen
+    trajectories (the oracle takes ~0.1 s per trajectory at this horizon), pattern and bounds for the problem, and every
+    trajectory of the batch against the same trajectory evaluated alone (bitwise: no cross-talk inside the batch)."""
+    from oracle_lib import Oracle
+    N, B = 200, 16
+    st = stairs_settings(N, model)
+    base_x, base_p = make_workload(st, model, batch=1, seed=1005)
+    x = np.repeat(base_x, B, axis=0)
+    for b in range(B):
+        x[b] += 0.02 * np.random.RandomState(2000 + b).standard_normal(x.shape[1])
+    place_on_step_flanks(x[:2], st, seed=5)   # two guesses with contact points on the flanks of the bumps
+    p = np.repeat(base_p, B, axis=0)
+    eng, orc = HipNlp(st, model, batch=B), Oracle(st, model)
+    assert (eng.n, eng.m, eng.nnz, eng.np) == (orc.n, orc.m, orc.nnz, orc.np) == (189 * N + 6, orc.m, orc.nnz, 79 * N + 326)
+    ir, jc = eng.sparsity()
+    iro, jco = orc.sparsity()
+    assert np.array_equal(ir, iro) and np.array_equal(jc, jco)
+    eng.set_params(p)
+    f, grad, g, jac = eng.eval(x)
+    lbx, ubx, lbg, ubg = eng.bounds()
+    lbo, ubo = orc.bounds(p[0])
+    assert np.array_equal(lbg, lbo) and np.array_equal(ubg, ubo)
+    for b in (0, 1, 7, 15):
+        fo, grado, go, jaco = orc.eval(x[b], p[b])
+        assert rel(f[b], fo) < TOL and rel(grad[b], grado) < TOL and rel(g[b], go) < TOL and rel(jac[b], jaco) < TOL, b
+    assert np.abs(jac[0]).max() > 100.0   # the flank derivatives are exercised
+    one = HipNlp(st, model, batch=1)
+    one.set_params(p[:1])
+    for b in (3, 12):
+        f1, grad1, g1, jac1 = one.eval(x[b:b + 1])
+        assert f1[0] == f[b] and np.array_equal(grad1[0], grad[b]) and np.array_equal(g1[0], g[b]) and np.array_equal(jac1[0], jac[b])
+
+
+def test_config4_periodic_100_matches_oracle(model, HipNlp):
+    """BASELINE config 4 at its own shape (the bench workload: periodic walking, N = 100, seed 1004): every entry of
+    f, grad f, g, jac g against the oracle, pattern and bounds included."""
+    from oracle_lib import Oracle
+    st = periodic_step_settings(100, model)
+    x, p = make_workload(st, model, batch=1, seed=1004)
+    eng, orc = HipNlp(st, model), Oracle(st, model)
+    assert (eng.n, eng.m, eng.nnz) == (orc.n, orc.m, orc.nnz) == (18906, 27505, 137879)
+    ir, jc = eng.sparsity()
+    iro, jco = orc.sparsity()
+    assert np.array_equal(ir, iro) and np.array_equal(jc, jco)
+    eng.set_params(p)
+    f, grad, g, jac = eng.eval(x)
+    fo, grado, go, jaco = orc.eval(x[0], p[0])
+    assert rel(f[0], fo) < TOL and rel(grad[0], grado) < TOL and rel(g[0], go) < TOL and rel(jac[0], jaco) < TOL
+    lbx, ubx, lbg, ubg = eng.bounds()
+    lbo, ubo = orc.bounds(p[0])
+    assert np.array_equal(lbg, lbo) and np.array_equal(ubg, ubo)
+    names, terms = eng.cost_terms()
+    assert np.allclose(terms[0], orc.cost_terms(), rtol=1e-12, atol=1e-10)
+
+
 def test_large_horizon_properties(model, HipNlp):
     """N = 100 (BASELINE config 4): size-independent properties — defect linearity in dt, zero defects on a
     trapezoid-consistent trajectory, Jacobian consistent with finite differences of g along a random direction."""
@@ -330,7 +387,9 @@ def test_maximum_sizes_and_shard_consistency(model, HipNlp):
 
 def test_sharded_callback_reassembly_on_gpu(model, HipNlp):
     """ShardedCallback on the GPU at world size 1: the fused shard buffer of the whole horizon goes through the
-    library's one-launch reassembly (hipnlp_reassemble) and must equal the unsharded callback bit for bit; f is the in-kernel sum."""
+    library's one-launch reassembly (hipnlp_reassemble) and must equal the unsharded callback bit for bit; f is the in-kernel sum.
+    x CHANGES ON EVERY CALL and there are no warm-up repeats: a result that is not ordered behind its own shard evaluation (the
+    evaluation on one stream, the reassembly on another) would show the previous iterate's values."""
     import torch
     from hippopt_amd.sharded import ShardedCallback, hip_shard_backend, hip_shard_info
     N = 24
@@ -338,17 +397,109 @@ def test_sharded_callback_reassembly_on_gpu(model, HipNlp):
     x, p = make_workload(st, model, batch=1, seed=77)
     full = HipNlp(st, model)
     full.set_params(p)
-    f, grad, g, jac = full.eval(x)
     dev = torch.device("cuda", 0)
     sh = HipNlp(st, model, knot_begin=0, knot_end=N)
     sh.set_params(p)
     cb = ShardedCallback(N, sh.n, sh.m, sh.nnz, hip_shard_info(sh, 0, N), hip_shard_backend(sh), dev)
-    xd = torch.from_numpy(x[0]).to(dev)
-    for _ in range(3):
-        fs, grads, jacs, gs = cb(xd)
+    rng = np.random.RandomState(4)
+    xs = [x[0] + 1e-2 * i * rng.standard_normal(x.shape[1]) for i in range(6)]
+    xds = [torch.from_numpy(xi).to(dev) for xi in xs]
     torch.cuda.synchronize()
-    assert float(fs) == f[0]
-    assert np.array_equal(grads.cpu().numpy(), grad[0]) and np.array_equal(jacs.cpu().numpy(), jac[0]) and np.array_equal(gs.cpu().numpy(), g[0])
+    got = []
+    for xd in xds:   # back to back, results copied out on the caller's stream without an explicit synchronisation in between
+        fs, grads, jacs, gs = cb(xd)
+        got.append((fs.clone(), grads.clone(), jacs.clone(), gs.clone()))
+    torch.cuda.synchronize()
+    for xi, (fs, grads, jacs, gs) in zip(xs, got):
+        f, grad, g, jac = full.eval(xi[None, :])
+        assert float(fs) == f[0]
+        assert np.array_equal(grads.cpu().numpy(), grad[0]) and np.array_equal(jacs.cpu().numpy(), jac[0]) and np.array_equal(gs.cpu().numpy(), g[0])
+
+
+def test_host_path_want_mask_lazy_fetch_and_views(model, HipNlp):
+    """hipnlp_eval / hipnlp_eval_pinned: the kernel stores the wanted outputs straight into the pinned block; the others stay in
+    HBM and are fetched when a later new_x = 0 call asks.  Every combination must return exactly the values of one full evaluation
+    at the SAME x (alternating iterates, so a stale block would show), whatever the prefetch set."""
+    from hippopt_amd.hipnlp import HipNlpError
+    st = periodic_step_settings(9, model)
+    x, p = make_workload(st, model, batch=2, seed=41)
+    x2 = x + 1e-2 * np.random.RandomState(1).standard_normal(x.shape)
+    eng = HipNlp(st, model, batch=2)
+    eng.set_params(p)
+    ref = {0: [a.copy() for a in eng.eval(x)], 1: [a.copy() for a in eng.eval(x2)]}
+    names = ("f", "grad", "g", "jac")
+    for prefetch in (("f", "grad", "g"), (), ("f", "grad", "g", "jac"), ("jac",)):
+        eng.set_prefetch(prefetch)
+        for i, first in enumerate(names):
+            xi, r = (x, ref[0]) if i % 2 == 0 else (x2, ref[1])
+            out = eng.eval(xi, want=(first,))                       # a new evaluation that asks for ONE output
+            assert [o is not None for o in out] == [n == first for n in names]
+            assert np.array_equal(out[i], r[i])
+            for j, later in enumerate(names):                        # the others afterwards, from the cached evaluation
+                o2 = eng.eval(xi * 0.0, new_x=False, want=(later,))  # (x is ignored when new_x = 0)
+                assert np.array_equal(o2[j], r[j]), (prefetch, first, later)
+        views = eng.eval_pinned(x2, want=("g", "jac"))
+        assert views[0] is None and views[1] is None and np.array_equal(views[2], ref[1][2]) and np.array_equal(views[3], ref[1][3])
+        vf = eng.eval_pinned(x2, new_x=False, want=("f", "grad"))
+        assert np.array_equal(vf[0], ref[1][0]) and np.array_equal(vf[1], ref[1][1])
+    names_t, terms = eng.cost_terms()
+    assert np.allclose(terms.sum(axis=1), ref[1][0], rtol=1e-13)
+    # a non-finite evaluation: the outputs are filled BEFORE the error code comes back (IPOPT looks at the NaNs and cuts the step)
+    bad = x.copy()
+    bad[1, 130:134] = 0.0   # zero quaternion in trajectory 1
+    with pytest.raises(HipNlpError) as e:
+        eng.eval(bad)
+    assert e.value.code == _abi.E_NUMERIC
+    f, grad, g, jac = eng.eval(bad, nan_ok=True)
+    assert not np.all(np.isfinite(jac[1])) and np.array_equal(jac[0], ref[0][3][0]) and np.array_equal(g[0], ref[0][2][0])
+    f, grad, g, jac = eng.eval(x)   # and the handle recovers
+    assert np.array_equal(jac, ref[0][3]) and np.array_equal(f, ref[0][0])
+    # caller arrays registered with the library are stored to by the kernel itself (no staging copy): same values, also on a
+    # cached (new_x = 0) request for an output the evaluation has already delivered into the caller's array
+    import ctypes as C
+    reg = [np.zeros_like(a) for a in ref[0]]
+    for a in reg[1:]:
+        assert eng.lib.hipnlp_host_register(C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes), None) == 0
+    try:
+        for xi, r in ((x2, ref[1]), (x, ref[0])):
+            out = eng.eval(xi, out=tuple(reg))
+            for o, want in zip(out, r):
+                assert np.array_equal(o, want)
+            reg[3][:] = 0.0
+            eng.eval(xi, new_x=False, want=("jac",), out=(None, None, None, reg[3]))
+            assert np.array_equal(reg[3], r[3])
+    finally:
+        for a in reg[1:]:
+            eng.lib.hipnlp_host_unregister(C.c_void_p(a.ctypes.data))
+
+
+def test_host_sink_shards_store_into_one_registered_buffer(model, HipNlp):
+    """HostSink (SURVEY §5's alternative to the all-gather): the knot kernels of two shard handles store their g / jac / grad f
+    straight into ONE registered host buffer in the reference's order — no collective, no staging copy.  Bitwise equal to the
+    unsharded evaluation; the rank partial costs sum to f."""
+    import torch
+    from hippopt_amd.sharded import HostSink, knot_range
+    N = 17
+    st = periodic_step_settings(N, model)
+    x, p = make_workload(st, model, batch=1, seed=52)
+    full = HipNlp(st, model)
+    full.set_params(p)
+    f, grad, g, jac = full.eval(x)
+    sink = HostSink("hipnlp_test_sink_%d" % __import__("os").getpid(), full.n, full.m, full.nnz, world=2, rank=0)
+    xd = torch.from_numpy(x[0]).cuda()
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for r in range(2):
+        kb, ke = knot_range(N, 2, r)
+        sh = HipNlp(st, model, knot_begin=kb, knot_end=ke)
+        sh.set_params(p)
+        fp, gradp, gp, jacp = sink.pointers()
+        sh.eval_device(xd.data_ptr(), sink.dev + 8 * r, gradp, gp, jacp, stream=stream.cuda_stream)
+        stream.synchronize()
+    fparts, grad_h, jac_h, g_h = sink.views()
+    assert np.array_equal(grad_h, grad[0]) and np.array_equal(jac_h, jac[0]) and np.array_equal(g_h, g[0])
+    assert abs(sink.f() - f[0]) <= 1e-13 * max(1.0, abs(f[0]))
+    sink.close()
 
 
 def test_profile_runs_and_kernel_count(model, HipNlp):

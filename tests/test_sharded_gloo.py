@@ -62,7 +62,7 @@ def _worker(rank, world, port, horizon, result_q):
     info = {"glen": 189 * (ke - kb) + (6 if ke == horizon else 0), "jlen": int(((col_knot >= kb) & (col_knot < ke)).sum()),
             "nk": ke - kb, "stage_rows": np.stack([rows_all[k] for k in range(kb, ke)])}
 
-    def compute(xt, f_view, grad_view, jac_view, stage_view):
+    def compute(xt, f_view, grad_view, jac_view, stage_view, stream_handle):
         gs, js, stg = _emulated_shard(emu, rows_all, kb, ke, horizon, xt.numpy(), p[0])
         f_view[0] = float(rank + 1)  # partial costs: checked as a sum below
         grad_view.copy_(torch.from_numpy(np.ascontiguousarray(gs)))
@@ -88,7 +88,7 @@ def test_sharded_reassembly_world2(horizon):
     procs = [ctx.Process(target=_worker, args=(r, world, port, horizon, q)) for r in range(world)]
     for pr in procs:
         pr.start()
-    results = [q.get(timeout=180) for _ in range(world)]
+    results = [q.get(timeout=120) for _ in range(world)]
     for pr in procs:
         pr.join(timeout=60)
         assert pr.exitcode == 0
@@ -97,10 +97,26 @@ def test_sharded_reassembly_world2(horizon):
 
 def test_knot_range_tiles_the_horizon():
     from hippopt_amd.sharded import knot_range
-    for horizon in (7, 100, 101, 800):
-        for world in (1, 2, 4, 8):
-            cover = []
+    for horizon in (7, 9, 100, 101, 800):
+        for world in (1, 2, 4, 7, 8):
+            if world > horizon:
+                continue
+            cover, sizes = [], []
             for r in range(world):
                 a, b = knot_range(horizon, world, r)
+                assert b > a   # never empty (hipnlp_create reads (0, 0) as "whole horizon" and rejects an empty shard)
                 cover += list(range(a, b))
-            assert cover == list(range(horizon))
+                sizes.append(b - a)
+            assert cover == list(range(horizon)) and max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        knot_range(3, 4, 0)   # more ranks than knots: refused on every rank, before any collective
+
+
+def test_overlapping_shards_are_refused():
+    """every reassembly slot must be written exactly once: a row two shards claim is an error, not a silent overwrite"""
+    from hippopt_amd.sharded import G_STAGE, ShardedCallback
+    rows = np.full((1, G_STAGE), -1, np.int32)
+    rows[0, :4] = [0, 1, 2, 2]   # row 2 twice, row 3 never
+    info = {"glen": 3, "jlen": 5, "nk": 1, "stage_rows": rows}
+    with pytest.raises(ValueError, match="written twice 1"):
+        ShardedCallback(1, 3, 4, 5, info, lambda *a: None, torch.device("cpu"))
