@@ -307,13 +307,16 @@ struct Layout {
     // Kinematic tables from the C descriptor; validates the topology the kernel is specialised for.
     static bool make_kin_tables(const hipnlp_robot_model& md, KinTables& kt, std::string& err) {
         kt = KinTables{};
-        int nchild[NL], child[NL][4];
-        for (int l = 0; l < NL; ++l) nchild[l] = 0;
+        // Any tree rooted at link 0: the child link of joint j is link j + 1, parent[j] is ANY other link.  The joint order is the
+        // reference's joints_name_list order (it fixes the x layout, variables.py:182-217) and need not be topological — ergoCub's
+        // list names torso_pitch before torso_roll whatever the URDF chains first.  Everything below walks parent links, never
+        // index order.
         for (int j = 0; j < NJ; ++j) {
             const int par = md.parent[j];
-            if (par < 0 || par > j) { err = "robot model: parent[j] must satisfy 0 <= parent[j] <= j (topological order)"; return false; }
-            if (nchild[par] >= 4) { err = "robot model: more than 4 children on one link"; return false; }
-            child[par][nchild[par]++] = j + 1;
+            if (par < 0 || par >= NL || par == j + 1) { err = "robot model: parent[j] must be a link in 0..23 other than the joint's own child link"; return false; }
+            int steps = 0, l = j + 1;
+            while (l > 0 && steps <= NL) { l = md.parent[l - 1]; ++steps; if (l < 0 || l >= NL) break; }
+            if (l != 0) { err = "robot model: the parent links do not form a tree rooted at link 0"; return false; }
             double an = 0;
             for (int i = 0; i < 3; ++i) { kt.axis[j][i] = md.axis[j][i]; an += md.axis[j][i] * md.axis[j][i]; }
             if (!(an > 0.999999 && an < 1.000001)) { err = "robot model: joint axes must be unit vectors"; return false; }
@@ -333,9 +336,9 @@ struct Layout {
             if (md.frame_link[f] < 0 || md.frame_link[f] >= NL) { err = "robot model: bad frame link"; return false; }
             for (int i = 0; i < 9; ++i) kt.frame_R[f][i] = md.frame_R[f][i];
             for (int i = 0; i < 3; ++i) kt.frame_o[f][i] = md.frame_o[f][i];
-            std::vector<int> path;
+            std::vector<int> path;   // joints root -> frame link, in path order
             for (int l = md.frame_link[f]; l > 0; l = md.parent[l - 1]) path.push_back(l - 1);
-            std::sort(path.begin(), path.end());
+            std::reverse(path.begin(), path.end());
             const int want = f == HIPNLP_FRAME_CHEST ? CHEST_PATH : LEG_PATH;
             if (int(path.size()) != want) { err = "robot model: the kernel is specialised for 6-joint leg chains and a 3-joint chest chain"; return false; }
             for (int q = 0; q < want; ++q) {
@@ -352,7 +355,7 @@ struct Layout {
             std::vector<int> path;
             for (int q = j + 1; q > 0; q = md.parent[q - 1]) path.push_back(q - 1);
             if (path.size() > 8) { err = "robot model: a chain is deeper than 8 joints"; return false; }
-            std::sort(path.begin(), path.end());
+            std::reverse(path.begin(), path.end());   // root -> j, in path order
             // FRONT padded: the last element is always joint j itself, so the state before the last product is the parent's
             const int npad = 8 - int(path.size());
             for (int q = 0; q < 8; ++q) kt.anc[j][q] = int8_t(q < npad ? NJ : path[size_t(q - npad)]);
@@ -363,7 +366,7 @@ struct Layout {
             int n = 0;
             for (int l = 0; l < NL; ++l) {
                 bool in = false;
-                for (int q = l; ; q = md.parent[q - 1]) { if (q == i) { in = true; break; } if (q == 0) break; }
+                for (int q = l; ; q = md.parent[q - 1]) { if (q == i) { in = true; break; } if (q == 0) break; }   // (a tree: checked above)
                 if (in) kt.desc[i][n++] = int8_t(l);
             }
             kt.ndesc[i] = int16_t(n);
@@ -376,7 +379,6 @@ struct Layout {
             for (int i = 0; i < NL; ++i) kt.comp_order[i] = int16_t(order[size_t(i)]);
             for (int g = 0; g < NL / 4; ++g) kt.comp_cnt[g] = kt.ndesc[order[size_t(4 * g)]];   // sorted: the first of the group is the largest
         }
-        (void)nchild; (void)child;
         for (int i = 0; i < 105; ++i) {
             int slot, desc;
             const int var = final_row_var(i, &slot, &desc);

@@ -230,10 +230,11 @@ template <class Em> HD void t_hess_ss(HCtx<Em>& h, int t) {
     int j = 0;
     while ((j + 1) * (j + 2) / 2 <= t) ++j;
     const int i = t - j * (j + 1) / 2;
-    bool anc = false;
-    for (int q = 0; q < 8; ++q) anc = anc || (int(cx.kt.anc[j][q]) == i);
-    if (!anc) return;
-    double v = dot3(cx.s.aw[i], h.hx.Y[j]);
+    // related pairs only; the ancestor of the two carries the axis (the joint numbering need not be topological)
+    bool i_anc = false, j_anc = false;
+    for (int q = 0; q < 8; ++q) { i_anc = i_anc || (int(cx.kt.anc[j][q]) == i); j_anc = j_anc || (int(cx.kt.anc[i][q]) == j); }
+    if (!i_anc && !j_anc) return;
+    double v = i_anc ? dot3(cx.s.aw[i], h.hx.Y[j]) : dot3(cx.s.aw[j], h.hx.Y[i]);
     if (i == j) v += 2.0 * h.hx.sigma * cx.st.m_jreg * cx.st.w_jreg[j];
     cx.em.H(hs::SS + t, pv::S + j, pv::S + i, v);
 }

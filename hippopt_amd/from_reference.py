@@ -1,0 +1,149 @@
+"""From the reference's OWN objects to the engine's C-ABI inputs: (hipnlp_desc, p, x).
+
+INTEGRATION.md's table of "where each hipnlp_desc field comes from", as code.  Duck-typed: nothing of hippopt is imported here, the
+functions read attributes of whatever objects the caller holds —
+
+* `settings`   turnkey_planners/humanoid_kinodynamic/settings.py:12-147  (`Settings`; the fields that are baked into the CasADi graph
+               become hipnlp_settings, the ones that are Opti parameters are already inside `variables`)
+* `variables`  turnkey_planners/humanoid_kinodynamic/variables.py:256-374 (`Variables`), EXPANDED over the horizon
+               (`MultipleShootingSolver._extend_structure_to_horizon(variables, horizon=N)`, base/multiple_shooting_solver.py:64-181 —
+               what `OptimalControlProblem.create` does at planner.py:76-80) and filled with the guess / references / initial and
+               final state a script would hand to `Planner.set_initial_guess` (physical units)
+* the robot    settings.robot_urdf + joints_name_list + root_link + the foot / chest frame names (planner.py:43-50) through
+               hippopt_amd.urdf_model.load_urdf — or a ready RobotModel
+
+and reproduce what the reference does between those objects and CasADi: the flattening order of `to_dicts()` (= opti.variable() /
+opti.parameter() creation order, base/opti_solver.py:251-333), the variable / parameter split, and the mass regularisation of forces
+and momenta (planner.py:932-982) — so that `x` and `p` are exactly what the reference's nlpsol sees as x0 and p.
+"""
+import numpy as np
+
+from . import _abi
+from .kinodyn_layout import yaw_corner_indices
+from .kinodyn_settings import KinodynSettings
+
+# reference Settings field -> KinodynSettings field of the same meaning (settings.py:19-125)
+_SAME_NAME = (
+    "horizon_length", "time_step", "planar_dcc_height_multiplier", "dcc_gain", "dcc_epsilon", "static_friction",
+    "maximum_velocity_control", "maximum_force_derivative", "maximum_angular_momentum", "minimum_com_height",
+    "minimum_feet_lateral_distance", "maximum_feet_relative_height", "maximum_joint_positions", "minimum_joint_positions",
+    "maximum_joint_velocities", "minimum_joint_velocities", "final_state_expression_weight", "periodicity_expression_weight",
+    "contacts_centroid_cost_multiplier", "com_linear_velocity_cost_weights", "com_linear_velocity_cost_multiplier",
+    "desired_frame_quaternion_cost_multiplier", "base_quaternion_cost_multiplier", "base_quaternion_velocity_cost_multiplier",
+    "joint_regularization_cost_weights", "joint_regularization_cost_multiplier", "force_regularization_cost_multiplier",
+    "foot_yaw_regularization_cost_multiplier", "swing_foot_height_cost_multiplier", "contact_velocity_control_cost_multiplier",
+    "contact_force_control_cost_multiplier",
+)
+
+
+def expression_type(value):
+    """hp.ExpressionType (base/problem.py:15-19: skip / subject_to / minimize) -> HIPNLP_EXPR_*; ints pass through"""
+    if value is None:
+        return _abi.EXPR_SKIP
+    if isinstance(value, (int, np.integer)):
+        return int(value)
+    name = getattr(value, "name", str(value)).lower()
+    for key, code in (("skip", _abi.EXPR_SKIP), ("subject_to", _abi.EXPR_SUBJECT_TO), ("minimize", _abi.EXPR_MINIMIZE)):
+        if name.endswith(key):
+            return code
+    raise ValueError(f"unknown expression type {value!r}")
+
+
+def descriptors_of(contact_points_side):
+    """[4, 3] position_in_foot_frame of a list of ContactPointDescriptor (robot_planning/variables/contacts.py:20-65)"""
+    return np.array([np.asarray(d.position_in_foot_frame, float).reshape(3) for d in contact_points_side])
+
+
+def settings_from_reference(settings, terrain_steps=None) -> KinodynSettings:
+    """The numeric mirror of a reference `Settings`.  terrain_steps: the keyword arguments of every `SmoothTerrain.step(...)` term of
+    a TerrainSum terrain (main_walking_on_stairs.py:18-28) as a list of dicts — the reference's terrain object keeps them only inside
+    CasADi functions, so they cannot be read back; leave None for the default PlanarTerrain (settings.py:91-92)."""
+    out = KinodynSettings()
+    for name in _SAME_NAME:
+        v = getattr(settings, name, None)
+        if v is not None:
+            setattr(out, name, np.asarray(v, float).copy() if isinstance(v, (list, tuple, np.ndarray)) else v)
+    out.horizon_length = int(settings.horizon_length)
+    g = getattr(settings, "gravity", None)
+    if g is not None:
+        out.gravity = np.asarray(g, float).reshape(-1)
+    out.final_state_expression_type = expression_type(getattr(settings, "final_state_expression_type", None))
+    out.periodicity_expression_type = expression_type(getattr(settings, "periodicity_expression_type", None))
+    cp = settings.contact_points
+    out.left_descriptors, out.right_descriptors = descriptors_of(cp.left), descriptors_of(cp.right)
+    if out.left_descriptors.shape != (4, 3) or out.right_descriptors.shape != (4, 3):
+        raise ValueError("the engine is built for four contact points per foot (ContactPointDescriptor.rectangular_foot)")
+    terrain = getattr(settings, "terrain", None)
+    tname = type(terrain).__name__ if terrain is not None else "PlanarTerrain"
+    if terrain_steps:
+        out.terrain, out.terrain_steps = _abi.TERRAIN_SMOOTH_STEPS, [dict(t) for t in terrain_steps]
+    elif tname == "PlanarTerrain":
+        out.terrain = _abi.TERRAIN_PLANAR
+    else:
+        raise ValueError(f"settings.terrain is a {tname}: pass terrain_steps=[{{length, width, height, position, ...}}, ...] "
+                         "(the arguments of its SmoothTerrain.step terms)")
+    # what decides joint_reg_as_coded (planner.py:505-520) is the CasADi version the reference runs on: as coded
+    out.joint_reg_as_coded = True
+    for name in ("joint_regularization_cost_weights", "maximum_joint_positions", "minimum_joint_positions",
+                 "maximum_joint_velocities", "minimum_joint_velocities"):
+        if len(np.atleast_1d(getattr(out, name))) != _abi.NJ:
+            raise ValueError(f"settings.{name} must have {_abi.NJ} entries")
+    return out
+
+
+def model_from_reference(settings):
+    """the robot of `adam.casadi.KinDynComputations(settings.robot_urdf, settings.joints_name_list, settings.root_link)`"""
+    from .urdf_model import load_urdf
+    cp = settings.contact_points
+    frames = (cp.left[0].foot_frame, cp.right[0].foot_frame, settings.desired_frame_quaternion_cost_frame_name)
+    return load_urdf(settings.robot_urdf, list(settings.joints_name_list), root_link=settings.root_link, frames=frames)
+
+
+def _is_force_or_momentum(name):
+    """the leaves `_apply_mass_regularization` divides by the total mass (planner.py:949-980)"""
+    if name.startswith("references"):
+        return False
+    if name.endswith(".centroidal_momentum") or name == "centroidal_momentum":
+        return not name.startswith("final_state")          # the final state carries no momentum (HumanoidState)
+    return name.endswith(".f") and ".contact_points." in name
+
+
+def flatten_reference(variables, total_mass, mass_regularization=True):
+    """(x, p, variable names, parameter names) of a horizon-expanded reference `Variables` tree, in creation order."""
+    values, meta = variables.to_dicts()
+    xs, ps, xn, pn = [], [], [], []
+    for name, value in values.items():
+        if value is None:
+            raise ValueError(f"{name} is None: the structure must be filled (guess, references, initial and final state)")
+        arr = np.asarray(value, float).reshape(-1)
+        if mass_regularization and _is_force_or_momentum(name):
+            arr = arr / total_mass
+        storage = meta[name].get("StorageType")   # OptimizationObject.StorageTypeField (base/optimization_object.py:23)
+        if storage == "variable":
+            xs.append(arr); xn.append((name, arr.size))
+        elif storage == "parameter":
+            ps.append(arr); pn.append((name, arr.size))
+        else:
+            raise ValueError(f"{name}: unsupported storage type {storage!r}")
+    return np.concatenate(xs), np.concatenate(ps), xn, pn
+
+
+def from_reference(settings, variables, model=None, terrain_steps=None, batch=1, device=0, mass_regularization=True):
+    """(DescC, x [n], p [np], KinodynSettings, RobotModel): everything hipnlp_create / hipnlp_set_params / hipnlp_eval need, from a
+    reference `Settings` and a filled, horizon-expanded reference `Variables`."""
+    numeric = settings_from_reference(settings, terrain_steps)
+    if model is None:
+        model = model_from_reference(settings)
+    x, p, xn, pn = flatten_reference(variables, model.get_total_mass(), mass_regularization)
+    N = numeric.horizon_length
+    if x.size != _abi.NXK * N + _abi.NXG or p.size != _abi.NPK * N + _abi.NPG:
+        raise ValueError(f"not the kinodynamic Variables tree the engine evaluates: {x.size} variables and {p.size} parameters for "
+                         f"horizon {N} (expected {_abi.NXK * N + _abi.NXG} and {_abi.NPK * N + _abi.NPG})")
+    desc = _abi.DescC()
+    desc.settings = numeric.to_c()
+    desc.model = model.to_c()
+    desc.batch, desc.knot_begin, desc.knot_end, desc.device = int(batch), 0, 0, int(device)
+    return desc, x, p, numeric, model
+
+
+__all__ = ["expression_type", "settings_from_reference", "model_from_reference", "flatten_reference", "from_reference", "yaw_corner_indices"]

@@ -128,14 +128,19 @@ def _ip(a):
 class HipNlp:
     """One engine handle: a kinodynamic NLP (settings + robot model) on one HIP device."""
 
-    def __init__(self, settings, model, batch=1, knot_begin=0, knot_end=0, device=0):
+    def __init__(self, settings, model, batch=1, knot_begin=0, knot_end=0, device=0, desc=None):
+        """desc: a ready hipnlp_desc (e.g. hippopt_amd.from_reference.from_reference) instead of settings / model"""
         self.lib = load_library()
-        self.desc = _abi.DescC()
-        self.desc.settings = settings.to_c()
-        self.desc.model = model.to_c()
-        self.desc.batch = int(batch)
-        self.desc.knot_begin, self.desc.knot_end = int(knot_begin), int(knot_end)
-        self.desc.device = int(device)
+        if desc is not None:
+            self.desc = desc
+            batch = desc.batch
+        else:
+            self.desc = _abi.DescC()
+            self.desc.settings = settings.to_c()
+            self.desc.model = model.to_c()
+            self.desc.batch = int(batch)
+            self.desc.knot_begin, self.desc.knot_end = int(knot_begin), int(knot_end)
+            self.desc.device = int(device)
         h = C.c_void_p()
         rc = self.lib.hipnlp_create(C.byref(self.desc), C.byref(h))
         if rc != 0:
@@ -146,6 +151,13 @@ class HipNlp:
         self.dims = d
         self.batch = int(batch)
         self.n, self.m, self.nnz, self.np = d.n, d.m, d.nnz, d.np
+
+    @classmethod
+    def from_desc(cls, desc):
+        """an engine from a hipnlp_desc structure or its raw bytes (a committed fixture, another process, ...)"""
+        if not isinstance(desc, _abi.DescC):
+            desc = _abi.DescC.from_buffer_copy(bytes(desc))
+        return cls(None, None, desc=desc)
 
     def close(self):
         if getattr(self, "h", None):

@@ -97,13 +97,29 @@ class RobotModel:
     def link_poses(self, pb, quat_xyzw, s):
         q = np.asarray(quat_xyzw, float)
         q = q / np.linalg.norm(q)
-        R = [rot_from_quat_xyzw(q)]
-        o = [np.asarray(pb, float)]
-        for j in range(self.NDoF):
+        R = [None] * (self.NDoF + 1)
+        o = [None] * (self.NDoF + 1)
+        R[0], o[0] = rot_from_quat_xyzw(q), np.asarray(pb, float)
+        for j in self.evaluation_order():
             par = int(self.parent[j])
-            R.append(R[par] @ self.R_fix[j] @ rot_axis_angle(self.axis[j], s[j]))
-            o.append(o[par] + R[par] @ self.o_fix[j])
+            R[j + 1] = R[par] @ self.R_fix[j] @ rot_axis_angle(self.axis[j], s[j])
+            o[j + 1] = o[par] + R[par] @ self.o_fix[j]
         return R, o
+
+    def evaluation_order(self):
+        """joints ordered so that each comes after the joint moving its parent link (the numbering is joints_name_list order,
+        which need not follow the tree)"""
+        done, order = {0}, []
+        while len(order) < self.NDoF:
+            progressed = False
+            for j in range(self.NDoF):
+                if (j + 1) not in done and int(self.parent[j]) in done:
+                    done.add(j + 1)
+                    order.append(j)
+                    progressed = True
+            if not progressed:
+                raise ValueError("the parent links do not form a tree rooted at link 0")
+        return order
 
     def frame_pose(self, frame, pb, quat_xyzw, s):
         R, o = self.link_poses(pb, quat_xyzw, s)

@@ -256,11 +256,29 @@ template <class S> M3<S> rotation_from_axis_angle(const double* axis, const S& q
 
 template <class S> struct LinkPose { M3<S> R; V3<S> o; };
 
+// joints in an order in which every joint comes after the joint that moves its parent link (the joint numbering is the
+// reference's joints_name_list order, which need not follow the tree)
+inline void joint_evaluation_order(const hipnlp_robot_model& md, int* order /*NJ*/) {
+    bool done[HIPNLP_NL];
+    for (int i = 0; i < HIPNLP_NL; ++i) done[i] = i == 0;
+    int n = 0;
+    while (n < HIPNLP_NJ) {
+        const int before = n;
+        for (int j = 0; j < HIPNLP_NJ; ++j)
+            if (!done[j + 1] && done[md.parent[j]]) { done[j + 1] = true; order[n++] = j; }
+        if (n == before) break;   // not a tree rooted at link 0 (rejected by the engine's own model check)
+    }
+    for (int j = 0; n < HIPNLP_NJ && j < HIPNLP_NJ; ++j) if (!done[j + 1]) { done[j + 1] = true; order[n++] = j; }
+}
+
 // world_H_link for every link: H_b * prod(parent_H_child(s_j))  (adam forward_kinematics)
 template <class S> void all_link_poses(const hipnlp_robot_model& md, const V3<S>& pb, const M3<S>& Rb, const S* s, LinkPose<S>* out,
                                        const bool* needed = nullptr) {
     out[0].R = Rb; out[0].o = pb;
-    for (int j = 0; j < HIPNLP_NJ; ++j) {
+    int order[HIPNLP_NJ];
+    joint_evaluation_order(md, order);
+    for (int q = 0; q < HIPNLP_NJ; ++q) {
+        const int j = order[q];
         if (needed && !needed[j + 1]) continue;
         const LinkPose<S>& par = out[md.parent[j]];
         M3<S> Rloc = mul(m3c<S>(md.R_fix[j]), rotation_from_axis_angle(md.axis[j], s[j]));
@@ -303,7 +321,10 @@ template <class S> void centroidal_momentum(const hipnlp_robot_model& md, const 
     all_link_poses(md, pb, Rb, s, links);
     V3<S> w[HIPNLP_NL], vo[HIPNLP_NL];  // angular velocity and linear velocity of the link-frame origin
     w[0] = omega; vo[0] = pb_dot;
-    for (int j = 0; j < HIPNLP_NJ; ++j) {
+    int order[HIPNLP_NJ];
+    joint_evaluation_order(md, order);
+    for (int q = 0; q < HIPNLP_NJ; ++q) {
+        const int j = order[q];
         int par = md.parent[j];
         V3<S> a = mul(links[j + 1].R, v3c<S>(md.axis[j]));
         w[j + 1] = w[par] + scale(a, s_dot[j]);

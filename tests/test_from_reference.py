@@ -1,0 +1,87 @@
+"""hippopt_amd.from_reference: the adapter from the reference's own `Settings` / `Variables` objects to (hipnlp_desc, p, x).
+tools/gen_from_reference_fixture.py runs it ON THE REFERENCE'S CLASSES in the build container and commits the result
+(tests/golden/from_reference_periodic_N4.npz); here the fixture is replayed against the build's own settings / model classes, and the
+adapter is exercised again on duck-typed stand-ins (the reference does not travel to the test machine)."""
+import ctypes
+import os
+import types
+
+import numpy as np
+import pytest
+
+from hippopt_amd import _abi
+from hippopt_amd.from_reference import expression_type, flatten_reference, from_reference, settings_from_reference
+from hippopt_amd.kinodyn_settings import periodic_step_settings, stairs_terrain_steps
+from hippopt_amd.synthetic import make_workload
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "from_reference_periodic_N4.npz")
+
+
+def test_fixture_from_the_reference_objects_matches_the_builds_own_classes(model):
+    z = np.load(GOLD)
+    N = int(z["horizon"])
+    st = periodic_step_settings(N, model)
+    x, p = make_workload(st, model, batch=1, seed=int(z["seed"]))
+    assert np.max(np.abs(z["x"] - x[0])) < 1e-15 and np.max(np.abs(z["p"] - p[0])) < 1e-15   # mass regularisation applied by the adapter
+    mine = _abi.DescC()
+    mine.settings, mine.model, mine.batch = st.to_c(), model.to_c(), 1
+    blob = np.frombuffer(ctypes.string_at(ctypes.addressof(mine), ctypes.sizeof(mine)), dtype=np.uint8)
+    ref = _abi.DescC.from_buffer_copy(z["desc"].tobytes())
+    assert ref.settings.horizon == N and ref.batch == 1
+    # field by field where rounding may differ (the model went through URDF text), byte for byte elsewhere
+    for name in ("R_fix", "o_fix", "axis", "mass", "com", "inertia", "frame_R", "frame_o"):
+        a = np.frombuffer(bytes(getattr(ref.model, name)), dtype=np.float64)
+        b = np.frombuffer(bytes(getattr(mine.model, name)), dtype=np.float64)
+        assert np.max(np.abs(a - b)) < 1e-15, name
+    assert list(ref.model.parent) == list(mine.model.parent) and list(ref.model.frame_link) == list(mine.model.frame_link)
+    assert bytes(ref.settings) == bytes(mine.settings)
+    assert z["desc"].size == blob.size
+
+
+def _duck_settings(model, N):
+    cp = types.SimpleNamespace(
+        left=[types.SimpleNamespace(foot_frame="l_sole", position_in_foot_frame=d) for d in periodic_step_settings(N, model).left_descriptors],
+        right=[types.SimpleNamespace(foot_frame="r_sole", position_in_foot_frame=d) for d in periodic_step_settings(N, model).right_descriptors])
+    st = periodic_step_settings(N, model)
+    fields = {f: getattr(st, f) for f in ("horizon_length", "time_step", "dcc_gain", "dcc_epsilon", "maximum_force_derivative",
+                                          "maximum_angular_momentum", "joint_regularization_cost_weights", "maximum_joint_positions",
+                                          "minimum_joint_positions", "maximum_joint_velocities", "minimum_joint_velocities")}
+    return types.SimpleNamespace(contact_points=cp, terrain=None, gravity=st.gravity, root_link="root_link",
+                                 desired_frame_quaternion_cost_frame_name="chest", joints_name_list=list(model.joint_names),
+                                 final_state_expression_type=types.SimpleNamespace(name="subject_to"),
+                                 periodicity_expression_type=types.SimpleNamespace(name="skip"), **fields)
+
+
+def test_settings_mapping_and_errors(model):
+    s = _duck_settings(model, 6)
+    num = settings_from_reference(s)
+    assert num.horizon_length == 6 and num.final_state_expression_type == _abi.EXPR_SUBJECT_TO and num.periodicity_expression_type == _abi.EXPR_SKIP
+    assert num.dcc_gain == 40.0 and num.terrain == _abi.TERRAIN_PLANAR
+    assert expression_type(2) == 2 and expression_type(types.SimpleNamespace(name="ExpressionType.minimize")) == _abi.EXPR_MINIMIZE
+    s.terrain = type("TerrainSum", (), {})()
+    with pytest.raises(ValueError, match="terrain_steps"):
+        settings_from_reference(s)
+    num = settings_from_reference(s, terrain_steps=stairs_terrain_steps())
+    assert num.terrain == _abi.TERRAIN_SMOOTH_STEPS and num.to_c().n_terrain_steps == 2
+    s.joint_regularization_cost_weights = np.ones(5)
+    with pytest.raises(ValueError, match="23 entries"):
+        settings_from_reference(s, terrain_steps=stairs_terrain_steps())
+
+
+def test_flatten_through_the_mirror_structure(model):
+    """the build's own OptimizationObject mirror has the reference's to_dicts() contract: the adapter flattens it the same way"""
+    from hippopt_amd.base import extend_structure_to_horizon
+    from hippopt_amd.turnkey_planners.humanoid_kinodynamic import Settings
+    from hippopt_amd.turnkey_planners.humanoid_kinodynamic.variables import Variables
+    N = 3
+    st = Settings.from_numeric(periodic_step_settings(N, model))
+    tree = extend_structure_to_horizon(Variables(settings=st, kin_dyn_object=model), horizon=N)
+    x, p, xn, pn = flatten_reference(tree, model.get_total_mass())
+    assert x.size == 189 * N + 6 and p.size == 79 * N + 326
+    assert xn[0][0].endswith("contact_points.left[0].v") and xn[-1][0] == "initial_state.centroidal_momentum"
+    s = _duck_settings(model, N)
+    desc, x2, p2, num, m2 = from_reference(s, tree, model=model)
+    assert desc.settings.horizon == N and np.array_equal(x, x2) and np.array_equal(p, p2)
+    s.horizon_length = 5
+    with pytest.raises(ValueError, match="not the kinodynamic Variables tree"):
+        from_reference(s, tree, model=model)

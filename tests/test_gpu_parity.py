@@ -660,3 +660,47 @@ def test_hessian_at_full_size_is_the_derivative_of_the_lagrangian_gradient(model
     for b in range(B):
         Hd = hessian_times(hr, hc, vals[b], eng.n, d[b])
         assert np.max(np.abs(Hd - fd[b])) <= (1e-6 if workload == "periodic" else 1e-4) * max(1.0, np.max(np.abs(Hd)))
+
+
+def test_engine_from_the_reference_objects_fixture(model, HipNlp):
+    """tests/golden/from_reference_periodic_N4.npz = what hippopt_amd.from_reference produced from the reference's own Settings /
+    Variables objects (tools/gen_from_reference_fixture.py): the engine created from the stored hipnlp_desc BYTES, fed the stored
+    p and x, against the oracle."""
+    import os
+    from oracle_lib import Oracle
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "from_reference_periodic_N4.npz"))
+    eng = HipNlp.from_desc(z["desc"].tobytes())
+    eng.set_params(z["p"][None, :])
+    f, grad, g, jac = eng.eval(z["x"][None, :])
+    st = periodic_step_settings(int(z["horizon"]), model)
+    orc = Oracle(st, model)
+    fo, grado, go, jaco = orc.eval(z["x"], z["p"])
+    assert (eng.n, eng.m, eng.nnz) == (orc.n, orc.m, orc.nnz)
+    assert rel(f[0], fo) < TOL and rel(grad[0], grado) < TOL and rel(g[0], go) < TOL and rel(jac[0], jaco) < TOL
+
+
+@pytest.mark.parametrize("seed", [0, 3])
+def test_joint_numbering_that_does_not_follow_the_tree(model, HipNlp, seed):
+    """A joints_name_list need not list a joint after its parent joint (ergoCub's names torso_pitch before torso_roll): a randomly
+    renumbered robot, callback quartet and exact Hessian against the oracle, planar and smooth terrain."""
+    from hess_util import hess_mismatch, triplets_to_dict
+    from oracle_lib import Oracle
+    from test_kernel_body_hostemu import renumbered
+    m2 = renumbered(model, np.random.RandomState(seed).permutation(23))
+    for maker, N, tol in ((periodic_step_settings, 9, TOL), (stairs_settings, 5, 1e-9)):
+        st = maker(N, m2)
+        x, p = make_workload(st, m2, batch=2, seed=950 + seed)
+        eng, orc = HipNlp(st, m2, batch=2), Oracle(st, m2)
+        ir, jc = eng.sparsity()
+        iro, jco = orc.sparsity()
+        assert np.array_equal(ir, iro) and np.array_equal(jc, jco)
+        eng.set_params(p)
+        f, grad, g, jac = eng.eval(x)
+        lam = np.random.RandomState(seed).standard_normal((2, orc.m))
+        hr, hc = eng.hess_sparsity()
+        hv = eng.eval_hess(x, 0.7, lam)
+        for b in range(2):
+            fo, grado, go, jaco = orc.eval(x[b], p[b])
+            assert rel(f[b], fo) < TOL and rel(grad[b], grado) < TOL and rel(g[b], go) < TOL and rel(jac[b], jaco) < TOL
+            err, where = hess_mismatch(triplets_to_dict(hr, hc, hv[b]), triplets_to_dict(*orc.hess(x[b], p[b], 0.7, lam[b])))
+            assert err <= tol, (b, where)

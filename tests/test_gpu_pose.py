@@ -277,3 +277,28 @@ def test_pose_device_pointer_paths(model):
     assert np.array_equal(fd.cpu().numpy(), f) and np.array_equal(jacd.cpu().numpy().reshape(B, -1), jac)
     assert np.array_equal(gd.cpu().numpy().reshape(B, -1), g) and np.array_equal(gradd.cpu().numpy().reshape(B, -1), grad)
     assert np.array_equal(hd.cpu().numpy().reshape(B, -1), hv)
+
+
+def test_pose_with_a_joint_numbering_that_does_not_follow_the_tree(model):
+    """the pose kernels on a randomly renumbered robot (a joints_name_list that does not list joints parent-first), against the oracle"""
+    from hippopt_amd.hipnlp import HipPose
+    from hippopt_amd.pose_settings import make_pose_workload, pose_finder_settings
+    from oracle_lib import PoseOracle
+    from test_kernel_body_hostemu import renumbered
+    m2 = renumbered(model, np.random.RandomState(5).permutation(23))
+    pst = pose_finder_settings(m2)
+    x, p = make_pose_workload(pst, m2, batch=2, seed=19)
+    pose, orc = HipPose(pst, m2, batch=2), PoseOracle(pst, m2)
+    pose.set_params(p)
+    f, grad, g, jac = pose.eval(x)
+    lam = np.random.RandomState(2).standard_normal((2, pose.m))
+    hr, hc = pose.hess_sparsity()
+    hv = pose.eval_hess(x, 0.9, lam)
+    for b in range(2):
+        fo, grado, go, jaco = orc.eval(x[b], p[b])
+        for a, r in ((f[b], fo), (grad[b], grado), (g[b], go), (jac[b], jaco)):
+            assert np.max(np.abs(np.asarray(a) - np.asarray(r)) / np.maximum(1.0, np.abs(np.asarray(r)))) < 1e-11
+        Ho = np.tril(orc.hess(x[b], p[b], 0.9, lam[b]))
+        H = np.zeros_like(Ho)
+        H[hr, hc] = hv[b]
+        assert np.max(np.abs(H - Ho) / np.maximum(1.0, np.abs(Ho))) < 1e-11

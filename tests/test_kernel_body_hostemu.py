@@ -119,14 +119,85 @@ def test_invalid_models_are_rejected(model):
     import copy
     bad = copy.deepcopy(model)
     bad.parent = bad.parent.copy()
-    bad.parent[5] = 9  # parent after child: not topologically ordered
+    bad.parent[5] = 7  # link 6 under link 7, which hangs under link 6: a cycle, not a tree rooted at link 0
     with pytest.raises(RuntimeError):
         HostEmu(periodic_step_settings(3, bad), bad)
+    bad3 = copy.deepcopy(model)
+    bad3.parent = bad3.parent.copy()
+    bad3.parent[4] = 5  # a joint whose parent link is its own child link
+    with pytest.raises(RuntimeError):
+        HostEmu(periodic_step_settings(3, bad3), bad3)
     bad2 = copy.deepcopy(model)
     bad2.frame_link = bad2.frame_link.copy()
     bad2.frame_link[0] = 15  # sole on the knee link: 4-joint chain, the kernel wants 6
     with pytest.raises(RuntimeError):
         HostEmu(periodic_step_settings(3, bad2), bad2)
+
+
+def renumbered(model, perm):
+    """the same robot with joint j renamed perm[j] (child link j + 1 -> perm[j] + 1): what a joints_name_list that does not follow
+    the kinematic tree produces (the x layout is the list order, variables.py:182-217)"""
+    import copy
+    m = copy.deepcopy(model)
+    nj = len(perm)
+    link = np.concatenate([[0], np.asarray(perm) + 1])   # old link -> new link
+    for j in range(nj):
+        jn = perm[j]
+        m.parent[jn] = link[model.parent[j]]
+        m.R_fix[jn], m.o_fix[jn], m.axis[jn] = model.R_fix[j], model.o_fix[j], model.axis[j]
+        m.min_joint_positions[jn], m.max_joint_positions[jn] = model.min_joint_positions[j], model.max_joint_positions[j]
+    for l in range(nj + 1):
+        m.mass[link[l]], m.com[link[l]], m.inertia[link[l]] = model.mass[l], model.com[l], model.inertia[l]
+    m.frame_link = np.array([link[l] for l in model.frame_link], np.int32)
+    m.joint_names = [None] * nj
+    for j in range(nj):
+        m.joint_names[perm[j]] = model.joint_names[j]
+    return m
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_joint_numbering_need_not_follow_the_tree(model, seed):
+    """ergoCub's joints_name_list names torso_pitch before torso_roll whatever the URDF chains first: the engine takes ANY numbering
+    of a tree rooted at link 0.  A randomly renumbered robot against the oracle (callback quartet and exact Hessian), and the cost
+    against the same robot in tree order at the same physical state."""
+    from hess_util import hess_mismatch, triplets_to_dict
+    perm = np.random.RandomState(seed).permutation(23)
+    m2 = renumbered(model, perm)
+    assert any(int(m2.parent[j]) > j + 1 for j in range(23))   # really not topological
+    for maker, N in ((periodic_step_settings, 4), (stairs_settings, 3)):
+        st2 = maker(N, m2)
+        st2.joint_regularization_cost_weights = np.linspace(0.5, 2.0, 23)
+        x2, p2 = make_workload(st2, m2, 1, 900 + seed)
+        o, he = Oracle(st2, m2), HostEmu(st2, m2)
+        fo, grado, go, jaco = o.eval(x2[0], p2[0])
+        f, grad, g, jac, _ = he.eval(x2[0], p2[0])
+        iro, jco = o.sparsity()
+        ir, jc = he.sparsity()
+        assert np.array_equal(ir, iro) and np.array_equal(jc, jco)
+        assert rel(f, fo) < 1e-11 and rel(grad, grado) < 1e-11 and rel(g, go) < 1e-11 and rel(jac, jaco) < 1e-11
+        lam = np.random.RandomState(seed).standard_normal(o.m)
+        ref = triplets_to_dict(*o.hess(x2[0], p2[0], 0.7, lam))
+        hr, hc = he.hess_sparsity()
+        err, where = hess_mismatch(triplets_to_dict(hr, hc, he.hess(x2[0], p2[0], 0.7, lam)), ref)
+        assert err < (1e-9 if maker is stairs_settings else 1e-11), where
+    # the same physical state in tree order gives the same cost
+    from hippopt_amd import kinodyn_layout as KL
+    st1, st2 = periodic_step_settings(4, model), periodic_step_settings(4, m2)
+    st2.joint_regularization_cost_weights = np.linspace(0.5, 2.0, 23)
+    st1.joint_regularization_cost_weights = st2.joint_regularization_cost_weights[perm]
+    x2, p2 = make_workload(st2, m2, 1, 77)
+    x1, p1 = x2.copy(), p2.copy()
+    pl = KL.ParamLayout(4)
+    joint_blocks_x = [189 * k + off for k in range(4) for off in (134, 157)]
+    joint_blocks_p = [pl.ref(k) + pl.REF["joint_regularization"] for k in range(4)] + [pl.init + 79, pl.fin + 79, pl.jpmax, pl.jpmin, pl.jvmax, pl.jvmin]
+    for b in joint_blocks_x:
+        x1[0, b:b + 23] = x2[0, b + perm]
+    for b in joint_blocks_p:
+        p1[0, b:b + 23] = p2[0, b + perm]
+    f2, _, g2, _, _ = HostEmu(st2, m2).eval(x2[0], p2[0])
+    f1, _, g1, _, _ = HostEmu(st1, model).eval(x1[0], p1[0])
+    assert abs(f1 - f2) <= 1e-10 * max(1.0, abs(f2))
+    assert abs(np.sort(g1) - np.sort(g2)).max() <= 1e-10 * max(1.0, np.abs(g2).max())   # the rows are a permutation of each other
 
 
 # ---- exact Hessian of the Lagrangian (knot_hess_body.h) -------------------------------------------------------------------------
