@@ -206,7 +206,8 @@ def host_visible(eng, x_np, horizon, batch):
         t0 = time.perf_counter()
         for i in range(reps):
             eng.eval(xs[i % 4], want=want, out=out)
-        res[name] = {"ms_per_call": 1e3 * (time.perf_counter() - t0) / reps}
+        res[name] = {"ms_per_call": 1e3 * (time.perf_counter() - t0) / reps,
+                     "library_us [x staging, enqueue, wait for the GPU, copies out]": [round(float(v), 2) for v in eng.host_breakdown()]}
     for i in range(10):
         eng.eval_pinned(xs[i % 4])
     t0 = time.perf_counter()

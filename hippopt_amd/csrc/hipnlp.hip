@@ -1040,7 +1040,10 @@ int hipnlp_stage_rows(const hipnlp_handle* h, int k, int32_t* rows) {
 // staging copy), the others stay in device memory.  A cached evaluation (new_x = 0): outputs not on the host yet are fetched from
 // the device copies with one asynchronous copy each.  (Measured on MI355X, profiles/r02_pcie_probe.txt: launch + synchronise 11.6 us;
 // kernel stores to pinned memory 56 GB/s; the same bytes through device memory + hipMemcpyAsync: + 10 us.)
-struct HostDest { double *f = nullptr, *grad = nullptr, *g = nullptr, *jac = nullptr; };   // device-visible addresses of registered caller arrays (or null)
+struct HostDest {   // registered caller arrays: device-visible addresses (or null) and the host addresses they belong to
+    double *f = nullptr, *grad = nullptr, *g = nullptr, *jac = nullptr;
+    double *grad_host = nullptr, *g_host = nullptr, *jac_host = nullptr;
+};
 static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned want, const HostDest& dst = HostDest(), unsigned* direct = nullptr) {
     const size_t B = size_t(h->batch), n = size_t(h->L.n), m = size_t(h->L.m), nnz = size_t(h->L.nnz);
     if (direct) *direct = 0;
@@ -1086,14 +1089,25 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
         h->have_result = false;
         return host_evaluate(h, h->h_x, 1, want, dst, direct);
     }
-    if (missing) {
+    if (missing) {   // still in HBM: one copy each — straight into the caller's array when that is registered (page-locked), else into the pinned block
         HIP_TRY(h, hipSetDevice(h->dev));
+        unsigned to_caller = 0;
         if (missing & HIPNLP_WANT_F) HIP_TRY(h, hipMemcpyAsync(h->h_f, h->d_f, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        if (missing & HIPNLP_WANT_GRAD) HIP_TRY(h, hipMemcpyAsync(h->h_grad, h->d_grad, B * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        if (missing & HIPNLP_WANT_G) HIP_TRY(h, hipMemcpyAsync(h->h_g, h->d_g, B * m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        if (missing & HIPNLP_WANT_JAC) HIP_TRY(h, hipMemcpyAsync(h->h_jac, h->d_jac, B * nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (missing & HIPNLP_WANT_GRAD) {
+            if (dst.grad_host) to_caller |= HIPNLP_WANT_GRAD;
+            HIP_TRY(h, hipMemcpyAsync(dst.grad_host ? dst.grad_host : h->h_grad, h->d_grad, B * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        }
+        if (missing & HIPNLP_WANT_G) {
+            if (dst.g_host) to_caller |= HIPNLP_WANT_G;
+            HIP_TRY(h, hipMemcpyAsync(dst.g_host ? dst.g_host : h->h_g, h->d_g, B * m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        }
+        if (missing & HIPNLP_WANT_JAC) {
+            if (dst.jac_host) to_caller |= HIPNLP_WANT_JAC;
+            HIP_TRY(h, hipMemcpyAsync(dst.jac_host ? dst.jac_host : h->h_jac, h->d_jac, B * nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        }
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        h->on_host |= missing;
+        h->on_host |= missing & ~to_caller;   // (an output copied into a caller array stays in HBM: a later request copies again)
+        if (direct) *direct |= to_caller;
     }
     return HIPNLP_OK;
 }
@@ -1112,6 +1126,9 @@ int hipnlp_eval(hipnlp_handle* h, const double* x, int new_x, double* f, double*
     dst.grad = device_address_of(grad_f, B * n * sizeof(double));
     dst.g = device_address_of(g, B * m * sizeof(double));
     dst.jac = device_address_of(jac, B * nnz * sizeof(double));
+    dst.grad_host = dst.grad ? grad_f : nullptr;
+    dst.g_host = dst.g ? g : nullptr;
+    dst.jac_host = dst.jac ? jac : nullptr;
     unsigned direct = 0;
     const int rc = host_evaluate(h, x, new_x, want, dst, &direct);
     if (rc != HIPNLP_OK) return rc;

@@ -76,6 +76,78 @@ class _PoseEngine:
         return self._pose.eval_hess(x, obj_factor, lam)[0]
 
 
+class _SimpleBoundsLift:
+    """What nlpsol's `detect_simple_bounds` does to the NLP before IPOPT sees it (the reference runs Opti with
+    {"expand": True, "detect_simple_bounds": True}, main_periodic_step.py:109-110): every row of g that is exactly ONE decision
+    variable — the u_v and joint position / velocity boxes of planner.py:386-405,699-719 (70 rows per interior knot), the `x_0 ==
+    initial_state` rows and the final-state rows — leaves g and its Jacobian and becomes a bound on that variable (lbx / ubx).
+    The engine keeps evaluating its full, fixed layout (`hipnlp_simple_rows` marks the rows); this wrapper presents the reduced
+    problem to the NLP driver: g and jac g restricted to the kept rows (index arrays computed once), the lifted bounds folded into
+    lbx / ubx, and the multipliers mapped back so that `Output.constraint_multipliers` still carries every named constraint: the
+    multiplier of a lifted row is the bound multiplier of its variable (z_U - z_L), given to the row whose bound is the active one."""
+
+    def __init__(self, eng):
+        self._eng = eng
+        self.n, self.m_full = eng.n, eng.m
+        is_simple, var = eng.simple_rows()
+        self.lifted_rows = np.nonzero(is_simple)[0]
+        self.lifted_vars = var[self.lifted_rows].astype(np.int64)
+        self.keep_rows = np.nonzero(is_simple == 0)[0]
+        self.m = int(self.keep_rows.size)
+        new_row = np.full(self.m_full, -1, np.int64)
+        new_row[self.keep_rows] = np.arange(self.m)
+        ir, jc = eng.sparsity()
+        self.keep_entries = np.nonzero(new_row[ir] >= 0)[0]
+        self._ir = new_row[ir[self.keep_entries]].astype(np.int32)
+        self._jc = jc[self.keep_entries].astype(np.int32)
+        self.nnz = int(self.keep_entries.size)
+        self._lam_full = np.zeros(self.m_full)
+
+    def __getattr__(self, name):   # cost_terms, row_blocks, hess_sparsity, set_params, ...: the engine's own
+        return getattr(self._eng, name)
+
+    def bounds(self):
+        lbx, ubx, lbg, ubg = self._eng.bounds()
+        lbx, ubx = lbx.copy(), ubx.copy()
+        np.maximum.at(lbx, self.lifted_vars, lbg[self.lifted_rows])
+        np.minimum.at(ubx, self.lifted_vars, ubg[self.lifted_rows])
+        self._lbg_lift, self._ubg_lift, self._lbx, self._ubx = lbg[self.lifted_rows], ubg[self.lifted_rows], lbx, ubx
+        return lbx, ubx, lbg[self.keep_rows], ubg[self.keep_rows]
+
+    def sparsity(self):
+        return self._ir, self._jc
+
+    def eval(self, x, new_x=True, want=("f", "grad", "g", "jac"), nan_ok=False):
+        f, grad, g, jac = self._eng.eval(x, new_x=new_x, want=want, nan_ok=nan_ok)
+        return f, grad, (g[:, self.keep_rows] if g is not None else None), (jac[:, self.keep_entries] if jac is not None else None)
+
+    def full_multipliers(self, lam_reduced, lam_x=None):
+        """lambda over ALL rows of the engine's layout from the reduced problem's row multipliers and the multipliers lam_x of the
+        variable bounds (signed, Lagrangian f + lambda^T g + lam_x^T x: IPOPT's mult_x_U - mult_x_L).  The multiplier of a variable's
+        bound goes to the lifted row that defines the bound the variable ended up with (the first one, should several rows define
+        the same bound); the other lifted rows of that variable are inactive."""
+        lam = np.zeros(self.m_full)
+        if lam_reduced is not None:
+            lam[self.keep_rows] = np.asarray(lam_reduced, float).reshape(-1)
+        if lam_x is not None:
+            lx = np.asarray(lam_x, float).reshape(-1)
+            v = self.lifted_vars
+            defines = np.where(lx[v] >= 0.0, self._ubg_lift <= self._ubx[v], self._lbg_lift >= self._lbx[v])
+            first = np.zeros(v.size, bool)
+            seen = set()
+            for i in np.nonzero(defines)[0]:
+                if int(v[i]) not in seen:
+                    seen.add(int(v[i]))
+                    first[i] = True
+            lam[self.lifted_rows] = np.where(first, lx[v], 0.0)
+        return lam
+
+    def eval_hess(self, x, obj_factor, lam, out=None):
+        self._lam_full[:] = 0.0
+        self._lam_full[self.keep_rows] = np.asarray(lam, float).reshape(-1)   # lifted rows are linear: no second derivatives
+        return self._eng.eval_hess(x, obj_factor, self._lam_full[None, :])
+
+
 class _CallbackCache:
     """What IPOPT's `new_x` flag does for a C caller: the four callbacks of one iterate share ONE evaluation (one kernel launch, one
     device-to-host copy); a callback at an x the engine has already evaluated only copies its own output out of the staging block."""
@@ -109,7 +181,7 @@ class _CallbackCache:
 class HipNlpSolver:
     def __init__(self, settings, model, device=0, inner_solver="auto", options_solver=None, problem="kinodynamic",
                  callback_criterion: CallbackCriterion = None, callback_save_costs=True, callback_save_constraint_multipliers=True,
-                 error_on_fail=True):
+                 error_on_fail=True, detect_simple_bounds=True):
         """callback_* as in OptiSolver (opti_solver.py:105-131).  error_on_fail: CasADi's Opti raises when IPOPT does not report
         success (e.g. Maximum_Iterations_Exceeded), which is what triggers the best-iterate fallback of opti_solver.py:479-520;
         False keeps the last iterate of an unconverged run instead (useful for smoke runs with a few iterations)."""
@@ -118,6 +190,8 @@ class HipNlpSolver:
         self._callback_save_constraint_multipliers = callback_save_constraint_multipliers
         self._callback = None
         self._error_on_fail = error_on_fail
+        # casadi_opti_options["detect_simple_bounds"] of the reference scripts (main_periodic_step.py:110): kinodynamic problem only
+        self._detect_simple_bounds = bool(detect_simple_bounds) and problem == "kinodynamic"
         if problem not in ("kinodynamic", "pose"):
             raise ValueError("problem must be 'kinodynamic' or 'pose'")
         self._problem_kind = problem
@@ -129,6 +203,7 @@ class HipNlpSolver:
         self._var_index, self._par_index = {}, {}
         self._n = self._np = 0
         self._engine = None
+        self._lift = None
         self._values = self._cost_value = None
         self._cost_values, self._multipliers = {}, {}
         self._problem = None
@@ -251,10 +326,20 @@ class HipNlpSolver:
         return self.get_cost_expressions()
 
     # ---- solve --------------------------------------------------------------------------------------------
-    def solve(self):
+    def nlp_view(self):
+        """the engine as the NLP driver sees it: with the single-variable rows lifted into bounds when detect_simple_bounds is on"""
         eng = self.engine()
+        if self._detect_simple_bounds:
+            if self._lift is None or self._lift._eng is not eng:
+                self._lift = _SimpleBoundsLift(eng)
+            return self._lift
+        return eng
+
+    def solve(self):
+        full = self.engine()
         x0, p = self._pack()
-        eng.set_params(p[None, :])
+        full.set_params(p[None, :])
+        eng = self.nlp_view()
         lbx, ubx, lbg, ubg = eng.bounds()
         ir, jc = eng.sparsity()
 
@@ -284,7 +369,10 @@ class HipNlpSolver:
             if solver == "ipopt":
                 x, lam, info = self._solve_ipopt(eng, x0, lbx, ubx, lbg, ubg, ir, jc)
             else:
-                x, lam, info = self._solve_scipy(eng, x0, lbg, ubg, ir, jc)
+                x, lam, info = self._solve_scipy(eng, x0, lbx, ubx, lbg, ubg, ir, jc)
+            lam = self._expand_multipliers(eng, lam, info.get("lam_x"))
+            info["callbacks"] = dict(self._cache.calls, evaluations=self._cache.evaluations)
+            info["nlp"] = {"n": eng.n, "m": eng.m, "nnz": int(len(ir)), "simple_bounds_lifted": int(full.m - eng.m)}
             if self._error_on_fail and not info.get("success", True):
                 failure = RuntimeError("solver status: " + str(info.get("message", info.get("status"))))
         except Exception as err:  # noqa: BLE001
@@ -297,16 +385,24 @@ class HipNlpSolver:
             self._logger.warning("The solver failed to solve the problem, but the callback managed to save an intermediate "
                                  f"solution at iteration {cb.best_iteration}.")
             x = cb.best_x
-            lam = cb.best_constraint_multipliers if cb.best_constraint_multipliers is not None else np.zeros(eng.m)
+            lam = cb.best_constraint_multipliers if cb.best_constraint_multipliers is not None else np.zeros(full.m)
             self._cost_value = float(cb.best_cost)
             self._cost_values = dict(cb.best_cost_values) if self._callback_save_costs else {}
-            self._store_solution(eng, x, lam, with_multipliers=self._callback_save_constraint_multipliers)
+            self._store_solution(full, x, lam, with_multipliers=self._callback_save_constraint_multipliers)
             return
-        f, grad, g, jac = eng.eval(x[None, :])
+        f, grad, g, jac = full.eval(x[None, :])
         self._cost_value = float(f[0])
-        names, terms = eng.cost_terms()
+        names, terms = full.cost_terms()
         self._cost_values = {n: float(v) for n, v in zip(names, terms[0])}
-        self._store_solution(eng, x, lam)
+        self._store_solution(full, x, lam)
+
+    @staticmethod
+    def _expand_multipliers(eng, lam, lam_x=None):
+        """multipliers over every row of the engine's layout (the named constraints of Output.constraint_multipliers), whether or not
+        the NLP driver saw the reduced problem"""
+        if isinstance(eng, _SimpleBoundsLift) and lam is not None:
+            return eng.full_multipliers(lam, lam_x)
+        return lam
 
     def _store_solution(self, eng, x, lam, with_multipliers=True):
         self._multipliers = {}
@@ -318,13 +414,15 @@ class HipNlpSolver:
         values.from_dict(update)
         self._values = values
 
-    def _iterate_callback(self, iteration, x, cost, inf_pr, multipliers):
+    def _iterate_callback(self, iteration, x, cost, inf_pr, multipliers, lam_x=None):
         if self._callback is not None:
+            if multipliers is not None and self._lift is not None and self._detect_simple_bounds:
+                multipliers = self._lift.full_multipliers(multipliers, lam_x)
             self._callback(IterateInfo(int(iteration), float(cost), float(inf_pr)), x, multipliers,
                            (lambda: self._cost_values_at(np.asarray(x, float))) if self._callback_save_costs else None)
 
-    def _solve_scipy(self, eng, x0, lbg, ubg, ir, jc):
-        from scipy.optimize import BFGS, NonlinearConstraint, minimize
+    def _solve_scipy(self, eng, x0, lbx, ubx, lbg, ubg, ir, jc):
+        from scipy.optimize import BFGS, Bounds, NonlinearConstraint, minimize
         from scipy.sparse import csc_matrix
         m, n = eng.m, eng.n
 
@@ -370,13 +468,17 @@ class HipNlpSolver:
         nlc = NonlinearConstraint(cons, lbg, ubg, jac=jac, hess=hess_c)
         opts = {"maxiter": int(self._options.get("max_iter", 50)), "verbose": int(self._options.get("verbose", 0)),
                 "gtol": float(self._options.get("tol", 1e-6))}
+        bounded = bool(np.any(np.isfinite(lbx)) or np.any(np.isfinite(ubx)))   # (lifted single-variable rows: detect_simple_bounds)
+
         def on_iterate(xk, state):
-            self._iterate_callback(state.nit, xk, state.fun, state.constr_violation, state.v[0] if len(state.v) else None)
+            self._iterate_callback(state.nit, xk, state.fun, state.constr_violation, state.v[0] if len(state.v) else None,
+                                   state.v[1] if bounded and len(state.v) > 1 else None)
             return False
-        res = minimize(fun, x0, jac=grad, hess=hess_f, constraints=[nlc], method="trust-constr", options=opts, callback=on_iterate)
+        res = minimize(fun, x0, jac=grad, hess=hess_f, constraints=[nlc], bounds=Bounds(lbx, ubx) if bounded else None,
+                       method="trust-constr", options=opts, callback=on_iterate)
         lam = res.v[0] if len(res.v) else np.zeros(m)
         return res.x, lam, {"status": res.status, "success": res.status in (1, 2), "message": res.message, "iterations": res.nit,
-                            "constr_violation": res.constr_violation}
+                            "constr_violation": res.constr_violation, "lam_x": res.v[1] if bounded and len(res.v) > 1 else None}
 
     def _solve_ipopt(self, eng, x0, lbx, ubx, lbg, ubg, ir, jc):
         import cyipopt
@@ -404,13 +506,14 @@ class HipNlpSolver:
             def intermediate(self, alg_mod, iter_count, obj_value, inf_pr, inf_du, mu, d_norm, regularization_size, alpha_du, alpha_pr,
                              ls_trials):
                 x_it = getattr(self, "x_last", x0)   # cyipopt < 1.3 has no get_current_iterate: the last point the Jacobian saw
-                lam_it = None
+                lam_it = lam_x_it = None
                 try:
                     it = nlp.get_current_iterate()
                     x_it, lam_it = it["x"], it["mult_g"]
+                    lam_x_it = np.asarray(it["mult_x_U"]) - np.asarray(it["mult_x_L"])
                 except Exception:  # noqa: BLE001
                     pass
-                outer._iterate_callback(iter_count, x_it, obj_value, inf_pr, lam_it)
+                outer._iterate_callback(iter_count, x_it, obj_value, inf_pr, lam_it, lam_x_it)
                 return True
         exact = hasattr(eng, "eval_hess") and outer._options.get("hessian_approximation", "exact") != "limited-memory"
         if exact:
@@ -435,6 +538,8 @@ class HipNlpSolver:
         info = dict(info)
         info["success"] = info.get("status", -1) in (0, 1)   # Solve_Succeeded / Solved_To_Acceptable_Level
         info["message"] = info.get("status_msg", "")
+        if "mult_x_U" in info and "mult_x_L" in info:
+            info["lam_x"] = np.asarray(info["mult_x_U"]) - np.asarray(info["mult_x_L"])
         return x, info["mult_g"], info
 
     def get_values(self):

@@ -274,6 +274,12 @@ def test_planner_solve_plumbing(model):
     assert np.isfinite(out.cost_value)
     info = pl.optimization_solver._last_info
     assert info["constr_violation"] < viol0
+    # detect_simple_bounds (main_periodic_step.py:109-110): the driver saw the reduced problem, the output still names every constraint
+    assert info["nlp"]["simple_bounds_lifted"] == 70 * 2 + 47 + 81 and info["nlp"]["m"] == eng.m - info["nlp"]["simple_bounds_lifted"]
+    assert out.constraint_multipliers["joint_velocity_bounds"].shape == (3, 23) and info["callbacks"]["evaluations"] > 0
+    full = Planner(st, model, error_on_fail=False)
+    full.optimization_solver._detect_simple_bounds = False
+    assert full.optimization_solver.nlp_view() is full.optimization_solver.engine()
 
 
 def test_in_launch_reduction_stress(model, HipNlp):
@@ -704,3 +710,35 @@ def test_joint_numbering_that_does_not_follow_the_tree(model, HipNlp, seed):
             assert rel(f[b], fo) < TOL and rel(grad[b], grado) < TOL and rel(g[b], go) < TOL and rel(jac[b], jaco) < TOL
             err, where = hess_mismatch(triplets_to_dict(hr, hc, hv[b]), triplets_to_dict(*orc.hess(x[b], p[b], 0.7, lam[b])))
             assert err <= tol, (b, where)
+
+
+def test_sixteen_batched_guesses_through_the_engine(model, HipNlp):
+    """SURVEY 8f rank 2 as the row is written: 16 contact-phase descriptions -> ONE [16][n] block of decision vectors
+    (hippopt_amd.robot_planning.batched_guess) -> one launch of HipNlp(batch=16) on the stairs configuration (BASELINE config 5's
+    terrain, the reference's own horizon N = 50, main_walking_on_stairs.py:70).  Every guess against the same guess evaluated
+    alone (bitwise), three of them against the oracle."""
+    from oracle_lib import Oracle
+    from hippopt_amd.robot_planning.batched_guess import batched_guess_block
+    from test_batched_guess import make_case
+    N, B = 50, 16
+    st = stairs_settings(N, model)
+    rng = np.random.RandomState(50)
+    cases = [make_case(g, N * st.time_step, rng) for g in range(B)]
+    x = batched_guess_block([c[2] for c in cases], [c[3] for c in cases], [c[0] for c in cases], cases[0][1], N, st.time_step,
+                            model.get_total_mass())
+    _, p1 = make_workload(st, model, batch=1, seed=60)
+    p = np.repeat(p1, B, axis=0)
+    eng = HipNlp(st, model, batch=B)
+    eng.set_params(p)
+    f, grad, g, jac = eng.eval(x)
+    assert np.all(np.isfinite(f)) and np.all(np.isfinite(g)) and np.all(np.isfinite(jac))
+    assert len({float(v) for v in f}) == B    # sixteen different guesses
+    one = HipNlp(st, model, batch=1)
+    one.set_params(p1)
+    orc = Oracle(st, model)
+    for b in range(B):
+        f1, grad1, g1, jac1 = one.eval(x[b:b + 1])
+        assert f1[0] == f[b] and np.array_equal(g1[0], g[b]) and np.array_equal(jac1[0], jac[b]) and np.array_equal(grad1[0], grad[b])
+        if b in (0, 7, 15):
+            fo, grado, go, jaco = orc.eval(x[b], p[b])
+            assert rel(f[b], fo) < TOL and rel(grad[b], grado) < TOL and rel(g[b], go) < TOL and rel(jac[b], jaco) < TOL
