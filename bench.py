@@ -197,49 +197,48 @@ def host_visible(eng, x_np, horizon, batch):
     outs = eng.eval(x_np)
     kinds = {"f": ("f",), "g": ("g",), "grad": ("grad",), "jac": ("jac",), "f+g (trial point)": ("f", "g"), "all": ("f", "grad", "g", "jac")}
     res = {}
-    reps = 200
     eng.set_prefetch(())   # exactly what the call asks for crosses PCIe
+    def best_of(fn, passes=3, calls=100):
+        """ms per call: the fastest of `passes` passes of `calls` calls (wall-clock loops of ~30 us calls pick up transient host
+        effects — one pass of a fresh process ran 8x slower than its neighbours with the library's own share unchanged)"""
+        for i in range(10):
+            fn(i)
+        best = float("inf")
+        for _ in range(passes):
+            t0 = time.perf_counter()
+            for i in range(calls):
+                fn(i)
+            best = min(best, (time.perf_counter() - t0) / calls)
+        return 1e3 * best
     for name, want in kinds.items():
         out = tuple(o if k in want else None for k, o in zip(("f", "grad", "g", "jac"), outs))
-        for i in range(10):
-            eng.eval(xs[i % 4], want=want, out=out)
-        t0 = time.perf_counter()
-        for i in range(reps):
-            eng.eval(xs[i % 4], want=want, out=out)
-        res[name] = {"ms_per_call": 1e3 * (time.perf_counter() - t0) / reps,
+        res[name] = {"ms_per_call": best_of(lambda i: eng.eval(xs[i % 4], want=want, out=out)),
                      "library_us [x staging, enqueue, wait for the GPU, copies out]": [round(float(v), 2) for v in eng.host_breakdown()]}
-    for i in range(10):
-        eng.eval_pinned(xs[i % 4])
-    t0 = time.perf_counter()
-    for i in range(reps):
-        eng.eval_pinned(xs[i % 4])
-    res["all (zero-copy views of the pinned block)"] = {"ms_per_call": 1e3 * (time.perf_counter() - t0) / reps}
+    res["all (zero-copy views of the pinned block)"] = {"ms_per_call": best_of(lambda i: eng.eval_pinned(xs[i % 4]))}
     # caller arrays registered with the library once (hipnlp_host_register): the kernel stores straight into them, no staging copy
     eng.register_outputs(outs)
     try:
         for name, want in (("g", ("g",)), ("jac", ("jac",)), ("all", ("f", "grad", "g", "jac"))):
             out = tuple(o if k in want else None for k, o in zip(("f", "grad", "g", "jac"), outs))
-            for i in range(10):
-                eng.eval(xs[i % 4], want=want, out=out)
-            t0 = time.perf_counter()
-            for i in range(reps):
-                eng.eval(xs[i % 4], want=want, out=out)
-            res[name + " (caller arrays registered: direct kernel stores)"] = {"ms_per_call": 1e3 * (time.perf_counter() - t0) / reps}
+            res[name + " (caller arrays registered: direct kernel stores)"] = {"ms_per_call": best_of(lambda i: eng.eval(xs[i % 4], want=want, out=out))}
     finally:
         eng.unregister_outputs(outs)
     # an IPOPT iterate with the default prefetch set {f, grad, g}: f and g at the trial point (new x), then grad f and jac g at the
     # accepted point (new_x = 0: grad is already on the host, jac is fetched from HBM)
     eng.set_prefetch(("f", "grad", "g"))
     f_, grad_, g_, jac_ = outs
-    for i in range(10):
-        eng.eval(xs[i % 4], want=("f",), out=(f_, None, None, None))
-    t0 = time.perf_counter()
-    for i in range(reps):
+
+    def iterate(i):
         eng.eval(xs[i % 4], new_x=True, want=("f",), out=(f_, None, None, None))
         eng.eval(xs[i % 4], new_x=False, want=("g",), out=(None, None, g_, None))
         eng.eval(xs[i % 4], new_x=False, want=("grad",), out=(None, grad_, None, None))
         eng.eval(xs[i % 4], new_x=False, want=("jac",), out=(None, None, None, jac_))
-    res["ipopt iterate: eval_f, eval_g, eval_grad_f, eval_jac_g as four calls"] = {"ms_per_call": 1e3 * (time.perf_counter() - t0) / reps}
+    res["ipopt iterate: eval_f, eval_g, eval_grad_f, eval_jac_g as four calls"] = {"ms_per_call": best_of(iterate)}
+    eng.register_outputs(outs)
+    try:
+        res["ipopt iterate as four calls (caller arrays registered)"] = {"ms_per_call": best_of(iterate)}
+    finally:
+        eng.unregister_outputs(outs)
     for v in res.values():
         v["knots_per_s"] = horizon * batch / (v["ms_per_call"] * 1e-3)
     return res

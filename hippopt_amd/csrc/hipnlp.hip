@@ -74,7 +74,11 @@ template <int TERRAIN> struct DevEm {
     double* g;
     double* jac;
     __device__ __forceinline__ void G(int slot, int, double v) { g[slot] = v; }
+#ifdef HIPNLP_DIAG_LDS
+    __device__ __forceinline__ void J(int slot, int, int, double v) { jac[slot & 511] = v; }
+#else
     __device__ __forceinline__ void J(int slot, int, int, double v) { jac[slot] = v; }
+#endif
 };
 
 // LDS image of the read-only tables every phase indexes per lane (global memory would cost one L2 round trip per phase)
@@ -87,7 +91,12 @@ struct SharedTables {
 //            (<= 168 VGPRs).  The throughput variant.
 // WAVES = 8: 512 threads, the roles of the knot program spread over twice the waves (two per SIMD).  The latency variant, used
 //            when the launch has at most one workgroup per CU anyway (knots x batch <= 256), e.g. one 100-knot trajectory.
-template <int TERRAIN, int WAVES> __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 3 : 2, WAVES == 4 ? 3 : 2)))
+#ifdef HIPNLP_DIAG_LDS
+#define HIPNLP_WG_PER_CU 4
+#else
+#define HIPNLP_WG_PER_CU 3
+#endif
+template <int TERRAIN, int WAVES> __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? HIPNLP_WG_PER_CU : 2, WAVES == 4 ? HIPNLP_WG_PER_CU : 2)))
 void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const double* pk_p, const GParams* gp_p, int N_p, int n_p, int kb_p, KArgs a) {
     // the leading scalar arguments repeat what the staging loads need: the build preloads them into SGPRs
     // (-mllvm -amdgpu-kernarg-preload-count), so the first global loads do not wait for a kernarg fetch
@@ -320,7 +329,11 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     double jvals[JP_ITERS], gvals[G_ITERS], grvals[GR_ITERS];
     // (unconditional, clamped indices, no branch: every LDS read of the copy-out is in flight before the first wait)
 #pragma unroll
+#ifdef HIPNLP_DIAG_LDS
+    for (int it = 0; it < JP_ITERS; ++it) jvals[it] = s.jac[jp[it] >= 0 ? (jp[it] & 511) : 0];
+#else
     for (int it = 0; it < JP_ITERS; ++it) jvals[it] = s.jac[jp[it] >= 0 ? jp[it] : 0];
+#endif
 #pragma unroll
     for (int it = 0; it < G_ITERS; ++it) gvals[it] = s.g[(tid + it * WG) < gs::COUNT ? tid + it * WG : 0];
 #pragma unroll
@@ -348,7 +361,11 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 #pragma unroll
         for (int it = 0; it < JP_ITERS; ++it) if (jp[it] >= 0) out[tid + it * WG] = jvals[it];
         // entries in the horizon-global columns (constants) sit right behind the last knot's block: the last knot writes them
+#ifdef HIPNLP_DIAG_LDS
+        if (last && tid < n_glob) a.jac[int64_t(b) * a.jac_stride + (int64_t(jac_glob_base) - a.jac_off) + tid] = s.jac[jpg & 511];
+#else
         if (last && tid < n_glob) a.jac[int64_t(b) * a.jac_stride + (int64_t(jac_glob_base) - a.jac_off) + tid] = s.jac[jpg];
+#endif
     }
     if (a.g) {
         double* out = a.g + size_t(b) * a.m;

@@ -98,7 +98,11 @@ struct alignas(16) KnotScratch {
     int pub_ready, pub_pad_;   // set by t_frames once the last cost term of an ordinary knot is final (device: polled by the publishing wave)
     double grad[XPAD];
     double g[gs::COUNT];
+#ifdef HIPNLP_DIAG_LDS   // TIMING-ONLY diagnostic build (wrong results): the Jacobian staging folded onto 512 slots, to measure what a fourth workgroup per CU would buy
+    double jac[512];
+#else
     double jac[js::COUNT];
+#endif
 };
 
 enum : int { CM = 0, CH = 1, CI = 4, CKL = 10, CKA = 13 };  // offsets inside KnotScratch::comp[i]

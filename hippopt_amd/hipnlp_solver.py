@@ -469,15 +469,39 @@ class HipNlpSolver:
         opts = {"maxiter": int(self._options.get("max_iter", 50)), "verbose": int(self._options.get("verbose", 0)),
                 "gtol": float(self._options.get("tol", 1e-6))}
         bounded = bool(np.any(np.isfinite(lbx)) or np.any(np.isfinite(ubx)))   # (lifted single-variable rows: detect_simple_bounds)
+        # IPOPT's termination tests on the stand-in driver (the reference scripts stop on them: tol 1e-3, constr_viol_tol 1e-4,
+        # acceptable_tol 10, acceptable_iter 2, acceptable_obj_change_tol 1, main_single_step_flat_ground.py:105-130): optimal when
+        # max(|grad L|_inf, constraint violation) <= tol and the violation <= constr_viol_tol; "acceptable" when the same error is
+        # <= acceptable_tol, the violation <= acceptable_constr_viol_tol and the relative cost change <= acceptable_obj_change_tol
+        # for acceptable_iter consecutive iterations.  (IPOPT scales its error by the multiplier norms; this one is unscaled.)
+        o = self._options
+        tol, cv_tol = float(o.get("tol", 1e-8)), float(o.get("constr_viol_tol", 1e-4))
+        acc_tol, acc_iter = float(o.get("acceptable_tol", 1e-6)), int(o.get("acceptable_iter", 15))
+        acc_cv, acc_obj = float(o.get("acceptable_constr_viol_tol", 1e-2)), float(o.get("acceptable_obj_change_tol", 1e20))
+        stop = {"reason": None, "run": 0, "f_prev": None}
+        ipopt_tests = any(k in o for k in ("constr_viol_tol", "acceptable_tol", "acceptable_iter"))   # only when the script sets them
 
         def on_iterate(xk, state):
             self._iterate_callback(state.nit, xk, state.fun, state.constr_violation, state.v[0] if len(state.v) else None,
                                    state.v[1] if bounded and len(state.v) > 1 else None)
+            if not ipopt_tests:
+                return False
+            err = max(float(state.optimality), float(state.constr_violation))
+            if err <= tol and state.constr_violation <= cv_tol:
+                stop["reason"] = "Solve_Succeeded"
+                return True
+            df = abs(state.fun - stop["f_prev"]) / max(1.0, abs(state.fun)) if stop["f_prev"] is not None else np.inf
+            stop["f_prev"] = float(state.fun)
+            stop["run"] = stop["run"] + 1 if (err <= acc_tol and state.constr_violation <= acc_cv and df <= acc_obj) else 0
+            if acc_iter > 0 and stop["run"] >= acc_iter:
+                stop["reason"] = "Solved_To_Acceptable_Level"
+                return True
             return False
         res = minimize(fun, x0, jac=grad, hess=hess_f, constraints=[nlc], bounds=Bounds(lbx, ubx) if bounded else None,
                        method="trust-constr", options=opts, callback=on_iterate)
         lam = res.v[0] if len(res.v) else np.zeros(m)
-        return res.x, lam, {"status": res.status, "success": res.status in (1, 2), "message": res.message, "iterations": res.nit,
+        return res.x, lam, {"status": stop["reason"] or res.status, "success": stop["reason"] is not None or res.status in (1, 2),
+                            "message": stop["reason"] or res.message, "iterations": res.nit, "optimality": float(res.optimality),
                             "constr_violation": res.constr_violation, "lam_x": res.v[1] if bounded and len(res.v) > 1 else None}
 
     def _solve_ipopt(self, eng, x0, lbx, ubx, lbg, ubg, ir, jc):

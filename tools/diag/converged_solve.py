@@ -85,10 +85,14 @@ def main():
     pst.point_position_regularization_cost_multiplier = 100.0
     pf = pose_finder.Planner(pst, model, error_on_fail=False)
     initial, info_i = pose(pf, pst, (0.0, 0.0, COM_HEIGHT), (0.0, 0.1, 0.0), (0.0, -0.1, 0.0))
+    print("pose finder, initial state:", info_i, file=sys.stderr, flush=True)
     final, info_f = pose(pf, pst, (0.15, 0.0, COM_HEIGHT), (0.0, 0.1, 0.0), (0.3, -0.1, 0.0))
+    print("pose finder, final state:", info_f, file=sys.stderr, flush=True)
 
     # ---- planner settings (get_planner_settings, :17-130) -------------------------------------------------------------------------
-    opts = {"max_iter": ITERS, "tol": 1e-3, "hessian_approximation": HESSIAN, "verbose": int(os.environ.get("SOLVE_VERBOSE", "0"))}
+    # the termination options of the reference script (main_single_step_flat_ground.py:105-130)
+    opts = {"max_iter": ITERS, "tol": 1e-3, "constr_viol_tol": 1e-4, "acceptable_tol": 10.0, "acceptable_iter": 2,
+            "acceptable_obj_change_tol": 1.0, "hessian_approximation": HESSIAN, "verbose": int(os.environ.get("SOLVE_VERBOSE", "0"))}
     st = Settings.from_numeric(single_step_settings(N, model), solver_options=opts)
     planner = Planner(st, model, error_on_fail=False)
     T = N * st.time_step
@@ -138,6 +142,16 @@ def main():
             engine_s[0] += time.perf_counter() - t
     hipnlp_solver._CallbackCache.eval = timed_eval
     sol = planner.optimization_solver
+    # progress on stderr every 25 iterations (a silent GPU job is taken to be hung)
+    inner_cb = sol._iterate_callback
+    t_start = [time.perf_counter()]
+
+    def progress(iteration, x, cost, inf_pr, multipliers, lam_x=None):
+        if int(iteration) % 10 == 0:
+            print("iteration %5d  cost %.6g  constraint violation %.3e  (%.1f s, engine %.2f s)" % (
+                int(iteration), float(cost), float(inf_pr), time.perf_counter() - t_start[0], engine_s[0]), file=sys.stderr, flush=True)
+        return inner_cb(iteration, x, cost, inf_pr, multipliers, lam_x)
+    sol._iterate_callback = progress
     eng = sol.engine()
     hess_s, hess_n = [0.0], [0]
     eval_hess = eng.eval_hess
@@ -156,6 +170,7 @@ def main():
     _, _, lbg, ubg = eng.bounds()
     viol0 = float(np.max(np.maximum(0, np.maximum(lbg - g0[0], g0[0] - ubg))))
     t0 = time.perf_counter()
+    t_start[0] = t0
     out = planner.solve()
     wall = time.perf_counter() - t0
     info = sol._last_info
@@ -167,6 +182,7 @@ def main():
         "iterations": info.get("iterations", info.get("iter_count")), "status": info.get("status"), "message": str(info.get("message"))[:120],
         "success": bool(info.get("success")),
         "cost": out.cost_value, "constraint_violation": info.get("constr_violation"), "constraint_violation_at_guess": viol0,
+        "optimality": info.get("optimality"), "termination_options": {k: opts[k] for k in ("tol", "constr_viol_tol", "acceptable_tol", "acceptable_iter", "acceptable_obj_change_tol")},
         "callbacks": info.get("callbacks"), "hessian_evaluations": hess_n[0],
         "wall_s": wall, "engine_s": engine_s[0] + hess_s[0], "driver_s": wall - engine_s[0] - hess_s[0],
         "engine_us_per_callback_evaluation": 1e6 * engine_s[0] / max(1, (info.get("callbacks") or {}).get("evaluations", 1)),
