@@ -69,40 +69,57 @@ struct KArgs {
 #endif
 };
 
-template <int TERRAIN> struct DevEm {
+// The planar callback kernel runs on the COMPACT scratch (knot_body.h, KnotScratchT<true>: <= 40 KB of LDS per workgroup with the
+// lite tables below: four workgroups per CU); the smooth-terrain kernel keeps the full layout (its terrain staging lives in own[] /
+// comp[] during phases A - B, where the compact layout parks the joint records and the joint frames).
+// Only the four-wave (throughput) variant: the eight-wave latency variant has one workgroup per CU whatever its LDS, and its duration
+// is that of the SLOWEST workgroup — the last knot, whose end rows would wait for global memory in the compact layout (measured:
+// 10.0 -> 10.9 us per 100-knot launch).
+template <int TERRAIN, int WAVES = 4> struct DevEm {
     static constexpr int kTerrain = TERRAIN;
+    static constexpr bool kCompact = TERRAIN == HIPNLP_TERRAIN_PLANAR && WAVES == 4;
+    using Scratch = KnotScratchT<kCompact>;
     double* g;
     double* jac;
-    __device__ __forceinline__ void G(int slot, int, double v) { g[slot] = v; }
-#ifdef HIPNLP_DIAG_LDS
-    __device__ __forceinline__ void J(int slot, int, int, double v) { jac[slot & 511] = v; }
-#else
+    __device__ __forceinline__ void G(int slot, int, double v) { g[slot] = v; }   // (horizon-end rows go through emit_g_end)
     __device__ __forceinline__ void J(int slot, int, int, double v) { jac[slot] = v; }
-#endif
 };
 
 // LDS image of the read-only tables every phase indexes per lane (global memory would cost one L2 round trip per phase)
-struct SharedTables {
+template <bool COMPACT> struct SharedTablesT;
+template <> struct SharedTablesT<false> {
     HeadTables head;
     GParams gp;
+    __device__ __forceinline__ const KinTables& kin() const { return head.kt; }
+    __device__ __forceinline__ const KSettings& settings() const { return head.ks; }
 };
+template <> struct alignas(16) SharedTablesT<true> {   // without the blocks read once per knot / by the end knots only (6.9 KB)
+    KSettings ks;
+    KinLite kt;
+    GParamsLite gp;
+    __device__ __forceinline__ const KinLite& kin() const { return kt; }
+    __device__ __forceinline__ const KSettings& settings() const { return ks; }
+};
+using SharedTables = SharedTablesT<false>;
+static_assert(sizeof(KSettings) % 8 == 0 && sizeof(KinLite) % 8 == 0 && sizeof(GParamsLite) % 8 == 0, "copied in 8-byte words");
 
 // WAVES = 4: 256 threads; 3 waves per SIMD = 3 workgroups per CU (the LDS bound): the register allocation is capped there
 //            (<= 168 VGPRs).  The throughput variant.
 // WAVES = 8: 512 threads, the roles of the knot program spread over twice the waves (two per SIMD).  The latency variant, used
 //            when the launch has at most one workgroup per CU anyway (knots x batch <= 256), e.g. one 100-knot trajectory.
-#ifdef HIPNLP_DIAG_LDS
-#define HIPNLP_WG_PER_CU 4
-#else
-#define HIPNLP_WG_PER_CU 3
-#endif
-template <int TERRAIN, int WAVES> __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? HIPNLP_WG_PER_CU : 2, WAVES == 4 ? HIPNLP_WG_PER_CU : 2)))
+// Four workgroups per CU for the planar four-wave kernel (compact scratch + lite tables: <= 40 KB of LDS, <= 128 VGPRs); three for
+// the smooth-terrain one (52 KB).
+template <int TERRAIN, int WAVES> __global__ __launch_bounds__(64 * WAVES)
+__attribute__((amdgpu_waves_per_eu(WAVES == 4 ? (DevEm<TERRAIN, WAVES>::kCompact ? 4 : 3) : 2, WAVES == 4 ? (DevEm<TERRAIN, WAVES>::kCompact ? 4 : 3) : 2)))
 void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const double* pk_p, const GParams* gp_p, int N_p, int n_p, int kb_p, KArgs a) {
     // the leading scalar arguments repeat what the staging loads need: the build preloads them into SGPRs
     // (-mllvm -amdgpu-kernarg-preload-count), so the first global loads do not wait for a kernarg fetch
     constexpr int WG = 64 * WAVES;
-    __shared__ KnotScratch s;
-    __shared__ SharedTables tabs;
+    constexpr bool COMPACT = DevEm<TERRAIN, WAVES>::kCompact;
+    using Scratch = typename DevEm<TERRAIN, WAVES>::Scratch;
+    __shared__ Scratch s;
+    __shared__ SharedTablesT<COMPACT> tabs;
+    static_assert(!COMPACT || sizeof(Scratch) + sizeof(SharedTablesT<COMPACT>) <= 40 * 1024, "four workgroups per CU: 40 KB of LDS each");
 #ifdef HIPNLP_STAMPS
     const unsigned long long st_entry = __builtin_amdgcn_s_memtime(), st_real0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long st_issued = 0, st_loaded = 0;
@@ -122,20 +139,32 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     const int first = k == 0, last = k == N - 1;
     const DeviceTables& tb = *tb_p;
     // ---- stage the knot records and the tables in LDS.  Every global load is issued before the first LDS store waits for
-    // one (compile-time trip counts, 16-byte words): ONE memory round trip instead of one per loop iteration.
+    // one (compile-time trip counts): ONE memory round trip instead of one per loop iteration.
+    // Full layout: the whole HeadTables + GParams.  Compact layout: KSettings, the KinLite prefix of the kinematic tables, the
+    // GParamsLite prefix of the parameters, and the joint frames (read by phase A only) parked in comp[].
     {
-        constexpr int HV = int(sizeof(HeadTables) / 16), HV_ITERS = (HV + WG - 1) / WG;
-        constexpr int GV = int(sizeof(GParams) / 8), GV_ITERS = (GV + WG - 1) / WG;
         constexpr int XV_ITERS = (XPAD + WG - 1) / WG;
         static_assert(PK_STRIDE <= WG && NXG <= 8, "one parameter word per thread");
-        const uint4* hsrc = reinterpret_cast<const uint4*>(&tb.head);
-        const double* gsrc = reinterpret_cast<const double*>(gp_p + b);
-        uint4 hv[HV_ITERS];
-        double gv[GV_ITERS], xv[XV_ITERS], xmv[XV_ITERS], xov[XV_ITERS];
+        // blocks of 8-byte words: (source, destination, words)
+        constexpr int W0 = COMPACT ? int(sizeof(KSettings) / 8) : int(sizeof(HeadTables) / 8);
+        constexpr int W1 = COMPACT ? int(sizeof(KinLite) / 8) : 0;
+        constexpr int W2 = COMPACT ? int(sizeof(GParamsLite) / 8) : int(sizeof(GParams) / 8);
+        constexpr int W3 = COMPACT ? JFIX_DOUBLES : 0;
+        constexpr int I0 = (W0 + WG - 1) / WG, I1 = (W1 + WG - 1) / WG, I2 = (W2 + WG - 1) / WG, I3 = (W3 + WG - 1) / WG;
+        const double* src0 = COMPACT ? reinterpret_cast<const double*>(&tb.head.ks) : reinterpret_cast<const double*>(&tb.head);
+        const double* src1 = reinterpret_cast<const double*>(static_cast<const KinLite*>(&tb.head.kt));
+        const double* src2 = reinterpret_cast<const double*>(gp_p + b);
+        const double* src3 = reinterpret_cast<const double*>(&tb.head.kt.jf);
+        double v0[I0 > 0 ? I0 : 1], v1[I1 > 0 ? I1 : 1], v2[I2 > 0 ? I2 : 1], v3[I3 > 0 ? I3 : 1];
+        double xv[XV_ITERS], xmv[XV_ITERS], xov[XV_ITERS];
 #pragma unroll
-        for (int it = 0; it < HV_ITERS; ++it) { const int i = tid + it * WG; hv[it] = i < HV ? hsrc[i] : uint4{0u, 0u, 0u, 0u}; }
+        for (int it = 0; it < I0; ++it) { const int i = tid + it * WG; v0[it] = i < W0 ? src0[i] : 0.0; }
 #pragma unroll
-        for (int it = 0; it < GV_ITERS; ++it) { const int i = tid + it * WG; gv[it] = i < GV ? gsrc[i] : 0.0; }
+        for (int it = 0; it < I1; ++it) { const int i = tid + it * WG; v1[it] = i < W1 ? src1[i] : 0.0; }
+#pragma unroll
+        for (int it = 0; it < I2; ++it) { const int i = tid + it * WG; v2[it] = i < W2 ? src2[i] : 0.0; }
+#pragma unroll
+        for (int it = 0; it < I3; ++it) { const int i = tid + it * WG; v3[it] = i < W3 ? src3[i] : 0.0; }
 #pragma unroll
         for (int it = 0; it < XV_ITERS; ++it) {
             const int i = tid + it * WG;
@@ -151,12 +180,21 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         st_loaded = __builtin_amdgcn_s_memtime();
 #endif
-        uint4* hdst = reinterpret_cast<uint4*>(&tabs.head);
-        double* gdst = reinterpret_cast<double*>(&tabs.gp);
+        double *dst0, *dst1 = nullptr, *dst2, *dst3 = nullptr;
+        if constexpr (COMPACT) {
+            dst0 = reinterpret_cast<double*>(&tabs.ks); dst1 = reinterpret_cast<double*>(&tabs.kt);
+            dst2 = reinterpret_cast<double*>(&tabs.gp); dst3 = &s.comp[0][0];
+        } else {
+            dst0 = reinterpret_cast<double*>(&tabs.head); dst2 = reinterpret_cast<double*>(&tabs.gp);
+        }
 #pragma unroll
-        for (int it = 0; it < HV_ITERS; ++it) { const int i = tid + it * WG; if (i < HV) hdst[i] = hv[it]; }
+        for (int it = 0; it < I0; ++it) { const int i = tid + it * WG; if (i < W0) dst0[i] = v0[it]; }
 #pragma unroll
-        for (int it = 0; it < GV_ITERS; ++it) { const int i = tid + it * WG; if (i < GV) gdst[i] = gv[it]; }
+        for (int it = 0; it < I1; ++it) { const int i = tid + it * WG; if (i < W1) dst1[i] = v1[it]; }
+#pragma unroll
+        for (int it = 0; it < I2; ++it) { const int i = tid + it * WG; if (i < W2) dst2[i] = v2[it]; }
+#pragma unroll
+        for (int it = 0; it < I3; ++it) { const int i = tid + it * WG; if (i < W3) dst3[i] = v3[it]; }
 #pragma unroll
         for (int it = 0; it < XV_ITERS; ++it) { const int i = tid + it * WG; if (i < XPAD) { s.x[i] = xv[it]; s.xm[i] = xmv[it]; } if (i < NPER) s.xo[i] = xov[it]; }
         if (tid < PK_STRIDE) s.pk[tid] = pkv;
@@ -192,7 +230,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     // loads) and sums them in a FIXED order (bitwise reproducible whatever the arrival order); nobody ever waits for another
     // workgroup.  Only the (rare) minimize-mode horizon-end terms of the first / last knot are final too late for the hiding.
     constexpr int PUBW = WAVES == 8 ? 7 : 3;
-    const bool ends_late = (first || last) && (tabs.head.ks.final_type == HIPNLP_EXPR_MINIMIZE || tabs.head.ks.periodicity_type == HIPNLP_EXPR_MINIMIZE);
+    const bool ends_late = (first || last) && (tabs.settings().final_type == HIPNLP_EXPR_MINIMIZE || tabs.settings().periodicity_type == HIPNLP_EXPR_MINIMIZE);
     unsigned long long pub_old = 0;
     int pub_bad = 0;
     auto pub_store = [&]() __attribute__((always_inline)) {
@@ -285,8 +323,8 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     };
 
     KnotInfo ki{k, N, first, last};
-    DevEm<TERRAIN> em{s.g, s.jac};
-    Ctx<DevEm<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
+    DevEm<TERRAIN, WAVES> em{s.g, s.jac};
+    Ctx<DevEm<TERRAIN, WAVES>> cx(s, tabs.kin(), tabs.settings(), tabs.gp, ki, em, &tb.head.kt, gp_p + b);
     // The program is instantiated ONCE PER WAVE (a generic lambda over the wave number as a compile-time constant: a task group is
     // compiled into the one instance whose wave runs it) and dispatched by one switch, so that every wave executes a CONTIGUOUS
     // instruction stream from the first phase to the last.  Written as `if (wave == w) { ... }` blocks phase after phase, every
@@ -329,13 +367,9 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     double jvals[JP_ITERS], gvals[G_ITERS], grvals[GR_ITERS];
     // (unconditional, clamped indices, no branch: every LDS read of the copy-out is in flight before the first wait)
 #pragma unroll
-#ifdef HIPNLP_DIAG_LDS
-    for (int it = 0; it < JP_ITERS; ++it) jvals[it] = s.jac[jp[it] >= 0 ? (jp[it] & 511) : 0];
-#else
     for (int it = 0; it < JP_ITERS; ++it) jvals[it] = s.jac[jp[it] >= 0 ? jp[it] : 0];
-#endif
 #pragma unroll
-    for (int it = 0; it < G_ITERS; ++it) gvals[it] = s.g[(tid + it * WG) < gs::COUNT ? tid + it * WG : 0];
+    for (int it = 0; it < G_ITERS; ++it) gvals[it] = s.g_at((tid + it * WG) < gs::COUNT ? tid + it * WG : 0);
 #pragma unroll
     for (int it = 0; it < GR_ITERS; ++it) grvals[it] = s.grad[(tid + it * WG) < NXK ? tid + it * WG : 0];
 #pragma unroll
@@ -361,11 +395,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 #pragma unroll
         for (int it = 0; it < JP_ITERS; ++it) if (jp[it] >= 0) out[tid + it * WG] = jvals[it];
         // entries in the horizon-global columns (constants) sit right behind the last knot's block: the last knot writes them
-#ifdef HIPNLP_DIAG_LDS
-        if (last && tid < n_glob) a.jac[int64_t(b) * a.jac_stride + (int64_t(jac_glob_base) - a.jac_off) + tid] = s.jac[jpg & 511];
-#else
         if (last && tid < n_glob) a.jac[int64_t(b) * a.jac_stride + (int64_t(jac_glob_base) - a.jac_off) + tid] = s.jac[jpg];
-#endif
     }
     if (a.g) {
         double* out = a.g + size_t(b) * a.m;

@@ -167,7 +167,7 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
 // The Hessian program runs none of the tasks that emit Jacobian entries: the jac staging area (the last 15.7 KB of the scratch) is not
 // allocated, which brings the workgroup to 46 KB of LDS — three per CU (register cap 168).
 template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3, 3))) void hipnlp_pose_hess_kernel(PArgs a) {
-    static_assert(offsetof(KnotScratch, jac) + sizeof(KnotScratch::jac) == sizeof(KnotScratch), "jac is the last member of the scratch");
+    static_assert(offsetof(KnotScratch, jac) + sizeof(KnotScratch::jac) + 16 > sizeof(KnotScratch), "jac is the last member of the scratch (up to tail padding)");
     __shared__ alignas(16) double s_raw[offsetof(KnotScratch, jac) / sizeof(double)];
     KnotScratch& s = *reinterpret_cast<KnotScratch*>(s_raw);
     __shared__ PoseShared tabs;
@@ -456,14 +456,13 @@ int hipnlp_pose_eval_hess(hipnlp_pose_handle* h, const double* x, const double* 
     if (!h->params_set) { h->err = "parameters not set (hipnlp_pose_set_params)"; return HIPNLP_E_PARAMS; }
     const size_t B = size_t(h->batch), m = size_t(h->L.m), hn = size_t(h->L.hnnz);
     HIP_TRY(h, hipSetDevice(h->dev));
-    if (!h->d_hess) {
-        HIP_TRY(h, hipMalloc(&h->d_sigma, B * sizeof(double)));
-        HIP_TRY(h, hipMalloc(&h->d_lambda, B * m * sizeof(double)));
-        HIP_TRY(h, hipMalloc(&h->d_hess, B * hn * sizeof(double)));
-        HIP_TRY(h, hipHostMalloc(&h->h_sigma, B * sizeof(double)));
-        HIP_TRY(h, hipHostMalloc(&h->h_lambda, B * m * sizeof(double)));
-        HIP_TRY(h, hipHostMalloc(&h->h_hess, B * hn * sizeof(double)));
-    }
+    // every piece allocated at most once: a failure half way leaves the pieces that exist for the next attempt (nothing leaks)
+    if (!h->d_sigma) HIP_TRY(h, hipMalloc(&h->d_sigma, B * sizeof(double)));
+    if (!h->d_lambda) HIP_TRY(h, hipMalloc(&h->d_lambda, B * m * sizeof(double)));
+    if (!h->d_hess) HIP_TRY(h, hipMalloc(&h->d_hess, B * hn * sizeof(double)));
+    if (!h->h_sigma) HIP_TRY(h, hipHostMalloc(&h->h_sigma, B * sizeof(double)));
+    if (!h->h_lambda) HIP_TRY(h, hipHostMalloc(&h->h_lambda, B * m * sizeof(double)));
+    if (!h->h_hess) HIP_TRY(h, hipHostMalloc(&h->h_hess, B * hn * sizeof(double)));
     std::memcpy(h->h_x, x, B * POSE_NX * sizeof(double));
     std::memcpy(h->h_sigma, obj_factor, B * sizeof(double));
     std::memcpy(h->h_lambda, lambda, B * m * sizeof(double));

@@ -22,6 +22,8 @@
 #pragma once
 #include <math.h>
 
+#include <type_traits>
+
 #include "nlp_defs.h"
 
 // Lanes of ONE wavefront exchanging data through LDS (no other wave involved): the hardware executes a
@@ -62,7 +64,38 @@ static_assert(sizeof(JointRec) == 128, "joint record");
 enum : int { JR_L = 0, JR_OF = 9, JR_C = 12, JR_SD = 15 };
 HD constexpr int jr_pos(int i, int e) { return ((((e >> 1) ^ (i & 7)) << 1) | (e & 1)); }   // physical position of logical double e of record i
 
-struct alignas(16) KnotScratch {
+// Two layouts of the scratch:
+//   KnotScratchT<false>  every array has its own storage (host recorders / emulation, smooth-terrain and pose / Hessian kernels)
+//   KnotScratchT<true>   the COMPACT device layout of the planar callback kernel (four workgroups per CU need <= 40 KB of LDS per
+//                        workgroup): arrays whose lifetimes do not overlap share storage —
+//                          * own[] (written in phase C, read in phase D) lives on top of the joint records Jr[] (written in phase A,
+//                            dead once the forward kinematics of phase B has read them); own[NL] (the zero slot written in phase A)
+//                            lies behind the last joint record;
+//                          * the g rows of the horizon ends (final state, periodicity: first / last knot only, written in phase E)
+//                            live in EndTerms::c of the same union (the minimize-mode cost partials they exclude row by row);
+//                          * the joint frames (read in phase A only) and then the link inertials (read in phase C only) are parked in
+//                            comp[] (composites: written in phase D) instead of occupying LDS for the whole program: `tables_in_comp`.
+template <bool COMPACT> struct ScratchJrOwn;
+template <> struct ScratchJrOwn<false> {
+    JointRec Jr[NJ + 1];
+    union {  // own[] is dead once the composites are formed; the (rare) minimize-mode end terms reuse its space
+        double own[NL + 1][LSTR];  // per link, same layout as comp; slot NL = 0 (padding of the descendant lists)
+        EndTerms ends;
+    };
+    double g[gs::COUNT];
+};
+template <> struct ScratchJrOwn<true> {
+    union {
+        JointRec Jr[NJ + 1];
+        double own[NL + 1][LSTR];
+        EndTerms ends;
+    };
+    double g[gs::FIN];   // slots >= gs::FIN (horizon-end rows) are ends.c[slot - gs::FIN]
+};
+static_assert(sizeof(JointRec) * NJ <= sizeof(double) * LSTR * NL, "own[NL] (zero slot, written while Jr is live) must lie behind the joint records it shares storage with");
+
+template <bool COMPACT> struct alignas(16) KnotScratchT : ScratchJrOwn<COMPACT> {
+    static constexpr bool compact = COMPACT;
     double x[XPAD];    // knot k
     double xm[XPAD];   // knot k-1 (zeros at k = 0)
     double xo[NPER];   // periodicity variables of the other end of the horizon, by periodicity row (only loaded at k = 0 and k = N-1)
@@ -72,16 +105,11 @@ struct alignas(16) KnotScratch {
     double qn[4], qnorm, inv_qnorm, Rb[9], G[12] /* 3x4: dtheta = G dqhat */, omega[3], dwq[12] /* d omega/d qb (3x4) */;
     // kinematics in base-centred coordinates (origin = base origin; h_ang and relative positions are
     // invariant to the base position / linear velocity)
-    // per joint, ONE 128-byte record the FK lanes stream with 16-byte LDS reads: [ parent_R_child (9) | o_fix (3) |
+    // per joint, ONE 128-byte record the FK lanes stream with 16-byte LDS reads (ScratchJrOwn::Jr): [ parent_R_child (9) | o_fix (3) |
     // c = R_fix axis = parent-frame joint axis (3) | sdot ]; slot NJ = [identity | 0 | 0 | 0] (padding of the ancestor lists)
-    JointRec Jr[NJ + 1];
     double Uj[NJ + 1][3];   // (o_j x a_j) sdot_j ; slot NJ = 0
     double Rw[NL][9], ow[NL][3], aw[NJ + 1][3];  // padding slot aw[NJ] = 0
     double wv[NL][3], vo[NL][3];  // link angular velocity; velocity of the body point at the origin
-    union {  // own[] is dead once the composites are formed; the (rare) minimize-mode end terms reuse its space
-        double own[NL + 1][LSTR];  // per link, same layout as comp; slot NL = 0 (padding of the descendant lists)
-        EndTerms ends;
-    };
     double comp[NL][LSTR];  // composite per link: [m | first moment h (3) | inertia@O xx,xy,xz,yy,yz,zz (6) | subtree momentum lin (3) | ang (3)]
     double com[3], klin[3], kang[3], hang[3];
     double dth_h[3][3];  // d hang / d theta_e   [e][i]
@@ -97,13 +125,15 @@ struct alignas(16) KnotScratch {
     double cost[NCT];
     int pub_ready, pub_pad_;   // set by t_frames once the last cost term of an ordinary knot is final (device: polled by the publishing wave)
     double grad[XPAD];
-    double g[gs::COUNT];
-#ifdef HIPNLP_DIAG_LDS   // TIMING-ONLY diagnostic build (wrong results): the Jacobian staging folded onto 512 slots, to measure what a fourth workgroup per CU would buy
-    double jac[512];
-#else
     double jac[js::COUNT];
-#endif
+    // value of native g slot `slot` / where the emitter stores it
+    HD double& g_at(int slot) {
+        if constexpr (COMPACT) return slot >= gs::FIN ? this->ends.c[slot - gs::FIN] : this->g[slot];
+        else return this->g[slot];
+    }
 };
+using KnotScratch = KnotScratchT<false>;
+static_assert(LINR_DOUBLES <= JFIX_DOUBLES && JFIX_DOUBLES <= NL * LSTR, "the parked tables must fit in comp[]");
 
 enum : int { CM = 0, CH = 1, CI = 4, CKL = 10, CKA = 13 };  // offsets inside KnotScratch::comp[i]
 
@@ -112,16 +142,61 @@ struct KnotInfo {
     int first, last;  // k == 0, k == N-1   (the recorder sets both)
 };
 
+// emitter traits: Em::Scratch (default KnotScratch) selects the scratch layout
+template <class Em, class = void> struct ScratchOf { using type = KnotScratch; };
+template <class Em> struct ScratchOf<Em, std::void_t<typename Em::Scratch>> { using type = typename Em::Scratch; };
+
 template <class Em> struct Ctx {
-    KnotScratch& s;
-    const KinTables& kt;
+    using Scratch = typename ScratchOf<Em>::type;
+    using Kin = std::conditional_t<Scratch::compact, KinLite, KinTables>;
+    using GP = std::conditional_t<Scratch::compact, GParamsLite, GParams>;
+    Scratch& s;
+    const Kin& kt;
     const KSettings& st;
-    const GParams& gp;
+    const GP& gp;
     KnotInfo ki;
     Em em;
-    HD Ctx(KnotScratch& s_, const KinTables& kt_, const KSettings& st_, const GParams& gp_, KnotInfo ki_, Em em_)
-        : s(s_), kt(kt_), st(st_), gp(gp_), ki(ki_), em(em_) {}
+    // the FULL tables wherever they live (compact device layout: global memory; elsewhere: the same objects as kt / gp)
+    const KinTables* gkt;
+    const GParams* ggp;
+    HD Ctx(Scratch& s_, const Kin& kt_, const KSettings& st_, const GP& gp_, KnotInfo ki_, Em em_, const KinTables* gkt_ = nullptr, const GParams* ggp_ = nullptr)
+        : s(s_), kt(kt_), st(st_), gp(gp_), ki(ki_), em(em_), gkt(gkt_), ggp(ggp_) {
+        if constexpr (!Scratch::compact) {
+            if (!gkt) gkt = &kt_;
+            if (!ggp) ggp = &gp_;
+        }
+    }
 };
+
+// ---- tables that are read once per knot: from the scratch in the compact layout (parked in comp[], see KnotScratchT), else from kt --
+// joint frames of joint j: phase A only
+template <class Em> HD const double* kin_R_fix(const Ctx<Em>& cx, int j) {
+    if constexpr (Ctx<Em>::Scratch::compact) return &cx.s.comp[0][0] + 9 * j; else return cx.kt.jf.R_fix[j];
+}
+template <class Em> HD const double* kin_o_fix(const Ctx<Em>& cx, int j) {
+    if constexpr (Ctx<Em>::Scratch::compact) return &cx.s.comp[0][0] + 9 * NJ + 3 * j; else return cx.kt.jf.o_fix[j];
+}
+template <class Em> HD const double* kin_axis(const Ctx<Em>& cx, int j) {
+    if constexpr (Ctx<Em>::Scratch::compact) return &cx.s.comp[0][0] + 12 * NJ + 3 * j; else return cx.kt.jf.axis[j];
+}
+// link inertials of link i: phase C only
+template <class Em> HD double kin_mass(const Ctx<Em>& cx, int i) {
+    if constexpr (Ctx<Em>::Scratch::compact) return (&cx.s.comp[0][0])[i]; else return cx.kt.li.mass[i];
+}
+template <class Em> HD const double* kin_com(const Ctx<Em>& cx, int i) {
+    if constexpr (Ctx<Em>::Scratch::compact) return &cx.s.comp[0][0] + NL + 3 * i; else return cx.kt.li.com[i];
+}
+template <class Em> HD const double* kin_inertia(const Ctx<Em>& cx, int i) {
+    if constexpr (Ctx<Em>::Scratch::compact) return &cx.s.comp[0][0] + 4 * NL + 9 * i; else return cx.kt.li.inertia[i];
+}
+// g rows of the horizon ends (native slots >= gs::FIN): compact layout -> ends.c (see KnotScratchT)
+template <class Em> HD void emit_g_end(Ctx<Em>& cx, int slot, int id, double v) {
+    if constexpr (Ctx<Em>::Scratch::compact) { (void)id; cx.s.ends.c[slot - gs::FIN] = v; }
+    else cx.em.G(slot, id, v);
+}
+// horizon-end tables and final-state values: first / last knot only (compact layout: straight from global memory)
+template <class Em> HD const EndTables& end_tables(const Ctx<Em>& cx) { return cx.gkt->en; }
+template <class Em> HD const double* final_rhs(const Ctx<Em>& cx) { return cx.ggp->final_rhs; }
 
 // The terrain kind is a COMPILE-TIME constant of the device emitters (one kernel instantiation per terrain: the planar kernel
 // must not pay registers for the smooth-terrain jets) and a run-time value (Em::kTerrain < 0) for the host-side recorders.
@@ -269,7 +344,7 @@ HD void terrain_Z_jet(const KSettings& st, double px, double py, int order, doub
 // --- contact points, component-wise: lane (c, i), 24 tasks.  planner.py:721-744, 646-654, 699-719 ----
 // (the trapezoid defects of the point states are a task group of their own: they share nothing with the rest but the knot record)
 template <class Em> HD void t_points_dyn(Ctx<Em>& cx, int t) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     const int c = t / 3, i = t - 3 * c;
     const double* x = s.x + PT_ * c;
     const double* xm = s.xm + PT_ * c;
@@ -293,7 +368,7 @@ template <class Em> HD void t_points_dyn(Ctx<Em>& cx, int t) {
     em.J(jb + js::PDYN + 12 + i, row_id(RK_PDYN_X0, c, i), cb + P_ + i, 1.0);
 }
 template <class Em> HD void t_points_vec(Ctx<Em>& cx, int t) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     const int c = t / 3, i = t - 3 * c;
     const double* x = s.x + PT_ * c;
     const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
@@ -398,17 +473,17 @@ template <class Em> HD void point_hnf_planar(Ctx<Em>& cx, int c) {
 //   t_terrain_planar / _dcc / _hnf / _swing (phase B, lane c each, on different waves): the rows, their Jacobian entries, the swing cost.
 struct TerrainStage { TerrainFrame tf; double Zh[7]; };   // Zh = Z[3..9]: second and third derivatives (for udot)
 static_assert(sizeof(TerrainStage) * NC <= sizeof(double) * NL * LSTR, "terrain staging must fit in own[0..NL) (own[NL] is the zero slot)");
-HD TerrainStage* terrain_stage(KnotScratch& s, int c) { return reinterpret_cast<TerrainStage*>(&s.own[0][0]) + c; }
+template <class S> HD TerrainStage* terrain_stage(S& s, int c) { return reinterpret_cast<TerrainStage*>(&s.own[0][0]) + c; }
 
 // the jet of ONE bump at ONE point: lane (c, bump), NC x HIPNLP_MAX_TERRAIN_STEPS tasks; parked in the composite area (written only
 // three phases later).  (Splitting a bump's jet further over three lanes by derivative order, and the com height jet over bump
 // lanes, measured slower: the common prefix — powers and the exponential — dominates and is then computed three times.)  t_terrain_stage follows on the same wave, adds the bumps in order and builds the frame.
 constexpr int TERRAIN_BUMP_TASKS = NC * HIPNLP_MAX_TERRAIN_STEPS;
 static_assert(sizeof(double) * 10 * TERRAIN_BUMP_TASKS <= sizeof(double) * NL * LSTR, "bump jets must fit in comp[]");
-HD double* terrain_bump_part(KnotScratch& s, int c, int sidx) { return &s.comp[0][0] + 10 * (HIPNLP_MAX_TERRAIN_STEPS * c + sidx); }
+template <class S> HD double* terrain_bump_part(S& s, int c, int sidx) { return &s.comp[0][0] + 10 * (HIPNLP_MAX_TERRAIN_STEPS * c + sidx); }
 template <class Em> HD void t_terrain_bump(Ctx<Em>& cx, int t) {
     if (terrain_is_planar(cx)) return;
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     const int c = t / HIPNLP_MAX_TERRAIN_STEPS, sidx = t - HIPNLP_MAX_TERRAIN_STEPS * c;
     if (sidx >= cx.st.n_steps) return;
     const double* p = s.x + PT_ * c + P_;
@@ -420,7 +495,7 @@ template <class Em> HD void t_terrain_bump(Ctx<Em>& cx, int t) {
 }
 template <class Em> HD void t_terrain_stage(Ctx<Em>& cx, int c) {
     if (terrain_is_planar(cx)) return;
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     HIPNLP_WAVE_SYNC();   // the bump jets of this wave's t_terrain_bump
     const double* p = s.x + PT_ * c + P_;
     double Z[10];
@@ -436,7 +511,7 @@ template <class Em> HD void t_terrain_stage(Ctx<Em>& cx, int c) {
 // planar complementarity  v - R_t diag(tau,tau,1) u   (E3)
 template <class Em> HD void t_terrain_planar(Ctx<Em>& cx, int c) {
     if (terrain_is_planar(cx)) return;
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
     const double* v = s.x + cb + V_;
@@ -460,7 +535,7 @@ template <class Em> HD void t_terrain_planar(Ctx<Em>& cx, int c) {
 // dcc margin  eps - k h (n.f) - [hdot (n.f) + h f.ndot + h (n.fdot)]   (E4)
 template <class Em> HD void t_terrain_dcc(Ctx<Em>& cx, int c) {
     if (terrain_is_planar(cx)) return;
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
     const double* f = s.x + cb + F_;
@@ -502,7 +577,7 @@ template <class Em> HD void t_terrain_hnf(Ctx<Em>& cx, int c) {
 // swing height heuristic on the smooth terrain (value and gradient; t_foot_costs adds to that gradient: same wave, behind this)
 template <class Em> HD void t_terrain_swing(Ctx<Em>& cx, int c) {
     if (terrain_is_planar(cx)) return;
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     const int cb = PT_ * c;
     const double* v = s.x + cb + V_;
     const TerrainFrame& tf = terrain_stage(s, c)->tf;
@@ -520,7 +595,7 @@ template <class Em> HD void t_terrain_swing(Ctx<Em>& cx, int c) {
 
 // --- contact points, scalar rows and cost values: lane c, 8 tasks.  planner.py:656-697, 855-895 --------
 template <class Em> HD void t_points_scalar(Ctx<Em>& cx, int c) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     const double* x = s.x + PT_ * c;
     const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
     Em& em = cx.em;
@@ -543,7 +618,7 @@ template <class Em> HD void t_points_scalar(Ctx<Em>& cx, int c) {
 
 // sums of the point-local cost partials: lane = term (swing, u_v, f_dot), runs behind t_points_scalar on the same wave
 template <class Em> HD void t_points_cost(Ctx<Em>& cx, int t) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     HIPNLP_WAVE_SYNC();
     double acc = 0.0;
     for (int p = 0; p < NC; ++p) acc += s.c_pt[p][t];
@@ -551,7 +626,7 @@ template <class Em> HD void t_points_cost(Ctx<Em>& cx, int t) {
 }
 
 // identity / zero padding slots of the ancestor and descendant lists, lanes e < 16
-HD void scratch_padding(KnotScratch& s, int e) {
+template <class S> HD void scratch_padding(S& s, int e) {
     if (e < 16) s.own[NL][e] = 0.0;
     if (e < 16) s.Jr[NJ].d[jr_pos(NJ, e)] = (e < 9 && e % 4 == 0) ? 1.0 : 0.0;   // L = I, of = c = 0, sd = 0
     if (e < 3) { s.aw[NJ][e] = 0.0; s.Uj[NJ][e] = 0.0; }
@@ -559,7 +634,7 @@ HD void scratch_padding(KnotScratch& s, int e) {
 
 // --- trivial dynamics of base / joints / com, lane e over 33 state components.  planner.py:522-564 -----
 template <class Em> HD void t_dyn(Ctx<Em>& cx, int e) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     const double half = 0.5 * cx.gp.dt;
     int X, Y, L, i, kin, gslot, gx0, jslot;
     if (e < 3) { i = e; L = 3; X = PB_ + i; Y = VB_ + i; kin = RK_PBDYN_IN; gslot = gs::PBDYN; gx0 = gs::PB_X0; jslot = js::PBDYN; }
@@ -582,8 +657,8 @@ template <class Em> HD void t_dyn(Ctx<Em>& cx, int e) {
 // parent_R_child = R_fix * (cq (I - a a^T) + sq [a]x + a a^T)   (adam R_from_axis_angle) -> the joint record s.Jr[j]
 // (a rotation about the joint axis leaves the axis in place: parent_R_child axis = R_fix axis, a constant)
 template <class Em> HD void joint_transform(Ctx<Em>& cx, int j) {
-    KnotScratch& s = cx.s;
-    const double* a = cx.kt.axis[j];
+    auto& s = cx.s;
+    const double* a = kin_axis(cx, j);
     double sq, cq;
     sincos(s.x[S_ + j], &sq, &cq);
     double Ra[9];
@@ -593,18 +668,18 @@ template <class Em> HD void joint_transform(Ctx<Em>& cx, int j) {
     Ra[3] += sq * a[2]; Ra[5] -= sq * a[0];
     Ra[6] -= sq * a[1]; Ra[7] += sq * a[0];
     double L[9], c[3];
-    matmul3(cx.kt.R_fix[j], Ra, L);
-    matvec3(cx.kt.R_fix[j], a, c);
+    matmul3(kin_R_fix(cx, j), Ra, L);
+    matvec3(kin_R_fix(cx, j), a, c);
     double* rec = s.Jr[j].d;
     const int sw = (j & 7) << 1;   // jr_pos(j, e) = e ^ sw
     for (int e = 0; e < 9; ++e) rec[(JR_L + e) ^ sw] = L[e];
-    for (int r = 0; r < 3; ++r) { rec[(JR_OF + r) ^ sw] = cx.kt.o_fix[j][r]; rec[(JR_C + r) ^ sw] = c[r]; }
+    for (int r = 0; r < 3; ++r) { rec[(JR_OF + r) ^ sw] = kin_o_fix(cx, j)[r]; rec[(JR_C + r) ^ sw] = c[r]; }
     rec[JR_SD ^ sw] = s.x[SD_ + j];
 }
 
 // --- joint-wise rows, joint regularisation cost and the local joint transform, lane j (23) -------------
 template <class Em> HD void t_joint_rows(Ctx<Em>& cx, int j) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     em.G(gs::JPB + j, row_id(RK_JPB, 0, j), s.x[S_ + j]);
     em.J(js::JPB + j, row_id(RK_JPB, 0, j), S_ + j, 1.0);
@@ -625,7 +700,7 @@ template <class Em> HD void t_joint_rows(Ctx<Em>& cx, int j) {
 template <class Em> HD void t_joints(Ctx<Em>& cx, int j) { joint_transform(cx, j); }
 
 template <class Em> HD void t_joint_cost(Ctx<Em>& cx, int) {  // behind t_joints on the same wave
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     HIPNLP_WAVE_SYNC();
     double acc = 0.0;
     for (int q = 0; q < NJ; ++q) acc += s.c_joint[q];
@@ -634,7 +709,7 @@ template <class Em> HD void t_joint_cost(Ctx<Em>& cx, int) {  // behind t_joints
 
 // --- unitary quaternion row (planner.py:276-282) + base quaternion error cost (E13, raw q), 1 task ------
 template <class Em> HD void t_unitq(Ctx<Em>& cx, int) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     const double on = cx.ki.first ? 0.0 : 1.0;
     const double* q = s.x + QB_;
@@ -657,7 +732,7 @@ template <class Em> HD void t_unitq(Ctx<Em>& cx, int) {
 
 // --- small global rows / costs: lanes 0..2 component-wise, lane 3 scalar: 4 tasks ---------------------------
 template <class Em> HD void t_small(Ctx<Em>& cx, int t) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     if (t < 3) {  // angular momentum bound rows h[3:]*mass (planner.py:342-350); gradient of the com velocity cost
         const int i = t;
@@ -695,7 +770,7 @@ template <class Em> HD void t_small(Ctx<Em>& cx, int t) {
 // --- feet: lane 0 centroids (relative height row + centroid cost, planner.py:215-264);
 //           lanes 1,2 yaw alignment errors of the left / right foot (E9, planner.py:773-853): 3 tasks -------
 template <class Em> HD void t_feet(Ctx<Em>& cx, int t) {   // t = 0: centroids; t = 1, 2: yaw of the left / right foot
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     const double on = cx.ki.first ? 0.0 : 1.0;
     if (t == 0) {
@@ -741,7 +816,7 @@ template <class Em> HD void t_feet_yaw(Ctx<Em>& cx, int foot) { t_feet(cx, 1 + f
 template <class Em> HD void t_base(Ctx<Em>& cx, int e) {
     // lane e works on row e with the cyclic index triple (e, e1, e2): every entry of R, G, H has one closed form in
     // (a, b, c) = (q_e, q_e1, q_e2), so no lane indexes a register array with a run-time index
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     const double* q = s.x + QB_;
     const double* qd = s.x + QD_;
     const int e1 = e == 2 ? 0 : e + 1, e2 = e == 0 ? 2 : e - 1;
@@ -781,7 +856,7 @@ template <class Em> HD void t_fk_rot_at(Ctx<Em>& cx, int t, int q0) {
     //   row r of R_j = row r of R_b L_a1 ... L_j        o_j[r] = sum_a (row r of R_parent(a)) . o_fix_a
     //   a_j[r] = (row r of R_j) . axis_j                w_j[r] = omega[r] + sum_a a_a[r] sdot_a
     // (padding slot NJ: L = I, o_fix = c = sdot = 0)
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     const int j = t / 3, r = t - 3 * j;
     double v0 = s.Rb[3 * r], v1 = s.Rb[3 * r + 1], v2 = s.Rb[3 * r + 2];
     double o = 0.0, w = s.omega[r], ar = 0.0;
@@ -823,7 +898,7 @@ template <class Em> HD void t_fk_rot_b(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t +
 // velocity of the body point of link i at the (base-centred) origin: vO_i = sum over the joints a on the path root -> i of
 // U_a = (o_a x a_a) sdot_a.  t_link_u (lane j) forms U_j, t_links (same wave, behind it) sums the ancestors' (padding: U_NJ = 0)
 template <class Em> HD void t_link_u(Ctx<Em>& cx, int j) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     HIPNLP_WAVE_SYNC();   // o_j, a_j: components written by three lanes of this wave (t_fk_rot_a / _b)
     double u[3];
     cross3(s.ow[j + 1], s.aw[j], u);
@@ -832,7 +907,7 @@ template <class Em> HD void t_link_u(Ctx<Em>& cx, int j) {
 }
 template <class Em> HD void t_link_u_a(Ctx<Em>& cx, int j) { t_link_u(cx, j); }              // behind t_fk_rot_a on its wave
 template <class Em> HD void t_link_u_b(Ctx<Em>& cx, int j) { t_link_u(cx, j + FK_SPLIT); }   // behind t_fk_rot_b on its wave
-HD void link_origin_velocity(const KnotScratch& s, const KinTables& kt, int i, double* v) {
+template <class S, class K> HD void link_origin_velocity(const S& s, const K& kt, int i, double* v) {
     v[0] = v[1] = v[2] = 0.0;
     if (i == 0) return;
     double u[8][3];
@@ -847,6 +922,22 @@ HD void link_origin_velocity(const KnotScratch& s, const KinTables& kt, int i, d
         for (int r = 0; r < 3; ++r) v[r] += u[q][r];
 }
 
+// Compact layout only: the link inertials [mass | com | inertia] (read in phase C) replace the joint frames (read in phase A) in
+// comp[] (free until the composites of phase D): 64 lanes copy them from global memory during phase B, where the wave has slack.
+constexpr int STAGE_TABLE_TASKS = 64;
+template <class Em> HD void t_stage_link_tables(Ctx<Em>& cx, int t) {
+    if constexpr (Ctx<Em>::Scratch::compact) {
+        const double* src = reinterpret_cast<const double*>(&cx.gkt->li);
+        double* dst = &cx.s.comp[0][0];
+        constexpr int ITERS = (LINR_DOUBLES + STAGE_TABLE_TASKS - 1) / STAGE_TABLE_TASKS;
+        double v[ITERS];
+        HIPNLP_UNROLL
+        for (int it = 0; it < ITERS; ++it) { const int i = t + it * STAGE_TABLE_TASKS; v[it] = i < LINR_DOUBLES ? src[i] : 0.0; }
+        HIPNLP_UNROLL
+        for (int it = 0; it < ITERS; ++it) { const int i = t + it * STAGE_TABLE_TASKS; if (i < LINR_DOUBLES) dst[i] = v[it]; }
+    } else { (void)cx; (void)t; }
+}
+
 // (the branches of t_hdyn diverge inside a wave: entries and rows + com entries are task groups of their own)
 template <class Em> HD void t_hdyn(Ctx<Em>& cx, int t);
 template <class Em> HD void t_hdyn_entries(Ctx<Em>& cx, int t) { t_hdyn(cx, t); }
@@ -854,7 +945,7 @@ template <class Em> HD void t_hdyn_rows(Ctx<Em>& cx, int t) { t_hdyn(cx, t + 48)
 // --- centroidal momentum dynamics (T7 on E1): lanes (c, e) 48 entry tasks + lanes 48..59 row tasks -----------
 constexpr int HDYN_TASKS = 60;
 template <class Em> HD void t_hdyn(Ctx<Em>& cx, int t) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     const double half = 0.5 * cx.gp.dt;
     if (t < 48) {
@@ -896,7 +987,7 @@ template <class Em> HD void t_hdyn(Ctx<Em>& cx, int t) {
 //     centroid and yaw costs on p.  planner.py:746-853, 249-264 ----------------------------------------------
 constexpr int FOOT_TASKS = 30;
 template <class Em> HD void t_foot_costs(Ctx<Em>& cx, int t) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     HIPNLP_WAVE_SYNC();   // smooth terrain: the swing-cost gradient of the same wave's t_terrain_hnf is accumulated into below
     const double on = cx.ki.first ? 0.0 : 1.0;
     if (t < 6) {
@@ -926,7 +1017,7 @@ template <class Em> HD void t_foot_costs(Ctx<Em>& cx, int t) {
 }
 
 template <class Em> HD void t_foot_cost_sum(Ctx<Em>& cx, int t) {  // behind t_foot_costs (force partials) / t_feet (yaw)
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     HIPNLP_WAVE_SYNC();
     if (t == 0) s.cost[CT_FREG] = ((s.c_force[0][0] + s.c_force[0][1]) + s.c_force[0][2]) + ((s.c_force[1][0] + s.c_force[1][1]) + s.c_force[1][2]);
     else s.cost[CT_YAW] = s.c_yaw[0] + s.c_yaw[1];
@@ -935,26 +1026,26 @@ template <class Em> HD void t_foot_cost_sum(Ctx<Em>& cx, int t) {  // behind t_f
 // --- horizon-end rows (final state planner.py:407-425, periodicity :897-930), lanes over rows ----------------
 constexpr int ENDS_TASKS = 105 + 84;
 template <class Em> HD void t_ends(Ctx<Em>& cx, int t) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     if (!cx.ki.first && !cx.ki.last) return;
     s.ends.c[t] = 0.0;
     s.ends.g[t] = 0.0;
     if (t < 105) {
         if (!cx.ki.last) return;
-        const int var = cx.kt.fin_var[t];
-        const double lhs = var >= 0 ? s.x[var] : s.pk[PK_DESC + cx.kt.fin_desc[t]];
+        const int var = end_tables(cx).fin_var[t];
+        const double lhs = var >= 0 ? s.x[var] : s.pk[PK_DESC + end_tables(cx).fin_desc[t]];
         if (cx.st.final_type == HIPNLP_EXPR_MINIMIZE) {
-            const double e = lhs - cx.gp.final_rhs[t];
+            const double e = lhs - final_rhs(cx)[t];
             s.ends.c[t] = cx.st.final_weight * e * e;
             s.ends.g[t] = 2.0 * cx.st.final_weight * e;
         } else if (cx.st.final_type == HIPNLP_EXPR_SUBJECT_TO) {
-            em.G(gs::FIN + t, row_id(RK_FIN, 0, t), lhs);
-            if (var >= 0) em.J(js::FIN + cx.kt.fin_slot[t], row_id(RK_FIN, 0, t), var, 1.0);
+            emit_g_end(cx, gs::FIN + t, row_id(RK_FIN, 0, t), lhs);
+            if (var >= 0) em.J(js::FIN + end_tables(cx).fin_slot[t], row_id(RK_FIN, 0, t), var, 1.0);
         }
     } else {
         const int i = t - 105;
-        const int var = cx.kt.per_var[i];
+        const int var = end_tables(cx).per_var[i];
         if (cx.st.periodicity_type == HIPNLP_EXPR_MINIMIZE) {
             if (!cx.ki.first && !cx.ki.last) return;
             // e = x_0 - x_{N-1};  at the last knot xo = x_0, at the first knot xo = x_{N-1}
@@ -963,7 +1054,7 @@ template <class Em> HD void t_ends(Ctx<Em>& cx, int t) {
             s.ends.g[t] = (cx.ki.last ? -2.0 : 2.0) * cx.st.periodicity_weight * e;  // d/dx_{N-1} = -2we, d/dx_0 = +2we
         } else if (cx.st.periodicity_type == HIPNLP_EXPR_SUBJECT_TO) {
             if (cx.ki.last) {
-                em.G(gs::PER + i, row_id(RK_PERN, 0, i), s.xo[i] - s.x[var]);
+                emit_g_end(cx, gs::PER + i, row_id(RK_PERN, 0, i), s.xo[i] - s.x[var]);
                 em.J(js::PERN + i, row_id(RK_PERN, 0, i), var, -1.0);
             }
             if (cx.ki.first) em.J(js::PER0 + i, row_id(RK_PER0, 0, i), var, 1.0);
@@ -977,18 +1068,18 @@ template <class Em> HD void t_ends(Ctx<Em>& cx, int t) {
 // t_links (lane i): first moment, origin velocity and momentum of the link;  t_link_inertia (lane i, another wave): rotational
 // inertia about the origin.  The momentum takes I_O w as R (I (R^T w)) + m (c^2 w - c (c.w)), so neither waits for the other.
 template <class Em> HD void t_links(Ctx<Em>& cx, int i) {
-    KnotScratch& s = cx.s;
-    const double m = cx.kt.mass[i];
+    auto& s = cx.s;
+    const double m = kin_mass(cx, i);
     double vo[3];
     link_origin_velocity(s, cx.kt, i, vo);
     for (int r = 0; r < 3; ++r) s.vo[i][r] = vo[r];
     const double* R = s.Rw[i];
     const double* w = s.wv[i];
     double c[3], h[3], wl[3], Iwl[3], Iw[3];
-    matvec3(R, cx.kt.com[i], c);
+    matvec3(R, kin_com(cx, i), c);
     for (int r = 0; r < 3; ++r) c[r] += s.ow[i][r];
     for (int r = 0; r < 3; ++r) wl[r] = R[r] * w[0] + R[3 + r] * w[1] + R[6 + r] * w[2];   // R^T w
-    matvec3(cx.kt.inertia[i], wl, Iwl);
+    matvec3(kin_inertia(cx, i), wl, Iwl);
     matvec3(R, Iwl, Iw);
     const double c2 = dot3(c, c), cw = dot3(c, w);
     double* cp = s.own[i];
@@ -1002,13 +1093,13 @@ template <class Em> HD void t_links(Ctx<Em>& cx, int i) {
     for (int r = 0; r < 3; ++r) cp[CKA + r] = Iw[r] + m * (c2 * w[r] - c[r] * cw) + b[r];
 }
 template <class Em> HD void t_link_inertia(Ctx<Em>& cx, int i) {
-    KnotScratch& s = cx.s;
-    const double m = cx.kt.mass[i];
+    auto& s = cx.s;
+    const double m = kin_mass(cx, i);
     const double* R = s.Rw[i];
     double c[3], RI[9];
-    matvec3(R, cx.kt.com[i], c);
+    matvec3(R, kin_com(cx, i), c);
     for (int r = 0; r < 3; ++r) c[r] += s.ow[i][r];
-    matmul3(R, cx.kt.inertia[i], RI);
+    matmul3(R, kin_inertia(cx, i), RI);
     // (R I R^T)(r, q) = RI row r . R row q; the six entries of the symmetric part
     const double c2 = dot3(c, c);
     double* cp = s.own[i] + CI;
@@ -1020,7 +1111,7 @@ template <class Em> HD void t_link_inertia(Ctx<Em>& cx, int i) {
     cp[5] = dot3(RI + 6, R + 6) + m * (c2 - c[2] * c[2]);
 }
 template <class Em> HD void t_frames(Ctx<Em>& cx, int f) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     const int L = cx.kt.frame_link[f];
     matmul3(s.Rw[L], cx.kt.frame_R[f], s.fr_R[f]);
     double o[3];
@@ -1053,7 +1144,7 @@ template <class Em> HD void t_frames(Ctx<Em>& cx, int f) {
 // 1-2-2-1 over four waves or one per wave over eight.
 static_assert(NL * 16 == 6 * 64, "six wave iterations of composite tasks (16 used components per link)");
 template <class Em> HD void t_composite(Ctx<Em>& cx, int t) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     const int i = cx.kt.comp_order[t >> 4], r = t & 15;
     // trip count of the wave iteration = largest subtree among its four links (uniform: scalar loop); shorter lists are padded
     // with the zero slot own[NL]
@@ -1083,7 +1174,7 @@ template <class Em> HD void t_composite_g3(Ctx<Em>& cx, int t) { t_composite(cx,
 template <class Em> HD void t_composite_g4(Ctx<Em>& cx, int t) { t_composite(cx, t + 256); }
 template <class Em> HD void t_composite_g5(Ctx<Em>& cx, int t) { t_composite(cx, t + 320); }   // the four smallest
 template <class Em> HD void t_pkin(Ctx<Em>& cx, int c) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     const int f = c < 4 ? 0 : 1;
     double r3[3];
     matvec3(s.fr_R[f], s.pk + PK_DESC + 3 * c, r3);
@@ -1094,7 +1185,7 @@ template <class Em> HD void t_pkin(Ctx<Em>& cx, int c) {
 // PHASE F — derivative columns.  lanes 0..22: joint j ; lanes 23..25: base rotation theta_e / omega_e
 // ===================================================================================================
 template <class Em> HD void t_columns(Ctx<Em>& cx, int t) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     const double inv_M = 1.0 / cx.kt.total_mass, inv_mass = 1.0 / cx.gp.mass;
     // totals of the whole tree (every lane needs them; lane 0 publishes them for the row assembly)
@@ -1151,7 +1242,7 @@ template <class Em> HD void t_columns(Ctx<Em>& cx, int t) {
 // joint columns of the frame-based terms, lane j (23), on a wave of its own in the column phase: chest-frame orientation cost
 // gradient and the feet lateral distance row
 template <class Em> HD void t_frame_columns(Ctx<Em>& cx, int j) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     const double* a = s.aw[j];
     const double* o = s.ow[j + 1];
@@ -1178,7 +1269,7 @@ template <class Em> HD void t_frame_columns(Ctx<Em>& cx, int j) {
 // columns of the centroidal momentum matrix (angular rows): d hang / d sdot_j = I_sub S_j about the CoM; lanes as t_columns,
 // on another wave of the same phase
 template <class Em> HD void t_cmm_columns(Ctx<Em>& cx, int t) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     const double inv_M = 1.0 / cx.kt.total_mass, inv_mass = 1.0 / cx.gp.mass;
     double com[3], a[3], o[3] = {0.0, 0.0, 0.0}, t1[3], t2[3];
@@ -1206,7 +1297,7 @@ template <class Em> HD void t_cmm_columns(Ctx<Em>& cx, int t) {
 // ===================================================================================================
 // contact-point kinematic consistency  p - (p_b + pkin)  (K1, planner.py:590-632): lane (c, i), 24 tasks
 template <class Em> HD void t_kinc(Ctx<Em>& cx, int t) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     const int c = t / 3, i = t - 3 * c, jb = js::PT_STRIDE * c, gb = gs::PT_STRIDE * c, cb = PT_ * c;
     const double* r = s.pkin[c];  // base-centred
@@ -1220,7 +1311,7 @@ template <class Em> HD void t_kinc(Ctx<Em>& cx, int t) {
 }
 // d pkin / d s_j = a_j x (pkin - o_j) for the joints of the leg path: lane (c, q) 48 tasks, three rows each (another wave)
 template <class Em> HD void t_kinc_s(Ctx<Em>& cx, int t) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     const int c = t / LEG_PATH, q = t - LEG_PATH * c, f = c < 4 ? 0 : 1, jb = js::PT_STRIDE * c;
     const int j = cx.kt.leg_joint[f][q];
@@ -1232,7 +1323,7 @@ template <class Em> HD void t_kinc_s(Ctx<Em>& cx, int t) {
 }
 // com == CoM(pb, qn, s)  (K2, planner.py:285-306): lanes (i, l) 12 for the q_b entries, lanes 12..14 rows
 template <class Em> HD void t_comc(Ctx<Em>& cx, int t) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     const double* r = s.com;
     if (t < 12) {
@@ -1248,7 +1339,7 @@ template <class Em> HD void t_comc(Ctx<Em>& cx, int t) {
 }
 // h[3:] == CMM(...)[3:] / mass  (K3, planner.py:309-339): lanes (i, l) 12 for q_b / qdot_b, lanes 12..14 rows
 template <class Em> HD void t_cmmc(Ctx<Em>& cx, int t) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     const double inv_mass = 1.0 / cx.gp.mass;
     if (t < 12) {
@@ -1268,7 +1359,7 @@ template <class Em> HD void t_cmmc(Ctx<Em>& cx, int t) {
 }
 // feet distance value (K4) on lane 4; chest cost gradient on q_b, lanes 0..3: 5 tasks
 template <class Em> HD void t_feetd(Ctx<Em>& cx, int t) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     if (t == 4) {
         const double* yr = s.fr_R[1];
@@ -1286,18 +1377,22 @@ template <class Em> HD void t_feetd(Ctx<Em>& cx, int t) {
 // minimize-mode end terms: lane 0 sums the cost partials, lanes 1.. add the gradient shares (phase G, behind t_feetd)
 constexpr int ENDS_FINISH_TASKS = 1 + ENDS_TASKS;
 template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     HIPNLP_WAVE_SYNC();
     const bool active = (cx.ki.last || cx.ki.first) && (cx.st.final_type == HIPNLP_EXPR_MINIMIZE || cx.st.periodicity_type == HIPNLP_EXPR_MINIMIZE);
     if (t == 0) {
+        // (only the rows that ARE costs: in the compact layout the c[] entries of subject_to rows hold their g values)
         double e = 0.0;
-        if (active && cx.ki.last) for (int i = 0; i < ENDS_TASKS; ++i) e += s.ends.c[i];
+        if (active && cx.ki.last) {
+            if (cx.st.final_type == HIPNLP_EXPR_MINIMIZE) for (int i = 0; i < 105; ++i) e += s.ends.c[i];
+            if (cx.st.periodicity_type == HIPNLP_EXPR_MINIMIZE) for (int i = 105; i < ENDS_TASKS; ++i) e += s.ends.c[i];
+        }
         s.cost[CT_ENDS] = e;
     } else if (active) {
         const int i = t - 1;
         const double gv = s.ends.g[i];
         if (gv != 0.0) {
-            const int var = i < 105 ? cx.kt.fin_var[i] : cx.kt.per_var[i - 105];
+            const int var = i < 105 ? end_tables(cx).fin_var[i] : end_tables(cx).per_var[i - 105];
             if (var >= 0) s.grad[var] += gv;  // every variable appears in at most one final row and one periodicity row,
         }                                      // and the two row sets are disjoint (states vs controls/velocities)
     }
@@ -1317,6 +1412,7 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
     BARRIER                                                                               \
     R(0, 0, t_fk_rot_a, FK_TASKS_A) R(0, 0, t_link_u_a, FK_SPLIT)                         \
     R(3, 1, t_fk_rot_b, FK_TASKS_B) R(3, 1, t_link_u_b, NJ - FK_SPLIT)                    \
+    R(1, 5, t_stage_link_tables, STAGE_TABLE_TASKS)                                       \
     R(1, 2, t_hdyn_entries, 48) R(1, 3, t_hdyn_rows, HDYN_TASKS - 48)                     \
     R(2, 7, t_terrain_hnf, NC) R(2, 4, t_terrain_swing, NC) R(2, 4, t_points_cost, 3) R(2, 4, t_foot_costs, FOOT_TASKS) R(2, 4, t_foot_cost_sum, 2) \
     R(1, 5, t_terrain_planar, NC) R(0, 6, t_terrain_dcc, NC) R(-1, 7, t_joint_cost, 1)    \

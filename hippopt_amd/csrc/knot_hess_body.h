@@ -147,10 +147,10 @@ template <class Em> HD double ends_diag(const KHCtx<Em>& h, int var) {
     double v = 0.0;
     if (cx.ki.last && cx.st.final_type == HIPNLP_EXPR_MINIMIZE)
         HIPNLP_ROLLED
-        for (int t = 0; t < 105; ++t) if (int(cx.kt.fin_var[t]) == var) v += 2.0 * h.hx.sigma * cx.st.final_weight;
+        for (int t = 0; t < 105; ++t) if (int(end_tables(cx).fin_var[t]) == var) v += 2.0 * h.hx.sigma * cx.st.final_weight;
     if ((cx.ki.first || cx.ki.last) && cx.st.periodicity_type == HIPNLP_EXPR_MINIMIZE)
         HIPNLP_ROLLED
-        for (int t = 0; t < 84; ++t) if (int(cx.kt.per_var[t]) == var) v += 2.0 * h.hx.sigma * cx.st.periodicity_weight;
+        for (int t = 0; t < 84; ++t) if (int(end_tables(cx).per_var[t]) == var) v += 2.0 * h.hx.sigma * cx.st.periodicity_weight;
     return v;
 }
 
@@ -173,7 +173,7 @@ template <class Em> HD double freg_diag(const KHCtx<Em>& h, int c) {
 // --- point-local entries: lane c (8) --------------------------------------------------------------------------------------------
 template <class Em> HD void t_kh_point(KHCtx<Em>& h, int c) {
     Ctx<Em>& cx = h.cx;
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     const double* lam = h.lam;
     const double sigma = h.hx.sigma;
@@ -228,7 +228,7 @@ template <class Em> HD void t_kh_ff(KHCtx<Em>& h, int t) {
 // contact centroid + yaw alignment share of (p_hi[a], p_lo[b]); structural tells whether a cross-coordinate entry exists at all
 template <class Em> HD double pp_costs(const KHCtx<Em>& h, int hi, int lo, int a, int b, bool& yaw_struct) {
     const Ctx<Em>& cx = h.cx;
-    const KnotScratch& s = cx.s;
+    const auto& s = cx.s;
     const double on = cx.ki.first ? 0.0 : 1.0;
     const int foot = hi >> 2;
     double yaw = 0.0;
@@ -247,7 +247,7 @@ template <class Em> HD double pp_costs(const KHCtx<Em>& h, int hi, int lo, int a
 }
 template <class Em> HD void t_kh_pp(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     const int pair = t / 5, e = t - 5 * pair;
     const int hi = tri_row(pair);
     const int lo = pair - hi * (hi + 1) / 2;
@@ -284,7 +284,7 @@ template <class Em> HD void t_kh_pp(KHCtx<Em>& h, int t) {
 template <class Em> HD void t_kh_point_smooth(KHCtx<Em>& h, int c) {
     Ctx<Em>& cx = h.cx;
     if (terrain_is_planar(cx)) return;
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     const double* lam = h.lam;
     const int gb = gs::PT_STRIDE * c, hb = hk::SP + hk::SP_STRIDE * c, cb = PT_ * c;
@@ -377,13 +377,13 @@ template <class Em> HD void t_kh_diag(KHCtx<Em>& h, int t) {
 template <class Em> HD void t_kh_percouple(KHCtx<Em>& h, int i) {
     Ctx<Em>& cx = h.cx;
     if (cx.st.periodicity_type != HIPNLP_EXPR_MINIMIZE || !cx.ki.last) return;
-    cx.em.H(hk::PERC + i, int(cx.kt.per_var[i]), COL_FIRST + int(cx.kt.per_var[i]), -2.0 * h.hx.sigma * cx.st.periodicity_weight);
+    cx.em.H(hk::PERC + i, int(end_tables(cx).per_var[i]), COL_FIRST + int(end_tables(cx).per_var[i]), -2.0 * h.hx.sigma * cx.st.periodicity_weight);
 }
 
 // --- centroidal momentum, shared quantities: lane 0 ---------------------------------------------------------------------------------
 template <class Em> HD void t_kh_mom0(KHCtx<Em>& h, int) {
     Ctx<Em>& cx = h.cx;
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     KHessScratch& hx = h.hx;
     const double* c0 = s.comp[0];
     const double M = cx.kt.total_mass;
@@ -407,7 +407,7 @@ template <class Em> HD void t_kh_mom0(KHCtx<Em>& h, int) {
 // --- centroidal momentum, per joint / base axis: lanes NJ + 3 (behind t_kh_mom0) -----------------------------------------------------
 template <class Em> HD void t_kh_joint(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     KHessScratch& hx = h.hx;
     SV6 S, v, hC, ell, t1, t2;
     const int link = t < NJ ? t + 1 : 0;
@@ -448,7 +448,7 @@ template <class Em> HD void t_kh_joint(KHCtx<Em>& h, int t) {
 //     Same construction as t_hess_Y of the pose finder.  lane j (23) -----------------------------------------------------------------
 template <class Em> HD void t_kh_Y(KHCtx<Em>& h, int j) {
     Ctx<Em>& cx = h.cx;
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     const double* lam = h.lam;
     const double* a = s.aw[j];
     const double* o = s.ow[j + 1];
@@ -522,7 +522,7 @@ HD bool kh_related(const KHessScratch& hx, int i, int j) { return (((hx.rel[j] >
 constexpr int KH_SS_TASKS = NJ * (NJ + 1) / 2;
 template <class Em> HD void t_kh_ss_far(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     const KHessScratch& hx = h.hx;
     const int j = tri_row(t);
     const int i = t - j * (j + 1) / 2;
@@ -546,7 +546,7 @@ template <class Em> HD void t_kh_ss_far(KHCtx<Em>& h, int t) {
 constexpr int KH_NEAR_TASKS = NJ * 8;
 template <class Em> HD void t_kh_ss_near(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     const KHessScratch& hx = h.hx;
     const int d = t >> 3, k = int(cx.kt.anc[d][t & 7]);   // k on the path root -> d (inclusive)
     if (k >= NJ) return;
@@ -614,7 +614,7 @@ template <class Em> HD void t_kh_theta(KHCtx<Em>& h, int t) {
 //     chain to the quaternion:  dtheta = G dq / |q|,  d omega / dq = dwq,  d omega / d qdot = G
 template <class Em> HD void t_kh_sq(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
-    const KnotScratch& s = cx.s;
+    const auto& s = cx.s;
     HIPNLP_WAVE_SYNC();
     const int j = t >> 2, l = t & 3;
     const double* Y = h.hx.Y[j];
@@ -624,7 +624,7 @@ template <class Em> HD void t_kh_sq(KHCtx<Em>& h, int t) {
 }
 template <class Em> HD void t_kh_sqd(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
-    const KnotScratch& s = cx.s;
+    const auto& s = cx.s;
     const int j = t >> 2, l = t & 3;
     double v = 0.0;
     for (int m = 0; m < 3; ++m) v += s.G[4 * m + l] * h.hx.WS[m][j];
@@ -632,7 +632,7 @@ template <class Em> HD void t_kh_sqd(KHCtx<Em>& h, int t) {
 }
 template <class Em> HD void t_kh_sdq(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
-    const KnotScratch& s = cx.s;
+    const auto& s = cx.s;
     const int j = t >> 2, l = t & 3;
     double v = 0.0;
     for (int m = 0; m < 3; ++m) v += s.G[4 * m + l] * s.inv_qnorm * h.hx.TSD[m][j];
@@ -653,7 +653,7 @@ HD void What_col(const double* t, int l, double* out) {
 // --- (q_r, qdot_c): lanes 16 ------------------------------------------------------------------------------------------------------------------
 template <class Em> HD void t_kh_qqd(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
-    const KnotScratch& s = cx.s;
+    const auto& s = cx.s;
     const KHessScratch& hx = h.hx;
     const int r = t >> 2, c = t & 3;
     // (theta_m, omega_m') = (dcom_m x mu) . G_m'.l - (S_m x l) . G_m' - (I^C_0 l) . (S_m x S_m')
@@ -685,7 +685,7 @@ template <class Em> HD void t_kh_qqd(KHCtx<Em>& h, int t) {
 template <class Em> HD void t_kh_qq0(KHCtx<Em>& h, int) {
     HIPNLP_WAVE_SYNC();   // behind t_kh_mom0 on its wave
     Ctx<Em>& cx = h.cx;
-    const KnotScratch& s = cx.s;
+    const auto& s = cx.s;
     KHessScratch& hx = h.hx;
     const double* lam = h.lam;
     const double on = cx.ki.first ? 0.0 : 1.0;
@@ -721,7 +721,7 @@ template <class Em> HD void t_kh_qq0(KHCtx<Em>& h, int) {
 //   Hess_q Phi(q / |q|) = J B J + ( -(g qh^T + qh g^T + (g.qh) I) + 3 (g.qh) qh qh^T ) / |q|^2,   J = (I - qh qh^T) / |q|
 template <class Em> HD void t_kh_qq(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
-    const KnotScratch& s = cx.s;
+    const auto& s = cx.s;
     const KHessScratch& hx = h.hx;
     const double* lam = h.lam;
     const double sigma = hx.sigma, on = cx.ki.first ? 0.0 : 1.0;

@@ -318,16 +318,16 @@ struct Layout {
             while (l > 0 && steps <= NL) { l = md.parent[l - 1]; ++steps; if (l < 0 || l >= NL) break; }
             if (l != 0) { err = "robot model: the parent links do not form a tree rooted at link 0"; return false; }
             double an = 0;
-            for (int i = 0; i < 3; ++i) { kt.axis[j][i] = md.axis[j][i]; an += md.axis[j][i] * md.axis[j][i]; }
+            for (int i = 0; i < 3; ++i) { kt.jf.axis[j][i] = md.axis[j][i]; an += md.axis[j][i] * md.axis[j][i]; }
             if (!(an > 0.999999 && an < 1.000001)) { err = "robot model: joint axes must be unit vectors"; return false; }
-            for (int i = 0; i < 9; ++i) kt.R_fix[j][i] = md.R_fix[j][i];
+            for (int i = 0; i < 9; ++i) kt.jf.R_fix[j][i] = md.R_fix[j][i];
         }
         kt.total_mass = 0;
         for (int l = 0; l < NL; ++l) {
-            kt.mass[l] = md.mass[l];
+            kt.li.mass[l] = md.mass[l];
             kt.total_mass += md.mass[l];
-            for (int i = 0; i < 3; ++i) kt.com[l][i] = md.com[l][i];
-            for (int i = 0; i < 9; ++i) kt.inertia[l][i] = md.inertia[l][i];
+            for (int i = 0; i < 3; ++i) kt.li.com[l][i] = md.com[l][i];
+            for (int i = 0; i < 9; ++i) kt.li.inertia[l][i] = md.inertia[l][i];
         }
         if (!(kt.total_mass > 0)) { err = "robot model: total mass must be positive"; return false; }
         for (int j = 0; j < NJ; ++j) { kt.leg_pos[0][j] = kt.leg_pos[1][j] = kt.chest_pos[j] = -1; }
@@ -351,7 +351,7 @@ struct Layout {
         // ancestor lists (path root -> j) and descendant lists (subtree of link i)
         for (int j = 0; j < NJ; ++j) {
             kt.par_link[j] = md.parent[j];
-            for (int i = 0; i < 3; ++i) kt.o_fix[j][i] = md.o_fix[j][i];
+            for (int i = 0; i < 3; ++i) kt.jf.o_fix[j][i] = md.o_fix[j][i];
             std::vector<int> path;
             for (int q = j + 1; q > 0; q = md.parent[q - 1]) path.push_back(q - 1);
             if (path.size() > 8) { err = "robot model: a chain is deeper than 8 joints"; return false; }
@@ -382,9 +382,9 @@ struct Layout {
         for (int i = 0; i < 105; ++i) {
             int slot, desc;
             const int var = final_row_var(i, &slot, &desc);
-            kt.fin_var[i] = int16_t(var); kt.fin_slot[i] = int16_t(slot); kt.fin_desc[i] = int16_t(desc);
+            kt.en.fin_var[i] = int16_t(var); kt.en.fin_slot[i] = int16_t(slot); kt.en.fin_desc[i] = int16_t(desc);
         }
-        for (int i = 0; i < 84; ++i) kt.per_var[i] = int16_t(periodicity_row_var(i));
+        for (int i = 0; i < 84; ++i) kt.en.per_var[i] = int16_t(periodicity_row_var(i));
         return true;
     }
 

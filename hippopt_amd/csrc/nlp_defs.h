@@ -7,6 +7,7 @@
 //   record  : host, values ignored, ids recorded -> layout.cpp derives g rows / CCS positions
 //   hostemu : tests only (tests/hostemu), values + ids on the CPU to debug the body without a GPU
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/hipnlp.h"
@@ -37,14 +38,21 @@ enum : int { PK_DESC = 0, PK_REF = 24, PK_YAWSC = 79,
              R_VREF = 17, R_FQ = 20, R_BQ = 24, R_BQV = 28, R_JREG = 32 };
 
 // ---- horizon-global parameters the kernels need (bounds-only parameters stay on the host) -----
-struct GParams {
+// GParamsLite: what every knot reads; GParams adds the final-state values, which only the LAST knot reads and only in `minimize`
+// mode (the compact device layout leaves them in global memory)
+struct GParamsLite {
     double dt, kt, kbs, eps, mu, mass;
     double gravity[6];
+};
+struct GParams : GParamsLite {
     double final_rhs[105];  // final_state values in final-row order (only read in `minimize` mode)
 };
 
 // ---- kinematic tree tables (device copy of hipnlp_robot_model + derived topology) ----------------
-struct KinTables {
+// KinLite: the tables every phase indexes per lane (LDS on the device).  KinTables adds the blocks that are read ONCE per knot
+// (joint frames: phase A only; link inertials: phase C only) or only by the first / last knot (horizon-end row tables): the compact
+// device layout does not keep those in LDS for the whole program (knot_body.h, KnotScratchT<true>).
+struct KinLite {
     int32_t leg_pos[2][NJ];     // position of joint j in the root->sole path (0..5) or -1
     int32_t leg_joint[2][LEG_PATH];
     int32_t chest_pos[NJ];      // position in the root->chest path or -1
@@ -52,19 +60,28 @@ struct KinTables {
     // tree as ancestor / descendant lists: every lane sums over its own list, no loop-carried dependence
     int32_t par_link[NJ];       // parent link of joint j
     int32_t fk_first[2];        // first useful position of the (front-padded) ancestor lists of joints [0, FK_SPLIT) / [FK_SPLIT, NJ)
-    alignas(8) int8_t anc[NJ][8];  // (read as one 8-byte word) joints on the path root -> j (inclusive, ascending, j LAST), FRONT padded with NJ (identity / zero slot)
+    alignas(8) int8_t anc[NJ][8];  // (read as one 8-byte word) joints on the path root -> j (inclusive, in path order, j LAST), FRONT padded with NJ (identity / zero slot)
     alignas(8) int8_t desc[NL][NL];  // (read as 8-byte words) links of the subtree rooted at link i (inclusive), padded with NL (zero slot)
     int16_t ndesc[NL];          // size of that subtree
     int16_t comp_order[NL];     // links by decreasing subtree size (order of the composite tasks)
     int16_t comp_cnt[NL / 4];   // largest subtree in each group of four links of that order
-    // horizon-end rows
-    int16_t fin_var[105], fin_slot[105], fin_desc[105];  // variable / slot among the 81 variable rows / descriptor index (3c+i) or -1
-    int16_t per_var[84];
-    double R_fix[NJ][9], o_fix[NJ][3], axis[NJ][3];
-    double mass[NL], com[NL][3], inertia[NL][9];
     double frame_R[3][9], frame_o[3][3];
     double total_mass;
 };
+struct JointFix { double R_fix[NJ][9], o_fix[NJ][3], axis[NJ][3]; };        // joint frames (phase A only)
+struct LinkInertials { double mass[NL], com[NL][3], inertia[NL][9]; };      // link inertials in the link frame (phase C only)
+struct EndTables {   // horizon-end rows (first / last knot only)
+    int16_t fin_var[105], fin_slot[105], fin_desc[105];  // variable / slot among the 81 variable rows / descriptor index (3c+i) or -1
+    int16_t per_var[84];
+};
+struct KinTables : KinLite {
+    EndTables en;
+    JointFix jf;
+    LinkInertials li;
+};
+constexpr int JFIX_DOUBLES = NJ * 15, LINR_DOUBLES = NL * 13;
+static_assert(sizeof(KinLite) % 8 == 0, "KinLite is copied in 8-byte words");
+static_assert(sizeof(JointFix) == sizeof(double) * JFIX_DOUBLES && sizeof(LinkInertials) == sizeof(double) * LINR_DOUBLES, "contiguous blocks of doubles");
 
 // ---- graph constants (hipnlp_settings, flattened for the kernel) ------------------------------------
 struct TerrainStepK {   // one SmoothTerrain.step bump, pre-digested: a = ax dx + ay dy, b = bx dx + by dy (dx = p_x - ox, ...)

@@ -25,7 +25,7 @@ HD constexpr int pose_to_knot_col(int i) {
 
 // --- contact point c: relaxed complementarity, height, normal force, friction rows; point regularisations.  lane c (8) ------
 template <class Em> HD void t_pose_points(Ctx<Em>& cx, int c) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
     const double* p = s.x + cb + P_;
@@ -76,7 +76,7 @@ template <class Em> HD void t_pose_points(Ctx<Em>& cx, int c) {
 // --- static balance (planner.py:487-509): lanes (c, e) 48 Jacobian entries, lanes 48..53 rows, lanes 54..59 com entries --------
 constexpr int POSE_BALANCE_TASKS = 60;
 template <class Em> HD void t_pose_balance(Ctx<Em>& cx, int t) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     const double* com = s.x + COM_;
     scratch_padding(s, t);
@@ -109,7 +109,7 @@ template <class Em> HD void t_pose_balance(Ctx<Em>& cx, int t) {
 
 // --- joints: bound rows, e^T diag(w) e regularisation (planner.py:575-589), local joint transform.  lane j (23) --------------
 template <class Em> HD void t_pose_joints(Ctx<Em>& cx, int j) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     em.G(gs::JPB + j, row_id(RK_JPB, 0, j), s.x[S_ + j]);
     em.J(js::JPB + j, row_id(RK_JPB, 0, j), S_ + j, 1.0);
@@ -122,7 +122,7 @@ template <class Em> HD void t_pose_joints(Ctx<Em>& cx, int j) {
 
 // --- com position error (planner.py:566-573): lanes 0..2 components, lane 3 value.  4 tasks -----------------------------------
 template <class Em> HD void t_pose_com(Ctx<Em>& cx, int t) {
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     Em& em = cx.em;
     const int mode = cx.st.pose_com_type;
     if (t < 3) {

@@ -98,7 +98,7 @@ HD constexpr int tri(int r, int c) { return r * (r + 1) / 2 + c; }   // r >= c
 //   costs: point position / force / average force regularisations  (:724-768)
 template <class Em> HD void t_hess_point(HCtx<Em>& h, int c) {
     Ctx<Em>& cx = h.cx;
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     const double* lam = h.hx.lam;
     const double sigma = h.hx.sigma;
     const int gb = gs::PT_STRIDE * c, hb = hs::PT_STRIDE * c, cb = PT_ * c;
@@ -185,7 +185,7 @@ HD void chest_error(const KnotScratch& s, double* E) {
 //   L = sum_c w_c . pkin_c + w_com . com_kin + sigma m (tr E - 3)^2,   w_c = -lambda(kinematics consistency), w_com = -lambda(com consistency)
 template <class Em> HD void t_hess_Y(HCtx<Em>& h, int j) {
     Ctx<Em>& cx = h.cx;
-    KnotScratch& s = cx.s;
+    auto& s = cx.s;
     const double* lam = h.hx.lam;
     const double* a = s.aw[j];
     const double* o = s.ow[j + 1];
@@ -242,7 +242,7 @@ template <class Em> HD void t_hess_ss(HCtx<Em>& h, int t) {
 // --- (s_j, q_l): lanes (j, l) ---------------------------------------------------------------------------------------------------
 template <class Em> HD void t_hess_qs(HCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
-    const KnotScratch& s = cx.s;
+    const auto& s = cx.s;
     const int j = t >> 2, l = t & 3;
     const double* Y = h.hx.Y[j];
     cx.em.H(hs::QS + t, pv::S + j, pv::QB + l, (s.G[l] * Y[0] + s.G[4 + l] * Y[1] + s.G[8 + l] * Y[2]) * s.inv_qnorm);
@@ -253,7 +253,7 @@ template <class Em> HD void t_hess_qs(HCtx<Em>& h, int t) {
 //   Hess_q F = J B J + ( -(g qh^T + qh g^T + (g.qh) I) + 3 (g.qh) qh qh^T ) / |q|^2,   J = (I - qh qh^T) / |q|,  g, B = gradient, Hessian of Phi
 template <class Em> HD void t_hess_qq(HCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
-    const KnotScratch& s = cx.s;
+    const auto& s = cx.s;
     const double* lam = h.hx.lam;
     const double sigma = h.hx.sigma;
     int r = 0;

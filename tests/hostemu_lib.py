@@ -64,11 +64,14 @@ class HostEmu:
             out.append((name.value.decode(), a.value, b.value, c.value, d.value))
         return out
 
-    def eval(self, x, p):
+    def eval(self, x, p, compact=False):
+        """compact: on the COMPACT scratch layout of the planar device kernel (arrays with disjoint lifetimes share storage)"""
         f = C.c_double()
         grad, g, jac, ct = np.zeros(self.n), np.full(self.m, np.nan), np.full(self.nnz, np.nan), np.zeros(_abi.NCOST_TERMS)
-        self.lib.hostemu_eval(C.c_void_p(self.h), _dp(np.ascontiguousarray(x)), _dp(np.ascontiguousarray(p)),
-                              C.byref(f), _dp(grad), _dp(g), _dp(jac), _dp(ct))
+        fn = self.lib.hostemu_eval_compact if compact else self.lib.hostemu_eval
+        rc = fn(C.c_void_p(self.h), _dp(np.ascontiguousarray(x)), _dp(np.ascontiguousarray(p)), C.byref(f), _dp(grad), _dp(g), _dp(jac), _dp(ct))
+        if compact and rc != 0:
+            raise RuntimeError("the compact layout is the planar kernel's")
         return f.value, grad, g, jac, ct
 
 

@@ -282,3 +282,26 @@ def test_hessian_body_matches_reference_planner_fixture(model, name):
     ir, jc = he.hess_sparsity()
     vals = he.hess(z["x"], z["p"], float(z["hess_sigma"]), z["hess_lambda"])
     assert rel(hessian_times(ir, jc, vals, he.n, z["hess_dirs"]), z["hess_times_dirs"]) <= (1e-9 if "stairs" in name else TOL)
+
+
+@pytest.mark.parametrize("mode", ["subject_to", "minimize", "mixed", "single"])
+def test_compact_scratch_layout_gives_the_same_values(model, mode):
+    """The planar device kernel runs on a compact scratch (four workgroups per CU): own[] on top of the joint records, the horizon-end
+    g rows inside the end-term partials, joint frames and link inertials parked in comp[].  Emulated in program order on the host:
+    bitwise the values of the full layout, in every combination of the horizon-end expression types."""
+    N = 5
+    st = single_step_settings(N, model) if mode == "single" else periodic_step_settings(N, model)
+    if mode == "minimize":
+        st.final_state_expression_type = st.periodicity_expression_type = _abi.EXPR_MINIMIZE
+        st.final_state_expression_weight, st.periodicity_expression_weight = 2.0, 0.5
+    if mode == "mixed":
+        st.periodicity_expression_type = _abi.EXPR_MINIMIZE
+        st.periodicity_expression_weight = 0.25
+    x, p = make_workload(st, model, 1, 700)
+    he = HostEmu(st, model)
+    full = he.eval(x[0], p[0])
+    comp = he.eval(x[0], p[0], compact=True)
+    for a, b in zip(full, comp):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    fo, grado, go, jaco = Oracle(st, model).eval(x[0], p[0])
+    assert rel(np.array(comp[0]), np.array(fo)) < TOL and rel(comp[2], go) < TOL and rel(comp[3], jaco) < TOL and rel(comp[1], grado) < TOL

@@ -91,7 +91,7 @@ def main():
 
     # ---- planner settings (get_planner_settings, :17-130) -------------------------------------------------------------------------
     # the termination options of the reference script (main_single_step_flat_ground.py:105-130)
-    opts = {"max_iter": ITERS, "tol": 1e-3, "constr_viol_tol": 1e-4, "acceptable_tol": 10.0, "acceptable_iter": 2,
+    opts = {"max_iter": ITERS, "tol": 1e-3, "constr_viol_tol": 1e-4, "acceptable_tol": 10.0, "acceptable_iter": int(os.environ.get("SOLVE_ACCEPTABLE_ITER", "2")),
             "acceptable_obj_change_tol": 1.0, "hessian_approximation": HESSIAN, "verbose": int(os.environ.get("SOLVE_VERBOSE", "0"))}
     st = Settings.from_numeric(single_step_settings(N, model), solver_options=opts)
     planner = Planner(st, model, error_on_fail=False)

@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/prof_<tag>/ (written by tools/diag/profile_round.sh) into the committed summaries under profiles/:
-kernel stats CSVs, PMC means per dispatch, the 8-B-per-lane calibration of FETCH_SIZE / WRITE_SIZE, and
-profiles/traffic.json (HBM bytes per launch that bench.py reports as roofline.traffic)."""
+kernel-stats CSVs per workload, PMC means per dispatch, the 8-B-per-lane calibration of FETCH_SIZE / WRITE_SIZE, and
+profiles/traffic.json (HBM bytes per launch and VALU wave-instructions per knot that bench.py reports, labelled as looked up)."""
 import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -18,7 +19,7 @@ os.makedirs(dst, exist_ok=True)
 
 def newest(pattern):
     """gpurun merges every run into gpurun_out/: keep only the files of the latest run of each pass."""
-    files = glob.glob(pattern)
+    files = glob.glob(pattern, recursive=True)
     if not files:
         return []
     t = max(os.path.getmtime(f) for f in files)
@@ -27,7 +28,7 @@ def newest(pattern):
 
 def counter_means(d, kernel_substr):
     out = {}
-    for f in newest(os.path.join(d, "*", "*counter_collection.csv")):
+    for f in newest(os.path.join(d, "**", "*counter_collection.csv")):
         acc = {}
         for r in csv.DictReader(open(f)):
             if kernel_substr in r["Kernel_Name"]:
@@ -38,57 +39,92 @@ def counter_means(d, kernel_substr):
     return out
 
 
+def kernel_stats(d, wanted):
+    out = {}
+    for f in newest(os.path.join(d, "**", "*kernel_stats.csv")):
+        for r in csv.DictReader(open(f)):
+            for key, sub in wanted.items():
+                if sub in r["Name"]:
+                    out[key + "_avg_ns"] = float(r["AverageNs"])
+                    out[key + "_calls"] = int(r["Calls"])
+                    out[key + "_name"] = r["Name"][:120]
+        return out, f
+    return out, None
+
+
 calib = {}
 cf = counter_means(os.path.join(src, "calib_fetch"), "copy8")
 cw = counter_means(os.path.join(src, "calib_write"), "copy8")
 known = float(1 << 30)
-# rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB
-calib["fetch_kib_per_launch"] = cf.get("FETCH_SIZE")
+calib["fetch_kib_per_launch"] = cf.get("FETCH_SIZE")       # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB
 calib["write_kib_per_launch"] = cw.get("WRITE_SIZE")
 calib["known_bytes_each"] = known
 calib["fetch_correction"] = known / (cf["FETCH_SIZE"] * 1024.0) if cf.get("FETCH_SIZE") else None
 calib["write_correction"] = known / (cw["WRITE_SIZE"] * 1024.0) if cw.get("WRITE_SIZE") else None
 summary = {"calibration_8B_per_lane": calib, "workloads": {}}
-traffic = {}
-for B in (1, 64, 1024):
-    w = {}
-    for f in newest(os.path.join(src, "trace_B%d" % B, "*", "*kernel_stats.csv")):
-        shutil.copy(f, os.path.join(dst, "%s_kernel_stats_N100_B%d.csv" % (tag, B)))
-        for r in csv.DictReader(open(f)):
-            if "knot_kernel" in r["Name"]:
-                w["knot_kernel_avg_ns"] = float(r["AverageNs"])
-                w["knot_kernel_calls"] = int(r["Calls"])
-            if "reduce_kernel" in r["Name"]:
-                w["reduce_kernel_avg_ns"] = float(r["AverageNs"])
-    fe = counter_means(os.path.join(src, "fetch_B%d" % B), "knot_kernel")
-    wr = counter_means(os.path.join(src, "write_B%d" % B), "knot_kernel")
-    sq = counter_means(os.path.join(src, "sq_B%d" % B), "knot_kernel")
-    w["FETCH_SIZE_kib"] = fe.get("FETCH_SIZE")
-    w["WRITE_SIZE_kib"] = wr.get("WRITE_SIZE")
+tpath = os.path.join(dst, "traffic.json")
+traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+names = sorted({os.path.basename(p)[len("trace_"):] for p in glob.glob(os.path.join(src, "trace_*")) if os.path.isdir(p) and "hess" not in p})
+for name in names:
+    m = re.match(r"(\w+?)_N(\d+)_B(\d+)$", name)
+    N, B = int(m.group(2)), int(m.group(3))
+    knots = N * B
+    w, f = kernel_stats(os.path.join(src, "trace_" + name), {"knot_kernel": "knot_kernel", "reduce_kernel": "reduce_kernel"})
+    if f:
+        shutil.copy(f, os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, name)))
+    fe = counter_means(os.path.join(src, "fetch_" + name), "knot_kernel")
+    wr = counter_means(os.path.join(src, "write_" + name), "knot_kernel")
+    sq = counter_means(os.path.join(src, "sq_" + name), "knot_kernel")
+    w["FETCH_SIZE_kib"], w["WRITE_SIZE_kib"] = fe.get("FETCH_SIZE"), wr.get("WRITE_SIZE")
     w["sq"] = {k: v for k, v in sq.items() if not k.endswith("_n")}
+    bj = os.path.join(src, "bench_%s.json" % name)
+    if os.path.exists(bj) and os.path.getsize(bj) > 0:
+        w["bench"] = json.load(open(bj))
+        shutil.copy(bj, os.path.join(dst, "%s_bench_%s.json" % (tag, name)))
+        w["algorithmic_bytes_per_launch"] = w["bench"]["roofline"]["algorithmic_bytes_per_knot"] * knots
+    ent = {"round": tag}
     if fe.get("FETCH_SIZE") is not None and wr.get("WRITE_SIZE") is not None and calib["fetch_correction"]:
         hbm = fe["FETCH_SIZE"] * 1024.0 * calib["fetch_correction"] + wr["WRITE_SIZE"] * 1024.0 * calib["write_correction"]
         w["hbm_bytes_per_launch_corrected"] = hbm
-        w["algorithmic_bytes_per_launch"] = 16936 * 100 * B
-        traffic["N100_B%d" % B] = {"hbm_bytes_per_launch": hbm, "fetch_kib": fe["FETCH_SIZE"], "write_kib": wr["WRITE_SIZE"],
-                                   "fetch_correction": calib["fetch_correction"], "write_correction": calib["write_correction"], "round": tag}
-    bj = os.path.join(src, "bench_B%d.json" % B)
-    if os.path.exists(bj) and os.path.getsize(bj) > 0:
-        w["bench"] = json.load(open(bj))
-        shutil.copy(bj, os.path.join(dst, "%s_bench_N100_B%d.json" % (tag, B)))
-    summary["workloads"]["N100_B%d" % B] = w
-for f in newest(os.path.join(src, "trace_hess", "*", "*kernel_stats.csv")):
-    shutil.copy(f, os.path.join(dst, "%s_hess_kernel_stats.csv" % tag))
-hb = os.path.join(src, "hess_bench.jsonl")
-if os.path.exists(hb):
-    lines = [l for l in open(hb) if l.startswith("{")]
-    open(os.path.join(dst, "%s_hess_bench.jsonl" % tag), "w").writelines(lines)
-    summary["exact_hessian"] = [json.loads(l) for l in lines]
+        ent.update({"hbm_bytes_per_launch": hbm, "fetch_kib": fe["FETCH_SIZE"], "write_kib": wr["WRITE_SIZE"],
+                    "fetch_correction": calib["fetch_correction"], "write_correction": calib["write_correction"]})
+    if sq.get("SQ_INSTS_VALU"):
+        ent["valu_wave_insts_per_knot"] = sq["SQ_INSTS_VALU"] / knots
+        w["valu_wave_insts_per_knot"] = ent["valu_wave_insts_per_knot"]
+        w["salu_wave_insts_per_knot"] = sq.get("SQ_INSTS_SALU", 0.0) / knots
+        w["lds_wave_insts_per_knot"] = sq.get("SQ_INSTS_LDS", 0.0) / knots
+        if sq.get("SQ_WAVE_CYCLES"):
+            w["wait_fraction_of_wave_cycles"] = sq.get("SQ_WAIT_ANY", 0.0) / sq["SQ_WAVE_CYCLES"]
+    if len(ent) > 1:
+        traffic[name] = ent
+    summary["workloads"][name] = w
+summary["exact_hessian"] = {}
+for hw in ("periodic", "stairs"):
+    h, f = kernel_stats(os.path.join(src, "trace_hess_" + hw), {"hess_kernel": "knot_hess_kernel"})
+    if f:
+        shutil.copy(f, os.path.join(dst, "%s_hess_kernel_stats_%s.csv" % (tag, hw)))
+    hb = os.path.join(src, "hess_bench_%s.jsonl" % hw)
+    if os.path.exists(hb):
+        lines = [l for l in open(hb) if l.startswith("{")]
+        open(os.path.join(dst, "%s_hess_bench_%s.jsonl" % (tag, hw)), "w").writelines(lines)
+        h["bench"] = [json.loads(l) for l in lines]
+    fe = counter_means(os.path.join(src, "fetch_hess_" + hw), "knot_hess_kernel")
+    wr = counter_means(os.path.join(src, "write_hess_" + hw), "knot_hess_kernel")
+    if fe.get("FETCH_SIZE") is not None and wr.get("WRITE_SIZE") is not None and calib["fetch_correction"]:
+        h["hbm_bytes_per_launch_corrected_B64"] = fe["FETCH_SIZE"] * 1024.0 * calib["fetch_correction"] + wr["WRITE_SIZE"] * 1024.0 * calib["write_correction"]
+    summary["exact_hessian"][hw] = h
 json.dump(summary, open(os.path.join(dst, "%s_summary.json" % tag), "w"), indent=1)
-json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
-print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk not in ("bench", "sq")} for k, v in summary["workloads"].items()}, indent=1))
+json.dump(traffic, open(tpath, "w"), indent=1)
 print(json.dumps(calib, indent=1))
 for k, v in summary["workloads"].items():
+    line = "%-22s knot kernel %.1f ns x %s" % (k, v.get("knot_kernel_avg_ns", float("nan")), v.get("knot_kernel_calls"))
     if "bench" in v:
         b = v["bench"]
-        print(k, "knots/s %.3g" % b["value"], "kernel_ms %.4f" % b["roofline"]["kernel_ms"], "frac %.4f" % b["roofline"]["frac"])
+        line += " | bench %.3g knots/s kernel_ms %.5f frac %.4f" % (b["value"], b["roofline"]["kernel_ms"], b["roofline"]["frac"])
+    if "hbm_bytes_per_launch_corrected" in v:
+        line += " | HBM %.3g B vs algorithmic %.3g B" % (v["hbm_bytes_per_launch_corrected"], v.get("algorithmic_bytes_per_launch", float("nan")))
+    if "valu_wave_insts_per_knot" in v:
+        line += " | VALU/knot %.0f SALU %.0f LDS %.0f wait %.2f" % (v["valu_wave_insts_per_knot"], v["salu_wave_insts_per_knot"], v["lds_wave_insts_per_knot"], v.get("wait_fraction_of_wave_cycles", float("nan")))
+    print(line)
+for hw, h in summary["exact_hessian"].items():
+    print("hessian", hw, {k: v for k, v in h.items() if k != "bench"}, [(b["workload"][-20:], round(b["ms_per_eval"], 5)) for b in h.get("bench", [])])
