@@ -33,6 +33,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (guides/MI355X_MICROARCH.md)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0   # G wave-instructions/s: 256 CUs x 4 SIMDs x 2.4 GHz, 4 issue cycles per wave64 VALU instruction
 KNOTS_PER_GPU = 100
+# BENCH_REHEARSAL=1: the N ranks of `--gpus N` all use device 0 and talk over gloo (RCCL refuses two ranks on one device): a plumbing
+# check of the multi-rank paths on a one-GPU box, labelled as such in the JSON line — never a measurement.
+REHEARSAL = os.environ.get("BENCH_REHEARSAL") == "1"
 
 
 def parse_args():
@@ -59,6 +62,8 @@ def spawn_ranks(n):
     GPU, relay their output, exit with their code.  (Never an exec of a process that has initialised the GPU.)"""
     import torch
     have = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+    if REHEARSAL and have >= 1:
+        have = n   # every rank on device 0 (plumbing check of the N-rank paths on a one-GPU box)
     if have < n:
         sys.stderr.write("bench.py --gpus %d: only %d HIP device(s) visible; refusing to report a smaller world as n_gpus=%d\n" % (n, have, n))
         sys.exit(2)
@@ -271,12 +276,17 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the engine has no CPU fallback)")
+    if REHEARSAL:
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit("bench.py: rank %d has no device %d (%d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if REHEARSAL:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         assert dist.get_world_size() == world
 
     model = synthetic_ergocub()
@@ -465,7 +475,7 @@ def main():
                                    % (args.horizon, args.batch),
                        "horizon": main_res["horizon"], "batch": args.batch, "knots_per_step": main_res["knots_per_step"],
                        "parallelism": main_res["parallelism"], "ranks": world,
-                       "collective_backend": ("nccl (RCCL), %d ranks" % dist.get_world_size()) if world > 1 else None,
+                       "collective_backend": (("gloo, %d ranks on ONE device: REHEARSAL of the plumbing, not a measurement" if REHEARSAL else "nccl (RCCL), %d ranks") % dist.get_world_size()) if world > 1 else None,
                        "n": int(d.n), "m": int(d.m), "nnz": int(d.nnz), "nnz_per_knot": nnz_knot},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,

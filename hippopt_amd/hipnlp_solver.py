@@ -557,6 +557,8 @@ class HipNlpSolver:
         if not exact:
             nlp.add_option("hessian_approximation", "limited-memory")  # main_periodic_step.py:116
         for k, v in outer._options.items():
+            if k in ("verbose", "detect_simple_bounds"):   # options of the stand-in driver / of Opti, not of IPOPT
+                continue
             nlp.add_option(k, v)
         x, info = nlp.solve(x0)
         info = dict(info)

@@ -106,7 +106,14 @@ class ShardedCallback:
     def _run(self, x, stream_handle):
         self.compute_shard(x, *self.views, stream_handle)
         if self.world > 1:
-            dist.all_gather_into_tensor(self.all, self.buf, group=self.group)
+            if self.device.type == "cuda" and dist.get_backend(self.group) == "gloo":
+                # rehearsal of the plumbing with several ranks on one GPU (RCCL refuses that; gloo gathers host tensors only)
+                torch.cuda.current_stream(self.device).synchronize()
+                host = torch.empty(self.world * self.shard_len, dtype=torch.float64)
+                dist.all_gather_into_tensor(host, self.buf.cpu(), group=self.group)
+                self.all.copy_(host)
+            else:
+                dist.all_gather_into_tensor(self.all, self.buf, group=self.group)
             gathered = self.all
         else:
             gathered = self.buf

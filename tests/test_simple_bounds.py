@@ -2,8 +2,6 @@
 the NLP the driver sees has the single-variable rows lifted into lbx / ubx.  Checked on the host emulation of the engine (no GPU
 here): sizes against SURVEY 8a (274 - 70 rows per interior knot), the reduced g / jac g are the kept rows of the full ones, and the
 multipliers map back onto every named constraint."""
-import ctypes as C
-
 import numpy as np
 
 from hippopt_amd.hipnlp_solver import _SimpleBoundsLift
@@ -12,31 +10,7 @@ from hippopt_amd.synthetic import make_workload
 from hostemu_lib import HostEmu
 
 
-class EmuEngine:
-    """the method set the NLP drivers use on HipNlp, backed by the host emulation"""
-
-    def __init__(self, st, model, p):
-        self.he, self.p = HostEmu(st, model), p
-        self.n, self.m, self.nnz = self.he.n, self.he.m, self.he.nnz
-
-    def simple_rows(self):
-        a, b = np.zeros(self.m, np.int32), np.zeros(self.m, np.int32)
-        self.he.lib.hostemu_simple_rows(C.c_void_p(self.he.h), a.ctypes.data_as(C.POINTER(C.c_int)), b.ctypes.data_as(C.POINTER(C.c_int)))
-        return a, b
-
-    def sparsity(self):
-        return self.he.sparsity()
-
-    def row_blocks(self):
-        return self.he.row_blocks()
-
-    def bounds(self):
-        lb, ub = self.he.bounds(self.p)
-        return np.full(self.n, -np.inf), np.full(self.n, np.inf), lb, ub
-
-    def eval(self, x, new_x=True, want=None, nan_ok=False):
-        f, grad, g, jac, _ = self.he.eval(np.asarray(x).reshape(-1), self.p)
-        return np.array([f]), grad[None], g[None], jac[None]
+from emu_engine import EmuEngine  # noqa: E402
 
 
 def test_reduced_problem_sizes_and_values(model):
