@@ -518,9 +518,14 @@ def main():
             cb["gpu_over_cpu"] = {"device_resident_vs_1_thread": line["value"] / cb["value"],
                                   "device_resident_vs_all_cores": line["value"] / cb["all_cores"]["value"]}
             if "host_visible" in line and "all" in line["host_visible"]:
-                hv_rate = line["host_visible"]["all"]["knots_per_s"]
-                cb["gpu_over_cpu"]["host_visible_vs_1_thread"] = hv_rate / cb["value"]
-                cb["gpu_over_cpu"]["host_visible_vs_all_cores"] = hv_rate / cb["all_cores"]["value"]
+                # at the boundary IPOPT binds, all four outputs per call: plain caller arrays / arrays registered with the library /
+                # one objective (or trial-point) call
+                hv = line["host_visible"]
+                for tag, key in (("host_visible_all", "all"), ("host_visible_all_registered", "all (caller arrays registered: direct kernel stores)"),
+                                 ("host_visible_f", "f")):
+                    if key in hv:
+                        cb["gpu_over_cpu"][tag + "_vs_1_thread"] = hv[key]["knots_per_s"] / cb["value"]
+                        cb["gpu_over_cpu"][tag + "_vs_all_cores"] = hv[key]["knots_per_s"] / cb["all_cores"]["value"]
             line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
     if world > 1:
