@@ -52,6 +52,30 @@ template <int K> HD J2<K> j2_ipow(const J2<K>& a, int m) {   // a^m, integer m >
     for (int n = 0; n <= K; ++n) { gn[n] = binom * ipow_d(a.c[0], m - n); binom = binom * double(m - n) / double(n + 1); }
     return j2_compose(a, gn);
 }
+// (a0 + ax X + ay Y)^m for an integer m > K, in closed form (multinomial theorem): the coefficient of X^i Y^j is
+// m (m-1) ... (m-i-j+1) / (i! j!)  a0^(m-i-j) ax^i ay^j.  No polynomial products and no temporaries: the two footprint powers of every
+// bump were half of the truncated products of the terrain jet and most of its register pressure.
+template <int K> HD J2<K> j2_linpow(double a0, double ax, double ay, int m) {
+    J2<K> r;
+    double p[K + 1];              // a0^(m-d), d = 0..K
+    p[K] = ipow_d(a0, m - K);
+    for (int d = K - 1; d >= 0; --d) p[d] = p[d + 1] * a0;
+    double ff = 1.0;              // m (m-1) ... (m-d+1)
+    for (int d = 0; d <= K; ++d) {
+        double xi = 1.0;          // ax^i / i!  with i = d - j, built from j = d downwards
+        // coefficient(i, j) = ff * p[d] * (ax^i / i!) * (ay^j / j!)
+        double yj[K + 1];
+        yj[0] = 1.0;
+        for (int j = 1; j <= d; ++j) yj[j] = yj[j - 1] * ay / double(j);
+        for (int i = 0; i <= d; ++i) {
+            const int j = d - i;
+            r.c[J2<K>::idx(i, j)] = ff * p[d] * xi * yj[j];
+            xi = xi * ax / double(i + 1);
+        }
+        ff = ff * double(m - d);
+    }
+    return r;
+}
 template <int K> HD J2<K> j2_pow(const J2<K>& a, double alpha) {   // a^alpha, a_0 > 0
     double gn[K + 1];
     gn[0] = pow(a.c[0], alpha);
@@ -77,10 +101,8 @@ HD J2<4> terrain_Z_j4(const KSettings& st, double px, double py) {
         const TerrainStepK& t = st.steps[sidx];
         Z.c[0] += t.oz;
         const double dx = px - t.ox, dy = py - t.oy;
-        J2<4> a, b;
-        a.c[0] = t.ax * dx + t.ay * dy; a.c[J2<4>::idx(1, 0)] = t.ax; a.c[J2<4>::idx(0, 1)] = t.ay;
-        b.c[0] = t.bx * dx + t.by * dy; b.c[J2<4>::idx(1, 0)] = t.bx; b.c[J2<4>::idx(0, 1)] = t.by;
-        const J2<4> g = j2_ipow(a, t.m) + j2_ipow(b, t.m);
+        // the footprint coordinates a, b are LINEAR in (p_x, p_y): their powers in closed form
+        const J2<4> g = j2_linpow<4>(t.ax * dx + t.ay * dy, t.ax, t.ay, t.m) + j2_linpow<4>(t.bx * dx + t.by * dy, t.bx, t.by, t.m);
         const J2<4> w = j2_ipow(g, t.r);
         if (!(w.c[0] < 700.0)) continue;
         double gn[5];

@@ -37,9 +37,19 @@ if __name__ == "__main__":
         from hippopt_amd.synthetic import place_on_step_flanks
         place_on_step_flanks(x, st, seed=1)
     eng = hipnlp.HipNlp(st, model, batch=batch)
+    eng.set_host_timing(True)
     eng.set_params(p)
-    for _ in range(20):
-        eng.eval(x)
+    if os.environ.get("STAMPS_DEVICE") == "1":   # the device-pointer path (bench.py's `value`): x resident in HBM
+        import torch
+        xd = torch.tensor(x, device="cuda")
+        outs = [torch.empty(k, dtype=torch.float64, device="cuda") for k in (batch, batch * eng.n, batch * eng.m, batch * eng.nnz)]
+        stream = torch.cuda.Stream()
+        for _ in range(20):
+            eng.eval_device(xd.data_ptr(), *[o.data_ptr() for o in outs], stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+    else:
+        for _ in range(20):
+            eng.eval(x)
     out = np.zeros((100 * batch, 8, 128), np.uint64)
     eng.lib.hipnlp_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
     eng.lib.hipnlp_debug_stamps(eng.h, out.ctypes.data_as(C.c_void_p))
@@ -79,4 +89,5 @@ if __name__ == "__main__":
         print("entry -> end per workgroup: median %d  max %d (workgroup %d)" % (np.median(e), e.max(), int(np.argmax(e))))
         t_first = o[:, :, 0].min()
         print("first entry of the grid -> last end of the grid: %d cycles; last entry %d" % (o[:, :, 8 + 2 * nb].max() - t_first, o[:, :, 0].min(axis=1).max() - t_first))
-    print("kernel ms:", eng.last_kernel_ms())
+    if os.environ.get("STAMPS_DEVICE") != "1":
+        print("kernel ms:", eng.last_kernel_ms())
