@@ -272,16 +272,22 @@ template <class Em> HD void t_kh_pp(KHCtx<Em>& h, int t) {
     cx.em.H(hk::PP + t, PT_ * hi + P_ + e, PT_ * lo + P_ + e, v);
 }
 
-// (Measured: the same work staged over three task groups — one lane per (point, bump) for the jets, per point for the frame parked in
-//  the dead jac area, per (point, block) for the entries — ran no faster alone (48.6 us per 100-knot stairs Hessian either way) and
-//  slower at batch 64 (0.72 vs 0.63 ms): kept as one task per point.)
-// (Also measured, behind the kinematics-only program: the terrain frame evaluated one phase earlier and parked in the dead jac area, the
-//  entries split four ways over the four waves — 34.3 us / 0.460 ms against 35.8 us / 0.457 ms for this single task: the truncated-Taylor
-//  arithmetic of the frame itself is the long pole, not the assembly.)
-// --- smooth terrain: the dense blocks of one contact point, lane c (8).  Lagrangian of the point with f, v, f_dot, u_v constant:
+// --- smooth terrain: the dense blocks of one contact point.  Lagrangian of the point with f, v, f_dot, u_v constant:
 //       L = C_u . u + l_d (-kbs h nf - hdot nf - h (ndot . f) - h (n . fdot)) + l_h h + l_n nf + l_f (mu^2 nf^2 - (x.f)^2 - (y.f)^2)
 //           + sigma m_sw/2 ((h - h_d)^2 + (x.v)^2 + (y.v)^2),      C_u = -sum_i l_pl,i (x_i tau, y_i tau, n_i),  tau = tanh(kt h)
-template <class Em> HD void t_kh_point_smooth(KHCtx<Em>& h, int c) {
+//     with n, x, y the terrain frame, nf = n.f, hdot = grad h . v, ndot = (dn/dp) v.
+// Two tasks on two waves (round 1 had ONE task per point that built the whole frame as nineteen second-order jets — 190 doubles live
+// next to the truncated-Taylor arithmetic: 256 VGPRs plus ~100 spilled to scratch memory — and assembled everything from them):
+//   t_kh_point_smooth_pp     lane c: the (p, p) block = Hessian of L.  Every term of L contracts the frame with a CONSTANT vector
+//                            (f, v, f_dot, the multipliers): the contractions are taken while the frame still is a set of
+//                            two-variable jets (J2<3>: linear combinations, and x.c = iq (q c_0 - n_0 (n_1 c_1 + n_2 c_2)),
+//                            y.c = iq (n_2 c_1 - n_1 c_2): three products for a pair instead of nine), so only thirteen
+//                            second-order jets ever exist.  Needs Z to fourth order (ndot . f = v . grad (n . f)).
+//   t_kh_point_smooth_mixed  lane c: the mixed blocks (u, p), (f, p), (f, f), (p, f_dot), (p, v), (f, v), (v, v): GRADIENTS of
+//                            dL/du, dL/df, dL/df_dot, dL/dv — first-order jets (G3) over a frame one order lower (Z to third order).
+// (Measured in round 1: staging the single task over (point, bump) / point / (point, block) lanes through the dead jac area ran no
+//  faster — the arithmetic of the frame was the long pole, not the assembly; what changed here is the arithmetic itself.)
+template <class Em> HD void t_kh_point_smooth_pp(KHCtx<Em>& h, int c) {
     Ctx<Em>& cx = h.cx;
     if (terrain_is_planar(cx)) return;
     auto& s = cx.s;
@@ -289,6 +295,7 @@ template <class Em> HD void t_kh_point_smooth(KHCtx<Em>& h, int c) {
     const double* lam = h.lam;
     const int gb = gs::PT_STRIDE * c, hb = hk::SP + hk::SP_STRIDE * c, cb = PT_ * c;
     const double* x = s.x + cb;
+    const double* p = x + P_;
     const double* f = x + F_;
     const double* v = x + V_;
     const double* fd = x + FD_;
@@ -297,56 +304,116 @@ template <class Em> HD void t_kh_point_smooth(KHCtx<Em>& h, int c) {
     const double l_d = lam[gb + gs::DCC], l_h = lam[gb + gs::HEIGHT], l_n = lam[gb + gs::NORMAL], l_f = lam[gb + gs::FRICTION];
     const double* lp = lam + gb + gs::PLANAR;
     const double kbs = cx.gp.kbs, kt = cx.gp.kt, mu2 = cx.gp.mu * cx.gp.mu;
-    TerrainFrameT3 tf;
-    terrain_frame_t3(cx.st, x + P_, tf);
-    const double tv = tanh(kt * tf.h.v), t1 = kt * (1.0 - tv * tv), t2 = -2.0 * kt * tv * t1;
-    const T3 tau = t3_chain(tf.h, tv, t1, t2);
-    // coefficients of u
-    T3 Cu[3];
-    Cu[0] = (tf.xv[0] * lp[0] + tf.xv[1] * lp[1] + tf.xv[2] * lp[2]) * tau * -1.0;
-    Cu[1] = (tf.yv[0] * lp[0] + tf.yv[1] * lp[1] + tf.yv[2] * lp[2]) * tau * -1.0;
-    Cu[2] = (tf.n[0] * lp[0] + tf.n[1] * lp[1] + tf.n[2] * lp[2]) * -1.0;
-    const T3 nf = tf.n[0] * f[0] + tf.n[1] * f[1] + tf.n[2] * f[2];
-    const T3 xf = tf.xv[0] * f[0] + tf.xv[1] * f[1] + tf.xv[2] * f[2], yf = tf.yv[0] * f[0] + tf.yv[1] * f[1] + tf.yv[2] * f[2];
-    const T3 xvv = tf.xv[0] * v[0] + tf.xv[1] * v[1] + tf.xv[2] * v[2], yvv = tf.yv[0] * v[0] + tf.yv[1] * v[1] + tf.yv[2] * v[2];
-    const T3 nfd = tf.n[0] * fd[0] + tf.n[1] * fd[1] + tf.n[2] * fd[2];
-    const T3 hdot = tf.gh[0] * v[0] + tf.gh[1] * v[1] + tf.gh[2] * v[2];
-    T3 nd[3];   // ndot_j = sum_i dn_j/dp_i v_i
-    for (int j = 0; j < 3; ++j) nd[j] = tf.dn[j][0] * v[0] + tf.dn[j][1] * v[1];
-    const T3 fnd = nd[0] * f[0] + nd[1] * f[1] + nd[2] * f[2];
-    T3 dh = tf.h;
-    dh.v -= s.pk[PK_REF + R_SWING];
-    const T3 L = Cu[0] * u[0] + Cu[1] * u[1] + Cu[2] * u[2]
-               + (tf.h * nf * kbs + hdot * nf + tf.h * fnd + tf.h * nfd) * (-l_d)
-               + tf.h * l_h + nf * l_n + (nf * nf * mu2 - xf * xf - yf * yf) * l_f
-               + (dh * dh + xvv * xvv + yvv * yvv) * (0.5 * msw);
+    // L is ACCUMULATED term by term: every contraction leaves the two-variable jets as a second-order jet (six numbers instead of ten;
+    // only n . f is needed to third order, for its gradient), goes into L at once and is dropped — at no point do more than L, h,
+    // tau and the five frame jets (n_0, n_1, n_2, q, iq) live together.
+    T3 L;
+    {
+        const J2<4> Z = terrain_Z_j<4>(cx.st, p[0], p[1]);
+        const J2<3> u1 = -j2_dx(Z), u2 = -j2_dy(Z);   // grad h = (u1, u2, 1)
+        T3 hT = t3_from(-j2_trunc<4, 2>(Z));
+        hT.v += p[2]; hT.g[2] = 1.0;
+        T3 hdot = t3_from(u1 * v[0] + u2 * v[1]);
+        hdot.v += v[2];
+        const double tv = tanh(kt * hT.v), t1 = kt * (1.0 - tv * tv), t2 = -2.0 * kt * tv * t1;
+        const T3 tau = t3_chain(hT, tv, t1, t2);
+        T3 dh = hT;
+        dh.v -= s.pk[PK_REF + R_SWING];
+        L = hT * l_h + (dh * dh) * (0.5 * msw);
+        const J2<3> n2 = j2_pow(J2<3>(1.0) + u1 * u1 + u2 * u2, -0.5);
+        const J2<3> n0 = u1 * n2, n1 = u2 * n2;
+        {
+            const J2<3> nf = n0 * f[0] + n1 * f[1] + n2 * f[2];
+            const T3 nfT = t3_from(nf);
+            const T3 fnd = t3_from(j2_dx(nf) * v[0] + j2_dy(nf) * v[1]);   // (dn/dp v) . f = v . grad (n . f)
+            const T3 nfdT = t3_from(n0 * fd[0] + n1 * fd[1] + n2 * fd[2]);
+            L = L + (hT * (nfT * kbs + fnd + nfdT) + hdot * nfT) * (-l_d) + nfT * l_n + (nfT * nfT) * (mu2 * l_f);
+        }
+        L = L + t3_from(n0 * lp[0] + n1 * lp[1] + n2 * lp[2]) * (-u[2]);
+        const J2<3> q = n1 * n1 + n2 * n2;            // same closed form as terrain_frame (knot_body.h)
+        const J2<3> iq = j2_pow(q, -0.5);
+        // x . c = iq (q c_0 - n_0 (n_1 c_1 + n_2 c_2)),   y . c = iq (n_2 c_1 - n_1 c_2)
+        { const T3 xfT = t3_from(iq * (q * f[0] - n0 * (n1 * f[1] + n2 * f[2]))); L = L - (xfT * xfT) * l_f; }
+        { const T3 yfT = t3_from(iq * (n2 * f[1] - n1 * f[2])); L = L - (yfT * yfT) * l_f; }
+        { const T3 xvT = t3_from(iq * (q * v[0] - n0 * (n1 * v[1] + n2 * v[2]))); L = L + (xvT * xvT) * (0.5 * msw); }
+        { const T3 yvT = t3_from(iq * (n2 * v[1] - n1 * v[2])); L = L + (yvT * yvT) * (0.5 * msw); }
+        { const T3 xlpT = t3_from(iq * (q * lp[0] - n0 * (n1 * lp[1] + n2 * lp[2]))); L = L + (xlpT * tau) * (-u[0]); }
+        { const T3 ylpT = t3_from(iq * (n2 * lp[1] - n1 * lp[2])); L = L + (ylpT * tau) * (-u[1]); }
+    }
     bool ys;
     for (int a = 0; a < 3; ++a)
         for (int b = 0; b <= a; ++b)
             em.H(hb + hk::SP_PP + tri(a, b), cb + P_ + a, cb + P_ + b, L.H[t3h(a, b)] + pp_costs(h, c, c, a, b, ys) + (a == b ? ends_diag(h, cb + P_ + a) : 0.0));
+}
+template <class Em> HD void t_kh_point_smooth_mixed(KHCtx<Em>& h, int c) {
+    Ctx<Em>& cx = h.cx;
+    if (terrain_is_planar(cx)) return;
+    auto& s = cx.s;
+    Em& em = cx.em;
+    const double* lam = h.lam;
+    const int gb = gs::PT_STRIDE * c, hb = hk::SP + hk::SP_STRIDE * c, cb = PT_ * c;
+    const double* x = s.x + cb;
+    const double* p = x + P_;
+    const double* f = x + F_;
+    const double* v = x + V_;
+    const double on = cx.ki.first ? 0.0 : 1.0, msw = h.hx.sigma * on * cx.st.m_swing;
+    const double l_d = lam[gb + gs::DCC], l_n = lam[gb + gs::NORMAL], l_f = lam[gb + gs::FRICTION];
+    const double* lp = lam + gb + gs::PLANAR;
+    const double kbs = cx.gp.kbs, kt = cx.gp.kt, mu2 = cx.gp.mu * cx.gp.mu;
+    G3 hG, gh[3], n[3], xv[3], yv[3], dn[3][2];
+    {
+        const J2<3> Z = terrain_Z_j<3>(cx.st, p[0], p[1]);
+        const J2<2> u1 = -j2_dx(Z), u2 = -j2_dy(Z);
+        hG.v = p[2] - Z.c[0]; hG.g[0] = u1.c[0]; hG.g[1] = u2.c[0]; hG.g[2] = 1.0;
+        gh[0] = g3_from(u1); gh[1] = g3_from(u2); gh[2] = G3(1.0);
+        const J2<2> n2 = j2_pow(J2<2>(1.0) + u1 * u1 + u2 * u2, -0.5);
+        const J2<2> n0 = u1 * n2, n1 = u2 * n2;
+        n[0] = g3_from(n0); n[1] = g3_from(n1); n[2] = g3_from(n2);
+        dn[0][0] = g3_from(j2_dx(n0)); dn[0][1] = g3_from(j2_dy(n0));
+        dn[1][0] = g3_from(j2_dx(n1)); dn[1][1] = g3_from(j2_dy(n1));
+        dn[2][0] = g3_from(j2_dx(n2)); dn[2][1] = g3_from(j2_dy(n2));
+        // the tangent axes are needed to first order only
+        const J2<1> m0 = j2_trunc<2, 1>(n0), m1 = j2_trunc<2, 1>(n1), m2 = j2_trunc<2, 1>(n2);
+        const J2<1> q = m1 * m1 + m2 * m2;
+        const J2<1> iq = j2_pow(q, -0.5);
+        xv[0] = g3_from(q * iq); xv[1] = g3_from(-(m1 * m0) * iq); xv[2] = g3_from(-(m2 * m0) * iq);
+        yv[0] = G3(0.0); yv[1] = g3_from(m2 * iq); yv[2] = g3_from(-(m1 * iq));
+    }
+    const double tv = tanh(kt * hG.v), t1 = kt * (1.0 - tv * tv);
+    G3 tau;
+    tau.v = tv;
+    for (int i = 0; i < 3; ++i) tau.g[i] = t1 * hG.g[i];
+    const G3 nf = n[0] * f[0] + n[1] * f[1] + n[2] * f[2];
+    const G3 xf = xv[0] * f[0] + xv[1] * f[1] + xv[2] * f[2], yf = yv[1] * f[1] + yv[2] * f[2];
+    const G3 xvv = xv[0] * v[0] + xv[1] * v[1] + xv[2] * v[2], yvv = yv[1] * v[1] + yv[2] * v[2];
+    const G3 hdot = gh[0] * v[0] + gh[1] * v[1] + gh[2] * v[2];
     double nu[3];
     hdyn_multiplier(h, nu);
     const double dff = freg_diag(h, c);
     for (int j = 0; j < 3; ++j) {
-        for (int i = 0; i < 3; ++i) em.H(hb + hk::SP_UP + 3 * j + i, cb + U_ + j, cb + P_ + i, Cu[j].g[i]);
-        const T3 dLdf = (tf.h * tf.n[j] * kbs + hdot * tf.n[j] + tf.h * nd[j]) * (-l_d) + tf.n[j] * l_n + (nf * tf.n[j] * mu2 - xf * tf.xv[j] - yf * tf.yv[j]) * (2.0 * l_f);
+        // coefficient of u_j in L: C_u,j
+        const G3 Cu = j == 0 ? (xv[0] * lp[0] + xv[1] * lp[1] + xv[2] * lp[2]) * tau * -1.0
+                    : (j == 1 ? (yv[1] * lp[1] + yv[2] * lp[2]) * tau * -1.0 : (n[0] * lp[0] + n[1] * lp[1] + n[2] * lp[2]) * -1.0);
+        for (int i = 0; i < 3; ++i) em.H(hb + hk::SP_UP + 3 * j + i, cb + U_ + j, cb + P_ + i, Cu.g[i]);
+        const G3 nd = dn[j][0] * v[0] + dn[j][1] * v[1];   // ndot_j = sum_i dn_j/dp_i v_i
+        const G3 dLdf = (hG * n[j] * kbs + hdot * n[j] + hG * nd) * (-l_d) + n[j] * l_n + (nf * n[j] * mu2 - xf * xv[j] - yf * yv[j]) * (2.0 * l_f);
         for (int i = 0; i < 3; ++i) em.H(hb + hk::SP_FP + 3 * j + i, cb + F_ + j, cb + P_ + i, dLdf.g[i] + skew_rc(nu, j, i));
         for (int i = 0; i <= j; ++i)
             em.H(hb + hk::SP_FF + tri(j, i), cb + F_ + j, cb + F_ + i,
-                 2.0 * l_f * (mu2 * tf.n[j].v * tf.n[i].v - tf.xv[j].v * tf.xv[i].v - tf.yv[j].v * tf.yv[i].v) + (i == j ? dff + ends_diag(h, cb + F_ + j) : 0.0));
-        const T3 dLdfd = tf.h * tf.n[j] * (-l_d);
+                 2.0 * l_f * (mu2 * n[j].v * n[i].v - xv[j].v * xv[i].v - yv[j].v * yv[i].v) + (i == j ? dff + ends_diag(h, cb + F_ + j) : 0.0));
+        const G3 dLdfd = hG * n[j] * (-l_d);
         for (int i = 0; i < 3; ++i) em.H(hb + hk::SP_PFD + 3 * i + j, cb + P_ + i, cb + FD_ + j, dLdfd.g[i]);
     }
     for (int i = 0; i < 3; ++i) {
         // dL/dv_i = l_d (-gh_i nf - h sum_j dn_j/dp_i f_j) + m_sw ((x.v) x_i + (y.v) y_i)
-        T3 dnf = T3(0.0);
-        if (i < 2) dnf = tf.dn[0][i] * f[0] + tf.dn[1][i] * f[1] + tf.dn[2][i] * f[2];
-        const T3 dLdv = (tf.gh[i] * nf + tf.h * dnf) * (-l_d) + (xvv * tf.xv[i] + yvv * tf.yv[i]) * msw;
+        G3 dnf = G3(0.0);
+        if (i < 2) dnf = dn[0][i] * f[0] + dn[1][i] * f[1] + dn[2][i] * f[2];
+        const G3 dLdv = (gh[i] * nf + hG * dnf) * (-l_d) + (xvv * xv[i] + yvv * yv[i]) * msw;
         for (int j = 0; j < 3; ++j) em.H(hb + hk::SP_PV + 3 * j + i, cb + P_ + j, cb + V_ + i, dLdv.g[j]);
         for (int j = 0; j < 3; ++j)
-            em.H(hb + hk::SP_FV + 3 * j + i, cb + F_ + j, cb + V_ + i, -l_d * (tf.gh[i].v * tf.n[j].v + tf.h.v * (i < 2 ? tf.dn[j][i].v : 0.0)));
+            em.H(hb + hk::SP_FV + 3 * j + i, cb + F_ + j, cb + V_ + i, -l_d * (gh[i].v * n[j].v + hG.v * (i < 2 ? dn[j][i].v : 0.0)));
         for (int j = 0; j <= i; ++j)
-            em.H(hb + hk::SP_VV + tri(i, j), cb + V_ + i, cb + V_ + j, msw * (tf.xv[i].v * tf.xv[j].v + tf.yv[i].v * tf.yv[j].v) + (i == j ? ends_diag(h, cb + V_ + i) : 0.0));
+            em.H(hb + hk::SP_VV + tri(i, j), cb + V_ + i, cb + V_ + j, msw * (xv[i].v * xv[j].v + yv[i].v * yv[j].v) + (i == j ? ends_diag(h, cb + V_ + i) : 0.0));
     }
 }
 
@@ -784,7 +851,7 @@ template <class Em> HD void t_kh_ssd_far_b(KHCtx<Em>& h, int t) { t_kh_ssd_far(h
     RH(1, t_kh_diag, 42) RH(1, t_kh_percouple, 84) RH(2, t_kh_point, NC) RH(2, t_kh_ff, 36) RH(3, t_kh_pp, 180)  \
     BARRIER                                                                                                      \
     KIN(0, t_fk_rot_a, FK_TASKS_A) KIN(0, t_link_u_a, FK_SPLIT) KIN(3, t_fk_rot_b, FK_TASKS_B) KIN(3, t_link_u_b, NJ - FK_SPLIT) \
-    RH(2, t_kh_point_smooth, NC)                                                                                 \
+    RH(2, t_kh_point_smooth_pp, NC) RH(1, t_kh_point_smooth_mixed, NC)                                           \
     BARRIER                                                                                                      \
     KIN(0, t_links, NL) KIN(1, t_frames, 3) KIN(2, t_link_inertia, NL)                                           \
     BARRIER                                                                                                      \

@@ -7,8 +7,9 @@
 //          (product = truncated polynomial product; composition with an analytic g by Horner on its Taylor coefficients);
 //          Z as J2<4>, the terrain frame (n, x, y) and grad h as J2<3>, dn/dp as J2<2> by differentiation;
 //   T3     a function of (p_x, p_y, p_z) to second order (value, gradient, Hessian), in which the Lagrangian of the point is
-//          assembled with f, v, f_dot, u_v as constants: its Hessian is the (p, p) block, the gradients of dL/df, dL/dv, ... are
-//          the mixed blocks.
+//          assembled with f, v, f_dot, u_v as constants: its Hessian is the (p, p) block (t_kh_point_smooth_pp);
+//   G3     value and gradient in (p_x, p_y, p_z): the mixed blocks are the gradients of dL/df, dL/dv, ... and need the terrain one
+//          order lower (Z as J2<3>, the frame as J2<2>; t_kh_point_smooth_mixed).
 #pragma once
 #include "knot_body.h"
 
@@ -94,20 +95,20 @@ template <int K> HD J2<K - 1> j2_dy(const J2<K>& a) {
 }
 template <int K, int L> HD J2<L> j2_trunc(const J2<K>& a) { J2<L> r; for (int i = 0; i < J2<L>::NC_; ++i) r.c[i] = a.c[i]; return r; }
 
-// Z(p_x, p_y) of the terrain as a fourth-order jet (same guard against underflow as terrain_bump_jet)
-HD J2<4> terrain_Z_j4(const KSettings& st, double px, double py) {
-    J2<4> Z;
+// Z(p_x, p_y) of the terrain as a jet of order K (same guard against underflow as terrain_bump_jet)
+template <int K> HD J2<K> terrain_Z_j(const KSettings& st, double px, double py) {
+    J2<K> Z;
     for (int sidx = 0; sidx < st.n_steps; ++sidx) {
         const TerrainStepK& t = st.steps[sidx];
         Z.c[0] += t.oz;
         const double dx = px - t.ox, dy = py - t.oy;
         // the footprint coordinates a, b are LINEAR in (p_x, p_y): their powers in closed form
-        const J2<4> g = j2_linpow<4>(t.ax * dx + t.ay * dy, t.ax, t.ay, t.m) + j2_linpow<4>(t.bx * dx + t.by * dy, t.bx, t.by, t.m);
-        const J2<4> w = j2_ipow(g, t.r);
+        const J2<K> g = j2_linpow<K>(t.ax * dx + t.ay * dy, t.ax, t.ay, t.m) + j2_linpow<K>(t.bx * dx + t.by * dy, t.bx, t.by, t.m);
+        const J2<K> w = j2_ipow(g, t.r);
         if (!(w.c[0] < 700.0)) continue;
-        double gn[5];
-        const double e = t.height * exp(-w.c[0]);
-        gn[0] = e; gn[1] = -e; gn[2] = e / 2.0; gn[3] = -e / 6.0; gn[4] = e / 24.0;   // H exp(-w) in powers of (w - w_0)
+        double gn[K + 1];   // H exp(-w) in powers of (w - w_0): H e^{-w_0} (-1)^n / n!
+        gn[0] = t.height * exp(-w.c[0]);
+        for (int n = 1; n <= K; ++n) gn[n] = -gn[n - 1] / double(n);
         Z = Z + j2_compose(w, gn);
     }
     return Z;
@@ -145,27 +146,20 @@ template <int K> HD T3 t3_from(const J2<K>& a) {   // a function of (p_x, p_y) o
     return r;
 }
 
-// terrain frame at (p_x, p_y) with everything the point rows differentiate (terrain_descriptor.py:45-80)
-struct TerrainFrameT3 {
-    T3 h, gh[3], n[3], xv[3], yv[3];
-    T3 dn[3][2];   // d n_j / d p_i, i = x, y  (n does not depend on p_z)
+// ---- first order in three variables (p_x, p_y, p_z): value and gradient --------------------------------------------------------------
+struct G3 {
+    double v, g[3];
+    HD G3() : v(0.0) { g[0] = g[1] = g[2] = 0.0; }
+    HD explicit G3(double c) : v(c) { g[0] = g[1] = g[2] = 0.0; }
 };
-HD void terrain_frame_t3(const KSettings& st, const double* p, TerrainFrameT3& t) {
-    const J2<4> Z = terrain_Z_j4(st, p[0], p[1]);
-    const J2<3> u1 = -j2_dx(Z), u2 = -j2_dy(Z);   // grad h = (u1, u2, 1)
-    const J2<3> inn = j2_pow(J2<3>(1.0) + u1 * u1 + u2 * u2, -0.5);
-    const J2<3> n0 = u1 * inn, n1 = u2 * inn, n2 = inn;
-    const J2<3> q = n1 * n1 + n2 * n2;            // same closed form as terrain_frame (knot_body.h)
-    const J2<3> iq = j2_pow(q, -0.5);
-    t.h = t3_from(-j2_trunc<4, 2>(Z));
-    t.h.v += p[2]; t.h.g[2] = 1.0;
-    t.gh[0] = t3_from(u1); t.gh[1] = t3_from(u2); t.gh[2] = T3(1.0);
-    t.n[0] = t3_from(n0); t.n[1] = t3_from(n1); t.n[2] = t3_from(n2);
-    t.xv[0] = t3_from(q * iq); t.xv[1] = t3_from(-(n1 * n0) * iq); t.xv[2] = t3_from(-(n2 * n0) * iq);
-    t.yv[0] = T3(0.0); t.yv[1] = t3_from(n2 * iq); t.yv[2] = t3_from(-(n1 * iq));
-    t.dn[0][0] = t3_from(j2_dx(n0)); t.dn[0][1] = t3_from(j2_dy(n0));
-    t.dn[1][0] = t3_from(j2_dx(n1)); t.dn[1][1] = t3_from(j2_dy(n1));
-    t.dn[2][0] = t3_from(j2_dx(n2)); t.dn[2][1] = t3_from(j2_dy(n2));
+HD G3 operator+(const G3& a, const G3& b) { G3 r; r.v = a.v + b.v; for (int i = 0; i < 3; ++i) r.g[i] = a.g[i] + b.g[i]; return r; }
+HD G3 operator-(const G3& a, const G3& b) { G3 r; r.v = a.v - b.v; for (int i = 0; i < 3; ++i) r.g[i] = a.g[i] - b.g[i]; return r; }
+HD G3 operator*(const G3& a, double s) { G3 r; r.v = a.v * s; for (int i = 0; i < 3; ++i) r.g[i] = a.g[i] * s; return r; }
+HD G3 operator*(const G3& a, const G3& b) { G3 r; r.v = a.v * b.v; for (int i = 0; i < 3; ++i) r.g[i] = a.g[i] * b.v + a.v * b.g[i]; return r; }
+template <int K> HD G3 g3_from(const J2<K>& a) {   // a function of (p_x, p_y) only
+    G3 r;
+    r.v = a.c[0]; r.g[0] = a.c[J2<K>::idx(1, 0)]; r.g[1] = a.c[J2<K>::idx(0, 1)];
+    return r;
 }
 
 }  // namespace hipnlp
