@@ -69,7 +69,7 @@ struct KArgs {
 #endif
 };
 
-// The planar callback kernel runs on the COMPACT scratch (knot_body.h, KnotScratchT<true>: <= 40 KB of LDS per workgroup with the
+// The planar callback kernel runs on the COMPACT scratch (knot_body.h, KnotScratchT<LAYOUT_COMPACT / LAYOUT_COMPACT_TERRAIN>: <= 40 KB of LDS per workgroup with the
 // lite tables below: four workgroups per CU); the smooth-terrain kernel keeps the full layout (its terrain staging lives in own[] /
 // comp[] during phases A - B, where the compact layout parks the joint records and the joint frames).
 // Only the four-wave (throughput) variant: the eight-wave latency variant has one workgroup per CU whatever its LDS, and its duration
@@ -77,8 +77,9 @@ struct KArgs {
 // 10.0 -> 10.9 us per 100-knot launch).
 template <int TERRAIN, int WAVES = 4> struct DevEm {
     static constexpr int kTerrain = TERRAIN;
-    static constexpr bool kCompact = TERRAIN == HIPNLP_TERRAIN_PLANAR && WAVES == 4;
-    using Scratch = KnotScratchT<kCompact>;
+    static constexpr int kLayout = WAVES != 4 ? LAYOUT_FULL : (TERRAIN == HIPNLP_TERRAIN_PLANAR ? LAYOUT_COMPACT : LAYOUT_COMPACT_TERRAIN);
+    static constexpr bool kCompact = kLayout != LAYOUT_FULL;
+    using Scratch = KnotScratchT<kLayout>;
     double* g;
     double* jac;
     __device__ __forceinline__ void G(int slot, int, double v) { g[slot] = v; }   // (horizon-end rows go through emit_g_end)
@@ -107,10 +108,9 @@ static_assert(sizeof(KSettings) % 8 == 0 && sizeof(KinLite) % 8 == 0 && sizeof(G
 //            (<= 168 VGPRs).  The throughput variant.
 // WAVES = 8: 512 threads, the roles of the knot program spread over twice the waves (two per SIMD).  The latency variant, used
 //            when the launch has at most one workgroup per CU anyway (knots x batch <= 256), e.g. one 100-knot trajectory.
-// Four workgroups per CU for the planar four-wave kernel (compact scratch + lite tables: <= 40 KB of LDS, <= 128 VGPRs); three for
-// the smooth-terrain one (52 KB).
+// Four workgroups per CU for the four-wave kernels (compact scratch + lite tables: <= 40 KB of LDS, <= 128 VGPRs).
 template <int TERRAIN, int WAVES> __global__ __launch_bounds__(64 * WAVES)
-__attribute__((amdgpu_waves_per_eu(WAVES == 4 ? (DevEm<TERRAIN, WAVES>::kCompact ? 4 : 3) : 2, WAVES == 4 ? (DevEm<TERRAIN, WAVES>::kCompact ? 4 : 3) : 2)))
+__attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 4 : 2, WAVES == 4 ? 4 : 2)))
 void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const double* pk_p, const GParams* gp_p, int N_p, int n_p, int kb_p, KArgs a) {
     // the leading scalar arguments repeat what the staging loads need: the build preloads them into SGPRs
     // (-mllvm -amdgpu-kernarg-preload-count), so the first global loads do not wait for a kernarg fetch
@@ -149,7 +149,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         constexpr int W0 = COMPACT ? int(sizeof(KSettings) / 8) : int(sizeof(HeadTables) / 8);
         constexpr int W1 = COMPACT ? int(sizeof(KinLite) / 8) : 0;
         constexpr int W2 = COMPACT ? int(sizeof(GParamsLite) / 8) : int(sizeof(GParams) / 8);
-        constexpr int W3 = COMPACT ? JFIX_DOUBLES : 0;
+        constexpr int W3 = Scratch::tables_in_comp ? JFIX_DOUBLES : 0;
         constexpr int I0 = (W0 + WG - 1) / WG, I1 = (W1 + WG - 1) / WG, I2 = (W2 + WG - 1) / WG, I3 = (W3 + WG - 1) / WG;
         const double* src0 = COMPACT ? reinterpret_cast<const double*>(&tb.head.ks) : reinterpret_cast<const double*>(&tb.head);
         const double* src1 = reinterpret_cast<const double*>(static_cast<const KinLite*>(&tb.head.kt));
@@ -324,7 +324,8 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 
     KnotInfo ki{k, N, first, last};
     DevEm<TERRAIN, WAVES> em{s.g, s.jac};
-    Ctx<DevEm<TERRAIN, WAVES>> cx(s, tabs.kin(), tabs.settings(), tabs.gp, ki, em, &tb.head.kt, gp_p + b);
+    // (the full tables: global memory for the compact layouts; the full layout's LDS copy otherwise — the constructor's default)
+    Ctx<DevEm<TERRAIN, WAVES>> cx(s, tabs.kin(), tabs.settings(), tabs.gp, ki, em, COMPACT ? &tb.head.kt : nullptr, COMPACT ? gp_p + b : nullptr);
     // The program is instantiated ONCE PER WAVE (a generic lambda over the wave number as a compile-time constant: a task group is
     // compiled into the one instance whose wave runs it) and dispatched by one switch, so that every wave executes a CONTIGUOUS
     // instruction stream from the first phase to the last.  Written as `if (wave == w) { ... }` blocks phase after phase, every

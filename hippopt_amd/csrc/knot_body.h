@@ -64,17 +64,21 @@ static_assert(sizeof(JointRec) == 128, "joint record");
 enum : int { JR_L = 0, JR_OF = 9, JR_C = 12, JR_SD = 15 };
 HD constexpr int jr_pos(int i, int e) { return ((((e >> 1) ^ (i & 7)) << 1) | (e & 1)); }   // physical position of logical double e of record i
 
-// Two layouts of the scratch:
-//   KnotScratchT<false>  every array has its own storage (host recorders / emulation, smooth-terrain and pose / Hessian kernels)
-//   KnotScratchT<true>   the COMPACT device layout of the planar callback kernel (four workgroups per CU need <= 40 KB of LDS per
-//                        workgroup): arrays whose lifetimes do not overlap share storage —
+// Three layouts of the scratch (LAYOUT_*):
+//   KnotScratchT<0>  every array has its own storage (host recorders / emulation, eight-wave and pose / Hessian kernels)
+//   KnotScratchT<1>  the COMPACT device layout of the planar four-wave callback kernel (four workgroups per CU need <= 40 KB of
+//   KnotScratchT<2>  LDS per workgroup) and of the smooth-terrain one: arrays whose lifetimes do not overlap share storage —
 //                          * own[] (written in phase C, read in phase D) lives on top of the joint records Jr[] (written in phase A,
 //                            dead once the forward kinematics of phase B has read them); own[NL] (the zero slot written in phase A)
 //                            lies behind the last joint record;
 //                          * the g rows of the horizon ends (final state, periodicity: first / last knot only, written in phase E)
 //                            live in EndTerms::c of the same union (the minimize-mode cost partials they exclude row by row);
-//                          * the joint frames (read in phase A only) and then the link inertials (read in phase C only) are parked in
-//                            comp[] (composites: written in phase D) instead of occupying LDS for the whole program: `tables_in_comp`.
+//                          * layout 1: the joint frames (read in phase A only) and then the link inertials (read in phase C only) are
+//                            parked in comp[] (composites: written in phase D) instead of occupying LDS for the whole program;
+//                          * layout 2 (smooth terrain): comp[] holds the bump jets and then, IN PLACE, the terrain frames of the eight
+//                            points during phases A - B (the full layout parks the frames in own[], which here lies on the joint
+//                            records); the joint frames and link inertials are read from global memory by the lanes that need them.
+constexpr int LAYOUT_FULL = 0, LAYOUT_COMPACT = 1, LAYOUT_COMPACT_TERRAIN = 2;
 template <bool COMPACT> struct ScratchJrOwn;
 template <> struct ScratchJrOwn<false> {
     JointRec Jr[NJ + 1];
@@ -94,8 +98,10 @@ template <> struct ScratchJrOwn<true> {
 };
 static_assert(sizeof(JointRec) * NJ <= sizeof(double) * LSTR * NL, "own[NL] (zero slot, written while Jr is live) must lie behind the joint records it shares storage with");
 
-template <bool COMPACT> struct alignas(16) KnotScratchT : ScratchJrOwn<COMPACT> {
-    static constexpr bool compact = COMPACT;
+template <int LAYOUT> struct alignas(16) KnotScratchT : ScratchJrOwn<LAYOUT != LAYOUT_FULL> {
+    static constexpr int layout = LAYOUT;
+    static constexpr bool compact = LAYOUT != LAYOUT_FULL;
+    static constexpr bool tables_in_comp = LAYOUT == LAYOUT_COMPACT;
     double x[XPAD];    // knot k
     double xm[XPAD];   // knot k-1 (zeros at k = 0)
     double xo[NPER];   // periodicity variables of the other end of the horizon, by periodicity row (only loaded at k = 0 and k = N-1)
@@ -128,11 +134,11 @@ template <bool COMPACT> struct alignas(16) KnotScratchT : ScratchJrOwn<COMPACT> 
     double jac[js::COUNT];
     // value of native g slot `slot` / where the emitter stores it
     HD double& g_at(int slot) {
-        if constexpr (COMPACT) return slot >= gs::FIN ? this->ends.c[slot - gs::FIN] : this->g[slot];
+        if constexpr (compact) return slot >= gs::FIN ? this->ends.c[slot - gs::FIN] : this->g[slot];
         else return this->g[slot];
     }
 };
-using KnotScratch = KnotScratchT<false>;
+using KnotScratch = KnotScratchT<LAYOUT_FULL>;
 static_assert(LINR_DOUBLES <= JFIX_DOUBLES && JFIX_DOUBLES <= NL * LSTR, "the parked tables must fit in comp[]");
 
 enum : int { CM = 0, CH = 1, CI = 4, CKL = 10, CKA = 13 };  // offsets inside KnotScratch::comp[i]
@@ -168,26 +174,27 @@ template <class Em> struct Ctx {
     }
 };
 
-// ---- tables that are read once per knot: from the scratch in the compact layout (parked in comp[], see KnotScratchT), else from kt --
+// ---- tables that are read once per knot: layout 1: parked in comp[] (see KnotScratchT); else from the full tables (gkt: the LDS copy in
+//      the full layout, global memory in layout 2)
 // joint frames of joint j: phase A only
 template <class Em> HD const double* kin_R_fix(const Ctx<Em>& cx, int j) {
-    if constexpr (Ctx<Em>::Scratch::compact) return &cx.s.comp[0][0] + 9 * j; else return cx.kt.jf.R_fix[j];
+    if constexpr (Ctx<Em>::Scratch::tables_in_comp) return &cx.s.comp[0][0] + 9 * j; else return cx.gkt->jf.R_fix[j];
 }
 template <class Em> HD const double* kin_o_fix(const Ctx<Em>& cx, int j) {
-    if constexpr (Ctx<Em>::Scratch::compact) return &cx.s.comp[0][0] + 9 * NJ + 3 * j; else return cx.kt.jf.o_fix[j];
+    if constexpr (Ctx<Em>::Scratch::tables_in_comp) return &cx.s.comp[0][0] + 9 * NJ + 3 * j; else return cx.gkt->jf.o_fix[j];
 }
 template <class Em> HD const double* kin_axis(const Ctx<Em>& cx, int j) {
-    if constexpr (Ctx<Em>::Scratch::compact) return &cx.s.comp[0][0] + 12 * NJ + 3 * j; else return cx.kt.jf.axis[j];
+    if constexpr (Ctx<Em>::Scratch::tables_in_comp) return &cx.s.comp[0][0] + 12 * NJ + 3 * j; else return cx.gkt->jf.axis[j];
 }
 // link inertials of link i: phase C only
 template <class Em> HD double kin_mass(const Ctx<Em>& cx, int i) {
-    if constexpr (Ctx<Em>::Scratch::compact) return (&cx.s.comp[0][0])[i]; else return cx.kt.li.mass[i];
+    if constexpr (Ctx<Em>::Scratch::tables_in_comp) return (&cx.s.comp[0][0])[i]; else return cx.gkt->li.mass[i];
 }
 template <class Em> HD const double* kin_com(const Ctx<Em>& cx, int i) {
-    if constexpr (Ctx<Em>::Scratch::compact) return &cx.s.comp[0][0] + NL + 3 * i; else return cx.kt.li.com[i];
+    if constexpr (Ctx<Em>::Scratch::tables_in_comp) return &cx.s.comp[0][0] + NL + 3 * i; else return cx.gkt->li.com[i];
 }
 template <class Em> HD const double* kin_inertia(const Ctx<Em>& cx, int i) {
-    if constexpr (Ctx<Em>::Scratch::compact) return &cx.s.comp[0][0] + 4 * NL + 9 * i; else return cx.kt.li.inertia[i];
+    if constexpr (Ctx<Em>::Scratch::tables_in_comp) return &cx.s.comp[0][0] + 4 * NL + 9 * i; else return cx.gkt->li.inertia[i];
 }
 // g rows of the horizon ends (native slots >= gs::FIN): compact layout -> ends.c (see KnotScratchT)
 template <class Em> HD void emit_g_end(Ctx<Em>& cx, int slot, int id, double v) {
@@ -472,8 +479,13 @@ template <class Em> HD void point_hnf_planar(Ctx<Em>& cx, int c) {
 //       the (not yet used) per-link area of the scratch;
 //   t_terrain_planar / _dcc / _hnf / _swing (phase B, lane c each, on different waves): the rows, their Jacobian entries, the swing cost.
 struct TerrainStage { TerrainFrame tf; double Zh[7]; };   // Zh = Z[3..9]: second and third derivatives (for udot)
-static_assert(sizeof(TerrainStage) * NC <= sizeof(double) * NL * LSTR, "terrain staging must fit in own[0..NL) (own[NL] is the zero slot)");
-template <class S> HD TerrainStage* terrain_stage(S& s, int c) { return reinterpret_cast<TerrainStage*>(&s.own[0][0]) + c; }
+static_assert(sizeof(TerrainStage) * NC <= sizeof(double) * NL * LSTR, "terrain staging must fit in own[0..NL) (own[NL] is the zero slot) / in comp[]");
+template <class S> HD TerrainStage* terrain_stage(S& s, int c) {
+    // compact layouts: own[] lies on the joint records, which are live while the terrain frames are: the frames take the place of the
+    // bump jets in comp[] (written IN PLACE by t_terrain_stage: every lane has read its jets before any lane stores its frame)
+    if constexpr (S::compact) return reinterpret_cast<TerrainStage*>(&s.comp[0][0]) + c;
+    else return reinterpret_cast<TerrainStage*>(&s.own[0][0]) + c;
+}
 
 // the jet of ONE bump at ONE point: lane (c, bump), NC x HIPNLP_MAX_TERRAIN_STEPS tasks; parked in the composite area (written only
 // three phases later).  (Splitting a bump's jet further over three lanes by derivative order, and the com height jet over bump
@@ -500,10 +512,26 @@ template <class Em> HD void t_terrain_stage(Ctx<Em>& cx, int c) {
     const double* p = s.x + PT_ * c + P_;
     double Z[10];
     for (int i = 0; i < 10; ++i) Z[i] = 0.0;
-    for (int sidx = 0; sidx < cx.st.n_steps; ++sidx) {   // same order as terrain_Z_jet
-        const double* part = terrain_bump_part(s, c, sidx);
-        for (int i = 0; i < 10; ++i) Z[i] += part[i];
-    }
+    auto sum_parts = [&](int cc, double* z) {
+        for (int sidx = 0; sidx < cx.st.n_steps; ++sidx) {   // same order as terrain_Z_jet
+            const double* part = terrain_bump_part(s, cc, sidx);
+            for (int i = 0; i < 10; ++i) z[i] += part[i];
+        }
+    };
+#if defined(__HIP_DEVICE_COMPILE__)
+    sum_parts(c, Z);
+#else
+    // Host (recorders, emulation): the lanes of a task run one after the other.  In the compact layouts the frame of point c
+    // overwrites bump jets of points c, c + 1 that the device's lanes have all read by then (one wave, lockstep): read them for
+    // every lane when the first lane runs, as the wave does.
+    if constexpr (std::remove_reference_t<decltype(s)>::compact) {
+        static thread_local double zall[NC][10];
+        if (c == 0)
+            for (int cc = 0; cc < NC; ++cc) { for (int i = 0; i < 10; ++i) zall[cc][i] = 0.0; sum_parts(cc, zall[cc]); }
+        for (int i = 0; i < 10; ++i) Z[i] = zall[c][i];
+    } else sum_parts(c, Z);
+#endif
+    HIPNLP_WAVE_SYNC();   // (compact layouts: the frames below overwrite the bump jets every lane of this wave has just read)
     TerrainStage* st = terrain_stage(s, c);
     terrain_frame(Z, p[2], st->tf);
     for (int i = 0; i < 7; ++i) st->Zh[i] = Z[3 + i];
@@ -926,7 +954,7 @@ template <class S, class K> HD void link_origin_velocity(const S& s, const K& kt
 // comp[] (free until the composites of phase D): 64 lanes copy them from global memory during phase B, where the wave has slack.
 constexpr int STAGE_TABLE_TASKS = 64;
 template <class Em> HD void t_stage_link_tables(Ctx<Em>& cx, int t) {
-    if constexpr (Ctx<Em>::Scratch::compact) {
+    if constexpr (Ctx<Em>::Scratch::tables_in_comp) {
         const double* src = reinterpret_cast<const double*>(&cx.gkt->li);
         double* dst = &cx.s.comp[0][0];
         constexpr int ITERS = (LINR_DOUBLES + STAGE_TABLE_TASKS - 1) / STAGE_TABLE_TASKS;

@@ -51,7 +51,7 @@ struct GParams : GParamsLite {
 // ---- kinematic tree tables (device copy of hipnlp_robot_model + derived topology) ----------------
 // KinLite: the tables every phase indexes per lane (LDS on the device).  KinTables adds the blocks that are read ONCE per knot
 // (joint frames: phase A only; link inertials: phase C only) or only by the first / last knot (horizon-end row tables): the compact
-// device layout does not keep those in LDS for the whole program (knot_body.h, KnotScratchT<true>).
+// device layout does not keep those in LDS for the whole program (knot_body.h, KnotScratchT<LAYOUT_COMPACT>).
 struct KinLite {
     int32_t leg_pos[2][NJ];     // position of joint j in the root->sole path (0..5) or -1
     int32_t leg_joint[2][LEG_PATH];

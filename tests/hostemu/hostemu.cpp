@@ -22,12 +22,12 @@ struct ValueEm {
     void H(int slot, int, int, double v) { hess[slot] = v; }
 };
 
-// the COMPACT device layout of the planar callback kernel (KnotScratchT<true>: shared storage for arrays with disjoint lifetimes,
+// the COMPACT device layout of the planar callback kernel (KnotScratchT<LAYOUT_COMPACT*>: shared storage for arrays with disjoint lifetimes,
 // joint frames / link inertials parked in comp[], horizon-end g rows in ends.c): emulated phase by phase in program order, so a
 // lifetime overlap shows up as a wrong value here, without a GPU
-struct ValueEmC {
+template <int LAYOUT> struct ValueEmC {
     static constexpr int kTerrain = -1;
-    using Scratch = KnotScratchT<true>;
+    using Scratch = KnotScratchT<LAYOUT>;
     double* g;
     double* jac;
     void G(int slot, int, double v) { g[slot] = v; }
@@ -42,6 +42,53 @@ struct hostemu_handle {
     HessLayout HL;
     bool has_hess = false;
 };
+
+// the same evaluation on the compact scratch layouts of the device (LAYOUT_COMPACT: planar terrain; LAYOUT_COMPACT_TERRAIN: smooth)
+template <int LAYOUT> static int eval_compact(const hostemu_handle* h, const double* x, const double* p, double* f, double* grad, double* g, double* jac, double* cost_terms) {
+    const Layout& L = h->L;
+    const int N = L.N;
+    std::vector<double> pk(size_t(N) * PK_STRIDE);
+    GParams gp;
+    pack_params(p, N, pk.data(), gp);
+    for (int i = 0; i < NCT; ++i) cost_terms[i] = 0.0;
+    for (int i = 0; i < L.n; ++i) grad[i] = 0.0;
+    using S = KnotScratchT<LAYOUT>;
+    S* s = new S();
+    for (int k = 0; k < N; ++k) {
+        std::fill(reinterpret_cast<double*>(s), reinterpret_cast<double*>(s) + sizeof(S) / sizeof(double), std::nan(""));
+        for (int i = 0; i < XPAD; ++i) { s->x[i] = 0; s->xm[i] = 0; }
+        for (int i = 0; i < NPER; ++i) s->xo[i] = 0;
+        for (int i = 0; i < NXK; ++i) { s->x[i] = x[NXK * k + i]; s->xm[i] = k > 0 ? x[NXK * (k - 1) + i] : 0.0; }
+        for (int i = 0; i < NPER; ++i) s->xo[i] = k == 0 ? x[NXK * (N - 1) + periodicity_row_var(i)] : (k == N - 1 ? x[periodicity_row_var(i)] : 0.0);
+        for (int i = 0; i < NXG; ++i) s->xg[i] = x[NXK * N + i];
+        for (int i = 0; i < PK_STRIDE; ++i) s->pk[i] = pk[size_t(k) * PK_STRIDE + i];
+        if (S::tables_in_comp) {   // staging of the kernel: the joint frames parked in comp[]
+            const double* jf = reinterpret_cast<const double*>(&h->kt.jf);
+            for (int i = 0; i < JFIX_DOUBLES; ++i) (&s->comp[0][0])[i] = jf[i];
+        }
+        KnotInfo ki{k, N, k == 0, k == N - 1};
+        ValueEmC<LAYOUT> em{s->g, s->jac};
+        Ctx<ValueEmC<LAYOUT>> cx(*s, static_cast<const KinLite&>(h->kt), h->ks, static_cast<const GParamsLite&>(gp), ki, em, &h->kt, &gp);
+#define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
+        HIPNLP_KNOT_PROGRAM(HOST_R, )
+#undef HOST_R
+        const int v = L.variant_of(k);
+        const long jb = L.jac_base(k);
+        for (int i = 0; i < L.nnz_v[v]; ++i) jac[jb + i] = s->jac[L.jperm[v][size_t(i)]];
+        if (k == N - 1) for (size_t i = 0; i < L.jperm_glob.size(); ++i) jac[L.jac_glob_base + long(i)] = s->jac[L.jperm_glob[i]];
+        for (int slot = 0; slot < gs::COUNT; ++slot) {
+            const int a = L.g_a[v][size_t(slot)];
+            if (a >= 0) g[a + L.g_b[size_t(slot)] * k] = s->g_at(slot);
+        }
+        for (int i = 0; i < NXK; ++i) grad[NXK * k + i] = s->grad[i];
+        for (int i = 0; i < NCT; ++i) cost_terms[i] += s->cost[i];
+    }
+    delete s;
+    double ft = 0.0;
+    for (int i = 0; i < NCT; ++i) ft += cost_terms[i];
+    *f = ft;
+    return 0;
+}
 
 extern "C" {
 
@@ -167,51 +214,9 @@ void hostemu_eval(const hostemu_handle* h, const double* x, const double* p, dou
     *f = ft;
 }
 
-// the same evaluation on the compact scratch layout (planar terrain only, as on the device)
 int hostemu_eval_compact(const hostemu_handle* h, const double* x, const double* p, double* f, double* grad, double* g, double* jac, double* cost_terms) {
-    if (h->d.settings.terrain != HIPNLP_TERRAIN_PLANAR) return -1;
-    const Layout& L = h->L;
-    const int N = L.N;
-    std::vector<double> pk(size_t(N) * PK_STRIDE);
-    GParams gp;
-    pack_params(p, N, pk.data(), gp);
-    for (int i = 0; i < NCT; ++i) cost_terms[i] = 0.0;
-    for (int i = 0; i < L.n; ++i) grad[i] = 0.0;
-    using S = KnotScratchT<true>;
-    S* s = new S();
-    for (int k = 0; k < N; ++k) {
-        std::fill(reinterpret_cast<double*>(s), reinterpret_cast<double*>(s) + sizeof(S) / sizeof(double), std::nan(""));
-        for (int i = 0; i < XPAD; ++i) { s->x[i] = 0; s->xm[i] = 0; }
-        for (int i = 0; i < NPER; ++i) s->xo[i] = 0;
-        for (int i = 0; i < NXK; ++i) { s->x[i] = x[NXK * k + i]; s->xm[i] = k > 0 ? x[NXK * (k - 1) + i] : 0.0; }
-        for (int i = 0; i < NPER; ++i) s->xo[i] = k == 0 ? x[NXK * (N - 1) + periodicity_row_var(i)] : (k == N - 1 ? x[periodicity_row_var(i)] : 0.0);
-        for (int i = 0; i < NXG; ++i) s->xg[i] = x[NXK * N + i];
-        for (int i = 0; i < PK_STRIDE; ++i) s->pk[i] = pk[size_t(k) * PK_STRIDE + i];
-        // staging of the kernel: the joint frames parked in comp[]
-        const double* jf = reinterpret_cast<const double*>(&h->kt.jf);
-        for (int i = 0; i < JFIX_DOUBLES; ++i) (&s->comp[0][0])[i] = jf[i];
-        KnotInfo ki{k, N, k == 0, k == N - 1};
-        ValueEmC em{s->g, s->jac};
-        Ctx<ValueEmC> cx(*s, static_cast<const KinLite&>(h->kt), h->ks, static_cast<const GParamsLite&>(gp), ki, em, &h->kt, &gp);
-#define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
-        HIPNLP_KNOT_PROGRAM(HOST_R, )
-#undef HOST_R
-        const int v = L.variant_of(k);
-        const long jb = L.jac_base(k);
-        for (int i = 0; i < L.nnz_v[v]; ++i) jac[jb + i] = s->jac[L.jperm[v][size_t(i)]];
-        if (k == N - 1) for (size_t i = 0; i < L.jperm_glob.size(); ++i) jac[L.jac_glob_base + long(i)] = s->jac[L.jperm_glob[i]];
-        for (int slot = 0; slot < gs::COUNT; ++slot) {
-            const int a = L.g_a[v][size_t(slot)];
-            if (a >= 0) g[a + L.g_b[size_t(slot)] * k] = s->g_at(slot);
-        }
-        for (int i = 0; i < NXK; ++i) grad[NXK * k + i] = s->grad[i];
-        for (int i = 0; i < NCT; ++i) cost_terms[i] += s->cost[i];
-    }
-    delete s;
-    double ft = 0.0;
-    for (int i = 0; i < NCT; ++i) ft += cost_terms[i];
-    *f = ft;
-    return 0;
+    return h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR ? eval_compact<LAYOUT_COMPACT>(h, x, p, f, grad, g, jac, cost_terms)
+                                                          : eval_compact<LAYOUT_COMPACT_TERRAIN>(h, x, p, f, grad, g, jac, cost_terms);
 }
 
 // ---- static pose finder: the pose program of pose_body.h + the copy-out of hipnlp_pose_kernel -------------------------------

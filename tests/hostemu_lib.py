@@ -71,7 +71,7 @@ class HostEmu:
         fn = self.lib.hostemu_eval_compact if compact else self.lib.hostemu_eval
         rc = fn(C.c_void_p(self.h), _dp(np.ascontiguousarray(x)), _dp(np.ascontiguousarray(p)), C.byref(f), _dp(grad), _dp(g), _dp(jac), _dp(ct))
         if compact and rc != 0:
-            raise RuntimeError("the compact layout is the planar kernel's")
+            raise RuntimeError("hostemu_eval_compact failed")
         return f.value, grad, g, jac, ct
 
 

@@ -284,20 +284,22 @@ def test_hessian_body_matches_reference_planner_fixture(model, name):
     assert rel(hessian_times(ir, jc, vals, he.n, z["hess_dirs"]), z["hess_times_dirs"]) <= (1e-9 if "stairs" in name else TOL)
 
 
-@pytest.mark.parametrize("mode", ["subject_to", "minimize", "mixed", "single"])
+@pytest.mark.parametrize("mode", ["subject_to", "minimize", "mixed", "single", "stairs", "stairs-minimize"])
 def test_compact_scratch_layout_gives_the_same_values(model, mode):
     """The planar device kernel runs on a compact scratch (four workgroups per CU): own[] on top of the joint records, the horizon-end
     g rows inside the end-term partials, joint frames and link inertials parked in comp[].  Emulated in program order on the host:
     bitwise the values of the full layout, in every combination of the horizon-end expression types."""
     N = 5
-    st = single_step_settings(N, model) if mode == "single" else periodic_step_settings(N, model)
-    if mode == "minimize":
+    st = single_step_settings(N, model) if mode == "single" else (stairs_settings(N, model) if mode.startswith("stairs") else periodic_step_settings(N, model))
+    if mode in ("minimize", "stairs-minimize"):
         st.final_state_expression_type = st.periodicity_expression_type = _abi.EXPR_MINIMIZE
         st.final_state_expression_weight, st.periodicity_expression_weight = 2.0, 0.5
     if mode == "mixed":
         st.periodicity_expression_type = _abi.EXPR_MINIMIZE
         st.periodicity_expression_weight = 0.25
     x, p = make_workload(st, model, 1, 700)
+    if mode.startswith("stairs"):
+        place_on_step_flanks(x, st, seed=2)
     he = HostEmu(st, model)
     full = he.eval(x[0], p[0])
     comp = he.eval(x[0], p[0], compact=True)
