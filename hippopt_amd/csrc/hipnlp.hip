@@ -69,7 +69,7 @@ struct KArgs {
 #endif
 };
 
-// The planar callback kernel runs on the COMPACT scratch (knot_body.h, KnotScratchT<LAYOUT_COMPACT / LAYOUT_COMPACT_TERRAIN>: <= 40 KB of LDS per workgroup with the
+// The planar callback kernel runs on the COMPACT scratch (knot_body.h, KnotScratchT<LAYOUT_COMPACT>: <= 40 KB of LDS per workgroup with the
 // lite tables below: four workgroups per CU); the smooth-terrain kernel keeps the full layout (its terrain staging lives in own[] /
 // comp[] during phases A - B, where the compact layout parks the joint records and the joint frames).
 // Only the four-wave (throughput) variant: the eight-wave latency variant has one workgroup per CU whatever its LDS, and its duration
@@ -77,7 +77,7 @@ struct KArgs {
 // 10.0 -> 10.9 us per 100-knot launch).
 template <int TERRAIN, int WAVES = 4> struct DevEm {
     static constexpr int kTerrain = TERRAIN;
-    static constexpr int kLayout = WAVES != 4 ? LAYOUT_FULL : (TERRAIN == HIPNLP_TERRAIN_PLANAR ? LAYOUT_COMPACT : LAYOUT_COMPACT_TERRAIN);
+    static constexpr int kLayout = WAVES == 4 ? LAYOUT_COMPACT : LAYOUT_FULL;
     static constexpr bool kCompact = kLayout != LAYOUT_FULL;
     using Scratch = KnotScratchT<kLayout>;
     double* g;
@@ -140,8 +140,8 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     const DeviceTables& tb = *tb_p;
     // ---- stage the knot records and the tables in LDS.  Every global load is issued before the first LDS store waits for
     // one (compile-time trip counts): ONE memory round trip instead of one per loop iteration.
-    // Full layout: the whole HeadTables + GParams.  Compact layout: KSettings, the KinLite prefix of the kinematic tables, the
-    // GParamsLite prefix of the parameters, and the joint frames (read by phase A only) parked in comp[].
+    // Full layout: the whole HeadTables + GParams.  Compact layout: KSettings, the KinLite prefix of the kinematic tables and the
+    // GParamsLite prefix of the parameters.
     {
         constexpr int XV_ITERS = (XPAD + WG - 1) / WG;
         static_assert(PK_STRIDE <= WG && NXG <= 8, "one parameter word per thread");
@@ -149,13 +149,11 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         constexpr int W0 = COMPACT ? int(sizeof(KSettings) / 8) : int(sizeof(HeadTables) / 8);
         constexpr int W1 = COMPACT ? int(sizeof(KinLite) / 8) : 0;
         constexpr int W2 = COMPACT ? int(sizeof(GParamsLite) / 8) : int(sizeof(GParams) / 8);
-        constexpr int W3 = Scratch::tables_in_comp ? JFIX_DOUBLES : 0;
-        constexpr int I0 = (W0 + WG - 1) / WG, I1 = (W1 + WG - 1) / WG, I2 = (W2 + WG - 1) / WG, I3 = (W3 + WG - 1) / WG;
+        constexpr int I0 = (W0 + WG - 1) / WG, I1 = (W1 + WG - 1) / WG, I2 = (W2 + WG - 1) / WG;
         const double* src0 = COMPACT ? reinterpret_cast<const double*>(&tb.head.ks) : reinterpret_cast<const double*>(&tb.head);
         const double* src1 = reinterpret_cast<const double*>(static_cast<const KinLite*>(&tb.head.kt));
         const double* src2 = reinterpret_cast<const double*>(gp_p + b);
-        const double* src3 = reinterpret_cast<const double*>(&tb.head.kt.jf);
-        double v0[I0 > 0 ? I0 : 1], v1[I1 > 0 ? I1 : 1], v2[I2 > 0 ? I2 : 1], v3[I3 > 0 ? I3 : 1];
+        double v0[I0 > 0 ? I0 : 1], v1[I1 > 0 ? I1 : 1], v2[I2 > 0 ? I2 : 1];
         double xv[XV_ITERS], xmv[XV_ITERS], xov[XV_ITERS];
 #pragma unroll
         for (int it = 0; it < I0; ++it) { const int i = tid + it * WG; v0[it] = i < W0 ? src0[i] : 0.0; }
@@ -163,8 +161,6 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         for (int it = 0; it < I1; ++it) { const int i = tid + it * WG; v1[it] = i < W1 ? src1[i] : 0.0; }
 #pragma unroll
         for (int it = 0; it < I2; ++it) { const int i = tid + it * WG; v2[it] = i < W2 ? src2[i] : 0.0; }
-#pragma unroll
-        for (int it = 0; it < I3; ++it) { const int i = tid + it * WG; v3[it] = i < W3 ? src3[i] : 0.0; }
 #pragma unroll
         for (int it = 0; it < XV_ITERS; ++it) {
             const int i = tid + it * WG;
@@ -180,10 +176,10 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         st_loaded = __builtin_amdgcn_s_memtime();
 #endif
-        double *dst0, *dst1 = nullptr, *dst2, *dst3 = nullptr;
+        double *dst0, *dst1 = nullptr, *dst2;
         if constexpr (COMPACT) {
             dst0 = reinterpret_cast<double*>(&tabs.ks); dst1 = reinterpret_cast<double*>(&tabs.kt);
-            dst2 = reinterpret_cast<double*>(&tabs.gp); dst3 = &s.comp[0][0];
+            dst2 = reinterpret_cast<double*>(&tabs.gp);
         } else {
             dst0 = reinterpret_cast<double*>(&tabs.head); dst2 = reinterpret_cast<double*>(&tabs.gp);
         }
@@ -193,8 +189,6 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         for (int it = 0; it < I1; ++it) { const int i = tid + it * WG; if (i < W1) dst1[i] = v1[it]; }
 #pragma unroll
         for (int it = 0; it < I2; ++it) { const int i = tid + it * WG; if (i < W2) dst2[i] = v2[it]; }
-#pragma unroll
-        for (int it = 0; it < I3; ++it) { const int i = tid + it * WG; if (i < W3) dst3[i] = v3[it]; }
 #pragma unroll
         for (int it = 0; it < XV_ITERS; ++it) { const int i = tid + it * WG; if (i < XPAD) { s.x[i] = xv[it]; s.xm[i] = xmv[it]; } if (i < NPER) s.xo[i] = xov[it]; }
         if (tid < PK_STRIDE) s.pk[tid] = pkv;

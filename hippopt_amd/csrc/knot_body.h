@@ -64,21 +64,22 @@ static_assert(sizeof(JointRec) == 128, "joint record");
 enum : int { JR_L = 0, JR_OF = 9, JR_C = 12, JR_SD = 15 };
 HD constexpr int jr_pos(int i, int e) { return ((((e >> 1) ^ (i & 7)) << 1) | (e & 1)); }   // physical position of logical double e of record i
 
-// Three layouts of the scratch (LAYOUT_*):
-//   KnotScratchT<0>  every array has its own storage (host recorders / emulation, eight-wave and pose / Hessian kernels)
-//   KnotScratchT<1>  the COMPACT device layout of the planar four-wave callback kernel (four workgroups per CU need <= 40 KB of
-//   KnotScratchT<2>  LDS per workgroup) and of the smooth-terrain one: arrays whose lifetimes do not overlap share storage —
+// Two layouts of the scratch (LAYOUT_*):
+//   KnotScratchT<LAYOUT_FULL>     every array has its own storage (host recorders / emulation, eight-wave and pose / Hessian kernels)
+//   KnotScratchT<LAYOUT_COMPACT>  the device layout of the four-wave callback kernels (four workgroups per CU need <= 40 KB of LDS per
+//                                 workgroup): arrays whose lifetimes do not overlap share storage —
 //                          * own[] (written in phase C, read in phase D) lives on top of the joint records Jr[] (written in phase A,
 //                            dead once the forward kinematics of phase B has read them); own[NL] (the zero slot written in phase A)
 //                            lies behind the last joint record;
 //                          * the g rows of the horizon ends (final state, periodicity: first / last knot only, written in phase E)
 //                            live in EndTerms::c of the same union (the minimize-mode cost partials they exclude row by row);
-//                          * layout 1: the joint frames (read in phase A only) and then the link inertials (read in phase C only) are
-//                            parked in comp[] (composites: written in phase D) instead of occupying LDS for the whole program;
-//                          * layout 2 (smooth terrain): comp[] holds the bump jets and then, IN PLACE, the terrain frames of the eight
-//                            points during phases A - B (the full layout parks the frames in own[], which here lies on the joint
-//                            records); the joint frames and link inertials are read from global memory by the lanes that need them.
-constexpr int LAYOUT_FULL = 0, LAYOUT_COMPACT = 1, LAYOUT_COMPACT_TERRAIN = 2;
+//                          * smooth terrain: comp[] (composites: written in phase D) holds the bump jets and then, IN PLACE, the terrain
+//                            frames of the eight points during phases A - B (the full layout parks the frames in own[], which here
+//                            lies on the joint records);
+//                          * the tables that are read once per knot — joint frames (phase A), link inertials (phase C) — and the
+//                            horizon-end tables (first / last knot) are not staged into LDS at all: the lanes that need them read
+//                            them from global memory (parking them in comp[] instead measured 1.4 % slower).
+constexpr int LAYOUT_FULL = 0, LAYOUT_COMPACT = 1;
 template <bool COMPACT> struct ScratchJrOwn;
 template <> struct ScratchJrOwn<false> {
     JointRec Jr[NJ + 1];
@@ -101,7 +102,6 @@ static_assert(sizeof(JointRec) * NJ <= sizeof(double) * LSTR * NL, "own[NL] (zer
 template <int LAYOUT> struct alignas(16) KnotScratchT : ScratchJrOwn<LAYOUT != LAYOUT_FULL> {
     static constexpr int layout = LAYOUT;
     static constexpr bool compact = LAYOUT != LAYOUT_FULL;
-    static constexpr bool tables_in_comp = LAYOUT == LAYOUT_COMPACT;
     double x[XPAD];    // knot k
     double xm[XPAD];   // knot k-1 (zeros at k = 0)
     double xo[NPER];   // periodicity variables of the other end of the horizon, by periodicity row (only loaded at k = 0 and k = N-1)
@@ -139,7 +139,6 @@ template <int LAYOUT> struct alignas(16) KnotScratchT : ScratchJrOwn<LAYOUT != L
     }
 };
 using KnotScratch = KnotScratchT<LAYOUT_FULL>;
-static_assert(LINR_DOUBLES <= JFIX_DOUBLES && JFIX_DOUBLES <= NL * LSTR, "the parked tables must fit in comp[]");
 
 enum : int { CM = 0, CH = 1, CI = 4, CKL = 10, CKA = 13 };  // offsets inside KnotScratch::comp[i]
 
@@ -174,27 +173,26 @@ template <class Em> struct Ctx {
     }
 };
 
-// ---- tables that are read once per knot: layout 1: parked in comp[] (see KnotScratchT); else from the full tables (gkt: the LDS copy in
-//      the full layout, global memory in layout 2)
+// ---- tables that are read once per knot, from the full tables (gkt: the LDS copy in the full layout, global memory in the compact one)
 // joint frames of joint j: phase A only
 template <class Em> HD const double* kin_R_fix(const Ctx<Em>& cx, int j) {
-    if constexpr (Ctx<Em>::Scratch::tables_in_comp) return &cx.s.comp[0][0] + 9 * j; else return cx.gkt->jf.R_fix[j];
+    return cx.gkt->jf.R_fix[j];
 }
 template <class Em> HD const double* kin_o_fix(const Ctx<Em>& cx, int j) {
-    if constexpr (Ctx<Em>::Scratch::tables_in_comp) return &cx.s.comp[0][0] + 9 * NJ + 3 * j; else return cx.gkt->jf.o_fix[j];
+    return cx.gkt->jf.o_fix[j];
 }
 template <class Em> HD const double* kin_axis(const Ctx<Em>& cx, int j) {
-    if constexpr (Ctx<Em>::Scratch::tables_in_comp) return &cx.s.comp[0][0] + 12 * NJ + 3 * j; else return cx.gkt->jf.axis[j];
+    return cx.gkt->jf.axis[j];
 }
 // link inertials of link i: phase C only
 template <class Em> HD double kin_mass(const Ctx<Em>& cx, int i) {
-    if constexpr (Ctx<Em>::Scratch::tables_in_comp) return (&cx.s.comp[0][0])[i]; else return cx.gkt->li.mass[i];
+    return cx.gkt->li.mass[i];
 }
 template <class Em> HD const double* kin_com(const Ctx<Em>& cx, int i) {
-    if constexpr (Ctx<Em>::Scratch::tables_in_comp) return &cx.s.comp[0][0] + NL + 3 * i; else return cx.gkt->li.com[i];
+    return cx.gkt->li.com[i];
 }
 template <class Em> HD const double* kin_inertia(const Ctx<Em>& cx, int i) {
-    if constexpr (Ctx<Em>::Scratch::tables_in_comp) return &cx.s.comp[0][0] + 4 * NL + 9 * i; else return cx.gkt->li.inertia[i];
+    return cx.gkt->li.inertia[i];
 }
 // g rows of the horizon ends (native slots >= gs::FIN): compact layout -> ends.c (see KnotScratchT)
 template <class Em> HD void emit_g_end(Ctx<Em>& cx, int slot, int id, double v) {
@@ -950,22 +948,6 @@ template <class S, class K> HD void link_origin_velocity(const S& s, const K& kt
         for (int r = 0; r < 3; ++r) v[r] += u[q][r];
 }
 
-// Compact layout only: the link inertials [mass | com | inertia] (read in phase C) replace the joint frames (read in phase A) in
-// comp[] (free until the composites of phase D): 64 lanes copy them from global memory during phase B, where the wave has slack.
-constexpr int STAGE_TABLE_TASKS = 64;
-template <class Em> HD void t_stage_link_tables(Ctx<Em>& cx, int t) {
-    if constexpr (Ctx<Em>::Scratch::tables_in_comp) {
-        const double* src = reinterpret_cast<const double*>(&cx.gkt->li);
-        double* dst = &cx.s.comp[0][0];
-        constexpr int ITERS = (LINR_DOUBLES + STAGE_TABLE_TASKS - 1) / STAGE_TABLE_TASKS;
-        double v[ITERS];
-        HIPNLP_UNROLL
-        for (int it = 0; it < ITERS; ++it) { const int i = t + it * STAGE_TABLE_TASKS; v[it] = i < LINR_DOUBLES ? src[i] : 0.0; }
-        HIPNLP_UNROLL
-        for (int it = 0; it < ITERS; ++it) { const int i = t + it * STAGE_TABLE_TASKS; if (i < LINR_DOUBLES) dst[i] = v[it]; }
-    } else { (void)cx; (void)t; }
-}
-
 // (the branches of t_hdyn diverge inside a wave: entries and rows + com entries are task groups of their own)
 template <class Em> HD void t_hdyn(Ctx<Em>& cx, int t);
 template <class Em> HD void t_hdyn_entries(Ctx<Em>& cx, int t) { t_hdyn(cx, t); }
@@ -1440,7 +1422,6 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
     BARRIER                                                                               \
     R(0, 0, t_fk_rot_a, FK_TASKS_A) R(0, 0, t_link_u_a, FK_SPLIT)                         \
     R(3, 1, t_fk_rot_b, FK_TASKS_B) R(3, 1, t_link_u_b, NJ - FK_SPLIT)                    \
-    R(1, 5, t_stage_link_tables, STAGE_TABLE_TASKS)                                       \
     R(1, 2, t_hdyn_entries, 48) R(1, 3, t_hdyn_rows, HDYN_TASKS - 48)                     \
     R(2, 7, t_terrain_hnf, NC) R(2, 4, t_terrain_swing, NC) R(2, 4, t_points_cost, 3) R(2, 4, t_foot_costs, FOOT_TASKS) R(2, 4, t_foot_cost_sum, 2) \
     R(1, 5, t_terrain_planar, NC) R(0, 6, t_terrain_dcc, NC) R(-1, 7, t_joint_cost, 1)    \

@@ -22,7 +22,7 @@ struct ValueEm {
     void H(int slot, int, int, double v) { hess[slot] = v; }
 };
 
-// the COMPACT device layout of the planar callback kernel (KnotScratchT<LAYOUT_COMPACT*>: shared storage for arrays with disjoint lifetimes,
+// the COMPACT device layout of the planar callback kernel (KnotScratchT<LAYOUT_COMPACT>: shared storage for arrays with disjoint lifetimes,
 // joint frames / link inertials parked in comp[], horizon-end g rows in ends.c): emulated phase by phase in program order, so a
 // lifetime overlap shows up as a wrong value here, without a GPU
 template <int LAYOUT> struct ValueEmC {
@@ -43,7 +43,7 @@ struct hostemu_handle {
     bool has_hess = false;
 };
 
-// the same evaluation on the compact scratch layouts of the device (LAYOUT_COMPACT: planar terrain; LAYOUT_COMPACT_TERRAIN: smooth)
+// the same evaluation on the compact scratch layout of the device's four-wave kernels
 template <int LAYOUT> static int eval_compact(const hostemu_handle* h, const double* x, const double* p, double* f, double* grad, double* g, double* jac, double* cost_terms) {
     const Layout& L = h->L;
     const int N = L.N;
@@ -62,10 +62,6 @@ template <int LAYOUT> static int eval_compact(const hostemu_handle* h, const dou
         for (int i = 0; i < NPER; ++i) s->xo[i] = k == 0 ? x[NXK * (N - 1) + periodicity_row_var(i)] : (k == N - 1 ? x[periodicity_row_var(i)] : 0.0);
         for (int i = 0; i < NXG; ++i) s->xg[i] = x[NXK * N + i];
         for (int i = 0; i < PK_STRIDE; ++i) s->pk[i] = pk[size_t(k) * PK_STRIDE + i];
-        if (S::tables_in_comp) {   // staging of the kernel: the joint frames parked in comp[]
-            const double* jf = reinterpret_cast<const double*>(&h->kt.jf);
-            for (int i = 0; i < JFIX_DOUBLES; ++i) (&s->comp[0][0])[i] = jf[i];
-        }
         KnotInfo ki{k, N, k == 0, k == N - 1};
         ValueEmC<LAYOUT> em{s->g, s->jac};
         Ctx<ValueEmC<LAYOUT>> cx(*s, static_cast<const KinLite&>(h->kt), h->ks, static_cast<const GParamsLite&>(gp), ki, em, &h->kt, &gp);
@@ -215,8 +211,7 @@ void hostemu_eval(const hostemu_handle* h, const double* x, const double* p, dou
 }
 
 int hostemu_eval_compact(const hostemu_handle* h, const double* x, const double* p, double* f, double* grad, double* g, double* jac, double* cost_terms) {
-    return h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR ? eval_compact<LAYOUT_COMPACT>(h, x, p, f, grad, g, jac, cost_terms)
-                                                          : eval_compact<LAYOUT_COMPACT_TERRAIN>(h, x, p, f, grad, g, jac, cost_terms);
+    return eval_compact<LAYOUT_COMPACT>(h, x, p, f, grad, g, jac, cost_terms);
 }
 
 // ---- static pose finder: the pose program of pose_body.h + the copy-out of hipnlp_pose_kernel -------------------------------

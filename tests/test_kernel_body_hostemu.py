@@ -287,7 +287,7 @@ def test_hessian_body_matches_reference_planner_fixture(model, name):
 @pytest.mark.parametrize("mode", ["subject_to", "minimize", "mixed", "single", "stairs", "stairs-minimize"])
 def test_compact_scratch_layout_gives_the_same_values(model, mode):
     """The planar device kernel runs on a compact scratch (four workgroups per CU): own[] on top of the joint records, the horizon-end
-    g rows inside the end-term partials, joint frames and link inertials parked in comp[].  Emulated in program order on the host:
+    g rows inside the end-term partials, joint frames and link inertials read from the global tables.  Emulated in program order on the host:
     bitwise the values of the full layout, in every combination of the horizon-end expression types."""
     N = 5
     st = single_step_settings(N, model) if mode == "single" else (stairs_settings(N, model) if mode.startswith("stairs") else periodic_step_settings(N, model))
