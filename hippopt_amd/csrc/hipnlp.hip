@@ -34,11 +34,14 @@ namespace {
 // four (or eight) wavefronts per knot: role-specialised waves (knot_body.h, HIPNLP_KNOT_PROGRAM)
 static_assert(gs::COUNT == HIPNLP_G_STAGE, "HIPNLP_G_STAGE must equal the native g slot count");
 
+// (copy-out tables padded to whole workgroups of 512 lanes — -1 / 0 behind the entries — so that their prefetch is unconditional:
+//  a load inside a branch makes the compiler wait for ALL younger loads at the first s_waitcnt vmcnt)
+constexpr int GS_PAD = (gs::COUNT + 511) / 512 * 512, JS_PAD = (js::COUNT + 511) / 512 * 512;
 struct DeviceTables {
     HeadTables head;
-    int32_t g_a[3][gs::COUNT];
-    int32_t g_b[gs::COUNT];
-    int32_t jperm[3][js::COUNT];
+    int32_t g_a[3][GS_PAD];
+    int32_t g_b[GS_PAD];
+    int32_t jperm[3][JS_PAD];
     int32_t jperm_glob[16];
     int32_t nnz_v[3];
     int32_t n_glob, jac_glob_base;
@@ -53,10 +56,10 @@ struct KArgs {
     double* jac;            // [batch][nnz]    or null
     double* grad;           // [batch][n]      or null
     double* g_stage;        // [batch][nk][gs::COUNT] knot-major staging of g (sharded mode) or null
-    double* cost_knot;      // [batch][nk][NCT] per-knot cost partials (published with agent-scope stores, see publish_costs)
-    double* f;              // [batch]        total cost, written by the LAST workgroup of a trajectory to publish its partials
+    double* cost_knot;      // [batch][nk][NCT] per-knot cost partials (four-wave variant: summed by hipnlp_reduce_kernel)
+    double* f;              // [batch]        total cost (eight-wave variant: written by the trajectory's reducer workgroup)
     double* cost_terms;     // [batch][NCT]   per-term totals, same writer
-    unsigned long long* ticket;   // [batch]  arrivals so far, never reset: launch number `seq` is complete at seq * nk
+    unsigned long long* cost_pub;   // [batch][nk][NCT][2] eight-wave variant: {partial, partial ^ pub_pattern(seq)}, see the reducer
     int32_t* flag;          // [batch]        generation flag of the non-finite detector: == seq after a launch that produced one
     int32_t* flag_host;     // [batch] or null: the same flag in pinned host memory (host-buffer path: a plain store of seq — every
                             //         writer of a launch stores the same value, launches of a handle are stream ordered — so the
@@ -69,12 +72,10 @@ struct KArgs {
 #endif
 };
 
-// The planar callback kernel runs on the COMPACT scratch (knot_body.h, KnotScratchT<LAYOUT_COMPACT>: <= 40 KB of LDS per workgroup with the
-// lite tables below: four workgroups per CU); the smooth-terrain kernel keeps the full layout (its terrain staging lives in own[] /
-// comp[] during phases A - B, where the compact layout parks the joint records and the joint frames).
-// Only the four-wave (throughput) variant: the eight-wave latency variant has one workgroup per CU whatever its LDS, and its duration
-// is that of the SLOWEST workgroup — the last knot, whose end rows would wait for global memory in the compact layout (measured:
-// 10.0 -> 10.9 us per 100-knot launch).
+// The four-wave (throughput) callback kernels run on the COMPACT scratch (knot_body.h, KnotScratchT<LAYOUT_COMPACT>: <= 40 KB of LDS per
+// workgroup with the lite tables below: four workgroups per CU).  The eight-wave latency variant keeps the full layout: it has one
+// workgroup per CU whatever its LDS, and its duration is that of the SLOWEST workgroup — the last knot, whose end rows would wait
+// for global memory in the compact layout (measured: 10.0 -> 10.9 us per 100-knot launch).
 template <int TERRAIN, int WAVES = 4> struct DevEm {
     static constexpr int kTerrain = TERRAIN;
     static constexpr int kLayout = WAVES == 4 ? LAYOUT_COMPACT : LAYOUT_FULL;
@@ -104,6 +105,17 @@ template <> struct alignas(16) SharedTablesT<true> {   // without the blocks rea
 using SharedTables = SharedTablesT<false>;
 static_assert(sizeof(KSettings) % 8 == 0 && sizeof(KinLite) % 8 == 0 && sizeof(GParamsLite) % 8 == 0, "copied in 8-byte words");
 
+// Workgroup barrier that orders LDS traffic only.  The phases of the knot program exchange data through LDS and through nothing
+// else, so global loads may stay in flight across it: __syncthreads() carries a workgroup fence whose s_waitcnt vmcnt(0) makes every
+// barrier wait for the copy-out tables prefetched at the top of the kernel.  (The "memory" clobber keeps the compiler from moving
+// memory operations across it; the hardware wait covers the LDS operations of this wave.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Tag of a published cost partial (eight-wave variant): the pair {v, v ^ pub_pattern(seq)} is valid for launch `seq` and for no other,
+// whichever of its two words a reader happens to see first (see the reducer in hipnlp_knot_kernel).
+__device__ __forceinline__ unsigned long long pub_pattern(int32_t seq) { return ((unsigned long long)(uint32_t)seq * 0x9E3779B97F4A7C15ull) | 1ull; }
+constexpr int PUB_SPIN_CAP = 1 << 20;   // polls of the reducer before it gives up (each at least one memory round trip: > 1 s)
+
 // WAVES = 4: 256 threads; 3 waves per SIMD = 3 workgroups per CU (the LDS bound): the register allocation is capped there
 //            (<= 168 VGPRs).  The throughput variant.
 // WAVES = 8: 512 threads, the roles of the knot program spread over twice the waves (two per SIMD).  The latency variant, used
@@ -111,7 +123,7 @@ static_assert(sizeof(KSettings) % 8 == 0 && sizeof(KinLite) % 8 == 0 && sizeof(G
 // Four workgroups per CU for the four-wave kernels (compact scratch + lite tables: <= 40 KB of LDS, <= 128 VGPRs).
 template <int TERRAIN, int WAVES> __global__ __launch_bounds__(64 * WAVES)
 __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 4 : 2, WAVES == 4 ? 4 : 2)))
-void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const double* pk_p, const GParams* gp_p, int N_p, int n_p, int kb_p, KArgs a) {
+void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const double* pk_p, const GParams* gp_p, int N_p, int n_p, int kb_p, int nk_p, KArgs a) {
     // the leading scalar arguments repeat what the staging loads need: the build preloads them into SGPRs
     // (-mllvm -amdgpu-kernarg-preload-count), so the first global loads do not wait for a kernarg fetch
     constexpr int WG = 64 * WAVES;
@@ -132,7 +144,81 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     // (measured, 100 knots x 64, HBM bytes per launch: 26.6 -> 16.5 MB read, 109.6 -> 96.1 MB written; algorithmic: 13.7 + 94.7 MB).
     // A bijection for any row length: class j = x mod 8 owns q + (j < r) knots, q = nk / 8, r = nk mod 8.
     const int b = blockIdx.y;
-    const int kk = int((blockIdx.x & 7u) * (gridDim.x >> 3) + min(blockIdx.x & 7u, gridDim.x & 7u) + (blockIdx.x >> 3));
+    // (eight-wave variant: one more workgroup per grid row, the trajectory's cost reducer)
+    const unsigned nkx = unsigned(nk_p);   // (= gridDim.x, less the reducer; preloaded: the grid size is a kernarg load away)
+    if constexpr (WAVES == 8) {
+        if (blockIdx.x == nkx) {
+            // ---- total cost without a second kernel and without a tail ---------------------------------------------------------
+            // Every knot workgroup publishes its cost partials as soon as they are final (end of phase C) and goes on; THIS
+            // workgroup does nothing but poll them (agent-scope loads: the writers sit on other XCDs) until all carry this launch's
+            // tag, then sums them in the fixed order of hipnlp_reduce_kernel (bitwise the same f from both variants) — by the
+            // time the knot workgroups have streamed their outputs.  A published partial is the pair {v, v ^ pub_pattern(seq)}:
+            // two plain 8-byte agent-scope stores, no ordering between them needed — a reader that pairs a value with the tag
+            // of another launch sees v ^ tag != pattern unless both launches published the same v, in which case v is right.
+            // (The previous protocol — store, acknowledgement, ticket, read-back by the last arriver: three dependent cross-XCD
+            //  round trips behind the LAST workgroup's partials — left a tail of 4.4 k cycles on that workgroup: 22.6 k cycles
+            //  against 18.4 k for every other one, i.e. 2 of the launch's 10 us.)
+            // Forward progress: the reducer of row b waits only for workgroups dispatched before it; it is bounded anyway.
+            double* red = reinterpret_cast<double*>(&s);   // [nk][16]
+            static_assert(sizeof(Scratch) >= 256 * 16 * sizeof(double), "reducer staging: nk <= 256 in the eight-wave variant");
+            const unsigned long long pat = pub_pattern(a.seq);
+            const unsigned long long* base = a.cost_pub + size_t(b) * a.nk * NCT * 2;
+            const int t = lane & 15, q = lane >> 4;
+            constexpr int U = 8;   // wave w, lane (t, q): knots 4 w + q + 32 u
+            unsigned pending = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) if (t < NCT && 4 * wave + q + 32 * u < a.nk) pending |= 1u << u;
+            double val[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) val[u] = 0.0;
+            for (int spin = 0; __any(pending != 0u); ++spin) {
+                if (spin >= PUB_SPIN_CAP) {   // never observed; a knot workgroup that died must not hang the device
+#pragma unroll
+                    for (int u = 0; u < U; ++u) if ((pending >> u) & 1u) val[u] = __builtin_nan("");
+                    if (lane == 0) { atomicMax(a.flag + b, a.seq); if (a.flag_host) a.flag_host[b] = a.seq; }
+                    break;
+                }
+                unsigned long long v[U], g[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const unsigned long long* pp = base + (size_t(4 * wave + q + 32 * u) * NCT + t) * 2;
+                    const bool want = (pending >> u) & 1u;
+                    v[u] = want ? __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                    g[u] = want ? __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (((pending >> u) & 1u) && (v[u] ^ g[u]) == pat) { val[u] = __longlong_as_double((long long)v[u]); pending &= ~(1u << u); }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int kq = 4 * wave + q + 32 * u; if (kq < a.nk) red[kq * 16 + t] = t < NCT ? val[u] : 0.0; }
+            __syncthreads();
+            if (wave == 0) {
+                // knot k belongs to group k % 16; a group is summed in ascending k; lane (t, q) holds the groups 4 w + q, w = 0..3
+                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int k0 = q; k0 < a.nk; k0 += 128) {
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) { const int kq = k0 + 4 * u; acc[u & 3] += kq < a.nk ? red[kq * 16 + t] : 0.0; }
+                }
+                double P[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    double pw = acc[w];
+                    pw += __shfl_xor(pw, 16, 64);
+                    pw += __shfl_xor(pw, 32, 64);
+                    P[w] = pw;
+                }
+                const double term = ((P[0] + P[1]) + P[2]) + P[3];
+                if (lane < NCT) a.cost_terms[size_t(b) * NCT + lane] = term;
+                double tot = 0.0;
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) tot += __shfl(term, c, 64);
+                if (lane == 0) a.f[b] = tot;
+            }
+            return;
+        }
+    }
+    const int kk = int((blockIdx.x & 7u) * (nkx >> 3) + min(blockIdx.x & 7u, nkx & 7u) + (blockIdx.x >> 3));
     const int k = kb_p + kk;
     const int N = N_p;
     const double* x = x_p + size_t(b) * n_p;
@@ -142,6 +228,13 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     // one (compile-time trip counts): ONE memory round trip instead of one per loop iteration.
     // Full layout: the whole HeadTables + GParams.  Compact layout: KSettings, the KinLite prefix of the kinematic tables and the
     // GParamsLite prefix of the parameters.
+    // copy-out tables of this knot's variant: fetched together with the staging loads, consumed at the very end — they stay in flight
+    // across the (LDS-only) barriers of the program
+    constexpr int JP_ITERS = (js::COUNT + WG - 1) / WG, G_ITERS = (gs::COUNT + WG - 1) / WG;
+    const int v = first ? VAR_FIRST : (last ? VAR_LAST : VAR_INTERIOR);
+    int nnz_first = 0, nnz_interior = 0, n_glob = 0, jac_glob_base = 0;   // (scalars of the copy-out: read behind the vector loads, used at the end)
+    int jpg = 0;
+    int32_t jp[JP_ITERS], ga[G_ITERS], gb[G_ITERS];
     {
         constexpr int XV_ITERS = (XPAD + WG - 1) / WG;
         static_assert(PK_STRIDE <= WG && NXG <= 8, "one parameter word per thread");
@@ -171,6 +264,17 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         }
         const double pkv = tid < PK_STRIDE ? pk_p[(size_t(b) * N + k) * PK_STRIDE + tid] : 0.0;
         const double xgv = tid < NXG ? x[size_t(NXK) * N + tid] : 0.0;
+        jpg = tb.jperm_glob[tid & 15];
+#pragma unroll
+        for (int it = 0; it < JP_ITERS; ++it) jp[it] = tb.jperm[v][tid + it * WG];
+#pragma unroll
+        for (int it = 0; it < G_ITERS; ++it) {
+            const int slot = tid + it * WG;
+            ga[it] = tb.g_a[v][slot];
+            gb[it] = tb.g_b[slot];
+        }
+        nnz_first = tb.nnz_v[VAR_FIRST]; nnz_interior = tb.nnz_v[VAR_INTERIOR]; jac_glob_base = tb.jac_glob_base;
+        n_glob = tb.n_glob;
 #ifdef HIPNLP_STAMPS
         st_issued = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -193,127 +297,30 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         for (int it = 0; it < XV_ITERS; ++it) { const int i = tid + it * WG; if (i < XPAD) { s.x[i] = xv[it]; s.xm[i] = xmv[it]; } if (i < NPER) s.xo[i] = xov[it]; }
         if (tid < PK_STRIDE) s.pk[tid] = pkv;
         if (tid < 8) s.xg[tid] = xgv;
-        if (tid == 0) s.pub_ready = 0;
     }
-    __syncthreads();
+    lds_barrier();
 
-    // copy-out tables of this knot's variant, fetched now so their latency hides behind the knot program
-    constexpr int JP_ITERS = (js::COUNT + WG - 1) / WG, G_ITERS = (gs::COUNT + WG - 1) / WG;
-    // (scalars of the copy-out: read behind the barrier on purpose.  Known before it, the compiler issues the copy-out table loads
-    //  before the barrier as well, which then waits for them: +14 % kernel time at batch 1024; kernarg copies of these scalars
-    //  measured +22 %)
-    const int v = first ? VAR_FIRST : (last ? VAR_LAST : VAR_INTERIOR);
-    const int64_t jbase = first ? 0 : int64_t(tb.nnz_v[VAR_FIRST]) + int64_t(k - 1) * tb.nnz_v[VAR_INTERIOR];
-    const int n_glob = last ? tb.n_glob : 0, jac_glob_base = tb.jac_glob_base;
-    const int jpg = (last && tid < 16) ? tb.jperm_glob[tid] : 0;
-    int32_t jp[JP_ITERS], ga[G_ITERS], gb[G_ITERS];
-#pragma unroll
-    // (the table is padded with -1 behind the knot variant's entries: the loads do not wait for the entry count, a global scalar)
-    for (int it = 0; it < JP_ITERS; ++it) { const int i = tid + it * WG; jp[it] = i < js::COUNT ? tb.jperm[v][i] : -1; }
-#pragma unroll
-    for (int it = 0; it < G_ITERS; ++it) {
-        const int slot = tid + it * WG;
-        ga[it] = slot < gs::COUNT ? tb.g_a[v][slot] : -1;
-        gb[it] = slot < gs::COUNT ? tb.g_b[slot] : 0;
-    }
-
-    // ---- total cost without a second kernel --------------------------------------------------------------------------------
-    // One wave (PUBW: idle in the late phases) PUBLISHES the knot's cost partials as soon as they are final — agent-scope stores,
-    // their acknowledgement, one ticket (fetch-add) per knot — spread over the barriers of the program so that every memory round
-    // trip hides behind a phase.  The workgroup that draws the last ticket of its trajectory reads all partials back (agent-scope
-    // loads) and sums them in a FIXED order (bitwise reproducible whatever the arrival order); nobody ever waits for another
-    // workgroup.  Only the (rare) minimize-mode horizon-end terms of the first / last knot are final too late for the hiding.
+    // ---- the knot's cost partials, published for the reducer workgroup of its trajectory (above) --------------------------------
+    // One wave (PUBW: no task in the late phases of the eight-wave program) stores them as soon as they are final: at the end of
+    // phase C for an ordinary knot; only the (rare) minimize-mode horizon-end terms of the first / last knot are final in phase F.
     constexpr int PUBW = WAVES == 8 ? 7 : 3;
     const bool ends_late = (first || last) && (tabs.settings().final_type == HIPNLP_EXPR_MINIMIZE || tabs.settings().periodicity_type == HIPNLP_EXPR_MINIMIZE);
-    unsigned long long pub_old = 0;
     int pub_bad = 0;
     auto pub_store = [&]() __attribute__((always_inline)) {
         if (lane < NCT) {
             const double cv = (lane == CT_ENDS && !ends_late) ? 0.0 : s.cost[lane];   // (t_ends_finish writes that zero only in phase F)
             pub_bad |= !isfinite(cv);
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.cost_knot + (size_t(b) * a.nk + kk) * NCT + lane),
-                               __double_as_longlong(cv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long* pp = a.cost_pub + ((size_t(b) * a.nk + kk) * NCT + lane) * 2;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(cv);
+            __hip_atomic_store(pp, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pp + 1, bits ^ pub_pattern(a.seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-    };
-    auto pub_ticket = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the partials are in memory (agent-scope stores are write-through)
-        unsigned long long old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(a.ticket + b, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pub_old = old;
-    };
-    // last arriver: the SAME summation tree as hipnlp_reduce_kernel (both variants give bitwise the same f): knot k belongs to
-    // group k % 16; groups are summed in ascending k, combined (g0 + g1) + (g2 + g3) four at a time, then ((P0 + P1) + P2) + P3.
-    // Lane (term t = lane % 16, q = lane / 16) holds the groups 4 w + q, w = 0..3: the knots k = q + 4 j, group index w = j % 4.
-    // 32 loads per lane in flight at once (one memory round trip for a horizon of up to 128 knots).
-    bool pub_last = false;
-    double pub_v[32];
-    const unsigned long long* pub_base = reinterpret_cast<const unsigned long long*>(a.cost_knot + size_t(b) * a.nk * NCT);
-    auto pub_issue = [&](int k0) __attribute__((always_inline)) {
-        const int t = lane & 15;
-#pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            const int kq = k0 + 4 * u;
-            pub_v[u] = (t < NCT && kq < a.nk) ? __longlong_as_double((long long)__hip_atomic_load(pub_base + size_t(kq) * NCT + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
-        }
-    };
-    auto pub_await_ticket = [&]() __attribute__((always_inline)) {   // waits for the ticket; the last arriver puts its first 32 loads per lane in flight
-        const unsigned long long old = (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane(int(pub_old & 0xffffffffull)) |
-                                       ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane(int(pub_old >> 32)) << 32);
-        pub_last = old + 1ull == (unsigned long long)a.seq * (unsigned long long)a.nk;   // (wave-uniform)
-        if (pub_last) pub_issue(lane >> 4);
-    };
-    auto pub_sum = [&]() __attribute__((always_inline)) {
-        if (!pub_last) return;
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int k0 = lane >> 4;;) {
-#pragma unroll
-            for (int u = 0; u < 32; ++u) acc[u & 3] += pub_v[u];
-            k0 += 128;
-            if (k0 >= a.nk) break;
-            pub_issue(k0);
-        }
-        double P[4];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            double pw = acc[w];
-            pw += __shfl_xor(pw, 16, 64);
-            pw += __shfl_xor(pw, 32, 64);
-            P[w] = pw;
-        }
-        const double term = ((P[0] + P[1]) + P[2]) + P[3];
-        if (lane < NCT) a.cost_terms[size_t(b) * NCT + lane] = term;
-        double tot = 0.0;
-#pragma unroll
-        for (int q = 0; q < NCT; ++q) tot += __shfl(term, q, 64);
-        if (lane == 0) a.f[b] = tot;
     };
     // called by every wave right behind barrier number `passed` (0 = the one that ends phase A)
     auto pub_step = [&](int passed) __attribute__((always_inline)) {
-        // (throughput variant: under load the acknowledgement of the partials takes long enough to stall the publishing wave at
-        //  its next barrier — measured -13 % at batch 64 — so it keeps the separate reduction kernel, cheap next to a long launch)
+        // (throughput variant: it keeps the separate reduction kernel, cheap next to a long launch)
         if (WAVES != 8 || wave != PUBW) return;
-        if (!ends_late) {
-            // Every cost term of an ordinary knot is final at the end of phase C; this wave has no task in phases D - F (eight-wave
-            // program).
-            // (Measured: publishing earlier, from inside phase C behind an LDS flag of t_frames, makes EVERY workgroup wait for the
-            //  acknowledgement — about 3 k cycles — at the barrier that ends phase C: 12.1 us per 100-knot step instead of 11.8.
-            //  Taking each step one phase after the previous one instead of waiting right away: 12.5 us.  What is left of the
-            //  tail, about 3.5 k cycles on the last arriver, is three dependent agent-scope round trips (acknowledgement, ticket,
-            //  read-back) of 2 - 3 k cycles each against the 7 k cycles left of the kernel; eight ticket counters by kk % 8 plus a
-            //  completion check — less same-address contention, one more round trip — measured slower: 11.47 vs 11.09 us; making
-            //  every cost term final one phase earlier (chest-frame cost from the joint records beside the forward kinematics) and
-            //  starting the protocol there: 11.14 us, and -8 % at batch for the extra task; finishing the protocol behind the
-            //  last barrier instead of inside phase F: 11.61 us.)
-            // partials at the end of phase C, ticket one phase later (the acknowledgement, ~3 k cycles, is back by then: waiting for
-            // it right away held EVERY workgroup at the barrier behind the now short composite phase), read-back and sum by the last
-            // arriver one phase after that.  (Measured per 100-knot step: 11.59 us store+ticket / sum; 11.54 us with the sum a
-            // further phase later; 11.09 us as below.  Publishing 16-byte pairs {partial, launch number} so that the ticket need
-            // not wait for the acknowledgement of the stores, the last arriver re-reading pairs that carry an older number:
-            // 12.7 us against 10.7 us for this version in the same session — the acknowledgement is already back one phase on.)
-            if (passed == 2) pub_store();
-            else if (passed == 3) pub_ticket();
-            else if (passed == 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pub_await_ticket(); pub_sum(); }
-        } else if (passed == 5) { pub_store(); pub_ticket(); pub_await_ticket(); pub_sum(); }
+        if (passed == (ends_late ? 5 : 2)) pub_store();
     };
 
     KnotInfo ki{k, N, first, last};
@@ -325,22 +332,35 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     // instruction stream from the first phase to the last.  Written as `if (wave == w) { ... }` blocks phase after phase, every
     // wave jumped over the other waves' code several times per phase, each jump a cold instruction-cache line.  The waves still meet
     // at the same barriers: every instance contains all of them.
+#ifdef HIPNLP_STAMPS
+    unsigned long long st_task[24];   // diagnostic build: the time every task group of this wave ends, in program order
+    int st_nt = 0;
+#define DEV_R(w4, w8, fn, nt) if constexpr ((WAVES == 4 ? (w4) : (w8)) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
+#else
 #define DEV_R(w4, w8, fn, nt) if constexpr ((WAVES == 4 ? (w4) : (w8)) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
+#endif
 #ifdef HIPNLP_STAMPS
     // diagnostic build: every wave keeps, IN REGISTERS, its arrival time at each barrier and the time it leaves it; one store
     // per wave at the very end (a store before a barrier would make the barrier wait for its acknowledgement).
     unsigned long long st_arr[8], st_dep[8];
     const unsigned long long st_staged = __builtin_amdgcn_s_memtime();
     int bid = 0;
-#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); __syncthreads(); st_dep[bid] = __builtin_amdgcn_s_memtime(); if constexpr (WAVES == 8 && W == PUBW) pub_step(bid); bid++;
+#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); if constexpr (WAVES == 8 && W == PUBW) pub_step(bid); bid++;
 #else
     int bid = 0;
-#define DEV_BARRIER __syncthreads(); if constexpr (WAVES == 8 && W == PUBW) pub_step(bid); bid++;
+#define DEV_BARRIER lds_barrier(); if constexpr (WAVES == 8 && W == PUBW) pub_step(bid); bid++;
 #endif
     auto run_wave = [&](auto wc) __attribute__((always_inline)) {
         constexpr int W = decltype(wc)::value;
         HIPNLP_KNOT_PROGRAM(DEV_R, DEV_BARRIER)
     };
+#ifdef HIPNLP_TWOPASS
+    // diagnostic: the knot program twice; the stamps of the FIRST pass are kept beside those of the second (instruction fetch: the
+    // second pass finds its code in the instruction cache)
+    unsigned long long st_first[8], st_first0 = 0;
+    for (int pass_ = 0; pass_ < 2; ++pass_) {
+    if (pass_ == 1) { for (int i = 0; i < 8; ++i) st_first[i] = st_arr[i]; st_first0 = st_staged; bid = 0; st_nt = 0; __syncthreads(); st_first[7] = __builtin_amdgcn_s_memtime(); }
+#endif
     switch (wave) {
         case 0: run_wave(std::integral_constant<int, 0>{}); break;
         case 1: run_wave(std::integral_constant<int, 1>{}); break;
@@ -351,12 +371,16 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         case 6: if constexpr (WAVES == 8) run_wave(std::integral_constant<int, 6>{}); break;
         default: if constexpr (WAVES == 8) run_wave(std::integral_constant<int, 7>{}); break;
     }
+#ifdef HIPNLP_TWOPASS
+    }
+#endif
 #undef DEV_R
 #undef DEV_BARRIER
 
     // ---- stream the knot's outputs ---------------------------------------------------------------------
     // All LDS reads and the non-finite check come first, then nothing but stores; the non-finite flag is kept per wavefront
     // (the reduction kernel ORs them), so no workgroup barrier stands between the last task and the stores.
+    const int64_t jbase = first ? 0 : int64_t(nnz_first) + int64_t(k - 1) * nnz_interior;
     int bad = 0;
     constexpr int GR_ITERS = (NXK + WG - 1) / WG;
     double jvals[JP_ITERS], gvals[G_ITERS], grvals[GR_ITERS];
@@ -423,6 +447,11 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             stamp_out[0] = st_entry; stamp_out[1] = st_staged; stamp_out[2] = (unsigned long long)bid;
             for (int i = 0; i < 8; ++i) { stamp_out[8 + 2 * i] = i <= bid ? st_arr[i] : 0; stamp_out[9 + 2 * i] = i < bid ? st_dep[i] : 0; }
             stamp_out[3] = st_real0; stamp_out[4] = __builtin_amdgcn_s_memrealtime(); stamp_out[5] = st_issued; stamp_out[6] = st_loaded;
+            stamp_out[7] = (unsigned long long)st_nt;
+#ifdef HIPNLP_TWOPASS
+            stamp_out[64] = st_first0; for (int i = 0; i < 8; ++i) stamp_out[65 + i] = st_first[i];
+#endif
+            for (int i = 0; i < 24; ++i) stamp_out[32 + i] = i < st_nt ? st_task[i] : 0;
         }
     }
 #endif
@@ -506,7 +535,7 @@ template <int TERRAIN> __global__ __launch_bounds__(256) __attribute__((amdgpu_w
             const int ga = k + 1 < N ? tb.g_a[k + 1 == N - 1 ? VAR_LAST : VAR_INTERIOR][slot] : -1;
             hx.lam_next[tid] = ga >= 0 ? lam[ga + tb.g_b[slot] * (k + 1)] : 0.0;
         }
-        if (tid == 0) { hx.sigma = a.sigma[b]; s.pub_ready = 0; }
+        if (tid == 0) hx.sigma = a.sigma[b];
     }
     __syncthreads();
     // copy-out permutation, fetched now so that its latency hides behind the programs
@@ -640,7 +669,7 @@ struct hipnlp_handle {
     double *d_cost_knot = nullptr, *d_cost_terms = nullptr;
     GParams* d_gp = nullptr;
     int32_t* d_flag = nullptr;              // [batch] generation flag of the non-finite detector (== seq of the launch that raised it)
-    unsigned long long* d_ticket = nullptr;  // [batch] arrivals, never reset
+    unsigned long long* d_cost_pub = nullptr;  // [batch][nk][NCT][2] tagged partials of the eight-wave variant (zero = never valid)
     int32_t seq = 0, seq_result = -1;        // launches so far; launch the cached host result belongs to
     unsigned long long* d_stamps = nullptr;
     // pinned host staging
@@ -685,7 +714,7 @@ static void free_all(hipnlp_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* dptrs[] = {h->d_tb, h->d_x, h->d_pk, h->d_cost_knot, h->d_gp, h->d_ticket, h->d_out, h->d_ht, h->d_sigma, h->d_hess, h->d_hflag};
+    void* dptrs[] = {h->d_tb, h->d_x, h->d_pk, h->d_cost_knot, h->d_gp, h->d_cost_pub, h->d_out, h->d_ht, h->d_sigma, h->d_hess, h->d_hflag};
     for (void* q : dptrs) if (q) (void)hipFree(q);
     void* hptrs[] = {h->h_x, h->h_out, h->h_hess, h->h_hflag, h->h_sl};
     for (void* q : hptrs) if (q) (void)hipHostFree(q);
@@ -767,8 +796,8 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
         std::memset(h->h_out, 0, h->out_bytes);
     }
     CREATE_TRY(hipMalloc(&h->d_cost_knot, B * size_t(h->nk) * NCT * sizeof(double)));
-    CREATE_TRY(hipMalloc(&h->d_ticket, B * sizeof(unsigned long long)));
-    CREATE_TRY(hipMemset(h->d_ticket, 0, B * sizeof(unsigned long long)));
+    CREATE_TRY(hipMalloc(&h->d_cost_pub, B * size_t(h->nk) * NCT * 2 * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemset(h->d_cost_pub, 0, B * size_t(h->nk) * NCT * 2 * sizeof(unsigned long long)));
     CREATE_TRY(hipMemset(h->d_flag, 0, B * sizeof(int32_t)));
     // (measured: non-coherent pinned memory for this block — cacheable in the GPU's L2 within a launch, so that the halo record would
     //  not cross PCIe twice — changes nothing: 22.3 us of GPU wait per objective call either way)
@@ -790,8 +819,8 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     tb->head.kt = h->kt;
     tb->head.ks = Layout::make_ksettings(st);
     for (int v = 0; v < 3; ++v) {
-        for (int s = 0; s < gs::COUNT; ++s) tb->g_a[v][s] = h->L.g_a[v][size_t(s)];
-        for (int i = 0; i < js::COUNT; ++i) tb->jperm[v][i] = size_t(i) < h->L.jperm[v].size() ? h->L.jperm[v][size_t(i)] : -1;
+        for (int s = 0; s < GS_PAD; ++s) tb->g_a[v][s] = s < gs::COUNT ? h->L.g_a[v][size_t(s)] : -1;
+        for (int i = 0; i < JS_PAD; ++i) tb->jperm[v][i] = size_t(i) < h->L.jperm[v].size() ? h->L.jperm[v][size_t(i)] : -1;
         tb->nnz_v[v] = h->L.nnz_v[v];
     }
     for (int s = 0; s < gs::COUNT; ++s) tb->g_b[s] = h->L.g_b[size_t(s)];
@@ -888,7 +917,7 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     } else {
         a.jac_stride = h->L.nnz; a.jac_off = 0; a.grad_stride = h->L.n; a.grad_off = 0;
     }
-    a.cost_knot = h->d_cost_knot; a.f = f_dev; a.ticket = h->d_ticket; a.flag = h->d_flag;
+    a.cost_knot = h->d_cost_knot; a.f = f_dev; a.cost_pub = h->d_cost_pub; a.flag = h->d_flag;
     // host-buffer path: per-term costs (96 B per trajectory) and the non-finite flag go straight to the pinned block
     a.cost_terms = host_block ? h->hd_cost_terms : h->d_cost_terms;
     a.flag_host = host_block ? h->hd_flag : nullptr;
@@ -910,14 +939,14 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     a.stamps = h->d_stamps;
 #endif
     if (timed) HIP_TRY(h, hipEventRecord(e0, s));
-    const dim3 grid(unsigned(h->nk), unsigned(h->batch));
+    const dim3 grid(unsigned(h->nk) + (h->wide ? 1u : 0u), unsigned(h->batch));   // (eight-wave variant: + the row's cost reducer)
     const bool planar = h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR;
     if (h->wide) {   // at most one workgroup per CU: eight waves per knot
-        if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a);
-        else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a);
+        if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+        else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
     } else {
-        if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 4>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a);
-        else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 4>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a);
+        if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 4>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+        else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 4>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 1)], s));
     if (!h->wide)

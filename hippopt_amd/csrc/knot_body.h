@@ -129,7 +129,6 @@ template <int LAYOUT> struct alignas(16) KnotScratchT : ScratchJrOwn<LAYOUT != L
     // cost partials, reduced by t_reduce
     double c_pt[NC][3], c_joint[NJ], c_force[2][3], c_yaw[2];
     double cost[NCT];
-    int pub_ready, pub_pad_;   // set by t_frames once the last cost term of an ordinary knot is final (device: polled by the publishing wave)
     double grad[XPAD];
     double jac[js::COUNT];
     // value of native g slot `slot` / where the emitter stores it
@@ -1136,7 +1135,6 @@ template <class Em> HD void t_frames(Ctx<Em>& cx, int f) {
         const double on = cx.ki.first ? 0.0 : 1.0;
         const double m = on * cx.st.m_frameq;
         s.cost[CT_FRAMEQ] = m * (e * e);
-        s.pub_ready = 1;   // (behind the cost in this lane's LDS order)
         s.chest_dc = 2.0 * m * e;
         s.chest_w[0] = M[7] - M[5]; s.chest_w[1] = M[2] - M[6]; s.chest_w[2] = M[3] - M[1];
     }

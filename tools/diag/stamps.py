@@ -15,7 +15,7 @@ SO = os.path.join(ROOT, "tools", "diag", "_build", "libhipnlp_stamps%s.so" % os.
 
 def build():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DHIPNLP_STAMPS", "-mllvm", "-amdgpu-kernarg-preload-count=16"] + ([] if not os.environ.get("STAMPS_VARIANT") else ["-DHIPNLP_DIAG_SKIP=" + os.environ["STAMPS_VARIANT"]]) + [
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DHIPNLP_STAMPS", "-mllvm", "-amdgpu-kernarg-preload-count=16"] + ([] if not os.environ.get("STAMPS_VARIANT") else (["-DHIPNLP_TWOPASS"] if os.environ["STAMPS_VARIANT"] == "twopass" else ["-DHIPNLP_DIAG_SKIP=" + os.environ["STAMPS_VARIANT"]])) + [
                            "-o", SO, os.path.join(ROOT, "hippopt_amd", "csrc", "hipnlp.hip"), os.path.join(ROOT, "hippopt_amd", "csrc", "hipnlp_pose.hip")])
 
 
@@ -72,8 +72,40 @@ if __name__ == "__main__":
         dep = max(int(blk[w, 9 + 2 * i] - t0) for w in waves)
         print("B%d arrivals %s  last %d (phase %+d)  released %d" % (i, arr, max(arr), max(arr) - prev, dep))
         prev = dep
+    # task groups of every wave, in program order (names from the program table: the wave's column of HIPNLP_KNOT_PROGRAM)
+    import re
+    prog = open(os.path.join(ROOT, "hippopt_amd", "csrc", "knot_body.h")).read()
+    prog = prog[prog.index("#define HIPNLP_KNOT_PROGRAM(R, BARRIER)") + len("#define HIPNLP_KNOT_PROGRAM(R, BARRIER)"):]
+    items = re.findall(r"R\((-?\d+), (-?\d+), (\w+), [^)]*\)|(BARRIER)", prog)
+    for w in waves:
+        names, b = [], 0
+        for w4, w8, fn, bar in items[0:]:
+            if bar:
+                b += 1
+                continue
+            if int(w4 if len(waves) == 4 else w8) == w:
+                names.append((b, fn))
+        n = int(blk[w, 7])
+        prev_t = int(blk[w, 1] - t0)
+        prev_b = 0
+        line = []
+        for i in range(min(n, len(names))):
+            bb, fn = names[i]
+            if bb != prev_b:
+                prev_t = int(blk[w, 9 + 2 * (bb - 1)] - t0)   # released from the barrier before this phase
+                prev_b = bb
+            t = int(blk[w, 32 + i] - t0)
+            line.append("%s[%d] %+d" % (fn, bb, t - prev_t))
+            prev_t = t
+        print("wave %d tasks: %s" % (w, "  ".join(line)))
     end = [int(blk[w, 8 + 2 * nb] - t0) for w in waves]
     print("end (stores issued) %s  (+%d)" % (end, max(end) - prev))
+    if blk[waves[0], 64] != 0:   # -DHIPNLP_TWOPASS: the stamps above are those of the SECOND pass over the knot program
+        first = [[int(blk[w, 65 + i] - blk[w, 64]) for i in range(nb)] for w in waves]
+        start2 = [int(blk[w, 72]) for w in waves]
+        second = [[int(blk[w, 8 + 2 * i]) - start2[j] for i in range(nb)] for j, w in enumerate(waves)]
+        print("two passes: arrival at barrier i since the start of the pass, max over waves:  first %s   second %s" % (
+            [max(f[i] for f in first) for i in range(nb)], [max(f[i] for f in second) for i in range(nb)]))
     real = [(int(blk[w, 4] - blk[w, 3])) for w in waves]
     cyc = [(int(blk[w, 8 + 2 * nb] - blk[w, 0])) for w in waves]
     print("realtime ticks (100 MHz) per wave %s -> shader clock ~ %.0f MHz" % (real, 100.0 * np.mean(cyc) / max(1.0, np.mean(real))))
