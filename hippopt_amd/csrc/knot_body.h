@@ -885,23 +885,31 @@ template <class Em> HD void t_fk_rot_at(Ctx<Em>& cx, int t, int q0) {
     const int j = t / 3, r = t - 3 * j;
     double v0 = s.Rb[3 * r], v1 = s.Rb[3 * r + 1], v2 = s.Rb[3 * r + 2];
     double o = 0.0, w = s.omega[r], ar = 0.0;
-    // q0: every list of this task group is padded up to there (group-uniform: the leading identity steps are skipped)
-    // (measured: reading the record of step q + 1 while step q is computed — explicit software pipelining — is 5 % slower on the
-    //  eight-wave kernel, which then holds 248 VGPRs, and no faster at batch)
+    // q0: every list of this task group is padded up to there (group-uniform: the arithmetic of the leading identity steps is skipped).
+    // The record of step q + 1 is read while step q is computed (two register buffers, static step numbers): a step is one LDS round
+    // trip PLUS three dependent levels of fp64 arithmetic otherwise, ~360 cycles, eight times over on the longest chain of phase B.
+    int ia[8];
     HIPNLP_UNROLL
-    for (int q = q0; q < 8; ++q) {
-        const int ia = cx.kt.anc[j][q];
-        const double* rp = s.Jr[ia].d;
-        const int sw = (ia & 7) << 1;
-        double rec[16];   // the eight 16-byte chunks of the record, un-swizzled into registers
+    for (int q = 0; q < 8; ++q) ia[q] = cx.kt.anc[j][q];
+    double rec[2][16];   // the eight 16-byte chunks of a record, un-swizzled into registers
+    auto fetch = [&](int q, double* rc) {
+        const double* rp = s.Jr[ia[q]].d;
+        const int sw = (ia[q] & 7) << 1;
         HIPNLP_UNROLL
-        for (int ch = 0; ch < 8; ++ch) { const int pp = (2 * ch) ^ sw; rec[2 * ch] = rp[pp]; rec[2 * ch + 1] = rp[pp + 1]; }
-        const double* L = rec + JR_L;
-        const double* of = rec + JR_OF;
-        const double* cc = rec + JR_C;
+        for (int ch = 0; ch < 8; ++ch) { const int pp = (2 * ch) ^ sw; rc[2 * ch] = rp[pp]; rc[2 * ch + 1] = rp[pp + 1]; }
+    };
+    fetch(0, rec[0]);
+    HIPNLP_UNROLL
+    for (int q = 0; q < 8; ++q) {
+        if (q + 1 < 8) fetch(q + 1, rec[(q + 1) & 1]);
+        if (q < q0) continue;
+        const double* rq = rec[q & 1];
+        const double* L = rq + JR_L;
+        const double* of = rq + JR_OF;
+        const double* cc = rq + JR_C;
         o += v0 * of[0] + v1 * of[1] + v2 * of[2];
         ar = v0 * cc[0] + v1 * cc[1] + v2 * cc[2];   // (row r of R_parent) . (R_fix axis) = (row r of R_a) . axis
-        w += ar * rec[JR_SD];
+        w += ar * rq[JR_SD];
         const double n0 = v0 * L[0] + v1 * L[3] + v2 * L[6];
         const double n1 = v0 * L[1] + v1 * L[4] + v2 * L[7];
         const double n2 = v0 * L[2] + v1 * L[5] + v2 * L[8];
@@ -1411,17 +1419,21 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
 // of an eight-wave workgroup (the kernel variant for launches that leave most CUs idle: one workgroup per CU anyway, so the
 // phases are spread over twice the waves); host: plain loop.  Groups of one phase run concurrently on different waves;
 // BARRIER separates phases.  Groups that rely on running BEHIND another group of their wave (HIPNLP_WAVE_SYNC) share both ids.
+// HIPNLP_W8(p, s): wave of the eight-wave workgroup on the planar / on the smooth terrain (defined where the device expands the
+// program; host expansions ignore the wave ids).  The eight waves sit two per SIMD (w and w + 4): a phase's longest task wants a
+// partner with little to issue — on the planar terrain the terrain tasks are empty, so the pairing differs between the two.
 // ---------------------------------------------------------------------------------------------------
 #define HIPNLP_KNOT_PROGRAM(R, BARRIER)                                                   \
-    R(0, 0, t_points_vec, 3 * NC) R(0, 2, t_joint_rows, NJ)                               \
-    R(1, 2, t_points_scalar, NC) R(1, 3, t_dyn, 7 + NJ + 3) R(1, 7, t_terrain_bump, TERRAIN_BUMP_TASKS) R(1, 7, t_terrain_stage, NC) R(1, 1, t_unitq, 1) \
-    R(2, 4, t_joints, NJ) R(2, 1, t_feet_yaw, 2) R(2, 1, t_feet_centroid, 1)              \
+    R(0, 0, t_points_vec, 3 * NC) R(0, HIPNLP_W8(7, 2), t_joint_rows, NJ)                 \
+    R(1, HIPNLP_W8(7, 2), t_points_scalar, NC) R(1, 3, t_dyn, 7 + NJ + 3) R(1, 7, t_terrain_bump, TERRAIN_BUMP_TASKS) R(1, 7, t_terrain_stage, NC) R(1, 1, t_unitq, 1) \
+    R(2, HIPNLP_W8(2, 4), t_joints, NJ) R(2, 1, t_feet_yaw, 2) R(2, HIPNLP_W8(4, 1), t_feet_centroid, 1) \
     R(3, 5, t_base, 3) R(3, 6, t_small, 4) R(3, 3, t_points_dyn, 3 * NC)                  \
     BARRIER                                                                               \
     R(0, 0, t_fk_rot_a, FK_TASKS_A) R(0, 0, t_link_u_a, FK_SPLIT)                         \
     R(3, 1, t_fk_rot_b, FK_TASKS_B) R(3, 1, t_link_u_b, NJ - FK_SPLIT)                    \
     R(1, 2, t_hdyn_entries, 48) R(1, 3, t_hdyn_rows, HDYN_TASKS - 48)                     \
-    R(2, 7, t_terrain_hnf, NC) R(2, 4, t_terrain_swing, NC) R(2, 4, t_points_cost, 3) R(2, 4, t_foot_costs, FOOT_TASKS) R(2, 4, t_foot_cost_sum, 2) \
+    R(2, 7, t_terrain_hnf, NC) R(2, HIPNLP_W8(6, 4), t_terrain_swing, NC) R(2, HIPNLP_W8(6, 4), t_points_cost, 3) \
+    R(2, HIPNLP_W8(6, 4), t_foot_costs, FOOT_TASKS) R(2, HIPNLP_W8(6, 4), t_foot_cost_sum, 2) \
     R(1, 5, t_terrain_planar, NC) R(0, 6, t_terrain_dcc, NC) R(-1, 7, t_joint_cost, 1)    \
     BARRIER                                                                               \
     R(0, 0, t_links, NL) R(1, 1, t_frames, 3) R(2, 2, t_link_inertia, NL) R(3, -1, t_joint_cost, 1) \
