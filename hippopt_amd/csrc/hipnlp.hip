@@ -89,7 +89,7 @@ template <int TERRAIN, int WAVES = 4> struct DevEm {
 
 // LDS image of the read-only tables every phase indexes per lane (global memory would cost one L2 round trip per phase)
 template <bool COMPACT> struct SharedTablesT;
-template <> struct SharedTablesT<false> {
+template <> struct alignas(16) SharedTablesT<false> {
     HeadTables head;
     GParams gp;
     __device__ __forceinline__ const KinTables& kin() const { return head.kt; }
@@ -224,46 +224,75 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     const double* x = x_p + size_t(b) * n_p;
     const int first = k == 0, last = k == N - 1;
     const DeviceTables& tb = *tb_p;
-    // ---- stage the knot records and the tables in LDS.  Every global load is issued before the first LDS store waits for
-    // one (compile-time trip counts): ONE memory round trip instead of one per loop iteration.
+    // ---- stage the knot records and the tables in LDS: straight from global memory into LDS (global_load_lds_dwordx4: lane l of a wave
+    // delivers 16 bytes at LDS base + 16 l — no VGPR round trip, no ds_write; one instruction moves 1 KB), the 1 KB chunks of all
+    // blocks dealt round-robin over the waves.  (The previous version — every thread loads 8-byte words into registers and stores them
+    // to LDS — spent ~250 instructions per wave here, a tenth of the 100-knot launch.)
     // Full layout: the whole HeadTables + GParams.  Compact layout: KSettings, the KinLite prefix of the kinematic tables and the
     // GParamsLite prefix of the parameters.
-    // copy-out tables of this knot's variant: fetched together with the staging loads, consumed at the very end — they stay in flight
-    // across the (LDS-only) barriers of the program
+    // Copy-out tables of this knot's variant: fetched once the staging loads have landed (the compiler waits for EVERY outstanding
+    // load before an LDS access that follows a direct load), consumed at the very end — they stay in flight across the (LDS-only)
+    // barriers of the program.
     constexpr int JP_ITERS = (js::COUNT + WG - 1) / WG, G_ITERS = (gs::COUNT + WG - 1) / WG;
     const int v = first ? VAR_FIRST : (last ? VAR_LAST : VAR_INTERIOR);
     int nnz_first = 0, nnz_interior = 0, n_glob = 0, jac_glob_base = 0;   // (scalars of the copy-out: read behind the vector loads, used at the end)
     int jpg = 0;
     int32_t jp[JP_ITERS], ga[G_ITERS], gb[G_ITERS];
     {
-        constexpr int XV_ITERS = (XPAD + WG - 1) / WG;
-        static_assert(PK_STRIDE <= WG && NXG <= 8, "one parameter word per thread");
-        // blocks of 8-byte words: (source, destination, words)
-        constexpr int W0 = COMPACT ? int(sizeof(KSettings) / 8) : int(sizeof(HeadTables) / 8);
-        constexpr int W1 = COMPACT ? int(sizeof(KinLite) / 8) : 0;
-        constexpr int W2 = COMPACT ? int(sizeof(GParamsLite) / 8) : int(sizeof(GParams) / 8);
-        constexpr int I0 = (W0 + WG - 1) / WG, I1 = (W1 + WG - 1) / WG, I2 = (W2 + WG - 1) / WG;
-        const double* src0 = COMPACT ? reinterpret_cast<const double*>(&tb.head.ks) : reinterpret_cast<const double*>(&tb.head);
-        const double* src1 = reinterpret_cast<const double*>(static_cast<const KinLite*>(&tb.head.kt));
-        const double* src2 = reinterpret_cast<const double*>(gp_p + b);
-        double v0[I0 > 0 ? I0 : 1], v1[I1 > 0 ? I1 : 1], v2[I2 > 0 ? I2 : 1];
-        double xv[XV_ITERS], xmv[XV_ITERS], xov[XV_ITERS];
-#pragma unroll
-        for (int it = 0; it < I0; ++it) { const int i = tid + it * WG; v0[it] = i < W0 ? src0[i] : 0.0; }
-#pragma unroll
-        for (int it = 0; it < I1; ++it) { const int i = tid + it * WG; v1[it] = i < W1 ? src1[i] : 0.0; }
-#pragma unroll
-        for (int it = 0; it < I2; ++it) { const int i = tid + it * WG; v2[it] = i < W2 ? src2[i] : 0.0; }
-#pragma unroll
-        for (int it = 0; it < XV_ITERS; ++it) {
-            const int i = tid + it * WG;
-            const bool in = i < NXK;
-            xv[it] = in ? x[size_t(NXK) * k + i] : 0.0;
-            xmv[it] = (in && !first) ? x[size_t(NXK) * (k - 1) + i] : 0.0;
-            xov[it] = (i < NPER && (first || last)) ? x[size_t(NXK) * (first ? N - 1 : 0) + periodicity_row_var(i)] : 0.0;
+        static_assert(sizeof(KSettings) % 16 == 0 && sizeof(KinLite) % 16 == 0 && sizeof(GParamsLite) % 16 == 0 && sizeof(HeadTables) % 16 == 0 &&
+                      sizeof(GParams) % 16 == 0 && (PK_STRIDE * 8) % 16 == 0, "staged in 16-byte pieces");
+        // the record x_k is NXK = 189 doubles: 94 pieces + one double, which goes through a register like the gathered words below
+        constexpr int XB = NXK * 8 / 16 * 16, XREM = NXK - XB / 8;
+        static_assert(XREM <= 1 && NXG * 8 % 16 == 0 && NXG <= 8, "record staging");
+        // (scalars of the copy-out, used at the end: read BEFORE the direct loads — behind them the compiler no longer treats global
+        //  memory as unwritten and would fetch these through vector registers)
+        nnz_first = tb.nnz_v[VAR_FIRST]; nnz_interior = tb.nnz_v[VAR_INTERIOR]; jac_glob_base = tb.jac_glob_base;
+        n_glob = tb.n_glob;
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        // a block of `bytes` (multiple of 16): wave (w + rot) mod WAVES moves the 1 KB chunk w of each round of WG x 16 bytes; `rot`
+        // walks on by the chunks used, so that the small blocks land on different waves (everything here folds at compile time
+        // except the wave number: no scalar branch, one predicated instruction per block and round)
+        int rot = 0;
+        auto stage = [&](const void* src, void* dst, int bytes) __attribute__((always_inline)) {
+            for (int r0 = 0; r0 < bytes; r0 += WG * 16) {
+                const int wv = (wave_u + WAVES - rot % WAVES) & (WAVES - 1);
+                const int off = r0 + wv * 1024 + lane * 16;
+                if (off < bytes)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(src) + off),
+                                                     (__attribute__((address_space(3))) void*)(static_cast<char*>(dst) + r0 + wv * 1024), 16, 0, 0);
+                rot += ((bytes - r0 < WG * 16 ? bytes - r0 : WG * 16) + 1023) / 1024;
+            }
+        };
+        stage(x + size_t(NXK) * k, s.x, XB);
+        if (!first) stage(x + size_t(NXK) * (k - 1), s.xm, XB); else rot += (XB + 1023) / 1024;
+        stage(pk_p + (size_t(b) * N + k) * PK_STRIDE, s.pk, PK_STRIDE * 8);
+        stage(x + size_t(NXK) * N, s.xg, NXG * 8);
+        if constexpr (COMPACT) {
+            stage(static_cast<const GParamsLite*>(gp_p + b), &tabs.gp, int(sizeof(GParamsLite)));
+            stage(&tb.head.ks, &tabs.ks, int(sizeof(KSettings)));
+            stage(static_cast<const KinLite*>(&tb.head.kt), &tabs.kt, int(sizeof(KinLite)));
+        } else {
+            stage(gp_p + b, &tabs.gp, int(sizeof(GParams)));
+            stage(&tb.head, &tabs.head, int(sizeof(HeadTables)));
         }
-        const double pkv = tid < PK_STRIDE ? pk_p[(size_t(b) * N + k) * PK_STRIDE + tid] : 0.0;
-        const double xgv = tid < NXG ? x[size_t(NXK) * N + tid] : 0.0;
+        // through registers: the odd last double of the two records; horizon ends only: the periodicity variables of the other end
+        double xrem = 0.0, xov = 0.0;
+        if (XREM && tid < 2 && !(first && tid == 1)) xrem = x[size_t(NXK) * (k - tid) + XB / 8];
+        if (first || last) { if (tid < NPER) xov = x[size_t(NXK) * (first ? N - 1 : 0) + periodicity_row_var(tid)]; }
+#ifdef HIPNLP_STAMPS
+        st_issued = __builtin_amdgcn_s_memtime();
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the staging loads of THIS wave have landed in LDS (before it signals the barrier)
+#ifdef HIPNLP_STAMPS
+        st_loaded = __builtin_amdgcn_s_memtime();
+#endif
+        if (first || last) { if (tid < NPER) s.xo[tid] = xov; }
+        if (XREM && tid < 2) (tid ? s.xm : s.x)[XB / 8] = xrem;
+        if (first) { for (int i = tid; i < XB / 8; i += WG) s.xm[i] = 0.0; }
+        // pads (no staging load touches them)
+        if (tid >= 64 && tid < 64 + XPAD - NXK) { s.x[NXK + tid - 64] = 0.0; s.xm[NXK + tid - 64] = 0.0; }
+        if (tid >= 128 && tid < 128 + 8 - NXG) s.xg[NXG + tid - 128] = 0.0;
+        // copy-out tables: issued now, consumed at the very end
         jpg = tb.jperm_glob[tid & 15];
 #pragma unroll
         for (int it = 0; it < JP_ITERS; ++it) jp[it] = tb.jperm[v][tid + it * WG];
@@ -273,30 +302,6 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             ga[it] = tb.g_a[v][slot];
             gb[it] = tb.g_b[slot];
         }
-        nnz_first = tb.nnz_v[VAR_FIRST]; nnz_interior = tb.nnz_v[VAR_INTERIOR]; jac_glob_base = tb.jac_glob_base;
-        n_glob = tb.n_glob;
-#ifdef HIPNLP_STAMPS
-        st_issued = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        st_loaded = __builtin_amdgcn_s_memtime();
-#endif
-        double *dst0, *dst1 = nullptr, *dst2;
-        if constexpr (COMPACT) {
-            dst0 = reinterpret_cast<double*>(&tabs.ks); dst1 = reinterpret_cast<double*>(&tabs.kt);
-            dst2 = reinterpret_cast<double*>(&tabs.gp);
-        } else {
-            dst0 = reinterpret_cast<double*>(&tabs.head); dst2 = reinterpret_cast<double*>(&tabs.gp);
-        }
-#pragma unroll
-        for (int it = 0; it < I0; ++it) { const int i = tid + it * WG; if (i < W0) dst0[i] = v0[it]; }
-#pragma unroll
-        for (int it = 0; it < I1; ++it) { const int i = tid + it * WG; if (i < W1) dst1[i] = v1[it]; }
-#pragma unroll
-        for (int it = 0; it < I2; ++it) { const int i = tid + it * WG; if (i < W2) dst2[i] = v2[it]; }
-#pragma unroll
-        for (int it = 0; it < XV_ITERS; ++it) { const int i = tid + it * WG; if (i < XPAD) { s.x[i] = xv[it]; s.xm[i] = xmv[it]; } if (i < NPER) s.xo[i] = xov[it]; }
-        if (tid < PK_STRIDE) s.pk[tid] = pkv;
-        if (tid < 8) s.xg[tid] = xgv;
     }
     lds_barrier();
 

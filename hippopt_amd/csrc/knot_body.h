@@ -102,7 +102,7 @@ static_assert(sizeof(JointRec) * NJ <= sizeof(double) * LSTR * NL, "own[NL] (zer
 template <int LAYOUT> struct alignas(16) KnotScratchT : ScratchJrOwn<LAYOUT != LAYOUT_FULL> {
     static constexpr int layout = LAYOUT;
     static constexpr bool compact = LAYOUT != LAYOUT_FULL;
-    double x[XPAD];    // knot k
+    alignas(16) double x[XPAD];    // knot k   (x, xm, xg, pk: 16-byte aligned, staged by direct global -> LDS loads)
     double xm[XPAD];   // knot k-1 (zeros at k = 0)
     double xo[NPER];   // periodicity variables of the other end of the horizon, by periodicity row (only loaded at k = 0 and k = N-1)
     double xg[8];      // horizon-global variables (initial_state.centroidal_momentum)

@@ -40,11 +40,11 @@ enum : int { PK_DESC = 0, PK_REF = 24, PK_YAWSC = 79,
 // ---- horizon-global parameters the kernels need (bounds-only parameters stay on the host) -----
 // GParamsLite: what every knot reads; GParams adds the final-state values, which only the LAST knot reads and only in `minimize`
 // mode (the compact device layout leaves them in global memory)
-struct GParamsLite {
+struct alignas(16) GParamsLite {   // (16: staged into LDS in 16-byte pieces)
     double dt, kt, kbs, eps, mu, mass;
     double gravity[6];
 };
-struct GParams : GParamsLite {
+struct alignas(16) GParams : GParamsLite {
     double final_rhs[105];  // final_state values in final-row order (only read in `minimize` mode)
 };
 
@@ -52,7 +52,7 @@ struct GParams : GParamsLite {
 // KinLite: the tables every phase indexes per lane (LDS on the device).  KinTables adds the blocks that are read ONCE per knot
 // (joint frames: phase A only; link inertials: phase C only) or only by the first / last knot (horizon-end row tables): the compact
 // device layout does not keep those in LDS for the whole program (knot_body.h, KnotScratchT<LAYOUT_COMPACT>).
-struct KinLite {
+struct alignas(16) KinLite {
     int32_t leg_pos[2][NJ];     // position of joint j in the root->sole path (0..5) or -1
     int32_t leg_joint[2][LEG_PATH];
     int32_t chest_pos[NJ];      // position in the root->chest path or -1
@@ -88,7 +88,7 @@ struct TerrainStepK {   // one SmoothTerrain.step bump, pre-digested: a = ax dx 
     double ox, oy, oz, height, ax, ay, bx, by;
     int32_t m, r;       // exponents 2*edge_sharpness and 2*side_sharpness
 };
-struct KSettings {
+struct alignas(16) KSettings {
     int32_t horizon, final_type, periodicity_type, joint_reg_as_coded, hdyn_x0;
     int32_t terrain, n_steps;
     TerrainStepK steps[HIPNLP_MAX_TERRAIN_STEPS];
