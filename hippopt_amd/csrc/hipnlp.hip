@@ -119,10 +119,11 @@ constexpr int PUB_SPIN_CAP = 1 << 20;   // polls of the reducer before it gives 
 // WAVES = 4: 256 threads; 3 waves per SIMD = 3 workgroups per CU (the LDS bound): the register allocation is capped there
 //            (<= 168 VGPRs).  The throughput variant.
 // WAVES = 8: 512 threads, the roles of the knot program spread over twice the waves (two per SIMD).  The latency variant, used
-//            when the launch has at most one workgroup per CU anyway (knots x batch <= 256), e.g. one 100-knot trajectory.
+//            when the whole launch is resident at once at two workgroups per CU ((knots + 1) x batch <= 512), e.g. one 100-knot
+//            trajectory.
 // Four workgroups per CU for the four-wave kernels (compact scratch + lite tables: <= 40 KB of LDS, <= 128 VGPRs).
 template <int TERRAIN, int WAVES> __global__ __launch_bounds__(64 * WAVES)
-__attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 4 : 2, WAVES == 4 ? 4 : 2)))
+__attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 4 : 2, 4)))
 void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const double* pk_p, const GParams* gp_p, int N_p, int n_p, int kb_p, int nk_p, KArgs a) {
     // the leading scalar arguments repeat what the staging loads need: the build preloads them into SGPRs
     // (-mllvm -amdgpu-kernarg-preload-count), so the first global loads do not wait for a kernarg fetch
@@ -661,7 +662,7 @@ struct hipnlp_handle {
     Layout L;
     KinTables kt;
     int batch = 1, kb = 0, ke = 0, nk = 0, np = 0;
-    bool wide = false;   // eight-wave kernel variant (launches of at most one workgroup per CU)
+    bool wide = false;   // eight-wave kernel variant (launches that are resident at once at two workgroups per CU)
     int dev = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -756,7 +757,11 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     h->nk = h->ke - h->kb;
     {
         const char* force = std::getenv("HIPNLP_WAVES");   // diagnostic override: 4 or 8
-        h->wide = force ? std::atoi(force) == 8 : (long(h->nk) * long(desc->batch) <= 256);
+        // eight waves per knot while every workgroup of the launch (+ one reducer per trajectory) is resident at once: two per CU
+        // (<= 128 VGPRs, 2 x 52 KB of LDS).  Measured at N = 100 (tools/diag/wide_sweep.sh): +28 .. +31 % over the four-wave kernel for
+        // batch 2 .. 5, nothing once the launch exceeds the 512 slots (batch 6: 36.9 against 38.0 M knots/s).
+        const bool fits = h->nk <= 256 && (long(h->nk) + 1) * long(desc->batch) <= 512;
+        h->wide = force ? (std::atoi(force) == 8 && h->nk <= 256) : fits;
     }
     std::string e;
     if (!Layout::make_kin_tables(desc->model, h->kt, e)) return fail(HIPNLP_E_INVALID, e);
@@ -948,7 +953,7 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     if (timed) HIP_TRY(h, hipEventRecord(e0, s));
     const dim3 grid(unsigned(h->nk) + (h->wide ? 1u : 0u), unsigned(h->batch));   // (eight-wave variant: + the row's cost reducer)
     const bool planar = h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR;
-    if (h->wide) {   // at most one workgroup per CU: eight waves per knot
+    if (h->wide) {   // the whole launch resident at once: eight waves per knot
         if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
         else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
     } else {

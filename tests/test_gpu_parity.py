@@ -517,15 +517,15 @@ def test_host_sink_shards_store_into_one_registered_buffer(model, HipNlp):
 
 
 def test_profile_runs_and_kernel_count(model, HipNlp):
-    """hipnlp_kernels_per_eval (1 for launches of at most 256 knots, 2 beyond) and the run-bracketed event timing."""
+    """hipnlp_kernels_per_eval (1 while (knots + 1) x batch <= 512, 2 beyond) and the run-bracketed event timing."""
     import torch
     st = periodic_step_settings(12, model)
     x, p = make_workload(st, model, batch=1, seed=3)
     small = HipNlp(st, model)
     small.set_params(p)
     assert small.kernels_per_eval() == 1
-    xb, pb = make_workload(st, model, batch=32, seed=3)
-    big = HipNlp(st, model, batch=32)
+    assert HipNlp(st, model, batch=32).kernels_per_eval() == 1   # 13 x 32 workgroups: two per CU
+    big = HipNlp(st, model, batch=64)
     assert big.kernels_per_eval() == 2
     dev = torch.device("cuda", 0)
     xd = torch.from_numpy(x).to(dev)
