@@ -287,13 +287,15 @@ template <class Em> HD void t_kh_pp(KHCtx<Em>& h, int t) {
 //                            dL/du, dL/df, dL/df_dot, dL/dv — first-order jets (G3) over a frame one order lower (Z to third order).
 // (Measured in round 1: staging the single task over (point, bump) / point / (point, block) lanes through the dead jac area ran no
 //  faster — the arithmetic of the frame was the long pole, not the assembly; what changed here is the arithmetic itself.)
+constexpr int PP_STAGE = 46;   // doubles handed from t_kh_point_smooth_pp to _pp2 per contact point
+static_assert(PP_STAGE * NC <= js::COUNT, "(p, p) staging lives in the Jacobian staging area");
+template <class S> HD double* pp_stage(S& s, int c) { return &s.jac[0] + PP_STAGE * c; }
 template <class Em> HD void t_kh_point_smooth_pp(KHCtx<Em>& h, int c) {
     Ctx<Em>& cx = h.cx;
     if (terrain_is_planar(cx)) return;
     auto& s = cx.s;
-    Em& em = cx.em;
     const double* lam = h.lam;
-    const int gb = gs::PT_STRIDE * c, hb = hk::SP + hk::SP_STRIDE * c, cb = PT_ * c;
+    const int gb = gs::PT_STRIDE * c, cb = PT_ * c;
     const double* x = s.x + cb;
     const double* p = x + P_;
     const double* f = x + F_;
@@ -303,10 +305,10 @@ template <class Em> HD void t_kh_point_smooth_pp(KHCtx<Em>& h, int c) {
     const double on = cx.ki.first ? 0.0 : 1.0, msw = h.hx.sigma * on * cx.st.m_swing;
     const double l_d = lam[gb + gs::DCC], l_h = lam[gb + gs::HEIGHT], l_n = lam[gb + gs::NORMAL], l_f = lam[gb + gs::FRICTION];
     const double* lp = lam + gb + gs::PLANAR;
-    const double kbs = cx.gp.kbs, kt = cx.gp.kt, mu2 = cx.gp.mu * cx.gp.mu;
+    const double kbs = cx.gp.kbs, mu2 = cx.gp.mu * cx.gp.mu;
     // L is ACCUMULATED term by term: every contraction leaves the two-variable jets as a second-order jet (six numbers instead of ten;
-    // only n . f is needed to third order, for its gradient), goes into L at once and is dropped — at no point do more than L, h,
-    // tau and the five frame jets (n_0, n_1, n_2, q, iq) live together.
+    // only n . f is needed to third order, for its gradient), goes into L at once and is dropped.  This task: the terms in h, hdot
+    // and the normal; t_kh_point_smooth_pp2: the terms in the tangent axes.
     T3 L;
     {
         const J2<4> Z = terrain_Z_j<4>(cx.st, p[0], p[1]);
@@ -315,8 +317,6 @@ template <class Em> HD void t_kh_point_smooth_pp(KHCtx<Em>& h, int c) {
         hT.v += p[2]; hT.g[2] = 1.0;
         T3 hdot = t3_from(u1 * v[0] + u2 * v[1]);
         hdot.v += v[2];
-        const double tv = tanh(kt * hT.v), t1 = kt * (1.0 - tv * tv), t2 = -2.0 * kt * tv * t1;
-        const T3 tau = t3_chain(hT, tv, t1, t2);
         T3 dh = hT;
         dh.v -= s.pk[PK_REF + R_SWING];
         L = hT * l_h + (dh * dh) * (0.5 * msw);
@@ -330,6 +330,44 @@ template <class Em> HD void t_kh_point_smooth_pp(KHCtx<Em>& h, int c) {
             L = L + (hT * (nfT * kbs + fnd + nfdT) + hdot * nfT) * (-l_d) + nfT * l_n + (nfT * nfT) * (mu2 * l_f);
         }
         L = L + t3_from(n0 * lp[0] + n1 * lp[1] + n2 * lp[2]) * (-u[2]);
+        // handed to t_kh_point_smooth_pp2 (next phase, another wave): the normal, the height jet and the Hessian of L so far — through
+        // the Jacobian staging area of the knot scratch, which the Hessian program never writes
+        double* st = pp_stage(s, c);
+        for (int i = 0; i < 10; ++i) { st[i] = n0.c[i]; st[10 + i] = n1.c[i]; st[20 + i] = n2.c[i]; }
+        st[30] = hT.v;
+        for (int i = 0; i < 3; ++i) st[31 + i] = hT.g[i];
+        for (int i = 0; i < 6; ++i) { st[34 + i] = hT.H[i]; st[40 + i] = L.H[i]; }
+    }
+}
+// second half of the (p, p) block: the six terms that contract the TANGENT axes x, y of the terrain frame with f, v and the planar
+// multipliers.  A task of its own so that the jets of the first half (Z to fourth order, grad h, hdot, the n . f family) and the
+// tangent-axis jets (q, iq, the contractions) are never live together: as one task the kernel spilled 34 VGPRs at the 256 cap.
+template <class Em> HD void t_kh_point_smooth_pp2(KHCtx<Em>& h, int c) {
+    Ctx<Em>& cx = h.cx;
+    if (terrain_is_planar(cx)) return;
+    auto& s = cx.s;
+    Em& em = cx.em;
+    const double* lam = h.lam;
+    const int gb = gs::PT_STRIDE * c, hb = hk::SP + hk::SP_STRIDE * c, cb = PT_ * c;
+    const double* x = s.x + cb;
+    const double* f = x + F_;
+    const double* v = x + V_;
+    const double* u = x + U_;
+    const double on = cx.ki.first ? 0.0 : 1.0, msw = h.hx.sigma * on * cx.st.m_swing;
+    const double l_f = lam[gb + gs::FRICTION];
+    const double* lp = lam + gb + gs::PLANAR;
+    const double kt = cx.gp.kt;
+    const double* st = pp_stage(s, c);
+    T3 L;
+    {
+        J2<3> n0, n1, n2;
+        T3 hT;
+        for (int i = 0; i < 10; ++i) { n0.c[i] = st[i]; n1.c[i] = st[10 + i]; n2.c[i] = st[20 + i]; }
+        hT.v = st[30];
+        for (int i = 0; i < 3; ++i) hT.g[i] = st[31 + i];
+        for (int i = 0; i < 6; ++i) hT.H[i] = st[34 + i];
+        const double tv = tanh(kt * hT.v), t1 = kt * (1.0 - tv * tv), t2 = -2.0 * kt * tv * t1;
+        const T3 tau = t3_chain(hT, tv, t1, t2);
         const J2<3> q = n1 * n1 + n2 * n2;            // same closed form as terrain_frame (knot_body.h)
         const J2<3> iq = j2_pow(q, -0.5);
         // x . c = iq (q c_0 - n_0 (n_1 c_1 + n_2 c_2)),   y . c = iq (n_2 c_1 - n_1 c_2)
@@ -343,7 +381,8 @@ template <class Em> HD void t_kh_point_smooth_pp(KHCtx<Em>& h, int c) {
     bool ys;
     for (int a = 0; a < 3; ++a)
         for (int b = 0; b <= a; ++b)
-            em.H(hb + hk::SP_PP + tri(a, b), cb + P_ + a, cb + P_ + b, L.H[t3h(a, b)] + pp_costs(h, c, c, a, b, ys) + (a == b ? ends_diag(h, cb + P_ + a) : 0.0));
+            em.H(hb + hk::SP_PP + tri(a, b), cb + P_ + a, cb + P_ + b,
+                 st[40 + t3h(a, b)] + L.H[t3h(a, b)] + pp_costs(h, c, c, a, b, ys) + (a == b ? ends_diag(h, cb + P_ + a) : 0.0));
 }
 template <class Em> HD void t_kh_point_smooth_mixed(KHCtx<Em>& h, int c) {
     Ctx<Em>& cx = h.cx;
@@ -853,7 +892,7 @@ template <class Em> HD void t_kh_ssd_far_b(KHCtx<Em>& h, int t) { t_kh_ssd_far(h
     KIN(0, t_fk_rot_a, FK_TASKS_A) KIN(0, t_link_u_a, FK_SPLIT) KIN(3, t_fk_rot_b, FK_TASKS_B) KIN(3, t_link_u_b, NJ - FK_SPLIT) \
     RH(2, t_kh_point_smooth_pp, NC) RH(1, t_kh_point_smooth_mixed, NC)                                           \
     BARRIER                                                                                                      \
-    KIN(0, t_links, NL) KIN(1, t_frames, 3) KIN(2, t_link_inertia, NL)                                           \
+    KIN(0, t_links, NL) KIN(1, t_frames, 3) KIN(2, t_link_inertia, NL) RH(3, t_kh_point_smooth_pp2, NC)          \
     BARRIER                                                                                                      \
     KIN(0, t_composite_g0, 64) KIN(1, t_composite_g1, 64) KIN(1, t_composite_g2, 64)                             \
     KIN(2, t_composite_g3, 64) KIN(2, t_composite_g4, 64) KIN(3, t_composite_g5, 64) KIN(3, t_pkin, NC)          \
