@@ -484,7 +484,7 @@ def main():
                          "launches_timed": main_res["nprof"], "event_stride": stride, "timing": timing,
                          "algorithmic_bytes_per_knot": bytes_knot, "knots_per_launch": local_knots,
                          "regime": "latency bound: %d workgroups on 256 CUs (all resident at once), one dependent knot program each" % local_knots
-                                   if eng.kernels_per_eval() == 1 else "issue / latency bound (fp64 VALU), not HBM bound: see `valu`"},
+                                   if local_knots + args.batch <= 512 else "issue / latency bound (fp64 VALU), not HBM bound: see `valu`"},
         }
         if valu and kern_ms > 0:
             ginst = valu * local_knots / (kern_ms * 1e-3) / 1e9

@@ -145,9 +145,9 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     // (measured, 100 knots x 64, HBM bytes per launch: 26.6 -> 16.5 MB read, 109.6 -> 96.1 MB written; algorithmic: 13.7 + 94.7 MB).
     // A bijection for any row length: class j = x mod 8 owns q + (j < r) knots, q = nk / 8, r = nk mod 8.
     const int b = blockIdx.y;
-    // (eight-wave variant: one more workgroup per grid row, the trajectory's cost reducer)
+    // (launches of at most 256 knots per trajectory: one more workgroup per grid row, the trajectory's cost reducer)
     const unsigned nkx = unsigned(nk_p);   // (= gridDim.x, less the reducer; preloaded: the grid size is a kernarg load away)
-    if constexpr (WAVES == 8) {
+    {
         if (blockIdx.x == nkx) {
             // ---- total cost without a second kernel and without a tail ---------------------------------------------------------
             // Every knot workgroup publishes its cost partials as soon as they are final (end of phase C) and goes on; THIS
@@ -161,45 +161,53 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             //  against 18.4 k for every other one, i.e. 2 of the launch's 10 us.)
             // Forward progress: the reducer of row b waits only for workgroups dispatched before it; it is bounded anyway.
             double* red = reinterpret_cast<double*>(&s);   // [nk][16]
-            static_assert(sizeof(Scratch) >= 256 * 16 * sizeof(double), "reducer staging: nk <= 256 in the eight-wave variant");
+            static_assert(sizeof(Scratch) >= 256 * 16 * sizeof(double), "reducer staging: nk <= 256");
             const unsigned long long pat = pub_pattern(a.seq);
             const unsigned long long* base = a.cost_pub + size_t(b) * a.nk * NCT * 2;
             const int t = lane & 15, q = lane >> 4;
-            constexpr int U = 8;   // wave w, lane (t, q): knots 4 w + q + 32 u
+            constexpr int KR = 4 * WAVES, U = 256 / KR;   // wave w, lane (t, q): knots 4 w + q + KR u
             unsigned pending = 0;
 #pragma unroll
-            for (int u = 0; u < U; ++u) if (t < NCT && 4 * wave + q + 32 * u < a.nk) pending |= 1u << u;
-            double val[U];
+            for (int u = 0; u < U; ++u) if (t < NCT && 4 * wave + q + KR * u < a.nk) pending |= 1u << u;
+            // (a partial goes to the LDS staging the moment it is seen valid: no register array of them)
+            if (t >= NCT) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) val[u] = 0.0;
+                for (int u = 0; u < U; ++u) { const int kq = 4 * wave + q + KR * u; if (kq < a.nk) red[kq * 16 + t] = 0.0; }
+            }
             for (int spin = 0; __any(pending != 0u); ++spin) {
                 if (spin >= PUB_SPIN_CAP) {   // never observed; a knot workgroup that died must not hang the device
 #pragma unroll
-                    for (int u = 0; u < U; ++u) if ((pending >> u) & 1u) val[u] = __builtin_nan("");
+                    for (int u = 0; u < U; ++u) if ((pending >> u) & 1u) red[(4 * wave + q + KR * u) * 16 + t] = __builtin_nan("");
                     if (lane == 0) { atomicMax(a.flag + b, a.seq); if (a.flag_host) a.flag_host[b] = a.seq; }
                     break;
                 }
-                unsigned long long v[U], g[U];
+                // (eight pairs per pass: sixteen in flight at once would not fit the four-wave kernel's 128 VGPRs)
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const unsigned long long* pp = base + (size_t(4 * wave + q + 32 * u) * NCT + t) * 2;
-                    const bool want = (pending >> u) & 1u;
-                    v[u] = want ? __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-                    g[u] = want ? __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                for (int u0 = 0; u0 < U; u0 += 8) {
+                    if (!__any(((pending >> u0) & 0xffu) != 0u)) continue;
+                    unsigned long long v[8], g[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const unsigned long long* pp = base + (size_t(4 * wave + q + KR * (u0 + u)) * NCT + t) * 2;
+                        const bool want = (pending >> (u0 + u)) & 1u;
+                        v[u] = want ? __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                        g[u] = want ? __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (((pending >> (u0 + u)) & 1u) && (v[u] ^ g[u]) == pat) {
+                            red[(4 * wave + q + KR * (u0 + u)) * 16 + t] = __longlong_as_double((long long)v[u]);
+                            pending &= ~(1u << (u0 + u));
+                        }
                 }
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (((pending >> u) & 1u) && (v[u] ^ g[u]) == pat) { val[u] = __longlong_as_double((long long)v[u]); pending &= ~(1u << u); }
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u) { const int kq = 4 * wave + q + 32 * u; if (kq < a.nk) red[kq * 16 + t] = t < NCT ? val[u] : 0.0; }
             __syncthreads();
             if (wave == 0) {
                 // knot k belongs to group k % 16; a group is summed in ascending k; lane (t, q) holds the groups 4 w + q, w = 0..3
                 double acc[4] = {0.0, 0.0, 0.0, 0.0};
-                for (int k0 = q; k0 < a.nk; k0 += 128) {
+                for (int k0 = q; k0 < a.nk; k0 += 32) {   // (eight LDS reads in flight; acc[w] takes its knots in ascending order)
 #pragma unroll
-                    for (int u = 0; u < 32; ++u) { const int kq = k0 + 4 * u; acc[u & 3] += kq < a.nk ? red[kq * 16 + t] : 0.0; }
+                    for (int u = 0; u < 8; ++u) { const int kq = k0 + 4 * u; acc[u & 3] += kq < a.nk ? red[kq * 16 + t] : 0.0; }
                 }
                 double P[4];
 #pragma unroll
@@ -307,7 +315,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     lds_barrier();
 
     // ---- the knot's cost partials, published for the reducer workgroup of its trajectory (above) --------------------------------
-    // One wave (PUBW: no task in the late phases of the eight-wave program) stores them as soon as they are final: at the end of
+    // One wave (PUBW) stores them as soon as they are final: at the end of
     // phase C for an ordinary knot; only the (rare) minimize-mode horizon-end terms of the first / last knot are final in phase F.
     constexpr int PUBW = WAVES == 8 ? 7 : 3;
     const bool ends_late = (first || last) && (tabs.settings().final_type == HIPNLP_EXPR_MINIMIZE || tabs.settings().periodicity_type == HIPNLP_EXPR_MINIMIZE);
@@ -324,8 +332,8 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     };
     // called by every wave right behind barrier number `passed` (0 = the one that ends phase A)
     auto pub_step = [&](int passed) __attribute__((always_inline)) {
-        // (throughput variant: it keeps the separate reduction kernel, cheap next to a long launch)
-        if (WAVES != 8 || wave != PUBW) return;
+        // (a.cost_pub == null: trajectories of more than 256 knots keep the separate reduction kernel)
+        if (!a.cost_pub || wave != PUBW) return;
         if (passed == (ends_late ? 5 : 2)) pub_store();
     };
 
@@ -352,10 +360,10 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     unsigned long long st_arr[8], st_dep[8];
     const unsigned long long st_staged = __builtin_amdgcn_s_memtime();
     int bid = 0;
-#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); if constexpr (WAVES == 8 && W == PUBW) pub_step(bid); bid++;
+#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); if constexpr (W == PUBW) pub_step(bid); bid++;
 #else
     int bid = 0;
-#define DEV_BARRIER lds_barrier(); if constexpr (WAVES == 8 && W == PUBW) pub_step(bid); bid++;
+#define DEV_BARRIER lds_barrier(); if constexpr (W == PUBW) pub_step(bid); bid++;
 #endif
     auto run_wave = [&](auto wc) __attribute__((always_inline)) {
         constexpr int W = decltype(wc)::value;
@@ -405,7 +413,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     for (int it = 0; it < G_ITERS; ++it) bad |= (ga[it] >= 0) & !isfinite(gvals[it]);
 #pragma unroll
     for (int it = 0; it < GR_ITERS; ++it) bad |= ((tid + it * WG) < NXK) & !isfinite(grvals[it]);
-    if (WAVES == 8) { if (wave == PUBW) bad |= pub_bad; }
+    if (a.cost_pub) { if (wave == PUBW) bad |= pub_bad; }
     else if (tid < NCT) {
         const double cval = s.cost[tid];
         bad |= !isfinite(cval);
@@ -663,6 +671,7 @@ struct hipnlp_handle {
     KinTables kt;
     int batch = 1, kb = 0, ke = 0, nk = 0, np = 0;
     bool wide = false;   // eight-wave kernel variant (launches that are resident at once at two workgroups per CU)
+    bool fused = false;  // the total cost is summed inside the knot launch by one reducer workgroup per trajectory (knots <= 256)
     int dev = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -762,6 +771,11 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
         // batch 2 .. 5, nothing once the launch exceeds the 512 slots (batch 6: 36.9 against 38.0 M knots/s).
         const bool fits = h->nk <= 256 && (long(h->nk) + 1) * long(desc->batch) <= 512;
         h->wide = force ? (std::atoi(force) == 8 && h->nk <= 256) : fits;
+        const char* sep = std::getenv("HIPNLP_SEPARATE_REDUCE");   // diagnostic override: the reduction kernel behind the four-wave kernel
+        // (measured, four-wave kernel, N = 100: + 2.4 % at x 64 and + 6.5 % on the stairs 200 x 16, whose second launch is 3 of 53 us;
+        //  - 1.1 % at x 1024, where ten rows are in flight and as many reducers spin in workgroup slots: long launches keep the kernel)
+        const bool small_launch = long(h->nk) * long(desc->batch) <= 32768;
+        h->fused = h->nk <= 256 && (h->wide || (small_launch && !(sep && std::atoi(sep) == 1)));
     }
     std::string e;
     if (!Layout::make_kin_tables(desc->model, h->kt, e)) return fail(HIPNLP_E_INVALID, e);
@@ -929,7 +943,7 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     } else {
         a.jac_stride = h->L.nnz; a.jac_off = 0; a.grad_stride = h->L.n; a.grad_off = 0;
     }
-    a.cost_knot = h->d_cost_knot; a.f = f_dev; a.cost_pub = h->d_cost_pub; a.flag = h->d_flag;
+    a.cost_knot = h->d_cost_knot; a.f = f_dev; a.cost_pub = h->fused ? h->d_cost_pub : nullptr; a.flag = h->d_flag;
     // host-buffer path: per-term costs (96 B per trajectory) and the non-finite flag go straight to the pinned block
     a.cost_terms = host_block ? h->hd_cost_terms : h->d_cost_terms;
     a.flag_host = host_block ? h->hd_flag : nullptr;
@@ -951,7 +965,7 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     a.stamps = h->d_stamps;
 #endif
     if (timed) HIP_TRY(h, hipEventRecord(e0, s));
-    const dim3 grid(unsigned(h->nk) + (h->wide ? 1u : 0u), unsigned(h->batch));   // (eight-wave variant: + the row's cost reducer)
+    const dim3 grid(unsigned(h->nk) + (h->fused ? 1u : 0u), unsigned(h->batch));   // (+ the row's cost reducer)
     const bool planar = h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR;
     if (h->wide) {   // the whole launch resident at once: eight waves per knot
         if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
@@ -961,7 +975,7 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
         else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 4>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 1)], s));
-    if (!h->wide)
+    if (!h->fused)
         hipLaunchKernelGGL(hipnlp_reduce_kernel, dim3(unsigned(h->batch)), dim3(RWG), 0, s, (const double*)h->d_cost_knot, h->nk, f_dev, a.cost_terms);
     if (timed) HIP_TRY(h, hipEventRecord(e2, s));
     if (run_last) {
@@ -1351,7 +1365,7 @@ int hipnlp_reassemble(const double* gathered_dev, const int64_t* src_dev, double
     return hipGetLastError() == hipSuccess ? HIPNLP_OK : HIPNLP_E_NODEVICE;
 }
 
-int hipnlp_kernels_per_eval(const hipnlp_handle* h) { return h ? (h->wide ? 1 : 2) : HIPNLP_E_INVALID; }
+int hipnlp_kernels_per_eval(const hipnlp_handle* h) { return h ? (h->fused ? 1 : 2) : HIPNLP_E_INVALID; }
 
 int hipnlp_profile_end(hipnlp_handle* h, double* mean_knot_kernel_ms, double* mean_launch_ms, int* count) {
     if (!h) return HIPNLP_E_INVALID;

@@ -304,9 +304,9 @@ int hipnlp_profile_end(hipnlp_handle* h, double* mean_knot_kernel_ms, double* me
  * in between); profile_end then returns the mean duration per launch of the runs (dispatch gaps between the launches of a run
  * included) and the number of launches measured.  For launches so short that an event pair around each would dominate. */
 int hipnlp_profile_begin_runs(hipnlp_handle* h, int max_runs, int run_len);
-/* Kernel launches behind one device-path evaluation: 1 (latency variant: launches whose workgroups — one per knot, plus one cost
- * reducer per trajectory — are all resident at once, (knots + 1) x batch <= 512 and knots <= 256; the cost is summed inside the knot
- * kernel) or 2 (throughput variant: knot kernel + cost reduction kernel). */
+/* Kernel launches behind one device-path evaluation: 1 (trajectories of at most 256 knots in launches of at most 32768 knots: the
+ * cost is summed inside the knot launch by one reducer workgroup per trajectory) or 2 (otherwise: knot kernel + cost reduction
+ * kernel). */
 int hipnlp_kernels_per_eval(const hipnlp_handle* h);
 
 /* =====================================================================================================================

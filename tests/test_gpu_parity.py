@@ -310,6 +310,20 @@ def test_in_launch_reduction_stress(model, HipNlp):
     eng.eval(x, want=("f",))
     _, t1 = eng.cost_terms()
     assert np.array_equal(t0, t1)
+    # the reducer workgroup inside the launch and the separate reduction kernel (kept for long trajectories / launches) sum in the
+    # same fixed tree: bitwise the same f and per-term costs
+    assert eng.kernels_per_eval() == 1
+    import os
+    os.environ["HIPNLP_SEPARATE_REDUCE"] = "1"
+    try:
+        sep = HipNlp(st, model, batch=batch)
+    finally:
+        del os.environ["HIPNLP_SEPARATE_REDUCE"]
+    assert sep.kernels_per_eval() == 2
+    sep.set_params(p)
+    fsep, *_ = sep.eval(x, want=("f",))
+    _, tsep = sep.cost_terms()
+    assert np.array_equal(fsep, f0) and np.array_equal(tsep, t0)
     from oracle_lib import Oracle
     orc = Oracle(st, model)
     for b in (0, 37, 95):
@@ -517,16 +531,15 @@ def test_host_sink_shards_store_into_one_registered_buffer(model, HipNlp):
 
 
 def test_profile_runs_and_kernel_count(model, HipNlp):
-    """hipnlp_kernels_per_eval (1 while (knots + 1) x batch <= 512, 2 beyond) and the run-bracketed event timing."""
+    """hipnlp_kernels_per_eval (1 up to 256 knots per trajectory in launches of up to 32768 knots, 2 beyond) and the run-bracketed event timing."""
     import torch
     st = periodic_step_settings(12, model)
     x, p = make_workload(st, model, batch=1, seed=3)
     small = HipNlp(st, model)
     small.set_params(p)
     assert small.kernels_per_eval() == 1
-    assert HipNlp(st, model, batch=32).kernels_per_eval() == 1   # 13 x 32 workgroups: two per CU
-    big = HipNlp(st, model, batch=64)
-    assert big.kernels_per_eval() == 2
+    assert HipNlp(st, model, batch=64).kernels_per_eval() == 1   # (the cost is summed by a reducer workgroup per trajectory)
+    assert HipNlp(periodic_step_settings(300, model), model).kernels_per_eval() == 2   # more than 256 knots per trajectory
     dev = torch.device("cuda", 0)
     xd = torch.from_numpy(x).to(dev)
     outs = [torch.empty(k, dtype=torch.float64, device=dev) for k in (1, small.n, small.m, small.nnz)]
