@@ -1137,7 +1137,7 @@ int hipnlp_stage_rows(const hipnlp_handle* h, int k, int32_t* rows) {
 // A NEW evaluation: x is copied into the pinned staging block (the kernel reads it from there), ONE kernel launch evaluates all four
 // outputs; the ones in want | prefetch are stored by the kernel straight into the pinned block (PCIe stores, no copy command, no
 // staging copy), the others stay in device memory.  A cached evaluation (new_x = 0): outputs not on the host yet are fetched from
-// the device copies with one asynchronous copy each.  (Measured on MI355X, profiles/r02_pcie_probe.txt: launch + synchronise 11.6 us;
+// the device copies with one asynchronous copy each.  (Measured on MI355X, profiles/r02_pcie_probe.txt: launch + synchronise 13 us;
 // kernel stores to pinned memory 56 GB/s; the same bytes through device memory + hipMemcpyAsync: + 10 us.)
 struct HostDest {   // registered caller arrays: device-visible addresses (or null) and the host addresses they belong to
     double *f = nullptr, *grad = nullptr, *g = nullptr, *jac = nullptr;

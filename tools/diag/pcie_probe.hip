@@ -16,7 +16,7 @@
 
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// spin `cycles` of s_memtime (emulates the knot program), then every workgroup streams `per_wg` doubles to out (coalesced), and
+// spin `cycles` ticks of the 100 MHz real-time counter (emulates the knot program), then every workgroup streams `per_wg` doubles to out (coalesced), and
 // optionally reads `rd_per_wg` doubles of x first; the last workgroup to finish raises *flag = seq (system scope)
 __global__ __launch_bounds__(512) void work_kernel(const double* x, int rd_per_wg, double* out, long per_wg, long cycles, unsigned* counter,
                                                    volatile int* flag, int seq, int scatter_run) {
@@ -28,8 +28,8 @@ __global__ __launch_bounds__(512) void work_kernel(const double* x, int rd_per_w
         __syncthreads();
         acc = sx[(threadIdx.x + 1) & 511];
     }
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    while (long(__builtin_amdgcn_s_memtime() - t0) < cycles) { }
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // (100 MHz; s_memtime counts shader clocks)
+    while (long(__builtin_amdgcn_s_memrealtime() - t0) < cycles) { }
     double* o = out + size_t(blockIdx.x) * per_wg;
     if (scatter_run <= 0) {
         for (long i = threadIdx.x; i < per_wg; i += blockDim.x) o[i] = acc + double(i);
@@ -88,7 +88,7 @@ int main() {
     for (size_t i = 0; i < NX * 2; ++i) h_x[i] = double(i);
     *h_flag = 0;
     int seq = 0;
-    const long CYC = 800;   // s_memtime ticks at 100 MHz: 8 us of "knot program"
+    const long CYC = 800;   // ticks of the 100 MHz real-time counter: 8 us of "knot program"
 
     std::printf("== launch + completion\n");
     std::printf("empty kernel + hipStreamSynchronize            %7.1f us\n", median_us(REPS, [&] {
