@@ -14,8 +14,10 @@ N > 1 : one rank per GPU.  `python bench.py --gpus N` started WITHOUT torch.dist
         is one of the ranks.  `value` is north_star's path: ONE trajectory whose horizon grows with N (100 knots per GPU, weak
         scaling), shooting intervals sharded contiguously, every step ending with ONE RCCL all-gather of the fused shard buffers + the
         one-launch reassembly of [grad f | jac g | g] in reference order on every rank.  Beside it: `independent_trajectories` (N
-        replicas, no collective — BASELINE config 5's batched-guess shape) and `host_sink` (no collective either: every rank's kernel
-        stores its shard straight into ONE shared pinned host buffer, what a CPU-side IPOPT consumes).
+        replicas, no collective — BASELINE config 5's batched-guess shape), `peer_store` (the same reassembled outputs on every
+        rank by plain stores over xGMI into IPC-shared buffers + flags: no collective, no reassembly pass; checked bit for bit
+        against the all-gather path before it is timed) and `host_sink` (no collective either: every rank's kernel stores its
+        shard straight into ONE shared pinned host buffer, what a CPU-side IPOPT consumes).
 The JSON line carries `roofline` (HIP-event timed knot kernel vs the 8 TB/s HBM peak, plus the fp64 VALU-issue ceiling) and
 `cpu_baseline` (rank 0, N = 1 only).
 """
@@ -388,6 +390,42 @@ def main():
             e2 = max_over_ranks(time.perf_counter() - t1)
         res["shard_resident"] = {"knots_per_s": hz * ksteps / e2, "ms_per_step": 1e3 * e2 / ksteps, "steps": ksteps,
                                  "note": "knot shards evaluated, outputs left shard-resident in each rank's HBM (no all-gather / reassembly)"}
+        # beside it: the same reassembled outputs on every rank by peer stores over xGMI instead of all-gather + reassembly
+        # (sharded.PeerExchange); checked bit for bit against the collective's result on every rank before it is timed
+        try:
+            from hippopt_amd.sharded import PeerExchange
+            px = PeerExchange(cb)
+            with torch.cuda.stream(cb.stream):
+                ref = [t.clone() for t in cb(xs[1 % nvar])]
+                got = [t.clone() for t in px(xs[1 % nvar])]
+                got2 = [t.clone() for t in px(xs[1 % nvar])]          # the other buffer parity
+            fence()
+            same = all(torch.equal(a, b_) and torch.equal(a, c_) for a, b_, c_ in zip(ref, got, got2)) and not px.timed_out()
+            flags = torch.tensor([1.0 if same else 0.0], device=device)
+            if world > 1:
+                if dist.get_backend() == "gloo":
+                    fl = flags.cpu(); dist.all_reduce(fl, op=dist.ReduceOp.MIN); flags = fl
+                else:
+                    dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+            if float(flags[0]) != 1.0:
+                raise RuntimeError("peer exchange differs from the all-gather path on some rank")
+            with torch.cuda.stream(cb.stream):
+                for i in range(min(warmup, 50)):
+                    px(xs[i % nvar])
+                fence()
+                t1 = time.perf_counter()
+                for i in range(ksteps):
+                    px(xs[i % nvar])
+                fence()
+                e4 = max_over_ranks(time.perf_counter() - t1)
+            late = px.timed_out()
+            res["peer_store"] = {"knots_per_s": hz * ksteps / e4, "ms_per_step": 1e3 * e4 / ksteps, "steps": ksteps, "timed_out": bool(late),
+                                 "verified": "bitwise equal to the all-gather path on every rank, both buffer parities",
+                                 "note": "no collective, no reassembly pass: every rank pushes its shard, entry by entry at its final position, into "
+                                         "the [grad | jac | g | f] buffer of EVERY rank with plain stores over xGMI (HIP IPC), then flags"}
+            px.close()
+        except Exception as err:  # noqa: BLE001  (an extra measurement must not take `value` down with it)
+            res["peer_store"] = {"error": "%s: %s" % (type(err).__name__, err)}
         # beside it: no collective, every rank's kernel stores its shard straight into ONE shared pinned host buffer
         try:
             name = "hipnlp_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid() if world > 1 else os.getpid())
@@ -433,7 +471,7 @@ def main():
                 r = run_knot_sharded(max(1, min(args.steps, 500)), min(args.warmup, 50))
                 k = max(1, min(args.steps, 500))
                 side = {"knots_per_s": r["knots_per_step"] * k / r["el"], "ms_per_step": 1e3 * r["el"] / k, "parallelism": r["parallelism"],
-                        "shard_resident": r.get("shard_resident"), "host_sink": r.get("host_sink")}
+                        "shard_resident": r.get("shard_resident"), "peer_store": r.get("peer_store"), "host_sink": r.get("host_sink")}
             except Exception as err:  # noqa: BLE001
                 side = {"error": "%s: %s" % (type(err).__name__, err)}
 
@@ -492,7 +530,7 @@ def main():
                                         "frac": ginst / VALU_PEAK_GINST, "valu_wave_insts_per_knot": valu,
                                         "source": "SQ_INSTS_VALU per launch from profiles/traffic.json (separate rocprofv3 --pmc pass) x this run's kernel rate; "
                                                   "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 issue cycles per wave64 instruction"}
-        for key in ("shard_resident", "host_sink"):
+        for key in ("shard_resident", "peer_store", "host_sink"):
             if main_res.get(key) is not None:
                 line[key] = main_res[key]
         if side is not None:

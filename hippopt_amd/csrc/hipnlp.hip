@@ -1365,6 +1365,90 @@ int hipnlp_reassemble(const double* gathered_dev, const int64_t* src_dev, double
     return hipGetLastError() == hipSuccess ? HIPNLP_OK : HIPNLP_E_NODEVICE;
 }
 
+// ---- peer exchange without a collective (include/hipnlp.h) ----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hipnlp_peer_push_kernel(const double* __restrict__ shard, const int64_t* __restrict__ dst, int64_t count,
+                                                               double* const* __restrict__ peer_out, int world) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const int64_t d = dst[i];
+        if (d < 0) continue;
+        const double v = shard[i];
+        for (int r = 0; r < world; ++r) peer_out[r][d] = v;   // (consecutive lanes: consecutive addresses on every link)
+    }
+}
+__global__ void hipnlp_peer_signal_kernel(unsigned long long* const* peer_flags, int world, int rank, unsigned long long seq) {
+    __threadfence_system();   // (the push kernel ended before this one started: its stores are performed; ordered before the flags system-wide)
+    const int r = threadIdx.x;
+    if (r < world) __hip_atomic_store(peer_flags[r] + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void hipnlp_peer_wait_kernel(const unsigned long long* flags, int world, unsigned long long seq, double* out, int64_t f_off, int* status) {
+    const int r = threadIdx.x;
+    int late = 0;
+    if (r < world) {
+        int spins = 0;
+        while (__hip_atomic_load(flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            if (++spins > (1 << 20)) { late = 1; break; }   // (a rank that died must not hang this device)
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    late = __any(late);
+    __threadfence_system();
+    if (r == 0) {
+        double f = 0.0;
+        for (int q = 0; q < world; ++q) f += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(out + f_off + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        out[f_off + world] = late ? __builtin_nan("") : f;
+        *status = late;
+    }
+}
+
+int hipnlp_ipc_alloc(size_t bytes, int device, void** dev_ptr, void* handle_out) {
+    if (!dev_ptr || !handle_out || bytes == 0) return HIPNLP_E_INVALID;
+    static_assert(sizeof(hipIpcMemHandle_t) == HIPNLP_IPC_HANDLE_BYTES, "IPC handle size");
+    if (hipSetDevice(device) != hipSuccess) return HIPNLP_E_NODEVICE;
+    void* p = nullptr;
+    // uncached / fine-grained: a peer's stores must not meet stale lines in this device's L2 (what RCCL does for its own buffers)
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return HIPNLP_E_NODEVICE; }
+    }
+    if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return HIPNLP_E_NODEVICE; }
+    hipIpcMemHandle_t hnd;
+    if (hipIpcGetMemHandle(&hnd, p) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return HIPNLP_E_NODEVICE; }
+    std::memcpy(handle_out, &hnd, sizeof hnd);
+    *dev_ptr = p;
+    return HIPNLP_OK;
+}
+int hipnlp_ipc_open(const void* handle, int device, void** dev_ptr) {
+    if (!handle || !dev_ptr) return HIPNLP_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return HIPNLP_E_NODEVICE;
+    hipIpcMemHandle_t hnd;
+    std::memcpy(&hnd, handle, sizeof hnd);
+    void* p = nullptr;
+    if (hipIpcOpenMemHandle(&p, hnd, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return HIPNLP_E_NODEVICE; }
+    *dev_ptr = p;
+    return HIPNLP_OK;
+}
+int hipnlp_ipc_close(void* dev_ptr) { return dev_ptr && hipIpcCloseMemHandle(dev_ptr) == hipSuccess ? HIPNLP_OK : HIPNLP_E_INVALID; }
+int hipnlp_ipc_free(void* dev_ptr) { return dev_ptr && hipFree(dev_ptr) == hipSuccess ? HIPNLP_OK : HIPNLP_E_INVALID; }
+
+int hipnlp_peer_push(const double* shard_dev, const int64_t* dst_dev, int64_t count, double* const* peer_out_dev, int world, void* stream) {
+    if (!shard_dev || !dst_dev || !peer_out_dev || count < 0 || world < 1) return HIPNLP_E_INVALID;
+    const int64_t blocks = (count + 255) / 256;
+    const unsigned grid = unsigned(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks));
+    hipLaunchKernelGGL(hipnlp_peer_push_kernel, dim3(grid), dim3(256), 0, hipStream_t(stream), shard_dev, dst_dev, count, peer_out_dev, world);
+    return hipGetLastError() == hipSuccess ? HIPNLP_OK : HIPNLP_E_NODEVICE;
+}
+int hipnlp_peer_signal(unsigned long long* const* peer_flags_dev, int world, int rank, unsigned long long seq, void* stream) {
+    if (!peer_flags_dev || world < 1 || world > 64 || rank < 0 || rank >= world) return HIPNLP_E_INVALID;
+    hipLaunchKernelGGL(hipnlp_peer_signal_kernel, dim3(1), dim3(64), 0, hipStream_t(stream), peer_flags_dev, world, rank, seq);
+    return hipGetLastError() == hipSuccess ? HIPNLP_OK : HIPNLP_E_NODEVICE;
+}
+int hipnlp_peer_wait(const unsigned long long* flags_dev, int world, unsigned long long seq, double* out_dev, int64_t f_off, int* status_dev, void* stream) {
+    if (!flags_dev || !out_dev || !status_dev || world < 1 || world > 64) return HIPNLP_E_INVALID;
+    hipLaunchKernelGGL(hipnlp_peer_wait_kernel, dim3(1), dim3(64), 0, hipStream_t(stream), flags_dev, world, seq, out_dev, f_off, status_dev);
+    return hipGetLastError() == hipSuccess ? HIPNLP_OK : HIPNLP_E_NODEVICE;
+}
+
 int hipnlp_kernels_per_eval(const hipnlp_handle* h) { return h ? (h->fused ? 1 : 2) : HIPNLP_E_INVALID; }
 
 int hipnlp_profile_end(hipnlp_handle* h, double* mean_knot_kernel_ms, double* mean_launch_ms, int* count) {

@@ -7,6 +7,10 @@ Two ways to hand the shards' outputs to the consumer of the callback:
   CPU tests) of a fused per-rank output buffer, then ONE launch (hipnlp_reassemble) that writes [grad f | jac values | g] in the
   reference's order on every rank.  Fused shard buffer of rank r (all ranks use the same padded length, the all-gather is regular):
       [ f partial (1) | grad shard (glen_max) | jac shard (jlen_max) | g staging (nk_max * G_STAGE) ]
+* `PeerExchange` — the same result as `ShardedCallback` without a collective and without a reassembly pass: every rank pushes its
+  fused shard buffer, entry by entry at its final position, into the output buffer of EVERY rank with plain stores over xGMI
+  (buffers shared through HIP IPC handles), then raises a flag on every rank; torch.distributed only moves the 64-byte handles
+  once, at set-up.
 * `HostSink` — SURVEY §5's alternative for a CPU-side IPOPT: no collective at all.  Every rank's knot kernel stores its shard of
   g / jac / grad f straight into ONE shared, pinned host buffer (a POSIX shared-memory segment every rank maps and registers with the
   HIP runtime), already in the reference's order; rank partial costs land in f_parts[rank] and are summed in rank order.
@@ -155,6 +159,131 @@ class ShardedCallback:
         with torch.cuda.stream(self.stream):
             self.compute_shard(x, *self.views, self.stream.cuda_stream)
         cur.wait_stream(self.stream)
+
+
+class PeerExchange:
+    """The reassembled [grad | jac | g | f] of `ShardedCallback` on every rank by peer stores instead of all-gather + reassembly
+    (include/hipnlp.h, "the same exchange WITHOUT a collective").  Built on a ShardedCallback (same shard buffer, same tiling):
+
+        px = PeerExchange(cb)
+        f, grad, jac, g = px(x)          # views of this rank's output buffer of the step's parity
+
+    Two output buffers alternate between steps: a rank starts pushing step i + 1 once every rank has signalled step i, i.e. has
+    finished its own push of step i — at which point a slow rank may still be READING step i, so step i + 1 goes to the other
+    buffer (and step i + 2 cannot start before everyone has signalled i + 1, which comes behind their use of step i in stream order).
+    The caller orders its consumption of the views before its next call on the same stream, as with ShardedCallback."""
+
+    def __init__(self, cb):
+        import ctypes as C
+        if cb.device.type != "cuda":
+            raise RuntimeError("PeerExchange needs the HIP engine (peer stores between device buffers)")
+        self.cb = cb
+        self.world, self.rank = cb.world, cb.rank
+        lib = cb._lib
+        self._lib = lib
+        vp, i64 = C.c_void_p, C.c_int64
+        lib.hipnlp_ipc_alloc.argtypes = [C.c_size_t, C.c_int, C.POINTER(vp), C.c_char_p]
+        lib.hipnlp_ipc_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+        lib.hipnlp_ipc_close.argtypes = [vp]
+        lib.hipnlp_ipc_free.argtypes = [vp]
+        lib.hipnlp_peer_push.argtypes = [vp, vp, i64, vp, C.c_int, vp]
+        lib.hipnlp_peer_signal.argtypes = [vp, C.c_int, C.c_int, C.c_ulonglong, vp]
+        lib.hipnlp_peer_wait.argtypes = [vp, C.c_int, C.c_ulonglong, vp, i64, vp, vp]
+        self.tot = cb.n + cb.nnz + cb.m
+        self.olen = self.tot + self.world + 1             # [grad | jac | g | f partials (world) | f]
+        dev_index = cb.device.index if cb.device.index is not None else torch.cuda.current_device()
+        self.dev_index = dev_index
+        # this rank's buffers: two output buffers and one flag array, in ONE allocation (one IPC handle)
+        self.flag_words = 64
+        nbytes = 8 * (2 * self.olen + self.flag_words)
+        mine = vp()
+        handle = C.create_string_buffer(64)
+        if lib.hipnlp_ipc_alloc(C.c_size_t(nbytes), dev_index, C.byref(mine), handle) != 0:
+            raise RuntimeError("hipnlp_ipc_alloc failed")
+        self._mine = mine.value
+        handles = [None] * self.world
+        if self.world > 1:
+            dist.all_gather_object(handles, bytes(handle.raw), group=cb.group)
+        else:
+            handles = [bytes(handle.raw)]
+        self._opened = []
+        bases = []
+        for r in range(self.world):
+            if r == self.rank:
+                bases.append(self._mine)
+                continue
+            p = vp()
+            if lib.hipnlp_ipc_open(handles[r], dev_index, C.byref(p)) != 0:
+                raise RuntimeError("hipnlp_ipc_open failed for the buffer of rank %d" % r)
+            self._opened.append(p.value)
+            bases.append(p.value)
+        dev = cb.device
+        # device arrays of pointers: output buffer of every rank per parity, flag array of every rank
+        self.peer_out = [torch.tensor([b + 8 * par * self.olen for b in bases], dtype=torch.int64, device=dev) for par in (0, 1)]
+        self.peer_flags = torch.tensor([b + 8 * 2 * self.olen for b in bases], dtype=torch.int64, device=dev)
+        self.my_flags = self._mine + 8 * 2 * self.olen
+        # destination of every entry of MY fused shard buffer in the output buffer (the inverse of the reassembly index)
+        src = cb.src.cpu().numpy()
+        dst = np.full(cb.shard_len, -1, dtype=np.int64)
+        lo, hi = self.rank * cb.shard_len, (self.rank + 1) * cb.shard_len
+        own = np.nonzero((src >= lo) & (src < hi))[0]
+        dst[src[own] - lo] = own
+        dst[0] = self.tot + self.rank                    # the cost partial
+        self.dst = torch.from_numpy(dst).to(dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.seq = 0
+        self._views = []
+        for par in (0, 1):   # torch views of this rank's own output buffers
+            self._views.append(_device_view(self._mine + 8 * par * self.olen, self.olen, dev))
+        if self.world > 1:
+            dist.barrier(group=cb.group)                  # every rank has opened every buffer
+
+    def __call__(self, x):
+        cb = self.cb
+        cur = torch.cuda.current_stream(cb.device)
+        if cur.cuda_stream != cb.stream.cuda_stream:
+            cb.stream.wait_stream(cur)
+        with torch.cuda.stream(cb.stream):
+            sh = cb.stream.cuda_stream
+            cb.compute_shard(x, *cb.views, sh)
+            self.seq += 1
+            par = self.seq & 1
+            lib = self._lib
+            rc = lib.hipnlp_peer_push(cb.buf.data_ptr(), self.dst.data_ptr(), cb.shard_len, self.peer_out[par].data_ptr(), self.world, sh)
+            rc |= lib.hipnlp_peer_signal(self.peer_flags.data_ptr(), self.world, self.rank, self.seq, sh)
+            out = self._views[par]
+            rc |= lib.hipnlp_peer_wait(self.my_flags, self.world, self.seq, out.data_ptr(), self.tot, self.status.data_ptr(), sh)
+            if rc != 0:
+                raise RuntimeError("peer exchange: a launch failed")
+        if cur.cuda_stream != cb.stream.cuda_stream:
+            cur.wait_stream(cb.stream)
+        n, nnz = cb.n, cb.nnz
+        return out[self.tot + self.world], out[:n], out[n:n + nnz], out[n + nnz:self.tot]
+
+    def timed_out(self):
+        """True if a wait gave up (a rank never signalled): synchronises the callback's stream"""
+        self.cb.stream.synchronize()
+        return bool(self.status.item())
+
+    def close(self):
+        if getattr(self, "_mine", None):
+            self.cb.stream.synchronize()
+            if self.world > 1:
+                dist.barrier(group=self.cb.group)         # nobody still pushes into a buffer about to go
+            for p in self._opened:
+                self._lib.hipnlp_ipc_close(p)
+            self._views = []
+            self._lib.hipnlp_ipc_free(self._mine)
+            self._mine = None
+
+
+def _device_view(ptr, count, device):
+    """float64 torch view of `count` doubles of device memory that torch did not allocate (the owner keeps it alive)"""
+    class _Holder:
+        pass
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+    return torch.as_tensor(h, device=device)
 
 
 def hip_shard_backend(engine):

@@ -279,6 +279,30 @@ int hipnlp_stage_rows(const hipnlp_handle* h, int k, int32_t* rows /*[HIPNLP_G_S
 int hipnlp_reassemble(const double* gathered_dev, const int64_t* src_dev, double* out_dev, int64_t count, int world, int64_t shard_len,
                       double* f_out_dev, void* stream);
 
+/* ---- the same exchange WITHOUT a collective: peer stores over xGMI (one process per GPU) ----------------------------
+ * xGMI is point to point: instead of a ring all-gather followed by a reassembly pass, every rank pushes its fused shard buffer —
+ * entry by entry, already at its position in the reference's order — into the output buffer of EVERY rank (its own included) with
+ * one kernel of plain stores, then raises its flag in every rank's flag array; a rank's outputs are complete when all `world` flags
+ * carry the step number.  The buffers live in fine-grained device memory shared through HIP IPC handles (64 bytes each, moved
+ * between the processes by any channel: hippopt_amd/sharded.py uses torch.distributed's object gather once, at set-up); nothing here
+ * depends on torch or RCCL.  All calls are enqueued on `stream` of the CURRENT device and not synchronised.
+ *   hipnlp_ipc_alloc   fine-grained (uncached) device memory on `device`, zeroed, + its IPC handle
+ *   hipnlp_ipc_open    maps a peer's allocation into this process (enables peer access to its device on demand)
+ *   hipnlp_peer_push   peer_out[r][dst[i]] = shard[i] for every rank r and every i < count with dst[i] >= 0 (peer_out: a DEVICE array
+ *                      of `world` device pointers)
+ *   hipnlp_peer_signal system-scope fence, then peer_flags[r][rank] = seq for every r (peer_flags: device array of world pointers)
+ *   hipnlp_peer_wait   spins (bounded: *status_dev = 1 after ~2^20 polls — seconds —, 0 otherwise) until flags[r] >= seq for all r, then
+ *                      out[f_off + world] = sum over r, in rank order, of out[f_off + r] (the cost partials)                        */
+#define HIPNLP_IPC_HANDLE_BYTES 64
+int hipnlp_ipc_alloc(size_t bytes, int device, void** dev_ptr, void* handle_out /*[HIPNLP_IPC_HANDLE_BYTES]*/);
+int hipnlp_ipc_open(const void* handle /*[HIPNLP_IPC_HANDLE_BYTES]*/, int device, void** dev_ptr);
+int hipnlp_ipc_close(void* dev_ptr);
+int hipnlp_ipc_free(void* dev_ptr);
+int hipnlp_peer_push(const double* shard_dev, const int64_t* dst_dev, int64_t count, double* const* peer_out_dev, int world, void* stream);
+int hipnlp_peer_signal(unsigned long long* const* peer_flags_dev, int world, int rank, unsigned long long seq, void* stream);
+int hipnlp_peer_wait(const unsigned long long* flags_dev, int world, unsigned long long seq, double* out_dev, int64_t f_off,
+                     int* status_dev, void* stream);
+
 /* Per-named-cost values of the last evaluation (Output.cost_values, base/problem.py:28-56):
  * values[batch][HIPNLP_NCOST_TERMS], summed over knots, in the order of hipnlp_cost_term_name(). */
 #define HIPNLP_NCOST_TERMS 12

@@ -444,6 +444,58 @@ def test_sharded_callback_reassembly_on_gpu(model, HipNlp):
         assert np.array_equal(grads.cpu().numpy(), grad[0]) and np.array_equal(jacs.cpu().numpy(), jac[0]) and np.array_equal(gs.cpu().numpy(), g[0])
 
 
+def test_peer_exchange_equals_the_gathered_callback(model, HipNlp):
+    """PeerExchange (peer stores into IPC-shared output buffers + flags, no collective, no reassembly pass) at world size 1: the
+    rank pushes into its own buffer; bitwise the unsharded callback, on alternating iterates and both buffer parities."""
+    import torch
+    from hippopt_amd.sharded import PeerExchange, ShardedCallback, hip_shard_backend, hip_shard_info
+    N = 24
+    st = periodic_step_settings(N, model)
+    x, p = make_workload(st, model, batch=1, seed=78)
+    full = HipNlp(st, model)
+    full.set_params(p)
+    dev = torch.device("cuda", 0)
+    sh = HipNlp(st, model, knot_begin=0, knot_end=N)
+    sh.set_params(p)
+    cb = ShardedCallback(N, sh.n, sh.m, sh.nnz, hip_shard_info(sh, 0, N), hip_shard_backend(sh), dev)
+    px = PeerExchange(cb)
+    rng = np.random.RandomState(5)
+    xs = [x[0] + 1e-2 * i * rng.standard_normal(x.shape[1]) for i in range(5)]
+    got = []
+    for xi in xs:
+        fs, grads, jacs, gs = px(torch.from_numpy(xi).to(dev))
+        got.append((fs.clone(), grads.clone(), jacs.clone(), gs.clone()))
+    assert not px.timed_out()
+    for xi, (fs, grads, jacs, gs) in zip(xs, got):
+        f, grad, g, jac = full.eval(xi[None, :])
+        assert float(fs) == f[0]
+        assert np.array_equal(grads.cpu().numpy(), grad[0]) and np.array_equal(jacs.cpu().numpy(), jac[0]) and np.array_equal(gs.cpu().numpy(), g[0])
+    px.close()
+
+
+def test_two_ranks_on_one_gpu_rehearsal():
+    """`bench.py --gpus 2` as the driver starts it, with both ranks on device 0 and gloo as the rendezvous (BENCH_REHEARSAL=1: RCCL
+    refuses two ranks on one device).  Not a measurement: it runs the N > 1 code paths across two PROCESSES — self-spawned ranks,
+    the knot-sharded all-gather path as `value`, the peer exchange (IPC handles opened by the other process, flags, both buffer
+    parities: checked bit for bit against the all-gather result inside bench.py) and the shared host sink."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5", "--no-cpu-baseline",
+                          "--no-hessian", "--no-host"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    side = {k: line.get(k) or line["config"].get(k) for k in ("peer_store", "host_sink", "shard_resident")}
+    assert side["peer_store"] and "error" not in side["peer_store"], side["peer_store"]
+    assert side["peer_store"]["verified"].startswith("bitwise") and not side["peer_store"]["timed_out"]
+    assert side["host_sink"] and "error" not in side["host_sink"], side["host_sink"]
+
+
 def test_host_path_want_mask_lazy_fetch_and_views(model, HipNlp):
     """hipnlp_eval / hipnlp_eval_pinned: the kernel stores the wanted outputs straight into the pinned block; the others stay in
     HBM and are fetched when a later new_x = 0 call asks.  Every combination must return exactly the values of one full evaluation
