@@ -523,37 +523,58 @@ template <int TERRAIN> __global__ __launch_bounds__(256) __attribute__((amdgpu_w
     const double* x = a.x + size_t(b) * a.n;
     const DeviceTables& tb = *a.tb;
     {
-        constexpr int HV = int(sizeof(HeadTables) / 16), GV = int(sizeof(GParams) / 8);
-        const uint4* hsrc = reinterpret_cast<const uint4*>(&tb.head);
-        uint4* hdst = reinterpret_cast<uint4*>(&tabs.head);
-        for (int i = tid; i < HV; i += WG) hdst[i] = hsrc[i];
-        const double* gsrc = reinterpret_cast<const double*>(a.gp + b);
-        double* gdst = reinterpret_cast<double*>(&tabs.gp);
-        for (int i = tid; i < GV; i += WG) gdst[i] = gsrc[i];
-        for (int i = tid; i < XPAD; i += WG) {
-            const bool in = i < NXK;
-            s.x[i] = in ? x[size_t(NXK) * k + i] : 0.0;
-            s.xm[i] = (in && !first) ? x[size_t(NXK) * (k - 1) + i] : 0.0;
-        }
-        for (int i = tid; i < NPER; i += WG) s.xo[i] = (first || last) ? x[size_t(NXK) * (first ? N - 1 : 0) + periodicity_row_var(i)] : 0.0;
-        if (tid < PK_STRIDE) s.pk[tid] = a.pk[(size_t(b) * N + k) * PK_STRIDE + tid];
-        if (tid < 8) s.xg[tid] = tid < NXG ? x[size_t(NXK) * N + tid] : 0.0;
+        // staged as in hipnlp_knot_kernel: records and tables straight from global memory into LDS, 1 KB chunks dealt over the waves
+        constexpr int WAVES = WG / 64;
+        constexpr int XB = NXK * 8 / 16 * 16, XREM = NXK - XB / 8;
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        int rot = 0;
+        auto stage = [&](const void* src, void* dst, int bytes) __attribute__((always_inline)) {
+            for (int r0 = 0; r0 < bytes; r0 += WG * 16) {
+                const int wv = (wave_u + WAVES - rot % WAVES) & (WAVES - 1);
+                const int off = r0 + wv * 1024 + lane * 16;
+                if (off < bytes)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(src) + off),
+                                                     (__attribute__((address_space(3))) void*)(static_cast<char*>(dst) + r0 + wv * 1024), 16, 0, 0);
+                rot += ((bytes - r0 < WG * 16 ? bytes - r0 : WG * 16) + 1023) / 1024;
+            }
+        };
         // multipliers of the rows this knot owns, by native slot (the same slot -> row map that scatters g), in the g staging area of
-        // the scratch (the Hessian program emits no g); of the next interval's angular momentum rows
+        // the scratch (the Hessian program emits no g); of the next interval's angular momentum rows.  Two dependent global reads
+        // (row map, then multiplier): all row-map words first, all multipliers behind them — two round trips, not two per iteration.
         const double* lam = a.lambda + size_t(b) * a.m;
         const int v = first ? VAR_FIRST : (last ? VAR_LAST : VAR_INTERIOR);
-        for (int slot = tid; slot < gs::COUNT; slot += WG) {
-            const int ga = tb.g_a[v][slot];
-            s.g[slot] = ga >= 0 ? lam[ga + tb.g_b[slot] * k] : 0.0;
-        }
-        if (tid < 3) {
-            const int slot = gs::HDYN + 3 + tid;
-            const int ga = k + 1 < N ? tb.g_a[k + 1 == N - 1 ? VAR_LAST : VAR_INTERIOR][slot] : -1;
-            hx.lam_next[tid] = ga >= 0 ? lam[ga + tb.g_b[slot] * (k + 1)] : 0.0;
-        }
-        if (tid == 0) hx.sigma = a.sigma[b];
+        constexpr int LG_ITERS = (gs::COUNT + WG - 1) / WG;
+        int lga[LG_ITERS], lgb[LG_ITERS];
+#pragma unroll
+        for (int it = 0; it < LG_ITERS; ++it) { lga[it] = tb.g_a[v][tid + it * WG]; lgb[it] = tb.g_b[tid + it * WG]; }   // (padded tables)
+        int nga = -1, ngb = 0;
+        if (tid < 3 && k + 1 < N) { const int slot = gs::HDYN + 3 + tid; nga = tb.g_a[k + 1 == N - 1 ? VAR_LAST : VAR_INTERIOR][slot]; ngb = tb.g_b[slot]; }
+        const double sig = a.sigma[b];
+        stage(x + size_t(NXK) * k, s.x, XB);
+        if (!first) stage(x + size_t(NXK) * (k - 1), s.xm, XB); else rot += (XB + 1023) / 1024;
+        stage(a.pk + (size_t(b) * N + k) * PK_STRIDE, s.pk, PK_STRIDE * 8);
+        stage(x + size_t(NXK) * N, s.xg, NXG * 8);
+        stage(a.gp + b, &tabs.gp, int(sizeof(GParams)));
+        stage(&tb.head, &tabs.head, int(sizeof(HeadTables)));
+        double xrem = 0.0, xov = 0.0;
+        if (XREM && tid < 2 && !(first && tid == 1)) xrem = x[size_t(NXK) * (k - tid) + XB / 8];
+        if (first || last) { if (tid < NPER) xov = x[size_t(NXK) * (first ? N - 1 : 0) + periodicity_row_var(tid)]; }
+        double lv[LG_ITERS];
+#pragma unroll
+        for (int it = 0; it < LG_ITERS; ++it) lv[it] = lga[it] >= 0 ? lam[lga[it] + lgb[it] * k] : 0.0;
+        const double lnext = nga >= 0 ? lam[nga + ngb * (k + 1)] : 0.0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the staging loads of THIS wave have landed in LDS
+        if (first || last) { if (tid < NPER) s.xo[tid] = xov; }
+        if (XREM && tid < 2) (tid ? s.xm : s.x)[XB / 8] = xrem;
+        if (first) { for (int i = tid; i < XB / 8; i += WG) s.xm[i] = 0.0; }
+        if (tid >= 64 && tid < 64 + XPAD - NXK) { s.x[NXK + tid - 64] = 0.0; s.xm[NXK + tid - 64] = 0.0; }
+        if (tid >= 128 && tid < 128 + 8 - NXG) s.xg[NXG + tid - 128] = 0.0;
+#pragma unroll
+        for (int it = 0; it < LG_ITERS; ++it) { const int slot = tid + it * WG; if (slot < gs::COUNT) s.g[slot] = lv[it]; }
+        if (tid < 3) hx.lam_next[tid] = lnext;
+        if (tid == 0) hx.sigma = sig;
     }
-    __syncthreads();
+    lds_barrier();
     // copy-out permutation, fetched now so that its latency hides behind the programs
     const HessTables& ht = *a.ht;
     constexpr int HP_ITERS = (hk::COUNT + WG - 1) / WG;
@@ -569,7 +590,7 @@ template <int TERRAIN> __global__ __launch_bounds__(256) __attribute__((amdgpu_w
     // (one contiguous program instance per wave, as in hipnlp_knot_kernel)
 #define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_RH(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); }
-#define DEV_BARRIER __syncthreads();
+#define DEV_BARRIER lds_barrier();
     auto run_wave = [&](auto wc) __attribute__((always_inline)) {
         constexpr int W = decltype(wc)::value;
         HIPNLP_KNOT_HESS_PROGRAM(DEV_KIN, DEV_RH, DEV_BARRIER)
