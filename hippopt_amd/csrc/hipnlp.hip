@@ -458,7 +458,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 #ifdef HIPNLP_STAMPS
     {
         st_arr[bid] = __builtin_amdgcn_s_memtime();   // after the vote and the store issue
-        unsigned long long* stamp_out = a.stamps + ((size_t(blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 128;
+        unsigned long long* stamp_out = a.stamps + ((size_t(blockIdx.y) * nkx + blockIdx.x) * 8 + wave) * 128;   // (knot workgroups only: nkx per row)
         if (lane == 0) {
             stamp_out[0] = st_entry; stamp_out[1] = st_staged; stamp_out[2] = (unsigned long long)bid;
             for (int i = 0; i < 8; ++i) { stamp_out[8 + 2 * i] = i <= bid ? st_arr[i] : 0; stamp_out[9 + 2 * i] = i < bid ? st_dep[i] : 0; }
