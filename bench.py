@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (guides/MI355X_MICROARCH.md)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0   # G wave-instructions/s: 256 CUs x 4 SIMDs x 2.4 GHz, 4 issue cycles per wave64 VALU instruction
+LDS_PEAK_GCYC = 256 * 2.4   # G LDS-array cycles/s: one access group per cycle and CU (guides/MI355X_MICROARCH.md, LDS)
 KNOTS_PER_GPU = 100
 # BENCH_REHEARSAL=1: the N ranks of `--gpus N` all use device 0 and talk over gloo (RCCL refuses two ranks on one device): a plumbing
 # check of the multi-rank paths on a one-GPU box, labelled as such in the JSON line — never a measurement.
@@ -487,13 +488,14 @@ def main():
             else ("HIP events around every %d-th knot-kernel launch" % stride)
         # PMC-derived figures cannot be collected inside a timed run (rocprofv3 --pmc passes are separate processes): they are looked up
         # in the committed summary of the same command and labelled as such
-        traffic = valu = None
+        traffic = valu = lds_cyc = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
                 ent = json.load(open(tp)).get("%s_N%d_B%d" % (args.workload, main_res["horizon"], args.batch), {})
                 traffic = ent.get("hbm_bytes_per_launch")
                 valu = ent.get("valu_wave_insts_per_knot")
+                lds_cyc = ent.get("lds_array_cycles_per_knot")
             except Exception:  # noqa: BLE001
                 pass
         line = {
@@ -530,6 +532,13 @@ def main():
                                         "frac": ginst / VALU_PEAK_GINST, "valu_wave_insts_per_knot": valu,
                                         "source": "SQ_INSTS_VALU per launch from profiles/traffic.json (separate rocprofv3 --pmc pass) x this run's kernel rate; "
                                                   "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 issue cycles per wave64 instruction"}
+        if lds_cyc and kern_ms > 0:
+            # the CU's LDS array serves one wave access group per cycle: 256 CUs x 2.4 GHz array cycles per second
+            gcyc = lds_cyc * local_knots / (kern_ms * 1e-3) / 1e9
+            line["roofline"]["lds"] = {"bound": "lds array cycles", "achieved": gcyc, "peak": LDS_PEAK_GCYC, "unit": "G array-cycles/s", "frac": gcyc / LDS_PEAK_GCYC,
+                                       "lds_array_cycles_per_knot": lds_cyc,
+                                       "source": "SQ_LDS_IDX_ACTIVE per launch from profiles/traffic.json (separate rocprofv3 --pmc pass) x this run's kernel rate; "
+                                                 "peak = 256 CUs x 2.4 GHz (stores also occupy the VGPR -> LDS path, not counted here)"}
         for key in ("shard_resident", "peer_store", "host_sink"):
             if main_res.get(key) is not None:
                 line[key] = main_res[key]

@@ -21,6 +21,7 @@ for W in $WORKLOADS; do
   run fetch_$NAME --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$NAME -- python3 bench.py --steps 20 --warmup 5 $ARGS $COMMON
   run write_$NAME --pmc WRITE_SIZE --output-format csv -d $OUT/write_$NAME -- python3 bench.py --steps 20 --warmup 5 $ARGS $COMMON
   run sq_$NAME --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/sq_$NAME -- python3 bench.py --steps 20 --warmup 5 $ARGS $COMMON
+  run lds_$NAME --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/lds_$NAME -- python3 bench.py --steps 20 --warmup 5 $ARGS $COMMON
   python3 bench.py --steps $([ $B -ge 1024 ] && echo 50 || echo 1000) --warmup 50 $ARGS $COMMON > $OUT/bench_$NAME.json 2>/dev/null
 done
 for HW in periodic stairs; do

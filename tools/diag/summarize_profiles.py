@@ -75,7 +75,9 @@ for name in names:
     fe = counter_means(os.path.join(src, "fetch_" + name), "knot_kernel")
     wr = counter_means(os.path.join(src, "write_" + name), "knot_kernel")
     sq = counter_means(os.path.join(src, "sq_" + name), "knot_kernel")
+    lds = counter_means(os.path.join(src, "lds_" + name), "knot_kernel")
     w["FETCH_SIZE_kib"], w["WRITE_SIZE_kib"] = fe.get("FETCH_SIZE"), wr.get("WRITE_SIZE")
+    w["lds"] = {k: v for k, v in lds.items() if not k.endswith("_n")}
     w["sq"] = {k: v for k, v in sq.items() if not k.endswith("_n")}
     bj = os.path.join(src, "bench_%s.json" % name)
     if os.path.exists(bj) and os.path.getsize(bj) > 0:
@@ -95,6 +97,12 @@ for name in names:
         w["lds_wave_insts_per_knot"] = sq.get("SQ_INSTS_LDS", 0.0) / knots
         if sq.get("SQ_WAVE_CYCLES"):
             w["wait_fraction_of_wave_cycles"] = sq.get("SQ_WAIT_ANY", 0.0) / sq["SQ_WAVE_CYCLES"]
+    if lds.get("SQ_LDS_IDX_ACTIVE"):
+        ent["lds_array_cycles_per_knot"] = lds["SQ_LDS_IDX_ACTIVE"] / knots
+        w["lds_array_cycles_per_knot"] = ent["lds_array_cycles_per_knot"]
+        w["lds_bank_conflict_cycles_per_knot"] = lds.get("SQ_LDS_BANK_CONFLICT", 0.0) / knots
+        if lds.get("SQ_BUSY_CU_CYCLES"):
+            w["lds_array_busy_fraction_of_cu_cycles"] = lds["SQ_LDS_IDX_ACTIVE"] / lds["SQ_BUSY_CU_CYCLES"]
     if len(ent) > 1:
         traffic[name] = ent
     summary["workloads"][name] = w
