@@ -79,13 +79,16 @@ struct PoseShared {
     GParams gp;
 };
 
+// workgroup barrier that orders LDS traffic only (see hipnlp.hip): the copy-out tables prefetched into registers stay in flight across it
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // tables, parameters and the pose's variables -> LDS (ends with a workgroup barrier)
 __device__ __forceinline__ void pose_stage(const PArgs& a, KnotScratch& s, PoseShared& tabs, int b, int tid) {
     const PoseTables& tb = *a.tb;
     // every global load in flight before the first LDS store waits for one (see hipnlp_knot_kernel)
     constexpr int HV = int(sizeof(HeadTables) / 16), HV_ITERS = (HV + WG - 1) / WG;
     constexpr int GV = int(sizeof(GParams) / 8), GV_ITERS = (GV + WG - 1) / WG;
-    static_assert(XPAD <= WG && PK_STRIDE <= WG && POSE_NX <= WG, "one record word per thread");
+    static_assert(XPAD <= WG && PK_STRIDE <= WG && POSE_NX <= WG && POSE_MAX_NNZ % WG == 0, "one record word per thread");
     const uint4* hsrc = reinterpret_cast<const uint4*>(&tb.head);
     const double* gsrc = reinterpret_cast<const double*>(a.gp + b);
     uint4 hv[HV_ITERS];
@@ -119,13 +122,21 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     const int b = blockIdx.x;
     const PoseTables& tb = *a.tb;
     pose_stage(a, s, tabs, b, tid);
+    // copy-out tables (CCS permutation, g row map): fetched now, consumed at the very end
+    constexpr int JP_ITERS = (POSE_MAX_NNZ + WG - 1) / WG, GR_ITERS = (gs::COUNT + WG - 1) / WG;
+    int32_t jp[JP_ITERS], gr[GR_ITERS];
+#pragma unroll
+    for (int it = 0; it < JP_ITERS; ++it) jp[it] = tb.jperm[tid + it * WG];          // (POSE_MAX_NNZ is a multiple of the workgroup)
+#pragma unroll
+    for (int it = 0; it < GR_ITERS; ++it) { const int slot = tid + it * WG; gr[it] = slot < gs::COUNT ? tb.g_row[slot] : -1; }
+    const int nnz = tb.nnz, m = tb.m;
 
     KnotInfo ki{1, 3, 0, 0};   // "interior knot": the k >= 1 rows / costs of the shared tasks are active
     PoseEm<TERRAIN> em{s.g, s.jac};
     Ctx<PoseEm<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
     // (one contiguous program instance per wave, as in hipnlp_knot_kernel: no wave jumps over the other waves' code)
 #define DEV_R(w, w8, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
-#define DEV_BARRIER __syncthreads();
+#define DEV_BARRIER lds_barrier();
     auto run_wave = [&](auto wc) __attribute__((always_inline)) {
         constexpr int W = decltype(wc)::value;
         HIPNLP_POSE_PROGRAM(DEV_R, DEV_BARRIER)
@@ -141,15 +152,14 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
 
     int bad = 0;
     if (a.jac) {
-        double* out = a.jac + size_t(b) * tb.nnz;
-        for (int e = tid; e < tb.nnz; e += WG) { const double v = s.jac[tb.jperm[e]]; bad |= !isfinite(v); out[e] = v; }
+        double* out = a.jac + size_t(b) * nnz;
+#pragma unroll
+        for (int it = 0; it < JP_ITERS; ++it) { const int e = tid + it * WG; if (e < nnz) { const double v = s.jac[jp[it]]; bad |= !isfinite(v); out[e] = v; } }
     }
     if (a.g) {
-        double* out = a.g + size_t(b) * tb.m;
-        for (int slot = tid; slot < gs::COUNT; slot += WG) {
-            const int r = tb.g_row[slot];
-            if (r >= 0) { const double v = s.g[slot]; bad |= !isfinite(v); out[r] = v; }
-        }
+        double* out = a.g + size_t(b) * m;
+#pragma unroll
+        for (int it = 0; it < GR_ITERS; ++it) { const int slot = tid + it * WG; if (gr[it] >= 0) { const double v = s.g[slot]; bad |= !isfinite(v); out[gr[it]] = v; } }
     }
     if (a.grad && tid < POSE_NX) { const double v = s.grad[pose_to_knot_col(tid)]; bad |= !isfinite(v); a.grad[size_t(b) * POSE_NX + tid] = v; }
     if (tid == 0) {
@@ -182,6 +192,11 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     if (tid == 0) hx.sigma = a.sigma[b];
     pose_stage(a, s, tabs, b, tid);
 
+    constexpr int HP_ITERS = (POSE_MAX_HNNZ + WG - 1) / WG;
+    int32_t hp[HP_ITERS];
+#pragma unroll
+    for (int it = 0; it < HP_ITERS; ++it) { const int e = tid + it * WG; hp[it] = e < POSE_MAX_HNNZ ? tb.hperm[e] : 0; }   // (copy-out permutation, consumed at the end)
+    const int hnnz = tb.hnnz;
     KnotInfo ki{1, 3, 0, 0};
     PoseHessEm<TERRAIN> em{s.g, nullptr, hx.H};   // (no task of the Hessian program emits a Jacobian entry)
     Ctx<PoseHessEm<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
@@ -189,7 +204,7 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     // (one contiguous program instance per wave, as in hipnlp_knot_kernel: no wave jumps over the other waves' code)
 #define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_RH(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); }
-#define DEV_BARRIER __syncthreads();
+#define DEV_BARRIER lds_barrier();
     auto run_wave = [&](auto wc) __attribute__((always_inline)) {
         constexpr int W = decltype(wc)::value;
         HIPNLP_POSE_HESS_PROGRAM(DEV_KIN, DEV_RH, DEV_BARRIER)
@@ -204,8 +219,9 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
 #undef DEV_RH
 #undef DEV_BARRIER
     int bad = 0;
-    double* out = a.hess + size_t(b) * tb.hnnz;
-    for (int e = tid; e < tb.hnnz; e += WG) { const double v = hx.H[tb.hperm[e]]; bad |= !isfinite(v); out[e] = v; }
+    double* out = a.hess + size_t(b) * hnnz;
+#pragma unroll
+    for (int it = 0; it < HP_ITERS; ++it) { const int e = tid + it * WG; if (e < hnnz) { const double v = hx.H[hp[it]]; bad |= !isfinite(v); out[e] = v; } }
     const int anybad = __syncthreads_or(bad);
     if (tid == 0) a.flags[b] = anybad;
 }
