@@ -23,6 +23,9 @@ template <int KIND> __global__ __launch_bounds__(1024) void k(unsigned long long
         if (KIND == 2) { asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(a0) : "v"(addr) : "memory"); acc += a0; }
         if (KIND == 3) { double2 q; asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(q) : "v"(addr) : "memory"); acc += q.x + q.y; }
         if (KIND == 4) { asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24\n\ts_waitcnt lgkmcnt(0)" : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3) : "v"(addr) : "memory"); acc += a0 + a1 + a2 + a3; }
+        if (KIND == 6) { asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %1 offset:8\n\ts_waitcnt lgkmcnt(0)" :: "v"(addr), "v"(acc) : "memory"); }
+        if (KIND == 7) { asm volatile("ds_write2_b64 %0, %1, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" :: "v"(addr), "v"(acc) : "memory"); }
+        if (KIND == 8) { asm volatile("ds_write_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(addr), "v"(acc) : "memory"); }
         if (KIND == 5) { double2 q, p; asm volatile("ds_read2_b64 %0, %2 offset1:1\n\tds_read2_b64 %1, %2 offset0:2 offset1:3\n\ts_waitcnt lgkmcnt(0)" : "=v"(q), "=v"(p) : "v"(addr) : "memory"); acc += q.x + q.y + p.x + p.y; }
     }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
@@ -50,6 +53,9 @@ int main() {
         if (run<3>("one ds_read_b128 (16-byte aligned)", stride, d_c, d_s)) return 1;
         if (run<4>("four ds_read_b64 (four adjacent doubles)", stride, d_c, d_s)) return 1;
         if (run<5>("two ds_read2_b64 (the same four doubles)", stride, d_c, d_s)) return 1;
+        if (run<8>("one ds_write_b64", stride, d_c, d_s)) return 1;
+        if (run<6>("two ds_write_b64 (adjacent doubles)", stride, d_c, d_s)) return 1;
+        if (run<7>("one ds_write2_b64 (the same two doubles)", stride, d_c, d_s)) return 1;
     }
     return 0;
 }
