@@ -430,7 +430,13 @@ def main():
         # beside it: no collective, every rank's kernel stores its shard straight into ONE shared pinned host buffer
         try:
             name = "hipnlp_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid() if world > 1 else os.getpid())
-            sink = HostSink(name, eng.n, eng.m, eng.nnz, world, rank, barrier=(dist.barrier if world > 1 else None))
+            def agree(ok):
+                if world == 1:
+                    return ok
+                oks = [None] * world
+                dist.all_gather_object(oks, bool(ok))
+                return all(oks)
+            sink = HostSink(name, eng.n, eng.m, eng.nnz, world, rank, barrier=(dist.barrier if world > 1 else None), agree=agree)
             fp, gradp, gp, jacp = sink.pointers()
 
             def hstep(i):

@@ -196,27 +196,43 @@ class PeerExchange:
         # this rank's buffers: two output buffers and one flag array, in ONE allocation (one IPC handle)
         self.flag_words = 64
         nbytes = 8 * (2 * self.olen + self.flag_words)
+        # Every failure below is made COLLECTIVE before anybody raises: a rank that threw on its own would leave the others waiting in
+        # the next collective for ever.
         mine = vp()
         handle = C.create_string_buffer(64)
-        if lib.hipnlp_ipc_alloc(C.c_size_t(nbytes), dev_index, C.byref(mine), handle) != 0:
-            raise RuntimeError("hipnlp_ipc_alloc failed")
-        self._mine = mine.value
+        mine_ok = lib.hipnlp_ipc_alloc(C.c_size_t(nbytes), dev_index, C.byref(mine), handle) == 0
+        self._mine = mine.value if mine_ok else None
         handles = [None] * self.world
         if self.world > 1:
-            dist.all_gather_object(handles, bytes(handle.raw), group=cb.group)
+            dist.all_gather_object(handles, bytes(handle.raw) if mine_ok else None, group=cb.group)
         else:
-            handles = [bytes(handle.raw)]
+            handles = [bytes(handle.raw) if mine_ok else None]
         self._opened = []
         bases = []
-        for r in range(self.world):
-            if r == self.rank:
-                bases.append(self._mine)
-                continue
-            p = vp()
-            if lib.hipnlp_ipc_open(handles[r], dev_index, C.byref(p)) != 0:
-                raise RuntimeError("hipnlp_ipc_open failed for the buffer of rank %d" % r)
-            self._opened.append(p.value)
-            bases.append(p.value)
+        opened_ok = all(h is not None for h in handles)
+        if opened_ok:
+            for r in range(self.world):
+                if r == self.rank:
+                    bases.append(self._mine)
+                    continue
+                p = vp()
+                if lib.hipnlp_ipc_open(handles[r], dev_index, C.byref(p)) != 0:
+                    opened_ok = False
+                    break
+                self._opened.append(p.value)
+                bases.append(p.value)
+        oks = [opened_ok]
+        if self.world > 1:
+            oks = [None] * self.world
+            dist.all_gather_object(oks, opened_ok, group=cb.group)
+        if not all(oks):
+            for p in self._opened:
+                lib.hipnlp_ipc_close(p)
+            if self._mine:
+                lib.hipnlp_ipc_free(self._mine)
+            self._mine = None
+            raise RuntimeError("peer exchange set-up failed on rank(s) %s (hipnlp_ipc_alloc / hipnlp_ipc_open: no peer access between the devices?)"
+                               % [r for r, ok in enumerate(oks) if not ok])
         dev = cb.device
         # device arrays of pointers: output buffer of every rank per parity, flag array of every rank
         self.peer_out = [torch.tensor([b + 8 * par * self.olen for b in bases], dtype=torch.int64, device=dev) for par in (0, 1)]
@@ -312,7 +328,9 @@ class HostSink:
     name: shared-memory name all ranks agree on (rank 0 creates, the others open after a barrier the caller provides through
     `barrier()`); world = 1 needs no barrier."""
 
-    def __init__(self, name, n, m, nnz, world, rank, barrier=None):
+    def __init__(self, name, n, m, nnz, world, rank, barrier=None, agree=None):
+        """agree(ok) -> bool: True iff EVERY rank passed ok (a collective; replaces the second barrier).  Without it a rank whose
+        registration fails raises alone and leaves the others in the barrier."""
         import ctypes as C
         from .hipnlp import load_library
         self.n, self.m, self.nnz, self.world, self.rank = n, m, nnz, world, rank
@@ -338,13 +356,18 @@ class HostSink:
         dev = C.c_void_p()
         self._addr = self.host.ctypes.data
         rc = self._lib.hipnlp_host_register(C.c_void_p(self._addr), C.c_size_t(nbytes), C.byref(dev))
-        if rc != 0:
-            raise RuntimeError("hipnlp_host_register failed (%d)" % rc)
-        self.dev = dev.value
-        if barrier is not None:
-            barrier()   # every rank holds its mapping: the name can go
+        self.dev = dev.value if rc == 0 else None
+        if agree is not None:
+            all_ok = agree(rc == 0)
+        else:
+            all_ok = rc == 0
+            if barrier is not None and all_ok:
+                barrier()   # every rank holds its mapping: the name can go
         if rank == 0:
             os.unlink(self.path)
+        if not all_ok:
+            self.close()
+            raise RuntimeError("hipnlp_host_register failed on this or another rank (%d here)" % rc)
 
     def pointers(self):
         """device-visible addresses (f partial of this rank, grad, g, jac) for HipNlp.eval_device on a shard handle"""
