@@ -245,6 +245,10 @@ def host_visible(eng, x_np, horizon, batch):
     eng.register_outputs(outs)
     try:
         res["ipopt iterate as four calls (caller arrays registered)"] = {"ms_per_call": best_of(iterate)}
+        # opt-in: the new-x call also fills the registered arrays the later calls will pass (hipnlp_set_early_outputs)
+        eng.set_early_outputs(True)
+        res["ipopt iterate as four calls (caller arrays registered, early outputs)"] = {"ms_per_call": best_of(iterate)}
+        eng.set_early_outputs(False)
     finally:
         eng.unregister_outputs(outs)
     for v in res.values():

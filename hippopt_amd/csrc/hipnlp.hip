@@ -723,6 +723,12 @@ struct hipnlp_handle {
     unsigned prefetch = HIPNLP_WANT_F | HIPNLP_WANT_GRAD | HIPNLP_WANT_G;   // brought to the host by every new evaluation
     unsigned on_host = 0;         // outputs of the cached result that are in the pinned block
     unsigned gone = 0;            // outputs of the cached result the kernel stored into registered caller arrays (in neither block)
+    // hipnlp_set_early_outputs: registered caller arrays seen in earlier calls (host address; the device address is looked up again at
+    // every use: a range may have been unregistered since), and which outputs of the cached result already sit in them
+    bool early = false;
+    double* seen_host[3] = {nullptr, nullptr, nullptr};   // grad, g, jac
+    double* early_host[3] = {nullptr, nullptr, nullptr};
+    unsigned early_mask = 0;
     bool time_host = false;       // bracket host-path launches with events (hipnlp_set_host_timing)
     double host_us[4] = {0, 0, 0, 0};   // wall clock of the last host-path evaluation: x staging, enqueue, wait for the GPU, copies out
     std::vector<double> p;
@@ -1190,6 +1196,22 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
         if ((want & HIPNLP_WANT_GRAD) && dst.grad) { ograd = dst.grad; dmask |= HIPNLP_WANT_GRAD; }
         if ((want & HIPNLP_WANT_G) && dst.g) { og = dst.g; dmask |= HIPNLP_WANT_G; }
         if ((want & HIPNLP_WANT_JAC) && dst.jac) { ojac = dst.jac; dmask |= HIPNLP_WANT_JAC; }
+        // early outputs (opt-in): what this call does NOT ask for goes straight into the registered caller array an earlier call
+        // passed for it — IPOPT's eval_g / eval_grad_f / eval_jac_g at this x then find their values in place
+        h->early_mask = 0;
+        if (h->early) {
+            const unsigned bit[3] = {HIPNLP_WANT_GRAD, HIPNLP_WANT_G, HIPNLP_WANT_JAC};
+            const size_t bytes[3] = {B * n * sizeof(double), B * m * sizeof(double), B * nnz * sizeof(double)};
+            double** outp[3] = {&ograd, &og, &ojac};
+            for (int q = 0; q < 3; ++q) {
+                if ((want & bit[q]) || !h->seen_host[q]) continue;
+                double* dev = device_address_of(h->seen_host[q], bytes[q]);
+                if (!dev) { h->seen_host[q] = nullptr; continue; }   // (unregistered since)
+                *outp[q] = dev;
+                h->early_host[q] = h->seen_host[q];
+                h->early_mask |= bit[q];
+            }
+        }
         int rc = launch(h, xsrc, of, ograd, og, ojac, h->stream, nullptr, false, h->time_host, true);
         if (rc != HIPNLP_OK) return rc;
         const auto t2 = std::chrono::steady_clock::now();
@@ -1200,9 +1222,15 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
         h->host_us[2] = std::chrono::duration<double, std::micro>(t3 - t2).count();
         h->have_result = true;
         h->seq_result = h->seq;
-        h->on_host = to_host & ~dmask;
-        h->gone = dmask;
+        h->on_host = to_host & ~dmask & ~h->early_mask;
+        h->gone = dmask | h->early_mask;
         if (direct) *direct = dmask;
+    }
+    if (h->early_mask && !(new_x)) {   // a cached request for an output that already sits in the caller's own array
+        const unsigned bit[3] = {HIPNLP_WANT_GRAD, HIPNLP_WANT_G, HIPNLP_WANT_JAC};
+        double* const asked[3] = {dst.grad_host, dst.g_host, dst.jac_host};
+        for (int q = 0; q < 3; ++q)
+            if ((want & bit[q]) && (h->early_mask & bit[q]) && asked[q] == h->early_host[q] && direct) *direct |= bit[q];
     }
     unsigned missing = want & HIPNLP_WANT_ALL & ~h->on_host & ~(direct ? *direct : 0u);
     if (missing & h->gone) {   // stored into a caller array by the evaluation and now asked for again: evaluate again (rare)
@@ -1252,6 +1280,9 @@ int hipnlp_eval(hipnlp_handle* h, const double* x, int new_x, double* f, double*
     unsigned direct = 0;
     const int rc = host_evaluate(h, x, new_x, want, dst, &direct);
     if (rc != HIPNLP_OK) return rc;
+    if (dst.grad_host) h->seen_host[0] = dst.grad_host;
+    if (dst.g_host) h->seen_host[1] = dst.g_host;
+    if (dst.jac_host) h->seen_host[2] = dst.jac_host;
     const auto t0 = std::chrono::steady_clock::now();
     if (f) std::memcpy(f, h->h_f, B * sizeof(double));
     if (grad_f && !(direct & HIPNLP_WANT_GRAD)) std::memcpy(grad_f, h->h_grad, B * n * sizeof(double));
@@ -1272,6 +1303,13 @@ int hipnlp_eval_pinned(hipnlp_handle* h, const double* x, int new_x, unsigned wa
     if (g) *g = (want & HIPNLP_WANT_G) ? h->h_g : nullptr;
     if (jac) *jac = (want & HIPNLP_WANT_JAC) ? h->h_jac : nullptr;
     return host_numeric_status(h);
+}
+
+int hipnlp_set_early_outputs(hipnlp_handle* h, int on) {
+    if (!h) return HIPNLP_E_INVALID;
+    h->early = on != 0;
+    if (!h->early) { h->early_mask = 0; }
+    return HIPNLP_OK;
 }
 
 int hipnlp_set_prefetch(hipnlp_handle* h, unsigned mask) {

@@ -22,7 +22,7 @@ EXPORTS = [
     "hipnlp_eval_device_shard", "hipnlp_stage_rows", "hipnlp_reassemble",
     "hipnlp_ipc_alloc", "hipnlp_ipc_open", "hipnlp_ipc_close", "hipnlp_ipc_free", "hipnlp_peer_push", "hipnlp_peer_signal", "hipnlp_peer_wait",
     "hipnlp_hess_nnz", "hipnlp_hess_sparsity", "hipnlp_eval_hess", "hipnlp_eval_hess_device",
-    "hipnlp_eval_pinned", "hipnlp_set_prefetch", "hipnlp_set_host_timing", "hipnlp_host_register", "hipnlp_host_unregister",
+    "hipnlp_eval_pinned", "hipnlp_set_prefetch", "hipnlp_set_early_outputs", "hipnlp_set_host_timing", "hipnlp_host_register", "hipnlp_host_unregister",
     "hipnlp_host_breakdown",
     "hipnlp_pose_create", "hipnlp_pose_destroy", "hipnlp_pose_last_error", "hipnlp_pose_get_dims", "hipnlp_pose_set_params",
     "hipnlp_pose_bounds", "hipnlp_pose_sparsity", "hipnlp_pose_eval", "hipnlp_pose_eval_device", "hipnlp_pose_cost_terms",
@@ -110,6 +110,7 @@ def load_library():
     lib.hipnlp_reassemble.argtypes = [vp, vp, vp, C.c_int64, C.c_int, C.c_int64, vp, vp]
     lib.hipnlp_eval_pinned.argtypes = [vp, dp, C.c_int, C.c_uint, C.POINTER(dp), C.POINTER(dp), C.POINTER(dp), C.POINTER(dp)]
     lib.hipnlp_set_prefetch.argtypes = [vp, C.c_uint]
+    lib.hipnlp_set_early_outputs.argtypes = [vp, C.c_int]
     lib.hipnlp_set_host_timing.argtypes = [vp, C.c_int]
     lib.hipnlp_host_register.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.hipnlp_host_unregister.argtypes = [vp]
@@ -239,6 +240,10 @@ class HipNlp:
         self.last_views = tuple(np.ctypeslib.as_array(q, shape=sh) if q else None for q, sh in zip(ptrs, shapes)) if rc in (0, -5) else None
         self._check(rc)
         return self.last_views
+
+    def set_early_outputs(self, on=True):
+        """a new evaluation also fills the registered caller arrays earlier calls passed (hipnlp_set_early_outputs; see include/hipnlp.h)"""
+        self._check(self.lib.hipnlp_set_early_outputs(self.h, 1 if on else 0))
 
     def set_prefetch(self, want=("f", "grad", "g")):
         """outputs every new evaluation brings to the host besides the ones its call asks for (hipnlp_set_prefetch)"""

@@ -444,6 +444,41 @@ def test_sharded_callback_reassembly_on_gpu(model, HipNlp):
         assert np.array_equal(grads.cpu().numpy(), grad[0]) and np.array_equal(jacs.cpu().numpy(), jac[0]) and np.array_equal(gs.cpu().numpy(), g[0])
 
 
+def test_early_outputs_into_registered_arrays(model, HipNlp):
+    """hipnlp_set_early_outputs: the new-x call (eval_f) already fills the registered arrays the later eval_g / eval_grad_f / eval_jac_g
+    calls pass; alternating iterates, so values left over from the previous x would show; a cached call with ANOTHER array is
+    still served correctly (by a fresh evaluation), and unregistering turns the mode off for that array."""
+    st = periodic_step_settings(9, model)
+    x, p = make_workload(st, model, batch=1, seed=43)
+    x2 = x + 1e-2 * np.random.RandomState(2).standard_normal(x.shape)
+    eng = HipNlp(st, model)
+    eng.set_params(p)
+    ref = {0: [a.copy() for a in eng.eval(x)], 1: [a.copy() for a in eng.eval(x2)]}
+    outs = [np.zeros_like(a) for a in ref[0]]
+    eng.register_outputs(outs)
+    try:
+        eng.set_early_outputs(True)
+        f_, grad_, g_, jac_ = outs
+        for i in range(6):
+            xi, r = (x, ref[0]) if i % 2 == 0 else (x2, ref[1])
+            eng.eval(xi, new_x=True, want=("f",), out=(f_, None, None, None))
+            if i > 0:   # the arrays have been seen: they already hold this x's values, before being asked for
+                assert np.array_equal(g_, r[2]) and np.array_equal(grad_, r[1]) and np.array_equal(jac_, r[3])
+            eng.eval(xi, new_x=False, want=("g",), out=(None, None, g_, None))
+            eng.eval(xi, new_x=False, want=("grad",), out=(None, grad_, None, None))
+            eng.eval(xi, new_x=False, want=("jac",), out=(None, None, None, jac_))
+            assert f_[0] == r[0][0] and np.array_equal(g_, r[2]) and np.array_equal(grad_, r[1]) and np.array_equal(jac_, r[3])
+        other = np.zeros_like(jac_)   # a cached request with an array the library has not filled
+        eng.eval(x2, new_x=True, want=("f",), out=(f_, None, None, None))
+        eng.eval(x2, new_x=False, want=("jac",), out=(None, None, None, other))
+        assert np.array_equal(other, ref[1][3])
+    finally:
+        eng.set_early_outputs(False)
+        eng.unregister_outputs(outs)
+    got = eng.eval(x, new_x=True)   # back to the plain path, unregistered arrays
+    assert np.array_equal(got[3], ref[0][3])
+
+
 def test_peer_exchange_equals_the_gathered_callback(model, HipNlp):
     """PeerExchange (peer stores into IPC-shared output buffers + flags, no collective, no reassembly pass) at world size 1: the
     rank pushes into its own buffer; bitwise the unsharded callback, on alternating iterates and both buffer parities."""

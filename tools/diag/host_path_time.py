@@ -63,6 +63,17 @@ for reg in (False, True):
         eng.lib.hipnlp_eval(eng.h, xp[i % 4], 0, *a_gr)
         eng.lib.hipnlp_eval(eng.h, xp[i % 4], 0, *a_j)
     print("ipopt iterate (f new x, then g, grad, jac cached), registered=%s: %.1f us" % (reg, 1e6 * (time.perf_counter() - t0) / 300))
+eng.register_outputs(outs)
+eng.set_early_outputs(True)
+t0 = time.perf_counter()
+for i in range(300):
+    eng.lib.hipnlp_eval(eng.h, xp[i % 4], 1, *a_f)
+    eng.lib.hipnlp_eval(eng.h, xp[i % 4], 0, *a_g)
+    eng.lib.hipnlp_eval(eng.h, xp[i % 4], 0, *a_gr)
+    eng.lib.hipnlp_eval(eng.h, xp[i % 4], 0, *a_j)
+print("ipopt iterate, registered + early outputs (hipnlp_set_early_outputs): %.1f us" % (1e6 * (time.perf_counter() - t0) / 300))
+eng.set_early_outputs(False)
+eng.unregister_outputs(outs)
 lam = np.random.RandomState(0).standard_normal((1, eng.m))
 hv = eng.eval_hess(x, 1.0, lam)
 t0 = time.perf_counter()
