@@ -7,8 +7,9 @@
 // component) / Jacobian entries), collects all outputs of the knot in LDS at compile-time native slots and finally streams
 // them out: the knot's CCS column block of jac g as ONE contiguous run (permuted through a prefetched int table), grad f
 // contiguous, g scattered into the reference's constraint-type-major order, the cost partials per knot.  The total cost is summed
-// in a fixed order (bitwise reproducible f): inside the knot kernel by the workgroup that publishes its partials last (eight-wave
-// latency variant: one kernel launch per callback set), by a second tiny kernel behind the four-wave throughput variant.
+// in a fixed order (bitwise reproducible f) inside the same launch by one more workgroup per trajectory that polls the knots' tagged
+// partials (one kernel launch per callback set), or by a second tiny kernel for trajectories of more than 256 knots / long launches.
+// The build splits the compiler's two-address LDS reads in the assembly of these kernels (tools/asm_patch.py, __graft_entry__.build).
 // hipnlp_knot_hess_kernel evaluates the exact Hessian of the Lagrangian (knot_hess_body.h) behind the same knot program.
 #include <hip/hip_runtime.h>
 
@@ -116,8 +117,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ unsigned long long pub_pattern(int32_t seq) { return ((unsigned long long)(uint32_t)seq * 0x9E3779B97F4A7C15ull) | 1ull; }
 constexpr int PUB_SPIN_CAP = 1 << 20;   // polls of the reducer before it gives up (each at least one memory round trip: > 1 s)
 
-// WAVES = 4: 256 threads; 3 waves per SIMD = 3 workgroups per CU (the LDS bound): the register allocation is capped there
-//            (<= 168 VGPRs).  The throughput variant.
+// WAVES = 4: 256 threads; 4 waves per SIMD = 4 workgroups per CU (<= 128 VGPRs, <= 40 KB of LDS on the compact scratch).  The
+//            throughput variant.
 // WAVES = 8: 512 threads, the roles of the knot program spread over twice the waves (two per SIMD).  The latency variant, used
 //            when the whole launch is resident at once at two workgroups per CU ((knots + 1) x batch <= 512), e.g. one 100-knot
 //            trajectory.
