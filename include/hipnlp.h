@@ -263,7 +263,9 @@ int hipnlp_eval_hess_device(hipnlp_handle* h, const double* x_dev, const double*
 /* Device-resident variant: all pointers are device pointers on desc.device (or device-visible addresses of registered host
  * memory, hipnlp_host_register), same shapes.  Work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the handle's
  * own non-blocking stream — NOT the legacy default stream: order other work against it with an explicit stream) and NOT
- * synchronised. */
+ * synchronised.  Launches of ONE handle must not overlap on the device (one stream at a time, or ordered streams), and a launch is
+ * not replayable from a captured hipGraph: every launch carries its own sequence number, which tags the cost partials the launch's
+ * reducer workgroup waits for and the non-finite flag. */
 int hipnlp_eval_device(hipnlp_handle* h, const double* x_dev,
                        double* f_dev, double* grad_dev, double* g_dev, double* jac_dev,
                        void* stream);
