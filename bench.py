@@ -333,7 +333,10 @@ def main():
         # EVERY launch would inflate a 100-knot step by two thirds (DESIGN.md §5 "Measuring").  When a step is exactly ONE kernel
         # launch of ~10 us the events bracket RUNS of `stride` consecutive launches and the run duration is divided by the run length.
         if single_kernel_step:
-            eng.profile_begin_runs(max(1, steps // (4 * stride)), stride)
+            if steps < 4 * stride:   # a short timed region is ONE run: its two events sit at the region's own boundaries, none inside it
+                eng.profile_begin_runs(1, steps)
+            else:
+                eng.profile_begin_runs(steps // (4 * stride), stride)
         else:
             eng.profile_begin((steps + stride - 1) // stride, stride)
         t0 = time.perf_counter()
@@ -494,7 +497,8 @@ def main():
         local_knots = main_res["local_knots"]
         kern_ms = main_res["kern_ms"]
         achieved = bytes_knot * local_knots / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        timing = ("HIP events around runs of %d consecutive launches / %d (one kernel launch per step)" % (stride, stride)) if main_res["single_kernel_step"] \
+        run_len = stride if args.steps >= 4 * stride else args.steps
+        timing = ("HIP events around runs of %d consecutive launches / %d (one kernel launch per step)" % (run_len, run_len)) if main_res["single_kernel_step"] \
             else ("HIP events around every %d-th knot-kernel launch" % stride)
         # PMC-derived figures cannot be collected inside a timed run (rocprofv3 --pmc passes are separate processes): they are looked up
         # in the committed summary of the same command and labelled as such
