@@ -43,6 +43,11 @@ struct DeviceTables {
     int32_t g_a[3][GS_PAD];
     int32_t g_b[GS_PAD];
     int32_t jperm[3][JS_PAD];
+    // the same two tables THREAD-MAJOR for the callback kernel of this handle (workgroup of 256 or 512 threads): the entries
+    // (tid, tid + WG, tid + 2 WG, ...) one thread uses are contiguous, so its prefetch is one or two wide loads instead of one dword
+    // load per entry (eleven loads and their address arithmetic in the staging of every wave)
+    int32_t jperm_t[3][JS_PAD];
+    int32_t gab_t[3][2 * GS_PAD];   // pairs {g_a, g_b}
     int32_t jperm_glob[16];
     int32_t nnz_v[3];
     int32_t n_glob, jac_glob_base;
@@ -305,12 +310,11 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         // copy-out tables: issued now, consumed at the very end
         jpg = tb.jperm_glob[tid & 15];
 #pragma unroll
-        for (int it = 0; it < JP_ITERS; ++it) jp[it] = tb.jperm[v][tid + it * WG];
+        for (int it = 0; it < JP_ITERS; ++it) jp[it] = tb.jperm_t[v][tid * (JS_PAD / WG) + it];      // (thread-major: wide loads)
 #pragma unroll
         for (int it = 0; it < G_ITERS; ++it) {
-            const int slot = tid + it * WG;
-            ga[it] = tb.g_a[v][slot];
-            gb[it] = tb.g_b[slot];
+            ga[it] = tb.gab_t[v][2 * (tid * (GS_PAD / WG) + it)];
+            gb[it] = tb.gab_t[v][2 * (tid * (GS_PAD / WG) + it) + 1];
         }
     }
     lds_barrier();
@@ -878,6 +882,17 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
         tb->nnz_v[v] = h->L.nnz_v[v];
     }
     for (int s = 0; s < gs::COUNT; ++s) tb->g_b[s] = h->L.g_b[size_t(s)];
+    {
+        const int wg = h->wide ? 512 : 256, jt = JS_PAD / wg, gt = GS_PAD / wg;
+        for (int v = 0; v < 3; ++v)
+            for (int t = 0; t < wg; ++t) {
+                for (int it = 0; it < jt; ++it) tb->jperm_t[v][t * jt + it] = tb->jperm[v][t + it * wg];
+                for (int it = 0; it < gt; ++it) {
+                    tb->gab_t[v][2 * (t * gt + it)] = tb->g_a[v][t + it * wg];
+                    tb->gab_t[v][2 * (t * gt + it) + 1] = tb->g_b[t + it * wg];
+                }
+            }
+    }
     tb->n_glob = int(h->L.jperm_glob.size());
     for (int i = 0; i < tb->n_glob; ++i) tb->jperm_glob[i] = h->L.jperm_glob[size_t(i)];
     tb->jac_glob_base = h->L.jac_glob_base;
