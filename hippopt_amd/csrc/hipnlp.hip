@@ -1021,8 +1021,7 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     if (!h->fused)
         hipLaunchKernelGGL(hipnlp_reduce_kernel, dim3(unsigned(h->batch)), dim3(RWG), 0, s, (const double*)h->d_cost_knot, h->nk, f_dev, a.cost_terms);
     if (timed) HIP_TRY(h, hipEventRecord(e2, s));
-    if (run_last) {
-        HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 1)], s));
+    if (run_last) {   // (ONE event behind the run: kernel end and launch end coincide for a run)
         HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 2)], s));
         h->prof_open = false;
         h->prof_n++;
@@ -1533,7 +1532,7 @@ int hipnlp_profile_end(hipnlp_handle* h, double* mean_knot_kernel_ms, double* me
     for (int i = 0; i < h->prof_n; ++i) {
         float m1 = 0.f, m2 = 0.f;
         HIP_TRY(h, hipEventSynchronize(h->prof_ev[size_t(3 * i + 2)]));
-        HIP_TRY(h, hipEventElapsedTime(&m1, h->prof_ev[size_t(3 * i)], h->prof_ev[size_t(3 * i + 1)]));
+        HIP_TRY(h, hipEventElapsedTime(&m1, h->prof_ev[size_t(3 * i)], h->prof_ev[size_t(3 * i + (h->prof_run > 0 ? 2 : 1))]));
         HIP_TRY(h, hipEventElapsedTime(&m2, h->prof_ev[size_t(3 * i)], h->prof_ev[size_t(3 * i + 2)]));
         a += m1; b += m2;
     }
