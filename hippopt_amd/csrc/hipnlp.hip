@@ -13,7 +13,9 @@
 // hipnlp_knot_hess_kernel evaluates the exact Hessian of the Lagrangian (knot_hess_body.h) behind the same knot program.
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
@@ -803,6 +805,7 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
         // batch 2 .. 5, nothing once the launch exceeds the 512 slots (batch 6: 36.9 against 38.0 M knots/s).
         const bool fits = h->nk <= 256 && (long(h->nk) + 1) * long(desc->batch) <= 512;
         h->wide = force ? (std::atoi(force) == 8 && h->nk <= 256) : fits;
+        if (const char* s0 = std::getenv("HIPNLP_DEBUG_SEQ0")) h->seq = h->hseq = std::atoi(s0);   // diagnostic: launch numbers start here (tests of the wrap)
         const char* sep = std::getenv("HIPNLP_SEPARATE_REDUCE");   // diagnostic override: the reduction kernel behind the four-wave kernel
         // (measured, four-wave kernel, N = 100: + 2.4 % at x 64 and + 6.5 % on the stairs 200 x 16, whose second launch is 3 of 53 us;
         //  - 1.1 % at x 1024, where ten rows are in flight and as many reducers spin in workgroup slots: long launches keep the kernel)
@@ -990,6 +993,19 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     // host-buffer path: per-term costs (96 B per trajectory) and the non-finite flag go straight to the pinned block
     a.cost_terms = host_block ? h->hd_cost_terms : h->d_cost_terms;
     a.flag_host = host_block ? h->hd_flag : nullptr;
+    if (h->seq == INT32_MAX) {
+        // the launch number tags the cost partials and is the generation of the non-finite flags: before it would wrap (2^31 launches:
+        // hours of back-to-back 100-knot callbacks) everything that carries one starts over
+        HIP_TRY(h, hipStreamSynchronize(s));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipMemset(h->d_flag, 0, size_t(h->batch) * sizeof(int32_t)));
+        std::memset(h->h_flag, 0, size_t(h->batch) * sizeof(int32_t));
+        if (h->d_cost_pub) HIP_TRY(h, hipMemset(h->d_cost_pub, 0, size_t(h->batch) * size_t(h->nk) * NCT * 2 * sizeof(unsigned long long)));
+        HIP_TRY(h, hipDeviceSynchronize());
+        h->seq = 0;
+        h->seq_result = -1;
+        h->have_result = false;
+    }
     a.seq = ++h->seq; a.pad_ = 0;
     a.N = h->L.N; a.n = h->L.n; a.m = h->L.m; a.nnz = h->L.nnz; a.knot_begin = h->kb; a.nk = h->nk;
     bool prof = false, run_first = false, run_last = false;
@@ -1095,6 +1111,13 @@ static int hess_launch(hipnlp_handle* h, const double* x_dev, const double* sigm
     a.flag_host = host_block ? h->hd_hflag : nullptr;
     a.N = h->L.N; a.n = h->L.n; a.m = h->L.m; a.knot_begin = h->kb;
     a.hstride = hess_count(h); a.hoff = h->HL.knot_base(h->kb);
+    if (h->hseq == INT32_MAX) {   // (generation of the Hessian kernel's non-finite flags: start over before it wraps)
+        HIP_TRY(h, hipDeviceSynchronize());
+        HIP_TRY(h, hipMemset(h->d_hflag, 0, size_t(h->batch) * sizeof(int32_t)));
+        std::memset(h->h_hflag, 0, size_t(h->batch) * sizeof(int32_t));
+        HIP_TRY(h, hipDeviceSynchronize());
+        h->hseq = 0;
+    }
     a.seq = ++h->hseq; a.pad_ = 0;
     if (h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR)
         hipLaunchKernelGGL(hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_PLANAR>, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(256), 0, s, a);

@@ -444,6 +444,38 @@ def test_sharded_callback_reassembly_on_gpu(model, HipNlp):
         assert np.array_equal(grads.cpu().numpy(), grad[0]) and np.array_equal(jacs.cpu().numpy(), jac[0]) and np.array_equal(gs.cpu().numpy(), g[0])
 
 
+def test_launch_number_wrap(model, HipNlp):
+    """The launch number tags the published cost partials and is the generation of the non-finite flags; at 2^31 - 1 it starts
+    over (flags and tags cleared).  HIPNLP_DEBUG_SEQ0 starts the count just below: evaluations across the wrap give bitwise the
+    values of a fresh handle, and a non-finite x is still reported on both sides of it."""
+    import os
+    from hippopt_amd.hipnlp import HipNlpError
+    st = periodic_step_settings(8, model)
+    x, p = make_workload(st, model, batch=2, seed=5)
+    x2 = x + 1e-2 * np.random.RandomState(7).standard_normal(x.shape)
+    ref = HipNlp(st, model, batch=2)
+    ref.set_params(p)
+    r1, r2 = [a.copy() for a in ref.eval(x)], [a.copy() for a in ref.eval(x2)]
+    os.environ["HIPNLP_DEBUG_SEQ0"] = str(2 ** 31 - 4)
+    try:
+        eng = HipNlp(st, model, batch=2)
+    finally:
+        del os.environ["HIPNLP_DEBUG_SEQ0"]
+    eng.set_params(p)
+    bad = x.copy()
+    bad[1, 40] = np.nan
+    for i in range(8):   # launches 2^31 - 3 ... then 1, 2, ...
+        xi, r = (x, r1) if i % 2 == 0 else (x2, r2)
+        got = eng.eval(xi)
+        assert all(np.array_equal(a, b_) for a, b_ in zip(got, r)), i
+        if i in (1, 5):
+            with pytest.raises(HipNlpError):
+                eng.eval(bad)
+    hv_ref = ref.eval_hess(x, 1.0, np.ones((2, ref.m)))
+    for _ in range(6):
+        assert np.array_equal(eng.eval_hess(x, 1.0, np.ones((2, eng.m))), hv_ref)
+
+
 def test_early_outputs_into_registered_arrays(model, HipNlp):
     """hipnlp_set_early_outputs: the new-x call (eval_f) already fills the registered arrays the later eval_g / eval_grad_f / eval_jac_g
     calls pass; alternating iterates, so values left over from the previous x would show; a cached call with ANOTHER array is
