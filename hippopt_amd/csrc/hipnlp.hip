@@ -354,6 +354,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     // wave jumped over the other waves' code several times per phase, each jump a cold instruction-cache line.  The waves still meet
     // at the same barriers: every instance contains all of them.
 #define HIPNLP_W8(p, s) (TERRAIN == HIPNLP_TERRAIN_PLANAR ? (p) : (s))
+#define HIPNLP_W4(p, s) (TERRAIN == HIPNLP_TERRAIN_PLANAR ? (p) : (s))
 #ifdef HIPNLP_STAMPS
     unsigned long long st_task[24];   // diagnostic build: the time every task group of this wave ends, in program order
     int st_nt = 0;
@@ -399,6 +400,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 #undef DEV_R
 #undef DEV_BARRIER
 #undef HIPNLP_W8
+#undef HIPNLP_W4
 
     // ---- stream the knot's outputs ---------------------------------------------------------------------
     // All LDS reads and the non-finite check come first, then nothing but stores; the non-finite flag is kept per wavefront

@@ -755,10 +755,28 @@ template <class Em> HD void t_unitq(Ctx<Em>& cx, int) {
     s.grad[QB_ + 3] = 2.0 * m * (e[0] * ax + e[1] * ay + e[2] * az + e[3] * aw);
 }
 
+// --- smooth terrain: the jet of the terrain at the com (minimum com height row), one lane per bump; t_small (behind it on the same
+//     wave) adds the bumps in order.  (As ONE lane of t_small the n_steps bump jets — integer powers and an exp each — were the longest
+//     chain of the first phase of the four-wave stairs kernel: 6.7 k cycles.)  Parked at the very end of comp[], behind the bump jets
+//     and the terrain frames of the contact points.
+template <class S> HD double* terrain_com_part(S& s, int sidx) { return &s.comp[0][0] + NL * LSTR - 3 * HIPNLP_MAX_TERRAIN_STEPS + 3 * sidx; }
+static_assert(sizeof(TerrainStage) * NC + sizeof(double) * 3 * HIPNLP_MAX_TERRAIN_STEPS <= sizeof(double) * NL * LSTR &&
+              sizeof(double) * (10 * TERRAIN_BUMP_TASKS + 3 * HIPNLP_MAX_TERRAIN_STEPS) <= sizeof(double) * NL * LSTR, "com bump parts behind the point staging in comp[]");
+template <class Em> HD void t_com_bump(Ctx<Em>& cx, int sidx) {
+    if (terrain_is_planar(cx) || sidx >= cx.st.n_steps) return;
+    auto& s = cx.s;
+    double Z[10];
+    for (int i = 0; i < 10; ++i) Z[i] = 0.0;
+    terrain_bump_jet(cx.st.steps[sidx], s.x[COM_], s.x[COM_ + 1], 1, Z);
+    double* out = terrain_com_part(s, sidx);
+    for (int i = 0; i < 3; ++i) out[i] = Z[i];
+}
+
 // --- small global rows / costs: lanes 0..2 component-wise, lane 3 scalar: 4 tasks ---------------------------
 template <class Em> HD void t_small(Ctx<Em>& cx, int t) {
     auto& s = cx.s;
     Em& em = cx.em;
+    if (!terrain_is_planar(cx)) HIPNLP_WAVE_SYNC();   // the com bump parts of t_com_bump
     if (t < 3) {  // angular momentum bound rows h[3:]*mass (planner.py:342-350); gradient of the com velocity cost
         const int i = t;
         em.G(gs::AMB + i, row_id(RK_AMB, 0, i), s.x[H_ + 3 + i] * cx.gp.mass);
@@ -772,8 +790,11 @@ template <class Em> HD void t_small(Ctx<Em>& cx, int t) {
             em.G(gs::COMH, row_id(RK_COMH, 0, 0), s.x[COM_ + 2]);
             em.J(js::COMH + 2, row_id(RK_COMH, 0, 0), COM_ + 2, 1.0);
         } else {
-            double Z[10];
-            terrain_Z_jet(cx.st, s.x[COM_], s.x[COM_ + 1], 1, Z);
+            double Z[3] = {0.0, 0.0, 0.0};
+            for (int sidx = 0; sidx < cx.st.n_steps; ++sidx) {   // (t_com_bump, this wave)
+                const double* part = terrain_com_part(s, sidx);
+                for (int i = 0; i < 3; ++i) Z[i] += part[i];
+            }
             em.G(gs::COMH, row_id(RK_COMH, 0, 0), s.x[COM_ + 2] - Z[0]);
             em.J(js::COMH + 0, row_id(RK_COMH, 0, 0), COM_ + 0, -Z[1]);
             em.J(js::COMH + 1, row_id(RK_COMH, 0, 0), COM_ + 1, -Z[2]);
@@ -1419,22 +1440,22 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
 // of an eight-wave workgroup (the kernel variant for launches that leave most CUs idle: one workgroup per CU anyway, so the
 // phases are spread over twice the waves); host: plain loop.  Groups of one phase run concurrently on different waves;
 // BARRIER separates phases.  Groups that rely on running BEHIND another group of their wave (HIPNLP_WAVE_SYNC) share both ids.
-// HIPNLP_W8(p, s): wave of the eight-wave workgroup on the planar / on the smooth terrain (defined where the device expands the
+// HIPNLP_W4(p, s) / HIPNLP_W8(p, s): wave of the four- / eight-wave workgroup on the planar / on the smooth terrain (defined where the device expands the
 // program; host expansions ignore the wave ids).  The eight waves sit two per SIMD (w and w + 4): a phase's longest task wants a
 // partner with little to issue — on the planar terrain the terrain tasks are empty, so the pairing differs between the two.
 // ---------------------------------------------------------------------------------------------------
 #define HIPNLP_KNOT_PROGRAM(R, BARRIER)                                                   \
     R(0, 0, t_points_vec, 3 * NC) R(0, HIPNLP_W8(7, 2), t_joint_rows, NJ)                 \
-    R(1, HIPNLP_W8(7, 2), t_points_scalar, NC) R(1, 3, t_dyn, 7 + NJ + 3) R(1, 7, t_terrain_bump, TERRAIN_BUMP_TASKS) R(1, 7, t_terrain_stage, NC) R(1, 1, t_unitq, 1) \
+    R(1, HIPNLP_W8(7, 2), t_points_scalar, NC) R(HIPNLP_W4(1, 0), 3, t_dyn, 7 + NJ + 3) R(1, 7, t_terrain_bump, TERRAIN_BUMP_TASKS) R(1, 7, t_terrain_stage, NC) R(HIPNLP_W4(1, 0), 1, t_unitq, 1) \
     R(2, HIPNLP_W8(2, 4), t_joints, NJ) R(2, 1, t_feet_yaw, 2) R(2, HIPNLP_W8(4, 1), t_feet_centroid, 1) \
-    R(3, 5, t_base, 3) R(3, 6, t_small, 4) R(3, 3, t_points_dyn, 3 * NC)                  \
+    R(3, 5, t_base, 3) R(3, 6, t_com_bump, HIPNLP_MAX_TERRAIN_STEPS) R(3, 6, t_small, 4) R(3, 3, t_points_dyn, 3 * NC) \
     BARRIER                                                                               \
     R(0, 0, t_fk_rot_a, FK_TASKS_A) R(0, 0, t_link_u_a, FK_SPLIT)                         \
     R(3, 1, t_fk_rot_b, FK_TASKS_B) R(3, 1, t_link_u_b, NJ - FK_SPLIT)                    \
     R(1, 2, t_hdyn_entries, 48) R(1, 3, t_hdyn_rows, HDYN_TASKS - 48)                     \
     R(2, 7, t_terrain_hnf, NC) R(2, HIPNLP_W8(6, 4), t_terrain_swing, NC) R(2, HIPNLP_W8(6, 4), t_points_cost, 3) \
     R(2, HIPNLP_W8(6, 4), t_foot_costs, FOOT_TASKS) R(2, HIPNLP_W8(6, 4), t_foot_cost_sum, 2) \
-    R(1, 5, t_terrain_planar, NC) R(0, 6, t_terrain_dcc, NC) R(-1, 7, t_joint_cost, 1)    \
+    R(1, 5, t_terrain_planar, NC) R(HIPNLP_W4(0, 3), 6, t_terrain_dcc, NC) R(-1, 7, t_joint_cost, 1)    \
     BARRIER                                                                               \
     R(0, 0, t_links, NL) R(1, 1, t_frames, 3) R(2, 2, t_link_inertia, NL) R(3, -1, t_joint_cost, 1) \
     BARRIER                                                                               \
