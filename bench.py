@@ -427,11 +427,12 @@ def main():
                 fence()
                 e4 = max_over_ranks(time.perf_counter() - t1)
             late = px.timed_out()
+            fence()                      # every rank's pushes are complete: the buffers can go without another collective
+            px.close(barrier=False)
             res["peer_store"] = {"knots_per_s": hz * ksteps / e4, "ms_per_step": 1e3 * e4 / ksteps, "steps": ksteps, "timed_out": bool(late),
                                  "verified": "bitwise equal to the all-gather path on every rank, both buffer parities",
                                  "note": "no collective, no reassembly pass: every rank pushes its shard, entry by entry at its final position, into "
                                          "the [grad | jac | g | f] buffer of EVERY rank with plain stores over xGMI (HIP IPC), then flags"}
-            px.close()
         except Exception as err:  # noqa: BLE001  (an extra measurement must not take `value` down with it)
             res["peer_store"] = {"error": "%s: %s" % (type(err).__name__, err)}
         # beside it: no collective, every rank's kernel stores its shard straight into ONE shared pinned host buffer

@@ -281,10 +281,11 @@ class PeerExchange:
         self.cb.stream.synchronize()
         return bool(self.status.item())
 
-    def close(self):
+    def close(self, barrier=True):
+        """barrier=False: the caller has just been through a barrier of its own behind the last step (every rank's pushes are complete)"""
         if getattr(self, "_mine", None):
             self.cb.stream.synchronize()
-            if self.world > 1:
+            if self.world > 1 and barrier:
                 dist.barrier(group=self.cb.group)         # nobody still pushes into a buffer about to go
             for p in self._opened:
                 self._lib.hipnlp_ipc_close(p)
