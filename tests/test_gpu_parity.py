@@ -89,6 +89,50 @@ def test_minimize_modes_and_intended_joint_cost(model, HipNlp):
     assert rel(f[0], fo) < TOL and rel(grad[0], grado) < TOL and rel(g[0], go) < TOL and rel(jac[0], jaco) < TOL
 
 
+def test_random_configurations_both_kernel_variants(model, HipNlp):
+    """A seeded sweep over what selects code paths — terrain, horizon (incl. N = 2, 3: no interior knot / one), batch, the three modes of
+    the horizon-end expressions, the J6 reading, the kernel variant (HIPNLP_WAVES) and the reduction (in the launch / separate kernel)
+    — every result entrywise against the oracle.  The same x / p go through both variants: equal to 1e-13, f bitwise per variant
+    pair of reductions."""
+    import os
+    from oracle_lib import Oracle
+    rng = np.random.RandomState(20260)
+    modes = (_abi.EXPR_SKIP, _abi.EXPR_SUBJECT_TO, _abi.EXPR_MINIMIZE)
+    for case in range(10):
+        stairs = bool(rng.randint(2))
+        N = int(rng.choice([2, 3, 4, 7, 11]))
+        st = (stairs_settings if stairs else periodic_step_settings)(N, model)
+        st.final_state_expression_type = modes[rng.randint(3)]
+        st.final_state_expression_weight = float(rng.uniform(0.5, 3.0))
+        st.periodicity_expression_type = modes[rng.randint(3)]
+        st.periodicity_expression_weight = float(rng.uniform(0.5, 3.0))
+        st.joint_reg_as_coded = bool(rng.randint(2))
+        B = int(rng.choice([1, 2, 3]))
+        x, p = make_workload(st, model, batch=B, seed=300 + case)
+        if stairs:
+            place_on_step_flanks(x[:1], st, seed=case)
+        orc = Oracle(st, model)
+        refs = [orc.eval(x[b], p[b]) for b in range(B)]
+        outs = {}
+        for waves, sep in ((4, 0), (4, 1), (8, 0)):
+            os.environ["HIPNLP_WAVES"], os.environ["HIPNLP_SEPARATE_REDUCE"] = str(waves), str(sep)
+            try:
+                eng = HipNlp(st, model, batch=B)
+            finally:
+                del os.environ["HIPNLP_WAVES"], os.environ["HIPNLP_SEPARATE_REDUCE"]
+            assert (eng.n, eng.m, eng.nnz) == (orc.n, orc.m, orc.nnz), case
+            eng.set_params(p)
+            f, grad, g, jac = eng.eval(x)
+            for b in range(B):
+                fo, grado, go, jaco = refs[b]
+                assert rel(f[b], fo) < TOL and rel(grad[b], grado) < TOL and rel(g[b], go) < TOL and rel(jac[b], jaco) < TOL, (case, waves, sep, b)
+            outs[(waves, sep)] = (f.copy(), grad.copy(), g.copy(), jac.copy())
+        assert np.array_equal(outs[(4, 0)][0], outs[(4, 1)][0])     # the two reductions of one kernel: the same tree
+        assert all(np.array_equal(a, b_) for a, b_ in zip(outs[(4, 0)][1:], outs[(4, 1)][1:]))
+        for a, b_ in zip(outs[(4, 0)], outs[(8, 0)]):
+            assert rel(a, b_) < 1e-13, case
+
+
 def test_batch_and_determinism(model, HipNlp):
     from oracle_lib import Oracle
     st = periodic_step_settings(12, model)
