@@ -947,6 +947,11 @@ template <class Em> HD void t_fk_rot_b(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t +
 //  three steps + the base element instead of up to seven ancestor steps, ping-pong between the joint records and comp[].  Correct
 //  (all GPU tests), phase B 3.5 k -> 2.9 k cycles, +1.3 % at batch 64, but -2.6 % on the 100-knot step, whose duration is set by
 //  the workgroup that finishes the cost reduction; not kept.)
+// (Round 2 repeated it in place on the joint records, two lanes per joint — lane (j, 0): two columns of P and t, lane (j, 1): the
+//  third column, v and u = c_j; 46 lanes of ONE wave, a third of the LDS reads and half the fp64 instructions of the ancestor sums;
+//  0 scratch at 104-128 VGPRs.  Correct (65 GPU tests) and again not kept: 8.21 us against 7.88 on the 100-knot launch, -3 % at
+//  batch 4, +-0.5 % at x 64 / x 1024 / stairs 200 x 16: three DEPENDENT rounds of load -> 9 fma levels -> store -> wave fence are a
+//  longer chain than eight pipelined ancestor reads, and at batch the saved LDS reads were not what the launch waited for.)
 // (A level-synchronous variant — one step per joint, the wave walking the tree level by level behind wave-level fences — was
 //  measured at 4.7 k cycles against 3.4 k for these ancestor sums: a level costs two dependent LDS round trips, ~680 cycles.)
 // velocity of the body point of link i at the (base-centred) origin: vO_i = sum over the joints a on the path root -> i of
