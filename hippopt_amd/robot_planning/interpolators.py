@@ -28,7 +28,8 @@ def linear_interpolator(initial, final, number_of_points: int) -> list:
 def quaternion_slerp(initial, final, number_of_points: int) -> list:
     assert not isinstance(initial, list) and not isinstance(final, list)
     initial, final = _as_col(np.asarray(initial, float)), _as_col(np.asarray(final, float))
-    angle = np.arccos(float((initial.T @ final).reshape(-1)[0]))
+    with np.errstate(invalid="ignore"):   # a dot product of 1 + ulp gives NaN, as cs.acos does: NaN > 1e-6 is false, `initial` is returned
+        angle = np.arccos(float((initial.T @ final).reshape(-1)[0]))
     out = []
     for t_i in np.linspace(start=0.0, stop=1.0, num=number_of_points):
         out.append(slerp_step(initial, final, t_i) if abs(angle) > 1e-6 else initial)

@@ -3,10 +3,11 @@
 base/problem.py:58-79).
 
 The reference stores that dictionary with `hdf5storage.savemat` (MAT v7.3 = HDF5).  Neither hdf5storage nor h5py is in this
-image, so the container here is MAT v5 through `scipy.io.savemat` — same nested struct / cell layout, loadable in MATLAB and with
-`scipy.io.loadmat`; a v7.3 writer can be swapped in behind `save_mat` where h5py exists.  Keys that are not valid MATLAB
-field names are kept as they are on the reference side too (hdf5storage escapes them; scipy truncates names > 31 chars unless
-long_field_names is set, which it is)."""
+image, but the HDF5 C library is: `mat73.py` binds it with ctypes and writes / reads MAT v7.3 in hdf5storage's MATLAB-compatible
+layout (structs as groups, cells as object references into "/#refs#", reversed dimensions, MATLAB_class attributes, the MAT
+header in the user block) — the default container where the library is found.  Without it (or with `format="5"`) the container
+is MAT v5 through `scipy.io.savemat` — same nested struct / cell layout, loadable in MATLAB and with `scipy.io.loadmat`
+(scipy truncates names > 31 chars unless long_field_names is set, which it is).  `load_mat` recognises either."""
 import numpy as np
 
 
@@ -41,15 +42,27 @@ def to_mat_dict(output=None, guess=None, **extra) -> dict:
     return d
 
 
-def save_mat(file_name: str, output=None, guess=None, **extra) -> dict:
-    from scipy.io import savemat
+def save_mat(file_name: str, output=None, guess=None, format: str = None, **extra) -> dict:
+    """format: "7.3" (what the reference writes; needs the HDF5 C library), "5", or None = "7.3" where possible."""
+    from . import mat73
     d = to_mat_dict(output, guess, **extra)
-    savemat(file_name, d, long_field_names=True, oned_as="column")
+    if format is None:
+        format = "7.3" if mat73.available() else "5"
+    if format == "7.3":
+        mat73.savemat(file_name, d, appendmat=False)
+    elif format == "5":
+        from scipy.io import savemat
+        savemat(file_name, d, long_field_names=True, oned_as="column")
+    else:
+        raise ValueError("format is '7.3' or '5'")
     return d
 
 
 def load_mat(file_name: str) -> dict:
     """Back to nested dicts / lists / ndarrays (structs -> dict, cell arrays -> list)."""
+    from . import mat73
+    if mat73.is_v73(file_name):
+        return mat73.loadmat(file_name)
     from scipy.io import loadmat
     raw = loadmat(file_name, struct_as_record=False, squeeze_me=True)
 
