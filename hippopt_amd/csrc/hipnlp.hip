@@ -86,6 +86,7 @@ struct KArgs {
 // for global memory in the compact layout (measured: 10.0 -> 10.9 us per 100-knot launch).
 template <int TERRAIN, int WAVES = 4> struct DevEm {
     static constexpr int kTerrain = TERRAIN;
+    static constexpr int kWaves = WAVES;
     static constexpr int kLayout = WAVES == 4 ? LAYOUT_COMPACT : LAYOUT_FULL;
     static constexpr bool kCompact = kLayout != LAYOUT_FULL;
     using Scratch = KnotScratchT<kLayout>;
@@ -1394,7 +1395,7 @@ int hipnlp_cost_terms(hipnlp_handle* h, double* values) {
     if (!h || !values) return HIPNLP_E_INVALID;
     if (!h->have_result) {   // a device-path evaluation: its per-term costs are in device memory (the host path stores them straight to the pinned block)
         HIP_TRY(h, hipSetDevice(h->dev));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipDeviceSynchronize());   // (the launch may sit on a stream of the caller's: hipnlp_eval_device(..., stream))
         HIP_TRY(h, hipMemcpy(h->h_cost_terms, h->d_cost_terms, size_t(h->batch) * NCT * sizeof(double), hipMemcpyDeviceToHost));
     }
     std::memcpy(values, h->h_cost_terms, size_t(h->batch) * NCT * sizeof(double));

@@ -484,23 +484,51 @@ template <class S> HD TerrainStage* terrain_stage(S& s, int c) {
     else return reinterpret_cast<TerrainStage*>(&s.own[0][0]) + c;
 }
 
-// the jet of ONE bump at ONE point: lane (c, bump), NC x HIPNLP_MAX_TERRAIN_STEPS tasks; parked in the composite area (written only
-// three phases later).  (Splitting a bump's jet further over three lanes by derivative order, and the com height jet over bump
-// lanes, measured slower: the common prefix — powers and the exponential — dominates and is then computed three times.)  t_terrain_stage follows on the same wave, adds the bumps in order and builds the frame.
-constexpr int TERRAIN_BUMP_TASKS = NC * HIPNLP_MAX_TERRAIN_STEPS;
-static_assert(sizeof(double) * 10 * TERRAIN_BUMP_TASKS <= sizeof(double) * NL * LSTR, "bump jets must fit in comp[]");
+// the jet of ONE bump at ONE point: lane (c, bump), (NC + 1) x HIPNLP_MAX_TERRAIN_STEPS tasks — the eight contact points and, as a ninth
+// point, the com (the minimum com height row needs h_terrain(com): same instruction stream, four more lanes of the same wave; as a
+// task of its own on another wave — one lane per bump — it was the longest chain of the first phase of the four-wave stairs kernel
+// at batch: 3.7 k cycles next to a 3.6 k cycles t_small).  Parked in the composite area (written only three phases later); the
+// lanes of unused bumps store zeros, so that the sums below run over a FIXED number of parts, all read in one round trip (adding a
+// zero part changes no bit).  (Splitting a bump's jet further over three lanes by derivative order measured slower: the common
+// prefix — powers and the exponential — dominates and is then computed three times.)  t_terrain_stage follows on the same wave,
+// adds the bumps in order and builds the frames; the com's three numbers wait at the very end of comp[] — behind the bump jets
+// and the frames that take their place in the compact layouts — for t_com_height two phases later.
+constexpr int TERRAIN_BUMP_TASKS = (NC + 1) * HIPNLP_MAX_TERRAIN_STEPS;
 template <class S> HD double* terrain_bump_part(S& s, int c, int sidx) { return &s.comp[0][0] + 10 * (HIPNLP_MAX_TERRAIN_STEPS * c + sidx); }
+template <class S> HD double* terrain_com_part(S& s, int sidx) { return &s.comp[0][0] + NL * LSTR - 3 * HIPNLP_MAX_TERRAIN_STEPS + 3 * sidx; }
+static_assert(sizeof(TerrainStage) * NC + sizeof(double) * 3 * HIPNLP_MAX_TERRAIN_STEPS <= sizeof(double) * NL * LSTR &&
+              sizeof(double) * (10 * NC * HIPNLP_MAX_TERRAIN_STEPS + 3 * HIPNLP_MAX_TERRAIN_STEPS) <= sizeof(double) * NL * LSTR, "bump jets / frames and the com parts behind them must fit in comp[]");
 template <class Em> HD void t_terrain_bump(Ctx<Em>& cx, int t) {
     if (terrain_is_planar(cx)) return;
     auto& s = cx.s;
     const int c = t / HIPNLP_MAX_TERRAIN_STEPS, sidx = t - HIPNLP_MAX_TERRAIN_STEPS * c;
-    if (sidx >= cx.st.n_steps) return;
-    const double* p = s.x + PT_ * c + P_;
+    const double* p = c < NC ? s.x + PT_ * c + P_ : s.x + COM_;
     double Z[10];
     for (int i = 0; i < 10; ++i) Z[i] = 0.0;
-    terrain_bump_jet(cx.st.steps[sidx], p[0], p[1], 3, Z);
-    double* out = terrain_bump_part(s, c, sidx);
-    for (int i = 0; i < 10; ++i) out[i] = Z[i];
+    if (sidx < cx.st.n_steps) terrain_bump_jet(cx.st.steps[sidx], p[0], p[1], 3, Z);
+    if (c < NC) {
+        double* out = terrain_bump_part(s, c, sidx);
+        for (int i = 0; i < 10; ++i) out[i] = Z[i];
+    } else {
+        double* out = terrain_com_part(s, sidx);
+        for (int i = 0; i < 3; ++i) out[i] = Z[i];
+    }
+}
+// minimum com height on the smooth terrain: com_z - h_terrain(com) (planner.py:352-362; the planar row is part of t_small).  One lane,
+// in the third phase, on a wave with nothing else to do there.
+template <class Em> HD void t_com_height(Ctx<Em>& cx, int) {
+    if (terrain_is_planar(cx)) return;
+    auto& s = cx.s;
+    Em& em = cx.em;
+    double Z[3] = {0.0, 0.0, 0.0};
+    for (int sidx = 0; sidx < HIPNLP_MAX_TERRAIN_STEPS; ++sidx) {   // same order as terrain_Z_jet (unused bumps: zeros)
+        const double* part = terrain_com_part(s, sidx);
+        for (int i = 0; i < 3; ++i) Z[i] += part[i];
+    }
+    em.G(gs::COMH, row_id(RK_COMH, 0, 0), s.x[COM_ + 2] - Z[0]);
+    em.J(js::COMH + 0, row_id(RK_COMH, 0, 0), COM_ + 0, -Z[1]);
+    em.J(js::COMH + 1, row_id(RK_COMH, 0, 0), COM_ + 1, -Z[2]);
+    em.J(js::COMH + 2, row_id(RK_COMH, 0, 0), COM_ + 2, 1.0);
 }
 template <class Em> HD void t_terrain_stage(Ctx<Em>& cx, int c) {
     if (terrain_is_planar(cx)) return;
@@ -510,7 +538,7 @@ template <class Em> HD void t_terrain_stage(Ctx<Em>& cx, int c) {
     double Z[10];
     for (int i = 0; i < 10; ++i) Z[i] = 0.0;
     auto sum_parts = [&](int cc, double* z) {
-        for (int sidx = 0; sidx < cx.st.n_steps; ++sidx) {   // same order as terrain_Z_jet
+        for (int sidx = 0; sidx < HIPNLP_MAX_TERRAIN_STEPS; ++sidx) {   // same order as terrain_Z_jet (unused bumps: zeros)
             const double* part = terrain_bump_part(s, cc, sidx);
             for (int i = 0; i < 10; ++i) z[i] += part[i];
         }
@@ -755,28 +783,10 @@ template <class Em> HD void t_unitq(Ctx<Em>& cx, int) {
     s.grad[QB_ + 3] = 2.0 * m * (e[0] * ax + e[1] * ay + e[2] * az + e[3] * aw);
 }
 
-// --- smooth terrain: the jet of the terrain at the com (minimum com height row), one lane per bump; t_small (behind it on the same
-//     wave) adds the bumps in order.  (As ONE lane of t_small the n_steps bump jets — integer powers and an exp each — were the longest
-//     chain of the first phase of the four-wave stairs kernel: 6.7 k cycles.)  Parked at the very end of comp[], behind the bump jets
-//     and the terrain frames of the contact points.
-template <class S> HD double* terrain_com_part(S& s, int sidx) { return &s.comp[0][0] + NL * LSTR - 3 * HIPNLP_MAX_TERRAIN_STEPS + 3 * sidx; }
-static_assert(sizeof(TerrainStage) * NC + sizeof(double) * 3 * HIPNLP_MAX_TERRAIN_STEPS <= sizeof(double) * NL * LSTR &&
-              sizeof(double) * (10 * TERRAIN_BUMP_TASKS + 3 * HIPNLP_MAX_TERRAIN_STEPS) <= sizeof(double) * NL * LSTR, "com bump parts behind the point staging in comp[]");
-template <class Em> HD void t_com_bump(Ctx<Em>& cx, int sidx) {
-    if (terrain_is_planar(cx) || sidx >= cx.st.n_steps) return;
-    auto& s = cx.s;
-    double Z[10];
-    for (int i = 0; i < 10; ++i) Z[i] = 0.0;
-    terrain_bump_jet(cx.st.steps[sidx], s.x[COM_], s.x[COM_ + 1], 1, Z);
-    double* out = terrain_com_part(s, sidx);
-    for (int i = 0; i < 3; ++i) out[i] = Z[i];
-}
-
 // --- small global rows / costs: lanes 0..2 component-wise, lane 3 scalar: 4 tasks ---------------------------
 template <class Em> HD void t_small(Ctx<Em>& cx, int t) {
     auto& s = cx.s;
     Em& em = cx.em;
-    if (!terrain_is_planar(cx)) HIPNLP_WAVE_SYNC();   // the com bump parts of t_com_bump
     if (t < 3) {  // angular momentum bound rows h[3:]*mass (planner.py:342-350); gradient of the com velocity cost
         const int i = t;
         em.G(gs::AMB + i, row_id(RK_AMB, 0, i), s.x[H_ + 3 + i] * cx.gp.mass);
@@ -786,18 +796,8 @@ template <class Em> HD void t_small(Ctx<Em>& cx, int t) {
         s.grad[H_ + 3 + i] = 0.0;
         s.grad[COM_ + i] = 0.0; s.grad[PB_ + i] = 0.0; s.grad[VB_ + i] = 0.0;
     } else {      // minimum com height: h_terrain(com) = com_z ; com velocity and base quaternion velocity costs (k >= 0)
-        if (terrain_is_planar(cx)) {
+        if (terrain_is_planar(cx)) {   // (smooth terrain: t_com_height, behind the bump jets)
             em.G(gs::COMH, row_id(RK_COMH, 0, 0), s.x[COM_ + 2]);
-            em.J(js::COMH + 2, row_id(RK_COMH, 0, 0), COM_ + 2, 1.0);
-        } else {
-            double Z[3] = {0.0, 0.0, 0.0};
-            for (int sidx = 0; sidx < cx.st.n_steps; ++sidx) {   // (t_com_bump, this wave)
-                const double* part = terrain_com_part(s, sidx);
-                for (int i = 0; i < 3; ++i) Z[i] += part[i];
-            }
-            em.G(gs::COMH, row_id(RK_COMH, 0, 0), s.x[COM_ + 2] - Z[0]);
-            em.J(js::COMH + 0, row_id(RK_COMH, 0, 0), COM_ + 0, -Z[1]);
-            em.J(js::COMH + 1, row_id(RK_COMH, 0, 0), COM_ + 1, -Z[2]);
             em.J(js::COMH + 2, row_id(RK_COMH, 0, 0), COM_ + 2, 1.0);
         }
         double c = 0.0;
@@ -983,7 +983,15 @@ template <class S, class K> HD void link_origin_velocity(const S& s, const K& kt
 
 // (the branches of t_hdyn diverge inside a wave: entries and rows + com entries are task groups of their own)
 template <class Em> HD void t_hdyn(Ctx<Em>& cx, int t);
-template <class Em> HD void t_hdyn_entries(Ctx<Em>& cx, int t) { t_hdyn(cx, t); }
+// The entry tasks depend on the knot record only.  In the four-wave kernel of the SMOOTH terrain the first phase is set by one wave
+// (bump jets -> terrain frames) while the others wait, so they run there (t_hdyn_entries_a) instead of in the second phase; every
+// other instantiation (emitters without kWaves: host recorders / emulation; the planar and the eight-wave kernels) runs them in
+// the second phase.  Exactly one of the two task groups does the work.
+template <class Em, class = void> struct em_waves { static constexpr int value = 0; };
+template <class Em> struct em_waves<Em, std::void_t<decltype(Em::kWaves)>> { static constexpr int value = Em::kWaves; };
+template <class Em> constexpr bool hdyn_entries_early = em_waves<Em>::value == 4 && Em::kTerrain == HIPNLP_TERRAIN_SMOOTH_STEPS;
+template <class Em> HD void t_hdyn_entries_a(Ctx<Em>& cx, int t) { if constexpr (hdyn_entries_early<Em>) t_hdyn(cx, t); }
+template <class Em> HD void t_hdyn_entries(Ctx<Em>& cx, int t) { if constexpr (!hdyn_entries_early<Em>) t_hdyn(cx, t); }
 template <class Em> HD void t_hdyn_rows(Ctx<Em>& cx, int t) { t_hdyn(cx, t + 48); }
 // --- centroidal momentum dynamics (T7 on E1): lanes (c, e) 48 entry tasks + lanes 48..59 row tasks -----------
 constexpr int HDYN_TASKS = 60;
@@ -1451,18 +1459,18 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
 // ---------------------------------------------------------------------------------------------------
 #define HIPNLP_KNOT_PROGRAM(R, BARRIER)                                                   \
     R(0, 0, t_points_vec, 3 * NC) R(0, HIPNLP_W8(7, 2), t_joint_rows, NJ)                 \
-    R(1, HIPNLP_W8(7, 2), t_points_scalar, NC) R(HIPNLP_W4(1, 0), 3, t_dyn, 7 + NJ + 3) R(1, 7, t_terrain_bump, TERRAIN_BUMP_TASKS) R(1, 7, t_terrain_stage, NC) R(HIPNLP_W4(1, 0), 1, t_unitq, 1) \
-    R(2, HIPNLP_W8(2, 4), t_joints, NJ) R(2, 1, t_feet_yaw, 2) R(2, HIPNLP_W8(4, 1), t_feet_centroid, 1) \
-    R(3, 5, t_base, 3) R(3, 6, t_com_bump, HIPNLP_MAX_TERRAIN_STEPS) R(3, 6, t_small, 4) R(3, 3, t_points_dyn, 3 * NC) \
+    R(HIPNLP_W4(1, 3), HIPNLP_W8(7, 2), t_points_scalar, NC) R(HIPNLP_W4(1, 0), 3, t_dyn, 7 + NJ + 3) R(1, 7, t_terrain_bump, TERRAIN_BUMP_TASKS) R(1, 7, t_terrain_stage, NC) R(HIPNLP_W4(1, 0), 1, t_unitq, 1) \
+    R(2, HIPNLP_W8(2, 4), t_joints, NJ) R(2, 1, t_feet_yaw, 2) R(2, HIPNLP_W8(4, 1), t_feet_centroid, 1) R(HIPNLP_W4(-1, 2), -1, t_hdyn_entries_a, 48) \
+    R(3, 5, t_base, 3) R(3, 6, t_small, 4) R(3, 3, t_points_dyn, 3 * NC) \
     BARRIER                                                                               \
     R(0, 0, t_fk_rot_a, FK_TASKS_A) R(0, 0, t_link_u_a, FK_SPLIT)                         \
     R(3, 1, t_fk_rot_b, FK_TASKS_B) R(3, 1, t_link_u_b, NJ - FK_SPLIT)                    \
-    R(1, 2, t_hdyn_entries, 48) R(1, 3, t_hdyn_rows, HDYN_TASKS - 48)                     \
+    R(1, 2, t_hdyn_entries, 48) R(HIPNLP_W4(1, 3), 3, t_hdyn_rows, HDYN_TASKS - 48)                     \
     R(2, 7, t_terrain_hnf, NC) R(2, HIPNLP_W8(6, 4), t_terrain_swing, NC) R(2, HIPNLP_W8(6, 4), t_points_cost, 3) \
     R(2, HIPNLP_W8(6, 4), t_foot_costs, FOOT_TASKS) R(2, HIPNLP_W8(6, 4), t_foot_cost_sum, 2) \
-    R(1, 5, t_terrain_planar, NC) R(HIPNLP_W4(0, 3), 6, t_terrain_dcc, NC) R(-1, 7, t_joint_cost, 1)    \
+    R(1, 5, t_terrain_planar, NC) R(HIPNLP_W4(0, 1), 6, t_terrain_dcc, NC) R(-1, 7, t_joint_cost, 1)    \
     BARRIER                                                                               \
-    R(0, 0, t_links, NL) R(1, 1, t_frames, 3) R(2, 2, t_link_inertia, NL) R(3, -1, t_joint_cost, 1) \
+    R(0, 0, t_links, NL) R(1, 1, t_frames, 3) R(2, 2, t_link_inertia, NL) R(3, -1, t_joint_cost, 1) R(3, 3, t_com_height, 1) \
     BARRIER                                                                               \
     R(0, 0, t_composite_g0, 64) R(1, 1, t_composite_g1, 64) R(1, 2, t_composite_g2, 64)   \
     R(2, 3, t_composite_g3, 64) R(2, 4, t_composite_g4, 64) R(3, 5, t_composite_g5, 64) R(3, 6, t_pkin, NC) \
