@@ -1456,11 +1456,13 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
 // HIPNLP_W4(p, s) / HIPNLP_W8(p, s): wave of the four- / eight-wave workgroup on the planar / on the smooth terrain (defined where the device expands the
 // program; host expansions ignore the wave ids).  The eight waves sit two per SIMD (w and w + 4): a phase's longest task wants a
 // partner with little to issue — on the planar terrain the terrain tasks are empty, so the pairing differs between the two.
+// A group listed twice with wave -1 in one of the places (t_joint_cost, t_pkin) runs in a different PHASE in the two kernel variants; such
+// groups only write scratch (no emitter calls), so the host expansions, which run both, compute the same thing twice.
 // ---------------------------------------------------------------------------------------------------
 #define HIPNLP_KNOT_PROGRAM(R, BARRIER)                                                   \
     R(0, 0, t_points_vec, 3 * NC) R(0, HIPNLP_W8(7, 2), t_joint_rows, NJ)                 \
     R(HIPNLP_W4(1, 3), HIPNLP_W8(7, 2), t_points_scalar, NC) R(HIPNLP_W4(1, 0), 3, t_dyn, 7 + NJ + 3) R(1, 7, t_terrain_bump, TERRAIN_BUMP_TASKS) R(1, 7, t_terrain_stage, NC) R(HIPNLP_W4(1, 0), 1, t_unitq, 1) \
-    R(2, HIPNLP_W8(2, 4), t_joints, NJ) R(2, 1, t_feet_yaw, 2) R(2, HIPNLP_W8(4, 1), t_feet_centroid, 1) R(HIPNLP_W4(-1, 2), -1, t_hdyn_entries_a, 48) \
+    R(2, HIPNLP_W8(2, 4), t_joints, NJ) R(HIPNLP_W4(1, 2), 1, t_feet_yaw, 2) R(2, HIPNLP_W8(4, 1), t_feet_centroid, 1) R(HIPNLP_W4(-1, 2), -1, t_hdyn_entries_a, 48) \
     R(3, 5, t_base, 3) R(3, 6, t_small, 4) R(3, 3, t_points_dyn, 3 * NC) \
     BARRIER                                                                               \
     R(0, 0, t_fk_rot_a, FK_TASKS_A) R(0, 0, t_link_u_a, FK_SPLIT)                         \
@@ -1473,9 +1475,9 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
     R(0, 0, t_links, NL) R(1, 1, t_frames, 3) R(2, 2, t_link_inertia, NL) R(3, -1, t_joint_cost, 1) R(3, 3, t_com_height, 1) \
     BARRIER                                                                               \
     R(0, 0, t_composite_g0, 64) R(1, 1, t_composite_g1, 64) R(1, 2, t_composite_g2, 64)   \
-    R(2, 3, t_composite_g3, 64) R(2, 4, t_composite_g4, 64) R(3, 5, t_composite_g5, 64) R(3, 6, t_pkin, NC) \
+    R(2, 3, t_composite_g3, 64) R(2, 4, t_composite_g4, 64) R(3, 5, t_composite_g5, 64) R(-1, 6, t_pkin, NC) \
     BARRIER                                                                               \
-    R(0, 0, t_columns, NJ + 3) R(1, 1, t_cmm_columns, NJ + 3) R(2, 2, t_frame_columns, NJ) R(3, 3, t_ends, ENDS_TASKS) \
+    R(0, 0, t_columns, NJ + 3) R(1, 1, t_cmm_columns, NJ + 3) R(2, 2, t_frame_columns, NJ) R(3, 3, t_ends, ENDS_TASKS) R(3, -1, t_pkin, NC) \
     BARRIER                                                                               \
     R(0, 0, t_kinc, 3 * NC) R(1, 1, t_comc, 15) R(2, 2, t_cmmc, 15) R(2, 3, t_kinc_s, NC * LEG_PATH) \
     R(3, 4, t_feetd, 5) R(3, 4, t_ends_finish, ENDS_FINISH_TASKS)                         \

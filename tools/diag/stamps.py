@@ -101,6 +101,41 @@ if __name__ == "__main__":
         print("wave %d tasks: %s" % (w, "  ".join(line)))
     end = [int(blk[w, 8 + 2 * nb] - t0) for w in waves]
     print("end (stores issued) %s  (+%d)" % (end, max(end) - prev))
+    # the same table as MEDIANS over all workgroups of the launch (one workgroup's stamps move by +-30 % under load)
+    oa = out.astype(np.int64)
+    t0a = oa[:, waves, 0].min(axis=1)
+    ph = []
+    prev_a = oa[:, waves, 1].max(axis=1) - t0a
+    print("medians over %d workgroups: staged %d" % (len(oa), np.median(prev_a)))
+    for i in range(nb):
+        last = oa[:, waves, 8 + 2 * i].max(axis=1) - t0a
+        rel = oa[:, waves, 9 + 2 * i].max(axis=1) - t0a
+        ph.append(int(np.median(last - prev_a)))
+        prev_a = rel
+    print("  phases (last arrival - previous release): %s   copy-out %d   entry -> end %d" % (
+        ph, np.median(oa[:, waves, 8 + 2 * nb].max(axis=1) - t0a - prev_a), np.median(oa[:, waves, 8 + 2 * nb].max(axis=1) - t0a)))
+    for w in waves:
+        names, b = [], 0
+        for w4, w8, fn, bar in items:
+            if bar:
+                b += 1
+                continue
+            if int(w4 if len(waves) == 4 else w8) == w:
+                names.append((b, fn))
+        n = int(blk[w, 7])
+        line, tot, prev_b = [], {}, -1
+        for i in range(min(n, len(names))):
+            bb, fn = names[i]
+            if bb != prev_b:
+                prev_t = oa[:, w, 9 + 2 * (bb - 1)] if bb > 0 else oa[:, w, 1]
+                prev_b = bb
+            t = oa[:, w, 32 + i]
+            d = int(np.median(t - prev_t))
+            tot[bb] = tot.get(bb, 0) + d
+            line.append("%s[%d] %d" % (fn, bb, d))
+            prev_t = t
+        print("  wave %d: %s" % (w, "  ".join(line)))
+        print("          per phase: %s" % "  ".join("%d: %d" % kv for kv in sorted(tot.items())))
     if blk[waves[0], 64] != 0:   # -DHIPNLP_TWOPASS: the stamps above are those of the SECOND pass over the knot program
         first = [[int(blk[w, 65 + i] - blk[w, 64]) for i in range(nb)] for w in waves]
         start2 = [int(blk[w, 72]) for w in waves]
