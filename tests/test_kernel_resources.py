@@ -1,0 +1,65 @@
+"""The occupancy figures DESIGN.md and the launch logic (hipnlp.hip: `wide`, `fused`) assume, checked on the BUILT library's own code
+objects (tools/kernel_resources.py): a source change that makes the compiler unroll one loop can cost 70 VGPRs and a workgroup per
+CU without failing any numerical test (seen once: 8.3 instead of 7.9 us per 100-knot launch, x 64 30 % slower).  CPU only."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import kernel_resources  # noqa: E402
+
+LIB = os.path.join(ROOT, "hippopt_amd", "lib", "libhipnlp.so")
+LDS_PER_CU = 160 * 1024
+VGPR_FILE = 512          # per SIMD lane (unified VGPR + AGPR file of gfx950)
+
+
+def _granule(v):         # the allocation granularity of the register file is 8
+    return (v + 7) // 8 * 8
+
+
+@pytest.fixture(scope="module")
+def res():
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build()
+    if not os.path.exists(os.path.join(kernel_resources.LLVM, "llvm-readelf")):
+        pytest.skip("no llvm-readelf")
+    return kernel_resources.kernel_resources(LIB)
+
+
+def test_every_kernel_is_there_and_none_needs_scratch(res):
+    expect = {"hipnlp_knot_kernel<0,4>", "hipnlp_knot_kernel<1,4>", "hipnlp_knot_kernel<0,8>", "hipnlp_knot_kernel<1,8>", "hipnlp_knot_hess_kernel<0>",
+              "hipnlp_knot_hess_kernel<1>", "hipnlp_pose_kernel<0>", "hipnlp_pose_kernel<1>", "hipnlp_pose_hess_kernel<0>", "hipnlp_pose_hess_kernel<1>",
+              "hipnlp_reduce_kernel", "hipnlp_reassemble_kernel", "hipnlp_peer_push_kernel", "hipnlp_peer_signal_kernel", "hipnlp_peer_wait_kernel"}
+    assert expect <= set(res), sorted(expect - set(res))
+    for name, r in res.items():
+        assert r["scratch"] == 0, "%s spills %d B per lane to scratch" % (name, r["scratch"])
+
+
+@pytest.mark.parametrize("terrain", [0, 1])
+def test_four_wave_callback_kernel_fits_four_workgroups_per_cu(res, terrain):
+    r = res["hipnlp_knot_kernel<%d,4>" % terrain]
+    assert r["wg"] == 256
+    assert 4 * r["lds"] <= LDS_PER_CU, r
+    assert _granule(r["vgpr"] + r["agpr"]) * 4 <= VGPR_FILE, r      # four waves per SIMD
+
+
+@pytest.mark.parametrize("terrain", [0, 1])
+def test_eight_wave_callback_kernel_fits_two_workgroups_per_cu(res, terrain):
+    """hipnlp.hip picks it for (knots + 1) x batch <= 512 = 256 CUs x 2"""
+    r = res["hipnlp_knot_kernel<%d,8>" % terrain]
+    assert r["wg"] == 512
+    assert 2 * r["lds"] <= LDS_PER_CU, r
+    assert _granule(r["vgpr"] + r["agpr"]) * 4 <= VGPR_FILE, r      # 2 workgroups x 8 waves over 4 SIMDs
+
+
+def test_hessian_and_pose_kernels(res):
+    for t in (0, 1):
+        h = res["hipnlp_knot_hess_kernel<%d>" % t]
+        assert h["lds"] <= LDS_PER_CU and _granule(h["vgpr"] + h["agpr"]) <= 256, h
+        p = res["hipnlp_pose_kernel<%d>" % t]
+        assert 3 * p["lds"] <= LDS_PER_CU and _granule(p["vgpr"] + p["agpr"]) * 3 <= VGPR_FILE, p   # three per CU (DESIGN, pose kernels)
+        ph = res["hipnlp_pose_hess_kernel<%d>" % t]
+        assert 3 * ph["lds"] <= LDS_PER_CU and _granule(ph["vgpr"] + ph["agpr"]) * 3 <= VGPR_FILE, ph
