@@ -605,6 +605,12 @@ def test_two_ranks_on_one_gpu_rehearsal():
     assert side["peer_store"] and "error" not in side["peer_store"], side["peer_store"]
     assert side["peer_store"]["verified"].startswith("bitwise") and not side["peer_store"]["timed_out"]
     assert side["host_sink"] and "error" not in side["host_sink"], side["host_sink"]
+    # `value` is the faster of the two verified exchanges, timed over the same K steps; the line says which
+    ag, ps = line["all_gather"], side["peer_store"]
+    assert ag["steps"] == ps["steps"] == line["steps"] == 30
+    assert line["config"]["exchange"] == ("peer_store" if ps["ms_per_step"] < ag["ms_per_step"] else "all_gather")
+    assert abs(line["ms_per_step"] - min(ag["ms_per_step"], ps["ms_per_step"])) < 1e-9
+    assert ("peer stores" in line["config"]["parallelism"]) == (line["config"]["exchange"] == "peer_store")
 
 
 def test_host_path_want_mask_lazy_fetch_and_views(model, HipNlp):
