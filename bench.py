@@ -13,10 +13,11 @@ N > 1 : one rank per GPU.  `python bench.py --gpus N` started WITHOUT torch.dist
         processes, before anything touches a GPU) and relays rank 0's JSON line; started BY torch.distributed.run (WORLD_SIZE set) it
         is one of the ranks.  `value` is north_star's path: ONE trajectory whose horizon grows with N (100 knots per GPU, weak
         scaling), shooting intervals sharded contiguously, every step ending with [grad f | jac g | g | f] of the whole trajectory in
-        reference order on EVERY rank.  Two exchanges do that and both are timed the same way (W warm-up steps, exactly K steps between
+        reference order on EVERY rank.  Three exchanges do that and all are timed the same way (W warm-up steps, exactly K steps between
         barrier + synchronize, maximum over ranks): `all_gather` (ONE RCCL all-gather of the fused shard buffers + the one-launch
-        reassembly) and `peer_store` (plain stores over xGMI into IPC-shared buffers + flags: no collective, no reassembly pass;
-        checked bit for bit against the all-gather path on every rank before it is timed).  `value` is the faster of the two on
+        reassembly), `peer_store` (plain stores over xGMI into IPC-shared buffers + flags: no collective, no reassembly pass) and
+        `peer_direct` (the same with the knot kernel itself storing into every rank's buffer); the peer exchanges are checked bit
+        for bit against the all-gather path on every rank before they are timed.  `value` is the fastest of the three on
         this node (`config.exchange` says which; a peer exchange that fails to set up, differs or times out leaves the collective).
         Beside it: `independent_trajectories` (N replicas, no collective — BASELINE config 5's batched-guess shape) and `host_sink`
         (no collective either: every rank's kernel stores its shard straight into ONE shared pinned host buffer, what a CPU-side
@@ -401,56 +402,68 @@ def main():
             e2 = max_over_ranks(time.perf_counter() - t1)
         res["shard_resident"] = {"knots_per_s": hz * ksteps / e2, "ms_per_step": 1e3 * e2 / ksteps, "steps": ksteps,
                                  "note": "knot shards evaluated, outputs left shard-resident in each rank's HBM (no all-gather / reassembly)"}
-        # beside it: the same reassembled outputs on every rank by peer stores over xGMI instead of all-gather + reassembly
-        # (sharded.PeerExchange); checked bit for bit against the collective's result on every rank before it is timed
-        try:
-            from hippopt_amd.sharded import PeerExchange
-            px = PeerExchange(cb)
-            with torch.cuda.stream(cb.stream):
-                ref = [t.clone() for t in cb(xs[1 % nvar])]
-                got = [t.clone() for t in px(xs[1 % nvar])]
-                got2 = [t.clone() for t in px(xs[1 % nvar])]          # the other buffer parity
-            fence()
-            same = all(torch.equal(a, b_) and torch.equal(a, c_) for a, b_, c_ in zip(ref, got, got2)) and not px.timed_out()
-            flags = torch.tensor([1.0 if same else 0.0], device=device)
-            if world > 1:
-                if dist.get_backend() == "gloo":
-                    fl = flags.cpu(); dist.all_reduce(fl, op=dist.ReduceOp.MIN); flags = fl
-                else:
-                    dist.all_reduce(flags, op=dist.ReduceOp.MIN)
-            if float(flags[0]) != 1.0:
-                raise RuntimeError("peer exchange differs from the all-gather path on some rank")
-            # timed like the main leg: W warm-up steps, then EXACTLY K steps between barrier + synchronize, maximum over the ranks —
-            # so that either exchange can be the step behind `value` (below)
-            with torch.cuda.stream(cb.stream):
-                for i in range(warmup):
-                    px(xs[i % nvar])
+        # the same reassembled outputs on every rank by peer stores over xGMI instead of all-gather + reassembly (sharded.PeerExchange):
+        # `peer_store` pushes the fused shard buffer with one kernel behind the shard evaluation, `peer_direct` lets the knot kernel
+        # itself store into every rank's buffer (hipnlp_eval_device_peers).  Each is checked bit for bit against the collective's
+        # result on every rank (both buffer parities) before it is timed, and timed like the main leg: W warm-up steps, then EXACTLY
+        # K steps between barrier + synchronize, maximum over the ranks — so that any of the three can be the step behind `value`.
+        from hippopt_amd.sharded import PeerExchange
+
+        def time_peer(engine, note):
+            px = None
+            try:
+                px = PeerExchange(cb, engine=engine)
+                with torch.cuda.stream(cb.stream):
+                    ref = [t.clone() for t in cb(xs[1 % nvar])]
+                    got = [t.clone() for t in px(xs[1 % nvar])]
+                    got2 = [t.clone() for t in px(xs[1 % nvar])]          # the other buffer parity
                 fence()
-                t1 = time.perf_counter()
-                for i in range(steps):
-                    px(xs[i % nvar])
-                fence()
-                e4 = max_over_ranks(time.perf_counter() - t1)
-            late = px.timed_out()
-            fence()                      # every rank's pushes are complete: the buffers can go without another collective
-            px.close(barrier=False)
-            res["peer_store"] = {"knots_per_s": hz * steps / e4, "ms_per_step": 1e3 * e4 / steps, "steps": steps, "timed_out": bool(late),
-                                 "verified": "bitwise equal to the all-gather path on every rank, both buffer parities",
-                                 "note": "no collective, no reassembly pass: every rank pushes its shard, entry by entry at its final position, into "
-                                         "the [grad | jac | g | f] buffer of EVERY rank with plain stores over xGMI (HIP IPC), then flags"}
-            # `value` is the step of north_star's path — knot shards evaluated, [grad | jac | g | f] of the WHOLE trajectory on every
-            # rank — with whichever of the two exchanges is faster on this node (same results, checked bit for bit above); the
-            # other one stays beside it.  One rank: there is no exchange to choose, the collective's path is kept.
-            res["all_gather"] = {"knots_per_s": hz * steps / res["el"], "ms_per_step": 1e3 * res["el"] / steps, "steps": steps}
-            if world > 1 and not late and e4 < res["el"]:
-                res["el"] = e4
-                res["exchange"] = "peer_store"
-                res["parallelism"] = "knot-sharded x%d (contiguous shooting intervals) + peer stores over xGMI into every rank's output buffer (HIP IPC; no collective, no reassembly pass)" % world
-            else:
-                res["exchange"] = "all_gather"
-        except Exception as err:  # noqa: BLE001  (an extra measurement must not take `value` down with it)
-            res["peer_store"] = {"error": "%s: %s" % (type(err).__name__, err)}
-            res["exchange"] = "all_gather"
+                same = all(torch.equal(a, b_) and torch.equal(a, c_) for a, b_, c_ in zip(ref, got, got2)) and not px.timed_out()
+                flags = torch.tensor([1.0 if same else 0.0], device=device)
+                if world > 1:
+                    if dist.get_backend() == "gloo":
+                        fl = flags.cpu(); dist.all_reduce(fl, op=dist.ReduceOp.MIN); flags = fl
+                    else:
+                        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+                if float(flags[0]) != 1.0:
+                    raise RuntimeError("peer exchange differs from the all-gather path on some rank")
+                with torch.cuda.stream(cb.stream):
+                    for i in range(warmup):
+                        px(xs[i % nvar])
+                    fence()
+                    t1 = time.perf_counter()
+                    for i in range(steps):
+                        px(xs[i % nvar])
+                    fence()
+                    e4 = max_over_ranks(time.perf_counter() - t1)
+                late = px.timed_out()
+                fence()                      # every rank's pushes are complete: the buffers can go without another collective
+                px.close(barrier=False)
+                return e4, {"knots_per_s": hz * steps / e4, "ms_per_step": 1e3 * e4 / steps, "steps": steps, "timed_out": bool(late),
+                            "verified": "bitwise equal to the all-gather path on every rank, both buffer parities", "note": note}
+            except Exception as err:  # noqa: BLE001  (an extra measurement must not take `value` down with it)
+                # (a rank-local failure past the collective set-up leaves the other ranks in a collective: the launcher's timeout ends
+                #  the run; set-up failures and mismatches are agreed on collectively and land here on every rank)
+                return None, {"error": "%s: %s" % (type(err).__name__, err)}
+
+        e_ps, res["peer_store"] = time_peer(None, "no collective, no reassembly pass: every rank pushes its shard, entry by entry at its final position, into "
+                                                  "the [grad | jac | g | f] buffer of EVERY rank with plain stores over xGMI (HIP IPC), then flags")
+        e_pd = None
+        if eng.kernels_per_eval() == 1:
+            e_pd, res["peer_direct"] = time_peer(eng, "as peer_store with the push folded into the evaluation: the knot kernel stores the shard's entries "
+                                                      "at their final positions into every rank's buffer (hipnlp_eval_device_peers); three launches per step")
+        # `value` is the step of north_star's path — knot shards evaluated, [grad | jac | g | f] of the WHOLE trajectory on every rank —
+        # with whichever exchange is fastest on this node (same results, checked bit for bit above); the others stay beside it.
+        # One rank: there is no exchange to choose, the collective's path is kept.
+        res["all_gather"] = {"knots_per_s": hz * steps / res["el"], "ms_per_step": 1e3 * res["el"] / steps, "steps": steps}
+        res["exchange"] = "all_gather"
+        labels = {"peer_store": "peer stores over xGMI into every rank's output buffer (HIP IPC; no collective, no reassembly pass)",
+                  "peer_direct": "the knot kernel storing straight into every rank's output buffer over xGMI (HIP IPC; no collective, no push or reassembly pass)"}
+        for name, e in (("peer_store", e_ps), ("peer_direct", e_pd)):
+            if world > 1 and e is not None and not res[name]["timed_out"] and e < res["el"]:
+                res["el"] = e
+                res["exchange"] = name
+                res["parallelism"] = "knot-sharded x%d (contiguous shooting intervals) + %s" % (world, labels[name])
         # beside it: no collective, every rank's kernel stores its shard straight into ONE shared pinned host buffer
         try:
             name = "hipnlp_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid() if world > 1 else os.getpid())
@@ -572,7 +585,7 @@ def main():
                                                  "peak = 256 CUs x 2.4 GHz (stores also occupy the VGPR -> LDS path, not counted here)"}
         if main_res.get("exchange"):
             line["config"]["exchange"] = main_res["exchange"]
-        for key in ("all_gather", "shard_resident", "peer_store", "host_sink"):
+        for key in ("all_gather", "shard_resident", "peer_store", "peer_direct", "host_sink"):
             if main_res.get(key) is not None:
                 line[key] = main_res[key]
         if side is not None:

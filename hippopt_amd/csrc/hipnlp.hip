@@ -75,6 +75,10 @@ struct KArgs {
     int32_t seq, pad_;      // launch number of this handle (1, 2, ...)
     int32_t N, n, m, nnz, knot_begin, nk;
     int64_t jac_stride, jac_off, grad_stride, grad_off;  // output addressing: full arrays (stride nnz / n, offset 0) or shard-local
+    // peer mode (hipnlp_eval_device_peers; batch 1): instead of g / jac / grad / f above, the shard's values go — at their FINAL positions —
+    // into the buffer [grad (n) | jac (nnz) | g (m) | f partials (npeer) | f] of every one of npeer ranks (this device's own among them)
+    double* const* peer_out;   // [npeer] device-visible base addresses, or null
+    int32_t npeer, peer_rank;
 #ifdef HIPNLP_STAMPS
     unsigned long long* stamps;  // diagnostic build only: [blocks][32] s_memtime at every barrier (never in the product library)
 #endif
@@ -231,7 +235,13 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
                 double tot = 0.0;
 #pragma unroll
                 for (int c = 0; c < NCT; ++c) tot += __shfl(term, c, 64);
-                if (lane == 0) a.f[b] = tot;
+                if (lane == 0) {
+                    a.f[b] = tot;
+                    if (a.peer_out) {   // this shard's cost, to every rank's slot for this rank
+                        const int64_t o_f = int64_t(a.n) + a.nnz + a.m + a.peer_rank;
+                        for (int r = 0; r < a.npeer; ++r) a.peer_out[r][o_f] = tot;
+                    }
+                }
             }
             return;
         }
@@ -435,6 +445,26 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     if (HIPNLP_DIAG_SKIP & 2) a.g = nullptr;
     if (HIPNLP_DIAG_SKIP & 4) a.grad = nullptr;
 #endif
+    if (a.peer_out) {
+        // peer mode: the same stores as below, once per rank, into that rank's buffer at the entries' final positions (jbase, the g
+        // row map and the knot's grad offset are those of the WHOLE problem); the transfers over the links overlap with the knot
+        // programs of the workgroups still running — no push pass, no reassembly pass behind the kernel
+        const int64_t o_jac = a.n, o_g = int64_t(a.n) + a.nnz;
+        for (int r = 0; r < a.npeer; ++r) {
+            double* base = a.peer_out[r];
+            double* oj = base + o_jac + jbase;
+#pragma unroll
+            for (int it = 0; it < JP_ITERS; ++it) if (jp[it] >= 0) oj[tid + it * WG] = jvals[it];
+            if (last && tid < n_glob) base[o_jac + int64_t(jac_glob_base) + tid] = s.jac[jpg];
+            double* og = base + o_g;
+#pragma unroll
+            for (int it = 0; it < G_ITERS; ++it) if (ga[it] >= 0) og[ga[it] + gb[it] * k] = gvals[it];
+            double* ogr = base + int64_t(NXK) * k;
+#pragma unroll
+            for (int it = 0; it < GR_ITERS; ++it) { const int i = tid + it * WG; if (i < NXK) ogr[i] = grvals[it]; }
+            if (last && tid < NXG) base[int64_t(NXK) * N + tid] = 0.0;
+        }
+    }
     if (a.jac) {
         double* out = a.jac + int64_t(b) * a.jac_stride + (jbase - a.jac_off);
 #pragma unroll
@@ -981,8 +1011,10 @@ int hipnlp_sparsity(const hipnlp_handle* h, int32_t* irow, int32_t* jcol) {
 // 100-knot callback.  The host-buffer path (hipnlp_eval, PCIe bound anyway) is always timed; the device path is timed only for
 // the launches an armed profile selects (every stride-th launch), so that measuring does not change what is measured.
 static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, hipStream_t s,
-                  double* g_stage = nullptr, bool shard_local = false, bool always_timed = false, bool host_block = false) {
+                  double* g_stage = nullptr, bool shard_local = false, bool always_timed = false, bool host_block = false,
+                  double* const* peer_out = nullptr, int npeer = 0, int peer_rank = 0) {
     KArgs a;
+    a.peer_out = peer_out; a.npeer = npeer; a.peer_rank = peer_rank;
     a.tb = h->d_tb; a.x = x_dev; a.pk = h->d_pk; a.gp = h->d_gp;
     a.g = g_dev; a.jac = jac_dev; a.grad = grad_dev; a.g_stage = g_stage;
     if (shard_local) {
@@ -1189,6 +1221,16 @@ int hipnlp_eval_device_shard(hipnlp_handle* h, const double* x_dev, double* f_de
     HIP_TRY(h, hipSetDevice(h->dev));
     h->have_result = false;
     return launch(h, x_dev, f_dev ? f_dev : h->d_f, grad_shard, nullptr, jac_shard, stream ? hipStream_t(stream) : h->stream, g_stage, true);
+}
+
+int hipnlp_eval_device_peers(hipnlp_handle* h, const double* x_dev, double* const* peer_out_dev, int world, int rank, void* stream) {
+    if (!h || !x_dev || !peer_out_dev || world < 1 || rank < 0 || rank >= world) return HIPNLP_E_INVALID;
+    if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
+    if (h->batch != 1) { h->err = "hipnlp_eval_device_peers: one trajectory per handle (batch 1)"; return HIPNLP_E_INVALID; }
+    if (!h->fused) { h->err = "hipnlp_eval_device_peers: shards of at most 256 knots (the shard's cost is summed inside the launch)"; return HIPNLP_E_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->dev));
+    h->have_result = false;
+    return launch(h, x_dev, h->d_f, nullptr, nullptr, nullptr, stream ? hipStream_t(stream) : h->stream, nullptr, false, false, false, peer_out_dev, world, rank);
 }
 
 int hipnlp_stage_rows(const hipnlp_handle* h, int k, int32_t* rows) {

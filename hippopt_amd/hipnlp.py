@@ -20,7 +20,7 @@ EXPORTS = [
     "hipnlp_cost_terms", "hipnlp_cost_term_name", "hipnlp_num_row_blocks", "hipnlp_row_block",
     "hipnlp_last_kernel_ms", "hipnlp_profile_begin", "hipnlp_profile_end", "hipnlp_kernels_per_eval", "hipnlp_profile_begin_runs",
     "hipnlp_eval_device_shard", "hipnlp_stage_rows", "hipnlp_reassemble",
-    "hipnlp_ipc_alloc", "hipnlp_ipc_open", "hipnlp_ipc_close", "hipnlp_ipc_free", "hipnlp_peer_push", "hipnlp_peer_signal", "hipnlp_peer_wait",
+    "hipnlp_ipc_alloc", "hipnlp_ipc_open", "hipnlp_ipc_close", "hipnlp_ipc_free", "hipnlp_peer_push", "hipnlp_peer_signal", "hipnlp_peer_wait", "hipnlp_eval_device_peers",
     "hipnlp_hess_nnz", "hipnlp_hess_sparsity", "hipnlp_eval_hess", "hipnlp_eval_hess_device",
     "hipnlp_eval_pinned", "hipnlp_set_prefetch", "hipnlp_set_early_outputs", "hipnlp_set_host_timing", "hipnlp_host_register", "hipnlp_host_unregister",
     "hipnlp_host_breakdown",
@@ -339,6 +339,10 @@ class HipNlp:
     def eval_device_shard(self, x_ptr, f_ptr, grad_ptr, g_stage_ptr, jac_ptr, stream=0):
         self._check(self.lib.hipnlp_eval_device_shard(self.h, C.c_void_p(x_ptr), C.c_void_p(f_ptr or None), C.c_void_p(grad_ptr or None),
                                                       C.c_void_p(g_stage_ptr or None), C.c_void_p(jac_ptr or None), C.c_void_p(stream or None)))
+
+    def eval_device_peers(self, x_ptr, peer_out_ptr, world, rank, stream=0):
+        """hipnlp_eval_device_peers: the shard's outputs at their final positions in every rank's [grad | jac | g | f partials | f] buffer"""
+        self._check(self.lib.hipnlp_eval_device_peers(self.h, C.c_void_p(x_ptr), C.c_void_p(peer_out_ptr), int(world), int(rank), C.c_void_p(stream or None)))
 
     def stage_rows(self, k):
         rows = np.zeros(G_STAGE, np.int32)

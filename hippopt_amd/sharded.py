@@ -168,16 +168,24 @@ class PeerExchange:
         px = PeerExchange(cb)
         f, grad, jac, g = px(x)          # views of this rank's output buffer of the step's parity
 
+    With `engine` (the rank's HipNlp shard handle; shards of at most 256 knots) the push is folded into the evaluation
+    (hipnlp_eval_device_peers): the knot kernel itself stores the shard's entries at their final positions in every rank's buffer —
+    the link transfers overlap with the knot programs still running, and a step is three launches (evaluate, signal, wait)
+    instead of four plus the staging of g.
+
     Two output buffers alternate between steps: a rank starts pushing step i + 1 once every rank has signalled step i, i.e. has
     finished its own push of step i — at which point a slow rank may still be READING step i, so step i + 1 goes to the other
     buffer (and step i + 2 cannot start before everyone has signalled i + 1, which comes behind their use of step i in stream order).
     The caller orders its consumption of the views before its next call on the same stream, as with ShardedCallback."""
 
-    def __init__(self, cb):
+    def __init__(self, cb, engine=None):
         import ctypes as C
         if cb.device.type != "cuda":
             raise RuntimeError("PeerExchange needs the HIP engine (peer stores between device buffers)")
         self.cb = cb
+        self.engine = engine
+        if engine is not None and engine.kernels_per_eval() != 1:
+            raise RuntimeError("PeerExchange(engine=...): the shard's cost must be summed inside the knot launch (shards of at most 256 knots)")
         self.world, self.rank = cb.world, cb.rank
         lib = cb._lib
         self._lib = lib
@@ -261,11 +269,15 @@ class PeerExchange:
             cb.stream.wait_stream(cur)
         with torch.cuda.stream(cb.stream):
             sh = cb.stream.cuda_stream
-            cb.compute_shard(x, *cb.views, sh)
             self.seq += 1
             par = self.seq & 1
             lib = self._lib
-            rc = lib.hipnlp_peer_push(cb.buf.data_ptr(), self.dst.data_ptr(), cb.shard_len, self.peer_out[par].data_ptr(), self.world, sh)
+            if self.engine is not None:
+                self.engine.eval_device_peers(x.data_ptr(), self.peer_out[par].data_ptr(), self.world, self.rank, stream=sh)
+                rc = 0
+            else:
+                cb.compute_shard(x, *cb.views, sh)
+                rc = lib.hipnlp_peer_push(cb.buf.data_ptr(), self.dst.data_ptr(), cb.shard_len, self.peer_out[par].data_ptr(), self.world, sh)
             rc |= lib.hipnlp_peer_signal(self.peer_flags.data_ptr(), self.world, self.rank, self.seq, sh)
             out = self._views[par]
             rc |= lib.hipnlp_peer_wait(self.my_flags, self.world, self.seq, out.data_ptr(), self.tot, self.status.data_ptr(), sh)

@@ -312,6 +312,14 @@ int hipnlp_peer_push(const double* shard_dev, const int64_t* dst_dev, int64_t co
 int hipnlp_peer_signal(unsigned long long* const* peer_flags_dev, int world, int rank, unsigned long long seq, void* stream);
 int hipnlp_peer_wait(const unsigned long long* flags_dev, int world, unsigned long long seq, double* out_dev, int64_t f_off,
                      int* status_dev, void* stream);
+/* The push folded into the evaluation: the knot kernel of a shard handle (batch 1, at most 256 knots in the shard) stores the shard's
+ * grad f / jac g / g entries — at their FINAL positions — and the shard's cost straight into the buffer of every rank,
+ *     peer_out[r] = [grad f (n) | jac g (nnz) | g (m) | cost partial of rank 0 .. world-1 | f]      (n, m, nnz of the whole problem),
+ * the layout hipnlp_peer_push fills (f_off = n + nnz + m for hipnlp_peer_wait): the transfers over the links overlap with the knot
+ * programs still running, and neither a push nor a reassembly launch follows.  peer_out_dev: DEVICE array of `world` device-visible
+ * base addresses (hipnlp_ipc_alloc / hipnlp_ipc_open).  Then hipnlp_peer_signal and hipnlp_peer_wait as above.  Enqueued on `stream`
+ * (NULL: the handle's own stream), not synchronised; the non-finite flag of the handle works as with hipnlp_eval_device. */
+int hipnlp_eval_device_peers(hipnlp_handle* h, const double* x_dev, double* const* peer_out_dev, int world, int rank, void* stream);
 
 /* Per-named-cost values of the last evaluation (Output.cost_values, base/problem.py:28-56):
  * values[batch][HIPNLP_NCOST_TERMS], summed over knots, in the order of hipnlp_cost_term_name(). */

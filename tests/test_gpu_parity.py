@@ -1,5 +1,7 @@
 """GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
 Tolerance: fp64, max |a-b| / max(1,|b|) <= 1e-11 for every entry of f, grad f, g, jac g."""
+import os
+
 import numpy as np
 import pytest
 
@@ -569,19 +571,77 @@ def test_peer_exchange_equals_the_gathered_callback(model, HipNlp):
     sh = HipNlp(st, model, knot_begin=0, knot_end=N)
     sh.set_params(p)
     cb = ShardedCallback(N, sh.n, sh.m, sh.nnz, hip_shard_info(sh, 0, N), hip_shard_backend(sh), dev)
-    px = PeerExchange(cb)
     rng = np.random.RandomState(5)
     xs = [x[0] + 1e-2 * i * rng.standard_normal(x.shape[1]) for i in range(5)]
-    got = []
-    for xi in xs:
-        fs, grads, jacs, gs = px(torch.from_numpy(xi).to(dev))
-        got.append((fs.clone(), grads.clone(), jacs.clone(), gs.clone()))
-    assert not px.timed_out()
-    for xi, (fs, grads, jacs, gs) in zip(xs, got):
+    for engine in (None, sh):   # push kernel behind the shard evaluation / stores folded into the evaluation (hipnlp_eval_device_peers)
+        px = PeerExchange(cb, engine=engine)
+        got = []
+        for xi in xs:
+            fs, grads, jacs, gs = px(torch.from_numpy(xi).to(dev))
+            got.append((fs.clone(), grads.clone(), jacs.clone(), gs.clone()))
+        assert not px.timed_out()
+        for xi, (fs, grads, jacs, gs) in zip(xs, got):
+            f, grad, g, jac = full.eval(xi[None, :])
+            assert float(fs) == f[0]
+            assert np.array_equal(grads.cpu().numpy(), grad[0]) and np.array_equal(jacs.cpu().numpy(), jac[0]) and np.array_equal(gs.cpu().numpy(), g[0])
+        px.close()
+
+
+@pytest.mark.parametrize("terrain,waves,split", [("planar", 8, 12), ("planar", 4, 9), ("stairs", 8, 15), ("stairs", 4, 1)])
+def test_evaluation_that_stores_into_every_ranks_buffer(model, HipNlp, terrain, waves, split):
+    """hipnlp_eval_device_peers: the knot kernel of a shard handle writes the shard's entries at their FINAL positions into the
+    [grad | jac | g | f partials | f] buffer of every rank.  Two shard handles of one process play two ranks (uneven shards, both
+    kernel variants, both terrains); both buffers must hold, bit for bit, the unsharded callback's grad / jac / g, and the cost
+    partials the all-gather path sums."""
+    import torch
+    N = 24
+    st = (stairs_settings if terrain == "stairs" else periodic_step_settings)(N, model)
+    x, p = make_workload(st, model, batch=1, seed=91)
+    dev = torch.device("cuda", 0)
+    os.environ["HIPNLP_WAVES"] = str(waves)
+    try:
+        full = HipNlp(st, model)
+        shards = [HipNlp(st, model, knot_begin=0, knot_end=split), HipNlp(st, model, knot_begin=split, knot_end=N)]
+    finally:
+        del os.environ["HIPNLP_WAVES"]
+    for e in [full] + shards:
+        e.set_params(p)
+    n, m, nnz = full.n, full.m, full.nnz
+    tot, world = n + nnz + m, 2
+    bufs = [torch.full((tot + world + 1,), float("nan"), dtype=torch.float64, device=dev) for _ in range(world)]
+    table = torch.tensor([b.data_ptr() for b in bufs], dtype=torch.int64, device=dev)
+    flags = torch.zeros(64, dtype=torch.int64, device=dev)
+    ftab = torch.tensor([flags.data_ptr()], dtype=torch.int64, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.Stream()
+    lib = full.lib
+    import ctypes as C
+    vp = C.c_void_p
+    lib.hipnlp_peer_signal.argtypes = [vp, C.c_int, C.c_int, C.c_ulonglong, vp]
+    lib.hipnlp_peer_wait.argtypes = [vp, C.c_int, C.c_ulonglong, vp, C.c_int64, vp, vp]
+    rng = np.random.RandomState(3)
+    for step in (1, 2, 3):
+        xi = x[0] + 1e-2 * step * rng.standard_normal(x.shape[1])
+        xd = torch.from_numpy(xi).to(dev)
+        with torch.cuda.stream(stream):
+            for r, e in enumerate(shards):
+                e.eval_device_peers(xd.data_ptr(), table.data_ptr(), world, r, stream=stream.cuda_stream)
+                # (one process: both "ranks" signal into the one flag array)
+                assert lib.hipnlp_peer_signal(ftab.data_ptr(), 1, 0, step, stream.cuda_stream) == 0
+        stream.synchronize()
+        flags[1] = flags[0]   # the wait below is that of "rank 0": both slots must carry the step
+        with torch.cuda.stream(stream):
+            assert lib.hipnlp_peer_wait(flags.data_ptr(), world, step, bufs[0].data_ptr(), tot, status.data_ptr(), stream.cuda_stream) == 0
+        stream.synchronize()
+        assert int(status.item()) == 0
         f, grad, g, jac = full.eval(xi[None, :])
-        assert float(fs) == f[0]
-        assert np.array_equal(grads.cpu().numpy(), grad[0]) and np.array_equal(jacs.cpu().numpy(), jac[0]) and np.array_equal(gs.cpu().numpy(), g[0])
-    px.close()
+        for b in bufs:
+            o = b.cpu().numpy()
+            assert np.array_equal(o[:n], grad[0]) and np.array_equal(o[n:n + nnz], jac[0]) and np.array_equal(o[n + nnz:tot], g[0])
+            assert np.isfinite(o[tot:tot + world]).all() and abs((o[tot] + o[tot + 1]) - f[0]) <= 1e-12 * abs(f[0])
+        assert float(bufs[0][tot + world]) == float(bufs[0][tot]) + float(bufs[0][tot + 1])   # hipnlp_peer_wait: partials in rank order
+        for b in bufs:
+            b.fill_(float("nan"))
 
 
 def test_two_ranks_on_one_gpu_rehearsal():
@@ -601,16 +661,18 @@ def test_two_ranks_on_one_gpu_rehearsal():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["value"] > 0
-    side = {k: line.get(k) or line["config"].get(k) for k in ("peer_store", "host_sink", "shard_resident")}
-    assert side["peer_store"] and "error" not in side["peer_store"], side["peer_store"]
-    assert side["peer_store"]["verified"].startswith("bitwise") and not side["peer_store"]["timed_out"]
+    side = {k: line.get(k) or line["config"].get(k) for k in ("peer_store", "peer_direct", "host_sink", "shard_resident")}
+    for k in ("peer_store", "peer_direct"):
+        assert side[k] and "error" not in side[k], side[k]
+        assert side[k]["verified"].startswith("bitwise") and not side[k]["timed_out"]
     assert side["host_sink"] and "error" not in side["host_sink"], side["host_sink"]
-    # `value` is the faster of the two verified exchanges, timed over the same K steps; the line says which
-    ag, ps = line["all_gather"], side["peer_store"]
-    assert ag["steps"] == ps["steps"] == line["steps"] == 30
-    assert line["config"]["exchange"] == ("peer_store" if ps["ms_per_step"] < ag["ms_per_step"] else "all_gather")
-    assert abs(line["ms_per_step"] - min(ag["ms_per_step"], ps["ms_per_step"])) < 1e-9
-    assert ("peer stores" in line["config"]["parallelism"]) == (line["config"]["exchange"] == "peer_store")
+    # `value` is the fastest of the three verified exchanges, timed over the same K steps; the line says which
+    legs = {"all_gather": line["all_gather"], "peer_store": side["peer_store"], "peer_direct": side["peer_direct"]}
+    assert all(v["steps"] == line["steps"] == 30 for v in legs.values())
+    best = min(legs, key=lambda k: legs[k]["ms_per_step"])
+    assert line["config"]["exchange"] == best
+    assert abs(line["ms_per_step"] - legs[best]["ms_per_step"]) < 1e-9
+    assert ("every rank's output buffer" in line["config"]["parallelism"]) == (best != "all_gather")
 
 
 def test_host_path_want_mask_lazy_fetch_and_views(model, HipNlp):
