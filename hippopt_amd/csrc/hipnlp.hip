@@ -135,7 +135,9 @@ constexpr int PUB_SPIN_CAP = 1 << 20;   // polls of the reducer before it gives 
 //            when the whole launch is resident at once at two workgroups per CU ((knots + 1) x batch <= 512), e.g. one 100-knot
 //            trajectory.
 // Four workgroups per CU for the four-wave kernels (compact scratch + lite tables: <= 40 KB of LDS, <= 128 VGPRs).
-template <int TERRAIN, int WAVES> __global__ __launch_bounds__(64 * WAVES)
+// PEERS: the instantiation behind hipnlp_eval_device_peers (outputs into every rank's buffer); a template parameter rather than a
+// run-time branch — as a branch the unused path cost the plain callback 1.2 % at N = 100 (7.99 against 7.89 us) and 0.8 % at x 64.
+template <int TERRAIN, int WAVES, bool PEERS = false> __global__ __launch_bounds__(64 * WAVES)
 __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 4 : 2, 4)))
 void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const double* pk_p, const GParams* gp_p, int N_p, int n_p, int kb_p, int nk_p, KArgs a) {
     // the leading scalar arguments repeat what the staging loads need: the build preloads them into SGPRs
@@ -237,7 +239,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
                 for (int c = 0; c < NCT; ++c) tot += __shfl(term, c, 64);
                 if (lane == 0) {
                     a.f[b] = tot;
-                    if (a.peer_out) {   // this shard's cost, to every rank's slot for this rank
+                    if constexpr (PEERS) {   // this shard's cost, to every rank's slot for this rank
                         const int64_t o_f = int64_t(a.n) + a.nnz + a.m + a.peer_rank;
                         for (int r = 0; r < a.npeer; ++r) a.peer_out[r][o_f] = tot;
                     }
@@ -445,7 +447,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     if (HIPNLP_DIAG_SKIP & 2) a.g = nullptr;
     if (HIPNLP_DIAG_SKIP & 4) a.grad = nullptr;
 #endif
-    if (a.peer_out) {
+    if constexpr (PEERS) {
         // peer mode: the same stores as below, once per rank, into that rank's buffer at the entries' final positions (jbase, the g
         // row map and the knot's grad offset are those of the WHOLE problem); the transfers over the links overlap with the knot
         // programs of the workgroups still running — no push pass, no reassembly pass behind the kernel
@@ -1061,7 +1063,15 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     if (timed) HIP_TRY(h, hipEventRecord(e0, s));
     const dim3 grid(unsigned(h->nk) + (h->fused ? 1u : 0u), unsigned(h->batch));   // (+ the row's cost reducer)
     const bool planar = h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR;
-    if (h->wide) {   // the whole launch resident at once: eight waves per knot
+    if (peer_out) {
+        if (h->wide) {
+            if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+            else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+        } else {
+            if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 4, true>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+            else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 4, true>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+        }
+    } else if (h->wide) {   // the whole launch resident at once: eight waves per knot
         if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
         else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
     } else {

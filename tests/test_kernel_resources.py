@@ -38,18 +38,20 @@ def test_every_kernel_is_there_and_none_needs_scratch(res):
         assert r["scratch"] == 0, "%s spills %d B per lane to scratch" % (name, r["scratch"])
 
 
+@pytest.mark.parametrize("peers", ["", ",true"])
 @pytest.mark.parametrize("terrain", [0, 1])
-def test_four_wave_callback_kernel_fits_four_workgroups_per_cu(res, terrain):
-    r = res["hipnlp_knot_kernel<%d,4>" % terrain]
+def test_four_wave_callback_kernel_fits_four_workgroups_per_cu(res, terrain, peers):
+    r = res["hipnlp_knot_kernel<%d,4%s>" % (terrain, peers)]
     assert r["wg"] == 256
     assert 4 * r["lds"] <= LDS_PER_CU, r
     assert _granule(r["vgpr"] + r["agpr"]) * 4 <= VGPR_FILE, r      # four waves per SIMD
 
 
+@pytest.mark.parametrize("peers", ["", ",true"])
 @pytest.mark.parametrize("terrain", [0, 1])
-def test_eight_wave_callback_kernel_fits_two_workgroups_per_cu(res, terrain):
+def test_eight_wave_callback_kernel_fits_two_workgroups_per_cu(res, terrain, peers):
     """hipnlp.hip picks it for (knots + 1) x batch <= 512 = 256 CUs x 2"""
-    r = res["hipnlp_knot_kernel<%d,8>" % terrain]
+    r = res["hipnlp_knot_kernel<%d,8%s>" % (terrain, peers)]
     assert r["wg"] == 512
     assert 2 * r["lds"] <= LDS_PER_CU, r
     assert _granule(r["vgpr"] + r["agpr"]) * 4 <= VGPR_FILE, r      # 2 workgroups x 8 waves over 4 SIMDs

@@ -55,9 +55,12 @@ def kernel_resources(lib_path=None):
                 if m:
                     n0 = m.end()
                     short = name[n0:n0 + int(m.group(1))]
-                    t = re.match(r"I((?:Li\d+E)+)E", name[n0 + int(m.group(1)):])
+                    t = re.match(r"I((?:L[ib]\d+E)+)E", name[n0 + int(m.group(1)):])
                     if t:
-                        short += "<" + ",".join(re.findall(r"Li(\d+)E", t.group(1))) + ">"
+                        args = re.findall(r"L([ib])(\d+)E", t.group(1))
+                        while args and args[-1] == ("b", "0"):   # (trailing `false` defaults are left out: <0,4> is <0,4,false>)
+                            args.pop()
+                        short += "<" + ",".join(("true" if v == "1" else "false") if k == "b" else v for k, v in args) + ">"
                 res[short] = {"vgpr": num("vgpr_count"), "agpr": int(blk.split()[0]), "sgpr": num("sgpr_count"), "scratch": num("private_segment_fixed_size"),
                               "lds": num("group_segment_fixed_size"), "wg": num("max_flat_workgroup_size")}
     return res
