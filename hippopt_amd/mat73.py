@@ -80,6 +80,10 @@ def _lib():
             L.H5open.restype = C.c_int
             if L.H5open() < 0:
                 raise OSError("H5open failed")
+            ver = (C.c_uint * 3)()
+            L.H5get_libversion(C.byref(ver, 0), C.byref(ver, 4), C.byref(ver, 8))
+            if (ver[0], ver[1]) < (1, 10):   # hid_t is a 32-bit int before 1.10: the 64-bit prototypes below would read garbage
+                raise OSError("HDF5 %d.%d.%d is older than 1.10" % tuple(ver))
             _LIB = _Api(L, path)
             return _LIB
         except (OSError, AttributeError) as e:   # a library without one of the symbols is as good as none
