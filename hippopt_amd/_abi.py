@@ -78,7 +78,7 @@ class DimsC(C.Structure):
 
 
 # ---- static pose finder (hipnlp_pose_*) ----------------------------------------------------------------------
-POSE_NX, POSE_NP, POSE_NCOST_TERMS = 81, 202, 7
+POSE_NX, POSE_NP, POSE_NCOST_TERMS = 81, 202, 9
 
 
 class PoseSettingsC(C.Structure):
@@ -98,6 +98,11 @@ class PoseSettingsC(C.Structure):
         ("force_regularization_cost_multiplier", C.c_double),
         ("average_force_regularization_cost_multiplier", C.c_double),
         ("point_position_regularization_cost_multiplier", C.c_double),
+        ("hand_type", C.c_int32 * 2),
+        ("hand_frame_link", C.c_int32 * 2),
+        ("hand_frame_R", (C.c_double * 9) * 2),
+        ("hand_frame_o", (C.c_double * 3) * 2),
+        ("hand_regularization_cost_multiplier", C.c_double * 2),
     ]
 
 

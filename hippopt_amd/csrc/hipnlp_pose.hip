@@ -36,6 +36,7 @@ struct PoseTables {
     int32_t nnz, m;
     int32_t hperm[POSE_MAX_HNNZ];
     int32_t hnnz, pad_;
+    PoseHands hands;
 };
 
 struct PArgs {
@@ -134,6 +135,7 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     KnotInfo ki{1, 3, 0, 0};   // "interior knot": the k >= 1 rows / costs of the shared tasks are active
     PoseEm<TERRAIN> em{s.g, s.jac};
     Ctx<PoseEm<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
+    cx.hands = &tb.hands;
     // (one contiguous program instance per wave, as in hipnlp_knot_kernel: no wave jumps over the other waves' code)
 #define DEV_R(w, w8, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_BARRIER lds_barrier();
@@ -200,6 +202,7 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     KnotInfo ki{1, 3, 0, 0};
     PoseHessEm<TERRAIN> em{s.g, nullptr, hx.H};   // (no task of the Hessian program emits a Jacobian entry)
     Ctx<PoseHessEm<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
+    cx.hands = &tb.hands;
     HCtx<PoseHessEm<TERRAIN>> hcx{cx, hx};
     // (one contiguous program instance per wave, as in hipnlp_knot_kernel: no wave jumps over the other waves' code)
 #define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
@@ -343,6 +346,7 @@ int hipnlp_pose_create(const hipnlp_pose_desc* desc, hipnlp_pose_handle** out) {
     std::memset(tb, 0, sizeof(PoseTables));
     tb->head.kt = h->kt;
     tb->head.ks = PoseLayout::make_ksettings(st);
+    tb->hands = PoseLayout::make_hands(st);
     for (int s = 0; s < gs::COUNT; ++s) tb->g_row[s] = h->L.g_row[size_t(s)];
     for (int e = 0; e < h->L.nnz; ++e) tb->jperm[e] = h->L.jperm[size_t(e)];
     tb->nnz = h->L.nnz; tb->m = h->L.m;
@@ -509,7 +513,8 @@ int hipnlp_pose_cost_terms(hipnlp_pose_handle* h, double* values) {
 
 const char* hipnlp_pose_cost_term_name(int i) {
     static const char* names[POSE_NCT] = {"base_quaternion_error", "frame_rotation_error", "com_position_error", "joint_positions_error",
-                                          "average_force_regularization", "point_position_regularization", "force_regularization"};
+                                          "average_force_regularization", "point_position_regularization", "force_regularization",
+                                          "left_hand_position_error", "right_hand_position_error"};
     return (i >= 0 && i < POSE_NCT) ? names[i] : "";
 }
 

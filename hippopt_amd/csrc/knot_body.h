@@ -163,6 +163,7 @@ template <class Em> struct Ctx {
     // the FULL tables wherever they live (compact device layout: global memory; elsewhere: the same objects as kt / gp)
     const KinTables* gkt;
     const GParams* ggp;
+    const PoseHands* hands = nullptr;   // pose finder only (set by its kernels / host expansions behind the constructor)
     HD Ctx(Scratch& s_, const Kin& kt_, const KSettings& st_, const GP& gp_, KnotInfo ki_, Em em_, const KinTables* gkt_ = nullptr, const GParams* ggp_ = nullptr)
         : s(s_), kt(kt_), st(st_), gp(gp_), ki(ki_), em(em_), gkt(gkt_), ggp(ggp_) {
         if constexpr (!Scratch::compact) {

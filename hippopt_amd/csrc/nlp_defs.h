@@ -126,7 +126,15 @@ enum RowKind : int {
     RK_UNITQ, RK_COMC, RK_CMMC, RK_AMB, RK_COMH, RK_FEETD, RK_JPB, RK_JVB, RK_FEETH,
     RK_FIN, RK_PER0, RK_PERN,
     // static pose finder only (pose_body.h)
-    RK_PCOMPL, RK_PBAL, RK_PCOMERR, RK_PPREG, RK_COUNT
+    RK_PCOMPL, RK_PBAL, RK_PCOMERR, RK_PPREG, RK_PHAND, RK_COUNT
+};
+// hand position expressions of the pose finder (pose_body.h; planner.py:596-660): read from global memory by the two hand task
+// groups — not part of KSettings, which every kernel stages into LDS
+struct PoseHands {
+    int32_t type[2];      // HIPNLP_EXPR_* of the left / right hand
+    int32_t link[2];      // link the hand frame is attached to
+    double R[2][9], o[2][3];   // link_T_frame
+    double mult[2];       // regularisation cost multipliers
 };
 HD constexpr int row_id(int kind, int c, int i) { return (kind << 16) | (c << 8) | i; }
 HD constexpr int rid_kind(int id) { return id >> 16; }

@@ -16,7 +16,7 @@ namespace hipnlp {
 
 constexpr int POSE_NX = HIPNLP_POSE_NX, POSE_NP = HIPNLP_POSE_NP, POSE_NCT = HIPNLP_POSE_NCOST_TERMS;
 // pose references live in the (otherwise unused) previous-knot record of the scratch: s.xm[XR_*]
-enum : int { XR_P = 0, XR_F = 24, XR_COM = 48, XR_COUNT = 51 };
+enum : int { XR_P = 0, XR_F = 24, XR_COM = 48, XR_HREF = 51 /* references.left / right_hand_position */, XR_HIN = 57 /* left / right_hand_position_in_frame */, XR_COUNT = 63 };
 // pose variable i (reference creation order) -> column of the knot record
 HD constexpr int pose_to_knot_col(int i) {
     return i < 48 ? PT_ * (i / 6) + ((i % 6) < 3 ? P_ + (i % 6) : F_ + (i % 6) - 3)
@@ -138,6 +138,87 @@ template <class Em> HD void t_pose_com(Ctx<Em>& cx, int t) {
     }
 }
 
+// --- hand position expressions (planner.py:596-660):  P_h = p_b + r_h,  r_h = o_L + R_L (o_frame + R_frame p_in)  (base-centred,
+//     world-oriented link pose of the forward kinematics)  against references.<side>_hand_position.
+//     subject_to: three rows P_h - ref == 0;  minimize: mult * |P_h - ref|^2.   d r_h / d s_j = a_j x (r_h - o_j) for the joints j
+//     on the path root -> hand link (kt.anc of the link's joint: at most eight), d r_h / d q_b = -[r_h]x G / |q|, d P_h / d p_b = I.
+// Scratch: the per-point momentum partials hd[][][] of the knot program are unused by the pose program.
+//   hb[0..5] r_h, hb[6..11] e_h = P_h - ref, hb[12..13] cost.   Native slots: the (unused) trapezoid-defect slots of the knot program —
+//   g: gs::FDYN + i of point h;  jac: js::FDYN + {0: p_b,i | 1..4: q_b | 5..12: path joint q} of point 4 h + i.
+template <class S> HD auto pose_hand_buf(S& s) -> decltype(&s.hd[0][0][0]) { return &s.hd[0][0][0]; }
+static_assert(sizeof(KnotScratch::hd) >= 14 * sizeof(double), "hand buffer");
+constexpr int POSE_HAND_PATH = 8;
+// phase C (the links' world poses are there): lane h
+template <class Em> HD void t_pose_hand_pts(Ctx<Em>& cx, int h) {
+    auto& s = cx.s;
+    double* hb = pose_hand_buf(s);
+    if (!cx.hands || cx.hands->type[h] == HIPNLP_EXPR_SKIP) { hb[12 + h] = 0.0; return; }
+    const PoseHands& hd = *cx.hands;
+    const int L = hd.link[h];
+    double q[3], t[3], r[3];
+    matvec3(hd.R[h], s.xm + XR_HIN + 3 * h, q);
+    for (int i = 0; i < 3; ++i) t[i] = hd.o[h][i] + q[i];
+    matvec3(s.Rw[L], t, r);
+    double c = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        r[i] += s.ow[L][i];
+        const double e = s.x[PB_ + i] + r[i] - s.xm[XR_HREF + 3 * h + i];
+        hb[3 * h + i] = r[i];
+        hb[6 + 3 * h + i] = e;
+        c += e * e;
+    }
+    hb[12 + h] = hd.type[h] == HIPNLP_EXPR_MINIMIZE ? hd.mult[h] * c : 0.0;
+}
+// last phase, BEHIND t_feetd on its wave (which adds the chest cost to grad q_b), the left hand's group before the right hand's (their
+// gradient shares meet in p_b, q_b and the torso joints: one group = one read-modify-write per address).  Lanes 0..2: row i /
+// p_b,i / q_b (lane i takes component i, lane 0 also the fourth); lanes 3..10: joint q of the path root -> hand link.
+constexpr int POSE_HAND_TASKS = 3 + POSE_HAND_PATH;
+template <class Em> HD void pose_hand_rows(Ctx<Em>& cx, int t, int h) {
+    auto& s = cx.s;
+    Em& em = cx.em;
+    HIPNLP_WAVE_SYNC();
+    if (!cx.hands) return;
+    const PoseHands& hd = *cx.hands;
+    const int mode = hd.type[h];
+    if (mode == HIPNLP_EXPR_SKIP) return;
+    const double* hb = pose_hand_buf(s);
+    const double* r = hb + 3 * h;
+    const double* e = hb + 6 + 3 * h;
+    const double m2 = 2.0 * hd.mult[h];
+    if (t < 3) {
+        const int i = t, jb = js::PT_STRIDE * (4 * h + i) + js::FDYN;
+        if (mode == HIPNLP_EXPR_SUBJECT_TO) {
+            em.G(gs::PT_STRIDE * h + gs::FDYN + i, row_id(RK_PHAND, h, i), e[i]);
+            em.J(jb + 0, row_id(RK_PHAND, h, i), PB_ + i, 1.0);
+            const double X0 = skew_rc(r, i, 0), X1 = skew_rc(r, i, 1), X2 = skew_rc(r, i, 2);
+            for (int l = 0; l < 4; ++l)
+                em.J(jb + 1 + l, row_id(RK_PHAND, h, i), QB_ + l, -(X0 * s.G[l] + X1 * s.G[4 + l] + X2 * s.G[8 + l]) * s.inv_qnorm);
+        } else {   // minimize: gradient 2 m J^T e
+            s.grad[PB_ + i] += m2 * e[i];
+            for (int l = i; l < 4; l += 3) {
+                double acc = 0.0;
+                for (int n = 0; n < 3; ++n)
+                    acc += e[n] * (skew_rc(r, n, 0) * s.G[l] + skew_rc(r, n, 1) * s.G[4 + l] + skew_rc(r, n, 2) * s.G[8 + l]);
+                s.grad[QB_ + l] += -m2 * acc * s.inv_qnorm;
+            }
+        }
+    } else {
+        const int q = t - 3;
+        const int j = cx.kt.anc[hd.link[h] - 1][q];   // joint q of the path root -> hand link (front padded with NJ)
+        if (j >= NJ) return;
+        double d[3], x[3];
+        for (int n = 0; n < 3; ++n) d[n] = r[n] - s.ow[j + 1][n];
+        cross3(s.aw[j], d, x);
+        if (mode == HIPNLP_EXPR_SUBJECT_TO) {
+            for (int i = 0; i < 3; ++i) em.J(js::PT_STRIDE * (4 * h + i) + js::FDYN + 5 + q, row_id(RK_PHAND, h, i), S_ + j, x[i]);
+        } else {
+            s.grad[S_ + j] += m2 * dot3(e, x);
+        }
+    }
+}
+template <class Em> HD void t_pose_hand_rows_l(Ctx<Em>& cx, int t) { pose_hand_rows(cx, t, 0); }
+template <class Em> HD void t_pose_hand_rows_r(Ctx<Em>& cx, int t) { pose_hand_rows(cx, t, 1); }
+
 // cost term t of the pose (order of hipnlp_pose_cost_term_name) from the scratch, after the program has run
 HD double pose_cost_term(const KnotScratch& s, int t) {
     switch (t) {
@@ -145,6 +226,7 @@ HD double pose_cost_term(const KnotScratch& s, int t) {
         case 1: return s.cost[CT_FRAMEQ];
         case 2: return s.cost[CT_COMVEL];
         case 3: return s.cost[CT_JREG];
+        case 7: case 8: return (&s.hd[0][0][0])[12 + (t - 7)];   // left / right hand position error (pose_hand_buf)
         default: {
             const int k = t == 4 ? 2 : (t == 5 ? 0 : 1);   // average force | point position | force
             double a = 0.0;
@@ -163,14 +245,14 @@ HD double pose_cost_term(const KnotScratch& s, int t) {
     R(0, 0, t_fk_rot_a, FK_TASKS_A) R(0, 0, t_link_u_a, FK_SPLIT)                         \
     R(3, 3, t_fk_rot_b, FK_TASKS_B) R(3, 3, t_link_u_b, NJ - FK_SPLIT)                    \
     BARRIER                                                                               \
-    R(0, 0, t_links, NL) R(1, 1, t_frames, 3) R(2, 2, t_link_inertia, NL)                 \
+    R(0, 0, t_links, NL) R(1, 1, t_frames, 3) R(2, 2, t_link_inertia, NL) R(3, 3, t_pose_hand_pts, 2) \
     BARRIER                                                                               \
     R(0, 0, t_composite_g0, 64) R(1, 1, t_composite_g1, 64) R(1, 1, t_composite_g2, 64)   \
     R(2, 2, t_composite_g3, 64) R(2, 2, t_composite_g4, 64) R(3, 3, t_composite_g5, 64) R(3, 3, t_pkin, NC) \
     BARRIER                                                                               \
     R(0, 0, t_columns, NJ + 3) R(2, 2, t_frame_columns, NJ)                               \
     BARRIER                                                                               \
-    R(0, 0, t_kinc, 3 * NC) R(1, 1, t_comc, 15) R(2, 2, t_kinc_s, NC * LEG_PATH) R(3, 3, t_feetd, 4) \
+    R(0, 0, t_kinc, 3 * NC) R(1, 1, t_comc, 15) R(2, 2, t_kinc_s, NC * LEG_PATH) R(3, 3, t_feetd, 4) R(3, 3, t_pose_hand_rows_l, POSE_HAND_TASKS) R(3, 3, t_pose_hand_rows_r, POSE_HAND_TASKS) \
     BARRIER
 
 }  // namespace hipnlp

@@ -34,7 +34,11 @@ constexpr int COMD = COMF + 6 * NC;    // [3]      com diagonal
 constexpr int QQ = COMD + 3;           // [10]     lower 4x4 of (q_b, q_b)
 constexpr int QS = QQ + 10;            // [NJ][4]  row s_j, column q_l
 constexpr int SS = QS + 4 * NJ;        // [NJ (NJ + 1) / 2]  row s_j, column s_i (i <= j): j (j + 1) / 2 + i; ancestor pairs only
-constexpr int COUNT = SS + NJ * (NJ + 1) / 2;
+// hand position expressions in minimize mode (2 sigma m J^T J couples p_b with itself, q_b and the joints of the hand's path)
+constexpr int PBD = SS + NJ * (NJ + 1) / 2;   // [3]      (p_b, p_b) diagonal
+constexpr int QPB = PBD + 3;           // [4][3]   row q_l, column p_b,i
+constexpr int SPB = QPB + 12;          // [NJ][3]  row s_j, column p_b,i
+constexpr int COUNT = SPB + 3 * NJ;
 }  // namespace hs
 
 struct HessScratch {
@@ -181,6 +185,68 @@ HD void chest_error(const KnotScratch& s, double* E) {
     matmul3(s.fr_R[HIPNLP_FRAME_CHEST], Rdt, E);
 }
 
+// ---- hand position expressions (pose_body.h: t_pose_hand_pts has left r_h and e_h = P_h - ref in the scratch) ---------------------
+//   subject_to: lambda_h . P_h;   minimize: sigma m |P_h - ref|^2 = second-derivative part with the weight 2 sigma m e_h  +  2 sigma m J^T J,
+//   J = [ I | D_q | D_s ],  D_q(:, l) = -(r_h x G_l) / |q|,  D_s(:, j) = a_j x (r_h - o_j) for the joints j of the hand's path.
+template <class Em> HD int hand_mode(const HCtx<Em>& h, int hnd) { return h.cx.hands ? h.cx.hands->type[hnd] : HIPNLP_EXPR_SKIP; }
+template <class Em> HD bool hand_on_path(const HCtx<Em>& h, int hnd, int j) {
+    const int jl = h.cx.hands->link[hnd] - 1;
+    bool on = false;
+    for (int q = 0; q < 8; ++q) on = on || (int(h.cx.kt.anc[jl][q]) == j);
+    return on;
+}
+// weight of r_h in the Lagrangian: the multipliers of its rows / 2 sigma m e_h
+template <class Em> HD void hand_weight(const HCtx<Em>& h, int hnd, double* w) {
+    const int mode = hand_mode(h, hnd);
+    const double* hb = pose_hand_buf(h.cx.s);
+    for (int i = 0; i < 3; ++i)
+        w[i] = mode == HIPNLP_EXPR_SUBJECT_TO ? h.hx.lam[gs::PT_STRIDE * hnd + gs::FDYN + i]
+                                              : (mode == HIPNLP_EXPR_MINIMIZE ? 2.0 * h.hx.sigma * h.cx.hands->mult[hnd] * hb[6 + 3 * hnd + i] : 0.0);
+}
+template <class Em> HD double hand_jtj_scale(const HCtx<Em>& h, int hnd) {
+    return hand_mode(h, hnd) == HIPNLP_EXPR_MINIMIZE ? 2.0 * h.hx.sigma * h.cx.hands->mult[hnd] : 0.0;
+}
+template <class Em> HD void hand_dq(const HCtx<Em>& h, int hnd, int l, double* d) {   // D_q(:, l)
+    const auto& s = h.cx.s;
+    const double* r = pose_hand_buf(s) + 3 * hnd;
+    const double Gl[3] = {s.G[l], s.G[4 + l], s.G[8 + l]};
+    double c[3];
+    cross3(r, Gl, c);
+    for (int i = 0; i < 3; ++i) d[i] = -c[i] * s.inv_qnorm;
+}
+template <class Em> HD void hand_ds(const HCtx<Em>& h, int hnd, int j, double* x) {   // D_s(:, j), j on the path
+    const auto& s = h.cx.s;
+    const double* r = pose_hand_buf(s) + 3 * hnd;
+    double d[3];
+    for (int n = 0; n < 3; ++n) d[n] = r[n] - s.ow[j + 1][n];
+    cross3(s.aw[j], d, x);
+}
+// (p_b, p_b), (q_b, p_b), (s_j, p_b) of 2 sigma m J^T J: lanes 0..2 | 3..14 (l, i) | 15.. (j, i).  Entries exist only for hands in minimize mode.
+constexpr int HESS_HAND_TASKS = 3 + 12 + 3 * NJ;
+template <class Em> HD void t_hess_hand(HCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    const double k0 = hand_jtj_scale(h, 0), k1 = hand_jtj_scale(h, 1);
+    if (k0 == 0.0 && k1 == 0.0 && hand_mode(h, 0) != HIPNLP_EXPR_MINIMIZE && hand_mode(h, 1) != HIPNLP_EXPR_MINIMIZE) return;
+    const bool m0 = hand_mode(h, 0) == HIPNLP_EXPR_MINIMIZE, m1 = hand_mode(h, 1) == HIPNLP_EXPR_MINIMIZE;
+    if (t < 3) {
+        cx.em.H(hs::PBD + t, pv::PB + t, pv::PB + t, k0 + k1);
+    } else if (t < 15) {
+        const int l = (t - 3) / 3, i = (t - 3) - 3 * l;
+        double v = 0.0, d[3];
+        if (m0) { hand_dq(h, 0, l, d); v += k0 * d[i]; }
+        if (m1) { hand_dq(h, 1, l, d); v += k1 * d[i]; }
+        cx.em.H(hs::QPB + (t - 3), pv::QB + l, pv::PB + i, v);
+    } else {
+        const int j = (t - 15) / 3, i = (t - 15) - 3 * j;
+        const bool p0 = m0 && hand_on_path(h, 0, j), p1 = m1 && hand_on_path(h, 1, j);
+        if (!p0 && !p1) return;
+        double v = 0.0, x[3];
+        if (p0) { hand_ds(h, 0, j, x); v += k0 * x[i]; }
+        if (p1) { hand_ds(h, 1, j, x); v += k1 * x[i]; }
+        cx.em.H(hs::SPB + (t - 15), pv::S + j, pv::PB + i, v);
+    }
+}
+
 // --- Y_j = d/d theta [ dL/ds_j ]  (theta: world-frame rotation of the base), lane j (23) -------------------------------------------
 //   L = sum_c w_c . pkin_c + w_com . com_kin + sigma m (tr E - 3)^2,   w_c = -lambda(kinematics consistency), w_com = -lambda(com consistency)
 template <class Em> HD void t_hess_Y(HCtx<Em>& h, int j) {
@@ -210,6 +276,16 @@ template <class Em> HD void t_hess_Y(HCtx<Em>& h, int j) {
             for (int r = 0; r < 3; ++r) Y[r] += t1[r];
         }
     }
+    for (int hnd = 0; hnd < 2; ++hnd) {   // hand points: weight w_h on r_h
+        if (hand_mode(h, hnd) == HIPNLP_EXPR_SKIP || !hand_on_path(h, hnd, j)) continue;
+        double w[3];
+        hand_weight(h, hnd, w);
+        const double* rh = pose_hand_buf(s) + 3 * hnd;
+        for (int r = 0; r < 3; ++r) t1[r] = rh[r] - o[r];
+        cross3(a, t1, t2);
+        cross3(t2, w, t1);
+        for (int r = 0; r < 3; ++r) Y[r] += t1[r];
+    }
     if (cx.kt.chest_pos[j] >= 0) {
         double E[9], Ea[3];
         chest_error(s, E);
@@ -236,6 +312,14 @@ template <class Em> HD void t_hess_ss(HCtx<Em>& h, int t) {
     if (!i_anc && !j_anc) return;
     double v = i_anc ? dot3(cx.s.aw[i], h.hx.Y[j]) : dot3(cx.s.aw[j], h.hx.Y[i]);
     if (i == j) v += 2.0 * h.hx.sigma * cx.st.m_jreg * cx.st.w_jreg[j];
+    for (int hnd = 0; hnd < 2; ++hnd) {   // 2 sigma m D_s^T D_s of a hand in minimize mode (both joints on its path)
+        const double k = hand_jtj_scale(h, hnd);
+        if (k == 0.0 || !hand_on_path(h, hnd, i) || !hand_on_path(h, hnd, j)) continue;
+        double xi[3], xj[3];
+        hand_ds(h, hnd, i, xi);
+        hand_ds(h, hnd, j, xj);
+        v += k * dot3(xi, xj);
+    }
     cx.em.H(hs::SS + t, pv::S + j, pv::S + i, v);
 }
 
@@ -245,7 +329,16 @@ template <class Em> HD void t_hess_qs(HCtx<Em>& h, int t) {
     const auto& s = cx.s;
     const int j = t >> 2, l = t & 3;
     const double* Y = h.hx.Y[j];
-    cx.em.H(hs::QS + t, pv::S + j, pv::QB + l, (s.G[l] * Y[0] + s.G[4 + l] * Y[1] + s.G[8 + l] * Y[2]) * s.inv_qnorm);
+    double v = (s.G[l] * Y[0] + s.G[4 + l] * Y[1] + s.G[8 + l] * Y[2]) * s.inv_qnorm;
+    for (int hnd = 0; hnd < 2; ++hnd) {   // 2 sigma m D_s^T D_q
+        const double k = hand_jtj_scale(h, hnd);
+        if (k == 0.0 || !hand_on_path(h, hnd, j)) continue;
+        double x[3], d[3];
+        hand_ds(h, hnd, j, x);
+        hand_dq(h, hnd, l, d);
+        v += k * dot3(x, d);
+    }
+    cx.em.H(hs::QS + t, pv::S + j, pv::QB + l, v);
 }
 
 // --- (q_b, q_b): lanes over the lower triangle (10); every lane forms the small matrices itself ------------------------------------
@@ -272,6 +365,13 @@ template <class Em> HD void t_hess_qq(HCtx<Em>& h, int t) {
             for (int p = 0; p < NC; ++p) acc += -lam[gs::PT_STRIDE * p + gs::KINC + a] * s.pkin[p][b];
             Mw[3 * a + b] = acc;
         }
+    for (int hnd = 0; hnd < 2; ++hnd) {   // hand points: w_h r_h^T
+        if (hand_mode(h, hnd) == HIPNLP_EXPR_SKIP) continue;
+        double w[3];
+        hand_weight(h, hnd, w);
+        const double* rh = pose_hand_buf(s) + 3 * hnd;
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) Mw[3 * a + b] += w[a] * rh[b];
+    }
     matmul3(Mw, s.Rb, M);
     const double trM = M[0] + M[4] + M[8];
     const double al[3] = {M[7] - M[5], M[2] - M[6], M[3] - M[1]};
@@ -296,6 +396,14 @@ template <class Em> HD void t_hess_qq(HCtx<Em>& h, int t) {
     const double ger = -(axE[0] * s.G[r] + axE[1] * s.G[4 + r] + axE[2] * s.G[8 + r]) * inv_n;
     const double gec = -(axE[0] * s.G[c] + axE[1] * s.G[4 + c] + axE[2] * s.G[8 + c]) * inv_n;
     v += m2 * ger * gec;
+    for (int hnd = 0; hnd < 2; ++hnd) {   // 2 sigma m D_q^T D_q
+        const double k = hand_jtj_scale(h, hnd);
+        if (k == 0.0) continue;
+        double dr[3], dc[3];
+        hand_dq(h, hnd, r, dr);
+        hand_dq(h, hnd, c, dc);
+        v += k * dot3(dr, dc);
+    }
     if (r == c) {
         const double* qd = s.pk + PK_REF + R_BQ;   // base quaternion error is linear in q: Hessian 2 m |q_d|^2 I  (E13)
         v += 2.0 * lam[gs::UNITQ] + 2.0 * sigma * cx.st.m_baseq * (qd[0] * qd[0] + qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3]);
@@ -312,14 +420,14 @@ template <class Em> HD void t_kin_padding(Ctx<Em>& cx, int e) { scratch_padding(
     BARRIER                                                                                                       \
     KIN(0, t_fk_rot_a, FK_TASKS_A) KIN(0, t_link_u_a, FK_SPLIT) KIN(3, t_fk_rot_b, FK_TASKS_B) KIN(3, t_link_u_b, NJ - FK_SPLIT) \
     BARRIER                                                                                                       \
-    KIN(0, t_links, NL) KIN(1, t_frames, 3) KIN(2, t_link_inertia, NL)                                            \
+    KIN(0, t_links, NL) KIN(1, t_frames, 3) KIN(2, t_link_inertia, NL) KIN(3, t_pose_hand_pts, 2)                 \
     BARRIER                                                                                                       \
     KIN(0, t_composite_g0, 64) KIN(1, t_composite_g1, 64) KIN(1, t_composite_g2, 64)                              \
     KIN(2, t_composite_g3, 64) KIN(2, t_composite_g4, 64) KIN(3, t_composite_g5, 64) KIN(3, t_pkin, NC)           \
     BARRIER                                                                                                       \
     RH(2, t_hess_Y, NJ) RH(3, t_hess_qq, 10)                                                                      \
     BARRIER                                                                                                       \
-    RH(0, t_hess_ss, HESS_SS_TASKS) RH(1, t_hess_qs, 4 * NJ)                                                      \
+    RH(0, t_hess_ss, HESS_SS_TASKS) RH(1, t_hess_qs, 4 * NJ) RH(2, t_hess_hand, HESS_HAND_TASKS)                  \
     BARRIER
 
 }  // namespace hipnlp

@@ -11,7 +11,7 @@ struct PoseRowBlock { std::string name; int first_row, rows; };
 // parameter offsets in the reference's creation order (tests/golden/pose_*.npz "pnames")
 namespace pp {
 constexpr int DESC = 0, MASS = 24, GRAV = 27, REF = 33 /* per point: p 9c, f 9c+3, descriptor 9c+6 */, REF_PB = 105, REF_QB = 108,
-              REF_S = 112, REF_COM = 135, REF_FQ = 138, EPS = 148, MU = 149, SMAX = 150, SMIN = 173;
+              REF_S = 112, REF_COM = 135, REF_FQ = 138, REF_LH = 142 /* right: + 3 */, EPS = 148, MU = 149, SMAX = 150, SMIN = 173, LH_IN = 196 /* right: + 3 */;
 }
 
 struct PoseLayout {
@@ -61,7 +61,23 @@ struct PoseLayout {
         return k;
     }
 
+    static PoseHands make_hands(const hipnlp_pose_settings& st) {
+        PoseHands hd{};
+        for (int h = 0; h < 2; ++h) {
+            hd.type[h] = st.hand_type[h];
+            hd.link[h] = st.hand_type[h] == HIPNLP_EXPR_SKIP ? 1 : st.hand_frame_link[h];
+            for (int i = 0; i < 9; ++i) hd.R[h][i] = st.hand_frame_R[h][i];
+            for (int i = 0; i < 3; ++i) hd.o[h][i] = st.hand_frame_o[h][i];
+            hd.mult[h] = st.hand_regularization_cost_multiplier[h];
+        }
+        return hd;
+    }
+
     bool build(const hipnlp_pose_settings& st, const KinTables& kt) {
+        for (int h = 0; h < 2; ++h) {
+            if (st.hand_type[h] != HIPNLP_EXPR_SKIP && st.hand_type[h] != HIPNLP_EXPR_SUBJECT_TO && st.hand_type[h] != HIPNLP_EXPR_MINIMIZE) { error = "hand_type: not an expression type"; return false; }
+            if (st.hand_type[h] != HIPNLP_EXPR_SKIP && (st.hand_frame_link[h] < 1 || st.hand_frame_link[h] >= NL)) { error = "hand_frame_link: a link below a joint (1 .. links - 1)"; return false; }
+        }
         m = 0;
         blocks.clear();
         for (int a = 0; a < RK_COUNT; ++a) for (int c = 0; c < NC; ++c) blk[a][c] = -1;
@@ -82,6 +98,9 @@ struct PoseLayout {
             const int mode = c < 4 ? st.left_point_position_type : st.right_point_position_type;
             if (mode == HIPNLP_EXPR_SUBJECT_TO) add(RK_PPREG, c, point_name(c) + ".p_regularization", 1);
         }
+        for (int h = 0; h < 2; ++h)                              // :596-660
+            if (st.hand_type[h] == HIPNLP_EXPR_SUBJECT_TO) add(RK_PHAND, h, h == 0 ? "left_hand_position_error" : "right_hand_position_error", 3);
+        const PoseHands hands = make_hands(st);
         // ---- record the native slots of the pose program ------------------------------------------------------
         std::vector<int> grow(gs::COUNT, -1), jrid(js::COUNT, -1), jc(js::COUNT, -1), hr(hs::COUNT, -1), hc(hs::COUNT, -1);
         bool dup = false;
@@ -95,6 +114,7 @@ struct PoseLayout {
             KnotInfo ki{1, 3, 0, 0};
             RecordEm em{grow.data(), jrid.data(), jc.data(), &dup, hr.data(), hc.data()};
             Ctx<RecordEm> cx(*s, kt, ks, gp, ki, em);
+            cx.hands = &hands;
 #define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
             HIPNLP_POSE_PROGRAM(HOST_R, )
 #undef HOST_R
@@ -161,7 +181,7 @@ struct PoseLayout {
             fill(RK_KINC, c, eq0); fill(RK_PPREG, c, eq0);
         }
         fill(RK_UNITQ, 0, [](int, double& lo, double& hi) { lo = hi = 1.0; });
-        fill(RK_COMC, 0, eq0); fill(RK_PBAL, 0, eq0); fill(RK_PCOMERR, 0, eq0);
+        fill(RK_COMC, 0, eq0); fill(RK_PBAL, 0, eq0); fill(RK_PCOMERR, 0, eq0); fill(RK_PHAND, 0, eq0); fill(RK_PHAND, 1, eq0);
         fill(RK_JPB, 0, [&](int i, double& lo, double& hi) { lo = p[pp::SMIN + i]; hi = p[pp::SMAX + i]; });
     }
 };
@@ -178,6 +198,7 @@ inline void pack_pose_params(const double* p, double* pk, double* xr, GParams& g
     for (int c = 0; c < NC; ++c)
         for (int i = 0; i < 3; ++i) { xr[XR_P + 3 * c + i] = p[pp::REF + 9 * c + i]; xr[XR_F + 3 * c + i] = p[pp::REF + 9 * c + 3 + i]; }
     for (int i = 0; i < 3; ++i) xr[XR_COM + i] = p[pp::REF_COM + i];
+    for (int i = 0; i < 6; ++i) { xr[XR_HREF + i] = p[pp::REF_LH + i]; xr[XR_HIN + i] = p[pp::LH_IN + i]; }
     gp = GParams{};
     gp.mass = p[pp::MASS]; gp.eps = p[pp::EPS]; gp.mu = p[pp::MU];
     for (int i = 0; i < 6; ++i) gp.gravity[i] = p[pp::GRAV + i];

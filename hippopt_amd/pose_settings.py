@@ -41,6 +41,17 @@ class PoseSettings:
     force_regularization_cost_multiplier: float = 0.2
     average_force_regularization_cost_multiplier: float = 10.0
     point_position_regularization_cost_multiplier: float = 100.0
+    # hand position expressions (planner.py:62-69, 86-91, 596-660).  The reference names the frames
+    # (left_hand_frame_name / right_hand_frame_name); here a frame is (link index, link_R_frame [3,3], link_o_frame [3]) —
+    # `hand_frame(model, link)` / `urdf_model.resolve_frame` produce it.  `lef_hand_position_in_frame` is the reference's spelling.
+    left_hand_frame: tuple = None
+    right_hand_frame: tuple = None
+    lef_hand_position_in_frame: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(3))
+    right_hand_position_in_frame: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(3))
+    left_hand_regularization_cost_multiplier: float = 1.0
+    right_hand_regularization_cost_multiplier: float = 1.0
+    left_hand_expression_type: int = _abi.EXPR_SKIP
+    right_hand_expression_type: int = _abi.EXPR_SKIP
 
     def __post_init__(self):
         if self.left_descriptors is None:
@@ -73,6 +84,21 @@ class PoseSettings:
         s.force_regularization_cost_multiplier = float(self.force_regularization_cost_multiplier)
         s.average_force_regularization_cost_multiplier = float(self.average_force_regularization_cost_multiplier)
         s.point_position_regularization_cost_multiplier = float(self.point_position_regularization_cost_multiplier)
+        hands = ((self.left_hand_expression_type, self.left_hand_frame, self.left_hand_regularization_cost_multiplier, "left"),
+                 (self.right_hand_expression_type, self.right_hand_frame, self.right_hand_regularization_cost_multiplier, "right"))
+        for h, (mode, frame, mult, side) in enumerate(hands):
+            s.hand_type[h] = int(mode)
+            s.hand_regularization_cost_multiplier[h] = float(mult)
+            if int(mode) == _abi.EXPR_SKIP:
+                continue
+            if frame is None:   # planner.py:165-170, 180-185: "<side>_hand_frame_name is None"
+                raise ValueError("%s_hand_frame is None but %s_hand_expression_type is not skip" % (side, side))
+            link, R, o = frame
+            s.hand_frame_link[h] = int(link)
+            for i, v in enumerate(np.asarray(R, float).reshape(9)):
+                s.hand_frame_R[h][i] = float(v)
+            for i, v in enumerate(np.asarray(o, float).reshape(3)):
+                s.hand_frame_o[h][i] = float(v)
         return s
 
 
@@ -103,11 +129,29 @@ def pack_pose_parameters(settings: PoseSettings, model: RobotModel, references: 
     p[P_REF_S:P_REF_S + NJ] = references["joints"]
     p[P_REF_COM:P_REF_COM + 3] = references["com"]
     p[P_REF_FQ:P_REF_FQ + 4] = references["frame_quaternion"]
+    p[P_REF_LH:P_REF_LH + 3] = references.get("left_hand_position", np.zeros(3))      # planner.py:221-222: zeros by default
+    p[P_REF_RH:P_REF_RH + 3] = references.get("right_hand_position", np.zeros(3))
+    p[P_LH_IN:P_LH_IN + 3] = settings.lef_hand_position_in_frame
+    p[P_RH_IN:P_RH_IN + 3] = settings.right_hand_position_in_frame
     p[P_EPS] = settings.relaxed_complementarity_epsilon
     p[P_MU] = settings.static_friction
     p[P_SMAX:P_SMAX + NJ] = settings.maximum_joint_positions
     p[P_SMIN:P_SMIN + NJ] = settings.minimum_joint_positions
     return p
+
+
+def hand_frame(model: RobotModel, link: int, rpy=(0.0, 0.0, 0.0), offset=(0.0, 0.0, 0.0)) -> tuple:
+    """A frame rigidly attached to `link` (what a URDF's fixed-joint hand frame resolves to): (link, link_R_frame, link_o_frame)."""
+    from .robot_model import rot_from_rpy
+    return int(link), rot_from_rpy(*rpy), np.asarray(offset, float)
+
+
+def hand_point_position(settings: PoseSettings, model: RobotModel, hand: int, pb, quat_xyzw, s) -> np.ndarray:
+    """World position of the hand point (numpy FK of the model): a reference for synthetic workloads and tests."""
+    link, R, o = settings.left_hand_frame if hand == 0 else settings.right_hand_frame
+    p_in = settings.lef_hand_position_in_frame if hand == 0 else settings.right_hand_position_in_frame
+    Rl, ol = model.link_poses(pb, quat_xyzw, s)
+    return ol[link] + Rl[link] @ (np.asarray(o, float) + np.asarray(R, float) @ np.asarray(p_in, float))
 
 
 def make_pose_workload(settings: PoseSettings, model: RobotModel, batch: int = 1, seed: int = 3000):
@@ -136,5 +180,8 @@ def make_pose_workload(settings: PoseSettings, model: RobotModel, batch: int = 1
                 "base_position": pb + 0.01 * rng.standard_normal(3), "base_quaternion": qr / np.linalg.norm(qr),
                 "joints": s + 0.1 * rng.standard_normal(NJ), "com": np.array([0.0, 0.0, 0.7]) + 0.02 * rng.standard_normal(3),
                 "frame_quaternion": fq / np.linalg.norm(fq)}
+        for hnd, (key, mode) in enumerate((("left_hand_position", settings.left_hand_expression_type), ("right_hand_position", settings.right_hand_expression_type))):
+            if mode != _abi.EXPR_SKIP:   # a reference a few centimetres off where the hand is
+                refs[key] = hand_point_position(settings, model, hnd, pb, qn, s) + 0.03 * rng.standard_normal(3)
         ps[b] = pack_pose_parameters(settings, model, refs)
     return xs, ps

@@ -368,14 +368,15 @@ int hipnlp_kernels_per_eval(const hipnlp_handle* h);
  *   g        subject_to call order: per point {complementarity, height, normal, friction, kinematics_consistency(3)},
  *            unitary_quaternion, com_kinematics_consistency(3), centroidal_momentum_dynamics(6),
  *            joint_position_bounds(23), then the optional sumsqr(.) == 0 rows of com / point positions in subject_to mode
+ *            ... and of the left / right hand position (three rows each) in subject_to mode
  *   f        base_quaternion_error, frame_rotation_error, com_position_error, joint_positions_error, per foot the
- *            force average / point position / force regularisations
- * Not built (HIPNLP_E_INVALID): the hand position expressions (settings default: skip) and the parametric-link model
- * (adam.parametric; parametric_link_names is None in humanoid_pose_finder/main.py).
+ *            force average / point position / force regularisations, left / right hand position error (minimize mode)
+ * Not built (HIPNLP_E_INVALID): the parametric-link model (adam.parametric; parametric_link_names is None in
+ * humanoid_pose_finder/main.py).
  * ===================================================================================================================== */
 #define HIPNLP_POSE_NX 81
 #define HIPNLP_POSE_NP 202
-#define HIPNLP_POSE_NCOST_TERMS 7
+#define HIPNLP_POSE_NCOST_TERMS 9
 
 typedef struct hipnlp_pose_settings {
     int32_t terrain;                    /* settings.terrain: HIPNLP_TERRAIN_*                       (planner.py:80) */
@@ -393,6 +394,16 @@ typedef struct hipnlp_pose_settings {
     double force_regularization_cost_multiplier;
     double average_force_regularization_cost_multiplier;
     double point_position_regularization_cost_multiplier;
+    /* hand position expressions (planner.py:596-660; a zeroed tail = the settings' default: both skipped):
+     *   position of the point hand_position_in_frame (parameter p[196..201]) of the frame settings.left/right_hand_frame_name
+     *   == references.left/right_hand_position (p[142..147]);  subject_to: three equality rows "left_hand_position_error" /
+     *   "right_hand_position_error" behind the rows above;  minimize: multiplier * sumsqr(error)  (base/problem.py:95-174).
+     *   The frame is given as in hipnlp_robot_model: the link it is rigidly attached to and link_T_frame. */
+    int32_t hand_type[2];               /* settings.left/right_hand_expression_type: HIPNLP_EXPR_*  (planner.py:88, 91) */
+    int32_t hand_frame_link[2];
+    double hand_frame_R[2][9];
+    double hand_frame_o[2][3];
+    double hand_regularization_cost_multiplier[2];   /* settings.left/right_hand_regularization_cost_multiplier */
 } hipnlp_pose_settings;
 
 typedef struct hipnlp_pose_desc {

@@ -29,13 +29,14 @@ enum : int { NJ = HIPNLP_NJ, NC = HIPNLP_NC, NX = HIPNLP_POSE_NX, NP = HIPNLP_PO
              X_PB = 48, X_QB = 51, X_S = 55, X_COM = 78,
              // parameters (reference creation order; tests/golden/pose_*.npz "pnames")
              P_DESC = 0, P_MASS = 24, P_GRAV = 27, P_REF = 33 /* per point: p 9c, f 9c+3, descriptor 9c+6 */,
-             P_REF_PB = 105, P_REF_QB = 108, P_REF_S = 112, P_REF_COM = 135, P_REF_FQ = 138, P_EPS = 148, P_MU = 149,
-             P_SMAX = 150, P_SMIN = 173 };
+             P_REF_PB = 105, P_REF_QB = 108, P_REF_S = 112, P_REF_COM = 135, P_REF_FQ = 138, P_REF_LH = 142 /* right: + 3 */, P_EPS = 148, P_MU = 149,
+             P_SMAX = 150, P_SMIN = 173, P_LH_IN = 196 /* right: + 3 */ };
 constexpr double kInf = std::numeric_limits<double>::infinity();
-enum : int { CT_BASEQ = 0, CT_FRAMEQ, CT_COM, CT_JOINT, CT_FAVG, CT_PREG, CT_FREG, NCT };
+enum : int { CT_BASEQ = 0, CT_FRAMEQ, CT_COM, CT_JOINT, CT_FAVG, CT_PREG, CT_FREG, CT_LHAND, CT_RHAND, NCT };
 static_assert(NCT == HIPNLP_POSE_NCOST_TERMS, "cost terms");
 static const char* kCostNames[NCT] = {"base_quaternion_error", "frame_rotation_error", "com_position_error", "joint_positions_error",
-                                      "average_force_regularization", "point_position_regularization", "force_regularization"};
+                                      "average_force_regularization", "point_position_regularization", "force_regularization",
+                                      "left_hand_position_error", "right_hand_position_error"};
 
 struct RowBlock { std::string name; int first, rows; };
 
@@ -109,6 +110,21 @@ template <class S> void evaluate(const hipnlp_pose_desc& d, const S* x, const do
         S acc = S(0.0);
         for (int j = 0; j < NJ; ++j) { const S ej = s[j] - par(P_REF_S + j); acc = acc + ej * S(st.joint_regularization_cost_weights[j]) * ej; }
         cost[CT_JOINT] = S(st.joint_regularization_cost_multiplier) * acc;
+        // hand position expressions  :596-660  (cs.MX(position == reference): three equality rows in subject_to mode,
+        // multiplier * sumsqr(position - reference) in minimize mode, base/problem.py:95-174)
+        for (int hnd = 0; hnd < 2; ++hnd) {
+            if (st.hand_type[hnd] == HIPNLP_EXPR_SKIP) continue;
+            bool needed[HIPNLP_NL];
+            chain_mask(md, st.hand_frame_link[hnd], needed);
+            LinkPose<S> links[HIPNLP_NL];
+            all_link_poses(md, pb, Rb, s, links, needed);
+            const LinkPose<S>& lk = links[st.hand_frame_link[hnd]];
+            // point_position_from_kinematics (expressions/kinematics.py): world_H_frame applied to the point in the frame
+            const V3<S> pos = lk.o + mul(lk.R, v3c<S>(st.hand_frame_o[hnd]) + mul(m3c<S>(st.hand_frame_R[hnd]), par3(P_LH_IN + 3 * hnd)));
+            const V3<S> e = pos - par3(P_REF_LH + 3 * hnd);
+            if (st.hand_type[hnd] == HIPNLP_EXPR_MINIMIZE) cost[CT_LHAND + hnd] = S(st.hand_regularization_cost_multiplier[hnd]) * dot(e, e);
+            else { block(hnd == 0 ? "left_hand_position_error" : "right_hand_position_error", 3); for (int i = 0; i < 3; ++i) row(e[i], 0.0, 0.0); }
+        }
     }
     // ---- _add_foot_regularization  :724-768 (left, then right)
     for (int foot = 0; foot < 2; ++foot) {

@@ -219,6 +219,7 @@ struct hostemu_pose_handle {
     hipnlp_pose_desc d;
     KinTables kt;
     KSettings ks;
+    PoseHands hands;
     PoseLayout L;
 };
 
@@ -233,6 +234,7 @@ hostemu_pose_handle* hostemu_pose_create(const hipnlp_pose_desc* desc, char* err
         return nullptr;
     }
     h->ks = PoseLayout::make_ksettings(desc->settings);
+    h->hands = PoseLayout::make_hands(desc->settings);
     return h;
 }
 void hostemu_pose_destroy(hostemu_pose_handle* h) { delete h; }
@@ -261,6 +263,7 @@ void hostemu_pose_eval(const hostemu_pose_handle* h, const double* x, const doub
     KnotInfo ki{1, 3, 0, 0};
     ValueEm em{s->g, s->jac};
     Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
+    cx.hands = &h->hands;
 #define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
     HIPNLP_POSE_PROGRAM(HOST_R, )
 #undef HOST_R
@@ -296,6 +299,7 @@ void hostemu_pose_hess(const hostemu_pose_handle* h, const double* x, const doub
     KnotInfo ki{1, 3, 0, 0};
     ValueEm em{s->g, s->jac, hx->H};
     Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
+    cx.hands = &h->hands;
     HCtx<ValueEm> hcx{cx, *hx};
 #define HOST_KIN(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
 #define HOST_RH(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(hcx, t_);

@@ -8,7 +8,7 @@ import pytest
 
 from hippopt_amd.pose_settings import make_pose_workload
 from test_golden_pose import GOLD, check_against_fixture, pose_settings_for
-from test_pose_body_hostemu import variants
+from test_pose_body_hostemu import VARIANTS, variants
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-11
@@ -19,14 +19,14 @@ def rel(a, b):
     return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
 
 
-@pytest.mark.parametrize("name", ["default", "constrained", "steps"])
+@pytest.mark.parametrize("name", VARIANTS)
 def test_pose_matches_oracle(model, name):
     from hippopt_amd.hipnlp import HipPose
     from oracle_lib import PoseOracle
     st = variants(model)[name]
     B = 5
     x, p = make_pose_workload(st, model, B, 800)
-    if name == "steps":
+    if name.endswith("steps"):
         rng = np.random.RandomState(2)
         for b in range(2):
             for c in range(8):
@@ -144,7 +144,7 @@ def test_pose_planner_solves(model):
 
 
 # ---- exact Hessian of the Lagrangian (IPOPT eval_h) through the C-ABI --------------------------------------------------------
-@pytest.mark.parametrize("name", ["default", "constrained", "steps"])
+@pytest.mark.parametrize("name", VARIANTS)
 def test_pose_hessian_matches_oracle(model, name):
     from hippopt_amd.hipnlp import HipPose
     from oracle_lib import PoseOracle
@@ -152,7 +152,7 @@ def test_pose_hessian_matches_oracle(model, name):
     st = variants(model)[name]
     B = 6
     x, p = make_pose_workload(st, model, B, 950)
-    if name == "steps":
+    if name.endswith("steps"):
         flank_points(x[0], 4)
         flank_points(x[1], 6)
     eng, orc = HipPose(st, model, batch=B), PoseOracle(st, model)
@@ -163,7 +163,7 @@ def test_pose_hessian_matches_oracle(model, name):
     sig = rng.uniform(0.2, 2.0, B)
     vals = eng.eval_hess(x, sig, lam)
     for b in range(B):
-        hess_check(ir, jc, vals[b], orc.hess(x[b], p[b], float(sig[b]), lam[b]), 1e-10 if name == "steps" else TOL)
+        hess_check(ir, jc, vals[b], orc.hess(x[b], p[b], float(sig[b]), lam[b]), 1e-10 if name.endswith("steps") else TOL)
     assert np.array_equal(vals, eng.eval_hess(x, sig, lam))     # bitwise reproducible
     # the first-order callbacks are unaffected by a Hessian call in between
     f, grad, g, jac = eng.eval(x)

@@ -30,10 +30,31 @@ def variants(model):
     c.terrain_steps = [{"length": 0.6, "width": 0.8, "height": 0.2, "position": (0.45, 0.0, 0.0)},
                        {"length": 0.3, "width": 0.5, "height": 0.1, "position": (-0.2, 0.1, 0.02), "orientation": 0.6, "edge_sharpness": 3, "side_sharpness": 4}]
     c.com_position_expression_type = _abi.EXPR_SKIP
-    return {"default": a, "constrained": b, "steps": c}
+    # hand position expressions (planner.py:596-660): frames on the last arm links of the synthetic tree, one hand per mode
+    from hippopt_amd.pose_settings import hand_frame
+    d = pose_finder_settings(model)
+    d.left_hand_frame = hand_frame(model, 7, (0.1, -0.2, 0.3), (0.02, 0.01, -0.05))
+    d.right_hand_frame = hand_frame(model, 11, (0.0, 0.1, 0.0), (0.0, 0.0, -0.04))
+    d.lef_hand_position_in_frame = np.array([0.01, 0.02, 0.03])
+    d.left_hand_expression_type, d.right_hand_expression_type = _abi.EXPR_SUBJECT_TO, _abi.EXPR_MINIMIZE
+    d.left_hand_regularization_cost_multiplier, d.right_hand_regularization_cost_multiplier = 0.7, 3.0
+    e = pose_finder_settings(model)
+    e.terrain, e.terrain_steps = c.terrain, c.terrain_steps
+    e.left_hand_frame, e.right_hand_frame = d.left_hand_frame, d.right_hand_frame
+    e.right_hand_position_in_frame = np.array([0.0, -0.02, 0.05])
+    e.left_hand_expression_type, e.right_hand_expression_type = _abi.EXPR_MINIMIZE, _abi.EXPR_SUBJECT_TO
+    e.left_hand_regularization_cost_multiplier = 12.0
+    f = pose_finder_settings(model)      # both hands minimised (their gradient shares meet in p_b, q_b and the torso joints)
+    f.left_hand_frame, f.right_hand_frame = d.left_hand_frame, d.right_hand_frame
+    f.left_hand_expression_type = f.right_hand_expression_type = _abi.EXPR_MINIMIZE
+    f.right_hand_regularization_cost_multiplier = 2.5
+    return {"default": a, "constrained": b, "steps": c, "hands": d, "hands_steps": e, "hands_costs": f}
 
 
-@pytest.mark.parametrize("name", ["default", "constrained", "steps"])
+VARIANTS = ["default", "constrained", "steps", "hands", "hands_steps", "hands_costs"]
+
+
+@pytest.mark.parametrize("name", VARIANTS)
 def test_pose_body_matches_oracle(model, name):
     st = variants(model)[name]
     o, e = PoseOracle(st, model), PoseHostEmu(st, model)
@@ -43,7 +64,7 @@ def test_pose_body_matches_oracle(model, name):
     ir2, jc2 = e.sparsity()
     assert np.array_equal(ir, ir2) and np.array_equal(jc, jc2)
     x, p = make_pose_workload(st, model, 3, 700)
-    if name == "steps":   # contact points on the flanks of the first bump
+    if name.endswith("steps"):   # contact points on the flanks of the first bump
         rng = np.random.RandomState(1)
         for c in range(8):
             x[0][6 * c] = 0.45 + rng.choice([-1.0, 1.0]) * 0.3 * rng.uniform(0.95, 1.01)
@@ -95,13 +116,13 @@ def flank_points(x, seed):
         x[6 * c + 2] = 0.1 + 0.05 * rng.standard_normal()
 
 
-@pytest.mark.parametrize("name", ["default", "constrained", "steps"])
+@pytest.mark.parametrize("name", VARIANTS)
 def test_pose_hessian_body_matches_oracle(model, name):
     st = variants(model)[name]
     o, e = PoseOracle(st, model), PoseHostEmu(st, model)
     ir, jc = e.hess_sparsity()
     x, p = make_pose_workload(st, model, 3, 900)
-    if name == "steps":
+    if name.endswith("steps"):
         flank_points(x[0], 4)
     rng = np.random.RandomState(5)
     pattern = np.zeros((o.n, o.n), bool)
@@ -110,7 +131,7 @@ def test_pose_hessian_body_matches_oracle(model, name):
         Href = o.hess(x[b], p[b], sigma, lam)
         vals = e.hess(x[b], p[b], sigma, lam)
         assert not np.isnan(vals).any()
-        hess_check(ir, jc, vals, Href, 1e-10 if name == "steps" else TOL)
+        hess_check(ir, jc, vals, Href, 1e-10 if name.endswith("steps") else TOL)
         pattern |= np.tril(Href) != 0.0
     # the pattern is tight: every entry of it is non-zero at some sample
     mine = np.zeros_like(pattern)
