@@ -62,6 +62,15 @@ class RobotModel:
     joint_names: list = dataclasses.field(default_factory=lambda: list(JOINT_NAMES))
     min_joint_positions: np.ndarray = None
     max_joint_positions: np.ndarray = None
+    # every named frame of the source description: name -> (moving link it is rigidly attached to, link_R_frame, link_o_frame);
+    # what a frame NAME of the reference's settings (e.g. left_hand_frame_name) resolves to.  None: names unknown.
+    named_frames: dict = None
+
+    def resolve_frame(self, name) -> tuple:
+        if not self.named_frames or name not in self.named_frames:
+            raise ValueError("frame '%s' is not known to this model" % name)
+        link, R, o = self.named_frames[name]
+        return int(link), np.array(R, float), np.array(o, float)
 
     @property
     def NDoF(self):  # noqa: N802  (adam KinDynComputations.NDoF, used at variables.py:319)
@@ -188,5 +197,8 @@ def synthetic_ergocub(seed: int = 0) -> RobotModel:
     frame_R = np.stack([rot_from_rpy(*(0.02 * rng.uniform(-1, 1, 3))) for _ in range(3)])
     frame_o = np.array([[0.03, 0.0, -0.06], [0.03, 0.0, -0.06], [0.0, 0.0, 0.15]])
     lim = np.array([0.6, 0.4, 0.6] + [1.6, 1.4, 1.0, 1.6] * 2 + [1.4, 0.6, 0.8, 1.6, 0.7, 0.4] * 2)
+    named = {n: (int(frame_link[f]), frame_R[f], frame_o[f]) for f, n in enumerate(("l_sole", "r_sole", "chest"))}
+    named["l_hand_palm"] = (7, rot_from_rpy(0.1, -0.2, 0.3), np.array([0.02, 0.01, -0.05]))    # ends of the two arm chains
+    named["r_hand_palm"] = (11, rot_from_rpy(0.0, 0.1, 0.0), np.array([0.0, 0.0, -0.04]))
     return RobotModel(parent, R_fix, o_fix, axis, link_mass, com, inertia, frame_link, frame_R, frame_o,
-                      min_joint_positions=-lim, max_joint_positions=lim)
+                      min_joint_positions=-lim, max_joint_positions=lim, named_frames=named)

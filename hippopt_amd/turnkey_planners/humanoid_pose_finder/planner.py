@@ -2,8 +2,9 @@
 and the Planner surface (:323-955: set_initial_guess / get_initial_guess / set_references / solve / get_variables_structure,
 mass regularisation of the forces), with the engine-backed solver plugin in place of OptiSolver + CasADi.
 
-Not mirrored: the hand position expressions (default `skip`) and the parametric-link model (adam.parametric), see
-include/hipnlp.h."""
+The hand position expressions (planner.py:62-69, 596-660) take the reference's frame NAMES (`left_hand_frame_name`,
+`right_hand_frame_name`), resolved through the model's named frames (a URDF's links, `RobotModel.resolve_frame`).
+Not mirrored: the parametric-link model (adam.parametric), see include/hipnlp.h."""
 import copy
 import dataclasses
 
@@ -22,6 +23,8 @@ class Settings(PoseSettings):
     root_link: str = "root_link"
     contact_points: hp_rp.FeetContactPointDescriptors = None
     desired_frame_quaternion_cost_frame_name: str = "chest"
+    left_hand_frame_name: str = None
+    right_hand_frame_name: str = None
     solver_options: dict = dataclasses.field(default_factory=dict)
 
     def __post_init__(self):
@@ -32,8 +35,14 @@ class Settings(PoseSettings):
             self.contact_points.right = hp_rp.ContactPointDescriptor.rectangular_foot("r_sole", 0.232, 0.1, [0.116, 0.05, 0.0])
 
     def is_valid(self) -> bool:
-        return (self.gravity is not None and len(self.gravity) == 6 and self.maximum_joint_positions is not None
-                and self.minimum_joint_positions is not None and self.joint_regularization_cost_weights is not None)
+        from ... import _abi
+        ok = (self.gravity is not None and len(self.gravity) == 6 and self.maximum_joint_positions is not None
+              and self.minimum_joint_positions is not None and self.joint_regularization_cost_weights is not None)
+        for mode, name, frame in ((self.left_hand_expression_type, self.left_hand_frame_name, self.left_hand_frame),
+                                  (self.right_hand_expression_type, self.right_hand_frame_name, self.right_hand_frame)):
+            if mode is None or (mode != _abi.EXPR_SKIP and name is None and frame is None):   # planner.py:162-186
+                ok = False
+        return ok
 
 
 @dataclasses.dataclass
@@ -81,8 +90,8 @@ class Variables(OptimizationObject):
         self.relaxed_complementarity_epsilon = settings.relaxed_complementarity_epsilon
         self.maximum_joint_positions = settings.maximum_joint_positions
         self.minimum_joint_positions = settings.minimum_joint_positions
-        self.left_hand_position_in_frame = np.zeros(3)
-        self.right_hand_position_in_frame = np.zeros(3)
+        self.left_hand_position_in_frame = np.asarray(settings.lef_hand_position_in_frame, float)      # planner.py:298-299
+        self.right_hand_position_in_frame = np.asarray(settings.right_hand_position_in_frame, float)
 
 
 class Planner:
@@ -90,6 +99,10 @@ class Planner:
         if not settings.is_valid():
             raise ValueError("Settings are not valid")
         self.settings = copy.deepcopy(settings)
+        for side in ("left", "right"):   # frame names -> (link, link_T_frame) of the model
+            name = getattr(self.settings, side + "_hand_frame_name")
+            if name is not None and getattr(self.settings, side + "_hand_frame") is None:
+                setattr(self.settings, side + "_hand_frame", model.resolve_frame(name))
         self.kin_dyn_object = model
         self.numeric_mass = model.get_total_mass()
         self.variables = Variables(settings=self.settings, kin_dyn_object=model)

@@ -176,7 +176,8 @@ def load_urdf(source, joints_name_list, root_link="root_link", frames=tuple(FRAM
             raise UrdfError(f"frame '{fname}' is not a link reachable from '{root_link}'")
         frame_link[f], frame_R[f], frame_o[f] = placed[fname]
     return RobotModel(parent, R_fix, o_fix, axis, mass, com, inertia, frame_link, frame_R, frame_o,
-                      joint_names=list(joints_name_list), min_joint_positions=lo, max_joint_positions=hi)
+                      joint_names=list(joints_name_list), min_joint_positions=lo, max_joint_positions=hi,
+                      named_frames={n: (int(v[0]), np.array(v[1]), np.array(v[2])) for n, v in placed.items()})
 
 
 def rpy_from_rot(R):

@@ -249,6 +249,60 @@ def test_pose_planner_converges_with_exact_hessian(model):
     assert cost <= results["limited-memory"][2] + 1e-9
 
 
+def test_pose_planner_reaches_for_a_point_with_its_hands(model):
+    """The hand position expressions (planner.py:596-660) through the planner mirror: frame NAMES resolved by the model, the left hand
+    held on a reference by three equality rows, the right hand pulled towards one by its cost; exact Hessian.  After the solve the
+    left hand point is where the reference is, the right hand has moved towards its reference, and the multipliers of the hand
+    rows come back under the reference's constraint name."""
+    from hippopt_amd import _abi
+    from hippopt_amd.pose_settings import hand_point_position
+    from hippopt_amd.turnkey_planners.humanoid_pose_finder import Planner, References, Settings
+    st = Settings(solver_options={"max_iter": 200, "hessian_approximation": "exact"})
+    st.maximum_joint_positions = np.array(model.max_joint_positions, float)
+    st.minimum_joint_positions = np.array(model.min_joint_positions, float)
+    st.left_hand_frame_name, st.right_hand_frame_name = "l_hand_palm", "r_hand_palm"
+    st.left_hand_expression_type, st.right_hand_expression_type = _abi.EXPR_SUBJECT_TO, _abi.EXPR_MINIMIZE
+    st.right_hand_regularization_cost_multiplier = 200.0
+    st.lef_hand_position_in_frame = np.array([0.0, 0.0, -0.02])
+    pl = Planner(st, model, error_on_fail=False)
+    assert pl.settings.left_hand_frame[0] == 7 and pl.settings.right_hand_frame[0] == 11
+    mass = model.get_total_mass()
+    x, _ = make_pose_workload(pl.settings, model, 1, 42)
+    qn = x[0][51:55] / np.linalg.norm(x[0][51:55])
+    start = [hand_point_position(pl.settings, model, h, x[0][48:51], qn, x[0][55:78]) for h in (0, 1)]
+    targets = [start[0] + np.array([0.06, 0.03, 0.05]), start[1] + np.array([0.05, -0.04, 0.06])]
+    refs = References(contact_point_descriptors=st.contact_points, number_of_joints=23)
+    refs.left_hand_position, refs.right_hand_position = targets[0].copy(), targets[1].copy()
+    refs.state.com = x[0][78:81].copy()
+    for c, pt in enumerate(refs.state.contact_points.left + refs.state.contact_points.right):
+        pt.p = x[0][6 * c:6 * c + 3].copy()
+        pt.p[2] = 0.0
+        pt.f = np.array([0.0, 0.0, mass * 9.80665 / 8])
+    refs.state.kinematics.joints.positions = x[0][55:78].copy()
+    pl.set_references(refs)
+    guess = pl.get_initial_guess()
+    for c, pt in enumerate(guess.state.contact_points.left + guess.state.contact_points.right):
+        pt.p = x[0][6 * c:6 * c + 3].copy()
+        pt.f = x[0][6 * c + 3:6 * c + 6] * mass
+    guess.state.kinematics.base.position = x[0][48:51].copy()
+    guess.state.kinematics.base.quaternion_xyzw = x[0][51:55].copy()
+    guess.state.kinematics.joints.positions = x[0][55:78].copy()
+    guess.state.com = x[0][78:81].copy()
+    pl.set_initial_guess(guess)
+    out = pl.solve()
+    info = pl.optimization_solver._last_info
+    assert info["status"] in (1, 2) and info["constr_violation"] < 1e-8, info
+    kin = out.values.state.kinematics
+    q = np.asarray(kin.base.quaternion_xyzw, float).reshape(-1)
+    got = [hand_point_position(pl.settings, model, h, np.asarray(kin.base.position, float).reshape(-1), q / np.linalg.norm(q),
+                               np.asarray(kin.joints.positions, float).reshape(-1)) for h in (0, 1)]
+    assert np.max(np.abs(got[0] - targets[0])) < 1e-7                                      # held by the equality rows
+    assert np.linalg.norm(got[1] - targets[1]) < 0.5 * np.linalg.norm(start[1] - targets[1])   # pulled by the cost
+    assert "left_hand_position_error" in out.constraint_multipliers and np.asarray(out.constraint_multipliers["left_hand_position_error"]).size == 3
+    assert "right_hand_position_error" in out.cost_values and out.cost_values["right_hand_position_error"] >= 0.0
+    assert "right_hand_position_error" not in out.constraint_multipliers
+
+
 def test_pose_device_pointer_paths(model):
     """hipnlp_pose_eval_device / hipnlp_pose_eval_hess_device with torch device pointers equal the host-buffer paths bit for bit."""
     import torch
