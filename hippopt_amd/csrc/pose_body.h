@@ -140,7 +140,7 @@ template <class Em> HD void t_pose_com(Ctx<Em>& cx, int t) {
 
 // --- hand position expressions (planner.py:596-660):  P_h = p_b + r_h,  r_h = o_L + R_L (o_frame + R_frame p_in)  (base-centred,
 //     world-oriented link pose of the forward kinematics)  against references.<side>_hand_position.
-//     subject_to: three rows P_h - ref == 0;  minimize: mult * |P_h - ref|^2.   d r_h / d s_j = a_j x (r_h - o_j) for the joints j
+//     subject_to: three rows ref <= P_h <= ref (Opti's canonical form of P_h == parameter);  minimize: mult * |P_h - ref|^2.   d r_h / d s_j = a_j x (r_h - o_j) for the joints j
 //     on the path root -> hand link (kt.anc of the link's joint: at most eight), d r_h / d q_b = -[r_h]x G / |q|, d P_h / d p_b = I.
 // Scratch: the per-point momentum partials hd[][][] of the knot program are unused by the pose program.
 //   hb[0..5] r_h, hb[6..11] e_h = P_h - ref, hb[12..13] cost.   Native slots: the (unused) trapezoid-defect slots of the knot program —
@@ -188,7 +188,8 @@ template <class Em> HD void pose_hand_rows(Ctx<Em>& cx, int t, int h) {
     if (t < 3) {
         const int i = t, jb = js::PT_STRIDE * (4 * h + i) + js::FDYN;
         if (mode == HIPNLP_EXPR_SUBJECT_TO) {
-            em.G(gs::PT_STRIDE * h + gs::FDYN + i, row_id(RK_PHAND, h, i), e[i]);
+            // (Opti's canonical form of `position == parameter`: the row is the position, its bounds are the reference)
+            em.G(gs::PT_STRIDE * h + gs::FDYN + i, row_id(RK_PHAND, h, i), s.x[PB_ + i] + r[i]);
             em.J(jb + 0, row_id(RK_PHAND, h, i), PB_ + i, 1.0);
             const double X0 = skew_rc(r, i, 0), X1 = skew_rc(r, i, 1), X2 = skew_rc(r, i, 2);
             for (int l = 0; l < 4; ++l)

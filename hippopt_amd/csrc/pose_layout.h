@@ -181,7 +181,8 @@ struct PoseLayout {
             fill(RK_KINC, c, eq0); fill(RK_PPREG, c, eq0);
         }
         fill(RK_UNITQ, 0, [](int, double& lo, double& hi) { lo = hi = 1.0; });
-        fill(RK_COMC, 0, eq0); fill(RK_PBAL, 0, eq0); fill(RK_PCOMERR, 0, eq0); fill(RK_PHAND, 0, eq0); fill(RK_PHAND, 1, eq0);
+        fill(RK_COMC, 0, eq0); fill(RK_PBAL, 0, eq0); fill(RK_PCOMERR, 0, eq0);
+        for (int h = 0; h < 2; ++h) fill(RK_PHAND, h, [&](int i, double& lo, double& hi) { lo = hi = p[pp::REF_LH + 3 * h + i]; });
         fill(RK_JPB, 0, [&](int i, double& lo, double& hi) { lo = p[pp::SMIN + i]; hi = p[pp::SMAX + i]; });
     }
 };

@@ -396,8 +396,9 @@ typedef struct hipnlp_pose_settings {
     double point_position_regularization_cost_multiplier;
     /* hand position expressions (planner.py:596-660; a zeroed tail = the settings' default: both skipped):
      *   position of the point hand_position_in_frame (parameter p[196..201]) of the frame settings.left/right_hand_frame_name
-     *   == references.left/right_hand_position (p[142..147]);  subject_to: three equality rows "left_hand_position_error" /
-     *   "right_hand_position_error" behind the rows above;  minimize: multiplier * sumsqr(error)  (base/problem.py:95-174).
+     *   == references.left/right_hand_position (p[142..147]);  subject_to: three rows "left_hand_position_error" /
+     *   "right_hand_position_error" behind the rows above, in Opti's canonical form of `expression == parameter`: g = the position,
+     *   lbg = ubg = the reference;  minimize: multiplier * sumsqr(position - reference)  (base/problem.py:95-174).
      *   The frame is given as in hipnlp_robot_model: the link it is rigidly attached to and link_T_frame. */
     int32_t hand_type[2];               /* settings.left/right_hand_expression_type: HIPNLP_EXPR_*  (planner.py:88, 91) */
     int32_t hand_frame_link[2];

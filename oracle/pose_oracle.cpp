@@ -123,7 +123,10 @@ template <class S> void evaluate(const hipnlp_pose_desc& d, const S* x, const do
             const V3<S> pos = lk.o + mul(lk.R, v3c<S>(st.hand_frame_o[hnd]) + mul(m3c<S>(st.hand_frame_R[hnd]), par3(P_LH_IN + 3 * hnd)));
             const V3<S> e = pos - par3(P_REF_LH + 3 * hnd);
             if (st.hand_type[hnd] == HIPNLP_EXPR_MINIMIZE) cost[CT_LHAND + hnd] = S(st.hand_regularization_cost_multiplier[hnd]) * dot(e, e);
-            else { block(hnd == 0 ? "left_hand_position_error" : "right_hand_position_error", 3); for (int i = 0; i < 3; ++i) row(e[i], 0.0, 0.0); }
+            else {   // Opti's canonical form of `expression == parameter`: g = expression, lbg = ubg = the parameter's value
+                block(hnd == 0 ? "left_hand_position_error" : "right_hand_position_error", 3);
+                for (int i = 0; i < 3; ++i) row(pos[i], p[P_REF_LH + 3 * hnd + i], p[P_REF_LH + 3 * hnd + i]);
+            }
         }
     }
     // ---- _add_foot_regularization  :724-768 (left, then right)

@@ -23,6 +23,12 @@ def pose_settings_for(meta, model):
         st.com_position_expression_type = _abi.EXPR_SUBJECT_TO
         st.left_point_position_expression_type = _abi.EXPR_SUBJECT_TO
         st.right_point_position_expression_type = _abi.EXPR_SKIP
+    if meta["config"] == "hands":   # tools/gen_pose_fixtures.py::hands_settings
+        st.left_hand_frame, st.right_hand_frame = model.resolve_frame("l_hand_palm"), model.resolve_frame("r_hand_palm")
+        st.lef_hand_position_in_frame = np.array([0.01, 0.02, 0.03])
+        st.right_hand_position_in_frame = np.array([0.0, -0.02, 0.05])
+        st.left_hand_expression_type, st.right_hand_expression_type = _abi.EXPR_SUBJECT_TO, _abi.EXPR_MINIMIZE
+        st.left_hand_regularization_cost_multiplier, st.right_hand_regularization_cost_multiplier = 0.7, 3.0
     return st
 
 
@@ -47,7 +53,7 @@ def check_against_fixture(z, ir, jc, f, grad, g, jac, lb, ub, tol=TOL):
     assert np.max(np.abs(jac[~seen]), initial=0.0) < 1e-12
 
 
-@pytest.mark.parametrize("name", ["pose_default", "pose_step_constrained"])
+@pytest.mark.parametrize("name", ["pose_default", "pose_step_constrained", "pose_hands"])
 def test_pose_oracle_matches_reference_assembly(model, name):
     z = np.load(os.path.join(GOLD, name + ".npz"))
     st = pose_settings_for(json.loads(str(z["meta"])), model)
@@ -105,7 +111,7 @@ def test_pose_fixture_layout_names():
     assert off["maximum_joint_positions"] == ps.P_SMAX and off["minimum_joint_positions"] == ps.P_SMIN
 
 
-@pytest.mark.parametrize("name", ["pose_default", "pose_step_constrained"])
+@pytest.mark.parametrize("name", ["pose_default", "pose_step_constrained", "pose_hands"])
 def test_pose_oracle_hessian_matches_reference_graph(model, name):
     """Hessian of the Lagrangian (IPOPT eval_h; the reference pose finder runs IPOPT with the exact Hessian,
     humanoid_pose_finder/main.py:101): the oracle's forward-over-forward AD against second derivatives taken on the reference

@@ -54,7 +54,7 @@ def test_pose_matches_oracle(model, name):
     assert np.array_equal(f, f2) and np.array_equal(jac, jac2) and np.array_equal(g, g2) and np.array_equal(grad, grad2)
 
 
-@pytest.mark.parametrize("name", ["pose_default", "pose_step_constrained"])
+@pytest.mark.parametrize("name", ["pose_default", "pose_step_constrained", "pose_hands"])
 def test_pose_matches_reference_fixture(model, name):
     from hippopt_amd.hipnlp import HipPose
     z = np.load(os.path.join(GOLD, name + ".npz"))
@@ -171,7 +171,7 @@ def test_pose_hessian_matches_oracle(model, name):
     assert rel(f[2], fo) < TOL and rel(grad[2], grado) < TOL and rel(g[2], go) < TOL and rel(jac[2], jaco) < TOL
 
 
-@pytest.mark.parametrize("name", ["pose_default", "pose_step_constrained"])
+@pytest.mark.parametrize("name", ["pose_default", "pose_step_constrained", "pose_hands"])
 def test_pose_hessian_matches_reference_fixture(model, name):
     from hippopt_amd.hipnlp import HipPose
     from test_pose_body_hostemu import hess_check

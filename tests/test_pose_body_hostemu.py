@@ -81,7 +81,7 @@ def test_pose_body_matches_oracle(model, name):
         assert np.array_equal(lb, lb2) and np.array_equal(ub, ub2)
 
 
-@pytest.mark.parametrize("name", ["pose_default", "pose_step_constrained"])
+@pytest.mark.parametrize("name", ["pose_default", "pose_step_constrained", "pose_hands"])
 def test_pose_body_matches_reference_fixture(model, name):
     z = np.load(os.path.join(GOLD, name + ".npz"))
     st = pose_settings_for(json.loads(str(z["meta"])), model)
@@ -139,7 +139,7 @@ def test_pose_hessian_body_matches_oracle(model, name):
     assert np.array_equal(mine, pattern)
 
 
-@pytest.mark.parametrize("name", ["pose_default", "pose_step_constrained"])
+@pytest.mark.parametrize("name", ["pose_default", "pose_step_constrained", "pose_hands"])
 def test_pose_hessian_body_matches_reference_fixture(model, name):
     z = np.load(os.path.join(GOLD, name + ".npz"))
     st = pose_settings_for(json.loads(str(z["meta"])), model)

@@ -52,14 +52,17 @@ class KinDynComputations:
 
     def forward_kinematics_fun(self, frame):
         from hippopt_amd.robot_model import FRAME_NAMES
-        f = FRAME_NAMES.index(frame)
         md = self.md
+        if frame in FRAME_NAMES:
+            f = FRAME_NAMES.index(frame)
+            link, fR, fo = int(md.frame_link[f]), md.frame_R[f], md.frame_o[f]
+        else:   # any other named frame of the model (e.g. the hand frames of the pose finder)
+            link, fR, fo = md.resolve_frame(frame)
         H = cs.MX.sym("H", 4, 4)
         s = cs.MX.sym("s", md.NDoF)
-        link = int(md.frame_link[f])
         R, o = self._poses(H, s, self._chain(link))
-        Rf = cs.mtimes(R[link], cs.DM(md.frame_R[f]))
-        of = o[link] + cs.mtimes(R[link], cs.DM(md.frame_o[f]))
+        Rf = cs.mtimes(R[link], cs.DM(fR))
+        of = o[link] + cs.mtimes(R[link], cs.DM(fo))
         T = cs.vertcat(cs.horzcat(Rf, of), cs.DM([[0.0, 0.0, 0.0, 1.0]]))
         return cs.Function("T_fk", [H, s], [T])
 

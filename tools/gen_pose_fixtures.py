@@ -49,6 +49,15 @@ def reference_settings(mine):
     s.com_position_expression_type = EXPR[mine.com_position_expression_type]
     s.left_point_position_expression_type = EXPR[mine.left_point_position_expression_type]
     s.right_point_position_expression_type = EXPR[mine.right_point_position_expression_type]
+    # hand position expressions (planner.py:62-69): frame NAMES on the reference side
+    s.left_hand_expression_type = EXPR[mine.left_hand_expression_type]
+    s.right_hand_expression_type = EXPR[mine.right_hand_expression_type]
+    s.left_hand_frame_name = getattr(mine, "left_hand_frame_name", None)
+    s.right_hand_frame_name = getattr(mine, "right_hand_frame_name", None)
+    s.lef_hand_position_in_frame = np.asarray(mine.lef_hand_position_in_frame, float)
+    s.right_hand_position_in_frame = np.asarray(mine.right_hand_position_in_frame, float)
+    s.left_hand_regularization_cost_multiplier = mine.left_hand_regularization_cost_multiplier
+    s.right_hand_regularization_cost_multiplier = mine.right_hand_regularization_cost_multiplier
     if mine.terrain == _abi.TERRAIN_SMOOTH_STEPS:   # main_complex_poses.py:268-274
         terrain = None
         for st in mine.terrain_steps:
@@ -157,6 +166,18 @@ def step_settings(model):
     return st
 
 
+def hands_settings(model):
+    """Both hand position expressions: the left hand as three equality rows, the right hand as a cost (planner.py:596-660)."""
+    st = pose_finder_settings(model)
+    st.left_hand_frame_name, st.right_hand_frame_name = "l_hand_palm", "r_hand_palm"
+    st.left_hand_frame, st.right_hand_frame = model.resolve_frame("l_hand_palm"), model.resolve_frame("r_hand_palm")
+    st.lef_hand_position_in_frame = np.array([0.01, 0.02, 0.03])
+    st.right_hand_position_in_frame = np.array([0.0, -0.02, 0.05])
+    st.left_hand_expression_type, st.right_hand_expression_type = _abi.EXPR_SUBJECT_TO, _abi.EXPR_MINIMIZE
+    st.left_hand_regularization_cost_multiplier, st.right_hand_regularization_cost_multiplier = 0.7, 3.0
+    return st
+
+
 def on_the_flank(x):
     rng = np.random.RandomState(11)
     for c in range(8):
@@ -172,6 +193,7 @@ def main():
     model = synthetic_ergocub()
     generate("default", pose_finder_settings(model), model, 5001)
     generate("step_constrained", step_settings(model), model, 5002, tweak=on_the_flank)
+    generate("hands", hands_settings(model), model, 5003)
 
 
 if __name__ == "__main__":
