@@ -78,7 +78,9 @@ template <int TERRAIN> struct PoseHessEm {
 struct PoseShared {
     HeadTables head;
     GParams gp;
+    PoseHands hands;   // (208 B; read by several task groups of both kernels: an LDS copy, not a global load per use)
 };
+static_assert(sizeof(PoseHands) % 8 == 0 && sizeof(PoseHands) / 8 <= WG, "staged as 8-byte words, one per thread");
 
 // workgroup barrier that orders LDS traffic only (see hipnlp.hip): the copy-out tables prefetched into registers stay in flight across it
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -98,6 +100,8 @@ __device__ __forceinline__ void pose_stage(const PArgs& a, KnotScratch& s, PoseS
     for (int it = 0; it < HV_ITERS; ++it) { const int i = tid + it * WG; hv[it] = i < HV ? hsrc[i] : uint4{0u, 0u, 0u, 0u}; }
 #pragma unroll
     for (int it = 0; it < GV_ITERS; ++it) { const int i = tid + it * WG; gv[it] = i < GV ? gsrc[i] : 0.0; }
+    constexpr int HW = int(sizeof(PoseHands) / 8);
+    const double hwv = tid < HW ? reinterpret_cast<const double*>(&tb.hands)[tid] : 0.0;
     const double xrv = tid < XR_STRIDE ? a.xr[size_t(b) * XR_STRIDE + tid] : 0.0;
     const double pkv = tid < PK_STRIDE ? a.pk[size_t(b) * PK_STRIDE + tid] : 0.0;
     const double xval = tid < POSE_NX ? a.x[size_t(b) * POSE_NX + tid] : 0.0;
@@ -107,6 +111,7 @@ __device__ __forceinline__ void pose_stage(const PArgs& a, KnotScratch& s, PoseS
     for (int it = 0; it < HV_ITERS; ++it) { const int i = tid + it * WG; if (i < HV) hdst[i] = hv[it]; }
 #pragma unroll
     for (int it = 0; it < GV_ITERS; ++it) { const int i = tid + it * WG; if (i < GV) gdst[i] = gv[it]; }
+    if (tid < HW) reinterpret_cast<double*>(&tabs.hands)[tid] = hwv;
     if (tid < XPAD) { s.x[tid] = 0.0; s.xm[tid] = xrv; }
     if (tid < PK_STRIDE) s.pk[tid] = pkv;
     __syncthreads();
@@ -135,7 +140,7 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     KnotInfo ki{1, 3, 0, 0};   // "interior knot": the k >= 1 rows / costs of the shared tasks are active
     PoseEm<TERRAIN> em{s.g, s.jac};
     Ctx<PoseEm<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
-    cx.hands = &tb.hands;
+    cx.hands = &tabs.hands;
     // (one contiguous program instance per wave, as in hipnlp_knot_kernel: no wave jumps over the other waves' code)
 #define DEV_R(w, w8, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_BARRIER lds_barrier();
@@ -202,7 +207,7 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     KnotInfo ki{1, 3, 0, 0};
     PoseHessEm<TERRAIN> em{s.g, nullptr, hx.H};   // (no task of the Hessian program emits a Jacobian entry)
     Ctx<PoseHessEm<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
-    cx.hands = &tb.hands;
+    cx.hands = &tabs.hands;
     HCtx<PoseHessEm<TERRAIN>> hcx{cx, hx};
     // (one contiguous program instance per wave, as in hipnlp_knot_kernel: no wave jumps over the other waves' code)
 #define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
