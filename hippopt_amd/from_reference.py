@@ -146,4 +146,94 @@ def from_reference(settings, variables, model=None, terrain_steps=None, batch=1,
     return desc, x, p, numeric, model
 
 
-__all__ = ["expression_type", "settings_from_reference", "model_from_reference", "flatten_reference", "from_reference", "yaw_corner_indices"]
+# ---- the static pose finder (turnkey_planners/humanoid_pose_finder/planner.py) --------------------------------------------------------
+# reference pose Settings field -> PoseSettings field of the same name (planner.py:19-91)
+_POSE_SAME_NAME = (
+    "relaxed_complementarity_epsilon", "static_friction", "maximum_joint_positions", "minimum_joint_positions",
+    "base_quaternion_cost_multiplier", "desired_frame_quaternion_cost_multiplier", "com_regularization_cost_multiplier",
+    "joint_regularization_cost_weights", "joint_regularization_cost_multiplier", "force_regularization_cost_multiplier",
+    "average_force_regularization_cost_multiplier", "point_position_regularization_cost_multiplier",
+    "lef_hand_position_in_frame", "right_hand_position_in_frame", "left_hand_regularization_cost_multiplier",
+    "right_hand_regularization_cost_multiplier",
+)
+
+
+def pose_settings_from_reference(settings, model, terrain_steps=None):
+    """The numeric mirror (pose_settings.PoseSettings) of a reference pose-finder `Settings` (planner.py:19-193).  The hand frame NAMES
+    (left_hand_frame_name / right_hand_frame_name, :62, :66) are resolved through `model` (RobotModel.resolve_frame: every link of the
+    URDF); terrain_steps as in settings_from_reference."""
+    from .pose_settings import PoseSettings
+    out = PoseSettings()
+    for name in _POSE_SAME_NAME:
+        v = getattr(settings, name, None)
+        if v is not None:
+            setattr(out, name, np.asarray(v, float).copy() if isinstance(v, (list, tuple, np.ndarray)) else v)
+    g = getattr(settings, "gravity", None)
+    if g is not None:
+        out.gravity = np.asarray(g, float).reshape(-1)
+    for name in ("com_position_expression_type", "left_point_position_expression_type", "right_point_position_expression_type",
+                 "left_hand_expression_type", "right_hand_expression_type"):
+        setattr(out, name, expression_type(getattr(settings, name, None)))
+    cp = settings.contact_points
+    out.left_descriptors, out.right_descriptors = descriptors_of(cp.left), descriptors_of(cp.right)
+    if out.left_descriptors.shape != (4, 3) or out.right_descriptors.shape != (4, 3):
+        raise ValueError("the engine is built for four contact points per foot (ContactPointDescriptor.rectangular_foot)")
+    for side in ("left", "right"):
+        if getattr(out, side + "_hand_expression_type") == _abi.EXPR_SKIP:
+            continue
+        name = getattr(settings, side + "_hand_frame_name", None)
+        if name is None:   # planner.py:165-170, 180-185
+            raise ValueError(f"{side}_hand_frame_name is None but {side}_hand_expression_type is not skip")
+        setattr(out, side + "_hand_frame", model.resolve_frame(name))
+    terrain = getattr(settings, "terrain", None)
+    tname = type(terrain).__name__ if terrain is not None else "PlanarTerrain"
+    if terrain_steps:
+        out.terrain, out.terrain_steps = _abi.TERRAIN_SMOOTH_STEPS, [dict(t) for t in terrain_steps]
+    elif tname == "PlanarTerrain":
+        out.terrain = _abi.TERRAIN_PLANAR
+    else:
+        raise ValueError(f"settings.terrain is a {tname}: pass terrain_steps=[{{length, width, height, position, ...}}, ...]")
+    if getattr(settings, "parametric_link_names", None) is not None:
+        raise ValueError("parametric_link_names: the parametric-link model (adam.parametric) is not built")
+    return out
+
+
+def flatten_pose_reference(variables, total_mass, mass_regularization=True):
+    """(x [81], p [202], names) of a reference pose-finder `Variables` tree (planner.py:229-320) in creation order.  The pose finder's
+    mass regularisation (planner.py:788-850) divides the contact forces of the state AND of the references by the total mass."""
+    values, meta = variables.to_dicts()
+    xs, ps, xn, pn = [], [], [], []
+    for name, value in values.items():
+        if value is None:
+            raise ValueError(f"{name} is None: the structure must be filled (guess and references)")
+        arr = np.asarray(value, float).reshape(-1)
+        if mass_regularization and name.endswith(".f") and ".contact_points." in name:
+            arr = arr / total_mass
+        storage = meta[name].get("StorageType")
+        if storage == "variable":
+            xs.append(arr); xn.append((name, arr.size))
+        elif storage == "parameter":
+            ps.append(arr); pn.append((name, arr.size))
+        else:
+            raise ValueError(f"{name}: unsupported storage type {storage!r}")
+    return np.concatenate(xs), np.concatenate(ps), xn, pn
+
+
+def pose_from_reference(settings, variables, model=None, terrain_steps=None, batch=1, device=0, mass_regularization=True):
+    """(PoseDescC, x [81], p [202], PoseSettings, RobotModel): everything hipnlp_pose_create / _set_params / _eval need, from a
+    reference pose-finder `Settings` and a filled `Variables`."""
+    if model is None:
+        model = model_from_reference(settings)
+    numeric = pose_settings_from_reference(settings, model, terrain_steps)
+    x, p, xn, pn = flatten_pose_reference(variables, model.get_total_mass(), mass_regularization)
+    if x.size != _abi.POSE_NX or p.size != _abi.POSE_NP:
+        raise ValueError(f"not the pose finder's Variables tree: {x.size} variables and {p.size} parameters (expected {_abi.POSE_NX} and {_abi.POSE_NP})")
+    desc = _abi.PoseDescC()
+    desc.settings = numeric.to_c()
+    desc.model = model.to_c()
+    desc.batch, desc.device = int(batch), int(device)
+    return desc, x, p, numeric, model
+
+
+__all__ = ["expression_type", "settings_from_reference", "model_from_reference", "flatten_reference", "from_reference", "yaw_corner_indices",
+           "pose_settings_from_reference", "flatten_pose_reference", "pose_from_reference"]

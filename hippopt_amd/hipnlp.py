@@ -353,13 +353,17 @@ class HipNlp:
 class HipPose:
     """One pose-finder handle (hipnlp_pose_*): `batch` independent static poses per launch on one HIP device."""
 
-    def __init__(self, settings, model, batch=1, device=0):
+    def __init__(self, settings, model, batch=1, device=0, desc=None):
         self.lib = load_library()
-        self.desc = _abi.PoseDescC()
-        self.desc.settings = settings.to_c()
-        self.desc.model = model.to_c()
-        self.desc.batch = int(batch)
-        self.desc.device = int(device)
+        if desc is None:
+            self.desc = _abi.PoseDescC()
+            self.desc.settings = settings.to_c()
+            self.desc.model = model.to_c()
+            self.desc.batch = int(batch)
+            self.desc.device = int(device)
+        else:   # a ready hipnlp_pose_desc (from_reference.pose_from_reference, a committed fixture)
+            self.desc = desc
+            batch = int(desc.batch)
         h = C.c_void_p()
         rc = self.lib.hipnlp_pose_create(C.byref(self.desc), C.byref(h))
         if rc != 0:
@@ -369,6 +373,13 @@ class HipPose:
         self._check(self.lib.hipnlp_pose_get_dims(self.h, C.byref(d)))
         self.batch = int(batch)
         self.n, self.m, self.nnz, self.np = d.n, d.m, d.nnz, d.np
+
+    @classmethod
+    def from_desc(cls, desc):
+        """a pose handle from a hipnlp_pose_desc structure or its raw bytes"""
+        if not isinstance(desc, _abi.PoseDescC):
+            desc = _abi.PoseDescC.from_buffer_copy(bytes(desc))
+        return cls(None, None, desc=desc)
 
     def close(self):
         if getattr(self, "h", None):

@@ -188,9 +188,10 @@ def rpy_from_rot(R):
     return np.array([0.0, np.pi / 2 * np.sign(sy), np.arctan2(-R[0, 1] * np.sign(sy), R[1, 1])])
 
 
-def to_urdf(model: RobotModel, name="robot", root_link="root_link", frames=tuple(FRAME_NAMES)) -> str:
+def to_urdf(model: RobotModel, name="robot", root_link="root_link", frames=tuple(FRAME_NAMES), extra_frames=()) -> str:
     """A URDF of an engine model (one link per degree of freedom, the three frames as massless links behind fixed joints): the
-    inverse of load_urdf up to rounding, used to exchange models with tools that read URDF and by the loader's round-trip tests."""
+    inverse of load_urdf up to rounding, used to exchange models with tools that read URDF and by the loader's round-trip tests.
+    extra_frames: names of further named frames of the model (RobotModel.named_frames, e.g. the hand frames) to write the same way."""
     f = lambda v: " ".join(repr(float(t)) for t in v)  # noqa: E731
     lname = [root_link] + [model.joint_names[j] + "_link" for j in range(model.NDoF)]
     out = [f'<robot name="{name}">']
@@ -208,5 +209,10 @@ def to_urdf(model: RobotModel, name="robot", root_link="root_link", frames=tuple
         out.append(f'  <link name="{fname}"/>')
         out.append(f'  <joint name="{fname}_fixed_joint" type="fixed"><parent link="{lname[int(model.frame_link[k])]}"/><child link="{fname}"/>'
                    f'<origin xyz="{f(model.frame_o[k])}" rpy="{f(rpy_from_rot(model.frame_R[k]))}"/></joint>')
+    for fname in extra_frames:
+        link, R, o = model.resolve_frame(fname)
+        out.append(f'  <link name="{fname}"/>')
+        out.append(f'  <joint name="{fname}_fixed_joint" type="fixed"><parent link="{lname[link]}"/><child link="{fname}"/>'
+                   f'<origin xyz="{f(o)}" rpy="{f(rpy_from_rot(R))}"/></joint>')
     out.append("</robot>")
     return "\n".join(out)

@@ -85,3 +85,85 @@ def test_flatten_through_the_mirror_structure(model):
     s.horizon_length = 5
     with pytest.raises(ValueError, match="not the kinodynamic Variables tree"):
         from_reference(s, tree, model=model)
+
+
+# ---- the pose finder ---------------------------------------------------------------------------------------------------------------
+POSE_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pose_from_reference.npz")
+
+
+def _pose_numeric(model):
+    """tools/gen_pose_from_reference_fixture.py::numeric_settings"""
+    from hippopt_amd.pose_settings import pose_finder_settings
+    st = pose_finder_settings(model)
+    st.left_hand_frame, st.right_hand_frame = model.resolve_frame("l_hand_palm"), model.resolve_frame("r_hand_palm")
+    st.lef_hand_position_in_frame = np.array([0.01, 0.02, 0.03])
+    st.right_hand_position_in_frame = np.array([0.0, -0.02, 0.05])
+    st.left_hand_expression_type, st.right_hand_expression_type = _abi.EXPR_SUBJECT_TO, _abi.EXPR_MINIMIZE
+    st.left_hand_regularization_cost_multiplier, st.right_hand_regularization_cost_multiplier = 0.7, 3.0
+    st.com_position_expression_type = _abi.EXPR_SUBJECT_TO
+    return st
+
+
+def test_pose_fixture_from_the_reference_objects_matches_the_builds_own_classes(model):
+    """tests/golden/pose_from_reference.npz = pose_from_reference on the reference's own pose-finder Settings / Variables (hand frames by
+    NAME, resolved through the URDF the reference settings point at): the same desc as the build's own classes give, x and p the seeded pose."""
+    from hippopt_amd.pose_settings import make_pose_workload
+    z = np.load(POSE_GOLD)
+    st = _pose_numeric(model)
+    x, p = make_pose_workload(st, model, 1, int(z["seed"]))
+    assert np.max(np.abs(z["x"] - x[0])) < 1e-15 and np.max(np.abs(z["p"] - p[0])) < 1e-15
+    ref = _abi.PoseDescC.from_buffer_copy(z["desc"].tobytes())
+    mine = _abi.PoseDescC()
+    mine.settings, mine.model, mine.batch = st.to_c(), model.to_c(), 1
+    assert ref.batch == 1 and list(ref.settings.hand_type) == [_abi.EXPR_SUBJECT_TO, _abi.EXPR_MINIMIZE] and list(ref.settings.hand_frame_link) == [7, 11]
+    for name in ("R_fix", "o_fix", "axis", "mass", "com", "inertia", "frame_R", "frame_o"):     # (the model went through URDF text)
+        a = np.frombuffer(bytes(getattr(ref.model, name)), dtype=np.float64)
+        b = np.frombuffer(bytes(getattr(mine.model, name)), dtype=np.float64)
+        assert np.max(np.abs(a - b)) < 1e-15, name
+    for name in ("hand_frame_R", "hand_frame_o"):                                                # (so did the hand frames)
+        a = np.frombuffer(bytes(getattr(ref.settings, name)), dtype=np.float64)
+        b = np.frombuffer(bytes(getattr(mine.settings, name)), dtype=np.float64)
+        assert np.max(np.abs(a - b)) < 1e-15, name
+        ctypes.memmove(ctypes.addressof(getattr(ref.settings, name)), bytes(getattr(mine.settings, name)), a.nbytes)
+    assert bytes(ref.settings) == bytes(mine.settings)
+
+
+def test_pose_settings_mapping_and_errors(model):
+    from hippopt_amd.from_reference import flatten_pose_reference, pose_from_reference, pose_settings_from_reference
+    from hippopt_amd.turnkey_planners.humanoid_pose_finder import Settings
+    from hippopt_amd.turnkey_planners.humanoid_pose_finder.planner import Variables
+    num = _pose_numeric(model)
+    cp = types.SimpleNamespace(left=[types.SimpleNamespace(foot_frame="l_sole", position_in_foot_frame=d) for d in num.left_descriptors],
+                               right=[types.SimpleNamespace(foot_frame="r_sole", position_in_foot_frame=d) for d in num.right_descriptors])
+    s = types.SimpleNamespace(contact_points=cp, terrain=None, gravity=num.gravity, parametric_link_names=None,
+                              left_hand_frame_name="l_hand_palm", right_hand_frame_name=None,
+                              left_hand_expression_type=types.SimpleNamespace(name="subject_to"), right_hand_expression_type=types.SimpleNamespace(name="skip"),
+                              com_position_expression_type=types.SimpleNamespace(name="minimize"),
+                              left_point_position_expression_type=None, right_point_position_expression_type=2,
+                              maximum_joint_positions=num.maximum_joint_positions, minimum_joint_positions=num.minimum_joint_positions,
+                              lef_hand_position_in_frame=[0.1, 0.0, 0.0], static_friction=0.4)
+    out = pose_settings_from_reference(s, model)
+    assert out.left_hand_expression_type == _abi.EXPR_SUBJECT_TO and out.right_hand_expression_type == _abi.EXPR_SKIP
+    assert out.left_hand_frame[0] == 7 and out.right_hand_frame is None and out.static_friction == 0.4
+    assert out.left_point_position_expression_type == _abi.EXPR_SKIP and out.right_point_position_expression_type == _abi.EXPR_MINIMIZE
+    c = out.to_c()
+    assert list(c.hand_type) == [_abi.EXPR_SUBJECT_TO, _abi.EXPR_SKIP] and c.hand_frame_link[0] == 7
+    s.right_hand_expression_type = types.SimpleNamespace(name="minimize")
+    with pytest.raises(ValueError, match="right_hand_frame_name is None"):
+        pose_settings_from_reference(s, model)
+    s.right_hand_frame_name = "no_such_frame"
+    with pytest.raises(ValueError, match="not known to this model"):
+        pose_settings_from_reference(s, model)
+    s.right_hand_frame_name = "r_hand_palm"
+    s.parametric_link_names = ["l_upper_leg"]
+    with pytest.raises(ValueError, match="parametric"):
+        pose_settings_from_reference(s, model)
+    # the build's own Variables mirror flattens like the reference's (to_dicts contract): 81 variables, 202 parameters
+    st = Settings()
+    st.maximum_joint_positions, st.minimum_joint_positions = num.maximum_joint_positions, num.minimum_joint_positions
+    tree = Variables(settings=st, kin_dyn_object=model)
+    x, p, xn, pn = flatten_pose_reference(tree, model.get_total_mass())
+    assert x.size == 81 and p.size == 202 and pn[-1][0] == "right_hand_position_in_frame" and xn[0][0].endswith("left[0].p")
+    s.parametric_link_names = None
+    desc, x2, p2, num2, m2 = pose_from_reference(s, tree, model=model)
+    assert desc.batch == 1 and np.array_equal(x, x2) and np.array_equal(p, p2) and list(desc.settings.hand_frame_link) == [7, 11]

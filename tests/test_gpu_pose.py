@@ -303,6 +303,27 @@ def test_pose_planner_reaches_for_a_point_with_its_hands(model):
     assert "right_hand_position_error" not in out.constraint_multipliers
 
 
+def test_pose_engine_from_the_reference_objects_fixture(model):
+    """tests/golden/pose_from_reference.npz = what from_reference.pose_from_reference produced from the reference's own pose-finder
+    Settings / Variables (tools/gen_pose_from_reference_fixture.py; hand frames by name): the engine created from the stored
+    hipnlp_pose_desc BYTES, fed the stored p and x, against the oracle — callback quartet and exact Hessian."""
+    from hippopt_amd.hipnlp import HipPose
+    from oracle_lib import PoseOracle
+    from test_from_reference import POSE_GOLD, _pose_numeric
+    from test_pose_body_hostemu import hess_check
+    z = np.load(POSE_GOLD)
+    eng = HipPose.from_desc(z["desc"].tobytes())
+    eng.set_params(z["p"][None, :])
+    f, grad, g, jac = eng.eval(z["x"][None, :])
+    orc = PoseOracle(_pose_numeric(model), model)
+    fo, grado, go, jaco = orc.eval(z["x"], z["p"])
+    assert (eng.n, eng.m, eng.nnz) == (orc.n, orc.m, orc.nnz)
+    assert rel(f[0], fo) < TOL and rel(grad[0], grado) < TOL and rel(g[0], go) < TOL and rel(jac[0], jaco) < TOL
+    lam = np.random.RandomState(2).standard_normal((1, eng.m))
+    ir, jc = eng.hess_sparsity()
+    hess_check(ir, jc, eng.eval_hess(z["x"][None, :], np.array([0.9]), lam)[0], orc.hess(z["x"], z["p"], 0.9, lam[0]), TOL)
+
+
 def test_pose_device_pointer_paths(model):
     """hipnlp_pose_eval_device / hipnlp_pose_eval_hess_device with torch device pointers equal the host-buffer paths bit for bit."""
     import torch
