@@ -1207,11 +1207,13 @@ int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor
         xsrc = h->d_x;
     }
     HIP_TRY(h, hipMemcpyAsync(h->d_sigma, h->h_sl, B * (1 + m) * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    // the values leave the kernel as PCIe stores into the pinned block: no copy command behind the launch
-    rc = hess_launch(h, xsrc, h->d_sigma, h->d_lambda, h->hd_hess, h->stream, true);
+    // the values leave the kernel as PCIe stores into the pinned block — or straight into the CALLER'S array when that lies in a range
+    // registered with hipnlp_host_register (no 1.2 MB host copy behind the launch): no copy command either way
+    double* direct = device_address_of(hess, B * hn * sizeof(double));
+    rc = hess_launch(h, xsrc, h->d_sigma, h->d_lambda, direct ? direct : h->hd_hess, h->stream, true);
     if (rc != HIPNLP_OK) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    std::memcpy(hess, h->h_hess, B * hn * sizeof(double));
+    if (!direct) std::memcpy(hess, h->h_hess, B * hn * sizeof(double));
     for (size_t b = 0; b < B; ++b)
         if (h->h_hflag[b] == h->hseq) { h->err = "non-finite value produced by the evaluation"; return HIPNLP_E_NUMERIC; }
     return HIPNLP_OK;

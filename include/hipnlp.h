@@ -254,6 +254,8 @@ int hipnlp_host_unregister(void* p);
  * fourth order: truncated Taylor polynomials, knot_hess_terrain.h).
  *   hipnlp_hess_nnz / _sparsity   structure (the `values == NULL` call of eval_h); a shard handle reports its own knots' blocks
  *   hipnlp_eval_hess              host buffers: x [batch][n], obj_factor [batch], lambda [batch][m] -> values [batch][nnz_h]
+ *                                 (a `values` array inside a range registered with hipnlp_host_register is written by the kernel
+ *                                 directly: 70 instead of 113 us per 100-knot call)
  *   hipnlp_eval_hess_device       device pointers, enqueued on `stream`, not synchronised                                   */
 int hipnlp_hess_nnz(hipnlp_handle* h, int64_t* nnz_h);
 int hipnlp_hess_sparsity(hipnlp_handle* h, int32_t* irow, int32_t* jcol);

@@ -523,6 +523,28 @@ def test_launch_number_wrap(model, HipNlp):
         assert np.array_equal(eng.eval_hess(x, 1.0, np.ones((2, eng.m))), hv_ref)
 
 
+def test_hessian_values_straight_into_a_registered_array(model, HipNlp):
+    """hipnlp_eval_hess with the caller's value array inside a range registered with hipnlp_host_register: the kernel stores into it
+    directly (no pinned block, no host copy); the same values as the plain path, also after the array has been unregistered again."""
+    st = periodic_step_settings(12, model)
+    x, p = make_workload(st, model, batch=2, seed=64)
+    eng = HipNlp(st, model, batch=2)
+    eng.set_params(p)
+    lam = np.random.RandomState(3).standard_normal((2, eng.m))
+    ref = eng.eval_hess(x, [0.7, 1.3], lam)
+    out = np.full_like(ref, np.nan)
+    eng.register_outputs([out])
+    try:
+        got = eng.eval_hess(x, [0.7, 1.3], lam, out=out)
+        assert got is out and np.array_equal(out, ref)
+        x2 = x + 1e-3
+        assert np.array_equal(eng.eval_hess(x2, [0.7, 1.3], lam, out=out), eng.eval_hess(x2, [0.7, 1.3], lam))
+    finally:
+        eng.unregister_outputs([out])
+    out[:] = np.nan
+    assert np.array_equal(eng.eval_hess(x, [0.7, 1.3], lam, out=out), ref)
+
+
 def test_early_outputs_into_registered_arrays(model, HipNlp):
     """hipnlp_set_early_outputs: the new-x call (eval_f) already fills the registered arrays the later eval_g / eval_grad_f / eval_jac_g
     calls pass; alternating iterates, so values left over from the previous x would show; a cached call with ANOTHER array is

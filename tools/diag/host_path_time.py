@@ -80,3 +80,13 @@ t0 = time.perf_counter()
 for _ in range(200):
     eng.eval_hess(x, 1.0, lam, out=hv)
 print("eval_hess host path: %.1f us" % (1e6 * (time.perf_counter() - t0) / 200))
+eng.register_outputs([hv])
+for _ in range(20):
+    eng.eval_hess(x, 1.0, lam, out=hv)
+t0 = time.perf_counter()
+for _ in range(200):
+    eng.eval_hess(x, 1.0, lam, out=hv)
+print("eval_hess host path, caller array registered: %.1f us" % (1e6 * (time.perf_counter() - t0) / 200))
+ref = eng.eval_hess(x, 1.0, lam)
+assert np.array_equal(ref, hv)
+eng.unregister_outputs([hv])
