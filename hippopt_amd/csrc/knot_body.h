@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "nlp_defs.h"
+#include "knot_tanh.h"
 
 // Lanes of ONE wavefront exchanging data through LDS (no other wave involved): the hardware executes a
 // wave's LDS operations in order, so only the compiler must be kept from moving accesses across this point.
@@ -299,7 +300,7 @@ HD D2 operator*(const D2& a, double c) { return D2(a.v * c, a.x * c, a.y * c); }
 HD D2 operator*(double c, const D2& a) { return D2(a.v * c, a.x * c, a.y * c); }
 HD D2 operator/(const D2& a, const D2& b) { const double q = a.v / b.v, i = 1.0 / b.v; return D2(q, (a.x - q * b.x) * i, (a.y - q * b.y) * i); }
 HD D2 d2sqrt(const D2& a) { const double r = sqrt(a.v), i = 0.5 / r; return D2(r, a.x * i, a.y * i); }
-HD D2 d2tanh(const D2& a) { const double t = tanh(a.v), d = 1.0 - t * t; return D2(t, a.x * d, a.y * d); }
+HD D2 d2tanh(const D2& a) { const double t = knot_tanh(a.v), d = 1.0 - t * t; return D2(t, a.x * d, a.y * d); }
 
 HD double ipow_d(double x, int n) { double r = 1.0, b = x; while (n > 0) { if (n & 1) r *= b; n >>= 1; if (n) b *= b; } return r; }
 
@@ -382,7 +383,7 @@ template <class Em> HD void t_points_vec(Ctx<Em>& cx, int t) {
     const bool planar = terrain_is_planar(cx);
     em.J(jb + js::PLANAR_V + i, row_id(RK_PLANAR, c, i), cb + V_ + i, 1.0);
     if (planar) {  // planar complementarity  v - R_t diag(tau,tau,1) u,  tau = tanh(kt h(p))   (E3; R_t = I, h = p_z)
-        const double tau = tanh(cx.gp.kt * pz);
+        const double tau = knot_tanh(cx.gp.kt * pz);
         const double mult = i < 2 ? tau : 1.0;
         em.G(gb + gs::PLANAR + i, row_id(RK_PLANAR, c, i), x[V_ + i] - mult * x[U_ + i]);
         em.J(jb + js::PLANAR_U + 3 * i + i, row_id(RK_PLANAR, c, i), cb + U_ + i, -mult);

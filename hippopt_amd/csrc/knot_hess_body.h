@@ -185,7 +185,7 @@ template <class Em> HD void t_kh_point(KHCtx<Em>& h, int c) {
     hdyn_multiplier(h, nu);
     if (planar) {   // (smooth terrain: t_kh_point_smooth emits the dense blocks that contain these)
         // planar complementarity  v_i - tanh(kt p_z) u_i  (E3)
-        const double kt = cx.gp.kt, tau = tanh(kt * x[P_ + 2]), dtau = kt * (1.0 - tau * tau);
+        const double kt = cx.gp.kt, tau = knot_tanh(kt * x[P_ + 2]), dtau = kt * (1.0 - tau * tau);
         for (int i = 0; i < 2; ++i) em.H(hb + hk::PL_U + i, cb + U_ + i, cb + P_ + 2, -lam[gb + gs::PLANAR + i] * dtau);
         // dcc margin  eps - kbs p_z f_z - (v_z f_z + p_z fdot_z)  (E4)
         const double l_d = lam[gb + gs::DCC];
@@ -264,7 +264,7 @@ template <class Em> HD void t_kh_pp(KHCtx<Em>& h, int t) {
         v += ends_diag(h, PT_ * hi + P_ + e);
         if (e == 2) {
             const double* x = s.x + PT_ * hi;
-            const double kt = cx.gp.kt, tau = tanh(kt * x[P_ + 2]), dtau = kt * (1.0 - tau * tau), ddtau = -2.0 * kt * tau * dtau;
+            const double kt = cx.gp.kt, tau = knot_tanh(kt * x[P_ + 2]), dtau = kt * (1.0 - tau * tau), ddtau = -2.0 * kt * tau * dtau;
             const double* lp = h.lam + gs::PT_STRIDE * hi + gs::PLANAR;
             v += sigma * on * cx.st.m_swing - (lp[0] * x[U_] + lp[1] * x[U_ + 1]) * ddtau;
         }
@@ -366,7 +366,7 @@ template <class Em> HD void t_kh_point_smooth_pp2(KHCtx<Em>& h, int c) {
         hT.v = st[30];
         for (int i = 0; i < 3; ++i) hT.g[i] = st[31 + i];
         for (int i = 0; i < 6; ++i) hT.H[i] = st[34 + i];
-        const double tv = tanh(kt * hT.v), t1 = kt * (1.0 - tv * tv), t2 = -2.0 * kt * tv * t1;
+        const double tv = knot_tanh(kt * hT.v), t1 = kt * (1.0 - tv * tv), t2 = -2.0 * kt * tv * t1;
         const T3 tau = t3_chain(hT, tv, t1, t2);
         const J2<3> q = n1 * n1 + n2 * n2;            // same closed form as terrain_frame (knot_body.h)
         const J2<3> iq = j2_pow(q, -0.5);
@@ -418,7 +418,7 @@ template <class Em> HD void t_kh_point_smooth_mixed(KHCtx<Em>& h, int c) {
         xv[0] = g3_from(q * iq); xv[1] = g3_from(-(m1 * m0) * iq); xv[2] = g3_from(-(m2 * m0) * iq);
         yv[0] = G3(0.0); yv[1] = g3_from(m2 * iq); yv[2] = g3_from(-(m1 * iq));
     }
-    const double tv = tanh(kt * hG.v), t1 = kt * (1.0 - tv * tv);
+    const double tv = knot_tanh(kt * hG.v), t1 = kt * (1.0 - tv * tv);
     G3 tau;
     tau.v = tv;
     for (int i = 0; i < 3; ++i) tau.g[i] = t1 * hG.g[i];

@@ -10,7 +10,7 @@ from hippopt_amd import _abi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = os.path.join(ROOT, "tests", "_build", "libhipnlp_hostemu.so")
 SRC = [os.path.join(ROOT, "tests", "hostemu", "hostemu.cpp")] + [
-    os.path.join(ROOT, "hippopt_amd", "csrc", f) for f in ("layout.h", "knot_body.h", "nlp_defs.h", "pose_body.h", "pose_hess_body.h", "pose_layout.h", "knot_hess_body.h", "knot_hess_layout.h", "knot_hess_terrain.h")]
+    os.path.join(ROOT, "hippopt_amd", "csrc", f) for f in ("layout.h", "knot_body.h", "nlp_defs.h", "pose_body.h", "pose_hess_body.h", "pose_layout.h", "knot_hess_body.h", "knot_hess_layout.h", "knot_hess_terrain.h", "knot_tanh.h")]
 
 
 def build():
