@@ -132,3 +132,57 @@ def test_refuses_what_the_format_cannot_hold(tmp_path):
     open(tmp_path / "n.mat", "wb").write(b"not a mat file")
     with pytest.raises(mat73.Mat73Error):
         mat73.loadmat(str(tmp_path / "n.mat"))
+
+
+def _random_tree(rng, depth=0):
+    kind = rng.randint(9 if depth < 3 else 6)
+    if kind == 0:
+        return float(rng.standard_normal())
+    if kind == 1:
+        shape = tuple(int(v) for v in rng.randint(0, 4, size=rng.randint(1, 4)))
+        return rng.standard_normal(shape)
+    if kind == 2:
+        return "".join(chr(int(c)) for c in rng.choice([65, 97, 0x00e9, 0x4e2d, 0x1f600, 32, 48], size=rng.randint(0, 6)))
+    if kind == 3:
+        return bool(rng.randint(2))
+    if kind == 4:
+        return rng.randint(-5, 5, size=(2, 3)).astype([np.int8, np.uint16, np.int32, np.int64, np.uint8][rng.randint(5)])
+    if kind == 5:
+        return None
+    if kind in (6, 7):
+        return {("k%d" % i if rng.randint(2) else "odd name[%d]" % i): _random_tree(rng, depth + 1) for i in range(rng.randint(0, 4))}
+    return [_random_tree(rng, depth + 1) for _ in range(rng.randint(0, 4))]
+
+
+def _same(a, b, path="/"):
+    """what loadmat (squeezing) must give back for what savemat was handed"""
+    if isinstance(a, dict):
+        assert isinstance(b, dict) and set(a) == set(b), path
+        for k in a:
+            _same(a[k], b[k], path + k + "/")
+    elif isinstance(a, list):
+        assert isinstance(b, list) and len(a) == len(b), (path, a, b)
+        for i, (u, v) in enumerate(zip(a, b)):
+            _same(u, v, "%s[%d]/" % (path, i))
+    elif isinstance(a, str):
+        assert b == a, (path, a, b)
+    elif a is None:
+        assert isinstance(b, np.ndarray) and b.size == 0, path
+    else:
+        x = np.asarray(a)
+        assert isinstance(b, np.ndarray), (path, type(b))
+        if x.size == 0:
+            assert b.size == 0, path
+        else:
+            assert b.dtype == (np.bool_ if x.dtype == np.bool_ else x.dtype if x.dtype.kind in "iu" else np.float64), (path, b.dtype, x.dtype)
+            assert np.array_equal(np.squeeze(x), b), path
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_nested_structures_round_trip(tmp_path, seed):
+    """seeded random trees of structs / cells / arrays of 0-3 dimensions (empty ones included) / integers / logicals / strings with
+    characters outside the BMP / unset leaves, through a file and back"""
+    rng = np.random.RandomState(100 + seed)
+    d = {"v%d" % i: _random_tree(rng) for i in range(5)}
+    f = mat73.savemat(str(tmp_path / ("r%d.mat" % seed)), d, compress=bool(seed % 2))
+    _same(d, mat73.loadmat(f))
