@@ -1482,7 +1482,7 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
     R(0, 0, t_columns, NJ + 3) R(1, 1, t_cmm_columns, NJ + 3) R(2, 2, t_frame_columns, NJ) R(3, 3, t_ends, ENDS_TASKS) R(3, -1, t_pkin, NC) \
     BARRIER                                                                               \
     R(0, 0, t_kinc, 3 * NC) R(1, 1, t_comc, 15) R(2, 2, t_cmmc, 15) R(2, 3, t_kinc_s, NC * LEG_PATH) \
-    R(3, 4, t_feetd, 5) R(3, 4, t_ends_finish, ENDS_FINISH_TASKS)                         \
+    R(3, 4, t_feetd, 5) R(3, 5, t_ends_finish, ENDS_FINISH_TASKS)                         \
     BARRIER
 
 }  // namespace hipnlp
