@@ -94,12 +94,12 @@ struct PoseLayout {
         add(RK_PBAL, 0, "centroidal_momentum_dynamics", 6);      // :487-509
         add(RK_JPB, 0, "joint_position_bounds", NJ);             // :511-519
         if (st.com_position_type == HIPNLP_EXPR_SUBJECT_TO) add(RK_PCOMERR, 0, "com_position_error", 1);   // :566-573
+        for (int h = 0; h < 2; ++h)                              // :596-660 (still inside _add_kinematics_regularization: BEFORE the feet)
+            if (st.hand_type[h] == HIPNLP_EXPR_SUBJECT_TO) add(RK_PHAND, h, h == 0 ? "left_hand_position_error" : "right_hand_position_error", 3);
         for (int c = 0; c < NC; ++c) {                           // :385-396, :752-759
             const int mode = c < 4 ? st.left_point_position_type : st.right_point_position_type;
             if (mode == HIPNLP_EXPR_SUBJECT_TO) add(RK_PPREG, c, point_name(c) + ".p_regularization", 1);
         }
-        for (int h = 0; h < 2; ++h)                              // :596-660
-            if (st.hand_type[h] == HIPNLP_EXPR_SUBJECT_TO) add(RK_PHAND, h, h == 0 ? "left_hand_position_error" : "right_hand_position_error", 3);
         const PoseHands hands = make_hands(st);
         // ---- record the native slots of the pose program ------------------------------------------------------
         std::vector<int> grow(gs::COUNT, -1), jrid(js::COUNT, -1), jc(js::COUNT, -1), hr(hs::COUNT, -1), hc(hs::COUNT, -1);

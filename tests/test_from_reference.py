@@ -100,6 +100,7 @@ def _pose_numeric(model):
     st.right_hand_position_in_frame = np.array([0.0, -0.02, 0.05])
     st.left_hand_expression_type, st.right_hand_expression_type = _abi.EXPR_SUBJECT_TO, _abi.EXPR_MINIMIZE
     st.left_hand_regularization_cost_multiplier, st.right_hand_regularization_cost_multiplier = 0.7, 3.0
+    st.right_point_position_expression_type = _abi.EXPR_SUBJECT_TO   # (rows BEHIND the hand rows: planner.py:385-399)
     st.com_position_expression_type = _abi.EXPR_SUBJECT_TO
     return st
 

@@ -324,6 +324,58 @@ def test_pose_engine_from_the_reference_objects_fixture(model):
     hess_check(ir, jc, eng.eval_hess(z["x"][None, :], np.array([0.9]), lam)[0], orc.hess(z["x"], z["p"], 0.9, lam[0]), TOL)
 
 
+def test_pose_random_configurations(model):
+    """A seeded sweep over what selects code paths of the pose finder — terrain, the expression modes of the com / point positions /
+    hands, hand frames on ANY link (leg links too: their paths overlap the contact points'), multipliers, batch — callback quartet and
+    exact Hessian entrywise against the oracle.  (HIPNLP_SWEEP_SEED / HIPNLP_SWEEP_CASES: longer one-off sweeps on a GPU box.)"""
+    import os
+    from hippopt_amd import _abi
+    from hippopt_amd.hipnlp import HipPose
+    from hippopt_amd.pose_settings import hand_frame, pose_finder_settings
+    from oracle_lib import PoseOracle
+    from test_pose_body_hostemu import flank_points, hess_check
+    rng = np.random.RandomState(int(os.environ.get("HIPNLP_SWEEP_SEED", "515")))
+    modes = (_abi.EXPR_SKIP, _abi.EXPR_SUBJECT_TO, _abi.EXPR_MINIMIZE)
+    for case in range(int(os.environ.get("HIPNLP_SWEEP_CASES", "6"))):
+        st = pose_finder_settings(model)
+        steps = bool(rng.randint(2))
+        if steps:
+            st.terrain = _abi.TERRAIN_SMOOTH_STEPS
+            st.terrain_steps = [{"length": 0.6, "width": 0.8, "height": 0.2, "position": (0.45, 0.0, 0.0)},
+                                {"length": 0.3, "width": 0.5, "height": 0.1, "position": (-0.2, 0.1, 0.02), "orientation": 0.6, "edge_sharpness": 3, "side_sharpness": 4}][:1 + rng.randint(2)]
+        st.com_position_expression_type = modes[rng.randint(3)]
+        st.left_point_position_expression_type = modes[rng.randint(3)]
+        st.right_point_position_expression_type = modes[rng.randint(3)]
+        st.left_hand_expression_type, st.right_hand_expression_type = modes[rng.randint(3)], modes[rng.randint(3)]
+        st.left_hand_frame = hand_frame(model, int(rng.randint(1, 24)), tuple(rng.uniform(-0.5, 0.5, 3)), tuple(rng.uniform(-0.1, 0.1, 3)))
+        st.right_hand_frame = hand_frame(model, int(rng.randint(1, 24)), tuple(rng.uniform(-0.5, 0.5, 3)), tuple(rng.uniform(-0.1, 0.1, 3)))
+        st.lef_hand_position_in_frame, st.right_hand_position_in_frame = rng.uniform(-0.05, 0.05, 3), rng.uniform(-0.05, 0.05, 3)
+        st.left_hand_regularization_cost_multiplier, st.right_hand_regularization_cost_multiplier = float(rng.uniform(0.1, 20.0)), float(rng.uniform(0.1, 20.0))
+        B = int(rng.choice([1, 2, 5]))
+        x, p = make_pose_workload(st, model, B, 1200 + case)
+        if steps:
+            flank_points(x[0], case)
+        eng, orc = HipPose(st, model, batch=B), PoseOracle(st, model)
+        assert (eng.n, eng.m, eng.nnz) == (orc.n, orc.m, orc.nnz), case
+        ir, jc = eng.sparsity()
+        iro, jco = orc.sparsity()
+        assert np.array_equal(ir, iro) and np.array_equal(jc, jco), case
+        eng.set_params(p)
+        f, grad, g, jac = eng.eval(x)
+        lam = rng.standard_normal((B, eng.m))
+        sig = rng.uniform(0.2, 2.0, B)
+        hr, hc = eng.hess_sparsity()
+        hv = eng.eval_hess(x, sig, lam)
+        tol = 1e-10 if steps else TOL
+        for b in range(B):
+            fo, grado, go, jaco = orc.eval(x[b], p[b])
+            assert rel(f[b], fo) < tol and rel(grad[b], grado) < tol and rel(g[b], go) < tol and rel(jac[b], jaco) < tol, (case, b)
+            hess_check(hr, hc, hv[b], orc.hess(x[b], p[b], float(sig[b]), lam[b]), tol)
+            lb, ub = orc.bounds(p[b])
+            lb2, ub2 = eng.bounds()
+            assert np.array_equal(lb, lb2[b]) and np.array_equal(ub, ub2[b]), case
+
+
 def test_pose_device_pointer_paths(model):
     """hipnlp_pose_eval_device / hipnlp_pose_eval_hess_device with torch device pointers equal the host-buffer paths bit for bit."""
     import torch
