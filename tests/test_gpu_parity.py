@@ -130,6 +130,14 @@ def test_random_configurations_both_kernel_variants(model, HipNlp):
                 fo, grado, go, jaco = refs[b]
                 assert rel(f[b], fo) < TOL and rel(grad[b], grado) < TOL and rel(g[b], go) < TOL and rel(jac[b], jaco) < TOL, (case, waves, sep, b)
             outs[(waves, sep)] = (f.copy(), grad.copy(), g.copy(), jac.copy())
+        # exact Hessian of the Lagrangian at the same points, random multipliers / objective factors (entrywise against the oracle)
+        from hess_util import hess_mismatch, triplets_to_dict
+        lam, sig = rng.standard_normal((B, orc.m)), rng.uniform(0.0, 2.0, B)
+        hr, hc = eng.hess_sparsity()
+        hv = eng.eval_hess(x, sig, lam)
+        for b in range(B):
+            err, where = hess_mismatch(triplets_to_dict(hr, hc, hv[b]), triplets_to_dict(*orc.hess(x[b], p[b], float(sig[b]), lam[b])))
+            assert err <= (1e-9 if stairs else TOL), (case, b, where)
         assert np.array_equal(outs[(4, 0)][0], outs[(4, 1)][0])     # the two reductions of one kernel: the same tree
         assert all(np.array_equal(a, b_) for a, b_ in zip(outs[(4, 0)][1:], outs[(4, 1)][1:]))
         for a, b_ in zip(outs[(4, 0)], outs[(8, 0)]):
