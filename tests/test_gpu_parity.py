@@ -675,6 +675,48 @@ def test_evaluation_that_stores_into_every_ranks_buffer(model, HipNlp, terrain, 
             b.fill_(float("nan"))
 
 
+def test_peer_mode_random_shardings(model, HipNlp):
+    """hipnlp_eval_device_peers over a seeded sweep: horizon, 2-5 "ranks" (shard handles of one process) with random cut points — shards of
+    one knot, the first and the last knot alone or together with interior ones —, both terrains, both kernel variants, the three
+    modes of the horizon-end expressions: every rank's buffer bitwise the unsharded callback's grad / jac / g, the shard costs
+    summing to f."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(int(os.environ.get("HIPNLP_SWEEP_SEED", "77")))
+    modes = (_abi.EXPR_SKIP, _abi.EXPR_SUBJECT_TO, _abi.EXPR_MINIMIZE)
+    stream = torch.cuda.Stream()
+    for case in range(int(os.environ.get("HIPNLP_SWEEP_CASES", "6"))):
+        stairs = bool(rng.randint(2))
+        N = int(rng.choice([2, 3, 5, 8, 13]))
+        world = int(rng.randint(2, min(N, 5) + 1))
+        cuts = [0] + sorted(rng.choice(np.arange(1, N), size=world - 1, replace=False).tolist()) + [N]
+        st = (stairs_settings if stairs else periodic_step_settings)(N, model)
+        st.final_state_expression_type, st.periodicity_expression_type = modes[rng.randint(3)], modes[rng.randint(3)]
+        x, p = make_workload(st, model, batch=1, seed=600 + case)
+        os.environ["HIPNLP_WAVES"] = str(int(rng.choice([4, 8])))
+        try:
+            full = HipNlp(st, model)
+            shards = [HipNlp(st, model, knot_begin=cuts[r], knot_end=cuts[r + 1]) for r in range(world)]
+        finally:
+            del os.environ["HIPNLP_WAVES"]
+        for e in [full] + shards:
+            e.set_params(p)
+        n, m, nnz = full.n, full.m, full.nnz
+        tot = n + nnz + m
+        bufs = [torch.full((tot + world + 1,), float("nan"), dtype=torch.float64, device=dev) for _ in range(world)]
+        table = torch.tensor([b.data_ptr() for b in bufs], dtype=torch.int64, device=dev)
+        xd = torch.from_numpy(x[0]).to(dev)
+        with torch.cuda.stream(stream):
+            for r, e in enumerate(shards):
+                e.eval_device_peers(xd.data_ptr(), table.data_ptr(), world, r, stream=stream.cuda_stream)
+        stream.synchronize()
+        f, grad, g, jac = full.eval(x)
+        for b in bufs:
+            o = b.cpu().numpy()
+            assert np.array_equal(o[:n], grad[0]) and np.array_equal(o[n:n + nnz], jac[0]) and np.array_equal(o[n + nnz:tot], g[0]), (case, cuts)
+            assert np.isfinite(o[tot:tot + world]).all() and abs(o[tot:tot + world].sum() - f[0]) <= 1e-12 * max(1.0, abs(f[0])), (case, cuts)
+
+
 def test_two_ranks_on_one_gpu_rehearsal():
     """`bench.py --gpus 2` as the driver starts it, with both ranks on device 0 and gloo as the rendezvous (BENCH_REHEARSAL=1: RCCL
     refuses two ranks on one device).  Not a measurement: it runs the N > 1 code paths across two PROCESSES — self-spawned ranks,
