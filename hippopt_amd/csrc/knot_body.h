@@ -1470,7 +1470,7 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
     R(0, 0, t_fk_rot_a, FK_TASKS_A) R(0, 0, t_link_u_a, FK_SPLIT)                         \
     R(3, 1, t_fk_rot_b, FK_TASKS_B) R(3, 1, t_link_u_b, NJ - FK_SPLIT)                    \
     R(1, 2, t_hdyn_entries, 48) R(HIPNLP_W4(1, 3), 3, t_hdyn_rows, HDYN_TASKS - 48)                     \
-    R(2, 7, t_terrain_hnf, NC) R(2, HIPNLP_W8(6, 4), t_terrain_swing, NC) R(2, HIPNLP_W8(6, 2), t_points_cost, 3) \
+    R(2, 7, t_terrain_hnf, NC) R(2, HIPNLP_W8(6, 4), t_terrain_swing, NC) R(2, HIPNLP_W8(6, 4), t_points_cost, 3) \
     R(2, HIPNLP_W8(6, 4), t_foot_costs, FOOT_TASKS) R(2, HIPNLP_W8(6, 4), t_foot_cost_sum, 2) \
     R(1, 5, t_terrain_planar, NC) R(HIPNLP_W4(0, 1), 6, t_terrain_dcc, NC) R(-1, 7, t_joint_cost, 1)    \
     BARRIER                                                                               \
