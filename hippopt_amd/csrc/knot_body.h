@@ -1458,6 +1458,9 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
 // HIPNLP_W4(p, s) / HIPNLP_W8(p, s): wave of the four- / eight-wave workgroup on the planar / on the smooth terrain (defined where the device expands the
 // program; host expansions ignore the wave ids).  The eight waves sit two per SIMD (w and w + 4): a phase's longest task wants a
 // partner with little to issue — on the planar terrain the terrain tasks are empty, so the pairing differs between the two.
+// Same-wave chains of the second phase (do not separate): t_terrain_swing -> t_points_cost (sums the per-point costs the swing task wrote)
+// -> t_foot_costs (adds to the swing gradient) -> t_foot_cost_sum.  (The host expansions run the groups in table order and cannot see a
+// group moved to another wave of the same phase: only the GPU parity tests do — test_smooth_terrain_matches_oracle caught exactly that.)
 // A group listed twice with wave -1 in one of the places (t_joint_cost, t_pkin) runs in a different PHASE in the two kernel variants; such
 // groups only write scratch (no emitter calls), so the host expansions, which run both, compute the same thing twice.
 // ---------------------------------------------------------------------------------------------------
