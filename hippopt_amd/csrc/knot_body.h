@@ -1458,9 +1458,12 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
 // HIPNLP_W4(p, s) / HIPNLP_W8(p, s): wave of the four- / eight-wave workgroup on the planar / on the smooth terrain (defined where the device expands the
 // program; host expansions ignore the wave ids).  The eight waves sit two per SIMD (w and w + 4): a phase's longest task wants a
 // partner with little to issue — on the planar terrain the terrain tasks are empty, so the pairing differs between the two.
+// Same-wave chain of the last phase (do not separate): t_feetd -> t_ends_finish (both add into grad q_b: on two waves the two
+// read-modify-writes of one scratch entry would race — tried for +0.3 %, caught by the wave-order test below, undone).
 // Same-wave chains of the second phase (do not separate): t_terrain_swing -> t_points_cost (sums the per-point costs the swing task wrote)
 // -> t_foot_costs (adds to the swing gradient) -> t_foot_cost_sum.  (The host expansions run the groups in table order and cannot see a
-// group moved to another wave of the same phase: only the GPU parity tests do — test_smooth_terrain_matches_oracle caught exactly that.)
+// group moved to another wave of the same phase: tests/test_kernel_body_hostemu.py runs every phase wave by wave in permuted wave orders
+// for that, and the GPU parity tests — test_smooth_terrain_matches_oracle caught one such move.)
 // A group listed twice with wave -1 in one of the places (t_joint_cost, t_pkin) runs in a different PHASE in the two kernel variants; such
 // groups only write scratch (no emitter calls), so the host expansions, which run both, compute the same thing twice.
 // ---------------------------------------------------------------------------------------------------
@@ -1485,7 +1488,7 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
     R(0, 0, t_columns, NJ + 3) R(1, 1, t_cmm_columns, NJ + 3) R(2, 2, t_frame_columns, NJ) R(3, 3, t_ends, ENDS_TASKS) R(3, -1, t_pkin, NC) \
     BARRIER                                                                               \
     R(0, 0, t_kinc, 3 * NC) R(1, 1, t_comc, 15) R(2, 2, t_cmmc, 15) R(2, 3, t_kinc_s, NC * LEG_PATH) \
-    R(3, 4, t_feetd, 5) R(3, 5, t_ends_finish, ENDS_FINISH_TASKS)                         \
+    R(3, 4, t_feetd, 5) R(3, 4, t_ends_finish, ENDS_FINISH_TASKS)                         \
     BARRIER
 
 }  // namespace hipnlp

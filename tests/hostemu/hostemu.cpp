@@ -5,6 +5,7 @@
 // It is NOT part of the product: libhipnlp.so does not contain it and hipnlp_eval never falls back to it.
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "../../hippopt_amd/csrc/knot_hess_layout.h"
@@ -86,7 +87,23 @@ template <int LAYOUT> static int eval_compact(const hostemu_handle* h, const dou
     return 0;
 }
 
+// wave-order emulation (tests only): the groups of a phase collected in table order, run wave by wave in a permuted order of the waves
+struct WaveOrder {
+    int waves, order;
+    std::vector<std::pair<int, std::function<void()>>> groups;
+    void add(int w, std::function<void()> fn) { if (w >= 0) groups.push_back({w, std::move(fn)}); }
+    void flush() {
+        for (int q = 0; q < waves; ++q) {
+            const int w = order == 0 ? q : (order == 1 ? waves - 1 - q : (q + waves / 2) % waves);
+            for (auto& gq : groups) if (gq.first == w) gq.second();
+        }
+        groups.clear();
+    }
+};
+static int g_wave_order = -1;   // >= 0: the pose / Hessian emulations below run their programs through WaveOrder (hostemu_set_wave_order)
+
 extern "C" {
+void hostemu_set_wave_order(int order) { g_wave_order = order; }
 
 hostemu_handle* hostemu_create(const hipnlp_desc* desc, char* err, int errlen) {
     hostemu_handle* h = new hostemu_handle();
@@ -138,9 +155,23 @@ void hostemu_hess(const hostemu_handle* h, const double* x, const double* p, dou
         // multipliers by native slot, in the g staging area of the scratch (the Hessian program emits no g)
         for (int slot = 0; slot < gs::COUNT; ++slot) { const int a = L.g_a[v][size_t(slot)]; s->g[slot] = a >= 0 ? lambda[a + L.g_b[size_t(slot)] * k] : 0.0; }
         KHCtx<ValueEm> hcx{cx, *hx, s->g};
+        if (g_wave_order < 0) {
 #define HOST_KIN(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
 #define HOST_RH(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(hcx, t_);
-        HIPNLP_KNOT_HESS_PROGRAM(HOST_KIN, HOST_RH, )
+            HIPNLP_KNOT_HESS_PROGRAM(HOST_KIN, HOST_RH, )
+#undef HOST_KIN
+#undef HOST_RH
+        } else {   // every phase wave by wave in a permuted order of the four waves
+            WaveOrder wo{4, g_wave_order, {}};
+#define HOST_KIN(w, fn, nt) wo.add((w), [&cx]() { for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_); });
+#define HOST_RH(w, fn, nt) wo.add((w), [&hcx]() { for (int t_ = 0; t_ < (nt); ++t_) fn(hcx, t_); });
+#define HOST_BARRIER wo.flush();
+            HIPNLP_KNOT_HESS_PROGRAM(HOST_KIN, HOST_RH, HOST_BARRIER)
+#undef HOST_KIN
+#undef HOST_RH
+#undef HOST_BARRIER
+            wo.flush();
+        }
 #undef HOST_KIN
 #undef HOST_RH
         for (int i = 0; i < HL.nnz_knot; ++i) hess[HL.knot_base(k) + i] = hx->H[HL.perm[size_t(i)]];
@@ -210,6 +241,69 @@ void hostemu_eval(const hostemu_handle* h, const double* x, const double* p, dou
     *f = ft;
 }
 
+// The knot program with the task groups of every phase run WAVE BY WAVE in a chosen order of the waves (order 0: ascending, 1: descending,
+// 2: rotated by waves / 2), the groups of one wave in table order — what the device guarantees and nothing more.  Groups on different
+// waves of one phase must not depend on each other (they run concurrently on the GPU): any order must give the values of the plain
+// table-order run, bit for bit.  waves = 4 / 8 picks the column of the program table; the terrain picks HIPNLP_W4 / W8's alternative.
+int hostemu_eval_wave_order(const hostemu_handle* h, const double* x, const double* p, int waves, int order, double* f, double* grad, double* g,
+                            double* jac, double* cost_terms) {
+    if ((waves != 4 && waves != 8) || order < 0 || order > 2) return -1;
+    const Layout& L = h->L;
+    const int N = L.N;
+    const bool planar_rt = h->ks.terrain == HIPNLP_TERRAIN_PLANAR;
+    std::vector<double> pk(size_t(N) * PK_STRIDE);
+    GParams gp;
+    pack_params(p, N, pk.data(), gp);
+    for (int i = 0; i < NCT; ++i) cost_terms[i] = 0.0;
+    for (int i = 0; i < L.n; ++i) grad[i] = 0.0;
+    KnotScratch* s = new KnotScratch();
+    for (int k = 0; k < N; ++k) {
+        std::fill(reinterpret_cast<double*>(s), reinterpret_cast<double*>(s) + sizeof(KnotScratch) / sizeof(double), std::nan(""));
+        for (int i = 0; i < XPAD; ++i) { s->x[i] = 0; s->xm[i] = 0; }
+        for (int i = 0; i < NPER; ++i) s->xo[i] = 0;
+        for (int i = 0; i < NXK; ++i) { s->x[i] = x[NXK * k + i]; s->xm[i] = k > 0 ? x[NXK * (k - 1) + i] : 0.0; }
+        for (int i = 0; i < NPER; ++i) s->xo[i] = k == 0 ? x[NXK * (N - 1) + periodicity_row_var(i)] : (k == N - 1 ? x[periodicity_row_var(i)] : 0.0);
+        for (int i = 0; i < NXG; ++i) s->xg[i] = x[NXK * N + i];
+        for (int i = 0; i < PK_STRIDE; ++i) s->pk[i] = pk[size_t(k) * PK_STRIDE + i];
+        KnotInfo ki{k, N, k == 0, k == N - 1};
+        ValueEm em{s->g, s->jac};
+        Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
+        std::vector<std::pair<int, std::function<void()>>> groups;   // (wave, group) of the current phase, in table order
+        auto flush = [&]() {
+            for (int q = 0; q < waves; ++q) {
+                const int w = order == 0 ? q : (order == 1 ? waves - 1 - q : (q + waves / 2) % waves);
+                for (auto& gq : groups) if (gq.first == w) gq.second();
+            }
+            groups.clear();
+        };
+#define HIPNLP_W4(a, b) (planar_rt ? (a) : (b))
+#define HIPNLP_W8(a, b) (planar_rt ? (a) : (b))
+#define HOST_R(w4, w8, fn, nt) { const int w_ = waves == 4 ? (w4) : (w8); if (w_ >= 0) groups.push_back({w_, [&cx]() { for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_); }}); }
+#define HOST_BARRIER flush();
+        HIPNLP_KNOT_PROGRAM(HOST_R, HOST_BARRIER)
+#undef HOST_R
+#undef HOST_BARRIER
+#undef HIPNLP_W4
+#undef HIPNLP_W8
+        flush();
+        const int v = L.variant_of(k);
+        const long jb = L.jac_base(k);
+        for (int i = 0; i < L.nnz_v[v]; ++i) jac[jb + i] = s->jac[L.jperm[v][size_t(i)]];
+        if (k == N - 1) for (size_t i = 0; i < L.jperm_glob.size(); ++i) jac[L.jac_glob_base + long(i)] = s->jac[L.jperm_glob[i]];
+        for (int slot = 0; slot < gs::COUNT; ++slot) {
+            const int a = L.g_a[v][size_t(slot)];
+            if (a >= 0) g[a + L.g_b[size_t(slot)] * k] = s->g[slot];
+        }
+        for (int i = 0; i < NXK; ++i) grad[NXK * k + i] = s->grad[i];
+        for (int i = 0; i < NCT; ++i) cost_terms[i] += s->cost[i];
+    }
+    delete s;
+    double ft = 0.0;
+    for (int i = 0; i < NCT; ++i) ft += cost_terms[i];
+    *f = ft;
+    return 0;
+}
+
 int hostemu_eval_compact(const hostemu_handle* h, const double* x, const double* p, double* f, double* grad, double* g, double* jac, double* cost_terms) {
     return eval_compact<LAYOUT_COMPACT>(h, x, p, f, grad, g, jac, cost_terms);
 }
@@ -264,9 +358,19 @@ void hostemu_pose_eval(const hostemu_pose_handle* h, const double* x, const doub
     ValueEm em{s->g, s->jac};
     Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
     cx.hands = &h->hands;
+    if (g_wave_order < 0) {
 #define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
-    HIPNLP_POSE_PROGRAM(HOST_R, )
+        HIPNLP_POSE_PROGRAM(HOST_R, )
 #undef HOST_R
+    } else {   // every phase wave by wave in a permuted order of the four waves (see hostemu_eval_wave_order)
+        WaveOrder wo{4, g_wave_order, {}};
+#define HOST_R(w4, w8, fn, nt) wo.add((w4), [&cx]() { for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_); });
+#define HOST_BARRIER wo.flush();
+        HIPNLP_POSE_PROGRAM(HOST_R, HOST_BARRIER)
+#undef HOST_R
+#undef HOST_BARRIER
+        wo.flush();
+    }
     for (int e = 0; e < L.nnz; ++e) jac[e] = s->jac[L.jperm[size_t(e)]];
     for (int slot = 0; slot < gs::COUNT; ++slot) if (L.g_row[size_t(slot)] >= 0) g[L.g_row[size_t(slot)]] = s->g[slot];
     for (int i = 0; i < POSE_NX; ++i) grad[i] = s->grad[pose_to_knot_col(i)];
@@ -301,11 +405,23 @@ void hostemu_pose_hess(const hostemu_pose_handle* h, const double* x, const doub
     Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
     cx.hands = &h->hands;
     HCtx<ValueEm> hcx{cx, *hx};
+    if (g_wave_order < 0) {
 #define HOST_KIN(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
 #define HOST_RH(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(hcx, t_);
-    HIPNLP_POSE_HESS_PROGRAM(HOST_KIN, HOST_RH, )
+        HIPNLP_POSE_HESS_PROGRAM(HOST_KIN, HOST_RH, )
 #undef HOST_KIN
 #undef HOST_RH
+    } else {
+        WaveOrder wo{4, g_wave_order, {}};
+#define HOST_KIN(w, fn, nt) wo.add((w), [&cx]() { for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_); });
+#define HOST_RH(w, fn, nt) wo.add((w), [&hcx]() { for (int t_ = 0; t_ < (nt); ++t_) fn(hcx, t_); });
+#define HOST_BARRIER wo.flush();
+        HIPNLP_POSE_HESS_PROGRAM(HOST_KIN, HOST_RH, HOST_BARRIER)
+#undef HOST_KIN
+#undef HOST_RH
+#undef HOST_BARRIER
+        wo.flush();
+    }
     for (int e = 0; e < L.hnnz; ++e) hess[e] = hx->H[L.hperm[size_t(e)]];
     delete hx;
     delete s;

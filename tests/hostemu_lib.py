@@ -75,6 +75,26 @@ class HostEmu:
         return f.value, grad, g, jac, ct
 
 
+def _eval_wave_order(self, x, p, waves, order):
+    """the knot program with every phase's groups run wave by wave in a permuted wave order (hostemu_eval_wave_order)"""
+    f = C.c_double()
+    grad, g, jac, ct = np.zeros(self.n), np.full(self.m, np.nan), np.full(self.nnz, np.nan), np.zeros(_abi.NCOST_TERMS)
+    rc = self.lib.hostemu_eval_wave_order(C.c_void_p(self.h), _dp(np.ascontiguousarray(x)), _dp(np.ascontiguousarray(p)), int(waves), int(order),
+                                          C.byref(f), _dp(grad), _dp(g), _dp(jac), _dp(ct))
+    if rc != 0:
+        raise RuntimeError("hostemu_eval_wave_order failed")
+    return f.value, grad, g, jac, ct
+
+
+HostEmu.eval_wave_order = _eval_wave_order
+
+
+def set_wave_order(order):
+    """order >= 0: the pose program and the two Hessian programs run every phase wave by wave in that order of the four waves
+    (0 ascending, 1 descending, 2 rotated by two); -1: plain table order"""
+    C.CDLL(build()).hostemu_set_wave_order(int(order))   # (the same library object every CDLL of this path shares)
+
+
 def _hostemu_hess_methods():
     def hess_sparsity(self):
         self.lib.hostemu_hess_nnz.restype = C.c_long

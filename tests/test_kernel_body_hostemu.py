@@ -307,3 +307,50 @@ def test_compact_scratch_layout_gives_the_same_values(model, mode):
         assert np.array_equal(np.asarray(a), np.asarray(b))
     fo, grado, go, jaco = Oracle(st, model).eval(x[0], p[0])
     assert rel(np.array(comp[0]), np.array(fo)) < TOL and rel(comp[2], go) < TOL and rel(comp[3], jaco) < TOL and rel(comp[1], grado) < TOL
+
+
+@pytest.mark.parametrize("terrain", ["planar", "stairs"])
+@pytest.mark.parametrize("waves", [4, 8])
+def test_groups_of_one_phase_on_different_waves_do_not_depend_on_each_other(model, terrain, waves):
+    """On the GPU the task groups of one phase run concurrently on different waves; only the groups of ONE wave are ordered (table order).
+    The host expansions run everything in table order and cannot see a dependency between two waves of a phase (a task group moved to
+    another wave of its phase once passed every CPU test and failed on the GPU).  Here every phase's groups run wave by wave in three
+    different orders of the waves — for both columns of the program table, both terrains, all variants of the horizon ends: the results
+    must be the table-order results, bit for bit (also catches two waves adding into one scratch entry: the order would show in the
+    last bits)."""
+    from hippopt_amd.kinodyn_settings import stairs_settings
+    from hippopt_amd.synthetic import place_on_step_flanks
+    N = 4
+    st = (stairs_settings if terrain == "stairs" else periodic_step_settings)(N, model)
+    st.final_state_expression_type = st.periodicity_expression_type = _abi.EXPR_MINIMIZE
+    x, p = make_workload(st, model, batch=1, seed=321)
+    if terrain == "stairs":
+        place_on_step_flanks(x, st, seed=2)
+    e = HostEmu(st, model)
+    ref = e.eval(x[0], p[0])
+    for order in (0, 1, 2):
+        got = e.eval_wave_order(x[0], p[0], waves, order)
+        assert got[0] == ref[0], (order, got[0], ref[0])
+        for a, b, name in zip(got[1:], ref[1:], ("grad", "g", "jac", "cost terms")):
+            assert np.array_equal(a, b), (order, name, int(np.argmax(a != b)))
+
+
+@pytest.mark.parametrize("terrain", ["planar", "stairs"])
+def test_hessian_program_phases_are_wave_order_independent(model, terrain):
+    """the same check for the Hessian program of the knot (four waves): every phase wave by wave in three orders of the waves"""
+    import hostemu_lib
+    st = (stairs_settings if terrain == "stairs" else periodic_step_settings)(3, model)
+    st.final_state_expression_type = st.periodicity_expression_type = _abi.EXPR_MINIMIZE
+    x, p = make_workload(st, model, batch=1, seed=322)
+    if terrain == "stairs":
+        place_on_step_flanks(x, st, seed=3)
+    e = HostEmu(st, model)
+    lam = np.random.RandomState(6).standard_normal(e.m)
+    ref = e.hess(x[0], p[0], 0.8, lam)
+    try:
+        for order in (0, 1, 2):
+            hostemu_lib.set_wave_order(order)
+            got = e.hess(x[0], p[0], 0.8, lam)
+            assert np.array_equal(got, ref), (order, int(np.argmax(got != ref)))
+    finally:
+        hostemu_lib.set_wave_order(-1)

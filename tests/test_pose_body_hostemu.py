@@ -147,3 +147,28 @@ def test_pose_hessian_body_matches_reference_fixture(model, name):
     ir, jc = e.hess_sparsity()
     vals = e.hess(z["x"], z["p"], float(z["hess_sigma"]), z["hess_lambda"])
     hess_check(ir, jc, vals, z["hess"], 1e-10)
+
+
+@pytest.mark.parametrize("name", VARIANTS)
+def test_pose_program_phases_are_wave_order_independent(model, name):
+    """Groups of one phase on different waves run concurrently on the GPU: the pose program and its Hessian program, every phase wave by
+    wave in three orders of the four waves (in-wave table order kept), must give the table-order values bit for bit (cross-wave
+    dependencies inside a phase, two waves adding into one scratch entry)."""
+    import hostemu_lib
+    st = variants(model)[name]
+    e = PoseHostEmu(st, model)
+    x, p = make_pose_workload(st, model, 1, 1500)
+    if name.endswith("steps"):
+        flank_points(x[0], 4)
+    lam = np.random.RandomState(7).standard_normal(e.m)
+    ref, href = e.eval(x[0], p[0]), e.hess(x[0], p[0], 1.1, lam)
+    try:
+        for order in (0, 1, 2):
+            hostemu_lib.set_wave_order(order)
+            got, hgot = e.eval(x[0], p[0]), e.hess(x[0], p[0], 1.1, lam)
+            assert got[0] == ref[0]
+            for a, b, what in zip(got[1:], ref[1:], ("grad", "g", "jac", "cost terms")):
+                assert np.array_equal(a, b), (order, what, int(np.argmax(a != b)))
+            assert np.array_equal(hgot, href), (order, int(np.argmax(hgot != href)))
+    finally:
+        hostemu_lib.set_wave_order(-1)
