@@ -44,6 +44,21 @@ struct hostemu_handle {
     bool has_hess = false;
 };
 
+// wave-order emulation (tests only): the groups of a phase collected in table order, run wave by wave in a permuted order of the waves
+struct WaveOrder {
+    int waves, order;
+    std::vector<std::pair<int, std::function<void()>>> groups;
+    void add(int w, std::function<void()> fn) { if (w >= 0) groups.push_back({w, std::move(fn)}); }
+    void flush() {
+        for (int q = 0; q < waves; ++q) {
+            const int w = order == 0 ? q : (order == 1 ? waves - 1 - q : (q + waves / 2) % waves);
+            for (auto& gq : groups) if (gq.first == w) gq.second();
+        }
+        groups.clear();
+    }
+};
+static int g_wave_order = -1;   // >= 0: the pose / Hessian emulations below run their programs through WaveOrder (hostemu_set_wave_order)
+
 // the same evaluation on the compact scratch layout of the device's four-wave kernels
 template <int LAYOUT> static int eval_compact(const hostemu_handle* h, const double* x, const double* p, double* f, double* grad, double* g, double* jac, double* cost_terms) {
     const Layout& L = h->L;
@@ -66,9 +81,24 @@ template <int LAYOUT> static int eval_compact(const hostemu_handle* h, const dou
         KnotInfo ki{k, N, k == 0, k == N - 1};
         ValueEmC<LAYOUT> em{s->g, s->jac};
         Ctx<ValueEmC<LAYOUT>> cx(*s, static_cast<const KinLite&>(h->kt), h->ks, static_cast<const GParamsLite&>(gp), ki, em, &h->kt, &gp);
+        if (g_wave_order < 0) {
 #define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
-        HIPNLP_KNOT_PROGRAM(HOST_R, )
+            HIPNLP_KNOT_PROGRAM(HOST_R, )
 #undef HOST_R
+        } else {   // the four-wave column of the table, every phase wave by wave in a permuted order (arrays that share storage in this layout!)
+            const bool planar_rt = h->ks.terrain == HIPNLP_TERRAIN_PLANAR;
+            WaveOrder wo{4, g_wave_order, {}};
+#define HIPNLP_W4(a, b) (planar_rt ? (a) : (b))
+#define HIPNLP_W8(a, b) (planar_rt ? (a) : (b))
+#define HOST_R(w4, w8, fn, nt) wo.add((w4), [&cx]() { for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_); });
+#define HOST_BARRIER wo.flush();
+            HIPNLP_KNOT_PROGRAM(HOST_R, HOST_BARRIER)
+#undef HOST_R
+#undef HOST_BARRIER
+#undef HIPNLP_W4
+#undef HIPNLP_W8
+            wo.flush();
+        }
         const int v = L.variant_of(k);
         const long jb = L.jac_base(k);
         for (int i = 0; i < L.nnz_v[v]; ++i) jac[jb + i] = s->jac[L.jperm[v][size_t(i)]];
@@ -86,21 +116,6 @@ template <int LAYOUT> static int eval_compact(const hostemu_handle* h, const dou
     *f = ft;
     return 0;
 }
-
-// wave-order emulation (tests only): the groups of a phase collected in table order, run wave by wave in a permuted order of the waves
-struct WaveOrder {
-    int waves, order;
-    std::vector<std::pair<int, std::function<void()>>> groups;
-    void add(int w, std::function<void()> fn) { if (w >= 0) groups.push_back({w, std::move(fn)}); }
-    void flush() {
-        for (int q = 0; q < waves; ++q) {
-            const int w = order == 0 ? q : (order == 1 ? waves - 1 - q : (q + waves / 2) % waves);
-            for (auto& gq : groups) if (gq.first == w) gq.second();
-        }
-        groups.clear();
-    }
-};
-static int g_wave_order = -1;   // >= 0: the pose / Hessian emulations below run their programs through WaveOrder (hostemu_set_wave_order)
 
 extern "C" {
 void hostemu_set_wave_order(int order) { g_wave_order = order; }

@@ -354,3 +354,26 @@ def test_hessian_program_phases_are_wave_order_independent(model, terrain):
             assert np.array_equal(got, ref), (order, int(np.argmax(got != ref)))
     finally:
         hostemu_lib.set_wave_order(-1)
+
+
+@pytest.mark.parametrize("terrain", ["planar", "stairs"])
+def test_compact_layout_phases_are_wave_order_independent(model, terrain):
+    """the four-wave column on the COMPACT scratch (arrays with disjoint lifetimes share storage): two waves of one phase touching
+    storage that is shared in this layout would show as an order dependence"""
+    import hostemu_lib
+    st = (stairs_settings if terrain == "stairs" else periodic_step_settings)(4, model)
+    st.final_state_expression_type = st.periodicity_expression_type = _abi.EXPR_SUBJECT_TO
+    x, p = make_workload(st, model, batch=1, seed=323)
+    if terrain == "stairs":
+        place_on_step_flanks(x, st, seed=4)
+    e = HostEmu(st, model)
+    ref = e.eval(x[0], p[0], compact=True)
+    try:
+        for order in (0, 1, 2):
+            hostemu_lib.set_wave_order(order)
+            got = e.eval(x[0], p[0], compact=True)
+            assert got[0] == ref[0]
+            for a, b, what in zip(got[1:], ref[1:], ("grad", "g", "jac", "cost terms")):
+                assert np.array_equal(a, b), (order, what, int(np.argmax(a != b)))
+    finally:
+        hostemu_lib.set_wave_order(-1)
