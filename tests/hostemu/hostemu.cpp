@@ -23,6 +23,17 @@ struct ValueEm {
     void H(int slot, int, int, double v) { hess[slot] = v; }
 };
 
+// an emitter with the compile-time traits of a device instantiation (hipnlp_knot_kernel<TERRAIN, WAVES>): task groups whose placement
+// depends on them (hdyn_entries_early, knot_body.h) then run where the device runs them — used by the wave-order emulation
+template <int WAVES, int TERRAIN> struct ValueEmV {
+    static constexpr int kTerrain = TERRAIN;
+    static constexpr int kWaves = WAVES;
+    double* g;
+    double* jac;
+    void G(int slot, int, double v) { g[slot] = v; }
+    void J(int slot, int, int, double v) { jac[slot] = v; }
+};
+
 // the COMPACT device layout of the planar callback kernel (KnotScratchT<LAYOUT_COMPACT>: shared storage for arrays with disjoint lifetimes,
 // joint frames / link inertials parked in comp[], horizon-end g rows in ends.c): emulated phase by phase in program order, so a
 // lifetime overlap shows up as a wrong value here, without a GPU
@@ -116,6 +127,66 @@ template <int LAYOUT> static int eval_compact(const hostemu_handle* h, const dou
     *f = ft;
     return 0;
 }
+
+template <int WAVES, int TERRAIN> static int eval_wave_order_t(const hostemu_handle* h, const double* x, const double* p, int order, double* f, double* grad, double* g,
+                                                               double* jac, double* cost_terms) {
+    constexpr int waves = WAVES;
+    const Layout& L = h->L;
+    const int N = L.N;
+    constexpr bool planar_rt = TERRAIN == HIPNLP_TERRAIN_PLANAR;
+    std::vector<double> pk(size_t(N) * PK_STRIDE);
+    GParams gp;
+    pack_params(p, N, pk.data(), gp);
+    for (int i = 0; i < NCT; ++i) cost_terms[i] = 0.0;
+    for (int i = 0; i < L.n; ++i) grad[i] = 0.0;
+    KnotScratch* s = new KnotScratch();
+    for (int k = 0; k < N; ++k) {
+        std::fill(reinterpret_cast<double*>(s), reinterpret_cast<double*>(s) + sizeof(KnotScratch) / sizeof(double), std::nan(""));
+        for (int i = 0; i < XPAD; ++i) { s->x[i] = 0; s->xm[i] = 0; }
+        for (int i = 0; i < NPER; ++i) s->xo[i] = 0;
+        for (int i = 0; i < NXK; ++i) { s->x[i] = x[NXK * k + i]; s->xm[i] = k > 0 ? x[NXK * (k - 1) + i] : 0.0; }
+        for (int i = 0; i < NPER; ++i) s->xo[i] = k == 0 ? x[NXK * (N - 1) + periodicity_row_var(i)] : (k == N - 1 ? x[periodicity_row_var(i)] : 0.0);
+        for (int i = 0; i < NXG; ++i) s->xg[i] = x[NXK * N + i];
+        for (int i = 0; i < PK_STRIDE; ++i) s->pk[i] = pk[size_t(k) * PK_STRIDE + i];
+        KnotInfo ki{k, N, k == 0, k == N - 1};
+        ValueEmV<WAVES, TERRAIN> em{s->g, s->jac};
+        Ctx<ValueEmV<WAVES, TERRAIN>> cx(*s, h->kt, h->ks, gp, ki, em);
+        std::vector<std::pair<int, std::function<void()>>> groups;   // (wave, group) of the current phase, in table order
+        auto flush = [&]() {
+            for (int q = 0; q < waves; ++q) {
+                const int w = order == 0 ? q : (order == 1 ? waves - 1 - q : (q + waves / 2) % waves);
+                for (auto& gq : groups) if (gq.first == w) gq.second();
+            }
+            groups.clear();
+        };
+#define HIPNLP_W4(a, b) (planar_rt ? (a) : (b))
+#define HIPNLP_W8(a, b) (planar_rt ? (a) : (b))
+#define HOST_R(w4, w8, fn, nt) { const int w_ = waves == 4 ? (w4) : (w8); if (w_ >= 0) groups.push_back({w_, [&cx]() { for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_); }}); }
+#define HOST_BARRIER flush();
+        HIPNLP_KNOT_PROGRAM(HOST_R, HOST_BARRIER)
+#undef HOST_R
+#undef HOST_BARRIER
+#undef HIPNLP_W4
+#undef HIPNLP_W8
+        flush();
+        const int v = L.variant_of(k);
+        const long jb = L.jac_base(k);
+        for (int i = 0; i < L.nnz_v[v]; ++i) jac[jb + i] = s->jac[L.jperm[v][size_t(i)]];
+        if (k == N - 1) for (size_t i = 0; i < L.jperm_glob.size(); ++i) jac[L.jac_glob_base + long(i)] = s->jac[L.jperm_glob[i]];
+        for (int slot = 0; slot < gs::COUNT; ++slot) {
+            const int a = L.g_a[v][size_t(slot)];
+            if (a >= 0) g[a + L.g_b[size_t(slot)] * k] = s->g[slot];
+        }
+        for (int i = 0; i < NXK; ++i) grad[NXK * k + i] = s->grad[i];
+        for (int i = 0; i < NCT; ++i) cost_terms[i] += s->cost[i];
+    }
+    delete s;
+    double ft = 0.0;
+    for (int i = 0; i < NCT; ++i) ft += cost_terms[i];
+    *f = ft;
+    return 0;
+}
+
 
 extern "C" {
 void hostemu_set_wave_order(int order) { g_wave_order = order; }
@@ -263,60 +334,11 @@ void hostemu_eval(const hostemu_handle* h, const double* x, const double* p, dou
 int hostemu_eval_wave_order(const hostemu_handle* h, const double* x, const double* p, int waves, int order, double* f, double* grad, double* g,
                             double* jac, double* cost_terms) {
     if ((waves != 4 && waves != 8) || order < 0 || order > 2) return -1;
-    const Layout& L = h->L;
-    const int N = L.N;
-    const bool planar_rt = h->ks.terrain == HIPNLP_TERRAIN_PLANAR;
-    std::vector<double> pk(size_t(N) * PK_STRIDE);
-    GParams gp;
-    pack_params(p, N, pk.data(), gp);
-    for (int i = 0; i < NCT; ++i) cost_terms[i] = 0.0;
-    for (int i = 0; i < L.n; ++i) grad[i] = 0.0;
-    KnotScratch* s = new KnotScratch();
-    for (int k = 0; k < N; ++k) {
-        std::fill(reinterpret_cast<double*>(s), reinterpret_cast<double*>(s) + sizeof(KnotScratch) / sizeof(double), std::nan(""));
-        for (int i = 0; i < XPAD; ++i) { s->x[i] = 0; s->xm[i] = 0; }
-        for (int i = 0; i < NPER; ++i) s->xo[i] = 0;
-        for (int i = 0; i < NXK; ++i) { s->x[i] = x[NXK * k + i]; s->xm[i] = k > 0 ? x[NXK * (k - 1) + i] : 0.0; }
-        for (int i = 0; i < NPER; ++i) s->xo[i] = k == 0 ? x[NXK * (N - 1) + periodicity_row_var(i)] : (k == N - 1 ? x[periodicity_row_var(i)] : 0.0);
-        for (int i = 0; i < NXG; ++i) s->xg[i] = x[NXK * N + i];
-        for (int i = 0; i < PK_STRIDE; ++i) s->pk[i] = pk[size_t(k) * PK_STRIDE + i];
-        KnotInfo ki{k, N, k == 0, k == N - 1};
-        ValueEm em{s->g, s->jac};
-        Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
-        std::vector<std::pair<int, std::function<void()>>> groups;   // (wave, group) of the current phase, in table order
-        auto flush = [&]() {
-            for (int q = 0; q < waves; ++q) {
-                const int w = order == 0 ? q : (order == 1 ? waves - 1 - q : (q + waves / 2) % waves);
-                for (auto& gq : groups) if (gq.first == w) gq.second();
-            }
-            groups.clear();
-        };
-#define HIPNLP_W4(a, b) (planar_rt ? (a) : (b))
-#define HIPNLP_W8(a, b) (planar_rt ? (a) : (b))
-#define HOST_R(w4, w8, fn, nt) { const int w_ = waves == 4 ? (w4) : (w8); if (w_ >= 0) groups.push_back({w_, [&cx]() { for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_); }}); }
-#define HOST_BARRIER flush();
-        HIPNLP_KNOT_PROGRAM(HOST_R, HOST_BARRIER)
-#undef HOST_R
-#undef HOST_BARRIER
-#undef HIPNLP_W4
-#undef HIPNLP_W8
-        flush();
-        const int v = L.variant_of(k);
-        const long jb = L.jac_base(k);
-        for (int i = 0; i < L.nnz_v[v]; ++i) jac[jb + i] = s->jac[L.jperm[v][size_t(i)]];
-        if (k == N - 1) for (size_t i = 0; i < L.jperm_glob.size(); ++i) jac[L.jac_glob_base + long(i)] = s->jac[L.jperm_glob[i]];
-        for (int slot = 0; slot < gs::COUNT; ++slot) {
-            const int a = L.g_a[v][size_t(slot)];
-            if (a >= 0) g[a + L.g_b[size_t(slot)] * k] = s->g[slot];
-        }
-        for (int i = 0; i < NXK; ++i) grad[NXK * k + i] = s->grad[i];
-        for (int i = 0; i < NCT; ++i) cost_terms[i] += s->cost[i];
-    }
-    delete s;
-    double ft = 0.0;
-    for (int i = 0; i < NCT; ++i) ft += cost_terms[i];
-    *f = ft;
-    return 0;
+    const bool planar = h->ks.terrain == HIPNLP_TERRAIN_PLANAR;
+    if (waves == 4) return planar ? eval_wave_order_t<4, HIPNLP_TERRAIN_PLANAR>(h, x, p, order, f, grad, g, jac, cost_terms)
+                                  : eval_wave_order_t<4, HIPNLP_TERRAIN_SMOOTH_STEPS>(h, x, p, order, f, grad, g, jac, cost_terms);
+    return planar ? eval_wave_order_t<8, HIPNLP_TERRAIN_PLANAR>(h, x, p, order, f, grad, g, jac, cost_terms)
+                  : eval_wave_order_t<8, HIPNLP_TERRAIN_SMOOTH_STEPS>(h, x, p, order, f, grad, g, jac, cost_terms);
 }
 
 int hostemu_eval_compact(const hostemu_handle* h, const double* x, const double* p, double* f, double* grad, double* g, double* jac, double* cost_terms) {
