@@ -1,88 +1,106 @@
-"""Contact-point / floating-base / humanoid dataclasses: the per-knot memory layout of the kinodynamic NLP.
-Mirror of robot_planning/variables/contacts.py:20-166, floating_base.py:16-185, humanoid.py:21-56 (field names, storage
-types and — decisive for the flat order — the multiple-inheritance field order: derivative fields first)."""
+"""Contact-point / floating-base / humanoid nodes of the variable tree: the per-knot memory layout of the kinodynamic NLP.
+
+The CONTRACT is the reference's (robot_planning/variables/contacts.py:20-166, floating_base.py:16-185, humanoid.py:21-56): node
+names, leaf names, storage kinds, constructor arguments and — decisive for the flat order — the field order of nodes with two
+bases (derivative leaves first).  The DECLARATION is this build's: one `declare(...)` table per node (`hippopt_amd/base/schema.py`)
+instead of a hand-written dataclass each; `tests/golden/kinodyn_structure.json`, produced by the reference's own classes, pins
+that both give the same flat names, order, sizes and variable / parameter split (tests/test_structure.py).
+"""
 import copy
 import dataclasses
 
 import numpy as np
 
-from ..base import (CompositeType, OptimizationObject, OverridableVariable, Parameter, StorageType, default_composite_field,
-                    default_storage_field)
+from ..base import OverridableVariable, Parameter
+from ..base.schema import argument, child, declare, leaf, plain
+
+_M = __name__
+
+
+def _zeros(count):
+    return lambda: np.zeros(count)
+
+
+def _identity_quaternion():
+    return np.array([0.0, 0.0, 0.0, 1.0])
+
+
+# ---- contact points -------------------------------------------------------------------------------------------------------------
+def _descriptor_setup(self, input_foot_frame, input_position_in_foot_frame):
+    if input_foot_frame is not None:
+        self.foot_frame = input_foot_frame
+    if input_position_in_foot_frame is not None:
+        self.position_in_foot_frame = input_position_in_foot_frame
+
+
+def _rectangular_foot(foot_frame, x_length, y_length, top_left_point_position):
+    """the four corners of a rectangular sole, counter-clockwise from the top-left one (contacts.py:38-65)"""
+    corner = np.asarray(top_left_point_position, float)
+    steps = np.array([[0.0, 0.0], [-1.0, 0.0], [-1.0, -1.0], [0.0, -1.0]]) * [x_length, y_length]
+    return [ContactPointDescriptor(input_foot_frame=foot_frame, input_position_in_foot_frame=corner + np.append(step, 0.0)) for step in steps]
+
+
+ContactPointDescriptor = declare(
+    "ContactPointDescriptor",
+    {"position_in_foot_frame": leaf(Parameter), "foot_frame": plain(), "input_foot_frame": argument(), "input_position_in_foot_frame": argument()},
+    setup=_descriptor_setup, methods={"rectangular_foot": staticmethod(_rectangular_foot)}, module=_M)
+
+
+def _point_setup(self, input_descriptor):
+    if input_descriptor is not None:
+        self.descriptor = copy.deepcopy(input_descriptor)
+
+
+ContactPointState = declare(
+    "ContactPointState",
+    {"p": leaf(OverridableVariable, _zeros(3)), "f": leaf(OverridableVariable, _zeros(3)),
+     "descriptor": child(lambda: ContactPointDescriptor(), time_varying=False), "input_descriptor": argument()},
+    setup=_point_setup, module=_M)
+
+ContactPointStateDerivative = declare(
+    "ContactPointStateDerivative", {"v": leaf(OverridableVariable, _zeros(3)), "f_dot": leaf(OverridableVariable, _zeros(3))}, module=_M)
 
 
 @dataclasses.dataclass
-class ContactPointDescriptor(OptimizationObject):
-    position_in_foot_frame: StorageType = default_storage_field(Parameter)
-    foot_frame: str = dataclasses.field(default=None)
-    input_foot_frame: dataclasses.InitVar[str] = dataclasses.field(default=None)
-    input_position_in_foot_frame: dataclasses.InitVar[np.ndarray] = dataclasses.field(default=None)
+class FootContactState(list, ContactPointState.__mro__[1]):
+    """the contact points of one foot (a list that is also a node: contacts.py:97-127)"""
 
-    def __post_init__(self, input_foot_frame, input_position_in_foot_frame):
-        if input_foot_frame is not None:
-            self.foot_frame = input_foot_frame
-        if input_position_in_foot_frame is not None:
-            self.position_in_foot_frame = input_position_in_foot_frame
-
-    @staticmethod
-    def rectangular_foot(foot_frame, x_length, y_length, top_left_point_position):
-        tl = np.asarray(top_left_point_position, float)
-        return [ContactPointDescriptor(input_foot_frame=foot_frame, input_position_in_foot_frame=tl + d)
-                for d in ([0.0, 0.0, 0.0], [-x_length, 0.0, 0.0], [-x_length, -y_length, 0.0], [0.0, -y_length, 0.0])]
-
-
-@dataclasses.dataclass
-class ContactPointState(OptimizationObject):
-    p: StorageType = default_storage_field(OverridableVariable)
-    f: StorageType = default_storage_field(OverridableVariable)
-    descriptor: CompositeType = default_composite_field(factory=ContactPointDescriptor, time_varying=False)
-    input_descriptor: dataclasses.InitVar[ContactPointDescriptor] = dataclasses.field(default=None)
-
-    def __post_init__(self, input_descriptor):
-        self.p = np.zeros(3) if self.p is None else self.p
-        self.f = np.zeros(3) if self.f is None else self.f
-        if input_descriptor is not None:
-            self.descriptor = copy.deepcopy(input_descriptor)
-
-
-@dataclasses.dataclass
-class ContactPointStateDerivative(OptimizationObject):
-    v: StorageType = default_storage_field(OverridableVariable)
-    f_dot: StorageType = default_storage_field(OverridableVariable)
-
-    def __post_init__(self):
-        self.v = np.zeros(3) if self.v is None else self.v
-        self.f_dot = np.zeros(3) if self.f_dot is None else self.f_dot
-
-
-@dataclasses.dataclass
-class FootContactState(list, OptimizationObject):
-    def set_from_parent_frame_transform(self, transform):   # contacts.py:103-107
-        for contact_point in self:
-            contact_point.p = transform.translation() + transform.rotation().act(contact_point.descriptor.position_in_foot_frame)
+    def set_from_parent_frame_transform(self, transform):
+        origin, turn = transform.translation(), transform.rotation()
+        for point in self:
+            point.p = origin + turn.act(point.descriptor.position_in_foot_frame)
 
     @staticmethod
     def from_list(input_list):
-        out = FootContactState()
-        out.extend(input_list)
-        return out
+        foot = FootContactState()
+        foot.extend(input_list)
+        return foot
 
     @staticmethod
-    def from_parent_frame_transform(descriptor, transform):   # contacts.py:116-127
-        out = FootContactState()
-        for contact_point_descriptor in descriptor:
-            out.append(ContactPointState(input_descriptor=contact_point_descriptor))
-        out.set_from_parent_frame_transform(transform)
-        return out
+    def from_parent_frame_transform(descriptor, transform):
+        foot = FootContactState.from_list([ContactPointState(input_descriptor=d) for d in descriptor])
+        foot.set_from_parent_frame_transform(transform)
+        return foot
 
 
 @dataclasses.dataclass
-class FeetContactPointDescriptors:
+class _LeftRight:
     left: list = dataclasses.field(default_factory=list)
     right: list = dataclasses.field(default_factory=list)
 
 
+class FeetContactPointDescriptors(_LeftRight):
+    """descriptors of the contact points of the two feet"""
+
+
+class FeetContactPhasesDescriptor(_LeftRight):
+    """contact phase lists of the two feet (contacts.py:163-166)"""
+
+
 @dataclasses.dataclass
-class FootContactPhaseDescriptor:   # contacts.py:142-160
+class FootContactPhaseDescriptor:
+    """one stance of a foot (contacts.py:142-160): where, with which force, from when to when; `mid_swing_transform`: the pose
+    half way through the swing that FOLLOWS this stance (None: half way to the next stance, with its orientation)"""
     transform: object = None
     mid_swing_transform: object = None
     force: np.ndarray = None
@@ -94,121 +112,83 @@ class FootContactPhaseDescriptor:   # contacts.py:142-160
         if self.transform is None:
             self.transform = SE3.from_translation_and_rotation(np.zeros(3), SO3.Identity())
         if self.force is None:
-            self.force = np.zeros(3)
-            self.force[2] = 100
+            self.force = np.array([0.0, 0.0, 100.0])
 
 
-@dataclasses.dataclass
-class FeetContactPhasesDescriptor:   # contacts.py:163-166
-    left: list = dataclasses.field(default_factory=list)
-    right: list = dataclasses.field(default_factory=list)
+FeetContactPoints = declare("FeetContactPoints", {"left": child(FootContactState), "right": child(FootContactState)}, module=_M)
+
+# ---- floating base, joints ------------------------------------------------------------------------------------------------------
+FreeFloatingObjectState = declare(
+    "FreeFloatingObjectState", {"position": leaf(OverridableVariable, _zeros(3)), "quaternion_xyzw": leaf(OverridableVariable, _identity_quaternion)},
+    module=_M)
+FreeFloatingObjectStateDerivative = declare(
+    "FreeFloatingObjectStateDerivative",
+    {"linear_velocity": leaf(OverridableVariable, _zeros(3)), "quaternion_velocity_xyzw": leaf(OverridableVariable, _zeros(4))}, module=_M)
+FreeFloatingObject = declare("FreeFloatingObject", {}, bases=(FreeFloatingObjectState, FreeFloatingObjectStateDerivative), module=_M)
 
 
-@dataclasses.dataclass
-class FeetContactPoints(OptimizationObject):
-    left: list = default_composite_field(factory=FootContactState)
-    right: list = default_composite_field(factory=FootContactState)
+def _tree_state_setup(self, number_of_joints_state):
+    if number_of_joints_state is not None and self.positions is None:
+        self.positions = np.zeros(number_of_joints_state)
 
 
-@dataclasses.dataclass
-class FreeFloatingObjectState(OptimizationObject):
-    position: StorageType = default_storage_field(OverridableVariable)
-    quaternion_xyzw: StorageType = default_storage_field(OverridableVariable)
-
-    def __post_init__(self):
-        self.position = np.zeros(3) if self.position is None else self.position
-        if self.quaternion_xyzw is None:
-            self.quaternion_xyzw = np.array([0.0, 0.0, 0.0, 1.0])
+def _tree_derivative_setup(self, number_of_joints_derivative):
+    if number_of_joints_derivative is not None:
+        self.velocities = np.zeros(number_of_joints_derivative)
 
 
-@dataclasses.dataclass
-class FreeFloatingObjectStateDerivative(OptimizationObject):
-    linear_velocity: StorageType = default_storage_field(OverridableVariable)
-    quaternion_velocity_xyzw: StorageType = default_storage_field(OverridableVariable)
-
-    def __post_init__(self):
-        self.linear_velocity = np.zeros(3) if self.linear_velocity is None else self.linear_velocity
-        self.quaternion_velocity_xyzw = np.zeros(4) if self.quaternion_velocity_xyzw is None else self.quaternion_velocity_xyzw
+def _tree_setup(self, number_of_joints_derivative=None, number_of_joints_state=None):
+    counts = [c for c in (number_of_joints_state, number_of_joints_derivative) if c is not None]
+    if counts:   # one count serves both halves
+        _tree_state_setup(self, counts[0])
+        _tree_derivative_setup(self, counts[-1])
 
 
-@dataclasses.dataclass
-class FreeFloatingObject(FreeFloatingObjectState, FreeFloatingObjectStateDerivative):
-    def __post_init__(self):
-        FreeFloatingObjectState.__post_init__(self)
-        FreeFloatingObjectStateDerivative.__post_init__(self)
+KinematicTreeState = declare("KinematicTreeState", {"positions": leaf(OverridableVariable), "number_of_joints_state": argument(0)},
+                             setup=_tree_state_setup, module=_M)
+KinematicTreeStateDerivative = declare("KinematicTreeStateDerivative",
+                                       {"velocities": leaf(OverridableVariable), "number_of_joints_derivative": argument()},
+                                       setup=_tree_derivative_setup, module=_M)
+KinematicTree = declare("KinematicTree", {}, bases=(KinematicTreeState, KinematicTreeStateDerivative), setup=_tree_setup, module=_M)
 
 
-@dataclasses.dataclass
-class KinematicTreeState(OptimizationObject):
-    positions: StorageType = default_storage_field(OverridableVariable)
-    number_of_joints_state: dataclasses.InitVar[int] = dataclasses.field(default=0)
-
-    def __post_init__(self, number_of_joints_state):
-        if number_of_joints_state is not None and self.positions is None:
-            self.positions = np.zeros(number_of_joints_state)
+def _system_state_setup(self, number_of_joints_state):
+    if number_of_joints_state is not None:
+        self.joints = KinematicTreeState(number_of_joints_state=number_of_joints_state)
 
 
-@dataclasses.dataclass
-class KinematicTreeStateDerivative(OptimizationObject):
-    velocities: StorageType = default_storage_field(OverridableVariable)
-    number_of_joints_derivative: dataclasses.InitVar[int] = dataclasses.field(default=None)
-
-    def __post_init__(self, number_of_joints_derivative):
-        if number_of_joints_derivative is not None:
-            self.velocities = np.zeros(number_of_joints_derivative)
+def _system_setup(self, number_of_joints):
+    if number_of_joints is not None:
+        self.joints = KinematicTree(number_of_joints_state=number_of_joints)
 
 
-@dataclasses.dataclass
-class KinematicTree(KinematicTreeState, KinematicTreeStateDerivative):
-    def __post_init__(self, number_of_joints_derivative=None, number_of_joints_state=None):
-        if number_of_joints_derivative is not None or number_of_joints_state is not None:
-            ns = number_of_joints_derivative if number_of_joints_state is None else number_of_joints_state
-            nd = ns if number_of_joints_derivative is None else number_of_joints_derivative
-            KinematicTreeState.__post_init__(self, number_of_joints_state=ns)
-            KinematicTreeStateDerivative.__post_init__(self, number_of_joints_derivative=nd)
+def _system_as_state(self):
+    """positions only (floating_base.py:179-185): the state half of a system that also carries velocities"""
+    state = FloatingBaseSystemState()
+    state.base.position, state.base.quaternion_xyzw, state.joints.positions = self.base.position, self.base.quaternion_xyzw, self.joints.positions
+    return state
 
 
-@dataclasses.dataclass
-class FloatingBaseSystemState(OptimizationObject):
-    base: CompositeType = default_composite_field(factory=FreeFloatingObjectState)
-    joints: CompositeType = default_composite_field(factory=KinematicTreeState)
-    number_of_joints_state: dataclasses.InitVar[int] = dataclasses.field(default=None)
-
-    def __post_init__(self, number_of_joints_state):
-        if number_of_joints_state is not None:
-            self.joints = KinematicTreeState(number_of_joints_state=number_of_joints_state)
+FloatingBaseSystemState = declare(
+    "FloatingBaseSystemState",
+    {"base": child(lambda: FreeFloatingObjectState()), "joints": child(lambda: KinematicTreeState()), "number_of_joints_state": argument()},
+    setup=_system_state_setup, module=_M)
+FloatingBaseSystem = declare(
+    "FloatingBaseSystem", {"base": child(lambda: FreeFloatingObject()), "joints": child(lambda: KinematicTree()), "number_of_joints": argument()},
+    setup=_system_setup, methods={"to_floating_base_system_state": _system_as_state}, module=_M)
 
 
-@dataclasses.dataclass
-class FloatingBaseSystem(OptimizationObject):
-    base: CompositeType = default_composite_field(factory=FreeFloatingObject)
-    joints: CompositeType = default_composite_field(factory=KinematicTree)
-    number_of_joints: dataclasses.InitVar[int] = dataclasses.field(default=None)
-
-    def __post_init__(self, number_of_joints):
-        if number_of_joints is not None:
-            self.joints = KinematicTree(number_of_joints_state=number_of_joints)
-
-    def to_floating_base_system_state(self):
-        out = FloatingBaseSystemState()
-        out.base.position = self.base.position
-        out.base.quaternion_xyzw = self.base.quaternion_xyzw
-        out.joints.positions = self.joints.positions
-        return out
+# ---- humanoid -------------------------------------------------------------------------------------------------------------------
+def _humanoid_setup(self, contact_point_descriptors, number_of_joints):
+    if contact_point_descriptors is not None:
+        for side in ("left", "right"):
+            setattr(self.contact_points, side, [ContactPointState(input_descriptor=d) for d in getattr(contact_point_descriptors, side)])
+    if number_of_joints is not None:
+        self.kinematics = FloatingBaseSystemState(number_of_joints_state=number_of_joints)
 
 
-@dataclasses.dataclass
-class HumanoidState(OptimizationObject):
-    contact_points: CompositeType = default_composite_field(factory=FeetContactPoints, time_varying=False)
-    kinematics: CompositeType = default_composite_field(factory=FloatingBaseSystemState, time_varying=False)
-    com: StorageType = default_storage_field(OverridableVariable)
-    contact_point_descriptors: dataclasses.InitVar[FeetContactPointDescriptors] = dataclasses.field(default=None)
-    number_of_joints: dataclasses.InitVar[int] = dataclasses.field(default=None)
-
-    def __post_init__(self, contact_point_descriptors, number_of_joints):
-        if contact_point_descriptors is not None:
-            self.contact_points.left = [ContactPointState(input_descriptor=pt) for pt in contact_point_descriptors.left]
-            self.contact_points.right = [ContactPointState(input_descriptor=pt) for pt in contact_point_descriptors.right]
-        if number_of_joints is not None:
-            self.kinematics = FloatingBaseSystemState(number_of_joints_state=number_of_joints)
-        self.com = np.zeros(3) if self.com is None else self.com
+HumanoidState = declare(
+    "HumanoidState",
+    {"contact_points": child(lambda: FeetContactPoints(), time_varying=False), "kinematics": child(lambda: FloatingBaseSystemState(), time_varying=False),
+     "com": leaf(OverridableVariable, _zeros(3)), "contact_point_descriptors": argument(), "number_of_joints": argument()},
+    setup=_humanoid_setup, module=_M)
