@@ -3,6 +3,8 @@ import ctypes as C
 
 NJ, NL, NC, NXK, NPK, NXG, NPG = 23, 24, 8, 189, 79, 6, 326
 NCOST_TERMS = 12
+ABI_VERSION = 2
+FLAG_DETECT_SIMPLE_BOUNDS = 1
 
 EXPR_SKIP, EXPR_SUBJECT_TO, EXPR_MINIMIZE = 0, 1, 2
 TERRAIN_PLANAR, TERRAIN_SMOOTH_STEPS, MAX_TERRAIN_STEPS = 0, 1, 4
@@ -68,13 +70,19 @@ class DescC(C.Structure):
         ("knot_begin", C.c_int32),
         ("knot_end", C.c_int32),
         ("device", C.c_int32),
+        ("abi_version", C.c_int32),
+        ("flags", C.c_int32),
     ]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.abi_version = ABI_VERSION
 
 
 class DimsC(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n", "m", "nnz", "np", "nnz_knot", "m_knot",
-        "shard_g_rows", "shard_nnz", "shard_grad", "shard_jac_off", "shard_grad_off")]
+        "shard_g_rows", "shard_nnz", "shard_grad", "shard_jac_off", "shard_grad_off", "m_full", "n_lifted")]
 
 
 # ---- static pose finder (hipnlp_pose_*) ----------------------------------------------------------------------
@@ -107,7 +115,12 @@ class PoseSettingsC(C.Structure):
 
 
 class PoseDescC(C.Structure):
-    _fields_ = [("settings", PoseSettingsC), ("model", RobotModelC), ("batch", C.c_int32), ("device", C.c_int32)]
+    _fields_ = [("settings", PoseSettingsC), ("model", RobotModelC), ("batch", C.c_int32), ("device", C.c_int32),
+                ("abi_version", C.c_int32), ("flags", C.c_int32)]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.abi_version = ABI_VERSION
 
 
 class PoseDimsC(C.Structure):

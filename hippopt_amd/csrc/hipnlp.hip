@@ -432,7 +432,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 #pragma unroll
     for (int it = 0; it < JP_ITERS; ++it) bad |= (jp[it] >= 0) & !isfinite(jvals[it]);
 #pragma unroll
-    for (int it = 0; it < G_ITERS; ++it) bad |= (ga[it] >= 0) & !isfinite(gvals[it]);
+    for (int it = 0; it < G_ITERS; ++it) bad |= (ga[it] != G_NONE) & !isfinite(gvals[it]);
 #pragma unroll
     for (int it = 0; it < GR_ITERS; ++it) bad |= ((tid + it * WG) < NXK) & !isfinite(grvals[it]);
     if (a.cost_pub) { if (wave == PUBW) bad |= pub_bad; }
@@ -460,7 +460,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             if (last && tid < n_glob) base[o_jac + int64_t(jac_glob_base) + tid] = s.jac[jpg];
             double* og = base + o_g;
 #pragma unroll
-            for (int it = 0; it < G_ITERS; ++it) if (ga[it] >= 0) og[ga[it] + gb[it] * k] = gvals[it];
+            for (int it = 0; it < G_ITERS; ++it) if (ga[it] != G_NONE) og[ga[it] + gb[it] * k] = gvals[it];
             double* ogr = base + int64_t(NXK) * k;
 #pragma unroll
             for (int it = 0; it < GR_ITERS; ++it) { const int i = tid + it * WG; if (i < NXK) ogr[i] = grvals[it]; }
@@ -477,14 +477,14 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     if (a.g) {
         double* out = a.g + size_t(b) * a.m;
 #pragma unroll
-        for (int it = 0; it < G_ITERS; ++it) if (ga[it] >= 0) out[ga[it] + gb[it] * k] = gvals[it];
+        for (int it = 0; it < G_ITERS; ++it) if (ga[it] != G_NONE) out[ga[it] + gb[it] * k] = gvals[it];
     }
     if (a.g_stage) {
         double* out = a.g_stage + (size_t(b) * a.nk + kk) * gs::COUNT;
 #pragma unroll
         for (int it = 0; it < G_ITERS; ++it) {
             const int slot = tid + it * WG;
-            if (slot < gs::COUNT) out[slot] = ga[it] >= 0 ? gvals[it] : 0.0;
+            if (slot < gs::COUNT) out[slot] = ga[it] != G_NONE ? gvals[it] : 0.0;
         }
     }
     if (a.grad) {
@@ -589,7 +589,7 @@ template <int TERRAIN> __global__ __launch_bounds__(256) __attribute__((amdgpu_w
         int lga[LG_ITERS], lgb[LG_ITERS];
 #pragma unroll
         for (int it = 0; it < LG_ITERS; ++it) { lga[it] = tb.g_a[v][tid + it * WG]; lgb[it] = tb.g_b[tid + it * WG]; }   // (padded tables)
-        int nga = -1, ngb = 0;
+        int nga = G_NONE, ngb = 0;
         if (tid < 3 && k + 1 < N) { const int slot = gs::HDYN + 3 + tid; nga = tb.g_a[k + 1 == N - 1 ? VAR_LAST : VAR_INTERIOR][slot]; ngb = tb.g_b[slot]; }
         const double sig = a.sigma[b];
         stage(x + size_t(NXK) * k, s.x, XB);
@@ -603,8 +603,8 @@ template <int TERRAIN> __global__ __launch_bounds__(256) __attribute__((amdgpu_w
         if (first || last) { if (tid < NPER) xov = x[size_t(NXK) * (first ? N - 1 : 0) + periodicity_row_var(tid)]; }
         double lv[LG_ITERS];
 #pragma unroll
-        for (int it = 0; it < LG_ITERS; ++it) lv[it] = lga[it] >= 0 ? lam[lga[it] + lgb[it] * k] : 0.0;
-        const double lnext = nga >= 0 ? lam[nga + ngb * (k + 1)] : 0.0;
+        for (int it = 0; it < LG_ITERS; ++it) lv[it] = lga[it] != G_NONE ? lam[lga[it] + lgb[it] * k] : 0.0;
+        const double lnext = nga != G_NONE ? lam[nga + ngb * (k + 1)] : 0.0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the staging loads of THIS wave have landed in LDS
         if (first || last) { if (tid < NPER) s.xo[tid] = xov; }
         if (XREM && tid < 2) (tid ? s.xm : s.x)[XB / 8] = xrem;
@@ -815,6 +815,12 @@ extern "C" {
 
 const char* hipnlp_last_error(const hipnlp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+int hipnlp_abi_version(void) { return HIPNLP_ABI_VERSION; }
+#ifndef HIPNLP_BUILD_VARIANT
+#define HIPNLP_BUILD_VARIANT "plain hipcc"
+#endif
+const char* hipnlp_build_info(void) { return "gfx950; " HIPNLP_BUILD_VARIANT; }
+
 int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     if (!desc || !out) { g_create_error = "null argument"; return HIPNLP_E_INVALID; }
     *out = nullptr;
@@ -823,6 +829,10 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     h->d = *desc;
     const hipnlp_settings& st = desc->settings;
     auto fail = [&](int code, const std::string& msg) { g_create_error = msg; free_all(h); return code; };
+    if (desc->abi_version != HIPNLP_ABI_VERSION)
+        return fail(HIPNLP_E_INVALID, "hipnlp_desc.abi_version is " + std::to_string(desc->abi_version) + ", this library implements HIPNLP_ABI_VERSION " +
+                                          std::to_string(HIPNLP_ABI_VERSION) + " (the caller was built against another include/hipnlp.h, or left the field unset)");
+    if (desc->flags & ~HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS) return fail(HIPNLP_E_INVALID, "unknown bits in hipnlp_desc.flags");
     if (st.horizon < 2) return fail(HIPNLP_E_INVALID, "settings.horizon must be >= 2");
     if (const char* te = Layout::check_terrain(st.terrain, st.n_terrain_steps, st.terrain_steps)) return fail(HIPNLP_E_INVALID, te);
     if (desc->batch < 1) return fail(HIPNLP_E_INVALID, "batch must be >= 1");
@@ -849,7 +859,7 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     }
     std::string e;
     if (!Layout::make_kin_tables(desc->model, h->kt, e)) return fail(HIPNLP_E_INVALID, e);
-    if (!h->L.build(st, h->kt)) return fail(HIPNLP_E_INVALID, h->L.error);
+    if (!h->L.build(st, h->kt, (desc->flags & HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS) != 0)) return fail(HIPNLP_E_INVALID, h->L.error);
     h->np = ParamOffsets(st.horizon).np();
     if (h->L.jperm_glob.size() > 16) return fail(HIPNLP_E_INVALID, "internal: too many global-column entries");
 
@@ -915,7 +925,7 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     tb->head.kt = h->kt;
     tb->head.ks = Layout::make_ksettings(st);
     for (int v = 0; v < 3; ++v) {
-        for (int s = 0; s < GS_PAD; ++s) tb->g_a[v][s] = s < gs::COUNT ? h->L.g_a[v][size_t(s)] : -1;
+        for (int s = 0; s < GS_PAD; ++s) tb->g_a[v][s] = s < gs::COUNT ? h->L.g_a[v][size_t(s)] : G_NONE;
         for (int i = 0; i < JS_PAD; ++i) tb->jperm[v][i] = size_t(i) < h->L.jperm[v].size() ? h->L.jperm[v][size_t(i)] : -1;
         tb->nnz_v[v] = h->L.nnz_v[v];
     }
@@ -959,9 +969,11 @@ int hipnlp_get_dims(const hipnlp_handle* h, hipnlp_dims* o) {
     int rows = 0;
     for (int k = h->kb; k < h->ke; ++k) {
         const int v = L.variant_of(k);
-        for (int s = 0; s < gs::COUNT; ++s) rows += L.g_a[v][size_t(s)] >= 0;
+        for (int s = 0; s < gs::COUNT; ++s) rows += L.g_a[v][size_t(s)] != G_NONE;
     }
     o->shard_g_rows = rows;
+    o->m_full = L.m_full;
+    o->n_lifted = L.n_lifted;
     return HIPNLP_OK;
 }
 
@@ -984,14 +996,19 @@ int hipnlp_set_params(hipnlp_handle* h, const double* p) {
 int hipnlp_bounds(const hipnlp_handle* h, double* lbx, double* ubx, double* lbg, double* ubg) {
     if (!h) return HIPNLP_E_INVALID;
     if (!h->params_set) return HIPNLP_E_PARAMS;
-    const double inf = std::numeric_limits<double>::infinity();
-    if (lbx) for (int i = 0; i < h->L.n; ++i) lbx[i] = -inf;
-    if (ubx) for (int i = 0; i < h->L.n; ++i) ubx[i] = inf;
-    if (lbg || ubg) {
-        std::vector<double> lo(size_t(h->L.m)), hi(size_t(h->L.m));
-        h->L.bounds(h->p.data(), lo.data(), hi.data());
-        if (lbg) std::memcpy(lbg, lo.data(), lo.size() * sizeof(double));
-        if (ubg) std::memcpy(ubg, hi.data(), hi.size() * sizeof(double));
+    h->L.bounds(h->p.data(), lbx, ubx, lbg, ubg);
+    return HIPNLP_OK;
+}
+
+int hipnlp_lift_map(const hipnlp_handle* h, int32_t* kept_row, double* lb_full, double* ub_full) {
+    if (!h) return HIPNLP_E_INVALID;
+    if ((lb_full || ub_full) && !h->params_set) return HIPNLP_E_PARAMS;
+    if (kept_row) h->L.kept_rows(kept_row);
+    if (lb_full || ub_full) {
+        std::vector<double> lo(size_t(h->L.m_full)), hi(size_t(h->L.m_full));
+        h->L.bounds_full(h->p.data(), lo.data(), hi.data());
+        if (lb_full) std::memcpy(lb_full, lo.data(), lo.size() * sizeof(double));
+        if (ub_full) std::memcpy(ub_full, hi.data(), hi.size() * sizeof(double));
     }
     return HIPNLP_OK;
 }
@@ -1250,7 +1267,7 @@ int hipnlp_stage_rows(const hipnlp_handle* h, int k, int32_t* rows) {
     const int v = h->L.variant_of(k);
     for (int s = 0; s < gs::COUNT; ++s) {
         const int a = h->L.g_a[v][size_t(s)];
-        rows[s] = a >= 0 ? a + h->L.g_b[size_t(s)] * k : -1;
+        rows[s] = a != G_NONE ? a + h->L.g_b[size_t(s)] * k : -1;
     }
     return HIPNLP_OK;
 }

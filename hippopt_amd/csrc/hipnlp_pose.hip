@@ -315,6 +315,10 @@ int hipnlp_pose_create(const hipnlp_pose_desc* desc, hipnlp_pose_handle** out) {
     h->d = *desc;
     const hipnlp_pose_settings& st = desc->settings;
     auto fail = [&](int code, const std::string& msg) { g_pose_create_error = msg; pose_free_all(h); return code; };
+    if (desc->abi_version != HIPNLP_ABI_VERSION)
+        return fail(HIPNLP_E_INVALID, "hipnlp_pose_desc.abi_version is " + std::to_string(desc->abi_version) + ", this library implements HIPNLP_ABI_VERSION " +
+                                          std::to_string(HIPNLP_ABI_VERSION) + " (the caller was built against another include/hipnlp.h, or left the field unset)");
+    if (desc->flags != 0) return fail(HIPNLP_E_INVALID, "unknown bits in hipnlp_pose_desc.flags");
     if (const char* te = Layout::check_terrain(st.terrain, st.n_terrain_steps, st.terrain_steps)) return fail(HIPNLP_E_INVALID, te);
     for (int t : {st.com_position_type, st.left_point_position_type, st.right_point_position_type})
         if (t != HIPNLP_EXPR_SKIP && t != HIPNLP_EXPR_SUBJECT_TO && t != HIPNLP_EXPR_MINIMIZE) return fail(HIPNLP_E_INVALID, "bad expression type");

@@ -39,7 +39,11 @@ inline int final_row_var(int i, int* slot, int* desc) {
 }
 struct RowBlock {
     std::string name;
-    int first_row, rows, k0, nk;
+    int first_row, rows, k0, nk;      // the reference's named constraint: rows in FULL numbering (every subject_to row)
+    // detect_simple_bounds (Layout::lifted): the rows of the block that stay in g — `kept` of its `rows` per knot, row i at position
+    // kidx[i] (-1: lifted into a bound on its variable), the first of them at first_kept of the reduced numbering
+    int first_kept = 0, kept = 0;
+    std::vector<int16_t> kidx;
 };
 
 enum Variant : int { VAR_FIRST = 0, VAR_INTERIOR = 1, VAR_LAST = 2 };
@@ -89,11 +93,16 @@ struct ParamOffsets {
 
 struct Layout {
     int N = 0, n = 0, m = 0, nnz = 0;
+    // detect_simple_bounds (main_periodic_step.py:109-110: Opti runs nlpsol with {"detect_simple_bounds": True}): rows of g that are
+    // exactly ONE decision variable leave g and jac g and become bounds on that variable.  lifted: this layout IS the reduced NLP
+    // (m = rows kept, the CCS pattern without the lifted rows); m_full = rows of the reference's full subject_to list either way.
+    int m_full = 0, n_lifted = 0;
+    bool lifted = false;
     bool has_final = false, has_per = false, has_hx0 = false;
     std::vector<RowBlock> blocks;
     int blk[RK_COUNT][NC];                // directory index of (kind, point) or -1
     // kernel tables
-    std::vector<int32_t> g_a[3];          // [gs::COUNT] row of slot at knot k is g_a + g_b*k ; -1 = not written
+    std::vector<int32_t> g_a[3];          // [gs::COUNT] row of slot at knot k is g_a + g_b*k ; G_NONE = not written
     std::vector<int32_t> g_b;
     std::vector<int32_t> jperm[3];        // CCS position (within the knot's column block) -> native slot
     std::vector<int32_t> jperm_glob;      // entries in the horizon-global columns (written by knot 0)
@@ -109,10 +118,32 @@ struct Layout {
     long jac_base(int k) const { return k == 0 ? 0 : long(nnz_v[VAR_FIRST]) + long(k - 1) * nnz_v[VAR_INTERIOR]; }
 
     int add(const std::string& name, int rows, int k0, int nk) {
-        RowBlock b{name, m, rows, k0, nk};
-        m += rows * nk;
+        RowBlock b{name, m_full, rows, k0, nk};
+        m_full += rows * nk;
         blocks.push_back(b);
         return int(blocks.size()) - 1;
+    }
+    // row i of block b at its kk-th knot, in the numbering of THIS layout (-1: lifted)
+    int row_of(const RowBlock& b, int kk, int i) const {
+        if (!lifted) return b.first_row + b.rows * kk + i;
+        return b.kidx[size_t(i)] < 0 ? -1 : b.first_kept + b.kept * kk + b.kidx[size_t(i)];
+    }
+    // decision variable (0..188 within the knot) behind row i of a (kind, point) block when that row is exactly one variable, else -1:
+    // the x_0 == initial_state rows, the u_v and joint boxes of planner.py:386-405,699-719, the final-state rows that hold a variable
+    static int simple_var(int kind, int c, int i) {
+        switch (kind) {
+            case RK_FDYN_X0: return PT_ * c + F_ + i;
+            case RK_PDYN_X0: return PT_ * c + P_ + i;
+            case RK_UB: return PT_ * c + U_ + i;
+            case RK_PBDYN_X0: return PB_ + i;
+            case RK_QBDYN_X0: return QB_ + i;
+            case RK_SDYN_X0: return S_ + i;
+            case RK_COMDYN_X0: return COM_ + i;
+            case RK_JPB: return S_ + i;
+            case RK_JVB: return SD_ + i;
+            case RK_FIN: { int slot, desc; return final_row_var(i, &slot, &desc); }
+            default: return -1;
+        }
     }
     void add_dyn(const std::string& name, int L, int kin, int c, bool x0) {
         if (x0) blk[kin + 2][c] = add(name + "[0]", L, 0, 1);
@@ -127,21 +158,22 @@ struct Layout {
         const RowBlock& b = blocks[size_t(bi)];
         switch (kind) {
             case RK_FDYN_OUT: case RK_PDYN_OUT: case RK_PBDYN_OUT: case RK_QBDYN_OUT: case RK_SDYN_OUT: case RK_COMDYN_OUT: case RK_HDYN_OUT:
-                return (k + 1 <= N - 1) ? b.first_row + b.rows * k + i : -1;   // row of knot k+1 (k0 = 1)
+                return (k + 1 <= N - 1) ? row_of(b, k, i) : -1;   // row of knot k+1 (k0 = 1)
             case RK_FDYN_X0: case RK_PDYN_X0: case RK_PBDYN_X0: case RK_QBDYN_X0: case RK_SDYN_X0: case RK_COMDYN_X0: case RK_HDYN_X0: case RK_PER0:
-                return k == 0 ? b.first_row + i : -1;
+                return k == 0 ? row_of(b, 0, i) : -1;
             case RK_FIN: case RK_PERN:
-                return k == N - 1 ? b.first_row + i : -1;
+                return k == N - 1 ? row_of(b, 0, i) : -1;
             default:
-                return (k >= b.k0 && k < b.k0 + b.nk) ? b.first_row + b.rows * (k - b.k0) + i : -1;
+                return (k >= b.k0 && k < b.k0 + b.nk) ? row_of(b, k - b.k0, i) : -1;
         }
     }
 
-    bool build(const hipnlp_settings& st, const KinTables& kt) {
+    bool build(const hipnlp_settings& st, const KinTables& kt, bool lift_simple_bounds = false) {
         N = st.horizon;
         if (N < 2) { error = "horizon must be >= 2"; return false; }
         n = NXK * N + NXG;
-        m = 0;
+        m = m_full = n_lifted = 0;
+        lifted = lift_simple_bounds;
         blocks.clear();
         for (int a = 0; a < RK_COUNT; ++a) for (int c = 0; c < NC; ++c) blk[a][c] = -1;
         has_final = st.final_state_type == HIPNLP_EXPR_SUBJECT_TO;
@@ -178,6 +210,26 @@ struct Layout {
         blk[RK_FEETH][0] = add("maximum_feet_relative_height", 1, 1, N - 1);  // planner.py:215-247
         if (has_per) blk[RK_PER0][0] = blk[RK_PERN][0] = add("periodicity_expression", 84, N - 1, 1);  // planner.py:897-930
 
+        // ---- rows kept by detect_simple_bounds: per block, the position of every row among the kept ones ---------------
+        for (RowBlock& b : blocks) { b.kidx.assign(size_t(b.rows), 0); for (int i = 0; i < b.rows; ++i) b.kidx[size_t(i)] = int16_t(i); b.kept = b.rows; }
+        for (int kind = 0; kind < RK_COUNT; ++kind)
+            for (int c = 0; c < NC; ++c) {
+                if (blk[kind][c] < 0) continue;
+                RowBlock& b = blocks[size_t(blk[kind][c])];
+                bool any = false;
+                for (int i = 0; i < b.rows; ++i) any |= simple_var(kind, c, i) >= 0;
+                if (!any) continue;
+                int q = 0;
+                for (int i = 0; i < b.rows; ++i) b.kidx[size_t(i)] = simple_var(kind, c, i) >= 0 ? int16_t(-1) : int16_t(q++);
+                b.kept = q;
+            }
+        {
+            int at = 0;
+            for (RowBlock& b : blocks) { b.first_kept = at; at += b.kept * b.nk; }
+            n_lifted = m_full - at;
+            m = lifted ? at : m_full;
+        }
+
         // ---- record the kernel body's native slots --------------------------------------------------
         std::vector<int> grow(gs::COUNT, -1), jrid(js::COUNT, -1), jc(js::COUNT, -1);
         bool dup = false;
@@ -200,14 +252,14 @@ struct Layout {
 
         // ---- g tables ------------------------------------------------------------------------------------
         g_b.assign(gs::COUNT, 0);
-        for (int v = 0; v < 3; ++v) g_a[v].assign(gs::COUNT, -1);
+        for (int v = 0; v < 3; ++v) g_a[v].assign(gs::COUNT, G_NONE);
         const int krep[3] = {0, 1, N - 1};
         for (int slot = 0; slot < gs::COUNT; ++slot) {
             if (grow[size_t(slot)] < 0) continue;
             const int rid = grow[size_t(slot)];
             const int bi = blk[rid_kind(rid)][rid_point(rid)];
             if (bi < 0) continue;
-            const int stride = blocks[size_t(bi)].nk > 1 ? blocks[size_t(bi)].rows : 0;
+            const int stride = blocks[size_t(bi)].nk > 1 ? (lifted ? blocks[size_t(bi)].kept : blocks[size_t(bi)].rows) : 0;
             g_b[size_t(slot)] = stride;
             for (int v = 0; v < 3; ++v) {
                 if (v == VAR_INTERIOR && N < 3) continue;
@@ -388,8 +440,43 @@ struct Layout {
         return true;
     }
 
-    // Canonical bounds (CasADi Opti canon form) from the parameter vector p (one trajectory)
-    void bounds(const double* p, double* lbg, double* ubg) const {
+    // Bounds of THIS layout's NLP from the parameter vector p (one trajectory); any pointer may be null.  Full layout: lbx / ubx
+    // infinite (the reference adds no explicit variable bounds), lbg / ubg [m_full] the canonical row bounds.  Lifted layout: the
+    // bounds of the lifted rows folded into lbx / ubx (the tightest of the rows that bound a variable), lbg / ubg [m] of the kept rows.
+    void bounds(const double* p, double* lbx, double* ubx, double* lbg, double* ubg) const {
+        const double inf = std::numeric_limits<double>::infinity();
+        const size_t mf = static_cast<size_t>(m_full);
+        if (lbx) for (int i = 0; i < n; ++i) lbx[i] = -inf;
+        if (ubx) for (int i = 0; i < n; ++i) ubx[i] = inf;
+        if (!lifted && !lbg && !ubg) return;
+        std::vector<double> lo(mf, 0.0), hi(mf, 0.0);
+        bounds_full(p, lo.data(), hi.data());
+        if (!lifted) {
+            if (lbg) std::copy(lo.begin(), lo.end(), lbg);
+            if (ubg) std::copy(hi.begin(), hi.end(), ubg);
+            return;
+        }
+        std::vector<int32_t> simple(mf, 0), var(mf, -1), kept(mf, -1);
+        simple_rows(simple.data(), var.data());
+        kept_rows(kept.data());
+        for (size_t r = 0; r < mf; ++r) {
+            if (kept[r] >= 0) {
+                if (lbg) lbg[kept[r]] = lo[r];
+                if (ubg) ubg[kept[r]] = hi[r];
+            } else {
+                if (lbx) lbx[var[r]] = std::max(lbx[var[r]], lo[r]);
+                if (ubx) ubx[var[r]] = std::min(ubx[var[r]], hi[r]);
+            }
+        }
+    }
+    // row of THIS layout behind every row of the full list (-1: lifted); the identity for a full layout
+    void kept_rows(int32_t* kept) const {
+        for (const RowBlock& b : blocks)
+            for (int kk = 0; kk < b.nk; ++kk)
+                for (int i = 0; i < b.rows; ++i) kept[b.first_row + b.rows * kk + i] = row_of(b, kk, i);
+    }
+    // Canonical bounds of every row of the reference's subject_to list (CasADi Opti canon form), FULL numbering
+    void bounds_full(const double* p, double* lbg, double* ubg) const {
         const double inf = std::numeric_limits<double>::infinity();
         const ParamOffsets po(N);
         auto fill = [&](int kind, int c, auto fn) {
@@ -442,32 +529,21 @@ struct Layout {
         return p[fo + 79 + (r - 4)];
     }
     // rows that are exactly one decision variable (candidates for nlpsol detect_simple_bounds)
-    void simple_rows(int32_t* is_simple, int32_t* var) const {
-        for (int i = 0; i < m; ++i) { is_simple[i] = 0; var[i] = -1; }
-        auto mark = [&](int kind, int c, auto varfn) {
-            const int bi = blk[kind][c];
-            if (bi < 0) return;
-            const RowBlock& b = blocks[size_t(bi)];
-            for (int kk = 0; kk < b.nk; ++kk)
-                for (int i = 0; i < b.rows; ++i) {
-                    const int v = varfn(i);
-                    if (v < 0) continue;
-                    is_simple[b.first_row + b.rows * kk + i] = 1;
-                    var[b.first_row + b.rows * kk + i] = NXK * (b.k0 + kk) + v;
-                }
-        };
-        for (int c = 0; c < NC; ++c) {
-            mark(RK_FDYN_X0, c, [c](int i) { return PT_ * c + F_ + i; });
-            mark(RK_PDYN_X0, c, [c](int i) { return PT_ * c + P_ + i; });
-            mark(RK_UB, c, [c](int i) { return PT_ * c + U_ + i; });
-        }
-        mark(RK_PBDYN_X0, 0, [](int i) { return PB_ + i; });
-        mark(RK_QBDYN_X0, 0, [](int i) { return QB_ + i; });
-        mark(RK_SDYN_X0, 0, [](int i) { return S_ + i; });
-        mark(RK_COMDYN_X0, 0, [](int i) { return COM_ + i; });
-        mark(RK_JPB, 0, [](int i) { return S_ + i; });
-        mark(RK_JVB, 0, [](int i) { return SD_ + i; });
-        mark(RK_FIN, 0, [](int i) { int slot, desc; return final_row_var(i, &slot, &desc); });
+    void simple_rows(int32_t* is_simple, int32_t* var) const {   // (FULL numbering, whether or not this layout is lifted)
+        for (int i = 0; i < m_full; ++i) { is_simple[i] = 0; var[i] = -1; }
+        for (int kind = 0; kind < RK_COUNT; ++kind)
+            for (int c = 0; c < NC; ++c) {
+                const int bi = blk[kind][c];
+                if (bi < 0) continue;
+                const RowBlock& b = blocks[size_t(bi)];
+                for (int kk = 0; kk < b.nk; ++kk)
+                    for (int i = 0; i < b.rows; ++i) {
+                        const int v = simple_var(kind, c, i);
+                        if (v < 0) continue;
+                        is_simple[b.first_row + b.rows * kk + i] = 1;
+                        var[b.first_row + b.rows * kk + i] = NXK * (b.k0 + kk) + v;
+                    }
+            }
     }
 };
 

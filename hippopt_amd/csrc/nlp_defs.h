@@ -9,6 +9,7 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <limits.h>
 
 #include "../../include/hipnlp.h"
 
@@ -19,6 +20,11 @@
 #endif
 
 namespace hipnlp {
+
+// "no row" in the slot -> row tables (g_a).  A valid g_a may be NEGATIVE (row = g_a + g_b k, and a block that starts at knot 1 with
+// its first row at 0 — the lifted layout begins with one — has g_a = -g_b), so validity is a value of its own, not a sign.
+constexpr int32_t G_NONE = INT32_MIN;
+
 
 constexpr int NJ = HIPNLP_NJ, NL = HIPNLP_NL, NC = HIPNLP_NC, NXK = HIPNLP_NXK, NXG = HIPNLP_NXG;
 constexpr int LEG_PATH = 6;    // joints between root_link and each sole frame (ergoCub topology)

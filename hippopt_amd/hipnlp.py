@@ -15,8 +15,9 @@ _LIB_PATH = os.environ.get("HIPNLP_LIB_PATH") or os.path.join(os.path.dirname(os
 _lib = None
 
 EXPORTS = [
+    "hipnlp_abi_version", "hipnlp_build_info",
     "hipnlp_create", "hipnlp_destroy", "hipnlp_last_error", "hipnlp_get_dims", "hipnlp_set_params",
-    "hipnlp_bounds", "hipnlp_simple_rows", "hipnlp_sparsity", "hipnlp_eval", "hipnlp_eval_device",
+    "hipnlp_bounds", "hipnlp_simple_rows", "hipnlp_lift_map", "hipnlp_sparsity", "hipnlp_eval", "hipnlp_eval_device",
     "hipnlp_cost_terms", "hipnlp_cost_term_name", "hipnlp_num_row_blocks", "hipnlp_row_block",
     "hipnlp_last_kernel_ms", "hipnlp_profile_begin", "hipnlp_profile_end", "hipnlp_kernels_per_eval", "hipnlp_profile_begin_runs",
     "hipnlp_eval_device_shard", "hipnlp_stage_rows", "hipnlp_reassemble",
@@ -40,6 +41,11 @@ class HipNlpError(RuntimeError):
 
 def library_path():
     return _LIB_PATH
+
+
+def build_info():
+    """how the loaded library was built (hipnlp_build_info): recorded by bench.py beside every measurement"""
+    return load_library().hipnlp_build_info().decode()
 
 
 def load_library():
@@ -67,6 +73,10 @@ def load_library():
     lib.hipnlp_set_params.argtypes = [vp, dp]
     lib.hipnlp_bounds.argtypes = [vp, dp, dp, dp, dp]
     lib.hipnlp_simple_rows.argtypes = [vp, ip, ip]
+    lib.hipnlp_lift_map.argtypes = [vp, ip, dp, dp]
+    lib.hipnlp_build_info.restype = C.c_char_p
+    if lib.hipnlp_abi_version() != _abi.ABI_VERSION:
+        raise ImportError(f"{_LIB_PATH} implements ABI version {lib.hipnlp_abi_version()}, this package expects {_abi.ABI_VERSION}: rebuild the library")
     lib.hipnlp_sparsity.argtypes = [vp, ip, ip]
     lib.hipnlp_eval.argtypes = [vp, dp, C.c_int, dp, dp, dp, dp]
     lib.hipnlp_eval_device.argtypes = [vp, vp, vp, vp, vp, vp, vp]
@@ -130,8 +140,10 @@ def _ip(a):
 class HipNlp:
     """One engine handle: a kinodynamic NLP (settings + robot model) on one HIP device."""
 
-    def __init__(self, settings, model, batch=1, knot_begin=0, knot_end=0, device=0, desc=None):
-        """desc: a ready hipnlp_desc (e.g. hippopt_amd.from_reference.from_reference) instead of settings / model"""
+    def __init__(self, settings, model, batch=1, knot_begin=0, knot_end=0, device=0, desc=None, detect_simple_bounds=False):
+        """desc: a ready hipnlp_desc (e.g. hippopt_amd.from_reference.from_reference) instead of settings / model
+        detect_simple_bounds: the handle is the REDUCED NLP nlpsol hands to IPOPT under Opti's {"detect_simple_bounds": True}
+        (HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS): single-variable rows are bounds on x, not rows of g"""
         self.lib = load_library()
         if desc is not None:
             self.desc = desc
@@ -143,6 +155,7 @@ class HipNlp:
             self.desc.batch = int(batch)
             self.desc.knot_begin, self.desc.knot_end = int(knot_begin), int(knot_end)
             self.desc.device = int(device)
+            self.desc.flags = _abi.FLAG_DETECT_SIMPLE_BOUNDS if detect_simple_bounds else 0
         h = C.c_void_p()
         rc = self.lib.hipnlp_create(C.byref(self.desc), C.byref(h))
         if rc != 0:
@@ -153,6 +166,9 @@ class HipNlp:
         self.dims = d
         self.batch = int(batch)
         self.n, self.m, self.nnz, self.np = d.n, d.m, d.nnz, d.np
+        self.m_full, self.n_lifted = d.m_full, d.n_lifted
+        self.lifted = bool(self.desc.flags & _abi.FLAG_DETECT_SIMPLE_BOUNDS)
+        self.params_generation = 0   # bumped by set_params (what caches of parameter-dependent data key on)
 
     @classmethod
     def from_desc(cls, desc):
@@ -179,6 +195,7 @@ class HipNlp:
     def set_params(self, p):
         p = np.ascontiguousarray(p, dtype=np.float64).reshape(self.batch, self.np)
         self._check(self.lib.hipnlp_set_params(self.h, _dp(p)))
+        self.params_generation += 1
 
     def bounds(self):
         lbx, ubx, lbg, ubg = np.empty(self.n), np.empty(self.n), np.empty(self.m), np.empty(self.m)
@@ -186,9 +203,19 @@ class HipNlp:
         return lbx, ubx, lbg, ubg
 
     def simple_rows(self):
-        a, b = np.zeros(self.m, np.int32), np.zeros(self.m, np.int32)
+        """(is_simple, var_index) over the FULL subject_to list (m_full rows)"""
+        a, b = np.zeros(self.m_full, np.int32), np.zeros(self.m_full, np.int32)
         self._check(self.lib.hipnlp_simple_rows(self.h, _ip(a), _ip(b)))
         return a, b
+
+    def lift_map(self, with_bounds=True):
+        """(kept_row [m_full], lb_full, ub_full): this handle's row behind every row of the full list (-1: lifted into a bound) and the
+        canonical bounds of every full row (None without `with_bounds`; they need the parameters)"""
+        kept = np.zeros(self.m_full, np.int32)
+        lb = np.empty(self.m_full) if with_bounds else None
+        ub = np.empty(self.m_full) if with_bounds else None
+        self._check(self.lib.hipnlp_lift_map(self.h, _ip(kept), _dp(lb), _dp(ub)))
+        return kept, lb, ub
 
     def sparsity(self):
         ir, jc = np.zeros(self.nnz, np.int32), np.zeros(self.nnz, np.int32)
@@ -373,6 +400,9 @@ class HipPose:
         self._check(self.lib.hipnlp_pose_get_dims(self.h, C.byref(d)))
         self.batch = int(batch)
         self.n, self.m, self.nnz, self.np = d.n, d.m, d.nnz, d.np
+        self.m_full, self.n_lifted = d.m_full, d.n_lifted
+        self.lifted = bool(self.desc.flags & _abi.FLAG_DETECT_SIMPLE_BOUNDS)
+        self.params_generation = 0   # bumped by set_params (what caches of parameter-dependent data key on)
 
     @classmethod
     def from_desc(cls, desc):

@@ -77,62 +77,55 @@ class _PoseEngine:
 
 
 class _SimpleBoundsLift:
-    """What nlpsol's `detect_simple_bounds` does to the NLP before IPOPT sees it (the reference runs Opti with
-    {"expand": True, "detect_simple_bounds": True}, main_periodic_step.py:109-110): every row of g that is exactly ONE decision
-    variable — the u_v and joint position / velocity boxes of planner.py:386-405,699-719 (70 rows per interior knot), the `x_0 ==
-    initial_state` rows and the final-state rows — leaves g and its Jacobian and becomes a bound on that variable (lbx / ubx).
-    The engine keeps evaluating its full, fixed layout (`hipnlp_simple_rows` marks the rows); this wrapper presents the reduced
-    problem to the NLP driver: g and jac g restricted to the kept rows (index arrays computed once), the lifted bounds folded into
-    lbx / ubx, and the multipliers mapped back so that `Output.constraint_multipliers` still carries every named constraint: the
-    multiplier of a lifted row is the bound multiplier of its variable (z_U - z_L), given to the row whose bound is the active one."""
+    """The NLP as nlpsol's `detect_simple_bounds` presents it to IPOPT (the reference runs Opti with {"expand": True,
+    "detect_simple_bounds": True}, main_periodic_step.py:109-110): every row of g that is exactly ONE decision variable — the u_v and
+    joint position / velocity boxes of planner.py:386-405,699-719 (70 rows per interior knot), the `x_0 == initial_state` rows and the
+    final-state rows — is a bound on that variable (lbx / ubx), not a row of g.
+    The engine handle itself IS that reduced problem (HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS: the kernels neither compute nor move the
+    lifted rows; sizes, pattern, bounds, g, jac g and the Hessian's multipliers are the reduced ones): nothing is gathered on the
+    host.  What is left here is the way BACK for the multipliers, so that `Output.constraint_multipliers` still carries every named
+    constraint: the multiplier of a lifted row is the bound multiplier of its variable (z_U - z_L), given to the row whose bound is
+    the active one (`hipnlp_lift_map`)."""
 
     def __init__(self, eng):
+        if not getattr(eng, "lifted", False):
+            raise ValueError("the engine handle was not created with detect_simple_bounds")
         self._eng = eng
-        self.n, self.m_full = eng.n, eng.m
-        is_simple, var = eng.simple_rows()
-        self.lifted_rows = np.nonzero(is_simple)[0]
+        self.n, self.m, self.nnz, self.m_full = eng.n, eng.m, eng.nnz, eng.m_full
+        _, var = eng.simple_rows()
+        self.kept_row, _, _ = eng.lift_map(with_bounds=False)
+        self.keep_rows = np.nonzero(self.kept_row >= 0)[0]      # full rows that stay in g, in the reduced problem's order
+        self.lifted_rows = np.nonzero(self.kept_row < 0)[0]
         self.lifted_vars = var[self.lifted_rows].astype(np.int64)
-        self.keep_rows = np.nonzero(is_simple == 0)[0]
-        self.m = int(self.keep_rows.size)
-        new_row = np.full(self.m_full, -1, np.int64)
-        new_row[self.keep_rows] = np.arange(self.m)
-        ir, jc = eng.sparsity()
-        self.keep_entries = np.nonzero(new_row[ir] >= 0)[0]
-        self._ir = new_row[ir[self.keep_entries]].astype(np.int32)
-        self._jc = jc[self.keep_entries].astype(np.int32)
-        self.nnz = int(self.keep_entries.size)
-        self._lam_full = np.zeros(self.m_full)
+        self._snapshot = None   # (params generation, bounds of the lifted rows, bounds of their variables)
 
-    def __getattr__(self, name):   # cost_terms, row_blocks, hess_sparsity, set_params, ...: the engine's own
+    def __getattr__(self, name):   # bounds, sparsity, eval, eval_hess, cost_terms, row_blocks, set_params, ...: the engine's own
         return getattr(self._eng, name)
 
-    def bounds(self):
-        lbx, ubx, lbg, ubg = self._eng.bounds()
-        lbx, ubx = lbx.copy(), ubx.copy()
-        np.maximum.at(lbx, self.lifted_vars, lbg[self.lifted_rows])
-        np.minimum.at(ubx, self.lifted_vars, ubg[self.lifted_rows])
-        self._lbg_lift, self._ubg_lift, self._lbx, self._ubx = lbg[self.lifted_rows], ubg[self.lifted_rows], lbx, ubx
-        return lbx, ubx, lbg[self.keep_rows], ubg[self.keep_rows]
-
-    def sparsity(self):
-        return self._ir, self._jc
-
-    def eval(self, x, new_x=True, want=("f", "grad", "g", "jac"), nan_ok=False):
-        f, grad, g, jac = self._eng.eval(x, new_x=new_x, want=want, nan_ok=nan_ok)
-        return f, grad, (g[:, self.keep_rows] if g is not None else None), (jac[:, self.keep_entries] if jac is not None else None)
+    def _lifted_bounds(self):
+        """bounds of the lifted rows and of their variables for the engine's CURRENT parameters (taken again whenever set_params ran:
+        a snapshot made by an earlier bounds() call would assign multipliers by the previous initial / final state)"""
+        gen = getattr(self._eng, "params_generation", None)
+        if self._snapshot is None or gen is None or self._snapshot[0] != gen:
+            _, lb_full, ub_full = self._eng.lift_map(with_bounds=True)
+            lbx, ubx, _, _ = self._eng.bounds()
+            v = self.lifted_vars
+            self._snapshot = (gen, lb_full[self.lifted_rows], ub_full[self.lifted_rows], lbx[v], ubx[v])
+        return self._snapshot[1:]
 
     def full_multipliers(self, lam_reduced, lam_x=None):
-        """lambda over ALL rows of the engine's layout from the reduced problem's row multipliers and the multipliers lam_x of the
-        variable bounds (signed, Lagrangian f + lambda^T g + lam_x^T x: IPOPT's mult_x_U - mult_x_L).  The multiplier of a variable's
-        bound goes to the lifted row that defines the bound the variable ended up with (the first one, should several rows define
-        the same bound); the other lifted rows of that variable are inactive."""
+        """lambda over ALL rows of the reference's subject_to list from the reduced problem's row multipliers and the multipliers
+        lam_x of the variable bounds (signed, Lagrangian f + lambda^T g + lam_x^T x: IPOPT's mult_x_U - mult_x_L).  The multiplier of
+        a variable's bound goes to the lifted row that defines the bound the variable ended up with (the first one, should several
+        rows define the same bound); the other lifted rows of that variable are inactive."""
         lam = np.zeros(self.m_full)
         if lam_reduced is not None:
             lam[self.keep_rows] = np.asarray(lam_reduced, float).reshape(-1)
         if lam_x is not None:
             lx = np.asarray(lam_x, float).reshape(-1)
             v = self.lifted_vars
-            defines = np.where(lx[v] >= 0.0, self._ubg_lift <= self._ubx[v], self._lbg_lift >= self._lbx[v])
+            lb_row, ub_row, lb_var, ub_var = self._lifted_bounds()
+            defines = np.where(lx[v] >= 0.0, ub_row <= ub_var, lb_row >= lb_var)
             first = np.zeros(v.size, bool)
             seen = set()
             for i in np.nonzero(defines)[0]:
@@ -141,11 +134,6 @@ class _SimpleBoundsLift:
                     first[i] = True
             lam[self.lifted_rows] = np.where(first, lx[v], 0.0)
         return lam
-
-    def eval_hess(self, x, obj_factor, lam, out=None):
-        self._lam_full[:] = 0.0
-        self._lam_full[self.keep_rows] = np.asarray(lam, float).reshape(-1)   # lifted rows are linear: no second derivatives
-        return self._eng.eval_hess(x, obj_factor, self._lam_full[None, :])
 
 
 class _CallbackCache:
@@ -305,7 +293,7 @@ class HipNlpSolver:
             if self._problem_kind == "pose":
                 self._engine = _PoseEngine(HipPose(self._settings, self._model, batch=1, device=self._device))
             else:
-                self._engine = HipNlp(self._settings, self._model, batch=1, device=self._device)
+                self._engine = HipNlp(self._settings, self._model, batch=1, device=self._device, detect_simple_bounds=self._detect_simple_bounds)
         return self._engine
 
     def get_constraint_expressions(self):
@@ -327,9 +315,10 @@ class HipNlpSolver:
 
     # ---- solve --------------------------------------------------------------------------------------------
     def nlp_view(self):
-        """the engine as the NLP driver sees it: with the single-variable rows lifted into bounds when detect_simple_bounds is on"""
+        """the engine as the NLP driver sees it.  With detect_simple_bounds the handle is the reduced problem (single-variable rows
+        are bounds) and the view adds the way back from its multipliers to every named constraint."""
         eng = self.engine()
-        if self._detect_simple_bounds:
+        if getattr(eng, "lifted", False):
             if self._lift is None or self._lift._eng is not eng:
                 self._lift = _SimpleBoundsLift(eng)
             return self._lift
@@ -372,7 +361,7 @@ class HipNlpSolver:
                 x, lam, info = self._solve_scipy(eng, x0, lbx, ubx, lbg, ubg, ir, jc)
             lam = self._expand_multipliers(eng, lam, info.get("lam_x"))
             info["callbacks"] = dict(self._cache.calls, evaluations=self._cache.evaluations)
-            info["nlp"] = {"n": eng.n, "m": eng.m, "nnz": int(len(ir)), "simple_bounds_lifted": int(full.m - eng.m)}
+            info["nlp"] = {"n": eng.n, "m": eng.m, "nnz": int(len(ir)), "simple_bounds_lifted": int(getattr(full, "m_full", full.m) - eng.m)}
             if self._error_on_fail and not info.get("success", True):
                 failure = RuntimeError("solver status: " + str(info.get("message", info.get("status"))))
         except Exception as err:  # noqa: BLE001
@@ -385,12 +374,12 @@ class HipNlpSolver:
             self._logger.warning("The solver failed to solve the problem, but the callback managed to save an intermediate "
                                  f"solution at iteration {cb.best_iteration}.")
             x = cb.best_x
-            lam = cb.best_constraint_multipliers if cb.best_constraint_multipliers is not None else np.zeros(full.m)
+            lam = cb.best_constraint_multipliers if cb.best_constraint_multipliers is not None else np.zeros(getattr(full, "m_full", full.m))
             self._cost_value = float(cb.best_cost)
             self._cost_values = dict(cb.best_cost_values) if self._callback_save_costs else {}
             self._store_solution(full, x, lam, with_multipliers=self._callback_save_constraint_multipliers)
             return
-        f, grad, g, jac = full.eval(x[None, :])
+        f, *_ = full.eval(x[None, :], want=("f",))
         self._cost_value = float(f[0])
         names, terms = full.cost_terms()
         self._cost_values = {n: float(v) for n, v in zip(names, terms[0])}
@@ -416,7 +405,7 @@ class HipNlpSolver:
 
     def _iterate_callback(self, iteration, x, cost, inf_pr, multipliers, lam_x=None):
         if self._callback is not None:
-            if multipliers is not None and self._lift is not None and self._detect_simple_bounds:
+            if multipliers is not None and self._lift is not None and getattr(self.engine(), "lifted", False):
                 multipliers = self._lift.full_multipliers(multipliers, lam_x)
             self._callback(IterateInfo(int(iteration), float(cost), float(inf_pr)), x, multipliers,
                            (lambda: self._cost_values_at(np.asarray(x, float))) if self._callback_save_costs else None)

@@ -43,6 +43,12 @@
 extern "C" {
 #endif
 
+/* ABI version of this header.  The caller stores it in hipnlp_desc.abi_version / hipnlp_pose_desc.abi_version; hipnlp_create and
+ * hipnlp_pose_create refuse a descriptor built against another version (a C caller compiled against an older header would pass a
+ * shorter struct).  History: 1 = rounds 1-2 (no version field); 2 = abi_version + flags in the descriptors, m_full / n_lifted in
+ * hipnlp_dims, detect_simple_bounds layout, resident callback kernel, IPOPT callback quartet (hipnlp_ipopt.h).                  */
+#define HIPNLP_ABI_VERSION 2
+
 #define HIPNLP_NJ 23        /* actuated joints (ergoCub: torso 3, arms 4+4, legs 6+6) */
 #define HIPNLP_NL 24        /* links = root + one per joint                            */
 #define HIPNLP_NC 8         /* contact points: left[0..3], right[0..3]                 */
@@ -90,7 +96,8 @@ typedef struct hipnlp_terrain_step {
 
 /*
  * Kinematic tree, adam-robotics conventions:
- *   child link of joint j is link j+1; parent[j] < j+1 (topological order); link 0 = root_link.
+ *   child link of joint j is link j+1; parent[j] is ANY other link of a tree rooted at link 0 = root_link (the joint order is the
+ *   reference's joints_name_list order, which fixes the x layout and need not follow the tree; chains of at most 8 joints).
  *   parent_T_child(s_j) = [ R_fix[j] * Rot(axis[j], s_j) , o_fix[j] ]   (URDF origin xyz/rpy, then axis rotation)
  *   inertials are expressed in the link frame: mass, com, 3x3 inertia about the com (row-major).
  *   frames: rigidly attached to frame_link[f] with link_T_frame = [frame_R[f], frame_o[f]].
@@ -155,7 +162,20 @@ typedef struct hipnlp_desc {
     int32_t knot_begin;  /* shard: this handle evaluates knots [knot_begin, knot_end) of every trajectory   */
     int32_t knot_end;    /*        (0, horizon) = whole horizon.  See DESIGN.md §6 (multi-GPU)              */
     int32_t device;      /* HIP device ordinal                                                               */
+    int32_t abi_version; /* HIPNLP_ABI_VERSION of the header the caller was compiled against (checked by hipnlp_create) */
+    int32_t flags;       /* HIPNLP_FLAG_*                                                                     */
 } hipnlp_desc;
+
+/* hipnlp_desc.flags
+ *   DETECT_SIMPLE_BOUNDS  the handle IS the NLP nlpsol hands to IPOPT when Opti runs with {"detect_simple_bounds": True}
+ *                         (main_periodic_step.py:109-110): every row of g that is exactly one decision variable — the u_v and
+ *                         joint position / velocity boxes (planner.py:386-405,699-719; 70 rows per interior knot), the
+ *                         `x_0 == initial_state` rows, the final-state rows that hold a variable — leaves g and jac g and becomes a
+ *                         bound on that variable: m, nnz, the sparsity pattern, g, jac g, lbg / ubg and the multipliers of
+ *                         hipnlp_eval_hess are those of the REDUCED problem, lbx / ubx carry the lifted bounds; the kernels never
+ *                         compute or move the lifted rows.  hipnlp_lift_map relates the reduced rows to the reference's full list
+ *                         of named constraints (hipnlp_row_block stays in full numbering).                                        */
+#define HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS 1
 
 typedef struct hipnlp_dims {
     int32_t n;        /* decision variables per trajectory = 189*N + 6                */
@@ -170,10 +190,14 @@ typedef struct hipnlp_dims {
     int32_t shard_grad;     /* grad entries written by this handle  */
     int32_t shard_jac_off;  /* offset of the handle's jac block in the CCS value array */
     int32_t shard_grad_off; /* offset of the handle's block in grad f                  */
+    int32_t m_full;         /* rows of the reference's full subject_to list (== m without DETECT_SIMPLE_BOUNDS)   */
+    int32_t n_lifted;       /* rows of that list that are exactly one decision variable (m_full - n_lifted = m when lifted) */
 } hipnlp_dims;
 
 typedef struct hipnlp_handle hipnlp_handle;
 
+int hipnlp_abi_version(void);            /* HIPNLP_ABI_VERSION the library was built with */
+const char* hipnlp_build_info(void);     /* how the library was built (e.g. "gfx950; ds_read2_b64 split in the assembly" or "gfx950; plain hipcc") */
 int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out);
 void hipnlp_destroy(hipnlp_handle* h);
 const char* hipnlp_last_error(const hipnlp_handle* h); /* h may be NULL: last create() error */
@@ -183,13 +207,20 @@ int hipnlp_get_dims(const hipnlp_handle* h, hipnlp_dims* out);
 int hipnlp_set_params(hipnlp_handle* h, const double* p);
 
 /* Canonical bounds (CasADi Opti canon form), valid after set_params.  Any pointer may be NULL.
- * lbx/ubx: [n] (+-inf: the reference adds no explicit variable bounds; see hipnlp_simple_rows)
+ * lbx/ubx: [n] (+-inf: the reference adds no explicit variable bounds; with DETECT_SIMPLE_BOUNDS: the bounds of the lifted rows)
  * lbg/ubg: [m] of trajectory 0 (bounds depend on parameters only)                              */
 int hipnlp_bounds(const hipnlp_handle* h, double* lbx, double* ubx, double* lbg, double* ubg);
 
-/* is_simple[m]: 1 where row i of g is exactly one decision variable (candidate for
- * nlpsol's detect_simple_bounds, main_periodic_step.py:110); var_index[m]: that variable or -1. */
+/* is_simple[m_full]: 1 where row i of the FULL subject_to list is exactly one decision variable (what nlpsol's
+ * detect_simple_bounds lifts, main_periodic_step.py:110); var_index[m_full]: that variable or -1. */
 int hipnlp_simple_rows(const hipnlp_handle* h, int32_t* is_simple, int32_t* var_index);
+/* The handle's rows against the reference's full list of named constraints (hipnlp_row_block): kept_row[m_full] = row of this
+ * handle's g behind full row r, or -1 when the row was lifted into a bound (identity without DETECT_SIMPLE_BOUNDS);
+ * lb_full / ub_full [m_full] = canonical bounds of every full row (valid after set_params).  What a binding needs to hand
+ * IPOPT's multipliers back per named constraint (Output.constraint_multipliers, opti_solver.py:530-537): lambda of a kept row is
+ * lambda[kept_row]; the multiplier of a lifted row is the bound multiplier z_U - z_L of its variable (hipnlp_simple_rows), given
+ * to the row whose bound is the active one.  Any pointer may be NULL. */
+int hipnlp_lift_map(const hipnlp_handle* h, int32_t* kept_row, double* lb_full, double* ub_full);
 
 /* CCS pattern as triplets sorted by (col,row): irow[nnz], jcol[nnz] (IPOPT eval_jac_g, values==NULL call) */
 int hipnlp_sparsity(const hipnlp_handle* h, int32_t* irow, int32_t* jcol);
@@ -329,7 +360,8 @@ int hipnlp_eval_device_peers(hipnlp_handle* h, const double* x_dev, double* cons
 int hipnlp_cost_terms(hipnlp_handle* h, double* values);
 const char* hipnlp_cost_term_name(int i);
 
-/* Row-block directory: name (reference constraint base name), first row, rows per knot, first knot, knots. */
+/* Row-block directory: name (reference constraint base name), first row, rows per knot, first knot, knots — in the numbering of the
+ * FULL subject_to list (m_full rows), whether or not the handle was created with DETECT_SIMPLE_BOUNDS. */
 int hipnlp_num_row_blocks(const hipnlp_handle* h);
 int hipnlp_row_block(const hipnlp_handle* h, int i, const char** name,
                      int32_t* first_row, int32_t* rows_per_knot, int32_t* first_knot, int32_t* n_knots);
@@ -414,6 +446,8 @@ typedef struct hipnlp_pose_desc {
     hipnlp_robot_model model;
     int32_t batch;    /* independent poses per call (>= 1) */
     int32_t device;
+    int32_t abi_version;   /* HIPNLP_ABI_VERSION (checked by hipnlp_pose_create) */
+    int32_t flags;         /* none defined: 0 */
 } hipnlp_pose_desc;
 
 typedef struct hipnlp_pose_dims { int32_t n, m, nnz, np; } hipnlp_pose_dims;

@@ -116,7 +116,7 @@ template <int LAYOUT> static int eval_compact(const hostemu_handle* h, const dou
         if (k == N - 1) for (size_t i = 0; i < L.jperm_glob.size(); ++i) jac[L.jac_glob_base + long(i)] = s->jac[L.jperm_glob[i]];
         for (int slot = 0; slot < gs::COUNT; ++slot) {
             const int a = L.g_a[v][size_t(slot)];
-            if (a >= 0) g[a + L.g_b[size_t(slot)] * k] = s->g_at(slot);
+            if (a != G_NONE) g[a + L.g_b[size_t(slot)] * k] = s->g_at(slot);
         }
         for (int i = 0; i < NXK; ++i) grad[NXK * k + i] = s->grad[i];
         for (int i = 0; i < NCT; ++i) cost_terms[i] += s->cost[i];
@@ -175,7 +175,7 @@ template <int WAVES, int TERRAIN> static int eval_wave_order_t(const hostemu_han
         if (k == N - 1) for (size_t i = 0; i < L.jperm_glob.size(); ++i) jac[L.jac_glob_base + long(i)] = s->jac[L.jperm_glob[i]];
         for (int slot = 0; slot < gs::COUNT; ++slot) {
             const int a = L.g_a[v][size_t(slot)];
-            if (a >= 0) g[a + L.g_b[size_t(slot)] * k] = s->g[slot];
+            if (a != G_NONE) g[a + L.g_b[size_t(slot)] * k] = s->g[slot];
         }
         for (int i = 0; i < NXK; ++i) grad[NXK * k + i] = s->grad[i];
         for (int i = 0; i < NCT; ++i) cost_terms[i] += s->cost[i];
@@ -195,7 +195,7 @@ hostemu_handle* hostemu_create(const hipnlp_desc* desc, char* err, int errlen) {
     hostemu_handle* h = new hostemu_handle();
     h->d = *desc;
     std::string e;
-    if (!Layout::make_kin_tables(desc->model, h->kt, e) || !h->L.build(desc->settings, h->kt)) {
+    if (!Layout::make_kin_tables(desc->model, h->kt, e) || !h->L.build(desc->settings, h->kt, (desc->flags & HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS) != 0)) {
         if (e.empty()) e = h->L.error;
         std::strncpy(err, e.c_str(), size_t(errlen - 1));
         delete h;
@@ -231,15 +231,15 @@ void hostemu_hess(const hostemu_handle* h, const double* x, const double* p, dou
         const int v = L.variant_of(k);
         for (int i = 0; i < 3; ++i) {
             const int slot = gs::HDYN + 3 + i, vn = L.variant_of(k + 1);
-            const int a = k + 1 < N ? L.g_a[vn][size_t(slot)] : -1;
-            hx->lam_next[i] = a >= 0 ? lambda[a + L.g_b[size_t(slot)] * (k + 1)] : 0.0;
+            const int a = k + 1 < N ? L.g_a[vn][size_t(slot)] : G_NONE;
+            hx->lam_next[i] = a != G_NONE ? lambda[a + L.g_b[size_t(slot)] * (k + 1)] : 0.0;
         }
         hx->sigma = sigma;
         KnotInfo ki{k, N, k == 0, k == N - 1};
         ValueEm em{s->g, s->jac, hx->H};
         Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
         // multipliers by native slot, in the g staging area of the scratch (the Hessian program emits no g)
-        for (int slot = 0; slot < gs::COUNT; ++slot) { const int a = L.g_a[v][size_t(slot)]; s->g[slot] = a >= 0 ? lambda[a + L.g_b[size_t(slot)] * k] : 0.0; }
+        for (int slot = 0; slot < gs::COUNT; ++slot) { const int a = L.g_a[v][size_t(slot)]; s->g[slot] = a != G_NONE ? lambda[a + L.g_b[size_t(slot)] * k] : 0.0; }
         KHCtx<ValueEm> hcx{cx, *hx, s->g};
         if (g_wave_order < 0) {
 #define HOST_KIN(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
@@ -270,7 +270,10 @@ void hostemu_dims(const hostemu_handle* h, int* n, int* m, int* nnz) { *n = h->L
 void hostemu_sparsity(const hostemu_handle* h, int* irow, int* jcol) {
     for (int i = 0; i < h->L.nnz; ++i) { irow[i] = h->L.irow[size_t(i)]; jcol[i] = h->L.jcol[size_t(i)]; }
 }
-void hostemu_bounds(const hostemu_handle* h, const double* p, double* lbg, double* ubg) { h->L.bounds(p, lbg, ubg); }
+void hostemu_bounds(const hostemu_handle* h, const double* p, double* lbg, double* ubg) { h->L.bounds(p, nullptr, nullptr, lbg, ubg); }
+void hostemu_bounds_x(const hostemu_handle* h, const double* p, double* lbx, double* ubx) { h->L.bounds(p, lbx, ubx, nullptr, nullptr); }
+void hostemu_lift_map(const hostemu_handle* h, int* kept_row) { h->L.kept_rows(kept_row); }
+int hostemu_m_full(const hostemu_handle* h) { return h->L.m_full; }
 void hostemu_simple_rows(const hostemu_handle* h, int* is_simple, int* var) { h->L.simple_rows(is_simple, var); }
 int hostemu_num_row_blocks(const hostemu_handle* h) { return int(h->L.blocks.size()); }
 void hostemu_row_block(const hostemu_handle* h, int i, const char** name, int* first, int* rows, int* k0, int* nk) {
@@ -280,7 +283,7 @@ void hostemu_row_block(const hostemu_handle* h, int i, const char** name, int* f
 
 void hostemu_stage_rows(const hostemu_handle* h, int k, int* rows) {
     const int v = h->L.variant_of(k);
-    for (int s = 0; s < gs::COUNT; ++s) { const int a = h->L.g_a[v][size_t(s)]; rows[s] = a >= 0 ? a + h->L.g_b[size_t(s)] * k : -1; }
+    for (int s = 0; s < gs::COUNT; ++s) { const int a = h->L.g_a[v][size_t(s)]; rows[s] = a != G_NONE ? a + h->L.g_b[size_t(s)] * k : -1; }
 }
 
 void hostemu_eval(const hostemu_handle* h, const double* x, const double* p, double* f, double* grad, double* g, double* jac, double* cost_terms) {
@@ -316,7 +319,7 @@ void hostemu_eval(const hostemu_handle* h, const double* x, const double* p, dou
         if (k == N - 1) for (size_t i = 0; i < L.jperm_glob.size(); ++i) jac[L.jac_glob_base + long(i)] = s->jac[L.jperm_glob[i]];
         for (int slot = 0; slot < gs::COUNT; ++slot) {
             const int a = L.g_a[v][size_t(slot)];
-            if (a >= 0) g[a + L.g_b[size_t(slot)] * k] = s->g[slot];
+            if (a != G_NONE) g[a + L.g_b[size_t(slot)] * k] = s->g[slot];
         }
         for (int i = 0; i < NXK; ++i) grad[NXK * k + i] = s->grad[i];
         for (int i = 0; i < NCT; ++i) cost_terms[i] += s->cost[i];

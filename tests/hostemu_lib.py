@@ -29,7 +29,7 @@ def _ip(a):
 
 
 class HostEmu:
-    def __init__(self, settings, model):
+    def __init__(self, settings, model, detect_simple_bounds=False):
         self.lib = C.CDLL(build())
         self.lib.hostemu_create.restype = C.c_void_p
         self.desc = _abi.DescC()
@@ -37,6 +37,7 @@ class HostEmu:
         self.desc.model = model.to_c()
         self.desc.batch = 1
         self.desc.knot_begin, self.desc.knot_end = 0, settings.horizon_length
+        self.desc.flags = _abi.FLAG_DETECT_SIMPLE_BOUNDS if detect_simple_bounds else 0
         err = C.create_string_buffer(256)
         self.h = self.lib.hostemu_create(C.byref(self.desc), err, 256)
         if not self.h:
@@ -54,6 +55,17 @@ class HostEmu:
         lb, ub = np.zeros(self.m), np.zeros(self.m)
         self.lib.hostemu_bounds(C.c_void_p(self.h), _dp(np.ascontiguousarray(p)), _dp(lb), _dp(ub))
         return lb, ub
+
+    def bounds_x(self, p):
+        lb, ub = np.zeros(self.n), np.zeros(self.n)
+        self.lib.hostemu_bounds_x(C.c_void_p(self.h), _dp(np.ascontiguousarray(p)), _dp(lb), _dp(ub))
+        return lb, ub
+
+    def kept_rows(self):
+        """row of this layout behind every row of the full subject_to list (-1: lifted into a bound)"""
+        out = np.zeros(self.lib.hostemu_m_full(C.c_void_p(self.h)), np.int32)
+        self.lib.hostemu_lift_map(C.c_void_p(self.h), _ip(out))
+        return out
 
     def row_blocks(self):
         out = []
@@ -122,7 +134,7 @@ _hostemu_hess_methods()
 class PoseHostEmu:
     """Host emulation of the pose program (pose_body.h) + the pose layout tables."""
 
-    def __init__(self, settings, model):
+    def __init__(self, settings, model, detect_simple_bounds=False):
         self.lib = C.CDLL(build())
         self.lib.hostemu_pose_create.restype = C.c_void_p
         self.desc = _abi.PoseDescC()

@@ -27,12 +27,50 @@ def test_header_symbols_are_exported():
     assert sorted(hipnlp.EXPORTS) == names
 
 
-def test_struct_sizes_match_header():
-    # the ctypes mirrors must have the C layout: robot model = 23 ints + 3 ints (+pad) + doubles
-    assert C.sizeof(_abi.RobotModelC) % 8 == 0
-    n_double = 23 * 9 + 23 * 3 + 23 * 3 + 24 + 24 * 3 + 24 * 9 + 3 * 9 + 3 * 3
-    assert C.sizeof(_abi.RobotModelC) == 8 * n_double + 4 * 24 + 4 * 4  # parent[23]+pad, frame_link[3]+pad
-    assert C.sizeof(_abi.DimsC) == 44
+def test_struct_layouts_match_the_c_header(tmp_path):
+    """sizes and member offsets as a C compiler lays include/hipnlp.h out, against the ctypes mirrors (a caller built against the
+    header and this package must agree byte for byte)"""
+    import subprocess
+    probes = [("hipnlp_robot_model", _abi.RobotModelC, ["parent", "R_fix", "mass", "frame_link", "frame_o"]),
+              ("hipnlp_terrain_step", _abi.TerrainStepC, ["position", "edge_sharpness"]),
+              ("hipnlp_settings", _abi.SettingsC, ["yaw_corner", "final_state_weight", "joint_regularization_cost_weights", "n_terrain_steps", "terrain_steps"]),
+              ("hipnlp_desc", _abi.DescC, ["model", "batch", "device", "abi_version", "flags"]),
+              ("hipnlp_dims", _abi.DimsC, ["nnz_knot", "shard_grad_off", "m_full", "n_lifted"]),
+              ("hipnlp_pose_settings", _abi.PoseSettingsC, ["com_position_type", "base_quaternion_cost_multiplier", "hand_type", "hand_regularization_cost_multiplier"]),
+              ("hipnlp_pose_desc", _abi.PoseDescC, ["model", "batch", "abi_version", "flags"]),
+              ("hipnlp_pose_dims", _abi.PoseDimsC, ["np"])]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hipnlp.h"', 'int main(void) {', '  printf("%d\\n", HIPNLP_ABI_VERSION);']
+    for cname, _, members in probes:
+        lines.append('  printf("%%zu\\n", sizeof(%s));' % cname)
+        lines += ['  printf("%%zu\\n", offsetof(%s, %s));' % (cname, m) for m in members]
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "abi_probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi_probe"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    out = iter(int(v) for v in subprocess.check_output([str(exe)]).split())
+    assert next(out) == _abi.ABI_VERSION == hipnlp.load_library().hipnlp_abi_version()
+    for cname, mirror, members in probes:
+        assert next(out) == C.sizeof(mirror), cname
+        for m in members:
+            assert next(out) == getattr(mirror, m).offset, (cname, m)
+
+
+def test_descriptor_of_another_abi_version_is_refused(model):
+    """hipnlp_create / hipnlp_pose_create check desc.abi_version before anything else (no device needed to be told)"""
+    from hippopt_amd.pose_settings import pose_finder_settings
+    lib = hipnlp.load_library()
+    desc = _abi.DescC()
+    desc.settings, desc.model, desc.batch = periodic_step_settings(4, model).to_c(), model.to_c(), 1
+    pose = _abi.PoseDescC()
+    pose.settings, pose.model, pose.batch = pose_finder_settings(model).to_c(), model.to_c(), 1
+    for d, create, last in ((desc, lib.hipnlp_create, lib.hipnlp_last_error), (pose, lib.hipnlp_pose_create, lib.hipnlp_pose_last_error)):
+        for version in (0, 1, _abi.ABI_VERSION + 1):
+            d.abi_version = version
+            h = C.c_void_p()
+            assert create(C.byref(d), C.byref(h)) == _abi.E_INVALID and not h.value
+            assert b"abi_version" in last(None)
+    assert "gfx950" in hipnlp.build_info()
 
 
 def test_no_device_is_a_loud_error(model):

@@ -338,11 +338,60 @@ def test_planner_solve_plumbing(model):
     info = pl.optimization_solver._last_info
     assert info["constr_violation"] < viol0
     # detect_simple_bounds (main_periodic_step.py:109-110): the driver saw the reduced problem, the output still names every constraint
-    assert info["nlp"]["simple_bounds_lifted"] == 70 * 2 + 47 + 81 and info["nlp"]["m"] == eng.m - info["nlp"]["simple_bounds_lifted"]
+    assert eng.lifted and info["nlp"]["simple_bounds_lifted"] == 70 * 2 + 47 + 81 == eng.m_full - eng.m and info["nlp"]["m"] == eng.m
     assert out.constraint_multipliers["joint_velocity_bounds"].shape == (3, 23) and info["callbacks"]["evaluations"] > 0
     full = Planner(st, model, error_on_fail=False)
     full.optimization_solver._detect_simple_bounds = False
     assert full.optimization_solver.nlp_view() is full.optimization_solver.engine()
+
+
+@pytest.mark.parametrize("maker,horizon,batch", [(periodic_step_settings, 100, 1), (periodic_step_settings, 9, 70), (single_step_settings, 2, 3),
+                                                  (stairs_settings, 12, 2), (stairs_settings, 7, 90)])
+def test_detect_simple_bounds_handle_is_the_reduced_problem(model, HipNlp, maker, horizon, batch):
+    """HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS: the handle evaluates the NLP nlpsol hands to IPOPT under {"detect_simple_bounds": True}
+    (main_periodic_step.py:109-110).  Against the full handle on the same inputs, both kernel variants and both terrains: g, jac g,
+    the pattern and the row bounds are the full problem's with the single-variable rows taken out (bitwise), the variable bounds are
+    those rows' bounds, f and grad f are unchanged, and the exact Hessian takes the reduced multipliers."""
+    st = maker(horizon, model)
+    x, p = make_workload(st, model, batch=batch, seed=4100 + horizon)
+    full, red = HipNlp(st, model, batch=batch), HipNlp(st, model, batch=batch, detect_simple_bounds=True)
+    full.set_params(p)
+    red.set_params(p)
+    simple, var = full.simple_rows()
+    kept, lb_full, ub_full = red.lift_map()
+    keep_rows = np.nonzero(simple == 0)[0]
+    assert red.lifted and not full.lifted and red.m_full == full.m == full.m_full and red.n_lifted == int(simple.sum())
+    assert np.array_equal(np.nonzero(kept >= 0)[0], keep_rows) and np.array_equal(kept[keep_rows], np.arange(red.m))
+    ir, jc = full.sparsity()
+    irr, jcr = red.sparsity()
+    keep_entries = np.nonzero(simple[ir] == 0)[0]
+    assert np.array_equal(keep_rows[irr], ir[keep_entries]) and np.array_equal(jcr, jc[keep_entries])
+    lbx, ubx, lbg, ubg = red.bounds()
+    _, _, lbg_f, ubg_f = full.bounds()
+    assert np.array_equal(lbg, lbg_f[keep_rows]) and np.array_equal(ubg, ubg_f[keep_rows]) and np.array_equal(lb_full, lbg_f) and np.array_equal(ub_full, ubg_f)
+    lifted = np.nonzero(simple)[0]
+    rl, ru = np.full(full.n, -np.inf), np.full(full.n, np.inf)
+    np.maximum.at(rl, var[lifted], lbg_f[lifted])
+    np.minimum.at(ru, var[lifted], ubg_f[lifted])
+    assert np.array_equal(lbx, rl) and np.array_equal(ubx, ru)
+    f, grad, g, jac = red.eval(x)
+    ff, gradf, gf, jacf = full.eval(x)
+    assert np.array_equal(f, ff) and np.array_equal(grad, gradf)
+    assert np.array_equal(g, gf[:, keep_rows]) and np.array_equal(jac, jacf[:, keep_entries])
+    # a trial-point call (f + g only) and a cached Jacobian request on the reduced handle
+    x2 = x + 1e-3
+    f2, _, g2, _ = red.eval(x2, want=("f", "g"))
+    _, _, _, j2 = red.eval(x2, new_x=False, want=("jac",))
+    ff2, _, gf2, jf2 = full.eval(x2)
+    assert np.array_equal(f2, ff2) and np.array_equal(g2, gf2[:, keep_rows]) and np.array_equal(j2, jf2[:, keep_entries])
+    # exact Hessian: the lifted rows are linear, their multipliers do not exist in the reduced problem
+    lam = np.random.RandomState(5).standard_normal((batch, red.m))
+    lam_full = np.zeros((batch, full.m))
+    lam_full[:, keep_rows] = lam
+    hr, hc = red.hess_sparsity()
+    hrf, hcf = full.hess_sparsity()
+    assert np.array_equal(hr, hrf) and np.array_equal(hc, hcf)
+    assert np.array_equal(red.eval_hess(x, 0.7, lam), full.eval_hess(x, 0.7, lam_full))
 
 
 def test_in_launch_reduction_stress(model, HipNlp):

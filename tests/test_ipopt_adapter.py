@@ -29,7 +29,7 @@ def test_ipopt_driver_end_to_end_on_the_emulated_engine(model, cyipopt_standin):
                                use_opti_callback=True, acceptable_constraint_violation=np.inf)
     pl = Planner(st, model, inner_solver="auto", error_on_fail=False)
     sol = pl.optimization_solver
-    emu = EmuEngine(st, model)
+    emu = EmuEngine(st, model, detect_simple_bounds=True)   # the handle HipNlpSolver creates: the reduced NLP (HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS)
     sol.engine = lambda: emu                      # the engine handle, emulated on the host
     x, p = make_workload(st, model, batch=1, seed=8)
     guess = pl.get_initial_guess()
@@ -48,5 +48,5 @@ def test_ipopt_driver_end_to_end_on_the_emulated_engine(model, cyipopt_standin):
     assert out.constraint_multipliers["joint_velocity_bounds"].shape == (N, 23)                 # lifted rows got their multipliers back
     assert out.constraint_multipliers["joint_position_dynamics"].shape == (N - 1, 23)
     cb = sol._callback
-    assert cb.best_iteration is not None and cb.best_constraint_multipliers.size == emu.m      # best-iterate store fed from intermediate()
+    assert cb.best_iteration is not None and cb.best_constraint_multipliers.size == emu.m_full      # best-iterate store fed from intermediate()
     assert np.isfinite(out.cost_value)
