@@ -200,9 +200,13 @@ def time_hessian(eng, x_np, knots):
     return res
 
 
-def host_visible(eng, x_np, horizon, batch):
+def host_visible(eng, x_np, horizon, batch, st=None, model=None):
     """The rate at the boundary IPOPT binds: hipnlp_eval with host buffers, per callback kind (the call's non-NULL outputs are its
-    want mask).  x changes on every call (new_x = 1), caller-owned output arrays reused as IPOPT's are.  Never `value`."""
+    want mask).  x changes on every call (new_x = 1), caller-owned output arrays reused as IPOPT's are.  Never `value`.
+    Legs: plain caller arrays with the library's defaults (arrays seen twice in a row are registered by the handle itself and become
+    direct kernel outputs), the same with auto-registration off (every output through the pinned block + a host copy), the resident
+    callback kernel (hipnlp_set_resident), an IPOPT iterate as four calls (raw C-ABI calls from Python), and the same iterate through
+    the product's own Python solver path (HipNlpSolver's callback objects: what cyipopt / SciPy are handed)."""
     import numpy as np
     rng = np.random.RandomState(11)
     xs = [x_np + 1e-3 * i * rng.standard_normal(x_np.shape) for i in range(4)]
@@ -210,6 +214,7 @@ def host_visible(eng, x_np, horizon, batch):
     kinds = {"f": ("f",), "g": ("g",), "grad": ("grad",), "jac": ("jac",), "f+g (trial point)": ("f", "g"), "all": ("f", "grad", "g", "jac")}
     res = {}
     eng.set_prefetch(())   # exactly what the call asks for crosses PCIe
+
     def best_of(fn, passes=3, calls=100):
         """ms per call: the fastest of `passes` passes of `calls` calls (wall-clock loops of ~30 us calls pick up transient host
         effects — one pass of a fresh process ran 8x slower than its neighbours with the library's own share unchanged)"""
@@ -222,17 +227,38 @@ def host_visible(eng, x_np, horizon, batch):
                 fn(i)
             best = min(best, (time.perf_counter() - t0) / calls)
         return 1e3 * best
-    for name, want in kinds.items():
-        out = tuple(o if k in want else None for k, o in zip(("f", "grad", "g", "jac"), outs))
-        res[name] = {"ms_per_call": best_of(lambda i: eng.eval(xs[i % 4], want=want, out=out)),
-                     "library_us [x staging, enqueue, wait for the GPU, copies out]": [round(float(v), 2) for v in eng.host_breakdown()]}
+
+    def sweep(tag, names=kinds):
+        for name in names:
+            want = kinds[name]
+            out = tuple(o if k in want else None for k, o in zip(("f", "grad", "g", "jac"), outs))
+            res[name + tag] = {"ms_per_call": best_of(lambda i: eng.eval(xs[i % 4], want=want, out=out)),
+                               "library_us [x staging, enqueue, wait for the GPU, copies out]": [round(float(v), 2) for v in eng.host_breakdown()]}
+    # the library's defaults: plain numpy arrays, nothing registered by the caller
+    sweep("")
+    res["all"]["note"] = "plain caller arrays, library defaults: the handle registers arrays it sees twice in a row (hipnlp_set_auto_register, verified at every use)"
+    eng.set_auto_register(False)
+    sweep(" (auto-registration off: pinned block + host copy)", ("f", "g", "jac", "all"))
     res["all (zero-copy views of the pinned block)"] = {"ms_per_call": best_of(lambda i: eng.eval_pinned(xs[i % 4]))}
-    # caller arrays registered with the library once (hipnlp_host_register): the kernel stores straight into them, no staging copy
+    eng.set_auto_register(True)
+    # caller arrays registered with the library explicitly (hipnlp_host_register): the kernel stores straight into them, no staging copy
     eng.register_outputs(outs)
     try:
         for name, want in (("g", ("g",)), ("jac", ("jac",)), ("all", ("f", "grad", "g", "jac"))):
             out = tuple(o if k in want else None for k, o in zip(("f", "grad", "g", "jac"), outs))
             res[name + " (caller arrays registered: direct kernel stores)"] = {"ms_per_call": best_of(lambda i: eng.eval(xs[i % 4], want=want, out=out))}
+        # the resident callback kernel: no launch, no stream synchronisation per call (doorbell + completion word in pinned memory)
+        try:
+            eng.set_resident(500.0)
+            sweep(" (resident kernel, registered arrays)", ("f", "f+g (trial point)", "jac", "all"))
+            res["resident"] = dict(eng.host_stats(), idle_limit_us=500.0)
+        except Exception as err:  # noqa: BLE001
+            res["resident"] = {"error": "%s: %s" % (type(err).__name__, err)}
+        finally:
+            try:
+                eng.set_resident(0.0)
+            except Exception:  # noqa: BLE001
+                pass
     finally:
         eng.unregister_outputs(outs)
     # an IPOPT iterate with the default prefetch set {f, grad, g}: f and g at the trial point (new x), then grad f and jac g at the
@@ -245,18 +271,52 @@ def host_visible(eng, x_np, horizon, batch):
         eng.eval(xs[i % 4], new_x=False, want=("g",), out=(None, None, g_, None))
         eng.eval(xs[i % 4], new_x=False, want=("grad",), out=(None, grad_, None, None))
         eng.eval(xs[i % 4], new_x=False, want=("jac",), out=(None, None, None, jac_))
-    res["ipopt iterate: eval_f, eval_g, eval_grad_f, eval_jac_g as four calls"] = {"ms_per_call": best_of(iterate)}
-    eng.register_outputs(outs)
+    eng.set_auto_register(False)
+    res["ipopt iterate: eval_f, eval_g, eval_grad_f, eval_jac_g as four calls (auto-registration off)"] = {"ms_per_call": best_of(iterate)}
+    eng.set_auto_register(True)
+    res["ipopt iterate as four calls (library defaults)"] = {"ms_per_call": best_of(iterate)}
+    # opt-in: the new-x call also fills the registered arrays the later calls will pass (hipnlp_set_early_outputs)
+    eng.set_early_outputs(True)
+    res["ipopt iterate as four calls (early outputs)"] = {"ms_per_call": best_of(iterate)}
     try:
-        res["ipopt iterate as four calls (caller arrays registered)"] = {"ms_per_call": best_of(iterate)}
-        # opt-in: the new-x call also fills the registered arrays the later calls will pass (hipnlp_set_early_outputs)
-        eng.set_early_outputs(True)
-        res["ipopt iterate as four calls (caller arrays registered, early outputs)"] = {"ms_per_call": best_of(iterate)}
-        eng.set_early_outputs(False)
+        eng.set_resident(500.0)
+        res["ipopt iterate as four calls (early outputs, resident kernel)"] = {"ms_per_call": best_of(iterate)}
+    except Exception as err:  # noqa: BLE001
+        res["ipopt iterate as four calls (early outputs, resident kernel)"] = {"error": str(err)}
     finally:
-        eng.unregister_outputs(outs)
+        try:
+            eng.set_resident(0.0)
+        except Exception:  # noqa: BLE001
+            pass
+    eng.set_early_outputs(False)
+    eng.unregister_outputs(outs)   # (what the handle registered by itself)
+    # the same iterate through the product's own solver path: the four callback objects HipNlpSolver hands to cyipopt / SciPy, on the
+    # NLP the reference's scripts solve (detect_simple_bounds: the reduced problem is the handle's own layout)
+    if st is not None and batch == 1:
+        try:
+            from hippopt_amd.hipnlp import HipNlp
+            from hippopt_amd.hipnlp_solver import _CallbackCache, _SimpleBoundsLift
+            red = HipNlp(st, model, batch=1, device=eng.desc.device, detect_simple_bounds=True)
+            red.set_params(eng._bench_params)
+            view = _SimpleBoundsLift(red)
+            flat = [xi[0] for xi in xs]
+            for tag, idle in (("", 0.0), (", resident kernel", 500.0)):
+                cache = _CallbackCache(view, resident_idle_us=idle)
+
+                def solver_iterate(i):
+                    cache.eval(flat[i % 4], ("f",))
+                    cache.eval(flat[i % 4], ("g",))
+                    cache.eval(flat[i % 4], ("grad",))
+                    cache.eval(flat[i % 4], ("jac",))
+                res["ipopt iterate through the Python solver path (HipNlpSolver callbacks, detect_simple_bounds%s)" % tag] = {
+                    "ms_per_call": best_of(solver_iterate), "nlp": {"n": red.n, "m": red.m, "nnz": red.nnz, "rows_lifted_into_bounds": red.m_full - red.m}}
+                cache.close()
+            red.close()
+        except Exception as err:  # noqa: BLE001
+            res["ipopt iterate through the Python solver path"] = {"error": "%s: %s" % (type(err).__name__, err)}
     for v in res.values():
-        v["knots_per_s"] = horizon * batch / (v["ms_per_call"] * 1e-3)
+        if "ms_per_call" in v:
+            v["knots_per_s"] = horizon * batch / (v["ms_per_call"] * 1e-3)
     return res
 
 
@@ -553,6 +613,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic (seeded trajectories on a synthetic 23-DoF ergoCub-topology model; no URDF/CasADi in the image)",
+            "build": None,
             "config": {"workload": {"periodic": "kinodynamic periodic walking, N=%d knots per GPU, batch %d (BASELINE config 4 shape)",
                                     "single": "kinodynamic single step on flat ground, N=%d knots per GPU, batch %d (BASELINE config 3 shape)",
                                     "stairs": "kinodynamic walking on stairs (smooth two-step terrain), N=%d knots per GPU, batch %d (BASELINE config 5 shape)"}[args.workload]
@@ -570,6 +631,8 @@ def main():
                          "regime": "latency bound: %d workgroups on 256 CUs (all resident at once), one dependent knot program each" % local_knots
                                    if local_knots + args.batch <= 512 else "issue / latency bound (fp64 VALU), not HBM bound: see `valu`"},
         }
+        from hippopt_amd.hipnlp import build_info
+        line["build"] = build_info()
         if valu and kern_ms > 0:
             ginst = valu * local_knots / (kern_ms * 1e-3) / 1e9
             line["roofline"]["valu"] = {"bound": "fp64 valu issue", "achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
@@ -593,7 +656,8 @@ def main():
         solo = world == 1 and not knot_sharded_value
         if solo and not args.no_host:
             try:
-                hv = host_visible(eng, main_res["x_np"], args.horizon, args.batch)
+                eng._bench_params = main_res["p_np"]
+                hv = host_visible(eng, main_res["x_np"], args.horizon, args.batch, st, model)
                 line["host_visible"] = hv
                 line["pcie_inclusive"] = dict(hv["all"], note="hipnlp_eval with caller-owned host arrays, all four outputs, new x every call: x copied to a pinned "
                                                              "block the kernel reads directly, outputs stored by the kernel straight into the pinned output block, "
@@ -615,7 +679,9 @@ def main():
                 # one objective (or trial-point) call
                 hv = line["host_visible"]
                 for tag, key in (("host_visible_all", "all"), ("host_visible_all_registered", "all (caller arrays registered: direct kernel stores)"),
-                                 ("host_visible_f", "f")):
+                                 ("host_visible_all_resident", "all (resident kernel, registered arrays)"),
+                                 ("host_visible_all_auto_registration_off", "all (auto-registration off: pinned block + host copy)"),
+                                 ("host_visible_f", "f"), ("host_visible_f_resident", "f (resident kernel, registered arrays)")):
                     if key in hv:
                         cb["gpu_over_cpu"][tag + "_vs_1_thread"] = hv[key]["knots_per_s"] / cb["value"]
                         cb["gpu_over_cpu"][tag + "_vs_all_cores"] = hv[key]["knots_per_s"] / cb["all_cores"]["value"]

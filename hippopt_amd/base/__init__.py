@@ -5,3 +5,6 @@ from .optimization_object import (  # noqa: F401
 from .horizon import extend_structure_to_horizon, flattened_names  # noqa: F401
 from .problem import ExpressionType, Output, ProblemNotSolvedException  # noqa: F401
 from . import opti_callback  # noqa: F401,E402
+from .optimal_control import (  # noqa: F401,E402
+    MultipleShootingSolver, OptimalControlProblem, OptimalControlProblemInstance, OptimizationSolver, TypedProblemError,
+)

@@ -24,11 +24,14 @@ EXPORTS = [
     "hipnlp_ipc_alloc", "hipnlp_ipc_open", "hipnlp_ipc_close", "hipnlp_ipc_free", "hipnlp_peer_push", "hipnlp_peer_signal", "hipnlp_peer_wait", "hipnlp_eval_device_peers",
     "hipnlp_hess_nnz", "hipnlp_hess_sparsity", "hipnlp_eval_hess", "hipnlp_eval_hess_device",
     "hipnlp_eval_pinned", "hipnlp_set_prefetch", "hipnlp_set_early_outputs", "hipnlp_set_host_timing", "hipnlp_host_register", "hipnlp_host_unregister",
-    "hipnlp_host_breakdown",
+    "hipnlp_host_breakdown", "hipnlp_set_auto_register", "hipnlp_set_resident", "hipnlp_host_stats",
     "hipnlp_pose_create", "hipnlp_pose_destroy", "hipnlp_pose_last_error", "hipnlp_pose_get_dims", "hipnlp_pose_set_params",
     "hipnlp_pose_bounds", "hipnlp_pose_sparsity", "hipnlp_pose_eval", "hipnlp_pose_eval_device", "hipnlp_pose_cost_terms",
     "hipnlp_pose_cost_term_name", "hipnlp_pose_num_row_blocks", "hipnlp_pose_row_block", "hipnlp_pose_last_kernel_ms",
     "hipnlp_pose_hess_nnz", "hipnlp_pose_hess_sparsity", "hipnlp_pose_eval_hess", "hipnlp_pose_eval_hess_device",
+    # include/hipnlp_ipopt.h: IPOPT's C callback quartet (+ eval_h) on top of the functions above
+    "hipnlp_ipopt_eval_f", "hipnlp_ipopt_eval_grad_f", "hipnlp_ipopt_eval_g", "hipnlp_ipopt_eval_jac_g", "hipnlp_ipopt_eval_h",
+    "hipnlp_ipopt_sizes", "hipnlp_ipopt_bounds", "hipnlp_ipopt_attach", "hipnlp_ipopt_detach",
 ]
 G_STAGE = 550
 
@@ -125,6 +128,9 @@ def load_library():
     lib.hipnlp_host_register.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.hipnlp_host_unregister.argtypes = [vp]
     lib.hipnlp_host_breakdown.argtypes = [vp, dp]
+    lib.hipnlp_set_auto_register.argtypes = [vp, C.c_int]
+    lib.hipnlp_set_resident.argtypes = [vp, C.c_double]
+    lib.hipnlp_host_stats.argtypes = [vp, C.POINTER(C.c_long)]
     _lib = lib
     return lib
 
@@ -246,7 +252,8 @@ class HipNlp:
             grad = np.empty((self.batch, self.n)) if "grad" in want else None
             g = np.empty((self.batch, self.m)) if "g" in want else None
             jac = np.empty((self.batch, self.nnz)) if "jac" in want else None
-        rc = self.lib.hipnlp_eval(self.h, _dp(x), 1 if new_x else 0, _dp(f), _dp(grad), _dp(g), _dp(jac))
+        # (new_x = None: unknown — the library compares x with its staging copy of the previous evaluation)
+        rc = self.lib.hipnlp_eval(self.h, _dp(x), -1 if new_x is None else (1 if new_x else 0), _dp(f), _dp(grad), _dp(g), _dp(jac))
         if not (nan_ok and rc == -5):
             self._check(rc)
         return f, grad, g, jac
@@ -297,6 +304,20 @@ class HipNlp:
         for a in arrays:
             if a is not None and a.nbytes >= 4096:
                 self.lib.hipnlp_host_unregister(C.c_void_p(a.ctypes.data))
+
+    def set_auto_register(self, on=True):
+        """hipnlp_set_auto_register: output arrays seen twice in a row at one address become direct kernel outputs (on by default)"""
+        self._check(self.lib.hipnlp_set_auto_register(self.h, 1 if on else 0))
+
+    def set_resident(self, idle_us=200.0):
+        """hipnlp_set_resident: the callback kernel waits on the device for a doorbell instead of being launched per call; it leaves
+        idle_us after its last callback.  0 switches the mode off."""
+        self._check(self.lib.hipnlp_set_resident(self.h, float(idle_us)))
+
+    def host_stats(self):
+        out = (C.c_long * 8)()
+        self._check(self.lib.hipnlp_host_stats(self.h, out))
+        return dict(zip(("auto_registered", "auto_fallbacks", "auto_ranges", "resident_sessions", "resident_calls", "resident_alive", "evaluations"), list(out)))
 
     def set_host_timing(self, on=True):
         self._check(self.lib.hipnlp_set_host_timing(self.h, 1 if on else 0))
@@ -400,9 +421,6 @@ class HipPose:
         self._check(self.lib.hipnlp_pose_get_dims(self.h, C.byref(d)))
         self.batch = int(batch)
         self.n, self.m, self.nnz, self.np = d.n, d.m, d.nnz, d.np
-        self.m_full, self.n_lifted = d.m_full, d.n_lifted
-        self.lifted = bool(self.desc.flags & _abi.FLAG_DETECT_SIMPLE_BOUNDS)
-        self.params_generation = 0   # bumped by set_params (what caches of parameter-dependent data key on)
 
     @classmethod
     def from_desc(cls, desc):

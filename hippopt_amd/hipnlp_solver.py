@@ -17,6 +17,7 @@ import numpy as np
 
 from . import _abi
 from .base import OptimizationObject, extend_structure_to_horizon
+from .base.optimal_control import OptimizationSolver, TypedProblemError
 from .base.opti_callback import CallbackCriterion, IterateInfo, SaveBestUnsolvedVariablesCallback
 from .base.optimization_object import STORAGE_TYPE
 from .hipnlp import HipNlpError
@@ -137,25 +138,55 @@ class _SimpleBoundsLift:
 
 
 class _CallbackCache:
-    """What IPOPT's `new_x` flag does for a C caller: the four callbacks of one iterate share ONE evaluation (one kernel launch, one
-    device-to-host copy); a callback at an x the engine has already evaluated only copies its own output out of the staging block."""
+    """What IPOPT's `new_x` flag does for a C caller: the four callbacks of one iterate share ONE evaluation.
 
-    def __init__(self, eng):
+    On an engine handle (HipNlp, directly or behind the detect_simple_bounds view) this is the library's own host path, used the
+    way INTEGRATION.md tells a C binding to use it: ONE set of output arrays for the whole solve (the handle registers them at
+    their second sight: the kernel stores straight into them, no staging copy), early outputs on (the first callback at a new x
+    fills all four arrays: one transfer per iterate), `new_x` unknown (the drivers without IPOPT's flag — cyipopt, SciPy — pass
+    none: the library compares x with its staging copy instead of Python comparing and copying 151 KB per callback), optionally the
+    resident callback kernel.  The callbacks hand out VIEWS of those arrays, valid until the next evaluation (cyipopt copies them
+    into IPOPT's arrays at once; the SciPy driver asks for copies where it keeps a result).
+    On anything else (the emulated engine of the CPU tests, the pose finder's 81-variable handle) it compares x itself."""
+
+    def __init__(self, eng, resident_idle_us=0.0):
         self._eng = eng
         self._x = None
         self.calls = {}          # callbacks served, by kind
-        self.evaluations = 0     # of which new evaluations (kernel launches)
+        self._evaluations = 0    # of which new evaluations (slow path; the fast path reads the handle's own counter)
+        self._fast = all(hasattr(eng, name) for name in ("set_early_outputs", "host_stats", "register_outputs"))
+        if self._fast:
+            self._out = (np.empty(1), np.empty((1, eng.n)), np.empty((1, eng.m)), np.empty((1, eng.nnz)))
+            self._pick = {w: tuple(o if k in w else None for k, o in zip(("f", "grad", "g", "jac"), self._out))
+                          for w in (("f",), ("grad",), ("g",), ("jac",), ("f", "grad", "g", "jac"))}
+            eng.set_early_outputs(True)
+            self._evaluations0 = eng.host_stats()["evaluations"]
+            if resident_idle_us and resident_idle_us > 0:
+                try:
+                    eng.set_resident(float(resident_idle_us))
+                except HipNlpError as err:   # a launch that is not resident at once: launched per callback, as before
+                    if err.code != -6:
+                        raise
 
-    def eval(self, x, want):
+    @property
+    def evaluations(self):
+        return self._eng.host_stats()["evaluations"] - self._evaluations0 if self._fast else self._evaluations
+
+    def eval(self, x, want, copy=False):
         """A non-finite evaluation (HIPNLP_E_NUMERIC) is NOT an exception here: the arrays come back as the kernel filled them and
         the NLP driver sees the NaN / Inf, as IPOPT does with CasADi's (it cuts the step and goes on; a Python exception out of a
         cyipopt callback would abort the solve).  Every other engine error still raises."""
+        kind = want[0] if len(want) == 1 else "all"
+        self.calls[kind] = self.calls.get(kind, 0) + 1
+        if self._fast:
+            out = self._eng.eval(x, new_x=None, want=want, out=self._pick.get(want) or tuple(o if k in want else None for k, o in zip(("f", "grad", "g", "jac"), self._out)),
+                                 nan_ok=True)
+            return tuple(None if o is None else o.copy() for o in out) if copy else out
         x = np.asarray(x, dtype=np.float64)
         new_x = self._x is None or not np.array_equal(x, self._x)
         if new_x:
             self._x = x.copy()
-        self.calls[want[0] if len(want) == 1 else "all"] = self.calls.get(want[0] if len(want) == 1 else "all", 0) + 1
-        self.evaluations += int(new_x)
+        self._evaluations += int(new_x)
         try:
             return self._eng.eval(x[None, :], new_x=new_x, want=want, nan_ok=True)
         except Exception:
@@ -165,14 +196,27 @@ class _CallbackCache:
     def invalidate(self):
         self._x = None
 
+    def close(self):
+        """the solve is over: the registered arrays go away with this object"""
+        if self._fast:
+            try:
+                self._eng.set_resident(0.0)
+            except HipNlpError:
+                pass
+            self._eng.set_early_outputs(False)
+            self._eng.unregister_outputs(self._out[1:])
 
-class HipNlpSolver:
+
+class HipNlpSolver(OptimizationSolver):
     def __init__(self, settings, model, device=0, inner_solver="auto", options_solver=None, problem="kinodynamic",
                  callback_criterion: CallbackCriterion = None, callback_save_costs=True, callback_save_constraint_multipliers=True,
-                 error_on_fail=True, detect_simple_bounds=True):
+                 error_on_fail=True, detect_simple_bounds=True, resident_idle_us=0.0):
         """callback_* as in OptiSolver (opti_solver.py:105-131).  error_on_fail: CasADi's Opti raises when IPOPT does not report
         success (e.g. Maximum_Iterations_Exceeded), which is what triggers the best-iterate fallback of opti_solver.py:479-520;
-        False keeps the last iterate of an unconverged run instead (useful for smoke runs with a few iterations)."""
+        False keeps the last iterate of an unconverged run instead (useful for smoke runs with a few iterations).
+        resident_idle_us > 0: the callbacks of the solve go through the resident callback kernel (hipnlp_set_resident) where the
+        handle allows it."""
+        self._resident_idle_us = float(resident_idle_us)
         self._callback_criterion = callback_criterion
         self._callback_save_costs = callback_save_costs
         self._callback_save_constraint_multipliers = callback_save_constraint_multipliers
@@ -305,10 +349,10 @@ class HipNlpSolver:
         return names
 
     def add_cost(self, input_cost, name=None):
-        raise NotImplementedError("HipNlpSolver evaluates the typed kinodynamic cost list built into the engine; symbolic costs need OptiSolver")
+        raise TypedProblemError("add_cost")
 
     def add_constraint(self, input_constraint, name=None):
-        raise NotImplementedError("HipNlpSolver evaluates the typed kinodynamic constraint list built into the engine; symbolic constraints need OptiSolver")
+        raise TypedProblemError("add_constraint")
 
     def cost_function(self):
         return self.get_cost_expressions()
@@ -352,7 +396,7 @@ class HipNlpSolver:
             names, terms = eng.cost_terms()
             return {n: float(v) for n, v in zip(names, terms[0])}
         self._cost_values_at = cost_values_at
-        self._cache = _CallbackCache(eng)
+        self._cache = _CallbackCache(eng, self._resident_idle_us)
         failure = None
         try:
             if solver == "ipopt":
@@ -366,6 +410,8 @@ class HipNlpSolver:
                 failure = RuntimeError("solver status: " + str(info.get("message", info.get("status"))))
         except Exception as err:  # noqa: BLE001
             failure, info = err, {"success": False, "message": str(err)}
+        finally:
+            self._cache.close()
         self._last_info = info
         if failure is not None:   # opti_solver.py:479-520: fall back to the best iterate the callback saved, else raise
             cb = self._callback
@@ -421,12 +467,12 @@ class HipNlpSolver:
             f, *_ = cache.eval(x, ("f",))
             return float(f[0])
 
-        def grad(x):
-            _, g_, *_ = cache.eval(x, ("grad",))
+        def grad(x):   # (copies: this driver keeps gradients and constraint values of earlier points)
+            _, g_, *_ = cache.eval(x, ("grad",), copy=True)
             return g_[0]
 
         def cons(x):
-            _, _, g, _ = cache.eval(x, ("g",))
+            _, _, g, _ = cache.eval(x, ("g",), copy=True)
             return g[0]
 
         def jac(x):

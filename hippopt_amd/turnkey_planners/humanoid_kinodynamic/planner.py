@@ -3,7 +3,7 @@ set_initial_guess / get_initial_guess / set_references / set_initial_state / set
 get_variables_structure), with the engine-backed solver plugin in place of OptiSolver + CasADi."""
 import copy
 
-from ...base import Output, extend_structure_to_horizon  # noqa: F401
+from ...base import MultipleShootingSolver, OptimalControlProblem, Output, extend_structure_to_horizon  # noqa: F401
 from ...base.opti_callback import AcceptablePrimalInfeasibility, BestCost
 from ...hipnlp_solver import HipNlpSolver
 from .settings import Settings
@@ -26,7 +26,10 @@ class Planner:
                                                 callback_save_costs=self.settings.opti_callback_save_costs,
                                                 callback_save_constraint_multipliers=self.settings.opti_callback_save_constraint_multipliers,
                                                 error_on_fail=error_on_fail)
-        self.optimization_solver.generate_optimization_objects(variables, horizon=self.settings.horizon_length)
+        # the wiring of the reference's planner (planner.py:72-80), names kept: only the optimization solver differs
+        self.solver = MultipleShootingSolver(optimization_solver=self.optimization_solver)
+        self.ocp = OptimalControlProblem.create(input_structure=variables, optimal_control_solver=self.solver,
+                                                horizon=self.settings.horizon_length)
         self.variables = self.optimization_solver.get_optimization_structure()
 
     # ---- mass regularisation (planner.py:932-1034): forces and momenta are divided by the total mass ---------
@@ -84,10 +87,9 @@ class Planner:
         self.set_initial_guess(guess)
 
     def solve(self) -> Output:
-        s = self.optimization_solver
-        s.solve()
-        return Output(values=self._undo_mass_regularization(s.get_values()), cost_value=s.get_cost_value(),
-                      cost_values=s.get_cost_values(), constraint_multipliers=s.get_constraint_multipliers())
+        output = self.ocp.problem.solve()
+        output.values = self._undo_mass_regularization(output.values)
+        return output
 
     def get_variables_structure(self) -> Variables:
         return copy.deepcopy(self.variables)

@@ -227,7 +227,8 @@ int hipnlp_sparsity(const hipnlp_handle* h, int32_t* irow, int32_t* jcol);
 
 /* Host-buffer callback quartet (IPOPT eval_f/eval_grad_f/eval_g/eval_jac_g in one fused launch).
  * x: [batch][n]; f: [batch]; grad_f: [batch][n]; g: [batch][m]; jac: [batch][nnz].  Any output may be NULL.
- * new_x = 0 lets the library return cached results of the previous evaluation.
+ * new_x = 0 lets the library return cached results of the previous evaluation (IPOPT's flag); new_x < 0 = "unknown": the library
+ * compares x with its staging copy of the previous evaluation (what a binding without IPOPT's flag — cyipopt, SciPy — passes).
  *
  * What crosses PCIe (the non-NULL outputs are the call's WANT MASK): a new evaluation copies x into a pinned staging block the
  * kernel reads directly, evaluates all four outputs in ONE launch and lets the kernel store the wanted ones — plus the handle's
@@ -273,6 +274,34 @@ int hipnlp_host_breakdown(const hipnlp_handle* h, double* us /*[4]*/);
  * each: hippopt_amd/sharded.py HostSink).  Process-wide (no handle); the caller unregisters before freeing the memory.           */
 int hipnlp_host_register(void* p, size_t bytes, void** dev_ptr);
 int hipnlp_host_unregister(void* p);
+/* Auto-registration (ON by default): a grad_f / g / jac array of at least 64 KB that hipnlp_eval sees at the same address on two
+ * CONSECUTIVE calls is registered by the handle itself (as hipnlp_host_register would) and is a direct kernel output from then on —
+ * a plain binding that simply passes IPOPT's arrays gets the fast path without knowing about it.  Safety: a registration pins the
+ * PAGES behind an address; should the caller free the array and the allocator map other pages at the same address, the kernel's
+ * stores would go to the old pages.  Every use of an auto-registered array is therefore verified: the call writes a word of its own
+ * into the first and the last entry before the evaluation and finds both overwritten afterwards (every entry of every output is
+ * written by every evaluation) — if not, the range is dropped, the address is left alone from then on and the call is served through
+ * the pinned block as for any unregistered array.  At most six ranges per handle (the oldest goes first); all are released by
+ * hipnlp_destroy or hipnlp_set_auto_register(h, 0).  Arrays registered explicitly with hipnlp_host_register are the caller's
+ * responsibility and are not verified. */
+int hipnlp_set_auto_register(hipnlp_handle* h, int on);
+/* Resident mode (off by default; handles whose whole launch is resident at once at one workgroup per compute unit — the eight-wave
+ * kernel, (knots + 1) x batch <= 256 — HIPNLP_E_UNSUPPORTED otherwise).  idle_us > 0: hipnlp_eval / hipnlp_eval_pinned no longer launch a kernel per callback.  The
+ * callback kernel stays on the device between calls; a call copies x into the pinned staging block, rings a doorbell word in pinned
+ * memory, and polls a completion word the kernel raises once every output the call wants on the host has been stored there
+ * (system-scope stores; no launch, no stream synchronisation: 15 / 21 / 42 us instead of 29 / 31 / 49 us per 100-knot call for f /
+ * f + grad f + g / all four, profiles/r03_doorbell_probe.txt).  The kernel leaves by itself idle_us after its last callback (every
+ * wait on the device is bounded by the real-time counter) and the next call starts another session, so a solver that spends
+ * milliseconds in its linear algebra between callbacks pays one launch per burst of callbacks, not one per callback.  While a session
+ * is open its workgroups occupy their compute units (one polling lane each); hipDeviceSynchronize and hipFree in the same process
+ * wait for the session to end (at most idle_us).  hipnlp_set_params, hipnlp_destroy and idle_us = 0 end the session at once.
+ * A session that does not answer within two seconds is abandoned, the call is served by a launch, and after three such sessions the
+ * mode switches itself off for the handle. */
+int hipnlp_set_resident(hipnlp_handle* h, double idle_us);
+/* Counters of the host-buffer path: out[0] arrays auto-registered so far, out[1] stale-mapping fallbacks, out[2] ranges currently
+ * auto-registered, out[3] resident sessions started, out[4] callbacks served by a resident session, out[5] a session is open,
+ * out[6] evaluations so far (kernel launches + resident callbacks), out[7] reserved. */
+int hipnlp_host_stats(const hipnlp_handle* h, long* out /*[8]*/);
 
 
 /* Exact Hessian of the Lagrangian  sigma f(x) + lambda^T g(x)  of the kinodynamic NLP — IPOPT's eval_h (IpStdCInterface.h:

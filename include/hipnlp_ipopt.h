@@ -1,0 +1,79 @@
+/*
+ * hipnlp_ipopt.h — IPOPT's C callback quartet (+ eval_h) as compiled symbols of libhipnlp.so.
+ *
+ * The reference reaches IPOPT through CasADi: opti.solver("ipopt", ...) (src/hippopt/base/opti_solver.py:123-125) and
+ * self._solver.solve() (:479); nlpsol's IPOPT plugin then hands IPOPT the callbacks of IpStdCInterface.h, which evaluate CasADi's
+ * nlp_f / nlp_grad_f / nlp_g / nlp_jac_g (/ nlp_hess_l) — the hot path.  The functions below ARE those callbacks
+ * for the engine: exactly the signatures IpStdCInterface.h declares (Eval_F_CB, Eval_Grad_F_CB, Eval_G_CB, Eval_Jac_G_CB, Eval_H_CB),
+ * user_data = the hipnlp_handle* of a handle with batch 1.  A maintainer binds them with
+ *
+ *     IpoptProblem nlp = CreateIpoptProblem(n, x_L, x_U, m, g_L, g_U, nele_jac, nele_hess, 0,   // C index style
+ *                                           hipnlp_ipopt_eval_f, hipnlp_ipopt_eval_g, hipnlp_ipopt_eval_grad_f,
+ *                                           hipnlp_ipopt_eval_jac_g, hipnlp_ipopt_eval_h);
+ *     IpoptSolve(nlp, x, NULL, &obj, mult_g, mult_x_L, mult_x_U, (UserDataPtr)handle);
+ *
+ * (INTEGRATION.md has the whole program).  IPOPT's protocol is honoured to the letter: a call with values == NULL returns the fixed
+ * sparsity structure (x may be NULL then), new_x == FALSE reuses the evaluation of the previous callback (one kernel evaluation per
+ * iterate, whichever callback comes first), an evaluation that produced a NaN / Inf returns FALSE (IPOPT then cuts the step: what it
+ * does with CasADi's NaNs), every other failure returns FALSE with the reason in hipnlp_last_error.
+ *
+ * The types are restated so that this header compiles without IPOPT; they are the ones of a default IPOPT build (IpTypes.h:
+ * ipnumber = double, ipindex = int; IpStdCInterface.h: Number, Index, Bool = int, UserDataPtr = void*).  Define
+ * HIPNLP_IPOPT_WITH_IPOPT_HEADER to take them from <IpStdCInterface.h> instead (a mismatch is then a compile error).
+ */
+#ifndef HIPNLP_IPOPT_H
+#define HIPNLP_IPOPT_H
+
+#include "hipnlp.h"
+
+#ifdef HIPNLP_IPOPT_WITH_IPOPT_HEADER
+#include <IpStdCInterface.h>
+#else
+typedef double Number;       /* IpStdCInterface.h: typedef ipnumber Number;  IpTypes.h: typedef double ipnumber */
+typedef int Index;           /* IpStdCInterface.h: typedef ipindex Index;    IpTypes.h: typedef int ipindex     */
+typedef int Bool;            /* IpStdCInterface.h: typedef int Bool                                           */
+typedef void* UserDataPtr;   /* IpStdCInterface.h: typedef void* UserDataPtr                                   */
+#ifndef TRUE
+#define TRUE (1)
+#endif
+#ifndef FALSE
+#define FALSE (0)
+#endif
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Eval_F_CB */
+Bool hipnlp_ipopt_eval_f(Index n, Number* x, Bool new_x, Number* obj_value, UserDataPtr user_data);
+/* Eval_Grad_F_CB */
+Bool hipnlp_ipopt_eval_grad_f(Index n, Number* x, Bool new_x, Number* grad_f, UserDataPtr user_data);
+/* Eval_G_CB */
+Bool hipnlp_ipopt_eval_g(Index n, Number* x, Bool new_x, Index m, Number* g, UserDataPtr user_data);
+/* Eval_Jac_G_CB: values == NULL -> iRow / jCol (0-based, CCS order: sorted by column, then row); else values */
+Bool hipnlp_ipopt_eval_jac_g(Index n, Number* x, Bool new_x, Index m, Index nele_jac, Index* iRow, Index* jCol, Number* values,
+                             UserDataPtr user_data);
+/* Eval_H_CB: lower triangle (iRow >= jCol) of obj_factor * hess f + sum_r lambda_r hess g_r; values == NULL -> structure.
+ * Only when the solve does not run hessian_approximation = limited-memory (the kinodynamic scripts do, main_periodic_step.py:116;
+ * the pose finder does not, humanoid_pose_finder/main.py:101). */
+Bool hipnlp_ipopt_eval_h(Index n, Number* x, Bool new_x, Number obj_factor, Index m, Number* lambda, Bool new_lambda, Index nele_hess,
+                         Index* iRow, Index* jCol, Number* values, UserDataPtr user_data);
+
+/* What CreateIpoptProblem needs.  Sizes of the handle's NLP (the reduced one for a handle created with
+ * HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS); nele_hess may be NULL (limited-memory runs pass 0 to CreateIpoptProblem). */
+int hipnlp_ipopt_sizes(hipnlp_handle* h, Index* n, Index* m, Index* nele_jac, Index* nele_hess);
+/* Bounds in IPOPT's convention: an infinite bound is -/+ 2e19 (beyond nlp_lower_bound_inf / nlp_upper_bound_inf = -/+ 1e19).
+ * Valid after hipnlp_set_params.  Any pointer may be NULL. */
+int hipnlp_ipopt_bounds(hipnlp_handle* h, Number* x_L, Number* x_U, Number* g_L, Number* g_U);
+/* Optional, around IpoptSolve: attach turns on what suits IPOPT's call pattern — early outputs (the first callback at a new x fills
+ * the g / grad f / jac g arrays the later callbacks will pass: one transfer per iterate), auto-registration of IPOPT's arrays, and,
+ * with resident_idle_us > 0, the resident callback kernel (hipnlp_set_resident); detach ends a resident session and releases the
+ * registrations (call it before the arrays IPOPT owned are freed, i.e. before FreeIpoptProblem). */
+int hipnlp_ipopt_attach(hipnlp_handle* h, double resident_idle_us);
+int hipnlp_ipopt_detach(hipnlp_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPNLP_IPOPT_H */

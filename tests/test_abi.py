@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_functions():
-    src = open(os.path.join(ROOT, "include", "hipnlp.h")).read()
+    src = open(os.path.join(ROOT, "include", "hipnlp.h")).read() + open(os.path.join(ROOT, "include", "hipnlp_ipopt.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(hipnlp_[a-z_0-9]+)\s*\(", src)))
 
