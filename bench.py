@@ -204,9 +204,9 @@ def host_visible(eng, x_np, horizon, batch, st=None, model=None):
     """The rate at the boundary IPOPT binds: hipnlp_eval with host buffers, per callback kind (the call's non-NULL outputs are its
     want mask).  x changes on every call (new_x = 1), caller-owned output arrays reused as IPOPT's are.  Never `value`.
     Legs: plain caller arrays with the library's defaults (arrays seen twice in a row are registered by the handle itself and become
-    direct kernel outputs), the same with auto-registration off (every output through the pinned block + a host copy), the resident
-    callback kernel (hipnlp_set_resident), an IPOPT iterate as four calls (raw C-ABI calls from Python), and the same iterate through
-    the product's own Python solver path (HipNlpSolver's callback objects: what cyipopt / SciPy are handed)."""
+    direct kernel outputs), the same with auto-registration off (every output through the pinned block + a host copy), an IPOPT
+    iterate as four calls (raw C-ABI calls from Python; and through IPOPT's own C callback symbols from a C program), and the same
+    iterate through the product's own Python solver path (HipNlpSolver's callback objects: what cyipopt / SciPy are handed)."""
     import numpy as np
     rng = np.random.RandomState(11)
     xs = [x_np + 1e-3 * i * rng.standard_normal(x_np.shape) for i in range(4)]
@@ -247,18 +247,6 @@ def host_visible(eng, x_np, horizon, batch, st=None, model=None):
         for name, want in (("g", ("g",)), ("jac", ("jac",)), ("all", ("f", "grad", "g", "jac"))):
             out = tuple(o if k in want else None for k, o in zip(("f", "grad", "g", "jac"), outs))
             res[name + " (caller arrays registered: direct kernel stores)"] = {"ms_per_call": best_of(lambda i: eng.eval(xs[i % 4], want=want, out=out))}
-        # the resident callback kernel: no launch, no stream synchronisation per call (doorbell + completion word in pinned memory)
-        try:
-            eng.set_resident(500.0)
-            sweep(" (resident kernel, registered arrays)", ("f", "f+g (trial point)", "jac", "all"))
-            res["resident"] = dict(eng.host_stats(), idle_limit_us=500.0)
-        except Exception as err:  # noqa: BLE001
-            res["resident"] = {"error": "%s: %s" % (type(err).__name__, err)}
-        finally:
-            try:
-                eng.set_resident(0.0)
-            except Exception:  # noqa: BLE001
-                pass
     finally:
         eng.unregister_outputs(outs)
     # an IPOPT iterate with the default prefetch set {f, grad, g}: f and g at the trial point (new x), then grad f and jac g at the
@@ -278,16 +266,6 @@ def host_visible(eng, x_np, horizon, batch, st=None, model=None):
     # opt-in: the new-x call also fills the registered arrays the later calls will pass (hipnlp_set_early_outputs)
     eng.set_early_outputs(True)
     res["ipopt iterate as four calls (early outputs)"] = {"ms_per_call": best_of(iterate)}
-    try:
-        eng.set_resident(500.0)
-        res["ipopt iterate as four calls (early outputs, resident kernel)"] = {"ms_per_call": best_of(iterate)}
-    except Exception as err:  # noqa: BLE001
-        res["ipopt iterate as four calls (early outputs, resident kernel)"] = {"error": str(err)}
-    finally:
-        try:
-            eng.set_resident(0.0)
-        except Exception:  # noqa: BLE001
-            pass
     eng.set_early_outputs(False)
     eng.unregister_outputs(outs)   # (what the handle registered by itself)
     # the same iterate through the product's own solver path: the four callback objects HipNlpSolver hands to cyipopt / SciPy, on the
@@ -300,24 +278,68 @@ def host_visible(eng, x_np, horizon, batch, st=None, model=None):
             red.set_params(eng._bench_params)
             view = _SimpleBoundsLift(red)
             flat = [xi[0] for xi in xs]
-            for tag, idle in (("", 0.0), (", resident kernel", 500.0)):
-                cache = _CallbackCache(view, resident_idle_us=idle)
+            cache = _CallbackCache(view)
 
-                def solver_iterate(i):
-                    cache.eval(flat[i % 4], ("f",))
-                    cache.eval(flat[i % 4], ("g",))
-                    cache.eval(flat[i % 4], ("grad",))
-                    cache.eval(flat[i % 4], ("jac",))
-                res["ipopt iterate through the Python solver path (HipNlpSolver callbacks, detect_simple_bounds%s)" % tag] = {
-                    "ms_per_call": best_of(solver_iterate), "nlp": {"n": red.n, "m": red.m, "nnz": red.nnz, "rows_lifted_into_bounds": red.m_full - red.m}}
-                cache.close()
+            def solver_iterate(i):
+                cache.eval(flat[i % 4], ("f",))
+                cache.eval(flat[i % 4], ("g",))
+                cache.eval(flat[i % 4], ("grad",))
+                cache.eval(flat[i % 4], ("jac",))
+            res["ipopt iterate through the Python solver path (HipNlpSolver callbacks, detect_simple_bounds)"] = {
+                "ms_per_call": best_of(solver_iterate), "nlp": {"n": red.n, "m": red.m, "nnz": red.nnz, "rows_lifted_into_bounds": red.m_full - red.m}}
+            cache.close()
             red.close()
         except Exception as err:  # noqa: BLE001
             res["ipopt iterate through the Python solver path"] = {"error": "%s: %s" % (type(err).__name__, err)}
+    # IPOPT's own C callback symbols (include/hipnlp_ipopt.h) driven from a C program in IPOPT's call order (tests/ipopt_harness:
+    # IPOPT itself is not in the image): an iterate as four C calls on arrays the program owns for the whole run
+    if st is not None and batch == 1:
+        try:
+            res["ipopt iterate as four C calls (hipnlp_ipopt_* symbols, C harness, detect_simple_bounds)"] = c_harness_iterate(st, model, x_np[0], eng._bench_params[0])
+        except Exception as err:  # noqa: BLE001
+            res["ipopt iterate as four C calls (hipnlp_ipopt_* symbols, C harness, detect_simple_bounds)"] = {"error": "%s: %s" % (type(err).__name__, err)}
     for v in res.values():
         if "ms_per_call" in v:
             v["knots_per_s"] = horizon * batch / (v["ms_per_call"] * 1e-3)
     return res
+
+
+def c_harness_iterate(st, model, x, p):
+    """builds tests/ipopt_harness/harness.c against the library (gcc) and runs its timing loop in a child process"""
+    import ctypes as C
+    import struct
+    import tempfile
+    import numpy as np
+    from hippopt_amd import _abi
+    from hippopt_amd.hipnlp import library_path
+    lib_dir = os.path.dirname(library_path())
+    tmp = tempfile.mkdtemp(prefix="hipnlp_harness_")
+    exe = os.path.join(tmp, "ipopt_harness")
+    subprocess.check_call(["gcc", "-std=c99", "-D_POSIX_C_SOURCE=199309L", "-O2", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "ipopt_harness", "harness.c"), "-L", lib_dir, "-lhipnlp", "-Wl,-rpath," + lib_dir, "-lm", "-o", exe])
+    desc = _abi.DescC()
+    desc.settings, desc.model, desc.batch, desc.flags = st.to_c(), model.to_c(), 1, _abi.FLAG_DETECT_SIMPLE_BOUNDS
+    rng = np.random.RandomState(3)
+    xs = np.stack([x + 1e-3 * i * rng.standard_normal(x.shape) for i in range(5)])
+    xs[-1, 130:134] = 0.0   # (the protocol replay ends with a point that evaluates to NaN; the timing loop leaves it out)
+    src = os.path.join(tmp, "in.bin")
+    blob = C.string_at(C.addressof(desc), C.sizeof(desc))
+    eng = __import__("hippopt_amd.hipnlp", fromlist=["HipNlp"]).HipNlp(st, model, detect_simple_bounds=True)
+    m = eng.m
+    eng.close()
+    with open(src, "wb") as f:
+        f.write(struct.pack("<6i", 0x49504F54, len(blob), p.size, xs.shape[0], 1, 0))
+        f.write(blob)
+        f.write(np.ascontiguousarray(p, np.float64).tobytes())
+        f.write(xs.tobytes())
+        f.write(np.zeros(m).tobytes())
+        f.write(struct.pack("<d", 1.0))
+    out = subprocess.run([exe, src, os.path.join(tmp, "out.bin"), "300"], capture_output=True, text=True, timeout=120)
+    if out.returncode != 0:
+        raise RuntimeError(out.stderr.strip())
+    t = json.loads(out.stdout.strip().splitlines()[-1])
+    return {"ms_per_call": 1e-3 * t["ipopt_iterate_four_c_calls_us"], "trial_point_two_c_calls_ms": 1e-3 * t["trial_point_two_c_calls_us"],
+            "arrays_registered_by_the_handle": t["auto_registered"]}
 
 
 def main():
@@ -469,16 +491,20 @@ def main():
         # K steps between barrier + synchronize, maximum over the ranks — so that any of the three can be the step behind `value`.
         from hippopt_amd.sharded import PeerExchange
 
-        def time_peer(engine, note):
+        def time_peer(engine, note, root_only=False):
             px = None
             try:
-                px = PeerExchange(cb, engine=engine)
+                px = PeerExchange(cb, engine=engine, root_only=root_only)   # (set-up ends with a bounded one-word handshake per peer)
                 with torch.cuda.stream(cb.stream):
                     ref = [t.clone() for t in cb(xs[1 % nvar])]
-                    got = [t.clone() for t in px(xs[1 % nvar])]
-                    got2 = [t.clone() for t in px(xs[1 % nvar])]          # the other buffer parity
+                    got = px(xs[1 % nvar])
+                    got = [t.clone() for t in got] if got[0] is not None else None
+                    got2 = px(xs[1 % nvar])                                # the other buffer parity
+                    got2 = [t.clone() for t in got2] if got2[0] is not None else None
                 fence()
-                same = all(torch.equal(a, b_) and torch.equal(a, c_) for a, b_, c_ in zip(ref, got, got2)) and not px.timed_out()
+                same = not px.timed_out()
+                if got is not None:   # (gather_to_root: rank 0 alone holds the outputs)
+                    same = same and all(torch.equal(a, b_) and torch.equal(a, c_) for a, b_, c_ in zip(ref, got, got2))
                 flags = torch.tensor([1.0 if same else 0.0], device=device)
                 if world > 1:
                     if dist.get_backend() == "gloo":
@@ -497,10 +523,13 @@ def main():
                     fence()
                     e4 = max_over_ranks(time.perf_counter() - t1)
                 late = px.timed_out()
+                sent = px.bytes_sent_per_step()
                 fence()                      # every rank's pushes are complete: the buffers can go without another collective
                 px.close(barrier=False)
                 return e4, {"knots_per_s": hz * steps / e4, "ms_per_step": 1e3 * e4 / steps, "steps": steps, "timed_out": bool(late),
-                            "verified": "bitwise equal to the all-gather path on every rank, both buffer parities", "note": note}
+                            "bytes_sent_per_rank_per_step": int(sent),
+                            "verified": "bitwise equal to the all-gather path on every rank that holds outputs, both buffer parities; "
+                                        "one-word handshake with every peer at set-up", "note": note}
             except Exception as err:  # noqa: BLE001  (an extra measurement must not take `value` down with it)
                 # (a rank-local failure past the collective set-up leaves the other ranks in a collective: the launcher's timeout ends
                 #  the run; set-up failures and mismatches are agreed on collectively and land here on every rank)
@@ -512,15 +541,29 @@ def main():
         if eng.kernels_per_eval() == 1:
             e_pd, res["peer_direct"] = time_peer(eng, "as peer_store with the push folded into the evaluation: the knot kernel stores the shard's entries "
                                                       "at their final positions into every rank's buffer (hipnlp_eval_device_peers); three launches per step")
-        # `value` is the step of north_star's path — knot shards evaluated, [grad | jac | g | f] of the WHOLE trajectory on every rank —
-        # with whichever exchange is fastest on this node (same results, checked bit for bit above); the others stay beside it.
-        # One rank: there is no exchange to choose, the collective's path is kept.
-        res["all_gather"] = {"knots_per_s": hz * steps / res["el"], "ms_per_step": 1e3 * res["el"] / steps, "steps": steps}
+        # gather_to_root: IPOPT is ONE consumer (rank 0's process): every rank stores its shard into rank 0's buffer only — 1 / world of
+        # the all-gather's bytes per link — and rank 0 tells the others when a step has been consumed (sharded.PeerExchange(root_only))
+        e_gr, res["gather_to_root"] = time_peer(eng if eng.kernels_per_eval() == 1 else None,
+                                                "only rank 0 receives [grad | jac | g | f]: every rank's knot kernel stores its shard straight into rank 0's buffer "
+                                                "over its own xGMI link (HIP IPC), rank 0 waits for all flags and signals back; the other ranks hold no outputs",
+                                                root_only=True)
+        # `value` is the step of north_star's path — knot shards evaluated, [grad | jac | g | f] of the WHOLE trajectory on every rank.
+        # It is the RCCL all-gather path unless a peer exchange is faster AND has been verified bit for bit in THIS run with every rank
+        # on a device of its own (a rehearsal with several ranks on one device exercises neither xGMI nor cross-device visibility and
+        # never qualifies).  gather_to_root delivers to rank 0 only — a different contract — and is reported beside `value`, never as it.
+        res["all_gather"] = {"knots_per_s": hz * steps / res["el"], "ms_per_step": 1e3 * res["el"] / steps, "steps": steps,
+                             "bytes_sent_per_rank_per_step": int(8 * cb.shard_len * (world - 1)), "rccl_ranks": world}
         res["exchange"] = "all_gather"
+        devs = [None] * world
+        if world > 1:
+            dist.all_gather_object(devs, (socket.gethostname(), int(torch.cuda.current_device()), str(torch.cuda.get_device_properties(device).uuid) if hasattr(torch.cuda.get_device_properties(device), "uuid") else ""))
+        distinct = world > 1 and len(set(devs)) == world and not REHEARSAL
+        res["peer_paths_eligible_for_value"] = ("yes: %d ranks on %d distinct devices, verified bitwise against the all-gather path in this run" % (world, world)) if distinct \
+            else "no: ranks share a device (rehearsal) or one rank: the all-gather path is `value`"
         labels = {"peer_store": "peer stores over xGMI into every rank's output buffer (HIP IPC; no collective, no reassembly pass)",
                   "peer_direct": "the knot kernel storing straight into every rank's output buffer over xGMI (HIP IPC; no collective, no push or reassembly pass)"}
         for name, e in (("peer_store", e_ps), ("peer_direct", e_pd)):
-            if world > 1 and e is not None and not res[name]["timed_out"] and e < res["el"]:
+            if distinct and e is not None and not res[name]["timed_out"] and e < res["el"]:
                 res["el"] = e
                 res["exchange"] = name
                 res["parallelism"] = "knot-sharded x%d (contiguous shooting intervals) + %s" % (world, labels[name])
@@ -648,7 +691,9 @@ def main():
                                                  "peak = 256 CUs x 2.4 GHz (stores also occupy the VGPR -> LDS path, not counted here)"}
         if main_res.get("exchange"):
             line["config"]["exchange"] = main_res["exchange"]
-        for key in ("all_gather", "shard_resident", "peer_store", "peer_direct", "host_sink"):
+        if main_res.get("peer_paths_eligible_for_value"):
+            line["config"]["peer_paths_eligible_for_value"] = main_res["peer_paths_eligible_for_value"]
+        for key in ("all_gather", "shard_resident", "peer_store", "peer_direct", "gather_to_root", "host_sink"):
             if main_res.get(key) is not None:
                 line[key] = main_res[key]
         if side is not None:
@@ -679,9 +724,8 @@ def main():
                 # one objective (or trial-point) call
                 hv = line["host_visible"]
                 for tag, key in (("host_visible_all", "all"), ("host_visible_all_registered", "all (caller arrays registered: direct kernel stores)"),
-                                 ("host_visible_all_resident", "all (resident kernel, registered arrays)"),
                                  ("host_visible_all_auto_registration_off", "all (auto-registration off: pinned block + host copy)"),
-                                 ("host_visible_f", "f"), ("host_visible_f_resident", "f (resident kernel, registered arrays)")):
+                                 ("host_visible_f", "f")):
                     if key in hv:
                         cb["gpu_over_cpu"][tag + "_vs_1_thread"] = hv[key]["knots_per_s"] / cb["value"]
                         cb["gpu_over_cpu"][tag + "_vs_all_cores"] = hv[key]["knots_per_s"] / cb["all_cores"]["value"]

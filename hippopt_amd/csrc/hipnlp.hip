@@ -31,6 +31,7 @@
 #include "layout.h"
 
 using namespace hipnlp;
+typedef unsigned long long u64;
 
 namespace {
 
@@ -129,47 +130,6 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ unsigned long long pub_pattern(int32_t seq) { return ((unsigned long long)(uint32_t)seq * 0x9E3779B97F4A7C15ull) | 1ull; }
 constexpr int PUB_SPIN_CAP = 1 << 20;   // polls of the reducer before it gives up (each at least one memory round trip: > 1 s)
 
-// ---- resident mode (hipnlp_set_resident; DESIGN.md §5 "The host-visible path") ----------------------------------------------------
-// A callback at the host boundary costs launch + completion (13 us around an 8 us kernel, profiles/r03_doorbell_probe.txt) before a
-// byte moves.  In resident mode the eight-wave kernel STAYS on the device between callbacks: one leader workgroup (the trajectory's
-// cost reducer of grid row 0) polls a doorbell word in pinned host memory and publishes it to the knot workgroups through device
-// memory; they run the knot program, store the outputs the word's mask asks for STRAIGHT into host memory with system-scope (sc0 sc1)
-// stores — measured: a plain store is acknowledged before it is visible to the host, an sc0 sc1 store is not — wait for their own
-// stores, count themselves done, and the last one raises the completion word the host polls: no launch, no stream synchronise, no
-// fence.  Every wait is bounded by the real-time counter: the leader leaves after `idle` without a doorbell (or on the exit word), a
-// workgroup that hears nothing for 2 x idle leaves by itself; the host notices (`exited`) and goes back to launching.
-typedef unsigned long long u64;
-constexpr u64 RES_EXIT = ~0ull;
-struct ResidentCtl {            // device memory (uncached accesses only)
-    u64 go;                     // leader -> knot workgroups: the doorbell word it acts on ((seq << 8) | destination mask), RES_EXIT, 0 = none yet
-    u64 pad0_[15];
-    unsigned done;              // workgroups that have finished, cumulative over the session
-    unsigned pad1_[31];
-};
-struct ResidentHost {           // pinned host memory
-    u64 bell;                   // host -> leader: (seq << 8) | destination mask — two bits per output (f, grad, g, jac from bit 0):
-                                // 0 = stays in device memory, 1 = the pinned block, 2 = the session's caller array; RES_EXIT = leave
-    u64 pad0_[7];
-    u64 done;                   // kernel -> host: the doorbell word whose outputs are complete in host memory
-    u64 pad1_[7];
-    u64 exited;                 // kernel -> host: non-zero once the leader has decided to leave (the last word it acted on + 1)
-    u64 pad2_[7];
-};
-struct RArgs {
-    ResidentHost* host;         // device-visible address of the pinned block
-    ResidentCtl* ctl;
-    double *hf, *hcost_terms, *hgrad, *hg, *hjac;   // the pinned output block (device-visible addresses)
-    double *cgrad, *cg, *cjac;                      // the session's registered caller arrays (device-visible addresses) or null
-    u64 last;                   // the doorbell word the host last saw completed (the kernel acts on the first word different from it)
-    long idle_ticks;            // 100 MHz real-time counter ticks without a doorbell after which the leader leaves
-};
-template <bool SYS> __device__ __forceinline__ void out_store(double* p, double v) {
-    if constexpr (SYS) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); else *p = v;
-}
-template <bool SYS> __device__ __forceinline__ void out_store(int32_t* p, int32_t v) {
-    if constexpr (SYS) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); else *p = v;
-}
-
 // WAVES = 4: 256 threads; 4 waves per SIMD = 4 workgroups per CU (<= 128 VGPRs, <= 40 KB of LDS on the compact scratch).  The
 //            throughput variant.
 // WAVES = 8: 512 threads, the roles of the knot program spread over twice the waves (two per SIMD).  The latency variant, used
@@ -178,10 +138,9 @@ template <bool SYS> __device__ __forceinline__ void out_store(int32_t* p, int32_
 // Four workgroups per CU for the four-wave kernels (compact scratch + lite tables: <= 40 KB of LDS, <= 128 VGPRs).
 // PEERS: the instantiation behind hipnlp_eval_device_peers (outputs into every rank's buffer); a template parameter rather than a
 // run-time branch — as a branch the unused path cost the plain callback 1.2 % at N = 100 (7.99 against 7.89 us) and 0.8 % at x 64.
-// RESIDENT: the instantiation behind hipnlp_set_resident (eight waves): the body below in a doorbell loop, outputs by sc0 sc1 stores.
-template <int TERRAIN, int WAVES, bool PEERS = false, bool RESIDENT = false> __global__ __launch_bounds__(64 * WAVES)
+template <int TERRAIN, int WAVES, bool PEERS = false> __global__ __launch_bounds__(64 * WAVES)
 __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 4 : 2, 4)))
-void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const double* pk_p, const GParams* gp_p, int N_p, int n_p, int kb_p, int nk_p, KArgs a, RArgs ra) {
+void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const double* pk_p, const GParams* gp_p, int N_p, int n_p, int kb_p, int nk_p, KArgs a) {
     // the leading scalar arguments repeat what the staging loads need: the build preloads them into SGPRs
     // (-mllvm -amdgpu-kernarg-preload-count), so the first global loads do not wait for a kernarg fetch
     constexpr int WG = 64 * WAVES;
@@ -194,26 +153,18 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     const unsigned long long st_entry = __builtin_amdgcn_s_memtime(), st_real0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long st_issued = 0, st_loaded = 0;
 #endif
-    // (thread and workgroup ids as plain variables: the resident instantiation launders them once per doorbell so that the lane and knot
-    //  arithmetic of the whole knot program is not hoisted out of its loop and held in registers across it; the launched kernels never
-    //  modify them)
-    int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    unsigned bx = blockIdx.x, by = blockIdx.y;
-    // (one callback set of this workgroup; in resident mode called once per doorbell)
-    // (the values that differ from doorbell to doorbell are PARAMETERS of the body: assigning to members of the by-value kernel argument
-    //  `a` instead turns it into a private copy in scratch memory — 300 bytes per lane and every register the kernel may have)
-    auto body = [&](const int32_t q_seq, double* const o_f, double* const o_ct, double* o_grad, double* o_g, double* o_jac) __attribute__((always_inline)) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // workgroup -> knot, XCD-aware: workgroups are dealt round-robin over the 8 XCDs (observed, relied on for speed only), each with
     // its own L2, so within one trajectory (one grid row) the workgroups x, x + 8, x + 16, ... share an XCD: they get CONSECUTIVE
     // knots.  The neighbour record x_{k-1} every knot reads is then found in the L2 its owner just filled, and the short runs that
     // neighbouring knots write into one 128-byte line of a constraint block of g meet in one L2 before they leave for HBM
     // (measured, 100 knots x 64, HBM bytes per launch: 26.6 -> 16.5 MB read, 109.6 -> 96.1 MB written; algorithmic: 13.7 + 94.7 MB).
     // A bijection for any row length: class j = x mod 8 owns q + (j < r) knots, q = nk / 8, r = nk mod 8.
-    const int b = by;
+    const int b = blockIdx.y;
     // (launches of at most 256 knots per trajectory: one more workgroup per grid row, the trajectory's cost reducer)
     const unsigned nkx = unsigned(nk_p);   // (= gridDim.x, less the reducer; preloaded: the grid size is a kernarg load away)
     {
-        if (bx == nkx) {
+        if (blockIdx.x == nkx) {
             // ---- total cost without a second kernel and without a tail ---------------------------------------------------------
             // Every knot workgroup publishes its cost partials as soon as they are final (end of phase C) and goes on; THIS
             // workgroup does nothing but poll them (agent-scope loads: the writers sit on other XCDs) until all carry this launch's
@@ -227,7 +178,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             // Forward progress: the reducer of row b waits only for workgroups dispatched before it; it is bounded anyway.
             double* red = reinterpret_cast<double*>(&s);   // [nk][16]
             static_assert(sizeof(Scratch) >= 256 * 16 * sizeof(double), "reducer staging: nk <= 256");
-            const unsigned long long pat = pub_pattern(q_seq);
+            const unsigned long long pat = pub_pattern(a.seq);
             const unsigned long long* base = a.cost_pub + size_t(b) * a.nk * NCT * 2;
             const int t = lane & 15, q = lane >> 4;
             constexpr int KR = 4 * WAVES, U = 256 / KR;   // wave w, lane (t, q): knots 4 w + q + KR u
@@ -243,7 +194,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
                 if (spin >= PUB_SPIN_CAP) {   // never observed; a knot workgroup that died must not hang the device
 #pragma unroll
                     for (int u = 0; u < U; ++u) if ((pending >> u) & 1u) red[(4 * wave + q + KR * u) * 16 + t] = __builtin_nan("");
-                    if (lane == 0) { atomicMax(a.flag + b, q_seq); if (a.flag_host) out_store<RESIDENT>(a.flag_host + b, q_seq); }
+                    if (lane == 0) { atomicMax(a.flag + b, a.seq); if (a.flag_host) a.flag_host[b] = a.seq; }
                     break;
                 }
                 // (eight pairs per pass: sixteen in flight at once would not fit the four-wave kernel's 128 VGPRs)
@@ -283,22 +234,22 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
                     P[w] = pw;
                 }
                 const double term = ((P[0] + P[1]) + P[2]) + P[3];
-                if (lane < NCT) out_store<RESIDENT>(o_ct + size_t(b) * NCT + lane, term);
+                if (lane < NCT) a.cost_terms[size_t(b) * NCT + lane] = term;
                 double tot = 0.0;
 #pragma unroll
                 for (int c = 0; c < NCT; ++c) tot += __shfl(term, c, 64);
                 if (lane == 0) {
-                    out_store<RESIDENT>(o_f + b, tot);
+                    a.f[b] = tot;
                     if constexpr (PEERS) {   // this shard's cost, to every rank's slot for this rank
-                        const int64_t off_f = int64_t(a.n) + a.nnz + a.m + a.peer_rank;
-                        for (int r = 0; r < a.npeer; ++r) a.peer_out[r][off_f] = tot;
+                        const int64_t o_f = int64_t(a.n) + a.nnz + a.m + a.peer_rank;
+                        for (int r = 0; r < a.npeer; ++r) a.peer_out[r][o_f] = tot;
                     }
                 }
             }
             return;
         }
     }
-    const int kk = int((bx & 7u) * (nkx >> 3) + min(bx & 7u, nkx & 7u) + (bx >> 3));
+    const int kk = int((blockIdx.x & 7u) * (nkx >> 3) + min(blockIdx.x & 7u, nkx & 7u) + (blockIdx.x >> 3));
     const int k = kb_p + kk;
     const int N = N_p;
     const double* x = x_p + size_t(b) * n_p;
@@ -333,27 +284,20 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         // walks on by the chunks used, so that the small blocks land on different waves (everything here folds at compile time
         // except the wave number: no scalar branch, one predicated instruction per block and round)
         int rot = 0;
-        // (FRESH: loads that must see what the host wrote since the previous doorbell — x in pinned host memory, which the device caches
-        //  like any other memory between kernel boundaries: a resident kernel reads it with system-scope (sc0 sc1) loads.  Measured
-        //  without: the second callback of a session evaluated the first one's x.)
-        auto stage_as = [&](const void* src, void* dst, int bytes, auto aux_c) __attribute__((always_inline)) {
-            constexpr int AUX = decltype(aux_c)::value;
+        auto stage = [&](const void* src, void* dst, int bytes) __attribute__((always_inline)) {
             for (int r0 = 0; r0 < bytes; r0 += WG * 16) {
                 const int wv = (wave_u + WAVES - rot % WAVES) & (WAVES - 1);
                 const int off = r0 + wv * 1024 + lane * 16;
                 if (off < bytes)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(src) + off),
-                                                     (__attribute__((address_space(3))) void*)(static_cast<char*>(dst) + r0 + wv * 1024), 16, 0, AUX);
+                                                     (__attribute__((address_space(3))) void*)(static_cast<char*>(dst) + r0 + wv * 1024), 16, 0, 0);
                 rot += ((bytes - r0 < WG * 16 ? bytes - r0 : WG * 16) + 1023) / 1024;
             }
         };
-        constexpr int AUX_FRESH = RESIDENT ? 17 : 0;   // cache policy bits of the load: sc0 (1) | sc1 (16) = system scope
-        auto stage = [&](const void* src, void* dst, int bytes) __attribute__((always_inline)) { stage_as(src, dst, bytes, std::integral_constant<int, 0>{}); };
-        auto stage_x = [&](const void* src, void* dst, int bytes) __attribute__((always_inline)) { stage_as(src, dst, bytes, std::integral_constant<int, AUX_FRESH>{}); };
-        stage_x(x + size_t(NXK) * k, s.x, XB);
-        if (!first) stage_x(x + size_t(NXK) * (k - 1), s.xm, XB); else rot += (XB + 1023) / 1024;
+        stage(x + size_t(NXK) * k, s.x, XB);
+        if (!first) stage(x + size_t(NXK) * (k - 1), s.xm, XB); else rot += (XB + 1023) / 1024;
         stage(pk_p + (size_t(b) * N + k) * PK_STRIDE, s.pk, PK_STRIDE * 8);
-        stage_x(x + size_t(NXK) * N, s.xg, NXG * 8);
+        stage(x + size_t(NXK) * N, s.xg, NXG * 8);
         if constexpr (COMPACT) {
             stage(static_cast<const GParamsLite*>(gp_p + b), &tabs.gp, int(sizeof(GParamsLite)));
             stage(&tb.head.ks, &tabs.ks, int(sizeof(KSettings)));
@@ -364,11 +308,8 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         }
         // through registers: the odd last double of the two records; horizon ends only: the periodicity variables of the other end
         double xrem = 0.0, xov = 0.0;
-        auto load_x = [&](const double* q) __attribute__((always_inline)) {
-            if constexpr (RESIDENT) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); else return *q;
-        };
-        if (XREM && tid < 2 && !(first && tid == 1)) xrem = load_x(x + size_t(NXK) * (k - tid) + XB / 8);
-        if (first || last) { if (tid < NPER) xov = load_x(x + size_t(NXK) * (first ? N - 1 : 0) + periodicity_row_var(tid)); }
+        if (XREM && tid < 2 && !(first && tid == 1)) xrem = x[size_t(NXK) * (k - tid) + XB / 8];
+        if (first || last) { if (tid < NPER) xov = x[size_t(NXK) * (first ? N - 1 : 0) + periodicity_row_var(tid)]; }
 #ifdef HIPNLP_STAMPS
         st_issued = __builtin_amdgcn_s_memtime();
 #endif
@@ -407,7 +348,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             unsigned long long* pp = a.cost_pub + ((size_t(b) * a.nk + kk) * NCT + lane) * 2;
             const unsigned long long bits = (unsigned long long)__double_as_longlong(cv);
             __hip_atomic_store(pp, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(pp + 1, bits ^ pub_pattern(q_seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pp + 1, bits ^ pub_pattern(a.seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
     // called by every wave right behind barrier number `passed` (0 = the one that ends phase A)
@@ -503,22 +444,22 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     }
     const int anybad = __any(bad);
 #ifdef HIPNLP_DIAG_SKIP
-    if (HIPNLP_DIAG_SKIP & 1) o_jac = nullptr;
-    if (HIPNLP_DIAG_SKIP & 2) o_g = nullptr;
-    if (HIPNLP_DIAG_SKIP & 4) o_grad = nullptr;
+    if (HIPNLP_DIAG_SKIP & 1) a.jac = nullptr;
+    if (HIPNLP_DIAG_SKIP & 2) a.g = nullptr;
+    if (HIPNLP_DIAG_SKIP & 4) a.grad = nullptr;
 #endif
     if constexpr (PEERS) {
         // peer mode: the same stores as below, once per rank, into that rank's buffer at the entries' final positions (jbase, the g
         // row map and the knot's grad offset are those of the WHOLE problem); the transfers over the links overlap with the knot
         // programs of the workgroups still running — no push pass, no reassembly pass behind the kernel
-        const int64_t off_jac = a.n, off_g = int64_t(a.n) + a.nnz;
+        const int64_t o_jac = a.n, o_g = int64_t(a.n) + a.nnz;
         for (int r = 0; r < a.npeer; ++r) {
             double* base = a.peer_out[r];
-            double* oj = base + off_jac + jbase;
+            double* oj = base + o_jac + jbase;
 #pragma unroll
             for (int it = 0; it < JP_ITERS; ++it) if (jp[it] >= 0) oj[tid + it * WG] = jvals[it];
-            if (last && tid < n_glob) base[off_jac + int64_t(jac_glob_base) + tid] = s.jac[jpg];
-            double* og = base + off_g;
+            if (last && tid < n_glob) base[o_jac + int64_t(jac_glob_base) + tid] = s.jac[jpg];
+            double* og = base + o_g;
 #pragma unroll
             for (int it = 0; it < G_ITERS; ++it) if (ga[it] != G_NONE) og[ga[it] + gb[it] * k] = gvals[it];
             double* ogr = base + int64_t(NXK) * k;
@@ -527,21 +468,17 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             if (last && tid < NXG) base[int64_t(NXK) * N + tid] = 0.0;
         }
     }
-    if (o_jac) {
-        double* out = o_jac + int64_t(b) * a.jac_stride + (jbase - a.jac_off);
+    if (a.jac) {
+        double* out = a.jac + int64_t(b) * a.jac_stride + (jbase - a.jac_off);
 #pragma unroll
-        for (int it = 0; it < JP_ITERS; ++it) if (jp[it] >= 0) out_store<RESIDENT>(out + tid + it * WG, jvals[it]);
+        for (int it = 0; it < JP_ITERS; ++it) if (jp[it] >= 0) out[tid + it * WG] = jvals[it];
         // entries in the horizon-global columns (constants) sit right behind the last knot's block: the last knot writes them
-        if (last && tid < n_glob) out_store<RESIDENT>(o_jac + int64_t(b) * a.jac_stride + (int64_t(jac_glob_base) - a.jac_off) + tid, s.jac[jpg]);
+        if (last && tid < n_glob) a.jac[int64_t(b) * a.jac_stride + (int64_t(jac_glob_base) - a.jac_off) + tid] = s.jac[jpg];
     }
-    if (o_g) {
-        double* out = o_g + size_t(b) * a.m;
+    if (a.g) {
+        double* out = a.g + size_t(b) * a.m;
 #pragma unroll
-        // (resident mode: PLAIN stores and one system-scope release per wave behind them.  The rows of a knot are runs of one to
-        //  twenty-three doubles scattered over the constraint blocks: as sc0 sc1 stores — one acknowledged fabric write per lane — they
-        //  cost a trial-point call 10 us, measured; the contiguous jac / grad runs above and below stay sc0 sc1: no fence for them)
         for (int it = 0; it < G_ITERS; ++it) if (ga[it] != G_NONE) out[ga[it] + gb[it] * k] = gvals[it];
-        if constexpr (RESIDENT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     }
     if (a.g_stage) {
         double* out = a.g_stage + (size_t(b) * a.nk + kk) * gs::COUNT;
@@ -551,20 +488,20 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             if (slot < gs::COUNT) out[slot] = ga[it] != G_NONE ? gvals[it] : 0.0;
         }
     }
-    if (o_grad) {
-        double* out = o_grad + int64_t(b) * a.grad_stride + (int64_t(NXK) * k - a.grad_off);
+    if (a.grad) {
+        double* out = a.grad + int64_t(b) * a.grad_stride + (int64_t(NXK) * k - a.grad_off);
 #pragma unroll
-        for (int it = 0; it < GR_ITERS; ++it) { const int i = tid + it * WG; if (i < NXK) out_store<RESIDENT>(out + i, grvals[it]); }
-        if (last && tid < NXG) out_store<RESIDENT>(o_grad + int64_t(b) * a.grad_stride + (int64_t(NXK) * N - a.grad_off) + tid, 0.0);  // the global variables carry no cost
+        for (int it = 0; it < GR_ITERS; ++it) { const int i = tid + it * WG; if (i < NXK) out[i] = grvals[it]; }
+        if (last && tid < NXG) a.grad[int64_t(b) * a.grad_stride + (int64_t(NXK) * N - a.grad_off) + tid] = 0.0;  // the global variables carry no cost
     }
     if (anybad && lane == 0) {   // generation flag: nothing to reset between launches
-        atomicMax(a.flag + b, q_seq);
-        if (a.flag_host) out_store<RESIDENT>(a.flag_host + b, q_seq);
+        atomicMax(a.flag + b, a.seq);
+        if (a.flag_host) a.flag_host[b] = a.seq;
     }
 #ifdef HIPNLP_STAMPS
     {
         st_arr[bid] = __builtin_amdgcn_s_memtime();   // after the vote and the store issue
-        unsigned long long* stamp_out = a.stamps + ((size_t(by) * nkx + bx) * 8 + wave) * 128;   // (knot workgroups only: nkx per row)
+        unsigned long long* stamp_out = a.stamps + ((size_t(blockIdx.y) * nkx + blockIdx.x) * 8 + wave) * 128;   // (knot workgroups only: nkx per row)
         if (lane == 0) {
             stamp_out[0] = st_entry; stamp_out[1] = st_staged; stamp_out[2] = (unsigned long long)bid;
             for (int i = 0; i < 8; ++i) { stamp_out[8 + 2 * i] = i <= bid ? st_arr[i] : 0; stamp_out[9 + 2 * i] = i < bid ? st_dep[i] : 0; }
@@ -577,66 +514,6 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         }
     }
 #endif
-    };   // body
-    if constexpr (!RESIDENT) {
-        body(a.seq, a.f, a.cost_terms, a.grad, a.g, a.jac);
-    } else {
-        // ---- resident mode: the body once per doorbell ------------------------------------------------------------------------
-        __shared__ u64 s_word;
-        const unsigned wgs = gridDim.x * gridDim.y;
-        const bool leader = blockIdx.x == unsigned(nk_p) && blockIdx.y == 0;
-        u64 last_word = 0, last_acted = ra.last;
-        unsigned rounds = 0;
-        for (;;) {
-            if (tid == 0) {
-                const u64 t0 = __builtin_amdgcn_s_memrealtime();
-                u64 word;
-                if (leader) {
-                    for (;;) {
-                        word = __hip_atomic_load(&ra.host->bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        if (word != last_acted) break;
-                        if (long(__builtin_amdgcn_s_memrealtime() - t0) > ra.idle_ticks) { word = RES_EXIT; break; }
-                    }
-                    if (word == RES_EXIT) __hip_atomic_store(&ra.host->exited, last_acted + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(&ra.ctl->go, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    for (;;) {
-                        word = __hip_atomic_load(&ra.ctl->go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (word != last_word) break;
-                        if (long(__builtin_amdgcn_s_memrealtime() - t0) > 2 * ra.idle_ticks) { word = RES_EXIT; break; }   // (a leader that never ran)
-                    }
-                }
-                s_word = word;
-            }
-            __syncthreads();
-            const u64 word = s_word;
-            __syncthreads();
-            if (word == RES_EXIT) break;
-            // (the pointers every load of the body starts from are laundered once per round: without it the compiler hoists the
-            //  loop-invariant address arithmetic of the whole knot program — every lane / knot index — out of the doorbell loop and holds
-            //  it in registers across it: 256 VGPRs and 300 bytes of scratch per lane instead of the 112 VGPRs of the launched kernel)
-            asm volatile("" : "+s"(tb_p), "+s"(x_p), "+s"(pk_p), "+s"(gp_p), "+s"(bx), "+s"(by), "+v"(lane) : : "memory");
-            tid = (wave << 6) | lane;   // (the wave number stays what the compiler knows it to be: a scalar)
-            last_word = last_acted = word;
-            const unsigned mask = unsigned(word & 0xffu);
-            // An output the doorbell does not ask for is NOT STORED (null): nothing a resident kernel leaves in device memory would be
-            // visible to a later copy command — its stores sit in this XCD's L2 until a release — and 1.5 MB of stores nobody reads
-            // cost a trial-point call more than its kernel.  The host evaluates again should such an output be asked for later.
-            auto pick = [](unsigned sel, double* pinned, double* caller) -> double* { return sel == 0 ? nullptr : (sel == 1 ? pinned : caller); };
-            // (f and the per-term costs — 8 + 96 bytes per trajectory — always go to the host, like the non-finite flag)
-            body(int32_t(word >> 8), ra.hf, ra.hcost_terms, pick((mask >> 2) & 3u, ra.hgrad, ra.cgrad),
-                 pick((mask >> 4) & 3u, ra.hg, ra.cg), pick((mask >> 6) & 3u, ra.hjac, ra.cjac));
-            // completion: every wave behind its own stores (sc0 sc1 stores are acknowledged once visible to the host), one lane per
-            // workgroup counts, the workgroup whose count completes the round raises the word the host polls
-            ++rounds;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                const unsigned old = __hip_atomic_fetch_add(&ra.ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old + 1 == rounds * wgs) __hip_atomic_store(&ra.host->done, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    }
 }
 
 // =====================================================================================================================
@@ -903,17 +780,6 @@ struct hipnlp_handle {
     const void* no_auto[3] = {nullptr, nullptr, nullptr};     // pointers that failed to register or failed the sentinel check: left alone
     unsigned long long sentinel_salt = 0;
     long auto_registered = 0, auto_fallbacks = 0;
-    // resident mode (hipnlp_set_resident): the eight-wave kernel waiting on the device for a doorbell in pinned memory
-    bool res_enabled = false, res_alive = false;
-    double res_idle_us = 0.0;
-    int res_failures = 0;                 // sessions that ended badly (no answer); three disable the mode for the handle
-    hipStream_t rstream = nullptr;
-    ResidentHost* h_res = nullptr;        // pinned
-    ResidentHost* hd_res = nullptr;       // its device-visible address
-    ResidentCtl* d_rctl = nullptr;
-    u64 res_last_done = 0;                // the doorbell word last seen completed
-    double* res_caller[3] = {nullptr, nullptr, nullptr};   // device-visible addresses of the session's caller arrays (grad, g, jac)
-    long res_sessions = 0, res_calls = 0;
     bool time_host = false;       // bracket host-path launches with events (hipnlp_set_host_timing)
     double host_us[4] = {0, 0, 0, 0};   // wall clock of the last host-path evaluation: x staging, enqueue, wait for the GPU, copies out
     std::vector<double> p;
@@ -943,21 +809,19 @@ static void free_all(hipnlp_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* dptrs[] = {h->d_tb, h->d_x, h->d_pk, h->d_cost_knot, h->d_gp, h->d_cost_pub, h->d_out, h->d_ht, h->d_sigma, h->d_hess, h->d_hflag, h->d_rctl};
+    void* dptrs[] = {h->d_tb, h->d_x, h->d_pk, h->d_cost_knot, h->d_gp, h->d_cost_pub, h->d_out, h->d_ht, h->d_sigma, h->d_hess, h->d_hflag};
     for (void* q : dptrs) if (q) (void)hipFree(q);
-    void* hptrs[] = {h->h_x, h->h_out, h->h_hess, h->h_hflag, h->h_sl, h->h_res};
+    void* hptrs[] = {h->h_x, h->h_out, h->h_hess, h->h_hflag, h->h_sl};
     for (void* q : hptrs) if (q) (void)hipHostFree(q);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
-    if (h->rstream) (void)hipStreamDestroy(h->rstream);
     delete h;
 }
 
 extern "C" {
 
-static int resident_retire(hipnlp_handle* h);
 static void auto_unregister_all(hipnlp_handle* h);
 
 const char* hipnlp_last_error(const hipnlp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
@@ -1102,7 +966,6 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
 void hipnlp_destroy(hipnlp_handle* h) {
     if (h) {
         (void)hipSetDevice(h->dev);
-        (void)resident_retire(h);
         auto_unregister_all(h);
     }
     free_all(h);
@@ -1134,8 +997,6 @@ int hipnlp_get_dims(const hipnlp_handle* h, hipnlp_dims* o) {
 int hipnlp_set_params(hipnlp_handle* h, const double* p) {
     if (!h || !p) return HIPNLP_E_INVALID;
     HIP_TRY(h, hipSetDevice(h->dev));
-    // (a resident session caches the parameter records it read: it ends here and the next callback starts another)
-    { const int rc = resident_retire(h); if (rc != HIPNLP_OK) return rc; }
     const size_t B = size_t(h->batch), N = size_t(h->L.N);
     h->p.assign(p, p + B * size_t(h->np));
     std::vector<double> pk(B * N * PK_STRIDE);
@@ -1187,7 +1048,7 @@ int hipnlp_sparsity(const hipnlp_handle* h, int32_t* irow, int32_t* jcol) {
 // the launches an armed profile selects (every stride-th launch), so that measuring does not change what is measured.
 static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, hipStream_t s,
                   double* g_stage = nullptr, bool shard_local = false, bool always_timed = false, bool host_block = false,
-                  double* const* peer_out = nullptr, int npeer = 0, int peer_rank = 0, const RArgs* resident = nullptr) {
+                  double* const* peer_out = nullptr, int npeer = 0, int peer_rank = 0) {
     KArgs a;
     a.peer_out = peer_out; a.npeer = npeer; a.peer_rank = peer_rank;
     a.tb = h->d_tb; a.x = x_dev; a.pk = h->d_pk; a.gp = h->d_gp;
@@ -1216,15 +1077,15 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
         h->seq_result = -1;
         h->have_result = false;
     }
-    a.seq = resident ? 0 : ++h->seq; a.pad_ = 0;   // (a resident session takes the launch number of every callback from its doorbell word)
+    a.seq = ++h->seq; a.pad_ = 0;
     a.N = h->L.N; a.n = h->L.n; a.m = h->L.m; a.nnz = h->L.nnz; a.knot_begin = h->kb; a.nk = h->nk;
     bool prof = false, run_first = false, run_last = false;
-    if (!resident && h->prof_cap > 0 && h->prof_run > 0) {        // runs of consecutive launches: one event before the first, one after the last
+    if (h->prof_cap > 0 && h->prof_run > 0) {        // runs of consecutive launches: one event before the first, one after the last
         const int pos = h->prof_seen % h->prof_run;
         run_first = !h->prof_open && h->prof_n < h->prof_cap && pos == 0;
         run_last = (h->prof_open || run_first) && pos == h->prof_run - 1;
         h->prof_seen++;
-    } else if (!resident && h->prof_cap > 0) { prof = h->prof_n < h->prof_cap && (h->prof_seen % h->prof_stride) == 0; h->prof_seen++; }
+    } else if (h->prof_cap > 0) { prof = h->prof_n < h->prof_cap && (h->prof_seen % h->prof_stride) == 0; h->prof_seen++; }
     const bool timed = prof || always_timed;
     hipEvent_t e0 = prof ? h->prof_ev[size_t(3 * h->prof_n)] : h->ev0;
     hipEvent_t e2 = prof ? h->prof_ev[size_t(3 * h->prof_n + 2)] : h->ev1;
@@ -1236,26 +1097,20 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     if (timed) HIP_TRY(h, hipEventRecord(e0, s));
     const dim3 grid(unsigned(h->nk) + (h->fused ? 1u : 0u), unsigned(h->batch));   // (+ the row's cost reducer)
     const bool planar = h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR;
-    if (resident) {   // the eight-wave kernel in its doorbell loop (hipnlp_set_resident); leaves by itself
-        if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8, false, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a, *resident);
-        else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8, false, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a, *resident);
-        HIP_TRY(h, hipGetLastError());
-        return HIPNLP_OK;
-    }
     if (peer_out) {
         if (h->wide) {
-            if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a, RArgs{});
-            else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a, RArgs{});
+            if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+            else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
         } else {
-            if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 4, true>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a, RArgs{});
-            else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 4, true>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a, RArgs{});
+            if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 4, true>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+            else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 4, true>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
         }
     } else if (h->wide) {   // the whole launch resident at once: eight waves per knot
-        if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a, RArgs{});
-        else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a, RArgs{});
+        if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+        else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
     } else {
-        if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 4>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a, RArgs{});
-        else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 4>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a, RArgs{});
+        if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 4>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+        else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 4>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 1)], s));
     if (!h->fused)
@@ -1434,80 +1289,6 @@ int hipnlp_stage_rows(const hipnlp_handle* h, int k, int32_t* rows) {
     return HIPNLP_OK;
 }
 
-// ---- resident sessions -------------------------------------------------------------------------------------------------------------
-static int resident_retire(hipnlp_handle* h) {
-    if (!h->res_alive) return HIPNLP_OK;
-    __atomic_store_n(&h->h_res->bell, RES_EXIT, __ATOMIC_RELEASE);
-    const hipError_t e = hipStreamSynchronize(h->rstream);   // bounded: every wait of the kernel is (idle limit)
-    h->res_alive = false;
-    __atomic_store_n(&h->h_res->bell, h->res_last_done, __ATOMIC_RELEASE);   // (the next session must not find the exit word)
-    if (e != hipSuccess) { h->err = std::string("resident kernel: ") + hipGetErrorString(e); return HIPNLP_E_NODEVICE; }
-    return HIPNLP_OK;
-}
-static int resident_start(hipnlp_handle* h, double* const caller[3]) {
-    if (!h->rstream) HIP_TRY(h, hipStreamCreateWithFlags(&h->rstream, hipStreamNonBlocking));
-    if (!h->h_res) {
-        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_res), sizeof(ResidentHost)));
-        std::memset(h->h_res, 0, sizeof(ResidentHost));
-        void* d = nullptr;
-        HIP_TRY(h, hipHostGetDevicePointer(&d, h->h_res, 0));
-        h->hd_res = static_cast<ResidentHost*>(d);
-    }
-    if (!h->d_rctl) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_rctl), sizeof(ResidentCtl)));
-    __atomic_store_n(&h->h_res->exited, 0ull, __ATOMIC_RELEASE);
-    __atomic_store_n(&h->h_res->bell, h->res_last_done, __ATOMIC_RELEASE);
-    HIP_TRY(h, hipMemsetAsync(h->d_rctl, 0, sizeof(ResidentCtl), h->rstream));
-    RArgs r;
-    r.host = h->hd_res; r.ctl = h->d_rctl;
-    r.hf = h->hd_f; r.hcost_terms = h->hd_cost_terms; r.hgrad = h->hd_grad; r.hg = h->hd_g; r.hjac = h->hd_jac;
-    r.cgrad = caller[0]; r.cg = caller[1]; r.cjac = caller[2];
-    r.last = h->res_last_done;
-    r.idle_ticks = long(h->res_idle_us * 100.0);   // 100 MHz real-time counter
-    for (int q = 0; q < 3; ++q) h->res_caller[q] = caller[q];
-    const int rc = launch(h, h->hd_x, h->d_f, h->d_grad, h->d_g, h->d_jac, h->rstream, nullptr, false, false, true, nullptr, 0, 0, &r);
-    if (rc != HIPNLP_OK) return rc;
-    h->res_alive = true;
-    h->res_sessions++;
-    return HIPNLP_OK;
-}
-// One callback through the resident kernel: rings the doorbell with the call's destination mask and waits for the completion word.
-// Returns HIPNLP_OK, or 1 when the resident path is not available for this call (the caller launches instead).
-static int resident_call(hipnlp_handle* h, unsigned mask, double* const caller[3]) {
-    if (h->seq >= INT32_MAX - 1) { (void)resident_retire(h); return 1; }   // (the launch path renews everything that carries a launch number)
-    bool fits = true;
-    for (int q = 0; q < 3; ++q) if (((mask >> (2 + 2 * q)) & 3u) == 2u && h->res_caller[q] != caller[q]) fits = false;
-    if (h->res_alive && !fits) { const int rc = resident_retire(h); if (rc != HIPNLP_OK) return rc; }
-    if (!h->res_alive) { const int rc = resident_start(h, caller); if (rc != HIPNLP_OK) return rc; }
-    const u64 word = (u64(uint32_t(++h->seq)) << 8) | u64(mask & 0xffu);
-    __atomic_store_n(&h->h_res->bell, word, __ATOMIC_RELEASE);
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spin = 1;; ++spin) {
-        if (__atomic_load_n(&h->h_res->done, __ATOMIC_ACQUIRE) == word) break;
-        if ((spin & 255u) == 0) {
-            if (__atomic_load_n(&h->h_res->exited, __ATOMIC_ACQUIRE) != 0) {
-                // the leader decided to leave (idle limit) while the doorbell was on its way: the kernel drains by itself; start over
-                HIP_TRY(h, hipStreamSynchronize(h->rstream));
-                h->res_alive = false;
-                if (__atomic_load_n(&h->h_res->done, __ATOMIC_ACQUIRE) == word) break;
-                const int rc = resident_start(h, caller);   // (acts on the word already in the doorbell: it differs from res_last_done)
-                if (rc != HIPNLP_OK) return rc;
-                __atomic_store_n(&h->h_res->bell, word, __ATOMIC_RELEASE);
-            } else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
-                // no answer: some workgroup never ran or left alone.  The kernel is bounded; wait it out, then launch instead.
-                __atomic_store_n(&h->h_res->bell, RES_EXIT, __ATOMIC_RELEASE);
-                (void)hipStreamSynchronize(h->rstream);
-                h->res_alive = false;
-                __atomic_store_n(&h->h_res->bell, h->res_last_done, __ATOMIC_RELEASE);
-                if (++h->res_failures >= 3) h->res_enabled = false;
-                return 1;
-            }
-        }
-    }
-    h->res_last_done = word;
-    h->res_calls++;
-    return HIPNLP_OK;
-}
-
 // ---- auto-registration of caller arrays ----------------------------------------------------------------------------------------------
 // (the ranges a handle registered by itself are the entries of g_ranges it owns; an explicit hipnlp_host_register of the same array
 //  takes the entry over, an explicit hipnlp_host_unregister removes it whoever owns it)
@@ -1539,7 +1320,6 @@ static double* caller_array_address(hipnlp_handle* h, int q, double* p, size_t b
     if (!dev && h->auto_reg && bytes >= AUTO_MIN_BYTES && h->last_seen[q] == p && h->no_auto[q] != p) {
         char* oldest = nullptr;
         if (auto_count(h, &oldest) >= AUTO_MAX) (void)hipnlp_host_unregister(oldest);
-        if (h->res_alive) (void)resident_retire(h);   // (page-locking memory while a kernel spins: not with a resident session open)
         void* d = nullptr;
         if (hipnlp_host_register(p, bytes, &d) == HIPNLP_OK) {
             // (diagnostic, tests only: HIPNLP_DEBUG_MISDIRECT_AUTO maps the array to the pinned block's copy of the output instead —
@@ -1566,7 +1346,8 @@ static double* caller_array_address(hipnlp_handle* h, int q, double* p, size_t b
 // earlier call), the pinned block (wanted or in the prefetch set), or device memory.  A cached evaluation (new_x = 0): outputs not on
 // the host yet are fetched from the device copies with one asynchronous copy each.  (Measured on MI355X, profiles/r02_pcie_probe.txt,
 // r03_doorbell_probe.txt: launch + synchronise 13 us; kernel stores to pinned memory 56 GB/s; the same bytes through device memory +
-// hipMemcpyAsync: + 10 us; the resident kernel's doorbell: launch + synchronise replaced by ~3 us.)
+// hipMemcpyAsync: + 10 us.  A resident kernel behind a doorbell in place of launch + synchronise was built, measured slower
+// once x is read fresh and the outputs are made visible to the host, and removed: profiles/r03_resident_experiment.txt.)
 struct HostDest {   // registered caller arrays: device-visible addresses (or null) and the host addresses they belong to
     double *grad = nullptr, *g = nullptr, *jac = nullptr;
     double *grad_host = nullptr, *g_host = nullptr, *jac_host = nullptr;
@@ -1619,17 +1400,9 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
                 checked[q] = true;
             }
         const bool f_host = (to_host & HIPNLP_WANT_F) != 0;
-        int rc = 1;
-        bool via_resident = false;
+        int rc;
         std::chrono::steady_clock::time_point t2, t3;
-        if (h->res_enabled && h->wide && h->x_zero_copy && !h->time_host) {
-            const unsigned mask = (f_host ? 1u : 0u) | (sel[0] << 2) | (sel[1] << 4) | (sel[2] << 6);
-            rc = resident_call(h, mask, caller_dev);
-            if (rc < 0) return rc;
-            t2 = t3 = std::chrono::steady_clock::now();
-            if (rc == 0) { via_resident = true; h->host_us[1] = 0.0; h->host_us[2] = std::chrono::duration<double, std::micro>(t3 - t1).count(); }
-        }
-        if (rc != 0) {   // launch + synchronise
+        {   // launch + synchronise
             const double* xsrc = h->hd_x;
             if (!h->x_zero_copy) {
                 HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_x, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -1654,7 +1427,6 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
             if (checked[q]) {
                 const u64* w = reinterpret_cast<const u64*>(caller_host[q]);
                 if (__atomic_load_n(&w[0], __ATOMIC_RELAXED) == sentinel || __atomic_load_n(&w[bytes[q] / 8 - 1], __ATOMIC_RELAXED) == sentinel) {
-                    if (h->res_alive) (void)resident_retire(h);
                     (void)hipnlp_host_unregister(caller_host[q]);
                     h->no_auto[q] = caller_host[q];
                     if (h->seen_host[q] == caller_host[q]) h->seen_host[q] = nullptr;
@@ -1671,12 +1443,9 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
         }
         h->have_result = true;
         h->seq_result = h->seq;
-        h->on_host = ((f_host || via_resident) ? HIPNLP_WANT_F : 0u);
+        h->on_host = (f_host ? HIPNLP_WANT_F : 0u);
         for (int q = 0; q < 3; ++q) if (sel[q] == 1u) h->on_host |= bit[q];
         h->gone = dmask | h->early_mask;
-        // (a resident kernel does not store what the call does not bring to the host: such an output exists nowhere and is evaluated
-        //  again should a later call ask for it)
-        if (via_resident) for (int q = 0; q < 3; ++q) if (sel[q] == 0u) h->gone |= bit[q];
         if (direct) *direct = dmask;
     }
     if (h->early_mask && !(new_x)) {   // a cached request for an output that already sits in the caller's own array
@@ -1692,7 +1461,6 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
     if (missing) {   // still in HBM: one copy each — straight into the caller's array when that is registered (page-locked), else into the pinned block
         HIP_TRY(h, hipSetDevice(h->dev));
         unsigned to_caller = 0;
-        // (the copies run on the handle's stream; a resident session writes device memory only while it works on a doorbell)
         if (missing & HIPNLP_WANT_F) HIP_TRY(h, hipMemcpyAsync(h->h_f, h->d_f, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         if (missing & HIPNLP_WANT_GRAD) {
             if (dst.grad_host) to_caller |= HIPNLP_WANT_GRAD;
@@ -1763,36 +1531,16 @@ int hipnlp_set_auto_register(hipnlp_handle* h, int on) {
     if (!h) return HIPNLP_E_INVALID;
     h->auto_reg = on != 0;
     if (!h->auto_reg) {
-        if (h->res_alive) (void)resident_retire(h);
         auto_unregister_all(h);
         for (int q = 0; q < 3; ++q) { h->last_seen[q] = nullptr; h->no_auto[q] = nullptr; }
     }
     return HIPNLP_OK;
 }
 
-int hipnlp_set_resident(hipnlp_handle* h, double idle_us) {
-    if (!h || !(idle_us >= 0.0) || idle_us > 1e6) return HIPNLP_E_INVALID;
-    if (idle_us == 0.0) {
-        h->res_enabled = false;
-        return resident_retire(h);
-    }
-    // one workgroup per compute unit: the resident instantiation may use every register of a SIMD's two waves
-    if (!h->wide || !h->fused || !h->x_zero_copy || (long(h->nk) + 1) * long(h->batch) > 256) {
-        h->err = "hipnlp_set_resident: only handles whose whole launch is resident at once at one workgroup per compute unit ((knots + 1) x batch <= 256)";
-        return HIPNLP_E_UNSUPPORTED;
-    }
-    if (h->res_alive && idle_us != h->res_idle_us) { const int rc = resident_retire(h); if (rc != HIPNLP_OK) return rc; }
-    h->res_idle_us = idle_us;
-    h->res_enabled = true;
-    h->res_failures = 0;
-    return HIPNLP_OK;
-}
-
 int hipnlp_host_stats(const hipnlp_handle* h, long* out /*[8]*/) {
     if (!h || !out) return HIPNLP_E_INVALID;
     out[0] = h->auto_registered; out[1] = h->auto_fallbacks; out[2] = long(auto_count(h));
-    out[3] = h->res_sessions; out[4] = h->res_calls; out[5] = h->res_alive ? 1 : 0;
-    out[6] = long(h->seq); out[7] = 0;
+    out[3] = long(h->seq); out[4] = out[5] = out[6] = out[7] = 0;
     return HIPNLP_OK;
 }
 
@@ -1940,23 +1688,30 @@ __global__ void hipnlp_peer_signal_kernel(unsigned long long* const* peer_flags,
     const int r = threadIdx.x;
     if (r < world) __hip_atomic_store(peer_flags[r] + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__global__ void hipnlp_peer_wait_kernel(const unsigned long long* flags, int world, unsigned long long seq, double* out, int64_t f_off, int* status) {
+// One workgroup of 64 x 4 threads.  A wait that gives up is STICKY: *status is only ever raised here (the host clears it), and every
+// output of the step is poisoned — f as before, and grad / jac / g as well (out[0 .. f_off)): a step whose pushes may be partial must
+// not look like an ordinary evaluation with a bad cost.
+__global__ __launch_bounds__(256) void hipnlp_peer_wait_kernel(const unsigned long long* flags, int world, unsigned long long seq, double* out, int64_t f_off, int* status) {
+    __shared__ int s_late;
     const int r = threadIdx.x;
-    int late = 0;
+    if (r == 0) s_late = 0;
+    __syncthreads();
     if (r < world) {
         int spins = 0;
         while (__hip_atomic_load(flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-            if (++spins > (1 << 20)) { late = 1; break; }   // (a rank that died must not hang this device)
+            if (++spins > (1 << 20)) { s_late = 1; break; }   // (a rank that died must not hang this device)
             __builtin_amdgcn_s_sleep(8);
         }
     }
-    late = __any(late);
+    __syncthreads();
+    const int late = s_late;
     __threadfence_system();
+    if (late) for (int64_t i = r; i < f_off; i += blockDim.x) out[i] = __builtin_nan("");
     if (r == 0) {
         double f = 0.0;
         for (int q = 0; q < world; ++q) f += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(out + f_off + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
         out[f_off + world] = late ? __builtin_nan("") : f;
-        *status = late;
+        if (late) atomicOr(status, 1);
     }
 }
 
@@ -2004,7 +1759,7 @@ int hipnlp_peer_signal(unsigned long long* const* peer_flags_dev, int world, int
 }
 int hipnlp_peer_wait(const unsigned long long* flags_dev, int world, unsigned long long seq, double* out_dev, int64_t f_off, int* status_dev, void* stream) {
     if (!flags_dev || !out_dev || !status_dev || world < 1 || world > 64) return HIPNLP_E_INVALID;
-    hipLaunchKernelGGL(hipnlp_peer_wait_kernel, dim3(1), dim3(64), 0, hipStream_t(stream), flags_dev, world, seq, out_dev, f_off, status_dev);
+    hipLaunchKernelGGL(hipnlp_peer_wait_kernel, dim3(1), dim3(256), 0, hipStream_t(stream), flags_dev, world, seq, out_dev, f_off, status_dev);
     return hipGetLastError() == hipSuccess ? HIPNLP_OK : HIPNLP_E_NODEVICE;
 }
 

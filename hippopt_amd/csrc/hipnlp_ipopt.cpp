@@ -103,26 +103,20 @@ int hipnlp_ipopt_bounds(hipnlp_handle* h, Number* x_L, Number* x_U, Number* g_L,
     return HIPNLP_OK;
 }
 
-int hipnlp_ipopt_attach(hipnlp_handle* h, double resident_idle_us) {
+int hipnlp_ipopt_attach(hipnlp_handle* h) {
     if (!h) return HIPNLP_E_INVALID;
     int rc = hipnlp_set_auto_register(h, 1);
     if (rc == HIPNLP_OK) rc = hipnlp_set_early_outputs(h, 1);
-    if (rc == HIPNLP_OK && resident_idle_us > 0.0) {
-        rc = hipnlp_set_resident(h, resident_idle_us);
-        if (rc == HIPNLP_E_UNSUPPORTED) rc = HIPNLP_OK;   // (a launch that is not resident at once: launched per callback as before)
-    }
     return rc;
 }
 
 int hipnlp_ipopt_detach(hipnlp_handle* h) {
     if (!h) return HIPNLP_E_INVALID;
-    int rc = hipnlp_set_resident(h, 0.0);
-    const int r2 = hipnlp_set_early_outputs(h, 0);
-    const int r3 = hipnlp_set_auto_register(h, 0);   // releases the registrations of IPOPT's arrays
-    const int r4 = hipnlp_set_auto_register(h, 1);
+    int rc = hipnlp_set_early_outputs(h, 0);
+    const int r2 = hipnlp_set_auto_register(h, 0);   // releases the registrations of IPOPT's arrays
+    const int r3 = hipnlp_set_auto_register(h, 1);
     if (rc == HIPNLP_OK) rc = r2;
     if (rc == HIPNLP_OK) rc = r3;
-    if (rc == HIPNLP_OK) rc = r4;
     return rc;
 }
 

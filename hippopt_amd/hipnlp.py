@@ -24,7 +24,7 @@ EXPORTS = [
     "hipnlp_ipc_alloc", "hipnlp_ipc_open", "hipnlp_ipc_close", "hipnlp_ipc_free", "hipnlp_peer_push", "hipnlp_peer_signal", "hipnlp_peer_wait", "hipnlp_eval_device_peers",
     "hipnlp_hess_nnz", "hipnlp_hess_sparsity", "hipnlp_eval_hess", "hipnlp_eval_hess_device",
     "hipnlp_eval_pinned", "hipnlp_set_prefetch", "hipnlp_set_early_outputs", "hipnlp_set_host_timing", "hipnlp_host_register", "hipnlp_host_unregister",
-    "hipnlp_host_breakdown", "hipnlp_set_auto_register", "hipnlp_set_resident", "hipnlp_host_stats",
+    "hipnlp_host_breakdown", "hipnlp_set_auto_register", "hipnlp_host_stats",
     "hipnlp_pose_create", "hipnlp_pose_destroy", "hipnlp_pose_last_error", "hipnlp_pose_get_dims", "hipnlp_pose_set_params",
     "hipnlp_pose_bounds", "hipnlp_pose_sparsity", "hipnlp_pose_eval", "hipnlp_pose_eval_device", "hipnlp_pose_cost_terms",
     "hipnlp_pose_cost_term_name", "hipnlp_pose_num_row_blocks", "hipnlp_pose_row_block", "hipnlp_pose_last_kernel_ms",
@@ -129,7 +129,6 @@ def load_library():
     lib.hipnlp_host_unregister.argtypes = [vp]
     lib.hipnlp_host_breakdown.argtypes = [vp, dp]
     lib.hipnlp_set_auto_register.argtypes = [vp, C.c_int]
-    lib.hipnlp_set_resident.argtypes = [vp, C.c_double]
     lib.hipnlp_host_stats.argtypes = [vp, C.POINTER(C.c_long)]
     _lib = lib
     return lib
@@ -309,15 +308,10 @@ class HipNlp:
         """hipnlp_set_auto_register: output arrays seen twice in a row at one address become direct kernel outputs (on by default)"""
         self._check(self.lib.hipnlp_set_auto_register(self.h, 1 if on else 0))
 
-    def set_resident(self, idle_us=200.0):
-        """hipnlp_set_resident: the callback kernel waits on the device for a doorbell instead of being launched per call; it leaves
-        idle_us after its last callback.  0 switches the mode off."""
-        self._check(self.lib.hipnlp_set_resident(self.h, float(idle_us)))
-
     def host_stats(self):
         out = (C.c_long * 8)()
         self._check(self.lib.hipnlp_host_stats(self.h, out))
-        return dict(zip(("auto_registered", "auto_fallbacks", "auto_ranges", "resident_sessions", "resident_calls", "resident_alive", "evaluations"), list(out)))
+        return dict(zip(("auto_registered", "auto_fallbacks", "auto_ranges", "evaluations"), list(out)))
 
     def set_host_timing(self, on=True):
         self._check(self.lib.hipnlp_set_host_timing(self.h, 1 if on else 0))

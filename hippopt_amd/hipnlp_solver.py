@@ -144,12 +144,12 @@ class _CallbackCache:
     way INTEGRATION.md tells a C binding to use it: ONE set of output arrays for the whole solve (the handle registers them at
     their second sight: the kernel stores straight into them, no staging copy), early outputs on (the first callback at a new x
     fills all four arrays: one transfer per iterate), `new_x` unknown (the drivers without IPOPT's flag — cyipopt, SciPy — pass
-    none: the library compares x with its staging copy instead of Python comparing and copying 151 KB per callback), optionally the
-    resident callback kernel.  The callbacks hand out VIEWS of those arrays, valid until the next evaluation (cyipopt copies them
+    none: the library compares x with its staging copy instead of Python comparing and copying 151 KB per callback).  The callbacks
+    hand out VIEWS of those arrays, valid until the next evaluation (cyipopt copies them
     into IPOPT's arrays at once; the SciPy driver asks for copies where it keeps a result).
     On anything else (the emulated engine of the CPU tests, the pose finder's 81-variable handle) it compares x itself."""
 
-    def __init__(self, eng, resident_idle_us=0.0):
+    def __init__(self, eng):
         self._eng = eng
         self._x = None
         self.calls = {}          # callbacks served, by kind
@@ -161,12 +161,6 @@ class _CallbackCache:
                           for w in (("f",), ("grad",), ("g",), ("jac",), ("f", "grad", "g", "jac"))}
             eng.set_early_outputs(True)
             self._evaluations0 = eng.host_stats()["evaluations"]
-            if resident_idle_us and resident_idle_us > 0:
-                try:
-                    eng.set_resident(float(resident_idle_us))
-                except HipNlpError as err:   # a launch that is not resident at once: launched per callback, as before
-                    if err.code != -6:
-                        raise
 
     @property
     def evaluations(self):
@@ -199,10 +193,6 @@ class _CallbackCache:
     def close(self):
         """the solve is over: the registered arrays go away with this object"""
         if self._fast:
-            try:
-                self._eng.set_resident(0.0)
-            except HipNlpError:
-                pass
             self._eng.set_early_outputs(False)
             self._eng.unregister_outputs(self._out[1:])
 
@@ -210,13 +200,10 @@ class _CallbackCache:
 class HipNlpSolver(OptimizationSolver):
     def __init__(self, settings, model, device=0, inner_solver="auto", options_solver=None, problem="kinodynamic",
                  callback_criterion: CallbackCriterion = None, callback_save_costs=True, callback_save_constraint_multipliers=True,
-                 error_on_fail=True, detect_simple_bounds=True, resident_idle_us=0.0):
+                 error_on_fail=True, detect_simple_bounds=True):
         """callback_* as in OptiSolver (opti_solver.py:105-131).  error_on_fail: CasADi's Opti raises when IPOPT does not report
         success (e.g. Maximum_Iterations_Exceeded), which is what triggers the best-iterate fallback of opti_solver.py:479-520;
-        False keeps the last iterate of an unconverged run instead (useful for smoke runs with a few iterations).
-        resident_idle_us > 0: the callbacks of the solve go through the resident callback kernel (hipnlp_set_resident) where the
-        handle allows it."""
-        self._resident_idle_us = float(resident_idle_us)
+        False keeps the last iterate of an unconverged run instead (useful for smoke runs with a few iterations)."""
         self._callback_criterion = callback_criterion
         self._callback_save_costs = callback_save_costs
         self._callback_save_constraint_multipliers = callback_save_constraint_multipliers
@@ -396,7 +383,7 @@ class HipNlpSolver(OptimizationSolver):
             names, terms = eng.cost_terms()
             return {n: float(v) for n, v in zip(names, terms[0])}
         self._cost_values_at = cost_values_at
-        self._cache = _CallbackCache(eng, self._resident_idle_us)
+        self._cache = _CallbackCache(eng)
         failure = None
         try:
             if solver == "ipopt":

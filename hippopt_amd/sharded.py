@@ -146,6 +146,49 @@ class ShardedCallback:
         cur.wait_stream(self.stream)
         return out
 
+    def to_root(self, x):
+        """gather_to_root by the collective: ONE consumer (IPOPT lives in rank 0's process), so only rank 0 receives — `dist.gather`
+        of the fused shard buffers (RCCL: one send per rank, 1 / world of the all-gather's bytes per link) and rank 0's one-launch
+        reassembly.  Returns (f, grad, jac, g) on rank 0, (None, None, None, None) on the others."""
+        def run(stream_handle):
+            self.compute_shard(x, *self.views, stream_handle)
+            if self.world > 1:
+                chunks = list(self.all.view(self.world, self.shard_len).unbind(0)) if self.rank == 0 else None
+                if self.device.type == "cuda" and dist.get_backend(self.group) == "gloo":   # (rehearsal: several ranks on one GPU)
+                    torch.cuda.current_stream(self.device).synchronize()
+                    host = [torch.empty(self.shard_len, dtype=torch.float64) for _ in range(self.world)] if self.rank == 0 else None
+                    dist.gather(self.buf.cpu(), host, dst=0, group=self.group)
+                    if self.rank == 0:
+                        self.all.copy_(torch.cat(host))
+                else:
+                    dist.gather(self.buf, chunks, dst=0, group=self.group)
+                if self.rank != 0:
+                    return None, None, None, None
+                gathered = self.all
+            else:
+                gathered = self.buf
+            tot = self.n + self.nnz + self.m
+            if self._lib is not None:
+                rc = self._lib.hipnlp_reassemble(gathered.data_ptr(), self.src.data_ptr(), self.out.data_ptr(), tot, self.world, self.shard_len,
+                                                 self.out.data_ptr() + 8 * tot, stream_handle)
+                if rc != 0:
+                    raise RuntimeError("hipnlp_reassemble failed (%d)" % rc)
+                f = self.out[tot]
+            else:
+                torch.index_select(gathered, 0, self.src, out=self.out[:tot])
+                f = gathered.index_select(0, self.f_src).sum()
+            return f, self.out[:self.n], self.out[self.n:self.n + self.nnz], self.out[self.n + self.nnz:tot]
+        if self.stream is None:
+            return run(0)
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream == self.stream.cuda_stream:
+            return run(self.stream.cuda_stream)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            out = run(self.stream.cuda_stream)
+        cur.wait_stream(self.stream)
+        return out
+
     def shard_only(self, x):
         """The rank's shard evaluated into its fused buffer, nothing exchanged (bench.py: outputs left shard-resident)."""
         if self.stream is None:
@@ -178,12 +221,18 @@ class PeerExchange:
     buffer (and step i + 2 cannot start before everyone has signalled i + 1, which comes behind their use of step i in stream order).
     The caller orders its consumption of the views before its next call on the same stream, as with ShardedCallback."""
 
-    def __init__(self, cb, engine=None):
+    def __init__(self, cb, engine=None, root_only=False, handshake_timeout_s=5.0):
+        """root_only: `gather_to_root` — only rank 0 (the process IPOPT lives in: ONE consumer) receives the reassembled outputs.
+        Every rank pushes its shard into rank 0's buffer alone: 1 / world of the all-gather's bytes per link, and rank 0's seven
+        links carry one shard each in parallel.  Rank 0 waits for all `world` flags as before and then stores the step number into
+        every rank's back-flag slot; a rank does not push step i + 2 (same buffer parity as step i) before it has seen rank 0's
+        back-flag for step i, so no rank runs ahead of the consumer by more than the two parities.  The other ranks get (None, ...)."""
         import ctypes as C
         if cb.device.type != "cuda":
             raise RuntimeError("PeerExchange needs the HIP engine (peer stores between device buffers)")
         self.cb = cb
         self.engine = engine
+        self.root_only = bool(root_only)
         if engine is not None and engine.kernels_per_eval() != 1:
             raise RuntimeError("PeerExchange(engine=...): the shard's cost must be summed inside the knot launch (shards of at most 256 knots)")
         self.world, self.rank = cb.world, cb.rank
@@ -254,13 +303,52 @@ class PeerExchange:
         dst[src[own] - lo] = own
         dst[0] = self.tot + self.rank                    # the cost partial
         self.dst = torch.from_numpy(dst).to(dev)
-        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)   # sticky: raised by a wait that gave up, cleared only here
         self.seq = 0
         self._views = []
         for par in (0, 1):   # torch views of this rank's own output buffers
             self._views.append(_device_view(self._mine + 8 * par * self.olen, self.olen, dev))
+        # flag words of a rank: [0, world) step flags | [world, 2 world) back-flags (gather_to_root: slot 0, written by rank 0) |
+        # [32, 32 + world) handshake
+        if 2 * self.world > 32 or 32 + self.world > self.flag_words:
+            raise RuntimeError("peer exchange: at most 16 ranks")
+        self.root_out = [torch.tensor([bases[0] + 8 * par * self.olen], dtype=torch.int64, device=dev) for par in (0, 1)]
+        self.root_flags = torch.tensor([bases[0] + 8 * 2 * self.olen], dtype=torch.int64, device=dev)
+        self.back_flags = torch.tensor([b + 8 * (2 * self.olen + self.world) for b in bases], dtype=torch.int64, device=dev)
+        self.my_back_flags = self._mine + 8 * (2 * self.olen + self.world)
+        self._scratch = torch.zeros(4, dtype=torch.float64, device=dev)
         if self.world > 1:
             dist.barrier(group=cb.group)                  # every rank has opened every buffer
+        self._handshake(bases, handshake_timeout_s)
+
+    def _handshake(self, bases, timeout_s):
+        """One word written into every peer's buffer and one word read from every peer, BEFORE anything is timed or trusted: mapping
+        a peer's allocation (hipnlp_ipc_open) says nothing about stores arriving there.  Every rank stores a token into its slot of
+        every rank's handshake words (the store path of the exchange itself: hipnlp_peer_signal) and waits — bounded by the wait
+        kernel, and by `timeout_s` on the host — for all `world` tokens in its own; the outcome is agreed on collectively, so a link
+        that does not deliver fails loudly on EVERY rank instead of hanging one of them."""
+        import time
+        cb, lib, dev = self.cb, self._lib, self.cb.device
+        token = 0x48414E44 + self.world   # the same on every rank
+        hs = torch.tensor([b + 8 * (2 * self.olen + 32) for b in bases], dtype=torch.int64, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        with torch.cuda.stream(cb.stream):
+            sh = cb.stream.cuda_stream
+            rc = lib.hipnlp_peer_signal(hs.data_ptr(), self.world, self.rank, token, sh)
+            rc |= lib.hipnlp_peer_wait(self._mine + 8 * (2 * self.olen + 32), self.world, token, self._scratch.data_ptr(), 0, status.data_ptr(), sh)
+            done = torch.cuda.Event()
+            done.record(cb.stream)
+        t0 = time.time()
+        while not done.query() and time.time() - t0 < timeout_s:
+            time.sleep(0.001)
+        ok = rc == 0 and done.query() and int(status.item()) == 0
+        oks = [ok]
+        if self.world > 1:
+            oks = [None] * self.world
+            dist.all_gather_object(oks, ok, group=cb.group)
+        if not all(oks):
+            raise RuntimeError("peer exchange handshake failed on rank(s) %s: a word stored into a peer's buffer did not arrive "
+                               "(peer access mapped but not working between these devices)" % [r for r, o in enumerate(oks) if not o])
 
     def __call__(self, x):
         cb = self.cb
@@ -272,26 +360,52 @@ class PeerExchange:
             self.seq += 1
             par = self.seq & 1
             lib = self._lib
+            rc = 0
+            targets = self.root_out[par] if self.root_only else self.peer_out[par]
+            ntargets = 1 if self.root_only else self.world
+            if self.root_only and self.seq > 2:
+                # the buffer of this parity was last used by step seq - 2: rank 0 must have consumed that step (its back-flag)
+                rc |= lib.hipnlp_peer_wait(self.my_back_flags, 1, self.seq - 2, self._scratch.data_ptr(), 0, self.status.data_ptr(), sh)
             if self.engine is not None:
-                self.engine.eval_device_peers(x.data_ptr(), self.peer_out[par].data_ptr(), self.world, self.rank, stream=sh)
-                rc = 0
+                self.engine.eval_device_peers(x.data_ptr(), targets.data_ptr(), ntargets, self.rank, stream=sh)
             else:
                 cb.compute_shard(x, *cb.views, sh)
-                rc = lib.hipnlp_peer_push(cb.buf.data_ptr(), self.dst.data_ptr(), cb.shard_len, self.peer_out[par].data_ptr(), self.world, sh)
-            rc |= lib.hipnlp_peer_signal(self.peer_flags.data_ptr(), self.world, self.rank, self.seq, sh)
+                rc |= lib.hipnlp_peer_push(cb.buf.data_ptr(), self.dst.data_ptr(), cb.shard_len, targets.data_ptr(), ntargets, sh)
+            flags = self.root_flags if self.root_only else self.peer_flags
+            rc |= lib.hipnlp_peer_signal(flags.data_ptr(), ntargets, self.rank, self.seq, sh)
             out = self._views[par]
-            rc |= lib.hipnlp_peer_wait(self.my_flags, self.world, self.seq, out.data_ptr(), self.tot, self.status.data_ptr(), sh)
+            if not self.root_only or self.rank == 0:
+                rc |= lib.hipnlp_peer_wait(self.my_flags, self.world, self.seq, out.data_ptr(), self.tot, self.status.data_ptr(), sh)
+            if self.root_only and self.rank == 0:   # "step seq is complete here": slot 0 of every rank's back-flags
+                rc |= lib.hipnlp_peer_signal(self.back_flags.data_ptr(), self.world, 0, self.seq, sh)
             if rc != 0:
                 raise RuntimeError("peer exchange: a launch failed")
         if cur.cuda_stream != cb.stream.cuda_stream:
             cur.wait_stream(cb.stream)
+        if self.root_only and self.rank != 0:
+            return None, None, None, None
         n, nnz = cb.n, cb.nnz
         return out[self.tot + self.world], out[:n], out[n:n + nnz], out[n + nnz:self.tot]
 
+    def bytes_sent_per_step(self):
+        """bytes this rank stores into OTHER ranks' buffers per step (what its xGMI links carry)"""
+        me = self.cb.infos[self.rank]
+        rows = int((np.asarray(me["stage_rows"]).reshape(-1) >= 0).sum())
+        shard = 8 * (me["glen"] + me["jlen"] + rows + 1)
+        if self.root_only:
+            return 0 if self.rank == 0 else shard
+        return shard * (self.world - 1)
+
     def timed_out(self):
-        """True if a wait gave up (a rank never signalled): synchronises the callback's stream"""
+        """True if ANY wait since set-up gave up (a rank never signalled; sticky: the flag is only raised on the device): the outputs
+        of such a step are NaN throughout.  Synchronises the callback's stream."""
         self.cb.stream.synchronize()
         return bool(self.status.item())
+
+    def check(self):
+        """raises if a wait has given up since set-up"""
+        if self.timed_out():
+            raise RuntimeError("peer exchange: a rank did not signal a step in time; the outputs of that step were poisoned (NaN)")
 
     def close(self, barrier=True):
         """barrier=False: the caller has just been through a barrier of its own behind the last step (every rank's pushes are complete)"""
@@ -353,45 +467,73 @@ class HostSink:
         self.count = self.o_g + m
         nbytes = ((self.count * 8 + 4095) // 4096) * 4096
         self.path = os.path.join("/dev/shm", name)
-        if rank == 0:
-            fd = os.open(self.path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
-            os.ftruncate(fd, nbytes)
+        self.dev = self.host = self._mm = None
+        rc, failure = -1, None
+        # Whatever goes wrong on this rank (mapping, loading the library, registering), it still takes part in the barrier / agreement
+        # below and rank 0 still removes the name: nothing is left behind in /dev/shm and nobody waits for a rank that raised alone.
+        try:
+            if rank == 0:
+                fd = os.open(self.path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
+                try:
+                    os.ftruncate(fd, nbytes)
+                except Exception:
+                    os.close(fd)
+                    raise
+        except Exception as err:  # noqa: BLE001
+            failure = err
         if barrier is not None:
             barrier()
-        if rank != 0:
-            fd = os.open(self.path, os.O_RDWR)
-        self._mm = mmap.mmap(fd, nbytes)
-        os.close(fd)
-        self.host = np.frombuffer(self._mm, dtype=np.float64, count=self.count)
-        self._lib = load_library()
-        self._lib.hipnlp_host_register.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
-        self._lib.hipnlp_host_unregister.argtypes = [C.c_void_p]
-        dev = C.c_void_p()
-        self._addr = self.host.ctypes.data
-        rc = self._lib.hipnlp_host_register(C.c_void_p(self._addr), C.c_size_t(nbytes), C.byref(dev))
-        self.dev = dev.value if rc == 0 else None
-        if agree is not None:
-            all_ok = agree(rc == 0)
-        else:
-            all_ok = rc == 0
-            if barrier is not None and all_ok:
-                barrier()   # every rank holds its mapping: the name can go
-        if rank == 0:
-            os.unlink(self.path)
+        try:
+            if failure is None:
+                if rank != 0:
+                    fd = os.open(self.path, os.O_RDWR)
+                try:
+                    self._mm = mmap.mmap(fd, nbytes)
+                finally:
+                    os.close(fd)
+                self.host = np.frombuffer(self._mm, dtype=np.float64, count=self.count)
+                self._lib = load_library()
+                self._lib.hipnlp_host_register.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+                self._lib.hipnlp_host_unregister.argtypes = [C.c_void_p]
+                dev = C.c_void_p()
+                self._addr = self.host.ctypes.data
+                rc = self._lib.hipnlp_host_register(C.c_void_p(self._addr), C.c_size_t(nbytes), C.byref(dev))
+                self.dev = dev.value if rc == 0 else None
+        except Exception as err:  # noqa: BLE001
+            failure = err
+        try:
+            if agree is not None:
+                all_ok = agree(rc == 0 and failure is None)
+            else:
+                all_ok = rc == 0 and failure is None
+                if barrier is not None:
+                    barrier()   # every rank holds its mapping (or has given up): the name can go
+        finally:
+            if rank == 0 and os.path.exists(self.path):
+                os.unlink(self.path)
         if not all_ok:
             self.close()
-            raise RuntimeError("hipnlp_host_register failed on this or another rank (%d here)" % rc)
+            raise RuntimeError("host sink set-up failed on this or another rank (here: %s)" % (failure if failure is not None else "hipnlp_host_register -> %d" % rc))
 
     def pointers(self):
         """device-visible addresses (f partial of this rank, grad, g, jac) for HipNlp.eval_device on a shard handle"""
         return (self.dev + 8 * self.rank, self.dev + 8 * self.o_grad, self.dev + 8 * self.o_g, self.dev + 8 * self.o_jac)
 
     def views(self):
-        """(f_parts[world], grad[n], jac[nnz], g[m]) numpy views of the shared buffer"""
+        """(f_parts[world], grad[n], jac[nnz], g[m]) numpy views of the shared buffer.
+        VALID ONLY behind a cross-rank fence: every rank's kernel stores its own shard, so a reader needs every rank's stream
+        synchronised AND a barrier between the ranks (a rank's own synchronise covers its own shard's stores only) — `sync(barrier)`."""
         h = self.host
         return h[:self.world], h[self.o_grad:self.o_jac], h[self.o_jac:self.o_g], h[self.o_g:self.count]
 
+    def sync(self, barrier, synchronize):
+        """the cross-rank fence views() / f() need: this rank's stream synchronised (`synchronize()`), then every rank through `barrier()`"""
+        synchronize()
+        if barrier is not None:
+            barrier()
+
     def f(self):
+        """sum of the rank partials in rank order (same fence requirement as views())"""
         parts = self.host[:self.world]
         tot = 0.0
         for r in range(self.world):   # rank order, as hipnlp_reassemble
@@ -402,10 +544,12 @@ class HostSink:
         if getattr(self, "dev", None):
             import ctypes as C
             self._lib.hipnlp_host_unregister(C.c_void_p(self._addr))
-            self.dev = None
-            self.host = None
+        self.dev = None
+        self.host = None
+        mm, self._mm = getattr(self, "_mm", None), None
+        if mm is not None:   # (whether or not the registration succeeded)
             try:
-                self._mm.close()
+                mm.close()
             except BufferError:   # a numpy view is still alive somewhere: the mapping goes with it
                 pass
 

@@ -46,7 +46,7 @@ extern "C" {
 /* ABI version of this header.  The caller stores it in hipnlp_desc.abi_version / hipnlp_pose_desc.abi_version; hipnlp_create and
  * hipnlp_pose_create refuse a descriptor built against another version (a C caller compiled against an older header would pass a
  * shorter struct).  History: 1 = rounds 1-2 (no version field); 2 = abi_version + flags in the descriptors, m_full / n_lifted in
- * hipnlp_dims, detect_simple_bounds layout, resident callback kernel, IPOPT callback quartet (hipnlp_ipopt.h).                  */
+ * hipnlp_dims, detect_simple_bounds layout, auto-registration, IPOPT callback quartet (hipnlp_ipopt.h).                           */
 #define HIPNLP_ABI_VERSION 2
 
 #define HIPNLP_NJ 23        /* actuated joints (ergoCub: torso 3, arms 4+4, legs 6+6) */
@@ -285,22 +285,8 @@ int hipnlp_host_unregister(void* p);
  * hipnlp_destroy or hipnlp_set_auto_register(h, 0).  Arrays registered explicitly with hipnlp_host_register are the caller's
  * responsibility and are not verified. */
 int hipnlp_set_auto_register(hipnlp_handle* h, int on);
-/* Resident mode (off by default; handles whose whole launch is resident at once at one workgroup per compute unit — the eight-wave
- * kernel, (knots + 1) x batch <= 256 — HIPNLP_E_UNSUPPORTED otherwise).  idle_us > 0: hipnlp_eval / hipnlp_eval_pinned no longer launch a kernel per callback.  The
- * callback kernel stays on the device between calls; a call copies x into the pinned staging block, rings a doorbell word in pinned
- * memory, and polls a completion word the kernel raises once every output the call wants on the host has been stored there
- * (system-scope stores; no launch, no stream synchronisation: 15 / 21 / 42 us instead of 29 / 31 / 49 us per 100-knot call for f /
- * f + grad f + g / all four, profiles/r03_doorbell_probe.txt).  The kernel leaves by itself idle_us after its last callback (every
- * wait on the device is bounded by the real-time counter) and the next call starts another session, so a solver that spends
- * milliseconds in its linear algebra between callbacks pays one launch per burst of callbacks, not one per callback.  While a session
- * is open its workgroups occupy their compute units (one polling lane each); hipDeviceSynchronize and hipFree in the same process
- * wait for the session to end (at most idle_us).  hipnlp_set_params, hipnlp_destroy and idle_us = 0 end the session at once.
- * A session that does not answer within two seconds is abandoned, the call is served by a launch, and after three such sessions the
- * mode switches itself off for the handle. */
-int hipnlp_set_resident(hipnlp_handle* h, double idle_us);
 /* Counters of the host-buffer path: out[0] arrays auto-registered so far, out[1] stale-mapping fallbacks, out[2] ranges currently
- * auto-registered, out[3] resident sessions started, out[4] callbacks served by a resident session, out[5] a session is open,
- * out[6] evaluations so far (kernel launches + resident callbacks), out[7] reserved. */
+ * auto-registered, out[3] evaluations so far (kernel launches), out[4..7] reserved (0). */
 int hipnlp_host_stats(const hipnlp_handle* h, long* out /*[8]*/);
 
 
@@ -363,8 +349,11 @@ int hipnlp_reassemble(const double* gathered_dev, const int64_t* src_dev, double
  *   hipnlp_peer_push   peer_out[r][dst[i]] = shard[i] for every rank r and every i < count with dst[i] >= 0 (peer_out: a DEVICE array
  *                      of `world` device pointers)
  *   hipnlp_peer_signal system-scope fence, then peer_flags[r][rank] = seq for every r (peer_flags: device array of world pointers)
- *   hipnlp_peer_wait   spins (bounded: *status_dev = 1 after ~2^20 polls — seconds —, 0 otherwise) until flags[r] >= seq for all r, then
- *                      out[f_off + world] = sum over r, in rank order, of out[f_off + r] (the cost partials)                        */
+ *   hipnlp_peer_wait   spins (bounded: ~2^20 polls — about a second) until flags[r] >= seq for all r, then
+ *                      out[f_off + world] = sum over r, in rank order, of out[f_off + r] (the cost partials).  A wait that gives up
+ *                      is sticky and loud: *status_dev is OR-ed with 1 (never cleared here: the host zeroes it when it sets the
+ *                      exchange up) and the whole step is poisoned — out[0 .. f_off) and the cost become NaN — so that pushes that
+ *                      may be partial cannot pass for an evaluation                                                               */
 #define HIPNLP_IPC_HANDLE_BYTES 64
 int hipnlp_ipc_alloc(size_t bytes, int device, void** dev_ptr, void* handle_out /*[HIPNLP_IPC_HANDLE_BYTES]*/);
 int hipnlp_ipc_open(const void* handle /*[HIPNLP_IPC_HANDLE_BYTES]*/, int device, void** dev_ptr);

@@ -67,10 +67,10 @@ int hipnlp_ipopt_sizes(hipnlp_handle* h, Index* n, Index* m, Index* nele_jac, In
  * Valid after hipnlp_set_params.  Any pointer may be NULL. */
 int hipnlp_ipopt_bounds(hipnlp_handle* h, Number* x_L, Number* x_U, Number* g_L, Number* g_U);
 /* Optional, around IpoptSolve: attach turns on what suits IPOPT's call pattern — early outputs (the first callback at a new x fills
- * the g / grad f / jac g arrays the later callbacks will pass: one transfer per iterate), auto-registration of IPOPT's arrays, and,
- * with resident_idle_us > 0, the resident callback kernel (hipnlp_set_resident); detach ends a resident session and releases the
- * registrations (call it before the arrays IPOPT owned are freed, i.e. before FreeIpoptProblem). */
-int hipnlp_ipopt_attach(hipnlp_handle* h, double resident_idle_us);
+ * the g / grad f / jac g arrays the later callbacks will pass: one transfer per iterate) and auto-registration of IPOPT's arrays;
+ * detach turns early outputs off and releases the registrations (call it before the arrays IPOPT owned are freed, i.e. before
+ * FreeIpoptProblem). */
+int hipnlp_ipopt_attach(hipnlp_handle* h);
 int hipnlp_ipopt_detach(hipnlp_handle* h);
 
 #ifdef __cplusplus

@@ -11,7 +11,7 @@
  * 3. A timing loop: IPOPT iterates as four C calls, microseconds per iterate on stdout.
  *
  * usage: harness <input.bin> <output.bin> [timing iterations]
- * input : int32 magic 0x49504F54, int32 desc_bytes, int32 np, int32 points, int32 attach, int32 resident_idle_us,
+ * input : int32 magic 0x49504F54, int32 desc_bytes, int32 np, int32 points, int32 attach, int32 reserved,
  *         desc bytes, p[np], x[points][n], lambda[m], obj_factor                                     (doubles little endian)
  * output: records { int32 kind (0 f, 1 grad, 2 g, 3 jac, 4 hess, 5 jac structure, 6 hess structure, 7 bounds), int32 point, int32 ok,
  *                   int32 count, double values[count] }
@@ -66,7 +66,7 @@ int main(int argc, char** argv) {
     if (!in) { perror(argv[1]); return 2; }
     int head[6];
     if (fread(head, sizeof(int), 6, in) != 6 || head[0] != 0x49504F54) { fprintf(stderr, "bad input file\n"); return 2; }
-    const int desc_bytes = head[1], np = head[2], points = head[3], attach = head[4], idle_us = head[5];
+    const int desc_bytes = head[1], np = head[2], points = head[3], attach = head[4];
     if (desc_bytes != (int)sizeof(hipnlp_desc)) { fprintf(stderr, "descriptor of %d bytes, header says %zu\n", desc_bytes, sizeof(hipnlp_desc)); return 2; }
     hipnlp_desc desc;
     if (fread(&desc, 1, sizeof desc, in) != sizeof desc) return 2;
@@ -106,7 +106,7 @@ int main(int argc, char** argv) {
         record(7, -1, ok, 2 * (n + m), b);
         free(b);
     }
-    if (attach && hipnlp_ipopt_attach(h, (double)idle_us) != HIPNLP_OK) { fprintf(stderr, "attach: %s\n", hipnlp_last_error(h)); return 1; }
+    if (attach && hipnlp_ipopt_attach(h) != HIPNLP_OK) { fprintf(stderr, "attach: %s\n", hipnlp_last_error(h)); return 1; }
 
     /* structure calls: values == NULL, x == NULL */
     record_indices(5, eval_jac_g(n, NULL, FALSE, m, nele_jac, iRow, jCol, NULL, ud), nele_jac, iRow, jCol);
@@ -161,8 +161,8 @@ int main(int argc, char** argv) {
         }
         long stats[8];
         hipnlp_host_stats(h, stats);
-        printf("{\"ipopt_iterate_four_c_calls_us\": %.2f, \"trial_point_two_c_calls_us\": %.2f, \"attach\": %d, \"resident_idle_us\": %d, "
-               "\"auto_registered\": %ld, \"resident_sessions\": %ld, \"resident_calls\": %ld}\n", best, trial, attach, idle_us, stats[0], stats[3], stats[4]);
+        printf("{\"ipopt_iterate_four_c_calls_us\": %.2f, \"trial_point_two_c_calls_us\": %.2f, \"attach\": %d, "
+               "\"auto_registered\": %ld, \"evaluations\": %ld}\n", best, trial, attach, stats[0], stats[3]);
     }
     if (attach) hipnlp_ipopt_detach(h);
     fclose(out);

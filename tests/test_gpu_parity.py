@@ -653,18 +653,54 @@ def test_peer_exchange_equals_the_gathered_callback(model, HipNlp):
     cb = ShardedCallback(N, sh.n, sh.m, sh.nnz, hip_shard_info(sh, 0, N), hip_shard_backend(sh), dev)
     rng = np.random.RandomState(5)
     xs = [x[0] + 1e-2 * i * rng.standard_normal(x.shape[1]) for i in range(5)]
-    for engine in (None, sh):   # push kernel behind the shard evaluation / stores folded into the evaluation (hipnlp_eval_device_peers)
-        px = PeerExchange(cb, engine=engine)
+    # push kernel behind the shard evaluation / stores folded into the evaluation (hipnlp_eval_device_peers); every rank receives /
+    # gather_to_root (rank 0 alone receives, back-flags pace the others: here rank 0 is the only rank)
+    for engine, root_only in ((None, False), (sh, False), (None, True), (sh, True)):
+        px = PeerExchange(cb, engine=engine, root_only=root_only)     # (set-up ends with the one-word handshake)
         got = []
         for xi in xs:
             fs, grads, jacs, gs = px(torch.from_numpy(xi).to(dev))
             got.append((fs.clone(), grads.clone(), jacs.clone(), gs.clone()))
         assert not px.timed_out()
+        px.check()
         for xi, (fs, grads, jacs, gs) in zip(xs, got):
             f, grad, g, jac = full.eval(xi[None, :])
             assert float(fs) == f[0]
             assert np.array_equal(grads.cpu().numpy(), grad[0]) and np.array_equal(jacs.cpu().numpy(), jac[0]) and np.array_equal(gs.cpu().numpy(), g[0])
+        assert px.bytes_sent_per_step() == 0       # one rank: nothing leaves the device
         px.close()
+    # the collective's gather_to_root at world size 1
+    fs, grads, jacs, gs = cb.to_root(torch.from_numpy(xs[1]).to(dev))
+    torch.cuda.synchronize()
+    f, grad, g, jac = full.eval(xs[1][None, :])
+    assert float(fs) == f[0] and np.array_equal(jacs.cpu().numpy(), jac[0]) and np.array_equal(gs.cpu().numpy(), g[0])
+
+
+def test_a_wait_that_gives_up_is_sticky_and_poisons_the_step(model, HipNlp):
+    """hipnlp_peer_wait on a flag that never comes: the status word is raised and STAYS raised over later, successful waits; grad / jac /
+    g of the step are NaN throughout, not only f (a timeout must not look like an ordinary evaluation)."""
+    import ctypes as C
+    import torch
+    lib = HipNlp.__module__ and __import__("hippopt_amd.hipnlp", fromlist=["load_library"]).load_library()
+    vp = C.c_void_p
+    lib.hipnlp_peer_wait.argtypes = [vp, C.c_int, C.c_ulonglong, vp, C.c_int64, vp, vp]
+    dev = torch.device("cuda", 0)
+    world, tot = 2, 1000
+    flags = torch.zeros(64, dtype=torch.int64, device=dev)
+    flags[0] = 5                                   # rank 0 signalled step 5, rank 1 never does
+    out = torch.ones(tot + world + 1, dtype=torch.float64, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.Stream()
+    assert lib.hipnlp_peer_wait(flags.data_ptr(), world, 5, out.data_ptr(), tot, status.data_ptr(), stream.cuda_stream) == 0
+    stream.synchronize()
+    assert int(status.item()) == 1 and bool(torch.isnan(out[:tot]).all()) and bool(torch.isnan(out[tot + world]))
+    flags[1] = 6
+    flags[0] = 6
+    out.fill_(2.0)
+    assert lib.hipnlp_peer_wait(flags.data_ptr(), world, 6, out.data_ptr(), tot, status.data_ptr(), stream.cuda_stream) == 0
+    stream.synchronize()
+    assert int(status.item()) == 1                 # sticky
+    assert float(out[tot + world]) == 4.0 and bool((out[:tot] == 2.0).all())
 
 
 @pytest.mark.parametrize("terrain,waves,split", [("planar", 8, 12), ("planar", 4, 9), ("stairs", 8, 15), ("stairs", 4, 1)])

@@ -48,10 +48,10 @@ def test_ipopt_callback_signatures_bind_and_symbols_are_exported():
     assert lib.hipnlp_ipopt_eval_f(5, None, 1, C.byref(obj), None) == 0
 
 
-def write_input(path, desc, p, xs, lam, obj_factor, attach, idle_us):
+def write_input(path, desc, p, xs, lam, obj_factor, attach):
     blob = C.string_at(C.addressof(desc), C.sizeof(desc))
     with open(path, "wb") as f:
-        f.write(struct.pack("<6i", 0x49504F54, len(blob), p.size, xs.shape[0], int(attach), int(idle_us)))
+        f.write(struct.pack("<6i", 0x49504F54, len(blob), p.size, xs.shape[0], int(attach), 0))
         f.write(blob)
         f.write(np.ascontiguousarray(p, np.float64).tobytes())
         f.write(np.ascontiguousarray(xs, np.float64).tobytes())
@@ -77,9 +77,9 @@ def rel(a, b):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("maker,horizon,lifted,attach,idle_us", [(periodic_step_settings, 30, False, 0, 0), (single_step_settings, 30, True, 1, 0),
-                                                                  (periodic_step_settings, 100, True, 1, 300)])
-def test_ipopt_protocol_replayed_in_c_matches_the_oracle(model, tmp_path, maker, horizon, lifted, attach, idle_us):
+@pytest.mark.parametrize("maker,horizon,lifted,attach", [(periodic_step_settings, 30, False, 0), (single_step_settings, 30, True, 1),
+                                                          (periodic_step_settings, 100, True, 1)])
+def test_ipopt_protocol_replayed_in_c_matches_the_oracle(model, tmp_path, maker, horizon, lifted, attach):
     from hess_util import hess_mismatch, triplets_to_dict
     from oracle_lib import Oracle
     st = maker(horizon, model)
@@ -108,15 +108,13 @@ def test_ipopt_protocol_replayed_in_c_matches_the_oracle(model, tmp_path, maker,
     lam_full = np.zeros(orc.m)
     lam_full[keep_rows] = lam
     src, dst = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
-    write_input(src, desc, p[0], xs, lam, 0.8, attach, idle_us)
+    write_input(src, desc, p[0], xs, lam, 0.8, attach)
     res = subprocess.run([build_harness(), src, dst, "200"], capture_output=True, text=True, timeout=240)
     assert res.returncode == 0, res.stderr
     timing = json.loads(res.stdout.strip().splitlines()[-1])
     assert timing["ipopt_iterate_four_c_calls_us"] > 0
     if attach:
-        assert timing["auto_registered"] >= 2                      # IPOPT's g and jac arrays (and the gradient the loop reuses)
-    if idle_us:
-        assert timing["resident_calls"] > 400
+        assert timing["auto_registered"] >= 1                      # IPOPT's jac array (g too when it reaches 64 KB; the gradient the loop reuses)
     recs = read_records(dst)
     seen = {k: 0 for k in KINDS.values()}
     ref = {}

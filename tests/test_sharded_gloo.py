@@ -74,6 +74,15 @@ def _worker(rank, world, port, horizon, result_q):
     f_ref, grad_ref, g_ref, jac_ref, _ = emu.eval(x[0], p[0])
     ok = (np.array_equal(grad.numpy(), grad_ref) and np.array_equal(jac.numpy(), jac_ref) and np.array_equal(g.numpy(), g_ref)
           and float(f) == sum(range(1, world + 1)))
+    # gather_to_root: one consumer — rank 0 alone receives the reassembled outputs (dist.gather), the others hold nothing
+    x2 = x[0] + 1e-3
+    f2, grad2, jac2, g2 = cb.to_root(torch.from_numpy(x2))
+    if rank == 0:
+        f_ref2, grad_ref2, g_ref2, jac_ref2, _ = emu.eval(x2, p[0])
+        ok = ok and (np.array_equal(grad2.numpy(), grad_ref2) and np.array_equal(jac2.numpy(), jac_ref2) and np.array_equal(g2.numpy(), g_ref2)
+                     and float(f2) == sum(range(1, world + 1)) and not np.array_equal(g_ref2, g_ref))
+    else:
+        ok = ok and f2 is None and grad2 is None and jac2 is None and g2 is None
     result_q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
