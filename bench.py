@@ -376,10 +376,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
+        import datetime
+        limit = datetime.timedelta(seconds=240)   # a collective one rank never reaches fails on the others instead of hanging the line
         if REHEARSAL:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=limit)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=limit)
         assert dist.get_world_size() == world
 
     model = synthetic_ergocub()
@@ -491,49 +493,69 @@ def main():
         # K steps between barrier + synchronize, maximum over the ranks — so that any of the three can be the step behind `value`.
         from hippopt_amd.sharded import PeerExchange
 
+        def agree_all(ok):
+            """True iff every rank says ok (a collective: every rank must call it at the same point)"""
+            if world == 1:
+                return bool(ok)
+            oks = [None] * world
+            dist.all_gather_object(oks, bool(ok))
+            return all(oks)
+
         def time_peer(engine, note, root_only=False):
-            px = None
+            """Every rank walks the SAME sequence of collectives whatever fails locally: a launch error on one rank is recorded, the
+            rank keeps its place in the fences and agreements, and all ranks leave together with the error — a rank that raised alone
+            would leave the others waiting in the next collective until the launcher's timeout, and the whole line would be lost."""
+            px, err_text = None, None
             try:
-                px = PeerExchange(cb, engine=engine, root_only=root_only)   # (set-up ends with a bounded one-word handshake per peer)
-                with torch.cuda.stream(cb.stream):
-                    ref = [t.clone() for t in cb(xs[1 % nvar])]
+                px = PeerExchange(cb, engine=engine, root_only=root_only)   # (collective-safe inside; ends with the bounded handshake)
+            except Exception as err:  # noqa: BLE001  (agreed on collectively inside the constructor: raised on every rank)
+                return None, {"error": "%s: %s" % (type(err).__name__, err)}
+            same, got, got2 = True, None, None
+            with torch.cuda.stream(cb.stream):
+                ref = [t.clone() for t in cb(xs[1 % nvar])]                # (collective: the all-gather path's result)
+                try:
                     got = px(xs[1 % nvar])
                     got = [t.clone() for t in got] if got[0] is not None else None
                     got2 = px(xs[1 % nvar])                                # the other buffer parity
                     got2 = [t.clone() for t in got2] if got2[0] is not None else None
-                fence()
+                except Exception as err:  # noqa: BLE001
+                    same, err_text = False, "%s: %s" % (type(err).__name__, err)
+            fence()
+            if same:
                 same = not px.timed_out()
                 if got is not None:   # (gather_to_root: rank 0 alone holds the outputs)
                     same = same and all(torch.equal(a, b_) and torch.equal(a, c_) for a, b_, c_ in zip(ref, got, got2))
-                flags = torch.tensor([1.0 if same else 0.0], device=device)
-                if world > 1:
-                    if dist.get_backend() == "gloo":
-                        fl = flags.cpu(); dist.all_reduce(fl, op=dist.ReduceOp.MIN); flags = fl
-                    else:
-                        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
-                if float(flags[0]) != 1.0:
-                    raise RuntimeError("peer exchange differs from the all-gather path on some rank")
-                with torch.cuda.stream(cb.stream):
+            if not agree_all(same):
+                fence()
+                px.close(barrier=False)
+                return None, {"error": err_text or "peer exchange differs from the all-gather path (or timed out, or failed) on some rank"}
+            ok, e4 = True, float("inf")
+            with torch.cuda.stream(cb.stream):
+                try:
                     for i in range(warmup):
                         px(xs[i % nvar])
-                    fence()
-                    t1 = time.perf_counter()
-                    for i in range(steps):
-                        px(xs[i % nvar])
-                    fence()
-                    e4 = max_over_ranks(time.perf_counter() - t1)
-                late = px.timed_out()
-                sent = px.bytes_sent_per_step()
-                fence()                      # every rank's pushes are complete: the buffers can go without another collective
-                px.close(barrier=False)
-                return e4, {"knots_per_s": hz * steps / e4, "ms_per_step": 1e3 * e4 / steps, "steps": steps, "timed_out": bool(late),
-                            "bytes_sent_per_rank_per_step": int(sent),
-                            "verified": "bitwise equal to the all-gather path on every rank that holds outputs, both buffer parities; "
-                                        "one-word handshake with every peer at set-up", "note": note}
-            except Exception as err:  # noqa: BLE001  (an extra measurement must not take `value` down with it)
-                # (a rank-local failure past the collective set-up leaves the other ranks in a collective: the launcher's timeout ends
-                #  the run; set-up failures and mismatches are agreed on collectively and land here on every rank)
-                return None, {"error": "%s: %s" % (type(err).__name__, err)}
+                except Exception as err:  # noqa: BLE001
+                    ok, err_text = False, "%s: %s" % (type(err).__name__, err)
+                fence()
+                t1 = time.perf_counter()
+                try:
+                    if ok:
+                        for i in range(steps):
+                            px(xs[i % nvar])
+                except Exception as err:  # noqa: BLE001
+                    ok, err_text = False, "%s: %s" % (type(err).__name__, err)
+                fence()
+                e4 = max_over_ranks(time.perf_counter() - t1)
+            late = px.timed_out()
+            sent = px.bytes_sent_per_step()
+            fence()                      # every rank's pushes are complete: the buffers can go without another collective
+            px.close(barrier=False)
+            if not agree_all(ok):
+                return None, {"error": err_text or "a launch of the timed loop failed on another rank"}
+            return e4, {"knots_per_s": hz * steps / e4, "ms_per_step": 1e3 * e4 / steps, "steps": steps, "timed_out": bool(late),
+                        "bytes_sent_per_rank_per_step": int(sent),
+                        "verified": "bitwise equal to the all-gather path on every rank that holds outputs, both buffer parities; "
+                                    "one-word handshake with every peer at set-up", "note": note}
 
         e_ps, res["peer_store"] = time_peer(None, "no collective, no reassembly pass: every rank pushes its shard, entry by entry at its final position, into "
                                                   "the [grad | jac | g | f] buffer of EVERY rank with plain stores over xGMI (HIP IPC), then flags")
@@ -608,6 +630,14 @@ def main():
                 r = run_replicas(max(1, min(args.steps, 1000)), min(args.warmup, 100))
                 side = {"knots_per_s": r["knots_per_step"] * max(1, min(args.steps, 1000)) / r["el"], "ms_per_step": 1e3 * r["el"] / max(1, min(args.steps, 1000)),
                         "parallelism": r["parallelism"], "note": "one 100-knot NLP per GPU (BASELINE config 5's batched-guess / MPC shape)"}
+                # every exchange against N x (one GPU evaluating 100 knots alone, measured in THIS run under the same load): the
+                # weak-scaling efficiency of that exchange.  (The driver computes its own from `value` of separate runs.)
+                for key in ("all_gather", "peer_store", "peer_direct", "gather_to_root", "host_sink", "shard_resident"):
+                    leg = main_res.get(key)
+                    if isinstance(leg, dict) and "knots_per_s" in leg:
+                        leg["efficiency_vs_n_independent_gpus"] = leg["knots_per_s"] / side["knots_per_s"]
+                side["efficiency_definition"] = ("knots_per_s(leg, N ranks) / knots_per_s(N independent 100-knot callbacks, one per GPU, this run) = "
+                                                 "knots_per_s(N) / (N x knots_per_s(1))")
             except Exception as err:  # noqa: BLE001
                 side = {"error": "%s: %s" % (type(err).__name__, err)}
     else:

@@ -59,9 +59,9 @@ class OptimizationObject:
     @staticmethod
     def _walk(obj, prefix, inherited, visit):
         """Depth-first traversal in declaration order.  visit(owner, field, index or None, full_name, value, metadata)."""
-        if isinstance(obj, list):
+        if isinstance(obj, list):   # (a list of lists — objects expanded in time inside a list — is named a[i][k].leaf)
             for i, elem in enumerate(obj):
-                OptimizationObject._walk(elem, f"{prefix}[{i}].", inherited, visit)
+                OptimizationObject._walk(elem, f"{prefix}[{i}]" + ("" if isinstance(elem, list) else "."), inherited, visit)
             return
         for field in dataclasses.fields(obj):
             value = getattr(obj, field.name)

@@ -1270,7 +1270,7 @@ int hipnlp_eval_device_shard(hipnlp_handle* h, const double* x_dev, double* f_de
 }
 
 int hipnlp_eval_device_peers(hipnlp_handle* h, const double* x_dev, double* const* peer_out_dev, int world, int rank, void* stream) {
-    if (!h || !x_dev || !peer_out_dev || world < 1 || rank < 0 || rank >= world) return HIPNLP_E_INVALID;
+    if (!h || !x_dev || !peer_out_dev || world < 1 || rank < 0 || rank >= 64) return HIPNLP_E_INVALID;   // (world: buffers stored to; rank: this shard's cost slot)
     if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
     if (h->batch != 1) { h->err = "hipnlp_eval_device_peers: one trajectory per handle (batch 1)"; return HIPNLP_E_INVALID; }
     if (!h->fused) { h->err = "hipnlp_eval_device_peers: shards of at most 256 knots (the shard's cost is summed inside the launch)"; return HIPNLP_E_INVALID; }

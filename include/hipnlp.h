@@ -368,7 +368,9 @@ int hipnlp_peer_wait(const unsigned long long* flags_dev, int world, unsigned lo
  *     peer_out[r] = [grad f (n) | jac g (nnz) | g (m) | cost partial of rank 0 .. world-1 | f]      (n, m, nnz of the whole problem),
  * the layout hipnlp_peer_push fills (f_off = n + nnz + m for hipnlp_peer_wait): the transfers over the links overlap with the knot
  * programs still running, and neither a push nor a reassembly launch follows.  peer_out_dev: DEVICE array of `world` device-visible
- * base addresses (hipnlp_ipc_alloc / hipnlp_ipc_open).  Then hipnlp_peer_signal and hipnlp_peer_wait as above.  Enqueued on `stream`
+ * base addresses (hipnlp_ipc_alloc / hipnlp_ipc_open) — the buffers this call stores into: every rank's, or rank 0's alone
+ * (world = 1: gather_to_root, one consumer); rank: the slot of this shard's cost partial (< 64; the buffers hold one slot per rank
+ * of the job, whatever `world` is here).  Then hipnlp_peer_signal and hipnlp_peer_wait as above.  Enqueued on `stream`
  * (NULL: the handle's own stream), not synchronised; the non-finite flag of the handle works as with hipnlp_eval_device. */
 int hipnlp_eval_device_peers(hipnlp_handle* h, const double* x_dev, double* const* peer_out_dev, int world, int rank, void* stream);
 

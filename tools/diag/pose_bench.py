@@ -15,7 +15,8 @@ model = synthetic_ergocub()
 st = pose_finder_settings(model)
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
-for B in (1, 256, 4096):
+WHAT = os.environ.get("POSE_WHAT", "")   # "callbacks" / "hessian": only that kernel (one configuration per rocprofv3 trace)
+for B in [int(b) for b in os.environ.get("POSE_BATCHES", "1,256,4096").split(",")]:
     x, p = make_pose_workload(st, model, B, 11)
     eng = HipPose(st, model, batch=B)
     eng.set_params(p)
@@ -32,6 +33,8 @@ for B in (1, 256, 4096):
     res = {"workload": "pose finder, batch %d" % B, "n": eng.n, "m": eng.m, "nnz": eng.nnz, "nnz_h": int(hr.size)}
     for name, fn in (("callbacks", lambda: eng.eval_device(xd.data_ptr(), f.data_ptr(), grad.data_ptr(), g.data_ptr(), jac.data_ptr(), stream)),
                      ("hessian", lambda: eng.eval_hess_device(xd.data_ptr(), sig.data_ptr(), lam.data_ptr(), hess.data_ptr(), stream))):
+        if WHAT and name != WHAT:
+            continue
         for _ in range(50):
             fn()
         torch.cuda.synchronize()

@@ -22,13 +22,27 @@ for W in $WORKLOADS; do
   run write_$NAME --pmc WRITE_SIZE --output-format csv -d $OUT/write_$NAME -- python3 bench.py --steps 20 --warmup 5 $ARGS $COMMON
   run sq_$NAME --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/sq_$NAME -- python3 bench.py --steps 20 --warmup 5 $ARGS $COMMON
   run lds_$NAME --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/lds_$NAME -- python3 bench.py --steps 20 --warmup 5 $ARGS $COMMON
+  # lane utilisation of the VALU issue slots: SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64) = share of live lanes per issued VALU cycle
+  run lane_$NAME --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d $OUT/lane_$NAME -- python3 bench.py --steps 20 --warmup 5 $ARGS $COMMON
   python3 bench.py --steps $([ $B -ge 1024 ] && echo 50 || echo 1000) --warmup 50 $ARGS $COMMON > $OUT/bench_$NAME.json 2>/dev/null
 done
-for HW in periodic stairs; do
-  echo "== hess $HW"
-  HESS_WORKLOAD=$HW HESS_BATCHES=1,16,64 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_hess_$HW -- python3 tools/diag/hess_bench.py > $OUT/hess_bench_$HW.jsonl 2> $OUT/trace_hess_$HW.log
-  HESS_WORKLOAD=$HW HESS_BATCHES=64 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_hess_$HW -- python3 tools/diag/hess_bench.py > /dev/null 2> $OUT/fetch_hess_$HW.log
-  HESS_WORKLOAD=$HW HESS_BATCHES=64 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_hess_$HW -- python3 tools/diag/hess_bench.py > /dev/null 2> $OUT/write_hess_$HW.log
+# exact Hessian and pose finder: ONE (kernel, N, batch) per trace, so that every CSV average is the duration of one configuration
+for CFG in periodic:100:1 periodic:100:64 stairs:200:16; do
+  HW=${CFG%%:*}; R=${CFG#*:}; HN=${R%%:*}; HB=${R#*:}
+  NAME=hess_${HW}_N${HN}_B${HB}
+  echo "== $NAME"
+  HESS_WORKLOAD=$HW HESS_N=$HN HESS_BATCHES=$HB rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$NAME -- python3 tools/diag/hess_bench.py > $OUT/bench_$NAME.jsonl 2> $OUT/trace_$NAME.log
+  HESS_WORKLOAD=$HW HESS_N=$HN HESS_BATCHES=$HB rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$NAME -- python3 tools/diag/hess_bench.py > /dev/null 2> $OUT/fetch_$NAME.log
+  HESS_WORKLOAD=$HW HESS_N=$HN HESS_BATCHES=$HB rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$NAME -- python3 tools/diag/hess_bench.py > /dev/null 2> $OUT/write_$NAME.log
+  HESS_WORKLOAD=$HW HESS_N=$HN HESS_BATCHES=$HB rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d $OUT/lane_$NAME -- python3 tools/diag/hess_bench.py > /dev/null 2> $OUT/lane_$NAME.log
+done
+for CFG in callbacks:1 callbacks:4096 hessian:1 hessian:4096; do
+  WHAT=${CFG%%:*}; PB=${CFG#*:}
+  NAME=pose_${WHAT}_B${PB}
+  echo "== $NAME"
+  POSE_WHAT=$WHAT POSE_BATCHES=$PB rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$NAME -- python3 tools/diag/pose_bench.py > $OUT/bench_$NAME.jsonl 2> $OUT/trace_$NAME.log
+  POSE_WHAT=$WHAT POSE_BATCHES=$PB rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$NAME -- python3 tools/diag/pose_bench.py > /dev/null 2> $OUT/fetch_$NAME.log
+  POSE_WHAT=$WHAT POSE_BATCHES=$PB rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$NAME -- python3 tools/diag/pose_bench.py > /dev/null 2> $OUT/write_$NAME.log
 done
 run calib_fetch --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -- tools/diag/_build/calib
 run calib_write --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -- tools/diag/_build/calib

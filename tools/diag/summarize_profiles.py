@@ -76,6 +76,7 @@ for name in names:
     wr = counter_means(os.path.join(src, "write_" + name), "knot_kernel")
     sq = counter_means(os.path.join(src, "sq_" + name), "knot_kernel")
     lds = counter_means(os.path.join(src, "lds_" + name), "knot_kernel")
+    lane = counter_means(os.path.join(src, "lane_" + name), "knot_kernel")
     w["FETCH_SIZE_kib"], w["WRITE_SIZE_kib"] = fe.get("FETCH_SIZE"), wr.get("WRITE_SIZE")
     w["lds"] = {k: v for k, v in lds.items() if not k.endswith("_n")}
     w["sq"] = {k: v for k, v in sq.items() if not k.endswith("_n")}
@@ -103,24 +104,43 @@ for name in names:
         w["lds_bank_conflict_cycles_per_knot"] = lds.get("SQ_LDS_BANK_CONFLICT", 0.0) / knots
         if lds.get("SQ_BUSY_CU_CYCLES"):
             w["lds_array_busy_fraction_of_cu_cycles"] = lds["SQ_LDS_IDX_ACTIVE"] / lds["SQ_BUSY_CU_CYCLES"]
+    if lane.get("SQ_ACTIVE_INST_VALU") and lane.get("SQ_THREAD_CYCLES_VALU"):
+        # live lanes per issued VALU cycle: thread-cycles / (instruction-cycles x 64 lanes)
+        w["lane"] = {k: v for k, v in lane.items() if not k.endswith("_n")}
+        ent["valu_lane_utilisation"] = w["valu_lane_utilisation"] = lane["SQ_THREAD_CYCLES_VALU"] / (lane["SQ_ACTIVE_INST_VALU"] * 64.0)
+        if lane.get("SQ_WAVE_CYCLES"):
+            w["valu_active_fraction_of_wave_cycles"] = lane["SQ_ACTIVE_INST_VALU"] / lane["SQ_WAVE_CYCLES"]
+            w["lds_issue_stall_fraction_of_wave_cycles"] = lane.get("SQ_WAIT_INST_LDS", 0.0) / lane["SQ_WAVE_CYCLES"]
     if len(ent) > 1:
         traffic[name] = ent
     summary["workloads"][name] = w
-summary["exact_hessian"] = {}
-for hw in ("periodic", "stairs"):
-    h, f = kernel_stats(os.path.join(src, "trace_hess_" + hw), {"hess_kernel": "knot_hess_kernel"})
+# exact Hessian and pose finder: one (kernel, N, batch) per trace directory (trace_hess_<terrain>_N<N>_B<B>, trace_pose_<what>_B<B>)
+summary["exact_hessian"], summary["pose_finder"] = {}, {}
+for d in sorted(glob.glob(os.path.join(src, "trace_hess_*")) + glob.glob(os.path.join(src, "trace_pose_*"))):
+    if not os.path.isdir(d):
+        continue
+    name = os.path.basename(d)[len("trace_"):]
+    kern = "knot_hess_kernel" if name.startswith("hess_") else ("pose_hess_kernel" if "hessian" in name else "pose_kernel")
+    h, f = kernel_stats(d, {"kernel": kern})
     if f:
-        shutil.copy(f, os.path.join(dst, "%s_hess_kernel_stats_%s.csv" % (tag, hw)))
-    hb = os.path.join(src, "hess_bench_%s.jsonl" % hw)
-    if os.path.exists(hb):
-        lines = [l for l in open(hb) if l.startswith("{")]
-        open(os.path.join(dst, "%s_hess_bench_%s.jsonl" % (tag, hw)), "w").writelines(lines)
+        shutil.copy(f, os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, name)))
+    bj = os.path.join(src, "bench_%s.jsonl" % name)
+    if os.path.exists(bj):
+        lines = [l for l in open(bj) if l.startswith("{")]
         h["bench"] = [json.loads(l) for l in lines]
-    fe = counter_means(os.path.join(src, "fetch_hess_" + hw), "knot_hess_kernel")
-    wr = counter_means(os.path.join(src, "write_hess_" + hw), "knot_hess_kernel")
+    fe = counter_means(os.path.join(src, "fetch_" + name), kern)
+    wr = counter_means(os.path.join(src, "write_" + name), kern)
+    lane = counter_means(os.path.join(src, "lane_" + name), kern)
+    ent = {"round": tag, "kernel": kern}
+    if h.get("kernel_avg_ns"):
+        ent["kernel_avg_ns"] = h["kernel_avg_ns"]
     if fe.get("FETCH_SIZE") is not None and wr.get("WRITE_SIZE") is not None and calib["fetch_correction"]:
-        h["hbm_bytes_per_launch_corrected_B64"] = fe["FETCH_SIZE"] * 1024.0 * calib["fetch_correction"] + wr["WRITE_SIZE"] * 1024.0 * calib["write_correction"]
-    summary["exact_hessian"][hw] = h
+        ent["hbm_bytes_per_launch"] = h["hbm_bytes_per_launch_corrected"] = fe["FETCH_SIZE"] * 1024.0 * calib["fetch_correction"] + wr["WRITE_SIZE"] * 1024.0 * calib["write_correction"]
+    if lane.get("SQ_ACTIVE_INST_VALU") and lane.get("SQ_THREAD_CYCLES_VALU"):
+        ent["valu_lane_utilisation"] = h["valu_lane_utilisation"] = lane["SQ_THREAD_CYCLES_VALU"] / (lane["SQ_ACTIVE_INST_VALU"] * 64.0)
+        h["lane"] = {k: v for k, v in lane.items() if not k.endswith("_n")}
+    traffic[name] = ent
+    summary["exact_hessian" if name.startswith("hess_") else "pose_finder"][name] = h
 json.dump(summary, open(os.path.join(dst, "%s_summary.json" % tag), "w"), indent=1)
 json.dump(traffic, open(tpath, "w"), indent=1)
 print(json.dumps(calib, indent=1))
@@ -134,5 +154,6 @@ for k, v in summary["workloads"].items():
     if "valu_wave_insts_per_knot" in v:
         line += " | VALU/knot %.0f SALU %.0f LDS %.0f wait %.2f" % (v["valu_wave_insts_per_knot"], v["salu_wave_insts_per_knot"], v["lds_wave_insts_per_knot"], v.get("wait_fraction_of_wave_cycles", float("nan")))
     print(line)
-for hw, h in summary["exact_hessian"].items():
-    print("hessian", hw, {k: v for k, v in h.items() if k != "bench"}, [(b["workload"][-20:], round(b["ms_per_eval"], 5)) for b in h.get("bench", [])])
+for group in ("exact_hessian", "pose_finder"):
+    for name, h in summary[group].items():
+        print(group, name, {k: v for k, v in h.items() if k not in ("bench", "lane")})
