@@ -521,14 +521,23 @@ def main():
                 except Exception as err:  # noqa: BLE001
                     same, err_text = False, "%s: %s" % (type(err).__name__, err)
             fence()
+            why = err_text
             if same:
-                same = not px.timed_out()
-                if got is not None:   # (gather_to_root: rank 0 alone holds the outputs)
-                    same = same and all(torch.equal(a, b_) and torch.equal(a, c_) for a, b_, c_ in zip(ref, got, got2))
+                if px.timed_out():
+                    same, why = False, "rank %d: a wait for the peers' flags gave up" % rank
+                elif got is not None:   # (gather_to_root: rank 0 alone holds the outputs)
+                    bad = [nm for nm, a, b_, c_ in zip(("f", "grad", "jac", "g"), ref, got, got2) if not (torch.equal(a, b_) and torch.equal(a, c_))]
+                    if bad:
+                        same, why = False, "rank %d: %s differ from the all-gather path" % (rank, ", ".join(bad))
+            whys = [None] * world
+            if world > 1:
+                dist.all_gather_object(whys, why)
+            else:
+                whys = [why]
             if not agree_all(same):
                 fence()
                 px.close(barrier=False)
-                return None, {"error": err_text or "peer exchange differs from the all-gather path (or timed out, or failed) on some rank"}
+                return None, {"error": "; ".join(w for w in whys if w) or "failed on some rank"}
             ok, e4 = True, float("inf")
             with torch.cuda.stream(cb.stream):
                 try:
@@ -665,14 +674,18 @@ def main():
             else ("HIP events around every %d-th knot-kernel launch" % stride)
         # PMC-derived figures cannot be collected inside a timed run (rocprofv3 --pmc passes are separate processes): they are looked up
         # in the committed summary of the same command and labelled as such
-        traffic = valu = lds_cyc = None
+        traffic = valu = lds_cyc = lane_util = None
+        hess_ent = {}
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
-                ent = json.load(open(tp)).get("%s_N%d_B%d" % (args.workload, main_res["horizon"], args.batch), {})
+                table = json.load(open(tp))
+                ent = table.get("%s_N%d_B%d" % (args.workload, main_res["horizon"], args.batch), {})
                 traffic = ent.get("hbm_bytes_per_launch")
                 valu = ent.get("valu_wave_insts_per_knot")
                 lds_cyc = ent.get("lds_array_cycles_per_knot")
+                lane_util = ent.get("valu_lane_utilisation")
+                hess_ent = table.get("hess_%s_N%d_B%d" % (args.workload, main_res["horizon"], args.batch), {})
             except Exception:  # noqa: BLE001
                 pass
         line = {
@@ -710,6 +723,8 @@ def main():
             ginst = valu * local_knots / (kern_ms * 1e-3) / 1e9
             line["roofline"]["valu"] = {"bound": "fp64 valu issue", "achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
                                         "frac": ginst / VALU_PEAK_GINST, "valu_wave_insts_per_knot": valu,
+                                        "lane_utilisation": lane_util,
+                                        "lane_utilisation_source": "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): live lanes per issued VALU cycle (profiles/traffic.json, separate --pmc pass)",
                                         "source": "SQ_INSTS_VALU per launch from profiles/traffic.json (separate rocprofv3 --pmc pass) x this run's kernel rate; "
                                                   "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 issue cycles per wave64 instruction"}
         if lds_cyc and kern_ms > 0:
@@ -743,6 +758,14 @@ def main():
             # beside the callback quartet (never `value`): the exact Hessian of the Lagrangian of the same NLP (hipnlp_eval_hess_device)
             try:
                 line["exact_hessian"] = time_hessian(eng, main_res["x_np"], args.horizon * args.batch)
+                eh = line["exact_hessian"]
+                # its own roofline block: algorithmic bytes (x, parameters, multipliers in; triplet values out) over the event-timed
+                # launch; HBM traffic and lane utilisation looked up from the committed per-configuration PMC passes
+                eh["roofline"] = {"bound": "hbm", "achieved": eh["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": eh["GBps"] / HBM_PEAK_GBS,
+                                  "traffic": hess_ent.get("hbm_bytes_per_launch"), "kernel": "hipnlp_knot_hess_kernel", "kernel_ms": eh["ms_per_eval"],
+                                  "rocprof_kernel_avg_ms": (hess_ent.get("kernel_avg_ns") or 0.0) * 1e-6 or None,
+                                  "valu_lane_utilisation": hess_ent.get("valu_lane_utilisation"),
+                                  "traffic_source": "profiles/traffic.json (hess_<workload>_N<N>_B<batch>: rocprofv3 --kernel-trace --stats and --pmc passes of tools/diag/hess_bench.py, one configuration per trace)"}
             except Exception as err:  # noqa: BLE001  (reported, never fatal to the bench line)
                 line["exact_hessian"] = {"error": str(err)}
         if world == 1 and not args.no_cpu_baseline:

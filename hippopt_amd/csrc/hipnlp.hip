@@ -1753,7 +1753,8 @@ int hipnlp_peer_push(const double* shard_dev, const int64_t* dst_dev, int64_t co
     return hipGetLastError() == hipSuccess ? HIPNLP_OK : HIPNLP_E_NODEVICE;
 }
 int hipnlp_peer_signal(unsigned long long* const* peer_flags_dev, int world, int rank, unsigned long long seq, void* stream) {
-    if (!peer_flags_dev || world < 1 || world > 64 || rank < 0 || rank >= world) return HIPNLP_E_INVALID;
+    // (world: flag arrays written to — every rank's, or one rank's: gather_to_root —; rank: this rank's slot in them)
+    if (!peer_flags_dev || world < 1 || world > 64 || rank < 0 || rank >= 64) return HIPNLP_E_INVALID;
     hipLaunchKernelGGL(hipnlp_peer_signal_kernel, dim3(1), dim3(64), 0, hipStream_t(stream), peer_flags_dev, world, rank, seq);
     return hipGetLastError() == hipSuccess ? HIPNLP_OK : HIPNLP_E_NODEVICE;
 }

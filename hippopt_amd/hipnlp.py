@@ -188,6 +188,11 @@ class HipNlp:
             self.h = None
 
     def __del__(self):
+        # (not while the interpreter is shutting down: the HIP runtime's own exit handlers may already have run, and the OS reclaims
+        #  device memory, registrations and streams with the process)
+        import sys
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:  # noqa: BLE001
@@ -429,6 +434,11 @@ class HipPose:
             self.h = None
 
     def __del__(self):
+        # (not while the interpreter is shutting down: the HIP runtime's own exit handlers may already have run, and the OS reclaims
+        #  device memory, registrations and streams with the process)
+        import sys
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:  # noqa: BLE001

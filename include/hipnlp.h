@@ -348,7 +348,8 @@ int hipnlp_reassemble(const double* gathered_dev, const int64_t* src_dev, double
  *   hipnlp_ipc_open    maps a peer's allocation into this process (enables peer access to its device on demand)
  *   hipnlp_peer_push   peer_out[r][dst[i]] = shard[i] for every rank r and every i < count with dst[i] >= 0 (peer_out: a DEVICE array
  *                      of `world` device pointers)
- *   hipnlp_peer_signal system-scope fence, then peer_flags[r][rank] = seq for every r (peer_flags: device array of world pointers)
+ *   hipnlp_peer_signal system-scope fence, then peer_flags[r][rank] = seq for every r < world (peer_flags: device array of `world` pointers —
+ *                      every rank's flag array, or a subset: gather_to_root signals rank 0 alone; rank < 64: this rank's slot)
  *   hipnlp_peer_wait   spins (bounded: ~2^20 polls — about a second) until flags[r] >= seq for all r, then
  *                      out[f_off + world] = sum over r, in rank order, of out[f_off + r] (the cost partials).  A wait that gives up
  *                      is sticky and loud: *status_dev is OR-ed with 1 (never cleared here: the host zeroes it when it sets the

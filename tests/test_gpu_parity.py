@@ -821,7 +821,7 @@ def test_two_ranks_on_one_gpu_rehearsal():
     assert line["n_gpus"] == 2 and line["value"] > 0
     side = {k: line.get(k) or line["config"].get(k) for k in ("peer_store", "peer_direct", "gather_to_root", "host_sink", "shard_resident")}
     for k in ("peer_store", "peer_direct", "gather_to_root"):
-        assert side[k] and "error" not in side[k], side[k]
+        assert side[k] and "error" not in side[k], (k, side[k])
         assert side[k]["verified"].startswith("bitwise") and not side[k]["timed_out"]
         assert side[k]["efficiency_vs_n_independent_gpus"] > 0 and side[k]["bytes_sent_per_rank_per_step"] >= 0
     assert side["gather_to_root"]["bytes_sent_per_rank_per_step"] == 0        # (rank 0 reports: it sends nothing, it receives)

@@ -64,7 +64,8 @@ calib["write_correction"] = known / (cw["WRITE_SIZE"] * 1024.0) if cw.get("WRITE
 summary = {"calibration_8B_per_lane": calib, "workloads": {}}
 tpath = os.path.join(dst, "traffic.json")
 traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
-names = sorted({os.path.basename(p)[len("trace_"):] for p in glob.glob(os.path.join(src, "trace_*")) if os.path.isdir(p) and "hess" not in p})
+names = sorted({os.path.basename(p)[len("trace_"):] for p in glob.glob(os.path.join(src, "trace_*"))
+                if os.path.isdir(p) and not os.path.basename(p).startswith(("trace_hess_", "trace_pose_"))})
 for name in names:
     m = re.match(r"(\w+?)_N(\d+)_B(\d+)$", name)
     N, B = int(m.group(2)), int(m.group(3))
