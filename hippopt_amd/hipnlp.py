@@ -5,6 +5,7 @@ raises when no HIP device is present.
 """
 import ctypes as C
 import os
+import sys as _sys
 
 import numpy as np
 
@@ -190,10 +191,9 @@ class HipNlp:
     def __del__(self):
         # (not while the interpreter is shutting down: the HIP runtime's own exit handlers may already have run, and the OS reclaims
         #  device memory, registrations and streams with the process)
-        import sys
-        if sys is None or sys.is_finalizing():
-            return
         try:
+            if _sys is None or _sys.is_finalizing():
+                return
             self.close()
         except Exception:  # noqa: BLE001
             pass
@@ -436,10 +436,9 @@ class HipPose:
     def __del__(self):
         # (not while the interpreter is shutting down: the HIP runtime's own exit handlers may already have run, and the OS reclaims
         #  device memory, registrations and streams with the process)
-        import sys
-        if sys is None or sys.is_finalizing():
-            return
         try:
+            if _sys is None or _sys.is_finalizing():
+                return
             self.close()
         except Exception:  # noqa: BLE001
             pass
