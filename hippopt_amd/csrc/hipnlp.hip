@@ -540,9 +540,13 @@ struct HArgs {
     int32_t* flag_host;     // [batch] or null: the same flag in pinned host memory (plain store of seq, see KArgs)
     int32_t N, n, m, knot_begin, seq, pad_;
     int64_t hstride, hoff;  // values of trajectory b start at hess + b * hstride; the handle's first knot block sits at -hoff
+#ifdef HIPNLP_STAMPS
+    unsigned long long* stamps;  // diagnostic build only (tools/diag/hess_stamps.py): [blocks][8][128] s_memtime per wave
+#endif
 };
-template <int TERRAIN> struct DevEmH {
+template <int TERRAIN, int LAYOUT> struct DevEmH {
     static constexpr int kTerrain = TERRAIN;
+    using Scratch = KnotScratchT<LAYOUT>;
     double* g;
     double* jac;
     double* hess;
@@ -551,13 +555,35 @@ template <int TERRAIN> struct DevEmH {
     __device__ __forceinline__ void H(int slot, int, int, double v) { hess[slot] = v; }
 };
 
-// (79 KB of LDS: two workgroups per CU = two waves per SIMD: the register allocation is capped there)
-template <int TERRAIN> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void hipnlp_knot_hess_kernel(HArgs a) {
-    static_assert(sizeof(KnotScratch) + sizeof(SharedTables) + sizeof(KHessScratch) <= 80 * 1024, "two workgroups per CU");
+// LDS.  The Hessian program runs none of the tasks that emit Jacobian entries or the cost gradient: the last members of the knot scratch
+// (grad, jac: 17.2 KB) are not allocated — on the smooth terrain the first 2.9 KB of jac, where the (p, p) point task hands over to its
+// second half (pp_stage).
+//   LAYOUT_FULL    (launches that are resident at once: knots x batch <= 512): 63 KB, two workgroups per CU;
+//   LAYOUT_COMPACT (planar terrain, longer launches): the compact scratch and the lite tables of the four-wave callback kernel —
+//                  own[] on the joint records, the once-per-knot tables read from global memory, no staging of the horizon-end
+//                  multipliers (no Hessian task reads them: those rows are linear) — 52 KB: THREE workgroups per CU; the planar program
+//                  needs 156 VGPRs (cap at three waves per SIMD: 168).  The smooth terrain's point tasks need 240 VGPRs: two waves per
+//                  SIMD whatever the LDS, so it keeps the full layout.
+template <int TERRAIN, int LAYOUT> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LAYOUT == LAYOUT_COMPACT ? 3 : 2, LAYOUT == LAYOUT_COMPACT ? 3 : 2)))
+void hipnlp_knot_hess_kernel(HArgs a) {
+    using Em = DevEmH<TERRAIN, LAYOUT>;
+    using Scratch = typename Em::Scratch;
+    constexpr bool COMPACT = Scratch::compact;
+    static_assert(!COMPACT || TERRAIN == HIPNLP_TERRAIN_PLANAR, "compact Hessian scratch: planar terrain (the smooth point tasks stage through jac)");
+    static_assert(offsetof(Scratch, jac) + sizeof(Scratch::jac) + 16 > sizeof(Scratch) && offsetof(Scratch, grad) + sizeof(Scratch::grad) == offsetof(Scratch, jac),
+                  "grad and jac are the last members of the scratch (up to tail padding)");
+    constexpr size_t S_BYTES = TERRAIN == HIPNLP_TERRAIN_PLANAR ? offsetof(Scratch, grad) : offsetof(Scratch, jac) + sizeof(double) * PP_STAGE * NC;
+    static_assert(S_BYTES % 16 == 0, "scratch prefix");
     constexpr int WG = 256;
-    __shared__ KnotScratch s;
-    __shared__ SharedTables tabs;
+    __shared__ alignas(16) double s_raw[S_BYTES / sizeof(double)];
+    Scratch& s = *reinterpret_cast<Scratch*>(s_raw);
+    __shared__ SharedTablesT<COMPACT> tabs;
     __shared__ KHessScratch hx;
+    static_assert(S_BYTES + sizeof(SharedTablesT<COMPACT>) + sizeof(KHessScratch) <= (COMPACT ? 160 * 1024 / 3 : 80 * 1024), "workgroups per CU");
+#ifdef HIPNLP_STAMPS
+    const unsigned long long st_entry = __builtin_amdgcn_s_memtime();
+#endif
+    constexpr int G_USED = COMPACT ? gs::FIN : gs::COUNT;   // multipliers staged by native slot (compact: the horizon-end rows have no storage in g[])
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = blockIdx.y;
     const int kk = int((blockIdx.x & 7u) * (gridDim.x >> 3) + min(blockIdx.x & 7u, gridDim.x & 7u) + (blockIdx.x >> 3));   // (XCD-aware, as in hipnlp_knot_kernel)
@@ -597,8 +623,14 @@ template <int TERRAIN> __global__ __launch_bounds__(256) __attribute__((amdgpu_w
         if (!first) stage(x + size_t(NXK) * (k - 1), s.xm, XB); else rot += (XB + 1023) / 1024;
         stage(a.pk + (size_t(b) * N + k) * PK_STRIDE, s.pk, PK_STRIDE * 8);
         stage(x + size_t(NXK) * N, s.xg, NXG * 8);
-        stage(a.gp + b, &tabs.gp, int(sizeof(GParams)));
-        stage(&tb.head, &tabs.head, int(sizeof(HeadTables)));
+        if constexpr (COMPACT) {
+            stage(static_cast<const GParamsLite*>(a.gp + b), &tabs.gp, int(sizeof(GParamsLite)));
+            stage(&tb.head.ks, &tabs.ks, int(sizeof(KSettings)));
+            stage(static_cast<const KinLite*>(&tb.head.kt), &tabs.kt, int(sizeof(KinLite)));
+        } else {
+            stage(a.gp + b, &tabs.gp, int(sizeof(GParams)));
+            stage(&tb.head, &tabs.head, int(sizeof(HeadTables)));
+        }
         double xrem = 0.0, xov = 0.0;
         if (XREM && tid < 2 && !(first && tid == 1)) xrem = x[size_t(NXK) * (k - tid) + XB / 8];
         if (first || last) { if (tid < NPER) xov = x[size_t(NXK) * (first ? N - 1 : 0) + periodicity_row_var(tid)]; }
@@ -613,7 +645,7 @@ template <int TERRAIN> __global__ __launch_bounds__(256) __attribute__((amdgpu_w
         if (tid >= 64 && tid < 64 + XPAD - NXK) { s.x[NXK + tid - 64] = 0.0; s.xm[NXK + tid - 64] = 0.0; }
         if (tid >= 128 && tid < 128 + 8 - NXG) s.xg[NXG + tid - 128] = 0.0;
 #pragma unroll
-        for (int it = 0; it < LG_ITERS; ++it) { const int slot = tid + it * WG; if (slot < gs::COUNT) s.g[slot] = lv[it]; }
+        for (int it = 0; it < LG_ITERS; ++it) { const int slot = tid + it * WG; if (slot < G_USED) s.g[slot] = lv[it]; }
         if (tid < 3) hx.lam_next[tid] = lnext;
         if (tid == 0) hx.sigma = sig;
     }
@@ -627,13 +659,22 @@ template <int TERRAIN> __global__ __launch_bounds__(256) __attribute__((amdgpu_w
     for (int it = 0; it < HP_ITERS; ++it) { const int i = tid + it * WG; hp[it] = i < hk::COUNT ? ht.perm[i] : -1; }   // (padded with -1 on the host)
     const int hpc = (last && tid < 84) ? ht.perm_couple[tid] : -1;   // (padded with -1 on the host)
     KnotInfo ki{k, N, first, last};
-    DevEmH<TERRAIN> em{s.g, s.jac, hx.H};
-    Ctx<DevEmH<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
-    KHCtx<DevEmH<TERRAIN>> hcx{cx, hx, s.g};
+    Em em{s.g, s.jac, hx.H};
+    Ctx<Em> cx(s, tabs.kin(), tabs.settings(), tabs.gp, ki, em, COMPACT ? &tb.head.kt : nullptr, COMPACT ? a.gp + b : nullptr);
+    KHCtx<Em> hcx{cx, hx, s.g};
     // (one contiguous program instance per wave, as in hipnlp_knot_kernel)
+#ifdef HIPNLP_STAMPS
+    unsigned long long st_task[24], st_arr[8], st_dep[8];   // diagnostic build: end of every task group of this wave in program order; barrier arrival / departure
+    int st_nt = 0, bid = 0;
+    const unsigned long long st_staged = __builtin_amdgcn_s_memtime();
+#define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
+#define DEV_RH(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
+#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); bid++;
+#else
 #define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_RH(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); }
 #define DEV_BARRIER lds_barrier();
+#endif
     auto run_wave = [&](auto wc) __attribute__((always_inline)) {
         constexpr int W = decltype(wc)::value;
         HIPNLP_KNOT_HESS_PROGRAM(DEV_KIN, DEV_RH, DEV_BARRIER)
@@ -660,6 +701,15 @@ template <int TERRAIN> __global__ __launch_bounds__(256) __attribute__((amdgpu_w
         atomicMax(a.flag + b, a.seq);
         if (a.flag_host) a.flag_host[b] = a.seq;
     }
+#ifdef HIPNLP_STAMPS
+    if (a.stamps && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* o = a.stamps + ((size_t(blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 128;
+        o[0] = st_entry; o[1] = st_staged; o[2] = (unsigned long long)bid; o[3] = (unsigned long long)st_nt; o[4] = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 8; ++i) { o[8 + 2 * i] = i < bid ? st_arr[i] : 0; o[9 + 2 * i] = i < bid ? st_dep[i] : 0; }
+        for (int i = 0; i < 24; ++i) o[32 + i] = i < st_nt ? st_task[i] : 0;
+    }
+#endif
 }
 
 
@@ -736,6 +786,7 @@ struct hipnlp_handle {
     int batch = 1, kb = 0, ke = 0, nk = 0, np = 0;
     bool wide = false;   // eight-wave kernel variant (launches that are resident at once at two workgroups per CU)
     bool fused = false;  // the total cost is summed inside the knot launch by one reducer workgroup per trajectory (knots <= 256)
+    bool hess_compact = false;   // exact Hessian, planar terrain: compact-scratch instantiation (three workgroups per CU) for launches of more than 512 workgroups
     int dev = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -867,6 +918,8 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
         //  - 1.1 % at x 1024, where ten rows are in flight and as many reducers spin in workgroup slots: long launches keep the kernel)
         const bool small_launch = long(h->nk) * long(desc->batch) <= 32768;
         h->fused = h->nk <= 256 && (h->wide || (small_launch && !(sep && std::atoi(sep) == 1)));
+        const char* hl = std::getenv("HIPNLP_HESS_LAYOUT");   // diagnostic override: full | compact
+        h->hess_compact = hl ? std::strcmp(hl, "compact") == 0 : long(h->nk) * long(desc->batch) > 512;
     }
     std::string e;
     if (!Layout::make_kin_tables(desc->model, h->kt, e)) return fail(HIPNLP_E_INVALID, e);
@@ -1198,10 +1251,17 @@ static int hess_launch(hipnlp_handle* h, const double* x_dev, const double* sigm
         h->hseq = 0;
     }
     a.seq = ++h->hseq; a.pad_ = 0;
-    if (h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR)
-        hipLaunchKernelGGL(hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_PLANAR>, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(256), 0, s, a);
+#ifdef HIPNLP_STAMPS
+    if (!h->d_stamps) HIP_TRY(h, hipMalloc(&h->d_stamps, size_t(h->nk) * size_t(h->batch) * 1024 * sizeof(unsigned long long)));
+    a.stamps = h->d_stamps;
+#endif
+    const dim3 hgrid(unsigned(h->nk), unsigned(h->batch));
+    if (h->d.settings.terrain != HIPNLP_TERRAIN_PLANAR)
+        hipLaunchKernelGGL((hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, LAYOUT_FULL>), hgrid, dim3(256), 0, s, a);
+    else if (h->hess_compact)   // (launches longer than the 512 workgroup slots of the full layout: three workgroups per CU)
+        hipLaunchKernelGGL((hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_PLANAR, LAYOUT_COMPACT>), hgrid, dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL(hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS>, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_PLANAR, LAYOUT_FULL>), hgrid, dim3(256), 0, s, a);
     HIP_TRY(h, hipGetLastError());
     return HIPNLP_OK;
 }

@@ -84,7 +84,7 @@ struct SV6 { double a[3], l[3]; };   // spatial vector [angular; linear]
 struct KHessScratch {
     double lam_next[3];      // multipliers of the angular momentum-dynamics rows of the NEXT interval (owned by knot k + 1)
     double sigma;
-    double Y[NJ][3];
+    double Y[NJ][3], Yc[NJ][3];   // Y_j (t_kh_Y: com and contact points; t_kh_Y_chest: chest cost, zero off the chest path) — consumers add the two
     // centroidal momentum: per joint j (0..NJ-1) and per base rotation axis e (NJ + e)
     SV6 S[NJ + 3], E[NJ + 3], Gm[NJ + 3], Sxl[NJ + 3], Cv[NJ + 3], Wv[NJ + 3];
     double dcmu[NJ + 3][3];  // (d com / d (s_j | theta_e)) x mu   (the com enters through l = [mu; com x mu] only)
@@ -92,6 +92,8 @@ struct KHessScratch {
     uint32_t rel[NJ + 1];    // bit i set: joint i lies on the path root -> j (inclusive)
     double TS[3][NJ], TSD[3][NJ], WS[3][NJ];   // centroidal momentum: (theta_m, s_j), (theta_m, sdot_j), (omega_m, s_j)
     double qqB[16], qqg[4], qq_axE[3], qq_m2;   // (q_b, q_b): Hessian B and gradient g of Phi(qhat) = <M, R(qhat)>, chest-error axis
+    double TW[3][3];         // (theta_m, omega_m') of the centroidal momentum term (t_kh_tw -> t_kh_qqd)
+    double qqMw[9];          // Mw of the (q_b, q_b) block (t_kh_qq0_mw -> t_kh_qq0)
     double H[hk::COUNT];
 };
 
@@ -271,6 +273,13 @@ template <class Em> HD void t_kh_pp(KHCtx<Em>& h, int t) {
     }
     cx.em.H(hk::PP + t, PT_ * hi + P_ + e, PT_ * lo + P_ + e, v);
 }
+
+// Placement of the 180 (p, p) lanes (three wave iterations of ~2 k cycles, no input but the knot record and the multipliers): where the
+// terrain's program leaves waves idle.  Planar: beside the forward kinematics (second phase, waves 1 and 2) and on wave 3 of the first
+// phase; smooth steps: behind the forward kinematics on waves 0 and 3, whose phase lasts as long as the dense point tasks of waves
+// 1 and 2.  Every lane range appears in both placements; exactly one of them does the work (as t_hdyn_entries_a / t_hdyn_entries).
+template <int BEGIN, class Em> HD void t_kh_pp_planar_at(KHCtx<Em>& h, int t) { if (terrain_is_planar(h.cx)) t_kh_pp(h, t + BEGIN); }
+template <int BEGIN, class Em> HD void t_kh_pp_smooth_at(KHCtx<Em>& h, int t) { if (!terrain_is_planar(h.cx)) t_kh_pp(h, t + BEGIN); }
 
 // --- smooth terrain: the dense blocks of one contact point.  Lagrangian of the point with f, v, f_dot, u_v constant:
 //       L = C_u . u + l_d (-kbs h nf - hdot nf - h (ndot . f) - h (n . fdot)) + l_h h + l_n nf + l_f (mu^2 nf^2 - (x.f)^2 - (y.f)^2)
@@ -510,33 +519,49 @@ template <class Em> HD void t_kh_mom0(KHCtx<Em>& h, int) {
     matvec3(hx.IG, hx.mu, hx.K);
 }
 
-// --- centroidal momentum, per joint / base axis: lanes NJ + 3 (behind t_kh_mom0) -----------------------------------------------------
+// --- centroidal momentum, per joint / base axis: lanes NJ + 3, two task groups on two waves (one group formed all six vectors in
+//     round 2: 3.4 k cycles of 26 lanes, next to an idle wave): t_kh_joint S, W = S x v, E;  t_kh_joint_b G = I^C S, S x l, C, dcom x mu.
+template <class Em> HD void kh_joint_axis(KHCtx<Em>& h, int t, SV6& S) {   // (selects, no branch: S stays in registers)
+    auto& s = h.cx.s;
+    const bool joint = t < NJ;
+    const int j = joint ? t : 0;
+    double l[3];
+    cross3(s.ow[j + 1], s.aw[j], l);
+    for (int i = 0; i < 3; ++i) { S.a[i] = joint ? s.aw[j][i] : ((i == t - NJ) ? 1.0 : 0.0); S.l[i] = joint ? l[i] : 0.0; }
+}
 template <class Em> HD void t_kh_joint(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
     auto& s = cx.s;
     KHessScratch& hx = h.hx;
-    SV6 S, v, hC, ell, t1, t2;
+    SV6 S, v, hC, t1, t2;
     const int link = t < NJ ? t + 1 : 0;
     if (t < NJ) {
         uint32_t mask = 0u;
         for (int q = 0; q < 8; ++q) { const int a = int(cx.kt.anc[t][q]); if (a < NJ) mask |= 1u << unsigned(a); }
         hx.rel[t] = mask;
-        for (int i = 0; i < 3; ++i) S.a[i] = s.aw[t][i];
-        cross3(s.ow[t + 1], s.aw[t], S.l);
-    } else {
-        for (int i = 0; i < 3; ++i) { S.a[i] = (i == t - NJ) ? 1.0 : 0.0; S.l[i] = 0.0; }
     }
+    kh_joint_axis(h, t, S);
     const double* cp = s.comp[link];
-    // l = [mu; com x mu], formed by every lane itself (t_kh_mom0 runs beside this task, not before it)
-    double mu[3], comv[3];
-    for (int i = 0; i < 3; ++i) { mu[i] = -h.lam[gs::CMMC + i] / cx.gp.mass; comv[i] = s.comp[0][CH + i] / cx.kt.total_mass; }
-    cross3(comv, mu, ell.l);
-    for (int i = 0; i < 3; ++i) { v.a[i] = s.wv[link][i]; v.l[i] = s.vo[link][i]; hC.a[i] = cp[CKA + i]; hC.l[i] = cp[CKL + i]; ell.a[i] = mu[i]; }
+    for (int i = 0; i < 3; ++i) { v.a[i] = s.wv[link][i]; v.l[i] = s.vo[link][i]; hC.a[i] = cp[CKA + i]; hC.l[i] = cp[CKL + i]; }
     hx.S[t] = S;
     crm6(S, v, hx.Wv[t]);                 // w = S x v
     crf6(S, hC, t1);
     inertia6(cp, hx.Wv[t], t2);
     for (int i = 0; i < 3; ++i) { hx.E[t].a[i] = t1.a[i] - t2.a[i]; hx.E[t].l[i] = t1.l[i] - t2.l[i]; }
+}
+template <class Em> HD void t_kh_joint_b(KHCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    auto& s = cx.s;
+    KHessScratch& hx = h.hx;
+    SV6 S, ell, t1, t2;
+    const int link = t < NJ ? t + 1 : 0;
+    kh_joint_axis(h, t, S);
+    const double* cp = s.comp[link];
+    // l = [mu; com x mu], formed by every lane itself (t_kh_mom0 runs beside this task, not before it)
+    double mu[3], comv[3];
+    for (int i = 0; i < 3; ++i) { mu[i] = -h.lam[gs::CMMC + i] / cx.gp.mass; comv[i] = s.comp[0][CH + i] / cx.kt.total_mass; }
+    cross3(comv, mu, ell.l);
+    for (int i = 0; i < 3; ++i) ell.a[i] = mu[i];
     inertia6(cp, S, hx.Gm[t]);
     crm6(S, ell, hx.Sxl[t]);
     inertia6(cp, hx.Sxl[t], t1);          // B = I^C (S x l)
@@ -558,7 +583,6 @@ template <class Em> HD void t_kh_Y(KHCtx<Em>& h, int j) {
     const double* lam = h.lam;
     const double* a = s.aw[j];
     const double* o = s.ow[j + 1];
-    const double on = cx.ki.first ? 0.0 : 1.0;
     double Y[3] = {0.0, 0.0, 0.0}, t1[3], t2[3];
     {
         const double* cp = s.comp[j + 1];
@@ -584,6 +608,15 @@ template <class Em> HD void t_kh_Y(KHCtx<Em>& h, int j) {
             for (int r = 0; r < 3; ++r) Y[r] += t1[r];
         }
     }
+    for (int r = 0; r < 3; ++r) h.hx.Y[j][r] = Y[r];
+}
+// the chest-cost part of Y_j (joints on the root -> chest path; zero elsewhere): lane j (23), on another wave than t_kh_Y
+template <class Em> HD void t_kh_Y_chest(KHCtx<Em>& h, int j) {
+    Ctx<Em>& cx = h.cx;
+    auto& s = cx.s;
+    const double* a = s.aw[j];
+    const double on = cx.ki.first ? 0.0 : 1.0;
+    double Y[3] = {0.0, 0.0, 0.0};
     if (cx.kt.chest_pos[j] >= 0) {
         double E[9], Ea[3];
         chest_error(s, E);
@@ -594,7 +627,7 @@ template <class Em> HD void t_kh_Y(KHCtx<Em>& h, int j) {
         const double m2 = 2.0 * h.hx.sigma * on * cx.st.m_frameq;
         for (int r = 0; r < 3; ++r) Y[r] += m2 * (e * (Ea[r] - trE * a[r]) + de * (-ax[r]));
     }
-    for (int r = 0; r < 3; ++r) h.hx.Y[j][r] = Y[r];
+    for (int r = 0; r < 3; ++r) h.hx.Yc[j][r] = Y[r];
 }
 
 // momentum entries of the theta-level blocks for base axis m (0..2) and joint j
@@ -658,7 +691,7 @@ template <class Em> HD void t_kh_ss_near(KHCtx<Em>& h, int t) {
     if (k >= NJ) return;
     const double on = cx.ki.first ? 0.0 : 1.0;
     // centroidal momentum; points, com, chest
-    double v = dot3(hx.dcmu[k], hx.E[d].l) + dot3(hx.dcmu[d], hx.E[k].l) - dot6(hx.Sxl[k], hx.E[d]) + dot6(hx.Wv[k], hx.Cv[d]) + dot3(s.aw[k], hx.Y[d]);
+    double v = dot3(hx.dcmu[k], hx.E[d].l) + dot3(hx.dcmu[d], hx.E[k].l) - dot6(hx.Sxl[k], hx.E[d]) + dot6(hx.Wv[k], hx.Cv[d]) + dot3(s.aw[k], hx.Y[d]) + dot3(s.aw[k], hx.Yc[d]);
     // feet lateral distance, both joints on one leg.  For j on the left leg dD/ds_j = y . (a_j x (o_l - o_j)), on the right leg
     // dD/ds_j = (a_j x y) . (o_l - o_j)
     const int Lk = cx.kt.leg_pos[0][k], Ld = cx.kt.leg_pos[0][d], Rk = cx.kt.leg_pos[1][k], Rd = cx.kt.leg_pos[1][d];
@@ -723,7 +756,7 @@ template <class Em> HD void t_kh_sq(KHCtx<Em>& h, int t) {
     const auto& s = cx.s;
     HIPNLP_WAVE_SYNC();
     const int j = t >> 2, l = t & 3;
-    const double* Y = h.hx.Y[j];
+    const double Y[3] = {h.hx.Y[j][0] + h.hx.Yc[j][0], h.hx.Y[j][1] + h.hx.Yc[j][1], h.hx.Y[j][2] + h.hx.Yc[j][2]};
     double v = (s.G[l] * Y[0] + s.G[4 + l] * Y[1] + s.G[8 + l] * Y[2]) * s.inv_qnorm;
     for (int m = 0; m < 3; ++m) v += s.G[4 * m + l] * s.inv_qnorm * h.hx.TS[m][j] + s.dwq[4 * m + l] * h.hx.WS[m][j];
     cx.em.H(hk::SQ + t, S_ + j, QB_ + l, v);
@@ -756,27 +789,31 @@ HD void What_col(const double* t, int l, double* out) {
     for (int r = 0; r < 3; ++r) out[r] = 2.0 * ((r == l ? t[3] : 0.0) + skew_rc(t, r, l));
 }
 
-// --- (q_r, qdot_c): lanes 16 ------------------------------------------------------------------------------------------------------------------
+// --- (theta_m, omega_m') = (dcom_m x mu) . G_m'.l - (S_m x l) . G_m' - (I^C_0 l) . (S_m x S_m'): lanes (m, m') 9.  (Round 2 formed the
+//     nine numbers inside every one of the sixteen (q_r, qdot_c) lanes, one after the other: 4.7 k cycles, the longest chain of the
+//     last phase.) ------------------------------------------------------------------------------------------------------------------------------
+template <class Em> HD void t_kh_tw(KHCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    const auto& s = cx.s;
+    KHessScratch& hx = h.hx;
+    const int m = t / 3, m2 = t - 3 * m;
+    SV6 ell, Il, sx;
+    for (int i = 0; i < 3; ++i) { ell.a[i] = hx.mu[i]; ell.l[i] = hx.ell_l[i]; }
+    inertia6(s.comp[0], ell, Il);
+    crm6(hx.S[NJ + m], hx.S[NJ + m2], sx);
+    hx.TW[m][m2] = dot3(hx.dcmu[NJ + m], hx.Gm[NJ + m2].l) - dot6(hx.Sxl[NJ + m], hx.Gm[NJ + m2]) - dot6(Il, sx);
+}
+// --- (q_r, qdot_c): lanes 16, behind t_kh_tw on the same wave ------------------------------------------------------------------------------------
 template <class Em> HD void t_kh_qqd(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
     const auto& s = cx.s;
     const KHessScratch& hx = h.hx;
+    HIPNLP_WAVE_SYNC();
     const int r = t >> 2, c = t & 3;
-    // (theta_m, omega_m') = (dcom_m x mu) . G_m'.l - (S_m x l) . G_m' - (I^C_0 l) . (S_m x S_m')
-    SV6 ell, Il, sx;
-    for (int i = 0; i < 3; ++i) { ell.a[i] = hx.mu[i]; ell.l[i] = hx.ell_l[i]; }
-    inertia6(s.comp[0], ell, Il);
     double v = 0.0;
-    HIPNLP_ROLLED
     for (int m = 0; m < 3; ++m) {
         const double gm = s.G[4 * m + r] * s.inv_qnorm;
-        const double* tt = hx.dcmu[NJ + m];
-        HIPNLP_ROLLED
-        for (int m2 = 0; m2 < 3; ++m2) {
-            crm6(hx.S[NJ + m], hx.S[NJ + m2], sx);
-            const double tw = dot3(tt, hx.Gm[NJ + m2].l) - dot6(hx.Sxl[NJ + m], hx.Gm[NJ + m2]) - dot6(Il, sx);
-            v += gm * tw * s.G[4 * m2 + c];
-        }
+        for (int m2 = 0; m2 < 3; ++m2) v += gm * hx.TW[m][m2] * s.G[4 * m2 + c];
     }
     // K . d2 omega / dq_r dqdot_c = K . W(J[:, r])[:, c],  J = (1 - qh qh^T) / |q|
     double Jr[4], col[3];
@@ -788,7 +825,9 @@ template <class Em> HD void t_kh_qqd(KHCtx<Em>& h, int t) {
 
 // --- (q_b, q_b), shared part: lane 0 forms  M = Mw R_b  and from it the Hessian B and the gradient g of  Phi(qhat) = <M, R(qhat)>
 //     (R(qh) = I + 2 w [v]x + 2 [v]x^2:  Phi = tr M + 2 w v.ax(M) + 2 v^T M v - 2 (v.v) tr M), behind t_kh_mom0 ---------------------
-template <class Em> HD void t_kh_qq0(KHCtx<Em>& h, int) {
+//     Mw = sum_c w_c pkin_c^T + w_com com^T + sigma 2 m e E^T + mu L_G^T + omega K^T  (world frame), one entry per lane (9), behind
+//     t_kh_mom0 on its wave; lane 0 then goes on alone (t_kh_qq0): M = Mw R_b, B, g.
+template <class Em> HD void t_kh_qq0_mw(KHCtx<Em>& h, int t) {
     HIPNLP_WAVE_SYNC();   // behind t_kh_mom0 on its wave
     Ctx<Em>& cx = h.cx;
     const auto& s = cx.s;
@@ -799,17 +838,22 @@ template <class Em> HD void t_kh_qq0(KHCtx<Em>& h, int) {
     chest_error(s, E);
     const double trE = E[0] + E[4] + E[8], e = trE - 3.0;
     const double m2 = 2.0 * hx.sigma * on * cx.st.m_frameq;
-    hx.qq_axE[0] = E[7] - E[5]; hx.qq_axE[1] = E[2] - E[6]; hx.qq_axE[2] = E[3] - E[1];
-    hx.qq_m2 = m2;
-    // Mw = sum_c w_c pkin_c^T + w_com com^T + sigma 2 m e E^T + mu L_G^T + omega K^T  (world frame);  M = Mw R_b
-    double Mw[9], M[9];
-    for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) {
-            double acc = -lam[gs::COMC + a] * hx.com[b] + m2 * e * E[3 * b + a] + hx.mu[a] * hx.LG[b] + s.omega[a] * hx.K[b];
-            for (int p = 0; p < NC; ++p) acc += -lam[gs::PT_STRIDE * p + gs::KINC + a] * s.pkin[p][b];
-            Mw[3 * a + b] = acc;
-        }
-    matmul3(Mw, s.Rb, M);
+    if (t == 0) {
+        hx.qq_axE[0] = E[7] - E[5]; hx.qq_axE[1] = E[2] - E[6]; hx.qq_axE[2] = E[3] - E[1];
+        hx.qq_m2 = m2;
+    }
+    const int a = t / 3, b = t - 3 * a;
+    double acc = -lam[gs::COMC + a] * hx.com[b] + m2 * e * E[3 * b + a] + hx.mu[a] * hx.LG[b] + s.omega[a] * hx.K[b];
+    for (int p = 0; p < NC; ++p) acc += -lam[gs::PT_STRIDE * p + gs::KINC + a] * s.pkin[p][b];
+    hx.qqMw[t] = acc;
+}
+template <class Em> HD void t_kh_qq0(KHCtx<Em>& h, int) {
+    HIPNLP_WAVE_SYNC();   // behind t_kh_qq0_mw on its wave
+    Ctx<Em>& cx = h.cx;
+    const auto& s = cx.s;
+    KHessScratch& hx = h.hx;
+    double M[9];
+    matmul3(hx.qqMw, s.Rb, M);
     const double trM = M[0] + M[4] + M[8];
     const double al[3] = {M[7] - M[5], M[2] - M[6], M[3] - M[1]};
     const double* qh = s.qn;
@@ -877,40 +921,67 @@ template <class Em> HD void t_kh_qq(KHCtx<Em>& h, int t) {
     cx.em.H(hk::QQ + t, QB_ + r, QB_ + c, v);
 }
 
-// the light (s, sdot) group in two lane ranges
-constexpr int KH_SSD_SPLIT = 5 * 64;
+// the light (s, sdot) group in three lane ranges (nine wave iterations of ~400 cycles: 5 + 3 + 1, filling up three waves)
+constexpr int KH_SSD_A = 5 * 64, KH_SSD_B = 3 * 64, KH_SSD_C = NJ * NJ - KH_SSD_A - KH_SSD_B;
+static_assert(KH_SSD_C > 0 && KH_SSD_C <= 64, "(s, sdot) lane ranges");
 template <class Em> HD void t_kh_ssd_far_a(KHCtx<Em>& h, int t) { t_kh_ssd_far(h, t); }
-template <class Em> HD void t_kh_ssd_far_b(KHCtx<Em>& h, int t) { t_kh_ssd_far(h, t + KH_SSD_SPLIT); }
+template <class Em> HD void t_kh_ssd_far_b(KHCtx<Em>& h, int t) { t_kh_ssd_far(h, t + KH_SSD_A); }
+template <class Em> HD void t_kh_ssd_far_c(KHCtx<Em>& h, int t) { t_kh_ssd_far(h, t + KH_SSD_A + KH_SSD_B); }
 
 // The Hessian program.  KIN(fn, n) runs a task of knot_body.h, RH(w, fn, n) a Hessian task, on wave w of four.  Only the KINEMATIC part
 // of the knot program runs (joint transforms, forward kinematics, link momenta, composites, contact-point kinematics: none of the
 // rows / Jacobian columns), and the Hessian tasks that need no kinematics fill the waves it leaves idle.
-#define HIPNLP_KNOT_HESS_PHASE1(KIN, RH, BARRIER)                                                                \
-    KIN(0, t_joints, NJ) KIN(1, t_base, 3) KIN(1, t_kin_padding, 16)                                             \
-    RH(1, t_kh_diag, 42) RH(1, t_kh_percouple, 84) RH(2, t_kh_point, NC) RH(2, t_kh_ff, 36) RH(3, t_kh_pp, 180)  \
-    BARRIER                                                                                                      \
+// Wave assignment from the per-wave timeline of tools/diag/hess_stamps.py (profiles/r03_hess_stamps_*.txt: cycles per task group, planar,
+// N = 100): round 2's table left the (p, p) lanes (5.9 k cycles) alone on the critical wave of the first phase and 10.2 k cycles on
+// wave 3 of the last phase against 5.2 - 7.6 k on the others.
+#define HIPNLP_KNOT_HESS_PHASE1A(KIN, RH, BARRIER)                                                               \
+    KIN(0, t_joints, NJ) RH(0, t_kh_ff, 36) KIN(1, t_base, 3) KIN(1, t_kin_padding, 16)                          \
+    RH(1, t_kh_diag, 42) RH(1, t_kh_percouple, 84) RH(2, t_kh_point, NC) RH(3, t_kh_pp_planar_at<128>, 52)       \
+    BARRIER
+#define HIPNLP_KNOT_HESS_PHASE1B(KIN, RH, BARRIER)                                                               \
     KIN(0, t_fk_rot_a, FK_TASKS_A) KIN(0, t_link_u_a, FK_SPLIT) KIN(3, t_fk_rot_b, FK_TASKS_B) KIN(3, t_link_u_b, NJ - FK_SPLIT) \
     RH(2, t_kh_point_smooth_pp, NC) RH(1, t_kh_point_smooth_mixed, NC)                                           \
-    BARRIER                                                                                                      \
+    RH(1, t_kh_pp_planar_at<0>, 64) RH(2, t_kh_pp_planar_at<64>, 64)                                             \
+    RH(0, t_kh_pp_smooth_at<0>, 90) RH(3, t_kh_pp_smooth_at<90>, 90)                                             \
+    BARRIER
+#define HIPNLP_KNOT_HESS_PHASE1C(KIN, RH, BARRIER)                                                               \
     KIN(0, t_links, NL) KIN(1, t_frames, 3) KIN(2, t_link_inertia, NL) RH(3, t_kh_point_smooth_pp2, NC)          \
-    BARRIER                                                                                                      \
+    BARRIER
+#define HIPNLP_KNOT_HESS_PHASE1D(KIN, RH, BARRIER)                                                               \
     KIN(0, t_composite_g0, 64) KIN(1, t_composite_g1, 64) KIN(1, t_composite_g2, 64)                             \
     KIN(2, t_composite_g3, 64) KIN(2, t_composite_g4, 64) KIN(3, t_composite_g5, 64) KIN(3, t_pkin, NC)          \
     BARRIER
 #define HIPNLP_KNOT_HESS_PHASE2(KIN, RH, BARRIER)                                                                \
-    RH(0, t_kh_joint, NJ + 3) RH(1, t_kh_Y, NJ) RH(2, t_kh_mom0, 1) RH(2, t_kh_qq0, 1)                           \
+    RH(0, t_kh_joint, NJ + 3) RH(1, t_kh_Y, NJ) RH(2, t_kh_mom0, 1) RH(2, t_kh_qq0_mw, 9) RH(2, t_kh_qq0, 1)     \
+    RH(3, t_kh_joint_b, NJ + 3) RH(3, t_kh_Y_chest, NJ)                                                          \
     BARRIER
 #define HIPNLP_KNOT_HESS_PHASE3(KIN, RH, BARRIER)                                                                \
-    RH(0, t_kh_ss_near, KH_NEAR_TASKS) RH(0, t_kh_qq, 10)                                                        \
-    RH(1, t_kh_ssd_near, 2 * KH_NEAR_TASKS)                                                                      \
-    RH(2, t_kh_ss_far, KH_SS_TASKS) RH(2, t_kh_ssd_far_a, KH_SSD_SPLIT)                                          \
-    RH(3, t_kh_theta, 3 * NJ) RH(3, t_kh_sq, 4 * NJ) RH(3, t_kh_sqd, 4 * NJ) RH(3, t_kh_sdq, 4 * NJ) RH(3, t_kh_qqd, 16) \
-    RH(3, t_kh_ssd_far_b, NJ * NJ - KH_SSD_SPLIT)                                                                \
+    RH(0, t_kh_ss_near, KH_NEAR_TASKS) RH(0, t_kh_ssd_far_a, KH_SSD_A)                                           \
+    RH(1, t_kh_ssd_near, 2 * KH_NEAR_TASKS) RH(1, t_kh_tw, 9) RH(1, t_kh_qqd, 16) RH(1, t_kh_ssd_far_c, KH_SSD_C) \
+    RH(2, t_kh_ss_far, KH_SS_TASKS) RH(2, t_kh_ssd_far_b, KH_SSD_B)                                              \
+    RH(3, t_kh_theta, 3 * NJ) RH(3, t_kh_sq, 4 * NJ) RH(3, t_kh_sqd, 4 * NJ) RH(3, t_kh_sdq, 4 * NJ) RH(3, t_kh_qq, 10) \
     BARRIER
-#if defined(HIPNLP_HESS_DIAG_PHASES)   // diagnostic builds only (tools/diag): the program truncated behind its first / second part
-#define HIPNLP_KNOT_HESS_PROGRAM(KIN, RH, BARRIER) HIPNLP_HESS_DIAG_SELECT(KIN, RH, BARRIER)
+// diagnostic builds only (tools/diag/hess_phases.sh): -DHIPNLP_HESS_DIAG_PHASES=n runs the first n of the six phases (the values are then wrong)
+#if !defined(HIPNLP_HESS_DIAG_PHASES)
+#define HIPNLP_HESS_DIAG_PHASES 6
+#endif
+#if HIPNLP_HESS_DIAG_PHASES >= 6
+#define HIPNLP_KNOT_HESS_PROGRAM(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE1A(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE1B(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE1C(KIN, RH, BARRIER) \
+    HIPNLP_KNOT_HESS_PHASE1D(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE2(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE3(KIN, RH, BARRIER)
+#elif HIPNLP_HESS_DIAG_PHASES == 5
+#define HIPNLP_KNOT_HESS_PROGRAM(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE1A(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE1B(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE1C(KIN, RH, BARRIER) \
+    HIPNLP_KNOT_HESS_PHASE1D(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE2(KIN, RH, BARRIER)
+#elif HIPNLP_HESS_DIAG_PHASES == 4
+#define HIPNLP_KNOT_HESS_PROGRAM(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE1A(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE1B(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE1C(KIN, RH, BARRIER) \
+    HIPNLP_KNOT_HESS_PHASE1D(KIN, RH, BARRIER)
+#elif HIPNLP_HESS_DIAG_PHASES == 3
+#define HIPNLP_KNOT_HESS_PROGRAM(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE1A(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE1B(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE1C(KIN, RH, BARRIER)
+#elif HIPNLP_HESS_DIAG_PHASES == 2
+#define HIPNLP_KNOT_HESS_PROGRAM(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE1A(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE1B(KIN, RH, BARRIER)
+#elif HIPNLP_HESS_DIAG_PHASES == 1
+#define HIPNLP_KNOT_HESS_PROGRAM(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE1A(KIN, RH, BARRIER)
 #else
-#define HIPNLP_KNOT_HESS_PROGRAM(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE1(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE2(KIN, RH, BARRIER) HIPNLP_KNOT_HESS_PHASE3(KIN, RH, BARRIER)
+#define HIPNLP_KNOT_HESS_PROGRAM(KIN, RH, BARRIER)
 #endif
 
 }  // namespace hipnlp

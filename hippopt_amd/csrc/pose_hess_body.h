@@ -178,7 +178,7 @@ template <class Em> HD void t_hess_misc(HCtx<Em>& h, int t) {
 }
 
 // chest-frame rotation error  E = R_chest R(q_d)^T  (K5) recomputed from the frame the pose program left in the scratch
-HD void chest_error(const KnotScratch& s, double* E) {
+template <class S> HD void chest_error(const S& s, double* E) {
     double Rd[9], Rdt[9];
     rot_from_quat(s.pk + PK_REF + R_FQ, Rd);
     for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) Rdt[3 * r + q] = Rd[3 * q + r];

@@ -967,6 +967,42 @@ def test_hessian_matches_oracle(model, HipNlp, maker, horizon):
     assert rel(f[0], fo) <= TOL and rel(g[0], go) <= TOL and rel(jac[0], jaco) <= TOL and rel(grad[0], grado) <= TOL
 
 
+def test_hessian_compact_layout_is_the_full_layout_bit_for_bit(model, HipNlp):
+    """The exact-Hessian kernel of the planar terrain has two instantiations: the full scratch (two workgroups per CU; launches of at
+    most 512 workgroups) and the compact scratch with the lite tables (three per CU; longer launches).  Same program, same arithmetic:
+    the same bits — each forced through HIPNLP_HESS_LAYOUT on a launch the other would get, cost-mode horizon ends included (the
+    compact layout reads their tables from global memory) — and the automatic choice on a launch of more than 512 workgroups against
+    the oracle."""
+    import os
+    from hess_util import hess_mismatch, triplets_to_dict
+    from oracle_lib import Oracle
+    st = periodic_step_settings(40, model)
+    st.final_state_expression_type = st.periodicity_expression_type = _abi.EXPR_MINIMIZE
+    st.final_state_expression_weight, st.periodicity_expression_weight = 2.0, 0.5
+    B = 14                                      # 560 workgroups: compact by itself
+    x, p = make_workload(st, model, batch=B, seed=3200)
+    rng = np.random.RandomState(6)
+    vals = {}
+    for layout in ("full", "compact", None):
+        if layout:
+            os.environ["HIPNLP_HESS_LAYOUT"] = layout
+        try:
+            eng = HipNlp(st, model, batch=B)
+        finally:
+            os.environ.pop("HIPNLP_HESS_LAYOUT", None)
+        eng.set_params(p)
+        if "lam" not in vals:
+            vals["lam"], vals["sig"] = rng.standard_normal((B, eng.m)), rng.uniform(0.0, 1.5, B)
+        vals[layout] = eng.eval_hess(x, vals["sig"], vals["lam"])
+        ir, jc = eng.hess_sparsity()
+        eng.close()
+    assert np.array_equal(vals["full"], vals["compact"]) and np.array_equal(vals[None], vals["compact"])
+    o = Oracle(st, model)
+    for b in (0, B - 1):
+        err, where = hess_mismatch(triplets_to_dict(ir, jc, vals[None][b]), triplets_to_dict(*o.hess(x[b], p[b], vals["sig"][b], vals["lam"][b])))
+        assert err <= TOL, (b, where)
+
+
 def test_hessian_cost_modes_batch_and_shards(model, HipNlp):
     from hess_util import hess_mismatch, triplets_to_dict
     from oracle_lib import Oracle

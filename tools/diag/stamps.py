@@ -16,7 +16,7 @@ SO = os.path.join(ROOT, "tools", "diag", "_build", "libhipnlp_stamps%s.so" % os.
 def build():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DHIPNLP_STAMPS", "-mllvm", "-amdgpu-kernarg-preload-count=16"] + ([] if not os.environ.get("STAMPS_VARIANT") else (["-DHIPNLP_TWOPASS"] if os.environ["STAMPS_VARIANT"] == "twopass" else ["-DHIPNLP_DIAG_SKIP=" + os.environ["STAMPS_VARIANT"]])) + [
-                           "-o", SO, os.path.join(ROOT, "hippopt_amd", "csrc", "hipnlp.hip"), os.path.join(ROOT, "hippopt_amd", "csrc", "hipnlp_pose.hip")])
+                           "-o", SO, os.path.join(ROOT, "hippopt_amd", "csrc", "hipnlp.hip"), os.path.join(ROOT, "hippopt_amd", "csrc", "hipnlp_pose.hip"), os.path.join(ROOT, "hippopt_amd", "csrc", "hipnlp_ipopt.cpp"), "-I", os.path.join(ROOT, "include")])
 
 
 if __name__ == "__main__":
