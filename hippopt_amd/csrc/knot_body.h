@@ -1430,8 +1430,13 @@ template <class Em> HD void t_feetd(Ctx<Em>& cx, int t) {
 constexpr int ENDS_FINISH_TASKS = 1 + ENDS_TASKS;
 template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
     auto& s = cx.s;
-    HIPNLP_WAVE_SYNC();
     const bool active = (cx.ki.last || cx.ki.first) && (cx.st.final_type == HIPNLP_EXPR_MINIMIZE || cx.st.periodicity_type == HIPNLP_EXPR_MINIMIZE);
+    // Nothing to add (interior knots; subject_to ends): no read-modify-write of grad, so no ordering behind t_feetd either.  (With the
+    // fence first, every one of the three wave iterations of this group waited for the wave's outstanding LDS operations and then
+    // for the settings words: 0.9 k cycles on an interior knot, 1.4 k on the first knot — the slowest workgroup of a launch — for
+    // storing one zero.)
+    if (!active) { if (t == 0) s.cost[CT_ENDS] = 0.0; return; }
+    HIPNLP_WAVE_SYNC();
     if (t == 0) {
         // (only the rows that ARE costs: in the compact layout the c[] entries of subject_to rows hold their g values)
         double e = 0.0;
