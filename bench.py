@@ -298,6 +298,25 @@ def host_visible(eng, x_np, horizon, batch, st=None, model=None):
             res["ipopt iterate as four C calls (hipnlp_ipopt_* symbols, C harness, detect_simple_bounds)"] = c_harness_iterate(st, model, x_np[0], eng._bench_params[0])
         except Exception as err:  # noqa: BLE001
             res["ipopt iterate as four C calls (hipnlp_ipopt_* symbols, C harness, detect_simple_bounds)"] = {"error": "%s: %s" % (type(err).__name__, err)}
+    # What the link itself costs: ONE hipMemcpy of the same bytes (f, grad f, g, jac g values) from HBM into pinned host memory and the
+    # wait for it — no kernel, no x upload.  No design that hands IPOPT all four arrays on the host can be faster than this plus the
+    # kernel's own time up to its first output; `all` above is to be read against it, not against the device-resident rate.
+    try:
+        import torch
+        nbytes = sum(int(o.nbytes) for o in outs)
+        src = torch.empty(nbytes, dtype=torch.uint8, device="cuda:%d" % eng.desc.device)
+        dst = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        stream = torch.cuda.Stream(device=src.device)
+
+        def copy_only(i):
+            with torch.cuda.stream(stream):
+                dst.copy_(src, non_blocking=True)
+            stream.synchronize()
+        ms = best_of(copy_only)
+        res["link floor: one D2H copy of the same bytes into pinned memory + wait (no kernel)"] = {
+            "ms_per_call": ms, "bytes": nbytes, "GBps": nbytes / (ms * 1e-3) / 1e9}
+    except Exception as err:  # noqa: BLE001
+        res["link floor: one D2H copy of the same bytes into pinned memory + wait (no kernel)"] = {"error": "%s: %s" % (type(err).__name__, err)}
     for v in res.values():
         if "ms_per_call" in v:
             v["knots_per_s"] = horizon * batch / (v["ms_per_call"] * 1e-3)
@@ -778,7 +797,8 @@ def main():
                 hv = line["host_visible"]
                 for tag, key in (("host_visible_all", "all"), ("host_visible_all_registered", "all (caller arrays registered: direct kernel stores)"),
                                  ("host_visible_all_auto_registration_off", "all (auto-registration off: pinned block + host copy)"),
-                                 ("host_visible_f", "f")):
+                                 ("host_visible_f", "f"),
+                                 ("link_floor_copy_of_the_same_bytes", "link floor: one D2H copy of the same bytes into pinned memory + wait (no kernel)")):
                     if key in hv:
                         cb["gpu_over_cpu"][tag + "_vs_1_thread"] = hv[key]["knots_per_s"] / cb["value"]
                         cb["gpu_over_cpu"][tag + "_vs_all_cores"] = hv[key]["knots_per_s"] / cb["all_cores"]["value"]

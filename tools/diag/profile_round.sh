@@ -27,7 +27,7 @@ for W in $WORKLOADS; do
   python3 bench.py --steps $([ $B -ge 1024 ] && echo 50 || echo 1000) --warmup 50 $ARGS $COMMON > $OUT/bench_$NAME.json 2>/dev/null
 done
 # exact Hessian and pose finder: ONE (kernel, N, batch) per trace, so that every CSV average is the duration of one configuration
-for CFG in periodic:100:1 periodic:100:64 stairs:200:16; do
+for CFG in periodic:100:1 periodic:100:64 periodic:100:256 stairs:200:16; do
   HW=${CFG%%:*}; R=${CFG#*:}; HN=${R%%:*}; HB=${R#*:}
   NAME=hess_${HW}_N${HN}_B${HB}
   echo "== $NAME"
