@@ -265,7 +265,8 @@ def host_visible(eng, x_np, horizon, batch, st=None, model=None):
     res["ipopt iterate as four calls (library defaults)"] = {"ms_per_call": best_of(iterate)}
     # opt-in: the new-x call also fills the registered arrays the later calls will pass (hipnlp_set_early_outputs)
     eng.set_early_outputs(True)
-    res["ipopt iterate as four calls (early outputs)"] = {"ms_per_call": best_of(iterate)}
+    res["ipopt iterate as four calls (early outputs)"] = {"ms_per_call": best_of(iterate),
+                                                           "note": "g and jac g early (IPOPT-safe set: the adapter's own scratch arrays); grad f through the pinned block"}
     eng.set_early_outputs(False)
     eng.unregister_outputs(outs)   # (what the handle registered by itself)
     # the same iterate through the product's own solver path: the four callback objects HipNlpSolver hands to cyipopt / SciPy, on the

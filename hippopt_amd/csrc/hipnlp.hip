@@ -819,7 +819,7 @@ struct hipnlp_handle {
     unsigned gone = 0;            // outputs of the cached result the kernel stored into registered caller arrays (in neither block)
     // hipnlp_set_early_outputs: registered caller arrays seen in earlier calls (host address; the device address is looked up again at
     // every use: a range may have been unregistered since), and which outputs of the cached result already sit in them
-    bool early = false;
+    bool early = false, early_grad = false;   // early outputs: g and jac g; grad f too only with hipnlp_set_early_outputs(h, 2)
     double* seen_host[3] = {nullptr, nullptr, nullptr};   // grad, g, jac
     double* early_host[3] = {nullptr, nullptr, nullptr};
     unsigned early_mask = 0;
@@ -1436,7 +1436,7 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
         for (int q = 0; q < 3; ++q) {
             sel[q] = (to_host & bit[q]) ? 1u : 0u;
             if ((want & bit[q]) && dev_of_dst[q]) { sel[q] = 2u; caller_dev[q] = dev_of_dst[q]; caller_host[q] = host_of_dst[q]; dmask |= bit[q]; }
-            else if (h->early && !(want & bit[q]) && h->seen_host[q]) {
+            else if (h->early && (q != 0 || h->early_grad) && !(want & bit[q]) && h->seen_host[q]) {
                 // early outputs (opt-in): what this call does NOT ask for goes straight into the registered caller array an earlier call
                 // passed for it — IPOPT's eval_g / eval_grad_f / eval_jac_g at this x then find their values in place
                 double* dev = device_address_of(h->seen_host[q], bytes[q]);
@@ -1605,8 +1605,9 @@ int hipnlp_host_stats(const hipnlp_handle* h, long* out /*[8]*/) {
 }
 
 int hipnlp_set_early_outputs(hipnlp_handle* h, int on) {
-    if (!h) return HIPNLP_E_INVALID;
+    if (!h || on < 0 || on > 2) return HIPNLP_E_INVALID;
     h->early = on != 0;
+    h->early_grad = on == 2;   // grad f only on explicit request: IPOPT's adapter hands eval_grad_f the storage of ITS OWN gradient vector
     if (!h->early) { h->early_mask = 0; }
     return HIPNLP_OK;
 }

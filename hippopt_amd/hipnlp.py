@@ -279,9 +279,10 @@ class HipNlp:
         self._check(rc)
         return self.last_views
 
-    def set_early_outputs(self, on=True):
-        """a new evaluation also fills the registered caller arrays earlier calls passed (hipnlp_set_early_outputs; see include/hipnlp.h)"""
-        self._check(self.lib.hipnlp_set_early_outputs(self.h, 1 if on else 0))
+    def set_early_outputs(self, on=True, grad=False):
+        """a new evaluation also fills the registered g / jac arrays earlier calls passed (hipnlp_set_early_outputs; see include/hipnlp.h);
+        grad=True: grad f too — only for callers whose grad array is scratch of their own (NOT IPOPT's own gradient vector)"""
+        self._check(self.lib.hipnlp_set_early_outputs(self.h, (2 if grad else 1) if on else 0))
 
     def set_prefetch(self, want=("f", "grad", "g")):
         """outputs every new evaluation brings to the host besides the ones its call asks for (hipnlp_set_prefetch)"""

@@ -168,7 +168,7 @@ class _CallbackCache:
                 ("hipnlp_eval", handle.lib))
             self._addr = {w: tuple(None if o is None else o.ctypes.data for o in out) for w, out in self._pick.items()}
             self._check = handle._check
-            eng.set_early_outputs(True)
+            eng.set_early_outputs(True, grad=True)    # (the arrays above are this object's own scratch: grad f may be early too)
             self._evaluations0 = eng.host_stats()["evaluations"]
 
     @property

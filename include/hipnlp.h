@@ -253,13 +253,18 @@ int hipnlp_eval_pinned(hipnlp_handle* h, const double* x, int new_x, unsigned wa
  * +7 us): IPOPT asks for f and g at every trial point and for grad f and jac g (new_x = 0) only at accepted ones.
  * HIPNLP_WANT_ALL makes every new evaluation move everything (one launch, no second round trip for jac g).                      */
 int hipnlp_set_prefetch(hipnlp_handle* h, unsigned mask);
-/* Early outputs (opt-in, off by default).  With it on, a NEW evaluation stores the outputs its call does NOT ask for straight into the
- * REGISTERED caller arrays (hipnlp_host_register) that earlier calls passed for them — before the caller asks.  IPOPT's sequence
- * eval_f(new x), eval_g, eval_grad_f, eval_jac_g then costs one launch that moves everything (49 us per 100 knots) and three calls that
- * return at once, instead of a second 1.1 MB transfer when the Jacobian is asked for (70 us); a rejected line-search trial point pays
- * for a Jacobian it never reads (49 instead of 26 us).  Contract: the contents of a registered output array are overwritten by every
- * new_x = 1 call on the handle from the moment the array has been passed once (IPOPT's TNLP adapter only reads its arrays right after
- * the callback that fills them).  A cached call (new_x = 0) that passes a DIFFERENT array for such an output re-evaluates. */
+/* Early outputs (opt-in, off by default).  on = 1: a NEW evaluation stores g and jac g — when its call does NOT ask for them —
+ * straight into the REGISTERED caller arrays (hipnlp_host_register, or registered by the handle itself) that earlier calls passed
+ * for them, before the caller asks.  IPOPT's sequence eval_f(new x), eval_g, eval_grad_f, eval_jac_g then costs one launch that moves
+ * everything and calls that return at once (grad f comes from the pinned block: one 151 KB host copy), instead of a second 1.1 MB
+ * transfer when the Jacobian is asked for; a rejected line-search trial point pays for a Jacobian it never reads.
+ * Contract: the contents of such a g / jac array are overwritten by every new_x call on the handle from the moment the array has been
+ * passed once.  That is safe for arrays the caller treats as scratch and re-reads right after the callback that fills them — IPOPT's
+ * TNLPAdapter evaluates g and the Jacobian values into buffers of its own (full_g_, jac_g_) and copies out of them.  It is NOT safe
+ * for grad f under IPOPT: the adapter hands eval_grad_f the storage of IPOPT's own gradient vector, which stays alive (as the
+ * gradient at the current iterate) while trial points are evaluated — so grad f is excluded unless the caller asks for it with
+ * on = 2, which is for callers whose grad array is scratch of their own too (hippopt_amd's HipNlpSolver callback cache).
+ * A cached call (new_x = 0) that passes a DIFFERENT array for such an output re-evaluates. */
 int hipnlp_set_early_outputs(hipnlp_handle* h, int on);
 /* Bracket host-path launches with HIP events (for hipnlp_last_kernel_ms); off by default: an event pair costs microseconds. */
 int hipnlp_set_host_timing(hipnlp_handle* h, int on);

@@ -66,8 +66,9 @@ int hipnlp_ipopt_sizes(hipnlp_handle* h, Index* n, Index* m, Index* nele_jac, In
 /* Bounds in IPOPT's convention: an infinite bound is -/+ 2e19 (beyond nlp_lower_bound_inf / nlp_upper_bound_inf = -/+ 1e19).
  * Valid after hipnlp_set_params.  Any pointer may be NULL. */
 int hipnlp_ipopt_bounds(hipnlp_handle* h, Number* x_L, Number* x_U, Number* g_L, Number* g_U);
-/* Optional, around IpoptSolve: attach turns on what suits IPOPT's call pattern — early outputs (the first callback at a new x fills
- * the g / grad f / jac g arrays the later callbacks will pass: one transfer per iterate) and auto-registration of IPOPT's arrays;
+/* Optional, around IpoptSolve: attach turns on what suits IPOPT's call pattern — early outputs for g and jac g (the first callback at a
+ * new x fills the arrays the later eval_g / eval_jac_g will pass — the TNLPAdapter's own full_g_ / jac_g_ buffers: one transfer per
+ * iterate; grad f is never written early: its destination is IPOPT's own gradient vector) and auto-registration of IPOPT's arrays;
  * detach turns early outputs off and releases the registrations (call it before the arrays IPOPT owned are freed, i.e. before
  * FreeIpoptProblem). */
 int hipnlp_ipopt_attach(hipnlp_handle* h);

@@ -115,12 +115,17 @@ int main(int argc, char** argv) {
     if (eval_g(n, xs, TRUE, m + 1, g, ud) != FALSE || eval_jac_g(n, xs, TRUE, m, nele_jac - 1, NULL, NULL, jac, ud) != FALSE ||
         eval_f(n + 1, xs, TRUE, &obj_factor, ud) != FALSE) { fprintf(stderr, "a call with wrong sizes was served\n"); return 1; }
 
+    /* IPOPT hands eval_grad_f the storage of ITS OWN gradient vector: the gradient at the current iterate must survive the
+     * evaluation of trial points untouched (no early output may land in it) */
+    double* grad_kept = (double*)must(malloc(sizeof(double) * (size_t)n));
+    const double* grad_current = NULL;
     for (int i = 0; i < points; ++i) {
         double* x = xs + (size_t)i * (size_t)n;
         double f = 0.0;
         int ok;
         if (i == 0) {   /* the starting point: derivatives first */
             ok = eval_grad_f(n, x, TRUE, grad[0], ud);  record(1, i, ok, n, grad[0]);
+            grad_current = grad[0];  memcpy(grad_kept, grad[0], sizeof(double) * (size_t)n);
             ok = eval_jac_g(n, x, FALSE, m, nele_jac, NULL, NULL, jac, ud);  record(3, i, ok, nele_jac, jac);
             ok = eval_f(n, x, FALSE, &f, ud);  record(0, i, ok, 1, &f);
             ok = eval_g(n, x, FALSE, m, g, ud);  record(2, i, ok, m, g);
@@ -129,8 +134,13 @@ int main(int argc, char** argv) {
         }
         ok = eval_f(n, x, TRUE, &f, ud);  record(0, i, ok, 1, &f);                 /* a line-search trial point */
         ok = eval_g(n, x, FALSE, m, g, ud);  record(2, i, ok, m, g);
+        if (grad_current && memcmp(grad_current, grad_kept, sizeof(double) * (size_t)n) != 0) {
+            fprintf(stderr, "the gradient vector of the current iterate was overwritten while trial point %d was evaluated\n", i);
+            return 1;
+        }
         if (i % 3 == 2) continue;                                                   /* rejected: IPOPT moves on */
         ok = eval_grad_f(n, x, FALSE, grad[i & 1], ud);  record(1, i, ok, n, grad[i & 1]);
+        grad_current = grad[i & 1];  memcpy(grad_kept, grad[i & 1], sizeof(double) * (size_t)n);
         ok = eval_jac_g(n, x, FALSE, m, nele_jac, NULL, NULL, jac, ud);  record(3, i, ok, nele_jac, jac);
         if (i % 2 == 0) { ok = eval_h(n, x, FALSE, obj_factor, m, lambda, TRUE, nele_hess, NULL, NULL, hess, ud);  record(4, i, ok, nele_hess, hess); }
     }

@@ -602,10 +602,13 @@ def test_hessian_values_straight_into_a_registered_array(model, HipNlp):
     assert np.array_equal(eng.eval_hess(x, [0.7, 1.3], lam, out=out), ref)
 
 
-def test_early_outputs_into_registered_arrays(model, HipNlp):
-    """hipnlp_set_early_outputs: the new-x call (eval_f) already fills the registered arrays the later eval_g / eval_grad_f / eval_jac_g
+@pytest.mark.parametrize("early_grad", [False, True])
+def test_early_outputs_into_registered_arrays(model, HipNlp, early_grad):
+    """hipnlp_set_early_outputs: the new-x call (eval_f) already fills the registered g / jac arrays the later eval_g / eval_jac_g
     calls pass; alternating iterates, so values left over from the previous x would show; a cached call with ANOTHER array is
-    still served correctly (by a fresh evaluation), and unregistering turns the mode off for that array."""
+    still served correctly (by a fresh evaluation), and unregistering turns the mode off for that array.
+    grad f is NOT touched early unless asked for (on = 2): IPOPT's adapter hands eval_grad_f the storage of its own gradient vector
+    of the current iterate, which must survive the evaluation of trial points."""
     st = periodic_step_settings(9, model)
     x, p = make_workload(st, model, batch=1, seed=43)
     x2 = x + 1e-2 * np.random.RandomState(2).standard_normal(x.shape)
@@ -615,13 +618,15 @@ def test_early_outputs_into_registered_arrays(model, HipNlp):
     outs = [np.zeros_like(a) for a in ref[0]]
     eng.register_outputs(outs)
     try:
-        eng.set_early_outputs(True)
+        eng.set_early_outputs(True, grad=early_grad)
         f_, grad_, g_, jac_ = outs
         for i in range(6):
             xi, r = (x, ref[0]) if i % 2 == 0 else (x2, ref[1])
+            prev = ref[1] if i % 2 == 0 else ref[0]
             eng.eval(xi, new_x=True, want=("f",), out=(f_, None, None, None))
-            if i > 0:   # the arrays have been seen: they already hold this x's values, before being asked for
-                assert np.array_equal(g_, r[2]) and np.array_equal(grad_, r[1]) and np.array_equal(jac_, r[3])
+            if i > 0:   # the arrays have been seen: g and jac already hold this x's values, before being asked for
+                assert np.array_equal(g_, r[2]) and np.array_equal(jac_, r[3])
+                assert np.array_equal(grad_, r[1] if early_grad else prev[1])     # the caller's gradient of the PREVIOUS point is intact
             eng.eval(xi, new_x=False, want=("g",), out=(None, None, g_, None))
             eng.eval(xi, new_x=False, want=("grad",), out=(None, grad_, None, None))
             eng.eval(xi, new_x=False, want=("jac",), out=(None, None, None, jac_))
