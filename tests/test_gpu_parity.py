@@ -517,8 +517,10 @@ def test_maximum_sizes_and_shard_consistency(model, HipNlp):
         assert np.array_equal(jacb[b], jac1[b % 8]) and np.array_equal(gb[b], g1[b % 8]) and fb[b] == f1[b % 8]
 
 
-def test_sharded_callback_reassembly_on_gpu(model, HipNlp):
-    """ShardedCallback on the GPU at world size 1: the fused shard buffer of the whole horizon goes through the
+@pytest.mark.parametrize("lifted", [False, True])
+def test_sharded_callback_reassembly_on_gpu(model, HipNlp, lifted):
+    """(lifted: the knot shards of the detect_simple_bounds problem — what a sharded solve of the reference's scripts evaluates.)
+    ShardedCallback on the GPU at world size 1: the fused shard buffer of the whole horizon goes through the
     library's one-launch reassembly (hipnlp_reassemble) and must equal the unsharded callback bit for bit; f is the in-kernel sum.
     x CHANGES ON EVERY CALL and there are no warm-up repeats: a result that is not ordered behind its own shard evaluation (the
     evaluation on one stream, the reassembly on another) would show the previous iterate's values."""
@@ -527,11 +529,12 @@ def test_sharded_callback_reassembly_on_gpu(model, HipNlp):
     N = 24
     st = periodic_step_settings(N, model)
     x, p = make_workload(st, model, batch=1, seed=77)
-    full = HipNlp(st, model)
+    full = HipNlp(st, model, detect_simple_bounds=lifted)
     full.set_params(p)
     dev = torch.device("cuda", 0)
-    sh = HipNlp(st, model, knot_begin=0, knot_end=N)
+    sh = HipNlp(st, model, knot_begin=0, knot_end=N, detect_simple_bounds=lifted)
     sh.set_params(p)
+    assert (sh.m < sh.m_full) == lifted
     cb = ShardedCallback(N, sh.n, sh.m, sh.nnz, hip_shard_info(sh, 0, N), hip_shard_backend(sh), dev)
     rng = np.random.RandomState(4)
     xs = [x[0] + 1e-2 * i * rng.standard_normal(x.shape[1]) for i in range(6)]
@@ -784,9 +787,10 @@ def test_peer_mode_random_shardings(model, HipNlp):
         st.final_state_expression_type, st.periodicity_expression_type = modes[rng.randint(3)], modes[rng.randint(3)]
         x, p = make_workload(st, model, batch=1, seed=600 + case)
         os.environ["HIPNLP_WAVES"] = str(int(rng.choice([4, 8])))
+        lift = bool(rng.randint(2))     # the detect_simple_bounds layout: shards of the reduced problem
         try:
-            full = HipNlp(st, model)
-            shards = [HipNlp(st, model, knot_begin=cuts[r], knot_end=cuts[r + 1]) for r in range(world)]
+            full = HipNlp(st, model, detect_simple_bounds=lift)
+            shards = [HipNlp(st, model, knot_begin=cuts[r], knot_end=cuts[r + 1], detect_simple_bounds=lift) for r in range(world)]
         finally:
             del os.environ["HIPNLP_WAVES"]
         for e in [full] + shards:
