@@ -1,185 +1,164 @@
-"""Iterate-callback criteria and the best-iterate store: mirror of hippopt.base.opti_callback (reference:
-base/opti_callback.py:24-249 criteria, :252-373 SaveBestUnsolvedVariablesCallback) and of the fallback in OptiSolver.solve
-(base/opti_solver.py:451-520).
+"""Iterate-callback criteria and the best-iterate store behind `use_opti_callback` (what hippopt.base.opti_callback provides:
+base/opti_callback.py:24-249 the criteria, :252-373 SaveBestUnsolvedVariablesCallback; used by the fallback of OptiSolver.solve,
+base/opti_solver.py:451-520).
 
-The reference's criteria read the current cost from `opti.debug.value(opti.f)` and the primal infeasibility from IPOPT's
+Specification (the reference's behaviour, restated):
+  * a criterion looks at the current iterate and answers `satisfied()`; `update()` is called only when the WHOLE criterion a store
+    was built with is satisfied, and moves the criterion's running record; `reset()` forgets the record;
+  * four scalar criteria over two quantities of an iterate — cost and primal infeasibility:
+        BestCost / BestPrimalInfeasibility         satisfied when the quantity is below the running best; update: best := quantity
+        AcceptableCost / AcceptablePrimalInfeasibility(threshold)
+                                                   satisfied when the quantity is below the fixed threshold; update: the best
+                                                   acceptable value seen so far (a record only, it does not enter `satisfied`)
+  * `a & b`, `a | b` combine criteria (anything else is a TypeError); a combination forwards iterate, update and reset to both sides;
+  * the store keeps x (and, when asked, the per-term costs and the constraint multipliers) of the last iterate that satisfied its
+    criterion.
+The reference's criteria pull the cost from `opti.debug.value(opti.f)` and the infeasibility from IPOPT's
 `stats()["iterations"]["inf_pr"][-1]`; here the NLP driver hands both over as an `IterateInfo` at every iteration (IPOPT's
-intermediate callback / SciPy's `callback(xk, state)`), the class names, combination operators and update rules are the same.
+intermediate callback / SciPy's `callback(xk, state)`).  One parametrised class stands behind the four scalar criteria and one behind
+the two combinations; the public class and attribute names are the reference's.
 """
 import abc
-import dataclasses
 import logging
+import operator
+from typing import NamedTuple
 
 import numpy as np
 
 
-@dataclasses.dataclass
-class IterateInfo:
+class IterateInfo(NamedTuple):
     iteration: int
     cost: float
     primal_infeasibility: float
 
 
 class CallbackCriterion(abc.ABC):
-    def __init__(self) -> None:
-        self.info = None
+    info = None      # the iterate under consideration (update_iterate)
 
     @abc.abstractmethod
-    def satisfied(self) -> bool:
-        pass
+    def satisfied(self) -> bool: ...
 
     @abc.abstractmethod
-    def update(self) -> None:
-        pass
+    def update(self) -> None: ...
 
     @abc.abstractmethod
-    def reset(self) -> None:
-        pass
-
-    def __or__(self, other):
-        if not isinstance(other, CallbackCriterion):
-            raise TypeError(other)
-        return OrCombinedCallbackCriterion(lhs=self, rhs=other)
-
-    def __ror__(self, other):
-        return self.__or__(other)
-
-    def __and__(self, other):
-        if not isinstance(other, CallbackCriterion):
-            raise TypeError(other)
-        return AndCombinedCallbackCriterion(lhs=self, rhs=other)
-
-    def __rand__(self, other):
-        return self.__and__(other)
+    def reset(self) -> None: ...
 
     def update_iterate(self, info: IterateInfo) -> None:
-        """Counterpart of update_opti_debug (opti_callback.py:76-78)."""
+        """what update_opti_debug does for the reference's criteria (opti_callback.py:76-78)"""
         self.info = info
 
+    def _combined(self, other, how):
+        if not isinstance(other, CallbackCriterion):
+            raise TypeError("a criterion combines with another criterion, not with " + type(other).__name__)
+        return how(lhs=self, rhs=other)
 
-class BestCost(CallbackCriterion):
-    def __init__(self) -> None:
-        CallbackCriterion.__init__(self)
-        self.best_cost = None
+    def __and__(self, other):
+        return self._combined(other, AndCombinedCallbackCriterion)
+
+    def __or__(self, other):
+        return self._combined(other, OrCombinedCallbackCriterion)
+
+    __rand__, __ror__ = __and__, __or__
+
+
+class _ScalarCriterion(CallbackCriterion):
+    """quantity < bound, where the bound is either the running record itself (Best*) or a fixed threshold (Acceptable*).
+    Subclasses name the quantity, the record attribute and — for the fixed kind — the threshold attribute."""
+    quantity = record = threshold = None
+
+    def __init__(self, *fixed, **named) -> None:
+        if self.threshold is not None:
+            value = fixed[0] if fixed else named.get(self.threshold, np.inf)
+            setattr(self, self.threshold, value)
         self.reset()
 
-    def reset(self) -> None:
-        self.best_cost = np.inf
-
-    def satisfied(self) -> bool:
-        return self.info.cost < self.best_cost
-
-    def update(self) -> None:
-        logging.getLogger("[hippopt_amd::BestCost]").debug(f"New best cost: {self.info.cost} (old: {self.best_cost})")
-        self.best_cost = self.info.cost
-
-
-class AcceptableCost(CallbackCriterion):
-    def __init__(self, acceptable_cost: float = np.inf) -> None:
-        CallbackCriterion.__init__(self)
-        self.acceptable_cost = acceptable_cost
-        self.best_acceptable_cost = None
-        self.reset()
+    def _now(self):
+        return getattr(self.info, self.quantity)
 
     def reset(self) -> None:
-        self.best_acceptable_cost = np.inf
+        setattr(self, self.record, np.inf)
 
     def satisfied(self) -> bool:
-        return self.info.cost < self.acceptable_cost
+        return self._now() < getattr(self, self.threshold or self.record)
 
     def update(self) -> None:
-        if self.info.cost < self.best_acceptable_cost:
-            self.best_acceptable_cost = self.info.cost
+        old, new = getattr(self, self.record), self._now()
+        if self.threshold is None or new < old:
+            logging.getLogger("[hippopt_amd::%s]" % type(self).__name__).debug("%s: %s -> %s", self.record, old, new)
+            setattr(self, self.record, new)
 
 
-class AcceptablePrimalInfeasibility(CallbackCriterion):
-    def __init__(self, acceptable_primal_infeasibility: float = np.inf) -> None:
-        CallbackCriterion.__init__(self)
-        self.acceptable_primal_infeasibility = acceptable_primal_infeasibility
-        self.best_acceptable_primal_infeasibility = None
-        self.reset()
-
-    def reset(self) -> None:
-        self.best_acceptable_primal_infeasibility = np.inf
-
-    def satisfied(self) -> bool:
-        return self.info.primal_infeasibility < self.acceptable_primal_infeasibility
-
-    def update(self) -> None:
-        if self.info.primal_infeasibility < self.best_acceptable_primal_infeasibility:
-            self.best_acceptable_primal_infeasibility = self.info.primal_infeasibility
+class BestCost(_ScalarCriterion):
+    quantity, record = "cost", "best_cost"
 
 
-class BestPrimalInfeasibility(CallbackCriterion):
-    def __init__(self) -> None:
-        CallbackCriterion.__init__(self)
-        self.best_primal_infeasibility = None
-        self.reset()
-
-    def reset(self) -> None:
-        self.best_primal_infeasibility = np.inf
-
-    def satisfied(self) -> bool:
-        return self.info.primal_infeasibility < self.best_primal_infeasibility
-
-    def update(self) -> None:
-        self.best_primal_infeasibility = self.info.primal_infeasibility
+class BestPrimalInfeasibility(_ScalarCriterion):
+    quantity, record = "primal_infeasibility", "best_primal_infeasibility"
 
 
-class CombinedCallbackCriterion(CallbackCriterion, abc.ABC):
+class AcceptableCost(_ScalarCriterion):
+    quantity, record, threshold = "cost", "best_acceptable_cost", "acceptable_cost"
+
+
+class AcceptablePrimalInfeasibility(_ScalarCriterion):
+    quantity, record, threshold = "primal_infeasibility", "best_acceptable_primal_infeasibility", "acceptable_primal_infeasibility"
+
+
+class CombinedCallbackCriterion(CallbackCriterion):
+    connective = None    # operator.and_ / operator.or_ on the two verdicts
+
     def __init__(self, lhs: CallbackCriterion, rhs: CallbackCriterion) -> None:
-        CallbackCriterion.__init__(self)
         self.lhs, self.rhs = lhs, rhs
 
-    def reset(self) -> None:
-        self.lhs.reset()
-        self.rhs.reset()
+    def _both(self, method, *args):
+        for side in (self.lhs, self.rhs):
+            getattr(side, method)(*args)
+
+    def satisfied(self) -> bool:
+        return bool(self.connective(self.lhs.satisfied(), self.rhs.satisfied()))
 
     def update(self) -> None:
-        self.lhs.update()
-        self.rhs.update()
+        self._both("update")
+
+    def reset(self) -> None:
+        self._both("reset")
 
     def update_iterate(self, info: IterateInfo) -> None:
-        self.lhs.update_iterate(info)
-        self.rhs.update_iterate(info)
-
-
-class OrCombinedCallbackCriterion(CombinedCallbackCriterion):
-    def satisfied(self) -> bool:
-        return self.lhs.satisfied() or self.rhs.satisfied()
+        self._both("update_iterate", info)
 
 
 class AndCombinedCallbackCriterion(CombinedCallbackCriterion):
-    def satisfied(self) -> bool:
-        return self.lhs.satisfied() and self.rhs.satisfied()
+    connective = staticmethod(operator.and_)
+
+
+class OrCombinedCallbackCriterion(CombinedCallbackCriterion):
+    connective = staticmethod(operator.or_)
 
 
 class SaveBestUnsolvedVariablesCallback:
-    """Keeps the iterate that last satisfied the criterion (opti_callback.py:310-373): x, cost, and — when asked — the
-    per-term costs and the constraint multipliers at that iterate."""
+    """x, cost and — when asked — per-term costs and constraint multipliers of the iterate that last satisfied the criterion
+    (opti_callback.py:310-373)."""
 
     def __init__(self, criterion: CallbackCriterion, save_costs: bool = True, save_constraint_multipliers: bool = True) -> None:
+        criterion.reset()
         self.criterion = criterion
-        self.criterion.reset()
         self.save_costs, self.save_constraint_multipliers = save_costs, save_constraint_multipliers
-        self.best_iteration = None
-        self.best_x = None
-        self.best_cost = None
+        self.best_iteration = self.best_x = self.best_cost = self.best_constraint_multipliers = None
         self.best_cost_values = {}
-        self.best_constraint_multipliers = None
-
-    def __call__(self, info: IterateInfo, x, multipliers=None, cost_values=None) -> None:
-        self.call(info, x, multipliers, cost_values)
 
     def call(self, info: IterateInfo, x, multipliers=None, cost_values=None) -> None:
-        self.criterion.update_iterate(info)
-        if self.criterion.satisfied():
-            self.criterion.update()
-            logging.getLogger("[hippopt_amd::SaveBestUnsolvedVariablesCallback]").info(f"[i={info.iteration}] New best intermediate variables")
-            self.best_iteration = info.iteration
-            self.best_cost = info.cost
-            self.best_x = np.array(x, dtype=float, copy=True)
-            if self.save_costs and cost_values is not None:
-                self.best_cost_values = dict(cost_values() if callable(cost_values) else cost_values)
-            if self.save_constraint_multipliers and multipliers is not None:
-                self.best_constraint_multipliers = np.array(multipliers, dtype=float, copy=True)
+        crit = self.criterion
+        crit.update_iterate(info)
+        if not crit.satisfied():
+            return
+        crit.update()
+        logging.getLogger("[hippopt_amd::SaveBestUnsolvedVariablesCallback]").info("[i=%d] New best intermediate variables", info.iteration)
+        self.best_iteration, self.best_cost = info.iteration, info.cost
+        self.best_x = np.array(x, dtype=float)
+        if cost_values is not None and self.save_costs:
+            self.best_cost_values = dict(cost_values() if callable(cost_values) else cost_values)
+        if multipliers is not None and self.save_constraint_multipliers:
+            self.best_constraint_multipliers = np.array(multipliers, dtype=float)
+
+    __call__ = call

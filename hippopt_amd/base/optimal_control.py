@@ -176,42 +176,21 @@ class MultipleShootingSolver:
         from .affine import add_expression_to_horizon
         add_expression_to_horizon(self, expression, mode=mode, apply_to_first_elements=apply_to_first_elements, name=name, **kwargs)
 
-    # ---- straight through ------------------------------------------------------------------------------------------------------
-    def set_initial_guess(self, initial_guess):
-        self._optimization_solver.set_initial_guess(initial_guess)
 
-    def get_initial_guess(self):
-        return self._optimization_solver.get_initial_guess()
+def _hand_through(method):
+    """a method of the transcription layer that is the plugin's method of the same name (same arguments, same result)"""
+    def forward(self, *args, **kwargs):
+        return getattr(self._optimization_solver, method)(*args, **kwargs)
+    forward.__name__ = method
+    forward.__doc__ = "OptimizationSolver." + method + " of the plugin this solver was built with"
+    return forward
 
-    def solve(self):
-        self._optimization_solver.solve()
 
-    def get_values(self):
-        return self._optimization_solver.get_values()
-
-    def get_cost_value(self):
-        return self._optimization_solver.get_cost_value()
-
-    def add_cost(self, input_cost, name=None):
-        self._optimization_solver.add_cost(input_cost=input_cost, name=name)
-
-    def add_constraint(self, input_constraint, name=None):
-        self._optimization_solver.add_constraint(input_constraint=input_constraint, name=name)
-
-    def cost_function(self):
-        return self._optimization_solver.cost_function()
-
-    def get_cost_expressions(self):
-        return self._optimization_solver.get_cost_expressions()
-
-    def get_constraint_expressions(self):
-        return self._optimization_solver.get_constraint_expressions()
-
-    def get_cost_values(self):
-        return self._optimization_solver.get_cost_values()
-
-    def get_constraint_multipliers(self):
-        return self._optimization_solver.get_constraint_multipliers()
+# what the transcription layer adds nothing to: guesses, the solve and its results, named costs / constraints
+for _name in ("set_initial_guess", "get_initial_guess", "solve", "get_values", "get_cost_value", "get_cost_values", "get_constraint_multipliers",
+              "add_cost", "add_constraint", "cost_function", "get_cost_expressions", "get_constraint_expressions"):
+    setattr(MultipleShootingSolver, _name, _hand_through(_name))
+del _name
 
 
 class OptimalControlProblemInstance:

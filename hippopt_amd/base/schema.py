@@ -8,7 +8,7 @@ reverse MRO, as for any dataclass) and the metadata `OptimizationObject` scans â
 """
 import dataclasses
 
-from .optimization_object import OptimizationObject, default_composite_field, default_storage_field
+from .optimization_object import OptimizationObject, default_composite_field, default_storage_field, time_varying_metadata
 
 
 def leaf(kind, default=None):
@@ -19,6 +19,11 @@ def leaf(kind, default=None):
 def child(factory, time_varying=True, kind=None):
     """a composite child built by `factory`; `kind` (Variable / Parameter): the storage kind its Overridable* leaves take"""
     return ("child", factory, (time_varying, kind))
+
+
+def series(default=None):
+    """a list of nodes that varies over time (no factory: the constructor or `setup` fills it), e.g. the masses of a toy OCP"""
+    return ("series", default, None)
 
 
 def plain(default=None):
@@ -32,7 +37,7 @@ def argument(default=None):
 
 
 def declare(name, fields, bases=(OptimizationObject,), setup=None, methods=None, module=None):
-    """fields: {name: leaf(...) | child(...) | plain(...) | argument(...)} in layout order"""
+    """fields: {name: leaf(...) | child(...) | series(...) | plain(...) | argument(...)} in layout order"""
     specs, defaults, arguments = [], {}, []
     for fname, (what, a, b) in fields.items():
         if what == "leaf":
@@ -41,6 +46,8 @@ def declare(name, fields, bases=(OptimizationObject,), setup=None, methods=None,
                 defaults[fname] = b
         elif what == "child":
             specs.append((fname, object, default_composite_field(cls=b[1], factory=a, time_varying=b[0])))
+        elif what == "series":
+            specs.append((fname, object, dataclasses.field(default=a, metadata=time_varying_metadata())))
         elif what == "plain":
             specs.append((fname, object, dataclasses.field(default=a)))
         else:

@@ -32,59 +32,66 @@ class Planner:
                                                 horizon=self.settings.horizon_length)
         self.variables = self.optimization_solver.get_optimization_structure()
 
-    # ---- mass regularisation (planner.py:932-1034): forces and momenta are divided by the total mass ---------
-    def _scale_mass(self, var: Variables, factor: float) -> Variables:
-        out = var
-        if out.initial_state is not None:
-            cm = out.initial_state.centroidal_momentum
-            if cm is not None and hasattr(cm, "shape") and len(cm.shape) > 0 and cm.shape[0] == 6:
-                out.initial_state.centroidal_momentum = cm * factor
-            for point in out.initial_state.contact_points.left + out.initial_state.contact_points.right:
-                point.f = point.f * factor
-        if out.final_state is not None:
-            for point in out.final_state.contact_points.left + out.final_state.contact_points.right:
-                point.f = point.f * factor
-        if out.system is None:
-            return out
-        for system in (out.system if isinstance(out.system, list) else [out.system]):
-            if system.centroidal_momentum is not None:
-                system.centroidal_momentum = system.centroidal_momentum * factor
-            for point in system.contact_points.left + system.contact_points.right:
-                if point.f is not None:
-                    point.f = point.f * factor
-        return out
+    # ---- mass regularisation (planner.py:932-1034): the solver works with forces and momenta divided by the total mass --------------
+    @staticmethod
+    def _mass_scaled(var: Variables):
+        """(owner, attribute) of every quantity of a variables tree that carries a factor of the robot's mass"""
+        ends = [state for state in (var.initial_state, var.final_state) if state is not None]
+        knots = [] if var.system is None else (var.system if isinstance(var.system, list) else [var.system])
+        for holder, optional in [(e, False) for e in ends] + [(k, True) for k in knots]:
+            for point in holder.contact_points.left + holder.contact_points.right:
+                if point.f is not None or not optional:      # (a state always carries its forces; a knot of a partial guess may not)
+                    yield point, "f"
+        momentum = None if var.initial_state is None else var.initial_state.centroidal_momentum
+        if momentum is not None and getattr(momentum, "shape", ()) and momentum.shape[0] == 6:
+            yield var.initial_state, "centroidal_momentum"
+        for knot in knots:
+            if knot.centroidal_momentum is not None:
+                yield knot, "centroidal_momentum"
+
+    def _rescaled(self, var: Variables, factor: float) -> Variables:
+        for owner, name in self._mass_scaled(var):
+            setattr(owner, name, getattr(owner, name) * factor)
+        return var
 
     def _apply_mass_regularization(self, var):
         if self.numeric_mass == 0:
             raise ValueError("The mass of the robot is zero. This is not supported.")
-        return self._scale_mass(var, 1.0 / self.numeric_mass)
+        return self._rescaled(var, 1.0 / self.numeric_mass)
 
     def _undo_mass_regularization(self, var):
-        return self._scale_mass(var, self.numeric_mass)
+        return self._rescaled(var, self.numeric_mass)
 
+    # ---- guesses: the plugin stores the REGULARISED tree; everything a user hands over or gets back is in physical units ----------------
     def set_initial_guess(self, initial_guess: Variables) -> None:
         self.optimization_solver.set_initial_guess(self._apply_mass_regularization(copy.deepcopy(initial_guess)))
 
     def get_initial_guess(self) -> Variables:
         return self._undo_mass_regularization(self.optimization_solver.get_initial_guess())
 
-    def set_references(self, references) -> None:
-        guess = self.optimization_solver.get_initial_guess()  # avoid the undo of the mass regularization (planner.py:1044-1057)
-        assert isinstance(guess.references, list)
-        assert not isinstance(references, list) or len(references) == len(guess.references)
-        for i in range(len(guess.references)):
-            guess.references[i] = references[i] if isinstance(references, list) else references
-        self.optimization_solver.set_initial_guess(guess)
+    def _replace_in_guess(self, field: str, value) -> None:
+        guess = self.get_initial_guess()
+        setattr(guess, field, value)
+        self.set_initial_guess(guess)
 
     def set_initial_state(self, initial_state) -> None:
-        guess = self.get_initial_guess()
-        guess.initial_state = initial_state
-        self.set_initial_guess(guess)
+        self._replace_in_guess("initial_state", initial_state)
 
     def set_final_state(self, final_state) -> None:
-        guess = self.get_initial_guess()
-        guess.final_state = final_state
-        self.set_initial_guess(guess)
+        self._replace_in_guess("final_state", final_state)
+
+    def set_references(self, references) -> None:
+        """one reference for every knot, or a list with one per knot; references carry no mass factor, so the stored (regularised)
+        tree is edited in place of a round trip through physical units (planner.py:1044-1057)"""
+        stored = self.optimization_solver.get_initial_guess()
+        slots = stored.references
+        if not isinstance(slots, list):
+            raise TypeError("the references of the expanded structure are one entry per knot")
+        per_knot = isinstance(references, list)
+        if per_knot and len(references) != len(slots):
+            raise ValueError("%d references for %d knots" % (len(references), len(slots)))
+        slots[:] = list(references) if per_knot else [references] * len(slots)
+        self.optimization_solver.set_initial_guess(stored)
 
     def solve(self) -> Output:
         output = self.ocp.problem.solve()

@@ -11,8 +11,8 @@ import dataclasses
 import numpy as np
 
 from ... import robot_planning as hp_rp
-from ...base import (CompositeType, OptimizationObject, Output, Parameter, StorageType, Variable, default_composite_field,
-                     default_storage_field)
+from ...base import Output, Parameter, Variable
+from ...base.schema import argument, child, declare, leaf
 from ...hipnlp_solver import HipNlpSolver
 from ...pose_settings import PoseSettings
 
@@ -45,53 +45,65 @@ class Settings(PoseSettings):
         return ok
 
 
-@dataclasses.dataclass
-class References(OptimizationObject):
-    state: CompositeType = default_composite_field(cls=Parameter, factory=hp_rp.HumanoidState)
-    frame_quaternion_xyzw: StorageType = default_storage_field(Parameter)
-    left_hand_position: StorageType = default_storage_field(Parameter)
-    right_hand_position: StorageType = default_storage_field(Parameter)
-    contact_point_descriptors: dataclasses.InitVar[hp_rp.FeetContactPointDescriptors] = dataclasses.field(default=None)
-    number_of_joints: dataclasses.InitVar[int] = dataclasses.field(default=None)
-
-    def __post_init__(self, contact_point_descriptors, number_of_joints):
-        self.state = hp_rp.HumanoidState(contact_point_descriptors=contact_point_descriptors, number_of_joints=number_of_joints)
-        self.frame_quaternion_xyzw = np.array([0.0, 0.0, 0.0, 1.0])
-        self.left_hand_position = np.zeros(3)
-        self.right_hand_position = np.zeros(3)
+def _humanoid_state(contact_point_descriptors, number_of_joints):
+    return hp_rp.HumanoidState(contact_point_descriptors=contact_point_descriptors, number_of_joints=number_of_joints)
 
 
-@dataclasses.dataclass
-class Variables(OptimizationObject):
-    state: CompositeType = default_composite_field(cls=Variable, factory=hp_rp.HumanoidState)
-    mass: StorageType = default_storage_field(Parameter)
-    parametric_link_length_multipliers: StorageType = default_storage_field(Parameter)
-    parametric_link_densities: StorageType = default_storage_field(Parameter)
-    gravity: StorageType = default_storage_field(Parameter)
-    references: CompositeType = default_composite_field(cls=Parameter, factory=References)
-    relaxed_complementarity_epsilon: StorageType = default_storage_field(Parameter)
-    static_friction: StorageType = default_storage_field(Parameter)
-    maximum_joint_positions: StorageType = default_storage_field(Parameter)
-    minimum_joint_positions: StorageType = default_storage_field(Parameter)
-    left_hand_position_in_frame: StorageType = default_storage_field(Parameter)
-    right_hand_position_in_frame: StorageType = default_storage_field(Parameter)
-    settings: dataclasses.InitVar[object] = dataclasses.field(default=None)
-    kin_dyn_object: dataclasses.InitVar[object] = dataclasses.field(default=None)
+def _references_setup(self, contact_point_descriptors=None, number_of_joints=None):
+    self.state = _humanoid_state(contact_point_descriptors, number_of_joints)
 
-    def __post_init__(self, settings, kin_dyn_object):
-        nj = kin_dyn_object.NDoF
-        self.state = hp_rp.HumanoidState(contact_point_descriptors=settings.contact_points, number_of_joints=nj)
-        self.references = References(contact_point_descriptors=settings.contact_points, number_of_joints=nj)
-        self.parametric_link_length_multipliers = 0.0   # non-parametric model (planner.py:266-270, :286-288)
-        self.parametric_link_densities = 0.0
-        self.mass = kin_dyn_object.get_total_mass()
-        self.gravity = np.asarray(settings.gravity, float)
-        self.static_friction = settings.static_friction
-        self.relaxed_complementarity_epsilon = settings.relaxed_complementarity_epsilon
-        self.maximum_joint_positions = settings.maximum_joint_positions
-        self.minimum_joint_positions = settings.minimum_joint_positions
-        self.left_hand_position_in_frame = np.asarray(settings.lef_hand_position_in_frame, float)      # planner.py:298-299
-        self.right_hand_position_in_frame = np.asarray(settings.right_hand_position_in_frame, float)
+
+# the two nodes of the pose finder's tree (planner.py:196-226, :229-320), one table each: leaves in layout order with their storage
+# kind and default, children with their factory, constructor-only arguments last (hippopt_amd/base/schema.py)
+References = declare("References", {
+    "state": child(hp_rp.HumanoidState, time_varying=False, kind=Parameter),
+    "frame_quaternion_xyzw": leaf(Parameter, lambda: np.array([0.0, 0.0, 0.0, 1.0])),
+    "left_hand_position": leaf(Parameter, lambda: np.zeros(3)),
+    "right_hand_position": leaf(Parameter, lambda: np.zeros(3)),
+    "contact_point_descriptors": argument(),
+    "number_of_joints": argument(),
+}, setup=_references_setup, module=__name__)
+
+# Variables leaf <- where its value comes from (Settings attribute, or a function of (settings, model)); the parametric-link
+# parameters exist in the layout (planner.py:266-270, :286-288) and are zero: the model is not parametric
+_PARAMETER_SOURCES = {
+    "mass": lambda st, model: model.get_total_mass(),
+    "parametric_link_length_multipliers": lambda st, model: 0.0,
+    "parametric_link_densities": lambda st, model: 0.0,
+    "gravity": lambda st, model: np.asarray(st.gravity, float),
+    "relaxed_complementarity_epsilon": "relaxed_complementarity_epsilon",
+    "static_friction": "static_friction",
+    "maximum_joint_positions": "maximum_joint_positions",
+    "minimum_joint_positions": "minimum_joint_positions",
+    "left_hand_position_in_frame": lambda st, model: np.asarray(st.lef_hand_position_in_frame, float),      # (sic: planner.py:298-299)
+    "right_hand_position_in_frame": lambda st, model: np.asarray(st.right_hand_position_in_frame, float),
+}
+
+
+def _variables_setup(self, settings=None, kin_dyn_object=None):
+    joints = kin_dyn_object.NDoF
+    self.state = _humanoid_state(settings.contact_points, joints)
+    self.references = References(contact_point_descriptors=settings.contact_points, number_of_joints=joints)
+    for name, source in _PARAMETER_SOURCES.items():
+        setattr(self, name, getattr(settings, source) if isinstance(source, str) else source(settings, kin_dyn_object))
+
+
+Variables = declare("Variables", {
+    "state": child(hp_rp.HumanoidState, time_varying=False, kind=Variable),
+    "mass": leaf(Parameter),
+    "parametric_link_length_multipliers": leaf(Parameter),
+    "parametric_link_densities": leaf(Parameter),
+    "gravity": leaf(Parameter),
+    "references": child(References, time_varying=False, kind=Parameter),
+    "relaxed_complementarity_epsilon": leaf(Parameter),
+    "static_friction": leaf(Parameter),
+    "maximum_joint_positions": leaf(Parameter),
+    "minimum_joint_positions": leaf(Parameter),
+    "left_hand_position_in_frame": leaf(Parameter),
+    "right_hand_position_in_frame": leaf(Parameter),
+    "settings": argument(),
+    "kin_dyn_object": argument(),
+}, setup=_variables_setup, module=__name__)
 
 
 class Planner:
@@ -110,23 +122,21 @@ class Planner:
                                                 options_solver=self.settings.solver_options, problem="pose", error_on_fail=error_on_fail)
         self.optimization_solver.generate_optimization_objects(self.variables)
 
-    # ---- mass regularisation (planner.py:788-850): contact forces of the state and of the references / mass ----------
-    def _scale_forces(self, var: Variables, factor: float) -> Variables:
+    # ---- mass regularisation (planner.py:788-850): the contact forces of the state and of the reference state, divided by the mass ----
+    def _forces_times(self, var: Variables, factor: float) -> Variables:
         if self.numeric_mass == 0:
             raise ValueError("The mass of the robot is zero. This is not supported.")
-        out = var
-        for holder in (out.state, out.references.state if out.references is not None else None):
-            if holder is None:
-                continue
+        holders = [var.state] + ([] if var.references is None else [var.references.state])
+        for holder in filter(None, holders):
             for point in holder.contact_points.left + holder.contact_points.right:
-                point.f = np.asarray(point.f, float) * factor
-        return out
+                point.f = factor * np.asarray(point.f, float)
+        return var
 
     def _apply_mass_regularization(self, var):
-        return self._scale_forces(var, 1.0 / self.numeric_mass)
+        return self._forces_times(var, 1.0 / self.numeric_mass)
 
     def _undo_mass_regularization(self, var):
-        return self._scale_forces(var, self.numeric_mass)
+        return self._forces_times(var, self.numeric_mass)
 
     def set_initial_guess(self, initial_guess: Variables) -> None:
         self.optimization_solver.set_initial_guess(self._apply_mass_regularization(copy.deepcopy(initial_guess)))
@@ -135,15 +145,18 @@ class Planner:
         return self._undo_mass_regularization(self.optimization_solver.get_initial_guess())
 
     def set_references(self, references: References) -> None:
-        guess = self.optimization_solver.get_initial_guess()  # avoid the undo of the mass regularization (planner.py:859-864)
-        guess.references = copy.deepcopy(references)
-        self.set_initial_guess(guess)
+        """As coded in the reference (planner.py:859-864): the STORED guess (already regularised) gets the new references and goes
+        through `set_initial_guess` as a whole — the reference forces are divided by the mass as they must be, and so are, once
+        more, the state forces of the stored guess.  Kept, because the iterate sequence of a solve depends on its initial guess."""
+        stored = self.optimization_solver.get_initial_guess()
+        stored.references = copy.deepcopy(references)
+        self.set_initial_guess(stored)
 
     def solve(self) -> Output:
-        s = self.optimization_solver
-        s.solve()
-        return Output(values=self._undo_mass_regularization(s.get_values()), cost_value=s.get_cost_value(),
-                      cost_values=s.get_cost_values(), constraint_multipliers=s.get_constraint_multipliers())
+        plugin = self.optimization_solver
+        plugin.solve()
+        return Output(values=self._undo_mass_regularization(plugin.get_values()), cost_value=plugin.get_cost_value(),
+                      cost_values=plugin.get_cost_values(), constraint_multipliers=plugin.get_constraint_multipliers())
 
     def get_variables_structure(self) -> Variables:
         return copy.deepcopy(self.variables)
