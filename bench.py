@@ -164,6 +164,32 @@ def cpu_baseline(settings, model, x, p):
     return out
 
 
+def ipopt_probe():
+    """BASELINE's metric has an "IPOPT wall-clock" half.  IPOPT is reached through cyipopt (Python) or libipopt's C interface (the
+    hipnlp_ipopt_* callbacks of include/hipnlp_ipopt.h); neither is in the image.  Probed at run time: when cyipopt imports, config 3
+    (single step, N = 30, the reference script's termination options) is solved to convergence through the planner mirror
+    (tools/diag/converged_solve.py picks IPOPT by itself then) and its wall clock is reported; otherwise the line says what is absent."""
+    import ctypes.util
+    import subprocess
+    out = {"libipopt": ctypes.util.find_library("ipopt") or "absent"}
+    try:
+        import cyipopt
+        out["cyipopt"] = getattr(cyipopt, "__version__", "importable")
+    except Exception as err:  # noqa: BLE001
+        out["cyipopt"] = "absent (%s)" % type(err).__name__
+        out["ipopt_wall_clock"] = ("unmeasured: no IPOPT on this box; the callbacks IPOPT would bind are timed in `host_visible` (the C symbols from a C program "
+                                   "in IPOPT's call order, the Python solver path), the NLP driver standing in for IPOPT in the solver tests is SciPy trust-constr")
+        return out
+    try:
+        env = dict(os.environ, SOLVE_N="30", SOLVE_ITERS="300")
+        run = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "diag", "converged_solve.py")],
+                             env=env, capture_output=True, text=True, timeout=600)
+        out["ipopt_wall_clock"] = json.loads(run.stdout.strip().splitlines()[-1]) if run.returncode == 0 else {"error": run.stderr[-500:]}
+    except Exception as err:  # noqa: BLE001
+        out["ipopt_wall_clock"] = {"error": "%s: %s" % (type(err).__name__, err)}
+    return out
+
+
 def time_hessian(eng, x_np, knots):
     """ms per evaluation of the exact Hessian of the Lagrangian with device pointers, timed with events on a non-default stream
     (the library maps a null stream pointer to its own stream, which torch events would not see)"""
@@ -804,6 +830,7 @@ def main():
                         cb["gpu_over_cpu"][tag + "_vs_1_thread"] = hv[key]["knots_per_s"] / cb["value"]
                         cb["gpu_over_cpu"][tag + "_vs_all_cores"] = hv[key]["knots_per_s"] / cb["all_cores"]["value"]
             line["cpu_baseline"] = cb
+            line["ipopt"] = ipopt_probe()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -487,6 +487,10 @@ template <class Em> HD void t_kh_diag(KHCtx<Em>& h, int t) {
     else { var = SD_ + (t - 19); v = 2.0 * sigma * on * cx.st.m_jreg * (cx.st.joint_reg_as_coded ? double(NJ) : 1.0); }   // J6
     cx.em.H(hk::DG + t, var, var, v + ends_diag(h, var));
 }
+// the diagonal / com-height lanes: 0.9 k cycles on the planar terrain, 4.7 k on the smooth one (the com's bump jets) — there they
+// run behind the forward kinematics of the second phase, like the (p, p) lanes
+template <class Em> HD void t_kh_diag_planar(KHCtx<Em>& h, int t) { if (terrain_is_planar(h.cx)) t_kh_diag(h, t); }
+template <class Em> HD void t_kh_diag_smooth(KHCtx<Em>& h, int t) { if (!terrain_is_planar(h.cx)) t_kh_diag(h, t); }
 
 // --- periodicity cost, coupling of the last knot with the first: lanes 84 (last knot only) -------------------------------------
 template <class Em> HD void t_kh_percouple(KHCtx<Em>& h, int i) {
@@ -936,13 +940,13 @@ template <class Em> HD void t_kh_ssd_far_c(KHCtx<Em>& h, int t) { t_kh_ssd_far(h
 // wave 3 of the last phase against 5.2 - 7.6 k on the others.
 #define HIPNLP_KNOT_HESS_PHASE1A(KIN, RH, BARRIER)                                                               \
     KIN(0, t_joints, NJ) RH(0, t_kh_ff, 36) KIN(1, t_base, 3) KIN(1, t_kin_padding, 16)                          \
-    RH(1, t_kh_diag, 42) RH(1, t_kh_percouple, 84) RH(2, t_kh_point, NC) RH(3, t_kh_pp_planar_at<128>, 52)       \
+    RH(1, t_kh_diag_planar, 42) RH(1, t_kh_percouple, 84) RH(2, t_kh_point, NC) RH(3, t_kh_pp_planar_at<128>, 52) \
     BARRIER
 #define HIPNLP_KNOT_HESS_PHASE1B(KIN, RH, BARRIER)                                                               \
     KIN(0, t_fk_rot_a, FK_TASKS_A) KIN(0, t_link_u_a, FK_SPLIT) KIN(3, t_fk_rot_b, FK_TASKS_B) KIN(3, t_link_u_b, NJ - FK_SPLIT) \
     RH(2, t_kh_point_smooth_pp, NC) RH(1, t_kh_point_smooth_mixed, NC)                                           \
     RH(1, t_kh_pp_planar_at<0>, 64) RH(2, t_kh_pp_planar_at<64>, 64)                                             \
-    RH(0, t_kh_pp_smooth_at<0>, 90) RH(3, t_kh_pp_smooth_at<90>, 90)                                             \
+    RH(0, t_kh_pp_smooth_at<0>, 90) RH(3, t_kh_pp_smooth_at<90>, 90) RH(0, t_kh_diag_smooth, 42)                 \
     BARRIER
 #define HIPNLP_KNOT_HESS_PHASE1C(KIN, RH, BARRIER)                                                               \
     KIN(0, t_links, NL) KIN(1, t_frames, 3) KIN(2, t_link_inertia, NL) RH(3, t_kh_point_smooth_pp2, NC)          \

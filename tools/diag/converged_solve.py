@@ -134,10 +134,10 @@ def main():
     engine_s = [0.0]
     inner = hipnlp_solver._CallbackCache.eval
 
-    def timed_eval(self, x, want):
+    def timed_eval(self, x, want, **kw):
         t = time.perf_counter()
         try:
-            return inner(self, x, want)
+            return inner(self, x, want, **kw)
         finally:
             engine_s[0] += time.perf_counter() - t
     hipnlp_solver._CallbackCache.eval = timed_eval
