@@ -137,7 +137,7 @@ HD bool is_anc(const KinTables& kt, int i, int j) {   // joint i on the path roo
 }
 // row r of the packed lower triangle that holds entry t:  r (r + 1) / 2 <= t < (r + 1)(r + 2) / 2
 HD int tri_row(int t) {
-    int r = int((sqrt(8.0 * double(t) + 1.0) - 1.0) * 0.5);
+    int r = int((sqrtf(8.0f * float(t) + 1.0f) - 1.0f) * 0.5f);   // (single precision: an estimate the two tests below make exact; t < 2^20)
     if ((r + 1) * (r + 2) / 2 <= t) ++r;
     if (r * (r + 1) / 2 > t) --r;
     return r;
