@@ -558,7 +558,7 @@ template <int TERRAIN, int LAYOUT> struct DevEmH {
 // LDS.  The Hessian program runs none of the tasks that emit Jacobian entries or the cost gradient: the last members of the knot scratch
 // (grad, jac: 17.2 KB) are not allocated — on the smooth terrain the first 2.9 KB of jac, where the (p, p) point task hands over to its
 // second half (pp_stage).
-//   LAYOUT_FULL    (launches that are resident at once: knots x batch <= 512): 63 KB, two workgroups per CU;
+//   LAYOUT_FULL    (launches that are resident at once: knots x batch <= 512): 64 KB (69 KB on the smooth terrain), two workgroups per CU;
 //   LAYOUT_COMPACT (planar terrain, longer launches): the compact scratch and the lite tables of the four-wave callback kernel —
 //                  own[] on the joint records, the once-per-knot tables read from global memory, no staging of the horizon-end
 //                  multipliers (no Hessian task reads them: those rows are linear) — 52 KB: THREE workgroups per CU; the planar program
