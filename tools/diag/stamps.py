@@ -150,6 +150,21 @@ if __name__ == "__main__":
     endt = out[:, :, 8 + 2 * nb].astype(np.int64).max(axis=1)
     print("grid: first entry -> last entry %d cycles, first entry -> last end %d cycles" % (ent.max() - ent.min(), endt.max() - ent.min()))
     o = out.astype(np.int64)
+    # the same on the 100 MHz real-time counter, which all XCDs share (s_memtime is a per-XCD clock: differences ACROSS workgroups of
+    # different XCDs mean nothing): entry of every workgroup's first wave and end of its last wave, relative to the first entry
+    used = o[:, :len(waves), :]
+    r_in, r_out = used[:, :, 3].min(axis=1), used[:, :, 4].max(axis=1)
+    t00 = r_in.min()
+    print("grid on the real-time counter (10 ns ticks): workgroups enter over %d ticks (median entry %d), end between %d and %d ticks after the first entry; "
+          "by XCD (workgroup index mod 8) median entry %s" % (r_in.max() - t00, int(np.median(r_in - t00)), (r_out - t00).min(), (r_out - t00).max(),
+                                                              [int(np.median(r_in[j::8] - t00)) for j in range(8)]))
+    nkx = len(r_in)
+    knot_of = [(xb & 7) * (nkx >> 3) + min(xb & 7, nkx & 7) + (xb >> 3) for xb in range(nkx)]
+    late = np.argsort(-r_out)[:5]
+    print("last workgroups to end: " + "; ".join("blockIdx %d (knot %d): enters at %d, ends at %d, lasts %d ticks" % (
+        int(i), knot_of[int(i)], int(r_in[i] - t00), int(r_out[i] - t00), int(r_out[i] - r_in[i])) for i in late))
+    print("workgroup life (ticks): median %d, first knot %d, last knot %d" % (
+        int(np.median(r_out - r_in)), int((r_out - r_in)[knot_of.index(0)]), int((r_out - r_in)[knot_of.index(nkx - 1)])))
     if len(waves) == 8:   # publishing wave (7): time from the release of B4 to its arrival at B5, per workgroup
         d = o[:, 7, 8 + 2 * 5] - o[:, 7, 9 + 2 * 4]
         print("wave 7, phase F (release B4 -> arrival B5): median %d  max %d (workgroup %d)" % (np.median(d), d.max(), int(np.argmax(d))))
