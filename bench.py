@@ -219,10 +219,17 @@ def time_hessian(eng, x_np, knots):
            "note": "lower-triangle triplets of sigma hess f + lambda^T hess g, block diagonal by knot; device pointers, no PCIe"}
     lam = np.random.RandomState(0).standard_normal((B, eng.m))
     hv = eng.eval_hess(x_np, 1.0, lam)
-    t0 = time.perf_counter()
-    for _ in range(30):
+    for _ in range(3):     # (the handle registers the value array at its second sight: once, outside the timed calls)
         eng.eval_hess(x_np, 1.0, lam, out=hv)
-    res["host_visible_ms"] = 1e3 * (time.perf_counter() - t0) / 30
+    per_call = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        eng.eval_hess(x_np, 1.0, lam, out=hv)
+        per_call.append(time.perf_counter() - t0)
+    per_call.sort()
+    res["host_visible_ms"] = 1e3 * per_call[len(per_call) // 2]
+    res["host_visible_note"] = ("median of 30 hipnlp_eval_hess calls through host buffers, the caller's value array reused (registered by the handle, "
+                                "direct kernel stores); slowest call %.3f ms" % (1e3 * per_call[-1]))
     return res
 
 

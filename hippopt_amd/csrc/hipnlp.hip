@@ -827,8 +827,8 @@ struct hipnlp_handle {
     // consecutive calls is page-locked and mapped (hipHostRegister) so that the kernel stores straight into it; every use is verified
     // with a sentinel (below), at most AUTO_MAX ranges per handle, unregistered by hipnlp_destroy
     bool auto_reg = true;
-    const void* last_seen[3] = {nullptr, nullptr, nullptr};   // grad, g, jac pointers of the previous call (second sight registers)
-    const void* no_auto[3] = {nullptr, nullptr, nullptr};     // pointers that failed to register or failed the sentinel check: left alone
+    const void* last_seen[4] = {nullptr, nullptr, nullptr, nullptr};   // grad, g, jac (hipnlp_eval) and Hessian-value (hipnlp_eval_hess) pointers of the previous call (second sight registers)
+    const void* no_auto[4] = {nullptr, nullptr, nullptr, nullptr};     // pointers that failed to register or failed the sentinel check: left alone
     unsigned long long sentinel_salt = 0;
     long auto_registered = 0, auto_fallbacks = 0;
     bool time_host = false;       // bracket host-path launches with events (hipnlp_set_host_timing)
@@ -874,6 +874,8 @@ static void free_all(hipnlp_handle* h) {
 extern "C" {
 
 static void auto_unregister_all(hipnlp_handle* h);
+static bool auto_owns(const hipnlp_handle* h, const void* p);
+static double* caller_array_address(hipnlp_handle* h, int q, double* p, size_t bytes);
 
 const char* hipnlp_last_error(const hipnlp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -1301,13 +1303,35 @@ int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor
         xsrc = h->d_x;
     }
     HIP_TRY(h, hipMemcpyAsync(h->d_sigma, h->h_sl, B * (1 + m) * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    // the values leave the kernel as PCIe stores into the pinned block — or straight into the CALLER'S array when that lies in a range
-    // registered with hipnlp_host_register (no 1.2 MB host copy behind the launch): no copy command either way
-    double* direct = device_address_of(hess, B * hn * sizeof(double));
+    // the values leave the kernel as PCIe stores into the pinned block — or straight into the CALLER'S array when that lies in a
+    // registered range (no 1.2 MB host copy behind the launch): registered by the caller, or by the handle itself at the array's second
+    // consecutive sight (IPOPT evaluates the Hessian into the value array of its own matrix); a store into an array the handle
+    // registered is verified with the sentinel words of the callback path, and served through the pinned block if it did not arrive
+    const size_t hbytes = B * hn * sizeof(double);
+    double* direct = caller_array_address(h, 3, hess, hbytes);
+    u64 sentinel = 0;
+    if (direct && auto_owns(h, hess)) {
+        sentinel = 0x7FF8C0DE00000000ull | (++h->sentinel_salt & 0xFFFFFFFFull);
+        u64* w = reinterpret_cast<u64*>(hess);
+        __atomic_store_n(&w[0], sentinel, __ATOMIC_RELAXED);
+        __atomic_store_n(&w[hbytes / 8 - 1], sentinel, __ATOMIC_RELAXED);
+    }
     rc = hess_launch(h, xsrc, h->d_sigma, h->d_lambda, direct ? direct : h->hd_hess, h->stream, true);
     if (rc != HIPNLP_OK) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (!direct) std::memcpy(hess, h->h_hess, B * hn * sizeof(double));
+    if (sentinel) {
+        const u64* w = reinterpret_cast<const u64*>(hess);
+        if (__atomic_load_n(&w[0], __ATOMIC_RELAXED) == sentinel || __atomic_load_n(&w[hbytes / 8 - 1], __ATOMIC_RELAXED) == sentinel) {
+            (void)hipnlp_host_unregister(hess);
+            h->no_auto[3] = hess;
+            h->auto_fallbacks++;
+            rc = hess_launch(h, xsrc, h->d_sigma, h->d_lambda, h->hd_hess, h->stream, true);
+            if (rc != HIPNLP_OK) return rc;
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            direct = nullptr;
+        }
+    }
+    if (!direct) std::memcpy(hess, h->h_hess, hbytes);
     for (size_t b = 0; b < B; ++b)
         if (h->h_hflag[b] == h->hseq) { h->err = "non-finite value produced by the evaluation"; return HIPNLP_E_NUMERIC; }
     return HIPNLP_OK;
@@ -1373,7 +1397,7 @@ static bool auto_owns(const hipnlp_handle* h, const void* p) {
 }
 constexpr size_t AUTO_MIN_BYTES = 64 * 1024;   // smaller arrays are cheaper to copy than to page-lock
 constexpr size_t AUTO_MAX = 6;
-// device-visible address of the caller's output array q (0 grad, 1 g, 2 jac), registering it at its second consecutive sight
+// device-visible address of the caller's output array q (0 grad, 1 g, 2 jac, 3 Hessian values), registering it at its second consecutive sight
 static double* caller_array_address(hipnlp_handle* h, int q, double* p, size_t bytes) {
     if (!p) return nullptr;   // (IPOPT passes one array per callback: "consecutive" means consecutive calls that pass this output)
     double* dev = device_address_of(p, bytes);
@@ -1384,7 +1408,7 @@ static double* caller_array_address(hipnlp_handle* h, int q, double* p, size_t b
         if (hipnlp_host_register(p, bytes, &d) == HIPNLP_OK) {
             // (diagnostic, tests only: HIPNLP_DEBUG_MISDIRECT_AUTO maps the array to the pinned block's copy of the output instead —
             //  stores that do not arrive in the caller's pages, the situation the sentinel check exists for, without unmapping anything)
-            if (std::getenv("HIPNLP_DEBUG_MISDIRECT_AUTO")) d = q == 0 ? (void*)h->hd_grad : (q == 1 ? (void*)h->hd_g : (void*)h->hd_jac);
+            if (std::getenv("HIPNLP_DEBUG_MISDIRECT_AUTO")) d = q == 0 ? (void*)h->hd_grad : (q == 1 ? (void*)h->hd_g : (q == 2 ? (void*)h->hd_jac : (void*)h->hd_hess));
             {
                 std::lock_guard<std::mutex> lock(g_ranges_mutex);
                 for (HostRange& r : g_ranges) if (r.host == reinterpret_cast<char*>(p)) { r.owner = h; r.dev = static_cast<char*>(d); }
@@ -1592,7 +1616,7 @@ int hipnlp_set_auto_register(hipnlp_handle* h, int on) {
     h->auto_reg = on != 0;
     if (!h->auto_reg) {
         auto_unregister_all(h);
-        for (int q = 0; q < 3; ++q) { h->last_seen[q] = nullptr; h->no_auto[q] = nullptr; }
+        for (int q = 0; q < 4; ++q) { h->last_seen[q] = nullptr; h->no_auto[q] = nullptr; }
     }
     return HIPNLP_OK;
 }

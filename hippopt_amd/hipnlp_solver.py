@@ -137,6 +137,25 @@ class _SimpleBoundsLift:
         return lam
 
 
+def _hessian_evaluator(eng):
+    """eng.eval_hess with ONE value array for the whole solve where the engine takes one (`out=`): the handle registers an output array
+    it sees twice in a row and stores into it directly, and a fresh 1.2 MB numpy array per call would pay its page faults each time.
+    The callers copy the values on (into a sparse matrix / into IPOPT's array) before the next evaluation."""
+    import inspect
+    try:
+        takes_out = "out" in inspect.signature(eng.eval_hess).parameters
+    except (TypeError, ValueError):
+        takes_out = False
+    keep = {}
+
+    def evaluate(x, obj_factor, lam):
+        if not takes_out:
+            return np.asarray(eng.eval_hess(x, obj_factor, lam)).reshape(-1)
+        keep["out"] = eng.eval_hess(x, obj_factor, lam, out=keep.get("out"))
+        return keep["out"].reshape(-1)
+    return evaluate
+
+
 class _CallbackCache:
     """What IPOPT's `new_x` flag does for a C caller: the four callbacks of one iterate share ONE evaluation.
 
@@ -495,13 +514,15 @@ class HipNlpSolver(OptimizationSolver):
             def sym(vals):
                 return csc_matrix((np.concatenate([vals, vals[off]]), (np.concatenate([hr, hc[off]]), np.concatenate([hc, hr[off]]))), shape=(n, n))
             zero_lam = np.zeros(m)
+            hessian = _hessian_evaluator(eng)
+
             def hess_f(x):   # (the Hessian evaluation reuses the engine's staging of x: the cached callback set is gone)
                 cache.invalidate()
-                return sym(np.asarray(eng.eval_hess(x[None, :], 1.0, zero_lam[None, :])).reshape(-1))
+                return sym(hessian(x[None, :], 1.0, zero_lam[None, :]))
 
             def hess_c(x, v):
                 cache.invalidate()
-                return sym(np.asarray(eng.eval_hess(x[None, :], 0.0, np.asarray(v)[None, :])).reshape(-1))
+                return sym(hessian(x[None, :], 0.0, np.asarray(v)[None, :]))
         nlc = NonlinearConstraint(cons, lbg, ubg, jac=jac, hess=hess_c)
         opts = {"maxiter": int(self._options.get("max_iter", 50)), "verbose": int(self._options.get("verbose", 0)),
                 "gtol": float(self._options.get("tol", 1e-6))}
@@ -586,9 +607,11 @@ class HipNlpSolver(OptimizationSolver):
                 exact = False
         if exact:   # eval_h from the engine: the pose finder runs IPOPT with the exact Hessian (humanoid_pose_finder/main.py:101)
             Callbacks.hessianstructure = lambda self: (hr, hc)
+            hessian = _hessian_evaluator(eng)
+
             def _hessian(self, x, lagrange, obj_factor):
                 cache.invalidate()   # (the Hessian evaluation reuses the engine's staging of x)
-                return np.asarray(eng.eval_hess(x[None, :], obj_factor, np.asarray(lagrange)[None, :])).reshape(-1)
+                return hessian(x[None, :], obj_factor, np.asarray(lagrange)[None, :])
             Callbacks.hessian = _hessian
         nlp = cyipopt.Problem(n=eng.n, m=eng.m, problem_obj=Callbacks(), lb=lbx, ub=ubx, cl=lbg, cu=ubg)
         if not exact:

@@ -279,7 +279,8 @@ int hipnlp_host_breakdown(const hipnlp_handle* h, double* us /*[4]*/);
  * each: hippopt_amd/sharded.py HostSink).  Process-wide (no handle); the caller unregisters before freeing the memory.           */
 int hipnlp_host_register(void* p, size_t bytes, void** dev_ptr);
 int hipnlp_host_unregister(void* p);
-/* Auto-registration (ON by default): a grad_f / g / jac array of at least 64 KB that hipnlp_eval sees at the same address on two
+/* Auto-registration (ON by default): a grad_f / g / jac array (hipnlp_eval) or Hessian-value array (hipnlp_eval_hess) of at least 64 KB
+ * that the call sees at the same address on two
  * CONSECUTIVE calls is registered by the handle itself (as hipnlp_host_register would) and is a direct kernel output from then on —
  * a plain binding that simply passes IPOPT's arrays gets the fast path without knowing about it.  Safety: a registration pins the
  * PAGES behind an address; should the caller free the array and the allocator map other pages at the same address, the kernel's

@@ -93,3 +93,45 @@ def test_new_x_unknown_is_decided_by_comparison(model, HipNlp):
     ref = eng.eval(xs[0], new_x=True)
     assert f0[0] == ref[0][0] and np.array_equal(g0, ref[2]) and f1[0] != f0[0]
     assert k0 > 0.0
+
+
+def test_hessian_value_array_is_registered_at_its_second_sight_and_verified(model, HipNlp):
+    """hipnlp_eval_hess: the caller's value array (IPOPT evaluates the Hessian into the value array of its own matrix) becomes a direct
+    kernel output at its second consecutive sight, verified by the sentinel words like the callback outputs; the values are those of
+    the path through the pinned block, bit for bit, and a store that does not arrive is caught and served through the pinned block."""
+    import os
+    st = periodic_step_settings(40, model)
+    x, p = make_workload(st, model, batch=1, seed=4500)
+    ref, eng = HipNlp(st, model), HipNlp(st, model)
+    for e in (ref, eng):
+        e.set_params(p)
+    ref.set_auto_register(False)
+    lam = np.random.RandomState(8).standard_normal((1, eng.m))
+    xs = iterates(x, 5)
+    out = np.empty((1, eng.hess_nnz()))
+    for i, xi in enumerate(xs):
+        got = eng.eval_hess(xi, 0.9, lam, out=out)
+        assert got is out and np.array_equal(out, ref.eval_hess(xi, 0.9, lam)), i
+        assert eng.host_stats()["auto_registered"] == (0 if i == 0 else 1)
+    assert eng.host_stats()["auto_fallbacks"] == 0
+    # the callback outputs of the same handle keep their own registrations beside it
+    cb = (np.empty(1), np.empty((1, eng.n)), np.empty((1, eng.m)), np.empty((1, eng.nnz)))
+    for xi in xs[:3]:
+        eng.eval(xi, out=cb)
+        assert all(np.array_equal(u, v) for u, v in zip(cb, ref.eval(xi)))
+    assert np.array_equal(eng.eval_hess(xs[1], 0.9, lam, out=out), ref.eval_hess(xs[1], 0.9, lam))
+    eng2 = HipNlp(st, model)
+    eng2.set_params(p)
+    out2 = np.empty((1, eng2.hess_nnz()))
+    os.environ["HIPNLP_DEBUG_MISDIRECT_AUTO"] = "1"
+    try:
+        eng2.eval_hess(xs[0], 0.9, lam, out=out2)
+        eng2.eval_hess(xs[1], 0.9, lam, out=out2)      # registered (misdirected), caught, served through the pinned block
+    finally:
+        del os.environ["HIPNLP_DEBUG_MISDIRECT_AUTO"]
+    assert np.array_equal(out2, ref.eval_hess(xs[1], 0.9, lam))
+    stats = eng2.host_stats()
+    assert stats["auto_registered"] == 1 and stats["auto_fallbacks"] == 1
+    assert np.array_equal(eng2.eval_hess(xs[2], 0.9, lam, out=out2), ref.eval_hess(xs[2], 0.9, lam)) and eng2.host_stats()["auto_registered"] == 1
+    eng.close()
+    eng2.close()
