@@ -415,6 +415,10 @@ template <class Em> HD void t_hess_qq(HCtx<Em>& h, int t) {
 // Only the KINEMATIC part of the pose program runs (joint transforms, forward kinematics, link quantities, composites, contact-point
 // kinematics: none of the rows / Jacobian columns); the Hessian tasks that need no kinematics sit on the waves its first phase leaves idle.
 template <class Em> HD void t_kin_padding(Ctx<Em>& cx, int e) { scratch_padding(cx.s, e); }
+// the 276 joint-pair lanes in two ranges on two waves (five wave iterations on one wave next to an idle one before)
+constexpr int HESS_SS_SPLIT = 3 * 64;
+template <class Em> HD void t_hess_ss_a(HCtx<Em>& h, int t) { t_hess_ss(h, t); }
+template <class Em> HD void t_hess_ss_b(HCtx<Em>& h, int t) { t_hess_ss(h, t + HESS_SS_SPLIT); }
 #define HIPNLP_POSE_HESS_PROGRAM(KIN, RH, BARRIER)                                                                \
     KIN(0, t_joints, NJ) KIN(1, t_base, 3) KIN(1, t_kin_padding, 16) RH(2, t_hess_point, NC) RH(3, t_hess_misc, HESS_MISC_TASKS) \
     BARRIER                                                                                                       \
@@ -427,7 +431,7 @@ template <class Em> HD void t_kin_padding(Ctx<Em>& cx, int e) { scratch_padding(
     BARRIER                                                                                                       \
     RH(2, t_hess_Y, NJ) RH(3, t_hess_qq, 10)                                                                      \
     BARRIER                                                                                                       \
-    RH(0, t_hess_ss, HESS_SS_TASKS) RH(1, t_hess_qs, 4 * NJ) RH(2, t_hess_hand, HESS_HAND_TASKS)                  \
+    RH(0, t_hess_ss_a, HESS_SS_SPLIT) RH(3, t_hess_ss_b, HESS_SS_TASKS - HESS_SS_SPLIT) RH(1, t_hess_qs, 4 * NJ) RH(2, t_hess_hand, HESS_HAND_TASKS) \
     BARRIER
 
 }  // namespace hipnlp
