@@ -994,7 +994,17 @@ template <class Em> struct em_waves<Em, std::void_t<decltype(Em::kWaves)>> { sta
 template <class Em> constexpr bool hdyn_entries_early = em_waves<Em>::value == 4 && Em::kTerrain == HIPNLP_TERRAIN_SMOOTH_STEPS;
 template <class Em> HD void t_hdyn_entries_a(Ctx<Em>& cx, int t) { if constexpr (hdyn_entries_early<Em>) t_hdyn(cx, t); }
 template <class Em> HD void t_hdyn_entries(Ctx<Em>& cx, int t) { if constexpr (!hdyn_entries_early<Em>) t_hdyn(cx, t); }
-template <class Em> HD void t_hdyn_rows(Ctx<Em>& cx, int t) { t_hdyn(cx, t + 48); }
+// The six rows sum the per-point shares t_points_vec left in hd[]: behind it on ITS wave in the first phase where the entries run
+// early (four-wave kernel on the smooth terrain: that phase waits for the terrain chain of another wave anyway, while the second phase
+// was set by the wave that carried these rows behind its half of the forward kinematics — 6.8 k against 4.0 - 4.8 k cycles under
+// load, profiles/r03_callback_stamps_stairs_B32.txt); in the second phase everywhere else.  Exactly one of the two groups works.
+template <class Em> HD void t_hdyn_rows_a(Ctx<Em>& cx, int t) {
+    if constexpr (hdyn_entries_early<Em>) {
+        HIPNLP_WAVE_SYNC();   // hd[] of this wave's t_points_vec
+        t_hdyn(cx, t + 48);
+    }
+}
+template <class Em> HD void t_hdyn_rows(Ctx<Em>& cx, int t) { if constexpr (!hdyn_entries_early<Em>) t_hdyn(cx, t + 48); }
 // --- centroidal momentum dynamics (T7 on E1): lanes (c, e) 48 entry tasks + lanes 48..59 row tasks -----------
 constexpr int HDYN_TASKS = 60;
 template <class Em> HD void t_hdyn(Ctx<Em>& cx, int t) {
@@ -1473,7 +1483,7 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
 // groups only write scratch (no emitter calls), so the host expansions, which run both, compute the same thing twice.
 // ---------------------------------------------------------------------------------------------------
 #define HIPNLP_KNOT_PROGRAM(R, BARRIER)                                                   \
-    R(0, 0, t_points_vec, 3 * NC) R(0, HIPNLP_W8(7, 2), t_joint_rows, NJ)                 \
+    R(0, 0, t_points_vec, 3 * NC) R(HIPNLP_W4(-1, 0), -1, t_hdyn_rows_a, HDYN_TASKS - 48) R(0, HIPNLP_W8(7, 2), t_joint_rows, NJ) \
     R(HIPNLP_W4(1, 3), HIPNLP_W8(7, 2), t_points_scalar, NC) R(HIPNLP_W4(1, 0), 3, t_dyn, 7 + NJ + 3) R(1, 7, t_terrain_bump, TERRAIN_BUMP_TASKS) R(1, 7, t_terrain_stage, NC) R(HIPNLP_W4(1, 0), 1, t_unitq, 1) \
     R(2, HIPNLP_W8(2, 4), t_joints, NJ) R(HIPNLP_W4(1, 2), 1, t_feet_yaw, 2) R(2, HIPNLP_W8(4, 1), t_feet_centroid, 1) R(HIPNLP_W4(-1, 2), -1, t_hdyn_entries_a, 48) \
     R(3, 5, t_base, 3) R(3, 6, t_small, 4) R(3, 3, t_points_dyn, 3 * NC) \
