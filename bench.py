@@ -60,6 +60,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hessian", action="store_true", help="skip the exact-Hessian figure reported beside the callback quartet")
     ap.add_argument("--no-host", action="store_true", help="skip the host-visible (PCIe-inclusive) figures")
+    ap.add_argument("--no-throughput", action="store_true", help="skip the batch-launch roofline block reported beside the headline")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the sharded paths on one GPU (debug)")
     return ap.parse_args()
 
@@ -302,13 +303,54 @@ def host_visible(eng, x_np, horizon, batch, st=None, model=None):
                                                            "note": "g and jac g early (IPOPT-safe set: the adapter's own scratch arrays); grad f through the pinned block"}
     eng.set_early_outputs(False)
     eng.unregister_outputs(outs)   # (what the handle registered by itself)
+    # HIPNLP_FLAG_JAC_VARYING_FIRST (what a triplet consumer such as IPOPT picks): the varying entries of a knot's block are ONE run,
+    # the stores that skip the constants are contiguous on the link
+    if st is not None:
+        try:
+            from hippopt_amd.hipnlp import HipNlp
+            vf = HipNlp(st, model, batch=batch, device=eng.desc.device, jac_varying_first=True)
+            vf.set_params(eng._bench_params)
+            vf.set_prefetch(())
+            vouts = vf.eval(x_np)
+            for name in ("jac", "all"):
+                want = kinds[name]
+                out = tuple(o if k in want else None for k, o in zip(("f", "grad", "g", "jac"), vouts))
+                res[name + " (varying-first order of a knot's jac block)"] = {
+                    "ms_per_call": best_of(lambda i: vf.eval(xs[i % 4], want=want, out=out)),
+                    "library_us [x staging, enqueue, wait for the GPU, copies out]": [round(float(v), 2) for v in vf.host_breakdown()]}
+            # the same handle with every entry of jac g stored on every call (hipnlp_set_constant_jacobian off) — same process, same arrays
+            vf.set_constant_jacobian(False)
+            for name in ("jac", "all"):
+                want = kinds[name]
+                out = tuple(o if k in want else None for k, o in zip(("f", "grad", "g", "jac"), vouts))
+                res[name + " (varying-first order, constant entries stored on every call)"] = {"ms_per_call": best_of(lambda i: vf.eval(xs[i % 4], want=want, out=out))}
+            vf.set_constant_jacobian(True)
+            vf.set_prefetch(("f", "grad", "g"))
+            vf_, vgrad_, vg_, vjac_ = vouts
+
+            def viterate(i):
+                vf.eval(xs[i % 4], new_x=True, want=("f",), out=(vf_, None, None, None))
+                vf.eval(xs[i % 4], new_x=False, want=("g",), out=(None, None, vg_, None))
+                vf.eval(xs[i % 4], new_x=False, want=("grad",), out=(None, vgrad_, None, None))
+                vf.eval(xs[i % 4], new_x=False, want=("jac",), out=(None, None, None, vjac_))
+            res["ipopt iterate as four calls (varying-first order, library defaults: jac g fetched when asked for)"] = {"ms_per_call": best_of(viterate)}
+            vf.set_early_outputs(True)
+            res["ipopt iterate as four calls (varying-first order, early outputs)"] = {"ms_per_call": best_of(viterate)}
+            vf.set_early_outputs(False)
+            stats = vf.host_stats()
+            res["all (varying-first order of a knot's jac block)"]["constant_entries"] = {
+                "of": int(vf.nnz) * batch, "constant": int(stats["constant_entries"]) * batch, "fills": stats["constant_fills"], "refills": stats["constant_refills"]}
+            vf.unregister_outputs(vouts)
+            vf.close()
+        except Exception as err:  # noqa: BLE001
+            res["all (varying-first order of a knot's jac block)"] = {"error": "%s: %s" % (type(err).__name__, err)}
     # the same iterate through the product's own solver path: the four callback objects HipNlpSolver hands to cyipopt / SciPy, on the
     # NLP the reference's scripts solve (detect_simple_bounds: the reduced problem is the handle's own layout)
     if st is not None and batch == 1:
         try:
             from hippopt_amd.hipnlp import HipNlp
             from hippopt_amd.hipnlp_solver import _CallbackCache, _SimpleBoundsLift
-            red = HipNlp(st, model, batch=1, device=eng.desc.device, detect_simple_bounds=True)
+            red = HipNlp(st, model, batch=1, device=eng.desc.device, detect_simple_bounds=True, jac_varying_first=True)   # (as HipNlpSolver.engine())
             red.set_params(eng._bench_params)
             view = _SimpleBoundsLift(red)
             flat = [xi[0] for xi in xs]
@@ -329,9 +371,12 @@ def host_visible(eng, x_np, horizon, batch, st=None, model=None):
     # IPOPT itself is not in the image): an iterate as four C calls on arrays the program owns for the whole run
     if st is not None and batch == 1:
         try:
-            res["ipopt iterate as four C calls (hipnlp_ipopt_* symbols, C harness, detect_simple_bounds)"] = c_harness_iterate(st, model, x_np[0], eng._bench_params[0])
+            res["ipopt iterate as four C calls (hipnlp_ipopt_* symbols, C harness, detect_simple_bounds, varying-first; hipnlp_ipopt_attach: nothing written early)"] = \
+                c_harness_iterate(st, model, x_np[0], eng._bench_params[0], attach=1)
+            res["ipopt iterate as four C calls (the same + hipnlp_ipopt_set_early_outputs: opt-in, see include/hipnlp_ipopt.h)"] = \
+                c_harness_iterate(st, model, x_np[0], eng._bench_params[0], attach=2)
         except Exception as err:  # noqa: BLE001
-            res["ipopt iterate as four C calls (hipnlp_ipopt_* symbols, C harness, detect_simple_bounds)"] = {"error": "%s: %s" % (type(err).__name__, err)}
+            res["ipopt iterate as four C calls (hipnlp_ipopt_* symbols, C harness)"] = {"error": "%s: %s" % (type(err).__name__, err)}
     # What the link itself costs: ONE hipMemcpy of the same bytes (f, grad f, g, jac g values) from HBM into pinned host memory and the
     # wait for it — no kernel, no x upload.  No design that hands IPOPT all four arrays on the host can be faster than this plus the
     # kernel's own time up to its first output; `all` above is to be read against it, not against the device-resident rate.
@@ -349,6 +394,17 @@ def host_visible(eng, x_np, horizon, batch, st=None, model=None):
         ms = best_of(copy_only)
         res["link floor: one D2H copy of the same bytes into pinned memory + wait (no kernel)"] = {
             "ms_per_call": ms, "bytes": nbytes, "GBps": nbytes / (ms * 1e-3) / 1e9}
+        # restated for the bytes that actually cross the link since the constant entries of jac g stay where they are
+        moved = nbytes - 8 * int(eng.host_stats()["constant_entries"]) * batch
+        src2, dst2 = src[:moved], dst[:moved]
+
+        def copy_moved(i):
+            with torch.cuda.stream(stream):
+                dst2.copy_(src2, non_blocking=True)
+            stream.synchronize()
+        ms2 = best_of(copy_moved)
+        res["link floor for the bytes actually moved (f, grad f, g and the varying entries of jac g)"] = {
+            "ms_per_call": ms2, "bytes": moved, "GBps": moved / (ms2 * 1e-3) / 1e9}
     except Exception as err:  # noqa: BLE001
         res["link floor: one D2H copy of the same bytes into pinned memory + wait (no kernel)"] = {"error": "%s: %s" % (type(err).__name__, err)}
     for v in res.values():
@@ -357,7 +413,142 @@ def host_visible(eng, x_np, horizon, batch, st=None, model=None):
     return res
 
 
-def c_harness_iterate(st, model, x, p):
+def throughput_block(model, device_index):
+    """The batch launches beside the headline (never `value`): each kernel's roofline figure from THIS run, HIP events on the launch
+    stream, a few dozen launches each.  Periodic N = 100 x 64 and x 1024, the stairs 200 x 16 (BASELINE config 5's whole job on one GPU),
+    the exact Hessian x 64, the pose finder x 4096.  Synthetic trajectories: one seeded base trajectory + N(0, 0.02^2) per trajectory
+    (SURVEY §8d), generated in one vectorised draw."""
+    import numpy as np
+    import torch
+    from hippopt_amd.hipnlp import HipNlp, HipPose
+    from hippopt_amd.kinodyn_settings import periodic_step_settings, stairs_settings
+    from hippopt_amd.pose_settings import make_pose_workload, pose_finder_settings
+    from hippopt_amd.synthetic import make_workload, place_on_step_flanks
+    dev = torch.device("cuda", device_index)
+    stream = torch.cuda.Stream(device=dev)
+    out = {"timing": "HIP events on the launch stream (callback kernels: the library's own events around every 16th knot-kernel launch, every 4th at x 1024; Hessian / pose: "
+                     "one pair of events around the timed launches, one kernel per launch)", "peak_GBps": HBM_PEAK_GBS}
+    t_all = time.perf_counter()
+
+    def batch_of(st, B, seed, stairs=False):
+        x1, p1 = make_workload(st, model, batch=1, seed=seed)
+        if stairs:
+            place_on_step_flanks(x1, st, seed=seed)
+        x = x1 + 0.02 * np.random.RandomState(seed + 1).standard_normal((B, x1.shape[1]))
+        x[0] = x1[0]
+        if stairs:   # the contact points and the com stay on the flanks of the bumps (no exp-underflow shortcut in the terrain jets)
+            N = st.horizon_length
+            cols = np.concatenate([189 * np.arange(N)[:, None] + np.array([15 * c + 6 + i for c in range(8) for i in range(3)] + [180, 181])[None, :]]).reshape(-1)
+            x[:, cols] = x1[0, cols][None, :] + 1e-3 * np.random.RandomState(seed + 2).standard_normal((B, cols.size))
+        return x, np.tile(p1, (B, 1))
+
+    def callbacks(tag, maker, N, B, seed, stairs=False):
+        st = maker(N, model)
+        x, p = batch_of(st, B, seed, stairs)
+        eng = HipNlp(st, model, batch=B, device=device_index)
+        eng.set_params(p)
+        with torch.cuda.stream(stream):
+            xd = torch.from_numpy(x).to(dev)
+            f = torch.empty(B, dtype=torch.float64, device=dev)
+            grad = torch.empty(B * eng.n, dtype=torch.float64, device=dev)
+            g = torch.empty(B * eng.m, dtype=torch.float64, device=dev)
+            jac = torch.empty(B * eng.nnz, dtype=torch.float64, device=dev)
+        stream.synchronize()
+        args = (xd.data_ptr(), f.data_ptr(), grad.data_ptr(), g.data_ptr(), jac.data_ptr())
+        # (short launches: enough of them for the clocks to settle — the first few dozen launches after an idle period run ~10 % slow)
+        reps, warm, ev = (24, 6, 4) if N * B > 50000 else (320, 160, 16)
+        for _ in range(warm):
+            eng.eval_device(*args, stream=stream.cuda_stream)
+        stream.synchronize()
+        eng.profile_begin(reps // ev, ev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.eval_device(*args, stream=stream.cuda_stream)
+        stream.synchronize()
+        wall = (time.perf_counter() - t0) / reps
+        kern_ms, launch_ms, nprof = eng.profile_end()
+        knots = N * B
+        bytes_knot = algorithmic_bytes_per_knot(int(eng.dims.nnz_knot))
+        gbps = bytes_knot * knots / (kern_ms * 1e-3) / 1e9
+        out[tag] = {"ms_per_launch": kern_ms, "knots_per_s": knots / (kern_ms * 1e-3), "knots_per_launch": knots, "kernel": "hipnlp_knot_kernel",
+                    "kernels_per_step": eng.kernels_per_eval(), "ms_per_step_incl_cost_reduction": launch_ms, "ms_per_step_wall_clock": 1e3 * wall,
+                    "launches_timed": nprof,
+                    "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
+                                 "algorithmic_bytes": bytes_knot * knots, "algorithmic_bytes_per_knot": bytes_knot}}
+        if tag.startswith("periodic") and B == 64:
+            hessian(eng, x, N, B)
+        eng.close()
+
+    def hessian(eng, x, N, B):
+        hn = eng.hess_nnz()
+        with torch.cuda.stream(stream):
+            xd = torch.from_numpy(x).to(dev)
+            ld = torch.from_numpy(np.random.RandomState(0).standard_normal((B, eng.m))).to(dev)
+            sd = torch.ones(B, dtype=torch.float64, device=dev)
+            hv = torch.empty((B, hn), dtype=torch.float64, device=dev)
+        stream.synchronize()
+        args = (xd.data_ptr(), sd.data_ptr(), ld.data_ptr(), hv.data_ptr())
+        for _ in range(40):
+            eng.eval_hess_device(*args, stream=stream.cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 100
+        e0.record(stream)
+        for _ in range(reps):
+            eng.eval_hess_device(*args, stream=stream.cuda_stream)
+        e1.record(stream)
+        stream.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        knots = N * B
+        bytes_knot = 8.0 * (189 + 79 + 274 + hn / N)
+        gbps = bytes_knot * knots / (ms * 1e-3) / 1e9
+        out["hessian_periodic_N%d_B%d" % (N, B)] = {"ms_per_launch": ms, "knots_per_s": knots / (ms * 1e-3), "knots_per_launch": knots, "kernel": "hipnlp_knot_hess_kernel",
+                                                    "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
+                                                                 "algorithmic_bytes": bytes_knot * knots, "algorithmic_bytes_per_knot": bytes_knot}}
+
+    def pose(B):
+        pst = pose_finder_settings(model)
+        x64, p64 = make_pose_workload(pst, model, 64, 11)     # (seeded poses tiled to the batch + N(0, 1e-3^2): the generator walks the tree pose by pose)
+        x = np.tile(x64, (B // 64, 1)) + 1e-3 * np.random.RandomState(12).standard_normal((B, x64.shape[1]))
+        p = np.tile(p64, (B // 64, 1))
+        eng = HipPose(pst, model, batch=B, device=device_index)
+        eng.set_params(p)
+        with torch.cuda.stream(stream):
+            xd = torch.from_numpy(x).to(dev)
+            f = torch.empty(B, dtype=torch.float64, device=dev)
+            grad = torch.empty(B * eng.n, dtype=torch.float64, device=dev)
+            g = torch.empty(B * eng.m, dtype=torch.float64, device=dev)
+            jac = torch.empty(B * eng.nnz, dtype=torch.float64, device=dev)
+        stream.synchronize()
+        args = (xd.data_ptr(), f.data_ptr(), grad.data_ptr(), g.data_ptr(), jac.data_ptr(), stream.cuda_stream)
+        for _ in range(100):
+            eng.eval_device(*args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 200
+        e0.record(stream)
+        for _ in range(reps):
+            eng.eval_device(*args)
+        e1.record(stream)
+        stream.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        bytes_pose = 8.0 * (eng.n + p.shape[1] + eng.m + eng.nnz + eng.n)
+        gbps = bytes_pose * B / (ms * 1e-3) / 1e9
+        out["pose_B%d" % B] = {"ms_per_launch": ms, "poses_per_s": B / (ms * 1e-3), "poses_per_launch": B, "kernel": "hipnlp_pose_kernel",
+                               "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
+                                            "algorithmic_bytes": bytes_pose * B, "algorithmic_bytes_per_pose": bytes_pose}}
+
+    for tag, fn in (("periodic_N100_B64", lambda: callbacks("periodic_N100_B64", periodic_step_settings, 100, 64, 1004)),
+                    ("periodic_N100_B1024", lambda: callbacks("periodic_N100_B1024", periodic_step_settings, 100, 1024, 1004)),
+                    ("stairs_N200_B16", lambda: callbacks("stairs_N200_B16", stairs_settings, 200, 16, 1004, stairs=True)),
+                    ("pose_B4096", lambda: pose(4096))):
+        try:
+            fn()
+        except Exception as err:  # noqa: BLE001  (an extra measurement must not take `value` down with it)
+            out[tag] = {"error": "%s: %s" % (type(err).__name__, err)}
+    out["seconds"] = time.perf_counter() - t_all
+    return out
+
+
+def c_harness_iterate(st, model, x, p, attach=1):
     """builds tests/ipopt_harness/harness.c against the library (gcc) and runs its timing loop in a child process"""
     import ctypes as C
     import struct
@@ -371,7 +562,7 @@ def c_harness_iterate(st, model, x, p):
     subprocess.check_call(["gcc", "-std=c99", "-D_POSIX_C_SOURCE=199309L", "-O2", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "ipopt_harness", "harness.c"), "-L", lib_dir, "-lhipnlp", "-Wl,-rpath," + lib_dir, "-lm", "-o", exe])
     desc = _abi.DescC()
-    desc.settings, desc.model, desc.batch, desc.flags = st.to_c(), model.to_c(), 1, _abi.FLAG_DETECT_SIMPLE_BOUNDS
+    desc.settings, desc.model, desc.batch, desc.flags = st.to_c(), model.to_c(), 1, _abi.FLAG_DETECT_SIMPLE_BOUNDS | _abi.FLAG_JAC_VARYING_FIRST
     rng = np.random.RandomState(3)
     xs = np.stack([x + 1e-3 * i * rng.standard_normal(x.shape) for i in range(5)])
     xs[-1, 130:134] = 0.0   # (the protocol replay ends with a point that evaluates to NaN; the timing loop leaves it out)
@@ -381,7 +572,7 @@ def c_harness_iterate(st, model, x, p):
     m = eng.m
     eng.close()
     with open(src, "wb") as f:
-        f.write(struct.pack("<6i", 0x49504F54, len(blob), p.size, xs.shape[0], 1, 0))
+        f.write(struct.pack("<6i", 0x49504F54, len(blob), p.size, xs.shape[0], int(attach), 0))
         f.write(blob)
         f.write(np.ascontiguousarray(p, np.float64).tobytes())
         f.write(xs.tobytes())
@@ -392,7 +583,7 @@ def c_harness_iterate(st, model, x, p):
         raise RuntimeError(out.stderr.strip())
     t = json.loads(out.stdout.strip().splitlines()[-1])
     return {"ms_per_call": 1e-3 * t["ipopt_iterate_four_c_calls_us"], "trial_point_two_c_calls_ms": 1e-3 * t["trial_point_two_c_calls_us"],
-            "arrays_registered_by_the_handle": t["auto_registered"]}
+            "arrays_registered_by_the_handle": t["auto_registered"], "constant_entries": t["constant_entries"], "constant_fills": t["constant_fills"]}
 
 
 def main():
@@ -826,6 +1017,17 @@ def main():
                                   "traffic_source": "profiles/traffic.json (hess_<workload>_N<N>_B<batch>: rocprofv3 --kernel-trace --stats and --pmc passes of tools/diag/hess_bench.py, one configuration per trace)"}
             except Exception as err:  # noqa: BLE001  (reported, never fatal to the bench line)
                 line["exact_hessian"] = {"error": str(err)}
+        if solo and not args.no_throughput:
+            # the batch launches, in the driver's own run: every roofline figure of DESIGN.md §5 from a fresh box
+            try:
+                line["throughput"] = throughput_block(model, local_rank)
+            except Exception as err:  # noqa: BLE001
+                line["throughput"] = {"error": "%s: %s" % (type(err).__name__, err)}
+        # device work done in the timed region, independent of any utilisation sampler (a 100-knot step keeps the GPU busy for 8 us
+        # between host synchronisations: rocm-smi's busy percentage reads 0): launches = steps x kernels per step
+        line["device_work"] = {"kernel_launches_in_timed_region": args.steps * eng.kernels_per_eval(), "kernels_per_step": eng.kernels_per_eval(),
+                               "evaluations_counted_by_the_handle": eng.host_stats()["evaluations"],
+                               "knot_evaluations_in_timed_region": main_res["local_knots"] * args.steps}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(st, model, main_res["x_np"][0], main_res["p_np"][0])
             cb["gpu_over_cpu"] = {"device_resident_vs_1_thread": line["value"] / cb["value"],
@@ -836,6 +1038,9 @@ def main():
                 hv = line["host_visible"]
                 for tag, key in (("host_visible_all", "all"), ("host_visible_all_registered", "all (caller arrays registered: direct kernel stores)"),
                                  ("host_visible_all_auto_registration_off", "all (auto-registration off: pinned block + host copy)"),
+                                 ("host_visible_all_varying_first_constants_stored_every_call", "all (varying-first order, constant entries stored on every call)"),
+                                 ("host_visible_all_varying_first", "all (varying-first order of a knot's jac block)"),
+                                 ("link_floor_for_the_bytes_actually_moved", "link floor for the bytes actually moved (f, grad f, g and the varying entries of jac g)"),
                                  ("host_visible_f", "f"),
                                  ("link_floor_copy_of_the_same_bytes", "link floor: one D2H copy of the same bytes into pinned memory + wait (no kernel)")):
                     if key in hv:

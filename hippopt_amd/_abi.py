@@ -5,6 +5,7 @@ NJ, NL, NC, NXK, NPK, NXG, NPG = 23, 24, 8, 189, 79, 6, 326
 NCOST_TERMS = 12
 ABI_VERSION = 2
 FLAG_DETECT_SIMPLE_BOUNDS = 1
+FLAG_JAC_VARYING_FIRST = 2
 
 EXPR_SKIP, EXPR_SUBJECT_TO, EXPR_MINIMIZE = 0, 1, 2
 TERRAIN_PLANAR, TERRAIN_SMOOTH_STEPS, MAX_TERRAIN_STEPS = 0, 1, 4

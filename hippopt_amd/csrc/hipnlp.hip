@@ -761,6 +761,17 @@ __global__ __launch_bounds__(256) void hipnlp_reassemble_kernel(const double* ga
     }
 }
 
+// Host path, Jacobian asked for after its evaluation (IPOPT's eval_jac_g with new_x = FALSE): the varying run of every knot block from
+// the complete values in HBM into a device-visible HOST array that already holds the constant entries (varying-first order of a block,
+// HIPNLP_FLAG_JAC_VARYING_FIRST).  One workgroup per knot; consecutive lanes, consecutive addresses on the link.
+__global__ __launch_bounds__(256) void hipnlp_fetch_vary_kernel(const double* __restrict__ src, double* __restrict__ dst, int kb, int N, int64_t nnz, int nnz_first,
+                                                                 int nnz_interior, int nv_first, int nv_interior, int nv_last) {
+    const int k = kb + int(blockIdx.x);
+    const int64_t base = int64_t(blockIdx.y) * nnz + (k == 0 ? 0 : int64_t(nnz_first) + int64_t(k - 1) * nnz_interior);
+    const int count = k == 0 ? nv_first : (k == N - 1 ? nv_last : nv_interior);
+    for (int i = threadIdx.x; i < count; i += 256) dst[base + i] = src[base + i];
+}
+
 thread_local std::string g_create_error;
 
 // host ranges registered through hipnlp_host_register: a caller-owned output array inside one of them is stored to DIRECTLY by the
@@ -828,9 +839,30 @@ struct hipnlp_handle {
     // with a sentinel (below), at most AUTO_MAX ranges per handle, unregistered by hipnlp_destroy
     bool auto_reg = true;
     const void* last_seen[4] = {nullptr, nullptr, nullptr, nullptr};   // grad, g, jac (hipnlp_eval) and Hessian-value (hipnlp_eval_hess) pointers of the previous call (second sight registers)
+    const void* in_call[4] = {nullptr, nullptr, nullptr, nullptr};     // output arrays of the call in progress (never evicted by it)
     const void* no_auto[4] = {nullptr, nullptr, nullptr, nullptr};     // pointers that failed to register or failed the sentinel check: left alone
     unsigned long long sentinel_salt = 0;
     long auto_registered = 0, auto_fallbacks = 0;
+    // Constant entries of jac g (Layout::jconst_pos; 43 % of the pattern at N = 100: the +-1, -dt/2, mass entries of the linear rows).
+    // In the varying-first order of a knot's block (HIPNLP_FLAG_JAC_VARYING_FIRST) a host destination of the Jacobian is FILLED with
+    // them once per parameter set — the pinned block and a registered caller array at their first use — and the kernel then stores
+    // the entries that depend on x only (d_tb_vary: the same tables with -1 at the constant positions of the copy-out permutation):
+    // a third fewer bytes on the PCIe-bound path, one contiguous run per knot.  Caller arrays are spot-checked before every such
+    // launch (csample) and re-filled when a check fails or the parameters changed.
+    DeviceTables* d_tb_vary = nullptr;
+    bool skip_const = true;                         // hipnlp_set_constant_jacobian
+    unsigned long long param_gen = 0;               // hipnlp_set_params calls so far
+    std::vector<std::vector<double>> ctpl;          // distinct templates [block of VAR_FIRST | VAR_INTERIOR | VAR_LAST | horizon-global]: the constant values at their positions
+    std::vector<int> ctpl_of_b;                     // template of trajectory b
+    std::vector<int32_t> cpos[3];                   // constant positions of a variant-v block
+    int ctpl_off[4] = {0, 0, 0, 0};
+    struct ConstFilled { const void* host; unsigned long long gen; };
+    ConstFilled cfilled[8] = {};                    // caller arrays that hold this handle's constants, and of which parameter set
+    int cfilled_next = 0;
+    unsigned long long pinned_const_gen = 0;        // parameter set whose constants the pinned block holds (0: none)
+    std::vector<std::pair<size_t, double>> csample; // (index into [batch][nnz], value): the spot check
+    size_t jac_first_vary = 0, jac_last_vary = 0;   // first / last entry of [batch][nnz] that depends on x (sentinel words of a store that skips the constants)
+    long const_fills = 0, const_refills = 0;
     bool time_host = false;       // bracket host-path launches with events (hipnlp_set_host_timing)
     double host_us[4] = {0, 0, 0, 0};   // wall clock of the last host-path evaluation: x staging, enqueue, wait for the GPU, copies out
     std::vector<double> p;
@@ -860,7 +892,7 @@ static void free_all(hipnlp_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* dptrs[] = {h->d_tb, h->d_x, h->d_pk, h->d_cost_knot, h->d_gp, h->d_cost_pub, h->d_out, h->d_ht, h->d_sigma, h->d_hess, h->d_hflag};
+    void* dptrs[] = {h->d_tb, h->d_tb_vary, h->d_x, h->d_pk, h->d_cost_knot, h->d_gp, h->d_cost_pub, h->d_out, h->d_ht, h->d_sigma, h->d_hess, h->d_hflag};
     for (void* q : dptrs) if (q) (void)hipFree(q);
     void* hptrs[] = {h->h_x, h->h_out, h->h_hess, h->h_hflag, h->h_sl};
     for (void* q : hptrs) if (q) (void)hipHostFree(q);
@@ -874,6 +906,10 @@ static void free_all(hipnlp_handle* h) {
 extern "C" {
 
 static void auto_unregister_all(hipnlp_handle* h);
+static void constants_prepare(hipnlp_handle* h, const std::vector<GParams>& gp);
+static void constants_fill(const hipnlp_handle* h, double* jac);
+static void constants_ensure(hipnlp_handle* h, double* jac_host);
+static int drop_stale_range(hipnlp_handle* h, void* p);
 static bool auto_owns(const hipnlp_handle* h, const void* p);
 static double* caller_array_address(hipnlp_handle* h, int q, double* p, size_t bytes);
 
@@ -896,7 +932,7 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     if (desc->abi_version != HIPNLP_ABI_VERSION)
         return fail(HIPNLP_E_INVALID, "hipnlp_desc.abi_version is " + std::to_string(desc->abi_version) + ", this library implements HIPNLP_ABI_VERSION " +
                                           std::to_string(HIPNLP_ABI_VERSION) + " (the caller was built against another include/hipnlp.h, or left the field unset)");
-    if (desc->flags & ~HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS) return fail(HIPNLP_E_INVALID, "unknown bits in hipnlp_desc.flags");
+    if (desc->flags & ~(HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS | HIPNLP_FLAG_JAC_VARYING_FIRST)) return fail(HIPNLP_E_INVALID, "unknown bits in hipnlp_desc.flags");
     if (st.horizon < 2) return fail(HIPNLP_E_INVALID, "settings.horizon must be >= 2");
     if (const char* te = Layout::check_terrain(st.terrain, st.n_terrain_steps, st.terrain_steps)) return fail(HIPNLP_E_INVALID, te);
     if (desc->batch < 1) return fail(HIPNLP_E_INVALID, "batch must be >= 1");
@@ -925,7 +961,9 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     }
     std::string e;
     if (!Layout::make_kin_tables(desc->model, h->kt, e)) return fail(HIPNLP_E_INVALID, e);
-    if (!h->L.build(st, h->kt, (desc->flags & HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS) != 0)) return fail(HIPNLP_E_INVALID, h->L.error);
+    if (!h->L.build(st, h->kt, (desc->flags & HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS) != 0, (desc->flags & HIPNLP_FLAG_JAC_VARYING_FIRST) != 0))
+        return fail(HIPNLP_E_INVALID, h->L.error);
+    if (const char* cj = std::getenv("HIPNLP_CONST_JAC")) h->skip_const = std::atoi(cj) != 0;   // diagnostic override of hipnlp_set_constant_jacobian's default
     h->np = ParamOffsets(st.horizon).np();
     if (h->L.jperm_glob.size() > 16) return fail(HIPNLP_E_INVALID, "internal: too many global-column entries");
 
@@ -1011,8 +1049,39 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     for (int i = 0; i < tb->n_glob; ++i) tb->jperm_glob[i] = h->L.jperm_glob[size_t(i)];
     tb->jac_glob_base = h->L.jac_glob_base;
     hipError_t ce = hipMemcpy(h->d_tb, tb, sizeof(DeviceTables), hipMemcpyHostToDevice);
+    if (ce == hipSuccess) {
+        // the tables of a launch that leaves the constant entries of jac g alone: no slot behind their positions, no horizon-global entries
+        const int wg = h->wide ? 512 : 256, jt = JS_PAD / wg;
+        for (int v = 0; v < 3; ++v) {
+            h->cpos[v].clear();
+            for (size_t i = 0; i < h->L.jconst_pos[v].size(); ++i)
+                if (h->L.jconst_pos[v][i]) {
+                    h->cpos[v].push_back(int32_t(i));
+                    tb->jperm[v][i] = -1;
+                    tb->jperm_t[v][(int(i) % wg) * jt + int(i) / wg] = -1;
+                }
+        }
+        tb->n_glob = 0;
+        ce = hipMalloc(&h->d_tb_vary, sizeof(DeviceTables));
+        if (ce == hipSuccess) ce = hipMemcpy(h->d_tb_vary, tb, sizeof(DeviceTables), hipMemcpyHostToDevice);
+    }
     delete tb;
     if (ce != hipSuccess) return fail(HIPNLP_E_NODEVICE, std::string("hipMemcpy tables: ") + hipGetErrorString(ce));
+    {
+        // first / last entry of [batch][nnz] that depends on x (where a store that skips the constants leaves its sentinel words)
+        const Layout& L = h->L;
+        h->jac_first_vary = h->jac_last_vary = 0;
+        bool found = false;
+        for (int k = h->kb; k < h->ke && !found; ++k) {
+            const int v = L.variant_of(k);
+            for (size_t i = 0; i < L.jconst_pos[v].size(); ++i) if (!L.jconst_pos[v][i]) { h->jac_first_vary = size_t(L.jac_base(k)) + i; found = true; break; }
+        }
+        found = false;
+        for (int k = h->ke - 1; k >= h->kb && !found; --k) {
+            const int v = L.variant_of(k);
+            for (size_t i = L.jconst_pos[v].size(); i-- > 0;) if (!L.jconst_pos[v][i]) { h->jac_last_vary = (B - 1) * nnz + size_t(L.jac_base(k)) + i; found = true; break; }
+        }
+    }
 #undef CREATE_TRY
     *out = h;
     return HIPNLP_OK;
@@ -1049,6 +1118,85 @@ int hipnlp_get_dims(const hipnlp_handle* h, hipnlp_dims* o) {
     return HIPNLP_OK;
 }
 
+// ---- the constant entries of jac g ---------------------------------------------------------------------------------------------------
+// Their values under the parameters just set: one pass of the knot program on the host per DISTINCT GParamsLite of the batch (dt and
+// the mass are what the constants hold; trajectories of a batch usually share them), kept as templates by block variant.
+static void constants_prepare(hipnlp_handle* h, const std::vector<GParams>& gp) {
+    const Layout& L = h->L;
+    h->param_gen++;
+    h->ctpl.clear();
+    h->ctpl_of_b.assign(size_t(h->batch), 0);
+    h->ctpl_off[0] = 0;
+    for (int v = 0; v < 3; ++v) h->ctpl_off[v + 1] = h->ctpl_off[v] + L.nnz_v[v];
+    std::vector<size_t> rep;   // trajectory each template was computed from
+    std::vector<double> cval(js::COUNT);
+    for (size_t b = 0; b < size_t(h->batch); ++b) {
+        int found = -1;
+        for (size_t t = 0; t < rep.size() && found < 0; ++t)
+            if (std::memcmp(static_cast<const GParamsLite*>(&gp[rep[t]]), static_cast<const GParamsLite*>(&gp[b]), sizeof(GParamsLite)) == 0) found = int(t);
+        if (found < 0) {
+            Layout::constant_values(h->d.settings, h->kt, gp[b], cval.data());
+            std::vector<double> t(size_t(h->ctpl_off[3]) + L.jperm_glob.size(), 0.0);
+            for (int v = 0; v < 3; ++v)
+                for (int32_t i : h->cpos[v]) t[size_t(h->ctpl_off[v] + i)] = cval[size_t(L.jperm[v][size_t(i)])];
+            for (size_t i = 0; i < L.jperm_glob.size(); ++i) t[size_t(h->ctpl_off[3]) + i] = cval[size_t(L.jperm_glob[i])];
+            found = int(h->ctpl.size());
+            h->ctpl.push_back(std::move(t));
+            rep.push_back(b);
+        }
+        h->ctpl_of_b[b] = found;
+    }
+    // the spot check of a caller array: the first and the last constant entry of the handle's knots and a few in between
+    h->csample.clear();
+    if (L.nconst_total > 0) {
+        const size_t nnz = size_t(L.nnz);
+        auto add = [&](size_t b, int k, size_t j) {
+            const int v = L.variant_of(k);
+            if (h->cpos[v].empty()) return;
+            const int32_t i = h->cpos[v][j % h->cpos[v].size()];
+            h->csample.push_back({b * nnz + size_t(L.jac_base(k)) + size_t(i), h->ctpl[size_t(h->ctpl_of_b[b])][size_t(h->ctpl_off[v] + i)]});
+        };
+        const size_t B = size_t(h->batch);
+        add(0, h->kb, 0);
+        for (int q = 1; q <= 14; ++q) add((B * size_t(q)) / 16, h->kb + int((long(h->nk) * q) / 16), size_t(37 * q));
+        add(B - 1, h->ke - 1, h->cpos[L.variant_of(h->ke - 1)].empty() ? 0 : h->cpos[L.variant_of(h->ke - 1)].size() - 1);
+    }
+    // (the pinned block, the library's own, is filled when a launch that skips the constants first stores into it: host_evaluate)
+}
+// the constant entries of this handle's knots into a host array jac [batch][nnz]
+static void constants_fill(const hipnlp_handle* h, double* jac) {
+    const Layout& L = h->L;
+    const size_t nnz = size_t(L.nnz);
+    for (size_t b = 0; b < size_t(h->batch); ++b) {
+        const std::vector<double>& t = h->ctpl[size_t(h->ctpl_of_b[b])];
+        double* out = jac + b * nnz;
+        for (int k = h->kb; k < h->ke; ++k) {
+            const int v = L.variant_of(k);
+            double* blk = out + L.jac_base(k);
+            const double* tv = t.data() + h->ctpl_off[v];
+            if (L.vary_first) std::memcpy(blk + L.nvary_v[v], tv + L.nvary_v[v], size_t(L.nnz_v[v] - L.nvary_v[v]) * sizeof(double));   // (one run behind the varying entries)
+            else for (int32_t i : h->cpos[v]) blk[i] = tv[i];
+        }
+        if (h->ke == L.N) for (size_t i = 0; i < L.jperm_glob.size(); ++i) out[size_t(L.jac_glob_base) + i] = t[size_t(h->ctpl_off[3]) + i];
+    }
+}
+// A host destination of the Jacobian that is not the library's own, about to receive a store that skips the constants: they must be
+// in place.  Known array of the current parameter set: spot check (a caller that wrote over its array gets it re-filled); anything
+// else: filled now.
+static void constants_ensure(hipnlp_handle* h, double* jac_host) {
+    int slot = -1;
+    for (int i = 0; i < 8; ++i) if (h->cfilled[i].host == jac_host) slot = i;
+    bool ok = slot >= 0 && h->cfilled[slot].gen == h->param_gen;
+    if (ok)
+        for (const auto& sv : h->csample)
+            if (std::memcmp(&jac_host[sv.first], &sv.second, sizeof(double)) != 0) { ok = false; h->const_refills++; break; }
+    if (ok) return;
+    constants_fill(h, jac_host);
+    h->const_fills++;
+    if (slot < 0) { slot = h->cfilled_next; h->cfilled_next = (h->cfilled_next + 1) % 8; }
+    h->cfilled[slot] = {jac_host, h->param_gen};
+}
+
 int hipnlp_set_params(hipnlp_handle* h, const double* p) {
     if (!h || !p) return HIPNLP_E_INVALID;
     HIP_TRY(h, hipSetDevice(h->dev));
@@ -1062,6 +1210,7 @@ int hipnlp_set_params(hipnlp_handle* h, const double* p) {
     HIP_TRY(h, hipMemcpy(h->d_gp, gp.data(), gp.size() * sizeof(GParams), hipMemcpyHostToDevice));
     h->params_set = true;
     h->have_result = false;
+    constants_prepare(h, gp);
     return HIPNLP_OK;
 }
 
@@ -1103,10 +1252,11 @@ int hipnlp_sparsity(const hipnlp_handle* h, int32_t* irow, int32_t* jcol) {
 // the launches an armed profile selects (every stride-th launch), so that measuring does not change what is measured.
 static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, hipStream_t s,
                   double* g_stage = nullptr, bool shard_local = false, bool always_timed = false, bool host_block = false,
-                  double* const* peer_out = nullptr, int npeer = 0, int peer_rank = 0) {
+                  double* const* peer_out = nullptr, int npeer = 0, int peer_rank = 0, bool vary_only = false) {
+    // vary_only: the constant entries of jac g are already at jac_dev (constants_ensure): the copy-out leaves them alone
     KArgs a;
     a.peer_out = peer_out; a.npeer = npeer; a.peer_rank = peer_rank;
-    a.tb = h->d_tb; a.x = x_dev; a.pk = h->d_pk; a.gp = h->d_gp;
+    a.tb = vary_only ? h->d_tb_vary : h->d_tb; a.x = x_dev; a.pk = h->d_pk; a.gp = h->d_gp;
     a.g = g_dev; a.jac = jac_dev; a.grad = grad_dev; a.g_stage = g_stage;
     if (shard_local) {
         hipnlp_dims dd;
@@ -1308,7 +1458,9 @@ int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor
     // consecutive sight (IPOPT evaluates the Hessian into the value array of its own matrix); a store into an array the handle
     // registered is verified with the sentinel words of the callback path, and served through the pinned block if it did not arrive
     const size_t hbytes = B * hn * sizeof(double);
+    h->in_call[0] = h->in_call[1] = h->in_call[2] = nullptr; h->in_call[3] = hess;
     double* direct = caller_array_address(h, 3, hess, hbytes);
+    h->in_call[3] = nullptr;
     u64 sentinel = 0;
     if (direct && auto_owns(h, hess)) {
         sentinel = 0x7FF8C0DE00000000ull | (++h->sentinel_salt & 0xFFFFFFFFull);
@@ -1322,7 +1474,7 @@ int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor
     if (sentinel) {
         const u64* w = reinterpret_cast<const u64*>(hess);
         if (__atomic_load_n(&w[0], __ATOMIC_RELAXED) == sentinel || __atomic_load_n(&w[hbytes / 8 - 1], __ATOMIC_RELAXED) == sentinel) {
-            (void)hipnlp_host_unregister(hess);
+            (void)drop_stale_range(h, hess);
             h->no_auto[3] = hess;
             h->auto_fallbacks++;
             rc = hess_launch(h, xsrc, h->d_sigma, h->d_lambda, h->hd_hess, h->stream, true);
@@ -1390,10 +1542,45 @@ static size_t auto_count(const hipnlp_handle* h, char** oldest = nullptr) {
     for (const HostRange& r : g_ranges) if (r.owner == h) { if (n == 0 && oldest) *oldest = r.host; ++n; }
     return n;
 }
-static bool auto_owns(const hipnlp_handle* h, const void* p) {
+// Is p inside a range that SOME handle registered by itself?  Such a mapping may have gone stale behind the library's back (the array
+// freed, its address reused), whichever handle uses it and wherever in the range p lies: every direct store into it is verified.
+// (The table is process wide: a second handle, or a pointer into the middle of a range, finds the same device address.)
+static bool auto_owns(const hipnlp_handle*, const void* p) {
     std::lock_guard<std::mutex> lock(g_ranges_mutex);
-    for (const HostRange& r : g_ranges) if (r.host == p && r.owner == h) return true;
+    const char* q = static_cast<const char*>(p);
+    for (const HostRange& r : g_ranges) if (r.owner != nullptr && q >= r.host && q < r.host + r.bytes) return true;
     return false;
+}
+// start of the registered range that contains p (what hipnlp_host_unregister wants), or null
+static void* range_base_of(const void* p) {
+    std::lock_guard<std::mutex> lock(g_ranges_mutex);
+    const char* q = static_cast<const char*>(p);
+    for (const HostRange& r : g_ranges) if (q >= r.host && q < r.host + r.bytes) return r.host;
+    return nullptr;
+}
+// a range is gone (stale mapping, eviction): nothing of the handle may point into it any more
+static void forget_range(hipnlp_handle* h, const char* base, size_t bytes) {
+    for (int q = 0; q < 3; ++q) {
+        const char* sh = reinterpret_cast<const char*>(h->seen_host[q]);
+        if (sh && sh >= base && sh < base + bytes) h->seen_host[q] = nullptr;
+        const char* eh = reinterpret_cast<const char*>(h->early_host[q]);
+        if (eh && eh >= base && eh < base + bytes) { h->early_host[q] = nullptr; h->early_mask &= ~(q == 0 ? HIPNLP_WANT_GRAD : (q == 1 ? HIPNLP_WANT_G : HIPNLP_WANT_JAC)); }
+    }
+    for (int i = 0; i < 8; ++i) {
+        const char* c = static_cast<const char*>(h->cfilled[i].host);
+        if (c && c >= base && c < base + bytes) h->cfilled[i] = {nullptr, 0};
+    }
+}
+static int drop_stale_range(hipnlp_handle* h, void* p) {
+    void* base = range_base_of(p);
+    if (!base) return HIPNLP_E_INVALID;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_ranges_mutex);
+        for (const HostRange& r : g_ranges) if (r.host == base) bytes = r.bytes;
+    }
+    forget_range(h, static_cast<const char*>(base), bytes);
+    return hipnlp_host_unregister(base);
 }
 constexpr size_t AUTO_MIN_BYTES = 64 * 1024;   // smaller arrays are cheaper to copy than to page-lock
 constexpr size_t AUTO_MAX = 6;
@@ -1402,8 +1589,27 @@ static double* caller_array_address(hipnlp_handle* h, int q, double* p, size_t b
     if (!p) return nullptr;   // (IPOPT passes one array per callback: "consecutive" means consecutive calls that pass this output)
     double* dev = device_address_of(p, bytes);
     if (!dev && h->auto_reg && bytes >= AUTO_MIN_BYTES && h->last_seen[q] == p && h->no_auto[q] != p) {
-        char* oldest = nullptr;
-        if (auto_count(h, &oldest) >= AUTO_MAX) (void)hipnlp_host_unregister(oldest);
+        if (auto_count(h) >= AUTO_MAX) {
+            // the oldest range of this handle that THIS call does not use goes (a range whose device address the call has already
+            // taken — grad before g before jac — must outlive the launch)
+            char* victim = nullptr;
+            size_t vbytes = 0;
+            {
+                std::lock_guard<std::mutex> lock(g_ranges_mutex);
+                for (const HostRange& r : g_ranges) {
+                    if (r.owner != h) continue;
+                    bool used = false;
+                    for (int i = 0; i < 4; ++i) {
+                        const char* c = static_cast<const char*>(h->in_call[i]);
+                        used |= c && c >= r.host && c < r.host + r.bytes;
+                    }
+                    if (!used) { victim = r.host; vbytes = r.bytes; break; }
+                }
+            }
+            if (!victim) { h->last_seen[q] = p; return nullptr; }   // (every range is in use by this call: the array goes through the pinned block)
+            forget_range(h, victim, vbytes);
+            (void)hipnlp_host_unregister(victim);
+        }
         void* d = nullptr;
         if (hipnlp_host_register(p, bytes, &d) == HIPNLP_OK) {
             // (diagnostic, tests only: HIPNLP_DEBUG_MISDIRECT_AUTO maps the array to the pinned block's copy of the output instead —
@@ -1473,14 +1679,28 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
         // arrays this handle registered by itself are verified at every use: a word of the call's own is written into the first and
         // the last entry; the kernel overwrites both (every entry of every output is written by every evaluation) — unless the mapping
         // went stale (the caller freed the array and the address now belongs to other pages): then the words are still there
+        // The Jacobian into a HOST destination: its constant entries (43 % of them at 100 knots) are put there once — the pinned block
+        // here, a caller array at its first use, spot-checked at every later one — and the launch stores the entries that depend on x only.
+        // (Only in the varying-first order of a block, where the varying entries are ONE run per knot: skipping the constants of a
+        //  CCS-ordered block leaves fragments of one to four doubles on the link — measured SLOWER than storing everything, 59.7
+        //  against 55.0 us per 100-knot call, profiles/r04_host_path.txt.)
+        bool vary_only = false;
+        if (h->skip_const && h->L.vary_first && h->L.nconst_total > 0 && sel[2] != 0u) {
+            if (sel[2] == 1u) {
+                if (h->pinned_const_gen != h->param_gen) { constants_fill(h, h->h_jac); h->pinned_const_gen = h->param_gen; }
+            } else constants_ensure(h, caller_host[2]);
+            vary_only = true;
+        }
         u64 sentinel = 0;
         bool checked[3] = {false, false, false};
+        size_t w_first[3] = {0, 0, 0}, w_last[3] = {bytes[0] / 8 - 1, bytes[1] / 8 - 1, bytes[2] / 8 - 1};
+        if (vary_only) { w_first[2] = h->jac_first_vary; w_last[2] = h->jac_last_vary; }   // (words the launch does write)
         for (int q = 0; q < 3; ++q)
             if (sel[q] == 2u && auto_owns(h, caller_host[q])) {
                 if (!sentinel) sentinel = 0x7FF8C0DE00000000ull | (++h->sentinel_salt & 0xFFFFFFFFull);   // (a quiet NaN no evaluation produces)
                 u64* w = reinterpret_cast<u64*>(caller_host[q]);
-                __atomic_store_n(&w[0], sentinel, __ATOMIC_RELAXED);
-                __atomic_store_n(&w[bytes[q] / 8 - 1], sentinel, __ATOMIC_RELAXED);
+                __atomic_store_n(&w[w_first[q]], sentinel, __ATOMIC_RELAXED);
+                __atomic_store_n(&w[w_last[q]], sentinel, __ATOMIC_RELAXED);
                 checked[q] = true;
             }
         const bool f_host = (to_host & HIPNLP_WANT_F) != 0;
@@ -1496,7 +1716,7 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
             double* const hbm[3] = {h->d_grad, h->d_g, h->d_jac};
             double* o[3];
             for (int q = 0; q < 3; ++q) o[q] = sel[q] == 2u ? caller_dev[q] : (sel[q] == 1u ? pinned[q] : hbm[q]);
-            rc = launch(h, xsrc, f_host ? h->hd_f : h->d_f, o[0], o[1], o[2], h->stream, nullptr, false, h->time_host, true);
+            rc = launch(h, xsrc, f_host ? h->hd_f : h->d_f, o[0], o[1], o[2], h->stream, nullptr, false, h->time_host, true, nullptr, 0, 0, vary_only);
             if (rc != HIPNLP_OK) return rc;
             t2 = std::chrono::steady_clock::now();
             HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1510,8 +1730,8 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
         for (int q = 0; q < 3; ++q)
             if (checked[q]) {
                 const u64* w = reinterpret_cast<const u64*>(caller_host[q]);
-                if (__atomic_load_n(&w[0], __ATOMIC_RELAXED) == sentinel || __atomic_load_n(&w[bytes[q] / 8 - 1], __ATOMIC_RELAXED) == sentinel) {
-                    (void)hipnlp_host_unregister(caller_host[q]);
+                if (__atomic_load_n(&w[w_first[q]], __ATOMIC_RELAXED) == sentinel || __atomic_load_n(&w[w_last[q]], __ATOMIC_RELAXED) == sentinel) {
+                    (void)drop_stale_range(h, caller_host[q]);
                     h->no_auto[q] = caller_host[q];
                     if (h->seen_host[q] == caller_host[q]) h->seen_host[q] = nullptr;
                     h->auto_fallbacks++;
@@ -1542,23 +1762,55 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
         h->have_result = false;
         return host_evaluate(h, h->h_x, 1, want, dst, direct);
     }
-    if (missing) {   // still in HBM: one copy each — straight into the caller's array when that is registered (page-locked), else into the pinned block
+    if (missing) {
+        // Still in HBM: one transfer each — straight into the caller's array when that is registered (page-locked), else into the
+        // pinned block.  The Jacobian into a registered array whose blocks list the varying entries first: a small kernel stores the
+        // varying run of every knot block (the constants are in place: constants_ensure), 628 KB instead of 1.1 MB at 100 knots.
+        // A copy into an array some handle registered by itself is verified with the sentinel words, like the direct stores of a new
+        // evaluation: a stale mapping is dropped and the output served through the pinned block.
         HIP_TRY(h, hipSetDevice(h->dev));
         unsigned to_caller = 0;
         if (missing & HIPNLP_WANT_F) HIP_TRY(h, hipMemcpyAsync(h->h_f, h->d_f, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        if (missing & HIPNLP_WANT_GRAD) {
-            if (dst.grad_host) to_caller |= HIPNLP_WANT_GRAD;
-            HIP_TRY(h, hipMemcpyAsync(dst.grad_host ? dst.grad_host : h->h_grad, h->d_grad, B * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        }
-        if (missing & HIPNLP_WANT_G) {
-            if (dst.g_host) to_caller |= HIPNLP_WANT_G;
-            HIP_TRY(h, hipMemcpyAsync(dst.g_host ? dst.g_host : h->h_g, h->d_g, B * m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        }
-        if (missing & HIPNLP_WANT_JAC) {
-            if (dst.jac_host) to_caller |= HIPNLP_WANT_JAC;
-            HIP_TRY(h, hipMemcpyAsync(dst.jac_host ? dst.jac_host : h->h_jac, h->d_jac, B * nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        double* const caller[3] = {dst.grad_host, dst.g_host, dst.jac_host};
+        double* const caller_dev[3] = {dst.grad, dst.g, dst.jac};
+        double* const pinned[3] = {h->h_grad, h->h_g, h->h_jac};
+        const double* const hbm[3] = {h->d_grad, h->d_g, h->d_jac};
+        u64 sentinel = 0;
+        bool checked[3] = {false, false, false};
+        size_t w_first[3] = {0, 0, 0}, w_last[3] = {bytes[0] / 8 - 1, bytes[1] / 8 - 1, bytes[2] / 8 - 1};
+        for (int q = 0; q < 3; ++q) {
+            if (!(missing & bit[q])) continue;
+            const bool vary_run = q == 2 && caller[q] && caller_dev[q] && h->skip_const && h->L.vary_first && h->L.nconst_total > 0;
+            if (vary_run) { constants_ensure(h, caller[q]); w_first[q] = h->jac_first_vary; w_last[q] = h->jac_last_vary; }
+            if (caller[q]) {
+                to_caller |= bit[q];
+                if (auto_owns(h, caller[q])) {
+                    if (!sentinel) sentinel = 0x7FF8C0DE00000000ull | (++h->sentinel_salt & 0xFFFFFFFFull);
+                    u64* w = reinterpret_cast<u64*>(caller[q]);
+                    __atomic_store_n(&w[w_first[q]], sentinel, __ATOMIC_RELAXED);
+                    __atomic_store_n(&w[w_last[q]], sentinel, __ATOMIC_RELAXED);
+                    checked[q] = true;
+                }
+            }
+            if (vary_run) {
+                const Layout& L = h->L;
+                hipLaunchKernelGGL(hipnlp_fetch_vary_kernel, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(256), 0, h->stream, hbm[q], caller_dev[q], h->kb, L.N,
+                                   int64_t(L.nnz), L.nnz_v[VAR_FIRST], L.nnz_v[VAR_INTERIOR], L.nvary_v[VAR_FIRST], L.nvary_v[VAR_INTERIOR], L.nvary_v[VAR_LAST]);
+                HIP_TRY(h, hipGetLastError());
+            } else HIP_TRY(h, hipMemcpyAsync(caller[q] ? caller[q] : pinned[q], hbm[q], bytes[q], hipMemcpyDeviceToHost, h->stream));
         }
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (int q = 0; q < 3; ++q)
+            if (checked[q]) {
+                const u64* w = reinterpret_cast<const u64*>(caller[q]);
+                if (__atomic_load_n(&w[w_first[q]], __ATOMIC_RELAXED) == sentinel || __atomic_load_n(&w[w_last[q]], __ATOMIC_RELAXED) == sentinel) {
+                    (void)drop_stale_range(h, caller[q]);
+                    h->no_auto[q] = caller[q];
+                    h->auto_fallbacks++;
+                    HIP_TRY(h, hipMemcpy(pinned[q], hbm[q], bytes[q], hipMemcpyDeviceToHost));
+                    to_caller &= ~bit[q];   // (hipnlp_eval copies it out of the pinned block)
+                }
+            }
         h->on_host |= missing & ~to_caller;   // (an output copied into a caller array stays in HBM: a later request copies again)
         if (direct) *direct |= to_caller;
     }
@@ -1576,6 +1828,7 @@ int hipnlp_eval(hipnlp_handle* h, const double* x, int new_x, double* f, double*
     const size_t B = size_t(h->batch), n = size_t(h->L.n), m = size_t(h->L.m), nnz = size_t(h->L.nnz);
     const unsigned want = (f ? HIPNLP_WANT_F : 0u) | (grad_f ? HIPNLP_WANT_GRAD : 0u) | (g ? HIPNLP_WANT_G : 0u) | (jac ? HIPNLP_WANT_JAC : 0u);
     HostDest dst;   // caller arrays inside a registered range (hipnlp_host_register, or registered by the handle itself): direct kernel outputs
+    h->in_call[0] = grad_f; h->in_call[1] = g; h->in_call[2] = jac; h->in_call[3] = nullptr;
     dst.grad = caller_array_address(h, 0, grad_f, B * n * sizeof(double));
     dst.g = caller_array_address(h, 1, g, B * m * sizeof(double));
     dst.jac = caller_array_address(h, 2, jac, B * nnz * sizeof(double));
@@ -1584,6 +1837,7 @@ int hipnlp_eval(hipnlp_handle* h, const double* x, int new_x, double* f, double*
     dst.jac_host = dst.jac ? jac : nullptr;
     unsigned direct = 0;
     const int rc = host_evaluate(h, x, new_x, want, dst, &direct);
+    h->in_call[0] = h->in_call[1] = h->in_call[2] = nullptr;
     if (rc != HIPNLP_OK) return rc;
     // (looked up again: the evaluation may have dropped an array whose mapping had gone stale)
     if (dst.grad_host && device_address_of(grad_f, B * n * sizeof(double))) h->seen_host[0] = dst.grad_host;
@@ -1624,7 +1878,7 @@ int hipnlp_set_auto_register(hipnlp_handle* h, int on) {
 int hipnlp_host_stats(const hipnlp_handle* h, long* out /*[8]*/) {
     if (!h || !out) return HIPNLP_E_INVALID;
     out[0] = h->auto_registered; out[1] = h->auto_fallbacks; out[2] = long(auto_count(h));
-    out[3] = long(h->seq); out[4] = out[5] = out[6] = out[7] = 0;
+    out[3] = long(h->seq); out[4] = h->const_fills; out[5] = h->const_refills; out[6] = long(h->L.nconst_total); out[7] = 0;
     return HIPNLP_OK;
 }
 
@@ -1633,6 +1887,17 @@ int hipnlp_set_early_outputs(hipnlp_handle* h, int on) {
     h->early = on != 0;
     h->early_grad = on == 2;   // grad f only on explicit request: IPOPT's adapter hands eval_grad_f the storage of ITS OWN gradient vector
     if (!h->early) { h->early_mask = 0; }
+    return HIPNLP_OK;
+}
+
+int hipnlp_set_constant_jacobian(hipnlp_handle* h, int on) {
+    if (!h) return HIPNLP_E_INVALID;
+    h->skip_const = on != 0;
+    return HIPNLP_OK;
+}
+int hipnlp_jac_constant_mask(const hipnlp_handle* h, unsigned char* mask) {
+    if (!h || !mask) return HIPNLP_E_INVALID;
+    h->L.constant_mask(mask);
     return HIPNLP_OK;
 }
 
@@ -1656,10 +1921,18 @@ int hipnlp_set_host_timing(hipnlp_handle* h, int on) {
 
 int hipnlp_host_register(void* p, size_t bytes, void** dev_ptr) {
     if (!p || !bytes) return HIPNLP_E_INVALID;
-    {   // an array a handle registered by itself: the caller takes the registration over
-        std::lock_guard<std::mutex> lock(g_ranges_mutex);
-        for (HostRange& r : g_ranges)
-            if (r.host == static_cast<char*>(p) && r.bytes >= bytes) { r.owner = nullptr; if (dev_ptr) *dev_ptr = r.dev; return HIPNLP_OK; }
+    {   // an array a handle registered by itself: the caller takes over — with a FRESH registration: the handle's one may be of pages
+        // that were freed since (its stores are verified, the caller's are not), so its device address is not handed on
+        bool taken = false;
+        {
+            std::lock_guard<std::mutex> lock(g_ranges_mutex);
+            for (HostRange& r : g_ranges) {
+                if (r.host != static_cast<char*>(p)) continue;
+                if (r.owner == nullptr && r.bytes >= bytes) { if (dev_ptr) *dev_ptr = r.dev; return HIPNLP_OK; }   // (registered by the caller before: as it is)
+                taken = true;
+            }
+        }
+        if (taken) (void)hipnlp_host_unregister(p);
     }
     if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return HIPNLP_E_NODEVICE; }
     void* d = nullptr;

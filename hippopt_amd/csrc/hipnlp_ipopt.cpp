@@ -48,9 +48,10 @@ Bool hipnlp_ipopt_eval_jac_g(Index n, Number* x, Bool new_x, Index m, Index nele
     hipnlp_handle* h = static_cast<hipnlp_handle*>(user_data);
     Sizes s;
     if (!sizes_of(h, s) || n != s.n || m != s.m || nele_jac != s.nnz) return FALSE;
-    if (!values) {   // the structure call (x is NULL)
+    if (!values) {   // the structure call (x is NULL): the handle's own order — CCS, or varying-first inside every knot block
         if (!iRow || !jCol) return FALSE;
         static_assert(sizeof(Index) == sizeof(int32_t), "IPOPT built with 32-bit indices");
+        static_assert(sizeof(Bool) == sizeof(int), "IpStdCInterface.h's Bool is an int in the builds these callbacks were written against (see INTEGRATION.md for IPOPT builds whose Bool is bool)");
         return served(hipnlp_sparsity(h, reinterpret_cast<int32_t*>(iRow), reinterpret_cast<int32_t*>(jCol)));
     }
     if (!x) return FALSE;
@@ -105,9 +106,16 @@ int hipnlp_ipopt_bounds(hipnlp_handle* h, Number* x_L, Number* x_U, Number* g_L,
 
 int hipnlp_ipopt_attach(hipnlp_handle* h) {
     if (!h) return HIPNLP_E_INVALID;
+    // auto-registration of IPOPT's arrays and nothing that writes into them before IPOPT asks: every callback fills exactly the array
+    // it was handed (the TNLPAdapter keeps full_g_ / jac_g_ as caches keyed by the tag of x — see hipnlp_ipopt_set_early_outputs)
     int rc = hipnlp_set_auto_register(h, 1);
-    if (rc == HIPNLP_OK) rc = hipnlp_set_early_outputs(h, 1);
+    if (rc == HIPNLP_OK) rc = hipnlp_set_early_outputs(h, 0);
     return rc;
+}
+
+int hipnlp_ipopt_set_early_outputs(hipnlp_handle* h, int on) {
+    if (!h) return HIPNLP_E_INVALID;
+    return hipnlp_set_early_outputs(h, on ? 1 : 0);   // (g and jac g only; never grad f: its destination is IPOPT's own gradient vector)
 }
 
 int hipnlp_ipopt_detach(hipnlp_handle* h) {

@@ -23,6 +23,7 @@
 #include <math.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "nlp_defs.h"
 #include "knot_tanh.h"
@@ -211,6 +212,18 @@ template <class Em> HD bool terrain_is_planar(const Ctx<Em>& cx) {
     else return cx.st.terrain == HIPNLP_TERRAIN_PLANAR;
 }
 
+// Entries of jac g that do NOT depend on x — literals and parameters only: +-1, -dt/2, the mass, +-1/4 (the trapezoid defects
+// integrators/implicit_trapezoid.py:24-39, the x0 rows base/multiple_shooting_solver.py:713-742, the single-variable bound rows
+// planner.py:386-405,699-719) — leave through emit_jc.  An emitter with a JC member sees them as such: the layout recorder marks the
+// slot constant (Layout::jconst), the parameter pass of hipnlp_set_params collects the values (a handle's host destinations are
+// filled with them once and its kernels then store the varying entries only); every other emitter takes them as ordinary entries.
+template <class Em, class = void> struct em_has_jc : std::false_type {};
+template <class Em> struct em_has_jc<Em, std::void_t<decltype(std::declval<Em&>().JC(0, 0, 0, 0.0))>> : std::true_type {};
+template <class Em> HD void emit_jc(Em& em, int slot, int rid, int col, double v) {
+    if constexpr (em_has_jc<Em>::value) em.JC(slot, rid, col, v);
+    else em.J(slot, rid, col, v);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // tiny helpers on raw arrays
 // ---------------------------------------------------------------------------------------------------
@@ -362,16 +375,16 @@ template <class Em> HD void t_points_dyn(Ctx<Em>& cx, int t) {
     em.G(gb + gs::PDYN + i, row_id(RK_PDYN_IN, c, i), x[P_ + i] - (xm[P_ + i] + half * (xm[V_ + i] + x[V_ + i])));
     em.G(gb + gs::FDYN_X0 + i, row_id(RK_FDYN_X0, c, i), x[F_ + i]);
     em.G(gb + gs::PDYN_X0 + i, row_id(RK_PDYN_X0, c, i), x[P_ + i]);
-    em.J(jb + js::FDYN + 0 + i, row_id(RK_FDYN_IN, c, i), cb + F_ + i, 1.0);
-    em.J(jb + js::FDYN + 3 + i, row_id(RK_FDYN_IN, c, i), cb + FD_ + i, -half);
-    em.J(jb + js::FDYN + 6 + i, row_id(RK_FDYN_OUT, c, i), cb + F_ + i, -1.0);
-    em.J(jb + js::FDYN + 9 + i, row_id(RK_FDYN_OUT, c, i), cb + FD_ + i, -half);
-    em.J(jb + js::FDYN + 12 + i, row_id(RK_FDYN_X0, c, i), cb + F_ + i, 1.0);
-    em.J(jb + js::PDYN + 0 + i, row_id(RK_PDYN_IN, c, i), cb + P_ + i, 1.0);
-    em.J(jb + js::PDYN + 3 + i, row_id(RK_PDYN_IN, c, i), cb + V_ + i, -half);
-    em.J(jb + js::PDYN + 6 + i, row_id(RK_PDYN_OUT, c, i), cb + P_ + i, -1.0);
-    em.J(jb + js::PDYN + 9 + i, row_id(RK_PDYN_OUT, c, i), cb + V_ + i, -half);
-    em.J(jb + js::PDYN + 12 + i, row_id(RK_PDYN_X0, c, i), cb + P_ + i, 1.0);
+    emit_jc(em, jb + js::FDYN + 0 + i, row_id(RK_FDYN_IN, c, i), cb + F_ + i, 1.0);
+    emit_jc(em, jb + js::FDYN + 3 + i, row_id(RK_FDYN_IN, c, i), cb + FD_ + i, -half);
+    emit_jc(em, jb + js::FDYN + 6 + i, row_id(RK_FDYN_OUT, c, i), cb + F_ + i, -1.0);
+    emit_jc(em, jb + js::FDYN + 9 + i, row_id(RK_FDYN_OUT, c, i), cb + FD_ + i, -half);
+    emit_jc(em, jb + js::FDYN + 12 + i, row_id(RK_FDYN_X0, c, i), cb + F_ + i, 1.0);
+    emit_jc(em, jb + js::PDYN + 0 + i, row_id(RK_PDYN_IN, c, i), cb + P_ + i, 1.0);
+    emit_jc(em, jb + js::PDYN + 3 + i, row_id(RK_PDYN_IN, c, i), cb + V_ + i, -half);
+    emit_jc(em, jb + js::PDYN + 6 + i, row_id(RK_PDYN_OUT, c, i), cb + P_ + i, -1.0);
+    emit_jc(em, jb + js::PDYN + 9 + i, row_id(RK_PDYN_OUT, c, i), cb + V_ + i, -half);
+    emit_jc(em, jb + js::PDYN + 12 + i, row_id(RK_PDYN_X0, c, i), cb + P_ + i, 1.0);
 }
 template <class Em> HD void t_points_vec(Ctx<Em>& cx, int t) {
     auto& s = cx.s;
@@ -381,19 +394,20 @@ template <class Em> HD void t_points_vec(Ctx<Em>& cx, int t) {
     Em& em = cx.em;
     const double pz = x[P_ + 2];
     const bool planar = terrain_is_planar(cx);
-    em.J(jb + js::PLANAR_V + i, row_id(RK_PLANAR, c, i), cb + V_ + i, 1.0);
+    emit_jc(em, jb + js::PLANAR_V + i, row_id(RK_PLANAR, c, i), cb + V_ + i, 1.0);
     if (planar) {  // planar complementarity  v - R_t diag(tau,tau,1) u,  tau = tanh(kt h(p))   (E3; R_t = I, h = p_z)
         const double tau = knot_tanh(cx.gp.kt * pz);
         const double mult = i < 2 ? tau : 1.0;
         em.G(gb + gs::PLANAR + i, row_id(RK_PLANAR, c, i), x[V_ + i] - mult * x[U_ + i]);
-        em.J(jb + js::PLANAR_U + 3 * i + i, row_id(RK_PLANAR, c, i), cb + U_ + i, -mult);
+        if (i < 2) em.J(jb + js::PLANAR_U + 3 * i + i, row_id(RK_PLANAR, c, i), cb + U_ + i, -mult);
+        else emit_jc(em, jb + js::PLANAR_U + 3 * i + i, row_id(RK_PLANAR, c, i), cb + U_ + i, -1.0);
         if (i < 2) em.J(jb + js::PLANAR_P + 3 * i + 2, row_id(RK_PLANAR, c, i), cb + P_ + 2, -(cx.gp.kt * (1.0 - tau * tau)) * x[U_ + i]);
     }
     // control bound rows
     em.G(gb + gs::UB + i, row_id(RK_UB, c, i), x[U_ + i]);
-    em.J(jb + js::UB + i, row_id(RK_UB, c, i), cb + U_ + i, 1.0);
+    emit_jc(em, jb + js::UB + i, row_id(RK_UB, c, i), cb + U_ + i, 1.0);
     em.G(gb + gs::FDB + i, row_id(RK_FDB, c, i), x[FD_ + i] * cx.gp.mass);
-    em.J(jb + js::FDB + i, row_id(RK_FDB, c, i), cb + FD_ + i, cx.gp.mass);
+    emit_jc(em, jb + js::FDB + i, row_id(RK_FDB, c, i), cb + FD_ + i, cx.gp.mass);
     // gradient of the point-local costs (k >= 1): swing height (E10), ||u_v||^2, ||f_dot||^2
     const double on = cx.ki.first ? 0.0 : 1.0;
     double* gr = s.grad + cb;
@@ -442,7 +456,8 @@ template <class Em> HD void point_hnf_smooth(Ctx<Em>& cx, int c, const TerrainFr
     const double gradh[3] = {tf.u1.v, tf.u2.v, 1.0};
     const D2 nf = n[0] * f[0] + n[1] * f[1] + n[2] * f[2];
     em.G(gb + gs::HEIGHT, row_id(RK_HEIGHT, c, 0), tf.h.v);
-    for (int j = 0; j < 3; ++j) em.J(jb + js::HEIGHT + j, row_id(RK_HEIGHT, c, 0), cb + P_ + j, gradh[j]);
+    for (int j = 0; j < 2; ++j) em.J(jb + js::HEIGHT + j, row_id(RK_HEIGHT, c, 0), cb + P_ + j, gradh[j]);
+    emit_jc(em, jb + js::HEIGHT + 2, row_id(RK_HEIGHT, c, 0), cb + P_ + 2, 1.0);
     em.G(gb + gs::NORMAL, row_id(RK_NORMAL, c, 0), nf.v);
     em.J(jb + js::NORMAL_P + 0, row_id(RK_NORMAL, c, 0), cb + P_ + 0, nf.x);
     em.J(jb + js::NORMAL_P + 1, row_id(RK_NORMAL, c, 0), cb + P_ + 1, nf.y);
@@ -463,9 +478,9 @@ template <class Em> HD void point_hnf_planar(Ctx<Em>& cx, int c) {
     const double* x = cx.s.x + cb;
     const double pz = x[P_ + 2], fz = x[F_ + 2];
     em.G(gb + gs::HEIGHT, row_id(RK_HEIGHT, c, 0), pz);
-    em.J(jb + js::HEIGHT + 2, row_id(RK_HEIGHT, c, 0), cb + P_ + 2, 1.0);
+    emit_jc(em, jb + js::HEIGHT + 2, row_id(RK_HEIGHT, c, 0), cb + P_ + 2, 1.0);
     em.G(gb + gs::NORMAL, row_id(RK_NORMAL, c, 0), fz);
-    em.J(jb + js::NORMAL_F + 2, row_id(RK_NORMAL, c, 0), cb + F_ + 2, 1.0);
+    emit_jc(em, jb + js::NORMAL_F + 2, row_id(RK_NORMAL, c, 0), cb + F_ + 2, 1.0);
     const double mu2 = cx.gp.mu * cx.gp.mu;
     em.G(gb + gs::FRICTION, row_id(RK_FRICTION, c, 0), -(x[F_] * x[F_]) - (x[F_ + 1] * x[F_ + 1]) + mu2 * (fz * fz));
     em.J(jb + js::FRICTION_F + 0, row_id(RK_FRICTION, c, 0), cb + F_ + 0, -2.0 * x[F_]);
@@ -530,7 +545,7 @@ template <class Em> HD void t_com_height(Ctx<Em>& cx, int) {
     em.G(gs::COMH, row_id(RK_COMH, 0, 0), s.x[COM_ + 2] - Z[0]);
     em.J(js::COMH + 0, row_id(RK_COMH, 0, 0), COM_ + 0, -Z[1]);
     em.J(js::COMH + 1, row_id(RK_COMH, 0, 0), COM_ + 1, -Z[2]);
-    em.J(js::COMH + 2, row_id(RK_COMH, 0, 0), COM_ + 2, 1.0);
+    emit_jc(em, js::COMH + 2, row_id(RK_COMH, 0, 0), COM_ + 2, 1.0);
 }
 template <class Em> HD void t_terrain_stage(Ctx<Em>& cx, int c) {
     if (terrain_is_planar(cx)) return;
@@ -702,11 +717,11 @@ template <class Em> HD void t_dyn(Ctx<Em>& cx, int e) {
     scratch_padding(s, e);
     em.G(gslot + i, row_id(kin, 0, i), s.x[X] - (s.xm[X] + half * (s.xm[Y] + s.x[Y])));
     em.G(gx0 + i, row_id(kx0, 0, i), s.x[X]);
-    em.J(jslot + 0 * L + i, row_id(kin, 0, i), X, 1.0);
-    em.J(jslot + 1 * L + i, row_id(kin, 0, i), Y, -half);
-    em.J(jslot + 2 * L + i, row_id(kout, 0, i), X, -1.0);
-    em.J(jslot + 3 * L + i, row_id(kout, 0, i), Y, -half);
-    em.J(jslot + 4 * L + i, row_id(kx0, 0, i), X, 1.0);
+    emit_jc(em, jslot + 0 * L + i, row_id(kin, 0, i), X, 1.0);
+    emit_jc(em, jslot + 1 * L + i, row_id(kin, 0, i), Y, -half);
+    emit_jc(em, jslot + 2 * L + i, row_id(kout, 0, i), X, -1.0);
+    emit_jc(em, jslot + 3 * L + i, row_id(kout, 0, i), Y, -half);
+    emit_jc(em, jslot + 4 * L + i, row_id(kx0, 0, i), X, 1.0);
 }
 
 // parent_R_child = R_fix * (cq (I - a a^T) + sq [a]x + a a^T)   (adam R_from_axis_angle) -> the joint record s.Jr[j]
@@ -737,9 +752,9 @@ template <class Em> HD void t_joint_rows(Ctx<Em>& cx, int j) {
     auto& s = cx.s;
     Em& em = cx.em;
     em.G(gs::JPB + j, row_id(RK_JPB, 0, j), s.x[S_ + j]);
-    em.J(js::JPB + j, row_id(RK_JPB, 0, j), S_ + j, 1.0);
+    emit_jc(em, js::JPB + j, row_id(RK_JPB, 0, j), S_ + j, 1.0);
     em.G(gs::JVB + j, row_id(RK_JVB, 0, j), s.x[SD_ + j]);
-    em.J(js::JVB + j, row_id(RK_JVB, 0, j), SD_ + j, 1.0);
+    emit_jc(em, js::JVB + j, row_id(RK_JVB, 0, j), SD_ + j, 1.0);
     // joint_positions_error  planner.py:505-520
     const double on = cx.ki.first ? 0.0 : 1.0;
     const double m = on * cx.st.m_jreg, w = cx.st.w_jreg[j];
@@ -792,7 +807,7 @@ template <class Em> HD void t_small(Ctx<Em>& cx, int t) {
     if (t < 3) {  // angular momentum bound rows h[3:]*mass (planner.py:342-350); gradient of the com velocity cost
         const int i = t;
         em.G(gs::AMB + i, row_id(RK_AMB, 0, i), s.x[H_ + 3 + i] * cx.gp.mass);
-        em.J(js::AMB + i, row_id(RK_AMB, 0, i), H_ + 3 + i, cx.gp.mass);
+        emit_jc(em, js::AMB + i, row_id(RK_AMB, 0, i), H_ + 3 + i, cx.gp.mass);
         const double e = s.x[H_ + i] - s.pk[PK_REF + R_VREF + i];
         s.grad[H_ + i] = 2.0 * cx.st.m_comvel * cx.st.w_comvel[i] * e;
         s.grad[H_ + 3 + i] = 0.0;
@@ -800,7 +815,7 @@ template <class Em> HD void t_small(Ctx<Em>& cx, int t) {
     } else {      // minimum com height: h_terrain(com) = com_z ; com velocity and base quaternion velocity costs (k >= 0)
         if (terrain_is_planar(cx)) {   // (smooth terrain: t_com_height, behind the bump jets)
             em.G(gs::COMH, row_id(RK_COMH, 0, 0), s.x[COM_ + 2]);
-            em.J(js::COMH + 2, row_id(RK_COMH, 0, 0), COM_ + 2, 1.0);
+            emit_jc(em, js::COMH + 2, row_id(RK_COMH, 0, 0), COM_ + 2, 1.0);
         }
         double c = 0.0;
         for (int i = 0; i < 4; ++i) {
@@ -827,7 +842,7 @@ template <class Em> HD void t_feet(Ctx<Em>& cx, int t) {   // t = 0: centroids; 
             for (int i = 0; i < 3; ++i) { cl[i] += s.x[PT_ * c + P_ + i]; cr[i] += s.x[PT_ * (c + 4) + P_ + i]; }
         for (int i = 0; i < 3; ++i) { cl[i] = cl[i] / 4.0; cr[i] = cr[i] / 4.0; }
         em.G(gs::FEETH, row_id(RK_FEETH, 0, 0), cl[2] - cr[2]);
-        for (int c = 0; c < NC; ++c) em.J(js::FEETH + c, row_id(RK_FEETH, 0, 0), PT_ * c + P_ + 2, c < 4 ? 0.25 : -0.25);
+        for (int c = 0; c < NC; ++c) emit_jc(em, js::FEETH + c, row_id(RK_FEETH, 0, 0), PT_ * c + P_ + 2, c < 4 ? 0.25 : -0.25);
         double cost = 0.0;
         const double m = on * cx.st.m_centroid;
         for (int i = 0; i < 3; ++i) {
@@ -1023,8 +1038,8 @@ template <class Em> HD void t_hdyn(Ctx<Em>& cx, int t) {
         em.J(js::HDYN_ANG_F_IN + 6 * c + e, row_id(RK_HDYN_IN, 0, row), cb + F_ + col, vf);
         em.J(js::HDYN_ANG_F_OUT + 6 * c + e, row_id(RK_HDYN_OUT, 0, row), cb + F_ + col, vf);
         if (e < 3) {
-            em.J(js::HDYN_LIN_F_IN + 3 * c + e, row_id(RK_HDYN_IN, 0, e), cb + F_ + e, -half);
-            em.J(js::HDYN_LIN_F_OUT + 3 * c + e, row_id(RK_HDYN_OUT, 0, e), cb + F_ + e, -half);
+            emit_jc(em, js::HDYN_LIN_F_IN + 3 * c + e, row_id(RK_HDYN_IN, 0, e), cb + F_ + e, -half);
+            emit_jc(em, js::HDYN_LIN_F_OUT + 3 * c + e, row_id(RK_HDYN_OUT, 0, e), cb + F_ + e, -half);
         }
     } else if (t < 54) {  // the six rows
         const int i = t - 48;
@@ -1032,10 +1047,10 @@ template <class Em> HD void t_hdyn(Ctx<Em>& cx, int t) {
         for (int c = 0; c < NC; ++c) { h0 += s.hd[0][c][i]; h1 += s.hd[1][c][i]; }
         em.G(gs::HDYN + i, row_id(RK_HDYN_IN, 0, i), s.x[H_ + i] - (s.xm[H_ + i] + half * (h0 + h1)));
         em.G(gs::H_X0 + i, row_id(RK_HDYN_X0, 0, i), s.x[H_ + i] - s.xg[i]);
-        em.J(js::HDYN_SELF_IN + i, row_id(RK_HDYN_IN, 0, i), H_ + i, 1.0);
-        em.J(js::HDYN_SELF_OUT + i, row_id(RK_HDYN_OUT, 0, i), H_ + i, -1.0);
-        em.J(js::HDYN_X0 + i, row_id(RK_HDYN_X0, 0, i), H_ + i, 1.0);
-        em.J(js::HDYN_X0G + i, row_id(RK_HDYN_X0, 0, i), COL_GLOBAL + i, -1.0);
+        emit_jc(em, js::HDYN_SELF_IN + i, row_id(RK_HDYN_IN, 0, i), H_ + i, 1.0);
+        emit_jc(em, js::HDYN_SELF_OUT + i, row_id(RK_HDYN_OUT, 0, i), H_ + i, -1.0);
+        emit_jc(em, js::HDYN_X0 + i, row_id(RK_HDYN_X0, 0, i), H_ + i, 1.0);
+        emit_jc(em, js::HDYN_X0G + i, row_id(RK_HDYN_X0, 0, i), COL_GLOBAL + i, -1.0);
     } else {              // d/dcom sum (p - com) x f = [sum f]x
         const int e = t - 54;
         double fs[3] = {0.0, 0.0, 0.0};
@@ -1104,7 +1119,7 @@ template <class Em> HD void t_ends(Ctx<Em>& cx, int t) {
             s.ends.g[t] = 2.0 * cx.st.final_weight * e;
         } else if (cx.st.final_type == HIPNLP_EXPR_SUBJECT_TO) {
             emit_g_end(cx, gs::FIN + t, row_id(RK_FIN, 0, t), lhs);
-            if (var >= 0) em.J(js::FIN + end_tables(cx).fin_slot[t], row_id(RK_FIN, 0, t), var, 1.0);
+            if (var >= 0) emit_jc(em, js::FIN + end_tables(cx).fin_slot[t], row_id(RK_FIN, 0, t), var, 1.0);
         }
     } else {
         const int i = t - 105;
@@ -1118,9 +1133,9 @@ template <class Em> HD void t_ends(Ctx<Em>& cx, int t) {
         } else if (cx.st.periodicity_type == HIPNLP_EXPR_SUBJECT_TO) {
             if (cx.ki.last) {
                 emit_g_end(cx, gs::PER + i, row_id(RK_PERN, 0, i), s.xo[i] - s.x[var]);
-                em.J(js::PERN + i, row_id(RK_PERN, 0, i), var, -1.0);
+                emit_jc(em, js::PERN + i, row_id(RK_PERN, 0, i), var, -1.0);
             }
-            if (cx.ki.first) em.J(js::PER0 + i, row_id(RK_PER0, 0, i), var, 1.0);
+            if (cx.ki.first) emit_jc(em, js::PER0 + i, row_id(RK_PER0, 0, i), var, 1.0);
         }
     }
 }
@@ -1364,8 +1379,8 @@ template <class Em> HD void t_kinc(Ctx<Em>& cx, int t) {
     const int c = t / 3, i = t - 3 * c, jb = js::PT_STRIDE * c, gb = gs::PT_STRIDE * c, cb = PT_ * c;
     const double* r = s.pkin[c];  // base-centred
     em.G(gb + gs::KINC + i, row_id(RK_KINC, c, i), s.x[cb + P_ + i] - (s.x[PB_ + i] + r[i]));
-    em.J(jb + js::KINC_P + i, row_id(RK_KINC, c, i), cb + P_ + i, 1.0);
-    em.J(jb + js::KINC_PB + i, row_id(RK_KINC, c, i), PB_ + i, -1.0);
+    emit_jc(em, jb + js::KINC_P + i, row_id(RK_KINC, c, i), cb + P_ + i, 1.0);
+    emit_jc(em, jb + js::KINC_PB + i, row_id(RK_KINC, c, i), PB_ + i, -1.0);
     // d pkin / d q_b = -[r]x G / |q|   ->  row entries = +[r]x G / |q|
     const double X0 = skew_rc(r, i, 0), X1 = skew_rc(r, i, 1), X2 = skew_rc(r, i, 2);
     for (int l = 0; l < 4; ++l)
@@ -1395,8 +1410,8 @@ template <class Em> HD void t_comc(Ctx<Em>& cx, int t) {
     } else {
         const int i = t - 12;
         em.G(gs::COMC + i, row_id(RK_COMC, 0, i), s.x[COM_ + i] - (s.x[PB_ + i] + r[i]));
-        em.J(js::COMC_COM + i, row_id(RK_COMC, 0, i), COM_ + i, 1.0);
-        em.J(js::COMC_PB + i, row_id(RK_COMC, 0, i), PB_ + i, -1.0);
+        emit_jc(em, js::COMC_COM + i, row_id(RK_COMC, 0, i), COM_ + i, 1.0);
+        emit_jc(em, js::COMC_PB + i, row_id(RK_COMC, 0, i), PB_ + i, -1.0);
     }
 }
 // h[3:] == CMM(...)[3:] / mass  (K3, planner.py:309-339): lanes (i, l) 12 for q_b / qdot_b, lanes 12..14 rows
@@ -1416,7 +1431,7 @@ template <class Em> HD void t_cmmc(Ctx<Em>& cx, int t) {
     } else {
         const int i = t - 12;
         em.G(gs::CMMC + i, row_id(RK_CMMC, 0, i), s.x[H_ + 3 + i] - s.hang[i] * inv_mass);
-        em.J(js::CMMC_H + i, row_id(RK_CMMC, 0, i), H_ + 3 + i, 1.0);
+        emit_jc(em, js::CMMC_H + i, row_id(RK_CMMC, 0, i), H_ + 3 + i, 1.0);
     }
 }
 // feet distance value (K4) on lane 4; chest cost gradient on q_b, lanes 0..3: 5 tasks

@@ -60,6 +60,11 @@ struct RecordEm {
     void H(int slot, int row, int col, double) { if (hrow[slot] != -1) *dup = true; hrow[slot] = row; hcol[slot] = col; }
     void G(int slot, int rid, double) { if (grow[slot] != -1) *dup = true; grow[slot] = rid; }
     void J(int slot, int rid, int col, double) { if (jrowid[slot] != -1) *dup = true; jrowid[slot] = rid; jcol[slot] = col; }
+    // an entry that does not depend on x (knot_body.h, emit_jc): the slot is marked constant and its value kept (a pass over the
+    // program with the handle's own parameters, Layout::constant_values, reads it back)
+    unsigned char* jconst = nullptr;   // [js::COUNT] or null
+    double* jcval = nullptr;           // [js::COUNT] or null
+    void JC(int slot, int rid, int col, double v) { J(slot, rid, col, v); if (jconst) jconst[slot] = 1; if (jcval) jcval[slot] = v; }
 };
 
 // parameter offsets in reference creation order (tests/golden/kinodyn_structure.json)
@@ -104,10 +109,21 @@ struct Layout {
     // kernel tables
     std::vector<int32_t> g_a[3];          // [gs::COUNT] row of slot at knot k is g_a + g_b*k ; G_NONE = not written
     std::vector<int32_t> g_b;
-    std::vector<int32_t> jperm[3];        // CCS position (within the knot's column block) -> native slot
+    std::vector<int32_t> jperm[3];        // position within the knot's column block -> native slot (CCS order, or — vary_first — the
+                                          // entries that depend on x in CCS order, then the constant ones in CCS order)
     std::vector<int32_t> jperm_glob;      // entries in the horizon-global columns (written by knot 0)
     int nnz_v[3] = {0, 0, 0};
     int jac_glob_base = 0;
+    // Entries of jac g that do not depend on x (emit_jc in knot_body.h: +-1, -dt/2, the mass, +-1/4 of the linear rows): 43 % of the
+    // pattern at N = 100.  jconst_slot marks the native slots, jconst_pos[v][i] position i of the column block of a variant-v knot,
+    // nvary_v[v] counts the entries of a block that DO depend on x; the horizon-global entries (jperm_glob) are all constant.
+    // vary_first (HIPNLP_FLAG_JAC_VARYING_FIRST): a knot's block lists its varying entries first — the kernel's stores into a host
+    // array whose constants were filled once are then ONE contiguous run per knot.  IPOPT takes triplets in any order.
+    bool vary_first = false;
+    std::vector<unsigned char> jconst_slot;
+    std::vector<unsigned char> jconst_pos[3];
+    int nvary_v[3] = {0, 0, 0};
+    int nconst_total = 0;                 // constant entries of the whole pattern
     std::vector<int32_t> irow, jcol;      // full pattern, CCS order
     std::string error;
 
@@ -168,8 +184,9 @@ struct Layout {
         }
     }
 
-    bool build(const hipnlp_settings& st, const KinTables& kt, bool lift_simple_bounds = false) {
+    bool build(const hipnlp_settings& st, const KinTables& kt, bool lift_simple_bounds = false, bool varying_first = false) {
         N = st.horizon;
+        vary_first = varying_first;
         if (N < 2) { error = "horizon must be >= 2"; return false; }
         n = NXK * N + NXG;
         m = m_full = n_lifted = 0;
@@ -232,6 +249,7 @@ struct Layout {
 
         // ---- record the kernel body's native slots --------------------------------------------------
         std::vector<int> grow(gs::COUNT, -1), jrid(js::COUNT, -1), jc(js::COUNT, -1);
+        jconst_slot.assign(js::COUNT, 0);
         bool dup = false;
         {
             KnotScratch* s = new KnotScratch();
@@ -242,6 +260,7 @@ struct Layout {
             gp.dt = 0.1; gp.mass = 1.0;
             KnotInfo ki{0, N, 1, 1};
             RecordEm em{grow.data(), jrid.data(), jc.data(), &dup};
+            em.jconst = jconst_slot.data();
             Ctx<RecordEm> cx(*s, kt, ks, gp, ki, em);
 #define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
             HIPNLP_KNOT_PROGRAM(HOST_R, )
@@ -284,9 +303,23 @@ struct Layout {
             std::sort(ent.begin(), ent.end());
             for (size_t i = 1; i < ent.size(); ++i)
                 if (ent[i].first == ent[i - 1].first) { error = "internal: duplicate jacobian entry"; return false; }
-            for (auto& e : ent) jperm[v].push_back(e.second);
+            if (vary_first)   // (stable: CCS order within the varying entries and within the constant ones)
+                std::stable_partition(ent.begin(), ent.end(), [&](const std::pair<std::pair<int, int>, int>& e) { return !jconst_slot[size_t(e.second)]; });
+            jconst_pos[v].clear();
+            nvary_v[v] = 0;
+            for (auto& e : ent) {
+                jperm[v].push_back(e.second);
+                jconst_pos[v].push_back(jconst_slot[size_t(e.second)]);
+                nvary_v[v] += !jconst_slot[size_t(e.second)];
+            }
             nnz_v[v] = int(ent.size());
-            if (v == VAR_FIRST) { std::sort(glob.begin(), glob.end()); for (auto& e : glob) jperm_glob.push_back(e.second); }
+            if (v == VAR_FIRST) {
+                std::sort(glob.begin(), glob.end());
+                for (auto& e : glob) {
+                    if (!jconst_slot[size_t(e.second)]) { error = "internal: an entry in a horizon-global column depends on x"; return false; }
+                    jperm_glob.push_back(e.second);
+                }
+            }
         }
         jac_glob_base = int(jac_base(N - 1)) + nnz_v[VAR_LAST];
         nnz = jac_glob_base + int(jperm_glob.size());
@@ -298,10 +331,39 @@ struct Layout {
             for (int slot : jperm[v]) { irow.push_back(resolve(jrid[size_t(slot)], k)); jcol.push_back(NXK * k + jc[size_t(slot)]); }
         }
         for (int slot : jperm_glob) { irow.push_back(resolve(jrid[size_t(slot)], 0)); jcol.push_back(NXK * N + (jc[size_t(slot)] - COL_GLOBAL)); }
-        for (size_t i = 1; i < irow.size(); ++i)
-            if (!(jcol[i - 1] < jcol[i] || (jcol[i - 1] == jcol[i] && irow[i - 1] < irow[i]))) { error = "internal: pattern not in CCS order"; return false; }
+        if (!vary_first)
+            for (size_t i = 1; i < irow.size(); ++i)
+                if (!(jcol[i - 1] < jcol[i] || (jcol[i - 1] == jcol[i] && irow[i - 1] < irow[i]))) { error = "internal: pattern not in CCS order"; return false; }
         if (int(irow.size()) != nnz) { error = "internal: nnz mismatch"; return false; }
+        nconst_total = int(jperm_glob.size());
+        for (int k = 0; k < N; ++k) nconst_total += nnz_v[variant_of(k)] - nvary_v[variant_of(k)];
         return true;
+    }
+
+    // is entry i of the pattern (0 .. nnz) constant?  (mask of the whole trajectory, in the order of irow / jcol)
+    void constant_mask(unsigned char* mask) const {
+        size_t at = 0;
+        for (int k = 0; k < N; ++k) for (unsigned char c : jconst_pos[variant_of(k)]) mask[at++] = c;
+        for (size_t i = 0; i < jperm_glob.size(); ++i) mask[at++] = 1;
+    }
+    // Values of the constant native slots under the parameters gp of ONE trajectory: the knot program run once on the host with an
+    // emitter that keeps what leaves through emit_jc (values of slots that are not constant: 0).  They do not depend on the knot.
+    static void constant_values(const hipnlp_settings& st, const KinTables& kt, const GParams& gp, double* cval /*[js::COUNT]*/) {
+        std::vector<int> grow(gs::COUNT, -1), jrid(js::COUNT, -1), jc(js::COUNT, -1);
+        std::fill(cval, cval + js::COUNT, 0.0);
+        bool dup = false;
+        KnotScratch* s = new KnotScratch();
+        std::fill(reinterpret_cast<double*>(s), reinterpret_cast<double*>(s) + sizeof(KnotScratch) / sizeof(double), 0.0);
+        s->x[QB_ + 3] = 1.0;
+        KSettings ks = make_ksettings(st);
+        KnotInfo ki{0, st.horizon, 1, 1};
+        RecordEm em{grow.data(), jrid.data(), jc.data(), &dup};
+        em.jcval = cval;
+        Ctx<RecordEm> cx(*s, kt, ks, gp, ki, em);
+#define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
+        HIPNLP_KNOT_PROGRAM(HOST_R, )
+#undef HOST_R
+        delete s;
     }
 
     // terrain description of the C-ABI -> pre-digested form the terrain jets read

@@ -25,14 +25,14 @@ EXPORTS = [
     "hipnlp_ipc_alloc", "hipnlp_ipc_open", "hipnlp_ipc_close", "hipnlp_ipc_free", "hipnlp_peer_push", "hipnlp_peer_signal", "hipnlp_peer_wait", "hipnlp_eval_device_peers",
     "hipnlp_hess_nnz", "hipnlp_hess_sparsity", "hipnlp_eval_hess", "hipnlp_eval_hess_device",
     "hipnlp_eval_pinned", "hipnlp_set_prefetch", "hipnlp_set_early_outputs", "hipnlp_set_host_timing", "hipnlp_host_register", "hipnlp_host_unregister",
-    "hipnlp_host_breakdown", "hipnlp_set_auto_register", "hipnlp_host_stats",
+    "hipnlp_host_breakdown", "hipnlp_set_auto_register", "hipnlp_host_stats", "hipnlp_set_constant_jacobian", "hipnlp_jac_constant_mask",
     "hipnlp_pose_create", "hipnlp_pose_destroy", "hipnlp_pose_last_error", "hipnlp_pose_get_dims", "hipnlp_pose_set_params",
     "hipnlp_pose_bounds", "hipnlp_pose_sparsity", "hipnlp_pose_eval", "hipnlp_pose_eval_device", "hipnlp_pose_cost_terms",
     "hipnlp_pose_cost_term_name", "hipnlp_pose_num_row_blocks", "hipnlp_pose_row_block", "hipnlp_pose_last_kernel_ms",
     "hipnlp_pose_hess_nnz", "hipnlp_pose_hess_sparsity", "hipnlp_pose_eval_hess", "hipnlp_pose_eval_hess_device",
     # include/hipnlp_ipopt.h: IPOPT's C callback quartet (+ eval_h) on top of the functions above
     "hipnlp_ipopt_eval_f", "hipnlp_ipopt_eval_grad_f", "hipnlp_ipopt_eval_g", "hipnlp_ipopt_eval_jac_g", "hipnlp_ipopt_eval_h",
-    "hipnlp_ipopt_sizes", "hipnlp_ipopt_bounds", "hipnlp_ipopt_attach", "hipnlp_ipopt_detach",
+    "hipnlp_ipopt_sizes", "hipnlp_ipopt_bounds", "hipnlp_ipopt_attach", "hipnlp_ipopt_detach", "hipnlp_ipopt_set_early_outputs",
 ]
 G_STAGE = 550
 
@@ -131,6 +131,8 @@ def load_library():
     lib.hipnlp_host_breakdown.argtypes = [vp, dp]
     lib.hipnlp_set_auto_register.argtypes = [vp, C.c_int]
     lib.hipnlp_host_stats.argtypes = [vp, C.POINTER(C.c_long)]
+    lib.hipnlp_set_constant_jacobian.argtypes = [vp, C.c_int]
+    lib.hipnlp_jac_constant_mask.argtypes = [vp, C.POINTER(C.c_ubyte)]
     _lib = lib
     return lib
 
@@ -146,10 +148,13 @@ def _ip(a):
 class HipNlp:
     """One engine handle: a kinodynamic NLP (settings + robot model) on one HIP device."""
 
-    def __init__(self, settings, model, batch=1, knot_begin=0, knot_end=0, device=0, desc=None, detect_simple_bounds=False):
+    def __init__(self, settings, model, batch=1, knot_begin=0, knot_end=0, device=0, desc=None, detect_simple_bounds=False,
+                 jac_varying_first=False):
         """desc: a ready hipnlp_desc (e.g. hippopt_amd.from_reference.from_reference) instead of settings / model
         detect_simple_bounds: the handle is the REDUCED NLP nlpsol hands to IPOPT under Opti's {"detect_simple_bounds": True}
-        (HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS): single-variable rows are bounds on x, not rows of g"""
+        (HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS): single-variable rows are bounds on x, not rows of g
+        jac_varying_first: HIPNLP_FLAG_JAC_VARYING_FIRST — inside a knot's block of jac g the entries that depend on x come first,
+        the constant ones behind them (triplet consumers such as IPOPT; `sparsity()` returns that order)"""
         self.lib = load_library()
         if desc is not None:
             self.desc = desc
@@ -161,7 +166,7 @@ class HipNlp:
             self.desc.batch = int(batch)
             self.desc.knot_begin, self.desc.knot_end = int(knot_begin), int(knot_end)
             self.desc.device = int(device)
-            self.desc.flags = _abi.FLAG_DETECT_SIMPLE_BOUNDS if detect_simple_bounds else 0
+            self.desc.flags = (_abi.FLAG_DETECT_SIMPLE_BOUNDS if detect_simple_bounds else 0) | (_abi.FLAG_JAC_VARYING_FIRST if jac_varying_first else 0)
         h = C.c_void_p()
         rc = self.lib.hipnlp_create(C.byref(self.desc), C.byref(h))
         if rc != 0:
@@ -317,7 +322,17 @@ class HipNlp:
     def host_stats(self):
         out = (C.c_long * 8)()
         self._check(self.lib.hipnlp_host_stats(self.h, out))
-        return dict(zip(("auto_registered", "auto_fallbacks", "auto_ranges", "evaluations"), list(out)))
+        return dict(zip(("auto_registered", "auto_fallbacks", "auto_ranges", "evaluations", "constant_fills", "constant_refills", "constant_entries"), list(out)))
+
+    def set_constant_jacobian(self, on=True):
+        """hipnlp_set_constant_jacobian: host destinations of jac g hold the constant entries, launches store the varying ones only (default on)"""
+        self._check(self.lib.hipnlp_set_constant_jacobian(self.h, 1 if on else 0))
+
+    def jac_constant_mask(self):
+        """bool [nnz] in the order of `sparsity()`: entries of jac g that do not depend on x"""
+        mask = np.zeros(self.nnz, np.uint8)
+        self._check(self.lib.hipnlp_jac_constant_mask(self.h, mask.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        return mask.astype(bool)
 
     def set_host_timing(self, on=True):
         self._check(self.lib.hipnlp_set_host_timing(self.h, 1 if on else 0))

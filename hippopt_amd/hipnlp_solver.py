@@ -358,7 +358,10 @@ class HipNlpSolver(OptimizationSolver):
             if self._problem_kind == "pose":
                 self._engine = _PoseEngine(HipPose(self._settings, self._model, batch=1, device=self._device))
             else:
-                self._engine = HipNlp(self._settings, self._model, batch=1, device=self._device, detect_simple_bounds=self._detect_simple_bounds)
+                # (the NLP drivers take jac g as triplets — IPOPT's jacobianstructure / a COO matrix: inside a knot's block the entries
+                #  that depend on x come first, so the host path stores ONE contiguous run per knot and leaves the constant ones alone)
+                self._engine = HipNlp(self._settings, self._model, batch=1, device=self._device, detect_simple_bounds=self._detect_simple_bounds,
+                                      jac_varying_first=True)
         return self._engine
 
     def get_constraint_expressions(self):

@@ -176,6 +176,16 @@ typedef struct hipnlp_desc {
  *                         compute or move the lifted rows.  hipnlp_lift_map relates the reduced rows to the reference's full list
  *                         of named constraints (hipnlp_row_block stays in full numbering).                                        */
 #define HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS 1
+/*   JAC_VARYING_FIRST     order of the non-zeros of jac g INSIDE the column block of a knot (hipnlp_sparsity, every jac value array):
+ *                         the entries that depend on x first (in CCS order), the constant ones behind them (in CCS order), instead of
+ *                         one CCS run.  43 % of the pattern at 100 knots is constant — the +-1, -dt/2, mass entries of the trapezoid
+ *                         defects (integrators/implicit_trapezoid.py:24-39), the x_0 rows (base/multiple_shooting_solver.py:713-742)
+ *                         and the single-variable bound rows (planner.py:386-405,699-719) — and the host path stores only the varying
+ *                         entries (hipnlp_set_constant_jacobian): in this order they are ONE contiguous run per knot on the PCIe
+ *                         link instead of fragments of a few doubles.  IPOPT takes triplets in any order (eval_jac_g's structure
+ *                         call), so a C binding sets the flag; a consumer that wants CasADi's CCS value array leaves it unset.
+ *                         Knot blocks keep their places and sizes (shards, hipnlp_dims are unchanged).                              */
+#define HIPNLP_FLAG_JAC_VARYING_FIRST 2
 
 typedef struct hipnlp_dims {
     int32_t n;        /* decision variables per trajectory = 189*N + 6                */
@@ -222,8 +232,12 @@ int hipnlp_simple_rows(const hipnlp_handle* h, int32_t* is_simple, int32_t* var_
  * to the row whose bound is the active one.  Any pointer may be NULL. */
 int hipnlp_lift_map(const hipnlp_handle* h, int32_t* kept_row, double* lb_full, double* ub_full);
 
-/* CCS pattern as triplets sorted by (col,row): irow[nnz], jcol[nnz] (IPOPT eval_jac_g, values==NULL call) */
+/* CCS pattern as triplets sorted by (col,row): irow[nnz], jcol[nnz] (IPOPT eval_jac_g, values==NULL call).
+ * With HIPNLP_FLAG_JAC_VARYING_FIRST: knot blocks in knot order, inside a block the varying entries (col,row)-sorted, then the constant ones. */
 int hipnlp_sparsity(const hipnlp_handle* h, int32_t* irow, int32_t* jcol);
+/* mask[nnz] (order of hipnlp_sparsity): 1 where the entry of jac g does not depend on x (its value is a function of the parameters:
+ * +-1, -dt/2, the mass, +-1/4), 0 elsewhere. */
+int hipnlp_jac_constant_mask(const hipnlp_handle* h, unsigned char* mask);
 
 /* Host-buffer callback quartet (IPOPT eval_f/eval_grad_f/eval_g/eval_jac_g in one fused launch).
  * x: [batch][n]; f: [batch]; grad_f: [batch][n]; g: [batch][m]; jac: [batch][nnz].  Any output may be NULL.
@@ -253,6 +267,20 @@ int hipnlp_eval_pinned(hipnlp_handle* h, const double* x, int new_x, unsigned wa
  * +7 us): IPOPT asks for f and g at every trial point and for grad f and jac g (new_x = 0) only at accepted ones.
  * HIPNLP_WANT_ALL makes every new evaluation move everything (one launch, no second round trip for jac g).                      */
 int hipnlp_set_prefetch(hipnlp_handle* h, unsigned mask);
+/* Constant entries of jac g on the host path (ON by default; takes effect on handles created with HIPNLP_FLAG_JAC_VARYING_FIRST only: in
+ * CCS order the varying entries of a block are fragments of one to four doubles, and storing fragments over PCIe measured slower than
+ * storing everything).  A HOST destination of the Jacobian values — the library's pinned block, or
+ * a caller array inside a registered range (hipnlp_host_register / auto-registration) — is filled with the constant entries ONCE per
+ * parameter set (the pinned block when a launch first needs it, a caller array at its first use and again after hipnlp_set_params);
+ * the kernel then stores the entries that depend on x only: 628 KB instead of 1.1 MB per 100-knot Jacobian on a path that is bound by
+ * the bytes crossing PCIe.  What the caller gets is the complete value array, every call.  Contract for a REGISTERED caller array: the
+ * caller does not write into it between calls (IPOPT's TNLPAdapter never touches its jac_g_ buffer).  A caller that does anyway is
+ * covered by a spot check — sixteen constant entries spread over the array, its first and its last among them, are compared before every
+ * such launch and the array is re-filled when one differs (hipnlp_host_stats out[5] counts these) — not by a guarantee: a caller
+ * that edits single entries of a registered Jacobian array must turn this off.  Arrays that are NOT registered always receive complete
+ * values by a copy out of the pinned block.  Device-resident outputs (hipnlp_eval_device) are not affected: every entry is stored.
+ * on = 0: every launch stores every entry (the behaviour of ABI 2 libraries before this switch existed). */
+int hipnlp_set_constant_jacobian(hipnlp_handle* h, int on);
 /* Early outputs (opt-in, off by default).  on = 1: a NEW evaluation stores g and jac g — when its call does NOT ask for them —
  * straight into the REGISTERED caller arrays (hipnlp_host_register, or registered by the handle itself) that earlier calls passed
  * for them, before the caller asks.  IPOPT's sequence eval_f(new x), eval_g, eval_grad_f, eval_jac_g then costs one launch that moves
@@ -287,12 +315,15 @@ int hipnlp_host_unregister(void* p);
  * stores would go to the old pages.  Every use of an auto-registered array is therefore verified: the call writes a word of its own
  * into the first and the last entry before the evaluation and finds both overwritten afterwards (every entry of every output is
  * written by every evaluation) — if not, the range is dropped, the address is left alone from then on and the call is served through
- * the pinned block as for any unregistered array.  At most six ranges per handle (the oldest goes first); all are released by
- * hipnlp_destroy or hipnlp_set_auto_register(h, 0).  Arrays registered explicitly with hipnlp_host_register are the caller's
- * responsibility and are not verified. */
+ * the pinned block as for any unregistered array.  The check covers every pointer into a range that ANY handle of the process registered
+ * by itself (the table of ranges is process wide).  At most six ranges per handle (the oldest one that the call in progress does not use
+ * goes first); all are released by hipnlp_destroy or hipnlp_set_auto_register(h, 0).  Arrays registered explicitly with
+ * hipnlp_host_register are the caller's responsibility and are not verified; registering an array a handle had registered by itself
+ * replaces that registration with a fresh one. */
 int hipnlp_set_auto_register(hipnlp_handle* h, int on);
 /* Counters of the host-buffer path: out[0] arrays auto-registered so far, out[1] stale-mapping fallbacks, out[2] ranges currently
- * auto-registered, out[3] evaluations so far (kernel launches), out[4..7] reserved (0). */
+ * auto-registered, out[3] evaluations so far (kernel launches), out[4] caller arrays filled with the constant Jacobian entries so far,
+ * out[5] of which re-fills after a failed spot check, out[6] constant entries of the handle's pattern, out[7] reserved (0). */
 int hipnlp_host_stats(const hipnlp_handle* h, long* out /*[8]*/);
 
 

@@ -28,6 +28,13 @@
 
 #ifdef HIPNLP_IPOPT_WITH_IPOPT_HEADER
 #include <IpStdCInterface.h>
+/* the callbacks below return and take Bool as an int-sized value (IPOPT <= 3.13: typedef int Bool; 3.14: typedef int Bool unless
+ * built otherwise): a build whose Bool has another size must not bind them silently ("IPOPT builds whose Bool is bool") */
+#if defined(__cplusplus)
+static_assert(sizeof(Bool) == sizeof(int), "hipnlp_ipopt.h: this IPOPT build's Bool is not int-sized; see INTEGRATION.md");
+#else
+_Static_assert(sizeof(Bool) == sizeof(int), "hipnlp_ipopt.h: this IPOPT build's Bool is not int-sized; see INTEGRATION.md");
+#endif
 #else
 typedef double Number;       /* IpStdCInterface.h: typedef ipnumber Number;  IpTypes.h: typedef double ipnumber */
 typedef int Index;           /* IpStdCInterface.h: typedef ipindex Index;    IpTypes.h: typedef int ipindex     */
@@ -66,13 +73,25 @@ int hipnlp_ipopt_sizes(hipnlp_handle* h, Index* n, Index* m, Index* nele_jac, In
 /* Bounds in IPOPT's convention: an infinite bound is -/+ 2e19 (beyond nlp_lower_bound_inf / nlp_upper_bound_inf = -/+ 1e19).
  * Valid after hipnlp_set_params.  Any pointer may be NULL. */
 int hipnlp_ipopt_bounds(hipnlp_handle* h, Number* x_L, Number* x_U, Number* g_L, Number* g_U);
-/* Optional, around IpoptSolve: attach turns on what suits IPOPT's call pattern — early outputs for g and jac g (the first callback at a
- * new x fills the arrays the later eval_g / eval_jac_g will pass — the TNLPAdapter's own full_g_ / jac_g_ buffers: one transfer per
- * iterate; grad f is never written early: its destination is IPOPT's own gradient vector) and auto-registration of IPOPT's arrays;
- * detach turns early outputs off and releases the registrations (call it before the arrays IPOPT owned are freed, i.e. before
- * FreeIpoptProblem). */
+/* Optional, around IpoptSolve.  attach: auto-registration of IPOPT's arrays (the g / jac-value buffers of the TNLPAdapter and the
+ * gradient vector become direct kernel outputs at their second sight, verified at every use) and NOTHING that writes into an array
+ * before IPOPT hands it to a callback: eval_f at a new x brings f, grad f and g to the library's pinned block (eval_g / eval_grad_f at
+ * that x are host copies), eval_jac_g with new_x = FALSE fetches the Jacobian from HBM into IPOPT's array — only its varying entries
+ * when the handle was created with HIPNLP_FLAG_JAC_VARYING_FIRST (recommended for IPOPT: triplets may come in any order).
+ * detach releases the registrations (call it before the arrays IPOPT owned are freed, i.e. before FreeIpoptProblem). */
 int hipnlp_ipopt_attach(hipnlp_handle* h);
 int hipnlp_ipopt_detach(hipnlp_handle* h);
+/* Early outputs for g and jac g (hipnlp_set_early_outputs(h, 1)) — OPT-IN, off after attach.  The first callback at a new x then also
+ * fills the arrays earlier eval_g / eval_jac_g calls passed: one PCIe transfer per iterate instead of two (47 against 70 us per
+ * 100-knot iterate).  It rests on an ASSUMPTION about IPOPT that this repository could not test (IPOPT is not in its
+ * image; only a C replay of the documented call order was run): that the adapter's g / jac buffers are scratch between callbacks.
+ * IPOPT's TNLPAdapter keeps them as CACHES keyed by the tag of x (x_tag_for_g_, x_tag_for_jac_g_): Eval_c and Eval_d (Eval_jac_c and
+ * Eval_jac_d) of one x share one evaluation.  If a build of IPOPT evaluates another point between the two — eval_f at a trial point
+ * between Eval_c(x1) and Eval_d(x1) — the early store has replaced the cached values and IPOPT would use g or jac g of the wrong point
+ * without any error.  Turn this on only after checking the iterates against a run with it off on the IPOPT build at hand (identical
+ * iterates = the interleaving does not occur there, including restoration and watchdog phases).  grad f is never written early: its
+ * destination is IPOPT's own gradient vector. */
+int hipnlp_ipopt_set_early_outputs(hipnlp_handle* h, int on);
 
 #ifdef __cplusplus
 }

@@ -195,7 +195,7 @@ hostemu_handle* hostemu_create(const hipnlp_desc* desc, char* err, int errlen) {
     hostemu_handle* h = new hostemu_handle();
     h->d = *desc;
     std::string e;
-    if (!Layout::make_kin_tables(desc->model, h->kt, e) || !h->L.build(desc->settings, h->kt, (desc->flags & HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS) != 0)) {
+    if (!Layout::make_kin_tables(desc->model, h->kt, e) || !h->L.build(desc->settings, h->kt, (desc->flags & HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS) != 0, (desc->flags & HIPNLP_FLAG_JAC_VARYING_FIRST) != 0)) {
         if (e.empty()) e = h->L.error;
         std::strncpy(err, e.c_str(), size_t(errlen - 1));
         delete h;
@@ -269,6 +269,26 @@ void hostemu_hess(const hostemu_handle* h, const double* x, const double* p, dou
 void hostemu_dims(const hostemu_handle* h, int* n, int* m, int* nnz) { *n = h->L.n; *m = h->L.m; *nnz = h->L.nnz; }
 void hostemu_sparsity(const hostemu_handle* h, int* irow, int* jcol) {
     for (int i = 0; i < h->L.nnz; ++i) { irow[i] = h->L.irow[size_t(i)]; jcol[i] = h->L.jcol[size_t(i)]; }
+}
+// constant entries of jac g: the mask in pattern order and — what hipnlp_set_params + the host path do — an array [nnz] holding the
+// constants under the parameters p at their positions, a poison value everywhere else
+void hostemu_constant_mask(const hostemu_handle* h, unsigned char* mask) { h->L.constant_mask(mask); }
+void hostemu_constant_fill(const hostemu_handle* h, const double* p, double poison, double* jac) {
+    const Layout& L = h->L;
+    std::vector<double> pk(size_t(L.N) * PK_STRIDE), cval(js::COUNT);
+    GParams gp;
+    pack_params(p, L.N, pk.data(), gp);
+    Layout::constant_values(h->d.settings, h->kt, gp, cval.data());
+    for (int i = 0; i < L.nnz; ++i) jac[i] = poison;
+    for (int k = 0; k < L.N; ++k) {
+        const int v = L.variant_of(k);
+        for (int i = 0; i < L.nnz_v[v]; ++i) if (L.jconst_pos[v][size_t(i)]) jac[L.jac_base(k) + i] = cval[size_t(L.jperm[v][size_t(i)])];
+    }
+    for (size_t i = 0; i < L.jperm_glob.size(); ++i) jac[L.jac_glob_base + long(i)] = cval[size_t(L.jperm_glob[i])];
+}
+void hostemu_vary_counts(const hostemu_handle* h, int* nvary /*[3]*/, int* nnz_v /*[3]*/, int* nconst_total) {
+    for (int v = 0; v < 3; ++v) { nvary[v] = h->L.nvary_v[v]; nnz_v[v] = h->L.nnz_v[v]; }
+    *nconst_total = h->L.nconst_total;
 }
 void hostemu_bounds(const hostemu_handle* h, const double* p, double* lbg, double* ubg) { h->L.bounds(p, nullptr, nullptr, lbg, ubg); }
 void hostemu_bounds_x(const hostemu_handle* h, const double* p, double* lbx, double* ubx) { h->L.bounds(p, lbx, ubx, nullptr, nullptr); }

@@ -29,7 +29,7 @@ def _ip(a):
 
 
 class HostEmu:
-    def __init__(self, settings, model, detect_simple_bounds=False):
+    def __init__(self, settings, model, detect_simple_bounds=False, jac_varying_first=False):
         self.lib = C.CDLL(build())
         self.lib.hostemu_create.restype = C.c_void_p
         self.desc = _abi.DescC()
@@ -37,7 +37,7 @@ class HostEmu:
         self.desc.model = model.to_c()
         self.desc.batch = 1
         self.desc.knot_begin, self.desc.knot_end = 0, settings.horizon_length
-        self.desc.flags = _abi.FLAG_DETECT_SIMPLE_BOUNDS if detect_simple_bounds else 0
+        self.desc.flags = (_abi.FLAG_DETECT_SIMPLE_BOUNDS if detect_simple_bounds else 0) | (_abi.FLAG_JAC_VARYING_FIRST if jac_varying_first else 0)
         err = C.create_string_buffer(256)
         self.h = self.lib.hostemu_create(C.byref(self.desc), err, 256)
         if not self.h:
@@ -50,6 +50,25 @@ class HostEmu:
         ir, jc = np.zeros(self.nnz, np.int32), np.zeros(self.nnz, np.int32)
         self.lib.hostemu_sparsity(C.c_void_p(self.h), _ip(ir), _ip(jc))
         return ir, jc
+
+    def constant_mask(self):
+        """bool [nnz] in pattern order: entries of jac g that do not depend on x (emit_jc in knot_body.h)"""
+        mask = np.zeros(self.nnz, np.uint8)
+        self.lib.hostemu_constant_mask(C.c_void_p(self.h), mask.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        return mask.astype(bool)
+
+    def constant_fill(self, p, poison=np.nan):
+        """[nnz]: the constant entries under the parameters p at their positions (what the library fills a host destination with),
+        `poison` everywhere else"""
+        out = np.zeros(self.nnz)
+        self.lib.hostemu_constant_fill(C.c_void_p(self.h), _dp(np.ascontiguousarray(p, dtype=np.float64)), C.c_double(poison), _dp(out))
+        return out
+
+    def vary_counts(self):
+        """(varying entries, all entries) of a first / interior / last knot block, constant entries of the whole pattern"""
+        a, b, c = (C.c_int * 3)(), (C.c_int * 3)(), C.c_int()
+        self.lib.hostemu_vary_counts(C.c_void_p(self.h), a, b, C.byref(c))
+        return list(a), list(b), c.value
 
     def bounds(self, p):
         lb, ub = np.zeros(self.m), np.zeros(self.m)

@@ -106,7 +106,10 @@ int main(int argc, char** argv) {
         record(7, -1, ok, 2 * (n + m), b);
         free(b);
     }
+    /* attach: 0 = plain handle, 1 = hipnlp_ipopt_attach (nothing is written into an array before IPOPT hands it to a callback),
+     * 2 = attach + the opt-in early outputs for g and jac g */
     if (attach && hipnlp_ipopt_attach(h) != HIPNLP_OK) { fprintf(stderr, "attach: %s\n", hipnlp_last_error(h)); return 1; }
+    if (attach == 2 && hipnlp_ipopt_set_early_outputs(h, 1) != HIPNLP_OK) { fprintf(stderr, "early outputs: %s\n", hipnlp_last_error(h)); return 1; }
 
     /* structure calls: values == NULL, x == NULL */
     record_indices(5, eval_jac_g(n, NULL, FALSE, m, nele_jac, iRow, jCol, NULL, ud), nele_jac, iRow, jCol);
@@ -119,6 +122,12 @@ int main(int argc, char** argv) {
      * evaluation of trial points untouched (no early output may land in it) */
     double* grad_kept = (double*)must(malloc(sizeof(double) * (size_t)n));
     const double* grad_current = NULL;
+    /* The TNLPAdapter keeps its g / jac-value buffers as CACHES keyed by the tag of x (Eval_c and Eval_d of one x share one
+     * evaluation): unless the early outputs were asked for, a callback at ANOTHER x must leave both buffers as their own callbacks
+     * filled them */
+    double* g_kept = (double*)must(malloc(sizeof(double) * (size_t)m));
+    double* jac_kept = (double*)must(malloc(sizeof(double) * (size_t)nele_jac));
+    int g_valid = 0, jac_valid = 0;
     for (int i = 0; i < points; ++i) {
         double* x = xs + (size_t)i * (size_t)n;
         double f = 0.0;
@@ -127,13 +136,21 @@ int main(int argc, char** argv) {
             ok = eval_grad_f(n, x, TRUE, grad[0], ud);  record(1, i, ok, n, grad[0]);
             grad_current = grad[0];  memcpy(grad_kept, grad[0], sizeof(double) * (size_t)n);
             ok = eval_jac_g(n, x, FALSE, m, nele_jac, NULL, NULL, jac, ud);  record(3, i, ok, nele_jac, jac);
+            memcpy(jac_kept, jac, sizeof(double) * (size_t)nele_jac);  jac_valid = 1;
             ok = eval_f(n, x, FALSE, &f, ud);  record(0, i, ok, 1, &f);
             ok = eval_g(n, x, FALSE, m, g, ud);  record(2, i, ok, m, g);
+            memcpy(g_kept, g, sizeof(double) * (size_t)m);  g_valid = 1;
             ok = eval_h(n, x, FALSE, obj_factor, m, lambda, TRUE, nele_hess, NULL, NULL, hess, ud);  record(4, i, ok, nele_hess, hess);
             continue;
         }
         ok = eval_f(n, x, TRUE, &f, ud);  record(0, i, ok, 1, &f);                 /* a line-search trial point */
+        if (attach != 2 && ((g_valid && memcmp(g, g_kept, sizeof(double) * (size_t)m) != 0) ||
+                            (jac_valid && memcmp(jac, jac_kept, sizeof(double) * (size_t)nele_jac) != 0))) {
+            fprintf(stderr, "eval_f at point %d wrote into the g / jac buffers of the previous point (no early outputs were asked for)\n", i);
+            return 1;
+        }
         ok = eval_g(n, x, FALSE, m, g, ud);  record(2, i, ok, m, g);
+        memcpy(g_kept, g, sizeof(double) * (size_t)m);  g_valid = 1;
         if (grad_current && memcmp(grad_current, grad_kept, sizeof(double) * (size_t)n) != 0) {
             fprintf(stderr, "the gradient vector of the current iterate was overwritten while trial point %d was evaluated\n", i);
             return 1;
@@ -142,6 +159,7 @@ int main(int argc, char** argv) {
         ok = eval_grad_f(n, x, FALSE, grad[i & 1], ud);  record(1, i, ok, n, grad[i & 1]);
         grad_current = grad[i & 1];  memcpy(grad_kept, grad[i & 1], sizeof(double) * (size_t)n);
         ok = eval_jac_g(n, x, FALSE, m, nele_jac, NULL, NULL, jac, ud);  record(3, i, ok, nele_jac, jac);
+        memcpy(jac_kept, jac, sizeof(double) * (size_t)nele_jac);  jac_valid = 1;
         if (i % 2 == 0) { ok = eval_h(n, x, FALSE, obj_factor, m, lambda, TRUE, nele_hess, NULL, NULL, hess, ud);  record(4, i, ok, nele_hess, hess); }
     }
 
@@ -172,7 +190,8 @@ int main(int argc, char** argv) {
         long stats[8];
         hipnlp_host_stats(h, stats);
         printf("{\"ipopt_iterate_four_c_calls_us\": %.2f, \"trial_point_two_c_calls_us\": %.2f, \"attach\": %d, "
-               "\"auto_registered\": %ld, \"evaluations\": %ld}\n", best, trial, attach, stats[0], stats[3]);
+               "\"auto_registered\": %ld, \"evaluations\": %ld, \"constant_fills\": %ld, \"constant_refills\": %ld, \"constant_entries\": %ld}\n",
+               best, trial, attach, stats[0], stats[3], stats[4], stats[5], stats[6]);
     }
     if (attach) hipnlp_ipopt_detach(h);
     fclose(out);

@@ -1,0 +1,199 @@
+"""The constant entries of jac g on the host path (hipnlp_set_constant_jacobian, HIPNLP_FLAG_JAC_VARYING_FIRST), through the C-ABI on
+the GPU, against the CPU oracle: a host destination of the Jacobian is filled with the constants once per parameter set and the kernel
+stores the varying entries only — what the caller reads must be the complete Jacobian, entry by entry, whichever way its array is fed
+(pinned block + copy, registered by the handle, registered by the caller, fetched after the evaluation), after a parameter change, and
+after the caller wrote over its own array."""
+import gc
+
+import numpy as np
+import pytest
+
+from hippopt_amd.kinodyn_settings import periodic_step_settings, stairs_settings
+from hippopt_amd.synthetic import make_workload, place_on_step_flanks
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-11
+
+
+@pytest.fixture(scope="module")
+def HipNlp():
+    from hippopt_amd.hipnlp import HipNlp as cls
+    return cls
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+def iterates(x, count, seed=3):
+    rng = np.random.RandomState(seed)
+    return [x + 1e-3 * i * rng.standard_normal(x.shape) for i in range(count)]
+
+
+def by_entry(eng, values):
+    ir, jc = eng.sparsity()
+    return {(int(r), int(c)): v for r, c, v in zip(ir, jc, values)}
+
+
+def test_every_way_of_feeding_the_callers_array_gives_the_oracles_jacobian(model, HipNlp):
+    from oracle_lib import Oracle
+    st = periodic_step_settings(45, model)           # (grad f, g and jac g all reach the 64 KB the handle registers by itself)
+    x, p = make_workload(st, model, batch=1, seed=7100)
+    orc = Oracle(st, model)
+    full = HipNlp(st, model)                      # every launch stores every entry: the behaviour before the switch existed
+    full.set_params(p)
+    full.set_constant_jacobian(False)
+    xs = iterates(x, 6)
+    want = [orc.eval(xi[0], p[0]) for xi in xs]
+    mask = full.jac_constant_mask()
+    assert 0.40 < mask.mean() < 0.46 and full.host_stats()["constant_entries"] == int(mask.sum())
+    for vary_first in (False, True):
+        eng = HipNlp(st, model, jac_varying_first=vary_first)
+        eng.set_params(p)
+        ref = by_entry(full, full.eval(xs[0])[3][0])
+        assert by_entry(eng, eng.eval(xs[0])[3][0]) == ref                      # fresh arrays: pinned block + copy, bit for bit
+        order = None
+        if vary_first:
+            ir, jc = eng.sparsity()
+            pos = {(int(r), int(c)): i for i, (r, c) in enumerate(zip(*full.sparsity()))}
+            order = np.array([pos[(int(r), int(c))] for r, c in zip(ir, jc)])
+        out = (np.empty(1), np.empty((1, eng.n)), np.empty((1, eng.m)), np.full((1, eng.nnz), np.nan))
+        for i, xi in enumerate(xs):                                             # the same arrays again and again: registered at the second sight
+            eng.eval(xi, out=out)
+            fo, grado, go, jaco = want[i]
+            jo = jaco if order is None else jaco[order]
+            assert rel(out[0][0], fo) < TOL and rel(out[1][0], grado) < TOL and rel(out[2][0], go) < TOL and rel(out[3][0], jo) < TOL, (vary_first, i)
+            fr = full.eval(xi)
+            assert np.array_equal(out[3][0], fr[3][0] if order is None else fr[3][0][order]), (vary_first, i)
+        stats = eng.host_stats()
+        # (the constants are skipped in the varying-first order only: in CCS order the varying entries are fragments on the link)
+        assert stats["auto_ranges"] == 3 and stats["constant_fills"] == int(vary_first) and stats["constant_refills"] == 0 and stats["auto_fallbacks"] == 0
+        # the caller writes over its own (registered) array: the spot check sees it, the constants come back
+        out[3][:] = 0.0
+        eng.eval(xs[1], out=out)
+        assert rel(out[3][0], want[1][3] if order is None else want[1][3][order]) < TOL
+        assert eng.host_stats()["constant_refills"] == int(vary_first)
+        # IPOPT's order with the Jacobian asked for AFTER its evaluation (new_x = 0): fetched from HBM into the registered array
+        f_, grad_, g_, jac_ = out
+        eng.eval(xs[3], new_x=True, want=("f",), out=(f_, None, None, None))
+        jac_[:] = np.nan
+        eng.eval(xs[3], new_x=False, want=("jac",), out=(None, None, None, jac_))
+        assert rel(jac_[0], want[3][3] if order is None else want[3][3][order]) < TOL
+        # arrays registered by the caller take the same route
+        mine = (np.empty(1), np.empty((1, eng.n)), np.empty((1, eng.m)), np.full((1, eng.nnz), 7.0))
+        eng.register_outputs(mine)
+        try:
+            for i in (4, 5):
+                eng.eval(xs[i], out=mine)
+                assert rel(mine[3][0], want[i][3] if order is None else want[i][3][order]) < TOL
+        finally:
+            eng.unregister_outputs(mine)
+        # the zero-copy views of the pinned block are complete too
+        views = eng.eval_pinned(xs[2])
+        assert rel(views[3][0], want[2][3] if order is None else want[2][3][order]) < TOL
+        eng.close()
+    full.close()
+
+
+def test_constants_follow_set_params(model, HipNlp):
+    """dt and the mass sit in the constant entries: a new parameter set re-fills every destination the handle has filled before"""
+    from oracle_lib import Oracle
+    st = periodic_step_settings(12, model)
+    x, p = make_workload(st, model, batch=1, seed=7200)
+    p2 = p.copy()
+    N = 12
+    p2[0, 24 * N + 3 + 105 + 105] *= 1.6      # dt   (ParamOffsets, layout.h)
+    p2[0, 24 * N] *= 0.85                     # mass
+    orc = Oracle(st, model)
+    eng = HipNlp(st, model, jac_varying_first=True)
+    ir, jc = eng.sparsity()
+    pos = {(int(r), int(c)): i for i, (r, c) in enumerate(zip(*orc.sparsity()))}
+    order = np.array([pos[(int(r), int(c))] for r, c in zip(ir, jc)])
+    big = (np.empty(1), np.empty((1, eng.n)), np.empty((1, eng.m)), np.empty((1, eng.nnz)))
+    eng.register_outputs(big)      # (at 12 knots the arrays are below the 64 KB the handle registers by itself)
+    try:
+        for params in (p, p2, p):
+            eng.set_params(params)
+            for xi in iterates(x, 3):
+                eng.eval(xi, out=big)
+                jo = orc.eval(xi[0], params[0])[3]
+                assert rel(big[3][0], jo[order]) < TOL
+            fresh = eng.eval(x)                       # unregistered: pinned block + copy
+            assert rel(fresh[3][0], orc.eval(x[0], params[0])[3][order]) < TOL
+        assert eng.host_stats()["constant_fills"] == 3 and eng.host_stats()["constant_refills"] == 0
+    finally:
+        eng.unregister_outputs(big)
+    eng.close()
+
+
+def test_batch_with_different_time_steps_and_the_stairs(model, HipNlp):
+    """per-trajectory constants (every trajectory of a batch has its own dt), smooth terrain (HEIGHT / NORMAL entries are no longer
+    constant there), both block orders, against a handle that stores every entry"""
+    st = stairs_settings(9, model)
+    B = 3
+    x, p = make_workload(st, model, batch=B, seed=7300)
+    place_on_step_flanks(x, st, seed=7300)
+    N = 9
+    for b in range(B):
+        p[b, 24 * N + 3 + 105 + 105] *= 1.0 + 0.25 * b
+    full = HipNlp(st, model, batch=B)
+    full.set_params(p)
+    full.set_constant_jacobian(False)
+    want = full.eval(x)
+    for vary_first in (False, True):
+        eng = HipNlp(st, model, batch=B, jac_varying_first=vary_first)
+        eng.set_params(p)
+        out = tuple(np.full_like(w, np.nan) for w in want)
+        eng.register_outputs(out)
+        try:
+            for _ in range(2):
+                eng.eval(x, out=out)
+                for b in range(B):
+                    assert by_entry(eng, out[3][b]) == by_entry(full, want[3][b]), (vary_first, b)
+                assert all(np.array_equal(a, w) for a, w in zip(out[:3], want[:3]))
+        finally:
+            eng.unregister_outputs(out)
+        eng.close()
+    full.close()
+
+
+def test_two_live_handles_and_an_array_address_that_is_reused(model, HipNlp):
+    """the table of registered ranges is process wide.  Handle A registers an array by itself; the array is freed and the
+    allocator hands its address to a new array, which handle B (or A) is given: the registration is of pages that are gone, and the
+    store must be verified whichever handle uses it — the values the caller reads are right, every time.  (Promoted from
+    tools/diag/autoreg_stress.py.)"""
+    st = periodic_step_settings(100, model)
+    x, p = make_workload(st, model, batch=1, seed=7400)
+    ref = HipNlp(st, model)
+    ref.set_params(p)
+    ref.set_auto_register(False)
+    ref.set_constant_jacobian(False)
+    xs = iterates(x, 4)
+    want = [ref.eval(xi) for xi in xs]
+    a, b = HipNlp(st, model), HipNlp(st, model)
+    for e in (a, b):
+        e.set_params(p)
+    reused = fallbacks = 0
+    for cycle in range(12):
+        out = (np.empty(1), np.empty((1, a.n)), np.empty((1, a.m)), np.empty((1, a.nnz)))
+        addr = out[3].ctypes.data
+        for i in range(3):                           # A registers the three arrays at their second sight
+            a.eval(xs[i], out=out)
+            assert all(np.array_equal(u, v) for u, v in zip(out, want[i])), ("A", cycle, i)
+        del out
+        gc.collect()
+        out2 = (np.empty(1), np.empty((1, a.n)), np.empty((1, a.m)), np.empty((1, a.nnz)))   # the allocator may hand the same addresses out again
+        reused += int(out2[3].ctypes.data == addr)
+        user = b if cycle % 2 == 0 else a
+        for i in range(3):
+            user.eval(xs[3 - i], out=out2)
+            assert all(np.array_equal(u, v) for u, v in zip(out2, want[3 - i])), ("second owner", cycle, i)
+        fallbacks = a.host_stats()["auto_fallbacks"] + b.host_stats()["auto_fallbacks"]
+        del out2
+        gc.collect()
+    # (whether the allocator hands an address out again, and whether it does so with the same pages behind it, is its business: what is
+    #  asserted is that the caller read the right values every time; the counters say what happened on this box)
+    print("addresses reused: %d of 12, verified fallbacks: %d" % (reused, fallbacks))
+    a.close()
+    b.close()
+    ref.close()

@@ -31,6 +31,7 @@ def test_caller_arrays_are_registered_at_their_second_sight_and_verified(model, 
     for e in (ref, eng):
         e.set_params(p)
     ref.set_auto_register(False)
+    ref.set_constant_jacobian(False)      # the reference stores every entry of jac g on every launch
     xs = iterates(x, 6)
     out = (np.empty(1), np.empty((1, eng.n)), np.empty((1, eng.m)), np.empty((1, eng.nnz)))
     for i, xi in enumerate(xs):
