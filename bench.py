@@ -705,10 +705,12 @@ def main():
                 "parallelism": "independent trajectories x%d, no collective" % world, "horizon": args.horizon}
 
     # ---- north_star: one trajectory, knot shards, one RCCL all-gather + one-launch reassembly per step ----------------------------
-    def run_knot_sharded(steps, warmup):
+    def run_knot_sharded(steps, warmup, total_horizon=None, legs=("shard_resident", "peer_store", "peer_direct", "gather_to_root", "host_sink")):
+        """total_horizon: knots of the ONE trajectory cut over the ranks (default: args.horizon per rank — the horizon grows with the
+        world, weak scaling); legs: which exchanges are timed beside the all-gather"""
         from hippopt_amd.sharded import HostSink, ShardedCallback, hip_shard_backend, hip_shard_info, knot_range
         assert args.batch == 1, "knot sharding evaluates one trajectory"
-        hz = args.horizon * world
+        hz = total_horizon or args.horizon * world
         st, x_np, p_np, xs = workload(hz, 1, 1004)   # the SAME trajectory on every rank
         kb, ke = knot_range(hz, world, rank)
         eng = HipNlp(st, model, batch=1, knot_begin=kb, knot_end=ke, device=local_rank)
@@ -724,7 +726,8 @@ def main():
                "parallelism": "knot-sharded x%d (contiguous shooting intervals) + one RCCL all-gather + one-launch reassembly" % world}
         # beside it: the shards evaluated and left in each rank's HBM (what the exchange costs on top)
         ksteps = max(1, min(steps, 1000))
-        with torch.cuda.stream(cb.stream):
+        if "shard_resident" in legs:
+          with torch.cuda.stream(cb.stream):
             for i in range(min(warmup, 50)):
                 cb.shard_only(xs[i % nvar])
             fence()
@@ -733,8 +736,8 @@ def main():
                 cb.shard_only(xs[i % nvar])
             fence()
             e2 = max_over_ranks(time.perf_counter() - t1)
-        res["shard_resident"] = {"knots_per_s": hz * ksteps / e2, "ms_per_step": 1e3 * e2 / ksteps, "steps": ksteps,
-                                 "note": "knot shards evaluated, outputs left shard-resident in each rank's HBM (no all-gather / reassembly)"}
+          res["shard_resident"] = {"knots_per_s": hz * ksteps / e2, "ms_per_step": 1e3 * e2 / ksteps, "steps": ksteps,
+                                   "note": "knot shards evaluated, outputs left shard-resident in each rank's HBM (no all-gather / reassembly)"}
         # the same reassembled outputs on every rank by peer stores over xGMI instead of all-gather + reassembly (sharded.PeerExchange):
         # `peer_store` pushes the fused shard buffer with one kernel behind the shard evaluation, `peer_direct` lets the knot kernel
         # itself store into every rank's buffer (hipnlp_eval_device_peers).  Each is checked bit for bit against the collective's
@@ -805,28 +808,30 @@ def main():
                 fence()
                 e4 = max_over_ranks(time.perf_counter() - t1)
             late = px.timed_out()
-            sent = px.bytes_sent_per_step()
+            sent = px.max_bytes_sent_per_step()    # (the busiest sender: rank 0 of a gather_to_root sends nothing, which says nothing)
             fence()                      # every rank's pushes are complete: the buffers can go without another collective
             px.close(barrier=False)
             if not agree_all(ok):
                 return None, {"error": err_text or "a launch of the timed loop failed on another rank"}
             return e4, {"knots_per_s": hz * steps / e4, "ms_per_step": 1e3 * e4 / steps, "steps": steps, "timed_out": bool(late),
-                        "bytes_sent_per_rank_per_step": int(sent),
+                        "bytes_sent_per_rank_per_step": int(sent), "bytes_sent_per_rank_per_step_is": "the maximum over the ranks",
                         "verified": "bitwise equal to the all-gather path on every rank that holds outputs, both buffer parities; "
                                     "one-word handshake with every peer at set-up", "note": note}
 
-        e_ps, res["peer_store"] = time_peer(None, "no collective, no reassembly pass: every rank pushes its shard, entry by entry at its final position, into "
-                                                  "the [grad | jac | g | f] buffer of EVERY rank with plain stores over xGMI (HIP IPC), then flags")
-        e_pd = None
-        if eng.kernels_per_eval() == 1:
+        e_ps = e_pd = None
+        if "peer_store" in legs:
+            e_ps, res["peer_store"] = time_peer(None, "no collective, no reassembly pass: every rank pushes its shard, entry by entry at its final position, into "
+                                                      "the [grad | jac | g | f] buffer of EVERY rank with plain stores over xGMI (HIP IPC), then flags")
+        if "peer_direct" in legs and eng.kernels_per_eval() == 1:
             e_pd, res["peer_direct"] = time_peer(eng, "as peer_store with the push folded into the evaluation: the knot kernel stores the shard's entries "
                                                       "at their final positions into every rank's buffer (hipnlp_eval_device_peers); three launches per step")
         # gather_to_root: IPOPT is ONE consumer (rank 0's process): every rank stores its shard into rank 0's buffer only — 1 / world of
         # the all-gather's bytes per link — and rank 0 tells the others when a step has been consumed (sharded.PeerExchange(root_only))
-        e_gr, res["gather_to_root"] = time_peer(eng if eng.kernels_per_eval() == 1 else None,
-                                                "only rank 0 receives [grad | jac | g | f]: every rank's knot kernel stores its shard straight into rank 0's buffer "
-                                                "over its own xGMI link (HIP IPC), rank 0 waits for all flags and signals back; the other ranks hold no outputs",
-                                                root_only=True)
+        if "gather_to_root" in legs:
+          e_gr, res["gather_to_root"] = time_peer(eng if eng.kernels_per_eval() == 1 else None,
+                                                  "only rank 0 receives [grad | jac | g | f]: every rank's knot kernel stores its shard straight into rank 0's buffer "
+                                                  "over its own xGMI link (HIP IPC), rank 0 waits for all flags and signals back (a rank is at most one step ahead of "
+                                                  "the consumer); the other ranks hold no outputs", root_only=True)
         # `value` is the step of north_star's path — knot shards evaluated, [grad | jac | g | f] of the WHOLE trajectory on every rank.
         # It is the RCCL all-gather path unless a peer exchange is faster AND has been verified bit for bit in THIS run with every rank
         # on a device of its own (a rehearsal with several ranks on one device exercises neither xGMI nor cross-device visibility and
@@ -843,11 +848,13 @@ def main():
         labels = {"peer_store": "peer stores over xGMI into every rank's output buffer (HIP IPC; no collective, no reassembly pass)",
                   "peer_direct": "the knot kernel storing straight into every rank's output buffer over xGMI (HIP IPC; no collective, no push or reassembly pass)"}
         for name, e in (("peer_store", e_ps), ("peer_direct", e_pd)):
-            if distinct and e is not None and not res[name]["timed_out"] and e < res["el"]:
+            if distinct and e is not None and name in res and not res[name].get("timed_out", True) and e < res["el"]:
                 res["el"] = e
                 res["exchange"] = name
                 res["parallelism"] = "knot-sharded x%d (contiguous shooting intervals) + %s" % (world, labels[name])
         # beside it: no collective, every rank's kernel stores its shard straight into ONE shared pinned host buffer
+        if "host_sink" not in legs:
+            return res
         try:
             name = "hipnlp_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid() if world > 1 else os.getpid())
             def agree(ok):
@@ -880,6 +887,154 @@ def main():
             res["host_sink"] = {"error": "%s: %s" % (type(err).__name__, err)}
         return res
 
+    # ---- BASELINE config 5 in its multi-GPU form: stairs N = 200, 16 batched initial guesses DEALT over the ranks, outputs on rank 0 ----
+    def run_config5(steps, warmup):
+        from hippopt_amd.kinodyn_settings import stairs_settings as stairs
+        from hippopt_amd.sharded import BatchDealtCallback, BatchPeerToRoot, batch_range, hip_batch_backend
+        N5, B5 = 200, 16
+        st = stairs(N5, model)
+        x1, p1 = make_workload(st, model, batch=1, seed=1004)
+        place_on_step_flanks(x1, st, seed=1004)
+        x_all = x1 + 0.02 * np.random.RandomState(1005).standard_normal((B5, x1.shape[1]))
+        x_all[0] = x1[0]
+        cols = (189 * np.arange(N5)[:, None] + np.array([15 * c + 6 + i for c in range(8) for i in range(3)] + [180, 181])[None, :]).reshape(-1)
+        x_all[:, cols] = x1[0, cols][None, :] + 1e-3 * np.random.RandomState(1006).standard_normal((B5, cols.size))   # (on the flanks of the bumps)
+        p_all = np.tile(p1, (B5, 1))
+        out = {"workload": "kinodynamic walking on stairs, N = 200 knots x 16 initial guesses (BASELINE configs[4]), the 16 trajectories dealt over the ranks "
+                           "(16 / %d per rank, one batched launch each), every trajectory's f, grad f, g, jac g delivered to rank 0" % world,
+               "scaling": "strong (the job is the 16 trajectories whatever the number of GPUs)", "ranks": world}
+        # the whole job on ONE GPU, measured on every rank at once (each evaluates all 16 trajectories by itself): the reference figure
+        full = HipNlp(st, model, batch=B5, device=local_rank)
+        full.set_params(p_all)
+        with torch.cuda.stream(work_stream):
+            xd = [torch.from_numpy(x_all + 1e-3 * i * np.random.RandomState(7).standard_normal(x_all.shape)).to(device) for i in range(2)]
+            o = [torch.empty(B5 * k, dtype=torch.float64, device=device) for k in (1, full.n, full.m, full.nnz)]
+        work_stream.synchronize()
+        ptrs = [t.data_ptr() for t in o]
+        for i in range(warmup):
+            full.eval_device(xd[i % 2].data_ptr(), *ptrs, stream=work_stream.cuda_stream)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            full.eval_device(xd[i % 2].data_ptr(), *ptrs, stream=work_stream.cuda_stream)
+        fence()
+        e1 = max_over_ranks(time.perf_counter() - t0)
+        one = N5 * B5 * steps / e1
+        out["one_gpu_whole_job"] = {"knots_per_s": one, "ms_per_step": 1e3 * e1 / steps, "steps": steps,
+                                    "note": "all 16 trajectories in one launch on one GPU, outputs left in its HBM (every rank measured this at the same time: the slowest)"}
+        ref_out = [t.clone() for t in o]   # (of xd[(steps - 1) % 2]; re-evaluated below for the comparison)
+        full.eval_device(xd[0].data_ptr(), *ptrs, stream=work_stream.cuda_stream)
+        work_stream.synchronize()
+        ref_out = [t.clone() for t in o]
+        full.close()
+        b0, b1 = batch_range(B5, world, rank)
+        eng = HipNlp(st, model, batch=b1 - b0, device=local_rank)
+        eng.set_params(p_all[b0:b1])
+        bc = BatchDealtCallback(B5, eng.n, eng.m, eng.nnz, hip_batch_backend(eng), device)
+        with torch.cuda.stream(bc.stream):
+            xl = [t[b0:b1].contiguous() for t in xd]
+        bc.stream.synchronize()
+
+        def agree_all(ok):
+            if world == 1:
+                return bool(ok)
+            oks = [None] * world
+            dist.all_gather_object(oks, bool(ok))
+            return all(oks)
+
+        def check(gathered):
+            """rank 0: every trajectory's outputs against the one-GPU evaluation of the whole batch (bitwise: the same kernel on the same inputs)"""
+            if rank != 0:
+                return True
+            rf, rgrad, rg, rjac = ref_out[0], ref_out[1].view(B5, -1), ref_out[2].view(B5, -1), ref_out[3].view(B5, -1)
+            for b in range(B5):
+                f, grad, g, jac = bc.trajectory(b, gathered)
+                if not (torch.equal(f, rf[b]) and torch.equal(grad, rgrad[b]) and torch.equal(g, rg[b]) and torch.equal(jac, rjac[b])):
+                    return False
+            return True
+
+        def timed(step_fn, note, sent, close=None):
+            ok, why = True, None
+            with torch.cuda.stream(bc.stream):
+                try:
+                    got = step_fn(xl[0])
+                    bc.stream.synchronize()
+                    ok = check(got.all if isinstance(got, BatchDealtCallback) else got) if got is not None else True
+                    if not ok:
+                        why = "rank 0: a trajectory differs from the one-GPU evaluation"
+                except Exception as err:  # noqa: BLE001
+                    ok, why = False, "%s: %s" % (type(err).__name__, err)
+            if not agree_all(ok):
+                whys = [why]
+                if world > 1:
+                    whys = [None] * world
+                    dist.all_gather_object(whys, why)
+                return {"error": "; ".join(w for w in whys if w) or "failed on some rank"}
+            with torch.cuda.stream(bc.stream):
+                for i in range(warmup):
+                    step_fn(xl[i % 2])
+                fence()
+                t1 = time.perf_counter()
+                for i in range(steps):
+                    step_fn(xl[i % 2])
+                fence()
+                e = max_over_ranks(time.perf_counter() - t1)
+            rate = N5 * B5 * steps / e
+            shared = REHEARSAL or world == 1
+            return {"knots_per_s": rate, "ms_per_step": 1e3 * e / steps, "steps": steps, "bytes_sent_per_rank_per_step": int(sent),
+                    "bytes_sent_per_rank_per_step_is": "the maximum over the ranks",
+                    "speedup_vs_one_gpu": None if shared else rate / one, "efficiency_vs_one_gpu": None if shared else rate / one / world,
+                    "verified": "every trajectory on rank 0 bitwise equal to the one-GPU evaluation of the whole batch", "note": note}
+
+        out["local_only"] = None
+        with torch.cuda.stream(bc.stream):
+            for i in range(warmup):
+                bc.local_only(xl[i % 2])
+            fence()
+            t1 = time.perf_counter()
+            for i in range(steps):
+                bc.local_only(xl[i % 2])
+            fence()
+            e = max_over_ranks(time.perf_counter() - t1)
+        out["local_only"] = {"knots_per_s": N5 * B5 * steps / e, "ms_per_step": 1e3 * e / steps, "steps": steps,
+                             "note": "every rank evaluates its %d trajectories, outputs left in its own HBM (what the delivery to rank 0 costs on top)" % (b1 - b0)}
+        out["rccl_gather"] = timed(bc.to_root, "ONE collective per step: dist.gather of the ranks' fused [f | grad | g | jac] buffers to rank 0 (RCCL over xGMI; "
+                                               "every trajectory's outputs are contiguous pieces of its rank's buffer: no reassembly pass)", bc.max_bytes_sent_per_step())
+        px = None
+        try:
+            px = BatchPeerToRoot(bc, eng)
+        except Exception as err:  # noqa: BLE001  (agreed on collectively inside the constructor)
+            out["peer_direct_to_root"] = {"error": "%s: %s" % (type(err).__name__, err)}
+        if px is not None:
+            out["peer_direct_to_root"] = timed(px, "no collective: every rank's batched knot kernel stores its trajectories' outputs straight into its piece of rank 0's "
+                                                   "buffer over its own xGMI link (HIP IPC), flags as in gather_to_root", px.max_bytes_sent_per_step())
+            late = px.timed_out()
+            fence()
+            px.close(barrier=False)
+            if isinstance(out["peer_direct_to_root"], dict) and "knots_per_s" in out["peer_direct_to_root"]:
+                out["peer_direct_to_root"]["timed_out"] = bool(late)
+        eng.close()
+        return out
+
+    # ---- BASELINE config 4 in its multi-GPU form: ONE periodic N = 100 trajectory cut over the ranks (strong scaling) ----------------
+    def run_config4_strong(steps, warmup, one_gpu_rate):
+        r = run_knot_sharded(steps, warmup, total_horizon=args.horizon, legs=("gather_to_root", "peer_direct"))
+        shared = REHEARSAL or world == 1
+        out = {"workload": "kinodynamic periodic walking, ONE trajectory of N = %d knots cut over the ranks (BASELINE configs[3]: %d knots per rank), "
+                           "[grad f | jac g | g | f] of the whole trajectory delivered every step" % (args.horizon, args.horizon // world),
+               "scaling": "strong (the job is the %d knots whatever the number of GPUs)" % args.horizon, "ranks": world,
+               "one_gpu_whole_trajectory_knots_per_s": one_gpu_rate,
+               "expectation": "below 1: a 100-knot callback is 8 us of one GPU; cut over N GPUs every step still pays launches and an exchange of the same 1.47 MB"}
+        for key in ("all_gather", "gather_to_root", "peer_direct"):
+            leg = r.get(key)
+            if isinstance(leg, dict) and "knots_per_s" in leg:
+                leg = dict(leg)
+                leg["speedup_vs_one_gpu"] = None if shared or not one_gpu_rate else leg["knots_per_s"] / one_gpu_rate
+                leg["efficiency_vs_one_gpu"] = None if shared or not one_gpu_rate else leg["knots_per_s"] / one_gpu_rate / world
+            out[key] = leg
+        r["eng"].close()
+        return out
+
     if knot_sharded_value:
         main_res = run_knot_sharded(args.steps, args.warmup)
         side = None
@@ -893,11 +1048,27 @@ def main():
                 for key in ("all_gather", "peer_store", "peer_direct", "gather_to_root", "host_sink", "shard_resident"):
                     leg = main_res.get(key)
                     if isinstance(leg, dict) and "knots_per_s" in leg:
-                        leg["efficiency_vs_n_independent_gpus"] = leg["knots_per_s"] / side["knots_per_s"]
+                        # (ranks that share a device — a rehearsal — time-slice it: the ratio would mean nothing)
+                        leg["efficiency_vs_n_independent_gpus"] = None if REHEARSAL else leg["knots_per_s"] / side["knots_per_s"]
                 side["efficiency_definition"] = ("knots_per_s(leg, N ranks) / knots_per_s(N independent 100-knot callbacks, one per GPU, this run) = "
                                                  "knots_per_s(N) / (N x knots_per_s(1))")
             except Exception as err:  # noqa: BLE001
                 side = {"error": "%s: %s" % (type(err).__name__, err)}
+            # the two configurations BASELINE names in their multi-GPU form, beside `value` (args.workload periodic only: config 4 is periodic)
+            extra = {}
+            ksteps = max(1, min(args.steps, 200))
+            if args.workload == "periodic":
+                one_rate = (side["knots_per_s"] / world) if isinstance(side, dict) and "knots_per_s" in side else None
+                for key, fn in (("config4_strong", lambda: run_config4_strong(ksteps, min(args.warmup, 50), one_rate)),
+                                ("config5", lambda: run_config5(ksteps, min(args.warmup, 20)))):
+                    if 16 % world != 0 and key == "config5":
+                        extra[key] = {"error": "16 trajectories cannot be dealt evenly over %d ranks" % world}
+                        continue
+                    try:
+                        extra[key] = fn()
+                    except Exception as err:  # noqa: BLE001  (reported; a rank-local failure inside is agreed on collectively before anybody leaves)
+                        extra[key] = {"error": "%s: %s" % (type(err).__name__, err)}
+            main_res["extra_legs"] = extra
     else:
         main_res = run_replicas(args.steps, args.warmup)
         side = None
@@ -992,6 +1163,8 @@ def main():
                 line[key] = main_res[key]
         if side is not None:
             line["independent_trajectories" if knot_sharded_value else "knot_sharded_allgather"] = side
+        for key, val in (main_res.get("extra_legs") or {}).items():
+            line[key] = val
         solo = world == 1 and not knot_sharded_value
         if solo and not args.no_host:
             try:

@@ -225,8 +225,9 @@ class PeerExchange:
         """root_only: `gather_to_root` — only rank 0 (the process IPOPT lives in: ONE consumer) receives the reassembled outputs.
         Every rank pushes its shard into rank 0's buffer alone: 1 / world of the all-gather's bytes per link, and rank 0's seven
         links carry one shard each in parallel.  Rank 0 waits for all `world` flags as before and then stores the step number into
-        every rank's back-flag slot; a rank does not push step i + 2 (same buffer parity as step i) before it has seen rank 0's
-        back-flag for step i, so no rank runs ahead of the consumer by more than the two parities.  The other ranks get (None, ...)."""
+        every rank's back-flag slot; a rank does not push step i + 1 before it has seen rank 0's back-flag for step i (raised in rank
+        0's stream behind its consumption of step i - 1, whose buffer parity step i + 1 reuses), so no rank runs ahead of the consumer
+        by more than one step.  The other ranks get (None, ...)."""
         import ctypes as C
         if cb.device.type != "cuda":
             raise RuntimeError("PeerExchange needs the HIP engine (peer stores between device buffers)")
@@ -363,9 +364,13 @@ class PeerExchange:
             rc = 0
             targets = self.root_out[par] if self.root_only else self.peer_out[par]
             ntargets = 1 if self.root_only else self.world
-            if self.root_only and self.seq > 2:
-                # the buffer of this parity was last used by step seq - 2: rank 0 must have consumed that step (its back-flag)
-                rc |= lib.hipnlp_peer_wait(self.my_back_flags, 1, self.seq - 2, self._scratch.data_ptr(), 0, self.status.data_ptr(), sh)
+            if self.root_only and self.rank != 0 and self.seq > 1:
+                # The buffer of this parity was last used by step seq - 2.  Rank 0 raises its back-flag for a step right behind its wait
+                # for that step's flags — BEFORE its consumer has read the outputs — so the flag of step seq - 2 does not say the buffer
+                # is free; the flag of step seq - 1 does: rank 0 raises it in its call for step seq - 1, which in rank 0's stream order
+                # lies behind its consumption of step seq - 2.  (No cycle: rank 0's wait for step seq - 1 needs this rank's signal of
+                # step seq - 1, sent in the previous call.)  A non-root rank is therefore never more than one step ahead of the consumer.
+                rc |= lib.hipnlp_peer_wait(self.my_back_flags, 1, self.seq - 1, self._scratch.data_ptr(), 0, self.status.data_ptr(), sh)
             if self.engine is not None:
                 self.engine.eval_device_peers(x.data_ptr(), targets.data_ptr(), ntargets, self.rank, stream=sh)
             else:
@@ -396,6 +401,17 @@ class PeerExchange:
             return 0 if self.rank == 0 else shard
         return shard * (self.world - 1)
 
+    def max_bytes_sent_per_step(self):
+        """the largest of bytes_sent_per_step() over the ranks (what the busiest sender's links carry; rank 0 of a gather_to_root sends
+        nothing, which says nothing about the exchange)"""
+        best = 0
+        for inf in self.cb.infos:
+            rows = int((np.asarray(inf["stage_rows"]).reshape(-1) >= 0).sum())
+            best = max(best, 8 * (inf["glen"] + inf["jlen"] + rows + 1))
+        if self.root_only:
+            return best if self.world > 1 else 0
+        return best * (self.world - 1)
+
     def timed_out(self):
         """True if ANY wait since set-up gave up (a rank never signalled; sticky: the flag is only raised on the device): the outputs
         of such a step are NaN throughout.  Synchronises the callback's stream."""
@@ -418,6 +434,270 @@ class PeerExchange:
             self._views = []
             self._lib.hipnlp_ipc_free(self._mine)
             self._mine = None
+
+
+def batch_range(batch, world, rank):
+    """Trajectories [begin, end) of rank `rank` when `batch` independent trajectories (initial guesses of one receding-horizon step,
+    BASELINE config 5) are dealt over `world` ranks: contiguous, equal shares (the collectives below move equal-sized pieces)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    if batch % world != 0:
+        raise ValueError(f"{batch} trajectories cannot be dealt evenly over {world} ranks")
+    q = batch // world
+    return rank * q, (rank + 1) * q
+
+
+class BatchDealtCallback:
+    """BASELINE config 5's multi-GPU form (SURVEY §8e "batch x knot flattened, then sharded", with the cut between trajectories):
+    `batch` independent trajectories dealt over the ranks (batch_range), every rank evaluates its own [b0, b1) with ONE launch of a
+    batched handle, and the outputs of ALL trajectories end up on rank 0 — the process the NLP drivers of the guesses live in.
+    No entry needs re-ordering: the fused buffer of a rank is [f (Bl) | grad (Bl n) | g (Bl m) | jac (Bl nnz)] and every trajectory's
+    four outputs are contiguous pieces of it, so rank 0 hands out VIEWS of the gathered buffers (`trajectory(b)`).
+
+        compute_batch(x_local, f_view, grad_view, g_view, jac_view, stream_handle)     fills the rank's views
+        to_root(x_local)   ONE collective (dist.gather: RCCL over xGMI, gloo in the CPU tests); returns self on rank 0, None elsewhere"""
+
+    def __init__(self, batch, n, m, nnz, compute_batch, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.batch, self.n, self.m, self.nnz = batch, n, m, nnz
+        self.b0, self.b1 = batch_range(batch, self.world, self.rank)
+        self.local = self.b1 - self.b0
+        self.compute_batch = compute_batch
+        self.device = torch.device(device)
+        Bl = self.local
+        self.o_grad, self.o_g, self.o_jac = Bl, Bl + Bl * n, Bl + Bl * (n + m)
+        self.shard_len = Bl * (1 + n + m + nnz)
+        self.buf = torch.zeros(self.shard_len, dtype=torch.float64, device=device)
+        self.all = torch.zeros(self.world * self.shard_len, dtype=torch.float64, device=device) if self.rank == 0 else None
+        self.views = self._views_of(self.buf)
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+
+    def _views_of(self, buf):
+        Bl, n, m, nnz = self.local, self.n, self.m, self.nnz
+        return (buf[0:Bl], buf[self.o_grad:self.o_g].view(Bl, n), buf[self.o_g:self.o_jac].view(Bl, m), buf[self.o_jac:self.shard_len].view(Bl, nnz))
+
+    def bytes_sent_per_step(self):
+        return 0 if self.rank == 0 else 8 * self.shard_len
+
+    def max_bytes_sent_per_step(self):
+        return 8 * self.shard_len if self.world > 1 else 0
+
+    def trajectory(self, b, gathered=None):
+        """(f, grad, g, jac) views of trajectory b in rank 0's gathered buffer"""
+        gathered = self.all if gathered is None else gathered
+        r, i = divmod(b, self.local)
+        f, grad, g, jac = self._views_of(gathered[r * self.shard_len:(r + 1) * self.shard_len])
+        return f[i], grad[i], g[i], jac[i]
+
+    def _run(self, x_local, stream_handle):
+        self.compute_batch(x_local, *self.views, stream_handle)
+        if self.world == 1:
+            self.all.copy_(self.buf)
+            return self
+        chunks = list(self.all.view(self.world, self.shard_len).unbind(0)) if self.rank == 0 else None
+        if self.device.type == "cuda" and dist.get_backend(self.group) == "gloo":   # rehearsal: several ranks on one GPU (gloo gathers host tensors)
+            torch.cuda.current_stream(self.device).synchronize()
+            host = [torch.empty(self.shard_len, dtype=torch.float64) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(self.buf.cpu(), host, dst=0, group=self.group)
+            if self.rank == 0:
+                self.all.copy_(torch.cat(host))
+        else:
+            dist.gather(self.buf, chunks, dst=0, group=self.group)
+        return self if self.rank == 0 else None
+
+    def to_root(self, x_local):
+        if self.stream is None:
+            return self._run(x_local, 0)
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream == self.stream.cuda_stream:
+            return self._run(x_local, self.stream.cuda_stream)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            out = self._run(x_local, self.stream.cuda_stream)
+        cur.wait_stream(self.stream)
+        return out
+
+    def local_only(self, x_local):
+        """the rank's trajectories evaluated into its own buffer, nothing exchanged (what the gather costs on top)"""
+        if self.stream is None:
+            self.compute_batch(x_local, *self.views, 0)
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != self.stream.cuda_stream:
+            self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.compute_batch(x_local, *self.views, self.stream.cuda_stream)
+        if cur.cuda_stream != self.stream.cuda_stream:
+            cur.wait_stream(self.stream)
+
+
+class BatchPeerToRoot:
+    """BatchDealtCallback's gather without a collective: rank 0 owns ONE device buffer [parity][rank][f | grad | g | jac] shared through a
+    HIP IPC handle, and every rank's batched knot kernel stores its trajectories' outputs straight into its piece of it over its own
+    xGMI link (hipnlp_eval_device with device-visible addresses of rank 0's buffer: the kernel needs no change, a trajectory's outputs
+    are contiguous runs).  Flags as in PeerExchange(root_only): a rank signals a step, rank 0 waits for all `world` signals and raises
+    the back-flag a rank waits for before it stores the step after the next one.  Returns the BatchDealtCallback (views of the step's
+    parity through `trajectory(b, gathered)`) on rank 0, None elsewhere."""
+
+    def __init__(self, bc, engine, handshake_timeout_s=5.0):
+        import ctypes as C
+        from .hipnlp import load_library
+        if bc.device.type != "cuda":
+            raise RuntimeError("BatchPeerToRoot needs the HIP engine")
+        self.bc, self.engine = bc, engine
+        self.world, self.rank = bc.world, bc.rank
+        lib = load_library()
+        self._lib = lib
+        vp, i64 = C.c_void_p, C.c_int64
+        lib.hipnlp_ipc_alloc.argtypes = [C.c_size_t, C.c_int, C.POINTER(vp), C.c_char_p]
+        lib.hipnlp_ipc_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+        lib.hipnlp_ipc_close.argtypes = [vp]
+        lib.hipnlp_ipc_free.argtypes = [vp]
+        lib.hipnlp_peer_signal.argtypes = [vp, C.c_int, C.c_int, C.c_ulonglong, vp]
+        lib.hipnlp_peer_wait.argtypes = [vp, C.c_int, C.c_ulonglong, vp, i64, vp, vp]
+        if 2 * self.world > 32:
+            raise RuntimeError("peer exchange: at most 16 ranks")
+        self.dev_index = bc.device.index if bc.device.index is not None else torch.cuda.current_device()
+        # every rank allocates (its flag words are written by rank 0); only rank 0's allocation holds output buffers
+        self.olen = self.world * bc.shard_len + self.world + 1       # [rank][f | grad | g | jac] | scratch of the wait kernel
+        self.flag_words = 64
+        words = (2 * self.olen if self.rank == 0 else 0) + self.flag_words
+        mine, handle = vp(), C.create_string_buffer(64)
+        mine_ok = lib.hipnlp_ipc_alloc(C.c_size_t(8 * words), self.dev_index, C.byref(mine), handle) == 0
+        self._mine = mine.value if mine_ok else None
+        handles = [bytes(handle.raw) if mine_ok else None]
+        if self.world > 1:
+            handles = [None] * self.world
+            dist.all_gather_object(handles, bytes(handle.raw) if mine_ok else None, group=bc.group)
+        self._opened, bases = [], []
+        opened_ok = all(h is not None for h in handles)
+        if opened_ok:
+            for r in range(self.world):
+                if r == self.rank:
+                    bases.append(self._mine)
+                    continue
+                if self.rank != 0 and r != 0:
+                    bases.append(0)            # (only rank 0 talks to everybody; the others talk to rank 0)
+                    continue
+                p = vp()
+                if lib.hipnlp_ipc_open(handles[r], self.dev_index, C.byref(p)) != 0:
+                    opened_ok = False
+                    break
+                self._opened.append(p.value)
+                bases.append(p.value)
+        oks = [opened_ok]
+        if self.world > 1:
+            oks = [None] * self.world
+            dist.all_gather_object(oks, opened_ok, group=bc.group)
+        if not all(oks):
+            self._release()
+            raise RuntimeError("batch peer exchange set-up failed on rank(s) %s (hipnlp_ipc_alloc / hipnlp_ipc_open)" % [r for r, ok in enumerate(oks) if not ok])
+        dev = bc.device
+        flag_off = [8 * (2 * self.olen if r == 0 else 0) for r in range(self.world)]
+        root = bases[0]
+        self.root_flags = torch.tensor([root + flag_off[0]], dtype=torch.int64, device=dev)            # step flags live on rank 0: [0, world)
+        self.my_flags = self._mine + flag_off[self.rank]
+        self.my_back_flags = self.my_flags + 8 * self.world                                           # back-flag slot 0 of every rank
+        self.back_flags = torch.tensor([b + fo + 8 * self.world for b, fo in zip(bases, flag_off)], dtype=torch.int64, device=dev) if self.rank == 0 else None
+        self.root_out = [root + 8 * par * self.olen for par in (0, 1)]
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._scratch = torch.zeros(4, dtype=torch.float64, device=dev)
+        self.seq = 0
+        self._gathered = [_device_view(self._mine + 8 * par * self.olen, self.olen, dev) for par in (0, 1)] if self.rank == 0 else None
+        if self.world > 1:
+            dist.barrier(group=bc.group)
+        self._handshake(bases, flag_off, handshake_timeout_s)
+
+    def _handshake(self, bases, flag_off, timeout_s):
+        """a token through the store path of the exchange, both ways, before anything is timed or trusted: every rank stores into its
+        slot of rank 0's handshake words, rank 0 into slot 0 of everybody's; the outcome is agreed on collectively"""
+        import time
+        bc, lib, dev = self.bc, self._lib, self.bc.device
+        token = 0x42415443 + self.world
+        with torch.cuda.stream(bc.stream):
+            sh = bc.stream.cuda_stream
+            to_root = torch.tensor([bases[0] + flag_off[0] + 8 * 32], dtype=torch.int64, device=dev)
+            rc = lib.hipnlp_peer_signal(to_root.data_ptr(), 1, self.rank, token, sh)
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
+            if self.rank == 0:
+                rc |= lib.hipnlp_peer_wait(self.my_flags + 8 * 32, self.world, token, self._scratch.data_ptr(), 0, status.data_ptr(), sh)
+                back = torch.tensor([b + fo + 8 * 48 for b, fo in zip(bases, flag_off)], dtype=torch.int64, device=dev)
+                rc |= lib.hipnlp_peer_signal(back.data_ptr(), self.world, 0, token, sh)
+            rc |= lib.hipnlp_peer_wait(self.my_flags + 8 * 48, 1, token, self._scratch.data_ptr(), 0, status.data_ptr(), sh)
+            done = torch.cuda.Event()
+            done.record(bc.stream)
+        t0 = time.time()
+        while not done.query() and time.time() - t0 < timeout_s:
+            time.sleep(0.001)
+        ok = rc == 0 and done.query() and int(status.item()) == 0
+        oks = [ok]
+        if self.world > 1:
+            oks = [None] * self.world
+            dist.all_gather_object(oks, ok, group=bc.group)
+        if not all(oks):
+            raise RuntimeError("batch peer exchange handshake failed on rank(s) %s" % [r for r, o in enumerate(oks) if not o])
+
+    def __call__(self, x_local):
+        bc, lib = self.bc, self._lib
+        cur = torch.cuda.current_stream(bc.device)
+        if cur.cuda_stream != bc.stream.cuda_stream:
+            bc.stream.wait_stream(cur)
+        with torch.cuda.stream(bc.stream):
+            sh = bc.stream.cuda_stream
+            self.seq += 1
+            par = self.seq & 1
+            rc = 0
+            if self.rank != 0 and self.seq > 1:   # (as PeerExchange(root_only): rank 0's back-flag of step seq - 1 lies behind its consumption of step seq - 2)
+                rc |= lib.hipnlp_peer_wait(self.my_back_flags, 1, self.seq - 1, self._scratch.data_ptr(), 0, self.status.data_ptr(), sh)
+            base = self.root_out[par] + 8 * self.rank * bc.shard_len
+            self.engine.eval_device(x_local.data_ptr(), base, base + 8 * bc.o_grad, base + 8 * bc.o_g, base + 8 * bc.o_jac, stream=sh)
+            rc |= lib.hipnlp_peer_signal(self.root_flags.data_ptr(), 1, self.rank, self.seq, sh)
+            if self.rank == 0:
+                out = self._gathered[par]
+                rc |= lib.hipnlp_peer_wait(self.my_flags, self.world, self.seq, out.data_ptr(), self.world * bc.shard_len, self.status.data_ptr(), sh)
+                rc |= lib.hipnlp_peer_signal(self.back_flags.data_ptr(), self.world, 0, self.seq, sh)
+            if rc != 0:
+                raise RuntimeError("batch peer exchange: a launch failed")
+        if cur.cuda_stream != bc.stream.cuda_stream:
+            cur.wait_stream(bc.stream)
+        return self._gathered[par][:self.world * bc.shard_len] if self.rank == 0 else None
+
+    def bytes_sent_per_step(self):
+        return 0 if self.rank == 0 else 8 * self.bc.shard_len
+
+    def max_bytes_sent_per_step(self):
+        return 8 * self.bc.shard_len if self.world > 1 else 0
+
+    def timed_out(self):
+        self.bc.stream.synchronize()
+        return bool(self.status.item())
+
+    def _release(self):
+        for p in getattr(self, "_opened", []):
+            self._lib.hipnlp_ipc_close(p)
+        self._opened = []
+        if getattr(self, "_mine", None):
+            self._lib.hipnlp_ipc_free(self._mine)
+        self._mine = None
+
+    def close(self, barrier=True):
+        if getattr(self, "_mine", None):
+            self.bc.stream.synchronize()
+            if self.world > 1 and barrier:
+                dist.barrier(group=self.bc.group)
+            self._gathered = None
+            self._release()
+
+
+def hip_batch_backend(engine):
+    """compute_batch backed by a batched HIP engine handle (hipnlp_eval_device on the rank's trajectories)"""
+    def compute(x_local, f_view, grad_view, g_view, jac_view, stream_handle):
+        if not stream_handle:
+            raise RuntimeError("the batch-dealt path needs an explicit (non-default) stream")
+        engine.eval_device(x_local.data_ptr(), f_view.data_ptr(), grad_view.data_ptr(), g_view.data_ptr(), jac_view.data_ptr(), stream=stream_handle)
+    return compute
 
 
 def _device_view(ptr, count, device):

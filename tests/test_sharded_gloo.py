@@ -104,6 +104,84 @@ def test_sharded_reassembly_world2(horizon):
     assert sorted(results) == [(0, True), (1, True)]
 
 
+def _batch_worker(rank, world, port, batch, horizon, result_q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hippopt_amd.kinodyn_settings import stairs_settings
+    from hippopt_amd.robot_model import synthetic_ergocub
+    from hippopt_amd.sharded import BatchDealtCallback, batch_range
+    from hippopt_amd.synthetic import make_workload, place_on_step_flanks
+    from hostemu_lib import HostEmu
+
+    model = synthetic_ergocub()
+    st = stairs_settings(horizon, model)
+    x, p = make_workload(st, model, batch, 77)          # the same on every rank
+    place_on_step_flanks(x, st, seed=77)
+    emu = HostEmu(st, model)
+    b0, b1 = batch_range(batch, world, rank)
+
+    def compute(xl, f_view, grad_view, g_view, jac_view, stream_handle):
+        for i in range(b1 - b0):
+            f, grad, g, jac, _ = emu.eval(xl[i].numpy(), p[b0 + i])
+            f_view[i] = float(f)
+            grad_view[i].copy_(torch.from_numpy(grad))
+            g_view[i].copy_(torch.from_numpy(g))
+            jac_view[i].copy_(torch.from_numpy(jac))
+
+    bc = BatchDealtCallback(batch, emu.n, emu.m, emu.nnz, compute, torch.device("cpu"))
+    ok = (bc.b0, bc.b1) == (b0, b1)
+    for shift in (0.0, 1e-3):     # two steps: the second overwrites the first
+        got = bc.to_root(torch.from_numpy(x[b0:b1] + shift))
+        if rank == 0:
+            ok = ok and got is bc
+            for b in range(batch):
+                f, grad, g, jac = bc.trajectory(b)
+                fr, gradr, gr, jacr, _ = emu.eval(x[b] + shift, p[b])
+                ok = ok and float(f) == float(fr) and np.array_equal(grad.numpy(), gradr) and np.array_equal(g.numpy(), gr) and np.array_equal(jac.numpy(), jacr)
+        else:
+            ok = ok and got is None
+    ok = ok and bc.max_bytes_sent_per_step() == 8 * (b1 - b0) * (1 + emu.n + emu.m + emu.nnz) and bc.bytes_sent_per_step() == (0 if rank == 0 else bc.max_bytes_sent_per_step())
+    result_q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_batch_dealt_over_the_ranks_reaches_rank_zero_world2():
+    """BASELINE config 5's multi-GPU form in small: independent trajectories (batched initial guesses on the stairs) dealt over two
+    ranks, one collective to rank 0, every trajectory's outputs views of the gathered buffer — no reassembly"""
+    world, batch, horizon = 2, 4, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batch_worker, args=(r, world, port, batch, horizon, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_batch_range_deals_evenly_or_refuses():
+    from hippopt_amd.sharded import batch_range
+    for world in (1, 2, 4, 8, 16):
+        cover = []
+        for r in range(world):
+            a, b = batch_range(16, world, r)
+            assert b - a == 16 // world
+            cover += list(range(a, b))
+        assert cover == list(range(16))
+    with pytest.raises(ValueError):
+        batch_range(16, 3, 0)
+
+
 def test_knot_range_tiles_the_horizon():
     from hippopt_amd.sharded import knot_range
     for horizon in (7, 9, 100, 101, 800):
