@@ -41,6 +41,10 @@ static_assert(gs::COUNT == HIPNLP_G_STAGE, "HIPNLP_G_STAGE must equal the native
 // (copy-out tables padded to whole workgroups of 512 lanes — -1 / 0 behind the entries — so that their prefetch is unconditional:
 //  a load inside a branch makes the compiler wait for ALL younger loads at the first s_waitcnt vmcnt)
 constexpr int GS_PAD = (gs::COUNT + 511) / 512 * 512, JS_PAD = (js::COUNT + 511) / 512 * 512;
+// Entries of a knot's block that depend on x — the only ones a VARY instantiation stores (at most: 791 on the planar terrain, 1041 on
+// the smooth steps; tests/test_constant_jacobian.py) — rounded up to whole workgroups of 512: the trip count of its copy-out.
+constexpr int vary_cap(int terrain, int wg) { return terrain == HIPNLP_TERRAIN_PLANAR ? 1024 : (wg == 256 ? 1280 : 1536); }
+constexpr int VCAP_MAX = 1536;
 struct DeviceTables {
     HeadTables head;
     int32_t g_a[3][GS_PAD];
@@ -54,6 +58,20 @@ struct DeviceTables {
     int32_t jperm_glob[16];
     int32_t nnz_v[3];
     int32_t n_glob, jac_glob_base;
+    // VARY instantiations (varying-first order of a block, constants left alone): the varying run only, thread-major as jperm_t,
+    // VCAP / WG entries per thread (padded with -1)
+    int32_t jpermv_t[3][VCAP_MAX];
+    int32_t nvary_v[3], pad_v;
+};
+
+// (see constants_check_and_repair)
+struct ConstCheck {
+    double* jac;               // [batch][jac_stride] destination (device memory), or null: nothing to check
+    const double* ctpl;        // [templates][ctpl_len]
+    const int32_t* ctpl_of_b;
+    int32_t* healed;
+    int64_t jac_stride, jac_off;
+    int32_t ctpl_len, ctpl_off[4], nnz_v[3], nvary_v[3], kb, nk, N, n_glob, jac_glob_base;
 };
 
 struct KArgs {
@@ -80,6 +98,9 @@ struct KArgs {
     // into the buffer [grad (n) | jac (nnz) | g (m) | f partials (npeer) | f] of every one of npeer ranks (this device's own among them)
     double* const* peer_out;   // [npeer] device-visible base addresses, or null
     int32_t npeer, peer_rank;
+    // VARY instantiations, jac in DEVICE memory: the constant entries are expected to be in place (filled once per parameter set by
+    // hipnlp_fill_const_kernel); the launch's reducer workgroup checks them (constants_check_and_repair); null pointers: no check
+    ConstCheck cc;
 #ifdef HIPNLP_STAMPS
     unsigned long long* stamps;  // diagnostic build only: [blocks][32] s_memtime at every barrier (never in the product library)
 #endif
@@ -89,7 +110,7 @@ struct KArgs {
 // workgroup with the lite tables below: four workgroups per CU).  The eight-wave latency variant keeps the full layout: it has one
 // workgroup per CU whatever its LDS, and its duration is that of the SLOWEST workgroup — the last knot, whose end rows would wait
 // for global memory in the compact layout (measured: 10.0 -> 10.9 us per 100-knot launch).
-template <int TERRAIN, int WAVES = 4> struct DevEm {
+template <int TERRAIN, int WAVES = 4, bool VARY = false> struct DevEm {
     static constexpr int kTerrain = TERRAIN;
     static constexpr int kWaves = WAVES;
     static constexpr int kLayout = WAVES == 4 ? LAYOUT_COMPACT : LAYOUT_FULL;
@@ -98,7 +119,14 @@ template <int TERRAIN, int WAVES = 4> struct DevEm {
     double* g;
     double* jac;
     __device__ __forceinline__ void G(int slot, int, double v) { g[slot] = v; }   // (horizon-end rows go through emit_g_end)
-    __device__ __forceinline__ void J(int slot, int, int, double v) { jac[slot] = v; }
+#ifdef HIPNLP_EXP_JAC_SLOTS   // (occupancy experiment: the compact scratch's jac staging folded onto 512 slots — timing only, WRONG values)
+    static constexpr int kFold = WAVES == 4 ? 511 : 0x7fffffff;
+#else
+    static constexpr int kFold = 0x7fffffff;
+#endif
+    __device__ __forceinline__ void J(int slot, int, int, double v) { jac[slot & kFold] = v; }
+    // entries that do not depend on x (emit_jc): a VARY instantiation neither stages nor stores them — its destination holds them
+    __device__ __forceinline__ void JC(int slot, int, int, double v) { if constexpr (!VARY) jac[slot & kFold] = v; }
 };
 
 // LDS image of the read-only tables every phase indexes per lane (global memory would cost one L2 round trip per phase)
@@ -130,6 +158,43 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ unsigned long long pub_pattern(int32_t seq) { return ((unsigned long long)(uint32_t)seq * 0x9E3779B97F4A7C15ull) | 1ull; }
 constexpr int PUB_SPIN_CAP = 1 << 20;   // polls of the reducer before it gives up (each at least one memory round trip: > 1 s)
 
+// VARY launches into a DEVICE destination: are the constant entries of trajectory b's knot blocks in place?  Run by the ONE workgroup
+// per trajectory that sums its cost (the reducer workgroup of the launch, or hipnlp_reduce_kernel behind it) — never by the knot
+// workgroups: two loads on their path, wherever they were issued, cost 4 - 10 % at batch (vector loads of table words with a wait
+// right behind them; then the round trip to HBM itself).  Thread t looks at the FIRST constant entry of the block of knot kb + t
+// (+ 256, ...); if any differs from the handle's template the workgroup puts the constants of ALL the trajectory's blocks back (rare —
+// a caller that wrote over its buffer — slow, right: the knot workgroups store other entries, nothing is written twice).
+__device__ __forceinline__ void constants_check_and_repair(const ConstCheck& c, int b, int nthreads, int* lds_flags /* one int per wave of the workgroup */) {
+    if (!c.jac || !c.ctpl) return;
+    const int tid = threadIdx.x;
+    const double* tpl = c.ctpl + int64_t(c.ctpl_of_b[b]) * c.ctpl_len;
+    double* out = c.jac + int64_t(b) * c.jac_stride - c.jac_off;
+    int miss = 0;
+    for (int t = tid; t < c.nk; t += nthreads) {
+        const int k = c.kb + t, v = k == 0 ? VAR_FIRST : (k == c.N - 1 ? VAR_LAST : VAR_INTERIOR);
+        if (c.nvary_v[v] >= c.nnz_v[v]) continue;
+        const int64_t base = k == 0 ? 0 : int64_t(c.nnz_v[VAR_FIRST]) + int64_t(k - 1) * c.nnz_v[VAR_INTERIOR];
+        const double seen = out[base + c.nvary_v[v]], want = tpl[c.ctpl_off[v] + c.nvary_v[v]];
+        miss |= __double_as_longlong(seen) != __double_as_longlong(want);
+    }
+    // (an OR over the workgroup through the caller's LDS words: __syncthreads_or brings 256 B of LDS of its own, which the four-wave
+    //  kernel — 40 KB to the byte for four workgroups per CU — does not have)
+    if ((tid & 63) == 0) lds_flags[tid >> 6] = 0;
+    __syncthreads();
+    if (__any(miss) && (tid & 63) == 0) lds_flags[tid >> 6] = 1;
+    __syncthreads();
+    int any = 0;
+    for (int w = 0; w < nthreads / 64; ++w) any |= lds_flags[w];
+    if (!any) return;
+    for (int t = 0; t < c.nk; ++t) {
+        const int k = c.kb + t, v = k == 0 ? VAR_FIRST : (k == c.N - 1 ? VAR_LAST : VAR_INTERIOR);
+        const int64_t base = k == 0 ? 0 : int64_t(c.nnz_v[VAR_FIRST]) + int64_t(k - 1) * c.nnz_v[VAR_INTERIOR];
+        for (int i = c.nvary_v[v] + tid; i < c.nnz_v[v]; i += nthreads) out[base + i] = tpl[c.ctpl_off[v] + i];
+    }
+    if (c.kb + c.nk == c.N) for (int i = tid; i < c.n_glob; i += nthreads) out[int64_t(c.jac_glob_base) + i] = tpl[c.ctpl_off[3] + i];
+    if (tid == 0) atomicAdd(c.healed, 1);
+}
+
 // WAVES = 4: 256 threads; 4 waves per SIMD = 4 workgroups per CU (<= 128 VGPRs, <= 40 KB of LDS on the compact scratch).  The
 //            throughput variant.
 // WAVES = 8: 512 threads, the roles of the knot program spread over twice the waves (two per SIMD).  The latency variant, used
@@ -138,14 +203,21 @@ constexpr int PUB_SPIN_CAP = 1 << 20;   // polls of the reducer before it gives 
 // Four workgroups per CU for the four-wave kernels (compact scratch + lite tables: <= 40 KB of LDS, <= 128 VGPRs).
 // PEERS: the instantiation behind hipnlp_eval_device_peers (outputs into every rank's buffer); a template parameter rather than a
 // run-time branch — as a branch the unused path cost the plain callback 1.2 % at N = 100 (7.99 against 7.89 us) and 0.8 % at x 64.
-template <int TERRAIN, int WAVES, bool PEERS = false> __global__ __launch_bounds__(64 * WAVES)
-__attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 4 : 2, 4)))
+// VARY: the instantiation for destinations that already hold the constant entries of jac g (varying-first order of a block): the
+// tasks do not stage them (DevEm::JC), the copy-out walks the varying run of the block only — half the trips on the planar terrain.
+template <int TERRAIN, int WAVES, bool PEERS = false, bool VARY = false> __global__ __launch_bounds__(64 * WAVES)
+#ifndef HIPNLP_EXP_WPE
+#define HIPNLP_EXP_WPE 4
+#endif
+__attribute__((amdgpu_waves_per_eu(WAVES == 4 ? (VARY ? HIPNLP_EXP_WPE : 4) : 2, WAVES == 4 && VARY ? HIPNLP_EXP_WPE : 4)))
 void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const double* pk_p, const GParams* gp_p, int N_p, int n_p, int kb_p, int nk_p, KArgs a) {
+    static_assert(!(PEERS && VARY), "the peer exchange stores every entry");
     // the leading scalar arguments repeat what the staging loads need: the build preloads them into SGPRs
     // (-mllvm -amdgpu-kernarg-preload-count), so the first global loads do not wait for a kernarg fetch
     constexpr int WG = 64 * WAVES;
-    constexpr bool COMPACT = DevEm<TERRAIN, WAVES>::kCompact;
-    using Scratch = typename DevEm<TERRAIN, WAVES>::Scratch;
+    using Em = DevEm<TERRAIN, WAVES, VARY>;
+    constexpr bool COMPACT = Em::kCompact;
+    using Scratch = typename Em::Scratch;
     __shared__ Scratch s;
     __shared__ SharedTablesT<COMPACT> tabs;
     static_assert(!COMPACT || sizeof(Scratch) + sizeof(SharedTablesT<COMPACT>) <= 40 * 1024, "four workgroups per CU: 40 KB of LDS each");
@@ -176,8 +248,12 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             //  round trips behind the LAST workgroup's partials — left a tail of 4.4 k cycles on that workgroup: 22.6 k cycles
             //  against 18.4 k for every other one, i.e. 2 of the launch's 10 us.)
             // Forward progress: the reducer of row b waits only for workgroups dispatched before it; it is bounded anyway.
+            if constexpr (VARY) constants_check_and_repair(a.cc, b, WG, reinterpret_cast<int*>(&s));   // (while the knot workgroups of the row run their programs)
+            __syncthreads();
             double* red = reinterpret_cast<double*>(&s);   // [nk][16]
+#ifndef HIPNLP_EXP_JAC_SLOTS
             static_assert(sizeof(Scratch) >= 256 * 16 * sizeof(double), "reducer staging: nk <= 256");
+#endif
             const unsigned long long pat = pub_pattern(a.seq);
             const unsigned long long* base = a.cost_pub + size_t(b) * a.nk * NCT * 2;
             const int t = lane & 15, q = lane >> 4;
@@ -264,11 +340,27 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     // Copy-out tables of this knot's variant: fetched once the staging loads have landed (the compiler waits for EVERY outstanding
     // load before an LDS access that follows a direct load), consumed at the very end — they stay in flight across the (LDS-only)
     // barriers of the program.
-    constexpr int JP_ITERS = (js::COUNT + WG - 1) / WG, G_ITERS = (gs::COUNT + WG - 1) / WG;
+    constexpr int JP_ITERS = VARY ? vary_cap(TERRAIN, WG) / WG : (js::COUNT + WG - 1) / WG, G_ITERS = (gs::COUNT + WG - 1) / WG;
     const int v = first ? VAR_FIRST : (last ? VAR_LAST : VAR_INTERIOR);
     int nnz_first = 0, nnz_interior = 0, n_glob = 0, jac_glob_base = 0;   // (scalars of the copy-out: read behind the vector loads, used at the end)
     int jpg = 0;
     int32_t jp[JP_ITERS], ga[G_ITERS], gb[G_ITERS];
+#ifdef HIPNLP_EXP_LATE_TABLES
+    constexpr bool LATE_TABLES = VARY && WAVES == 4;
+#else
+    constexpr bool LATE_TABLES = false;
+#endif
+    auto fetch_tables = [&]() __attribute__((always_inline)) {
+        const DeviceTables& tbl = *tb_p;
+        jpg = tbl.jperm_glob[tid & 15];
+#pragma unroll
+        for (int it = 0; it < JP_ITERS; ++it) jp[it] = VARY ? tbl.jpermv_t[v][tid * JP_ITERS + it] : tbl.jperm_t[v][tid * (JS_PAD / WG) + it];      // (thread-major: wide loads)
+#pragma unroll
+        for (int it = 0; it < G_ITERS; ++it) {
+            ga[it] = tbl.gab_t[v][2 * (tid * (GS_PAD / WG) + it)];
+            gb[it] = tbl.gab_t[v][2 * (tid * (GS_PAD / WG) + it) + 1];
+        }
+    };
     {
         static_assert(sizeof(KSettings) % 16 == 0 && sizeof(KinLite) % 16 == 0 && sizeof(GParamsLite) % 16 == 0 && sizeof(HeadTables) % 16 == 0 &&
                       sizeof(GParams) % 16 == 0 && (PK_STRIDE * 8) % 16 == 0, "staged in 16-byte pieces");
@@ -314,6 +406,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         st_issued = __builtin_amdgcn_s_memtime();
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the staging loads of THIS wave have landed in LDS (before it signals the barrier)
+
 #ifdef HIPNLP_STAMPS
         st_loaded = __builtin_amdgcn_s_memtime();
 #endif
@@ -323,15 +416,9 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         // pads (no staging load touches them)
         if (tid >= 64 && tid < 64 + XPAD - NXK) { s.x[NXK + tid - 64] = 0.0; s.xm[NXK + tid - 64] = 0.0; }
         if (tid >= 128 && tid < 128 + 8 - NXG) s.xg[NXG + tid - 128] = 0.0;
-        // copy-out tables: issued now, consumed at the very end
-        jpg = tb.jperm_glob[tid & 15];
-#pragma unroll
-        for (int it = 0; it < JP_ITERS; ++it) jp[it] = tb.jperm_t[v][tid * (JS_PAD / WG) + it];      // (thread-major: wide loads)
-#pragma unroll
-        for (int it = 0; it < G_ITERS; ++it) {
-            ga[it] = tb.gab_t[v][2 * (tid * (GS_PAD / WG) + it)];
-            gb[it] = tb.gab_t[v][2 * (tid * (GS_PAD / WG) + it) + 1];
-        }
+        // copy-out tables: issued now, consumed at the very end (LATE_TABLES: issued behind the last barrier but one instead — the
+        // registers they occupy from here to the end are what stands between the four-wave VARY kernel and a fifth wave per SIMD)
+        if constexpr (!LATE_TABLES) fetch_tables();
     }
     lds_barrier();
 
@@ -359,9 +446,9 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     };
 
     KnotInfo ki{k, N, first, last};
-    DevEm<TERRAIN, WAVES> em{s.g, s.jac};
+    Em em{s.g, s.jac};
     // (the full tables: global memory for the compact layouts; the full layout's LDS copy otherwise — the constructor's default)
-    Ctx<DevEm<TERRAIN, WAVES>> cx(s, tabs.kin(), tabs.settings(), tabs.gp, ki, em, COMPACT ? &tb.head.kt : nullptr, COMPACT ? gp_p + b : nullptr);
+    Ctx<Em> cx(s, tabs.kin(), tabs.settings(), tabs.gp, ki, em, COMPACT ? &tb.head.kt : nullptr, COMPACT ? gp_p + b : nullptr);
     // The program is instantiated ONCE PER WAVE (a generic lambda over the wave number as a compile-time constant: a task group is
     // compiled into the one instance whose wave runs it) and dispatched by one switch, so that every wave executes a CONTIGUOUS
     // instruction stream from the first phase to the last.  Written as `if (wave == w) { ... }` blocks phase after phase, every
@@ -385,7 +472,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 #define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); if constexpr (W == PUBW) pub_step(bid); bid++;
 #else
     int bid = 0;
-#define DEV_BARRIER lds_barrier(); if constexpr (W == PUBW) pub_step(bid); bid++;
+#define DEV_BARRIER lds_barrier(); if constexpr (W == PUBW) pub_step(bid); if constexpr (LATE_TABLES) { if (bid == 3) fetch_tables(); } bid++;
 #endif
     auto run_wave = [&](auto wc) __attribute__((always_inline)) {
         constexpr int W = decltype(wc)::value;
@@ -425,7 +512,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     double jvals[JP_ITERS], gvals[G_ITERS], grvals[GR_ITERS];
     // (unconditional, clamped indices, no branch: every LDS read of the copy-out is in flight before the first wait)
 #pragma unroll
-    for (int it = 0; it < JP_ITERS; ++it) jvals[it] = s.jac[jp[it] >= 0 ? jp[it] : 0];
+    for (int it = 0; it < JP_ITERS; ++it) jvals[it] = s.jac[(jp[it] >= 0 ? jp[it] : 0) & Em::kFold];
 #pragma unroll
     for (int it = 0; it < G_ITERS; ++it) gvals[it] = s.g_at((tid + it * WG) < gs::COUNT ? tid + it * WG : 0);
 #pragma unroll
@@ -473,7 +560,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 #pragma unroll
         for (int it = 0; it < JP_ITERS; ++it) if (jp[it] >= 0) out[tid + it * WG] = jvals[it];
         // entries in the horizon-global columns (constants) sit right behind the last knot's block: the last knot writes them
-        if (last && tid < n_glob) a.jac[int64_t(b) * a.jac_stride + (int64_t(jac_glob_base) - a.jac_off) + tid] = s.jac[jpg];
+        if constexpr (!VARY) { if (last && tid < n_glob) a.jac[int64_t(b) * a.jac_stride + (int64_t(jac_glob_base) - a.jac_off) + tid] = s.jac[jpg]; }
     }
     if (a.g) {
         double* out = a.g + size_t(b) * a.m;
@@ -719,9 +806,11 @@ void hipnlp_knot_hess_kernel(HArgs a) {
 // tree: two lane-shuffles inside the wave, four waves through LDS, twelve terms in order.  Bitwise reproducible.
 constexpr int RWG = 256, RCOL = 16, RGRP = RWG / RCOL, RUNR = 8;
 static_assert(NCT <= RCOL, "reduce columns");
-__global__ __launch_bounds__(RWG) void hipnlp_reduce_kernel(const double* cost_knot, int nk, double* f, double* cost_terms) {
+__global__ __launch_bounds__(RWG) void hipnlp_reduce_kernel(const double* cost_knot, int nk, double* f, double* cost_terms, ConstCheck cc) {
     __shared__ double part[RWG / 64][RCOL];
     const int b = blockIdx.x, tid = threadIdx.x, c = tid % RCOL, g = tid / RCOL, lane = tid & 63, wave = tid >> 6;
+    __shared__ int cc_flags[RWG / 64];
+    constants_check_and_repair(cc, b, RWG, cc_flags);   // (VARY launches into device memory; cc.jac == null otherwise)
     double acc = 0.0;
     for (int k0 = g; k0 < nk; k0 += RGRP * RUNR) {
         double v[RUNR];
@@ -770,6 +859,20 @@ __global__ __launch_bounds__(256) void hipnlp_fetch_vary_kernel(const double* __
     const int64_t base = int64_t(blockIdx.y) * nnz + (k == 0 ? 0 : int64_t(nnz_first) + int64_t(k - 1) * nnz_interior);
     const int count = k == 0 ? nv_first : (k == N - 1 ? nv_last : nv_interior);
     for (int i = threadIdx.x; i < count; i += 256) dst[base + i] = src[base + i];
+}
+
+// The constant entries of the handle's knots into a DEVICE array jac [batch][nnz] (varying-first order: the tail of every block, and
+// the horizon-global entries behind the last one), from the handle's templates: once per destination and parameter set.
+__global__ __launch_bounds__(256) void hipnlp_fill_const_kernel(double* __restrict__ jac, const double* __restrict__ ctpl, const int32_t* __restrict__ ctpl_of_b, int ctpl_len,
+                                                                 int off_first, int off_interior, int off_last, int off_glob, int kb, int N, int64_t nnz,
+                                                                 int nnz_first, int nnz_interior, int nnz_last, int nv_first, int nv_interior, int nv_last, int n_glob) {
+    const int k = kb + int(blockIdx.x), b = int(blockIdx.y);
+    const double* t = ctpl + int64_t(ctpl_of_b[b]) * ctpl_len;
+    const int64_t base = int64_t(b) * nnz + (k == 0 ? 0 : int64_t(nnz_first) + int64_t(k - 1) * nnz_interior);
+    const int nv = k == 0 ? nv_first : (k == N - 1 ? nv_last : nv_interior), end = k == 0 ? nnz_first : (k == N - 1 ? nnz_last : nnz_interior);
+    const double* tv = t + (k == 0 ? off_first : (k == N - 1 ? off_last : off_interior));
+    for (int i = nv + int(threadIdx.x); i < end; i += 256) jac[base + i] = tv[i];
+    if (k == N - 1) for (int i = int(threadIdx.x); i < n_glob; i += 256) jac[base + end + i] = t[off_glob + i];
 }
 
 thread_local std::string g_create_error;
@@ -849,7 +952,16 @@ struct hipnlp_handle {
     // the entries that depend on x only (d_tb_vary: the same tables with -1 at the constant positions of the copy-out permutation):
     // a third fewer bytes on the PCIe-bound path, one contiguous run per knot.  Caller arrays are spot-checked before every such
     // launch (csample) and re-filled when a check fails or the parameters changed.
-    DeviceTables* d_tb_vary = nullptr;
+    bool vary_ok = false;                           // varying-first layout whose varying runs fit the VARY instantiations' trip counts
+    bool vary_check = true;                         // the VARY kernels look at the constants they find in a device destination (HIPNLP_VARY_CHECK=0: diagnostic)
+    double* d_ctpl = nullptr;                       // device copy of the templates [ctpl.size()][ctpl_len] (the VARY kernels' self-healing check, the fill kernel)
+    int32_t* d_ctpl_of_b = nullptr;
+    int32_t* d_healed = nullptr;                    // wave slices of constants a VARY kernel had to put back (the caller wrote over a device buffer)
+    int ctpl_len = 0;
+    struct DevFilled { const void* dev; unsigned long long gen; };
+    DevFilled dfilled[8] = {};                      // device jac buffers of hipnlp_eval_device that hold this handle's constants, and of which parameter set
+    int dfilled_next = 0;
+    long dev_const_fills = 0;
     bool skip_const = true;                         // hipnlp_set_constant_jacobian
     unsigned long long param_gen = 0;               // hipnlp_set_params calls so far
     std::vector<std::vector<double>> ctpl;          // distinct templates [block of VAR_FIRST | VAR_INTERIOR | VAR_LAST | horizon-global]: the constant values at their positions
@@ -892,7 +1004,7 @@ static void free_all(hipnlp_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* dptrs[] = {h->d_tb, h->d_tb_vary, h->d_x, h->d_pk, h->d_cost_knot, h->d_gp, h->d_cost_pub, h->d_out, h->d_ht, h->d_sigma, h->d_hess, h->d_hflag};
+    void* dptrs[] = {h->d_tb, h->d_ctpl, h->d_ctpl_of_b, h->d_healed, h->d_x, h->d_pk, h->d_cost_knot, h->d_gp, h->d_cost_pub, h->d_out, h->d_ht, h->d_sigma, h->d_hess, h->d_hflag};
     for (void* q : dptrs) if (q) (void)hipFree(q);
     void* hptrs[] = {h->h_x, h->h_out, h->h_hess, h->h_hflag, h->h_sl};
     for (void* q : hptrs) if (q) (void)hipHostFree(q);
@@ -964,6 +1076,7 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     if (!h->L.build(st, h->kt, (desc->flags & HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS) != 0, (desc->flags & HIPNLP_FLAG_JAC_VARYING_FIRST) != 0))
         return fail(HIPNLP_E_INVALID, h->L.error);
     if (const char* cj = std::getenv("HIPNLP_CONST_JAC")) h->skip_const = std::atoi(cj) != 0;   // diagnostic override of hipnlp_set_constant_jacobian's default
+    if (const char* vc = std::getenv("HIPNLP_VARY_CHECK")) h->vary_check = std::atoi(vc) != 0;
     h->np = ParamOffsets(st.horizon).np();
     if (h->L.jperm_glob.size() > 16) return fail(HIPNLP_E_INVALID, "internal: too many global-column entries");
 
@@ -1048,23 +1161,24 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     tb->n_glob = int(h->L.jperm_glob.size());
     for (int i = 0; i < tb->n_glob; ++i) tb->jperm_glob[i] = h->L.jperm_glob[size_t(i)];
     tb->jac_glob_base = h->L.jac_glob_base;
-    hipError_t ce = hipMemcpy(h->d_tb, tb, sizeof(DeviceTables), hipMemcpyHostToDevice);
-    if (ce == hipSuccess) {
-        // the tables of a launch that leaves the constant entries of jac g alone: no slot behind their positions, no horizon-global entries
-        const int wg = h->wide ? 512 : 256, jt = JS_PAD / wg;
+    {
+        // the VARY instantiations (varying-first order): the varying run of a block, thread-major, -1 behind it
+        const int wg = h->wide ? 512 : 256, cap = vary_cap(st.terrain, wg), jt = cap / wg;
+        h->vary_ok = h->L.vary_first;
         for (int v = 0; v < 3; ++v) {
             h->cpos[v].clear();
-            for (size_t i = 0; i < h->L.jconst_pos[v].size(); ++i)
-                if (h->L.jconst_pos[v][i]) {
-                    h->cpos[v].push_back(int32_t(i));
-                    tb->jperm[v][i] = -1;
-                    tb->jperm_t[v][(int(i) % wg) * jt + int(i) / wg] = -1;
-                }
+            for (size_t i = 0; i < h->L.jconst_pos[v].size(); ++i) if (h->L.jconst_pos[v][i]) h->cpos[v].push_back(int32_t(i));
+            tb->nvary_v[v] = h->L.nvary_v[v];
+            for (int i = 0; i < VCAP_MAX; ++i) tb->jpermv_t[v][i] = -1;
+            if (h->L.nvary_v[v] > cap) h->vary_ok = false;   // (a settings combination with more varying entries than the kernels' trip count: every entry is stored)
         }
-        tb->n_glob = 0;
-        ce = hipMalloc(&h->d_tb_vary, sizeof(DeviceTables));
-        if (ce == hipSuccess) ce = hipMemcpy(h->d_tb_vary, tb, sizeof(DeviceTables), hipMemcpyHostToDevice);
+        if (h->vary_ok)
+            for (int v = 0; v < 3; ++v)
+                for (int i = 0; i < h->L.nvary_v[v]; ++i) tb->jpermv_t[v][(i % wg) * jt + i / wg] = h->L.jperm[v][size_t(i)];
     }
+    hipError_t ce = hipMemcpy(h->d_tb, tb, sizeof(DeviceTables), hipMemcpyHostToDevice);
+    if (ce == hipSuccess) ce = hipMalloc(&h->d_healed, sizeof(int32_t));
+    if (ce == hipSuccess) ce = hipMemset(h->d_healed, 0, sizeof(int32_t));
     delete tb;
     if (ce != hipSuccess) return fail(HIPNLP_E_NODEVICE, std::string("hipMemcpy tables: ") + hipGetErrorString(ce));
     {
@@ -1162,6 +1276,19 @@ static void constants_prepare(hipnlp_handle* h, const std::vector<GParams>& gp) 
         add(B - 1, h->ke - 1, h->cpos[L.variant_of(h->ke - 1)].empty() ? 0 : h->cpos[L.variant_of(h->ke - 1)].size() - 1);
     }
     // (the pinned block, the library's own, is filled when a launch that skips the constants first stores into it: host_evaluate)
+    // device copy for the VARY kernels' check and for the fill of device destinations (hipnlp_eval_device)
+    h->ctpl_len = h->ctpl.empty() ? 0 : int(h->ctpl[0].size());
+    if (h->vary_ok && h->ctpl_len > 0) {
+        if (h->d_ctpl) { (void)hipFree(h->d_ctpl); h->d_ctpl = nullptr; }
+        if (!h->d_ctpl_of_b && hipMalloc(&h->d_ctpl_of_b, size_t(h->batch) * sizeof(int32_t)) != hipSuccess) { h->d_ctpl_of_b = nullptr; h->vary_ok = false; }
+        if (h->vary_ok && hipMalloc(&h->d_ctpl, h->ctpl.size() * size_t(h->ctpl_len) * sizeof(double)) != hipSuccess) { h->d_ctpl = nullptr; h->vary_ok = false; }
+        if (h->vary_ok) {
+            for (size_t t = 0; t < h->ctpl.size(); ++t)
+                (void)hipMemcpy(h->d_ctpl + t * size_t(h->ctpl_len), h->ctpl[t].data(), size_t(h->ctpl_len) * sizeof(double), hipMemcpyHostToDevice);
+            std::vector<int32_t> of(h->ctpl_of_b.begin(), h->ctpl_of_b.end());
+            (void)hipMemcpy(h->d_ctpl_of_b, of.data(), of.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        }
+    }
 }
 // the constant entries of this handle's knots into a host array jac [batch][nnz]
 static void constants_fill(const hipnlp_handle* h, double* jac) {
@@ -1256,7 +1383,16 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     // vary_only: the constant entries of jac g are already at jac_dev (constants_ensure): the copy-out leaves them alone
     KArgs a;
     a.peer_out = peer_out; a.npeer = npeer; a.peer_rank = peer_rank;
-    a.tb = vary_only ? h->d_tb_vary : h->d_tb; a.x = x_dev; a.pk = h->d_pk; a.gp = h->d_gp;
+    a.tb = h->d_tb; a.x = x_dev; a.pk = h->d_pk; a.gp = h->d_gp;
+    {   // the check of the constants a VARY launch finds in a DEVICE destination (a host destination was spot-checked by the host: no reads over PCIe)
+        ConstCheck& c = a.cc;
+        const bool on = vary_only && !host_block && h->vary_check && jac_dev && h->d_ctpl;
+        c.jac = on ? jac_dev : nullptr; c.ctpl = on ? h->d_ctpl : nullptr; c.ctpl_of_b = h->d_ctpl_of_b; c.healed = h->d_healed;
+        c.jac_stride = h->L.nnz; c.jac_off = 0; c.ctpl_len = h->ctpl_len;
+        for (int v = 0; v < 4; ++v) c.ctpl_off[v] = h->ctpl_off[v];
+        for (int v = 0; v < 3; ++v) { c.nnz_v[v] = h->L.nnz_v[v]; c.nvary_v[v] = h->L.nvary_v[v]; }
+        c.kb = h->kb; c.nk = h->nk; c.N = h->L.N; c.n_glob = int(h->L.jperm_glob.size()); c.jac_glob_base = h->L.jac_glob_base;
+    }
     a.g = g_dev; a.jac = jac_dev; a.grad = grad_dev; a.g_stage = g_stage;
     if (shard_local) {
         hipnlp_dims dd;
@@ -1310,6 +1446,14 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
             if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 4, true>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
             else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 4, true>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
         }
+    } else if (vary_only) {   // the destination of jac g holds its constant entries: the varying run of every block only
+        if (h->wide) {
+            if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8, false, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+            else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8, false, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+        } else {
+            if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 4, false, true>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+            else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 4, false, true>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+        }
     } else if (h->wide) {   // the whole launch resident at once: eight waves per knot
         if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
         else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
@@ -1319,7 +1463,7 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 1)], s));
     if (!h->fused)
-        hipLaunchKernelGGL(hipnlp_reduce_kernel, dim3(unsigned(h->batch)), dim3(RWG), 0, s, (const double*)h->d_cost_knot, h->nk, f_dev, a.cost_terms);
+        hipLaunchKernelGGL(hipnlp_reduce_kernel, dim3(unsigned(h->batch)), dim3(RWG), 0, s, (const double*)h->d_cost_knot, h->nk, f_dev, a.cost_terms, a.cc);
     if (timed) HIP_TRY(h, hipEventRecord(e2, s));
     if (run_last) {   // (ONE event behind the run: kernel end and launch end coincide for a run)
         HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 2)], s));
@@ -1494,7 +1638,28 @@ int hipnlp_eval_device(hipnlp_handle* h, const double* x_dev, double* f_dev, dou
     if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
     HIP_TRY(h, hipSetDevice(h->dev));
     h->have_result = false;
-    return launch(h, x_dev, f_dev ? f_dev : h->d_f, grad_dev, g_dev, jac_dev, stream ? hipStream_t(stream) : h->stream);
+    hipStream_t s = stream ? hipStream_t(stream) : h->stream;
+    // Varying-first layout: a jac buffer is filled with the constant entries at its first sight (and again after hipnlp_set_params),
+    // on the caller's stream in front of the evaluation; from then on the launches store the varying run of every block only and
+    // check the constants they find (a buffer the caller wrote over is repaired by the kernel itself).
+    bool vary = false;
+    if (jac_dev && h->skip_const && h->vary_ok && h->d_ctpl && h->L.nconst_total > 0) {
+        int slot = -1;
+        for (int i = 0; i < 8; ++i) if (h->dfilled[i].dev == jac_dev) slot = i;
+        if (slot < 0 || h->dfilled[slot].gen != h->param_gen) {
+            const Layout& L = h->L;
+            hipLaunchKernelGGL(hipnlp_fill_const_kernel, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(256), 0, s, jac_dev, (const double*)h->d_ctpl,
+                               (const int32_t*)h->d_ctpl_of_b, h->ctpl_len, h->ctpl_off[0], h->ctpl_off[1], h->ctpl_off[2], h->ctpl_off[3], h->kb, L.N, int64_t(L.nnz),
+                               L.nnz_v[VAR_FIRST], L.nnz_v[VAR_INTERIOR], L.nnz_v[VAR_LAST], L.nvary_v[VAR_FIRST], L.nvary_v[VAR_INTERIOR], L.nvary_v[VAR_LAST],
+                               h->ke == L.N ? int(L.jperm_glob.size()) : 0);
+            HIP_TRY(h, hipGetLastError());
+            if (slot < 0) { slot = h->dfilled_next; h->dfilled_next = (h->dfilled_next + 1) % 8; }
+            h->dfilled[slot] = {jac_dev, h->param_gen};
+            h->dev_const_fills++;
+        }
+        vary = true;
+    }
+    return launch(h, x_dev, f_dev ? f_dev : h->d_f, grad_dev, g_dev, jac_dev, s, nullptr, false, false, false, nullptr, 0, 0, vary);
 }
 
 int hipnlp_eval_device_shard(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_shard, double* g_stage, double* jac_shard, void* stream) {
@@ -1685,7 +1850,7 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
         //  CCS-ordered block leaves fragments of one to four doubles on the link — measured SLOWER than storing everything, 59.7
         //  against 55.0 us per 100-knot call, profiles/r04_host_path.txt.)
         bool vary_only = false;
-        if (h->skip_const && h->L.vary_first && h->L.nconst_total > 0 && sel[2] != 0u) {
+        if (h->skip_const && h->vary_ok && h->L.nconst_total > 0 && sel[2] != 0u) {
             if (sel[2] == 1u) {
                 if (h->pinned_const_gen != h->param_gen) { constants_fill(h, h->h_jac); h->pinned_const_gen = h->param_gen; }
             } else constants_ensure(h, caller_host[2]);
@@ -1780,7 +1945,7 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
         size_t w_first[3] = {0, 0, 0}, w_last[3] = {bytes[0] / 8 - 1, bytes[1] / 8 - 1, bytes[2] / 8 - 1};
         for (int q = 0; q < 3; ++q) {
             if (!(missing & bit[q])) continue;
-            const bool vary_run = q == 2 && caller[q] && caller_dev[q] && h->skip_const && h->L.vary_first && h->L.nconst_total > 0;
+            const bool vary_run = q == 2 && caller[q] && caller_dev[q] && h->skip_const && h->vary_ok && h->L.nconst_total > 0;
             if (vary_run) { constants_ensure(h, caller[q]); w_first[q] = h->jac_first_vary; w_last[q] = h->jac_last_vary; }
             if (caller[q]) {
                 to_caller |= bit[q];
@@ -1878,7 +2043,10 @@ int hipnlp_set_auto_register(hipnlp_handle* h, int on) {
 int hipnlp_host_stats(const hipnlp_handle* h, long* out /*[8]*/) {
     if (!h || !out) return HIPNLP_E_INVALID;
     out[0] = h->auto_registered; out[1] = h->auto_fallbacks; out[2] = long(auto_count(h));
-    out[3] = long(h->seq); out[4] = h->const_fills; out[5] = h->const_refills; out[6] = long(h->L.nconst_total); out[7] = 0;
+    out[3] = long(h->seq); out[4] = h->const_fills + h->dev_const_fills; out[5] = h->const_refills; out[6] = long(h->L.nconst_total);
+    int32_t healed = 0;   // (wave slices of constants a VARY kernel put back into a device buffer; the copy waits for the device)
+    if (h->d_healed && hipSetDevice(h->dev) == hipSuccess && hipMemcpy(&healed, h->d_healed, sizeof healed, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); healed = -1; }
+    out[7] = healed;
     return HIPNLP_OK;
 }
 

@@ -132,7 +132,11 @@ template <int LAYOUT> struct alignas(16) KnotScratchT : ScratchJrOwn<LAYOUT != L
     double c_pt[NC][3], c_joint[NJ], c_force[2][3], c_yaw[2];
     double cost[NCT];
     double grad[XPAD];
+#ifdef HIPNLP_EXP_JAC_SLOTS
+    double jac[compact ? HIPNLP_EXP_JAC_SLOTS : js::COUNT];   // (occupancy experiment: resources only, results wrong)
+#else
     double jac[js::COUNT];
+#endif
     // value of native g slot `slot` / where the emitter stores it
     HD double& g_at(int slot) {
         if constexpr (compact) return slot >= gs::FIN ? this->ends.c[slot - gs::FIN] : this->g[slot];
@@ -926,13 +930,13 @@ template <class Em> HD void t_fk_rot_at(Ctx<Em>& cx, int t, int q0) {
     // q0: every list of this task group is padded up to there (group-uniform: the arithmetic of the leading identity steps is skipped).
     // The record of step q + 1 is read while step q is computed (two register buffers, static step numbers): a step is one LDS round
     // trip PLUS three dependent levels of fp64 arithmetic otherwise, ~360 cycles, eight times over on the longest chain of phase B.
-    int ia[8];
-    HIPNLP_UNROLL
-    for (int q = 0; q < 8; ++q) ia[q] = cx.kt.anc[j][q];
+    // (the eight ancestor indices stay packed in the 8-byte word they are stored as: two registers instead of eight)
+    const unsigned long long ia_w = *reinterpret_cast<const unsigned long long*>(cx.kt.anc[j]);
     double rec[2][16];   // the eight 16-byte chunks of a record, un-swizzled into registers
     auto fetch = [&](int q, double* rc) {
-        const double* rp = s.Jr[ia[q]].d;
-        const int sw = (ia[q] & 7) << 1;
+        const int iq = int((ia_w >> (8 * q)) & 0xffull);
+        const double* rp = s.Jr[iq].d;
+        const int sw = (iq & 7) << 1;
         HIPNLP_UNROLL
         for (int ch = 0; ch < 8; ++ch) { const int pp = (2 * ch) ^ sw; rc[2 * ch] = rp[pp]; rc[2 * ch + 1] = rp[pp + 1]; }
     };

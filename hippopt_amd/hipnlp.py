@@ -322,7 +322,7 @@ class HipNlp:
     def host_stats(self):
         out = (C.c_long * 8)()
         self._check(self.lib.hipnlp_host_stats(self.h, out))
-        return dict(zip(("auto_registered", "auto_fallbacks", "auto_ranges", "evaluations", "constant_fills", "constant_refills", "constant_entries"), list(out)))
+        return dict(zip(("auto_registered", "auto_fallbacks", "auto_ranges", "evaluations", "constant_fills", "constant_refills", "constant_entries", "constant_slices_healed"), list(out)))
 
     def set_constant_jacobian(self, on=True):
         """hipnlp_set_constant_jacobian: host destinations of jac g hold the constant entries, launches store the varying ones only (default on)"""

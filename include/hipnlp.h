@@ -278,7 +278,13 @@ int hipnlp_set_prefetch(hipnlp_handle* h, unsigned mask);
  * covered by a spot check — sixteen constant entries spread over the array, its first and its last among them, are compared before every
  * such launch and the array is re-filled when one differs (hipnlp_host_stats out[5] counts these) — not by a guarantee: a caller
  * that edits single entries of a registered Jacobian array must turn this off.  Arrays that are NOT registered always receive complete
- * values by a copy out of the pinned block.  Device-resident outputs (hipnlp_eval_device) are not affected: every entry is stored.
+ * values by a copy out of the pinned block.
+ * Device-resident outputs (hipnlp_eval_device, varying-first handles): a jac_dev buffer is filled with the constant entries at its first
+ * sight and again after hipnlp_set_params (one small launch on the call's stream, in front of the evaluation); the evaluations store the
+ * varying run of every knot block only and no longer stage the constants in LDS at all.  Same contract — the caller does not write into
+ * the buffer between calls — and the kernel itself checks it: every wave compares a few dozen of the constants it finds with the
+ * handle's templates and puts its slice of the block's constants back when one differs (hipnlp_host_stats out[7] counts such repairs).
+ * hipnlp_eval_device_shard / _peers are not affected: every entry is stored.
  * on = 0: every launch stores every entry (the behaviour of ABI 2 libraries before this switch existed). */
 int hipnlp_set_constant_jacobian(hipnlp_handle* h, int on);
 /* Early outputs (opt-in, off by default).  on = 1: a NEW evaluation stores g and jac g — when its call does NOT ask for them —
@@ -323,7 +329,8 @@ int hipnlp_host_unregister(void* p);
 int hipnlp_set_auto_register(hipnlp_handle* h, int on);
 /* Counters of the host-buffer path: out[0] arrays auto-registered so far, out[1] stale-mapping fallbacks, out[2] ranges currently
  * auto-registered, out[3] evaluations so far (kernel launches), out[4] caller arrays filled with the constant Jacobian entries so far,
- * out[5] of which re-fills after a failed spot check, out[6] constant entries of the handle's pattern, out[7] reserved (0). */
+ * out[5] of which re-fills after a failed spot check, out[6] constant entries of the handle's pattern, out[7] wave slices of constants
+ * the kernels put back into device buffers the caller had written over (read from the device: the call waits for a small copy). */
 int hipnlp_host_stats(const hipnlp_handle* h, long* out /*[8]*/);
 
 

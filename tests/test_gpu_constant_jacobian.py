@@ -197,3 +197,66 @@ def test_two_live_handles_and_an_array_address_that_is_reused(model, HipNlp):
     a.close()
     b.close()
     ref.close()
+
+
+def test_device_resident_jacobian_holds_its_constants_and_is_repaired_when_overwritten(model, HipNlp):
+    """hipnlp_eval_device on a varying-first handle: the jac buffer is filled with the constants at its first sight (and after
+    hipnlp_set_params), the launches store the varying run of every block only (VARY instantiations: the constants are not even
+    staged in LDS) — the buffer always holds the complete Jacobian; a buffer the caller wrote over is repaired by the kernel itself.
+    Both kernel variants (eight waves: one trajectory; four waves: a batch), both terrains, a shard handle too."""
+    import torch
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    for maker, N, B, shard in ((periodic_step_settings, 40, 1, None), (periodic_step_settings, 12, 48, None), (stairs_settings, 10, 1, None),
+                               (stairs_settings, 7, 80, None), (periodic_step_settings, 20, 1, (5, 13))):
+        st = maker(N, model)
+        x, p = make_workload(st, model, batch=B, seed=7500 + N)
+        if maker is stairs_settings:
+            place_on_step_flanks(x, st, seed=7500)
+        kw = dict(knot_begin=shard[0], knot_end=shard[1]) if shard else {}
+        full = HipNlp(st, model, batch=B, **kw)
+        eng = HipNlp(st, model, batch=B, jac_varying_first=True, **kw)
+        ir, jc = eng.sparsity()
+        pos = {(int(r), int(c)): i for i, (r, c) in enumerate(zip(*full.sparsity()))}
+        order = torch.from_numpy(np.array([pos[(int(r), int(c))] for r, c in zip(ir, jc)])).to(dev)
+        p2 = p.copy()
+        p2[:, 24 * N + 3 + 105 + 105] *= 1.3      # dt
+        with torch.cuda.stream(stream):
+            xd = [torch.from_numpy(xi).to(dev) for xi in iterates(x, 3)]
+            # (a shard handle writes its own knots' part of every array: what lies outside must compare equal too)
+            mk = lambda: [torch.full((B * k,), 0.0 if shard else float("nan"), dtype=torch.float64, device=dev) for k in (1, eng.n, eng.m, eng.nnz)]
+            out, ref, other = mk(), mk(), mk()
+        stream.synchronize()
+        sh = stream.cuda_stream
+
+        def both(i, dst):
+            full.eval_device(xd[i].data_ptr(), *[t.data_ptr() for t in ref], stream=sh)
+            eng.eval_device(xd[i].data_ptr(), *[t.data_ptr() for t in dst], stream=sh)
+            stream.synchronize()
+            for a, b_ in zip(dst[:3], ref[:3]):
+                assert torch.equal(a, b_), (maker.__name__, N, B, i)
+            got, want = dst[3].view(B, -1), ref[3].view(B, -1)[:, order]
+            if shard:   # (a shard handle writes the blocks of its own knots: the rest of the array is not its business)
+                mine = (torch.from_numpy(jc // 189).to(dev) >= shard[0]) & (torch.from_numpy(jc // 189).to(dev) < shard[1])
+                got, want = got[:, mine], want[:, mine]
+            assert torch.equal(got, want), (maker.__name__, N, B, i, int((got != want).sum()))
+        for params in (p, p2):
+            for e in (full, eng):
+                e.set_params(params)
+            for i in range(3):
+                both(i, out)
+            both(0, other)                      # a second buffer: filled at its first sight as well
+        assert eng.host_stats()["constant_slices_healed"] == 0
+        fills = eng.host_stats()["constant_fills"]
+        assert fills == 4                       # two buffers x two parameter sets
+        out[3].zero_()                          # the caller writes over its buffer between two calls ...
+        both(1, out)                            # ... and still reads the complete Jacobian
+        st_ = eng.host_stats()
+        assert st_["constant_slices_healed"] > 0 and st_["constant_fills"] == fills
+        both(2, out)
+        assert eng.host_stats()["constant_slices_healed"] == st_["constant_slices_healed"]    # repaired once, in place from then on
+        eng.set_constant_jacobian(False)        # every entry stored again: the same values
+        out[3].fill_(0.0 if shard else float("nan"))
+        both(0, out)
+        eng.close()
+        full.close()

@@ -38,7 +38,7 @@ def test_every_kernel_is_there_and_none_needs_scratch(res):
         assert r["scratch"] == 0, "%s spills %d B per lane to scratch" % (name, r["scratch"])
 
 
-@pytest.mark.parametrize("peers", ["", ",true"])
+@pytest.mark.parametrize("peers", ["", ",true", ",false,true"])     # plain, peer exchange, VARY (the constants of jac g are not staged or stored)
 @pytest.mark.parametrize("terrain", [0, 1])
 def test_four_wave_callback_kernel_fits_four_workgroups_per_cu(res, terrain, peers):
     r = res["hipnlp_knot_kernel<%d,4%s>" % (terrain, peers)]
@@ -47,7 +47,7 @@ def test_four_wave_callback_kernel_fits_four_workgroups_per_cu(res, terrain, pee
     assert _granule(r["vgpr"] + r["agpr"]) * 4 <= VGPR_FILE, r      # four waves per SIMD
 
 
-@pytest.mark.parametrize("peers", ["", ",true"])
+@pytest.mark.parametrize("peers", ["", ",true", ",false,true"])
 @pytest.mark.parametrize("terrain", [0, 1])
 def test_eight_wave_callback_kernel_fits_two_workgroups_per_cu(res, terrain, peers):
     """hipnlp.hip picks it for (knots + 1) x batch <= 512 = 256 CUs x 2"""
