@@ -115,18 +115,17 @@ template <int TERRAIN, int WAVES = 4, bool VARY = false> struct DevEm {
     static constexpr int kWaves = WAVES;
     static constexpr int kLayout = WAVES == 4 ? LAYOUT_COMPACT : LAYOUT_FULL;
     static constexpr bool kCompact = kLayout != LAYOUT_FULL;
-    using Scratch = KnotScratchT<kLayout>;
+    // VARY on the compact scratch: the staging of jac g holds the slots that may depend on x only (nlp_defs.h: [js::V0, js::V0 +
+    // js::vary_slots(terrain))) — 31.5 KB of LDS per workgroup on the planar terrain instead of 40.8: room for a FIFTH workgroup per CU
+    static constexpr bool kTrim = VARY && kCompact;
+    static constexpr int kJacOff = kTrim ? js::V0 : 0;
+    using Scratch = KnotScratchT<kLayout, kTrim ? js::vary_slots(TERRAIN == HIPNLP_TERRAIN_PLANAR) : js::COUNT>;
     double* g;
-    double* jac;
+    double* jac;   // (base of the staging moved back by kJacOff: indexed by native slot)
     __device__ __forceinline__ void G(int slot, int, double v) { g[slot] = v; }   // (horizon-end rows go through emit_g_end)
-#ifdef HIPNLP_EXP_JAC_SLOTS   // (occupancy experiment: the compact scratch's jac staging folded onto 512 slots — timing only, WRONG values)
-    static constexpr int kFold = WAVES == 4 ? 511 : 0x7fffffff;
-#else
-    static constexpr int kFold = 0x7fffffff;
-#endif
-    __device__ __forceinline__ void J(int slot, int, int, double v) { jac[slot & kFold] = v; }
+    __device__ __forceinline__ void J(int slot, int, int, double v) { jac[slot] = v; }
     // entries that do not depend on x (emit_jc): a VARY instantiation neither stages nor stores them — its destination holds them
-    __device__ __forceinline__ void JC(int slot, int, int, double v) { if constexpr (!VARY) jac[slot & kFold] = v; }
+    __device__ __forceinline__ void JC(int slot, int, int, double v) { if constexpr (!VARY) jac[slot] = v; }
 };
 
 // LDS image of the read-only tables every phase indexes per lane (global memory would cost one L2 round trip per phase)
@@ -156,6 +155,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // Tag of a published cost partial (eight-wave variant): the pair {v, v ^ pub_pattern(seq)} is valid for launch `seq` and for no other,
 // whichever of its two words a reader happens to see first (see the reducer in hipnlp_knot_kernel).
 __device__ __forceinline__ unsigned long long pub_pattern(int32_t seq) { return ((unsigned long long)(uint32_t)seq * 0x9E3779B97F4A7C15ull) | 1ull; }
+// knots per trajectory the in-launch reducer workgroup can stage in the scratch of its kernel ([nk][16] doubles): 256, less on the
+// trimmed scratch of the four-wave VARY kernels (hipnlp_create keeps `fused` within the smallest cap of the kernels a handle may launch)
+template <class Scratch> constexpr int reducer_cap() { return sizeof(Scratch) / (16 * sizeof(double)) >= 256 ? 256 : int(sizeof(Scratch) / (16 * sizeof(double))) / 16 * 16; }
 constexpr int PUB_SPIN_CAP = 1 << 20;   // polls of the reducer before it gives up (each at least one memory round trip: > 1 s)
 
 // VARY launches into a DEVICE destination: are the constant entries of trajectory b's knot blocks in place?  Run by the ONE workgroup
@@ -205,11 +207,15 @@ __device__ __forceinline__ void constants_check_and_repair(const ConstCheck& c, 
 // run-time branch — as a branch the unused path cost the plain callback 1.2 % at N = 100 (7.99 against 7.89 us) and 0.8 % at x 64.
 // VARY: the instantiation for destinations that already hold the constant entries of jac g (varying-first order of a block): the
 // tasks do not stage them (DevEm::JC), the copy-out walks the varying run of the block only — half the trips on the planar terrain.
-template <int TERRAIN, int WAVES, bool PEERS = false, bool VARY = false> __global__ __launch_bounds__(64 * WAVES)
-#ifndef HIPNLP_EXP_WPE
-#define HIPNLP_EXP_WPE 4
+// FIVE workgroups per CU: the four-wave VARY kernel of the planar terrain, whose trimmed Jacobian staging leaves 31.6 KB of LDS per
+// workgroup — with a register budget of 96 (five waves per SIMD), which it meets by fetching its copy-out tables behind the last
+// barrier but one instead of holding them from the first instruction (LATE_TABLES below).
+#ifndef HIPNLP_FIVE_PER_CU
+#define HIPNLP_FIVE_PER_CU 1
 #endif
-__attribute__((amdgpu_waves_per_eu(WAVES == 4 ? (VARY ? HIPNLP_EXP_WPE : 4) : 2, WAVES == 4 && VARY ? HIPNLP_EXP_WPE : 4)))
+template <int TERRAIN, int WAVES, bool VARY> constexpr bool five_per_cu = HIPNLP_FIVE_PER_CU && VARY && WAVES == 4 && TERRAIN == HIPNLP_TERRAIN_PLANAR;
+template <int TERRAIN, int WAVES, bool PEERS = false, bool VARY = false> __global__ __launch_bounds__(64 * WAVES)
+__attribute__((amdgpu_waves_per_eu(WAVES == 4 ? (five_per_cu<TERRAIN, WAVES, VARY> ? 5 : 4) : 2, five_per_cu<TERRAIN, WAVES, VARY> ? 5 : 4)))
 void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const double* pk_p, const GParams* gp_p, int N_p, int n_p, int kb_p, int nk_p, KArgs a) {
     static_assert(!(PEERS && VARY), "the peer exchange stores every entry");
     // the leading scalar arguments repeat what the staging loads need: the build preloads them into SGPRs
@@ -251,9 +257,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             if constexpr (VARY) constants_check_and_repair(a.cc, b, WG, reinterpret_cast<int*>(&s));   // (while the knot workgroups of the row run their programs)
             __syncthreads();
             double* red = reinterpret_cast<double*>(&s);   // [nk][16]
-#ifndef HIPNLP_EXP_JAC_SLOTS
-            static_assert(sizeof(Scratch) >= 256 * 16 * sizeof(double), "reducer staging: nk <= 256");
-#endif
+            static_assert(sizeof(Scratch) >= size_t(reducer_cap<Scratch>()) * 16 * sizeof(double) && reducer_cap<Scratch>() >= 200, "reducer staging");
             const unsigned long long pat = pub_pattern(a.seq);
             const unsigned long long* base = a.cost_pub + size_t(b) * a.nk * NCT * 2;
             const int t = lane & 15, q = lane >> 4;
@@ -345,11 +349,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     int nnz_first = 0, nnz_interior = 0, n_glob = 0, jac_glob_base = 0;   // (scalars of the copy-out: read behind the vector loads, used at the end)
     int jpg = 0;
     int32_t jp[JP_ITERS], ga[G_ITERS], gb[G_ITERS];
-#ifdef HIPNLP_EXP_LATE_TABLES
-    constexpr bool LATE_TABLES = VARY && WAVES == 4;
-#else
-    constexpr bool LATE_TABLES = false;
-#endif
+    constexpr bool LATE_TABLES = five_per_cu<TERRAIN, WAVES, VARY>;
     auto fetch_tables = [&]() __attribute__((always_inline)) {
         const DeviceTables& tbl = *tb_p;
         jpg = tbl.jperm_glob[tid & 15];
@@ -446,7 +446,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     };
 
     KnotInfo ki{k, N, first, last};
-    Em em{s.g, s.jac};
+    Em em{s.g, s.jac - Em::kJacOff};
     // (the full tables: global memory for the compact layouts; the full layout's LDS copy otherwise — the constructor's default)
     Ctx<Em> cx(s, tabs.kin(), tabs.settings(), tabs.gp, ki, em, COMPACT ? &tb.head.kt : nullptr, COMPACT ? gp_p + b : nullptr);
     // The program is instantiated ONCE PER WAVE (a generic lambda over the wave number as a compile-time constant: a task group is
@@ -472,7 +472,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 #define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); if constexpr (W == PUBW) pub_step(bid); bid++;
 #else
     int bid = 0;
-#define DEV_BARRIER lds_barrier(); if constexpr (W == PUBW) pub_step(bid); if constexpr (LATE_TABLES) { if (bid == 3) fetch_tables(); } bid++;
+#define DEV_BARRIER lds_barrier(); if constexpr (W == PUBW) pub_step(bid); if constexpr (LATE_TABLES) { if (bid == 4) fetch_tables(); } bid++;
 #endif
     auto run_wave = [&](auto wc) __attribute__((always_inline)) {
         constexpr int W = decltype(wc)::value;
@@ -512,7 +512,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     double jvals[JP_ITERS], gvals[G_ITERS], grvals[GR_ITERS];
     // (unconditional, clamped indices, no branch: every LDS read of the copy-out is in flight before the first wait)
 #pragma unroll
-    for (int it = 0; it < JP_ITERS; ++it) jvals[it] = s.jac[(jp[it] >= 0 ? jp[it] : 0) & Em::kFold];
+    for (int it = 0; it < JP_ITERS; ++it) jvals[it] = em.jac[jp[it] >= 0 ? jp[it] : Em::kJacOff];
 #pragma unroll
     for (int it = 0; it < G_ITERS; ++it) gvals[it] = s.g_at((tid + it * WG) < gs::COUNT ? tid + it * WG : 0);
 #pragma unroll
@@ -886,8 +886,11 @@ double* device_address_of(const void* p, size_t bytes) {
     if (!p) return nullptr;
     std::lock_guard<std::mutex> lock(g_ranges_mutex);
     const char* q = static_cast<const char*>(p);
-    for (const HostRange& r : g_ranges)
+    // (newest first: where a fresh registration and an older one that has gone stale both cover p, the fresh one answers)
+    for (size_t i = g_ranges.size(); i-- > 0;) {
+        const HostRange& r = g_ranges[i];
         if (q >= r.host && q + bytes <= r.host + r.bytes) return reinterpret_cast<double*>(r.dev + (q - r.host));
+    }
     return nullptr;
 }
 
@@ -996,6 +999,7 @@ struct hipnlp_handle {
         hipError_t e_ = (call);                                                                     \
         if (e_ != hipSuccess) {                                                                     \
             (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+            (void)hipGetLastError(); /* (reported here: not left behind for the next launch's check) */ \
             return HIPNLP_E_NODEVICE;                                                               \
         }                                                                                           \
     } while (0)
@@ -1017,6 +1021,7 @@ static void free_all(hipnlp_handle* h) {
 
 extern "C" {
 
+hipError_t hipnlp_internal_memcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
 static void auto_unregister_all(hipnlp_handle* h);
 static void constants_prepare(hipnlp_handle* h, const std::vector<GParams>& gp);
 static void constants_fill(const hipnlp_handle* h, double* jac);
@@ -1067,7 +1072,13 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
         // (measured, four-wave kernel, N = 100: + 2.4 % at x 64 and + 6.5 % on the stairs 200 x 16, whose second launch is 3 of 53 us;
         //  - 1.1 % at x 1024, where ten rows are in flight and as many reducers spin in workgroup slots: long launches keep the kernel)
         const bool small_launch = long(h->nk) * long(desc->batch) <= 32768;
-        h->fused = h->nk <= 256 && (h->wide || (small_launch && !(sep && std::atoi(sep) == 1)));
+        // (the reducer workgroup stages [nk][16] doubles in its kernel's scratch: 256 knots, fewer on the trimmed scratch of the four-wave
+        //  VARY kernels a varying-first handle launches)
+        int red_cap = 256;
+        if (!h->wide && (desc->flags & HIPNLP_FLAG_JAC_VARYING_FIRST))
+            red_cap = st.terrain == HIPNLP_TERRAIN_PLANAR ? reducer_cap<KnotScratchT<LAYOUT_COMPACT, js::vary_slots(true)>>()
+                                                          : reducer_cap<KnotScratchT<LAYOUT_COMPACT, js::vary_slots(false)>>();
+        h->fused = h->nk <= red_cap && (h->wide || (small_launch && !(sep && std::atoi(sep) == 1)));
         const char* hl = std::getenv("HIPNLP_HESS_LAYOUT");   // diagnostic override: full | compact
         h->hess_compact = hl ? std::strcmp(hl, "compact") == 0 : long(h->nk) * long(desc->batch) > 512;
     }
@@ -1176,7 +1187,7 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
             for (int v = 0; v < 3; ++v)
                 for (int i = 0; i < h->L.nvary_v[v]; ++i) tb->jpermv_t[v][(i % wg) * jt + i / wg] = h->L.jperm[v][size_t(i)];
     }
-    hipError_t ce = hipMemcpy(h->d_tb, tb, sizeof(DeviceTables), hipMemcpyHostToDevice);
+    hipError_t ce = hipnlp_internal_memcpy(h->d_tb, tb, sizeof(DeviceTables), hipMemcpyHostToDevice);
     if (ce == hipSuccess) ce = hipMalloc(&h->d_healed, sizeof(int32_t));
     if (ce == hipSuccess) ce = hipMemset(h->d_healed, 0, sizeof(int32_t));
     delete tb;
@@ -1284,9 +1295,9 @@ static void constants_prepare(hipnlp_handle* h, const std::vector<GParams>& gp) 
         if (h->vary_ok && hipMalloc(&h->d_ctpl, h->ctpl.size() * size_t(h->ctpl_len) * sizeof(double)) != hipSuccess) { h->d_ctpl = nullptr; h->vary_ok = false; }
         if (h->vary_ok) {
             for (size_t t = 0; t < h->ctpl.size(); ++t)
-                (void)hipMemcpy(h->d_ctpl + t * size_t(h->ctpl_len), h->ctpl[t].data(), size_t(h->ctpl_len) * sizeof(double), hipMemcpyHostToDevice);
+                (void)hipnlp_internal_memcpy(h->d_ctpl + t * size_t(h->ctpl_len), h->ctpl[t].data(), size_t(h->ctpl_len) * sizeof(double), hipMemcpyHostToDevice);
             std::vector<int32_t> of(h->ctpl_of_b.begin(), h->ctpl_of_b.end());
-            (void)hipMemcpy(h->d_ctpl_of_b, of.data(), of.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+            (void)hipnlp_internal_memcpy(h->d_ctpl_of_b, of.data(), of.size() * sizeof(int32_t), hipMemcpyHostToDevice);
         }
     }
 }
@@ -1333,8 +1344,8 @@ int hipnlp_set_params(hipnlp_handle* h, const double* p) {
     std::vector<GParams> gp(B);
     for (size_t b = 0; b < B; ++b) pack_params(p + b * size_t(h->np), int(N), pk.data() + b * N * PK_STRIDE, gp[b]);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy(h->d_pk, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->d_gp, gp.data(), gp.size() * sizeof(GParams), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipnlp_internal_memcpy(h->d_pk, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipnlp_internal_memcpy(h->d_gp, gp.data(), gp.size() * sizeof(GParams), hipMemcpyHostToDevice));
     h->params_set = true;
     h->have_result = false;
     constants_prepare(h, gp);
@@ -1504,7 +1515,7 @@ static int hess_prepare(hipnlp_handle* h) {
     for (int i = 0; i < hk::COUNT; ++i) t->perm[i] = i < h->HL.nnz_knot ? h->HL.perm[size_t(i)] : -1;
     for (int i = 0; i < 84; ++i) t->perm_couple[i] = i < h->HL.n_couple ? h->HL.perm_couple[size_t(i)] : -1;
     t->nnz_knot = h->HL.nnz_knot; t->n_couple = h->HL.n_couple;
-    const hipError_t e = hipMemcpy(h->d_ht, t, sizeof(HessTables), hipMemcpyHostToDevice);
+    const hipError_t e = hipnlp_internal_memcpy(h->d_ht, t, sizeof(HessTables), hipMemcpyHostToDevice);
     delete t;
     if (e != hipSuccess) { h->err = std::string("Hessian tables: ") + hipGetErrorString(e); return HIPNLP_E_NODEVICE; }
     h->hess_state = 1;
@@ -1972,7 +1983,7 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
                     (void)drop_stale_range(h, caller[q]);
                     h->no_auto[q] = caller[q];
                     h->auto_fallbacks++;
-                    HIP_TRY(h, hipMemcpy(pinned[q], hbm[q], bytes[q], hipMemcpyDeviceToHost));
+                    HIP_TRY(h, hipnlp_internal_memcpy(pinned[q], hbm[q], bytes[q], hipMemcpyDeviceToHost));
                     to_caller &= ~bit[q];   // (hipnlp_eval copies it out of the pinned block)
                 }
             }
@@ -2045,7 +2056,7 @@ int hipnlp_host_stats(const hipnlp_handle* h, long* out /*[8]*/) {
     out[0] = h->auto_registered; out[1] = h->auto_fallbacks; out[2] = long(auto_count(h));
     out[3] = long(h->seq); out[4] = h->const_fills + h->dev_const_fills; out[5] = h->const_refills; out[6] = long(h->L.nconst_total);
     int32_t healed = 0;   // (wave slices of constants a VARY kernel put back into a device buffer; the copy waits for the device)
-    if (h->d_healed && hipSetDevice(h->dev) == hipSuccess && hipMemcpy(&healed, h->d_healed, sizeof healed, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); healed = -1; }
+    if (h->d_healed && hipSetDevice(h->dev) == hipSuccess && hipnlp_internal_memcpy(&healed, h->d_healed, sizeof healed, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); healed = -1; }
     out[7] = healed;
     return HIPNLP_OK;
 }
@@ -2102,6 +2113,18 @@ int hipnlp_host_register(void* p, size_t bytes, void** dev_ptr) {
         }
         if (taken) (void)hipnlp_host_unregister(p);
     }
+    {   // Ranges that HANDLES registered by themselves and that overlap [p, p + bytes) describe memory that has changed hands — an
+        // array was freed and this one took its addresses: they go before the new registration is made (their owners look their
+        // arrays up again at every use and simply find nothing).
+        std::vector<char*> stale;
+        {
+            std::lock_guard<std::mutex> lock(g_ranges_mutex);
+            const char* q = static_cast<const char*>(p);
+            for (const HostRange& r : g_ranges)
+                if (r.owner != nullptr && q < r.host + r.bytes && r.host < q + bytes) stale.push_back(r.host);
+        }
+        for (char* sp : stale) (void)hipnlp_host_unregister(sp);
+    }
     if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return HIPNLP_E_NODEVICE; }
     void* d = nullptr;
     if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) { (void)hipHostUnregister(p); (void)hipGetLastError(); return HIPNLP_E_NODEVICE; }
@@ -2109,6 +2132,27 @@ int hipnlp_host_register(void* p, size_t bytes, void** dev_ptr) {
     std::lock_guard<std::mutex> lock(g_ranges_mutex);
     g_ranges.push_back(HostRange{static_cast<char*>(p), bytes, static_cast<char*>(d), nullptr});
     return HIPNLP_OK;
+}
+int hipnlp_host_release_auto_ranges(void) {
+    std::vector<char*> all;
+    {
+        std::lock_guard<std::mutex> lock(g_ranges_mutex);
+        for (const HostRange& r : g_ranges) if (r.owner != nullptr) all.push_back(r.host);
+    }
+    for (char* q : all) (void)hipnlp_host_unregister(q);
+    return int(all.size());
+}
+// A copy between plain host memory and the device that the runtime refuses with "invalid argument": the host buffer (heap memory of the
+// library or of the caller) may lie inside a range some handle registered by itself for an array that has been FREED since — the
+// allocator handed its addresses out again, the runtime still believes the old registration.  Those registrations are conveniences
+// the handles re-create whenever they see their arrays again: all are released and the copy is tried once more.
+extern "C" hipError_t hipnlp_internal_memcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    hipError_t e = hipMemcpy(dst, src, bytes, kind);
+    if (e == hipErrorInvalidValue) {
+        (void)hipGetLastError();
+        if (hipnlp_host_release_auto_ranges() > 0) e = hipMemcpy(dst, src, bytes, kind);
+    }
+    return e;
 }
 int hipnlp_host_unregister(void* p) {
     if (!p) return HIPNLP_E_INVALID;
@@ -2129,7 +2173,7 @@ int hipnlp_cost_terms(hipnlp_handle* h, double* values) {
     if (!h->have_result) {   // a device-path evaluation: its per-term costs are in device memory (the host path stores them straight to the pinned block)
         HIP_TRY(h, hipSetDevice(h->dev));
         HIP_TRY(h, hipDeviceSynchronize());   // (the launch may sit on a stream of the caller's: hipnlp_eval_device(..., stream))
-        HIP_TRY(h, hipMemcpy(h->h_cost_terms, h->d_cost_terms, size_t(h->batch) * NCT * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipnlp_internal_memcpy(h->h_cost_terms, h->d_cost_terms, size_t(h->batch) * NCT * sizeof(double), hipMemcpyDeviceToHost));
     }
     std::memcpy(values, h->h_cost_terms, size_t(h->batch) * NCT * sizeof(double));
     return HIPNLP_OK;
@@ -2320,7 +2364,7 @@ int hipnlp_debug_stamps(hipnlp_handle* h, unsigned long long* out /*[nk*batch][4
     HIP_TRY(h, hipSetDevice(h->dev));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipMemcpy(out, h->d_stamps, size_t(h->nk) * size_t(h->batch) * 1024 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipnlp_internal_memcpy(out, h->d_stamps, size_t(h->nk) * size_t(h->batch) * 1024 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return HIPNLP_OK;
 }
 #endif

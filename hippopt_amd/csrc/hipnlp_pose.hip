@@ -19,6 +19,9 @@
 
 #include "pose_layout.h"
 
+// (hipnlp.hip: hipMemcpy that survives a host buffer inside a stale self-registered range)
+extern "C" hipError_t hipnlp_internal_memcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+
 using namespace hipnlp;
 
 namespace {
@@ -268,6 +271,7 @@ struct hipnlp_pose_handle {
         hipError_t e_ = (call);                                                                     \
         if (e_ != hipSuccess) {                                                                     \
             (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+            (void)hipGetLastError();                                                                \
             return HIPNLP_E_NODEVICE;                                                               \
         }                                                                                           \
     } while (0)
@@ -377,7 +381,7 @@ int hipnlp_pose_create(const hipnlp_pose_desc* desc, hipnlp_pose_handle** out) {
     tb->nnz = h->L.nnz; tb->m = h->L.m;
     for (int e = 0; e < h->L.hnnz; ++e) tb->hperm[e] = h->L.hperm[size_t(e)];
     tb->hnnz = h->L.hnnz;
-    hipError_t ce = hipMemcpy(h->d_tb, tb, sizeof(PoseTables), hipMemcpyHostToDevice);
+    hipError_t ce = hipnlp_internal_memcpy(h->d_tb, tb, sizeof(PoseTables), hipMemcpyHostToDevice);
     delete tb;
     if (ce != hipSuccess) return fail(HIPNLP_E_NODEVICE, std::string("hipMemcpy tables: ") + hipGetErrorString(ce));
 #undef CREATE_TRY
@@ -402,9 +406,9 @@ int hipnlp_pose_set_params(hipnlp_pose_handle* h, const double* p) {
     std::vector<GParams> gp(B);
     for (size_t b = 0; b < B; ++b) pack_pose_params(p + b * POSE_NP, pk.data() + b * PK_STRIDE, xr.data() + b * XR_STRIDE, gp[b]);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy(h->d_pk, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->d_xr, xr.data(), xr.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->d_gp, gp.data(), gp.size() * sizeof(GParams), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipnlp_internal_memcpy(h->d_pk, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipnlp_internal_memcpy(h->d_xr, xr.data(), xr.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipnlp_internal_memcpy(h->d_gp, gp.data(), gp.size() * sizeof(GParams), hipMemcpyHostToDevice));
     h->params_set = true;
     h->have_result = false;
     return HIPNLP_OK;
@@ -529,7 +533,7 @@ int hipnlp_pose_cost_terms(hipnlp_pose_handle* h, double* values) {
     if (!h->have_result) {
         HIP_TRY(h, hipSetDevice(h->dev));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        HIP_TRY(h, hipMemcpy(h->h_cost, h->d_cost, size_t(h->batch) * POSE_NCT * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipnlp_internal_memcpy(h->h_cost, h->d_cost, size_t(h->batch) * POSE_NCT * sizeof(double), hipMemcpyDeviceToHost));
     }
     std::memcpy(values, h->h_cost, size_t(h->batch) * POSE_NCT * sizeof(double));
     return HIPNLP_OK;

@@ -101,7 +101,9 @@ template <> struct ScratchJrOwn<true> {
 };
 static_assert(sizeof(JointRec) * NJ <= sizeof(double) * LSTR * NL, "own[NL] (zero slot, written while Jr is live) must lie behind the joint records it shares storage with");
 
-template <int LAYOUT> struct alignas(16) KnotScratchT : ScratchJrOwn<LAYOUT != LAYOUT_FULL> {
+// JSLOTS: slots of the Jacobian staging `jac` (default: all of them).  A VARY kernel (hipnlp.hip) keeps the slots behind js::V0 only —
+// js::vary_slots(terrain) of them — and addresses them through a pointer moved back by js::V0.
+template <int LAYOUT, int JSLOTS = js::COUNT> struct alignas(16) KnotScratchT : ScratchJrOwn<LAYOUT != LAYOUT_FULL> {
     static constexpr int layout = LAYOUT;
     static constexpr bool compact = LAYOUT != LAYOUT_FULL;
     alignas(16) double x[XPAD];    // knot k   (x, xm, xg, pk: 16-byte aligned, staged by direct global -> LDS loads)
@@ -132,11 +134,7 @@ template <int LAYOUT> struct alignas(16) KnotScratchT : ScratchJrOwn<LAYOUT != L
     double c_pt[NC][3], c_joint[NJ], c_force[2][3], c_yaw[2];
     double cost[NCT];
     double grad[XPAD];
-#ifdef HIPNLP_EXP_JAC_SLOTS
-    double jac[compact ? HIPNLP_EXP_JAC_SLOTS : js::COUNT];   // (occupancy experiment: resources only, results wrong)
-#else
-    double jac[js::COUNT];
-#endif
+    double jac[JSLOTS];
     // value of native g slot `slot` / where the emitter stores it
     HD double& g_at(int slot) {
         if constexpr (compact) return slot >= gs::FIN ? this->ends.c[slot - gs::FIN] : this->g[slot];
@@ -209,12 +207,17 @@ template <class Em> HD void emit_g_end(Ctx<Em>& cx, int slot, int id, double v) 
 template <class Em> HD const EndTables& end_tables(const Ctx<Em>& cx) { return cx.gkt->en; }
 template <class Em> HD const double* final_rhs(const Ctx<Em>& cx) { return cx.ggp->final_rhs; }
 
+// base of contact point c's block of VARYING jac slots (nlp_defs.h, region P: its stride depends on the terrain); js::ptc(c) is the base
+// of the point's block of constant slots
+template <class Em> HD int js_pt(const Ctx<Em>& cx, int c);
 // The terrain kind is a COMPILE-TIME constant of the device emitters (one kernel instantiation per terrain: the planar kernel
 // must not pay registers for the smooth-terrain jets) and a run-time value (Em::kTerrain < 0) for the host-side recorders.
 template <class Em> HD bool terrain_is_planar(const Ctx<Em>& cx) {
     if constexpr (Em::kTerrain >= 0) return Em::kTerrain == HIPNLP_TERRAIN_PLANAR;
     else return cx.st.terrain == HIPNLP_TERRAIN_PLANAR;
 }
+
+template <class Em> HD int js_pt(const Ctx<Em>& cx, int c) { return js::PV0 + js::pt_stride(terrain_is_planar(cx)) * c; }
 
 // Entries of jac g that do NOT depend on x — literals and parameters only: +-1, -dt/2, the mass, +-1/4 (the trapezoid defects
 // integrators/implicit_trapezoid.py:24-39, the x0 rows base/multiple_shooting_solver.py:713-742, the single-variable bound rows
@@ -372,46 +375,46 @@ template <class Em> HD void t_points_dyn(Ctx<Em>& cx, int t) {
     const double* x = s.x + PT_ * c;
     const double* xm = s.xm + PT_ * c;
     const double half = 0.5 * cx.gp.dt;
-    const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
+    const int gb = gs::PT_STRIDE * c, jb = js_pt(cx, c), jc = js::ptc(c), cb = PT_ * c;
     Em& em = cx.em;
     // trapezoid defects of dot(f) = f_dot, dot(p) = v (T7) + x0 rows
     em.G(gb + gs::FDYN + i, row_id(RK_FDYN_IN, c, i), x[F_ + i] - (xm[F_ + i] + half * (xm[FD_ + i] + x[FD_ + i])));
     em.G(gb + gs::PDYN + i, row_id(RK_PDYN_IN, c, i), x[P_ + i] - (xm[P_ + i] + half * (xm[V_ + i] + x[V_ + i])));
     em.G(gb + gs::FDYN_X0 + i, row_id(RK_FDYN_X0, c, i), x[F_ + i]);
     em.G(gb + gs::PDYN_X0 + i, row_id(RK_PDYN_X0, c, i), x[P_ + i]);
-    emit_jc(em, jb + js::FDYN + 0 + i, row_id(RK_FDYN_IN, c, i), cb + F_ + i, 1.0);
-    emit_jc(em, jb + js::FDYN + 3 + i, row_id(RK_FDYN_IN, c, i), cb + FD_ + i, -half);
-    emit_jc(em, jb + js::FDYN + 6 + i, row_id(RK_FDYN_OUT, c, i), cb + F_ + i, -1.0);
-    emit_jc(em, jb + js::FDYN + 9 + i, row_id(RK_FDYN_OUT, c, i), cb + FD_ + i, -half);
-    emit_jc(em, jb + js::FDYN + 12 + i, row_id(RK_FDYN_X0, c, i), cb + F_ + i, 1.0);
-    emit_jc(em, jb + js::PDYN + 0 + i, row_id(RK_PDYN_IN, c, i), cb + P_ + i, 1.0);
-    emit_jc(em, jb + js::PDYN + 3 + i, row_id(RK_PDYN_IN, c, i), cb + V_ + i, -half);
-    emit_jc(em, jb + js::PDYN + 6 + i, row_id(RK_PDYN_OUT, c, i), cb + P_ + i, -1.0);
-    emit_jc(em, jb + js::PDYN + 9 + i, row_id(RK_PDYN_OUT, c, i), cb + V_ + i, -half);
-    emit_jc(em, jb + js::PDYN + 12 + i, row_id(RK_PDYN_X0, c, i), cb + P_ + i, 1.0);
+    emit_jc(em, jc + js::FDYN + 0 + i, row_id(RK_FDYN_IN, c, i), cb + F_ + i, 1.0);
+    emit_jc(em, jc + js::FDYN + 3 + i, row_id(RK_FDYN_IN, c, i), cb + FD_ + i, -half);
+    emit_jc(em, jc + js::FDYN + 6 + i, row_id(RK_FDYN_OUT, c, i), cb + F_ + i, -1.0);
+    emit_jc(em, jc + js::FDYN + 9 + i, row_id(RK_FDYN_OUT, c, i), cb + FD_ + i, -half);
+    emit_jc(em, jc + js::FDYN + 12 + i, row_id(RK_FDYN_X0, c, i), cb + F_ + i, 1.0);
+    emit_jc(em, jc + js::PDYN + 0 + i, row_id(RK_PDYN_IN, c, i), cb + P_ + i, 1.0);
+    emit_jc(em, jc + js::PDYN + 3 + i, row_id(RK_PDYN_IN, c, i), cb + V_ + i, -half);
+    emit_jc(em, jc + js::PDYN + 6 + i, row_id(RK_PDYN_OUT, c, i), cb + P_ + i, -1.0);
+    emit_jc(em, jc + js::PDYN + 9 + i, row_id(RK_PDYN_OUT, c, i), cb + V_ + i, -half);
+    emit_jc(em, jc + js::PDYN + 12 + i, row_id(RK_PDYN_X0, c, i), cb + P_ + i, 1.0);
 }
 template <class Em> HD void t_points_vec(Ctx<Em>& cx, int t) {
     auto& s = cx.s;
     const int c = t / 3, i = t - 3 * c;
     const double* x = s.x + PT_ * c;
-    const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
+    const int gb = gs::PT_STRIDE * c, jb = js_pt(cx, c), jc = js::ptc(c), cb = PT_ * c;
     Em& em = cx.em;
     const double pz = x[P_ + 2];
     const bool planar = terrain_is_planar(cx);
-    emit_jc(em, jb + js::PLANAR_V + i, row_id(RK_PLANAR, c, i), cb + V_ + i, 1.0);
+    emit_jc(em, jc + js::PLANAR_V + i, row_id(RK_PLANAR, c, i), cb + V_ + i, 1.0);
     if (planar) {  // planar complementarity  v - R_t diag(tau,tau,1) u,  tau = tanh(kt h(p))   (E3; R_t = I, h = p_z)
         const double tau = knot_tanh(cx.gp.kt * pz);
         const double mult = i < 2 ? tau : 1.0;
         em.G(gb + gs::PLANAR + i, row_id(RK_PLANAR, c, i), x[V_ + i] - mult * x[U_ + i]);
-        if (i < 2) em.J(jb + js::PLANAR_U + 3 * i + i, row_id(RK_PLANAR, c, i), cb + U_ + i, -mult);
-        else emit_jc(em, jb + js::PLANAR_U + 3 * i + i, row_id(RK_PLANAR, c, i), cb + U_ + i, -1.0);
-        if (i < 2) em.J(jb + js::PLANAR_P + 3 * i + 2, row_id(RK_PLANAR, c, i), cb + P_ + 2, -(cx.gp.kt * (1.0 - tau * tau)) * x[U_ + i]);
+        if (i < 2) em.J(jb + js::PL_U + i, row_id(RK_PLANAR, c, i), cb + U_ + i, -mult);
+        else emit_jc(em, jb + js::PL_UZ, row_id(RK_PLANAR, c, i), cb + U_ + i, -1.0);
+        if (i < 2) em.J(jb + js::PL_P + i, row_id(RK_PLANAR, c, i), cb + P_ + 2, -(cx.gp.kt * (1.0 - tau * tau)) * x[U_ + i]);
     }
     // control bound rows
     em.G(gb + gs::UB + i, row_id(RK_UB, c, i), x[U_ + i]);
-    emit_jc(em, jb + js::UB + i, row_id(RK_UB, c, i), cb + U_ + i, 1.0);
+    emit_jc(em, jc + js::UB + i, row_id(RK_UB, c, i), cb + U_ + i, 1.0);
     em.G(gb + gs::FDB + i, row_id(RK_FDB, c, i), x[FD_ + i] * cx.gp.mass);
-    emit_jc(em, jb + js::FDB + i, row_id(RK_FDB, c, i), cb + FD_ + i, cx.gp.mass);
+    emit_jc(em, jc + js::FDB + i, row_id(RK_FDB, c, i), cb + FD_ + i, cx.gp.mass);
     // gradient of the point-local costs (k >= 1): swing height (E10), ||u_v||^2, ||f_dot||^2
     const double on = cx.ki.first ? 0.0 : 1.0;
     double* gr = s.grad + cb;
@@ -454,14 +457,14 @@ HD void terrain_frame(const double* Z, double pz, TerrainFrame& t) {
 // height, normal force, friction cone rows of contact point c on the smooth terrain  (E15-E17, E6, E7); shared with pose_body.h
 template <class Em> HD void point_hnf_smooth(Ctx<Em>& cx, int c, const TerrainFrame& tf) {
     Em& em = cx.em;
-    const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
+    const int gb = gs::PT_STRIDE * c, jb = js_pt(cx, c), jc = js::ptc(c), cb = PT_ * c;
     const double* f = cx.s.x + cb + F_;
     const D2 *n = tf.n, *xv = tf.xv, *yv = tf.yv;
     const double gradh[3] = {tf.u1.v, tf.u2.v, 1.0};
     const D2 nf = n[0] * f[0] + n[1] * f[1] + n[2] * f[2];
     em.G(gb + gs::HEIGHT, row_id(RK_HEIGHT, c, 0), tf.h.v);
-    for (int j = 0; j < 2; ++j) em.J(jb + js::HEIGHT + j, row_id(RK_HEIGHT, c, 0), cb + P_ + j, gradh[j]);
-    emit_jc(em, jb + js::HEIGHT + 2, row_id(RK_HEIGHT, c, 0), cb + P_ + 2, 1.0);
+    for (int j = 0; j < 2; ++j) em.J(jb + js::HEIGHT_XY + j, row_id(RK_HEIGHT, c, 0), cb + P_ + j, gradh[j]);
+    emit_jc(em, jc + js::HEIGHT_Z, row_id(RK_HEIGHT, c, 0), cb + P_ + 2, 1.0);
     em.G(gb + gs::NORMAL, row_id(RK_NORMAL, c, 0), nf.v);
     em.J(jb + js::NORMAL_P + 0, row_id(RK_NORMAL, c, 0), cb + P_ + 0, nf.x);
     em.J(jb + js::NORMAL_P + 1, row_id(RK_NORMAL, c, 0), cb + P_ + 1, nf.y);
@@ -478,13 +481,13 @@ template <class Em> HD void point_hnf_smooth(Ctx<Em>& cx, int c, const TerrainFr
 // the same three rows on the planar terrain (E14: h = p_z, n = e_z, R_t = I)
 template <class Em> HD void point_hnf_planar(Ctx<Em>& cx, int c) {
     Em& em = cx.em;
-    const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
+    const int gb = gs::PT_STRIDE * c, jb = js_pt(cx, c), jc = js::ptc(c), cb = PT_ * c;
     const double* x = cx.s.x + cb;
     const double pz = x[P_ + 2], fz = x[F_ + 2];
     em.G(gb + gs::HEIGHT, row_id(RK_HEIGHT, c, 0), pz);
-    emit_jc(em, jb + js::HEIGHT + 2, row_id(RK_HEIGHT, c, 0), cb + P_ + 2, 1.0);
+    emit_jc(em, jc + js::HEIGHT_Z, row_id(RK_HEIGHT, c, 0), cb + P_ + 2, 1.0);
     em.G(gb + gs::NORMAL, row_id(RK_NORMAL, c, 0), fz);
-    emit_jc(em, jb + js::NORMAL_F + 2, row_id(RK_NORMAL, c, 0), cb + F_ + 2, 1.0);
+    emit_jc(em, jb + js::PL_NORMAL_FZ, row_id(RK_NORMAL, c, 0), cb + F_ + 2, 1.0);
     const double mu2 = cx.gp.mu * cx.gp.mu;
     em.G(gb + gs::FRICTION, row_id(RK_FRICTION, c, 0), -(x[F_] * x[F_]) - (x[F_ + 1] * x[F_ + 1]) + mu2 * (fz * fz));
     em.J(jb + js::FRICTION_F + 0, row_id(RK_FRICTION, c, 0), cb + F_ + 0, -2.0 * x[F_]);
@@ -547,9 +550,9 @@ template <class Em> HD void t_com_height(Ctx<Em>& cx, int) {
         for (int i = 0; i < 3; ++i) Z[i] += part[i];
     }
     em.G(gs::COMH, row_id(RK_COMH, 0, 0), s.x[COM_ + 2] - Z[0]);
-    em.J(js::COMH + 0, row_id(RK_COMH, 0, 0), COM_ + 0, -Z[1]);
-    em.J(js::COMH + 1, row_id(RK_COMH, 0, 0), COM_ + 1, -Z[2]);
-    emit_jc(em, js::COMH + 2, row_id(RK_COMH, 0, 0), COM_ + 2, 1.0);
+    em.J(js::COMH_XY + 0, row_id(RK_COMH, 0, 0), COM_ + 0, -Z[1]);
+    em.J(js::COMH_XY + 1, row_id(RK_COMH, 0, 0), COM_ + 1, -Z[2]);
+    emit_jc(em, js::COMH_Z, row_id(RK_COMH, 0, 0), COM_ + 2, 1.0);
 }
 template <class Em> HD void t_terrain_stage(Ctx<Em>& cx, int c) {
     if (terrain_is_planar(cx)) return;
@@ -587,7 +590,7 @@ template <class Em> HD void t_terrain_planar(Ctx<Em>& cx, int c) {
     if (terrain_is_planar(cx)) return;
     auto& s = cx.s;
     Em& em = cx.em;
-    const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
+    const int gb = gs::PT_STRIDE * c, jb = js_pt(cx, c), jc = js::ptc(c), cb = PT_ * c;
     const double* v = s.x + cb + V_;
     const double* u = s.x + cb + U_;
     const TerrainFrame& tf = terrain_stage(s, c)->tf;
@@ -611,7 +614,7 @@ template <class Em> HD void t_terrain_dcc(Ctx<Em>& cx, int c) {
     if (terrain_is_planar(cx)) return;
     auto& s = cx.s;
     Em& em = cx.em;
-    const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
+    const int gb = gs::PT_STRIDE * c, jb = js_pt(cx, c), jc = js::ptc(c), cb = PT_ * c;
     const double* f = s.x + cb + F_;
     const double* v = s.x + cb + V_;
     const double* fd = s.x + cb + FD_;
@@ -671,7 +674,7 @@ template <class Em> HD void t_terrain_swing(Ctx<Em>& cx, int c) {
 template <class Em> HD void t_points_scalar(Ctx<Em>& cx, int c) {
     auto& s = cx.s;
     const double* x = s.x + PT_ * c;
-    const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
+    const int gb = gs::PT_STRIDE * c, jb = js_pt(cx, c), jc = js::ptc(c), cb = PT_ * c;
     Em& em = cx.em;
     const double on = cx.ki.first ? 0.0 : 1.0;
     s.c_pt[c][1] = on * cx.st.m_ureg * (x[U_] * x[U_] + x[U_ + 1] * x[U_ + 1] + x[U_ + 2] * x[U_ + 2]);
@@ -680,10 +683,10 @@ template <class Em> HD void t_points_scalar(Ctx<Em>& cx, int c) {
     const double pz = x[P_ + 2], fz = x[F_ + 2], vz = x[V_ + 2], fdz = x[FD_ + 2];
     // dcc margin  eps - k h (n.f) - [hdot (n.f) + h f.ndot + h (n.fdot)]   (E4; n = e_z, ndot = 0, hdot = v_z)
     em.G(gb + gs::DCC, row_id(RK_DCC, c, 0), cx.gp.eps - cx.gp.kbs * (pz * fz) - (vz * fz + pz * fdz));
-    em.J(jb + js::DCC_P + 2, row_id(RK_DCC, c, 0), cb + P_ + 2, -cx.gp.kbs * fz - fdz);
-    em.J(jb + js::DCC_F + 2, row_id(RK_DCC, c, 0), cb + F_ + 2, -cx.gp.kbs * pz - vz);
-    em.J(jb + js::DCC_V + 2, row_id(RK_DCC, c, 0), cb + V_ + 2, -fz);
-    em.J(jb + js::DCC_FD + 2, row_id(RK_DCC, c, 0), cb + FD_ + 2, -pz);
+    em.J(jb + js::PL_DCC_P, row_id(RK_DCC, c, 0), cb + P_ + 2, -cx.gp.kbs * fz - fdz);
+    em.J(jb + js::PL_DCC_F, row_id(RK_DCC, c, 0), cb + F_ + 2, -cx.gp.kbs * pz - vz);
+    em.J(jb + js::PL_DCC_V, row_id(RK_DCC, c, 0), cb + V_ + 2, -fz);
+    em.J(jb + js::PL_DCC_FD, row_id(RK_DCC, c, 0), cb + FD_ + 2, -pz);
     point_hnf_planar(cx, c);
     // value of the swing-height cost (k >= 1)
     const double dh = pz - s.pk[PK_REF + R_SWING];
@@ -819,7 +822,7 @@ template <class Em> HD void t_small(Ctx<Em>& cx, int t) {
     } else {      // minimum com height: h_terrain(com) = com_z ; com velocity and base quaternion velocity costs (k >= 0)
         if (terrain_is_planar(cx)) {   // (smooth terrain: t_com_height, behind the bump jets)
             em.G(gs::COMH, row_id(RK_COMH, 0, 0), s.x[COM_ + 2]);
-            emit_jc(em, js::COMH + 2, row_id(RK_COMH, 0, 0), COM_ + 2, 1.0);
+            emit_jc(em, js::COMH_Z, row_id(RK_COMH, 0, 0), COM_ + 2, 1.0);
         }
         double c = 0.0;
         for (int i = 0; i < 4; ++i) {
@@ -1380,11 +1383,11 @@ template <class Em> HD void t_cmm_columns(Ctx<Em>& cx, int t) {
 template <class Em> HD void t_kinc(Ctx<Em>& cx, int t) {
     auto& s = cx.s;
     Em& em = cx.em;
-    const int c = t / 3, i = t - 3 * c, jb = js::PT_STRIDE * c, gb = gs::PT_STRIDE * c, cb = PT_ * c;
+    const int c = t / 3, i = t - 3 * c, jb = js_pt(cx, c), jc = js::ptc(c), gb = gs::PT_STRIDE * c, cb = PT_ * c;
     const double* r = s.pkin[c];  // base-centred
     em.G(gb + gs::KINC + i, row_id(RK_KINC, c, i), s.x[cb + P_ + i] - (s.x[PB_ + i] + r[i]));
-    emit_jc(em, jb + js::KINC_P + i, row_id(RK_KINC, c, i), cb + P_ + i, 1.0);
-    emit_jc(em, jb + js::KINC_PB + i, row_id(RK_KINC, c, i), PB_ + i, -1.0);
+    emit_jc(em, jc + js::KINC_P + i, row_id(RK_KINC, c, i), cb + P_ + i, 1.0);
+    emit_jc(em, jc + js::KINC_PB + i, row_id(RK_KINC, c, i), PB_ + i, -1.0);
     // d pkin / d q_b = -[r]x G / |q|   ->  row entries = +[r]x G / |q|
     const double X0 = skew_rc(r, i, 0), X1 = skew_rc(r, i, 1), X2 = skew_rc(r, i, 2);
     for (int l = 0; l < 4; ++l)
@@ -1394,7 +1397,7 @@ template <class Em> HD void t_kinc(Ctx<Em>& cx, int t) {
 template <class Em> HD void t_kinc_s(Ctx<Em>& cx, int t) {
     auto& s = cx.s;
     Em& em = cx.em;
-    const int c = t / LEG_PATH, q = t - LEG_PATH * c, f = c < 4 ? 0 : 1, jb = js::PT_STRIDE * c;
+    const int c = t / LEG_PATH, q = t - LEG_PATH * c, f = c < 4 ? 0 : 1, jb = js_pt(cx, c);
     const int j = cx.kt.leg_joint[f][q];
     const double* r = s.pkin[c];
     double d[3], x[3];

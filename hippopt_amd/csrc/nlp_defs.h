@@ -166,34 +166,68 @@ constexpr int PBDYN = G0, QBDYN = PBDYN + 3, SDYN = QBDYN + 4, COMDYN = SDYN + N
 // Native jac slots (per knot): every structural entry of the knot's COLUMN block
 // =====================================================================================================
 namespace js {
-// per point
+// Three regions, so that a kernel whose destination already holds the entries that do not depend on x (VARY instantiations,
+// hipnlp.hip) needs LDS for the varying ones only — 809 slots on the planar terrain, 1041 on the smooth steps, instead of 1962:
+//   D  [0, V0)       entries that NEVER depend on x (emitted through emit_jc and nothing else): per point (PTC_STRIDE each), then global
+//   B  [V0, PV0)     global entries that depend on x
+//   P  [PV0, COUNT)  per-point entries that depend on x, stride pt_stride(terrain): the part both terrains use first, then EITHER the
+//                    planar terrain's eight entries OR the smooth terrain's 39 (a slot behind offset PT_COMMON means different things on
+//                    the two terrains; exactly one set of point tasks runs per handle)
+// The static pose finder (pose_body.h) reuses the names for entries of its own; it allocates the whole range.
+// ---- D, per point: base ptc(c) ----
 constexpr int FDYN = 0;          // IN_X 3, IN_Y 3, OUT_X 3, OUT_Y 3, X0 3
 constexpr int PDYN = 15;
-// terrain-dependent rows: superset of the entries of the planar and the smooth terrains (unused slots are simply never emitted)
-constexpr int PLANAR_V = 30;                  // [3]       d row_i / d v_i
-constexpr int PLANAR_U = 33;                  // [3][3]    d row_i / d u_j   (planar terrain: diagonal only)
-constexpr int PLANAR_P = 42;                  // [3][3]    d row_i / d p_j   (planar terrain: rows 0,1 x column 2)
-constexpr int DCC_P = 51, DCC_F = 54, DCC_V = 57, DCC_FD = 60;   // [3] each (planar terrain: z component only)
-constexpr int HEIGHT = 63;                    // [3]  d h / d p          (planar: z)
-constexpr int NORMAL_P = 66, NORMAL_F = 68;   // [2] d(n.f)/d p_x,p_y ; [3] d/d f   (planar: f_z)
-constexpr int FRICTION_P = 71, FRICTION_F = 73;  // [2] ; [3]
-constexpr int UB = 76, FDB = 79;
-constexpr int KINC_P = 82, KINC_PB = 85, KINC_QB = 88, KINC_S = 100;  // QB [3][4], S [3][LEG_PATH]
-constexpr int PT_STRIDE = 100 + 3 * LEG_PATH;  // 118
-constexpr int G0 = NC * PT_STRIDE;            // 712
+constexpr int PLANAR_V = 30;                  // [3]  d row_i / d v_i = 1
+constexpr int UB = 33, FDB = 36;
+constexpr int KINC_P = 39, KINC_PB = 42;
+constexpr int HEIGHT_Z = 45;                  // d h / d p_z = 1 (both terrains)
+constexpr int PTC_STRIDE = 46;
+constexpr int CG0 = NC * PTC_STRIDE;          // 368
+// ---- D, global ----
 // trivial dynamics blocks: L*5 slots each: IN_X, IN_Y, OUT_X, OUT_Y, X0
-constexpr int PBDYN = G0, QBDYN = PBDYN + 15, SDYN = QBDYN + 20, COMDYN = SDYN + 5 * NJ;
+constexpr int PBDYN = CG0, QBDYN = PBDYN + 15, SDYN = QBDYN + 20, COMDYN = SDYN + 5 * NJ;
 constexpr int HDYN_SELF_IN = COMDYN + 15, HDYN_SELF_OUT = HDYN_SELF_IN + 6, HDYN_X0 = HDYN_SELF_OUT + 6, HDYN_X0G = HDYN_X0 + 6;
 constexpr int HDYN_LIN_F_IN = HDYN_X0G + 6, HDYN_LIN_F_OUT = HDYN_LIN_F_IN + 24;            // [c][i]
-constexpr int HDYN_ANG_P_IN = HDYN_LIN_F_OUT + 24, HDYN_ANG_P_OUT = HDYN_ANG_P_IN + 48;     // [c][6]
+constexpr int COMC_COM = HDYN_LIN_F_OUT + 24, COMC_PB = COMC_COM + 3, CMMC_H = COMC_PB + 3, AMB = CMMC_H + 3;
+constexpr int COMH_Z = AMB + 3;               // d h(com)/d com_z = 1 (both terrains)
+constexpr int JPB = COMH_Z + 1, JVB = JPB + NJ, FEETH = JVB + NJ;
+constexpr int FIN = FEETH + NC, PER0 = FIN + 81, PERN = PER0 + 84;
+constexpr int V0 = PERN + 84;                 // 921: first slot that may depend on x
+// ---- B: global, varying ----
+constexpr int HDYN_ANG_P_IN = V0, HDYN_ANG_P_OUT = HDYN_ANG_P_IN + 48;     // [c][6]
 constexpr int HDYN_ANG_F_IN = HDYN_ANG_P_OUT + 48, HDYN_ANG_F_OUT = HDYN_ANG_F_IN + 48;
 constexpr int HDYN_ANG_COM_IN = HDYN_ANG_F_OUT + 48, HDYN_ANG_COM_OUT = HDYN_ANG_COM_IN + 6;
 constexpr int UNITQ = HDYN_ANG_COM_OUT + 6;
-constexpr int COMC_COM = UNITQ + 4, COMC_PB = COMC_COM + 3, COMC_QB = COMC_PB + 3, COMC_S = COMC_QB + 12;  // S [3][NJ]
-constexpr int CMMC_H = COMC_S + 3 * NJ, CMMC_QB = CMMC_H + 3, CMMC_QD = CMMC_QB + 12, CMMC_S = CMMC_QD + 12, CMMC_SD = CMMC_S + 3 * NJ;
-constexpr int AMB = CMMC_SD + 3 * NJ, COMH = AMB + 3 /* [3] d h(com)/d com (planar: z) */, FEETD = COMH + 3;  // FEETD [2][LEG_PATH]
-constexpr int JPB = FEETD + 2 * LEG_PATH, JVB = JPB + NJ, FEETH = JVB + NJ;
-constexpr int FIN = FEETH + NC, PER0 = FIN + 81, PERN = PER0 + 84, COUNT = PERN + 84;
+constexpr int COMC_QB = UNITQ + 4, COMC_S = COMC_QB + 12;  // S [3][NJ]
+constexpr int CMMC_QB = COMC_S + 3 * NJ, CMMC_QD = CMMC_QB + 12, CMMC_S = CMMC_QD + 12, CMMC_SD = CMMC_S + 3 * NJ;
+constexpr int FEETD = CMMC_SD + 3 * NJ;       // [2][LEG_PATH]
+constexpr int COMH_XY = FEETD + 2 * LEG_PATH; // [2] d h(com)/d com_x, com_y (smooth terrain)
+constexpr int PV0 = COMH_XY + 2;              // 1386
+// ---- P, per point: base pt(terrain, c); offsets inside a point's block ----
+constexpr int FRICTION_F = 0;                 // [3]
+constexpr int KINC_QB = 3, KINC_S = 15;       // QB [3][4], S [3][LEG_PATH]
+constexpr int PT_COMMON = 15 + 3 * LEG_PATH;  // 33
+// planar terrain
+constexpr int PL_U = PT_COMMON;               // [2]  d row_i / d u_i, i = x, y (tau-dependent)
+constexpr int PL_P = PL_U + 2;                // [2]  d row_i / d p_z
+constexpr int PL_DCC_P = PL_P + 2, PL_DCC_F = PL_DCC_P + 1, PL_DCC_V = PL_DCC_F + 1, PL_DCC_FD = PL_DCC_V + 1;   // z components
+// (two entries that are constant on the planar terrain only — d(n.f)/d f_z = 1, d row_z / d u_z = -1; the smooth terrain computes them —
+//  live here, not in region D: js::COUNT stays what the four-wave kernels' 40 KB of LDS allow, at the price of 16 idle slots in a planar VARY kernel)
+constexpr int PL_NORMAL_FZ = PL_DCC_FD + 1, PL_UZ = PL_NORMAL_FZ + 1;
+constexpr int PT_STRIDE_PLANAR = PL_UZ + 1;   // 43
+// smooth terrain
+constexpr int PLANAR_U = PT_COMMON;           // [3][3]    d row_i / d u_j
+constexpr int PLANAR_P = PLANAR_U + 9;        // [3][3]    d row_i / d p_j
+constexpr int DCC_P = PLANAR_P + 9, DCC_F = DCC_P + 3, DCC_V = DCC_F + 3, DCC_FD = DCC_V + 3;   // [3] each
+constexpr int HEIGHT_XY = DCC_FD + 3;         // [2]  d h / d p_x, p_y
+constexpr int NORMAL_P = HEIGHT_XY + 2, NORMAL_F = NORMAL_P + 2;   // [2] d(n.f)/d p_x,p_y ; [3] d/d f
+constexpr int FRICTION_P = NORMAL_F + 3;      // [2]
+constexpr int PT_STRIDE_SMOOTH = FRICTION_P + 2;  // 72
+constexpr int COUNT = PV0 + NC * PT_STRIDE_SMOOTH;   // 1962
+HD constexpr int pt_stride(bool planar) { return planar ? PT_STRIDE_PLANAR : PT_STRIDE_SMOOTH; }
+HD constexpr int ptc(int c) { return PTC_STRIDE * c; }
+// slots a kernel of one terrain may touch behind V0 (what a VARY instantiation keeps in LDS)
+HD constexpr int vary_slots(bool planar) { return PV0 - V0 + NC * pt_stride(planar); }
 }  // namespace js
 
 // variable behind periodicity row i (0..83): per point (u_v, f_dot), then h, v_b, qdot_b, sdot (planner.py:897-922)

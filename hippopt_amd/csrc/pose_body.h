@@ -27,14 +27,14 @@ HD constexpr int pose_to_knot_col(int i) {
 template <class Em> HD void t_pose_points(Ctx<Em>& cx, int c) {
     auto& s = cx.s;
     Em& em = cx.em;
-    const int gb = gs::PT_STRIDE * c, jb = js::PT_STRIDE * c, cb = PT_ * c;
+    const int gb = gs::PT_STRIDE * c, jb = js_pt(cx, c), jc = js::ptc(c), cb = PT_ * c;
     const double* p = s.x + cb + P_;
     const double* f = s.x + cb + F_;
     const double mass = cx.gp.mass;
     if (terrain_is_planar(cx)) {   // eps - h(p) (n . f mass)  with  h = p_z, n = e_z
         em.G(gb + gs::DCC, row_id(RK_PCOMPL, c, 0), cx.gp.eps - p[2] * (f[2] * mass));
-        em.J(jb + js::DCC_P + 2, row_id(RK_PCOMPL, c, 0), cb + P_ + 2, -(f[2] * mass));
-        em.J(jb + js::DCC_F + 2, row_id(RK_PCOMPL, c, 0), cb + F_ + 2, -(p[2] * mass));
+        em.J(jb + js::PL_DCC_P, row_id(RK_PCOMPL, c, 0), cb + P_ + 2, -(f[2] * mass));
+        em.J(jb + js::PL_DCC_F, row_id(RK_PCOMPL, c, 0), cb + F_ + 2, -(p[2] * mass));
         point_hnf_planar(cx, c);
     } else {
         double Z[10];
@@ -69,7 +69,7 @@ template <class Em> HD void t_pose_points(Ctx<Em>& cx, int c) {
     s.c_pt[c][2] = cx.st.m_favg * ca;
     if (mode == HIPNLP_EXPR_SUBJECT_TO) {   // sumsqr(p - p_ref) == 0   (base/problem.py:146-151)
         em.G(gb + gs::UB, row_id(RK_PPREG, c, 0), cp);
-        for (int i = 0; i < 3; ++i) em.J(jb + js::UB + i, row_id(RK_PPREG, c, 0), cb + P_ + i, 2.0 * ep[i]);
+        for (int i = 0; i < 3; ++i) em.J(jc + js::UB + i, row_id(RK_PPREG, c, 0), cb + P_ + i, 2.0 * ep[i]);
     }
 }
 
@@ -129,7 +129,7 @@ template <class Em> HD void t_pose_com(Ctx<Em>& cx, int t) {
         const double e = s.x[COM_ + t] - s.xm[XR_COM + t];
         s.grad[COM_ + t] = mode == HIPNLP_EXPR_MINIMIZE ? 2.0 * cx.st.m_pcom * e : 0.0;
         s.grad[PB_ + t] = 0.0;
-        if (mode == HIPNLP_EXPR_SUBJECT_TO) em.J(js::COMH + t, row_id(RK_PCOMERR, 0, 0), COM_ + t, 2.0 * e);
+        if (mode == HIPNLP_EXPR_SUBJECT_TO) em.J(t < 2 ? js::COMH_XY + t : js::COMH_Z, row_id(RK_PCOMERR, 0, 0), COM_ + t, 2.0 * e);
     } else {
         double c = 0.0;
         for (int i = 0; i < 3; ++i) { const double e = s.x[COM_ + i] - s.xm[XR_COM + i]; c += e * e; }
@@ -186,7 +186,7 @@ template <class Em> HD void pose_hand_rows(Ctx<Em>& cx, int t, int h) {
     const double* e = hb + 6 + 3 * h;
     const double m2 = 2.0 * hd.mult[h];
     if (t < 3) {
-        const int i = t, jb = js::PT_STRIDE * (4 * h + i) + js::FDYN;
+        const int i = t, jb = js::ptc(4 * h + i) + js::FDYN;
         if (mode == HIPNLP_EXPR_SUBJECT_TO) {
             // (Opti's canonical form of `position == parameter`: the row is the position, its bounds are the reference)
             em.G(gs::PT_STRIDE * h + gs::FDYN + i, row_id(RK_PHAND, h, i), s.x[PB_ + i] + r[i]);
@@ -211,7 +211,7 @@ template <class Em> HD void pose_hand_rows(Ctx<Em>& cx, int t, int h) {
         for (int n = 0; n < 3; ++n) d[n] = r[n] - s.ow[j + 1][n];
         cross3(s.aw[j], d, x);
         if (mode == HIPNLP_EXPR_SUBJECT_TO) {
-            for (int i = 0; i < 3; ++i) em.J(js::PT_STRIDE * (4 * h + i) + js::FDYN + 5 + q, row_id(RK_PHAND, h, i), S_ + j, x[i]);
+            for (int i = 0; i < 3; ++i) em.J(js::ptc(4 * h + i) + js::FDYN + 5 + q, row_id(RK_PHAND, h, i), S_ + j, x[i]);
         } else {
             s.grad[S_ + j] += m2 * dot3(e, x);
         }

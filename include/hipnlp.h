@@ -327,6 +327,11 @@ int hipnlp_host_unregister(void* p);
  * hipnlp_host_register are the caller's responsibility and are not verified; registering an array a handle had registered by itself
  * replaces that registration with a fresh one. */
 int hipnlp_set_auto_register(hipnlp_handle* h, int on);
+/* Releases every range that handles of this process registered by themselves (returns how many); the handles register their arrays
+ * again when they next see them twice in a row.  For a caller about to free arrays it passed to hipnlp_eval: memory that is freed while
+ * a registration of it is alive and then handed out again by the allocator confuses the HIP runtime — a hipMemcpy from such memory is
+ * refused with "invalid argument" (the library's own copies release the ranges and retry when that happens). */
+int hipnlp_host_release_auto_ranges(void);
 /* Counters of the host-buffer path: out[0] arrays auto-registered so far, out[1] stale-mapping fallbacks, out[2] ranges currently
  * auto-registered, out[3] evaluations so far (kernel launches), out[4] caller arrays filled with the constant Jacobian entries so far,
  * out[5] of which re-fills after a failed spot check, out[6] constant entries of the handle's pattern, out[7] wave slices of constants

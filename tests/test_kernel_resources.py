@@ -69,3 +69,14 @@ def test_hessian_and_pose_kernels(res):
         assert 3 * p["lds"] <= LDS_PER_CU and _granule(p["vgpr"] + p["agpr"]) * 3 <= VGPR_FILE, p   # three per CU (DESIGN, pose kernels)
         ph = res["hipnlp_pose_hess_kernel<%d>" % t]
         assert 3 * ph["lds"] <= LDS_PER_CU and _granule(ph["vgpr"] + ph["agpr"]) * 3 <= VGPR_FILE, ph
+
+
+def test_planar_vary_kernel_fits_five_workgroups_per_cu(res):
+    """the four-wave VARY kernel of the planar terrain (destinations that hold the constant entries of jac g): trimmed Jacobian staging
+    (js::vary_slots) -> <= 32 KB of LDS, copy-out tables fetched behind the last barrier but one -> <= 96 VGPRs: FIVE workgroups per CU"""
+    r = res["hipnlp_knot_kernel<0,4,false,true>"]
+    assert r["wg"] == 256 and r["scratch"] == 0
+    assert 5 * r["lds"] <= LDS_PER_CU, r
+    assert _granule(r["vgpr"] + r["agpr"]) * 5 <= VGPR_FILE, r
+    s4 = res["hipnlp_knot_kernel<1,4,false,true>"]           # smooth terrain: 1041 varying slots, four per CU as before
+    assert 4 * s4["lds"] <= LDS_PER_CU and s4["lds"] < res["hipnlp_knot_kernel<1,4>"]["lds"]
