@@ -61,6 +61,9 @@ def parse_args():
     ap.add_argument("--no-hessian", action="store_true", help="skip the exact-Hessian figure reported beside the callback quartet")
     ap.add_argument("--no-host", action="store_true", help="skip the host-visible (PCIe-inclusive) figures")
     ap.add_argument("--no-throughput", action="store_true", help="skip the batch-launch roofline block reported beside the headline")
+    ap.add_argument("--varying-first", action="store_true",
+                    help="handles created with HIPNLP_FLAG_JAC_VARYING_FIRST (N = 1, independent trajectories): the order a triplet consumer such as IPOPT picks; "
+                         "the constant entries of jac g are filled once, the launches store the varying run of every knot block (VARY kernels)")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the sharded paths on one GPU (debug)")
     return ap.parse_args()
 
@@ -688,7 +691,7 @@ def main():
     # ---- independent trajectories: every rank evaluates its own NLP(s), nothing is exchanged ---------------------------------------
     def run_replicas(steps, warmup):
         st, x_np, p_np, xs = workload(args.horizon, args.batch, 1004 + rank)
-        eng = HipNlp(st, model, batch=args.batch, device=local_rank)
+        eng = HipNlp(st, model, batch=args.batch, device=local_rank, jac_varying_first=args.varying_first)
         eng.set_params(p_np)
         f_d = torch.empty(args.batch, dtype=torch.float64, device=device)
         grad_d = torch.empty(args.batch * eng.n, dtype=torch.float64, device=device)
@@ -1106,7 +1109,7 @@ def main():
         if os.path.exists(tp):
             try:
                 table = json.load(open(tp))
-                ent = table.get("%s_N%d_B%d" % (args.workload, main_res["horizon"], args.batch), {})
+                ent = table.get("%s_N%d_B%d%s" % (args.workload, main_res["horizon"], args.batch, "_vf" if args.varying_first else ""), {})
                 traffic = ent.get("hbm_bytes_per_launch")
                 valu = ent.get("valu_wave_insts_per_knot")
                 lds_cyc = ent.get("lds_array_cycles_per_knot")
@@ -1133,7 +1136,10 @@ def main():
                        "horizon": main_res["horizon"], "batch": args.batch, "knots_per_step": main_res["knots_per_step"],
                        "parallelism": main_res["parallelism"], "ranks": world,
                        "collective_backend": (("gloo, %d ranks on ONE device: REHEARSAL of the plumbing, not a measurement" if REHEARSAL else "nccl (RCCL), %d ranks") % dist.get_world_size()) if world > 1 else None,
-                       "n": int(d.n), "m": int(d.m), "nnz": int(d.nnz), "nnz_per_knot": nnz_knot},
+                       "n": int(d.n), "m": int(d.m), "nnz": int(d.nnz), "nnz_per_knot": nnz_knot,
+                       "jac_order": ("varying-first inside every knot block (HIPNLP_FLAG_JAC_VARYING_FIRST): the %d constant entries of jac g filled once, "
+                                     "the launches store the varying run of every block" % eng.host_stats()["constant_entries"]) if args.varying_first
+                                    else "CCS (CasADi's): every entry stored by every launch"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command in a separate session; null = not profiled)",

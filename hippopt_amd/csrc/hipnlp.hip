@@ -207,13 +207,13 @@ __device__ __forceinline__ void constants_check_and_repair(const ConstCheck& c, 
 // run-time branch — as a branch the unused path cost the plain callback 1.2 % at N = 100 (7.99 against 7.89 us) and 0.8 % at x 64.
 // VARY: the instantiation for destinations that already hold the constant entries of jac g (varying-first order of a block): the
 // tasks do not stage them (DevEm::JC), the copy-out walks the varying run of the block only — half the trips on the planar terrain.
-// FIVE workgroups per CU: the four-wave VARY kernel of the planar terrain, whose trimmed Jacobian staging leaves 31.6 KB of LDS per
-// workgroup — with a register budget of 96 (five waves per SIMD), which it meets by fetching its copy-out tables behind the last
+// FIVE workgroups per CU: the four-wave VARY kernels, whose trimmed scratch (KnotScratchT::trimmed) is 31.0 KB of LDS per workgroup on
+// the planar terrain and exactly 32 KB on the smooth steps — with a register budget of 96 (five waves per SIMD), which it meets by fetching its copy-out tables behind the last
 // barrier but one instead of holding them from the first instruction (LATE_TABLES below).
 #ifndef HIPNLP_FIVE_PER_CU
 #define HIPNLP_FIVE_PER_CU 1
 #endif
-template <int TERRAIN, int WAVES, bool VARY> constexpr bool five_per_cu = HIPNLP_FIVE_PER_CU && VARY && WAVES == 4 && TERRAIN == HIPNLP_TERRAIN_PLANAR;
+template <int TERRAIN, int WAVES, bool VARY> constexpr bool five_per_cu = HIPNLP_FIVE_PER_CU && VARY && WAVES == 4;
 template <int TERRAIN, int WAVES, bool PEERS = false, bool VARY = false> __global__ __launch_bounds__(64 * WAVES)
 __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? (five_per_cu<TERRAIN, WAVES, VARY> ? 5 : 4) : 2, five_per_cu<TERRAIN, WAVES, VARY> ? 5 : 4)))
 void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const double* pk_p, const GParams* gp_p, int N_p, int n_p, int kb_p, int nk_p, KArgs a) {
@@ -401,7 +401,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         // through registers: the odd last double of the two records; horizon ends only: the periodicity variables of the other end
         double xrem = 0.0, xov = 0.0;
         if (XREM && tid < 2 && !(first && tid == 1)) xrem = x[size_t(NXK) * (k - tid) + XB / 8];
-        if (first || last) { if (tid < NPER) xov = x[size_t(NXK) * (first ? N - 1 : 0) + periodicity_row_var(tid)]; }
+        if constexpr (!Scratch::trimmed) { if (first || last) { if (tid < NPER) xov = x[size_t(NXK) * (first ? N - 1 : 0) + periodicity_row_var(tid)]; } }
 #ifdef HIPNLP_STAMPS
         st_issued = __builtin_amdgcn_s_memtime();
 #endif
@@ -410,11 +410,11 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 #ifdef HIPNLP_STAMPS
         st_loaded = __builtin_amdgcn_s_memtime();
 #endif
-        if (first || last) { if (tid < NPER) s.xo[tid] = xov; }
+        if constexpr (!Scratch::trimmed) { if (first || last) { if (tid < NPER) s.xo[tid] = xov; } }
         if (XREM && tid < 2) (tid ? s.xm : s.x)[XB / 8] = xrem;
         if (first) { for (int i = tid; i < XB / 8; i += WG) s.xm[i] = 0.0; }
         // pads (no staging load touches them)
-        if (tid >= 64 && tid < 64 + XPAD - NXK) { s.x[NXK + tid - 64] = 0.0; s.xm[NXK + tid - 64] = 0.0; }
+        if (tid >= 64 && tid < 64 + Scratch::xpad - NXK) { s.x[NXK + tid - 64] = 0.0; s.xm[NXK + tid - 64] = 0.0; }
         if (tid >= 128 && tid < 128 + 8 - NXG) s.xg[NXG + tid - 128] = 0.0;
         // copy-out tables: issued now, consumed at the very end (LATE_TABLES: issued behind the last barrier but one instead — the
         // registers they occupy from here to the end are what stands between the four-wave VARY kernel and a fifth wave per SIMD)
@@ -449,6 +449,8 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     Em em{s.g, s.jac - Em::kJacOff};
     // (the full tables: global memory for the compact layouts; the full layout's LDS copy otherwise — the constructor's default)
     Ctx<Em> cx(s, tabs.kin(), tabs.settings(), tabs.gp, ki, em, COMPACT ? &tb.head.kt : nullptr, COMPACT ? gp_p + b : nullptr);
+    if constexpr (Scratch::trimmed) cx.x_other = x + size_t(NXK) * (first ? N - 1 : 0);
+    static_assert(!Scratch::hd_on_rw || hdyn_entries_early<Em>, "hd on Rw[1..]: only where the momentum rows are summed in the first phase (KnotScratchT::hd_on_rw)");
     // The program is instantiated ONCE PER WAVE (a generic lambda over the wave number as a compile-time constant: a task group is
     // compiled into the one instance whose wave runs it) and dispatched by one switch, so that every wave executes a CONTIGUOUS
     // instruction stream from the first phase to the last.  Written as `if (wave == w) { ... }` blocks phase after phase, every

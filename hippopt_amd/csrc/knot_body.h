@@ -101,14 +101,31 @@ template <> struct ScratchJrOwn<true> {
 };
 static_assert(sizeof(JointRec) * NJ <= sizeof(double) * LSTR * NL, "own[NL] (zero slot, written while Jr is live) must lie behind the joint records it shares storage with");
 
+// periodicity variables of the other end of the horizon, by periodicity row (only loaded at k = 0 and k = N-1): not in a trimmed scratch
+template <bool HAS> struct ScratchXo { double xo[NPER]; };
+template <> struct ScratchXo<false> {};
+// per point contribution to hdot at knots k-1 (0) and k (1): not in the trimmed scratch of the smooth terrain (hd_of below)
+template <bool HAS> struct ScratchHd { double hd[2][NC][6]; };
+template <> struct ScratchHd<false> {};
 // JSLOTS: slots of the Jacobian staging `jac` (default: all of them).  A VARY kernel (hipnlp.hip) keeps the slots behind js::V0 only —
 // js::vary_slots(terrain) of them — and addresses them through a pointer moved back by js::V0.
-template <int LAYOUT, int JSLOTS = js::COUNT> struct alignas(16) KnotScratchT : ScratchJrOwn<LAYOUT != LAYOUT_FULL> {
+template <int LAYOUT, int JSLOTS = js::COUNT> struct alignas(16) KnotScratchT : ScratchJrOwn<LAYOUT != LAYOUT_FULL>, ScratchXo<JSLOTS == js::COUNT>,
+                                                                                 ScratchHd<JSLOTS != js::vary_slots(false)> {
     static constexpr int layout = LAYOUT;
     static constexpr bool compact = LAYOUT != LAYOUT_FULL;
-    alignas(16) double x[XPAD];    // knot k   (x, xm, xg, pk: 16-byte aligned, staged by direct global -> LDS loads)
-    double xm[XPAD];   // knot k-1 (zeros at k = 0)
-    double xo[NPER];   // periodicity variables of the other end of the horizon, by periodicity row (only loaded at k = 0 and k = N-1)
+    // trimmed (the four-wave VARY kernels: 32 KB of LDS per workgroup and not a byte more on the smooth terrain): besides the
+    // Jacobian staging, the periodicity variables of the other horizon end — 84 doubles only the first and the last knot read, once —
+    // stay in global memory (per_other below), and the knot records carry one pad word instead of three
+    static constexpr bool trimmed = JSLOTS != js::COUNT;
+    // The trimmed scratch of the SMOOTH terrain (the four-wave VARY kernel: LDS is handed out in 1 280-byte granules on gfx950, five
+    // workgroups per CU means 25 granules = 32 000 B each) keeps the per-point momentum shares hd[][][] — 768 B — on the world
+    // rotations Rw[1..11]: in that kernel the shares are written (t_points_vec) and consumed (t_hdyn_rows_a, behind it on its wave)
+    // inside the FIRST phase, the forward kinematics writes Rw[1..] in the SECOND; t_base writes Rw[0] only.  (Valid for exactly the
+    // instantiation hdyn_entries_early<Em> describes; the planar kernel sums the shares in the second phase and keeps its own array.)
+    static constexpr bool hd_on_rw = JSLOTS == js::vary_slots(false) && JSLOTS != js::COUNT;
+    static constexpr int xpad = trimmed ? NXK + 1 : XPAD;
+    alignas(16) double x[xpad];    // knot k   (x, xm, xg, pk: 16-byte aligned, staged by direct global -> LDS loads)
+    double xm[xpad];   // knot k-1 (zeros at k = 0)
     double xg[8];      // horizon-global variables (initial_state.centroidal_momentum)
     double pk[PK_STRIDE];
     // base orientation
@@ -127,13 +144,12 @@ template <int LAYOUT, int JSLOTS = js::COUNT> struct alignas(16) KnotScratchT : 
     double fr_R[3][9], fr_o[3][3];
     double pkin[NC][3];
     double chest_w[3], chest_dc;  // ax(R_c R_d^T);  d cost / d trace
-    double hd[2][NC][6];          // per point contribution to hdot at knots k-1 (0) and k (1)
     double cen_g[3];              // d centroid cost / d p_c,i (same for the 8 points)
     double yaw_sc[2][4], yaw_e[2][2];  // per foot: sin/cos of yaw and of yaw+pi/2; alignment errors (forward, sideways)
     // cost partials, reduced by t_reduce
     double c_pt[NC][3], c_joint[NJ], c_force[2][3], c_yaw[2];
     double cost[NCT];
-    double grad[XPAD];
+    double grad[xpad];
     double jac[JSLOTS];
     // value of native g slot `slot` / where the emitter stores it
     HD double& g_at(int slot) {
@@ -168,6 +184,7 @@ template <class Em> struct Ctx {
     const KinTables* gkt;
     const GParams* ggp;
     const PoseHands* hands = nullptr;   // pose finder only (set by its kernels / host expansions behind the constructor)
+    const double* x_other = nullptr;    // trimmed scratch only: the knot record of the OTHER horizon end in global memory (first knot: the last one's, and vice versa)
     HD Ctx(Scratch& s_, const Kin& kt_, const KSettings& st_, const GP& gp_, KnotInfo ki_, Em em_, const KinTables* gkt_ = nullptr, const GParams* ggp_ = nullptr)
         : s(s_), kt(kt_), st(st_), gp(gp_), ki(ki_), em(em_), gkt(gkt_), ggp(ggp_) {
         if constexpr (!Scratch::compact) {
@@ -202,6 +219,16 @@ template <class Em> HD const double* kin_inertia(const Ctx<Em>& cx, int i) {
 template <class Em> HD void emit_g_end(Ctx<Em>& cx, int slot, int id, double v) {
     if constexpr (Ctx<Em>::Scratch::compact) { (void)id; cx.s.ends.c[slot - gs::FIN] = v; }
     else cx.em.G(slot, id, v);
+}
+// the per-point momentum shares [2][NC][6] (see KnotScratchT::hd_on_rw)
+template <class S> HD double* hd_of(S& s) {
+    if constexpr (S::hd_on_rw) { static_assert(sizeof(double) * 2 * NC * 6 <= sizeof(double) * 9 * (NL - 1), "hd on Rw[1..]"); return &s.Rw[1][0]; }
+    else return &s.hd[0][0][0];
+}
+// periodicity variable i of the other horizon end (first / last knot only): LDS copy, or — trimmed scratch — global memory
+template <class Em> HD double per_other(const Ctx<Em>& cx, int i) {
+    if constexpr (Ctx<Em>::Scratch::trimmed) return cx.x_other[periodicity_row_var(i)];
+    else return cx.s.xo[i];
 }
 // horizon-end tables and final-state values: first / last knot only (compact layout: straight from global memory)
 template <class Em> HD const EndTables& end_tables(const Ctx<Em>& cx) { return cx.gkt->en; }
@@ -430,8 +457,8 @@ template <class Em> HD void t_points_vec(Ctx<Em>& cx, int t) {
         const double* xx = w ? s.x : s.xm;
         double r[3];
         for (int q = 0; q < 3; ++q) r[q] = xx[cb + P_ + q] - xx[COM_ + q];
-        s.hd[w][c][i] = xx[cb + F_ + i];
-        s.hd[w][c][3 + i] = cross_comp(r, xx + cb + F_, i);
+        hd_of(s)[(w * NC + c) * 6 + i] = xx[cb + F_ + i];
+        hd_of(s)[(w * NC + c) * 6 + 3 + i] = cross_comp(r, xx + cb + F_, i);
     }
 }
 
@@ -1051,7 +1078,7 @@ template <class Em> HD void t_hdyn(Ctx<Em>& cx, int t) {
     } else if (t < 54) {  // the six rows
         const int i = t - 48;
         double h0 = cx.gp.gravity[i], h1 = cx.gp.gravity[i];
-        for (int c = 0; c < NC; ++c) { h0 += s.hd[0][c][i]; h1 += s.hd[1][c][i]; }
+        for (int c = 0; c < NC; ++c) { h0 += hd_of(s)[c * 6 + i]; h1 += hd_of(s)[(NC + c) * 6 + i]; }
         em.G(gs::HDYN + i, row_id(RK_HDYN_IN, 0, i), s.x[H_ + i] - (s.xm[H_ + i] + half * (h0 + h1)));
         em.G(gs::H_X0 + i, row_id(RK_HDYN_X0, 0, i), s.x[H_ + i] - s.xg[i]);
         emit_jc(em, js::HDYN_SELF_IN + i, row_id(RK_HDYN_IN, 0, i), H_ + i, 1.0);
@@ -1134,12 +1161,13 @@ template <class Em> HD void t_ends(Ctx<Em>& cx, int t) {
         if (cx.st.periodicity_type == HIPNLP_EXPR_MINIMIZE) {
             if (!cx.ki.first && !cx.ki.last) return;
             // e = x_0 - x_{N-1};  at the last knot xo = x_0, at the first knot xo = x_{N-1}
-            const double e = cx.ki.last ? (s.xo[i] - s.x[var]) : (s.x[var] - s.xo[i]);
+            const double xoi = per_other(cx, i);
+            const double e = cx.ki.last ? (xoi - s.x[var]) : (s.x[var] - xoi);
             if (cx.ki.last) s.ends.c[t] = cx.st.periodicity_weight * e * e;
             s.ends.g[t] = (cx.ki.last ? -2.0 : 2.0) * cx.st.periodicity_weight * e;  // d/dx_{N-1} = -2we, d/dx_0 = +2we
         } else if (cx.st.periodicity_type == HIPNLP_EXPR_SUBJECT_TO) {
             if (cx.ki.last) {
-                emit_g_end(cx, gs::PER + i, row_id(RK_PERN, 0, i), s.xo[i] - s.x[var]);
+                emit_g_end(cx, gs::PER + i, row_id(RK_PERN, 0, i), per_other(cx, i) - s.x[var]);
                 emit_jc(em, js::PERN + i, row_id(RK_PERN, 0, i), var, -1.0);
             }
             if (cx.ki.first) emit_jc(em, js::PER0 + i, row_id(RK_PER0, 0, i), var, 1.0);

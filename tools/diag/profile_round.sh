@@ -10,13 +10,13 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-WORKLOADS=${@:-"periodic_N100_B1:--batch=1 periodic_N100_B64:--batch=64 periodic_N100_B1024:--batch=1024 stairs_N200_B16:--workload=stairs,--horizon=200,--batch=16"}
+WORKLOADS=${@:-"periodic_N100_B1:--batch=1 periodic_N100_B64:--batch=64 periodic_N100_B1024:--batch=1024 stairs_N200_B16:--workload=stairs,--horizon=200,--batch=16 periodic_N100_B1_vf:--batch=1,--varying-first periodic_N100_B64_vf:--batch=64,--varying-first periodic_N100_B1024_vf:--batch=1024,--varying-first stairs_N200_B16_vf:--workload=stairs,--horizon=200,--batch=16,--varying-first"}
 run() { name=$1; shift; echo "== $name" ; rocprofv3 "$@" > $OUT/$name.log 2>&1; echo "   rc=$?"; }
 for W in $WORKLOADS; do
   NAME=${W%%:*}; ARGS=$(echo ${W#*:} | tr ',' ' ')
   B=$(echo $ARGS | sed -n 's/.*--batch=\([0-9]*\).*/\1/p'); B=${B:-1}
   STEPS=$([ $B -ge 1024 ] && echo 30 || echo 300)
-  COMMON="--no-cpu-baseline --no-hessian --no-host"
+  COMMON="--no-cpu-baseline --no-hessian --no-host --no-throughput"
   run trace_$NAME --kernel-trace --stats --output-format csv -d $OUT/trace_$NAME -- python3 bench.py --steps $STEPS --warmup 20 $ARGS $COMMON
   run fetch_$NAME --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$NAME -- python3 bench.py --steps 20 --warmup 5 $ARGS $COMMON
   run write_$NAME --pmc WRITE_SIZE --output-format csv -d $OUT/write_$NAME -- python3 bench.py --steps 20 --warmup 5 $ARGS $COMMON
