@@ -275,6 +275,12 @@ def host_visible(eng, x_np, horizon, batch, st=None, model=None):
     # the library's defaults: plain numpy arrays, nothing registered by the caller
     sweep("")
     res["all"]["note"] = "plain caller arrays, library defaults: the handle registers arrays it sees twice in a row (hipnlp_set_auto_register, verified at every use)"
+    raw0 = eng.raw_eval()
+    xaddr0 = [xi.ctypes.data for xi in xs]
+    addr0 = tuple(o.ctypes.data for o in outs)
+    res["all (raw C-ABI call)"] = {"ms_per_call": best_of(lambda i: raw0(xaddr0[i % 4], 1, *addr0)),
+                                   "library_us [x staging, enqueue, wait for the GPU, copies out]": [round(float(v), 2) for v in eng.host_breakdown()],
+                                   "note": "the same call as `all` without HipNlp.eval's numpy argument conversion: one foreign call on raw addresses, what a C binding pays"}
     eng.set_auto_register(False)
     sweep(" (auto-registration off: pinned block + host copy)", ("f", "g", "jac", "all"))
     res["all (zero-copy views of the pinned block)"] = {"ms_per_call": best_of(lambda i: eng.eval_pinned(xs[i % 4]))}
@@ -321,6 +327,16 @@ def host_visible(eng, x_np, horizon, batch, st=None, model=None):
                 out = tuple(o if k in want else None for k, o in zip(("f", "grad", "g", "jac"), vouts))
                 res[name + " (varying-first order of a knot's jac block)"] = {
                     "ms_per_call": best_of(lambda i: vf.eval(xs[i % 4], want=want, out=out)),
+                    "library_us [x staging, enqueue, wait for the GPU, copies out]": [round(float(v), 2) for v in vf.host_breakdown()]}
+            # ... and as ONE foreign call on raw addresses (HipNlp.raw_eval): what a C binding pays — the numpy argument conversion of
+            # HipNlp.eval is several microseconds of every figure above
+            raw = vf.raw_eval()
+            xaddr = [xi.ctypes.data for xi in xs]
+            for name in ("f", "jac", "all"):
+                want = kinds[name]
+                addr = tuple(o.ctypes.data if k in want else None for k, o in zip(("f", "grad", "g", "jac"), vouts))
+                res[name + " (varying-first order, raw C-ABI call)"] = {
+                    "ms_per_call": best_of(lambda i: raw(xaddr[i % 4], 1, *addr)),
                     "library_us [x staging, enqueue, wait for the GPU, copies out]": [round(float(v), 2) for v in vf.host_breakdown()]}
             # the same handle with every entry of jac g stored on every call (hipnlp_set_constant_jacobian off) — same process, same arrays
             vf.set_constant_jacobian(False)
@@ -1183,6 +1199,21 @@ def main():
                 eng._bench_params = main_res["p_np"]
                 hv = host_visible(eng, main_res["x_np"], args.horizon, args.batch, st, model)
                 line["host_visible"] = hv
+
+                def us(key):
+                    return round(1e3 * hv[key]["ms_per_call"], 2) if key in hv and "ms_per_call" in hv[key] else None
+                line["host_visible_summary"] = {
+                    "what": "microseconds per hipnlp_eval call that returns f, grad f, g AND jac g of one 100-knot trajectory in caller-owned host arrays, new x every call",
+                    "ccs_order_through_the_python_wrapper": us("all"),
+                    "ccs_order_one_foreign_call_on_raw_addresses": us("all (raw C-ABI call)"),
+                    "varying_first_order_through_the_python_wrapper": us("all (varying-first order of a knot's jac block)"),
+                    "varying_first_order_one_foreign_call_on_raw_addresses": us("all (varying-first order, raw C-ABI call)"),
+                    "jac_only_varying_first_raw_call": us("jac (varying-first order, raw C-ABI call)"),
+                    "ipopt_iterate_python_solver_path": us("ipopt iterate through the Python solver path (HipNlpSolver callbacks, detect_simple_bounds)"),
+                    "link_floor_for_the_bytes_moved": us("link floor for the bytes actually moved (f, grad f, g and the varying entries of jac g)"),
+                    "note": "varying-first = HIPNLP_FLAG_JAC_VARYING_FIRST, the order a triplet consumer (IPOPT) picks: the 43 % of jac g that does not depend on x is filled "
+                            "into the destination once, every call moves the varying run of each knot block; the python wrapper (HipNlp.eval) spends ~7 us per call on "
+                            "numpy argument conversion, a C binding does not"}
                 line["pcie_inclusive"] = dict(hv["all"], note="hipnlp_eval with caller-owned host arrays, all four outputs, new x every call: x copied to a pinned "
                                                              "block the kernel reads directly, outputs stored by the kernel straight into the pinned output block, "
                                                              "then copied into the caller's arrays; per callback kind in `host_visible`")
@@ -1222,9 +1253,11 @@ def main():
                 # one objective (or trial-point) call
                 hv = line["host_visible"]
                 for tag, key in (("host_visible_all", "all"), ("host_visible_all_registered", "all (caller arrays registered: direct kernel stores)"),
+                                 ("host_visible_all_raw_c_abi_call", "all (raw C-ABI call)"),
                                  ("host_visible_all_auto_registration_off", "all (auto-registration off: pinned block + host copy)"),
                                  ("host_visible_all_varying_first_constants_stored_every_call", "all (varying-first order, constant entries stored on every call)"),
                                  ("host_visible_all_varying_first", "all (varying-first order of a knot's jac block)"),
+                                 ("host_visible_all_varying_first_raw_c_abi_call", "all (varying-first order, raw C-ABI call)"),
                                  ("link_floor_for_the_bytes_actually_moved", "link floor for the bytes actually moved (f, grad f, g and the varying entries of jac g)"),
                                  ("host_visible_f", "f"),
                                  ("link_floor_copy_of_the_same_bytes", "link floor: one D2H copy of the same bytes into pinned memory + wait (no kernel)")):

@@ -267,6 +267,17 @@ class HipNlp:
             self._check(rc)
         return f, grad, g, jac
 
+    def raw_eval(self):
+        """hipnlp_eval as ONE foreign call on raw addresses: `call(x_addr, new_x, f_addr, grad_addr, g_addr, jac_addr) -> rc` (None for an
+        output that is not wanted).  What a C binding pays per callback: `eval` above spends several microseconds per call converting
+        its numpy arguments, which is a fifth of a 100-knot callback."""
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)(("hipnlp_eval", self.lib))
+        h = self.h.value
+
+        def call(x_addr, new_x, f_addr, grad_addr, g_addr, jac_addr):
+            return proto(h, x_addr, new_x, f_addr, grad_addr, g_addr, jac_addr)
+        return call
+
     WANT = {"f": 1, "grad": 2, "g": 4, "jac": 8}
 
     def eval_pinned(self, x, new_x=True, want=("f", "grad", "g", "jac")):
