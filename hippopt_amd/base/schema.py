@@ -73,8 +73,11 @@ def declare(name, fields, bases=(OptimizationObject,), setup=None, methods=None,
     cls.__leaf_defaults__ = defaults
     for klass in reversed(cls.__mro__):   # defaults of the declared bases, then this node's own
         own["defaults"].update(klass.__dict__.get("__leaf_defaults__", {}))
-    # every constructor-only argument the dataclass machinery passes to __post_init__, in its order (those of the bases first)
-    own["arguments"] = tuple(n for n, f in cls.__dataclass_fields__.items() if f._field_type is dataclasses._FIELD_INITVAR)
+    # every constructor-only argument the dataclass machinery passes to __post_init__, in its order (field order: those of the bases
+    # first); the names are the ones the `declare` tables of this node and of its bases listed as argument()
+    cls.__declared_arguments__ = tuple(arguments)
+    declared = {n for klass in cls.__mro__ for n in klass.__dict__.get("__declared_arguments__", ())}
+    own["arguments"] = tuple(n for n in cls.__dataclass_fields__ if n in declared)
     if module is not None:
         cls.__module__ = module
     return cls

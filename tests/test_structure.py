@@ -69,3 +69,23 @@ def test_rectangular_foot_and_yaw_corners():
     assert np.allclose(d, np.array(gold["left_descriptors"]))
     # bottom-right (-,-), top-right (+,-), top-left (+,+) of planner.py:789-819
     assert L.yaw_corner_indices(d) == (2, 3, 0)
+
+
+def test_declared_constructor_arguments_reach_setup_by_position_and_by_name():
+    """hippopt_amd/base/schema.py: the argument() names of a node and of its declared bases reach `setup` whether the constructor
+    gets them positionally (declaration order, bases first) or by keyword, and a leaf the constructor leaves None takes its default"""
+    from hippopt_amd.base.schema import argument, declare, leaf
+    from hippopt_amd.base import Variable
+
+    seen = []
+    Base = declare("Base", {"a": leaf(Variable, lambda: np.zeros(2)), "count": argument(1)}, setup=lambda self, **kw: seen.append(("base", kw)))
+    Node = declare("Node", {"b": leaf(Variable), "scale": argument(2.0)}, bases=(Base,), setup=lambda self, **kw: seen.append(("node", kw)))
+    assert Node.__declared_arguments__ == ("scale",) and Base.__declared_arguments__ == ("count",)
+    n = Node(None, 5, np.ones(3), 0.5)                      # fields in order: a, count, b, scale
+    assert seen[-1] == ("node", {"count": 5, "scale": 0.5}) and np.array_equal(n.a, np.zeros(2)) and np.array_equal(n.b, np.ones(3))
+    Node(scale=4.0, count=7)
+    assert seen[-1] == ("node", {"count": 7, "scale": 4.0})
+    Node()
+    assert seen[-1] == ("node", {"count": 1, "scale": 2.0})
+    Base(count=3)
+    assert seen[-1] == ("base", {"count": 3})
