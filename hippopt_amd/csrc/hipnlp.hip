@@ -661,7 +661,7 @@ void hipnlp_knot_hess_kernel(HArgs a) {
     static_assert(!COMPACT || TERRAIN == HIPNLP_TERRAIN_PLANAR, "compact Hessian scratch: planar terrain (the smooth point tasks stage through jac)");
     static_assert(offsetof(Scratch, jac) + sizeof(Scratch::jac) + 16 > sizeof(Scratch) && offsetof(Scratch, grad) + sizeof(Scratch::grad) == offsetof(Scratch, jac),
                   "grad and jac are the last members of the scratch (up to tail padding)");
-    constexpr size_t S_BYTES = TERRAIN == HIPNLP_TERRAIN_PLANAR ? offsetof(Scratch, grad) : offsetof(Scratch, jac) + sizeof(double) * PP_STAGE * NC;
+    constexpr size_t S_BYTES = TERRAIN == HIPNLP_TERRAIN_PLANAR ? offsetof(Scratch, grad) : offsetof(Scratch, jac) + sizeof(double) * (PP_STAGE * NC + KH_BUMP_COEF * KH_BUMP_TASKS);
     static_assert(S_BYTES % 16 == 0, "scratch prefix");
     constexpr int WG = 256;
     __shared__ alignas(16) double s_raw[S_BYTES / sizeof(double)];

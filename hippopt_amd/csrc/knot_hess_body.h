@@ -299,6 +299,39 @@ template <int BEGIN, class Em> HD void t_kh_pp_smooth_at(KHCtx<Em>& h, int t) { 
 constexpr int PP_STAGE = 46;   // doubles handed from t_kh_point_smooth_pp to _pp2 per contact point
 static_assert(PP_STAGE * NC <= js::COUNT, "(p, p) staging lives in the Jacobian staging area");
 template <class S> HD double* pp_stage(S& s, int c) { return &s.jac[0] + PP_STAGE * c; }
+// The bump jets, ONCE per (point, bump): lane (c, bump) of the first phase — the eight contact points and, as a ninth point, the com
+// (minimum com height row) — evaluates  H exp(-g^r)  to FOURTH order and parks the fifteen scaled coefficients behind the (p, p)
+// staging; the three consumers of the next phase add the parts: t_kh_point_smooth_pp to fourth order, t_kh_point_smooth_mixed to
+// third (a prefix: the coefficients are stored by total degree), the com lanes of t_kh_diag to second.  (Until round 4 each of the
+// three evaluated every bump for itself, one after the other on its own lane: the powers, the exponential and the compositions of the
+// bumps were 9 - 10 k of the 17 k cycles of either point task and 5 of the 6 k of the diagonal task.)  The lanes of unused bumps store
+// zeros: the sums run over a fixed number of parts (adding a zero part changes no bit).
+constexpr int KH_BUMP_TASKS = (NC + 1) * HIPNLP_MAX_TERRAIN_STEPS, KH_BUMP_COEF = J2<4>::NC_;
+static_assert(PP_STAGE * NC + KH_BUMP_COEF * KH_BUMP_TASKS <= js::COUNT, "bump jets live behind the (p, p) staging in the Jacobian staging area");
+template <class S> HD double* kh_bump_part(S& s, int c, int sidx) { return &s.jac[0] + PP_STAGE * NC + KH_BUMP_COEF * (HIPNLP_MAX_TERRAIN_STEPS * c + sidx); }
+template <class Em> HD void t_kh_bump(KHCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    if (terrain_is_planar(cx)) return;
+    auto& s = cx.s;
+    const int c = t / HIPNLP_MAX_TERRAIN_STEPS, sidx = t - HIPNLP_MAX_TERRAIN_STEPS * c;
+    const double* p = c < NC ? s.x + PT_ * c + P_ : s.x + COM_;
+    J2<4> bump;
+    if (sidx < cx.st.n_steps) {
+        terrain_bump_j<4>(cx.st.steps[sidx], p[0], p[1], bump);   // (false: the bump has vanished, its jet stays zero)
+        bump.c[0] += cx.st.steps[sidx].oz;
+    }
+    double* out = kh_bump_part(s, c, sidx);
+    for (int i = 0; i < KH_BUMP_COEF; ++i) out[i] = bump.c[i];
+}
+// Z(p_x, p_y) of the terrain at point c (NC: the com) to order K from the parts t_kh_bump left (same order of the bumps as terrain_Z_jet)
+template <int K, class S> HD J2<K> kh_terrain_Z(S& s, int c) {
+    J2<K> Z;
+    for (int sidx = 0; sidx < HIPNLP_MAX_TERRAIN_STEPS; ++sidx) {
+        const double* part = kh_bump_part(s, c, sidx);
+        for (int i = 0; i < J2<K>::NC_; ++i) Z.c[i] += part[i];
+    }
+    return Z;
+}
 template <class Em> HD void t_kh_point_smooth_pp(KHCtx<Em>& h, int c) {
     Ctx<Em>& cx = h.cx;
     if (terrain_is_planar(cx)) return;
@@ -320,7 +353,7 @@ template <class Em> HD void t_kh_point_smooth_pp(KHCtx<Em>& h, int c) {
     // and the normal; t_kh_point_smooth_pp2: the terms in the tangent axes.
     T3 L;
     {
-        const J2<4> Z = terrain_Z_j<4>(cx.st, p[0], p[1]);
+        const J2<4> Z = kh_terrain_Z<4>(s, c);
         const J2<3> u1 = -j2_dx(Z), u2 = -j2_dy(Z);   // grad h = (u1, u2, 1)
         T3 hT = t3_from(-j2_trunc<4, 2>(Z));
         hT.v += p[2]; hT.g[2] = 1.0;
@@ -329,7 +362,7 @@ template <class Em> HD void t_kh_point_smooth_pp(KHCtx<Em>& h, int c) {
         T3 dh = hT;
         dh.v -= s.pk[PK_REF + R_SWING];
         L = hT * l_h + (dh * dh) * (0.5 * msw);
-        const J2<3> n2 = j2_pow(J2<3>(1.0) + u1 * u1 + u2 * u2, -0.5);
+        const J2<3> n2 = j2_rsqrt(J2<3>(1.0) + u1 * u1 + u2 * u2);
         const J2<3> n0 = u1 * n2, n1 = u2 * n2;
         {
             const J2<3> nf = n0 * f[0] + n1 * f[1] + n2 * f[2];
@@ -378,7 +411,7 @@ template <class Em> HD void t_kh_point_smooth_pp2(KHCtx<Em>& h, int c) {
         const double tv = knot_tanh(kt * hT.v), t1 = kt * (1.0 - tv * tv), t2 = -2.0 * kt * tv * t1;
         const T3 tau = t3_chain(hT, tv, t1, t2);
         const J2<3> q = n1 * n1 + n2 * n2;            // same closed form as terrain_frame (knot_body.h)
-        const J2<3> iq = j2_pow(q, -0.5);
+        const J2<3> iq = j2_rsqrt(q);
         // x . c = iq (q c_0 - n_0 (n_1 c_1 + n_2 c_2)),   y . c = iq (n_2 c_1 - n_1 c_2)
         { const T3 xfT = t3_from(iq * (q * f[0] - n0 * (n1 * f[1] + n2 * f[2]))); L = L - (xfT * xfT) * l_f; }
         { const T3 yfT = t3_from(iq * (n2 * f[1] - n1 * f[2])); L = L - (yfT * yfT) * l_f; }
@@ -410,11 +443,11 @@ template <class Em> HD void t_kh_point_smooth_mixed(KHCtx<Em>& h, int c) {
     const double kbs = cx.gp.kbs, kt = cx.gp.kt, mu2 = cx.gp.mu * cx.gp.mu;
     G3 hG, gh[3], n[3], xv[3], yv[3], dn[3][2];
     {
-        const J2<3> Z = terrain_Z_j<3>(cx.st, p[0], p[1]);
+        const J2<3> Z = kh_terrain_Z<3>(s, c);
         const J2<2> u1 = -j2_dx(Z), u2 = -j2_dy(Z);
         hG.v = p[2] - Z.c[0]; hG.g[0] = u1.c[0]; hG.g[1] = u2.c[0]; hG.g[2] = 1.0;
         gh[0] = g3_from(u1); gh[1] = g3_from(u2); gh[2] = G3(1.0);
-        const J2<2> n2 = j2_pow(J2<2>(1.0) + u1 * u1 + u2 * u2, -0.5);
+        const J2<2> n2 = j2_rsqrt(J2<2>(1.0) + u1 * u1 + u2 * u2);
         const J2<2> n0 = u1 * n2, n1 = u2 * n2;
         n[0] = g3_from(n0); n[1] = g3_from(n1); n[2] = g3_from(n2);
         dn[0][0] = g3_from(j2_dx(n0)); dn[0][1] = g3_from(j2_dy(n0));
@@ -423,7 +456,7 @@ template <class Em> HD void t_kh_point_smooth_mixed(KHCtx<Em>& h, int c) {
         // the tangent axes are needed to first order only
         const J2<1> m0 = j2_trunc<2, 1>(n0), m1 = j2_trunc<2, 1>(n1), m2 = j2_trunc<2, 1>(n2);
         const J2<1> q = m1 * m1 + m2 * m2;
-        const J2<1> iq = j2_pow(q, -0.5);
+        const J2<1> iq = j2_rsqrt(q);
         xv[0] = g3_from(q * iq); xv[1] = g3_from(-(m1 * m0) * iq); xv[2] = g3_from(-(m2 * m0) * iq);
         yv[0] = G3(0.0); yv[1] = g3_from(m2 * iq); yv[2] = g3_from(-(m1 * iq));
     }
@@ -476,10 +509,9 @@ template <class Em> HD void t_kh_diag(KHCtx<Em>& h, int t) {
     else if (t < 9) {
         var = COM_ + (t - 6);
         if (!terrain_is_planar(cx) && t < 8) {   // minimum com height  com_z - Z(com_x, com_y)  (planner.py:353-358)
-            double Z[10];
-            terrain_Z_jet(cx.st, cx.s.x[COM_], cx.s.x[COM_ + 1], 2, Z);
-            v = -h.lam[gs::COMH] * (t == 6 ? Z[3] : Z[5]);
-            if (t == 7) cx.em.H(hk::COMXY, COM_ + 1, COM_, -h.lam[gs::COMH] * Z[4]);
+            const J2<2> Z = kh_terrain_Z<2>(cx.s, NC);   // (scaled coefficients: Z_xx = 2 c_20, Z_xy = c_11, Z_yy = 2 c_02)
+            v = -h.lam[gs::COMH] * 2.0 * (t == 6 ? Z.c[J2<2>::idx(2, 0)] : Z.c[J2<2>::idx(0, 2)]);
+            if (t == 7) cx.em.H(hk::COMXY, COM_ + 1, COM_, -h.lam[gs::COMH] * Z.c[J2<2>::idx(1, 1)]);
         }
     }
     else if (t < 15) { var = H_ + (t - 9); if (t < 12) v = 2.0 * sigma * cx.st.m_comvel * cx.st.w_comvel[t - 9]; }   // com velocity cost (k >= 0)
@@ -941,6 +973,7 @@ template <class Em> HD void t_kh_ssd_far_c(KHCtx<Em>& h, int t) { t_kh_ssd_far(h
 #define HIPNLP_KNOT_HESS_PHASE1A(KIN, RH, BARRIER)                                                               \
     KIN(0, t_joints, NJ) RH(0, t_kh_ff, 36) KIN(1, t_base, 3) KIN(1, t_kin_padding, 16)                          \
     RH(1, t_kh_diag_planar, 42) RH(1, t_kh_percouple, 84) RH(2, t_kh_point, NC) RH(3, t_kh_pp_planar_at<128>, 52) \
+    RH(3, t_kh_bump, KH_BUMP_TASKS)                                                                              \
     BARRIER
 #define HIPNLP_KNOT_HESS_PHASE1B(KIN, RH, BARRIER)                                                               \
     KIN(0, t_fk_rot_a, FK_TASKS_A) KIN(0, t_link_u_a, FK_SPLIT) KIN(3, t_fk_rot_b, FK_TASKS_B) KIN(3, t_link_u_b, NJ - FK_SPLIT) \

@@ -39,48 +39,62 @@ template <int K> HD J2<K> operator*(const J2<K>& a, const J2<K>& b) {
         }
     return r;
 }
-// g(a) for an analytic g with Taylor coefficients gn[n] = g^(n)(a_0) / n!
-template <int K> HD J2<K> j2_compose(const J2<K>& a, const double* gn) {
-    J2<K> d = a;
-    d.c[0] = 0.0;
-    J2<K> r(gn[K]);
-    for (int n = K - 1; n >= 0; --n) { r = r * d; r.c[0] += gn[n]; }
-    return r;
+// g(a) for an analytic g with Taylor coefficients gn[n] = g^(n)(a_0) / n!: Horner in d = a - a_0.  d has no constant term, so the
+// value after j steps is only needed — and only meaningful — up to total degree j: step j multiplies a degree-(j-1) polynomial with the
+// degree >= 1 part of d, truncated at degree j (2 + 9 + 25 + 55 = 91 multiply-adds for K = 4 where four full truncated products
+// take 280; the terms kept are the same, in the same order, so the coefficients are the ones the full products give).
+template <int K, int ORD> HD void j2_horner_step(J2<K>& r, const J2<K>& a, double g) {
+    double out[(ORD + 1) * (ORD + 2) / 2];
+    for (int i = 0; i < (ORD + 1) * (ORD + 2) / 2; ++i) out[i] = 0.0;
+    for (int d1 = 0; d1 < ORD; ++d1)
+        for (int j1 = 0; j1 <= d1; ++j1) {
+            const double av = r.c[d1 * (d1 + 1) / 2 + j1];
+            for (int d2 = 1; d1 + d2 <= ORD; ++d2)
+                for (int j2 = 0; j2 <= d2; ++j2) {
+                    const int d = d1 + d2;
+                    out[d * (d + 1) / 2 + j1 + j2] += av * a.c[d2 * (d2 + 1) / 2 + j2];
+                }
+        }
+    out[0] = g;
+    for (int i = 0; i < (ORD + 1) * (ORD + 2) / 2; ++i) r.c[i] = out[i];
 }
-template <int K> HD J2<K> j2_ipow(const J2<K>& a, int m) {   // a^m, integer m > K (a_0 may be zero or negative)
-    double gn[K + 1];
-    double binom = 1.0;
-    for (int n = 0; n <= K; ++n) { gn[n] = binom * ipow_d(a.c[0], m - n); binom = binom * double(m - n) / double(n + 1); }
-    return j2_compose(a, gn);
+template <int K, int ORD> HD void j2_horner(J2<K>& r, const J2<K>& a, const double* gn) {
+    if constexpr (ORD <= K) {
+        j2_horner_step<K, ORD>(r, a, gn[K - ORD]);
+        j2_horner<K, ORD + 1>(r, a, gn);
+    }
+}
+template <int K> HD J2<K> j2_compose(const J2<K>& a, const double* gn) {
+    J2<K> r(gn[K]);
+    j2_horner<K, 1>(r, a, gn);
+    return r;
 }
 // (a0 + ax X + ay Y)^m for an integer m > K, in closed form (multinomial theorem): the coefficient of X^i Y^j is
 // m (m-1) ... (m-i-j+1) / (i! j!)  a0^(m-i-j) ax^i ay^j.  No polynomial products and no temporaries: the two footprint powers of every
 // bump were half of the truncated products of the terrain jet and most of its register pressure.
+HD constexpr double j2_inv_fact(int n) { return n <= 1 ? 1.0 : (n == 2 ? 0.5 : (n == 3 ? 1.0 / 6.0 : (n == 4 ? 1.0 / 24.0 : 1.0 / 120.0))); }   // n <= 5
 template <int K> HD J2<K> j2_linpow(double a0, double ax, double ay, int m) {
     J2<K> r;
     double p[K + 1];              // a0^(m-d), d = 0..K
     p[K] = ipow_d(a0, m - K);
     for (int d = K - 1; d >= 0; --d) p[d] = p[d + 1] * a0;
+    double xi[K + 1], yj[K + 1];  // ax^i / i!, ay^j / j!  (reciprocal factorials as constants: no division in the task)
+    xi[0] = yj[0] = 1.0;
+    double xp = 1.0, yp = 1.0;
+    for (int i = 1; i <= K; ++i) { xp *= ax; yp *= ay; xi[i] = xp * j2_inv_fact(i); yj[i] = yp * j2_inv_fact(i); }
     double ff = 1.0;              // m (m-1) ... (m-d+1)
     for (int d = 0; d <= K; ++d) {
-        double xi = 1.0;          // ax^i / i!  with i = d - j, built from j = d downwards
-        // coefficient(i, j) = ff * p[d] * (ax^i / i!) * (ay^j / j!)
-        double yj[K + 1];
-        yj[0] = 1.0;
-        for (int j = 1; j <= d; ++j) yj[j] = yj[j - 1] * ay / double(j);
-        for (int i = 0; i <= d; ++i) {
-            const int j = d - i;
-            r.c[J2<K>::idx(i, j)] = ff * p[d] * xi * yj[j];
-            xi = xi * ax / double(i + 1);
-        }
+        const double fp = ff * p[d];
+        for (int i = 0; i <= d; ++i) r.c[J2<K>::idx(i, d - i)] = fp * xi[i] * yj[d - i];
         ff = ff * double(m - d);
     }
     return r;
 }
-template <int K> HD J2<K> j2_pow(const J2<K>& a, double alpha) {   // a^alpha, a_0 > 0
+template <int K> HD J2<K> j2_rsqrt(const J2<K>& a) {   // a^(-1/2), a_0 > 0: Taylor coefficients g_n = g_(n-1) (-1/2 - (n-1)) / (n a_0)
     double gn[K + 1];
-    gn[0] = pow(a.c[0], alpha);
-    for (int n = 1; n <= K; ++n) gn[n] = gn[n - 1] * (alpha - double(n - 1)) / (double(n) * a.c[0]);
+    const double r = sqrt(a.c[0]), inv = 1.0 / a.c[0];
+    gn[0] = r * inv;
+    for (int n = 1; n <= K; ++n) gn[n] = gn[n - 1] * ((-0.5 - double(n - 1)) / double(n)) * inv;
     return j2_compose(a, gn);
 }
 template <int K> HD J2<K - 1> j2_dx(const J2<K>& a) {
@@ -95,21 +109,36 @@ template <int K> HD J2<K - 1> j2_dy(const J2<K>& a) {
 }
 template <int K, int L> HD J2<L> j2_trunc(const J2<K>& a) { J2<L> r; for (int i = 0; i < J2<L>::NC_; ++i) r.c[i] = a.c[i]; return r; }
 
-// Z(p_x, p_y) of the terrain as a jet of order K (same guard against underflow as terrain_bump_jet)
+// One bump  H exp(-g^r)  of the terrain as a jet of order K, g = a^m + b^m with the footprint coordinates a, b LINEAR in (p_x, p_y):
+// their powers in closed form, and ONE composition with the Taylor coefficients of  F(t) = H exp(-t^r)  at t = g_0
+// (s_n = C(r, n) g_0^(r-n) are those of t^r;  E = exp(-s):  n e_n = -sum_k k s_k e_(n-k)) instead of a composition for the power and
+// another for the exponential.  false: exp(-w) underflows (same guard as terrain_bump_jet; also catches inf / nan of far-away
+// points) — the bump and all its derivatives vanish, `out` is left alone.
+template <int K> HD bool terrain_bump_j(const TerrainStepK& t, double px, double py, J2<K>& out) {
+    const double dx = px - t.ox, dy = py - t.oy;
+    const J2<K> g = j2_linpow<K>(t.ax * dx + t.ay * dy, t.ax, t.ay, t.m) + j2_linpow<K>(t.bx * dx + t.by * dy, t.bx, t.by, t.m);
+    double sn[K + 1], en[K + 1];
+    sn[K] = ipow_d(g.c[0], t.r - K);                                 // g_0^(r-n) ...
+    for (int n = K - 1; n >= 0; --n) sn[n] = sn[n + 1] * g.c[0];
+    double ff = 1.0;                                                 // ... times C(r, n) = r (r-1) ... (r-n+1) / n!
+    for (int n = 0; n <= K; ++n) { sn[n] *= ff * j2_inv_fact(n); ff *= double(t.r - n); }
+    if (!(sn[0] < 700.0)) return false;
+    en[0] = t.height * exp(-sn[0]);
+    for (int n = 1; n <= K; ++n) {
+        double acc = 0.0;
+        for (int k = 1; k <= n; ++k) acc += double(k) * sn[k] * en[n - k];
+        en[n] = acc * (-1.0 / double(n));
+    }
+    out = j2_compose(g, en);
+    return true;
+}
+// Z(p_x, p_y) of the terrain as a jet of order K
 template <int K> HD J2<K> terrain_Z_j(const KSettings& st, double px, double py) {
     J2<K> Z;
     for (int sidx = 0; sidx < st.n_steps; ++sidx) {
-        const TerrainStepK& t = st.steps[sidx];
-        Z.c[0] += t.oz;
-        const double dx = px - t.ox, dy = py - t.oy;
-        // the footprint coordinates a, b are LINEAR in (p_x, p_y): their powers in closed form
-        const J2<K> g = j2_linpow<K>(t.ax * dx + t.ay * dy, t.ax, t.ay, t.m) + j2_linpow<K>(t.bx * dx + t.by * dy, t.bx, t.by, t.m);
-        const J2<K> w = j2_ipow(g, t.r);
-        if (!(w.c[0] < 700.0)) continue;
-        double gn[K + 1];   // H exp(-w) in powers of (w - w_0): H e^{-w_0} (-1)^n / n!
-        gn[0] = t.height * exp(-w.c[0]);
-        for (int n = 1; n <= K; ++n) gn[n] = -gn[n - 1] / double(n);
-        Z = Z + j2_compose(w, gn);
+        Z.c[0] += st.steps[sidx].oz;
+        J2<K> bump;
+        if (terrain_bump_j<K>(st.steps[sidx], px, py, bump)) Z = Z + bump;
     }
     return Z;
 }

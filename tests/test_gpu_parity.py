@@ -136,7 +136,7 @@ def test_random_configurations_both_kernel_variants(model, HipNlp):
         hr, hc = eng.hess_sparsity()
         hv = eng.eval_hess(x, sig, lam)
         for b in range(B):
-            err, where = hess_mismatch(triplets_to_dict(hr, hc, hv[b]), triplets_to_dict(*orc.hess(x[b], p[b], float(sig[b]), lam[b])))
+            err, where = hess_mismatch(triplets_to_dict(hr, hc, hv[b]), triplets_to_dict(*orc.hess(x[b], p[b], float(sig[b]), lam[b])), diag_scaled=stairs)
             assert err <= (1e-9 if stairs else TOL), (case, b, where)
         assert np.array_equal(outs[(4, 0)][0], outs[(4, 1)][0])     # the two reductions of one kernel: the same tree
         assert all(np.array_equal(a, b_) for a, b_ in zip(outs[(4, 0)][1:], outs[(4, 1)][1:]))
@@ -1101,7 +1101,7 @@ def test_hessian_smooth_terrain_matches_oracle(model, HipNlp, oriented):
     vals = eng.eval_hess(x, 0.8, lam)
     assert np.array_equal(vals, eng.eval_hess(x, 0.8, lam))
     for b in range(B):
-        err, where = hess_mismatch(triplets_to_dict(ir, jc, vals[b]), triplets_to_dict(*o.hess(x[b], p[b], 0.8, lam[b])))
+        err, where = hess_mismatch(triplets_to_dict(ir, jc, vals[b]), triplets_to_dict(*o.hess(x[b], p[b], 0.8, lam[b])), diag_scaled=True)
         assert err <= 1e-9, (b, where)
 
 
@@ -1178,7 +1178,7 @@ def test_joint_numbering_that_does_not_follow_the_tree(model, HipNlp, seed):
         for b in range(2):
             fo, grado, go, jaco = orc.eval(x[b], p[b])
             assert rel(f[b], fo) < TOL and rel(grad[b], grado) < TOL and rel(g[b], go) < TOL and rel(jac[b], jaco) < TOL
-            err, where = hess_mismatch(triplets_to_dict(hr, hc, hv[b]), triplets_to_dict(*orc.hess(x[b], p[b], 0.7, lam[b])))
+            err, where = hess_mismatch(triplets_to_dict(hr, hc, hv[b]), triplets_to_dict(*orc.hess(x[b], p[b], 0.7, lam[b])), diag_scaled=maker is stairs_settings)
             assert err <= tol, (b, where)
 
 
