@@ -611,6 +611,11 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 // Hessian tasks; the knot's block of the triplet values leaves as one contiguous run.  Multipliers arrive in the reference's row
 // order and are gathered through the same slot -> row map that scatters g.
 // =====================================================================================================================
+#if HIPNLP_HESS_DIAG_PHASES >= 6
+#define HIPNLP_HESS_TABLES_AT 5   // behind the barrier that ends the fifth phase
+#else
+#define HIPNLP_HESS_TABLES_AT HIPNLP_HESS_DIAG_PHASES   // (diagnostic builds that stop early: behind the last barrier they have)
+#endif
 struct HessTables {
     int32_t perm[hk::COUNT];      // position in the knot block -> native slot
     int32_t perm_couple[84];
@@ -645,23 +650,20 @@ template <int TERRAIN, int LAYOUT> struct DevEmH {
 };
 
 // LDS.  The Hessian program runs none of the tasks that emit Jacobian entries or the cost gradient: the last members of the knot scratch
-// (grad, jac: 17.2 KB) are not allocated — on the smooth terrain the first 2.9 KB of jac, where the (p, p) point task hands over to its
-// second half (pp_stage).
-//   LAYOUT_FULL    (launches that are resident at once: knots x batch <= 512): 64 KB (69 KB on the smooth terrain), two workgroups per CU;
-//   LAYOUT_COMPACT (planar terrain, longer launches): the compact scratch and the lite tables of the four-wave callback kernel —
-//                  own[] on the joint records, the once-per-knot tables read from global memory, no staging of the horizon-end
-//                  multipliers (no Hessian task reads them: those rows are linear) — 52 KB: THREE workgroups per CU; the planar program
-//                  needs 156 VGPRs (cap at three waves per SIMD: 168).  The smooth terrain's point tasks need 240 VGPRs: two waves per
-//                  SIMD whatever the LDS, so it keeps the full layout.
+// (grad, jac: 17.2 KB) are not allocated.  The smooth terrain's point tasks hand their jets over through the per-joint spatial vectors of
+// the Hessian scratch, which are dead until the kinematic Hessian tasks (knot_hess_body.h: pp_stage, kh_bump_part).
+//   LAYOUT_FULL    (launches that are resident at once: knots x batch <= 512): 64 KB, two workgroups per CU;
+//   LAYOUT_COMPACT (longer launches): the compact scratch and the lite tables of the four-wave callback kernel — own[] on the joint
+//                  records, the once-per-knot tables read from global memory, no staging of the horizon-end multipliers (no Hessian task
+//                  reads them: those rows are linear) — 52 KB: THREE workgroups per CU, 168 VGPRs.
 template <int TERRAIN, int LAYOUT> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LAYOUT == LAYOUT_COMPACT ? 3 : 2, LAYOUT == LAYOUT_COMPACT ? 3 : 2)))
 void hipnlp_knot_hess_kernel(HArgs a) {
     using Em = DevEmH<TERRAIN, LAYOUT>;
     using Scratch = typename Em::Scratch;
     constexpr bool COMPACT = Scratch::compact;
-    static_assert(!COMPACT || TERRAIN == HIPNLP_TERRAIN_PLANAR, "compact Hessian scratch: planar terrain (the smooth point tasks stage through jac)");
     static_assert(offsetof(Scratch, jac) + sizeof(Scratch::jac) + 16 > sizeof(Scratch) && offsetof(Scratch, grad) + sizeof(Scratch::grad) == offsetof(Scratch, jac),
                   "grad and jac are the last members of the scratch (up to tail padding)");
-    constexpr size_t S_BYTES = TERRAIN == HIPNLP_TERRAIN_PLANAR ? offsetof(Scratch, grad) : offsetof(Scratch, jac) + sizeof(double) * (PP_STAGE * NC + KH_BUMP_COEF * KH_BUMP_TASKS);
+    constexpr size_t S_BYTES = offsetof(Scratch, grad);
     static_assert(S_BYTES % 16 == 0, "scratch prefix");
     constexpr int WG = 256;
     __shared__ alignas(16) double s_raw[S_BYTES / sizeof(double)];
@@ -739,14 +741,20 @@ void hipnlp_knot_hess_kernel(HArgs a) {
         if (tid == 0) hx.sigma = sig;
     }
     lds_barrier();
-    // copy-out permutation, fetched now so that its latency hides behind the programs
+    // copy-out permutation: fetched behind the fifth barrier, so that its latency hides behind the last phase and its registers (ten
+    // per lane on the smooth terrain) are free while the point tasks run
     const HessTables& ht = *a.ht;
     constexpr int HP_ITERS = (hk::COUNT + WG - 1) / WG;
-    const int cnt = ht.nnz_knot;
+    int cnt = 0, hpc = -1;
     int32_t hp[HP_ITERS];
+    auto fetch_tables = [&]() __attribute__((always_inline)) {
+        cnt = ht.nnz_knot;
 #pragma unroll
-    for (int it = 0; it < HP_ITERS; ++it) { const int i = tid + it * WG; hp[it] = i < hk::COUNT ? ht.perm[i] : -1; }   // (padded with -1 on the host)
-    const int hpc = (last && tid < 84) ? ht.perm_couple[tid] : -1;   // (padded with -1 on the host)
+        for (int it = 0; it < HP_ITERS; ++it) { const int i = tid + it * WG; hp[it] = i < hk::COUNT ? ht.perm[i] : -1; }   // (padded with -1 on the host)
+        hpc = (last && tid < 84) ? ht.perm_couple[tid] : -1;   // (padded with -1 on the host)
+    };
+    int bar = 0;   // barriers passed (the program is straight-line code: a constant at every use)
+    if (HIPNLP_HESS_TABLES_AT == 0) fetch_tables();
     KnotInfo ki{k, N, first, last};
     Em em{s.g, s.jac, hx.H};
     Ctx<Em> cx(s, tabs.kin(), tabs.settings(), tabs.gp, ki, em, COMPACT ? &tb.head.kt : nullptr, COMPACT ? a.gp + b : nullptr);
@@ -758,11 +766,11 @@ void hipnlp_knot_hess_kernel(HArgs a) {
     const unsigned long long st_staged = __builtin_amdgcn_s_memtime();
 #define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
 #define DEV_RH(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
-#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); bid++;
+#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); bid++; if (++bar == HIPNLP_HESS_TABLES_AT) fetch_tables();
 #else
 #define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_RH(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); }
-#define DEV_BARRIER lds_barrier();
+#define DEV_BARRIER lds_barrier(); if (++bar == HIPNLP_HESS_TABLES_AT) fetch_tables();
 #endif
     auto run_wave = [&](auto wc) __attribute__((always_inline)) {
         constexpr int W = decltype(wc)::value;
@@ -905,7 +913,7 @@ struct hipnlp_handle {
     int batch = 1, kb = 0, ke = 0, nk = 0, np = 0;
     bool wide = false;   // eight-wave kernel variant (launches that are resident at once at two workgroups per CU)
     bool fused = false;  // the total cost is summed inside the knot launch by one reducer workgroup per trajectory (knots <= 256)
-    bool hess_compact = false;   // exact Hessian, planar terrain: compact-scratch instantiation (three workgroups per CU) for launches of more than 512 workgroups
+    bool hess_compact = false;   // exact Hessian: compact-scratch instantiation (three workgroups per CU) for launches of more than 512 workgroups
     int dev = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1565,12 +1573,14 @@ static int hess_launch(hipnlp_handle* h, const double* x_dev, const double* sigm
     a.stamps = h->d_stamps;
 #endif
     const dim3 hgrid(unsigned(h->nk), unsigned(h->batch));
-    if (h->d.settings.terrain != HIPNLP_TERRAIN_PLANAR)
-        hipLaunchKernelGGL((hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, LAYOUT_FULL>), hgrid, dim3(256), 0, s, a);
-    else if (h->hess_compact)   // (launches longer than the 512 workgroup slots of the full layout: three workgroups per CU)
-        hipLaunchKernelGGL((hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_PLANAR, LAYOUT_COMPACT>), hgrid, dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_PLANAR, LAYOUT_FULL>), hgrid, dim3(256), 0, s, a);
+    const bool smooth = h->d.settings.terrain != HIPNLP_TERRAIN_PLANAR;
+    if (h->hess_compact) {   // (launches longer than the 512 workgroup slots of the full layout: three workgroups per CU)
+        if (smooth) hipLaunchKernelGGL((hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, LAYOUT_COMPACT>), hgrid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_PLANAR, LAYOUT_COMPACT>), hgrid, dim3(256), 0, s, a);
+    } else {
+        if (smooth) hipLaunchKernelGGL((hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, LAYOUT_FULL>), hgrid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_PLANAR, LAYOUT_FULL>), hgrid, dim3(256), 0, s, a);
+    }
     HIP_TRY(h, hipGetLastError());
     return HIPNLP_OK;
 }

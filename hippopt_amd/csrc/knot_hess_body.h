@@ -296,19 +296,26 @@ template <int BEGIN, class Em> HD void t_kh_pp_smooth_at(KHCtx<Em>& h, int t) { 
 //                            dL/du, dL/df, dL/df_dot, dL/dv — first-order jets (G3) over a frame one order lower (Z to third order).
 // (Measured in round 1: staging the single task over (point, bump) / point / (point, block) lanes through the dead jac area ran no
 //  faster — the arithmetic of the frame was the long pole, not the assembly; what changed here is the arithmetic itself.)
-constexpr int PP_STAGE = 46;   // doubles handed from t_kh_point_smooth_pp to _pp2 per contact point
-static_assert(PP_STAGE * NC <= js::COUNT, "(p, p) staging lives in the Jacobian staging area");
-template <class S> HD double* pp_stage(S& s, int c) { return &s.jac[0] + PP_STAGE * c; }
+constexpr int PP_STAGE = 34;   // doubles handed from t_kh_point_smooth_pp to _pp2 per contact point: the normal to SECOND order (3 x 6), the height jet (10), the Hessian of L so far (6)
 // The bump jets, ONCE per (point, bump): lane (c, bump) of the first phase — the eight contact points and, as a ninth point, the com
-// (minimum com height row) — evaluates  H exp(-g^r)  to FOURTH order and parks the fifteen scaled coefficients behind the (p, p)
-// staging; the three consumers of the next phase add the parts: t_kh_point_smooth_pp to fourth order, t_kh_point_smooth_mixed to
+// (minimum com height row) — evaluates  H exp(-g^r)  to FOURTH order and parks the fifteen scaled coefficients in the staging area;
+// the three consumers of the next phase add the parts: t_kh_point_smooth_pp to fourth order, t_kh_point_smooth_mixed to
 // third (a prefix: the coefficients are stored by total degree), the com lanes of t_kh_diag to second.  (Until round 4 each of the
 // three evaluated every bump for itself, one after the other on its own lane: the powers, the exponential and the compositions of the
 // bumps were 9 - 10 k of the 17 k cycles of either point task and 5 of the 6 k of the diagonal task.)  The lanes of unused bumps store
 // zeros: the sums run over a fixed number of parts (adding a zero part changes no bit).
 constexpr int KH_BUMP_TASKS = (NC + 1) * HIPNLP_MAX_TERRAIN_STEPS, KH_BUMP_COEF = J2<4>::NC_;
-static_assert(PP_STAGE * NC + KH_BUMP_COEF * KH_BUMP_TASKS <= js::COUNT, "bump jets live behind the (p, p) staging in the Jacobian staging area");
-template <class S> HD double* kh_bump_part(S& s, int c, int sidx) { return &s.jac[0] + PP_STAGE * NC + KH_BUMP_COEF * (HIPNLP_MAX_TERRAIN_STEPS * c + sidx); }
+// Both staging areas are dead before the kinematic Hessian tasks start: they lie on the per-joint spatial vectors of the Hessian scratch
+// (S .. Wv: written by t_kh_joint in the fifth phase), so the smooth terrain needs no LDS beyond the planar program's.
+constexpr int KH_STAGE_DOUBLES = 6 * 6 * (NJ + 3);
+static_assert(offsetof(KHessScratch, Wv) + sizeof(KHessScratch::Wv) - offsetof(KHessScratch, S) == sizeof(double) * KH_STAGE_DOUBLES, "S, E, Gm, Sxl, Cv, Wv are contiguous");
+static_assert(PP_STAGE * NC + KH_BUMP_COEF * KH_BUMP_TASKS <= KH_STAGE_DOUBLES, "(p, p) staging and bump jets live on the spatial vectors of the later phases");
+HD double* pp_stage(KHessScratch& hx, int c) { return reinterpret_cast<double*>(&hx.S[0]) + PP_STAGE * c; }
+// (the six tangent-axis terms of the (p, p) block wait in the composite area of the knot scratch, which the kinematic program writes two
+//  phases later)
+static_assert(6 * 6 * NC <= NL * LSTR, "tangent-axis terms of the (p, p) blocks fit in comp[]");
+template <class S> HD double* pp_term_stage(S& s, int c, int term) { return &s.comp[0][0] + 6 * (6 * c + term); }
+HD double* kh_bump_part(KHessScratch& hx, int c, int sidx) { return reinterpret_cast<double*>(&hx.S[0]) + PP_STAGE * NC + KH_BUMP_COEF * (HIPNLP_MAX_TERRAIN_STEPS * c + sidx); }
 template <class Em> HD void t_kh_bump(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
     if (terrain_is_planar(cx)) return;
@@ -320,14 +327,14 @@ template <class Em> HD void t_kh_bump(KHCtx<Em>& h, int t) {
         terrain_bump_j<4>(cx.st.steps[sidx], p[0], p[1], bump);   // (false: the bump has vanished, its jet stays zero)
         bump.c[0] += cx.st.steps[sidx].oz;
     }
-    double* out = kh_bump_part(s, c, sidx);
+    double* out = kh_bump_part(h.hx, c, sidx);
     for (int i = 0; i < KH_BUMP_COEF; ++i) out[i] = bump.c[i];
 }
 // Z(p_x, p_y) of the terrain at point c (NC: the com) to order K from the parts t_kh_bump left (same order of the bumps as terrain_Z_jet)
-template <int K, class S> HD J2<K> kh_terrain_Z(S& s, int c) {
+template <int K> HD J2<K> kh_terrain_Z(KHessScratch& hx, int c, int n_steps) {
     J2<K> Z;
-    for (int sidx = 0; sidx < HIPNLP_MAX_TERRAIN_STEPS; ++sidx) {
-        const double* part = kh_bump_part(s, c, sidx);
+    HIPNLP_ROLLED for (int sidx = 0; sidx < n_steps; ++sidx) {
+        const double* part = kh_bump_part(hx, c, sidx);
         for (int i = 0; i < J2<K>::NC_; ++i) Z.c[i] += part[i];
     }
     return Z;
@@ -353,7 +360,7 @@ template <class Em> HD void t_kh_point_smooth_pp(KHCtx<Em>& h, int c) {
     // and the normal; t_kh_point_smooth_pp2: the terms in the tangent axes.
     T3 L;
     {
-        const J2<4> Z = kh_terrain_Z<4>(s, c);
+        const J2<4> Z = kh_terrain_Z<4>(h.hx, c, cx.st.n_steps);
         const J2<3> u1 = -j2_dx(Z), u2 = -j2_dy(Z);   // grad h = (u1, u2, 1)
         T3 hT = t3_from(-j2_trunc<4, 2>(Z));
         hT.v += p[2]; hT.g[2] = 1.0;
@@ -372,63 +379,91 @@ template <class Em> HD void t_kh_point_smooth_pp(KHCtx<Em>& h, int c) {
             L = L + (hT * (nfT * kbs + fnd + nfdT) + hdot * nfT) * (-l_d) + nfT * l_n + (nfT * nfT) * (mu2 * l_f);
         }
         L = L + t3_from(n0 * lp[0] + n1 * lp[1] + n2 * lp[2]) * (-u[2]);
-        // handed to t_kh_point_smooth_pp2 (next phase, another wave): the normal, the height jet and the Hessian of L so far — through
-        // the Jacobian staging area of the knot scratch, which the Hessian program never writes
-        double* st = pp_stage(s, c);
-        for (int i = 0; i < 10; ++i) { st[i] = n0.c[i]; st[10 + i] = n1.c[i]; st[20 + i] = n2.c[i]; }
-        st[30] = hT.v;
-        for (int i = 0; i < 3; ++i) st[31 + i] = hT.g[i];
-        for (int i = 0; i < 6; ++i) { st[34 + i] = hT.H[i]; st[40 + i] = L.H[i]; }
+        // handed to t_kh_point_smooth_pp2 (next phase, another wave): the normal to second order, the height jet and the Hessian of L so
+        // far (pp_stage)
+        double* st = pp_stage(h.hx, c);
+        for (int i = 0; i < 6; ++i) { st[i] = n0.c[i]; st[6 + i] = n1.c[i]; st[12 + i] = n2.c[i]; }
+        st[18] = hT.v;
+        for (int i = 0; i < 3; ++i) st[19 + i] = hT.g[i];
+        for (int i = 0; i < 6; ++i) { st[22 + i] = hT.H[i]; st[28 + i] = L.H[i]; }
     }
 }
 // second half of the (p, p) block: the six terms that contract the TANGENT axes x, y of the terrain frame with f, v and the planar
 // multipliers.  A task of its own so that the jets of the first half (Z to fourth order, grad h, hdot, the n . f family) and the
 // tangent-axis jets (q, iq, the contractions) are never live together: as one task the kernel spilled 34 VGPRs at the 256 cap.
-template <class Em> HD void t_kh_point_smooth_pp2(KHCtx<Em>& h, int c) {
+template <class Em> HD void t_kh_point_smooth_pp2(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
     if (terrain_is_planar(cx)) return;
     auto& s = cx.s;
-    Em& em = cx.em;
     const double* lam = h.lam;
-    const int gb = gs::PT_STRIDE * c, hb = hk::SP + hk::SP_STRIDE * c, cb = PT_ * c;
+    HIPNLP_WAVE_SYNC();   // the first half (t_kh_point_smooth_pp) ran on this wave
+    const int c = t / 6, term = t - 6 * c;     // term: x.f, y.f, x.v, y.v, x.lp, y.lp
+    const int gb = gs::PT_STRIDE * c, cb = PT_ * c;
     const double* x = s.x + cb;
-    const double* f = x + F_;
-    const double* v = x + V_;
-    const double* u = x + U_;
     const double on = cx.ki.first ? 0.0 : 1.0, msw = h.hx.sigma * on * cx.st.m_swing;
-    const double l_f = lam[gb + gs::FRICTION];
-    const double* lp = lam + gb + gs::PLANAR;
+    const double* cv = term < 2 ? x + F_ : (term < 4 ? x + V_ : lam + gb + gs::PLANAR);   // the constant vector the axis is contracted with
+    const double c0 = cv[0], c1 = cv[1], c2 = cv[2];
+    const double scale = term < 2 ? -lam[gb + gs::FRICTION] : (term < 4 ? 0.5 * msw : -x[U_ + (term - 4)]);
     const double kt = cx.gp.kt;
-    const double* st = pp_stage(s, c);
-    T3 L;
-    {
-        J2<3> n0, n1, n2;
-        T3 hT;
-        for (int i = 0; i < 10; ++i) { n0.c[i] = st[i]; n1.c[i] = st[10 + i]; n2.c[i] = st[20 + i]; }
-        hT.v = st[30];
-        for (int i = 0; i < 3; ++i) hT.g[i] = st[31 + i];
-        for (int i = 0; i < 6; ++i) hT.H[i] = st[34 + i];
+    const double* st = pp_stage(h.hx, c);
+    // every term ends in t3_from, which reads a jet up to second order: the whole task runs on second-order jets (a product of two of
+    // them is 15 multiply-adds where the third-order one of the first half takes 35)
+    J2<2> n0, n1, n2;
+    T3 hT;
+    for (int i = 0; i < 6; ++i) { n0.c[i] = st[i]; n1.c[i] = st[6 + i]; n2.c[i] = st[12 + i]; }
+    hT.v = st[18];
+    for (int i = 0; i < 3; ++i) hT.g[i] = st[19 + i];
+    for (int i = 0; i < 6; ++i) hT.H[i] = st[22 + i];
+    const J2<2> q = n1 * n1 + n2 * n2;            // same closed form as terrain_frame (knot_body.h)
+    const J2<2> iq = j2_rsqrt(q);
+    // x . c = iq (q c_0 - n_0 (n_1 c_1 + n_2 c_2)),   y . c = iq (n_2 c_1 - n_1 c_2)
+    J2<2> w;
+    if ((term & 1) == 0) w = q * c0 - n0 * (n1 * c1 + n2 * c2);
+    else w = n2 * c1 - n1 * c2;
+    const T3 axis = t3_from(iq * w);
+    T3 other = axis;                               // friction cone and swing-height cost: the square; planar rows: times tanh(kt h)
+    if (term >= 4) {
         const double tv = knot_tanh(kt * hT.v), t1 = kt * (1.0 - tv * tv), t2 = -2.0 * kt * tv * t1;
-        const T3 tau = t3_chain(hT, tv, t1, t2);
-        const J2<3> q = n1 * n1 + n2 * n2;            // same closed form as terrain_frame (knot_body.h)
-        const J2<3> iq = j2_rsqrt(q);
-        // x . c = iq (q c_0 - n_0 (n_1 c_1 + n_2 c_2)),   y . c = iq (n_2 c_1 - n_1 c_2)
-        { const T3 xfT = t3_from(iq * (q * f[0] - n0 * (n1 * f[1] + n2 * f[2]))); L = L - (xfT * xfT) * l_f; }
-        { const T3 yfT = t3_from(iq * (n2 * f[1] - n1 * f[2])); L = L - (yfT * yfT) * l_f; }
-        { const T3 xvT = t3_from(iq * (q * v[0] - n0 * (n1 * v[1] + n2 * v[2]))); L = L + (xvT * xvT) * (0.5 * msw); }
-        { const T3 yvT = t3_from(iq * (n2 * v[1] - n1 * v[2])); L = L + (yvT * yvT) * (0.5 * msw); }
-        { const T3 xlpT = t3_from(iq * (q * lp[0] - n0 * (n1 * lp[1] + n2 * lp[2]))); L = L + (xlpT * tau) * (-u[0]); }
-        { const T3 ylpT = t3_from(iq * (n2 * lp[1] - n1 * lp[2])); L = L + (ylpT * tau) * (-u[1]); }
+        other = t3_chain(hT, tv, t1, t2);
     }
-    bool ys;
-    for (int a = 0; a < 3; ++a)
-        for (int b = 0; b <= a; ++b)
-            em.H(hb + hk::SP_PP + tri(a, b), cb + P_ + a, cb + P_ + b,
-                 st[40 + t3h(a, b)] + L.H[t3h(a, b)] + pp_costs(h, c, c, a, b, ys) + (a == b ? ends_diag(h, cb + P_ + a) : 0.0));
+    const T3 L = (axis * other) * scale;
+    double* out = pp_term_stage(s, c, term);
+    for (int i = 0; i < 6; ++i) out[i] = L.H[i];
 }
-template <class Em> HD void t_kh_point_smooth_mixed(KHCtx<Em>& h, int c) {
+// the (p, p) block of point c leaves: lane (c, entry) adds the two halves' shares, the cost terms and the horizon-end diagonal
+template <class Em> HD void t_kh_point_smooth_pp_emit(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
     if (terrain_is_planar(cx)) return;
+    HIPNLP_WAVE_SYNC();   // the six terms of this wave's t_kh_point_smooth_pp2
+    const int c = t / 6, e = t - 6 * c;
+    const int a = e < 1 ? 0 : (e < 3 ? 1 : 2), b = e - a * (a + 1) / 2;   // e = tri(a, b), b <= a
+    const int hb = hk::SP + hk::SP_STRIDE * c, cb = PT_ * c;
+    const int hidx = t3h(a, b);   // xx, xy, xz, yy, yz, zz
+    double v = pp_stage(h.hx, c)[28 + hidx];
+    for (int term = 0; term < 6; ++term) v += pp_term_stage(cx.s, c, term)[hidx];
+    bool ys;
+    v += pp_costs(h, c, c, a, b, ys);
+    if (a == b) v += ends_diag(h, cb + P_ + a);
+    cx.em.H(hb + hk::SP_PP + e, cb + P_ + a, cb + P_ + b, v);
+}
+// Lane (c, r), 6 x NC lanes: every lane builds the frame of its point (first-order jets: the common prefix, 3.2 k cycles) and emits ONE
+// slice of the blocks — r < 3: row j = r of the (u, p), (f, p), (f, f), (p, f_dot) blocks; r >= 3: column i = r - 3 of the (p, v), (f, v),
+// (v, v) blocks.  (As one lane per point the three rows and the three columns followed one another: 3.2 k more cycles on the longest
+// chain of the phase.)
+// (selects of NUMBERS passed by value: `c ? a.v : b.v` on two lvalues selects between their addresses and loads once, which sends the
+//  whole frame to scratch memory)
+HD double sel_d(bool c, double a, double b) { return c ? a : b; }
+HD G3 g3_pick2(const G3& a, const G3& b, bool first) {
+    G3 r;
+    r.v = sel_d(first, a.v, b.v);
+    for (int k = 0; k < 3; ++k) r.g[k] = sel_d(first, a.g[k], b.g[k]);
+    return r;
+}
+HD G3 g3_pick(const G3* a, int j) { return g3_pick2(a[0], g3_pick2(a[1], a[2], j == 1), j == 0); }
+template <class Em> HD void t_kh_point_smooth_mixed(KHCtx<Em>& h, int t) {
+    Ctx<Em>& cx = h.cx;
+    if (terrain_is_planar(cx)) return;
+    const int c = t / 6, r = t - 6 * c;
     auto& s = cx.s;
     Em& em = cx.em;
     const double* lam = h.lam;
@@ -437,22 +472,19 @@ template <class Em> HD void t_kh_point_smooth_mixed(KHCtx<Em>& h, int c) {
     const double* p = x + P_;
     const double* f = x + F_;
     const double* v = x + V_;
-    const double on = cx.ki.first ? 0.0 : 1.0, msw = h.hx.sigma * on * cx.st.m_swing;
-    const double l_d = lam[gb + gs::DCC], l_n = lam[gb + gs::NORMAL], l_f = lam[gb + gs::FRICTION];
     const double* lp = lam + gb + gs::PLANAR;
-    const double kbs = cx.gp.kbs, kt = cx.gp.kt, mu2 = cx.gp.mu * cx.gp.mu;
-    G3 hG, gh[3], n[3], xv[3], yv[3], dn[3][2];
+    G3 hG, gh[3], n[3], xv[3], yv[3], dn0[3], dn1[3];   // dn0[j] = d n_j / d p_x, dn1[j] = d n_j / d p_y
     {
-        const J2<3> Z = kh_terrain_Z<3>(s, c);
+        const J2<3> Z = kh_terrain_Z<3>(h.hx, c, cx.st.n_steps);
         const J2<2> u1 = -j2_dx(Z), u2 = -j2_dy(Z);
         hG.v = p[2] - Z.c[0]; hG.g[0] = u1.c[0]; hG.g[1] = u2.c[0]; hG.g[2] = 1.0;
         gh[0] = g3_from(u1); gh[1] = g3_from(u2); gh[2] = G3(1.0);
         const J2<2> n2 = j2_rsqrt(J2<2>(1.0) + u1 * u1 + u2 * u2);
         const J2<2> n0 = u1 * n2, n1 = u2 * n2;
         n[0] = g3_from(n0); n[1] = g3_from(n1); n[2] = g3_from(n2);
-        dn[0][0] = g3_from(j2_dx(n0)); dn[0][1] = g3_from(j2_dy(n0));
-        dn[1][0] = g3_from(j2_dx(n1)); dn[1][1] = g3_from(j2_dy(n1));
-        dn[2][0] = g3_from(j2_dx(n2)); dn[2][1] = g3_from(j2_dy(n2));
+        dn0[0] = g3_from(j2_dx(n0)); dn1[0] = g3_from(j2_dy(n0));
+        dn0[1] = g3_from(j2_dx(n1)); dn1[1] = g3_from(j2_dy(n1));
+        dn0[2] = g3_from(j2_dx(n2)); dn1[2] = g3_from(j2_dy(n2));
         // the tangent axes are needed to first order only
         const J2<1> m0 = j2_trunc<2, 1>(n0), m1 = j2_trunc<2, 1>(n1), m2 = j2_trunc<2, 1>(n2);
         const J2<1> q = m1 * m1 + m2 * m2;
@@ -460,6 +492,10 @@ template <class Em> HD void t_kh_point_smooth_mixed(KHCtx<Em>& h, int c) {
         xv[0] = g3_from(q * iq); xv[1] = g3_from(-(m1 * m0) * iq); xv[2] = g3_from(-(m2 * m0) * iq);
         yv[0] = G3(0.0); yv[1] = g3_from(m2 * iq); yv[2] = g3_from(-(m1 * iq));
     }
+    // (multipliers and gains are read behind the jets: the frame is what fills the registers)
+    const double on = cx.ki.first ? 0.0 : 1.0, msw = h.hx.sigma * on * cx.st.m_swing;
+    const double l_d = lam[gb + gs::DCC], l_n = lam[gb + gs::NORMAL], l_f = lam[gb + gs::FRICTION];
+    const double kbs = cx.gp.kbs, kt = cx.gp.kt, mu2 = cx.gp.mu * cx.gp.mu;
     const double tv = knot_tanh(kt * hG.v), t1 = kt * (1.0 - tv * tv);
     G3 tau;
     tau.v = tv;
@@ -471,30 +507,37 @@ template <class Em> HD void t_kh_point_smooth_mixed(KHCtx<Em>& h, int c) {
     double nu[3];
     hdyn_multiplier(h, nu);
     const double dff = freg_diag(h, c);
-    for (int j = 0; j < 3; ++j) {
-        // coefficient of u_j in L: C_u,j
-        const G3 Cu = j == 0 ? (xv[0] * lp[0] + xv[1] * lp[1] + xv[2] * lp[2]) * tau * -1.0
-                    : (j == 1 ? (yv[1] * lp[1] + yv[2] * lp[2]) * tau * -1.0 : (n[0] * lp[0] + n[1] * lp[1] + n[2] * lp[2]) * -1.0);
-        for (int i = 0; i < 3; ++i) em.H(hb + hk::SP_UP + 3 * j + i, cb + U_ + j, cb + P_ + i, Cu.g[i]);
-        const G3 nd = dn[j][0] * v[0] + dn[j][1] * v[1];   // ndot_j = sum_i dn_j/dp_i v_i
-        const G3 dLdf = (hG * n[j] * kbs + hdot * n[j] + hG * nd) * (-l_d) + n[j] * l_n + (nf * n[j] * mu2 - xf * xv[j] - yf * yv[j]) * (2.0 * l_f);
-        for (int i = 0; i < 3; ++i) em.H(hb + hk::SP_FP + 3 * j + i, cb + F_ + j, cb + P_ + i, dLdf.g[i] + skew_rc(nu, j, i));
-        for (int i = 0; i <= j; ++i)
-            em.H(hb + hk::SP_FF + tri(j, i), cb + F_ + j, cb + F_ + i,
-                 2.0 * l_f * (mu2 * n[j].v * n[i].v - xv[j].v * xv[i].v - yv[j].v * yv[i].v) + (i == j ? dff + ends_diag(h, cb + F_ + j) : 0.0));
-        const G3 dLdfd = hG * n[j] * (-l_d);
-        for (int i = 0; i < 3; ++i) em.H(hb + hk::SP_PFD + 3 * i + j, cb + P_ + i, cb + FD_ + j, dLdfd.g[i]);
-    }
-    for (int i = 0; i < 3; ++i) {
+    if (r < 3) {
+        const int j = r;
+        const G3 nj = g3_pick(n, j), xvj = g3_pick(xv, j), yvj = g3_pick(yv, j);
+        // coefficient of u_j in L: C_u,j = -(x . l_pl) tau, -(y . l_pl) tau, -(n . l_pl)
+        G3 ax[3];
+        HIPNLP_UNROLL for (int k = 0; k < 3; ++k) ax[k] = g3_pick2(xv[k], g3_pick2(yv[k], n[k], j == 1), j == 0);
+        const G3 al = ax[0] * lp[0] + ax[1] * lp[1] + ax[2] * lp[2];
+        const G3 Cu = g3_pick2(al * tau, al, j < 2) * -1.0;
+        HIPNLP_UNROLL for (int i = 0; i < 3; ++i) em.H(hb + hk::SP_UP + 3 * j + i, cb + U_ + j, cb + P_ + i, Cu.g[i]);
+        const G3 nd = g3_pick(dn0, j) * v[0] + g3_pick(dn1, j) * v[1];   // ndot_j = sum_i dn_j/dp_i v_i
+        const G3 dLdf = (hG * nj * kbs + hdot * nj + hG * nd) * (-l_d) + nj * l_n + (nf * nj * mu2 - xf * xvj - yf * yvj) * (2.0 * l_f);
+        HIPNLP_UNROLL for (int i = 0; i < 3; ++i) em.H(hb + hk::SP_FP + 3 * j + i, cb + F_ + j, cb + P_ + i, dLdf.g[i] + skew_rc(nu, j, i));
+        HIPNLP_UNROLL for (int i = 0; i < 3; ++i)
+            if (i <= j)
+                em.H(hb + hk::SP_FF + tri(j, i), cb + F_ + j, cb + F_ + i,
+                     2.0 * l_f * (mu2 * nj.v * n[i].v - xvj.v * xv[i].v - yvj.v * yv[i].v) + (i == j ? dff + ends_diag(h, cb + F_ + j) : 0.0));
+        const G3 dLdfd = hG * nj * (-l_d);
+        HIPNLP_UNROLL for (int i = 0; i < 3; ++i) em.H(hb + hk::SP_PFD + 3 * i + j, cb + P_ + i, cb + FD_ + j, dLdfd.g[i]);
+    } else {
+        const int i = r - 3;
         // dL/dv_i = l_d (-gh_i nf - h sum_j dn_j/dp_i f_j) + m_sw ((x.v) x_i + (y.v) y_i)
         G3 dnf = G3(0.0);
-        if (i < 2) dnf = dn[0][i] * f[0] + dn[1][i] * f[1] + dn[2][i] * f[2];
-        const G3 dLdv = (gh[i] * nf + hG * dnf) * (-l_d) + (xvv * xv[i] + yvv * yv[i]) * msw;
-        for (int j = 0; j < 3; ++j) em.H(hb + hk::SP_PV + 3 * j + i, cb + P_ + j, cb + V_ + i, dLdv.g[j]);
-        for (int j = 0; j < 3; ++j)
-            em.H(hb + hk::SP_FV + 3 * j + i, cb + F_ + j, cb + V_ + i, -l_d * (gh[i].v * n[j].v + hG.v * (i < 2 ? dn[j][i].v : 0.0)));
-        for (int j = 0; j <= i; ++j)
-            em.H(hb + hk::SP_VV + tri(i, j), cb + V_ + i, cb + V_ + j, msw * (xv[i].v * xv[j].v + yv[i].v * yv[j].v) + (i == j ? ends_diag(h, cb + V_ + i) : 0.0));
+        if (i < 2) dnf = g3_pick2(dn0[0], dn1[0], i == 0) * f[0] + g3_pick2(dn0[1], dn1[1], i == 0) * f[1] + g3_pick2(dn0[2], dn1[2], i == 0) * f[2];
+        const G3 ghi = g3_pick(gh, i), xvi = g3_pick(xv, i), yvi = g3_pick(yv, i);
+        const G3 dLdv = (ghi * nf + hG * dnf) * (-l_d) + (xvv * xvi + yvv * yvi) * msw;
+        HIPNLP_UNROLL for (int j = 0; j < 3; ++j) em.H(hb + hk::SP_PV + 3 * j + i, cb + P_ + j, cb + V_ + i, dLdv.g[j]);
+        HIPNLP_UNROLL for (int j = 0; j < 3; ++j)
+            em.H(hb + hk::SP_FV + 3 * j + i, cb + F_ + j, cb + V_ + i, -l_d * (ghi.v * n[j].v + hG.v * (i < 2 ? sel_d(i == 0, dn0[j].v, dn1[j].v) : 0.0)));
+        HIPNLP_UNROLL for (int j = 0; j < 3; ++j)
+            if (j <= i)
+                em.H(hb + hk::SP_VV + tri(i, j), cb + V_ + i, cb + V_ + j, msw * (xvi.v * xv[j].v + yvi.v * yv[j].v) + (i == j ? ends_diag(h, cb + V_ + i) : 0.0));
     }
 }
 
@@ -509,7 +552,7 @@ template <class Em> HD void t_kh_diag(KHCtx<Em>& h, int t) {
     else if (t < 9) {
         var = COM_ + (t - 6);
         if (!terrain_is_planar(cx) && t < 8) {   // minimum com height  com_z - Z(com_x, com_y)  (planner.py:353-358)
-            const J2<2> Z = kh_terrain_Z<2>(cx.s, NC);   // (scaled coefficients: Z_xx = 2 c_20, Z_xy = c_11, Z_yy = 2 c_02)
+            const J2<2> Z = kh_terrain_Z<2>(h.hx, NC, cx.st.n_steps);   // (scaled coefficients: Z_xx = 2 c_20, Z_xy = c_11, Z_yy = 2 c_02)
             v = -h.lam[gs::COMH] * 2.0 * (t == 6 ? Z.c[J2<2>::idx(2, 0)] : Z.c[J2<2>::idx(0, 2)]);
             if (t == 7) cx.em.H(hk::COMXY, COM_ + 1, COM_, -h.lam[gs::COMH] * Z.c[J2<2>::idx(1, 1)]);
         }
@@ -973,16 +1016,17 @@ template <class Em> HD void t_kh_ssd_far_c(KHCtx<Em>& h, int t) { t_kh_ssd_far(h
 #define HIPNLP_KNOT_HESS_PHASE1A(KIN, RH, BARRIER)                                                               \
     KIN(0, t_joints, NJ) RH(0, t_kh_ff, 36) KIN(1, t_base, 3) KIN(1, t_kin_padding, 16)                          \
     RH(1, t_kh_diag_planar, 42) RH(1, t_kh_percouple, 84) RH(2, t_kh_point, NC) RH(3, t_kh_pp_planar_at<128>, 52) \
-    RH(3, t_kh_bump, KH_BUMP_TASKS)                                                                              \
+    RH(3, t_kh_bump, KH_BUMP_TASKS) RH(1, t_kh_pp_smooth_at<0>, 90) RH(2, t_kh_pp_smooth_at<90>, 90)             \
     BARRIER
 #define HIPNLP_KNOT_HESS_PHASE1B(KIN, RH, BARRIER)                                                               \
     KIN(0, t_fk_rot_a, FK_TASKS_A) KIN(0, t_link_u_a, FK_SPLIT) KIN(3, t_fk_rot_b, FK_TASKS_B) KIN(3, t_link_u_b, NJ - FK_SPLIT) \
-    RH(2, t_kh_point_smooth_pp, NC) RH(1, t_kh_point_smooth_mixed, NC)                                           \
+    RH(2, t_kh_point_smooth_pp, NC) RH(2, t_kh_point_smooth_pp2, 6 * NC) RH(2, t_kh_point_smooth_pp_emit, 6 * NC) \
+    RH(1, t_kh_point_smooth_mixed, 6 * NC)                                                                       \
     RH(1, t_kh_pp_planar_at<0>, 64) RH(2, t_kh_pp_planar_at<64>, 64)                                             \
-    RH(0, t_kh_pp_smooth_at<0>, 90) RH(3, t_kh_pp_smooth_at<90>, 90) RH(0, t_kh_diag_smooth, 42)                 \
+    RH(0, t_kh_diag_smooth, 42)                                                                                  \
     BARRIER
 #define HIPNLP_KNOT_HESS_PHASE1C(KIN, RH, BARRIER)                                                               \
-    KIN(0, t_links, NL) KIN(1, t_frames, 3) KIN(2, t_link_inertia, NL) RH(3, t_kh_point_smooth_pp2, NC)          \
+    KIN(0, t_links, NL) KIN(1, t_frames, 3) KIN(2, t_link_inertia, NL)                                           \
     BARRIER
 #define HIPNLP_KNOT_HESS_PHASE1D(KIN, RH, BARRIER)                                                               \
     KIN(0, t_composite_g0, 64) KIN(1, t_composite_g1, 64) KIN(1, t_composite_g2, 64)                             \

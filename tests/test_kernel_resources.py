@@ -31,7 +31,7 @@ def res():
 
 def test_every_kernel_is_there_and_none_needs_scratch(res):
     expect = {"hipnlp_knot_kernel<0,4>", "hipnlp_knot_kernel<1,4>", "hipnlp_knot_kernel<0,8>", "hipnlp_knot_kernel<1,8>", "hipnlp_knot_hess_kernel<0,0>", "hipnlp_knot_hess_kernel<0,1>",
-              "hipnlp_knot_hess_kernel<1,0>", "hipnlp_pose_kernel<0>", "hipnlp_pose_kernel<1>", "hipnlp_pose_hess_kernel<0>", "hipnlp_pose_hess_kernel<1>",
+              "hipnlp_knot_hess_kernel<1,0>", "hipnlp_knot_hess_kernel<1,1>", "hipnlp_pose_kernel<0>", "hipnlp_pose_kernel<1>", "hipnlp_pose_hess_kernel<0>", "hipnlp_pose_hess_kernel<1>",
               "hipnlp_reduce_kernel", "hipnlp_reassemble_kernel", "hipnlp_peer_push_kernel", "hipnlp_peer_signal_kernel", "hipnlp_peer_wait_kernel"}
     assert expect <= set(res), sorted(expect - set(res))
     for name, r in res.items():
@@ -58,12 +58,13 @@ def test_eight_wave_callback_kernel_fits_two_workgroups_per_cu(res, terrain, pee
 
 
 def test_hessian_and_pose_kernels(res):
-    # exact Hessian of the kinodynamic NLP: full layout two workgroups per CU (both terrains), planar compact layout three
+    # exact Hessian of the kinodynamic NLP: full layout two workgroups per CU, compact layout three (both terrains; the smooth terrain's
+    # compact kernel is allowed a few spilled registers at the 168 cap: 12 B per lane in round 4, it had 228 B before its point tasks were split)
     for t in (0, 1):
         h = res["hipnlp_knot_hess_kernel<%d,0>" % t]
-        assert 2 * h["lds"] <= LDS_PER_CU and _granule(h["vgpr"] + h["agpr"]) * 2 <= VGPR_FILE, h
-    hc = res["hipnlp_knot_hess_kernel<0,1>"]
-    assert 3 * hc["lds"] <= LDS_PER_CU and _granule(hc["vgpr"] + hc["agpr"]) * 3 <= VGPR_FILE, hc
+        assert 2 * h["lds"] <= LDS_PER_CU and _granule(h["vgpr"] + h["agpr"]) * 2 <= VGPR_FILE and h["scratch"] == 0, h
+        hc = res["hipnlp_knot_hess_kernel<%d,1>" % t]
+        assert 3 * hc["lds"] <= LDS_PER_CU and _granule(hc["vgpr"] + hc["agpr"]) * 3 <= VGPR_FILE and hc["scratch"] <= (0 if t == 0 else 32), hc
     for t in (0, 1):
         p = res["hipnlp_pose_kernel<%d>" % t]
         assert 3 * p["lds"] <= LDS_PER_CU and _granule(p["vgpr"] + p["agpr"]) * 3 <= VGPR_FILE, p   # three per CU (DESIGN, pose kernels)

@@ -11,7 +11,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-SO = os.path.join(ROOT, "tools", "diag", "_build", "libhipnlp_stamps.so")
+SO = os.environ.get("STAMPS_SO") or os.path.join(ROOT, "tools", "diag", "_build", "libhipnlp_stamps.so")
 
 
 def program_tasks():
