@@ -434,7 +434,6 @@ template <class Em> HD void t_kh_point_smooth_pp2(KHCtx<Em>& h, int t) {
 template <class Em> HD void t_kh_point_smooth_pp_emit(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
     if (terrain_is_planar(cx)) return;
-    HIPNLP_WAVE_SYNC();   // the six terms of this wave's t_kh_point_smooth_pp2
     const int c = t / 6, e = t - 6 * c;
     const int a = e < 1 ? 0 : (e < 3 ? 1 : 2), b = e - a * (a + 1) / 2;   // e = tri(a, b), b <= a
     const int hb = hk::SP + hk::SP_STRIDE * c, cb = PT_ * c;
@@ -1016,17 +1015,17 @@ template <class Em> HD void t_kh_ssd_far_c(KHCtx<Em>& h, int t) { t_kh_ssd_far(h
 #define HIPNLP_KNOT_HESS_PHASE1A(KIN, RH, BARRIER)                                                               \
     KIN(0, t_joints, NJ) RH(0, t_kh_ff, 36) KIN(1, t_base, 3) KIN(1, t_kin_padding, 16)                          \
     RH(1, t_kh_diag_planar, 42) RH(1, t_kh_percouple, 84) RH(2, t_kh_point, NC) RH(3, t_kh_pp_planar_at<128>, 52) \
-    RH(3, t_kh_bump, KH_BUMP_TASKS) RH(1, t_kh_pp_smooth_at<0>, 90) RH(2, t_kh_pp_smooth_at<90>, 90)             \
+    RH(3, t_kh_bump, KH_BUMP_TASKS) RH(0, t_kh_pp_smooth_at<0>, 64) RH(1, t_kh_pp_smooth_at<64>, 64) RH(2, t_kh_pp_smooth_at<128>, 52) \
     BARRIER
 #define HIPNLP_KNOT_HESS_PHASE1B(KIN, RH, BARRIER)                                                               \
     KIN(0, t_fk_rot_a, FK_TASKS_A) KIN(0, t_link_u_a, FK_SPLIT) KIN(3, t_fk_rot_b, FK_TASKS_B) KIN(3, t_link_u_b, NJ - FK_SPLIT) \
-    RH(2, t_kh_point_smooth_pp, NC) RH(2, t_kh_point_smooth_pp2, 6 * NC) RH(2, t_kh_point_smooth_pp_emit, 6 * NC) \
+    RH(2, t_kh_point_smooth_pp, NC) RH(2, t_kh_point_smooth_pp2, 6 * NC)                                         \
     RH(1, t_kh_point_smooth_mixed, 6 * NC)                                                                       \
     RH(1, t_kh_pp_planar_at<0>, 64) RH(2, t_kh_pp_planar_at<64>, 64)                                             \
     RH(0, t_kh_diag_smooth, 42)                                                                                  \
     BARRIER
 #define HIPNLP_KNOT_HESS_PHASE1C(KIN, RH, BARRIER)                                                               \
-    KIN(0, t_links, NL) KIN(1, t_frames, 3) KIN(2, t_link_inertia, NL)                                           \
+    KIN(0, t_links, NL) KIN(1, t_frames, 3) KIN(2, t_link_inertia, NL) RH(3, t_kh_point_smooth_pp_emit, 6 * NC)  \
     BARRIER
 #define HIPNLP_KNOT_HESS_PHASE1D(KIN, RH, BARRIER)                                                               \
     KIN(0, t_composite_g0, 64) KIN(1, t_composite_g1, 64) KIN(1, t_composite_g2, 64)                             \
