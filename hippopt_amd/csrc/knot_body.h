@@ -349,7 +349,15 @@ HD D2 operator/(const D2& a, const D2& b) { const double q = a.v / b.v, i = 1.0 
 HD D2 d2sqrt(const D2& a) { const double r = sqrt(a.v), i = 0.5 / r; return D2(r, a.x * i, a.y * i); }
 HD D2 d2tanh(const D2& a) { const double t = knot_tanh(a.v), d = 1.0 - t * t; return D2(t, a.x * d, a.y * d); }
 
-HD double ipow_d(double x, int n) { double r = 1.0, b = x; while (n > 0) { if (n & 1) r *= b; n >>= 1; if (n) b *= b; } return r; }
+// x^n by squaring.  The first five bits without a branch (the terrain exponents: n < 32 for a sharpness up to 16; the lanes of a bump
+// task hold different bumps, so a loop over the bits of n is a divergent one), a loop for anything beyond; the products that reach
+// the result are the same, in the same order, either way.
+HD double ipow_d(double x, int n) {
+    double r = 1.0, b = x;
+    for (int i = 0; i < 5; ++i) { r = (n & 1) ? r * b : r; b = b * b; n >>= 1; }
+    while (n > 0) { if (n & 1) r *= b; n >>= 1; if (n) b *= b; }
+    return r;
+}
 
 // contribution of ONE bump to the jet (out is accumulated into)
 HD void terrain_bump_jet(const TerrainStepK& t, double px, double py, int order, double* out) {

@@ -72,19 +72,11 @@ template <int K> HD J2<K> j2_compose(const J2<K>& a, const double* gn) {
 // (a0 + ax X + ay Y)^m for an integer m > K, in closed form (multinomial theorem): the coefficient of X^i Y^j is
 // m (m-1) ... (m-i-j+1) / (i! j!)  a0^(m-i-j) ax^i ay^j.  No polynomial products and no temporaries: the two footprint powers of every
 // bump were half of the truncated products of the terrain jet and most of its register pressure.
-// x^n for the terrain exponents: five squarings without a branch (n < 32: sharpness up to 16), the loop of ipow_d for anything beyond.
-// The same products in the same order as ipow_d.
-HD double j2_ipow_d(double x, int n) {
-    double r = 1.0, b = x;
-    for (int i = 0; i < 5; ++i) { r = (n & 1) ? r * b : r; b = b * b; n >>= 1; }
-    while (n > 0) { if (n & 1) r *= b; n >>= 1; if (n) b *= b; }
-    return r;
-}
 HD constexpr double j2_inv_fact(int n) { return n <= 1 ? 1.0 : (n == 2 ? 0.5 : (n == 3 ? 1.0 / 6.0 : (n == 4 ? 1.0 / 24.0 : 1.0 / 120.0))); }   // n <= 5
 template <int K> HD J2<K> j2_linpow(double a0, double ax, double ay, int m) {
     J2<K> r;
     double p[K + 1];              // a0^(m-d), d = 0..K
-    p[K] = j2_ipow_d(a0, m - K);
+    p[K] = ipow_d(a0, m - K);
     for (int d = K - 1; d >= 0; --d) p[d] = p[d + 1] * a0;
     double xi[K + 1], yj[K + 1];  // ax^i / i!, ay^j / j!  (reciprocal factorials as constants: no division in the task)
     xi[0] = yj[0] = 1.0;
@@ -126,7 +118,7 @@ template <int K> HD bool terrain_bump_j(const TerrainStepK& t, double px, double
     const double dx = px - t.ox, dy = py - t.oy;
     const J2<K> g = j2_linpow<K>(t.ax * dx + t.ay * dy, t.ax, t.ay, t.m) + j2_linpow<K>(t.bx * dx + t.by * dy, t.bx, t.by, t.m);
     double sn[K + 1], en[K + 1];
-    sn[K] = j2_ipow_d(g.c[0], t.r - K);                                 // g_0^(r-n) ...
+    sn[K] = ipow_d(g.c[0], t.r - K);                                 // g_0^(r-n) ...
     for (int n = K - 1; n >= 0; --n) sn[n] = sn[n + 1] * g.c[0];
     double ff = 1.0;                                                 // ... times C(r, n) = r (r-1) ... (r-n+1) / n!
     for (int n = 0; n <= K; ++n) { sn[n] *= ff * j2_inv_fact(n); ff *= double(t.r - n); }
