@@ -608,7 +608,8 @@ def c_harness_iterate(st, model, x, p, attach=1):
         raise RuntimeError(out.stderr.strip())
     t = json.loads(out.stdout.strip().splitlines()[-1])
     return {"ms_per_call": 1e-3 * t["ipopt_iterate_four_c_calls_us"], "trial_point_two_c_calls_ms": 1e-3 * t["trial_point_two_c_calls_us"],
-            "arrays_registered_by_the_handle": t["auto_registered"], "constant_entries": t["constant_entries"], "constant_fills": t["constant_fills"]}
+            "arrays_registered_by_the_handle": t["auto_registered"], "constant_entries": t["constant_entries"], "constant_fills": t["constant_fills"],
+            "us_per_callback [eval_f, eval_g, eval_grad_f, eval_jac_g]": t.get("per_call_us")}
 
 
 def main():

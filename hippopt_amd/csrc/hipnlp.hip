@@ -913,6 +913,7 @@ struct hipnlp_handle {
     int batch = 1, kb = 0, ke = 0, nk = 0, np = 0;
     bool wide = false;   // eight-wave kernel variant (launches that are resident at once at two workgroups per CU)
     bool fused = false;  // the total cost is summed inside the knot launch by one reducer workgroup per trajectory (knots <= 256)
+    hipnlp_dims dims{};         // hipnlp_get_dims, filled by hipnlp_create
     bool hess_compact = false;   // exact Hessian: compact-scratch instantiation (three workgroups per CU) for launches of more than 512 workgroups
     int dev = 0;
     hipStream_t stream = nullptr;
@@ -1048,6 +1049,7 @@ int hipnlp_abi_version(void) { return HIPNLP_ABI_VERSION; }
 #endif
 const char* hipnlp_build_info(void) { return "gfx950; " HIPNLP_BUILD_VARIANT; }
 
+static void dims_fill(const hipnlp_handle* h, hipnlp_dims* o);
 int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     if (!desc || !out) { g_create_error = "null argument"; return HIPNLP_E_INVALID; }
     *out = nullptr;
@@ -1218,6 +1220,7 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
         }
     }
 #undef CREATE_TRY
+    dims_fill(h, &h->dims);
     *out = h;
     return HIPNLP_OK;
 }
@@ -1230,8 +1233,15 @@ void hipnlp_destroy(hipnlp_handle* h) {
     free_all(h);
 }
 
+// (computed once per handle: IPOPT's callbacks check their sizes against it at every call, and the row count below is a pass over
+//  every native slot of every knot — 3 us at 100 knots, four times per iterate until round 4)
+static void dims_fill(const hipnlp_handle* h, hipnlp_dims* o);
 int hipnlp_get_dims(const hipnlp_handle* h, hipnlp_dims* o) {
     if (!h || !o) return HIPNLP_E_INVALID;
+    *o = h->dims;
+    return HIPNLP_OK;
+}
+static void dims_fill(const hipnlp_handle* h, hipnlp_dims* o) {
     const Layout& L = h->L;
     o->n = L.n; o->m = L.m; o->nnz = L.nnz; o->np = h->np;
     o->nnz_knot = L.N >= 3 ? L.nnz_v[VAR_INTERIOR] : 0;
@@ -1250,7 +1260,6 @@ int hipnlp_get_dims(const hipnlp_handle* h, hipnlp_dims* o) {
     o->shard_g_rows = rows;
     o->m_full = L.m_full;
     o->n_lifted = L.n_lifted;
-    return HIPNLP_OK;
 }
 
 // ---- the constant entries of jac g ---------------------------------------------------------------------------------------------------

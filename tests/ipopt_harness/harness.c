@@ -164,17 +164,27 @@ int main(int argc, char** argv) {
     }
 
     if (timing > 0) {   /* an IPOPT iterate as four C calls on IPOPT's own arrays, new x every iterate */
-        double best = 1e30;
+        double best = 1e30, per_call[4] = {0.0, 0.0, 0.0, 0.0};   /* per_call: eval_f, eval_g, eval_grad_f, eval_jac_g of the best pass */
         for (int pass = 0; pass < 3; ++pass) {
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
             const double t0 = now_us();
             for (int it = 0; it < timing; ++it) {
                 double* x = xs + (size_t)(it % (points - 1)) * (size_t)n;   /* (the last point is the NaN one) */
                 double f;
-                if (!eval_f(n, x, TRUE, &f, ud) || !eval_g(n, x, FALSE, m, g, ud) || !eval_grad_f(n, x, FALSE, grad[0], ud) ||
-                    !eval_jac_g(n, x, FALSE, m, nele_jac, NULL, NULL, jac, ud)) { fprintf(stderr, "timing loop: a callback failed\n"); return 1; }
+                const double a0 = now_us();
+                Bool ok = eval_f(n, x, TRUE, &f, ud);
+                const double a1 = now_us();
+                ok = ok && eval_g(n, x, FALSE, m, g, ud);
+                const double a2 = now_us();
+                ok = ok && eval_grad_f(n, x, FALSE, grad[0], ud);
+                const double a3 = now_us();
+                ok = ok && eval_jac_g(n, x, FALSE, m, nele_jac, NULL, NULL, jac, ud);
+                const double a4 = now_us();
+                if (!ok) { fprintf(stderr, "timing loop: a callback failed\n"); return 1; }
+                acc[0] += a1 - a0; acc[1] += a2 - a1; acc[2] += a3 - a2; acc[3] += a4 - a3;
             }
             const double us = (now_us() - t0) / timing;
-            if (us < best) best = us;
+            if (us < best) { best = us; for (int c = 0; c < 4; ++c) per_call[c] = acc[c] / timing; }
         }
         double trial = 1e30;
         for (int pass = 0; pass < 3; ++pass) {
@@ -190,8 +200,9 @@ int main(int argc, char** argv) {
         long stats[8];
         hipnlp_host_stats(h, stats);
         printf("{\"ipopt_iterate_four_c_calls_us\": %.2f, \"trial_point_two_c_calls_us\": %.2f, \"attach\": %d, "
-               "\"auto_registered\": %ld, \"evaluations\": %ld, \"constant_fills\": %ld, \"constant_refills\": %ld, \"constant_entries\": %ld}\n",
-               best, trial, attach, stats[0], stats[3], stats[4], stats[5], stats[6]);
+               "\"auto_registered\": %ld, \"evaluations\": %ld, \"constant_fills\": %ld, \"constant_refills\": %ld, \"constant_entries\": %ld, "
+               "\"per_call_us\": [%.2f, %.2f, %.2f, %.2f]}\n",
+               best, trial, attach, stats[0], stats[3], stats[4], stats[5], stats[6], per_call[0], per_call[1], per_call[2], per_call[3]);
     }
     if (attach) hipnlp_ipopt_detach(h);
     fclose(out);
