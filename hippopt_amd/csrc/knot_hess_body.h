@@ -81,16 +81,15 @@ constexpr int COUNT = COMXY + 1;
 
 struct SV6 { double a[3], l[3]; };   // spatial vector [angular; linear]
 
-struct KHessScratch {
+struct alignas(16) KHessScratch {   // (16-byte alignment: the spatial vectors and the padded triples below are read as 128-bit words)
     double lam_next[3];      // multipliers of the angular momentum-dynamics rows of the NEXT interval (owned by knot k + 1)
     double sigma;
-    double Y[NJ][3], Yc[NJ][3];   // Y_j (t_kh_Y: com and contact points; t_kh_Y_chest: chest cost, zero off the chest path) — consumers add the two
+    double Y[NJ][4], Yc[NJ][4];   // Y_j (t_kh_Y: com and contact points; t_kh_Y_chest: chest cost, zero off the chest path) — consumers add the two
     // centroidal momentum: per joint j (0..NJ-1) and per base rotation axis e (NJ + e)
     SV6 S[NJ + 3], E[NJ + 3], Gm[NJ + 3], Sxl[NJ + 3], Cv[NJ + 3], Wv[NJ + 3];
-    double dcmu[NJ + 3][3];  // (d com / d (s_j | theta_e)) x mu   (the com enters through l = [mu; com x mu] only)
+    double dcmu[NJ + 3][4];  // (d com / d (s_j | theta_e)) x mu   (the com enters through l = [mu; com x mu] only)
     double mu[3], muP[3], K[3], LG[3], IG[9], ell_l[3], com[3];
     uint32_t rel[NJ + 1];    // bit i set: joint i lies on the path root -> j (inclusive)
-    double TS[3][NJ], TSD[3][NJ], WS[3][NJ];   // centroidal momentum: (theta_m, s_j), (theta_m, sdot_j), (omega_m, s_j)
     double qqB[16], qqg[4], qq_axE[3], qq_m2;   // (q_b, q_b): Hessian B and gradient g of Phi(qhat) = <M, R(qhat)>, chest-error axis
     double TW[3][3];         // (theta_m, omega_m') of the centroidal momentum term (t_kh_tw -> t_kh_qqd)
     double qqMw[9];          // Mw of the (q_b, q_b) block (t_kh_qq0_mw -> t_kh_qq0)
@@ -708,26 +707,6 @@ template <class Em> HD void t_kh_Y_chest(KHCtx<Em>& h, int j) {
     for (int r = 0; r < 3; ++r) h.hx.Yc[j][r] = Y[r];
 }
 
-// momentum entries of the theta-level blocks for base axis m (0..2) and joint j
-template <class Em> HD double mom_theta_s(const KHCtx<Em>& h, int m, int j) {   // (theta_m, s_j) without the d2com term (in Y)
-    const KHessScratch& hx = h.hx;
-    const int b = NJ + m;
-    double v = -dot6(hx.Sxl[b], hx.E[j]) + dot6(hx.Wv[b], hx.Cv[j]);
-    v += dot3(hx.dcmu[b], hx.E[j].l);
-    v += dot3(hx.dcmu[j], hx.E[b].l);
-    return v;
-}
-template <class Em> HD double mom_theta_sd(const KHCtx<Em>& h, int m, int j) {   // (theta_m, sdot_j)
-    const KHessScratch& hx = h.hx;
-    const int b = NJ + m;
-    return dot3(hx.dcmu[b], hx.Gm[j].l) - dot6(hx.Sxl[b], hx.Gm[j]);
-}
-template <class Em> HD double mom_omega_s(const KHCtx<Em>& h, int m, int j) {   // (omega_m, s_j)
-    const KHessScratch& hx = h.hx;
-    const int b = NJ + m;
-    return dot3(hx.dcmu[j], hx.Gm[b].l) - dot6(hx.Cv[j], hx.S[b]);
-}
-
 // --- (s_j, s_i) and (s_k, sdot_l).  Most joint pairs are UNRELATED (neither on the other's path to the root): only the dense terms
 //     through com(s) reach them — a few multiply-adds.  The related pairs (each joint with the <= 8 joints of its own path) carry the
 //     second derivatives proper.  Two task groups each, so that a wave iteration is either all light or all heavy:
@@ -820,40 +799,33 @@ template <class Em> HD void t_kh_ssd_near(KHCtx<Em>& h, int t) {
     cx.em.H(hk::SSD + k * NJ + l, S_ + k, SD_ + l, v);
 }
 
-// --- centroidal momentum, theta-level mixed entries: lanes (m, j) 69 -------------------------------------------------------------------
-template <class Em> HD void t_kh_theta(KHCtx<Em>& h, int t) {
-    const int m = t / NJ, j = t - NJ * m;
-    h.hx.TS[m][j] = mom_theta_s(h, m, j);
-    h.hx.TSD[m][j] = mom_theta_sd(h, m, j);
-    h.hx.WS[m][j] = mom_omega_s(h, m, j);
-}
-// --- (s_j, q_l), (s_j, qdot_l), (sdot_j, q_l): lanes (j, l) 92 each, behind t_kh_theta on the same wave ---------------------------------
-//     chain to the quaternion:  dtheta = G dq / |q|,  d omega / dq = dwq,  d omega / d qdot = G
-template <class Em> HD void t_kh_sq(KHCtx<Em>& h, int t) {
+// --- the joint rows of the theta-level blocks and their chain to the quaternion: lane j (NJ).  (theta_m, s_j), (theta_m, sdot_j),
+//     (omega_m, s_j) of the centroidal momentum for the three base axes m stay in the lane — row j against the columns NJ + m — and go
+//     straight into (s_j, q_l), (s_j, qdot_l), (sdot_j, q_l):  dtheta = G dq / |q|,  d omega / dq = dwq,  d omega / d qdot = G.
+//     (Until round 4 three arrays in LDS, 69 lanes to fill them and 3 x 92 lanes behind a wave fence to contract them.)
+template <class Em> HD void t_kh_theta_rows(KHCtx<Em>& h, int j) {
     Ctx<Em>& cx = h.cx;
     const auto& s = cx.s;
-    HIPNLP_WAVE_SYNC();
-    const int j = t >> 2, l = t & 3;
-    const double Y[3] = {h.hx.Y[j][0] + h.hx.Yc[j][0], h.hx.Y[j][1] + h.hx.Yc[j][1], h.hx.Y[j][2] + h.hx.Yc[j][2]};
-    double v = (s.G[l] * Y[0] + s.G[4 + l] * Y[1] + s.G[8 + l] * Y[2]) * s.inv_qnorm;
-    for (int m = 0; m < 3; ++m) v += s.G[4 * m + l] * s.inv_qnorm * h.hx.TS[m][j] + s.dwq[4 * m + l] * h.hx.WS[m][j];
-    cx.em.H(hk::SQ + t, S_ + j, QB_ + l, v);
-}
-template <class Em> HD void t_kh_sqd(KHCtx<Em>& h, int t) {
-    Ctx<Em>& cx = h.cx;
-    const auto& s = cx.s;
-    const int j = t >> 2, l = t & 3;
-    double v = 0.0;
-    for (int m = 0; m < 3; ++m) v += s.G[4 * m + l] * h.hx.WS[m][j];
-    cx.em.H(hk::SQD + t, S_ + j, QD_ + l, v);
-}
-template <class Em> HD void t_kh_sdq(KHCtx<Em>& h, int t) {
-    Ctx<Em>& cx = h.cx;
-    const auto& s = cx.s;
-    const int j = t >> 2, l = t & 3;
-    double v = 0.0;
-    for (int m = 0; m < 3; ++m) v += s.G[4 * m + l] * s.inv_qnorm * h.hx.TSD[m][j];
-    cx.em.H(hk::SDQ + t, SD_ + j, QB_ + l, v);
+    const KHessScratch& hx = h.hx;
+    const SV6 Ej = hx.E[j], Cj = hx.Cv[j], Gj = hx.Gm[j];
+    double dj[3], TS[3], TSD[3], WS[3];
+    for (int i = 0; i < 3; ++i) dj[i] = hx.dcmu[j][i];
+    for (int m = 0; m < 3; ++m) {
+        const int b = NJ + m;
+        TS[m] = -dot6(hx.Sxl[b], Ej) + dot6(hx.Wv[b], Cj) + dot3(hx.dcmu[b], Ej.l) + dot3(dj, hx.E[b].l);   // (theta_m, s_j) without the d2com term (in Y)
+        TSD[m] = dot3(hx.dcmu[b], Gj.l) - dot6(hx.Sxl[b], Gj);                                                // (theta_m, sdot_j)
+        WS[m] = dot3(dj, hx.Gm[b].l) - dot6(Cj, hx.S[b]);                                                     // (omega_m, s_j)
+    }
+    const double Y[3] = {hx.Y[j][0] + hx.Yc[j][0], hx.Y[j][1] + hx.Yc[j][1], hx.Y[j][2] + hx.Yc[j][2]};
+    for (int l = 0; l < 4; ++l) {
+        double v = (s.G[l] * Y[0] + s.G[4 + l] * Y[1] + s.G[8 + l] * Y[2]) * s.inv_qnorm;
+        for (int m = 0; m < 3; ++m) v += s.G[4 * m + l] * s.inv_qnorm * TS[m] + s.dwq[4 * m + l] * WS[m];
+        cx.em.H(hk::SQ + 4 * j + l, S_ + j, QB_ + l, v);
+        double vq = 0.0, vd = 0.0;
+        for (int m = 0; m < 3; ++m) { vq += s.G[4 * m + l] * WS[m]; vd += s.G[4 * m + l] * s.inv_qnorm * TSD[m]; }
+        cx.em.H(hk::SQD + 4 * j + l, S_ + j, QD_ + l, vq);
+        cx.em.H(hk::SDQ + 4 * j + l, SD_ + j, QB_ + l, vd);
+    }
 }
 
 // second derivative of  g . (q / |q|)  with respect to q, entry (r, c)
@@ -1039,7 +1011,7 @@ template <class Em> HD void t_kh_ssd_far_c(KHCtx<Em>& h, int t) { t_kh_ssd_far(h
     RH(0, t_kh_ss_near, KH_NEAR_TASKS) RH(0, t_kh_ssd_far_a, KH_SSD_A)                                           \
     RH(1, t_kh_ssd_near, 2 * KH_NEAR_TASKS) RH(1, t_kh_tw, 9) RH(1, t_kh_qqd, 16) RH(1, t_kh_ssd_far_c, KH_SSD_C) \
     RH(2, t_kh_ss_far, KH_SS_TASKS) RH(2, t_kh_ssd_far_b, KH_SSD_B)                                              \
-    RH(3, t_kh_theta, 3 * NJ) RH(3, t_kh_sq, 4 * NJ) RH(3, t_kh_sqd, 4 * NJ) RH(3, t_kh_sdq, 4 * NJ) RH(3, t_kh_qq, 10) \
+    RH(3, t_kh_theta_rows, NJ) RH(3, t_kh_qq, 10)                                                                \
     BARRIER
 // diagnostic builds only (tools/diag/hess_phases.sh): -DHIPNLP_HESS_DIAG_PHASES=n runs the first n of the six phases (the values are then wrong)
 #if !defined(HIPNLP_HESS_DIAG_PHASES)
