@@ -436,7 +436,7 @@ def host_visible(eng, x_np, horizon, batch, st=None, model=None):
 def throughput_block(model, device_index):
     """The batch launches beside the headline (never `value`): each kernel's roofline figure from THIS run, HIP events on the launch
     stream, a few dozen launches each.  Periodic N = 100 x 64 and x 1024, the stairs 200 x 16 (BASELINE config 5's whole job on one GPU),
-    the exact Hessian x 64, the pose finder x 4096.  Synthetic trajectories: one seeded base trajectory + N(0, 0.02^2) per trajectory
+    the exact Hessian x 64 and on the stairs 200 x 16, the pose finder x 4096.  Synthetic trajectories: one seeded base trajectory + N(0, 0.02^2) per trajectory
     (SURVEY §8d), generated in one vectorised draw."""
     import numpy as np
     import torch
@@ -497,11 +497,11 @@ def throughput_block(model, device_index):
                     "launches_timed": nprof,
                     "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
                                  "algorithmic_bytes": bytes_knot * knots, "algorithmic_bytes_per_knot": bytes_knot}}
-        if tag == "periodic_N100_B64":
-            hessian(eng, x, N, B)
+        if tag in ("periodic_N100_B64", "stairs_N200_B16"):
+            hessian(eng, x, N, B, "stairs" if stairs else "periodic")
         eng.close()
 
-    def hessian(eng, x, N, B):
+    def hessian(eng, x, N, B, workload):
         hn = eng.hess_nnz()
         with torch.cuda.stream(stream):
             xd = torch.from_numpy(x).to(dev)
@@ -523,7 +523,7 @@ def throughput_block(model, device_index):
         knots = N * B
         bytes_knot = 8.0 * (189 + 79 + 274 + hn / N)
         gbps = bytes_knot * knots / (ms * 1e-3) / 1e9
-        out["hessian_periodic_N%d_B%d" % (N, B)] = {"ms_per_launch": ms, "knots_per_s": knots / (ms * 1e-3), "knots_per_launch": knots, "kernel": "hipnlp_knot_hess_kernel",
+        out["hessian_%s_N%d_B%d" % (workload, N, B)] = {"ms_per_launch": ms, "knots_per_s": knots / (ms * 1e-3), "knots_per_launch": knots, "kernel": "hipnlp_knot_hess_kernel",
                                                     "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
                                                                  "algorithmic_bytes": bytes_knot * knots, "algorithmic_bytes_per_knot": bytes_knot}}
 

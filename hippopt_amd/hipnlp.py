@@ -4,6 +4,7 @@ There is no CPU fallback: loading fails loudly when the library is missing, and 
 raises when no HIP device is present.
 """
 import ctypes as C
+import weakref
 import os
 import sys as _sys
 
@@ -180,6 +181,9 @@ class HipNlp:
         self.m_full, self.n_lifted = d.m_full, d.n_lifted
         self.lifted = bool(self.desc.flags & _abi.FLAG_DETECT_SIMPLE_BOUNDS)
         self.params_generation = 0   # bumped by set_params (what caches of parameter-dependent data key on)
+        self._addresses = {}
+        self._h_value = h.value
+        self._eval_raw = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)(("hipnlp_eval", self.lib))
 
     @classmethod
     def from_desc(cls, desc):
@@ -192,6 +196,8 @@ class HipNlp:
         if getattr(self, "h", None):
             self.lib.hipnlp_destroy(self.h)
             self.h = None
+            self._h_value = None      # (a call on a closed handle is refused by the library: HIPNLP_E_INVALID)
+            self._addresses = {}
 
     def __del__(self):
         # (not while the interpreter is shutting down: the HIP runtime's own exit handlers may already have run, and the OS reclaims
@@ -253,7 +259,8 @@ class HipNlp:
         fresh 1 MB numpy arrays cost an mmap and their page faults on every call).
         nan_ok: a non-finite evaluation (HIPNLP_E_NUMERIC) returns the arrays as filled — NaN/Inf included — instead of raising:
         what an NLP driver wants at a line-search trial point (the reference hands CasADi's NaNs to IPOPT, which cuts the step)."""
-        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.batch, self.n)
+        if not (type(x) is np.ndarray and x.dtype == np.float64 and x.flags.c_contiguous and x.size == self.batch * self.n):
+            x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.batch, self.n)
         if out is not None:
             f, grad, g, jac = out
         else:
@@ -262,10 +269,29 @@ class HipNlp:
             g = np.empty((self.batch, self.m)) if "g" in want else None
             jac = np.empty((self.batch, self.nnz)) if "jac" in want else None
         # (new_x = None: unknown — the library compares x with its staging copy of the previous evaluation)
-        rc = self.lib.hipnlp_eval(self.h, _dp(x), -1 if new_x is None else (1 if new_x else 0), _dp(f), _dp(grad), _dp(g), _dp(jac))
+        # One foreign call on raw addresses; the address of an array is looked up once per array OBJECT (a solver hands in the same
+        # arrays iterate after iterate: five `ndarray.ctypes` objects per call were 6 of the 47 us of a 100-knot callback).
+        rc = self._eval_raw(self._h_value, self._address(x), -1 if new_x is None else (1 if new_x else 0),
+                            self._address(f), self._address(grad), self._address(g), self._address(jac))
         if not (nan_ok and rc == -5):
             self._check(rc)
         return f, grad, g, jac
+
+    def _address(self, a):
+        """data address of a numpy array, remembered per array object (a weak reference tells a live object from a reused id)"""
+        if a is None:
+            return None
+        ent = self._addresses.get(id(a))
+        if ent is not None and ent[0]() is a:
+            return ent[1]
+        if len(self._addresses) > 256:
+            self._addresses.clear()
+        addr = a.ctypes.data
+        try:
+            self._addresses[id(a)] = (weakref.ref(a), addr)
+        except TypeError:      # (not weakly referenceable: looked up every time)
+            pass
+        return addr
 
     def raw_eval(self):
         """hipnlp_eval as ONE foreign call on raw addresses: `call(x_addr, new_x, f_addr, grad_addr, g_addr, jac_addr) -> rc` (None for an
