@@ -2274,10 +2274,14 @@ __global__ __launch_bounds__(256) void hipnlp_peer_push_kernel(const double* __r
         for (int r = 0; r < world; ++r) peer_out[r][d] = v;   // (consecutive lanes: consecutive addresses on every link)
     }
 }
-__global__ void hipnlp_peer_signal_kernel(unsigned long long* const* peer_flags, int world, int rank, unsigned long long seq) {
+// A rank whose own status word is raised (a wait of ITS step gave up: what it pushed may have gone into a buffer that was still being
+// read) signals with the poison bit: the receiving wait passes and poisons the step there too.
+constexpr unsigned long long PEER_POISON = 1ull << 63;
+__global__ void hipnlp_peer_signal_kernel(unsigned long long* const* peer_flags, int world, int rank, unsigned long long seq, const int* status) {
     __threadfence_system();   // (the push kernel ended before this one started: its stores are performed; ordered before the flags system-wide)
     const int r = threadIdx.x;
-    if (r < world) __hip_atomic_store(peer_flags[r] + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long v = (status && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? (seq | PEER_POISON) : seq;
+    if (r < world) __hip_atomic_store(peer_flags[r] + rank, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // One workgroup of 64 x 4 threads.  A wait that gives up is STICKY: *status is only ever raised here (the host clears it), and every
 // output of the step is poisoned — f as before, and grad / jac / g as well (out[0 .. f_off)): a step whose pushes may be partial must
@@ -2289,10 +2293,12 @@ __global__ __launch_bounds__(256) void hipnlp_peer_wait_kernel(const unsigned lo
     __syncthreads();
     if (r < world) {
         int spins = 0;
-        while (__hip_atomic_load(flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+        unsigned long long fv;
+        while ((fv = __hip_atomic_load(flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) < seq) {   // (a poisoned flag is >= any step number)
             if (++spins > (1 << 20)) { s_late = 1; break; }   // (a rank that died must not hang this device)
             __builtin_amdgcn_s_sleep(8);
         }
+        if (fv & PEER_POISON) s_late = 1;   // the sender's own step had failed
     }
     __syncthreads();
     const int late = s_late;
@@ -2343,11 +2349,14 @@ int hipnlp_peer_push(const double* shard_dev, const int64_t* dst_dev, int64_t co
     hipLaunchKernelGGL(hipnlp_peer_push_kernel, dim3(grid), dim3(256), 0, hipStream_t(stream), shard_dev, dst_dev, count, peer_out_dev, world);
     return hipGetLastError() == hipSuccess ? HIPNLP_OK : HIPNLP_E_NODEVICE;
 }
-int hipnlp_peer_signal(unsigned long long* const* peer_flags_dev, int world, int rank, unsigned long long seq, void* stream) {
+int hipnlp_peer_signal_checked(unsigned long long* const* peer_flags_dev, int world, int rank, unsigned long long seq, const int* status_dev, void* stream) {
     // (world: flag arrays written to — every rank's, or one rank's: gather_to_root —; rank: this rank's slot in them)
-    if (!peer_flags_dev || world < 1 || world > 64 || rank < 0 || rank >= 64) return HIPNLP_E_INVALID;
-    hipLaunchKernelGGL(hipnlp_peer_signal_kernel, dim3(1), dim3(64), 0, hipStream_t(stream), peer_flags_dev, world, rank, seq);
+    if (!peer_flags_dev || world < 1 || world > 64 || rank < 0 || rank >= 64 || (seq & PEER_POISON)) return HIPNLP_E_INVALID;
+    hipLaunchKernelGGL(hipnlp_peer_signal_kernel, dim3(1), dim3(64), 0, hipStream_t(stream), peer_flags_dev, world, rank, seq, status_dev);
     return hipGetLastError() == hipSuccess ? HIPNLP_OK : HIPNLP_E_NODEVICE;
+}
+int hipnlp_peer_signal(unsigned long long* const* peer_flags_dev, int world, int rank, unsigned long long seq, void* stream) {
+    return hipnlp_peer_signal_checked(peer_flags_dev, world, rank, seq, nullptr, stream);
 }
 int hipnlp_peer_wait(const unsigned long long* flags_dev, int world, unsigned long long seq, double* out_dev, int64_t f_off, int* status_dev, void* stream) {
     if (!flags_dev || !out_dev || !status_dev || world < 1 || world > 64) return HIPNLP_E_INVALID;

@@ -23,7 +23,7 @@ EXPORTS = [
     "hipnlp_cost_terms", "hipnlp_cost_term_name", "hipnlp_num_row_blocks", "hipnlp_row_block",
     "hipnlp_last_kernel_ms", "hipnlp_profile_begin", "hipnlp_profile_end", "hipnlp_kernels_per_eval", "hipnlp_profile_begin_runs",
     "hipnlp_eval_device_shard", "hipnlp_stage_rows", "hipnlp_reassemble",
-    "hipnlp_ipc_alloc", "hipnlp_ipc_open", "hipnlp_ipc_close", "hipnlp_ipc_free", "hipnlp_peer_push", "hipnlp_peer_signal", "hipnlp_peer_wait", "hipnlp_eval_device_peers",
+    "hipnlp_ipc_alloc", "hipnlp_ipc_open", "hipnlp_ipc_close", "hipnlp_ipc_free", "hipnlp_peer_push", "hipnlp_peer_signal", "hipnlp_peer_signal_checked", "hipnlp_peer_wait", "hipnlp_eval_device_peers",
     "hipnlp_hess_nnz", "hipnlp_hess_sparsity", "hipnlp_eval_hess", "hipnlp_eval_hess_device",
     "hipnlp_eval_pinned", "hipnlp_set_prefetch", "hipnlp_set_early_outputs", "hipnlp_set_host_timing", "hipnlp_host_register", "hipnlp_host_unregister",
     "hipnlp_host_breakdown", "hipnlp_set_auto_register", "hipnlp_host_stats", "hipnlp_set_constant_jacobian", "hipnlp_jac_constant_mask", "hipnlp_host_release_auto_ranges",

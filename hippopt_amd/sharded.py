@@ -246,6 +246,7 @@ class PeerExchange:
         lib.hipnlp_ipc_free.argtypes = [vp]
         lib.hipnlp_peer_push.argtypes = [vp, vp, i64, vp, C.c_int, vp]
         lib.hipnlp_peer_signal.argtypes = [vp, C.c_int, C.c_int, C.c_ulonglong, vp]
+        lib.hipnlp_peer_signal_checked.argtypes = [vp, C.c_int, C.c_int, C.c_ulonglong, vp, vp]
         lib.hipnlp_peer_wait.argtypes = [vp, C.c_int, C.c_ulonglong, vp, i64, vp, vp]
         self.tot = cb.n + cb.nnz + cb.m
         self.olen = self.tot + self.world + 1             # [grad | jac | g | f partials (world) | f]
@@ -377,7 +378,8 @@ class PeerExchange:
                 cb.compute_shard(x, *cb.views, sh)
                 rc |= lib.hipnlp_peer_push(cb.buf.data_ptr(), self.dst.data_ptr(), cb.shard_len, targets.data_ptr(), ntargets, sh)
             flags = self.root_flags if self.root_only else self.peer_flags
-            rc |= lib.hipnlp_peer_signal(flags.data_ptr(), ntargets, self.rank, self.seq, sh)
+            # (checked: a rank whose own back-flag wait gave up has pushed into a buffer that may still have been read — it says so)
+            rc |= lib.hipnlp_peer_signal_checked(flags.data_ptr(), ntargets, self.rank, self.seq, self.status.data_ptr(), sh)
             out = self._views[par]
             if not self.root_only or self.rank == 0:
                 rc |= lib.hipnlp_peer_wait(self.my_flags, self.world, self.seq, out.data_ptr(), self.tot, self.status.data_ptr(), sh)
@@ -556,6 +558,7 @@ class BatchPeerToRoot:
         lib.hipnlp_ipc_close.argtypes = [vp]
         lib.hipnlp_ipc_free.argtypes = [vp]
         lib.hipnlp_peer_signal.argtypes = [vp, C.c_int, C.c_int, C.c_ulonglong, vp]
+        lib.hipnlp_peer_signal_checked.argtypes = [vp, C.c_int, C.c_int, C.c_ulonglong, vp, vp]
         lib.hipnlp_peer_wait.argtypes = [vp, C.c_int, C.c_ulonglong, vp, i64, vp, vp]
         if 2 * self.world > 32:
             raise RuntimeError("peer exchange: at most 16 ranks")
@@ -653,7 +656,7 @@ class BatchPeerToRoot:
                 rc |= lib.hipnlp_peer_wait(self.my_back_flags, 1, self.seq - 1, self._scratch.data_ptr(), 0, self.status.data_ptr(), sh)
             base = self.root_out[par] + 8 * self.rank * bc.shard_len
             self.engine.eval_device(x_local.data_ptr(), base, base + 8 * bc.o_grad, base + 8 * bc.o_g, base + 8 * bc.o_jac, stream=sh)
-            rc |= lib.hipnlp_peer_signal(self.root_flags.data_ptr(), 1, self.rank, self.seq, sh)
+            rc |= lib.hipnlp_peer_signal_checked(self.root_flags.data_ptr(), 1, self.rank, self.seq, self.status.data_ptr(), sh)
             if self.rank == 0:
                 out = self._gathered[par]
                 rc |= lib.hipnlp_peer_wait(self.my_flags, self.world, self.seq, out.data_ptr(), self.world * bc.shard_len, self.status.data_ptr(), sh)

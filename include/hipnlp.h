@@ -399,11 +399,14 @@ int hipnlp_reassemble(const double* gathered_dev, const int64_t* src_dev, double
  *                      of `world` device pointers)
  *   hipnlp_peer_signal system-scope fence, then peer_flags[r][rank] = seq for every r < world (peer_flags: device array of `world` pointers —
  *                      every rank's flag array, or a subset: gather_to_root signals rank 0 alone; rank < 64: this rank's slot)
+ *   hipnlp_peer_signal_checked  the same, but with bit 63 set in the value when *status_dev != 0 at that point of the stream: the step of
+ *                      THIS rank has failed (a wait of its own gave up), what it pushed must not pass for an evaluation on the
+ *                      receiving side either — hipnlp_peer_wait takes a flag with that bit for "arrived, poisoned" (seq < 2^63)
  *   hipnlp_peer_wait   spins (bounded: ~2^20 polls — about a second) until flags[r] >= seq for all r, then
  *                      out[f_off + world] = sum over r, in rank order, of out[f_off + r] (the cost partials).  A wait that gives up
  *                      is sticky and loud: *status_dev is OR-ed with 1 (never cleared here: the host zeroes it when it sets the
  *                      exchange up) and the whole step is poisoned — out[0 .. f_off) and the cost become NaN — so that pushes that
- *                      may be partial cannot pass for an evaluation                                                               */
+ *                      may be partial cannot pass for an evaluation; a flag that carries the poison bit does the same              */
 #define HIPNLP_IPC_HANDLE_BYTES 64
 int hipnlp_ipc_alloc(size_t bytes, int device, void** dev_ptr, void* handle_out /*[HIPNLP_IPC_HANDLE_BYTES]*/);
 int hipnlp_ipc_open(const void* handle /*[HIPNLP_IPC_HANDLE_BYTES]*/, int device, void** dev_ptr);
@@ -411,6 +414,8 @@ int hipnlp_ipc_close(void* dev_ptr);
 int hipnlp_ipc_free(void* dev_ptr);
 int hipnlp_peer_push(const double* shard_dev, const int64_t* dst_dev, int64_t count, double* const* peer_out_dev, int world, void* stream);
 int hipnlp_peer_signal(unsigned long long* const* peer_flags_dev, int world, int rank, unsigned long long seq, void* stream);
+int hipnlp_peer_signal_checked(unsigned long long* const* peer_flags_dev, int world, int rank, unsigned long long seq, const int* status_dev,
+                               void* stream);
 int hipnlp_peer_wait(const unsigned long long* flags_dev, int world, unsigned long long seq, double* out_dev, int64_t f_off,
                      int* status_dev, void* stream);
 /* The push folded into the evaluation: the knot kernel of a shard handle (batch 1, at most 256 knots in the shard) stores the shard's

@@ -708,6 +708,20 @@ def test_a_wait_that_gives_up_is_sticky_and_poisons_the_step(model, HipNlp):
     assert lib.hipnlp_peer_wait(flags.data_ptr(), world, 6, out.data_ptr(), tot, status.data_ptr(), stream.cuda_stream) == 0
     stream.synchronize()
     assert int(status.item()) == 1                 # sticky
+    # ... and it travels: a rank whose status word is raised signals with the poison bit (hipnlp_peer_signal_checked), the wait on the
+    # receiving side passes at once and poisons ITS step (a push into a buffer that may still have been read must not pass for an evaluation)
+    vp = C.c_void_p
+    lib.hipnlp_peer_signal_checked.argtypes = [vp, C.c_int, C.c_int, C.c_ulonglong, vp, vp]
+    flags2 = torch.zeros(world, dtype=torch.int64, device=dev)
+    ftab = torch.tensor([flags2.data_ptr()], dtype=torch.int64, device=dev)
+    status2 = torch.zeros(1, dtype=torch.int32, device=dev)
+    for r in range(world):   # rank 1 signals with a raised status word, the others with a clean one
+        assert lib.hipnlp_peer_signal_checked(ftab.data_ptr(), 1, r, 9, (status if r == 1 else status2).data_ptr(), stream.cuda_stream) == 0
+    out2 = torch.zeros(tot + world + 1, dtype=torch.float64, device=dev)
+    assert lib.hipnlp_peer_wait(flags2.data_ptr(), world, 9, out2.data_ptr(), tot, status2.data_ptr(), stream.cuda_stream) == 0
+    stream.synchronize()
+    assert int(status2.item()) == 1 and bool(torch.isnan(out2[:tot]).all()) and bool(torch.isnan(out2[tot + world]))
+    assert int(flags2[1].item()) & 0xFFFFFFFF == 9 and int(flags2[0].item()) == 9
     assert float(out[tot + world]) == 4.0 and bool((out[:tot] == 2.0).all())
 
 
