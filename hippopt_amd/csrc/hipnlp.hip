@@ -616,7 +616,8 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 #else
 #define HIPNLP_HESS_TABLES_AT HIPNLP_HESS_DIAG_PHASES   // (diagnostic builds that stop early: behind the last barrier they have)
 #endif
-struct HessTables {
+struct alignas(16) HessTables {
+    KHFarLists far;               // unrelated joint pairs of the model (first: 16-byte aligned for the staging loads)
     int32_t perm[hk::COUNT];      // position in the knot block -> native slot
     int32_t perm_couple[84];
     int32_t nnz_knot, n_couple;
@@ -722,6 +723,7 @@ void hipnlp_knot_hess_kernel(HArgs a) {
             stage(a.gp + b, &tabs.gp, int(sizeof(GParams)));
             stage(&tb.head, &tabs.head, int(sizeof(HeadTables)));
         }
+        stage(&a.ht->far, &hx.far, int(sizeof(KHFarLists)));
         double xrem = 0.0, xov = 0.0;
         if (XREM && tid < 2 && !(first && tid == 1)) xrem = x[size_t(NXK) * (k - tid) + XB / 8];
         if (first || last) { if (tid < NPER) xov = x[size_t(NXK) * (first ? N - 1 : 0) + periodicity_row_var(tid)]; }
@@ -1534,6 +1536,7 @@ static int hess_prepare(hipnlp_handle* h) {
     for (int i = 0; i < hk::COUNT; ++i) t->perm[i] = i < h->HL.nnz_knot ? h->HL.perm[size_t(i)] : -1;
     for (int i = 0; i < 84; ++i) t->perm_couple[i] = i < h->HL.n_couple ? h->HL.perm_couple[size_t(i)] : -1;
     t->nnz_knot = h->HL.nnz_knot; t->n_couple = h->HL.n_couple;
+    kh_fill_far_lists(h->kt, t->far);
     const hipError_t e = hipnlp_internal_memcpy(h->d_ht, t, sizeof(HessTables), hipMemcpyHostToDevice);
     delete t;
     if (e != hipSuccess) { h->err = std::string("Hessian tables: ") + hipGetErrorString(e); return HIPNLP_E_NODEVICE; }

@@ -81,6 +81,16 @@ constexpr int COUNT = COMXY + 1;
 
 struct SV6 { double a[3], l[3]; };   // spatial vector [angular; linear]
 
+// The joint pairs that are UNRELATED (neither joint on the other's path to the root), as lists: only the terms through com(s) reach them, and
+// their lanes need not be found among the related ones (until round 4 a lane per pair of the full triangle / square asked `related?` and
+// went idle: two of five wave iterations of the (s, s) lanes, three of nine of the (s, sdot) ones).  A property of the model: built on the
+// host (kh_fill_far_lists), staged with the tables.
+struct alignas(16) KHFarLists {
+    int32_t n_ss, n_ssd, pad_[2];
+    uint16_t ss[(NJ * (NJ + 1) / 2 + 7) / 8 * 8];   // (j << 8) | i, j > i
+    uint16_t ssd[(NJ * NJ + 7) / 8 * 8];            // (k << 8) | l: row s_k, column sdot_l
+};
+static_assert(sizeof(KHFarLists) % 16 == 0, "staged in 16-byte pieces");
 struct alignas(16) KHessScratch {   // (16-byte alignment: the spatial vectors and the padded triples below are read as 128-bit words)
     double lam_next[3];      // multipliers of the angular momentum-dynamics rows of the NEXT interval (owned by knot k + 1)
     double sigma;
@@ -94,6 +104,7 @@ struct alignas(16) KHessScratch {   // (16-byte alignment: the spatial vectors a
     double TW[3][3];         // (theta_m, omega_m') of the centroidal momentum term (t_kh_tw -> t_kh_qqd)
     double qqMw[9];          // Mw of the (q_b, q_b) block (t_kh_qq0_mw -> t_kh_qq0)
     double H[hk::COUNT];
+    KHFarLists far;
 };
 
 template <class Em> struct KHCtx {
@@ -710,19 +721,30 @@ template <class Em> HD void t_kh_Y_chest(KHCtx<Em>& h, int j) {
 // --- (s_j, s_i) and (s_k, sdot_l).  Most joint pairs are UNRELATED (neither on the other's path to the root): only the dense terms
 //     through com(s) reach them — a few multiply-adds.  The related pairs (each joint with the <= 8 joints of its own path) carry the
 //     second derivatives proper.  Two task groups each, so that a wave iteration is either all light or all heavy:
-//       t_kh_ss_far   lanes over the lower triangle 276, skips related pairs (+ the feet-distance term of one joint on each leg)
+//       t_kh_ss_far   lanes over the LIST of unrelated pairs (+ the feet-distance term of one joint on each leg)
 //       t_kh_ss_near  lanes (j, q) 184: the pair (anc[j][q], j)
-//       t_kh_ssd_far  lanes NJ x NJ, skips related pairs
+//       t_kh_ssd_far  lanes over the list of unrelated (k, l)
 //       t_kh_ssd_near lanes (j, q, direction) 368: (k, l) = (anc[j][q], j) and (j, anc[j][q])
-HD bool kh_related(const KHessScratch& hx, int i, int j) { return (((hx.rel[j] >> unsigned(i)) | (hx.rel[i] >> unsigned(j))) & 1u) != 0u; }
+inline void kh_fill_far_lists(const KinLite& kt, KHFarLists& f) {   // host only
+    uint32_t rel[NJ];
+    for (int j = 0; j < NJ; ++j) {
+        rel[j] = 0u;
+        for (int q = 0; q < 8; ++q) { const int a = int(kt.anc[j][q]); if (a < NJ) rel[j] |= 1u << unsigned(a); }
+    }
+    auto related = [&](int i, int j) { return (((rel[j] >> unsigned(i)) | (rel[i] >> unsigned(j))) & 1u) != 0u; };
+    f.n_ss = f.n_ssd = 0; f.pad_[0] = f.pad_[1] = 0;
+    for (auto& v : f.ss) v = 0;
+    for (auto& v : f.ssd) v = 0;
+    for (int j = 0; j < NJ; ++j) for (int i = 0; i < j; ++i) if (!related(i, j)) f.ss[f.n_ss++] = uint16_t((j << 8) | i);
+    for (int k = 0; k < NJ; ++k) for (int l = 0; l < NJ; ++l) if (!related(k, l)) f.ssd[f.n_ssd++] = uint16_t((k << 8) | l);
+}
 constexpr int KH_SS_TASKS = NJ * (NJ + 1) / 2;
 template <class Em> HD void t_kh_ss_far(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
     auto& s = cx.s;
     const KHessScratch& hx = h.hx;
-    const int j = tri_row(t);
-    const int i = t - j * (j + 1) / 2;
-    if (kh_related(hx, i, j)) return;
+    if (t >= hx.far.n_ss) return;
+    const int pr = int(hx.far.ss[t]), j = pr >> 8, i = pr & 0xff;
     double v = dot3(hx.dcmu[i], hx.E[j].l) + dot3(hx.dcmu[j], hx.E[i].l);
     // feet lateral distance  D = y_r . (o_l - o_r)  (K4; base fixed), one joint on each leg:  (a_R x y) . (a_L x (o_l - o_L))
     const int Li = cx.kt.leg_pos[0][i], Lj = cx.kt.leg_pos[0][j], Ri = cx.kt.leg_pos[1][i], Rj = cx.kt.leg_pos[1][j];
@@ -737,7 +759,7 @@ template <class Em> HD void t_kh_ss_far(KHCtx<Em>& h, int t) {
         cross3(s.aw[jl], u3, u2);
         v += h.lam[gs::FEETD] * dot3(u1, u2);
     }
-    cx.em.H(hk::SS + t, S_ + j, S_ + i, v);
+    cx.em.H(hk::SS + j * (j + 1) / 2 + i, S_ + j, S_ + i, v);
 }
 constexpr int KH_NEAR_TASKS = NJ * 8;
 template <class Em> HD void t_kh_ss_near(KHCtx<Em>& h, int t) {
@@ -780,9 +802,9 @@ template <class Em> HD void t_kh_ss_near(KHCtx<Em>& h, int t) {
 template <class Em> HD void t_kh_ssd_far(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
     const KHessScratch& hx = h.hx;
-    const int k = t / NJ, l = t - NJ * k;
-    if (kh_related(hx, k, l)) return;
-    cx.em.H(hk::SSD + t, S_ + k, SD_ + l, dot3(hx.dcmu[k], hx.Gm[l].l));
+    if (t >= hx.far.n_ssd) return;
+    const int pr = int(hx.far.ssd[t]), k = pr >> 8, l = pr & 0xff;
+    cx.em.H(hk::SSD + k * NJ + l, S_ + k, SD_ + l, dot3(hx.dcmu[k], hx.Gm[l].l));
 }
 template <class Em> HD void t_kh_ssd_near(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
@@ -971,9 +993,9 @@ template <class Em> HD void t_kh_qq(KHCtx<Em>& h, int t) {
     cx.em.H(hk::QQ + t, QB_ + r, QB_ + c, v);
 }
 
-// the light (s, sdot) group in three lane ranges (nine wave iterations of ~400 cycles: 5 + 3 + 1, filling up three waves)
-constexpr int KH_SSD_A = 5 * 64, KH_SSD_B = 3 * 64, KH_SSD_C = NJ * NJ - KH_SSD_A - KH_SSD_B;
-static_assert(KH_SSD_C > 0 && KH_SSD_C <= 64, "(s, sdot) lane ranges");
+// the light (s, sdot) group — its list of unrelated pairs — in three lane ranges on three waves (two, three and the remaining wave iterations)
+constexpr int KH_SSD_A = 2 * 64, KH_SSD_B = 3 * 64, KH_SSD_C = NJ * NJ - KH_SSD_A - KH_SSD_B;
+static_assert(KH_SSD_C > 0, "(s, sdot) lane ranges");
 template <class Em> HD void t_kh_ssd_far_a(KHCtx<Em>& h, int t) { t_kh_ssd_far(h, t); }
 template <class Em> HD void t_kh_ssd_far_b(KHCtx<Em>& h, int t) { t_kh_ssd_far(h, t + KH_SSD_A); }
 template <class Em> HD void t_kh_ssd_far_c(KHCtx<Em>& h, int t) { t_kh_ssd_far(h, t + KH_SSD_A + KH_SSD_B); }
@@ -1009,8 +1031,8 @@ template <class Em> HD void t_kh_ssd_far_c(KHCtx<Em>& h, int t) { t_kh_ssd_far(h
     BARRIER
 #define HIPNLP_KNOT_HESS_PHASE3(KIN, RH, BARRIER)                                                                \
     RH(0, t_kh_ss_near, KH_NEAR_TASKS) RH(0, t_kh_ssd_far_a, KH_SSD_A)                                           \
-    RH(1, t_kh_ssd_near, 2 * KH_NEAR_TASKS) RH(1, t_kh_tw, 9) RH(1, t_kh_qqd, 16) RH(1, t_kh_ssd_far_c, KH_SSD_C) \
-    RH(2, t_kh_ss_far, KH_SS_TASKS) RH(2, t_kh_ssd_far_b, KH_SSD_B)                                              \
+    RH(1, t_kh_ssd_near, 2 * KH_NEAR_TASKS) RH(1, t_kh_ssd_far_b, KH_SSD_B)                                      \
+    RH(2, t_kh_ss_far, KH_SS_TASKS) RH(2, t_kh_tw, 9) RH(2, t_kh_qqd, 16) RH(2, t_kh_ssd_far_c, KH_SSD_C)         \
     RH(3, t_kh_theta_rows, NJ) RH(3, t_kh_qq, 10)                                                                \
     BARRIER
 // diagnostic builds only (tools/diag/hess_phases.sh): -DHIPNLP_HESS_DIAG_PHASES=n runs the first n of the six phases (the values are then wrong)

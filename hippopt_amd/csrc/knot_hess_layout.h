@@ -33,6 +33,7 @@ struct HessLayout {
         std::fill(reinterpret_cast<double*>(s), reinterpret_cast<double*>(s) + sizeof(KnotScratch) / sizeof(double), 0.0);
         std::fill(reinterpret_cast<double*>(hx), reinterpret_cast<double*>(hx) + sizeof(KHessScratch) / sizeof(double), 0.0);
         s->x[QB_ + 3] = 1.0;
+        kh_fill_far_lists(kt, hx->far);
         KSettings ks = Layout::make_ksettings(st);
         GParams gp{};
         gp.dt = 0.1; gp.mass = 1.0;

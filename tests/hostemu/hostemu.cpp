@@ -235,6 +235,7 @@ void hostemu_hess(const hostemu_handle* h, const double* x, const double* p, dou
             hx->lam_next[i] = a != G_NONE ? lambda[a + L.g_b[size_t(slot)] * (k + 1)] : 0.0;
         }
         hx->sigma = sigma;
+        kh_fill_far_lists(h->kt, hx->far);
         KnotInfo ki{k, N, k == 0, k == N - 1};
         ValueEm em{s->g, s->jac, hx->H};
         Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
