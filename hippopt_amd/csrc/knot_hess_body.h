@@ -86,9 +86,10 @@ struct SV6 { double a[3], l[3]; };   // spatial vector [angular; linear]
 // went idle: two of five wave iterations of the (s, s) lanes, three of nine of the (s, sdot) ones).  A property of the model: built on the
 // host (kh_fill_far_lists), staged with the tables.
 struct alignas(16) KHFarLists {
-    int32_t n_ss, n_ssd, pad_[2];
+    int32_t n_ss, n_ssd, n_near, pad_;
     uint16_t ss[(NJ * (NJ + 1) / 2 + 7) / 8 * 8];   // (j << 8) | i, j > i
     uint16_t ssd[(NJ * NJ + 7) / 8 * 8];            // (k << 8) | l: row s_k, column sdot_l
+    uint16_t near[NJ * 8];                           // the RELATED pairs: (d << 8) | k, k on the path root -> d (inclusive) — the ancestor lists without their padding
 };
 static_assert(sizeof(KHFarLists) % 16 == 0, "staged in 16-byte pieces");
 struct alignas(16) KHessScratch {   // (16-byte alignment: the spatial vectors and the padded triples below are read as 128-bit words)
@@ -722,9 +723,9 @@ template <class Em> HD void t_kh_Y_chest(KHCtx<Em>& h, int j) {
 //     through com(s) reach them — a few multiply-adds.  The related pairs (each joint with the <= 8 joints of its own path) carry the
 //     second derivatives proper.  Two task groups each, so that a wave iteration is either all light or all heavy:
 //       t_kh_ss_far   lanes over the LIST of unrelated pairs (+ the feet-distance term of one joint on each leg)
-//       t_kh_ss_near  lanes (j, q) 184: the pair (anc[j][q], j)
+//       t_kh_ss_near  lanes over the list of related pairs (k, d), k on the path of d
 //       t_kh_ssd_far  lanes over the list of unrelated (k, l)
-//       t_kh_ssd_near lanes (j, q, direction) 368: (k, l) = (anc[j][q], j) and (j, anc[j][q])
+//       t_kh_ssd_near the same list twice: (k, l) = (a, d) and (d, a)
 inline void kh_fill_far_lists(const KinLite& kt, KHFarLists& f) {   // host only
     uint32_t rel[NJ];
     for (int j = 0; j < NJ; ++j) {
@@ -732,9 +733,11 @@ inline void kh_fill_far_lists(const KinLite& kt, KHFarLists& f) {   // host only
         for (int q = 0; q < 8; ++q) { const int a = int(kt.anc[j][q]); if (a < NJ) rel[j] |= 1u << unsigned(a); }
     }
     auto related = [&](int i, int j) { return (((rel[j] >> unsigned(i)) | (rel[i] >> unsigned(j))) & 1u) != 0u; };
-    f.n_ss = f.n_ssd = 0; f.pad_[0] = f.pad_[1] = 0;
+    f.n_ss = f.n_ssd = f.n_near = 0; f.pad_ = 0;
     for (auto& v : f.ss) v = 0;
     for (auto& v : f.ssd) v = 0;
+    for (auto& v : f.near) v = 0;
+    for (int d = 0; d < NJ; ++d) for (int q = 0; q < 8; ++q) { const int k = int(kt.anc[d][q]); if (k < NJ) f.near[f.n_near++] = uint16_t((d << 8) | k); }
     for (int j = 0; j < NJ; ++j) for (int i = 0; i < j; ++i) if (!related(i, j)) f.ss[f.n_ss++] = uint16_t((j << 8) | i);
     for (int k = 0; k < NJ; ++k) for (int l = 0; l < NJ; ++l) if (!related(k, l)) f.ssd[f.n_ssd++] = uint16_t((k << 8) | l);
 }
@@ -766,8 +769,8 @@ template <class Em> HD void t_kh_ss_near(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
     auto& s = cx.s;
     const KHessScratch& hx = h.hx;
-    const int d = t >> 3, k = int(cx.kt.anc[d][t & 7]);   // k on the path root -> d (inclusive)
-    if (k >= NJ) return;
+    if (t >= hx.far.n_near) return;
+    const int pr = int(hx.far.near[t]), d = pr >> 8, k = pr & 0xff;   // k on the path root -> d (inclusive)
     const double on = cx.ki.first ? 0.0 : 1.0;
     // centroidal momentum; points, com, chest
     double v = dot3(hx.dcmu[k], hx.E[d].l) + dot3(hx.dcmu[d], hx.E[k].l) - dot6(hx.Sxl[k], hx.E[d]) + dot6(hx.Wv[k], hx.Cv[d]) + dot3(s.aw[k], hx.Y[d]) + dot3(s.aw[k], hx.Yc[d]);
@@ -809,9 +812,10 @@ template <class Em> HD void t_kh_ssd_far(KHCtx<Em>& h, int t) {
 template <class Em> HD void t_kh_ssd_near(KHCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
     const KHessScratch& hx = h.hx;
-    const int dir = t >= KH_NEAR_TASKS ? 1 : 0, tt = t - dir * KH_NEAR_TASKS;
-    const int d = tt >> 3, a = int(cx.kt.anc[d][tt & 7]);   // a on the path root -> d (inclusive)
-    if (a >= NJ || (dir == 1 && a == d)) return;
+    const int nn = hx.far.n_near;
+    if (t >= 2 * nn) return;
+    const int dir = t >= nn ? 1 : 0, pr = int(hx.far.near[t - dir * nn]), d = pr >> 8, a = pr & 0xff;   // a on the path root -> d (inclusive)
+    if (dir == 1 && a == d) return;
     const int k = dir == 0 ? a : d, l = dir == 0 ? d : a;   // row s_k, column sdot_l
     const double on = cx.ki.first ? 0.0 : 1.0;
     double v = dot3(hx.dcmu[k], hx.Gm[l].l);
@@ -1030,9 +1034,9 @@ template <class Em> HD void t_kh_ssd_far_c(KHCtx<Em>& h, int t) { t_kh_ssd_far(h
     RH(3, t_kh_joint_b, NJ + 3) RH(3, t_kh_Y_chest, NJ)                                                          \
     BARRIER
 #define HIPNLP_KNOT_HESS_PHASE3(KIN, RH, BARRIER)                                                                \
-    RH(0, t_kh_ss_near, KH_NEAR_TASKS) RH(0, t_kh_ssd_far_a, KH_SSD_A)                                           \
+    RH(0, t_kh_ss_near, KH_NEAR_TASKS) RH(0, t_kh_ssd_far_a, KH_SSD_A) RH(0, t_kh_ssd_far_c, KH_SSD_C)           \
     RH(1, t_kh_ssd_near, 2 * KH_NEAR_TASKS) RH(1, t_kh_ssd_far_b, KH_SSD_B)                                      \
-    RH(2, t_kh_ss_far, KH_SS_TASKS) RH(2, t_kh_tw, 9) RH(2, t_kh_qqd, 16) RH(2, t_kh_ssd_far_c, KH_SSD_C)         \
+    RH(2, t_kh_ss_far, KH_SS_TASKS) RH(2, t_kh_tw, 9) RH(2, t_kh_qqd, 16)                                        \
     RH(3, t_kh_theta_rows, NJ) RH(3, t_kh_qq, 10)                                                                \
     BARRIER
 // diagnostic builds only (tools/diag/hess_phases.sh): -DHIPNLP_HESS_DIAG_PHASES=n runs the first n of the six phases (the values are then wrong)

@@ -59,12 +59,13 @@ def test_eight_wave_callback_kernel_fits_two_workgroups_per_cu(res, terrain, pee
 
 def test_hessian_and_pose_kernels(res):
     # exact Hessian of the kinodynamic NLP: full layout two workgroups per CU, compact layout three (both terrains; the smooth terrain's
-    # compact kernel is allowed a few spilled registers at the 168 cap: 12 B per lane in round 4, it had 228 B before its point tasks were split)
+    # compact kernel sits at the 168 cap without scratch since its point tasks were split and the copy-out tables are fetched late)
     for t in (0, 1):
         h = res["hipnlp_knot_hess_kernel<%d,0>" % t]
         assert 2 * h["lds"] <= LDS_PER_CU and _granule(h["vgpr"] + h["agpr"]) * 2 <= VGPR_FILE and h["scratch"] == 0, h
         hc = res["hipnlp_knot_hess_kernel<%d,1>" % t]
-        assert 3 * hc["lds"] <= LDS_PER_CU and _granule(hc["vgpr"] + hc["agpr"]) * 3 <= VGPR_FILE and hc["scratch"] <= (0 if t == 0 else 32), hc
+        # (LDS is handed out in granules of 1 280 B: three workgroups need 3 x ceil(lds / 1280) granules of the CU's 128)
+        assert 3 * (-(-hc["lds"] // 1280)) * 1280 <= LDS_PER_CU and _granule(hc["vgpr"] + hc["agpr"]) * 3 <= VGPR_FILE and hc["scratch"] == 0, hc
     for t in (0, 1):
         p = res["hipnlp_pose_kernel<%d>" % t]
         assert 3 * p["lds"] <= LDS_PER_CU and _granule(p["vgpr"] + p["agpr"]) * 3 <= VGPR_FILE, p   # three per CU (DESIGN, pose kernels)
