@@ -299,28 +299,26 @@ template <class Em> HD void t_hess_Y(HCtx<Em>& h, int j) {
     for (int r = 0; r < 3; ++r) h.hx.Y[j][r] = Y[r];
 }
 
-// --- (s_j, s_i), i ancestor-or-self of j: lanes over the lower triangle ---------------------------------------------------------
-constexpr int HESS_SS_TASKS = NJ * (NJ + 1) / 2;
+// --- (s_j, s_i), related pairs only: lane (d, q) walks the ancestor list of joint d — k = anc[d][q] lies on the path root -> d (inclusive)
+//     and carries the axis (the joint numbering need not be topological).  (Until round 4 a lane per entry of the lower triangle searched
+//     its row with a loop, compared both ancestor lists and went idle for the unrelated pairs: five wave iterations for ~110 entries.)
+constexpr int HESS_SS_TASKS = NJ * 8;
 template <class Em> HD void t_hess_ss(HCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
-    int j = 0;
-    while ((j + 1) * (j + 2) / 2 <= t) ++j;
-    const int i = t - j * (j + 1) / 2;
-    // related pairs only; the ancestor of the two carries the axis (the joint numbering need not be topological)
-    bool i_anc = false, j_anc = false;
-    for (int q = 0; q < 8; ++q) { i_anc = i_anc || (int(cx.kt.anc[j][q]) == i); j_anc = j_anc || (int(cx.kt.anc[i][q]) == j); }
-    if (!i_anc && !j_anc) return;
-    double v = i_anc ? dot3(cx.s.aw[i], h.hx.Y[j]) : dot3(cx.s.aw[j], h.hx.Y[i]);
-    if (i == j) v += 2.0 * h.hx.sigma * cx.st.m_jreg * cx.st.w_jreg[j];
+    const int d = t >> 3, k = int(cx.kt.anc[d][t & 7]);
+    if (k >= NJ) return;   // (front padding of the list)
+    double v = dot3(cx.s.aw[k], h.hx.Y[d]);
+    if (k == d) v += 2.0 * h.hx.sigma * cx.st.m_jreg * cx.st.w_jreg[d];
     for (int hnd = 0; hnd < 2; ++hnd) {   // 2 sigma m D_s^T D_s of a hand in minimize mode (both joints on its path)
-        const double k = hand_jtj_scale(h, hnd);
-        if (k == 0.0 || !hand_on_path(h, hnd, i) || !hand_on_path(h, hnd, j)) continue;
-        double xi[3], xj[3];
-        hand_ds(h, hnd, i, xi);
-        hand_ds(h, hnd, j, xj);
-        v += k * dot3(xi, xj);
+        const double sc = hand_jtj_scale(h, hnd);
+        if (sc == 0.0 || !hand_on_path(h, hnd, k) || !hand_on_path(h, hnd, d)) continue;
+        double xk[3], xd[3];
+        hand_ds(h, hnd, k, xk);
+        hand_ds(h, hnd, d, xd);
+        v += sc * dot3(xk, xd);
     }
-    cx.em.H(hs::SS + t, pv::S + j, pv::S + i, v);
+    const int hi = k > d ? k : d, lo = k > d ? d : k;
+    cx.em.H(hs::SS + hi * (hi + 1) / 2 + lo, pv::S + hi, pv::S + lo, v);
 }
 
 // --- (s_j, q_l): lanes (j, l) ---------------------------------------------------------------------------------------------------
@@ -415,8 +413,8 @@ template <class Em> HD void t_hess_qq(HCtx<Em>& h, int t) {
 // Only the KINEMATIC part of the pose program runs (joint transforms, forward kinematics, link quantities, composites, contact-point
 // kinematics: none of the rows / Jacobian columns); the Hessian tasks that need no kinematics sit on the waves its first phase leaves idle.
 template <class Em> HD void t_kin_padding(Ctx<Em>& cx, int e) { scratch_padding(cx.s, e); }
-// the 276 joint-pair lanes in two ranges on two waves (five wave iterations on one wave next to an idle one before)
-constexpr int HESS_SS_SPLIT = 3 * 64;
+// the related joint-pair lanes in two ranges on two waves
+constexpr int HESS_SS_SPLIT = 2 * 64;
 template <class Em> HD void t_hess_ss_a(HCtx<Em>& h, int t) { t_hess_ss(h, t); }
 template <class Em> HD void t_hess_ss_b(HCtx<Em>& h, int t) { t_hess_ss(h, t + HESS_SS_SPLIT); }
 #define HIPNLP_POSE_HESS_PROGRAM(KIN, RH, BARRIER)                                                                \
