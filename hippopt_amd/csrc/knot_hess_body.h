@@ -951,8 +951,7 @@ template <class Em> HD void t_kh_qq(KHCtx<Em>& h, int t) {
     const KHessScratch& hx = h.hx;
     const double* lam = h.lam;
     const double sigma = hx.sigma, on = cx.ki.first ? 0.0 : 1.0;
-    int r = 0;
-    while ((r + 1) * (r + 2) / 2 <= t) ++r;
+    const int r = t < 1 ? 0 : (t < 3 ? 1 : (t < 6 ? 2 : 3));   // row of entry t of the packed lower 4 x 4 triangle
     const int c = t - r * (r + 1) / 2;
     const double* qh = s.qn;
     const double inv_n = s.inv_qnorm;

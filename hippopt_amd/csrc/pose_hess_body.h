@@ -347,8 +347,7 @@ template <class Em> HD void t_hess_qq(HCtx<Em>& h, int t) {
     const auto& s = cx.s;
     const double* lam = h.hx.lam;
     const double sigma = h.hx.sigma;
-    int r = 0;
-    while ((r + 1) * (r + 2) / 2 <= t) ++r;
+    const int r = t < 1 ? 0 : (t < 3 ? 1 : (t < 6 ? 2 : 3));   // row of entry t of the packed lower 4 x 4 triangle
     const int c = t - r * (r + 1) / 2;
     double E[9];
     chest_error(s, E);
