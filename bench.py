@@ -448,7 +448,7 @@ def host_visible(eng, x_np, horizon, batch, st=None, model=None):
 def throughput_block(model, device_index):
     """The batch launches beside the headline (never `value`): each kernel's roofline figure from THIS run, HIP events on the launch
     stream, a few dozen launches each.  Periodic N = 100 x 64 and x 1024, the stairs 200 x 16 (BASELINE config 5's whole job on one GPU),
-    the exact Hessian x 64 and on the stairs 200 x 16, the pose finder x 4096.  Synthetic trajectories: one seeded base trajectory + N(0, 0.02^2) per trajectory
+    the exact Hessian x 64 and on the stairs 200 x 16, the pose finder x 4096 with its exact Hessian.  Synthetic trajectories: one seeded base trajectory + N(0, 0.02^2) per trajectory
     (SURVEY §8d), generated in one vectorised draw."""
     import numpy as np
     import torch
@@ -569,6 +569,27 @@ def throughput_block(model, device_index):
         out["pose_B%d" % B] = {"ms_per_launch": ms, "poses_per_s": B / (ms * 1e-3), "poses_per_launch": B, "kernel": "hipnlp_pose_kernel",
                                "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
                                             "algorithmic_bytes": bytes_pose * B, "algorithmic_bytes_per_pose": bytes_pose}}
+        # the pose finder's exact Hessian (the planner that runs IPOPT with it): x, p, lambda in, lower-triangle values out
+        hn = eng.hess_sparsity()[0].size
+        with torch.cuda.stream(stream):
+            ld = torch.from_numpy(np.random.RandomState(1).standard_normal((B, eng.m))).to(dev)
+            sd = torch.ones(B, dtype=torch.float64, device=dev)
+            hv = torch.empty((B, hn), dtype=torch.float64, device=dev)
+        stream.synchronize()
+        hargs = (xd.data_ptr(), sd.data_ptr(), ld.data_ptr(), hv.data_ptr(), stream.cuda_stream)
+        for _ in range(100):
+            eng.eval_hess_device(*hargs)
+        e0.record(stream)
+        for _ in range(reps):
+            eng.eval_hess_device(*hargs)
+        e1.record(stream)
+        stream.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        bytes_h = 8.0 * (eng.n + p.shape[1] + eng.m + hn)
+        gbps = bytes_h * B / (ms * 1e-3) / 1e9
+        out["pose_hessian_B%d" % B] = {"ms_per_launch": ms, "poses_per_s": B / (ms * 1e-3), "poses_per_launch": B, "kernel": "hipnlp_pose_hess_kernel",
+                                       "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
+                                                    "algorithmic_bytes": bytes_h * B, "algorithmic_bytes_per_pose": bytes_h}}
 
     for tag, fn in (("periodic_N100_B64", lambda: callbacks("periodic_N100_B64", periodic_step_settings, 100, 64, 1004)),
                     ("periodic_N100_B1024", lambda: callbacks("periodic_N100_B1024", periodic_step_settings, 100, 1024, 1004)),
