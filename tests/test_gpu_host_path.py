@@ -168,3 +168,37 @@ def test_library_copies_survive_heap_memory_inside_a_stale_registration(model, H
         big.close()
         one.close()
     eng.close()
+
+
+def test_eval_remembers_addresses_per_array_object_not_per_id(model, HipNlp):
+    """HipNlp.eval looks the data address of an argument array up once per array OBJECT (id + weak reference).  Arrays that die and
+    whose ids are handed out again (CPython reuses them at once) must not inherit the dead array's address: the outputs of every call
+    land in the arrays of that call, whatever happened to earlier ones; non-contiguous / non-float64 x still goes through a conversion."""
+    import gc
+    st = periodic_step_settings(12, model)
+    x, p = make_workload(st, model, batch=1, seed=4700)
+    eng, ref = HipNlp(st, model), HipNlp(st, model)
+    for e in (eng, ref):
+        e.set_params(p)
+    ref.set_auto_register(False)
+    want = ref.eval(x)
+    ids = set()
+    for cycle in range(6):
+        out = (np.full(1, np.nan), np.full((1, eng.n), np.nan), np.full((1, eng.m), np.nan), np.full((1, eng.nnz), np.nan))
+        ids.update(id(o) for o in out)
+        xi = x.copy()
+        got = eng.eval(xi, out=out)
+        assert all(g is o for g, o in zip(got, out)) and all(np.array_equal(u, v) for u, v in zip(out, want)), cycle
+        del out, got, xi
+        gc.collect()
+    assert len(ids) < 24       # ids were reused across the cycles (otherwise this test did not exercise what it is about)
+    # x as a strided view and as float32: converted, same values up to the conversion
+    wide = np.zeros((1, 2 * eng.n))
+    wide[:, ::2] = x
+    assert all(np.array_equal(u, v) for u, v in zip(eng.eval(wide[:, ::2]), want))
+    f32 = eng.eval(x.astype(np.float32))
+    assert np.array_equal(f32[0], ref.eval(x.astype(np.float32).astype(np.float64))[0])
+    eng.close()
+    ref.close()
+    with pytest.raises(Exception):
+        eng.eval(x)            # a closed handle is refused, not dereferenced
