@@ -1307,7 +1307,7 @@ template <class Em> HD void t_pkin(Ctx<Em>& cx, int c) {
 template <class Em> HD void t_columns(Ctx<Em>& cx, int t) {
     auto& s = cx.s;
     Em& em = cx.em;
-    const double inv_M = 1.0 / cx.kt.total_mass, inv_mass = 1.0 / cx.gp.mass;
+    const double inv_M = cx.kt.inv_total_mass, inv_mass = 1.0 / cx.gp.mass;
     // totals of the whole tree (every lane needs them; lane 0 publishes them for the row assembly)
     double com[3], klin[3], kang[3], t1[3], t2[3];
     for (int r = 0; r < 3; ++r) { com[r] = s.comp[0][CH + r] * inv_M; klin[r] = s.comp[0][CKL + r]; kang[r] = s.comp[0][CKA + r]; }
@@ -1391,7 +1391,7 @@ template <class Em> HD void t_frame_columns(Ctx<Em>& cx, int j) {
 template <class Em> HD void t_cmm_columns(Ctx<Em>& cx, int t) {
     auto& s = cx.s;
     Em& em = cx.em;
-    const double inv_M = 1.0 / cx.kt.total_mass, inv_mass = 1.0 / cx.gp.mass;
+    const double inv_M = cx.kt.inv_total_mass, inv_mass = 1.0 / cx.gp.mass;
     double com[3], a[3], o[3] = {0.0, 0.0, 0.0}, t1[3], t2[3];
     for (int r = 0; r < 3; ++r) com[r] = s.comp[0][CH + r] * inv_M;
     int i;

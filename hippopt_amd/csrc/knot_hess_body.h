@@ -590,10 +590,10 @@ template <class Em> HD void t_kh_mom0(KHCtx<Em>& h, int) {
     auto& s = cx.s;
     KHessScratch& hx = h.hx;
     const double* c0 = s.comp[0];
-    const double M = cx.kt.total_mass;
+    const double M = 1.0 / cx.kt.inv_total_mass;
     for (int i = 0; i < 3; ++i) hx.mu[i] = -h.lam[gs::CMMC + i] / cx.gp.mass;
     double com[3];
-    for (int i = 0; i < 3; ++i) { com[i] = c0[CH + i] / M; hx.com[i] = com[i]; }
+    for (int i = 0; i < 3; ++i) { com[i] = c0[CH + i] * cx.kt.inv_total_mass; hx.com[i] = com[i]; }
     cross3(com, hx.mu, hx.ell_l);
     cross3(hx.mu, c0 + CKL, hx.muP);
     // L_G = L_O - com x P ;  I_G = I_O - M (|c|^2 1 - c c^T) ;  K = I_G mu
@@ -648,7 +648,7 @@ template <class Em> HD void t_kh_joint_b(KHCtx<Em>& h, int t) {
     const double* cp = s.comp[link];
     // l = [mu; com x mu], formed by every lane itself (t_kh_mom0 runs beside this task, not before it)
     double mu[3], comv[3];
-    for (int i = 0; i < 3; ++i) { mu[i] = -h.lam[gs::CMMC + i] / cx.gp.mass; comv[i] = s.comp[0][CH + i] / cx.kt.total_mass; }
+    for (int i = 0; i < 3; ++i) { mu[i] = -h.lam[gs::CMMC + i] / cx.gp.mass; comv[i] = s.comp[0][CH + i] * cx.kt.inv_total_mass; }
     cross3(comv, mu, ell.l);
     for (int i = 0; i < 3; ++i) ell.a[i] = mu[i];
     inertia6(cp, S, hx.Gm[t]);
@@ -659,7 +659,7 @@ template <class Em> HD void t_kh_joint_b(KHCtx<Em>& h, int t) {
     crf6(S, t2, t3);
     for (int i = 0; i < 3; ++i) { hx.Cv[t].a[i] = t1.a[i] - t3.a[i]; hx.Cv[t].l[i] = t1.l[i] - t3.l[i]; }
     double dcv[3];
-    for (int i = 0; i < 3; ++i) dcv[i] = hx.Gm[t].l[i] / cx.kt.total_mass;
+    for (int i = 0; i < 3; ++i) dcv[i] = hx.Gm[t].l[i] * cx.kt.inv_total_mass;
     cross3(dcv, mu, hx.dcmu[t]);
 }
 
@@ -675,7 +675,7 @@ template <class Em> HD void t_kh_Y(KHCtx<Em>& h, int j) {
     double Y[3] = {0.0, 0.0, 0.0}, t1[3], t2[3];
     {
         const double* cp = s.comp[j + 1];
-        const double inv_M = 1.0 / cx.kt.total_mass;
+        const double inv_M = cx.kt.inv_total_mass;
         for (int r = 0; r < 3; ++r) t1[r] = (cp[CH + r] - cp[CM] * o[r]) * inv_M;
         cross3(a, t1, t2);
         double mu[3], muP[3];   // mu x P, formed here (t_kh_mom0 runs beside this task)

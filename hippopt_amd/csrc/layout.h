@@ -436,14 +436,15 @@ struct Layout {
             if (!(an > 0.999999 && an < 1.000001)) { err = "robot model: joint axes must be unit vectors"; return false; }
             for (int i = 0; i < 9; ++i) kt.jf.R_fix[j][i] = md.R_fix[j][i];
         }
-        kt.total_mass = 0;
+        double total_mass = 0;
         for (int l = 0; l < NL; ++l) {
             kt.li.mass[l] = md.mass[l];
-            kt.total_mass += md.mass[l];
+            total_mass += md.mass[l];
             for (int i = 0; i < 3; ++i) kt.li.com[l][i] = md.com[l][i];
             for (int i = 0; i < 9; ++i) kt.li.inertia[l][i] = md.inertia[l][i];
         }
-        if (!(kt.total_mass > 0)) { err = "robot model: total mass must be positive"; return false; }
+        if (!(total_mass > 0)) { err = "robot model: total mass must be positive"; return false; }
+        kt.inv_total_mass = 1.0 / total_mass;
         for (int j = 0; j < NJ; ++j) { kt.leg_pos[0][j] = kt.leg_pos[1][j] = kt.chest_pos[j] = -1; }
         for (int f = 0; f < 3; ++f) {
             kt.frame_link[f] = md.frame_link[f];

@@ -258,7 +258,7 @@ template <class Em> HD void t_hess_Y(HCtx<Em>& h, int j) {
     double Y[3] = {0.0, 0.0, 0.0}, t1[3], t2[3];
     {   // com: d com / d s_j = a_j x (h_sub - m_sub o_j) / M
         const double* cp = s.comp[j + 1];
-        const double inv_M = 1.0 / cx.kt.total_mass;
+        const double inv_M = cx.kt.inv_total_mass;
         for (int r = 0; r < 3; ++r) t1[r] = (cp[CH + r] - cp[CM] * o[r]) * inv_M;
         cross3(a, t1, t2);
         const double w[3] = {-lam[gs::COMC], -lam[gs::COMC + 1], -lam[gs::COMC + 2]};
@@ -358,7 +358,7 @@ template <class Em> HD void t_hess_qq(HCtx<Em>& h, int t) {
     double Mw[9], M[9];
     for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b) {
-            double acc = -lam[gs::COMC + a] * (s.comp[0][CH + b] / cx.kt.total_mass) + m2 * e * E[3 * b + a];   // com = first moment of the whole tree / mass
+            double acc = -lam[gs::COMC + a] * (s.comp[0][CH + b] * cx.kt.inv_total_mass) + m2 * e * E[3 * b + a];   // com = first moment of the whole tree / mass
             for (int p = 0; p < NC; ++p) acc += -lam[gs::PT_STRIDE * p + gs::KINC + a] * s.pkin[p][b];
             Mw[3 * a + b] = acc;
         }
