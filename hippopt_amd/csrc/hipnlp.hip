@@ -45,6 +45,11 @@ constexpr int GS_PAD = (gs::COUNT + 511) / 512 * 512, JS_PAD = (js::COUNT + 511)
 // the smooth steps; tests/test_constant_jacobian.py) — rounded up to whole workgroups of 512: the trip count of its copy-out.
 constexpr int vary_cap(int terrain, int wg) { return terrain == HIPNLP_TERRAIN_PLANAR ? 1024 : (wg == 256 ? 1280 : 1536); }
 constexpr int VCAP_MAX = 1536;
+// Entries of the thread-major copy-out tables (jperm_t, jpermv_t, the g_b half of gab_t) carry COPY_EARLY when their native slot gets its
+// value in the first two phases of the knot program (Layout::jslot_phase / gslot_phase: recorded, not declared): the eight-wave kernel of
+// a launch into HOST memory stores those behind the second barrier — 42 % of a knot's bytes start over the link while the kinematic
+// phases still run — and leaves them out of the copy-out at the end.
+constexpr int32_t COPY_EARLY = 1 << 30, COPY_SLOT = COPY_EARLY - 1;
 struct DeviceTables {
     HeadTables head;
     int32_t g_a[3][GS_PAD];
@@ -91,7 +96,7 @@ struct KArgs {
     int32_t* flag_host;     // [batch] or null: the same flag in pinned host memory (host-buffer path: a plain store of seq — every
                             //         writer of a launch stores the same value, launches of a handle are stream ordered — so the
                             //         host needs no copy of the device flag behind the launch)
-    int32_t seq, pad_;      // launch number of this handle (1, 2, ...)
+    int32_t seq, early;     // launch number of this handle (1, 2, ...); early: outputs go to host memory — what is final after the second phase leaves then
     int32_t N, n, m, nnz, knot_begin, nk;
     int64_t jac_stride, jac_off, grad_stride, grad_off;  // output addressing: full arrays (stride nnz / n, offset 0) or shard-local
     // peer mode (hipnlp_eval_device_peers; batch 1): instead of g / jac / grad / f above, the shard's values go — at their FINAL positions —
@@ -465,16 +470,46 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 #else
 #define DEV_R(w4, w8, fn, nt) if constexpr ((WAVES == 4 ? (w4) : (w8)) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #endif
+    // Early copy-out (eight-wave kernel, launches into host memory: a.early): behind the second barrier every thread stores those of ITS
+    // entries of g and jac g whose slot is final by then (COPY_EARLY in its table words) — a third of jac g's varying entries and five rows
+    // of g in six: 4.2 of a knot's 10.1 KB are on the link three microseconds before the program ends.  The copy-out at the end skips them
+    // (its non-finite check still reads every slot).
+    // (compiled into EVERY eight-wave instantiation, the peer-store ones too, whose launches never set a.early: with the hook in some and not in
+    //  others the compiler contracted a few multiply-adds of the smooth-terrain tasks differently — last-bit differences between kernels whose
+    //  outputs the peer exchange checks bit for bit against the all-gather path)
+    constexpr bool EARLY_OUT = WAVES == 8;
+    // A store the COMPILER does not know about (inline assembly): behind an ordinary store it puts `s_waitcnt vmcnt(0)` in front of the
+    // next LDS access (this kernel has used LDS-direct loads, and the counter is shared), i.e. the wave would sit out the round trip of its
+    // early stores over PCIe at the next barrier — measured: no gain at all.  Nothing here waits for these stores; waits the compiler
+    // places for its own later loads can only wait longer (the counter is in order).  base: uniform; byte_off < 2^31.
+    auto store_unwaited = [](double* base, int byte_off, double v) __attribute__((always_inline)) {
+        asm volatile("global_store_dwordx2 %0, %1, %2 sc0 sc1" ::"v"(byte_off), "v"(v), "s"(base) : "memory");   // (system scope: written through the L2)
+    };
+    const bool early_on = EARLY_OUT && a.early != 0;
+    auto early_out = [&]() __attribute__((always_inline)) {
+        if (!early_on) return;
+        if (a.jac) {
+            const int64_t jb0 = first ? 0 : int64_t(nnz_first) + int64_t(k - 1) * nnz_interior;
+            double* out = a.jac + int64_t(b) * a.jac_stride + (jb0 - a.jac_off);
+#pragma unroll
+            for (int it = 0; it < JP_ITERS; ++it) if (jp[it] >= 0 && (jp[it] & COPY_EARLY)) store_unwaited(out, (tid + it * WG) * 8, em.jac[jp[it] & COPY_SLOT]);
+        }
+        if (a.g) {
+            double* out = a.g + size_t(b) * a.m;
+#pragma unroll
+            for (int it = 0; it < G_ITERS; ++it) if (ga[it] != G_NONE && (gb[it] & COPY_EARLY)) store_unwaited(out, (ga[it] + (gb[it] & COPY_SLOT) * k) * 8, s.g_at(tid + it * WG));
+        }
+    };
 #ifdef HIPNLP_STAMPS
     // diagnostic build: every wave keeps, IN REGISTERS, its arrival time at each barrier and the time it leaves it; one store
     // per wave at the very end (a store before a barrier would make the barrier wait for its acknowledgement).
     unsigned long long st_arr[8], st_dep[8];
     const unsigned long long st_staged = __builtin_amdgcn_s_memtime();
     int bid = 0;
-#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); if constexpr (W == PUBW) pub_step(bid); bid++;
+#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); if constexpr (W == PUBW) pub_step(bid); if constexpr (EARLY_OUT) { if (bid == 1) early_out(); } bid++;
 #else
     int bid = 0;
-#define DEV_BARRIER lds_barrier(); if constexpr (W == PUBW) pub_step(bid); if constexpr (LATE_TABLES) { if (bid == 4) fetch_tables(); } bid++;
+#define DEV_BARRIER lds_barrier(); if constexpr (W == PUBW) pub_step(bid); if constexpr (LATE_TABLES) { if (bid == 4) fetch_tables(); } if constexpr (EARLY_OUT) { if (bid == 1) early_out(); } bid++;
 #endif
     auto run_wave = [&](auto wc) __attribute__((always_inline)) {
         constexpr int W = decltype(wc)::value;
@@ -514,7 +549,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     double jvals[JP_ITERS], gvals[G_ITERS], grvals[GR_ITERS];
     // (unconditional, clamped indices, no branch: every LDS read of the copy-out is in flight before the first wait)
 #pragma unroll
-    for (int it = 0; it < JP_ITERS; ++it) jvals[it] = em.jac[jp[it] >= 0 ? jp[it] : Em::kJacOff];
+    for (int it = 0; it < JP_ITERS; ++it) jvals[it] = em.jac[jp[it] >= 0 ? (jp[it] & COPY_SLOT) : Em::kJacOff];
 #pragma unroll
     for (int it = 0; it < G_ITERS; ++it) gvals[it] = s.g_at((tid + it * WG) < gs::COUNT ? tid + it * WG : 0);
 #pragma unroll
@@ -550,7 +585,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             if (last && tid < n_glob) base[o_jac + int64_t(jac_glob_base) + tid] = s.jac[jpg];
             double* og = base + o_g;
 #pragma unroll
-            for (int it = 0; it < G_ITERS; ++it) if (ga[it] != G_NONE) og[ga[it] + gb[it] * k] = gvals[it];
+            for (int it = 0; it < G_ITERS; ++it) if (ga[it] != G_NONE) og[ga[it] + (gb[it] & COPY_SLOT) * k] = gvals[it];
             double* ogr = base + int64_t(NXK) * k;
 #pragma unroll
             for (int it = 0; it < GR_ITERS; ++it) { const int i = tid + it * WG; if (i < NXK) ogr[i] = grvals[it]; }
@@ -560,14 +595,14 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     if (a.jac) {
         double* out = a.jac + int64_t(b) * a.jac_stride + (jbase - a.jac_off);
 #pragma unroll
-        for (int it = 0; it < JP_ITERS; ++it) if (jp[it] >= 0) out[tid + it * WG] = jvals[it];
+        for (int it = 0; it < JP_ITERS; ++it) if (jp[it] >= 0 && !(early_on && (jp[it] & COPY_EARLY))) out[tid + it * WG] = jvals[it];
         // entries in the horizon-global columns (constants) sit right behind the last knot's block: the last knot writes them
         if constexpr (!VARY) { if (last && tid < n_glob) a.jac[int64_t(b) * a.jac_stride + (int64_t(jac_glob_base) - a.jac_off) + tid] = s.jac[jpg]; }
     }
     if (a.g) {
         double* out = a.g + size_t(b) * a.m;
 #pragma unroll
-        for (int it = 0; it < G_ITERS; ++it) if (ga[it] != G_NONE) out[ga[it] + gb[it] * k] = gvals[it];
+        for (int it = 0; it < G_ITERS; ++it) if (ga[it] != G_NONE && !(early_on && (gb[it] & COPY_EARLY))) out[ga[it] + (gb[it] & COPY_SLOT) * k] = gvals[it];
     }
     if (a.g_stage) {
         double* out = a.g_stage + (size_t(b) * a.nk + kk) * gs::COUNT;
@@ -916,6 +951,8 @@ struct hipnlp_handle {
     bool wide = false;   // eight-wave kernel variant (launches that are resident at once at two workgroups per CU)
     bool fused = false;  // the total cost is summed inside the knot launch by one reducer workgroup per trajectory (knots <= 256)
     hipnlp_dims dims{};         // hipnlp_get_dims, filled by hipnlp_create
+    bool early_store_always = false;   // diagnostic (HIPNLP_EARLY_STORE=2): also for hipnlp_eval_device launches
+    bool early_store = true;    // launches into host memory store what is final after the second phase then (diagnostic override: HIPNLP_EARLY_STORE=0)
     bool hess_compact = false;   // exact Hessian: compact-scratch instantiation (three workgroups per CU) for launches of more than 512 workgroups
     int dev = 0;
     hipStream_t stream = nullptr;
@@ -1102,6 +1139,7 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
         return fail(HIPNLP_E_INVALID, h->L.error);
     if (const char* cj = std::getenv("HIPNLP_CONST_JAC")) h->skip_const = std::atoi(cj) != 0;   // diagnostic override of hipnlp_set_constant_jacobian's default
     if (const char* vc = std::getenv("HIPNLP_VARY_CHECK")) h->vary_check = std::atoi(vc) != 0;
+    if (const char* es = std::getenv("HIPNLP_EARLY_STORE")) { h->early_store = std::atoi(es) != 0; h->early_store_always = std::atoi(es) == 2; }   // diagnostic override (A/B in one process)
     h->np = ParamOffsets(st.horizon).np();
     if (h->L.jperm_glob.size() > 16) return fail(HIPNLP_E_INVALID, "internal: too many global-column entries");
 
@@ -1176,10 +1214,14 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
         const int wg = h->wide ? 512 : 256, jt = JS_PAD / wg, gt = GS_PAD / wg;
         for (int v = 0; v < 3; ++v)
             for (int t = 0; t < wg; ++t) {
-                for (int it = 0; it < jt; ++it) tb->jperm_t[v][t * jt + it] = tb->jperm[v][t + it * wg];
+                for (int it = 0; it < jt; ++it) {
+                    const int32_t slot = tb->jperm[v][t + it * wg];
+                    tb->jperm_t[v][t * jt + it] = slot >= 0 && h->L.jslot_phase[size_t(slot)] <= 1 ? (slot | COPY_EARLY) : slot;
+                }
                 for (int it = 0; it < gt; ++it) {
-                    tb->gab_t[v][2 * (t * gt + it)] = tb->g_a[v][t + it * wg];
-                    tb->gab_t[v][2 * (t * gt + it) + 1] = tb->g_b[t + it * wg];
+                    const int gslot = t + it * wg;
+                    tb->gab_t[v][2 * (t * gt + it)] = tb->g_a[v][gslot];
+                    tb->gab_t[v][2 * (t * gt + it) + 1] = tb->g_b[gslot];   // (the rows of g stay with the copy-out at the end: their runs are 24 - 192 B, and written through the L2 one by one they cost more link time than the early start saves — measured: g alone 11.9 -> 21 us)
                 }
             }
     }
@@ -1199,7 +1241,10 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
         }
         if (h->vary_ok)
             for (int v = 0; v < 3; ++v)
-                for (int i = 0; i < h->L.nvary_v[v]; ++i) tb->jpermv_t[v][(i % wg) * jt + i / wg] = h->L.jperm[v][size_t(i)];
+                for (int i = 0; i < h->L.nvary_v[v]; ++i) {
+                    const int32_t slot = h->L.jperm[v][size_t(i)];
+                    tb->jpermv_t[v][(i % wg) * jt + i / wg] = h->L.jslot_phase[size_t(slot)] <= 1 ? (slot | COPY_EARLY) : slot;
+                }
     }
     hipError_t ce = hipnlp_internal_memcpy(h->d_tb, tb, sizeof(DeviceTables), hipMemcpyHostToDevice);
     if (ce == hipSuccess) ce = hipMalloc(&h->d_healed, sizeof(int32_t));
@@ -1437,6 +1482,9 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     // host-buffer path: per-term costs (96 B per trajectory) and the non-finite flag go straight to the pinned block
     a.cost_terms = host_block ? h->hd_cost_terms : h->d_cost_terms;
     a.flag_host = host_block ? h->hd_flag : nullptr;
+    // (only launches that store the varying RUN of every block: written through the L2, the early entries of a CCS-ordered block are isolated
+    //  doubles on the link — measured 49 -> 258 us per 100-knot call)
+    a.early = ((host_block && h->early_store) || h->early_store_always) && vary_only ? 1 : 0;
     if (h->seq == INT32_MAX) {
         // the launch number tags the cost partials and is the generation of the non-finite flags: before it would wrap (2^31 launches:
         // hours of back-to-back 100-knot callbacks) everything that carries one starts over
@@ -1450,7 +1498,7 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
         h->seq_result = -1;
         h->have_result = false;
     }
-    a.seq = ++h->seq; a.pad_ = 0;
+    a.seq = ++h->seq;
     a.N = h->L.N; a.n = h->L.n; a.m = h->L.m; a.nnz = h->L.nnz; a.knot_begin = h->kb; a.nk = h->nk;
     bool prof = false, run_first = false, run_last = false;
     if (h->prof_cap > 0 && h->prof_run > 0) {        // runs of consecutive launches: one event before the first, one after the last

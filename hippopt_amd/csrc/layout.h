@@ -58,8 +58,12 @@ struct RecordEm {
     int* hrow = nullptr;   // [hs::COUNT] Hessian slots (pose_hess_body.h): row / column variable or -1
     int* hcol = nullptr;
     void H(int slot, int row, int col, double) { if (hrow[slot] != -1) *dup = true; hrow[slot] = row; hcol[slot] = col; }
-    void G(int slot, int rid, double) { if (grow[slot] != -1) *dup = true; grow[slot] = rid; }
-    void J(int slot, int rid, int col, double) { if (jrowid[slot] != -1) *dup = true; jrowid[slot] = rid; jcol[slot] = col; }
+    void G(int slot, int rid, double) { if (grow[slot] != -1) *dup = true; grow[slot] = rid; if (gphase) gphase[slot] = (unsigned char)phase; }
+    void J(int slot, int rid, int col, double) { if (jrowid[slot] != -1) *dup = true; jrowid[slot] = rid; jcol[slot] = col; if (jphase) jphase[slot] = (unsigned char)phase; }
+    // the phase of the knot program (barriers passed) in which a slot gets its value: what is final after the second phase can leave early
+    int phase = 0;
+    unsigned char* gphase = nullptr;   // [gs::COUNT] or null
+    unsigned char* jphase = nullptr;   // [js::COUNT] or null
     // an entry that does not depend on x (knot_body.h, emit_jc): the slot is marked constant and its value kept (a pass over the
     // program with the handle's own parameters, Layout::constant_values, reads it back)
     unsigned char* jconst = nullptr;   // [js::COUNT] or null
@@ -120,6 +124,7 @@ struct Layout {
     // vary_first (HIPNLP_FLAG_JAC_VARYING_FIRST): a knot's block lists its varying entries first — the kernel's stores into a host
     // array whose constants were filled once are then ONE contiguous run per knot.  IPOPT takes triplets in any order.
     bool vary_first = false;
+    std::vector<unsigned char> gslot_phase, jslot_phase;   // [gs::COUNT], [js::COUNT]: phase of the knot program in which the slot gets its value (255: never)
     std::vector<unsigned char> jconst_slot;
     std::vector<unsigned char> jconst_pos[3];
     int nvary_v[3] = {0, 0, 0};
@@ -261,9 +266,15 @@ struct Layout {
             KnotInfo ki{0, N, 1, 1};
             RecordEm em{grow.data(), jrid.data(), jc.data(), &dup};
             em.jconst = jconst_slot.data();
+            gslot_phase.assign(gs::COUNT, 255);
+            jslot_phase.assign(js::COUNT, 255);
+            em.gphase = gslot_phase.data();
+            em.jphase = jslot_phase.data();
             Ctx<RecordEm> cx(*s, kt, ks, gp, ki, em);
 #define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
-            HIPNLP_KNOT_PROGRAM(HOST_R, )
+#define HOST_BAR cx.em.phase++;
+            HIPNLP_KNOT_PROGRAM(HOST_R, HOST_BAR)
+#undef HOST_BAR
 #undef HOST_R
             delete s;
         }

@@ -128,6 +128,9 @@ template <int LAYOUT> static int eval_compact(const hostemu_handle* h, const dou
     return 0;
 }
 
+// entries of jac g that the eight-wave kernel of a launch into host memory stores behind the SECOND barrier (Layout::jslot_phase <= 1)
+// and whose staged value at that point is not the final one, counted over the knots of the last wave-order evaluation
+static long g_early_violations = 0;
 template <int WAVES, int TERRAIN> static int eval_wave_order_t(const hostemu_handle* h, const double* x, const double* p, int order, double* f, double* grad, double* g,
                                                                double* jac, double* cost_terms) {
     constexpr int waves = WAVES;
@@ -162,7 +165,9 @@ template <int WAVES, int TERRAIN> static int eval_wave_order_t(const hostemu_han
 #define HIPNLP_W4(a, b) (planar_rt ? (a) : (b))
 #define HIPNLP_W8(a, b) (planar_rt ? (a) : (b))
 #define HOST_R(w4, w8, fn, nt) { const int w_ = waves == 4 ? (w4) : (w8); if (w_ >= 0) groups.push_back({w_, [&cx]() { for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_); }}); }
-#define HOST_BARRIER flush();
+        int barriers = 0;
+        std::vector<double> snap(js::COUNT);
+#define HOST_BARRIER flush(); if (++barriers == 2) std::memcpy(snap.data(), s->jac, sizeof(double) * js::COUNT);
         HIPNLP_KNOT_PROGRAM(HOST_R, HOST_BARRIER)
 #undef HOST_R
 #undef HOST_BARRIER
@@ -171,6 +176,11 @@ template <int WAVES, int TERRAIN> static int eval_wave_order_t(const hostemu_han
         flush();
         const int v = L.variant_of(k);
         const long jb = L.jac_base(k);
+        if (k == 0) g_early_violations = 0;
+        for (int i = 0; i < L.nnz_v[v]; ++i) {
+            const int slot = L.jperm[v][size_t(i)];
+            if (L.jslot_phase[size_t(slot)] <= 1 && std::memcmp(&snap[size_t(slot)], &s->jac[slot], sizeof(double)) != 0) g_early_violations++;
+        }
         for (int i = 0; i < L.nnz_v[v]; ++i) jac[jb + i] = s->jac[L.jperm[v][size_t(i)]];
         if (k == N - 1) for (size_t i = 0; i < L.jperm_glob.size(); ++i) jac[L.jac_glob_base + long(i)] = s->jac[L.jperm_glob[i]];
         for (int slot = 0; slot < gs::COUNT; ++slot) {
@@ -190,6 +200,7 @@ template <int WAVES, int TERRAIN> static int eval_wave_order_t(const hostemu_han
 
 extern "C" {
 void hostemu_set_wave_order(int order) { g_wave_order = order; }
+long hostemu_early_violations(void) { return g_early_violations; }
 
 hostemu_handle* hostemu_create(const hipnlp_desc* desc, char* err, int errlen) {
     hostemu_handle* h = new hostemu_handle();
@@ -290,6 +301,21 @@ void hostemu_constant_fill(const hostemu_handle* h, const double* p, double pois
 void hostemu_vary_counts(const hostemu_handle* h, int* nvary /*[3]*/, int* nnz_v /*[3]*/, int* nconst_total) {
     for (int v = 0; v < 3; ++v) { nvary[v] = h->L.nvary_v[v]; nnz_v[v] = h->L.nnz_v[v]; }
     *nconst_total = h->L.nconst_total;
+}
+// phase of the knot program (barriers passed) in which every entry of jac g (pattern order) and every row of g gets its value
+void hostemu_output_phases(const hostemu_handle* h, unsigned char* jac_phase /*[nnz]*/, unsigned char* g_phase /*[m]*/) {
+    const Layout& L = h->L;
+    for (int i = 0; i < L.nnz; ++i) jac_phase[i] = 255;
+    for (int i = 0; i < L.m; ++i) g_phase[i] = 255;
+    for (int k = 0; k < L.N; ++k) {
+        const int v = L.variant_of(k);
+        for (int i = 0; i < L.nnz_v[v]; ++i) jac_phase[L.jac_base(k) + i] = L.jslot_phase[size_t(L.jperm[v][size_t(i)])];
+        for (int slot = 0; slot < gs::COUNT; ++slot) {
+            const int a = L.g_a[v][size_t(slot)];
+            if (a != G_NONE) g_phase[a + L.g_b[size_t(slot)] * k] = L.gslot_phase[size_t(slot)];
+        }
+    }
+    for (size_t i = 0; i < L.jperm_glob.size(); ++i) jac_phase[L.jac_glob_base + long(i)] = L.jslot_phase[size_t(L.jperm_glob[i])];
 }
 void hostemu_bounds(const hostemu_handle* h, const double* p, double* lbg, double* ubg) { h->L.bounds(p, nullptr, nullptr, lbg, ubg); }
 void hostemu_bounds_x(const hostemu_handle* h, const double* p, double* lbx, double* ubx) { h->L.bounds(p, lbx, ubx, nullptr, nullptr); }

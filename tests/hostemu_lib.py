@@ -70,6 +70,17 @@ class HostEmu:
         self.lib.hostemu_vary_counts(C.c_void_p(self.h), a, b, C.byref(c))
         return list(a), list(b), c.value
 
+    def early_violations(self):
+        """entries marked final after the second phase whose staged value changed later, in the last wave-order evaluation"""
+        self.lib.hostemu_early_violations.restype = C.c_long
+        return int(self.lib.hostemu_early_violations())
+
+    def output_phases(self):
+        """phase of the knot program (barriers passed) in which every entry of jac g (pattern order) / every row of g gets its value"""
+        jp, gp = np.zeros(self.nnz, np.uint8), np.zeros(self.m, np.uint8)
+        self.lib.hostemu_output_phases(C.c_void_p(self.h), jp.ctypes.data_as(C.c_void_p), gp.ctypes.data_as(C.c_void_p))
+        return jp, gp
+
     def bounds(self, p):
         lb, ub = np.zeros(self.m), np.zeros(self.m)
         self.lib.hostemu_bounds(C.c_void_p(self.h), _dp(np.ascontiguousarray(p)), _dp(lb), _dp(ub))

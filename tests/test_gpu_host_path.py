@@ -202,3 +202,44 @@ def test_eval_remembers_addresses_per_array_object_not_per_id(model, HipNlp):
     ref.close()
     with pytest.raises(Exception):
         eng.eval(x)            # a closed handle is refused, not dereferenced
+
+
+@pytest.mark.parametrize("terrain", ["planar", "stairs"])
+def test_early_copy_out_of_the_host_path_changes_no_bit(model, HipNlp, terrain):
+    """A varying-first handle's launches into host memory store the entries of jac g that are final after the second phase of the knot
+    program behind that phase's barrier (written through the L2, so that they cross the link while the kinematic phases run) and leave
+    them out of the copy-out at the end.  Which entries those are is RECORDED from the knot program (Layout::jslot_phase), not declared:
+    a slot that got its value later than recorded would leave with a stale value.  Every output of every call must be bit for bit what
+    the handle without the early pass gives (HIPNLP_EARLY_STORE=0, read by hipnlp_create) — plain arrays (pinned block) and arrays the
+    handle has registered (direct stores), all four outputs and jac alone."""
+    import os
+    from hippopt_amd.kinodyn_settings import stairs_settings
+    from hippopt_amd.synthetic import place_on_step_flanks
+    st = (stairs_settings if terrain == "stairs" else periodic_step_settings)(45, model)
+    x, p = make_workload(st, model, batch=1, seed=4800)
+    if terrain == "stairs":
+        place_on_step_flanks(x, st, seed=4800)
+    engs = []
+    for flag in ("1", "0"):
+        os.environ["HIPNLP_EARLY_STORE"] = flag
+        try:
+            engs.append(HipNlp(st, model, jac_varying_first=True))
+        finally:
+            del os.environ["HIPNLP_EARLY_STORE"]
+        engs[-1].set_params(p)
+    early, plain = engs
+    outs = [(np.empty(1), np.empty((1, e.n)), np.empty((1, e.m)), np.empty((1, e.nnz))) for e in engs]
+    xs = iterates(x, 5)
+    for i, xi in enumerate(xs):
+        for e, out in zip(engs, outs):
+            e.eval(xi, out=out)                      # (first call: pinned block; from the second on: the registered arrays)
+        assert all(np.array_equal(u, v) for u, v in zip(*outs)), i
+    assert early.host_stats()["auto_ranges"] == plain.host_stats()["auto_ranges"] == 3
+    for i, xi in enumerate(xs):                      # jac g alone, into the registered arrays and into fresh ones
+        for e, out in zip(engs, outs):
+            e.eval(xi + 1e-4, want=("jac",), out=(None, None, None, out[3]))
+        assert np.array_equal(outs[0][3], outs[1][3]), i
+        ja, jb = (e.eval(xi - 1e-4, want=("jac",))[3] for e in engs)
+        assert np.array_equal(ja, jb), i
+    for e in engs:
+        e.close()

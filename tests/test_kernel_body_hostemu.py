@@ -333,6 +333,11 @@ def test_groups_of_one_phase_on_different_waves_do_not_depend_on_each_other(mode
         assert got[0] == ref[0], (order, got[0], ref[0])
         for a, b, name in zip(got[1:], ref[1:], ("grad", "g", "jac", "cost terms")):
             assert np.array_equal(a, b), (order, name, int(np.argmax(a != b)))
+        # the entries of jac g recorded as final after the second phase (what a launch into host memory stores early) ARE final there,
+        # in this column of the program table and whatever the order of the waves
+        assert e.early_violations() == 0, (order, e.early_violations())
+    jp, gp = e.output_phases()
+    assert jp.max() <= 5 and (jp <= 1).sum() > 0.25 * jp.size and gp.max() <= 5     # every entry has a phase; a good part is early
 
 
 @pytest.mark.parametrize("terrain", ["planar", "stairs"])
