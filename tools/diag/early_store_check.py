@@ -16,12 +16,13 @@ from hippopt_amd.synthetic import make_workload, place_on_step_flanks  # noqa: E
 model = synthetic_ergocub()
 for name, maker in (("periodic", periodic_step_settings), ("stairs", stairs_settings)):
     for vf in (False, True):
-        st = maker(24, model)
-        x, p = make_workload(st, model, batch=1, seed=91)
+        B = int(os.environ.get("CHECK_BATCH", "1"))
+        st = maker(int(os.environ.get("CHECK_N", "24")), model)
+        x, p = make_workload(st, model, batch=B, seed=91)
         engs = []
         for e in ("1", "0"):
             os.environ["HIPNLP_EARLY_STORE"] = e
-            engs.append(HipNlp(st, model, jac_varying_first=vf))
+            engs.append(HipNlp(st, model, batch=B, jac_varying_first=vf))
             engs[-1].set_params(p)
         del os.environ["HIPNLP_EARLY_STORE"]
         x = x + 1e-2 * np.random.RandomState(3).standard_normal(x.shape)
