@@ -62,6 +62,7 @@ struct PArgs {
 
 template <int TERRAIN> struct PoseEm {
     static constexpr int kTerrain = TERRAIN;
+    using Scratch = KnotScratchT<LAYOUT_COMPACT, js::PV0 + NC * js::pt_stride(TERRAIN == HIPNLP_TERRAIN_PLANAR)>;   // (PoseScratchT below)
     double* g;
     double* jac;
     __device__ __forceinline__ void G(int slot, int, double v) { g[slot] = v; }
@@ -70,6 +71,7 @@ template <int TERRAIN> struct PoseEm {
 
 template <int TERRAIN> struct PoseHessEm {
     static constexpr int kTerrain = TERRAIN;
+    using Scratch = KnotScratchT<LAYOUT_COMPACT, js::PV0 + NC * js::pt_stride(TERRAIN == HIPNLP_TERRAIN_PLANAR)>;
     double* g;
     double* jac;
     double* h;
@@ -78,55 +80,83 @@ template <int TERRAIN> struct PoseHessEm {
     __device__ __forceinline__ void H(int slot, int, int, double v) { h[slot] = v; }
 };
 
-struct PoseShared {
-    HeadTables head;
-    GParams gp;
-    PoseHands hands;   // (208 B; read by several task groups of both kernels: an LDS copy, not a global load per use)
-};
-static_assert(sizeof(PoseHands) % 8 == 0 && sizeof(PoseHands) / 8 <= WG, "staged as 8-byte words, one per thread");
+// LDS of a pose workgroup: the COMPACT knot scratch (knot_body.h: own[] on the joint records, which are dead once the forward kinematics
+// has read them) with the Jacobian staging cut to the slots a kernel of its terrain can touch, and the LITE tables of the four-wave
+// callback kernels (the joint frames and link inertials, read once per pose, come from global memory) instead of the whole HeadTables:
+// 38.5 KB on the planar terrain, 40.8 KB on the smooth steps (52.8 KB before) -> FOUR workgroups per CU (LDS is handed out in granules
+// of 1 280 B: 32 granules each).
+constexpr int pose_jslots(int terrain) { return js::PV0 + NC * js::pt_stride(terrain == HIPNLP_TERRAIN_PLANAR); }
+template <int TERRAIN> using PoseScratchT = KnotScratchT<LAYOUT_COMPACT, pose_jslots(TERRAIN)>;
+static_assert(pose_jslots(HIPNLP_TERRAIN_SMOOTH_STEPS) == js::COUNT && pose_jslots(HIPNLP_TERRAIN_PLANAR) != js::vary_slots(false), "pose scratch: hd[] (the hand buffer) must exist");
+
+// the hand tables (224 B; read by several task groups of both kernels: an LDS copy, not a global load per use): in the tables block, or —
+// smooth terrain, whose scratch keeps the periodicity variables xo[] no pose task reads — on top of those (the 224 B that keep the
+// workgroup inside 32 granules)
+template <bool OWN_HANDS> struct PoseSharedT;
+// (bad: the workgroup's non-finite vote — a word here instead of __syncthreads_or, whose reduction brings 256 B of LDS of its own)
+template <> struct alignas(16) PoseSharedT<true> { KSettings ks; KinLite kt; GParamsLite gp; PoseHands hands; int32_t bad, pad_[3]; };
+template <> struct alignas(16) PoseSharedT<false> { KSettings ks; KinLite kt; GParamsLite gp; int32_t bad, pad_[3]; };
+// every wave ORs its vote into tabs.bad (cleared by pose_stage); returns the workgroup's vote in every thread
+template <class T> __device__ __forceinline__ int pose_vote(T& tabs, int bad, int lane) {
+    if (__any(bad) && lane == 0) tabs.bad = 1;   // (all writers store the same value)
+    __syncthreads();
+    return tabs.bad;
+}
+static_assert(sizeof(PoseHands) % 8 == 0 && sizeof(PoseHands) <= sizeof(double) * NPER, "staged as 8-byte words; fits on xo[]");
+template <class S, class T> __device__ __forceinline__ PoseHands* pose_hands(S& s, T& tabs) {
+    if constexpr (S::trimmed) return &tabs.hands;
+    else return reinterpret_cast<PoseHands*>(s.xo);
+}
 
 // workgroup barrier that orders LDS traffic only (see hipnlp.hip): the copy-out tables prefetched into registers stay in flight across it
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // tables, parameters and the pose's variables -> LDS (ends with a workgroup barrier)
-__device__ __forceinline__ void pose_stage(const PArgs& a, KnotScratch& s, PoseShared& tabs, int b, int tid) {
+template <class S, class T> __device__ __forceinline__ void pose_stage(const PArgs& a, S& s, T& tabs, int b, int tid) {
     const PoseTables& tb = *a.tb;
-    // every global load in flight before the first LDS store waits for one (see hipnlp_knot_kernel)
-    constexpr int HV = int(sizeof(HeadTables) / 16), HV_ITERS = (HV + WG - 1) / WG;
-    constexpr int GV = int(sizeof(GParams) / 8), GV_ITERS = (GV + WG - 1) / WG;
-    static_assert(XPAD <= WG && PK_STRIDE <= WG && POSE_NX <= WG && POSE_MAX_NNZ % WG == 0, "one record word per thread");
-    const uint4* hsrc = reinterpret_cast<const uint4*>(&tb.head);
-    const double* gsrc = reinterpret_cast<const double*>(a.gp + b);
-    uint4 hv[HV_ITERS];
-    double gv[GV_ITERS];
+    // every global load in flight before the first LDS store waits for one (see hipnlp_knot_kernel).  Four pieces, as 8-byte words:
+    // settings | lite kinematic tables (the KinLite prefix of the full ones) | lite parameters of this pose | hand tables
+    constexpr int W0 = int(sizeof(KSettings) / 8), W1 = W0 + int(sizeof(KinLite) / 8), W2 = W1 + int(sizeof(GParamsLite) / 8), W3 = W2 + int(sizeof(PoseHands) / 8);
+    constexpr int T_ITERS = (W3 + WG - 1) / WG;
+    static_assert(sizeof(KSettings) % 8 == 0 && sizeof(KinLite) % 8 == 0 && sizeof(GParamsLite) % 8 == 0, "copied in 8-byte words");
+    static_assert(S::xpad <= WG && PK_STRIDE <= WG && POSE_NX <= WG && POSE_MAX_NNZ % WG == 0 && XR_STRIDE <= S::xpad, "one record word per thread");
+    const double* src0 = reinterpret_cast<const double*>(&tb.head.ks);
+    const double* src1 = reinterpret_cast<const double*>(static_cast<const KinLite*>(&tb.head.kt));
+    const double* src2 = reinterpret_cast<const double*>(static_cast<const GParamsLite*>(a.gp + b));
+    const double* src3 = reinterpret_cast<const double*>(&tb.hands);
+    double* dst0 = reinterpret_cast<double*>(&tabs.ks);
+    double* dst1 = reinterpret_cast<double*>(&tabs.kt);
+    double* dst2 = reinterpret_cast<double*>(&tabs.gp);
+    double* dst3 = reinterpret_cast<double*>(pose_hands(s, tabs));
+    double tv[T_ITERS];
 #pragma unroll
-    for (int it = 0; it < HV_ITERS; ++it) { const int i = tid + it * WG; hv[it] = i < HV ? hsrc[i] : uint4{0u, 0u, 0u, 0u}; }
-#pragma unroll
-    for (int it = 0; it < GV_ITERS; ++it) { const int i = tid + it * WG; gv[it] = i < GV ? gsrc[i] : 0.0; }
-    constexpr int HW = int(sizeof(PoseHands) / 8);
-    const double hwv = tid < HW ? reinterpret_cast<const double*>(&tb.hands)[tid] : 0.0;
+    for (int it = 0; it < T_ITERS; ++it) {
+        const int i = tid + it * WG;
+        tv[it] = i < W0 ? src0[i] : (i < W1 ? src1[i - W0] : (i < W2 ? src2[i - W1] : (i < W3 ? src3[i - W2] : 0.0)));
+    }
     const double xrv = tid < XR_STRIDE ? a.xr[size_t(b) * XR_STRIDE + tid] : 0.0;
     const double pkv = tid < PK_STRIDE ? a.pk[size_t(b) * PK_STRIDE + tid] : 0.0;
     const double xval = tid < POSE_NX ? a.x[size_t(b) * POSE_NX + tid] : 0.0;
-    uint4* hdst = reinterpret_cast<uint4*>(&tabs.head);
-    double* gdst = reinterpret_cast<double*>(&tabs.gp);
 #pragma unroll
-    for (int it = 0; it < HV_ITERS; ++it) { const int i = tid + it * WG; if (i < HV) hdst[i] = hv[it]; }
-#pragma unroll
-    for (int it = 0; it < GV_ITERS; ++it) { const int i = tid + it * WG; if (i < GV) gdst[i] = gv[it]; }
-    if (tid < HW) reinterpret_cast<double*>(&tabs.hands)[tid] = hwv;
-    if (tid < XPAD) { s.x[tid] = 0.0; s.xm[tid] = xrv; }
+    for (int it = 0; it < T_ITERS; ++it) {
+        const int i = tid + it * WG;
+        if (i < W0) dst0[i] = tv[it]; else if (i < W1) dst1[i - W0] = tv[it]; else if (i < W2) dst2[i - W1] = tv[it]; else if (i < W3) dst3[i - W2] = tv[it];
+    }
+    if (tid < S::xpad) { s.x[tid] = 0.0; s.xm[tid] = xrv; }
     if (tid < PK_STRIDE) s.pk[tid] = pkv;
+    if (tid == 0) tabs.bad = 0;
     __syncthreads();
     if (tid < POSE_NX) s.x[pose_to_knot_col(tid)] = xval;
     __syncthreads();
 }
 
-// Two waves per SIMD (<= 256 VGPRs, two workgroups per CU).  Capped at 168 for the three workgroups the LDS would allow, the
-// compiler spilled 12-18 VGPRs to scratch and the kernel ran 3.6x slower (0.33 ms vs 0.09 ms for 4096 poses).
-template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3, 3))) void hipnlp_pose_kernel(PArgs a) {
-    __shared__ KnotScratch s;
-    __shared__ PoseShared tabs;
+// Four workgroups per CU: <= 128 VGPRs (110 used), <= 40 960 B of LDS.
+template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void hipnlp_pose_kernel(PArgs a) {
+    using Scratch = PoseScratchT<TERRAIN>;
+    static_assert(std::is_same_v<Scratch, typename PoseEm<TERRAIN>::Scratch>, "the emitter names the scratch the tasks run on");
+    __shared__ Scratch s;
+    __shared__ PoseSharedT<Scratch::trimmed> tabs;
+    static_assert(sizeof(Scratch) + sizeof(PoseSharedT<Scratch::trimmed>) <= 40960, "four workgroups per CU");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = blockIdx.x;
     const PoseTables& tb = *a.tb;
@@ -142,8 +172,8 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
 
     KnotInfo ki{1, 3, 0, 0};   // "interior knot": the k >= 1 rows / costs of the shared tasks are active
     PoseEm<TERRAIN> em{s.g, s.jac};
-    Ctx<PoseEm<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
-    cx.hands = &tabs.hands;
+    Ctx<PoseEm<TERRAIN>> cx(s, tabs.kt, tabs.ks, tabs.gp, ki, em, &tb.head.kt, a.gp + b);   // (full tables: global memory)
+    cx.hands = pose_hands(s, tabs);
     // (one contiguous program instance per wave, as in hipnlp_knot_kernel: no wave jumps over the other waves' code)
 #define DEV_R(w, w8, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_BARRIER lds_barrier();
@@ -178,19 +208,23 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
         bad |= !isfinite(tot);
         if (a.f) a.f[b] = tot;
     }
-    const int anybad = __syncthreads_or(bad);
+    const int anybad = pose_vote(tabs, bad, lane);
     if (tid == 0) a.flags[b] = anybad;
 }
 
 // Exact Hessian of the Lagrangian (IPOPT eval_h, pose_hess_body.h): the pose program runs as in hipnlp_pose_kernel (its g / jac
 // values stay in LDS, unused), the Hessian tasks run behind it and the workgroup streams out the lower-triangle CCS value run.
-// The Hessian program runs none of the tasks that emit Jacobian entries: the jac staging area (the last 15.7 KB of the scratch) is not
-// allocated, which brings the workgroup to 46 KB of LDS — three per CU (register cap 168).
-template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(3, 3))) void hipnlp_pose_hess_kernel(PArgs a) {
-    static_assert(offsetof(KnotScratch, jac) + sizeof(KnotScratch::jac) + 16 > sizeof(KnotScratch), "jac is the last member of the scratch (up to tail padding)");
-    __shared__ alignas(16) double s_raw[offsetof(KnotScratch, jac) / sizeof(double)];
-    KnotScratch& s = *reinterpret_cast<KnotScratch*>(s_raw);
-    __shared__ PoseShared tabs;
+// The Hessian program runs none of the tasks that emit Jacobian entries: the jac staging area (the last 13.8 / 15.7 KB of the scratch) is
+// not allocated.
+// Workgroups per CU: the LDS (35.4 / 35.9 KB with the compact scratch and the lite tables) allows four; the planar kernel fits the 128
+// registers that takes (126, no scratch), the smooth terrain's spills 60 B per lane there and stays at three (150 VGPRs).
+template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(TERRAIN == HIPNLP_TERRAIN_PLANAR ? 4 : 3, TERRAIN == HIPNLP_TERRAIN_PLANAR ? 4 : 3)))
+void hipnlp_pose_hess_kernel(PArgs a) {
+    using Scratch = PoseScratchT<TERRAIN>;
+    static_assert(offsetof(Scratch, jac) + sizeof(Scratch::jac) + 16 > sizeof(Scratch), "jac is the last member of the scratch (up to tail padding)");
+    __shared__ alignas(16) double s_raw[offsetof(Scratch, jac) / sizeof(double)];
+    Scratch& s = *reinterpret_cast<Scratch*>(s_raw);
+    __shared__ PoseSharedT<Scratch::trimmed> tabs;
     __shared__ HessScratch hx;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = blockIdx.x;
@@ -209,8 +243,8 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     const int hnnz = tb.hnnz;
     KnotInfo ki{1, 3, 0, 0};
     PoseHessEm<TERRAIN> em{s.g, nullptr, hx.H};   // (no task of the Hessian program emits a Jacobian entry)
-    Ctx<PoseHessEm<TERRAIN>> cx(s, tabs.head.kt, tabs.head.ks, tabs.gp, ki, em);
-    cx.hands = &tabs.hands;
+    Ctx<PoseHessEm<TERRAIN>> cx(s, tabs.kt, tabs.ks, tabs.gp, ki, em, &tb.head.kt, a.gp + b);
+    cx.hands = pose_hands(s, tabs);
     HCtx<PoseHessEm<TERRAIN>> hcx{cx, hx};
     // (one contiguous program instance per wave, as in hipnlp_knot_kernel: no wave jumps over the other waves' code)
 #define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
@@ -233,7 +267,7 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     double* out = a.hess + size_t(b) * hnnz;
 #pragma unroll
     for (int it = 0; it < HP_ITERS; ++it) { const int e = tid + it * WG; if (e < hnnz) { const double v = hx.H[hp[it]]; bad |= !isfinite(v); out[e] = v; } }
-    const int anybad = __syncthreads_or(bad);
+    const int anybad = pose_vote(tabs, bad, lane);
     if (tid == 0) a.flags[b] = anybad;
 }
 

@@ -221,7 +221,7 @@ template <class Em> HD void t_pose_hand_rows_l(Ctx<Em>& cx, int t) { pose_hand_r
 template <class Em> HD void t_pose_hand_rows_r(Ctx<Em>& cx, int t) { pose_hand_rows(cx, t, 1); }
 
 // cost term t of the pose (order of hipnlp_pose_cost_term_name) from the scratch, after the program has run
-HD double pose_cost_term(const KnotScratch& s, int t) {
+template <class S> HD double pose_cost_term(const S& s, int t) {
     switch (t) {
         case 0: return s.cost[CT_BASEQ];
         case 1: return s.cost[CT_FRAMEQ];
