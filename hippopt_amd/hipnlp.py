@@ -198,6 +198,7 @@ class HipNlp:
             self.h = None
             self._h_value = None      # (a call on a closed handle is refused by the library: HIPNLP_E_INVALID)
             self._addresses = {}
+            self._transient = self._transient_hess = None
 
     def __del__(self):
         # (not while the interpreter is shutting down: the HIP runtime's own exit handlers may already have run, and the OS reclaims
@@ -273,6 +274,12 @@ class HipNlp:
         # arrays iterate after iterate: five `ndarray.ctypes` objects per call were 6 of the 47 us of a 100-knot callback).
         rc = self._eval_raw(self._h_value, self._address(x), -1 if new_x is None else (1 if new_x else 0),
                             self._address(f), self._address(grad), self._address(g), self._address(jac))
+        if out is None:
+            # Arrays allocated HERE are transient: the caller drops them when it likes, and the allocator hands their addresses out
+            # again at once — "the same array twice in a row" for the library, which would page-lock memory that is freed a moment
+            # later (hipnlp_set_auto_register is meant for a solver's own arrays, which outlive the solve).  Holding the previous
+            # call's arrays until the next one has allocated its own makes two consecutive calls see different addresses.
+            self._transient = (f, grad, g, jac)
         if not (nan_ok and rc == -5):
             self._check(rc)
         return f, grad, g, jac
@@ -400,6 +407,7 @@ class HipNlp:
         sig = np.ascontiguousarray(np.broadcast_to(np.asarray(obj_factor, dtype=np.float64), (self.batch,)))
         if out is None:
             out = np.empty((self.batch, self.hess_nnz()))
+            self._transient_hess = out     # (see eval: no two consecutive calls on the same freshly allocated address)
         self._check(self.lib.hipnlp_eval_hess(self.h, _dp(x), _dp(sig), _dp(lam), _dp(out)))
         return out
 

@@ -243,3 +243,23 @@ def test_early_copy_out_of_the_host_path_changes_no_bit(model, HipNlp, terrain):
         assert np.array_equal(ja, jb), i
     for e in engs:
         e.close()
+
+
+def test_arrays_the_wrapper_allocates_itself_are_never_page_locked(model, HipNlp):
+    """HipNlp.eval / eval_hess without `out=` hand back fresh arrays the caller drops when it likes; the allocator would hand the same
+    addresses out again on the next call and the handle would take that for "the same array twice in a row" and page-lock memory that
+    is freed a moment later (a stale registration poisons every later HIP operation on host pointers inside it).  The wrapper holds the
+    previous call's arrays until the next call has allocated its own: no registration ever, same values."""
+    st = periodic_step_settings(9, model)
+    x, p = make_workload(st, model, batch=1, seed=4900)
+    eng = HipNlp(st, model)
+    eng.set_params(p)
+    lam = np.random.RandomState(2).standard_normal((1, eng.m))
+    first, first_h = [a.copy() for a in eng.eval(x)], eng.eval_hess(x, 0.5, lam).copy()
+    for i in range(6):
+        got = [a.copy() for a in eng.eval(x)]           # the returned arrays die here, call after call
+        assert all(np.array_equal(u, v) for u, v in zip(got, first)), i
+        assert np.array_equal(eng.eval_hess(x, 0.5, lam), first_h), i
+    stats = eng.host_stats()
+    assert stats["auto_registered"] == 0 and stats["auto_ranges"] == 0
+    eng.close()
