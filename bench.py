@@ -474,10 +474,12 @@ def throughput_block(model, device_index):
             x[:, cols] = x1[0, cols][None, :] + 1e-3 * np.random.RandomState(seed + 2).standard_normal((B, cols.size))
         return x, np.tile(p1, (B, 1))
 
-    def callbacks(tag, maker, N, B, seed, stairs=False, vary_first=False):
+    def callbacks(tag, maker, N, B, seed, stairs=False, vary_first=False, ccs_constants_in_place=False):
         st = maker(N, model)
         x, p = batch_of(st, B, seed, stairs)
         eng = HipNlp(st, model, batch=B, device=device_index, jac_varying_first=vary_first)
+        if ccs_constants_in_place:     # CasADi's CCS order with hipnlp_set_constant_jacobian(h, 1): VARY kernels, varying entries stored at their CCS positions
+            eng.set_constant_jacobian(True)
         eng.set_params(p)
         with torch.cuda.stream(stream):
             xd = torch.from_numpy(x).to(dev)
@@ -504,7 +506,9 @@ def throughput_block(model, device_index):
         gbps = bytes_knot * knots / (kern_ms * 1e-3) / 1e9
         out[tag] = {"ms_per_launch": kern_ms, "knots_per_s": knots / (kern_ms * 1e-3), "knots_per_launch": knots,
                     "kernel": "hipnlp_knot_kernel" + (" (VARY instantiation: varying-first order of a block, the 43 % of jac g that does not depend on x filled once, "
-                                                      "neither staged in LDS nor stored again; algorithmic bytes unchanged)" if vary_first else ""),
+                                                      "neither staged in LDS nor stored again; algorithmic bytes unchanged)" if vary_first else
+                                                      (" (VARY instantiation on a handle in CasADi's CCS order, hipnlp_set_constant_jacobian(h, 1): the constant entries filled once, "
+                                                       "the varying ones stored at their CCS positions; algorithmic bytes unchanged)" if ccs_constants_in_place else "")),
                     "kernels_per_step": eng.kernels_per_eval(), "ms_per_step_incl_cost_reduction": launch_ms, "ms_per_step_wall_clock": 1e3 * wall,
                     "launches_timed": nprof,
                     "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
@@ -597,6 +601,8 @@ def throughput_block(model, device_index):
                     ("periodic_N100_B64_varying_first", lambda: callbacks("periodic_N100_B64_varying_first", periodic_step_settings, 100, 64, 1004, vary_first=True)),
                     ("periodic_N100_B1024_varying_first", lambda: callbacks("periodic_N100_B1024_varying_first", periodic_step_settings, 100, 1024, 1004, vary_first=True)),
                     ("stairs_N200_B16_varying_first", lambda: callbacks("stairs_N200_B16_varying_first", stairs_settings, 200, 16, 1004, stairs=True, vary_first=True)),
+                    ("periodic_N100_B64_ccs_constants_in_place", lambda: callbacks("periodic_N100_B64_ccs_constants_in_place", periodic_step_settings, 100, 64, 1004, ccs_constants_in_place=True)),
+                    ("periodic_N100_B1024_ccs_constants_in_place", lambda: callbacks("periodic_N100_B1024_ccs_constants_in_place", periodic_step_settings, 100, 1024, 1004, ccs_constants_in_place=True)),
                     ("pose_B4096", lambda: pose(4096))):
         try:
             fn()

@@ -50,6 +50,13 @@ constexpr int VCAP_MAX = 1536;
 // a launch into HOST memory stores those behind the second barrier — 42 % of a knot's bytes start over the link while the kinematic
 // phases still run — and leaves them out of the copy-out at the end.
 constexpr int32_t COPY_EARLY = 1 << 30, COPY_SLOT = COPY_EARLY - 1;
+// A word of the Jacobian copy-out tables: native slot in bits 0..11; jpermv_t (VARY instantiations) also carries the entry's POSITION in
+// its knot block in bits 12..23 — the index of the varying run for a varying-first handle, the CCS position for a handle in CasADi's order,
+// whose varying entries are scattered over the block (device destinations only: scattered 8-byte stores belong in HBM, not on PCIe).
+constexpr int32_t JP_SLOT = 0xfff, JP_POS_SHIFT = 12, JP_POS = 0xfff;
+static_assert(js::COUNT <= JP_SLOT + 1, "slot field of a copy-out word");
+__host__ __device__ constexpr int jp_slot(int32_t w) { return w & JP_SLOT; }
+__host__ __device__ constexpr int jp_pos(int32_t w) { return (w >> JP_POS_SHIFT) & JP_POS; }
 struct DeviceTables {
     HeadTables head;
     int32_t g_a[3][GS_PAD];
@@ -76,8 +83,10 @@ struct ConstCheck {
     const int32_t* ctpl_of_b;
     int32_t* healed;
     int64_t jac_stride, jac_off;
-    int32_t ctpl_len, ctpl_off[4], nnz_v[3], nvary_v[3], kb, nk, N, n_glob, jac_glob_base;
+    int32_t ctpl_len, ctpl_off[4], nnz_v[3], first_const[3] /* position of a block's first constant entry, -1: none */, kb, nk, N, n_glob, jac_glob_base;
 };
+// the templates hold this word (a quiet NaN no constant has) at the positions of a block that depend on x
+constexpr unsigned long long CTPL_VARYING = 0x7FF8C0DEC0DE0001ull;
 
 struct KArgs {
     const DeviceTables* tb;
@@ -179,9 +188,9 @@ __device__ __forceinline__ void constants_check_and_repair(const ConstCheck& c, 
     int miss = 0;
     for (int t = tid; t < c.nk; t += nthreads) {
         const int k = c.kb + t, v = k == 0 ? VAR_FIRST : (k == c.N - 1 ? VAR_LAST : VAR_INTERIOR);
-        if (c.nvary_v[v] >= c.nnz_v[v]) continue;
+        if (c.first_const[v] < 0) continue;
         const int64_t base = k == 0 ? 0 : int64_t(c.nnz_v[VAR_FIRST]) + int64_t(k - 1) * c.nnz_v[VAR_INTERIOR];
-        const double seen = out[base + c.nvary_v[v]], want = tpl[c.ctpl_off[v] + c.nvary_v[v]];
+        const double seen = out[base + c.first_const[v]], want = tpl[c.ctpl_off[v] + c.first_const[v]];
         miss |= __double_as_longlong(seen) != __double_as_longlong(want);
     }
     // (an OR over the workgroup through the caller's LDS words: __syncthreads_or brings 256 B of LDS of its own, which the four-wave
@@ -196,7 +205,11 @@ __device__ __forceinline__ void constants_check_and_repair(const ConstCheck& c, 
     for (int t = 0; t < c.nk; ++t) {
         const int k = c.kb + t, v = k == 0 ? VAR_FIRST : (k == c.N - 1 ? VAR_LAST : VAR_INTERIOR);
         const int64_t base = k == 0 ? 0 : int64_t(c.nnz_v[VAR_FIRST]) + int64_t(k - 1) * c.nnz_v[VAR_INTERIOR];
-        for (int i = c.nvary_v[v] + tid; i < c.nnz_v[v]; i += nthreads) out[base + i] = tpl[c.ctpl_off[v] + i];
+        if (c.first_const[v] < 0) continue;
+        for (int i = c.first_const[v] + tid; i < c.nnz_v[v]; i += nthreads) {
+            const double tv = tpl[c.ctpl_off[v] + i];
+            if ((unsigned long long)__double_as_longlong(tv) != CTPL_VARYING) out[base + i] = tv;
+        }
     }
     if (c.kb + c.nk == c.N) for (int i = tid; i < c.n_glob; i += nthreads) out[int64_t(c.jac_glob_base) + i] = tpl[c.ctpl_off[3] + i];
     if (tid == 0) atomicAdd(c.healed, 1);
@@ -492,7 +505,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             const int64_t jb0 = first ? 0 : int64_t(nnz_first) + int64_t(k - 1) * nnz_interior;
             double* out = a.jac + int64_t(b) * a.jac_stride + (jb0 - a.jac_off);
 #pragma unroll
-            for (int it = 0; it < JP_ITERS; ++it) if (jp[it] >= 0 && (jp[it] & COPY_EARLY)) store_unwaited(out, (tid + it * WG) * 8, em.jac[jp[it] & COPY_SLOT]);
+            for (int it = 0; it < JP_ITERS; ++it) if (jp[it] >= 0 && (jp[it] & COPY_EARLY)) store_unwaited(out, (VARY ? jp_pos(jp[it]) : tid + it * WG) * 8, em.jac[jp_slot(jp[it])]);
         }
         if (a.g) {
             double* out = a.g + size_t(b) * a.m;
@@ -549,7 +562,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     double jvals[JP_ITERS], gvals[G_ITERS], grvals[GR_ITERS];
     // (unconditional, clamped indices, no branch: every LDS read of the copy-out is in flight before the first wait)
 #pragma unroll
-    for (int it = 0; it < JP_ITERS; ++it) jvals[it] = em.jac[jp[it] >= 0 ? (jp[it] & COPY_SLOT) : Em::kJacOff];
+    for (int it = 0; it < JP_ITERS; ++it) jvals[it] = em.jac[jp[it] >= 0 ? jp_slot(jp[it]) : Em::kJacOff];
 #pragma unroll
     for (int it = 0; it < G_ITERS; ++it) gvals[it] = s.g_at((tid + it * WG) < gs::COUNT ? tid + it * WG : 0);
 #pragma unroll
@@ -595,7 +608,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     if (a.jac) {
         double* out = a.jac + int64_t(b) * a.jac_stride + (jbase - a.jac_off);
 #pragma unroll
-        for (int it = 0; it < JP_ITERS; ++it) if (jp[it] >= 0 && !(early_on && (jp[it] & COPY_EARLY))) out[tid + it * WG] = jvals[it];
+        for (int it = 0; it < JP_ITERS; ++it) if (jp[it] >= 0 && !(early_on && (jp[it] & COPY_EARLY))) out[VARY ? jp_pos(jp[it]) : tid + it * WG] = jvals[it];
         // entries in the horizon-global columns (constants) sit right behind the last knot's block: the last knot writes them
         if constexpr (!VARY) { if (last && tid < n_glob) a.jac[int64_t(b) * a.jac_stride + (int64_t(jac_glob_base) - a.jac_off) + tid] = s.jac[jpg]; }
     }
@@ -908,8 +921,8 @@ __global__ __launch_bounds__(256) void hipnlp_fetch_vary_kernel(const double* __
     for (int i = threadIdx.x; i < count; i += 256) dst[base + i] = src[base + i];
 }
 
-// The constant entries of the handle's knots into a DEVICE array jac [batch][nnz] (varying-first order: the tail of every block, and
-// the horizon-global entries behind the last one), from the handle's templates: once per destination and parameter set.
+// The constant entries of the handle's knots into a DEVICE array jac [batch][nnz] (varying-first order: the tail of every block; CCS order:
+// wherever they sit; and the horizon-global entries behind the last block), from the handle's templates: once per destination and parameter set.
 __global__ __launch_bounds__(256) void hipnlp_fill_const_kernel(double* __restrict__ jac, const double* __restrict__ ctpl, const int32_t* __restrict__ ctpl_of_b, int ctpl_len,
                                                                  int off_first, int off_interior, int off_last, int off_glob, int kb, int N, int64_t nnz,
                                                                  int nnz_first, int nnz_interior, int nnz_last, int nv_first, int nv_interior, int nv_last, int n_glob) {
@@ -918,7 +931,9 @@ __global__ __launch_bounds__(256) void hipnlp_fill_const_kernel(double* __restri
     const int64_t base = int64_t(b) * nnz + (k == 0 ? 0 : int64_t(nnz_first) + int64_t(k - 1) * nnz_interior);
     const int nv = k == 0 ? nv_first : (k == N - 1 ? nv_last : nv_interior), end = k == 0 ? nnz_first : (k == N - 1 ? nnz_last : nnz_interior);
     const double* tv = t + (k == 0 ? off_first : (k == N - 1 ? off_last : off_interior));
-    for (int i = nv + int(threadIdx.x); i < end; i += 256) jac[base + i] = tv[i];
+    // (nv: the block's first constant entry — behind the varying run of a varying-first block, anywhere in a CCS block, whose varying
+    //  positions carry CTPL_VARYING in the template)
+    for (int i = nv + int(threadIdx.x); i < end; i += 256) { const double c = tv[i]; if ((unsigned long long)__double_as_longlong(c) != CTPL_VARYING) jac[base + i] = c; }
     if (k == N - 1) for (int i = int(threadIdx.x); i < n_glob; i += 256) jac[base + end + i] = t[off_glob + i];
 }
 
@@ -1005,7 +1020,7 @@ struct hipnlp_handle {
     // the entries that depend on x only (d_tb_vary: the same tables with -1 at the constant positions of the copy-out permutation):
     // a third fewer bytes on the PCIe-bound path, one contiguous run per knot.  Caller arrays are spot-checked before every such
     // launch (csample) and re-filled when a check fails or the parameters changed.
-    bool vary_ok = false;                           // varying-first layout whose varying runs fit the VARY instantiations' trip counts
+    bool vary_ok = false;                           // the varying entries of every block fit the VARY instantiations' trip counts (either order of a block)
     bool vary_check = true;                         // the VARY kernels look at the constants they find in a device destination (HIPNLP_VARY_CHECK=0: diagnostic)
     double* d_ctpl = nullptr;                       // device copy of the templates [ctpl.size()][ctpl_len] (the VARY kernels' self-healing check, the fill kernel)
     int32_t* d_ctpl_of_b = nullptr;
@@ -1015,7 +1030,7 @@ struct hipnlp_handle {
     DevFilled dfilled[8] = {};                      // device jac buffers of hipnlp_eval_device that hold this handle's constants, and of which parameter set
     int dfilled_next = 0;
     long dev_const_fills = 0;
-    bool skip_const = true;                         // hipnlp_set_constant_jacobian
+    bool skip_const = true;                         // hipnlp_set_constant_jacobian (hipnlp_create: on for varying-first handles, off — until asked for — for CCS handles)
     unsigned long long param_gen = 0;               // hipnlp_set_params calls so far
     std::vector<std::vector<double>> ctpl;          // distinct templates [block of VAR_FIRST | VAR_INTERIOR | VAR_LAST | horizon-global]: the constant values at their positions
     std::vector<int> ctpl_of_b;                     // template of trajectory b
@@ -1124,9 +1139,9 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
         //  - 1.1 % at x 1024, where ten rows are in flight and as many reducers spin in workgroup slots: long launches keep the kernel)
         const bool small_launch = long(h->nk) * long(desc->batch) <= 32768;
         // (the reducer workgroup stages [nk][16] doubles in its kernel's scratch: 256 knots, fewer on the trimmed scratch of the four-wave
-        //  VARY kernels a varying-first handle launches)
+        //  VARY kernels a handle launches for destinations that hold the constant entries)
         int red_cap = 256;
-        if (!h->wide && (desc->flags & HIPNLP_FLAG_JAC_VARYING_FIRST))
+        if (!h->wide)   // (either order of a block: device destinations get the VARY kernels)
             red_cap = st.terrain == HIPNLP_TERRAIN_PLANAR ? reducer_cap<KnotScratchT<LAYOUT_COMPACT, js::vary_slots(true)>>()
                                                           : reducer_cap<KnotScratchT<LAYOUT_COMPACT, js::vary_slots(false)>>();
         h->fused = h->nk <= red_cap && (h->wide || (small_launch && !(sep && std::atoi(sep) == 1)));
@@ -1137,6 +1152,7 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     if (!Layout::make_kin_tables(desc->model, h->kt, e)) return fail(HIPNLP_E_INVALID, e);
     if (!h->L.build(st, h->kt, (desc->flags & HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS) != 0, (desc->flags & HIPNLP_FLAG_JAC_VARYING_FIRST) != 0))
         return fail(HIPNLP_E_INVALID, h->L.error);
+    h->skip_const = h->L.vary_first;   // (a CCS handle stores every entry unless hipnlp_set_constant_jacobian(h, 1) asks for the scheme: the contract on the destination is the caller's to accept)
     if (const char* cj = std::getenv("HIPNLP_CONST_JAC")) h->skip_const = std::atoi(cj) != 0;   // diagnostic override of hipnlp_set_constant_jacobian's default
     if (const char* vc = std::getenv("HIPNLP_VARY_CHECK")) h->vary_check = std::atoi(vc) != 0;
     if (const char* es = std::getenv("HIPNLP_EARLY_STORE")) { h->early_store = std::atoi(es) != 0; h->early_store_always = std::atoi(es) == 2; }   // diagnostic override (A/B in one process)
@@ -1231,8 +1247,9 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     {
         // the VARY instantiations (varying-first order): the varying run of a block, thread-major, -1 behind it
         const int wg = h->wide ? 512 : 256, cap = vary_cap(st.terrain, wg), jt = cap / wg;
-        h->vary_ok = h->L.vary_first;
+        h->vary_ok = true;
         for (int v = 0; v < 3; ++v) {
+            if (h->L.nnz_v[v] > JP_POS + 1) h->vary_ok = false;
             h->cpos[v].clear();
             for (size_t i = 0; i < h->L.jconst_pos[v].size(); ++i) if (h->L.jconst_pos[v][i]) h->cpos[v].push_back(int32_t(i));
             tb->nvary_v[v] = h->L.nvary_v[v];
@@ -1241,9 +1258,11 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
         }
         if (h->vary_ok)
             for (int v = 0; v < 3; ++v)
-                for (int i = 0; i < h->L.nvary_v[v]; ++i) {
-                    const int32_t slot = h->L.jperm[v][size_t(i)];
-                    tb->jpermv_t[v][(i % wg) * jt + i / wg] = h->L.jslot_phase[size_t(slot)] <= 1 ? (slot | COPY_EARLY) : slot;
+                for (int pos = 0, i = 0; pos < h->L.nnz_v[v]; ++pos) {   // i: index among the block's varying entries, in the order of the block
+                    if (h->L.jconst_pos[v][size_t(pos)]) continue;
+                    const int32_t slot = h->L.jperm[v][size_t(pos)];
+                    tb->jpermv_t[v][(i % wg) * jt + i / wg] = slot | (pos << JP_POS_SHIFT) | (h->L.jslot_phase[size_t(slot)] <= 1 ? COPY_EARLY : 0);
+                    ++i;
                 }
     }
     hipError_t ce = hipnlp_internal_memcpy(h->d_tb, tb, sizeof(DeviceTables), hipMemcpyHostToDevice);
@@ -1327,7 +1346,9 @@ static void constants_prepare(hipnlp_handle* h, const std::vector<GParams>& gp) 
             if (std::memcmp(static_cast<const GParamsLite*>(&gp[rep[t]]), static_cast<const GParamsLite*>(&gp[b]), sizeof(GParamsLite)) == 0) found = int(t);
         if (found < 0) {
             Layout::constant_values(h->d.settings, h->kt, gp[b], cval.data());
-            std::vector<double> t(size_t(h->ctpl_off[3]) + L.jperm_glob.size(), 0.0);
+            double vary_mark;
+            { const unsigned long long w = CTPL_VARYING; std::memcpy(&vary_mark, &w, sizeof w); }
+            std::vector<double> t(size_t(h->ctpl_off[3]) + L.jperm_glob.size(), vary_mark);
             for (int v = 0; v < 3; ++v)
                 for (int32_t i : h->cpos[v]) t[size_t(h->ctpl_off[v] + i)] = cval[size_t(L.jperm[v][size_t(i)])];
             for (size_t i = 0; i < L.jperm_glob.size(); ++i) t[size_t(h->ctpl_off[3]) + i] = cval[size_t(L.jperm_glob[i])];
@@ -1467,7 +1488,7 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
         c.jac = on ? jac_dev : nullptr; c.ctpl = on ? h->d_ctpl : nullptr; c.ctpl_of_b = h->d_ctpl_of_b; c.healed = h->d_healed;
         c.jac_stride = h->L.nnz; c.jac_off = 0; c.ctpl_len = h->ctpl_len;
         for (int v = 0; v < 4; ++v) c.ctpl_off[v] = h->ctpl_off[v];
-        for (int v = 0; v < 3; ++v) { c.nnz_v[v] = h->L.nnz_v[v]; c.nvary_v[v] = h->L.nvary_v[v]; }
+        for (int v = 0; v < 3; ++v) { c.nnz_v[v] = h->L.nnz_v[v]; c.first_const[v] = h->cpos[v].empty() ? -1 : h->cpos[v][0]; }
         c.kb = h->kb; c.nk = h->nk; c.N = h->L.N; c.n_glob = int(h->L.jperm_glob.size()); c.jac_glob_base = h->L.jac_glob_base;
     }
     a.g = g_dev; a.jac = jac_dev; a.grad = grad_dev; a.g_stage = g_stage;
@@ -1722,18 +1743,20 @@ int hipnlp_eval_device(hipnlp_handle* h, const double* x_dev, double* f_dev, dou
     HIP_TRY(h, hipSetDevice(h->dev));
     h->have_result = false;
     hipStream_t s = stream ? hipStream_t(stream) : h->stream;
-    // Varying-first layout: a jac buffer is filled with the constant entries at its first sight (and again after hipnlp_set_params),
-    // on the caller's stream in front of the evaluation; from then on the launches store the varying run of every block only and
-    // check the constants they find (a buffer the caller wrote over is repaired by the kernel itself).
+    // A jac buffer is filled with the constant entries at its first sight (and again after hipnlp_set_params), on the caller's stream in
+    // front of the evaluation; from then on the launches store the varying entries of every block only — one run in the varying-first
+    // order, scattered 8-byte stores in CasADi's CCS order (they meet in the L2 before they leave for HBM) — and check the constants
+    // they find (a buffer the caller wrote over is repaired by the kernel itself).
     bool vary = false;
     if (jac_dev && h->skip_const && h->vary_ok && h->d_ctpl && h->L.nconst_total > 0) {
         int slot = -1;
         for (int i = 0; i < 8; ++i) if (h->dfilled[i].dev == jac_dev) slot = i;
         if (slot < 0 || h->dfilled[slot].gen != h->param_gen) {
             const Layout& L = h->L;
+            auto fc = [&](int v) { return h->cpos[v].empty() ? L.nnz_v[v] : int(h->cpos[v][0]); };   // first constant position of a block (none: its end)
             hipLaunchKernelGGL(hipnlp_fill_const_kernel, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(256), 0, s, jac_dev, (const double*)h->d_ctpl,
                                (const int32_t*)h->d_ctpl_of_b, h->ctpl_len, h->ctpl_off[0], h->ctpl_off[1], h->ctpl_off[2], h->ctpl_off[3], h->kb, L.N, int64_t(L.nnz),
-                               L.nnz_v[VAR_FIRST], L.nnz_v[VAR_INTERIOR], L.nnz_v[VAR_LAST], L.nvary_v[VAR_FIRST], L.nvary_v[VAR_INTERIOR], L.nvary_v[VAR_LAST],
+                               L.nnz_v[VAR_FIRST], L.nnz_v[VAR_INTERIOR], L.nnz_v[VAR_LAST], fc(VAR_FIRST), fc(VAR_INTERIOR), fc(VAR_LAST),
                                h->ke == L.N ? int(L.jperm_glob.size()) : 0);
             HIP_TRY(h, hipGetLastError());
             if (slot < 0) { slot = h->dfilled_next; h->dfilled_next = (h->dfilled_next + 1) % 8; }
@@ -1933,7 +1956,7 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
         //  CCS-ordered block leaves fragments of one to four doubles on the link — measured SLOWER than storing everything, 59.7
         //  against 55.0 us per 100-knot call, profiles/r04_host_path.txt.)
         bool vary_only = false;
-        if (h->skip_const && h->vary_ok && h->L.nconst_total > 0 && sel[2] != 0u) {
+        if (h->skip_const && h->vary_ok && h->L.vary_first && h->L.nconst_total > 0 && sel[2] != 0u) {   // (host destinations: the varying RUN of a varying-first block only)
             if (sel[2] == 1u) {
                 if (h->pinned_const_gen != h->param_gen) { constants_fill(h, h->h_jac); h->pinned_const_gen = h->param_gen; }
             } else constants_ensure(h, caller_host[2]);
@@ -2028,7 +2051,7 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
         size_t w_first[3] = {0, 0, 0}, w_last[3] = {bytes[0] / 8 - 1, bytes[1] / 8 - 1, bytes[2] / 8 - 1};
         for (int q = 0; q < 3; ++q) {
             if (!(missing & bit[q])) continue;
-            const bool vary_run = q == 2 && caller[q] && caller_dev[q] && h->skip_const && h->vary_ok && h->L.nconst_total > 0;
+            const bool vary_run = q == 2 && caller[q] && caller_dev[q] && h->skip_const && h->vary_ok && h->L.vary_first && h->L.nconst_total > 0;
             if (vary_run) { constants_ensure(h, caller[q]); w_first[q] = h->jac_first_vary; w_last[q] = h->jac_last_vary; }
             if (caller[q]) {
                 to_caller |= bit[q];

@@ -369,7 +369,9 @@ class HipNlp:
         return dict(zip(("auto_registered", "auto_fallbacks", "auto_ranges", "evaluations", "constant_fills", "constant_refills", "constant_entries", "constant_slices_healed"), list(out)))
 
     def set_constant_jacobian(self, on=True):
-        """hipnlp_set_constant_jacobian: host destinations of jac g hold the constant entries, launches store the varying ones only (default on)"""
+        """hipnlp_set_constant_jacobian: destinations of jac g hold the constant entries, launches store the varying ones only.  Default: on
+        for varying-first handles (host and device destinations); a handle in CCS order stores every entry unless this asks for the
+        scheme — then its DEVICE destinations (`eval_device`) are filled once and receive the varying entries at their CCS positions."""
         self._check(self.lib.hipnlp_set_constant_jacobian(self.h, 1 if on else 0))
 
     def jac_constant_mask(self):

@@ -279,13 +279,16 @@ int hipnlp_set_prefetch(hipnlp_handle* h, unsigned mask);
  * such launch and the array is re-filled when one differs (hipnlp_host_stats out[5] counts these) — not by a guarantee: a caller
  * that edits single entries of a registered Jacobian array must turn this off.  Arrays that are NOT registered always receive complete
  * values by a copy out of the pinned block.
- * Device-resident outputs (hipnlp_eval_device, varying-first handles): a jac_dev buffer is filled with the constant entries at its first
+ * Device-resident outputs (hipnlp_eval_device): a jac_dev buffer is filled with the constant entries at its first
  * sight and again after hipnlp_set_params (one small launch on the call's stream, in front of the evaluation); the evaluations store the
- * varying run of every knot block only and no longer stage the constants in LDS at all.  Same contract — the caller does not write into
+ * varying entries of every knot block only — one run in the varying-first order, scattered over the block in CasADi's CCS order (on = 1
+ * on a handle WITHOUT HIPNLP_FLAG_JAC_VARYING_FIRST asks for exactly this: device destinations only, host destinations of a CCS handle keep
+ * receiving every entry) — and no longer stage the constants in LDS at all.  Same contract — the caller does not write into
  * the buffer between calls — and the kernel itself checks it: every wave compares a few dozen of the constants it finds with the
  * handle's templates and puts its slice of the block's constants back when one differs (hipnlp_host_stats out[7] counts such repairs).
  * hipnlp_eval_device_shard / _peers are not affected: every entry is stored.
- * on = 0: every launch stores every entry (the behaviour of ABI 2 libraries before this switch existed). */
+ * on = 0: every launch stores every entry (the behaviour of ABI 2 libraries before this switch existed).
+ * Default: on for handles created with HIPNLP_FLAG_JAC_VARYING_FIRST, off for handles in CCS order. */
 int hipnlp_set_constant_jacobian(hipnlp_handle* h, int on);
 /* Early outputs (opt-in, off by default).  on = 1: a NEW evaluation stores g and jac g — when its call does NOT ask for them —
  * straight into the REGISTERED caller arrays (hipnlp_host_register, or registered by the handle itself) that earlier calls passed

@@ -199,10 +199,13 @@ def test_two_live_handles_and_an_array_address_that_is_reused(model, HipNlp):
     ref.close()
 
 
-def test_device_resident_jacobian_holds_its_constants_and_is_repaired_when_overwritten(model, HipNlp):
-    """hipnlp_eval_device on a varying-first handle: the jac buffer is filled with the constants at its first sight (and after
-    hipnlp_set_params), the launches store the varying run of every block only (VARY instantiations: the constants are not even
-    staged in LDS) — the buffer always holds the complete Jacobian; a buffer the caller wrote over is repaired by the kernel itself.
+@pytest.mark.parametrize("vary_first", [True, False])
+def test_device_resident_jacobian_holds_its_constants_and_is_repaired_when_overwritten(model, HipNlp, vary_first):
+    """hipnlp_eval_device: the jac buffer is filled with the constants at its first sight (and after hipnlp_set_params), the launches
+    store the varying entries of every block only (VARY instantiations: the constants are not even staged in LDS) — one run per block
+    on a varying-first handle, scattered over the block on a handle in CasADi's CCS order — the buffer always holds the complete
+    Jacobian; a buffer the caller wrote over is repaired by the kernel itself.  Reference: the CCS handle with
+    hipnlp_set_constant_jacobian off (every entry computed, staged and stored by every launch).
     Both kernel variants (eight waves: one trajectory; four waves: a batch), both terrains, a shard handle too."""
     import torch
     dev = torch.device("cuda", 0)
@@ -214,11 +217,15 @@ def test_device_resident_jacobian_holds_its_constants_and_is_repaired_when_overw
         if maker is stairs_settings:
             place_on_step_flanks(x, st, seed=7500)
         kw = dict(knot_begin=shard[0], knot_end=shard[1]) if shard else {}
-        full = HipNlp(st, model, batch=B, **kw)
-        eng = HipNlp(st, model, batch=B, jac_varying_first=True, **kw)
+        full = HipNlp(st, model, batch=B, **kw)                              # (a CCS handle stores every entry unless asked)
+        eng = HipNlp(st, model, batch=B, jac_varying_first=vary_first, **kw)
+        if not vary_first:
+            eng.set_constant_jacobian(True)                                  # CCS order, device destinations: opt-in
         ir, jc = eng.sparsity()
         pos = {(int(r), int(c)): i for i, (r, c) in enumerate(zip(*full.sparsity()))}
         order = torch.from_numpy(np.array([pos[(int(r), int(c))] for r, c in zip(ir, jc)])).to(dev)
+        if not vary_first:
+            assert torch.equal(order, torch.arange(order.numel(), device=dev))
         p2 = p.copy()
         p2[:, 24 * N + 3 + 105 + 105] *= 1.3      # dt
         with torch.cuda.stream(stream):
@@ -246,7 +253,7 @@ def test_device_resident_jacobian_holds_its_constants_and_is_repaired_when_overw
             for i in range(3):
                 both(i, out)
             both(0, other)                      # a second buffer: filled at its first sight as well
-        assert eng.host_stats()["constant_slices_healed"] == 0
+        assert eng.host_stats()["constant_slices_healed"] == 0 and full.host_stats()["constant_fills"] == 0
         fills = eng.host_stats()["constant_fills"]
         assert fills == 4                       # two buffers x two parameter sets
         out[3].zero_()                          # the caller writes over its buffer between two calls ...

@@ -11,8 +11,10 @@ cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 WORKLOADS=${@:-"periodic_N100_B1:--batch=1 periodic_N100_B64:--batch=64 periodic_N100_B1024:--batch=1024 stairs_N200_B16:--workload=stairs,--horizon=200,--batch=16 periodic_N100_B1_vf:--batch=1,--varying-first periodic_N100_B64_vf:--batch=64,--varying-first periodic_N100_B1024_vf:--batch=1024,--varying-first stairs_N200_B16_vf:--workload=stairs,--horizon=200,--batch=16,--varying-first"}
+PARTS=${PROFILE_PARTS:-"bench hess pose calib"}   # which parts run (a whole round does not fit one gpurun call of 20 minutes)
+has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
 run() { name=$1; shift; echo "== $name" ; rocprofv3 "$@" > $OUT/$name.log 2>&1; echo "   rc=$?"; }
-for W in $WORKLOADS; do
+has bench && for W in $WORKLOADS; do
   NAME=${W%%:*}; ARGS=$(echo ${W#*:} | tr ',' ' ')
   B=$(echo $ARGS | sed -n 's/.*--batch=\([0-9]*\).*/\1/p'); B=${B:-1}
   STEPS=$([ $B -ge 1024 ] && echo 30 || echo 300)
@@ -27,7 +29,7 @@ for W in $WORKLOADS; do
   python3 bench.py --steps $([ $B -ge 1024 ] && echo 50 || echo 1000) --warmup 50 $ARGS $COMMON > $OUT/bench_$NAME.json 2>/dev/null
 done
 # exact Hessian and pose finder: ONE (kernel, N, batch) per trace, so that every CSV average is the duration of one configuration
-for CFG in periodic:100:1 periodic:100:64 periodic:100:256 stairs:200:16; do
+has hess && for CFG in periodic:100:1 periodic:100:64 periodic:100:256 stairs:200:16; do
   HW=${CFG%%:*}; R=${CFG#*:}; HN=${R%%:*}; HB=${R#*:}
   NAME=hess_${HW}_N${HN}_B${HB}
   echo "== $NAME"
@@ -36,7 +38,7 @@ for CFG in periodic:100:1 periodic:100:64 periodic:100:256 stairs:200:16; do
   HESS_WORKLOAD=$HW HESS_N=$HN HESS_BATCHES=$HB rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$NAME -- python3 tools/diag/hess_bench.py > /dev/null 2> $OUT/write_$NAME.log
   HESS_WORKLOAD=$HW HESS_N=$HN HESS_BATCHES=$HB rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d $OUT/lane_$NAME -- python3 tools/diag/hess_bench.py > /dev/null 2> $OUT/lane_$NAME.log
 done
-for CFG in callbacks:1 callbacks:4096 hessian:1 hessian:4096; do
+has pose && for CFG in callbacks:1 callbacks:4096 hessian:1 hessian:4096; do
   WHAT=${CFG%%:*}; PB=${CFG#*:}
   NAME=pose_${WHAT}_B${PB}
   echo "== $NAME"
@@ -44,6 +46,6 @@ for CFG in callbacks:1 callbacks:4096 hessian:1 hessian:4096; do
   POSE_WHAT=$WHAT POSE_BATCHES=$PB rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$NAME -- python3 tools/diag/pose_bench.py > /dev/null 2> $OUT/fetch_$NAME.log
   POSE_WHAT=$WHAT POSE_BATCHES=$PB rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$NAME -- python3 tools/diag/pose_bench.py > /dev/null 2> $OUT/write_$NAME.log
 done
-run calib_fetch --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -- tools/diag/_build/calib
-run calib_write --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -- tools/diag/_build/calib
+has calib && run calib_fetch --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -- tools/diag/_build/calib
+has calib && run calib_write --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -- tools/diag/_build/calib
 ls $OUT | head -60
