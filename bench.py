@@ -64,6 +64,9 @@ def parse_args():
     ap.add_argument("--varying-first", action="store_true",
                     help="handles created with HIPNLP_FLAG_JAC_VARYING_FIRST (N = 1, independent trajectories): the order a triplet consumer such as IPOPT picks; "
                          "the constant entries of jac g are filled once, the launches store the varying run of every knot block (VARY kernels)")
+    ap.add_argument("--ccs-constants-in-place", action="store_true",
+                    help="CCS-order handle with hipnlp_set_constant_jacobian(h, 1) (N = 1, independent trajectories): the device destination of jac g holds the "
+                         "constant entries, the launches store the varying ones at their CCS positions (VARY kernels)")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the sharded paths on one GPU (debug)")
     return ap.parse_args()
 
@@ -748,6 +751,8 @@ def main():
     def run_replicas(steps, warmup):
         st, x_np, p_np, xs = workload(args.horizon, args.batch, 1004 + rank)
         eng = HipNlp(st, model, batch=args.batch, device=local_rank, jac_varying_first=args.varying_first)
+        if args.ccs_constants_in_place and not args.varying_first:
+            eng.set_constant_jacobian(True)
         eng.set_params(p_np)
         f_d = torch.empty(args.batch, dtype=torch.float64, device=device)
         grad_d = torch.empty(args.batch * eng.n, dtype=torch.float64, device=device)
@@ -1165,7 +1170,7 @@ def main():
         if os.path.exists(tp):
             try:
                 table = json.load(open(tp))
-                ent = table.get("%s_N%d_B%d%s" % (args.workload, main_res["horizon"], args.batch, "_vf" if args.varying_first else ""), {})
+                ent = table.get("%s_N%d_B%d%s" % (args.workload, main_res["horizon"], args.batch, "_vf" if args.varying_first else ("_ccsv" if args.ccs_constants_in_place else "")), {})
                 traffic = ent.get("hbm_bytes_per_launch")
                 valu = ent.get("valu_wave_insts_per_knot")
                 lds_cyc = ent.get("lds_array_cycles_per_knot")
@@ -1195,7 +1200,8 @@ def main():
                        "n": int(d.n), "m": int(d.m), "nnz": int(d.nnz), "nnz_per_knot": nnz_knot,
                        "jac_order": ("varying-first inside every knot block (HIPNLP_FLAG_JAC_VARYING_FIRST): the %d constant entries of jac g filled once, "
                                      "the launches store the varying run of every block" % eng.host_stats()["constant_entries"]) if args.varying_first
-                                    else "CCS (CasADi's): every entry stored by every launch"},
+                                    else ("CCS (CasADi's), hipnlp_set_constant_jacobian(h, 1): the constant entries of jac g filled once, the launches store the varying ones at their CCS positions"
+                                          if args.ccs_constants_in_place else "CCS (CasADi's): every entry stored by every launch")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command in a separate session; null = not profiled)",

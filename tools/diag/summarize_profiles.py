@@ -67,7 +67,7 @@ traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
 names = sorted({os.path.basename(p)[len("trace_"):] for p in glob.glob(os.path.join(src, "trace_*"))
                 if os.path.isdir(p) and not os.path.basename(p).startswith(("trace_hess_", "trace_pose_"))})
 for name in names:
-    m = re.match(r"(\w+?)_N(\d+)_B(\d+)(_vf)?$", name)   # (_vf: handles with HIPNLP_FLAG_JAC_VARYING_FIRST, VARY kernels)
+    m = re.match(r"(\w+?)_N(\d+)_B(\d+)(_vf|_ccsv)?$", name)   # (_vf: handles with HIPNLP_FLAG_JAC_VARYING_FIRST, VARY kernels; _ccsv: CCS handles with hipnlp_set_constant_jacobian(h, 1))
     N, B = int(m.group(2)), int(m.group(3))
     knots = N * B
     w, f = kernel_stats(os.path.join(src, "trace_" + name), {"knot_kernel": "knot_kernel", "reduce_kernel": "reduce_kernel"})
