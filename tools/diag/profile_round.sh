@@ -37,6 +37,7 @@ has hess && for CFG in periodic:100:1 periodic:100:64 periodic:100:256 stairs:20
   HESS_WORKLOAD=$HW HESS_N=$HN HESS_BATCHES=$HB rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$NAME -- python3 tools/diag/hess_bench.py > /dev/null 2> $OUT/fetch_$NAME.log
   HESS_WORKLOAD=$HW HESS_N=$HN HESS_BATCHES=$HB rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$NAME -- python3 tools/diag/hess_bench.py > /dev/null 2> $OUT/write_$NAME.log
   HESS_WORKLOAD=$HW HESS_N=$HN HESS_BATCHES=$HB rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d $OUT/lane_$NAME -- python3 tools/diag/hess_bench.py > /dev/null 2> $OUT/lane_$NAME.log
+  HESS_WORKLOAD=$HW HESS_N=$HN HESS_BATCHES=$HB rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/lds_$NAME -- python3 tools/diag/hess_bench.py > /dev/null 2> $OUT/lds_$NAME.log
 done
 has pose && for CFG in callbacks:1 callbacks:4096 hessian:1 hessian:4096; do
   WHAT=${CFG%%:*}; PB=${CFG#*:}
@@ -45,6 +46,9 @@ has pose && for CFG in callbacks:1 callbacks:4096 hessian:1 hessian:4096; do
   POSE_WHAT=$WHAT POSE_BATCHES=$PB rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$NAME -- python3 tools/diag/pose_bench.py > $OUT/bench_$NAME.jsonl 2> $OUT/trace_$NAME.log
   POSE_WHAT=$WHAT POSE_BATCHES=$PB rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$NAME -- python3 tools/diag/pose_bench.py > /dev/null 2> $OUT/fetch_$NAME.log
   POSE_WHAT=$WHAT POSE_BATCHES=$PB rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$NAME -- python3 tools/diag/pose_bench.py > /dev/null 2> $OUT/write_$NAME.log
+  # what bounds the batch launches: live lanes per issued VALU instruction, VALU / LDS instruction counts, LDS array cycles against CU-busy cycles
+  POSE_WHAT=$WHAT POSE_BATCHES=$PB rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d $OUT/lane_$NAME -- python3 tools/diag/pose_bench.py > /dev/null 2> $OUT/lane_$NAME.log
+  POSE_WHAT=$WHAT POSE_BATCHES=$PB rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/lds_$NAME -- python3 tools/diag/pose_bench.py > /dev/null 2> $OUT/lds_$NAME.log
 done
 has calib && run calib_fetch --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -- tools/diag/_build/calib
 has calib && run calib_write --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -- tools/diag/_build/calib

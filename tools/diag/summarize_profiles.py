@@ -140,6 +140,23 @@ for d in sorted(glob.glob(os.path.join(src, "trace_hess_*")) + glob.glob(os.path
     if lane.get("SQ_ACTIVE_INST_VALU") and lane.get("SQ_THREAD_CYCLES_VALU"):
         ent["valu_lane_utilisation"] = h["valu_lane_utilisation"] = lane["SQ_THREAD_CYCLES_VALU"] / (lane["SQ_ACTIVE_INST_VALU"] * 64.0)
         h["lane"] = {k: v for k, v in lane.items() if not k.endswith("_n")}
+    # per unit (knot-Hessian / pose) and against the CU-busy cycles: which unit the batch launch keeps busy
+    mu = re.search(r"_N(\d+)_B(\d+)$", name) or re.search(r"_B(\d+)$", name)
+    units = (int(mu.group(1)) * int(mu.group(2)) if mu.re.groups == 2 else int(mu.group(1))) if mu else None
+    ldsc = counter_means(os.path.join(src, "lds_" + name), kern)
+    if units and lane.get("SQ_INSTS_VALU"):
+        ent["valu_wave_insts_per_unit"] = h["valu_wave_insts_per_unit"] = lane["SQ_INSTS_VALU"] / units
+        h["lds_wave_insts_per_unit"] = lane.get("SQ_INSTS_LDS", 0.0) / units
+        if lane.get("SQ_WAVE_CYCLES"):
+            h["wait_fraction_of_wave_cycles"] = lane.get("SQ_WAIT_ANY", 0.0) / lane["SQ_WAVE_CYCLES"]
+    if units and ldsc.get("SQ_LDS_IDX_ACTIVE"):
+        ent["lds_array_cycles_per_unit"] = h["lds_array_cycles_per_unit"] = ldsc["SQ_LDS_IDX_ACTIVE"] / units
+        if ldsc.get("SQ_BUSY_CU_CYCLES"):
+            h["cu_busy_cycles_per_unit"] = ldsc["SQ_BUSY_CU_CYCLES"] / units
+            h["lds_array_busy_fraction_of_cu_cycles"] = ldsc["SQ_LDS_IDX_ACTIVE"] / ldsc["SQ_BUSY_CU_CYCLES"]
+            if lane.get("SQ_INSTS_VALU"):   # fp64 VALU: one wave-instruction holds a SIMD's issue slot for 4 cycles, 4 SIMDs per CU
+                h["valu_issue_busy_fraction_of_cu_cycles"] = lane["SQ_INSTS_VALU"] / ldsc["SQ_BUSY_CU_CYCLES"]
+        h["lds"] = {k: v for k, v in ldsc.items() if not k.endswith("_n")}
     traffic[name] = ent
     summary["exact_hessian" if name.startswith("hess_") else "pose_finder"][name] = h
 json.dump(summary, open(os.path.join(dst, "%s_summary.json" % tag), "w"), indent=1)
