@@ -996,6 +996,7 @@ struct hipnlp_handle {
     double *hd_x = nullptr, *hd_f = nullptr, *hd_cost_terms = nullptr, *hd_grad = nullptr, *hd_g = nullptr, *hd_jac = nullptr;
     int32_t* hd_flag = nullptr;
     bool x_zero_copy = true;      // the kernel reads x from pinned host memory (small problems) instead of an H2D copy first
+    bool lam_zero_copy = true;    // hipnlp_eval_hess: the kernel gathers sigma / lambda out of the pinned block too (small problems; HIPNLP_HESS_LAM_ZERO_COPY=0/1 overrides)
     unsigned prefetch = HIPNLP_WANT_F | HIPNLP_WANT_GRAD | HIPNLP_WANT_G;   // brought to the host by every new evaluation
     unsigned on_host = 0;         // outputs of the cached result that are in the pinned block
     unsigned gone = 0;            // outputs of the cached result the kernel stored into registered caller arrays (in neither block)
@@ -1211,6 +1212,11 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
         // x over PCIe by the kernel itself (the halo record is read twice): wins while x is small (151 KB at 100 knots: ~5 us
         // less than the copy command, profiles/r02_pcie_probe.txt); big batches go through one H2D copy and the L2
         h->x_zero_copy = B * n * sizeof(double) <= (size_t(1) << 20);
+        // (the multipliers of hipnlp_eval_hess likewise: 220 KB at 100 knots.  The knot workgroups gather them through the slot -> row map —
+        //  runs of 3 - 24 doubles per constraint block — and even as such fragments on the link they arrive sooner than behind a copy
+        //  command and its hand-over to the kernel: 67.5 -> 59.7 us per 100-knot Hessian through host buffers, tools/diag/hess_host_ab.py)
+        h->lam_zero_copy = B * (1 + m) * sizeof(double) <= (size_t(1) << 20);
+        if (const char* lz = std::getenv("HIPNLP_HESS_LAM_ZERO_COPY")) h->lam_zero_copy = std::atoi(lz) != 0;   // diagnostic override (A/B in one process)
     }
     CREATE_TRY(hipMemset(h->d_g, 0, B * m * sizeof(double)));
     CREATE_TRY(hipMemset(h->d_jac, 0, B * nnz * sizeof(double)));
@@ -1700,7 +1706,14 @@ int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor
         HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_x, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
         xsrc = h->d_x;
     }
-    HIP_TRY(h, hipMemcpyAsync(h->d_sigma, h->h_sl, B * (1 + m) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const double* sl_dev = h->d_sigma;
+    if (h->lam_zero_copy) {   // the kernel gathers the multipliers straight out of the pinned block, no copy command in front of it
+        void* hd = nullptr;
+        HIP_TRY(h, hipHostGetDevicePointer(&hd, h->h_sl, 0));
+        sl_dev = static_cast<const double*>(hd);
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(h->d_sigma, h->h_sl, B * (1 + m) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
     // the values leave the kernel as PCIe stores into the pinned block — or straight into the CALLER'S array when that lies in a
     // registered range (no 1.2 MB host copy behind the launch): registered by the caller, or by the handle itself at the array's second
     // consecutive sight (IPOPT evaluates the Hessian into the value array of its own matrix); a store into an array the handle
@@ -1716,7 +1729,7 @@ int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor
         __atomic_store_n(&w[0], sentinel, __ATOMIC_RELAXED);
         __atomic_store_n(&w[hbytes / 8 - 1], sentinel, __ATOMIC_RELAXED);
     }
-    rc = hess_launch(h, xsrc, h->d_sigma, h->d_lambda, direct ? direct : h->hd_hess, h->stream, true);
+    rc = hess_launch(h, xsrc, sl_dev, sl_dev + B, direct ? direct : h->hd_hess, h->stream, true);
     if (rc != HIPNLP_OK) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (sentinel) {
@@ -1725,7 +1738,7 @@ int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor
             (void)drop_stale_range(h, hess);
             h->no_auto[3] = hess;
             h->auto_fallbacks++;
-            rc = hess_launch(h, xsrc, h->d_sigma, h->d_lambda, h->hd_hess, h->stream, true);
+            rc = hess_launch(h, xsrc, sl_dev, sl_dev + B, h->hd_hess, h->stream, true);
             if (rc != HIPNLP_OK) return rc;
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             direct = nullptr;
