@@ -664,11 +664,15 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 #else
 #define HIPNLP_HESS_TABLES_AT HIPNLP_HESS_DIAG_PHASES   // (diagnostic builds that stop early: behind the last barrier they have)
 #endif
+constexpr int HK_PAD = (hk::COUNT + 7) / 8 * 8;   // (16-byte pieces for the staging loads)
 struct alignas(16) HessTables {
     KHFarLists far;               // unrelated joint pairs of the model (first: 16-byte aligned for the staging loads)
     int32_t perm[hk::COUNT];      // position in the knot block -> native slot
     int32_t perm_couple[84];
     int32_t nnz_knot, n_couple;
+    // DIRECT instantiation: native slot -> position in the knot's block of the value run (the periodicity coupling entries, which the last
+    // knot writes right behind its block: nnz_knot + i), -1: not in the pattern
+    alignas(16) int16_t inv[HK_PAD];
 };
 struct HArgs {
     const DeviceTables* tb;
@@ -681,21 +685,34 @@ struct HArgs {
     double* hess;           // [batch][nnz_h]
     int32_t* flag;          // [batch] generation flag: == seq after a launch in which the trajectory produced a non-finite value
     int32_t* flag_host;     // [batch] or null: the same flag in pinned host memory (plain store of seq, see KArgs)
-    int32_t N, n, m, knot_begin, seq, pad_;
+    int32_t N, n, m, knot_begin, seq, nnz_knot /* entries of a knot's block (DIRECT: the block base is needed before the tables are) */;
     int64_t hstride, hoff;  // values of trajectory b start at hess + b * hstride; the handle's first knot block sits at -hoff
 #ifdef HIPNLP_STAMPS
     unsigned long long* stamps;  // diagnostic build only (tools/diag/hess_stamps.py): [blocks][8][128] s_memtime per wave
 #endif
 };
-template <int TERRAIN, int LAYOUT> struct DevEmH {
+// DIRECT: every entry is emitted exactly once per knot (the recorder refuses a second emission, the host emulation poisons the staging and
+// finds every entry of the pattern written at every knot) — so an entry can go straight to its place in the destination instead of
+// through 17.5 KB of LDS staging and a copy-out pass: `hess` is the knot's block in the value run, `inv` the slot -> position table (an
+// LDS copy), `nf` turns NaN when a non-finite value is emitted (v * 0 is NaN for NaN and Inf, +-0 otherwise).  Scattered 8-byte stores:
+// for DEVICE destinations only (they meet in the L2; on PCIe fragments cost more than everything they save).
+template <int TERRAIN, int LAYOUT, bool DIRECT = false> struct DevEmH {
     static constexpr int kTerrain = TERRAIN;
     using Scratch = KnotScratchT<LAYOUT>;
     double* g;
     double* jac;
     double* hess;
+    const int16_t* inv = nullptr;
+    double nf = 0.0;
     __device__ __forceinline__ void G(int slot, int, double v) { g[slot] = v; }
     __device__ __forceinline__ void J(int slot, int, int, double v) { jac[slot] = v; }
-    __device__ __forceinline__ void H(int slot, int, int, double v) { hess[slot] = v; }
+    __device__ __forceinline__ void H(int slot, int, int, double v) {
+        if constexpr (DIRECT) {
+            const int p = inv[slot];
+            if (p >= 0) hess[p] = v;
+            nf += v * 0.0;
+        } else hess[slot] = v;
+    }
 };
 
 // LDS.  The Hessian program runs none of the tasks that emit Jacobian entries or the cost gradient: the last members of the knot scratch
@@ -705,9 +722,13 @@ template <int TERRAIN, int LAYOUT> struct DevEmH {
 //   LAYOUT_COMPACT (longer launches): the compact scratch and the lite tables of the four-wave callback kernel — own[] on the joint
 //                  records, the once-per-knot tables read from global memory, no staging of the horizon-end multipliers (no Hessian task
 //                  reads them: those rows are linear) — 52 KB: THREE workgroups per CU, 168 VGPRs.
-template <int TERRAIN, int LAYOUT> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LAYOUT == LAYOUT_COMPACT ? 3 : 2, LAYOUT == LAYOUT_COMPACT ? 3 : 2)))
+//   DIRECT (compact layout, planar terrain, device destinations): no staging of the entries at all (DevEmH) — 40.5 KB: FOUR workgroups per
+//                  CU, 128 VGPRs.
+template <int TERRAIN, int LAYOUT, bool DIRECT = false> __global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(DIRECT ? 4 : (LAYOUT == LAYOUT_COMPACT ? 3 : 2), DIRECT ? 4 : (LAYOUT == LAYOUT_COMPACT ? 3 : 2))))
 void hipnlp_knot_hess_kernel(HArgs a) {
-    using Em = DevEmH<TERRAIN, LAYOUT>;
+    static_assert(!DIRECT || LAYOUT == LAYOUT_COMPACT, "the direct stores belong to the batch launches");
+    using Em = DevEmH<TERRAIN, LAYOUT, DIRECT>;
     using Scratch = typename Em::Scratch;
     constexpr bool COMPACT = Scratch::compact;
     static_assert(offsetof(Scratch, jac) + sizeof(Scratch::jac) + 16 > sizeof(Scratch) && offsetof(Scratch, grad) + sizeof(Scratch::grad) == offsetof(Scratch, jac),
@@ -718,8 +739,12 @@ void hipnlp_knot_hess_kernel(HArgs a) {
     __shared__ alignas(16) double s_raw[S_BYTES / sizeof(double)];
     Scratch& s = *reinterpret_cast<Scratch*>(s_raw);
     __shared__ SharedTablesT<COMPACT> tabs;
-    __shared__ KHessScratch hx;
-    static_assert(S_BYTES + sizeof(SharedTablesT<COMPACT>) + sizeof(KHessScratch) <= (COMPACT ? 160 * 1024 / 3 : 80 * 1024), "workgroups per CU");
+    static_assert(offsetof(KHessScratch, H) + sizeof(KHessScratch::H) == sizeof(KHessScratch) && offsetof(KHessScratch, H) % 16 == 0, "H is the last member of the Hessian scratch");
+    constexpr size_t HX_BYTES = DIRECT ? offsetof(KHessScratch, H) : sizeof(KHessScratch);
+    __shared__ alignas(16) double hx_raw[HX_BYTES / sizeof(double)];
+    KHessScratch& hx = *reinterpret_cast<KHessScratch*>(hx_raw);
+    __shared__ alignas(16) int16_t inv_s[DIRECT ? HK_PAD : 8];
+    static_assert(S_BYTES + sizeof(SharedTablesT<COMPACT>) + HX_BYTES + sizeof(inv_s) <= (DIRECT ? 40960 : (COMPACT ? 160 * 1024 / 3 : 80 * 1024)), "workgroups per CU");
 #ifdef HIPNLP_STAMPS
     const unsigned long long st_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -772,6 +797,7 @@ void hipnlp_knot_hess_kernel(HArgs a) {
             stage(&tb.head, &tabs.head, int(sizeof(HeadTables)));
         }
         stage(&a.ht->far, &hx.far, int(sizeof(KHFarLists)));
+        if constexpr (DIRECT) stage(a.ht->inv, inv_s, int(sizeof(inv_s)));
         double xrem = 0.0, xov = 0.0;
         if (XREM && tid < 2 && !(first && tid == 1)) xrem = x[size_t(NXK) * (k - tid) + XB / 8];
         if (first || last) { if (tid < NPER) xov = x[size_t(NXK) * (first ? N - 1 : 0) + periodicity_row_var(tid)]; }
@@ -804,9 +830,9 @@ void hipnlp_knot_hess_kernel(HArgs a) {
         hpc = (last && tid < 84) ? ht.perm_couple[tid] : -1;   // (padded with -1 on the host)
     };
     int bar = 0;   // barriers passed (the program is straight-line code: a constant at every use)
-    if (HIPNLP_HESS_TABLES_AT == 0) fetch_tables();
+    if (!DIRECT && HIPNLP_HESS_TABLES_AT == 0) fetch_tables();
     KnotInfo ki{k, N, first, last};
-    Em em{s.g, s.jac, hx.H};
+    Em em{s.g, s.jac, DIRECT ? a.hess + int64_t(b) * a.hstride + (int64_t(a.nnz_knot) * k - a.hoff) : hx.H, inv_s};
     Ctx<Em> cx(s, tabs.kin(), tabs.settings(), tabs.gp, ki, em, COMPACT ? &tb.head.kt : nullptr, COMPACT ? a.gp + b : nullptr);
     KHCtx<Em> hcx{cx, hx, s.g};
     // (one contiguous program instance per wave, as in hipnlp_knot_kernel)
@@ -816,11 +842,11 @@ void hipnlp_knot_hess_kernel(HArgs a) {
     const unsigned long long st_staged = __builtin_amdgcn_s_memtime();
 #define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
 #define DEV_RH(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
-#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); bid++; if (++bar == HIPNLP_HESS_TABLES_AT) fetch_tables();
+#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); bid++; if (++bar == HIPNLP_HESS_TABLES_AT) { if constexpr (!DIRECT) fetch_tables(); }
 #else
 #define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_RH(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); }
-#define DEV_BARRIER lds_barrier(); if (++bar == HIPNLP_HESS_TABLES_AT) fetch_tables();
+#define DEV_BARRIER lds_barrier(); if (++bar == HIPNLP_HESS_TABLES_AT) { if constexpr (!DIRECT) fetch_tables(); }
 #endif
     auto run_wave = [&](auto wc) __attribute__((always_inline)) {
         constexpr int W = decltype(wc)::value;
@@ -835,15 +861,19 @@ void hipnlp_knot_hess_kernel(HArgs a) {
 #undef DEV_KIN
 #undef DEV_RH
 #undef DEV_BARRIER
-    double* out = a.hess + int64_t(b) * a.hstride + (int64_t(cnt) * k - a.hoff);
     int bad = 0;
-    double hv[HP_ITERS];
+    if constexpr (DIRECT) {
+        bad = cx.em.nf != cx.em.nf;   // (the entries are in place: every lane has watched what it emitted)
+    } else {
+        double* out = a.hess + int64_t(b) * a.hstride + (int64_t(cnt) * k - a.hoff);
+        double hv[HP_ITERS];
 #pragma unroll
-    for (int it = 0; it < HP_ITERS; ++it) hv[it] = hx.H[hp[it] >= 0 ? hp[it] : 0];   // every LDS read in flight before the first store
-    const double hvc = hx.H[hpc >= 0 ? hpc : 0];
+        for (int it = 0; it < HP_ITERS; ++it) hv[it] = hx.H[hp[it] >= 0 ? hp[it] : 0];   // every LDS read in flight before the first store
+        const double hvc = hx.H[hpc >= 0 ? hpc : 0];
 #pragma unroll
-    for (int it = 0; it < HP_ITERS; ++it) if (hp[it] >= 0) { bad |= !isfinite(hv[it]); out[tid + it * WG] = hv[it]; }
-    if (hpc >= 0) { bad |= !isfinite(hvc); a.hess[int64_t(b) * a.hstride + (int64_t(cnt) * N - a.hoff) + tid] = hvc; }
+        for (int it = 0; it < HP_ITERS; ++it) if (hp[it] >= 0) { bad |= !isfinite(hv[it]); out[tid + it * WG] = hv[it]; }
+        if (hpc >= 0) { bad |= !isfinite(hvc); a.hess[int64_t(b) * a.hstride + (int64_t(cnt) * N - a.hoff) + tid] = hvc; }
+    }
     if (__any(bad) && lane == 0) {   // nothing to reset between launches
         atomicMax(a.flag + b, a.seq);
         if (a.flag_host) a.flag_host[b] = a.seq;
@@ -969,6 +999,7 @@ struct hipnlp_handle {
     bool early_store_always = false;   // diagnostic (HIPNLP_EARLY_STORE=2): also for hipnlp_eval_device launches
     bool early_store = true;    // launches into host memory store what is final after the second phase then (diagnostic override: HIPNLP_EARLY_STORE=0)
     bool hess_compact = false;   // exact Hessian: compact-scratch instantiation (three workgroups per CU) for launches of more than 512 workgroups
+    bool hess_direct = true;     // ... and, planar terrain into device memory, the instantiation without LDS staging of the entries (diagnostic override: HIPNLP_HESS_DIRECT=0)
     int dev = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1148,6 +1179,7 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
         h->fused = h->nk <= red_cap && (h->wide || (small_launch && !(sep && std::atoi(sep) == 1)));
         const char* hl = std::getenv("HIPNLP_HESS_LAYOUT");   // diagnostic override: full | compact
         h->hess_compact = hl ? std::strcmp(hl, "compact") == 0 : long(h->nk) * long(desc->batch) > 512;
+        if (const char* hd = std::getenv("HIPNLP_HESS_DIRECT")) h->hess_direct = std::atoi(hd) != 0;
     }
     std::string e;
     if (!Layout::make_kin_tables(desc->model, h->kt, e)) return fail(HIPNLP_E_INVALID, e);
@@ -1611,6 +1643,9 @@ static int hess_prepare(hipnlp_handle* h) {
     for (int i = 0; i < hk::COUNT; ++i) t->perm[i] = i < h->HL.nnz_knot ? h->HL.perm[size_t(i)] : -1;
     for (int i = 0; i < 84; ++i) t->perm_couple[i] = i < h->HL.n_couple ? h->HL.perm_couple[size_t(i)] : -1;
     t->nnz_knot = h->HL.nnz_knot; t->n_couple = h->HL.n_couple;
+    for (int i = 0; i < HK_PAD; ++i) t->inv[i] = -1;
+    for (int i = 0; i < h->HL.nnz_knot; ++i) t->inv[h->HL.perm[size_t(i)]] = int16_t(i);
+    for (int i = 0; i < h->HL.n_couple; ++i) t->inv[h->HL.perm_couple[size_t(i)]] = int16_t(h->HL.nnz_knot + i);
     kh_fill_far_lists(h->kt, t->far);
     const hipError_t e = hipnlp_internal_memcpy(h->d_ht, t, sizeof(HessTables), hipMemcpyHostToDevice);
     delete t;
@@ -1654,7 +1689,7 @@ static int hess_launch(hipnlp_handle* h, const double* x_dev, const double* sigm
         HIP_TRY(h, hipDeviceSynchronize());
         h->hseq = 0;
     }
-    a.seq = ++h->hseq; a.pad_ = 0;
+    a.seq = ++h->hseq; a.nnz_knot = h->HL.nnz_knot;
 #ifdef HIPNLP_STAMPS
     if (!h->d_stamps) HIP_TRY(h, hipMalloc(&h->d_stamps, size_t(h->nk) * size_t(h->batch) * 1024 * sizeof(unsigned long long)));
     a.stamps = h->d_stamps;
@@ -1663,6 +1698,9 @@ static int hess_launch(hipnlp_handle* h, const double* x_dev, const double* sigm
     const bool smooth = h->d.settings.terrain != HIPNLP_TERRAIN_PLANAR;
     if (h->hess_compact) {   // (launches longer than the 512 workgroup slots of the full layout: three workgroups per CU)
         if (smooth) hipLaunchKernelGGL((hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, LAYOUT_COMPACT>), hgrid, dim3(256), 0, s, a);
+        // planar terrain, DEVICE destination: the entries go straight to their places (no LDS staging: four workgroups per CU); a host
+        // destination keeps the staged kernel, whose copy-out leaves as one run per knot (scattered 8-byte stores do not belong on PCIe)
+        else if (h->hess_direct && !host_block) hipLaunchKernelGGL((hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_PLANAR, LAYOUT_COMPACT, true>), hgrid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_PLANAR, LAYOUT_COMPACT>), hgrid, dim3(256), 0, s, a);
     } else {
         if (smooth) hipLaunchKernelGGL((hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, LAYOUT_FULL>), hgrid, dim3(256), 0, s, a);

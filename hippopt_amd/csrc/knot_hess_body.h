@@ -104,8 +104,8 @@ struct alignas(16) KHessScratch {   // (16-byte alignment: the spatial vectors a
     double qqB[16], qqg[4], qq_axE[3], qq_m2;   // (q_b, q_b): Hessian B and gradient g of Phi(qhat) = <M, R(qhat)>, chest-error axis
     double TW[3][3];         // (theta_m, omega_m') of the centroidal momentum term (t_kh_tw -> t_kh_qqd)
     double qqMw[9];          // Mw of the (q_b, q_b) block (t_kh_qq0_mw -> t_kh_qq0)
-    double H[hk::COUNT];
     KHFarLists far;
+    double H[hk::COUNT];     // LAST: the kernel that stores its entries straight into the destination (hipnlp.hip, DIRECT) does not allocate it
 };
 
 template <class Em> struct KHCtx {

@@ -66,6 +66,9 @@ def test_hessian_and_pose_kernels(res):
         hc = res["hipnlp_knot_hess_kernel<%d,1>" % t]
         # (LDS is handed out in granules of 1 280 B: three workgroups need 3 x ceil(lds / 1280) granules of the CU's 128)
         assert 3 * (-(-hc["lds"] // 1280)) * 1280 <= LDS_PER_CU and _granule(hc["vgpr"] + hc["agpr"]) * 3 <= VGPR_FILE and hc["scratch"] == 0, hc
+    # the planar Hessian kernel that stores its entries straight into a device destination (no LDS staging): four workgroups per CU
+    hd = res["hipnlp_knot_hess_kernel<0,1,true>"]
+    assert 4 * (-(-hd["lds"] // 1280)) * 1280 <= LDS_PER_CU and _granule(hd["vgpr"] + hd["agpr"]) * 4 <= VGPR_FILE and hd["scratch"] == 0, hd
     # pose kernels on the compact scratch with the lite tables: LDS for four workgroups per CU (32 granules of 1 280 B each); the callback
     # kernels and the planar Hessian kernel fit the 128 registers that takes, the smooth terrain's Hessian kernel stays at three per CU
     for t in (0, 1):
