@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-WORKLOADS=${@:-"periodic_N100_B1:--batch=1 periodic_N100_B64:--batch=64 periodic_N100_B1024:--batch=1024 stairs_N200_B16:--workload=stairs,--horizon=200,--batch=16 periodic_N100_B1_vf:--batch=1,--varying-first periodic_N100_B64_vf:--batch=64,--varying-first periodic_N100_B1024_vf:--batch=1024,--varying-first stairs_N200_B16_vf:--workload=stairs,--horizon=200,--batch=16,--varying-first periodic_N100_B64_ccsv:--batch=64,--ccs-constants-in-place periodic_N100_B1024_ccsv:--batch=1024,--ccs-constants-in-place"}
+WORKLOADS=${@:-"periodic_N100_B64:--batch=64 periodic_N100_B1:--batch=1 periodic_N100_B1024:--batch=1024 stairs_N200_B16:--workload=stairs,--horizon=200,--batch=16 periodic_N100_B1_vf:--batch=1,--varying-first periodic_N100_B64_vf:--batch=64,--varying-first periodic_N100_B1024_vf:--batch=1024,--varying-first stairs_N200_B16_vf:--workload=stairs,--horizon=200,--batch=16,--varying-first periodic_N100_B64_ccsv:--batch=64,--ccs-constants-in-place periodic_N100_B1024_ccsv:--batch=1024,--ccs-constants-in-place"}
 PARTS=${PROFILE_PARTS:-"bench hess pose calib"}   # which parts run (a whole round does not fit one gpurun call of 20 minutes)
 has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
 run() { name=$1; shift; echo "== $name" ; rocprofv3 "$@" > $OUT/$name.log 2>&1; echo "   rc=$?"; }
