@@ -84,6 +84,7 @@ struct ConstCheck {
     int32_t* healed;
     int64_t jac_stride, jac_off;
     int32_t ctpl_len, ctpl_off[4], nnz_v[3], first_const[3] /* position of a block's first constant entry, -1: none */, kb, nk, N, n_glob, jac_glob_base;
+    int32_t samp[3][4];        // four constant positions of a variant-v block, spread over its constants (first and last among them; -1: none)
 };
 // the templates hold this word (a quiet NaN no constant has) at the positions of a block that depend on x
 constexpr unsigned long long CTPL_VARYING = 0x7FF8C0DEC0DE0001ull;
@@ -177,9 +178,11 @@ constexpr int PUB_SPIN_CAP = 1 << 20;   // polls of the reducer before it gives 
 // VARY launches into a DEVICE destination: are the constant entries of trajectory b's knot blocks in place?  Run by the ONE workgroup
 // per trajectory that sums its cost (the reducer workgroup of the launch, or hipnlp_reduce_kernel behind it) — never by the knot
 // workgroups: two loads on their path, wherever they were issued, cost 4 - 10 % at batch (vector loads of table words with a wait
-// right behind them; then the round trip to HBM itself).  Thread t looks at the FIRST constant entry of the block of knot kb + t
-// (+ 256, ...); if any differs from the handle's template the workgroup puts the constants of ALL the trajectory's blocks back (rare —
-// a caller that wrote over its buffer — slow, right: the knot workgroups store other entries, nothing is written twice).
+// right behind them; then the round trip to HBM itself).  Thread t looks at FOUR constant entries of the block of knot kb + t (+ 256, ...)
+// — the first, the last and two in between (ConstCheck::samp) —; if any differs from the handle's template the workgroup puts the
+// constants of ALL the trajectory's blocks back (rare — a caller that wrote over its buffer — slow, right: the knot workgroups store
+// other entries, nothing is written twice).  A SAMPLE: constants overwritten elsewhere in a block are not seen — a caller that hands
+// over other memory at an address the handle has filled (a tensor freed and re-allocated) says so with hipnlp_forget_jac_destination.
 __device__ __forceinline__ void constants_check_and_repair(const ConstCheck& c, int b, int nthreads, int* lds_flags /* one int per wave of the workgroup */) {
     if (!c.jac || !c.ctpl) return;
     const int tid = threadIdx.x;
@@ -190,8 +193,12 @@ __device__ __forceinline__ void constants_check_and_repair(const ConstCheck& c, 
         const int k = c.kb + t, v = k == 0 ? VAR_FIRST : (k == c.N - 1 ? VAR_LAST : VAR_INTERIOR);
         if (c.first_const[v] < 0) continue;
         const int64_t base = k == 0 ? 0 : int64_t(c.nnz_v[VAR_FIRST]) + int64_t(k - 1) * c.nnz_v[VAR_INTERIOR];
-        const double seen = out[base + c.first_const[v]], want = tpl[c.ctpl_off[v] + c.first_const[v]];
-        miss |= __double_as_longlong(seen) != __double_as_longlong(want);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int sp = c.samp[v][q] >= 0 ? c.samp[v][q] : c.first_const[v];
+            const double seen = out[base + sp], want = tpl[c.ctpl_off[v] + sp];
+            miss |= __double_as_longlong(seen) != __double_as_longlong(want);
+        }
     }
     // (an OR over the workgroup through the caller's LDS words: __syncthreads_or brings 256 B of LDS of its own, which the four-wave
     //  kernel — 40 KB to the byte for four workgroups per CU — does not have)
@@ -519,7 +526,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     unsigned long long st_arr[8], st_dep[8];
     const unsigned long long st_staged = __builtin_amdgcn_s_memtime();
     int bid = 0;
-#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); if constexpr (W == PUBW) pub_step(bid); if constexpr (EARLY_OUT) { if (bid == 1) early_out(); } bid++;
+#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); if constexpr (W == PUBW) pub_step(bid); if constexpr (LATE_TABLES) { if (bid == 4) fetch_tables(); } if constexpr (EARLY_OUT) { if (bid == 1) early_out(); } bid++;
 #else
     int bid = 0;
 #define DEV_BARRIER lds_barrier(); if constexpr (W == PUBW) pub_step(bid); if constexpr (LATE_TABLES) { if (bid == 4) fetch_tables(); } if constexpr (EARLY_OUT) { if (bid == 1) early_out(); } bid++;
@@ -709,8 +716,7 @@ template <int TERRAIN, int LAYOUT, bool DIRECT = false> struct DevEmH {
     __device__ __forceinline__ void H(int slot, int, int, double v) {
         if constexpr (DIRECT) {
             const int p = inv[slot];
-            if (p >= 0) hess[p] = v;
-            nf += v * 0.0;
+            if (p >= 0) { hess[p] = v; nf += v * 0.0; }   // (entries of the pattern only: what the staged kernel's copy-out looks at)
         } else hess[slot] = v;
     }
 };
@@ -969,11 +975,32 @@ __global__ __launch_bounds__(256) void hipnlp_fill_const_kernel(double* __restri
 
 thread_local std::string g_create_error;
 
+// Diagnostic overrides from the environment (kernel variant, launch numbering, A/B switches of one process): compiled into the test /
+// measurement build only (-DHIPNLP_DIAG: tests/_build/libhipnlp_diag.so, same device code).  The shipped library reads NO environment
+// variable: what a handle does is decided by hipnlp_desc and the hipnlp_set_* calls alone.
+#ifdef HIPNLP_DIAG
+inline const char* diag_env(const char* name) { return std::getenv(name); }
+#else
+inline const char* diag_env(const char*) { return nullptr; }
+#endif
+
 // host ranges registered through hipnlp_host_register: a caller-owned output array inside one of them is stored to DIRECTLY by the
 // kernel (hipnlp_eval looks its pointers up here), no staging copy
-struct HostRange { char* host; size_t bytes; char* dev; const void* owner; };   // owner: the handle that registered the range by itself, or null (the caller did)
+struct HostRange { char* host; size_t bytes; char* dev; const void* owner; unsigned long long id; };   // owner: the handle that registered the range by itself, or null (the caller did); id: of THIS registration (never reused)
 std::mutex g_ranges_mutex;
 std::vector<HostRange> g_ranges;
+unsigned long long g_range_ids = 0;   // (under g_ranges_mutex)
+// the registration that answers for p (device_address_of's rule: the newest range that covers it), 0: none
+unsigned long long registration_of(const void* p, size_t bytes) {
+    if (!p) return 0;
+    std::lock_guard<std::mutex> lock(g_ranges_mutex);
+    const char* q = static_cast<const char*>(p);
+    for (size_t i = g_ranges.size(); i-- > 0;) {
+        const HostRange& r = g_ranges[i];
+        if (q >= r.host && q + bytes <= r.host + r.bytes) return r.id;
+    }
+    return 0;
+}
 double* device_address_of(const void* p, size_t bytes) {
     if (!p) return nullptr;
     std::lock_guard<std::mutex> lock(g_ranges_mutex);
@@ -1068,7 +1095,9 @@ struct hipnlp_handle {
     std::vector<int> ctpl_of_b;                     // template of trajectory b
     std::vector<int32_t> cpos[3];                   // constant positions of a variant-v block
     int ctpl_off[4] = {0, 0, 0, 0};
-    struct ConstFilled { const void* host; unsigned long long gen; };
+    // (reg: the registration — HostRange::id — the array was filled under.  An array that was unregistered since, by whoever, and comes back
+    //  at the same address is a NEW registration: whatever its pages hold now, it is filled again before a launch skips the constants)
+    struct ConstFilled { const void* host; unsigned long long gen, reg; };
     ConstFilled cfilled[8] = {};                    // caller arrays that hold this handle's constants, and of which parameter set
     int cfilled_next = 0;
     unsigned long long pinned_const_gen = 0;        // parameter set whose constants the pinned block holds (0: none)
@@ -1159,14 +1188,14 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     if (h->kb < 0 || h->ke > st.horizon || h->kb >= h->ke) return fail(HIPNLP_E_INVALID, "bad knot shard [knot_begin, knot_end)");
     h->nk = h->ke - h->kb;
     {
-        const char* force = std::getenv("HIPNLP_WAVES");   // diagnostic override: 4 or 8
+        const char* force = diag_env("HIPNLP_WAVES");   // diagnostic override: 4 or 8
         // eight waves per knot while every workgroup of the launch (+ one reducer per trajectory) is resident at once: two per CU
         // (<= 128 VGPRs, 2 x 52 KB of LDS).  Measured at N = 100 (tools/diag/wide_sweep.sh): +28 .. +31 % over the four-wave kernel for
         // batch 2 .. 5, nothing once the launch exceeds the 512 slots (batch 6: 36.9 against 38.0 M knots/s).
         const bool fits = h->nk <= 256 && (long(h->nk) + 1) * long(desc->batch) <= 512;
         h->wide = force ? (std::atoi(force) == 8 && h->nk <= 256) : fits;
-        if (const char* s0 = std::getenv("HIPNLP_DEBUG_SEQ0")) h->seq = h->hseq = std::atoi(s0);   // diagnostic: launch numbers start here (tests of the wrap)
-        const char* sep = std::getenv("HIPNLP_SEPARATE_REDUCE");   // diagnostic override: the reduction kernel behind the four-wave kernel
+        if (const char* s0 = diag_env("HIPNLP_DEBUG_SEQ0")) h->seq = h->hseq = std::atoi(s0);   // diagnostic: launch numbers start here (tests of the wrap)
+        const char* sep = diag_env("HIPNLP_SEPARATE_REDUCE");   // diagnostic override: the reduction kernel behind the four-wave kernel
         // (measured, four-wave kernel, N = 100: + 2.4 % at x 64 and + 6.5 % on the stairs 200 x 16, whose second launch is 3 of 53 us;
         //  - 1.1 % at x 1024, where ten rows are in flight and as many reducers spin in workgroup slots: long launches keep the kernel)
         const bool small_launch = long(h->nk) * long(desc->batch) <= 32768;
@@ -1177,18 +1206,18 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
             red_cap = st.terrain == HIPNLP_TERRAIN_PLANAR ? reducer_cap<KnotScratchT<LAYOUT_COMPACT, js::vary_slots(true)>>()
                                                           : reducer_cap<KnotScratchT<LAYOUT_COMPACT, js::vary_slots(false)>>();
         h->fused = h->nk <= red_cap && (h->wide || (small_launch && !(sep && std::atoi(sep) == 1)));
-        const char* hl = std::getenv("HIPNLP_HESS_LAYOUT");   // diagnostic override: full | compact
+        const char* hl = diag_env("HIPNLP_HESS_LAYOUT");   // diagnostic override: full | compact
         h->hess_compact = hl ? std::strcmp(hl, "compact") == 0 : long(h->nk) * long(desc->batch) > 512;
-        if (const char* hd = std::getenv("HIPNLP_HESS_DIRECT")) h->hess_direct = std::atoi(hd) != 0;
+        if (const char* hd = diag_env("HIPNLP_HESS_DIRECT")) h->hess_direct = std::atoi(hd) != 0;
     }
     std::string e;
     if (!Layout::make_kin_tables(desc->model, h->kt, e)) return fail(HIPNLP_E_INVALID, e);
     if (!h->L.build(st, h->kt, (desc->flags & HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS) != 0, (desc->flags & HIPNLP_FLAG_JAC_VARYING_FIRST) != 0))
         return fail(HIPNLP_E_INVALID, h->L.error);
     h->skip_const = h->L.vary_first;   // (a CCS handle stores every entry unless hipnlp_set_constant_jacobian(h, 1) asks for the scheme: the contract on the destination is the caller's to accept)
-    if (const char* cj = std::getenv("HIPNLP_CONST_JAC")) h->skip_const = std::atoi(cj) != 0;   // diagnostic override of hipnlp_set_constant_jacobian's default
-    if (const char* vc = std::getenv("HIPNLP_VARY_CHECK")) h->vary_check = std::atoi(vc) != 0;
-    if (const char* es = std::getenv("HIPNLP_EARLY_STORE")) { h->early_store = std::atoi(es) != 0; h->early_store_always = std::atoi(es) == 2; }   // diagnostic override (A/B in one process)
+    if (const char* cj = diag_env("HIPNLP_CONST_JAC")) h->skip_const = std::atoi(cj) != 0;   // diagnostic override of hipnlp_set_constant_jacobian's default
+    if (const char* vc = diag_env("HIPNLP_VARY_CHECK")) h->vary_check = std::atoi(vc) != 0;
+    if (const char* es = diag_env("HIPNLP_EARLY_STORE")) { h->early_store = std::atoi(es) != 0; h->early_store_always = std::atoi(es) == 2; }   // diagnostic override (A/B in one process)
     h->np = ParamOffsets(st.horizon).np();
     if (h->L.jperm_glob.size() > 16) return fail(HIPNLP_E_INVALID, "internal: too many global-column entries");
 
@@ -1248,7 +1277,7 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
         //  runs of 3 - 24 doubles per constraint block — and even as such fragments on the link they arrive sooner than behind a copy
         //  command and its hand-over to the kernel: 67.5 -> 59.7 us per 100-knot Hessian through host buffers, tools/diag/hess_host_ab.py)
         h->lam_zero_copy = B * (1 + m) * sizeof(double) <= (size_t(1) << 20);
-        if (const char* lz = std::getenv("HIPNLP_HESS_LAM_ZERO_COPY")) h->lam_zero_copy = std::atoi(lz) != 0;   // diagnostic override (A/B in one process)
+        if (const char* lz = diag_env("HIPNLP_HESS_LAM_ZERO_COPY")) h->lam_zero_copy = std::atoi(lz) != 0;   // diagnostic override (A/B in one process)
     }
     CREATE_TRY(hipMemset(h->d_g, 0, B * m * sizeof(double)));
     CREATE_TRY(hipMemset(h->d_jac, 0, B * nnz * sizeof(double)));
@@ -1285,7 +1314,7 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     {
         // the VARY instantiations (varying-first order): the varying run of a block, thread-major, -1 behind it
         const int wg = h->wide ? 512 : 256, cap = vary_cap(st.terrain, wg), jt = cap / wg;
-        h->vary_ok = true;
+        h->vary_ok = h->L.vary_partition_ok;   // (a varying slot outside the window the trimmed scratch stages: every entry is stored, by the kernels on the full staging)
         for (int v = 0; v < 3; ++v) {
             if (h->L.nnz_v[v] > JP_POS + 1) h->vary_ok = false;
             h->cpos[v].clear();
@@ -1449,7 +1478,8 @@ static void constants_fill(const hipnlp_handle* h, double* jac) {
 static void constants_ensure(hipnlp_handle* h, double* jac_host) {
     int slot = -1;
     for (int i = 0; i < 8; ++i) if (h->cfilled[i].host == jac_host) slot = i;
-    bool ok = slot >= 0 && h->cfilled[slot].gen == h->param_gen;
+    const unsigned long long reg = registration_of(jac_host, size_t(h->batch) * size_t(h->L.nnz) * sizeof(double));
+    bool ok = slot >= 0 && h->cfilled[slot].gen == h->param_gen && reg != 0 && h->cfilled[slot].reg == reg;
     if (ok)
         for (const auto& sv : h->csample)
             if (std::memcmp(&jac_host[sv.first], &sv.second, sizeof(double)) != 0) { ok = false; h->const_refills++; break; }
@@ -1457,7 +1487,7 @@ static void constants_ensure(hipnlp_handle* h, double* jac_host) {
     constants_fill(h, jac_host);
     h->const_fills++;
     if (slot < 0) { slot = h->cfilled_next; h->cfilled_next = (h->cfilled_next + 1) % 8; }
-    h->cfilled[slot] = {jac_host, h->param_gen};
+    h->cfilled[slot] = {jac_host, h->param_gen, reg};
 }
 
 int hipnlp_set_params(hipnlp_handle* h, const double* p) {
@@ -1526,7 +1556,11 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
         c.jac = on ? jac_dev : nullptr; c.ctpl = on ? h->d_ctpl : nullptr; c.ctpl_of_b = h->d_ctpl_of_b; c.healed = h->d_healed;
         c.jac_stride = h->L.nnz; c.jac_off = 0; c.ctpl_len = h->ctpl_len;
         for (int v = 0; v < 4; ++v) c.ctpl_off[v] = h->ctpl_off[v];
-        for (int v = 0; v < 3; ++v) { c.nnz_v[v] = h->L.nnz_v[v]; c.first_const[v] = h->cpos[v].empty() ? -1 : h->cpos[v][0]; }
+        for (int v = 0; v < 3; ++v) {
+            c.nnz_v[v] = h->L.nnz_v[v]; c.first_const[v] = h->cpos[v].empty() ? -1 : h->cpos[v][0];
+            const size_t nc = h->cpos[v].size();
+            for (size_t q = 0; q < 4; ++q) c.samp[v][q] = nc ? h->cpos[v][(q * (nc - 1)) / 3] : -1;
+        }
         c.kb = h->kb; c.nk = h->nk; c.N = h->L.N; c.n_glob = int(h->L.jperm_glob.size()); c.jac_glob_base = h->L.jac_glob_base;
     }
     a.g = g_dev; a.jac = jac_dev; a.grad = grad_dev; a.g_stage = g_stage;
@@ -1890,7 +1924,7 @@ static void forget_range(hipnlp_handle* h, const char* base, size_t bytes) {
     }
     for (int i = 0; i < 8; ++i) {
         const char* c = static_cast<const char*>(h->cfilled[i].host);
-        if (c && c >= base && c < base + bytes) h->cfilled[i] = {nullptr, 0};
+        if (c && c >= base && c < base + bytes) h->cfilled[i] = {nullptr, 0, 0};
     }
 }
 static int drop_stale_range(hipnlp_handle* h, void* p) {
@@ -1936,7 +1970,7 @@ static double* caller_array_address(hipnlp_handle* h, int q, double* p, size_t b
         if (hipnlp_host_register(p, bytes, &d) == HIPNLP_OK) {
             // (diagnostic, tests only: HIPNLP_DEBUG_MISDIRECT_AUTO maps the array to the pinned block's copy of the output instead —
             //  stores that do not arrive in the caller's pages, the situation the sentinel check exists for, without unmapping anything)
-            if (std::getenv("HIPNLP_DEBUG_MISDIRECT_AUTO")) d = q == 0 ? (void*)h->hd_grad : (q == 1 ? (void*)h->hd_g : (q == 2 ? (void*)h->hd_jac : (void*)h->hd_hess));
+            if (diag_env("HIPNLP_DEBUG_MISDIRECT_AUTO")) d = q == 0 ? (void*)h->hd_grad : (q == 1 ? (void*)h->hd_g : (q == 2 ? (void*)h->hd_jac : (void*)h->hd_hess));
             {
                 std::lock_guard<std::mutex> lock(g_ranges_mutex);
                 for (HostRange& r : g_ranges) if (r.host == reinterpret_cast<char*>(p)) { r.owner = h; r.dev = static_cast<char*>(d); }
@@ -2220,6 +2254,15 @@ int hipnlp_set_constant_jacobian(hipnlp_handle* h, int on) {
     h->skip_const = on != 0;
     return HIPNLP_OK;
 }
+int hipnlp_forget_jac_destination(hipnlp_handle* h, const void* p) {
+    if (!h) return HIPNLP_E_INVALID;
+    int n = 0;
+    for (int i = 0; i < 8; ++i) {
+        if (h->dfilled[i].dev && (!p || h->dfilled[i].dev == p)) { h->dfilled[i] = {nullptr, 0}; ++n; }
+        if (h->cfilled[i].host && (!p || h->cfilled[i].host == p)) { h->cfilled[i] = {nullptr, 0, 0}; ++n; }
+    }
+    return n;
+}
 int hipnlp_jac_constant_mask(const hipnlp_handle* h, unsigned char* mask) {
     if (!h || !mask) return HIPNLP_E_INVALID;
     h->L.constant_mask(mask);
@@ -2276,7 +2319,7 @@ int hipnlp_host_register(void* p, size_t bytes, void** dev_ptr) {
     if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) { (void)hipHostUnregister(p); (void)hipGetLastError(); return HIPNLP_E_NODEVICE; }
     if (dev_ptr) *dev_ptr = d;
     std::lock_guard<std::mutex> lock(g_ranges_mutex);
-    g_ranges.push_back(HostRange{static_cast<char*>(p), bytes, static_cast<char*>(d), nullptr});
+    g_ranges.push_back(HostRange{static_cast<char*>(p), bytes, static_cast<char*>(d), nullptr, ++g_range_ids});
     return HIPNLP_OK;
 }
 int hipnlp_host_release_auto_ranges(void) {

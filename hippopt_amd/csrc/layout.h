@@ -129,6 +129,12 @@ struct Layout {
     std::vector<unsigned char> jconst_pos[3];
     int nvary_v[3] = {0, 0, 0};
     int nconst_total = 0;                 // constant entries of the whole pattern
+    // The trimmed scratch of the four-wave VARY kernels stages the slots [js::V0, js::V0 + js::vary_slots(terrain)) only, addressed through
+    // a base moved back by js::V0: every recorded slot that is NOT constant must lie in that window (a slot below it would be a store in
+    // front of the staging, one behind it a store into grad[]).  Checked from what the recorder saw, not from the numbering's intent;
+    // hipnlp_create launches no VARY kernel for a layout that fails it (tests/test_constant_jacobian.py asserts it holds).
+    bool vary_partition_ok = false;
+    int vary_slot_min = -1, vary_slot_max = -1;   // smallest / largest recorded slot that depends on x
     std::vector<int32_t> irow, jcol;      // full pattern, CCS order
     std::string error;
 
@@ -279,6 +285,17 @@ struct Layout {
             delete s;
         }
         if (dup) { error = "internal: native slot emitted twice"; return false; }
+        {
+            const int v_end = js::V0 + js::vary_slots(st.terrain == HIPNLP_TERRAIN_PLANAR);
+            vary_partition_ok = true;
+            vary_slot_min = vary_slot_max = -1;
+            for (int slot = 0; slot < js::COUNT; ++slot) {
+                if (jrid[size_t(slot)] < 0 || jconst_slot[size_t(slot)]) continue;
+                if (vary_slot_min < 0) vary_slot_min = slot;
+                vary_slot_max = slot;
+                if (slot < js::V0 || slot >= v_end) vary_partition_ok = false;
+            }
+        }
 
         // ---- g tables ------------------------------------------------------------------------------------
         g_b.assign(gs::COUNT, 0);

@@ -14,7 +14,7 @@ from . import _abi
 
 # (HIPNLP_LIB_PATH: diagnostic override to load another BUILD of the same HIP library, e.g. an A/B variant under tools/diag/_build)
 _LIB_PATH = os.environ.get("HIPNLP_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhipnlp.so")
-_lib = None
+_libs = {}     # path -> bound library (the product library; tests also load the diagnostic build of the same sources beside it)
 
 EXPORTS = [
     "hipnlp_abi_version", "hipnlp_build_info",
@@ -26,7 +26,7 @@ EXPORTS = [
     "hipnlp_ipc_alloc", "hipnlp_ipc_open", "hipnlp_ipc_close", "hipnlp_ipc_free", "hipnlp_peer_push", "hipnlp_peer_signal", "hipnlp_peer_signal_checked", "hipnlp_peer_wait", "hipnlp_eval_device_peers",
     "hipnlp_hess_nnz", "hipnlp_hess_sparsity", "hipnlp_eval_hess", "hipnlp_eval_hess_device",
     "hipnlp_eval_pinned", "hipnlp_set_prefetch", "hipnlp_set_early_outputs", "hipnlp_set_host_timing", "hipnlp_host_register", "hipnlp_host_unregister",
-    "hipnlp_host_breakdown", "hipnlp_set_auto_register", "hipnlp_host_stats", "hipnlp_set_constant_jacobian", "hipnlp_jac_constant_mask", "hipnlp_host_release_auto_ranges",
+    "hipnlp_host_breakdown", "hipnlp_set_auto_register", "hipnlp_host_stats", "hipnlp_set_constant_jacobian", "hipnlp_forget_jac_destination", "hipnlp_jac_constant_mask", "hipnlp_host_release_auto_ranges",
     "hipnlp_pose_create", "hipnlp_pose_destroy", "hipnlp_pose_last_error", "hipnlp_pose_get_dims", "hipnlp_pose_set_params",
     "hipnlp_pose_bounds", "hipnlp_pose_sparsity", "hipnlp_pose_eval", "hipnlp_pose_eval_device", "hipnlp_pose_cost_terms",
     "hipnlp_pose_cost_term_name", "hipnlp_pose_num_row_blocks", "hipnlp_pose_row_block", "hipnlp_pose_last_kernel_ms",
@@ -53,13 +53,15 @@ def build_info():
     return load_library().hipnlp_build_info().decode()
 
 
-def load_library():
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(_LIB_PATH):
+def load_library(path=None):
+    """the bound C library.  path: another BUILD of the same sources (tests: the diagnostic build, tests/_build/libhipnlp_diag.so, whose
+    hipnlp_create honours the HIPNLP_* environment overrides the shipped library does not read); default: the product library"""
+    path = path or _LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise ImportError(
-            f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). The engine has no CPU fallback.")
     try:
         # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64; if libhipnlp.so pulled in /opt/rocm's copy first, a
@@ -67,7 +69,7 @@ def load_library():
         import torch  # noqa: F401
     except ImportError:
         pass
-    lib = C.CDLL(_LIB_PATH)
+    lib = C.CDLL(path)
     dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
     lib.hipnlp_create.argtypes = [C.POINTER(_abi.DescC), C.POINTER(vp)]
     lib.hipnlp_destroy.argtypes = [vp]
@@ -81,7 +83,7 @@ def load_library():
     lib.hipnlp_lift_map.argtypes = [vp, ip, dp, dp]
     lib.hipnlp_build_info.restype = C.c_char_p
     if lib.hipnlp_abi_version() != _abi.ABI_VERSION:
-        raise ImportError(f"{_LIB_PATH} implements ABI version {lib.hipnlp_abi_version()}, this package expects {_abi.ABI_VERSION}: rebuild the library")
+        raise ImportError(f"{path} implements ABI version {lib.hipnlp_abi_version()}, this package expects {_abi.ABI_VERSION}: rebuild the library")
     lib.hipnlp_sparsity.argtypes = [vp, ip, ip]
     lib.hipnlp_eval.argtypes = [vp, dp, C.c_int, dp, dp, dp, dp]
     lib.hipnlp_eval_device.argtypes = [vp, vp, vp, vp, vp, vp, vp]
@@ -134,7 +136,8 @@ def load_library():
     lib.hipnlp_host_stats.argtypes = [vp, C.POINTER(C.c_long)]
     lib.hipnlp_set_constant_jacobian.argtypes = [vp, C.c_int]
     lib.hipnlp_jac_constant_mask.argtypes = [vp, C.POINTER(C.c_ubyte)]
-    _lib = lib
+    lib.hipnlp_forget_jac_destination.argtypes = [vp, vp]
+    _libs[path] = lib
     return lib
 
 
@@ -150,13 +153,14 @@ class HipNlp:
     """One engine handle: a kinodynamic NLP (settings + robot model) on one HIP device."""
 
     def __init__(self, settings, model, batch=1, knot_begin=0, knot_end=0, device=0, desc=None, detect_simple_bounds=False,
-                 jac_varying_first=False):
+                 jac_varying_first=False, library=None):
         """desc: a ready hipnlp_desc (e.g. hippopt_amd.from_reference.from_reference) instead of settings / model
         detect_simple_bounds: the handle is the REDUCED NLP nlpsol hands to IPOPT under Opti's {"detect_simple_bounds": True}
         (HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS): single-variable rows are bounds on x, not rows of g
         jac_varying_first: HIPNLP_FLAG_JAC_VARYING_FIRST — inside a knot's block of jac g the entries that depend on x come first,
-        the constant ones behind them (triplet consumers such as IPOPT; `sparsity()` returns that order)"""
-        self.lib = load_library()
+        the constant ones behind them (triplet consumers such as IPOPT; `sparsity()` returns that order)
+        library: path of another build of the library (tests: the diagnostic build); default: the product library"""
+        self.lib = load_library(library)
         if desc is not None:
             self.desc = desc
             batch = desc.batch
@@ -373,6 +377,14 @@ class HipNlp:
         for varying-first handles (host and device destinations); a handle in CCS order stores every entry unless this asks for the
         scheme — then its DEVICE destinations (`eval_device`) are filled once and receive the varying entries at their CCS positions."""
         self._check(self.lib.hipnlp_set_constant_jacobian(self.h, 1 if on else 0))
+
+    def forget_jac_destination(self, ptr=0):
+        """hipnlp_forget_jac_destination: the buffer at `ptr` (0: every one the handle remembers) no longer counts as holding the constant
+        entries — for callers whose allocator may hand out the address of a freed jac buffer again; returns the records dropped"""
+        n = self.lib.hipnlp_forget_jac_destination(self.h, C.c_void_p(ptr or None))
+        if n < 0:
+            self._check(n)
+        return n
 
     def jac_constant_mask(self):
         """bool [nnz] in the order of `sparsity()`: entries of jac g that do not depend on x"""

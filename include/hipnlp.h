@@ -284,12 +284,22 @@ int hipnlp_set_prefetch(hipnlp_handle* h, unsigned mask);
  * varying entries of every knot block only — one run in the varying-first order, scattered over the block in CasADi's CCS order (on = 1
  * on a handle WITHOUT HIPNLP_FLAG_JAC_VARYING_FIRST asks for exactly this: device destinations only, host destinations of a CCS handle keep
  * receiving every entry) — and no longer stage the constants in LDS at all.  Same contract — the caller does not write into
- * the buffer between calls — and the kernel itself checks it: every wave compares a few dozen of the constants it finds with the
- * handle's templates and puts its slice of the block's constants back when one differs (hipnlp_host_stats out[7] counts such repairs).
+ * the buffer between calls — and the launch itself samples it: the one workgroup per trajectory that sums the cost compares FOUR constant
+ * entries of every knot block (its first, its last, two in between) with the handle's templates and puts the constants of all the
+ * trajectory's blocks back when one differs (hipnlp_host_stats out[7] counts such repairs).  A sample, not a guarantee: constants
+ * overwritten elsewhere in a block are returned as they are.  The record "this buffer holds the constants" is keyed by the buffer's
+ * ADDRESS: a caller that frees a jac buffer and later hands over other memory at the same address (a caching allocator does that) must
+ * call hipnlp_forget_jac_destination first — the next evaluation then fills the buffer again.
  * hipnlp_eval_device_shard / _peers are not affected: every entry is stored.
  * on = 0: every launch stores every entry (the behaviour of ABI 2 libraries before this switch existed).
  * Default: on for handles created with HIPNLP_FLAG_JAC_VARYING_FIRST, off for handles in CCS order. */
 int hipnlp_set_constant_jacobian(hipnlp_handle* h, int on);
+/* Forget that the jac destination at address p (device buffer of hipnlp_eval_device, or registered host array of hipnlp_eval) holds this
+ * handle's constant entries; p = NULL: every destination the handle remembers.  The next evaluation into it fills the constants again.
+ * For callers whose allocator may hand out the same address for a new buffer.  Returns the number of records dropped (>= 0), or an
+ * error code (< 0).  Host arrays need no such call since ABI-compatible revision 5: their record is tied to the array's REGISTRATION
+ * (hipnlp_host_register / auto-registration), and an array that was unregistered — by anybody — is filled again when it comes back. */
+int hipnlp_forget_jac_destination(hipnlp_handle* h, const void* p);
 /* Early outputs (opt-in, off by default).  on = 1: a NEW evaluation stores g and jac g — when its call does NOT ask for them —
  * straight into the REGISTERED caller arrays (hipnlp_host_register, or registered by the handle itself) that earlier calls passed
  * for them, before the caller asks.  IPOPT's sequence eval_f(new x), eval_g, eval_grad_f, eval_jac_g then costs one launch that moves

@@ -302,6 +302,11 @@ void hostemu_vary_counts(const hostemu_handle* h, int* nvary /*[3]*/, int* nnz_v
     for (int v = 0; v < 3; ++v) { nvary[v] = h->L.nvary_v[v]; nnz_v[v] = h->L.nnz_v[v]; }
     *nconst_total = h->L.nconst_total;
 }
+// the window of native slots the trimmed scratch of the four-wave VARY kernels stages, and what the recorder saw (Layout::vary_partition_ok)
+void hostemu_vary_partition(const hostemu_handle* h, int* out /*[5]: ok, smallest varying slot, largest, window begin, window end*/) {
+    out[0] = h->L.vary_partition_ok ? 1 : 0; out[1] = h->L.vary_slot_min; out[2] = h->L.vary_slot_max;
+    out[3] = js::V0; out[4] = js::V0 + js::vary_slots(h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR);
+}
 // phase of the knot program (barriers passed) in which every entry of jac g (pattern order) and every row of g gets its value
 void hostemu_output_phases(const hostemu_handle* h, unsigned char* jac_phase /*[nnz]*/, unsigned char* g_phase /*[m]*/) {
     const Layout& L = h->L;

@@ -70,6 +70,12 @@ class HostEmu:
         self.lib.hostemu_vary_counts(C.c_void_p(self.h), a, b, C.byref(c))
         return list(a), list(b), c.value
 
+    def vary_partition(self):
+        """(ok, smallest recorded slot that depends on x, largest, window begin, window end): Layout::vary_partition_ok and its evidence"""
+        out = (C.c_int * 5)()
+        self.lib.hostemu_vary_partition(C.c_void_p(self.h), out)
+        return bool(out[0]), out[1], out[2], out[3], out[4]
+
     def early_violations(self):
         """entries marked final after the second phase whose staged value changed later, in the last wave-order evaluation"""
         self.lib.hostemu_early_violations.restype = C.c_long

@@ -120,3 +120,18 @@ def test_varying_first_order_is_a_permutation_inside_every_knot_block(model, mak
     # what the library fills in is consistent with the order
     fill = vf.constant_fill(p[0])
     assert np.array_equal(fill[mask].view(np.uint64), j2[mask].view(np.uint64))
+
+
+@pytest.mark.parametrize("maker", [periodic_step_settings, single_step_settings, stairs_settings])
+@pytest.mark.parametrize("lifted", [False, True])
+def test_varying_slots_lie_inside_the_window_the_trimmed_scratch_stages(model, maker, lifted):
+    """The four-wave VARY kernels stage jac slots [js::V0, js::V0 + js::vary_slots(terrain)) only, through a base moved back by js::V0: a
+    recorded slot that depends on x outside that window would be a store outside the staging (in front of it, or into grad[]).  The layout
+    derives the flag from what the RECORDER saw (hipnlp_create launches no VARY kernel when it is false): it must hold for every shipped
+    settings combination, in both orders of a block, and the window must be used up to its last few slots (no stale slack)."""
+    st = maker(6, model)
+    for vf in (False, True):
+        e = HostEmu(st, model, detect_simple_bounds=lifted, jac_varying_first=vf)
+        ok, lo, hi, w0, w1 = e.vary_partition()
+        assert ok and w0 <= lo <= hi < w1, (ok, lo, hi, w0, w1)
+        assert w0 == 921

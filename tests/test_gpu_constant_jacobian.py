@@ -267,3 +267,99 @@ def test_device_resident_jacobian_holds_its_constants_and_is_repaired_when_overw
         both(0, out)
         eng.close()
         full.close()
+
+
+def test_a_host_array_that_comes_back_under_a_new_registration_is_filled_again(model, HipNlp):
+    """the record "this caller array holds the constants" used to be keyed by the bare address and the parameter generation.
+    IPOPT frees its jac buffer, the next solve gets the same address (unchanged parameters), another user of the allocator wrote into
+    the pages in between — anywhere but at the sixteen sampled entries: the launch stored the varying run only and the caller read wrong
+    constants.  The record is now tied to the array's REGISTRATION: an array that was unregistered — by the public call, by
+    hipnlp_host_release_auto_ranges, by a handle's eviction — is a new registration when it comes back, and is filled before it is trusted."""
+    from oracle_lib import Oracle
+    st = periodic_step_settings(40, model)
+    x, p = make_workload(st, model, batch=1, seed=7700)
+    xs = iterates(x, 6)
+    orc = Oracle(st, model)
+    eng = HipNlp(st, model, jac_varying_first=True)
+    eng.set_params(p)
+    full = HipNlp(st, model)
+    full.set_params(p)
+    mask = eng.jac_constant_mask()
+    want = [by_entry(full, full.eval(xi, want=("jac",))[3][0]) for xi in xs]
+    assert rel(np.array([want[0][k] for k in sorted(want[0])]), np.array([v for _, v in sorted(by_entry(full, orc.eval(xs[0][0], p[0])[3]).items())])) < TOL
+    jac = np.empty((1, eng.nnz))
+
+    def spoil():
+        """every constant entry but the ones a spot check could look at first / last: what a second user of the pages leaves behind"""
+        idx = np.flatnonzero(mask)
+        jac[0, idx[7:-7:3]] = 12345.0
+
+    # (a) registered by the caller, unregistered, spoiled, registered again
+    for round_ in range(2):
+        eng.register_outputs([jac])
+        for i in range(2):
+            eng.eval(xs[i + 2 * round_], want=("jac",), out=(None, None, None, jac))
+            assert by_entry(eng, jac[0]) == want[i + 2 * round_], ("caller registration", round_, i)
+        eng.unregister_outputs([jac])
+        spoil()
+    # (b) registered by the handle itself at the second sight, released by the process-wide call, spoiled, seen twice again
+    for round_ in range(2):
+        for i in range(3):
+            eng.eval(xs[i + round_], want=("jac",), out=(None, None, None, jac))
+            assert by_entry(eng, jac[0]) == want[i + round_], ("auto registration", round_, i)
+        assert eng.host_stats()["auto_ranges"] >= 1
+        eng.lib.hipnlp_host_release_auto_ranges()
+        spoil()
+    fills = eng.host_stats()["constant_fills"]
+    assert fills >= 4, fills      # every fresh registration was filled (two by the caller, two by the handle)
+    eng.close()
+    full.close()
+
+
+@pytest.mark.parametrize("vary_first", [True, False])
+def test_device_buffer_sample_check_and_forget(model, HipNlp, vary_first):
+    """the in-launch check of a device destination looks at four constants of every knot block (first, last, two between), not
+    at the first alone; and hipnlp_forget_jac_destination drops the record of a buffer whose address now means other memory (a freed and
+    re-allocated tensor): the next evaluation fills it again."""
+    import torch
+    dev = torch.device("cuda", 0)
+    st = periodic_step_settings(30, model)
+    B = 3
+    x, p = make_workload(st, model, batch=B, seed=7800)
+    full = HipNlp(st, model, batch=B)
+    eng = HipNlp(st, model, batch=B, jac_varying_first=vary_first)
+    if not vary_first:
+        eng.set_constant_jacobian(True)
+    for e in (full, eng):
+        e.set_params(p)
+    pos = {(int(r), int(c)): i for i, (r, c) in enumerate(zip(*full.sparsity()))}
+    order = torch.from_numpy(np.array([pos[(int(r), int(c))] for r, c in zip(*eng.sparsity())])).to(dev)
+    mask = torch.from_numpy(eng.jac_constant_mask()).to(dev)
+    xd = [torch.from_numpy(xi).to(dev) for xi in iterates(x, 3)]
+    mk = lambda: [torch.full((B * k,), float("nan"), dtype=torch.float64, device=dev) for k in (1, eng.n, eng.m, eng.nnz)]
+    out, ref = mk(), mk()
+
+    def check(i):
+        full.eval_device(xd[i].data_ptr(), *[t.data_ptr() for t in ref])
+        eng.eval_device(xd[i].data_ptr(), *[t.data_ptr() for t in out])
+        torch.cuda.synchronize()
+        assert torch.equal(out[3].view(B, -1), ref[3].view(B, -1)[:, order]), i
+    check(0)
+    healed = eng.host_stats()["constant_slices_healed"]
+    # the LAST constant of one interior knot block of the second trajectory (the old check looked at the first constant of a block only)
+    jc = torch.from_numpy(eng.sparsity()[1]).to(dev)
+    blk = (jc // 189) == 11
+    last_const = int(torch.nonzero(blk & mask)[-1])
+    out[3].view(B, -1)[1, last_const] = -7.0
+    check(1)
+    assert eng.host_stats()["constant_slices_healed"] > healed
+    # other memory at the same address: nothing the sample could see (every constant but the sampled ones), said with the forget call
+    fills = eng.host_stats()["constant_fills"]
+    out[3].fill_(float("nan"))
+    assert eng.forget_jac_destination(out[3].data_ptr()) == 1
+    check(2)
+    assert eng.host_stats()["constant_fills"] == fills + 1
+    assert eng.forget_jac_destination(0) == 1 and eng.forget_jac_destination(out[3].data_ptr()) == 0
+    check(0)
+    eng.close()
+    full.close()

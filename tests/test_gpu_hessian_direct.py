@@ -10,16 +10,14 @@ import pytest
 from hippopt_amd import _abi
 from hippopt_amd.kinodyn_settings import periodic_step_settings, single_step_settings
 from hippopt_amd.synthetic import make_workload
+from diag_lib import diag_library, diag_overrides
 
 pytestmark = pytest.mark.gpu
 
 
 def handle(HipNlp, st, model, B, direct, **kw):
-    os.environ["HIPNLP_HESS_DIRECT"] = "1" if direct else "0"
-    try:
-        return HipNlp(st, model, batch=B, **kw)
-    finally:
-        del os.environ["HIPNLP_HESS_DIRECT"]
+    with diag_overrides(HIPNLP_HESS_DIRECT=1 if direct else 0) as lib:
+        return HipNlp(st, model, batch=B, library=lib, **kw)
 
 
 @pytest.mark.parametrize("case", ["periodic 100 x 8", "periodicity as a cost 9 x 70", "single step 30 x 20", "shard [3, 11) of 14 x 80", "non-finite iterates 12 x 50"])

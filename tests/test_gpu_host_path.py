@@ -6,6 +6,7 @@ import pytest
 
 from hippopt_amd.kinodyn_settings import periodic_step_settings
 from hippopt_amd.synthetic import make_workload
+from diag_lib import diag_library, diag_overrides
 
 pytestmark = pytest.mark.gpu
 
@@ -55,15 +56,13 @@ def test_caller_arrays_are_registered_at_their_second_sight_and_verified(model, 
     # unmapping memory under a live registration — a device write to an unmapped page is a GPU fault — but by the library's test
     # hook HIPNLP_DEBUG_MISDIRECT_AUTO: the array the handle registers is mapped to the pinned block's copy of the output instead
     import os
-    eng2 = HipNlp(st, model)
+    from diag_lib import diag_library, diag_overrides
+    eng2 = HipNlp(st, model, library=diag_library())     # (the hook exists in the diagnostic build only)
     eng2.set_params(p)
     jac2 = np.empty((1, eng2.nnz))
-    os.environ["HIPNLP_DEBUG_MISDIRECT_AUTO"] = "1"
-    try:
+    with diag_overrides(HIPNLP_DEBUG_MISDIRECT_AUTO=1):
         eng2.eval(xs[0], want=("jac",), out=(None, None, None, jac2))      # first sight
         eng2.eval(xs[1], want=("jac",), out=(None, None, None, jac2))      # second sight: registered (misdirected), verified, dropped
-    finally:
-        del os.environ["HIPNLP_DEBUG_MISDIRECT_AUTO"]
     assert np.array_equal(jac2, ref.eval(xs[1], want=("jac",))[3])          # right values all the same
     stats = eng2.host_stats()
     assert stats["auto_registered"] == 1 and stats["auto_fallbacks"] == 1 and stats["auto_ranges"] == 0
@@ -121,15 +120,13 @@ def test_hessian_value_array_is_registered_at_its_second_sight_and_verified(mode
         eng.eval(xi, out=cb)
         assert all(np.array_equal(u, v) for u, v in zip(cb, ref.eval(xi)))
     assert np.array_equal(eng.eval_hess(xs[1], 0.9, lam, out=out), ref.eval_hess(xs[1], 0.9, lam))
-    eng2 = HipNlp(st, model)
+    from diag_lib import diag_library, diag_overrides
+    eng2 = HipNlp(st, model, library=diag_library())
     eng2.set_params(p)
     out2 = np.empty((1, eng2.hess_nnz()))
-    os.environ["HIPNLP_DEBUG_MISDIRECT_AUTO"] = "1"
-    try:
+    with diag_overrides(HIPNLP_DEBUG_MISDIRECT_AUTO=1):
         eng2.eval_hess(xs[0], 0.9, lam, out=out2)
         eng2.eval_hess(xs[1], 0.9, lam, out=out2)      # registered (misdirected), caught, served through the pinned block
-    finally:
-        del os.environ["HIPNLP_DEBUG_MISDIRECT_AUTO"]
     assert np.array_equal(out2, ref.eval_hess(xs[1], 0.9, lam))
     stats = eng2.host_stats()
     assert stats["auto_registered"] == 1 and stats["auto_fallbacks"] == 1
@@ -221,11 +218,8 @@ def test_early_copy_out_of_the_host_path_changes_no_bit(model, HipNlp, terrain):
         place_on_step_flanks(x, st, seed=4800)
     engs = []
     for flag in ("1", "0"):
-        os.environ["HIPNLP_EARLY_STORE"] = flag
-        try:
-            engs.append(HipNlp(st, model, jac_varying_first=True))
-        finally:
-            del os.environ["HIPNLP_EARLY_STORE"]
+        with diag_overrides(HIPNLP_EARLY_STORE=flag) as lib:
+            engs.append(HipNlp(st, model, jac_varying_first=True, library=lib))
         engs[-1].set_params(p)
     early, plain = engs
     outs = [(np.empty(1), np.empty((1, e.n)), np.empty((1, e.m)), np.empty((1, e.nnz))) for e in engs]

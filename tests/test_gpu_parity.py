@@ -8,6 +8,7 @@ import pytest
 from hippopt_amd import _abi
 from hippopt_amd.kinodyn_settings import periodic_step_settings, single_step_settings, stairs_settings
 from hippopt_amd.synthetic import make_workload, place_on_step_flanks
+from diag_lib import diag_overrides
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-11
@@ -118,11 +119,8 @@ def test_random_configurations_both_kernel_variants(model, HipNlp):
         refs = [orc.eval(x[b], p[b]) for b in range(B)]
         outs = {}
         for waves, sep in ((4, 0), (4, 1), (8, 0)):
-            os.environ["HIPNLP_WAVES"], os.environ["HIPNLP_SEPARATE_REDUCE"] = str(waves), str(sep)
-            try:
-                eng = HipNlp(st, model, batch=B)
-            finally:
-                del os.environ["HIPNLP_WAVES"], os.environ["HIPNLP_SEPARATE_REDUCE"]
+            with diag_overrides(HIPNLP_WAVES=waves, HIPNLP_SEPARATE_REDUCE=sep) as lib:   # (kernel variants by force: the diagnostic build)
+                eng = HipNlp(st, model, batch=B, library=lib)
             assert (eng.n, eng.m, eng.nnz) == (orc.n, orc.m, orc.nnz), case
             eng.set_params(p)
             f, grad, g, jac = eng.eval(x)
@@ -417,12 +415,8 @@ def test_in_launch_reduction_stress(model, HipNlp):
     # the reducer workgroup inside the launch and the separate reduction kernel (kept for long trajectories / launches) sum in the
     # same fixed tree: bitwise the same f and per-term costs
     assert eng.kernels_per_eval() == 1
-    import os
-    os.environ["HIPNLP_SEPARATE_REDUCE"] = "1"
-    try:
-        sep = HipNlp(st, model, batch=batch)
-    finally:
-        del os.environ["HIPNLP_SEPARATE_REDUCE"]
+    with diag_overrides(HIPNLP_SEPARATE_REDUCE=1) as lib:
+        sep = HipNlp(st, model, batch=batch, library=lib)
     assert sep.kernels_per_eval() == 2
     sep.set_params(p)
     fsep, *_ = sep.eval(x, want=("f",))
@@ -563,11 +557,8 @@ def test_launch_number_wrap(model, HipNlp):
     ref = HipNlp(st, model, batch=2)
     ref.set_params(p)
     r1, r2 = [a.copy() for a in ref.eval(x)], [a.copy() for a in ref.eval(x2)]
-    os.environ["HIPNLP_DEBUG_SEQ0"] = str(2 ** 31 - 4)
-    try:
-        eng = HipNlp(st, model, batch=2)
-    finally:
-        del os.environ["HIPNLP_DEBUG_SEQ0"]
+    with diag_overrides(HIPNLP_DEBUG_SEQ0=2 ** 31 - 4) as lib:
+        eng = HipNlp(st, model, batch=2, library=lib)
     eng.set_params(p)
     bad = x.copy()
     bad[1, 40] = np.nan
@@ -736,12 +727,9 @@ def test_evaluation_that_stores_into_every_ranks_buffer(model, HipNlp, terrain, 
     st = (stairs_settings if terrain == "stairs" else periodic_step_settings)(N, model)
     x, p = make_workload(st, model, batch=1, seed=91)
     dev = torch.device("cuda", 0)
-    os.environ["HIPNLP_WAVES"] = str(waves)
-    try:
-        full = HipNlp(st, model)
-        shards = [HipNlp(st, model, knot_begin=0, knot_end=split), HipNlp(st, model, knot_begin=split, knot_end=N)]
-    finally:
-        del os.environ["HIPNLP_WAVES"]
+    with diag_overrides(HIPNLP_WAVES=waves) as lib:
+        full = HipNlp(st, model, library=lib)
+        shards = [HipNlp(st, model, knot_begin=0, knot_end=split, library=lib), HipNlp(st, model, knot_begin=split, knot_end=N, library=lib)]
     for e in [full] + shards:
         e.set_params(p)
     n, m, nnz = full.n, full.m, full.nnz
@@ -800,13 +788,11 @@ def test_peer_mode_random_shardings(model, HipNlp):
         st = (stairs_settings if stairs else periodic_step_settings)(N, model)
         st.final_state_expression_type, st.periodicity_expression_type = modes[rng.randint(3)], modes[rng.randint(3)]
         x, p = make_workload(st, model, batch=1, seed=600 + case)
-        os.environ["HIPNLP_WAVES"] = str(int(rng.choice([4, 8])))
+        waves = int(rng.choice([4, 8]))
         lift = bool(rng.randint(2))     # the detect_simple_bounds layout: shards of the reduced problem
-        try:
-            full = HipNlp(st, model, detect_simple_bounds=lift)
-            shards = [HipNlp(st, model, knot_begin=cuts[r], knot_end=cuts[r + 1], detect_simple_bounds=lift) for r in range(world)]
-        finally:
-            del os.environ["HIPNLP_WAVES"]
+        with diag_overrides(HIPNLP_WAVES=waves) as lib:
+            full = HipNlp(st, model, detect_simple_bounds=lift, library=lib)
+            shards = [HipNlp(st, model, knot_begin=cuts[r], knot_end=cuts[r + 1], detect_simple_bounds=lift, library=lib) for r in range(world)]
         for e in [full] + shards:
             e.set_params(p)
         n, m, nnz = full.n, full.m, full.nnz
@@ -840,8 +826,15 @@ def test_two_ranks_on_one_gpu_rehearsal():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5", "--no-cpu-baseline",
                           "--no-hessian", "--no-host"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["value"] > 0
+    # the LAST line is the short one the driver parses; the line before it (BENCH_DETAILS ...) carries every leg in full
+    lines = out.stdout.strip().splitlines()
+    final = json.loads(lines[-1])
+    assert len(lines[-1]) < 6000 and final["n_gpus"] == 2 and final["value"] > 0 and final["config"]["exchange"] == "all_gather"
+    assert set(final["exchanges"]) >= {"all_gather", "peer_store", "peer_direct", "gather_to_root", "host_sink"} and "REHEARSAL" in final["config"]["backend"]
+    detail_lines = [ln for ln in lines if ln.startswith("BENCH_DETAILS ")]
+    assert len(detail_lines) == 1
+    line = json.loads(detail_lines[0][len("BENCH_DETAILS "):])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and abs(line["value"] - final["value"]) <= 1e-6 * line["value"]
     side = {k: line.get(k) or line["config"].get(k) for k in ("peer_store", "peer_direct", "gather_to_root", "host_sink", "shard_resident")}
     for k in ("peer_store", "peer_direct", "gather_to_root"):
         assert side[k] and "error" not in side[k], (k, side[k])
@@ -1021,11 +1014,10 @@ def test_hessian_compact_layout_is_the_full_layout_bit_for_bit(model, HipNlp):
     vals = {}
     for layout in ("full", "compact", None):
         if layout:
-            os.environ["HIPNLP_HESS_LAYOUT"] = layout
-        try:
+            with diag_overrides(HIPNLP_HESS_LAYOUT=layout) as lib:
+                eng = HipNlp(st, model, batch=B, library=lib)
+        else:
             eng = HipNlp(st, model, batch=B)
-        finally:
-            os.environ.pop("HIPNLP_HESS_LAYOUT", None)
         eng.set_params(p)
         if "lam" not in vals:
             vals["lam"], vals["sig"] = rng.standard_normal((B, eng.m)), rng.uniform(0.0, 1.5, B)

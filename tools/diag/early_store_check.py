@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """GPU box: the host-path outputs with and without the early copy-out (HIPNLP_EARLY_STORE read by hipnlp_create), entry by entry."""
 import os
+# (the environment overrides below exist in the diagnostic build of the library only: __graft_entry__.build() -> tests/_build)
+DIAG_SO = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "_build", "libhipnlp_diag.so")
 import sys
 
 import numpy as np
@@ -22,7 +24,7 @@ for name, maker in (("periodic", periodic_step_settings), ("stairs", stairs_sett
         engs = []
         for e in ("1", "0"):
             os.environ["HIPNLP_EARLY_STORE"] = e
-            engs.append(HipNlp(st, model, batch=B, jac_varying_first=vf))
+            engs.append(HipNlp(st, model, batch=B, jac_varying_first=vf, library=DIAG_SO))
             engs[-1].set_params(p)
         del os.environ["HIPNLP_EARLY_STORE"]
         x = x + 1e-2 * np.random.RandomState(3).standard_normal(x.shape)

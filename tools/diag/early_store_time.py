@@ -2,6 +2,8 @@
 """GPU box: the host-buffer callback (all four outputs, varying-first handle, caller arrays registered by the handle) with and without the
 early copy-out (HIPNLP_EARLY_STORE, read by hipnlp_create): wall clock per call, the library's own breakdown, the kernel's duration by events."""
 import os
+# (the environment overrides below exist in the diagnostic build of the library only: __graft_entry__.build() -> tests/_build)
+DIAG_SO = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "_build", "libhipnlp_diag.so")
 import sys
 import time
 
@@ -21,7 +23,7 @@ xs = [x + 1e-3 * i for i in range(4)]
 engs = {}
 for e in ("1", "0"):
     os.environ["HIPNLP_EARLY_STORE"] = e
-    engs[e] = HipNlp(st, model, jac_varying_first=True)
+    engs[e] = HipNlp(st, model, jac_varying_first=True, library=DIAG_SO)
     engs[e].set_params(p)
     engs[e].set_prefetch(())
 del os.environ["HIPNLP_EARLY_STORE"]

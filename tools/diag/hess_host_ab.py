@@ -3,6 +3,8 @@
 process alternating — multipliers through the H2D copy command (default) against the kernel reading them from pinned memory
 (HIPNLP_HESS_LAM_ZERO_COPY=1)."""
 import os
+# (the environment overrides below exist in the diagnostic build of the library only: __graft_entry__.build() -> tests/_build)
+DIAG_SO = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "_build", "libhipnlp_diag.so")
 import sys
 import time
 
@@ -21,7 +23,7 @@ x, p = make_workload(st, model, batch=1, seed=3)
 engs = {}
 for tag, env in (("copy command", "0"), ("zero copy", "1")):
     os.environ["HIPNLP_HESS_LAM_ZERO_COPY"] = env
-    engs[tag] = HipNlp(st, model)
+    engs[tag] = HipNlp(st, model, library=DIAG_SO)
     engs[tag].set_params(p)
 del os.environ["HIPNLP_HESS_LAM_ZERO_COPY"]
 lam = np.random.RandomState(0).standard_normal((1, engs["zero copy"].m))

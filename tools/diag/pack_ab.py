@@ -3,6 +3,8 @@
 kernel: outputs bit for bit (same arithmetic, same summation tree) and launch time, one JSON line per configuration."""
 import json
 import os
+# (the environment overrides below exist in the diagnostic build of the library only: __graft_entry__.build() -> tests/_build)
+DIAG_SO = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "_build", "libhipnlp_diag.so")
 import sys
 
 import numpy as np
@@ -26,7 +28,7 @@ def engine(st, B, pack, kw):
     os.environ["HIPNLP_PACK"] = str(pack)
     os.environ["HIPNLP_WAVES"] = "4"
     try:
-        return HipNlp(st, model, batch=B, **kw)
+        return HipNlp(st, model, batch=B, library=DIAG_SO, **kw)
     finally:
         del os.environ["HIPNLP_PACK"], os.environ["HIPNLP_WAVES"]
 

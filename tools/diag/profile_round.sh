@@ -26,7 +26,7 @@ has bench && for W in $WORKLOADS; do
   run lds_$NAME --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/lds_$NAME -- python3 bench.py --steps 20 --warmup 5 $ARGS $COMMON
   # lane utilisation of the VALU issue slots: SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64) = share of live lanes per issued VALU cycle
   run lane_$NAME --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d $OUT/lane_$NAME -- python3 bench.py --steps 20 --warmup 5 $ARGS $COMMON
-  python3 bench.py --steps $([ $B -ge 1024 ] && echo 50 || echo 1000) --warmup 50 $ARGS $COMMON > $OUT/bench_$NAME.json 2>/dev/null
+  python3 bench.py --steps $([ $B -ge 1024 ] && echo 50 || echo 1000) --warmup 50 $ARGS $COMMON --details-out $OUT/bench_$NAME.json > /dev/null 2>&1
 done
 # exact Hessian and pose finder: ONE (kernel, N, batch) per trace, so that every CSV average is the duration of one configuration
 has hess && for CFG in periodic:100:1 periodic:100:64 periodic:100:256 stairs:200:16; do
