@@ -68,6 +68,8 @@ def parse_args():
                     help="CCS-order handle with hipnlp_set_constant_jacobian(h, 1) (N = 1, independent trajectories): the device destination of jac g holds the "
                          "constant entries, the launches store the varying ones at their CCS positions (VARY kernels)")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the sharded paths on one GPU (debug)")
+    ap.add_argument("--exchange-every-entry", action="store_true",
+                    help="N > 1: CCS-order shard handles whose exchanges move every entry of jac g on every step (round 4's exchanges; default: the varying entries only)")
     ap.add_argument("--details-out", default=None, help="also write the full record (the BENCH_DETAILS line) to this file")
     return ap.parse_args()
 
@@ -181,11 +183,16 @@ def compact_line(d):
     for key in ("all_gather", "shard_resident", "peer_store", "peer_direct", "gather_to_root", "host_sink"):
         leg = d.get(key)
         if isinstance(leg, dict):
-            ex[key] = "error" if "error" in leg else [_sig(leg.get("ms_per_step"), 4), _sig(leg.get("knots_per_s"), 4), leg.get("bytes_sent_per_rank_per_step"),
+            ex[key] = "error" if "error" in leg else [_sig(leg.get("ms_per_step"), 4), _sig(leg.get("knots_per_s"), 4),
+                                                      leg.get("bytes_sent_per_rank_per_step", leg.get("bytes_stored_per_rank_per_step")),
                                                       _sig(leg.get("efficiency_vs_n_independent_gpus"), 3)]
+            if key == "host_sink" and "error" not in leg:
+                ex[key].append(_sig(leg.get("efficiency_vs_one_gpu_host_visible"), 3))
     if ex:
-        out["exchange_columns"] = "ms per step, knots per s, bytes sent per rank and step (max over ranks), efficiency vs N independent GPUs"
+        out["exchange_columns"] = ("ms per step, knots per s, bytes sent per rank and step (max over ranks), efficiency vs N independent GPUs "
+                                   "(host_sink: + efficiency vs N x one GPU's host-visible rate)")
         out["exchanges"] = ex
+        out["exchange_moves"] = d.get("exchange_moves")
     for key in ("independent_trajectories", "knot_sharded_allgather"):
         leg = d.get(key)
         if isinstance(leg, dict):
@@ -908,14 +915,18 @@ def main():
     def run_knot_sharded(steps, warmup, total_horizon=None, legs=("shard_resident", "peer_store", "peer_direct", "gather_to_root", "host_sink")):
         """total_horizon: knots of the ONE trajectory cut over the ranks (default: args.horizon per rank — the horizon grows with the
         world, weak scaling); legs: which exchanges are timed beside the all-gather"""
-        from hippopt_amd.sharded import HostSink, ShardedCallback, hip_shard_backend, hip_shard_info, knot_range
+        from hippopt_amd.sharded import HostSink, ShardedCallback, hip_constants, hip_shard_backend, hip_shard_info, knot_range
         assert args.batch == 1, "knot sharding evaluates one trajectory"
         hz = total_horizon or args.horizon * world
         st, x_np, p_np, xs = workload(hz, 1, 1004)   # the SAME trajectory on every rank
         kb, ke = knot_range(hz, world, rank)
-        eng = HipNlp(st, model, batch=1, knot_begin=kb, knot_end=ke, device=local_rank)
+        # Shard handles list the varying entries of a knot block first (HIPNLP_FLAG_JAC_VARYING_FIRST) and every exchange moves the varying
+        # runs only: the 43 % of jac g that never changes is put into the receiving buffers once per parameter set (--exchange-every-entry:
+        # round 4's exchanges, every entry on every step, for an A/B in one session)
+        compact = not args.exchange_every_entry
+        eng = HipNlp(st, model, batch=1, knot_begin=kb, knot_end=ke, device=local_rank, jac_varying_first=compact)
         eng.set_params(p_np)
-        cb = ShardedCallback(hz, eng.n, eng.m, eng.nnz, hip_shard_info(eng, kb, ke), hip_shard_backend(eng), device)
+        cb = ShardedCallback(hz, eng.n, eng.m, eng.nnz, hip_shard_info(eng, kb, ke), hip_shard_backend(eng, compact), device, **(hip_constants(eng) if compact else {}))
         torch.cuda.synchronize()
         # the whole loop runs on the callback's own stream (shard evaluation, all-gather and reassembly are ordered on it; entering it
         # once here saves two cross-stream event waits per step)
@@ -923,6 +934,7 @@ def main():
             el, kern_ms, launch_ms, nprof = run_timed(lambda i: cb(xs[i % nvar]), eng, steps, warmup, False)
         res = {"eng": eng, "st": st, "x_np": x_np, "p_np": p_np, "el": el, "kern_ms": kern_ms, "launch_ms": launch_ms, "nprof": nprof,
                "knots_per_step": hz, "local_knots": ke - kb, "single_kernel_step": False, "horizon": hz,
+               "exchange_moves": "the varying entries of jac g only (the constants are in the receiving buffers)" if compact else "every entry of jac g",
                "parallelism": "knot-sharded x%d (contiguous shooting intervals) + one RCCL all-gather + one-launch reassembly" % world}
         # beside it: the shards evaluated and left in each rank's HBM (what the exchange costs on top)
         ksteps = max(1, min(steps, 1000))
@@ -1037,7 +1049,7 @@ def main():
         # on a device of its own (a rehearsal with several ranks on one device exercises neither xGMI nor cross-device visibility and
         # never qualifies).  gather_to_root delivers to rank 0 only — a different contract — and is reported beside `value`, never as it.
         res["all_gather"] = {"knots_per_s": hz * steps / res["el"], "ms_per_step": 1e3 * res["el"] / steps, "steps": steps,
-                             "bytes_sent_per_rank_per_step": int(8 * cb.shard_len * (world - 1)), "rccl_ranks": world}
+                             "bytes_sent_per_rank_per_step": int(cb.bytes_sent_per_step()), "rccl_ranks": world}
         res["exchange"] = "all_gather"
         devs = [None] * world
         if world > 1:
@@ -1077,8 +1089,37 @@ def main():
                 work_stream.synchronize()    # the consumer (IPOPT) needs this callback before it produces the next x
             fence()
             e3 = max_over_ranks(time.perf_counter() - t1)
+            # its baseline is what ONE GPU hands a CPU-side IPOPT: hipnlp_eval through host buffers, all four outputs, one 100-knot trajectory
+            # (rank 0 measures it here, the others wait at the fence): efficiency = rate(host_sink, N ranks) / (N x that rate)
+            one_gpu_host = None
+            try:
+                if rank == 0:
+                    st1 = maker(args.horizon, model)
+                    x1, p1 = make_workload(st1, model, batch=1, seed=1004)
+                    e1 = HipNlp(st1, model, batch=1, device=local_rank, jac_varying_first=True)
+                    e1.set_params(p1)
+                    e1.set_prefetch(())
+                    o1 = e1.eval(x1)
+                    x1s = [x1 + 1e-3 * i for i in range(4)]
+                    for i in range(20):
+                        e1.eval(x1s[i % 4], out=o1)
+                    best = float("inf")
+                    for _ in range(3):
+                        t1 = time.perf_counter()
+                        for i in range(100):
+                            e1.eval(x1s[i % 4], out=o1)
+                        best = min(best, (time.perf_counter() - t1) / 100)
+                    e1.unregister_outputs(o1)
+                    e1.close()
+                    one_gpu_host = args.horizon / best
+            except Exception:  # noqa: BLE001
+                one_gpu_host = None
+            fence()
             res["host_sink"] = {"knots_per_s": hz * ksteps / e3, "ms_per_step": 1e3 * e3 / ksteps, "steps": ksteps,
                                 "f": sink.f(),
+                                "one_gpu_host_visible_knots_per_s": one_gpu_host,
+                                "efficiency_vs_one_gpu_host_visible": None if (REHEARSAL or not one_gpu_host or total_horizon) else (hz * ksteps / e3) / (world * one_gpu_host),
+                                "bytes_stored_per_rank_per_step": int(8 * (eng.dims.shard_grad + eng.dims.shard_g_rows + (eng.jac_vary_layout()["shard_len"] if compact else eng.dims.shard_nnz) + 1)),
                                 "note": "no collective: each rank's knot kernel stores its shard of [grad | jac | g] straight into ONE "
                                         "shared pinned host buffer (POSIX shared memory registered with HIP by every rank), in reference "
                                         "order; synchronised after every step"}
@@ -1090,7 +1131,7 @@ def main():
     # ---- BASELINE config 5 in its multi-GPU form: stairs N = 200, 16 batched initial guesses DEALT over the ranks, outputs on rank 0 ----
     def run_config5(steps, warmup):
         from hippopt_amd.kinodyn_settings import stairs_settings as stairs
-        from hippopt_amd.sharded import BatchDealtCallback, BatchPeerToRoot, batch_range, hip_batch_backend
+        from hippopt_amd.sharded import BatchDealtCallback, BatchPeerToRoot, batch_range, hip_batch_backend, hip_constants
         N5, B5 = 200, 16
         st = stairs(N5, model)
         x1, p1 = make_workload(st, model, batch=1, seed=1004)
@@ -1104,7 +1145,8 @@ def main():
                            "(16 / %d per rank, one batched launch each), every trajectory's f, grad f, g, jac g delivered to rank 0" % world,
                "scaling": "strong (the job is the 16 trajectories whatever the number of GPUs)", "ranks": world}
         # the whole job on ONE GPU, measured on every rank at once (each evaluates all 16 trajectories by itself): the reference figure
-        full = HipNlp(st, model, batch=B5, device=local_rank)
+        compact = not args.exchange_every_entry
+        full = HipNlp(st, model, batch=B5, device=local_rank, jac_varying_first=compact)
         full.set_params(p_all)
         with torch.cuda.stream(work_stream):
             xd = [torch.from_numpy(x_all + 1e-3 * i * np.random.RandomState(7).standard_normal(x_all.shape)).to(device) for i in range(2)]
@@ -1128,9 +1170,10 @@ def main():
         ref_out = [t.clone() for t in o]
         full.close()
         b0, b1 = batch_range(B5, world, rank)
-        eng = HipNlp(st, model, batch=b1 - b0, device=local_rank)
+        eng = HipNlp(st, model, batch=b1 - b0, device=local_rank, jac_varying_first=compact)
         eng.set_params(p_all[b0:b1])
-        bc = BatchDealtCallback(B5, eng.n, eng.m, eng.nnz, hip_batch_backend(eng), device)
+        # (the gather moves the varying entries of jac g; rank 0's complete array holds every trajectory's constants, gathered once)
+        bc = BatchDealtCallback(B5, eng.n, eng.m, eng.nnz, hip_batch_backend(eng, compact), device, **(hip_constants(eng) if compact else {}))
         with torch.cuda.stream(bc.stream):
             xl = [t[b0:b1].contiguous() for t in xd]
         bc.stream.synchronize()
@@ -1159,7 +1202,7 @@ def main():
                 try:
                     got = step_fn(xl[0])
                     bc.stream.synchronize()
-                    ok = check(got.all if isinstance(got, BatchDealtCallback) else got) if got is not None else True
+                    ok = check(None if isinstance(got, BatchDealtCallback) else got) if got is not None else True
                     if not ok:
                         why = "rank 0: a trajectory differs from the one-GPU evaluation"
                 except Exception as err:  # noqa: BLE001
@@ -1367,7 +1410,7 @@ def main():
             line["config"]["exchange"] = main_res["exchange"]
         if main_res.get("peer_paths_eligible_for_value"):
             line["config"]["peer_paths_eligible_for_value"] = main_res["peer_paths_eligible_for_value"]
-        for key in ("all_gather", "shard_resident", "peer_store", "peer_direct", "gather_to_root", "host_sink"):
+        for key in ("all_gather", "shard_resident", "peer_store", "peer_direct", "gather_to_root", "host_sink", "exchange_moves"):
             if main_res.get(key) is not None:
                 line[key] = main_res[key]
         if side is not None:

@@ -109,6 +109,10 @@ struct KArgs {
     int32_t seq, early;     // launch number of this handle (1, 2, ...); early: outputs go to host memory — what is final after the second phase leaves then
     int32_t N, n, m, nnz, knot_begin, nk;
     int64_t jac_stride, jac_off, grad_stride, grad_off;  // output addressing: full arrays (stride nnz / n, offset 0) or shard-local
+    // VARY instantiations: entries per knot block of the DESTINATION of jac g — the block lengths of the pattern (nnz_v: the destination
+    // holds the constants between the varying runs) or, for a COMPACT destination (hipnlp_eval_device_vary / _shard_vary: what an exchange
+    // between GPUs moves), the lengths of the varying runs alone (nvary_v: run behind run, no constants anywhere)
+    int32_t jb_first, jb_interior;
     // peer mode (hipnlp_eval_device_peers; batch 1): instead of g / jac / grad / f above, the shard's values go — at their FINAL positions —
     // into the buffer [grad (n) | jac (nnz) | g (m) | f partials (npeer) | f] of every one of npeer ranks (this device's own among them)
     double* const* peer_out;   // [npeer] device-visible base addresses, or null
@@ -238,11 +242,11 @@ __device__ __forceinline__ void constants_check_and_repair(const ConstCheck& c, 
 #ifndef HIPNLP_FIVE_PER_CU
 #define HIPNLP_FIVE_PER_CU 1
 #endif
-template <int TERRAIN, int WAVES, bool VARY> constexpr bool five_per_cu = HIPNLP_FIVE_PER_CU && VARY && WAVES == 4;
+// (the peer-store VARY kernels — one store loop per rank behind the program — keep the four-per-CU register budget)
+template <int TERRAIN, int WAVES, bool VARY, bool PEERS = false> constexpr bool five_per_cu = HIPNLP_FIVE_PER_CU && VARY && WAVES == 4 && !PEERS;
 template <int TERRAIN, int WAVES, bool PEERS = false, bool VARY = false> __global__ __launch_bounds__(64 * WAVES)
-__attribute__((amdgpu_waves_per_eu(WAVES == 4 ? (five_per_cu<TERRAIN, WAVES, VARY> ? 5 : 4) : 2, five_per_cu<TERRAIN, WAVES, VARY> ? 5 : 4)))
+__attribute__((amdgpu_waves_per_eu(WAVES == 4 ? (five_per_cu<TERRAIN, WAVES, VARY, PEERS> ? 5 : 4) : 2, five_per_cu<TERRAIN, WAVES, VARY, PEERS> ? 5 : 4)))
 void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const double* pk_p, const GParams* gp_p, int N_p, int n_p, int kb_p, int nk_p, KArgs a) {
-    static_assert(!(PEERS && VARY), "the peer exchange stores every entry");
     // the leading scalar arguments repeat what the staging loads need: the build preloads them into SGPRs
     // (-mllvm -amdgpu-kernarg-preload-count), so the first global loads do not wait for a kernarg fetch
     constexpr int WG = 64 * WAVES;
@@ -374,7 +378,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     int nnz_first = 0, nnz_interior = 0, n_glob = 0, jac_glob_base = 0;   // (scalars of the copy-out: read behind the vector loads, used at the end)
     int jpg = 0;
     int32_t jp[JP_ITERS], ga[G_ITERS], gb[G_ITERS];
-    constexpr bool LATE_TABLES = five_per_cu<TERRAIN, WAVES, VARY>;
+    constexpr bool LATE_TABLES = five_per_cu<TERRAIN, WAVES, VARY, PEERS>;
     auto fetch_tables = [&]() __attribute__((always_inline)) {
         const DeviceTables& tbl = *tb_p;
         jpg = tbl.jperm_glob[tid & 15];
@@ -509,7 +513,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     auto early_out = [&]() __attribute__((always_inline)) {
         if (!early_on) return;
         if (a.jac) {
-            const int64_t jb0 = first ? 0 : int64_t(nnz_first) + int64_t(k - 1) * nnz_interior;
+            const int64_t jb0 = first ? 0 : (VARY ? int64_t(a.jb_first) + int64_t(k - 1) * a.jb_interior : int64_t(nnz_first) + int64_t(k - 1) * nnz_interior);
             double* out = a.jac + int64_t(b) * a.jac_stride + (jb0 - a.jac_off);
 #pragma unroll
             for (int it = 0; it < JP_ITERS; ++it) if (jp[it] >= 0 && (jp[it] & COPY_EARLY)) store_unwaited(out, (VARY ? jp_pos(jp[it]) : tid + it * WG) * 8, em.jac[jp_slot(jp[it])]);
@@ -563,7 +567,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     // ---- stream the knot's outputs ---------------------------------------------------------------------
     // All LDS reads and the non-finite check come first, then nothing but stores; the non-finite flag is kept per wavefront
     // (the reduction kernel ORs them), so no workgroup barrier stands between the last task and the stores.
-    const int64_t jbase = first ? 0 : int64_t(nnz_first) + int64_t(k - 1) * nnz_interior;
+    const int64_t jbase = first ? 0 : (VARY ? int64_t(a.jb_first) + int64_t(k - 1) * a.jb_interior : int64_t(nnz_first) + int64_t(k - 1) * nnz_interior);
     int bad = 0;
     constexpr int GR_ITERS = (NXK + WG - 1) / WG;
     double jvals[JP_ITERS], gvals[G_ITERS], grvals[GR_ITERS];
@@ -601,8 +605,9 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             double* base = a.peer_out[r];
             double* oj = base + o_jac + jbase;
 #pragma unroll
-            for (int it = 0; it < JP_ITERS; ++it) if (jp[it] >= 0) oj[tid + it * WG] = jvals[it];
-            if (last && tid < n_glob) base[o_jac + int64_t(jac_glob_base) + tid] = s.jac[jpg];
+            for (int it = 0; it < JP_ITERS; ++it) if (jp[it] >= 0) oj[VARY ? jp_pos(jp[it]) : tid + it * WG] = jvals[it];
+            // (VARY: every rank's buffer holds the constants — hipnlp_fill_jac_constants — the horizon-global entries among them)
+            if constexpr (!VARY) { if (last && tid < n_glob) base[o_jac + int64_t(jac_glob_base) + tid] = s.jac[jpg]; }
             double* og = base + o_g;
 #pragma unroll
             for (int it = 0; it < G_ITERS; ++it) if (ga[it] != G_NONE) og[ga[it] + (gb[it] & COPY_SLOT) * k] = gvals[it];
@@ -716,7 +721,12 @@ template <int TERRAIN, int LAYOUT, bool DIRECT = false> struct DevEmH {
     __device__ __forceinline__ void H(int slot, int, int, double v) {
         if constexpr (DIRECT) {
             const int p = inv[slot];
-            if (p >= 0) { hess[p] = v; nf += v * 0.0; }   // (entries of the pattern only: what the staged kernel's copy-out looks at)
+            if (p >= 0) hess[p] = v;
+            // (every emitted value, pattern entry or not — ADVICE r04 asked for pattern entries only, as the staged kernel's copy-out; with the
+            //  accumulation inside the branch the compiler contracted multiply-adds of the tasks differently and 88 entries of the
+            //  "periodicity as a cost" case lost their bit-identity with the staged kernel (r05_gputest1.log): the stronger property is kept.
+            //  A slot outside the pattern carries a zero multiplier; it is non-finite only where x itself is, and then pattern entries are too.)
+            nf += v * 0.0;
         } else hess[slot] = v;
     }
 };
@@ -946,6 +956,19 @@ __global__ __launch_bounds__(256) void hipnlp_reassemble_kernel(const double* ga
     }
 }
 
+// ... and with a destination index (out[dst[i]] = gathered[src[i]]): the entries the shards did NOT send — the constant entries of jac g,
+// put into `out` once per parameter set — are left alone.
+__global__ __launch_bounds__(256) void hipnlp_reassemble_scatter_kernel(const double* gathered, const int64_t* src, const int64_t* dst, double* out, int64_t count,
+                                                                        int world, int64_t shard_len, double* f_out) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += stride) out[dst[i]] = gathered[src[i]];
+    if (f_out && blockIdx.x == 0 && threadIdx.x == 0) {
+        double f = 0.0;
+        for (int r = 0; r < world; ++r) f += gathered[int64_t(r) * shard_len];
+        *f_out = f;
+    }
+}
+
 // Host path, Jacobian asked for after its evaluation (IPOPT's eval_jac_g with new_x = FALSE): the varying run of every knot block from
 // the complete values in HBM into a device-visible HOST array that already holds the constant entries (varying-first order of a block,
 // HIPNLP_FLAG_JAC_VARYING_FIRST).  One workgroup per knot; consecutive lanes, consecutive addresses on the link.
@@ -1085,7 +1108,7 @@ struct hipnlp_handle {
     int32_t* d_ctpl_of_b = nullptr;
     int32_t* d_healed = nullptr;                    // wave slices of constants a VARY kernel had to put back (the caller wrote over a device buffer)
     int ctpl_len = 0;
-    struct DevFilled { const void* dev; unsigned long long gen; };
+    struct DevFilled { const void* dev; unsigned long long gen; bool remote; };   // remote: not this device's own memory (a registered host range, a peer's buffer): never read back by the launch
     DevFilled dfilled[8] = {};                      // device jac buffers of hipnlp_eval_device that hold this handle's constants, and of which parameter set
     int dfilled_next = 0;
     long dev_const_fills = 0;
@@ -1543,16 +1566,25 @@ int hipnlp_sparsity(const hipnlp_handle* h, int32_t* irow, int32_t* jcol) {
 // Timing: an event record drains the stream around the kernel and costs several microseconds, more than a third of a
 // 100-knot callback.  The host-buffer path (hipnlp_eval, PCIe bound anyway) is always timed; the device path is timed only for
 // the launches an armed profile selects (every stride-th launch), so that measuring does not change what is measured.
+// entries in the varying runs of the knots [0, k): where knot k's run starts in a compact destination
+static int64_t vary_base(const Layout& L, int k) {
+    if (k <= 0) return 0;
+    int64_t at = L.nvary_v[VAR_FIRST] + int64_t(std::min(k, L.N - 1) - 1) * L.nvary_v[VAR_INTERIOR];
+    if (k >= L.N) at += L.nvary_v[VAR_LAST];
+    return at;
+}
 static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, hipStream_t s,
                   double* g_stage = nullptr, bool shard_local = false, bool always_timed = false, bool host_block = false,
-                  double* const* peer_out = nullptr, int npeer = 0, int peer_rank = 0, bool vary_only = false) {
+                  double* const* peer_out = nullptr, int npeer = 0, int peer_rank = 0, bool vary_only = false, bool compact = false, bool no_check = false) {
     // vary_only: the constant entries of jac g are already at jac_dev (constants_ensure): the copy-out leaves them alone
+    // compact (with vary_only): jac_dev is a COMPACT destination — the varying runs of the knot blocks behind one another, no room for constants
+    // no_check: the destination is not local device memory (a registered host range, a peer's buffer): the launch does not read it back
     KArgs a;
     a.peer_out = peer_out; a.npeer = npeer; a.peer_rank = peer_rank;
     a.tb = h->d_tb; a.x = x_dev; a.pk = h->d_pk; a.gp = h->d_gp;
     {   // the check of the constants a VARY launch finds in a DEVICE destination (a host destination was spot-checked by the host: no reads over PCIe)
         ConstCheck& c = a.cc;
-        const bool on = vary_only && !host_block && h->vary_check && jac_dev && h->d_ctpl;
+        const bool on = vary_only && !host_block && !compact && !no_check && !peer_out && h->vary_check && jac_dev && h->d_ctpl;
         c.jac = on ? jac_dev : nullptr; c.ctpl = on ? h->d_ctpl : nullptr; c.ctpl_of_b = h->d_ctpl_of_b; c.healed = h->d_healed;
         c.jac_stride = h->L.nnz; c.jac_off = 0; c.ctpl_len = h->ctpl_len;
         for (int v = 0; v < 4; ++v) c.ctpl_off[v] = h->ctpl_off[v];
@@ -1564,12 +1596,15 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
         c.kb = h->kb; c.nk = h->nk; c.N = h->L.N; c.n_glob = int(h->L.jperm_glob.size()); c.jac_glob_base = h->L.jac_glob_base;
     }
     a.g = g_dev; a.jac = jac_dev; a.grad = grad_dev; a.g_stage = g_stage;
+    a.jb_first = compact ? h->L.nvary_v[VAR_FIRST] : h->L.nnz_v[VAR_FIRST];
+    a.jb_interior = compact ? h->L.nvary_v[VAR_INTERIOR] : h->L.nnz_v[VAR_INTERIOR];
     if (shard_local) {
         hipnlp_dims dd;
         hipnlp_get_dims(h, &dd);
         a.jac_stride = dd.shard_nnz; a.jac_off = dd.shard_jac_off; a.grad_stride = dd.shard_grad; a.grad_off = dd.shard_grad_off;
+        if (compact) { a.jac_stride = vary_base(h->L, h->ke) - vary_base(h->L, h->kb); a.jac_off = vary_base(h->L, h->kb); }
     } else {
-        a.jac_stride = h->L.nnz; a.jac_off = 0; a.grad_stride = h->L.n; a.grad_off = 0;
+        a.jac_stride = compact ? vary_base(h->L, h->L.N) : int64_t(h->L.nnz); a.jac_off = 0; a.grad_stride = h->L.n; a.grad_off = 0;
     }
     a.cost_knot = h->d_cost_knot; a.f = f_dev; a.cost_pub = h->fused ? h->d_cost_pub : nullptr; a.flag = h->d_flag;
     // host-buffer path: per-term costs (96 B per trajectory) and the non-finite flag go straight to the pinned block
@@ -1611,7 +1646,15 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     if (timed) HIP_TRY(h, hipEventRecord(e0, s));
     const dim3 grid(unsigned(h->nk) + (h->fused ? 1u : 0u), unsigned(h->batch));   // (+ the row's cost reducer)
     const bool planar = h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR;
-    if (peer_out) {
+    if (peer_out && vary_only) {   // every rank's buffer holds the constant entries: the varying run of every block, at its place in the pattern, once per rank
+        if (h->wide) {
+            if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8, true, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+            else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8, true, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+        } else {
+            if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 4, true, true>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+            else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 4, true, true>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+        }
+    } else if (peer_out) {
         if (h->wide) {
             if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
             else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
@@ -1822,6 +1865,19 @@ int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor
     return HIPNLP_OK;
 }
 
+// Is p memory of the handle's own device?  (A VARY launch samples the constants it finds in its jac destination — reads that belong in
+// HBM, not on PCIe or xGMI: a destination inside a registered host range (a shared host sink) or in a peer's buffer (opened through IPC) is
+// filled like any other and never read back.)  Asked once per destination, when it is first seen.
+static bool is_local_device_memory(const hipnlp_handle* h, const void* p) {
+    {
+        std::lock_guard<std::mutex> lock(g_ranges_mutex);
+        const char* q = static_cast<const char*>(p);
+        for (const HostRange& r : g_ranges) if (q >= r.dev && q < r.dev + r.bytes) return false;
+    }
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return true; }   // (unknown to the runtime: treated as the caller says — device memory)
+    return at.type == hipMemoryTypeDevice && at.device == h->dev;
+}
 int hipnlp_eval_device(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, void* stream) {
     if (!h || !x_dev) return HIPNLP_E_INVALID;
     if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
@@ -1832,7 +1888,7 @@ int hipnlp_eval_device(hipnlp_handle* h, const double* x_dev, double* f_dev, dou
     // front of the evaluation; from then on the launches store the varying entries of every block only — one run in the varying-first
     // order, scattered 8-byte stores in CasADi's CCS order (they meet in the L2 before they leave for HBM) — and check the constants
     // they find (a buffer the caller wrote over is repaired by the kernel itself).
-    bool vary = false;
+    bool vary = false, remote = false;
     if (jac_dev && h->skip_const && h->vary_ok && h->d_ctpl && h->L.nconst_total > 0) {
         int slot = -1;
         for (int i = 0; i < 8; ++i) if (h->dfilled[i].dev == jac_dev) slot = i;
@@ -1845,12 +1901,13 @@ int hipnlp_eval_device(hipnlp_handle* h, const double* x_dev, double* f_dev, dou
                                h->ke == L.N ? int(L.jperm_glob.size()) : 0);
             HIP_TRY(h, hipGetLastError());
             if (slot < 0) { slot = h->dfilled_next; h->dfilled_next = (h->dfilled_next + 1) % 8; }
-            h->dfilled[slot] = {jac_dev, h->param_gen};
+            h->dfilled[slot] = {jac_dev, h->param_gen, !is_local_device_memory(h, jac_dev)};
             h->dev_const_fills++;
         }
         vary = true;
+        remote = h->dfilled[slot].remote;
     }
-    return launch(h, x_dev, f_dev ? f_dev : h->d_f, grad_dev, g_dev, jac_dev, s, nullptr, false, false, false, nullptr, 0, 0, vary);
+    return launch(h, x_dev, f_dev ? f_dev : h->d_f, grad_dev, g_dev, jac_dev, s, nullptr, false, false, false, nullptr, 0, 0, vary, false, remote);
 }
 
 int hipnlp_eval_device_shard(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_shard, double* g_stage, double* jac_shard, void* stream) {
@@ -1869,6 +1926,62 @@ int hipnlp_eval_device_peers(hipnlp_handle* h, const double* x_dev, double* cons
     HIP_TRY(h, hipSetDevice(h->dev));
     h->have_result = false;
     return launch(h, x_dev, h->d_f, nullptr, nullptr, nullptr, stream ? hipStream_t(stream) : h->stream, nullptr, false, false, false, peer_out_dev, world, rank);
+}
+
+// ---- what an exchange between GPUs moves: the varying runs only (include/hipnlp.h, "Exchanges without the constants of jac g") ------------
+static int vary_ready(hipnlp_handle* h, const char* who) {
+    if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
+    if (!h->L.vary_first) { h->err = std::string(who) + ": the handle must list the varying entries of a knot block first (HIPNLP_FLAG_JAC_VARYING_FIRST)"; return HIPNLP_E_UNSUPPORTED; }
+    if (!h->vary_ok || !h->d_ctpl) { h->err = std::string(who) + ": this settings combination has more varying entries per block than the kernels' trip count"; return HIPNLP_E_UNSUPPORTED; }
+    return HIPNLP_OK;
+}
+int hipnlp_jac_vary_layout(const hipnlp_handle* h, int64_t* out) {
+    if (!h || !out) return HIPNLP_E_INVALID;
+    const Layout& L = h->L;
+    out[0] = L.nvary_v[VAR_FIRST]; out[1] = L.N >= 3 ? L.nvary_v[VAR_INTERIOR] : 0; out[2] = L.nvary_v[VAR_LAST];
+    out[3] = vary_base(L, L.N); out[4] = vary_base(L, h->kb); out[5] = vary_base(L, h->ke) - vary_base(L, h->kb);
+    return HIPNLP_OK;
+}
+int hipnlp_fill_jac_constants(hipnlp_handle* h, double* jac_dev, int whole_horizon, void* stream) {
+    if (!h || !jac_dev) return HIPNLP_E_INVALID;
+    if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
+    if (!h->d_ctpl || !h->d_ctpl_of_b) { h->err = "hipnlp_fill_jac_constants: no constant templates for this handle"; return HIPNLP_E_UNSUPPORTED; }
+    HIP_TRY(h, hipSetDevice(h->dev));
+    const Layout& L = h->L;
+    const int kb = whole_horizon ? 0 : h->kb, ke = whole_horizon ? L.N : h->ke;
+    auto fc = [&](int v) { return h->cpos[v].empty() ? L.nnz_v[v] : int(h->cpos[v][0]); };
+    hipLaunchKernelGGL(hipnlp_fill_const_kernel, dim3(unsigned(ke - kb), unsigned(h->batch)), dim3(256), 0, stream ? hipStream_t(stream) : h->stream, jac_dev,
+                       (const double*)h->d_ctpl, (const int32_t*)h->d_ctpl_of_b, h->ctpl_len, h->ctpl_off[0], h->ctpl_off[1], h->ctpl_off[2], h->ctpl_off[3], kb, L.N,
+                       int64_t(L.nnz), L.nnz_v[VAR_FIRST], L.nnz_v[VAR_INTERIOR], L.nnz_v[VAR_LAST], fc(VAR_FIRST), fc(VAR_INTERIOR), fc(VAR_LAST),
+                       ke == L.N ? int(L.jperm_glob.size()) : 0);
+    HIP_TRY(h, hipGetLastError());
+    return HIPNLP_OK;
+}
+int hipnlp_eval_device_vary(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_vary_dev, void* stream) {
+    if (!h || !x_dev) return HIPNLP_E_INVALID;
+    const int rc = vary_ready(h, "hipnlp_eval_device_vary");
+    if (rc != HIPNLP_OK) return rc;
+    HIP_TRY(h, hipSetDevice(h->dev));
+    h->have_result = false;
+    return launch(h, x_dev, f_dev ? f_dev : h->d_f, grad_dev, g_dev, jac_vary_dev, stream ? hipStream_t(stream) : h->stream, nullptr, false, false, false, nullptr, 0, 0, true, true);
+}
+int hipnlp_eval_device_shard_vary(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_shard, double* g_stage, double* jac_vary_shard, void* stream) {
+    if (!h || !x_dev) return HIPNLP_E_INVALID;
+    const int rc = vary_ready(h, "hipnlp_eval_device_shard_vary");
+    if (rc != HIPNLP_OK) return rc;
+    HIP_TRY(h, hipSetDevice(h->dev));
+    h->have_result = false;
+    return launch(h, x_dev, f_dev ? f_dev : h->d_f, grad_shard, nullptr, jac_vary_shard, stream ? hipStream_t(stream) : h->stream, g_stage, true, false, false, nullptr, 0, 0, true, true);
+}
+int hipnlp_eval_device_peers_vary(hipnlp_handle* h, const double* x_dev, double* const* peer_out_dev, int world, int rank, void* stream) {
+    if (!h || !x_dev || !peer_out_dev || world < 1 || rank < 0 || rank >= 64) return HIPNLP_E_INVALID;
+    const int rc = vary_ready(h, "hipnlp_eval_device_peers_vary");
+    if (rc != HIPNLP_OK) return rc;
+    if (h->batch != 1) { h->err = "hipnlp_eval_device_peers_vary: one trajectory per handle (batch 1)"; return HIPNLP_E_INVALID; }
+    if (!h->fused) { h->err = "hipnlp_eval_device_peers_vary: shards of at most 256 knots (the shard's cost is summed inside the launch)"; return HIPNLP_E_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->dev));
+    h->have_result = false;
+    return launch(h, x_dev, h->d_f, nullptr, nullptr, nullptr, stream ? hipStream_t(stream) : h->stream, nullptr, false, false, false, peer_out_dev, world, rank, true);
 }
 
 int hipnlp_stage_rows(const hipnlp_handle* h, int k, int32_t* rows) {
@@ -2258,7 +2371,7 @@ int hipnlp_forget_jac_destination(hipnlp_handle* h, const void* p) {
     if (!h) return HIPNLP_E_INVALID;
     int n = 0;
     for (int i = 0; i < 8; ++i) {
-        if (h->dfilled[i].dev && (!p || h->dfilled[i].dev == p)) { h->dfilled[i] = {nullptr, 0}; ++n; }
+        if (h->dfilled[i].dev && (!p || h->dfilled[i].dev == p)) { h->dfilled[i] = {nullptr, 0, false}; ++n; }
         if (h->cfilled[i].host && (!p || h->cfilled[i].host == p)) { h->cfilled[i] = {nullptr, 0, 0}; ++n; }
     }
     return n;
@@ -2428,6 +2541,15 @@ int hipnlp_reassemble(const double* gathered_dev, const int64_t* src_dev, double
     const int64_t blocks = (count + 255) / 256;
     const unsigned grid = unsigned(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
     hipLaunchKernelGGL(hipnlp_reassemble_kernel, dim3(grid), dim3(256), 0, hipStream_t(stream), gathered_dev, src_dev, out_dev, count, world, shard_len, f_out_dev);
+    return hipGetLastError() == hipSuccess ? HIPNLP_OK : HIPNLP_E_NODEVICE;
+}
+
+int hipnlp_reassemble_scatter(const double* gathered_dev, const int64_t* src_dev, const int64_t* dst_dev, double* out_dev, int64_t count, int world, int64_t shard_len,
+                              double* f_out_dev, void* stream) {
+    if (!gathered_dev || !src_dev || !dst_dev || !out_dev || count < 0 || world < 1) return HIPNLP_E_INVALID;
+    const int64_t blocks = (count + 255) / 256;
+    const unsigned grid = unsigned(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
+    hipLaunchKernelGGL(hipnlp_reassemble_scatter_kernel, dim3(grid), dim3(256), 0, hipStream_t(stream), gathered_dev, src_dev, dst_dev, out_dev, count, world, shard_len, f_out_dev);
     return hipGetLastError() == hipSuccess ? HIPNLP_OK : HIPNLP_E_NODEVICE;
 }
 

@@ -23,6 +23,7 @@ EXPORTS = [
     "hipnlp_cost_terms", "hipnlp_cost_term_name", "hipnlp_num_row_blocks", "hipnlp_row_block",
     "hipnlp_last_kernel_ms", "hipnlp_profile_begin", "hipnlp_profile_end", "hipnlp_kernels_per_eval", "hipnlp_profile_begin_runs",
     "hipnlp_eval_device_shard", "hipnlp_stage_rows", "hipnlp_reassemble",
+    "hipnlp_jac_vary_layout", "hipnlp_fill_jac_constants", "hipnlp_eval_device_vary", "hipnlp_eval_device_shard_vary", "hipnlp_eval_device_peers_vary", "hipnlp_reassemble_scatter",
     "hipnlp_ipc_alloc", "hipnlp_ipc_open", "hipnlp_ipc_close", "hipnlp_ipc_free", "hipnlp_peer_push", "hipnlp_peer_signal", "hipnlp_peer_signal_checked", "hipnlp_peer_wait", "hipnlp_eval_device_peers",
     "hipnlp_hess_nnz", "hipnlp_hess_sparsity", "hipnlp_eval_hess", "hipnlp_eval_hess_device",
     "hipnlp_eval_pinned", "hipnlp_set_prefetch", "hipnlp_set_early_outputs", "hipnlp_set_host_timing", "hipnlp_host_register", "hipnlp_host_unregister",
@@ -137,6 +138,12 @@ def load_library(path=None):
     lib.hipnlp_set_constant_jacobian.argtypes = [vp, C.c_int]
     lib.hipnlp_jac_constant_mask.argtypes = [vp, C.POINTER(C.c_ubyte)]
     lib.hipnlp_forget_jac_destination.argtypes = [vp, vp]
+    lib.hipnlp_jac_vary_layout.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.hipnlp_fill_jac_constants.argtypes = [vp, vp, C.c_int, vp]
+    lib.hipnlp_eval_device_vary.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.hipnlp_eval_device_shard_vary.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.hipnlp_eval_device_peers_vary.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.hipnlp_reassemble_scatter.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int64, vp, vp]
     _libs[path] = lib
     return lib
 
@@ -184,6 +191,8 @@ class HipNlp:
         self.n, self.m, self.nnz, self.np = d.n, d.m, d.nnz, d.np
         self.m_full, self.n_lifted = d.m_full, d.n_lifted
         self.lifted = bool(self.desc.flags & _abi.FLAG_DETECT_SIMPLE_BOUNDS)
+        self.jac_varying_first = bool(self.desc.flags & _abi.FLAG_JAC_VARYING_FIRST)
+        self.constants_in_place = self.jac_varying_first   # (hipnlp_create's default for hipnlp_set_constant_jacobian)
         self.params_generation = 0   # bumped by set_params (what caches of parameter-dependent data key on)
         self._addresses = {}
         self._h_value = h.value
@@ -377,6 +386,7 @@ class HipNlp:
         for varying-first handles (host and device destinations); a handle in CCS order stores every entry unless this asks for the
         scheme — then its DEVICE destinations (`eval_device`) are filled once and receive the varying entries at their CCS positions."""
         self._check(self.lib.hipnlp_set_constant_jacobian(self.h, 1 if on else 0))
+        self.constants_in_place = bool(on)
 
     def forget_jac_destination(self, ptr=0):
         """hipnlp_forget_jac_destination: the buffer at `ptr` (0: every one the handle remembers) no longer counts as holding the constant
@@ -399,6 +409,30 @@ class HipNlp:
         """Device-pointer variant (ints from tensor.data_ptr()); asynchronous on `stream`."""
         self._check(self.lib.hipnlp_eval_device(self.h, C.c_void_p(x_ptr), C.c_void_p(f_ptr or None), C.c_void_p(grad_ptr or None),
                                                 C.c_void_p(g_ptr or None), C.c_void_p(jac_ptr or None), C.c_void_p(stream or None)))
+
+    # ---- exchanges without the constants of jac g (include/hipnlp.h; varying-first handles) ---------------------------------
+    def jac_vary_layout(self):
+        """hipnlp_jac_vary_layout as a dict: varying entries of a first / interior / last knot block, of the whole horizon, in front of
+        this handle's first knot, of this handle's knots"""
+        out = (C.c_int64 * 6)()
+        self._check(self.lib.hipnlp_jac_vary_layout(self.h, out))
+        return dict(zip(("first", "interior", "last", "total", "shard_off", "shard_len"), [int(v) for v in out]))
+
+    def fill_jac_constants(self, jac_ptr, whole_horizon=True, stream=0):
+        """the constant entries of jac g into the complete value array [batch][nnz] at jac_ptr (device-visible address)"""
+        self._check(self.lib.hipnlp_fill_jac_constants(self.h, C.c_void_p(jac_ptr), 1 if whole_horizon else 0, C.c_void_p(stream or None)))
+
+    def eval_device_vary(self, x_ptr, f_ptr=0, grad_ptr=0, g_ptr=0, jac_vary_ptr=0, stream=0):
+        """eval_device with a COMPACT jac destination [batch][jac_vary_layout()["total"]]: the varying runs of the knot blocks only"""
+        vp = C.c_void_p
+        self._check(self.lib.hipnlp_eval_device_vary(self.h, vp(x_ptr), vp(f_ptr or None), vp(grad_ptr or None), vp(g_ptr or None), vp(jac_vary_ptr or None), vp(stream or None)))
+
+    def eval_device_shard_vary(self, x_ptr, f_ptr, grad_ptr, stage_ptr, jac_vary_ptr, stream=0):
+        vp = C.c_void_p
+        self._check(self.lib.hipnlp_eval_device_shard_vary(self.h, vp(x_ptr), vp(f_ptr or None), vp(grad_ptr or None), vp(stage_ptr or None), vp(jac_vary_ptr or None), vp(stream or None)))
+
+    def eval_device_peers_vary(self, x_ptr, peer_out_ptr, world, rank, stream=0):
+        self._check(self.lib.hipnlp_eval_device_peers_vary(self.h, C.c_void_p(x_ptr), C.c_void_p(peer_out_ptr), int(world), int(rank), C.c_void_p(stream or None)))
 
     # ---- exact Hessian of the Lagrangian (IPOPT eval_h): lower-triangle triplets, block diagonal by knot ---------------------
     def hess_nnz(self):

@@ -11,6 +11,12 @@ Two ways to hand the shards' outputs to the consumer of the callback:
   fused shard buffer, entry by entry at its final position, into the output buffer of EVERY rank with plain stores over xGMI
   (buffers shared through HIP IPC handles), then raises a flag on every rank; torch.distributed only moves the 64-byte handles
   once, at set-up.
+  Without the constants of jac g (`const_mask` / `const_fill`; shard handles created with HIPNLP_FLAG_JAC_VARYING_FIRST): 43 % of the
+  Jacobian pattern never changes between callbacks (the +-1, -dt/2, mass entries of the linear rows the transcription emits,
+  base/multiple_shooting_solver.py:713-742).  The fused shard buffer then carries the VARYING RUN of every knot block only, the
+  reassembled buffer of every rank (rank 0's alone for the gathers to the root) is filled with the constants once per parameter set
+  (`refresh_constants()`, again after every set_params), and the reassembly writes the entries the shards sent and nothing else:
+  0.68 of the bytes on the links, the exchange being the bound of this path.
 * `HostSink` — SURVEY §5's alternative for a CPU-side IPOPT: no collective at all.  Every rank's knot kernel stores its shard of
   g / jac / grad f straight into ONE shared, pinned host buffer (a POSIX shared-memory segment every rank maps and registers with the
   HIP runtime), already in the reference's order; rank partial costs land in f_parts[rank] and are summed in rank order.
@@ -46,8 +52,12 @@ class ShardedCallback:
     for the caller's current stream first (x is ready) and the caller's stream waits for it at the end (the returned views are
     ordered for whoever uses them next, and the next call cannot overwrite buffers still being read)."""
 
-    def __init__(self, horizon, n, m, nnz, shard_info, compute_shard, device, group=None):
-        """shard_info: dict(glen, jlen, nk, stage_rows [nk, G_STAGE] int32 global rows or -1) of THIS rank."""
+    def __init__(self, horizon, n, m, nnz, shard_info, compute_shard, device, group=None, const_mask=None, const_fill=None):
+        """shard_info: dict(glen, jlen, nk, stage_rows [nk, G_STAGE] int32 global rows or -1) of THIS rank.
+        const_mask (bool [nnz], the same on every rank: entries of jac g that do not depend on x) + const_fill(jac_view, stream_handle)
+        (writes the constant entries of the WHOLE horizon into a [nnz] view of this rank's memory): the shards exchange the varying
+        entries only — shard_info then carries "jvary", the varying entries of the rank's jac range, and compute_shard fills a jac view
+        of that length (the varying runs of the rank's knot blocks behind one another, in pattern order)."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -60,8 +70,17 @@ class ShardedCallback:
         else:
             infos = [shard_info]
         self.infos = infos
+        self.compact = const_mask is not None
+        self.const_fill = const_fill
+        if self.compact:
+            if const_fill is None or any("jvary" not in i for i in infos):
+                raise ValueError("const_mask needs const_fill and shard_info['jvary'] on every rank")
+            const_mask = np.asarray(const_mask, dtype=bool)
+            if const_mask.shape != (nnz,):
+                raise ValueError("const_mask must have one flag per entry of the pattern")
+        jkey = "jvary" if self.compact else "jlen"
         self.glen_max = max(i["glen"] for i in infos)
-        self.jlen_max = max(i["jlen"] for i in infos)
+        self.jlen_max = max(i[jkey] for i in infos)
         self.nk_max = max(i["nk"] for i in infos)
         self.o_grad = 1
         self.o_jac = 1 + self.glen_max
@@ -73,7 +92,7 @@ class ShardedCallback:
         self.views = (
             self.buf[0:1],
             self.buf[self.o_grad:self.o_grad + me["glen"]],
-            self.buf[self.o_jac:self.o_jac + me["jlen"]],
+            self.buf[self.o_jac:self.o_jac + me[jkey]],
             self.buf[self.o_stage:self.o_stage + me["nk"] * G_STAGE],
         )
         # index of every entry of [grad | jac | g] inside the gathered buffer; every slot is written exactly once
@@ -84,18 +103,31 @@ class ShardedCallback:
             base = r * self.shard_len
             src[go:go + inf["glen"]] = base + self.o_grad + np.arange(inf["glen"])
             go += inf["glen"]
-            src[n + jo:n + jo + inf["jlen"]] = base + self.o_jac + np.arange(inf["jlen"])
+            if self.compact:   # the varying entries of the rank's range, in pattern order; the constants have no source
+                vary = np.nonzero(~const_mask[jo:jo + inf["jlen"]])[0]
+                if vary.size != inf["jvary"]:
+                    raise ValueError("rank %d: %d varying entries in its jac range, shard_info says %d" % (r, vary.size, inf["jvary"]))
+                src[n + jo + vary] = base + self.o_jac + np.arange(vary.size)
+            else:
+                src[n + jo:n + jo + inf["jlen"]] = base + self.o_jac + np.arange(inf["jlen"])
             jo += inf["jlen"]
             rows = np.asarray(inf["stage_rows"], dtype=np.int64).reshape(-1)
             valid = np.nonzero(rows >= 0)[0]
             np.add.at(hits, rows[valid], 1)
             src[n + nnz + rows[valid]] = base + self.o_stage + valid
-        if go != n or jo != nnz or (src < 0).any() or (hits != 1).any():
+        unsourced = src < 0
+        if self.compact:
+            unsourced[n:n + nnz] &= ~const_mask
+        if go != n or jo != nnz or unsourced.any() or (hits != 1).any():
             raise ValueError("shards do not tile the problem: grad %d/%d jac %d/%d rows missing %d, rows written twice %d"
                              % (go, n, jo, nnz, int((hits == 0).sum()), int((hits > 1).sum())))
-        self.src = torch.from_numpy(src).to(device)
+        self.src = torch.from_numpy(src).to(device)          # (-1 at the constant entries of a compact exchange)
+        if self.compact:
+            dst_c = np.nonzero(src >= 0)[0]
+            self.dst_c = torch.from_numpy(dst_c).to(device)
+            self.src_c = torch.from_numpy(src[dst_c]).to(device)
         self.f_src = torch.arange(self.world, device=device) * self.shard_len
-        self.out = torch.empty(n + nnz + m + 1, dtype=torch.float64, device=device)   # [grad | jac | g | f]
+        self.out = torch.zeros(n + nnz + m + 1, dtype=torch.float64, device=device)   # [grad | jac | g | f]
         self._lib = None
         self.stream = None
         if self.device.type == "cuda":   # one HIP launch for the whole reassembly (hipnlp_reassemble); CPU tests: torch ops
@@ -103,9 +135,52 @@ class ShardedCallback:
             from .hipnlp import load_library
             self._lib = load_library()
             self._lib.hipnlp_reassemble.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+            self._lib.hipnlp_reassemble_scatter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
             self.stream = torch.cuda.Stream(device=self.device)
             if not self.stream.cuda_stream:
                 raise RuntimeError("expected a non-default HIP stream")
+        self.refresh_constants()
+
+    def refresh_constants(self):
+        """(compact exchange) the constant entries of jac g into this rank's reassembled buffer: at set-up, and again after every change of
+        the parameters (dt and the mass are what the constants hold).  Ordered on the callback's stream."""
+        if not self.compact:
+            return
+        view = self.out[self.n:self.n + self.nnz]
+        if self.stream is None:
+            self.const_fill(view, 0)
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != self.stream.cuda_stream:
+            self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.const_fill(view, self.stream.cuda_stream)
+        if cur.cuda_stream != self.stream.cuda_stream:
+            cur.wait_stream(self.stream)
+
+    def bytes_sent_per_step(self):
+        """bytes of this rank's fused shard buffer that reach every other rank in one all-gather"""
+        return 8 * self.shard_len * (self.world - 1)
+
+    def _reassemble(self, gathered, stream_handle):
+        tot = self.n + self.nnz + self.m
+        if self._lib is not None:
+            if self.compact:
+                rc = self._lib.hipnlp_reassemble_scatter(gathered.data_ptr(), self.src_c.data_ptr(), self.dst_c.data_ptr(), self.out.data_ptr(), self.src_c.numel(),
+                                                         self.world, self.shard_len, self.out.data_ptr() + 8 * tot, stream_handle)
+            else:
+                rc = self._lib.hipnlp_reassemble(gathered.data_ptr(), self.src.data_ptr(), self.out.data_ptr(), tot, self.world, self.shard_len,
+                                                 self.out.data_ptr() + 8 * tot, stream_handle)
+            if rc != 0:
+                raise RuntimeError("hipnlp_reassemble failed (%d)" % rc)
+            f = self.out[tot]
+        else:
+            if self.compact:
+                self.out[:tot].index_copy_(0, self.dst_c, gathered.index_select(0, self.src_c))
+            else:
+                torch.index_select(gathered, 0, self.src, out=self.out[:tot])
+            f = gathered.index_select(0, self.f_src).sum()
+        return f, self.out[:self.n], self.out[self.n:self.n + self.nnz], self.out[self.n + self.nnz:tot]
 
     def _run(self, x, stream_handle):
         self.compute_shard(x, *self.views, stream_handle)
@@ -121,17 +196,7 @@ class ShardedCallback:
             gathered = self.all
         else:
             gathered = self.buf
-        tot = self.n + self.nnz + self.m
-        if self._lib is not None:
-            rc = self._lib.hipnlp_reassemble(gathered.data_ptr(), self.src.data_ptr(), self.out.data_ptr(), tot, self.world, self.shard_len,
-                                             self.out.data_ptr() + 8 * tot, stream_handle)
-            if rc != 0:
-                raise RuntimeError("hipnlp_reassemble failed (%d)" % rc)
-            f = self.out[tot]
-        else:
-            torch.index_select(gathered, 0, self.src, out=self.out[:tot])
-            f = gathered.index_select(0, self.f_src).sum()
-        return f, self.out[:self.n], self.out[self.n:self.n + self.nnz], self.out[self.n + self.nnz:tot]
+        return self._reassemble(gathered, stream_handle)
 
     def __call__(self, x):
         """One callback set for the whole horizon.  Returns (f, grad, jac, g) views of the reassembled buffer."""
@@ -167,17 +232,7 @@ class ShardedCallback:
                 gathered = self.all
             else:
                 gathered = self.buf
-            tot = self.n + self.nnz + self.m
-            if self._lib is not None:
-                rc = self._lib.hipnlp_reassemble(gathered.data_ptr(), self.src.data_ptr(), self.out.data_ptr(), tot, self.world, self.shard_len,
-                                                 self.out.data_ptr() + 8 * tot, stream_handle)
-                if rc != 0:
-                    raise RuntimeError("hipnlp_reassemble failed (%d)" % rc)
-                f = self.out[tot]
-            else:
-                torch.index_select(gathered, 0, self.src, out=self.out[:tot])
-                f = gathered.index_select(0, self.f_src).sum()
-            return f, self.out[:self.n], self.out[self.n:self.n + self.nnz], self.out[self.n + self.nnz:tot]
+            return self._reassemble(gathered, stream_handle)
         if self.stream is None:
             return run(0)
         cur = torch.cuda.current_stream(self.device)
@@ -322,6 +377,19 @@ class PeerExchange:
         if self.world > 1:
             dist.barrier(group=cb.group)                  # every rank has opened every buffer
         self._handshake(bases, handshake_timeout_s)
+        self.refresh_constants()
+
+    def refresh_constants(self):
+        """(compact exchange: the callback was built with const_mask / const_fill) the constant entries of jac g into this rank's OWN two
+        output buffers — the peers store the varying runs around them.  At set-up and after every change of the parameters; a rank
+        that receives nothing (gather_to_root, rank != 0) holds nothing.  Collective-free: every rank fills its own memory."""
+        cb = self.cb
+        if not cb.compact or (self.root_only and self.rank != 0):
+            return
+        with torch.cuda.stream(cb.stream):
+            for par in (0, 1):
+                cb.const_fill(self._views[par][cb.n:cb.n + cb.nnz], cb.stream.cuda_stream)
+        cb.stream.synchronize()
 
     def _handshake(self, bases, timeout_s):
         """One word written into every peer's buffer and one word read from every peer, BEFORE anything is timed or trusted: mapping
@@ -373,7 +441,8 @@ class PeerExchange:
                 # step seq - 1, sent in the previous call.)  A non-root rank is therefore never more than one step ahead of the consumer.
                 rc |= lib.hipnlp_peer_wait(self.my_back_flags, 1, self.seq - 1, self._scratch.data_ptr(), 0, self.status.data_ptr(), sh)
             if self.engine is not None:
-                self.engine.eval_device_peers(x.data_ptr(), targets.data_ptr(), ntargets, self.rank, stream=sh)
+                # (compact exchange: the varying runs only, at their places in the pattern — the receivers' buffers hold the constants)
+                (self.engine.eval_device_peers_vary if cb.compact else self.engine.eval_device_peers)(x.data_ptr(), targets.data_ptr(), ntargets, self.rank, stream=sh)
             else:
                 cb.compute_shard(x, *cb.views, sh)
                 rc |= lib.hipnlp_peer_push(cb.buf.data_ptr(), self.dst.data_ptr(), cb.shard_len, targets.data_ptr(), ntargets, sh)
@@ -398,7 +467,7 @@ class PeerExchange:
         """bytes this rank stores into OTHER ranks' buffers per step (what its xGMI links carry)"""
         me = self.cb.infos[self.rank]
         rows = int((np.asarray(me["stage_rows"]).reshape(-1) >= 0).sum())
-        shard = 8 * (me["glen"] + me["jlen"] + rows + 1)
+        shard = 8 * (me["glen"] + me["jvary" if self.cb.compact else "jlen"] + rows + 1)
         if self.root_only:
             return 0 if self.rank == 0 else shard
         return shard * (self.world - 1)
@@ -409,7 +478,7 @@ class PeerExchange:
         best = 0
         for inf in self.cb.infos:
             rows = int((np.asarray(inf["stage_rows"]).reshape(-1) >= 0).sum())
-            best = max(best, 8 * (inf["glen"] + inf["jlen"] + rows + 1))
+            best = max(best, 8 * (inf["glen"] + inf["jvary" if self.cb.compact else "jlen"] + rows + 1))
         if self.root_only:
             return best if self.world > 1 else 0
         return best * (self.world - 1)
@@ -457,9 +526,15 @@ class BatchDealtCallback:
     four outputs are contiguous pieces of it, so rank 0 hands out VIEWS of the gathered buffers (`trajectory(b)`).
 
         compute_batch(x_local, f_view, grad_view, g_view, jac_view, stream_handle)     fills the rank's views
-        to_root(x_local)   ONE collective (dist.gather: RCCL over xGMI, gloo in the CPU tests); returns self on rank 0, None elsewhere"""
+        to_root(x_local)   ONE collective (dist.gather: RCCL over xGMI, gloo in the CPU tests); returns self on rank 0, None elsewhere
 
-    def __init__(self, batch, n, m, nnz, compute_batch, device, group=None):
+    Without the constants of jac g (`const_mask` + `const_fill`, as ShardedCallback): the jac view of a rank is [Bl][nvary] — the varying
+    runs of every trajectory's knot blocks — and so is what the gather moves; rank 0 keeps a COMPLETE [batch][nnz] value array whose
+    constant entries arrive ONCE per parameter set (`refresh_constants()`: a one-off gather of every rank's constants — trajectories may
+    differ in dt and mass) and scatters the varying entries into it behind every gather (one launch): `trajectory(b)` hands out views of
+    it as before."""
+
+    def __init__(self, batch, n, m, nnz, compute_batch, device, group=None, const_mask=None, const_fill=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -469,16 +544,57 @@ class BatchDealtCallback:
         self.compute_batch = compute_batch
         self.device = torch.device(device)
         Bl = self.local
+        self.compact = const_mask is not None
+        self.const_fill = const_fill
+        self.jw = nnz                                    # entries of a trajectory's jac in the exchange buffer
+        if self.compact:
+            if const_fill is None:
+                raise ValueError("const_mask needs const_fill")
+            const_mask = np.asarray(const_mask, dtype=bool)
+            if const_mask.shape != (nnz,):
+                raise ValueError("const_mask must have one flag per entry of the pattern")
+            self.jw = int((~const_mask).sum())
+            self.vary_idx = torch.from_numpy(np.nonzero(~const_mask)[0]).to(device)
         self.o_grad, self.o_g, self.o_jac = Bl, Bl + Bl * n, Bl + Bl * (n + m)
-        self.shard_len = Bl * (1 + n + m + nnz)
+        self.shard_len = Bl * (1 + n + m + self.jw)
+        self.full_len = Bl * (1 + n + m + nnz)           # a rank's piece of a buffer that holds complete Jacobians (BatchPeerToRoot)
         self.buf = torch.zeros(self.shard_len, dtype=torch.float64, device=device)
         self.all = torch.zeros(self.world * self.shard_len, dtype=torch.float64, device=device) if self.rank == 0 else None
+        self.full_jac = torch.zeros(batch, nnz, dtype=torch.float64, device=device) if (self.compact and self.rank == 0) else None
         self.views = self._views_of(self.buf)
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.refresh_constants()
 
-    def _views_of(self, buf):
-        Bl, n, m, nnz = self.local, self.n, self.m, self.nnz
-        return (buf[0:Bl], buf[self.o_grad:self.o_g].view(Bl, n), buf[self.o_g:self.o_jac].view(Bl, m), buf[self.o_jac:self.shard_len].view(Bl, nnz))
+    def _views_of(self, buf, complete=False):
+        Bl, n, m = self.local, self.n, self.m
+        jw = self.nnz if complete else self.jw
+        return (buf[0:Bl], buf[self.o_grad:self.o_g].view(Bl, n), buf[self.o_g:self.o_jac].view(Bl, m), buf[self.o_jac:self.o_jac + Bl * jw].view(Bl, jw))
+
+    def refresh_constants(self):
+        """(compact exchange) every rank's constants — of ITS trajectories, under the parameters last set — into rank 0's complete
+        array: one gather per parameter set (a collective: every rank calls it, at set-up and after every set_params)"""
+        if not self.compact:
+            return
+        mine = torch.zeros(self.local, self.nnz, dtype=torch.float64, device=self.device)
+        if self.stream is None:
+            self.const_fill(mine, 0)
+        else:
+            cur = torch.cuda.current_stream(self.device)
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                self.const_fill(mine, self.stream.cuda_stream)
+            self.stream.synchronize()
+        if self.world == 1:
+            self.full_jac.copy_(mine)
+            return
+        on_host = self.device.type == "cuda" and dist.get_backend(self.group) == "gloo"   # (rehearsal: gloo gathers host tensors)
+        piece = mine.cpu() if on_host else mine
+        if self.rank == 0:
+            parts = [torch.empty_like(piece) for _ in range(self.world)]
+            dist.gather(piece, parts, dst=0, group=self.group)
+            self.full_jac.copy_(torch.cat(parts).to(self.device))
+        else:
+            dist.gather(piece, None, dst=0, group=self.group)
 
     def bytes_sent_per_step(self):
         return 0 if self.rank == 0 else 8 * self.shard_len
@@ -487,16 +603,26 @@ class BatchDealtCallback:
         return 8 * self.shard_len if self.world > 1 else 0
 
     def trajectory(self, b, gathered=None):
-        """(f, grad, g, jac) views of trajectory b in rank 0's gathered buffer"""
-        gathered = self.all if gathered is None else gathered
+        """(f, grad, g, jac) views of trajectory b on rank 0: of the last to_root's result, or — `gathered` — of a buffer that holds the
+        ranks' pieces with COMPLETE Jacobians (BatchPeerToRoot)"""
         r, i = divmod(b, self.local)
-        f, grad, g, jac = self._views_of(gathered[r * self.shard_len:(r + 1) * self.shard_len])
-        return f[i], grad[i], g[i], jac[i]
+        if gathered is not None:
+            f, grad, g, jac = self._views_of(gathered[r * self.full_len:(r + 1) * self.full_len], complete=True)
+            return f[i], grad[i], g[i], jac[i]
+        f, grad, g, jac = self._views_of(self.all[r * self.shard_len:(r + 1) * self.shard_len])
+        return f[i], grad[i], g[i], (self.full_jac[b] if self.compact else jac[i])
+
+    def _expand(self):
+        """(rank 0, compact exchange) the gathered varying entries into their places of the complete array: one launch"""
+        if self.compact:
+            got = self.all.view(self.world, self.shard_len)[:, self.o_jac:].reshape(self.world, self.local, self.jw)
+            self.full_jac.view(self.world, self.local, self.nnz).index_copy_(2, self.vary_idx, got)
 
     def _run(self, x_local, stream_handle):
         self.compute_batch(x_local, *self.views, stream_handle)
         if self.world == 1:
             self.all.copy_(self.buf)
+            self._expand()
             return self
         chunks = list(self.all.view(self.world, self.shard_len).unbind(0)) if self.rank == 0 else None
         if self.device.type == "cuda" and dist.get_backend(self.group) == "gloo":   # rehearsal: several ranks on one GPU (gloo gathers host tensors)
@@ -507,6 +633,8 @@ class BatchDealtCallback:
                 self.all.copy_(torch.cat(host))
         else:
             dist.gather(self.buf, chunks, dst=0, group=self.group)
+        if self.rank == 0:
+            self._expand()
         return self if self.rank == 0 else None
 
     def to_root(self, x_local):
@@ -564,7 +692,7 @@ class BatchPeerToRoot:
             raise RuntimeError("peer exchange: at most 16 ranks")
         self.dev_index = bc.device.index if bc.device.index is not None else torch.cuda.current_device()
         # every rank allocates (its flag words are written by rank 0); only rank 0's allocation holds output buffers
-        self.olen = self.world * bc.shard_len + self.world + 1       # [rank][f | grad | g | jac] | scratch of the wait kernel
+        self.olen = self.world * bc.full_len + self.world + 1        # [rank][f | grad | g | jac (complete)] | scratch of the wait kernel
         self.flag_words = 64
         words = (2 * self.olen if self.rank == 0 else 0) + self.flag_words
         mine, handle = vp(), C.create_string_buffer(64)
@@ -654,24 +782,34 @@ class BatchPeerToRoot:
             rc = 0
             if self.rank != 0 and self.seq > 1:   # (as PeerExchange(root_only): rank 0's back-flag of step seq - 1 lies behind its consumption of step seq - 2)
                 rc |= lib.hipnlp_peer_wait(self.my_back_flags, 1, self.seq - 1, self._scratch.data_ptr(), 0, self.status.data_ptr(), sh)
-            base = self.root_out[par] + 8 * self.rank * bc.shard_len
+            # (a varying-first engine fills the constants of its piece at its first sight of it — once per parity and parameter set, over its
+            #  link — and stores the varying runs from then on: hipnlp_eval_device)
+            base = self.root_out[par] + 8 * self.rank * bc.full_len
             self.engine.eval_device(x_local.data_ptr(), base, base + 8 * bc.o_grad, base + 8 * bc.o_g, base + 8 * bc.o_jac, stream=sh)
             rc |= lib.hipnlp_peer_signal_checked(self.root_flags.data_ptr(), 1, self.rank, self.seq, self.status.data_ptr(), sh)
             if self.rank == 0:
                 out = self._gathered[par]
-                rc |= lib.hipnlp_peer_wait(self.my_flags, self.world, self.seq, out.data_ptr(), self.world * bc.shard_len, self.status.data_ptr(), sh)
+                rc |= lib.hipnlp_peer_wait(self.my_flags, self.world, self.seq, out.data_ptr(), self.world * bc.full_len, self.status.data_ptr(), sh)
                 rc |= lib.hipnlp_peer_signal(self.back_flags.data_ptr(), self.world, 0, self.seq, sh)
             if rc != 0:
                 raise RuntimeError("batch peer exchange: a launch failed")
         if cur.cuda_stream != bc.stream.cuda_stream:
             cur.wait_stream(bc.stream)
-        return self._gathered[par][:self.world * bc.shard_len] if self.rank == 0 else None
+        return self._gathered[par][:self.world * bc.full_len] if self.rank == 0 else None
+
+    def _piece_bytes(self):
+        """what a rank's launch stores into rank 0's buffer per step: complete Jacobians, or — an engine whose destinations hold the
+        constants (varying-first handle, hipnlp_set_constant_jacobian on: the default) — their varying runs only"""
+        bc = self.bc
+        skips = getattr(self.engine, "jac_varying_first", False) and getattr(self.engine, "constants_in_place", True)
+        jw = self.engine.jac_vary_layout()["total"] if skips else bc.nnz
+        return 8 * bc.local * (1 + bc.n + bc.m + jw)
 
     def bytes_sent_per_step(self):
-        return 0 if self.rank == 0 else 8 * self.bc.shard_len
+        return 0 if self.rank == 0 else self._piece_bytes()
 
     def max_bytes_sent_per_step(self):
-        return 8 * self.bc.shard_len if self.world > 1 else 0
+        return self._piece_bytes() if self.world > 1 else 0
 
     def timed_out(self):
         self.bc.stream.synchronize()
@@ -694,12 +832,14 @@ class BatchPeerToRoot:
             self._release()
 
 
-def hip_batch_backend(engine):
-    """compute_batch backed by a batched HIP engine handle (hipnlp_eval_device on the rank's trajectories)"""
+def hip_batch_backend(engine, compact=False):
+    """compute_batch backed by a batched HIP engine handle (hipnlp_eval_device on the rank's trajectories).  compact: the jac view is
+    [Bl][nvary] — the varying runs of every trajectory's knot blocks (hipnlp_eval_device_vary; a varying-first handle)"""
     def compute(x_local, f_view, grad_view, g_view, jac_view, stream_handle):
         if not stream_handle:
             raise RuntimeError("the batch-dealt path needs an explicit (non-default) stream")
-        engine.eval_device(x_local.data_ptr(), f_view.data_ptr(), grad_view.data_ptr(), g_view.data_ptr(), jac_view.data_ptr(), stream=stream_handle)
+        (engine.eval_device_vary if compact else engine.eval_device)(x_local.data_ptr(), f_view.data_ptr(), grad_view.data_ptr(), g_view.data_ptr(), jac_view.data_ptr(),
+                                                                     stream=stream_handle)
     return compute
 
 
@@ -712,21 +852,33 @@ def _device_view(ptr, count, device):
     return torch.as_tensor(h, device=device)
 
 
-def hip_shard_backend(engine):
-    """compute_shard backed by the HIP engine handle that owns this rank's knots."""
+def hip_shard_backend(engine, compact=False):
+    """compute_shard backed by the HIP engine handle that owns this rank's knots.  compact: the jac view receives the varying runs of the
+    rank's knot blocks only (hipnlp_eval_device_shard_vary; a handle created with jac_varying_first=True)."""
     def compute(x, f_view, grad_view, jac_view, stage_view, stream_handle):
         if not stream_handle:
             raise RuntimeError("the sharded path needs an explicit (non-default) stream: a NULL stream means different streams to "
                                "hipnlp_eval_device_shard and hipnlp_reassemble")
-        engine.eval_device_shard(x.data_ptr(), f_view.data_ptr(), grad_view.data_ptr(), stage_view.data_ptr(), jac_view.data_ptr(),
-                                 stream=stream_handle)
+        (engine.eval_device_shard_vary if compact else engine.eval_device_shard)(x.data_ptr(), f_view.data_ptr(), grad_view.data_ptr(), stage_view.data_ptr(),
+                                                                                  jac_view.data_ptr(), stream=stream_handle)
     return compute
 
 
 def hip_shard_info(engine, knot_begin, knot_end):
     d = engine.dims
     rows = np.stack([engine.stage_rows(k) for k in range(knot_begin, knot_end)])
-    return {"glen": int(d.shard_grad), "jlen": int(d.shard_nnz), "nk": knot_end - knot_begin, "stage_rows": rows}
+    info = {"glen": int(d.shard_grad), "jlen": int(d.shard_nnz), "nk": knot_end - knot_begin, "stage_rows": rows}
+    if getattr(engine, "jac_varying_first", False):
+        info["jvary"] = engine.jac_vary_layout()["shard_len"]
+    return info
+
+
+def hip_constants(engine):
+    """const_mask / const_fill of a varying-first HIP engine handle for ShardedCallback and BatchDealtCallback: the mask of the handle's
+    pattern, and hipnlp_fill_jac_constants on the caller's view (whole horizon: a shard handle knows the whole pattern)"""
+    def fill(jac_view, stream_handle):
+        engine.fill_jac_constants(jac_view.data_ptr(), True, stream_handle)
+    return {"const_mask": engine.jac_constant_mask(), "const_fill": fill}
 
 
 class HostSink:

@@ -442,6 +442,40 @@ int hipnlp_peer_wait(const unsigned long long* flags_dev, int world, unsigned lo
  * (NULL: the handle's own stream), not synchronised; the non-finite flag of the handle works as with hipnlp_eval_device. */
 int hipnlp_eval_device_peers(hipnlp_handle* h, const double* x_dev, double* const* peer_out_dev, int world, int rank, void* stream);
 
+/* ---- Exchanges without the constants of jac g (multi-GPU) ---------------------------------------------------------------
+ * 43 % of the Jacobian pattern of the kinodynamic NLP never changes between callbacks: the +-1 / -dt/2 / mass entries of the linear rows the
+ * transcription emits (trapezoid defects and x_0 rows: /root/reference/src/hippopt/base/multiple_shooting_solver.py:713-742,
+ * integrators/implicit_trapezoid.py:24-39).  An exchange between GPUs — the bound of the knot-sharded path — has no reason to move
+ * them every step: on a handle created with HIPNLP_FLAG_JAC_VARYING_FIRST the shards hand over the VARYING RUN of every knot block
+ * only, and the consumer's buffer (the reassembled array on every rank, rank 0's gather buffer, a shared host sink) holds the constant
+ * entries, put there once per parameter set by hipnlp_fill_jac_constants.  All of these need HIPNLP_FLAG_JAC_VARYING_FIRST
+ * (HIPNLP_E_UNSUPPORTED otherwise) and hipnlp_set_params first; device pointers, enqueued on `stream` (NULL: the handle's own), not
+ * synchronised.
+ *   hipnlp_jac_vary_layout         out[0..2] varying entries of a first / interior / last knot block, out[3] of the whole horizon,
+ *                                  out[4] of the knots in front of this handle's first knot, out[5] of this handle's knots: a COMPACT
+ *                                  destination lists the varying runs of the knot blocks behind one another (knot k's run at
+ *                                  out[0] + (k - 1) out[1] for k >= 1), entry i of a run being entry i of the knot's block in the pattern
+ *                                  (hipnlp_sparsity; hipnlp_jac_constant_mask is 0 exactly there)
+ *   hipnlp_fill_jac_constants      the constant entries (values under the parameters last set) into jac_dev [batch][nnz], a complete
+ *                                  value array in the handle's pattern order: of the handle's own knots, or — whole_horizon != 0 — of every
+ *                                  knot and the horizon-global columns (a shard handle knows the whole pattern: the reassembled buffer
+ *                                  of a rank is filled by that rank).  Again after every hipnlp_set_params that changes dt or the mass.
+ *   hipnlp_eval_device_vary        hipnlp_eval_device with a compact jac destination: jac_vary_dev [batch][out[3]]
+ *   hipnlp_eval_device_shard_vary  hipnlp_eval_device_shard with a compact jac shard: jac_vary_shard [batch][out[5]]
+ *   hipnlp_eval_device_peers_vary  hipnlp_eval_device_peers storing the varying runs only, at their places in the pattern, into buffers
+ *                                  whose jac part holds the constants (hipnlp_fill_jac_constants(..., whole_horizon = 1) on the buffer's
+ *                                  owner)
+ *   hipnlp_reassemble_scatter      hipnlp_reassemble with a destination index: out[dst[i]] = gathered[src[i]], i < count — entries of
+ *                                  `out` no shard sends (the constants) are left alone                                                 */
+int hipnlp_jac_vary_layout(const hipnlp_handle* h, int64_t* out /*[6]*/);
+int hipnlp_fill_jac_constants(hipnlp_handle* h, double* jac_dev, int whole_horizon, void* stream);
+int hipnlp_eval_device_vary(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_vary_dev, void* stream);
+int hipnlp_eval_device_shard_vary(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_shard, double* g_stage, double* jac_vary_shard,
+                                  void* stream);
+int hipnlp_eval_device_peers_vary(hipnlp_handle* h, const double* x_dev, double* const* peer_out_dev, int world, int rank, void* stream);
+int hipnlp_reassemble_scatter(const double* gathered_dev, const int64_t* src_dev, const int64_t* dst_dev, double* out_dev, int64_t count, int world,
+                              int64_t shard_len, double* f_out_dev, void* stream);
+
 /* Per-named-cost values of the last evaluation (Output.cost_values, base/problem.py:28-56):
  * values[batch][HIPNLP_NCOST_TERMS], summed over knots, in the order of hipnlp_cost_term_name(). */
 #define HIPNLP_NCOST_TERMS 12

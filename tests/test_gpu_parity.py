@@ -511,38 +511,53 @@ def test_maximum_sizes_and_shard_consistency(model, HipNlp):
         assert np.array_equal(jacb[b], jac1[b % 8]) and np.array_equal(gb[b], g1[b % 8]) and fb[b] == f1[b % 8]
 
 
-@pytest.mark.parametrize("lifted", [False, True])
-def test_sharded_callback_reassembly_on_gpu(model, HipNlp, lifted):
+@pytest.mark.parametrize("lifted,compact", [(False, False), (True, False), (False, True), (True, True)])
+def test_sharded_callback_reassembly_on_gpu(model, HipNlp, lifted, compact):
     """(lifted: the knot shards of the detect_simple_bounds problem — what a sharded solve of the reference's scripts evaluates.)
     ShardedCallback on the GPU at world size 1: the fused shard buffer of the whole horizon goes through the
     library's one-launch reassembly (hipnlp_reassemble) and must equal the unsharded callback bit for bit; f is the in-kernel sum.
     x CHANGES ON EVERY CALL and there are no warm-up repeats: a result that is not ordered behind its own shard evaluation (the
-    evaluation on one stream, the reassembly on another) would show the previous iterate's values."""
+    evaluation on one stream, the reassembly on another) would show the previous iterate's values.
+    compact: the exchange without the constants of jac g (varying-first handles: the fused buffer carries the varying runs, the reassembled
+    buffer holds the constants, hipnlp_reassemble_scatter writes around them) — also across a set_params that changes dt."""
     import torch
-    from hippopt_amd.sharded import ShardedCallback, hip_shard_backend, hip_shard_info
+    from hippopt_amd.sharded import ShardedCallback, hip_constants, hip_shard_backend, hip_shard_info
     N = 24
     st = periodic_step_settings(N, model)
     x, p = make_workload(st, model, batch=1, seed=77)
-    full = HipNlp(st, model, detect_simple_bounds=lifted)
+    full = HipNlp(st, model, detect_simple_bounds=lifted, jac_varying_first=compact)
     full.set_params(p)
+    full.set_constant_jacobian(False)            # the reference stores every entry on every call
     dev = torch.device("cuda", 0)
-    sh = HipNlp(st, model, knot_begin=0, knot_end=N, detect_simple_bounds=lifted)
+    sh = HipNlp(st, model, knot_begin=0, knot_end=N, detect_simple_bounds=lifted, jac_varying_first=compact)
     sh.set_params(p)
     assert (sh.m < sh.m_full) == lifted
-    cb = ShardedCallback(N, sh.n, sh.m, sh.nnz, hip_shard_info(sh, 0, N), hip_shard_backend(sh), dev)
+    info = hip_shard_info(sh, 0, N)
+    cb = ShardedCallback(N, sh.n, sh.m, sh.nnz, info, hip_shard_backend(sh, compact), dev, **(hip_constants(sh) if compact else {}))
+    if compact:
+        lay = sh.jac_vary_layout()
+        assert info["jvary"] == lay["shard_len"] == lay["total"] == int((~sh.jac_constant_mask()).sum()) and lay["shard_off"] == 0
+        assert cb.shard_len == 1 + info["glen"] + info["jvary"] + N * 550 and info["jvary"] < 0.62 * info["jlen"]
     rng = np.random.RandomState(4)
     xs = [x[0] + 1e-2 * i * rng.standard_normal(x.shape[1]) for i in range(6)]
     xds = [torch.from_numpy(xi).to(dev) for xi in xs]
     torch.cuda.synchronize()
-    got = []
-    for xd in xds:   # back to back, results copied out on the caller's stream without an explicit synchronisation in between
-        fs, grads, jacs, gs = cb(xd)
-        got.append((fs.clone(), grads.clone(), jacs.clone(), gs.clone()))
-    torch.cuda.synchronize()
-    for xi, (fs, grads, jacs, gs) in zip(xs, got):
-        f, grad, g, jac = full.eval(xi[None, :])
-        assert float(fs) == f[0]
-        assert np.array_equal(grads.cpu().numpy(), grad[0]) and np.array_equal(jacs.cpu().numpy(), jac[0]) and np.array_equal(gs.cpu().numpy(), g[0])
+    p2 = p.copy()
+    p2[:, 24 * N + 3 + 105 + 105] *= 1.3             # dt: the constants of the trapezoid defects change with it
+    for params in ((p, p2) if compact else (p,)):
+        if params is p2:
+            full.set_params(p2)
+            sh.set_params(p2)
+            cb.refresh_constants()
+        got = []
+        for xd in xds:   # back to back, results copied out on the caller's stream without an explicit synchronisation in between
+            fs, grads, jacs, gs = cb(xd)
+            got.append((fs.clone(), grads.clone(), jacs.clone(), gs.clone()))
+        torch.cuda.synchronize()
+        for xi, (fs, grads, jacs, gs) in zip(xs, got):
+            f, grad, g, jac = full.eval(xi[None, :])
+            assert float(fs) == f[0]
+            assert np.array_equal(grads.cpu().numpy(), grad[0]) and np.array_equal(jacs.cpu().numpy(), jac[0]) and np.array_equal(gs.cpu().numpy(), g[0])
 
 
 def test_launch_number_wrap(model, HipNlp):
@@ -636,20 +651,24 @@ def test_early_outputs_into_registered_arrays(model, HipNlp, early_grad):
     assert np.array_equal(got[3], ref[0][3])
 
 
-def test_peer_exchange_equals_the_gathered_callback(model, HipNlp):
+@pytest.mark.parametrize("compact", [False, True])
+def test_peer_exchange_equals_the_gathered_callback(model, HipNlp, compact):
     """PeerExchange (peer stores into IPC-shared output buffers + flags, no collective, no reassembly pass) at world size 1: the
-    rank pushes into its own buffer; bitwise the unsharded callback, on alternating iterates and both buffer parities."""
+    rank pushes into its own buffer; bitwise the unsharded callback, on alternating iterates and both buffer parities.
+    compact: the varying runs of jac g only (varying-first handles; hipnlp_eval_device_peers_vary for the folded push), the receiver's
+    two buffers hold the constants — refreshed after a set_params that changes dt."""
     import torch
-    from hippopt_amd.sharded import PeerExchange, ShardedCallback, hip_shard_backend, hip_shard_info
+    from hippopt_amd.sharded import PeerExchange, ShardedCallback, hip_constants, hip_shard_backend, hip_shard_info
     N = 24
     st = periodic_step_settings(N, model)
     x, p = make_workload(st, model, batch=1, seed=78)
-    full = HipNlp(st, model)
+    full = HipNlp(st, model, jac_varying_first=compact)
     full.set_params(p)
+    full.set_constant_jacobian(False)
     dev = torch.device("cuda", 0)
-    sh = HipNlp(st, model, knot_begin=0, knot_end=N)
+    sh = HipNlp(st, model, knot_begin=0, knot_end=N, jac_varying_first=compact)
     sh.set_params(p)
-    cb = ShardedCallback(N, sh.n, sh.m, sh.nnz, hip_shard_info(sh, 0, N), hip_shard_backend(sh), dev)
+    cb = ShardedCallback(N, sh.n, sh.m, sh.nnz, hip_shard_info(sh, 0, N), hip_shard_backend(sh, compact), dev, **(hip_constants(sh) if compact else {}))
     rng = np.random.RandomState(5)
     xs = [x[0] + 1e-2 * i * rng.standard_normal(x.shape[1]) for i in range(5)]
     # push kernel behind the shard evaluation / stores folded into the evaluation (hipnlp_eval_device_peers); every rank receives /
@@ -667,8 +686,25 @@ def test_peer_exchange_equals_the_gathered_callback(model, HipNlp):
             assert float(fs) == f[0]
             assert np.array_equal(grads.cpu().numpy(), grad[0]) and np.array_equal(jacs.cpu().numpy(), jac[0]) and np.array_equal(gs.cpu().numpy(), g[0])
         assert px.bytes_sent_per_step() == 0       # one rank: nothing leaves the device
+        if compact:     # a parameter change: new constants into the receiver's buffers, then the same comparison under the new parameters
+            p2 = p.copy()
+            p2[:, 24 * N + 3 + 105 + 105] *= 0.8
+            for e in (full, sh):
+                e.set_params(p2)
+            px.refresh_constants()
+            for xi in xs[:3]:
+                fs, grads, jacs, gs = px(torch.from_numpy(xi).to(dev))
+                torch.cuda.synchronize()
+                f, grad, g, jac = full.eval(xi[None, :])
+                assert float(fs) == f[0] and np.array_equal(jacs.cpu().numpy(), jac[0]) and np.array_equal(gs.cpu().numpy(), g[0])
+            for e in (full, sh):
+                e.set_params(p)
+            # (what a rank would send: a third less than the exchange of every entry)
+            me = cb.infos[0]
+            assert px.max_bytes_sent_per_step() == 0 and me["jvary"] < 0.62 * me["jlen"]
         px.close()
     # the collective's gather_to_root at world size 1
+    cb.refresh_constants()
     fs, grads, jacs, gs = cb.to_root(torch.from_numpy(xs[1]).to(dev))
     torch.cuda.synchronize()
     f, grad, g, jac = full.eval(xs[1][None, :])
@@ -716,25 +752,37 @@ def test_a_wait_that_gives_up_is_sticky_and_poisons_the_step(model, HipNlp):
     assert float(out[tot + world]) == 4.0 and bool((out[:tot] == 2.0).all())
 
 
+@pytest.mark.parametrize("vary", [False, True])
 @pytest.mark.parametrize("terrain,waves,split", [("planar", 8, 12), ("planar", 4, 9), ("stairs", 8, 15), ("stairs", 4, 1)])
-def test_evaluation_that_stores_into_every_ranks_buffer(model, HipNlp, terrain, waves, split):
+def test_evaluation_that_stores_into_every_ranks_buffer(model, HipNlp, terrain, waves, split, vary):
     """hipnlp_eval_device_peers: the knot kernel of a shard handle writes the shard's entries at their FINAL positions into the
     [grad | jac | g | f partials | f] buffer of every rank.  Two shard handles of one process play two ranks (uneven shards, both
     kernel variants, both terrains); both buffers must hold, bit for bit, the unsharded callback's grad / jac / g, and the cost
-    partials the all-gather path sums."""
+    partials the all-gather path sums.
+    vary: hipnlp_eval_device_peers_vary on varying-first handles — the buffers hold the constant entries of jac g
+    (hipnlp_fill_jac_constants, whole horizon, by a SHARD handle), the kernels store the varying runs at their places in the pattern."""
     import torch
     N = 24
     st = (stairs_settings if terrain == "stairs" else periodic_step_settings)(N, model)
     x, p = make_workload(st, model, batch=1, seed=91)
+    if terrain == "stairs":
+        place_on_step_flanks(x, st, seed=91)
     dev = torch.device("cuda", 0)
     with diag_overrides(HIPNLP_WAVES=waves) as lib:
-        full = HipNlp(st, model, library=lib)
-        shards = [HipNlp(st, model, knot_begin=0, knot_end=split, library=lib), HipNlp(st, model, knot_begin=split, knot_end=N, library=lib)]
+        full = HipNlp(st, model, library=lib, jac_varying_first=vary)
+        shards = [HipNlp(st, model, knot_begin=0, knot_end=split, library=lib, jac_varying_first=vary),
+                  HipNlp(st, model, knot_begin=split, knot_end=N, library=lib, jac_varying_first=vary)]
     for e in [full] + shards:
         e.set_params(p)
+    full.set_constant_jacobian(False)
     n, m, nnz = full.n, full.m, full.nnz
     tot, world = n + nnz + m, 2
     bufs = [torch.full((tot + world + 1,), float("nan"), dtype=torch.float64, device=dev) for _ in range(world)]
+
+    def constants_in_place():
+        if vary:   # (one buffer by each shard handle: either knows the whole pattern)
+            for r, b in enumerate(bufs):
+                shards[r].fill_jac_constants(b.data_ptr() + 8 * n, True, stream.cuda_stream)
     table = torch.tensor([b.data_ptr() for b in bufs], dtype=torch.int64, device=dev)
     flags = torch.zeros(64, dtype=torch.int64, device=dev)
     ftab = torch.tensor([flags.data_ptr()], dtype=torch.int64, device=dev)
@@ -750,8 +798,9 @@ def test_evaluation_that_stores_into_every_ranks_buffer(model, HipNlp, terrain, 
         xi = x[0] + 1e-2 * step * rng.standard_normal(x.shape[1])
         xd = torch.from_numpy(xi).to(dev)
         with torch.cuda.stream(stream):
+            constants_in_place()
             for r, e in enumerate(shards):
-                e.eval_device_peers(xd.data_ptr(), table.data_ptr(), world, r, stream=stream.cuda_stream)
+                (e.eval_device_peers_vary if vary else e.eval_device_peers)(xd.data_ptr(), table.data_ptr(), world, r, stream=stream.cuda_stream)
                 # (one process: both "ranks" signal into the one flag array)
                 assert lib.hipnlp_peer_signal(ftab.data_ptr(), 1, 0, step, stream.cuda_stream) == 0
         stream.synchronize()
@@ -921,32 +970,54 @@ def test_host_path_want_mask_lazy_fetch_and_views(model, HipNlp):
             eng.lib.hipnlp_host_unregister(C.c_void_p(a.ctypes.data))
 
 
-def test_host_sink_shards_store_into_one_registered_buffer(model, HipNlp):
+@pytest.mark.parametrize("order", ["ccs", "ccs, constants in place", "varying first"])
+def test_host_sink_shards_store_into_one_registered_buffer(model, HipNlp, order):
     """HostSink (SURVEY §5's alternative to the all-gather): the knot kernels of two shard handles store their g / jac / grad f
     straight into ONE registered host buffer in the reference's order — no collective, no staging copy.  Bitwise equal to the
-    unsharded evaluation; the rank partial costs sum to f."""
+    unsharded evaluation; the rank partial costs sum to f.
+    Both orders of a knot block; with the constants in place (the default of varying-first handles; opt-in in CCS order) every shard
+    handle fills the constants of ITS knots into the sink at its first sight of it — and again after a set_params — and stores the
+    varying entries from then on; a destination in host memory is never read back by the launch (no check over PCIe)."""
     import torch
     from hippopt_amd.sharded import HostSink, knot_range
     N = 17
+    vf = order == "varying first"
     st = periodic_step_settings(N, model)
     x, p = make_workload(st, model, batch=1, seed=52)
-    full = HipNlp(st, model)
-    full.set_params(p)
-    f, grad, g, jac = full.eval(x)
+    full = HipNlp(st, model, jac_varying_first=vf)
+    full.set_constant_jacobian(False)
     sink = HostSink("hipnlp_test_sink_%d" % __import__("os").getpid(), full.n, full.m, full.nnz, world=2, rank=0)
-    xd = torch.from_numpy(x[0]).cuda()
+    xs = [x[0] + 1e-2 * i * np.random.RandomState(8).standard_normal(x.shape[1]) for i in range(3)]
+    xd = [torch.from_numpy(xi).cuda() for xi in xs]
     stream = torch.cuda.Stream()
     torch.cuda.synchronize()
+    shards = []
     for r in range(2):
         kb, ke = knot_range(N, 2, r)
-        sh = HipNlp(st, model, knot_begin=kb, knot_end=ke)
-        sh.set_params(p)
-        fp, gradp, gp, jacp = sink.pointers()
-        sh.eval_device(xd.data_ptr(), sink.dev + 8 * r, gradp, gp, jacp, stream=stream.cuda_stream)
-        stream.synchronize()
-    fparts, grad_h, jac_h, g_h = sink.views()
-    assert np.array_equal(grad_h, grad[0]) and np.array_equal(jac_h, jac[0]) and np.array_equal(g_h, g[0])
-    assert abs(sink.f() - f[0]) <= 1e-13 * max(1.0, abs(f[0]))
+        sh = HipNlp(st, model, knot_begin=kb, knot_end=ke, jac_varying_first=vf)
+        if order != "ccs":
+            sh.set_constant_jacobian(True)
+        shards.append(sh)
+    p2 = p.copy()
+    p2[:, 24 * N + 3 + 105 + 105] *= 1.25             # dt
+    fills = 0
+    for params in (p, p2):
+        full.set_params(params)
+        for sh in shards:
+            sh.set_params(params)
+        for i in range(3):
+            f, grad, g, jac = full.eval(xs[i][None, :])
+            fp, gradp, gp, jacp = sink.pointers()
+            for r, sh in enumerate(shards):
+                sh.eval_device(xd[i].data_ptr(), sink.dev + 8 * r, gradp, gp, jacp, stream=stream.cuda_stream)
+                stream.synchronize()
+            fparts, grad_h, jac_h, g_h = sink.views()
+            assert np.array_equal(grad_h, grad[0]) and np.array_equal(jac_h, jac[0]) and np.array_equal(g_h, g[0]), (order, i)
+            assert abs(sink.f() - f[0]) <= 1e-13 * max(1.0, abs(f[0]))
+        fills += 1
+        for sh in shards:
+            stats = sh.host_stats()
+            assert stats["constant_fills"] == (0 if order == "ccs" else fills) and stats["constant_slices_healed"] == 0, (order, stats)
     sink.close()
 
 

@@ -35,7 +35,7 @@ def _emulated_shard(emu, layout_rows, kb, ke, horizon, x_np, p_np):
     return grad[189 * kb:189 * kb + glen], jac[sel], stage
 
 
-def _worker(rank, world, port, horizon, result_q):
+def _worker(rank, world, port, horizon, result_q, compact=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "tests")):
@@ -54,22 +54,46 @@ def _worker(rank, world, port, horizon, result_q):
     model = synthetic_ergocub()
     st = periodic_step_settings(horizon, model)
     x, p = make_workload(st, model, 1, 31)
-    emu = HostEmu(st, model)
+    # compact: the exchange without the constants of jac g — handles in the varying-first order of a knot block (HIPNLP_FLAG_JAC_VARYING_FIRST),
+    # the shards hand over the varying runs, every rank's reassembled buffer holds the constants (filled once per parameter set)
+    emu = HostEmu(st, model, jac_varying_first=compact)
     rows_all = stage_rows_from_blocks(emu, horizon)
     kb, ke = knot_range(horizon, world, rank)
     ir, jc = emu.sparsity()
     col_knot = np.minimum(jc // 189, horizon - 1)
-    info = {"glen": 189 * (ke - kb) + (6 if ke == horizon else 0), "jlen": int(((col_knot >= kb) & (col_knot < ke)).sum()),
+    sel = (col_knot >= kb) & (col_knot < ke)
+    info = {"glen": 189 * (ke - kb) + (6 if ke == horizon else 0), "jlen": int(sel.sum()),
             "nk": ke - kb, "stage_rows": np.stack([rows_all[k] for k in range(kb, ke)])}
+    mask = emu.constant_mask()
+    params = {"p": p[0].copy()}
+    fills = []
+    kw = {}
+    if compact:
+        info["jvary"] = int((sel & ~mask).sum())
+
+        def const_fill(view, stream_handle):      # what hipnlp_fill_jac_constants does on the GPU: the constants under the parameters last set
+            const = emu.constant_fill(params["p"])
+            view[torch.from_numpy(mask)] = torch.from_numpy(const[mask])
+            fills.append(1)
+        kw = dict(const_mask=mask, const_fill=const_fill)
 
     def compute(xt, f_view, grad_view, jac_view, stage_view, stream_handle):
-        gs, js, stg = _emulated_shard(emu, rows_all, kb, ke, horizon, xt.numpy(), p[0])
+        gs, js, stg = _emulated_shard(emu, rows_all, kb, ke, horizon, xt.numpy(), params["p"])
+        if compact:
+            js = js[~mask[sel]]                   # the varying runs of the rank's knot blocks, behind one another
         f_view[0] = float(rank + 1)  # partial costs: checked as a sum below
         grad_view.copy_(torch.from_numpy(np.ascontiguousarray(gs)))
         jac_view.copy_(torch.from_numpy(np.ascontiguousarray(js)))
         stage_view.copy_(torch.from_numpy(stg.reshape(-1)))
 
-    cb = ShardedCallback(horizon, emu.n, emu.m, emu.nnz, info, compute, torch.device("cpu"))
+    cb = ShardedCallback(horizon, emu.n, emu.m, emu.nnz, info, compute, torch.device("cpu"), **kw)
+    if compact:
+        # what the all-gather moves: a third of the Jacobian less (0.43 of its entries are constants)
+        plain_len = 1 + max(189 * (ke_ - kb_) + (6 if ke_ == horizon else 0) for kb_, ke_ in (knot_range(horizon, world, r) for r in range(world))) \
+            + max(int(((col_knot >= kb_) & (col_knot < ke_)).sum()) for kb_, ke_ in (knot_range(horizon, world, r) for r in range(world))) \
+            + max(ke_ - kb_ for kb_, ke_ in (knot_range(horizon, world, r) for r in range(world))) * 550
+        assert cb.shard_len < plain_len and cb.bytes_sent_per_step() == 8 * cb.shard_len * (world - 1)
+        assert 0.35 < mask.mean() < 0.5 and len(fills) == 1
     f, grad, jac, g = cb(torch.from_numpy(x[0]))
     f_ref, grad_ref, g_ref, jac_ref, _ = emu.eval(x[0], p[0])
     ok = (np.array_equal(grad.numpy(), grad_ref) and np.array_equal(jac.numpy(), jac_ref) and np.array_equal(g.numpy(), g_ref)
@@ -83,18 +107,35 @@ def _worker(rank, world, port, horizon, result_q):
                      and float(f2) == sum(range(1, world + 1)) and not np.array_equal(g_ref2, g_ref))
     else:
         ok = ok and f2 is None and grad2 is None and jac2 is None and g2 is None
+    if compact:
+        # a set_params that changes dt: the constants (-dt/2 entries of the trapezoid defects) change with it — refreshed, then every entry
+        # of the reassembled Jacobian equals the emulation's under the NEW parameters (and differs from the old one at constant positions)
+        p_new = p[0].copy()
+        p_new[24 * horizon + 3 + 105 + 105] *= 1.3          # ParamOffsets::dt (layout.h)
+        params["p"] = p_new
+        cb.refresh_constants()
+        f3, grad3, jac3, g3 = cb(torch.from_numpy(x2))
+        _, grad_ref3, g_ref3, jac_ref3, _ = emu.eval(x2, p_new)
+        _, _, _, jac_old, _ = emu.eval(x2, p[0])
+        ok = ok and np.array_equal(jac3.numpy(), jac_ref3) and np.array_equal(g3.numpy(), g_ref3) and np.array_equal(grad3.numpy(), grad_ref3)
+        ok = ok and (jac_ref3[mask] != jac_old[mask]).any() and len(fills) == 2
+        f4, grad4, jac4, g4 = cb.to_root(torch.from_numpy(x[0]))
+        if rank == 0:
+            ok = ok and np.array_equal(jac4.numpy(), emu.eval(x[0], p_new)[3])
+        else:
+            ok = ok and jac4 is None
     result_q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("horizon", [7, 10])
-def test_sharded_reassembly_world2(horizon):
+@pytest.mark.parametrize("horizon,compact", [(7, False), (10, False), (7, True), (10, True)])
+def test_sharded_reassembly_world2(horizon, compact):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, horizon, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, horizon, q, compact)) for r in range(world)]
     for pr in procs:
         pr.start()
     results = [q.get(timeout=120) for _ in range(world)]
@@ -104,7 +145,7 @@ def test_sharded_reassembly_world2(horizon):
     assert sorted(results) == [(0, True), (1, True)]
 
 
-def _batch_worker(rank, world, port, batch, horizon, result_q):
+def _batch_worker(rank, world, port, batch, horizon, result_q, compact=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "tests")):
@@ -123,8 +164,12 @@ def _batch_worker(rank, world, port, batch, horizon, result_q):
     st = stairs_settings(horizon, model)
     x, p = make_workload(st, model, batch, 77)          # the same on every rank
     place_on_step_flanks(x, st, seed=77)
-    emu = HostEmu(st, model)
+    emu = HostEmu(st, model, jac_varying_first=compact)
     b0, b1 = batch_range(batch, world, rank)
+    mask = emu.constant_mask()
+    if compact:
+        p = p.copy()
+        p[:, 24 * horizon + 3 + 105 + 105] *= 1.0 + 0.1 * np.arange(batch)     # every trajectory its own dt: its own constants
 
     def compute(xl, f_view, grad_view, g_view, jac_view, stream_handle):
         for i in range(b1 - b0):
@@ -132,9 +177,14 @@ def _batch_worker(rank, world, port, batch, horizon, result_q):
             f_view[i] = float(f)
             grad_view[i].copy_(torch.from_numpy(grad))
             g_view[i].copy_(torch.from_numpy(g))
-            jac_view[i].copy_(torch.from_numpy(jac))
+            jac_view[i].copy_(torch.from_numpy(jac[~mask] if compact else jac))
 
-    bc = BatchDealtCallback(batch, emu.n, emu.m, emu.nnz, compute, torch.device("cpu"))
+    def const_fill(view, stream_handle):          # [local][nnz]: the constants of THIS rank's trajectories
+        for i in range(b1 - b0):
+            const = emu.constant_fill(p[b0 + i])
+            view[i][torch.from_numpy(mask)] = torch.from_numpy(const[mask])
+    kw = dict(const_mask=mask, const_fill=const_fill) if compact else {}
+    bc = BatchDealtCallback(batch, emu.n, emu.m, emu.nnz, compute, torch.device("cpu"), **kw)
     ok = (bc.b0, bc.b1) == (b0, b1)
     for shift in (0.0, 1e-3):     # two steps: the second overwrites the first
         got = bc.to_root(torch.from_numpy(x[b0:b1] + shift))
@@ -146,20 +196,24 @@ def _batch_worker(rank, world, port, batch, horizon, result_q):
                 ok = ok and float(f) == float(fr) and np.array_equal(grad.numpy(), gradr) and np.array_equal(g.numpy(), gr) and np.array_equal(jac.numpy(), jacr)
         else:
             ok = ok and got is None
-    ok = ok and bc.max_bytes_sent_per_step() == 8 * (b1 - b0) * (1 + emu.n + emu.m + emu.nnz) and bc.bytes_sent_per_step() == (0 if rank == 0 else bc.max_bytes_sent_per_step())
+    jw = int((~mask).sum()) if compact else emu.nnz
+    ok = ok and bc.max_bytes_sent_per_step() == 8 * (b1 - b0) * (1 + emu.n + emu.m + jw) and bc.bytes_sent_per_step() == (0 if rank == 0 else bc.max_bytes_sent_per_step())
+    ok = ok and (not compact or jw < 0.7 * emu.nnz)
     result_q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_batch_dealt_over_the_ranks_reaches_rank_zero_world2():
+@pytest.mark.parametrize("compact", [False, True])
+def test_batch_dealt_over_the_ranks_reaches_rank_zero_world2(compact):
     """BASELINE config 5's multi-GPU form in small: independent trajectories (batched initial guesses on the stairs) dealt over two
-    ranks, one collective to rank 0, every trajectory's outputs views of the gathered buffer — no reassembly"""
+    ranks, one collective to rank 0, every trajectory's outputs views of the gathered buffer — no reassembly.  compact: the gather moves
+    the varying entries of jac g only; rank 0's complete array holds every trajectory's constants (gathered once per parameter set)"""
     world, batch, horizon = 2, 4, 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_batch_worker, args=(r, world, port, batch, horizon, q)) for r in range(world)]
+    procs = [ctx.Process(target=_batch_worker, args=(r, world, port, batch, horizon, q, compact)) for r in range(world)]
     for pr in procs:
         pr.start()
     results = [q.get(timeout=120) for _ in range(world)]
