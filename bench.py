@@ -926,7 +926,7 @@ def main():
         compact = not args.exchange_every_entry
         eng = HipNlp(st, model, batch=1, knot_begin=kb, knot_end=ke, device=local_rank, jac_varying_first=compact)
         eng.set_params(p_np)
-        cb = ShardedCallback(hz, eng.n, eng.m, eng.nnz, hip_shard_info(eng, kb, ke), hip_shard_backend(eng, compact), device, **(hip_constants(eng) if compact else {}))
+        cb = ShardedCallback(hz, eng.n, eng.m, eng.nnz, hip_shard_info(eng, kb, ke, compact), hip_shard_backend(eng, compact), device, **(hip_constants(eng) if compact else {}))
         torch.cuda.synchronize()
         # the whole loop runs on the callback's own stream (shard evaluation, all-gather and reassembly are ordered on it; entering it
         # once here saves two cross-stream event waits per step)

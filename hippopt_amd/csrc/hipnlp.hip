@@ -50,6 +50,13 @@ constexpr int VCAP_MAX = 1536;
 // a launch into HOST memory stores those behind the second barrier — 42 % of a knot's bytes start over the link while the kinematic
 // phases still run — and leaves them out of the copy-out at the end.
 constexpr int32_t COPY_EARLY = 1 << 30, COPY_SLOT = COPY_EARLY - 1;
+// The g_b half of a gab_t word: bits 0..15 the row stride of the slot's constraint block (rows per knot), bits 16..25 the slot's POSITION
+// among the valid slots of its knot variant (a compact g staging — hipnlp_eval_device_shard_vary — lists the rows a knot owns behind one
+// another instead of at their 550 native slots), bit 30 COPY_EARLY.
+constexpr int32_t GB_STRIDE = 0xffff, GB_POS_SHIFT = 16, GB_POS = 0x3ff;
+static_assert(gs::COUNT <= GB_POS + 1, "position field of a g copy-out word");
+__host__ __device__ constexpr int gb_stride(int32_t w) { return w & GB_STRIDE; }
+__host__ __device__ constexpr int gb_pos(int32_t w) { return (w >> GB_POS_SHIFT) & GB_POS; }
 // A word of the Jacobian copy-out tables: native slot in bits 0..11; jpermv_t (VARY instantiations) also carries the entry's POSITION in
 // its knot block in bits 12..23 — the index of the varying run for a varying-first handle, the CCS position for a handle in CasADi's order,
 // whose varying entries are scattered over the block (device destinations only: scattered 8-byte stores belong in HBM, not on PCIe).
@@ -113,6 +120,10 @@ struct KArgs {
     // holds the constants between the varying runs) or, for a COMPACT destination (hipnlp_eval_device_vary / _shard_vary: what an exchange
     // between GPUs moves), the lengths of the varying runs alone (nvary_v: run behind run, no constants anywhere)
     int32_t jb_first, jb_interior;
+    // ... and, for a compact g staging (gsb_first > 0), the rows a first / an interior knot owns, the rows of one trajectory's staging and
+    // the rows owned by the knots in front of the handle's first one
+    int32_t gsb_first, gsb_interior;
+    int64_t gs_stride, gs_off;
     // peer mode (hipnlp_eval_device_peers; batch 1): instead of g / jac / grad / f above, the shard's values go — at their FINAL positions —
     // into the buffer [grad (n) | jac (nnz) | g (m) | f partials (npeer) | f] of every one of npeer ranks (this device's own among them)
     double* const* peer_out;   // [npeer] device-visible base addresses, or null
@@ -491,6 +502,10 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     unsigned long long st_task[24];   // diagnostic build: the time every task group of this wave ends, in program order
     int st_nt = 0;
 #define DEV_R(w4, w8, fn, nt) if constexpr ((WAVES == 4 ? (w4) : (w8)) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
+#elif defined(HIPNLP_TASK_MARKS)
+    // diagnostic compile (tools/diag/isa_tasks.sh: assembly only, never a library): comment markers around every task group, so that
+    // tools/diag/isa_mix.py can say which task group carries how many instructions of which kind
+#define DEV_R(w4, w8, fn, nt) if constexpr ((WAVES == 4 ? (w4) : (w8)) == W) { asm volatile("; TASK_BEGIN " #fn); for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); asm volatile("; TASK_END " #fn); }
 #else
 #define DEV_R(w4, w8, fn, nt) if constexpr ((WAVES == 4 ? (w4) : (w8)) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #endif
@@ -521,7 +536,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         if (a.g) {
             double* out = a.g + size_t(b) * a.m;
 #pragma unroll
-            for (int it = 0; it < G_ITERS; ++it) if (ga[it] != G_NONE && (gb[it] & COPY_EARLY)) store_unwaited(out, (ga[it] + (gb[it] & COPY_SLOT) * k) * 8, s.g_at(tid + it * WG));
+            for (int it = 0; it < G_ITERS; ++it) if (ga[it] != G_NONE && (gb[it] & COPY_EARLY)) store_unwaited(out, (ga[it] + gb_stride(gb[it]) * k) * 8, s.g_at(tid + it * WG));
         }
     };
 #ifdef HIPNLP_STAMPS
@@ -610,7 +625,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             if constexpr (!VARY) { if (last && tid < n_glob) base[o_jac + int64_t(jac_glob_base) + tid] = s.jac[jpg]; }
             double* og = base + o_g;
 #pragma unroll
-            for (int it = 0; it < G_ITERS; ++it) if (ga[it] != G_NONE) og[ga[it] + (gb[it] & COPY_SLOT) * k] = gvals[it];
+            for (int it = 0; it < G_ITERS; ++it) if (ga[it] != G_NONE) og[ga[it] + gb_stride(gb[it]) * k] = gvals[it];
             double* ogr = base + int64_t(NXK) * k;
 #pragma unroll
             for (int it = 0; it < GR_ITERS; ++it) { const int i = tid + it * WG; if (i < NXK) ogr[i] = grvals[it]; }
@@ -627,14 +642,22 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     if (a.g) {
         double* out = a.g + size_t(b) * a.m;
 #pragma unroll
-        for (int it = 0; it < G_ITERS; ++it) if (ga[it] != G_NONE && !(early_on && (gb[it] & COPY_EARLY))) out[ga[it] + (gb[it] & COPY_SLOT) * k] = gvals[it];
+        for (int it = 0; it < G_ITERS; ++it) if (ga[it] != G_NONE && !(early_on && (gb[it] & COPY_EARLY))) out[ga[it] + gb_stride(gb[it]) * k] = gvals[it];
     }
     if (a.g_stage) {
-        double* out = a.g_stage + (size_t(b) * a.nk + kk) * gs::COUNT;
+        bool dense = false;
+        if constexpr (VARY) dense = a.gsb_first > 0;
+        if (dense) {   // compact staging: the rows this knot owns behind one another, knot behind knot (no zeros for the slots it does not own)
+            double* out = a.g_stage + int64_t(b) * a.gs_stride + ((first ? 0 : int64_t(a.gsb_first) + int64_t(k - 1) * a.gsb_interior) - a.gs_off);
 #pragma unroll
-        for (int it = 0; it < G_ITERS; ++it) {
-            const int slot = tid + it * WG;
-            if (slot < gs::COUNT) out[slot] = ga[it] != G_NONE ? gvals[it] : 0.0;
+            for (int it = 0; it < G_ITERS; ++it) if (ga[it] != G_NONE) out[gb_pos(gb[it])] = gvals[it];
+        } else {
+            double* out = a.g_stage + (size_t(b) * a.nk + kk) * gs::COUNT;
+#pragma unroll
+            for (int it = 0; it < G_ITERS; ++it) {
+                const int slot = tid + it * WG;
+                if (slot < gs::COUNT) out[slot] = ga[it] != G_NONE ? gvals[it] : 0.0;
+            }
         }
     }
     if (a.grad) {
@@ -1102,6 +1125,8 @@ struct hipnlp_handle {
     // the entries that depend on x only (d_tb_vary: the same tables with -1 at the constant positions of the copy-out permutation):
     // a third fewer bytes on the PCIe-bound path, one contiguous run per knot.  Caller arrays are spot-checked before every such
     // launch (csample) and re-filled when a check fails or the parameters changed.
+    int gs_rows_v[3] = {0, 0, 0};                   // rows of g a first / interior / last knot owns (valid staging slots)
+    bool gs_compact_ok = true;
     bool vary_ok = false;                           // the varying entries of every block fit the VARY instantiations' trip counts (either order of a block)
     bool vary_check = true;                         // the VARY kernels look at the constants they find in a device destination (HIPNLP_VARY_CHECK=0: diagnostic)
     double* d_ctpl = nullptr;                       // device copy of the templates [ctpl.size()][ctpl_len] (the VARY kernels' self-healing check, the fill kernel)
@@ -1318,6 +1343,15 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     for (int s = 0; s < gs::COUNT; ++s) tb->g_b[s] = h->L.g_b[size_t(s)];
     {
         const int wg = h->wide ? 512 : 256, jt = JS_PAD / wg, gt = GS_PAD / wg;
+        // position of a slot among the slots a knot of variant v owns (slot order)
+        std::vector<int32_t> gpos[3];
+        for (int v = 0; v < 3; ++v) {
+            gpos[v].assign(GS_PAD, 0);
+            int at = 0;
+            for (int sl = 0; sl < gs::COUNT; ++sl) if (tb->g_a[v][sl] != G_NONE) gpos[v][size_t(sl)] = at++;
+            h->gs_rows_v[v] = at;
+            for (int sl = 0; sl < gs::COUNT; ++sl) if (tb->g_b[sl] & ~GB_STRIDE) h->gs_compact_ok = false;   // (a row stride beyond the field: never)
+        }
         for (int v = 0; v < 3; ++v)
             for (int t = 0; t < wg; ++t) {
                 for (int it = 0; it < jt; ++it) {
@@ -1327,7 +1361,7 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
                 for (int it = 0; it < gt; ++it) {
                     const int gslot = t + it * wg;
                     tb->gab_t[v][2 * (t * gt + it)] = tb->g_a[v][gslot];
-                    tb->gab_t[v][2 * (t * gt + it) + 1] = tb->g_b[gslot];   // (the rows of g stay with the copy-out at the end: their runs are 24 - 192 B, and written through the L2 one by one they cost more link time than the early start saves — measured: g alone 11.9 -> 21 us)
+                    tb->gab_t[v][2 * (t * gt + it) + 1] = tb->g_b[gslot] | (gpos[v][gslot] << GB_POS_SHIFT);   // (the rows of g stay with the copy-out at the end: their runs are 24 - 192 B, and written through the L2 one by one they cost more link time than the early start saves — measured: g alone 11.9 -> 21 us)
                 }
             }
     }
@@ -1573,6 +1607,14 @@ static int64_t vary_base(const Layout& L, int k) {
     if (k >= L.N) at += L.nvary_v[VAR_LAST];
     return at;
 }
+// rows of g owned by the knots [0, k): where knot k's rows start in a compact staging
+static int64_t gs_base(const hipnlp_handle* h, int k) {
+    const int N = h->L.N;
+    if (k <= 0) return 0;
+    int64_t at = h->gs_rows_v[VAR_FIRST] + int64_t(std::min(k, N - 1) - 1) * h->gs_rows_v[VAR_INTERIOR];
+    if (k >= N) at += h->gs_rows_v[VAR_LAST];
+    return at;
+}
 static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, hipStream_t s,
                   double* g_stage = nullptr, bool shard_local = false, bool always_timed = false, bool host_block = false,
                   double* const* peer_out = nullptr, int npeer = 0, int peer_rank = 0, bool vary_only = false, bool compact = false, bool no_check = false) {
@@ -1598,6 +1640,11 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     a.g = g_dev; a.jac = jac_dev; a.grad = grad_dev; a.g_stage = g_stage;
     a.jb_first = compact ? h->L.nvary_v[VAR_FIRST] : h->L.nnz_v[VAR_FIRST];
     a.jb_interior = compact ? h->L.nvary_v[VAR_INTERIOR] : h->L.nnz_v[VAR_INTERIOR];
+    a.gsb_first = a.gsb_interior = 0; a.gs_stride = a.gs_off = 0;
+    if (compact && g_stage && h->gs_compact_ok) {   // the rows of g in a compact staging: as many per knot as the knot owns
+        a.gsb_first = h->gs_rows_v[VAR_FIRST]; a.gsb_interior = h->gs_rows_v[VAR_INTERIOR];
+        a.gs_off = gs_base(h, h->kb); a.gs_stride = gs_base(h, h->ke) - a.gs_off;
+    }
     if (shard_local) {
         hipnlp_dims dd;
         hipnlp_get_dims(h, &dd);
@@ -1969,6 +2016,7 @@ int hipnlp_eval_device_shard_vary(hipnlp_handle* h, const double* x_dev, double*
     if (!h || !x_dev) return HIPNLP_E_INVALID;
     const int rc = vary_ready(h, "hipnlp_eval_device_shard_vary");
     if (rc != HIPNLP_OK) return rc;
+    if (g_stage && !h->gs_compact_ok) { h->err = "hipnlp_eval_device_shard_vary: a row stride of this layout does not fit the copy-out word"; return HIPNLP_E_UNSUPPORTED; }
     HIP_TRY(h, hipSetDevice(h->dev));
     h->have_result = false;
     return launch(h, x_dev, f_dev ? f_dev : h->d_f, grad_shard, nullptr, jac_vary_shard, stream ? hipStream_t(stream) : h->stream, g_stage, true, false, false, nullptr, 0, 0, true, true);

@@ -234,10 +234,15 @@ class _CallbackCache:
 class HipNlpSolver(OptimizationSolver):
     def __init__(self, settings, model, device=0, inner_solver="auto", options_solver=None, problem="kinodynamic",
                  callback_criterion: CallbackCriterion = None, callback_save_costs=True, callback_save_constraint_multipliers=True,
-                 error_on_fail=True, detect_simple_bounds=True):
+                 error_on_fail=True, detect_simple_bounds=True, jac_varying_first=True):
         """callback_* as in OptiSolver (opti_solver.py:105-131).  error_on_fail: CasADi's Opti raises when IPOPT does not report
         success (e.g. Maximum_Iterations_Exceeded), which is what triggers the best-iterate fallback of opti_solver.py:479-520;
-        False keeps the last iterate of an unconverged run instead (useful for smoke runs with a few iterations)."""
+        False keeps the last iterate of an unconverged run instead (useful for smoke runs with a few iterations).
+        jac_varying_first: the order in which the engine hands jac g to the NLP driver as triplets — True (default): the varying
+        entries of a knot block first (the host path then moves them alone); False: CasADi's CCS order, what the reference's nlpsol
+        hands IPOPT (opti_solver.py:479).  The drivers build their matrix from the triplets, so the order cannot change a solve:
+        tests/test_gpu_solver_order.py runs the planners through both and compares every iterate.
+        iterate_trace (attribute): set to a list to have (iteration, x, cost, primal infeasibility) of every iterate appended."""
         self._callback_criterion = callback_criterion
         self._callback_save_costs = callback_save_costs
         self._callback_save_constraint_multipliers = callback_save_constraint_multipliers
@@ -245,6 +250,8 @@ class HipNlpSolver(OptimizationSolver):
         self._error_on_fail = error_on_fail
         # casadi_opti_options["detect_simple_bounds"] of the reference scripts (main_periodic_step.py:110): kinodynamic problem only
         self._detect_simple_bounds = bool(detect_simple_bounds) and problem == "kinodynamic"
+        self._jac_varying_first = bool(jac_varying_first)
+        self.iterate_trace = None
         if problem not in ("kinodynamic", "pose"):
             raise ValueError("problem must be 'kinodynamic' or 'pose'")
         self._problem_kind = problem
@@ -361,7 +368,7 @@ class HipNlpSolver(OptimizationSolver):
                 # (the NLP drivers take jac g as triplets — IPOPT's jacobianstructure / a COO matrix: inside a knot's block the entries
                 #  that depend on x come first, so the host path stores ONE contiguous run per knot and leaves the constant ones alone)
                 self._engine = HipNlp(self._settings, self._model, batch=1, device=self._device, detect_simple_bounds=self._detect_simple_bounds,
-                                      jac_varying_first=True)
+                                      jac_varying_first=self._jac_varying_first)
         return self._engine
 
     def get_constraint_expressions(self):
@@ -474,6 +481,8 @@ class HipNlpSolver(OptimizationSolver):
         self._values = values
 
     def _iterate_callback(self, iteration, x, cost, inf_pr, multipliers, lam_x=None):
+        if self.iterate_trace is not None:
+            self.iterate_trace.append((int(iteration), np.array(x, dtype=float, copy=True), float(cost), float(inf_pr)))
         if self._callback is not None:
             if multipliers is not None and self._lift is not None and getattr(self.engine(), "lifted", False):
                 multipliers = self._lift.full_multipliers(multipliers, lam_x)

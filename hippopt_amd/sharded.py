@@ -82,10 +82,13 @@ class ShardedCallback:
         self.glen_max = max(i["glen"] for i in infos)
         self.jlen_max = max(i[jkey] for i in infos)
         self.nk_max = max(i["nk"] for i in infos)
+        # staging of g: G_STAGE native slots per knot (stage_rows: -1 where a knot owns no row) — or, "slen" given, the rows a rank's knots
+        # own behind one another (a compact exchange: stage_rows then lists them, all >= 0)
+        self.slen_max = max(i.get("slen", i["nk"] * G_STAGE) for i in infos)
         self.o_grad = 1
         self.o_jac = 1 + self.glen_max
         self.o_stage = self.o_jac + self.jlen_max
-        self.shard_len = self.o_stage + self.nk_max * G_STAGE
+        self.shard_len = self.o_stage + self.slen_max
         self.buf = torch.zeros(self.shard_len, dtype=torch.float64, device=device)
         self.all = torch.zeros(self.world * self.shard_len, dtype=torch.float64, device=device)
         me = infos[self.rank]
@@ -93,7 +96,7 @@ class ShardedCallback:
             self.buf[0:1],
             self.buf[self.o_grad:self.o_grad + me["glen"]],
             self.buf[self.o_jac:self.o_jac + me[jkey]],
-            self.buf[self.o_stage:self.o_stage + me["nk"] * G_STAGE],
+            self.buf[self.o_stage:self.o_stage + me.get("slen", me["nk"] * G_STAGE)],
         )
         # index of every entry of [grad | jac | g] inside the gathered buffer; every slot is written exactly once
         src = np.full(n + nnz + m, -1, dtype=np.int64)
@@ -864,12 +867,19 @@ def hip_shard_backend(engine, compact=False):
     return compute
 
 
-def hip_shard_info(engine, knot_begin, knot_end):
+def hip_shard_info(engine, knot_begin, knot_end, compact=False):
+    """shard_info of ShardedCallback for a HIP engine handle.  compact (a varying-first handle): the record of a compact exchange — what
+    hipnlp_eval_device_shard_vary fills: the varying runs of jac g ("jvary") and a staging of g that lists the rows the rank's knots own
+    behind one another ("slen" rows, all of stage_rows >= 0) instead of G_STAGE native slots per knot"""
     d = engine.dims
     rows = np.stack([engine.stage_rows(k) for k in range(knot_begin, knot_end)])
     info = {"glen": int(d.shard_grad), "jlen": int(d.shard_nnz), "nk": knot_end - knot_begin, "stage_rows": rows}
-    if getattr(engine, "jac_varying_first", False):
+    if compact:
         info["jvary"] = engine.jac_vary_layout()["shard_len"]
+        info["stage_rows"] = rows[rows >= 0]          # (row-major: knot behind knot, slot order inside a knot)
+        info["slen"] = int(d.shard_g_rows)
+        if info["stage_rows"].size != info["slen"]:
+            raise RuntimeError("staging rows of the shard: %d, hipnlp_get_dims says %d" % (info["stage_rows"].size, info["slen"]))
     return info
 
 

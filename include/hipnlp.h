@@ -461,7 +461,10 @@ int hipnlp_eval_device_peers(hipnlp_handle* h, const double* x_dev, double* cons
  *                                  knot and the horizon-global columns (a shard handle knows the whole pattern: the reassembled buffer
  *                                  of a rank is filled by that rank).  Again after every hipnlp_set_params that changes dt or the mass.
  *   hipnlp_eval_device_vary        hipnlp_eval_device with a compact jac destination: jac_vary_dev [batch][out[3]]
- *   hipnlp_eval_device_shard_vary  hipnlp_eval_device_shard with a compact jac shard: jac_vary_shard [batch][out[5]]
+ *   hipnlp_eval_device_shard_vary  hipnlp_eval_device_shard with a compact jac shard: jac_vary_shard [batch][out[5]] — and a compact
+ *                                  staging of g: g_stage [batch][shard_g_rows] lists, knot behind knot, the rows each knot owns in the
+ *                                  order of its staging slots (the entries >= 0 of hipnlp_stage_rows(k), in slot order), instead of
+ *                                  HIPNLP_G_STAGE slots per knot of which half are unused
  *   hipnlp_eval_device_peers_vary  hipnlp_eval_device_peers storing the varying runs only, at their places in the pattern, into buffers
  *                                  whose jac part holds the constants (hipnlp_fill_jac_constants(..., whole_horizon = 1) on the buffer's
  *                                  owner)

@@ -532,12 +532,13 @@ def test_sharded_callback_reassembly_on_gpu(model, HipNlp, lifted, compact):
     sh = HipNlp(st, model, knot_begin=0, knot_end=N, detect_simple_bounds=lifted, jac_varying_first=compact)
     sh.set_params(p)
     assert (sh.m < sh.m_full) == lifted
-    info = hip_shard_info(sh, 0, N)
+    info = hip_shard_info(sh, 0, N, compact)
     cb = ShardedCallback(N, sh.n, sh.m, sh.nnz, info, hip_shard_backend(sh, compact), dev, **(hip_constants(sh) if compact else {}))
     if compact:
         lay = sh.jac_vary_layout()
         assert info["jvary"] == lay["shard_len"] == lay["total"] == int((~sh.jac_constant_mask()).sum()) and lay["shard_off"] == 0
-        assert cb.shard_len == 1 + info["glen"] + info["jvary"] + N * 550 and info["jvary"] < 0.62 * info["jlen"]
+        assert cb.shard_len == 1 + info["glen"] + info["jvary"] + info["slen"] and info["jvary"] < 0.62 * info["jlen"] and info["slen"] == sh.m + 0 * N
+        assert (info["stage_rows"] >= 0).all() and np.array_equal(np.sort(info["stage_rows"]), np.arange(sh.m))   # every row of g once, no padding
     rng = np.random.RandomState(4)
     xs = [x[0] + 1e-2 * i * rng.standard_normal(x.shape[1]) for i in range(6)]
     xds = [torch.from_numpy(xi).to(dev) for xi in xs]
@@ -668,7 +669,7 @@ def test_peer_exchange_equals_the_gathered_callback(model, HipNlp, compact):
     dev = torch.device("cuda", 0)
     sh = HipNlp(st, model, knot_begin=0, knot_end=N, jac_varying_first=compact)
     sh.set_params(p)
-    cb = ShardedCallback(N, sh.n, sh.m, sh.nnz, hip_shard_info(sh, 0, N), hip_shard_backend(sh, compact), dev, **(hip_constants(sh) if compact else {}))
+    cb = ShardedCallback(N, sh.n, sh.m, sh.nnz, hip_shard_info(sh, 0, N, compact), hip_shard_backend(sh, compact), dev, **(hip_constants(sh) if compact else {}))
     rng = np.random.RandomState(5)
     xs = [x[0] + 1e-2 * i * rng.standard_normal(x.shape[1]) for i in range(5)]
     # push kernel behind the shard evaluation / stores folded into the evaluation (hipnlp_eval_device_peers); every rank receives /

@@ -172,3 +172,51 @@ def test_ipopt_protocol_replayed_in_c_matches_the_oracle(model, tmp_path, maker,
             assert err < TOL, where
     # the protocol was really walked: accepted points asked for everything, rejected trial points for f and g only
     assert seen["f"] == points and seen["g"] == points and seen["grad"] == seen["jac"] and 0 < seen["grad"] < points and seen["hess"] >= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("maker,horizon,lifted,attach", [(single_step_settings, 30, True, 1), (periodic_step_settings, 10, True, 2), (periodic_step_settings, 100, False, 1)])
+def test_both_triplet_orders_hand_ipopt_the_same_matrix(model, tmp_path, maker, horizon, lifted, attach):
+    """north_star asks for the reference's iterate sequence; the reference hands IPOPT CasADi's CCS triplet order (base/opti_solver.py:479 ->
+    nlpsol), HipNlpSolver and the C binding of INTEGRATION.md create varying-first handles.  IPOPT reads jac g as a SET of triplets
+    (it builds its own matrix from iRow / jCol once and copies values by position ever after): the same protocol replayed in C through
+    both orders must deliver, at every point, bit for bit the same {(iRow, jCol): value} and the same f, grad f, g and Hessian values —
+    then no solver behind the callbacks can tell the orders apart.  (What is NOT verified here: IPOPT / MUMPS themselves — absent.)"""
+    st = maker(horizon, model)
+    x, p = make_workload(st, model, batch=1, seed=5100 + horizon)
+    rng = np.random.RandomState(4)
+    points = 6
+    xs = np.stack([x[0] + 1e-3 * i * rng.standard_normal(x[0].shape) for i in range(points)])
+    recs = {}
+    m_red = None
+    for vary_first in (False, True):
+        desc = _abi.DescC()
+        desc.settings, desc.model, desc.batch = st.to_c(), model.to_c(), 1
+        desc.flags = (_abi.FLAG_DETECT_SIMPLE_BOUNDS if lifted else 0) | (_abi.FLAG_JAC_VARYING_FIRST if vary_first else 0)
+        if m_red is None:
+            eng = hipnlp.HipNlp(st, model, detect_simple_bounds=lifted)
+            m_red = eng.m
+            eng.close()
+            lam = rng.standard_normal(m_red)
+        src, dst = str(tmp_path / ("in%d.bin" % vary_first)), str(tmp_path / ("out%d.bin" % vary_first))
+        write_input(src, desc, p[0], xs, lam, 0.8, attach)
+        res = subprocess.run([build_harness(), src, dst, "20"], capture_output=True, text=True, timeout=240)
+        assert res.returncode == 0, res.stderr
+        recs[vary_first] = read_records(dst)
+    a, b = recs[False], recs[True]
+    assert [(k, pt, ok) for k, pt, ok, _ in a] == [(k, pt, ok) for k, pt, ok, _ in b]       # the same walk through the protocol
+    rc = {}
+    for order, rs in recs.items():
+        for kind, point, ok, v in rs:
+            if kind == "jac_structure":
+                rc[order] = list(zip(v[:v.size // 2].astype(int).tolist(), v[v.size // 2:].astype(int).tolist()))
+    assert rc[False] != rc[True] and sorted(rc[False]) == sorted(rc[True]) and rc[False] == sorted(rc[False], key=lambda t: (t[1], t[0]))   # CCS = column major
+    compared = 0
+    for (kind, point, ok, va), (_, _, _, vb) in zip(a, b):
+        if kind == "jac":
+            da, db = dict(zip(rc[False], va.view(np.int64).tolist())), dict(zip(rc[True], vb.view(np.int64).tolist()))
+            assert da == db, (point, sum(1 for k in da if da[k] != db[k]))
+            compared += 1
+        elif kind in ("f", "grad", "g", "hess", "bounds", "hess_structure"):
+            assert np.array_equal(va.view(np.int64), vb.view(np.int64)), (kind, point)
+    assert compared >= 2

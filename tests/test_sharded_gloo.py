@@ -70,6 +70,8 @@ def _worker(rank, world, port, horizon, result_q, compact=False):
     kw = {}
     if compact:
         info["jvary"] = int((sel & ~mask).sum())
+        info["stage_rows"] = info["stage_rows"][info["stage_rows"] >= 0]     # the staging of g lists the owned rows only
+        info["slen"] = int(info["stage_rows"].size)
 
         def const_fill(view, stream_handle):      # what hipnlp_fill_jac_constants does on the GPU: the constants under the parameters last set
             const = emu.constant_fill(params["p"])
@@ -81,6 +83,7 @@ def _worker(rank, world, port, horizon, result_q, compact=False):
         gs, js, stg = _emulated_shard(emu, rows_all, kb, ke, horizon, xt.numpy(), params["p"])
         if compact:
             js = js[~mask[sel]]                   # the varying runs of the rank's knot blocks, behind one another
+            stg = stg[np.stack([rows_all[k] for k in range(kb, ke)]) >= 0]
         f_view[0] = float(rank + 1)  # partial costs: checked as a sum below
         grad_view.copy_(torch.from_numpy(np.ascontiguousarray(gs)))
         jac_view.copy_(torch.from_numpy(np.ascontiguousarray(js)))
