@@ -43,7 +43,11 @@
 // dependent round trips of ~130 cycles for an eight-term sum).  Only where a sum of LDS values is long: staging the operands of
 // ordinary tasks this way measured slower.
 #define HIPNLP_ISSUE_FENCE() __builtin_amdgcn_sched_barrier(0)
+// An integer the compiler must take as it is (no instruction): behind it, `x ^ literal` stays ONE xor — left to itself the compiler splits
+// a word it knows to be (a << 7) | (b << 4) into its parts again and pays two or three operations per derived address.
+#define HIPNLP_OPAQUE(x) asm volatile("" : "+v"(x))
 #else
+#define HIPNLP_OPAQUE(x) ((void)0)
 #define HIPNLP_ISSUE_FENCE() ((void)0)
 #define HIPNLP_WAVE_SYNC() ((void)0)
 #define HIPNLP_UNIFORM(x) (x)
@@ -58,13 +62,16 @@ namespace hipnlp {
 constexpr int LSTR = 17;
 struct EndTerms { double c[105 + 84], g[105 + 84]; };  // minimize-mode end rows: cost partial and gradient share of row i
 
-// Joint record: 16 doubles [ L (9) | of (3) | c (3) | sd ] in eight 16-byte chunks.  The FK lanes read the SAME chunk of DIFFERENT
-// records in one instruction; at the natural 128-byte stride those all sit in the same four LDS banks.  Chunk q of record i is
-// therefore stored at position q ^ (i & 7): eight consecutive records put any given chunk in eight different bank groups.
-struct alignas(16) JointRec { double d[16]; };
-static_assert(sizeof(JointRec) == 128, "joint record");
+// Joint record: 16 doubles [ L (9) | of (3) | c (3) | sd ] in eight 16-byte chunks, at a stride of 144 bytes.  The FK lanes read the SAME
+// chunk of DIFFERENT records in one instruction (ds_read_b128: sixteen lanes share the 256-byte bank row); at the natural 128-byte stride
+// those all sit in the same four banks.  At nine 16-byte slots per record, chunk q of record i lies in slot (9 i + q) mod 16: records
+// whose numbers differ by less than sixteen never meet.  (Rounds 1 - 4 kept the 128-byte stride and stored chunk q at position q ^ (i & 7):
+// the same freedom from conflicts, but every chunk address was an xor of a per-lane word — twelve integer instructions per ancestor step
+// of the forward kinematics where a multiply and eight immediate offsets do, round 5: -170 VALU instructions per knot.)
+struct alignas(16) JointRec { double d[18]; };
+static_assert(sizeof(JointRec) == 144, "joint record");
 enum : int { JR_L = 0, JR_OF = 9, JR_C = 12, JR_SD = 15 };
-HD constexpr int jr_pos(int i, int e) { return ((((e >> 1) ^ (i & 7)) << 1) | (e & 1)); }   // physical position of logical double e of record i
+HD constexpr int jr_pos(int, int e) { return e; }   // physical position of logical double e of record i
 
 // Two layouts of the scratch (LAYOUT_*):
 //   KnotScratchT<LAYOUT_FULL>     every array has its own storage (host recorders / emulation, eight-wave and pose / Hessian kernels)
@@ -99,7 +106,8 @@ template <> struct ScratchJrOwn<true> {
     };
     double g[gs::FIN];   // slots >= gs::FIN (horizon-end rows) are ends.c[slot - gs::FIN]
 };
-static_assert(sizeof(JointRec) * NJ <= sizeof(double) * LSTR * NL, "own[NL] (zero slot, written while Jr is live) must lie behind the joint records it shares storage with");
+// (compact layout: own[] lies ON the joint records, its zero slot own[NL] on the last two of them — written with the rest of own[], by
+//  t_links in the third phase, when the forward kinematics has read the records)
 
 // periodicity variables of the other end of the horizon, by periodicity row (only loaded at k = 0 and k = N-1): not in a trimmed scratch
 template <bool HAS> struct ScratchXo { double xo[NPER]; };
@@ -145,7 +153,7 @@ template <int LAYOUT, int JSLOTS = js::COUNT> struct alignas(16) KnotScratchT : 
     double pkin[NC][3];
     double chest_w[3], chest_dc;  // ax(R_c R_d^T);  d cost / d trace
     double cen_g[3];              // d centroid cost / d p_c,i (same for the 8 points)
-    double yaw_sc[2][4], yaw_e[2][2];  // per foot: sin/cos of yaw and of yaw+pi/2; alignment errors (forward, sideways)
+    double yaw_e[2][2];  // per foot: alignment errors (forward, sideways); (the sin / cos of the yaw references are read where they are: pk[PK_YAWSC ..])
     // cost partials, reduced by t_reduce
     double c_pt[NC][3], c_joint[NJ], c_force[2][3], c_yaw[2];
     double cost[NCT];
@@ -197,23 +205,23 @@ template <class Em> struct Ctx {
 // ---- tables that are read once per knot, from the full tables (gkt: the LDS copy in the full layout, global memory in the compact one)
 // joint frames of joint j: phase A only
 template <class Em> HD const double* kin_R_fix(const Ctx<Em>& cx, int j) {
-    return cx.gkt->jf.R_fix[j];
+    return cx.gkt->jf.j[j].R_fix;
 }
 template <class Em> HD const double* kin_o_fix(const Ctx<Em>& cx, int j) {
-    return cx.gkt->jf.o_fix[j];
+    return cx.gkt->jf.j[j].o_fix;
 }
 template <class Em> HD const double* kin_axis(const Ctx<Em>& cx, int j) {
-    return cx.gkt->jf.axis[j];
+    return cx.gkt->jf.j[j].axis;
 }
 // link inertials of link i: phase C only
 template <class Em> HD double kin_mass(const Ctx<Em>& cx, int i) {
-    return cx.gkt->li.mass[i];
+    return cx.gkt->li.l[i].mass;
 }
 template <class Em> HD const double* kin_com(const Ctx<Em>& cx, int i) {
-    return cx.gkt->li.com[i];
+    return cx.gkt->li.l[i].com;
 }
 template <class Em> HD const double* kin_inertia(const Ctx<Em>& cx, int i) {
-    return cx.gkt->li.inertia[i];
+    return cx.gkt->li.l[i].inertia;
 }
 // g rows of the horizon ends (native slots >= gs::FIN): compact layout -> ends.c (see KnotScratchT)
 template <class Em> HD void emit_g_end(Ctx<Em>& cx, int slot, int id, double v) {
@@ -461,12 +469,14 @@ template <class Em> HD void t_points_vec(Ctx<Em>& cx, int t) {
     gr[FD_ + i] = 2.0 * on * cx.st.m_fdreg * x[FD_ + i];
     gr[F_ + i] = 0.0;
     // contribution of this point to hdot at k-1 and k   (E1): component i of f and of (p - com) x f
+    // (the two components of p - com the lane needs, read at its own indices: a three-entry register array indexed by the lane's
+    //  component is eight selects per product)
+    const int i1 = i == 2 ? 0 : i + 1, i2 = i == 0 ? 2 : i - 1;
     for (int w = 0; w < 2; ++w) {
         const double* xx = w ? s.x : s.xm;
-        double r[3];
-        for (int q = 0; q < 3; ++q) r[q] = xx[cb + P_ + q] - xx[COM_ + q];
+        const double r1 = xx[cb + P_ + i1] - xx[COM_ + i1], r2 = xx[cb + P_ + i2] - xx[COM_ + i2];
         hd_of(s)[(w * NC + c) * 6 + i] = xx[cb + F_ + i];
-        hd_of(s)[(w * NC + c) * 6 + 3 + i] = cross_comp(r, xx + cb + F_, i);
+        hd_of(s)[(w * NC + c) * 6 + 3 + i] = r1 * xx[cb + F_ + i2] - r2 * xx[cb + F_ + i1];   // component i of (p - com) x f
     }
 }
 
@@ -739,7 +749,7 @@ template <class Em> HD void t_points_cost(Ctx<Em>& cx, int t) {
 
 // identity / zero padding slots of the ancestor and descendant lists, lanes e < 16
 template <class S> HD void scratch_padding(S& s, int e) {
-    if (e < 16) s.own[NL][e] = 0.0;
+    // (the zero slot own[NL] of the descendant lists: t_links — in the compact layouts it lies on joint records that are live here)
     if (e < 16) s.Jr[NJ].d[jr_pos(NJ, e)] = (e < 9 && e % 4 == 0) ? 1.0 : 0.0;   // L = I, of = c = 0, sd = 0
     if (e < 3) { s.aw[NJ][e] = 0.0; s.Uj[NJ][e] = 0.0; }
 }
@@ -748,17 +758,26 @@ template <class S> HD void scratch_padding(S& s, int e) {
 template <class Em> HD void t_dyn(Ctx<Em>& cx, int e) {
     auto& s = cx.s;
     const double half = 0.5 * cx.gp.dt;
-    int X, Y, L, i, kin, gslot, gx0, jslot;
-    if (e < 3) { i = e; L = 3; X = PB_ + i; Y = VB_ + i; kin = RK_PBDYN_IN; gslot = gs::PBDYN; gx0 = gs::PB_X0; jslot = js::PBDYN; }
-    else if (e < 7) { i = e - 3; L = 4; X = QB_ + i; Y = QD_ + i; kin = RK_QBDYN_IN; gslot = gs::QBDYN; gx0 = gs::QB_X0; jslot = js::QBDYN; }
-    else if (e < 7 + NJ) { i = e - 7; L = NJ; X = S_ + i; Y = SD_ + i; kin = RK_SDYN_IN; gslot = gs::SDYN; gx0 = gs::S_X0; jslot = js::SDYN; }
-    else { i = e - 7 - NJ; L = 3; X = COM_ + i; Y = H_ + i; kin = RK_COMDYN_IN; gslot = gs::COMDYN; gx0 = gs::COM_X0; jslot = js::COMDYN; }
+    int L, i, kin, jslot;
+    if (e < 3) { i = e; L = 3; kin = RK_PBDYN_IN; jslot = js::PBDYN; }
+    else if (e < 7) { i = e - 3; L = 4; kin = RK_QBDYN_IN; jslot = js::QBDYN; }
+    else if (e < 7 + NJ) { i = e - 7; L = NJ; kin = RK_SDYN_IN; jslot = js::SDYN; }
+    else { i = e - 7 - NJ; L = 3; kin = RK_COMDYN_IN; jslot = js::COMDYN; }
     const int kout = kin + 1, kx0 = kin + 2;
+    // The four state blocks are neighbours in the knot record and in the native g slots: the variable, its rate and the two g slots of lane
+    // e are e plus a constant (two for the variable, three for the rate) — what the VARY kernels, whose constant entries are gone, have left
+    // of this task is four reads, three operations and two stores, and the chain above (kept for the row ids and the constant entries' slots)
+    // was a dozen selects in front of them.
+    static_assert(QB_ == PB_ + 3 && COM_ == S_ + NJ && QD_ == VB_ + 3, "state blocks of t_dyn");
+    static_assert(gs::QBDYN == gs::PBDYN + 3 && gs::SDYN == gs::PBDYN + 7 && gs::COMDYN == gs::PBDYN + 7 + NJ, "g slots of t_dyn");
+    static_assert(gs::QB_X0 == gs::PB_X0 + 3 && gs::S_X0 == gs::PB_X0 + 7 && gs::COM_X0 == gs::PB_X0 + 7 + NJ, "x0 slots of t_dyn");
+    const int X = e + (e < 7 ? PB_ : S_ - 7);
+    const int Y = e + (e < 7 ? VB_ : (e < 7 + NJ ? SD_ - 7 : H_ - 7 - NJ));
     Em& em = cx.em;
     // padding slots of the ancestor / descendant lists (identity rotation, zero terms), one element per lane
     scratch_padding(s, e);
-    em.G(gslot + i, row_id(kin, 0, i), s.x[X] - (s.xm[X] + half * (s.xm[Y] + s.x[Y])));
-    em.G(gx0 + i, row_id(kx0, 0, i), s.x[X]);
+    em.G(gs::PBDYN + e, row_id(kin, 0, i), s.x[X] - (s.xm[X] + half * (s.xm[Y] + s.x[Y])));
+    em.G(gs::PB_X0 + e, row_id(kx0, 0, i), s.x[X]);
     emit_jc(em, jslot + 0 * L + i, row_id(kin, 0, i), X, 1.0);
     emit_jc(em, jslot + 1 * L + i, row_id(kin, 0, i), Y, -half);
     emit_jc(em, jslot + 2 * L + i, row_id(kout, 0, i), X, -1.0);
@@ -783,10 +802,9 @@ template <class Em> HD void joint_transform(Ctx<Em>& cx, int j) {
     matmul3(kin_R_fix(cx, j), Ra, L);
     matvec3(kin_R_fix(cx, j), a, c);
     double* rec = s.Jr[j].d;
-    const int sw = (j & 7) << 1;   // jr_pos(j, e) = e ^ sw
-    for (int e = 0; e < 9; ++e) rec[(JR_L + e) ^ sw] = L[e];
-    for (int r = 0; r < 3; ++r) { rec[(JR_OF + r) ^ sw] = kin_o_fix(cx, j)[r]; rec[(JR_C + r) ^ sw] = c[r]; }
-    rec[JR_SD ^ sw] = s.x[SD_ + j];
+    for (int e = 0; e < 9; ++e) rec[JR_L + e] = L[e];
+    for (int r = 0; r < 3; ++r) { rec[JR_OF + r] = kin_o_fix(cx, j)[r]; rec[JR_C + r] = c[r]; }
+    rec[JR_SD] = s.x[SD_ + j];
 }
 
 // --- joint-wise rows, joint regularisation cost and the local joint transform, lane j (23) -------------
@@ -907,7 +925,6 @@ template <class Em> HD void t_feet(Ctx<Em>& cx, int t) {   // t = 0: centroids; 
         const double* ptl = s.x + PT_ * tl + P_;
         const double ef = -s1 * (ptr[0] - pbr[0]) + c1 * (ptr[1] - pbr[1]);
         const double es = -s2 * (ptl[0] - ptr[0]) + c2 * (ptl[1] - ptr[1]);
-        s.yaw_sc[foot][0] = s1; s.yaw_sc[foot][1] = c1; s.yaw_sc[foot][2] = s2; s.yaw_sc[foot][3] = c2;
         s.yaw_e[foot][0] = ef; s.yaw_e[foot][1] = es;
         s.c_yaw[foot] = on * cx.st.m_yaw * (0.5 * (ef * ef + es * es));
     }
@@ -970,18 +987,18 @@ template <class Em> HD void t_fk_rot_at(Ctx<Em>& cx, int t, int q0) {
     // trip PLUS three dependent levels of fp64 arithmetic otherwise, ~360 cycles, eight times over on the longest chain of phase B.
     // (the eight ancestor indices stay packed in the 8-byte word they are stored as: two registers instead of eight)
     const unsigned long long ia_w = *reinterpret_cast<const unsigned long long*>(cx.kt.anc[j]);
-    double rec[2][16];   // the eight 16-byte chunks of a record, un-swizzled into registers
-    auto fetch = [&](int q, double* rc) {
-        const int iq = int((ia_w >> (8 * q)) & 0xffull);
-        const double* rp = s.Jr[iq].d;
-        const int sw = (iq & 7) << 1;
+    double rec[2][16];   // the eight 16-byte chunks of a record
+    auto fetch = [&](int q, double* rc) {   // (one multiply for the record's address, the eight chunks at immediate offsets)
+        const double* rp = s.Jr[int((ia_w >> (8 * q)) & 0xffull)].d;
         HIPNLP_UNROLL
-        for (int ch = 0; ch < 8; ++ch) { const int pp = (2 * ch) ^ sw; rc[2 * ch] = rp[pp]; rc[2 * ch + 1] = rp[pp + 1]; }
+        for (int e = 0; e < 16; ++e) rc[e] = rp[e];
     };
-    fetch(0, rec[0]);
+    // (the records of the leading identity steps are not read either: eight 16-byte reads — 32 LDS-array cycles — per skipped step, and the
+    //  LDS array is the busiest unit of the batch launches beside the VALU; q0 is group-uniform: scalar branches)
+    if (q0 == 0) fetch(0, rec[0]);
     HIPNLP_UNROLL
     for (int q = 0; q < 8; ++q) {
-        if (q + 1 < 8) fetch(q + 1, rec[(q + 1) & 1]);
+        if (q + 1 < 8 && q + 1 >= q0) fetch(q + 1, rec[(q + 1) & 1]);
         if (q < q0) continue;
         const double* rq = rec[q & 1];
         const double* L = rq + JR_L;
@@ -995,10 +1012,15 @@ template <class Em> HD void t_fk_rot_at(Ctx<Em>& cx, int t, int q0) {
         const double n2 = v0 * L[2] + v1 * L[5] + v2 * L[8];
         v0 = n0; v1 = n1; v2 = n2;
     }
-    s.Rw[j + 1][3 * r] = v0; s.Rw[j + 1][3 * r + 1] = v1; s.Rw[j + 1][3 * r + 2] = v2;
-    s.aw[j][r] = ar;
-    s.ow[j + 1][r] = o;
-    s.wv[j + 1][r] = w;
+    // (the store addresses are derived from the task number AGAIN, behind a wall the compiler cannot see through: kept from the top of the
+    //  task, they are live across the whole walk — 64 registers of records in flight — and the five-per-CU kernels, at 96 registers, spilled one)
+    int t2 = t;
+    HIPNLP_OPAQUE(t2);
+    const int j2 = t2 / 3, r2 = t2 - 3 * j2;
+    s.Rw[j2 + 1][3 * r2] = v0; s.Rw[j2 + 1][3 * r2 + 1] = v1; s.Rw[j2 + 1][3 * r2 + 2] = v2;
+    s.aw[j2][r2] = ar;
+    s.ow[j2 + 1][r2] = o;
+    s.wv[j2 + 1][r2] = w;
 }
 template <class Em> HD void t_fk_rot_a(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t, HIPNLP_UNIFORM(cx.kt.fk_first[0])); }
 template <class Em> HD void t_fk_rot_b(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t + FK_TASKS_A, HIPNLP_UNIFORM(cx.kt.fk_first[1])); }
@@ -1029,9 +1051,10 @@ template <class S, class K> HD void link_origin_velocity(const S& s, const K& kt
     v[0] = v[1] = v[2] = 0.0;
     if (i == 0) return;
     double u[8][3];
+    const unsigned long long aw8 = *reinterpret_cast<const unsigned long long*>(kt.anc[i - 1]);   // (the eight indices as the one word they are stored as)
     HIPNLP_UNROLL
     for (int q = 0; q < 8; ++q) {
-        const double* uq = s.Uj[kt.anc[i - 1][q]];
+        const double* uq = s.Uj[int((aw8 >> (8 * q)) & 0xffull)];
         for (int r = 0; r < 3; ++r) u[q][r] = uq[r];
     }
     HIPNLP_ISSUE_FENCE();   // all 24 reads in flight before the first add
@@ -1125,7 +1148,8 @@ template <class Em> HD void t_foot_costs(Ctx<Em>& cx, int t) {
         if (i < 2) {
             const double my = on * cx.st.m_yaw;
             const double ef = s.yaw_e[foot][0], es = s.yaw_e[foot][1];
-            const double s1 = s.yaw_sc[foot][0], c1 = s.yaw_sc[foot][1], s2 = s.yaw_sc[foot][2], c2 = s.yaw_sc[foot][3];
+            const double* sc = s.pk + PK_YAWSC + 4 * foot;   // sin / cos of the yaw reference and of yaw + pi/2 (pack_params)
+            const double s1 = sc[0], c1 = sc[1], s2 = sc[2], c2 = sc[3];
             // d ef: (p_tr - p_br) . (-s1, c1) ; d es: (p_tl - p_tr) . (-s2, c2)
             const double df = i == 0 ? -s1 : c1, ds = i == 0 ? -s2 : c2;
             if (cl == cx.st.yaw_corner[foot][0]) gsum += -my * ef * df;
@@ -1191,6 +1215,7 @@ template <class Em> HD void t_ends(Ctx<Em>& cx, int t) {
 template <class Em> HD void t_links(Ctx<Em>& cx, int i) {
     auto& s = cx.s;
     const double m = kin_mass(cx, i);
+    if (i < 16) s.own[NL][i] = 0.0;   // the zero slot of the descendant lists (scratch_padding)
     double vo[3];
     link_origin_velocity(s, cx.kt, i, vo);
     for (int r = 0; r < 3; ++r) s.vo[i][r] = vo[r];
@@ -1275,6 +1300,16 @@ template <class Em> HD void t_composite(Ctx<Em>& cx, int t) {
     const unsigned long long* dw = reinterpret_cast<const unsigned long long*>(cx.kt.desc[i]);
     const unsigned long long w3[3] = {dw[0], dw[1], dw[2]};
     double acc = 0.0;
+    if (cnt <= 4) {   // (wave-uniform) the small subtrees — four of the six iteration groups of the ergoCub tree: four records, not eight
+        double v[4];  // (the terms left out are the zero slot's: no bit of the sum changes)
+        HIPNLP_UNROLL
+        for (int u = 0; u < 4; ++u) v[u] = s.own[int((w3[0] >> (8 * u)) & 0xffull)][r];
+        HIPNLP_ISSUE_FENCE();
+        HIPNLP_UNROLL
+        for (int u = 0; u < 4; ++u) acc += v[u];
+        s.comp[i][r] = acc;
+        return;
+    }
     HIPNLP_UNROLL
     for (int c = 0; c < 3; ++c) {
         if (8 * c >= cnt) break;   // (wave-uniform)

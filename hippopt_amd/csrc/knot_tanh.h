@@ -18,6 +18,17 @@
 
 namespace hipnlp {
 
+// q = q r + c, c a literal.  Device: ONE v_fma_f64 with the coefficient in a scalar register pair (two s_mov_b32 on the scalar unit).  Left
+// to the compiler, a Horner step with a 64-bit literal addend becomes two v_mov_b32 — the literal into the destination of a two-address
+// v_fmac — in front of the multiply-add: 24 of the 161 vector instructions of the contact-row task, on the unit the batch launches are
+// bound by.  (A table in constant memory does not help: the compiler loads it into SGPRs and then copies them to VGPRs for the same
+// v_fmac.)  The same operation on the same values either way.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FM_HORNER(q, r, c) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(q) : "v"(q), "v"(r), "s"(double(c)))
+#else
+#define FM_HORNER(q, r, c) q = fm_fma(q, r, c)
+#endif
+
 HD double fm_fma(double a, double b, double c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_fma(a, b, c);
@@ -51,17 +62,17 @@ HD double fm_expm1_neg(double y) {
     const double rt = (hi - r) - lo;                  // r + rt = the reduced argument to ~2^-100
     // Taylor coefficients 1/n!, n = 3..14, Horner in r
     double q = 1.0 / 87178291200.0;
-    q = fm_fma(q, r, 1.0 / 6227020800.0);
-    q = fm_fma(q, r, 1.0 / 479001600.0);
-    q = fm_fma(q, r, 1.0 / 39916800.0);
-    q = fm_fma(q, r, 1.0 / 3628800.0);
-    q = fm_fma(q, r, 1.0 / 362880.0);
-    q = fm_fma(q, r, 1.0 / 40320.0);
-    q = fm_fma(q, r, 1.0 / 5040.0);
-    q = fm_fma(q, r, 1.0 / 720.0);
-    q = fm_fma(q, r, 1.0 / 120.0);
-    q = fm_fma(q, r, 1.0 / 24.0);
-    q = fm_fma(q, r, 1.0 / 6.0);
+    FM_HORNER(q, r, 1.0 / 6227020800.0);
+    FM_HORNER(q, r, 1.0 / 479001600.0);
+    FM_HORNER(q, r, 1.0 / 39916800.0);
+    FM_HORNER(q, r, 1.0 / 3628800.0);
+    FM_HORNER(q, r, 1.0 / 362880.0);
+    FM_HORNER(q, r, 1.0 / 40320.0);
+    FM_HORNER(q, r, 1.0 / 5040.0);
+    FM_HORNER(q, r, 1.0 / 720.0);
+    FM_HORNER(q, r, 1.0 / 120.0);
+    FM_HORNER(q, r, 1.0 / 24.0);
+    FM_HORNER(q, r, 1.0 / 6.0);
     const double r2 = r * r;
     // e^(r + rt) - 1 = (r + rt) + r^2 / 2 + r^3 q + rt (e^r - 1 ...) ~ r + (rt + rt r + r^2 / 2 + r^3 q)
     const double p = r + (fm_fma(rt, r, rt) + fm_fma(r2 * r, q, 0.5 * r2));

@@ -460,16 +460,16 @@ struct Layout {
             while (l > 0 && steps <= NL) { l = md.parent[l - 1]; ++steps; if (l < 0 || l >= NL) break; }
             if (l != 0) { err = "robot model: the parent links do not form a tree rooted at link 0"; return false; }
             double an = 0;
-            for (int i = 0; i < 3; ++i) { kt.jf.axis[j][i] = md.axis[j][i]; an += md.axis[j][i] * md.axis[j][i]; }
+            for (int i = 0; i < 3; ++i) { kt.jf.j[j].axis[i] = md.axis[j][i]; an += md.axis[j][i] * md.axis[j][i]; }
             if (!(an > 0.999999 && an < 1.000001)) { err = "robot model: joint axes must be unit vectors"; return false; }
-            for (int i = 0; i < 9; ++i) kt.jf.R_fix[j][i] = md.R_fix[j][i];
+            for (int i = 0; i < 9; ++i) kt.jf.j[j].R_fix[i] = md.R_fix[j][i];
         }
         double total_mass = 0;
         for (int l = 0; l < NL; ++l) {
-            kt.li.mass[l] = md.mass[l];
+            kt.li.l[l].mass = md.mass[l];
             total_mass += md.mass[l];
-            for (int i = 0; i < 3; ++i) kt.li.com[l][i] = md.com[l][i];
-            for (int i = 0; i < 9; ++i) kt.li.inertia[l][i] = md.inertia[l][i];
+            for (int i = 0; i < 3; ++i) kt.li.l[l].com[i] = md.com[l][i];
+            for (int i = 0; i < 9; ++i) kt.li.l[l].inertia[i] = md.inertia[l][i];
         }
         if (!(total_mass > 0)) { err = "robot model: total mass must be positive"; return false; }
         kt.inv_total_mass = 1.0 / total_mass;
@@ -494,7 +494,7 @@ struct Layout {
         // ancestor lists (path root -> j) and descendant lists (subtree of link i)
         for (int j = 0; j < NJ; ++j) {
             kt.par_link[j] = md.parent[j];
-            for (int i = 0; i < 3; ++i) kt.jf.o_fix[j][i] = md.o_fix[j][i];
+            for (int i = 0; i < 3; ++i) kt.jf.j[j].o_fix[i] = md.o_fix[j][i];
             std::vector<int> path;
             for (int q = j + 1; q > 0; q = md.parent[q - 1]) path.push_back(q - 1);
             if (path.size() > 8) { err = "robot model: a chain is deeper than 8 joints"; return false; }

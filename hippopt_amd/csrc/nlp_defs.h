@@ -75,8 +75,13 @@ struct alignas(16) KinLite {
     double inv_total_mass;      // 1 / (sum of the link masses): every use of the total mass on the device is a division by it, and the first one heads the
                                 // dependent chain of the derivative-column tasks (an IEEE division is ~35 dependent instructions)
 };
-struct JointFix { double R_fix[NJ][9], o_fix[NJ][3], axis[NJ][3]; };        // joint frames (phase A only)
-struct LinkInertials { double mass[NL], com[NL][3], inertia[NL][9]; };      // link inertials in the link frame (phase C only)
+// (one record per joint / per link: the lane that needs a joint's frame or a link's inertials forms ONE address — in the compact device
+//  layouts a 64-bit global one — and reads the fields at immediate offsets; three arrays side by side cost three address chains)
+//  (no padding: the full layouts stage these tables in LDS, and the Hessian kernel's 64 KB are used to the last 128 bytes)
+struct JointFixRec { double R_fix[9], o_fix[3], axis[3]; };   // 120 B
+struct LinkInertialsRec { double inertia[9], com[3], mass; }; // 104 B
+struct JointFix { JointFixRec j[NJ]; };                                      // joint frames (phase A only)
+struct LinkInertials { LinkInertialsRec l[NL]; };                            // link inertials in the link frame (phase C only)
 struct EndTables {   // horizon-end rows (first / last knot only)
     int16_t fin_var[105], fin_slot[105], fin_desc[105];  // variable / slot among the 81 variable rows / descriptor index (3c+i) or -1
     int16_t per_var[84];

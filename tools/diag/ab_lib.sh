@@ -11,7 +11,7 @@ OUT=gpurun_out/ab_$NAME.txt
 one() {  # label, extra env, bench args
   local label=$1 lib=$2; shift 2
   if [ -n "$lib" ]; then export HIPNLP_LIB_PATH=$lib; else unset HIPNLP_LIB_PATH; fi
-  python3 bench.py --no-cpu-baseline --no-hessian --no-host --no-throughput "$@" 2>/dev/null | tail -1 | python3 -c "
+  python3 bench.py --no-cpu-baseline --no-hessian --no-host --no-throughput ${AB_FLAGS:-} "$@" 2>/dev/null | tail -1 | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 print('%-8s %-34s value %.4g knots/s  ms_per_step %.5f  kernel_ms %.5f' % ('$label', ' '.join(sys.argv[1:]), d['value'], d['ms_per_step'], d['roofline']['kernel_ms']))" "$@" >> $OUT
