@@ -722,6 +722,11 @@ struct HArgs {
     int32_t* flag_host;     // [batch] or null: the same flag in pinned host memory (plain store of seq, see KArgs)
     int32_t N, n, m, knot_begin, seq, nnz_knot /* entries of a knot's block (DIRECT: the block base is needed before the tables are) */;
     int64_t hstride, hoff;  // values of trajectory b start at hess + b * hstride; the handle's first knot block sits at -hoff
+    // launches into HOST memory (full layout): the entries [0, early_run) of a knot's block — the point columns come first in (column,
+    // row) order — are all emitted in the first three phases (HessLayout::early_run: recorded, every entry is emitted exactly once); they
+    // leave behind the third barrier, written through the L2, while the kinematic phases still run: a quarter (planar) to two fifths
+    // (smooth steps) of a knot's bytes are on the link three phases before the program ends.  0: everything at the end.
+    int32_t early_run, early_phase;
 #ifdef HIPNLP_STAMPS
     unsigned long long* stamps;  // diagnostic build only (tools/diag/hess_stamps.py): [blocks][8][128] s_memtime per wave
 #endif
@@ -870,6 +875,28 @@ void hipnlp_knot_hess_kernel(HArgs a) {
     };
     int bar = 0;   // barriers passed (the program is straight-line code: a constant at every use)
     if (!DIRECT && HIPNLP_HESS_TABLES_AT == 0) fetch_tables();
+    // early copy-out (see HArgs::early_run): full layout only — the compact kernels sit at their register caps, and their launches are the
+    // batch ones, whose hundreds of workgroups spread their stores over the launch by themselves
+    constexpr bool EARLY_OUT = !DIRECT && LAYOUT == LAYOUT_FULL;
+    constexpr int EARLY_ITERS = 3;   // (early_run <= 768: 394 on the planar terrain, 732 on the smooth steps; hess_launch checks)
+    int32_t hpe[EARLY_ITERS];
+    const int early_run = EARLY_OUT ? a.early_run : 0;
+    if constexpr (EARLY_OUT) {
+#pragma unroll
+        for (int it = 0; it < EARLY_ITERS; ++it) hpe[it] = ht.perm[min(tid + it * WG, hk::COUNT - 1)];   // (positions behind the run: not used)
+    }
+    auto early_out = [&]() __attribute__((always_inline)) {
+        if constexpr (EARLY_OUT) {
+            if (early_run <= 0) return;
+            double* out = a.hess + int64_t(b) * a.hstride + (int64_t(a.nnz_knot) * k - a.hoff);
+#pragma unroll
+            for (int it = 0; it < EARLY_ITERS; ++it) {
+                const int pos = tid + it * WG;
+                // (a store the compiler does not know about, as in hipnlp_knot_kernel: nothing waits for it)
+                if (pos < early_run) asm volatile("global_store_dwordx2 %0, %1, %2 sc0 sc1" ::"v"(pos * 8), "v"(hx.H[hpe[it]]), "s"(out) : "memory");
+            }
+        }
+    };
     KnotInfo ki{k, N, first, last};
     Em em{s.g, s.jac, DIRECT ? a.hess + int64_t(b) * a.hstride + (int64_t(a.nnz_knot) * k - a.hoff) : hx.H, inv_s};
     Ctx<Em> cx(s, tabs.kin(), tabs.settings(), tabs.gp, ki, em, COMPACT ? &tb.head.kt : nullptr, COMPACT ? a.gp + b : nullptr);
@@ -881,11 +908,11 @@ void hipnlp_knot_hess_kernel(HArgs a) {
     const unsigned long long st_staged = __builtin_amdgcn_s_memtime();
 #define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
 #define DEV_RH(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
-#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); bid++; if (++bar == HIPNLP_HESS_TABLES_AT) { if constexpr (!DIRECT) fetch_tables(); }
+#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); bid++; if (++bar == HIPNLP_HESS_TABLES_AT) { if constexpr (!DIRECT) fetch_tables(); } if (bar == a.early_phase) early_out();
 #else
 #define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_RH(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); }
-#define DEV_BARRIER lds_barrier(); if (++bar == HIPNLP_HESS_TABLES_AT) { if constexpr (!DIRECT) fetch_tables(); }
+#define DEV_BARRIER lds_barrier(); if (++bar == HIPNLP_HESS_TABLES_AT) { if constexpr (!DIRECT) fetch_tables(); } if (bar == a.early_phase) early_out();
 #endif
     auto run_wave = [&](auto wc) __attribute__((always_inline)) {
         constexpr int W = decltype(wc)::value;
@@ -910,7 +937,7 @@ void hipnlp_knot_hess_kernel(HArgs a) {
         for (int it = 0; it < HP_ITERS; ++it) hv[it] = hx.H[hp[it] >= 0 ? hp[it] : 0];   // every LDS read in flight before the first store
         const double hvc = hx.H[hpc >= 0 ? hpc : 0];
 #pragma unroll
-        for (int it = 0; it < HP_ITERS; ++it) if (hp[it] >= 0) { bad |= !isfinite(hv[it]); out[tid + it * WG] = hv[it]; }
+        for (int it = 0; it < HP_ITERS; ++it) if (hp[it] >= 0) { bad |= !isfinite(hv[it]); if (tid + it * WG >= early_run) out[tid + it * WG] = hv[it]; }
         if (hpc >= 0) { bad |= !isfinite(hvc); a.hess[int64_t(b) * a.hstride + (int64_t(cnt) * N - a.hoff) + tid] = hvc; }
     }
     if (__any(bad) && lane == 0) {   // nothing to reset between launches
@@ -1151,6 +1178,9 @@ struct hipnlp_handle {
     unsigned long long pinned_const_gen = 0;        // parameter set whose constants the pinned block holds (0: none)
     std::vector<std::pair<size_t, double>> csample; // (index into [batch][nnz], value): the spot check
     size_t jac_first_vary = 0, jac_last_vary = 0;   // first / last entry of [batch][nnz] that depends on x (sentinel words of a store that skips the constants)
+    // first / last word of [batch][n], [batch][m], [batch][nnz] that THIS handle's launches write (a shard handle writes the entries of its
+    // own knots: the sentinel words that verify a self-registered array must lie where the kernel stores)
+    size_t out_first[3] = {0, 0, 0}, out_last[3] = {0, 0, 0};
     long const_fills = 0, const_refills = 0;
     bool time_host = false;       // bracket host-path launches with events (hipnlp_set_host_timing)
     double host_us[4] = {0, 0, 0, 0};   // wall clock of the last host-path evaluation: x staging, enqueue, wait for the GPU, copies out
@@ -1411,6 +1441,26 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     }
 #undef CREATE_TRY
     dims_fill(h, &h->dims);
+    {
+        const Layout& L = h->L;
+        const size_t Bm1 = size_t(h->batch) - 1;
+        h->out_first[0] = size_t(h->dims.shard_grad_off);
+        h->out_last[0] = Bm1 * size_t(L.n) + size_t(h->dims.shard_grad_off) + size_t(h->dims.shard_grad) - 1;
+        long rmin = LONG_MAX, rmax = -1;
+        for (int k = h->kb; k < h->ke; ++k) {
+            const int v = L.variant_of(k);
+            for (int sl = 0; sl < gs::COUNT; ++sl) {
+                const int a = L.g_a[v][size_t(sl)];
+                if (a == G_NONE) continue;
+                const long r = long(a) + long(L.g_b[size_t(sl)]) * k;
+                rmin = std::min(rmin, r); rmax = std::max(rmax, r);
+            }
+        }
+        h->out_first[1] = size_t(rmax >= 0 ? rmin : 0);
+        h->out_last[1] = Bm1 * size_t(L.m) + size_t(rmax >= 0 ? rmax : 0);
+        h->out_first[2] = size_t(h->dims.shard_jac_off);
+        h->out_last[2] = Bm1 * size_t(L.nnz) + size_t(h->dims.shard_jac_off) + size_t(h->dims.shard_nnz) - 1;
+    }
     *out = h;
     return HIPNLP_OK;
 }
@@ -1814,6 +1864,8 @@ static int hess_launch(hipnlp_handle* h, const double* x_dev, const double* sigm
         h->hseq = 0;
     }
     a.seq = ++h->hseq; a.nnz_knot = h->HL.nnz_knot;
+    a.early_run = (host_block && h->early_store && !h->hess_compact && h->HL.early_run <= 3 * 256) ? h->HL.early_run : 0;
+    a.early_phase = a.early_run > 0 ? h->HL.early_phase : 0;
 #ifdef HIPNLP_STAMPS
     if (!h->d_stamps) HIP_TRY(h, hipMalloc(&h->d_stamps, size_t(h->nk) * size_t(h->batch) * 1024 * sizeof(unsigned long long)));
     a.stamps = h->d_stamps;
@@ -2210,8 +2262,8 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
         }
         u64 sentinel = 0;
         bool checked[3] = {false, false, false};
-        size_t w_first[3] = {0, 0, 0}, w_last[3] = {bytes[0] / 8 - 1, bytes[1] / 8 - 1, bytes[2] / 8 - 1};
-        if (vary_only) { w_first[2] = h->jac_first_vary; w_last[2] = h->jac_last_vary; }   // (words the launch does write)
+        size_t w_first[3] = {h->out_first[0], h->out_first[1], h->out_first[2]}, w_last[3] = {h->out_last[0], h->out_last[1], h->out_last[2]};   // (words the launch writes)
+        if (vary_only) { w_first[2] = h->jac_first_vary; w_last[2] = h->jac_last_vary; }
         for (int q = 0; q < 3; ++q)
             if (sel[q] == 2u && auto_owns(h, caller_host[q])) {
                 if (!sentinel) sentinel = 0x7FF8C0DE00000000ull | (++h->sentinel_salt & 0xFFFFFFFFull);   // (a quiet NaN no evaluation produces)
@@ -2294,7 +2346,7 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
         const double* const hbm[3] = {h->d_grad, h->d_g, h->d_jac};
         u64 sentinel = 0;
         bool checked[3] = {false, false, false};
-        size_t w_first[3] = {0, 0, 0}, w_last[3] = {bytes[0] / 8 - 1, bytes[1] / 8 - 1, bytes[2] / 8 - 1};
+        size_t w_first[3] = {0, 0, 0}, w_last[3] = {bytes[0] / 8 - 1, bytes[1] / 8 - 1, bytes[2] / 8 - 1};   // (whole-array copies)
         for (int q = 0; q < 3; ++q) {
             if (!(missing & bit[q])) continue;
             const bool vary_run = q == 2 && caller[q] && caller_dev[q] && h->skip_const && h->vary_ok && h->L.vary_first && h->L.nconst_total > 0;

@@ -22,6 +22,11 @@ struct HessLayout {
     std::vector<int32_t> perm;        // [nnz_knot] position in the knot block -> native slot
     std::vector<int32_t> lrow, lcol;  // [nnz_knot] variable offsets inside the knot record
     std::vector<int32_t> perm_couple, crow, ccol;   // coupling: slot, variable of the last knot (row), of the first knot (column)
+    // phase of the Hessian program (barriers passed) in which the entry at position i of a knot block is emitted — every entry is emitted
+    // exactly once (a second emission is refused above), so that is when its value is final; early_run: the entries [0, early_run) of a
+    // block — the point columns come first in (column, row) order — that are ALL final behind barrier number EARLY_PHASE
+    std::vector<unsigned char> pos_phase;
+    int early_run = 0, early_phase = 0;   // early_phase: the barrier (1 = the first) behind which the run is final — the earliest of the first three that gives the longest run
     std::string error;
 
     bool build(const hipnlp_settings& st, const KinTables& kt) {
@@ -39,11 +44,15 @@ struct HessLayout {
         gp.dt = 0.1; gp.mass = 1.0;
         KnotInfo ki{0, N, 1, 1};
         RecordEm em{grow.data(), jrid.data(), jc.data(), &dup, hrow.data(), hcol.data()};
+        std::vector<unsigned char> hphase(hk::COUNT, 255);
+        em.hphase = hphase.data();
         Ctx<RecordEm> cx(*s, kt, ks, gp, ki, em);
         KHCtx<RecordEm> hcx{cx, *hx, s->g};
 #define HOST_KIN(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
 #define HOST_RH(w, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(hcx, t_);
-        HIPNLP_KNOT_HESS_PROGRAM(HOST_KIN, HOST_RH, )
+#define HOST_BAR cx.em.phase++;
+        HIPNLP_KNOT_HESS_PROGRAM(HOST_KIN, HOST_RH, HOST_BAR)
+#undef HOST_BAR
 #undef HOST_KIN
 #undef HOST_RH
         delete hx;
@@ -65,6 +74,14 @@ struct HessLayout {
         perm.clear(); lrow.clear(); lcol.clear(); perm_couple.clear(); crow.clear(); ccol.clear();
         for (auto& e : ent) { perm.push_back(e.second); lcol.push_back(e.first.first); lrow.push_back(e.first.second); }
         for (auto& e : cpl) { perm_couple.push_back(e.second); ccol.push_back(e.first.first); crow.push_back(e.first.second); }
+        pos_phase.clear();
+        for (int32_t slot : perm) pos_phase.push_back(hphase[size_t(slot)]);
+        early_run = 0; early_phase = 0;
+        for (int P = 1; P <= 3; ++P) {   // (at least the last three phases of the six still to run)
+            int run = 0;
+            while (run < int(pos_phase.size()) && pos_phase[size_t(run)] < P) ++run;
+            if (run > early_run) { early_run = run; early_phase = P; }
+        }
         nnz_knot = int(perm.size());
         n_couple = int(perm_couple.size());
         nnz = long(nnz_knot) * N + n_couple;

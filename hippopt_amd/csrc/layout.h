@@ -57,7 +57,8 @@ struct RecordEm {
     bool* dup;
     int* hrow = nullptr;   // [hs::COUNT] Hessian slots (pose_hess_body.h): row / column variable or -1
     int* hcol = nullptr;
-    void H(int slot, int row, int col, double) { if (hrow[slot] != -1) *dup = true; hrow[slot] = row; hcol[slot] = col; }
+    unsigned char* hphase = nullptr;   // [hk::COUNT] or null: phase of the Hessian program (barriers passed) in which the slot is emitted — every slot once
+    void H(int slot, int row, int col, double) { if (hrow[slot] != -1) *dup = true; hrow[slot] = row; hcol[slot] = col; if (hphase) hphase[slot] = (unsigned char)phase; }
     void G(int slot, int rid, double) { if (grow[slot] != -1) *dup = true; grow[slot] = rid; if (gphase) gphase[slot] = (unsigned char)phase; }
     void J(int slot, int rid, int col, double) { if (jrowid[slot] != -1) *dup = true; jrowid[slot] = rid; jcol[slot] = col; if (jphase) jphase[slot] = (unsigned char)phase; }
     // the phase of the knot program (barriers passed) in which a slot gets its value: what is final after the second phase can leave early
