@@ -435,8 +435,16 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             stage(&tb.head.ks, &tabs.ks, int(sizeof(KSettings)));
             stage(static_cast<const KinLite*>(&tb.head.kt), &tabs.kt, int(sizeof(KinLite)));
         } else {
+#ifdef HIPNLP_DIAG_LITE_STAGE
+            // timing-only diagnostic build (wrong values): the eight-wave kernel stages the lite tables only — 10.6 instead of 26.4 KB per
+            // workgroup: what a shorter prologue could be worth on the 100-knot launch
+            stage(static_cast<const GParamsLite*>(gp_p + b), &tabs.gp, int(sizeof(GParamsLite)));
+            stage(static_cast<const KinLite*>(&tb.head.kt), &tabs.head.kt, int(sizeof(KinLite)));
+            stage(&tb.head.ks, &tabs.head.ks, int(sizeof(KSettings)));
+#else
             stage(gp_p + b, &tabs.gp, int(sizeof(GParams)));
             stage(&tb.head, &tabs.head, int(sizeof(HeadTables)));
+#endif
         }
         // through registers: the odd last double of the two records; horizon ends only: the periodicity variables of the other end
         double xrem = 0.0, xov = 0.0;
@@ -506,6 +514,12 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     // diagnostic compile (tools/diag/isa_tasks.sh: assembly only, never a library): comment markers around every task group, so that
     // tools/diag/isa_mix.py can say which task group carries how many instructions of which kind
 #define DEV_R(w4, w8, fn, nt) if constexpr ((WAVES == 4 ? (w4) : (w8)) == W) { asm volatile("; TASK_BEGIN " #fn); for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); asm volatile("; TASK_END " #fn); }
+#elif defined(HIPNLP_DIAG_HALF_LATE)
+    // timing-only diagnostic build (wrong values; tools/diag/headline_experiments.sh): the task groups of the LAST TWO phases — derivative
+    // columns, row assembly — run on HALF their lanes, what one of TWO workgroups per knot would be left with if those phases were split by
+    // column range.  Every group of those phases is one wave iteration whatever its lane count: the launch does not
+    // get shorter (profiles/r05_headline_experiments.txt).
+#define DEV_R(w4, w8, fn, nt) if constexpr ((WAVES == 4 ? (w4) : (w8)) == W) { for (int t_ = lane; t_ < (bid >= 4 ? ((nt) + 1) / 2 : (nt)); t_ += 64) fn(cx, t_); }
 #else
 #define DEV_R(w4, w8, fn, nt) if constexpr ((WAVES == 4 ? (w4) : (w8)) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #endif

@@ -239,6 +239,52 @@ def test_early_copy_out_of_the_host_path_changes_no_bit(model, HipNlp, terrain):
         e.close()
 
 
+@pytest.mark.parametrize("terrain", ["planar", "stairs"])
+def test_early_copy_out_of_the_hessian_host_path_changes_no_bit(model, HipNlp, terrain):
+    """hipnlp_eval_hess through host buffers: the entries at the start of a knot's block — the point columns, a quarter (planar) to two fifths
+    (smooth steps) of its bytes — are all emitted in the first phases of the Hessian program and leave behind that barrier, written
+    through the L2, while the kinematic phases still run; the copy-out at the end skips them.  Which entries those are is RECORDED
+    (HessLayout::pos_phase: every entry is emitted exactly once).  Bit for bit the handle without the early pass (HIPNLP_EARLY_STORE=0 on the
+    diagnostic build) and the device path, with fresh value arrays (pinned block) and a reused one (registered by the handle: direct stores);
+    a batch of two and a shard handle too (the run of a shard's first knot starts where its values do)."""
+    import torch
+    from hippopt_amd.kinodyn_settings import stairs_settings
+    from hippopt_amd.synthetic import place_on_step_flanks
+    for B, kw in ((1, {}), (2, {}), (1, dict(knot_begin=7, knot_end=31))):
+        st = (stairs_settings if terrain == "stairs" else periodic_step_settings)(45, model)
+        x, p = make_workload(st, model, batch=B, seed=4850)
+        if terrain == "stairs":
+            place_on_step_flanks(x, st, seed=4850)
+        engs = []
+        for flag in ("1", "0"):
+            with diag_overrides(HIPNLP_EARLY_STORE=flag) as lib:
+                engs.append(HipNlp(st, model, batch=B, library=lib, **kw))
+            engs[-1].set_params(p)
+        dev_eng = HipNlp(st, model, batch=B, **kw)      # the product library's device path: its own staged launch, everything stored at the end
+        dev_eng.set_params(p)
+        rng = np.random.RandomState(9)
+        lam, sig = rng.standard_normal((B, engs[0].m)), rng.uniform(0.3, 1.5, B)
+        hn = engs[0].hess_nnz()
+        outs = [np.full((B, hn), np.nan) for _ in engs]
+        dev = torch.device("cuda", 0)
+        ld, sd = torch.from_numpy(lam).to(dev), torch.from_numpy(sig).to(dev)
+        for i, xi in enumerate(iterates(x, 4)):
+            fresh = [e.eval_hess(xi, sig, lam) for e in engs]                       # fresh arrays: through the pinned block
+            assert np.array_equal(fresh[0].view(np.int64), fresh[1].view(np.int64)), (terrain, B, kw, i)
+            for e, o in zip(engs, outs):
+                o.fill(np.nan)
+                e.eval_hess(xi, sig, lam, out=o)                                    # the same array again and again: registered at its second sight
+            assert np.array_equal(outs[0].view(np.int64), outs[1].view(np.int64)) and np.array_equal(outs[0].view(np.int64), fresh[0].view(np.int64)), (terrain, B, kw, i)
+            hd = torch.full((B, hn), float("nan"), dtype=torch.float64, device=dev)
+            xd = torch.from_numpy(xi).to(dev)
+            dev_eng.eval_hess_device(xd.data_ptr(), sd.data_ptr(), ld.data_ptr(), hd.data_ptr())
+            torch.cuda.synchronize()
+            assert np.array_equal(hd.cpu().numpy().view(np.int64), outs[0].view(np.int64)), (terrain, B, kw, i)
+        assert engs[0].host_stats()["auto_fallbacks"] == 0
+        for e in engs + [dev_eng]:
+            e.close()
+
+
 def test_arrays_the_wrapper_allocates_itself_are_never_page_locked(model, HipNlp):
     """HipNlp.eval / eval_hess without `out=` hand back fresh arrays the caller drops when it likes; the allocator would hand the same
     addresses out again on the next call and the handle would take that for "the same array twice in a row" and page-lock memory that
