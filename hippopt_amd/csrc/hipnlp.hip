@@ -91,7 +91,8 @@ struct ConstCheck {
     int32_t* healed;
     int64_t jac_stride, jac_off;
     int32_t ctpl_len, ctpl_off[4], nnz_v[3], first_const[3] /* position of a block's first constant entry, -1: none */, kb, nk, N, n_glob, jac_glob_base;
-    int32_t samp[3][4];        // four constant positions of a variant-v block, spread over its constants (first and last among them; -1: none)
+    int32_t samp[3][4];        // four constant positions of a variant-v block: {first, last, two in between} (-1: none)
+    int32_t parity;            // launch number & 1: even launches look at samp[.][0..1], odd ones at samp[.][2..3] (two loads per knot and launch)
 };
 // the templates hold this word (a quiet NaN no constant has) at the positions of a block that depend on x
 constexpr unsigned long long CTPL_VARYING = 0x7FF8C0DEC0DE0001ull;
@@ -193,8 +194,10 @@ constexpr int PUB_SPIN_CAP = 1 << 20;   // polls of the reducer before it gives 
 // VARY launches into a DEVICE destination: are the constant entries of trajectory b's knot blocks in place?  Run by the ONE workgroup
 // per trajectory that sums its cost (the reducer workgroup of the launch, or hipnlp_reduce_kernel behind it) — never by the knot
 // workgroups: two loads on their path, wherever they were issued, cost 4 - 10 % at batch (vector loads of table words with a wait
-// right behind them; then the round trip to HBM itself).  Thread t looks at FOUR constant entries of the block of knot kb + t (+ 256, ...)
-// — the first, the last and two in between (ConstCheck::samp) —; if any differs from the handle's template the workgroup puts the
+// right behind them; then the round trip to HBM itself).  Thread t looks at constant entries of the block of knot kb + t (+ 256, ...):
+// FOUR positions — the first, the last and two in between (ConstCheck::samp) — two per launch, alternating with the launch number (every
+// sampled load is a sector of HBM traffic of its own: four per knot and launch doubled the reduction kernel behind a x 1024 launch,
+// 10.6 -> 21.9 us); if any differs from the handle's template the workgroup puts the
 // constants of ALL the trajectory's blocks back (rare — a caller that wrote over its buffer — slow, right: the knot workgroups store
 // other entries, nothing is written twice).  A SAMPLE: constants overwritten elsewhere in a block are not seen — a caller that hands
 // over other memory at an address the handle has filled (a tensor freed and re-allocated) says so with hipnlp_forget_jac_destination.
@@ -209,7 +212,8 @@ __device__ __forceinline__ void constants_check_and_repair(const ConstCheck& c, 
         if (c.first_const[v] < 0) continue;
         const int64_t base = k == 0 ? 0 : int64_t(c.nnz_v[VAR_FIRST]) + int64_t(k - 1) * c.nnz_v[VAR_INTERIOR];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q0 = 0; q0 < 2; ++q0) {
+            const int q = 2 * c.parity + q0;
             const int sp = c.samp[v][q] >= 0 ? c.samp[v][q] : c.first_const[v];
             const double seen = out[base + sp], want = tpl[c.ctpl_off[v] + sp];
             miss |= __double_as_longlong(seen) != __double_as_longlong(want);
@@ -1697,7 +1701,8 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
         for (int v = 0; v < 3; ++v) {
             c.nnz_v[v] = h->L.nnz_v[v]; c.first_const[v] = h->cpos[v].empty() ? -1 : h->cpos[v][0];
             const size_t nc = h->cpos[v].size();
-            for (size_t q = 0; q < 4; ++q) c.samp[v][q] = nc ? h->cpos[v][(q * (nc - 1)) / 3] : -1;
+            const size_t at[4] = {0, nc ? nc - 1 : 0, nc ? (nc - 1) / 3 : 0, nc ? (2 * (nc - 1)) / 3 : 0};   // {first, last, two in between}
+            for (size_t q = 0; q < 4; ++q) c.samp[v][q] = nc ? h->cpos[v][at[q]] : -1;
         }
         c.kb = h->kb; c.nk = h->nk; c.N = h->L.N; c.n_glob = int(h->L.jperm_glob.size()); c.jac_glob_base = h->L.jac_glob_base;
     }
@@ -1738,6 +1743,7 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
         h->have_result = false;
     }
     a.seq = ++h->seq;
+    a.cc.parity = a.seq & 1;
     a.N = h->L.N; a.n = h->L.n; a.m = h->L.m; a.nnz = h->L.nnz; a.knot_begin = h->kb; a.nk = h->nk;
     bool prof = false, run_first = false, run_last = false;
     if (h->prof_cap > 0 && h->prof_run > 0) {        // runs of consecutive launches: one event before the first, one after the last

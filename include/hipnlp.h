@@ -284,9 +284,10 @@ int hipnlp_set_prefetch(hipnlp_handle* h, unsigned mask);
  * varying entries of every knot block only — one run in the varying-first order, scattered over the block in CasADi's CCS order (on = 1
  * on a handle WITHOUT HIPNLP_FLAG_JAC_VARYING_FIRST asks for exactly this: device destinations only, host destinations of a CCS handle keep
  * receiving every entry) — and no longer stage the constants in LDS at all.  Same contract — the caller does not write into
- * the buffer between calls — and the launch itself samples it: the one workgroup per trajectory that sums the cost compares FOUR constant
- * entries of every knot block (its first, its last, two in between) with the handle's templates and puts the constants of all the
- * trajectory's blocks back when one differs (hipnlp_host_stats out[7] counts such repairs).  A sample, not a guarantee: constants
+ * the buffer between calls — and the launch itself samples it: the one workgroup per trajectory that sums the cost compares constant
+ * entries of every knot block with the handle's templates — four positions per block (its first, its last, two in between), two of them
+ * per launch, alternating — and puts the constants of all the trajectory's blocks back when one differs (hipnlp_host_stats out[7] counts
+ * such repairs).  A sample, not a guarantee: constants
  * overwritten elsewhere in a block are returned as they are.  The record "this buffer holds the constants" is keyed by the buffer's
  * ADDRESS: a caller that frees a jac buffer and later hands over other memory at the same address (a caching allocator does that) must
  * call hipnlp_forget_jac_destination first — the next evaluation then fills the buffer again.

@@ -351,6 +351,10 @@ def test_device_buffer_sample_check_and_forget(model, HipNlp, vary_first):
     blk = (jc // 189) == 11
     last_const = int(torch.nonzero(blk & mask)[-1])
     out[3].view(B, -1)[1, last_const] = -7.0
+    # (the four sampled positions of a block are looked at two per launch, alternating with the launch number: within two launches)
+    for i in (1, 2):
+        eng.eval_device(xd[i].data_ptr(), *[t.data_ptr() for t in out])
+    torch.cuda.synchronize()
     check(1)
     assert eng.host_stats()["constant_slices_healed"] > healed
     # other memory at the same address: nothing the sample could see (every constant but the sampled ones), said with the forget call
