@@ -221,9 +221,10 @@ long hostemu_hess_nnz(const hostemu_handle* h) { return h->has_hess ? h->HL.nnz 
 const char* hostemu_hess_error(const hostemu_handle* h) { return h->HL.error.c_str(); }
 void hostemu_hess_sparsity(const hostemu_handle* h, int* irow, int* jcol) { h->HL.pattern(irow, jcol); }
 // phase of the Hessian program in which the entry at every position of a knot block is emitted; returns the length of the early run
-int hostemu_hess_phases(const hostemu_handle* h, unsigned char* pos_phase /*[nnz_knot]*/) {
+int hostemu_hess_phases(const hostemu_handle* h, unsigned char* pos_phase /*[nnz_knot]*/, int* early_phase) {
     for (size_t i = 0; i < h->HL.pos_phase.size(); ++i) pos_phase[i] = h->HL.pos_phase[i];
-    return h->HL.early_run + 4096 * h->HL.early_phase;
+    if (early_phase) *early_phase = h->HL.early_phase;
+    return h->HL.early_run;
 }
 // the Hessian tasks of knot_hess_body.h behind the knot program, multiplier gather and copy-out as in hipnlp_knot_hess_kernel
 void hostemu_hess(const hostemu_handle* h, const double* x, const double* p, double sigma, const double* lambda, double* hess) {

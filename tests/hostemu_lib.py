@@ -76,6 +76,18 @@ class HostEmu:
         self.lib.hostemu_vary_partition(C.c_void_p(self.h), out)
         return bool(out[0]), out[1], out[2], out[3], out[4]
 
+    def hess_phases(self):
+        """(phase of the Hessian program in which the entry at every position of a knot block is emitted, length of the early run, barrier
+        behind which that run is final): HessLayout::pos_phase / early_run / early_phase"""
+        n = self.lib.hostemu_hess_nnz(C.c_void_p(self.h))
+        ir, jc = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        self.lib.hostemu_hess_sparsity(C.c_void_p(self.h), _ip(ir), _ip(jc))
+        nnz_knot = int(((jc // 189) == 1).sum())
+        ph, ep = np.zeros(nnz_knot, np.uint8), C.c_int()
+        self.lib.hostemu_hess_phases.restype = C.c_int
+        run = self.lib.hostemu_hess_phases(C.c_void_p(self.h), ph.ctypes.data_as(C.POINTER(C.c_ubyte)), C.byref(ep))
+        return ph, int(run), int(ep.value), (ir[(jc // 189) == 1] % 189, jc[(jc // 189) == 1] % 189)
+
     def early_violations(self):
         """entries marked final after the second phase whose staged value changed later, in the last wave-order evaluation"""
         self.lib.hostemu_early_violations.restype = C.c_long

@@ -382,3 +382,21 @@ def test_compact_layout_phases_are_wave_order_independent(model, terrain):
                 assert np.array_equal(a, b), (order, what, int(np.argmax(a != b)))
     finally:
         hostemu_lib.set_wave_order(-1)
+
+
+@pytest.mark.parametrize("terrain", ["planar", "stairs"])
+def test_hessian_early_run_is_what_the_recorder_saw(model, terrain):
+    """hipnlp_eval_hess through host buffers stores the entries [0, early_run) of a knot's block behind barrier number early_phase of the
+    Hessian program (hipnlp.hip, HArgs::early_run).  The run is RECORDED (HessLayout::pos_phase: every entry is emitted exactly once — a
+    second emission is refused — so the phase of its emission is when it is final), not declared: every entry of the run is emitted in an
+    earlier phase than the barrier, the run is maximal, it covers the point columns (the first 120 variables of a knot, first in
+    (column, row) order) and at least three of the six phases are still to run behind it."""
+    from hippopt_amd.kinodyn_settings import periodic_step_settings, stairs_settings
+    from hostemu_lib import HostEmu
+    e = HostEmu((stairs_settings if terrain == "stairs" else periodic_step_settings)(4, model), model)
+    ph, run, barrier, (rows, cols) = e.hess_phases()
+    assert ph.size == (1878 if terrain == "stairs" else 1539) and ph.max() == 5 and (ph != 255).all()
+    assert 1 <= barrier <= 3 and (ph[:run] < barrier).all() and ph[run] >= barrier
+    assert run == (732 if terrain == "stairs" else 394) and barrier == (3 if terrain == "stairs" else 2)
+    assert (cols < 120).sum() <= run and (cols[:run] < 130).all() and (cols[run:] >= 120).all()     # the point columns (and a few base columns behind them) are the run
+    assert run <= 3 * 256       # (three positions per thread of the 256-thread kernel)
