@@ -405,6 +405,21 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             gb[it] = tbl.gab_t[v][2 * (tid * (GS_PAD / WG) + it) + 1];
         }
     };
+    // Eight-wave kernels (whose launches into host memory store early, early_out below): the tables are fetched WITH the staging loads and
+    // CONSUMED — as far as the compiler can tell: an empty assembly statement that reads and "writes" them — right behind the staging wait.
+    // Fetched behind that wait and left to their first real use, the compiler's wait for them stands behind early stores (between the
+    // early entries of jac g and those of g, and again in front of the final stores): `s_waitcnt vmcnt(0)`, ONE counter for loads and
+    // stores, i.e. the wave sits out the acknowledgement of what it has just sent to host memory before it may send the rest.
+    // (VARY only: the launches that store early are the varying-first handle's; the eleven extra loads in front of the staging wait cost the
+    //  100-knot launch 0.08 - 0.1 us, which the CCS kernels — bench.py's `value` — have no reason to pay)
+    constexpr bool TABLES_WITH_STAGING = !LATE_TABLES && WAVES == 8 && VARY;
+    auto tables_are_here = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < JP_ITERS; ++it) asm volatile("" : "+v"(jp[it]));
+#pragma unroll
+        for (int it = 0; it < G_ITERS; ++it) asm volatile("" : "+v"(ga[it]), "+v"(gb[it]));
+        asm volatile("" : "+v"(jpg));
+    };
     {
         static_assert(sizeof(KSettings) % 16 == 0 && sizeof(KinLite) % 16 == 0 && sizeof(GParamsLite) % 16 == 0 && sizeof(HeadTables) % 16 == 0 &&
                       sizeof(GParams) % 16 == 0 && (PK_STRIDE * 8) % 16 == 0, "staged in 16-byte pieces");
@@ -457,7 +472,9 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 #ifdef HIPNLP_STAMPS
         st_issued = __builtin_amdgcn_s_memtime();
 #endif
+        if constexpr (TABLES_WITH_STAGING) fetch_tables();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the staging loads of THIS wave have landed in LDS (before it signals the barrier)
+        if constexpr (TABLES_WITH_STAGING) tables_are_here();
 
 #ifdef HIPNLP_STAMPS
         st_loaded = __builtin_amdgcn_s_memtime();
@@ -470,7 +487,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
         if (tid >= 128 && tid < 128 + 8 - NXG) s.xg[NXG + tid - 128] = 0.0;
         // copy-out tables: issued now, consumed at the very end (LATE_TABLES: issued behind the last barrier but one instead — the
         // registers they occupy from here to the end are what stands between the four-wave VARY kernel and a fifth wave per SIMD)
-        if constexpr (!LATE_TABLES) fetch_tables();
+        if constexpr (!LATE_TABLES && !TABLES_WITH_STAGING) fetch_tables();
     }
     lds_barrier();
 
@@ -579,7 +596,10 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     for (int pass_ = 0; pass_ < 2; ++pass_) {
     if (pass_ == 1) { for (int i = 0; i < 8; ++i) st_first[i] = st_arr[i]; st_first0 = st_staged; bid = 0; st_nt = 0; __syncthreads(); st_first[7] = __builtin_amdgcn_s_memtime(); }
 #endif
-    switch (wave) {
+    // (on the wave number as a SCALAR: dispatched on the per-lane value the switch is built out of execution masks — every instance skipped
+    //  by a branch on an empty mask — and the path that skips them all reaches the copy-out with the table fetch unconsumed: the wait that
+    //  tables_are_here() moves in front of the early stores would be back in front of the final ones)
+    switch (__builtin_amdgcn_readfirstlane(wave)) {
         case 0: run_wave(std::integral_constant<int, 0>{}); break;
         case 1: run_wave(std::integral_constant<int, 1>{}); break;
         case 2: run_wave(std::integral_constant<int, 2>{}); break;
@@ -879,8 +899,14 @@ void hipnlp_knot_hess_kernel(HArgs a) {
         if (tid == 0) hx.sigma = sig;
     }
     lds_barrier();
-    // copy-out permutation: fetched behind the fifth barrier, so that its latency hides behind the last phase and its registers (ten
-    // per lane on the smooth terrain) are free while the point tasks run
+    // copy-out permutation.  Compact layout (the batch launches, at their register caps): fetched behind the fifth barrier, so that its
+    // latency hides behind the last phase and its registers (ten per lane on the smooth terrain) are free while the point tasks run.
+    // Full layout (two workgroups per CU, 134 / 184 of 256 VGPRs): fetched at ENTRY.  Its launches into host memory send the run at the
+    // start of the block early (early_out below); a fetch behind those stores is followed by a wait for it, and that wait — the counter is
+    // shared and in order — sits out the acknowledgement of the early stores too: 0.3 - 0.6 MB of a hundred workgroups queued on the link.
+    // Measured before this was understood: the early run a GAIN of 3.7 - 4.7 us per 100-knot Hessian in two sessions and a LOSS of 2 - 3.6 us
+    // (planar) / 6 - 8 us (smooth steps: its run leaves one barrier later and is twice as long) in five others, by the box's link.
+    constexpr int TABLES_AT = LAYOUT == LAYOUT_FULL ? 0 : HIPNLP_HESS_TABLES_AT;
     const HessTables& ht = *a.ht;
     constexpr int HP_ITERS = (hk::COUNT + WG - 1) / WG;
     int cnt = 0, hpc = -1;
@@ -892,17 +918,23 @@ void hipnlp_knot_hess_kernel(HArgs a) {
         hpc = (last && tid < 84) ? ht.perm_couple[tid] : -1;   // (padded with -1 on the host)
     };
     int bar = 0;   // barriers passed (the program is straight-line code: a constant at every use)
-    if (!DIRECT && HIPNLP_HESS_TABLES_AT == 0) fetch_tables();
+    if (!DIRECT && TABLES_AT == 0) fetch_tables();
+    // ... and CONSUMED, as far as the compiler can tell, behind the first barrier of the program (an empty assembly statement that reads
+    // and "writes" them: the wait for the fetch goes there, a phase after its issue, where it is free, and what the copy-out uses is no
+    // longer the result of a load).  Left to the first real use — the copy-out at the
+    // end — the wait would stand behind the early stores: `s_waitcnt vmcnt(0)`, the one counter for loads and stores, i.e. every wave would
+    // sit out the acknowledgement of what it sent to host memory a few microseconds earlier before it may send the rest.
+    auto tables_are_here = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < HP_ITERS; ++it) asm volatile("" : "+v"(hp[it]));
+        asm volatile("" : "+v"(hpc), "+v"(cnt));
+    };
     // early copy-out (see HArgs::early_run): full layout only — the compact kernels sit at their register caps, and their launches are the
     // batch ones, whose hundreds of workgroups spread their stores over the launch by themselves
     constexpr bool EARLY_OUT = !DIRECT && LAYOUT == LAYOUT_FULL;
     constexpr int EARLY_ITERS = 3;   // (early_run <= 768: 394 on the planar terrain, 732 on the smooth steps; hess_launch checks)
-    int32_t hpe[EARLY_ITERS];
+    static_assert(!EARLY_OUT || (TABLES_AT == 0 && EARLY_ITERS <= HP_ITERS), "the early run reads the permutation words fetched at entry");
     const int early_run = EARLY_OUT ? a.early_run : 0;
-    if constexpr (EARLY_OUT) {
-#pragma unroll
-        for (int it = 0; it < EARLY_ITERS; ++it) hpe[it] = ht.perm[min(tid + it * WG, hk::COUNT - 1)];   // (positions behind the run: not used)
-    }
     auto early_out = [&]() __attribute__((always_inline)) {
         if constexpr (EARLY_OUT) {
             if (early_run <= 0) return;
@@ -911,7 +943,7 @@ void hipnlp_knot_hess_kernel(HArgs a) {
             for (int it = 0; it < EARLY_ITERS; ++it) {
                 const int pos = tid + it * WG;
                 // (a store the compiler does not know about, as in hipnlp_knot_kernel: nothing waits for it)
-                if (pos < early_run) asm volatile("global_store_dwordx2 %0, %1, %2 sc0 sc1" ::"v"(pos * 8), "v"(hx.H[hpe[it]]), "s"(out) : "memory");
+                if (pos < early_run) asm volatile("global_store_dwordx2 %0, %1, %2 sc0 sc1" ::"v"(pos * 8), "v"(hx.H[hp[it]]), "s"(out) : "memory");
             }
         }
     };
@@ -926,17 +958,20 @@ void hipnlp_knot_hess_kernel(HArgs a) {
     const unsigned long long st_staged = __builtin_amdgcn_s_memtime();
 #define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
 #define DEV_RH(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
-#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); bid++; if (++bar == HIPNLP_HESS_TABLES_AT) { if constexpr (!DIRECT) fetch_tables(); } if (bar == a.early_phase) early_out();
+#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); bid++; if (++bar == TABLES_AT) { if constexpr (!DIRECT) fetch_tables(); } if constexpr (!DIRECT && TABLES_AT == 0) { if (bar == 1) tables_are_here(); } if (bar == a.early_phase) early_out();
 #else
 #define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_RH(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); }
-#define DEV_BARRIER lds_barrier(); if (++bar == HIPNLP_HESS_TABLES_AT) { if constexpr (!DIRECT) fetch_tables(); } if (bar == a.early_phase) early_out();
+#define DEV_BARRIER lds_barrier(); if (++bar == TABLES_AT) { if constexpr (!DIRECT) fetch_tables(); } if constexpr (!DIRECT && TABLES_AT == 0) { if (bar == 1) tables_are_here(); } if (bar == a.early_phase) early_out();
 #endif
     auto run_wave = [&](auto wc) __attribute__((always_inline)) {
         constexpr int W = decltype(wc)::value;
         HIPNLP_KNOT_HESS_PROGRAM(DEV_KIN, DEV_RH, DEV_BARRIER)
     };
-    switch (wave) {
+    // (dispatched on the wave number as a SCALAR: on the per-lane value the compiler builds the switch out of execution masks — every
+    //  instance skipped by a branch on an empty mask — and a path that skips all four reaches the copy-out with the table fetch unconsumed:
+    //  the wait tables_are_here() moves forward would be back in front of the final stores)
+    switch (__builtin_amdgcn_readfirstlane(wave)) {
         case 0: run_wave(std::integral_constant<int, 0>{}); break;
         case 1: run_wave(std::integral_constant<int, 1>{}); break;
         case 2: run_wave(std::integral_constant<int, 2>{}); break;
@@ -1159,6 +1194,7 @@ struct hipnlp_handle {
     // consecutive calls is page-locked and mapped (hipHostRegister) so that the kernel stores straight into it; every use is verified
     // with a sentinel (below), at most AUTO_MAX ranges per handle, unregistered by hipnlp_destroy
     bool auto_reg = true;
+    bool x_staged = false;        // h_x (and d_x, for handles whose launches read x from HBM) hold the x of the latest host-buffer call
     const void* last_seen[4] = {nullptr, nullptr, nullptr, nullptr};   // grad, g, jac (hipnlp_eval) and Hessian-value (hipnlp_eval_hess) pointers of the previous call (second sight registers)
     const void* in_call[4] = {nullptr, nullptr, nullptr, nullptr};     // output arrays of the call in progress (never evicted by it)
     const void* no_auto[4] = {nullptr, nullptr, nullptr, nullptr};     // pointers that failed to register or failed the sentinel check: left alone
@@ -1914,6 +1950,9 @@ int hipnlp_eval_hess_device(hipnlp_handle* h, const double* x_dev, const double*
     return hess_launch(h, x_dev, obj_factor_dev, lambda_dev, hess_dev, stream ? hipStream_t(stream) : h->stream);
 }
 int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor, const double* lambda, double* hess) {
+    return hipnlp_eval_hess_at(h, x, 1, obj_factor, lambda, hess);
+}
+int hipnlp_eval_hess_at(hipnlp_handle* h, const double* x, int new_x, const double* obj_factor, const double* lambda, double* hess) {
     if (!h || !x || !obj_factor || !lambda || !hess) return HIPNLP_E_INVALID;
     if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
     int rc = hess_prepare(h);
@@ -1931,15 +1970,24 @@ int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor
         HIP_TRY(h, hipHostGetDevicePointer(&hd, h->h_hess, 0));
         h->hd_hess = static_cast<double*>(hd);
     }
-    h->have_result = false;   // (the staging copy of x is shared with hipnlp_eval)
-    std::memcpy(h->h_x, x, B * n * sizeof(double));
+    // x: the staging copy hipnlp_eval uses.  new_x = 0 (IPOPT's flag: eval_h at the x of the callbacks before it — every accepted
+    // iterate): the copy of the previous call IS this x — no 151 KB host copy in front of the launch (3 - 4 us of a 100-knot call); new_x < 0:
+    // unknown, compared; nothing staged yet: copied whatever the flag says
+    bool stage_x = new_x != 0 || !h->x_staged;
+    if (new_x < 0 && h->x_staged) stage_x = x != h->h_x && std::memcmp(x, h->h_x, B * n * sizeof(double)) != 0;
+    if (stage_x) {
+        h->have_result = false;   // (the staging copy of x is shared with hipnlp_eval)
+        h->x_staged = false;
+        std::memcpy(h->h_x, x, B * n * sizeof(double));
+    }
     std::memcpy(h->h_sl, obj_factor, B * sizeof(double));
     std::memcpy(h->h_sl + B, lambda, B * m * sizeof(double));
     const double* xsrc = h->hd_x;   // x: read by the kernel straight from the pinned staging copy, as in hipnlp_eval
     if (!h->x_zero_copy) {
-        HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_x, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (stage_x) HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_x, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
         xsrc = h->d_x;
     }
+    h->x_staged = true;
     const double* sl_dev = h->d_sigma;
     if (h->lam_zero_copy) {   // the kernel gathers the multipliers straight out of the pinned block, no copy command in front of it
         void* hd = nullptr;
@@ -2241,6 +2289,7 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
         HIP_TRY(h, hipSetDevice(h->dev));
         const unsigned to_host = (want | h->prefetch) & HIPNLP_WANT_ALL;
         const auto t0 = std::chrono::steady_clock::now();
+        h->x_staged = false;
         if (x != h->h_x) std::memcpy(h->h_x, x, B * n * sizeof(double));
         const auto t1 = std::chrono::steady_clock::now();
         h->have_result = false;
@@ -2307,6 +2356,7 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
             for (int q = 0; q < 3; ++q) o[q] = sel[q] == 2u ? caller_dev[q] : (sel[q] == 1u ? pinned[q] : hbm[q]);
             rc = launch(h, xsrc, f_host ? h->hd_f : h->d_f, o[0], o[1], o[2], h->stream, nullptr, false, h->time_host, true, nullptr, 0, 0, vary_only);
             if (rc != HIPNLP_OK) return rc;
+            h->x_staged = true;   // (the pinned copy — and the device copy, where the launch reads that — hold this x: hipnlp_eval_hess_at, new_x = 0)
             t2 = std::chrono::steady_clock::now();
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             t3 = std::chrono::steady_clock::now();

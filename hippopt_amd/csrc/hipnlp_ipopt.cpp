@@ -60,7 +60,7 @@ Bool hipnlp_ipopt_eval_jac_g(Index n, Number* x, Bool new_x, Index m, Index nele
 
 Bool hipnlp_ipopt_eval_h(Index n, Number* x, Bool new_x, Number obj_factor, Index m, Number* lambda, Bool new_lambda, Index nele_hess,
                          Index* iRow, Index* jCol, Number* values, UserDataPtr user_data) {
-    (void)new_x; (void)new_lambda;   // (the Hessian is one launch of its own: nothing of the callback quartet is reused)
+    (void)new_lambda;   // (the Hessian is one launch of its own; what it can reuse of the callbacks before it is the staged copy of x: new_x)
     hipnlp_handle* h = static_cast<hipnlp_handle*>(user_data);
     Sizes s;
     int64_t nh = 0;
@@ -70,7 +70,7 @@ Bool hipnlp_ipopt_eval_h(Index n, Number* x, Bool new_x, Number obj_factor, Inde
         return served(hipnlp_hess_sparsity(h, reinterpret_cast<int32_t*>(iRow), reinterpret_cast<int32_t*>(jCol)));
     }
     if (!x || !lambda) return FALSE;
-    return served(hipnlp_eval_hess(h, x, &obj_factor, lambda, values));
+    return served(hipnlp_eval_hess_at(h, x, new_x ? 1 : 0, &obj_factor, lambda, values));
 }
 
 int hipnlp_ipopt_sizes(hipnlp_handle* h, Index* n, Index* m, Index* nele_jac, Index* nele_hess) {

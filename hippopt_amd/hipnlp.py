@@ -25,7 +25,7 @@ EXPORTS = [
     "hipnlp_eval_device_shard", "hipnlp_stage_rows", "hipnlp_reassemble",
     "hipnlp_jac_vary_layout", "hipnlp_fill_jac_constants", "hipnlp_eval_device_vary", "hipnlp_eval_device_shard_vary", "hipnlp_eval_device_peers_vary", "hipnlp_reassemble_scatter",
     "hipnlp_ipc_alloc", "hipnlp_ipc_open", "hipnlp_ipc_close", "hipnlp_ipc_free", "hipnlp_peer_push", "hipnlp_peer_signal", "hipnlp_peer_signal_checked", "hipnlp_peer_wait", "hipnlp_eval_device_peers",
-    "hipnlp_hess_nnz", "hipnlp_hess_sparsity", "hipnlp_eval_hess", "hipnlp_eval_hess_device",
+    "hipnlp_hess_nnz", "hipnlp_hess_sparsity", "hipnlp_eval_hess", "hipnlp_eval_hess_at", "hipnlp_eval_hess_device",
     "hipnlp_eval_pinned", "hipnlp_set_prefetch", "hipnlp_set_early_outputs", "hipnlp_set_host_timing", "hipnlp_host_register", "hipnlp_host_unregister",
     "hipnlp_host_breakdown", "hipnlp_set_auto_register", "hipnlp_host_stats", "hipnlp_set_constant_jacobian", "hipnlp_forget_jac_destination", "hipnlp_jac_constant_mask", "hipnlp_host_release_auto_ranges",
     "hipnlp_pose_create", "hipnlp_pose_destroy", "hipnlp_pose_last_error", "hipnlp_pose_get_dims", "hipnlp_pose_set_params",
@@ -122,6 +122,7 @@ def load_library(path=None):
     lib.hipnlp_hess_nnz.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.hipnlp_hess_sparsity.argtypes = [vp, ip, ip]
     lib.hipnlp_eval_hess.argtypes = [vp, dp, dp, dp, dp]
+    lib.hipnlp_eval_hess_at.argtypes = [vp, dp, C.c_int, dp, dp, dp]
     lib.hipnlp_eval_hess_device.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.hipnlp_kernels_per_eval.argtypes = [vp]
     lib.hipnlp_profile_begin_runs.argtypes = [vp, C.c_int, C.c_int]
@@ -447,16 +448,18 @@ class HipNlp:
         self._check(self.lib.hipnlp_hess_sparsity(self.h, _ip(ir), _ip(jc)))
         return ir, jc
 
-    def eval_hess(self, x, obj_factor, lam, out=None):
+    def eval_hess(self, x, obj_factor, lam, out=None, new_x=True):
         """values [batch][nnz_h] of  obj_factor * hess f + sum_r lam_r hess g_r  at x (obj_factor: scalar or [batch]).
-        out: the array of a previous call to fill again (a fresh 1.2 MB numpy array costs its page faults on every call)."""
+        out: the array of a previous call to fill again (a fresh 1.2 MB numpy array costs its page faults on every call).
+        new_x: IPOPT's flag of eval_h — False: x is the x of the previous eval / eval_hess call on this handle (its staged copy is used);
+        None: unknown (compared)."""
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.batch, self.n)
         lam = np.ascontiguousarray(lam, dtype=np.float64).reshape(self.batch, self.m)
         sig = np.ascontiguousarray(np.broadcast_to(np.asarray(obj_factor, dtype=np.float64), (self.batch,)))
         if out is None:
             out = np.empty((self.batch, self.hess_nnz()))
             self._transient_hess = out     # (see eval: no two consecutive calls on the same freshly allocated address)
-        self._check(self.lib.hipnlp_eval_hess(self.h, _dp(x), _dp(sig), _dp(lam), _dp(out)))
+        self._check(self.lib.hipnlp_eval_hess_at(self.h, _dp(x), -1 if new_x is None else int(bool(new_x)), _dp(sig), _dp(lam), _dp(out)))
         return out
 
     def eval_hess_device(self, x_ptr, obj_factor_ptr, lam_ptr, hess_ptr, stream=None):

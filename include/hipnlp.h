@@ -369,6 +369,11 @@ int hipnlp_host_stats(const hipnlp_handle* h, long* out /*[8]*/);
 int hipnlp_hess_nnz(hipnlp_handle* h, int64_t* nnz_h);
 int hipnlp_hess_sparsity(hipnlp_handle* h, int32_t* irow, int32_t* jcol);
 int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor, const double* lambda, double* values);
+/* The same with IPOPT's new_x flag (Eval_H_CB: FALSE when x is the x of the evaluation callbacks before it — the case at every accepted
+ * iterate): new_x = 0 = the x of the previous host-buffer call on this handle (hipnlp_eval*, hipnlp_eval_hess*) — its staged copy is
+ * used, no host copy of x in front of the launch; new_x < 0 = unknown (compared); anything else, or nothing staged yet: x is copied.
+ * hipnlp_eval_hess is new_x = 1; hipnlp_ipopt_eval_h passes IPOPT's flag. */
+int hipnlp_eval_hess_at(hipnlp_handle* h, const double* x, int new_x, const double* obj_factor, const double* lambda, double* values);
 int hipnlp_eval_hess_device(hipnlp_handle* h, const double* x_dev, const double* obj_factor_dev, const double* lambda_dev,
                             double* values_dev, void* stream);
 /* Device-resident variant: all pointers are device pointers on desc.device (or device-visible addresses of registered host

@@ -95,6 +95,32 @@ def test_new_x_unknown_is_decided_by_comparison(model, HipNlp):
     assert k0 > 0.0
 
 
+def test_hessian_with_ipopts_new_x_flag_uses_the_staged_x(model, HipNlp):
+    """hipnlp_eval_hess_at: new_x = FALSE (IPOPT's eval_h at an accepted iterate: the x of the callbacks before it) skips the host copy
+    of x and evaluates at the x the previous host-buffer call staged — the same bits as the plain call; with nothing staged the flag is
+    ignored; `unknown` is decided by comparison"""
+    st = periodic_step_settings(12, model)
+    x, p = make_workload(st, model, batch=1, seed=4410)
+    xs = iterates(x, 3)
+    eng = HipNlp(st, model)
+    eng.set_params(p)
+    lam = np.random.RandomState(5).standard_normal((1, eng.m))
+    ref = [eng.eval_hess(xi, 0.7, lam).copy() for xi in xs]
+    assert not np.array_equal(ref[0], ref[1])
+    fresh = HipNlp(st, model)
+    fresh.set_params(p)
+    assert np.array_equal(fresh.eval_hess(xs[1], 0.7, lam, new_x=False), ref[1])        # nothing staged yet: copied whatever the flag says
+    fresh.eval(xs[2], want=("f", "g"))                                                   # IPOPT's sequence: callbacks at x, then eval_h(new_x = FALSE)
+    assert np.array_equal(fresh.eval_hess(xs[2], 0.7, lam, new_x=False), ref[2])
+    assert np.array_equal(fresh.eval_hess(xs[0], 0.7, lam, new_x=False), ref[2])        # the CONTRACT: the staged x, not the argument
+    assert np.array_equal(fresh.eval_hess(xs[0], 0.7, lam, new_x=None), ref[0])         # unknown: compared, differs, copied
+    assert np.array_equal(fresh.eval_hess(xs[0].copy(), 0.7, lam, new_x=None), ref[0])  # unknown: equal values in another array
+    assert np.array_equal(fresh.eval_hess(xs[1], 0.7, lam), ref[1])                     # the plain call: new x
+    # and the callbacks after a Hessian at a new x see that x as staged (new_x = False serves the cached evaluation only if there is one)
+    f_ref = eng.eval(xs[1], want=("f",))[0][0]
+    assert fresh.eval(xs[1], new_x=None, want=("f",))[0][0] == f_ref
+
+
 def test_hessian_value_array_is_registered_at_its_second_sight_and_verified(model, HipNlp):
     """hipnlp_eval_hess: the caller's value array (IPOPT evaluates the Hessian into the value array of its own matrix) becomes a direct
     kernel output at its second consecutive sight, verified by the sentinel words like the callback outputs; the values are those of
