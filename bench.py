@@ -381,6 +381,7 @@ def time_hessian(eng, x_np, knots):
     eng.unregister_outputs([hv])    # (the handle registered the value array by itself: released before the array goes away)
     res["host_visible_ms"] = 1e3 * min(passes)
     res["host_visible_ms_new_x_false"] = 1e3 * min(same_x)
+    res["early_run"] = eng.hessian_early_run()    # (what the handle decided from its own first calls on THIS host, and the two minima in us)
     res["host_visible_note"] = ("hipnlp_eval_hess through host buffers, new x every call, the caller's value array reused (registered by the handle, direct kernel "
                                 "stores, the run at the start of every knot block leaving early): the fastest of 4 passes of 50 calls; slowest pass %.3f ms" % (1e3 * max(passes)))
     return res

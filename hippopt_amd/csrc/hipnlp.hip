@@ -1151,6 +1151,11 @@ struct hipnlp_handle {
     hipnlp_dims dims{};         // hipnlp_get_dims, filled by hipnlp_create
     bool early_store_always = false;   // diagnostic (HIPNLP_EARLY_STORE=2): also for hipnlp_eval_device launches
     bool early_store = true;    // launches into host memory store what is final after the second phase then (diagnostic override: HIPNLP_EARLY_STORE=0)
+    // hipnlp_eval_hess*: the run at the start of every knot block leaves early (HArgs::early_run) — 1 / 0, or -1 = decided by the handle from
+    // its own first calls (hipnlp_set_hessian_early_run).  The same kernel, the same values either way; which one is faster depends on
+    // the HOST: 4 us sooner per 100-knot Hessian on some boxes of one pool, 2 - 3 us later on others (profiles/r05_early_stores_by_box.txt).
+    int hess_early_mode = -1, hess_early_choice = -1, hess_tune_calls = 0;
+    double hess_tune_best[2] = {1e30, 1e30};
     bool hess_compact = false;   // exact Hessian: compact-scratch instantiation (three workgroups per CU) for launches of more than 512 workgroups
     bool hess_direct = true;     // ... and, planar terrain into device memory, the instantiation without LDS staging of the entries (diagnostic override: HIPNLP_HESS_DIRECT=0)
     int dev = 0;
@@ -1350,6 +1355,7 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     if (const char* cj = diag_env("HIPNLP_CONST_JAC")) h->skip_const = std::atoi(cj) != 0;   // diagnostic override of hipnlp_set_constant_jacobian's default
     if (const char* vc = diag_env("HIPNLP_VARY_CHECK")) h->vary_check = std::atoi(vc) != 0;
     if (const char* es = diag_env("HIPNLP_EARLY_STORE")) { h->early_store = std::atoi(es) != 0; h->early_store_always = std::atoi(es) == 2; }   // diagnostic override (A/B in one process)
+    if (const char* he = diag_env("HIPNLP_HESS_EARLY_RUN")) h->hess_early_mode = std::atoi(he);   // diagnostic: -1 / 0 / 1, as hipnlp_set_hessian_early_run
     h->np = ParamOffsets(st.horizon).np();
     if (h->L.jperm_glob.size() > 16) return fail(HIPNLP_E_INVALID, "internal: too many global-column entries");
 
@@ -1905,7 +1911,7 @@ int hipnlp_hess_sparsity(hipnlp_handle* h, int32_t* irow, int32_t* jcol) {
     return HIPNLP_OK;
 }
 static int hess_launch(hipnlp_handle* h, const double* x_dev, const double* sigma_dev, const double* lambda_dev, double* hess_dev, hipStream_t s,
-                       bool host_block = false) {
+                       bool host_block = false, bool early = false) {
     HArgs a;
     a.tb = h->d_tb; a.ht = h->d_ht; a.x = x_dev; a.pk = h->d_pk; a.gp = h->d_gp;
     a.sigma = sigma_dev; a.lambda = lambda_dev; a.hess = hess_dev; a.flag = h->d_hflag;
@@ -1920,7 +1926,7 @@ static int hess_launch(hipnlp_handle* h, const double* x_dev, const double* sigm
         h->hseq = 0;
     }
     a.seq = ++h->hseq; a.nnz_knot = h->HL.nnz_knot;
-    a.early_run = (host_block && h->early_store && !h->hess_compact && h->HL.early_run <= 3 * 256) ? h->HL.early_run : 0;
+    a.early_run = (host_block && early && !h->hess_compact && h->HL.early_run <= 3 * 256) ? h->HL.early_run : 0;
     a.early_phase = a.early_run > 0 ? h->HL.early_phase : 0;
 #ifdef HIPNLP_STAMPS
     if (!h->d_stamps) HIP_TRY(h, hipMalloc(&h->d_stamps, size_t(h->nk) * size_t(h->batch) * 1024 * sizeof(unsigned long long)));
@@ -2011,16 +2017,36 @@ int hipnlp_eval_hess_at(hipnlp_handle* h, const double* x, int new_x, const doub
         __atomic_store_n(&w[0], sentinel, __ATOMIC_RELAXED);
         __atomic_store_n(&w[hbytes / 8 - 1], sentinel, __ATOMIC_RELAXED);
     }
-    rc = hess_launch(h, xsrc, sl_dev, sl_dev + B, direct ? direct : h->hd_hess, h->stream, true);
+    // early run: forced on / off, or — the default — tried both ways on the handle's own first calls (three calls to warm up, then six
+    // of each kind alternating, launch to completion on the host's clock, the faster minimum wins): which way is faster is a property of
+    // the host the call runs on, not of the kernel
+    constexpr int TUNE_WARM = 3, TUNE_SAMPLES = 12;
+    bool early = h->early_store && h->hess_early_mode != 0;
+    bool sample = false;
+    if (h->early_store && h->hess_early_mode < 0) {
+        if (h->hess_early_choice >= 0) early = h->hess_early_choice != 0;
+        else {
+            const int c = h->hess_tune_calls++;
+            sample = c >= TUNE_WARM;
+            early = sample ? ((c - TUNE_WARM) & 1) != 0 : true;
+        }
+    }
+    const auto t_launch = std::chrono::steady_clock::now();
+    rc = hess_launch(h, xsrc, sl_dev, sl_dev + B, direct ? direct : h->hd_hess, h->stream, true, early);
     if (rc != HIPNLP_OK) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (sample) {
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_launch).count();
+        h->hess_tune_best[early ? 1 : 0] = std::min(h->hess_tune_best[early ? 1 : 0], us);
+        if (h->hess_tune_calls >= TUNE_WARM + TUNE_SAMPLES) h->hess_early_choice = h->hess_tune_best[1] <= h->hess_tune_best[0] ? 1 : 0;
+    }
     if (sentinel) {
         const u64* w = reinterpret_cast<const u64*>(hess);
         if (__atomic_load_n(&w[0], __ATOMIC_RELAXED) == sentinel || __atomic_load_n(&w[hbytes / 8 - 1], __ATOMIC_RELAXED) == sentinel) {
             (void)drop_stale_range(h, hess);
             h->no_auto[3] = hess;
             h->auto_fallbacks++;
-            rc = hess_launch(h, xsrc, sl_dev, sl_dev + B, h->hd_hess, h->stream, true);
+            rc = hess_launch(h, xsrc, sl_dev, sl_dev + B, h->hd_hess, h->stream, true, early);
             if (rc != HIPNLP_OK) return rc;
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             direct = nullptr;
@@ -2529,6 +2555,21 @@ int hipnlp_set_early_outputs(hipnlp_handle* h, int on) {
     h->early = on != 0;
     h->early_grad = on == 2;   // grad f only on explicit request: IPOPT's adapter hands eval_grad_f the storage of ITS OWN gradient vector
     if (!h->early) { h->early_mask = 0; }
+    return HIPNLP_OK;
+}
+
+int hipnlp_set_hessian_early_run(hipnlp_handle* h, int mode) {
+    if (!h || mode < -1 || mode > 1) return HIPNLP_E_INVALID;
+    h->hess_early_mode = mode;
+    h->hess_early_choice = -1; h->hess_tune_calls = 0; h->hess_tune_best[0] = h->hess_tune_best[1] = 1e30;   // (auto: decided afresh)
+    return HIPNLP_OK;
+}
+int hipnlp_get_hessian_early_run(const hipnlp_handle* h, int* mode, int* chosen, double* us_off, double* us_on) {
+    if (!h) return HIPNLP_E_INVALID;
+    if (mode) *mode = h->hess_early_mode;
+    if (chosen) *chosen = h->hess_early_mode >= 0 ? h->hess_early_mode : h->hess_early_choice;
+    if (us_off) *us_off = h->hess_tune_best[0] < 1e29 ? h->hess_tune_best[0] : 0.0;
+    if (us_on) *us_on = h->hess_tune_best[1] < 1e29 ? h->hess_tune_best[1] : 0.0;
     return HIPNLP_OK;
 }
 

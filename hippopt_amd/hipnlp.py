@@ -25,7 +25,7 @@ EXPORTS = [
     "hipnlp_eval_device_shard", "hipnlp_stage_rows", "hipnlp_reassemble",
     "hipnlp_jac_vary_layout", "hipnlp_fill_jac_constants", "hipnlp_eval_device_vary", "hipnlp_eval_device_shard_vary", "hipnlp_eval_device_peers_vary", "hipnlp_reassemble_scatter",
     "hipnlp_ipc_alloc", "hipnlp_ipc_open", "hipnlp_ipc_close", "hipnlp_ipc_free", "hipnlp_peer_push", "hipnlp_peer_signal", "hipnlp_peer_signal_checked", "hipnlp_peer_wait", "hipnlp_eval_device_peers",
-    "hipnlp_hess_nnz", "hipnlp_hess_sparsity", "hipnlp_eval_hess", "hipnlp_eval_hess_at", "hipnlp_eval_hess_device",
+    "hipnlp_hess_nnz", "hipnlp_hess_sparsity", "hipnlp_eval_hess", "hipnlp_eval_hess_at", "hipnlp_set_hessian_early_run", "hipnlp_get_hessian_early_run", "hipnlp_eval_hess_device",
     "hipnlp_eval_pinned", "hipnlp_set_prefetch", "hipnlp_set_early_outputs", "hipnlp_set_host_timing", "hipnlp_host_register", "hipnlp_host_unregister",
     "hipnlp_host_breakdown", "hipnlp_set_auto_register", "hipnlp_host_stats", "hipnlp_set_constant_jacobian", "hipnlp_forget_jac_destination", "hipnlp_jac_constant_mask", "hipnlp_host_release_auto_ranges",
     "hipnlp_pose_create", "hipnlp_pose_destroy", "hipnlp_pose_last_error", "hipnlp_pose_get_dims", "hipnlp_pose_set_params",
@@ -123,6 +123,8 @@ def load_library(path=None):
     lib.hipnlp_hess_sparsity.argtypes = [vp, ip, ip]
     lib.hipnlp_eval_hess.argtypes = [vp, dp, dp, dp, dp]
     lib.hipnlp_eval_hess_at.argtypes = [vp, dp, C.c_int, dp, dp, dp]
+    lib.hipnlp_set_hessian_early_run.argtypes = [vp, C.c_int]
+    lib.hipnlp_get_hessian_early_run.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), dp, dp]
     lib.hipnlp_eval_hess_device.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.hipnlp_kernels_per_eval.argtypes = [vp]
     lib.hipnlp_profile_begin_runs.argtypes = [vp, C.c_int, C.c_int]
@@ -461,6 +463,18 @@ class HipNlp:
             self._transient_hess = out     # (see eval: no two consecutive calls on the same freshly allocated address)
         self._check(self.lib.hipnlp_eval_hess_at(self.h, _dp(x), -1 if new_x is None else int(bool(new_x)), _dp(sig), _dp(lam), _dp(out)))
         return out
+
+    def set_hessian_early_run(self, mode):
+        """eval_hess into host memory: the run at the start of every knot block leaves early — True / False, or None: the handle decides from
+        its own first calls (the default; include/hipnlp.h)"""
+        self._check(self.lib.hipnlp_set_hessian_early_run(self.h, -1 if mode is None else int(bool(mode))))
+
+    def hessian_early_run(self):
+        """{"mode": None | bool, "in_use": None (not decided yet) | bool, "us_off", "us_on": the minima the decision rests on}"""
+        mode, chosen, off, on = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+        self._check(self.lib.hipnlp_get_hessian_early_run(self.h, C.byref(mode), C.byref(chosen), C.byref(off), C.byref(on)))
+        tri = lambda v: None if v < 0 else bool(v)  # noqa: E731
+        return {"mode": tri(mode.value), "in_use": tri(chosen.value), "us_off": off.value, "us_on": on.value}
 
     def eval_hess_device(self, x_ptr, obj_factor_ptr, lam_ptr, hess_ptr, stream=None):
         vp = C.c_void_p

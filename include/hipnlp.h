@@ -374,6 +374,14 @@ int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor
  * used, no host copy of x in front of the launch; new_x < 0 = unknown (compared); anything else, or nothing staged yet: x is copied.
  * hipnlp_eval_hess is new_x = 1; hipnlp_ipopt_eval_h passes IPOPT's flag. */
 int hipnlp_eval_hess_at(hipnlp_handle* h, const double* x, int new_x, const double* obj_factor, const double* lambda, double* values);
+/* hipnlp_eval_hess* into host memory: the run at the start of every knot block (the point columns: a quarter of the values on the planar
+ * terrain, two fifths on the smooth steps) is final long before the program ends and can leave then — the same kernel, the same values,
+ * bit for bit.  Whether that is FASTER is a property of the host: measured 4 us sooner per 100-knot Hessian on some boxes of one pool and
+ * 2 - 3 us later on others.  mode 1 / 0: on / off; -1 (the default): the handle tries both on its own first calls (three to warm up, six
+ * of each kind, launch to completion on the host's clock) and keeps the faster one; setting a mode starts that over.
+ * hipnlp_get_hessian_early_run: the mode, what is in use (-1: not decided yet) and the two minima in microseconds (0: not measured). */
+int hipnlp_set_hessian_early_run(hipnlp_handle* h, int mode);
+int hipnlp_get_hessian_early_run(const hipnlp_handle* h, int* mode, int* chosen, double* us_off, double* us_on);
 int hipnlp_eval_hess_device(hipnlp_handle* h, const double* x_dev, const double* obj_factor_dev, const double* lambda_dev,
                             double* values_dev, void* stream);
 /* Device-resident variant: all pointers are device pointers on desc.device (or device-visible addresses of registered host

@@ -270,9 +270,9 @@ def test_early_copy_out_of_the_hessian_host_path_changes_no_bit(model, HipNlp, t
     """hipnlp_eval_hess through host buffers: the entries at the start of a knot's block — the point columns, a quarter (planar) to two fifths
     (smooth steps) of its bytes — are all emitted in the first phases of the Hessian program and leave behind that barrier, written
     through the L2, while the kinematic phases still run; the copy-out at the end skips them.  Which entries those are is RECORDED
-    (HessLayout::pos_phase: every entry is emitted exactly once).  Bit for bit the handle without the early pass (HIPNLP_EARLY_STORE=0 on the
-    diagnostic build) and the device path, with fresh value arrays (pinned block) and a reused one (registered by the handle: direct stores);
-    a batch of two and a shard handle too (the run of a shard's first knot starts where its values do)."""
+    (HessLayout::pos_phase: every entry is emitted exactly once).  Bit for bit the handle without the early pass
+    (hipnlp_set_hessian_early_run) and the device path, with fresh value arrays (pinned block) and a reused one (registered by the handle:
+    direct stores); a batch of two and a shard handle too (the run of a shard's first knot starts where its values do)."""
     import torch
     from hippopt_amd.kinodyn_settings import stairs_settings
     from hippopt_amd.synthetic import place_on_step_flanks
@@ -282,9 +282,10 @@ def test_early_copy_out_of_the_hessian_host_path_changes_no_bit(model, HipNlp, t
         if terrain == "stairs":
             place_on_step_flanks(x, st, seed=4850)
         engs = []
-        for flag in ("1", "0"):
-            with diag_overrides(HIPNLP_EARLY_STORE=flag) as lib:
-                engs.append(HipNlp(st, model, batch=B, library=lib, **kw))
+        for flag in (True, False):
+            engs.append(HipNlp(st, model, batch=B, **kw))
+            engs[-1].set_hessian_early_run(flag)
+            assert engs[-1].hessian_early_run()["mode"] is flag and engs[-1].hessian_early_run()["in_use"] is flag
             engs[-1].set_params(p)
         dev_eng = HipNlp(st, model, batch=B, **kw)      # the product library's device path: its own staged launch, everything stored at the end
         dev_eng.set_params(p)
@@ -309,6 +310,34 @@ def test_early_copy_out_of_the_hessian_host_path_changes_no_bit(model, HipNlp, t
         assert engs[0].host_stats()["auto_fallbacks"] == 0
         for e in engs + [dev_eng]:
             e.close()
+
+
+def test_hessian_early_run_is_decided_by_the_handle_from_its_own_first_calls(model, HipNlp):
+    """Default mode of hipnlp_set_hessian_early_run: whether the run at the start of every knot block leaves early is faster is a property
+    of the HOST (measured both ways on boxes of one pool), so the handle tries both on its first calls — three to warm up, six of each kind —
+    and keeps the faster; the values are the same bits whatever it does, and setting a mode starts the trial over."""
+    st = periodic_step_settings(30, model)
+    x, p = make_workload(st, model, batch=1, seed=4870)
+    eng, ref = HipNlp(st, model), HipNlp(st, model)
+    for e in (eng, ref):
+        e.set_params(p)
+    ref.set_hessian_early_run(False)
+    lam = np.random.RandomState(2).standard_normal((1, eng.m))
+    out, want = np.empty((1, eng.hess_nnz())), np.empty((1, eng.hess_nnz()))
+    assert eng.hessian_early_run() == {"mode": None, "in_use": None, "us_off": 0.0, "us_on": 0.0}
+    xs = iterates(x, 5)
+    for i in range(20):
+        eng.eval_hess(xs[i % 5], 0.9, lam, out=out)
+        ref.eval_hess(xs[i % 5], 0.9, lam, out=want)
+        assert np.array_equal(out, want), i
+        state = eng.hessian_early_run()
+        assert (state["in_use"] is None) == (i < 14), (i, state)        # decided by the fifteenth call (3 + 12)
+    assert state["mode"] is None and state["us_off"] > 0.0 and state["us_on"] > 0.0
+    assert state["in_use"] == (state["us_on"] <= state["us_off"])
+    eng.set_hessian_early_run(None)                                     # the trial starts over
+    assert eng.hessian_early_run()["in_use"] is None
+    eng.close()
+    ref.close()
 
 
 def test_arrays_the_wrapper_allocates_itself_are_never_page_locked(model, HipNlp):

@@ -10,8 +10,8 @@ OUT=gpurun_out/early_boxes_$(date +%H%M%S).txt
   echo "--- callback path (hipnlp_eval, all four outputs, varying-first): early store 1 / 0"
   timeout -k 10 200 python3 tools/diag/early_store_time.py 2>&1 | grep -v amdgpu.ids | cut -c1-200
   echo "--- exact Hessian, planar"
-  timeout -k 10 200 python3 tools/diag/hess_early_ab.py 2>&1 | grep -v amdgpu.ids | cut -c1-80
+  timeout -k 10 200 python3 tools/diag/hess_early_ab.py 2>&1 | grep -v amdgpu.ids | cut -c1-160
   echo "--- exact Hessian, smooth steps"
-  HESS_WORKLOAD=stairs timeout -k 10 200 python3 tools/diag/hess_early_ab.py 2>&1 | grep -v amdgpu.ids | cut -c1-80
+  HESS_WORKLOAD=stairs timeout -k 10 200 python3 tools/diag/hess_early_ab.py 2>&1 | grep -v amdgpu.ids | cut -c1-160
 } > $OUT 2>&1
 cat $OUT

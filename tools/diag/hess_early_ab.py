@@ -1,10 +1,8 @@
 #!/usr/bin/env python3
 """GPU box: hipnlp_eval_hess through host buffers (value array registered by the handle: direct kernel stores), two handles in one
-process alternating — every entry stored at the end of a knot's program (HIPNLP_EARLY_STORE=0 on the diagnostic build) against the run at
-the start of a knot's block leaving behind its barrier (the default).  HESS_N, HESS_WORKLOAD=periodic|stairs."""
+process alternating — every entry stored at the end of a knot's program against the run at the start of a knot's block leaving behind its
+barrier (hipnlp_set_hessian_early_run 0 / 1), and what a third handle left to decide by itself chose.  HESS_N, HESS_WORKLOAD=periodic|stairs."""
 import os
-# (the environment overrides below exist in the diagnostic build of the library only: __graft_entry__.build() -> tests/_build)
-DIAG_SO = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "_build", "libhipnlp_diag.so")
 import sys
 import time
 
@@ -21,11 +19,10 @@ model = synthetic_ergocub()
 st = (stairs_settings if os.environ.get("HESS_WORKLOAD") == "stairs" else periodic_step_settings)(N, model)
 x, p = make_workload(st, model, batch=1, seed=3)
 engs = {}
-for tag, env in (("at the end", "0"), ("early run", "1")):
-    os.environ["HIPNLP_EARLY_STORE"] = env
-    engs[tag] = HipNlp(st, model, library=DIAG_SO)
+for tag, mode in (("at the end", False), ("early run", True), ("decided by handle", None)):
+    engs[tag] = HipNlp(st, model)
+    engs[tag].set_hessian_early_run(mode)
     engs[tag].set_params(p)
-del os.environ["HIPNLP_EARLY_STORE"]
 lam = np.random.RandomState(0).standard_normal((1, engs["early run"].m))
 xs = [x + 1e-4 * i for i in range(4)]
 outs = {t: e.eval_hess(x, 1.0, lam).copy() for t, e in engs.items()}
@@ -41,4 +38,4 @@ for rep in range(5):
             e.eval_hess(xs[i % 4], 1.0, lam, out=outs[t])
         best[t] = min(best[t], (time.perf_counter() - t0) / 100)
 for t in engs:
-    print("%-14s %.1f us per hipnlp_eval_hess (N = %d, best of 5 x 100 calls)" % (t, 1e6 * best[t], N), engs[t].host_stats())
+    print("%-18s %.1f us per hipnlp_eval_hess (N = %d, best of 5 x 100 calls)  %s" % (t, 1e6 * best[t], N, engs[t].hessian_early_run()))
