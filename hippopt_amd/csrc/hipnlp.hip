@@ -762,9 +762,10 @@ struct HArgs {
     int64_t hstride, hoff;  // values of trajectory b start at hess + b * hstride; the handle's first knot block sits at -hoff
     // launches into HOST memory (full layout): the entries [0, early_run) of a knot's block — the point columns come first in (column,
     // row) order — are all emitted in the first three phases (HessLayout::early_run: recorded, every entry is emitted exactly once); they
-    // leave behind the third barrier, written through the L2, while the kinematic phases still run: a quarter (planar) to two fifths
-    // (smooth steps) of a knot's bytes are on the link three phases before the program ends.  0: everything at the end.
-    int32_t early_run, early_phase;
+    // leave behind the barrier that makes them final (hess_early_phase: the second on the planar terrain, the third on the smooth steps),
+    // written through the L2, while the kinematic phases still run: a quarter (planar) to two fifths (smooth steps) of a knot's bytes are
+    // on the link three phases before the program ends.  0: everything at the end.
+    int32_t early_run;
 #ifdef HIPNLP_STAMPS
     unsigned long long* stamps;  // diagnostic build only (tools/diag/hess_stamps.py): [blocks][8][128] s_memtime per wave
 #endif
@@ -806,6 +807,7 @@ template <int TERRAIN, int LAYOUT, bool DIRECT = false> struct DevEmH {
 //                  reads them: those rows are linear) — 52 KB: THREE workgroups per CU, 168 VGPRs.
 //   DIRECT (compact layout, planar terrain, device destinations): no staging of the entries at all (DevEmH) — 40.5 KB: FOUR workgroups per
 //                  CU, 128 VGPRs.
+constexpr int hess_early_phase(int terrain) { return terrain == HIPNLP_TERRAIN_PLANAR ? 2 : 3; }
 template <int TERRAIN, int LAYOUT, bool DIRECT = false> __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(DIRECT ? 4 : (LAYOUT == LAYOUT_COMPACT ? 3 : 2), DIRECT ? 4 : (LAYOUT == LAYOUT_COMPACT ? 3 : 2))))
 void hipnlp_knot_hess_kernel(HArgs a) {
@@ -934,6 +936,10 @@ void hipnlp_knot_hess_kernel(HArgs a) {
     constexpr bool EARLY_OUT = !DIRECT && LAYOUT == LAYOUT_FULL;
     constexpr int EARLY_ITERS = 3;   // (early_run <= 768: 394 on the planar terrain, 732 on the smooth steps; hess_launch checks)
     static_assert(!EARLY_OUT || (TABLES_AT == 0 && EARLY_ITERS <= HP_ITERS), "the early run reads the permutation words fetched at entry");
+    // the barrier behind which the run leaves: a constant of the program (two phases emit the planar point columns, three those of the smooth
+    // steps), so that the stores stand in the code ONCE per wave, not behind every barrier; hess_launch arms the run only where the
+    // recorded layout says the same (HessLayout::early_phase)
+    constexpr int EARLY_PHASE = hess_early_phase(TERRAIN);
     const int early_run = EARLY_OUT ? a.early_run : 0;
     auto early_out = [&]() __attribute__((always_inline)) {
         if constexpr (EARLY_OUT) {
@@ -958,11 +964,11 @@ void hipnlp_knot_hess_kernel(HArgs a) {
     const unsigned long long st_staged = __builtin_amdgcn_s_memtime();
 #define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
 #define DEV_RH(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
-#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); bid++; if (++bar == TABLES_AT) { if constexpr (!DIRECT) fetch_tables(); } if constexpr (!DIRECT && TABLES_AT == 0) { if (bar == 1) tables_are_here(); } if (bar == a.early_phase) early_out();
+#define DEV_BARRIER st_arr[bid] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[bid] = __builtin_amdgcn_s_memtime(); bid++; if (++bar == TABLES_AT) { if constexpr (!DIRECT) fetch_tables(); } if constexpr (!DIRECT && TABLES_AT == 0) { if (bar == 1) tables_are_here(); } if (bar == EARLY_PHASE) early_out();
 #else
 #define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_RH(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); }
-#define DEV_BARRIER lds_barrier(); if (++bar == TABLES_AT) { if constexpr (!DIRECT) fetch_tables(); } if constexpr (!DIRECT && TABLES_AT == 0) { if (bar == 1) tables_are_here(); } if (bar == a.early_phase) early_out();
+#define DEV_BARRIER lds_barrier(); if (++bar == TABLES_AT) { if constexpr (!DIRECT) fetch_tables(); } if constexpr (!DIRECT && TABLES_AT == 0) { if (bar == 1) tables_are_here(); } if (bar == EARLY_PHASE) early_out();
 #endif
     auto run_wave = [&](auto wc) __attribute__((always_inline)) {
         constexpr int W = decltype(wc)::value;
@@ -1926,8 +1932,7 @@ static int hess_launch(hipnlp_handle* h, const double* x_dev, const double* sigm
         h->hseq = 0;
     }
     a.seq = ++h->hseq; a.nnz_knot = h->HL.nnz_knot;
-    a.early_run = (host_block && early && !h->hess_compact && h->HL.early_run <= 3 * 256) ? h->HL.early_run : 0;
-    a.early_phase = a.early_run > 0 ? h->HL.early_phase : 0;
+    a.early_run = (host_block && early && !h->hess_compact && h->HL.early_run <= 3 * 256 && h->HL.early_phase == hess_early_phase(h->d.settings.terrain)) ? h->HL.early_run : 0;
 #ifdef HIPNLP_STAMPS
     if (!h->d_stamps) HIP_TRY(h, hipMalloc(&h->d_stamps, size_t(h->nk) * size_t(h->batch) * 1024 * sizeof(unsigned long long)));
     a.stamps = h->d_stamps;
