@@ -70,6 +70,8 @@ def parse_args():
     ap.add_argument("--force-sharded", action="store_true", help="exercise the sharded paths on one GPU (debug)")
     ap.add_argument("--exchange-every-entry", action="store_true",
                     help="N > 1: CCS-order shard handles whose exchanges move every entry of jac g on every step (round 4's exchanges; default: the varying entries only)")
+    ap.add_argument("--no-numa-pin", action="store_true",
+                    help="do not restrict the process to the CPUs of the card's NUMA node (the host-buffer legs are 2 - 5 us slower per call from the other socket)")
     ap.add_argument("--details-out", default=None, help="also write the full record (the BENCH_DETAILS line) to this file")
     return ap.parse_args()
 
@@ -141,7 +143,7 @@ def compact_line(d):
     out["build"] = (d.get("build") or "")[:120]
     out["config"] = {"workload": cfg.get("workload"), "horizon": cfg.get("horizon"), "batch": cfg.get("batch"), "n": cfg.get("n"), "m": cfg.get("m"),
                      "nnz": cfg.get("nnz"), "jac_order": (cfg.get("jac_order") or "").split(":")[0].split(",")[0][:48], "ranks": cfg.get("ranks"),
-                     "exchange": cfg.get("exchange")}
+                     "exchange": cfg.get("exchange"), "numa": (cfg.get("numa") or "")[:60] or None}
     out["roofline"] = {k: _sig(roof.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms",
                                                      "algorithmic_bytes_per_knot", "bytes_moved_per_knot", "frac_moved")}
     cb = d.get("cpu_baseline")
@@ -842,6 +844,13 @@ def main():
         raise SystemExit("bench.py: rank %d has no device %d (%d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # the process on the side of the host its card hangs off, before anything it will hand to the library is allocated (first touch): the
+    # host-buffer legs are link-bound and measured 2 - 5 us per call slower from the other socket (profiles/r05_early_stores_by_box.txt);
+    # what a deployment does with numactl / sched_setaffinity — hippopt_amd.hipnlp.pin_to_device_numa_node
+    numa = None
+    if not args.no_numa_pin:
+        from hippopt_amd.hipnlp import pin_to_device_numa_node
+        numa = pin_to_device_numa_node(local_rank)
     if world > 1:
         import datetime
         limit = datetime.timedelta(seconds=240)   # a collective one rank never reaches fails on the others instead of hanging the line
@@ -1409,6 +1418,7 @@ def main():
         }
         from hippopt_amd.hipnlp import build_info
         line["build"] = build_info()
+        line["config"]["numa"] = ("process pinned to the %d allowed CPUs of NUMA node %d, the card's" % (numa["cpus"], numa["node"])) if numa else "process not pinned (--no-numa-pin, or the card's node unknown)"
         if valu and kern_ms > 0:
             ginst = valu * local_knots / (kern_ms * 1e-3) / 1e9
             line["roofline"]["valu"] = {"bound": "fp64 valu issue", "achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",

@@ -23,6 +23,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <cctype>
 #include <tuple>
 #include <type_traits>
 #include <vector>
@@ -1306,6 +1307,22 @@ int hipnlp_abi_version(void) { return HIPNLP_ABI_VERSION; }
 #define HIPNLP_BUILD_VARIANT "plain hipcc"
 #endif
 const char* hipnlp_build_info(void) { return "gfx950; " HIPNLP_BUILD_VARIANT; }
+
+// NUMA node of the host the card hangs off (Linux sysfs of its PCI function); -1: not known
+int hipnlp_device_numa_node(int device, int* node) {
+    if (!node) return HIPNLP_E_INVALID;
+    *node = -1;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, int(sizeof bus), device) != hipSuccess) { (void)hipGetLastError(); return HIPNLP_E_NODEVICE; }
+    for (char* c = bus; *c; ++c) *c = char(std::tolower(static_cast<unsigned char>(*c)));
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+    if (FILE* f = std::fopen(path.c_str(), "r")) {
+        int n = -1;
+        if (std::fscanf(f, "%d", &n) == 1) *node = n;
+        std::fclose(f);
+    }
+    return HIPNLP_OK;
+}
 
 static void dims_fill(const hipnlp_handle* h, hipnlp_dims* o);
 int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {

@@ -208,6 +208,11 @@ typedef struct hipnlp_handle hipnlp_handle;
 
 int hipnlp_abi_version(void);            /* HIPNLP_ABI_VERSION the library was built with */
 const char* hipnlp_build_info(void);     /* how the library was built (e.g. "gfx950; ds_read2_b64 split in the assembly" or "gfx950; plain hipcc") */
+/* NUMA node of the host that card `device` hangs off (-1: not known).  The host-buffer paths want the calling thread and the arrays it
+ * passes on THAT node (its CPUs: /sys/devices/system/node/node<N>/cpulist): on a two-socket host the same call measured 37.6 - 39.0 us
+ * with the caller pinned to the card's node and 40.2 - 41.7 us on the other one (hipnlp_eval, all four outputs, 100 knots), the exact
+ * Hessian 55 against 60 - 62 us — and its early run (hipnlp_set_hessian_early_run) a gain on the card's node, a loss on the other. */
+int hipnlp_device_numa_node(int device, int* node);
 int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out);
 void hipnlp_destroy(hipnlp_handle* h);
 const char* hipnlp_last_error(const hipnlp_handle* h); /* h may be NULL: last create() error */

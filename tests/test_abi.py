@@ -88,3 +88,10 @@ def test_invalid_descriptor_codes(model):
     with pytest.raises(hipnlp.HipNlpError) as e:
         hipnlp.HipNlp(st, model)
     assert e.value.code == _abi.E_INVALID
+
+
+def test_cpulist_of_a_numa_node_is_parsed():
+    from hippopt_amd.hipnlp import parse_cpulist
+    assert parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert parse_cpulist("64-127,192-255") == set(range(64, 128)) | set(range(192, 256))
+    assert parse_cpulist("") == set()

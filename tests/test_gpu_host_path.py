@@ -340,6 +340,27 @@ def test_hessian_early_run_is_decided_by_the_handle_from_its_own_first_calls(mod
     ref.close()
 
 
+def test_the_process_can_be_put_on_the_cards_side_of_the_host():
+    """hipnlp_device_numa_node / pin_to_device_numa_node: the node is the one sysfs names for the card's PCI function, the calling thread ends
+    up on CPUs of that node only (and only on CPUs it was allowed before); a host that does not say changes nothing"""
+    import os
+    from hippopt_amd.hipnlp import device_numa_node, parse_cpulist, pin_to_device_numa_node
+    before = os.sched_getaffinity(0)
+    try:
+        node = device_numa_node(0)
+        got = pin_to_device_numa_node(0)
+        if node is None:
+            assert got is None and os.sched_getaffinity(0) == before
+        else:
+            cpus = parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read())
+            if cpus & before:
+                assert got == {"node": node, "cpus": len(cpus & before)} and os.sched_getaffinity(0) == cpus & before
+            else:
+                assert got is None and os.sched_getaffinity(0) == before
+    finally:
+        os.sched_setaffinity(0, before)
+
+
 def test_arrays_the_wrapper_allocates_itself_are_never_page_locked(model, HipNlp):
     """HipNlp.eval / eval_hess without `out=` hand back fresh arrays the caller drops when it likes; the allocator would hand the same
     addresses out again on the next call and the handle would take that for "the same array twice in a row" and page-lock memory that
