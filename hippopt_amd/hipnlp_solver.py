@@ -234,7 +234,7 @@ class _CallbackCache:
 class HipNlpSolver(OptimizationSolver):
     def __init__(self, settings, model, device=0, inner_solver="auto", options_solver=None, problem="kinodynamic",
                  callback_criterion: CallbackCriterion = None, callback_save_costs=True, callback_save_constraint_multipliers=True,
-                 error_on_fail=True, detect_simple_bounds=True, jac_varying_first=True):
+                 error_on_fail=True, detect_simple_bounds=True, jac_varying_first=True, pin_to_device_numa_node=False):
         """callback_* as in OptiSolver (opti_solver.py:105-131).  error_on_fail: CasADi's Opti raises when IPOPT does not report
         success (e.g. Maximum_Iterations_Exceeded), which is what triggers the best-iterate fallback of opti_solver.py:479-520;
         False keeps the last iterate of an unconverged run instead (useful for smoke runs with a few iterations).
@@ -242,6 +242,9 @@ class HipNlpSolver(OptimizationSolver):
         entries of a knot block first (the host path then moves them alone); False: CasADi's CCS order, what the reference's nlpsol
         hands IPOPT (opti_solver.py:479).  The drivers build their matrix from the triplets, so the order cannot change a solve:
         tests/test_gpu_solver_order.py runs the planners through both and compares every iterate.
+        pin_to_device_numa_node: restrict the calling thread to the CPUs of the card's NUMA node before the engine and its arrays are
+        created (hippopt_amd.hipnlp.pin_to_device_numa_node: the callbacks are link-bound, 2 - 5 us per call slower from the other
+        socket of the host).  Off by default: it changes the affinity of the CALLER's thread; a deployment does it once for the process.
         iterate_trace (attribute): set to a list to have (iteration, x, cost, primal infeasibility) of every iterate appended."""
         self._callback_criterion = callback_criterion
         self._callback_save_costs = callback_save_costs
@@ -251,6 +254,7 @@ class HipNlpSolver(OptimizationSolver):
         # casadi_opti_options["detect_simple_bounds"] of the reference scripts (main_periodic_step.py:110): kinodynamic problem only
         self._detect_simple_bounds = bool(detect_simple_bounds) and problem == "kinodynamic"
         self._jac_varying_first = bool(jac_varying_first)
+        self._pin = bool(pin_to_device_numa_node)
         self.iterate_trace = None
         if problem not in ("kinodynamic", "pose"):
             raise ValueError("problem must be 'kinodynamic' or 'pose'")
@@ -361,7 +365,9 @@ class HipNlpSolver(OptimizationSolver):
     # ---- engine -------------------------------------------------------------------------------------------
     def engine(self):
         if self._engine is None:
-            from .hipnlp import HipNlp, HipPose  # raises loudly without the library / a device
+            from .hipnlp import HipNlp, HipPose, pin_to_device_numa_node  # raises loudly without the library / a device
+            if self._pin:
+                pin_to_device_numa_node(self._device)
             if self._problem_kind == "pose":
                 self._engine = _PoseEngine(HipPose(self._settings, self._model, batch=1, device=self._device))
             else:
