@@ -260,7 +260,11 @@ __device__ __forceinline__ void constants_check_and_repair(const ConstCheck& c, 
 #endif
 // (the peer-store VARY kernels — one store loop per rank behind the program — keep the four-per-CU register budget)
 template <int TERRAIN, int WAVES, bool VARY, bool PEERS = false> constexpr bool five_per_cu = HIPNLP_FIVE_PER_CU && VARY && WAVES == 4 && !PEERS;
-template <int TERRAIN, int WAVES, bool PEERS = false, bool VARY = false> __global__ __launch_bounds__(64 * WAVES)
+// STORES_EARLY: the instantiation behind launches that arm the early copy-out (a.early: eight-wave VARY launches into host memory).  The
+// hook itself is compiled into every eight-wave kernel (see EARLY_OUT below); what this parameter moves is the fetch of the copy-out tables —
+// in front of the staging wait, where no wait for them can end up behind an early store, at 0.1 - 0.15 us of prologue that the launches
+// which never store early (the device-resident ones) do not pay.
+template <int TERRAIN, int WAVES, bool PEERS = false, bool VARY = false, bool STORES_EARLY = false> __global__ __launch_bounds__(64 * WAVES)
 __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? (five_per_cu<TERRAIN, WAVES, VARY, PEERS> ? 5 : 4) : 2, five_per_cu<TERRAIN, WAVES, VARY, PEERS> ? 5 : 4)))
 void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const double* pk_p, const GParams* gp_p, int N_p, int n_p, int kb_p, int nk_p, KArgs a) {
     // the leading scalar arguments repeat what the staging loads need: the build preloads them into SGPRs
@@ -411,9 +415,8 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     // Fetched behind that wait and left to their first real use, the compiler's wait for them stands behind early stores (between the
     // early entries of jac g and those of g, and again in front of the final stores): `s_waitcnt vmcnt(0)`, ONE counter for loads and
     // stores, i.e. the wave sits out the acknowledgement of what it has just sent to host memory before it may send the rest.
-    // (VARY only: the launches that store early are the varying-first handle's; the eleven extra loads in front of the staging wait cost the
-    //  100-knot launch 0.08 - 0.1 us, which the CCS kernels — bench.py's `value` — have no reason to pay)
-    constexpr bool TABLES_WITH_STAGING = !LATE_TABLES && WAVES == 8 && VARY;
+    static_assert(!STORES_EARLY || (WAVES == 8 && VARY && !PEERS), "launches that store early: the eight-wave VARY kernels of the host path");
+    constexpr bool TABLES_WITH_STAGING = STORES_EARLY;
     auto tables_are_here = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < JP_ITERS; ++it) asm volatile("" : "+v"(jp[it]));
@@ -560,7 +563,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     auto store_unwaited = [](double* base, int byte_off, double v) __attribute__((always_inline)) {
         asm volatile("global_store_dwordx2 %0, %1, %2 sc0 sc1" ::"v"(byte_off), "v"(v), "s"(base) : "memory");   // (system scope: written through the L2)
     };
-    const bool early_on = EARLY_OUT && a.early != 0;
+    const bool early_on = EARLY_OUT && STORES_EARLY && a.early != 0;   // (armed by the launch AND in the instantiation whose tables are safe to wait for)
     auto early_out = [&]() __attribute__((always_inline)) {
         if (!early_on) return;
         if (a.jac) {
@@ -1845,7 +1848,10 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
             else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 4, true>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
         }
     } else if (vary_only) {   // the destination of jac g holds its constant entries: the varying run of every block only
-        if (h->wide) {
+        if (h->wide && a.early) {   // (launches into host memory that send their early entries ahead)
+            if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8, false, true, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+            else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8, false, true, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+        } else if (h->wide) {
             if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8, false, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
             else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8, false, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
         } else {
