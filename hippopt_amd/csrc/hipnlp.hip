@@ -410,7 +410,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             gb[it] = tbl.gab_t[v][2 * (tid * (GS_PAD / WG) + it) + 1];
         }
     };
-    // Eight-wave kernels (whose launches into host memory store early, early_out below): the tables are fetched WITH the staging loads and
+    // STORES_EARLY (launches into host memory that store early, early_out below): the tables are fetched WITH the staging loads and
     // CONSUMED — as far as the compiler can tell: an empty assembly statement that reads and "writes" them — right behind the staging wait.
     // Fetched behind that wait and left to their first real use, the compiler's wait for them stands behind early stores (between the
     // early entries of jac g and those of g, and again in front of the final stores): `s_waitcnt vmcnt(0)`, ONE counter for loads and
@@ -552,9 +552,11 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     // entries of g and jac g whose slot is final by then (COPY_EARLY in its table words) — a third of jac g's varying entries and five rows
     // of g in six: 4.2 of a knot's 10.1 KB are on the link three microseconds before the program ends.  The copy-out at the end skips them
     // (its non-finite check still reads every slot).
-    // (compiled into EVERY eight-wave instantiation, the peer-store ones too, whose launches never set a.early: with the hook in some and not in
-    //  others the compiler contracted a few multiply-adds of the smooth-terrain tasks differently — last-bit differences between kernels whose
-    //  outputs the peer exchange checks bit for bit against the all-gather path)
+    // (compiled into EVERY eight-wave instantiation behind a run-time test of a.early, the peer-store ones and the plain ones too, whose
+    //  launches never arm it — only the STORES_EARLY instantiation is launched with a.early set: with the hook in some kernels and not in
+    //  others the compiler contracts a few multiply-adds of the smooth-terrain tasks differently — last-bit differences between kernels
+    //  whose outputs are compared bit for bit.  Tried again in round 5 with the hook as a compile-time property of the one instantiation:
+    //  tests/test_gpu_constant_jacobian.py::test_batch_with_different_time_steps_and_the_stairs fails on the last bit of entries of jac g.)
     constexpr bool EARLY_OUT = WAVES == 8;
     // A store the COMPILER does not know about (inline assembly): behind an ordinary store it puts `s_waitcnt vmcnt(0)` in front of the
     // next LDS access (this kernel has used LDS-direct loads, and the counter is shared), i.e. the wave would sit out the round trip of its
@@ -563,7 +565,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     auto store_unwaited = [](double* base, int byte_off, double v) __attribute__((always_inline)) {
         asm volatile("global_store_dwordx2 %0, %1, %2 sc0 sc1" ::"v"(byte_off), "v"(v), "s"(base) : "memory");   // (system scope: written through the L2)
     };
-    const bool early_on = EARLY_OUT && STORES_EARLY && a.early != 0;   // (armed by the launch AND in the instantiation whose tables are safe to wait for)
+    const bool early_on = EARLY_OUT && a.early != 0;
     auto early_out = [&]() __attribute__((always_inline)) {
         if (!early_on) return;
         if (a.jac) {
