@@ -34,6 +34,9 @@ def test_final_line_of_the_default_run_is_short_and_complete():
     assert back["metric"] == details["metric"] and back["unit"] == "knots/s" and back["dtype"] == "f64"
     assert set(back["config"]) >= {"workload", "horizon", "batch", "n", "m", "nnz", "jac_order", "ranks", "exchange"}
     assert "model" not in back["config"]
+    # where the process ran (bench.py pins itself to the card's NUMA node): passed through, cut to a short string
+    pinned = bench.compact_line(dict(details, config=dict(details["config"], numa="process pinned to the 128 allowed CPUs of NUMA node 1, the card's")))
+    assert pinned["config"]["numa"].startswith("process pinned to the 128 allowed CPUs of NUMA node 1") and len(pinned["config"]["numa"]) <= 60
     roof = back["roofline"]
     assert set(roof) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes_per_knot"}
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s"
