@@ -24,6 +24,7 @@
 #include <new>
 #include <string>
 #include <cctype>
+#include <sched.h>
 #include <tuple>
 #include <type_traits>
 #include <vector>
@@ -1312,6 +1313,40 @@ int hipnlp_abi_version(void) { return HIPNLP_ABI_VERSION; }
 #define HIPNLP_BUILD_VARIANT "plain hipcc"
 #endif
 const char* hipnlp_build_info(void) { return "gfx950; " HIPNLP_BUILD_VARIANT; }
+
+// the calling THREAD onto the CPUs of the card's node (those of them it may run on); nothing changes when the node is unknown or none of
+// its CPUs is allowed
+int hipnlp_pin_thread_to_device_numa_node(int device, int* node_out, int* cpus_out) {
+    int node = -1;
+    if (node_out) *node_out = -1;
+    if (cpus_out) *cpus_out = 0;
+    const int rc = hipnlp_device_numa_node(device, &node);
+    if (rc != HIPNLP_OK) return rc;
+    if (node < 0) return HIPNLP_OK;
+    FILE* f = std::fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r");
+    if (!f) return HIPNLP_OK;
+    char text[4096] = {0};
+    const size_t got = std::fread(text, 1, sizeof text - 1, f);
+    std::fclose(f);
+    text[got] = 0;
+    cpu_set_t allowed, want;
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return HIPNLP_OK;
+    int count = 0;
+    for (const char* c = text; *c;) {   // "0-63,128-191"
+        if (!std::isdigit(static_cast<unsigned char>(*c))) { ++c; continue; }
+        char* end = nullptr;
+        long lo = std::strtol(c, &end, 10), hi = lo;
+        if (*end == '-') hi = std::strtol(end + 1, &end, 10);
+        for (long cpu = lo; cpu <= hi && cpu < CPU_SETSIZE; ++cpu)
+            if (CPU_ISSET(int(cpu), &allowed)) { CPU_SET(int(cpu), &want); ++count; }
+        c = end;
+    }
+    if (count == 0 || sched_setaffinity(0, sizeof want, &want) != 0) return HIPNLP_OK;
+    if (node_out) *node_out = node;
+    if (cpus_out) *cpus_out = count;
+    return HIPNLP_OK;
+}
 
 // NUMA node of the host the card hangs off (Linux sysfs of its PCI function); -1: not known
 int hipnlp_device_numa_node(int device, int* node) {

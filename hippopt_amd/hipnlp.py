@@ -25,7 +25,7 @@ EXPORTS = [
     "hipnlp_eval_device_shard", "hipnlp_stage_rows", "hipnlp_reassemble",
     "hipnlp_jac_vary_layout", "hipnlp_fill_jac_constants", "hipnlp_eval_device_vary", "hipnlp_eval_device_shard_vary", "hipnlp_eval_device_peers_vary", "hipnlp_reassemble_scatter",
     "hipnlp_ipc_alloc", "hipnlp_ipc_open", "hipnlp_ipc_close", "hipnlp_ipc_free", "hipnlp_peer_push", "hipnlp_peer_signal", "hipnlp_peer_signal_checked", "hipnlp_peer_wait", "hipnlp_eval_device_peers",
-    "hipnlp_device_numa_node",
+    "hipnlp_device_numa_node", "hipnlp_pin_thread_to_device_numa_node",
     "hipnlp_hess_nnz", "hipnlp_hess_sparsity", "hipnlp_eval_hess", "hipnlp_eval_hess_at", "hipnlp_set_hessian_early_run", "hipnlp_get_hessian_early_run", "hipnlp_eval_hess_device",
     "hipnlp_eval_pinned", "hipnlp_set_prefetch", "hipnlp_set_early_outputs", "hipnlp_set_host_timing", "hipnlp_host_register", "hipnlp_host_unregister",
     "hipnlp_host_breakdown", "hipnlp_set_auto_register", "hipnlp_host_stats", "hipnlp_set_constant_jacobian", "hipnlp_forget_jac_destination", "hipnlp_jac_constant_mask", "hipnlp_host_release_auto_ranges",

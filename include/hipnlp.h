@@ -213,6 +213,10 @@ const char* hipnlp_build_info(void);     /* how the library was built (e.g. "gfx
  * with the caller pinned to the card's node and 40.2 - 41.7 us on the other one (hipnlp_eval, all four outputs, 100 knots), the exact
  * Hessian 55 against 60 - 62 us — and its early run (hipnlp_set_hessian_early_run) a gain on the card's node, a loss on the other. */
 int hipnlp_device_numa_node(int device, int* node);
+/* ... and the calling THREAD onto the CPUs of that node (sched_setaffinity with those of them it is allowed to run on; arrays it
+ * allocates from then on follow by first touch).  node_out / cpus_out (may be NULL): the node and the number of CPUs the thread now has —
+ * -1 / 0 when nothing was changed (node unknown, none of its CPUs allowed). */
+int hipnlp_pin_thread_to_device_numa_node(int device, int* node_out, int* cpus_out);
 int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out);
 void hipnlp_destroy(hipnlp_handle* h);
 const char* hipnlp_last_error(const hipnlp_handle* h); /* h may be NULL: last create() error */

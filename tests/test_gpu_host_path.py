@@ -357,6 +357,17 @@ def test_the_process_can_be_put_on_the_cards_side_of_the_host():
                 assert got == {"node": node, "cpus": len(cpus & before)} and os.sched_getaffinity(0) == cpus & before
             else:
                 assert got is None and os.sched_getaffinity(0) == before
+        # the C entry point (what a C / IPOPT caller uses) does the same to the calling thread
+        import ctypes as C
+        from hippopt_amd.hipnlp import load_library
+        after_python = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, before)
+        lib = load_library()
+        lib.hipnlp_pin_thread_to_device_numa_node.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        n_out, c_out = C.c_int(-7), C.c_int(-7)
+        assert lib.hipnlp_pin_thread_to_device_numa_node(0, C.byref(n_out), C.byref(c_out)) == 0
+        assert os.sched_getaffinity(0) == after_python
+        assert (n_out.value, c_out.value) == ((got["node"], got["cpus"]) if got else (-1, 0))
     finally:
         os.sched_setaffinity(0, before)
 
