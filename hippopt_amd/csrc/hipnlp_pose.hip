@@ -283,6 +283,7 @@ struct hipnlp_pose_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_valid = false, params_set = false, have_result = false;
+    bool time_host = false;   // hipnlp_pose_set_host_timing: the host-buffer calls bracket their launch with events (each record drains the stream: ~3 us of a 25 us call)
     PoseTables* d_tb = nullptr;
     double *d_x = nullptr, *d_pk = nullptr, *d_xr = nullptr, *d_f = nullptr, *d_grad = nullptr, *d_g = nullptr, *d_jac = nullptr, *d_cost = nullptr;
     GParams* d_gp = nullptr;
@@ -478,7 +479,7 @@ int hipnlp_pose_eval(hipnlp_pose_handle* h, const double* x, double* f, double* 
     // x is read by the kernel from the pinned staging copy, every output is stored by the kernel into its pinned block (PCIe stores):
     // one launch and one synchronisation, no copy command (56 -> 31 us per call for one pose through the ctypes binding, the Hessian 63 -> 42 us; tools/diag/pose_host_time.py)
     std::memcpy(h->h_x, x, B * POSE_NX * sizeof(double));
-    const int rc = pose_launch(h, h->hd_x, h->hd_f, h->hd_grad, h->hd_g, h->hd_jac, h->stream, true, true);
+    const int rc = pose_launch(h, h->hd_x, h->hd_f, h->hd_grad, h->hd_g, h->hd_jac, h->stream, h->time_host, true);
     if (rc != HIPNLP_OK) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->have_result = true;
@@ -553,7 +554,7 @@ int hipnlp_pose_eval_hess(hipnlp_pose_handle* h, const double* x, const double* 
     std::memcpy(h->h_x, x, B * POSE_NX * sizeof(double));
     std::memcpy(h->h_sigma, obj_factor, B * sizeof(double));
     std::memcpy(h->h_lambda, lambda, B * m * sizeof(double));
-    const int rc = pose_hess_launch(h, h->hd_x, h->hd_sigma, h->hd_lambda, h->hd_hess, h->stream, true, true);
+    const int rc = pose_hess_launch(h, h->hd_x, h->hd_sigma, h->hd_lambda, h->hd_hess, h->stream, h->time_host, true);
     if (rc != HIPNLP_OK) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     std::memcpy(hess, h->h_hess, B * hn * sizeof(double));
@@ -591,9 +592,16 @@ int hipnlp_pose_row_block(const hipnlp_pose_handle* h, int i, const char** name,
     return HIPNLP_OK;
 }
 
+int hipnlp_pose_set_host_timing(hipnlp_pose_handle* h, int on) {
+    if (!h) return HIPNLP_E_INVALID;
+    h->time_host = on != 0;
+    if (!h->time_host) h->timing_valid = false;
+    return HIPNLP_OK;
+}
+
 int hipnlp_pose_last_kernel_ms(hipnlp_pose_handle* h, float* ms) {
     if (!h || !ms) return HIPNLP_E_INVALID;
-    if (!h->timing_valid) { h->err = "no timed evaluation yet (hipnlp_pose_eval)"; return HIPNLP_E_INVALID; }
+    if (!h->timing_valid) { h->err = "no timed evaluation yet (hipnlp_pose_set_host_timing(h, 1), then hipnlp_pose_eval / hipnlp_pose_eval_hess)"; return HIPNLP_E_INVALID; }
     HIP_TRY(h, hipSetDevice(h->dev));
     HIP_TRY(h, hipEventSynchronize(h->ev1));
     HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));

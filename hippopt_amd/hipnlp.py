@@ -31,7 +31,7 @@ EXPORTS = [
     "hipnlp_host_breakdown", "hipnlp_set_auto_register", "hipnlp_host_stats", "hipnlp_set_constant_jacobian", "hipnlp_forget_jac_destination", "hipnlp_jac_constant_mask", "hipnlp_host_release_auto_ranges",
     "hipnlp_pose_create", "hipnlp_pose_destroy", "hipnlp_pose_last_error", "hipnlp_pose_get_dims", "hipnlp_pose_set_params",
     "hipnlp_pose_bounds", "hipnlp_pose_sparsity", "hipnlp_pose_eval", "hipnlp_pose_eval_device", "hipnlp_pose_cost_terms",
-    "hipnlp_pose_cost_term_name", "hipnlp_pose_num_row_blocks", "hipnlp_pose_row_block", "hipnlp_pose_last_kernel_ms",
+    "hipnlp_pose_cost_term_name", "hipnlp_pose_num_row_blocks", "hipnlp_pose_row_block", "hipnlp_pose_last_kernel_ms", "hipnlp_pose_set_host_timing",
     "hipnlp_pose_hess_nnz", "hipnlp_pose_hess_sparsity", "hipnlp_pose_eval_hess", "hipnlp_pose_eval_hess_device",
     # include/hipnlp_ipopt.h: IPOPT's C callback quartet (+ eval_h) on top of the functions above
     "hipnlp_ipopt_eval_f", "hipnlp_ipopt_eval_grad_f", "hipnlp_ipopt_eval_g", "hipnlp_ipopt_eval_jac_g", "hipnlp_ipopt_eval_h",
@@ -681,6 +681,11 @@ class HipPose:
             self._check(self.lib.hipnlp_pose_row_block(self.h, i, C.byref(name), C.byref(a), C.byref(b)))
             out.append((name.value.decode(), a.value, b.value))
         return out
+
+    def set_host_timing(self, on=True):
+        """host-buffer calls bracket their launch with HIP events (off by default: the records cost ~3 us of a 25 us call)"""
+        self.lib.hipnlp_pose_set_host_timing.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.hipnlp_pose_set_host_timing(self.h, 1 if on else 0))
 
     def last_kernel_ms(self):
         ms = C.c_float()

@@ -628,6 +628,9 @@ int hipnlp_pose_cost_terms(hipnlp_pose_handle* h, double* values /*[batch][HIPNL
 const char* hipnlp_pose_cost_term_name(int i);
 int hipnlp_pose_num_row_blocks(const hipnlp_pose_handle* h);
 int hipnlp_pose_row_block(const hipnlp_pose_handle* h, int i, const char** name, int32_t* first_row, int32_t* rows);
+/* kernel duration of the last host-buffer call by HIP events — only for calls made with the timing ON (off by default since round 5: the
+ * two event records drain the stream around the launch, ~3 us of a 25 us call for one pose) */
+int hipnlp_pose_set_host_timing(hipnlp_pose_handle* h, int on);
 int hipnlp_pose_last_kernel_ms(hipnlp_pose_handle* h, float* ms);
 
 #ifdef __cplusplus

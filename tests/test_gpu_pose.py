@@ -92,6 +92,7 @@ def test_pose_errors_and_large_batch(model):
     xb += 1e-3 * np.random.RandomState(0).standard_normal(xb.shape)
     big = HipPose(st, model, batch=B)
     big.set_params(pb)
+    big.set_host_timing(True)
     f, grad, g, jac = big.eval(xb)
     orc = PoseOracle(st, model)
     for b in (0, 17, 2049, B - 1):
@@ -200,6 +201,7 @@ def test_pose_hessian_large_batch_and_errors(model):
         eng.eval_hess(xb, 1.0, lam)
     assert ei.value.code == -4                      # parameters not set
     eng.set_params(pb)
+    eng.set_host_timing(True)
     vals = eng.eval_hess(xb, 1.0, lam)
     print("pose Hessian kernel, batch %d: %.3f ms" % (B, eng.last_kernel_ms()))
     orc = PoseOracle(st, model)
