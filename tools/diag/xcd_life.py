@@ -28,3 +28,7 @@ for rep in range(12):
     xcd=np.arange(100)%8
     res.append(([int(np.median(life[xcd==j])) for j in range(8)], [int(np.median(cyc[xcd==j])) for j in range(8)], [int(np.median(staged[xcd==j])) for j in range(8)], int(life.max()), int(np.median(life))))
 for r in res: print("life ticks by XCD", r[0], " cycles", r[1], " staged", r[2], " max", r[3], "median", r[4])
+# wave entries of a few workgroups relative to their first wave (shader cycles), and entry -> staging loads issued per wave
+for g in (3, 50, 97):
+    e = o[g, :, 0]
+    print("workgroup %d: wave entries since the first %s   entry -> loads issued, per wave %s   -> loads arrived %s" % (g, list((e - e.min()).astype(int)), list((o[g, :, 5] - e).astype(int)), list((o[g, :, 6] - e).astype(int))))
