@@ -1166,7 +1166,8 @@ struct hipnlp_handle {
     bool early_store = true;    // launches into host memory store what is final after the second phase then (diagnostic override: HIPNLP_EARLY_STORE=0)
     // hipnlp_eval_hess*: the run at the start of every knot block leaves early (HArgs::early_run) — 1 / 0, or -1 = decided by the handle from
     // its own first calls (hipnlp_set_hessian_early_run).  The same kernel, the same values either way; which one is faster depends on
-    // the HOST: 4 us sooner per 100-knot Hessian on some boxes of one pool, 2 - 3 us later on others (profiles/r05_early_stores_by_box.txt).
+    // the HOST: 4 - 7 us sooner per 100-knot Hessian with the caller on the card's NUMA node, 2 - 3 us later from the other socket
+    // (profiles/r05_early_stores_by_box.txt).
     int hess_early_mode = -1, hess_early_choice = -1, hess_tune_calls = 0;
     double hess_tune_best[2] = {1e30, 1e30};
     bool hess_compact = false;   // exact Hessian: compact-scratch instantiation (three workgroups per CU) for launches of more than 512 workgroups
@@ -2042,7 +2043,7 @@ int hipnlp_eval_hess_at(hipnlp_handle* h, const double* x, int new_x, const doub
         h->hd_hess = static_cast<double*>(hd);
     }
     // x: the staging copy hipnlp_eval uses.  new_x = 0 (IPOPT's flag: eval_h at the x of the callbacks before it — every accepted
-    // iterate): the copy of the previous call IS this x — no 151 KB host copy in front of the launch (3 - 4 us of a 100-knot call); new_x < 0:
+    // iterate): the copy of the previous call IS this x — no 151 KB host copy in front of the launch (1.7 - 2.2 us of a 100-knot call, tools/diag/hess_new_x_ab.py); new_x < 0:
     // unknown, compared; nothing staged yet: copied whatever the flag says
     bool stage_x = new_x != 0 || !h->x_staged;
     if (new_x < 0 && h->x_staged) stage_x = x != h->h_x && std::memcmp(x, h->h_x, B * n * sizeof(double)) != 0;
@@ -2084,7 +2085,8 @@ int hipnlp_eval_hess_at(hipnlp_handle* h, const double* x, int new_x, const doub
     }
     // early run: forced on / off, or — the default — tried both ways on the handle's own first calls (three calls to warm up, then six
     // of each kind alternating, launch to completion on the host's clock, the faster minimum wins): which way is faster is a property of
-    // the host the call runs on, not of the kernel
+    // the SOCKET of the host the caller sits on, not of the kernel (a gain on the card's NUMA node, a loss across the socket interconnect:
+    // profiles/r05_early_stores_by_box.txt)
     constexpr int TUNE_WARM = 3, TUNE_SAMPLES = 12;
     bool early = h->early_store && h->hess_early_mode != 0;
     bool sample = false;

@@ -385,8 +385,8 @@ int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor
 int hipnlp_eval_hess_at(hipnlp_handle* h, const double* x, int new_x, const double* obj_factor, const double* lambda, double* values);
 /* hipnlp_eval_hess* into host memory: the run at the start of every knot block (the point columns: a quarter of the values on the planar
  * terrain, two fifths on the smooth steps) is final long before the program ends and can leave then — the same kernel, the same values,
- * bit for bit.  Whether that is FASTER is a property of the host: measured 4 us sooner per 100-knot Hessian on some boxes of one pool and
- * 2 - 3 us later on others.  mode 1 / 0: on / off; -1 (the default): the handle tries both on its own first calls (three to warm up, six
+ * bit for bit.  Whether that is FASTER is a property of the host: measured 4 - 7 us sooner per 100-knot Hessian with the calling thread on
+ * the card's NUMA node (hipnlp_pin_thread_to_device_numa_node) and 2 - 3 us later from the other socket of the same box.  mode 1 / 0: on / off; -1 (the default): the handle tries both on its own first calls (three to warm up, six
  * of each kind, launch to completion on the host's clock) and keeps the faster one; setting a mode starts that over.
  * hipnlp_get_hessian_early_run: the mode, what is in use (-1: not decided yet) and the two minima in microseconds (0: not measured). */
 int hipnlp_set_hessian_early_run(hipnlp_handle* h, int mode);
