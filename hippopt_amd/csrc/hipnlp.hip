@@ -1154,8 +1154,14 @@ double* device_address_of(const void* p, size_t bytes) {
 
 }  // namespace
 
+struct MultiState;
 struct hipnlp_handle {
     hipnlp_desc d;
+    // hipnlp_multi_create: this handle is the FRONT of one shard handle per device.  It owns the NLP's host side — layout, bounds, the
+    // constant entries of jac g, the pinned staging of x and of the outputs, the bookkeeping of the caller's arrays — and no device
+    // memory, no stream: every evaluation is the shards' (multi_* below).
+    MultiState* multi = nullptr;
+    bool is_front = false;
     Layout L;
     KinTables kt;
     int batch = 1, kb = 0, ke = 0, nk = 0, np = 0;
@@ -1281,6 +1287,14 @@ struct hipnlp_handle {
         }                                                                                           \
     } while (0)
 
+#define NOT_FRONT(h, who)                                                                                                       \
+    do {                                                                                                                      \
+        if ((h)->is_front) {                                                                                                  \
+            (h)->err = who ": a multi-device handle (hipnlp_multi_create) serves the host-buffer calls only";                \
+            return HIPNLP_E_UNSUPPORTED;                                                                                      \
+        }                                                                                                                     \
+    } while (0)
+
 static void free_all(hipnlp_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->dev);
@@ -1306,6 +1320,7 @@ static void constants_ensure(hipnlp_handle* h, double* jac_host);
 static int drop_stale_range(hipnlp_handle* h, void* p);
 static bool auto_owns(const hipnlp_handle* h, const void* p);
 static double* caller_array_address(hipnlp_handle* h, int q, double* p, size_t bytes);
+static int multi_set_params(hipnlp_handle* h, const double* p);
 
 const char* hipnlp_last_error(const hipnlp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -1366,12 +1381,15 @@ int hipnlp_device_numa_node(int device, int* node) {
 }
 
 static void dims_fill(const hipnlp_handle* h, hipnlp_dims* o);
-int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
+// front: the host side of a handle only (hipnlp_multi_create) — no stream, no device memory, the pinned blocks allocated so that every
+// device of the process may read and write them
+static int create_handle(const hipnlp_desc* desc, hipnlp_handle** out, bool front) {
     if (!desc || !out) { g_create_error = "null argument"; return HIPNLP_E_INVALID; }
     *out = nullptr;
     hipnlp_handle* h = new (std::nothrow) hipnlp_handle();
     if (!h) { g_create_error = "out of memory"; return HIPNLP_E_ALLOC; }
     h->d = *desc;
+    h->is_front = front;
     const hipnlp_settings& st = desc->settings;
     auto fail = [&](int code, const std::string& msg) { g_create_error = msg; free_all(h); return code; };
     if (desc->abi_version != HIPNLP_ABI_VERSION)
@@ -1429,21 +1447,24 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     if (desc->device < 0 || desc->device >= ndev) return fail(HIPNLP_E_INVALID, "bad device ordinal");
     h->dev = desc->device;
 #define CREATE_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(HIPNLP_E_NODEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+#define DEV_TRY(call) do { if (!front) CREATE_TRY(call); } while (0)   /* (a front handle owns no stream and no device memory) */
+    // pinned blocks of a front handle: read and written by the kernels of EVERY shard's device
+    const unsigned pin_flags = front ? (hipHostMallocPortable | hipHostMallocMapped) : hipHostMallocDefault;
     CREATE_TRY(hipSetDevice(h->dev));
-    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    CREATE_TRY(hipEventCreate(&h->ev0));
-    CREATE_TRY(hipEventCreate(&h->ev1));
+    DEV_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    DEV_TRY(hipEventCreate(&h->ev0));
+    DEV_TRY(hipEventCreate(&h->ev1));
     const size_t B = size_t(h->batch), n = size_t(h->L.n), m = size_t(h->L.m), nnz = size_t(h->L.nnz), N = size_t(st.horizon);
-    CREATE_TRY(hipMalloc(&h->d_tb, sizeof(DeviceTables)));
-    CREATE_TRY(hipMalloc(&h->d_x, B * n * sizeof(double)));
-    CREATE_TRY(hipMalloc(&h->d_pk, B * N * PK_STRIDE * sizeof(double)));
-    CREATE_TRY(hipMalloc(&h->d_gp, B * sizeof(GParams)));
+    DEV_TRY(hipMalloc(&h->d_tb, sizeof(DeviceTables)));
+    DEV_TRY(hipMalloc(&h->d_x, B * n * sizeof(double)));
+    DEV_TRY(hipMalloc(&h->d_pk, B * N * PK_STRIDE * sizeof(double)));
+    DEV_TRY(hipMalloc(&h->d_gp, B * sizeof(GParams)));
     // every output of the host-buffer path in ONE device block and ONE pinned mirror: [f | cost terms | grad | g | jac | flag],
     // copied back with a single asynchronous copy (six separate copies cost ~8 us each in launch overhead alone)
     const size_t out_doubles = B * (1 + NCT + n + m + nnz);
     h->out_bytes = out_doubles * sizeof(double) + ((B * sizeof(int32_t) + 7) / 8) * 8;
-    CREATE_TRY(hipMalloc(&h->d_out, h->out_bytes));
-    CREATE_TRY(hipHostMalloc(&h->h_out, h->out_bytes));
+    DEV_TRY(hipMalloc(&h->d_out, h->out_bytes));
+    CREATE_TRY(hipHostMalloc(&h->h_out, h->out_bytes, pin_flags));
     auto carve = [&](char* base) {
         double* p = reinterpret_cast<double*>(base);
         double* f_ = p; p += B;
@@ -1453,7 +1474,7 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
         double* j_ = p; p += B * nnz;
         return std::make_tuple(f_, ct_, gr_, g_, j_, reinterpret_cast<int32_t*>(p));
     };
-    std::tie(h->d_f, h->d_cost_terms, h->d_grad, h->d_g, h->d_jac, h->d_flag) = carve(static_cast<char*>(h->d_out));
+    if (!front) std::tie(h->d_f, h->d_cost_terms, h->d_grad, h->d_g, h->d_jac, h->d_flag) = carve(static_cast<char*>(h->d_out));
     std::tie(h->h_f, h->h_cost_terms, h->h_grad, h->h_g, h->h_jac, h->h_flag) = carve(static_cast<char*>(h->h_out));
     {
         void* od = nullptr;
@@ -1461,13 +1482,13 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
         std::tie(h->hd_f, h->hd_cost_terms, h->hd_grad, h->hd_g, h->hd_jac, h->hd_flag) = carve(static_cast<char*>(od));
         std::memset(h->h_out, 0, h->out_bytes);
     }
-    CREATE_TRY(hipMalloc(&h->d_cost_knot, B * size_t(h->nk) * NCT * sizeof(double)));
-    CREATE_TRY(hipMalloc(&h->d_cost_pub, B * size_t(h->nk) * NCT * 2 * sizeof(unsigned long long)));
-    CREATE_TRY(hipMemset(h->d_cost_pub, 0, B * size_t(h->nk) * NCT * 2 * sizeof(unsigned long long)));
-    CREATE_TRY(hipMemset(h->d_flag, 0, B * sizeof(int32_t)));
+    DEV_TRY(hipMalloc(&h->d_cost_knot, B * size_t(h->nk) * NCT * sizeof(double)));
+    DEV_TRY(hipMalloc(&h->d_cost_pub, B * size_t(h->nk) * NCT * 2 * sizeof(unsigned long long)));
+    DEV_TRY(hipMemset(h->d_cost_pub, 0, B * size_t(h->nk) * NCT * 2 * sizeof(unsigned long long)));
+    DEV_TRY(hipMemset(h->d_flag, 0, B * sizeof(int32_t)));
     // (measured: non-coherent pinned memory for this block — cacheable in the GPU's L2 within a launch, so that the halo record would
     //  not cross PCIe twice — changes nothing: 22.3 us of GPU wait per objective call either way)
-    CREATE_TRY(hipHostMalloc(&h->h_x, B * n * sizeof(double)));
+    CREATE_TRY(hipHostMalloc(&h->h_x, B * n * sizeof(double), pin_flags));
     {
         void* xd = nullptr;
         CREATE_TRY(hipHostGetDevicePointer(&xd, h->h_x, 0));
@@ -1481,9 +1502,9 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
         h->lam_zero_copy = B * (1 + m) * sizeof(double) <= (size_t(1) << 20);
         if (const char* lz = diag_env("HIPNLP_HESS_LAM_ZERO_COPY")) h->lam_zero_copy = std::atoi(lz) != 0;   // diagnostic override (A/B in one process)
     }
-    CREATE_TRY(hipMemset(h->d_g, 0, B * m * sizeof(double)));
-    CREATE_TRY(hipMemset(h->d_jac, 0, B * nnz * sizeof(double)));
-    CREATE_TRY(hipMemset(h->d_grad, 0, B * n * sizeof(double)));
+    DEV_TRY(hipMemset(h->d_g, 0, B * m * sizeof(double)));
+    DEV_TRY(hipMemset(h->d_jac, 0, B * nnz * sizeof(double)));
+    DEV_TRY(hipMemset(h->d_grad, 0, B * n * sizeof(double)));
     // tables
     DeviceTables* tb = new DeviceTables();
     std::memset(tb, 0, sizeof(DeviceTables));
@@ -1543,9 +1564,9 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
                     ++i;
                 }
     }
-    hipError_t ce = hipnlp_internal_memcpy(h->d_tb, tb, sizeof(DeviceTables), hipMemcpyHostToDevice);
-    if (ce == hipSuccess) ce = hipMalloc(&h->d_healed, sizeof(int32_t));
-    if (ce == hipSuccess) ce = hipMemset(h->d_healed, 0, sizeof(int32_t));
+    hipError_t ce = front ? hipSuccess : hipnlp_internal_memcpy(h->d_tb, tb, sizeof(DeviceTables), hipMemcpyHostToDevice);
+    if (!front && ce == hipSuccess) ce = hipMalloc(&h->d_healed, sizeof(int32_t));
+    if (!front && ce == hipSuccess) ce = hipMemset(h->d_healed, 0, sizeof(int32_t));
     delete tb;
     if (ce != hipSuccess) return fail(HIPNLP_E_NODEVICE, std::string("hipMemcpy tables: ") + hipGetErrorString(ce));
     {
@@ -1563,6 +1584,7 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
             for (size_t i = L.jconst_pos[v].size(); i-- > 0;) if (!L.jconst_pos[v][i]) { h->jac_last_vary = (B - 1) * nnz + size_t(L.jac_base(k)) + i; found = true; break; }
         }
     }
+#undef DEV_TRY
 #undef CREATE_TRY
     dims_fill(h, &h->dims);
     {
@@ -1588,11 +1610,14 @@ int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) {
     *out = h;
     return HIPNLP_OK;
 }
+int hipnlp_create(const hipnlp_desc* desc, hipnlp_handle** out) { return create_handle(desc, out, false); }
 
+static void multi_destroy(hipnlp_handle* h);
 void hipnlp_destroy(hipnlp_handle* h) {
     if (h) {
         (void)hipSetDevice(h->dev);
         auto_unregister_all(h);
+        if (h->multi) multi_destroy(h);
     }
     free_all(h);
 }
@@ -1674,7 +1699,7 @@ static void constants_prepare(hipnlp_handle* h, const std::vector<GParams>& gp) 
     // (the pinned block, the library's own, is filled when a launch that skips the constants first stores into it: host_evaluate)
     // device copy for the VARY kernels' check and for the fill of device destinations (hipnlp_eval_device)
     h->ctpl_len = h->ctpl.empty() ? 0 : int(h->ctpl[0].size());
-    if (h->vary_ok && h->ctpl_len > 0) {
+    if (h->vary_ok && h->ctpl_len > 0 && !h->is_front) {   // (a front handle fills HOST destinations only: its shards hold the device copies)
         if (h->d_ctpl) { (void)hipFree(h->d_ctpl); h->d_ctpl = nullptr; }
         if (!h->d_ctpl_of_b && hipMalloc(&h->d_ctpl_of_b, size_t(h->batch) * sizeof(int32_t)) != hipSuccess) { h->d_ctpl_of_b = nullptr; h->vary_ok = false; }
         if (h->vary_ok && hipMalloc(&h->d_ctpl, h->ctpl.size() * size_t(h->ctpl_len) * sizeof(double)) != hipSuccess) { h->d_ctpl = nullptr; h->vary_ok = false; }
@@ -1729,9 +1754,14 @@ int hipnlp_set_params(hipnlp_handle* h, const double* p) {
     std::vector<double> pk(B * N * PK_STRIDE);
     std::vector<GParams> gp(B);
     for (size_t b = 0; b < B; ++b) pack_params(p + b * size_t(h->np), int(N), pk.data() + b * N * PK_STRIDE, gp[b]);
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipnlp_internal_memcpy(h->d_pk, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(h, hipnlp_internal_memcpy(h->d_gp, gp.data(), gp.size() * sizeof(GParams), hipMemcpyHostToDevice));
+    if (h->multi) {   // every shard takes the whole parameter array (its kernels index the knot records by global knot number)
+        const int rc = multi_set_params(h, p);
+        if (rc != HIPNLP_OK) return rc;
+    } else {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipnlp_internal_memcpy(h->d_pk, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipnlp_internal_memcpy(h->d_gp, gp.data(), gp.size() * sizeof(GParams), hipMemcpyHostToDevice));
+    }
     h->params_set = true;
     h->have_result = false;
     constants_prepare(h, gp);
@@ -1791,7 +1821,11 @@ static int64_t gs_base(const hipnlp_handle* h, int k) {
 }
 static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, hipStream_t s,
                   double* g_stage = nullptr, bool shard_local = false, bool always_timed = false, bool host_block = false,
-                  double* const* peer_out = nullptr, int npeer = 0, int peer_rank = 0, bool vary_only = false, bool compact = false, bool no_check = false) {
+                  double* const* peer_out = nullptr, int npeer = 0, int peer_rank = 0, bool vary_only = false, bool compact = false, bool no_check = false,
+                  double* cost_dst = nullptr) {
+    // cost_dst (shard launches of a multi-device handle): [batch][nk][NCT], device-visible HOST memory — the knot workgroups store their
+    // cost partials there and nothing on the device sums them (no reducer workgroup, no reduction kernel: f_dev is not written); the one
+    // caller sums the partials of all shards in the order of the device reduction (multi_reduce_costs)
     // vary_only: the constant entries of jac g are already at jac_dev (constants_ensure): the copy-out leaves them alone
     // compact (with vary_only): jac_dev is a COMPACT destination — the varying runs of the knot blocks behind one another, no room for constants
     // no_check: the destination is not local device memory (a registered host range, a peer's buffer): the launch does not read it back
@@ -1828,7 +1862,8 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     } else {
         a.jac_stride = compact ? vary_base(h->L, h->L.N) : int64_t(h->L.nnz); a.jac_off = 0; a.grad_stride = h->L.n; a.grad_off = 0;
     }
-    a.cost_knot = h->d_cost_knot; a.f = f_dev; a.cost_pub = h->fused ? h->d_cost_pub : nullptr; a.flag = h->d_flag;
+    const bool fused = h->fused && !cost_dst;
+    a.cost_knot = cost_dst ? cost_dst : h->d_cost_knot; a.f = f_dev; a.cost_pub = fused ? h->d_cost_pub : nullptr; a.flag = h->d_flag;
     // host-buffer path: per-term costs (96 B per trajectory) and the non-finite flag go straight to the pinned block
     a.cost_terms = host_block ? h->hd_cost_terms : h->d_cost_terms;
     a.flag_host = host_block ? h->hd_flag : nullptr;
@@ -1867,7 +1902,7 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     a.stamps = h->d_stamps;
 #endif
     if (timed) HIP_TRY(h, hipEventRecord(e0, s));
-    const dim3 grid(unsigned(h->nk) + (h->fused ? 1u : 0u), unsigned(h->batch));   // (+ the row's cost reducer)
+    const dim3 grid(unsigned(h->nk) + (fused ? 1u : 0u), unsigned(h->batch));   // (+ the row's cost reducer)
     const bool planar = h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR;
     if (peer_out && vary_only) {   // every rank's buffer holds the constant entries: the varying run of every block, at its place in the pattern, once per rank
         if (h->wide) {
@@ -1904,7 +1939,7 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
         else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 4>), grid, dim3(256), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n + 1)], s));
-    if (!h->fused)
+    if (!fused && !cost_dst)
         hipLaunchKernelGGL(hipnlp_reduce_kernel, dim3(unsigned(h->batch)), dim3(RWG), 0, s, (const double*)h->d_cost_knot, h->nk, f_dev, a.cost_terms, a.cc);
     if (timed) HIP_TRY(h, hipEventRecord(e2, s));
     if (run_last) {   // (ONE event behind the run: kernel end and launch end coincide for a run)
@@ -1919,6 +1954,235 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
 }
 
 
+// =====================================================================================================================
+// One caller, several devices (hipnlp_multi_create).  The reference has ONE caller of the callbacks — IPOPT, inside the process that runs
+// self._solver.solve() (/root/reference/src/hippopt/base/opti_solver.py:479) — and that caller holds x and wants f, grad f, g, jac g in
+// arrays of its own.  A multi-device handle serves it behind the host-buffer entry points of a plain handle: the horizon is cut into
+// contiguous knot ranges (the defects of interval k -> k + 1 belong to the owner of knot k + 1, the naming of
+// base/multiple_shooting_solver.py:713-742: a shard reads the record of the knot in front of its first one — the halo — besides its own,
+// the six horizon-global variables, and the record of the other horizon end where it owns knot 0 or N - 1), one shard handle per device;
+// a call stages x ONCE in a pinned block every device reads over its own link, launches every shard's kernel — which stores the
+// shard's entries of grad f / g / jac g at their final places in the caller's registered arrays (or the front's pinned block), over
+// that device's own link — and waits for all of them.  Nothing crosses between the devices; nothing is reassembled.
+// The total cost is summed by the caller: every knot workgroup stores its twelve cost partials into a pinned block and the host adds
+// them in the order of the device reduction (hipnlp_reduce_kernel) — f and the per-term costs are, bit for bit, those of ONE handle over
+// the whole horizon whatever the number of shards.
+// =====================================================================================================================
+struct MultiState {
+    std::vector<hipnlp_handle*> shards;
+    double* h_cost = nullptr;             // pinned: shard s's block [batch][nk_s][NCT] at cost_off[s]
+    std::vector<double*> hd_cost;         // ... and its device-visible address
+    std::vector<size_t> cost_off;
+    std::vector<double> shard_us;         // [shards][2] of the last evaluation: enqueue, completion seen (host clock, from the start of the enqueue loop)
+};
+
+static void multi_destroy(hipnlp_handle* h) {
+    MultiState* M = h->multi;
+    if (!M) return;
+    for (hipnlp_handle* s : M->shards) hipnlp_destroy(s);
+    if (M->h_cost) (void)hipHostFree(M->h_cost);
+    delete M;
+    h->multi = nullptr;
+}
+
+static int multi_set_params(hipnlp_handle* h, const double* p) {
+    for (hipnlp_handle* s : h->multi->shards) {
+        const int rc = hipnlp_set_params(s, p);
+        if (rc != HIPNLP_OK) { h->err = "shard on device " + std::to_string(s->dev) + ": " + s->err; return rc; }
+    }
+    return HIPNLP_OK;
+}
+
+// a range of every trajectory's row of a [batch][pitch] array between host and device (one copy command whatever the batch)
+static hipError_t copy_rows(void* dst, const void* src, size_t pitch_doubles, size_t off, size_t count, size_t B, hipMemcpyKind kind, hipStream_t st) {
+    char* d = static_cast<char*>(dst) + off * sizeof(double);
+    const char* s = static_cast<const char*>(src) + off * sizeof(double);
+    if (count == 0) return hipSuccess;
+    if (B == 1) return hipMemcpyAsync(d, s, count * sizeof(double), kind, st);
+    return hipMemcpy2DAsync(d, pitch_doubles * sizeof(double), s, pitch_doubles * sizeof(double), count * sizeof(double), B, kind, st);
+}
+// x for a shard whose launches read it from HBM (big batches): its own knots' records and the halo record in front of them, the
+// horizon-global variables, and the record of the other horizon end for the owner of knot 0 / N - 1 (the periodicity rows) — out of
+// the front's pinned copy into the SAME places of the shard's device array, on the shard's stream
+static int multi_stage_x(hipnlp_handle* h, hipnlp_handle* s) {
+    const size_t B = size_t(h->batch), n = size_t(h->L.n), N = size_t(h->L.N);
+    const size_t k0 = s->kb > 0 ? size_t(s->kb) - 1 : 0;
+    HIP_TRY(h, copy_rows(s->d_x, h->h_x, n, NXK * k0, NXK * (size_t(s->ke) - k0), B, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(h, copy_rows(s->d_x, h->h_x, n, NXK * N, NXG, B, hipMemcpyHostToDevice, s->stream));
+    if (s->kb == 0 && size_t(s->ke) < N) HIP_TRY(h, copy_rows(s->d_x, h->h_x, n, NXK * (N - 1), NXK, B, hipMemcpyHostToDevice, s->stream));
+    if (size_t(s->ke) == N && s->kb > 1) HIP_TRY(h, copy_rows(s->d_x, h->h_x, n, 0, NXK, B, hipMemcpyHostToDevice, s->stream));
+    return HIPNLP_OK;
+}
+static int multi_sync(hipnlp_handle* h) {
+    for (hipnlp_handle* s : h->multi->shards) HIP_TRY(h, hipStreamSynchronize(s->stream));
+    return HIPNLP_OK;
+}
+// f[b] and cost_terms[b][.] from the knots' partials, in the order of hipnlp_reduce_kernel / the in-launch reducer: knot k belongs to
+// group k mod 16, a group is summed in ascending k from +0 (with the same padding zeros), four groups of a quarter as (g0 + g1) + (g2 + g3),
+// the quarters as ((p0 + p1) + p2) + p3, the twelve terms in order
+static void multi_reduce_costs(hipnlp_handle* h) {
+    const MultiState& M = *h->multi;
+    const int N = h->L.N;
+    std::vector<const double*> row(static_cast<size_t>(N), nullptr);   // partials of knot k: [NCT]
+    for (int b = 0; b < h->batch; ++b) {
+        for (size_t i = 0; i < M.shards.size(); ++i) {
+            const hipnlp_handle* s = M.shards[i];
+            for (int kk = 0; kk < s->nk; ++kk) row[size_t(s->kb + kk)] = M.h_cost + M.cost_off[i] + (size_t(b) * size_t(s->nk) + size_t(kk)) * NCT;
+        }
+        double tot = 0.0;
+        for (int c = 0; c < NCT; ++c) {
+            double G[RGRP];
+            for (int g = 0; g < RGRP; ++g) {
+                double acc = 0.0;
+                for (int k0 = g; k0 < N; k0 += RGRP * RUNR)
+                    for (int u = 0; u < RUNR; ++u) { const int k = k0 + u * RGRP; acc += k < N ? row[size_t(k)][c] : 0.0; }
+                G[g] = acc;
+            }
+            double P[4];
+            for (int w = 0; w < 4; ++w) P[w] = (G[4 * w] + G[4 * w + 1]) + (G[4 * w + 2] + G[4 * w + 3]);
+            const double term = ((P[0] + P[1]) + P[2]) + P[3];
+            h->h_cost_terms[size_t(b) * NCT + size_t(c)] = term;
+            tot += term;
+        }
+        h->h_f[b] = tot;
+    }
+}
+static_assert(RGRP == 16 && RWG / 64 == 4, "multi_reduce_costs restates the tree of hipnlp_reduce_kernel");
+
+// One evaluation by all shards.  o[q] (grad, g, jac): a device-visible HOST address every shard stores its entries into — the caller's
+// registered array or the front's pinned block — or null: the output stays in the HBM of each shard (its own d_grad / d_g / d_jac).
+static int multi_evaluate(hipnlp_handle* h, double* const o[3], bool vary_only, std::chrono::steady_clock::time_point* t_enqueued) {
+    MultiState& M = *h->multi;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t i = 0; i < M.shards.size(); ++i) {
+        hipnlp_handle* s = M.shards[i];
+        HIP_TRY(h, hipSetDevice(s->dev));
+        const double* xsrc = h->hd_x;
+        if (!h->x_zero_copy) {
+            const int rc = multi_stage_x(h, s);
+            if (rc != HIPNLP_OK) return rc;
+            xsrc = s->d_x;
+        }
+        s->early_store = h->early_store;
+        const int rc = launch(s, xsrc, s->d_f, o[0] ? o[0] : s->d_grad, o[1] ? o[1] : s->d_g, o[2] ? o[2] : s->d_jac, s->stream, nullptr, false, false, true,
+                              nullptr, 0, 0, vary_only && o[2] != nullptr, false, false, M.hd_cost[i]);
+        if (rc != HIPNLP_OK) { h->err = "shard on device " + std::to_string(s->dev) + ": " + s->err; return rc; }
+        M.shard_us[2 * i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (t_enqueued) *t_enqueued = std::chrono::steady_clock::now();
+    for (size_t i = 0; i < M.shards.size(); ++i) {
+        HIP_TRY(h, hipStreamSynchronize(M.shards[i]->stream));
+        M.shard_us[2 * i + 1] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (h->seq == INT32_MAX) { std::memset(h->h_flag, 0, size_t(h->batch) * sizeof(int32_t)); h->seq = 0; }   // (the generation of the front's non-finite flags)
+    ++h->seq;
+    for (const hipnlp_handle* s : M.shards)
+        for (int b = 0; b < h->batch; ++b) if (s->h_flag[b] == s->seq) h->h_flag[b] = h->seq;
+    multi_reduce_costs(h);
+    return HIPNLP_OK;
+}
+// A cached output that is still in the shards' HBM, asked for now (new_x = 0): every shard sends its part — q = 0: its knots' entries
+// of grad f; q = 2: its knot blocks of jac g (vary_run: the varying run of every block, by a small kernel, into a destination that holds
+// the constants) — to dst (host address: a registered caller array or the pinned block; dst_dev: its device-visible address).
+// Enqueued on the shards' streams; multi_sync afterwards.  (g is never fetched this way: its rows are scattered over the constraint
+// blocks; an evaluation that left g in HBM marks it `gone` and a later request evaluates again.)
+static int multi_fetch(hipnlp_handle* h, int q, double* dst, double* dst_dev, bool vary_run) {
+    const size_t B = size_t(h->batch);
+    for (hipnlp_handle* s : h->multi->shards) {
+        HIP_TRY(h, hipSetDevice(s->dev));
+        const Layout& L = s->L;
+        if (q == 0) HIP_TRY(h, copy_rows(dst, s->d_grad, size_t(L.n), size_t(s->dims.shard_grad_off), size_t(s->dims.shard_grad), B, hipMemcpyDeviceToHost, s->stream));
+        else if (vary_run) {
+            hipLaunchKernelGGL(hipnlp_fetch_vary_kernel, dim3(unsigned(s->nk), unsigned(s->batch)), dim3(256), 0, s->stream, (const double*)s->d_jac, dst_dev, s->kb, L.N,
+                               int64_t(L.nnz), L.nnz_v[VAR_FIRST], L.nnz_v[VAR_INTERIOR], L.nvary_v[VAR_FIRST], L.nvary_v[VAR_INTERIOR], L.nvary_v[VAR_LAST]);
+            HIP_TRY(h, hipGetLastError());
+        } else HIP_TRY(h, copy_rows(dst, s->d_jac, size_t(L.nnz), size_t(s->dims.shard_jac_off), size_t(s->dims.shard_nnz), B, hipMemcpyDeviceToHost, s->stream));
+    }
+    return HIPNLP_OK;
+}
+
+int hipnlp_multi_create(const hipnlp_desc* desc, const int32_t* devices, int n_devices, hipnlp_handle** out) {
+    if (!desc || !out || !devices) { g_create_error = "null argument"; return HIPNLP_E_INVALID; }
+    *out = nullptr;
+    if (n_devices < 1 || n_devices > 64) { g_create_error = "hipnlp_multi_create: 1 .. 64 devices"; return HIPNLP_E_INVALID; }
+    const int N = desc->settings.horizon;
+    if (!((desc->knot_begin == 0 && desc->knot_end == 0) || (desc->knot_begin == 0 && desc->knot_end == N))) {
+        g_create_error = "hipnlp_multi_create: the descriptor names the whole horizon (knot_begin = knot_end = 0); the library cuts it";
+        return HIPNLP_E_INVALID;
+    }
+    if (n_devices > N) { g_create_error = "hipnlp_multi_create: more devices than knots (every shard owns at least one knot)"; return HIPNLP_E_INVALID; }
+    hipnlp_desc fd = *desc;
+    fd.knot_begin = fd.knot_end = 0;
+    fd.device = devices[0];
+    hipnlp_handle* h = nullptr;
+    int rc = create_handle(&fd, &h, true);
+    if (rc != HIPNLP_OK) return rc;
+    MultiState* M = new (std::nothrow) MultiState();
+    if (!M) { g_create_error = "out of memory"; hipnlp_destroy(h); return HIPNLP_E_ALLOC; }
+    h->multi = M;
+    auto fail = [&](int code, const std::string& msg) { g_create_error = msg; hipnlp_destroy(h); return code; };
+    // contiguous, balanced, never empty: the first (N mod n_devices) shards own one knot more (hippopt_amd/sharded.py knot_range)
+    const int q = N / n_devices, r = N % n_devices;
+    size_t cost_doubles = 0;
+    for (int i = 0; i < n_devices; ++i) {
+        hipnlp_desc sd = *desc;
+        sd.device = devices[i];
+        sd.knot_begin = i * q + std::min(i, r);
+        sd.knot_end = sd.knot_begin + q + (i < r ? 1 : 0);
+        hipnlp_handle* s = nullptr;
+        rc = hipnlp_create(&sd, &s);
+        if (rc != HIPNLP_OK) return fail(rc, "shard " + std::to_string(i) + " on device " + std::to_string(devices[i]) + ": " + g_create_error);
+        M->shards.push_back(s);
+        // (the shard handles serve the front and nobody else: they register nothing by themselves)
+        s->auto_reg = false;
+        M->cost_off.push_back(cost_doubles);
+        cost_doubles += size_t(s->batch) * size_t(s->nk) * NCT;
+    }
+    M->shard_us.assign(size_t(2 * n_devices), 0.0);
+    if (hipSetDevice(h->dev) != hipSuccess || hipHostMalloc(&M->h_cost, cost_doubles * sizeof(double), hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        M->h_cost = nullptr;
+        return fail(HIPNLP_E_ALLOC, "hipnlp_multi_create: pinned block of the cost partials");
+    }
+    std::memset(M->h_cost, 0, cost_doubles * sizeof(double));
+    // the pinned blocks are addressed by the kernels of every device through ONE device-visible address (as the registered arrays of the
+    // caller are: the table of ranges holds one address per range): a runtime that maps them elsewhere on some device is refused here
+    for (int i = 0; i < n_devices; ++i) {
+        void *cd = nullptr, *xd = nullptr, *od = nullptr;
+        if (hipSetDevice(devices[i]) != hipSuccess || hipHostGetDevicePointer(&cd, M->h_cost, 0) != hipSuccess || hipHostGetDevicePointer(&xd, h->h_x, 0) != hipSuccess ||
+            hipHostGetDevicePointer(&od, h->h_out, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(HIPNLP_E_NODEVICE, "hipnlp_multi_create: device " + std::to_string(devices[i]) + " cannot address the pinned staging blocks");
+        }
+        if (xd != static_cast<void*>(h->hd_x) || od != static_cast<void*>(h->hd_f))
+            return fail(HIPNLP_E_UNSUPPORTED, "hipnlp_multi_create: device " + std::to_string(devices[i]) + " maps pinned host memory at an address of its own");
+        M->hd_cost.push_back(static_cast<double*>(cd) + M->cost_off[size_t(i)]);
+    }
+    (void)hipSetDevice(h->dev);
+    *out = h;
+    return HIPNLP_OK;
+}
+
+int hipnlp_multi_info(const hipnlp_handle* h, int32_t* n_shards, int32_t* devices, int32_t* knot_begin, int32_t* knot_end, int32_t* waves) {
+    if (!h || !n_shards) return HIPNLP_E_INVALID;
+    const int cap = *n_shards;
+    *n_shards = h->multi ? int(h->multi->shards.size()) : 0;
+    if (!h->multi) return HIPNLP_OK;
+    for (int i = 0; i < *n_shards && i < cap; ++i) {
+        const hipnlp_handle* s = h->multi->shards[size_t(i)];
+        if (devices) devices[i] = s->dev;
+        if (knot_begin) knot_begin[i] = s->kb;
+        if (knot_end) knot_end[i] = s->ke;
+        if (waves) waves[i] = s->wide ? 8 : 4;
+    }
+    return HIPNLP_OK;
+}
+int hipnlp_multi_breakdown(const hipnlp_handle* h, double* us) {
+    if (!h || !h->multi || !us) return HIPNLP_E_INVALID;
+    std::memcpy(us, h->multi->shard_us.data(), h->multi->shard_us.size() * sizeof(double));
+    return HIPNLP_OK;
+}
+
 // ---- exact Hessian of the Lagrangian (IPOPT eval_h) ----------------------------------------------------------------------------
 static int hess_prepare(hipnlp_handle* h) {
     if (h->hess_state == 1) return HIPNLP_OK;
@@ -1927,6 +2191,14 @@ static int hess_prepare(hipnlp_handle* h) {
         h->hess_layout_built = true;
     }
     if (!h->hess_layout_ok) { h->hess_state = -1; h->err = h->HL.error; return HIPNLP_E_UNSUPPORTED; }
+    if (h->multi) {   // a front handle keeps the layout (structure, counts); the tables and flags are the shards'
+        for (hipnlp_handle* s : h->multi->shards) {
+            const int rc = hess_prepare(s);
+            if (rc != HIPNLP_OK) { h->err = "shard on device " + std::to_string(s->dev) + ": " + s->err; return rc; }
+        }
+        h->hess_state = 1;
+        return HIPNLP_OK;
+    }
     // device side: every piece is allocated at most once; a failure leaves the pieces that exist for the next attempt
     HIP_TRY(h, hipSetDevice(h->dev));
     if (!h->d_ht) HIP_TRY(h, hipMalloc(&h->d_ht, sizeof(HessTables)));
@@ -1978,13 +2250,16 @@ int hipnlp_hess_sparsity(hipnlp_handle* h, int32_t* irow, int32_t* jcol) {
     return HIPNLP_OK;
 }
 static int hess_launch(hipnlp_handle* h, const double* x_dev, const double* sigma_dev, const double* lambda_dev, double* hess_dev, hipStream_t s,
-                       bool host_block = false, bool early = false) {
+                       bool host_block = false, bool early = false, int64_t whole_stride = 0) {
+    // whole_stride > 0 (shard launches of a multi-device handle): hess_dev is the value array of the WHOLE horizon [batch][whole_stride]; the
+    // shard's knot blocks go to their places in it
     HArgs a;
     a.tb = h->d_tb; a.ht = h->d_ht; a.x = x_dev; a.pk = h->d_pk; a.gp = h->d_gp;
     a.sigma = sigma_dev; a.lambda = lambda_dev; a.hess = hess_dev; a.flag = h->d_hflag;
     a.flag_host = host_block ? h->hd_hflag : nullptr;
     a.N = h->L.N; a.n = h->L.n; a.m = h->L.m; a.knot_begin = h->kb;
     a.hstride = hess_count(h); a.hoff = h->HL.knot_base(h->kb);
+    if (whole_stride > 0) { a.hstride = whole_stride; a.hoff = 0; }
     if (h->hseq == INT32_MAX) {   // (generation of the Hessian kernel's non-finite flags: start over before it wraps)
         HIP_TRY(h, hipDeviceSynchronize());
         HIP_TRY(h, hipMemset(h->d_hflag, 0, size_t(h->batch) * sizeof(int32_t)));
@@ -2015,6 +2290,7 @@ static int hess_launch(hipnlp_handle* h, const double* x_dev, const double* sigm
 }
 int hipnlp_eval_hess_device(hipnlp_handle* h, const double* x_dev, const double* obj_factor_dev, const double* lambda_dev, double* hess_dev, void* stream) {
     if (!h || !x_dev || !obj_factor_dev || !lambda_dev || !hess_dev) return HIPNLP_E_INVALID;
+    NOT_FRONT(h, "hipnlp_eval_hess_device");
     if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
     const int rc = hess_prepare(h);
     if (rc != HIPNLP_OK) return rc;
@@ -2033,11 +2309,12 @@ int hipnlp_eval_hess_at(hipnlp_handle* h, const double* x, int new_x, const doub
     HIP_TRY(h, hipSetDevice(h->dev));
     // inputs [sigma | lambda] in one device block with a pinned mirror: one H2D copy (the kernel gathers the multipliers through the
     // slot -> row map: scattered 8-byte reads belong in HBM, not on PCIe); every piece allocated at most once
-    if (!h->d_sigma) { HIP_TRY(h, hipMalloc(&h->d_sigma, B * (1 + m) * sizeof(double))); h->d_lambda = h->d_sigma + B; }
-    if (!h->h_sl) HIP_TRY(h, hipHostMalloc(&h->h_sl, B * (1 + m) * sizeof(double)));
-    if (!h->d_hess) HIP_TRY(h, hipMalloc(&h->d_hess, B * hn * sizeof(double)));
+    const unsigned pin_flags = h->is_front ? (hipHostMallocPortable | hipHostMallocMapped) : hipHostMallocDefault;   // (a front's blocks: every shard's device)
+    if (!h->d_sigma && !h->is_front) { HIP_TRY(h, hipMalloc(&h->d_sigma, B * (1 + m) * sizeof(double))); h->d_lambda = h->d_sigma + B; }
+    if (!h->h_sl) HIP_TRY(h, hipHostMalloc(&h->h_sl, B * (1 + m) * sizeof(double), pin_flags));
+    if (!h->d_hess && !h->is_front) HIP_TRY(h, hipMalloc(&h->d_hess, B * hn * sizeof(double)));
     if (!h->h_hess) {
-        HIP_TRY(h, hipHostMalloc(&h->h_hess, B * hn * sizeof(double)));
+        HIP_TRY(h, hipHostMalloc(&h->h_hess, B * hn * sizeof(double), pin_flags));
         void* hd = nullptr;
         HIP_TRY(h, hipHostGetDevicePointer(&hd, h->h_hess, 0));
         h->hd_hess = static_cast<double*>(hd);
@@ -2055,7 +2332,7 @@ int hipnlp_eval_hess_at(hipnlp_handle* h, const double* x, int new_x, const doub
     std::memcpy(h->h_sl, obj_factor, B * sizeof(double));
     std::memcpy(h->h_sl + B, lambda, B * m * sizeof(double));
     const double* xsrc = h->hd_x;   // x: read by the kernel straight from the pinned staging copy, as in hipnlp_eval
-    if (!h->x_zero_copy) {
+    if (!h->x_zero_copy && !h->multi) {
         if (stage_x) HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_x, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
         xsrc = h->d_x;
     }
@@ -2065,9 +2342,37 @@ int hipnlp_eval_hess_at(hipnlp_handle* h, const double* x, int new_x, const doub
         void* hd = nullptr;
         HIP_TRY(h, hipHostGetDevicePointer(&hd, h->h_sl, 0));
         sl_dev = static_cast<const double*>(hd);
-    } else {
+    } else if (!h->multi) {
         HIP_TRY(h, hipMemcpyAsync(h->d_sigma, h->h_sl, B * (1 + m) * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
+    // one Hessian by this handle's device — or by every shard's: its knot blocks into their places of the whole value array `dest`, x and
+    // the multipliers out of the front's pinned blocks (big batches: out of the shard's own device copies, made on its stream first)
+    auto run = [&](double* dest, bool early_run) -> int {
+        if (!h->multi) {
+            const int rl = hess_launch(h, xsrc, sl_dev, sl_dev + B, dest, h->stream, true, early_run);
+            if (rl != HIPNLP_OK) return rl;
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            return HIPNLP_OK;
+        }
+        for (hipnlp_handle* s : h->multi->shards) {
+            HIP_TRY(h, hipSetDevice(s->dev));
+            const double *xs = xsrc, *sl = sl_dev;
+            if (!h->x_zero_copy) {
+                const int rs = multi_stage_x(h, s);
+                if (rs != HIPNLP_OK) return rs;
+                xs = s->d_x;
+            }
+            if (!h->lam_zero_copy) {
+                if (!s->d_sigma) { HIP_TRY(h, hipMalloc(&s->d_sigma, B * (1 + m) * sizeof(double))); s->d_lambda = s->d_sigma + B; }
+                HIP_TRY(h, hipMemcpyAsync(s->d_sigma, h->h_sl, B * (1 + m) * sizeof(double), hipMemcpyHostToDevice, s->stream));
+                sl = s->d_sigma;
+            }
+            s->early_store = h->early_store;
+            const int rl = hess_launch(s, xs, sl, sl + B, dest, s->stream, true, early_run, int64_t(hn));
+            if (rl != HIPNLP_OK) { h->err = "shard on device " + std::to_string(s->dev) + ": " + s->err; return rl; }
+        }
+        return multi_sync(h);
+    };
     // the values leave the kernel as PCIe stores into the pinned block — or straight into the CALLER'S array when that lies in a
     // registered range (no 1.2 MB host copy behind the launch): registered by the caller, or by the handle itself at the array's second
     // consecutive sight (IPOPT evaluates the Hessian into the value array of its own matrix); a store into an array the handle
@@ -2099,9 +2404,8 @@ int hipnlp_eval_hess_at(hipnlp_handle* h, const double* x, int new_x, const doub
         }
     }
     const auto t_launch = std::chrono::steady_clock::now();
-    rc = hess_launch(h, xsrc, sl_dev, sl_dev + B, direct ? direct : h->hd_hess, h->stream, true, early);
+    rc = run(direct ? direct : h->hd_hess, early);
     if (rc != HIPNLP_OK) return rc;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (sample) {
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_launch).count();
         h->hess_tune_best[early ? 1 : 0] = std::min(h->hess_tune_best[early ? 1 : 0], us);
@@ -2113,13 +2417,18 @@ int hipnlp_eval_hess_at(hipnlp_handle* h, const double* x, int new_x, const doub
             (void)drop_stale_range(h, hess);
             h->no_auto[3] = hess;
             h->auto_fallbacks++;
-            rc = hess_launch(h, xsrc, sl_dev, sl_dev + B, h->hd_hess, h->stream, true, early);
+            rc = run(h->hd_hess, early);
             if (rc != HIPNLP_OK) return rc;
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
             direct = nullptr;
         }
     }
     if (!direct) std::memcpy(hess, h->h_hess, hbytes);
+    if (h->multi) {
+        for (const hipnlp_handle* s : h->multi->shards)
+            for (size_t b = 0; b < B; ++b)
+                if (s->h_hflag[b] == s->hseq) { h->err = "non-finite value produced by the evaluation"; return HIPNLP_E_NUMERIC; }
+        return HIPNLP_OK;
+    }
     for (size_t b = 0; b < B; ++b)
         if (h->h_hflag[b] == h->hseq) { h->err = "non-finite value produced by the evaluation"; return HIPNLP_E_NUMERIC; }
     return HIPNLP_OK;
@@ -2140,6 +2449,7 @@ static bool is_local_device_memory(const hipnlp_handle* h, const void* p) {
 }
 int hipnlp_eval_device(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, void* stream) {
     if (!h || !x_dev) return HIPNLP_E_INVALID;
+    NOT_FRONT(h, "hipnlp_eval_device");
     if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
     HIP_TRY(h, hipSetDevice(h->dev));
     h->have_result = false;
@@ -2172,6 +2482,7 @@ int hipnlp_eval_device(hipnlp_handle* h, const double* x_dev, double* f_dev, dou
 
 int hipnlp_eval_device_shard(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_shard, double* g_stage, double* jac_shard, void* stream) {
     if (!h || !x_dev) return HIPNLP_E_INVALID;
+    NOT_FRONT(h, "hipnlp_eval_device_shard");
     if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
     HIP_TRY(h, hipSetDevice(h->dev));
     h->have_result = false;
@@ -2180,6 +2491,7 @@ int hipnlp_eval_device_shard(hipnlp_handle* h, const double* x_dev, double* f_de
 
 int hipnlp_eval_device_peers(hipnlp_handle* h, const double* x_dev, double* const* peer_out_dev, int world, int rank, void* stream) {
     if (!h || !x_dev || !peer_out_dev || world < 1 || rank < 0 || rank >= 64) return HIPNLP_E_INVALID;   // (world: buffers stored to; rank: this shard's cost slot)
+    NOT_FRONT(h, "hipnlp_eval_device_peers");
     if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
     if (h->batch != 1) { h->err = "hipnlp_eval_device_peers: one trajectory per handle (batch 1)"; return HIPNLP_E_INVALID; }
     if (!h->fused) { h->err = "hipnlp_eval_device_peers: shards of at most 256 knots (the shard's cost is summed inside the launch)"; return HIPNLP_E_INVALID; }
@@ -2204,6 +2516,7 @@ int hipnlp_jac_vary_layout(const hipnlp_handle* h, int64_t* out) {
 }
 int hipnlp_fill_jac_constants(hipnlp_handle* h, double* jac_dev, int whole_horizon, void* stream) {
     if (!h || !jac_dev) return HIPNLP_E_INVALID;
+    NOT_FRONT(h, "hipnlp_fill_jac_constants");
     if (!h->params_set) { h->err = "parameters not set (hipnlp_set_params)"; return HIPNLP_E_PARAMS; }
     if (!h->d_ctpl || !h->d_ctpl_of_b) { h->err = "hipnlp_fill_jac_constants: no constant templates for this handle"; return HIPNLP_E_UNSUPPORTED; }
     HIP_TRY(h, hipSetDevice(h->dev));
@@ -2219,6 +2532,7 @@ int hipnlp_fill_jac_constants(hipnlp_handle* h, double* jac_dev, int whole_horiz
 }
 int hipnlp_eval_device_vary(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_vary_dev, void* stream) {
     if (!h || !x_dev) return HIPNLP_E_INVALID;
+    NOT_FRONT(h, "hipnlp_eval_device_vary");
     const int rc = vary_ready(h, "hipnlp_eval_device_vary");
     if (rc != HIPNLP_OK) return rc;
     HIP_TRY(h, hipSetDevice(h->dev));
@@ -2227,6 +2541,7 @@ int hipnlp_eval_device_vary(hipnlp_handle* h, const double* x_dev, double* f_dev
 }
 int hipnlp_eval_device_shard_vary(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_shard, double* g_stage, double* jac_vary_shard, void* stream) {
     if (!h || !x_dev) return HIPNLP_E_INVALID;
+    NOT_FRONT(h, "hipnlp_eval_device_shard_vary");
     const int rc = vary_ready(h, "hipnlp_eval_device_shard_vary");
     if (rc != HIPNLP_OK) return rc;
     if (g_stage && !h->gs_compact_ok) { h->err = "hipnlp_eval_device_shard_vary: a row stride of this layout does not fit the copy-out word"; return HIPNLP_E_UNSUPPORTED; }
@@ -2236,6 +2551,7 @@ int hipnlp_eval_device_shard_vary(hipnlp_handle* h, const double* x_dev, double*
 }
 int hipnlp_eval_device_peers_vary(hipnlp_handle* h, const double* x_dev, double* const* peer_out_dev, int world, int rank, void* stream) {
     if (!h || !x_dev || !peer_out_dev || world < 1 || rank < 0 || rank >= 64) return HIPNLP_E_INVALID;
+    NOT_FRONT(h, "hipnlp_eval_device_peers_vary");
     const int rc = vary_ready(h, "hipnlp_eval_device_peers_vary");
     if (rc != HIPNLP_OK) return rc;
     if (h->batch != 1) { h->err = "hipnlp_eval_device_peers_vary: one trajectory per handle (batch 1)"; return HIPNLP_E_INVALID; }
@@ -2437,7 +2753,18 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
         const bool f_host = (to_host & HIPNLP_WANT_F) != 0;
         int rc;
         std::chrono::steady_clock::time_point t2, t3;
-        {   // launch + synchronise
+        if (h->multi) {   // every shard's launch, every shard's stores into the same arrays, one wait for all (multi_evaluate)
+            double* const pinned[3] = {h->hd_grad, h->hd_g, h->hd_jac};
+            double* o[3];
+            for (int q = 0; q < 3; ++q) o[q] = sel[q] == 2u ? caller_dev[q] : (sel[q] == 1u ? pinned[q] : nullptr);
+            t2 = t1;
+            rc = multi_evaluate(h, o, vary_only, &t2);
+            if (rc != HIPNLP_OK) return rc;
+            h->x_staged = true;
+            t3 = std::chrono::steady_clock::now();
+            h->host_us[1] = std::chrono::duration<double, std::micro>(t2 - t1).count();
+            h->host_us[2] = std::chrono::duration<double, std::micro>(t3 - t2).count();
+        } else {   // launch + synchronise
             const double* xsrc = h->hd_x;
             if (!h->x_zero_copy) {
                 HIP_TRY(h, hipMemcpyAsync(h->d_x, h->h_x, B * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -2479,9 +2806,10 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
         }
         h->have_result = true;
         h->seq_result = h->seq;
-        h->on_host = (f_host ? HIPNLP_WANT_F : 0u);
+        h->on_host = (f_host || h->multi ? HIPNLP_WANT_F : 0u);   // (a multi-device handle sums the cost on the host: always there)
         for (int q = 0; q < 3; ++q) if (sel[q] == 1u) h->on_host |= bit[q];
         h->gone = dmask | h->early_mask;
+        if (h->multi && sel[1] == 0u) h->gone |= HIPNLP_WANT_G;   // (left in the shards' HBM, scattered over the constraint blocks: asked for later, evaluated again)
         if (direct) *direct = dmask;
     }
     if (h->early_mask && !(new_x)) {   // a cached request for an output that already sits in the caller's own array
@@ -2502,7 +2830,7 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
         // evaluation: a stale mapping is dropped and the output served through the pinned block.
         HIP_TRY(h, hipSetDevice(h->dev));
         unsigned to_caller = 0;
-        if (missing & HIPNLP_WANT_F) HIP_TRY(h, hipMemcpyAsync(h->h_f, h->d_f, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if ((missing & HIPNLP_WANT_F) && !h->multi) HIP_TRY(h, hipMemcpyAsync(h->h_f, h->d_f, B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         double* const caller[3] = {dst.grad_host, dst.g_host, dst.jac_host};
         double* const caller_dev[3] = {dst.grad, dst.g, dst.jac};
         double* const pinned[3] = {h->h_grad, h->h_g, h->h_jac};
@@ -2524,14 +2852,18 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
                     checked[q] = true;
                 }
             }
-            if (vary_run) {
+            if (h->multi) {
+                const int rc = multi_fetch(h, q, caller[q] ? caller[q] : pinned[q], caller_dev[q], vary_run);
+                if (rc != HIPNLP_OK) return rc;
+            } else if (vary_run) {
                 const Layout& L = h->L;
                 hipLaunchKernelGGL(hipnlp_fetch_vary_kernel, dim3(unsigned(h->nk), unsigned(h->batch)), dim3(256), 0, h->stream, hbm[q], caller_dev[q], h->kb, L.N,
                                    int64_t(L.nnz), L.nnz_v[VAR_FIRST], L.nnz_v[VAR_INTERIOR], L.nvary_v[VAR_FIRST], L.nvary_v[VAR_INTERIOR], L.nvary_v[VAR_LAST]);
                 HIP_TRY(h, hipGetLastError());
             } else HIP_TRY(h, hipMemcpyAsync(caller[q] ? caller[q] : pinned[q], hbm[q], bytes[q], hipMemcpyDeviceToHost, h->stream));
         }
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->multi) { const int rc = multi_sync(h); if (rc != HIPNLP_OK) return rc; }
+        else HIP_TRY(h, hipStreamSynchronize(h->stream));
         for (int q = 0; q < 3; ++q)
             if (checked[q]) {
                 const u64* w = reinterpret_cast<const u64*>(caller[q]);
@@ -2539,7 +2871,11 @@ static int host_evaluate(hipnlp_handle* h, const double* x, int new_x, unsigned 
                     (void)drop_stale_range(h, caller[q]);
                     h->no_auto[q] = caller[q];
                     h->auto_fallbacks++;
-                    HIP_TRY(h, hipnlp_internal_memcpy(pinned[q], hbm[q], bytes[q], hipMemcpyDeviceToHost));
+                    if (h->multi) {
+                        int rc = multi_fetch(h, q, pinned[q], nullptr, false);
+                        if (rc == HIPNLP_OK) rc = multi_sync(h);
+                        if (rc != HIPNLP_OK) return rc;
+                    } else HIP_TRY(h, hipnlp_internal_memcpy(pinned[q], hbm[q], bytes[q], hipMemcpyDeviceToHost));
                     to_caller &= ~bit[q];   // (hipnlp_eval copies it out of the pinned block)
                 }
             }
@@ -2750,6 +3086,7 @@ int hipnlp_host_unregister(void* p) {
 
 int hipnlp_cost_terms(hipnlp_handle* h, double* values) {
     if (!h || !values) return HIPNLP_E_INVALID;
+    if (h->is_front && !h->have_result) { h->err = "hipnlp_cost_terms: no evaluation yet (hipnlp_eval)"; return HIPNLP_E_INVALID; }   // (summed on the host by every evaluation)
     if (!h->have_result) {   // a device-path evaluation: its per-term costs are in device memory (the host path stores them straight to the pinned block)
         HIP_TRY(h, hipSetDevice(h->dev));
         HIP_TRY(h, hipDeviceSynchronize());   // (the launch may sit on a stream of the caller's: hipnlp_eval_device(..., stream))
@@ -2781,6 +3118,7 @@ int hipnlp_row_block(const hipnlp_handle* h, int i, const char** name, int32_t* 
 
 int hipnlp_last_kernel_ms(hipnlp_handle* h, float* ms) {
     if (!h || !ms) return HIPNLP_E_INVALID;
+    NOT_FRONT(h, "hipnlp_last_kernel_ms");
     if (!h->timing_valid) { h->err = "no timed evaluation yet (hipnlp_eval, or a launch sampled by hipnlp_profile_begin)"; return HIPNLP_E_INVALID; }
     HIP_TRY(h, hipSetDevice(h->dev));
     HIP_TRY(h, hipEventSynchronize(h->last_e2));
@@ -2790,6 +3128,7 @@ int hipnlp_last_kernel_ms(hipnlp_handle* h, float* ms) {
 
 int hipnlp_profile_begin(hipnlp_handle* h, int max_launches, int stride) {
     if (!h || max_launches < 0 || stride < 1) return HIPNLP_E_INVALID;
+    NOT_FRONT(h, "hipnlp_profile_begin");
     HIP_TRY(h, hipSetDevice(h->dev));
     while (int(h->prof_ev.size()) < 3 * max_launches) {
         hipEvent_t e;
@@ -2932,10 +3271,11 @@ int hipnlp_peer_wait(const unsigned long long* flags_dev, int world, unsigned lo
     return hipGetLastError() == hipSuccess ? HIPNLP_OK : HIPNLP_E_NODEVICE;
 }
 
-int hipnlp_kernels_per_eval(const hipnlp_handle* h) { return h ? (h->fused ? 1 : 2) : HIPNLP_E_INVALID; }
+int hipnlp_kernels_per_eval(const hipnlp_handle* h) { return h ? (h->fused || h->is_front ? 1 : 2) : HIPNLP_E_INVALID; }   // (a multi-device handle: one knot launch per shard, the cost summed on the host)
 
 int hipnlp_profile_end(hipnlp_handle* h, double* mean_knot_kernel_ms, double* mean_launch_ms, int* count) {
     if (!h) return HIPNLP_E_INVALID;
+    NOT_FRONT(h, "hipnlp_profile_end");
     HIP_TRY(h, hipSetDevice(h->dev));
     double a = 0.0, b = 0.0;
     for (int i = 0; i < h->prof_n; ++i) {
@@ -2959,6 +3299,8 @@ int hipnlp_profile_end(hipnlp_handle* h, double* mean_knot_kernel_ms, double* me
 
 #ifdef HIPNLP_STAMPS
 int hipnlp_debug_stamps(hipnlp_handle* h, unsigned long long* out /*[nk*batch][4][16]*/) {
+    if (!h) return HIPNLP_E_INVALID;
+    NOT_FRONT(h, "hipnlp_debug_stamps");
     HIP_TRY(h, hipSetDevice(h->dev));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipDeviceSynchronize());

@@ -28,6 +28,7 @@ EXPORTS = [
     "hipnlp_device_numa_node", "hipnlp_pin_thread_to_device_numa_node",
     "hipnlp_hess_nnz", "hipnlp_hess_sparsity", "hipnlp_eval_hess", "hipnlp_eval_hess_at", "hipnlp_set_hessian_early_run", "hipnlp_get_hessian_early_run", "hipnlp_eval_hess_device",
     "hipnlp_eval_pinned", "hipnlp_set_prefetch", "hipnlp_set_early_outputs", "hipnlp_set_host_timing", "hipnlp_host_register", "hipnlp_host_unregister",
+    "hipnlp_multi_create", "hipnlp_multi_info", "hipnlp_multi_breakdown",
     "hipnlp_host_breakdown", "hipnlp_set_auto_register", "hipnlp_host_stats", "hipnlp_set_constant_jacobian", "hipnlp_forget_jac_destination", "hipnlp_jac_constant_mask", "hipnlp_host_release_auto_ranges",
     "hipnlp_pose_create", "hipnlp_pose_destroy", "hipnlp_pose_last_error", "hipnlp_pose_get_dims", "hipnlp_pose_set_params",
     "hipnlp_pose_bounds", "hipnlp_pose_sparsity", "hipnlp_pose_eval", "hipnlp_pose_eval_device", "hipnlp_pose_cost_terms",
@@ -188,6 +189,9 @@ def load_library(path=None):
     lib.hipnlp_eval_device_shard_vary.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.hipnlp_eval_device_peers_vary.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
     lib.hipnlp_reassemble_scatter.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int64, vp, vp]
+    lib.hipnlp_multi_create.argtypes = [C.POINTER(_abi.DescC), ip, C.c_int, C.POINTER(vp)]
+    lib.hipnlp_multi_info.argtypes = [vp, ip, ip, ip, ip, ip]
+    lib.hipnlp_multi_breakdown.argtypes = [vp, dp]
     _libs[path] = lib
     return lib
 
@@ -201,16 +205,19 @@ def _ip(a):
 
 
 class HipNlp:
-    """One engine handle: a kinodynamic NLP (settings + robot model) on one HIP device."""
+    """One engine handle: a kinodynamic NLP (settings + robot model) on one HIP device — or, `devices=[...]`, on several behind the
+    same host-buffer calls (hipnlp_multi_create: one caller, the horizon cut into one contiguous knot range per entry)."""
 
     def __init__(self, settings, model, batch=1, knot_begin=0, knot_end=0, device=0, desc=None, detect_simple_bounds=False,
-                 jac_varying_first=False, library=None):
+                 jac_varying_first=False, library=None, devices=None):
         """desc: a ready hipnlp_desc (e.g. hippopt_amd.from_reference.from_reference) instead of settings / model
         detect_simple_bounds: the handle is the REDUCED NLP nlpsol hands to IPOPT under Opti's {"detect_simple_bounds": True}
         (HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS): single-variable rows are bounds on x, not rows of g
         jac_varying_first: HIPNLP_FLAG_JAC_VARYING_FIRST — inside a knot's block of jac g the entries that depend on x come first,
         the constant ones behind them (triplet consumers such as IPOPT; `sparsity()` returns that order)
-        library: path of another build of the library (tests: the diagnostic build); default: the product library"""
+        library: path of another build of the library (tests: the diagnostic build); default: the product library
+        devices: HIP ordinals, one shard of the horizon per entry (an ordinal may repeat: its shards share the card) — the handle then
+        serves eval / eval_pinned / eval_hess / cost_terms and the metadata calls; the device-pointer calls raise HipNlpError(-6)"""
         self.lib = load_library(library)
         if desc is not None:
             self.desc = desc
@@ -224,7 +231,14 @@ class HipNlp:
             self.desc.device = int(device)
             self.desc.flags = (_abi.FLAG_DETECT_SIMPLE_BOUNDS if detect_simple_bounds else 0) | (_abi.FLAG_JAC_VARYING_FIRST if jac_varying_first else 0)
         h = C.c_void_p()
-        rc = self.lib.hipnlp_create(C.byref(self.desc), C.byref(h))
+        self.devices = None if devices is None else [int(v) for v in devices]
+        if self.devices is not None:
+            if knot_begin or knot_end:
+                raise ValueError("devices=[...] cuts the whole horizon itself: no knot_begin / knot_end")
+            dev = (C.c_int32 * len(self.devices))(*self.devices)
+            rc = self.lib.hipnlp_multi_create(C.byref(self.desc), dev, len(self.devices), C.byref(h))
+        else:
+            rc = self.lib.hipnlp_create(C.byref(self.desc), C.byref(h))
         if rc != 0:
             raise HipNlpError(rc, self.lib.hipnlp_last_error(None).decode())
         self.h = h
@@ -424,6 +438,19 @@ class HipNlp:
         out = (C.c_long * 8)()
         self._check(self.lib.hipnlp_host_stats(self.h, out))
         return dict(zip(("auto_registered", "auto_fallbacks", "auto_ranges", "evaluations", "constant_fills", "constant_refills", "constant_entries", "constant_slices_healed"), list(out)))
+
+    def shards(self):
+        """hipnlp_multi_info: [{"device", "knot_begin", "knot_end", "waves"}] of a multi-device handle ([] for a plain one)"""
+        n = C.c_int32(64)
+        arr = [(C.c_int32 * 64)() for _ in range(4)]
+        self._check(self.lib.hipnlp_multi_info(self.h, C.byref(n), *arr))
+        return [dict(zip(("device", "knot_begin", "knot_end", "waves"), (int(a[i]) for a in arr))) for i in range(n.value)]
+
+    def multi_breakdown(self):
+        """us [shards, 2] of the last evaluation of a multi-device handle: (enqueued, seen complete) on the host clock, from the start of the launch loop"""
+        out = np.zeros((len(self.shards()), 2))
+        self._check(self.lib.hipnlp_multi_breakdown(self.h, _dp(out)))
+        return out
 
     def set_constant_jacobian(self, on=True):
         """hipnlp_set_constant_jacobian: destinations of jac g hold the constant entries, launches store the varying ones only.  Default: on

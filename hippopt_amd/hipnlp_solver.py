@@ -234,7 +234,7 @@ class _CallbackCache:
 class HipNlpSolver(OptimizationSolver):
     def __init__(self, settings, model, device=0, inner_solver="auto", options_solver=None, problem="kinodynamic",
                  callback_criterion: CallbackCriterion = None, callback_save_costs=True, callback_save_constraint_multipliers=True,
-                 error_on_fail=True, detect_simple_bounds=True, jac_varying_first=True, pin_to_device_numa_node=False):
+                 error_on_fail=True, detect_simple_bounds=True, jac_varying_first=True, pin_to_device_numa_node=False, devices=None):
         """callback_* as in OptiSolver (opti_solver.py:105-131).  error_on_fail: CasADi's Opti raises when IPOPT does not report
         success (e.g. Maximum_Iterations_Exceeded), which is what triggers the best-iterate fallback of opti_solver.py:479-520;
         False keeps the last iterate of an unconverged run instead (useful for smoke runs with a few iterations).
@@ -245,6 +245,9 @@ class HipNlpSolver(OptimizationSolver):
         pin_to_device_numa_node: restrict the calling thread to the CPUs of the card's NUMA node before the engine and its arrays are
         created (hippopt_amd.hipnlp.pin_to_device_numa_node: the callbacks are link-bound, 2 - 5 us per call slower from the other
         socket of the host).  Off by default: it changes the affinity of the CALLER's thread; a deployment does it once for the process.
+        devices: HIP ordinals — the kinodynamic horizon is cut into one contiguous knot range per entry and every callback of the ONE NLP
+        driver in this process is evaluated by all of them (hipnlp_multi_create: x staged once, every shard storing its entries straight
+        into the driver's arrays over its own link); an ordinal may repeat.  None: one handle on `device`.
         iterate_trace (attribute): set to a list to have (iteration, x, cost, primal infeasibility) of every iterate appended."""
         self._callback_criterion = callback_criterion
         self._callback_save_costs = callback_save_costs
@@ -260,6 +263,9 @@ class HipNlpSolver(OptimizationSolver):
             raise ValueError("problem must be 'kinodynamic' or 'pose'")
         self._problem_kind = problem
         self._settings, self._model, self._device = settings, model, device
+        self._devices = None if devices is None else [int(d) for d in devices]
+        if self._devices is not None and problem != "kinodynamic":
+            raise ValueError("devices=[...] shards the kinodynamic horizon; the pose finder is a single knot")
         self._inner_solver = inner_solver
         self._options = dict(options_solver or {})
         self._logger = logging.getLogger("[hippopt_amd::HipNlpSolver]")
@@ -367,14 +373,14 @@ class HipNlpSolver(OptimizationSolver):
         if self._engine is None:
             from .hipnlp import HipNlp, HipPose, pin_to_device_numa_node  # raises loudly without the library / a device
             if self._pin:
-                pin_to_device_numa_node(self._device)
+                pin_to_device_numa_node(self._devices[0] if self._devices else self._device)
             if self._problem_kind == "pose":
                 self._engine = _PoseEngine(HipPose(self._settings, self._model, batch=1, device=self._device))
             else:
                 # (the NLP drivers take jac g as triplets — IPOPT's jacobianstructure / a COO matrix: inside a knot's block the entries
                 #  that depend on x come first, so the host path stores ONE contiguous run per knot and leaves the constant ones alone)
                 self._engine = HipNlp(self._settings, self._model, batch=1, device=self._device, detect_simple_bounds=self._detect_simple_bounds,
-                                      jac_varying_first=self._jac_varying_first)
+                                      jac_varying_first=self._jac_varying_first, devices=self._devices)
         return self._engine
 
     def get_constraint_expressions(self):

@@ -11,7 +11,9 @@ from .variables import Variables
 
 
 class Planner:
-    def __init__(self, settings: Settings, model, device: int = 0, inner_solver: str = "auto", error_on_fail: bool = True) -> None:
+    def __init__(self, settings: Settings, model, device: int = 0, inner_solver: str = "auto", error_on_fail: bool = True, devices=None) -> None:
+        """devices: HIP ordinals — the horizon is cut into one knot range per entry, every callback of the one NLP driver is evaluated by
+        all of them (HipNlpSolver(devices=...)); None: one handle on `device`"""
         if not settings.is_valid():
             raise ValueError("Settings are not valid")
         self.settings = copy.deepcopy(settings)
@@ -25,7 +27,7 @@ class Planner:
                                                 options_solver=self.settings.solver_options, callback_criterion=opti_callback,
                                                 callback_save_costs=self.settings.opti_callback_save_costs,
                                                 callback_save_constraint_multipliers=self.settings.opti_callback_save_constraint_multipliers,
-                                                error_on_fail=error_on_fail)
+                                                error_on_fail=error_on_fail, devices=devices)
         # the wiring of the reference's planner (planner.py:72-80), names kept: only the optimization solver differs
         self.solver = MultipleShootingSolver(optimization_solver=self.optimization_solver)
         self.ocp = OptimalControlProblem.create(input_structure=variables, optimal_control_solver=self.solver,

@@ -502,6 +502,43 @@ int hipnlp_eval_device_peers_vary(hipnlp_handle* h, const double* x_dev, double*
 int hipnlp_reassemble_scatter(const double* gathered_dev, const int64_t* src_dev, const int64_t* dst_dev, double* out_dev, int64_t count, int world,
                               int64_t shard_len, double* f_out_dev, void* stream);
 
+/* ---- One caller, several devices ---------------------------------------------------------------------------------------------------------
+ * The reference has ONE caller of the callbacks: IPOPT, in the process that runs self._solver.solve()
+ * (/root/reference/src/hippopt/base/opti_solver.py:479); x lives in that process's memory and f, grad f, g, jac g are wanted in arrays of
+ * its own.  hipnlp_multi_create serves that caller from SEVERAL devices behind the host-buffer entry points above: the handle it returns
+ * is used exactly like one of hipnlp_create — hipnlp_set_params, hipnlp_bounds, hipnlp_sparsity, hipnlp_eval, hipnlp_eval_pinned,
+ * hipnlp_eval_hess / _at, hipnlp_hess_nnz / _sparsity, hipnlp_cost_terms, the hipnlp_set_* switches of the host path, hipnlp_host_stats,
+ * the hipnlp_ipopt_* callbacks, hipnlp_destroy — with the same results:
+ *   - the horizon is cut into n_devices contiguous knot ranges, the first (horizon mod n_devices) of them one knot longer; the rows of the
+ *     trapezoid defect of interval k -> k + 1 belong to the owner of knot k + 1 (the naming of base/multiple_shooting_solver.py:713-742),
+ *     so a shard READS the record of the knot in front of its first one (the halo) besides its own, the six horizon-global variables, and
+ *     the record of the other horizon end where it owns knot 0 or knot N - 1 (periodicity rows); one shard handle per entry of devices[]
+ *     (a device may be named more than once: its shards then share it — how the path is tested on one card);
+ *   - an evaluation copies x ONCE into a pinned block that the kernels of every device read over their own link (big batches: each shard
+ *     copies the records it reads into its own HBM first, on its own stream), launches every shard's kernel — which stores the shard's
+ *     entries of grad f, g and jac g AT THEIR FINAL PLACES in the caller's arrays (registered: hipnlp_host_register, or by the handle at
+ *     their second sight) or in the handle's pinned block, over that device's own link — and waits for all of them.  No data moves
+ *     between the devices and nothing is reassembled;
+ *   - f and the per-term costs are summed by the caller's thread from the knots' partials (96 B per knot, stored to pinned memory by the
+ *     knot workgroups) in the order of the device reduction: bit for bit the f of one handle over the whole horizon, whatever the cut;
+ *     grad f, g, jac g and the Hessian values are those of the knot programs, which do not depend on the cut either (a shard small
+ *     enough to be resident at once runs the eight-wave instantiation of the same program, hipnlp_multi_info: equal to 1e-13, not bit
+ *     for bit, where that differs from the instantiation one handle over the whole horizon would run);
+ *   - an output that is NOT brought to the host by its evaluation (hipnlp_set_prefetch) stays in the shards' HBM; grad f and jac g are
+ *     fetched from there when a later new_x = 0 call asks (one copy per shard), g — scattered over the constraint blocks — is evaluated again.
+ * The device-resident entry points (hipnlp_eval_device*, hipnlp_eval_hess_device, hipnlp_fill_jac_constants, the profiling calls) answer
+ * HIPNLP_E_UNSUPPORTED on such a handle: they belong to one device.
+ *   hipnlp_multi_create     desc: the whole horizon (knot_begin = knot_end = 0; desc->device is ignored); devices[n_devices]: HIP ordinals
+ *   hipnlp_multi_info       *n_shards: in = capacity of the arrays, out = shards of the handle (0: a plain handle); devices / knot_begin /
+ *                           knot_end / waves (4 or 8: the instantiation of the knot kernel the shard launches) may be NULL
+ *   hipnlp_multi_breakdown  us[n_shards][2]: host clock of the last evaluation from the start of the launch loop — shard i enqueued,
+ *                           shard i seen complete (the shards are waited for in order).  Diagnostic.
+ * MEASURED on one card only (several shards of one device, tests/test_gpu_multi.py, bench.py `one_caller`); with one device per shard:
+ * unmeasured in this repository. */
+int hipnlp_multi_create(const hipnlp_desc* desc, const int32_t* devices, int n_devices, hipnlp_handle** out);
+int hipnlp_multi_info(const hipnlp_handle* h, int32_t* n_shards, int32_t* devices, int32_t* knot_begin, int32_t* knot_end, int32_t* waves);
+int hipnlp_multi_breakdown(const hipnlp_handle* h, double* us);
+
 /* Per-named-cost values of the last evaluation (Output.cost_values, base/problem.py:28-56):
  * values[batch][HIPNLP_NCOST_TERMS], summed over knots, in the order of hipnlp_cost_term_name(). */
 #define HIPNLP_NCOST_TERMS 12

@@ -11,7 +11,8 @@
  * 3. A timing loop: IPOPT iterates as four C calls, microseconds per iterate on stdout.
  *
  * usage: harness <input.bin> <output.bin> [timing iterations]
- * input : int32 magic 0x49504F54, int32 desc_bytes, int32 np, int32 points, int32 attach, int32 reserved,
+ * input : int32 magic 0x49504F54, int32 desc_bytes, int32 np, int32 points, int32 attach, int32 shards (0: hipnlp_create; > 0:
+ *         hipnlp_multi_create with that many shards, all on desc.device — one caller, several shard handles behind the same callbacks),
  *         desc bytes, p[np], x[points][n], lambda[m], obj_factor                                     (doubles little endian)
  * output: records { int32 kind (0 f, 1 grad, 2 g, 3 jac, 4 hess, 5 jac structure, 6 hess structure, 7 bounds), int32 point, int32 ok,
  *                   int32 count, double values[count] }
@@ -66,7 +67,7 @@ int main(int argc, char** argv) {
     if (!in) { perror(argv[1]); return 2; }
     int head[6];
     if (fread(head, sizeof(int), 6, in) != 6 || head[0] != 0x49504F54) { fprintf(stderr, "bad input file\n"); return 2; }
-    const int desc_bytes = head[1], np = head[2], points = head[3], attach = head[4];
+    const int desc_bytes = head[1], np = head[2], points = head[3], attach = head[4], shards = head[5];
     if (desc_bytes != (int)sizeof(hipnlp_desc)) { fprintf(stderr, "descriptor of %d bytes, header says %zu\n", desc_bytes, sizeof(hipnlp_desc)); return 2; }
     hipnlp_desc desc;
     if (fread(&desc, 1, sizeof desc, in) != sizeof desc) return 2;
@@ -74,7 +75,12 @@ int main(int argc, char** argv) {
     if (fread(p, sizeof(double), (size_t)np, in) != (size_t)np) return 2;
 
     hipnlp_handle* h = NULL;
-    if (hipnlp_create(&desc, &h) != HIPNLP_OK) { fprintf(stderr, "hipnlp_create: %s\n", hipnlp_last_error(NULL)); return 1; }
+    if (shards > 0) {   /* IPOPT's process drives several shard handles through the same five callbacks */
+        int32_t devices[64];
+        if (shards > 64) { fprintf(stderr, "at most 64 shards\n"); return 2; }
+        for (int i = 0; i < shards; ++i) devices[i] = desc.device;
+        if (hipnlp_multi_create(&desc, devices, shards, &h) != HIPNLP_OK) { fprintf(stderr, "hipnlp_multi_create: %s\n", hipnlp_last_error(NULL)); return 1; }
+    } else if (hipnlp_create(&desc, &h) != HIPNLP_OK) { fprintf(stderr, "hipnlp_create: %s\n", hipnlp_last_error(NULL)); return 1; }
     if (hipnlp_set_params(h, p) != HIPNLP_OK) { fprintf(stderr, "hipnlp_set_params: %s\n", hipnlp_last_error(h)); return 1; }
     Index n = 0, m = 0, nele_jac = 0, nele_hess = 0;
     if (hipnlp_ipopt_sizes(h, &n, &m, &nele_jac, &nele_hess) != HIPNLP_OK) { fprintf(stderr, "sizes: %s\n", hipnlp_last_error(h)); return 1; }
@@ -199,10 +205,10 @@ int main(int argc, char** argv) {
         }
         long stats[8];
         hipnlp_host_stats(h, stats);
-        printf("{\"ipopt_iterate_four_c_calls_us\": %.2f, \"trial_point_two_c_calls_us\": %.2f, \"attach\": %d, "
+        printf("{\"ipopt_iterate_four_c_calls_us\": %.2f, \"trial_point_two_c_calls_us\": %.2f, \"attach\": %d, \"shards\": %d, "
                "\"auto_registered\": %ld, \"evaluations\": %ld, \"constant_fills\": %ld, \"constant_refills\": %ld, \"constant_entries\": %ld, "
                "\"per_call_us\": [%.2f, %.2f, %.2f, %.2f]}\n",
-               best, trial, attach, stats[0], stats[3], stats[4], stats[5], stats[6], per_call[0], per_call[1], per_call[2], per_call[3]);
+               best, trial, attach, shards, stats[0], stats[3], stats[4], stats[5], stats[6], per_call[0], per_call[1], per_call[2], per_call[3]);
     }
     if (attach) hipnlp_ipopt_detach(h);
     fclose(out);

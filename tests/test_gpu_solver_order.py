@@ -16,10 +16,10 @@ from hippopt_amd.synthetic import make_workload
 pytestmark = pytest.mark.gpu
 
 
-def solve(model, numeric, vary_first, seed, max_iter):
+def solve(model, numeric, vary_first, seed, max_iter, devices=None):
     from hippopt_amd.turnkey_planners.humanoid_kinodynamic import Planner, Settings
     st = Settings.from_numeric(numeric, solver_options={"max_iter": max_iter})
-    pl = Planner(st, model, error_on_fail=False, inner_solver="trust-constr")
+    pl = Planner(st, model, error_on_fail=False, inner_solver="trust-constr", devices=devices)
     sol = pl.optimization_solver
     sol._jac_varying_first = vary_first            # (before the engine exists: HipNlpSolver(..., jac_varying_first=) through the planner's wiring)
     x, p = make_workload(st, model, batch=1, seed=seed)

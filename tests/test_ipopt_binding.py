@@ -48,10 +48,10 @@ def test_ipopt_callback_signatures_bind_and_symbols_are_exported():
     assert lib.hipnlp_ipopt_eval_f(5, None, 1, C.byref(obj), None) == 0
 
 
-def write_input(path, desc, p, xs, lam, obj_factor, attach):
+def write_input(path, desc, p, xs, lam, obj_factor, attach, shards=0):
     blob = C.string_at(C.addressof(desc), C.sizeof(desc))
     with open(path, "wb") as f:
-        f.write(struct.pack("<6i", 0x49504F54, len(blob), p.size, xs.shape[0], int(attach), 0))
+        f.write(struct.pack("<6i", 0x49504F54, len(blob), p.size, xs.shape[0], int(attach), int(shards)))
         f.write(blob)
         f.write(np.ascontiguousarray(p, np.float64).tobytes())
         f.write(np.ascontiguousarray(xs, np.float64).tobytes())
@@ -220,3 +220,41 @@ def test_both_triplet_orders_hand_ipopt_the_same_matrix(model, tmp_path, maker, 
         elif kind in ("f", "grad", "g", "hess", "bounds", "hess_structure"):
             assert np.array_equal(va.view(np.int64), vb.view(np.int64)), (kind, point)
     assert compared >= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("maker,horizon,lifted,attach,vary_first,shards", [(periodic_step_settings, 100, True, 1, True, 4), (single_step_settings, 30, True, 2, True, 3),
+                                                                            (periodic_step_settings, 30, False, 0, False, 2)])
+def test_ipopt_protocol_through_a_multi_device_handle(model, tmp_path, maker, horizon, lifted, attach, vary_first, shards):
+    """One caller, several shard handles (hipnlp_multi_create) behind the SAME five callbacks: IPOPT's protocol replayed in C against a
+    handle of `shards` shards of device 0 records, at every call, the bits the plain handle records — structure, bounds, f, grad f, g,
+    jac g, the Hessian values, and FALSE at the NaN point."""
+    st = maker(horizon, model)
+    x, p = make_workload(st, model, batch=1, seed=5200 + horizon)
+    rng = np.random.RandomState(6)
+    points = 7
+    xs = np.stack([x[0] + 1e-3 * i * rng.standard_normal(x[0].shape) for i in range(points)])
+    xs[-1, 189 * (horizon // 2) + 130:189 * (horizon // 2) + 134] = 0.0      # zero base quaternion in the middle of the horizon -> NaN
+    desc = _abi.DescC()
+    desc.settings, desc.model, desc.batch = st.to_c(), model.to_c(), 1
+    desc.flags = (_abi.FLAG_DETECT_SIMPLE_BOUNDS if lifted else 0) | (_abi.FLAG_JAC_VARYING_FIRST if vary_first else 0)
+    eng = hipnlp.HipNlp(st, model, detect_simple_bounds=lifted)
+    lam = rng.standard_normal(eng.m)
+    eng.close()
+    recs, timing = {}, {}
+    for k in (0, shards):
+        src, dst = str(tmp_path / ("in%d.bin" % k)), str(tmp_path / ("out%d.bin" % k))
+        write_input(src, desc, p[0], xs, lam, 0.8, attach, shards=k)
+        res = subprocess.run([build_harness(), src, dst, "200"], capture_output=True, text=True, timeout=240)
+        assert res.returncode == 0, res.stderr
+        recs[k] = read_records(dst)
+        timing[k] = json.loads(res.stdout.strip().splitlines()[-1])
+    assert timing[shards]["shards"] == shards and timing[0]["shards"] == 0
+    a, b = recs[0], recs[shards]
+    assert [(k, pt, ok) for k, pt, ok, _ in a] == [(k, pt, ok) for k, pt, ok, _ in b]
+    assert any(ok == 0 for _, pt, ok, _ in b if pt == points - 1)
+    for (kind, point, ok, va), (_, _, _, vb) in zip(a, b):
+        if point == points - 1:
+            continue                                           # (the NaN point: which entries are NaN is the same, their payload bits need not be)
+        assert np.array_equal(va.view(np.int64), vb.view(np.int64)), (kind, point)
+    print("IPOPT iterate as four C calls, us: one handle %.1f, %d shards of one device %.1f" % (timing[0]["ipopt_iterate_four_c_calls_us"], shards, timing[shards]["ipopt_iterate_four_c_calls_us"]))
