@@ -195,6 +195,21 @@ def compact_line(d):
                                    "(host_sink: + efficiency vs N x one GPU's host-visible rate)")
         out["exchanges"] = ex
         out["exchange_moves"] = d.get("exchange_moves")
+    oc = d.get("one_caller")
+    if isinstance(oc, dict):
+        blocks = {"": oc} if "rows" in oc else oc      # (N > 1: one block; N = 1: a block per shard count of the one card)
+        rows = {}
+        for tag, blk in blocks.items():
+            if not isinstance(blk, dict) or "rows" not in blk:
+                rows[tag or "error"] = "error"
+                continue
+            for mode, row in blk["rows"].items():
+                rows[("%s, " % tag if tag else "") + ("threads" if "one launching thread" in mode else "caller launches")] = [
+                    _sig(row.get("us_per_callback_all_four_outputs"), 4), _sig(row.get("knots_per_s"), 4), _sig(row.get("us_per_exact_hessian"), 4)]
+        out["one_caller_columns"] = "us per hipnlp_eval (x from host memory, all four outputs into host arrays), knots per s, us per exact Hessian"
+        out["one_caller"] = rows
+        if "rows" in oc:
+            out["one_caller_devices"] = "%d distinct" % oc.get("distinct_devices", 0)
     for key in ("independent_trajectories", "knot_sharded_allgather"):
         leg = d.get(key)
         if isinstance(leg, dict):
@@ -220,7 +235,7 @@ def compact_line(d):
     out["details"] = "the line before this one (prefix BENCH_DETAILS) carries every leg in full"
     text = json.dumps(out, separators=(",", ":"))
     if len(text) > FINAL_LINE_LIMIT:      # never the contract's keys: the side rows go first
-        for key in ("config5", "config4_strong", "exact_hessian", "throughput_columns", "exchange_columns", "host_visible", "throughput", "exchanges"):
+        for key in ("config5", "config4_strong", "one_caller_columns", "exact_hessian", "throughput_columns", "exchange_columns", "one_caller", "host_visible", "throughput", "exchanges"):
             out.pop(key, None)
             text = json.dumps(out, separators=(",", ":"))
             if len(text) <= FINAL_LINE_LIMIT:
@@ -772,6 +787,55 @@ def throughput_block(model, device_index):
     return out
 
 
+def one_caller(st, model, x_np, p_np, devices, calls=300, numa_note=None):
+    """ONE process — the one the NLP driver lives in (the reference's self._solver.solve(), base/opti_solver.py:479) — drives every
+    device: hipnlp_multi_create behind hipnlp_eval.  x starts in this process's host memory every call, f / grad f / g / jac g arrive
+    in its own (registered) host arrays: the whole callback, input half included.  Per call: all four outputs; the exact Hessian
+    beside it.  devices with repeated ordinals = several shards of one card (a rehearsal of the host side: the shards share its link)."""
+    import numpy as np
+    from hippopt_amd.hipnlp import HipNlp
+    rng = np.random.RandomState(3)
+    xs = [x_np + 1e-4 * rng.standard_normal(x_np.shape) for _ in range(8)]
+    out = {"devices": list(devices), "distinct_devices": len(set(devices)), "calls": calls, "rows": {}}
+    for threads in ((False, True) if len(devices) > 1 else (False,)):
+        eng = HipNlp(st, model, detect_simple_bounds=True, jac_varying_first=True, devices=list(devices))
+        try:
+            eng.set_params(p_np)
+            eng.set_threads(threads)
+            arrs = (np.empty(1), np.empty((1, eng.n)), np.empty((1, eng.m)), np.empty((1, eng.nnz)))
+            for i in range(30):
+                eng.eval(xs[i % 8], out=arrs)
+            best = float("inf")
+            for _ in range(4):
+                t0 = time.perf_counter()
+                for i in range(calls):
+                    eng.eval(xs[i % 8], out=arrs)
+                best = min(best, (time.perf_counter() - t0) / calls)
+            lam = rng.standard_normal((1, eng.m))
+            hess = np.empty((1, eng.hess_nnz()))
+            for i in range(30):
+                eng.eval_hess(xs[i % 8], 1.0, lam, out=hess)
+            hbest = float("inf")
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for i in range(calls):
+                    eng.eval_hess(xs[i % 8], 1.0, lam, out=hess)
+                hbest = min(hbest, (time.perf_counter() - t0) / calls)
+            eng.eval(xs[0], out=arrs)
+            row = {"us_per_callback_all_four_outputs": 1e6 * best, "knots_per_s": st.horizon_length / best, "us_per_exact_hessian": 1e6 * hbest,
+                   "shard_us_enqueued_completed": [[round(float(v), 1) for v in r] for r in eng.multi_breakdown()], "shards": eng.shards()}
+            out["rows"]["one launching thread per shard" if threads else "the caller's thread launches every shard"] = row
+        finally:
+            eng.close()
+    out["note"] = ("x in the caller's host memory -> one pinned staging copy every device reads -> every shard's kernel stores its entries straight into the caller's "
+                   "registered arrays over its own link -> the caller sums the cost; no data between devices (hipnlp_multi_create, include/hipnlp.h)")
+    if len(set(devices)) < len(devices):
+        out["note"] += "; SHARDS SHARE A CARD HERE: a rehearsal of the host side (one link), not a multi-GPU measurement"
+    if numa_note:
+        out["numa"] = numa_note
+    return out
+
+
 def c_harness_iterate(st, model, x, p, attach=1):
     """builds tests/ipopt_harness/harness.c against the library (gcc) and runs its timing loop in a child process"""
     import ctypes as C
@@ -942,7 +1006,7 @@ def main():
     def run_knot_sharded(steps, warmup, total_horizon=None, legs=("shard_resident", "peer_store", "peer_direct", "gather_to_root", "host_sink")):
         """total_horizon: knots of the ONE trajectory cut over the ranks (default: args.horizon per rank — the horizon grows with the
         world, weak scaling); legs: which exchanges are timed beside the all-gather"""
-        from hippopt_amd.sharded import HostSink, ShardedCallback, hip_constants, hip_shard_backend, hip_shard_info, knot_range
+        from hippopt_amd.sharded import HostSink, ShardedCallback, XFeed, hip_constants, hip_shard_backend, hip_shard_info, knot_range
         assert args.batch == 1, "knot sharding evaluates one trajectory"
         hz = total_horizon or args.horizon * world
         st, x_np, p_np, xs = workload(hz, 1, 1004)   # the SAME trajectory on every rank
@@ -955,24 +1019,33 @@ def main():
         eng.set_params(p_np)
         cb = ShardedCallback(hz, eng.n, eng.m, eng.nnz, hip_shard_info(eng, kb, ke, compact), hip_shard_backend(eng, compact), device, **(hip_constants(eng) if compact else {}))
         torch.cuda.synchronize()
+        # EVERY step of every leg below starts from x in rank 0's HOST memory (pinned), where the one caller of the callbacks — IPOPT,
+        # base/opti_solver.py:479 — has it: rank 0's H2D copy and the broadcast to the other ranks are inside the timed region
+        # (sharded.XFeed).  Rounds 1 - 5 started every leg from x already resident on every rank: half a callback.
+        feed = XFeed(eng.n, device)
+        xh = [feed.stage(t.cpu().numpy()) for t in xs] if rank == 0 else None
+
+        def fx(i):
+            return feed.feed(xh[i % nvar] if rank == 0 else None)
         # the whole loop runs on the callback's own stream (shard evaluation, all-gather and reassembly are ordered on it; entering it
         # once here saves two cross-stream event waits per step)
         with torch.cuda.stream(cb.stream):
-            el, kern_ms, launch_ms, nprof = run_timed(lambda i: cb(xs[i % nvar]), eng, steps, warmup, False)
+            el, kern_ms, launch_ms, nprof = run_timed(lambda i: cb(fx(i)), eng, steps, warmup, False)
         res = {"eng": eng, "st": st, "x_np": x_np, "p_np": p_np, "el": el, "kern_ms": kern_ms, "launch_ms": launch_ms, "nprof": nprof,
                "knots_per_step": hz, "local_knots": ke - kb, "single_kernel_step": False, "horizon": hz,
                "exchange_moves": "the varying entries of jac g only (the constants are in the receiving buffers)" if compact else "every entry of jac g",
+               "x_source": "rank 0's pinned host memory every step: H2D on rank 0 + broadcast to the other ranks inside the timed region (sharded.XFeed)",
                "parallelism": "knot-sharded x%d (contiguous shooting intervals) + one RCCL all-gather + one-launch reassembly" % world}
         # beside it: the shards evaluated and left in each rank's HBM (what the exchange costs on top)
         ksteps = max(1, min(steps, 1000))
         if "shard_resident" in legs:
           with torch.cuda.stream(cb.stream):
             for i in range(min(warmup, 50)):
-                cb.shard_only(xs[i % nvar])
+                cb.shard_only(fx(i))
             fence()
             t1 = time.perf_counter()
             for i in range(ksteps):
-                cb.shard_only(xs[i % nvar])
+                cb.shard_only(fx(i))
             fence()
             e2 = max_over_ranks(time.perf_counter() - t1)
           res["shard_resident"] = {"knots_per_s": hz * ksteps / e2, "ms_per_step": 1e3 * e2 / ksteps, "steps": ksteps,
@@ -1003,11 +1076,11 @@ def main():
                 return None, {"error": "%s: %s" % (type(err).__name__, err)}
             same, got, got2 = True, None, None
             with torch.cuda.stream(cb.stream):
-                ref = [t.clone() for t in cb(xs[1 % nvar])]                # (collective: the all-gather path's result)
+                ref = [t.clone() for t in cb(fx(1))]                       # (collective: the all-gather path's result)
                 try:
-                    got = px(xs[1 % nvar])
+                    got = px(fx(1))
                     got = [t.clone() for t in got] if got[0] is not None else None
-                    got2 = px(xs[1 % nvar])                                # the other buffer parity
+                    got2 = px(fx(1))                                       # the other buffer parity
                     got2 = [t.clone() for t in got2] if got2[0] is not None else None
                 except Exception as err:  # noqa: BLE001
                     same, err_text = False, "%s: %s" % (type(err).__name__, err)
@@ -1033,7 +1106,7 @@ def main():
             with torch.cuda.stream(cb.stream):
                 try:
                     for i in range(warmup):
-                        px(xs[i % nvar])
+                        px(fx(i))
                 except Exception as err:  # noqa: BLE001
                     ok, err_text = False, "%s: %s" % (type(err).__name__, err)
                 fence()
@@ -1041,7 +1114,7 @@ def main():
                 try:
                     if ok:
                         for i in range(steps):
-                            px(xs[i % nvar])
+                            px(fx(i))
                 except Exception as err:  # noqa: BLE001
                     ok, err_text = False, "%s: %s" % (type(err).__name__, err)
                 fence()
@@ -1104,16 +1177,30 @@ def main():
                 return all(oks)
             sink = HostSink(name, eng.n, eng.m, eng.nnz, world, rank, barrier=(dist.barrier if world > 1 else None), agree=agree)
             fp, gradp, gp, jacp = sink.pointers()
+            xp = sink.x_pointer()
+            xnp = [t.cpu().numpy().reshape(-1) for t in xs]
+            step_no = [0]
 
             def hstep(i):
-                eng.eval_device(xs[i % nvar].data_ptr(), fp, gradp, gp, jacp, stream=work_stream.cuda_stream)
+                # one caller, one process per GPU, no collective: rank 0 posts x into the shared segment, every rank's kernel reads it from
+                # there over its own PCIe link and stores its shard's outputs into the segment; rank 0 has the callback when every rank's
+                # slot carries the step number (HostSink: post_x / wait_x / done / wait_all)
+                step_no[0] += 1
+                if rank == 0:
+                    sink.post_x(xnp[i % nvar], step_no[0])
+                else:
+                    sink.wait_x(step_no[0])
+                eng.eval_device(xp, fp, gradp, gp, jacp, stream=work_stream.cuda_stream)
+                work_stream.synchronize()
+                sink.done(step_no[0])
+                if rank == 0:
+                    sink.wait_all(step_no[0])   # the consumer (IPOPT) needs this callback before it produces the next x
             for i in range(min(warmup, 50)):
                 hstep(i)
             fence()
             t1 = time.perf_counter()
             for i in range(ksteps):
                 hstep(i)
-                work_stream.synchronize()    # the consumer (IPOPT) needs this callback before it produces the next x
             fence()
             e3 = max_over_ranks(time.perf_counter() - t1)
             # its baseline is what ONE GPU hands a CPU-side IPOPT: hipnlp_eval through host buffers, all four outputs, one 100-knot trajectory
@@ -1147,18 +1234,27 @@ def main():
                                 "one_gpu_host_visible_knots_per_s": one_gpu_host,
                                 "efficiency_vs_one_gpu_host_visible": None if (REHEARSAL or not one_gpu_host or total_horizon) else (hz * ksteps / e3) / (world * one_gpu_host),
                                 "bytes_stored_per_rank_per_step": int(8 * (eng.dims.shard_grad + eng.dims.shard_g_rows + (eng.jac_vary_layout()["shard_len"] if compact else eng.dims.shard_nnz) + 1)),
-                                "note": "no collective: each rank's knot kernel stores its shard of [grad | jac | g] straight into ONE "
-                                        "shared pinned host buffer (POSIX shared memory registered with HIP by every rank), in reference "
-                                        "order; synchronised after every step"}
+                                "note": "no collective: rank 0 posts x into a POSIX shared-memory segment every rank has registered with HIP, every rank's knot "
+                                        "kernel reads x from it and stores its shard of [grad | jac | g] straight into it (reference order), rank 0 waits for "
+                                        "every rank's step word — x starts in rank 0's host memory and the outputs end there, every step"}
             sink.close()
         except Exception as err:  # noqa: BLE001  (an extra measurement must not take `value` down with it)
             res["host_sink"] = {"error": "%s: %s" % (type(err).__name__, err)}
+        # rank 0 ALONE drives every device of the job (hipnlp_multi_create): the other ranks wait at the fence, their cards idle
+        fence()
+        if rank == 0:
+            try:
+                res["one_caller"] = one_caller(st, model, x_np, p_np, [0] * world if REHEARSAL else list(range(world)), calls=min(300, max(50, ksteps)),
+                                               numa_note=None)
+            except Exception as err:  # noqa: BLE001
+                res["one_caller"] = {"error": "%s: %s" % (type(err).__name__, err)}
+        fence()
         return res
 
     # ---- BASELINE config 5 in its multi-GPU form: stairs N = 200, 16 batched initial guesses DEALT over the ranks, outputs on rank 0 ----
     def run_config5(steps, warmup):
         from hippopt_amd.kinodyn_settings import stairs_settings as stairs
-        from hippopt_amd.sharded import BatchDealtCallback, BatchPeerToRoot, batch_range, hip_batch_backend, hip_constants
+        from hippopt_amd.sharded import BatchDealtCallback, BatchPeerToRoot, XDeal, batch_range, hip_batch_backend, hip_constants
         N5, B5 = 200, 16
         st = stairs(N5, model)
         x1, p1 = make_workload(st, model, batch=1, seed=1004)
@@ -1201,9 +1297,14 @@ def main():
         eng.set_params(p_all[b0:b1])
         # (the gather moves the varying entries of jac g; rank 0's complete array holds every trajectory's constants, gathered once)
         bc = BatchDealtCallback(B5, eng.n, eng.m, eng.nnz, hip_batch_backend(eng, compact), device, **(hip_constants(eng) if compact else {}))
-        with torch.cuda.stream(bc.stream):
-            xl = [t[b0:b1].contiguous() for t in xd]
-        bc.stream.synchronize()
+        # the guesses of a step start in rank 0's HOST memory (where their NLP drivers live) and are dealt to the ranks inside the timed
+        # region: H2D on rank 0 + dist.scatter (sharded.XDeal)
+        dealer = XDeal(B5, eng.n, device)
+        xh = [dealer.stage(t.cpu().numpy()) for t in xd] if rank == 0 else None
+
+        def xl_of(i):
+            return dealer.deal(xh[i % 2] if rank == 0 else None)
+        out["x_source"] = "rank 0's pinned host memory every step: H2D on rank 0 + scatter of every rank's trajectories inside the timed region (sharded.XDeal)"
 
         def agree_all(ok):
             if world == 1:
@@ -1227,7 +1328,7 @@ def main():
             ok, why = True, None
             with torch.cuda.stream(bc.stream):
                 try:
-                    got = step_fn(xl[0])
+                    got = step_fn(xl_of(0))
                     bc.stream.synchronize()
                     ok = check(None if isinstance(got, BatchDealtCallback) else got) if got is not None else True
                     if not ok:
@@ -1242,11 +1343,11 @@ def main():
                 return {"error": "; ".join(w for w in whys if w) or "failed on some rank"}
             with torch.cuda.stream(bc.stream):
                 for i in range(warmup):
-                    step_fn(xl[i % 2])
+                    step_fn(xl_of(i))
                 fence()
                 t1 = time.perf_counter()
                 for i in range(steps):
-                    step_fn(xl[i % 2])
+                    step_fn(xl_of(i))
                 fence()
                 e = max_over_ranks(time.perf_counter() - t1)
             rate = N5 * B5 * steps / e
@@ -1259,11 +1360,11 @@ def main():
         out["local_only"] = None
         with torch.cuda.stream(bc.stream):
             for i in range(warmup):
-                bc.local_only(xl[i % 2])
+                bc.local_only(xl_of(i))
             fence()
             t1 = time.perf_counter()
             for i in range(steps):
-                bc.local_only(xl[i % 2])
+                bc.local_only(xl_of(i))
             fence()
             e = max_over_ranks(time.perf_counter() - t1)
         out["local_only"] = {"knots_per_s": N5 * B5 * steps / e, "ms_per_step": 1e3 * e / steps, "steps": steps,
@@ -1438,7 +1539,7 @@ def main():
             line["config"]["exchange"] = main_res["exchange"]
         if main_res.get("peer_paths_eligible_for_value"):
             line["config"]["peer_paths_eligible_for_value"] = main_res["peer_paths_eligible_for_value"]
-        for key in ("all_gather", "shard_resident", "peer_store", "peer_direct", "gather_to_root", "host_sink", "exchange_moves"):
+        for key in ("all_gather", "shard_resident", "peer_store", "peer_direct", "gather_to_root", "host_sink", "exchange_moves", "x_source", "one_caller"):
             if main_res.get(key) is not None:
                 line[key] = main_res[key]
         if side is not None:
@@ -1473,6 +1574,15 @@ def main():
                                                              "the caller's arrays (registered by the handle at their second sight); per callback kind in `host_visible`")
             except Exception as err:  # noqa: BLE001
                 line["host_visible"] = {"error": "%s: %s" % (type(err).__name__, err)}
+        if solo and not args.no_host and args.batch == 1:
+            # the one-caller path on this one card: 1, 2 and 4 shard handles of device 0 behind hipnlp_eval (what the host side adds per shard)
+            oc = {}
+            for k in (1, 2, 4):
+                try:
+                    oc["%d shard%s of device %d" % (k, "" if k == 1 else "s", local_rank)] = one_caller(st, model, main_res["x_np"], main_res["p_np"], [local_rank] * k, calls=200)
+                except Exception as err:  # noqa: BLE001
+                    oc["%d shards" % k] = {"error": "%s: %s" % (type(err).__name__, err)}
+            line["one_caller"] = oc
         if solo and not args.no_hessian:
             # beside the callback quartet (never `value`): the exact Hessian of the Lagrangian of the same NLP (hipnlp_eval_hess_device)
             try:

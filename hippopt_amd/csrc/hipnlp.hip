@@ -20,7 +20,11 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <string>
 #include <cctype>
@@ -1974,11 +1978,86 @@ struct MultiState {
     std::vector<double*> hd_cost;         // ... and its device-visible address
     std::vector<size_t> cost_off;
     std::vector<double> shard_us;         // [shards][2] of the last evaluation: enqueue, completion seen (host clock, from the start of the enqueue loop)
+    // ---- one launching thread per shard (hipnlp_multi_set_threads) -------------------------------------------------------------------
+    // Enqueueing a kernel costs the host 4 - 6 us and waiting for a stream a few more: done by the caller's thread one shard after the
+    // other, the last of eight shards would start 40 us after the first — longer than the whole callback of one device.  With threads on,
+    // shard i > 0 has a worker bound to its device: the caller publishes a job (a ticket number), runs shard 0's part itself and waits
+    // for the others; every worker stages / launches / waits for ITS shard.  A worker polls for the next ticket for `spin_us` after its
+    // last job (IPOPT's callbacks come in bursts, microseconds apart) and sleeps on a condition variable after that (between bursts
+    // IPOPT factorises for milliseconds: no core is burnt meanwhile; the first callback of a burst pays one wake-up).
+    std::vector<std::thread> workers;
+    std::function<int(size_t)> job;       // what every shard does for the ticket in flight; rc per shard in job_rc
+    std::vector<int> job_rc;
+    std::atomic<unsigned long long> ticket{0};
+    std::atomic<int> done{0};
+    std::atomic<int> sleepers{0};
+    std::atomic<bool> quit{false};
+    std::mutex mx;
+    std::condition_variable cv;
+    double spin_us = 200.0;
+    bool threads = false;
 };
+
+static void multi_worker(MultiState* M, size_t i) {
+    (void)hipSetDevice(M->shards[i]->dev);   // (the current device is a property of the thread: set once)
+    unsigned long long seen = 0;
+    auto last = std::chrono::steady_clock::now();
+    for (;;) {
+        unsigned long long t = M->ticket.load(std::memory_order_acquire);
+        if (t == seen) {
+            if (M->quit.load(std::memory_order_relaxed)) return;
+            if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - last).count() < M->spin_us) { __builtin_ia32_pause(); continue; }
+            std::unique_lock<std::mutex> lock(M->mx);
+            M->sleepers.fetch_add(1, std::memory_order_seq_cst);
+            M->cv.wait(lock, [&] { return M->ticket.load(std::memory_order_acquire) != seen || M->quit.load(std::memory_order_relaxed); });
+            M->sleepers.fetch_sub(1, std::memory_order_seq_cst);
+            continue;
+        }
+        seen = t;
+        M->job_rc[i] = M->job(i);
+        M->done.fetch_add(1, std::memory_order_release);
+        last = std::chrono::steady_clock::now();
+    }
+}
+// every shard runs job(i): by its worker (threads on), shard 0 by the caller; or one after the other by the caller.  First failure wins.
+static int multi_failed(hipnlp_handle* h, size_t i, int rc);
+static int multi_run(hipnlp_handle* h, std::function<int(size_t)> job) {
+    MultiState& M = *h->multi;
+    const size_t S = M.shards.size();
+    if (!M.threads || S == 1) {
+        for (size_t i = 0; i < S; ++i) {
+            HIP_TRY(h, hipSetDevice(M.shards[i]->dev));
+            const int rc = job(i);
+            if (rc != HIPNLP_OK) return multi_failed(h, i, rc);
+        }
+        return HIPNLP_OK;
+    }
+    M.job = std::move(job);
+    M.done.store(0, std::memory_order_relaxed);
+    M.ticket.fetch_add(1, std::memory_order_seq_cst);
+    if (M.sleepers.load(std::memory_order_seq_cst) > 0) { std::lock_guard<std::mutex> lock(M.mx); M.cv.notify_all(); }
+    M.job_rc[0] = M.job(0);
+    while (M.done.load(std::memory_order_acquire) < int(S) - 1) __builtin_ia32_pause();
+    for (size_t i = 0; i < S; ++i) if (M.job_rc[i] != HIPNLP_OK) return multi_failed(h, i, M.job_rc[i]);
+    return HIPNLP_OK;
+}
+static void multi_stop_workers(MultiState* M) {
+    if (M->workers.empty()) return;
+    {
+        std::lock_guard<std::mutex> lock(M->mx);
+        M->quit.store(true, std::memory_order_seq_cst);
+    }
+    M->cv.notify_all();
+    for (std::thread& t : M->workers) t.join();
+    M->workers.clear();
+    M->quit.store(false, std::memory_order_seq_cst);
+    M->threads = false;
+}
 
 static void multi_destroy(hipnlp_handle* h) {
     MultiState* M = h->multi;
     if (!M) return;
+    multi_stop_workers(M);
     for (hipnlp_handle* s : M->shards) hipnlp_destroy(s);
     if (M->h_cost) (void)hipHostFree(M->h_cost);
     delete M;
@@ -1989,6 +2068,28 @@ static int multi_set_params(hipnlp_handle* h, const double* p) {
     for (hipnlp_handle* s : h->multi->shards) {
         const int rc = hipnlp_set_params(s, p);
         if (rc != HIPNLP_OK) { h->err = "shard on device " + std::to_string(s->dev) + ": " + s->err; return rc; }
+    }
+    return HIPNLP_OK;
+}
+
+// The cut, and what of x a shard reads (pure arithmetic: no device) — hipnlp_multi_create and multi_stage_x follow it; the CPU tests
+// evaluate the knot program on x poisoned everywhere else (tests/test_multi_plan.py).
+//   knots  contiguous, balanced, never empty: the first (horizon mod n_shards) shards own one knot more (hippopt_amd/sharded.py knot_range)
+//   x      [0] the shard's own records and the HALO record in front of them (the trapezoid defect of interval k - 1 -> k is a row of knot k:
+//              base/multiple_shooting_solver.py:713-742),  [1] the six horizon-global variables,  [2] the record of the LAST knot for the
+//              owner of knot 0,  [3] the record of knot 0 for the owner of the last knot (the periodicity rows couple the two ends:
+//              turnkey_planners/humanoid_kinodynamic/planner.py:897-930) — {offset, count} in doubles, count 0: nothing more to read
+int hipnlp_multi_plan(int horizon, int n_shards, int shard, int32_t* knot_begin, int32_t* knot_end, int64_t* x_ranges) {
+    if (horizon < 2 || n_shards < 1 || n_shards > horizon || shard < 0 || shard >= n_shards) return HIPNLP_E_INVALID;
+    const int q = horizon / n_shards, r = horizon % n_shards;
+    const int kb = shard * q + std::min(shard, r), ke = kb + q + (shard < r ? 1 : 0);
+    if (knot_begin) *knot_begin = kb;
+    if (knot_end) *knot_end = ke;
+    if (x_ranges) {
+        const int64_t N = horizon, k0 = kb > 0 ? kb - 1 : 0;
+        const int64_t ranges[4][2] = {{NXK * k0, NXK * (ke - k0)}, {NXK * N, NXG},
+                                      {NXK * (N - 1), (kb == 0 && ke < N) ? NXK : 0}, {0, (ke == N && kb > 1) ? NXK : 0}};
+        std::memcpy(x_ranges, ranges, sizeof ranges);
     }
     return HIPNLP_OK;
 }
@@ -2004,19 +2105,26 @@ static hipError_t copy_rows(void* dst, const void* src, size_t pitch_doubles, si
 // x for a shard whose launches read it from HBM (big batches): its own knots' records and the halo record in front of them, the
 // horizon-global variables, and the record of the other horizon end for the owner of knot 0 / N - 1 (the periodicity rows) — out of
 // the front's pinned copy into the SAME places of the shard's device array, on the shard's stream
-static int multi_stage_x(hipnlp_handle* h, hipnlp_handle* s) {
-    const size_t B = size_t(h->batch), n = size_t(h->L.n), N = size_t(h->L.N);
-    const size_t k0 = s->kb > 0 ? size_t(s->kb) - 1 : 0;
-    HIP_TRY(h, copy_rows(s->d_x, h->h_x, n, NXK * k0, NXK * (size_t(s->ke) - k0), B, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(h, copy_rows(s->d_x, h->h_x, n, NXK * N, NXG, B, hipMemcpyHostToDevice, s->stream));
-    if (s->kb == 0 && size_t(s->ke) < N) HIP_TRY(h, copy_rows(s->d_x, h->h_x, n, NXK * (N - 1), NXK, B, hipMemcpyHostToDevice, s->stream));
-    if (size_t(s->ke) == N && s->kb > 1) HIP_TRY(h, copy_rows(s->d_x, h->h_x, n, 0, NXK, B, hipMemcpyHostToDevice, s->stream));
+// (errors are left in the SHARD's handle: this runs on the shard's launching thread when there is one)
+static int multi_stage_x(const hipnlp_handle* h, hipnlp_handle* s, size_t shard) {
+    const size_t B = size_t(h->batch), n = size_t(h->L.n);
+    int64_t rg[4][2];
+    if (hipnlp_multi_plan(h->L.N, int(h->multi->shards.size()), int(shard), nullptr, nullptr, &rg[0][0]) != HIPNLP_OK) { s->err = "internal: hipnlp_multi_plan"; return HIPNLP_E_INVALID; }
+    for (int i = 0; i < 4; ++i)
+        if (rg[i][1] > 0) HIP_TRY(s, copy_rows(s->d_x, h->h_x, n, size_t(rg[i][0]), size_t(rg[i][1]), B, hipMemcpyHostToDevice, s->stream));
     return HIPNLP_OK;
+}
+// the message of the shard that failed, into the front
+static int multi_failed(hipnlp_handle* h, size_t i, int rc) {
+    const hipnlp_handle* s = h->multi->shards[i];
+    h->err = "shard " + std::to_string(i) + " on device " + std::to_string(s->dev) + ": " + s->err;
+    return rc;
 }
 static int multi_sync(hipnlp_handle* h) {
     for (hipnlp_handle* s : h->multi->shards) HIP_TRY(h, hipStreamSynchronize(s->stream));
     return HIPNLP_OK;
 }
+static int multi_run(hipnlp_handle* h, std::function<int(size_t)> job);
 // f[b] and cost_terms[b][.] from the knots' partials, in the order of hipnlp_reduce_kernel / the in-launch reducer: knot k belongs to
 // group k mod 16, a group is summed in ascending k from +0 (with the same padding zeros), four groups of a quarter as (g0 + g1) + (g2 + g3),
 // the quarters as ((p0 + p1) + p2) + p3, the twelve terms in order
@@ -2054,26 +2162,38 @@ static_assert(RGRP == 16 && RWG / 64 == 4, "multi_reduce_costs restates the tree
 static int multi_evaluate(hipnlp_handle* h, double* const o[3], bool vary_only, std::chrono::steady_clock::time_point* t_enqueued) {
     MultiState& M = *h->multi;
     const auto t0 = std::chrono::steady_clock::now();
-    for (size_t i = 0; i < M.shards.size(); ++i) {
+    double* const og = o[0]; double* const ogg = o[1]; double* const oj = o[2];
+    // the part of shard i: stage (big batches), launch, wait — on its own stream, from whichever thread runs it
+    auto enqueue = [&M, h, og, ogg, oj, vary_only, t0](size_t i) -> int {
         hipnlp_handle* s = M.shards[i];
-        HIP_TRY(h, hipSetDevice(s->dev));
         const double* xsrc = h->hd_x;
         if (!h->x_zero_copy) {
-            const int rc = multi_stage_x(h, s);
+            const int rc = multi_stage_x(h, s, i);
             if (rc != HIPNLP_OK) return rc;
             xsrc = s->d_x;
         }
         s->early_store = h->early_store;
-        const int rc = launch(s, xsrc, s->d_f, o[0] ? o[0] : s->d_grad, o[1] ? o[1] : s->d_g, o[2] ? o[2] : s->d_jac, s->stream, nullptr, false, false, true,
-                              nullptr, 0, 0, vary_only && o[2] != nullptr, false, false, M.hd_cost[i]);
-        if (rc != HIPNLP_OK) { h->err = "shard on device " + std::to_string(s->dev) + ": " + s->err; return rc; }
+        const int rc = launch(s, xsrc, s->d_f, og ? og : s->d_grad, ogg ? ogg : s->d_g, oj ? oj : s->d_jac, s->stream, nullptr, false, false, true,
+                              nullptr, 0, 0, vary_only && oj != nullptr, false, false, M.hd_cost[i]);
         M.shard_us[2 * i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    }
-    if (t_enqueued) *t_enqueued = std::chrono::steady_clock::now();
-    for (size_t i = 0; i < M.shards.size(); ++i) {
-        HIP_TRY(h, hipStreamSynchronize(M.shards[i]->stream));
+        return rc;
+    };
+    auto wait = [&M, t0](size_t i) -> int {
+        const hipError_t e = hipStreamSynchronize(M.shards[i]->stream);
         M.shard_us[2 * i + 1] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (e != hipSuccess) { M.shards[i]->err = std::string("hipStreamSynchronize: ") + hipGetErrorString(e); (void)hipGetLastError(); return HIPNLP_E_NODEVICE; }
+        return HIPNLP_OK;
+    };
+    int rc;
+    if (M.threads && M.shards.size() > 1) {
+        rc = multi_run(h, [&](size_t i) -> int { const int r = enqueue(i); return r != HIPNLP_OK ? r : wait(i); });
+        if (t_enqueued) *t_enqueued = t0 + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double, std::micro>(M.shard_us[0]));
+    } else {   // the caller's thread: every launch first, then every wait
+        rc = multi_run(h, enqueue);
+        if (t_enqueued) *t_enqueued = std::chrono::steady_clock::now();
+        if (rc == HIPNLP_OK) rc = multi_run(h, wait);
     }
+    if (rc != HIPNLP_OK) return rc;
     if (h->seq == INT32_MAX) { std::memset(h->h_flag, 0, size_t(h->batch) * sizeof(int32_t)); h->seq = 0; }   // (the generation of the front's non-finite flags)
     ++h->seq;
     for (const hipnlp_handle* s : M.shards)
@@ -2088,19 +2208,21 @@ static int multi_evaluate(hipnlp_handle* h, double* const o[3], bool vary_only, 
 // blocks; an evaluation that left g in HBM marks it `gone` and a later request evaluates again.)
 static int multi_fetch(hipnlp_handle* h, int q, double* dst, double* dst_dev, bool vary_run) {
     const size_t B = size_t(h->batch);
-    for (hipnlp_handle* s : h->multi->shards) {
-        HIP_TRY(h, hipSetDevice(s->dev));
+    return multi_run(h, [=](size_t i) -> int {
+        hipnlp_handle* s = h->multi->shards[i];
         const Layout& L = s->L;
-        if (q == 0) HIP_TRY(h, copy_rows(dst, s->d_grad, size_t(L.n), size_t(s->dims.shard_grad_off), size_t(s->dims.shard_grad), B, hipMemcpyDeviceToHost, s->stream));
+        if (q == 0) HIP_TRY(s, copy_rows(dst, s->d_grad, size_t(L.n), size_t(s->dims.shard_grad_off), size_t(s->dims.shard_grad), B, hipMemcpyDeviceToHost, s->stream));
         else if (vary_run) {
             hipLaunchKernelGGL(hipnlp_fetch_vary_kernel, dim3(unsigned(s->nk), unsigned(s->batch)), dim3(256), 0, s->stream, (const double*)s->d_jac, dst_dev, s->kb, L.N,
                                int64_t(L.nnz), L.nnz_v[VAR_FIRST], L.nnz_v[VAR_INTERIOR], L.nvary_v[VAR_FIRST], L.nvary_v[VAR_INTERIOR], L.nvary_v[VAR_LAST]);
-            HIP_TRY(h, hipGetLastError());
-        } else HIP_TRY(h, copy_rows(dst, s->d_jac, size_t(L.nnz), size_t(s->dims.shard_jac_off), size_t(s->dims.shard_nnz), B, hipMemcpyDeviceToHost, s->stream));
-    }
-    return HIPNLP_OK;
+            HIP_TRY(s, hipGetLastError());
+        } else HIP_TRY(s, copy_rows(dst, s->d_jac, size_t(L.nnz), size_t(s->dims.shard_jac_off), size_t(s->dims.shard_nnz), B, hipMemcpyDeviceToHost, s->stream));
+        if (h->multi->threads) HIP_TRY(s, hipStreamSynchronize(s->stream));   // (its own thread waits for it; the caller's multi_sync then finds the streams idle)
+        return HIPNLP_OK;
+    });
 }
 
+int hipnlp_multi_set_threads(hipnlp_handle* h, int on, double spin_us);
 int hipnlp_multi_create(const hipnlp_desc* desc, const int32_t* devices, int n_devices, hipnlp_handle** out) {
     if (!desc || !out || !devices) { g_create_error = "null argument"; return HIPNLP_E_INVALID; }
     *out = nullptr;
@@ -2121,14 +2243,11 @@ int hipnlp_multi_create(const hipnlp_desc* desc, const int32_t* devices, int n_d
     if (!M) { g_create_error = "out of memory"; hipnlp_destroy(h); return HIPNLP_E_ALLOC; }
     h->multi = M;
     auto fail = [&](int code, const std::string& msg) { g_create_error = msg; hipnlp_destroy(h); return code; };
-    // contiguous, balanced, never empty: the first (N mod n_devices) shards own one knot more (hippopt_amd/sharded.py knot_range)
-    const int q = N / n_devices, r = N % n_devices;
     size_t cost_doubles = 0;
     for (int i = 0; i < n_devices; ++i) {
         hipnlp_desc sd = *desc;
         sd.device = devices[i];
-        sd.knot_begin = i * q + std::min(i, r);
-        sd.knot_end = sd.knot_begin + q + (i < r ? 1 : 0);
+        (void)hipnlp_multi_plan(N, n_devices, i, &sd.knot_begin, &sd.knot_end, nullptr);   // (the cut)
         hipnlp_handle* s = nullptr;
         rc = hipnlp_create(&sd, &s);
         if (rc != HIPNLP_OK) return fail(rc, "shard " + std::to_string(i) + " on device " + std::to_string(devices[i]) + ": " + g_create_error);
@@ -2160,6 +2279,10 @@ int hipnlp_multi_create(const hipnlp_desc* desc, const int32_t* devices, int n_d
     }
     (void)hipSetDevice(h->dev);
     *out = h;
+    // one launching thread per shard by default: from the caller's thread alone the waits for the shards' streams come one after the other,
+    // ~9 us each (measured with shards of one card: 47 / 64 / 114 us per 100-knot callback with 2 / 4 / 8 shards against 45 / 56 / 72 with
+    // threads, profiles/r06_multi_probe.txt); hipnlp_multi_set_threads(h, 0, -1) turns them off
+    if (n_devices > 1 && hipnlp_multi_set_threads(h, 1, -1.0) != HIPNLP_OK) h->err.clear();   // (no threads: the caller's thread does it all)
     return HIPNLP_OK;
 }
 
@@ -2175,6 +2298,23 @@ int hipnlp_multi_info(const hipnlp_handle* h, int32_t* n_shards, int32_t* device
         if (knot_end) knot_end[i] = s->ke;
         if (waves) waves[i] = s->wide ? 8 : 4;
     }
+    return HIPNLP_OK;
+}
+int hipnlp_multi_set_threads(hipnlp_handle* h, int on, double spin_us) {
+    if (!h || !h->multi) return HIPNLP_E_INVALID;
+    MultiState* M = h->multi;
+    if (spin_us >= 0.0) M->spin_us = spin_us;
+    if (!on) { multi_stop_workers(M); return HIPNLP_OK; }
+    if (M->threads) return HIPNLP_OK;
+    M->job_rc.assign(M->shards.size(), HIPNLP_OK);
+    try {
+        for (size_t i = 1; i < M->shards.size(); ++i) M->workers.emplace_back(multi_worker, M, i);
+    } catch (...) {
+        multi_stop_workers(M);
+        h->err = "hipnlp_multi_set_threads: could not start the launching threads";
+        return HIPNLP_E_ALLOC;
+    }
+    M->threads = true;
     return HIPNLP_OK;
 }
 int hipnlp_multi_breakdown(const hipnlp_handle* h, double* us) {
@@ -2354,24 +2494,28 @@ int hipnlp_eval_hess_at(hipnlp_handle* h, const double* x, int new_x, const doub
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             return HIPNLP_OK;
         }
-        for (hipnlp_handle* s : h->multi->shards) {
-            HIP_TRY(h, hipSetDevice(s->dev));
+        const int rm = multi_run(h, [&](size_t i) -> int {   // (shard i: on its launching thread when there is one; errors in the shard's handle)
+            hipnlp_handle* s = h->multi->shards[i];
             const double *xs = xsrc, *sl = sl_dev;
             if (!h->x_zero_copy) {
-                const int rs = multi_stage_x(h, s);
+                const int rs = multi_stage_x(h, s, i);
                 if (rs != HIPNLP_OK) return rs;
                 xs = s->d_x;
             }
             if (!h->lam_zero_copy) {
-                if (!s->d_sigma) { HIP_TRY(h, hipMalloc(&s->d_sigma, B * (1 + m) * sizeof(double))); s->d_lambda = s->d_sigma + B; }
-                HIP_TRY(h, hipMemcpyAsync(s->d_sigma, h->h_sl, B * (1 + m) * sizeof(double), hipMemcpyHostToDevice, s->stream));
+                if (!s->d_sigma) { HIP_TRY(s, hipMalloc(&s->d_sigma, B * (1 + m) * sizeof(double))); s->d_lambda = s->d_sigma + B; }
+                HIP_TRY(s, hipMemcpyAsync(s->d_sigma, h->h_sl, B * (1 + m) * sizeof(double), hipMemcpyHostToDevice, s->stream));
                 sl = s->d_sigma;
             }
             s->early_store = h->early_store;
             const int rl = hess_launch(s, xs, sl, sl + B, dest, s->stream, true, early_run, int64_t(hn));
-            if (rl != HIPNLP_OK) { h->err = "shard on device " + std::to_string(s->dev) + ": " + s->err; return rl; }
-        }
-        return multi_sync(h);
+            if (rl != HIPNLP_OK) return rl;
+            if (!h->multi->threads) return HIPNLP_OK;   // (the caller's thread: every launch first, the waits below)
+            HIP_TRY(s, hipStreamSynchronize(s->stream));
+            return HIPNLP_OK;
+        });
+        if (rm != HIPNLP_OK) return rm;
+        return h->multi->threads ? HIPNLP_OK : multi_sync(h);
     };
     // the values leave the kernel as PCIe stores into the pinned block — or straight into the CALLER'S array when that lies in a
     // registered range (no 1.2 MB host copy behind the launch): registered by the caller, or by the handle itself at the array's second

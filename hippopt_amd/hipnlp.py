@@ -28,7 +28,7 @@ EXPORTS = [
     "hipnlp_device_numa_node", "hipnlp_pin_thread_to_device_numa_node",
     "hipnlp_hess_nnz", "hipnlp_hess_sparsity", "hipnlp_eval_hess", "hipnlp_eval_hess_at", "hipnlp_set_hessian_early_run", "hipnlp_get_hessian_early_run", "hipnlp_eval_hess_device",
     "hipnlp_eval_pinned", "hipnlp_set_prefetch", "hipnlp_set_early_outputs", "hipnlp_set_host_timing", "hipnlp_host_register", "hipnlp_host_unregister",
-    "hipnlp_multi_create", "hipnlp_multi_info", "hipnlp_multi_breakdown",
+    "hipnlp_multi_create", "hipnlp_multi_plan", "hipnlp_multi_info", "hipnlp_multi_breakdown", "hipnlp_multi_set_threads",
     "hipnlp_host_breakdown", "hipnlp_set_auto_register", "hipnlp_host_stats", "hipnlp_set_constant_jacobian", "hipnlp_forget_jac_destination", "hipnlp_jac_constant_mask", "hipnlp_host_release_auto_ranges",
     "hipnlp_pose_create", "hipnlp_pose_destroy", "hipnlp_pose_last_error", "hipnlp_pose_get_dims", "hipnlp_pose_set_params",
     "hipnlp_pose_bounds", "hipnlp_pose_sparsity", "hipnlp_pose_eval", "hipnlp_pose_eval_device", "hipnlp_pose_cost_terms",
@@ -94,6 +94,15 @@ def pin_to_device_numa_node(device=0):
         return None
     os.sched_setaffinity(0, cpus)
     return {"node": node, "cpus": len(cpus)}
+
+
+def multi_plan(horizon, n_shards, shard):
+    """hipnlp_multi_plan (no device needed): ((knot_begin, knot_end), [(offset, count), ...] of x in doubles) of one shard of a multi-device handle"""
+    kb, ke, rg = C.c_int32(), C.c_int32(), (C.c_int64 * 8)()
+    rc = load_library().hipnlp_multi_plan(int(horizon), int(n_shards), int(shard), C.byref(kb), C.byref(ke), rg)
+    if rc != 0:
+        raise HipNlpError(rc, "hipnlp_multi_plan: bad arguments")
+    return (kb.value, ke.value), [(int(rg[2 * i]), int(rg[2 * i + 1])) for i in range(4) if rg[2 * i + 1] > 0]
 
 
 def load_library(path=None):
@@ -191,7 +200,9 @@ def load_library(path=None):
     lib.hipnlp_reassemble_scatter.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int64, vp, vp]
     lib.hipnlp_multi_create.argtypes = [C.POINTER(_abi.DescC), ip, C.c_int, C.POINTER(vp)]
     lib.hipnlp_multi_info.argtypes = [vp, ip, ip, ip, ip, ip]
+    lib.hipnlp_multi_plan.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, C.POINTER(C.c_int64)]
     lib.hipnlp_multi_breakdown.argtypes = [vp, dp]
+    lib.hipnlp_multi_set_threads.argtypes = [vp, C.c_int, C.c_double]
     _libs[path] = lib
     return lib
 
@@ -445,6 +456,11 @@ class HipNlp:
         arr = [(C.c_int32 * 64)() for _ in range(4)]
         self._check(self.lib.hipnlp_multi_info(self.h, C.byref(n), *arr))
         return [dict(zip(("device", "knot_begin", "knot_end", "waves"), (int(a[i]) for a in arr))) for i in range(n.value)]
+
+    def set_threads(self, on=True, spin_us=-1.0):
+        """hipnlp_multi_set_threads: one launching thread per shard of a multi-device handle (spin_us: how long a worker polls for the
+        next job before it sleeps; < 0: unchanged)"""
+        self._check(self.lib.hipnlp_multi_set_threads(self.h, 1 if on else 0, float(spin_us)))
 
     def multi_breakdown(self):
         """us [shards, 2] of the last evaluation of a multi-device handle: (enqueued, seen complete) on the host clock, from the start of the launch loop"""

@@ -43,6 +43,96 @@ def knot_range(horizon, world, rank):
     return begin, begin + q + (1 if rank < r else 0)
 
 
+class XFeed:
+    """The INPUT half of a sharded callback.  The reference has one caller of the callbacks — IPOPT, inside the process that runs
+    `self._solver.solve()` (/root/reference/src/hippopt/base/opti_solver.py:479) — so with one process per GPU every new x exists in
+    rank 0's HOST memory and nowhere else.  `feed(x_host)` brings it to every rank's device: rank 0 copies it into its device buffer
+    (from pinned memory, asynchronously on the current stream) and broadcasts that buffer (RCCL broadcast over xGMI through
+    torch.distributed backend "nccl"; "gloo" in the CPU tests and in rehearsals with several ranks on one card).  The whole x is
+    sent — 1.5 KB per knot, a tenth of what the outputs move back — rather than each rank's knots + one-knot halo + the horizon ends
+    (hipnlp_multi_plan lists those ranges): one regular collective instead of `world` irregular sends.
+    Returns the device tensor every rank evaluates from; valid until the next feed."""
+
+    def __init__(self, n, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = torch.device(device)
+        self.n = int(n)
+        self.x = torch.zeros(self.n, dtype=torch.float64, device=self.device)
+        self._host = None   # (gloo moves host tensors only: the rehearsal's staging)
+
+    def stage(self, x):
+        """a pinned host copy of x (what a caller that feeds the same arrays again and again keeps): rank 0 only"""
+        t = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64).reshape(-1))
+        if t.numel() != self.n:
+            raise ValueError("x has %d entries, the problem has %d variables" % (t.numel(), self.n))
+        return t.pin_memory() if self.device.type == "cuda" else t.clone()
+
+    def feed(self, x_host=None):
+        """x_host: rank 0's host tensor (None on the other ranks).  A collective: every rank calls it."""
+        if self.rank == 0:
+            if x_host is None:
+                raise ValueError("rank 0 feeds x")
+            self.x.copy_(x_host.reshape(-1), non_blocking=True)
+        if self.world > 1:
+            if self.device.type == "cuda" and dist.get_backend(self.group) == "gloo":
+                if self._host is None:
+                    self._host = torch.empty(self.n, dtype=torch.float64)
+                if self.rank == 0:
+                    torch.cuda.current_stream(self.device).synchronize()
+                    self._host.copy_(self.x)
+                dist.broadcast(self._host, 0, group=self.group)
+                if self.rank != 0:
+                    self.x.copy_(self._host)
+            else:
+                dist.broadcast(self.x, 0, group=self.group)
+        return self.x
+
+
+class XDeal:
+    """XFeed for trajectories dealt over the ranks (BatchDealtCallback, BASELINE config 5's batched initial guesses): the [batch][n]
+    array of all guesses exists in rank 0's host memory — where the NLP drivers of the guesses live; `deal(x_host)` copies it to rank
+    0's device and scatters every rank ITS trajectories [b0, b1) (dist.scatter: RCCL over xGMI; gloo on the CPU and in rehearsals).
+    Returns the rank's [b1 - b0][n] device tensor, valid until the next deal."""
+
+    def __init__(self, batch, n, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = torch.device(device)
+        self.batch, self.n = int(batch), int(n)
+        self.b0, self.b1 = batch_range(self.batch, self.world, self.rank)
+        self.full = torch.zeros(self.batch, self.n, dtype=torch.float64, device=self.device) if self.rank == 0 else None
+        self.local = torch.zeros(self.b1 - self.b0, self.n, dtype=torch.float64, device=self.device)
+
+    def stage(self, x_all):
+        t = torch.as_tensor(np.ascontiguousarray(x_all, dtype=np.float64)).reshape(self.batch, self.n)
+        return t.pin_memory() if self.device.type == "cuda" else t.clone()
+
+    def deal(self, x_host=None):
+        """x_host: rank 0's [batch][n] host tensor (None elsewhere).  A collective: every rank calls it."""
+        if self.rank == 0:
+            if x_host is None:
+                raise ValueError("rank 0 deals x")
+            self.full.copy_(x_host, non_blocking=True)
+        if self.world == 1:
+            self.local.copy_(self.full)
+            return self.local
+        per = self.b1 - self.b0
+        if self.device.type == "cuda" and dist.get_backend(self.group) == "gloo":     # (rehearsal: gloo moves host tensors)
+            host = torch.empty(per, self.n, dtype=torch.float64)
+            parts = None
+            if self.rank == 0:
+                torch.cuda.current_stream(self.device).synchronize()
+                parts = [c.contiguous() for c in self.full.cpu().split(per)]
+            dist.scatter(host, parts, src=0, group=self.group)
+            self.local.copy_(host)
+        else:
+            dist.scatter(self.local, list(self.full.split(per)) if self.rank == 0 else None, src=0, group=self.group)
+        return self.local
+
+
 class ShardedCallback:
     """compute_shard(x, f_view, grad_view, jac_view, stage_view, stream) fills the rank's views (any backend).
 
@@ -52,8 +142,11 @@ class ShardedCallback:
     for the caller's current stream first (x is ready) and the caller's stream waits for it at the end (the returned views are
     ordered for whoever uses them next, and the next call cannot overwrite buffers still being read)."""
 
-    def __init__(self, horizon, n, m, nnz, shard_info, compute_shard, device, group=None, const_mask=None, const_fill=None):
+    def __init__(self, horizon, n, m, nnz, shard_info, compute_shard, device, group=None, const_mask=None, const_fill=None, param_gen=None):
         """shard_info: dict(glen, jlen, nk, stage_rows [nk, G_STAGE] int32 global rows or -1) of THIS rank.
+        param_gen() -> the generation of the engine's parameters (HipNlp.params_generation; hip_constants supplies it): the constants the
+        receiving buffers hold are those of ONE parameter set — every call compares and refreshes by itself when set_params has run
+        since (a missed refresh_constants() would hand out a Jacobian with the old dt / mass entries, silently).
         const_mask (bool [nnz], the same on every rank: entries of jac g that do not depend on x) + const_fill(jac_view, stream_handle)
         (writes the constant entries of the WHOLE horizon into a [nnz] view of this rank's memory): the shards exchange the varying
         entries only — shard_info then carries "jvary", the varying entries of the rank's jac range, and compute_shard fills a jac view
@@ -72,6 +165,9 @@ class ShardedCallback:
         self.infos = infos
         self.compact = const_mask is not None
         self.const_fill = const_fill
+        self.param_gen = param_gen
+        self._filled_gen = None          # generation of the parameters whose constants self.out holds
+        self._gen_listeners = []         # (PeerExchange: buffers of its own that hold the same constants)
         if self.compact:
             if const_fill is None or any("jvary" not in i for i in infos):
                 raise ValueError("const_mask needs const_fill and shard_info['jvary'] on every rank")
@@ -149,6 +245,7 @@ class ShardedCallback:
         the parameters (dt and the mass are what the constants hold).  Ordered on the callback's stream."""
         if not self.compact:
             return
+        self._filled_gen = self.param_gen() if self.param_gen is not None else None
         view = self.out[self.n:self.n + self.nnz]
         if self.stream is None:
             self.const_fill(view, 0)
@@ -160,6 +257,14 @@ class ShardedCallback:
             self.const_fill(view, self.stream.cuda_stream)
         if cur.cuda_stream != self.stream.cuda_stream:
             cur.wait_stream(self.stream)
+
+    def _fresh(self):
+        """the constants in the receiving buffers belong to the engine's CURRENT parameters: refreshed here when set_params has run
+        since they were filled (collective-free: every rank fills its own memory, and every rank's set_params bumps its own counter)"""
+        if self.compact and self.param_gen is not None and self.param_gen() != self._filled_gen:
+            self.refresh_constants()
+            for listener in self._gen_listeners:
+                listener()
 
     def bytes_sent_per_step(self):
         """bytes of this rank's fused shard buffer that reach every other rank in one all-gather"""
@@ -203,6 +308,7 @@ class ShardedCallback:
 
     def __call__(self, x):
         """One callback set for the whole horizon.  Returns (f, grad, jac, g) views of the reassembled buffer."""
+        self._fresh()
         if self.stream is None:
             return self._run(x, 0)
         cur = torch.cuda.current_stream(self.device)
@@ -218,6 +324,8 @@ class ShardedCallback:
         """gather_to_root by the collective: ONE consumer (IPOPT lives in rank 0's process), so only rank 0 receives — `dist.gather`
         of the fused shard buffers (RCCL: one send per rank, 1 / world of the all-gather's bytes per link) and rank 0's one-launch
         reassembly.  Returns (f, grad, jac, g) on rank 0, (None, None, None, None) on the others."""
+        self._fresh()
+
         def run(stream_handle):
             self.compute_shard(x, *self.views, stream_handle)
             if self.world > 1:
@@ -387,6 +495,7 @@ class PeerExchange:
         output buffers — the peers store the varying runs around them.  At set-up and after every change of the parameters; a rank
         that receives nothing (gather_to_root, rank != 0) holds nothing.  Collective-free: every rank fills its own memory."""
         cb = self.cb
+        self._filled_gen = cb.param_gen() if cb.param_gen is not None else None
         if not cb.compact or (self.root_only and self.rank != 0):
             return
         with torch.cuda.stream(cb.stream):
@@ -425,6 +534,8 @@ class PeerExchange:
 
     def __call__(self, x):
         cb = self.cb
+        if cb.compact and cb.param_gen is not None and cb.param_gen() != getattr(self, "_filled_gen", None):
+            self.refresh_constants()     # (set_params has run since this exchange's own two buffers were filled)
         cur = torch.cuda.current_stream(cb.device)
         if cur.cuda_stream != cb.stream.cuda_stream:
             cb.stream.wait_stream(cur)
@@ -537,7 +648,12 @@ class BatchDealtCallback:
     differ in dt and mass) and scatters the varying entries into it behind every gather (one launch): `trajectory(b)` hands out views of
     it as before."""
 
-    def __init__(self, batch, n, m, nnz, compute_batch, device, group=None, const_mask=None, const_fill=None):
+    def __init__(self, batch, n, m, nnz, compute_batch, device, group=None, const_mask=None, const_fill=None, param_gen=None):
+        """param_gen() -> generation of the engine's parameters: refresh_constants() here is a COLLECTIVE (every rank's constants travel
+        to rank 0), so a stale buffer cannot be repaired by the rank that notices — to_root raises instead of returning a Jacobian with
+        the constants of the previous parameters."""
+        self.param_gen = param_gen
+        self._filled_gen = None
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -576,6 +692,7 @@ class BatchDealtCallback:
     def refresh_constants(self):
         """(compact exchange) every rank's constants — of ITS trajectories, under the parameters last set — into rank 0's complete
         array: one gather per parameter set (a collective: every rank calls it, at set-up and after every set_params)"""
+        self._filled_gen = self.param_gen() if self.param_gen is not None else None
         if not self.compact:
             return
         mine = torch.zeros(self.local, self.nnz, dtype=torch.float64, device=self.device)
@@ -640,7 +757,13 @@ class BatchDealtCallback:
             self._expand()
         return self if self.rank == 0 else None
 
+    def _check_fresh(self):
+        if self.compact and self.param_gen is not None and self.param_gen() != self._filled_gen:
+            raise RuntimeError("the parameters changed (set_params) since the constants of jac g were gathered: call refresh_constants() "
+                               "on EVERY rank (a collective) before the next exchange")
+
     def to_root(self, x_local):
+        self._check_fresh()
         if self.stream is None:
             return self._run(x_local, 0)
         cur = torch.cuda.current_stream(self.device)
@@ -888,7 +1011,8 @@ def hip_constants(engine):
     pattern, and hipnlp_fill_jac_constants on the caller's view (whole horizon: a shard handle knows the whole pattern)"""
     def fill(jac_view, stream_handle):
         engine.fill_jac_constants(jac_view.data_ptr(), True, stream_handle)
-    return {"const_mask": engine.jac_constant_mask(), "const_fill": fill}
+    # (param_gen: the receiving buffers hold the constants of ONE parameter set; the callbacks compare it at every call)
+    return {"const_mask": engine.jac_constant_mask(), "const_fill": fill, "param_gen": lambda: engine.params_generation}
 
 
 class HostSink:
@@ -909,7 +1033,9 @@ class HostSink:
         self.o_grad = 8 * ((world + 7) // 8)
         self.o_jac = self.o_grad + n
         self.o_g = self.o_jac + nnz
-        self.count = self.o_g + m
+        self.o_x = self.o_g + m                              # x of the step in flight, written by rank 0 (the one caller), read by every rank's kernel
+        self.o_mail = 8 * ((self.o_x + n + 7) // 8)          # int64 words: [0] step number rank 0 has posted x for, [8 + r] step rank r has completed
+        self.count = self.o_mail + 8 + 8 * ((world + 7) // 8)
         nbytes = ((self.count * 8 + 4095) // 4096) * 4096
         self.path = os.path.join("/dev/shm", name)
         self.dev = self.host = self._mm = None
@@ -937,6 +1063,7 @@ class HostSink:
                 finally:
                     os.close(fd)
                 self.host = np.frombuffer(self._mm, dtype=np.float64, count=self.count)
+                self.mail = np.frombuffer(self._mm, dtype=np.int64, count=self.count)[self.o_mail:]
                 self._lib = load_library()
                 self._lib.hipnlp_host_register.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
                 self._lib.hipnlp_host_unregister.argtypes = [C.c_void_p]
@@ -964,12 +1091,50 @@ class HostSink:
         """device-visible addresses (f partial of this rank, grad, g, jac) for HipNlp.eval_device on a shard handle"""
         return (self.dev + 8 * self.rank, self.dev + 8 * self.o_grad, self.dev + 8 * self.o_g, self.dev + 8 * self.o_jac)
 
+    # ---- one caller, one process per GPU: x in, "done" back, through the shared segment (no collective on the path) ------------------
+    # Rank 0 is the process the NLP driver lives in.  A step: rank 0 writes x into the segment and posts the step number; every rank
+    # (rank 0 too) sees the number, launches its shard's kernel — which READS x out of the segment over the rank's own PCIe link and
+    # stores its outputs into it — waits for its own stream and writes the step number into its slot; rank 0 has the callback when all
+    # `world` slots carry the number.  The multi-process sibling of hipnlp_multi_create (one process, one launching thread per shard).
+    def x_pointer(self):
+        """device-visible address of the x area: what every rank passes to HipNlp.eval_device as x"""
+        return self.dev + 8 * self.o_x
+
+    def post_x(self, x, step):
+        """rank 0: x of step `step` (1, 2, ...) into the segment, then the step number (x86: stores are seen in program order)"""
+        self.host[self.o_x:self.o_x + self.n] = np.asarray(x, dtype=np.float64).reshape(-1)
+        self.mail[0] = step
+
+    def wait_x(self, step, timeout_s=20.0):
+        """every rank: until rank 0 has posted x of step `step`"""
+        mail = self.mail
+        if mail[0] >= step:
+            return
+        import time
+        t_end = time.perf_counter() + timeout_s
+        while mail[0] < step:
+            if time.perf_counter() > t_end:
+                raise TimeoutError("rank %d: x of step %d was never posted" % (self.rank, step))
+
+    def done(self, step):
+        """this rank's stores of step `step` are complete (call behind the synchronise of its stream)"""
+        self.mail[8 + self.rank] = step
+
+    def wait_all(self, step, timeout_s=20.0):
+        """rank 0: until every rank has completed step `step`"""
+        slots = self.mail[8:8 + self.world]
+        import time
+        t_end = time.perf_counter() + timeout_s
+        while int(slots.min()) < step:
+            if time.perf_counter() > t_end:
+                raise TimeoutError("ranks %s never completed step %d" % ([r for r in range(self.world) if slots[r] < step], step))
+
     def views(self):
         """(f_parts[world], grad[n], jac[nnz], g[m]) numpy views of the shared buffer.
         VALID ONLY behind a cross-rank fence: every rank's kernel stores its own shard, so a reader needs every rank's stream
         synchronised AND a barrier between the ranks (a rank's own synchronise covers its own shard's stores only) — `sync(barrier)`."""
         h = self.host
-        return h[:self.world], h[self.o_grad:self.o_jac], h[self.o_jac:self.o_g], h[self.o_g:self.count]
+        return h[:self.world], h[self.o_grad:self.o_jac], h[self.o_jac:self.o_g], h[self.o_g:self.o_x]
 
     def sync(self, barrier, synchronize):
         """the cross-rank fence views() / f() need: this rank's stream synchronised (`synchronize()`), then every rank through `barrier()`"""
@@ -991,6 +1156,7 @@ class HostSink:
             self._lib.hipnlp_host_unregister(C.c_void_p(self._addr))
         self.dev = None
         self.host = None
+        self.mail = None
         mm, self._mm = getattr(self, "_mm", None), None
         if mm is not None:   # (whether or not the registration succeeded)
             try:

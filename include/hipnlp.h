@@ -536,8 +536,22 @@ int hipnlp_reassemble_scatter(const double* gathered_dev, const int64_t* src_dev
  * MEASURED on one card only (several shards of one device, tests/test_gpu_multi.py, bench.py `one_caller`); with one device per shard:
  * unmeasured in this repository. */
 int hipnlp_multi_create(const hipnlp_desc* desc, const int32_t* devices, int n_devices, hipnlp_handle** out);
+/* The cut and what of x a shard reads — pure arithmetic, no device (what hipnlp_multi_create follows): knots [*knot_begin, *knot_end) of
+ * shard `shard` of n_shards, and x_ranges[4][2] = {offset, count} in doubles of one trajectory's x: [0] the shard's records with the halo
+ * record in front of them, [1] the six horizon-global variables, [2] the last knot's record for the owner of knot 0, [3] the first knot's
+ * record for the owner of the last knot (count 0: not read).  A shard's kernel reads x NOWHERE else: a caller that keeps x in pieces
+ * (or a transport that ships it) needs to deliver exactly these. */
+int hipnlp_multi_plan(int horizon, int n_shards, int shard, int32_t* knot_begin, int32_t* knot_end, int64_t* x_ranges /*[4][2]*/);
 int hipnlp_multi_info(const hipnlp_handle* h, int32_t* n_shards, int32_t* devices, int32_t* knot_begin, int32_t* knot_end, int32_t* waves);
 int hipnlp_multi_breakdown(const hipnlp_handle* h, double* us);
+/* One launching thread per shard.  Enqueueing a kernel costs the host 4 - 6 us and waiting for its stream a few more: from the caller's
+ * thread, one shard after the other, shard i starts ~i x 10 us behind shard 0 — with eight shards longer than the callback of ONE device.
+ * on = 1: shards 1 .. n-1 get a worker thread bound to their device; an evaluation publishes its job, the caller's thread does shard 0's
+ * part and waits for the workers.  A worker polls for the next job for spin_us microseconds after its last one (IPOPT's callbacks come in
+ * bursts, microseconds apart: default 200; < 0: leave as it is) and then sleeps until woken (IPOPT factorises for milliseconds between
+ * bursts: no core is burnt meanwhile, the first callback of a burst pays one wake-up).  on = 0: the caller's thread launches every shard,
+ * then waits for every shard.  hipnlp_multi_create turns the threads ON for handles of more than one shard.  Values are the same either way. */
+int hipnlp_multi_set_threads(hipnlp_handle* h, int on, double spin_us);
 
 /* Per-named-cost values of the last evaluation (Output.cost_values, base/problem.py:28-56):
  * values[batch][HIPNLP_NCOST_TERMS], summed over knots, in the order of hipnlp_cost_term_name(). */

@@ -344,6 +344,48 @@ void hostemu_stage_rows(const hostemu_handle* h, int k, int* rows) {
     for (int s = 0; s < gs::COUNT; ++s) { const int a = h->L.g_a[v][size_t(s)]; rows[s] = a != G_NONE ? a + h->L.g_b[size_t(s)] * k : -1; }
 }
 
+// The knots [kb, ke) of the horizon — what ONE shard handle of a multi-device handle evaluates (hipnlp_multi_create): its kernel reads
+// x at the places the staging below reads it and writes the entries of grad f / g / jac g its knots own into the arrays of the WHOLE
+// problem; cost_knot [N][NCT] receives the knots' cost partials.  Nothing else of the arrays is touched.
+void hostemu_eval_range(const hostemu_handle* h, const double* x, const double* p, int kb, int ke, double* grad, double* g, double* jac, double* cost_knot) {
+    const Layout& L = h->L;
+    const int N = L.N;
+    std::vector<double> pk(size_t(N) * PK_STRIDE);
+    GParams gp;
+    pack_params(p, N, pk.data(), gp);
+    KnotScratch* s = new KnotScratch();
+    for (int k = kb; k < ke; ++k) {
+        std::fill(reinterpret_cast<double*>(s), reinterpret_cast<double*>(s) + sizeof(KnotScratch) / sizeof(double), std::nan(""));
+        for (int i = 0; i < XPAD; ++i) { s->x[i] = 0; s->xm[i] = 0; }
+        for (int i = 0; i < NPER; ++i) s->xo[i] = 0;
+        for (int i = 0; i < NXK; ++i) {
+            s->x[i] = x[NXK * k + i];
+            s->xm[i] = k > 0 ? x[NXK * (k - 1) + i] : 0.0;
+        }
+        for (int i = 0; i < NPER; ++i) s->xo[i] = k == 0 ? x[NXK * (N - 1) + periodicity_row_var(i)] : (k == N - 1 ? x[periodicity_row_var(i)] : 0.0);
+        for (int i = 0; i < NXG; ++i) s->xg[i] = x[NXK * N + i];
+        for (int i = 0; i < PK_STRIDE; ++i) s->pk[i] = pk[size_t(k) * PK_STRIDE + i];
+        KnotInfo ki{k, N, k == 0, k == N - 1};
+        ValueEm em{s->g, s->jac};
+        Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
+#define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
+        HIPNLP_KNOT_PROGRAM(HOST_R, )
+#undef HOST_R
+        const int v = L.variant_of(k);
+        const long jb = L.jac_base(k);
+        for (int i = 0; i < L.nnz_v[v]; ++i) jac[jb + i] = s->jac[L.jperm[v][size_t(i)]];
+        if (k == N - 1) for (size_t i = 0; i < L.jperm_glob.size(); ++i) jac[L.jac_glob_base + long(i)] = s->jac[L.jperm_glob[i]];
+        for (int slot = 0; slot < gs::COUNT; ++slot) {
+            const int a = L.g_a[v][size_t(slot)];
+            if (a != G_NONE) g[a + L.g_b[size_t(slot)] * k] = s->g[slot];
+        }
+        for (int i = 0; i < NXK; ++i) grad[NXK * k + i] = s->grad[i];
+        if (k == N - 1) for (int i = 0; i < NXG; ++i) grad[NXK * N + i] = 0.0;   // (the global variables carry no cost: the last knot writes the zeros)
+        for (int i = 0; i < NCT; ++i) cost_knot[size_t(k) * NCT + i] = s->cost[i];
+    }
+    delete s;
+}
+
 void hostemu_eval(const hostemu_handle* h, const double* x, const double* p, double* f, double* grad, double* g, double* jac, double* cost_terms) {
     const Layout& L = h->L;
     const int N = L.N;

@@ -74,6 +74,18 @@ def test_shard_handles_on_one_device_give_the_plain_handles_bits(model, HipNlp, 
     assert stats["auto_ranges"] == big >= 2 and stats["auto_fallbacks"] == 0
     if vary_first:
         assert stats["constant_fills"] >= 1
+    # one launching thread per shard: the same bits
+    multi.set_threads(True, spin_us=50.0)
+    for i, xi in enumerate(iterates(x, 4, seed=8)):
+        ref = plain.eval(xi)
+        got = multi.eval(xi, out=out)
+        assert all(bits_equal(u, v) for u, v in zip(got, ref)), i
+        assert bits_equal(multi.eval_hess(xi, 0.7, lam, out=hess), plain.eval_hess(xi, 0.7, lam)), i
+        if i == 1:
+            import time
+            time.sleep(0.01)                              # (the workers go to sleep: the next call wakes them)
+    if n_shards == 3:
+        multi.set_threads(False)
     # IPOPT's order with new_x = FALSE behind the first callback: one evaluation, outputs that stayed in the shards' HBM are fetched
     xi = iterates(x, 7)[6]
     ref = plain.eval(xi)

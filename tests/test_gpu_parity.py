@@ -548,8 +548,7 @@ def test_sharded_callback_reassembly_on_gpu(model, HipNlp, lifted, compact):
     for params in ((p, p2) if compact else (p,)):
         if params is p2:
             full.set_params(p2)
-            sh.set_params(p2)
-            cb.refresh_constants()
+            sh.set_params(p2)     # (no refresh_constants(): the callback sees the engine's parameter generation move and refreshes by itself)
         got = []
         for xd in xds:   # back to back, results copied out on the caller's stream without an explicit synchronisation in between
             fs, grads, jacs, gs = cb(xd)
@@ -691,8 +690,7 @@ def test_peer_exchange_equals_the_gathered_callback(model, HipNlp, compact):
             p2 = p.copy()
             p2[:, 24 * N + 3 + 105 + 105] *= 0.8
             for e in (full, sh):
-                e.set_params(p2)
-            px.refresh_constants()
+                e.set_params(p2)  # (no px.refresh_constants(): keyed on the engine's parameter generation, as the callback's own buffer)
             for xi in xs[:3]:
                 fs, grads, jacs, gs = px(torch.from_numpy(xi).to(dev))
                 torch.cuda.synchronize()
@@ -704,8 +702,7 @@ def test_peer_exchange_equals_the_gathered_callback(model, HipNlp, compact):
             me = cb.infos[0]
             assert px.max_bytes_sent_per_step() == 0 and me["jvary"] < 0.62 * me["jlen"]
         px.close()
-    # the collective's gather_to_root at world size 1
-    cb.refresh_constants()
+    # the collective's gather_to_root at world size 1 (the parameters went back to p above: refreshed by the call itself)
     fs, grads, jacs, gs = cb.to_root(torch.from_numpy(xs[1]).to(dev))
     torch.cuda.synchronize()
     f, grad, g, jac = full.eval(xs[1][None, :])

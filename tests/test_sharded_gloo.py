@@ -65,7 +65,7 @@ def _worker(rank, world, port, horizon, result_q, compact=False):
     info = {"glen": 189 * (ke - kb) + (6 if ke == horizon else 0), "jlen": int(sel.sum()),
             "nk": ke - kb, "stage_rows": np.stack([rows_all[k] for k in range(kb, ke)])}
     mask = emu.constant_mask()
-    params = {"p": p[0].copy()}
+    params = {"p": p[0].copy(), "gen": 1}       # ("gen": what HipNlp.params_generation is for the HIP engine — bumped by every set_params)
     fills = []
     kw = {}
     if compact:
@@ -77,7 +77,7 @@ def _worker(rank, world, port, horizon, result_q, compact=False):
             const = emu.constant_fill(params["p"])
             view[torch.from_numpy(mask)] = torch.from_numpy(const[mask])
             fills.append(1)
-        kw = dict(const_mask=mask, const_fill=const_fill)
+        kw = dict(const_mask=mask, const_fill=const_fill, param_gen=lambda: params["gen"])
 
     def compute(xt, f_view, grad_view, jac_view, stage_view, stream_handle):
         gs, js, stg = _emulated_shard(emu, rows_all, kb, ke, horizon, xt.numpy(), params["p"])
@@ -97,10 +97,22 @@ def _worker(rank, world, port, horizon, result_q, compact=False):
             + max(ke_ - kb_ for kb_, ke_ in (knot_range(horizon, world, r) for r in range(world))) * 550
         assert cb.shard_len < plain_len and cb.bytes_sent_per_step() == 8 * cb.shard_len * (world - 1)
         assert 0.35 < mask.mean() < 0.5 and len(fills) == 1
-    f, grad, jac, g = cb(torch.from_numpy(x[0]))
+    # the INPUT half: x exists in rank 0's host memory only (the process IPOPT lives in, opti_solver.py:479) — the other rank starts
+    # from garbage and gets x through the feed (a broadcast), then every rank evaluates its shard from what it received
+    from hippopt_amd.sharded import XFeed
+    feed = XFeed(emu.n, torch.device("cpu"))
+    x_in = feed.feed(feed.stage(x[0]) if rank == 0 else None)
+    fed_ok = np.array_equal(x_in.numpy(), x[0])
+    f, grad, jac, g = cb(x_in)
     f_ref, grad_ref, g_ref, jac_ref, _ = emu.eval(x[0], p[0])
-    ok = (np.array_equal(grad.numpy(), grad_ref) and np.array_equal(jac.numpy(), jac_ref) and np.array_equal(g.numpy(), g_ref)
+    ok = (fed_ok and np.array_equal(grad.numpy(), grad_ref) and np.array_equal(jac.numpy(), jac_ref) and np.array_equal(g.numpy(), g_ref)
           and float(f) == sum(range(1, world + 1)))
+    if rank == 0:
+        try:
+            feed.stage(x[0][:-1])
+            ok = False
+        except ValueError:
+            pass
     # gather_to_root: one consumer — rank 0 alone receives the reassembled outputs (dist.gather), the others hold nothing
     x2 = x[0] + 1e-3
     f2, grad2, jac2, g2 = cb.to_root(torch.from_numpy(x2))
@@ -116,7 +128,7 @@ def _worker(rank, world, port, horizon, result_q, compact=False):
         p_new = p[0].copy()
         p_new[24 * horizon + 3 + 105 + 105] *= 1.3          # ParamOffsets::dt (layout.h)
         params["p"] = p_new
-        cb.refresh_constants()
+        params["gen"] += 1                                  # (a set_params; NO refresh_constants(): the callback notices and refreshes by itself)
         f3, grad3, jac3, g3 = cb(torch.from_numpy(x2))
         _, grad_ref3, g_ref3, jac_ref3, _ = emu.eval(x2, p_new)
         _, _, _, jac_old, _ = emu.eval(x2, p[0])
@@ -186,11 +198,17 @@ def _batch_worker(rank, world, port, batch, horizon, result_q, compact=False):
         for i in range(b1 - b0):
             const = emu.constant_fill(p[b0 + i])
             view[i][torch.from_numpy(mask)] = torch.from_numpy(const[mask])
-    kw = dict(const_mask=mask, const_fill=const_fill) if compact else {}
+    gen = {"v": 1}
+    kw = dict(const_mask=mask, const_fill=const_fill, param_gen=lambda: gen["v"]) if compact else {}
     bc = BatchDealtCallback(batch, emu.n, emu.m, emu.nnz, compute, torch.device("cpu"), **kw)
     ok = (bc.b0, bc.b1) == (b0, b1)
+    # the guesses exist in rank 0's host memory (where their NLP drivers live): dealt to the ranks by a scatter
+    from hippopt_amd.sharded import XDeal
+    dealer = XDeal(batch, emu.n, torch.device("cpu"))
     for shift in (0.0, 1e-3):     # two steps: the second overwrites the first
-        got = bc.to_root(torch.from_numpy(x[b0:b1] + shift))
+        xl = dealer.deal(dealer.stage(x + shift) if rank == 0 else None)
+        ok = ok and np.array_equal(xl.numpy(), x[b0:b1] + shift)
+        got = bc.to_root(xl)
         if rank == 0:
             ok = ok and got is bc
             for b in range(batch):
@@ -199,6 +217,18 @@ def _batch_worker(rank, world, port, batch, horizon, result_q, compact=False):
                 ok = ok and float(f) == float(fr) and np.array_equal(grad.numpy(), gradr) and np.array_equal(g.numpy(), gr) and np.array_equal(jac.numpy(), jacr)
         else:
             ok = ok and got is None
+    if compact:
+        # a set_params without the (collective) refresh: the exchange refuses to hand out a Jacobian with the old constants, on every rank;
+        # after the refresh it runs again
+        gen["v"] += 1
+        try:
+            bc.to_root(torch.from_numpy(x[b0:b1]))
+            ok = False
+        except RuntimeError as err:
+            ok = ok and "refresh_constants" in str(err)
+        bc.refresh_constants()
+        got = bc.to_root(torch.from_numpy(x[b0:b1]))
+        ok = ok and ((got is bc) if rank == 0 else (got is None))
     jw = int((~mask).sum()) if compact else emu.nnz
     ok = ok and bc.max_bytes_sent_per_step() == 8 * (b1 - b0) * (1 + emu.n + emu.m + jw) and bc.bytes_sent_per_step() == (0 if rank == 0 else bc.max_bytes_sent_per_step())
     ok = ok and (not compact or jw < 0.7 * emu.nnz)
