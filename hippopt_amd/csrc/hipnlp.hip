@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -1180,6 +1181,9 @@ struct hipnlp_handle {
     // (profiles/r05_early_stores_by_box.txt).
     int hess_early_mode = -1, hess_early_choice = -1, hess_tune_calls = 0;
     double hess_tune_best[2] = {1e30, 1e30};
+    std::vector<double> hess_tune_us[2];   // (auto mode without a NUMA answer: the samples of each kind; their medians decide)
+    int hess_early_why = 0;                // how the choice was made: HESS_WHY_*
+    int hess_caller_node = -1, hess_card_node = -1;
     bool hess_compact = false;   // exact Hessian: compact-scratch instantiation (three workgroups per CU) for launches of more than 512 workgroups
     bool hess_direct = true;     // ... and, planar terrain into device memory, the instantiation without LDS staging of the entries (diagnostic override: HIPNLP_HESS_DIRECT=0)
     int dev = 0;
@@ -2437,6 +2441,30 @@ int hipnlp_eval_hess_device(hipnlp_handle* h, const double* x_dev, const double*
     HIP_TRY(h, hipSetDevice(h->dev));
     return hess_launch(h, x_dev, obj_factor_dev, lambda_dev, hess_dev, stream ? hipStream_t(stream) : h->stream);
 }
+// how a handle in auto mode (hipnlp_set_hessian_early_run(h, -1)) came to its choice
+enum { HESS_WHY_UNDECIDED = 0, HESS_WHY_FORCED = 1, HESS_WHY_NOT_ARMABLE = 2, HESS_WHY_NUMA_SAME = 3, HESS_WHY_NUMA_OTHER = 4, HESS_WHY_MEASURED = 5 };
+// NUMA node of the CPU the calling thread runs on (Linux sysfs: the node whose cpulist holds it); -1: not known / one node only says nothing
+static int numa_node_of_calling_thread() {
+    const int cpu = sched_getcpu();
+    if (cpu < 0) return -1;
+    for (int node = 0; node < 64; ++node) {
+        FILE* f = std::fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r");
+        if (!f) { if (node == 0) return -1; break; }
+        char text[4096] = {0};
+        const size_t got = std::fread(text, 1, sizeof text - 1, f);
+        std::fclose(f);
+        text[got] = 0;
+        for (const char* c = text; *c;) {
+            if (!std::isdigit(static_cast<unsigned char>(*c))) { ++c; continue; }
+            char* end = nullptr;
+            long lo = std::strtol(c, &end, 10), hi = lo;
+            if (*end == '-') hi = std::strtol(end + 1, &end, 10);
+            if (cpu >= lo && cpu <= hi) return node;
+            c = end;
+        }
+    }
+    return -1;
+}
 int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor, const double* lambda, double* hess) {
     return hipnlp_eval_hess_at(h, x, 1, obj_factor, lambda, hess);
 }
@@ -2532,14 +2560,33 @@ int hipnlp_eval_hess_at(hipnlp_handle* h, const double* x, int new_x, const doub
         __atomic_store_n(&w[0], sentinel, __ATOMIC_RELAXED);
         __atomic_store_n(&w[hbytes / 8 - 1], sentinel, __ATOMIC_RELAXED);
     }
-    // early run: forced on / off, or — the default — tried both ways on the handle's own first calls (three calls to warm up, then six
-    // of each kind alternating, launch to completion on the host's clock, the faster minimum wins): which way is faster is a property of
-    // the SOCKET of the host the caller sits on, not of the kernel (a gain on the card's NUMA node, a loss across the socket interconnect:
-    // profiles/r05_early_stores_by_box.txt)
-    constexpr int TUNE_WARM = 3, TUNE_SAMPLES = 12;
+    // early run: forced on / off, or — the default — decided ONCE per handle, by what the profiles say decides it (profiles/
+    // r05_early_stores_by_box.txt): a gain when the calling thread sits on the card's NUMA node, a loss across the socket interconnect.
+    //   1. a launch that cannot arm the early run at all (compact Hessian layout: long launches; a pattern whose early run is not the one
+    //      the kernel was built for) has nothing to decide: off, no sampling;
+    //   2. both NUMA nodes known: on if they are the same node, off otherwise — no clock involved: the same choice in every run;
+    //   3. otherwise (one-node hosts, containers that hide the topology): measured on the handle's own first calls — three to warm up, then
+    //      nine of each kind alternating, launch to completion on the host's clock, the lower MEDIAN wins (one scheduler hiccup among
+    //      six samples and a minimum used to flip this).
+    // hipnlp_get_hessian_early_run / hipnlp_hessian_early_run_reason say what was decided and why.
+    constexpr int TUNE_WARM = 3, TUNE_SAMPLES = 18;
     bool early = h->early_store && h->hess_early_mode != 0;
     bool sample = false;
+    if (h->hess_early_mode >= 0) h->hess_early_why = HESS_WHY_FORCED;
     if (h->early_store && h->hess_early_mode < 0) {
+        if (h->hess_early_choice < 0) {
+            const hipnlp_handle* s0 = h->multi ? h->multi->shards[0] : h;   // (the shards of a multi-device handle share the layout decisions of their sizes)
+            const bool armable = !s0->hess_compact && h->HL.early_run <= 3 * 256 && h->HL.early_run > 0 && h->HL.early_phase == hess_early_phase(h->d.settings.terrain);
+            if (!armable) { h->hess_early_choice = 0; h->hess_early_why = HESS_WHY_NOT_ARMABLE; }
+            else if (h->hess_tune_calls == 0) {
+                h->hess_caller_node = numa_node_of_calling_thread();
+                if (hipnlp_device_numa_node(h->dev, &h->hess_card_node) != HIPNLP_OK) h->hess_card_node = -1;
+                if (h->hess_caller_node >= 0 && h->hess_card_node >= 0) {
+                    h->hess_early_choice = h->hess_caller_node == h->hess_card_node ? 1 : 0;
+                    h->hess_early_why = h->hess_early_choice ? HESS_WHY_NUMA_SAME : HESS_WHY_NUMA_OTHER;
+                }
+            }
+        }
         if (h->hess_early_choice >= 0) early = h->hess_early_choice != 0;
         else {
             const int c = h->hess_tune_calls++;
@@ -2552,8 +2599,16 @@ int hipnlp_eval_hess_at(hipnlp_handle* h, const double* x, int new_x, const doub
     if (rc != HIPNLP_OK) return rc;
     if (sample) {
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_launch).count();
-        h->hess_tune_best[early ? 1 : 0] = std::min(h->hess_tune_best[early ? 1 : 0], us);
-        if (h->hess_tune_calls >= TUNE_WARM + TUNE_SAMPLES) h->hess_early_choice = h->hess_tune_best[1] <= h->hess_tune_best[0] ? 1 : 0;
+        h->hess_tune_us[early ? 1 : 0].push_back(us);
+        if (h->hess_tune_calls >= TUNE_WARM + TUNE_SAMPLES) {
+            for (int q = 0; q < 2; ++q) {   // (medians: reported through hipnlp_get_hessian_early_run)
+                std::vector<double>& v = h->hess_tune_us[q];
+                std::sort(v.begin(), v.end());
+                h->hess_tune_best[q] = v.empty() ? 1e30 : v[v.size() / 2];
+            }
+            h->hess_early_choice = h->hess_tune_best[1] <= h->hess_tune_best[0] ? 1 : 0;
+            h->hess_early_why = HESS_WHY_MEASURED;
+        }
     }
     if (sentinel) {
         const u64* w = reinterpret_cast<const u64*>(hess);
@@ -3109,7 +3164,20 @@ int hipnlp_set_hessian_early_run(hipnlp_handle* h, int mode) {
     if (!h || mode < -1 || mode > 1) return HIPNLP_E_INVALID;
     h->hess_early_mode = mode;
     h->hess_early_choice = -1; h->hess_tune_calls = 0; h->hess_tune_best[0] = h->hess_tune_best[1] = 1e30;   // (auto: decided afresh)
+    h->hess_tune_us[0].clear(); h->hess_tune_us[1].clear();
+    h->hess_early_why = mode >= 0 ? HESS_WHY_FORCED : HESS_WHY_UNDECIDED;
     return HIPNLP_OK;
+}
+const char* hipnlp_hessian_early_run_reason(const hipnlp_handle* h) {
+    if (!h) return "";
+    switch (h->hess_early_mode >= 0 ? HESS_WHY_FORCED : h->hess_early_why) {
+        case HESS_WHY_FORCED: return "set by the caller (hipnlp_set_hessian_early_run)";
+        case HESS_WHY_NOT_ARMABLE: return "off: this handle's Hessian launches cannot send a run ahead (compact layout of long launches, or no early run in the pattern)";
+        case HESS_WHY_NUMA_SAME: return "on: the calling thread runs on the card's NUMA node";
+        case HESS_WHY_NUMA_OTHER: return "off: the calling thread runs on another NUMA node than the card's";
+        case HESS_WHY_MEASURED: return "measured on the handle's first calls (NUMA nodes not known): the lower median of nine calls of each kind";
+        default: return "not decided yet (decided by the first hipnlp_eval_hess call)";
+    }
 }
 int hipnlp_get_hessian_early_run(const hipnlp_handle* h, int* mode, int* chosen, double* us_off, double* us_on) {
     if (!h) return HIPNLP_E_INVALID;

@@ -26,7 +26,7 @@ EXPORTS = [
     "hipnlp_jac_vary_layout", "hipnlp_fill_jac_constants", "hipnlp_eval_device_vary", "hipnlp_eval_device_shard_vary", "hipnlp_eval_device_peers_vary", "hipnlp_reassemble_scatter",
     "hipnlp_ipc_alloc", "hipnlp_ipc_open", "hipnlp_ipc_close", "hipnlp_ipc_free", "hipnlp_peer_push", "hipnlp_peer_signal", "hipnlp_peer_signal_checked", "hipnlp_peer_wait", "hipnlp_eval_device_peers",
     "hipnlp_device_numa_node", "hipnlp_pin_thread_to_device_numa_node",
-    "hipnlp_hess_nnz", "hipnlp_hess_sparsity", "hipnlp_eval_hess", "hipnlp_eval_hess_at", "hipnlp_set_hessian_early_run", "hipnlp_get_hessian_early_run", "hipnlp_eval_hess_device",
+    "hipnlp_hess_nnz", "hipnlp_hess_sparsity", "hipnlp_eval_hess", "hipnlp_eval_hess_at", "hipnlp_set_hessian_early_run", "hipnlp_get_hessian_early_run", "hipnlp_hessian_early_run_reason", "hipnlp_eval_hess_device",
     "hipnlp_eval_pinned", "hipnlp_set_prefetch", "hipnlp_set_early_outputs", "hipnlp_set_host_timing", "hipnlp_host_register", "hipnlp_host_unregister",
     "hipnlp_multi_create", "hipnlp_multi_plan", "hipnlp_multi_info", "hipnlp_multi_breakdown", "hipnlp_multi_set_threads",
     "hipnlp_host_breakdown", "hipnlp_set_auto_register", "hipnlp_host_stats", "hipnlp_set_constant_jacobian", "hipnlp_forget_jac_destination", "hipnlp_jac_constant_mask", "hipnlp_host_release_auto_ranges",
@@ -176,6 +176,8 @@ def load_library(path=None):
     lib.hipnlp_eval_hess_at.argtypes = [vp, dp, C.c_int, dp, dp, dp]
     lib.hipnlp_set_hessian_early_run.argtypes = [vp, C.c_int]
     lib.hipnlp_get_hessian_early_run.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), dp, dp]
+    lib.hipnlp_hessian_early_run_reason.argtypes = [vp]
+    lib.hipnlp_hessian_early_run_reason.restype = C.c_char_p
     lib.hipnlp_eval_hess_device.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.hipnlp_kernels_per_eval.argtypes = [vp]
     lib.hipnlp_profile_begin_runs.argtypes = [vp, C.c_int, C.c_int]
@@ -554,11 +556,13 @@ class HipNlp:
         self._check(self.lib.hipnlp_set_hessian_early_run(self.h, -1 if mode is None else int(bool(mode))))
 
     def hessian_early_run(self):
-        """{"mode": None | bool, "in_use": None (not decided yet) | bool, "us_off", "us_on": the minima the decision rests on}"""
+        """{"mode": None | bool, "in_use": None (not decided yet) | bool, "us_off", "us_on": the medians a MEASURED decision rests on (0: decided
+        without a clock), "why": how the choice was made}"""
         mode, chosen, off, on = C.c_int(), C.c_int(), C.c_double(), C.c_double()
         self._check(self.lib.hipnlp_get_hessian_early_run(self.h, C.byref(mode), C.byref(chosen), C.byref(off), C.byref(on)))
         tri = lambda v: None if v < 0 else bool(v)  # noqa: E731
-        return {"mode": tri(mode.value), "in_use": tri(chosen.value), "us_off": off.value, "us_on": on.value}
+        return {"mode": tri(mode.value), "in_use": tri(chosen.value), "us_off": off.value, "us_on": on.value,
+                "why": self.lib.hipnlp_hessian_early_run_reason(self.h).decode()}
 
     def eval_hess_device(self, x_ptr, obj_factor_ptr, lam_ptr, hess_ptr, stream=None):
         vp = C.c_void_p

@@ -386,11 +386,17 @@ int hipnlp_eval_hess_at(hipnlp_handle* h, const double* x, int new_x, const doub
 /* hipnlp_eval_hess* into host memory: the run at the start of every knot block (the point columns: a quarter of the values on the planar
  * terrain, two fifths on the smooth steps) is final long before the program ends and can leave then — the same kernel, the same values,
  * bit for bit.  Whether that is FASTER is a property of the host: measured 4 - 7 us sooner per 100-knot Hessian with the calling thread on
- * the card's NUMA node (hipnlp_pin_thread_to_device_numa_node) and 2 - 3 us later from the other socket of the same box.  mode 1 / 0: on / off; -1 (the default): the handle tries both on its own first calls (three to warm up, six
- * of each kind, launch to completion on the host's clock) and keeps the faster one; setting a mode starts that over.
- * hipnlp_get_hessian_early_run: the mode, what is in use (-1: not decided yet) and the two minima in microseconds (0: not measured). */
+ * the card's NUMA node (hipnlp_pin_thread_to_device_numa_node) and 2 - 3 us later from the other socket of the same box.  mode 1 / 0: on / off;
+ * -1 (the default): decided once, by the handle's first Hessian call, without a clock wherever the host says enough — off when the
+ * handle's launches cannot send a run ahead at all (long launches on the compact layout), on when the calling thread runs on the card's
+ * NUMA node (sysfs), off when it runs on another one — the same choice in every run on the same host; only where the topology is not
+ * known (one-node hosts, containers) does the handle try both on its own first calls (three to warm up, nine of each kind alternating,
+ * launch to completion on the host's clock) and keep the kind with the lower MEDIAN.  Setting a mode starts that over.
+ * hipnlp_get_hessian_early_run: the mode, what is in use (-1: not decided yet) and — measured choices only — the two medians in
+ * microseconds (0: not measured); hipnlp_hessian_early_run_reason: one sentence on how the choice was made. */
 int hipnlp_set_hessian_early_run(hipnlp_handle* h, int mode);
 int hipnlp_get_hessian_early_run(const hipnlp_handle* h, int* mode, int* chosen, double* us_off, double* us_on);
+const char* hipnlp_hessian_early_run_reason(const hipnlp_handle* h);
 int hipnlp_eval_hess_device(hipnlp_handle* h, const double* x_dev, const double* obj_factor_dev, const double* lambda_dev,
                             double* values_dev, void* stream);
 /* Device-resident variant: all pointers are device pointers on desc.device (or device-visible addresses of registered host

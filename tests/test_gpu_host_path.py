@@ -312,32 +312,60 @@ def test_early_copy_out_of_the_hessian_host_path_changes_no_bit(model, HipNlp, t
             e.close()
 
 
-def test_hessian_early_run_is_decided_by_the_handle_from_its_own_first_calls(model, HipNlp):
+def test_hessian_early_run_is_decided_once_and_says_why(model, HipNlp):
     """Default mode of hipnlp_set_hessian_early_run: whether the run at the start of every knot block leaves early is faster is a property
-    of the HOST (measured both ways on boxes of one pool), so the handle tries both on its first calls — three to warm up, six of each kind —
-    and keeps the faster; the values are the same bits whatever it does, and setting a mode starts the trial over."""
+    of the HOST — a gain with the calling thread on the card's NUMA node, a loss from the other socket — so the handle decides at its first
+    Hessian call from what sysfs says (no clock: the same choice in every run); where the topology is not known it measures both ways on
+    its first calls (three to warm up, nine of each kind, medians).  A handle whose launches cannot send a run ahead (long launches on the
+    compact layout) decides nothing and says so.  The values are the same bits whatever it does; setting a mode starts it over."""
+    from hippopt_amd.hipnlp import device_numa_node, parse_cpulist
+    import os
     st = periodic_step_settings(30, model)
     x, p = make_workload(st, model, batch=1, seed=4870)
     eng, ref = HipNlp(st, model), HipNlp(st, model)
     for e in (eng, ref):
         e.set_params(p)
     ref.set_hessian_early_run(False)
+    assert ref.hessian_early_run()["why"].startswith("set by the caller")
     lam = np.random.RandomState(2).standard_normal((1, eng.m))
     out, want = np.empty((1, eng.hess_nnz())), np.empty((1, eng.hess_nnz()))
-    assert eng.hessian_early_run() == {"mode": None, "in_use": None, "us_off": 0.0, "us_on": 0.0}
+    state = eng.hessian_early_run()
+    assert (state["mode"], state["in_use"], state["us_off"], state["us_on"]) == (None, None, 0.0, 0.0) and state["why"].startswith("not decided yet")
+    card = device_numa_node(0)
+    mine = None
+    if card is not None:
+        cpu = os.sched_getaffinity(0)
+        for node in range(64):
+            try:
+                cpus = parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read())
+            except OSError:
+                break
+            if cpu <= cpus:                       # (every CPU this thread may run on belongs to ONE node: the answer cannot change under the test)
+                mine = node
     xs = iterates(x, 5)
-    for i in range(20):
+    for i in range(24):
         eng.eval_hess(xs[i % 5], 0.9, lam, out=out)
         ref.eval_hess(xs[i % 5], 0.9, lam, out=want)
         assert np.array_equal(out, want), i
         state = eng.hessian_early_run()
-        assert (state["in_use"] is None) == (i < 14), (i, state)        # decided by the fifteenth call (3 + 12)
-    assert state["mode"] is None and state["us_off"] > 0.0 and state["us_on"] > 0.0
-    assert state["in_use"] == (state["us_on"] <= state["us_off"])
-    eng.set_hessian_early_run(None)                                     # the trial starts over
+        if card is not None and mine is not None:
+            assert state["in_use"] is (mine == card), (i, state)          # from the first call on, without a clock
+            assert state["us_off"] == 0.0 and state["us_on"] == 0.0 and "NUMA node" in state["why"]
+    assert state["mode"] is None and state["in_use"] is not None           # decided by now either way (3 + 18 calls when measured)
+    if "measured" in state["why"]:
+        assert state["us_off"] > 0.0 and state["us_on"] > 0.0 and state["in_use"] == (state["us_on"] <= state["us_off"])
+    eng.set_hessian_early_run(None)                                        # starts over
     assert eng.hessian_early_run()["in_use"] is None
     eng.close()
     ref.close()
+    # a handle whose Hessian launches are long (compact layout: more than 512 workgroups) cannot send a run ahead: nothing to decide
+    big = HipNlp(st, model, batch=20)
+    xb, pb = make_workload(st, model, batch=20, seed=4871)
+    big.set_params(pb)
+    big.eval_hess(xb, 1.0, np.zeros((20, big.m)))
+    state = big.hessian_early_run()
+    assert state["in_use"] is False and state["why"].startswith("off: this handle's Hessian launches cannot send a run ahead")
+    big.close()
 
 
 def test_the_process_can_be_put_on_the_cards_side_of_the_host():
