@@ -943,6 +943,7 @@ def main():
     # the process on the side of the host its card hangs off, before anything it will hand to the library is allocated (first touch): the
     # host-buffer legs are link-bound and measured 2 - 5 us per call slower from the other socket (profiles/r05_early_stores_by_box.txt);
     # what a deployment does with numactl / sched_setaffinity — hippopt_amd.hipnlp.pin_to_device_numa_node
+    affinity_at_start = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None   # (the CPU baseline runs under this one again)
     numa = None
     if not args.no_numa_pin:
         from hippopt_amd.hipnlp import pin_to_device_numa_node
@@ -1641,7 +1642,17 @@ def main():
                                "evaluations_counted_by_the_handle": eng.host_stats()["evaluations"],
                                "knot_evaluations_in_timed_region": main_res["local_knots"] * args.steps}
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(st, model, main_res["x_np"][0], main_res["p_np"][0])
+            # under the affinity the process STARTED with: the pin to the card's NUMA node is for the link-bound GPU legs; the CPU port gets
+            # every core the job was given (its nproc and OpenMP team were limited to one node)
+            pinned_now = os.sched_getaffinity(0) if affinity_at_start is not None else None
+            if affinity_at_start is not None:
+                os.sched_setaffinity(0, affinity_at_start)
+            try:
+                cb = cpu_baseline(st, model, main_res["x_np"][0], main_res["p_np"][0])
+            finally:
+                if pinned_now is not None:
+                    os.sched_setaffinity(0, pinned_now)
+            cb["affinity"] = "the %d CPUs the process started with (the NUMA pin of the GPU legs lifted for this leg)" % len(affinity_at_start) if affinity_at_start is not None else "unknown"
             cb["gpu_over_cpu"] = {"device_resident_vs_1_thread": line["value"] / cb["value"],
                                   "device_resident_vs_all_cores": line["value"] / cb["all_cores"]["value"]}
             if "host_visible" in line and "all" in line["host_visible"]:

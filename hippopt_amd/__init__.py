@@ -3,7 +3,7 @@ solver boundary."""
 
 # the reference's planner-level names (hippopt/__init__.py): `import hippopt_amd as hp` keeps planner.py:65-80 reading the same
 from .base import (  # noqa: F401,E402
-    ExpressionType, MultipleShootingSolver, OptimalControlProblem, OptimizationObject, OptimizationSolver, Output, OverridableParameter,
+    ExpressionType, MultipleShootingSolver, OptimalControlProblem, OptimizationObject, OptimizationProblem, OptimizationSolver, Output, OverridableParameter,
     OverridableVariable, Parameter, StorageType, TimeExpansion, TypedProblemError, Variable, default_composite_field,
     default_storage_field, time_varying_metadata,
 )

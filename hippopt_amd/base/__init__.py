@@ -8,3 +8,4 @@ from . import opti_callback  # noqa: F401,E402
 from .optimal_control import (  # noqa: F401,E402
     MultipleShootingSolver, OptimalControlProblem, OptimalControlProblemInstance, OptimizationSolver, TypedProblemError,
 )
+from .optimization_problem import OptimizationProblem, OptimizationProblemInstance  # noqa: F401,E402

@@ -63,6 +63,8 @@ class Affine:
 
     # ---- algebra ----------------------------------------------------------------------------------------------------------
     def _combine(self, other, sign):
+        if isinstance(other, Quadratic):                 # affine +- quadratic
+            return (other * sign)._combine(self, 1.0)
         other = Affine.lift(other, self)
         mine = self if len(self) == len(other) else Affine.lift(self, other) if len(self) == 1 else self
         if len(mine) == 1 and len(other) > 1:
@@ -92,9 +94,13 @@ class Affine:
         return self * -1.0
 
     def __mul__(self, factor):
+        if isinstance(factor, Quadratic):
+            return factor * self
         if isinstance(factor, Affine):
+            if any(factor.rows) and any(self.rows):
+                return Quadratic.product(self, factor)      # (row by row: what `*` is between two CasADi column vectors)
             if any(factor.rows):
-                raise ValueError("the product of two expressions is not affine")
+                return factor * self
             factor = factor.const if len(factor) > 1 else factor.const[0]
         factor = np.asarray(factor, float).reshape(-1)
         if factor.size not in (1, len(self)):
@@ -107,6 +113,13 @@ class Affine:
     def __truediv__(self, divisor):
         return self * (1.0 / np.asarray(divisor, float))
 
+    def __pow__(self, exponent):
+        if exponent == 1:
+            return self
+        if exponent == 2:
+            return Quadratic.product(self, self)
+        raise ValueError("only squares of affine expressions are supported")
+
     # ---- relations ---------------------------------------------------------------------------------------------------------
     def __eq__(self, other):   # noqa: PLW1641  (expressions are not hashable on purpose)
         return Relation(self - other, "eq")
@@ -115,6 +128,8 @@ class Affine:
         return Relation(self - other, "le")
 
     def __ge__(self, other):
+        if isinstance(other, Quadratic):
+            return Relation(other - self, "le")
         return Relation(Affine.lift(other, self) - self, "le")
 
     __hash__ = None
@@ -134,6 +149,121 @@ class Affine:
             for (leaf, i), c in row.items():
                 out[r] += c * np.asarray(values[leaf], float).reshape(-1)[i]
         return out
+
+
+class Quadratic:
+    """rows x 1 quadratic forms: row r = affine[r] + sum coeff[r][(k, l)] * entry k * entry l  (k <= l in a fixed order of the leaf entries).
+    What the products of the reference's toy problems are — `a[k] * cs.power(x[k], 2) + b[k] * x[k]`, `x * x`, `(x - 5) ** 2`
+    (test/test_optimization_problem.py:30-68, 194-254) — and nothing more general: a quadratic times an expression is refused."""
+
+    __array_priority__ = 1000
+
+    def __init__(self, quad, affine):
+        self.quad = quad            # list of {((leaf, i), (leaf, j)): coefficient}
+        self.affine = affine        # Affine of the same length
+
+    @staticmethod
+    def product(a, b):
+        a, b = Affine.lift(a), Affine.lift(b)
+        if len(a) == 1 and len(b) > 1:
+            a = Affine([dict(a.rows[0]) for _ in range(len(b))], np.full(len(b), a.const[0]))
+        if len(b) == 1 and len(a) > 1:
+            b = Affine([dict(b.rows[0]) for _ in range(len(a))], np.full(len(a), b.const[0]))
+        if len(a) != len(b):
+            raise ValueError(f"expressions of {len(a)} and {len(b)} rows do not multiply row by row")
+        quad, lin_rows, const = [], [], np.zeros(len(a))
+        for r in range(len(a)):
+            q, lin = {}, {}
+            for ka, va in a.rows[r].items():
+                for kb, vb in b.rows[r].items():
+                    key = (ka, kb) if ka <= kb else (kb, ka)
+                    q[key] = q.get(key, 0.0) + va * vb
+            for k, v in a.rows[r].items():
+                lin[k] = lin.get(k, 0.0) + v * b.const[r]
+            for k, v in b.rows[r].items():
+                lin[k] = lin.get(k, 0.0) + v * a.const[r]
+            const[r] = a.const[r] * b.const[r]
+            quad.append(q)
+            lin_rows.append(lin)
+        return Quadratic(quad, Affine(lin_rows, const))
+
+    def __len__(self):
+        return len(self.quad)
+
+    def __getitem__(self, item):
+        if isinstance(item, slice):
+            return Quadratic(self.quad[item], self.affine[item])
+        return Quadratic([self.quad[item]], self.affine[item])
+
+    def _combine(self, other, sign):
+        if isinstance(other, Quadratic):
+            if len(other) != len(self):
+                raise ValueError("quadratic expressions of different lengths do not combine")
+            quad = []
+            for a, b in zip(self.quad, other.quad):
+                q = dict(a)
+                for k, v in b.items():
+                    q[k] = q.get(k, 0.0) + sign * v
+                quad.append(q)
+            return Quadratic(quad, self.affine._combine(other.affine, sign))
+        return Quadratic([dict(q) for q in self.quad], self.affine._combine(other, sign))
+
+    def __add__(self, other):
+        return self._combine(other, 1.0)
+
+    __radd__ = __add__
+
+    def __sub__(self, other):
+        return self._combine(other, -1.0)
+
+    def __rsub__(self, other):
+        return (-self)._combine(other, 1.0)
+
+    def __neg__(self):
+        return self * -1.0
+
+    def __mul__(self, factor):
+        if isinstance(factor, Quadratic) or (isinstance(factor, Affine) and any(factor.rows)):
+            raise ValueError("the product of a quadratic expression and an expression is not quadratic")
+        if isinstance(factor, Affine):
+            factor = factor.const if len(factor) > 1 else factor.const[0]
+        f = np.broadcast_to(np.asarray(factor, float).reshape(-1), (len(self),))
+        return Quadratic([{k: v * f[r] for k, v in q.items()} for r, q in enumerate(self.quad)], self.affine * f)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, divisor):
+        return self * (1.0 / np.asarray(divisor, float))
+
+    def __eq__(self, other):   # noqa: PLW1641
+        return Relation(self - other, "eq")
+
+    def __le__(self, other):
+        return Relation(self - other, "le")
+
+    def __ge__(self, other):
+        return Relation(-(self - other), "le")
+
+    __hash__ = None
+
+    def leaves(self):
+        return {k[0] for q in self.quad for pair in q for k in pair} | self.affine.leaves()
+
+    def renamed(self, mapping):
+        ren = lambda k: (mapping.get(k[0], k[0]), k[1])  # noqa: E731
+        return Quadratic([{tuple(sorted((ren(ka), ren(kb)))): v for (ka, kb), v in q.items()} for q in self.quad], self.affine.renamed(mapping))
+
+    def value(self, values):
+        out = self.affine.value(values)
+        for r, q in enumerate(self.quad):
+            for (ka, kb), c in q.items():
+                out[r] += c * np.asarray(values[ka[0]], float).reshape(-1)[ka[1]] * np.asarray(values[kb[0]], float).reshape(-1)[kb[1]]
+        return out
+
+
+def power(expression, exponent):
+    """`cs.power(x, 2)` of the reference's toy costs"""
+    return Affine.lift(expression) ** exponent
 
 
 class Symbol(Affine):
@@ -199,9 +329,13 @@ def as_cost(expression, scaling=1.0, name=None):
         if isinstance(e, Relation):
             if e.kind != "eq":
                 raise ValueError("The conversion from an inequality to a cost is not yet supported")
+            if isinstance(e.difference, Quadratic):
+                raise ValueError("sumsqr of a quadratic expression is a quartic cost: not supported by the affine / quadratic expressions")
             yield label, SumOfSquares(e.difference, scaling)
         elif isinstance(e, SumOfSquares):
             yield label, e * scaling
+        elif isinstance(e, Quadratic):
+            yield label, e * scaling                  # a quadratic cost (its rows are summed)
         else:
             yield label, Affine.lift(e) * scaling     # a linear cost
 
@@ -211,7 +345,7 @@ def as_constraint(expression, expected_value=0.0, name=None):
         if isinstance(e, Relation):
             yield label, e
         else:
-            e = Affine.lift(e)
+            e = e if isinstance(e, Quadratic) else Affine.lift(e)
             if len(e) != 1:
                 raise ValueError("The input expression is not supported.")
             yield label, e == expected_value

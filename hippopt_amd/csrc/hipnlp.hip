@@ -1247,7 +1247,7 @@ struct hipnlp_handle {
     int32_t* d_ctpl_of_b = nullptr;
     int32_t* d_healed = nullptr;                    // wave slices of constants a VARY kernel had to put back (the caller wrote over a device buffer)
     int ctpl_len = 0;
-    struct DevFilled { const void* dev; unsigned long long gen; bool remote; };   // remote: not this device's own memory (a registered host range, a peer's buffer): never read back by the launch
+    struct DevFilled { const void* dev; unsigned long long gen; bool remote; unsigned launches; };   // remote: not this device's own memory (a registered host range, a peer's buffer): never read back by the launch; launches: into THIS buffer so far (which pair of sample positions the next one looks at)
     DevFilled dfilled[8] = {};                      // device jac buffers of hipnlp_eval_device that hold this handle's constants, and of which parameter set
     int dfilled_next = 0;
     long dev_const_fills = 0;
@@ -1830,7 +1830,10 @@ static int64_t gs_base(const hipnlp_handle* h, int k) {
 static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, hipStream_t s,
                   double* g_stage = nullptr, bool shard_local = false, bool always_timed = false, bool host_block = false,
                   double* const* peer_out = nullptr, int npeer = 0, int peer_rank = 0, bool vary_only = false, bool compact = false, bool no_check = false,
-                  double* cost_dst = nullptr) {
+                  double* cost_dst = nullptr, int cc_parity = -1) {
+    // cc_parity: which pair of the four sample positions of a block the constants self-check of this launch looks at (0 / 1), counted per
+    // DESTINATION by the caller; -1: by the handle's launch number (callers that alternate two jac buffers with the same parity would
+    // otherwise show every buffer one pair only)
     // cost_dst (shard launches of a multi-device handle): [batch][nk][NCT], device-visible HOST memory — the knot workgroups store their
     // cost partials there and nothing on the device sums them (no reducer workgroup, no reduction kernel: f_dev is not written); the one
     // caller sums the partials of all shards in the order of the device reduction (multi_reduce_costs)
@@ -1892,7 +1895,7 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
         h->have_result = false;
     }
     a.seq = ++h->seq;
-    a.cc.parity = a.seq & 1;
+    a.cc.parity = cc_parity >= 0 ? (cc_parity & 1) : (a.seq & 1);
     a.N = h->L.N; a.n = h->L.n; a.m = h->L.m; a.nnz = h->L.nnz; a.knot_begin = h->kb; a.nk = h->nk;
     bool prof = false, run_first = false, run_last = false;
     if (h->prof_cap > 0 && h->prof_run > 0) {        // runs of consecutive launches: one event before the first, one after the last
@@ -2492,6 +2495,16 @@ int hipnlp_eval_hess_at(hipnlp_handle* h, const double* x, int new_x, const doub
     // unknown, compared; nothing staged yet: copied whatever the flag says
     bool stage_x = new_x != 0 || !h->x_staged;
     if (new_x < 0 && h->x_staged) stage_x = x != h->h_x && std::memcmp(x, h->h_x, B * n * sizeof(double)) != 0;
+    if (new_x == 0 && h->x_staged && x != h->h_x) {
+        // "the x of the callbacks before it" is the CALLER's claim about THIS handle's staged copy: a binding that evaluates the callbacks
+        // on one handle and the Hessian on another, or that passes IPOPT's flag on after an evaluation elsewhere, would get the Hessian at
+        // a stale x without any error.  Sixty-four words spread over x are compared (nanoseconds): a differing sample stages x as new_x = 1
+        // would.  A sample, not a proof — the contract stays "same handle, same x" (include/hipnlp.h) — but the silent case is the one
+        // where x differs nearly everywhere (another iterate).
+        const size_t total = B * n, stride = std::max<size_t>(1, total / 64);
+        for (size_t i = 0; i < total && !stage_x; i += stride) stage_x = std::memcmp(&x[i], &h->h_x[i], sizeof(double)) != 0;
+        if (!stage_x) stage_x = std::memcmp(&x[total - 1], &h->h_x[total - 1], sizeof(double)) != 0;
+    }
     if (stage_x) {
         h->have_result = false;   // (the staging copy of x is shared with hipnlp_eval)
         h->x_staged = false;
@@ -2658,6 +2671,7 @@ int hipnlp_eval_device(hipnlp_handle* h, const double* x_dev, double* f_dev, dou
     // order, scattered 8-byte stores in CasADi's CCS order (they meet in the L2 before they leave for HBM) — and check the constants
     // they find (a buffer the caller wrote over is repaired by the kernel itself).
     bool vary = false, remote = false;
+    int parity = -1;
     if (jac_dev && h->skip_const && h->vary_ok && h->d_ctpl && h->L.nconst_total > 0) {
         int slot = -1;
         for (int i = 0; i < 8; ++i) if (h->dfilled[i].dev == jac_dev) slot = i;
@@ -2670,13 +2684,14 @@ int hipnlp_eval_device(hipnlp_handle* h, const double* x_dev, double* f_dev, dou
                                h->ke == L.N ? int(L.jperm_glob.size()) : 0);
             HIP_TRY(h, hipGetLastError());
             if (slot < 0) { slot = h->dfilled_next; h->dfilled_next = (h->dfilled_next + 1) % 8; }
-            h->dfilled[slot] = {jac_dev, h->param_gen, !is_local_device_memory(h, jac_dev)};
+            h->dfilled[slot] = {jac_dev, h->param_gen, !is_local_device_memory(h, jac_dev), 0u};
             h->dev_const_fills++;
         }
         vary = true;
         remote = h->dfilled[slot].remote;
+        parity = int(h->dfilled[slot].launches++ & 1u);   // (per destination: every buffer sees all four sample positions of a block in two launches INTO IT)
     }
-    return launch(h, x_dev, f_dev ? f_dev : h->d_f, grad_dev, g_dev, jac_dev, s, nullptr, false, false, false, nullptr, 0, 0, vary, false, remote);
+    return launch(h, x_dev, f_dev ? f_dev : h->d_f, grad_dev, g_dev, jac_dev, s, nullptr, false, false, false, nullptr, 0, 0, vary, false, remote, nullptr, parity);
 }
 
 int hipnlp_eval_device_shard(hipnlp_handle* h, const double* x_dev, double* f_dev, double* grad_shard, double* g_stage, double* jac_shard, void* stream) {
@@ -3197,7 +3212,7 @@ int hipnlp_forget_jac_destination(hipnlp_handle* h, const void* p) {
     if (!h) return HIPNLP_E_INVALID;
     int n = 0;
     for (int i = 0; i < 8; ++i) {
-        if (h->dfilled[i].dev && (!p || h->dfilled[i].dev == p)) { h->dfilled[i] = {nullptr, 0, false}; ++n; }
+        if (h->dfilled[i].dev && (!p || h->dfilled[i].dev == p)) { h->dfilled[i] = {nullptr, 0, false, 0u}; ++n; }
         if (h->cfilled[i].host && (!p || h->cfilled[i].host == p)) { h->cfilled[i] = {nullptr, 0, 0}; ++n; }
     }
     return n;

@@ -11,7 +11,7 @@ import dataclasses
 import numpy as np
 
 from ... import robot_planning as hp_rp
-from ...base import Output, Parameter, Variable
+from ...base import OptimizationProblem, Output, Parameter, Variable
 from ...base.schema import argument, child, declare, leaf
 from ...hipnlp_solver import HipNlpSolver
 from ...pose_settings import PoseSettings
@@ -120,7 +120,8 @@ class Planner:
         self.variables = Variables(settings=self.settings, kin_dyn_object=model)
         self.optimization_solver = HipNlpSolver(self.settings, model, device=device, inner_solver=inner_solver,
                                                 options_solver=self.settings.solver_options, problem="pose", error_on_fail=error_on_fail)
-        self.optimization_solver.generate_optimization_objects(self.variables)
+        # the reference's wiring (planner.py:334-343), names kept: only the optimization solver differs
+        self.op = OptimizationProblem.create(input_structure=self.variables, optimization_solver=self.optimization_solver)
 
     # ---- mass regularisation (planner.py:788-850): the contact forces of the state and of the reference state, divided by the mass ----
     def _forces_times(self, var: Variables, factor: float) -> Variables:
@@ -153,10 +154,9 @@ class Planner:
         self.set_initial_guess(stored)
 
     def solve(self) -> Output:
-        plugin = self.optimization_solver
-        plugin.solve()
-        return Output(values=self._undo_mass_regularization(plugin.get_values()), cost_value=plugin.get_cost_value(),
-                      cost_values=plugin.get_cost_values(), constraint_multipliers=plugin.get_constraint_multipliers())
+        output = self.op.problem.solve()          # (planner.py:866-869)
+        return Output(values=self._undo_mass_regularization(output.values), cost_value=output.cost_value,
+                      cost_values=output.cost_values, constraint_multipliers=output.constraint_multipliers)
 
     def get_variables_structure(self) -> Variables:
         return copy.deepcopy(self.variables)

@@ -295,7 +295,7 @@ int hipnlp_set_prefetch(hipnlp_handle* h, unsigned mask);
  * receiving every entry) — and no longer stage the constants in LDS at all.  Same contract — the caller does not write into
  * the buffer between calls — and the launch itself samples it: the one workgroup per trajectory that sums the cost compares constant
  * entries of every knot block with the handle's templates — four positions per block (its first, its last, two in between), two of them
- * per launch, alternating — and puts the constants of all the trajectory's blocks back when one differs (hipnlp_host_stats out[7] counts
+ * per launch, alternating with the launches INTO THAT BUFFER — and puts the constants of all the trajectory's blocks back when one differs (hipnlp_host_stats out[7] counts
  * such repairs).  A sample, not a guarantee: constants
  * overwritten elsewhere in a block are returned as they are.  The record "this buffer holds the constants" is keyed by the buffer's
  * ADDRESS: a caller that frees a jac buffer and later hands over other memory at the same address (a caching allocator does that) must
@@ -381,6 +381,8 @@ int hipnlp_eval_hess(hipnlp_handle* h, const double* x, const double* obj_factor
 /* The same with IPOPT's new_x flag (Eval_H_CB: FALSE when x is the x of the evaluation callbacks before it — the case at every accepted
  * iterate): new_x = 0 = the x of the previous host-buffer call on this handle (hipnlp_eval*, hipnlp_eval_hess*) — its staged copy is
  * used, no host copy of x in front of the launch; new_x < 0 = unknown (compared); anything else, or nothing staged yet: x is copied.
+ * new_x = 0 is a statement about THIS handle: the callbacks at x ran on it.  (Sixty-four words of x are compared with the staged copy
+ * all the same and a differing sample stages x: a binding that runs the callbacks on another handle gets the right Hessian, not a stale one.)
  * hipnlp_eval_hess is new_x = 1; hipnlp_ipopt_eval_h passes IPOPT's flag. */
 int hipnlp_eval_hess_at(hipnlp_handle* h, const double* x, int new_x, const double* obj_factor, const double* lambda, double* values);
 /* hipnlp_eval_hess* into host memory: the run at the start of every knot block (the point columns: a quarter of the values on the planar
