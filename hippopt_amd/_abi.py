@@ -3,7 +3,7 @@ import ctypes as C
 
 NJ, NL, NC, NXK, NPK, NXG, NPG = 23, 24, 8, 189, 79, 6, 326
 NCOST_TERMS = 12
-ABI_VERSION = 2
+ABI_VERSION = 3
 FLAG_DETECT_SIMPLE_BOUNDS = 1
 FLAG_JAC_VARYING_FIRST = 2
 
@@ -31,7 +31,7 @@ class RobotModelC(C.Structure):
 
 class TerrainStepC(C.Structure):
     _fields_ = [("length", C.c_double), ("width", C.c_double), ("height", C.c_double), ("position", C.c_double * 3),
-                ("orientation", C.c_double), ("edge_sharpness", C.c_int32), ("side_sharpness", C.c_int32)]
+                ("orientation", C.c_double), ("edge_sharpness", C.c_int32), ("side_sharpness", C.c_int32), ("top_normal", C.c_double * 3)]
 
 
 class SettingsC(C.Structure):

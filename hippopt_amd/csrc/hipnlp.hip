@@ -1439,6 +1439,7 @@ static int create_handle(const hipnlp_desc* desc, hipnlp_handle** out, bool fron
     }
     std::string e;
     if (!Layout::make_kin_tables(desc->model, h->kt, e)) return fail(HIPNLP_E_INVALID, e);
+    Layout::fill_terrain_tops(h->kt, st.terrain, st.n_terrain_steps, st.terrain_steps);
     if (!h->L.build(st, h->kt, (desc->flags & HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS) != 0, (desc->flags & HIPNLP_FLAG_JAC_VARYING_FIRST) != 0))
         return fail(HIPNLP_E_INVALID, h->L.error);
     h->skip_const = h->L.vary_first;   // (a CCS handle stores every entry unless hipnlp_set_constant_jacobian(h, 1) asks for the scheme: the contract on the destination is the caller's to accept)

@@ -365,6 +365,7 @@ int hipnlp_pose_create(const hipnlp_pose_desc* desc, hipnlp_pose_handle** out) {
     h->batch = desc->batch;
     std::string e;
     if (!Layout::make_kin_tables(desc->model, h->kt, e)) return fail(HIPNLP_E_INVALID, e);
+    Layout::fill_terrain_tops(h->kt, st.terrain, st.n_terrain_steps, st.terrain_steps);
     if (!h->L.build(st, h->kt)) return fail(HIPNLP_E_INVALID, h->L.error);
     if (h->L.nnz > POSE_MAX_NNZ) return fail(HIPNLP_E_INVALID, "internal: pose pattern larger than POSE_MAX_NNZ");
 

@@ -367,12 +367,13 @@ HD double ipow_d(double x, int n) {
     return r;
 }
 
-// contribution of ONE bump to the jet (out is accumulated into)
-HD void terrain_bump_jet(const TerrainStepK& t, double px, double py, int order, double* out) {
+// contribution of ONE bump to the jet (out is accumulated into).  slope_x / slope_y: TerrainTops of this step, read only when the step says
+// its top is sloped (step_sloped): Z_s = exp(-g^r) pi,  pi = height + slope_x dx + slope_y dy  (smooth_terrain.py:211, 238-264).
+HD void terrain_bump_jet(const TerrainStepK& t, double px, double py, int order, double* out, const double* slope_x = nullptr, const double* slope_y = nullptr) {
     out[0] += t.oz;
     const double dx = px - t.ox, dy = py - t.oy;
     const double a = t.ax * dx + t.ay * dy, b = t.bx * dx + t.by * dy;
-    const int m = t.m, r = t.r;
+    const int m = step_m(t), r = t.r;
     const double am3 = ipow_d(a, m - 3), bm3 = ipow_d(b, m - 3);
     const double A0 = am3 * a * a * a, A1 = m * am3 * a * a, A2 = double(m * (m - 1)) * am3 * a, A3 = double(m * (m - 1) * (m - 2)) * am3;
     const double B0 = bm3 * b * b * b, B1 = m * bm3 * b * b, B2 = double(m * (m - 1)) * bm3 * b, B3 = double(m * (m - 1) * (m - 2)) * bm3;
@@ -381,6 +382,32 @@ HD void terrain_bump_jet(const TerrainStepK& t, double px, double py, int order,
     const double w = gr3 * g * g * g;
     if (!(w < 700.0)) return;  // exp(-w) underflows (also catches inf / nan of far-away points): the bump and all its derivatives vanish
     const double w1 = r * gr3 * g * g, w2 = double(r * (r - 1)) * gr3 * g, w3 = double(r * (r - 1) * (r - 2)) * gr3;
+    if (step_sloped(t) && slope_x) {
+        // F = exp(-g^r) and its partials (the flat-top formulas below with height 1), then the product with the LINEAR top pi
+        const double e0 = exp(-w), e1 = -e0 * w1, e2 = e0 * (w1 * w1 - w2), e3 = e0 * (-w1 * w1 * w1 + 3.0 * w1 * w2 - w3);
+        const double pix = *slope_x, piy = *slope_y, pi0 = t.height + pix * dx + piy * dy;
+        const double gx = A1 * t.ax + B1 * t.bx, gy = A1 * t.ay + B1 * t.by;
+        const double Fx = e1 * gx, Fy = e1 * gy;
+        out[0] += e0 * pi0;
+        out[1] += Fx * pi0 + e0 * pix;
+        out[2] += Fy * pi0 + e0 * piy;
+        if (order < 2) return;
+        const double gxx = A2 * t.ax * t.ax + B2 * t.bx * t.bx, gxy = A2 * t.ax * t.ay + B2 * t.bx * t.by, gyy = A2 * t.ay * t.ay + B2 * t.by * t.by;
+        const double Fxx = e2 * gx * gx + e1 * gxx, Fxy = e2 * gx * gy + e1 * gxy, Fyy = e2 * gy * gy + e1 * gyy;
+        out[3] += Fxx * pi0 + 2.0 * Fx * pix;
+        out[4] += Fxy * pi0 + Fx * piy + Fy * pix;
+        out[5] += Fyy * pi0 + 2.0 * Fy * piy;
+        if (order < 3) return;
+        const double gxxx = A3 * t.ax * t.ax * t.ax + B3 * t.bx * t.bx * t.bx, gxxy = A3 * t.ax * t.ax * t.ay + B3 * t.bx * t.bx * t.by;
+        const double gxyy = A3 * t.ax * t.ay * t.ay + B3 * t.bx * t.by * t.by, gyyy = A3 * t.ay * t.ay * t.ay + B3 * t.by * t.by * t.by;
+        const double Fxxx = e3 * gx * gx * gx + e2 * (3.0 * gxx * gx) + e1 * gxxx, Fxxy = e3 * gx * gx * gy + e2 * (gxx * gy + 2.0 * gxy * gx) + e1 * gxxy;
+        const double Fxyy = e3 * gx * gy * gy + e2 * (gyy * gx + 2.0 * gxy * gy) + e1 * gxyy, Fyyy = e3 * gy * gy * gy + e2 * (3.0 * gyy * gy) + e1 * gyyy;
+        out[6] += Fxxx * pi0 + 3.0 * Fxx * pix;
+        out[7] += Fxxy * pi0 + 2.0 * Fxy * pix + Fxx * piy;
+        out[8] += Fxyy * pi0 + 2.0 * Fxy * piy + Fyy * pix;
+        out[9] += Fyyy * pi0 + 3.0 * Fyy * piy;
+        return;
+    }
     const double psi = t.height * exp(-w);
     const double p1 = -psi * w1, p2 = psi * (w1 * w1 - w2), p3 = psi * (-w1 * w1 * w1 + 3.0 * w1 * w2 - w3);
     const double gx = A1 * t.ax + B1 * t.bx, gy = A1 * t.ay + B1 * t.by;
@@ -401,9 +428,10 @@ HD void terrain_bump_jet(const TerrainStepK& t, double px, double py, int order,
     out[9] += p3 * gy * gy * gy + p2 * (3.0 * gyy * gy) + p1 * gyyy;
 }
 // Z and its partials up to third order: out = [Z, Zx, Zy, Zxx, Zxy, Zyy, Zxxx, Zxxy, Zxyy, Zyyy]
-HD void terrain_Z_jet(const KSettings& st, double px, double py, int order, double* out) {
+HD void terrain_Z_jet(const KSettings& st, double px, double py, int order, double* out, const TerrainTops* tops = nullptr) {
     for (int i = 0; i < 10; ++i) out[i] = 0.0;
-    for (int sidx = 0; sidx < st.n_steps; ++sidx) terrain_bump_jet(st.steps[sidx], px, py, order, out);
+    for (int sidx = 0; sidx < st.n_steps; ++sidx)
+        terrain_bump_jet(st.steps[sidx], px, py, order, out, tops ? &tops->px[sidx] : nullptr, tops ? &tops->py[sidx] : nullptr);
 }
 
 // ===================================================================================================
@@ -574,7 +602,7 @@ template <class Em> HD void t_terrain_bump(Ctx<Em>& cx, int t) {
     const double* p = c < NC ? s.x + PT_ * c + P_ : s.x + COM_;
     double Z[10];
     for (int i = 0; i < 10; ++i) Z[i] = 0.0;
-    if (sidx < cx.st.n_steps) terrain_bump_jet(cx.st.steps[sidx], p[0], p[1], 3, Z);
+    if (sidx < cx.st.n_steps) terrain_bump_jet(cx.st.steps[sidx], p[0], p[1], 3, Z, &cx.gkt->tops.px[sidx], &cx.gkt->tops.py[sidx]);
     if (c < NC) {
         double* out = terrain_bump_part(s, c, sidx);
         for (int i = 0; i < 10; ++i) out[i] = Z[i];

@@ -335,7 +335,7 @@ template <class Em> HD void t_kh_bump(KHCtx<Em>& h, int t) {
     const double* p = c < NC ? s.x + PT_ * c + P_ : s.x + COM_;
     J2<4> bump;
     if (sidx < cx.st.n_steps) {
-        terrain_bump_j<4>(cx.st.steps[sidx], p[0], p[1], bump);   // (false: the bump has vanished, its jet stays zero)
+        terrain_bump_j<4>(cx.st.steps[sidx], p[0], p[1], bump, &cx.gkt->tops.px[sidx], &cx.gkt->tops.py[sidx]);   // (false: the bump has vanished, its jet stays zero)
         bump.c[0] += cx.st.steps[sidx].oz;
     }
     double* out = kh_bump_part(h.hx, c, sidx);

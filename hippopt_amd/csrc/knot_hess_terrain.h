@@ -114,31 +114,46 @@ template <int K, int L> HD J2<L> j2_trunc(const J2<K>& a) { J2<L> r; for (int i 
 // (s_n = C(r, n) g_0^(r-n) are those of t^r;  E = exp(-s):  n e_n = -sum_k k s_k e_(n-k)) instead of a composition for the power and
 // another for the exponential.  false: exp(-w) underflows (same guard as terrain_bump_jet; also catches inf / nan of far-away
 // points) — the bump and all its derivatives vanish, `out` is left alone.
-template <int K> HD bool terrain_bump_j(const TerrainStepK& t, double px, double py, J2<K>& out) {
+// slope_x / slope_y (TerrainTops; read only for a step with a sloped top): the jet of exp(-g^r) times the LINEAR top
+// pi = height + slope_x dx + slope_y dy — in scaled coefficients a convolution with a three-term polynomial.
+template <int K> HD bool terrain_bump_j(const TerrainStepK& t, double px, double py, J2<K>& out, const double* slope_x = nullptr, const double* slope_y = nullptr) {
     const double dx = px - t.ox, dy = py - t.oy;
-    const J2<K> g = j2_linpow<K>(t.ax * dx + t.ay * dy, t.ax, t.ay, t.m) + j2_linpow<K>(t.bx * dx + t.by * dy, t.bx, t.by, t.m);
+    const bool sloped = step_sloped(t) && slope_x;
+    const J2<K> g = j2_linpow<K>(t.ax * dx + t.ay * dy, t.ax, t.ay, step_m(t)) + j2_linpow<K>(t.bx * dx + t.by * dy, t.bx, t.by, step_m(t));
     double sn[K + 1], en[K + 1];
     sn[K] = ipow_d(g.c[0], t.r - K);                                 // g_0^(r-n) ...
     for (int n = K - 1; n >= 0; --n) sn[n] = sn[n + 1] * g.c[0];
     double ff = 1.0;                                                 // ... times C(r, n) = r (r-1) ... (r-n+1) / n!
     for (int n = 0; n <= K; ++n) { sn[n] *= ff * j2_inv_fact(n); ff *= double(t.r - n); }
     if (!(sn[0] < 700.0)) return false;
-    en[0] = t.height * exp(-sn[0]);
+    en[0] = (sloped ? 1.0 : t.height) * exp(-sn[0]);
     for (int n = 1; n <= K; ++n) {
         double acc = 0.0;
         for (int k = 1; k <= n; ++k) acc += double(k) * sn[k] * en[n - k];
         en[n] = acc * (-1.0 / double(n));
     }
     out = j2_compose(g, en);
+    if (sloped) {
+        const double pix = *slope_x, piy = *slope_y, pi0 = t.height + pix * dx + piy * dy;
+        J2<K> f = out;
+        for (int d = 0; d <= K; ++d)
+            for (int j = 0; j <= d; ++j) {
+                const int i = d - j;
+                double v = f.c[J2<K>::idx(i, j)] * pi0;
+                if (i > 0) v += f.c[J2<K>::idx(i - 1, j)] * pix;
+                if (j > 0) v += f.c[J2<K>::idx(i, j - 1)] * piy;
+                out.c[J2<K>::idx(i, j)] = v;
+            }
+    }
     return true;
 }
 // Z(p_x, p_y) of the terrain as a jet of order K
-template <int K> HD J2<K> terrain_Z_j(const KSettings& st, double px, double py) {
+template <int K> HD J2<K> terrain_Z_j(const KSettings& st, double px, double py, const TerrainTops* tops = nullptr) {
     J2<K> Z;
     for (int sidx = 0; sidx < st.n_steps; ++sidx) {
         Z.c[0] += st.steps[sidx].oz;
         J2<K> bump;
-        if (terrain_bump_j<K>(st.steps[sidx], px, py, bump)) Z = Z + bump;
+        if (terrain_bump_j<K>(st.steps[sidx], px, py, bump, tops ? &tops->px[sidx] : nullptr, tops ? &tops->py[sidx] : nullptr)) Z = Z + bump;
     }
     return Z;
 }

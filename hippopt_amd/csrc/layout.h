@@ -407,6 +407,25 @@ struct Layout {
             o.ax = 2.0 / t.length * c; o.ay = 2.0 / t.length * sn;       // a = (2/L) q_x,  q = Rz^T (p - o)
             o.bx = -2.0 / t.width * sn; o.by = 2.0 / t.width * c;        // b = (2/W) q_y
             o.m = 2 * t.edge_sharpness; o.r = 2 * t.side_sharpness;
+            if (step_has_sloped_top(t)) o.m |= STEP_SLOPED;
+        }
+    }
+    static bool step_has_sloped_top(const hipnlp_terrain_step& t) { return t.top_normal[0] != 0.0 || t.top_normal[1] != 0.0; }
+    // the sloped tops of the steps, beside the tables the kernels read once per knot (nlp_defs.h TerrainTops): the top plane of step s is
+    // pi(q) = height - (n_x q_x + n_y q_y) / n_z in the step's frame q = Rz(orientation)^T (p - position), n the normalised top_normal
+    // (smooth_terrain.py:238-264); in world coordinates pi = height + px (p_x - o_x) + py (p_y - o_y)
+    static void fill_terrain_tops(KinTables& kt, int terrain, int n_steps, const hipnlp_terrain_step* steps) {
+        for (int i = 0; i < HIPNLP_MAX_TERRAIN_STEPS; ++i) kt.tops.px[i] = kt.tops.py[i] = 0.0;
+        if (terrain != HIPNLP_TERRAIN_SMOOTH_STEPS) return;
+        for (int i = 0; i < n_steps && i < HIPNLP_MAX_TERRAIN_STEPS; ++i) {
+            const hipnlp_terrain_step& t = steps[i];
+            if (!step_has_sloped_top(t)) continue;
+            const double norm = std::sqrt(t.top_normal[0] * t.top_normal[0] + t.top_normal[1] * t.top_normal[1] + t.top_normal[2] * t.top_normal[2]);
+            const double nx = t.top_normal[0] / norm, ny = t.top_normal[1] / norm, nz = t.top_normal[2] / norm;
+            const double sx = -nx / nz, sy = -ny / nz;                       // d pi / d q_x, d pi / d q_y
+            const double c = std::cos(t.orientation), sn = std::sin(t.orientation);
+            kt.tops.px[i] = sx * c - sy * sn;                                // q_x = c dx + sn dy,  q_y = -sn dx + c dy
+            kt.tops.py[i] = sx * sn + sy * c;
         }
     }
     // validation shared by hipnlp_create / hipnlp_pose_create; returns an error message or nullptr
@@ -417,6 +436,13 @@ struct Layout {
             for (int i = 0; i < n_steps; ++i)
                 if (!(steps[i].length > 0) || !(steps[i].width > 0) || steps[i].edge_sharpness < 2 || steps[i].side_sharpness < 2)
                     return "terrain step: length, width must be positive and the sharpness exponents >= 2";
+            for (int i = 0; i < n_steps; ++i) {   // a zero vector = the flat top (top_normal_direction=None); else smooth_terrain.py:247-256
+                const double* n = steps[i].top_normal;
+                const double norm = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                if (norm == 0.0) continue;
+                if (!(norm >= 1e-6)) return "terrain step: the top normal direction must be non-zero";
+                if (!(std::fabs(n[2] / norm) >= 1e-6)) return "terrain step: the top normal direction must not be parallel to the xy-plane";
+            }
         }
         return nullptr;
     }

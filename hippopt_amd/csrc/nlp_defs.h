@@ -86,10 +86,19 @@ struct EndTables {   // horizon-end rows (first / last knot only)
     int16_t fin_var[105], fin_slot[105], fin_desc[105];  // variable / slot among the 81 variable rows / descriptor index (3c+i) or -1
     int16_t per_var[84];
 };
+// Sloped tops of the terrain steps (SmoothTerrain.step(top_normal_direction=...), utilities/smooth_terrain.py:238-264): the top surface
+// pi(q_xy) = height - (n_x q_x + n_y q_y) / n_z of step s, in world coordinates  pi = height + px[s] (p_x - o_x) + py[s] (p_y - o_y).
+// Read by the lanes of a bump task only for steps whose TerrainStepK says so (step_sloped): kept OUT of KSettings, whose LDS copy in the
+// compact layouts has no byte to spare (the five-per-CU smooth-terrain kernel: 31 984 of 32 000 B), behind the tables that the compact
+// layouts read from global memory once per knot.
+struct TerrainTops {
+    double px[HIPNLP_MAX_TERRAIN_STEPS], py[HIPNLP_MAX_TERRAIN_STEPS];
+};
 struct KinTables : KinLite {
     EndTables en;
     JointFix jf;
     LinkInertials li;
+    TerrainTops tops;
 };
 constexpr int JFIX_DOUBLES = NJ * 15, LINR_DOUBLES = NL * 13;
 static_assert(sizeof(KinLite) % 8 == 0, "KinLite is copied in 8-byte words");
@@ -98,8 +107,11 @@ static_assert(sizeof(JointFix) == sizeof(double) * JFIX_DOUBLES && sizeof(LinkIn
 // ---- graph constants (hipnlp_settings, flattened for the kernel) ------------------------------------
 struct TerrainStepK {   // one SmoothTerrain.step bump, pre-digested: a = ax dx + ay dy, b = bx dx + by dy (dx = p_x - ox, ...)
     double ox, oy, oz, height, ax, ay, bx, by;
-    int32_t m, r;       // exponents 2*edge_sharpness and 2*side_sharpness
+    int32_t m, r;       // exponents 2*edge_sharpness (bit 16: the top of the step is sloped, TerrainTops) and 2*side_sharpness
 };
+constexpr int32_t STEP_SLOPED = 1 << 16;
+HD constexpr int step_m(const TerrainStepK& t) { return t.m & (STEP_SLOPED - 1); }
+HD constexpr bool step_sloped(const TerrainStepK& t) { return (t.m & STEP_SLOPED) != 0; }
 struct alignas(16) KSettings {
     int32_t horizon, final_type, periodicity_type, joint_reg_as_coded, hdyn_x0;
     int32_t terrain, n_steps;

@@ -38,7 +38,7 @@ template <class Em> HD void t_pose_points(Ctx<Em>& cx, int c) {
         point_hnf_planar(cx, c);
     } else {
         double Z[10];
-        terrain_Z_jet(cx.st, p[0], p[1], 2, Z);
+        terrain_Z_jet(cx.st, p[0], p[1], 2, Z, &cx.gkt->tops);
         TerrainFrame tf;
         terrain_frame(Z, p[2], tf);
         const D2 nf = tf.n[0] * f[0] + tf.n[1] * f[1] + tf.n[2] * f[2];

@@ -128,7 +128,7 @@ template <class Em> HD void t_hess_point(HCtx<Em>& h, int c) {
     const double* p = s.x + cb + P_;
     const double* f = s.x + cb + F_;
     double Z[10];
-    terrain_Z_jet(cx.st, p[0], p[1], 3, Z);
+    terrain_Z_jet(cx.st, p[0], p[1], 3, Z, &cx.gkt->tops);
     TerrainFrame2 tf;
     terrain_frame2(Z, p[2], tf);
     const T2 nf = tf.n[0] * f[0] + tf.n[1] * f[1] + tf.n[2] * f[2];

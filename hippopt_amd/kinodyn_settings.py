@@ -120,6 +120,9 @@ def _fill_terrain_steps(s, terrain_steps):
         t.orientation = float(st.get("orientation", 0.0))
         t.edge_sharpness = int(st.get("edge_sharpness", 5))
         t.side_sharpness = int(st.get("side_sharpness", 10))
+        normal = st.get("top_normal_direction", st.get("top_normal"))        # SmoothTerrain.step(top_normal_direction=...): None = the flat top
+        for j in range(3):
+            t.top_normal[j] = 0.0 if normal is None else float(normal[j])
 
 
 def periodic_step_settings(horizon=30, model=None) -> KinodynSettings:
@@ -156,6 +159,20 @@ def stairs_terrain_steps(length=0.45, width=0.8, height=0.1):
         {"length": 2 * length, "width": width, "height": height, "position": (1.5 * length, 0.0, 0.0)},
         {"length": 0.9 * length, "width": width, "height": height, "position": (2 * length, 0.0, 0.0)},
     ]
+
+
+def ramp_terrain_steps(length=0.45, width=0.8, height=0.1, normal_direction=(-0.2, 0.0, 1.0)):
+    """The ramp of main_walking_on_ramp.py:18-30: ONE step of twice the length whose top is the plane with the given normal; the script
+    calls get_ramp(length=step_length / 2 = 0.45, width=0.8, height=step_height = 0.1, normal_direction=[-0.2, 0, 1]) (:397-409)."""
+    return [{"length": 2 * length, "width": width, "height": height, "position": (1.5 * length, 0.0, 0.0),
+             "top_normal_direction": tuple(float(v) for v in normal_direction)}]
+
+
+def ramp_settings(horizon=50, model=None) -> KinodynSettings:
+    """main_walking_on_ramp.py: the stairs script's constants on the ramp terrain (smooth step with a sloped top)."""
+    s = stairs_settings(horizon, model)
+    s.terrain_steps = ramp_terrain_steps()
+    return s
 
 
 def stairs_settings(horizon=50, model=None) -> KinodynSettings:

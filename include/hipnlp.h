@@ -46,8 +46,9 @@ extern "C" {
 /* ABI version of this header.  The caller stores it in hipnlp_desc.abi_version / hipnlp_pose_desc.abi_version; hipnlp_create and
  * hipnlp_pose_create refuse a descriptor built against another version (a C caller compiled against an older header would pass a
  * shorter struct).  History: 1 = rounds 1-2 (no version field); 2 = abi_version + flags in the descriptors, m_full / n_lifted in
- * hipnlp_dims, detect_simple_bounds layout, auto-registration, IPOPT callback quartet (hipnlp_ipopt.h).                           */
-#define HIPNLP_ABI_VERSION 2
+ * hipnlp_dims, detect_simple_bounds layout, auto-registration, IPOPT callback quartet (hipnlp_ipopt.h); 3 = round 6:
+ * hipnlp_terrain_step.top_normal (sloped step tops: the descriptors grew by 24 bytes per terrain step).                            */
+#define HIPNLP_ABI_VERSION 3
 
 #define HIPNLP_NJ 23        /* actuated joints (ergoCub: torso 3, arms 4+4, legs 6+6) */
 #define HIPNLP_NL 24        /* links = root + one per joint                            */
@@ -76,6 +77,7 @@ extern "C" {
  *   SMOOTH_STEPS  TerrainSum of SmoothTerrain.step bumps (utilities/smooth_terrain.py:201-227,266-336, terrain_sum.py:19-38;
  *                 the stairs of main_walking_on_stairs.py:18-28):  h = p_z - sum_s [ H_s exp(-g_s^(2 side_s)) + o_s,z ],
  *                 g_s = (2 q_x / L_s)^(2 edge_s) + (2 q_y / W_s)^(2 edge_s),  q = Rz(orientation_s)^T (p - o_s);
+ *                 a step with a sloped top (hipnlp_terrain_step.top_normal):  H_s  ->  pi_s(q) = H_s - (n_x q_x + n_y q_y) / n_z;
  *                 normal / orientation from the TerrainDescriptor defaults (utilities/terrain_descriptor.py:45-80)      */
 #define HIPNLP_TERRAIN_PLANAR 0
 #define HIPNLP_TERRAIN_SMOOTH_STEPS 1
@@ -87,6 +89,12 @@ typedef struct hipnlp_terrain_step {
     double orientation;     /* yaw of the bump (rad) */
     int32_t edge_sharpness; /* default 5  (exponent 2*edge on the footprint) */
     int32_t side_sharpness; /* default 10 (exponent 2*side on g)            */
+    /* SmoothTerrain.step(top_normal_direction=...) (utilities/smooth_terrain.py:238-264; the ramp of main_walking_on_ramp.py:18-30,
+     * 403-409): the top surface of the step is the plane through (0, 0, height) of the step's frame with this normal,
+     *     pi(q_x, q_y) = height - (n_x q_x + n_y q_y) / n_z,   n = top_normal / |top_normal|,
+     * and the bump is exp(-g^(2 side)) pi(q).  The zero vector (a zeroed struct) = the reference's None: the flat top, pi = height.
+     * Refused as the reference refuses them: |top_normal| < 1e-6 (but not zero), |n_z| < 1e-6. */
+    double top_normal[3];
 } hipnlp_terrain_step;
 
 /* Frame slots of hipnlp_robot_model.frame_* */

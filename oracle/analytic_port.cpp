@@ -48,7 +48,8 @@ port_handle* port_create(const hipnlp_desc* desc, char* err, int errlen) {
     port_handle* h = new port_handle();
     h->d = *desc;
     std::string e;
-    if (!Layout::make_kin_tables(desc->model, h->kt, e) || !h->L.build(desc->settings, h->kt)) {
+    if (Layout::make_kin_tables(desc->model, h->kt, e)) Layout::fill_terrain_tops(h->kt, desc->settings.terrain, desc->settings.n_terrain_steps, desc->settings.terrain_steps);
+    if (!e.empty() || !h->L.build(desc->settings, h->kt)) {
         if (e.empty()) e = h->L.error;
         std::strncpy(err, e.c_str(), size_t(errlen - 1));
         delete h;

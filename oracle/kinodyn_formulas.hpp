@@ -135,7 +135,15 @@ template <class S> S terrain_height(const TerrainSpec& ts, const V3<S>& p) {
         S dx = p[0] - S(st.position[0]), dy = p[1] - S(st.position[1]);
         S qx = S(c) * dx + S(sn) * dy, qy = S(-sn) * dx + S(c) * dy;           // inv(T) (p - offset), T = Rz(orientation)
         S g = ipow(S(2.0 / st.length) * qx, 2 * st.edge_sharpness) + ipow(S(2.0 / st.width) * qy, 2 * st.edge_sharpness);
-        S z_terrain = exp(-ipow(g, 2 * st.side_sharpness)) * S(st.height);      // smooth_terrain.py:211 (top surface = height)
+        // top surface pi(q_xy): the height, or — SmoothTerrain.step(top_normal_direction=n) — the plane through (0, 0, height) with the
+        // normalised normal n:  height - n_x / n_z q_x - n_y / n_z q_y   (smooth_terrain.py:238-264; a zero vector = None = flat)
+        S top = S(st.height);
+        const double nn = std::sqrt(st.top_normal[0] * st.top_normal[0] + st.top_normal[1] * st.top_normal[1] + st.top_normal[2] * st.top_normal[2]);
+        if (nn > 0.0) {
+            const double nx = st.top_normal[0] / nn, ny = st.top_normal[1] / nn, nz = st.top_normal[2] / nn;
+            top = S(-nx / nz) * qx + S(-ny / nz) * qy + S(st.height);
+        }
+        S z_terrain = exp(-ipow(g, 2 * st.side_sharpness)) * top;               // smooth_terrain.py:211
         h = h - (z_terrain + S(st.position[2]));
     }
     return h;

@@ -206,7 +206,8 @@ hostemu_handle* hostemu_create(const hipnlp_desc* desc, char* err, int errlen) {
     hostemu_handle* h = new hostemu_handle();
     h->d = *desc;
     std::string e;
-    if (!Layout::make_kin_tables(desc->model, h->kt, e) || !h->L.build(desc->settings, h->kt, (desc->flags & HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS) != 0, (desc->flags & HIPNLP_FLAG_JAC_VARYING_FIRST) != 0)) {
+    if (Layout::make_kin_tables(desc->model, h->kt, e)) Layout::fill_terrain_tops(h->kt, desc->settings.terrain, desc->settings.n_terrain_steps, desc->settings.terrain_steps);
+    if (!e.empty() || !h->L.build(desc->settings, h->kt, (desc->flags & HIPNLP_FLAG_DETECT_SIMPLE_BOUNDS) != 0, (desc->flags & HIPNLP_FLAG_JAC_VARYING_FIRST) != 0)) {
         if (e.empty()) e = h->L.error;
         std::strncpy(err, e.c_str(), size_t(errlen - 1));
         delete h;
@@ -461,7 +462,8 @@ hostemu_pose_handle* hostemu_pose_create(const hipnlp_pose_desc* desc, char* err
     hostemu_pose_handle* h = new hostemu_pose_handle();
     h->d = *desc;
     std::string e;
-    if (!Layout::make_kin_tables(desc->model, h->kt, e) || !h->L.build(desc->settings, h->kt)) {
+    if (Layout::make_kin_tables(desc->model, h->kt, e)) Layout::fill_terrain_tops(h->kt, desc->settings.terrain, desc->settings.n_terrain_steps, desc->settings.terrain_steps);
+    if (!e.empty() || !h->L.build(desc->settings, h->kt)) {
         if (e.empty()) e = h->L.error;
         std::strncpy(err, e.c_str(), size_t(errlen - 1));
         delete h;

@@ -24,6 +24,9 @@ def settings_for(meta, model):
         return single_step_settings(N, model)
     if meta["config"] == "stairs":
         return stairs_settings(N, model)
+    if meta["config"] == "ramp":      # main_walking_on_ramp.py: one step with a sloped top
+        from hippopt_amd.kinodyn_settings import ramp_settings
+        return ramp_settings(N, model)
     st = periodic_step_settings(N, model)
     if meta["config"] == "costends":
         st.final_state_expression_type = _abi.EXPR_MINIMIZE
@@ -37,7 +40,7 @@ def rel(a, b):
     return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if np.size(a) else 0.0
 
 
-@pytest.mark.parametrize("name", ["planner_periodic_N3", "planner_single_N3", "planner_costends_N2", "planner_stairs_N3"])
+@pytest.mark.parametrize("name", ["planner_periodic_N3", "planner_single_N3", "planner_costends_N2", "planner_stairs_N3", "planner_ramp_N3"])
 def test_oracle_matches_reference_planner_assembly(model, name):
     z = np.load(os.path.join(GOLD, name + ".npz"))
     meta = json.loads(str(z["meta"]))
@@ -83,7 +86,7 @@ def test_oracle_matches_reference_planner_assembly(model, name):
     assert got == expect
 
 
-HESS_FIXTURES = ["planner_periodic_N3", "planner_single_N3", "planner_costends_N2", "planner_stairs_N3"]
+HESS_FIXTURES = ["planner_periodic_N3", "planner_single_N3", "planner_costends_N2", "planner_stairs_N3", "planner_ramp_N3"]
 
 
 def hessian_times(rows, cols, vals, n, D):

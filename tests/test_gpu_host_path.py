@@ -112,7 +112,10 @@ def test_hessian_with_ipopts_new_x_flag_uses_the_staged_x(model, HipNlp):
     assert np.array_equal(fresh.eval_hess(xs[1], 0.7, lam, new_x=False), ref[1])        # nothing staged yet: copied whatever the flag says
     fresh.eval(xs[2], want=("f", "g"))                                                   # IPOPT's sequence: callbacks at x, then eval_h(new_x = FALSE)
     assert np.array_equal(fresh.eval_hess(xs[2], 0.7, lam, new_x=False), ref[2])
-    assert np.array_equal(fresh.eval_hess(xs[0], 0.7, lam, new_x=False), ref[2])        # the CONTRACT: the staged x, not the argument
+    # a caller whose new_x = FALSE is wrong (the callbacks ran elsewhere, another iterate was evaluated in between): sixty-four words of x
+    # are compared with the staged copy, a differing sample stages the argument — the Hessian of the x that was passed, not a stale one
+    assert np.array_equal(fresh.eval_hess(xs[0], 0.7, lam, new_x=False), ref[0])
+    assert np.array_equal(fresh.eval_hess(xs[0], 0.7, lam, new_x=False), ref[0])        # (... which is the staged one from then on)
     assert np.array_equal(fresh.eval_hess(xs[0], 0.7, lam, new_x=None), ref[0])         # unknown: compared, differs, copied
     assert np.array_equal(fresh.eval_hess(xs[0].copy(), 0.7, lam, new_x=None), ref[0])  # unknown: equal values in another array
     assert np.array_equal(fresh.eval_hess(xs[1], 0.7, lam), ref[1])                     # the plain call: new x

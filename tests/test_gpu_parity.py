@@ -276,7 +276,7 @@ def test_large_horizon_properties(model, HipNlp):
     assert np.max(np.abs(gr[0][first:first + rows * nk])) < 1e-13
 
 
-@pytest.mark.parametrize("name", ["planner_periodic_N3", "planner_single_N3", "planner_costends_N2", "planner_stairs_N3"])
+@pytest.mark.parametrize("name", ["planner_periodic_N3", "planner_single_N3", "planner_costends_N2", "planner_stairs_N3", "planner_ramp_N3"])
 def test_gpu_matches_reference_planner_fixtures(model, HipNlp, name):
     """HIP path against the golden vectors generated by executing the reference's planner code on the CasADi-API stand-in
     (tools/gen_planner_fixtures.py): same x, p -> g (reference row order), bounds, f, grad f, jac g."""
@@ -304,7 +304,7 @@ def test_gpu_matches_reference_planner_fixtures(model, HipNlp, name):
         from test_golden_planner import hessian_times
         hr, hc = eng.hess_sparsity()
         hv = eng.eval_hess(z["x"][None, :], float(z["hess_sigma"]), z["hess_lambda"][None, :])[0]
-        assert rel(hessian_times(hr, hc, hv, eng.n, z["hess_dirs"]), z["hess_times_dirs"]) < (1e-9 if "stairs" in name else TOL)
+        assert rel(hessian_times(hr, hc, hv, eng.n, z["hess_dirs"]), z["hess_times_dirs"]) < (1e-9 if ("stairs" in name or "ramp" in name) else TOL)
 
 
 def test_planner_solve_plumbing(model):
@@ -1287,3 +1287,44 @@ def test_sixteen_batched_guesses_through_the_engine(model, HipNlp):
         if b in (0, 7, 15):
             fo, grado, go, jaco = orc.eval(x[b], p[b])
             assert rel(f[b], fo) < TOL and rel(grad[b], grado) < TOL and rel(g[b], go) < TOL and rel(jac[b], jaco) < TOL
+
+
+@pytest.mark.parametrize("name,batch,horizon", [("ramp", 2, 50), ("mixed", 1, 5), ("mixed", 120, 6)])
+def test_sloped_step_tops_match_oracle(model, HipNlp, name, batch, horizon):
+    """SmoothTerrain.step(top_normal_direction=...) (utilities/smooth_terrain.py:238-264; the ramp of main_walking_on_ramp.py:18-30,
+    403-409): z_t = exp(-g^(2s)) pi(q_xy) with pi the plane of the given normal.  Callback quartet and exact Hessian against the oracle —
+    the eight-wave kernels (small launches) and the four-wave / compact ones (batch 120), contact points on the flanks and on the top."""
+    from hess_util import hess_mismatch, triplets_to_dict
+    from oracle_lib import Oracle
+    from test_sloped_terrain import terrains
+    st = terrains(horizon, model)[name]
+    x, p = make_workload(st, model, batch=batch, seed=8500 + horizon)
+    place_on_step_flanks(x[:1], st, seed=horizon)
+    eng, orc = HipNlp(st, model, batch=batch), Oracle(st, model)
+    ir, jc = eng.sparsity()
+    iro, jco = orc.sparsity()
+    assert np.array_equal(ir, iro) and np.array_equal(jc, jco)
+    eng.set_params(p)
+    f, grad, g, jac = eng.eval(x)
+    lam = np.random.RandomState(3).standard_normal((batch, orc.m))
+    hr, hc = eng.hess_sparsity()
+    hv = eng.eval_hess(x, 0.7, lam)
+    for b in sorted({0, batch - 1, batch // 2}):
+        fo, grado, go, jaco = orc.eval(x[b], p[b])
+        assert rel(f[b], fo) < TOL and rel(grad[b], grado) < TOL and rel(g[b], go) < TOL and rel(jac[b], jaco) < TOL, b
+        err, where = hess_mismatch(triplets_to_dict(hr, hc, hv[b]), triplets_to_dict(*orc.hess(x[b], p[b], 0.7, lam[b])), diag_scaled=True)
+        assert err <= 1e-9, (b, where)
+    # the slope is there: the same steps with flat tops give other rows
+    flat = terrains(horizon, model)[name]
+    flat.terrain_steps = [dict(t, top_normal_direction=None) for t in flat.terrain_steps]
+    ef = HipNlp(flat, model, batch=batch)
+    ef.set_params(p)
+    assert np.max(np.abs(ef.eval(x, want=("g",))[2] - g)) > 1e-3
+    # a varying-first handle through host arrays and two shards of the card: the same bits as the plain handle
+    if batch == 1:
+        multi = HipNlp(st, model, jac_varying_first=True, devices=[0, 0])
+        plain = HipNlp(st, model, jac_varying_first=True)
+        for e in (multi, plain):
+            e.set_params(p)
+        assert all(np.array_equal(u, v) for u, v in zip(multi.eval(x), plain.eval(x)))
+        assert np.array_equal(multi.eval_hess(x, 0.7, lam), plain.eval_hess(x, 0.7, lam))

@@ -431,3 +431,31 @@ def test_pose_with_a_joint_numbering_that_does_not_follow_the_tree(model):
         H = np.zeros_like(Ho)
         H[hr, hc] = hv[b]
         assert np.max(np.abs(H - Ho) / np.maximum(1.0, np.abs(Ho))) < 1e-11
+
+
+def test_pose_on_steps_with_sloped_tops(model):
+    """the pose finder on SmoothTerrain.step(top_normal_direction=...) steps (smooth_terrain.py:238-264): callbacks and exact Hessian of a
+    batch against the pose oracle"""
+    from hippopt_amd import _abi
+    from hippopt_amd.hipnlp import HipPose
+    from hippopt_amd.pose_settings import make_pose_workload, pose_finder_settings
+    from oracle_lib import PoseOracle
+    from test_pose_body_hostemu import flank_points, hess_check
+    st = pose_finder_settings(model)
+    st.terrain = _abi.TERRAIN_SMOOTH_STEPS
+    st.terrain_steps = [{"length": 0.9, "width": 0.8, "height": 0.1, "position": (0.3, 0.0, 0.0), "top_normal_direction": (-0.2, 0.0, 1.0)},
+                        {"length": 0.3, "width": 0.5, "height": 0.1, "position": (-0.2, 0.1, 0.02), "orientation": 0.6, "edge_sharpness": 3, "side_sharpness": 4,
+                         "top_normal_direction": (0.1, 0.2, 1.5)}]
+    B = 5
+    x, p = make_pose_workload(st, model, batch=B, seed=8600)
+    flank_points(x[0], 4)
+    eng, orc = HipPose(st, model, batch=B), PoseOracle(st, model)
+    eng.set_params(p)
+    f, grad, g, jac = eng.eval(x)
+    lam = np.random.RandomState(8).standard_normal((B, orc.m))
+    hr, hc = eng.hess_sparsity()
+    hv = eng.eval_hess(x, 0.9, lam)
+    for b in range(B):
+        fo, grado, go, jaco = orc.eval(x[b], p[b])
+        assert rel(f[b], fo) < 1e-9 and rel(grad[b], grado) < 1e-9 and rel(g[b], go) < TOL and rel(jac[b], jaco) < 1e-9
+        hess_check(hr, hc, hv[b], orc.hess(x[b], p[b], 0.9, lam[b]), 1e-10)
