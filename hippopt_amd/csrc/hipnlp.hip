@@ -88,6 +88,12 @@ struct DeviceTables {
     // VCAP / WG entries per thread (padded with -1)
     int32_t jpermv_t[3][VCAP_MAX];
     int32_t nvary_v[3], pad_v;
+    // SPLIT instantiations (two workgroups per knot: knot_body.h "Workgroup specialisation"): the same thread-major tables with the entries
+    // the OTHER half of the program owns blanked (-1 / G_NONE) — [0] the kinematic workgroup's, [1] the model-free one's
+    int32_t split_jperm_t[2][3][JS_PAD];
+    int32_t split_gab_t[2][3][2 * GS_PAD];
+    int32_t split_jpermv_t[2][3][VCAP_MAX];
+    int32_t split_jperm_glob[2][16];
 };
 
 // (see constants_check_and_repair)
@@ -165,6 +171,18 @@ template <int TERRAIN, int WAVES = 4, bool VARY = false> struct DevEm {
     // entries that do not depend on x (emit_jc): a VARY instantiation neither stages nor stores them — its destination holds them
     __device__ __forceinline__ void JC(int slot, int, int, double v) { if constexpr (!VARY) jac[slot] = v; }
 };
+
+#ifdef HIPNLP_DIAG_TASKSET
+constexpr bool diag_same(const char* a, const char* b) { while (*a && *a == *b) { ++a; ++b; } return *a == *b; }
+constexpr bool diag_task_is_kinematic(const char* n) {
+    const char* kin[] = {"t_joints", "t_base", "t_fk_rot_a", "t_fk_rot_b", "t_link_u_a", "t_link_u_b", "t_links", "t_frames", "t_link_inertia", "t_composite_g0",
+                         "t_composite_g1", "t_composite_g2", "t_composite_g3", "t_composite_g4", "t_composite_g5", "t_pkin", "t_columns", "t_cmm_columns",
+                         "t_frame_columns", "t_kinc", "t_comc", "t_cmmc", "t_kinc_s", "t_feetd"};
+    for (const char* k : kin) if (diag_same(n, k)) return true;
+    return false;
+}
+constexpr bool diag_task_kept(const char* n) { return diag_task_is_kinematic(n) == (HIPNLP_DIAG_TASKSET == 1); }
+#endif
 
 // LDS image of the read-only tables every phase indexes per lane (global memory would cost one L2 round trip per phase)
 template <bool COMPACT> struct SharedTablesT;
@@ -270,9 +288,14 @@ template <int TERRAIN, int WAVES, bool VARY, bool PEERS = false> constexpr bool 
 // hook itself is compiled into every eight-wave kernel (see EARLY_OUT below); what this parameter moves is the fetch of the copy-out tables —
 // in front of the staging wait, where no wait for them can end up behind an early store, at 0.1 - 0.15 us of prologue that the launches
 // which never store early (the device-resident ones) do not pay.
-template <int TERRAIN, int WAVES, bool PEERS = false, bool VARY = false, bool STORES_EARLY = false> __global__ __launch_bounds__(64 * WAVES)
+// SPLIT: two workgroups per knot in one launch (eight-wave kernels of launches that leave CUs idle: device destinations, one workgroup per
+// CU) — workgroups [0, nk) of a grid row run the kinematic half of the knot program, [nk, 2 nk) the model-free half (knot_body.h,
+// split_task_is_model_free), each stores the outputs its half owns; the row's reducer is workgroup 2 nk.  Measured on the 100-knot launch
+// with timing-only builds (tools/diag/taskset_experiment.sh): either half alone ends 0.6 - 1.4 us before the whole program does.
+template <int TERRAIN, int WAVES, bool PEERS = false, bool VARY = false, bool STORES_EARLY = false, bool SPLIT = false> __global__ __launch_bounds__(64 * WAVES)
 __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? (five_per_cu<TERRAIN, WAVES, VARY, PEERS> ? 5 : 4) : 2, five_per_cu<TERRAIN, WAVES, VARY, PEERS> ? 5 : 4)))
 void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const double* pk_p, const GParams* gp_p, int N_p, int n_p, int kb_p, int nk_p, KArgs a) {
+    static_assert(!SPLIT || (WAVES == 8 && !PEERS && !STORES_EARLY), "two workgroups per knot: the eight-wave kernels of device-resident launches");
     // the leading scalar arguments repeat what the staging loads need: the build preloads them into SGPRs
     // (-mllvm -amdgpu-kernarg-preload-count), so the first global loads do not wait for a kernarg fetch
     constexpr int WG = 64 * WAVES;
@@ -297,7 +320,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     // (launches of at most 256 knots per trajectory: one more workgroup per grid row, the trajectory's cost reducer)
     const unsigned nkx = unsigned(nk_p);   // (= gridDim.x, less the reducer; preloaded: the grid size is a kernarg load away)
     {
-        if (blockIdx.x == nkx) {
+        if (blockIdx.x == (SPLIT ? 2u * nkx : nkx)) {
             // ---- total cost without a second kernel and without a tail ---------------------------------------------------------
             // Every knot workgroup publishes its cost partials as soon as they are final (end of phase C) and goes on; THIS
             // workgroup does nothing but poll them (agent-scope loads: the writers sit on other XCDs) until all carry this launch's
@@ -314,8 +337,11 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             double* red = reinterpret_cast<double*>(&s);   // [nk][16]
             static_assert(sizeof(Scratch) >= size_t(reducer_cap<Scratch>()) * 16 * sizeof(double) && reducer_cap<Scratch>() >= 200, "reducer staging");
             const unsigned long long pat = pub_pattern(a.seq);
-            const unsigned long long* base = a.cost_pub + size_t(b) * a.nk * NCT * 2;
             const int t = lane & 15, q = lane >> 4;
+            // (SPLIT: every cost term is published by the workgroup whose half of the program owns it — the model-free workgroups' partials
+            //  live behind those of the kinematic ones: [2][batch][nk][NCT][2])
+            const unsigned long long* base = a.cost_pub + size_t(b) * a.nk * NCT * 2 +
+                                             ((SPLIT && t < NCT && split_cost_is_model_free(t)) ? size_t(gridDim.y) * a.nk * NCT * 2 : size_t(0));
             constexpr int KR = 4 * WAVES, U = 256 / KR;   // wave w, lane (t, q): knots 4 w + q + KR u
             unsigned pending = 0;
 #pragma unroll
@@ -384,7 +410,9 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             return;
         }
     }
-    const int kk = int((blockIdx.x & 7u) * (nkx >> 3) + min(blockIdx.x & 7u, nkx & 7u) + (blockIdx.x >> 3));
+    const bool wg_m = SPLIT && blockIdx.x >= nkx;              // (SPLIT) this workgroup runs the model-free half of the knot program
+    const unsigned bx = wg_m ? blockIdx.x - nkx : blockIdx.x;  // (both halves of a knot walk the XCDs the same way: they read the same records)
+    const int kk = int((bx & 7u) * (nkx >> 3) + min(bx & 7u, nkx & 7u) + (bx >> 3));
     const int k = kb_p + kk;
     const int N = N_p;
     const double* x = x_p + size_t(b) * n_p;
@@ -407,6 +435,18 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     constexpr bool LATE_TABLES = five_per_cu<TERRAIN, WAVES, VARY, PEERS>;
     auto fetch_tables = [&]() __attribute__((always_inline)) {
         const DeviceTables& tbl = *tb_p;
+        if constexpr (SPLIT) {   // this half's entries only (the other half's are -1 / G_NONE)
+            const int hw = wg_m ? 1 : 0;
+            jpg = tbl.split_jperm_glob[hw][tid & 15];
+#pragma unroll
+            for (int it = 0; it < JP_ITERS; ++it) jp[it] = VARY ? tbl.split_jpermv_t[hw][v][tid * JP_ITERS + it] : tbl.split_jperm_t[hw][v][tid * (JS_PAD / WG) + it];
+#pragma unroll
+            for (int it = 0; it < G_ITERS; ++it) {
+                ga[it] = tbl.split_gab_t[hw][v][2 * (tid * (GS_PAD / WG) + it)];
+                gb[it] = tbl.split_gab_t[hw][v][2 * (tid * (GS_PAD / WG) + it) + 1];
+            }
+            return;
+        }
         jpg = tbl.jperm_glob[tid & 15];
 #pragma unroll
         for (int it = 0; it < JP_ITERS; ++it) jp[it] = VARY ? tbl.jpermv_t[v][tid * JP_ITERS + it] : tbl.jperm_t[v][tid * (JS_PAD / WG) + it];      // (thread-major: wide loads)
@@ -508,10 +548,10 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     const bool ends_late = (first || last) && (tabs.settings().final_type == HIPNLP_EXPR_MINIMIZE || tabs.settings().periodicity_type == HIPNLP_EXPR_MINIMIZE);
     int pub_bad = 0;
     auto pub_store = [&]() __attribute__((always_inline)) {
-        if (lane < NCT) {
+        if (lane < NCT && (!SPLIT || split_cost_is_model_free(lane) == wg_m)) {   // (SPLIT: the terms this workgroup's half of the program owns)
             const double cv = (lane == CT_ENDS && !ends_late) ? 0.0 : s.cost[lane];   // (t_ends_finish writes that zero only in phase F)
             pub_bad |= !isfinite(cv);
-            unsigned long long* pp = a.cost_pub + ((size_t(b) * a.nk + kk) * NCT + lane) * 2;
+            unsigned long long* pp = a.cost_pub + ((size_t(b) * a.nk + kk) * NCT + lane) * 2 + (wg_m ? size_t(gridDim.y) * a.nk * NCT * 2 : size_t(0));
             const unsigned long long bits = (unsigned long long)__double_as_longlong(cv);
             __hip_atomic_store(pp, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(pp + 1, bits ^ pub_pattern(a.seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -551,8 +591,15 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     // column range.  Every group of those phases is one wave iteration whatever its lane count: the launch does not
     // get shorter (profiles/r05_headline_experiments.txt).
 #define DEV_R(w4, w8, fn, nt) if constexpr ((WAVES == 4 ? (w4) : (w8)) == W) { for (int t_ = lane; t_ < (bid >= 4 ? ((nt) + 1) / 2 : (nt)); t_ += 64) fn(cx, t_); }
+#elif defined(HIPNLP_DIAG_TASKSET)
+    // timing-only diagnostic build (wrong values; tools/diag/taskset_experiment.sh): the knot program with ONE of its two halves —
+    // 1: the task groups that need the robot model (joints, base, forward kinematics, links, composites, derivative columns, the
+    // kinematic consistency rows), 2: the model-free ones (contact rows, linear defects, momentum dynamics, costs, horizon ends) — what a
+    // workgroup of either kind would be left with if the two were specialised inside one launch
+#define DEV_R(w4, w8, fn, nt) if constexpr ((WAVES == 4 ? (w4) : (w8)) == W && diag_task_kept(#fn)) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #else
-#define DEV_R(w4, w8, fn, nt) if constexpr ((WAVES == 4 ? (w4) : (w8)) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
+    // (SPLIT: a workgroup runs the groups of its half — a scalar branch on a workgroup-uniform value; without SPLIT the test folds away)
+#define DEV_R(w4, w8, fn, nt) if constexpr ((WAVES == 4 ? (w4) : (w8)) == W) { constexpr bool mf_ = split_task_is_model_free(#fn); if (!SPLIT || mf_ == wg_m) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); } }
 #endif
     // Early copy-out (eight-wave kernel, launches into host memory: a.early): behind the second barrier every thread stores those of ITS
     // entries of g and jac g whose slot is final by then (COPY_EARLY in its table words) — a third of jac g's varying entries and five rows
@@ -648,14 +695,18 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 #pragma unroll
     for (int it = 0; it < G_ITERS; ++it) bad |= (ga[it] != G_NONE) & !isfinite(gvals[it]);
 #pragma unroll
-    for (int it = 0; it < GR_ITERS; ++it) bad |= ((tid + it * WG) < NXK) & !isfinite(grvals[it]);
+    for (int it = 0; it < GR_ITERS; ++it) bad |= ((tid + it * WG) < NXK) & (!SPLIT || split_grad_is_model_free(tid + it * WG) == wg_m) & !isfinite(grvals[it]);
     if (a.cost_pub) { if (wave == PUBW) bad |= pub_bad; }
     else if (tid < NCT) {
         const double cval = s.cost[tid];
         bad |= !isfinite(cval);
         a.cost_knot[(size_t(b) * a.nk + kk) * NCT + tid] = cval;
     }
+#ifdef HIPNLP_DIAG_TASKSET
+    const int anybad = 0 * __any(bad);   // (the half of the program that is compiled out leaves its slots unwritten: their garbage must not raise the flag — 12 800 atomics on 16 words doubled the stairs launch)
+#else
     const int anybad = __any(bad);
+#endif
 #ifdef HIPNLP_DIAG_SKIP
     if (HIPNLP_DIAG_SKIP & 1) a.jac = nullptr;
     if (HIPNLP_DIAG_SKIP & 2) a.g = nullptr;
@@ -687,7 +738,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 #pragma unroll
         for (int it = 0; it < JP_ITERS; ++it) if (jp[it] >= 0 && !(early_on && (jp[it] & COPY_EARLY))) out[VARY ? jp_pos(jp[it]) : tid + it * WG] = jvals[it];
         // entries in the horizon-global columns (constants) sit right behind the last knot's block: the last knot writes them
-        if constexpr (!VARY) { if (last && tid < n_glob) a.jac[int64_t(b) * a.jac_stride + (int64_t(jac_glob_base) - a.jac_off) + tid] = s.jac[jpg]; }
+        if constexpr (!VARY) { if (last && tid < n_glob && (!SPLIT || jpg >= 0)) a.jac[int64_t(b) * a.jac_stride + (int64_t(jac_glob_base) - a.jac_off) + tid] = s.jac[SPLIT ? max(jpg, 0) : jpg]; }
     }
     if (a.g) {
         double* out = a.g + size_t(b) * a.m;
@@ -713,8 +764,8 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     if (a.grad) {
         double* out = a.grad + int64_t(b) * a.grad_stride + (int64_t(NXK) * k - a.grad_off);
 #pragma unroll
-        for (int it = 0; it < GR_ITERS; ++it) { const int i = tid + it * WG; if (i < NXK) out[i] = grvals[it]; }
-        if (last && tid < NXG) a.grad[int64_t(b) * a.grad_stride + (int64_t(NXK) * N - a.grad_off) + tid] = 0.0;  // the global variables carry no cost
+        for (int it = 0; it < GR_ITERS; ++it) { const int i = tid + it * WG; if (i < NXK && (!SPLIT || split_grad_is_model_free(i) == wg_m)) out[i] = grvals[it]; }
+        if (last && tid < NXG && !wg_m) a.grad[int64_t(b) * a.grad_stride + (int64_t(NXK) * N - a.grad_off) + tid] = 0.0;  // the global variables carry no cost
     }
     if (anybad && lane == 0) {   // generation flag: nothing to reset between launches
         atomicMax(a.flag + b, a.seq);
@@ -1171,6 +1222,9 @@ struct hipnlp_handle {
     KinTables kt;
     int batch = 1, kb = 0, ke = 0, nk = 0, np = 0;
     bool wide = false;   // eight-wave kernel variant (launches that are resident at once at two workgroups per CU)
+    // two workgroups per knot (SPLIT instantiations): device-resident launches of the eight-wave kernels that leave at least half of the
+    // CUs idle — (2 knots + 1) x batch workgroups on 256 CUs, one each — and whose horizon ends are not costs (knot_body.h)
+    bool split = false;
     bool fused = false;  // the total cost is summed inside the knot launch by one reducer workgroup per trajectory (knots <= 256)
     hipnlp_dims dims{};         // hipnlp_get_dims, filled by hipnlp_create
     bool early_store_always = false;   // diagnostic (HIPNLP_EARLY_STORE=2): also for hipnlp_eval_device launches
@@ -1433,6 +1487,9 @@ static int create_handle(const hipnlp_desc* desc, hipnlp_handle** out, bool fron
             red_cap = st.terrain == HIPNLP_TERRAIN_PLANAR ? reducer_cap<KnotScratchT<LAYOUT_COMPACT, js::vary_slots(true)>>()
                                                           : reducer_cap<KnotScratchT<LAYOUT_COMPACT, js::vary_slots(false)>>();
         h->fused = h->nk <= red_cap && (h->wide || (small_launch && !(sep && std::atoi(sep) == 1)));
+        h->split = h->wide && h->fused && (2 * long(h->nk) + 1) * long(desc->batch) <= 256 &&
+                   st.final_state_type != HIPNLP_EXPR_MINIMIZE && st.periodicity_type != HIPNLP_EXPR_MINIMIZE;
+        if (const char* sp = diag_env("HIPNLP_SPLIT")) h->split = h->split && std::atoi(sp) != 0;   // diagnostic override (A/B in one process)
         const char* hl = diag_env("HIPNLP_HESS_LAYOUT");   // diagnostic override: full | compact
         h->hess_compact = hl ? std::strcmp(hl, "compact") == 0 : long(h->nk) * long(desc->batch) > 512;
         if (const char* hd = diag_env("HIPNLP_HESS_DIRECT")) h->hess_direct = std::atoi(hd) != 0;
@@ -1492,8 +1549,9 @@ static int create_handle(const hipnlp_desc* desc, hipnlp_handle** out, bool fron
         std::memset(h->h_out, 0, h->out_bytes);
     }
     DEV_TRY(hipMalloc(&h->d_cost_knot, B * size_t(h->nk) * NCT * sizeof(double)));
-    DEV_TRY(hipMalloc(&h->d_cost_pub, B * size_t(h->nk) * NCT * 2 * sizeof(unsigned long long)));
-    DEV_TRY(hipMemset(h->d_cost_pub, 0, B * size_t(h->nk) * NCT * 2 * sizeof(unsigned long long)));
+    // (twice: the SPLIT launches publish the model-free workgroups' partials behind those of the kinematic ones)
+    DEV_TRY(hipMalloc(&h->d_cost_pub, 2 * B * size_t(h->nk) * NCT * 2 * sizeof(unsigned long long)));
+    DEV_TRY(hipMemset(h->d_cost_pub, 0, 2 * B * size_t(h->nk) * NCT * 2 * sizeof(unsigned long long)));
     DEV_TRY(hipMemset(h->d_flag, 0, B * sizeof(int32_t)));
     // (measured: non-coherent pinned memory for this block — cacheable in the GPU's L2 within a launch, so that the halo record would
     //  not cross PCIe twice — changes nothing: 22.3 us of GPU wait per objective call either way)
@@ -1572,6 +1630,33 @@ static int create_handle(const hipnlp_desc* desc, hipnlp_handle** out, bool fron
                     tb->jpermv_t[v][(i % wg) * jt + i / wg] = slot | (pos << JP_POS_SHIFT) | (h->L.jslot_phase[size_t(slot)] <= 1 ? COPY_EARLY : 0);
                     ++i;
                 }
+    }
+    {
+        // SPLIT instantiations: the thread-major tables once per half of the program, the other half's entries blanked (recorded owners:
+        // Layout::jslot_owner / gslot_owner)
+        const int wg = h->wide ? 512 : 256, jt = JS_PAD / wg, gt = GS_PAD / wg;
+        for (int hw = 0; hw < 2; ++hw) {
+            for (int v = 0; v < 3; ++v) {
+                for (int i = 0; i < wg * jt; ++i) {
+                    const int32_t w = tb->jperm_t[v][i];
+                    tb->split_jperm_t[hw][v][i] = (w >= 0 && h->L.jslot_owner[size_t(w & COPY_SLOT & JP_SLOT)] == hw) ? w : -1;
+                }
+                for (int i = wg * jt; i < JS_PAD; ++i) tb->split_jperm_t[hw][v][i] = -1;
+                for (int t = 0; t < wg; ++t)
+                    for (int it = 0; it < gt; ++it) {
+                        const int gslot = t + it * wg, at = 2 * (t * gt + it);
+                        const bool mine = gslot < gs::COUNT && h->L.gslot_owner[size_t(gslot)] == hw;
+                        tb->split_gab_t[hw][v][at] = mine ? tb->gab_t[v][at] : G_NONE;
+                        tb->split_gab_t[hw][v][at + 1] = tb->gab_t[v][at + 1];
+                    }
+                for (int i = 0; i < VCAP_MAX; ++i) {
+                    const int32_t w = tb->jpermv_t[v][i];
+                    tb->split_jpermv_t[hw][v][i] = (w >= 0 && h->L.jslot_owner[size_t(jp_slot(w))] == hw) ? w : -1;
+                }
+            }
+            for (int i = 0; i < 16; ++i)
+                tb->split_jperm_glob[hw][i] = (i < tb->n_glob && h->L.jslot_owner[size_t(tb->jperm_glob[i])] == hw) ? tb->jperm_glob[i] : -1;
+        }
     }
     hipError_t ce = front ? hipSuccess : hipnlp_internal_memcpy(h->d_tb, tb, sizeof(DeviceTables), hipMemcpyHostToDevice);
     if (!front && ce == hipSuccess) ce = hipMalloc(&h->d_healed, sizeof(int32_t));
@@ -1889,7 +1974,7 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         HIP_TRY(h, hipMemset(h->d_flag, 0, size_t(h->batch) * sizeof(int32_t)));
         std::memset(h->h_flag, 0, size_t(h->batch) * sizeof(int32_t));
-        if (h->d_cost_pub) HIP_TRY(h, hipMemset(h->d_cost_pub, 0, size_t(h->batch) * size_t(h->nk) * NCT * 2 * sizeof(unsigned long long)));
+        if (h->d_cost_pub) HIP_TRY(h, hipMemset(h->d_cost_pub, 0, 2 * size_t(h->batch) * size_t(h->nk) * NCT * 2 * sizeof(unsigned long long)));
         HIP_TRY(h, hipDeviceSynchronize());
         h->seq = 0;
         h->seq_result = -1;
@@ -1910,12 +1995,23 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     hipEvent_t e2 = prof ? h->prof_ev[size_t(3 * h->prof_n + 2)] : h->ev1;
     if (run_first) { HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n)], s)); h->prof_open = true; }
 #ifdef HIPNLP_STAMPS
-    if (!h->d_stamps) HIP_TRY(h, hipMalloc(&h->d_stamps, size_t(h->nk) * size_t(h->batch) * 1024 * sizeof(unsigned long long)));
+    if (!h->d_stamps) HIP_TRY(h, hipMalloc(&h->d_stamps, 2 * size_t(h->nk) * size_t(h->batch) * 1024 * sizeof(unsigned long long)));   // (SPLIT launches: two workgroups per knot)
     a.stamps = h->d_stamps;
 #endif
     if (timed) HIP_TRY(h, hipEventRecord(e0, s));
-    const dim3 grid(unsigned(h->nk) + (fused ? 1u : 0u), unsigned(h->batch));   // (+ the row's cost reducer)
+    // two workgroups per knot: device destinations of the whole-array kind only (no staging of g for an exchange, no peers, no early stores)
+    const bool split = h->split && fused && !peer_out && !g_stage && !host_block && !a.early && !compact;
+    const dim3 grid((split ? 2u : 1u) * unsigned(h->nk) + (fused ? 1u : 0u), unsigned(h->batch));   // (+ the row's cost reducer)
     const bool planar = h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR;
+    if (split) {
+        if (vary_only) {
+            if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8, false, true, false, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+            else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8, false, true, false, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+        } else {
+            if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8, false, false, false, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+            else hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, 8, false, false, false, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
+        }
+    } else
     if (peer_out && vary_only) {   // every rank's buffer holds the constant entries: the varying run of every block, at its place in the pattern, once per rank
         if (h->wide) {
             if (planar) hipLaunchKernelGGL((hipnlp_knot_kernel<HIPNLP_TERRAIN_PLANAR, 8, true, true>), grid, dim3(512), 0, s, a.tb, a.x, a.pk, a.gp, a.N, a.n, a.knot_begin, a.nk, a);
@@ -2418,7 +2514,7 @@ static int hess_launch(hipnlp_handle* h, const double* x_dev, const double* sigm
     a.seq = ++h->hseq; a.nnz_knot = h->HL.nnz_knot;
     a.early_run = (host_block && early && !h->hess_compact && h->HL.early_run <= 3 * 256 && h->HL.early_phase == hess_early_phase(h->d.settings.terrain)) ? h->HL.early_run : 0;
 #ifdef HIPNLP_STAMPS
-    if (!h->d_stamps) HIP_TRY(h, hipMalloc(&h->d_stamps, size_t(h->nk) * size_t(h->batch) * 1024 * sizeof(unsigned long long)));
+    if (!h->d_stamps) HIP_TRY(h, hipMalloc(&h->d_stamps, 2 * size_t(h->nk) * size_t(h->batch) * 1024 * sizeof(unsigned long long)));   // (SPLIT launches: two workgroups per knot)
     a.stamps = h->d_stamps;
 #endif
     const dim3 hgrid(unsigned(h->nk), unsigned(h->batch));

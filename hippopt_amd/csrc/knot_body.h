@@ -1627,4 +1627,27 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
     R(3, 4, t_feetd, 5) R(3, 4, t_ends_finish, ENDS_FINISH_TASKS)                         \
     BARRIER
 
+// ---------------------------------------------------------------------------------------------------
+// Workgroup specialisation (hipnlp.hip, SPLIT instantiations): the knot program cut into two halves that run on TWO workgroups of one
+// launch — the task groups that need the robot model (joints, base, forward kinematics, links, composites, derivative columns, the
+// kinematic consistency rows; with them the cheap groups the kinematic ones lean on: t_joint_rows / t_joint_cost initialise grad S_ / SD_
+// and t_unitq grad QB_, to which kinematic groups add; t_dyn writes the padding slots of the ancestor lists), and the MODEL-FREE ones below: contact-point rows, terrain, linear trapezoid defects,
+// momentum dynamics, point costs, horizon ends.  No group of one half reads scratch a group of the other half writes, every native slot
+// of g / jac g and every cost term is written by one half, and the gradient splits by variable: entries [QB_, COM_) belong to the kinematic
+// half, the others (point variables, v_b, qdot_b, p_b, com, h) to the model-free one — tests/test_split_program.py runs the halves on two
+// poisoned scratches and finds the merged outputs equal to the one-scratch run, bit for bit.
+// (Horizon-end terms in `minimize` mode add into every gradient entry: launches of such settings keep the one-workgroup kernels.)
+// ---------------------------------------------------------------------------------------------------
+HD constexpr bool split_same(const char* a, const char* b) { while (*a && *a == *b) { ++a; ++b; } return *a == *b; }
+HD constexpr bool split_task_is_model_free(const char* n) {
+    const char* mf[] = {"t_points_vec", "t_points_scalar", "t_points_dyn", "t_terrain_bump", "t_terrain_stage", "t_terrain_planar", "t_terrain_dcc",
+                        "t_terrain_hnf", "t_terrain_swing", "t_points_cost", "t_foot_costs", "t_foot_cost_sum", "t_feet_yaw", "t_feet_centroid",
+                        "t_hdyn_rows_a", "t_hdyn_entries_a", "t_hdyn_entries", "t_hdyn_rows", "t_small", "t_com_height", "t_ends", "t_ends_finish"};
+    for (const char* k : mf) if (split_same(n, k)) return true;
+    return false;
+}
+HD constexpr bool split_grad_is_model_free(int i) { return i < QB_ || i >= COM_; }   // (x layout: ... | q_b 130 | sdot 134 | s 157 | com 180 | h 183)
+HD constexpr bool split_cost_is_model_free(int t) { return !(t == CT_FRAMEQ || t == CT_BASEQ || t == CT_JREG); }
+static_assert(QB_ == 130 && SD_ == 134 && S_ == 157 && COM_ == 180 && VB_ == 120, "gradient ownership of the split program follows the x layout");
+
 }  // namespace hipnlp

@@ -59,8 +59,12 @@ struct RecordEm {
     int* hcol = nullptr;
     unsigned char* hphase = nullptr;   // [hk::COUNT] or null: phase of the Hessian program (barriers passed) in which the slot is emitted — every slot once
     void H(int slot, int row, int col, double) { if (hrow[slot] != -1) *dup = true; hrow[slot] = row; hcol[slot] = col; if (hphase) hphase[slot] = (unsigned char)phase; }
-    void G(int slot, int rid, double) { if (grow[slot] != -1) *dup = true; grow[slot] = rid; if (gphase) gphase[slot] = (unsigned char)phase; }
-    void J(int slot, int rid, int col, double) { if (jrowid[slot] != -1) *dup = true; jrowid[slot] = rid; jcol[slot] = col; if (jphase) jphase[slot] = (unsigned char)phase; }
+    void G(int slot, int rid, double) { if (grow[slot] != -1) *dup = true; grow[slot] = rid; if (gphase) gphase[slot] = (unsigned char)phase; if (gowner) gowner[slot] = owner; }
+    void J(int slot, int rid, int col, double) { if (jrowid[slot] != -1) *dup = true; jrowid[slot] = rid; jcol[slot] = col; if (jphase) jphase[slot] = (unsigned char)phase; if (jowner) jowner[slot] = owner; }
+    // which half of the split program (knot_body.h, split_task_is_model_free) emits a slot: 1 = the model-free half, 0 = the kinematic one
+    unsigned char owner = 0;
+    unsigned char* gowner = nullptr;   // [gs::COUNT] or null
+    unsigned char* jowner = nullptr;   // [js::COUNT] or null
     // the phase of the knot program (barriers passed) in which a slot gets its value: what is final after the second phase can leave early
     int phase = 0;
     unsigned char* gphase = nullptr;   // [gs::COUNT] or null
@@ -126,6 +130,7 @@ struct Layout {
     // array whose constants were filled once are then ONE contiguous run per knot.  IPOPT takes triplets in any order.
     bool vary_first = false;
     std::vector<unsigned char> gslot_phase, jslot_phase;   // [gs::COUNT], [js::COUNT]: phase of the knot program in which the slot gets its value (255: never)
+    std::vector<unsigned char> gslot_owner, jslot_owner;   // ... and the half of the split program that emits it (1: model-free, 0: kinematic; recorded)
     std::vector<unsigned char> jconst_slot;
     std::vector<unsigned char> jconst_pos[3];
     int nvary_v[3] = {0, 0, 0};
@@ -277,8 +282,12 @@ struct Layout {
             jslot_phase.assign(js::COUNT, 255);
             em.gphase = gslot_phase.data();
             em.jphase = jslot_phase.data();
+            gslot_owner.assign(gs::COUNT, 0);
+            jslot_owner.assign(js::COUNT, 0);
+            em.gowner = gslot_owner.data();
+            em.jowner = jslot_owner.data();
             Ctx<RecordEm> cx(*s, kt, ks, gp, ki, em);
-#define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
+#define HOST_R(w4, w8, fn, nt) cx.em.owner = split_task_is_model_free(#fn) ? 1 : 0; for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
 #define HOST_BAR cx.em.phase++;
             HIPNLP_KNOT_PROGRAM(HOST_R, HOST_BAR)
 #undef HOST_BAR

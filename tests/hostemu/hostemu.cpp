@@ -387,6 +387,58 @@ void hostemu_eval_range(const hostemu_handle* h, const double* x, const double* 
     delete s;
 }
 
+// The split program (knot_body.h, "Workgroup specialisation"): every knot evaluated by TWO passes on two scratches poisoned with NaN — one
+// runs the kinematic half of the task groups, the other the model-free half — and every output taken from the pass that owns it (slots of g
+// and jac g by the recorded owner of the slot, gradient entries and cost terms by the ownership rules).  A group of one half that read
+// scratch written by the other half, or an output both halves write, shows up as a NaN or a wrong bit against hostemu_eval.
+// Returns the number of outputs whose owner did not write them (still poison).
+int hostemu_eval_split(const hostemu_handle* h, const double* x, const double* p, double* f, double* grad, double* g, double* jac, double* cost_terms) {
+    const Layout& L = h->L;
+    const int N = L.N;
+    std::vector<double> pk(size_t(N) * PK_STRIDE);
+    GParams gp;
+    pack_params(p, N, pk.data(), gp);
+    for (int i = 0; i < NCT; ++i) cost_terms[i] = 0.0;
+    int unwritten = 0;
+    KnotScratch* half[2] = {new KnotScratch(), new KnotScratch()};
+    for (int k = 0; k < N; ++k) {
+        for (int q = 0; q < 2; ++q) {
+            KnotScratch* s = half[q];
+            std::fill(reinterpret_cast<double*>(s), reinterpret_cast<double*>(s) + sizeof(KnotScratch) / sizeof(double), std::nan(""));
+            for (int i = 0; i < XPAD; ++i) { s->x[i] = 0; s->xm[i] = 0; }
+            for (int i = 0; i < NPER; ++i) s->xo[i] = 0;
+            for (int i = 0; i < NXK; ++i) { s->x[i] = x[NXK * k + i]; s->xm[i] = k > 0 ? x[NXK * (k - 1) + i] : 0.0; }
+            for (int i = 0; i < NPER; ++i) s->xo[i] = k == 0 ? x[NXK * (N - 1) + periodicity_row_var(i)] : (k == N - 1 ? x[periodicity_row_var(i)] : 0.0);
+            for (int i = 0; i < NXG; ++i) s->xg[i] = x[NXK * N + i];
+            for (int i = 0; i < PK_STRIDE; ++i) s->pk[i] = pk[size_t(k) * PK_STRIDE + i];
+            KnotInfo ki{k, N, k == 0, k == N - 1};
+            ValueEm em{s->g, s->jac};
+            Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
+            const char* both = std::getenv("HOSTEMU_SPLIT_BOTH");   // debugging aid: a group run by BOTH halves (which group does the other half miss?)
+#define HOST_R(w4, w8, fn, nt) if (int(split_task_is_model_free(#fn)) == q || (both && split_same(#fn, both))) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
+            HIPNLP_KNOT_PROGRAM(HOST_R, )
+#undef HOST_R
+        }
+        const int v = L.variant_of(k);
+        const long jb = L.jac_base(k);
+        for (int i = 0; i < L.nnz_v[v]; ++i) { const int slot = L.jperm[v][size_t(i)]; jac[jb + i] = half[L.jslot_owner[size_t(slot)]]->jac[slot]; unwritten += std::isnan(jac[jb + i]); }
+        if (k == N - 1) for (size_t i = 0; i < L.jperm_glob.size(); ++i) { const int slot = L.jperm_glob[i]; jac[L.jac_glob_base + long(i)] = half[L.jslot_owner[size_t(slot)]]->jac[slot]; }
+        for (int slot = 0; slot < gs::COUNT; ++slot) {
+            const int a = L.g_a[v][size_t(slot)];
+            if (a != G_NONE) { g[a + L.g_b[size_t(slot)] * k] = half[L.gslot_owner[size_t(slot)]]->g[slot]; unwritten += std::isnan(half[L.gslot_owner[size_t(slot)]]->g[slot]); }
+        }
+        for (int i = 0; i < NXK; ++i) { grad[NXK * k + i] = half[split_grad_is_model_free(i) ? 1 : 0]->grad[i]; unwritten += std::isnan(grad[NXK * k + i]); }
+        for (int i = 0; i < NCT; ++i) { const double c = half[split_cost_is_model_free(i) ? 1 : 0]->cost[i]; cost_terms[i] += c; unwritten += std::isnan(c); }
+    }
+    for (int i = 0; i < NXG; ++i) grad[NXK * N + i] = 0.0;
+    delete half[0];
+    delete half[1];
+    double ft = 0.0;
+    for (int i = 0; i < NCT; ++i) ft += cost_terms[i];
+    *f = ft;
+    return unwritten;
+}
+
 void hostemu_eval(const hostemu_handle* h, const double* x, const double* p, double* f, double* grad, double* g, double* jac, double* cost_terms) {
     const Layout& L = h->L;
     const int N = L.N;

@@ -1328,3 +1328,44 @@ def test_sloped_step_tops_match_oracle(model, HipNlp, name, batch, horizon):
             e.set_params(p)
         assert all(np.array_equal(u, v) for u, v in zip(multi.eval(x), plain.eval(x)))
         assert np.array_equal(multi.eval_hess(x, 0.7, lam), plain.eval_hess(x, 0.7, lam))
+
+
+@pytest.mark.parametrize("maker,horizon,batch,vary_first", [(periodic_step_settings, 100, 1, False), (periodic_step_settings, 100, 1, True), (stairs_settings, 50, 2, False),
+                                                            (single_step_settings, 30, 4, True)])
+def test_two_workgroups_per_knot_give_the_one_workgroup_bits(model, maker, horizon, batch, vary_first):
+    """Workgroup specialisation (SPLIT instantiations of hipnlp_knot_kernel; knot_body.h "Workgroup specialisation"): device-resident
+    launches that leave half the CUs idle run the kinematic and the model-free half of the knot program on two workgroups per knot.
+    Scheduling only (the reference's list is unchanged: turnkey_planners/humanoid_kinodynamic/planner.py:124-176): f, grad f, g, jac g
+    are, bit for bit, those of the one-workgroup kernel (the diagnostic build's HIPNLP_SPLIT=0) — and those of the oracle to 1e-11."""
+    import torch
+    from diag_lib import diag_library, diag_overrides
+    from hippopt_amd.hipnlp import HipNlp
+    from oracle_lib import Oracle
+    st = maker(horizon, model)
+    x, p = make_workload(st, model, batch=batch, seed=8900 + horizon)
+    if st.terrain != 0:
+        place_on_step_flanks(x[:1], st, seed=3)
+    dev = torch.device("cuda", 0)
+    xd = torch.from_numpy(x).to(dev)
+    outs = {}
+    for split in (1, 0):
+        with diag_overrides(HIPNLP_SPLIT=split):
+            eng = HipNlp(st, model, batch=batch, jac_varying_first=vary_first, library=diag_library())
+        eng.set_params(p)
+        o = [torch.full((batch * k,), float("nan"), dtype=torch.float64, device=dev) for k in (1, eng.n, eng.m, eng.nnz)]
+        for _ in range(3):      # (the jac buffer of a varying-first handle receives its constants at first sight, the varying runs ever after)
+            eng.eval_device(xd.data_ptr(), *[t.data_ptr() for t in o])
+        torch.cuda.synchronize()
+        outs[split] = [t.cpu().numpy().reshape(batch, -1) for t in o]
+        names, terms = eng.cost_terms()
+        outs[split].append(terms)
+        eng.close()
+    for name, a, b in zip(("f", "grad", "g", "jac", "cost terms"), outs[1], outs[0]):
+        assert not np.isnan(a).any() and np.array_equal(a.view(np.uint64), b.view(np.uint64)), name
+    orc = Oracle(st, model)
+    ir, jc = orc.sparsity()
+    fo, grado, go, jaco = orc.eval(x[0], p[0])
+    f, grad, g, jac = (v[0] for v in outs[1][:4])
+    assert rel(f[0], fo) < TOL and rel(grad, grado) < TOL and rel(g, go) < TOL
+    if not vary_first:
+        assert rel(jac, jaco) < TOL
