@@ -580,7 +580,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
 #ifdef HIPNLP_STAMPS
     unsigned long long st_task[24];   // diagnostic build: the time every task group of this wave ends, in program order
     int st_nt = 0;
-#define DEV_R(w4, w8, fn, nt) if constexpr ((WAVES == 4 ? (w4) : (w8)) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
+#define DEV_R(w4, w8, fn, nt) if constexpr ((WAVES == 4 ? (w4) : (w8)) == W) { constexpr bool mf_ = split_task_is_model_free(#fn); if (!SPLIT || mf_ == wg_m) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); } if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
 #elif defined(HIPNLP_TASK_MARKS)
     // diagnostic compile (tools/diag/isa_tasks.sh: assembly only, never a library): comment markers around every task group, so that
     // tools/diag/isa_mix.py can say which task group carries how many instructions of which kind
@@ -1487,7 +1487,9 @@ static int create_handle(const hipnlp_desc* desc, hipnlp_handle** out, bool fron
             red_cap = st.terrain == HIPNLP_TERRAIN_PLANAR ? reducer_cap<KnotScratchT<LAYOUT_COMPACT, js::vary_slots(true)>>()
                                                           : reducer_cap<KnotScratchT<LAYOUT_COMPACT, js::vary_slots(false)>>();
         h->fused = h->nk <= red_cap && (h->wide || (small_launch && !(sep && std::atoi(sep) == 1)));
-        h->split = h->wide && h->fused && (2 * long(h->nk) + 1) * long(desc->batch) <= 256 &&
+        long split_max = 256;   // workgroups of a split launch: one per CU
+        if (const char* sm = diag_env("HIPNLP_SPLIT_MAX")) split_max = std::atol(sm);   // diagnostic: where the regime ends
+        h->split = h->wide && h->fused && (2 * long(h->nk) + 1) * long(desc->batch) <= split_max &&
                    st.final_state_type != HIPNLP_EXPR_MINIMIZE && st.periodicity_type != HIPNLP_EXPR_MINIMIZE;
         if (const char* sp = diag_env("HIPNLP_SPLIT")) h->split = h->split && std::atoi(sp) != 0;   // diagnostic override (A/B in one process)
         const char* hl = diag_env("HIPNLP_HESS_LAYOUT");   // diagnostic override: full | compact
@@ -1995,7 +1997,10 @@ static int launch(hipnlp_handle* h, const double* x_dev, double* f_dev, double* 
     hipEvent_t e2 = prof ? h->prof_ev[size_t(3 * h->prof_n + 2)] : h->ev1;
     if (run_first) { HIP_TRY(h, hipEventRecord(h->prof_ev[size_t(3 * h->prof_n)], s)); h->prof_open = true; }
 #ifdef HIPNLP_STAMPS
-    if (!h->d_stamps) HIP_TRY(h, hipMalloc(&h->d_stamps, 2 * size_t(h->nk) * size_t(h->batch) * 1024 * sizeof(unsigned long long)));   // (SPLIT launches: two workgroups per knot)
+    if (!h->d_stamps) {   // (SPLIT launches: two workgroups per knot)
+        HIP_TRY(h, hipMalloc(&h->d_stamps, 2 * size_t(h->nk) * size_t(h->batch) * 1024 * sizeof(unsigned long long)));
+        HIP_TRY(h, hipMemset(h->d_stamps, 0, 2 * size_t(h->nk) * size_t(h->batch) * 1024 * sizeof(unsigned long long)));
+    }
     a.stamps = h->d_stamps;
 #endif
     if (timed) HIP_TRY(h, hipEventRecord(e0, s));
@@ -3628,7 +3633,7 @@ int hipnlp_debug_stamps(hipnlp_handle* h, unsigned long long* out /*[nk*batch][4
     HIP_TRY(h, hipSetDevice(h->dev));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipnlp_internal_memcpy(out, h->d_stamps, size_t(h->nk) * size_t(h->batch) * 1024 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipnlp_internal_memcpy(out, h->d_stamps, 2 * size_t(h->nk) * size_t(h->batch) * 1024 * sizeof(unsigned long long), hipMemcpyDeviceToHost));   // (out: [2 nk batch][8][128])
     return HIPNLP_OK;
 }
 #endif

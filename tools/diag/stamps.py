@@ -50,9 +50,18 @@ if __name__ == "__main__":
     else:
         for _ in range(20):
             eng.eval(x)
-    out = np.zeros((100 * batch, 8, 128), np.uint64)
+    out = np.zeros((2 * 100 * batch, 8, 128), np.uint64)    # (room for the two workgroups per knot of a SPLIT launch)
     eng.lib.hipnlp_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
     eng.lib.hipnlp_debug_stamps(eng.h, out.ctypes.data_as(C.c_void_p))
+    # SPLIT launches (batch 1, device path): workgroups [0, 100) run the kinematic half of the program, [100, 200) the model-free half.
+    # STAMPS_HALF=k / m picks one half (default: k when the launch was split, the whole launch otherwise)
+    was_split = batch == 1 and bool(out[100:200, 0, 0].any())
+    half = os.environ.get("STAMPS_HALF", "k" if was_split else "")
+    if was_split:
+        print("SPLIT launch: %s workgroups" % ("kinematic" if half == "k" else "model-free"))
+        out = out[:100] if half == "k" else out[100:200]
+    else:
+        out = out[:100 * batch]
     which = int(os.environ.get('STAMPS_WG', len(out) // 2))
     if which < 0:   # the workgroup with the longest entry -> end
         nb_ = int(out[0, 0, 2])
