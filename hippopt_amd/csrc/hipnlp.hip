@@ -512,6 +512,8 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
             stage(&tb.head.ks, &tabs.head.ks, int(sizeof(KSettings)));
 #else
             stage(gp_p + b, &tabs.gp, int(sizeof(GParams)));
+            // (SPLIT: both halves stage every table.  The model-free half without the joint frames and link inertials it never reads — 5.2 of the
+            //  8.4 KB — measured no different: 7.47 - 7.54 against 7.46 - 7.48 us per 100-knot launch)
             stage(&tb.head, &tabs.head, int(sizeof(HeadTables)));
 #endif
         }
