@@ -77,3 +77,36 @@ def test_shards_that_read_only_their_ranges_tile_the_whole_evaluation(model, mak
         assert np.array_equal(got.view(np.uint64), ref.view(np.uint64)), name
     assert np.all(np.isfinite(cost))
     assert np.allclose(cost.sum(axis=0), ct, rtol=1e-14, atol=1e-14)
+
+
+def test_multi_create_refuses_bad_arguments_before_it_needs_a_device(model):
+    """hipnlp_multi_create validates the cut first (no device needed to be told); with a valid request and no device it fails as loudly as
+    hipnlp_create does — there is no CPU path behind either"""
+    import torch
+    from hippopt_amd import hipnlp
+    lib = hipnlp.load_library()
+    desc = _abi.DescC()
+    desc.settings, desc.model, desc.batch = periodic_step_settings(4, model).to_c(), model.to_c(), 1
+    h = C.c_void_p()
+
+    def create(devices, d=desc):
+        arr = (C.c_int32 * max(1, len(devices)))(*devices)
+        rc = lib.hipnlp_multi_create(C.byref(d), arr, len(devices), C.byref(h))
+        return rc, lib.hipnlp_last_error(None).decode()
+    rc, msg = create([])
+    assert rc == _abi.E_INVALID and "1 .. 64" in msg and not h.value
+    rc, msg = create([0] * 5)                       # five shards, four knots
+    assert rc == _abi.E_INVALID and "more devices than knots" in msg
+    part = _abi.DescC.from_buffer_copy(bytes(desc))
+    part.knot_begin, part.knot_end = 1, 3           # the library cuts the horizon itself
+    rc, msg = create([0, 0], part)
+    assert rc == _abi.E_INVALID and "whole horizon" in msg
+    old = _abi.DescC.from_buffer_copy(bytes(desc))
+    old.abi_version = _abi.ABI_VERSION - 1
+    rc, msg = create([0, 0], old)
+    assert rc == _abi.E_INVALID and "abi_version" in msg
+    if not torch.cuda.is_available():
+        rc, msg = create([0, 0])
+        assert rc == _abi.E_NODEVICE and "no CPU fallback" in msg and not h.value
+    n = C.c_int32(4)
+    assert lib.hipnlp_multi_info(None, C.byref(n), None, None, None, None) == _abi.E_INVALID
