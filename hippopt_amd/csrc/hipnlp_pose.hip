@@ -58,6 +58,9 @@ struct PArgs {
     const double* sigma;   // [batch]   objective factor
     const double* lambda;  // [batch][m]
     double* hess;          // [batch][hnnz]
+#ifdef HIPNLP_STAMPS
+    unsigned long long* stamps;   // diagnostic build only (tools/diag/pose_stamps.py): [batch][4 waves][64] s_memtime words
+#endif
 };
 
 template <int TERRAIN> struct PoseEm {
@@ -157,10 +160,18 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     __shared__ Scratch s;
     __shared__ PoseSharedT<Scratch::trimmed> tabs;
     static_assert(sizeof(Scratch) + sizeof(PoseSharedT<Scratch::trimmed>) <= 40960, "four workgroups per CU");
+#ifdef HIPNLP_STAMPS
+    const unsigned long long st_entry = __builtin_amdgcn_s_memtime();
+#endif
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = blockIdx.x;
     const PoseTables& tb = *a.tb;
     pose_stage(a, s, tabs, b, tid);
+#ifdef HIPNLP_STAMPS
+    const unsigned long long st_staged = __builtin_amdgcn_s_memtime();
+    unsigned long long st_arr[8], st_dep[8], st_task[24];
+    int st_nb = 0, st_nt = 0;
+#endif
     // copy-out tables (CCS permutation, g row map): fetched now, consumed at the very end
     constexpr int JP_ITERS = (POSE_MAX_NNZ + WG - 1) / WG, GR_ITERS = (gs::COUNT + WG - 1) / WG;
     int32_t jp[JP_ITERS], gr[GR_ITERS];
@@ -175,8 +186,13 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     Ctx<PoseEm<TERRAIN>> cx(s, tabs.kt, tabs.ks, tabs.gp, ki, em, &tb.head.kt, a.gp + b);   // (full tables: global memory)
     cx.hands = pose_hands(s, tabs);
     // (one contiguous program instance per wave, as in hipnlp_knot_kernel: no wave jumps over the other waves' code)
+#ifdef HIPNLP_STAMPS
+#define DEV_R(w, w8, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
+#define DEV_BARRIER st_arr[st_nb] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[st_nb] = __builtin_amdgcn_s_memtime(); st_nb++;
+#else
 #define DEV_R(w, w8, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_BARRIER lds_barrier();
+#endif
     auto run_wave = [&](auto wc) __attribute__((always_inline)) {
         constexpr int W = decltype(wc)::value;
         HIPNLP_POSE_PROGRAM(DEV_R, DEV_BARRIER)
@@ -210,6 +226,14 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     }
     const int anybad = pose_vote(tabs, bad, lane);
     if (tid == 0) a.flags[b] = anybad;
+#ifdef HIPNLP_STAMPS
+    if (a.stamps && lane == 0) {   // [0] entry [1] staged [2] barriers [3] task groups [4] end | [8 + 2 i] arrival at / [9 + 2 i] departure from barrier i | [32 + t] end of task group t
+        unsigned long long* o = a.stamps + (size_t(b) * 4 + wave) * 64;
+        o[0] = st_entry; o[1] = st_staged; o[2] = st_nb; o[3] = st_nt; o[4] = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < st_nb; ++i) { o[8 + 2 * i] = st_arr[i]; o[9 + 2 * i] = st_dep[i]; }
+        for (int i = 0; i < st_nt; ++i) o[32 + i] = st_task[i];
+    }
+#endif
 }
 
 // Exact Hessian of the Lagrangian (IPOPT eval_h, pose_hess_body.h): the pose program runs as in hipnlp_pose_kernel (its g / jac
@@ -226,6 +250,9 @@ void hipnlp_pose_hess_kernel(PArgs a) {
     Scratch& s = *reinterpret_cast<Scratch*>(s_raw);
     __shared__ PoseSharedT<Scratch::trimmed> tabs;
     __shared__ HessScratch hx;
+#ifdef HIPNLP_STAMPS
+    const unsigned long long st_entry = __builtin_amdgcn_s_memtime();
+#endif
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = blockIdx.x;
     const PoseTables& tb = *a.tb;
@@ -235,6 +262,11 @@ void hipnlp_pose_hess_kernel(PArgs a) {
     }
     if (tid == 0) hx.sigma = a.sigma[b];
     pose_stage(a, s, tabs, b, tid);
+#ifdef HIPNLP_STAMPS
+    const unsigned long long st_staged = __builtin_amdgcn_s_memtime();
+    unsigned long long st_arr[10], st_dep[10], st_task[24];
+    int st_nb = 0, st_nt = 0;
+#endif
 
     constexpr int HP_ITERS = (POSE_MAX_HNNZ + WG - 1) / WG;
     int32_t hp[HP_ITERS];
@@ -247,9 +279,15 @@ void hipnlp_pose_hess_kernel(PArgs a) {
     cx.hands = pose_hands(s, tabs);
     HCtx<PoseHessEm<TERRAIN>> hcx{cx, hx};
     // (one contiguous program instance per wave, as in hipnlp_knot_kernel: no wave jumps over the other waves' code)
+#ifdef HIPNLP_STAMPS
+#define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
+#define DEV_RH(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
+#define DEV_BARRIER st_arr[st_nb] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[st_nb] = __builtin_amdgcn_s_memtime(); st_nb++;
+#else
 #define DEV_KIN(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_RH(w, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(hcx, t_); }
 #define DEV_BARRIER lds_barrier();
+#endif
     auto run_wave = [&](auto wc) __attribute__((always_inline)) {
         constexpr int W = decltype(wc)::value;
         HIPNLP_POSE_HESS_PROGRAM(DEV_KIN, DEV_RH, DEV_BARRIER)
@@ -269,6 +307,14 @@ void hipnlp_pose_hess_kernel(PArgs a) {
     for (int it = 0; it < HP_ITERS; ++it) { const int e = tid + it * WG; if (e < hnnz) { const double v = hx.H[hp[it]]; bad |= !isfinite(v); out[e] = v; } }
     const int anybad = pose_vote(tabs, bad, lane);
     if (tid == 0) a.flags[b] = anybad;
+#ifdef HIPNLP_STAMPS
+    if (a.stamps && lane == 0) {
+        unsigned long long* o = a.stamps + (size_t(b) * 4 + wave) * 64;
+        o[0] = st_entry; o[1] = st_staged; o[2] = st_nb; o[3] = st_nt; o[4] = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < st_nb; ++i) { o[8 + 2 * i] = st_arr[i]; o[9 + 2 * i] = st_dep[i]; }
+        for (int i = 0; i < st_nt; ++i) o[32 + i] = st_task[i];
+    }
+#endif
 }
 
 thread_local std::string g_pose_create_error;
@@ -299,6 +345,9 @@ struct hipnlp_pose_handle {
     double *d_sigma = nullptr, *d_lambda = nullptr, *d_hess = nullptr, *h_sigma = nullptr, *h_lambda = nullptr, *h_hess = nullptr;
     std::vector<double> p;
     std::string err;
+#ifdef HIPNLP_STAMPS
+    unsigned long long* d_stamps = nullptr;   // diagnostic build only
+#endif
 };
 
 #define HIP_TRY(h, call)                                                                            \
@@ -331,6 +380,10 @@ static int pose_launch(hipnlp_pose_handle* h, const double* x_dev, double* f_dev
     a.tb = h->d_tb; a.x = x_dev; a.pk = h->d_pk; a.xr = h->d_xr; a.gp = h->d_gp;
     a.f = f_dev; a.grad = grad_dev; a.g = g_dev; a.jac = jac_dev;
     a.cost_terms = host_block ? h->hd_cost : h->d_cost; a.flags = host_block ? h->hd_flags : h->d_flags;
+#ifdef HIPNLP_STAMPS
+    if (!h->d_stamps) { HIP_TRY(h, hipMalloc(&h->d_stamps, size_t(h->batch) * 256 * sizeof(unsigned long long))); HIP_TRY(h, hipMemset(h->d_stamps, 0, size_t(h->batch) * 256 * sizeof(unsigned long long))); }
+    a.stamps = h->d_stamps;
+#endif
     if (timed) HIP_TRY(h, hipEventRecord(h->ev0, s));   // host-buffer path only (an event record drains the stream)
     if (h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR)
         hipLaunchKernelGGL(hipnlp_pose_kernel<HIPNLP_TERRAIN_PLANAR>, dim3(unsigned(h->batch)), dim3(WG), 0, s, a);
@@ -512,6 +565,10 @@ static int pose_hess_launch(hipnlp_pose_handle* h, const double* x_dev, const do
     a.tb = h->d_tb; a.x = x_dev; a.pk = h->d_pk; a.xr = h->d_xr; a.gp = h->d_gp;
     a.cost_terms = h->d_cost; a.flags = host_block ? h->hd_flags : h->d_flags;
     a.sigma = sigma_dev; a.lambda = lambda_dev; a.hess = hess_dev;
+#ifdef HIPNLP_STAMPS
+    if (!h->d_stamps) { HIP_TRY(h, hipMalloc(&h->d_stamps, size_t(h->batch) * 256 * sizeof(unsigned long long))); HIP_TRY(h, hipMemset(h->d_stamps, 0, size_t(h->batch) * 256 * sizeof(unsigned long long))); }
+    a.stamps = h->d_stamps;
+#endif
     if (timed) HIP_TRY(h, hipEventRecord(h->ev0, s));
     if (h->d.settings.terrain == HIPNLP_TERRAIN_PLANAR)
         hipLaunchKernelGGL(hipnlp_pose_hess_kernel<HIPNLP_TERRAIN_PLANAR>, dim3(unsigned(h->batch)), dim3(WG), 0, s, a);
@@ -608,5 +665,15 @@ int hipnlp_pose_last_kernel_ms(hipnlp_pose_handle* h, float* ms) {
     HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
     return HIPNLP_OK;
 }
+
+#ifdef HIPNLP_STAMPS
+int hipnlp_pose_debug_stamps(hipnlp_pose_handle* h, unsigned long long* out /*[batch][4][64]*/) {
+    if (!h || !out || !h->d_stamps) return HIPNLP_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->dev));
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipnlp_internal_memcpy(out, h->d_stamps, size_t(h->batch) * 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return HIPNLP_OK;
+}
+#endif
 
 }  // extern "C"
