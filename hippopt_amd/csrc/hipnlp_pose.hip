@@ -30,6 +30,7 @@ constexpr int WG = 256;
 constexpr int XR_STRIDE = 64;
 constexpr int POSE_MAX_NNZ = 1024;
 constexpr int POSE_MAX_HNNZ = hs::COUNT;
+constexpr int POSE_MAX_M = 256;   // one thread per row stages the multipliers (m = 89 .. 104 by mode)
 static_assert(XR_COUNT <= XR_STRIDE, "pose reference record");
 
 struct PoseTables {
@@ -40,6 +41,7 @@ struct PoseTables {
     int32_t hperm[POSE_MAX_HNNZ];
     int32_t hnnz, pad_;
     PoseHands hands;
+    int32_t row_slot[POSE_MAX_M];   // native g slot of row i (the inverse of g_row; -1 behind m): the Hessian kernel scatters the multipliers with it
 };
 
 struct PArgs {
@@ -58,6 +60,7 @@ struct PArgs {
     const double* sigma;   // [batch]   objective factor
     const double* lambda;  // [batch][m]
     double* hess;          // [batch][hnnz]
+    int32_t m;             // rows of one pose (a kernel argument: the address of a pose's multipliers does not wait for a table)
 #ifdef HIPNLP_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/diag/pose_stamps.py): [batch][4 waves][64] s_memtime words
 #endif
@@ -115,7 +118,8 @@ template <class S, class T> __device__ __forceinline__ PoseHands* pose_hands(S& 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // tables, parameters and the pose's variables -> LDS (ends with a workgroup barrier)
-template <class S, class T> __device__ __forceinline__ void pose_stage(const PArgs& a, S& s, T& tabs, int b, int tid) {
+struct PoseStageNoMid { __device__ __forceinline__ void operator()() const {} };
+template <class S, class T, class Mid = PoseStageNoMid> __device__ __forceinline__ void pose_stage(const PArgs& a, S& s, T& tabs, int b, int tid, Mid mid = Mid()) {
     const PoseTables& tb = *a.tb;
     // every global load in flight before the first LDS store waits for one (see hipnlp_knot_kernel).  Four pieces, as 8-byte words:
     // settings | lite kinematic tables (the KinLite prefix of the full ones) | lite parameters of this pose | hand tables
@@ -150,6 +154,7 @@ template <class S, class T> __device__ __forceinline__ void pose_stage(const PAr
     if (tid == 0) tabs.bad = 0;
     __syncthreads();
     if (tid < POSE_NX) s.x[pose_to_knot_col(tid)] = xval;
+    mid();   // (LDS stores of the caller that must follow stores it made before the call)
     __syncthreads();
 }
 
@@ -218,9 +223,9 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
         for (int it = 0; it < GR_ITERS; ++it) { const int slot = tid + it * WG; if (gr[it] >= 0) { const double v = s.g[slot]; bad |= !isfinite(v); out[gr[it]] = v; } }
     }
     if (a.grad && tid < POSE_NX) { const double v = s.grad[pose_to_knot_col(tid)]; bad |= !isfinite(v); a.grad[size_t(b) * POSE_NX + tid] = v; }
-    if (tid == 0) {
-        double tot = 0.0;
-        for (int t = 0; t < POSE_NCT; ++t) { const double v = pose_cost_term(s, t); tot += v; a.cost_terms[size_t(b) * POSE_NCT + t] = v; }
+    if (tid < POSE_NCT) a.cost_terms[size_t(b) * POSE_NCT + tid] = pose_cost_term(s, tid);
+    if (tid == 0) {   // (t_pose_cost_total: the nine terms in their order)
+        const double tot = s.cost[CT_POSE_TOTAL];
         bad |= !isfinite(tot);
         if (a.f) a.f[b] = tot;
     }
@@ -256,12 +261,16 @@ void hipnlp_pose_hess_kernel(PArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = blockIdx.x;
     const PoseTables& tb = *a.tb;
-    for (int slot = tid; slot < gs::COUNT; slot += WG) {
-        const int r = tb.g_row[slot];
-        hx.lam[slot] = r >= 0 ? a.lambda[size_t(b) * tb.m + r] : 0.0;
-    }
-    if (tid == 0) hx.sigma = a.sigma[b];
-    pose_stage(a, s, tabs, b, tid);
+    // the multiplier of every native g slot: thread i fetches the multiplier of ROW i and the slot that row lives in — two independent
+    // loads, in flight together with the staging loads below — and scatters it between the two barriers of the staging, over zeros.
+    // (Until round 6: slot -> row -> multiplier, two dependent round trips in front of the staging: 6.1 k cycles of a 21.8 k cycle pose.)
+    const int m = a.m;
+    double lam_i = 0.0, sig = 0.0;
+    int slot_i = -1;
+    if (tid < m) { lam_i = a.lambda[size_t(b) * m + tid]; slot_i = tb.row_slot[tid]; }
+    if (tid == 0) sig = a.sigma[b];
+    for (int slot = tid; slot < gs::COUNT; slot += WG) hx.lam[slot] = 0.0;
+    pose_stage(a, s, tabs, b, tid, [&]() { if (slot_i >= 0) hx.lam[slot_i] = lam_i; if (tid == 0) hx.sigma = sig; });
 #ifdef HIPNLP_STAMPS
     const unsigned long long st_staged = __builtin_amdgcn_s_memtime();
     unsigned long long st_arr[10], st_dep[10], st_task[24];
@@ -376,7 +385,7 @@ static void pose_free_all(hipnlp_pose_handle* h) {
 
 static int pose_launch(hipnlp_pose_handle* h, const double* x_dev, double* f_dev, double* grad_dev, double* g_dev, double* jac_dev, hipStream_t s,
                        bool timed, bool host_block = false) {
-    PArgs a;
+    PArgs a{};
     a.tb = h->d_tb; a.x = x_dev; a.pk = h->d_pk; a.xr = h->d_xr; a.gp = h->d_gp;
     a.f = f_dev; a.grad = grad_dev; a.g = g_dev; a.jac = jac_dev;
     a.cost_terms = host_block ? h->hd_cost : h->d_cost; a.flags = host_block ? h->hd_flags : h->d_flags;
@@ -421,6 +430,7 @@ int hipnlp_pose_create(const hipnlp_pose_desc* desc, hipnlp_pose_handle** out) {
     Layout::fill_terrain_tops(h->kt, st.terrain, st.n_terrain_steps, st.terrain_steps);
     if (!h->L.build(st, h->kt)) return fail(HIPNLP_E_INVALID, h->L.error);
     if (h->L.nnz > POSE_MAX_NNZ) return fail(HIPNLP_E_INVALID, "internal: pose pattern larger than POSE_MAX_NNZ");
+    if (h->L.m > POSE_MAX_M) return fail(HIPNLP_E_INVALID, "internal: more rows than POSE_MAX_M");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(HIPNLP_E_NODEVICE, "no HIP device available (the engine has no CPU fallback)");
@@ -466,6 +476,8 @@ int hipnlp_pose_create(const hipnlp_pose_desc* desc, hipnlp_pose_handle** out) {
     tb->head.ks = PoseLayout::make_ksettings(st);
     tb->hands = PoseLayout::make_hands(st);
     for (int s = 0; s < gs::COUNT; ++s) tb->g_row[s] = h->L.g_row[size_t(s)];
+    for (int r = 0; r < POSE_MAX_M; ++r) tb->row_slot[r] = -1;
+    for (int s = 0; s < gs::COUNT; ++s) if (h->L.g_row[size_t(s)] >= 0) tb->row_slot[h->L.g_row[size_t(s)]] = s;   // (PoseLayout::build: every row in exactly one slot)
     for (int e = 0; e < h->L.nnz; ++e) tb->jperm[e] = h->L.jperm[size_t(e)];
     tb->nnz = h->L.nnz; tb->m = h->L.m;
     for (int e = 0; e < h->L.hnnz; ++e) tb->hperm[e] = h->L.hperm[size_t(e)];
@@ -564,7 +576,7 @@ static int pose_hess_launch(hipnlp_pose_handle* h, const double* x_dev, const do
     PArgs a{};
     a.tb = h->d_tb; a.x = x_dev; a.pk = h->d_pk; a.xr = h->d_xr; a.gp = h->d_gp;
     a.cost_terms = h->d_cost; a.flags = host_block ? h->hd_flags : h->d_flags;
-    a.sigma = sigma_dev; a.lambda = lambda_dev; a.hess = hess_dev;
+    a.sigma = sigma_dev; a.lambda = lambda_dev; a.hess = hess_dev; a.m = h->L.m;
 #ifdef HIPNLP_STAMPS
     if (!h->d_stamps) { HIP_TRY(h, hipMalloc(&h->d_stamps, size_t(h->batch) * 256 * sizeof(unsigned long long))); HIP_TRY(h, hipMemset(h->d_stamps, 0, size_t(h->batch) * 256 * sizeof(unsigned long long))); }
     a.stamps = h->d_stamps;

@@ -73,39 +73,57 @@ template <class Em> HD void t_pose_points(Ctx<Em>& cx, int c) {
     }
 }
 
-// --- static balance (planner.py:487-509): lanes (c, e) 48 Jacobian entries, lanes 48..53 rows, lanes 54..59 com entries --------
-constexpr int POSE_BALANCE_TASKS = 60;
-template <class Em> HD void t_pose_balance(Ctx<Em>& cx, int t) {
+// where the point group runs: on the planar terrain (3.2 k cycles) beside the forward kinematics of the second phase, so that the first
+// phase is the joint transforms alone; on the smooth steps (7.4 k: the jets of the bumps) from the first instruction on
+template <class Em> HD void t_pose_points_first(Ctx<Em>& cx, int c) { if (!terrain_is_planar(cx)) t_pose_points(cx, c); }
+template <class Em> HD void t_pose_points_second(Ctx<Em>& cx, int c) { if (terrain_is_planar(cx)) t_pose_points(cx, c); }
+
+// --- static balance (planner.py:487-509) as three task groups (one group until round 6: its three branches ran one after the other on
+//     one wave and set the length of the first phase — 6.2 k cycles of a 21.7 k cycle pose at batch, tools/diag/pose_stamps.py).  None of
+//     them needs the robot model: they sit where the kinematic chain leaves a wave idle.
+//     entries: lanes (c, e) 48, the Jacobian entries in p_c and f_c -----------------------------------------------------------------
+constexpr int POSE_BALANCE_ENTRIES = 48, POSE_BALANCE_COM = 6;
+template <class Em> HD void t_pose_balance_entries(Ctx<Em>& cx, int t) {
     auto& s = cx.s;
     Em& em = cx.em;
     const double* com = s.x + COM_;
-    scratch_padding(s, t);
-    if (t < 48) {
-        const int c = t / 6, e = t - 6 * c, r = cross_row(e), q = cross_col(e), cb = PT_ * c;
-        const double* f = s.x + cb + F_;
-        const double a[3] = {s.x[cb + P_] - com[0], s.x[cb + P_ + 1] - com[1], s.x[cb + P_ + 2] - com[2]};
-        em.J(js::HDYN_ANG_P_OUT + 6 * c + e, row_id(RK_PBAL, 0, 3 + r), cb + P_ + q, -skew_entry(f, e));   // d (a x f)/d a = -[f]x
-        em.J(js::HDYN_ANG_F_OUT + 6 * c + e, row_id(RK_PBAL, 0, 3 + r), cb + F_ + q, skew_entry(a, e));    // d (a x f)/d f =  [a]x
-        if (e < 3) em.J(js::HDYN_LIN_F_OUT + 3 * c + e, row_id(RK_PBAL, 0, e), cb + F_ + e, 1.0);
-    } else if (t < 54) {
-        const int i = t - 48;
-        double acc = cx.gp.gravity[i];
-        for (int c = 0; c < NC; ++c) {
-            const int cb = PT_ * c;
-            if (i < 3) acc += s.x[cb + F_ + i];
-            else {
-                const double a[3] = {s.x[cb + P_] - com[0], s.x[cb + P_ + 1] - com[1], s.x[cb + P_ + 2] - com[2]};
-                acc += cross_comp(a, s.x + cb + F_, i - 3);
-            }
-        }
-        em.G(gs::HDYN + i, row_id(RK_PBAL, 0, i), acc);
-    } else {
-        const int e = t - 54, r = cross_row(e), q = cross_col(e);
-        double fs[3] = {0.0, 0.0, 0.0};
-        for (int c = 0; c < NC; ++c) for (int i = 0; i < 3; ++i) fs[i] += s.x[PT_ * c + F_ + i];
-        em.J(js::HDYN_ANG_COM_OUT + e, row_id(RK_PBAL, 0, 3 + r), COM_ + q, skew_entry(fs, e));   // d/d com = +[sum f]x
-    }
+    const int c = t / 6, e = t - 6 * c, r = cross_row(e), q = cross_col(e), cb = PT_ * c;
+    const double* f = s.x + cb + F_;
+    const double a[3] = {s.x[cb + P_] - com[0], s.x[cb + P_ + 1] - com[1], s.x[cb + P_ + 2] - com[2]};
+    em.J(js::HDYN_ANG_P_OUT + 6 * c + e, row_id(RK_PBAL, 0, 3 + r), cb + P_ + q, -skew_entry(f, e));   // d (a x f)/d a = -[f]x
+    em.J(js::HDYN_ANG_F_OUT + 6 * c + e, row_id(RK_PBAL, 0, 3 + r), cb + F_ + q, skew_entry(a, e));    // d (a x f)/d f =  [a]x
+    if (e < 3) em.J(js::HDYN_LIN_F_OUT + 3 * c + e, row_id(RK_PBAL, 0, e), cb + F_ + e, 1.0);
 }
+//     rows: the three force rows and the three moment rows as two groups of three lanes (as one group of six the two branches ran one after
+//     the other inside the loop over the points, every iteration waiting for its own LDS reads: 3.9 k cycles at batch) --------------------
+template <class Em> HD void t_pose_balance_rows_lin(Ctx<Em>& cx, int i) {
+    auto& s = cx.s;
+    double acc = cx.gp.gravity[i];
+    for (int c = 0; c < NC; ++c) acc += s.x[PT_ * c + F_ + i];
+    cx.em.G(gs::HDYN + i, row_id(RK_PBAL, 0, i), acc);
+}
+template <class Em> HD void t_pose_balance_rows_ang(Ctx<Em>& cx, int i) {
+    auto& s = cx.s;
+    const double* com = s.x + COM_;
+    double acc = cx.gp.gravity[3 + i];
+    for (int c = 0; c < NC; ++c) {
+        const int cb = PT_ * c;
+        const double a[3] = {s.x[cb + P_] - com[0], s.x[cb + P_ + 1] - com[1], s.x[cb + P_ + 2] - com[2]};
+        acc += cross_comp(a, s.x + cb + F_, i);
+    }
+    cx.em.G(gs::HDYN + 3 + i, row_id(RK_PBAL, 0, 3 + i), acc);
+}
+//     com entries: lane e (6) -------------------------------------------------------------------------------------------------------
+template <class Em> HD void t_pose_balance_com(Ctx<Em>& cx, int e) {
+    auto& s = cx.s;
+    Em& em = cx.em;
+    const int r = cross_row(e), q = cross_col(e);
+    double fs[3] = {0.0, 0.0, 0.0};
+    for (int c = 0; c < NC; ++c) for (int i = 0; i < 3; ++i) fs[i] += s.x[PT_ * c + F_ + i];
+    em.J(js::HDYN_ANG_COM_OUT + e, row_id(RK_PBAL, 0, 3 + r), COM_ + q, skew_entry(fs, e));   // d/d com = +[sum f]x
+}
+// identity / zero padding slots of the ancestor lists (first phase: the forward kinematics of the second reads them), lanes e < 16
+template <class Em> HD void t_kin_padding(Ctx<Em>& cx, int e) { scratch_padding(cx.s, e); }
 
 // --- joints: bound rows, e^T diag(w) e regularisation (planner.py:575-589), local joint transform.  lane j (23) --------------
 template <class Em> HD void t_pose_joints(Ctx<Em>& cx, int j) {
@@ -220,6 +238,28 @@ template <class Em> HD void pose_hand_rows(Ctx<Em>& cx, int t, int h) {
 template <class Em> HD void t_pose_hand_rows_l(Ctx<Em>& cx, int t) { pose_hand_rows(cx, t, 0); }
 template <class Em> HD void t_pose_hand_rows_r(Ctx<Em>& cx, int t) { pose_hand_rows(cx, t, 1); }
 
+// the three sums over the contact points among the cost terms (point position | force | average force regularisation: c_pt[.][k]), lane k (3),
+// in a phase behind t_pose_points on a wave the kinematic chain leaves idle — until round 6 the first thread of the workgroup added them
+// up, 24 dependent additions, between the last barrier and the copy-out.  Parked in cost slots no task of the pose program writes.
+static_assert(CT_SWING + 2 < CT_COMVEL && CT_UREG == CT_SWING + 1 && CT_FDREG == CT_SWING + 2, "three cost slots the pose program does not use");
+template <class Em> HD void t_pose_cost_sums(Ctx<Em>& cx, int k) {
+    auto& s = cx.s;
+    double a = 0.0;
+    for (int c = 0; c < NC; ++c) a += s.c_pt[c][k];
+    s.cost[CT_SWING + k] = a;
+}
+// the cost of the pose: the nine terms in their order, one lane, in a phase behind the last task that writes one of them (t_frames and
+// t_pose_hand_pts in the third) — the copy-out stores nine terms from nine lanes and this sum (until round 6 its first thread walked the
+// terms between the last barrier and its stores: 1.2 k of the 2.1 k cycles of the copy-out)
+constexpr int CT_POSE_TOTAL = CT_ENDS;
+static_assert(CT_POSE_TOTAL > CT_JREG && CT_POSE_TOTAL != CT_FRAMEQ && CT_POSE_TOTAL != CT_BASEQ, "a cost slot the pose program does not use");
+template <class S> HD double pose_cost_term(const S& s, int t);
+template <class Em> HD void t_pose_cost_total(Ctx<Em>& cx, int) {
+    auto& s = cx.s;
+    double tot = 0.0;
+    for (int t = 0; t < POSE_NCT; ++t) tot += pose_cost_term(s, t);
+    s.cost[CT_POSE_TOTAL] = tot;
+}
 // cost term t of the pose (order of hipnlp_pose_cost_term_name) from the scratch, after the program has run
 template <class S> HD double pose_cost_term(const S& s, int t) {
     switch (t) {
@@ -228,30 +268,31 @@ template <class S> HD double pose_cost_term(const S& s, int t) {
         case 2: return s.cost[CT_COMVEL];
         case 3: return s.cost[CT_JREG];
         case 7: case 8: return (&s.hd[0][0][0])[12 + (t - 7)];   // left / right hand position error (pose_hand_buf)
-        default: {
-            const int k = t == 4 ? 2 : (t == 5 ? 0 : 1);   // average force | point position | force
-            double a = 0.0;
-            for (int c = 0; c < NC; ++c) a += s.c_pt[c][k];
-            return a;
-        }
+        default: return s.cost[CT_SWING + (t == 4 ? 2 : (t == 5 ? 0 : 1))];   // average force | point position | force (t_pose_cost_sums)
     }
 }
 
 // The pose program: same notation as HIPNLP_KNOT_PROGRAM (always four waves: both role ids are the same).
+// The chain every pose waits for is joints / base -> forward kinematics -> links -> composites -> derivative columns -> consistency rows;
+// the task groups that need no robot model (contact rows, static balance, com / quaternion / joint costs) run beside it on the waves it
+// leaves idle (round 6: first phase 6.3 k -> 3 k cycles at batch; nothing of the values changes, only where a group runs).
 #define HIPNLP_POSE_PROGRAM(R, BARRIER)                                                   \
-    R(0, 0, t_pose_points, NC) R(1, 1, t_pose_balance, POSE_BALANCE_TASKS)                \
-    R(2, 2, t_pose_joints, NJ) R(2, 2, t_joint_cost, 1)                                   \
-    R(3, 3, t_base, 3) R(3, 3, t_pose_com, 4) R(3, 3, t_unitq, 1)                         \
+    R(0, 0, t_pose_points_first, NC)                                                      \
+    R(1, 1, t_pose_balance_rows_lin, 3) R(1, 1, t_pose_balance_rows_ang, 3) R(1, 1, t_pose_balance_com, POSE_BALANCE_COM) \
+    R(2, 2, t_pose_joints, NJ)                                                            \
+    R(3, 3, t_base, 3) R(3, 3, t_kin_padding, 16)                                         \
     BARRIER                                                                               \
     R(0, 0, t_fk_rot_a, FK_TASKS_A) R(0, 0, t_link_u_a, FK_SPLIT)                         \
+    R(1, 1, t_pose_points_second, NC)                                                     \
+    R(2, 2, t_joint_cost, 1) R(2, 2, t_pose_com, 4) R(2, 2, t_unitq, 1)                   \
     R(3, 3, t_fk_rot_b, FK_TASKS_B) R(3, 3, t_link_u_b, NJ - FK_SPLIT)                    \
     BARRIER                                                                               \
-    R(0, 0, t_links, NL) R(1, 1, t_frames, 3) R(2, 2, t_link_inertia, NL) R(3, 3, t_pose_hand_pts, 2) \
+    R(0, 0, t_links, NL) R(1, 1, t_frames, 3) R(2, 2, t_link_inertia, NL) R(3, 3, t_pose_hand_pts, 2) R(3, 3, t_pose_cost_sums, 3) \
     BARRIER                                                                               \
     R(0, 0, t_composite_g0, 64) R(1, 1, t_composite_g1, 64) R(1, 1, t_composite_g2, 64)   \
     R(2, 2, t_composite_g3, 64) R(2, 2, t_composite_g4, 64) R(3, 3, t_composite_g5, 64) R(3, 3, t_pkin, NC) \
     BARRIER                                                                               \
-    R(0, 0, t_columns, NJ + 3) R(2, 2, t_frame_columns, NJ)                               \
+    R(0, 0, t_columns, NJ + 3) R(1, 1, t_pose_balance_entries, POSE_BALANCE_ENTRIES) R(2, 2, t_frame_columns, NJ) R(3, 3, t_pose_cost_total, 1) \
     BARRIER                                                                               \
     R(0, 0, t_kinc, 3 * NC) R(1, 1, t_comc, 15) R(2, 2, t_kinc_s, NC * LEG_PATH) R(3, 3, t_feetd, 4) R(3, 3, t_pose_hand_rows_l, POSE_HAND_TASKS) R(3, 3, t_pose_hand_rows_r, POSE_HAND_TASKS) \
     BARRIER

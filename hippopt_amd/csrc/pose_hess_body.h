@@ -410,25 +410,26 @@ template <class Em> HD void t_hess_qq(HCtx<Em>& h, int t) {
 
 // The Hessian program of the pose finder.  KIN(w, fn, n) runs a task of knot_body.h, RH(w, fn, n) a Hessian task, on wave w of four.
 // Only the KINEMATIC part of the pose program runs (joint transforms, forward kinematics, link quantities, composites, contact-point
-// kinematics: none of the rows / Jacobian columns); the Hessian tasks that need no kinematics sit on the waves its first phase leaves idle.
-template <class Em> HD void t_kin_padding(Ctx<Em>& cx, int e) { scratch_padding(cx.s, e); }
+// kinematics: none of the rows / Jacobian columns); the Hessian tasks that need no kinematics sit on the waves the forward kinematics
+// of the second phase leaves idle (round 6: the first phase is the joint transforms and the base alone), the hand block beside Y / (q, q).
 // the related joint-pair lanes in two ranges on two waves
 constexpr int HESS_SS_SPLIT = 2 * 64;
 template <class Em> HD void t_hess_ss_a(HCtx<Em>& h, int t) { t_hess_ss(h, t); }
 template <class Em> HD void t_hess_ss_b(HCtx<Em>& h, int t) { t_hess_ss(h, t + HESS_SS_SPLIT); }
 #define HIPNLP_POSE_HESS_PROGRAM(KIN, RH, BARRIER)                                                                \
-    KIN(0, t_joints, NJ) KIN(1, t_base, 3) KIN(1, t_kin_padding, 16) RH(2, t_hess_point, NC) RH(3, t_hess_misc, HESS_MISC_TASKS) \
+    KIN(0, t_joints, NJ) KIN(1, t_base, 3) KIN(1, t_kin_padding, 16)                                              \
     BARRIER                                                                                                       \
-    KIN(0, t_fk_rot_a, FK_TASKS_A) KIN(0, t_link_u_a, FK_SPLIT) KIN(3, t_fk_rot_b, FK_TASKS_B) KIN(3, t_link_u_b, NJ - FK_SPLIT) \
+    KIN(0, t_fk_rot_a, FK_TASKS_A) KIN(0, t_link_u_a, FK_SPLIT) RH(1, t_hess_misc, HESS_MISC_TASKS) RH(2, t_hess_point, NC) \
+    KIN(3, t_fk_rot_b, FK_TASKS_B) KIN(3, t_link_u_b, NJ - FK_SPLIT)                                              \
     BARRIER                                                                                                       \
     KIN(0, t_links, NL) KIN(1, t_frames, 3) KIN(2, t_link_inertia, NL) KIN(3, t_pose_hand_pts, 2)                 \
     BARRIER                                                                                                       \
     KIN(0, t_composite_g0, 64) KIN(1, t_composite_g1, 64) KIN(1, t_composite_g2, 64)                              \
     KIN(2, t_composite_g3, 64) KIN(2, t_composite_g4, 64) KIN(3, t_composite_g5, 64) KIN(3, t_pkin, NC)           \
     BARRIER                                                                                                       \
-    RH(2, t_hess_Y, NJ) RH(3, t_hess_qq, 10)                                                                      \
+    RH(0, t_hess_hand, HESS_HAND_TASKS) RH(2, t_hess_Y, NJ) RH(3, t_hess_qq, 10)                                  \
     BARRIER                                                                                                       \
-    RH(0, t_hess_ss_a, HESS_SS_SPLIT) RH(3, t_hess_ss_b, HESS_SS_TASKS - HESS_SS_SPLIT) RH(1, t_hess_qs, 4 * NJ) RH(2, t_hess_hand, HESS_HAND_TASKS) \
+    RH(0, t_hess_ss_a, HESS_SS_SPLIT) RH(3, t_hess_ss_b, HESS_SS_TASKS - HESS_SS_SPLIT) RH(1, t_hess_qs, 4 * NJ)  \
     BARRIER
 
 }  // namespace hipnlp

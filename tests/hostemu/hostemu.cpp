@@ -570,7 +570,8 @@ void hostemu_pose_eval(const hostemu_pose_handle* h, const double* x, const doub
     for (int i = 0; i < POSE_NX; ++i) grad[i] = s->grad[pose_to_knot_col(i)];
     double ft = 0.0;
     for (int t = 0; t < POSE_NCT; ++t) { cost_terms[t] = pose_cost_term(*s, t); ft += cost_terms[t]; }
-    *f = ft;
+    (void)ft;
+    *f = s->cost[CT_POSE_TOTAL];   // (t_pose_cost_total: the kernel's f — NaN if the task ran before a term it adds was written)
     delete s;
 }
 void hostemu_pose_hess_dims(const hostemu_pose_handle* h, int* hnnz) { *hnnz = h->L.hnnz; }

@@ -7,6 +7,9 @@ import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+from hippopt_amd import hipnlp as _hipnlp
+if os.environ.get("POSE_LIB"):   # another build of the library (diagnostic A/B)
+    _hipnlp._LIB_PATH = os.path.join(ROOT, os.environ["POSE_LIB"])
 from hippopt_amd.hipnlp import HipPose
 from hippopt_amd.pose_settings import make_pose_workload, pose_finder_settings
 from hippopt_amd.robot_model import synthetic_ergocub
