@@ -68,6 +68,7 @@ struct PArgs {
 
 template <int TERRAIN> struct PoseEm {
     static constexpr int kTerrain = TERRAIN;
+    static constexpr bool kStatic = true;   // (knot_body.h em_static: the velocities of a pose are zero)
     using Scratch = KnotScratchT<LAYOUT_COMPACT, js::PV0 + NC * js::pt_stride(TERRAIN == HIPNLP_TERRAIN_PLANAR)>;   // (PoseScratchT below)
     double* g;
     double* jac;
@@ -77,7 +78,8 @@ template <int TERRAIN> struct PoseEm {
 
 template <int TERRAIN> struct PoseHessEm {
     static constexpr int kTerrain = TERRAIN;
-    using Scratch = KnotScratchT<LAYOUT_COMPACT, js::PV0 + NC * js::pt_stride(TERRAIN == HIPNLP_TERRAIN_PLANAR)>;
+    static constexpr bool kStatic = true;
+    using Scratch = KnotScratchT<LAYOUT_COMPACT_NOG, js::PV0 + NC * js::pt_stride(TERRAIN == HIPNLP_TERRAIN_PLANAR)>;   // (no row, no gradient entry is emitted: neither staging exists)
     double* g;
     double* jac;
     double* h;
@@ -211,21 +213,30 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
 #undef DEV_R
 #undef DEV_BARRIER
 
+    // copy-out: every LDS read in flight before the first store (as read -> wait -> store per piece, behind a branch each, the eight
+    // pieces went one after the other: 2.3 k cycles at batch against 0.9 k in the Hessian kernel, which has two)
     int bad = 0;
+    double jv[JP_ITERS], gv[GR_ITERS];
+#pragma unroll
+    for (int it = 0; it < JP_ITERS; ++it) jv[it] = s.jac[jp[it]];                    // (behind nnz the table holds slot 0)
+#pragma unroll
+    for (int it = 0; it < GR_ITERS; ++it) gv[it] = s.g[gr[it] >= 0 ? tid + it * WG : 0];
+    const double gradv = s.grad[pose_to_knot_col(tid < POSE_NX ? tid : 0)];
+    const double costv = pose_cost_terms_out(s)[tid < POSE_NCT ? tid : 0];           // (t_pose_cost_total: the nine terms side by side)
+    const double tot = s.cost[CT_POSE_TOTAL];                                         // (and their sum, in their order)
     if (a.jac) {
         double* out = a.jac + size_t(b) * nnz;
 #pragma unroll
-        for (int it = 0; it < JP_ITERS; ++it) { const int e = tid + it * WG; if (e < nnz) { const double v = s.jac[jp[it]]; bad |= !isfinite(v); out[e] = v; } }
+        for (int it = 0; it < JP_ITERS; ++it) { const int e = tid + it * WG; if (e < nnz) { bad |= !isfinite(jv[it]); out[e] = jv[it]; } }
     }
     if (a.g) {
         double* out = a.g + size_t(b) * m;
 #pragma unroll
-        for (int it = 0; it < GR_ITERS; ++it) { const int slot = tid + it * WG; if (gr[it] >= 0) { const double v = s.g[slot]; bad |= !isfinite(v); out[gr[it]] = v; } }
+        for (int it = 0; it < GR_ITERS; ++it) if (gr[it] >= 0) { bad |= !isfinite(gv[it]); out[gr[it]] = gv[it]; }
     }
-    if (a.grad && tid < POSE_NX) { const double v = s.grad[pose_to_knot_col(tid)]; bad |= !isfinite(v); a.grad[size_t(b) * POSE_NX + tid] = v; }
-    if (tid < POSE_NCT) a.cost_terms[size_t(b) * POSE_NCT + tid] = pose_cost_term(s, tid);
-    if (tid == 0) {   // (t_pose_cost_total: the nine terms in their order)
-        const double tot = s.cost[CT_POSE_TOTAL];
+    if (a.grad && tid < POSE_NX) { bad |= !isfinite(gradv); a.grad[size_t(b) * POSE_NX + tid] = gradv; }
+    if (tid < POSE_NCT) a.cost_terms[size_t(b) * POSE_NCT + tid] = costv;
+    if (tid == 0) {
         bad |= !isfinite(tot);
         if (a.f) a.f[b] = tot;
     }
@@ -245,13 +256,15 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
 // values stay in LDS, unused), the Hessian tasks run behind it and the workgroup streams out the lower-triangle CCS value run.
 // The Hessian program runs none of the tasks that emit Jacobian entries: the jac staging area (the last 13.8 / 15.7 KB of the scratch) is
 // not allocated.
-// Workgroups per CU: the LDS (35.4 / 35.9 KB with the compact scratch and the lite tables) allows four; the planar kernel fits the 128
-// registers that takes (126, no scratch), the smooth terrain's spills 60 B per lane there and stays at three (150 VGPRs).
-template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(TERRAIN == HIPNLP_TERRAIN_PLANAR ? 4 : 3, TERRAIN == HIPNLP_TERRAIN_PLANAR ? 4 : 3)))
+// Workgroups per CU (round 6): the scratch ends in front of the gradient and carries no staging of g (the Hessian program emits neither), the
+// (q_b, q_b) block is formed by three small task groups instead of one that held 124 registers: 31.0 KB and 92 VGPRs on the planar terrain ->
+// FIVE workgroups per CU (25 granules of 1 280 B, 96 registers); the smooth terrain's kernel (158 VGPRs for the second-order jets) stays at three.
+template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(TERRAIN == HIPNLP_TERRAIN_PLANAR ? 5 : 3, TERRAIN == HIPNLP_TERRAIN_PLANAR ? 5 : 3)))
 void hipnlp_pose_hess_kernel(PArgs a) {
-    using Scratch = PoseScratchT<TERRAIN>;
-    static_assert(offsetof(Scratch, jac) + sizeof(Scratch::jac) + 16 > sizeof(Scratch), "jac is the last member of the scratch (up to tail padding)");
-    __shared__ alignas(16) double s_raw[offsetof(Scratch, jac) / sizeof(double)];
+    using Scratch = typename PoseHessEm<TERRAIN>::Scratch;
+    static_assert(offsetof(Scratch, jac) + sizeof(Scratch::jac) + 16 > sizeof(Scratch) && offsetof(Scratch, grad) + sizeof(Scratch::grad) == offsetof(Scratch, jac),
+                  "grad and jac are the last two members of the scratch (up to tail padding)");
+    __shared__ alignas(16) double s_raw[offsetof(Scratch, grad) / sizeof(double)];
     Scratch& s = *reinterpret_cast<Scratch*>(s_raw);
     __shared__ PoseSharedT<Scratch::trimmed> tabs;
     __shared__ HessScratch hx;
@@ -283,7 +296,7 @@ void hipnlp_pose_hess_kernel(PArgs a) {
     for (int it = 0; it < HP_ITERS; ++it) { const int e = tid + it * WG; hp[it] = e < POSE_MAX_HNNZ ? tb.hperm[e] : 0; }   // (copy-out permutation, consumed at the end)
     const int hnnz = tb.hnnz;
     KnotInfo ki{1, 3, 0, 0};
-    PoseHessEm<TERRAIN> em{s.g, nullptr, hx.H};   // (no task of the Hessian program emits a Jacobian entry)
+    PoseHessEm<TERRAIN> em{nullptr, nullptr, hx.H};   // (no task of the Hessian program emits a row or a Jacobian entry)
     Ctx<PoseHessEm<TERRAIN>> cx(s, tabs.kt, tabs.ks, tabs.gp, ki, em, &tb.head.kt, a.gp + b);
     cx.hands = pose_hands(s, tabs);
     HCtx<PoseHessEm<TERRAIN>> hcx{cx, hx};

@@ -88,9 +88,9 @@ HD constexpr int jr_pos(int, int e) { return e; }   // physical position of logi
 //                          * the tables that are read once per knot — joint frames (phase A), link inertials (phase C) — and the
 //                            horizon-end tables (first / last knot) are not staged into LDS at all: the lanes that need them read
 //                            them from global memory (parking them in comp[] instead measured 1.4 % slower).
-constexpr int LAYOUT_FULL = 0, LAYOUT_COMPACT = 1;
-template <bool COMPACT> struct ScratchJrOwn;
-template <> struct ScratchJrOwn<false> {
+constexpr int LAYOUT_FULL = 0, LAYOUT_COMPACT = 1, LAYOUT_COMPACT_NOG = 2 /* compact, and no staging of g: the pose finder's Hessian kernel, whose program emits no row */;
+template <int LAYOUT> struct ScratchJrOwn;
+template <> struct ScratchJrOwn<LAYOUT_FULL> {
     JointRec Jr[NJ + 1];
     union {  // own[] is dead once the composites are formed; the (rare) minimize-mode end terms reuse its space
         double own[NL + 1][LSTR];  // per link, same layout as comp; slot NL = 0 (padding of the descendant lists)
@@ -98,13 +98,20 @@ template <> struct ScratchJrOwn<false> {
     };
     double g[gs::COUNT];
 };
-template <> struct ScratchJrOwn<true> {
+template <> struct ScratchJrOwn<LAYOUT_COMPACT> {
     union {
         JointRec Jr[NJ + 1];
         double own[NL + 1][LSTR];
         EndTerms ends;
     };
     double g[gs::FIN];   // slots >= gs::FIN (horizon-end rows) are ends.c[slot - gs::FIN]
+};
+template <> struct ScratchJrOwn<LAYOUT_COMPACT_NOG> {
+    union {
+        JointRec Jr[NJ + 1];
+        double own[NL + 1][LSTR];
+        EndTerms ends;
+    };
 };
 // (compact layout: own[] lies ON the joint records, its zero slot own[NL] on the last two of them — written with the rest of own[], by
 //  t_links in the third phase, when the forward kinematics has read the records)
@@ -117,7 +124,7 @@ template <bool HAS> struct ScratchHd { double hd[2][NC][6]; };
 template <> struct ScratchHd<false> {};
 // JSLOTS: slots of the Jacobian staging `jac` (default: all of them).  A VARY kernel (hipnlp.hip) keeps the slots behind js::V0 only —
 // js::vary_slots(terrain) of them — and addresses them through a pointer moved back by js::V0.
-template <int LAYOUT, int JSLOTS = js::COUNT> struct alignas(16) KnotScratchT : ScratchJrOwn<LAYOUT != LAYOUT_FULL>, ScratchXo<JSLOTS == js::COUNT>,
+template <int LAYOUT, int JSLOTS = js::COUNT> struct alignas(16) KnotScratchT : ScratchJrOwn<LAYOUT>, ScratchXo<JSLOTS == js::COUNT>,
                                                                                  ScratchHd<JSLOTS != js::vary_slots(false)> {
     static constexpr int layout = LAYOUT;
     static constexpr bool compact = LAYOUT != LAYOUT_FULL;
@@ -1000,6 +1007,13 @@ template <class Em> HD void t_base(Ctx<Em>& cx, int e) {
 // Forward kinematics and link velocities as ANCESTOR SUMS: lane (joint j, component r), 69 tasks per pass.
 // Every lane walks its own (padded) ancestor list, so no lane waits for another one inside a pass; the passes
 // run back to back on one wave (HIPNLP_WAVE_SYNC between them).
+// Emitters of a STATIC problem (Em::kStatic: the pose finder's device kernels — every velocity of the knot record is zero): the kinematic
+// tasks leave out what only the velocities feed — link angular velocities and origin velocities, link / subtree momenta, the
+// velocity-product columns — and what reads them.  No value the pose finder emits depends on any of it (the host recorders and the
+// emulation run the full tasks on the zero velocities: same outputs).
+template <class Em, class = void> struct em_static_t { static constexpr bool value = false; };
+template <class Em> struct em_static_t<Em, std::void_t<decltype(Em::kStatic)>> { static constexpr bool value = Em::kStatic; };
+template <class Em> constexpr bool em_static = em_static_t<Em>::value;
 constexpr int FK_TASKS_A = 3 * FK_SPLIT, FK_TASKS_B = 3 * (NJ - FK_SPLIT);
 template <class Em> HD void t_fk_rot_at(Ctx<Em>& cx, int t, int q0) {
     // lane (joint j, component r) walks the front-padded ancestor list of j ONCE and accumulates, for its component r:
@@ -1034,7 +1048,7 @@ template <class Em> HD void t_fk_rot_at(Ctx<Em>& cx, int t, int q0) {
         const double* cc = rq + JR_C;
         o += v0 * of[0] + v1 * of[1] + v2 * of[2];
         ar = v0 * cc[0] + v1 * cc[1] + v2 * cc[2];   // (row r of R_parent) . (R_fix axis) = (row r of R_a) . axis
-        w += ar * rq[JR_SD];
+        if constexpr (!em_static<Em>) w += ar * rq[JR_SD];
         const double n0 = v0 * L[0] + v1 * L[3] + v2 * L[6];
         const double n1 = v0 * L[1] + v1 * L[4] + v2 * L[7];
         const double n2 = v0 * L[2] + v1 * L[5] + v2 * L[8];
@@ -1048,7 +1062,7 @@ template <class Em> HD void t_fk_rot_at(Ctx<Em>& cx, int t, int q0) {
     s.Rw[j2 + 1][3 * r2] = v0; s.Rw[j2 + 1][3 * r2 + 1] = v1; s.Rw[j2 + 1][3 * r2 + 2] = v2;
     s.aw[j2][r2] = ar;
     s.ow[j2 + 1][r2] = o;
-    s.wv[j2 + 1][r2] = w;
+    if constexpr (!em_static<Em>) s.wv[j2 + 1][r2] = w;
 }
 template <class Em> HD void t_fk_rot_a(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t, HIPNLP_UNIFORM(cx.kt.fk_first[0])); }
 template <class Em> HD void t_fk_rot_b(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t + FK_TASKS_A, HIPNLP_UNIFORM(cx.kt.fk_first[1])); }
@@ -1066,6 +1080,7 @@ template <class Em> HD void t_fk_rot_b(Ctx<Em>& cx, int t) { t_fk_rot_at(cx, t +
 // velocity of the body point of link i at the (base-centred) origin: vO_i = sum over the joints a on the path root -> i of
 // U_a = (o_a x a_a) sdot_a.  t_link_u (lane j) forms U_j, t_links (same wave, behind it) sums the ancestors' (padding: U_NJ = 0)
 template <class Em> HD void t_link_u(Ctx<Em>& cx, int j) {
+    if constexpr (em_static<Em>) { (void)cx; (void)j; return; }
     auto& s = cx.s;
     HIPNLP_WAVE_SYNC();   // o_j, a_j: components written by three lanes of this wave (t_fk_rot_a / _b)
     double u[3];
@@ -1244,6 +1259,15 @@ template <class Em> HD void t_links(Ctx<Em>& cx, int i) {
     auto& s = cx.s;
     const double m = kin_mass(cx, i);
     if (i < 16) s.own[NL][i] = 0.0;   // the zero slot of the descendant lists (scratch_padding)
+    if constexpr (em_static<Em>) {    // mass and first moment only (the momenta are zero and nothing reads them)
+        const double* R = s.Rw[i];
+        double c[3];
+        matvec3(R, kin_com(cx, i), c);
+        double* cp = s.own[i];
+        cp[CM] = m;
+        for (int r = 0; r < 3; ++r) cp[CH + r] = m * (c[r] + s.ow[i][r]);
+        return;
+    }
     double vo[3];
     link_origin_velocity(s, cx.kt, i, vo);
     for (int r = 0; r < 3; ++r) s.vo[i][r] = vo[r];
@@ -1319,6 +1343,7 @@ static_assert(NL * 16 == 6 * 64, "six wave iterations of composite tasks (16 use
 template <class Em> HD void t_composite(Ctx<Em>& cx, int t) {
     auto& s = cx.s;
     const int i = cx.kt.comp_order[t >> 4], r = t & 15;
+    if constexpr (em_static<Em>) { if (r >= CKL) return; }   // (subtree momenta: not formed, not read)
     // trip count of the wave iteration = largest subtree among its four links (uniform: scalar loop); shorter lists are padded
     // with the zero slot own[NL]
     const int cnt = HIPNLP_UNIFORM(int(cx.kt.comp_cnt[t >> 6]));
@@ -1370,6 +1395,19 @@ template <class Em> HD void t_pkin(Ctx<Em>& cx, int c) {
 template <class Em> HD void t_columns(Ctx<Em>& cx, int t) {
     auto& s = cx.s;
     Em& em = cx.em;
+    if constexpr (em_static<Em>) {   // the com columns alone: d com / d s_j = a_j x (h_sub - m_sub o_j) / M
+        const double inv_M = cx.kt.inv_total_mass;
+        if (t == 0) for (int r = 0; r < 3; ++r) s.com[r] = s.comp[0][CH + r] * inv_M;
+        if (t < NJ) {
+            const int i = t + 1;
+            const double cm = s.comp[i][CM];
+            double a[3], t1[3], dcom[3];
+            for (int r = 0; r < 3; ++r) { a[r] = s.aw[t][r]; t1[r] = s.comp[i][CH + r] - cm * s.ow[i][r]; }
+            cross3(a, t1, dcom);
+            for (int r = 0; r < 3; ++r) em.J(js::COMC_S + NJ * r + t, row_id(RK_COMC, 0, r), S_ + t, -(dcom[r] * inv_M));
+        }
+        return;
+    }
     const double inv_M = cx.kt.inv_total_mass, inv_mass = 1.0 / cx.gp.mass;
     // totals of the whole tree (every lane needs them; lane 0 publishes them for the row assembly)
     double com[3], klin[3], kang[3], t1[3], t2[3];

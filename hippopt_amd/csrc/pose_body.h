@@ -254,11 +254,15 @@ template <class Em> HD void t_pose_cost_sums(Ctx<Em>& cx, int k) {
 constexpr int CT_POSE_TOTAL = CT_ENDS;
 static_assert(CT_POSE_TOTAL > CT_JREG && CT_POSE_TOTAL != CT_FRAMEQ && CT_POSE_TOTAL != CT_BASEQ, "a cost slot the pose program does not use");
 template <class S> HD double pose_cost_term(const S& s, int t);
+// (the nine terms once more, side by side, for the copy-out: on the per-point partials c_pt[0..2][], which t_pose_cost_sums has consumed)
+template <class S> HD auto pose_cost_terms_out(S& s) -> decltype(&s.c_pt[0][0]) { return &s.c_pt[0][0]; }
+static_assert(POSE_NCT <= 3 * NC, "the terms fit on the point partials");
 template <class Em> HD void t_pose_cost_total(Ctx<Em>& cx, int) {
     auto& s = cx.s;
-    double tot = 0.0;
-    for (int t = 0; t < POSE_NCT; ++t) tot += pose_cost_term(s, t);
+    double tot = 0.0, v[POSE_NCT];
+    for (int t = 0; t < POSE_NCT; ++t) { v[t] = pose_cost_term(s, t); tot += v[t]; }
     s.cost[CT_POSE_TOTAL] = tot;
+    for (int t = 0; t < POSE_NCT; ++t) pose_cost_terms_out(s)[t] = v[t];
 }
 // cost term t of the pose (order of hipnlp_pose_cost_term_name) from the scratch, after the program has run
 template <class S> HD double pose_cost_term(const S& s, int t) {
@@ -277,8 +281,8 @@ template <class S> HD double pose_cost_term(const S& s, int t) {
 // the task groups that need no robot model (contact rows, static balance, com / quaternion / joint costs) run beside it on the waves it
 // leaves idle (round 6: first phase 6.3 k -> 3 k cycles at batch; nothing of the values changes, only where a group runs).
 #define HIPNLP_POSE_PROGRAM(R, BARRIER)                                                   \
-    R(0, 0, t_pose_points_first, NC)                                                      \
-    R(1, 1, t_pose_balance_rows_lin, 3) R(1, 1, t_pose_balance_rows_ang, 3) R(1, 1, t_pose_balance_com, POSE_BALANCE_COM) \
+    R(0, 0, t_pose_points_first, NC) R(0, 0, t_pose_balance_rows_ang, 3)                  \
+    R(1, 1, t_pose_balance_rows_lin, 3) R(1, 1, t_pose_balance_com, POSE_BALANCE_COM)     \
     R(2, 2, t_pose_joints, NJ)                                                            \
     R(3, 3, t_base, 3) R(3, 3, t_kin_padding, 16)                                         \
     BARRIER                                                                               \

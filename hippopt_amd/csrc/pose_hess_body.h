@@ -44,7 +44,9 @@ constexpr int COUNT = SPB + 3 * NJ;
 struct HessScratch {
     double lam[gs::COUNT];   // multiplier of the row a native g slot belongs to (0 for slots without a row)
     double sigma, pad_;
-    double Y[NJ][3];
+    double Y[NJ][3];         // Y_j, the share of the com / hand / chest terms (t_hess_Y_a)
+    double Y2[NJ][3];        //      the share of the contact points of the leg the joint belongs to (t_hess_Y_b); zero for the other joints
+    double qq[24];           // (q_b, q_b) in three steps: [0..8] Mw, [9..17] M = Mw R_b, [18..20] ax(E), [21] tr E - 3
     double H[hs::COUNT];
 };
 
@@ -249,7 +251,8 @@ template <class Em> HD void t_hess_hand(HCtx<Em>& h, int t) {
 
 // --- Y_j = d/d theta [ dL/ds_j ]  (theta: world-frame rotation of the base), lane j (23) -------------------------------------------
 //   L = sum_c w_c . pkin_c + w_com . com_kin + sigma m (tr E - 3)^2,   w_c = -lambda(kinematics consistency), w_com = -lambda(com consistency)
-template <class Em> HD void t_hess_Y(HCtx<Em>& h, int j) {
+//   In two groups on two waves (one group until round 6: 2.9 k cycles of the 3.6 k cycle phase it shares with (q_b, q_b)); the consumers add the two.
+template <class Em> HD void t_hess_Y_a(HCtx<Em>& h, int j) {
     Ctx<Em>& cx = h.cx;
     auto& s = cx.s;
     const double* lam = h.hx.lam;
@@ -264,17 +267,6 @@ template <class Em> HD void t_hess_Y(HCtx<Em>& h, int j) {
         const double w[3] = {-lam[gs::COMC], -lam[gs::COMC + 1], -lam[gs::COMC + 2]};
         cross3(t2, w, t1);
         for (int r = 0; r < 3; ++r) Y[r] += t1[r];
-    }
-    for (int foot = 0; foot < 2; ++foot) {
-        if (cx.kt.leg_pos[foot][j] < 0) continue;
-        for (int c = 4 * foot; c < 4 * foot + 4; ++c) {
-            for (int r = 0; r < 3; ++r) t1[r] = s.pkin[c][r] - o[r];
-            cross3(a, t1, t2);
-            const double* lk = lam + gs::PT_STRIDE * c + gs::KINC;
-            const double w[3] = {-lk[0], -lk[1], -lk[2]};
-            cross3(t2, w, t1);
-            for (int r = 0; r < 3; ++r) Y[r] += t1[r];
-        }
     }
     for (int hnd = 0; hnd < 2; ++hnd) {   // hand points: weight w_h on r_h
         if (hand_mode(h, hnd) == HIPNLP_EXPR_SKIP || !hand_on_path(h, hnd, j)) continue;
@@ -298,6 +290,28 @@ template <class Em> HD void t_hess_Y(HCtx<Em>& h, int j) {
     }
     for (int r = 0; r < 3; ++r) h.hx.Y[j][r] = Y[r];
 }
+template <class Em> HD void t_hess_Y_b(HCtx<Em>& h, int j) {
+    Ctx<Em>& cx = h.cx;
+    auto& s = cx.s;
+    const double* lam = h.hx.lam;
+    const double* a = s.aw[j];
+    const double* o = s.ow[j + 1];
+    double Y[3] = {0.0, 0.0, 0.0}, t1[3], t2[3];
+    for (int foot = 0; foot < 2; ++foot) {
+        if (cx.kt.leg_pos[foot][j] < 0) continue;
+        for (int c = 4 * foot; c < 4 * foot + 4; ++c) {
+            for (int r = 0; r < 3; ++r) t1[r] = s.pkin[c][r] - o[r];
+            cross3(a, t1, t2);
+            const double* lk = lam + gs::PT_STRIDE * c + gs::KINC;
+            const double w[3] = {-lk[0], -lk[1], -lk[2]};
+            cross3(t2, w, t1);
+            for (int r = 0; r < 3; ++r) Y[r] += t1[r];
+        }
+    }
+    for (int r = 0; r < 3; ++r) h.hx.Y2[j][r] = Y[r];
+}
+// Y_j as its consumers see it
+template <class Em> HD void hess_Y(const HCtx<Em>& h, int j, double* Y) { for (int r = 0; r < 3; ++r) Y[r] = h.hx.Y[j][r] + h.hx.Y2[j][r]; }
 
 // --- (s_j, s_i), related pairs only: lane (d, q) walks the ancestor list of joint d — k = anc[d][q] lies on the path root -> d (inclusive)
 //     and carries the axis (the joint numbering need not be topological).  (Until round 4 a lane per entry of the lower triangle searched
@@ -307,7 +321,9 @@ template <class Em> HD void t_hess_ss(HCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
     const int d = t >> 3, k = int(cx.kt.anc[d][t & 7]);
     if (k >= NJ) return;   // (front padding of the list)
-    double v = dot3(cx.s.aw[k], h.hx.Y[d]);
+    double Yd[3];
+    hess_Y(h, d, Yd);
+    double v = dot3(cx.s.aw[k], Yd);
     if (k == d) v += 2.0 * h.hx.sigma * cx.st.m_jreg * cx.st.w_jreg[d];
     for (int hnd = 0; hnd < 2; ++hnd) {   // 2 sigma m D_s^T D_s of a hand in minimize mode (both joints on its path)
         const double sc = hand_jtj_scale(h, hnd);
@@ -326,7 +342,8 @@ template <class Em> HD void t_hess_qs(HCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
     const auto& s = cx.s;
     const int j = t >> 2, l = t & 3;
-    const double* Y = h.hx.Y[j];
+    double Y[3];
+    hess_Y(h, j, Y);
     double v = (s.G[l] * Y[0] + s.G[4 + l] * Y[1] + s.G[8 + l] * Y[2]) * s.inv_qnorm;
     for (int hnd = 0; hnd < 2; ++hnd) {   // 2 sigma m D_s^T D_q
         const double k = hand_jtj_scale(h, hnd);
@@ -342,6 +359,37 @@ template <class Em> HD void t_hess_qs(HCtx<Em>& h, int t) {
 // --- (q_b, q_b): lanes over the lower triangle (10); every lane forms the small matrices itself ------------------------------------
 //   F(q) = <M, R(q / |q|)>,  R(qh) = I + 2 w [v]x + 2 [v]x^2:  Phi(qh) = tr M + 2 w v.ax(M) + 2 v^T M v - 2 (v.v) tr M
 //   Hess_q F = J B J + ( -(g qh^T + qh g^T + (g.qh) I) + 3 (g.qh) qh qh^T ) / |q|^2,   J = (I - qh qh^T) / |q|,  g, B = gradient, Hessian of Phi
+//   Three groups (one group of ten lanes until round 6, every lane forming Mw, M, B and g for itself: 3.5 k cycles, the longest chain of the
+//   Hessian program): Mw entry by entry (nine lanes), M = Mw R_b entry by entry (nine lanes, behind it on its wave), the ten entries from M
+//   (next phase, on the wave the joint blocks leave idle).
+template <class Em> HD void t_hess_qq_mw(HCtx<Em>& h, int t) {   // lane (a, b): Mw = sum_c w_c pkin_c^T + w_com com^T + sigma 2 m e E^T  (world frame)
+    Ctx<Em>& cx = h.cx;
+    const auto& s = cx.s;
+    const double* lam = h.hx.lam;
+    const int a = t / 3, b = t - 3 * a;
+    double E[9];
+    chest_error(s, E);
+    const double trE = E[0] + E[4] + E[8], e = trE - 3.0;
+    const double m2 = 2.0 * h.hx.sigma * cx.st.m_frameq;
+    double acc = -lam[gs::COMC + a] * (s.comp[0][CH + b] * cx.kt.inv_total_mass) + m2 * e * E[3 * b + a];   // com = first moment of the whole tree / mass
+    for (int p = 0; p < NC; ++p) acc += -lam[gs::PT_STRIDE * p + gs::KINC + a] * s.pkin[p][b];
+    for (int hnd = 0; hnd < 2; ++hnd) {   // hand points: w_h r_h^T
+        if (hand_mode(h, hnd) == HIPNLP_EXPR_SKIP) continue;
+        double w[3];
+        hand_weight(h, hnd, w);
+        acc += w[a] * (pose_hand_buf(s) + 3 * hnd)[b];
+    }
+    h.hx.qq[t] = acc;
+    if (t < 3) h.hx.qq[18 + t] = t == 0 ? E[7] - E[5] : (t == 1 ? E[2] - E[6] : E[3] - E[1]);   // ax(E)
+    if (t == 3) h.hx.qq[21] = e;
+}
+template <class Em> HD void t_hess_qq_m(HCtx<Em>& h, int t) {    // lane (a, b): M = Mw R_b  (behind t_hess_qq_mw on its wave)
+    HIPNLP_WAVE_SYNC();
+    const int a = t / 3, b = t - 3 * a;
+    const double* Mw = h.hx.qq;
+    const double* Rb = h.cx.s.Rb;
+    h.hx.qq[9 + t] = Mw[3 * a] * Rb[b] + Mw[3 * a + 1] * Rb[3 + b] + Mw[3 * a + 2] * Rb[6 + b];
+}
 template <class Em> HD void t_hess_qq(HCtx<Em>& h, int t) {
     Ctx<Em>& cx = h.cx;
     const auto& s = cx.s;
@@ -349,27 +397,9 @@ template <class Em> HD void t_hess_qq(HCtx<Em>& h, int t) {
     const double sigma = h.hx.sigma;
     const int r = t < 1 ? 0 : (t < 3 ? 1 : (t < 6 ? 2 : 3));   // row of entry t of the packed lower 4 x 4 triangle
     const int c = t - r * (r + 1) / 2;
-    double E[9];
-    chest_error(s, E);
-    const double trE = E[0] + E[4] + E[8], e = trE - 3.0;
-    const double axE[3] = {E[7] - E[5], E[2] - E[6], E[3] - E[1]};
+    const double* M = h.hx.qq + 9;
+    const double* axE = h.hx.qq + 18;
     const double m2 = 2.0 * sigma * cx.st.m_frameq;
-    // Mw = sum_c w_c pkin_c^T + w_com com^T + sigma 2 m e E^T  (world frame);  M = Mw R_b
-    double Mw[9], M[9];
-    for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) {
-            double acc = -lam[gs::COMC + a] * (s.comp[0][CH + b] * cx.kt.inv_total_mass) + m2 * e * E[3 * b + a];   // com = first moment of the whole tree / mass
-            for (int p = 0; p < NC; ++p) acc += -lam[gs::PT_STRIDE * p + gs::KINC + a] * s.pkin[p][b];
-            Mw[3 * a + b] = acc;
-        }
-    for (int hnd = 0; hnd < 2; ++hnd) {   // hand points: w_h r_h^T
-        if (hand_mode(h, hnd) == HIPNLP_EXPR_SKIP) continue;
-        double w[3];
-        hand_weight(h, hnd, w);
-        const double* rh = pose_hand_buf(s) + 3 * hnd;
-        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) Mw[3 * a + b] += w[a] * rh[b];
-    }
-    matmul3(Mw, s.Rb, M);
     const double trM = M[0] + M[4] + M[8];
     const double al[3] = {M[7] - M[5], M[2] - M[6], M[3] - M[1]};
     const double* qh = s.qn;
@@ -427,9 +457,9 @@ template <class Em> HD void t_hess_ss_b(HCtx<Em>& h, int t) { t_hess_ss(h, t + H
     KIN(0, t_composite_g0, 64) KIN(1, t_composite_g1, 64) KIN(1, t_composite_g2, 64)                              \
     KIN(2, t_composite_g3, 64) KIN(2, t_composite_g4, 64) KIN(3, t_composite_g5, 64) KIN(3, t_pkin, NC)           \
     BARRIER                                                                                                       \
-    RH(0, t_hess_hand, HESS_HAND_TASKS) RH(2, t_hess_Y, NJ) RH(3, t_hess_qq, 10)                                  \
+    RH(0, t_hess_hand, HESS_HAND_TASKS) RH(1, t_hess_Y_a, NJ) RH(2, t_hess_Y_b, NJ) RH(3, t_hess_qq_mw, 9) RH(3, t_hess_qq_m, 9) \
     BARRIER                                                                                                       \
-    RH(0, t_hess_ss_a, HESS_SS_SPLIT) RH(3, t_hess_ss_b, HESS_SS_TASKS - HESS_SS_SPLIT) RH(1, t_hess_qs, 4 * NJ)  \
+    RH(0, t_hess_ss_a, HESS_SS_SPLIT) RH(3, t_hess_ss_b, HESS_SS_TASKS - HESS_SS_SPLIT) RH(1, t_hess_qs, 4 * NJ) RH(2, t_hess_qq, 10) \
     BARRIER
 
 }  // namespace hipnlp

@@ -70,13 +70,14 @@ def test_hessian_and_pose_kernels(res):
     hd = res["hipnlp_knot_hess_kernel<0,1,true>"]
     assert 4 * (-(-hd["lds"] // 1280)) * 1280 <= LDS_PER_CU and _granule(hd["vgpr"] + hd["agpr"]) * 4 <= VGPR_FILE and hd["scratch"] == 0, hd
     # pose kernels on the compact scratch with the lite tables: LDS for four workgroups per CU (32 granules of 1 280 B each); the callback
-    # kernels and the planar Hessian kernel fit the 128 registers that takes, the smooth terrain's Hessian kernel stays at three per CU
+    # kernels fit the 128 registers that takes, the smooth terrain's Hessian kernel stays at three per CU
     for t in (0, 1):
         p = res["hipnlp_pose_kernel<%d>" % t]
         assert 4 * (-(-p["lds"] // 1280)) * 1280 <= LDS_PER_CU and _granule(p["vgpr"] + p["agpr"]) * 4 <= VGPR_FILE and p["scratch"] == 0, p
         ph = res["hipnlp_pose_hess_kernel<%d>" % t]
-        per_cu = 4 if t == 0 else 3
-        assert 4 * (-(-ph["lds"] // 1280)) * 1280 <= LDS_PER_CU and _granule(ph["vgpr"] + ph["agpr"]) * per_cu <= VGPR_FILE and ph["scratch"] == 0, ph
+        # round 6: the planar Hessian kernel at FIVE per CU (no staging of g / grad f in its scratch, the (q_b, q_b) block in three small groups)
+        per_cu = 5 if t == 0 else 3
+        assert per_cu * (-(-ph["lds"] // 1280)) * 1280 <= LDS_PER_CU and _granule(ph["vgpr"] + ph["agpr"]) * per_cu <= VGPR_FILE and ph["scratch"] == 0, ph
 
 
 @pytest.mark.parametrize("terrain", [0, 1])
