@@ -563,7 +563,7 @@ void hipnlp_knot_kernel(const DeviceTables* tb_p, const double* x_p, const doubl
     auto pub_step = [&](int passed) __attribute__((always_inline)) {
         // (a.cost_pub == null: trajectories of more than 256 knots keep the separate reduction kernel)
         if (!a.cost_pub || wave != PUBW) return;
-        if (passed == (ends_late ? 5 : 2)) pub_store();
+        if (passed == (ends_late ? 5 : 2)) pub_store();   // (every task group that writes a cost term runs in the first three phases, in every variant of the program)
     };
 
     KnotInfo ki{k, N, first, last};

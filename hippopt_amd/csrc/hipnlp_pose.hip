@@ -196,6 +196,10 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
 #ifdef HIPNLP_STAMPS
 #define DEV_R(w, w8, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); if (st_nt < 24) st_task[st_nt++] = __builtin_amdgcn_s_memtime(); }
 #define DEV_BARRIER st_arr[st_nb] = __builtin_amdgcn_s_memtime(); lds_barrier(); st_dep[st_nb] = __builtin_amdgcn_s_memtime(); st_nb++;
+#elif defined(HIPNLP_TASK_MARKS)
+    // diagnostic compile (assembly only, never a library): comment markers around every task group for tools/diag/isa_mix.py / reading the ISA
+#define DEV_R(w, w8, fn, nt) if constexpr ((w) == W) { asm volatile("; TASK_BEGIN " #fn); for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); asm volatile("; TASK_END " #fn); }
+#define DEV_BARRIER lds_barrier();
 #else
 #define DEV_R(w, w8, fn, nt) if constexpr ((w) == W) { for (int t_ = lane; t_ < (nt); t_ += 64) fn(cx, t_); }
 #define DEV_BARRIER lds_barrier();

@@ -927,28 +927,11 @@ template <class Em> HD void t_small(Ctx<Em>& cx, int t) {
 
 // --- feet: lane 0 centroids (relative height row + centroid cost, planner.py:215-264);
 //           lanes 1,2 yaw alignment errors of the left / right foot (E9, planner.py:773-853): 3 tasks -------
-template <class Em> HD void t_feet(Ctx<Em>& cx, int t) {   // t = 0: centroids; t = 1, 2: yaw of the left / right foot
+template <class Em> HD void t_feet(Ctx<Em>& cx, int t) {   // t = 1, 2: yaw of the left / right foot
     auto& s = cx.s;
-    Em& em = cx.em;
     const double on = cx.ki.first ? 0.0 : 1.0;
-    if (t == 0) {
-        double cl[3] = {0, 0, 0}, cr[3] = {0, 0, 0};
-        for (int c = 0; c < 4; ++c)
-            for (int i = 0; i < 3; ++i) { cl[i] += s.x[PT_ * c + P_ + i]; cr[i] += s.x[PT_ * (c + 4) + P_ + i]; }
-        for (int i = 0; i < 3; ++i) { cl[i] = cl[i] / 4.0; cr[i] = cr[i] / 4.0; }
-        em.G(gs::FEETH, row_id(RK_FEETH, 0, 0), cl[2] - cr[2]);
-        for (int c = 0; c < NC; ++c) emit_jc(em, js::FEETH + c, row_id(RK_FEETH, 0, 0), PT_ * c + P_ + 2, c < 4 ? 0.25 : -0.25);
-        double cost = 0.0;
-        const double m = on * cx.st.m_centroid;
-        for (int i = 0; i < 3; ++i) {
-            const double e = s.pk[PK_REF + R_CREF + i] - 0.5 * (cl[i] + cr[i]);
-            const double w = s.pk[PK_REF + R_CW + i];
-            cost += e * w * e;
-            s.cen_g[i] = -0.25 * m * w * e;  // 2 w e * d e / d p_c,i = 2 w e (-0.5/4)
-        }
-        s.cost[CT_CENTROID] = m * cost;
-    } else {
-        const int foot = t - 1;
+    {
+        const int foot = t - 1;   // (t = 0 was the centroid lane: t_feet_centroid below)
         const double yaw = s.pk[PK_REF + (foot == 0 ? R_YAW_L : R_YAW_R)];
         const int br = 4 * foot + cx.st.yaw_corner[foot][0], tr = 4 * foot + cx.st.yaw_corner[foot][1], tl = 4 * foot + cx.st.yaw_corner[foot][2];
         // sin/cos of the yaw reference and of yaw + pi/2: parameters only, precomputed by pack_params
@@ -966,7 +949,29 @@ template <class Em> HD void t_feet(Ctx<Em>& cx, int t) {   // t = 0: centroids; 
 }
 
 // the two branches of t_feet as task groups of their own, so that they can sit on different waves of phase A
-template <class Em> HD void t_feet_centroid(Ctx<Em>& cx, int) { t_feet(cx, 0); }
+// centroids: lane i < 3 the component i of both centroids (relative height row on lane 2), its share of the centroid cost and of the
+// cost's gradient; lane c < 8 the constant entry of the height row in p_c,z.  (One lane for all of it until round 6: 24 reads and three
+// error terms one after the other, 1.7 - 1.9 k cycles at batch, as long as the base task it shares a wave with in the four-wave kernels.)
+// The three cost shares wait in chest_w[] — written by t_frames two phases later — for t_foot_cost_sum in the second phase.
+constexpr int FEET_CENTROID_TASKS = NC;
+template <class S> HD double* centroid_cost_parts(S& s) { return s.chest_w; }
+template <class Em> HD void t_feet_centroid(Ctx<Em>& cx, int t) {
+    auto& s = cx.s;
+    Em& em = cx.em;
+    emit_jc(em, js::FEETH + t, row_id(RK_FEETH, 0, 0), PT_ * t + P_ + 2, t < 4 ? 0.25 : -0.25);
+    if (t >= 3) return;
+    const int i = t;
+    const double on = cx.ki.first ? 0.0 : 1.0;
+    double cl = 0.0, cr = 0.0;
+    for (int c = 0; c < 4; ++c) { cl += s.x[PT_ * c + P_ + i]; cr += s.x[PT_ * (c + 4) + P_ + i]; }
+    cl = cl / 4.0; cr = cr / 4.0;
+    if (i == 2) em.G(gs::FEETH, row_id(RK_FEETH, 0, 0), cl - cr);
+    const double m = on * cx.st.m_centroid;
+    const double e = s.pk[PK_REF + R_CREF + i] - 0.5 * (cl + cr);
+    const double w = s.pk[PK_REF + R_CW + i];
+    centroid_cost_parts(s)[i] = e * w * e;
+    s.cen_g[i] = -0.25 * m * w * e;  // 2 w e * d e / d p_c,i = 2 w e (-0.5/4)
+}
 template <class Em> HD void t_feet_yaw(Ctx<Em>& cx, int foot) { t_feet(cx, 1 + foot); }
 
 // --- base orientation: normalised quaternion (E11), R_b, G, omega (E12), d omega / d q_b: lane e = row (3 tasks) ---------
@@ -1207,7 +1212,12 @@ template <class Em> HD void t_foot_cost_sum(Ctx<Em>& cx, int t) {  // behind t_f
     auto& s = cx.s;
     HIPNLP_WAVE_SYNC();
     if (t == 0) s.cost[CT_FREG] = ((s.c_force[0][0] + s.c_force[0][1]) + s.c_force[0][2]) + ((s.c_force[1][0] + s.c_force[1][1]) + s.c_force[1][2]);
-    else s.cost[CT_YAW] = s.c_yaw[0] + s.c_yaw[1];
+    else if (t == 1) s.cost[CT_YAW] = s.c_yaw[0] + s.c_yaw[1];
+    else {   // the centroid cost from the three shares t_feet_centroid left (its own order of the sum: component 0, 1, 2)
+        const double on = cx.ki.first ? 0.0 : 1.0;
+        const double* cp = centroid_cost_parts(s);
+        s.cost[CT_CENTROID] = (on * cx.st.m_centroid) * ((cp[0] + cp[1]) + cp[2]);
+    }
 }
 
 // --- horizon-end rows (final state planner.py:407-425, periodicity :897-930), lanes over rows ----------------
@@ -1625,6 +1635,24 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Where a task group runs in the FOUR-WAVE kernels of the planar terrain (round 6).  At batch a launch is (workgroups / resident
+// workgroups) x the lifetime of ONE workgroup (tools/diag/stamps.py at x 64: 22.6 k cycles, of which the first phase 5.4 k — four waves carry
+// 18 k cycles of task groups there, but the only ones the second phase waits for are the joint transforms, 2.9 k, and the base, 2.4 k).  The
+// groups below need nothing but the knot record and nobody waits for them before the last phases: in that kernel they run where the
+// kinematic chain leaves a wave idle (fn_l: second / third phase); everywhere else — eight-wave kernels, smooth terrain, host recorders and
+// emulation (emitters without kWaves) — in the first phase as before (fn_e).  Exactly one of the two groups of a pair does the work.
+template <class Em> constexpr bool sched4p = em_waves<Em>::value == 4 && Em::kTerrain == HIPNLP_TERRAIN_PLANAR;
+#define HIPNLP_TASK_PAIR(fn)                                                                                        \
+    template <class Em> HD void fn##_e(Ctx<Em>& cx, int t) { if constexpr (!sched4p<Em>) fn(cx, t); }              \
+    template <class Em> HD void fn##_l(Ctx<Em>& cx, int t) { if constexpr (sched4p<Em>) fn(cx, t); }
+// (Every group that writes a COST TERM stays inside the first three phases: the cost partials of a knot are published behind the third barrier, hipnlp.hip pub_step.)
+HIPNLP_TASK_PAIR(t_joint_rows)   // second phase: grad S_ / SD_ are first added to in the fifth (t_frame_columns), c_joint is read by t_joint_cost in the third
+HIPNLP_TASK_PAIR(t_unitq)        // third phase: grad QB_ is first added to in the last (t_feetd)
+HIPNLP_TASK_PAIR(t_small)        // third phase: grad H_ / COM_ / PB_ / VB_ / QD_: only t_ends_finish (last phase) adds
+HIPNLP_TASK_PAIR(t_points_dyn)   // fifth phase: rows and constant entries of the knot record alone, no cost term
+#undef HIPNLP_TASK_PAIR
+
+// ---------------------------------------------------------------------------------------------------
 // The knot program.  R(w4, w8, fn, n): run tasks 0..n-1 of fn on the lanes of wave w4 of a four-wave workgroup, or of wave w8
 // of an eight-wave workgroup (the kernel variant for launches that leave most CUs idle: one workgroup per CU anyway, so the
 // phases are spread over twice the waves); host: plain loop.  Groups of one phase run concurrently on different waves;
@@ -1642,24 +1670,26 @@ template <class Em> HD void t_ends_finish(Ctx<Em>& cx, int t) {
 // groups only write scratch (no emitter calls), so the host expansions, which run both, compute the same thing twice.
 // ---------------------------------------------------------------------------------------------------
 #define HIPNLP_KNOT_PROGRAM(R, BARRIER)                                                   \
-    R(0, 0, t_points_vec, 3 * NC) R(HIPNLP_W4(-1, 0), -1, t_hdyn_rows_a, HDYN_TASKS - 48) R(0, HIPNLP_W8(7, 2), t_joint_rows, NJ) \
-    R(HIPNLP_W4(1, 3), HIPNLP_W8(7, 2), t_points_scalar, NC) R(HIPNLP_W4(1, 0), 3, t_dyn, 7 + NJ + 3) R(1, 7, t_terrain_bump, TERRAIN_BUMP_TASKS) R(1, 7, t_terrain_stage, NC) R(HIPNLP_W4(1, 0), 1, t_unitq, 1) \
-    R(2, HIPNLP_W8(2, 4), t_joints, NJ) R(HIPNLP_W4(1, 2), 1, t_feet_yaw, 2) R(2, HIPNLP_W8(4, 1), t_feet_centroid, 1) R(HIPNLP_W4(-1, 2), -1, t_hdyn_entries_a, 48) \
-    R(3, 5, t_base, 3) R(3, 6, t_small, 4) R(3, 3, t_points_dyn, 3 * NC) \
+    R(0, 0, t_points_vec, 3 * NC) R(HIPNLP_W4(-1, 0), -1, t_hdyn_rows_a, HDYN_TASKS - 48) R(0, HIPNLP_W8(7, 2), t_joint_rows_e, NJ) \
+    R(HIPNLP_W4(1, 3), HIPNLP_W8(7, 2), t_points_scalar, NC) R(HIPNLP_W4(1, 0), 3, t_dyn, 7 + NJ + 3) R(1, 7, t_terrain_bump, TERRAIN_BUMP_TASKS) R(1, 7, t_terrain_stage, NC) R(HIPNLP_W4(1, 0), 1, t_unitq_e, 1) \
+    R(2, HIPNLP_W8(2, 4), t_joints, NJ) R(2, 1, t_feet_yaw, 2) R(HIPNLP_W4(3, 2), HIPNLP_W8(4, 1), t_feet_centroid, FEET_CENTROID_TASKS) R(HIPNLP_W4(-1, 2), -1, t_hdyn_entries_a, 48) \
+    R(3, 5, t_base, 3) R(3, 6, t_small_e, 4) R(3, 3, t_points_dyn_e, 3 * NC) \
     BARRIER                                                                               \
     R(0, 0, t_fk_rot_a, FK_TASKS_A) R(0, 0, t_link_u_a, FK_SPLIT)                         \
     R(3, 1, t_fk_rot_b, FK_TASKS_B) R(3, 1, t_link_u_b, NJ - FK_SPLIT)                    \
     R(1, 2, t_hdyn_entries, 48) R(HIPNLP_W4(1, 3), 3, t_hdyn_rows, HDYN_TASKS - 48)                     \
+    R(2, -1, t_joint_rows_l, NJ)                                                          \
     R(2, 7, t_terrain_hnf, NC) R(2, HIPNLP_W8(6, 4), t_terrain_swing, NC) R(2, HIPNLP_W8(6, 4), t_points_cost, 3) \
-    R(2, HIPNLP_W8(6, 4), t_foot_costs, FOOT_TASKS) R(2, HIPNLP_W8(6, 4), t_foot_cost_sum, 2) \
+    R(2, HIPNLP_W8(6, 4), t_foot_costs, FOOT_TASKS) R(2, HIPNLP_W8(6, 4), t_foot_cost_sum, 3) \
     R(1, 5, t_terrain_planar, NC) R(HIPNLP_W4(0, 1), 6, t_terrain_dcc, NC) R(-1, 7, t_joint_cost, 1)    \
     BARRIER                                                                               \
-    R(0, 0, t_links, NL) R(1, 1, t_frames, 3) R(2, 2, t_link_inertia, NL) R(3, -1, t_joint_cost, 1) R(3, 3, t_com_height, 1) \
+    R(0, 0, t_links, NL) R(1, 1, t_frames, 3) R(2, 2, t_link_inertia, NL) R(2, -1, t_unitq_l, 1) \
+    R(3, -1, t_small_l, 4) R(3, -1, t_joint_cost, 1) R(3, 3, t_com_height, 1)             \
     BARRIER                                                                               \
     R(0, 0, t_composite_g0, 64) R(1, 1, t_composite_g1, 64) R(1, 2, t_composite_g2, 64)   \
     R(2, 3, t_composite_g3, 64) R(2, 4, t_composite_g4, 64) R(3, 5, t_composite_g5, 64) R(-1, 6, t_pkin, NC) \
     BARRIER                                                                               \
-    R(0, 0, t_columns, NJ + 3) R(1, 1, t_cmm_columns, NJ + 3) R(2, 2, t_frame_columns, NJ) R(3, 3, t_ends, ENDS_TASKS) R(3, -1, t_pkin, NC) \
+    R(0, 0, t_columns, NJ + 3) R(1, 1, t_cmm_columns, NJ + 3) R(1, -1, t_points_dyn_l, 3 * NC) R(2, 2, t_frame_columns, NJ) R(3, 3, t_ends, ENDS_TASKS) R(3, -1, t_pkin, NC) \
     BARRIER                                                                               \
     R(0, 0, t_kinc, 3 * NC) R(1, 1, t_comc, 15) R(2, 2, t_cmmc, 15) R(2, 3, t_kinc_s, NC * LEG_PATH) \
     R(3, 4, t_feetd, 5) R(3, 4, t_ends_finish, ENDS_FINISH_TASKS)                         \
@@ -1680,7 +1710,8 @@ HD constexpr bool split_same(const char* a, const char* b) { while (*a && *a == 
 HD constexpr bool split_task_is_model_free(const char* n) {
     const char* mf[] = {"t_points_vec", "t_points_scalar", "t_points_dyn", "t_terrain_bump", "t_terrain_stage", "t_terrain_planar", "t_terrain_dcc",
                         "t_terrain_hnf", "t_terrain_swing", "t_points_cost", "t_foot_costs", "t_foot_cost_sum", "t_feet_yaw", "t_feet_centroid",
-                        "t_hdyn_rows_a", "t_hdyn_entries_a", "t_hdyn_entries", "t_hdyn_rows", "t_small", "t_com_height", "t_ends", "t_ends_finish"};
+                        "t_hdyn_rows_a", "t_hdyn_entries_a", "t_hdyn_entries", "t_hdyn_rows", "t_small", "t_small_e", "t_small_l", "t_points_dyn_e", "t_points_dyn_l",
+                        "t_com_height", "t_ends", "t_ends_finish"};
     for (const char* k : mf) if (split_same(n, k)) return true;
     return false;
 }

@@ -36,7 +36,7 @@ if __name__ == "__main__":
     if stairs:
         from hippopt_amd.synthetic import place_on_step_flanks
         place_on_step_flanks(x, st, seed=1)
-    eng = hipnlp.HipNlp(st, model, batch=batch)
+    eng = hipnlp.HipNlp(st, model, batch=batch, jac_varying_first=os.environ.get('STAMPS_VF') == '1')   # STAMPS_VF=1: the VARY kernels
     eng.set_host_timing(True)
     eng.set_params(p)
     if os.environ.get("STAMPS_DEVICE") == "1":   # the device-pointer path (bench.py's `value`): x resident in HBM
