@@ -66,20 +66,24 @@ struct PArgs {
 #endif
 };
 
+constexpr int pose_jslots(int terrain) { return pjs::slots(terrain == HIPNLP_TERRAIN_PLANAR); }
 template <int TERRAIN> struct PoseEm {
     static constexpr int kTerrain = TERRAIN;
     static constexpr bool kStatic = true;   // (knot_body.h em_static: the velocities of a pose are zero)
-    using Scratch = KnotScratchT<LAYOUT_COMPACT, js::PV0 + NC * js::pt_stride(TERRAIN == HIPNLP_TERRAIN_PLANAR)>;   // (PoseScratchT below)
+    using Scratch = KnotScratchT<LAYOUT_COMPACT, pose_jslots(TERRAIN), true>;   // (PoseScratchT below)
     double* g;
-    double* jac;
+    double* jac;    // the staging (pose_body.h pjs): [per-point constants | kept global constants | varying regions]
+    double* jacv;   // the same, moved back so that a native slot of the varying regions indexes it directly
     __device__ __forceinline__ void G(int slot, int, double v) { g[slot] = v; }
-    __device__ __forceinline__ void J(int slot, int, int, double v) { jac[slot] = v; }
+    __device__ __forceinline__ void J(int slot, int, int, double v) { jacv[slot] = v; }                 // (entries that depend on x: slots >= js::V0)
+    __device__ __forceinline__ void JC(int slot, int, int, double v) { jac[pjs::index(slot)] = v; }     // (constants: any region)
+    __device__ __forceinline__ void JD(int slot, int, int, double v) { jac[pjs::index(slot)] = v; }     // (the pose finder's own entries in slots of region D)
 };
 
 template <int TERRAIN> struct PoseHessEm {
     static constexpr int kTerrain = TERRAIN;
     static constexpr bool kStatic = true;
-    using Scratch = KnotScratchT<LAYOUT_COMPACT_NOG, js::PV0 + NC * js::pt_stride(TERRAIN == HIPNLP_TERRAIN_PLANAR)>;   // (no row, no gradient entry is emitted: neither staging exists)
+    using Scratch = KnotScratchT<LAYOUT_COMPACT_NOG, pose_jslots(TERRAIN), true>;   // (no row, no gradient entry is emitted: neither staging exists)
     double* g;
     double* jac;
     double* h;
@@ -89,13 +93,13 @@ template <int TERRAIN> struct PoseHessEm {
 };
 
 // LDS of a pose workgroup: the COMPACT knot scratch (knot_body.h: own[] on the joint records, which are dead once the forward kinematics
-// has read them) with the Jacobian staging cut to the slots a kernel of its terrain can touch, and the LITE tables of the four-wave
-// callback kernels (the joint frames and link inertials, read once per pose, come from global memory) instead of the whole HeadTables:
-// 38.5 KB on the planar terrain, 40.8 KB on the smooth steps (52.8 KB before) -> FOUR workgroups per CU (LDS is handed out in granules
-// of 1 280 B: 32 granules each).
-constexpr int pose_jslots(int terrain) { return js::PV0 + NC * js::pt_stride(terrain == HIPNLP_TERRAIN_PLANAR); }
-template <int TERRAIN> using PoseScratchT = KnotScratchT<LAYOUT_COMPACT, pose_jslots(TERRAIN)>;
-static_assert(pose_jslots(HIPNLP_TERRAIN_SMOOTH_STEPS) == js::COUNT && pose_jslots(HIPNLP_TERRAIN_PLANAR) != js::vary_slots(false), "pose scratch: hd[] (the hand buffer) must exist");
+// has read them) in its STATIC form (no velocity arrays, a 64-word reference record in place of the previous knot's), a Jacobian staging
+// cut to the pieces the pose program touches (pose_body.h pjs), and the LITE tables of the four-wave callback kernels (the joint frames
+// and link inertials, read once per pose, come from global memory) instead of the whole HeadTables: 31.8 KB on the planar terrain ->
+// FIVE workgroups per CU (LDS is handed out in granules of 1 280 B: 25 granules each; 38.5 KB and four per CU until round 6).
+template <int TERRAIN> using PoseScratchT = KnotScratchT<LAYOUT_COMPACT, pose_jslots(TERRAIN), true>;
+static_assert(pose_jslots(HIPNLP_TERRAIN_SMOOTH_STEPS) != js::COUNT && pose_jslots(HIPNLP_TERRAIN_PLANAR) != js::vary_slots(false) && pose_jslots(HIPNLP_TERRAIN_SMOOTH_STEPS) != js::vary_slots(false),
+              "pose scratch: trimmed (the hand tables live in the tables block), and hd[] (the hand buffer) must exist");
 
 // the hand tables (224 B; read by several task groups of both kernels: an LDS copy, not a global load per use): in the tables block, or —
 // smooth terrain, whose scratch keeps the periodicity variables xo[] no pose task reads — on top of those (the 224 B that keep the
@@ -128,7 +132,7 @@ template <class S, class T, class Mid = PoseStageNoMid> __device__ __forceinline
     constexpr int W0 = int(sizeof(KSettings) / 8), W1 = W0 + int(sizeof(KinLite) / 8), W2 = W1 + int(sizeof(GParamsLite) / 8), W3 = W2 + int(sizeof(PoseHands) / 8);
     constexpr int T_ITERS = (W3 + WG - 1) / WG;
     static_assert(sizeof(KSettings) % 8 == 0 && sizeof(KinLite) % 8 == 0 && sizeof(GParamsLite) % 8 == 0, "copied in 8-byte words");
-    static_assert(S::xpad <= WG && PK_STRIDE <= WG && POSE_NX <= WG && POSE_MAX_NNZ % WG == 0 && XR_STRIDE <= S::xpad, "one record word per thread");
+    static_assert(S::xpad <= WG && PK_STRIDE <= WG && POSE_NX <= WG && POSE_MAX_NNZ % WG == 0 && XR_STRIDE <= S::xm_len, "one record word per thread");
     const double* src0 = reinterpret_cast<const double*>(&tb.head.ks);
     const double* src1 = reinterpret_cast<const double*>(static_cast<const KinLite*>(&tb.head.kt));
     const double* src2 = reinterpret_cast<const double*>(static_cast<const GParamsLite*>(a.gp + b));
@@ -151,7 +155,8 @@ template <class S, class T, class Mid = PoseStageNoMid> __device__ __forceinline
         const int i = tid + it * WG;
         if (i < W0) dst0[i] = tv[it]; else if (i < W1) dst1[i - W0] = tv[it]; else if (i < W2) dst2[i - W1] = tv[it]; else if (i < W3) dst3[i - W2] = tv[it];
     }
-    if (tid < S::xpad) { s.x[tid] = 0.0; s.xm[tid] = xrv; }
+    if (tid < S::xpad) s.x[tid] = 0.0;
+    if (tid < XR_STRIDE) s.xm[tid] = xrv;
     if (tid < PK_STRIDE) s.pk[tid] = pkv;
     if (tid == 0) tabs.bad = 0;
     __syncthreads();
@@ -160,13 +165,14 @@ template <class S, class T, class Mid = PoseStageNoMid> __device__ __forceinline
     __syncthreads();
 }
 
-// Four workgroups per CU: <= 128 VGPRs (110 used), <= 40 960 B of LDS.
-template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void hipnlp_pose_kernel(PArgs a) {
+// Planar terrain: FIVE workgroups per CU (<= 96 VGPRs: 90 used since the static kinematics; <= 32 000 B of LDS); smooth steps: four (123 VGPRs).
+template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(TERRAIN == HIPNLP_TERRAIN_PLANAR ? 5 : 4, TERRAIN == HIPNLP_TERRAIN_PLANAR ? 5 : 4)))
+void hipnlp_pose_kernel(PArgs a) {
     using Scratch = PoseScratchT<TERRAIN>;
     static_assert(std::is_same_v<Scratch, typename PoseEm<TERRAIN>::Scratch>, "the emitter names the scratch the tasks run on");
     __shared__ Scratch s;
     __shared__ PoseSharedT<Scratch::trimmed> tabs;
-    static_assert(sizeof(Scratch) + sizeof(PoseSharedT<Scratch::trimmed>) <= 40960, "four workgroups per CU");
+    static_assert(sizeof(Scratch) + sizeof(PoseSharedT<Scratch::trimmed>) <= (TERRAIN == HIPNLP_TERRAIN_PLANAR ? 32000 : 40960), "five / four workgroups per CU");
 #ifdef HIPNLP_STAMPS
     const unsigned long long st_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -189,7 +195,7 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     const int nnz = tb.nnz, m = tb.m;
 
     KnotInfo ki{1, 3, 0, 0};   // "interior knot": the k >= 1 rows / costs of the shared tasks are active
-    PoseEm<TERRAIN> em{s.g, s.jac};
+    PoseEm<TERRAIN> em{s.g, s.jac, s.jac - (js::V0 - pjs::DSLOTS)};
     Ctx<PoseEm<TERRAIN>> cx(s, tabs.kt, tabs.ks, tabs.gp, ki, em, &tb.head.kt, a.gp + b);   // (full tables: global memory)
     cx.hands = pose_hands(s, tabs);
     // (one contiguous program instance per wave, as in hipnlp_knot_kernel: no wave jumps over the other waves' code)
@@ -222,7 +228,7 @@ template <int TERRAIN> __global__ __launch_bounds__(WG) __attribute__((amdgpu_wa
     int bad = 0;
     double jv[JP_ITERS], gv[GR_ITERS];
 #pragma unroll
-    for (int it = 0; it < JP_ITERS; ++it) jv[it] = s.jac[jp[it]];                    // (behind nnz the table holds slot 0)
+    for (int it = 0; it < JP_ITERS; ++it) jv[it] = s.jac[jp[it]];                    // (the table holds STAGING indices, pjs::index; behind nnz: 0)
 #pragma unroll
     for (int it = 0; it < GR_ITERS; ++it) gv[it] = s.g[gr[it] >= 0 ? tid + it * WG : 0];
     const double gradv = s.grad[pose_to_knot_col(tid < POSE_NX ? tid : 0)];
@@ -495,7 +501,11 @@ int hipnlp_pose_create(const hipnlp_pose_desc* desc, hipnlp_pose_handle** out) {
     for (int s = 0; s < gs::COUNT; ++s) tb->g_row[s] = h->L.g_row[size_t(s)];
     for (int r = 0; r < POSE_MAX_M; ++r) tb->row_slot[r] = -1;
     for (int s = 0; s < gs::COUNT; ++s) if (h->L.g_row[size_t(s)] >= 0) tb->row_slot[h->L.g_row[size_t(s)]] = s;   // (PoseLayout::build: every row in exactly one slot)
-    for (int e = 0; e < h->L.nnz; ++e) tb->jperm[e] = h->L.jperm[size_t(e)];
+    for (int e = 0; e < h->L.nnz; ++e) {   // (the device table holds indices of the compacted staging)
+        const int slot = h->L.jperm[size_t(e)];
+        if (!pjs::kept(slot)) { delete tb; return fail(HIPNLP_E_INVALID, "internal: a Jacobian slot of the pose pattern outside the staged pieces (pose_body.h pjs)"); }
+        tb->jperm[e] = pjs::index(slot);
+    }
     tb->nnz = h->L.nnz; tb->m = h->L.m;
     for (int e = 0; e < h->L.hnnz; ++e) tb->hperm[e] = h->L.hperm[size_t(e)];
     tb->hnnz = h->L.hnnz;

@@ -124,7 +124,7 @@ template <bool HAS> struct ScratchHd { double hd[2][NC][6]; };
 template <> struct ScratchHd<false> {};
 // JSLOTS: slots of the Jacobian staging `jac` (default: all of them).  A VARY kernel (hipnlp.hip) keeps the slots behind js::V0 only —
 // js::vary_slots(terrain) of them — and addresses them through a pointer moved back by js::V0.
-template <int LAYOUT, int JSLOTS = js::COUNT> struct alignas(16) KnotScratchT : ScratchJrOwn<LAYOUT>, ScratchXo<JSLOTS == js::COUNT>,
+template <int LAYOUT, int JSLOTS = js::COUNT, bool STATIC = false> struct alignas(16) KnotScratchT : ScratchJrOwn<LAYOUT>, ScratchXo<JSLOTS == js::COUNT>,
                                                                                  ScratchHd<JSLOTS != js::vary_slots(false)> {
     static constexpr int layout = LAYOUT;
     static constexpr bool compact = LAYOUT != LAYOUT_FULL;
@@ -139,8 +139,13 @@ template <int LAYOUT, int JSLOTS = js::COUNT> struct alignas(16) KnotScratchT : 
     // instantiation hdyn_entries_early<Em> describes; the planar kernel sums the shares in the second phase and keeps its own array.)
     static constexpr bool hd_on_rw = JSLOTS == js::vary_slots(false) && JSLOTS != js::COUNT;
     static constexpr int xpad = trimmed ? NXK + 1 : XPAD;
+    // STATIC (the pose finder's device kernels, Em::kStatic: no velocity of the record is non-zero and no task group that reads one runs):
+    // the scratch carries neither the velocity arrays Uj / wv / vo (zero-length below: the layout of every other instantiation is what it
+    // was) nor a whole previous-knot record — the pose finder keeps its 63 reference values there (pose_body.h XR_*)
+    static constexpr bool has_velocities = !STATIC;
+    static constexpr int xm_len = STATIC ? 64 : xpad;
     alignas(16) double x[xpad];    // knot k   (x, xm, xg, pk: 16-byte aligned, staged by direct global -> LDS loads)
-    double xm[xpad];   // knot k-1 (zeros at k = 0)
+    double xm[xm_len]; // knot k-1 (zeros at k = 0)
     double xg[8];      // horizon-global variables (initial_state.centroidal_momentum)
     double pk[PK_STRIDE];
     // base orientation
@@ -149,9 +154,9 @@ template <int LAYOUT, int JSLOTS = js::COUNT> struct alignas(16) KnotScratchT : 
     // invariant to the base position / linear velocity)
     // per joint, ONE 128-byte record the FK lanes stream with 16-byte LDS reads (ScratchJrOwn::Jr): [ parent_R_child (9) | o_fix (3) |
     // c = R_fix axis = parent-frame joint axis (3) | sdot ]; slot NJ = [identity | 0 | 0 | 0] (padding of the ancestor lists)
-    double Uj[NJ + 1][3];   // (o_j x a_j) sdot_j ; slot NJ = 0
+    double Uj[STATIC ? 0 : NJ + 1][3];   // (o_j x a_j) sdot_j ; slot NJ = 0
     double Rw[NL][9], ow[NL][3], aw[NJ + 1][3];  // padding slot aw[NJ] = 0
-    double wv[NL][3], vo[NL][3];  // link angular velocity; velocity of the body point at the origin
+    double wv[STATIC ? 0 : NL][3], vo[STATIC ? 0 : NL][3];  // link angular velocity; velocity of the body point at the origin
     double comp[NL][LSTR];  // composite per link: [m | first moment h (3) | inertia@O xx,xy,xz,yy,yz,zz (6) | subtree momentum lin (3) | ang (3)]
     double com[3], klin[3], kang[3], hang[3];
     double dth_h[3][3];  // d hang / d theta_e   [e][i]
@@ -268,6 +273,14 @@ template <class Em> HD int js_pt(const Ctx<Em>& cx, int c) { return js::PV0 + js
 // filled with them once and its kernels then store the varying entries only); every other emitter takes them as ordinary entries.
 template <class Em, class = void> struct em_has_jc : std::false_type {};
 template <class Em> struct em_has_jc<Em, std::void_t<decltype(std::declval<Em&>().JC(0, 0, 0, 0.0))>> : std::true_type {};
+// an entry that DEPENDS on x but lives in a slot of the constant region D (only the pose finder has such: it reuses slots of rows it does not
+// have — pose_body.h): an emitter with a JD member maps the region itself (the pose kernels stage a compacted copy of it)
+template <class Em, class = void> struct em_has_jd : std::false_type {};
+template <class Em> struct em_has_jd<Em, std::void_t<decltype(std::declval<Em&>().JD(0, 0, 0, 0.0))>> : std::true_type {};
+template <class Em> HD void emit_jd(Em& em, int slot, int rid, int col, double v) {
+    if constexpr (em_has_jd<Em>::value) em.JD(slot, rid, col, v);
+    else em.J(slot, rid, col, v);
+}
 template <class Em> HD void emit_jc(Em& em, int slot, int rid, int col, double v) {
     if constexpr (em_has_jc<Em>::value) em.JC(slot, rid, col, v);
     else em.J(slot, rid, col, v);
@@ -786,7 +799,7 @@ template <class Em> HD void t_points_cost(Ctx<Em>& cx, int t) {
 template <class S> HD void scratch_padding(S& s, int e) {
     // (the zero slot own[NL] of the descendant lists: t_links — in the compact layouts it lies on joint records that are live here)
     if (e < 16) s.Jr[NJ].d[jr_pos(NJ, e)] = (e < 9 && e % 4 == 0) ? 1.0 : 0.0;   // L = I, of = c = 0, sd = 0
-    if (e < 3) { s.aw[NJ][e] = 0.0; s.Uj[NJ][e] = 0.0; }
+    if (e < 3) { s.aw[NJ][e] = 0.0; if constexpr (S::has_velocities) s.Uj[NJ][e] = 0.0; }
 }
 
 // --- trivial dynamics of base / joints / com, lane e over 33 state components.  planner.py:522-564 -----
@@ -1001,7 +1014,8 @@ template <class Em> HD void t_base(Ctx<Em>& cx, int e) {
     Gr[e] = Ge; Gr[e1] = Ge1; Gr[e2] = Ge2; Gr[3] = G3;
     Dr[e] = (He - hq * a) * inv_n; Dr[e1] = (He1 - hq * b) * inv_n; Dr[e2] = (He2 - hq * c) * inv_n; Dr[3] = (H3 - hq * w) * inv_n;
     s.omega[e] = om;
-    s.ow[0][e] = 0.0; s.wv[0][e] = om; s.vo[0][e] = 0.0;   // root link in base-centred coordinates
+    s.ow[0][e] = 0.0;   // root link in base-centred coordinates
+    if constexpr (std::remove_reference_t<decltype(s)>::has_velocities) { s.wv[0][e] = om; s.vo[0][e] = 0.0; }
 }
 
 // ===================================================================================================

@@ -23,6 +23,19 @@ HD constexpr int pose_to_knot_col(int i) {
                   : (i < 51 ? PB_ + (i - 48) : (i < 55 ? QB_ + (i - 51) : (i < 78 ? S_ + (i - 55) : COM_ + (i - 78))));
 }
 
+// The Jacobian staging of the pose finder's device kernels (round 6): of the constant region D of the native slots (nlp_defs.h, [0, js::V0))
+// the pose program touches the per-point part [0, js::CG0) and, of the global part, [js::HDYN_LIN_F_OUT, js::JVB) alone — balance force
+// entries, com consistency constants, the com height entry, the joint bound rows.  The staging keeps those two pieces and the varying
+// regions: 428 + 809 slots on the planar terrain instead of 1 730 (3.9 KB of LDS: with the static scratch, five workgroups per CU).
+// hipnlp_pose_create checks that every slot of the recorded pattern lies in a kept piece.
+namespace pjs {
+constexpr int D0 = js::CG0, G0 = js::HDYN_LIN_F_OUT, G1 = js::JVB, DSLOTS = D0 + (G1 - G0);
+static_assert(G0 <= js::COMC_COM && js::COMC_PB + 3 <= G1 && G0 <= js::COMH_Z && js::COMH_Z < G1 && G0 <= js::JPB && js::JPB + NJ <= G1 && G1 <= js::V0, "the kept piece of the global constants");
+HD constexpr bool kept(int slot) { return slot < D0 || (slot >= G0 && slot < G1) || slot >= js::V0; }
+HD constexpr int index(int slot) { return slot < D0 ? slot : (slot < js::V0 ? slot - (G0 - D0) : slot - (js::V0 - DSLOTS)); }   // staging index of a kept native slot
+HD constexpr int slots(bool planar) { return DSLOTS + js::vary_slots(planar); }
+}  // namespace pjs
+
 // --- contact point c: relaxed complementarity, height, normal force, friction rows; point regularisations.  lane c (8) ------
 template <class Em> HD void t_pose_points(Ctx<Em>& cx, int c) {
     auto& s = cx.s;
@@ -69,7 +82,7 @@ template <class Em> HD void t_pose_points(Ctx<Em>& cx, int c) {
     s.c_pt[c][2] = cx.st.m_favg * ca;
     if (mode == HIPNLP_EXPR_SUBJECT_TO) {   // sumsqr(p - p_ref) == 0   (base/problem.py:146-151)
         em.G(gb + gs::UB, row_id(RK_PPREG, c, 0), cp);
-        for (int i = 0; i < 3; ++i) em.J(jc + js::UB + i, row_id(RK_PPREG, c, 0), cb + P_ + i, 2.0 * ep[i]);
+        for (int i = 0; i < 3; ++i) emit_jd(em, jc + js::UB + i, row_id(RK_PPREG, c, 0), cb + P_ + i, 2.0 * ep[i]);
     }
 }
 
@@ -92,7 +105,7 @@ template <class Em> HD void t_pose_balance_entries(Ctx<Em>& cx, int t) {
     const double a[3] = {s.x[cb + P_] - com[0], s.x[cb + P_ + 1] - com[1], s.x[cb + P_ + 2] - com[2]};
     em.J(js::HDYN_ANG_P_OUT + 6 * c + e, row_id(RK_PBAL, 0, 3 + r), cb + P_ + q, -skew_entry(f, e));   // d (a x f)/d a = -[f]x
     em.J(js::HDYN_ANG_F_OUT + 6 * c + e, row_id(RK_PBAL, 0, 3 + r), cb + F_ + q, skew_entry(a, e));    // d (a x f)/d f =  [a]x
-    if (e < 3) em.J(js::HDYN_LIN_F_OUT + 3 * c + e, row_id(RK_PBAL, 0, e), cb + F_ + e, 1.0);
+    if (e < 3) emit_jd(em, js::HDYN_LIN_F_OUT + 3 * c + e, row_id(RK_PBAL, 0, e), cb + F_ + e, 1.0);
 }
 //     rows: the three force rows and the three moment rows as two groups of three lanes (as one group of six the two branches ran one after
 //     the other inside the loop over the points, every iteration waiting for its own LDS reads: 3.9 k cycles at batch) --------------------
@@ -130,7 +143,7 @@ template <class Em> HD void t_pose_joints(Ctx<Em>& cx, int j) {
     auto& s = cx.s;
     Em& em = cx.em;
     em.G(gs::JPB + j, row_id(RK_JPB, 0, j), s.x[S_ + j]);
-    em.J(js::JPB + j, row_id(RK_JPB, 0, j), S_ + j, 1.0);
+    emit_jd(em, js::JPB + j, row_id(RK_JPB, 0, j), S_ + j, 1.0);
     const double e = s.x[S_ + j] - s.pk[PK_REF + R_JREG + j];
     const double mw = cx.st.m_jreg * cx.st.w_jreg[j];
     s.c_joint[j] = mw * e * e;
@@ -147,7 +160,7 @@ template <class Em> HD void t_pose_com(Ctx<Em>& cx, int t) {
         const double e = s.x[COM_ + t] - s.xm[XR_COM + t];
         s.grad[COM_ + t] = mode == HIPNLP_EXPR_MINIMIZE ? 2.0 * cx.st.m_pcom * e : 0.0;
         s.grad[PB_ + t] = 0.0;
-        if (mode == HIPNLP_EXPR_SUBJECT_TO) em.J(t < 2 ? js::COMH_XY + t : js::COMH_Z, row_id(RK_PCOMERR, 0, 0), COM_ + t, 2.0 * e);
+        if (mode == HIPNLP_EXPR_SUBJECT_TO) { if (t < 2) em.J(js::COMH_XY + t, row_id(RK_PCOMERR, 0, 0), COM_ + t, 2.0 * e); else emit_jd(em, js::COMH_Z, row_id(RK_PCOMERR, 0, 0), COM_ + t, 2.0 * e); }
     } else {
         double c = 0.0;
         for (int i = 0; i < 3; ++i) { const double e = s.x[COM_ + i] - s.xm[XR_COM + i]; c += e * e; }
@@ -208,10 +221,10 @@ template <class Em> HD void pose_hand_rows(Ctx<Em>& cx, int t, int h) {
         if (mode == HIPNLP_EXPR_SUBJECT_TO) {
             // (Opti's canonical form of `position == parameter`: the row is the position, its bounds are the reference)
             em.G(gs::PT_STRIDE * h + gs::FDYN + i, row_id(RK_PHAND, h, i), s.x[PB_ + i] + r[i]);
-            em.J(jb + 0, row_id(RK_PHAND, h, i), PB_ + i, 1.0);
+            emit_jd(em, jb + 0, row_id(RK_PHAND, h, i), PB_ + i, 1.0);
             const double X0 = skew_rc(r, i, 0), X1 = skew_rc(r, i, 1), X2 = skew_rc(r, i, 2);
             for (int l = 0; l < 4; ++l)
-                em.J(jb + 1 + l, row_id(RK_PHAND, h, i), QB_ + l, -(X0 * s.G[l] + X1 * s.G[4 + l] + X2 * s.G[8 + l]) * s.inv_qnorm);
+                emit_jd(em, jb + 1 + l, row_id(RK_PHAND, h, i), QB_ + l, -(X0 * s.G[l] + X1 * s.G[4 + l] + X2 * s.G[8 + l]) * s.inv_qnorm);
         } else {   // minimize: gradient 2 m J^T e
             s.grad[PB_ + i] += m2 * e[i];
             for (int l = i; l < 4; l += 3) {
@@ -229,7 +242,7 @@ template <class Em> HD void pose_hand_rows(Ctx<Em>& cx, int t, int h) {
         for (int n = 0; n < 3; ++n) d[n] = r[n] - s.ow[j + 1][n];
         cross3(s.aw[j], d, x);
         if (mode == HIPNLP_EXPR_SUBJECT_TO) {
-            for (int i = 0; i < 3; ++i) em.J(js::ptc(4 * h + i) + js::FDYN + 5 + q, row_id(RK_PHAND, h, i), S_ + j, x[i]);
+            for (int i = 0; i < 3; ++i) emit_jd(em, js::ptc(4 * h + i) + js::FDYN + 5 + q, row_id(RK_PHAND, h, i), S_ + j, x[i]);
         } else {
             s.grad[S_ + j] += m2 * dot3(e, x);
         }

@@ -73,7 +73,10 @@ def test_hessian_and_pose_kernels(res):
     # kernels fit the 128 registers that takes, the smooth terrain's Hessian kernel stays at three per CU
     for t in (0, 1):
         p = res["hipnlp_pose_kernel<%d>" % t]
-        assert 4 * (-(-p["lds"] // 1280)) * 1280 <= LDS_PER_CU and _granule(p["vgpr"] + p["agpr"]) * 4 <= VGPR_FILE and p["scratch"] == 0, p
+        # round 6: the planar callback kernel at FIVE per CU (static scratch without velocity arrays, Jacobian staging cut to the pieces the pose
+        # program touches, static kinematics: 31.8 KB, 90 VGPRs); the smooth terrain's stays at four (123 VGPRs)
+        pcu = 5 if t == 0 else 4
+        assert pcu * (-(-p["lds"] // 1280)) * 1280 <= LDS_PER_CU and _granule(p["vgpr"] + p["agpr"]) * pcu <= VGPR_FILE and p["scratch"] == 0, p
         ph = res["hipnlp_pose_hess_kernel<%d>" % t]
         # round 6: the planar Hessian kernel at FIVE per CU (no staging of g / grad f in its scratch, the (q_b, q_b) block in three small groups)
         per_cu = 5 if t == 0 else 3
