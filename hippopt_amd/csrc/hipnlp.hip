@@ -831,6 +831,7 @@ struct HArgs {
     // written through the L2, while the kinematic phases still run: a quarter (planar) to two fifths (smooth steps) of a knot's bytes are
     // on the link three phases before the program ends.  0: everything at the end.
     int32_t early_run;
+    double* trash;          // DIRECT launches: [workgroups] where the emitter puts a value whose slot is not in the pattern (see DevEmH::H)
 #ifdef HIPNLP_STAMPS
     unsigned long long* stamps;  // diagnostic build only (tools/diag/hess_stamps.py): [blocks][8][128] s_memtime per wave
 #endif
@@ -842,18 +843,24 @@ struct HArgs {
 // for DEVICE destinations only (they meet in the L2; on PCIe fragments cost more than everything they save).
 template <int TERRAIN, int LAYOUT, bool DIRECT = false> struct DevEmH {
     static constexpr int kTerrain = TERRAIN;
+    static constexpr bool kBatch = LAYOUT == LAYOUT_COMPACT;   // (knot_hess_body.h kh_batch: the placement of task groups in launches longer than the chip)
     using Scratch = KnotScratchT<LAYOUT>;
     double* g;
     double* jac;
     double* hess;
     const int16_t* inv = nullptr;
+    double* trash = nullptr;   // (DIRECT: this workgroup's word for values outside the pattern)
     double nf = 0.0;
     __device__ __forceinline__ void G(int slot, int, double v) { g[slot] = v; }
     __device__ __forceinline__ void J(int slot, int, int, double v) { jac[slot] = v; }
     __device__ __forceinline__ void H(int slot, int, int, double v) {
         if constexpr (DIRECT) {
+            // (no branch around the store: with one, every emission was its own basic block — slot -> position read, wait, compare,
+            //  store, one after the other, 380 cycles per entry at batch, tools/diag/hess_stamps.py; a value outside the pattern goes to a
+            //  word of the workgroup's own instead, and the position reads of a task group's entries are in flight together)
             const int p = inv[slot];
-            if (p >= 0) hess[p] = v;
+            double* dst = p >= 0 ? hess + p : trash;
+            *dst = v;
             // (every emitted value, pattern entry or not — ADVICE r04 asked for pattern entries only, as the staged kernel's copy-out; with the
             //  accumulation inside the branch the compiler contracted multiply-adds of the tasks differently and 88 entries of the
             //  "periodicity as a cost" case lost their bit-identity with the staged kernel (r05_gputest1.log): the stronger property is kept.
@@ -1019,7 +1026,7 @@ void hipnlp_knot_hess_kernel(HArgs a) {
         }
     };
     KnotInfo ki{k, N, first, last};
-    Em em{s.g, s.jac, DIRECT ? a.hess + int64_t(b) * a.hstride + (int64_t(a.nnz_knot) * k - a.hoff) : hx.H, inv_s};
+    Em em{s.g, s.jac, DIRECT ? a.hess + int64_t(b) * a.hstride + (int64_t(a.nnz_knot) * k - a.hoff) : hx.H, inv_s, DIRECT ? a.trash + (size_t(blockIdx.y) * gridDim.x + blockIdx.x) : nullptr};
     Ctx<Em> cx(s, tabs.kin(), tabs.settings(), tabs.gp, ki, em, COMPACT ? &tb.head.kt : nullptr, COMPACT ? a.gp + b : nullptr);
     KHCtx<Em> hcx{cx, hx, s.g};
     // (one contiguous program instance per wave, as in hipnlp_knot_kernel)
@@ -1336,6 +1343,7 @@ struct hipnlp_handle {
     HessTables* d_ht = nullptr;
     double *d_sigma = nullptr, *d_lambda = nullptr /* inside the d_sigma block */, *d_hess = nullptr, *h_hess = nullptr, *h_sl = nullptr;
     int32_t *d_hflag = nullptr, *h_hflag = nullptr, *hd_hflag = nullptr /* device-visible address of h_hflag */;
+    double* d_htrash = nullptr;   // [nk * batch] DIRECT Hessian launches: one word per workgroup (HArgs::trash)
     double* hd_hess = nullptr;   // device-visible address of h_hess
     int32_t hseq = 0;   // Hessian launches so far (generation of d_hflag)
     std::string err;
@@ -1363,7 +1371,7 @@ static void free_all(hipnlp_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->dev);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* dptrs[] = {h->d_tb, h->d_ctpl, h->d_ctpl_of_b, h->d_healed, h->d_x, h->d_pk, h->d_cost_knot, h->d_gp, h->d_cost_pub, h->d_out, h->d_ht, h->d_sigma, h->d_hess, h->d_hflag};
+    void* dptrs[] = {h->d_tb, h->d_ctpl, h->d_ctpl_of_b, h->d_healed, h->d_x, h->d_pk, h->d_cost_knot, h->d_gp, h->d_cost_pub, h->d_out, h->d_ht, h->d_sigma, h->d_hess, h->d_hflag, h->d_htrash};
     for (void* q : dptrs) if (q) (void)hipFree(q);
     void* hptrs[] = {h->h_x, h->h_out, h->h_hess, h->h_hflag, h->h_sl};
     for (void* q : hptrs) if (q) (void)hipHostFree(q);
@@ -2526,6 +2534,11 @@ static int hess_launch(hipnlp_handle* h, const double* x_dev, const double* sigm
 #endif
     const dim3 hgrid(unsigned(h->nk), unsigned(h->batch));
     const bool smooth = h->d.settings.terrain != HIPNLP_TERRAIN_PLANAR;
+    a.trash = nullptr;
+    if (h->hess_compact && !smooth && h->hess_direct && !host_block) {   // (the direct emitter's word per workgroup)
+        if (!h->d_htrash) HIP_TRY(h, hipMalloc(&h->d_htrash, size_t(h->nk) * size_t(h->batch) * sizeof(double)));
+        a.trash = h->d_htrash;
+    }
     if (h->hess_compact) {   // (launches longer than the 512 workgroup slots of the full layout: three workgroups per CU)
         if (smooth) hipLaunchKernelGGL((hipnlp_knot_hess_kernel<HIPNLP_TERRAIN_SMOOTH_STEPS, LAYOUT_COMPACT>), hgrid, dim3(256), 0, s, a);
         // planar terrain, DEVICE destination: the entries go straight to their places (no LDS staging: four workgroups per CU); a host

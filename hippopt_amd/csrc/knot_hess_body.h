@@ -183,45 +183,103 @@ template <class Em> HD double freg_diag(const KHCtx<Em>& h, int c) {
     return 2.0 * h.hx.sigma * (cx.ki.first ? 0.0 : 1.0) * cx.st.m_freg * (1.0 - 2.0 * alpha[cl] + a2);
 }
 
-// --- point-local entries: lane c (8) --------------------------------------------------------------------------------------------
-template <class Em> HD void t_kh_point(KHCtx<Em>& h, int c) {
+// (no multiply-add contraction inside a function that starts with this: the direct-store and the staged kernel must produce the same bits,
+//  tests/test_gpu_hessian_direct.py, and where a sum has a term that is zero in most workgroups the compiler contracted it differently in the two)
+#if defined(__clang__)
+#define HIPNLP_NO_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define HIPNLP_NO_CONTRACT
+#endif
+// the horizon-end shares of several diagonal entries at once, behind ONE (workgroup-uniform) branch: an interior knot — and every knot unless
+// an end group is a cost — gets zeros without a call, and the entries that add them are then emitted in one straight line (with a call of
+// ends_diag, i.e. two branches and two rolled loops, between any two emissions the slot -> position reads and the stores of the direct
+// emitter went one by one: 400 cycles per entry at batch)
+template <class Em> HD bool ends_are_costs(const KHCtx<Em>& h) {
+    const Ctx<Em>& cx = h.cx;
+    return (cx.ki.last && cx.st.final_type == HIPNLP_EXPR_MINIMIZE) || ((cx.ki.first || cx.ki.last) && cx.st.periodicity_type == HIPNLP_EXPR_MINIMIZE);
+}
+template <int N, class Em> HD void ends_diag_n(const KHCtx<Em>& h, int var0, double* ed) {
+    for (int i = 0; i < N; ++i) ed[i] = 0.0;
+    if (ends_are_costs(h)) for (int i = 0; i < N; ++i) ed[i] = ends_diag(h, var0 + i);
+}
+
+// --- point-local entries: lane c (8), in four task groups (one group until round 6: 29 entries per lane one after the other — 8.2 k cycles on
+//     one wave of the first phase of a batch launch, whose other waves are done after 3.1 - 4.2 k: tools/diag/hess_stamps.py) -----------------
+//     a: complementarity, dcc margin, friction cone (planar terrain; the smooth terrain's dense point blocks contain these)
+template <class Em> HD void t_kh_point_a(KHCtx<Em>& h, int c) {
+    HIPNLP_NO_CONTRACT
     Ctx<Em>& cx = h.cx;
     auto& s = cx.s;
     Em& em = cx.em;
+    if (!terrain_is_planar(cx)) return;
     const double* lam = h.lam;
-    const double sigma = h.hx.sigma;
     const int gb = gs::PT_STRIDE * c, hb = hk::PT * c, cb = PT_ * c;
     const double* x = s.x + cb;
+    // planar complementarity  v_i - tanh(kt p_z) u_i  (E3)
+    const double kt = cx.gp.kt, tau = knot_tanh(kt * x[P_ + 2]), dtau = kt * (1.0 - tau * tau);
+    for (int i = 0; i < 2; ++i) em.H(hb + hk::PL_U + i, cb + U_ + i, cb + P_ + 2, -lam[gb + gs::PLANAR + i] * dtau);
+    // dcc margin  eps - kbs p_z f_z - (v_z f_z + p_z fdot_z)  (E4)
+    const double l_d = lam[gb + gs::DCC];
+    em.H(hb + hk::DC_FP, cb + F_ + 2, cb + P_ + 2, -cx.gp.kbs * l_d);
+    em.H(hb + hk::DC_FV, cb + F_ + 2, cb + V_ + 2, -l_d);
+    em.H(hb + hk::DC_PFD, cb + P_ + 2, cb + FD_ + 2, -l_d);
+    // friction cone + own share of the force-ratio regularisation
+    const double dff = freg_diag(h, c);
+    const double l_f = lam[gb + gs::FRICTION], mu2 = cx.gp.mu * cx.gp.mu;
+    double ed[3];
+    ends_diag_n<3>(h, cb + F_, ed);
+    for (int i = 0; i < 3; ++i)
+        em.H(hb + hk::FD + i, cb + F_ + i, cb + F_ + i, dff + (i < 2 ? -2.0 * l_f : 2.0 * mu2 * l_f) + ed[i]);
+}
+//     b: nu . ((p - com) x f) in (f, p), swing height (planar terrain)
+template <class Em> HD void t_kh_point_b(KHCtx<Em>& h, int c) {
+    HIPNLP_NO_CONTRACT
+    Ctx<Em>& cx = h.cx;
+    Em& em = cx.em;
+    if (!terrain_is_planar(cx)) return;
+    const int hb = hk::PT * c, cb = PT_ * c;
     const double on = cx.ki.first ? 0.0 : 1.0;
-    const bool planar = terrain_is_planar(cx);
     double nu[3];
     hdyn_multiplier(h, nu);
-    if (planar) {   // (smooth terrain: t_kh_point_smooth emits the dense blocks that contain these)
-        // planar complementarity  v_i - tanh(kt p_z) u_i  (E3)
-        const double kt = cx.gp.kt, tau = knot_tanh(kt * x[P_ + 2]), dtau = kt * (1.0 - tau * tau);
-        for (int i = 0; i < 2; ++i) em.H(hb + hk::PL_U + i, cb + U_ + i, cb + P_ + 2, -lam[gb + gs::PLANAR + i] * dtau);
-        // dcc margin  eps - kbs p_z f_z - (v_z f_z + p_z fdot_z)  (E4)
-        const double l_d = lam[gb + gs::DCC];
-        em.H(hb + hk::DC_FP, cb + F_ + 2, cb + P_ + 2, -cx.gp.kbs * l_d);
-        em.H(hb + hk::DC_FV, cb + F_ + 2, cb + V_ + 2, -l_d);
-        em.H(hb + hk::DC_PFD, cb + P_ + 2, cb + FD_ + 2, -l_d);
-        // friction cone + own share of the force-ratio regularisation
-        const double dff = freg_diag(h, c);
-        const double l_f = lam[gb + gs::FRICTION], mu2 = cx.gp.mu * cx.gp.mu;
-        for (int i = 0; i < 3; ++i)
-            em.H(hb + hk::FD + i, cb + F_ + i, cb + F_ + i, dff + (i < 2 ? -2.0 * l_f : 2.0 * mu2 * l_f) + ends_diag(h, cb + F_ + i));
-        // nu . ((p - com) x f)
-        for (int e = 0; e < 6; ++e) em.H(hb + hk::HD_FP + e, cb + F_ + cross_row(e), cb + P_ + cross_col(e), skew_rc(nu, cross_row(e), cross_col(e)));
-        // swing height (E10, planar)  (k >= 1)
-        for (int i = 0; i < 3; ++i) em.H(hb + hk::VD + i, cb + V_ + i, cb + V_ + i, (i < 2 ? sigma * on * cx.st.m_swing : 0.0) + ends_diag(h, cb + V_ + i));
-    }
-    for (int e = 0; e < 6; ++e) em.H(hb + hk::CF + e, COM_ + cross_row(e), cb + F_ + cross_col(e), -skew_rc(nu, cross_col(e), cross_row(e)));
-    // ||u_v||^2, ||f_dot||^2   (k >= 1)
+    double ed[3];
+    ends_diag_n<3>(h, cb + V_, ed);
+    for (int e = 0; e < 6; ++e) em.H(hb + hk::HD_FP + e, cb + F_ + cross_row(e), cb + P_ + cross_col(e), skew_rc(nu, cross_row(e), cross_col(e)));
+    // swing height (E10, planar)  (k >= 1)
+    for (int i = 0; i < 3; ++i) em.H(hb + hk::VD + i, cb + V_ + i, cb + V_ + i, (i < 2 ? h.hx.sigma * on * cx.st.m_swing : 0.0) + ed[i]);
+}
+//     c: nu . ((p - com) x f) in (com, f)
+template <class Em> HD void t_kh_point_c(KHCtx<Em>& h, int c) {
+    Ctx<Em>& cx = h.cx;
+    const int hb = hk::PT * c, cb = PT_ * c;
+    double nu[3];
+    hdyn_multiplier(h, nu);
+    for (int e = 0; e < 6; ++e) cx.em.H(hb + hk::CF + e, COM_ + cross_row(e), cb + F_ + cross_col(e), -skew_rc(nu, cross_col(e), cross_row(e)));
+}
+//     d: ||u_v||^2, ||f_dot||^2   (k >= 1)
+template <class Em> HD void t_kh_point_d(KHCtx<Em>& h, int c) {
+    HIPNLP_NO_CONTRACT
+    Ctx<Em>& cx = h.cx;
+    const int hb = hk::PT * c, cb = PT_ * c;
+    const double sigma = h.hx.sigma, on = cx.ki.first ? 0.0 : 1.0;
+    double edf[3], edu[3];
+    ends_diag_n<3>(h, cb + FD_, edf);
+    ends_diag_n<3>(h, cb + U_, edu);
     for (int i = 0; i < 3; ++i) {
-        em.H(hb + hk::FDD + i, cb + FD_ + i, cb + FD_ + i, 2.0 * sigma * on * cx.st.m_fdreg + ends_diag(h, cb + FD_ + i));
-        em.H(hb + hk::UD + i, cb + U_ + i, cb + U_ + i, 2.0 * sigma * on * cx.st.m_ureg + ends_diag(h, cb + U_ + i));
+        cx.em.H(hb + hk::FDD + i, cb + FD_ + i, cb + FD_ + i, 2.0 * sigma * on * cx.st.m_fdreg + edf[i]);
+        cx.em.H(hb + hk::UD + i, cb + U_ + i, cb + U_ + i, 2.0 * sigma * on * cx.st.m_ureg + edu[i]);
     }
 }
+// Where c and d run: in the first phase behind a and b (every instantiation whose recorded entry phases matter: the full-layout kernel stores
+// the leading run of a knot's block behind the second barrier, HessLayout::early_run) — or, in the COMPACT kernels of the planar terrain (batch
+// launches; emitters with kBatch), in the third phase on the wave the link tasks leave idle.  Exactly one group of a pair does the work.
+template <class Em, class = void> struct kh_batch_t { static constexpr bool value = false; };
+template <class Em> struct kh_batch_t<Em, std::void_t<decltype(Em::kBatch)>> { static constexpr bool value = Em::kBatch && Em::kTerrain == HIPNLP_TERRAIN_PLANAR; };
+template <class Em> constexpr bool kh_batch = kh_batch_t<Em>::value;
+// (b in the fifth phase on the wave of t_kh_joint as well: the first phase 5.3 k -> 4.4 k cycles, x 256 unchanged, x 64 83.5 -> 85.1 us: not kept)
+template <class Em> HD void t_kh_point_c_e(KHCtx<Em>& h, int c) { if constexpr (!kh_batch<Em>) t_kh_point_c(h, c); }
+template <class Em> HD void t_kh_point_c_l(KHCtx<Em>& h, int c) { if constexpr (kh_batch<Em>) t_kh_point_c(h, c); }
+template <class Em> HD void t_kh_point_d_e(KHCtx<Em>& h, int c) { if constexpr (!kh_batch<Em>) t_kh_point_d(h, c); }
+template <class Em> HD void t_kh_point_d_l(KHCtx<Em>& h, int c) { if constexpr (kh_batch<Em>) t_kh_point_d(h, c); }
 
 // --- force-ratio regularisation across the points of one foot (planner.py:746-771): lanes (foot, pair, i) 36 ------------------
 template <class Em> HD void t_kh_ff(KHCtx<Em>& h, int t) {
@@ -1011,7 +1069,7 @@ template <class Em> HD void t_kh_ssd_far_c(KHCtx<Em>& h, int t) { t_kh_ssd_far(h
 // wave 3 of the last phase against 5.2 - 7.6 k on the others.
 #define HIPNLP_KNOT_HESS_PHASE1A(KIN, RH, BARRIER)                                                               \
     KIN(0, t_joints, NJ) RH(0, t_kh_ff, 36) KIN(1, t_base, 3) KIN(1, t_kin_padding, 16)                          \
-    RH(1, t_kh_diag_planar, 42) RH(1, t_kh_percouple, 84) RH(2, t_kh_point, NC) RH(3, t_kh_pp_planar_at<128>, 52) \
+    RH(1, t_kh_diag_planar, 42) RH(1, t_kh_percouple, 84) RH(2, t_kh_point_a, NC) RH(2, t_kh_point_b, NC) RH(2, t_kh_point_c_e, NC) RH(2, t_kh_point_d_e, NC) RH(3, t_kh_pp_planar_at<128>, 52) \
     RH(3, t_kh_bump, KH_BUMP_TASKS) RH(0, t_kh_pp_smooth_at<0>, 64) RH(1, t_kh_pp_smooth_at<64>, 64) RH(2, t_kh_pp_smooth_at<128>, 52) \
     BARRIER
 #define HIPNLP_KNOT_HESS_PHASE1B(KIN, RH, BARRIER)                                                               \
@@ -1022,7 +1080,7 @@ template <class Em> HD void t_kh_ssd_far_c(KHCtx<Em>& h, int t) { t_kh_ssd_far(h
     RH(0, t_kh_diag_smooth, 42)                                                                                  \
     BARRIER
 #define HIPNLP_KNOT_HESS_PHASE1C(KIN, RH, BARRIER)                                                               \
-    KIN(0, t_links, NL) KIN(1, t_frames, 3) KIN(2, t_link_inertia, NL) RH(3, t_kh_point_smooth_pp_emit, 6 * NC)  \
+    KIN(0, t_links, NL) KIN(1, t_frames, 3) KIN(2, t_link_inertia, NL) RH(3, t_kh_point_smooth_pp_emit, 6 * NC) RH(3, t_kh_point_c_l, NC) RH(3, t_kh_point_d_l, NC) \
     BARRIER
 #define HIPNLP_KNOT_HESS_PHASE1D(KIN, RH, BARRIER)                                                               \
     KIN(0, t_composite_g0, 64) KIN(1, t_composite_g1, 64) KIN(1, t_composite_g2, 64)                             \
