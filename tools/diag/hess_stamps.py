@@ -49,10 +49,10 @@ if __name__ == "__main__":
     for _ in range(20):
         eng.eval_hess_device(xd.data_ptr(), sd.data_ptr(), ld.data_ptr(), out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    raw = np.zeros((N * batch, 8, 128), np.uint64)
+    raw = np.zeros((2 * N * batch, 8, 128), np.uint64)[: 2 * N * batch]   # (hipnlp_debug_stamps copies the room of a SPLIT launch: two workgroups per knot)
     eng.lib.hipnlp_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
     eng.lib.hipnlp_debug_stamps(eng.h, raw.ctypes.data_as(C.c_void_p))
-    o = raw.astype(np.int64)[:, :4]
+    o = raw[: N * batch].astype(np.int64)[:, :4]
     t0 = o[:, :, 0].min(axis=1, keepdims=True)                       # entry of the workgroup's first wave
     nb = int(o[0, 0, 2])
     total = (o[:, :, 4].max(axis=1) - t0[:, 0])
