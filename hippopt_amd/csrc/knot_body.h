@@ -1339,6 +1339,9 @@ template <class Em> HD void t_frames(Ctx<Em>& cx, int f) {
     double o[3];
     matvec3(s.Rw[L], cx.kt.frame_o[f], o);
     for (int r = 0; r < 3; ++r) s.fr_o[f][r] = s.ow[L][r] + o[r];
+    // (static emitters — the pose finder's device kernels — form the chest error in a task group of their own, beside this one: its lane did
+    //  twice the work of the two foot frames, and this group set the length of the third phase once the link task had lost its velocities)
+    if constexpr (em_static<Em>) return;
     if (f == HIPNLP_FRAME_CHEST) {  // rotation error R_chest R(q_d)^T  (K5) -> trace and ax()
         double Rd[9], M[9], Rdt[9];
         rot_from_quat(s.pk + PK_REF + R_FQ, Rd);

@@ -251,6 +251,25 @@ template <class Em> HD void pose_hand_rows(Ctx<Em>& cx, int t, int h) {
 template <class Em> HD void t_pose_hand_rows_l(Ctx<Em>& cx, int t) { pose_hand_rows(cx, t, 0); }
 template <class Em> HD void t_pose_hand_rows_r(Ctx<Em>& cx, int t) { pose_hand_rows(cx, t, 1); }
 
+// chest-frame orientation error of a STATIC emitter (t_frames leaves it out there): R_chest from the link's world rotation — the product t_frames
+// forms for fr_R, once more, so that this group waits for nobody in its phase — then cost, d cost / d trace and ax(R_chest R_d^T) as t_frames.  1 lane.
+template <class Em> HD void t_pose_chest(Ctx<Em>& cx, int) {
+    if constexpr (em_static<Em>) {
+        auto& s = cx.s;
+        const int f = HIPNLP_FRAME_CHEST;
+        double Rc[9], Rd[9], M[9], Rdt[9];
+        matmul3(s.Rw[cx.kt.frame_link[f]], cx.kt.frame_R[f], Rc);
+        rot_from_quat(s.pk + PK_REF + R_FQ, Rd);
+        for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) Rdt[3 * r + q] = Rd[3 * q + r];
+        matmul3(Rc, Rdt, M);
+        const double e = (M[0] + M[4] + M[8]) - 3.0;
+        const double on = cx.ki.first ? 0.0 : 1.0;
+        const double m = on * cx.st.m_frameq;
+        s.cost[CT_FRAMEQ] = m * (e * e);
+        s.chest_dc = 2.0 * m * e;
+        s.chest_w[0] = M[7] - M[5]; s.chest_w[1] = M[2] - M[6]; s.chest_w[2] = M[3] - M[1];
+    } else { (void)cx; }
+}
 // the three sums over the contact points among the cost terms (point position | force | average force regularisation: c_pt[.][k]), lane k (3),
 // in a phase behind t_pose_points on a wave the kinematic chain leaves idle — until round 6 the first thread of the workgroup added them
 // up, 24 dependent additions, between the last barrier and the copy-out.  Parked in cost slots no task of the pose program writes.
@@ -300,11 +319,11 @@ template <class S> HD double pose_cost_term(const S& s, int t) {
     R(3, 3, t_base, 3) R(3, 3, t_kin_padding, 16)                                         \
     BARRIER                                                                               \
     R(0, 0, t_fk_rot_a, FK_TASKS_A) R(0, 0, t_link_u_a, FK_SPLIT)                         \
-    R(1, 1, t_pose_points_second, NC)                                                     \
+    R(1, 1, t_pose_points_second, NC) R(1, 1, t_pose_cost_sums, 3)                        \
     R(2, 2, t_joint_cost, 1) R(2, 2, t_pose_com, 4) R(2, 2, t_unitq, 1)                   \
     R(3, 3, t_fk_rot_b, FK_TASKS_B) R(3, 3, t_link_u_b, NJ - FK_SPLIT)                    \
     BARRIER                                                                               \
-    R(0, 0, t_links, NL) R(1, 1, t_frames, 3) R(2, 2, t_link_inertia, NL) R(3, 3, t_pose_hand_pts, 2) R(3, 3, t_pose_cost_sums, 3) \
+    R(0, 0, t_links, NL) R(1, 1, t_frames, 3) R(2, 2, t_link_inertia, NL) R(3, 3, t_pose_hand_pts, 2) R(3, 3, t_pose_chest, 1) \
     BARRIER                                                                               \
     R(0, 0, t_composite_g0, 64) R(1, 1, t_composite_g1, 64) R(1, 1, t_composite_g2, 64)   \
     R(2, 2, t_composite_g3, 64) R(2, 2, t_composite_g4, 64) R(3, 3, t_composite_g5, 64) R(3, 3, t_pkin, NC) \

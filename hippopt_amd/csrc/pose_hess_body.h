@@ -46,7 +46,7 @@ struct HessScratch {
     double sigma, pad_;
     double Y[NJ][3];         // Y_j, the share of the com / hand / chest terms (t_hess_Y_a)
     double Y2[NJ][3];        //      the share of the contact points of the leg the joint belongs to (t_hess_Y_b); zero for the other joints
-    double qq[24];           // (q_b, q_b) in three steps: [0..8] Mw, [9..17] M = Mw R_b, [18..20] ax(E), [21] tr E - 3
+    double qq[32];           // (q_b, q_b) in three steps: [0..8] Mw, [9..17] M = Mw R_b; [18..20] ax(E), [21] tr E - 3, [22..30] E, [31] tr E (t_hess_chest)
     double H[hs::COUNT];
 };
 
@@ -179,7 +179,24 @@ template <class Em> HD void t_hess_misc(HCtx<Em>& h, int t) {
     }
 }
 
-// chest-frame rotation error  E = R_chest R(q_d)^T  (K5) recomputed from the frame the pose program left in the scratch
+// chest-frame rotation error  E = R_chest R(q_d)^T  (K5), once per pose (round 6: t_hess_qq_mw's nine lanes and the torso lanes of t_hess_Y_a
+// each recomputed it from the frame — a quaternion, a transpose and a product at the head of the two longest chains of the fifth phase):
+// 1 lane, third phase, beside t_frames (R_chest from the link's world rotation, the product t_frames forms for fr_R: it waits for nobody).
+template <class Em> HD void t_hess_chest(HCtx<Em>& h, int) {
+    const auto& s = h.cx.s;
+    const int f = HIPNLP_FRAME_CHEST;
+    double Rc[9], Rd[9], Rdt[9], E[9];
+    matmul3(s.Rw[h.cx.kt.frame_link[f]], h.cx.kt.frame_R[f], Rc);
+    rot_from_quat(s.pk + PK_REF + R_FQ, Rd);
+    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) Rdt[3 * r + q] = Rd[3 * q + r];
+    matmul3(Rc, Rdt, E);
+    double* o = h.hx.qq;
+    for (int i = 0; i < 9; ++i) o[22 + i] = E[i];
+    const double trE = E[0] + E[4] + E[8];
+    o[31] = trE; o[21] = trE - 3.0;
+    o[18] = E[7] - E[5]; o[19] = E[2] - E[6]; o[20] = E[3] - E[1];
+}
+// (the same from the frame t_frames left in the scratch: the kinodynamic Hessian's tasks, knot_hess_body.h)
 template <class S> HD void chest_error(const S& s, double* E) {
     double Rd[9], Rdt[9];
     rot_from_quat(s.pk + PK_REF + R_FQ, Rd);
@@ -279,10 +296,10 @@ template <class Em> HD void t_hess_Y_a(HCtx<Em>& h, int j) {
         for (int r = 0; r < 3; ++r) Y[r] += t1[r];
     }
     if (cx.kt.chest_pos[j] >= 0) {
-        double E[9], Ea[3];
-        chest_error(s, E);
-        const double trE = E[0] + E[4] + E[8], e = trE - 3.0;
-        const double ax[3] = {E[7] - E[5], E[2] - E[6], E[3] - E[1]};
+        const double* E = h.hx.qq + 22;   // (t_hess_chest)
+        const double* ax = h.hx.qq + 18;
+        const double trE = h.hx.qq[31], e = h.hx.qq[21];
+        double Ea[3];
         matvec3(E, a, Ea);
         const double de = -dot3(ax, a);                     // d e / d s_j
         const double m2 = 2.0 * h.hx.sigma * cx.st.m_frameq;
@@ -367,9 +384,8 @@ template <class Em> HD void t_hess_qq_mw(HCtx<Em>& h, int t) {   // lane (a, b):
     const auto& s = cx.s;
     const double* lam = h.hx.lam;
     const int a = t / 3, b = t - 3 * a;
-    double E[9];
-    chest_error(s, E);
-    const double trE = E[0] + E[4] + E[8], e = trE - 3.0;
+    const double* E = h.hx.qq + 22;   // (t_hess_chest)
+    const double e = h.hx.qq[21];
     const double m2 = 2.0 * h.hx.sigma * cx.st.m_frameq;
     double acc = -lam[gs::COMC + a] * (s.comp[0][CH + b] * cx.kt.inv_total_mass) + m2 * e * E[3 * b + a];   // com = first moment of the whole tree / mass
     for (int p = 0; p < NC; ++p) acc += -lam[gs::PT_STRIDE * p + gs::KINC + a] * s.pkin[p][b];
@@ -380,8 +396,6 @@ template <class Em> HD void t_hess_qq_mw(HCtx<Em>& h, int t) {   // lane (a, b):
         acc += w[a] * (pose_hand_buf(s) + 3 * hnd)[b];
     }
     h.hx.qq[t] = acc;
-    if (t < 3) h.hx.qq[18 + t] = t == 0 ? E[7] - E[5] : (t == 1 ? E[2] - E[6] : E[3] - E[1]);   // ax(E)
-    if (t == 3) h.hx.qq[21] = e;
 }
 template <class Em> HD void t_hess_qq_m(HCtx<Em>& h, int t) {    // lane (a, b): M = Mw R_b  (behind t_hess_qq_mw on its wave)
     HIPNLP_WAVE_SYNC();
@@ -452,7 +466,7 @@ template <class Em> HD void t_hess_ss_b(HCtx<Em>& h, int t) { t_hess_ss(h, t + H
     KIN(0, t_fk_rot_a, FK_TASKS_A) KIN(0, t_link_u_a, FK_SPLIT) RH(1, t_hess_misc, HESS_MISC_TASKS) RH(2, t_hess_point, NC) \
     KIN(3, t_fk_rot_b, FK_TASKS_B) KIN(3, t_link_u_b, NJ - FK_SPLIT)                                              \
     BARRIER                                                                                                       \
-    KIN(0, t_links, NL) KIN(1, t_frames, 3) KIN(2, t_link_inertia, NL) KIN(3, t_pose_hand_pts, 2)                 \
+    KIN(0, t_links, NL) KIN(1, t_frames, 3) KIN(2, t_link_inertia, NL) KIN(3, t_pose_hand_pts, 2) RH(3, t_hess_chest, 1) \
     BARRIER                                                                                                       \
     KIN(0, t_composite_g0, 64) KIN(1, t_composite_g1, 64) KIN(1, t_composite_g2, 64)                              \
     KIN(2, t_composite_g3, 64) KIN(2, t_composite_g4, 64) KIN(3, t_composite_g5, 64) KIN(3, t_pkin, NC)           \

@@ -14,13 +14,13 @@ sys.path.insert(0, ROOT)
 SO = os.path.join(ROOT, "tools", "diag", "_build", "libhipnlp_stamps.so")
 
 CALLBACK_TASKS = [["t_pose_points_first", "t_pose_balance_rows_ang", "t_fk_rot_a", "t_link_u_a", "t_links", "t_composite_g0", "t_columns", "t_kinc"],
-                  ["t_pose_balance_rows_lin", "t_pose_balance_com", "t_pose_points_second", "t_frames", "t_composite_g1", "t_composite_g2", "t_pose_balance_entries", "t_comc"],
+                  ["t_pose_balance_rows_lin", "t_pose_balance_com", "t_pose_points_second", "t_pose_cost_sums", "t_frames", "t_composite_g1", "t_composite_g2", "t_pose_balance_entries", "t_comc"],
                   ["t_pose_joints", "t_joint_cost", "t_pose_com", "t_unitq", "t_link_inertia", "t_composite_g3", "t_composite_g4", "t_frame_columns", "t_kinc_s"],
-                  ["t_base", "t_kin_padding", "t_fk_rot_b", "t_link_u_b", "t_pose_hand_pts", "t_pose_cost_sums", "t_composite_g5", "t_pkin", "t_pose_cost_total", "t_feetd", "t_pose_hand_rows_l", "t_pose_hand_rows_r"]]
+                  ["t_base", "t_kin_padding", "t_fk_rot_b", "t_link_u_b", "t_pose_hand_pts", "t_pose_chest", "t_composite_g5", "t_pkin", "t_pose_cost_total", "t_feetd", "t_pose_hand_rows_l", "t_pose_hand_rows_r"]]
 HESS_TASKS = [["t_joints", "t_fk_rot_a", "t_link_u_a", "t_links", "t_composite_g0", "t_hess_hand", "t_hess_ss_a"],
               ["t_base", "t_kin_padding", "t_hess_misc", "t_frames", "t_composite_g1", "t_composite_g2", "t_hess_Y_a", "t_hess_qs"],
               ["t_hess_point", "t_link_inertia", "t_composite_g3", "t_composite_g4", "t_hess_Y_b", "t_hess_qq"],
-              ["t_fk_rot_b", "t_link_u_b", "t_pose_hand_pts", "t_composite_g5", "t_pkin", "t_hess_qq_mw", "t_hess_qq_m", "t_hess_ss_b"]]
+              ["t_fk_rot_b", "t_link_u_b", "t_pose_hand_pts", "t_hess_chest", "t_composite_g5", "t_pkin", "t_hess_qq_mw", "t_hess_qq_m", "t_hess_ss_b"]]
 
 if __name__ == "__main__":
     from hippopt_amd import hipnlp
