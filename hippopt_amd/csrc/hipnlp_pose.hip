@@ -101,9 +101,8 @@ template <int TERRAIN> using PoseScratchT = KnotScratchT<LAYOUT_COMPACT, pose_js
 static_assert(pose_jslots(HIPNLP_TERRAIN_SMOOTH_STEPS) != js::COUNT && pose_jslots(HIPNLP_TERRAIN_PLANAR) != js::vary_slots(false) && pose_jslots(HIPNLP_TERRAIN_SMOOTH_STEPS) != js::vary_slots(false),
               "pose scratch: trimmed (the hand tables live in the tables block), and hd[] (the hand buffer) must exist");
 
-// the hand tables (224 B; read by several task groups of both kernels: an LDS copy, not a global load per use): in the tables block, or —
-// smooth terrain, whose scratch keeps the periodicity variables xo[] no pose task reads — on top of those (the 224 B that keep the
-// workgroup inside 32 granules)
+// the hand tables (224 B; read by several task groups of both kernels: an LDS copy, not a global load per use) live in the tables block (every
+// pose scratch is a trimmed one since round 6; an untrimmed scratch would park them on the periodicity variables xo[] no pose task reads)
 template <bool OWN_HANDS> struct PoseSharedT;
 // (bad: the workgroup's non-finite vote — a word here instead of __syncthreads_or, whose reduction brings 256 B of LDS of its own)
 template <> struct alignas(16) PoseSharedT<true> { KSettings ks; KinLite kt; GParamsLite gp; PoseHands hands; int32_t bad, pad_[3]; };

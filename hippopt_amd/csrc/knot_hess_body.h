@@ -723,7 +723,7 @@ template <class Em> HD void t_kh_joint_b(KHCtx<Em>& h, int t) {
 
 // --- Y_j = d/d theta [ dL/ds_j ]  (theta: world-frame rotation of the base) for the part of the Lagrangian that is LINEAR in
 //     points rigidly attached to links: contact points, com (incl. the com inside the momentum term: weight mu x P), chest cost.
-//     Same construction as t_hess_Y of the pose finder.  lane j (23) -----------------------------------------------------------------
+//     Same construction as t_hess_Y_a / _b of the pose finder.  lane j (23) -----------------------------------------------------------------
 template <class Em> HD void t_kh_Y(KHCtx<Em>& h, int j) {
     Ctx<Em>& cx = h.cx;
     auto& s = cx.s;

@@ -69,8 +69,7 @@ def test_hessian_and_pose_kernels(res):
     # the planar Hessian kernel that stores its entries straight into a device destination (no LDS staging): four workgroups per CU
     hd = res["hipnlp_knot_hess_kernel<0,1,true>"]
     assert 4 * (-(-hd["lds"] // 1280)) * 1280 <= LDS_PER_CU and _granule(hd["vgpr"] + hd["agpr"]) * 4 <= VGPR_FILE and hd["scratch"] == 0, hd
-    # pose kernels on the compact scratch with the lite tables: LDS for four workgroups per CU (32 granules of 1 280 B each); the callback
-    # kernels fit the 128 registers that takes, the smooth terrain's Hessian kernel stays at three per CU
+    # pose kernels on the compact (static) scratch with the lite tables: planar terrain five per CU, smooth steps four (callbacks) / three (Hessian)
     for t in (0, 1):
         p = res["hipnlp_pose_kernel<%d>" % t]
         # round 6: the planar callback kernel at FIVE per CU (static scratch without velocity arrays, Jacobian staging cut to the pieces the pose

@@ -85,7 +85,7 @@ if __name__ == "__main__":
     import re
     prog = open(os.path.join(ROOT, "hippopt_amd", "csrc", "knot_body.h")).read()
     prog = prog[prog.index("#define HIPNLP_KNOT_PROGRAM(R, BARRIER)") + len("#define HIPNLP_KNOT_PROGRAM(R, BARRIER)"):]
-    prog = re.sub(r"HIPNLP_W[48]\((\d+), (\d+)\)", (lambda m: m.group(2) if stairs else m.group(1)), prog)
+    prog = re.sub(r"HIPNLP_W[48]\((-?\d+), (-?\d+)\)", (lambda m: m.group(2) if stairs else m.group(1)), prog)
     items = re.findall(r"R\((-?\d+), (-?\d+), (\w+), [^)]*\)|(BARRIER)", prog)
     for w in waves:
         names, b = [], 0
