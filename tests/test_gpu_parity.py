@@ -243,6 +243,33 @@ def test_config4_periodic_100_matches_oracle(model, HipNlp):
     assert np.allclose(terms[0], orc.cost_terms(), rtol=1e-12, atol=1e-10)
 
 
+@pytest.mark.parametrize("vary_first", [False, True])
+def test_config4_x64_full_occupancy_has_no_cross_talk(model, HipNlp, vary_first):
+    """BASELINE config 4 as the throughput legs launch it: N = 100 x 64 trajectories, 6 400 knot workgroups of the four-wave kernels, four
+    (CCS) / five (varying-first) per CU over several rounds, the reducer workgroups of the trajectories among them.  Size-independent
+    properties: one trajectory entrywise against the oracle, every trajectory bit for bit what it is in another order of the batch (nothing
+    depends on the position in the launch or on the workgroups that share a CU), every output finite."""
+    from oracle_lib import Oracle
+    st = periodic_step_settings(100, model)
+    B = 64
+    x, p = make_workload(st, model, batch=B, seed=1004)
+    eng, orc = HipNlp(st, model, batch=B, jac_varying_first=vary_first), Oracle(st, model)
+    eng.set_params(p)
+    f, grad, g, jac = (np.array(a) for a in eng.eval(x))
+    assert all(np.isfinite(a).all() for a in (f, grad, g, jac))
+    ir, jc = eng.sparsity()
+    iro, jco = orc.sparsity()
+    b = 37
+    fo, grado, go, jaco = orc.eval(x[b], p[b])
+    order = np.lexsort((ir, jc)) if vary_first else np.arange(ir.size)   # (the varying-first handle reports its own entry order)
+    assert rel(f[b], fo) < TOL and rel(grad[b], grado) < TOL and rel(g[b], go) < TOL
+    assert np.array_equal(ir[order], iro) and np.array_equal(jc[order], jco) and rel(jac[b][order], jaco) < TOL
+    perm = np.random.RandomState(7).permutation(B)
+    eng.set_params(p[perm])
+    f2, grad2, g2, jac2 = eng.eval(x[perm])
+    assert np.array_equal(f2, f[perm]) and np.array_equal(grad2, grad[perm]) and np.array_equal(g2, g[perm]) and np.array_equal(jac2, jac[perm])
+
+
 def test_large_horizon_properties(model, HipNlp):
     """N = 100 (BASELINE config 4): size-independent properties — defect linearity in dt, zero defects on a
     trapezoid-consistent trajectory, Jacobian consistent with finite differences of g along a random direction."""

@@ -99,6 +99,13 @@ def test_pose_errors_and_large_batch(model):
         fo, grado, go, jaco = orc.eval(xb[b], pb[b])
         assert rel(f[b], fo) < TOL and rel(grad[b], grado) < TOL and rel(g[b], go) < TOL and rel(jac[b], jaco) < TOL
     print("pose kernel, batch %d: %.3f ms" % (B, big.last_kernel_ms()))
+    # every pose of the full launch (five workgroups per CU, several rounds): its outputs do not depend on where in the batch it sits or on
+    # which poses share its CU — the same poses in another order give the same bits, pose by pose
+    perm = np.random.RandomState(5).permutation(B)
+    big.set_params(pb[perm])
+    f2, grad2, g2, jac2 = big.eval(xb[perm])
+    assert np.array_equal(f2, f[perm]) and np.array_equal(grad2, grad[perm]) and np.array_equal(g2, g[perm]) and np.array_equal(jac2, jac[perm])
+    assert np.isfinite(jac).all() and np.isfinite(g).all()
 
 
 def test_pose_planner_solves(model):
@@ -208,6 +215,12 @@ def test_pose_hessian_large_batch_and_errors(model):
     ir, jc = eng.hess_sparsity()
     for b in (0, 31, 1025, B - 1):
         hess_check(ir, jc, vals[b], orc.hess(xb[b], pb[b], 1.0, lam[b]), TOL)
+    # (as for the callbacks: the same poses in another order of the batch give the same bits, pose by pose)
+    perm = rng.permutation(B)
+    eng.set_params(pb[perm])
+    vals2 = eng.eval_hess(xb[perm], 1.0, lam[perm])
+    assert np.array_equal(vals2, vals[perm]) and np.isfinite(vals).all()
+    eng.set_params(pb)
     xb[3][51:55] = 0.0
     with pytest.raises(HipNlpError) as ei:
         eng.eval_hess(xb, 1.0, lam)
