@@ -23,6 +23,22 @@ struct ValueEm {
     void H(int slot, int, int, double v) { hess[slot] = v; }
 };
 
+// the pose finder's device emitter (hipnlp_pose.hip PoseEm): a Jacobian staging cut to the pieces of the native numbering the pose program
+// touches (pose_body.h pjs).  J indexes a pointer moved back by a constant on the device — a slot below js::V0 through J would land in front of
+// the staging; JC / JD map any kept slot.  Violations are counted (hostemu_pose_map_violations), values go where the device puts them.
+static long g_pose_map_violations = 0;
+struct ValueEmPoseStaged {
+    static constexpr int kTerrain = -1;
+    double* g;
+    double* stg;
+    double* hess = nullptr;
+    void G(int slot, int, double v) { g[slot] = v; }
+    void J(int slot, int, int, double v) { if (slot < js::V0) { g_pose_map_violations++; return; } stg[pjs::index(slot)] = v; }
+    void JC(int slot, int, int, double v) { if (!pjs::kept(slot)) { g_pose_map_violations++; return; } stg[pjs::index(slot)] = v; }
+    void JD(int slot, int, int, double v) { JC(slot, 0, 0, v); }
+    void H(int slot, int, int, double v) { hess[slot] = v; }
+};
+
 // an emitter with the compile-time traits of a device instantiation (hipnlp_knot_kernel<TERRAIN, WAVES>): task groups whose placement
 // depends on them (hdyn_entries_early, knot_body.h) then run where the device runs them — used by the wave-order emulation
 template <int WAVES, int TERRAIN> struct ValueEmV {
@@ -549,8 +565,9 @@ void hostemu_pose_eval(const hostemu_pose_handle* h, const double* x, const doub
     for (int i = 0; i < 64; ++i) s->xm[i] = xr[i];
     for (int i = 0; i < PK_STRIDE; ++i) s->pk[i] = pk[i];
     KnotInfo ki{1, 3, 0, 0};
-    ValueEm em{s->g, s->jac};
-    Ctx<ValueEm> cx(*s, h->kt, h->ks, gp, ki, em);
+    std::vector<double> stg(size_t(pjs::slots(false)), std::nan(""));   // (the larger of the two terrains' stagings)
+    ValueEmPoseStaged em{s->g, stg.data()};
+    Ctx<ValueEmPoseStaged> cx(*s, h->kt, h->ks, gp, ki, em);
     cx.hands = &h->hands;
     if (g_wave_order < 0) {
 #define HOST_R(w4, w8, fn, nt) for (int t_ = 0; t_ < (nt); ++t_) fn(cx, t_);
@@ -565,7 +582,11 @@ void hostemu_pose_eval(const hostemu_pose_handle* h, const double* x, const doub
 #undef HOST_BARRIER
         wo.flush();
     }
-    for (int e = 0; e < L.nnz; ++e) jac[e] = s->jac[L.jperm[size_t(e)]];
+    for (int e = 0; e < L.nnz; ++e) {   // (the device table holds pjs::index of the pattern's slots; hipnlp_pose_create refuses a slot that is not kept)
+        const int slot = L.jperm[size_t(e)];
+        if (!pjs::kept(slot)) { g_pose_map_violations++; jac[e] = std::nan(""); continue; }
+        jac[e] = stg[size_t(pjs::index(slot))];
+    }
     for (int slot = 0; slot < gs::COUNT; ++slot) if (L.g_row[size_t(slot)] >= 0) g[L.g_row[size_t(slot)]] = s->g[slot];
     for (int i = 0; i < POSE_NX; ++i) grad[i] = s->grad[pose_to_knot_col(i)];
     double ft = 0.0;
@@ -574,6 +595,7 @@ void hostemu_pose_eval(const hostemu_pose_handle* h, const double* x, const doub
     *f = s->cost[CT_POSE_TOTAL];   // (t_pose_cost_total: the kernel's f — NaN if the task ran before a term it adds was written)
     delete s;
 }
+long hostemu_pose_map_violations(void) { return g_pose_map_violations; }
 void hostemu_pose_hess_dims(const hostemu_pose_handle* h, int* hnnz) { *hnnz = h->L.hnnz; }
 void hostemu_pose_hess_sparsity(const hostemu_pose_handle* h, int* irow, int* jcol) {
     for (int i = 0; i < h->L.hnnz; ++i) { irow[i] = h->L.hrow[size_t(i)]; jcol[i] = h->L.hcol[size_t(i)]; }

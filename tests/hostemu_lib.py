@@ -223,6 +223,13 @@ class PoseHostEmu:
                                    C.byref(f), _dp(grad), _dp(g), _dp(jac), _dp(ct))
         return f.value, grad, g, jac, ct
 
+    def map_violations(self):
+        """entries the pose program sent through the device emitter's staging map (pose_body.h pjs) in a way the device kernel could not serve:
+        a slot of the constant region through J, a slot outside the kept pieces through JC / JD or in the pattern (count since the library
+        was loaded)"""
+        self.lib.hostemu_pose_map_violations.restype = C.c_long
+        return int(self.lib.hostemu_pose_map_violations())
+
     def hess_sparsity(self):
         n = C.c_int()
         self.lib.hostemu_pose_hess_dims(C.c_void_p(self.h), C.byref(n))

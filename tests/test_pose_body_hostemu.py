@@ -79,6 +79,8 @@ def test_pose_body_matches_oracle(model, name):
         lb, ub = o.bounds(p[b])
         lb2, ub2 = e.bounds(p[b])
         assert np.array_equal(lb, lb2) and np.array_equal(ub, ub2)
+    # the emulation runs the pose program on the DEVICE emitter's cut Jacobian staging (pose_body.h pjs): every emission was one the device can serve
+    assert e.map_violations() == 0
 
 
 @pytest.mark.parametrize("name", ["pose_default", "pose_step_constrained", "pose_hands"])
