@@ -20,13 +20,13 @@ def handle(HipNlp, st, model, B, direct, **kw):
         return HipNlp(st, model, batch=B, library=lib, **kw)
 
 
-@pytest.mark.parametrize("case", ["periodic 100 x 8", "periodicity as a cost 9 x 70", "single step 30 x 20", "shard [3, 11) of 14 x 80", "non-finite iterates 12 x 50"])
+@pytest.mark.parametrize("case", ["periodic 100 x 8", "periodic 100 x 64 (the throughput leg: 6 400 workgroups, several rounds of four per CU)", "periodicity as a cost 9 x 70", "single step 30 x 20", "shard [3, 11) of 14 x 80", "non-finite iterates 12 x 50"])
 def test_direct_store_hessian_kernel_is_the_staged_kernel_bit_for_bit(model, case):
     import torch
     from hippopt_amd.hipnlp import HipNlp
     kw = {}
     if case.startswith("periodic 100"):
-        st, B = periodic_step_settings(100, model), 8
+        st, B = periodic_step_settings(100, model), (64 if "x 64" in case else 8)
     elif case.startswith("periodicity"):
         st, B = periodic_step_settings(9, model), 70
         st.periodicity_expression_type = _abi.EXPR_MINIMIZE
