@@ -615,7 +615,14 @@ void hostemu_pose_hess(const hostemu_pose_handle* h, const double* x, const doub
     for (int i = 0; i < POSE_NX; ++i) s->x[pose_to_knot_col(i)] = x[i];
     for (int i = 0; i < 64; ++i) s->xm[i] = xr[i];
     for (int i = 0; i < PK_STRIDE; ++i) s->pk[i] = pk[i];
-    for (int slot = 0; slot < gs::COUNT; ++slot) hx->lam[slot] = L.g_row[size_t(slot)] >= 0 ? lambda[L.g_row[size_t(slot)]] : 0.0;
+    // the multipliers as the device kernel stages them (hipnlp_pose.hip): zeros, then thread i scatters the multiplier of ROW i to the slot of row i
+    // (the inverse of g_row: every row of the pattern lives in exactly one slot — a row without a slot would lose its multiplier here)
+    for (int slot = 0; slot < gs::COUNT; ++slot) hx->lam[slot] = 0.0;
+    {
+        std::vector<int> row_slot(size_t(L.m), -1);
+        for (int slot = 0; slot < gs::COUNT; ++slot) if (L.g_row[size_t(slot)] >= 0) row_slot[size_t(L.g_row[size_t(slot)])] = slot;
+        for (int r = 0; r < L.m; ++r) if (row_slot[size_t(r)] >= 0) hx->lam[row_slot[size_t(r)]] = lambda[r]; else g_pose_map_violations++;
+    }
     hx->sigma = sigma;
     KnotInfo ki{1, 3, 0, 0};
     ValueEm em{s->g, s->jac, hx->H};

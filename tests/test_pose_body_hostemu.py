@@ -139,6 +139,7 @@ def test_pose_hessian_body_matches_oracle(model, name):
     mine = np.zeros_like(pattern)
     mine[ir, jc] = True
     assert np.array_equal(mine, pattern)
+    assert e.map_violations() == 0   # (the multipliers went in as the device kernel stages them: row i to the slot of row i)
 
 
 @pytest.mark.parametrize("name", ["pose_default", "pose_step_constrained", "pose_hands"])
